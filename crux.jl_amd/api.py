@@ -1,0 +1,782 @@
+"""Host-side mirror of the Crux.jl interface for the actor-learner hot path, over the C ABI of libcruxhip.so.
+
+Julia is not installed where this is built, so the host layer that `north_star` asks to keep in Julia is mirrored here
+in Python with the reference's names and argument meaning (Julia's `f!` is spelled `f_`). The Julia shim that binds the
+same C symbols with `ccall` is shown in INTEGRATION.md. Every class/function cites the reference definition it mirrors
+(paths under sisl/Crux.jl v0.1.4).
+
+Array convention: like the Julia arrays, columns are (features, batch) with the batch LAST; numpy arrays returned here
+are Fortran-ordered so their memory is identical to the Julia array's (and to what crosses the C ABI).
+"""
+import ctypes as C
+import math
+import numpy as np
+
+from . import _lib as L
+
+# --------------------------------------------------------------------------------------------------------------
+# context
+# --------------------------------------------------------------------------------------------------------------
+_default_ctx = None
+
+
+class Context:
+    """One HIP stream + error slot (crux_ctx). `stream` may be a raw hipStream_t (e.g. torch's current stream)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = L.load()
+        h = C.c_void_p()
+        rc = self.lib.crux_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != 0:
+            raise L.CruxError(rc, "no usable MI355X/HIP device %d (libcruxhip has no CPU fallback)" % device)
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != 0:
+            raise L.CruxError(rc, (self.lib.crux_last_error(self.h) or b"").decode())
+        return rc
+
+    def sync(self):
+        self.check(self.lib.crux_sync(self.h))
+
+    def prof_enable(self, on=True):
+        self.check(self.lib.crux_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self.check(self.lib.crux_prof_reset(self.h))
+
+    def prof_get(self, slot):
+        ms, n = C.c_double(), C.c_int64()
+        self.check(self.lib.crux_prof_get(self.h, L.PROF[slot] if isinstance(slot, str) else slot, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.lib.crux_device_alloc(self.h, int(nbytes), C.byref(p)))
+        return p
+
+    def free(self, p):
+        self.lib.crux_device_free(self.h, p)
+
+    def d2h(self, d_ptr, arr):
+        self.check(self.lib.crux_memcpy_d2h(self.h, arr.ctypes.data_as(C.c_void_p), d_ptr, arr.nbytes))
+        return arr
+
+    def h2d(self, d_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.lib.crux_memcpy_h2d(self.h, d_ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def close(self):
+        if self.h:
+            self.lib.crux_ctx_destroy(self.h)
+            self.h = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def set_default_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# --------------------------------------------------------------------------------------------------------------
+# spaces  (src/spaces.jl:1-43)
+# --------------------------------------------------------------------------------------------------------------
+class DiscreteSpace:
+    """DiscreteSpace(N, vals) -- actions stored as Bool one-hot columns (src/spaces.jl:2-8,18,24)."""
+
+    def __init__(self, N, vals=None):
+        if not isinstance(N, (int, np.integer)):
+            vals = list(N); N = len(vals)
+        self.N = int(N)
+        self.vals = list(range(1, self.N + 1)) if vals is None else list(vals)
+
+
+class ContinuousSpace:
+    """ContinuousSpace(dims, type; mu, sigma) (src/spaces.jl:10-16); tovec whitens with (v-mu)/sigma (:25)."""
+
+    def __init__(self, dims, type=np.float32, mu=0.0, sigma=1.0):
+        self.dims = (int(dims),) if isinstance(dims, (int, np.integer)) else tuple(int(d) for d in dims)
+        self.type = type
+        self.mu, self.sigma = mu, sigma
+
+
+def dim(S):
+    return (S.N,) if isinstance(S, DiscreteSpace) else S.dims
+
+
+# --------------------------------------------------------------------------------------------------------------
+# networks  (src/policies.jl:68-157, 246-276, 315-350)
+# --------------------------------------------------------------------------------------------------------------
+class Dense:
+    """Flux.Dense(in => out, act)."""
+
+    def __init__(self, inp, out, act="identity"):
+        self.inp, self.out, self.act = int(inp), int(out), act if isinstance(act, str) else getattr(act, "__name__", "identity")
+
+
+class Chain:
+    """Flux.Chain(Dense...)."""
+
+    def __init__(self, *layers):
+        self.layers = list(layers)
+        for a, b in zip(self.layers[:-1], self.layers[1:]):
+            if a.out != b.inp:
+                raise ValueError("Chain: layer widths do not match (%d -> %d)" % (a.out, b.inp))
+
+    @property
+    def dims(self):
+        return [self.layers[0].inp] + [l.out for l in self.layers]
+
+    @property
+    def acts(self):
+        return [L.ACT[l.act] for l in self.layers]
+
+
+class NetworkPolicy:
+    """Device-resident Chain(Dense...) + optional trailing trainables; the crux_mlp handle."""
+
+    def __init__(self, network, n_extra=0, extra_init=0.0, ctx=None, seed=0, stream=0):
+        self.ctx = ctx or default_context()
+        self.network = network
+        self.n_extra = int(n_extra)
+        dims = (C.c_int32 * len(network.dims))(*network.dims)
+        acts = (C.c_int32 * len(network.acts))(*network.acts)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.crux_mlp_create(self.ctx.h, len(network.layers), dims, acts, self.n_extra, C.byref(h)))
+        self.h = h
+        self.ctx.check(self.ctx.lib.crux_mlp_init_glorot(self.h, int(seed), int(stream), float(extra_init)))
+        self.optimizer = None
+
+    # Flux.params(pi) as one flat Float32 vector in Flux order (W1,b1,W2,b2,...,extras)
+    @property
+    def n_params(self):
+        return int(self.ctx.lib.crux_mlp_n_params(self.h))
+
+    def get_params(self):
+        out = np.empty(self.n_params, np.float32)
+        self.ctx.check(self.ctx.lib.crux_mlp_get_params(self.h, _vp(out), out.size))
+        return out
+
+    def set_params(self, flat):
+        flat = np.ascontiguousarray(flat, np.float32)
+        self.ctx.check(self.ctx.lib.crux_mlp_set_params(self.h, _vp(flat), flat.size))
+
+    def params(self):
+        """List of arrays like Flux.params: W (out,in) column-major, b (out,), ..., extras."""
+        flat, out, off = self.get_params(), [], 0
+        d = self.network.dims
+        for l in range(len(d) - 1):
+            n = d[l + 1] * d[l]
+            out.append(flat[off:off + n].reshape((d[l + 1], d[l]), order="F")); off += n
+            out.append(flat[off:off + d[l + 1]].copy()); off += d[l + 1]
+        if self.n_extra:
+            out.append(flat[off:off + self.n_extra].copy())
+        return out
+
+    def forward(self, s):
+        """value(pi, s) for ContinuousNetwork / raw logits for DiscreteNetwork (src/policies.jl:94,120)."""
+        s = np.asarray(s, np.float32)
+        d_in, d_out = self.network.dims[0], self.network.dims[-1]
+        if s.ndim == 1:
+            s = s.reshape(d_in, 1)
+        if s.shape[0] != d_in:
+            raise ValueError("value: input has %d rows, network expects %d" % (s.shape[0], d_in))
+        B = s.shape[1]
+        x = np.asfortranarray(s)
+        y = np.empty((d_out, B), np.float32, order="F")
+        self.ctx.check(self.ctx.lib.crux_mlp_forward_host(self.h, _vp(x), B, _vp(y)))
+        return y
+
+    def attach_optimizer(self, opt):
+        self.optimizer = opt
+        self.ctx.check(self.ctx.lib.crux_adam_init(self.h, opt.eta, opt.beta[0], opt.beta[1], opt.epsilon))
+
+    def adam_state(self):
+        m, v, bp = np.empty(self.n_params, np.float32), np.empty(self.n_params, np.float32), np.empty(2, np.float64)
+        self.ctx.check(self.ctx.lib.crux_adam_get_state(self.h, _vp(m), _vp(v), _vp(bp)))
+        return m, v, bp
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.ctx.h:
+                self.ctx.lib.crux_mlp_destroy(self.h)
+        except Exception:
+            pass
+
+
+class ContinuousNetwork(NetworkPolicy):
+    """ContinuousNetwork(network, output_dim) (src/policies.jl:68-98)."""
+    head = "deterministic"
+
+    def __init__(self, network, output_dim=None, **kw):
+        super().__init__(network, **kw)
+        self.output_dim = output_dim or network.dims[-1]
+
+
+class DiscreteNetwork(NetworkPolicy):
+    """DiscreteNetwork(network, outputs): softmax logit_conversion, categorical sampling (src/policies.jl:104-157)."""
+    head = "categorical"
+
+    def __init__(self, network, outputs, always_stochastic=False, **kw):
+        super().__init__(network, **kw)
+        self.outputs = list(outputs)
+        self.always_stochastic = always_stochastic
+        if len(self.outputs) != network.dims[-1]:
+            raise ValueError("DiscreteNetwork: %d outputs for %d logits" % (len(self.outputs), network.dims[-1]))
+
+
+class GaussianPolicy(NetworkPolicy):
+    """GaussianPolicy(mu::ContinuousNetwork, logSigma::AbstractArray): constant trainable log-std (src/policies.jl:315-350)."""
+    head = "gaussian"
+
+    def __init__(self, mu_chain, logSigma, **kw):
+        logSigma = np.asarray(logSigma, np.float32).reshape(-1)
+        super().__init__(mu_chain, n_extra=logSigma.size, **kw)
+        p = self.get_params(); p[-logSigma.size:] = logSigma; self.set_params(p)
+
+
+class ActorCritic:
+    """ActorCritic(A, C) (src/policies.jl:246-276): actor(pi)=A, critic(pi)=C, value(pi,s)=value(C,s)."""
+
+    def __init__(self, A, C_):
+        self.A, self.C = A, C_
+
+
+def actor(pi):
+    return pi.A if isinstance(pi, ActorCritic) else pi
+
+
+def critic(pi):
+    return pi.C if isinstance(pi, ActorCritic) else pi
+
+
+def value(pi, s):
+    """POMDPs.value(pi, s) (src/policies.jl:94,120,265)."""
+    return critic(pi).forward(s)
+
+
+def polyak_average_(to, frm, tau=1.0):
+    """polyak_average!(to, from, tau) (src/policies.jl:48-59)."""
+    to.ctx.check(to.ctx.lib.crux_polyak(to.h, frm.h, float(tau)))
+
+
+def copyto_(to, frm):
+    """Base.copyto!(to, from) on network parameters (src/policies.jl:61-65)."""
+    to.ctx.check(to.ctx.lib.crux_mlp_copy(to.h, frm.h))
+
+
+class PolicyParams:
+    """PolicyParams(pi; space, pi_explore, pi_minus) (src/policies.jl:12-19)."""
+
+    def __init__(self, pi, space=None, pi_explore=None, pi_minus=None):
+        self.pi, self.pi_explore, self.pi_minus = pi, pi_explore if pi_explore is not None else pi, pi_minus
+        a = actor(pi)
+        self.space = space or (DiscreteSpace(len(a.outputs), a.outputs) if isinstance(a, DiscreteNetwork) else ContinuousSpace(a.network.dims[-1]))
+
+
+class Adam:
+    """Flux.Optimise.Adam(eta, beta, epsilon): Float64 fields; Adam(3f-4) stores Float64(3f-4)."""
+
+    def __init__(self, eta=0.001, beta=(0.9, 0.999), epsilon=1e-8):
+        self.eta = float(np.float32(eta)) if isinstance(eta, np.float32) else float(eta)
+        self.beta, self.epsilon = (float(beta[0]), float(beta[1])), float(epsilon)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# experience buffer (src/experience_buffer.jl)
+# --------------------------------------------------------------------------------------------------------------
+_F32_KEYS = ["return", "logprob", "advantage", "value"]
+
+
+def _np_dtype(key, act_kind):
+    if key in ("s", "sp", "r", "weight") or key in _F32_KEYS:
+        return np.float32
+    if key == "a":
+        return np.bool_ if act_kind == L.ACTION_DISCRETE else np.float32
+    if key in ("done", "episode_end"):
+        return np.bool_
+    return np.int64
+
+
+def mdp_data(S, A, capacity, extras=()):
+    """mdp_data(S, A, capacity, extras) (src/experience_buffer.jl:4-35): host Dict of zero (weight: one) columns."""
+    od, ad = int(np.prod(dim(S))), int(np.prod(dim(A)))
+    kind = L.ACTION_DISCRETE if isinstance(A, DiscreteSpace) else L.ACTION_CONTINUOUS
+    d = {"s": np.zeros((od, capacity), np.float32, order="F"), "a": np.zeros((ad, capacity), _np_dtype("a", kind), order="F"),
+         "sp": np.zeros((od, capacity), np.float32, order="F"), "r": np.zeros((1, capacity), np.float32, order="F"),
+         "done": np.zeros((1, capacity), np.bool_, order="F"), "episode_end": np.zeros((1, capacity), np.bool_, order="F")}
+    for k in extras:
+        if k in _F32_KEYS:
+            d[k] = np.zeros((1, capacity), np.float32, order="F")
+        elif k == "weight":
+            d[k] = np.ones((1, capacity), np.float32, order="F")
+        elif k in ("t", "i"):
+            d[k] = np.zeros((1, capacity), np.int64, order="F")
+        else:
+            raise KeyError("Unrecognized key: %s" % k)
+    return d
+
+
+class ExperienceBuffer:
+    """ExperienceBuffer(S, A, capacity, extras; prioritized, priority_params) (src/experience_buffer.jl:53-80).
+
+    Columns live in HBM as separate arrays (SoA across keys, one transition's features contiguous)."""
+
+    def __init__(self, S, A, capacity, extras=(), prioritized=False, priority_params=None, ctx=None):
+        self.ctx = ctx or default_context()
+        self.S, self.A = S, A
+        self.obs_dim, self.act_dim = int(np.prod(dim(S))), int(np.prod(dim(A)))
+        self.act_kind = L.ACTION_DISCRETE if isinstance(A, DiscreteSpace) else L.ACTION_CONTINUOUS
+        mask = 0
+        for k in extras:
+            mask |= 1 << L.COL[k]
+        pp = priority_params or {}
+        self.alpha = float(pp.get("alpha", 0.6))
+        self.beta = pp.get("beta", lambda i: 0.5)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.crux_buffer_create(self.ctx.h, self.obs_dim, self.act_dim, self.act_kind, int(capacity), mask,
+                                                       1 if prioritized else 0, self.alpha, C.byref(h)))
+        self.h = h
+        self.prioritized = bool(prioritized)
+
+    # Base functions (:176-192)
+    def __len__(self):
+        return int(self.ctx.lib.crux_buffer_len(self.h))
+
+    @property
+    def capacity(self):
+        return int(self.ctx.lib.crux_buffer_capacity(self.h))
+
+    @property
+    def next_ind(self):
+        """1-based like the reference field."""
+        return int(self.ctx.lib.crux_buffer_next_ind(self.h)) + 1
+
+    @property
+    def total_count(self):
+        return int(self.ctx.lib.crux_buffer_total_count(self.h))
+
+    def haskey(self, k):
+        return k in L.COL and bool(self.ctx.lib.crux_buffer_has_column(self.h, L.COL[k]))
+
+    def keys(self):
+        return [k for k in L.COL if self.haskey(k)]
+
+    def _shape(self, k, n):
+        rows = self.obs_dim if k in ("s", "sp") else self.act_dim if k == "a" else 1
+        return (rows, n)
+
+    def __getitem__(self, k):
+        """b[key] = view of the first length(b) columns (:176); returned as a host copy."""
+        n = len(self)
+        out = np.empty(self._shape(k, n), _np_dtype(k, self.act_kind), order="F")
+        self.ctx.check(self.ctx.lib.crux_buffer_read_column(self.h, L.COL[k], _vp(out), n))
+        return out
+
+    def __setitem__(self, k, v):
+        """b[key] .= v."""
+        n = len(self)
+        v = np.asfortranarray(np.broadcast_to(np.asarray(v, _np_dtype(k, self.act_kind)), self._shape(k, n)))
+        self.ctx.check(self.ctx.lib.crux_buffer_write_column(self.h, L.COL[k], _vp(v), n))
+
+    def column_ptr(self, k):
+        p = C.c_void_p()
+        self.ctx.check(self.ctx.lib.crux_buffer_column_ptr(self.h, L.COL[k], C.byref(p)))
+        return p.value
+
+    def isprioritized(self):
+        return self.prioritized
+
+    def clear_(self):
+        self.ctx.check(self.ctx.lib.crux_buffer_clear(self.h)); return self
+
+    def push_(self, data, ids=None):
+        """push!(b, data; ids) (:232-259). `data` is a dict of (features, N) arrays or another ExperienceBuffer.
+        Returns the (1-based) destination indices I like the reference."""
+        if isinstance(data, ExperienceBuffer):
+            if ids is None:
+                ids0 = None; n = len(data)
+            else:
+                ids0 = np.ascontiguousarray(np.asarray(ids, np.int64) - 1); n = ids0.size
+            I = np.empty(n, np.int64)
+            self.ctx.check(self.ctx.lib.crux_buffer_push_buffer(self.h, data.h, _vp(ids0), n, _vp(I)))
+            return I + 1
+        first = next(iter(data.values()))
+        N = np.asarray(first).shape[-1]
+        cols = (C.c_void_p * L.NCOLS)()
+        keep = []
+        for k, v in data.items():
+            if k not in L.COL or not self.haskey(k):
+                continue
+            arr = np.asarray(v)
+            arr = arr.reshape(self._shape(k, N)) if arr.ndim == 1 else arr
+            if arr.shape[:-1] != self._shape(k, N)[:-1]:
+                raise L.CruxError(L.EINVAL, "push!: column :%s has shape %s, buffer expects %s (@assert size(v1)[1:end-1] == size(v2)[1:end-1])" % (k, arr.shape, self._shape(k, N)))
+            arr = np.asfortranarray(arr.astype(_np_dtype(k, self.act_kind)))
+            if ids is not None:
+                arr = np.asfortranarray(arr[:, np.asarray(ids) - 1])
+            keep.append(arr); cols[L.COL[k]] = arr.ctypes.data
+        if ids is not None:
+            N = len(ids)
+        I = np.empty(N, np.int64)
+        self.ctx.check(self.ctx.lib.crux_buffer_push_host(self.h, N, cols, _vp(I)))
+        return I + 1
+
+    def shuffle_(self, perm):
+        """shuffle!(b) with an explicit 1-based permutation (:118-124)."""
+        p = np.ascontiguousarray(np.asarray(perm, np.int64) - 1)
+        self.ctx.check(self.ctx.lib.crux_buffer_permute(self.h, _vp(p))); return self
+
+    def minibatch(self, indices):
+        """minibatch_copy(b, indices) (:171) with 1-based indices -> dict of host arrays."""
+        ids = np.ascontiguousarray(np.asarray(indices, np.int64) - 1)
+        outs = (C.c_void_p * L.NCOLS)(); res = {}
+        for k in self.keys():
+            res[k] = np.empty(self._shape(k, ids.size), _np_dtype(k, self.act_kind), order="F"); outs[L.COL[k]] = res[k].ctypes.data
+        self.ctx.check(self.ctx.lib.crux_buffer_gather_host(self.h, _vp(ids), ids.size, outs))
+        return res
+
+    def get_last_N_indices(self, N):
+        """get_last_N_indices(b, N) (:223-229), 1-based."""
+        out = np.empty(max(1, min(N, len(self))), np.int64)
+        n = self.ctx.lib.crux_buffer_last_n_indices(self.h, int(N), _vp(out))
+        return out[:n] + 1
+
+    @property
+    def indices(self):
+        n = self.capacity; out = np.empty(n, np.int64)
+        self.ctx.check(self.ctx.lib.crux_buffer_indices(self.h, _vp(out), n))
+        return out
+
+    def update_priorities_(self, I, v):
+        """update_priorities!(b, I, v) (:290-301); I 1-based; v Float64 or Float32 array (dtype is significant)."""
+        I0 = np.ascontiguousarray(np.asarray(I, np.int64) - 1)
+        v = np.ascontiguousarray(v)
+        is64 = v.dtype == np.float64
+        if not is64:
+            v = v.astype(np.float32)
+        self.ctx.check(self.ctx.lib.crux_per_update(self.h, _vp(I0), _vp(v), 1 if is64 else 0, I0.size))
+
+    def priority_params(self):
+        pr = np.empty(self.capacity, np.float32); mx, mn = C.c_float(), C.c_float()
+        self.ctx.check(self.ctx.lib.crux_per_get(self.h, _vp(pr), C.byref(mx), C.byref(mn), None))
+        return {"priorities": pr, "max_priority": mx.value, "min_priority": mn.value, "alpha": self.alpha}
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.ctx.h:
+                self.ctx.lib.crux_buffer_destroy(self.h)
+        except Exception:
+            pass
+
+
+def capacity(b):
+    return b.capacity
+
+
+def split_batches(N, fracs):
+    """split_batches(N, fracs) (src/experience_buffer.jl:126-131)."""
+    if not isinstance(fracs, (list, tuple, np.ndarray)) or not math.isclose(sum(fracs), 1.0, rel_tol=1e-8):
+        raise AssertionError("sum(fracs) must be 1")
+    b = [int(math.floor(N * f)) for f in fracs]
+    b[0] += N - sum(b)
+    return b
+
+
+# --------------------------------------------------------------------------------------------------------------
+# sampler (src/sampler.jl)
+# --------------------------------------------------------------------------------------------------------------
+class GymMDP:
+    """Stand-in for POMDPGym's GymPOMDP(:CartPole) etc.: names a dynamics kind that runs inside the rollout kernel.
+    n_envs independent-seed copies are stepped together (env-major Vector{Sampler} semantics)."""
+
+    def __init__(self, kind, n_envs=1, seed=0, discount=0.99):
+        self.kind, self.n_envs, self.seed, self.discount = kind, int(n_envs), int(seed), float(discount)
+        self.obs_dim, self.act_dim, self.discrete = {"cartpole": (4, 2, True), "pendulum": (3, 1, False)}[kind]
+
+    def state_space(self, mu=0.0, sigma=1.0):
+        """state_space(mdp; mu, sigma) (src/spaces.jl:34-43)."""
+        return ContinuousSpace(self.obs_dim, np.float32, mu, sigma)
+
+    def action_space(self):
+        return DiscreteSpace(self.act_dim) if self.discrete else ContinuousSpace(self.act_dim)
+
+
+def CartPoleMDP(**kw):
+    return GymMDP("cartpole", **kw)
+
+
+def PendulumMDP(**kw):
+    return GymMDP("pendulum", **kw)
+
+
+def discount(mdp):
+    return mdp.discount
+
+
+class LinearDecaySchedule:
+    """LinearDecaySchedule(start, stop, steps) (src/utils.jl:116-126)."""
+
+    def __init__(self, start, stop, steps):
+        self.start, self.stop, self.steps = float(start), float(stop), int(steps)
+
+    def __call__(self, i):
+        rate = (self.start - self.stop) / self.steps
+        return max(self.stop, self.start - i * rate)
+
+
+class EpsGreedyPolicy:
+    """ϵGreedyPolicy(eps, actions) = MixedPolicy(eps, uniform random action) (src/policies.jl:466-494)."""
+
+    def __init__(self, eps, actions):
+        self.eps = eps if isinstance(eps, LinearDecaySchedule) else LinearDecaySchedule(eps, eps, 1)
+        self.actions = list(actions)
+
+
+class GaussianNoiseExplorationPolicy:
+    """GaussianNoiseExplorationPolicy(sigma; a_min, a_max, eps_min, eps_max) (src/policies.jl:499-514)."""
+
+    def __init__(self, sigma=0.01, a_min=-np.inf, a_max=np.inf, eps_min=-np.inf, eps_max=np.inf):
+        self.sigma, self.a_min, self.a_max, self.eps_min, self.eps_max = float(sigma), float(a_min), float(a_max), float(eps_min), float(eps_max)
+
+
+class Sampler:
+    """Sampler(mdp, agent; max_steps, required_columns, lambda, S) (src/sampler.jl:1-29) for mdp.n_envs environments."""
+
+    def __init__(self, mdp, agent, S=None, max_steps=100, required_columns=(), lam=float("nan"), ctx=None):
+        self.ctx = ctx or default_context()
+        self.mdp = mdp
+        self.agent = agent if isinstance(agent, PolicyParams) else PolicyParams(agent)
+        self.S = S or mdp.state_space()
+        self.max_steps, self.required_columns = int(max_steps), list(required_columns)
+        self.gamma, self.lam = np.float32(discount(mdp)), np.float32(lam)
+        od = mdp.obs_dim
+        mu = np.ascontiguousarray(np.broadcast_to(np.asarray(self.S.mu, np.float32), (od,)))
+        sg = np.ascontiguousarray(np.broadcast_to(np.asarray(self.S.sigma, np.float32), (od,)))
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.crux_env_create(self.ctx.h, L.ENV[mdp.kind], mdp.n_envs, self.max_steps, float(self.gamma), _vp(mu), _vp(sg),
+                                                    mdp.seed, 0, 0, C.byref(h)))
+        self.h = h
+
+    @property
+    def n_envs(self):
+        return self.mdp.n_envs
+
+    def state(self):
+        sd = int(self.ctx.lib.crux_env_state_dim(self.h)); E = self.n_envs
+        st, el, nr = np.empty((sd, E), np.float64, order="F"), np.empty(E, np.int64), np.empty(E, np.int64)
+        self.ctx.check(self.ctx.lib.crux_env_get_state(self.h, _vp(st), _vp(el), _vp(nr)))
+        return st, el, nr
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.ctx.h:
+                self.ctx.lib.crux_env_destroy(self.h)
+        except Exception:
+            pass
+
+
+def _rollout_cfg(sampler, explore, reset, i):
+    cfg = L.RolloutCfg()
+    pi_on, pe = actor(sampler.agent.pi), sampler.agent.pi_explore
+    cfg.explore, cfg.reset_at_end, cfg.i0 = int(bool(explore)), int(bool(reset)), int(i)
+    cfg.eps_steps, cfg.noise_sigma = 0, -1.0
+    cfg.noise_eps_min, cfg.noise_eps_max, cfg.a_min, cfg.a_max = -np.inf, np.inf, -np.inf, np.inf
+    if isinstance(pe, EpsGreedyPolicy):
+        cfg.head = L.HEAD["greedy_q"]; cfg.eps_start, cfg.eps_stop, cfg.eps_steps = pe.eps.start, pe.eps.stop, pe.eps.steps
+    elif isinstance(pe, GaussianNoiseExplorationPolicy):
+        cfg.head = L.HEAD["deterministic"]; cfg.noise_sigma = pe.sigma
+        cfg.noise_eps_min, cfg.noise_eps_max, cfg.a_min, cfg.a_max = pe.eps_min, pe.eps_max, pe.a_min, pe.a_max
+    else:
+        cfg.head = L.HEAD[pi_on.head]
+    return cfg, pi_on
+
+
+def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=None):
+    """steps!(sampler, buffer; Nsteps, explore, i, reset, cb) (src/sampler.jl:139-173).
+
+    Nsteps counts transitions over all of the sampler's environments (Nsteps/n_envs per environment, env-major).
+    GAE / returns are filled like terminate_episode! does (:56-57) when the buffer carries those columns and holds
+    exactly this rollout (the on-policy case, buffer capacity == Nsteps). Returns the info dict (avg_r as record_avgr)."""
+    E = sampler.n_envs
+    if Nsteps % E:
+        raise ValueError("steps!: Nsteps=%d is not a multiple of n_envs=%d" % (Nsteps, E))
+    cfg, pi_on = _rollout_cfg(sampler, explore, reset, i)
+    sr, ne = C.c_double(), C.c_int64()
+    sampler.ctx.check(sampler.ctx.lib.crux_rollout(sampler.h, pi_on.h, C.byref(cfg), buffer.h, Nsteps // E, C.byref(sr), C.byref(ne)))
+    if buffer.haskey("advantage") and len(buffer) == Nsteps:
+        fill_gae_(buffer, critic(sampler.agent.pi), sampler.lam, sampler.gamma)
+    if buffer.haskey("return") and len(buffer) == Nsteps:
+        fill_returns_(buffer, sampler.gamma)
+    info = {"sum_r": sr.value, "n_episode_end": ne.value, "avg_r": sr.value / ne.value if ne.value else float("nan")}
+    if cb:
+        cb(buffer, info)
+    return info
+
+
+def fill_gae_(buffer, V, lam, gamma):
+    """fill_gae!(d::ExperienceBuffer, V, lambda, gamma) (src/sampler.jl:255-273)."""
+    buffer.ctx.check(buffer.ctx.lib.crux_fill_gae(buffer.h, critic(V).h, float(lam), float(gamma)))
+
+
+def fill_returns_(buffer, gamma):
+    """fill_returns! over episodes(buffer) (src/sampler.jl:275-281)."""
+    buffer.ctx.check(buffer.ctx.lib.crux_fill_returns(buffer.h, float(gamma)))
+
+
+def whiten_(buffer, key="advantage"):
+    """buffer[key] .= whiten(buffer[key]) (src/utils.jl:41-42, ppo.jl:61)."""
+    buffer.ctx.check(buffer.ctx.lib.crux_whiten(buffer.h, L.COL[key]))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# training (src/training.jl)
+# --------------------------------------------------------------------------------------------------------------
+class _Loss:
+    def __init__(self, name):
+        self.name = name
+
+
+ppo_loss = _Loss("ppo")            # src/model_free/rl/ppo.jl:4-21
+value_mse_loss = _Loss("value_mse")  # (pi, P, D) -> Flux.mse(value(pi, D[:s]), D[:return])  ppo.jl:60
+
+
+class TrainingParams:
+    """TrainingParams(; loss, optimizer=Adam(3f-4), batch_size=128, epochs=80, early_stopping, name, max_batches)
+    (src/training.jl:1-11). early_stopping is expressed as target_kl (PPO's `infos[end][:kl] > target_kl`, ppo.jl:59)."""
+
+    def __init__(self, loss, optimizer=None, batch_size=128, epochs=80, target_kl=None, name="", max_batches=math.inf,
+                 shuffle_seed=0):
+        self.loss = loss
+        self.optimizer = optimizer or Adam(np.float32(3e-4))
+        self.batch_size, self.epochs, self.target_kl, self.name, self.max_batches = int(batch_size), int(epochs), target_kl, name, max_batches
+        self.shuffle_seed, self.shuffle_counter = int(shuffle_seed), 0
+
+
+def _train_cfg(pi, p, P):
+    cfg = L.TrainCfg()
+    cfg.loss = L.LOSS[p.loss.name]
+    cfg.head = L.HEAD.get(getattr(pi, "head", "deterministic"), 3)
+    cfg.batch_size, cfg.epochs = p.batch_size, p.epochs
+    cfg.max_batches = 0 if p.max_batches in (None, math.inf) else int(p.max_batches)
+    cfg.eps_clip, cfg.lambda_p, cfg.lambda_e = float(P.get("eps", 0.2)), float(P.get("lambda_p", 1.0)), float(P.get("lambda_e", 0.1))
+    cfg.target_kl = -1.0 if p.target_kl is None else float(p.target_kl)
+    cfg.shuffle_seed, cfg.shuffle_counter = p.shuffle_seed, p.shuffle_counter
+    return cfg
+
+
+def _info_dict(p, raw, extra=True):
+    d = {p.name + "loss": float(raw[L.INFO["loss"]]), p.name + "grad_norm": float(raw[L.INFO["grad_norm"]])}
+    if p.loss.name == "ppo":
+        for k in ("entropy", "kl", "clip_fraction", "avg_advantage", "avg_return"):
+            d[k] = float(raw[L.INFO[k]])
+    return d
+
+
+def _ensure_opt(pi, p):
+    if pi.optimizer is not p.optimizer:
+        pi.attach_optimizer(p.optimizer)
+
+
+def train_(pi, p, P, D, indices, info=None):
+    """Flux.Optimise.train!(pi, loss, p; info) on minibatch(D, indices) (src/training.jl:13-25); 1-based indices.
+    Raises CruxError(ENAN) like `error("NaN detected!")` (:20)."""
+    _ensure_opt(pi, p)
+    ids = np.ascontiguousarray(np.asarray(indices, np.int64) - 1)
+    raw = np.zeros(L.INFO_N, np.float32)
+    cfg = _train_cfg(pi, p, P)
+    pi.ctx.check(pi.ctx.lib.crux_train_step(pi.h, D.h, C.byref(cfg), _vp(ids), ids.size, _vp(raw)))
+    info = info if info is not None else {}
+    info.update(_info_dict(p, raw))
+    return info
+
+
+def batch_train_(pi, p, P, D, info=None, perms=None):
+    """batch_train!(pi, p, P, D; info) (src/training.jl:28-55): epochs x (shuffle!, partition, train!) with max_batches and
+    early stopping, as ONE persistent kernel. perms: optional (epochs, len) 1-based permutations (else Philox)."""
+    _ensure_opt(pi, p)
+    cfg = _train_cfg(pi, p, P)
+    pp = None
+    if perms is not None:
+        pp = np.ascontiguousarray(np.asarray(perms, np.int64) - 1)
+        if pp.shape != (p.epochs, len(D)):
+            raise ValueError("batch_train!: perms must have shape (epochs, length(D))")
+    raw = np.zeros(L.INFO_N, np.float32)
+    ep = np.zeros((p.epochs, L.INFO_N), np.float32)
+    pi.ctx.check(pi.ctx.lib.crux_batch_train(pi.h, D.h, C.byref(cfg), _vp(pp), _vp(raw), _vp(ep)))
+    p.shuffle_counter += int(raw[L.INFO["epochs_run"]])
+    info = info if info is not None else {}
+    info.update(_info_dict(p, raw))
+    info[p.name + "batches_trained"] = int(raw[L.INFO["batches_trained"]])
+    info["_epochs_run"] = int(raw[L.INFO["epochs_run"]])
+    info["_epoch_infos"] = ep[: info["_epochs_run"]]
+    return info
+
+
+# --------------------------------------------------------------------------------------------------------------
+# on-policy solver + PPO (src/model_free/on_policy.jl, src/model_free/rl/ppo.jl:40-65)
+# --------------------------------------------------------------------------------------------------------------
+class OnPolicySolver:
+    """OnPolicySolver(; agent, S, N, dN, max_steps, a_opt, c_opt, P, lambda_gae, required_columns, post_batch_callback)
+    (src/model_free/on_policy.jl:31-54)."""
+
+    def __init__(self, agent, S, N=1000, dN=200, max_steps=100, a_opt=None, c_opt=None, P=None, lambda_gae=0.95,
+                 required_columns=(), post_batch_callback=None, post_sample_callback=None, i=0):
+        self.agent, self.S, self.N, self.dN, self.max_steps = agent, S, int(N), int(dN), int(max_steps)
+        self.a_opt, self.c_opt, self.P = a_opt, c_opt, P or {}
+        self.lambda_gae, self.required_columns = np.float32(lambda_gae), list(required_columns)
+        self.post_batch_callback, self.post_sample_callback, self.i = post_batch_callback, post_sample_callback, int(i)
+        self.buffer, self.sampler, self.history = None, None, []
+
+
+def policy_gradient_training(solver, D):
+    """policy_gradient_training(S, D) (src/model_free/on_policy.jl:56-78): actor batch_train!, then critic."""
+    info = {}
+    batch_train_(actor(solver.agent.pi), solver.a_opt, solver.P, D, info=info)
+    if solver.c_opt is not None:
+        batch_train_(critic(solver.agent.pi), solver.c_opt, solver.P, D, info=info)
+    return info
+
+
+def solve(solver, mdp):
+    """POMDPs.solve(S::OnPolicySolver, mdp) (src/model_free/on_policy.jl:80-109), logging left out (SURVEY #14)."""
+    if solver.buffer is None:
+        solver.buffer = ExperienceBuffer(solver.S, solver.agent.space, solver.dN, solver.required_columns)
+        solver.sampler = Sampler(mdp, solver.agent, S=solver.S, required_columns=solver.required_columns, lam=solver.lambda_gae,
+                                 max_steps=solver.max_steps)
+    D, s = solver.buffer, solver.sampler
+    stop = solver.i + solver.N - solver.dN
+    i = solver.i
+    while i <= stop:
+        solver.i = i
+        info = steps_(s, D, Nsteps=solver.dN, explore=True, i=i, reset=True, cb=solver.post_sample_callback)     # :96
+        if solver.post_batch_callback:
+            solver.post_batch_callback(D, info)                                                                   # :99
+        tinfo = policy_gradient_training(solver, D)                                                               # :102
+        tinfo.update({k: v for k, v in info.items() if k == "avg_r"})
+        solver.history.append(tinfo)
+        i += solver.dN
+    solver.i += solver.dN
+    return solver.agent.pi
+
+
+def PPO(pi, S, eps=0.2, lambda_p=1.0, lambda_e=0.1, target_kl=0.012, a_opt=None, c_opt=None, required_columns=(), **kw):
+    """PPO(; pi::ActorCritic, eps, lambda_p, lambda_e, target_kl, a_opt, c_opt, ...) (src/model_free/rl/ppo.jl:40-65)."""
+    a_opt, c_opt = dict(a_opt or {}), dict(c_opt or {})
+    cols = list(dict.fromkeys(list(required_columns) + ["return", "logprob", "advantage"]))
+    return OnPolicySolver(agent=PolicyParams(pi), S=S, P={"eps": eps, "lambda_p": lambda_p, "lambda_e": lambda_e},
+                          a_opt=TrainingParams(loss=ppo_loss, target_kl=target_kl, name="actor_", **a_opt),
+                          c_opt=TrainingParams(loss=value_mse_loss, name="critic_", **c_opt),
+                          post_batch_callback=lambda D, info: whiten_(D, "advantage"),
+                          required_columns=cols, **kw)

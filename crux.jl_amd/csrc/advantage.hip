@@ -1,0 +1,115 @@
+// advantage.hip -- fill_gae! / fill_returns! / whiten on device columns.
+// Reference: src/sampler.jl:255-281 (GAE + returns), src/utils.jl:41-42 (whiten), episodes() src/experience_buffer.jl:194-212.
+#include "common.h"
+
+int32_t crux_mlp_forward_impl(crux_mlp* net, const float* d_x, int64_t B, float* d_y, const float* params_override);
+int32_t crux_values_fast(crux_mlp* net, const float* d_x, int64_t B, float* d_y);   // mfma path (train_mfma.hip); returns CRUX_EUNSUP if shape unsupported
+
+// One thread per episode: a thread sitting on an episode-end row (or the last row) walks its episode backwards.
+// The recurrence is evaluated sequentially in Float32 with the reference's association
+//   A = ((c*A + r) + ((1f0 - done)*gamma)*Vsp) - Vs        (sampler.jl:269)
+//   R = r + gamma*R                                        (sampler.jl:278)
+// so results are bit-identical to the scalar loop given the same V(s), V(sp).
+__global__ void k_gae_returns(const float* __restrict__ r, const uint8_t* __restrict__ done, const uint8_t* __restrict__ ee,
+                              const float* __restrict__ Vs, const float* __restrict__ Vsp, float lambda, float gamma, int64_t n,
+                              float* __restrict__ adv, float* __restrict__ ret, int32_t* __restrict__ nan_flag) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (!(ee[i] || i == n - 1)) continue;
+    float A = 0.f, R = 0.f; const float c = __fmul_rn(lambda, gamma);
+    bool bad = false;
+    for (int64_t k = i; k >= 0 && (k == i || !ee[k]); --k) {
+      const float rk = r[k];
+      if (adv) {
+        const float t2 = __fadd_rn(__fmul_rn(c, A), rk);
+        const float t3 = __fmul_rn(__fmul_rn(__fsub_rn(1.f, done[k] ? 1.f : 0.f), gamma), Vsp[k]);
+        A = __fsub_rn(__fadd_rn(t2, t3), Vs[k]);
+        adv[k] = A; bad |= isnan(A);
+      }
+      if (ret) { R = __fadd_rn(rk, __fmul_rn(gamma, R)); ret[k] = R; }
+    }
+    if (bad) atomicOr(nan_flag, 1);
+  }
+}
+
+// whiten(v) = (v .- mean(v)) ./ std(v), Bessel-corrected std; single block, deterministic tree reductions in Float64.
+__global__ __launch_bounds__(1024) void k_whiten(float* __restrict__ v, int64_t n) {
+  __shared__ double red[16];
+  __shared__ float sh_mean, sh_sd;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double s = 0.0;
+  for (int64_t i = tid; i < n; i += 1024) s += (double)v[i];
+  s = wave_sum_d(s); if (lane == 0) red[wid] = s; __syncthreads();
+  if (tid == 0) { double t = 0; for (int w = 0; w < 16; ++w) t += red[w]; sh_mean = (float)(t / (double)n); }
+  __syncthreads();
+  const double mean = (double)sh_mean;
+  double ss = 0.0;
+  for (int64_t i = tid; i < n; i += 1024) { const double d = (double)v[i] - mean; ss += d * d; }
+  ss = wave_sum_d(ss); __syncthreads(); if (lane == 0) red[wid] = ss; __syncthreads();
+  if (tid == 0) { double t = 0; for (int w = 0; w < 16; ++w) t += red[w]; sh_sd = (float)sqrt(t / (double)(n - 1)); }
+  __syncthreads();
+  const float mf = sh_mean, sd = sh_sd;
+  for (int64_t i = tid; i < n; i += 1024) v[i] = __fdiv_rn(__fsub_rn(v[i], mf), sd);
+}
+
+static int32_t values(crux_mlp* critic, const float* d_x, int64_t n, float* d_y) {
+  int32_t rc = crux_values_fast(critic, d_x, n, d_y);
+  if (rc == CRUX_EUNSUP) rc = crux_mlp_forward_impl(critic, d_x, n, d_y, nullptr);
+  return rc;
+}
+
+extern "C" {
+
+int32_t crux_fill_gae(crux_buffer* b, crux_mlp* critic, float lambda, float gamma) {
+  if (!b || !critic) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx;
+  if (!has_col(b, CRUX_COL_ADVANTAGE)) return crux_fail(c, CRUX_EINVAL, "fill_gae!: buffer has no :advantage column");
+  if (critic->nd.dims[critic->nd.L] != 1 || critic->nd.dims[0] != b->obs_dim) return crux_fail(c, CRUX_EINVAL, "fill_gae!: critic must map obs(%d) -> 1 (@assert length(Vs) == 1)", b->obs_dim);
+  const int64_t n = b->elements; if (n == 0) return CRUX_OK;
+  const size_t vb = ((4 * (size_t)n + 255) / 256) * 256;
+  char* sc = (char*)crux_scratch(c, 2 * vb + 256);
+  if (!sc) return crux_fail(c, CRUX_ENOMEM, "fill_gae!: scratch");
+  float* Vs = (float*)sc; float* Vsp = (float*)(sc + vb); int32_t* flag = (int32_t*)(sc + 2 * vb);
+  HIPCHK(c, hipMemsetAsync(flag, 0, 4, c->stream));
+  crux_prof_begin(c, CRUX_PROF_VALUES);
+  int32_t rc = values(critic, (const float*)b->col[CRUX_COL_S], n, Vs); if (rc) return rc;
+  rc = values(critic, (const float*)b->col[CRUX_COL_SP], n, Vsp); if (rc) return rc;
+  crux_prof_end(c, CRUX_PROF_VALUES);
+  crux_prof_begin(c, CRUX_PROF_GAE);
+  hipLaunchKernelGGL(k_gae_returns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE],
+                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], Vs, Vsp, lambda, gamma, n, (float*)b->col[CRUX_COL_ADVANTAGE], (float*)nullptr, flag);
+  crux_prof_end(c, CRUX_PROF_GAE);
+  rc = crux_launch_check(c, "k_gae_returns"); if (rc) return rc;
+  int32_t h = 0;
+  HIPCHK(c, hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (h) return crux_fail(c, CRUX_ENAN, "fill_gae!: NaN advantage (@assert !isnan(A))");
+  return CRUX_OK;
+}
+
+int32_t crux_fill_returns(crux_buffer* b, float gamma) {
+  if (!b) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx;
+  if (!has_col(b, CRUX_COL_RETURN)) return crux_fail(c, CRUX_EINVAL, "fill_returns!: buffer has no :return column");
+  const int64_t n = b->elements; if (n == 0) return CRUX_OK;
+  int32_t* flag = (int32_t*)crux_scratch(c, 256);
+  if (!flag) return crux_fail(c, CRUX_ENOMEM, "fill_returns!: scratch");
+  crux_prof_begin(c, CRUX_PROF_GAE);
+  hipLaunchKernelGGL(k_gae_returns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE],
+                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], (const float*)nullptr, (const float*)nullptr, 0.f, gamma, n, (float*)nullptr, (float*)b->col[CRUX_COL_RETURN], flag);
+  crux_prof_end(c, CRUX_PROF_GAE);
+  return crux_launch_check(c, "k_gae_returns");
+}
+
+int32_t crux_whiten(crux_buffer* b, int32_t key) {
+  if (!b) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx;
+  if (!has_col(b, key) || col_elem(b, key) != 4 || col_rows(b, key) != 1) return crux_fail(c, CRUX_EINVAL, "whiten: column %d is not a 1 x N Float32 column", key);
+  const int64_t n = b->elements;
+  if (n < 2) return crux_fail(c, CRUX_EINVAL, "whiten: need at least 2 elements");
+  crux_prof_begin(c, CRUX_PROF_WHITEN);
+  hipLaunchKernelGGL(k_whiten, dim3(1), dim3(1024), 0, c->stream, (float*)b->col[key], n);
+  crux_prof_end(c, CRUX_PROF_WHITEN);
+  return crux_launch_check(c, "k_whiten");
+}
+
+}  // extern "C"

@@ -1,0 +1,337 @@
+// buffer.hip -- ExperienceBuffer: device SoA columns, ring push, gather, permutation, priorities.
+// Reference: src/experience_buffer.jl (mdp_data :4-35, ExperienceBuffer :53-80, shuffle! :118-124,
+// minibatch :170-171, get_last_N_indices :223-229, push! :232-259, update_priorities! :290-301).
+#include "common.h"
+
+// ---- kernels ------------------------------------------------------------------------------------
+// row gather/scatter on a column: dst[dst_idx[j]] = src[src_idx[j]] (idx NULL => j). Rows are `stride`
+// bytes; W = access width in bytes (4 when stride % 4 == 0, else 1). Consecutive threads touch
+// consecutive bytes of a row, so a wave covers whole rows contiguously.
+template <typename T>
+__global__ void k_copy_rows(T* __restrict__ dst, const int64_t* __restrict__ dst_idx, const T* __restrict__ src,
+                            const int64_t* __restrict__ src_idx, int64_t n, int32_t row_elems) {
+  const int64_t total = n * row_elems;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = t / row_elems; const int32_t e = (int32_t)(t - j * row_elems);
+    const int64_t sj = src_idx ? src_idx[j] : j, dj = dst_idx ? dst_idx[j] : j;
+    dst[dj * row_elems + e] = src[sj * row_elems + e];
+  }
+}
+__global__ void k_copy_rows_i32idx(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, const int32_t* __restrict__ src_idx,
+                                   int64_t n, int32_t row_elems) {
+  const int64_t total = n * row_elems;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = t / row_elems; const int32_t e = (int32_t)(t - j * row_elems);
+    dst[j * row_elems + e] = src[(int64_t)src_idx[j] * row_elems + e];
+  }
+}
+__global__ void k_copy_rows_i32idx_u8(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, const int32_t* __restrict__ src_idx,
+                                      int64_t n, int32_t row_elems) {
+  const int64_t total = n * row_elems;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = t / row_elems; const int32_t e = (int32_t)(t - j * row_elems);
+    dst[j * row_elems + e] = src[(int64_t)src_idx[j] * row_elems + e];
+  }
+}
+__global__ void k_fill_f32(float* p, float v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_fill_f32_idx(float* p, const int64_t* idx, float v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[idx[i]] = v;
+}
+
+// update_priorities! (:290-301): val = v + eps(Float32); priorities[I] = val^alpha; max/min track the
+// un-powered val (Float32 fields). Positive floats order like their bit patterns, so atomicMax/Min on
+// the int view reproduce the sequential max/min exactly.
+__global__ void k_per_update(float* __restrict__ pr, float* __restrict__ pminmax, const int64_t* __restrict__ I,
+                             const double* __restrict__ v64, const float* __restrict__ v32, const float* __restrict__ vconst_from_max,
+                             float alpha, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double val;
+    if (vconst_from_max) val = (double)vconst_from_max[0] + (double)1.1920928955078125e-07f;   // push!: max_priority*ones(N) (Float64)
+    else if (v64) val = v64[i] + (double)1.1920928955078125e-07f;
+    else { const float vf = __fadd_rn(v32[i], 1.1920928955078125e-07f); val = (double)vf; }
+    pr[I[i]] = (float)pow(val, (double)alpha);
+    const float vf32 = (float)val;
+    atomicMax((int*)&pminmax[0], __float_as_int(vf32));
+    atomicMin((int*)&pminmax[1], __float_as_int(vf32));
+  }
+}
+
+static unsigned grid_for(int64_t total) { int64_t nb = (total + 255) / 256; if (nb < 1) nb = 1; if (nb > 8192) nb = 8192; return (unsigned)nb; }
+
+// copy rows between columns with 64-bit index arrays resident on the device
+static void launch_copy_rows(crux_ctx* c, void* dst, const int64_t* d_dst_idx, const void* src, const int64_t* d_src_idx, int64_t n, size_t stride) {
+  if (n <= 0) return;
+  if (stride % 4 == 0) { const int32_t re = (int32_t)(stride / 4);
+    hipLaunchKernelGGL(k_copy_rows<uint32_t>, dim3(grid_for(n * re)), dim3(256), 0, c->stream, (uint32_t*)dst, d_dst_idx, (const uint32_t*)src, d_src_idx, n, re); }
+  else { const int32_t re = (int32_t)stride;
+    hipLaunchKernelGGL(k_copy_rows<uint8_t>, dim3(grid_for(n * re)), dim3(256), 0, c->stream, (uint8_t*)dst, d_dst_idx, (const uint8_t*)src, d_src_idx, n, re); }
+}
+
+// exported to other translation units ------------------------------------------------------------------
+int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I) {
+  I.resize((size_t)N);
+  for (int64_t j = 0; j < N; ++j) I[(size_t)j] = (b->next_ind + j) % b->capacity;   // mod1.(next_ind:next_ind+N-1, C) (:236)
+  return CRUX_OK;
+}
+void crux_buffer_ring_advance(crux_buffer* b, int64_t N) {   // :256-257
+  b->total_count += N;
+  b->elements = b->elements + N < b->capacity ? b->elements + N : b->capacity;
+  b->next_ind = (b->next_ind + N) % b->capacity;
+}
+// priorities of freshly pushed rows (:254); d_I device index array
+int32_t crux_buffer_per_on_push(crux_buffer* b, const int64_t* d_I, int64_t N) {
+  if (!b->prioritized || N <= 0) return CRUX_OK;
+  // all pushed rows get max_priority; the kernel reads pminmax[0] live, which this update can only re-set to itself
+  hipLaunchKernelGGL(k_per_update, dim3(grid_for(N)), dim3(256), 0, b->ctx->stream, b->priorities, b->pminmax, d_I, (const double*)nullptr,
+                     (const float*)nullptr, (const float*)b->pminmax, b->alpha, N);
+  b->cumsum_valid = false;
+  return crux_launch_check(b->ctx, "k_per_update(push)");
+}
+// physical permutation of every column by a device int32 order: new[:,j] = old[:,order[j]]
+int32_t crux_buffer_apply_order(crux_buffer* b, const int32_t* d_order, int64_t n) {
+  crux_ctx* c = b->ctx;
+  size_t maxst = 0; for (int k = 0; k < CRUX_NCOLS; ++k) if (has_col(b, k) && col_stride(b, k) > maxst) maxst = col_stride(b, k);
+  void* tmp = crux_scratch(c, maxst * (size_t)n + 256);
+  if (!tmp) return crux_fail(c, CRUX_ENOMEM, "apply_order: scratch");
+  for (int k = 0; k < CRUX_NCOLS; ++k) {
+    if (!has_col(b, k)) continue;
+    const size_t st = col_stride(b, k);
+    if (st % 4 == 0) { const int32_t re = (int32_t)(st / 4);
+      hipLaunchKernelGGL(k_copy_rows_i32idx, dim3(grid_for(n * re)), dim3(256), 0, c->stream, (uint32_t*)tmp, (const uint32_t*)b->col[k], d_order, n, re); }
+    else { const int32_t re = (int32_t)st;
+      hipLaunchKernelGGL(k_copy_rows_i32idx_u8, dim3(grid_for(n * re)), dim3(256), 0, c->stream, (uint8_t*)tmp, (const uint8_t*)b->col[k], d_order, n, re); }
+    HIPCHK(c, hipMemcpyAsync(b->col[k], tmp, st * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return crux_launch_check(c, "apply_order");
+}
+
+extern "C" {
+
+int32_t crux_buffer_create(crux_ctx* ctx, int32_t obs_dim, int32_t act_dim, int32_t act_kind, int64_t capacity, uint32_t column_mask,
+                           int32_t prioritized, float alpha, crux_buffer** out) {
+  if (!ctx || !out) return CRUX_EINVAL;
+  if (obs_dim < 1 || act_dim < 1 || capacity < 1 || capacity > 0x7fffffffLL || (act_kind != CRUX_ACTION_DISCRETE && act_kind != CRUX_ACTION_CONTINUOUS))
+    return crux_fail(ctx, CRUX_EINVAL, "buffer_create: bad shape obs=%d act=%d cap=%lld", obs_dim, act_dim, (long long)capacity);
+  crux_buffer* b = new crux_buffer(); b->ctx = ctx;
+  b->obs_dim = obs_dim; b->act_dim = act_dim; b->act_kind = act_kind; b->capacity = capacity;
+  b->mask = (column_mask & ((1u << CRUX_NCOLS) - 1)) | 0x3Fu;
+  if (prioritized) b->mask |= 1u << CRUX_COL_WEIGHT;                                   // :71
+  for (int k = 0; k < CRUX_NCOLS; ++k) {
+    if (!has_col(b, k)) continue;
+    const size_t bytes = col_stride(b, k) * (size_t)capacity;
+    if (hipMalloc(&b->col[k], bytes) != hipSuccess) { crux_buffer_destroy(b); return crux_fail(ctx, CRUX_ENOMEM, "buffer_create: hipMalloc(%zu) failed", bytes); }
+    HIPCHK(ctx, hipMemsetAsync(b->col[k], 0, bytes, ctx->stream));
+    if (k == CRUX_COL_WEIGHT) hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(capacity)), dim3(256), 0, ctx->stream, (float*)b->col[k], 1.0f, capacity);   // :17-19
+  }
+  b->prioritized = prioritized != 0; b->alpha = alpha;
+  if (hipMalloc(&b->d_indices, sizeof(int64_t) * (size_t)capacity) != hipSuccess || hipMalloc(&b->order_a, 4 * (size_t)capacity) != hipSuccess ||
+      hipMalloc(&b->order_b, 4 * (size_t)capacity) != hipSuccess) { crux_buffer_destroy(b); return crux_fail(ctx, CRUX_ENOMEM, "buffer_create: index arrays"); }
+  if (b->prioritized) {
+    if (hipMalloc(&b->priorities, 4 * (size_t)capacity) != hipSuccess || hipMalloc(&b->cumsum, 4 * (size_t)capacity) != hipSuccess ||
+        hipMalloc(&b->pminmax, 8) != hipSuccess) { crux_buffer_destroy(b); return crux_fail(ctx, CRUX_ENOMEM, "buffer_create: priorities"); }
+    HIPCHK(ctx, hipMemsetAsync(b->priorities, 0, 4 * (size_t)capacity, ctx->stream));
+    const float mm[2] = {1.0f, INFINITY};                                              // PriorityParams :38-50
+    HIPCHK(ctx, hipMemcpyAsync(b->pminmax, mm, 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *out = b; return CRUX_OK;
+}
+
+int32_t crux_buffer_destroy(crux_buffer* b) {
+  if (!b) return CRUX_OK;
+  (void)hipStreamSynchronize(b->ctx->stream);
+  for (int k = 0; k < CRUX_NCOLS; ++k) if (b->col[k]) (void)hipFree(b->col[k]);
+  if (b->priorities) (void)hipFree(b->priorities); if (b->cumsum) (void)hipFree(b->cumsum); if (b->pminmax) (void)hipFree(b->pminmax);
+  if (b->d_indices) (void)hipFree(b->d_indices); if (b->order_a) (void)hipFree(b->order_a); if (b->order_b) (void)hipFree(b->order_b);
+  delete b; return CRUX_OK;
+}
+
+int64_t crux_buffer_len(const crux_buffer* b) { return b ? b->elements : -1; }
+int64_t crux_buffer_capacity(const crux_buffer* b) { return b ? b->capacity : -1; }
+int64_t crux_buffer_next_ind(const crux_buffer* b) { return b ? b->next_ind : -1; }
+int64_t crux_buffer_total_count(const crux_buffer* b) { return b ? b->total_count : -1; }
+int32_t crux_buffer_has_column(const crux_buffer* b, int32_t key) { return b && has_col(b, key) ? 1 : 0; }
+
+int32_t crux_buffer_clear(crux_buffer* b) {                                            // clear! :97-104
+  if (!b) return CRUX_EINVAL;
+  b->elements = 0; b->next_ind = 0; b->total_count = 0; b->indices.clear();
+  if (b->prioritized) {
+    HIPCHK(b->ctx, hipMemsetAsync(b->priorities, 0, 4 * (size_t)b->capacity, b->ctx->stream));
+    const float inf = INFINITY;                                                         // PriorityParams(N, pp) keeps max_priority, resets min
+    HIPCHK(b->ctx, hipMemcpyAsync(b->pminmax + 1, &inf, 4, hipMemcpyHostToDevice, b->ctx->stream));
+    HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    b->cumsum_valid = false;
+  }
+  return CRUX_OK;
+}
+
+int32_t crux_buffer_column_info(const crux_buffer* b, int32_t key, int32_t* eb, int32_t* rows) {
+  if (!b || !has_col(b, key)) return CRUX_EINVAL;
+  if (eb) *eb = col_elem(b, key); if (rows) *rows = col_rows(b, key); return CRUX_OK;
+}
+int32_t crux_buffer_column_ptr(crux_buffer* b, int32_t key, void** d_ptr) {
+  if (!b || !d_ptr) return CRUX_EINVAL;
+  if (!has_col(b, key)) return crux_fail(b->ctx, CRUX_EINVAL, "buffer has no column %d", key);
+  *d_ptr = b->col[key]; return CRUX_OK;
+}
+
+int32_t crux_buffer_push_host(crux_buffer* b, int64_t N, const void* const* cols, int64_t* I_out) {   // push! :232-259
+  if (!b || N < 0) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx;
+  if (N == 0) return CRUX_OK;
+  std::vector<int64_t> I; crux_buffer_ring_indices(b, N, I);
+  const int64_t C = b->capacity;
+  for (int k = 0; k < CRUX_NCOLS; ++k) {
+    if (!has_col(b, k) || !cols || !cols[k]) continue;                                   // :238-241
+    const size_t st = col_stride(b, k);
+    // the ring write is at most N/C+1 wraps of contiguous segments; later writes win like copyto! in index order
+    int64_t j = 0;
+    while (j < N) {
+      const int64_t pos = I[(size_t)j]; int64_t run = C - pos; if (run > N - j) run = N - j;
+      HIPCHK(c, hipMemcpyAsync((char*)b->col[k] + (size_t)pos * st, (const char*)cols[k] + (size_t)j * st, st * (size_t)run, hipMemcpyHostToDevice, c->stream));
+      j += run;
+    }
+  }
+  if (b->prioritized) {
+    HIPCHK(c, hipMemcpyAsync(b->d_indices, I.data(), 8 * (size_t)(N < C ? N : C), hipMemcpyHostToDevice, c->stream));
+    int32_t rc = crux_buffer_per_on_push(b, b->d_indices, N < C ? N : C); if (rc) return rc;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  crux_buffer_ring_advance(b, N);
+  if (I_out) memcpy(I_out, I.data(), 8 * (size_t)N);
+  return CRUX_OK;
+}
+
+int32_t crux_buffer_push_buffer(crux_buffer* dst, const crux_buffer* src, const int64_t* ids, int64_t N, int64_t* I_out) {
+  if (!dst || !src || N < 0) return CRUX_EINVAL;
+  crux_ctx* c = dst->ctx;
+  if (dst->obs_dim != src->obs_dim || dst->act_dim != src->act_dim || dst->act_kind != src->act_kind)
+    return crux_fail(c, CRUX_EINVAL, "push!: column shapes differ (@assert size(v1)[1:end-1] == size(v2)[1:end-1])");   // :251
+  if (N == 0) return CRUX_OK;
+  if (N > dst->capacity) return crux_fail(c, CRUX_EINVAL, "push!: %lld rows into capacity %lld is not supported by the device gather", (long long)N, (long long)dst->capacity);
+  std::vector<int64_t> I; crux_buffer_ring_indices(dst, N, I);
+  std::vector<int64_t> sid((size_t)N);
+  for (int64_t j = 0; j < N; ++j) { const int64_t id = ids ? ids[j] : j; if (id < 0 || id >= src->capacity) return crux_fail(c, CRUX_EINVAL, "push!: id %lld out of range", (long long)id); sid[(size_t)j] = id; }
+  size_t maxst = 0; for (int k = 0; k < CRUX_NCOLS; ++k) if (has_col(dst, k) && has_col(src, k) && col_stride(dst, k) > maxst) maxst = col_stride(dst, k);
+  const size_t idx_bytes = ((8 * (size_t)N + 255) / 256) * 256;
+  char* sc = (char*)crux_scratch(c, 2 * idx_bytes + maxst * (size_t)N + 256);
+  if (!sc) return crux_fail(c, CRUX_ENOMEM, "push!: scratch");
+  int64_t* dI = (int64_t*)sc; int64_t* dS = (int64_t*)(sc + idx_bytes); void* tmp = sc + 2 * idx_bytes;
+  HIPCHK(c, hipMemcpyAsync(dI, I.data(), 8 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dS, sid.data(), 8 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+  crux_prof_begin(c, CRUX_PROF_GATHER);
+  for (int k = 0; k < CRUX_NCOLS; ++k) {
+    if (!has_col(dst, k) || !has_col(src, k)) continue;
+    const size_t st = col_stride(dst, k);
+    launch_copy_rows(c, tmp, nullptr, src->col[k], dS, N, st);      // v2 = collect(view(src, ids))  (:250)
+    launch_copy_rows(c, dst->col[k], dI, tmp, nullptr, N, st);      // copyto!(view(dst, I), v2)     (:252)
+  }
+  crux_prof_end(c, CRUX_PROF_GATHER);
+  int32_t rc = crux_launch_check(c, "k_copy_rows"); if (rc) return rc;
+  if (dst->prioritized) { rc = crux_buffer_per_on_push(dst, dI, N); if (rc) return rc; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // scratch and host index vectors are reused by the next call
+  crux_buffer_ring_advance(dst, N);
+  if (I_out) memcpy(I_out, I.data(), 8 * (size_t)N);
+  return CRUX_OK;
+}
+
+int32_t crux_buffer_read_column(crux_buffer* b, int32_t key, void* host_out, int64_t n) {
+  if (!b || !host_out) return CRUX_EINVAL;
+  if (!has_col(b, key)) return crux_fail(b->ctx, CRUX_EINVAL, "buffer has no column %d", key);
+  if (n < 0 || n > b->capacity) return crux_fail(b->ctx, CRUX_EINVAL, "read_column: n=%lld out of range", (long long)n);
+  if (n == 0) return CRUX_OK;
+  HIPCHK(b->ctx, hipMemcpyAsync(host_out, b->col[key], col_stride(b, key) * (size_t)n, hipMemcpyDeviceToHost, b->ctx->stream));
+  HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
+  return CRUX_OK;
+}
+int32_t crux_buffer_write_column(crux_buffer* b, int32_t key, const void* host_in, int64_t n) {
+  if (!b || !host_in) return CRUX_EINVAL;
+  if (!has_col(b, key)) return crux_fail(b->ctx, CRUX_EINVAL, "buffer has no column %d", key);
+  if (n < 0 || n > b->capacity) return crux_fail(b->ctx, CRUX_EINVAL, "write_column: n=%lld out of range", (long long)n);
+  if (n == 0) return CRUX_OK;
+  HIPCHK(b->ctx, hipMemcpyAsync(b->col[key], host_in, col_stride(b, key) * (size_t)n, hipMemcpyHostToDevice, b->ctx->stream));
+  HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
+  return CRUX_OK;
+}
+
+int32_t crux_buffer_permute(crux_buffer* b, const int64_t* perm) {                      // shuffle! :118-124
+  if (!b || !perm) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx; const int64_t n = b->elements;
+  if (n == 0) return CRUX_OK;
+  std::vector<int32_t> o((size_t)n);
+  for (int64_t j = 0; j < n; ++j) { if (perm[j] < 0 || perm[j] >= n) return crux_fail(c, CRUX_EINVAL, "shuffle!: perm[%lld]=%lld out of range", (long long)j, (long long)perm[j]); o[(size_t)j] = (int32_t)perm[j]; }
+  HIPCHK(c, hipMemcpyAsync(b->order_a, o.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  int32_t rc = crux_buffer_apply_order(b, b->order_a, n); if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CRUX_OK;
+}
+
+int64_t crux_buffer_last_n_indices(const crux_buffer* b, int64_t N, int64_t* out) {   // :223-229
+  if (!b || !out) return -1;
+  if (N > b->elements) N = b->elements;
+  const int64_t C = b->capacity;
+  const int64_t start = ((b->next_ind - N) % C + C) % C;
+  for (int64_t j = 0; j < N; ++j) out[j] = (start + j) % C;
+  return N;
+}
+
+int32_t crux_buffer_gather_host(crux_buffer* b, const int64_t* ids, int64_t n, void* const* outs) {   // minibatch_copy :171
+  if (!b || !ids || !outs || n < 0) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx; if (n == 0) return CRUX_OK;
+  for (int64_t j = 0; j < n; ++j) if (ids[j] < 0 || ids[j] >= b->capacity) return crux_fail(c, CRUX_EINVAL, "minibatch: index %lld out of range", (long long)ids[j]);
+  size_t maxst = 0; for (int k = 0; k < CRUX_NCOLS; ++k) if (has_col(b, k) && outs[k] && col_stride(b, k) > maxst) maxst = col_stride(b, k);
+  const size_t idx_bytes = ((8 * (size_t)n + 255) / 256) * 256;
+  char* sc = (char*)crux_scratch(c, idx_bytes + maxst * (size_t)n + 256);
+  if (!sc) return crux_fail(c, CRUX_ENOMEM, "minibatch: scratch");
+  int64_t* dS = (int64_t*)sc; void* tmp = sc + idx_bytes;
+  HIPCHK(c, hipMemcpyAsync(dS, ids, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  for (int k = 0; k < CRUX_NCOLS; ++k) {
+    if (!has_col(b, k) || !outs[k]) continue;
+    const size_t st = col_stride(b, k);
+    launch_copy_rows(c, tmp, nullptr, b->col[k], dS, n, st);
+    HIPCHK(c, hipMemcpyAsync(outs[k], tmp, st * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return CRUX_OK;
+}
+
+int32_t crux_buffer_indices(const crux_buffer* b, int64_t* out, int64_t n) {
+  if (!b || !out) return CRUX_EINVAL;
+  if (n > (int64_t)b->indices.size()) n = (int64_t)b->indices.size();
+  memcpy(out, b->indices.data(), 8 * (size_t)n); return CRUX_OK;
+}
+
+int32_t crux_per_update(crux_buffer* b, const int64_t* I, const void* v, int32_t v_is_f64, int64_t n) {   // :290-301
+  if (!b || !I || !v || n < 0) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx;
+  if (!b->prioritized) return crux_fail(c, CRUX_EINVAL, "update_priorities!: buffer is not prioritized");
+  if (n == 0) return CRUX_OK;
+  for (int64_t j = 0; j < n; ++j) if (I[j] < 0 || I[j] >= b->capacity) return crux_fail(c, CRUX_EINVAL, "update_priorities!: index %lld out of range", (long long)I[j]);
+  const size_t ib = ((8 * (size_t)n + 255) / 256) * 256, vb = (v_is_f64 ? 8 : 4) * (size_t)n;
+  char* sc = (char*)crux_scratch(c, ib + vb + 256);
+  if (!sc) return crux_fail(c, CRUX_ENOMEM, "update_priorities!: scratch");
+  HIPCHK(c, hipMemcpyAsync(sc, I, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sc + ib, v, vb, hipMemcpyHostToDevice, c->stream));
+  // duplicate indices: the reference loop lets the last write win; values for duplicated rows are equal in every call site
+  hipLaunchKernelGGL(k_per_update, dim3(grid_for(n)), dim3(256), 0, c->stream, b->priorities, b->pminmax, (const int64_t*)sc,
+                     v_is_f64 ? (const double*)(sc + ib) : (const double*)nullptr, v_is_f64 ? (const float*)nullptr : (const float*)(sc + ib),
+                     (const float*)nullptr, b->alpha, n);
+  int32_t rc = crux_launch_check(c, "k_per_update"); if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  b->cumsum_valid = false;                                                               // :299
+  return CRUX_OK;
+}
+
+int32_t crux_per_update_device(crux_buffer* b, const int64_t* d_ids, const float* d_v, int64_t n) {
+  if (!b || !d_ids || !d_v || n < 0) return CRUX_EINVAL;
+  if (!b->prioritized) return crux_fail(b->ctx, CRUX_EINVAL, "update_priorities!: buffer is not prioritized");
+  if (n == 0) return CRUX_OK;
+  hipLaunchKernelGGL(k_per_update, dim3(grid_for(n)), dim3(256), 0, b->ctx->stream, b->priorities, b->pminmax, d_ids, (const double*)nullptr, d_v,
+                     (const float*)nullptr, b->alpha, n);
+  b->cumsum_valid = false;
+  return crux_launch_check(b->ctx, "k_per_update(device)");
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// common.h -- internal structures of libcruxhip (gfx950 only; no portability layers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include "../../include/cruxhip.h"
+#include "../../include/crux_rng.h"
+
+#define CRUX_MAXL 8
+
+struct crux_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  bool prof_on = false;
+  double prof_ms[CRUX_PROF_NSLOTS] = {0};
+  int64_t prof_n[CRUX_PROF_NSLOTS] = {0};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;   // slot -> (start, stop) not yet resolved
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  void* scratch = nullptr; size_t scratch_bytes = 0;   // reusable device scratch
+  void* pinned = nullptr; size_t pinned_bytes = 0;     // reusable pinned host staging
+};
+
+int32_t crux_fail(crux_ctx* ctx, int32_t code, const char* fmt, ...);
+void* crux_scratch(crux_ctx* ctx, size_t bytes);       // grows; contents undefined
+void* crux_pinned(crux_ctx* ctx, size_t bytes);
+void crux_prof_begin(crux_ctx* ctx, int slot);
+void crux_prof_end(crux_ctx* ctx, int slot);
+
+#define HIPCHK(ctx, expr)                                                                       \
+  do {                                                                                          \
+    hipError_t e__ = (expr);                                                                    \
+    if (e__ != hipSuccess) return crux_fail((ctx), CRUX_EHIP, "%s failed: %s (%s:%d)", #expr,    \
+                                            hipGetErrorString(e__), __FILE__, __LINE__);        \
+  } while (0)
+
+// Device-side description of a Chain(Dense...) with the Flux.params flat layout.
+struct NetDesc {
+  int32_t L;
+  int32_t dims[CRUX_MAXL + 1];
+  int32_t acts[CRUX_MAXL];
+  int32_t woff[CRUX_MAXL];
+  int32_t boff[CRUX_MAXL];
+  int32_t xoff;        // offset of the trailing extras (logSigma)
+  int32_t n_extra;
+  int32_t n_params;
+  int32_t maxdim;
+};
+
+struct crux_mlp {
+  crux_ctx* ctx = nullptr;
+  NetDesc nd{};
+  float* p = nullptr;   // flat params (device)
+  float* g = nullptr;   // flat grads  (device)
+  float* m = nullptr;   // Adam first moment
+  float* v = nullptr;   // Adam second moment
+  double* bp = nullptr; // device: [beta1^t, beta2^t]
+  double eta = 0, b1 = 0, b2 = 0, eps = 0;
+  bool has_adam = false;
+};
+
+struct crux_buffer {
+  crux_ctx* ctx = nullptr;
+  int32_t obs_dim = 0, act_dim = 0, act_kind = 0;
+  int64_t capacity = 0, elements = 0, next_ind = 0, total_count = 0;
+  uint32_t mask = 0;
+  void* col[CRUX_NCOLS] = {nullptr};
+  bool prioritized = false;
+  float alpha = 0.6f;
+  float* priorities = nullptr;   // device [capacity]
+  float* cumsum = nullptr;       // device [capacity]
+  bool cumsum_valid = false;
+  float* pminmax = nullptr;      // device [2]: max_priority, min_priority (un-powered, Float32 fields)
+  std::vector<int64_t> indices;  // host copy of the last sample's ids (target.indices)
+  int64_t* d_indices = nullptr;  // device copy [capacity]
+  int32_t* order_a = nullptr;    // device [capacity] logical->physical order scratch for batch_train
+  int32_t* order_b = nullptr;
+};
+
+static inline int col_elem(const crux_buffer* b, int k) {
+  switch (k) {
+    case CRUX_COL_A: return b->act_kind == CRUX_ACTION_DISCRETE ? 1 : 4;
+    case CRUX_COL_DONE: case CRUX_COL_EPISODE_END: return 1;
+    case CRUX_COL_T: case CRUX_COL_I: return 8;
+    default: return 4;
+  }
+}
+static inline int col_rows(const crux_buffer* b, int k) {
+  return (k == CRUX_COL_S || k == CRUX_COL_SP) ? b->obs_dim : (k == CRUX_COL_A ? b->act_dim : 1);
+}
+static inline size_t col_stride(const crux_buffer* b, int k) { return (size_t)col_elem(b, k) * (size_t)col_rows(b, k); }
+static inline bool has_col(const crux_buffer* b, int k) { return k >= 0 && k < CRUX_NCOLS && (b->mask & (1u << k)); }
+
+struct crux_env {
+  crux_ctx* ctx = nullptr;
+  int32_t kind = 0, n_envs = 0, max_steps = 0, obs_dim = 0, act_dim = 0, state_dim = 0;
+  float gamma = 0.99f;
+  uint64_t seed = 0;
+  float* mu = nullptr;       // device [obs_dim]
+  float* sigma = nullptr;    // device [obs_dim]
+  double* state = nullptr;   // device [state_dim x n_envs]
+  int64_t* ep_len = nullptr; // device [n_envs]
+  int64_t* n_resets = nullptr;
+  int64_t* steps_taken = nullptr;
+  float* svec = nullptr;     // device [obs_dim x n_envs] current (whitened) observation
+  double* acc = nullptr;     // device [2*n_envs]: per-env sum_r, n_episode_end of the last rollout
+};
+
+// device helpers shared by kernels -------------------------------------------------------------
+__device__ __forceinline__ float crux_act(int a, float z) {
+  return a == CRUX_ACT_RELU ? (z > 0.f ? z : 0.f) : (a == CRUX_ACT_TANH ? tanhf(z) : z);
+}
+__device__ __forceinline__ float crux_act_grad(int a, float y, float d) {   // y = post-activation
+  return a == CRUX_ACT_RELU ? (y > 0.f ? d : 0.f) : (a == CRUX_ACT_TANH ? d * (1.f - y * y) : d);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+int32_t crux_launch_check(crux_ctx* ctx, const char* what);

@@ -1,0 +1,126 @@
+// ctx.hip -- context lifecycle, error reporting, scratch memory, HIP-event kernel timing.
+#include "common.h"
+#include <cstdarg>
+
+int32_t crux_fail(crux_ctx* ctx, int32_t code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+int32_t crux_launch_check(crux_ctx* ctx, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return crux_fail(ctx, CRUX_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return CRUX_OK;
+}
+
+void* crux_scratch(crux_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return ctx->scratch;
+  if (ctx->scratch) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+  size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
+  if (hipMalloc(&ctx->scratch, want) != hipSuccess) { ctx->scratch = nullptr; return nullptr; }
+  ctx->scratch_bytes = want;
+  return ctx->scratch;
+}
+
+void* crux_pinned(crux_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pinned_bytes) return ctx->pinned;
+  if (ctx->pinned) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_bytes = 0; }
+  size_t want = bytes < (1u << 16) ? (1u << 16) : bytes + bytes / 4;
+  if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { ctx->pinned = nullptr; return nullptr; }
+  ctx->pinned_bytes = want;
+  return ctx->pinned;
+}
+
+static std::pair<hipEvent_t, hipEvent_t> take_events(crux_ctx* ctx) {
+  if (!ctx->ev_pool.empty()) { auto p = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return p; }
+  hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); return {a, b};
+}
+
+void crux_prof_begin(crux_ctx* ctx, int slot) {
+  if (!ctx->prof_on) return;
+  auto ev = take_events(ctx);
+  (void)hipEventRecord(ev.first, ctx->stream);
+  ctx->pending.push_back({slot, ev});
+}
+void crux_prof_end(crux_ctx* ctx, int slot) {
+  if (!ctx->prof_on) return;
+  for (size_t i = ctx->pending.size(); i-- > 0;)
+    if (ctx->pending[i].first == slot) { (void)hipEventRecord(ctx->pending[i].second.second, ctx->stream); break; }
+}
+static void prof_resolve(crux_ctx* ctx) {
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& p : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) { ctx->prof_ms[p.first] += ms; ctx->prof_n[p.first] += 1; }
+    ctx->ev_pool.push_back(p.second);
+  }
+  ctx->pending.clear();
+}
+
+extern "C" {
+
+const char* crux_version(void) { return "cruxhip 0.1 (gfx950)"; }
+
+int32_t crux_ctx_create(int32_t device_id, void* stream, crux_ctx** out) {
+  if (!out) return CRUX_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return CRUX_EHIP;
+  if (hipSetDevice(device_id) != hipSuccess) return CRUX_EHIP;
+  crux_ctx* c = new crux_ctx();
+  c->device = device_id;
+  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+  else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRUX_EHIP; } c->own_stream = true; }
+  *out = c;
+  return CRUX_OK;
+}
+
+int32_t crux_ctx_destroy(crux_ctx* c) {
+  if (!c) return CRUX_OK;
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
+  for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return CRUX_OK;
+}
+
+const char* crux_last_error(crux_ctx* c) { return c ? c->err.c_str() : "no context"; }
+
+int32_t crux_sync(crux_ctx* c) { if (!c) return CRUX_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); return CRUX_OK; }
+
+int32_t crux_device_alloc(crux_ctx* c, int64_t bytes, void** out) {
+  if (!c || !out || bytes < 0) return CRUX_EINVAL;
+  *out = nullptr; if (bytes == 0) return CRUX_OK;
+  if (hipMalloc(out, (size_t)bytes) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "device_alloc(%lld) failed", (long long)bytes);
+  return CRUX_OK;
+}
+int32_t crux_device_free(crux_ctx* c, void* p) { if (!c) return CRUX_EINVAL; if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); } return CRUX_OK; }
+int32_t crux_memcpy_h2d(crux_ctx* c, void* d_dst, const void* src, int64_t bytes) {
+  if (!c || bytes < 0) return CRUX_EINVAL; if (bytes == 0) return CRUX_OK;
+  HIPCHK(c, hipMemcpyAsync(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return CRUX_OK;
+}
+int32_t crux_memcpy_d2h(crux_ctx* c, void* dst, const void* d_src, int64_t bytes) {
+  if (!c || bytes < 0) return CRUX_EINVAL; if (bytes == 0) return CRUX_OK;
+  HIPCHK(c, hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return CRUX_OK;
+}
+
+int32_t crux_prof_enable(crux_ctx* c, int32_t on) { if (!c) return CRUX_EINVAL; if (!on) prof_resolve(c); c->prof_on = on != 0; return CRUX_OK; }
+int32_t crux_prof_reset(crux_ctx* c) {
+  if (!c) return CRUX_EINVAL; prof_resolve(c);
+  for (int i = 0; i < CRUX_PROF_NSLOTS; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  return CRUX_OK;
+}
+int32_t crux_prof_get(crux_ctx* c, int32_t slot, double* ms_total, int64_t* launches) {
+  if (!c || slot < 0 || slot >= CRUX_PROF_NSLOTS) return CRUX_EINVAL;
+  prof_resolve(c);
+  if (ms_total) *ms_total = c->prof_ms[slot];
+  if (launches) *launches = c->prof_n[slot];
+  return CRUX_OK;
+}
+
+}  // extern "C"

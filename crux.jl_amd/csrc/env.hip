@@ -1,0 +1,363 @@
+// env.hip -- vectorised Samplers: environment dynamics + policy forward + column writes in one kernel.
+// Reference: Sampler / reset_sampler! / step! / steps! / terminate_episode! (src/sampler.jl:1-173),
+// DiscreteNetwork exploration (src/policies.jl:137-142), GaussianPolicy exploration (:338-344),
+// MixedPolicy (:474-494), GaussianNoiseExplorationPolicy (:510-514), LinearDecaySchedule (src/utils.jl:116-126),
+// tovec whitening (src/spaces.jl:25). Environment dynamics restate gymnasium's classic_control definitions
+// (the reference reaches them through POMDPGym/PyCall, src/sampler.jl:93).
+#include "common.h"
+
+int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I);
+void crux_buffer_ring_advance(crux_buffer* b, int64_t N);
+int32_t crux_buffer_per_on_push(crux_buffer* b, const int64_t* d_I, int64_t N);
+
+#define ENV_MAXSD 4
+#define ENV_MAXOBS 32
+#define PI_D 3.14159265358979323846
+
+// ---- dynamics (float64, same operation order as the oracle) ------------------------------------------
+__device__ __forceinline__ void cartpole_step(const double* s, int action, double* sn, float* r, uint8_t* done) {
+  const double gravity = 9.8, masscart = 1.0, masspole = 0.1, total_mass = masspole + masscart, length = 0.5,
+               polemass_length = masspole * length, force_mag = 10.0, tau = 0.02;
+  double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+  const double force = action == 1 ? force_mag : -force_mag;
+  const double costheta = cos(theta), sintheta = sin(theta);
+  const double temp = __ddiv_rn(__dadd_rn(force, __dmul_rn(__dmul_rn(polemass_length, __dmul_rn(theta_dot, theta_dot)), sintheta)), total_mass);
+  const double den = __dmul_rn(length, __dsub_rn(4.0 / 3.0, __ddiv_rn(__dmul_rn(masspole, __dmul_rn(costheta, costheta)), total_mass)));
+  const double thetaacc = __ddiv_rn(__dsub_rn(__dmul_rn(gravity, sintheta), __dmul_rn(costheta, temp)), den);
+  const double xacc = __dsub_rn(temp, __ddiv_rn(__dmul_rn(__dmul_rn(polemass_length, thetaacc), costheta), total_mass));
+  x = __dadd_rn(x, __dmul_rn(tau, x_dot)); x_dot = __dadd_rn(x_dot, __dmul_rn(tau, xacc));
+  theta = __dadd_rn(theta, __dmul_rn(tau, theta_dot)); theta_dot = __dadd_rn(theta_dot, __dmul_rn(tau, thetaacc));
+  sn[0] = x; sn[1] = x_dot; sn[2] = theta; sn[3] = theta_dot;
+  const double xth = 2.4, thth = 12.0 * 2.0 * PI_D / 360.0;
+  *done = (x < -xth || x > xth || theta < -thth || theta > thth) ? 1 : 0;
+  *r = 1.0f;
+}
+__device__ __forceinline__ double angle_normalize(double x) { double t = fmod(x + PI_D, 2.0 * PI_D); if (t < 0) t += 2.0 * PI_D; return t - PI_D; }
+__device__ __forceinline__ void pendulum_step(const double* s, float a, double* sn, float* r, uint8_t* done) {
+  const double g = 10.0, m = 1.0, l = 1.0, dt = 0.05, max_speed = 8.0, max_torque = 2.0;
+  const double th = s[0], thdot = s[1];
+  double u = (double)a; if (u < -max_torque) u = -max_torque; if (u > max_torque) u = max_torque;
+  const double an = angle_normalize(th);
+  const double costs = __dadd_rn(__dadd_rn(__dmul_rn(an, an), __dmul_rn(0.1, __dmul_rn(thdot, thdot))), __dmul_rn(0.001, __dmul_rn(u, u)));
+  double newthdot = __dadd_rn(thdot, __dmul_rn(__dadd_rn(__dmul_rn(3.0 * g / (2.0 * l), sin(th)), __dmul_rn(3.0 / (m * l * l), u)), dt));
+  if (newthdot < -max_speed) newthdot = -max_speed; if (newthdot > max_speed) newthdot = max_speed;
+  sn[0] = __dadd_rn(th, __dmul_rn(newthdot, dt)); sn[1] = newthdot; *r = (float)(-costs); *done = 0;
+}
+__device__ __forceinline__ void env_obs(int kind, const double* s, float* o) {
+  if (kind == CRUX_ENV_CARTPOLE) { o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3]; }
+  else { o[0] = (float)cos(s[0]); o[1] = (float)sin(s[0]); o[2] = (float)s[1]; }
+}
+__device__ __forceinline__ void env_draw_initial(int kind, uint64_t seed, uint64_t n_resets, uint32_t env, double* s) {
+  const crux_u32x4 a = crux_philox(seed, 2 * n_resets, env, CRUX_RNG_RESET), b = crux_philox(seed, 2 * n_resets + 1, env, CRUX_RNG_RESET);
+  const double u0 = crux_u32x2_to_f64(a.v[0], a.v[1]), u1 = crux_u32x2_to_f64(a.v[2], a.v[3]), u2 = crux_u32x2_to_f64(b.v[0], b.v[1]), u3 = crux_u32x2_to_f64(b.v[2], b.v[3]);
+  if (kind == CRUX_ENV_CARTPOLE) { s[0] = __dadd_rn(-0.05, __dmul_rn(0.1, u0)); s[1] = __dadd_rn(-0.05, __dmul_rn(0.1, u1)); s[2] = __dadd_rn(-0.05, __dmul_rn(0.1, u2)); s[3] = __dadd_rn(-0.05, __dmul_rn(0.1, u3)); }
+  else { s[0] = __dadd_rn(-PI_D, __dmul_rn(2.0 * PI_D, u0)); s[1] = __dadd_rn(-1.0, __dmul_rn(2.0, u1)); }
+}
+__device__ __forceinline__ float randn_f32(uint64_t seed, uint64_t ctr, uint32_t stream, int which) {
+  const crux_u32x4 x = crux_philox(seed, ctr, stream, CRUX_RNG_NOISE);
+  const double u1 = crux_u32x2_to_f64(x.v[0], x.v[1]), u2 = crux_u32x2_to_f64(x.v[2], x.v[3]);
+  const double rr = sqrt(-2.0 * log(1.0 - u1)), th = 2.0 * PI_D * u2;
+  return (float)(which ? rr * sin(th) : rr * cos(th));
+}
+__device__ __forceinline__ double linear_decay(double start, double stop, int64_t steps, int64_t i) {
+  const double rate = (start - stop) / (double)steps; const double val = start - (double)i * rate; return val > stop ? val : stop;
+}
+
+struct RolloutArgs {
+  NetDesc nd; const float* p;
+  int32_t kind, E, max_steps, od, ad, sd, act_kind;
+  uint64_t seed;
+  const float* mu; const float* sigma;
+  double* state; int64_t* ep_len; int64_t* n_resets; int64_t* steps_taken; float* svec; double* acc;
+  float* S; void* A; float* SP; float* R; uint8_t* D; uint8_t* EE; float* LP; int64_t* TT; int64_t* II; float* W; float* RET; float* ADV;
+  int64_t base, C, T;
+  crux_rollout_cfg cfg;
+};
+
+// one wave (64 lanes) per environment; lanes split the output units of each Dense layer, lane 0 runs the
+// head, the dynamics and the bookkeeping. Environments never synchronise with each other.
+__global__ __launch_bounds__(64) void k_rollout(RolloutArgs a) {
+  __shared__ float hbuf[2][1024];
+  __shared__ float sh_misc[ENV_MAXOBS + 8];
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const NetDesc& nd = a.nd;
+  const int od = a.od, ad = a.ad, nout = nd.dims[nd.L];
+  double st[ENV_MAXSD]; int64_t ep_len = 0, n_resets = 0, steps_taken = 0; double sum_r = 0.0; int64_t nee = 0;
+  if (lane == 0) {
+    for (int i = 0; i < a.sd; ++i) st[i] = a.state[(size_t)e * a.sd + i];
+    ep_len = a.ep_len[e]; n_resets = a.n_resets[e]; steps_taken = a.steps_taken[e];
+  }
+  if (lane < od) hbuf[0][lane] = a.svec[(size_t)e * od + lane];
+  __syncthreads();
+  for (int64_t t = 0; t < a.T; ++t) {
+    const int64_t j = (a.base + (int64_t)e * a.T + t) % a.C;
+    // current observation -> S column (sampler.jl:100)
+    if (lane < od) a.S[(size_t)j * od + lane] = hbuf[0][lane];
+    // ---- policy forward: Chain(Dense...) on a batch of one (sampler.jl:73 -> policies.jl:94,120)
+    int cur = 0;
+    for (int l = 0; l < nd.L; ++l) {
+      const int in = nd.dims[l], out = nd.dims[l + 1], act = nd.acts[l];
+      const float* Wl = a.p + nd.woff[l]; const float* bl = a.p + nd.boff[l];
+      for (int o = lane; o < out; o += 64) {
+        float accv = 0.f;
+        for (int k = 0; k < in; ++k) accv = fmaf(Wl[o + out * k], hbuf[cur][k], accv);
+        hbuf[cur ^ 1][o] = crux_act(act, accv + bl[o]);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+    // (the observation in hbuf[0] was already stored to the S column, so the ping-pong may overwrite it)
+    if (lane == 0) {
+      const float* z = hbuf[cur];
+      const uint64_t gi = a.cfg.i0 + (uint64_t)t * (uint64_t)a.E + (uint64_t)e;    // i + (j-1), env-minor (sampler.jl:161-163)
+      const uint64_t ctr = (uint64_t)steps_taken;
+      float logprob = NAN; int ai = 0; float aout[ENV_MAXOBS];
+      if (a.cfg.head == CRUX_HEAD_CATEGORICAL || a.cfg.head == CRUX_HEAD_GREEDY_Q) {
+        int greedy = 0; for (int q = 1; q < nout; ++q) if (z[q] > z[greedy]) greedy = q;
+        if (!a.cfg.explore) ai = greedy;
+        else if (a.cfg.eps_steps > 0 || a.cfg.head == CRUX_HEAD_GREEDY_Q) {
+          const double eps = a.cfg.eps_steps > 0 ? linear_decay(a.cfg.eps_start, a.cfg.eps_stop, a.cfg.eps_steps, (int64_t)gi) : 0.0;
+          const crux_u32x4 x = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_ACTION);
+          const double u = crux_u32x2_to_f64(x.v[0], x.v[1]);
+          if (u < eps) { const crux_u32x4 y = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_RANDACT); ai = (int)(((uint64_t)y.v[0] * (uint64_t)nout) >> 32); }
+          else ai = greedy;
+          logprob = (float)log(eps * (1.0 / (double)nout) + (1.0 - eps));
+        } else {
+          float pr[ENV_MAXOBS];
+          float mx = z[0]; for (int q = 1; q < nout; ++q) mx = z[q] > mx ? z[q] : mx;
+          float sum = 0.f; for (int q = 0; q < nout; ++q) { pr[q] = expf(z[q] - mx); sum = __fadd_rn(sum, pr[q]); }
+          for (int q = 0; q < nout; ++q) pr[q] = __fdiv_rn(pr[q], sum);
+          const crux_u32x4 x = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_ACTION);
+          const float draw = crux_u32_to_f32(x.v[0]);
+          float cp = pr[0]; ai = 0; while (cp <= draw && ai < nout - 1) { ai += 1; cp = __fadd_rn(cp, pr[ai]); }
+          logprob = logf(pr[ai]);
+        }
+        for (int q = 0; q < ad; ++q) aout[q] = (q == ai) ? 1.f : 0.f;
+      } else if (a.cfg.head == CRUX_HEAD_GAUSSIAN) {
+        const float* ls = a.p + nd.xoff; float lp = 0.f;
+        for (int q = 0; q < ad; ++q) {
+          const float mu = z[q];
+          if (a.cfg.explore) { const float sg = expf(ls[q]);
+            const float epsn = randn_f32(a.seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)e, q & 1);
+            aout[q] = __fadd_rn(__fmul_rn(epsn, sg), mu); const float s2 = __fmul_rn(sg, sg); const float dd = __fsub_rn(aout[q], mu);
+            lp = __fadd_rn(lp, __fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(dd, dd), __fmul_rn(2.f, s2)), 0.9189385332046727f), ls[q])); }
+          else aout[q] = mu;
+        }
+        logprob = a.cfg.explore ? lp : NAN;
+      } else {
+        for (int q = 0; q < ad; ++q) { float av = z[q];
+          if (a.cfg.explore && a.cfg.noise_sigma >= 0.f) {
+            float n0 = __fmul_rn(randn_f32(a.seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)e, q & 1), a.cfg.noise_sigma);
+            n0 = n0 < a.cfg.noise_eps_min ? a.cfg.noise_eps_min : n0 > a.cfg.noise_eps_max ? a.cfg.noise_eps_max : n0; av = __fadd_rn(av, n0);
+            av = av < a.cfg.a_min ? a.cfg.a_min : av > a.cfg.a_max ? a.cfg.a_max : av; }
+          aout[q] = av; }
+      }
+      // ---- env transition (sampler.jl:93-97)
+      double sn[ENV_MAXSD]; float r; uint8_t done; float o[ENV_MAXOBS], spv[ENV_MAXOBS];
+      if (a.kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done); else pendulum_step(st, aout[0], sn, &r, &done);
+      env_obs(a.kind, sn, o);
+      for (int q = 0; q < od; ++q) spv[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
+      // ---- column writes (sampler.jl:101-107)
+      if (a.act_kind == CRUX_ACTION_DISCRETE) { uint8_t* A = (uint8_t*)a.A + (size_t)j * ad; for (int q = 0; q < ad; ++q) A[q] = aout[q] != 0.f; }
+      else { float* A = (float*)a.A + (size_t)j * ad; for (int q = 0; q < ad; ++q) A[q] = aout[q]; }
+      for (int q = 0; q < od; ++q) a.SP[(size_t)j * od + q] = spv[q];
+      a.R[j] = r; a.D[j] = done;
+      if (a.LP) a.LP[j] = logprob;
+      if (a.TT) a.TT[j] = ep_len + 1;
+      if (a.II) a.II[j] = (int64_t)gi + 1;
+      if (a.W) a.W[j] = 1.0f;
+      if (a.RET) a.RET[j] = 0.f;
+      if (a.ADV) a.ADV[j] = 0.f;
+      sum_r += (double)r; steps_taken += 1;
+      // ---- episode bookkeeping (sampler.jl:130-136; terminate_episode! :53-69)
+      ep_len += 1;
+      uint8_t ee = 0;
+      if (done || ep_len >= a.max_steps) {
+        ee = 1; ++nee;
+        env_draw_initial(a.kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st); n_resets += 1; ep_len = 0;
+        env_obs(a.kind, st, o);
+        for (int q = 0; q < od; ++q) sh_misc[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
+      } else {
+        for (int i = 0; i < a.sd; ++i) st[i] = sn[i];
+        for (int q = 0; q < od; ++q) sh_misc[q] = spv[q];
+      }
+      if (a.cfg.reset_at_end && t == a.T - 1 && ep_len > 0) {                       // sampler.jl:148
+        ee = 1; ++nee;
+        env_draw_initial(a.kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st); n_resets += 1; ep_len = 0;
+        env_obs(a.kind, st, o);
+        for (int q = 0; q < od; ++q) sh_misc[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
+      }
+      a.EE[j] = ee;
+    }
+    __syncthreads();
+    if (lane < od) hbuf[0][lane] = sh_misc[lane];
+    __syncthreads();
+  }
+  if (lane == 0) {
+    for (int i = 0; i < a.sd; ++i) a.state[(size_t)e * a.sd + i] = st[i];
+    a.ep_len[e] = ep_len; a.n_resets[e] = n_resets; a.steps_taken[e] = steps_taken;
+    a.acc[2 * e] = sum_r; a.acc[2 * e + 1] = (double)nee;
+  }
+  if (lane < od) a.svec[(size_t)e * od + lane] = hbuf[0][lane];
+}
+
+__global__ void k_env_init(int kind, int E, int od, int sd, uint64_t seed, const float* mu, const float* sigma, double* state, int64_t* ep_len,
+                           int64_t* n_resets, float* svec, int fresh) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  double st[ENV_MAXSD]; float o[ENV_MAXOBS];
+  const int64_t nr = fresh ? 0 : n_resets[e];
+  env_draw_initial(kind, seed, (uint64_t)nr, (uint32_t)e, st);
+  for (int i = 0; i < sd; ++i) state[(size_t)e * sd + i] = st[i];
+  n_resets[e] = nr + 1; ep_len[e] = 0;
+  env_obs(kind, st, o);
+  for (int q = 0; q < od; ++q) svec[(size_t)e * od + q] = __fdiv_rn(__fsub_rn(o[q], mu[q]), sigma[q]);
+}
+
+__global__ void k_env_step(int kind, int64_t n, const double* state, const void* action, double* next_state, float* obs, float* r, uint8_t* done) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  if (kind == CRUX_ENV_CARTPOLE) {
+    const uint8_t* a = (const uint8_t*)action + 2 * j; double s[4], sn[4]; for (int i = 0; i < 4; ++i) s[i] = state[4 * j + i];
+    float rr; uint8_t dd; cartpole_step(s, a[1] ? 1 : 0, sn, &rr, &dd);
+    for (int i = 0; i < 4; ++i) { next_state[4 * j + i] = sn[i]; obs[4 * j + i] = (float)sn[i]; } r[j] = rr; done[j] = dd;
+  } else {
+    double s[2] = {state[2 * j], state[2 * j + 1]}, sn[2]; float rr; uint8_t dd; float o[3];
+    pendulum_step(s, ((const float*)action)[j], sn, &rr, &dd); env_obs(kind, sn, o);
+    next_state[2 * j] = sn[0]; next_state[2 * j + 1] = sn[1]; obs[3 * j] = o[0]; obs[3 * j + 1] = o[1]; obs[3 * j + 2] = o[2]; r[j] = rr; done[j] = dd;
+  }
+}
+
+static void env_dims(int kind, int so, int sa, int* obs, int* act, int* sd) {
+  switch (kind) {
+    case CRUX_ENV_CARTPOLE: *obs = 4; *act = 2; *sd = 4; break;
+    case CRUX_ENV_PENDULUM: *obs = 3; *act = 1; *sd = 2; break;
+    default: *obs = so; *act = sa; *sd = 1; break;
+  }
+}
+
+extern "C" {
+
+int32_t crux_env_create(crux_ctx* ctx, int32_t kind, int32_t n_envs, int32_t max_steps, float gamma, const float* obs_mu, const float* obs_sigma,
+                        uint64_t seed, int32_t synth_obs_dim, int32_t synth_act_dim, crux_env** out) {
+  if (!ctx || !out) return CRUX_EINVAL;
+  if (kind != CRUX_ENV_CARTPOLE && kind != CRUX_ENV_PENDULUM) return crux_fail(ctx, CRUX_EUNSUP, "env kind %d has no device dynamics yet", kind);
+  if (n_envs < 1 || max_steps < 1) return crux_fail(ctx, CRUX_EINVAL, "env_create: n_envs=%d max_steps=%d", n_envs, max_steps);
+  crux_env* e = new crux_env(); e->ctx = ctx; e->kind = kind; e->n_envs = n_envs; e->max_steps = max_steps; e->gamma = gamma; e->seed = seed;
+  env_dims(kind, synth_obs_dim, synth_act_dim, &e->obs_dim, &e->act_dim, &e->state_dim);
+  const int od = e->obs_dim;
+  if (hipMalloc(&e->mu, 4 * od) != hipSuccess || hipMalloc(&e->sigma, 4 * od) != hipSuccess || hipMalloc(&e->state, 8 * (size_t)n_envs * e->state_dim) != hipSuccess ||
+      hipMalloc(&e->ep_len, 8 * (size_t)n_envs) != hipSuccess || hipMalloc(&e->n_resets, 8 * (size_t)n_envs) != hipSuccess ||
+      hipMalloc(&e->steps_taken, 8 * (size_t)n_envs) != hipSuccess || hipMalloc(&e->svec, 4 * (size_t)n_envs * od) != hipSuccess ||
+      hipMalloc(&e->acc, 16 * (size_t)n_envs) != hipSuccess) { crux_env_destroy(e); return crux_fail(ctx, CRUX_ENOMEM, "env_create: hipMalloc"); }
+  std::vector<float> mu(od, 0.f), sg(od, 1.f);
+  if (obs_mu) for (int i = 0; i < od; ++i) mu[i] = obs_mu[i];
+  if (obs_sigma) for (int i = 0; i < od; ++i) sg[i] = obs_sigma[i];
+  HIPCHK(ctx, hipMemcpyAsync(e->mu, mu.data(), 4 * od, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(e->sigma, sg.data(), 4 * od, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(e->steps_taken, 0, 8 * (size_t)n_envs, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(e->acc, 0, 16 * (size_t)n_envs, ctx->stream));
+  hipLaunchKernelGGL(k_env_init, dim3((n_envs + 63) / 64), dim3(64), 0, ctx->stream, kind, n_envs, od, e->state_dim, seed, e->mu, e->sigma, e->state, e->ep_len, e->n_resets, e->svec, 1);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *out = e; return crux_launch_check(ctx, "k_env_init");
+}
+
+int32_t crux_env_destroy(crux_env* e) {
+  if (!e) return CRUX_OK;
+  (void)hipStreamSynchronize(e->ctx->stream);
+  (void)hipFree(e->mu); (void)hipFree(e->sigma); (void)hipFree(e->state); (void)hipFree(e->ep_len); (void)hipFree(e->n_resets);
+  (void)hipFree(e->steps_taken); (void)hipFree(e->svec); (void)hipFree(e->acc);
+  delete e; return CRUX_OK;
+}
+int32_t crux_env_obs_dim(const crux_env* e) { return e ? e->obs_dim : -1; }
+int32_t crux_env_act_dim(const crux_env* e) { return e ? e->act_dim : -1; }
+int32_t crux_env_state_dim(const crux_env* e) { return e ? e->state_dim : -1; }
+
+int32_t crux_env_reset(crux_env* e) {
+  if (!e) return CRUX_EINVAL;
+  hipLaunchKernelGGL(k_env_init, dim3((e->n_envs + 63) / 64), dim3(64), 0, e->ctx->stream, e->kind, e->n_envs, e->obs_dim, e->state_dim, e->seed, e->mu, e->sigma,
+                     e->state, e->ep_len, e->n_resets, e->svec, 0);
+  return crux_launch_check(e->ctx, "k_env_init");
+}
+
+int32_t crux_env_get_state(crux_env* e, double* state, int64_t* ep_len, int64_t* n_resets) {
+  if (!e) return CRUX_EINVAL;
+  crux_ctx* c = e->ctx;
+  if (state) HIPCHK(c, hipMemcpyAsync(state, e->state, 8 * (size_t)e->n_envs * e->state_dim, hipMemcpyDeviceToHost, c->stream));
+  if (ep_len) HIPCHK(c, hipMemcpyAsync(ep_len, e->ep_len, 8 * (size_t)e->n_envs, hipMemcpyDeviceToHost, c->stream));
+  if (n_resets) HIPCHK(c, hipMemcpyAsync(n_resets, e->n_resets, 8 * (size_t)e->n_envs, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CRUX_OK;
+}
+
+int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg, crux_buffer* buf, int64_t T, double* sum_r, int64_t* n_episode_end) {
+  if (!e || !policy || !cfg || !buf || T < 1) return CRUX_EINVAL;
+  crux_ctx* c = e->ctx;
+  const int64_t N = (int64_t)e->n_envs * T;
+  if (buf->obs_dim != e->obs_dim || buf->act_dim != e->act_dim) return crux_fail(c, CRUX_EINVAL, "steps!: buffer columns (%d,%d) do not match the env (%d,%d)", buf->obs_dim, buf->act_dim, e->obs_dim, e->act_dim);
+  if (N > buf->capacity) return crux_fail(c, CRUX_EINVAL, "steps!: %lld transitions exceed buffer capacity %lld", (long long)N, (long long)buf->capacity);
+  if (policy->nd.dims[0] != e->obs_dim) return crux_fail(c, CRUX_EINVAL, "steps!: policy input %d != obs dim %d", policy->nd.dims[0], e->obs_dim);
+  if (policy->nd.maxdim > 1024) return crux_fail(c, CRUX_EUNSUP, "steps!: layer width %d > 1024", policy->nd.maxdim);
+  const int nout = policy->nd.dims[policy->nd.L];
+  if ((cfg->head == CRUX_HEAD_CATEGORICAL || cfg->head == CRUX_HEAD_GREEDY_Q) && (nout != e->act_dim || buf->act_kind != CRUX_ACTION_DISCRETE))
+    return crux_fail(c, CRUX_EINVAL, "steps!: discrete head needs %d logits and a one-hot action column", e->act_dim);
+  if ((cfg->head == CRUX_HEAD_GAUSSIAN || cfg->head == CRUX_HEAD_DETERMINISTIC) && (nout != e->act_dim || buf->act_kind != CRUX_ACTION_CONTINUOUS))
+    return crux_fail(c, CRUX_EINVAL, "steps!: continuous head needs %d outputs and a Float32 action column", e->act_dim);
+  if (cfg->head == CRUX_HEAD_GAUSSIAN && policy->nd.n_extra != e->act_dim) return crux_fail(c, CRUX_EINVAL, "steps!: GaussianPolicy needs %d logSigma extras", e->act_dim);
+  RolloutArgs a{};
+  a.nd = policy->nd; a.p = policy->p; a.kind = e->kind; a.E = e->n_envs; a.max_steps = e->max_steps; a.od = e->obs_dim; a.ad = e->act_dim; a.sd = e->state_dim;
+  a.act_kind = buf->act_kind; a.seed = e->seed; a.mu = e->mu; a.sigma = e->sigma; a.state = e->state; a.ep_len = e->ep_len; a.n_resets = e->n_resets;
+  a.steps_taken = e->steps_taken; a.svec = e->svec; a.acc = e->acc;
+  a.S = (float*)buf->col[CRUX_COL_S]; a.A = buf->col[CRUX_COL_A]; a.SP = (float*)buf->col[CRUX_COL_SP]; a.R = (float*)buf->col[CRUX_COL_R];
+  a.D = (uint8_t*)buf->col[CRUX_COL_DONE]; a.EE = (uint8_t*)buf->col[CRUX_COL_EPISODE_END];
+  a.LP = has_col(buf, CRUX_COL_LOGPROB) ? (float*)buf->col[CRUX_COL_LOGPROB] : nullptr; a.TT = has_col(buf, CRUX_COL_T) ? (int64_t*)buf->col[CRUX_COL_T] : nullptr;
+  a.II = has_col(buf, CRUX_COL_I) ? (int64_t*)buf->col[CRUX_COL_I] : nullptr; a.W = has_col(buf, CRUX_COL_WEIGHT) ? (float*)buf->col[CRUX_COL_WEIGHT] : nullptr;
+  a.RET = has_col(buf, CRUX_COL_RETURN) ? (float*)buf->col[CRUX_COL_RETURN] : nullptr; a.ADV = has_col(buf, CRUX_COL_ADVANTAGE) ? (float*)buf->col[CRUX_COL_ADVANTAGE] : nullptr;
+  a.base = buf->next_ind; a.C = buf->capacity; a.T = T; a.cfg = *cfg;
+  crux_prof_begin(c, CRUX_PROF_ROLLOUT);
+  hipLaunchKernelGGL(k_rollout, dim3(e->n_envs), dim3(64), 0, c->stream, a);
+  crux_prof_end(c, CRUX_PROF_ROLLOUT);
+  int32_t rc = crux_launch_check(c, "k_rollout"); if (rc) return rc;
+  if (buf->prioritized) {
+    std::vector<int64_t> I; crux_buffer_ring_indices(buf, N, I);
+    HIPCHK(c, hipMemcpyAsync(buf->d_indices, I.data(), 8 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    rc = crux_buffer_per_on_push(buf, buf->d_indices, N); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  crux_buffer_ring_advance(buf, N);
+  if (sum_r || n_episode_end) {
+    std::vector<double> acc(2 * (size_t)e->n_envs);
+    HIPCHK(c, hipMemcpyAsync(acc.data(), e->acc, 16 * (size_t)e->n_envs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double sr = 0; int64_t ne = 0; for (int k = 0; k < e->n_envs; ++k) { sr += acc[2 * k]; ne += (int64_t)acc[2 * k + 1]; }
+    if (sum_r) *sum_r = sr; if (n_episode_end) *n_episode_end = ne;
+  }
+  return CRUX_OK;
+}
+
+int32_t crux_env_step_host(crux_ctx* c, int32_t kind, int64_t n, const double* state, const void* action, const double* uniforms, double* next_state,
+                           float* obs, float* r, uint8_t* done) {
+  (void)uniforms;
+  if (!c || n < 0 || !state || !action) return CRUX_EINVAL;
+  if (kind != CRUX_ENV_CARTPOLE && kind != CRUX_ENV_PENDULUM) return crux_fail(c, CRUX_EUNSUP, "env kind %d has no device dynamics yet", kind);
+  if (n == 0) return CRUX_OK;
+  const int sd = kind == CRUX_ENV_CARTPOLE ? 4 : 2, od = kind == CRUX_ENV_CARTPOLE ? 4 : 3;
+  const size_t ab = kind == CRUX_ENV_CARTPOLE ? 2 * (size_t)n : 4 * (size_t)n;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t o_s = 0, o_a = o_s + al(8 * (size_t)n * sd), o_ns = o_a + al(ab), o_o = o_ns + al(8 * (size_t)n * sd), o_r = o_o + al(4 * (size_t)n * od), o_d = o_r + al(4 * (size_t)n);
+  char* sc = (char*)crux_scratch(c, o_d + al((size_t)n));
+  if (!sc) return crux_fail(c, CRUX_ENOMEM, "env_step: scratch");
+  HIPCHK(c, hipMemcpyAsync(sc + o_s, state, 8 * (size_t)n * sd, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sc + o_a, action, ab, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_env_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, kind, n, (const double*)(sc + o_s), (const void*)(sc + o_a),
+                     (double*)(sc + o_ns), (float*)(sc + o_o), (float*)(sc + o_r), (uint8_t*)(sc + o_d));
+  int32_t rc = crux_launch_check(c, "k_env_step"); if (rc) return rc;
+  if (next_state) HIPCHK(c, hipMemcpyAsync(next_state, sc + o_ns, 8 * (size_t)n * sd, hipMemcpyDeviceToHost, c->stream));
+  if (obs) HIPCHK(c, hipMemcpyAsync(obs, sc + o_o, 4 * (size_t)n * od, hipMemcpyDeviceToHost, c->stream));
+  if (r) HIPCHK(c, hipMemcpyAsync(r, sc + o_r, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  if (done) HIPCHK(c, hipMemcpyAsync(done, sc + o_d, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CRUX_OK;
+}
+
+}  // extern "C"

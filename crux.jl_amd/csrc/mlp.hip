@@ -1,0 +1,221 @@
+// mlp.hip -- Chain(Dense...) networks: parameters, generic forward, polyak, Adam.
+// Reference: Flux Chain/Dense wrapped by ContinuousNetwork / DiscreteNetwork (src/policies.jl:68-157),
+// polyak_average! (src/policies.jl:48-59), Flux.update!(Adam) (src/training.jl:21).
+#include "common.h"
+
+static void fill_desc(NetDesc& nd, int32_t L, const int32_t* dims, const int32_t* acts, int32_t n_extra) {
+  nd.L = L; int off = 0; nd.maxdim = 0;
+  for (int i = 0; i <= L; ++i) { nd.dims[i] = dims[i]; if (dims[i] > nd.maxdim) nd.maxdim = dims[i]; }
+  for (int l = 0; l < L; ++l) {
+    nd.acts[l] = acts[l]; nd.woff[l] = off; off += dims[l + 1] * dims[l]; nd.boff[l] = off; off += dims[l + 1];
+  }
+  nd.xoff = off; nd.n_extra = n_extra; nd.n_params = off + n_extra;
+}
+
+// ---- generic forward: one block = TS samples, activations ping-pong in LDS as [sample][feature] ----
+#define FWD_TS 32
+__global__ __launch_bounds__(256) void k_mlp_forward(NetDesc nd, const float* __restrict__ p, const float* __restrict__ x,
+                                                     int64_t B, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* h0 = sm; float* h1 = sm + (size_t)nd.maxdim * FWD_TS;
+  const int tid = threadIdx.x;
+  for (int64_t s0 = (int64_t)blockIdx.x * FWD_TS; s0 < B; s0 += (int64_t)gridDim.x * FWD_TS) {
+    const int ns = (int)((B - s0) < FWD_TS ? (B - s0) : FWD_TS);
+    const int in0 = nd.dims[0];
+    for (int idx = tid; idx < in0 * ns; idx += 256) h0[idx] = x[s0 * in0 + idx];
+    __syncthreads();
+    for (int l = 0; l < nd.L; ++l) {
+      const int in = nd.dims[l], out = nd.dims[l + 1], act = nd.acts[l];
+      const float* W = p + nd.woff[l]; const float* b = p + nd.boff[l];
+      for (int idx = tid; idx < out * ns; idx += 256) {
+        const int o = idx % out, s = idx / out;
+        float acc = 0.f;
+        for (int k = 0; k < in; ++k) acc = fmaf(W[o + out * k], h0[s * in + k], acc);
+        h1[s * out + o] = crux_act(act, acc + b[o]);
+      }
+      __syncthreads();
+      float* t = h0; h0 = h1; h1 = t;
+    }
+    const int outL = nd.dims[nd.L];
+    for (int idx = tid; idx < outL * ns; idx += 256) y[s0 * outL + idx] = h0[idx];
+    __syncthreads();
+  }
+}
+
+int32_t crux_mlp_forward_impl(crux_mlp* net, const float* d_x, int64_t B, float* d_y, const float* params_override);
+
+__global__ void k_glorot(NetDesc nd, float* p, uint64_t seed, uint32_t stream, float extra_init) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= nd.n_params) return;
+  if (gid >= nd.xoff) { p[gid] = extra_init; return; }
+  int64_t ctr = 0;
+  for (int l = 0; l < nd.L; ++l) {
+    const int64_t nw = (int64_t)nd.dims[l] * nd.dims[l + 1];
+    if (gid >= nd.woff[l] && gid < nd.boff[l]) {
+      const float scale = sqrtf(24.0f / (float)(nd.dims[l] + nd.dims[l + 1]));
+      crux_u32x4 x = crux_philox(seed, (uint64_t)(ctr + (gid - nd.woff[l])), stream, CRUX_RNG_INIT);
+      p[gid] = (crux_u32_to_f32(x.v[0]) - 0.5f) * scale;
+      return;
+    }
+    if (gid >= nd.boff[l] && gid < nd.boff[l] + nd.dims[l + 1]) { p[gid] = 0.f; return; }
+    ctr += nw;
+  }
+}
+
+__global__ void k_polyak(float* __restrict__ to, const float* __restrict__ from, float tau, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float omt = __fsub_rn(1.0f, tau);
+  to[i] = __fadd_rn(__fmul_rn(tau, from[i]), __fmul_rn(omt, to[i]));   // tau .* from .+ (1f0 - tau) .* to, no contraction
+}
+
+// Flux.Optimise.Adam apply! with Float64 scalar fields: each broadcast evaluated in Float64 per element,
+// rounded to Float32 on store.
+__global__ void k_adam_apply(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             const double* __restrict__ bp, double eta, double b1, double b2, double eps, float gscale, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double bp1 = bp[0], bp2 = bp[1];
+  const float gi = g[i] * gscale;
+  const double gd = (double)gi;
+  const float mi = (float)(b1 * (double)m[i] + (1.0 - b1) * gd);
+  const float vi = (float)(b2 * (double)v[i] + ((1.0 - b2) * gd) * gd);
+  const float d = (float)((double)mi / (1.0 - bp1) / (sqrt((double)vi / (1.0 - bp2)) + eps) * eta);
+  m[i] = mi; v[i] = vi; p[i] = p[i] - d;
+}
+__global__ void k_adam_advance(double* bp, double b1, double b2) { bp[0] *= b1; bp[1] *= b2; }
+
+extern "C" {
+
+int32_t crux_mlp_create(crux_ctx* ctx, int32_t L, const int32_t* dims, const int32_t* acts, int32_t n_extra, crux_mlp** out) {
+  if (!ctx || !out || !dims || !acts) return CRUX_EINVAL;
+  if (L < 1 || L > CRUX_MAXL || n_extra < 0) return crux_fail(ctx, CRUX_EINVAL, "mlp: n_layers %d out of range", L);
+  for (int i = 0; i <= L; ++i) if (dims[i] < 1 || dims[i] > 1024) return crux_fail(ctx, CRUX_EINVAL, "mlp: dim %d = %d unsupported", i, dims[i]);
+  crux_mlp* n = new crux_mlp(); n->ctx = ctx;
+  fill_desc(n->nd, L, dims, acts, n_extra);
+  const size_t bytes = sizeof(float) * (size_t)n->nd.n_params;
+  if (hipMalloc(&n->p, bytes) != hipSuccess || hipMalloc(&n->g, bytes) != hipSuccess || hipMalloc(&n->m, bytes) != hipSuccess ||
+      hipMalloc(&n->v, bytes) != hipSuccess || hipMalloc(&n->bp, 2 * sizeof(double)) != hipSuccess) { delete n; return crux_fail(ctx, CRUX_ENOMEM, "mlp: hipMalloc failed"); }
+  HIPCHK(ctx, hipMemsetAsync(n->p, 0, bytes, ctx->stream)); HIPCHK(ctx, hipMemsetAsync(n->g, 0, bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(n->m, 0, bytes, ctx->stream)); HIPCHK(ctx, hipMemsetAsync(n->v, 0, bytes, ctx->stream));
+  *out = n; return CRUX_OK;
+}
+
+int32_t crux_mlp_destroy(crux_mlp* n) {
+  if (!n) return CRUX_OK;
+  (void)hipStreamSynchronize(n->ctx->stream);
+  (void)hipFree(n->p); (void)hipFree(n->g); (void)hipFree(n->m); (void)hipFree(n->v); (void)hipFree(n->bp);
+  delete n; return CRUX_OK;
+}
+
+int64_t crux_mlp_n_params(const crux_mlp* n) { return n ? n->nd.n_params : -1; }
+float* crux_mlp_params_ptr(crux_mlp* n) { return n ? n->p : nullptr; }
+float* crux_mlp_grads_ptr(crux_mlp* n) { return n ? n->g : nullptr; }
+
+int32_t crux_mlp_set_params(crux_mlp* n, const float* h, int64_t cnt) {
+  if (!n || !h) return CRUX_EINVAL;
+  if (cnt != n->nd.n_params) return crux_fail(n->ctx, CRUX_EINVAL, "set_params: got %lld values, network has %d", (long long)cnt, n->nd.n_params);
+  HIPCHK(n->ctx, hipMemcpyAsync(n->p, h, sizeof(float) * (size_t)cnt, hipMemcpyHostToDevice, n->ctx->stream));
+  HIPCHK(n->ctx, hipStreamSynchronize(n->ctx->stream));
+  return CRUX_OK;
+}
+int32_t crux_mlp_get_params(crux_mlp* n, float* h, int64_t cnt) {
+  if (!n || !h) return CRUX_EINVAL;
+  if (cnt != n->nd.n_params) return crux_fail(n->ctx, CRUX_EINVAL, "get_params: asked %lld values, network has %d", (long long)cnt, n->nd.n_params);
+  HIPCHK(n->ctx, hipMemcpyAsync(h, n->p, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost, n->ctx->stream));
+  HIPCHK(n->ctx, hipStreamSynchronize(n->ctx->stream));
+  return CRUX_OK;
+}
+
+int32_t crux_mlp_init_glorot(crux_mlp* n, uint64_t seed, uint32_t stream, float extra_init) {
+  if (!n) return CRUX_EINVAL;
+  const int nb = (n->nd.n_params + 255) / 256;
+  hipLaunchKernelGGL(k_glorot, dim3(nb), dim3(256), 0, n->ctx->stream, n->nd, n->p, seed, stream, extra_init);
+  return crux_launch_check(n->ctx, "k_glorot");
+}
+
+int32_t crux_mlp_forward(crux_mlp* n, const float* d_x, int64_t B, float* d_y) {
+  if (!n || !d_x || !d_y || B < 0) return CRUX_EINVAL;
+  return crux_mlp_forward_impl(n, d_x, B, d_y, nullptr);
+}
+
+int32_t crux_mlp_forward_host(crux_mlp* n, const float* x, int64_t B, float* y) {
+  if (!n || !x || !y || B < 0) return CRUX_EINVAL;
+  if (B == 0) return CRUX_OK;
+  crux_ctx* c = n->ctx;
+  const size_t bi = sizeof(float) * (size_t)B * n->nd.dims[0], bo = sizeof(float) * (size_t)B * n->nd.dims[n->nd.L];
+  char* sc = (char*)crux_scratch(c, bi + bo + 256);
+  if (!sc) return crux_fail(c, CRUX_ENOMEM, "forward_host: scratch");
+  float* dx = (float*)sc; float* dy = (float*)(sc + ((bi + 255) / 256) * 256);
+  HIPCHK(c, hipMemcpyAsync(dx, x, bi, hipMemcpyHostToDevice, c->stream));
+  int32_t rc = crux_mlp_forward_impl(n, dx, B, dy, nullptr); if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(y, dy, bo, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CRUX_OK;
+}
+
+int32_t crux_mlp_copy(crux_mlp* to, const crux_mlp* from) {
+  if (!to || !from) return CRUX_EINVAL;
+  if (to->nd.n_params != from->nd.n_params) return crux_fail(to->ctx, CRUX_EINVAL, "copyto!: parameter counts differ");
+  HIPCHK(to->ctx, hipMemcpyAsync(to->p, from->p, sizeof(float) * (size_t)to->nd.n_params, hipMemcpyDeviceToDevice, to->ctx->stream));
+  return CRUX_OK;
+}
+
+int32_t crux_polyak(crux_mlp* to, const crux_mlp* from, float tau) {
+  if (!to || !from) return CRUX_EINVAL;
+  if (to->nd.n_params != from->nd.n_params) return crux_fail(to->ctx, CRUX_EINVAL, "polyak_average!: parameter counts differ");
+  const int64_t n = to->nd.n_params;
+  hipLaunchKernelGGL(k_polyak, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, to->ctx->stream, to->p, from->p, tau, n);
+  return crux_launch_check(to->ctx, "k_polyak");
+}
+
+int32_t crux_adam_init(crux_mlp* n, double eta, double b1, double b2, double eps) {
+  if (!n) return CRUX_EINVAL;
+  n->eta = eta; n->b1 = b1; n->b2 = b2; n->eps = eps; n->has_adam = true;
+  const size_t bytes = sizeof(float) * (size_t)n->nd.n_params;
+  HIPCHK(n->ctx, hipMemsetAsync(n->m, 0, bytes, n->ctx->stream)); HIPCHK(n->ctx, hipMemsetAsync(n->v, 0, bytes, n->ctx->stream));
+  double bp[2] = {b1, b2};
+  HIPCHK(n->ctx, hipMemcpyAsync(n->bp, bp, sizeof bp, hipMemcpyHostToDevice, n->ctx->stream));
+  HIPCHK(n->ctx, hipStreamSynchronize(n->ctx->stream));
+  return CRUX_OK;
+}
+int32_t crux_adam_get_state(crux_mlp* n, float* m, float* v, double* bp) {
+  if (!n) return CRUX_EINVAL;
+  const size_t bytes = sizeof(float) * (size_t)n->nd.n_params;
+  if (m) HIPCHK(n->ctx, hipMemcpyAsync(m, n->m, bytes, hipMemcpyDeviceToHost, n->ctx->stream));
+  if (v) HIPCHK(n->ctx, hipMemcpyAsync(v, n->v, bytes, hipMemcpyDeviceToHost, n->ctx->stream));
+  if (bp) HIPCHK(n->ctx, hipMemcpyAsync(bp, n->bp, 2 * sizeof(double), hipMemcpyDeviceToHost, n->ctx->stream));
+  HIPCHK(n->ctx, hipStreamSynchronize(n->ctx->stream));
+  return CRUX_OK;
+}
+int32_t crux_adam_set_state(crux_mlp* n, const float* m, const float* v, const double* bp) {
+  if (!n) return CRUX_EINVAL;
+  const size_t bytes = sizeof(float) * (size_t)n->nd.n_params;
+  if (m) HIPCHK(n->ctx, hipMemcpyAsync(n->m, m, bytes, hipMemcpyHostToDevice, n->ctx->stream));
+  if (v) HIPCHK(n->ctx, hipMemcpyAsync(n->v, v, bytes, hipMemcpyHostToDevice, n->ctx->stream));
+  if (bp) HIPCHK(n->ctx, hipMemcpyAsync(n->bp, bp, 2 * sizeof(double), hipMemcpyHostToDevice, n->ctx->stream));
+  HIPCHK(n->ctx, hipStreamSynchronize(n->ctx->stream));
+  return CRUX_OK;
+}
+
+int32_t crux_adam_apply(crux_mlp* n, float grad_scale) {
+  if (!n) return CRUX_EINVAL;
+  if (!n->has_adam) return crux_fail(n->ctx, CRUX_EINVAL, "adam_apply: crux_adam_init was not called");
+  const int64_t cnt = n->nd.n_params;
+  hipLaunchKernelGGL(k_adam_apply, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n->ctx->stream, n->p, n->g, n->m, n->v, n->bp,
+                     n->eta, n->b1, n->b2, n->eps, grad_scale, cnt);
+  hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, n->ctx->stream, n->bp, n->b1, n->b2);
+  return crux_launch_check(n->ctx, "k_adam_apply");
+}
+
+}  // extern "C"
+
+int32_t crux_mlp_forward_impl(crux_mlp* n, const float* d_x, int64_t B, float* d_y, const float* params_override) {
+  if (B == 0) return CRUX_OK;
+  crux_ctx* c = n->ctx;
+  const size_t lds = sizeof(float) * 2 * (size_t)n->nd.maxdim * FWD_TS;
+  if (lds > 65536) return crux_fail(c, CRUX_EUNSUP, "mlp_forward: layer width %d exceeds the generic kernel's LDS tile", n->nd.maxdim);
+  int64_t nb = (B + FWD_TS - 1) / FWD_TS; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)nb), dim3(256), lds, c->stream, n->nd, params_override ? params_override : n->p, d_x, B, d_y);
+  return crux_launch_check(c, "k_mlp_forward");
+}

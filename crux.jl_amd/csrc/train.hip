@@ -1,0 +1,391 @@
+// train.hip -- learner: train! / batch_train! as ONE persistent single-workgroup kernel (generic shapes).
+// Reference: src/training.jl:13-55 (train!, batch_train!), src/model_free/rl/ppo.jl:4-21,59-60 (ppo_loss, critic mse),
+// src/policies.jl:133-155 (categorical logpdf/entropy), :333-348 (gaussian logpdf/entropy), src/utils.jl:49-55 (grad norm),
+// src/utils.jl:76-87 (td_loss), Flux Adam, aggregate_info aliasing.
+//
+// This is the shape-generic kernel: every Dense layer is a loop, activations live in LDS in chunks of TR_CH samples,
+// parameters / moments stay in global memory (L2 resident). It is the correctness baseline and the fallback for shapes
+// the MFMA kernel (train_mfma.hip) does not cover. Both implement the same TrainArgs contract.
+#include "train_args.h"
+
+int32_t crux_buffer_apply_order(crux_buffer* b, const int32_t* d_order, int64_t n);
+int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled);
+
+#define TR_CH 32
+#define EPS32F 1.1920928955078125e-07f
+
+__device__ __forceinline__ double block_sum_d(double v, double* red, int tid) {
+  // 256 threads = 4 waves. Deterministic: wave butterfly then fixed-order sum of 4 partials.
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  const double t = ((red[0] + red[1]) + red[2]) + red[3];
+  return t;
+}
+
+__global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ double red[4];
+  const NetDesc& nd = a.nd;
+  const int tid = threadIdx.x;
+  const int L = nd.L, nout = nd.dims[L], od = nd.dims[0];
+  // LDS carve: acts[l] (l=0..L) [sample][feature], two delta buffers, per-sample extras scratch
+  float* acts[CRUX_MAXL + 1]; int off = 0;
+  for (int l = 0; l <= L; ++l) { acts[l] = sm + off; off += nd.dims[l] * TR_CH; }
+  float* dA = sm + off; off += nd.maxdim * TR_CH;
+  float* dB = sm + off; off += nd.maxdim * TR_CH;
+  float* exs = sm + off;   // [TR_CH x n_extra] per-sample logSigma gradient contributions
+
+  double bp1 = a.bp[0], bp2 = a.bp[1];   // every thread carries the beta powers in registers (identical values)
+  const float lo = 1.f - a.eps_clip, hi = 1.f + a.eps_clip;
+  int32_t* order_cur = a.order_a; int32_t* order_nxt = a.order_b;
+  long long total_batches = 0; int epochs_run = 0; int err = 0; bool stop = false;
+  float info[CRUX_INFO_N];
+#pragma unroll
+  for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
+
+  const int n_epochs = a.ids ? 1 : a.epochs;
+  if (!a.ids) { for (int64_t j = tid; j < a.len; j += 256) order_cur[j] = (int32_t)j; __syncthreads(); }
+
+  for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
+    if (!a.ids) {
+      // shuffle!(D): new[:,j] = old[:,perm[j]]  (experience_buffer.jl:118-124) as an index composition
+      if (a.perms) { for (int64_t j = tid; j < a.len; j += 256) order_nxt[j] = order_cur[a.perms[(int64_t)ep * a.len + j]]; }
+      else { const crux_perm pp = crux_perm_make(a.shuffle_seed, a.shuffle_counter + (uint64_t)ep, 0, (uint32_t)a.len);
+        for (int64_t j = tid; j < a.len; j += 256) order_nxt[j] = order_cur[crux_perm_at(&pp, (uint32_t)j)]; }
+      __syncthreads();
+      int32_t* t = order_cur; order_cur = order_nxt; order_nxt = t;
+    }
+    const int64_t total_rows = a.ids ? a.n_ids : a.len;
+    for (int64_t st = 0; st < total_rows; st += a.bs) {                     // partition(1:len, batch_size) (training.jl:40)
+      const int nb = (int)((total_rows - st) < a.bs ? (total_rows - st) : a.bs);
+      const float invB = 1.0f / (float)nb;
+      for (int i = tid; i < nd.n_params; i += 256) a.g[i] = 0.f;
+      double s_lossp = 0, s_H = 0, s_kl = 0, s_adv = 0, s_ret = 0, s_clip = 0, s_sq = 0, s_q = 0;
+      for (int c0 = 0; c0 < nb; c0 += TR_CH) {
+        const int ns = (nb - c0) < TR_CH ? (nb - c0) : TR_CH;
+        // ---- gather the chunk's observations (minibatch view, experience_buffer.jl:170)
+        for (int idx = tid; idx < od * ns; idx += 256) { const int s = idx / od, k = idx - s * od;
+          const int64_t row = a.ids ? (int64_t)a.ids[st + c0 + s] : (int64_t)order_cur[st + c0 + s];
+          acts[0][s * od + k] = a.S[row * od + k]; }
+        __syncthreads();
+        // ---- forward
+        for (int l = 0; l < L; ++l) {
+          const int in = nd.dims[l], out = nd.dims[l + 1], act = nd.acts[l];
+          const float* W = a.p + nd.woff[l]; const float* b = a.p + nd.boff[l];
+          for (int idx = tid; idx < out * ns; idx += 256) { const int o = idx % out, s = idx / out;
+            float acc = 0.f;
+            for (int k = 0; k < in; ++k) acc = fmaf(W[o + out * k], acts[l][s * in + k], acc);
+            acts[l + 1][s * out + o] = crux_act(act, acc + b[o]); }
+          __syncthreads();
+        }
+        // ---- loss head: one thread per sample -> d(loss)/d(output) into dA[s*nout + k]
+        if (tid < ns) {
+          const int s = tid; const int64_t row = a.ids ? (int64_t)a.ids[st + c0 + s] : (int64_t)order_cur[st + c0 + s];
+          const float* z = acts[L] + s * nout; float* dy = dA + s * nout;
+          if (a.loss == CRUX_LOSS_VALUE_MSE) {                                   // Flux.mse(value(pi,s), return)  ppo.jl:60
+            const float d = z[0] - a.RET[row]; s_sq += (double)(d * d); dy[0] = 2.f * d * invB;
+          } else if (a.loss == CRUX_LOSS_TD_INTERNAL) {                          // td_loss utils.jl:76-87
+            const uint8_t* av = (const uint8_t*)a.A + row * a.ad; float Q = 0.f;
+            for (int k = 0; k < nout; ++k) Q += z[k] * (av[k] ? 1.f : 0.f);
+            const float d = Q - a.Y[row]; const float w = a.Wt ? a.Wt[row] : 1.f;
+            s_sq += (double)(d * d * w); s_q += (double)Q;
+            for (int k = 0; k < nout; ++k) dy[k] = av[k] ? 2.f * d * w * invB : 0.f;
+          } else {                                                                // ppo_loss ppo.jl:4-21
+            const float A = a.ADV[row], oldlp = a.LP[row]; float newlp = 0.f, H = 0.f, r, g;
+            if (a.head == CRUX_HEAD_CATEGORICAL) {
+              const uint8_t* av = (const uint8_t*)a.A + row * a.ad;
+              float mx = z[0]; for (int k = 1; k < nout; ++k) mx = z[k] > mx ? z[k] : mx;
+              float sum = 0.f; for (int k = 0; k < nout; ++k) sum += expf(z[k] - mx);
+              float q = 0.f, hp = 0.f;
+              for (int k = 0; k < nout; ++k) { const float pk = expf(z[k] - mx) / sum; q += pk * (av[k] ? 1.f : 0.f);
+                const float lg = logf(pk + EPS32F); H -= pk * lg; hp += (-lg - pk / (pk + EPS32F)) * pk; }
+              newlp = logf(q);
+              r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A;
+              g = (u <= cl) ? A : 0.f; s_lossp += (double)(u <= cl ? u : cl);
+              for (int k = 0; k < nout; ++k) { const float pk = expf(z[k] - mx) / sum; const float lg = logf(pk + EPS32F);
+                const float hk = -lg - pk / (pk + EPS32F);
+                const float dlogpi = pk * ((av[k] ? 1.f : 0.f) / q) - pk;
+                dy[k] = invB * (-a.lambda_p * g * r * dlogpi - a.lambda_e * (pk * (hk - hp))); }
+            } else {                                                              // GaussianPolicy policies.jl:333-348
+              const float* av = (const float*)a.A + row * a.ad; const float* ls = a.p + nd.xoff;
+              for (int k = 0; k < a.ad; ++k) { const float sg = expf(ls[k]); const float d = av[k] - z[k];
+                newlp += (-(d * d) / (2.f * sg * sg) - 0.9189385332046727f - ls[k]); }
+              r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A;
+              g = (u <= cl) ? A : 0.f; s_lossp += (double)(u <= cl ? u : cl);
+              for (int k = 0; k < a.ad; ++k) { const float sg = expf(ls[k]); const float s2 = sg * sg; const float d = av[k] - z[k];
+                dy[k] = invB * (-a.lambda_p * g * r * (d / s2));
+                exs[s * a.ad + k] = invB * (-a.lambda_p * g * r * ((d * d) / s2 - 1.f)); }
+            }
+            s_H += (double)H; s_kl += (double)(oldlp - newlp); s_adv += (double)A; if (a.RET) s_ret += (double)a.RET[row];
+            if (r > hi || r < lo) s_clip += 1.0;
+          }
+        }
+        __syncthreads();
+        if (a.loss == CRUX_LOSS_PPO && a.head == CRUX_HEAD_GAUSSIAN && tid < a.ad) {   // deterministic per-dimension sum over the chunk
+          float acc = 0.f; for (int s = 0; s < ns; ++s) acc += exs[s * a.ad + tid]; a.g[nd.xoff + tid] += acc; }
+        // ---- backward through the layers
+        float* dcur = dA; float* dnxt = dB;
+        for (int l = L - 1; l >= 0; --l) {
+          const int in = nd.dims[l], out = nd.dims[l + 1], act = nd.acts[l];
+          for (int idx = tid; idx < out * ns; idx += 256) dcur[idx] = crux_act_grad(act, acts[l + 1][idx], dcur[idx]);
+          __syncthreads();
+          const float* W = a.p + nd.woff[l];
+          for (int pidx = tid; pidx < out * in + out; pidx += 256) {
+            float acc = 0.f;
+            if (pidx < out * in) { const int o = pidx % out, k = pidx / out;
+              for (int s = 0; s < ns; ++s) acc = fmaf(dcur[s * out + o], acts[l][s * in + k], acc);
+              a.g[nd.woff[l] + pidx] += acc; }
+            else { const int o = pidx - out * in; for (int s = 0; s < ns; ++s) acc += dcur[s * out + o]; a.g[nd.boff[l] + o] += acc; }
+          }
+          if (l > 0) {
+            for (int idx = tid; idx < in * ns; idx += 256) { const int k = idx % in, s = idx / in; float acc = 0.f;
+              for (int o = 0; o < out; ++o) acc = fmaf(W[o + out * k], dcur[s * out + o], acc);
+              dnxt[s * in + k] = acc; }
+          }
+          __syncthreads();
+          float* t = dcur; dcur = dnxt; dnxt = t;
+        }
+      }
+      if (a.loss == CRUX_LOSS_PPO && a.head == CRUX_HEAD_GAUSSIAN && tid < a.ad) a.g[nd.xoff + tid] += -a.lambda_e;   // d(-le*H)/dlogSigma, H scalar
+      // ---- reductions: stats and grad norm (utils.jl:49-55)
+      double ssq = 0.0; for (int i = tid; i < nd.n_params; i += 256) { const double gi = (double)a.g[i]; ssq += gi * gi; }
+      const double t_ssq = block_sum_d(ssq, red, tid);
+      const double t_lossp = block_sum_d(s_lossp, red, tid), t_H = block_sum_d(s_H, red, tid), t_kl = block_sum_d(s_kl, red, tid);
+      const double t_adv = block_sum_d(s_adv, red, tid), t_ret = block_sum_d(s_ret, red, tid), t_clip = block_sum_d(s_clip, red, tid);
+      const double t_sq = block_sum_d(s_sq, red, tid), t_q = block_sum_d(s_q, red, tid);
+      const float gnorm = (float)sqrt(t_ssq);
+#pragma unroll
+      for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
+      if (a.loss == CRUX_LOSS_PPO) {
+        const float p_loss = (float)(-(t_lossp / (double)nb)); float entropy, e_loss;
+        if (a.head == CRUX_HEAD_CATEGORICAL) { entropy = (float)(t_H / (double)nb); e_loss = -entropy; }
+        else { float Hs = 1.4189385332046727f; for (int k = 0; k < a.ad; ++k) Hs += a.p[nd.xoff + k]; entropy = Hs; e_loss = -Hs; }
+        info[CRUX_INFO_LOSS] = a.lambda_p * p_loss + a.lambda_e * e_loss; info[CRUX_INFO_ENTROPY] = entropy; info[CRUX_INFO_KL] = (float)(t_kl / (double)nb);
+        info[CRUX_INFO_CLIP_FRACTION] = (float)t_clip / (float)nb; info[CRUX_INFO_AVG_ADVANTAGE] = (float)(t_adv / (double)nb); info[CRUX_INFO_AVG_RETURN] = (float)(t_ret / (double)nb);
+      } else { info[CRUX_INFO_LOSS] = (float)(t_sq / (double)nb); if (a.loss == CRUX_LOSS_TD_INTERNAL) info[2] = (float)(t_q / (double)nb); }
+      info[CRUX_INFO_GRAD_NORM] = gnorm;
+      if (isnan(gnorm)) { err = CRUX_ENAN; break; }                            // training.jl:20 -- no update
+      // ---- Flux.update!(Adam) (training.jl:21), Float64 per element like the reference
+      if (a.apply) {
+        for (int i = tid; i < nd.n_params; i += 256) {
+          const double gd = (double)a.g[i];
+          const float mi = (float)(a.b1 * (double)a.m[i] + (1.0 - a.b1) * gd);
+          const float vi = (float)(a.b2 * (double)a.v[i] + ((1.0 - a.b2) * gd) * gd);
+          const float d = (float)((double)mi / (1.0 - bp1) / (sqrt((double)vi / (1.0 - bp2)) + a.eps) * a.eta);
+          a.m[i] = mi; a.v[i] = vi; a.p[i] = a.p[i] - d;
+        }
+        bp1 *= a.b1; bp2 *= a.b2;
+      }
+      __syncthreads();
+      total_batches += 1;
+      if (a.max_batches > 0 && total_batches >= a.max_batches) break;          // training.jl:45
+      if (a.target_kl >= 0.f && a.loss == CRUX_LOSS_PPO && info[CRUX_INFO_KL] > a.target_kl) break;   // :46
+    }
+    if (err) break;
+    if (tid < CRUX_INFO_N && a.epoch_infos) a.epoch_infos[(size_t)ep * CRUX_INFO_N + tid] = info[tid];   // aggregate == last minibatch (Q3)
+    epochs_run += 1;
+    if (a.target_kl >= 0.f && a.loss == CRUX_LOSS_PPO && info[CRUX_INFO_KL] > a.target_kl) stop = true;  // :49
+    if (a.max_batches > 0 && total_batches >= a.max_batches) stop = true;                                // :50
+  }
+  if (tid == 0) {
+    a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
+    a.bp[0] = bp1; a.bp[1] = bp2;
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------
+static size_t generic_lds_bytes(const NetDesc& nd) {
+  size_t fl = 0; for (int l = 0; l <= nd.L; ++l) fl += (size_t)nd.dims[l] * TR_CH;
+  fl += 2 * (size_t)nd.maxdim * TR_CH + (size_t)TR_CH * (nd.n_extra > 0 ? nd.n_extra : 1);
+  return fl * sizeof(float);
+}
+
+static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, int internal_loss) {
+  crux_ctx* c = net->ctx;
+  if (!net->has_adam) return crux_fail(c, CRUX_EINVAL, "train!: crux_adam_init was not called for this network");
+  if (net->nd.dims[0] != buf->obs_dim) return crux_fail(c, CRUX_EINVAL, "train!: network input %d != obs dim %d", net->nd.dims[0], buf->obs_dim);
+  memset(&a, 0, sizeof a);
+  a.nd = net->nd; a.p = net->p; a.g = net->g; a.m = net->m; a.v = net->v; a.bp = net->bp; a.eta = net->eta; a.b1 = net->b1; a.b2 = net->b2; a.eps = net->eps;
+  a.S = (const float*)buf->col[CRUX_COL_S]; a.A = buf->col[CRUX_COL_A];
+  a.LP = has_col(buf, CRUX_COL_LOGPROB) ? (const float*)buf->col[CRUX_COL_LOGPROB] : nullptr;
+  a.ADV = has_col(buf, CRUX_COL_ADVANTAGE) ? (const float*)buf->col[CRUX_COL_ADVANTAGE] : nullptr;
+  a.RET = has_col(buf, CRUX_COL_RETURN) ? (const float*)buf->col[CRUX_COL_RETURN] : nullptr;
+  a.od = buf->obs_dim; a.ad = buf->act_dim; a.act_kind = buf->act_kind;
+  a.loss = internal_loss; a.head = cfg->head; a.bs = cfg->batch_size; a.epochs = cfg->epochs; a.max_batches = cfg->max_batches;
+  a.eps_clip = cfg->eps_clip; a.lambda_p = cfg->lambda_p; a.lambda_e = cfg->lambda_e; a.target_kl = cfg->target_kl;
+  a.shuffle_seed = cfg->shuffle_seed; a.shuffle_counter = cfg->shuffle_counter;
+  a.len = buf->elements; a.order_a = buf->order_a; a.order_b = buf->order_b; a.apply = 1;
+  const int nout = net->nd.dims[net->nd.L];
+  if (internal_loss == CRUX_LOSS_PPO) {
+    if (!a.LP || !a.ADV) return crux_fail(c, CRUX_EINVAL, "ppo_loss: buffer needs :logprob and :advantage columns");
+    if (cfg->head == CRUX_HEAD_CATEGORICAL) { if (nout != buf->act_dim || buf->act_kind != CRUX_ACTION_DISCRETE || nout > 32) return crux_fail(c, CRUX_EINVAL, "ppo_loss: categorical head needs %d logits over a one-hot action column", buf->act_dim); }
+    else if (cfg->head == CRUX_HEAD_GAUSSIAN) { if (nout != buf->act_dim || buf->act_kind != CRUX_ACTION_CONTINUOUS || net->nd.n_extra != buf->act_dim) return crux_fail(c, CRUX_EINVAL, "ppo_loss: gaussian head needs %d means + %d logSigma extras over a Float32 action column", buf->act_dim, buf->act_dim); }
+    else return crux_fail(c, CRUX_EINVAL, "ppo_loss: head %d unsupported", cfg->head);
+  } else if (internal_loss == CRUX_LOSS_VALUE_MSE) {
+    if (!a.RET || nout != 1) return crux_fail(c, CRUX_EINVAL, "critic mse: needs a :return column and a scalar-output network");
+  }
+  if (cfg->batch_size < 1) return crux_fail(c, CRUX_EINVAL, "train!: batch_size %d", cfg->batch_size);
+  return CRUX_OK;
+}
+
+static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot) {
+  bool handled = false;
+  crux_prof_begin(c, prof_slot);
+  int32_t rc = crux_train_mfma_launch(c, a, &handled);
+  if (!handled) {
+    const size_t lds = generic_lds_bytes(a.nd);
+    if (lds > 160 * 1024 - 64) return crux_fail(c, CRUX_EUNSUP, "train!: network too wide for the generic learner kernel (%zu B of LDS)", lds);
+    static size_t attr_set = 0;
+    if (lds > 64 * 1024 && lds > attr_set) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = lds; }
+    hipLaunchKernelGGL(k_train_generic, dim3(1), dim3(256), lds, c->stream, a);
+    rc = crux_launch_check(c, "k_train_generic");
+  }
+  crux_prof_end(c, prof_slot);
+  return rc;
+}
+
+// runs the kernel and interprets status; info_out = aggregate over epochs (aggregate_info(infos), training.jl:54)
+static int32_t run_batch(crux_mlp* net, crux_buffer* buf, TrainArgs& a, int n_epochs, float* info_out, float* epoch_infos, bool permute_after) {
+  crux_ctx* c = net->ctx;
+  const size_t eb = sizeof(float) * CRUX_INFO_N * (size_t)(n_epochs > 0 ? n_epochs : 1);
+  char* sc = (char*)crux_scratch(c, eb + 256 + (a.perms ? 0 : 0));
+  if (!sc) return crux_fail(c, CRUX_ENOMEM, "train!: scratch");
+  a.status = (int32_t*)sc; a.epoch_infos = (float*)(sc + 256);
+  HIPCHK(c, hipMemsetAsync(sc, 0, eb + 256, c->stream));
+  const int slot = a.loss == CRUX_LOSS_PPO ? CRUX_PROF_TRAIN_ACTOR : (a.loss == CRUX_LOSS_VALUE_MSE ? CRUX_PROF_TRAIN_CRITIC : CRUX_PROF_TD_STEP);
+  int32_t rc = launch_train(c, a, slot); if (rc) return rc;
+  int32_t st[4]; std::vector<float> ei((size_t)CRUX_INFO_N * (size_t)(n_epochs > 0 ? n_epochs : 1));
+  HIPCHK(c, hipMemcpyAsync(st, a.status, sizeof st, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(ei.data(), a.epoch_infos, eb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (permute_after && st[2] > 0) {   // materialise the composed epoch shuffles so the buffer order matches the reference's
+    rc = crux_buffer_apply_order(buf, st[3] ? buf->order_b : buf->order_a, buf->elements); if (rc) return rc;
+  }
+  if (info_out) {
+    for (int q = 0; q < CRUX_INFO_N; ++q) { double s = 0; for (int e = 0; e < st[2]; ++e) s += (double)ei[(size_t)e * CRUX_INFO_N + q]; info_out[q] = st[2] ? (float)(s / (double)st[2]) : 0.f; }
+    info_out[CRUX_INFO_BATCHES_TRAINED] = (float)st[1]; info_out[CRUX_INFO_EPOCHS_RUN] = (float)st[2];
+    if (st[0] == CRUX_ENAN && st[2] == 0) for (int q = 0; q < 2; ++q) info_out[q] = NAN;
+  }
+  if (epoch_infos) memcpy(epoch_infos, ei.data(), sizeof(float) * CRUX_INFO_N * (size_t)st[2]);
+  if (st[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
+  if (st[0]) return crux_fail(c, st[0], "learner kernel reported status %d", st[0]);
+  return CRUX_OK;
+}
+
+static int32_t upload_ids(crux_ctx* c, crux_buffer* buf, const int64_t* ids, int64_t n, int32_t** d_ids) {
+  std::vector<int32_t> h((size_t)n);
+  for (int64_t j = 0; j < n; ++j) { if (ids[j] < 0 || ids[j] >= buf->capacity) return crux_fail(c, CRUX_EINVAL, "minibatch index %lld out of range", (long long)ids[j]); h[(size_t)j] = (int32_t)ids[j]; }
+  if (n > buf->capacity) return crux_fail(c, CRUX_EINVAL, "minibatch larger than buffer capacity");
+  HIPCHK(c, hipMemcpyAsync(buf->order_b, h.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *d_ids = buf->order_b;
+  return CRUX_OK;
+}
+
+int32_t crux_values_fast(crux_mlp* net, const float* d_x, int64_t B, float* d_y);
+
+extern "C" {
+
+int32_t crux_batch_train(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int64_t* perms, float* info_out, float* epoch_infos) {
+  if (!net || !buf || !cfg) return CRUX_EINVAL;
+  crux_ctx* c = net->ctx;
+  if (buf->elements <= 0) return crux_fail(c, CRUX_EINVAL, "batch_train!: empty buffer");
+  if (cfg->epochs < 1) return crux_fail(c, CRUX_EINVAL, "batch_train!: epochs %d", cfg->epochs);
+  TrainArgs a; int32_t rc = fill_args(a, net, buf, cfg, cfg->loss); if (rc) return rc;
+  int64_t* d_perms = nullptr;
+  if (perms) {
+    const int64_t len = buf->elements;
+    for (int64_t i = 0; i < (int64_t)cfg->epochs * len; ++i) if (perms[i] < 0 || perms[i] >= len) return crux_fail(c, CRUX_EINVAL, "batch_train!: perms[%lld] out of range", (long long)i);
+    if (hipMalloc(&d_perms, 8 * (size_t)cfg->epochs * (size_t)len) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "batch_train!: perms");
+    hipError_t e = hipMemcpyAsync(d_perms, perms, 8 * (size_t)cfg->epochs * (size_t)len, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { (void)hipFree(d_perms); return crux_fail(c, CRUX_EHIP, "batch_train!: perms upload"); }
+    a.perms = d_perms;
+  }
+  rc = run_batch(net, buf, a, cfg->epochs, info_out, epoch_infos, true);
+  if (d_perms) { (void)hipStreamSynchronize(c->stream); (void)hipFree(d_perms); }
+  return rc;
+}
+
+static int32_t step_impl(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids, int64_t n, float* info_out, int apply) {
+  if (!net || !buf || !cfg || !ids || n < 1) return CRUX_EINVAL;
+  crux_ctx* c = net->ctx;
+  TrainArgs a; int32_t rc = fill_args(a, net, buf, cfg, cfg->loss); if (rc) return rc;
+  int32_t* d_ids = nullptr; rc = upload_ids(c, buf, ids, n, &d_ids); if (rc) return rc;
+  a.ids = d_ids; a.n_ids = n; a.bs = (int32_t)n; a.epochs = 1; a.max_batches = 0; a.target_kl = -1.f; a.apply = apply;
+  return run_batch(net, buf, a, 1, info_out, nullptr, false);
+}
+
+int32_t crux_train_step(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids, int64_t n, float* info_out) {
+  return step_impl(net, buf, cfg, ids, n, info_out, 1);
+}
+int32_t crux_loss_grad(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids, int64_t n, float* info_out) {
+  return step_impl(net, buf, cfg, ids, n, info_out, 0);
+}
+int32_t crux_loss_grad_device_ids(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int32_t* d_ids, int64_t n, float* d_info) {
+  if (!net || !buf || !cfg || !d_ids || n < 1) return CRUX_EINVAL;
+  TrainArgs a; int32_t rc = fill_args(a, net, buf, cfg, cfg->loss); if (rc) return rc;
+  a.ids = d_ids; a.n_ids = n; a.bs = (int32_t)n; a.epochs = 1; a.max_batches = 0; a.target_kl = -1.f; a.apply = 0;
+  crux_ctx* c = net->ctx;
+  char* sc = (char*)crux_scratch(c, 1024);
+  if (!sc) return crux_fail(c, CRUX_ENOMEM, "loss_grad: scratch");
+  a.status = (int32_t*)sc; a.epoch_infos = d_info ? d_info : (float*)(sc + 256);
+  return launch_train(c, a, a.loss == CRUX_LOSS_PPO ? CRUX_PROF_TRAIN_ACTOR : CRUX_PROF_TRAIN_CRITIC);
+}
+
+// ---- off-policy pieces ------------------------------------------------------------------------------
+int32_t crux_td_step(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight, float* info_out) {
+  if (!net || !batch || !d_y) return CRUX_EINVAL;
+  crux_ctx* c = net->ctx;
+  if (batch->elements < 1) return crux_fail(c, CRUX_EINVAL, "td_loss: empty batch");
+  if (batch->act_kind != CRUX_ACTION_DISCRETE || net->nd.dims[net->nd.L] != batch->act_dim) return crux_fail(c, CRUX_EINVAL, "td_loss: needs a one-hot action column matching the Q outputs");
+  if (use_weight && !has_col(batch, CRUX_COL_WEIGHT)) return crux_fail(c, CRUX_EINVAL, "td_loss(weight=:weight): batch has no :weight column");
+  crux_train_cfg cfg{}; cfg.loss = CRUX_LOSS_VALUE_MSE; cfg.head = CRUX_HEAD_GREEDY_Q; cfg.batch_size = (int32_t)batch->elements; cfg.epochs = 1; cfg.target_kl = -1.f;
+  TrainArgs a; int32_t rc = fill_args(a, net, batch, &cfg, CRUX_LOSS_TD_INTERNAL); if (rc) return rc;
+  std::vector<int64_t> ids((size_t)batch->elements); for (size_t j = 0; j < ids.size(); ++j) ids[j] = (int64_t)j;
+  int32_t* d_ids = nullptr; rc = upload_ids(c, batch, ids.data(), batch->elements, &d_ids); if (rc) return rc;
+  a.ids = d_ids; a.n_ids = batch->elements; a.Y = d_y; a.Wt = use_weight ? (const float*)batch->col[CRUX_COL_WEIGHT] : nullptr; a.target_kl = -1.f;
+  return run_batch(net, batch, a, 1, info_out, nullptr, false);
+}
+
+}  // extern "C"
+
+// ---- dqn_target / td_error -----------------------------------------------------------------------------
+int32_t crux_mlp_forward_impl(crux_mlp* net, const float* d_x, int64_t B, float* d_y, const float* params_override);
+
+__global__ void k_dqn_target(const float* __restrict__ q, int nout, const float* __restrict__ r, const uint8_t* __restrict__ done, float gamma, int64_t n, float* __restrict__ y) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (s >= n) return;
+  float mx = q[s * nout]; for (int k = 1; k < nout; ++k) mx = q[s * nout + k] > mx ? q[s * nout + k] : mx;
+  y[s] = __fadd_rn(r[s], __fmul_rn(__fmul_rn(gamma, __fsub_rn(1.f, done[s] ? 1.f : 0.f)), mx));   // r .+ gamma .* (1 .- done) .* max  (dqn.jl:5)
+}
+__global__ void k_td_error(const float* __restrict__ q, int nout, const uint8_t* __restrict__ a, const float* __restrict__ y, int64_t n, float* __restrict__ err) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (s >= n) return;
+  float Q = 0.f; for (int k = 0; k < nout; ++k) Q = __fadd_rn(Q, __fmul_rn(q[s * nout + k], a[s * nout + k] ? 1.f : 0.f));
+  err[s] = fabsf(__fsub_rn(Q, y[s]));
+}
+
+extern "C" {
+
+int32_t crux_dqn_target(crux_mlp* tn, crux_buffer* batch, float gamma, float* d_y) {
+  if (!tn || !batch || !d_y) return CRUX_EINVAL;
+  crux_ctx* c = tn->ctx; const int64_t n = batch->elements; if (n == 0) return CRUX_OK;
+  const int nout = tn->nd.dims[tn->nd.L];
+  float* q = (float*)crux_scratch(c, 4 * (size_t)n * nout + 256); if (!q) return crux_fail(c, CRUX_ENOMEM, "dqn_target: scratch");
+  int32_t rc = crux_mlp_forward_impl(tn, (const float*)batch->col[CRUX_COL_SP], n, q, nullptr); if (rc) return rc;
+  hipLaunchKernelGGL(k_dqn_target, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, q, nout, (const float*)batch->col[CRUX_COL_R], (const uint8_t*)batch->col[CRUX_COL_DONE], gamma, n, d_y);
+  return crux_launch_check(c, "k_dqn_target");
+}
+
+int32_t crux_td_error(crux_mlp* net, crux_buffer* batch, const float* d_y, float* d_err) {
+  if (!net || !batch || !d_y || !d_err) return CRUX_EINVAL;
+  crux_ctx* c = net->ctx; const int64_t n = batch->elements; if (n == 0) return CRUX_OK;
+  const int nout = net->nd.dims[net->nd.L];
+  if (batch->act_kind != CRUX_ACTION_DISCRETE || nout != batch->act_dim) return crux_fail(c, CRUX_EINVAL, "td_error: needs a one-hot action column matching the Q outputs");
+  float* q = (float*)crux_scratch(c, 4 * (size_t)n * nout + 256); if (!q) return crux_fail(c, CRUX_ENOMEM, "td_error: scratch");
+  int32_t rc = crux_mlp_forward_impl(net, (const float*)batch->col[CRUX_COL_S], n, q, nullptr); if (rc) return rc;
+  hipLaunchKernelGGL(k_td_error, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, q, nout, (const uint8_t*)batch->col[CRUX_COL_A], d_y, n, d_err);
+  return crux_launch_check(c, "k_td_error");
+}
+
+}  // extern "C"

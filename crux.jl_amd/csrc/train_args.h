@@ -1,0 +1,25 @@
+// train_args.h -- argument block shared by the learner kernels (generic and MFMA).
+#pragma once
+#include "common.h"
+
+#define CRUX_LOSS_TD_INTERNAL 2   // td_loss (src/utils.jl:76-87); reached through crux_td_step
+
+struct TrainArgs {
+  NetDesc nd;
+  float* p; float* g; float* m; float* v; double* bp;
+  double eta, b1, b2, eps;
+  const float* S; const void* A; const float* LP; const float* ADV; const float* RET; const float* Y; const float* Wt;
+  int32_t od, ad, act_kind;
+  int32_t loss, head, bs, epochs;
+  long long max_batches;
+  float eps_clip, lambda_p, lambda_e, target_kl;
+  uint64_t shuffle_seed, shuffle_counter;
+  int64_t len;
+  int32_t* order_a; int32_t* order_b;
+  const int64_t* perms;      // device [epochs x len] or NULL
+  const int32_t* ids;        // device explicit rows (single-step mode) or NULL
+  int64_t n_ids;
+  int32_t apply;             // 1: Adam update after each minibatch
+  float* epoch_infos;        // device [epochs x CRUX_INFO_N]
+  int32_t* status;           // device [4]: err, batches_trained, epochs_run, final order selector
+};

@@ -1,0 +1,69 @@
+"""Multi-GPU: independent-seed environment shards per rank + gradient exchange.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in CPU tests). Rollout, GAE,
+buffer writes and minibatch gradients are rank-local; the only exchange is a SUM all-reduce of the flattened gradient
+(actor: 4 610 floats for the 4-64-64-2 net) before Adam, so parameters and Adam state stay replicated.
+
+The reference has no collectives at all; this module is new functionality, defined so that
+sync_every == 1 reproduces single-GPU training on the concatenated global minibatch (up to summation order).
+"""
+import ctypes as C
+import math
+import numpy as np
+
+from . import _lib as L
+
+
+def shard_seed(base_seed, rank):
+    """Environment seed of a rank: Philox key differs per rank so shards are independent."""
+    return (int(base_seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03 + 1) & 0xFFFFFFFFFFFFFFFF
+
+
+def partition_envs(n_envs_global, world_size, rank):
+    """Contiguous env ranges [lo, hi) per rank (rank g owns envs g*E/N .. (g+1)*E/N)."""
+    per = n_envs_global // world_size
+    if per * world_size != n_envs_global:
+        raise ValueError("n_envs_global must be divisible by world_size")
+    return rank * per, (rank + 1) * per
+
+
+class GradAllReducer:
+    """All-reduces a network's flat gradient in place. The gradient buffer lives in the library (crux_mlp_grads_ptr);
+    it is exposed to torch without a copy through __cuda_array_interface__ so RCCL reads/writes it directly."""
+
+    def __init__(self, net, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.net, self.group = torch, dist, net, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.tensor = None
+
+    def _wrap(self):
+        if self.tensor is None:
+            ptr = self.net.ctx.lib.crux_mlp_grads_ptr(self.net.h)
+            n = self.net.n_params
+
+            class _Iface:
+                __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+            self.tensor = self.torch.as_tensor(_Iface(), device="cuda:%d" % self.net.ctx.device)
+        return self.tensor
+
+    def __call__(self):
+        if self.world == 1:
+            return 1.0
+        self.net.ctx.sync()                 # the library's stream must have produced the gradient
+        t = self._wrap()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.torch.cuda.current_stream().synchronize()
+        return 1.0 / self.world            # scale applied inside crux_adam_apply
+
+
+def train_minibatch_synced(pi, p, P, D, ids0, reducer, cfg_builder):
+    """One data-parallel gradient step: local loss+grad -> all-reduce(sum) -> Adam on the mean gradient."""
+    cfg = cfg_builder(pi, p, P)
+    raw = np.zeros(L.INFO_N, np.float32)
+    ids0 = np.ascontiguousarray(ids0, np.int64)
+    pi.ctx.check(pi.ctx.lib.crux_loss_grad(pi.h, D.h, C.byref(cfg), ids0.ctypes.data_as(C.c_void_p), ids0.size, raw.ctypes.data_as(C.c_void_p)))
+    scale = reducer()
+    pi.ctx.check(pi.ctx.lib.crux_adam_apply(pi.h, float(scale)))
+    return raw

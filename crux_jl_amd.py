@@ -1,0 +1,10 @@
+"""Import shim: makes the package directory `crux.jl_amd/` importable as `crux_jl_amd`."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "crux.jl_amd")
+_spec = importlib.util.spec_from_file_location("crux_jl_amd", os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["crux_jl_amd"] = _mod
+_spec.loader.exec_module(_mod)

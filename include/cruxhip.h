@@ -1,0 +1,267 @@
+/* cruxhip.h -- C ABI of libcruxhip.so: the MI355X (gfx950) actor-learner hot path behind Crux.jl's
+ * Sampler / ExperienceBuffer / batch_train! seams.
+ *
+ * Every entry point names the reference interface it replaces (file:line under sisl/Crux.jl v0.1.4).
+ * The reference has no FFI; its seams are Julia multiple dispatch on the container type
+ * (src/devices.jl:1-21, src/experience_buffer.jl:53,87-95) and function-valued solver fields
+ * (src/training.jl:1-11, src/model_free/on_policy.jl:44-45). A Julia shim binds these symbols with
+ * `ccall`; the Python mirror in crux.jl_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *  - every function returns int32 status: 0 ok, <0 error (message via crux_last_error).
+ *  - arrays are laid out exactly like the Julia arrays: column-major (features..., batch), batch last;
+ *    Dense weight is out x in column-major; Bool columns are 1 byte.
+ *  - indices cross the ABI 0-based (Julia callers subtract 1).
+ *  - host pointers are borrowed for the duration of the call; `d_` prefixed pointers are device memory.
+ *  - one context per host thread; calls on a context are stream-ordered and asynchronous unless they
+ *    return host data.
+ */
+#ifndef CRUXHIP_H
+#define CRUXHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes ------------------------------------------------------------------------------ */
+#define CRUX_OK       0
+#define CRUX_EINVAL  -1  /* shape/dtype mismatch  == @assert at src/experience_buffer.jl:251        */
+#define CRUX_ENAN    -2  /* NaN grad norm / advantage == src/training.jl:20, src/sampler.jl:270     */
+#define CRUX_EHIP    -3  /* HIP runtime failure                                                    */
+#define CRUX_ERCCL   -4  /* collective failure                                                     */
+#define CRUX_ENOMEM  -5
+#define CRUX_EUNSUP  -6  /* configuration not supported by any kernel                              */
+
+typedef struct crux_ctx crux_ctx;
+typedef struct crux_mlp crux_mlp;
+typedef struct crux_buffer crux_buffer;
+typedef struct crux_env crux_env;
+
+/* lifecycle --------------------------------------------------------------------------------- */
+/* stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create a private one. */
+int32_t crux_ctx_create(int32_t device_id, void* stream, crux_ctx** out);
+int32_t crux_ctx_destroy(crux_ctx* ctx);
+const char* crux_last_error(crux_ctx* ctx);
+int32_t crux_sync(crux_ctx* ctx);
+const char* crux_version(void);
+
+/* raw device memory for callers without their own allocator (targets, td errors, ...). */
+int32_t crux_device_alloc(crux_ctx* ctx, int64_t bytes, void** d_out);
+int32_t crux_device_free(crux_ctx* ctx, void* d_ptr);
+int32_t crux_memcpy_h2d(crux_ctx* ctx, void* d_dst, const void* src, int64_t bytes);
+int32_t crux_memcpy_d2h(crux_ctx* ctx, void* dst, const void* d_src, int64_t bytes);
+
+/* kernel timing on the context's stream (HIP events). slot = one of CRUX_PROF_*.                */
+enum { CRUX_PROF_ROLLOUT = 0, CRUX_PROF_VALUES = 1, CRUX_PROF_GAE = 2, CRUX_PROF_WHITEN = 3,
+       CRUX_PROF_TRAIN_ACTOR = 4, CRUX_PROF_TRAIN_CRITIC = 5, CRUX_PROF_PER_SCAN = 6,
+       CRUX_PROF_PER_SEARCH = 7, CRUX_PROF_GATHER = 8, CRUX_PROF_TD_STEP = 9, CRUX_PROF_NSLOTS = 16 };
+int32_t crux_prof_enable(crux_ctx* ctx, int32_t on);
+int32_t crux_prof_reset(crux_ctx* ctx);
+/* returns accumulated milliseconds and launch count for a slot (synchronises the stream). */
+int32_t crux_prof_get(crux_ctx* ctx, int32_t slot, double* ms_total, int64_t* launches);
+
+/* networks: Chain(Dense...) --------------------------------------------------------------------
+ * replaces Flux Chain(Dense(in,out,act)...) wrapped by ContinuousNetwork / DiscreteNetwork
+ * (src/policies.jl:68-98,104-157). Flat parameter vector = Flux.params order: W1,b1,W2,b2,... then
+ * `n_extra` trailing trainables (GaussianPolicy's ConstantLayer logSigma, src/policies.jl:315-320,
+ * src/utils.jl:31-36). */
+enum { CRUX_ACT_IDENTITY = 0, CRUX_ACT_RELU = 1, CRUX_ACT_TANH = 2 };
+int32_t crux_mlp_create(crux_ctx* ctx, int32_t n_layers, const int32_t* dims /*n_layers+1*/,
+                        const int32_t* acts /*n_layers*/, int32_t n_extra, crux_mlp** out);
+int32_t crux_mlp_destroy(crux_mlp* net);
+int64_t crux_mlp_n_params(const crux_mlp* net);
+int32_t crux_mlp_set_params(crux_mlp* net, const float* host_flat, int64_t n);
+int32_t crux_mlp_get_params(crux_mlp* net, float* host_flat, int64_t n);
+float*  crux_mlp_params_ptr(crux_mlp* net);        /* device pointer to the flat parameters      */
+float*  crux_mlp_grads_ptr(crux_mlp* net);         /* device pointer to the flat gradient scratch */
+/* Flux glorot_uniform: U(+-sqrt(6/(in+out))) weights, zero bias; extras set to `extra_init`.    */
+int32_t crux_mlp_init_glorot(crux_mlp* net, uint64_t seed, uint32_t stream, float extra_init);
+/* y[out x B] = net(x[in x B]); value(pi, s) (src/policies.jl:94,120). Device pointers.          */
+int32_t crux_mlp_forward(crux_mlp* net, const float* d_x, int64_t B, float* d_y);
+/* same with host pointers (copies in/out, synchronous).                                          */
+int32_t crux_mlp_forward_host(crux_mlp* net, const float* x, int64_t B, float* y);
+/* copyto!(to, from) (src/policies.jl:61-65) and polyak_average!(to, from, tau) (:48-59).         */
+int32_t crux_mlp_copy(crux_mlp* to, const crux_mlp* from);
+int32_t crux_polyak(crux_mlp* to, const crux_mlp* from, float tau);
+
+/* optimiser: Flux.Optimise.Adam(eta, (b1,b2), eps) attached to one network
+ * (TrainingParams.optimizer, src/training.jl:3; Flux.update! at :21). State = (m, v, beta powers). */
+int32_t crux_adam_init(crux_mlp* net, double eta, double beta1, double beta2, double eps);
+int32_t crux_adam_get_state(crux_mlp* net, float* m_host, float* v_host, double* beta_pow /*2*/);
+int32_t crux_adam_set_state(crux_mlp* net, const float* m_host, const float* v_host, const double* beta_pow);
+
+/* experience buffer ------------------------------------------------------------------------------
+ * replaces mdp_data / ExperienceBuffer (src/experience_buffer.jl:4-35,53-80). Columns are separate
+ * device arrays (SoA across keys; one transition's features contiguous within a key).           */
+enum { CRUX_COL_S = 0, CRUX_COL_A = 1, CRUX_COL_SP = 2, CRUX_COL_R = 3, CRUX_COL_DONE = 4,
+       CRUX_COL_EPISODE_END = 5, CRUX_COL_RETURN = 6, CRUX_COL_LOGPROB = 7, CRUX_COL_ADVANTAGE = 8,
+       CRUX_COL_WEIGHT = 9, CRUX_COL_T = 10, CRUX_COL_I = 11, CRUX_COL_VALUE = 12, CRUX_NCOLS = 13 };
+enum { CRUX_ACTION_DISCRETE = 0 /* Bool one-hot, 1 byte each (src/spaces.jl:18,24) */,
+       CRUX_ACTION_CONTINUOUS = 1 /* Float32 */ };
+/* column_mask: bit k set => optional column k present (S,A,SP,R,DONE,EPISODE_END always are).   */
+int32_t crux_buffer_create(crux_ctx* ctx, int32_t obs_dim, int32_t act_dim, int32_t act_kind,
+                           int64_t capacity, uint32_t column_mask, int32_t prioritized, float alpha,
+                           crux_buffer** out);
+int32_t crux_buffer_destroy(crux_buffer* b);
+int64_t crux_buffer_len(const crux_buffer* b);         /* Base.length   (:182)                    */
+int64_t crux_buffer_capacity(const crux_buffer* b);    /* capacity      (:184)                    */
+int64_t crux_buffer_next_ind(const crux_buffer* b);    /* 0-based next_ind                        */
+int64_t crux_buffer_total_count(const crux_buffer* b);
+int32_t crux_buffer_has_column(const crux_buffer* b, int32_t key);
+int32_t crux_buffer_clear(crux_buffer* b);             /* clear!        (:97-104)                 */
+/* element size in bytes and rows-per-transition of a column (e.g. S: 4, obs_dim).               */
+int32_t crux_buffer_column_info(const crux_buffer* b, int32_t key, int32_t* elem_bytes, int32_t* rows);
+int32_t crux_buffer_column_ptr(crux_buffer* b, int32_t key, void** d_ptr);
+/* push!(b, data) (:232-259): ring write of n transitions from host columns. cols[k]==NULL means
+ * "data has no key k" (skipped, :238-241). Writes the destination indices I (0-based) if I_out.   */
+int32_t crux_buffer_push_host(crux_buffer* b, int64_t n, const void* const* cols /*CRUX_NCOLS*/,
+                              int64_t* I_out);
+/* push!(target, source, ids=ids) (:232-259): device gather of rows `ids` (host array, 0-based; NULL
+ * => 0..n-1) of `src` into the ring of `dst`.                                                     */
+int32_t crux_buffer_push_buffer(crux_buffer* dst, const crux_buffer* src, const int64_t* ids, int64_t n,
+                                int64_t* I_out);
+/* copy the first `n` (<= len) transitions of a column to the host: b[key] (:176).                */
+int32_t crux_buffer_read_column(crux_buffer* b, int32_t key, void* host_out, int64_t n);
+/* overwrite the first n transitions of a column from the host (b[key] .= x).                      */
+int32_t crux_buffer_write_column(crux_buffer* b, int32_t key, const void* host_in, int64_t n);
+/* shuffle!(b) with an explicit permutation (:118-124): new[:,j] = old[:,perm[j]], every column.    */
+int32_t crux_buffer_permute(crux_buffer* b, const int64_t* perm /*len*/);
+/* get_last_N_indices (:223-229), 0-based; returns count written.                                  */
+int64_t crux_buffer_last_n_indices(const crux_buffer* b, int64_t N, int64_t* out);
+/* minibatch_copy(b, indices) (:171): gather rows to host; outs[k]==NULL skips a column.            */
+int32_t crux_buffer_gather_host(crux_buffer* b, const int64_t* ids, int64_t n, void* const* outs);
+/* indices of the last sample!() into this (staging) buffer: target.indices (:319,338).            */
+int32_t crux_buffer_indices(const crux_buffer* b, int64_t* out, int64_t n);
+
+/* prioritized replay (src/experience_buffer.jl:38-50,290-301,324-349) ---------------------------- */
+/* update_priorities!(b, I, v): v Float64 (v_is_f64=1) or Float32.                                 */
+int32_t crux_per_update(crux_buffer* b, const int64_t* I, const void* v, int32_t v_is_f64, int64_t n);
+/* same with device-resident ids (int64) and Float32 values (the td-error path, off_policy.jl:83).   */
+int32_t crux_per_update_device(crux_buffer* b, const int64_t* d_ids, const float* d_v, int64_t n);
+/* prioritized_sample!(target, source; i, B): `rands` = B Float64 uniforms (NULL => Philox draw with
+ * counter `i`). Writes ids into target.indices, IS weights into source[:weight], gathers rows.     */
+int32_t crux_per_sample(crux_buffer* target, crux_buffer* source, int64_t B, const double* rands,
+                        float beta, uint64_t i);
+/* uniform_sample!(target, source; B) (:317-321): `ids` host array or NULL => Philox draw.          */
+int32_t crux_uniform_sample(crux_buffer* target, crux_buffer* source, int64_t B, const int64_t* ids,
+                            uint64_t i);
+int32_t crux_per_get(crux_buffer* b, float* priorities /*capacity or NULL*/, float* max_priority,
+                     float* min_priority, float* cumsum /*len or NULL*/);
+
+/* environments + rollout (src/sampler.jl:1-173) --------------------------------------------------- */
+enum { CRUX_ENV_CARTPOLE = 0, CRUX_ENV_PENDULUM = 1, CRUX_ENV_GRIDWORLD = 2, CRUX_ENV_SYNTH = 3 };
+enum { CRUX_HEAD_CATEGORICAL = 0 /* DiscreteNetwork softmax head (policies.jl:104-157)            */,
+       CRUX_HEAD_GAUSSIAN = 1    /* GaussianPolicy, const logSigma extras (policies.jl:315-350)    */,
+       CRUX_HEAD_GREEDY_Q = 2    /* action(::DiscreteNetwork) argmax (policies.jl:124)             */,
+       CRUX_HEAD_DETERMINISTIC = 3 /* ContinuousNetwork action (policies.jl:92)                    */ };
+/* n_envs Samplers of one mdp kind (Sampler struct, src/sampler.jl:1-22). obs_mu/obs_sigma: the
+ * ContinuousSpace whitening of tovec (src/spaces.jl:25); NULL => 0 / 1. synth_* used by SYNTH.    */
+int32_t crux_env_create(crux_ctx* ctx, int32_t kind, int32_t n_envs, int32_t max_steps, float gamma,
+                        const float* obs_mu, const float* obs_sigma, uint64_t seed,
+                        int32_t synth_obs_dim, int32_t synth_act_dim, crux_env** out);
+int32_t crux_env_destroy(crux_env* env);
+int32_t crux_env_obs_dim(const crux_env* env);
+int32_t crux_env_act_dim(const crux_env* env);
+int32_t crux_env_reset(crux_env* env);                /* reset_sampler! for every env (:31-43)   */
+/* read back the per-env sampler state: f64 state [state_dim x n_envs], episode_length, resets.   */
+int32_t crux_env_get_state(crux_env* env, double* state, int64_t* episode_length, int64_t* n_resets);
+int32_t crux_env_state_dim(const crux_env* env);
+
+typedef struct {
+  int32_t explore;        /* steps!(...; explore=) (:139)                                          */
+  int32_t reset_at_end;   /* steps!(...; reset=)   (:148)                                          */
+  int32_t head;           /* CRUX_HEAD_*                                                           */
+  /* MixedPolicy / eps-greedy (policies.jl:466-494): eps(i)=max(stop, start - i*(start-stop)/steps)
+     (utils.jl:116-126); eps_steps==0 disables. */
+  double eps_start, eps_stop; int64_t eps_steps;
+  /* GaussianNoiseExplorationPolicy (policies.jl:499-514); noise_sigma<0 disables. */
+  float noise_sigma, noise_eps_min, noise_eps_max, a_min, a_max;
+  uint64_t i0;            /* steps!(...; i=) global interaction counter at the first step          */
+} crux_rollout_cfg;
+
+/* steps!(samplers, buffer; Nsteps=T, explore, reset, i) (:139-173) for all envs at once, env-major:
+ * rows [e*T, (e+1)*T) of the pushed block belong to env e (== hcat of E single-Sampler rollouts).
+ * The T*n_envs transitions are ring-pushed into `buf` (push!, experience_buffer.jl:232-259). The
+ * policy forward (exploration / action, sampler.jl:73), the env transition (:89-97), the column
+ * writes (:100-107) and episode bookkeeping (:130-136, terminate_episode! :53-69 minus the GAE
+ * fill) run in one kernel. sum_r/n_episode_end feed record_avgr (ppo.jl:52-54).                 */
+int32_t crux_rollout(crux_env* env, crux_mlp* policy, const crux_rollout_cfg* cfg, crux_buffer* buf,
+                     int64_t T, double* sum_r, int64_t* n_episode_end);
+
+/* test hook: apply the env dynamics once to explicit states/actions (host arrays):
+ * state [state_dim x n] f64, action [act_dim x n] (Bool one-hot bytes or f32), uniforms [n] f64 for
+ * stochastic envs or NULL; out: next state, obs(sp) [obs_dim x n] f32, r f32, done u8.            */
+int32_t crux_env_step_host(crux_ctx* ctx, int32_t kind, int64_t n, const double* state, const void* action,
+                           const double* uniforms, double* next_state, float* obs, float* r,
+                           uint8_t* done);
+
+/* advantage pipeline (src/sampler.jl:255-281, src/utils.jl:41-42) --------------------------------- */
+/* fill_gae!(d::ExperienceBuffer, V, lambda, gamma) over episodes(d) (sampler.jl:255-273).          */
+int32_t crux_fill_gae(crux_buffer* b, crux_mlp* critic, float lambda, float gamma);
+/* fill_returns! for every episode of the buffer (sampler.jl:275-281).                             */
+int32_t crux_fill_returns(crux_buffer* b, float gamma);
+/* b[key] .= whiten(b[key]) (utils.jl:41-42; PPO post_batch_callback ppo.jl:61). Bessel-corrected. */
+int32_t crux_whiten(crux_buffer* b, int32_t key);
+
+/* learner (src/training.jl:1-55, src/model_free/rl/ppo.jl:4-21,59-60) ------------------------------ */
+enum { CRUX_LOSS_PPO = 0      /* ppo_loss with the head's logpdf/entropy (ppo.jl:4-21)            */,
+       CRUX_LOSS_VALUE_MSE = 1 /* Flux.mse(value(pi, s), return) (ppo.jl:60)                      */ };
+
+typedef struct {
+  int32_t loss;           /* CRUX_LOSS_*                                                          */
+  int32_t head;           /* CRUX_HEAD_* for PPO                                                  */
+  int32_t batch_size;     /* TrainingParams.batch_size (training.jl:5)                            */
+  int32_t epochs;         /* TrainingParams.epochs     (training.jl:6)                            */
+  int64_t max_batches;    /* TrainingParams.max_batches, <=0 => Inf (training.jl:10)               */
+  float eps_clip;         /* P[:eps]  (ppo.jl:9)                                                  */
+  float lambda_p;         /* P[:lp]   (ppo.jl:20)                                                 */
+  float lambda_e;         /* P[:le]   (ppo.jl:20)                                                 */
+  float target_kl;        /* early_stopping = infos[end][:kl] > target_kl (ppo.jl:59); <0 => off   */
+  uint64_t shuffle_seed;  /* Philox key for epoch permutations when perms==NULL                    */
+  uint64_t shuffle_counter; /* first epoch's permutation counter (advanced by the caller)          */
+  int32_t sync_every;     /* multi-GPU: host-level gradient exchange period in minibatches (0=off) */
+  int32_t reserved;
+} crux_train_cfg;
+
+/* info keys written by train!/batch_train! (training.jl:22-23,53; ppo.jl:13-19).                   */
+enum { CRUX_INFO_LOSS = 0, CRUX_INFO_GRAD_NORM = 1, CRUX_INFO_ENTROPY = 2, CRUX_INFO_KL = 3,
+       CRUX_INFO_CLIP_FRACTION = 4, CRUX_INFO_AVG_ADVANTAGE = 5, CRUX_INFO_AVG_RETURN = 6,
+       CRUX_INFO_BATCHES_TRAINED = 7, CRUX_INFO_EPOCHS_RUN = 8, CRUX_INFO_N = 16 };
+
+/* batch_train!(pi, p, P, D) (training.jl:28-55): epochs x (shuffle!, partition, train!) with
+ * max_batches and early stopping (incl. the aliased-info semantics), executed by
+ * one persistent kernel. perms: NULL (Philox permutations) or host int64 [epochs x len] 0-based
+ * permutations, one per epoch, applied exactly like shuffle! (new[:,j] = old[:,perm[j]]).
+ * The buffer's row ORDER after the call equals the reference's (all epoch shuffles applied).
+ * info_out[CRUX_INFO_N]: aggregate over epochs (mean of each epoch's last-minibatch info) +
+ * batches_trained. epoch_infos (optional, host [epochs x CRUX_INFO_N]) gets the per-epoch rows.   */
+int32_t crux_batch_train(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int64_t* perms,
+                         float* info_out, float* epoch_infos);
+
+/* train!(pi, loss, p) (training.jl:13-25): one gradient step on explicit rows `ids` (host, 0-based)
+ * of the buffer. Returns CRUX_ENAN (without updating) when the grad norm is NaN (:20).            */
+int32_t crux_train_step(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids,
+                        int64_t n, float* info_out);
+/* gradient only (no optimiser step): writes the flat gradient to crux_mlp_grads_ptr(net); used by
+ * the multi-GPU path (all-reduce between crux_loss_grad and crux_adam_apply) and by parity tests. */
+int32_t crux_loss_grad(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids,
+                       int64_t n, float* info_out);
+int32_t crux_loss_grad_device_ids(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg,
+                                  const int32_t* d_ids, int64_t n, float* d_info);
+/* Flux.update!(opt, params, grads) from crux_mlp_grads_ptr(net) scaled by `grad_scale`.            */
+int32_t crux_adam_apply(crux_mlp* net, float grad_scale);
+
+/* off-policy pieces (src/model_free/rl/dqn.jl:4-6, src/utils.jl:76-87,112) --------------------------- */
+/* y = r + gamma*(1-done)*max_a Q_target(sp)   (dqn_target) over the staging buffer -> d_y [len].  */
+int32_t crux_dqn_target(crux_mlp* target_net, crux_buffer* batch, float gamma, float* d_y);
+/* td_error = |Q(s,a) - y| (utils.jl:112) -> d_err [len].                                          */
+int32_t crux_td_error(crux_mlp* net, crux_buffer* batch, const float* d_y, float* d_err);
+/* train!(critic, td_loss) (utils.jl:76-87): one Adam step on mean((Q(s,a)-y)^2 [.* weight]).       */
+int32_t crux_td_step(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight,
+                     float* info_out /* LOSS, GRAD_NORM, [2]=Qavg */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRUXHIP_H */

@@ -1,0 +1,116 @@
+/* crux_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, single thread, fp32 in the reference's op order) of the sisl/Crux.jl
+ * hot path. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (libcruxhip.so, crux.jl_amd/) never does.
+ *
+ * PARITY PINNING: Julia is absent from the build container, so the reference itself cannot be run.
+ * The oracle is pinned against (a) the known-answer values in the reference's own tests
+ * (test/experience_buffer_tests.jl:23-51,121-147,177-180,193-205), (b) the recorded transitions
+ * shipped with the reference (examples/il/expert_data/{cartpole,pendulum}.bson -> tests/golden/),
+ * (c) KATs derived by hand from the cited lines, and (d) torch-CPU float64 autograd for gradients.
+ * Third-party numerics that no reference test pins (Flux Dense/Adam, Statistics.std, Base.cumsum
+ * pairwise order, Distributions.Categorical sampling) are restated from their published algorithms
+ * and are marked [3P] below: for those pieces parity is "unpinned" (see DESIGN.md).
+ *
+ * The function set mirrors include/cruxhip.h one-to-one (prefix orc_, host memory everywhere).
+ */
+#ifndef CRUX_ORACLE_H
+#define CRUX_ORACLE_H
+#include <stdint.h>
+#include "../include/cruxhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_mlp orc_mlp;
+typedef struct orc_buffer orc_buffer;
+typedef struct orc_env orc_env;
+
+/* networks */
+orc_mlp* orc_mlp_create(int32_t n_layers, const int32_t* dims, const int32_t* acts, int32_t n_extra);
+void orc_mlp_destroy(orc_mlp* net);
+int64_t orc_mlp_n_params(const orc_mlp* net);
+float* orc_mlp_params(orc_mlp* net);
+float* orc_mlp_grads(orc_mlp* net);
+int32_t orc_mlp_init_glorot(orc_mlp* net, uint64_t seed, uint32_t stream, float extra_init);
+int32_t orc_mlp_forward(orc_mlp* net, const float* x, int64_t B, float* y);
+int32_t orc_mlp_copy(orc_mlp* to, const orc_mlp* from);
+int32_t orc_polyak(orc_mlp* to, const orc_mlp* from, float tau);
+int32_t orc_adam_init(orc_mlp* net, double eta, double beta1, double beta2, double eps);
+int32_t orc_adam_get_state(orc_mlp* net, float* m, float* v, double* beta_pow);
+int32_t orc_adam_apply(orc_mlp* net, float grad_scale);
+
+/* buffer */
+orc_buffer* orc_buffer_create(int32_t obs_dim, int32_t act_dim, int32_t act_kind, int64_t capacity,
+                              uint32_t column_mask, int32_t prioritized, float alpha);
+void orc_buffer_destroy(orc_buffer* b);
+int64_t orc_buffer_len(const orc_buffer* b);
+int64_t orc_buffer_capacity(const orc_buffer* b);
+int64_t orc_buffer_next_ind(const orc_buffer* b);
+int64_t orc_buffer_total_count(const orc_buffer* b);
+int32_t orc_buffer_has_column(const orc_buffer* b, int32_t key);
+int32_t orc_buffer_clear(orc_buffer* b);
+int32_t orc_buffer_column_info(const orc_buffer* b, int32_t key, int32_t* elem_bytes, int32_t* rows);
+void* orc_buffer_column(orc_buffer* b, int32_t key);
+int32_t orc_buffer_push_host(orc_buffer* b, int64_t n, const void* const* cols, int64_t* I_out);
+int32_t orc_buffer_push_buffer(orc_buffer* dst, const orc_buffer* src, const int64_t* ids, int64_t n, int64_t* I_out);
+int32_t orc_buffer_permute(orc_buffer* b, const int64_t* perm);
+int64_t orc_buffer_last_n_indices(const orc_buffer* b, int64_t N, int64_t* out);
+int32_t orc_buffer_gather_host(orc_buffer* b, const int64_t* ids, int64_t n, void* const* outs);
+int32_t orc_buffer_indices(const orc_buffer* b, int64_t* out, int64_t n);
+/* episodes(b) via :episode_end (experience_buffer.jl:194-221): writes [start,end] pairs (0-based,
+ * inclusive); returns the number of episodes. */
+int64_t orc_buffer_episodes(const orc_buffer* b, int64_t* starts, int64_t* ends, int64_t max_eps);
+void orc_split_batches(int64_t N, const double* fracs, int32_t nf, int64_t* out);
+void orc_circ_inds(int64_t start0, int64_t n, int64_t C, int64_t* out);
+
+/* PER */
+int32_t orc_per_update(orc_buffer* b, const int64_t* I, const void* v, int32_t v_is_f64, int64_t n);
+int32_t orc_per_sample(orc_buffer* target, orc_buffer* source, int64_t B, const double* rands, float beta, uint64_t i, uint64_t seed);
+int32_t orc_uniform_sample(orc_buffer* target, orc_buffer* source, int64_t B, const int64_t* ids, uint64_t i, uint64_t seed);
+int32_t orc_per_get(orc_buffer* b, float* priorities, float* max_priority, float* min_priority, float* cumsum);
+void orc_pairwise_cumsum_f32(const float* v, int64_t n, float* out);
+
+/* env + rollout */
+orc_env* orc_env_create(int32_t kind, int32_t n_envs, int32_t max_steps, float gamma, const float* obs_mu,
+                        const float* obs_sigma, uint64_t seed, int32_t synth_obs_dim, int32_t synth_act_dim);
+void orc_env_destroy(orc_env* env);
+int32_t orc_env_obs_dim(const orc_env* env);
+int32_t orc_env_act_dim(const orc_env* env);
+int32_t orc_env_state_dim(const orc_env* env);
+int32_t orc_env_reset(orc_env* env);
+int32_t orc_env_get_state(orc_env* env, double* state, int64_t* episode_length, int64_t* n_resets);
+int32_t orc_rollout(orc_env* env, orc_mlp* policy, const crux_rollout_cfg* cfg, orc_buffer* buf, int64_t T,
+                    double* sum_r, int64_t* n_episode_end);
+int32_t orc_env_step_host(int32_t kind, int64_t n, const double* state, const void* action, const double* uniforms,
+                          double* next_state, float* obs, float* r, uint8_t* done);
+
+/* advantage pipeline */
+int32_t orc_fill_gae(orc_buffer* b, orc_mlp* critic, float lambda, float gamma);
+int32_t orc_fill_returns(orc_buffer* b, float gamma);
+int32_t orc_whiten(orc_buffer* b, int32_t key);
+/* fill_gae! on one explicit range with given V(s), V(sp) (sampler.jl:262-273) -- KAT helper. */
+void orc_gae_range(const float* r, const uint8_t* done, const float* Vs, const float* Vsp, int64_t start, int64_t stop,
+                   float lambda, float gamma, float* adv);
+void orc_returns_range(const float* r, int64_t start, int64_t stop, float gamma, float* ret);
+
+/* learner */
+int32_t orc_batch_train(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg, const int64_t* perms,
+                        float* info_out, float* epoch_infos);
+int32_t orc_train_step(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids, int64_t n, float* info_out);
+int32_t orc_loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids, int64_t n, float* info_out);
+
+/* off-policy */
+int32_t orc_dqn_target(orc_mlp* target_net, orc_buffer* batch, float gamma, float* y);
+int32_t orc_td_error(orc_mlp* net, orc_buffer* batch, const float* y, float* err);
+int32_t orc_td_step(orc_mlp* net, orc_buffer* batch, const float* y, int32_t use_weight, float* info_out);
+
+/* schedules: LinearDecaySchedule (utils.jl:116-126) */
+double orc_linear_decay(double start, double stop, int64_t steps, int64_t i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,119 @@
+"""Shared GPU-vs-oracle parity helpers (used by tests/ and by __graft_entry__.smoke())."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import crux_jl_amd as crux  # noqa: E402
+from crux_jl_amd import _lib as L  # noqa: E402
+import oracle as O  # noqa: E402
+
+ACTOR_DIMS, CRITIC_DIMS, ACTS = [4, 64, 64, 2], [4, 64, 64, 1], ["relu", "relu", "identity"]
+
+
+def chain(dims, acts):
+    return crux.Chain(*[crux.Dense(dims[i], dims[i + 1], acts[i]) for i in range(len(acts))])
+
+
+def make_pair(dims, acts, seed, stream, kind="continuous", n_extra=0, extra_init=0.0, outputs=None):
+    """The same glorot-initialised network on the GPU and in the oracle (identical Philox draws)."""
+    ch = chain(dims, acts)
+    if kind == "discrete":
+        g = crux.DiscreteNetwork(ch, outputs or list(range(1, dims[-1] + 1)), seed=seed, stream=stream)
+    elif kind == "gaussian":
+        g = crux.GaussianPolicy(ch, np.full(n_extra, extra_init, np.float32), seed=seed, stream=stream)
+    else:
+        g = crux.ContinuousNetwork(ch, seed=seed, stream=stream)
+    o = O.OMlp(dims, acts, n_extra).init_glorot(seed, stream, extra_init)
+    return g, o
+
+
+def rollout_cfg(explore=True, reset=True, head="categorical", i0=0):
+    cfg = L.RolloutCfg()
+    cfg.explore, cfg.reset_at_end, cfg.head, cfg.i0 = int(explore), int(reset), L.HEAD[head], i0
+    cfg.eps_steps, cfg.noise_sigma = 0, -1.0
+    cfg.noise_eps_min, cfg.noise_eps_max, cfg.a_min, cfg.a_max = -np.inf, np.inf, -np.inf, np.inf
+    return cfg
+
+
+def train_cfg(loss, head="categorical", batch_size=128, epochs=2, target_kl=-1.0, seed=11, counter=0, max_batches=0,
+              eps=0.2, lp=1.0, le=0.1):
+    cfg = L.TrainCfg()
+    cfg.loss, cfg.head, cfg.batch_size, cfg.epochs, cfg.max_batches = L.LOSS[loss], L.HEAD[head], batch_size, epochs, max_batches
+    cfg.eps_clip, cfg.lambda_p, cfg.lambda_e, cfg.target_kl = eps, lp, le, target_kl
+    cfg.shuffle_seed, cfg.shuffle_counter = seed, counter
+    return cfg
+
+
+def compare_buffers(gb, ob, keys=None, atol=2e-5, rtol=1e-4):
+    """max abs/rel differences per column between a GPU ExperienceBuffer and an oracle buffer."""
+    out = {}
+    for k in keys or gb.keys():
+        a, b = gb[k], ob[k]
+        if a.dtype == np.bool_ or a.dtype == np.int64:
+            out[k] = int((a != b).sum())
+        else:
+            nan_mismatch = (np.isnan(a) != np.isnan(b)).sum()
+            d = np.abs(np.nan_to_num(a) - np.nan_to_num(b))
+            out[k] = float(d.max()) if d.size else 0.0
+            if nan_mismatch:
+                out[k] = float("inf")
+    return out
+
+
+def ppo_iteration_parity(n_envs=4, T=64, batch_size=32, epochs=2, seed=3, max_steps=50, target_kl=-1.0, gamma=0.99, lam=0.95):
+    """One full PPO iteration (rollout -> GAE/returns -> whiten -> actor batch_train! -> critic batch_train!) on the GPU
+    and in the oracle with the same Philox-defined randomness; returns the differences."""
+    N = n_envs * T
+    extras = ["return", "logprob", "advantage"]
+    ga, oa = make_pair(ACTOR_DIMS, ACTS, seed, 0, "discrete")
+    gc, oc = make_pair(CRITIC_DIMS, ACTS, seed, 1)
+    res = {"init_params_equal": bool(np.array_equal(ga.get_params(), oa.params) and np.array_equal(gc.get_params(), oc.params))}
+    S, A = crux.ContinuousSpace(4), crux.DiscreteSpace(2)
+    gb = crux.ExperienceBuffer(S, A, N, extras)
+    ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, N, extras)
+    mdp = crux.CartPoleMDP(n_envs=n_envs, seed=seed, discount=gamma)
+    pi = crux.ActorCritic(ga, gc)
+    gs = crux.Sampler(mdp, pi, max_steps=max_steps, required_columns=extras, lam=lam)
+    oe = O.OEnv("cartpole", n_envs, max_steps, gamma, seed)
+    # rollout
+    ginfo = crux.steps_(gs, gb, Nsteps=N, explore=True, i=0, reset=True)
+    osr, one = oe.rollout(oa, rollout_cfg(), ob, T)
+    O.chk(O.lib().orc_fill_gae(ob.h, oc.h, lam, gamma)); O.chk(O.lib().orc_fill_returns(ob.h, gamma))
+    res["rollout"] = compare_buffers(gb, ob)
+    res["sum_r"] = (ginfo["sum_r"], osr); res["n_episode_end"] = (ginfo["n_episode_end"], one)
+    # whiten
+    crux.whiten_(gb, "advantage"); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
+    res["whiten"] = compare_buffers(gb, ob, ["advantage"])
+    # learner
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+    a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=batch_size, epochs=epochs, target_kl=None if target_kl < 0 else target_kl, name="actor_", shuffle_seed=seed + 100)
+    c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=batch_size, epochs=epochs, name="critic_", shuffle_seed=seed + 200)
+    oa.adam_init(float(np.float32(3e-4))); oc.adam_init(float(np.float32(3e-4)))
+    gi = crux.batch_train_(ga, a_opt, P, gb)
+    oinfo = np.zeros(L.INFO_N, np.float32)
+    cfg_a = train_cfg("ppo", "categorical", batch_size, epochs, target_kl, seed + 100)
+    O.chk(O.lib().orc_batch_train(oa.h, ob.h, C.byref(cfg_a), None, O.vpz(oinfo), None))
+    res["actor_param_maxdiff"] = float(np.abs(ga.get_params() - oa.params).max())
+    res["actor_info"] = {k: (gi.get(k if k in gi else "actor_" + k), float(oinfo[L.INFO[k]])) for k in ("loss", "grad_norm", "kl", "entropy")}
+    res["actor_batches"] = (gi["actor_batches_trained"], int(oinfo[L.INFO["batches_trained"]]))
+    res["order_after_actor"] = compare_buffers(gb, ob, ["s", "a", "advantage"])
+    gi2 = crux.batch_train_(gc, c_opt, P, gb)
+    oinfo2 = np.zeros(L.INFO_N, np.float32)
+    cfg_c = train_cfg("value_mse", "deterministic", batch_size, epochs, -1.0, seed + 200)
+    O.chk(O.lib().orc_batch_train(oc.h, ob.h, C.byref(cfg_c), None, O.vpz(oinfo2), None))
+    res["critic_param_maxdiff"] = float(np.abs(gc.get_params() - oc.params).max())
+    res["critic_info"] = {"loss": (gi2["critic_loss"], float(oinfo2[0])), "grad_norm": (gi2["critic_grad_norm"], float(oinfo2[1]))}
+    ok = res["init_params_equal"]
+    ok &= all(v == 0 for k, v in res["rollout"].items() if k in ("a", "done", "episode_end"))
+    ok &= all(v < 2e-4 for k, v in res["rollout"].items() if k in ("s", "sp", "r", "logprob", "advantage", "return"))
+    ok &= res["whiten"]["advantage"] < 2e-4
+    ok &= res["actor_param_maxdiff"] < 2e-4 and res["critic_param_maxdiff"] < 2e-4
+    ok &= res["actor_batches"][0] == res["actor_batches"][1]
+    ok &= res["order_after_actor"]["a"] == 0 and res["order_after_actor"]["s"] < 2e-5
+    res["ok"] = bool(ok)
+    return res
