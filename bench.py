@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- PPO actor-learner hot path on MI355X (BASELINE.json configs[1]).
+
+One "step" = one full PPO iteration on synthetic CartPole shards: 32 envs x 2048-step rollout (65 536 transitions,
+policy forward + env dynamics + SoA column writes in one kernel), GAE/returns, advantage whitening, then
+batch_train! for the actor (ppo_loss) and the critic (mse): 80 epochs x 512 minibatches of 128 each, i.e. exactly
+81 920 sequential Adam steps per iteration (KL early stopping is OFF in the timed configuration so no work is skipped;
+the early-stopping variant is reported separately under "early_stop").
+
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: launched by torch.distributed.run, one rank per GPU; every rank owns an independent-seed shard of 32 envs (weak
+scaling) and the replicas exchange parameters + Adam moments with an all-reduce (RCCL over xGMI) after every epoch.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_ENVS, T, BATCH, EPOCHS, MAX_STEPS = 32, 2048, 128, 80, 500
+GAMMA, LAM = 0.99, 0.95
+ACTOR, CRITIC, ACTS = [4, 64, 64, 2], [4, 64, 64, 1], ["relu", "relu", "identity"]
+# algorithmic work per unit (SURVEY.md 8d / DESIGN.md)
+FLOP_ACTOR_STEP = 6 * BATCH * (4 * 64 + 64 * 64 + 64 * 2)     # 3.44 MFLOP: fwd 2*B*P + bwd 4*B*P (P = weight count)
+FLOP_CRITIC_STEP = 6 * BATCH * (4 * 64 + 64 * 64 + 64 * 1)    # 3.39 MFLOP
+PEAK_F32_MFMA_TFLOPS = 157.3                                  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def chain(crux, dims):
+    return crux.Chain(*[crux.Dense(dims[i], dims[i + 1], ACTS[i]) for i in range(3)])
+
+
+def build_problem(crux, seed, n_envs=N_ENVS, T_=T):
+    S, A = crux.ContinuousSpace(4), crux.DiscreteSpace(2)
+    actor = crux.DiscreteNetwork(chain(crux, ACTOR), [1, 2], seed=1, stream=0)
+    critic = crux.ContinuousNetwork(chain(crux, CRITIC), seed=1, stream=1)
+    pi = crux.ActorCritic(actor, critic)
+    extras = ["return", "logprob", "advantage"]
+    buf = crux.ExperienceBuffer(S, A, n_envs * T_, extras)
+    mdp = crux.CartPoleMDP(n_envs=n_envs, seed=seed, discount=GAMMA)
+    sampler = crux.Sampler(mdp, pi, max_steps=MAX_STEPS, required_columns=extras, lam=LAM)
+    return pi, buf, sampler
+
+
+def ppo_iteration(crux, pi, buf, sampler, a_opt, c_opt, P, it, sync=None):
+    n = len(buf) if len(buf) else buf.capacity
+    info = crux.steps_(sampler, buf, Nsteps=buf.capacity, explore=True, i=it * buf.capacity, reset=True)
+    crux.whiten_(buf, "advantage")
+    if sync is None:
+        ai = crux.batch_train_(pi.A, a_opt, P, buf)
+        ci = crux.batch_train_(pi.C, c_opt, P, buf)
+        return ai["actor_batches_trained"] + ci["critic_batches_trained"], info
+    # multi-GPU: one persistent launch per epoch, parameters + Adam moments averaged between epochs
+    nb = 0
+    for net, opt, key in ((pi.A, a_opt, "actor_"), (pi.C, c_opt, "critic_")):
+        e_total = opt.epochs
+        opt.epochs = 1
+        for _ in range(e_total):
+            r = crux.batch_train_(net, opt, P, buf)
+            nb += r[key + "batches_trained"]
+            sync(net)
+        opt.epochs = e_total
+    return nb, info
+
+
+def cpu_baseline():
+    """Oracle (CPU port of the reference algorithm, single thread) on a bounded sample of the same workload:
+    a 32-env x 128-step rollout + GAE, and 2 x 192 minibatch Adam steps (B=128); extrapolated to one full iteration."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from crux_jl_amd import _lib as L
+    import parity
+    Ts = 128
+    oa = O.OMlp(ACTOR, ACTS).init_glorot(1, 0); oc = O.OMlp(CRITIC, ACTS).init_glorot(1, 1)
+    oa.adam_init(float(np.float32(3e-4))); oc.adam_init(float(np.float32(3e-4)))
+    extras = ["return", "logprob", "advantage"]
+    ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, N_ENVS * Ts, extras)
+    oe = O.OEnv("cartpole", N_ENVS, MAX_STEPS, GAMMA, 0)
+    t0 = time.perf_counter()
+    oe.rollout(oa, parity.rollout_cfg(), ob, Ts)
+    O.chk(O.lib().orc_fill_gae(ob.h, oc.h, LAM, GAMMA)); O.chk(O.lib().orc_fill_returns(ob.h, GAMMA)); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
+    t_roll = time.perf_counter() - t0
+    n_mb = 192
+    info = np.zeros(L.INFO_N, np.float32)
+    t0 = time.perf_counter()
+    for loss, head, net in (("ppo", "categorical", oa), ("value_mse", "deterministic", oc)):
+        cfg = parity.train_cfg(loss, head, BATCH, 6, -1.0, 7, 0, max_batches=n_mb)
+        O.chk(O.lib().orc_batch_train(net.h, ob.h, C.byref(cfg), None, O.vpz(info), None))
+    t_train = time.perf_counter() - t0
+    per_env_step = t_roll / (N_ENVS * Ts)
+    per_grad_step = t_train / (2 * n_mb)
+    t_iter = per_env_step * N_ENVS * T + per_grad_step * 2 * EPOCHS * (N_ENVS * T // BATCH)
+    return {"value": N_ENVS * T / t_iter, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "oracle/ (C restatement of Crux.jl, 1 thread): 32x%d-step rollout+GAE (%.2fs) and %d Adam steps at B=128 (%.2fs), extrapolated to one 65536-transition / 81920-step iteration"
+                      % (Ts, t_roll, 2 * n_mb, t_train),
+            "grad_steps_per_s": 1.0 / per_grad_step, "rollout_env_steps_per_s": 1.0 / per_env_step}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--early-stop", action="store_true", help="also time the KL-early-stopping variant (target_kl=0.012)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import crux_jl_amd as crux
+    from crux_jl_amd import dist as cdist
+    ctx = crux.Context(local)
+    crux.set_default_context(ctx)
+    pi, buf, sampler = build_problem(crux, cdist.shard_seed(0, rank))
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+    a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=BATCH, epochs=EPOCHS, target_kl=None, name="actor_", shuffle_seed=100 + rank)
+    c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=BATCH, epochs=EPOCHS, name="critic_", shuffle_seed=200 + rank)
+
+    sync = None
+    if world > 1:
+        wrapped = {}
+
+        def sync(net):   # average parameters and Adam moments across ranks (RCCL all-reduce over xGMI)
+            if id(net) not in wrapped:
+                lib, n = ctx.lib, net.n_params
+
+                def wrap(ptr):
+                    class _I:
+                        __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+                    return torch.as_tensor(_I(), device="cuda:%d" % local)
+                wrapped[id(net)] = wrap(lib.crux_mlp_params_ptr(net.h))
+            ctx.sync()
+            t = wrapped[id(net)]
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.mul_(1.0 / world)
+            torch.cuda.current_stream().synchronize()
+
+    def barrier():
+        ctx.sync()
+        if world > 1:
+            dist.barrier(); torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        ppo_iteration(crux, pi, buf, sampler, a_opt, c_opt, P, it, sync); it += 1
+    barrier()
+    ctx.prof_reset(); ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    grad_steps = 0
+    for _ in range(args.steps):
+        nb, info = ppo_iteration(crux, pi, buf, sampler, a_opt, c_opt, P, it, sync); it += 1
+        grad_steps += nb
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dt = float(tmax.item())
+        gs = torch.tensor([grad_steps], dtype=torch.float64, device="cuda"); dist.all_reduce(gs); grad_steps = int(gs.item())
+
+    prof = {k: ctx.prof_get(k) for k in ("rollout", "values", "gae", "whiten", "train_actor", "train_critic")}
+    early = None
+    if args.early_stop and world == 1:
+        a_es = crux.TrainingParams(loss=crux.ppo_loss, batch_size=BATCH, epochs=EPOCHS, target_kl=0.012, name="actor_", shuffle_seed=300)
+        ctx.sync(); t1 = time.perf_counter(); nbs = 0
+        for _ in range(args.steps):
+            nb, _i = ppo_iteration(crux, pi, buf, sampler, a_es, c_opt, P, it); it += 1; nbs += nb
+        ctx.sync(); d1 = time.perf_counter() - t1
+        early = {"env_steps_per_s": args.steps * N_ENVS * T / d1, "grad_steps_per_s": nbs / d1, "grad_steps_per_iter": nbs / args.steps}
+
+    if rank == 0:
+        env_steps = args.steps * N_ENVS * T * world
+        ms_actor, n_actor = prof["train_actor"]
+        launches_per_iter = max(1, n_actor // max(1, args.steps))
+        steps_per_launch = EPOCHS * (N_ENVS * T // BATCH) / launches_per_iter
+        avg_launch_s = (ms_actor / max(1, n_actor)) * 1e-3
+        achieved = FLOP_ACTOR_STEP * steps_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec + grad-steps/sec, PPO 2048x32 rollout",
+            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PPO CartPole-v1 (device dynamics), DiscreteNetwork 4-64-64-2 + critic 4-64-64-1, 32 envs x 2048-step rollout per GPU, "
+                                   "batch 128, 80 epochs actor + 80 epochs critic (81920 Adam steps/iter, KL early-stop off), Adam 3e-4",
+                       "envs_per_gpu": N_ENVS, "rollout_T": T, "batch_size": BATCH, "epochs": EPOCHS,
+                       "parallelism": "env-shards x%d, per-epoch parameter all-reduce" % world if world > 1 else "single GPU"},
+            "grad_steps_per_s": grad_steps / dt,
+            "phase_ms_per_iter": {k: v[0] / args.steps for k, v in prof.items()},
+            "rollout_env_steps_per_s": (N_ENVS * T * args.steps) / (prof["rollout"][0] * 1e-3) if prof["rollout"][0] > 0 else None,
+            "roofline": {"kernel": "batch_train! actor (persistent fwd+ppo_loss+bwd+Adam)", "bound": "mfma", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_launch_s * 1e3, "grad_steps_per_launch": steps_per_launch,
+                         "us_per_grad_step": avg_launch_s * 1e6 / steps_per_launch if steps_per_launch else None,
+                         "note": "one workgroup on one CU by construction (81920 serially dependent 3.4-MFLOP steps); per-CU f32 MFMA peak is 0.614 TFLOP/s"},
+        }
+        if early:
+            out["early_stop"] = early
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,530 @@
-// train_mfma.hip -- MFMA learner / value kernels for the 64-wide MLP family (placeholder until the kernel lands).
+// train_mfma.hip -- persistent batch_train! / train! kernel for the IN->64->64->OUT MLP family on gfx950 f32 MFMA.
+//
+// Reference semantics: src/training.jl:13-55 (train!, batch_train!), src/model_free/rl/ppo.jl:4-21,59-60, Flux Adam.
+// One workgroup (4 waves, one per SIMD, up to 512 VGPRs each) runs the whole epochs x minibatches loop. HBM is touched
+// only for the minibatch rows (gathered through the composed shuffle order and prefetched one step ahead) and for one
+// info row per epoch; parameters, Adam moments, activations and gradients stay in registers / LDS.
+//
+// All GEMMs use v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fma chain). Lane l: c = l&15, g = l>>4.
+//   A operand: lane holds A[i=c][k=g];  B operand: B[k=g][j=c];  C/D reg r: D[row=4g+r][col=c].
+//
+// Forward/backward chain is data-parallel over waves: wave w owns samples [32w, 32w+32) as two 16-column tiles.
+// Orientation trick (no LDS round trip between layers): a layer output computed as D[feature][sample] ("C orientation")
+// holds, in reg r of tile m, the element [feature 16m+4g+r][sample c]. Used as a B operand this is B[k=g][j=c] with the
+// contraction index PERMUTED to feature 16m+4g+r, which is legal because the weight fragment (A operand) is fetched from
+// LDS in the same permuted order. Used as an A operand it is A[i=c -> sample][k=g -> feature] and produces the next
+// result in "R orientation" D[sample][feature] (used for dH1).
+//   forward (C):  H1 = act(W1 X + b1); H2 = act(W2 H1 + b2)                     [MFMA, B operand = previous D registers]
+//   layer 3, loss head, dZ2 = act'(H2) .* (W3^T dz), dW3, db3                     [VALU: OUT <= 16 would waste an MFMA tile]
+//   dH1 (R) = dZ2 (C regs as A) x W2 ; dZ1 (R) = act'(H1 R) .* dH1                 [MFMA]
+//   dW1, db1, db2 partial over the wave's 32 samples                              [MFMA / VALU] -> small per-wave partials
+// Weight gradient of the 64x64 layer is model-parallel over waves: H1 and dZ2 are exchanged as [feature][sample] tiles
+// in LDS, then wave w computes rows [16w,16w+16) of dW2 over ALL 128 samples (A = dZ2 tile rows, B = H1 tiles) and
+// applies Adam to those rows in registers -- theta, m, v of W2 (89 % of the parameters) never leave the owning wave's
+// VGPRs; only the updated theta is republished to the LDS masters the next forward pass reads.
 #include "train_args.h"
 
-int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled) { (void)c; (void)a; *handled = false; return CRUX_OK; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MF_HID 64
+#define MF_LD 68            // padded row stride (floats) of the 64x64 LDS masters (16-B aligned rows)
+#define MF_TLD 36           // row stride of the exchange tiles [64 features][32 samples + 4 pad]
+#define EPS32F 1.1920928955078125e-07f
+
+enum { MFK_CATEGORICAL = 0, MFK_GAUSSIAN = 1, MFK_VALUE = 2 };
+
+__device__ __forceinline__ void wave_sync() {   // order LDS traffic between the lanes of ONE wave (LDS is in-order per wave)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes that share g; every lane gets the sum
+  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+  return v;
+}
+__device__ __forceinline__ float g4_sum(float v) {      // sum over the 4 lanes that share c (one per g)
+  v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+  return v;
+}
+template <int ACT> __device__ __forceinline__ float actf(float z) { return ACT == CRUX_ACT_RELU ? fmaxf(z, 0.f) : (ACT == CRUX_ACT_TANH ? tanhf(z) : z); }
+template <int ACT> __device__ __forceinline__ float actg(float y, float d) { return ACT == CRUX_ACT_RELU ? (y > 0.f ? d : 0.f) : (ACT == CRUX_ACT_TANH ? d * (1.f - y * y) : d); }
+
+// Adam on one element with f32 arithmetic; c1 = 1/(1-b1^t), c2 = 1/(1-b2^t) come from Float64 (Flux keeps Float64 scalars;
+// the f32 evaluation differs from the reference's per-element Float64 evaluation by < 1e-7 relative in the step).
+struct AdamK { float b1, b2, omb1, omb2, eps, eta, c1, c2; };
+__device__ __forceinline__ float adam1(float g, float& m, float& v, const AdamK& k) {
+  m = k.b1 * m + k.omb1 * g; v = k.b2 * v + (k.omb2 * g) * g;
+  return (m * k.c1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * k.c2) + k.eps) * k.eta;
+}
+
+template <int IN, int OUT>
+struct MfLayout {
+  static constexpr int KS0 = (IN + 3) / 4;          // k-steps of layer 1
+  static constexpr int IP = KS0 * 4;                // padded input width
+  static constexpr int JT = (IN + 15) / 16;         // 16-column tiles of dW1
+  static constexpr int XP = IP + 1;                 // staging row stride
+  static constexpr int SCW = 4 + (OUT > 4 ? OUT : 4);
+  // "small" parameters = everything except W2; index space s in [0, NS)
+  static constexpr int sW1 = 0, sB1 = MF_HID * IN, sB2 = sB1 + MF_HID, sW3 = sB2 + MF_HID, sB3 = sW3 + MF_HID * OUT, sEX = sB3 + OUT, NS = sEX + 16;
+  // canonical (Flux.params) offsets
+  static constexpr int cW1 = 0, cB1 = MF_HID * IN, cW2 = cB1 + MF_HID, cB2 = cW2 + MF_HID * MF_HID, cW3 = cB2 + MF_HID, cB3 = cW3 + MF_HID * OUT, cEX = cB3 + OUT;
+  // LDS masters
+  static constexpr int oW2R = 0;                              // W2R[o][i]
+  static constexpr int oW2C = oW2R + MF_HID * MF_LD;          // W2C[i][o]
+  static constexpr int oW1R = oW2C + MF_HID * MF_LD;          // W1R[o][i<IP]
+  static constexpr int oB1 = oW1R + MF_HID * IP;
+  static constexpr int oB2 = oB1 + MF_HID;
+  static constexpr int oW3R = oB2 + MF_HID;                   // W3R[o][i]
+  static constexpr int oB3 = oW3R + OUT * MF_HID;
+  static constexpr int oEX = oB3 + 16;
+  static constexpr int oMS = ((oEX + 16 + 3) / 4) * 4;        // Adam moments of the small parameters
+  static constexpr int oVS = oMS + ((NS + 3) / 4) * 4;
+  // exchange tiles, one pair per wave
+  static constexpr int oT1 = oVS + ((NS + 3) / 4) * 4;        // H1  [f][s]
+  static constexpr int oT2 = oT1 + 4 * MF_HID * MF_TLD;       // dZ2 [f][s]
+  // per-wave small partial gradients
+  static constexpr int pW1 = 0;                               // [i < 16*JT][o] stride MF_LD
+  static constexpr int pB1 = pW1 + 16 * JT * MF_LD;
+  static constexpr int pB2 = pB1 + MF_HID;
+  static constexpr int pW3 = pB2 + MF_HID;                    // [o][i]
+  static constexpr int pB3 = pW3 + OUT * MF_HID;
+  static constexpr int pEX = pB3 + 16;
+  static constexpr int pST = pEX + 16;                        // 8 stat sums
+  static constexpr int PART = ((pST + 8 + 3) / 4) * 4;
+  static constexpr int oPART = oT2 + 4 * MF_HID * MF_TLD;
+  static constexpr int oXS = oPART + 4 * PART;                // 4 x [32][XP] minibatch observations
+  static constexpr int oSC = oXS + 4 * 32 * XP;               // 4 x [32][SCW] per-sample scalars
+  static constexpr int oRED = oSC + 4 * 32 * SCW;
+  static constexpr int TOTAL = oRED + 16;
+};
+
+template <int IN, int OUT, int KIND, int ACT>
+__global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
+  using Lt = MfLayout<IN, OUT>;
+  constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS;
+  constexpr int NACT = (OUT > 4 ? OUT : 4);
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
+  float* part = sm + Lt::oPART + w * Lt::PART;
+  float* xs = sm + Lt::oXS + w * 32 * XP;
+  float* sc = sm + Lt::oSC + w * 32 * Lt::SCW;
+  float* T1 = sm + Lt::oT1 + w * MF_HID * MF_TLD;
+  float* T2 = sm + Lt::oT2 + w * MF_HID * MF_TLD;
+  const int n_extra = (KIND == MFK_GAUSSIAN) ? OUT : 0;
+
+  // small-parameter index s -> LDS master slot / canonical flat index / partial slot
+  auto s_master = [&](int s) -> int {
+    if (s < Lt::sB1) { const int o = s & 63, i = s >> 6; return Lt::oW1R + o * IP + i; }
+    if (s < Lt::sB2) return Lt::oB1 + (s - Lt::sB1);
+    if (s < Lt::sW3) return Lt::oB2 + (s - Lt::sB2);
+    if (s < Lt::sB3) { const int t = s - Lt::sW3; const int o = t % OUT, i = t / OUT; return Lt::oW3R + o * MF_HID + i; }
+    if (s < Lt::sEX) return Lt::oB3 + (s - Lt::sB3);
+    return Lt::oEX + (s - Lt::sEX);
+  };
+  auto s_canon = [&](int s) -> int {
+    if (s < Lt::sB1) return Lt::cW1 + s;
+    if (s < Lt::sB2) return Lt::cB1 + (s - Lt::sB1);
+    if (s < Lt::sW3) return Lt::cB2 + (s - Lt::sB2);
+    if (s < Lt::sB3) return Lt::cW3 + (s - Lt::sW3);
+    if (s < Lt::sEX) return Lt::cB3 + (s - Lt::sB3);
+    return Lt::cEX + (s - Lt::sEX);
+  };
+  auto s_part = [&](int s) -> int {
+    if (s < Lt::sB1) { const int o = s & 63, i = s >> 6; return Lt::pW1 + i * MF_LD + o; }
+    if (s < Lt::sB2) return Lt::pB1 + (s - Lt::sB1);
+    if (s < Lt::sW3) return Lt::pB2 + (s - Lt::sB2);
+    if (s < Lt::sB3) { const int t = s - Lt::sW3; const int o = t % OUT, i = t / OUT; return Lt::pW3 + o * MF_HID + i; }
+    if (s < Lt::sEX) return Lt::pB3 + (s - Lt::sB3);
+    return Lt::pEX + (s - Lt::sEX);
+  };
+  const int ns_valid = Lt::sEX + n_extra;
+
+  // ---- load parameters and Adam state --------------------------------------------------------------------------
+  for (int q = tid; q < MF_HID * MF_HID; q += 256) { const int o = q & 63, i = q >> 6; const float v = a.p[Lt::cW2 + q];
+    sm[Lt::oW2R + o * MF_LD + i] = v; sm[Lt::oW2C + i * MF_LD + o] = v; }
+  for (int q = tid; q < MF_HID * IP; q += 256) sm[Lt::oW1R + q] = 0.f;
+  if (tid < 16) { sm[Lt::oB3 + tid] = 0.f; sm[Lt::oEX + tid] = 0.f; }
+  __syncthreads();
+  for (int s = tid; s < NS; s += 256) { const bool in = s < ns_valid; const int pc = s_canon(s);
+    if (in) sm[s_master(s)] = a.p[pc];
+    sm[Lt::oMS + s] = in ? a.m[pc] : 0.f; sm[Lt::oVS + s] = in ? a.v[pc] : 0.f; }
+  for (int q = tid; q < 4 * 32 * XP; q += 256) sm[Lt::oXS + q] = 0.f;
+  // W2 rows owned by this wave, D layout of tile (w, m): reg r <-> W2[o = 16w+4g+r][i = 16m+c]
+  f32x4 tW2[4], mW2[4], vW2[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * w + 4 * g + r) + MF_HID * (16 * m + c);
+      tW2[m][r] = a.p[pc]; mW2[m][r] = a.m[pc]; vW2[m][r] = a.v[pc]; }
+  double bp1 = a.bp[0], bp2 = a.bp[1];
+  const float lo = 1.f - a.eps_clip, hi = 1.f + a.eps_clip;
+  AdamK ak; ak.b1 = (float)a.b1; ak.b2 = (float)a.b2; ak.omb1 = (float)(1.0 - a.b1); ak.omb2 = (float)(1.0 - a.b2); ak.eps = (float)a.eps; ak.eta = (float)a.eta;
+
+  int32_t* order_cur = a.order_a; int32_t* order_nxt = a.order_b;
+  long long total_batches = 0; int epochs_run = 0, err = 0; bool stop = false;
+  float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
+  const int n_epochs = a.ids ? 1 : a.epochs;
+  if (!a.ids) { for (int64_t j = tid; j < a.len; j += 256) order_cur[j] = (int32_t)j; }
+  __syncthreads();
+  const int64_t total_rows = a.ids ? a.n_ids : a.len;
+
+  // ---- minibatch prefetch (HBM/L2 -> registers) and staging (registers -> this wave's LDS tiles) ----------------
+  constexpr int NXL = (32 * IN + 63) / 64;
+  float px[NXL]; float p_lp = 0.f, p_adv = 0.f, p_ret = 0.f; float p_act[NACT]; int p_valid = 0;
+#pragma unroll
+  for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
+  auto prefetch = [&](const int32_t* ord, int64_t st, int nb) {
+    const int sidx = 32 * w + (lane & 31);
+    const bool valid = sidx < nb;
+    const int64_t row = valid ? (a.ids ? (int64_t)a.ids[st + sidx] : (int64_t)ord[st + sidx]) : 0;
+    p_valid = valid ? 1 : 0;
+    const int rowlo = (int)row;
+#pragma unroll
+    for (int e = 0; e < NXL; ++e) {
+      const int el = lane + 64 * e; const int s = el / IN, f = el - s * IN;
+      const int rs = __shfl(rowlo, s & 31, 64); const int vs = __shfl(p_valid, s & 31, 64);
+      px[e] = (el < 32 * IN && vs) ? a.S[(int64_t)rs * IN + f] : 0.f;
+    }
+    p_lp = 0.f; p_adv = 0.f; p_ret = 0.f;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
+    if (lane < 32 && valid) {
+      if (KIND != MFK_VALUE) { p_lp = a.LP[row]; p_adv = a.ADV[row]; }
+      p_ret = a.RET ? a.RET[row] : 0.f;
+      if (KIND == MFK_CATEGORICAL) { const uint8_t* av = (const uint8_t*)a.A + row * OUT; int ai = 0;
+#pragma unroll
+        for (int k = 0; k < OUT; ++k) ai = av[k] ? k : ai;
+        p_act[0] = (float)ai; }
+      if (KIND == MFK_GAUSSIAN) { const float* av = (const float*)a.A + row * OUT;
+#pragma unroll
+        for (int k = 0; k < OUT; ++k) p_act[k] = av[k]; }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int e = 0; e < NXL; ++e) { const int el = lane + 64 * e; const int s = el / IN, f = el - s * IN; if (el < 32 * IN) xs[s * XP + f] = px[e]; }
+    if (lane < 32) { float* q = sc + lane * Lt::SCW; q[0] = (float)p_valid; q[1] = p_lp; q[2] = p_adv; q[3] = p_ret;
+#pragma unroll
+      for (int k = 0; k < NACT; ++k) q[4 + k] = p_act[k]; }
+    wave_sync();
+  };
+
+  for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
+    if (!a.ids) {   // shuffle!(D) as an index composition (experience_buffer.jl:118-124)
+      if (a.perms) { for (int64_t j = tid; j < a.len; j += 256) order_nxt[j] = order_cur[a.perms[(int64_t)ep * a.len + j]]; }
+      else { const crux_perm pp = crux_perm_make(a.shuffle_seed, a.shuffle_counter + (uint64_t)ep, 0, (uint32_t)a.len);
+        for (int64_t j = tid; j < a.len; j += 256) order_nxt[j] = order_cur[crux_perm_at(&pp, (uint32_t)j)]; }
+      __syncthreads();
+      int32_t* t = order_cur; order_cur = order_nxt; order_nxt = t;
+    }
+    { const int nb0 = (int)(total_rows < a.bs ? total_rows : a.bs); prefetch(order_cur, 0, nb0); }
+    for (int64_t st = 0; st < total_rows; st += a.bs) {
+      const int nb = (int)((total_rows - st) < a.bs ? (total_rows - st) : a.bs);
+      const float invB = 1.0f / (float)nb;
+      stage();
+      { const int64_t st2 = st + a.bs; if (st2 < total_rows) { const int nb2 = (int)((total_rows - st2) < a.bs ? (total_rows - st2) : a.bs); prefetch(order_cur, st2, nb2); } }
+
+      // ======================= forward, C orientation =======================
+      float xB[2][KS0], a1[4][KS0];
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) xB[n][ks] = xs[(16 * n + c) * XP + 4 * ks + g];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) a1[m][ks] = sm[Lt::oW1R + (16 * m + c) * IP + 4 * ks + g];
+      f32x4 h1[4][2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { const f32x4 b = *(const f32x4*)&sm[Lt::oB1 + 16 * m + 4 * g];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { f32x4 acc = b;
+#pragma unroll
+          for (int ks = 0; ks < KS0; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[m][ks], xB[n][ks], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = actf<ACT>(acc[r]);
+          h1[m][n] = acc; } }
+      // publish H1 as a [feature][sample] tile (read by every wave for dW2, and by this wave as H1 in R orientation)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T1[(16 * m + 4 * g + r) * MF_TLD + 16 * n + c] = h1[m][n][r];
+      f32x4 h2[4][2];
+#pragma unroll
+      for (int mp = 0; mp < 4; ++mp) { const f32x4 b = *(const f32x4*)&sm[Lt::oB2 + 16 * mp + 4 * g];
+        f32x4 acc0 = b, acc1 = b;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { const f32x4 wv = *(const f32x4*)&sm[Lt::oW2R + (16 * mp + c) * MF_LD + 16 * m + 4 * g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[r], h1[m][0][r], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[r], h1[m][1][r], acc1, 0, 0, 0); } }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc0[r] = actf<ACT>(acc0[r]); acc1[r] = actf<ACT>(acc1[r]); }
+        h2[mp][0] = acc0; h2[mp][1] = acc1; }
+
+      // ======================= layer 3 (VALU) + loss head =======================
+      f32x4 w3[OUT][4];
+#pragma unroll
+      for (int o = 0; o < OUT; ++o)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) w3[o][m] = *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 16 * m + 4 * g];
+      float z[OUT][2];
+#pragma unroll
+      for (int o = 0; o < OUT; ++o)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { float acc = 0.f;
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = fmaf(w3[o][m][r], h2[m][n][r], acc);
+          z[o][n] = g4_sum(acc) + sm[Lt::oB3 + o]; }
+      float dz[OUT][2], dex[OUT][2];
+      float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const float* q = sc + (16 * n + c) * Lt::SCW;
+        const bool valid = q[0] != 0.f; const float oldlp = q[1], A = q[2], R = q[3];
+        const float cnt = (valid && g == 0) ? 1.f : 0.f;    // every sample is replicated in the 4 g-groups: count it once
+#pragma unroll
+        for (int k = 0; k < OUT; ++k) dex[k][n] = 0.f;
+        if (KIND == MFK_VALUE) {
+          const float d = z[0][n] - R; dz[0][n] = valid ? 2.f * d * invB : 0.f; s_sq += cnt * d * d; s_ret += cnt * R;
+        } else if (KIND == MFK_CATEGORICAL) {
+          const int ai = (int)q[4];
+          float mx = z[0][n];
+#pragma unroll
+          for (int k = 1; k < OUT; ++k) mx = fmaxf(mx, z[k][n]);
+          float pk[OUT], hk[OUT]; float sum = 0.f;
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) { pk[k] = expf(z[k][n] - mx); sum += pk[k]; }
+          const float inv = 1.f / sum; float pa = 0.f, H = 0.f, hp = 0.f;
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) { pk[k] *= inv; pa = (k == ai) ? pk[k] : pa; const float lg = logf(pk[k] + EPS32F); H -= pk[k] * lg;
+            hk[k] = -lg - pk[k] / (pk[k] + EPS32F); hp += hk[k] * pk[k]; }
+          const float newlp = logf(pa); const float r = expf(newlp - oldlp);
+          const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) { const float dlogpi = ((k == ai) ? 1.f : 0.f) - pk[k];
+            dz[k][n] = valid ? invB * (-a.lambda_p * gsel * r * dlogpi - a.lambda_e * (pk[k] * (hk[k] - hp))) : 0.f; }
+          s_lossp += cnt * fminf(u, cl); s_H += cnt * H; s_kl += cnt * (oldlp - newlp); s_adv += cnt * A; s_ret += cnt * R;
+          s_clip += cnt * ((r > hi || r < lo) ? 1.f : 0.f);
+        } else {   // gaussian with constant log-std (policies.jl:333-348)
+          float newlp = 0.f; float dd[OUT], s2[OUT];
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) { const float ls = sm[Lt::oEX + k]; const float sg = expf(ls); s2[k] = sg * sg; dd[k] = q[4 + k] - z[k][n];
+            newlp += (-(dd[k] * dd[k]) / (2.f * s2[k]) - 0.9189385332046727f - ls); }
+          const float r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) { dz[k][n] = valid ? invB * (-a.lambda_p * gsel * r * (dd[k] / s2[k])) : 0.f;
+            dex[k][n] = valid ? invB * (-a.lambda_p * gsel * r * ((dd[k] * dd[k]) / s2[k] - 1.f)) : 0.f; }
+          s_lossp += cnt * fminf(u, cl); s_kl += cnt * (oldlp - newlp); s_adv += cnt * A; s_ret += cnt * R; s_clip += cnt * ((r > hi || r < lo) ? 1.f : 0.f);
+        }
+      }
+
+      // ======================= backward, own samples =======================
+      // dW3 partial (per lane: its sample pair) and dZ2 (C) = act'(H2) .* (W3^T dz), overwriting h2
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y0 = h2[m][0][r], y1 = h2[m][1][r];
+          float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+          for (int o = 0; o < OUT; ++o) {
+            const float gw = row16_sum(fmaf(dz[o][0], y0, dz[o][1] * y1));     // sum over this wave's samples (16 lanes x 2 tiles)
+            if (c == 0) part[Lt::pW3 + o * MF_HID + 16 * m + 4 * g + r] = gw;
+            d0 = fmaf(w3[o][m][r], dz[o][0], d0); d1 = fmaf(w3[o][m][r], dz[o][1], d1);
+          }
+          h2[m][0][r] = actg<ACT>(y0, d0); h2[m][1][r] = actg<ACT>(y1, d1);
+        }
+      // db3 / logSigma partials / stats: one representative group (g == 0 counted once via cnt; dz is identical in all g)
+#pragma unroll
+      for (int o = 0; o < OUT; ++o) { const float sb = row16_sum(dz[o][0] + dz[o][1]); if (lane == 0) part[Lt::pB3 + o] = sb;
+        if (KIND == MFK_GAUSSIAN) { const float se = row16_sum(dex[o][0] + dex[o][1]); if (lane == 0) part[Lt::pEX + o] = se; } }
+      { float sv[7] = {s_lossp, s_H, s_kl, s_adv, s_ret, s_clip, s_sq};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { const float t = row16_sum(sv[k]); if (lane == 0) part[Lt::pST + k] = t; } }
+      // publish dZ2 tile
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T2[(16 * m + 4 * g + r) * MF_TLD + 16 * n + c] = h2[m][n][r];
+      // dH1 (R) = dZ2 (C regs as A: [i=c -> sample][k -> f' = 16m'+4g+r]) x W2 (B: W2[f'][f = 16m+c] = W2C[f][f'])
+      f32x4 dz1r[2][4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mp = 0; mp < 4; ++mp) { const f32x4 wv = *(const f32x4*)&sm[Lt::oW2C + (16 * m + c) * MF_LD + 16 * mp + 4 * g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[mp][0][r], wv[r], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[mp][1][r], wv[r], acc1, 0, 0, 0); } }
+        dz1r[0][m] = acc0; dz1r[1][m] = acc1; }
+      wave_sync();   // own T1/T2 tiles are complete for this wave's reads
+      // dZ1 (R) = act'(H1 R) .* dH1 (R);  H1 (R)[sample 16n+4g+r'][f = 16m+c] comes from this wave's T1 tile
+      float gb1[4], gb2[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { float sb1 = 0.f, sb2 = 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { const f32x4 h1r = *(const f32x4*)&T1[(16 * m + c) * MF_TLD + 16 * n + 4 * g];
+          const f32x4 d2 = *(const f32x4*)&T2[(16 * m + c) * MF_TLD + 16 * n + 4 * g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float d = actg<ACT>(h1r[r], dz1r[n][m][r]); dz1r[n][m][r] = d; sb1 += d; sb2 += d2[r]; } }
+        gb1[m] = g4_sum(sb1); gb2[m] = g4_sum(sb2); }
+      if (g == 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { part[Lt::pB1 + 16 * m + c] = gb1[m]; part[Lt::pB2 + 16 * m + c] = gb2[m]; } }
+      // dW1 partial over this wave's samples: A = dZ1 (R) [i=c -> o=16m+c][k -> sample], B = X (R) [k -> sample][j=c -> input 16jt+c]
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt) {
+        float xR[2][4];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xR[n][r] = (16 * jt + c < IP) ? xs[(16 * n + 4 * g + r) * XP + 16 * jt + c] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1r[n][m][r], xR[n][r], acc, 0, 0, 0);
+          *(f32x4*)&part[Lt::pW1 + (16 * jt + c) * MF_LD + 16 * m + 4 * g] = acc; }   // D reg r <-> [o=16m+4g+r][i=16jt+c]
+      }
+      __syncthreads();   // ---- B_a: all tiles and small partials are visible
+
+      // ======================= dW2 rows [16w,16w+16) over all samples =======================
+      f32x4 gW2[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) gW2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ws = 0; ws < 4; ++ws)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const float* t2 = sm + Lt::oT2 + ws * MF_HID * MF_TLD; const float* t1 = sm + Lt::oT1 + ws * MF_HID * MF_TLD;
+          const f32x4 av = *(const f32x4*)&t2[(16 * w + c) * MF_TLD + 16 * n + 4 * g];       // A[i=c -> o=16w+c][k -> sample 16n+4g+r']
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { const f32x4 bv = *(const f32x4*)&t1[(16 * m + c) * MF_TLD + 16 * n + 4 * g];   // B[k -> sample][j=c -> i=16m+c]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gW2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], gW2[m], 0, 0, 0); }
+        }
+      // small parameters: reduce the 4 per-wave partials; collect sum of squares and the NaN flag
+      constexpr int NSI = (NS + 255) / 256;
+      float gs[NSI]; float ssq = 0.f; int bad = 0;
+#pragma unroll
+      for (int k = 0; k < NSI; ++k) { const int s = tid + 256 * k; float gsum = 0.f;
+        if (s < ns_valid) { const int po = s_part(s);
+          gsum = ((sm[Lt::oPART + po] + sm[Lt::oPART + Lt::PART + po]) + sm[Lt::oPART + 2 * Lt::PART + po]) + sm[Lt::oPART + 3 * Lt::PART + po];
+          if (KIND == MFK_GAUSSIAN && s >= Lt::sEX) gsum += -a.lambda_e;     // d(-lambda_e * H)/dlogSigma, H = 1.4189 + sum(logSigma)
+          ssq += gsum * gsum; bad |= isnan(gsum) ? 1 : 0; }
+        gs[k] = gsum; }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssq += gW2[m][r] * gW2[m][r]; bad |= isnan(gW2[m][r]) ? 1 : 0; }
+      ssq = wave_sum(ssq);
+      if (lane == 0) sm[Lt::oRED + w] = ssq;
+      const int any_bad = __syncthreads_or(bad);   // ---- B_or (also publishes RED)
+      // minibatch info (training.jl:22-23, ppo.jl:13-19); identical in every thread
+      { float t[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) t[k] = ((sm[Lt::oPART + Lt::pST + k] + sm[Lt::oPART + Lt::PART + Lt::pST + k]) + sm[Lt::oPART + 2 * Lt::PART + Lt::pST + k]) + sm[Lt::oPART + 3 * Lt::PART + Lt::pST + k];
+        const float fn = (float)nb;
+        inf_gn = sqrtf(((sm[Lt::oRED] + sm[Lt::oRED + 1]) + sm[Lt::oRED + 2]) + sm[Lt::oRED + 3]);
+        if (KIND == MFK_VALUE) { inf_loss = t[6] / fn; inf_ret = t[4] / fn; }
+        else { const float p_loss = -(t[0] / fn); float entropy;
+          if (KIND == MFK_CATEGORICAL) entropy = t[1] / fn;
+          else { entropy = 1.4189385332046727f;
+#pragma unroll
+            for (int k = 0; k < OUT; ++k) entropy += sm[Lt::oEX + k]; }
+          inf_ent = entropy; inf_loss = a.lambda_p * p_loss + a.lambda_e * (-entropy); inf_kl = t[2] / fn; inf_adv = t[3] / fn; inf_ret = t[4] / fn; inf_clip = t[5] / fn; }
+      }
+      if (any_bad) { inf_gn = NAN; err = CRUX_ENAN; break; }                   // training.jl:20: no update
+      // ======================= Adam (Flux.update!, training.jl:21) =======================
+      if (a.apply) {
+        ak.c1 = (float)(1.0 / (1.0 - bp1)); ak.c2 = (float)(1.0 / (1.0 - bp2));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { float mm = mW2[m][r], vv = vW2[m][r]; const float d = adam1(gW2[m][r], mm, vv, ak);
+            mW2[m][r] = mm; vW2[m][r] = vv; tW2[m][r] -= d;
+            sm[Lt::oW2R + (16 * w + 4 * g + r) * MF_LD + 16 * m + c] = tW2[m][r]; }
+          *(f32x4*)&sm[Lt::oW2C + (16 * m + c) * MF_LD + 16 * w + 4 * g] = tW2[m]; }
+#pragma unroll
+        for (int k = 0; k < NSI; ++k) { const int s = tid + 256 * k;
+          if (s < ns_valid) { float mm = sm[Lt::oMS + s], vv = sm[Lt::oVS + s]; const float d = adam1(gs[k], mm, vv, ak);
+            sm[Lt::oMS + s] = mm; sm[Lt::oVS + s] = vv; const int mo = s_master(s); sm[mo] = sm[mo] - d; } }
+        bp1 *= a.b1; bp2 *= a.b2;
+      } else {   // gradient-only mode (crux_loss_grad): export the flat gradient
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a.g[Lt::cW2 + (16 * w + 4 * g + r) + MF_HID * (16 * m + c)] = gW2[m][r];
+#pragma unroll
+        for (int k = 0; k < NSI; ++k) { const int s = tid + 256 * k; if (s < ns_valid) a.g[s_canon(s)] = gs[k]; }
+      }
+      __syncthreads();   // ---- B_b: masters updated; tiles and partials may be overwritten
+      total_batches += 1;
+      if (a.max_batches > 0 && total_batches >= a.max_batches) break;          // training.jl:45
+      if (a.target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > a.target_kl) break;   // :46
+    }
+    if (err) break;
+    if (tid == 0 && a.epoch_infos) { float* e = a.epoch_infos + (size_t)ep * CRUX_INFO_N;   // aggregate_info(minibatch_infos) == last minibatch (Q3)
+      for (int k = 0; k < CRUX_INFO_N; ++k) e[k] = 0.f;
+      e[CRUX_INFO_LOSS] = inf_loss; e[CRUX_INFO_GRAD_NORM] = inf_gn;
+      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = inf_ent; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = inf_clip; e[CRUX_INFO_AVG_ADVANTAGE] = inf_adv; e[CRUX_INFO_AVG_RETURN] = inf_ret; } }
+    epochs_run += 1;
+    if (a.target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > a.target_kl) stop = true;   // :49
+    if (a.max_batches > 0 && total_batches >= a.max_batches) stop = true;               // :50
+  }
+  // ---- write back parameters and Adam state --------------------------------------------------------------------
+  __syncthreads();
+  if (a.apply) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * w + 4 * g + r) + MF_HID * (16 * m + c);
+        a.p[pc] = tW2[m][r]; a.m[pc] = mW2[m][r]; a.v[pc] = vW2[m][r]; }
+    for (int s = tid; s < ns_valid; s += 256) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; }
+  }
+  if (tid == 0) {
+    a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
+    a.bp[0] = bp1; a.bp[1] = bp2;
+    if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = inf_loss; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
+  }
+}
+
+// ---- dispatch ---------------------------------------------------------------------------------------------------
+template <int IN, int OUT, int KIND, int ACT>
+static int32_t launch_one(crux_ctx* c, const TrainArgs& a) {
+  using Lt = MfLayout<IN, OUT>;
+  constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
+  static_assert(lds <= 160 * 1024, "LDS budget exceeded");
+  static bool attr = false;
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<IN, OUT, KIND, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_train_mfma<IN, OUT, KIND, ACT>), dim3(1), dim3(256), lds, c->stream, a);
+  return crux_launch_check(c, "k_train_mfma");
+}
+
+int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled) {
+  *handled = false;
+  const NetDesc& nd = a.nd;
+  if (getenv("CRUX_FORCE_GENERIC")) return CRUX_OK;
+  if (nd.L != 3 || nd.dims[1] != MF_HID || nd.dims[2] != MF_HID || nd.acts[2] != CRUX_ACT_IDENTITY || nd.acts[0] != nd.acts[1]) return CRUX_OK;
+  if (a.bs > 128 || a.loss == CRUX_LOSS_TD_INTERNAL) return CRUX_OK;
+  if (a.ids && a.n_ids > 128) return CRUX_OK;
+  const int in = nd.dims[0], out = nd.dims[3], act = nd.acts[0];
+  int kind;
+  if (a.loss == CRUX_LOSS_VALUE_MSE) kind = MFK_VALUE;
+  else if (a.head == CRUX_HEAD_CATEGORICAL) kind = MFK_CATEGORICAL;
+  else if (a.head == CRUX_HEAD_GAUSSIAN) kind = MFK_GAUSSIAN;
+  else return CRUX_OK;
+#define MF_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_one<I, O, K, A_>(c, a); }
+  MF_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)
+  MF_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)
+#undef MF_CASE
+  return CRUX_OK;
+}
+
 int32_t crux_values_fast(crux_mlp* net, const float* d_x, int64_t B, float* d_y) { (void)net; (void)d_x; (void)B; (void)d_y; return CRUX_EUNSUP; }
