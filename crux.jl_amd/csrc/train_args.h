@@ -22,4 +22,5 @@ struct TrainArgs {
   int32_t apply;             // 1: Adam update after each minibatch
   float* epoch_infos;        // device [epochs x CRUX_INFO_N]
   int32_t* status;           // device [4]: err, batches_trained, epochs_run, final order selector
+  unsigned long long* dbg;   // optional phase-timing output (CRUX_MFMA_TIMING)
 };

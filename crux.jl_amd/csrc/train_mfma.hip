@@ -37,13 +37,34 @@ __device__ __forceinline__ void wave_sync() {   // order LDS traffic between the
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes that share g; every lane gets the sum
-  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-  return v;
+// DPP lane exchange inside a 16-lane row (pure VALU, no LDS crossbar): CTRL = row_mirror 0x140 (c <-> 15-c),
+// row_half_mirror 0x141 (c <-> c^7), quad_perm[3,2,1,0] 0x1B (c <-> c^3), quad_perm[1,0,3,2] 0xB1 (c <-> c^1).
+template <int CTRL> __device__ __forceinline__ float dpp_x(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float g4_sum(float v) {      // sum over the 4 lanes that share c (one per g)
-  v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-  return v;
+// Reduce-scatter of 16 per-lane values over the 16 lanes of a row: lane c returns sum over the row of v[c].
+// 15 exchanges instead of 64: after the step on bit b each lane keeps the half of the indices whose bit b equals its own.
+__device__ __forceinline__ float row16_reduce_scatter(const float (&v)[16], int c) {
+  const bool b3 = c & 8, b2 = c & 4, b1 = c & 2, b0 = c & 1;
+  float v8[8], v4[4], v2[2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float snd = b3 ? v[j] : v[j + 8], kp = b3 ? v[j + 8] : v[j]; v8[j] = kp + dpp_x<0x140>(snd); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float snd = b2 ? v8[j] : v8[j + 4], kp = b2 ? v8[j + 4] : v8[j]; v4[j] = kp + dpp_x<0x141>(snd); }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const float snd = b1 ? v4[j] : v4[j + 2], kp = b1 ? v4[j + 2] : v4[j]; v2[j] = kp + dpp_x<0x1B>(snd); }
+  const float snd = b0 ? v2[0] : v2[1], kp = b0 ? v2[1] : v2[0];
+  return kp + dpp_x<0xB1>(snd);
+}
+// Sum over the 4 lanes that share c (one per 16-lane row); every lane gets the total. v_permlane16/32_swap are written as
+// inline asm: the hipcc (ROCm 7.2) builtins return the same register for both results when both inputs are one value.
+// s_nop 1 before = the VALU-write -> permlane-read hazard (2 wait states); the trailing s_nop covers the consumer.
+__device__ __forceinline__ float g4_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  a = a + b; b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
 }
 template <int ACT> __device__ __forceinline__ float actf(float z) { return ACT == CRUX_ACT_RELU ? fmaxf(z, 0.f) : (ACT == CRUX_ACT_TANH ? tanhf(z) : z); }
 template <int ACT> __device__ __forceinline__ float actg(float y, float d) { return ACT == CRUX_ACT_RELU ? (y > 0.f ? d : 0.f) : (ACT == CRUX_ACT_TANH ? d * (1.f - y * y) : d); }
@@ -86,10 +107,9 @@ struct MfLayout {
   static constexpr int pB1 = pW1 + 16 * JT * MF_LD;
   static constexpr int pB2 = pB1 + MF_HID;
   static constexpr int pW3 = pB2 + MF_HID;                    // [o][i]
-  static constexpr int pB3 = pW3 + OUT * MF_HID;
-  static constexpr int pEX = pB3 + 16;
-  static constexpr int pST = pEX + 16;                        // 8 stat sums
-  static constexpr int PART = ((pST + 8 + 3) / 4) * 4;
+  static constexpr int pMISC = pW3 + OUT * MF_HID;            // [48]: 7 stat sums, then db3[OUT], then dlogSigma[OUT]
+  static constexpr int pST = pMISC, pB3 = pMISC + 7, pEX = pB3 + OUT;
+  static constexpr int PART = ((pMISC + 48 + 3) / 4) * 4;
   static constexpr int oPART = oT2 + 4 * MF_HID * MF_TLD;
   static constexpr int oXS = oPART + 4 * PART;                // 4 x [32][XP] minibatch observations
   static constexpr int oSC = oXS + 4 * 32 * XP;               // 4 x [32][SCW] per-sample scalars
@@ -97,7 +117,7 @@ struct MfLayout {
   static constexpr int TOTAL = oRED + 16;
 };
 
-template <int IN, int OUT, int KIND, int ACT>
+template <int IN, int OUT, int KIND, int ACT, bool TIMING = false>
 __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
   using Lt = MfLayout<IN, OUT>;
   constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS;
@@ -110,6 +130,10 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
   float* T1 = sm + Lt::oT1 + w * MF_HID * MF_TLD;
   float* T2 = sm + Lt::oT2 + w * MF_HID * MF_TLD;
   const int n_extra = (KIND == MFK_GAUSSIAN) ? OUT : 0;
+  // optional phase timing (s_memtime, shader cycles): per-wave totals in a.dbg[w*16 + phase]
+  unsigned long long tacc[12]; unsigned long long tlast = 0;
+  if (TIMING) { for (int k = 0; k < 12; ++k) tacc[k] = 0; tlast = __builtin_amdgcn_s_memtime(); }
+#define MF_T(ph) do { if (TIMING) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
 
   // small-parameter index s -> LDS master slot / canonical flat index / partial slot
   auto s_master = [&](int s) -> int {
@@ -137,6 +161,11 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
     return Lt::pEX + (s - Lt::sEX);
   };
   const int ns_valid = Lt::sEX + n_extra;
+  constexpr int NSI = (NS + 255) / 256;
+  int so_part[NSI], so_master[NSI]; bool so_ok[NSI], so_ex[NSI];
+#pragma unroll
+  for (int k = 0; k < NSI; ++k) { const int s = tid + 256 * k; so_ok[k] = s < ns_valid; so_ex[k] = s >= Lt::sEX;
+    so_part[k] = so_ok[k] ? s_part(s) : 0; so_master[k] = so_ok[k] ? s_master(s) : 0; }
 
   // ---- load parameters and Adam state --------------------------------------------------------------------------
   for (int q = tid; q < MF_HID * MF_HID; q += 256) { const int o = q & 63, i = q >> 6; const float v = a.p[Lt::cW2 + q];
@@ -172,12 +201,14 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
   float px[NXL]; float p_lp = 0.f, p_adv = 0.f, p_ret = 0.f; float p_act[NACT]; int p_valid = 0;
 #pragma unroll
   for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
-  auto prefetch = [&](const int32_t* ord, int64_t st, int nb) {
+  int n_row = 0, n_valid = 0;   // row index / validity of this lane's sample in the NEXT-to-be-fetched minibatch
+  auto fetch_index = [&](const int32_t* ord, int64_t st, int nb) {   // issued one step before fetch_data uses it
     const int sidx = 32 * w + (lane & 31);
-    const bool valid = sidx < nb;
-    const int64_t row = valid ? (a.ids ? (int64_t)a.ids[st + sidx] : (int64_t)ord[st + sidx]) : 0;
-    p_valid = valid ? 1 : 0;
-    const int rowlo = (int)row;
+    n_valid = sidx < nb ? 1 : 0;
+    n_row = n_valid ? (a.ids ? a.ids[st + sidx] : ord[st + sidx]) : 0;
+  };
+  auto fetch_data = [&]() {
+    const int rowlo = n_row; p_valid = n_valid; const int64_t row = rowlo;
 #pragma unroll
     for (int e = 0; e < NXL; ++e) {
       const int el = lane + 64 * e; const int s = el / IN, f = el - s * IN;
@@ -187,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
     p_lp = 0.f; p_adv = 0.f; p_ret = 0.f;
 #pragma unroll
     for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
-    if (lane < 32 && valid) {
+    if (lane < 32 && p_valid) {
       if (KIND != MFK_VALUE) { p_lp = a.LP[row]; p_adv = a.ADV[row]; }
       p_ret = a.RET ? a.RET[row] : 0.f;
       if (KIND == MFK_CATEGORICAL) { const uint8_t* av = (const uint8_t*)a.A + row * OUT; int ai = 0;
@@ -216,13 +247,19 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
       __syncthreads();
       int32_t* t = order_cur; order_cur = order_nxt; order_nxt = t;
     }
-    { const int nb0 = (int)(total_rows < a.bs ? total_rows : a.bs); prefetch(order_cur, 0, nb0); }
+    { const int nb0 = (int)(total_rows < a.bs ? total_rows : a.bs); fetch_index(order_cur, 0, nb0); fetch_data();
+      const int64_t st1 = a.bs; const int nb1 = st1 < total_rows ? (int)((total_rows - st1) < a.bs ? (total_rows - st1) : a.bs) : 0; fetch_index(order_cur, st1 < total_rows ? st1 : 0, nb1); }
     for (int64_t st = 0; st < total_rows; st += a.bs) {
       const int nb = (int)((total_rows - st) < a.bs ? (total_rows - st) : a.bs);
       const float invB = 1.0f / (float)nb;
+      ak.c1 = (float)(1.0 / (1.0 - bp1)); ak.c2 = (float)(1.0 / (1.0 - bp2));   // bias corrections of THIS step (independent of the data)
+      MF_T(0);
       stage();
-      { const int64_t st2 = st + a.bs; if (st2 < total_rows) { const int nb2 = (int)((total_rows - st2) < a.bs ? (total_rows - st2) : a.bs); prefetch(order_cur, st2, nb2); } }
+      if (st + a.bs < total_rows) fetch_data();    // rows of minibatch t+1 (their indices were loaded during step t-1)
+      { const int64_t st2 = st + 2 * (int64_t)a.bs; const int nb2 = st2 < total_rows ? (int)((total_rows - st2) < a.bs ? (total_rows - st2) : a.bs) : 0;
+        fetch_index(order_cur, st2 < total_rows ? st2 : 0, nb2); }
 
+      MF_T(1);
       // ======================= forward, C orientation =======================
       float xB[2][KS0], a1[4][KS0];
 #pragma unroll
@@ -250,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
         for (int n = 0; n < 2; ++n)
 #pragma unroll
           for (int r = 0; r < 4; ++r) T1[(16 * m + 4 * g + r) * MF_TLD + 16 * n + c] = h1[m][n][r];
+      MF_T(2);
       f32x4 h2[4][2];
 #pragma unroll
       for (int mp = 0; mp < 4; ++mp) { const f32x4 b = *(const f32x4*)&sm[Lt::oB2 + 16 * mp + 4 * g];
@@ -263,6 +301,7 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
         for (int r = 0; r < 4; ++r) { acc0[r] = actf<ACT>(acc0[r]); acc1[r] = actf<ACT>(acc1[r]); }
         h2[mp][0] = acc0; h2[mp][1] = acc1; }
 
+      MF_T(3);
       // ======================= layer 3 (VALU) + loss head =======================
       f32x4 w3[OUT][4];
 #pragma unroll
@@ -322,29 +361,39 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
         }
       }
 
+      MF_T(4);
       // ======================= backward, own samples =======================
-      // dW3 partial (per lane: its sample pair) and dZ2 (C) = act'(H2) .* (W3^T dz), overwriting h2
+      // dW3 partial over this wave's 32 samples and dZ2 (C) = act'(H2) .* (W3^T dz), overwriting h2
+#pragma unroll
+      for (int o = 0; o < OUT; ++o) { float pv[16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[4 * m + r] = fmaf(dz[o][0], h2[m][0][r], dz[o][1] * h2[m][1][r]);
+        // lane c ends up with the row total of index c = (m = c>>2, r = c&3), i.e. feature 16(c>>2) + 4g + (c&3)
+        part[Lt::pW3 + o * MF_HID + 16 * (c >> 2) + 4 * g + (c & 3)] = row16_reduce_scatter(pv, c); }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float y0 = h2[m][0][r], y1 = h2[m][1][r];
-          float d0 = 0.f, d1 = 0.f;
+        for (int r = 0; r < 4; ++r) { float d0 = 0.f, d1 = 0.f;
 #pragma unroll
-          for (int o = 0; o < OUT; ++o) {
-            const float gw = row16_sum(fmaf(dz[o][0], y0, dz[o][1] * y1));     // sum over this wave's samples (16 lanes x 2 tiles)
-            if (c == 0) part[Lt::pW3 + o * MF_HID + 16 * m + 4 * g + r] = gw;
-            d0 = fmaf(w3[o][m][r], dz[o][0], d0); d1 = fmaf(w3[o][m][r], dz[o][1], d1);
-          }
-          h2[m][0][r] = actg<ACT>(y0, d0); h2[m][1][r] = actg<ACT>(y1, d1);
-        }
-      // db3 / logSigma partials / stats: one representative group (g == 0 counted once via cnt; dz is identical in all g)
+          for (int o = 0; o < OUT; ++o) { d0 = fmaf(w3[o][m][r], dz[o][0], d0); d1 = fmaf(w3[o][m][r], dz[o][1], d1); }
+          h2[m][0][r] = actg<ACT>(h2[m][0][r], d0); h2[m][1][r] = actg<ACT>(h2[m][1][r], d1); }
+      // stats, db3 and dlogSigma: one reduce-scatter per 16 values; only row g == 0 carries the stats (cnt), dz is the same in every row
+      { constexpr int NV = 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0);
+        float mv[((NV + 15) / 16) * 16];
 #pragma unroll
-      for (int o = 0; o < OUT; ++o) { const float sb = row16_sum(dz[o][0] + dz[o][1]); if (lane == 0) part[Lt::pB3 + o] = sb;
-        if (KIND == MFK_GAUSSIAN) { const float se = row16_sum(dex[o][0] + dex[o][1]); if (lane == 0) part[Lt::pEX + o] = se; } }
-      { float sv[7] = {s_lossp, s_H, s_kl, s_adv, s_ret, s_clip, s_sq};
+        for (int k = 0; k < ((NV + 15) / 16) * 16; ++k) mv[k] = 0.f;
+        mv[0] = s_lossp; mv[1] = s_H; mv[2] = s_kl; mv[3] = s_adv; mv[4] = s_ret; mv[5] = s_clip; mv[6] = s_sq;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) { const float t = row16_sum(sv[k]); if (lane == 0) part[Lt::pST + k] = t; } }
+        for (int o = 0; o < OUT; ++o) { mv[7 + o] = dz[o][0] + dz[o][1]; if (KIND == MFK_GAUSSIAN) mv[7 + OUT + o] = dex[o][0] + dex[o][1]; }
+#pragma unroll
+        for (int ch = 0; ch < (NV + 15) / 16; ++ch) { float cv[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) cv[k] = mv[16 * ch + k];
+          const float t = row16_reduce_scatter(cv, c);
+          if (g == 0) part[Lt::pMISC + 16 * ch + c] = t; } }
+      MF_T(5);
       // publish dZ2 tile
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -362,6 +411,7 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
           for (int r = 0; r < 4; ++r) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[mp][0][r], wv[r], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[mp][1][r], wv[r], acc1, 0, 0, 0); } }
         dz1r[0][m] = acc0; dz1r[1][m] = acc1; }
+      MF_T(6);
       wave_sync();   // own T1/T2 tiles are complete for this wave's reads
       // dZ1 (R) = act'(H1 R) .* dH1 (R);  H1 (R)[sample 16n+4g+r'][f = 16m+c] comes from this wave's T1 tile
       float gb1[4], gb2[4];
@@ -392,7 +442,9 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
             for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1r[n][m][r], xR[n][r], acc, 0, 0, 0);
           *(f32x4*)&part[Lt::pW1 + (16 * jt + c) * MF_LD + 16 * m + 4 * g] = acc; }   // D reg r <-> [o=16m+4g+r][i=16jt+c]
       }
+      MF_T(7);
       __syncthreads();   // ---- B_a: all tiles and small partials are visible
+      MF_T(8);
 
       // ======================= dW2 rows [16w,16w+16) over all samples =======================
       f32x4 gW2[4];
@@ -409,14 +461,14 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) gW2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], gW2[m], 0, 0, 0); }
         }
+      MF_T(9);
       // small parameters: reduce the 4 per-wave partials; collect sum of squares and the NaN flag
-      constexpr int NSI = (NS + 255) / 256;
       float gs[NSI]; float ssq = 0.f; int bad = 0;
 #pragma unroll
-      for (int k = 0; k < NSI; ++k) { const int s = tid + 256 * k; float gsum = 0.f;
-        if (s < ns_valid) { const int po = s_part(s);
+      for (int k = 0; k < NSI; ++k) { float gsum = 0.f;
+        if (so_ok[k]) { const int po = so_part[k];
           gsum = ((sm[Lt::oPART + po] + sm[Lt::oPART + Lt::PART + po]) + sm[Lt::oPART + 2 * Lt::PART + po]) + sm[Lt::oPART + 3 * Lt::PART + po];
-          if (KIND == MFK_GAUSSIAN && s >= Lt::sEX) gsum += -a.lambda_e;     // d(-lambda_e * H)/dlogSigma, H = 1.4189 + sum(logSigma)
+          if (KIND == MFK_GAUSSIAN && so_ex[k]) gsum += -a.lambda_e;         // d(-lambda_e * H)/dlogSigma, H = 1.4189 + sum(logSigma)
           ssq += gsum * gsum; bad |= isnan(gsum) ? 1 : 0; }
         gs[k] = gsum; }
 #pragma unroll
@@ -425,7 +477,9 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
         for (int r = 0; r < 4; ++r) { ssq += gW2[m][r] * gW2[m][r]; bad |= isnan(gW2[m][r]) ? 1 : 0; }
       ssq = wave_sum(ssq);
       if (lane == 0) sm[Lt::oRED + w] = ssq;
+      MF_T(10);
       const int any_bad = __syncthreads_or(bad);   // ---- B_or (also publishes RED)
+      MF_T(8);
       // minibatch info (training.jl:22-23, ppo.jl:13-19); identical in every thread
       { float t[7];
 #pragma unroll
@@ -443,7 +497,6 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
       if (any_bad) { inf_gn = NAN; err = CRUX_ENAN; break; }                   // training.jl:20: no update
       // ======================= Adam (Flux.update!, training.jl:21) =======================
       if (a.apply) {
-        ak.c1 = (float)(1.0 / (1.0 - bp1)); ak.c2 = (float)(1.0 / (1.0 - bp2));
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -453,8 +506,8 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
           *(f32x4*)&sm[Lt::oW2C + (16 * m + c) * MF_LD + 16 * w + 4 * g] = tW2[m]; }
 #pragma unroll
         for (int k = 0; k < NSI; ++k) { const int s = tid + 256 * k;
-          if (s < ns_valid) { float mm = sm[Lt::oMS + s], vv = sm[Lt::oVS + s]; const float d = adam1(gs[k], mm, vv, ak);
-            sm[Lt::oMS + s] = mm; sm[Lt::oVS + s] = vv; const int mo = s_master(s); sm[mo] = sm[mo] - d; } }
+          if (so_ok[k]) { float mm = sm[Lt::oMS + s], vv = sm[Lt::oVS + s]; const float d = adam1(gs[k], mm, vv, ak);
+            sm[Lt::oMS + s] = mm; sm[Lt::oVS + s] = vv; const int mo = so_master[k]; sm[mo] = sm[mo] - d; } }
         bp1 *= a.b1; bp2 *= a.b2;
       } else {   // gradient-only mode (crux_loss_grad): export the flat gradient
 #pragma unroll
@@ -464,7 +517,9 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
 #pragma unroll
         for (int k = 0; k < NSI; ++k) { const int s = tid + 256 * k; if (s < ns_valid) a.g[s_canon(s)] = gs[k]; }
       }
+      MF_T(11);
       __syncthreads();   // ---- B_b: masters updated; tiles and partials may be overwritten
+      MF_T(8);
       total_batches += 1;
       if (a.max_batches > 0 && total_batches >= a.max_batches) break;          // training.jl:45
       if (a.target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > a.target_kl) break;   // :46
@@ -488,6 +543,7 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
         a.p[pc] = tW2[m][r]; a.m[pc] = mW2[m][r]; a.v[pc] = vW2[m][r]; }
     for (int s = tid; s < ns_valid; s += 256) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; }
   }
+  if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 12; ++k) a.dbg[w * 16 + k] = tacc[k]; }
   if (tid == 0) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     a.bp[0] = bp1; a.bp[1] = bp2;
@@ -496,14 +552,14 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
 }
 
 // ---- dispatch ---------------------------------------------------------------------------------------------------
-template <int IN, int OUT, int KIND, int ACT>
+template <int IN, int OUT, int KIND, int ACT, bool TIMING = false>
 static int32_t launch_one(crux_ctx* c, const TrainArgs& a) {
   using Lt = MfLayout<IN, OUT>;
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
   static_assert(lds <= 160 * 1024, "LDS budget exceeded");
   static bool attr = false;
-  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<IN, OUT, KIND, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-  hipLaunchKernelGGL((k_train_mfma<IN, OUT, KIND, ACT>), dim3(1), dim3(256), lds, c->stream, a);
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<IN, OUT, KIND, ACT, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_train_mfma<IN, OUT, KIND, ACT, TIMING>), dim3(1), dim3(256), lds, c->stream, a);
   return crux_launch_check(c, "k_train_mfma");
 }
 
@@ -520,6 +576,17 @@ int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled) {
   else if (a.head == CRUX_HEAD_CATEGORICAL) kind = MFK_CATEGORICAL;
   else if (a.head == CRUX_HEAD_GAUSSIAN) kind = MFK_GAUSSIAN;
   else return CRUX_OK;
+  if (getenv("CRUX_MFMA_TIMING") && in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) {
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) { if (hipMalloc(&dbg, 64 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
+    TrainArgs b = a; b.dbg = dbg; *handled = true;
+    int32_t rc = launch_one<4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU, true>(c, b); if (rc) return rc;
+    unsigned long long h[64]; HIPCHK(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+    static const char* nm[12] = {"loop+prefetch", "stage", "fwdL1+T1", "fwdL2", "L3+head", "dW3+dZ2+stats", "T2+dH1", "dZ1+db+dW1", "barrier-wait", "dW2", "small-reduce", "info+adam"};
+    for (int w = 0; w < 4; ++w) { fprintf(stderr, "[mfma-timing] wave %d:", w); unsigned long long tot = 0; for (int k = 0; k < 12; ++k) tot += h[w * 16 + k];
+      for (int k = 0; k < 12; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[w * 16 + k] / (double)tot); fprintf(stderr, " total=%llu cyc\n", tot); }
+    return CRUX_OK;
+  }
 #define MF_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_one<I, O, K, A_>(c, a); }
   MF_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)
   MF_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)
