@@ -843,3 +843,12 @@ int32_t orc_td_step(orc_mlp* net, orc_buffer* b, const float* y, int32_t use_wei
   if (isnan(info[CRUX_INFO_GRAD_NORM])) return CRUX_ENAN;
   return orc_adam_apply(net, 1.0f);
 }
+
+/* test hooks for the randomness spec in include/crux_rng.h */
+void orc_perm(uint64_t seed, uint64_t counter, uint32_t n, int64_t* out) {
+  crux_perm p = crux_perm_make(seed, counter, 0, n);
+  for (uint32_t j = 0; j < n; ++j) out[j] = (int64_t)crux_perm_at(&p, j);
+}
+void orc_philox(uint64_t seed, uint64_t counter, uint32_t stream, uint32_t purpose, uint32_t* out4) {
+  crux_u32x4 x = crux_philox(seed, counter, stream, purpose); for (int i = 0; i < 4; ++i) out4[i] = x.v[i];
+}

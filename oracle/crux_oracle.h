@@ -107,6 +107,9 @@ int32_t orc_dqn_target(orc_mlp* target_net, orc_buffer* batch, float gamma, floa
 int32_t orc_td_error(orc_mlp* net, orc_buffer* batch, const float* y, float* err);
 int32_t orc_td_step(orc_mlp* net, orc_buffer* batch, const float* y, int32_t use_weight, float* info_out);
 
+void orc_perm(uint64_t seed, uint64_t counter, uint32_t n, int64_t* out);
+void orc_philox(uint64_t seed, uint64_t counter, uint32_t stream, uint32_t purpose, uint32_t* out4);
+
 /* schedules: LinearDecaySchedule (utils.jl:116-126) */
 double orc_linear_decay(double start, double stop, int64_t steps, int64_t i);
 

@@ -1,0 +1,373 @@
+"""GPU parity of the individual C-ABI entry points against the CPU oracle and the reference's known answers."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import crux_jl_amd as crux
+from crux_jl_amd import _lib as L
+import oracle as O
+import parity
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---------------------------------------------------------------------------------------------------- networks
+@pytest.mark.parametrize("dims,acts", [([4, 64, 64, 2], ["relu", "relu", "identity"]), ([17, 64, 64, 6], ["tanh", "tanh", "identity"]),
+                                       ([2, 8, 4], ["relu", "identity"]), ([8, 256, 256, 4], ["relu", "relu", "identity"])])
+def test_mlp_init_and_forward_match_oracle(gpu_ctx, dims, acts):
+    g, o = parity.make_pair(dims, acts, 11, 2)
+    assert np.array_equal(g.get_params(), o.params)          # same Philox glorot draws
+    x = np.random.default_rng(0).standard_normal((dims[0], 301)).astype(np.float32)
+    yg, yo = g.forward(x), o.forward(x)
+    assert np.abs(yg - yo).max() <= 1e-5 * max(1.0, np.abs(yo).max())      # fp32 GEMM tolerance (accumulation order)
+    ps = g.params(); assert ps[0].shape == (dims[1], dims[0]) and ps[1].shape == (dims[1],)
+
+
+def test_polyak_and_copy_are_bit_exact(gpu_ctx):
+    g1, o1 = parity.make_pair([3, 16, 1], ["relu", "identity"], 1, 0); g2, o2 = parity.make_pair([3, 16, 1], ["relu", "identity"], 2, 0)
+    crux.polyak_average_(g1, g2, 0.005); O.chk(O.lib().orc_polyak(o1.h, o2.h, 0.005))
+    assert np.array_equal(g1.get_params(), o1.params)
+    crux.copyto_(g1, g2); assert np.array_equal(g1.get_params(), g2.get_params())
+
+
+def test_adam_apply_matches_flux_float64_semantics(gpu_ctx):
+    g, o = parity.make_pair([4, 32, 2], ["relu", "identity"], 3, 0)
+    g.attach_optimizer(crux.Adam(np.float32(3e-4))); o.adam_init(float(np.float32(3e-4)))
+    rng = np.random.default_rng(1)
+    gp = g.ctx.lib.crux_mlp_grads_ptr(g.h)
+    for _ in range(5):
+        gr = rng.standard_normal(o.n).astype(np.float32)
+        g.ctx.h2d(gp, gr); o.grads[:] = gr
+        g.ctx.check(g.ctx.lib.crux_adam_apply(g.h, 0.5)); O.chk(O.lib().orc_adam_apply(o.h, 0.5))
+    assert np.abs(g.get_params() - o.params).max() <= 1e-9     # device pow/sqrt/div in f64: identical after rounding
+    m, v, bp = g.adam_state(); om, ov, obp = o.adam_state()
+    assert np.array_equal(m, om) and np.array_equal(v, ov) and np.array_equal(bp, obp)
+
+
+# ---------------------------------------------------------------------------------------------------- buffer
+def _rand_data(rng, n, od, ad, discrete, extras=()):
+    d = {"s": rng.standard_normal((od, n)).astype(np.float32), "sp": rng.standard_normal((od, n)).astype(np.float32),
+         "r": rng.standard_normal((1, n)).astype(np.float32), "done": rng.random((1, n)) < 0.2, "episode_end": rng.random((1, n)) < 0.2}
+    if discrete:
+        a = np.zeros((ad, n), np.bool_); a[rng.integers(0, ad, n), np.arange(n)] = True; d["a"] = a
+    else:
+        d["a"] = rng.standard_normal((ad, n)).astype(np.float32)
+    for k in extras:
+        d[k] = rng.standard_normal((1, n)).astype(np.float32) if k != "t" else rng.integers(1, 50, (1, n))
+    return d
+
+
+def test_reference_buffer_tests_on_device(gpu_ctx):
+    """test/experience_buffer_tests.jl:32-51,121-174 replayed against the device buffer."""
+    b = crux.ExperienceBuffer(crux.ContinuousSpace(2), crux.ContinuousSpace(1), 100)
+    d = {"s": 2 * np.ones((2, 50)), "a": np.ones((1, 50)), "sp": np.ones((2, 50)), "r": np.ones((1, 50)), "done": np.zeros((1, 50)), "weight": np.zeros((1, 50))}
+    I = b.push_(d); assert list(I) == list(range(1, 51)) and len(b) == 50
+    assert list(b.get_last_N_indices(10)) == list(range(41, 51)) and list(b.get_last_N_indices(51)) == list(range(1, 51))
+    b.push_(d); b.push_(d)
+    assert list(b.get_last_N_indices(51)) == [100] + list(range(1, 51)) and b.next_ind == 51 and b.total_count == 150
+    assert list(b.get_last_N_indices(1000)) == list(range(51, 101)) + list(range(1, 51))
+    b = crux.ExperienceBuffer(crux.ContinuousSpace(2), crux.DiscreteSpace(4), 100)
+    assert b["a"].shape == (4, 0) and not b.haskey("weight")
+    b.push_({"s": 2 * np.ones((2, 1)), "a": np.ones((4, 1), bool), "sp": np.ones((2, 1)), "r": np.ones((1, 1)), "done": np.zeros((1, 1))})
+    assert len(b) == 1 and (b["s"] == 2).all() and b["a"].all()
+    rng = np.random.default_rng(0); a3 = rng.random((4, 3)) < 0.5
+    b.push_({"s": 3 * np.ones((2, 3)), "a": a3, "sp": 5 * np.ones((2, 3)), "r": 6 * np.ones((1, 3)), "done": np.ones((1, 3))})
+    assert len(b) == 4 and (b["s"][:, 1:] == 3).all() and (b["a"][:, 1:] == a3).all() and (b["r"][:, 1:] == 6).all()
+    b.push_(b)
+    assert len(b) == 8
+    for k in b.keys():
+        assert (b[k][:, :4] == b[k][:, 4:8]).all()
+    mb = b.minibatch([1, 2, 4])
+    for k in mb:
+        assert (mb[k] == b[k][:, [0, 1, 3]]).all()
+    with pytest.raises(crux.CruxError):      # @assert size(v1)[1:end-1] == size(v2)[1:end-1]
+        b.push_({"s": np.ones((3, 2)), "a": np.ones((4, 2), bool)})
+    b.clear_(); assert len(b) == 0 and b.next_ind == 1
+
+
+@pytest.mark.parametrize("cap,n_push", [(64, [10, 30, 40, 64, 7]), (1000, [999, 3])])
+def test_ring_push_wraps_like_oracle(gpu_ctx, cap, n_push):
+    rng = np.random.default_rng(2); extras = ["return", "logprob", "advantage", "t"]
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(5), crux.DiscreteSpace(3), cap, extras); ob = O.OBuffer(5, 3, L.ACTION_DISCRETE, cap, extras)
+    for n in n_push:
+        d = _rand_data(rng, n, 5, 3, True, extras)
+        assert np.array_equal(gb.push_(d), ob.push(d))
+        assert len(gb) == len(ob) and gb.next_ind == O.lib().orc_buffer_next_ind(ob.h) + 1
+        for k in gb.keys():
+            assert np.array_equal(gb[k], ob[k]), k
+    perm = rng.permutation(len(gb)) + 1
+    gb.shuffle_(perm); ob.permute(perm)
+    for k in gb.keys():
+        assert np.array_equal(gb[k], ob[k]), k
+    ids = rng.integers(1, len(gb) + 1, 17)
+    t_g = crux.ExperienceBuffer(crux.ContinuousSpace(5), crux.DiscreteSpace(3), 20, extras); t_o = O.OBuffer(5, 3, L.ACTION_DISCRETE, 20, extras)
+    assert np.array_equal(t_g.push_(gb, ids=ids), t_o.push_buffer(ob, ids))
+    for k in t_g.keys():
+        assert np.array_equal(t_g[k], t_o[k]), k
+
+
+def test_update_priorities_reference_kats_on_device(gpu_ctx):   # test/experience_buffer_tests.jl:193-205
+    b = crux.ExperienceBuffer(crux.ContinuousSpace(2), crux.DiscreteSpace(4), 50, prioritized=True)
+    assert b.haskey("weight") and len(b) == 0
+    b.update_priorities_([1, 2, 3], np.array([1.0, 2.0, 3.0]))
+    pp = b.priority_params()
+    assert pp["max_priority"] == 3.0
+    assert [float(x) for x in pp["priorities"][:3]] == [1.0000001192092896, 1.5157166719436646, 1.9331821203231812]
+    d = {"s": 2 * np.ones((2, 3)), "a": np.ones((4, 3), bool), "sp": np.ones((2, 3)), "r": np.ones((1, 3)), "done": np.zeros((1, 3))}
+    b.push_(d); b.push_(d)
+    pp = b.priority_params()
+    assert pp["max_priority"] == 3.0 and np.allclose(pp["priorities"][:6], np.float32(3.0) ** np.float32(0.6), rtol=1e-6)
+    b.update_priorities_([4, 5], np.array([0.5, 0.25], np.float32))     # Float32 path (td errors)
+    pp = b.priority_params(); assert pp["min_priority"] == np.float32(np.float32(0.25) + np.float32(1.1920929e-7))
+
+
+# ---------------------------------------------------------------------------------------------------- dynamics
+def test_device_dynamics_match_recordings(gpu_ctx):
+    z = np.load(os.path.join(GOLD, "cartpole_transitions.npz"))
+    s = np.ascontiguousarray(z["s"].T.astype(np.float64)); a = np.ascontiguousarray(z["a"].T.astype(np.uint8)); n = s.shape[0]
+    ns = np.zeros_like(s); obs = np.zeros((n, 4), np.float32); rr = np.zeros(n, np.float32); dd = np.zeros(n, np.uint8)
+    gpu_ctx.check(gpu_ctx.lib.crux_env_step_host(gpu_ctx.h, L.ENV["cartpole"], n, O.vpz(s), O.vpz(a), None, O.vpz(ns), O.vpz(obs), O.vpz(rr), O.vpz(dd)))
+    assert np.abs(obs - z["sp"].T).max() <= 1e-6 and (rr == 1).all() and (dd == z["done"][0]).all()
+    ons = np.zeros_like(s); oobs = np.zeros_like(obs); orr = np.zeros_like(rr); odd = np.zeros_like(dd)
+    O.chk(O.lib().orc_env_step_host(L.ENV["cartpole"], n, O.vpz(s), O.vpz(a), None, O.vpz(ons), O.vpz(oobs), O.vpz(orr), O.vpz(odd)))
+    assert np.abs(ns - ons).max() < 1e-14 and np.array_equal(obs, oobs)
+    z = np.load(os.path.join(GOLD, "pendulum_transitions.npz"))
+    s = np.ascontiguousarray(z["s"].T.astype(np.float64)); a = np.ascontiguousarray(z["a"].T.astype(np.float32)); n = s.shape[0]
+    ns = np.zeros_like(s); obs = np.zeros((n, 3), np.float32); rr = np.zeros(n, np.float32); dd = np.zeros(n, np.uint8)
+    gpu_ctx.check(gpu_ctx.lib.crux_env_step_host(gpu_ctx.h, L.ENV["pendulum"], n, O.vpz(s), O.vpz(a), None, O.vpz(ns), O.vpz(obs), O.vpz(rr), O.vpz(dd)))
+    assert np.abs(ns[:, 1] - z["sp"].T[:, 1]).max() < 2e-6 and np.abs(rr - z["r"][0]).max() < 5e-6
+
+
+# ---------------------------------------------------------------------------------------------------- rollouts
+def _rollout_pair(kind, head, n_envs, T, cap, extras, explore=True, reset=True, seed=4, max_steps=40, eps=None, noise=None, gext=0):
+    od, ad, disc = (4, 2, True) if kind == "cartpole" else (3, 1, False)
+    dims = [od, 32, 32, ad]
+    if head == "gaussian":
+        g, o = parity.make_pair(dims, ["tanh", "tanh", "identity"], seed, 0, "gaussian", n_extra=ad, extra_init=-0.5)
+    elif disc:
+        g, o = parity.make_pair(dims, ["relu", "relu", "identity"], seed, 0, "discrete")
+    else:
+        g, o = parity.make_pair(dims, ["relu", "relu", "identity"], seed, 0)
+    A = crux.DiscreteSpace(ad) if disc else crux.ContinuousSpace(ad)
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(od), A, cap, extras); ob = O.OBuffer(od, ad, L.ACTION_DISCRETE if disc else L.ACTION_CONTINUOUS, cap, extras)
+    mdp = crux.GymMDP(kind, n_envs=n_envs, seed=seed)
+    pe = crux.EpsGreedyPolicy(crux.LinearDecaySchedule(*eps), [1, 2]) if eps else crux.GaussianNoiseExplorationPolicy(**noise) if noise else None
+    gs = crux.Sampler(mdp, crux.PolicyParams(g, pi_explore=pe), max_steps=max_steps, required_columns=extras)
+    oe = O.OEnv(kind, n_envs, max_steps, 0.99, seed)
+    cfg = parity.rollout_cfg(explore, reset, "greedy_q" if eps else ("deterministic" if (noise or (not disc and head != "gaussian")) else head))
+    if eps:
+        cfg.eps_start, cfg.eps_stop, cfg.eps_steps = eps
+    if noise:
+        cfg.noise_sigma, cfg.a_min, cfg.a_max = noise["sigma"], noise.get("a_min", -np.inf), noise.get("a_max", np.inf)
+    return g, o, gb, ob, gs, oe, cfg
+
+
+@pytest.mark.parametrize("case", ["ppo_cartpole", "greedy_eval", "eps_greedy_offpolicy", "pendulum_gaussian", "pendulum_noise"])
+def test_rollout_matches_oracle(gpu_ctx, case):
+    if case == "ppo_cartpole":
+        g, o, gb, ob, gs, oe, cfg = _rollout_pair("cartpole", "categorical", 5, 97, 5 * 97, ["logprob", "t", "i"])
+        calls = [(5 * 97, 0)]
+    elif case == "greedy_eval":
+        g, o, gb, ob, gs, oe, cfg = _rollout_pair("cartpole", "categorical", 3, 60, 180, ["t"], explore=False, reset=False)
+        calls = [(180, 0)]
+    elif case == "eps_greedy_offpolicy":          # DQN-style: DN=4 per call into a ring, sampler state persists across calls
+        g, o, gb, ob, gs, oe, cfg = _rollout_pair("cartpole", "categorical", 2, 2, 50, ["weight", "t", "i"], reset=False, eps=(1.0, 0.1, 40))
+        calls = [(4, 4 * k) for k in range(20)]
+    elif case == "pendulum_gaussian":
+        g, o, gb, ob, gs, oe, cfg = _rollout_pair("pendulum", "gaussian", 4, 50, 200, ["logprob"], max_steps=30)
+        calls = [(200, 0)]
+    else:
+        g, o, gb, ob, gs, oe, cfg = _rollout_pair("pendulum", "deterministic", 4, 25, 100, [], reset=False, noise={"sigma": 0.3, "a_min": -2.0, "a_max": 2.0}, max_steps=30)
+        calls = [(100, 0), (100, 100)]
+    E = gs.n_envs
+    for (N, i0) in calls:
+        cfg.i0 = i0
+        info = crux.steps_(gs, gb, Nsteps=N, explore=bool(cfg.explore), i=i0, reset=bool(cfg.reset_at_end))
+        osr, one = oe.rollout(o, cfg, ob, N // E)
+        assert info["n_episode_end"] == one and abs(info["sum_r"] - osr) < 1e-3 * max(1, abs(osr))
+    diff = parity.compare_buffers(gb, ob)
+    for k in ("done", "episode_end", "t", "i"):
+        if k in diff:
+            assert diff[k] == 0, (k, diff)
+    if gb.act_kind == L.ACTION_DISCRETE:
+        assert diff["a"] == 0, diff
+    else:
+        assert diff["a"] < 1e-5, diff
+    for k in ("s", "sp", "r", "logprob", "weight"):
+        if k in diff:
+            assert diff[k] < 1e-4, (k, diff)
+    st_g, el_g, nr_g = gs.state(); st_o, el_o, nr_o = oe.state()
+    assert np.array_equal(el_g, el_o) and np.array_equal(nr_g, nr_o) and np.abs(st_g - st_o).max() < 1e-6
+    assert len(gb) == len(ob) and gb.next_ind == O.lib().orc_buffer_next_ind(ob.h) + 1
+
+
+# ---------------------------------------------------------------------------------------------------- advantage pipeline
+def test_gae_returns_whiten_match_oracle_on_random_episodes(gpu_ctx):
+    rng = np.random.default_rng(5); n = 3000; extras = ["return", "logprob", "advantage"]
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), n, extras); ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, n, extras)
+    d = _rand_data(rng, n, 4, 2, True, extras); d["episode_end"] = rng.random((1, n)) < 0.03; d["episode_end"][0, -1] = False   # last episode left open (:207-211)
+    gb.push_(d); ob.push(d)
+    gc, oc = parity.make_pair([4, 64, 64, 1], ["relu", "relu", "identity"], 6, 1)
+    crux.fill_gae_(gb, gc, 0.95, 0.99); crux.fill_returns_(gb, 0.99)
+    O.chk(O.lib().orc_fill_gae(ob.h, oc.h, 0.95, 0.99)); O.chk(O.lib().orc_fill_returns(ob.h, 0.99))
+    assert np.array_equal(gb["return"], ob["return"])                   # sequential Float32 scan: bit-exact
+    assert np.abs(gb["advantage"] - ob["advantage"]).max() < 5e-5       # depends on V(s) (fp32 GEMM tolerance)
+    crux.whiten_(gb, "advantage"); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
+    a = gb["advantage"][0]
+    assert np.abs(a - ob["advantage"][0]).max() < 2e-5 and abs(a.mean()) < 1e-5 and abs(a.std(ddof=1) - 1) < 1e-5
+    gb["r"] = np.full((1, n), np.nan, np.float32)
+    with pytest.raises(crux.CruxError) as e:
+        crux.fill_gae_(gb, gc, 0.95, 0.99)
+    assert e.value.code == L.ENAN                                       # @assert !isnan(A)
+
+
+# ---------------------------------------------------------------------------------------------------- learner
+def _train_pair(dims, acts, kind, n, od, ad, rng, n_extra=0):
+    extras = ["return", "logprob", "advantage"]
+    disc = kind != "gaussian"
+    g, o = parity.make_pair(dims, acts, 21, 0, "discrete" if kind == "categorical" else ("gaussian" if kind == "gaussian" else "continuous"), n_extra=n_extra, extra_init=-0.3)
+    A = crux.DiscreteSpace(ad) if disc else crux.ContinuousSpace(ad)
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(od), A, n, extras); ob = O.OBuffer(od, ad, L.ACTION_DISCRETE if disc else L.ACTION_CONTINUOUS, n, extras)
+    d = _rand_data(rng, n, od, ad, disc, extras)
+    d["logprob"] = (-0.7 + 0.05 * rng.standard_normal((1, n))).astype(np.float32) if disc else (-1.2 * ad + 0.1 * rng.standard_normal((1, n))).astype(np.float32)
+    gb.push_(d); ob.push(d)
+    return g, o, gb, ob
+
+
+@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("kind,dims,n,bs", [("categorical", [4, 64, 64, 2], 128, 128), ("categorical", [4, 64, 64, 2], 100, 37), ("value", [4, 64, 64, 1], 128, 128),
+                                             ("value", [4, 64, 64, 1], 77, 77), ("categorical", [6, 32, 5], 64, 64), ("gaussian", [17, 64, 64, 6], 96, 96)])
+def test_train_step_and_loss_grad_match_oracle(gpu_ctx, monkeypatch, force_generic, kind, dims, n, bs):
+    if force_generic:
+        monkeypatch.setenv("CRUX_FORCE_GENERIC", "1")
+    rng = np.random.default_rng(7); acts = ["relu"] * (len(dims) - 2) + ["identity"]
+    od, ad = dims[0], (dims[-1] if kind != "value" else 2)
+    g, o, gb, ob = _train_pair(dims, acts, kind if kind != "value" else "continuous", n, od, ad, rng, n_extra=dims[-1] if kind == "gaussian" else 0)
+    loss = crux.value_mse_loss if kind == "value" else crux.ppo_loss
+    p = crux.TrainingParams(loss=loss, batch_size=bs, epochs=1, name="x_"); P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+    o.adam_init(float(np.float32(3e-4)))
+    cfg = parity.train_cfg("value_mse" if kind == "value" else "ppo", "deterministic" if kind == "value" else kind, bs, 1)
+    ids = rng.permutation(n)[:bs].astype(np.int64)
+    # gradient only
+    g.attach_optimizer(p.optimizer); g.optimizer = p.optimizer
+    raw = np.zeros(L.INFO_N, np.float32); tc = crux.api._train_cfg(g, p, P)
+    g.ctx.check(g.ctx.lib.crux_loss_grad(g.h, gb.h, C.byref(tc), O.vpz(ids), ids.size, O.vpz(raw)))
+    oinfo = np.zeros(L.INFO_N, np.float32); O.chk(O.lib().orc_loss_grad(o.h, ob.h, C.byref(cfg), O.vpz(ids), ids.size, O.vpz(oinfo)))
+    gg = np.empty(o.n, np.float32); g.ctx.d2h(g.ctx.lib.crux_mlp_grads_ptr(g.h), gg)
+    scale = max(1.0, np.abs(o.grads).max())
+    assert np.abs(gg - o.grads).max() < 1e-4 * scale, np.abs(gg - o.grads).max()      # rel 1e-4
+    for k in ("loss", "grad_norm", "kl", "entropy", "clip_fraction", "avg_advantage", "avg_return"):
+        assert abs(raw[L.INFO[k]] - oinfo[L.INFO[k]]) < 1e-4 * max(1.0, abs(oinfo[L.INFO[k]])), k
+    assert np.array_equal(g.get_params(), o.params)                                   # gradient-only: parameters untouched
+    # three Adam steps on different minibatches
+    for s in range(3):
+        ids = rng.permutation(n)[:bs].astype(np.int64)
+        info = crux.train_(g, p, P, gb, ids + 1)
+        O.chk(O.lib().orc_train_step(o.h, ob.h, C.byref(cfg), O.vpz(ids), ids.size, O.vpz(oinfo)))
+        assert abs(info["x_loss"] - oinfo[0]) < 1e-4 * max(1, abs(oinfo[0]))
+    assert np.abs(g.get_params() - o.params).max() < 5e-6
+    m, v, bp = g.adam_state(); om, ov, obp = o.adam_state()
+    assert np.abs(m - om).max() < 1e-5 * max(1, np.abs(om).max()) and np.allclose(bp, obp, rtol=1e-12)
+
+
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_batch_train_early_stop_perms_and_ragged(gpu_ctx, monkeypatch, force_generic):
+    if force_generic:
+        monkeypatch.setenv("CRUX_FORCE_GENERIC", "1")
+    rng = np.random.default_rng(8); n = 300; bs = 64; epochs = 4
+    g, o, gb, ob = _train_pair([4, 64, 64, 2], ["relu", "relu", "identity"], "categorical", n, 4, 2, rng)
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+    perms = np.stack([rng.permutation(n) + 1 for _ in range(epochs)])
+    # (a) injected permutations, ragged last minibatch (300 = 4*64 + 44), no early stop
+    p = crux.TrainingParams(loss=crux.ppo_loss, optimizer=crux.Adam(1e-3), batch_size=bs, epochs=epochs, name="actor_")
+    o.adam_init(1e-3)
+    info = crux.batch_train_(g, p, P, gb, perms=perms)
+    cfg = parity.train_cfg("ppo", "categorical", bs, epochs); oinfo = np.zeros(L.INFO_N, np.float32); oep = np.zeros((epochs, L.INFO_N), np.float32)
+    p0 = np.ascontiguousarray(perms - 1)
+    O.chk(O.lib().orc_batch_train(o.h, ob.h, C.byref(cfg), O.vpz(p0), O.vpz(oinfo), O.vpz(oep)))
+    assert info["actor_batches_trained"] == int(oinfo[L.INFO["batches_trained"]]) == epochs * 5
+    assert np.abs(g.get_params() - o.params).max() < 2e-5
+    assert np.allclose(info["_epoch_infos"][:, :7], oep[:, :7], rtol=2e-3, atol=2e-5)
+    for k in gb.keys():                                                               # buffer order == all shuffles applied
+        assert np.array_equal(gb[k], ob[k]), k
+    # (b) KL early stopping with an aggressive step: same stopping minibatch as the oracle
+    p2 = crux.TrainingParams(loss=crux.ppo_loss, optimizer=crux.Adam(0.03), batch_size=32, epochs=5, target_kl=0.01, name="actor_", shuffle_seed=5)
+    o.adam_init(0.03); g.optimizer = None
+    info2 = crux.batch_train_(g, p2, P, gb)
+    cfg2 = parity.train_cfg("ppo", "categorical", 32, 5, 0.01, 5)
+    O.chk(O.lib().orc_batch_train(o.h, ob.h, C.byref(cfg2), None, O.vpz(oinfo), None))
+    assert info2["actor_batches_trained"] == int(oinfo[L.INFO["batches_trained"]]) and info2["_epochs_run"] == int(oinfo[L.INFO["epochs_run"]]) == 1
+    assert info2["kl"] > 0.01 and abs(info2["kl"] - oinfo[L.INFO["kl"]]) < 1e-3
+    # (c) max_batches
+    p3 = crux.TrainingParams(loss=crux.ppo_loss, batch_size=32, epochs=5, name="actor_", max_batches=13, shuffle_seed=9); g.optimizer = None
+    info3 = crux.batch_train_(g, p3, P, gb)
+    assert info3["actor_batches_trained"] == 13 and info3["_epochs_run"] == 2
+
+
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_nan_gradient_is_reported_and_parameters_are_kept(gpu_ctx, monkeypatch, force_generic):
+    if force_generic:
+        monkeypatch.setenv("CRUX_FORCE_GENERIC", "1")
+    rng = np.random.default_rng(9)
+    g, o, gb, ob = _train_pair([4, 64, 64, 1], ["relu", "relu", "identity"], "continuous", 128, 4, 2, rng)
+    gb["return"] = np.full((1, 128), np.nan, np.float32)
+    p = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=128, epochs=1, name="critic_")
+    before = g.get_params()
+    with pytest.raises(crux.CruxError) as e:
+        crux.train_(g, p, {}, gb, np.arange(1, 129))
+    assert e.value.code == L.ENAN and np.array_equal(g.get_params(), before)          # src/training.jl:20
+
+
+def test_dqn_target_td_error_td_step_match_oracle(gpu_ctx):
+    rng = np.random.default_rng(10); n = 128
+    g, o = parity.make_pair([2, 8, 4], ["relu", "identity"], 31, 0, "discrete"); gt, ot = parity.make_pair([2, 8, 4], ["relu", "identity"], 32, 0, "discrete")
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(2), crux.DiscreteSpace(4), n, ["weight"]); ob = O.OBuffer(2, 4, L.ACTION_DISCRETE, n, ["weight"])
+    d = _rand_data(rng, n, 2, 4, True); d["weight"] = rng.random((1, n)).astype(np.float32); gb.push_(d); ob.push(d)
+    ctx = g.ctx; dy = ctx.alloc(4 * n); de = ctx.alloc(4 * n)
+    ctx.check(ctx.lib.crux_dqn_target(gt.h, gb.h, 0.95, dy)); y = ctx.d2h(dy, np.empty(n, np.float32))
+    oy = np.empty(n, np.float32); O.chk(O.lib().orc_dqn_target(ot.h, ob.h, 0.95, O.vpz(oy)))
+    assert np.abs(y - oy).max() < 1e-5
+    ctx.h2d(dy, oy)
+    ctx.check(ctx.lib.crux_td_error(g.h, gb.h, dy, de)); err = ctx.d2h(de, np.empty(n, np.float32))
+    oerr = np.empty(n, np.float32); O.chk(O.lib().orc_td_error(o.h, ob.h, O.vpz(oy), O.vpz(oerr)))
+    assert np.abs(err - oerr).max() < 1e-5
+    g.attach_optimizer(crux.Adam(np.float32(1e-3))); o.adam_init(float(np.float32(1e-3)))
+    for use_w in (0, 1):
+        raw = np.zeros(L.INFO_N, np.float32); oinfo = np.zeros(L.INFO_N, np.float32)
+        ctx.check(ctx.lib.crux_td_step(g.h, gb.h, dy, use_w, O.vpz(raw))); O.chk(O.lib().orc_td_step(o.h, ob.h, O.vpz(oy), use_w, O.vpz(oinfo)))
+        assert abs(raw[0] - oinfo[0]) < 1e-5 * max(1, abs(oinfo[0])) and abs(raw[2] - oinfo[2]) < 1e-5 and abs(raw[1] - oinfo[1]) < 1e-4 * max(1, oinfo[1])
+    assert np.abs(g.get_params() - o.params).max() < 1e-6
+    ctx.free(dy); ctx.free(de)
+
+
+# ---------------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_iteration_properties(gpu_ctx):
+    """BASELINE configs[1] sizes (32 envs x 2048 steps, batch 128): size-independent invariants instead of an oracle replay."""
+    import bench
+    pi, buf, sampler = bench.build_problem(crux, 123)
+    info = crux.steps_(sampler, buf, Nsteps=buf.capacity, explore=True, i=0, reset=True)
+    s, sp, ee, done, r, t_ret, adv, lp, a = buf["s"], buf["sp"], buf["episode_end"][0], buf["done"][0], buf["r"][0], buf["return"][0], buf["advantage"][0], buf["logprob"][0], buf["a"]
+    N, T = buf.capacity, bench.T
+    assert len(buf) == N and ee.sum() == info["n_episode_end"] and r.sum() == info["sum_r"] == N
+    assert (ee[T - 1::T]).all()                                           # reset=true closes every env's rollout
+    assert (a.sum(0) == 1).all() and np.isfinite(lp).all() and (lp <= 0).all()
+    cont = ~ee[:-1]
+    assert np.array_equal(sp[:, :-1][:, cont], s[:, 1:][:, cont])         # s_{t+1} == sp_t inside an episode
+    assert (done <= ee).all()
+    # returns recurrence R_t = r_t + gamma R_{t+1}, restarting after each episode_end (fill_returns!, sampler.jl:275-281)
+    g32 = np.float32(0.99); nxt = np.where(ee[:-1], np.float32(0), t_ret[1:]).astype(np.float32)
+    assert np.array_equal(t_ret[:-1], (r[:-1] + g32 * nxt).astype(np.float32)) and t_ret[-1] == r[-1]
+    ep_len = np.diff(np.flatnonzero(np.concatenate([[True], ee])))
+    assert ep_len.max() <= bench.MAX_STEPS
+    crux.whiten_(buf, "advantage"); w = buf["advantage"][0]
+    assert abs(w.mean()) < 1e-4 and abs(w.std(ddof=1) - 1) < 1e-4
+    key = lambda b: np.sort(b["logprob"][0] * 1000 + b["return"][0])
+    before = key(buf); P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+    a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=128, epochs=2, name="actor_")
+    p0 = pi.A.get_params(); inf = crux.batch_train_(pi.A, a_opt, P, buf)
+    assert inf["actor_batches_trained"] == 2 * 512 and np.array_equal(key(buf), before)      # shuffles only permute rows
+    assert np.isfinite(pi.A.get_params()).all() and not np.array_equal(p0, pi.A.get_params())
+    assert 0.55 < inf["entropy"] <= np.log(2) + 1e-5
