@@ -468,6 +468,11 @@ class ExperienceBuffer:
             v = v.astype(np.float32)
         self.ctx.check(self.ctx.lib.crux_per_update(self.h, _vp(I0), _vp(v), 1 if is64 else 0, I0.size))
 
+    def cumsum(self):
+        out = np.empty(len(self), np.float32)
+        self.ctx.check(self.ctx.lib.crux_per_get(self.h, None, None, None, _vp(out)))
+        return out
+
     def priority_params(self):
         pr = np.empty(self.capacity, np.float32); mx, mn = C.c_float(), C.c_float()
         self.ctx.check(self.ctx.lib.crux_per_get(self.h, _vp(pr), C.byref(mx), C.byref(mn), None))
@@ -483,6 +488,39 @@ class ExperienceBuffer:
 
 def capacity(b):
     return b.capacity
+
+
+SAMPLE_SEED = 0x5EED5A3F   # Philox key of the library's replay-sampling draws (fixed; the counter is the caller's `i`)
+
+
+def uniform_sample_(target, source, B=None, ids=None, i=0):
+    """uniform_sample!(target, source; B) (src/experience_buffer.jl:317-321). ids: optional explicit 1-based rows (else Philox)."""
+    B = B or target.capacity
+    ids0 = None if ids is None else np.ascontiguousarray(np.asarray(ids, np.int64) - 1)
+    target.ctx.check(target.ctx.lib.crux_uniform_sample(target.h, source.h, B, _vp(ids0), int(i)))
+    return target.indices[:B] + 1
+
+
+def prioritized_sample_(target, source, B=None, i=1, rands=None):
+    """prioritized_sample!(target, source; i, B) (src/experience_buffer.jl:324-349). rands: optional B Float64 uniforms."""
+    B = B or target.capacity
+    r = None if rands is None else np.ascontiguousarray(rands, np.float64)
+    beta = np.float32(source.beta(i))
+    target.ctx.check(target.ctx.lib.crux_per_sample(target.h, source.h, B, _vp(r), float(beta), int(i)))
+    return target.indices[:B] + 1
+
+
+def rand_(target, *sources, i=1, fracs=None):
+    """Random.rand!(target, sources...; i, fracs) (src/experience_buffer.jl:303-315)."""
+    fr = list(fracs) if fracs is not None else [1.0 / len(sources)] * len(sources)
+    lens = [len(s) for s in sources]
+    if any(l == 0 for l in lens):
+        fr = [0.0 if l == 0 else f for f, l in zip(fr, lens)]; tot = sum(fr); fr = [f / tot for f in fr]
+    batches = split_batches(target.capacity, fr)
+    for b, B in zip(sources, batches):
+        if B == 0:
+            continue
+        prioritized_sample_(target, b, B=B, i=i) if b.isprioritized() else uniform_sample_(target, b, B=B, i=i)
 
 
 def split_batches(N, fracs):

@@ -3,6 +3,8 @@
 // minibatch :170-171, get_last_N_indices :223-229, push! :232-259, update_priorities! :290-301).
 #include "common.h"
 
+void crux_buffer_topo_free(crux_buffer* b);
+
 // ---- kernels ------------------------------------------------------------------------------------
 // row gather/scatter on a column: dst[dst_idx[j]] = src[src_idx[j]] (idx NULL => j). Rows are `stride`
 // bytes; W = access width in bytes (4 when stride % 4 == 0, else 1). Consecutive threads touch
@@ -142,6 +144,7 @@ int32_t crux_buffer_create(crux_ctx* ctx, int32_t obs_dim, int32_t act_dim, int3
 int32_t crux_buffer_destroy(crux_buffer* b) {
   if (!b) return CRUX_OK;
   (void)hipStreamSynchronize(b->ctx->stream);
+  crux_buffer_topo_free(b);
   for (int k = 0; k < CRUX_NCOLS; ++k) if (b->col[k]) (void)hipFree(b->col[k]);
   if (b->priorities) (void)hipFree(b->priorities); if (b->cumsum) (void)hipFree(b->cumsum); if (b->pminmax) (void)hipFree(b->pminmax);
   if (b->d_indices) (void)hipFree(b->d_indices); if (b->order_a) (void)hipFree(b->order_a); if (b->order_b) (void)hipFree(b->order_b);

@@ -79,6 +79,11 @@ struct crux_buffer {
   float* pminmax = nullptr;      // device [2]: max_priority, min_priority (un-powered, Float32 fields)
   std::vector<int64_t> indices;  // host copy of the last sample's ids (target.indices)
   int64_t* d_indices = nullptr;  // device copy [capacity]
+  // pairwise-cumsum tree of Base.cumsum for the current length (built on the host once per length, see per.hip)
+  int64_t topo_n = -1; int32_t topo_leaves = 0, topo_nodes = 0, topo_levels = 0;
+  int32_t* topo_leaf_start = nullptr; int32_t* topo_leaf_len = nullptr; int32_t* topo_leaf_node = nullptr;
+  int32_t* topo_left = nullptr; int32_t* topo_right = nullptr; int32_t* topo_level_off = nullptr;   // nodes sorted by level
+  float* topo_total = nullptr; float* topo_prefix = nullptr;
   int32_t* order_a = nullptr;    // device [capacity] logical->physical order scratch for batch_train
   int32_t* order_b = nullptr;
 };

@@ -1,21 +1,240 @@
-// per.hip -- prioritized / uniform replay sampling (src/experience_buffer.jl:303-349). Device scan + search land next;
-// until then the entry points report CRUX_EUNSUP loudly rather than falling back to host arithmetic.
+// per.hip -- replay sampling on device: prioritized_sample! / uniform_sample! / rand! pieces.
+// Reference: src/experience_buffer.jl:303-349. Compiled with -ffp-contract=off (the scan is order-defined).
+//
+// prioritized_sample! recomputes `cumsum(priorities[1:N])` whenever priorities changed (:329-332), i.e. once per gradient
+// step in DQN. Julia's Base.cumsum on a Float32 vector is accumulate_pairwise!: a binary recursion that
+// halves segments down to leaves of < 128 elements, sums leaves sequentially and combines child totals in a fixed tree.
+// Sample indices are bit-exact only if that summation tree is reproduced, so the scan here is that tree, parallelised:
+//   k_leaf_totals   one thread per leaf: sequential Float32 sum of the leaf            (streams N floats)
+//   k_tree          one block: child totals bottom-up, then prefixes top-down          (2 x leaves nodes)
+//   k_leaf_scan     one thread per leaf: c[i] = prefix + running leaf sum              (streams N floats in, N out)
+// followed by k_per_search (Float64 key against the Float32 cumsum, :335-340), the IS weights (:343-347) and the row gather.
+// The tree shape depends only on N and is built on the host once per buffer length.
 #include "common.h"
+#include <algorithm>
+
+int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I);
+void crux_buffer_ring_advance(crux_buffer* b, int64_t N);
+int32_t crux_buffer_per_on_push(crux_buffer* b, const int64_t* d_I, int64_t N);
+
+// ---- host: shape of accumulate_pairwise!(add_sum, c, v[2:n]) ----------------------------------------------------------
+struct TopoBuild { std::vector<int32_t> left, right, level, start, len; };
+static int32_t topo_rec(TopoBuild& t, int64_t i1, int64_t n, int lvl) {
+  const int32_t id = (int32_t)t.left.size();
+  t.left.push_back(-1); t.right.push_back(-1); t.level.push_back(lvl); t.start.push_back((int32_t)i1); t.len.push_back((int32_t)n);
+  if (n >= 128) { const int64_t n2 = n >> 1; const int32_t l = topo_rec(t, i1, n2, lvl + 1); const int32_t r = topo_rec(t, i1 + n2, n - n2, lvl + 1); t.left[id] = l; t.right[id] = r; }
+  return id;
+}
+
+static void topo_free(crux_buffer* b) {
+  int32_t** ps[] = {&b->topo_leaf_start, &b->topo_leaf_len, &b->topo_leaf_node, &b->topo_left, &b->topo_right, &b->topo_level_off};
+  for (auto p : ps) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (b->topo_total) { (void)hipFree(b->topo_total); b->topo_total = nullptr; }
+  if (b->topo_prefix) { (void)hipFree(b->topo_prefix); b->topo_prefix = nullptr; }
+  b->topo_n = -1;
+}
+void crux_buffer_topo_free(crux_buffer* b) { topo_free(b); }
+
+static int32_t topo_ensure(crux_buffer* b, int64_t N) {
+  crux_ctx* c = b->ctx;
+  if (b->topo_n == N) return CRUX_OK;
+  (void)hipStreamSynchronize(c->stream);
+  topo_free(b);
+  if (N < 2) { b->topo_n = N; b->topo_leaves = b->topo_nodes = b->topo_levels = 0; return CRUX_OK; }
+  TopoBuild t; topo_rec(t, 1, N - 1, 0);
+  const int nn = (int)t.left.size(); int maxlvl = 0; for (int v : t.level) if (v > maxlvl) maxlvl = v;
+  // renumber nodes so that each level is contiguous (level 0 first)
+  std::vector<int32_t> order(nn), newid(nn), lvl_off(maxlvl + 2, 0);
+  for (int i = 0; i < nn; ++i) lvl_off[t.level[i] + 1]++;
+  for (int l = 0; l <= maxlvl; ++l) lvl_off[l + 1] += lvl_off[l];
+  { std::vector<int32_t> cur(lvl_off.begin(), lvl_off.end() - 1); for (int i = 0; i < nn; ++i) { newid[i] = cur[t.level[i]]++; order[newid[i]] = i; } }
+  std::vector<int32_t> L(nn), R(nn), ls, ll, ln;
+  for (int k = 0; k < nn; ++k) { const int i = order[k]; L[k] = t.left[i] >= 0 ? newid[t.left[i]] : -1; R[k] = t.right[i] >= 0 ? newid[t.right[i]] : -1;
+    if (t.left[i] < 0) { ls.push_back(t.start[i]); ll.push_back(t.len[i]); ln.push_back(k); } }
+  const int nl = (int)ls.size();
+  { // leaves in memory order: a block of LEAF_BLK consecutive leaves then covers one contiguous span of the vector
+    std::vector<int32_t> idx(nl); for (int i = 0; i < nl; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b2) { return ls[a] < ls[b2]; });
+    std::vector<int32_t> a(nl), b2(nl), c2(nl); for (int i = 0; i < nl; ++i) { a[i] = ls[idx[i]]; b2[i] = ll[idx[i]]; c2[i] = ln[idx[i]]; }
+    ls.swap(a); ll.swap(b2); ln.swap(c2); }
+  auto up = [&](int32_t** d, const std::vector<int32_t>& h) -> bool {
+    if (hipMalloc(d, 4 * h.size()) != hipSuccess) return false;
+    return hipMemcpyAsync(*d, h.data(), 4 * h.size(), hipMemcpyHostToDevice, c->stream) == hipSuccess; };
+  if (!up(&b->topo_leaf_start, ls) || !up(&b->topo_leaf_len, ll) || !up(&b->topo_leaf_node, ln) || !up(&b->topo_left, L) || !up(&b->topo_right, R) || !up(&b->topo_level_off, lvl_off) ||
+      hipMalloc(&b->topo_total, 4 * (size_t)nn) != hipSuccess || hipMalloc(&b->topo_prefix, 4 * (size_t)nn) != hipSuccess) { topo_free(b); return crux_fail(c, CRUX_ENOMEM, "cumsum tree"); }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  b->topo_n = N; b->topo_leaves = nl; b->topo_nodes = nn; b->topo_levels = maxlvl + 1;
+  return CRUX_OK;
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------------------------
+// 64 consecutive leaves per block: their elements are contiguous in memory, so the block streams them coalesced into LDS and
+// each thread then walks its own leaf from LDS (leaf length <= 127).
+#define LEAF_BLK 64
+#define LEAF_MAX 127
+__global__ __launch_bounds__(LEAF_BLK) void k_leaf_totals(const float* __restrict__ v, const int32_t* __restrict__ lstart, const int32_t* __restrict__ llen,
+                                                          const int32_t* __restrict__ lnode, int nl, float* __restrict__ total) {
+  __shared__ float sm[LEAF_BLK * LEAF_MAX + 64];
+  const int l0 = blockIdx.x * LEAF_BLK, t = threadIdx.x, l = l0 + t;
+  const int lend = min(l0 + LEAF_BLK, nl) - 1;
+  const int base = lstart[l0], cnt = lstart[lend] + llen[lend] - base;
+  for (int i = t; i < cnt; i += LEAF_BLK) sm[i] = v[base + i];
+  __syncthreads();
+  if (l < nl) { const int o = lstart[l] - base, n = llen[l]; float s = sm[o]; for (int i = 1; i < n; ++i) s = s + sm[o + i]; total[lnode[l]] = s; }
+}
+__global__ __launch_bounds__(1024) void k_tree(const int32_t* __restrict__ left, const int32_t* __restrict__ right, const int32_t* __restrict__ lvl_off, int nlev,
+                                               float* __restrict__ total, float* __restrict__ prefix, const float* __restrict__ v) {
+  const int t = threadIdx.x;
+  for (int lv = nlev - 1; lv >= 0; --lv) {           // s_ = rec(left); s_ += rec(right)
+    for (int k = lvl_off[lv] + t; k < lvl_off[lv + 1]; k += 1024) if (left[k] >= 0) total[k] = total[left[k]] + total[right[k]];
+    __syncthreads();
+  }
+  if (t == 0) prefix[0] = v[0];                        // accumulate_pairwise!: s_ = v[1]; rec(c, v, s_, 2, n-1)
+  __syncthreads();
+  for (int lv = 0; lv < nlev; ++lv) {                 // left gets s, right gets s + s_left
+    for (int k = lvl_off[lv] + t; k < lvl_off[lv + 1]; k += 1024) if (left[k] >= 0) { const float s = prefix[k]; prefix[left[k]] = s; prefix[right[k]] = s + total[left[k]]; }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(LEAF_BLK) void k_leaf_scan(const float* __restrict__ v, const int32_t* __restrict__ lstart, const int32_t* __restrict__ llen,
+                                                        const int32_t* __restrict__ lnode, int nl, const float* __restrict__ prefix, float* __restrict__ c) {
+  __shared__ float sm[LEAF_BLK * LEAF_MAX + 64];
+  const int l0 = blockIdx.x * LEAF_BLK, t = threadIdx.x, l = l0 + t;
+  const int lend = min(l0 + LEAF_BLK, nl) - 1;
+  const int base = lstart[l0], cnt = lstart[lend] + llen[lend] - base;
+  for (int i = t; i < cnt; i += LEAF_BLK) sm[i] = v[base + i];
+  __syncthreads();
+  if (l < nl) { const int o = lstart[l] - base, n = llen[l]; const float s = prefix[lnode[l]]; float s_ = sm[o]; sm[o] = s + s_;
+    for (int i = 1; i < n; ++i) { s_ = s_ + sm[o + i]; sm[o + i] = s + s_; } }
+  __syncthreads();
+  for (int i = t; i < cnt; i += LEAF_BLK) c[base + i] = sm[i];
+  if (blockIdx.x == 0 && t == 0) c[0] = v[0];
+}
+__global__ void k_cumsum_tiny(const float* v, int64_t n, float* c) { if (threadIdx.x == 0 && blockIdx.x == 0) { if (n >= 1) c[0] = v[0]; } }
+
+// stratified search + importance weights (:335-347)
+__global__ void k_per_search(const float* __restrict__ cs, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B,
+                             const double* __restrict__ rands, uint64_t seed, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= B) return;
+  const float ptot = cs[N - 1];
+  const float dp = ptot / (float)B;
+  double u;
+  if (rands) u = rands[j];
+  else { const crux_u32x4 x = crux_philox(seed, ictr * (uint64_t)B + (uint64_t)j, 0, CRUX_RNG_SAMPLE); u = crux_u32x2_to_f64(x.v[0], x.v[1]); }
+  const double key = ((double)(j + 1) + u - 1.0) * (double)dp;
+  int64_t lo = 0, hi = N;
+  while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if ((double)cs[mid] < key) lo = mid + 1; else hi = mid; }
+  if (lo >= N) lo = N - 1;       // the reference would index out of bounds here
+  ids[j] = lo;
+  const float pmin = pminmax[1] / ptot;
+  const float max_w = powf(pmin * (float)N, -beta);
+  weight[lo] = powf(((float)N * pr[lo]) / ptot, beta) / max_w;
+}
+__global__ void k_uniform_ids(int64_t N, int64_t B, uint64_t seed, uint64_t ictr, int64_t* ids) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= B) return;
+  const crux_u32x4 x = crux_philox(seed, ictr * (uint64_t)B + (uint64_t)j, 0, CRUX_RNG_SAMPLE);
+  ids[j] = (int64_t)(((uint64_t)x.v[0] * (uint64_t)N) >> 32);
+}
+// gather rows src[ids[j]] into the ring of dst at (base + j) % C
+template <typename T>
+__global__ void k_gather_ring(T* __restrict__ dst, const T* __restrict__ src, const int64_t* __restrict__ ids, int64_t n, int32_t row_elems, int64_t base, int64_t C) {
+  const int64_t total = n * row_elems;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = t / row_elems; const int32_t e = (int32_t)(t - j * row_elems);
+    dst[((base + j) % C) * row_elems + e] = src[ids[j] * row_elems + e];
+  }
+}
+__global__ void k_ring_ids(int64_t* out, int64_t n, int64_t base, int64_t C) { const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (j < n) out[j] = (base + j) % C; }
+
+static unsigned gridn(int64_t total) { int64_t nb = (total + 255) / 256; if (nb < 1) nb = 1; if (nb > 8192) nb = 8192; return (unsigned)nb; }
+
+static int32_t ensure_cumsum(crux_buffer* s, int64_t N) {
+  crux_ctx* c = s->ctx;
+  if (s->cumsum_valid && s->topo_n == N) return CRUX_OK;
+  int32_t rc = topo_ensure(s, N); if (rc) return rc;
+  crux_prof_begin(c, CRUX_PROF_PER_SCAN);
+  if (N < 2) hipLaunchKernelGGL(k_cumsum_tiny, dim3(1), dim3(1), 0, c->stream, s->priorities, N, s->cumsum);
+  else {
+    const int nb = (s->topo_leaves + LEAF_BLK - 1) / LEAF_BLK;
+    hipLaunchKernelGGL(k_leaf_totals, dim3(nb), dim3(LEAF_BLK), 0, c->stream, s->priorities, s->topo_leaf_start, s->topo_leaf_len, s->topo_leaf_node, s->topo_leaves, s->topo_total);
+    hipLaunchKernelGGL(k_tree, dim3(1), dim3(1024), 0, c->stream, s->topo_left, s->topo_right, s->topo_level_off, s->topo_levels, s->topo_total, s->topo_prefix, s->priorities);
+    hipLaunchKernelGGL(k_leaf_scan, dim3(nb), dim3(LEAF_BLK), 0, c->stream, s->priorities, s->topo_leaf_start, s->topo_leaf_len, s->topo_leaf_node, s->topo_leaves, s->topo_prefix, s->cumsum);
+  }
+  crux_prof_end(c, CRUX_PROF_PER_SCAN);
+  s->cumsum_valid = true;
+  return crux_launch_check(c, "per scan");
+}
+
+// push!(target, source, ids=device ids) (:232-259): gather B rows into target's ring; target.indices mirrors the ids
+static int32_t gather_into(crux_buffer* target, crux_buffer* source, int64_t B, bool fetch_indices) {
+  crux_ctx* c = target->ctx;
+  const int64_t base = target->next_ind, C = target->capacity;
+  crux_prof_begin(c, CRUX_PROF_GATHER);
+  for (int k = 0; k < CRUX_NCOLS; ++k) {
+    if (!has_col(target, k) || !has_col(source, k)) continue;
+    const size_t st = col_stride(target, k);
+    if (st % 4 == 0) { const int32_t re = (int32_t)(st / 4);
+      hipLaunchKernelGGL(k_gather_ring<uint32_t>, dim3(gridn(B * re)), dim3(256), 0, c->stream, (uint32_t*)target->col[k], (const uint32_t*)source->col[k], (const int64_t*)target->d_indices, B, re, base, C); }
+    else { const int32_t re = (int32_t)st;
+      hipLaunchKernelGGL(k_gather_ring<uint8_t>, dim3(gridn(B * re)), dim3(256), 0, c->stream, (uint8_t*)target->col[k], (const uint8_t*)source->col[k], (const int64_t*)target->d_indices, B, re, base, C); }
+  }
+  crux_prof_end(c, CRUX_PROF_GATHER);
+  int32_t rc = crux_launch_check(c, "k_gather_ring"); if (rc) return rc;
+  if (target->prioritized) {       // buffer_like of a prioritized buffer is prioritized too (:84): push! runs update_priorities! on it
+    int64_t* ring = (int64_t*)crux_scratch(c, 8 * (size_t)B + 256); if (!ring) return crux_fail(c, CRUX_ENOMEM, "sample: scratch");
+    hipLaunchKernelGGL(k_ring_ids, dim3(gridn(B)), dim3(256), 0, c->stream, ring, B, base, C);
+    rc = crux_buffer_per_on_push(target, ring, B); if (rc) return rc;
+  }
+  if (fetch_indices) {
+    target->indices.resize((size_t)B);
+    HIPCHK(c, hipMemcpyAsync(target->indices.data(), target->d_indices, 8 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  crux_buffer_ring_advance(target, B);
+  return CRUX_OK;
+}
 
 extern "C" {
+
 int32_t crux_per_sample(crux_buffer* target, crux_buffer* source, int64_t B, const double* rands, float beta, uint64_t i) {
-  (void)source; (void)B; (void)rands; (void)beta; (void)i;
-  return crux_fail(target ? target->ctx : nullptr, CRUX_EUNSUP, "prioritized_sample!: device kernel not built yet");
+  if (!target || !source) return CRUX_EINVAL;
+  crux_ctx* c = target->ctx;
+  if (!source->prioritized || !has_col(source, CRUX_COL_WEIGHT)) return crux_fail(c, CRUX_EINVAL, "prioritized_sample!: source needs priorities and a :weight column (@assert haskey(source, :weight))");
+  const int64_t N = source->elements;
+  if (N <= 0 || B <= 0 || B > target->capacity) return crux_fail(c, CRUX_EINVAL, "prioritized_sample!: N=%lld B=%lld capacity=%lld", (long long)N, (long long)B, (long long)target->capacity);
+  if (target->obs_dim != source->obs_dim || target->act_dim != source->act_dim || target->act_kind != source->act_kind) return crux_fail(c, CRUX_EINVAL, "prioritized_sample!: column shapes differ");
+  int32_t rc = ensure_cumsum(source, N); if (rc) return rc;
+  double* d_r = nullptr;
+  if (rands) { d_r = (double*)crux_scratch(c, 8 * (size_t)B + 256); if (!d_r) return crux_fail(c, CRUX_ENOMEM, "prioritized_sample!: scratch");
+    HIPCHK(c, hipMemcpyAsync(d_r, rands, 8 * (size_t)B, hipMemcpyHostToDevice, c->stream)); }
+  crux_prof_begin(c, CRUX_PROF_PER_SEARCH);
+  hipLaunchKernelGGL(k_per_search, dim3(gridn(B)), dim3(256), 0, c->stream, source->cumsum, source->priorities, source->pminmax, N, B, (const double*)d_r,
+                     (uint64_t)0x5EED5A3Full, i, beta, target->d_indices, (float*)source->col[CRUX_COL_WEIGHT]);
+  crux_prof_end(c, CRUX_PROF_PER_SEARCH);
+  rc = crux_launch_check(c, "k_per_search"); if (rc) return rc;
+  return gather_into(target, source, B, true);
 }
+
 int32_t crux_uniform_sample(crux_buffer* target, crux_buffer* source, int64_t B, const int64_t* ids, uint64_t i) {
-  (void)source; (void)B; (void)ids; (void)i;
-  return crux_fail(target ? target->ctx : nullptr, CRUX_EUNSUP, "uniform_sample!: device kernel not built yet");
+  if (!target || !source) return CRUX_EINVAL;
+  crux_ctx* c = target->ctx;
+  const int64_t N = source->elements;
+  if (N <= 0 || B <= 0 || B > target->capacity) return crux_fail(c, CRUX_EINVAL, "uniform_sample!: N=%lld B=%lld capacity=%lld", (long long)N, (long long)B, (long long)target->capacity);
+  if (target->obs_dim != source->obs_dim || target->act_dim != source->act_dim || target->act_kind != source->act_kind) return crux_fail(c, CRUX_EINVAL, "uniform_sample!: column shapes differ");
+  if (ids) { for (int64_t j = 0; j < B; ++j) if (ids[j] < 0 || ids[j] >= N) return crux_fail(c, CRUX_EINVAL, "uniform_sample!: id %lld out of range", (long long)ids[j]);
+    HIPCHK(c, hipMemcpyAsync(target->d_indices, ids, 8 * (size_t)B, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+  else hipLaunchKernelGGL(k_uniform_ids, dim3(gridn(B)), dim3(256), 0, c->stream, N, B, (uint64_t)0x5EED5A3Full, i, target->d_indices);
+  return gather_into(target, source, B, true);
 }
+
 int32_t crux_per_get(crux_buffer* b, float* priorities, float* max_priority, float* min_priority, float* cumsum) {
   if (!b) return CRUX_EINVAL;
   crux_ctx* c = b->ctx;
   if (!b->prioritized) return crux_fail(c, CRUX_EINVAL, "buffer is not prioritized");
-  if (cumsum) return crux_fail(c, CRUX_EUNSUP, "cumsum: device scan not built yet");
+  if (cumsum && b->elements > 0) { int32_t rc = ensure_cumsum(b, b->elements); if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(cumsum, b->cumsum, 4 * (size_t)b->elements, hipMemcpyDeviceToHost, c->stream)); }
   float mm[2];
   HIPCHK(c, hipMemcpyAsync(mm, b->pminmax, 8, hipMemcpyDeviceToHost, c->stream));
   if (priorities) HIPCHK(c, hipMemcpyAsync(priorities, b->priorities, 4 * (size_t)b->capacity, hipMemcpyDeviceToHost, c->stream));
@@ -23,4 +242,5 @@ int32_t crux_per_get(crux_buffer* b, float* priorities, float* max_priority, flo
   if (max_priority) *max_priority = mm[0]; if (min_priority) *min_priority = mm[1];
   return CRUX_OK;
 }
-}
+
+}  // extern "C"

@@ -371,3 +371,66 @@ def test_full_size_iteration_properties(gpu_ctx):
     assert inf["actor_batches_trained"] == 2 * 512 and np.array_equal(key(buf), before)      # shuffles only permute rows
     assert np.isfinite(pi.A.get_params()).all() and not np.array_equal(p0, pi.A.get_params())
     assert 0.55 < inf["entropy"] <= np.log(2) + 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------- replay sampling
+@pytest.mark.parametrize("N", [1, 5, 127, 128, 129, 1000, 100_003, 1_000_000])
+def test_pairwise_cumsum_is_bit_exact(gpu_ctx, N):
+    rng = np.random.default_rng(N)
+    b = crux.ExperienceBuffer(crux.ContinuousSpace(1), crux.DiscreteSpace(2), N, prioritized=True)
+    a = np.zeros((2, N), bool); a[0] = True
+    b.push_({"s": np.zeros((1, N), np.float32), "a": a, "sp": np.zeros((1, N), np.float32), "r": np.zeros((1, N), np.float32), "done": np.zeros((1, N), bool)})
+    v = (np.abs(rng.standard_normal(N)) + 1e-3).astype(np.float32)
+    b.update_priorities_(np.arange(1, N + 1), v)
+    pr = b.priority_params()["priorities"]; ref = np.empty(N, np.float32)
+    O.lib().orc_pairwise_cumsum_f32(O.vpz(pr), N, O.vpz(ref))
+    assert np.array_equal(b.cumsum(), ref)
+
+
+@pytest.mark.parametrize("N,B", [(6, 1000), (5000, 128), (200_000, 128), (1_000_000, 128)])
+def test_prioritized_sample_matches_oracle(gpu_ctx, N, B):
+    rng = np.random.default_rng(N + B)
+    od, ad = 8, 4
+    src_g = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.DiscreteSpace(ad), N, prioritized=True); src_o = O.OBuffer(od, ad, L.ACTION_DISCRETE, N, prioritized=True, alpha=np.float32(0.6))
+    d = _rand_data(rng, N, od, ad, True); src_g.push_(d); src_o.push(d)
+    v = (np.abs(rng.standard_normal(N)) + 1e-3)                      # Float64 values, like the reference's test (:246)
+    I = np.arange(1, N + 1)
+    src_g.update_priorities_(I, v); I0 = np.ascontiguousarray(I - 1); O.chk(O.lib().orc_per_update(src_o.h, O.vpz(I0), O.vpz(v), 1, N))
+    tg = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.DiscreteSpace(ad), B, ["weight"]); to = O.OBuffer(od, ad, L.ACTION_DISCRETE, B, ["weight"])
+    for it, rands in enumerate([rng.random(B), None]):
+        ids_g = crux.prioritized_sample_(tg, src_g, B=B, i=it + 1, rands=rands)
+        O.chk(O.lib().orc_per_sample(to.h, src_o.h, B, O.vpz(rands) if rands is not None else None, 0.5, it + 1, crux.api.SAMPLE_SEED))
+        ids_o = np.empty(B, np.int64); O.chk(O.lib().orc_buffer_indices(to.h, O.vpz(ids_o), B))
+        assert np.array_equal(ids_g - 1, ids_o)                                            # bit-exact indices
+        for k in ("s", "a", "sp", "r", "done"):
+            assert np.array_equal(tg[k], to[k]), k
+        wg, wo = src_g["weight"][0], src_o["weight"][0]
+        assert np.abs(wg - wo).max() <= 4e-7 * max(1.0, wo.max()) and (wg[ids_o] <= 1 + 1e-6).all()
+        assert np.abs(tg["weight"] - to["weight"]).max() <= 4e-7
+    if N == 6:     # test/experience_buffer_tests.jl:246-262: stratified frequencies follow the priorities within 1 %
+        pr = src_g.priority_params()["priorities"][:N].astype(np.float64)
+        ids = crux.prioritized_sample_(tg, src_g, B=B, i=3)
+        freqs = np.bincount(ids - 1, minlength=N) / B
+        assert (np.abs(freqs - pr / pr.sum()) / (pr / pr.sum()) < 0.01).all()
+
+
+def test_uniform_sample_and_rand(gpu_ctx):
+    rng = np.random.default_rng(3); od, ad, N = 2, 4, 500
+    src_g = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.DiscreteSpace(ad), N); src_o = O.OBuffer(od, ad, L.ACTION_DISCRETE, N)
+    d = _rand_data(rng, N, od, ad, True); src_g.push_(d); src_o.push(d)
+    tg = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.DiscreteSpace(ad), 64); to = O.OBuffer(od, ad, L.ACTION_DISCRETE, 64)
+    ids = rng.integers(1, N + 1, 64)
+    got = crux.uniform_sample_(tg, src_g, ids=ids)                        # test/experience_buffer_tests.jl:214-222 with explicit ids
+    assert np.array_equal(got, ids) and np.array_equal(tg["s"], src_g["s"][:, ids - 1])
+    got = crux.uniform_sample_(tg, src_g, i=7)
+    O.chk(O.lib().orc_uniform_sample(to.h, src_o.h, 64, None, 7, crux.api.SAMPLE_SEED))
+    ids_o = np.empty(64, np.int64); O.chk(O.lib().orc_buffer_indices(to.h, O.vpz(ids_o), 64))
+    assert np.array_equal(got - 1, ids_o) and np.array_equal(tg["sp"], to["sp"]) and (got >= 1).all() and (got <= N).all()
+    # multi-source rand! fill order 4/3/3 (test/experience_buffer_tests.jl:224-242)
+    bufs = []
+    for val in (1.0, 2.0, 3.0):
+        t = crux.ExperienceBuffer(crux.ContinuousSpace(2), crux.DiscreteSpace(4), 10)
+        t.push_({"s": val * np.ones((2, 1)), "a": np.ones((4, 1), bool), "sp": np.ones((2, 1)), "r": np.ones((1, 1)), "done": np.zeros((1, 1))}); bufs.append(t)
+    t = crux.ExperienceBuffer(crux.ContinuousSpace(2), crux.DiscreteSpace(4), 10)
+    crux.rand_(t, *bufs)
+    s = t["s"]; assert (s[:, :4] == 1).all() and (s[:, 4:7] == 2).all() and (s[:, 7:] == 3).all()
