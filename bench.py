@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sync", action="store_true", help="exercise the multi-GPU parameter exchange even at world size 1 (testing)")
     ap.add_argument("--early-stop", action="store_true", help="also time the KL-early-stopping variant (target_kl=0.012)")
     args = ap.parse_args()
 
@@ -118,9 +119,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     dist = torch = None
-    if world > 1:
+    if world > 1 or args.force_sync:
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -135,7 +138,7 @@ def main():
     c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=BATCH, epochs=EPOCHS, name="critic_", shuffle_seed=200 + rank)
 
     sync = None
-    if world > 1:
+    if world > 1 or args.force_sync:
         wrapped = {}
 
         def sync(net):   # average parameters and Adam moments across ranks (RCCL all-reduce over xGMI)
@@ -146,16 +149,18 @@ def main():
                     class _I:
                         __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
                     return torch.as_tensor(_I(), device="cuda:%d" % local)
-                wrapped[id(net)] = wrap(lib.crux_mlp_params_ptr(net.h))
-            ctx.sync()
-            t = wrapped[id(net)]
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            t.mul_(1.0 / world)
+                pm, pv = C.c_void_p(), C.c_void_p()
+                ctx.check(lib.crux_adam_state_ptrs(net.h, C.byref(pm), C.byref(pv)))
+                wrapped[id(net)] = [wrap(lib.crux_mlp_params_ptr(net.h)), wrap(pm.value), wrap(pv.value)]
+            ctx.sync()                                   # the library's stream produced the values
+            for t in wrapped[id(net)]:                   # tensors alias library memory: RCCL reads/writes it in place
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                t.mul_(1.0 / world)
             torch.cuda.current_stream().synchronize()
 
     def barrier():
         ctx.sync()
-        if world > 1:
+        if dist is not None:
             dist.barrier(); torch.cuda.synchronize()
 
     it = 0
@@ -171,7 +176,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ctx.prof_enable(False)
-    if world > 1:
+    if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dt = float(tmax.item())
         gs = torch.tensor([grad_steps], dtype=torch.float64, device="cuda"); dist.all_reduce(gs); grad_steps = int(gs.item())
 
@@ -215,7 +220,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -56,6 +56,7 @@ SIGNATURES = {
     "crux_adam_init": (i32, [vp, f64, f64, f64, f64]),
     "crux_adam_get_state": (i32, [vp, vp, vp, vp]),
     "crux_adam_set_state": (i32, [vp, vp, vp, vp]),
+    "crux_adam_state_ptrs": (i32, [vp, P(vp), P(vp)]),
     "crux_buffer_create": (i32, [vp, i32, i32, i32, i64, u32, i32, f32, P(vp)]),
     "crux_buffer_destroy": (i32, [vp]),
     "crux_buffer_len": (i64, [vp]),

@@ -198,6 +198,8 @@ int32_t crux_adam_set_state(crux_mlp* n, const float* m, const float* v, const d
   return CRUX_OK;
 }
 
+int32_t crux_adam_state_ptrs(crux_mlp* n, float** d_m, float** d_v) { if (!n) return CRUX_EINVAL; if (d_m) *d_m = n->m; if (d_v) *d_v = n->v; return CRUX_OK; }
+
 int32_t crux_adam_apply(crux_mlp* n, float grad_scale) {
   if (!n) return CRUX_EINVAL;
   if (!n->has_adam) return crux_fail(n->ctx, CRUX_EINVAL, "adam_apply: crux_adam_init was not called");

@@ -90,6 +90,8 @@ int32_t crux_polyak(crux_mlp* to, const crux_mlp* from, float tau);
 int32_t crux_adam_init(crux_mlp* net, double eta, double beta1, double beta2, double eps);
 int32_t crux_adam_get_state(crux_mlp* net, float* m_host, float* v_host, double* beta_pow /*2*/);
 int32_t crux_adam_set_state(crux_mlp* net, const float* m_host, const float* v_host, const double* beta_pow);
+/* device pointers to the moment vectors (replica averaging in the multi-GPU path). */
+int32_t crux_adam_state_ptrs(crux_mlp* net, float** d_m, float** d_v);
 
 /* experience buffer ------------------------------------------------------------------------------
  * replaces mdp_data / ExperienceBuffer (src/experience_buffer.jl:4-35,53-80). Columns are separate
