@@ -55,9 +55,11 @@ def ppo_iteration(crux, pi, buf, sampler, a_opt, c_opt, P, it, sync=None):
     info = crux.steps_(sampler, buf, Nsteps=buf.capacity, explore=True, i=it * buf.capacity, reset=True)
     crux.whiten_(buf, "advantage")
     if sync is None:
-        ai = crux.batch_train_(pi.A, a_opt, P, buf)
-        ci = crux.batch_train_(pi.C, c_opt, P, buf)
-        return ai["actor_batches_trained"] + ci["critic_batches_trained"], info
+        class _S:       # the fields policy_gradient_training reads from an OnPolicySolver
+            pass
+        sv = _S(); sv.agent = crux.PolicyParams(pi); sv.a_opt, sv.c_opt, sv.P = a_opt, c_opt, P
+        ti = crux.policy_gradient_training(sv, buf)            # on_policy.jl:56-78 (actor then critic; overlapped when exact)
+        return ti["actor_batches_trained"] + ti["critic_batches_trained"], info
     # multi-GPU: one persistent launch per epoch, parameters + Adam moments averaged between epochs
     nb = 0
     for net, opt, key in ((pi.A, a_opt, "actor_"), (pi.C, c_opt, "critic_")):

@@ -93,6 +93,7 @@ SIGNATURES = {
     "crux_fill_returns": (i32, [vp, f32]),
     "crux_whiten": (i32, [vp, i32]),
     "crux_batch_train": (i32, [vp, vp, P(TrainCfg), vp, vp, vp]),
+    "crux_policy_gradient_training": (i32, [vp, vp, vp, P(TrainCfg), P(TrainCfg), vp, vp, vp, vp, vp, vp]),
     "crux_train_step": (i32, [vp, vp, P(TrainCfg), vp, i64, vp]),
     "crux_loss_grad": (i32, [vp, vp, P(TrainCfg), vp, i64, vp]),
     "crux_loss_grad_device_ids": (i32, [vp, vp, P(TrainCfg), vp, i64, vp]),

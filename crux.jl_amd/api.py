@@ -778,12 +778,26 @@ class OnPolicySolver:
         self.buffer, self.sampler, self.history = None, None, []
 
 
-def policy_gradient_training(solver, D):
-    """policy_gradient_training(S, D) (src/model_free/on_policy.jl:56-78): actor batch_train!, then critic."""
+def policy_gradient_training(solver, D, perms_a=None, perms_c=None):
+    """policy_gradient_training(S, D) (src/model_free/on_policy.jl:56-78): actor batch_train!, then critic batch_train!.
+    One C call: the two persistent learner kernels overlap on two CUs whenever that is exact (see cruxhip.h)."""
     info = {}
-    batch_train_(actor(solver.agent.pi), solver.a_opt, solver.P, D, info=info)
-    if solver.c_opt is not None:
-        batch_train_(critic(solver.agent.pi), solver.c_opt, solver.P, D, info=info)
+    A, Cn, pa, pc = actor(solver.agent.pi), critic(solver.agent.pi), solver.a_opt, solver.c_opt
+    if pc is None:
+        return batch_train_(A, pa, solver.P, D, info=info, perms=perms_a)
+    _ensure_opt(A, pa); _ensure_opt(Cn, pc)
+    ca, cc = _train_cfg(A, pa, solver.P), _train_cfg(Cn, pc, solver.P)
+    ra, rc_ = np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32)
+    ea, ec = np.zeros((pa.epochs, L.INFO_N), np.float32), np.zeros((pc.epochs, L.INFO_N), np.float32)
+    p1 = None if perms_a is None else np.ascontiguousarray(np.asarray(perms_a, np.int64) - 1)
+    p2 = None if perms_c is None else np.ascontiguousarray(np.asarray(perms_c, np.int64) - 1)
+    A.ctx.check(A.ctx.lib.crux_policy_gradient_training(A.h, Cn.h, D.h, C.byref(ca), C.byref(cc), _vp(p1), _vp(p2), _vp(ra), _vp(rc_), _vp(ea), _vp(ec)))
+    for p, raw in ((pa, ra), (pc, rc_)):
+        p.shuffle_counter += int(raw[L.INFO["epochs_run"]])
+        d = _info_dict(p, raw)
+        if p is pc:
+            d = {k: v for k, v in d.items() if k.startswith(p.name)}
+        info.update(d); info[p.name + "batches_trained"] = int(raw[L.INFO["batches_trained"]])
     return info
 
 

@@ -129,7 +129,8 @@ int32_t crux_buffer_create(crux_ctx* ctx, int32_t obs_dim, int32_t act_dim, int3
   }
   b->prioritized = prioritized != 0; b->alpha = alpha;
   if (hipMalloc(&b->d_indices, sizeof(int64_t) * (size_t)capacity) != hipSuccess || hipMalloc(&b->order_a, 4 * (size_t)capacity) != hipSuccess ||
-      hipMalloc(&b->order_b, 4 * (size_t)capacity) != hipSuccess) { crux_buffer_destroy(b); return crux_fail(ctx, CRUX_ENOMEM, "buffer_create: index arrays"); }
+      hipMalloc(&b->order_b, 4 * (size_t)capacity) != hipSuccess ||
+      hipMalloc(&b->order_c, 4 * (size_t)capacity) != hipSuccess || hipMalloc(&b->order_d, 4 * (size_t)capacity) != hipSuccess) { crux_buffer_destroy(b); return crux_fail(ctx, CRUX_ENOMEM, "buffer_create: index arrays"); }
   if (b->prioritized) {
     if (hipMalloc(&b->priorities, 4 * (size_t)capacity) != hipSuccess || hipMalloc(&b->cumsum, 4 * (size_t)capacity) != hipSuccess ||
         hipMalloc(&b->pminmax, 8) != hipSuccess) { crux_buffer_destroy(b); return crux_fail(ctx, CRUX_ENOMEM, "buffer_create: priorities"); }
@@ -148,6 +149,7 @@ int32_t crux_buffer_destroy(crux_buffer* b) {
   for (int k = 0; k < CRUX_NCOLS; ++k) if (b->col[k]) (void)hipFree(b->col[k]);
   if (b->priorities) (void)hipFree(b->priorities); if (b->cumsum) (void)hipFree(b->cumsum); if (b->pminmax) (void)hipFree(b->pminmax);
   if (b->d_indices) (void)hipFree(b->d_indices); if (b->order_a) (void)hipFree(b->order_a); if (b->order_b) (void)hipFree(b->order_b);
+  if (b->order_c) (void)hipFree(b->order_c); if (b->order_d) (void)hipFree(b->order_d);
   delete b; return CRUX_OK;
 }
 

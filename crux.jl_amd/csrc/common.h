@@ -25,6 +25,7 @@ struct crux_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   void* scratch = nullptr; size_t scratch_bytes = 0;   // reusable device scratch
   void* pinned = nullptr; size_t pinned_bytes = 0;     // reusable pinned host staging
+  hipStream_t aux_stream = nullptr; hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr;   // second learner stream (actor || critic)
 };
 
 int32_t crux_fail(crux_ctx* ctx, int32_t code, const char* fmt, ...);
@@ -86,6 +87,8 @@ struct crux_buffer {
   float* topo_total = nullptr; float* topo_prefix = nullptr;
   int32_t* order_a = nullptr;    // device [capacity] logical->physical order scratch for batch_train
   int32_t* order_b = nullptr;
+  int32_t* order_c = nullptr;    // second pair for the concurrent critic learner
+  int32_t* order_d = nullptr;
 };
 
 static inline int col_elem(const crux_buffer* b, int k) {

@@ -84,6 +84,7 @@ int32_t crux_ctx_destroy(crux_ctx* c) {
   for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->aux_ev0); (void)hipEventDestroy(c->aux_ev1); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return CRUX_OK;

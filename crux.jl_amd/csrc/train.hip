@@ -9,7 +9,7 @@
 #include "train_args.h"
 
 int32_t crux_buffer_apply_order(crux_buffer* b, const int32_t* d_order, int64_t n);
-int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled);
+int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream);
 
 #define TR_CH 32
 #define EPS32F 1.1920928955078125e-07f
@@ -47,6 +47,16 @@ __global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
 
   const int n_epochs = a.ids ? 1 : a.epochs;
   if (!a.ids) { for (int64_t j = tid; j < a.len; j += 256) order_cur[j] = (int32_t)j; __syncthreads(); }
+  if (!a.ids && a.pre_epochs > 0) {
+    __syncthreads();
+    for (int pe = 0; pe < a.pre_epochs; ++pe) {
+      if (a.pre_perms) { for (int64_t j = tid; j < a.len; j += 256) order_nxt[j] = order_cur[a.pre_perms[(int64_t)pe * a.len + j]]; }
+      else { const crux_perm pp = crux_perm_make(a.pre_seed, a.pre_counter + (uint64_t)pe, 0, (uint32_t)a.len);
+        for (int64_t j = tid; j < a.len; j += 256) order_nxt[j] = order_cur[crux_perm_at(&pp, (uint32_t)j)]; }
+      __syncthreads();
+      int32_t* t = order_cur; order_cur = order_nxt; order_nxt = t;
+    }
+  }
 
   for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
     if (!a.ids) {
@@ -230,19 +240,21 @@ static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const cr
   return CRUX_OK;
 }
 
-static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot) {
+static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_t stream = nullptr) {
   bool handled = false;
-  crux_prof_begin(c, prof_slot);
-  int32_t rc = crux_train_mfma_launch(c, a, &handled);
+  if (!stream) stream = c->stream;
+  const bool prof = stream == c->stream;      // HIP-event timing is kept on the context's main stream
+  if (prof) crux_prof_begin(c, prof_slot);
+  int32_t rc = crux_train_mfma_launch(c, a, &handled, stream);
   if (!handled) {
     const size_t lds = generic_lds_bytes(a.nd);
     if (lds > 160 * 1024 - 64) return crux_fail(c, CRUX_EUNSUP, "train!: network too wide for the generic learner kernel (%zu B of LDS)", lds);
     static size_t attr_set = 0;
     if (lds > 64 * 1024 && lds > attr_set) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = lds; }
-    hipLaunchKernelGGL(k_train_generic, dim3(1), dim3(256), lds, c->stream, a);
+    hipLaunchKernelGGL(k_train_generic, dim3(1), dim3(256), lds, stream, a);
     rc = crux_launch_check(c, "k_train_generic");
   }
-  crux_prof_end(c, prof_slot);
+  if (prof) crux_prof_end(c, prof_slot);
   return rc;
 }
 
@@ -332,6 +344,72 @@ int32_t crux_loss_grad_device_ids(crux_mlp* net, crux_buffer* buf, const crux_tr
   if (!sc) return crux_fail(c, CRUX_ENOMEM, "loss_grad: scratch");
   a.status = (int32_t*)sc; a.epoch_infos = d_info ? d_info : (float*)(sc + 256);
   return launch_train(c, a, a.loss == CRUX_LOSS_PPO ? CRUX_PROF_TRAIN_ACTOR : CRUX_PROF_TRAIN_CRITIC);
+}
+
+// policy_gradient_training (src/model_free/on_policy.jl:56-78): batch_train!(actor) then batch_train!(critic) on the same buffer.
+// The two learners touch disjoint parameters, so when the actor's epoch count is known in advance (no KL early stopping, no
+// max_batches) they run CONCURRENTLY as two persistent kernels on two CUs: the critic kernel first composes the actor's epoch
+// shuffles into its starting order (TrainArgs.pre_*), which reproduces exactly the row order it would see after the actor.
+static int32_t collect(crux_ctx* c, const TrainArgs& a, int n_epochs, float* info_out, float* epoch_infos, int32_t* st_out) {
+  const size_t eb = sizeof(float) * CRUX_INFO_N * (size_t)n_epochs;
+  int32_t st[4]; std::vector<float> ei((size_t)CRUX_INFO_N * (size_t)n_epochs);
+  HIPCHK(c, hipMemcpyAsync(st, a.status, sizeof st, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(ei.data(), a.epoch_infos, eb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (info_out) {
+    for (int q = 0; q < CRUX_INFO_N; ++q) { double s = 0; for (int e = 0; e < st[2]; ++e) s += (double)ei[(size_t)e * CRUX_INFO_N + q]; info_out[q] = st[2] ? (float)(s / (double)st[2]) : 0.f; }
+    info_out[CRUX_INFO_BATCHES_TRAINED] = (float)st[1]; info_out[CRUX_INFO_EPOCHS_RUN] = (float)st[2];
+  }
+  if (epoch_infos) memcpy(epoch_infos, ei.data(), sizeof(float) * CRUX_INFO_N * (size_t)st[2]);
+  memcpy(st_out, st, sizeof st);
+  return CRUX_OK;
+}
+
+extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* critic, crux_buffer* buf, const crux_train_cfg* cfg_a, const crux_train_cfg* cfg_c,
+                                                 const int64_t* perms_a, const int64_t* perms_c, float* info_a, float* info_c, float* epoch_infos_a, float* epoch_infos_c) {
+  if (!actor || !critic || !buf || !cfg_a || !cfg_c) return CRUX_EINVAL;
+  crux_ctx* c = actor->ctx;
+  const bool exact = cfg_a->target_kl < 0.f && cfg_a->max_batches <= 0 && !getenv("CRUX_SEQUENTIAL_LEARNERS");
+  if (!exact) {
+    int32_t rc = crux_batch_train(actor, buf, cfg_a, perms_a, info_a, epoch_infos_a); if (rc) return rc;
+    return crux_batch_train(critic, buf, cfg_c, perms_c, info_c, epoch_infos_c);
+  }
+  if (buf->elements <= 0 || cfg_a->epochs < 1 || cfg_c->epochs < 1) return crux_fail(c, CRUX_EINVAL, "policy_gradient_training: empty buffer or epochs < 1");
+  if (!c->aux_stream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev1, hipEventDisableTiming));
+  }
+  TrainArgs a, k; int32_t rc = fill_args(a, actor, buf, cfg_a, cfg_a->loss); if (rc) return rc;
+  rc = fill_args(k, critic, buf, cfg_c, cfg_c->loss); if (rc) return rc;
+  const int64_t len = buf->elements;
+  const size_t ea = sizeof(float) * CRUX_INFO_N * (size_t)cfg_a->epochs, ec = sizeof(float) * CRUX_INFO_N * (size_t)cfg_c->epochs;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t pa = perms_a ? al(8 * (size_t)cfg_a->epochs * (size_t)len) : 0, pc = perms_c ? al(8 * (size_t)cfg_c->epochs * (size_t)len) : 0;
+  char* sc = (char*)crux_scratch(c, 512 + al(ea) + al(ec) + pa + pc + 256);
+  if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_gradient_training: scratch");
+  a.status = (int32_t*)sc; k.status = (int32_t*)(sc + 256); a.epoch_infos = (float*)(sc + 512); k.epoch_infos = (float*)(sc + 512 + al(ea));
+  HIPCHK(c, hipMemsetAsync(sc, 0, 512 + al(ea) + al(ec), c->stream));
+  int64_t* d_pa = nullptr; int64_t* d_pc = nullptr;
+  if (perms_a) { d_pa = (int64_t*)(sc + 512 + al(ea) + al(ec)); for (int64_t i = 0; i < (int64_t)cfg_a->epochs * len; ++i) if (perms_a[i] < 0 || perms_a[i] >= len) return crux_fail(c, CRUX_EINVAL, "perms_a[%lld] out of range", (long long)i);
+    HIPCHK(c, hipMemcpyAsync(d_pa, perms_a, 8 * (size_t)cfg_a->epochs * (size_t)len, hipMemcpyHostToDevice, c->stream)); }
+  if (perms_c) { d_pc = (int64_t*)(sc + 512 + al(ea) + al(ec) + pa); for (int64_t i = 0; i < (int64_t)cfg_c->epochs * len; ++i) if (perms_c[i] < 0 || perms_c[i] >= len) return crux_fail(c, CRUX_EINVAL, "perms_c[%lld] out of range", (long long)i);
+    HIPCHK(c, hipMemcpyAsync(d_pc, perms_c, 8 * (size_t)cfg_c->epochs * (size_t)len, hipMemcpyHostToDevice, c->stream)); }
+  a.perms = d_pa; k.perms = d_pc;
+  k.order_a = buf->order_c; k.order_b = buf->order_d;
+  k.pre_epochs = cfg_a->epochs; k.pre_seed = cfg_a->shuffle_seed; k.pre_counter = cfg_a->shuffle_counter; k.pre_perms = d_pa;
+  HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
+  rc = launch_train(c, k, CRUX_PROF_TRAIN_CRITIC, c->aux_stream); if (rc) return rc;
+  HIPCHK(c, hipEventRecord(c->aux_ev1, c->aux_stream));
+  rc = launch_train(c, a, CRUX_PROF_TRAIN_ACTOR); if (rc) return rc;
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
+  int32_t sta[4], stc[4];
+  rc = collect(c, a, cfg_a->epochs, info_a, epoch_infos_a, sta); if (rc) return rc;
+  rc = collect(c, k, cfg_c->epochs, info_c, epoch_infos_c, stc); if (rc) return rc;
+  if (sta[0] == CRUX_ENAN || stc[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
+  if (sta[0] || stc[0]) return crux_fail(c, sta[0] ? sta[0] : stc[0], "learner kernel reported status %d/%d", sta[0], stc[0]);
+  // the critic's final order already contains the actor's shuffles: one physical permutation leaves the buffer as the reference would
+  return crux_buffer_apply_order(buf, stc[3] ? buf->order_d : buf->order_c, len);
 }
 
 // ---- off-policy pieces ------------------------------------------------------------------------------

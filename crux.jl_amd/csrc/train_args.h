@@ -17,6 +17,9 @@ struct TrainArgs {
   int64_t len;
   int32_t* order_a; int32_t* order_b;
   const int64_t* perms;      // device [epochs x len] or NULL
+  // shuffles that a PRECEDING batch_train! applied to the same buffer (actor before critic, on_policy.jl:65-69): composed into
+  // the starting order so this learner can run concurrently with the preceding one and still see the reference's row order
+  int32_t pre_epochs; uint64_t pre_seed, pre_counter; const int64_t* pre_perms;
   const int32_t* ids;        // device explicit rows (single-step mode) or NULL
   int64_t n_ids;
   int32_t apply;             // 1: Adam update after each minibatch

@@ -193,6 +193,16 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
   float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
   const int n_epochs = a.ids ? 1 : a.epochs;
   if (!a.ids) { for (int64_t j = tid; j < a.len; j += 256) order_cur[j] = (int32_t)j; }
+  if (!a.ids && a.pre_epochs > 0) {
+    __syncthreads();
+    for (int pe = 0; pe < a.pre_epochs; ++pe) {
+      if (a.pre_perms) { for (int64_t j = tid; j < a.len; j += 256) order_nxt[j] = order_cur[a.pre_perms[(int64_t)pe * a.len + j]]; }
+      else { const crux_perm pp = crux_perm_make(a.pre_seed, a.pre_counter + (uint64_t)pe, 0, (uint32_t)a.len);
+        for (int64_t j = tid; j < a.len; j += 256) order_nxt[j] = order_cur[crux_perm_at(&pp, (uint32_t)j)]; }
+      __syncthreads();
+      int32_t* t = order_cur; order_cur = order_nxt; order_nxt = t;
+    }
+  }
   __syncthreads();
   const int64_t total_rows = a.ids ? a.n_ids : a.len;
 
@@ -553,17 +563,17 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
 
 // ---- dispatch ---------------------------------------------------------------------------------------------------
 template <int IN, int OUT, int KIND, int ACT, bool TIMING = false>
-static int32_t launch_one(crux_ctx* c, const TrainArgs& a) {
+static int32_t launch_one(crux_ctx* c, const TrainArgs& a, hipStream_t stream) {
   using Lt = MfLayout<IN, OUT>;
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
   static_assert(lds <= 160 * 1024, "LDS budget exceeded");
   static bool attr = false;
   if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<IN, OUT, KIND, ACT, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-  hipLaunchKernelGGL((k_train_mfma<IN, OUT, KIND, ACT, TIMING>), dim3(1), dim3(256), lds, c->stream, a);
+  hipLaunchKernelGGL((k_train_mfma<IN, OUT, KIND, ACT, TIMING>), dim3(1), dim3(256), lds, stream, a);
   return crux_launch_check(c, "k_train_mfma");
 }
 
-int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled) {
+int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream) {
   *handled = false;
   const NetDesc& nd = a.nd;
   if (getenv("CRUX_FORCE_GENERIC")) return CRUX_OK;
@@ -580,14 +590,14 @@ int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled) {
     static unsigned long long* dbg = nullptr;
     if (!dbg) { if (hipMalloc(&dbg, 64 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
     TrainArgs b = a; b.dbg = dbg; *handled = true;
-    int32_t rc = launch_one<4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU, true>(c, b); if (rc) return rc;
-    unsigned long long h[64]; HIPCHK(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+    int32_t rc = launch_one<4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU, true>(c, b, stream); if (rc) return rc;
+    unsigned long long h[64]; HIPCHK(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, stream)); HIPCHK(c, hipStreamSynchronize(stream));
     static const char* nm[12] = {"loop+prefetch", "stage", "fwdL1+T1", "fwdL2", "L3+head", "dW3+dZ2+stats", "T2+dH1", "dZ1+db+dW1", "barrier-wait", "dW2", "small-reduce", "info+adam"};
     for (int w = 0; w < 4; ++w) { fprintf(stderr, "[mfma-timing] wave %d:", w); unsigned long long tot = 0; for (int k = 0; k < 12; ++k) tot += h[w * 16 + k];
       for (int k = 0; k < 12; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[w * 16 + k] / (double)tot); fprintf(stderr, " total=%llu cyc\n", tot); }
     return CRUX_OK;
   }
-#define MF_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_one<I, O, K, A_>(c, a); }
+#define MF_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_one<I, O, K, A_>(c, a, stream); }
   MF_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)
   MF_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)
 #undef MF_CASE

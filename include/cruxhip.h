@@ -241,6 +241,14 @@ enum { CRUX_INFO_LOSS = 0, CRUX_INFO_GRAD_NORM = 1, CRUX_INFO_ENTROPY = 2, CRUX_
 int32_t crux_batch_train(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int64_t* perms,
                          float* info_out, float* epoch_infos);
 
+/* policy_gradient_training(S, D) (src/model_free/on_policy.jl:56-78): batch_train!(actor) then batch_train!(critic) on one
+ * buffer. Results are those of the sequential reference order; when the actor's epoch count is fixed in advance (target_kl < 0,
+ * no max_batches) the two persistent learner kernels run concurrently on two CUs (the critic composes the actor's shuffles
+ * into its starting order), otherwise they run back to back. */
+int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* critic, crux_buffer* buf, const crux_train_cfg* cfg_actor,
+                                      const crux_train_cfg* cfg_critic, const int64_t* perms_actor, const int64_t* perms_critic,
+                                      float* info_actor, float* info_critic, float* epoch_infos_actor, float* epoch_infos_critic);
+
 /* train!(pi, loss, p) (training.jl:13-25): one gradient step on explicit rows `ids` (host, 0-based)
  * of the buffer. Returns CRUX_ENAN (without updating) when the grad norm is NaN (:20).            */
 int32_t crux_train_step(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids,

@@ -65,7 +65,7 @@ def compare_buffers(gb, ob, keys=None, atol=2e-5, rtol=1e-4):
     return out
 
 
-def ppo_iteration_parity(n_envs=4, T=64, batch_size=32, epochs=2, seed=3, max_steps=50, target_kl=-1.0, gamma=0.99, lam=0.95):
+def ppo_iteration_parity(n_envs=4, T=64, batch_size=32, epochs=2, seed=3, max_steps=50, target_kl=-1.0, gamma=0.99, lam=0.95, pair=False):
     """One full PPO iteration (rollout -> GAE/returns -> whiten -> actor batch_train! -> critic batch_train!) on the GPU
     and in the oracle with the same Philox-defined randomness; returns the differences."""
     N = n_envs * T
@@ -94,15 +94,22 @@ def ppo_iteration_parity(n_envs=4, T=64, batch_size=32, epochs=2, seed=3, max_st
     a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=batch_size, epochs=epochs, target_kl=None if target_kl < 0 else target_kl, name="actor_", shuffle_seed=seed + 100)
     c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=batch_size, epochs=epochs, name="critic_", shuffle_seed=seed + 200)
     oa.adam_init(float(np.float32(3e-4))); oc.adam_init(float(np.float32(3e-4)))
-    gi = crux.batch_train_(ga, a_opt, P, gb)
+    if pair:      # one call for actor + critic (policy_gradient_training): concurrent learner kernels when exact
+        class _S:
+            pass
+        sv = _S(); sv.agent = crux.PolicyParams(pi); sv.a_opt, sv.c_opt, sv.P = a_opt, c_opt, P
+        gi = crux.policy_gradient_training(sv, gb); gi2 = gi
+    else:
+        gi = crux.batch_train_(ga, a_opt, P, gb)
     oinfo = np.zeros(L.INFO_N, np.float32)
     cfg_a = train_cfg("ppo", "categorical", batch_size, epochs, target_kl, seed + 100)
     O.chk(O.lib().orc_batch_train(oa.h, ob.h, C.byref(cfg_a), None, O.vpz(oinfo), None))
     res["actor_param_maxdiff"] = float(np.abs(ga.get_params() - oa.params).max())
     res["actor_info"] = {k: (gi.get(k if k in gi else "actor_" + k), float(oinfo[L.INFO[k]])) for k in ("loss", "grad_norm", "kl", "entropy")}
     res["actor_batches"] = (gi["actor_batches_trained"], int(oinfo[L.INFO["batches_trained"]]))
-    res["order_after_actor"] = compare_buffers(gb, ob, ["s", "a", "advantage"])
-    gi2 = crux.batch_train_(gc, c_opt, P, gb)
+    if not pair:
+        res["order_after_actor"] = compare_buffers(gb, ob, ["s", "a", "advantage"])
+        gi2 = crux.batch_train_(gc, c_opt, P, gb)
     oinfo2 = np.zeros(L.INFO_N, np.float32)
     cfg_c = train_cfg("value_mse", "deterministic", batch_size, epochs, -1.0, seed + 200)
     O.chk(O.lib().orc_batch_train(oc.h, ob.h, C.byref(cfg_c), None, O.vpz(oinfo2), None))
@@ -114,6 +121,9 @@ def ppo_iteration_parity(n_envs=4, T=64, batch_size=32, epochs=2, seed=3, max_st
     ok &= res["whiten"]["advantage"] < 2e-4
     ok &= res["actor_param_maxdiff"] < 2e-4 and res["critic_param_maxdiff"] < 2e-4
     ok &= res["actor_batches"][0] == res["actor_batches"][1]
-    ok &= res["order_after_actor"]["a"] == 0 and res["order_after_actor"]["s"] < 2e-5
+    res["order_after_critic"] = compare_buffers(gb, ob, ["s", "a", "advantage"])
+    ok &= res["order_after_critic"]["a"] == 0 and res["order_after_critic"]["s"] < 2e-5
+    if not pair:
+        ok &= res["order_after_actor"]["a"] == 0 and res["order_after_actor"]["s"] < 2e-5
     res["ok"] = bool(ok)
     return res
