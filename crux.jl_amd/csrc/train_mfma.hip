@@ -208,7 +208,9 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
 
   // ---- minibatch prefetch (HBM/L2 -> registers) and staging (registers -> this wave's LDS tiles) ----------------
   constexpr int NXL = (32 * IN + 63) / 64;
-  float px[NXL]; float p_lp = 0.f, p_adv = 0.f, p_ret = 0.f; float p_act[NACT]; int p_valid = 0;
+  float px[NXL]; float p_lp = 0.f, p_adv = 0.f, p_ret = 0.f; float p_act[NACT]; int p_valid = 0; uint8_t p_abyte[OUT];
+#pragma unroll
+  for (int k = 0; k < OUT; ++k) p_abyte[k] = 0;
 #pragma unroll
   for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
   int n_row = 0, n_valid = 0;   // row index / validity of this lane's sample in the NEXT-to-be-fetched minibatch
@@ -231,10 +233,9 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
     if (lane < 32 && p_valid) {
       if (KIND != MFK_VALUE) { p_lp = a.LP[row]; p_adv = a.ADV[row]; }
       p_ret = a.RET ? a.RET[row] : 0.f;
-      if (KIND == MFK_CATEGORICAL) { const uint8_t* av = (const uint8_t*)a.A + row * OUT; int ai = 0;
-#pragma unroll
-        for (int k = 0; k < OUT; ++k) ai = av[k] ? k : ai;
-        p_act[0] = (float)ai; }
+      if (KIND == MFK_CATEGORICAL) { const uint8_t* av = (const uint8_t*)a.A + row * OUT;   // raw one-hot bytes; decoded in stage() so that
+#pragma unroll                                                                              // nothing here waits on a load
+        for (int k = 0; k < OUT; ++k) p_abyte[k] = av[k]; }
       if (KIND == MFK_GAUSSIAN) { const float* av = (const float*)a.A + row * OUT;
 #pragma unroll
         for (int k = 0; k < OUT; ++k) p_act[k] = av[k]; }
@@ -243,6 +244,10 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
   auto stage = [&]() {
 #pragma unroll
     for (int e = 0; e < NXL; ++e) { const int el = lane + 64 * e; const int s = el / IN, f = el - s * IN; if (el < 32 * IN) xs[s * XP + f] = px[e]; }
+    if (KIND == MFK_CATEGORICAL) { int ai = 0;
+#pragma unroll
+      for (int k = 0; k < OUT; ++k) ai = p_abyte[k] ? k : ai;
+      p_act[0] = (float)ai; }
     if (lane < 32) { float* q = sc + lane * Lt::SCW; q[0] = (float)p_valid; q[1] = p_lp; q[2] = p_adv; q[3] = p_ret;
 #pragma unroll
       for (int k = 0; k < NACT; ++k) q[4 + k] = p_act[k]; }
@@ -262,7 +267,8 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
     for (int64_t st = 0; st < total_rows; st += a.bs) {
       const int nb = (int)((total_rows - st) < a.bs ? (total_rows - st) : a.bs);
       const float invB = 1.0f / (float)nb;
-      ak.c1 = (float)(1.0 / (1.0 - bp1)); ak.c2 = (float)(1.0 / (1.0 - bp2));   // bias corrections of THIS step (independent of the data)
+      // bias corrections of THIS step: 1 - beta^t in Float64 (one multiply per step), reciprocal on the f32 unit (1 ulp)
+      ak.c1 = __builtin_amdgcn_rcpf((float)(1.0 - bp1)); ak.c2 = __builtin_amdgcn_rcpf((float)(1.0 - bp2));
       MF_T(0);
       stage();
       if (st + a.bs < total_rows) fetch_data();    // rows of minibatch t+1 (their indices were loaded during step t-1)
@@ -340,18 +346,20 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
         if (KIND == MFK_VALUE) {
           const float d = z[0][n] - R; dz[0][n] = valid ? 2.f * d * invB : 0.f; s_sq += cnt * d * d; s_ret += cnt * R;
         } else if (KIND == MFK_CATEGORICAL) {
+          // softmax / log / exp through the hardware transcendental units (v_exp_f32, v_log_f32, v_rcp_f32: ~1 ulp); arguments are
+          // O(1) so the absolute error stays < 1e-6, inside the fp32 loss tolerance of the parity tests (1e-4 rel)
           const int ai = (int)q[4];
           float mx = z[0][n];
 #pragma unroll
           for (int k = 1; k < OUT; ++k) mx = fmaxf(mx, z[k][n]);
           float pk[OUT], hk[OUT]; float sum = 0.f;
 #pragma unroll
-          for (int k = 0; k < OUT; ++k) { pk[k] = expf(z[k][n] - mx); sum += pk[k]; }
-          const float inv = 1.f / sum; float pa = 0.f, H = 0.f, hp = 0.f;
+          for (int k = 0; k < OUT; ++k) { pk[k] = __expf(z[k][n] - mx); sum += pk[k]; }
+          const float inv = __builtin_amdgcn_rcpf(sum); float pa = 0.f, H = 0.f, hp = 0.f;
 #pragma unroll
-          for (int k = 0; k < OUT; ++k) { pk[k] *= inv; pa = (k == ai) ? pk[k] : pa; const float lg = logf(pk[k] + EPS32F); H -= pk[k] * lg;
-            hk[k] = -lg - pk[k] / (pk[k] + EPS32F); hp += hk[k] * pk[k]; }
-          const float newlp = logf(pa); const float r = expf(newlp - oldlp);
+          for (int k = 0; k < OUT; ++k) { pk[k] *= inv; pa = (k == ai) ? pk[k] : pa; const float pe = pk[k] + EPS32F; const float lg = __logf(pe); H -= pk[k] * lg;
+            hk[k] = -lg - pk[k] * __builtin_amdgcn_rcpf(pe); hp += hk[k] * pk[k]; }
+          const float newlp = __logf(pa); const float r = __expf(newlp - oldlp);
           const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
 #pragma unroll
           for (int k = 0; k < OUT; ++k) { const float dlogpi = ((k == ai) ? 1.f : 0.f) - pk[k];
