@@ -88,9 +88,24 @@ struct MfLayout {
   static constexpr int sW1 = 0, sB1 = MF_HID * IN, sB2 = sB1 + MF_HID, sW3 = sB2 + MF_HID, sB3 = sW3 + MF_HID * OUT, sEX = sB3 + OUT, NS = sEX + 16;
   // canonical (Flux.params) offsets
   static constexpr int cW1 = 0, cB1 = MF_HID * IN, cW2 = cB1 + MF_HID, cB2 = cW2 + MF_HID * MF_HID, cW3 = cB2 + MF_HID, cB3 = cW3 + MF_HID * OUT, cEX = cB3 + OUT;
+  // per-wave small partial gradients
+  static constexpr int W1ROWS = IP < 16 * JT ? IP : 16 * JT;  // rows of the dW1 partial that are kept (inputs 0..IP-1)
+  static constexpr int pW1 = 0;                               // [i < W1ROWS][o] stride MF_LD
+  static constexpr int pB1 = pW1 + W1ROWS * MF_LD;
+  static constexpr int pB2 = pB1 + MF_HID;
+  static constexpr int pW3 = pB2 + MF_HID;                    // [o][i]
+  static constexpr int pMISC = pW3 + OUT * MF_HID;            // [48]: 7 stat sums, then db3[OUT], then dlogSigma[OUT]
+  static constexpr int pST = pMISC, pB3 = pMISC + 7, pEX = pB3 + OUT;
+  static constexpr int PART = ((pMISC + 48 + 3) / 4) * 4;
+  static constexpr int NSP = ((NS + 3) / 4) * 4;
+  // everything except the optional row-major copy of W2
+  static constexpr int BASE = MF_HID * MF_LD + MF_HID * IP + 2 * MF_HID + OUT * MF_HID + 32 + 4 + 2 * NSP + 8 * MF_HID * MF_TLD + 4 * PART + 4 * 32 * XP + 4 * 32 * SCW + 16;
+  // W2 is kept in two LDS layouts when it fits in the CU's 160 KB: W2R[o][i] gives the forward A fragments with b128 reads; without
+  // it they are gathered from W2C with b32 reads (same values, 4x the read instructions).
+  static constexpr bool HAS_W2R = BASE + MF_HID * MF_LD <= 40960;
   // LDS masters
   static constexpr int oW2R = 0;                              // W2R[o][i]
-  static constexpr int oW2C = oW2R + MF_HID * MF_LD;          // W2C[i][o]
+  static constexpr int oW2C = oW2R + (HAS_W2R ? MF_HID * MF_LD : 0);   // W2C[i][o]
   static constexpr int oW1R = oW2C + MF_HID * MF_LD;          // W1R[o][i<IP]
   static constexpr int oB1 = oW1R + MF_HID * IP;
   static constexpr int oB2 = oB1 + MF_HID;
@@ -98,23 +113,16 @@ struct MfLayout {
   static constexpr int oB3 = oW3R + OUT * MF_HID;
   static constexpr int oEX = oB3 + 16;
   static constexpr int oMS = ((oEX + 16 + 3) / 4) * 4;        // Adam moments of the small parameters
-  static constexpr int oVS = oMS + ((NS + 3) / 4) * 4;
+  static constexpr int oVS = oMS + NSP;
   // exchange tiles, one pair per wave
-  static constexpr int oT1 = oVS + ((NS + 3) / 4) * 4;        // H1  [f][s]
+  static constexpr int oT1 = oVS + NSP;                       // H1  [f][s]
   static constexpr int oT2 = oT1 + 4 * MF_HID * MF_TLD;       // dZ2 [f][s]
-  // per-wave small partial gradients
-  static constexpr int pW1 = 0;                               // [i < 16*JT][o] stride MF_LD
-  static constexpr int pB1 = pW1 + 16 * JT * MF_LD;
-  static constexpr int pB2 = pB1 + MF_HID;
-  static constexpr int pW3 = pB2 + MF_HID;                    // [o][i]
-  static constexpr int pMISC = pW3 + OUT * MF_HID;            // [48]: 7 stat sums, then db3[OUT], then dlogSigma[OUT]
-  static constexpr int pST = pMISC, pB3 = pMISC + 7, pEX = pB3 + OUT;
-  static constexpr int PART = ((pMISC + 48 + 3) / 4) * 4;
   static constexpr int oPART = oT2 + 4 * MF_HID * MF_TLD;
   static constexpr int oXS = oPART + 4 * PART;                // 4 x [32][XP] minibatch observations
   static constexpr int oSC = oXS + 4 * 32 * XP;               // 4 x [32][SCW] per-sample scalars
   static constexpr int oRED = oSC + 4 * 32 * SCW;
   static constexpr int TOTAL = oRED + 16;
+  static_assert(TOTAL <= 40960, "LDS budget (160 KB) exceeded");
 };
 
 template <int IN, int OUT, int KIND, int ACT, bool TIMING = false>
@@ -169,7 +177,8 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
 
   // ---- load parameters and Adam state --------------------------------------------------------------------------
   for (int q = tid; q < MF_HID * MF_HID; q += 256) { const int o = q & 63, i = q >> 6; const float v = a.p[Lt::cW2 + q];
-    sm[Lt::oW2R + o * MF_LD + i] = v; sm[Lt::oW2C + i * MF_LD + o] = v; }
+    if (Lt::HAS_W2R) sm[Lt::oW2R + o * MF_LD + i] = v;
+    sm[Lt::oW2C + i * MF_LD + o] = v; }
   for (int q = tid; q < MF_HID * IP; q += 256) sm[Lt::oW1R + q] = 0.f;
   if (tid < 16) { sm[Lt::oB3 + tid] = 0.f; sm[Lt::oEX + tid] = 0.f; }
   __syncthreads();
@@ -309,7 +318,11 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
       for (int mp = 0; mp < 4; ++mp) { const f32x4 b = *(const f32x4*)&sm[Lt::oB2 + 16 * mp + 4 * g];
         f32x4 acc0 = b, acc1 = b;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { const f32x4 wv = *(const f32x4*)&sm[Lt::oW2R + (16 * mp + c) * MF_LD + 16 * m + 4 * g];
+        for (int m = 0; m < 4; ++m) { f32x4 wv;
+          if (Lt::HAS_W2R) wv = *(const f32x4*)&sm[Lt::oW2R + (16 * mp + c) * MF_LD + 16 * m + 4 * g];
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wv[r] = sm[Lt::oW2C + (16 * m + 4 * g + r) * MF_LD + 16 * mp + c]; }
 #pragma unroll
           for (int r = 0; r < 4; ++r) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[r], h1[m][0][r], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[r], h1[m][1][r], acc1, 0, 0, 0); } }
@@ -458,7 +471,7 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
           for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1r[n][m][r], xR[n][r], acc, 0, 0, 0);
-          *(f32x4*)&part[Lt::pW1 + (16 * jt + c) * MF_LD + 16 * m + 4 * g] = acc; }   // D reg r <-> [o=16m+4g+r][i=16jt+c]
+          if (16 * jt + c < Lt::W1ROWS) *(f32x4*)&part[Lt::pW1 + (16 * jt + c) * MF_LD + 16 * m + 4 * g] = acc; }   // D reg r <-> [o=16m+4g+r][i=16jt+c]
       }
       MF_T(7);
       __syncthreads();   // ---- B_a: all tiles and small partials are visible
@@ -520,7 +533,7 @@ __global__ __launch_bounds__(256, 1) void k_train_mfma(TrainArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { float mm = mW2[m][r], vv = vW2[m][r]; const float d = adam1(gW2[m][r], mm, vv, ak);
             mW2[m][r] = mm; vW2[m][r] = vv; tW2[m][r] -= d;
-            sm[Lt::oW2R + (16 * w + 4 * g + r) * MF_LD + 16 * m + c] = tW2[m][r]; }
+            if (Lt::HAS_W2R) sm[Lt::oW2R + (16 * w + 4 * g + r) * MF_LD + 16 * m + c] = tW2[m][r]; }
           *(f32x4*)&sm[Lt::oW2C + (16 * m + c) * MF_LD + 16 * w + 4 * g] = tW2[m]; }
 #pragma unroll
         for (int k = 0; k < NSI; ++k) { const int s = tid + 256 * k;
@@ -574,7 +587,6 @@ template <int IN, int OUT, int KIND, int ACT, bool TIMING = false>
 static int32_t launch_one(crux_ctx* c, const TrainArgs& a, hipStream_t stream) {
   using Lt = MfLayout<IN, OUT>;
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
-  static_assert(lds <= 160 * 1024, "LDS budget exceeded");
   static bool attr = false;
   if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<IN, OUT, KIND, ACT, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
   hipLaunchKernelGGL((k_train_mfma<IN, OUT, KIND, ACT, TIMING>), dim3(1), dim3(256), lds, stream, a);
@@ -606,8 +618,14 @@ int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, h
     return CRUX_OK;
   }
 #define MF_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_one<I, O, K, A_>(c, a, stream); }
-  MF_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)
-  MF_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)
+  MF_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)     // C2 actor  (PPO CartPole)
+  MF_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)           // C2 critic
+  MF_CASE(17, 6, MFK_GAUSSIAN, CRUX_ACT_RELU)       // C5 actor  (PPO HalfCheetah-shaped, 17 obs / 6 act)
+  MF_CASE(17, 6, MFK_GAUSSIAN, CRUX_ACT_TANH)
+  MF_CASE(17, 1, MFK_VALUE, CRUX_ACT_RELU)          // C5 critic
+  MF_CASE(17, 1, MFK_VALUE, CRUX_ACT_TANH)
+  MF_CASE(3, 1, MFK_GAUSSIAN, CRUX_ACT_RELU)        // Pendulum actor
+  MF_CASE(3, 1, MFK_VALUE, CRUX_ACT_RELU)           // Pendulum critic
 #undef MF_CASE
   return CRUX_OK;
 }

@@ -238,12 +238,14 @@ def _train_pair(dims, acts, kind, n, od, ad, rng, n_extra=0):
 
 
 @pytest.mark.parametrize("force_generic", [False, True])
-@pytest.mark.parametrize("kind,dims,n,bs", [("categorical", [4, 64, 64, 2], 128, 128), ("categorical", [4, 64, 64, 2], 100, 37), ("value", [4, 64, 64, 1], 128, 128),
-                                             ("value", [4, 64, 64, 1], 77, 77), ("categorical", [6, 32, 5], 64, 64), ("gaussian", [17, 64, 64, 6], 96, 96)])
-def test_train_step_and_loss_grad_match_oracle(gpu_ctx, monkeypatch, force_generic, kind, dims, n, bs):
+@pytest.mark.parametrize("kind,dims,n,bs,act", [("categorical", [4, 64, 64, 2], 128, 128, "relu"), ("categorical", [4, 64, 64, 2], 100, 37, "relu"), ("value", [4, 64, 64, 1], 128, 128, "relu"),
+                                                 ("value", [4, 64, 64, 1], 77, 77, "relu"), ("categorical", [6, 32, 5], 64, 64, "relu"), ("gaussian", [17, 64, 64, 6], 96, 96, "relu"),
+                                                 ("gaussian", [17, 64, 64, 6], 128, 128, "tanh"), ("value", [17, 64, 64, 1], 128, 128, "tanh"), ("value", [17, 64, 64, 1], 50, 50, "relu"),
+                                                 ("gaussian", [3, 64, 64, 1], 128, 128, "relu"), ("value", [3, 64, 64, 1], 64, 64, "relu")])
+def test_train_step_and_loss_grad_match_oracle(gpu_ctx, monkeypatch, force_generic, kind, dims, n, bs, act):
     if force_generic:
         monkeypatch.setenv("CRUX_FORCE_GENERIC", "1")
-    rng = np.random.default_rng(7); acts = ["relu"] * (len(dims) - 2) + ["identity"]
+    rng = np.random.default_rng(7); acts = [act] * (len(dims) - 2) + ["identity"]
     od, ad = dims[0], (dims[-1] if kind != "value" else 2)
     g, o, gb, ob = _train_pair(dims, acts, kind if kind != "value" else "continuous", n, od, ad, rng, n_extra=dims[-1] if kind == "gaussian" else 0)
     loss = crux.value_mse_loss if kind == "value" else crux.ppo_loss
