@@ -74,6 +74,165 @@ struct RolloutArgs {
   crux_rollout_cfg cfg;
 };
 
+// Everything of step! after the policy forward (sampler.jl:73-136): action + logprob from the head, env transition, column writes,
+// episode bookkeeping. `writer` lanes store to the buffer; all callers advance identical copies of the sampler state.
+__device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* z, const int od, const int ad, const int nout, const int kind, const int e,
+                                             const int64_t t, const int64_t j, const bool writer, double* st, int64_t& ep_len, int64_t& n_resets,
+                                             int64_t& steps_taken, double& sum_r, int64_t& nee, float* next_obs) {
+  const int sd = kind == CRUX_ENV_CARTPOLE ? 4 : 2;
+      const uint64_t gi = a.cfg.i0 + (uint64_t)t * (uint64_t)a.E + (uint64_t)e;    // i + (j-1), env-minor (sampler.jl:161-163)
+      const uint64_t ctr = (uint64_t)steps_taken;
+      float logprob = NAN; int ai = 0; float aout[ENV_MAXOBS];
+      if (a.cfg.head == CRUX_HEAD_CATEGORICAL || a.cfg.head == CRUX_HEAD_GREEDY_Q) {
+        int greedy = 0; for (int q = 1; q < nout; ++q) if (z[q] > z[greedy]) greedy = q;
+        if (!a.cfg.explore) ai = greedy;
+        else if (a.cfg.eps_steps > 0 || a.cfg.head == CRUX_HEAD_GREEDY_Q) {
+          const double eps = a.cfg.eps_steps > 0 ? linear_decay(a.cfg.eps_start, a.cfg.eps_stop, a.cfg.eps_steps, (int64_t)gi) : 0.0;
+          const crux_u32x4 x = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_ACTION);
+          const double u = crux_u32x2_to_f64(x.v[0], x.v[1]);
+          if (u < eps) { const crux_u32x4 y = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_RANDACT); ai = (int)(((uint64_t)y.v[0] * (uint64_t)nout) >> 32); }
+          else ai = greedy;
+          logprob = (float)log(eps * (1.0 / (double)nout) + (1.0 - eps));
+        } else {
+          float pr[ENV_MAXOBS];
+          float mx = z[0]; for (int q = 1; q < nout; ++q) mx = z[q] > mx ? z[q] : mx;
+          float sum = 0.f; for (int q = 0; q < nout; ++q) { pr[q] = expf(z[q] - mx); sum = __fadd_rn(sum, pr[q]); }
+          for (int q = 0; q < nout; ++q) pr[q] = __fdiv_rn(pr[q], sum);
+          const crux_u32x4 x = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_ACTION);
+          const float draw = crux_u32_to_f32(x.v[0]);
+          float cp = pr[0]; ai = 0; while (cp <= draw && ai < nout - 1) { ai += 1; cp = __fadd_rn(cp, pr[ai]); }
+          logprob = logf(pr[ai]);
+        }
+        for (int q = 0; q < ad; ++q) aout[q] = (q == ai) ? 1.f : 0.f;
+      } else if (a.cfg.head == CRUX_HEAD_GAUSSIAN) {
+        const float* ls = a.p + a.nd.xoff; float lp = 0.f;
+        for (int q = 0; q < ad; ++q) {
+          const float mu = z[q];
+          if (a.cfg.explore) { const float sg = expf(ls[q]);
+            const float epsn = randn_f32(a.seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)e, q & 1);
+            aout[q] = __fadd_rn(__fmul_rn(epsn, sg), mu); const float s2 = __fmul_rn(sg, sg); const float dd = __fsub_rn(aout[q], mu);
+            lp = __fadd_rn(lp, __fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(dd, dd), __fmul_rn(2.f, s2)), 0.9189385332046727f), ls[q])); }
+          else aout[q] = mu;
+        }
+        logprob = a.cfg.explore ? lp : NAN;
+      } else {
+        for (int q = 0; q < ad; ++q) { float av = z[q];
+          if (a.cfg.explore && a.cfg.noise_sigma >= 0.f) {
+            float n0 = __fmul_rn(randn_f32(a.seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)e, q & 1), a.cfg.noise_sigma);
+            n0 = n0 < a.cfg.noise_eps_min ? a.cfg.noise_eps_min : n0 > a.cfg.noise_eps_max ? a.cfg.noise_eps_max : n0; av = __fadd_rn(av, n0);
+            av = av < a.cfg.a_min ? a.cfg.a_min : av > a.cfg.a_max ? a.cfg.a_max : av; }
+          aout[q] = av; }
+      }
+      // ---- env transition (sampler.jl:93-97)
+      double sn[ENV_MAXSD]; float r; uint8_t done; float o[ENV_MAXOBS], spv[ENV_MAXOBS];
+      if (kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done); else pendulum_step(st, aout[0], sn, &r, &done);
+      env_obs(kind, sn, o);
+      for (int q = 0; q < od; ++q) spv[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
+      // ---- column writes (sampler.jl:101-107)
+      if (writer) {
+        if (a.act_kind == CRUX_ACTION_DISCRETE) { uint8_t* A = (uint8_t*)a.A + (size_t)j * ad; for (int q = 0; q < ad; ++q) A[q] = aout[q] != 0.f; }
+        else { float* A = (float*)a.A + (size_t)j * ad; for (int q = 0; q < ad; ++q) A[q] = aout[q]; }
+        for (int q = 0; q < od; ++q) a.SP[(size_t)j * od + q] = spv[q];
+        a.R[j] = r; a.D[j] = done;
+        if (a.LP) a.LP[j] = logprob;
+        if (a.TT) a.TT[j] = ep_len + 1;
+        if (a.II) a.II[j] = (int64_t)gi + 1;
+        if (a.W) a.W[j] = 1.0f;
+        if (a.RET) a.RET[j] = 0.f;
+        if (a.ADV) a.ADV[j] = 0.f;
+      }
+      sum_r += (double)r; steps_taken += 1;
+      // ---- episode bookkeeping (sampler.jl:130-136; terminate_episode! :53-69)
+      ep_len += 1;
+      uint8_t ee = 0;
+      if (done || ep_len >= a.max_steps) {
+        ee = 1; ++nee;
+        env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st); n_resets += 1; ep_len = 0;
+        env_obs(kind, st, o);
+        for (int q = 0; q < od; ++q) next_obs[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
+      } else {
+        for (int i = 0; i < sd; ++i) st[i] = sn[i];
+        for (int q = 0; q < od; ++q) next_obs[q] = spv[q];
+      }
+      if (a.cfg.reset_at_end && t == a.T - 1 && ep_len > 0) {                       // sampler.jl:148
+        ee = 1; ++nee;
+        env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st); n_resets += 1; ep_len = 0;
+        env_obs(kind, st, o);
+        for (int q = 0; q < od; ++q) next_obs[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
+      }
+      if (writer) a.EE[j] = ee;
+}
+
+
+// ---- register-resident policy for the IN-64-64-OUT family ------------------------------------------------------------------------
+// One wave per environment. Lane j keeps row j of W1/W2 and column j of W3 in VGPRs for the whole rollout; every lane carries an
+// identical copy of the sampler state (Float64 dynamics, Philox draws and the head are evaluated redundantly), so the only
+// cross-lane traffic per step is the broadcast of H1 (64 floats through LDS) and one wave reduction per output.
+template <int CTRL> __device__ __forceinline__ float env_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float env_wave_sum_uniform(float v) {      // the same bits in every lane (readfirstlane of one reduction order)
+  v += env_dpp<0x128>(v); v += env_dpp<0x124>(v); v += env_dpp<0x122>(v); v += env_dpp<0x121>(v);     // row_ror 8,4,2,1: row totals
+  float a0 = v, b0 = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(b0));
+  a0 = a0 + b0; b0 = a0;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(b0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a0 + b0)));
+}
+template <int IN, int OUT, int ACT, int KIND>
+__global__ __launch_bounds__(64) void k_rollout_h64(RolloutArgs a) {
+  __shared__ __attribute__((aligned(16))) float sh[64];
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const NetDesc& nd = a.nd;
+  constexpr int SD = KIND == CRUX_ENV_CARTPOLE ? 4 : 2;
+  float w1[IN], w2[64], w3[OUT], b3[OUT];
+#pragma unroll
+  for (int k = 0; k < IN; ++k) w1[k] = a.p[nd.woff[0] + lane + 64 * k];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) w2[k] = a.p[nd.woff[1] + lane + 64 * k];
+#pragma unroll
+  for (int o = 0; o < OUT; ++o) { w3[o] = a.p[nd.woff[2] + o + OUT * lane]; b3[o] = a.p[nd.boff[2] + o]; }
+  const float b1 = a.p[nd.boff[0] + lane], b2 = a.p[nd.boff[1] + lane];
+  double st[ENV_MAXSD]; float x[IN], nx[ENV_MAXOBS];
+#pragma unroll
+  for (int i = 0; i < SD; ++i) st[i] = a.state[(size_t)e * SD + i];
+  int64_t ep_len = a.ep_len[e], n_resets = a.n_resets[e], steps_taken = a.steps_taken[e]; double sum_r = 0.0; int64_t nee = 0;
+#pragma unroll
+  for (int k = 0; k < IN; ++k) x[k] = a.svec[(size_t)e * IN + k];
+  for (int64_t t = 0; t < a.T; ++t) {
+    const int64_t j = (a.base + (int64_t)e * a.T + t) % a.C;
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < IN; ++k) a.S[(size_t)j * IN + k] = x[k];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < IN; ++k) acc = fmaf(w1[k], x[k], acc);
+    sh[lane] = crux_act(ACT, acc + b1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    acc = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) { const float4 hv = *(const float4*)&sh[4 * k4];
+      acc = fmaf(w2[4 * k4], hv.x, acc); acc = fmaf(w2[4 * k4 + 1], hv.y, acc); acc = fmaf(w2[4 * k4 + 2], hv.z, acc); acc = fmaf(w2[4 * k4 + 3], hv.w, acc); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const float h2 = crux_act(ACT, acc + b2);
+    float z[OUT];
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) z[o] = env_wave_sum_uniform(w3[o] * h2) + b3[o];
+    rollout_tail(a, z, IN, OUT, OUT, KIND, e, t, j, lane == 0, st, ep_len, n_resets, steps_taken, sum_r, nee, nx);
+#pragma unroll
+    for (int k = 0; k < IN; ++k) x[k] = nx[k];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < SD; ++i) a.state[(size_t)e * SD + i] = st[i];
+    a.ep_len[e] = ep_len; a.n_resets[e] = n_resets; a.steps_taken[e] = steps_taken;
+    a.acc[2 * e] = sum_r; a.acc[2 * e + 1] = (double)nee;
+#pragma unroll
+    for (int k = 0; k < IN; ++k) a.svec[(size_t)e * IN + k] = x[k];
+  }
+}
+
 // one wave (64 lanes) per environment; lanes split the output units of each Dense layer, lane 0 runs the
 // head, the dynamics and the bookkeeping. Environments never synchronise with each other.
 __global__ __launch_bounds__(64) void k_rollout(RolloutArgs a) {
@@ -107,88 +266,7 @@ __global__ __launch_bounds__(64) void k_rollout(RolloutArgs a) {
       cur ^= 1;
     }
     // (the observation in hbuf[0] was already stored to the S column, so the ping-pong may overwrite it)
-    if (lane == 0) {
-      const float* z = hbuf[cur];
-      const uint64_t gi = a.cfg.i0 + (uint64_t)t * (uint64_t)a.E + (uint64_t)e;    // i + (j-1), env-minor (sampler.jl:161-163)
-      const uint64_t ctr = (uint64_t)steps_taken;
-      float logprob = NAN; int ai = 0; float aout[ENV_MAXOBS];
-      if (a.cfg.head == CRUX_HEAD_CATEGORICAL || a.cfg.head == CRUX_HEAD_GREEDY_Q) {
-        int greedy = 0; for (int q = 1; q < nout; ++q) if (z[q] > z[greedy]) greedy = q;
-        if (!a.cfg.explore) ai = greedy;
-        else if (a.cfg.eps_steps > 0 || a.cfg.head == CRUX_HEAD_GREEDY_Q) {
-          const double eps = a.cfg.eps_steps > 0 ? linear_decay(a.cfg.eps_start, a.cfg.eps_stop, a.cfg.eps_steps, (int64_t)gi) : 0.0;
-          const crux_u32x4 x = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_ACTION);
-          const double u = crux_u32x2_to_f64(x.v[0], x.v[1]);
-          if (u < eps) { const crux_u32x4 y = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_RANDACT); ai = (int)(((uint64_t)y.v[0] * (uint64_t)nout) >> 32); }
-          else ai = greedy;
-          logprob = (float)log(eps * (1.0 / (double)nout) + (1.0 - eps));
-        } else {
-          float pr[ENV_MAXOBS];
-          float mx = z[0]; for (int q = 1; q < nout; ++q) mx = z[q] > mx ? z[q] : mx;
-          float sum = 0.f; for (int q = 0; q < nout; ++q) { pr[q] = expf(z[q] - mx); sum = __fadd_rn(sum, pr[q]); }
-          for (int q = 0; q < nout; ++q) pr[q] = __fdiv_rn(pr[q], sum);
-          const crux_u32x4 x = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_ACTION);
-          const float draw = crux_u32_to_f32(x.v[0]);
-          float cp = pr[0]; ai = 0; while (cp <= draw && ai < nout - 1) { ai += 1; cp = __fadd_rn(cp, pr[ai]); }
-          logprob = logf(pr[ai]);
-        }
-        for (int q = 0; q < ad; ++q) aout[q] = (q == ai) ? 1.f : 0.f;
-      } else if (a.cfg.head == CRUX_HEAD_GAUSSIAN) {
-        const float* ls = a.p + nd.xoff; float lp = 0.f;
-        for (int q = 0; q < ad; ++q) {
-          const float mu = z[q];
-          if (a.cfg.explore) { const float sg = expf(ls[q]);
-            const float epsn = randn_f32(a.seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)e, q & 1);
-            aout[q] = __fadd_rn(__fmul_rn(epsn, sg), mu); const float s2 = __fmul_rn(sg, sg); const float dd = __fsub_rn(aout[q], mu);
-            lp = __fadd_rn(lp, __fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(dd, dd), __fmul_rn(2.f, s2)), 0.9189385332046727f), ls[q])); }
-          else aout[q] = mu;
-        }
-        logprob = a.cfg.explore ? lp : NAN;
-      } else {
-        for (int q = 0; q < ad; ++q) { float av = z[q];
-          if (a.cfg.explore && a.cfg.noise_sigma >= 0.f) {
-            float n0 = __fmul_rn(randn_f32(a.seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)e, q & 1), a.cfg.noise_sigma);
-            n0 = n0 < a.cfg.noise_eps_min ? a.cfg.noise_eps_min : n0 > a.cfg.noise_eps_max ? a.cfg.noise_eps_max : n0; av = __fadd_rn(av, n0);
-            av = av < a.cfg.a_min ? a.cfg.a_min : av > a.cfg.a_max ? a.cfg.a_max : av; }
-          aout[q] = av; }
-      }
-      // ---- env transition (sampler.jl:93-97)
-      double sn[ENV_MAXSD]; float r; uint8_t done; float o[ENV_MAXOBS], spv[ENV_MAXOBS];
-      if (a.kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done); else pendulum_step(st, aout[0], sn, &r, &done);
-      env_obs(a.kind, sn, o);
-      for (int q = 0; q < od; ++q) spv[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
-      // ---- column writes (sampler.jl:101-107)
-      if (a.act_kind == CRUX_ACTION_DISCRETE) { uint8_t* A = (uint8_t*)a.A + (size_t)j * ad; for (int q = 0; q < ad; ++q) A[q] = aout[q] != 0.f; }
-      else { float* A = (float*)a.A + (size_t)j * ad; for (int q = 0; q < ad; ++q) A[q] = aout[q]; }
-      for (int q = 0; q < od; ++q) a.SP[(size_t)j * od + q] = spv[q];
-      a.R[j] = r; a.D[j] = done;
-      if (a.LP) a.LP[j] = logprob;
-      if (a.TT) a.TT[j] = ep_len + 1;
-      if (a.II) a.II[j] = (int64_t)gi + 1;
-      if (a.W) a.W[j] = 1.0f;
-      if (a.RET) a.RET[j] = 0.f;
-      if (a.ADV) a.ADV[j] = 0.f;
-      sum_r += (double)r; steps_taken += 1;
-      // ---- episode bookkeeping (sampler.jl:130-136; terminate_episode! :53-69)
-      ep_len += 1;
-      uint8_t ee = 0;
-      if (done || ep_len >= a.max_steps) {
-        ee = 1; ++nee;
-        env_draw_initial(a.kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st); n_resets += 1; ep_len = 0;
-        env_obs(a.kind, st, o);
-        for (int q = 0; q < od; ++q) sh_misc[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
-      } else {
-        for (int i = 0; i < a.sd; ++i) st[i] = sn[i];
-        for (int q = 0; q < od; ++q) sh_misc[q] = spv[q];
-      }
-      if (a.cfg.reset_at_end && t == a.T - 1 && ep_len > 0) {                       // sampler.jl:148
-        ee = 1; ++nee;
-        env_draw_initial(a.kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st); n_resets += 1; ep_len = 0;
-        env_obs(a.kind, st, o);
-        for (int q = 0; q < od; ++q) sh_misc[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
-      }
-      a.EE[j] = ee;
-    }
+    if (lane == 0) rollout_tail(a, hbuf[cur], od, ad, nout, a.kind, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
     __syncthreads();
     if (lane < od) hbuf[0][lane] = sh_misc[lane];
     __syncthreads();
@@ -315,6 +393,14 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
   a.RET = has_col(buf, CRUX_COL_RETURN) ? (float*)buf->col[CRUX_COL_RETURN] : nullptr; a.ADV = has_col(buf, CRUX_COL_ADVANTAGE) ? (float*)buf->col[CRUX_COL_ADVANTAGE] : nullptr;
   a.base = buf->next_ind; a.C = buf->capacity; a.T = T; a.cfg = *cfg;
   crux_prof_begin(c, CRUX_PROF_ROLLOUT);
+  const NetDesc& pn = policy->nd;
+  const bool h64 = pn.L == 3 && pn.dims[1] == 64 && pn.dims[2] == 64 && pn.acts[0] == pn.acts[1] && pn.acts[2] == CRUX_ACT_IDENTITY && !getenv("CRUX_FORCE_GENERIC");
+#define RO_CASE(I, O, A_, K) if (h64 && pn.dims[0] == I && nout == O && pn.acts[0] == A_ && e->kind == K) hipLaunchKernelGGL((k_rollout_h64<I, O, A_, K>), dim3(e->n_envs), dim3(64), 0, c->stream, a); else
+  RO_CASE(4, 2, CRUX_ACT_RELU, CRUX_ENV_CARTPOLE)
+  RO_CASE(4, 2, CRUX_ACT_TANH, CRUX_ENV_CARTPOLE)
+  RO_CASE(3, 1, CRUX_ACT_RELU, CRUX_ENV_PENDULUM)
+  RO_CASE(3, 1, CRUX_ACT_TANH, CRUX_ENV_PENDULUM)
+#undef RO_CASE
   hipLaunchKernelGGL(k_rollout, dim3(e->n_envs), dim3(64), 0, c->stream, a);
   crux_prof_end(c, CRUX_PROF_ROLLOUT);
   int32_t rc = crux_launch_check(c, "k_rollout"); if (rc) return rc;

@@ -142,9 +142,9 @@ def test_device_dynamics_match_recordings(gpu_ctx):
 
 
 # ---------------------------------------------------------------------------------------------------- rollouts
-def _rollout_pair(kind, head, n_envs, T, cap, extras, explore=True, reset=True, seed=4, max_steps=40, eps=None, noise=None, gext=0):
+def _rollout_pair(kind, head, n_envs, T, cap, extras, explore=True, reset=True, seed=4, max_steps=40, eps=None, noise=None, gext=0, hidden=32):
     od, ad, disc = (4, 2, True) if kind == "cartpole" else (3, 1, False)
-    dims = [od, 32, 32, ad]
+    dims = [od, hidden, hidden, ad]
     if head == "gaussian":
         g, o = parity.make_pair(dims, ["tanh", "tanh", "identity"], seed, 0, "gaussian", n_extra=ad, extra_init=-0.5)
     elif disc:
@@ -165,22 +165,23 @@ def _rollout_pair(kind, head, n_envs, T, cap, extras, explore=True, reset=True, 
     return g, o, gb, ob, gs, oe, cfg
 
 
+@pytest.mark.parametrize("hidden", [32, 64])      # 64 -> register-resident k_rollout_h64, 32 -> generic k_rollout
 @pytest.mark.parametrize("case", ["ppo_cartpole", "greedy_eval", "eps_greedy_offpolicy", "pendulum_gaussian", "pendulum_noise"])
-def test_rollout_matches_oracle(gpu_ctx, case):
+def test_rollout_matches_oracle(gpu_ctx, case, hidden):
     if case == "ppo_cartpole":
-        g, o, gb, ob, gs, oe, cfg = _rollout_pair("cartpole", "categorical", 5, 97, 5 * 97, ["logprob", "t", "i"])
+        g, o, gb, ob, gs, oe, cfg = _rollout_pair("cartpole", "categorical", 5, 97, 5 * 97, ["logprob", "t", "i"], hidden=hidden)
         calls = [(5 * 97, 0)]
     elif case == "greedy_eval":
-        g, o, gb, ob, gs, oe, cfg = _rollout_pair("cartpole", "categorical", 3, 60, 180, ["t"], explore=False, reset=False)
+        g, o, gb, ob, gs, oe, cfg = _rollout_pair("cartpole", "categorical", 3, 60, 180, ["t"], explore=False, reset=False, hidden=hidden)
         calls = [(180, 0)]
     elif case == "eps_greedy_offpolicy":          # DQN-style: DN=4 per call into a ring, sampler state persists across calls
-        g, o, gb, ob, gs, oe, cfg = _rollout_pair("cartpole", "categorical", 2, 2, 50, ["weight", "t", "i"], reset=False, eps=(1.0, 0.1, 40))
+        g, o, gb, ob, gs, oe, cfg = _rollout_pair("cartpole", "categorical", 2, 2, 50, ["weight", "t", "i"], reset=False, eps=(1.0, 0.1, 40), hidden=hidden)
         calls = [(4, 4 * k) for k in range(20)]
     elif case == "pendulum_gaussian":
-        g, o, gb, ob, gs, oe, cfg = _rollout_pair("pendulum", "gaussian", 4, 50, 200, ["logprob"], max_steps=30)
+        g, o, gb, ob, gs, oe, cfg = _rollout_pair("pendulum", "gaussian", 4, 50, 200, ["logprob"], max_steps=30, hidden=hidden)
         calls = [(200, 0)]
     else:
-        g, o, gb, ob, gs, oe, cfg = _rollout_pair("pendulum", "deterministic", 4, 25, 100, [], reset=False, noise={"sigma": 0.3, "a_min": -2.0, "a_max": 2.0}, max_steps=30)
+        g, o, gb, ob, gs, oe, cfg = _rollout_pair("pendulum", "deterministic", 4, 25, 100, [], reset=False, noise={"sigma": 0.3, "a_min": -2.0, "a_max": 2.0}, max_steps=30, hidden=hidden)
         calls = [(100, 0), (100, 100)]
     E = gs.n_envs
     for (N, i0) in calls:
