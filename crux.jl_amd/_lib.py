@@ -75,6 +75,7 @@ SIGNATURES = {
     "crux_buffer_last_n_indices": (i64, [vp, i64, vp]),
     "crux_buffer_gather_host": (i32, [vp, vp, i64, P(vp)]),
     "crux_buffer_indices": (i32, [vp, vp, i64]),
+    "crux_buffer_indices_ptr": (vp, [vp]),
     "crux_per_update": (i32, [vp, vp, vp, i32, i64]),
     "crux_per_update_device": (i32, [vp, vp, vp, i64]),
     "crux_per_sample": (i32, [vp, vp, i64, vp, f32, u64]),

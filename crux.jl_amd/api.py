@@ -541,7 +541,7 @@ class GymMDP:
 
     def __init__(self, kind, n_envs=1, seed=0, discount=0.99):
         self.kind, self.n_envs, self.seed, self.discount = kind, int(n_envs), int(seed), float(discount)
-        self.obs_dim, self.act_dim, self.discrete = {"cartpole": (4, 2, True), "pendulum": (3, 1, False)}[kind]
+        self.obs_dim, self.act_dim, self.discrete = {"cartpole": (4, 2, True), "pendulum": (3, 1, False), "gridworld": (2, 4, True)}[kind]
 
     def state_space(self, mu=0.0, sigma=1.0):
         """state_space(mdp; mu, sigma) (src/spaces.jl:34-43)."""
@@ -557,6 +557,12 @@ def CartPoleMDP(**kw):
 
 def PendulumMDP(**kw):
     return GymMDP("pendulum", **kw)
+
+
+def SimpleGridWorld(**kw):
+    """POMDPModels.SimpleGridWorld(size=(10,10), tprob=.7) of the README example (discount 0.95)."""
+    kw.setdefault("discount", 0.95)
+    return GymMDP("gridworld", **kw)
 
 
 def discount(mdp):
@@ -832,3 +838,97 @@ def PPO(pi, S, eps=0.2, lambda_p=1.0, lambda_e=0.1, target_kl=0.012, a_opt=None,
                           c_opt=TrainingParams(loss=value_mse_loss, name="critic_", **c_opt),
                           post_batch_callback=lambda D, info: whiten_(D, "advantage"),
                           required_columns=cols, **kw)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# off-policy solver + DQN (src/model_free/off_policy.jl, src/model_free/rl/dqn.jl)
+# --------------------------------------------------------------------------------------------------------------
+def buffer_like(b, capacity=None):
+    """buffer_like(b; capacity) (src/experience_buffer.jl:82-85): same columns, prioritized if b is (:84)."""
+    extras = [k for k in b.keys() if k not in ("s", "a", "sp", "r", "done", "episode_end")]
+    return ExperienceBuffer(b.S, b.A, capacity or b.capacity, extras, prioritized=b.isprioritized(), priority_params={"alpha": b.alpha, "beta": b.beta}, ctx=b.ctx)
+
+
+def extra_columns(b):
+    """extra_columns(b) (src/experience_buffer.jl:178)."""
+    return [k for k in b.keys() if k not in ("s", "a", "sp", "r", "done", "episode_end")]
+
+
+td_loss = _Loss("td")                # td_loss() (src/utils.jl:76-87)
+
+
+class OffPolicySolver:
+    """OffPolicySolver(; agent, S, N, dN=4, max_steps=100, c_opt, buffer_size=1000, buffer, buffer_init, target_fn, target_update)
+    (src/model_free/off_policy.jl:37-64). target_update defaults to polyak_average!(pi_minus, pi, 0.005) (:55)."""
+
+    def __init__(self, agent, S, N=1000, dN=4, max_steps=100, c_opt=None, buffer_size=1000, buffer=None, buffer_init=None, tau=0.005,
+                 prioritized=False, weighted_loss=False, i=0):
+        self.agent, self.S, self.N, self.dN, self.max_steps, self.c_opt, self.i = agent, S, int(N), int(dN), int(max_steps), c_opt, int(i)
+        self.buffer = buffer if buffer is not None else ExperienceBuffer(S, agent.space, buffer_size, prioritized=prioritized)
+        self.buffer_init = buffer_init if buffer_init is not None else max(c_opt.batch_size, 200)
+        self.tau, self.weighted_loss = float(tau), bool(weighted_loss)
+        self.sampler, self.batch, self.history = None, None, []
+        self._dy = self._derr = None
+
+
+def value_training(solver, D, gamma):
+    """value_training(S, D, gamma) (src/model_free/off_policy.jl:66-111) for the critic-only (DQN) case: per epoch
+    rand! -> dqn_target -> [update_priorities!(td_error)] -> train!(td_loss); then target_update once (:108)."""
+    pi, pim, buf, p, ctx = solver.agent.pi, solver.agent.pi_minus, solver.buffer, solver.c_opt, solver.buffer.ctx
+    _ensure_opt(pi, p)
+    B = D.capacity
+    if solver._dy is None:
+        solver._dy, solver._derr = ctx.alloc(4 * B), ctx.alloc(4 * B)
+    infos = []
+    for epoch in range(p.epochs):
+        rand_(D, buf, i=solver.i * p.epochs + epoch)                                                   # :71 (Philox counter unique per draw)
+        ctx.check(ctx.lib.crux_dqn_target(pim.h, D.h, float(gamma), solver._dy))                        # :80  dqn.jl:4-6
+        if buf.isprioritized():                                                                        # :83
+            ctx.check(ctx.lib.crux_td_error(pi.h, D.h, solver._dy, solver._derr))
+            ctx.check(ctx.lib.crux_per_update_device(buf.h, ctx.lib.crux_buffer_indices_ptr(D.h), solver._derr, B))
+        raw = np.zeros(L.INFO_N, np.float32)
+        ctx.check(ctx.lib.crux_td_step(pi.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))   # :91-93
+        infos.append({p.name + "loss": float(raw[0]), p.name + "grad_norm": float(raw[1]), "Qavg": float(raw[2])})
+    polyak_average_(pim, pi, solver.tau)                                                               # :108
+    return {k: float(np.mean([d[k] for d in infos])) for k in infos[0]}                                # aggregate_info (logging.jl:60-66)
+
+
+def _solve_off_policy(solver, mdp):
+    """POMDPs.solve(S::OffPolicySolver, mdp) (src/model_free/off_policy.jl:113-150), logging left out."""
+    gamma = np.float32(discount(mdp))
+    if solver.batch is None:
+        solver.batch = buffer_like(solver.buffer, capacity=solver.c_opt.batch_size)                     # :115
+        solver.sampler = Sampler(mdp, solver.agent, S=solver.S, max_steps=solver.max_steps, required_columns=extra_columns(solver.buffer))
+    D, s = solver.batch, solver.sampler
+    istart = solver.i
+    nfill = max(0, solver.buffer_init - len(solver.buffer))                                            # :122
+    if nfill > 0:
+        solver.i += nfill                                                                              # :125 (Q12: advanced BEFORE sampling)
+        steps_(s, solver.buffer, Nsteps=nfill, explore=True, i=solver.i)
+    i = solver.i
+    stop = istart + solver.N - solver.dN
+    while i <= stop:                                                                                   # :133
+        solver.i = i
+        steps_(s, solver.buffer, Nsteps=solver.dN, explore=True, i=i)                                  # :138
+        solver.history.append(value_training(solver, D, gamma))                                       # :143
+        i += solver.dN
+    solver.i += solver.dN
+    return solver.agent.pi
+
+
+def DQN(pi, S, N, dN=4, pi_explore=None, c_opt=None, **kw):
+    """DQN(; pi::DiscreteNetwork, N, dN=4, pi_explore=eps-greedy(LinearDecaySchedule(1., 0.1, N/2)), c_opt, ...) (src/model_free/rl/dqn.jl:27-46)."""
+    import copy
+    pe = pi_explore or EpsGreedyPolicy(LinearDecaySchedule(1.0, 0.1, N // 2), pi.outputs)
+    pim = DiscreteNetwork(pi.network, pi.outputs, ctx=pi.ctx); copyto_(pim, pi)                          # pi_minus = deepcopy(pi)
+    c = dict(c_opt or {}); c.setdefault("name", "critic_")
+    return OffPolicySolver(agent=PolicyParams(pi, pi_explore=pe, pi_minus=pim), S=S, N=N, dN=dN,
+                           c_opt=TrainingParams(loss=td_loss, epochs=dN, **c), **kw)
+
+
+_solve_on_policy = solve
+
+
+def solve(solver, mdp):  # noqa: F811
+    """POMDPs.solve(solver, mdp) for OnPolicySolver (on_policy.jl:80-109) and OffPolicySolver (off_policy.jl:113-150)."""
+    return _solve_off_policy(solver, mdp) if isinstance(solver, OffPolicySolver) else _solve_on_policy(solver, mdp)

@@ -302,6 +302,8 @@ int32_t crux_buffer_gather_host(crux_buffer* b, const int64_t* ids, int64_t n, v
   return CRUX_OK;
 }
 
+int64_t* crux_buffer_indices_ptr(crux_buffer* b) { return b ? b->d_indices : nullptr; }
+
 int32_t crux_buffer_indices(const crux_buffer* b, int64_t* out, int64_t n) {
   if (!b || !out) return CRUX_EINVAL;
   if (n > (int64_t)b->indices.size()) n = (int64_t)b->indices.size();

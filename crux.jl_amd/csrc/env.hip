@@ -43,15 +43,35 @@ __device__ __forceinline__ void pendulum_step(const double* s, float a, double* 
   if (newthdot < -max_speed) newthdot = -max_speed; if (newthdot > max_speed) newthdot = max_speed;
   sn[0] = __dadd_rn(th, __dmul_rn(newthdot, dt)); sn[1] = newthdot; *r = (float)(-costs); *done = 0;
 }
+// POMDPModels.SimpleGridWorld restated (README example, configs[0]); see the oracle for the definition.
+__device__ __forceinline__ float gridworld_reward(double x, double y) {
+  if (x == 4 && y == 3) return -10.f; if (x == 4 && y == 6) return -5.f; if (x == 9 && y == 3) return 10.f; if (x == 8 && y == 8) return 3.f; return 0.f;
+}
+__device__ __forceinline__ void gridworld_step(const double* s, int a, double u, double* sn, float* r, uint8_t* done) {
+  const double tprob = 0.7;
+  const double x = s[0], y = s[1];
+  const float rw = gridworld_reward(x, y);
+  *r = rw;
+  if (rw != 0.f) { sn[0] = -1; sn[1] = -1; *done = 1; return; }
+  int dir = a;
+  if (!(u < tprob)) { int k = (int)((u - tprob) / (1.0 - tprob) * 3.0); if (k > 2) k = 2; int cnt = 0;
+    for (int d = 0; d < 4; ++d) { if (d == a) continue; if (cnt == k) { dir = d; break; } ++cnt; } }
+  const double ddx = dir == 2 ? -1.0 : (dir == 3 ? 1.0 : 0.0), ddy = dir == 0 ? 1.0 : (dir == 1 ? -1.0 : 0.0);
+  double nx = x + ddx, ny = y + ddy;
+  if (nx < 1 || nx > 10 || ny < 1 || ny > 10) { nx = x; ny = y; }
+  sn[0] = nx; sn[1] = ny; *done = 0;
+}
 __device__ __forceinline__ void env_obs(int kind, const double* s, float* o) {
   if (kind == CRUX_ENV_CARTPOLE) { o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3]; }
-  else { o[0] = (float)cos(s[0]); o[1] = (float)sin(s[0]); o[2] = (float)s[1]; }
+  else if (kind == CRUX_ENV_PENDULUM) { o[0] = (float)cos(s[0]); o[1] = (float)sin(s[0]); o[2] = (float)s[1]; }
+  else { o[0] = (float)s[0]; o[1] = (float)s[1]; }
 }
 __device__ __forceinline__ void env_draw_initial(int kind, uint64_t seed, uint64_t n_resets, uint32_t env, double* s) {
   const crux_u32x4 a = crux_philox(seed, 2 * n_resets, env, CRUX_RNG_RESET), b = crux_philox(seed, 2 * n_resets + 1, env, CRUX_RNG_RESET);
   const double u0 = crux_u32x2_to_f64(a.v[0], a.v[1]), u1 = crux_u32x2_to_f64(a.v[2], a.v[3]), u2 = crux_u32x2_to_f64(b.v[0], b.v[1]), u3 = crux_u32x2_to_f64(b.v[2], b.v[3]);
   if (kind == CRUX_ENV_CARTPOLE) { s[0] = __dadd_rn(-0.05, __dmul_rn(0.1, u0)); s[1] = __dadd_rn(-0.05, __dmul_rn(0.1, u1)); s[2] = __dadd_rn(-0.05, __dmul_rn(0.1, u2)); s[3] = __dadd_rn(-0.05, __dmul_rn(0.1, u3)); }
-  else { s[0] = __dadd_rn(-PI_D, __dmul_rn(2.0 * PI_D, u0)); s[1] = __dadd_rn(-1.0, __dmul_rn(2.0, u1)); }
+  else if (kind == CRUX_ENV_PENDULUM) { s[0] = __dadd_rn(-PI_D, __dmul_rn(2.0 * PI_D, u0)); s[1] = __dadd_rn(-1.0, __dmul_rn(2.0, u1)); }
+  else { s[0] = 1.0 + floor(10.0 * u0); s[1] = 1.0 + floor(10.0 * u1); }
 }
 __device__ __forceinline__ float randn_f32(uint64_t seed, uint64_t ctr, uint32_t stream, int which) {
   const crux_u32x4 x = crux_philox(seed, ctr, stream, CRUX_RNG_NOISE);
@@ -125,7 +145,9 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
       }
       // ---- env transition (sampler.jl:93-97)
       double sn[ENV_MAXSD]; float r; uint8_t done; float o[ENV_MAXOBS], spv[ENV_MAXOBS];
-      if (kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done); else pendulum_step(st, aout[0], sn, &r, &done);
+      if (kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done);
+      else if (kind == CRUX_ENV_PENDULUM) pendulum_step(st, aout[0], sn, &r, &done);
+      else { const crux_u32x4 xd = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_ENVDYN); gridworld_step(st, ai, crux_u32x2_to_f64(xd.v[0], xd.v[1]), sn, &r, &done); }
       env_obs(kind, sn, o);
       for (int q = 0; q < od; ++q) spv[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
       // ---- column writes (sampler.jl:101-107)
@@ -285,16 +307,25 @@ __global__ void k_env_init(int kind, int E, int od, int sd, uint64_t seed, const
   if (e >= E) return;
   double st[ENV_MAXSD]; float o[ENV_MAXOBS];
   const int64_t nr = fresh ? 0 : n_resets[e];
+  st[0] = st[1] = st[2] = st[3] = 0.0; o[0] = o[1] = o[2] = o[3] = 0.f;
   env_draw_initial(kind, seed, (uint64_t)nr, (uint32_t)e, st);
-  for (int i = 0; i < sd; ++i) state[(size_t)e * sd + i] = st[i];
+#pragma unroll
+  for (int i = 0; i < ENV_MAXSD; ++i) if (i < sd) state[(size_t)e * sd + i] = st[i];      // static indices: keep the arrays in registers
   n_resets[e] = nr + 1; ep_len[e] = 0;
   env_obs(kind, st, o);
-  for (int q = 0; q < od; ++q) svec[(size_t)e * od + q] = __fdiv_rn(__fsub_rn(o[q], mu[q]), sigma[q]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) if (q < od) svec[(size_t)e * od + q] = __fdiv_rn(__fsub_rn(o[q], mu[q]), sigma[q]);
 }
 
-__global__ void k_env_step(int kind, int64_t n, const double* state, const void* action, double* next_state, float* obs, float* r, uint8_t* done) {
+__global__ void k_env_step(int kind, int64_t n, const double* state, const void* action, const double* uniforms, double* next_state, float* obs, float* r, uint8_t* done) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
+  if (kind == CRUX_ENV_GRIDWORLD) {
+    const uint8_t* a = (const uint8_t*)action + 4 * j; int act = 0; for (int q = 0; q < 4; ++q) if (a[q]) act = q;
+    double s[2] = {state[2 * j], state[2 * j + 1]}, sn[2]; float rr; uint8_t dd;
+    gridworld_step(s, act, uniforms ? uniforms[j] : 0.0, sn, &rr, &dd);
+    next_state[2 * j] = sn[0]; next_state[2 * j + 1] = sn[1]; obs[2 * j] = (float)sn[0]; obs[2 * j + 1] = (float)sn[1]; r[j] = rr; done[j] = dd; return;
+  }
   if (kind == CRUX_ENV_CARTPOLE) {
     const uint8_t* a = (const uint8_t*)action + 2 * j; double s[4], sn[4]; for (int i = 0; i < 4; ++i) s[i] = state[4 * j + i];
     float rr; uint8_t dd; cartpole_step(s, a[1] ? 1 : 0, sn, &rr, &dd);
@@ -310,6 +341,7 @@ static void env_dims(int kind, int so, int sa, int* obs, int* act, int* sd) {
   switch (kind) {
     case CRUX_ENV_CARTPOLE: *obs = 4; *act = 2; *sd = 4; break;
     case CRUX_ENV_PENDULUM: *obs = 3; *act = 1; *sd = 2; break;
+    case CRUX_ENV_GRIDWORLD: *obs = 2; *act = 4; *sd = 2; break;
     default: *obs = so; *act = sa; *sd = 1; break;
   }
 }
@@ -319,7 +351,7 @@ extern "C" {
 int32_t crux_env_create(crux_ctx* ctx, int32_t kind, int32_t n_envs, int32_t max_steps, float gamma, const float* obs_mu, const float* obs_sigma,
                         uint64_t seed, int32_t synth_obs_dim, int32_t synth_act_dim, crux_env** out) {
   if (!ctx || !out) return CRUX_EINVAL;
-  if (kind != CRUX_ENV_CARTPOLE && kind != CRUX_ENV_PENDULUM) return crux_fail(ctx, CRUX_EUNSUP, "env kind %d has no device dynamics yet", kind);
+  if (kind != CRUX_ENV_CARTPOLE && kind != CRUX_ENV_PENDULUM && kind != CRUX_ENV_GRIDWORLD) return crux_fail(ctx, CRUX_EUNSUP, "env kind %d has no device dynamics yet", kind);
   if (n_envs < 1 || max_steps < 1) return crux_fail(ctx, CRUX_EINVAL, "env_create: n_envs=%d max_steps=%d", n_envs, max_steps);
   crux_env* e = new crux_env(); e->ctx = ctx; e->kind = kind; e->n_envs = n_envs; e->max_steps = max_steps; e->gamma = gamma; e->seed = seed;
   env_dims(kind, synth_obs_dim, synth_act_dim, &e->obs_dim, &e->act_dim, &e->state_dim);
@@ -423,20 +455,21 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
 
 int32_t crux_env_step_host(crux_ctx* c, int32_t kind, int64_t n, const double* state, const void* action, const double* uniforms, double* next_state,
                            float* obs, float* r, uint8_t* done) {
-  (void)uniforms;
   if (!c || n < 0 || !state || !action) return CRUX_EINVAL;
-  if (kind != CRUX_ENV_CARTPOLE && kind != CRUX_ENV_PENDULUM) return crux_fail(c, CRUX_EUNSUP, "env kind %d has no device dynamics yet", kind);
+  if (kind != CRUX_ENV_CARTPOLE && kind != CRUX_ENV_PENDULUM && kind != CRUX_ENV_GRIDWORLD) return crux_fail(c, CRUX_EUNSUP, "env kind %d has no device dynamics yet", kind);
   if (n == 0) return CRUX_OK;
-  const int sd = kind == CRUX_ENV_CARTPOLE ? 4 : 2, od = kind == CRUX_ENV_CARTPOLE ? 4 : 3;
-  const size_t ab = kind == CRUX_ENV_CARTPOLE ? 2 * (size_t)n : 4 * (size_t)n;
+  const int sd = kind == CRUX_ENV_CARTPOLE ? 4 : 2, od = kind == CRUX_ENV_CARTPOLE ? 4 : (kind == CRUX_ENV_PENDULUM ? 3 : 2);
+  const size_t ab = kind == CRUX_ENV_CARTPOLE ? 2 * (size_t)n : 4 * (size_t)n;     // 2 / 4 one-hot bytes, or one Float32
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  const size_t o_s = 0, o_a = o_s + al(8 * (size_t)n * sd), o_ns = o_a + al(ab), o_o = o_ns + al(8 * (size_t)n * sd), o_r = o_o + al(4 * (size_t)n * od), o_d = o_r + al(4 * (size_t)n);
-  char* sc = (char*)crux_scratch(c, o_d + al((size_t)n));
+  const size_t o_s = 0, o_a = o_s + al(8 * (size_t)n * sd), o_ns = o_a + al(ab), o_o = o_ns + al(8 * (size_t)n * sd), o_r = o_o + al(4 * (size_t)n * od), o_d = o_r + al(4 * (size_t)n),
+               o_u = o_d + al((size_t)n);
+  char* sc = (char*)crux_scratch(c, o_u + al(8 * (size_t)n));
   if (!sc) return crux_fail(c, CRUX_ENOMEM, "env_step: scratch");
   HIPCHK(c, hipMemcpyAsync(sc + o_s, state, 8 * (size_t)n * sd, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(sc + o_a, action, ab, hipMemcpyHostToDevice, c->stream));
+  if (uniforms) HIPCHK(c, hipMemcpyAsync(sc + o_u, uniforms, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_env_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, kind, n, (const double*)(sc + o_s), (const void*)(sc + o_a),
-                     (double*)(sc + o_ns), (float*)(sc + o_o), (float*)(sc + o_r), (uint8_t*)(sc + o_d));
+                     uniforms ? (const double*)(sc + o_u) : (const double*)nullptr, (double*)(sc + o_ns), (float*)(sc + o_o), (float*)(sc + o_r), (uint8_t*)(sc + o_d));
   int32_t rc = crux_launch_check(c, "k_env_step"); if (rc) return rc;
   if (next_state) HIPCHK(c, hipMemcpyAsync(next_state, sc + o_ns, 8 * (size_t)n * sd, hipMemcpyDeviceToHost, c->stream));
   if (obs) HIPCHK(c, hipMemcpyAsync(obs, sc + o_o, 4 * (size_t)n * od, hipMemcpyDeviceToHost, c->stream));

@@ -133,6 +133,8 @@ int32_t crux_buffer_permute(crux_buffer* b, const int64_t* perm /*len*/);
 int64_t crux_buffer_last_n_indices(const crux_buffer* b, int64_t N, int64_t* out);
 /* minibatch_copy(b, indices) (:171): gather rows to host; outs[k]==NULL skips a column.            */
 int32_t crux_buffer_gather_host(crux_buffer* b, const int64_t* ids, int64_t n, void* const* outs);
+/* device copy of the same indices (int64, 0-based), e.g. to feed crux_per_update_device without a host round trip. */
+int64_t* crux_buffer_indices_ptr(crux_buffer* b);
 /* indices of the last sample!() into this (staging) buffer: target.indices (:319,338).            */
 int32_t crux_buffer_indices(const crux_buffer* b, int64_t* out, int64_t n);
 

