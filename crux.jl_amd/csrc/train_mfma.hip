@@ -542,6 +542,8 @@ static int32_t launch_one(crux_ctx* c, const TrainArgs& a, hipStream_t stream) {
   return crux_launch_check(c, "k_train_mfma");
 }
 
+int32_t crux_train_mfma8_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream);   // train_mfma8.hip
+
 int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream) {
   *handled = false;
   const NetDesc& nd = a.nd;
@@ -566,6 +568,8 @@ int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, h
       for (int k = 0; k < 12; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[w * 16 + k] / (double)tot); fprintf(stderr, " total=%llu cyc\n", tot); }
     return CRUX_OK;
   }
+  { static const bool four = getenv("CRUX_MFMA_WAVES4") != nullptr;   // A/B switch: force the 4-wave kernel
+    if (!four) { const int32_t rc = crux_train_mfma8_launch(c, a, kind, handled, stream); if (rc || *handled) return rc; } }
 #define MF_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_one<I, O, K, A_>(c, a, stream); }
   MF_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)     // C2 actor  (PPO CartPole)
   MF_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)           // C2 critic
