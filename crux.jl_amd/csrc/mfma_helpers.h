@@ -44,7 +44,10 @@ __device__ __forceinline__ float g4_sum(float v) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
   return a + b;
 }
-template <int ACT> __device__ __forceinline__ float actf(float z) { return ACT == CRUX_ACT_RELU ? fmaxf(z, 0.f) : (ACT == CRUX_ACT_TANH ? tanhf(z) : z); }
+// relu as ONE instruction: fmaxf() makes hipcc canonicalise the MFMA result first (v_max x,x,x), doubling the count. On the bit
+// pattern relu is a signed-integer max with 0 (negative floats and -0 are negative ints); a NaN keeps its bits and propagates.
+__device__ __forceinline__ float relu1(float z) { const int b = __builtin_bit_cast(int, z); return __builtin_bit_cast(float, b > 0 ? b : 0); }
+template <int ACT> __device__ __forceinline__ float actf(float z) { return ACT == CRUX_ACT_RELU ? relu1(z) : (ACT == CRUX_ACT_TANH ? tanhf(z) : z); }
 template <int ACT> __device__ __forceinline__ float actg(float y, float d) { return ACT == CRUX_ACT_RELU ? (y > 0.f ? d : 0.f) : (ACT == CRUX_ACT_TANH ? d * (1.f - y * y) : d); }
 
 // Adam on one element with f32 arithmetic; c1 = 1/(1-b1^t), c2 = 1/(1-b2^t) come from Float64 (Flux keeps Float64 scalars;
