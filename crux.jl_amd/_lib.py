@@ -102,6 +102,12 @@ SIGNATURES = {
     "crux_dqn_target": (i32, [vp, vp, f32, vp]),
     "crux_td_error": (i32, [vp, vp, vp, vp]),
     "crux_td_step": (i32, [vp, vp, vp, i32, vp]),
+    "crux_mlp_forward_cached": (i32, [vp, vp, i64, vp]),
+    "crux_mlp_backward": (i32, [vp, vp, i64, vp, f32, i32, vp]),
+    "crux_sac_target": (i32, [vp, vp, vp, vp, vp, f32, u64, u64, vp]),
+    "crux_sac_temp_step": (i32, [vp, vp, vp, f32, u64, u64, vp]),
+    "crux_double_q_step": (i32, [vp, vp, vp, vp, i32, vp]),
+    "crux_sac_actor_step": (i32, [vp, vp, vp, vp, vp, u64, u64, vp]),
 }
 
 _lib = None
@@ -139,7 +145,7 @@ ENV = {"cartpole": 0, "pendulum": 1, "gridworld": 2, "synth": 3}
 HEAD = {"categorical": 0, "gaussian": 1, "greedy_q": 2, "deterministic": 3}
 LOSS = {"ppo": 0, "value_mse": 1}
 INFO = {"loss": 0, "grad_norm": 1, "entropy": 2, "kl": 3, "clip_fraction": 4, "avg_advantage": 5, "avg_return": 6,
-        "batches_trained": 7, "epochs_run": 8}
+        "batches_trained": 7, "epochs_run": 8, "q1avg": 9, "q2avg": 10, "alpha": 11}
 INFO_N = 16
 PROF = {"rollout": 0, "values": 1, "gae": 2, "whiten": 3, "train_actor": 4, "train_critic": 5, "per_scan": 6,
         "per_search": 7, "gather": 8, "td_step": 9}

@@ -64,7 +64,8 @@ class Context:
         return arr
 
     def h2d(self, d_ptr, arr):
-        arr = np.ascontiguousarray(arr)
+        if not (arr.flags.c_contiguous or arr.flags.f_contiguous):
+            arr = np.ascontiguousarray(arr)          # raw memory is copied: column-major (Julia layout) arrays go up as they are
         self.check(self.lib.crux_memcpy_h2d(self.h, d_ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
 
     def close(self):
@@ -246,6 +247,32 @@ class GaussianPolicy(NetworkPolicy):
         p = self.get_params(); p[-logSigma.size:] = logSigma; self.set_params(p)
 
 
+class ParamVector(NetworkPolicy):
+    """A bare trainable vector with its own optimiser state (ConstantLayer, src/utils.jl:31-36; P[:SAC_log_alpha], sac.jl:96):
+    the crux_mlp handle with n_layers = 0."""
+    head = None
+
+    def __init__(self, values, ctx=None):
+        values = np.asarray(values, np.float32).reshape(-1)
+        self.ctx = ctx or default_context()
+        self.network, self.n_extra, self.optimizer = None, values.size, None
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.crux_mlp_create(self.ctx.h, 0, None, None, values.size, C.byref(h)))
+        self.h = h
+        self.set_params(values)
+
+    def params(self):
+        return [self.get_params()]
+
+
+class DoubleNetwork:
+    """DoubleNetwork(N1, N2) (src/policies.jl:162-187): value(pi, s, a) = (value(N1, s, a), value(N2, s, a))."""
+
+    def __init__(self, N1, N2):
+        self.N1, self.N2 = N1, N2
+        self.ctx = N1.ctx
+
+
 class ActorCritic:
     """ActorCritic(A, C) (src/policies.jl:246-276): actor(pi)=A, critic(pi)=C, value(pi,s)=value(C,s)."""
 
@@ -266,14 +293,41 @@ def value(pi, s):
     return critic(pi).forward(s)
 
 
+def _leaves(pi):
+    """layers(pi) flattened to the crux_mlp handles it is made of (src/policies.jl:171,255)."""
+    if isinstance(pi, ActorCritic):
+        return _leaves(pi.A) + _leaves(pi.C)
+    if isinstance(pi, DoubleNetwork):
+        return _leaves(pi.N1) + _leaves(pi.N2)
+    return [pi]
+
+
 def polyak_average_(to, frm, tau=1.0):
-    """polyak_average!(to, from, tau) (src/policies.jl:48-59)."""
-    to.ctx.check(to.ctx.lib.crux_polyak(to.h, frm.h, float(tau)))
+    """polyak_average!(to, from, tau) (src/policies.jl:48-59) over every layer of the (possibly composite) policy."""
+    for t, f in zip(_leaves(to), _leaves(frm)):
+        t.ctx.check(t.ctx.lib.crux_polyak(t.h, f.h, float(tau)))
 
 
 def copyto_(to, frm):
     """Base.copyto!(to, from) on network parameters (src/policies.jl:61-65)."""
-    to.ctx.check(to.ctx.lib.crux_mlp_copy(to.h, frm.h))
+    for t, f in zip(_leaves(to), _leaves(frm)):
+        t.ctx.check(t.ctx.lib.crux_mlp_copy(t.h, f.h))
+
+
+def clone_policy(pi):
+    """deepcopy(pi) for pi_minus (src/policies.jl:24-36): same architecture, copied parameters."""
+    if isinstance(pi, ActorCritic):
+        return ActorCritic(clone_policy(pi.A), clone_policy(pi.C))
+    if isinstance(pi, DoubleNetwork):
+        return DoubleNetwork(clone_policy(pi.N1), clone_policy(pi.N2))
+    if isinstance(pi, GaussianPolicy):
+        new = GaussianPolicy(pi.network, np.zeros(pi.n_extra, np.float32), ctx=pi.ctx)
+    elif isinstance(pi, DiscreteNetwork):
+        new = DiscreteNetwork(pi.network, pi.outputs, ctx=pi.ctx)
+    else:
+        new = ContinuousNetwork(pi.network, ctx=pi.ctx)
+    copyto_(new, pi)
+    return new
 
 
 class PolicyParams:
@@ -862,8 +916,9 @@ class OffPolicySolver:
     (src/model_free/off_policy.jl:37-64). target_update defaults to polyak_average!(pi_minus, pi, 0.005) (:55)."""
 
     def __init__(self, agent, S, N=1000, dN=4, max_steps=100, c_opt=None, buffer_size=1000, buffer=None, buffer_init=None, tau=0.005,
-                 prioritized=False, weighted_loss=False, i=0):
+                 prioritized=False, weighted_loss=False, i=0, a_opt=None, param_optimizers=None, P=None, target_fn="dqn", noise_seed=0):
         self.agent, self.S, self.N, self.dN, self.max_steps, self.c_opt, self.i = agent, S, int(N), int(dN), int(max_steps), c_opt, int(i)
+        self.a_opt, self.param_optimizers, self.P, self.target_fn, self.noise_seed = a_opt, list(param_optimizers or []), dict(P or {}), target_fn, int(noise_seed)
         self.buffer = buffer if buffer is not None else ExperienceBuffer(S, agent.space, buffer_size, prioritized=prioritized)
         self.buffer_init = buffer_init if buffer_init is not None else max(c_opt.batch_size, 200)
         self.tau, self.weighted_loss = float(tau), bool(weighted_loss)
@@ -871,9 +926,41 @@ class OffPolicySolver:
         self._dy = self._derr = None
 
 
+def _value_training_sac(solver, D, gamma):
+    """value_training (src/model_free/off_policy.jl:66-111) with SAC's pieces (src/model_free/rl/sac.jl): per epoch rand! -> sac_target ->
+    train!(log_alpha, sac_temp_loss) -> train!(critic, double_Q_loss) -> train!(actor, sac_actor_loss) -> target_update."""
+    pi, pim, buf, ctx = solver.agent.pi, solver.agent.pi_minus, solver.buffer, solver.buffer.ctx
+    A, Q, Qm, la = pi.A, pi.C, pim.C, solver.P["SAC_log_alpha"]
+    c_opt, a_opt = solver.c_opt, solver.a_opt
+    (_, t_opt), = solver.param_optimizers                                                               # Flux.params(SAC_log_alpha) => temp_ (sac.jl:101)
+    _ensure_opt(Q.N1, c_opt); _ensure_opt(Q.N2, c_opt); _ensure_opt(A, a_opt); _ensure_opt(la, t_opt)
+    if buf.isprioritized():
+        raise NotImplementedError("SAC with a prioritized buffer: td_error over a DoubleNetwork is not defined in the reference either")
+    B = D.capacity
+    if solver._dy is None:
+        solver._dy = ctx.alloc(4 * B)
+    infos, lib, raw = [], ctx.lib, np.zeros(L.INFO_N, np.float32)
+    for epoch in range(c_opt.epochs):
+        ctr = solver.i * c_opt.epochs + epoch                                                          # one Philox counter block per epoch
+        rand_(D, buf, i=ctr)                                                                           # :71
+        info = {}
+        ctx.check(lib.crux_sac_target(A.h, Qm.N1.h, Qm.N2.h, la.h, D.h, float(gamma), solver.noise_seed, 3 * ctr, solver._dy))           # :80
+        ctx.check(lib.crux_sac_temp_step(A.h, la.h, D.h, float(solver.P["SAC_H_target"]), solver.noise_seed, 3 * ctr + 1, _vp(raw)))     # :86-88
+        info.update({t_opt.name + "loss": float(raw[0]), t_opt.name + "grad_norm": float(raw[1]), "SAC alpha": float(raw[L.INFO["alpha"]])})
+        ctx.check(lib.crux_double_q_step(Q.N1.h, Q.N2.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))                  # :91-93
+        info.update({c_opt.name + "loss": float(raw[0]), c_opt.name + "grad_norm": float(raw[1]), "Q1avg": float(raw[L.INFO["q1avg"]]), "Q2avg": float(raw[L.INFO["q2avg"]])})
+        ctx.check(lib.crux_sac_actor_step(A.h, Q.N1.h, Q.N2.h, la.h, D.h, solver.noise_seed, 3 * ctr + 2, _vp(raw)))                     # :96-98
+        info.update({a_opt.name + "loss": float(raw[0]), a_opt.name + "grad_norm": float(raw[1]), "entropy": float(raw[L.INFO["entropy"]])})
+        polyak_average_(pim, pi, solver.tau)                                                           # :101
+        infos.append(info)
+    return {k: float(np.mean([d[k] for d in infos])) for k in infos[0]}
+
+
 def value_training(solver, D, gamma):
     """value_training(S, D, gamma) (src/model_free/off_policy.jl:66-111) for the critic-only (DQN) case: per epoch
     rand! -> dqn_target -> [update_priorities!(td_error)] -> train!(td_loss); then target_update once (:108)."""
+    if solver.target_fn == "sac":
+        return _value_training_sac(solver, D, gamma)
     pi, pim, buf, p, ctx = solver.agent.pi, solver.agent.pi_minus, solver.buffer, solver.c_opt, solver.buffer.ctx
     _ensure_opt(pi, p)
     B = D.capacity
@@ -924,6 +1011,24 @@ def DQN(pi, S, N, dN=4, pi_explore=None, c_opt=None, **kw):
     c = dict(c_opt or {}); c.setdefault("name", "critic_")
     return OffPolicySolver(agent=PolicyParams(pi, pi_explore=pe, pi_minus=pim), S=S, N=N, dN=dN,
                            c_opt=TrainingParams(loss=td_loss, epochs=dN, **c), **kw)
+
+
+sac_actor_loss, sac_temp_loss, double_Q_loss = _Loss("sac_actor"), _Loss("sac_temp"), _Loss("double_q")   # sac.jl:34-52, utils.jl:89-96
+
+
+def SAC(pi, S, N, dN=50, SAC_alpha=1.0, SAC_H_target=None, pi_explore=None, SAC_alpha_opt=None, a_opt=None, c_opt=None, **kw):
+    """SAC(; pi::ActorCritic{GaussianPolicy, DoubleNetwork}, dN=50, SAC_alpha=1f0, SAC_H_target=-dim(A), pi_explore=GaussianNoiseExplorationPolicy(0.1f0),
+    SAC_alpha_opt, a_opt, c_opt(epochs=dN), ...) (src/model_free/rl/sac.jl:75-106)."""
+    if not (isinstance(pi, ActorCritic) and isinstance(pi.A, GaussianPolicy) and isinstance(pi.C, DoubleNetwork)):
+        raise TypeError("SAC: pi must be ActorCritic(GaussianPolicy, DoubleNetwork(ContinuousNetwork, ContinuousNetwork))")
+    ad = pi.A.network.dims[-1]
+    P = {"SAC_log_alpha": ParamVector([np.log(np.float32(SAC_alpha))], ctx=pi.A.ctx), "SAC_H_target": np.float32(-ad if SAC_H_target is None else SAC_H_target)}
+    c = dict(c_opt or {}); c.setdefault("name", "critic_"); c.setdefault("epochs", dN)
+    a = dict(a_opt or {}); a.setdefault("name", "actor_")
+    t = dict(SAC_alpha_opt or {}); t.setdefault("name", "temp_")
+    return OffPolicySolver(agent=PolicyParams(pi, pi_explore=pi_explore or GaussianNoiseExplorationPolicy(0.1), pi_minus=clone_policy(pi)), S=S, N=N, dN=dN, P=P,
+                           param_optimizers=[(P["SAC_log_alpha"], TrainingParams(loss=sac_temp_loss, **t))],
+                           a_opt=TrainingParams(loss=sac_actor_loss, **a), c_opt=TrainingParams(loss=double_Q_loss, **c), target_fn="sac", **kw)
 
 
 _solve_on_policy = solve

@@ -64,6 +64,8 @@ struct crux_mlp {
   double* bp = nullptr; // device: [beta1^t, beta2^t]
   double eta = 0, b1 = 0, b2 = 0, eps = 0;
   bool has_adam = false;
+  float* ws = nullptr;  // dense-engine workspace (dense.hip): cached activations 1..L + two delta buffers, capacity ws_B samples
+  int64_t ws_B = 0;
 };
 
 struct crux_buffer {
@@ -140,3 +142,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 int32_t crux_launch_check(crux_ctx* ctx, const char* what);
+// dense.hip: differentiable Chain(Dense...) on the tile-GEMM engine
+int32_t crux_dense_forward(crux_mlp* n, const float* d_x, int64_t B, hipStream_t st);
+int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st);
+float* crux_dense_act(crux_mlp* n, int l);

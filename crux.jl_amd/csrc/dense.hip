@@ -1,0 +1,176 @@
+// dense.hip -- shape-generic differentiable Chain(Dense...) engine on gfx950 f32 MFMA: forward with cached activations and the
+// reverse pass (parameter gradients and input gradient). This is what Zygote's pullback of value(pi, x) does for the
+// off-policy learners (src/training.jl:16-18 through src/utils.jl:76-96, src/model_free/rl/sac.jl:34-52), where the hidden
+// layers are 256 wide (configs C3/C4) and a single-workgroup kernel no longer fits.
+//
+// Layout: activations are [feature][sample] column-major as in the reference (feature index fastest), weights out x in
+// column-major (W[o + out*k]). Every layer is one launch of a tile GEMM: one wave per 16x16 output tile, the K loop in chunks
+// of 16 with v_mfma_f32_16x16x4_f32 (exact f32 products, k-ordered fma chain, deterministic). Operands that are contiguous
+// along K are fetched as one 16-byte load per lane and chunk (lane group g takes k = 16q+4g+r for MFMA r -- any k permutation
+// is legal as long as both operands agree); the others as four coalesced dword loads. Operands live in L2/MALL: the whole
+// working set of C3/C4 (a few hundred KB) is far below the 4 MB L2 of one XCD.
+//   forward   Y[o,s]  = act(b[o] + sum_k W[o,k] X[k,s])                 M=out N=B K=in
+//   backward  dX[k,s] = act'(X[k,s]) * sum_o W[o,k] dZ[o,s]             M=in  N=B K=out   (act' of the layer that produced X)
+//   weights   dW[o,k] = scale * sum_s dZ[o,s] X[k,s];  db[o] = scale * sum_s dZ[o,s]      M=out N=in K=B
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { EPI_FWD = 0, EPI_BWD_DATA = 1, EPI_WGRAD = 2 };
+
+struct GemmArgs {
+  const float* A; int64_t sAi, sAk;      // A(i,k) = A[i*sAi + k*sAk]
+  const float* B; int64_t sBk, sBj;      // B(k,j) = B[k*sBk + j*sBj]
+  int M, N, K;
+  float* C; int64_t sCj;                 // C(i,j) = C[i + j*sCj]
+  int epi; const float* bias; int act; const float* ysrc; float scale;
+};
+
+template <bool AV, bool BV>
+__global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int tm = (q.M + 15) >> 4, tn = (q.N + 15) >> 4;
+  const int tile = blockIdx.x * 4 + wv;
+  if (tile >= tm * tn) return;
+  const int i0 = (tile % tm) << 4, j0 = (tile / tm) << 4;
+  const int ia = i0 + c, jb = j0 + c;
+  const bool va = ia < q.M, vb = jb < q.N;
+  const float* pa = q.A + (int64_t)(va ? ia : 0) * q.sAi;
+  const float* pb = q.B + (int64_t)(vb ? jb : 0) * q.sBj;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < q.K; k0 += 16) {
+    const int kb = k0 + 4 * g;
+    float a[4], b[4];
+    if (AV) { f32x4 t = {0.f, 0.f, 0.f, 0.f}; if (va && kb < q.K) t = *(const f32x4*)(pa + kb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = t[r]; }
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int kk = kb + r; a[r] = (va && kk < q.K) ? pa[(int64_t)kk * q.sAk] : 0.f; } }
+    if (BV) { f32x4 t = {0.f, 0.f, 0.f, 0.f}; if (vb && kb < q.K) t = *(const f32x4*)(pb + kb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[r] = t[r]; }
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int kk = kb + r; b[r] = (vb && kk < q.K) ? pb[(int64_t)kk * q.sBk] : 0.f; } }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[r], acc, 0, 0, 0);
+  }
+  // D layout: reg r <-> row i0+4g+r, column j0+c
+  const int j = j0 + c;
+  if (j >= q.N) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const int i = i0 + 4 * g + r; if (i >= q.M) continue;
+    const int64_t ci = (int64_t)i + (int64_t)j * q.sCj; float v = acc[r];
+    if (q.epi == EPI_FWD) v = crux_act(q.act, v + q.bias[i]);
+    else if (q.epi == EPI_BWD_DATA) { if (q.ysrc) v = crux_act_grad(q.act, q.ysrc[ci], v); }
+    else v *= q.scale;
+    q.C[ci] = v; }
+}
+
+// dZ = act'(Y) .* dY for the output layer
+__global__ void k_act_grad(const float* __restrict__ dy, const float* __restrict__ y, int act, int64_t n, float* __restrict__ dz) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+  dz[i] = crux_act_grad(act, y[i], dy[i]);
+}
+// db[o] = scale * sum_s dZ[o + out*s]: block = 64 outputs x 4 sample slices, fixed-order combine
+__global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dz, int out, int64_t B, float scale, float* __restrict__ gb) {
+  __shared__ float part[4][64];
+  const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6, o = blockIdx.x * 64 + ol;
+  float acc = 0.f;
+  if (o < out) for (int64_t s = sl; s < B; s += 4) acc += dz[o + (int64_t)out * s];
+  part[sl][ol] = acc;
+  __syncthreads();
+  if (sl == 0 && o < out) gb[o] = scale * (((part[0][ol] + part[1][ol]) + part[2][ol]) + part[3][ol]);
+}
+
+static inline bool vec_ok(const float* p, int64_t s_k, int64_t s_outer, int K) {
+  return s_k == 1 && (K & 3) == 0 && (s_outer & 3) == 0 && (((uintptr_t)p) & 15) == 0;
+}
+static int32_t launch_gemm(crux_ctx* c, const GemmArgs& q, hipStream_t st) {
+  const int tiles = ((q.M + 15) >> 4) * ((q.N + 15) >> 4);
+  const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+  const bool av = vec_ok(q.A, q.sAk, q.sAi, q.K), bv = vec_ok(q.B, q.sBk, q.sBj, q.K);
+  if (av && bv) hipLaunchKernelGGL((k_gemm16<true, true>), grid, block, 0, st, q);
+  else if (av) hipLaunchKernelGGL((k_gemm16<true, false>), grid, block, 0, st, q);
+  else if (bv) hipLaunchKernelGGL((k_gemm16<false, true>), grid, block, 0, st, q);
+  else hipLaunchKernelGGL((k_gemm16<false, false>), grid, block, 0, st, q);
+  return crux_launch_check(c, "k_gemm16");
+}
+
+// ---- per-network workspace: activations 1..L and two delta buffers, [maxdim x B] each --------------------------
+static int32_t ensure_ws(crux_mlp* n, int64_t B) {
+  if (n->ws && n->ws_B >= B) return CRUX_OK;
+  crux_ctx* c = n->ctx;
+  if (n->ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(n->ws); n->ws = nullptr; n->ws_B = 0; }
+  int64_t cap = 256; while (cap < B) cap *= 2;
+  size_t tot = 0; for (int l = 1; l <= n->nd.L; ++l) tot += (size_t)n->nd.dims[l] * (size_t)cap;
+  tot += 2 * (size_t)n->nd.maxdim * (size_t)cap;
+  if (hipMalloc(&n->ws, sizeof(float) * tot + 64) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "dense workspace: hipMalloc(%zu) failed", sizeof(float) * tot);
+  n->ws_B = cap; return CRUX_OK;
+}
+float* crux_dense_act(crux_mlp* n, int l) {   // l in 1..L
+  size_t off = 0; for (int q = 1; q < l; ++q) off += (size_t)n->nd.dims[q] * (size_t)n->ws_B;
+  return n->ws + off;
+}
+static float* ws_delta(crux_mlp* n, int which) {
+  size_t off = 0; for (int q = 1; q <= n->nd.L; ++q) off += (size_t)n->nd.dims[q] * (size_t)n->ws_B;
+  return n->ws + off + (size_t)which * (size_t)n->nd.maxdim * (size_t)n->ws_B;
+}
+
+int32_t crux_dense_forward(crux_mlp* n, const float* d_x, int64_t B, hipStream_t st) {
+  crux_ctx* c = n->ctx; const NetDesc& nd = n->nd;
+  if (nd.L < 1) return crux_fail(c, CRUX_EINVAL, "forward: the handle has no layers");
+  if (B < 1 || B > (1 << 20)) return crux_fail(c, CRUX_EINVAL, "forward: batch %lld out of range", (long long)B);
+  int32_t rc = ensure_ws(n, B); if (rc) return rc;
+  const float* x = d_x;
+  for (int l = 0; l < nd.L; ++l) {
+    const int in = nd.dims[l], out = nd.dims[l + 1];
+    GemmArgs q{}; q.A = n->p + nd.woff[l]; q.sAi = 1; q.sAk = out; q.B = x; q.sBk = 1; q.sBj = in; q.M = out; q.N = (int)B; q.K = in;
+    q.C = crux_dense_act(n, l + 1); q.sCj = out; q.epi = EPI_FWD; q.bias = n->p + nd.boff[l]; q.act = nd.acts[l];
+    rc = launch_gemm(c, q, st); if (rc) return rc;
+    x = q.C;
+  }
+  return CRUX_OK;
+}
+
+// Reverse pass after crux_dense_forward(n, d_x, B) with the same d_x. d_dy [out_L x B] is not modified.
+int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st) {
+  crux_ctx* c = n->ctx; const NetDesc& nd = n->nd;
+  if (nd.L < 1 || !n->ws || n->ws_B < B) return crux_fail(c, CRUX_EINVAL, "backward: no cached forward pass for this batch");
+  float* dcur = ws_delta(n, 0); float* dnxt = ws_delta(n, 1);
+  { const int64_t cnt = (int64_t)nd.dims[nd.L] * B;
+    hipLaunchKernelGGL(k_act_grad, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_dy, crux_dense_act(n, nd.L), nd.acts[nd.L - 1], cnt, dcur); }
+  for (int l = nd.L - 1; l >= 0; --l) {
+    const int in = nd.dims[l], out = nd.dims[l + 1];
+    const float* x = l == 0 ? d_x : crux_dense_act(n, l);
+    if (want_g) {
+      GemmArgs q{}; q.A = dcur; q.sAi = 1; q.sAk = out; q.B = x; q.sBk = in; q.sBj = 1; q.M = out; q.N = in; q.K = (int)B;
+      q.C = n->g + nd.woff[l]; q.sCj = out; q.epi = EPI_WGRAD; q.scale = gscale;
+      int32_t rc = launch_gemm(c, q, st); if (rc) return rc;
+      hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)((out + 63) / 64)), dim3(256), 0, st, dcur, out, B, gscale, n->g + nd.boff[l]);
+    }
+    if (l > 0 || d_dx) {
+      GemmArgs q{}; q.A = n->p + nd.woff[l]; q.sAi = out; q.sAk = 1; q.B = dcur; q.sBk = 1; q.sBj = out; q.M = in; q.N = (int)B; q.K = out;
+      q.C = l > 0 ? dnxt : d_dx; q.sCj = in; q.epi = EPI_BWD_DATA; q.ysrc = l > 0 ? x : nullptr; q.act = l > 0 ? nd.acts[l - 1] : CRUX_ACT_IDENTITY;
+      int32_t rc = launch_gemm(c, q, st); if (rc) return rc;
+      float* t = dcur; dcur = dnxt; dnxt = t;
+    }
+  }
+  return crux_launch_check(c, "dense backward");
+}
+
+extern "C" {
+
+int32_t crux_mlp_forward_cached(crux_mlp* net, const float* d_x, int64_t B, float* d_y) {
+  if (!net || !d_x) return CRUX_EINVAL;
+  int32_t rc = crux_dense_forward(net, d_x, B, net->ctx->stream); if (rc) return rc;
+  if (d_y) HIPCHK(net->ctx, hipMemcpyAsync(d_y, crux_dense_act(net, net->nd.L), sizeof(float) * (size_t)net->nd.dims[net->nd.L] * (size_t)B, hipMemcpyDeviceToDevice, net->ctx->stream));
+  return CRUX_OK;
+}
+int32_t crux_mlp_backward(crux_mlp* net, const float* d_x, int64_t B, const float* d_dy, float grad_scale, int32_t want_param_grads, float* d_dx) {
+  if (!net || !d_x || !d_dy) return CRUX_EINVAL;
+  return crux_dense_backward(net, d_x, B, d_dy, grad_scale, want_param_grads != 0, d_dx, net->ctx->stream);
+}
+
+}  // extern "C"

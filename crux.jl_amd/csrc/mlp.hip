@@ -88,11 +88,12 @@ __global__ void k_adam_advance(double* bp, double b1, double b2) { bp[0] *= b1; 
 extern "C" {
 
 int32_t crux_mlp_create(crux_ctx* ctx, int32_t L, const int32_t* dims, const int32_t* acts, int32_t n_extra, crux_mlp** out) {
-  if (!ctx || !out || !dims || !acts) return CRUX_EINVAL;
-  if (L < 1 || L > CRUX_MAXL || n_extra < 0) return crux_fail(ctx, CRUX_EINVAL, "mlp: n_layers %d out of range", L);
-  for (int i = 0; i <= L; ++i) if (dims[i] < 1 || dims[i] > 1024) return crux_fail(ctx, CRUX_EINVAL, "mlp: dim %d = %d unsupported", i, dims[i]);
+  if (!ctx || !out || (L > 0 && (!dims || !acts))) return CRUX_EINVAL;
+  if (L < 0 || L > CRUX_MAXL || n_extra < 0 || (L == 0 && n_extra < 1)) return crux_fail(ctx, CRUX_EINVAL, "mlp: n_layers %d / n_extra %d out of range", L, n_extra);
+  for (int i = 0; i <= L && L > 0; ++i) if (dims[i] < 1 || dims[i] > 1024) return crux_fail(ctx, CRUX_EINVAL, "mlp: dim %d = %d unsupported", i, dims[i]);
   crux_mlp* n = new crux_mlp(); n->ctx = ctx;
-  fill_desc(n->nd, L, dims, acts, n_extra);
+  const int32_t dim0[1] = {0};
+  fill_desc(n->nd, L, L > 0 ? dims : dim0, acts, n_extra);
   const size_t bytes = sizeof(float) * (size_t)n->nd.n_params;
   if (hipMalloc(&n->p, bytes) != hipSuccess || hipMalloc(&n->g, bytes) != hipSuccess || hipMalloc(&n->m, bytes) != hipSuccess ||
       hipMalloc(&n->v, bytes) != hipSuccess || hipMalloc(&n->bp, 2 * sizeof(double)) != hipSuccess) { delete n; return crux_fail(ctx, CRUX_ENOMEM, "mlp: hipMalloc failed"); }
@@ -104,7 +105,7 @@ int32_t crux_mlp_create(crux_ctx* ctx, int32_t L, const int32_t* dims, const int
 int32_t crux_mlp_destroy(crux_mlp* n) {
   if (!n) return CRUX_OK;
   (void)hipStreamSynchronize(n->ctx->stream);
-  (void)hipFree(n->p); (void)hipFree(n->g); (void)hipFree(n->m); (void)hipFree(n->v); (void)hipFree(n->bp);
+  (void)hipFree(n->p); (void)hipFree(n->g); (void)hipFree(n->m); (void)hipFree(n->v); (void)hipFree(n->bp); if (n->ws) (void)hipFree(n->ws);
   delete n; return CRUX_OK;
 }
 
@@ -215,6 +216,7 @@ int32_t crux_adam_apply(crux_mlp* n, float grad_scale) {
 int32_t crux_mlp_forward_impl(crux_mlp* n, const float* d_x, int64_t B, float* d_y, const float* params_override) {
   if (B == 0) return CRUX_OK;
   crux_ctx* c = n->ctx;
+  if (n->nd.L < 1) return crux_fail(c, CRUX_EINVAL, "mlp_forward: the handle is a bare parameter vector (n_layers = 0)");
   const size_t lds = sizeof(float) * 2 * (size_t)n->nd.maxdim * FWD_TS;
   if (lds > 65536) return crux_fail(c, CRUX_EUNSUP, "mlp_forward: layer width %d exceeds the generic kernel's LDS tile", n->nd.maxdim);
   int64_t nb = (B + FWD_TS - 1) / FWD_TS; if (nb > 4096) nb = 4096;

@@ -1,0 +1,256 @@
+// sac.hip -- SAC learner steps on the dense engine (dense.hip).
+// Reference: src/model_free/rl/sac.jl:4-9 (sac_target), :34-40 (sac_actor_loss), :45-52 (sac_temp_loss); double_Q_loss
+// src/utils.jl:89-96; GaussianPolicy exploration / gaussian_logpdf src/policies.jl:333-344; value(pi, s, a) = net(vcat(s, a))
+// src/policies.jl:96; train! src/training.jl:13-25 (gradient norm, NaN => error before the update, Adam).
+//
+// Each step is a short stream-ordered chain: tile GEMMs for the networks, small elementwise/reduction kernels for the heads,
+// and a device-side "norm is NaN => skip Adam" so that one host read-back per step (the info row) is the only synchronisation.
+#include "common.h"
+
+// Box-Muller standard normal, first output; identical to the rollout's definition (env.hip, oracle randn_f32).
+__device__ __forceinline__ float sac_randn(uint64_t seed, uint64_t ctr, uint32_t stream) {
+  const crux_u32x4 x = crux_philox(seed, ctr, stream, CRUX_RNG_NOISE);
+  const double u1 = crux_u32x2_to_f64(x.v[0], x.v[1]), u2 = crux_u32x2_to_f64(x.v[2], x.v[3]);
+  return (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * M_PI * u2));
+}
+
+// exploration(pi::GaussianPolicy, s) (policies.jl:338-344) from the cached means: a = eps*sigma + mu, logprob, eps; and sa = vcat(s, a).
+__global__ void k_gauss_explore(const float* __restrict__ mu, const float* __restrict__ ls, const float* __restrict__ s, int od, int ad, int64_t B,
+                                uint64_t seed, uint64_t counter, float* __restrict__ sa, float* __restrict__ lp, float* __restrict__ eps) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (j >= B) return;
+  float acc = 0.f;
+  for (int d = 0; d < ad; ++d) {
+    const float sg = expf(ls[d]); const float e = sac_randn(seed, counter, (uint32_t)(j * ad + d));
+    const float m = mu[j * ad + d]; const float a = __fadd_rn(__fmul_rn(e, sg), m);
+    const float s2 = __fmul_rn(sg, sg), df = __fsub_rn(a, m);
+    acc = __fadd_rn(acc, __fsub_rn(__fsub_rn(-(__fmul_rn(df, df)) / __fmul_rn(2.f, s2), 0.9189385332046727f), ls[d]));
+    if (sa) sa[j * (od + ad) + od + d] = a;
+    if (eps) eps[j * ad + d] = e;
+  }
+  if (sa) for (int k = 0; k < od; ++k) sa[j * (od + ad) + k] = s[j * od + k];
+  lp[j] = acc;
+}
+__global__ void k_concat_sa(const float* __restrict__ s, const float* __restrict__ a, int od, int ad, int64_t B, float* __restrict__ sa) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= B * (od + ad)) return;
+  const int64_t j = i / (od + ad); const int k = (int)(i - j * (od + ad));
+  sa[i] = k < od ? s[j * od + k] : a[j * ad + (k - od)];
+}
+__global__ void k_sac_target(const float* __restrict__ r, const uint8_t* __restrict__ done, const float* __restrict__ q1, const float* __restrict__ q2,
+                             const float* __restrict__ lp, const float* __restrict__ log_alpha, float gamma, int64_t B, float* __restrict__ y) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (j >= B) return;
+  const float alpha = expf(log_alpha[0]); const float mn = q2[j] < q1[j] ? q2[j] : q1[j];
+  y[j] = __fadd_rn(r[j], __fmul_rn(__fmul_rn(gamma, __fsub_rn(1.f, done[j] ? 1.f : 0.f)), __fsub_rn(mn, __fmul_rn(alpha, lp[j]))));
+}
+
+// deterministic single-block reductions (256 threads; double accumulators like the oracle)
+__device__ __forceinline__ double block_sum256(double v, double* red) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + red[2]) + red[3];
+}
+// sac_temp_loss: loss = -mean(alpha*(lp + H)); d/dlog_alpha = the same value. dev_info: [LOSS, GRAD_NORM, ALPHA]; ssq = grad^2 (NaN gate)
+__global__ __launch_bounds__(256) void k_temp_head(const float* __restrict__ lp, int64_t B, float H, const float* __restrict__ log_alpha, float* __restrict__ g,
+                                                   float* __restrict__ dinfo, double* __restrict__ ssq) {
+  __shared__ double red[4];
+  const float alpha = expf(log_alpha[0]); double st = 0;
+  for (int64_t j = threadIdx.x; j < B; j += 256) st += (double)(alpha * (lp[j] + H));
+  st = block_sum256(st, red);
+  if (threadIdx.x == 0) { const float m = (float)(st / (double)B); g[0] = -m; dinfo[CRUX_INFO_LOSS] = -m; dinfo[CRUX_INFO_GRAD_NORM] = fabsf(m); dinfo[CRUX_INFO_ALPHA] = alpha;
+    ssq[0] = (double)m * (double)m; }
+}
+// td head of one Q network: dy = 0.5 * 2 (Q - y) w / B; stats: sum (Q-y)^2 w, sum Q
+__global__ __launch_bounds__(256) void k_q_head(const float* __restrict__ Q, const float* __restrict__ y, const float* __restrict__ w, int64_t B, float scale,
+                                                float* __restrict__ dy, double* __restrict__ stats /* [2] */) {
+  __shared__ double red[4];
+  const float invB = 1.f / (float)B; double sl = 0, sq = 0;
+  for (int64_t j = threadIdx.x; j < B; j += 256) { const float d = Q[j] - y[j]; const float ww = w ? w[j] : 1.f; sl += (double)(d * d * ww); sq += (double)Q[j];
+    dy[j] = scale * (2.f * d * ww * invB); }
+  sl = block_sum256(sl, red); sq = block_sum256(sq, red);
+  if (threadIdx.x == 0) { stats[0] = sl; stats[1] = sq; }
+}
+// sum of squares of up to two flat gradients (norm(grads), utils.jl:49-55: sqrt of the sum of per-tensor squared norms)
+__global__ __launch_bounds__(1024) void k_sumsq2(const float* __restrict__ g1, int64_t n1, const float* __restrict__ g2, int64_t n2, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0;
+  for (int64_t i = threadIdx.x; i < n1; i += 1024) s += (double)g1[i] * (double)g1[i];
+  for (int64_t i = threadIdx.x; i < n2; i += 1024) s += (double)g2[i] * (double)g2[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0; for (int k = 0; k < 16; ++k) t += red[k]; out[0] = t; }
+}
+__global__ void k_critic_info(const double* __restrict__ st1, const double* __restrict__ st2, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) {
+  dinfo[CRUX_INFO_LOSS] = (float)(0.5 * (st1[0] / (double)B) + 0.5 * (st2[0] / (double)B));
+  dinfo[CRUX_INFO_Q1AVG] = (float)(st1[1] / (double)B); dinfo[CRUX_INFO_Q2AVG] = (float)(st2[1] / (double)B);
+  dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
+}
+// sac_actor_loss head: which Q is the minimum, d(-mean(min Q))/dQ, loss statistics
+__global__ __launch_bounds__(256) void k_actor_head(const float* __restrict__ q1, const float* __restrict__ q2, const float* __restrict__ lp, const float* __restrict__ log_alpha,
+                                                    int64_t B, float* __restrict__ dy1, float* __restrict__ dy2, double* __restrict__ stats /* [2] */) {
+  __shared__ double red[4];
+  const float alpha = expf(log_alpha[0]), invB = 1.f / (float)B; double sl = 0, slp = 0;
+  for (int64_t j = threadIdx.x; j < B; j += 256) { const bool second = q2[j] < q1[j]; const float mn = second ? q2[j] : q1[j];
+    sl += (double)(alpha * lp[j] - mn); slp += (double)lp[j]; dy1[j] = second ? 0.f : -invB; dy2[j] = second ? -invB : 0.f; }
+  sl = block_sum256(sl, red); slp = block_sum256(slp, red);
+  if (threadIdx.x == 0) { stats[0] = sl; stats[1] = slp; }
+}
+// reverse pass through exploration(): mubar [ad x B] and the per-sample logSigma contributions [ad x B] (see the oracle for the accumulation order)
+__global__ void k_actor_grad(const float* __restrict__ sa, const float* __restrict__ mu, const float* __restrict__ eps, const float* __restrict__ ls,
+                             const float* __restrict__ dsa1, const float* __restrict__ dsa2, const float* __restrict__ log_alpha, int od, int ad, int64_t B,
+                             float* __restrict__ dmu, float* __restrict__ dls) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= B * ad) return;
+  const int64_t j = i / ad; const int d = (int)(i - j * ad);
+  const float alpha = expf(log_alpha[0]); const float clp = alpha * (1.f / (float)B);
+  const float sg = expf(ls[d]), s2 = sg * sg, a = sa[j * (od + ad) + od + d], df = a - mu[i];
+  const float dq = dsa1[j * (od + ad) + od + d] + dsa2[j * (od + ad) + od + d];   // only the selected network's entry is non-zero
+  const float abar = clp * (-(df / s2)) + dq;
+  dmu[i] = clp * (df / s2) + abar;
+  dls[i] = clp * ((df * df) / s2 - 1.f) + abar * (eps[i] * sg);
+}
+__global__ void k_rowsum(const float* __restrict__ v, int ad, int64_t B, float* __restrict__ out) {   // out[d] = sum_j v[d + ad*j], sequential like the oracle
+  const int d = blockIdx.x * blockDim.x + threadIdx.x; if (d >= ad) return;
+  float acc = 0.f; for (int64_t j = 0; j < B; ++j) acc += v[d + (int64_t)ad * j];
+  out[d] = acc;
+}
+__global__ void k_actor_info(const double* __restrict__ st, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) {
+  dinfo[CRUX_INFO_LOSS] = (float)(st[0] / (double)B); dinfo[CRUX_INFO_ENTROPY] = (float)(-(st[1] / (double)B)); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
+}
+// Flux.update!(Adam) gated on the gradient norm: NaN => parameters untouched, status set (training.jl:20)
+__global__ void k_adam_gated(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, const double* __restrict__ bp,
+                             double eta, double b1, double b2, double eps, int64_t n, const double* __restrict__ ssq, int32_t* __restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (isnan(ssq[0])) { if (i == 0) status[0] = CRUX_ENAN; return; }
+  if (i >= n) return;
+  const double gd = (double)g[i];
+  const float mi = (float)(b1 * (double)m[i] + (1.0 - b1) * gd);
+  const float vi = (float)(b2 * (double)v[i] + ((1.0 - b2) * gd) * gd);
+  const float d = (float)((double)mi / (1.0 - bp[0]) / (sqrt((double)vi / (1.0 - bp[1])) + eps) * eta);
+  m[i] = mi; v[i] = vi; p[i] = p[i] - d;
+}
+__global__ void k_adam_advance_gated(double* bp, double b1, double b2, const double* __restrict__ ssq) { if (!isnan(ssq[0])) { bp[0] *= b1; bp[1] *= b2; } }
+
+static int32_t adam_gated(crux_mlp* n, const double* d_ssq, int32_t* d_status) {
+  crux_ctx* c = n->ctx;
+  if (!n->has_adam) return crux_fail(c, CRUX_EINVAL, "train!: crux_adam_init was not called on this handle");
+  const int64_t cnt = n->nd.n_params;
+  hipLaunchKernelGGL(k_adam_gated, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, n->p, n->g, n->m, n->v, n->bp, n->eta, n->b1, n->b2, n->eps, cnt, d_ssq, d_status);
+  hipLaunchKernelGGL(k_adam_advance_gated, dim3(1), dim3(1), 0, c->stream, n->bp, n->b1, n->b2, d_ssq);
+  return crux_launch_check(c, "k_adam_gated");
+}
+
+// scratch carve-up: one crux_scratch block per call
+struct Carve { char* p; size_t off; template <class T> T* take(size_t n) { T* r = (T*)(p + off); off += ((n * sizeof(T) + 255) / 256) * 256; return r; } };
+static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+static int32_t check_sac(crux_ctx* c, crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* la, crux_buffer* b, const char* who) {
+  const int od = b->obs_dim, ad = b->act_dim;
+  if (b->elements < 1) return crux_fail(c, CRUX_EINVAL, "%s: empty batch", who);
+  if (b->act_kind != CRUX_ACTION_CONTINUOUS) return crux_fail(c, CRUX_EINVAL, "%s: needs a continuous action column", who);
+  if (actor && (actor->nd.L < 1 || actor->nd.dims[0] != od || actor->nd.dims[actor->nd.L] != ad || actor->nd.n_extra != ad || ad > 64))
+    return crux_fail(c, CRUX_EINVAL, "%s: actor must be a GaussianPolicy handle %d -> %d with %d logSigma extras", who, od, ad, ad);
+  crux_mlp* qs[2] = {q1, q2};
+  for (int t = 0; t < 2; ++t) if (qs[t] && (qs[t]->nd.L < 1 || qs[t]->nd.dims[0] != od + ad || qs[t]->nd.dims[qs[t]->nd.L] != 1))
+    return crux_fail(c, CRUX_EINVAL, "%s: Q%d must map vcat(s, a) (%d) -> 1", who, t + 1, od + ad);
+  if (la && la->nd.n_params < 1) return crux_fail(c, CRUX_EINVAL, "%s: log_alpha handle has no parameters", who);
+  return CRUX_OK;
+}
+static int32_t finish_step(crux_ctx* c, const float* d_info, const int32_t* d_status, float* info_out, const char* who) {
+  float* h = (float*)crux_pinned(c, sizeof(float) * CRUX_INFO_N + 16); if (!h) return crux_fail(c, CRUX_ENOMEM, "%s: pinned staging", who);
+  HIPCHK(c, hipMemcpyAsync(h, d_info, sizeof(float) * CRUX_INFO_N, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h + CRUX_INFO_N, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (info_out) memcpy(info_out, h, sizeof(float) * CRUX_INFO_N);
+  int32_t st; memcpy(&st, h + CRUX_INFO_N, sizeof st);
+  if (st == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20) in %s", who);
+  return CRUX_OK;
+}
+
+extern "C" {
+
+int32_t crux_sac_target(crux_mlp* actor, crux_mlp* q1t, crux_mlp* q2t, crux_mlp* la, crux_buffer* b, float gamma, uint64_t seed, uint64_t counter, float* d_y) {
+  if (!actor || !q1t || !q2t || !la || !b || !d_y) return CRUX_EINVAL;
+  crux_ctx* c = actor->ctx; int32_t rc = check_sac(c, actor, q1t, q2t, la, b, "sac_target"); if (rc) return rc;
+  const int64_t B = b->elements; const int od = b->obs_dim, ad = b->act_dim;
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (od + ad + 1) + 1024), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "sac_target: scratch");
+  float* sa = cv.take<float>((size_t)B * (od + ad)); float* lp = cv.take<float>((size_t)B);
+  const float* SP = (const float*)b->col[CRUX_COL_SP];
+  rc = crux_dense_forward(actor, SP, B, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_gauss_explore, dim3(nblk(B)), dim3(256), 0, c->stream, crux_dense_act(actor, actor->nd.L), actor->p + actor->nd.xoff, SP, od, ad, B, seed, counter, sa, lp, (float*)nullptr);
+  rc = crux_dense_forward(q1t, sa, B, c->stream); if (rc) return rc;
+  rc = crux_dense_forward(q2t, sa, B, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_sac_target, dim3(nblk(B)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE],
+                     crux_dense_act(q1t, q1t->nd.L), crux_dense_act(q2t, q2t->nd.L), lp, la->p, gamma, B, d_y);
+  return crux_launch_check(c, "sac_target");
+}
+
+int32_t crux_sac_temp_step(crux_mlp* actor, crux_mlp* la, crux_buffer* b, float H_target, uint64_t seed, uint64_t counter, float* info_out) {
+  if (!actor || !la || !b) return CRUX_EINVAL;
+  crux_ctx* c = actor->ctx; int32_t rc = check_sac(c, actor, nullptr, nullptr, la, b, "sac_temp_loss"); if (rc) return rc;
+  const int64_t B = b->elements; const int od = b->obs_dim, ad = b->act_dim;
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B + 4096), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "sac_temp: scratch");
+  float* lp = cv.take<float>((size_t)B); float* dinfo = cv.take<float>(CRUX_INFO_N); double* ssq = cv.take<double>(1); int32_t* st = cv.take<int32_t>(1);
+  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 3, c->stream));
+  const float* S = (const float*)b->col[CRUX_COL_S];
+  rc = crux_dense_forward(actor, S, B, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_gauss_explore, dim3(nblk(B)), dim3(256), 0, c->stream, crux_dense_act(actor, actor->nd.L), actor->p + actor->nd.xoff, S, od, ad, B, seed, counter, (float*)nullptr, lp, (float*)nullptr);
+  HIPCHK(c, hipMemsetAsync(la->g, 0, sizeof(float) * (size_t)la->nd.n_params, c->stream));
+  hipLaunchKernelGGL(k_temp_head, dim3(1), dim3(256), 0, c->stream, lp, B, H_target, la->p, la->g, dinfo, ssq);
+  rc = adam_gated(la, ssq, st); if (rc) return rc;
+  return finish_step(c, dinfo, st, info_out, "sac_temp_loss");
+}
+
+int32_t crux_double_q_step(crux_mlp* q1, crux_mlp* q2, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out) {
+  if (!q1 || !q2 || !b || !d_y) return CRUX_EINVAL;
+  crux_ctx* c = q1->ctx; int32_t rc = check_sac(c, nullptr, q1, q2, nullptr, b, "double_Q_loss"); if (rc) return rc;
+  if (use_weight && !has_col(b, CRUX_COL_WEIGHT)) return crux_fail(c, CRUX_EINVAL, "double_Q_loss(weight=:weight): batch has no :weight column");
+  const int64_t B = b->elements; const int od = b->obs_dim, ad = b->act_dim;
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (od + ad + 1) + 8192), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "double_q: scratch");
+  float* sa = cv.take<float>((size_t)B * (od + ad)); float* dy = cv.take<float>((size_t)B); float* dinfo = cv.take<float>(CRUX_INFO_N);
+  double* st1 = cv.take<double>(2); double* st2 = cv.take<double>(2); double* ssq = cv.take<double>(1); int32_t* st = cv.take<int32_t>(1);
+  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 5, c->stream));
+  const float* w = use_weight ? (const float*)b->col[CRUX_COL_WEIGHT] : nullptr;
+  hipLaunchKernelGGL(k_concat_sa, dim3(nblk(B * (od + ad))), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_S], (const float*)b->col[CRUX_COL_A], od, ad, B, sa);
+  crux_mlp* qs[2] = {q1, q2}; double* sts[2] = {st1, st2};
+  for (int t = 0; t < 2; ++t) {
+    rc = crux_dense_forward(qs[t], sa, B, c->stream); if (rc) return rc;
+    hipLaunchKernelGGL(k_q_head, dim3(1), dim3(256), 0, c->stream, crux_dense_act(qs[t], qs[t]->nd.L), d_y, w, B, 0.5f, dy, sts[t]);
+    rc = crux_dense_backward(qs[t], sa, B, dy, 1.0f, true, nullptr, c->stream); if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, c->stream, q1->g, (int64_t)q1->nd.n_params, q2->g, (int64_t)q2->nd.n_params, ssq);
+  hipLaunchKernelGGL(k_critic_info, dim3(1), dim3(1), 0, c->stream, st1, st2, ssq, B, dinfo);
+  rc = adam_gated(q1, ssq, st); if (rc) return rc;
+  rc = adam_gated(q2, ssq, st); if (rc) return rc;
+  return finish_step(c, dinfo, st, info_out, "double_Q_loss");
+}
+
+int32_t crux_sac_actor_step(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* la, crux_buffer* b, uint64_t seed, uint64_t counter, float* info_out) {
+  if (!actor || !q1 || !q2 || !la || !b) return CRUX_EINVAL;
+  crux_ctx* c = actor->ctx; int32_t rc = check_sac(c, actor, q1, q2, la, b, "sac_actor_loss"); if (rc) return rc;
+  const int64_t B = b->elements; const int od = b->obs_dim, ad = b->act_dim, sd = od + ad;
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (3 * sd + 3 * ad + 3) + 16384), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "sac_actor: scratch");
+  float* sa = cv.take<float>((size_t)B * sd); float* dsa1 = cv.take<float>((size_t)B * sd); float* dsa2 = cv.take<float>((size_t)B * sd);
+  float* eps = cv.take<float>((size_t)B * ad); float* dmu = cv.take<float>((size_t)B * ad); float* dls = cv.take<float>((size_t)B * ad);
+  float* lp = cv.take<float>((size_t)B); float* dy1 = cv.take<float>((size_t)B); float* dy2 = cv.take<float>((size_t)B);
+  float* dinfo = cv.take<float>(CRUX_INFO_N); double* stats = cv.take<double>(2); double* ssq = cv.take<double>(1); int32_t* st = cv.take<int32_t>(1);
+  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 4, c->stream));
+  const float* S = (const float*)b->col[CRUX_COL_S];
+  rc = crux_dense_forward(actor, S, B, c->stream); if (rc) return rc;
+  float* mu = crux_dense_act(actor, actor->nd.L);
+  hipLaunchKernelGGL(k_gauss_explore, dim3(nblk(B)), dim3(256), 0, c->stream, mu, actor->p + actor->nd.xoff, S, od, ad, B, seed, counter, sa, lp, eps);
+  rc = crux_dense_forward(q1, sa, B, c->stream); if (rc) return rc;
+  rc = crux_dense_forward(q2, sa, B, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_actor_head, dim3(1), dim3(256), 0, c->stream, crux_dense_act(q1, q1->nd.L), crux_dense_act(q2, q2->nd.L), lp, la->p, B, dy1, dy2, stats);
+  rc = crux_dense_backward(q1, sa, B, dy1, 1.0f, false, dsa1, c->stream); if (rc) return rc;     // gradient w.r.t. vcat(s, a) only: the Q parameters are not trained here
+  rc = crux_dense_backward(q2, sa, B, dy2, 1.0f, false, dsa2, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_actor_grad, dim3(nblk(B * ad)), dim3(256), 0, c->stream, sa, mu, eps, actor->p + actor->nd.xoff, dsa1, dsa2, la->p, od, ad, B, dmu, dls);
+  rc = crux_dense_backward(actor, S, B, dmu, 1.0f, true, nullptr, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_rowsum, dim3(1), dim3(64), 0, c->stream, dls, ad, B, actor->g + actor->nd.xoff);
+  hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, c->stream, actor->g, (int64_t)actor->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+  hipLaunchKernelGGL(k_actor_info, dim3(1), dim3(1), 0, c->stream, stats, ssq, B, dinfo);
+  rc = adam_gated(actor, ssq, st); if (rc) return rc;
+  return finish_step(c, dinfo, st, info_out, "sac_actor_loss");
+}
+
+}  // extern "C"

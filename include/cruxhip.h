@@ -65,7 +65,8 @@ int32_t crux_prof_get(crux_ctx* ctx, int32_t slot, double* ms_total, int64_t* la
  * replaces Flux Chain(Dense(in,out,act)...) wrapped by ContinuousNetwork / DiscreteNetwork
  * (src/policies.jl:68-98,104-157). Flat parameter vector = Flux.params order: W1,b1,W2,b2,... then
  * `n_extra` trailing trainables (GaussianPolicy's ConstantLayer logSigma, src/policies.jl:315-320,
- * src/utils.jl:31-36). */
+ * src/utils.jl:31-36). n_layers = 0 with n_extra >= 1 is a bare trainable vector (a ConstantLayer on
+ * its own; SAC's log_alpha, src/model_free/rl/sac.jl:96) that owns parameters and Adam state only. */
 enum { CRUX_ACT_IDENTITY = 0, CRUX_ACT_RELU = 1, CRUX_ACT_TANH = 2 };
 int32_t crux_mlp_create(crux_ctx* ctx, int32_t n_layers, const int32_t* dims /*n_layers+1*/,
                         const int32_t* acts /*n_layers*/, int32_t n_extra, crux_mlp** out);
@@ -81,6 +82,12 @@ int32_t crux_mlp_init_glorot(crux_mlp* net, uint64_t seed, uint32_t stream, floa
 int32_t crux_mlp_forward(crux_mlp* net, const float* d_x, int64_t B, float* d_y);
 /* same with host pointers (copies in/out, synchronous).                                          */
 int32_t crux_mlp_forward_host(crux_mlp* net, const float* x, int64_t B, float* y);
+/* The pullback Zygote builds for value(pi, x) (src/training.jl:16-18) as an explicit call, on the MFMA dense engine:
+ * forward with cached activations, then for d(loss)/d(y) = d_dy [out x B]: parameter gradients (scaled by grad_scale,
+ * written to crux_mlp_grads_ptr; skipped when want_param_grads = 0) and d(loss)/d(x) into d_dx [in x B] (NULL = skip).   */
+int32_t crux_mlp_forward_cached(crux_mlp* net, const float* d_x, int64_t B, float* d_y /* NULL = keep internal only */);
+int32_t crux_mlp_backward(crux_mlp* net, const float* d_x, int64_t B, const float* d_dy, float grad_scale,
+                          int32_t want_param_grads, float* d_dx);
 /* copyto!(to, from) (src/policies.jl:61-65) and polyak_average!(to, from, tau) (:48-59).         */
 int32_t crux_mlp_copy(crux_mlp* to, const crux_mlp* from);
 int32_t crux_polyak(crux_mlp* to, const crux_mlp* from, float tau);
@@ -231,7 +238,8 @@ typedef struct {
 /* info keys written by train!/batch_train! (training.jl:22-23,53; ppo.jl:13-19).                   */
 enum { CRUX_INFO_LOSS = 0, CRUX_INFO_GRAD_NORM = 1, CRUX_INFO_ENTROPY = 2, CRUX_INFO_KL = 3,
        CRUX_INFO_CLIP_FRACTION = 4, CRUX_INFO_AVG_ADVANTAGE = 5, CRUX_INFO_AVG_RETURN = 6,
-       CRUX_INFO_BATCHES_TRAINED = 7, CRUX_INFO_EPOCHS_RUN = 8, CRUX_INFO_N = 16 };
+       CRUX_INFO_BATCHES_TRAINED = 7, CRUX_INFO_EPOCHS_RUN = 8, CRUX_INFO_Q1AVG = 9, CRUX_INFO_Q2AVG = 10,
+       CRUX_INFO_ALPHA = 11 /* "SAC alpha" (sac.jl:47) */, CRUX_INFO_N = 16 };
 
 /* batch_train!(pi, p, P, D) (training.jl:28-55): epochs x (shuffle!, partition, train!) with
  * max_batches and early stopping (incl. the aliased-info semantics), executed by
@@ -272,6 +280,30 @@ int32_t crux_td_error(crux_mlp* net, crux_buffer* batch, const float* d_y, float
 /* train!(critic, td_loss) (utils.jl:76-87): one Adam step on mean((Q(s,a)-y)^2 [.* weight]).       */
 int32_t crux_td_step(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight,
                      float* info_out /* LOSS, GRAD_NORM, [2]=Qavg */);
+
+
+/* SAC (src/model_free/rl/sac.jl) -----------------------------------------------------------------------
+ * actor: GaussianPolicy handle (mean network + n_extra = act_dim trainable logSigma, policies.jl:315-348);
+ * critic: DoubleNetwork = two ContinuousNetwork handles over vcat(s, a) (policies.jl:96,162-187); log_alpha:
+ * a bare-vector handle (n_layers 0, n_extra 1; sac.jl:96). `batch` is the staging buffer rand! filled
+ * (continuous actions). exploration's randn(Float32, size(mu)) (policies.jl:341) for batch column j, action
+ * dim d is randn(Philox(seed, counter, stream = j*act_dim + d, NOISE)); the three draws of one epoch (target,
+ * temperature, actor) take three different counters. Every *_step is train! (training.jl:13-25): loss ->
+ * gradient -> norm (NaN => CRUX_ENAN, no update) -> Adam. info_out is host [CRUX_INFO_N].                 */
+/* sac_target (sac.jl:4-9): y = r + gamma (1-done) (min(Q1-,Q2-)(sp,a') - exp(log_alpha) logprob(a')), a' ~ actor(sp). */
+int32_t crux_sac_target(crux_mlp* actor, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_mlp* log_alpha, crux_buffer* batch,
+                        float gamma, uint64_t seed, uint64_t counter, float* d_y);
+/* train!(params(SAC_log_alpha), sac_temp_loss) (sac.jl:45-52): LOSS, GRAD_NORM, ALPHA (pre-update).        */
+int32_t crux_sac_temp_step(crux_mlp* actor, crux_mlp* log_alpha, crux_buffer* batch, float H_target,
+                           uint64_t seed, uint64_t counter, float* info_out);
+/* train!(critic(pi), double_Q_loss) (utils.jl:89-96): 0.5 (mse(Q1(s,a),y) + mse(Q2(s,a),y)), optional
+ * weighted_mean(:weight); one gradient norm over both networks. LOSS, GRAD_NORM, Q1AVG, Q2AVG.             */
+int32_t crux_double_q_step(crux_mlp* q1, crux_mlp* q2, crux_buffer* batch, const float* d_y, int32_t use_weight,
+                           float* info_out);
+/* train!(actor(pi), sac_actor_loss) (sac.jl:34-40): mean(exp(log_alpha) logprob(a) - min(Q1,Q2)(s,a)),
+ * a ~ actor(s) reparameterised; LOSS, GRAD_NORM, ENTROPY (= -mean(logprob)).                               */
+int32_t crux_sac_actor_step(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* log_alpha, crux_buffer* batch,
+                            uint64_t seed, uint64_t counter, float* info_out);
 
 #ifdef __cplusplus
 }

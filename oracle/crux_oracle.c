@@ -32,7 +32,7 @@ static int64_t boff(const orc_mlp* n, int l) { return woff(n, l) + (int64_t)n->d
 static int64_t xoff(const orc_mlp* n) { return woff(n, n->n_layers); }
 
 orc_mlp* orc_mlp_create(int32_t n_layers, const int32_t* dims, const int32_t* acts, int32_t n_extra) {
-  if (n_layers < 1 || n_layers > MAXL) return NULL;
+  if (n_layers < 0 || n_layers > MAXL || (n_layers == 0 && n_extra < 1)) return NULL;   /* 0 layers = a bare trainable vector (ConstantLayer, utils.jl:31-36; SAC_log_alpha, sac.jl:96) */
   orc_mlp* n = (orc_mlp*)calloc(1, sizeof(orc_mlp));
   n->n_layers = n_layers; n->n_extra = n_extra;
   for (int i = 0; i <= n_layers; ++i) n->dims[i] = dims[i];
@@ -867,6 +867,144 @@ int32_t orc_td_step(orc_mlp* net, orc_buffer* b, const float* y, int32_t use_wei
   cc_free(net, &c);
   if (isnan(info[CRUX_INFO_GRAD_NORM])) return CRUX_ENAN;
   return orc_adam_apply(net, 1.0f);
+}
+
+/* ============================================================================================
+ * SAC                     src/model_free/rl/sac.jl:4-9,34-52; double_Q_loss src/utils.jl:89-96;
+ *                         GaussianPolicy exploration / gaussian_logpdf src/policies.jl:333-344
+ * Noise of batch column j, action dim d: randn(Philox(seed, counter, stream = j*ad + d, NOISE)).
+ * ============================================================================================ */
+/* reverse pass for one column: parameter gradients into g (if non-NULL) and d(loss)/d(input) into dx (if non-NULL). */
+static void bwd_col_dx(const orc_mlp* n, float** h, const float* dy, float* g, float* dx) {
+  float d0[1024], d1[1024];
+  float *d = d0, *dn = d1;
+  memcpy(d, dy, 4 * (size_t)n->dims[n->n_layers]);
+  for (int l = n->n_layers - 1; l >= 0; --l) {
+    int in = n->dims[l], out = n->dims[l + 1];
+    const float* W = n->p + woff(n, l);
+    for (int o = 0; o < out; ++o) {
+      float y = h[l + 1][o];
+      if (n->acts[l] == CRUX_ACT_RELU) d[o] = y > 0.f ? d[o] : 0.f;
+      else if (n->acts[l] == CRUX_ACT_TANH) d[o] = d[o] * (1.f - y * y);
+    }
+    if (g) { float* gW = g + woff(n, l); float* gb = g + boff(n, l);
+      for (int o = 0; o < out; ++o) gb[o] += d[o];
+      for (int k = 0; k < in; ++k) for (int o = 0; o < out; ++o) gW[o + (int64_t)out * k] += d[o] * h[l][k]; }
+    if (l > 0 || dx) {
+      float* dst = l > 0 ? dn : dx;
+      for (int k = 0; k < in; ++k) { float acc = 0.f; for (int o = 0; o < out; ++o) acc = acc + W[o + (int64_t)out * k] * d[o]; dst[k] = acc; }
+      float* t = d; d = dn; dn = t;
+    }
+  }
+}
+/* exploration(pi::GaussianPolicy, s) policies.jl:338-344 for one column; h = cache of the mean network (h[L] = mu). */
+static float gauss_explore_col(const orc_mlp* actor, float** h, uint64_t seed, uint64_t counter, int64_t j, float* a, float* eps) {
+  int ad = actor->dims[actor->n_layers]; const float* ls = actor->p + xoff(actor); const float* mu = h[actor->n_layers];
+  float lp = 0.f;
+  for (int d = 0; d < ad; ++d) {
+    float sg = expf(ls[d]);                                                   /* sigma = exp.(logSigma) :340 */
+    eps[d] = randn_f32(seed, counter, (uint32_t)(j * ad + d), 0);             /* :341 */
+    a[d] = eps[d] * sg + mu[d];                                               /* :342 */
+    float s2 = sg * sg, df = a[d] - mu[d];                                    /* gaussian_logpdf :333-336 */
+    lp = lp + ((-(df * df) / (2.f * s2) - 0.9189385332046727f) - ls[d]);
+  }
+  return lp;
+}
+static double sumsq_tensors(const orc_mlp* n) {   /* norm(grads): per-tensor 2-norms, then the 2-norm of those (utils.jl:49-55) */
+  double tot = 0;
+  for (int l = 0; l < n->n_layers; ++l) { int64_t w0 = woff(n, l), b0 = boff(n, l), b1 = b0 + n->dims[l + 1]; double sw = 0, sb = 0;
+    for (int64_t i = w0; i < b0; ++i) sw += (double)n->g[i] * n->g[i]; for (int64_t i = b0; i < b1; ++i) sb += (double)n->g[i] * n->g[i]; tot += sw + sb; }
+  double sx = 0; for (int64_t i = xoff(n); i < n->n_params; ++i) sx += (double)n->g[i] * n->g[i];
+  return tot + sx;
+}
+static int sac_shapes_ok(const orc_mlp* actor, const orc_mlp* q1, const orc_mlp* q2, const orc_buffer* b) {
+  int ad = actor->dims[actor->n_layers];
+  return b->act_kind == CRUX_ACTION_CONTINUOUS && actor->dims[0] == b->obs_dim && ad == b->act_dim && actor->n_extra == ad &&
+         q1->dims[0] == b->obs_dim + ad && q2->dims[0] == b->obs_dim + ad && q1->dims[q1->n_layers] == 1 && q2->dims[q2->n_layers] == 1;
+}
+
+/* sac_target sac.jl:4-9: y = r + gamma*(1-done)*(min(Q1^-, Q2^-)(sp, a') - exp(log_alpha)*logprob), a' ~ actor(pi)(sp). */
+int32_t orc_sac_target(orc_mlp* actor, orc_mlp* q1t, orc_mlp* q2t, orc_mlp* log_alpha, orc_buffer* b, float gamma, uint64_t seed, uint64_t counter, float* y) {
+  if (!sac_shapes_ok(actor, q1t, q2t, b) || log_alpha->n_params < 1) return CRUX_EINVAL;
+  int64_t n = b->elements; int od = b->obs_dim, ad = b->act_dim;
+  colcache ca = cc_alloc(actor), c1 = cc_alloc(q1t), c2 = cc_alloc(q2t);
+  const float* SP = (const float*)b->col[CRUX_COL_SP]; const float* R = (const float*)b->col[CRUX_COL_R]; const uint8_t* D = (const uint8_t*)b->col[CRUX_COL_DONE];
+  float a[64], eps[64], sa[1024]; float alpha = expf(log_alpha->p[0]);
+  for (int64_t j = 0; j < n; ++j) {
+    fwd_col(actor, SP + (size_t)j * od, ca.h); float lp = gauss_explore_col(actor, ca.h, seed, counter, j, a, eps);
+    memcpy(sa, SP + (size_t)j * od, 4 * (size_t)od); memcpy(sa + od, a, 4 * (size_t)ad);                 /* value(pi, s, a) = net(vcat(s, a)) policies.jl:96 */
+    fwd_col(q1t, sa, c1.h); fwd_col(q2t, sa, c2.h);
+    float qa = c1.h[q1t->n_layers][0], qb = c2.h[q2t->n_layers][0]; float mn = qb < qa ? qb : qa;
+    y[j] = R[j] + (gamma * (1.f - (D[j] ? 1.f : 0.f))) * (mn - alpha * lp);
+  }
+  cc_free(actor, &ca); cc_free(q1t, &c1); cc_free(q2t, &c2); return CRUX_OK;
+}
+
+/* sac_temp_loss sac.jl:45-52 + train! on Flux.params(SAC_log_alpha): loss = -mean(exp(log_alpha) .* (logprob .+ H_target)). */
+int32_t orc_sac_temp_step(orc_mlp* actor, orc_mlp* log_alpha, orc_buffer* b, float H_target, uint64_t seed, uint64_t counter, float* info) {
+  if (actor->dims[0] != b->obs_dim || actor->n_extra != actor->dims[actor->n_layers] || log_alpha->n_params < 1) return CRUX_EINVAL;
+  int64_t n = b->elements; if (n <= 0) return CRUX_EINVAL; int od = b->obs_dim;
+  colcache ca = cc_alloc(actor); const float* S = (const float*)b->col[CRUX_COL_S];
+  float a[64], eps[64]; float alpha = expf(log_alpha->p[0]); double st = 0;
+  for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
+  for (int64_t j = 0; j < n; ++j) { fwd_col(actor, S + (size_t)j * od, ca.h); float lp = gauss_explore_col(actor, ca.h, seed, counter, j, a, eps); st += (double)(alpha * (lp + H_target)); }
+  cc_free(actor, &ca);
+  float mean_at = (float)(st / (double)n);
+  memset(log_alpha->g, 0, 4 * (size_t)log_alpha->n_params);
+  log_alpha->g[0] = -mean_at;                              /* d/dlog_alpha of -mean(exp(log_alpha) .* t) = -mean(exp(log_alpha) .* t) */
+  info[CRUX_INFO_LOSS] = -mean_at; info[CRUX_INFO_GRAD_NORM] = fabsf(log_alpha->g[0]); info[CRUX_INFO_ALPHA] = alpha;
+  if (isnan(info[CRUX_INFO_GRAD_NORM])) return CRUX_ENAN;
+  return orc_adam_apply(log_alpha, 1.0f);
+}
+
+/* double_Q_loss utils.jl:89-96 + train!(critic(pi)) : 0.5*(mse(Q1(s,a), y) + mse(Q2(s,a), y)) [weighted_mean(:weight)], one gradient norm
+ * over the parameters of both networks, one Adam step each (one optimiser object, per-array state). */
+int32_t orc_double_q_step(orc_mlp* q1, orc_mlp* q2, orc_buffer* b, const float* y, int32_t use_weight, float* info) {
+  int64_t n = b->elements; int od = b->obs_dim, ad = b->act_dim; if (n <= 0 || b->act_kind != CRUX_ACTION_CONTINUOUS) return CRUX_EINVAL;
+  orc_mlp* qs[2] = {q1, q2}; for (int t = 0; t < 2; ++t) if (qs[t]->dims[0] != od + ad || qs[t]->dims[qs[t]->n_layers] != 1) return CRUX_EINVAL;
+  const float* S = (const float*)b->col[CRUX_COL_S]; const float* A = (const float*)b->col[CRUX_COL_A]; const float* W = use_weight ? (const float*)b->col[CRUX_COL_WEIGHT] : NULL;
+  for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
+  float sa[1024], invB = 1.f / (float)n; double loss = 0, tot = 0;
+  for (int t = 0; t < 2; ++t) { orc_mlp* net = qs[t]; colcache c = cc_alloc(net); memset(net->g, 0, 4 * (size_t)net->n_params); double sl = 0, sq = 0;
+    for (int64_t j = 0; j < n; ++j) { memcpy(sa, S + (size_t)j * od, 4 * (size_t)od); memcpy(sa + od, A + (size_t)j * ad, 4 * (size_t)ad);
+      fwd_col(net, sa, c.h); float Q = c.h[net->n_layers][0], d = Q - y[j], w = W ? W[j] : 1.f; sl += (double)(d * d * w); sq += (double)Q;
+      float dy = 0.5f * (2.f * d * w * invB); bwd_col_dx(net, c.h, &dy, net->g, NULL); }
+    loss += 0.5 * (sl / (double)n); info[t == 0 ? CRUX_INFO_Q1AVG : CRUX_INFO_Q2AVG] = (float)(sq / (double)n); tot += sumsq_tensors(net); cc_free(net, &c); }
+  info[CRUX_INFO_LOSS] = (float)loss; info[CRUX_INFO_GRAD_NORM] = (float)sqrt(tot);
+  if (isnan(info[CRUX_INFO_GRAD_NORM])) return CRUX_ENAN;
+  int32_t rc = orc_adam_apply(q1, 1.0f); if (rc) return rc; return orc_adam_apply(q2, 1.0f);
+}
+
+/* sac_actor_loss sac.jl:34-40 + train!(actor(pi)): mean(exp(log_alpha).*logprob .- min.(Q1(s,a), Q2(s,a))), a, logprob = exploration(pi.A, s);
+ * reverse mode as Zygote accumulates it: abar = d/da(logprob term) + dQmin/da;  mubar = d/dmu(logprob term) + abar;
+ * logSigmabar = d/dlogSigma(logprob term) + abar * eps * sigma. */
+int32_t orc_sac_actor_step(orc_mlp* actor, orc_mlp* q1, orc_mlp* q2, orc_mlp* log_alpha, orc_buffer* b, uint64_t seed, uint64_t counter, float* info) {
+  if (!sac_shapes_ok(actor, q1, q2, b) || log_alpha->n_params < 1) return CRUX_EINVAL;
+  int64_t n = b->elements; if (n <= 0) return CRUX_EINVAL; int od = b->obs_dim, ad = b->act_dim;
+  colcache ca = cc_alloc(actor), c1 = cc_alloc(q1), c2 = cc_alloc(q2);
+  const float* S = (const float*)b->col[CRUX_COL_S]; const float* ls = actor->p + xoff(actor);
+  float a[64], eps[64], sa[1024], dsa[1024], dmu[64]; float alpha = expf(log_alpha->p[0]), invB = 1.f / (float)n; double sl = 0, slp = 0;
+  for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
+  memset(actor->g, 0, 4 * (size_t)actor->n_params);
+  for (int64_t j = 0; j < n; ++j) {
+    fwd_col(actor, S + (size_t)j * od, ca.h); float lp = gauss_explore_col(actor, ca.h, seed, counter, j, a, eps);
+    memcpy(sa, S + (size_t)j * od, 4 * (size_t)od); memcpy(sa + od, a, 4 * (size_t)ad);
+    fwd_col(q1, sa, c1.h); fwd_col(q2, sa, c2.h);
+    float qa = c1.h[q1->n_layers][0], qb = c2.h[q2->n_layers][0]; int second = qb < qa; float mn = second ? qb : qa;
+    sl += (double)(alpha * lp - mn); slp += (double)lp;
+    float dyq = -invB; bwd_col_dx(second ? q2 : q1, second ? c2.h : c1.h, &dyq, NULL, dsa);            /* d(-mean(min Q))/d(vcat(s,a)) */
+    const float* mu = ca.h[actor->n_layers]; float clp = alpha * invB;                                  /* d(loss)/d(logprob_j) */
+    for (int d = 0; d < ad; ++d) { float sg = expf(ls[d]), s2 = sg * sg, df = a[d] - mu[d];
+      float abar = clp * (-(df / s2)) + dsa[od + d];
+      dmu[d] = clp * (df / s2) + abar;
+      actor->g[xoff(actor) + d] += clp * ((df * df) / s2 - 1.f) + abar * (eps[d] * sg); }
+    bwd_col_dx(actor, ca.h, dmu, actor->g, NULL);
+  }
+  cc_free(actor, &ca); cc_free(q1, &c1); cc_free(q2, &c2);
+  info[CRUX_INFO_LOSS] = (float)(sl / (double)n); info[CRUX_INFO_ENTROPY] = (float)(-(slp / (double)n));
+  info[CRUX_INFO_GRAD_NORM] = (float)sqrt(sumsq_tensors(actor));
+  if (isnan(info[CRUX_INFO_GRAD_NORM])) return CRUX_ENAN;
+  return orc_adam_apply(actor, 1.0f);
 }
 
 /* test hooks for the randomness spec in include/crux_rng.h */

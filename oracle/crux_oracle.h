@@ -106,6 +106,11 @@ int32_t orc_loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg, 
 int32_t orc_dqn_target(orc_mlp* target_net, orc_buffer* batch, float gamma, float* y);
 int32_t orc_td_error(orc_mlp* net, orc_buffer* batch, const float* y, float* err);
 int32_t orc_td_step(orc_mlp* net, orc_buffer* batch, const float* y, int32_t use_weight, float* info_out);
+/* SAC (src/model_free/rl/sac.jl:4-9,34-52; double_Q_loss src/utils.jl:89-96); log_alpha = orc_mlp_create(0, {0}, NULL, 1). */
+int32_t orc_sac_target(orc_mlp* actor, orc_mlp* q1_targ, orc_mlp* q2_targ, orc_mlp* log_alpha, orc_buffer* batch, float gamma, uint64_t seed, uint64_t counter, float* y);
+int32_t orc_sac_temp_step(orc_mlp* actor, orc_mlp* log_alpha, orc_buffer* batch, float H_target, uint64_t seed, uint64_t counter, float* info_out);
+int32_t orc_double_q_step(orc_mlp* q1, orc_mlp* q2, orc_buffer* batch, const float* y, int32_t use_weight, float* info_out);
+int32_t orc_sac_actor_step(orc_mlp* actor, orc_mlp* q1, orc_mlp* q2, orc_mlp* log_alpha, orc_buffer* batch, uint64_t seed, uint64_t counter, float* info_out);
 
 void orc_perm(uint64_t seed, uint64_t counter, uint32_t n, int64_t* out);
 void orc_philox(uint64_t seed, uint64_t counter, uint32_t stream, uint32_t purpose, uint32_t* out4);

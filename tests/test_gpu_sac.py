@@ -1,0 +1,212 @@
+"""GPU parity: dense engine (forward/backward of Chain(Dense...)) and the SAC learner steps vs the oracle.
+
+Reference seams: value(pi, s[, a]) src/policies.jl:94-96; Zygote pullback in train! src/training.jl:13-25;
+sac_target / sac_actor_loss / sac_temp_loss src/model_free/rl/sac.jl:4-9,34-52; double_Q_loss src/utils.jl:89-96;
+value_training / solve src/model_free/off_policy.jl:66-150. Tolerances: fp32 sums are re-associated by the MFMA
+tiles (k-chunked) -> 2e-5 absolute on parameters after a step of size ~1e-3, 1e-4 relative on losses and norms.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity
+from parity import crux, L, O
+
+pytestmark = pytest.mark.gpu
+
+
+def _np_mlp(params, dims, acts, x):
+    """float64 forward of Chain(Dense...) returning all activations."""
+    hs, off = [x.astype(np.float64)], 0
+    for l, act in enumerate(acts):
+        i, o = dims[l], dims[l + 1]
+        W = params[off:off + i * o].reshape((o, i), order="F").astype(np.float64); off += i * o
+        b = params[off:off + o].astype(np.float64); off += o
+        z = W @ hs[-1] + b[:, None]
+        hs.append(np.maximum(z, 0) if act == "relu" else np.tanh(z) if act == "tanh" else z)
+    return hs
+
+
+def _np_backward(params, dims, acts, hs, dy):
+    g, d = np.zeros_like(params, dtype=np.float64), dy.astype(np.float64)
+    offs, off = [], 0
+    for l in range(len(acts)):
+        offs.append(off); off += dims[l] * dims[l + 1] + dims[l + 1]
+    for l in reversed(range(len(acts))):
+        i, o = dims[l], dims[l + 1]
+        y = hs[l + 1]
+        d = d * (y > 0) if acts[l] == "relu" else d * (1 - y * y) if acts[l] == "tanh" else d
+        W = params[offs[l]:offs[l] + i * o].reshape((o, i), order="F").astype(np.float64)
+        g[offs[l]:offs[l] + i * o] = (d @ hs[l].T).reshape(-1, order="F")
+        g[offs[l] + i * o:offs[l] + i * o + o] = d.sum(axis=1)
+        d = W.T @ d
+    return g, d
+
+
+@pytest.mark.parametrize("dims,acts,B", [([3, 32, 1], ["tanh", "identity"], 37), ([2, 32, 1], ["relu", "tanh"], 256), ([4, 256, 256, 1], ["relu", "relu", "identity"], 256),
+                                         ([17, 64, 64, 6], ["tanh", "tanh", "identity"], 100), ([8, 256, 256, 4], ["relu", "relu", "identity"], 128), ([5, 7, 3], ["relu", "identity"], 19)])
+def test_dense_forward_backward_match_float64(gpu_ctx, dims, acts, B):
+    ctx = gpu_ctx
+    net = crux.ContinuousNetwork(parity.chain(dims, acts), seed=7, stream=2, ctx=ctx)
+    rng = np.random.default_rng(3)
+    p = net.get_params(); p += rng.normal(0, 0.05, p.size).astype(np.float32); net.set_params(p)      # non-zero biases
+    x = np.asfortranarray(rng.normal(0, 1, (dims[0], B)).astype(np.float32)); dy = np.asfortranarray(rng.normal(0, 1, (dims[-1], B)).astype(np.float32))
+    d_x, d_dy, d_y, d_dx = ctx.alloc(x.nbytes), ctx.alloc(dy.nbytes), ctx.alloc(dy.nbytes), ctx.alloc(x.nbytes)
+    ctx.h2d(d_x, x); ctx.h2d(d_dy, dy)
+    ctx.check(ctx.lib.crux_mlp_forward_cached(net.h, d_x, B, d_y))
+    ctx.check(ctx.lib.crux_mlp_backward(net.h, d_x, B, d_dy, 0.5, 1, d_dx))
+    y, dx, g = np.empty_like(dy), np.empty_like(x), np.empty(p.size, np.float32)
+    ctx.d2h(d_y, y); ctx.d2h(d_dx, dx); ctx.d2h(ctx.lib.crux_mlp_grads_ptr(net.h), g)
+    hs = _np_mlp(p, dims, acts, x); gref, dxref = _np_backward(p, dims, acts, hs, dy)
+    assert np.abs(y - hs[-1]).max() < 2e-5 * max(1, np.abs(hs[-1]).max())
+    assert np.abs(y - net.forward(x)).max() < 2e-5 * max(1, np.abs(hs[-1]).max())                      # generic forward kernel agrees too
+    assert np.abs(dx - dxref).max() < 1e-4 * max(1, np.abs(dxref).max())
+    assert np.abs(g - 0.5 * gref).max() < 1e-4 * max(1, np.abs(gref).max())
+    for d in (d_x, d_dy, d_y, d_dx):
+        ctx.free(d)
+
+
+def _grads(net, ctx):
+    g = np.empty(net.n_params, np.float32); ctx.d2h(ctx.lib.crux_mlp_grads_ptr(net.h), g); return g
+
+
+def _step_close(g, o, ctx, lr=1e-3):
+    """After one train!: gradients agree to 1e-4 of their scale; parameters agree except where Adam's first steps amplify rounding
+    (step = lr*g/(|g|+1e-8) is discontinuous at g = 0): at most 0.1 % of the entries may differ by more than 2e-5, none by more than lr/2."""
+    gg, og = _grads(g, ctx), o.grads
+    ok = np.abs(gg - og).max() <= 1e-4 * max(np.abs(og).max(), 1e-6)
+    d = np.abs(g.get_params() - o.params)
+    return bool(ok and d.max() < 0.5 * lr and np.mean(d > 2e-5) <= 1e-3)
+
+
+def _sac_pair(od, ad, hidden, q_act, a_acts, seed, ctx):
+    adims, qdims = [od] + hidden + [ad], [od + ad] + hidden + [1]
+    qacts = [q_act] * len(hidden) + ["identity"]
+    ga, oa = parity.make_pair(adims, a_acts, seed, 0, "gaussian", n_extra=ad, extra_init=-0.3)
+    g1, o1 = parity.make_pair(qdims, qacts, seed, 1); g2, o2 = parity.make_pair(qdims, qacts, seed, 2)
+    return (ga, g1, g2), (oa, o1, o2), (adims, qdims, qacts)
+
+
+def _batch_pair(rng, od, ad, B, ctx, weight=False):
+    extras = ["weight"] if weight else []
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.ContinuousSpace(ad), B, extras, ctx=ctx)
+    ob = O.OBuffer(od, ad, L.ACTION_CONTINUOUS, B, extras)
+    data = {"s": rng.normal(0, 1, (od, B)).astype(np.float32), "a": rng.uniform(-2, 2, (ad, B)).astype(np.float32), "sp": rng.normal(0, 1, (od, B)).astype(np.float32),
+            "r": rng.normal(-1, 1, (1, B)).astype(np.float32), "done": rng.random((1, B)) < 0.1, "episode_end": np.zeros((1, B), bool)}
+    if weight:
+        data["weight"] = rng.uniform(0.2, 1.0, (1, B)).astype(np.float32)
+    gb.push_(data); ob.push(data)
+    return gb, ob
+
+
+@pytest.mark.parametrize("od,ad,hidden,q_act,a_acts,B", [(2, 1, [32], "tanh", ["relu", "tanh"], 64),               # test/gym/solver_tests.jl:76-87 shapes
+                                                       (3, 1, [256, 256], "relu", ["relu", "relu", "identity"], 256),    # C4
+                                                       (17, 6, [64, 64], "relu", ["tanh", "tanh", "identity"], 100)])
+def test_sac_steps_match_oracle(gpu_ctx, od, ad, hidden, q_act, a_acts, B):
+    ctx, rng, seed = gpu_ctx, np.random.default_rng(11), 21
+    (ga, g1, g2), (oa, o1, o2), (adims, qdims, qacts) = _sac_pair(od, ad, hidden, q_act, a_acts, 5, ctx)
+    pim = crux.clone_policy(crux.ActorCritic(ga, crux.DoubleNetwork(g1, g2)))
+    ot1, ot2 = O.OMlp(qdims, qacts), O.OMlp(qdims, qacts)
+    # targets differ from the online nets
+    for gt, ot in ((pim.C.N1, ot1), (pim.C.N2, ot2)):
+        p = gt.get_params() + rng.normal(0, 0.02, gt.n_params).astype(np.float32); gt.set_params(p); ot.params[:] = p
+    gla = crux.ParamVector([np.log(np.float32(0.7))], ctx=ctx); ola = O.OMlp([0], [], 1); ola.params[:] = gla.get_params()
+    lr = float(np.float32(1e-3))
+    for g, o in ((ga, oa), (g1, o1), (g2, o2), (gla, ola)):
+        g.attach_optimizer(crux.Adam(np.float32(1e-3))); o.adam_init(lr)
+    gb, ob = _batch_pair(rng, od, ad, B, ctx, weight=True)
+    lib, ol = ctx.lib, O.lib()
+    d_y = ctx.alloc(4 * B); y, yo = np.empty(B, np.float32), np.empty(B, np.float32)
+    gi, oi = np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32)
+
+    def close(a, b, tol=1e-4):
+        return abs(a - b) <= tol * max(1.0, abs(b))
+
+    for rep in range(3):                                               # three epochs: Adam state and beta powers advance
+        ctr = 100 + rep
+        ctx.check(lib.crux_sac_target(ga.h, pim.C.N1.h, pim.C.N2.h, gla.h, gb.h, 0.99, seed, 3 * ctr, d_y)); ctx.d2h(d_y, y)
+        O.chk(ol.orc_sac_target(oa.h, ot1.h, ot2.h, ola.h, ob.h, 0.99, seed, 3 * ctr, O.vpz(yo)))
+        assert np.abs(y - yo).max() < 1e-4 * max(1, np.abs(yo).max())
+        ctx.check(lib.crux_sac_temp_step(ga.h, gla.h, gb.h, float(-ad), seed, 3 * ctr + 1, O.vpz(gi)))
+        O.chk(ol.orc_sac_temp_step(oa.h, ola.h, ob.h, float(-ad), seed, 3 * ctr + 1, O.vpz(oi)))
+        for k in ("loss", "grad_norm", "alpha"):
+            assert close(gi[L.INFO[k]], oi[L.INFO[k]]), ("temp", k, gi, oi)
+        assert np.abs(gla.get_params() - ola.params).max() < 2e-6
+        ctx.check(lib.crux_double_q_step(g1.h, g2.h, gb.h, d_y, rep % 2, O.vpz(gi)))
+        O.chk(ol.orc_double_q_step(o1.h, o2.h, ob.h, O.vpz(yo), rep % 2, O.vpz(oi)))
+        for k in ("loss", "grad_norm", "q1avg", "q2avg"):
+            assert close(gi[L.INFO[k]], oi[L.INFO[k]]), ("critic", k, gi, oi)
+        assert _step_close(g1, o1, ctx) and _step_close(g2, o2, ctx)
+        ctx.check(lib.crux_sac_actor_step(ga.h, g1.h, g2.h, gla.h, gb.h, seed, 3 * ctr + 2, O.vpz(gi)))
+        O.chk(ol.orc_sac_actor_step(oa.h, o1.h, o2.h, ola.h, ob.h, seed, 3 * ctr + 2, O.vpz(oi)))
+        for k in ("loss", "grad_norm", "entropy"):
+            assert close(gi[L.INFO[k]], oi[L.INFO[k]], 2e-4), ("actor", k, gi, oi)
+        assert _step_close(ga, oa, ctx)
+    m, v, bp = ga.adam_state(); mo, vo, bpo = oa.adam_state()
+    assert np.allclose(bp, bpo) and np.abs(m - mo).max() < 1e-5
+    ctx.free(d_y)
+
+
+def test_sac_nan_is_reported_and_nothing_is_updated(gpu_ctx):
+    ctx, rng = gpu_ctx, np.random.default_rng(2)
+    (ga, g1, g2), _, _ = _sac_pair(3, 1, [32], "relu", ["relu", "identity"], 9, ctx)
+    for g in (ga, g1, g2):
+        g.attach_optimizer(crux.Adam(np.float32(1e-3)))
+    gb, _ = _batch_pair(rng, 3, 1, 32, ctx)
+    d_y = ctx.alloc(4 * 32); y = np.zeros(32, np.float32); y[5] = np.nan; ctx.h2d(d_y, y)
+    before = (g1.get_params(), g2.get_params())
+    with pytest.raises(crux.CruxError) as e:
+        ctx.check(ctx.lib.crux_double_q_step(g1.h, g2.h, gb.h, d_y, 0, None))
+    assert e.value.code == L.ENAN
+    assert np.array_equal(g1.get_params(), before[0]) and np.array_equal(g2.get_params(), before[1])
+    assert np.allclose(g1.adam_state()[2], [0.9, 0.999])                                                # beta powers did not advance
+    ctx.free(d_y)
+
+
+def test_sac_solve_matches_oracle_loop(gpu_ctx):
+    """solve(::OffPolicySolver) with SAC on the Pendulum restatement (the reference's continuous solver test, test/gym/solver_tests.jl:87, at 32-wide nets)."""
+    ctx = gpu_ctx
+    E, dN, B, N, cap, seed, max_steps, nseed = 2, 4, 16, 24, 64, 6, 20, 77
+    (ga, g1, g2), (oa, o1, o2), (adims, qdims, qacts) = _sac_pair(3, 1, [32], "tanh", ["relu", "tanh"], 13, ctx)
+    S = crux.ContinuousSpace(3)
+    mdp = crux.PendulumMDP(n_envs=E, seed=seed)
+    pi = crux.ActorCritic(ga, crux.DoubleNetwork(g1, g2))
+    opt = {"batch_size": B, "optimizer": crux.Adam(np.float32(1e-3))}
+    solver = crux.SAC(pi, S, N=N, dN=dN, c_opt=dict(opt), a_opt=dict(opt), SAC_alpha_opt=dict(opt), buffer_size=cap, buffer_init=B, max_steps=max_steps, noise_seed=nseed,
+                      pi_explore=crux.GaussianNoiseExplorationPolicy(0.5, a_min=-2.0, a_max=2.0))
+    crux.solve(solver, mdp)
+    # ---- the same loop on the oracle
+    lr = float(np.float32(1e-3))
+    ota, ot1, ot2 = O.OMlp(adims, ["relu", "tanh"], 1), O.OMlp(qdims, qacts), O.OMlp(qdims, qacts)
+    for t, s in ((ota, oa), (ot1, o1), (ot2, o2)):
+        O.chk(O.lib().orc_mlp_copy(t.h, s.h))
+    ola = O.OMlp([0], [], 1); ola.params[:] = np.log(np.float32(1.0))
+    for o in (oa, o1, o2, ola):
+        o.adam_init(lr)
+    ob = O.OBuffer(3, 1, L.ACTION_CONTINUOUS, cap); obt = O.OBuffer(3, 1, L.ACTION_CONTINUOUS, B)
+    oe = O.OEnv("pendulum", E, max_steps, 0.99, seed)
+    cfg = parity.rollout_cfg(True, False, "deterministic"); cfg.noise_sigma, cfg.a_min, cfg.a_max = 0.5, -2.0, 2.0
+    i = 0; istart = 0
+    i += B; cfg.i0 = i; oe.rollout(oa, cfg, ob, B // E)
+    y, info, ol = np.empty(B, np.float32), np.zeros(L.INFO_N, np.float32), O.lib()
+    gamma = float(np.float32(crux.discount(mdp)))
+    while i <= istart + N - dN:
+        cfg.i0 = i; oe.rollout(oa, cfg, ob, dN // E)
+        for ep in range(dN):
+            ctr = i * dN + ep
+            O.chk(ol.orc_uniform_sample(obt.h, ob.h, B, None, ctr, crux.api.SAMPLE_SEED))
+            O.chk(ol.orc_sac_target(oa.h, ot1.h, ot2.h, ola.h, obt.h, gamma, nseed, 3 * ctr, O.vpz(y)))
+            O.chk(ol.orc_sac_temp_step(oa.h, ola.h, obt.h, -1.0, nseed, 3 * ctr + 1, O.vpz(info)))
+            O.chk(ol.orc_double_q_step(o1.h, o2.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+            O.chk(ol.orc_sac_actor_step(oa.h, o1.h, o2.h, ola.h, obt.h, nseed, 3 * ctr + 2, O.vpz(info)))
+            for t, s in ((ota, oa), (ot1, o1), (ot2, o2)):
+                O.chk(ol.orc_polyak(t.h, s.h, 0.005))
+        i += dN
+    assert solver.i == i and len(solver.buffer) == len(ob)
+    for k in ("s", "a", "sp", "r"):
+        assert np.abs(solver.buffer[k] - ob[k]).max() < 1e-4, k
+    assert np.array_equal(solver.buffer["done"], ob["done"])
+    for g, o in ((ga, oa), (g1, o1), (g2, o2), (solver.P["SAC_log_alpha"], ola), (solver.agent.pi_minus.C.N1, ot1), (solver.agent.pi_minus.A, ota)):
+        assert np.abs(g.get_params() - o.params).max() < 5e-5
+    assert abs(solver.history[-1]["actor_loss"]) < 1e3 and "SAC alpha" in solver.history[-1]

@@ -310,3 +310,75 @@ def test_ragged_last_minibatch_and_permutation_semantics():
     cfg = _cfg("value_mse", "deterministic"); cfg.batch_size, cfg.epochs = 32, 2
     info = np.zeros(L.INFO_N, np.float32); O.chk(lib.orc_batch_train(o.h, ob.h, C.byref(cfg), None, O.vpz(info), None))
     assert int(info[L.INFO["batches_trained"]]) == 6           # partition(1:70, 32) -> 32, 32, 6 per epoch (training.jl:40)
+
+
+# ---- SAC restatement: the analytic reverse pass of the oracle vs central differences of its own losses -----------------
+def _sac_oracle_setup(rng, od=3, ad=2, B=24):
+    adims, qdims = [od, 16, ad], [od + ad, 16, 1]
+    oa = O.OMlp(adims, ["tanh", "identity"], ad).init_glorot(3, 0, -0.4)
+    o1, o2 = O.OMlp(qdims, ["tanh", "identity"]).init_glorot(3, 1), O.OMlp(qdims, ["tanh", "identity"]).init_glorot(3, 2)
+    ola = O.OMlp([0], [], 1); ola.params[:] = np.log(np.float32(0.6))
+    ob = O.OBuffer(od, ad, L.ACTION_CONTINUOUS, B)
+    ob.push({"s": rng.normal(0, 1, (od, B)).astype(np.float32), "a": rng.uniform(-1, 1, (ad, B)).astype(np.float32), "sp": rng.normal(0, 1, (od, B)).astype(np.float32),
+             "r": rng.normal(0, 1, (1, B)).astype(np.float32), "done": rng.random((1, B)) < 0.2, "episode_end": np.zeros((1, B), bool)})
+    for o in (oa, o1, o2, ola):
+        o.adam_init(0.0)                                           # eta = 0: train! evaluates loss and gradient, the update is a no-op
+    return oa, o1, o2, ola, ob, B
+
+
+def _fd(loss_at, params, idx, h=2e-3):
+    out = []
+    for k in idx:
+        keep = params[k]
+        params[k] = keep + h; lp = loss_at()
+        params[k] = keep - h; lm = loss_at()
+        params[k] = keep; out.append((lp - lm) / (2 * h))
+    return np.array(out)
+
+
+def test_sac_oracle_gradients_match_finite_differences():
+    rng = np.random.default_rng(8)
+    oa, o1, o2, ola, ob, B = _sac_oracle_setup(rng)
+    info, ol = np.zeros(L.INFO_N, np.float32), O.lib()
+    # actor loss (sac.jl:34-40): gradient w.r.t. mean-network weights and logSigma
+    def actor_loss():
+        O.chk(ol.orc_sac_actor_step(oa.h, o1.h, o2.h, ola.h, ob.h, 5, 9, O.vpz(info))); return float(info[L.INFO["loss"]])
+    actor_loss(); g = oa.grads.copy()
+    idx = list(rng.choice(oa.n - 2, 8, replace=False)) + [oa.n - 2, oa.n - 1]
+    assert np.allclose(g[idx], _fd(actor_loss, oa.params, idx), rtol=3e-2, atol=2e-3)
+    # critic loss (utils.jl:89-96)
+    y = rng.normal(0, 1, B).astype(np.float32)
+    def critic_loss():
+        O.chk(ol.orc_double_q_step(o1.h, o2.h, ob.h, O.vpz(y), 0, O.vpz(info))); return float(info[L.INFO["loss"]])
+    critic_loss(); g1 = o1.grads.copy()
+    idx = list(rng.choice(o1.n, 8, replace=False))
+    assert np.allclose(g1[idx], _fd(critic_loss, o1.params, idx), rtol=3e-2, atol=2e-3)
+    # temperature loss (sac.jl:45-52): d/dlog_alpha
+    def temp_loss():
+        O.chk(ol.orc_sac_temp_step(oa.h, ola.h, ob.h, -2.0, 5, 10, O.vpz(info))); return float(info[L.INFO["loss"]])
+    temp_loss(); gl = ola.grads.copy()
+    assert np.allclose(gl[:1], _fd(temp_loss, ola.params, [0]), rtol=2e-2, atol=1e-3)
+
+
+def test_sac_target_restatement_against_numpy():
+    """sac_target (sac.jl:4-9) recomputed in float64 numpy from the noise definition in include/crux_rng.h."""
+    rng = np.random.default_rng(4)
+    oa, o1, o2, ola, ob, B = _sac_oracle_setup(rng)
+    y = np.empty(B, np.float32)
+    O.chk(O.lib().orc_sac_target(oa.h, o1.h, o2.h, ola.h, ob.h, 0.9, 5, 3, O.vpz(y)))
+    sp, r, done = ob["sp"].astype(np.float64), ob["r"][0].astype(np.float64), ob["done"][0]
+    mu = oa.forward(ob["sp"]).astype(np.float64); ls = oa.params[-2:].astype(np.float64); sg = np.exp(ls)
+    eps = np.empty_like(mu); out4 = (C.c_uint32 * 4)()
+    for j in range(B):
+        for d in range(2):
+            O.lib().orc_philox(5, 3, j * 2 + d, 2, out4)                                  # purpose 2 = CRUX_RNG_NOISE
+            u1 = (((out4[0] << 32) | out4[1]) >> 11) * 1.1102230246251565e-16
+            u2 = (((out4[2] << 32) | out4[3]) >> 11) * 1.1102230246251565e-16
+            eps[d, j] = np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+    a = eps * sg[:, None] + mu
+    lp = (-((a - mu) ** 2) / (2 * sg[:, None] ** 2) - 0.9189385332046727 - ls[:, None]).sum(axis=0)
+    sa = np.vstack([sp, a]).astype(np.float32)
+    qmin = np.minimum(o1.forward(sa)[0], o2.forward(sa)[0]).astype(np.float64)
+    yref = r + 0.9 * (1.0 - done) * (qmin - np.exp(np.float64(ola.params[0])) * lp)
+    assert np.abs(y - yref).max() < 2e-5 * max(1.0, np.abs(yref).max())
+    assert np.array_equal(y[done], ob["r"][0][done])
