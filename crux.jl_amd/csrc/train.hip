@@ -419,6 +419,11 @@ int32_t crux_td_step(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_
   if (batch->elements < 1) return crux_fail(c, CRUX_EINVAL, "td_loss: empty batch");
   if (batch->act_kind != CRUX_ACTION_DISCRETE || net->nd.dims[net->nd.L] != batch->act_dim) return crux_fail(c, CRUX_EINVAL, "td_loss: needs a one-hot action column matching the Q outputs");
   if (use_weight && !has_col(batch, CRUX_COL_WEIGHT)) return crux_fail(c, CRUX_EINVAL, "td_loss(weight=:weight): batch has no :weight column");
+  if (net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH) {   // wide critics (C3): tile-GEMM engine over many CUs instead of the single-workgroup kernel
+    if (!net->has_adam) return crux_fail(c, CRUX_EINVAL, "train!: crux_adam_init was not called for this network");
+    if (net->nd.dims[0] != batch->obs_dim) return crux_fail(c, CRUX_EINVAL, "train!: network input %d != obs dim %d", net->nd.dims[0], batch->obs_dim);
+    return crux_td_step_dense(net, batch, d_y, use_weight, info_out);
+  }
   crux_train_cfg cfg{}; cfg.loss = CRUX_LOSS_VALUE_MSE; cfg.head = CRUX_HEAD_GREEDY_Q; cfg.batch_size = (int32_t)batch->elements; cfg.epochs = 1; cfg.target_kl = -1.f;
   TrainArgs a; int32_t rc = fill_args(a, net, batch, &cfg, CRUX_LOSS_TD_INTERNAL); if (rc) return rc;
   std::vector<int64_t> ids((size_t)batch->elements); for (size_t j = 0; j < ids.size(); ++j) ids[j] = (int64_t)j;
@@ -450,7 +455,9 @@ int32_t crux_dqn_target(crux_mlp* tn, crux_buffer* batch, float gamma, float* d_
   crux_ctx* c = tn->ctx; const int64_t n = batch->elements; if (n == 0) return CRUX_OK;
   const int nout = tn->nd.dims[tn->nd.L];
   float* q = (float*)crux_scratch(c, 4 * (size_t)n * nout + 256); if (!q) return crux_fail(c, CRUX_ENOMEM, "dqn_target: scratch");
-  int32_t rc = crux_mlp_forward_impl(tn, (const float*)batch->col[CRUX_COL_SP], n, q, nullptr); if (rc) return rc;
+  int32_t rc;
+  if (tn->nd.maxdim >= CRUX_DENSE_MIN_WIDTH) { rc = crux_dense_forward(tn, (const float*)batch->col[CRUX_COL_SP], n, c->stream); if (rc) return rc; q = crux_dense_act(tn, tn->nd.L); }
+  else { rc = crux_mlp_forward_impl(tn, (const float*)batch->col[CRUX_COL_SP], n, q, nullptr); if (rc) return rc; }
   hipLaunchKernelGGL(k_dqn_target, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, q, nout, (const float*)batch->col[CRUX_COL_R], (const uint8_t*)batch->col[CRUX_COL_DONE], gamma, n, d_y);
   return crux_launch_check(c, "k_dqn_target");
 }
@@ -461,7 +468,9 @@ int32_t crux_td_error(crux_mlp* net, crux_buffer* batch, const float* d_y, float
   const int nout = net->nd.dims[net->nd.L];
   if (batch->act_kind != CRUX_ACTION_DISCRETE || nout != batch->act_dim) return crux_fail(c, CRUX_EINVAL, "td_error: needs a one-hot action column matching the Q outputs");
   float* q = (float*)crux_scratch(c, 4 * (size_t)n * nout + 256); if (!q) return crux_fail(c, CRUX_ENOMEM, "td_error: scratch");
-  int32_t rc = crux_mlp_forward_impl(net, (const float*)batch->col[CRUX_COL_S], n, q, nullptr); if (rc) return rc;
+  int32_t rc;
+  if (net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH) { rc = crux_dense_forward(net, (const float*)batch->col[CRUX_COL_S], n, c->stream); if (rc) return rc; q = crux_dense_act(net, net->nd.L); }
+  else { rc = crux_mlp_forward_impl(net, (const float*)batch->col[CRUX_COL_S], n, q, nullptr); if (rc) return rc; }
   hipLaunchKernelGGL(k_td_error, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, q, nout, (const uint8_t*)batch->col[CRUX_COL_A], d_y, n, d_err);
   return crux_launch_check(c, "k_td_error");
 }

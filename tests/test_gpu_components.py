@@ -324,11 +324,13 @@ def test_nan_gradient_is_reported_and_parameters_are_kept(gpu_ctx, monkeypatch, 
     assert e.value.code == L.ENAN and np.array_equal(g.get_params(), before)          # src/training.jl:20
 
 
-def test_dqn_target_td_error_td_step_match_oracle(gpu_ctx):
-    rng = np.random.default_rng(10); n = 128
-    g, o = parity.make_pair([2, 8, 4], ["relu", "identity"], 31, 0, "discrete"); gt, ot = parity.make_pair([2, 8, 4], ["relu", "identity"], 32, 0, "discrete")
-    gb = crux.ExperienceBuffer(crux.ContinuousSpace(2), crux.DiscreteSpace(4), n, ["weight"]); ob = O.OBuffer(2, 4, L.ACTION_DISCRETE, n, ["weight"])
-    d = _rand_data(rng, n, 2, 4, True); d["weight"] = rng.random((1, n)).astype(np.float32); gb.push_(d); ob.push(d)
+@pytest.mark.parametrize("dims,acts", [([2, 8, 4], ["relu", "identity"]),                                   # C1 (README network): single-workgroup kernel
+                                       ([8, 256, 256, 4], ["relu", "relu", "identity"])])                      # C3: dense tile-GEMM engine
+def test_dqn_target_td_error_td_step_match_oracle(gpu_ctx, dims, acts):
+    rng = np.random.default_rng(10); n = 128; od, na = dims[0], dims[-1]
+    g, o = parity.make_pair(dims, acts, 31, 0, "discrete"); gt, ot = parity.make_pair(dims, acts, 32, 0, "discrete")
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.DiscreteSpace(na), n, ["weight"]); ob = O.OBuffer(od, na, L.ACTION_DISCRETE, n, ["weight"])
+    d = _rand_data(rng, n, od, na, True); d["weight"] = rng.random((1, n)).astype(np.float32); gb.push_(d); ob.push(d)
     ctx = g.ctx; dy = ctx.alloc(4 * n); de = ctx.alloc(4 * n)
     ctx.check(ctx.lib.crux_dqn_target(gt.h, gb.h, 0.95, dy)); y = ctx.d2h(dy, np.empty(n, np.float32))
     oy = np.empty(n, np.float32); O.chk(O.lib().orc_dqn_target(ot.h, ob.h, 0.95, O.vpz(oy)))
@@ -342,7 +344,11 @@ def test_dqn_target_td_error_td_step_match_oracle(gpu_ctx):
         raw = np.zeros(L.INFO_N, np.float32); oinfo = np.zeros(L.INFO_N, np.float32)
         ctx.check(ctx.lib.crux_td_step(g.h, gb.h, dy, use_w, O.vpz(raw))); O.chk(O.lib().orc_td_step(o.h, ob.h, O.vpz(oy), use_w, O.vpz(oinfo)))
         assert abs(raw[0] - oinfo[0]) < 1e-5 * max(1, abs(oinfo[0])) and abs(raw[2] - oinfo[2]) < 1e-5 and abs(raw[1] - oinfo[1]) < 1e-4 * max(1, oinfo[1])
-    assert np.abs(g.get_params() - o.params).max() < 1e-6
+        gg = np.empty(g.n_params, np.float32); ctx.d2h(ctx.lib.crux_mlp_grads_ptr(g.h), gg)
+        if max(dims) >= 128:                                                       # the dense path leaves the flat gradient in crux_mlp_grads_ptr
+            assert np.abs(gg - o.grads).max() < 1e-4 * np.abs(o.grads).max()
+    dp = np.abs(g.get_params() - o.params)
+    assert dp.max() < (1e-6 if max(dims) < 128 else 5e-4) and np.mean(dp > 2e-5) <= 1e-3   # Adam's first steps amplify rounding where g ~ 0 (step = lr*g/(|g|+eps))
     ctx.free(dy); ctx.free(de)
 
 
