@@ -215,7 +215,7 @@ def main():
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "avg_launch_ms": avg_launch_s * 1e3, "grad_steps_per_launch": steps_per_launch,
                          "us_per_grad_step": avg_launch_s * 1e6 / steps_per_launch if steps_per_launch else None,
-                         "note": "one workgroup on one CU by construction (81920 serially dependent 3.4-MFLOP steps); per-CU f32 MFMA peak is 0.614 TFLOP/s"},
+                         "note": "81920 serially dependent 3.4-MFLOP steps: each learner step is split over two CUs of one XCD (gradient exchange through the shared L2), actor and critic run concurrently -> 4 CUs busy; per-CU f32 MFMA peak is 0.614 TFLOP/s"},
         }
         if early:
             out["early_stop"] = early
