@@ -558,7 +558,7 @@ int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, h
   else if (a.head == CRUX_HEAD_CATEGORICAL) kind = MFK_CATEGORICAL;
   else if (a.head == CRUX_HEAD_GAUSSIAN) kind = MFK_GAUSSIAN;
   else return CRUX_OK;
-  if (getenv("CRUX_MFMA_TIMING") && in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) {
+  if (getenv("CRUX_MFMA_TIMING") && getenv("CRUX_MFMA_WAVES4") && in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) {
     static unsigned long long* dbg = nullptr;
     if (!dbg) { if (hipMalloc(&dbg, 64 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
     TrainArgs b = a; b.dbg = dbg; *handled = true;

@@ -53,7 +53,7 @@ struct MfxLayout {
   static constexpr int TOTAL = oRED + 32;
 };
 
-template <int IN, int OUT, int KIND, int ACT>
+template <int IN, int OUT, int KIND, int ACT, bool TIMING = false>
 __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
   using Lt = MfxLayout<IN, OUT>;
   static_assert(Lt::TOTAL <= 40960, "LDS budget (160 KB) exceeded");
@@ -69,6 +69,10 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
   float* T1 = sm + Lt::oT1 + w * Lt::TILE;
   float* T2 = sm + Lt::oT2 + w * Lt::TILE;
   const int n_extra = (KIND == MFK_GAUSSIAN) ? OUT : 0;
+  // optional phase timing (s_memtime): per-wave totals in a.dbg[(4p + w)*16 + phase]  (CRUX_MFMA_TIMING=1)
+  unsigned long long tacc[16]; unsigned long long tlast = 0;
+  if (TIMING) { for (int k = 0; k < 16; ++k) tacc[k] = 0; tlast = __builtin_amdgcn_s_memtime(); }
+#define MX_T(ph) do { if (TIMING) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
   const int t_wr = (4 * g) * 16 + 4 * ((c >> 2) ^ tx_h(g)) + (c & 3);   // tile element (feature 4g [+16m+r], sample c)
   const int t_rd = c * 16 + 4 * (g ^ tx_h(c >> 2));                   // tile b128 (feature c [+16m], samples 4g..4g+3)
   const int mp0 = w; constexpr int m0 = 0;         // dW2 / W2 ownership: the four tiles (mp0 = w, m = 0..3) = rows [16w, 16w+16)
@@ -209,11 +213,13 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
       const int nb = (int)((total_rows - st) < a.bs ? (total_rows - st) : a.bs);
       const float invB = 1.0f / (float)nb;
       ak.c1 = __builtin_amdgcn_rcpf((float)(1.0 - bp1)); ak.c2 = __builtin_amdgcn_rcpf((float)(1.0 - bp2));
+      MX_T(0);
       stage();
       if (st + a.bs < total_rows) fetch_data();
       { const int64_t st2 = st + 2 * (int64_t)a.bs; const int nb2 = st2 < total_rows ? (int)((total_rows - st2) < a.bs ? (total_rows - st2) : a.bs) : 0;
         fetch_index(order_cur, st2 < total_rows ? st2 : 0, nb2); }
 
+      MX_T(1);
       // ======================= forward, C orientation: D[feature 16m+4g+r][sample c] =======================
       float xB[KS0];
 #pragma unroll
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) T1[t_wr + (16 * m + r) * 16] = h1[m][r];
+      MX_T(2);
       f32x4 h2[4];
 #pragma unroll
       for (int mq = 0; mq < 2; ++mq) {     // two independent accumulator chains per pass
@@ -248,6 +255,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
         for (int r = 0; r < 4; ++r) { acc0[r] = actf<ACT>(acc0[r]); acc1[r] = actf<ACT>(acc1[r]); }
         h2[2 * mq] = acc0; h2[2 * mq + 1] = acc1; }
 
+      MX_T(3);
       // ======================= layer 3 (VALU) + loss head =======================
       f32x4 w3[OUT][4];
 #pragma unroll
@@ -304,6 +312,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
         }
       }
 
+      MX_T(4);
       // ======================= backward, own samples =======================
 #pragma unroll
       for (int o = 0; o < OUT; ++o) { float pv[16];
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) T2[t_wr + (16 * m + r) * 16] = h2[m][r];
+      MX_T(5);
       // dH1 (R) = dZ2 (C regs as A: [i=c -> sample][k -> f' = 16mp+4g+r]) x W2 (B: W2[f'][f = 16m+c] = W2C[f][f'])
       f32x4 dz1r[4];
 #pragma unroll
@@ -347,6 +357,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
           for (int r = 0; r < 4; ++r) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[mp][r], wv0[r], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[mp][r], wv1[r], acc1, 0, 0, 0); } }
         dz1r[2 * mq] = acc0; dz1r[2 * mq + 1] = acc1; }
+      MX_T(6);
       wave_sync();   // own T1/T2 tiles are complete for this wave's reads
       // dZ1 (R)[sample 4g+r][f = 16m+c] = act'(H1 R) .* dH1 (R)
       float gb1[4], gb2[4];
@@ -372,7 +383,9 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
           for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1r[m][r], xR[r], acc, 0, 0, 0);
           if (16 * jt + c < Lt::W1ROWS) *(f32x4*)&part[Lt::pW1 + (16 * jt + c) * MF8_LD + 16 * m + 4 * g] = acc; }
       }
+      MX_T(7);
       __syncthreads();   // ---- B_a: all tiles and small partials are visible
+      MX_T(8);
 
       // ======================= partial dW2 rows [16w, 16w+16) over this workgroup's 64 samples =======================
       f32x4 gW2[4];
@@ -387,6 +400,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) gW2[mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], gW2[mm], 0, 0, 0); }
       }
+      MX_T(9);
       // small parameters: reduce the 4 per-wave partials of this workgroup
       float gs[NSI];
 #pragma unroll
@@ -408,6 +422,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
         for (int k = 0; k < NSI; ++k) mine[4096 + tid + NT * k] = gs[k];
         if (tid >= NT - 8 && tid < NT - 1) mine[4096 + NSI * NT + (tid - (NT - 8))] = stat_loc;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this lane has reached the L2
+        MX_T(10);
         __syncthreads();
         if (tid == 0) {
           __hip_atomic_fetch_add(a.xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -419,13 +434,15 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
         }
         __syncthreads();
         if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; break; }
+        MX_T(11);
         f32x4 pw[4]; float pg[NSI]; float ps = 0.f;
-        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
-                     "global_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(pw[0]), "=&v"(pw[1]), "=&v"(pw[2]), "=&v"(pw[3]) : "v"(peer + tid * 16) : "memory");
+        // all loads of the peer's slot are in flight together (one L2 round trip): the dword loads first, then the b128 block whose wait covers them
 #pragma unroll
         for (int k = 0; k < NSI; ++k) pg[k] = __hip_atomic_load(peer + 4096 + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid >= NT - 8 && tid < NT - 1) ps = __hip_atomic_load(peer + 4096 + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                     "global_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(pw[0]), "=&v"(pw[1]), "=&v"(pw[2]), "=&v"(pw[3]) : "v"(peer + tid * 16) : "memory");
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) gW2[mm] += pw[mm];      // a+b == b+a bitwise: both workgroups hold the same total
 #pragma unroll
@@ -444,7 +461,9 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
         for (int r = 0; r < 4; ++r) { ssq += gW2[mm][r] * gW2[mm][r]; bad |= isnan(gW2[mm][r]) ? 1 : 0; }
       ssq = wave_sum(ssq);
       if (lane == 0) sm[Lt::oRED + w] = ssq;
+      MX_T(12);
       const int any_bad = __syncthreads_or(bad);   // ---- B_or (also publishes RED)
+      MX_T(13);
       // minibatch info (training.jl:22-23, ppo.jl:13-19); identical in every thread
       { const float fn = (float)nb;
         float ss = sm[Lt::oRED];
@@ -483,7 +502,9 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
 #pragma unroll
         for (int k = 0; k < NSI; ++k) { const int s = tid + NT * k; if (s < ns_valid) a.g[s_canon(s)] = gs[k]; }
       }
+      MX_T(14);
       __syncthreads();   // ---- B_b: masters updated; tiles and partials may be overwritten
+      MX_T(15);
       total_batches += 1;
       if (a.max_batches > 0 && total_batches >= a.max_batches) break;          // training.jl:45
       if (a.target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > a.target_kl) break;   // :46
@@ -507,6 +528,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
         a.p[pc] = tW2[mm][r]; a.m[pc] = mW2[mm][r]; a.v[pc] = vW2[mm][r]; }
     for (int s = tid; s < ns_valid; s += NT) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; }
   }
+  if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(4 * p + w) * 16 + k] = tacc[k]; }
   if (tid == 0 && (p == 0 || err)) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     a.bp[0] = bp1; a.bp[1] = bp2;
@@ -540,20 +562,20 @@ static int x2_placement_ok(crux_ctx* c) {
   return cached;
 }
 
-template <int IN, int OUT, int KIND, int ACT>
+template <int IN, int OUT, int KIND, int ACT, bool TIMING = false>
 static int32_t launch_x2(crux_ctx* c, TrainArgs a, hipStream_t stream) {
   using Lt = MfxLayout<IN, OUT>;
   static_assert(Lt::FITS, "x2 layout must fit");
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
   static bool attr = false;
-  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma_x2<IN, OUT, KIND, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma_x2<IN, OUT, KIND, ACT, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
   // exchange area: one per stream the learners run on (actor || critic use the context's two streams concurrently)
   const int which = stream == c->stream ? 0 : 1;
   constexpr size_t xbytes = sizeof(float) * 4 * 8192 + 256;
   if (!c->xbuf[which]) { if (hipMalloc(&c->xbuf[which], xbytes) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "learner exchange buffer"); }
   a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * 4 * 8192);
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
-  hipLaunchKernelGGL((k_train_mfma_x2<IN, OUT, KIND, ACT>), dim3(16), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((k_train_mfma_x2<IN, OUT, KIND, ACT, TIMING>), dim3(16), dim3(256), lds, stream, a);
   return crux_launch_check(c, "k_train_mfma_x2");
 }
 
@@ -564,6 +586,18 @@ int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, boo
   if (off || a.ids || !a.apply || a.bs <= 64 || a.len < a.bs) return CRUX_OK;     // single steps and small batches stay on one CU
   if (!x2_placement_ok(c)) return CRUX_OK;
   const int in = a.nd.dims[0], out = a.nd.dims[3], act = a.nd.acts[0];
+  if (getenv("CRUX_MFMA_TIMING") && in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) {
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) { if (hipMalloc(&dbg, 128 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
+    TrainArgs b = a; b.dbg = dbg; *handled = true;
+    int32_t rc = launch_x2<4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU, true>(c, b, stream); if (rc) return rc;
+    unsigned long long h[128]; HIPCHK(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, stream)); HIPCHK(c, hipStreamSynchronize(stream));
+    static const char* nm[16] = {"loop+prefetch", "stage", "fwdL1+T1", "fwdL2", "L3+head", "dW3+dZ2+stats+T2", "dH1", "dZ1+db+dW1", "wait B_a", "dW2", "reduce+store", "exchange wait",
+                                 "load peer+total+ssq", "wait B_or", "info+adam", "wait B_b"};
+    for (int w = 0; w < 8; ++w) { fprintf(stderr, "[x2-timing] wg %d wave %d:", w >> 2, w & 3); unsigned long long tot = 0; for (int k = 0; k < 16; ++k) tot += h[w * 16 + k];
+      for (int k = 0; k < 16; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[w * 16 + k] / (double)tot); fprintf(stderr, " total=%llu\n", tot); }
+    return CRUX_OK;
+  }
 #define MFX_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_x2<I, O, K, A_>(c, a, stream); }
   MFX_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)     // C2 actor  (PPO CartPole)
   MFX_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)           // C2 critic
