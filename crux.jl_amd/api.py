@@ -748,6 +748,8 @@ class _Loss:
 
 ppo_loss = _Loss("ppo")            # src/model_free/rl/ppo.jl:4-21
 value_mse_loss = _Loss("value_mse")  # (pi, P, D) -> Flux.mse(value(pi, D[:s]), D[:return])  ppo.jl:60
+a2c_loss = _Loss("a2c")            # src/model_free/rl/a2c.jl:4-15
+reinforce_loss = _Loss("reinforce")  # src/model_free/rl/reinforce.jl:4-13
 
 
 class TrainingParams:
@@ -776,6 +778,9 @@ def _train_cfg(pi, p, P):
 
 def _info_dict(p, raw, extra=True):
     d = {p.name + "loss": float(raw[L.INFO["loss"]]), p.name + "grad_norm": float(raw[L.INFO["grad_norm"]])}
+    if p.loss.name in ("a2c", "reinforce"):
+        for k in ("entropy", "kl"):
+            d[k] = float(raw[L.INFO[k]])
     if p.loss.name == "ppo":
         for k in ("entropy", "kl", "clip_fraction", "avg_advantage", "avg_return"):
             d[k] = float(raw[L.INFO[k]])
@@ -892,6 +897,24 @@ def PPO(pi, S, eps=0.2, lambda_p=1.0, lambda_e=0.1, target_kl=0.012, a_opt=None,
                           c_opt=TrainingParams(loss=value_mse_loss, name="critic_", **c_opt),
                           post_batch_callback=lambda D, info: whiten_(D, "advantage"),
                           required_columns=cols, **kw)
+
+
+def A2C(pi, S, lambda_p=1.0, lambda_e=0.1, a_opt=None, c_opt=None, required_columns=(), **kw):
+    """A2C(; pi::ActorCritic, a_opt, c_opt, lambda_p=1f0, lambda_e=0.1f0, ...) (src/model_free/rl/a2c.jl:32-52): a2c_loss with the 0.015 KL early stop,
+    critic mse, advantages whitened after sampling (post_sample_callback, :48)."""
+    a_opt, c_opt = dict(a_opt or {}), dict(c_opt or {})
+    a_opt.setdefault("target_kl", 0.015)
+    cols = list(dict.fromkeys(list(required_columns) + ["return", "logprob", "advantage"]))
+    return OnPolicySolver(agent=PolicyParams(pi), S=S, P={"lambda_p": lambda_p, "lambda_e": lambda_e},
+                          a_opt=TrainingParams(loss=a2c_loss, name="actor_", **a_opt), c_opt=TrainingParams(loss=value_mse_loss, name="critic_", **c_opt),
+                          post_sample_callback=lambda D, info: whiten_(D, "advantage"), required_columns=cols, **kw)
+
+
+def REINFORCE(pi, S, a_opt=None, required_columns=(), **kw):
+    """REINFORCE(; pi, a_opt, ...) (src/model_free/rl/reinforce.jl:30-42): reinforce_loss with the 0.015 KL early stop; no critic, no GAE."""
+    a_opt = dict(a_opt or {}); a_opt.setdefault("target_kl", 0.015)
+    cols = list(dict.fromkeys(list(required_columns) + ["return", "logprob"]))
+    return OnPolicySolver(agent=PolicyParams(pi), S=S, a_opt=TrainingParams(loss=reinforce_loss, name="actor_", **a_opt), c_opt=None, required_columns=cols, **kw)
 
 
 # --------------------------------------------------------------------------------------------------------------

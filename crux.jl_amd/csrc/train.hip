@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
 
   double bp1 = a.bp[0], bp2 = a.bp[1];   // every thread carries the beta powers in registers (identical values)
   const float lo = 1.f - a.eps_clip, hi = 1.f + a.eps_clip;
+  const bool a2c = a.loss == CRUX_LOSS_A2C;
   int32_t* order_cur = a.order_a; int32_t* order_nxt = a.order_b;
   long long total_batches = 0; int epochs_run = 0; int err = 0; bool stop = false;
   float info[CRUX_INFO_N];
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
                 const float lg = logf(pk + EPS32F); H -= pk * lg; hp += (-lg - pk / (pk + EPS32F)) * pk; }
               newlp = logf(q);
               r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A;
-              g = (u <= cl) ? A : 0.f; s_lossp += (double)(u <= cl ? u : cl);
+              g = (u <= cl) ? A : 0.f; s_lossp += (double)(a2c ? newlp * A : (u <= cl ? u : cl));
+              if (a2c) { g = A; r = 1.f; }                                        // a2c_loss (a2c.jl:4-15): d(-mean(logpdf .* A)); clip statistics off below
               for (int k = 0; k < nout; ++k) { const float pk = expf(z[k] - mx) / sum; const float lg = logf(pk + EPS32F);
                 const float hk = -lg - pk / (pk + EPS32F);
                 const float dlogpi = pk * ((av[k] ? 1.f : 0.f) / q) - pk;
@@ -123,17 +125,18 @@ __global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
               for (int k = 0; k < a.ad; ++k) { const float sg = expf(ls[k]); const float d = av[k] - z[k];
                 newlp += (-(d * d) / (2.f * sg * sg) - 0.9189385332046727f - ls[k]); }
               r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A;
-              g = (u <= cl) ? A : 0.f; s_lossp += (double)(u <= cl ? u : cl);
+              g = (u <= cl) ? A : 0.f; s_lossp += (double)(a2c ? newlp * A : (u <= cl ? u : cl));
+              if (a2c) { g = A; r = 1.f; }
               for (int k = 0; k < a.ad; ++k) { const float sg = expf(ls[k]); const float s2 = sg * sg; const float d = av[k] - z[k];
                 dy[k] = invB * (-a.lambda_p * g * r * (d / s2));
                 exs[s * a.ad + k] = invB * (-a.lambda_p * g * r * ((d * d) / s2 - 1.f)); }
             }
             s_H += (double)H; s_kl += (double)(oldlp - newlp); s_adv += (double)A; if (a.RET) s_ret += (double)a.RET[row];
-            if (r > hi || r < lo) s_clip += 1.0;
+            if (!a2c && (r > hi || r < lo)) s_clip += 1.0;
           }
         }
         __syncthreads();
-        if (a.loss == CRUX_LOSS_PPO && a.head == CRUX_HEAD_GAUSSIAN && tid < a.ad) {   // deterministic per-dimension sum over the chunk
+        if (CRUX_IS_PG(a.loss) && a.head == CRUX_HEAD_GAUSSIAN && tid < a.ad) {   // deterministic per-dimension sum over the chunk
           float acc = 0.f; for (int s = 0; s < ns; ++s) acc += exs[s * a.ad + tid]; a.g[nd.xoff + tid] += acc; }
         // ---- backward through the layers
         float* dcur = dA; float* dnxt = dB;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
           float* t = dcur; dcur = dnxt; dnxt = t;
         }
       }
-      if (a.loss == CRUX_LOSS_PPO && a.head == CRUX_HEAD_GAUSSIAN && tid < a.ad) a.g[nd.xoff + tid] += -a.lambda_e;   // d(-le*H)/dlogSigma, H scalar
+      if (CRUX_IS_PG(a.loss) && a.head == CRUX_HEAD_GAUSSIAN && tid < a.ad) a.g[nd.xoff + tid] += -a.lambda_e;   // d(-le*H)/dlogSigma, H scalar
       // ---- reductions: stats and grad norm (utils.jl:49-55)
       double ssq = 0.0; for (int i = tid; i < nd.n_params; i += 256) { const double gi = (double)a.g[i]; ssq += gi * gi; }
       const double t_ssq = block_sum_d(ssq, red, tid);
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
       const float gnorm = (float)sqrt(t_ssq);
 #pragma unroll
       for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
-      if (a.loss == CRUX_LOSS_PPO) {
+      if (CRUX_IS_PG(a.loss)) {
         const float p_loss = (float)(-(t_lossp / (double)nb)); float entropy, e_loss;
         if (a.head == CRUX_HEAD_CATEGORICAL) { entropy = (float)(t_H / (double)nb); e_loss = -entropy; }
         else { float Hs = 1.4189385332046727f; for (int k = 0; k < a.ad; ++k) Hs += a.p[nd.xoff + k]; entropy = Hs; e_loss = -Hs; }
@@ -191,12 +194,12 @@ __global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
       __syncthreads();
       total_batches += 1;
       if (a.max_batches > 0 && total_batches >= a.max_batches) break;          // training.jl:45
-      if (a.target_kl >= 0.f && a.loss == CRUX_LOSS_PPO && info[CRUX_INFO_KL] > a.target_kl) break;   // :46
+      if (a.target_kl >= 0.f && CRUX_IS_PG(a.loss) && info[CRUX_INFO_KL] > a.target_kl) break;   // :46
     }
     if (err) break;
     if (tid < CRUX_INFO_N && a.epoch_infos) a.epoch_infos[(size_t)ep * CRUX_INFO_N + tid] = info[tid];   // aggregate == last minibatch (Q3)
     epochs_run += 1;
-    if (a.target_kl >= 0.f && a.loss == CRUX_LOSS_PPO && info[CRUX_INFO_KL] > a.target_kl) stop = true;  // :49
+    if (a.target_kl >= 0.f && CRUX_IS_PG(a.loss) && info[CRUX_INFO_KL] > a.target_kl) stop = true;  // :49
     if (a.max_batches > 0 && total_batches >= a.max_batches) stop = true;                                // :50
   }
   if (tid == 0) {
@@ -228,7 +231,11 @@ static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const cr
   a.shuffle_seed = cfg->shuffle_seed; a.shuffle_counter = cfg->shuffle_counter;
   a.len = buf->elements; a.order_a = buf->order_a; a.order_b = buf->order_b; a.apply = 1;
   const int nout = net->nd.dims[net->nd.L];
-  if (internal_loss == CRUX_LOSS_PPO) {
+  if (internal_loss == CRUX_LOSS_REINFORCE) {   // reinforce_loss (reinforce.jl:4-13) = a2c_loss with the return as the weight, lambda_p = 1, no entropy term
+    if (!a.RET || !a.LP) return crux_fail(c, CRUX_EINVAL, "reinforce_loss: buffer needs :return and :logprob columns");
+    a.ADV = a.RET; a.lambda_p = 1.f; a.lambda_e = 0.f; a.loss = internal_loss = CRUX_LOSS_A2C;
+  }
+  if (CRUX_IS_PG(internal_loss)) {
     if (!a.LP || !a.ADV) return crux_fail(c, CRUX_EINVAL, "ppo_loss: buffer needs :logprob and :advantage columns");
     if (cfg->head == CRUX_HEAD_CATEGORICAL) { if (nout != buf->act_dim || buf->act_kind != CRUX_ACTION_DISCRETE || nout > 32) return crux_fail(c, CRUX_EINVAL, "ppo_loss: categorical head needs %d logits over a one-hot action column", buf->act_dim); }
     else if (cfg->head == CRUX_HEAD_GAUSSIAN) { if (nout != buf->act_dim || buf->act_kind != CRUX_ACTION_CONTINUOUS || net->nd.n_extra != buf->act_dim) return crux_fail(c, CRUX_EINVAL, "ppo_loss: gaussian head needs %d means + %d logSigma extras over a Float32 action column", buf->act_dim, buf->act_dim); }
@@ -266,7 +273,7 @@ static int32_t run_batch(crux_mlp* net, crux_buffer* buf, TrainArgs& a, int n_ep
   if (!sc) return crux_fail(c, CRUX_ENOMEM, "train!: scratch");
   a.status = (int32_t*)sc; a.epoch_infos = (float*)(sc + 256);
   HIPCHK(c, hipMemsetAsync(sc, 0, eb + 256, c->stream));
-  const int slot = a.loss == CRUX_LOSS_PPO ? CRUX_PROF_TRAIN_ACTOR : (a.loss == CRUX_LOSS_VALUE_MSE ? CRUX_PROF_TRAIN_CRITIC : CRUX_PROF_TD_STEP);
+  const int slot = CRUX_IS_PG(a.loss) ? CRUX_PROF_TRAIN_ACTOR : (a.loss == CRUX_LOSS_VALUE_MSE ? CRUX_PROF_TRAIN_CRITIC : CRUX_PROF_TD_STEP);
   int32_t rc = launch_train(c, a, slot); if (rc) return rc;
   int32_t st[4]; std::vector<float> ei((size_t)CRUX_INFO_N * (size_t)(n_epochs > 0 ? n_epochs : 1));
   HIPCHK(c, hipMemcpyAsync(st, a.status, sizeof st, hipMemcpyDeviceToHost, c->stream));
@@ -343,7 +350,7 @@ int32_t crux_loss_grad_device_ids(crux_mlp* net, crux_buffer* buf, const crux_tr
   char* sc = (char*)crux_scratch(c, 1024);
   if (!sc) return crux_fail(c, CRUX_ENOMEM, "loss_grad: scratch");
   a.status = (int32_t*)sc; a.epoch_infos = d_info ? d_info : (float*)(sc + 256);
-  return launch_train(c, a, a.loss == CRUX_LOSS_PPO ? CRUX_PROF_TRAIN_ACTOR : CRUX_PROF_TRAIN_CRITIC);
+  return launch_train(c, a, CRUX_IS_PG(a.loss) ? CRUX_PROF_TRAIN_ACTOR : CRUX_PROF_TRAIN_CRITIC);
 }
 
 // policy_gradient_training (src/model_free/on_policy.jl:56-78): batch_train!(actor) then batch_train!(critic) on the same buffer.

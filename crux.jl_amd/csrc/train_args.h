@@ -2,7 +2,8 @@
 #pragma once
 #include "common.h"
 
-#define CRUX_LOSS_TD_INTERNAL 2   // td_loss (src/utils.jl:76-87); reached through crux_td_step
+#define CRUX_LOSS_TD_INTERNAL 2
+#define CRUX_IS_PG(l) ((l) == CRUX_LOSS_PPO || (l) == CRUX_LOSS_A2C)   // policy-gradient losses share the head, statistics and KL early stopping   // td_loss (src/utils.jl:76-87); reached through crux_td_step
 
 struct TrainArgs {
   NetDesc nd;

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
       tW2[mm][r] = a.p[pc]; mW2[mm][r] = a.m[pc]; vW2[mm][r] = a.v[pc]; }
   double bp1 = a.bp[0], bp2 = a.bp[1];
   const float lo = 1.f - a.eps_clip, hi = 1.f + a.eps_clip;
+  const bool a2c = a.loss == CRUX_LOSS_A2C;
   AdamK ak; ak.b1 = (float)a.b1; ak.b2 = (float)a.b2; ak.omb1 = (float)(1.0 - a.b1); ak.omb2 = (float)(1.0 - a.b2); ak.eps = (float)a.eps; ak.eta = (float)a.eta;
 
   int32_t* order_cur = a.order_a; int32_t* order_nxt = a.order_b;
@@ -294,21 +295,23 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
             hk[k] = -lg - pk[k] * __builtin_amdgcn_rcpf(pe); hp += hk[k] * pk[k]; }
           const float newlp = __logf(pa); const float r = __expf(newlp - oldlp);
           const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
+          const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;   // a2c_loss (a2c.jl:4-15): -mean(logpdf .* A)
 #pragma unroll
           for (int k = 0; k < OUT; ++k) { const float dlogpi = ((k == ai) ? 1.f : 0.f) - pk[k];
-            dz[k] = valid ? invB * (-a.lambda_p * gsel * r * dlogpi - a.lambda_e * (pk[k] * (hk[k] - hp))) : 0.f; }
-          s_lossp = cnt * fminf(u, cl); s_H = cnt * H; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R;
-          s_clip = cnt * ((r > hi || r < lo) ? 1.f : 0.f);
+            dz[k] = valid ? invB * (-a.lambda_p * coef * dlogpi - a.lambda_e * (pk[k] * (hk[k] - hp))) : 0.f; }
+          s_lossp = cnt * lterm; s_H = cnt * H; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R;
+          s_clip = cnt * clipv;
         } else {   // gaussian with constant log-std (policies.jl:333-348)
           float newlp = 0.f; float dd[OUT], s2[OUT];
 #pragma unroll
           for (int k = 0; k < OUT; ++k) { const float ls = sm[Lt::oEX + k]; const float sg = expf(ls); s2[k] = sg * sg; dd[k] = q[4 + k] - z[k];
             newlp += (-(dd[k] * dd[k]) / (2.f * s2[k]) - 0.9189385332046727f - ls); }
           const float r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
+          const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;   // a2c_loss (a2c.jl:4-15): -mean(logpdf .* A)
 #pragma unroll
-          for (int k = 0; k < OUT; ++k) { dz[k] = valid ? invB * (-a.lambda_p * gsel * r * (dd[k] / s2[k])) : 0.f;
-            dex[k] = valid ? invB * (-a.lambda_p * gsel * r * ((dd[k] * dd[k]) / s2[k] - 1.f)) : 0.f; }
-          s_lossp = cnt * fminf(u, cl); s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R; s_clip = cnt * ((r > hi || r < lo) ? 1.f : 0.f);
+          for (int k = 0; k < OUT; ++k) { dz[k] = valid ? invB * (-a.lambda_p * coef * (dd[k] / s2[k])) : 0.f;
+            dex[k] = valid ? invB * (-a.lambda_p * coef * ((dd[k] * dd[k]) / s2[k] - 1.f)) : 0.f; }
+          s_lossp = cnt * lterm; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R; s_clip = cnt * clipv;
         }
       }
 

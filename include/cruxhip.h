@@ -217,7 +217,9 @@ int32_t crux_whiten(crux_buffer* b, int32_t key);
 
 /* learner (src/training.jl:1-55, src/model_free/rl/ppo.jl:4-21,59-60) ------------------------------ */
 enum { CRUX_LOSS_PPO = 0      /* ppo_loss with the head's logpdf/entropy (ppo.jl:4-21)            */,
-       CRUX_LOSS_VALUE_MSE = 1 /* Flux.mse(value(pi, s), return) (ppo.jl:60)                      */ };
+       CRUX_LOSS_VALUE_MSE = 1 /* Flux.mse(value(pi, s), return) (ppo.jl:60)                      */,
+       CRUX_LOSS_A2C = 3       /* a2c_loss (a2c.jl:4-15): -lambda_p mean(logpdf .* advantage) - lambda_e mean(entropy) */,
+       CRUX_LOSS_REINFORCE = 4 /* reinforce_loss (reinforce.jl:4-13): -mean(logpdf .* return); entropy and kl are reported only */ };
 
 typedef struct {
   int32_t loss;           /* CRUX_LOSS_*                                                          */

@@ -726,9 +726,9 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
       sum_sq += (double)(d * d); dy[0] = 2.f * d * invB; bwd_col(net, c.h, dy, net->g); }
     info[CRUX_INFO_LOSS] = (float)(sum_sq / (double)n);
   } else {                                                                     /* ppo_loss ppo.jl:4-21 */
-    if (!(buf->mask & (1u << CRUX_COL_LOGPROB)) || !(buf->mask & (1u << CRUX_COL_ADVANTAGE))) { cc_free(net, &c); return CRUX_EINVAL; }
-    const float* LP = (const float*)buf->col[CRUX_COL_LOGPROB]; const float* ADV = (const float*)buf->col[CRUX_COL_ADVANTAGE];
     const float* RET = (buf->mask & (1u << CRUX_COL_RETURN)) ? (const float*)buf->col[CRUX_COL_RETURN] : NULL;
+    if (!(buf->mask & (1u << CRUX_COL_LOGPROB)) || (cfg->loss == CRUX_LOSS_REINFORCE ? !RET : !(buf->mask & (1u << CRUX_COL_ADVANTAGE)))) { cc_free(net, &c); return CRUX_EINVAL; }
+    const float* LP = (const float*)buf->col[CRUX_COL_LOGPROB]; const float* ADV = cfg->loss == CRUX_LOSS_REINFORCE ? RET : (const float*)buf->col[CRUX_COL_ADVANTAGE];
     float lo = 1.f - cfg->eps_clip, hi = 1.f + cfg->eps_clip;
     float* gx = net->g + xoff(net); const float* ls = net->p + xoff(net);
     for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s];
@@ -745,13 +745,16 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
           hk[k] = -l - p[k] / (p[k] + EPS32); hp = hp + hk[k] * p[k]; }
         float r = expf(newlp - oldlp), u = r * A, rc = r < lo ? lo : r > hi ? hi : r, cl = rc * A;
         float g = (u <= cl) ? A : 0.f;                       /* d min(u,c)/dr: ties -> first arg; clipped branch strictly smaller => clamp' = 0 */
-        sum_loss_p += (double)(u <= cl ? u : cl);
+        float coef = g * r, lterm = (u <= cl ? u : cl), lp_ = cfg->lambda_p, le_ = cfg->lambda_e;
+        if (cfg->loss == CRUX_LOSS_A2C) { coef = A; lterm = newlp * A; }                                   /* a2c.jl:6 */
+        else if (cfg->loss == CRUX_LOSS_REINFORCE) { coef = RET[id]; lterm = newlp * RET[id]; lp_ = 1.f; le_ = 0.f; }   /* reinforce.jl:12 */
+        sum_loss_p += (double)lterm;
         for (int k = 0; k < nout; ++k) {
           float dlogpi = p[k] * ((a[k] ? 1.f : 0.f) / q) - p[k];   /* = y_k - p_k for one-hot y */
           float dH = p[k] * (hk[k] - hp);
-          dy[k] = invB * (-cfg->lambda_p * g * r * dlogpi - cfg->lambda_e * dH);
+          dy[k] = invB * (-lp_ * coef * dlogpi - le_ * dH);
         }
-        if (r > hi || r < lo) ++nclip;
+        if (cfg->loss == CRUX_LOSS_PPO && (r > hi || r < lo)) ++nclip;
       } else {                                                                   /* GaussianPolicy policies.jl:333-348 */
         if (nout != ad || net->n_extra != ad) { cc_free(net, &c); return CRUX_EINVAL; }
         const float* a = (const float*)buf->col[CRUX_COL_A] + (size_t)id * ad;
@@ -760,11 +763,14 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
           newlp = newlp + (-(d * d) / (2.f * s2) - 0.9189385332046727f - ls[k]); }
         float r = expf(newlp - oldlp), u = r * A, rc = r < lo ? lo : r > hi ? hi : r, cl = rc * A;
         float g = (u <= cl) ? A : 0.f;
-        sum_loss_p += (double)(u <= cl ? u : cl);
+        float coef = g * r, lterm = (u <= cl ? u : cl), lp_ = cfg->lambda_p;
+        if (cfg->loss == CRUX_LOSS_A2C) { coef = A; lterm = newlp * A; }
+        else if (cfg->loss == CRUX_LOSS_REINFORCE) { coef = RET[id]; lterm = newlp * RET[id]; lp_ = 1.f; }
+        sum_loss_p += (double)lterm;
         for (int k = 0; k < ad; ++k) { float sg = expf(ls[k]); float s2 = sg * sg; float d = a[k] - z[k];
-          dy[k] = invB * (-cfg->lambda_p * g * r * (d / s2));
-          gx[k] += invB * (-cfg->lambda_p * g * r * ((d * d) / s2 - 1.f)); }
-        if (r > hi || r < lo) ++nclip;
+          dy[k] = invB * (-lp_ * coef * (d / s2));
+          gx[k] += invB * (-lp_ * coef * ((d * d) / s2 - 1.f)); }
+        if (cfg->loss == CRUX_LOSS_PPO && (r > hi || r < lo)) ++nclip;
       }
       sum_H += (double)H; sum_kl += (double)(oldlp - newlp); sum_adv += (double)A; if (RET) sum_ret += (double)RET[id];
       bwd_col(net, c.h, dy, net->g);
@@ -772,8 +778,8 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
     float p_loss = (float)(-(sum_loss_p / (double)n)), e_loss, entropy;
     if (cfg->head == CRUX_HEAD_CATEGORICAL) { entropy = (float)(sum_H / (double)n); e_loss = -entropy; }
     else { float Hs = 1.4189385332046727f; for (int k = 0; k < ad; ++k) Hs = Hs + ls[k]; entropy = Hs; e_loss = -Hs;   /* scalar entropy policies.jl:348 */
-      for (int k = 0; k < ad; ++k) gx[k] += -cfg->lambda_e; }
-    info[CRUX_INFO_LOSS] = cfg->lambda_p * p_loss + cfg->lambda_e * e_loss;                        /* ppo.jl:20 */
+      if (cfg->loss != CRUX_LOSS_REINFORCE) for (int k = 0; k < ad; ++k) gx[k] += -cfg->lambda_e; }
+    info[CRUX_INFO_LOSS] = cfg->loss == CRUX_LOSS_REINFORCE ? p_loss : cfg->lambda_p * p_loss + cfg->lambda_e * e_loss;   /* ppo.jl:20, a2c.jl:14, reinforce.jl:12 */
     info[CRUX_INFO_ENTROPY] = entropy; info[CRUX_INFO_KL] = (float)(sum_kl / (double)n);
     info[CRUX_INFO_CLIP_FRACTION] = (float)nclip / (float)n; info[CRUX_INFO_AVG_ADVANTAGE] = (float)(sum_adv / (double)n);
     info[CRUX_INFO_AVG_RETURN] = (float)(sum_ret / (double)n);
@@ -818,12 +824,12 @@ int32_t orc_batch_train(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg
       rc = orc_train_step(net, buf, cfg, ids, nb, info); if (rc) { free(perm); free(ids); return rc; }   /* :43 */
       total += 1;
       if (cfg->max_batches > 0 && total >= cfg->max_batches) { brk = 1; break; }                          /* :45 */
-      if (cfg->target_kl >= 0.f && cfg->loss == CRUX_LOSS_PPO && info[CRUX_INFO_KL] > cfg->target_kl) { brk = 1; break; }   /* :46 */
+      if (cfg->target_kl >= 0.f && cfg->loss != CRUX_LOSS_VALUE_MSE && info[CRUX_INFO_KL] > cfg->target_kl) { brk = 1; break; }   /* :46 */
     }
     (void)brk;
     for (int q = 0; q < CRUX_INFO_N; ++q) { agg[q] += (double)info[q]; if (epoch_infos) epoch_infos[(size_t)ep * CRUX_INFO_N + q] = info[q]; }   /* :48 */
     epochs_run += 1;
-    if (cfg->target_kl >= 0.f && cfg->loss == CRUX_LOSS_PPO && info[CRUX_INFO_KL] > cfg->target_kl) stop = 1;               /* :49 */
+    if (cfg->target_kl >= 0.f && cfg->loss != CRUX_LOSS_VALUE_MSE && info[CRUX_INFO_KL] > cfg->target_kl) stop = 1;               /* :49 */
     if (cfg->max_batches > 0 && total >= cfg->max_batches) stop = 1;                                      /* :50 */
   }
   for (int q = 0; q < CRUX_INFO_N; ++q) info_out[q] = epochs_run ? (float)(agg[q] / (double)epochs_run) : 0.f;   /* merge!(info, aggregate_info(infos)) :54 */

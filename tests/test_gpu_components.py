@@ -513,3 +513,31 @@ def test_dqn_solve_matches_oracle_loop(gpu_ctx, prioritized):
         pg = buf.priority_params(); pr = np.empty(cap, np.float32); mx, mn = C.c_float(), C.c_float()
         O.chk(O.lib().orc_per_get(ob.h, O.vpz(pr), C.byref(mx), C.byref(mn), None))
         assert np.allclose(pg["priorities"], pr, rtol=1e-4, atol=1e-6) and abs(pg["max_priority"] - mx.value) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------- A2C / REINFORCE losses
+@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("loss", ["a2c", "reinforce"])
+@pytest.mark.parametrize("kind,dims", [("categorical", [4, 64, 64, 2]), ("gaussian", [3, 64, 64, 1]), ("gaussian", [17, 64, 64, 6]), ("categorical", [6, 32, 5])])
+def test_a2c_and_reinforce_losses_match_oracle(gpu_ctx, monkeypatch, force_generic, loss, kind, dims):
+    """a2c_loss (src/model_free/rl/a2c.jl:4-15) and reinforce_loss (reinforce.jl:4-13) through train! and batch_train! (incl. the two-CU kernel)."""
+    if force_generic:
+        monkeypatch.setenv("CRUX_FORCE_GENERIC", "1")
+    rng = np.random.default_rng(17); acts = ["relu"] * (len(dims) - 2) + ["identity"]; n, bs = 256, 128
+    g, o, gb, ob = _train_pair(dims, acts, kind, n, dims[0], dims[-1], rng, n_extra=dims[-1] if kind == "gaussian" else 0)
+    lf = crux.a2c_loss if loss == "a2c" else crux.reinforce_loss
+    p = crux.TrainingParams(loss=lf, batch_size=bs, epochs=2, name="actor_", shuffle_seed=5); P = {"lambda_p": 0.8, "lambda_e": 0.05}
+    o.adam_init(float(np.float32(3e-4)))
+    cfg = parity.train_cfg(loss, kind, bs, 2, seed=5, lp=0.8, le=0.05)
+    ids = rng.permutation(n)[:bs].astype(np.int64)
+    info = crux.train_(g, p, P, gb, ids + 1); oinfo = np.zeros(L.INFO_N, np.float32)
+    O.chk(O.lib().orc_train_step(o.h, ob.h, C.byref(cfg), O.vpz(ids), ids.size, O.vpz(oinfo)))
+    for k, ok in (("actor_loss", "loss"), ("actor_grad_norm", "grad_norm"), ("kl", "kl"), ("entropy", "entropy")):
+        assert abs(info[k] - oinfo[L.INFO[ok]]) < 1e-4 * max(1.0, abs(oinfo[L.INFO[ok]])), (k, info[k], oinfo[L.INFO[ok]])
+    binfo = crux.batch_train_(g, p, P, gb)
+    O.chk(O.lib().orc_batch_train(o.h, ob.h, C.byref(cfg), None, O.vpz(oinfo), None))
+    assert binfo["actor_batches_trained"] == int(oinfo[L.INFO["batches_trained"]]) == 4
+    assert abs(binfo["actor_loss"] - oinfo[0]) < 1e-4 * max(1, abs(oinfo[0])) and abs(binfo["kl"] - oinfo[L.INFO["kl"]]) < 1e-5
+    assert np.abs(g.get_params() - o.params).max() < 2e-5
+    for k in ("s", "a", "advantage", "return"):
+        assert np.array_equal(gb[k], ob[k]), k                                        # both shuffles materialised identically

@@ -1,4 +1,5 @@
 """GPU parity: one PPO iteration through the C ABI vs the CPU oracle (same Philox-defined randomness)."""
+import numpy as np
 import pytest
 
 import parity
@@ -17,3 +18,46 @@ def test_policy_gradient_training_pair_matches_sequential_oracle(gpu_ctx, target
     """actor || critic concurrent learners (exact when no early stopping) and the sequential fallback (KL stop) both equal the oracle."""
     res = parity.ppo_iteration_parity(n_envs=8, T=64, batch_size=64, epochs=3, seed=21, target_kl=target_kl, pair=True)
     assert res["ok"], res
+
+
+@pytest.mark.parametrize("algo", ["a2c", "reinforce"])
+def test_a2c_and_reinforce_solve_match_oracle_loop(gpu_ctx, algo):
+    """solve(::OnPolicySolver) for A2C (a2c.jl:32-52) and REINFORCE (reinforce.jl:30-42): two iterations vs the same loop on the oracle."""
+    import ctypes as C
+    from parity import crux, L, O
+    E, T, bs, seed, iters = 4, 32, 32, 9, 2
+    N = E * T
+    ga, oa = parity.make_pair(parity.ACTOR_DIMS, parity.ACTS, seed, 0, "discrete")
+    gc, oc = parity.make_pair(parity.CRITIC_DIMS, parity.ACTS, seed, 1)
+    S = crux.ContinuousSpace(4)
+    mdp = crux.CartPoleMDP(n_envs=E, seed=seed)
+    opt = {"batch_size": bs, "epochs": 2, "shuffle_seed": 31}
+    if algo == "a2c":
+        solver = crux.A2C(crux.ActorCritic(ga, gc), S, N=iters * N, dN=N, max_steps=25, a_opt=dict(opt), c_opt=dict(opt, shuffle_seed=32), lambda_e=0.05)
+        extras = ["return", "logprob", "advantage"]
+    else:
+        solver = crux.REINFORCE(ga, S, N=iters * N, dN=N, max_steps=25, a_opt=dict(opt))
+        extras = ["return", "logprob"]
+    crux.solve(solver, mdp)
+    # ---- oracle loop (on_policy.jl:80-109)
+    ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, N, extras); oe = O.OEnv("cartpole", E, 25, 0.99, seed)
+    oa.adam_init(float(np.float32(3e-4))); oc.adam_init(float(np.float32(3e-4)))
+    info = np.zeros(L.INFO_N, np.float32); ol = O.lib(); ctr_a = ctr_c = 0
+    for it in range(iters):
+        cfg = parity.rollout_cfg(True, True, "categorical", i0=it * N)
+        oe.rollout(oa, cfg, ob, T)
+        if algo == "a2c":
+            O.chk(ol.orc_fill_gae(ob.h, oc.h, 0.95, 0.99))
+        O.chk(ol.orc_fill_returns(ob.h, 0.99))
+        if algo == "a2c":
+            O.chk(ol.orc_whiten(ob.h, L.COL["advantage"]))
+        ca = parity.train_cfg(algo, "categorical", bs, 2, 0.015, 31, counter=ctr_a, le=0.05 if algo == "a2c" else 0.1)
+        O.chk(ol.orc_batch_train(oa.h, ob.h, C.byref(ca), None, O.vpz(info), None))
+        ctr_a += int(info[L.INFO["epochs_run"]])
+        if algo == "a2c":
+            cc = parity.train_cfg("value_mse", "deterministic", bs, 2, -1.0, 32, counter=ctr_c)
+            O.chk(ol.orc_batch_train(oc.h, ob.h, C.byref(cc), None, O.vpz(info), None)); ctr_c += int(info[L.INFO["epochs_run"]])
+    assert np.abs(ga.get_params() - oa.params).max() < 2e-4
+    if algo == "a2c":
+        assert np.abs(gc.get_params() - oc.params).max() < 2e-4
+    assert np.isfinite(solver.history[-1]["actor_loss"]) and "kl" in solver.history[-1]

@@ -382,3 +382,29 @@ def test_sac_target_restatement_against_numpy():
     yref = r + 0.9 * (1.0 - done) * (qmin - np.exp(np.float64(ola.params[0])) * lp)
     assert np.abs(y - yref).max() < 2e-5 * max(1.0, np.abs(yref).max())
     assert np.array_equal(y[done], ob["r"][0][done])
+
+
+@pytest.mark.parametrize("loss", ["a2c", "reinforce"])
+@pytest.mark.parametrize("head", ["categorical", "gaussian"])
+def test_a2c_reinforce_gradients_vs_float64_autograd(loss, head):
+    """a2c_loss (a2c.jl:4-15), reinforce_loss (reinforce.jl:4-13) of the oracle vs torch float64 autograd of the reference formulas."""
+    rng = np.random.default_rng(12); n, acts = 48, ["tanh", "relu", "identity"]
+    disc = head == "categorical"; ad = 3 if disc else 2; dims = [4, 16, 16, ad]
+    o = O.OMlp(dims, acts, 0 if disc else ad).init_glorot(6, 0, -0.2); o.params[:] += 0.05 * rng.standard_normal(o.n).astype(np.float32)
+    ob = O.OBuffer(4, ad, L.ACTION_DISCRETE if disc else L.ACTION_CONTINUOUS, n, ["return", "logprob", "advantage"])
+    d = _fill(ob, n, rng, L.ACTION_DISCRETE if disc else L.ACTION_CONTINUOUS, ad)
+    ids = np.arange(n, dtype=np.int64); info = np.zeros(L.INFO_N, np.float32); cfg = _cfg(loss, head, lp=0.7, le=0.2)
+    O.chk(lib.orc_loss_grad(o.h, ob.h, C.byref(cfg), O.vpz(ids), n, O.vpz(info)))
+    p = _torch_net(o); z, off = _fwd(p, dims, acts, torch.tensor(d["s"], dtype=torch.float64))
+    a = torch.tensor(d["a"], dtype=torch.float64)
+    if disc:
+        pr = torch.softmax(z, 0); newlp = torch.log((pr * a).sum(0)); ent = (-(pr * torch.log(pr + float(np.finfo(np.float32).eps))).sum(0)).mean()
+    else:
+        ls = p[off:off + ad]; s2 = torch.exp(ls) ** 2
+        newlp = (-((a - z) ** 2) / (2 * s2[:, None]) - 0.9189385332046727 - ls[:, None]).sum(0); ent = 1.4189385332046727 + ls.sum()
+    w = torch.tensor(d["advantage" if loss == "a2c" else "return"][0], dtype=torch.float64)
+    total = 0.7 * (-(newlp * w).mean()) + 0.2 * (-ent) if loss == "a2c" else -(newlp * w).mean()
+    total.backward()
+    assert abs(info[0] - total.item()) < 1e-5 * max(1, abs(total.item()))
+    assert np.abs(o.grads - p.grad.numpy()).max() < 2e-6 * max(1, np.abs(p.grad.numpy()).max())
+    assert abs(info[L.INFO["entropy"]] - ent.item()) < 1e-5 and abs(info[L.INFO["kl"]] - (torch.tensor(d["logprob"][0], dtype=torch.float64) - newlp).mean().item()) < 1e-5
