@@ -17,7 +17,7 @@ class RolloutCfg(C.Structure):
     """crux_rollout_cfg (include/cruxhip.h)."""
     _fields_ = [("explore", i32), ("reset_at_end", i32), ("head", i32), ("eps_start", f64), ("eps_stop", f64),
                 ("eps_steps", i64), ("noise_sigma", f32), ("noise_eps_min", f32), ("noise_eps_max", f32),
-                ("a_min", f32), ("a_max", f32), ("i0", u64)]
+                ("a_min", f32), ("a_max", f32), ("logit_div", f32), ("i0", u64)]
 
 
 class TrainCfg(C.Structure):
@@ -101,6 +101,7 @@ SIGNATURES = {
     "crux_adam_apply": (i32, [vp, f32]),
     "crux_dqn_target": (i32, [vp, vp, f32, vp]),
     "crux_td_error": (i32, [vp, vp, vp, vp]),
+    "crux_softq_target": (i32, [vp, vp, f32, f32, vp]),
     "crux_td_step": (i32, [vp, vp, vp, i32, vp]),
     "crux_mlp_forward_cached": (i32, [vp, vp, i64, vp]),
     "crux_mlp_backward": (i32, [vp, vp, i64, vp, f32, i32, vp]),
@@ -108,6 +109,9 @@ SIGNATURES = {
     "crux_sac_temp_step": (i32, [vp, vp, vp, f32, u64, u64, vp]),
     "crux_double_q_step": (i32, [vp, vp, vp, vp, i32, vp]),
     "crux_sac_actor_step": (i32, [vp, vp, vp, vp, vp, u64, u64, vp]),
+    "crux_dpg_target": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, u64, u64, vp]),
+    "crux_q_step": (i32, [vp, vp, vp, i32, vp]),
+    "crux_dpg_actor_step": (i32, [vp, vp, vp, vp]),
 }
 
 _lib = None

@@ -698,6 +698,7 @@ def _rollout_cfg(sampler, explore, reset, i):
         cfg.noise_eps_min, cfg.noise_eps_max, cfg.a_min, cfg.a_max = pe.eps_min, pe.eps_max, pe.a_min, pe.a_max
     else:
         cfg.head = L.HEAD[pi_on.head]
+        cfg.logit_div = float(getattr(pi_on, "logit_div", 0.0))          # SoftQ: softmax(value ./ alpha) (softq.jl:53)
     return cfg, pi_on
 
 
@@ -979,11 +980,51 @@ def _value_training_sac(solver, D, gamma):
     return {k: float(np.mean([d[k] for d in infos])) for k in infos[0]}
 
 
+def _value_training_dpg(solver, D, gamma):
+    """value_training (src/model_free/off_policy.jl:66-111) for DDPG (ddpg.jl) and TD3 (td3.jl): per epoch rand! -> ddpg_target / td3_target ->
+    train!(critic, td_loss | double_Q_loss) -> train!(actor, -mean(Q(s, mu(s)))) -> target_update."""
+    pi, pim, buf, ctx = solver.agent.pi, solver.agent.pi_minus, solver.buffer, solver.buffer.ctx
+    A, Q, Am, Qm = pi.A, pi.C, pim.A, pim.C
+    twin = isinstance(Q, DoubleNetwork)
+    c_opt, a_opt = solver.c_opt, solver.a_opt
+    for q in ((Q.N1, Q.N2) if twin else (Q,)):
+        _ensure_opt(q, c_opt)
+    _ensure_opt(A, a_opt)
+    if buf.isprioritized():
+        raise NotImplementedError("DDPG/TD3 with a prioritized buffer is not wired up")
+    B = D.capacity
+    if solver._dy is None:
+        solver._dy = ctx.alloc(4 * B)
+    sm = solver.P.get("pi_smooth") if solver.target_fn == "td3" else None
+    infos, lib, raw = [], ctx.lib, np.zeros(L.INFO_N, np.float32)
+    for epoch in range(c_opt.epochs):
+        ctr = solver.i * c_opt.epochs + epoch
+        rand_(D, buf, i=ctr)                                                                           # :71
+        info = {}
+        ctx.check(lib.crux_dpg_target(Am.h, (Qm.N1 if twin else Qm).h, Qm.N2.h if (twin and solver.target_fn == "td3") else None, D.h, float(gamma),
+                                      sm.sigma if sm else -1.0, sm.eps_min if sm else 0.0, sm.eps_max if sm else 0.0, sm.a_min if sm else 0.0, sm.a_max if sm else 0.0,
+                                      solver.noise_seed, ctr, solver._dy))                             # :80
+        if twin:
+            ctx.check(lib.crux_double_q_step(Q.N1.h, Q.N2.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))
+            info.update({"Q1avg": float(raw[L.INFO["q1avg"]]), "Q2avg": float(raw[L.INFO["q2avg"]])})
+        else:
+            ctx.check(lib.crux_q_step(Q.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))
+            info["Qavg"] = float(raw[L.INFO["q1avg"]])
+        info.update({c_opt.name + "loss": float(raw[0]), c_opt.name + "grad_norm": float(raw[1])})   # :91-93
+        ctx.check(lib.crux_dpg_actor_step(A.h, (Q.N1 if twin else Q).h, D.h, _vp(raw)))                 # :96-98
+        info.update({a_opt.name + "loss": float(raw[0]), a_opt.name + "grad_norm": float(raw[1])})
+        polyak_average_(pim, pi, solver.tau)                                                           # :101
+        infos.append(info)
+    return {k: float(np.mean([d[k] for d in infos])) for k in infos[0]}
+
+
 def value_training(solver, D, gamma):
     """value_training(S, D, gamma) (src/model_free/off_policy.jl:66-111) for the critic-only (DQN) case: per epoch
     rand! -> dqn_target -> [update_priorities!(td_error)] -> train!(td_loss); then target_update once (:108)."""
     if solver.target_fn == "sac":
         return _value_training_sac(solver, D, gamma)
+    if solver.target_fn in ("ddpg", "td3"):
+        return _value_training_dpg(solver, D, gamma)
     pi, pim, buf, p, ctx = solver.agent.pi, solver.agent.pi_minus, solver.buffer, solver.c_opt, solver.buffer.ctx
     _ensure_opt(pi, p)
     B = D.capacity
@@ -992,7 +1033,10 @@ def value_training(solver, D, gamma):
     infos = []
     for epoch in range(p.epochs):
         rand_(D, buf, i=solver.i * p.epochs + epoch)                                                   # :71 (Philox counter unique per draw)
-        ctx.check(ctx.lib.crux_dqn_target(pim.h, D.h, float(gamma), solver._dy))                        # :80  dqn.jl:4-6
+        if solver.target_fn == "softq":
+            ctx.check(ctx.lib.crux_softq_target(pim.h, D.h, float(gamma), float(solver.P["alpha"]), solver._dy))   # :80  softq.jl:4-13
+        else:
+            ctx.check(ctx.lib.crux_dqn_target(pim.h, D.h, float(gamma), solver._dy))                    # :80  dqn.jl:4-6
         if buf.isprioritized():                                                                        # :83
             ctx.check(ctx.lib.crux_td_error(pi.h, D.h, solver._dy, solver._derr))
             ctx.check(ctx.lib.crux_per_update_device(buf.h, ctx.lib.crux_buffer_indices_ptr(D.h), solver._derr, B))
@@ -1052,6 +1096,42 @@ def SAC(pi, S, N, dN=50, SAC_alpha=1.0, SAC_H_target=None, pi_explore=None, SAC_
     return OffPolicySolver(agent=PolicyParams(pi, pi_explore=pi_explore or GaussianNoiseExplorationPolicy(0.1), pi_minus=clone_policy(pi)), S=S, N=N, dN=dN, P=P,
                            param_optimizers=[(P["SAC_log_alpha"], TrainingParams(loss=sac_temp_loss, **t))],
                            a_opt=TrainingParams(loss=sac_actor_loss, **a), c_opt=TrainingParams(loss=double_Q_loss, **c), target_fn="sac", **kw)
+
+
+def SoftQ(pi, S, N, dN=4, c_opt=None, alpha=1.0, **kw):
+    """SoftQ(; pi::DiscreteNetwork, N, dN=4, c_opt=(epochs=4,), alpha=1f0) (src/model_free/rl/softq.jl:31-58): the policy samples from
+    softmax(Q ./ alpha) (always_stochastic, :52-53), target = softq_target(alpha)."""
+    pi.always_stochastic, pi.logit_div = True, float(np.float32(alpha))
+    pim = DiscreteNetwork(pi.network, pi.outputs, ctx=pi.ctx); copyto_(pim, pi)
+    c = dict(c_opt or {}); c.setdefault("name", "critic_"); c.setdefault("epochs", 4)
+    return OffPolicySolver(agent=PolicyParams(pi, pi_minus=pim), S=S, N=N, dN=dN, c_opt=TrainingParams(loss=td_loss, **c), target_fn="softq", P={"alpha": np.float32(alpha)}, **kw)
+
+
+ddpg_actor_loss, td3_actor_loss = _Loss("ddpg_actor"), _Loss("td3_actor")   # ddpg.jl:26, td3.jl:12
+
+
+def _dpg_solver(pi, S, N, dN, pi_explore, a_opt, c_opt, target_fn, a_loss, c_loss, pi_smooth, kw):
+    c = dict(c_opt or {}); c.setdefault("name", "critic_"); c.setdefault("epochs", dN)
+    a = dict(a_opt or {}); a.setdefault("name", "actor_")
+    return OffPolicySolver(agent=PolicyParams(pi, pi_explore=pi_explore or GaussianNoiseExplorationPolicy(0.1), pi_minus=clone_policy(pi)), S=S, N=N, dN=dN,
+                           P={"pi_smooth": pi_smooth or GaussianNoiseExplorationPolicy(0.1, eps_min=-0.5, eps_max=0.5)},
+                           a_opt=TrainingParams(loss=a_loss, **a), c_opt=TrainingParams(loss=c_loss, **c), target_fn=target_fn, **kw)
+
+
+def DDPG(pi, S, N, dN=50, pi_explore=None, a_opt=None, c_opt=None, pi_smooth=None, **kw):
+    """DDPG(; pi::ActorCritic{ContinuousNetwork, ContinuousNetwork}, dN=50, pi_explore=GaussianNoiseExplorationPolicy(0.1f0), a_opt, c_opt(epochs=dN), ...)
+    (src/model_free/rl/ddpg.jl:46-70): ddpg_target, td_loss critic, ddpg_actor_loss."""
+    if not (isinstance(pi, ActorCritic) and isinstance(pi.A, ContinuousNetwork) and isinstance(pi.C, ContinuousNetwork)):
+        raise TypeError("DDPG: pi must be ActorCritic(ContinuousNetwork, ContinuousNetwork)")
+    return _dpg_solver(pi, S, N, dN, pi_explore, a_opt, c_opt, "ddpg", ddpg_actor_loss, td_loss, pi_smooth, kw)
+
+
+def TD3(pi, S, N, dN=50, pi_explore=None, a_opt=None, c_opt=None, pi_smooth=None, **kw):
+    """TD3(; pi::ActorCritic{ContinuousNetwork, DoubleNetwork}, dN=50, pi_smooth=GaussianNoiseExplorationPolicy(0.1f0, eps_min=-0.5f0, eps_max=0.5f0), ...)
+    (src/model_free/rl/td3.jl:30-58): td3_target, double_Q_loss critic, td3_actor_loss through critic.N1."""
+    if not (isinstance(pi, ActorCritic) and isinstance(pi.A, ContinuousNetwork) and isinstance(pi.C, DoubleNetwork)):
+        raise TypeError("TD3: pi must be ActorCritic(ContinuousNetwork, DoubleNetwork(ContinuousNetwork, ContinuousNetwork))")
+    return _dpg_solver(pi, S, N, dN, pi_explore, a_opt, c_opt, "td3", td3_actor_loss, double_Q_loss, pi_smooth, kw)
 
 
 _solve_on_policy = solve

@@ -115,8 +115,9 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
           logprob = (float)log(eps * (1.0 / (double)nout) + (1.0 - eps));
         } else {
           float pr[ENV_MAXOBS];
-          float mx = z[0]; for (int q = 1; q < nout; ++q) mx = z[q] > mx ? z[q] : mx;
-          float sum = 0.f; for (int q = 0; q < nout; ++q) { pr[q] = expf(z[q] - mx); sum = __fadd_rn(sum, pr[q]); }
+          const float ldiv = a.cfg.logit_div > 0.f ? a.cfg.logit_div : 1.f;                       // softmax(value ./ alpha) (softq.jl:53)
+          float mx = __fdiv_rn(z[0], ldiv); for (int q = 1; q < nout; ++q) { const float zq = __fdiv_rn(z[q], ldiv); mx = zq > mx ? zq : mx; }
+          float sum = 0.f; for (int q = 0; q < nout; ++q) { pr[q] = expf(__fdiv_rn(z[q], ldiv) - mx); sum = __fadd_rn(sum, pr[q]); }
           for (int q = 0; q < nout; ++q) pr[q] = __fdiv_rn(pr[q], sum);
           const crux_u32x4 x = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_ACTION);
           const float draw = crux_u32_to_f32(x.v[0]);

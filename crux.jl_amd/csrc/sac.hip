@@ -1,4 +1,4 @@
-// sac.hip -- SAC learner steps on the dense engine (dense.hip).
+// sac.hip -- off-policy actor-critic learner steps (SAC, DDPG, TD3) on the dense engine (dense.hip).
 // Reference: src/model_free/rl/sac.jl:4-9 (sac_target), :34-40 (sac_actor_loss), :45-52 (sac_temp_loss); double_Q_loss
 // src/utils.jl:89-96; GaussianPolicy exploration / gaussian_logpdf src/policies.jl:333-344; value(pi, s, a) = net(vcat(s, a))
 // src/policies.jl:96; train! src/training.jl:13-25 (gradient norm, NaN => error before the update, Adam).
@@ -40,6 +40,33 @@ __global__ void k_sac_target(const float* __restrict__ r, const uint8_t* __restr
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (j >= B) return;
   const float alpha = expf(log_alpha[0]); const float mn = q2[j] < q1[j] ? q2[j] : q1[j];
   y[j] = __fadd_rn(r[j], __fmul_rn(__fmul_rn(gamma, __fsub_rn(1.f, done[j] ? 1.f : 0.f)), __fsub_rn(mn, __fmul_rn(alpha, lp[j]))));
+}
+
+// DDPG / TD3 target actions (ddpg.jl:6-18, td3.jl:4-7): a' = mu(sp) [smoothed: clamp(a' + clamp(sigma*randn, eps_min, eps_max), a_min, a_max), policies.jl:510-514]; sa = vcat(sp, a')
+__global__ void k_dpg_action(const float* __restrict__ mu, const float* __restrict__ s, int od, int ad, int64_t B, float sigma, float emin, float emax, float amin, float amax,
+                             uint64_t seed, uint64_t counter, float* __restrict__ sa) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= B * (od + ad)) return;
+  const int64_t j = i / (od + ad); const int k = (int)(i - j * (od + ad));
+  if (k < od) { sa[i] = s[j * od + k]; return; }
+  const int d = k - od; float a = mu[j * ad + d];
+  if (sigma >= 0.f) { float e = __fmul_rn(sac_randn(seed, counter, (uint32_t)(j * ad + d)), sigma); e = fminf(fmaxf(e, emin), emax); a = fminf(fmaxf(__fadd_rn(a, e), amin), amax); }
+  sa[i] = a;
+}
+__global__ void k_dpg_target(const float* __restrict__ r, const uint8_t* __restrict__ done, const float* __restrict__ q1, const float* __restrict__ q2, float gamma, int64_t B, float* __restrict__ y) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (j >= B) return;
+  const float q = q2 ? (q2[j] < q1[j] ? q2[j] : q1[j]) : q1[j];
+  y[j] = __fadd_rn(r[j], __fmul_rn(__fmul_rn(gamma, __fsub_rn(1.f, done[j] ? 1.f : 0.f)), q));
+}
+__global__ void k_fill(float* __restrict__ p, float v, int64_t n) { const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+__global__ void k_slice_rows(const float* __restrict__ src, int ld, int off, int rows, int64_t B, float* __restrict__ dst) {   // dst[r + rows*j] = src[off + r + ld*j]
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= B * rows) return;
+  const int64_t j = i / rows; const int r = (int)(i - j * rows); dst[i] = src[off + r + (int64_t)ld * j];
+}
+__global__ void k_mean_info(const float* __restrict__ q, int64_t B, float sign, const double* __restrict__ ssq, float* __restrict__ dinfo) {   // single thread block of 256
+  __shared__ double red[4];
+  double s = 0; for (int64_t j = threadIdx.x; j < B; j += 256) s += (double)q[j];
+  s = wave_sum_d(s); __syncthreads(); if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s; __syncthreads();
+  if (threadIdx.x == 0) { dinfo[CRUX_INFO_LOSS] = sign * (float)((((red[0] + red[1]) + red[2]) + red[3]) / (double)B); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]); }
 }
 
 // deterministic single-block reductions (256 threads; double accumulators like the oracle)
@@ -232,28 +259,76 @@ int32_t crux_sac_temp_step(crux_mlp* actor, crux_mlp* la, crux_buffer* b, float 
   return finish_step(c, dinfo, st, info_out, "sac_temp_loss");
 }
 
-int32_t crux_double_q_step(crux_mlp* q1, crux_mlp* q2, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out) {
-  if (!q1 || !q2 || !b || !d_y) return CRUX_EINVAL;
-  crux_ctx* c = q1->ctx; int32_t rc = check_sac(c, nullptr, q1, q2, nullptr, b, "double_Q_loss"); if (rc) return rc;
-  if (use_weight && !has_col(b, CRUX_COL_WEIGHT)) return crux_fail(c, CRUX_EINVAL, "double_Q_loss(weight=:weight): batch has no :weight column");
-  const int64_t B = b->elements; const int od = b->obs_dim, ad = b->act_dim;
-  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (od + ad + 1) + 8192), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "double_q: scratch");
+static int32_t q_step_impl(crux_mlp* q1, crux_mlp* q2, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out, const char* who) {
+  crux_ctx* c = q1->ctx; int32_t rc = check_sac(c, nullptr, q1, q2, nullptr, b, who); if (rc) return rc;
+  if (use_weight && !has_col(b, CRUX_COL_WEIGHT)) return crux_fail(c, CRUX_EINVAL, "%s(weight=:weight): batch has no :weight column", who);
+  const int64_t B = b->elements; const int od = b->obs_dim, ad = b->act_dim; const int nq = q2 ? 2 : 1;
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (od + ad + 1) + 8192), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "%s: scratch", who);
   float* sa = cv.take<float>((size_t)B * (od + ad)); float* dy = cv.take<float>((size_t)B); float* dinfo = cv.take<float>(CRUX_INFO_N);
   double* st1 = cv.take<double>(2); double* st2 = cv.take<double>(2); double* ssq = cv.take<double>(1); int32_t* st = cv.take<int32_t>(1);
   HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 5, c->stream));
   const float* w = use_weight ? (const float*)b->col[CRUX_COL_WEIGHT] : nullptr;
   hipLaunchKernelGGL(k_concat_sa, dim3(nblk(B * (od + ad))), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_S], (const float*)b->col[CRUX_COL_A], od, ad, B, sa);
   crux_mlp* qs[2] = {q1, q2}; double* sts[2] = {st1, st2};
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < nq; ++t) {
     rc = crux_dense_forward(qs[t], sa, B, c->stream); if (rc) return rc;
-    hipLaunchKernelGGL(k_q_head, dim3(1), dim3(256), 0, c->stream, crux_dense_act(qs[t], qs[t]->nd.L), d_y, w, B, 0.5f, dy, sts[t]);
+    hipLaunchKernelGGL(k_q_head, dim3(1), dim3(256), 0, c->stream, crux_dense_act(qs[t], qs[t]->nd.L), d_y, w, B, nq == 2 ? 0.5f : 1.0f, dy, sts[t]);
     rc = crux_dense_backward(qs[t], sa, B, dy, 1.0f, true, nullptr, c->stream); if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, c->stream, q1->g, (int64_t)q1->nd.n_params, q2->g, (int64_t)q2->nd.n_params, ssq);
-  hipLaunchKernelGGL(k_critic_info, dim3(1), dim3(1), 0, c->stream, st1, st2, ssq, B, dinfo);
+  hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, c->stream, q1->g, (int64_t)q1->nd.n_params, q2 ? q2->g : (const float*)nullptr, (int64_t)(q2 ? q2->nd.n_params : 0), ssq);
+  hipLaunchKernelGGL(k_critic_info, dim3(1), dim3(1), 0, c->stream, st1, nq == 2 ? st2 : st1, ssq, B, dinfo);   // single Q: 0.5 l + 0.5 l = l
   rc = adam_gated(q1, ssq, st); if (rc) return rc;
-  rc = adam_gated(q2, ssq, st); if (rc) return rc;
-  return finish_step(c, dinfo, st, info_out, "double_Q_loss");
+  if (q2) { rc = adam_gated(q2, ssq, st); if (rc) return rc; }
+  return finish_step(c, dinfo, st, info_out, who);
+}
+int32_t crux_double_q_step(crux_mlp* q1, crux_mlp* q2, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out) {
+  if (!q1 || !q2 || !b || !d_y) return CRUX_EINVAL;
+  return q_step_impl(q1, q2, b, d_y, use_weight, info_out, "double_Q_loss");
+}
+int32_t crux_q_step(crux_mlp* q, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out) {
+  if (!q || !b || !d_y) return CRUX_EINVAL;
+  return q_step_impl(q, nullptr, b, d_y, use_weight, info_out, "td_loss");
+}
+
+int32_t crux_dpg_target(crux_mlp* actor_t, crux_mlp* q1t, crux_mlp* q2t, crux_buffer* b, float gamma, float sigma, float eps_min, float eps_max, float a_min, float a_max,
+                        uint64_t seed, uint64_t counter, float* d_y) {
+  if (!actor_t || !q1t || !b || !d_y) return CRUX_EINVAL;
+  crux_ctx* c = actor_t->ctx; int32_t rc = check_sac(c, nullptr, q1t, q2t, nullptr, b, "ddpg_target"); if (rc) return rc;
+  const int64_t B = b->elements; const int od = b->obs_dim, ad = b->act_dim;
+  if (actor_t->nd.L < 1 || actor_t->nd.dims[0] != od || actor_t->nd.dims[actor_t->nd.L] != ad) return crux_fail(c, CRUX_EINVAL, "ddpg_target: actor must map %d -> %d", od, ad);
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (od + ad) + 1024), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "ddpg_target: scratch");
+  float* sa = cv.take<float>((size_t)B * (od + ad));
+  const float* SP = (const float*)b->col[CRUX_COL_SP];
+  rc = crux_dense_forward(actor_t, SP, B, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_dpg_action, dim3(nblk(B * (od + ad))), dim3(256), 0, c->stream, crux_dense_act(actor_t, actor_t->nd.L), SP, od, ad, B, sigma, eps_min, eps_max, a_min, a_max, seed, counter, sa);
+  rc = crux_dense_forward(q1t, sa, B, c->stream); if (rc) return rc;
+  if (q2t) { rc = crux_dense_forward(q2t, sa, B, c->stream); if (rc) return rc; }
+  hipLaunchKernelGGL(k_dpg_target, dim3(nblk(B)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE],
+                     crux_dense_act(q1t, q1t->nd.L), q2t ? crux_dense_act(q2t, q2t->nd.L) : (const float*)nullptr, gamma, B, d_y);
+  return crux_launch_check(c, "ddpg_target");
+}
+
+int32_t crux_dpg_actor_step(crux_mlp* actor, crux_mlp* q, crux_buffer* b, float* info_out) {
+  if (!actor || !q || !b) return CRUX_EINVAL;
+  crux_ctx* c = actor->ctx; int32_t rc = check_sac(c, nullptr, q, nullptr, nullptr, b, "ddpg_actor_loss"); if (rc) return rc;
+  const int64_t B = b->elements; const int od = b->obs_dim, ad = b->act_dim, sd = od + ad;
+  if (actor->nd.L < 1 || actor->nd.dims[0] != od || actor->nd.dims[actor->nd.L] != ad) return crux_fail(c, CRUX_EINVAL, "ddpg_actor_loss: actor must map %d -> %d", od, ad);
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (2 * sd + ad + 1) + 8192), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "ddpg_actor: scratch");
+  float* sa = cv.take<float>((size_t)B * sd); float* dsa = cv.take<float>((size_t)B * sd); float* da = cv.take<float>((size_t)B * ad); float* dy = cv.take<float>((size_t)B);
+  float* dinfo = cv.take<float>(CRUX_INFO_N); double* ssq = cv.take<double>(1); int32_t* st = cv.take<int32_t>(1);
+  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 3, c->stream));
+  const float* S = (const float*)b->col[CRUX_COL_S];
+  rc = crux_dense_forward(actor, S, B, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_dpg_action, dim3(nblk(B * sd)), dim3(256), 0, c->stream, crux_dense_act(actor, actor->nd.L), S, od, ad, B, -1.f, 0.f, 0.f, 0.f, 0.f, (uint64_t)0, (uint64_t)0, sa);
+  rc = crux_dense_forward(q, sa, B, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_fill, dim3(nblk(B)), dim3(256), 0, c->stream, dy, -1.f / (float)B, B);                    // d(-mean(Q))/dQ
+  rc = crux_dense_backward(q, sa, B, dy, 1.0f, false, dsa, c->stream); if (rc) return rc;                        // the critic's parameters are not trained here
+  hipLaunchKernelGGL(k_slice_rows, dim3(nblk(B * ad)), dim3(256), 0, c->stream, dsa, sd, od, ad, B, da);
+  rc = crux_dense_backward(actor, S, B, da, 1.0f, true, nullptr, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, c->stream, actor->g, (int64_t)actor->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+  hipLaunchKernelGGL(k_mean_info, dim3(1), dim3(256), 0, c->stream, crux_dense_act(q, q->nd.L), B, -1.f, ssq, dinfo);
+  rc = adam_gated(actor, ssq, st); if (rc) return rc;
+  return finish_step(c, dinfo, st, info_out, "ddpg_actor_loss");
 }
 
 int32_t crux_sac_actor_step(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* la, crux_buffer* b, uint64_t seed, uint64_t counter, float* info_out) {

@@ -188,6 +188,8 @@ typedef struct {
   double eps_start, eps_stop; int64_t eps_steps;
   /* GaussianNoiseExplorationPolicy (policies.jl:499-514); noise_sigma<0 disables. */
   float noise_sigma, noise_eps_min, noise_eps_max, a_min, a_max;
+  float logit_div;        /* categorical head: probabilities = softmax(value ./ logit_div) (SoftQ's logit_conversion,
+                             rl/softq.jl:53); 0 = plain softmax. Occupies the former padding: the struct stays 72 bytes. */
   uint64_t i0;            /* steps!(...; i=) global interaction counter at the first step          */
 } crux_rollout_cfg;
 
@@ -277,6 +279,8 @@ int32_t crux_adam_apply(crux_mlp* net, float grad_scale);
 /* off-policy pieces (src/model_free/rl/dqn.jl:4-6, src/utils.jl:76-87,112) --------------------------- */
 /* y = r + gamma*(1-done)*max_a Q_target(sp)   (dqn_target) over the staging buffer -> d_y [len].  */
 int32_t crux_dqn_target(crux_mlp* target_net, crux_buffer* batch, float gamma, float* d_y);
+/* softq_target(alpha) (rl/softq.jl:4-13): y = r + gamma*(1-done)*alpha*logsumexp(Q_target(sp) ./ alpha) -> d_y [len].        */
+int32_t crux_softq_target(crux_mlp* target_net, crux_buffer* batch, float gamma, float alpha, float* d_y);
 /* td_error = |Q(s,a) - y| (utils.jl:112) -> d_err [len].                                          */
 int32_t crux_td_error(crux_mlp* net, crux_buffer* batch, const float* d_y, float* d_err);
 /* train!(critic, td_loss) (utils.jl:76-87): one Adam step on mean((Q(s,a)-y)^2 [.* weight]).       */
@@ -306,6 +310,20 @@ int32_t crux_double_q_step(crux_mlp* q1, crux_mlp* q2, crux_buffer* batch, const
  * a ~ actor(s) reparameterised; LOSS, GRAD_NORM, ENTROPY (= -mean(logprob)).                               */
 int32_t crux_sac_actor_step(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* log_alpha, crux_buffer* batch,
                             uint64_t seed, uint64_t counter, float* info_out);
+
+/* DDPG / TD3 (src/model_free/rl/ddpg.jl, td3.jl) -----------------------------------------------------------
+ * actor: deterministic ContinuousNetwork s -> a; critics: ContinuousNetwork over vcat(s, a).              */
+/* ddpg_target (ddpg.jl:6-8) when q2_targ = NULL and smooth_sigma < 0; td3_target (td3.jl:4-7) with both targets and the
+ * smoothing policy GaussianNoiseExplorationPolicy(sigma; eps_min, eps_max, a_min, a_max) (policies.jl:510-514):
+ * y = r + gamma (1-done) min_k Q_k^-(sp, clamp(mu^-(sp) + clamp(sigma randn, eps_min, eps_max), a_min, a_max)).          */
+int32_t crux_dpg_target(crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_buffer* batch, float gamma,
+                        float smooth_sigma, float eps_min, float eps_max, float a_min, float a_max,
+                        uint64_t seed, uint64_t counter, float* d_y);
+/* train!(critic, td_loss) for a critic over vcat(s, a) (utils.jl:76-87): LOSS, GRAD_NORM, Q1AVG.                           */
+int32_t crux_q_step(crux_mlp* q, crux_buffer* batch, const float* d_y, int32_t use_weight, float* info_out);
+/* train!(actor, ddpg_actor_loss | td3_actor_loss) (ddpg.jl:26, td3.jl:12): -mean(Q(s, mu(s))) with Q = critic (DDPG) or
+ * critic.N1 (TD3); only the actor is updated. LOSS, GRAD_NORM.                                                              */
+int32_t crux_dpg_actor_step(crux_mlp* actor, crux_mlp* q, crux_buffer* batch, float* info_out);
 
 #ifdef __cplusplus
 }

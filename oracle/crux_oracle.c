@@ -590,7 +590,8 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
           /* p1 = eps*exp(logpdf(ObjectCategorical)) = eps/n ; p2 = 1-eps ; log(p1+p2) (policies.jl:485-493) */
           logprob = (float)log(eps * (1.0 / (double)nout) + (1.0 - eps));
         } else {                                                                                 /* DiscreteNetwork exploration policies.jl:137-142 */
-          softmax_col(z, nout, p);
+          if (cfg->logit_div > 0.f) { float zs[64]; for (int q = 0; q < nout; ++q) zs[q] = z[q] / cfg->logit_div; softmax_col(zs, nout, p); }   /* softmax(value ./ alpha) softq.jl:53 */
+          else softmax_col(z, nout, p);
           crux_u32x4 x = crux_philox(e->seed, ctr, (uint32_t)k, CRUX_RNG_ACTION);
           float draw = crux_u32_to_f32(x.v[0]);
           /* [3P] Distributions rand(::DiscreteNonParametric): cp=p[1]; while cp <= draw && i<n: cp += p[++i] */
@@ -849,6 +850,17 @@ int32_t orc_dqn_target(orc_mlp* tn, orc_buffer* b, float gamma, float* y) {
     y[s] = R[s] + (gamma * (1.f - (D[s] ? 1.f : 0.f))) * mx; }                 /* r .+ gamma .* (1 .- done) .* max  dqn.jl:5 */
   cc_free(tn, &c); return CRUX_OK;
 }
+/* softq_target(alpha) softq.jl:4-13: r + gamma (1-done) alpha logsumexp(Q^-(sp) ./ alpha) [3P NNlib.logsumexp: max-shifted] */
+int32_t orc_softq_target(orc_mlp* tn, orc_buffer* b, float gamma, float alpha, float* y) {
+  int64_t n = b->elements; int nout = tn->dims[tn->n_layers]; colcache c = cc_alloc(tn);
+  const float* SP = (const float*)b->col[CRUX_COL_SP]; const float* R = (const float*)b->col[CRUX_COL_R]; const uint8_t* D = (const uint8_t*)b->col[CRUX_COL_DONE];
+  for (int64_t s = 0; s < n; ++s) { fwd_col(tn, SP + (size_t)s * b->obs_dim, c.h); const float* q = c.h[tn->n_layers];
+    float mx = q[0] / alpha; for (int k = 1; k < nout; ++k) { float v = q[k] / alpha; if (v > mx) mx = v; }
+    float sum = 0.f; for (int k = 0; k < nout; ++k) sum = sum + expf(q[k] / alpha - mx);
+    float sv = alpha * (mx + logf(sum));
+    y[s] = R[s] + (gamma * (1.f - (D[s] ? 1.f : 0.f))) * sv; }
+  cc_free(tn, &c); return CRUX_OK;
+}
 static float q_sa(const orc_buffer* b, const float* q, int64_t s) { /* value(pi, s, a_oh) = sum(value .* a_oh) policies.jl:122 */
   const uint8_t* a = (const uint8_t*)b->col[CRUX_COL_A] + (size_t)s * b->act_dim; float acc = 0.f;
   for (int k = 0; k < b->act_dim; ++k) acc = acc + q[k] * (a[k] ? 1.f : 0.f); return acc;
@@ -1009,6 +1021,58 @@ int32_t orc_sac_actor_step(orc_mlp* actor, orc_mlp* q1, orc_mlp* q2, orc_mlp* lo
   cc_free(actor, &ca); cc_free(q1, &c1); cc_free(q2, &c2);
   info[CRUX_INFO_LOSS] = (float)(sl / (double)n); info[CRUX_INFO_ENTROPY] = (float)(-(slp / (double)n));
   info[CRUX_INFO_GRAD_NORM] = (float)sqrt(sumsq_tensors(actor));
+  if (isnan(info[CRUX_INFO_GRAD_NORM])) return CRUX_ENAN;
+  return orc_adam_apply(actor, 1.0f);
+}
+
+/* ============================================================================================
+ * DDPG / TD3                       src/model_free/rl/ddpg.jl:6-26, td3.jl:4-12, policies.jl:510-514
+ * ============================================================================================ */
+static float clampf(float x, float lo, float hi) { return x < lo ? lo : x > hi ? hi : x; }
+int32_t orc_dpg_target(orc_mlp* actor_t, orc_mlp* q1t, orc_mlp* q2t, orc_buffer* b, float gamma, float sigma, float eps_min, float eps_max, float a_min, float a_max,
+                       uint64_t seed, uint64_t counter, float* y) {
+  int64_t n = b->elements; int od = b->obs_dim, ad = b->act_dim;
+  if (b->act_kind != CRUX_ACTION_CONTINUOUS || actor_t->dims[0] != od || actor_t->dims[actor_t->n_layers] != ad || q1t->dims[0] != od + ad || (q2t && q2t->dims[0] != od + ad)) return CRUX_EINVAL;
+  colcache ca = cc_alloc(actor_t), c1 = cc_alloc(q1t), c2; if (q2t) c2 = cc_alloc(q2t);
+  const float* SP = (const float*)b->col[CRUX_COL_SP]; const float* R = (const float*)b->col[CRUX_COL_R]; const uint8_t* D = (const uint8_t*)b->col[CRUX_COL_DONE];
+  float sa[1024];
+  for (int64_t j = 0; j < n; ++j) {
+    fwd_col(actor_t, SP + (size_t)j * od, ca.h); memcpy(sa, SP + (size_t)j * od, 4 * (size_t)od);
+    for (int d = 0; d < ad; ++d) { float a = ca.h[actor_t->n_layers][d];                               /* action(pi, sp) */
+      if (sigma >= 0.f) { float e = randn_f32(seed, counter, (uint32_t)(j * ad + d), 0) * sigma; a = clampf(a + clampf(e, eps_min, eps_max), a_min, a_max); }   /* policies.jl:512-513 */
+      sa[od + d] = a; }
+    fwd_col(q1t, sa, c1.h); float q = c1.h[q1t->n_layers][0];
+    if (q2t) { fwd_col(q2t, sa, c2.h); float qb = c2.h[q2t->n_layers][0]; q = qb < q ? qb : q; }       /* min.(value(pi, sp, ap)...) td3.jl:6 */
+    y[j] = R[j] + (gamma * (1.f - (D[j] ? 1.f : 0.f))) * q;
+  }
+  cc_free(actor_t, &ca); cc_free(q1t, &c1); if (q2t) cc_free(q2t, &c2); return CRUX_OK;
+}
+/* train!(critic, td_loss) with value(pi, s, a) = net(vcat(s, a)) (utils.jl:76-87, policies.jl:96) */
+int32_t orc_q_step(orc_mlp* q, orc_buffer* b, const float* y, int32_t use_weight, float* info) {
+  int64_t n = b->elements; int od = b->obs_dim, ad = b->act_dim; if (n <= 0 || b->act_kind != CRUX_ACTION_CONTINUOUS || q->dims[0] != od + ad || q->dims[q->n_layers] != 1) return CRUX_EINVAL;
+  const float* S = (const float*)b->col[CRUX_COL_S]; const float* A = (const float*)b->col[CRUX_COL_A]; const float* W = use_weight ? (const float*)b->col[CRUX_COL_WEIGHT] : NULL;
+  for (int k = 0; k < CRUX_INFO_N; ++k) info[k] = 0.f;
+  float sa[1024], invB = 1.f / (float)n; double sl = 0, sq = 0; colcache c = cc_alloc(q); memset(q->g, 0, 4 * (size_t)q->n_params);
+  for (int64_t j = 0; j < n; ++j) { memcpy(sa, S + (size_t)j * od, 4 * (size_t)od); memcpy(sa + od, A + (size_t)j * ad, 4 * (size_t)ad);
+    fwd_col(q, sa, c.h); float Q = c.h[q->n_layers][0], d = Q - y[j], w = W ? W[j] : 1.f; sl += (double)(d * d * w); sq += (double)Q;
+    float dy = 2.f * d * w * invB; bwd_col_dx(q, c.h, &dy, q->g, NULL); }
+  cc_free(q, &c);
+  info[CRUX_INFO_LOSS] = (float)(sl / (double)n); info[CRUX_INFO_Q1AVG] = (float)(sq / (double)n); info[CRUX_INFO_GRAD_NORM] = (float)sqrt(sumsq_tensors(q));
+  if (isnan(info[CRUX_INFO_GRAD_NORM])) return CRUX_ENAN;
+  return orc_adam_apply(q, 1.0f);
+}
+/* train!(actor, ddpg_actor_loss) ddpg.jl:26 / td3_actor_loss td3.jl:12: -mean(value(Q, s, action(pi, s))) */
+int32_t orc_dpg_actor_step(orc_mlp* actor, orc_mlp* q, orc_buffer* b, float* info) {
+  int64_t n = b->elements; int od = b->obs_dim, ad = b->act_dim;
+  if (n <= 0 || b->act_kind != CRUX_ACTION_CONTINUOUS || actor->dims[0] != od || actor->dims[actor->n_layers] != ad || q->dims[0] != od + ad || q->dims[q->n_layers] != 1) return CRUX_EINVAL;
+  colcache ca = cc_alloc(actor), cq = cc_alloc(q); const float* S = (const float*)b->col[CRUX_COL_S];
+  for (int k = 0; k < CRUX_INFO_N; ++k) info[k] = 0.f;
+  float sa[1024], dsa[1024], invB = 1.f / (float)n; double sq = 0; memset(actor->g, 0, 4 * (size_t)actor->n_params);
+  for (int64_t j = 0; j < n; ++j) { fwd_col(actor, S + (size_t)j * od, ca.h); memcpy(sa, S + (size_t)j * od, 4 * (size_t)od); memcpy(sa + od, ca.h[actor->n_layers], 4 * (size_t)ad);
+    fwd_col(q, sa, cq.h); sq += (double)cq.h[q->n_layers][0];
+    float dyq = -invB; bwd_col_dx(q, cq.h, &dyq, NULL, dsa); bwd_col_dx(actor, ca.h, dsa + od, actor->g, NULL); }
+  cc_free(actor, &ca); cc_free(q, &cq);
+  info[CRUX_INFO_LOSS] = (float)(-(sq / (double)n)); info[CRUX_INFO_GRAD_NORM] = (float)sqrt(sumsq_tensors(actor));
   if (isnan(info[CRUX_INFO_GRAD_NORM])) return CRUX_ENAN;
   return orc_adam_apply(actor, 1.0f);
 }

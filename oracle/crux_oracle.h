@@ -104,6 +104,7 @@ int32_t orc_loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg, 
 
 /* off-policy */
 int32_t orc_dqn_target(orc_mlp* target_net, orc_buffer* batch, float gamma, float* y);
+int32_t orc_softq_target(orc_mlp* target_net, orc_buffer* batch, float gamma, float alpha, float* y);   /* rl/softq.jl:1-13 */
 int32_t orc_td_error(orc_mlp* net, orc_buffer* batch, const float* y, float* err);
 int32_t orc_td_step(orc_mlp* net, orc_buffer* batch, const float* y, int32_t use_weight, float* info_out);
 /* SAC (src/model_free/rl/sac.jl:4-9,34-52; double_Q_loss src/utils.jl:89-96); log_alpha = orc_mlp_create(0, {0}, NULL, 1). */
@@ -111,6 +112,11 @@ int32_t orc_sac_target(orc_mlp* actor, orc_mlp* q1_targ, orc_mlp* q2_targ, orc_m
 int32_t orc_sac_temp_step(orc_mlp* actor, orc_mlp* log_alpha, orc_buffer* batch, float H_target, uint64_t seed, uint64_t counter, float* info_out);
 int32_t orc_double_q_step(orc_mlp* q1, orc_mlp* q2, orc_buffer* batch, const float* y, int32_t use_weight, float* info_out);
 int32_t orc_sac_actor_step(orc_mlp* actor, orc_mlp* q1, orc_mlp* q2, orc_mlp* log_alpha, orc_buffer* batch, uint64_t seed, uint64_t counter, float* info_out);
+/* DDPG / TD3 (src/model_free/rl/ddpg.jl:6-26, td3.jl:4-12) */
+int32_t orc_dpg_target(orc_mlp* actor_targ, orc_mlp* q1_targ, orc_mlp* q2_targ, orc_buffer* batch, float gamma, float sigma, float eps_min, float eps_max, float a_min, float a_max,
+                       uint64_t seed, uint64_t counter, float* y);
+int32_t orc_q_step(orc_mlp* q, orc_buffer* batch, const float* y, int32_t use_weight, float* info_out);
+int32_t orc_dpg_actor_step(orc_mlp* actor, orc_mlp* q, orc_buffer* batch, float* info_out);
 
 void orc_perm(uint64_t seed, uint64_t counter, uint32_t n, int64_t* out);
 void orc_philox(uint64_t seed, uint64_t counter, uint32_t stream, uint32_t purpose, uint32_t* out4);

@@ -541,3 +541,36 @@ def test_a2c_and_reinforce_losses_match_oracle(gpu_ctx, monkeypatch, force_gener
     assert np.abs(g.get_params() - o.params).max() < 2e-5
     for k in ("s", "a", "advantage", "return"):
         assert np.array_equal(gb[k], ob[k]), k                                        # both shuffles materialised identically
+
+
+def test_softq_target_and_solve_match_oracle(gpu_ctx):
+    """softq_target(alpha) and SoftQ's softmax(Q ./ alpha) exploration (src/model_free/rl/softq.jl:1-13,52-53) + the solve loop vs the oracle."""
+    E, dN, B, N, cap, seed, max_steps, alpha = 2, 4, 16, 40, 64, 8, 20, np.float32(0.5)
+    g, o = parity.make_pair([2, 8, 4], ["relu", "identity"], 43, 0, "discrete", outputs=["up", "down", "left", "right"])
+    S, A = crux.ContinuousSpace(2), crux.DiscreteSpace(4)
+    mdp = crux.SimpleGridWorld(n_envs=E, seed=seed)
+    solver = crux.SoftQ(g, S, N=N, dN=dN, alpha=alpha, c_opt={"batch_size": B, "optimizer": crux.Adam(np.float32(1e-3)), "epochs": dN}, buffer_size=cap, buffer_init=B, max_steps=max_steps)
+    crux.solve(solver, mdp)
+    ot = O.OMlp([2, 8, 4], ["relu", "identity"]); O.chk(O.lib().orc_mlp_copy(ot.h, o.h)); o.adam_init(float(np.float32(1e-3)))
+    ob = O.OBuffer(2, 4, L.ACTION_DISCRETE, cap); obt = O.OBuffer(2, 4, L.ACTION_DISCRETE, B)
+    oe = O.OEnv("gridworld", E, max_steps, 0.95, seed)
+    cfg = parity.rollout_cfg(True, False, "categorical"); cfg.logit_div = alpha
+    i = B; cfg.i0 = i; oe.rollout(o, cfg, ob, B // E)
+    y, info = np.empty(B, np.float32), np.zeros(L.INFO_N, np.float32)
+    while i <= N - dN:
+        cfg.i0 = i; oe.rollout(o, cfg, ob, dN // E)
+        for ep in range(dN):
+            O.chk(O.lib().orc_uniform_sample(obt.h, ob.h, B, None, i * dN + ep, crux.api.SAMPLE_SEED))
+            O.chk(O.lib().orc_softq_target(ot.h, obt.h, 0.95, alpha, O.vpz(y)))
+            O.chk(O.lib().orc_td_step(o.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+        O.chk(O.lib().orc_polyak(ot.h, o.h, 0.005))
+        i += dN
+    assert solver.i == i and len(solver.buffer) == len(ob)
+    for k in ("s", "a", "sp", "r", "done"):
+        assert np.array_equal(solver.buffer[k], ob[k]), k
+    assert np.abs(g.get_params() - o.params).max() < 2e-5 and np.abs(solver.agent.pi_minus.get_params() - ot.params).max() < 2e-5
+    # the target alone, on the last staged batch
+    dy = g.ctx.alloc(4 * B); g.ctx.check(g.ctx.lib.crux_softq_target(solver.agent.pi_minus.h, solver.batch.h, 0.95, float(alpha), dy))
+    yg = g.ctx.d2h(dy, np.empty(B, np.float32)); O.chk(O.lib().orc_softq_target(ot.h, obt.h, 0.95, alpha, O.vpz(y)))
+    assert np.abs(yg - y).max() < 1e-5
+    g.ctx.free(dy)

@@ -210,3 +210,86 @@ def test_sac_solve_matches_oracle_loop(gpu_ctx):
     for g, o in ((ga, oa), (g1, o1), (g2, o2), (solver.P["SAC_log_alpha"], ola), (solver.agent.pi_minus.C.N1, ot1), (solver.agent.pi_minus.A, ota)):
         assert np.abs(g.get_params() - o.params).max() < 5e-5
     assert abs(solver.history[-1]["actor_loss"]) < 1e3 and "SAC alpha" in solver.history[-1]
+
+
+# ---------------------------------------------------------------------------------------------------- DDPG / TD3
+@pytest.mark.parametrize("twin", [False, True])
+@pytest.mark.parametrize("od,ad,hidden,B", [(2, 1, [32], 64), (17, 6, [256, 256], 128)])
+def test_dpg_steps_match_oracle(gpu_ctx, twin, od, ad, hidden, B):
+    """ddpg_target / td3_target, td_loss over vcat(s, a), ddpg/td3 actor loss (ddpg.jl:6-26, td3.jl:4-12) vs the oracle."""
+    ctx, rng, seed = gpu_ctx, np.random.default_rng(23), 33
+    adims, qdims = [od] + hidden + [ad], [od + ad] + hidden + [1]
+    aacts, qacts = ["relu"] * len(hidden) + ["tanh"], ["relu"] * len(hidden) + ["identity"]
+    ga, oa = parity.make_pair(adims, aacts, 7, 0); g1, o1 = parity.make_pair(qdims, qacts, 7, 1); g2, o2 = parity.make_pair(qdims, qacts, 7, 2)
+    gat, oat = parity.make_pair(adims, aacts, 8, 0); g1t, o1t = parity.make_pair(qdims, qacts, 8, 1); g2t, o2t = parity.make_pair(qdims, qacts, 8, 2)
+    lr = float(np.float32(1e-3))
+    for g, o in ((ga, oa), (g1, o1), (g2, o2)):
+        g.attach_optimizer(crux.Adam(np.float32(1e-3))); o.adam_init(lr)
+    gb, ob = _batch_pair(rng, od, ad, B, ctx, weight=True)
+    lib, ol = ctx.lib, O.lib()
+    d_y = ctx.alloc(4 * B); y, yo = np.empty(B, np.float32), np.empty(B, np.float32)
+    gi, oi = np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32)
+    sm = (0.2, -0.5, 0.5, -1.0, 1.0) if twin else (-1.0, 0.0, 0.0, 0.0, 0.0)
+    for rep in range(2):
+        ctx.check(lib.crux_dpg_target(gat.h, g1t.h, g2t.h if twin else None, gb.h, 0.99, *sm, seed, 50 + rep, d_y)); ctx.d2h(d_y, y)
+        O.chk(ol.orc_dpg_target(oat.h, o1t.h, o2t.h if twin else None, ob.h, 0.99, *sm, seed, 50 + rep, O.vpz(yo)))
+        assert np.abs(y - yo).max() < 1e-4 * max(1, np.abs(yo).max())
+        if twin:
+            ctx.check(lib.crux_double_q_step(g1.h, g2.h, gb.h, d_y, rep, O.vpz(gi))); O.chk(ol.orc_double_q_step(o1.h, o2.h, ob.h, O.vpz(yo), rep, O.vpz(oi)))
+        else:
+            ctx.check(lib.crux_q_step(g1.h, gb.h, d_y, rep, O.vpz(gi))); O.chk(ol.orc_q_step(o1.h, ob.h, O.vpz(yo), rep, O.vpz(oi)))
+        for k in ("loss", "grad_norm", "q1avg"):
+            assert abs(gi[L.INFO[k]] - oi[L.INFO[k]]) <= 1e-4 * max(1.0, abs(oi[L.INFO[k]])), ("critic", k, gi, oi)
+        assert _step_close(g1, o1, ctx)
+        ctx.check(lib.crux_dpg_actor_step(ga.h, g1.h, gb.h, O.vpz(gi))); O.chk(ol.orc_dpg_actor_step(oa.h, o1.h, ob.h, O.vpz(oi)))
+        for k in ("loss", "grad_norm"):
+            assert abs(gi[L.INFO[k]] - oi[L.INFO[k]]) <= 2e-4 * max(1.0, abs(oi[L.INFO[k]])), ("actor", k, gi, oi)
+        assert _step_close(ga, oa, ctx)
+    ctx.free(d_y)
+
+
+@pytest.mark.parametrize("algo", ["ddpg", "td3"])
+def test_dpg_solve_runs_and_matches_oracle_loop(gpu_ctx, algo):
+    """solve(::OffPolicySolver) for DDPG / TD3 on the Pendulum restatement (test/gym/solver_tests.jl:85-86 shapes)."""
+    ctx = gpu_ctx
+    E, dN, B, N, cap, seed, max_steps, nseed = 2, 4, 16, 24, 64, 3, 20, 91
+    adims, qdims, aacts, qacts = [3, 32, 1], [4, 32, 1], ["relu", "tanh"], ["tanh", "identity"]
+    ga, oa = parity.make_pair(adims, aacts, 15, 0); g1, o1 = parity.make_pair(qdims, qacts, 15, 1); g2, o2 = parity.make_pair(qdims, qacts, 15, 2)
+    S = crux.ContinuousSpace(3); mdp = crux.PendulumMDP(n_envs=E, seed=seed)
+    twin = algo == "td3"
+    pi = crux.ActorCritic(ga, crux.DoubleNetwork(g1, g2) if twin else g1)
+    opt = {"batch_size": B, "optimizer": crux.Adam(np.float32(1e-3))}
+    ctor = crux.TD3 if twin else crux.DDPG
+    solver = ctor(pi, S, N=N, dN=dN, c_opt=dict(opt), a_opt=dict(opt), buffer_size=cap, buffer_init=B, max_steps=max_steps, noise_seed=nseed,
+                  pi_explore=crux.GaussianNoiseExplorationPolicy(0.3, a_min=-1.0, a_max=1.0))
+    crux.solve(solver, mdp)
+    lr = float(np.float32(1e-3)); ol = O.lib()
+    oat, o1t, o2t = O.OMlp(adims, aacts), O.OMlp(qdims, qacts), O.OMlp(qdims, qacts)
+    for t, s in ((oat, oa), (o1t, o1), (o2t, o2)):
+        O.chk(ol.orc_mlp_copy(t.h, s.h))
+    for o in (oa, o1, o2):
+        o.adam_init(lr)
+    ob = O.OBuffer(3, 1, L.ACTION_CONTINUOUS, cap); obt = O.OBuffer(3, 1, L.ACTION_CONTINUOUS, B)
+    oe = O.OEnv("pendulum", E, max_steps, 0.99, seed)
+    cfg = parity.rollout_cfg(True, False, "deterministic"); cfg.noise_sigma, cfg.a_min, cfg.a_max = 0.3, -1.0, 1.0
+    i = 0; i += B; cfg.i0 = i; oe.rollout(oa, cfg, ob, B // E)
+    y, info = np.empty(B, np.float32), np.zeros(L.INFO_N, np.float32); gamma = float(np.float32(crux.discount(mdp)))
+    sm = (np.float32(0.1), -0.5, 0.5, -np.inf, np.inf) if twin else (-1.0, 0.0, 0.0, 0.0, 0.0)
+    while i <= N - dN:
+        cfg.i0 = i; oe.rollout(oa, cfg, ob, dN // E)
+        for ep in range(dN):
+            ctr = i * dN + ep
+            O.chk(ol.orc_uniform_sample(obt.h, ob.h, B, None, ctr, crux.api.SAMPLE_SEED))
+            O.chk(ol.orc_dpg_target(oat.h, o1t.h, o2t.h if twin else None, obt.h, gamma, *sm, nseed, ctr, O.vpz(y)))
+            if twin:
+                O.chk(ol.orc_double_q_step(o1.h, o2.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+            else:
+                O.chk(ol.orc_q_step(o1.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+            O.chk(ol.orc_dpg_actor_step(oa.h, o1.h, obt.h, O.vpz(info)))
+            for t, s in ((oat, oa), (o1t, o1)) + (((o2t, o2),) if twin else ()):
+                O.chk(ol.orc_polyak(t.h, s.h, 0.005))
+        i += dN
+    assert solver.i == i and len(solver.buffer) == len(ob)
+    assert np.abs(solver.buffer["a"] - ob["a"]).max() < 1e-4 and np.abs(solver.buffer["s"] - ob["s"]).max() < 1e-4
+    for g, o in ((ga, oa), (g1, o1), (solver.agent.pi_minus.A, oat)) + (((g2, o2),) if twin else ()):
+        assert np.abs(g.get_params() - o.params).max() < 5e-5

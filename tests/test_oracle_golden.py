@@ -408,3 +408,29 @@ def test_a2c_reinforce_gradients_vs_float64_autograd(loss, head):
     assert abs(info[0] - total.item()) < 1e-5 * max(1, abs(total.item()))
     assert np.abs(o.grads - p.grad.numpy()).max() < 2e-6 * max(1, np.abs(p.grad.numpy()).max())
     assert abs(info[L.INFO["entropy"]] - ent.item()) < 1e-5 and abs(info[L.INFO["kl"]] - (torch.tensor(d["logprob"][0], dtype=torch.float64) - newlp).mean().item()) < 1e-5
+
+
+def test_dpg_oracle_gradients_match_finite_differences():
+    """ddpg_actor_loss (ddpg.jl:26) and td_loss over vcat(s, a) (utils.jl:76-87) of the oracle vs central differences of its own losses."""
+    rng = np.random.default_rng(18); od, ad, B = 3, 2, 24
+    oa = O.OMlp([od, 16, ad], ["relu", "tanh"]).init_glorot(4, 0); q = O.OMlp([od + ad, 16, 1], ["tanh", "identity"]).init_glorot(4, 1)
+    oa.params[:] += 0.1 * rng.standard_normal(oa.n).astype(np.float32)
+    ob = O.OBuffer(od, ad, L.ACTION_CONTINUOUS, B)
+    ob.push({"s": rng.normal(0, 1, (od, B)).astype(np.float32), "a": rng.uniform(-1, 1, (ad, B)).astype(np.float32), "sp": rng.normal(0, 1, (od, B)).astype(np.float32),
+             "r": rng.normal(0, 1, (1, B)).astype(np.float32), "done": rng.random((1, B)) < 0.2, "episode_end": np.zeros((1, B), bool)})
+    oa.adam_init(0.0); q.adam_init(0.0)
+    info, ol = np.zeros(L.INFO_N, np.float32), O.lib()
+    def actor_loss():
+        O.chk(ol.orc_dpg_actor_step(oa.h, q.h, ob.h, O.vpz(info))); return float(info[0])
+    actor_loss(); g = oa.grads.copy(); idx = list(rng.choice(oa.n, 10, replace=False))
+    assert np.allclose(g[idx], _fd(actor_loss, oa.params, idx), rtol=3e-2, atol=2e-3)
+    y = rng.normal(0, 1, B).astype(np.float32)
+    def critic_loss():
+        O.chk(ol.orc_q_step(q.h, ob.h, O.vpz(y), 0, O.vpz(info))); return float(info[0])
+    critic_loss(); gq = q.grads.copy(); idx = list(rng.choice(q.n, 10, replace=False))
+    assert np.allclose(gq[idx], _fd(critic_loss, q.params, idx), rtol=3e-2, atol=2e-3)
+    # ddpg_target on terminal rows is the reward; td3 smoothing respects the action clamp
+    yt = np.empty(B, np.float32); O.chk(ol.orc_dpg_target(oa.h, q.h, None, ob.h, 0.9, -1.0, 0.0, 0.0, 0.0, 0.0, 1, 2, O.vpz(yt)))
+    done = ob["done"][0]; assert np.array_equal(yt[done], ob["r"][0][done])
+    sa = np.vstack([ob["sp"], oa.forward(ob["sp"])]).astype(np.float32)
+    assert np.abs(yt - (ob["r"][0] + np.float32(0.9) * (1 - done) * q.forward(sa)[0])).max() < 1e-5
