@@ -724,6 +724,37 @@ def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=N
     return info
 
 
+def episodes_(sampler, Neps=1, explore=False, i=0, seed_offset=0x45564C):
+    """episodes!(sampler; Neps, explore, i) (src/sampler.jl:175-200) as a batched evaluation: Neps freshly reset copies of the sampler's
+    environment are rolled out in parallel (one wave each) for max_steps steps; the first episode of each copy is one evaluation episode.
+    Returns (data::ExperienceBuffer, metrics) with per-episode undiscounted / discounted returns, lengths and completion flags."""
+    mdp = sampler.mdp
+    em = GymMDP(mdp.kind, n_envs=int(Neps), seed=mdp.seed + int(seed_offset), discount=mdp.discount)
+    es = Sampler(em, sampler.agent, S=sampler.S, max_steps=sampler.max_steps, required_columns=(), ctx=sampler.ctx)
+    T = sampler.max_steps
+    data = ExperienceBuffer(sampler.S, sampler.agent.space, int(Neps) * T, ctx=sampler.ctx)
+    steps_(es, data, Nsteps=int(Neps) * T, explore=explore, i=i, reset=True)
+    und, dis = np.empty(Neps, np.float32), np.empty(Neps, np.float32)
+    ln, ok = np.empty(Neps, np.int64), np.empty(Neps, np.uint8)
+    sampler.ctx.check(sampler.ctx.lib.crux_first_episode_metrics(data.h, int(Neps), T, float(np.float32(discount(mdp))), _vp(und), _vp(dis), _vp(ln), _vp(ok)))
+    return data, {"undiscounted": und, "discounted": dis, "length": ln, "complete": ok.astype(bool)}
+
+
+def undiscounted_return(sampler, Neps=100, **kw):
+    """undiscounted_return(s::Sampler; Neps) (src/sampler.jl:219-220): sum of rewards per evaluation episode, averaged."""
+    return float(episodes_(sampler, Neps=Neps, **kw)[1]["undiscounted"].astype(np.float64).sum() / Neps)
+
+
+def discounted_return(sampler, Neps=100, **kw):
+    """discounted_return(s::Sampler; Neps) (src/sampler.jl:231-234)."""
+    return float(np.mean(episodes_(sampler, Neps=Neps, **kw)[1]["discounted"]))
+
+
+def failure(sampler, threshold=0.0, Neps=100, **kw):
+    """failure(s::Sampler; threshold, Neps) (src/sampler.jl:237-242): fraction of evaluation episodes whose undiscounted return is below threshold."""
+    return float(np.mean(episodes_(sampler, Neps=Neps, **kw)[1]["undiscounted"] < threshold))
+
+
 def fill_gae_(buffer, V, lam, gamma):
     """fill_gae!(d::ExperienceBuffer, V, lambda, gamma) (src/sampler.jl:255-273)."""
     buffer.ctx.check(buffer.ctx.lib.crux_fill_gae(buffer.h, critic(V).h, float(lam), float(gamma)))

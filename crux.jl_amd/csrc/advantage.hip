@@ -57,7 +57,40 @@ static int32_t values(crux_mlp* critic, const float* d_x, int64_t n, float* d_y)
   return rc;
 }
 
+// episodes!-style evaluation (sampler.jl:175-251) over an env-major rollout block: the FIRST episode of every environment.
+// undiscounted_return = sum(r) (:203-213), discounted_return = reverse recursion r + gamma*R in Float32 (:223-229), length.
+__global__ void k_first_episode_metrics(const float* __restrict__ r, const uint8_t* __restrict__ ee, int n_envs, int64_t T, float gamma,
+                                        float* __restrict__ und, float* __restrict__ dis, int64_t* __restrict__ len, uint8_t* __restrict__ complete) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x; if (e >= n_envs) return;
+  const int64_t base = (int64_t)e * T; int64_t stop = -1;
+  for (int64_t t = 0; t < T; ++t) if (ee[base + t]) { stop = t; break; }
+  complete[e] = stop >= 0 ? 1 : 0;
+  if (stop < 0) stop = T - 1;
+  float u = 0.f, d = 0.f;
+  for (int64_t t = 0; t <= stop; ++t) u = __fadd_rn(u, r[base + t]);
+  for (int64_t t = stop; t >= 0; --t) d = __fadd_rn(r[base + t], __fmul_rn(gamma, d));
+  und[e] = u; dis[e] = d; len[e] = stop + 1;
+}
+
 extern "C" {
+
+int32_t crux_first_episode_metrics(crux_buffer* b, int32_t n_envs, int64_t T, float gamma, float* undisc, float* disc, int64_t* length, uint8_t* complete) {
+  if (!b || n_envs < 1 || T < 1) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx;
+  if ((int64_t)n_envs * T != b->elements || b->next_ind != (b->elements % b->capacity)) return crux_fail(c, CRUX_EINVAL, "episode metrics: buffer must hold exactly one %d x %lld env-major rollout block", n_envs, (long long)T);
+  const size_t nb = (size_t)n_envs;
+  char* sc = (char*)crux_scratch(c, nb * 17 + 1024); if (!sc) return crux_fail(c, CRUX_ENOMEM, "episode metrics: scratch");
+  int64_t* d_len = (int64_t*)sc; float* d_u = (float*)(sc + 8 * nb); float* d_d = d_u + nb; uint8_t* d_c = (uint8_t*)(d_d + nb);
+  hipLaunchKernelGGL(k_first_episode_metrics, dim3((unsigned)((n_envs + 63) / 64)), dim3(64), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_EPISODE_END],
+                     n_envs, T, gamma, d_u, d_d, d_len, d_c);
+  int32_t rc = crux_launch_check(c, "k_first_episode_metrics"); if (rc) return rc;
+  if (undisc) HIPCHK(c, hipMemcpyAsync(undisc, d_u, 4 * nb, hipMemcpyDeviceToHost, c->stream));
+  if (disc) HIPCHK(c, hipMemcpyAsync(disc, d_d, 4 * nb, hipMemcpyDeviceToHost, c->stream));
+  if (length) HIPCHK(c, hipMemcpyAsync(length, d_len, 8 * nb, hipMemcpyDeviceToHost, c->stream));
+  if (complete) HIPCHK(c, hipMemcpyAsync(complete, d_c, nb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CRUX_OK;
+}
 
 int32_t crux_fill_gae(crux_buffer* b, crux_mlp* critic, float lambda, float gamma) {
   if (!b || !critic) return CRUX_EINVAL;

@@ -217,6 +217,13 @@ int32_t crux_fill_returns(crux_buffer* b, float gamma);
 /* b[key] .= whiten(b[key]) (utils.jl:41-42; PPO post_batch_callback ppo.jl:61). Bessel-corrected. */
 int32_t crux_whiten(crux_buffer* b, int32_t key);
 
+/* evaluation (episodes! / undiscounted_return / discounted_return / failure, src/sampler.jl:175-251): after a rollout of
+ * n_envs freshly reset environments for T = max_steps steps into an otherwise empty buffer, the FIRST episode of every
+ * environment: sum of rewards, discounted return (reverse Float32 recursion, :223-229), length, and whether it ended within T.
+ * Host output arrays [n_envs] (NULL = skip).                                                                          */
+int32_t crux_first_episode_metrics(crux_buffer* buf, int32_t n_envs, int64_t T, float gamma, float* undiscounted,
+                                   float* discounted, int64_t* length, uint8_t* complete);
+
 /* learner (src/training.jl:1-55, src/model_free/rl/ppo.jl:4-21,59-60) ------------------------------ */
 enum { CRUX_LOSS_PPO = 0      /* ppo_loss with the head's logpdf/entropy (ppo.jl:4-21)            */,
        CRUX_LOSS_VALUE_MSE = 1 /* Flux.mse(value(pi, s), return) (ppo.jl:60)                      */,

@@ -684,6 +684,19 @@ int32_t orc_fill_gae(orc_buffer* b, orc_mlp* critic, float lambda, float gamma) 
   for (int64_t i = 0; i < n; ++i) if (isnan(adv[i])) rc = CRUX_ENAN;                              /* @assert !isnan(A) :270 */
   free(Vs); free(Vsp); free(st); free(en); return rc;
 }
+/* episodes! metrics (sampler.jl:175-251) for the first episode of each env of an env-major n_envs x T block */
+int32_t orc_first_episode_metrics(orc_buffer* b, int32_t n_envs, int64_t T, float gamma, float* und, float* dis, int64_t* len, uint8_t* complete) {
+  if ((int64_t)n_envs * T != b->elements) return CRUX_EINVAL;
+  const float* r = (const float*)b->col[CRUX_COL_R]; const uint8_t* ee = (const uint8_t*)b->col[CRUX_COL_EPISODE_END];
+  for (int e = 0; e < n_envs; ++e) { int64_t base = (int64_t)e * T, stop = -1;
+    for (int64_t t = 0; t < T; ++t) if (ee[base + t]) { stop = t; break; }
+    if (complete) complete[e] = stop >= 0; if (stop < 0) stop = T - 1;
+    float u = 0.f, d = 0.f;
+    for (int64_t t = 0; t <= stop; ++t) u = u + r[base + t];                       /* sum(data[:r][1,start:stop]) :203 */
+    for (int64_t t = stop; t >= 0; --t) d = r[base + t] + gamma * d;                /* discounted_return :223-229 */
+    if (und) und[e] = u; if (dis) dis[e] = d; if (len) len[e] = stop + 1; }
+  return CRUX_OK;
+}
 int32_t orc_fill_returns(orc_buffer* b, float gamma) {
   if (!(b->mask & (1u << CRUX_COL_RETURN))) return CRUX_EINVAL;
   int64_t n = b->elements; if (n == 0) return CRUX_OK;

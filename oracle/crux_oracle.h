@@ -103,6 +103,7 @@ int32_t orc_train_step(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg,
 int32_t orc_loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids, int64_t n, float* info_out);
 
 /* off-policy */
+int32_t orc_first_episode_metrics(orc_buffer* b, int32_t n_envs, int64_t T, float gamma, float* und, float* dis, int64_t* len, uint8_t* complete);   /* sampler.jl:175-251 */
 int32_t orc_dqn_target(orc_mlp* target_net, orc_buffer* batch, float gamma, float* y);
 int32_t orc_softq_target(orc_mlp* target_net, orc_buffer* batch, float gamma, float alpha, float* y);   /* rl/softq.jl:1-13 */
 int32_t orc_td_error(orc_mlp* net, orc_buffer* batch, const float* y, float* err);

@@ -35,7 +35,7 @@ _SIG = {
     "orc_fill_gae": (i32, [vp, vp, f32, f32]), "orc_fill_returns": (i32, [vp, f32]), "orc_whiten": (i32, [vp, i32]),
     "orc_gae_range": (None, [vp, vp, vp, vp, i64, i64, f32, f32, vp]), "orc_returns_range": (None, [vp, i64, i64, f32, vp]),
     "orc_batch_train": (i32, [vp, vp, P(L.TrainCfg), vp, vp, vp]), "orc_train_step": (i32, [vp, vp, P(L.TrainCfg), vp, i64, vp]),
-    "orc_loss_grad": (i32, [vp, vp, P(L.TrainCfg), vp, i64, vp]), "orc_dqn_target": (i32, [vp, vp, f32, vp]), "orc_softq_target": (i32, [vp, vp, f32, f32, vp]), "orc_td_error": (i32, [vp, vp, vp, vp]),
+    "orc_loss_grad": (i32, [vp, vp, P(L.TrainCfg), vp, i64, vp]), "orc_first_episode_metrics": (i32, [vp, i32, i64, f32, vp, vp, vp, vp]), "orc_dqn_target": (i32, [vp, vp, f32, vp]), "orc_softq_target": (i32, [vp, vp, f32, f32, vp]), "orc_td_error": (i32, [vp, vp, vp, vp]),
     "orc_td_step": (i32, [vp, vp, vp, i32, vp]),
     "orc_sac_target": (i32, [vp, vp, vp, vp, vp, f32, u64, u64, vp]), "orc_sac_temp_step": (i32, [vp, vp, vp, f32, u64, u64, vp]),
     "orc_double_q_step": (i32, [vp, vp, vp, vp, i32, vp]), "orc_sac_actor_step": (i32, [vp, vp, vp, vp, vp, u64, u64, vp]),

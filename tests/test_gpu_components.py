@@ -574,3 +574,27 @@ def test_softq_target_and_solve_match_oracle(gpu_ctx):
     yg = g.ctx.d2h(dy, np.empty(B, np.float32)); O.chk(O.lib().orc_softq_target(ot.h, obt.h, 0.95, alpha, O.vpz(y)))
     assert np.abs(yg - y).max() < 1e-5
     g.ctx.free(dy)
+
+
+@pytest.mark.parametrize("kind,dims,acts,head", [("cartpole", [4, 64, 64, 2], ["relu", "relu", "identity"], "discrete"), ("pendulum", [3, 32, 1], ["relu", "tanh"], "continuous")])
+def test_batched_evaluation_matches_oracle(gpu_ctx, kind, dims, acts, head):
+    """episodes! / undiscounted_return / discounted_return / failure (src/sampler.jl:175-251) as a batched greedy evaluation vs the oracle."""
+    Neps, max_steps, seed = 24, 60, 12
+    g, o = parity.make_pair(dims, acts, 19, 0, head)
+    mdp = crux.GymMDP(kind, n_envs=2, seed=seed, discount=0.97)
+    s = crux.Sampler(mdp, g, max_steps=max_steps)
+    data, m = crux.episodes_(s, Neps=Neps)
+    # oracle: the same Neps fresh environments, greedy policy, one max_steps rollout each, first episode metrics
+    oe = O.OEnv(kind, Neps, max_steps, 0.97, seed + 0x45564C)
+    ob = O.OBuffer(dims[0], 2 if kind == "cartpole" else 1, L.ACTION_DISCRETE if kind == "cartpole" else L.ACTION_CONTINUOUS, Neps * max_steps)
+    cfg = parity.rollout_cfg(False, True, "categorical" if kind == "cartpole" else "deterministic")
+    oe.rollout(o, cfg, ob, max_steps)
+    und, dis, ln, ok = np.empty(Neps, np.float32), np.empty(Neps, np.float32), np.empty(Neps, np.int64), np.empty(Neps, np.uint8)
+    O.chk(O.lib().orc_first_episode_metrics(ob.h, Neps, max_steps, np.float32(0.97), O.vpz(und), O.vpz(dis), O.vpz(ln), O.vpz(ok)))
+    assert np.array_equal(m["length"], ln) and np.array_equal(m["complete"], ok.astype(bool)) and ok.all()
+    assert np.abs(m["undiscounted"] - und).max() < 1e-4 * max(1, np.abs(und).max()) and np.abs(m["discounted"] - dis).max() < 1e-4 * max(1, np.abs(dis).max())
+    if kind == "cartpole":
+        assert np.array_equal(m["undiscounted"], ln.astype(np.float32))                   # r == 1 per step
+        assert abs(crux.undiscounted_return(s, Neps=Neps) - ln.mean()) < 1e-6
+        assert crux.failure(s, threshold=1e9, Neps=Neps) == 1.0 and crux.failure(s, threshold=0.0, Neps=Neps) == 0.0
+    assert abs(crux.discounted_return(s, Neps=Neps) - float(np.mean(dis))) < 1e-4 * max(1, abs(float(np.mean(dis))))
