@@ -13,6 +13,8 @@ N>1: launched by torch.distributed.run, one rank per GPU; every rank owns an ind
 scaling) and the replicas exchange parameters + Adam moments with an all-reduce (RCCL over xGMI) after every epoch.
 Rank 0 prints ONE JSON line.
 """
+import os as _os
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: keep the two learner streams on separate hardware queues next to torch/RCCL streams
 import argparse
 import ctypes as C
 import json
@@ -60,17 +62,26 @@ def ppo_iteration(crux, pi, buf, sampler, a_opt, c_opt, P, it, sync=None):
         sv = _S(); sv.agent = crux.PolicyParams(pi); sv.a_opt, sv.c_opt, sv.P = a_opt, c_opt, P
         ti = crux.policy_gradient_training(sv, buf)            # on_policy.jl:56-78 (actor then critic; overlapped when exact)
         return ti["actor_batches_trained"] + ti["critic_batches_trained"], info
-    # multi-GPU: one persistent launch per epoch, parameters + Adam moments averaged between epochs
-    nb = 0
-    for net, opt, key in ((pi.A, a_opt, "actor_"), (pi.C, c_opt, "critic_")):
-        e_total = opt.epochs
-        opt.epochs = 1
-        for _ in range(e_total):
-            r = crux.batch_train_(net, opt, P, buf)
-            nb += r[key + "batches_trained"]
-            sync(net)
-        opt.epochs = e_total
+    # multi-GPU: one persistent launch per learner per `sync_every` epochs (actor || critic concurrently, as above), then the replicas'
+    # parameters and Adam moments are averaged with ONE all-reduce ("periodic" exchange of north_star; every epoch by default)
+    class _S:
+        pass
+    sv = _S(); sv.agent = crux.PolicyParams(pi); sv.a_opt, sv.c_opt, sv.P = a_opt, c_opt, P
+    nb, e_total, k = 0, a_opt.epochs, SYNC_EVERY
+    try:
+        done = 0
+        while done < e_total:
+            a_opt.epochs = c_opt.epochs = min(k, e_total - done)
+            ti = crux.policy_gradient_training(sv, buf)
+            nb += ti["actor_batches_trained"] + ti["critic_batches_trained"]
+            done += a_opt.epochs
+            sync((pi.A, pi.C))
+    finally:
+        a_opt.epochs = c_opt.epochs = e_total
     return nb, info
+
+
+SYNC_EVERY = int(os.environ.get("CRUX_SYNC_EVERY", "1"))   # epochs between parameter exchanges in the multi-GPU path
 
 
 def cpu_baseline():
@@ -143,21 +154,26 @@ def main():
     if world > 1 or args.force_sync:
         wrapped = {}
 
-        def sync(net):   # average parameters and Adam moments across ranks (RCCL all-reduce over xGMI)
-            if id(net) not in wrapped:
-                lib, n = ctx.lib, net.n_params
+        def sync(nets):   # average parameters and Adam moments of all networks across ranks: one RCCL all-reduce over xGMI
+            key = tuple(id(n) for n in nets)
+            if key not in wrapped:
+                lib, ts = ctx.lib, []
 
-                def wrap(ptr):
+                def wrap(ptr, n):
                     class _I:
                         __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
                     return torch.as_tensor(_I(), device="cuda:%d" % local)
-                pm, pv = C.c_void_p(), C.c_void_p()
-                ctx.check(lib.crux_adam_state_ptrs(net.h, C.byref(pm), C.byref(pv)))
-                wrapped[id(net)] = [wrap(lib.crux_mlp_params_ptr(net.h)), wrap(pm.value), wrap(pv.value)]
-            ctx.sync()                                   # the library's stream produced the values
-            for t in wrapped[id(net)]:                   # tensors alias library memory: RCCL reads/writes it in place
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                t.mul_(1.0 / world)
+                for net in nets:
+                    pm, pv = C.c_void_p(), C.c_void_p()
+                    ctx.check(lib.crux_adam_state_ptrs(net.h, C.byref(pm), C.byref(pv)))
+                    ts += [wrap(lib.crux_mlp_params_ptr(net.h), net.n_params), wrap(pm.value, net.n_params), wrap(pv.value, net.n_params)]
+                wrapped[key] = (ts, [t.numel() for t in ts])
+            ts, sizes = wrapped[key]
+            ctx.sync()                                   # the library's streams produced the values
+            flat = torch.cat(ts)                         # 6 x ~18 KB -> one 110 KB message (latency-bound either way on xGMI)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.mul_(1.0 / world)
+            torch._foreach_copy_(ts, list(flat.split(sizes)))   # tensors alias library memory
             torch.cuda.current_stream().synchronize()
 
     def barrier():

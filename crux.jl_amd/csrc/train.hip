@@ -383,7 +383,11 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   }
   if (buf->elements <= 0 || cfg_a->epochs < 1 || cfg_c->epochs < 1) return crux_fail(c, CRUX_EINVAL, "policy_gradient_training: empty buffer or epochs < 1");
   if (!c->aux_stream) {
-    HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    // The second learner stream gets its own priority level: ROCm multiplexes streams of one priority over a small pool of hardware
+    // queues (GPU_MAX_HW_QUEUES, default 4), and two streams that land on the same queue serialise their kernels -- measured: inside a
+    // process where torch had already created its streams the actor and critic kernels ran back to back (782 vs 431 ms per iteration).
+    int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+    if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi_p) != hipSuccess) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev1, hipEventDisableTiming));
   }
   TrainArgs a, k; int32_t rc = fill_args(a, actor, buf, cfg_a, cfg_a->loss); if (rc) return rc;
