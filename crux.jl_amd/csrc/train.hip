@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
   for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
 
   const int n_epochs = a.ids ? 1 : a.epochs;
-  if (!a.ids) { for (int64_t j = tid; j < a.len; j += 256) order_cur[j] = (int32_t)j; __syncthreads(); }
-  if (!a.ids && a.pre_epochs > 0) {
+  if (!a.ids && !a.ord_all) { for (int64_t j = tid; j < a.len; j += 256) order_cur[j] = (int32_t)j; __syncthreads(); }
+  if (!a.ids && !a.ord_all && a.pre_epochs > 0) {
     __syncthreads();
     for (int pe = 0; pe < a.pre_epochs; ++pe) {
       if (a.pre_perms) { for (int64_t j = tid; j < a.len; j += 256) order_nxt[j] = order_cur[a.pre_perms[(int64_t)pe * a.len + j]]; }
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
   }
 
   for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
-    if (!a.ids) {
+    if (!a.ids && a.ord_all) order_cur = const_cast<int32_t*>(a.ord_all) + (size_t)ep * (size_t)a.len;   // shuffle orders composed ahead of time by k_compose_order
+    else if (!a.ids) {
       // shuffle!(D): new[:,j] = old[:,perm[j]]  (experience_buffer.jl:118-124) as an index composition
       if (a.perms) { for (int64_t j = tid; j < a.len; j += 256) order_nxt[j] = order_cur[a.perms[(int64_t)ep * a.len + j]]; }
       else { const crux_perm pp = crux_perm_make(a.shuffle_seed, a.shuffle_counter + (uint64_t)ep, 0, (uint32_t)a.len);
@@ -247,6 +248,32 @@ static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const cr
   return CRUX_OK;
 }
 
+// shuffle!(D) of every epoch as index compositions, ahead of the learner launch and over the whole chip instead of inside the
+// single learner workgroup: out[j] = prev[perm_e(j)] (experience_buffer.jl:118-124 applied to the row order instead of the rows).
+__global__ void k_compose_order(const int32_t* __restrict__ prev, int32_t* __restrict__ out, crux_perm pp, const int64_t* __restrict__ perm_explicit, int64_t len) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (j >= len) return;
+  const int64_t src = perm_explicit ? perm_explicit[j] : (int64_t)crux_perm_at(&pp, (uint32_t)j);
+  out[j] = prev ? prev[src] : (int32_t)src;
+}
+// builds buf->ord_all[slot] = [n_epochs x len]; start = order the first epoch composes onto (NULL = identity = the physical row order)
+static int32_t build_orders(crux_ctx* c, crux_buffer* buf, int slot, const int32_t* start, uint64_t seed, uint64_t counter, const int64_t* d_perms, int n_epochs, hipStream_t st, int32_t** out) {
+  const int64_t len = buf->elements; const size_t need = (size_t)n_epochs * (size_t)len;
+  if (buf->ord_all_cap[slot] < need) {
+    if (buf->ord_all[slot]) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(buf->ord_all[slot]); buf->ord_all[slot] = nullptr; buf->ord_all_cap[slot] = 0; }
+    if (hipMalloc(&buf->ord_all[slot], 4 * need) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "batch_train!: %zu bytes for the epoch orders", 4 * need);
+    buf->ord_all_cap[slot] = need;
+  }
+  const int32_t* prev = start;
+  for (int e = 0; e < n_epochs; ++e) {
+    int32_t* o = buf->ord_all[slot] + (size_t)e * (size_t)len;
+    crux_perm pp = crux_perm_make(seed, counter + (uint64_t)e, 0, (uint32_t)len);
+    hipLaunchKernelGGL(k_compose_order, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, prev, o, pp, d_perms ? d_perms + (size_t)e * (size_t)len : (const int64_t*)nullptr, len);
+    prev = o;
+  }
+  *out = buf->ord_all[slot];
+  return crux_launch_check(c, "k_compose_order");
+}
+
 static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_t stream = nullptr) {
   bool handled = false;
   if (!stream) stream = c->stream;
@@ -274,13 +301,19 @@ static int32_t run_batch(crux_mlp* net, crux_buffer* buf, TrainArgs& a, int n_ep
   a.status = (int32_t*)sc; a.epoch_infos = (float*)(sc + 256);
   HIPCHK(c, hipMemsetAsync(sc, 0, eb + 256, c->stream));
   const int slot = CRUX_IS_PG(a.loss) ? CRUX_PROF_TRAIN_ACTOR : (a.loss == CRUX_LOSS_VALUE_MSE ? CRUX_PROF_TRAIN_CRITIC : CRUX_PROF_TD_STEP);
-  int32_t rc = launch_train(c, a, slot); if (rc) return rc;
+  int32_t rc;
+  if (!a.ids && a.len < ((int64_t)1 << 31) && !getenv("CRUX_ORDERS_IN_KERNEL")) {
+    int32_t* oa = nullptr; rc = build_orders(c, buf, 0, nullptr, a.shuffle_seed, a.shuffle_counter, a.perms, n_epochs, c->stream, &oa); if (rc) return rc;
+    a.ord_all = oa;
+  }
+  rc = launch_train(c, a, slot); if (rc) return rc;
   int32_t st[4]; std::vector<float> ei((size_t)CRUX_INFO_N * (size_t)(n_epochs > 0 ? n_epochs : 1));
   HIPCHK(c, hipMemcpyAsync(st, a.status, sizeof st, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(ei.data(), a.epoch_infos, eb, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (permute_after && st[2] > 0) {   // materialise the composed epoch shuffles so the buffer order matches the reference's
-    rc = crux_buffer_apply_order(buf, st[3] ? buf->order_b : buf->order_a, buf->elements); if (rc) return rc;
+    const int32_t* fin = a.ord_all ? a.ord_all + (size_t)(st[2] - 1) * (size_t)a.len : (st[3] ? buf->order_b : buf->order_a);
+    rc = crux_buffer_apply_order(buf, fin, buf->elements); if (rc) return rc;
   }
   if (info_out) {
     for (int q = 0; q < CRUX_INFO_N; ++q) { double s = 0; for (int e = 0; e < st[2]; ++e) s += (double)ei[(size_t)e * CRUX_INFO_N + q]; info_out[q] = st[2] ? (float)(s / (double)st[2]) : 0.f; }
@@ -408,6 +441,12 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   a.perms = d_pa; k.perms = d_pc;
   k.order_a = buf->order_c; k.order_b = buf->order_d;
   k.pre_epochs = cfg_a->epochs; k.pre_seed = cfg_a->shuffle_seed; k.pre_counter = cfg_a->shuffle_counter; k.pre_perms = d_pa;
+  if (len < ((int64_t)1 << 31) && !getenv("CRUX_ORDERS_IN_KERNEL")) {   // all epoch orders ahead of time; the critic's chain starts from the actor's last order
+    int32_t* oa = nullptr; int32_t* oc = nullptr;
+    rc = build_orders(c, buf, 0, nullptr, cfg_a->shuffle_seed, cfg_a->shuffle_counter, d_pa, cfg_a->epochs, c->stream, &oa); if (rc) return rc;
+    rc = build_orders(c, buf, 1, oa + (size_t)(cfg_a->epochs - 1) * (size_t)len, cfg_c->shuffle_seed, cfg_c->shuffle_counter, d_pc, cfg_c->epochs, c->stream, &oc); if (rc) return rc;
+    a.ord_all = oa; k.ord_all = oc;
+  }
   HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
   rc = launch_train(c, k, CRUX_PROF_TRAIN_CRITIC, c->aux_stream); if (rc) return rc;
@@ -420,7 +459,8 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   if (sta[0] == CRUX_ENAN || stc[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
   if (sta[0] || stc[0]) return crux_fail(c, sta[0] ? sta[0] : stc[0], "learner kernel reported status %d/%d", sta[0], stc[0]);
   // the critic's final order already contains the actor's shuffles: one physical permutation leaves the buffer as the reference would
-  return crux_buffer_apply_order(buf, stc[3] ? buf->order_d : buf->order_c, len);
+  if (stc[2] < 1) return CRUX_OK;
+  return crux_buffer_apply_order(buf, k.ord_all ? k.ord_all + (size_t)(stc[2] - 1) * (size_t)len : (stc[3] ? buf->order_d : buf->order_c), len);
 }
 
 // ---- off-policy pieces ------------------------------------------------------------------------------

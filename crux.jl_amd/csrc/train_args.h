@@ -18,6 +18,7 @@ struct TrainArgs {
   int64_t len;
   int32_t* order_a; int32_t* order_b;
   const int64_t* perms;      // device [epochs x len] or NULL
+  const int32_t* ord_all;    // device [epochs x len]: the composed shuffle order of every epoch, built before the launch (k_compose_order); NULL = compose in the kernel
   // shuffles that a PRECEDING batch_train! applied to the same buffer (actor before critic, on_policy.jl:65-69): composed into
   // the starting order so this learner can run concurrently with the preceding one and still see the reference's row order
   int32_t pre_epochs; uint64_t pre_seed, pre_counter; const int64_t* pre_perms;

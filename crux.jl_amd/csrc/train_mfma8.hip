@@ -128,8 +128,8 @@ __global__ __launch_bounds__(512) void k_train_mfma8(TrainArgs a) {
   long long total_batches = 0; int epochs_run = 0, err = 0; bool stop = false;
   float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
   const int n_epochs = a.ids ? 1 : a.epochs;
-  if (!a.ids) { for (int64_t j = tid; j < a.len; j += NT) order_cur[j] = (int32_t)j; }
-  if (!a.ids && a.pre_epochs > 0) {
+  if (!a.ids && !a.ord_all) { for (int64_t j = tid; j < a.len; j += NT) order_cur[j] = (int32_t)j; }
+  if (!a.ids && !a.ord_all && a.pre_epochs > 0) {
     __syncthreads();
     for (int pe = 0; pe < a.pre_epochs; ++pe) {
       if (a.pre_perms) { for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[a.pre_perms[(int64_t)pe * a.len + j]]; }
@@ -191,7 +191,8 @@ __global__ __launch_bounds__(512) void k_train_mfma8(TrainArgs a) {
   };
 
   for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
-    if (!a.ids) {   // shuffle!(D) as an index composition (experience_buffer.jl:118-124)
+    if (!a.ids && a.ord_all) order_cur = const_cast<int32_t*>(a.ord_all) + (size_t)ep * (size_t)a.len;   // shuffle orders composed ahead of time by k_compose_order
+    else if (!a.ids) {   // shuffle!(D) as an index composition (experience_buffer.jl:118-124)
       if (a.perms) { for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[a.perms[(int64_t)ep * a.len + j]]; }
       else { const crux_perm pp = crux_perm_make(a.shuffle_seed, a.shuffle_counter + (uint64_t)ep, 0, (uint32_t)a.len);
         for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[crux_perm_at(&pp, (uint32_t)j)]; }
