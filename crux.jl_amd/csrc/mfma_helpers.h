@@ -47,7 +47,10 @@ __device__ __forceinline__ float g4_sum(float v) {
 // relu as ONE instruction: fmaxf() makes hipcc canonicalise the MFMA result first (v_max x,x,x), doubling the count. On the bit
 // pattern relu is a signed-integer max with 0 (negative floats and -0 are negative ints); a NaN keeps its bits and propagates.
 __device__ __forceinline__ float relu1(float z) { const int b = __builtin_bit_cast(int, z); return __builtin_bit_cast(float, b > 0 ? b : 0); }
-template <int ACT> __device__ __forceinline__ float actf(float z) { return ACT == CRUX_ACT_RELU ? relu1(z) : (ACT == CRUX_ACT_TANH ? tanhf(z) : z); }
+// tanh through the hardware exp/rcp units: 1 - 2/(exp(2z) + 1), absolute error <= 2e-7 (saturates correctly at +-1); libm tanhf costs ~40 instructions
+// per element and the 17-64-64-6 tanh family evaluates 128 of them per sample and step.
+__device__ __forceinline__ float tanh_fast(float z) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * z) + 1.f); }
+template <int ACT> __device__ __forceinline__ float actf(float z) { return ACT == CRUX_ACT_RELU ? relu1(z) : (ACT == CRUX_ACT_TANH ? tanh_fast(z) : z); }
 template <int ACT> __device__ __forceinline__ float actg(float y, float d) { return ACT == CRUX_ACT_RELU ? (y > 0.f ? d : 0.f) : (ACT == CRUX_ACT_TANH ? d * (1.f - y * y) : d); }
 
 // Adam on one element with f32 arithmetic; c1 = 1/(1-b1^t), c2 = 1/(1-b2^t) come from Float64 (Flux keeps Float64 scalars;

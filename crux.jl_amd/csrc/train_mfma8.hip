@@ -291,13 +291,13 @@ __global__ __launch_bounds__(512) void k_train_mfma8(TrainArgs a) {
         } else {   // gaussian with constant log-std (policies.jl:333-348)
           float newlp = 0.f; float dd[OUT], s2[OUT];
 #pragma unroll
-          for (int k = 0; k < OUT; ++k) { const float ls = sm[Lt::oEX + k]; const float sg = expf(ls); s2[k] = sg * sg; dd[k] = q[4 + k] - z[k];
-            newlp += (-(dd[k] * dd[k]) / (2.f * s2[k]) - 0.9189385332046727f - ls); }
-          const float r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
+          for (int k = 0; k < OUT; ++k) { const float ls = sm[Lt::oEX + k]; s2[k] = __expf(-2.f * ls); dd[k] = q[4 + k] - z[k];   // s2 = 1/sigma^2 through v_exp_f32 (1 ulp)
+            newlp += (-(dd[k] * dd[k]) * (0.5f * s2[k]) - 0.9189385332046727f - ls); }
+          const float r = __expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
           const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;   // a2c_loss (a2c.jl:4-15): -mean(logpdf .* A)
 #pragma unroll
-          for (int k = 0; k < OUT; ++k) { dz[k] = valid ? invB * (-a.lambda_p * coef * (dd[k] / s2[k])) : 0.f;
-            dex[k] = valid ? invB * (-a.lambda_p * coef * ((dd[k] * dd[k]) / s2[k] - 1.f)) : 0.f; }
+          for (int k = 0; k < OUT; ++k) { dz[k] = valid ? invB * (-a.lambda_p * coef * (dd[k] * s2[k])) : 0.f;
+            dex[k] = valid ? invB * (-a.lambda_p * coef * ((dd[k] * dd[k]) * s2[k] - 1.f)) : 0.f; }
           s_lossp = cnt * lterm; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R; s_clip = cnt * clipv;
         }
       }

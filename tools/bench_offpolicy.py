@@ -71,6 +71,28 @@ def main():
     t_sac = timed(ctx, sac_epoch, a.steps)
     out["C4"] = {"workload": "SAC actor 3-256-256-1 + twin Q 4-256-256-1, B=256", "epoch_ms": 1e3 * t_sac, "epochs_per_s": 1.0 / t_sac,
                  "algorithmic_GFLOP_per_epoch": 0.58, "achieved_TFLOPs": 0.58e9 / t_sac / 1e12}
+    # ---- C5 learner only: PPO 17-64-64-6 Gaussian actor + 17-64-64-1 critic on 262144 synthetic rows (128 envs x 2048), batch 128, 4 epochs
+    n = 128 * 2048
+    S, A = crux.ContinuousSpace(17), crux.ContinuousSpace(6)
+    buf = crux.ExperienceBuffer(S, A, n, ["return", "logprob", "advantage"])
+    chunk = 65536
+    for _ in range(n // chunk):
+        buf.push_({"s": rng.normal(0, 1, (17, chunk)).astype(np.float32), "a": rng.uniform(-1, 1, (6, chunk)).astype(np.float32), "sp": rng.normal(0, 1, (17, chunk)).astype(np.float32),
+                   "r": rng.normal(0, 1, (1, chunk)).astype(np.float32), "done": np.zeros((1, chunk), bool), "episode_end": np.zeros((1, chunk), bool),
+                   "return": rng.normal(0, 1, (1, chunk)).astype(np.float32), "logprob": rng.normal(-6, 0.3, (1, chunk)).astype(np.float32), "advantage": rng.normal(0, 1, (1, chunk)).astype(np.float32)})
+    acts5 = ["tanh", "tanh", "identity"]
+    pi5 = crux.ActorCritic(crux.GaussianPolicy(chain([17, 64, 64, 6], acts5), np.full(6, -0.5, np.float32), seed=5), crux.ContinuousNetwork(chain([17, 64, 64, 1], acts5), seed=6))
+    class _S:
+        pass
+    sv = _S(); sv.agent = crux.PolicyParams(pi5); sv.P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.0}
+    sv.a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=128, epochs=4, name="actor_", shuffle_seed=1)
+    sv.c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=128, epochs=4, name="critic_", shuffle_seed=2)
+    def c5_train():
+        crux.policy_gradient_training(sv, buf)
+    t5 = timed(ctx, c5_train, 3, warmup=1)
+    steps5 = 2 * 4 * (n // 128)
+    out["C5_learner"] = {"workload": "PPO 17-64-64-6 tanh Gaussian actor || 17-64-64-1 critic, 262144 rows, B=128, 4+4 epochs (synthetic rows)", "ms_per_call": 1e3 * t5,
+                         "grad_steps_per_s": steps5 / t5, "us_per_actor_step": 1e6 * t5 / (steps5 / 2)}
     print(json.dumps(out))
 
 
