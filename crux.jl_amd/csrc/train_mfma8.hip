@@ -406,20 +406,26 @@ __global__ __launch_bounds__(512) void k_train_mfma8(TrainArgs a) {
         for (int q = 1; q < MF8_NW; ++q) t += sm[Lt::oPART + q * Lt::PART + Lt::pST + k];
         sm[Lt::oRED + 8 + k] = t; }
       const int any_bad = __syncthreads_or(bad);   // ---- B_or (also publishes RED)
-      // minibatch info (training.jl:22-23, ppo.jl:13-19); identical in every thread
-      { const float fn = (float)nb;
-        float ss = sm[Lt::oRED];
+      // minibatch info (training.jl:22-23, ppo.jl:13-19); identical in every thread. Only the epoch's last minibatch (or the one that stops the
+      // loop) is ever reported (aggregate_info over aliased dicts), so the full row is built lazily; the KL statistic that
+      // drives early stopping is the one value needed every step.
+      { const float* t = sm + Lt::oRED + 8;
+        if (KIND != MFK_VALUE && a.target_kl >= 0.f) inf_kl = t[2] * invB;
+        const bool report = any_bad || st + a.bs >= total_rows || (a.max_batches > 0 && total_batches + 1 >= a.max_batches) ||
+                            (KIND != MFK_VALUE && a.target_kl >= 0.f && inf_kl > a.target_kl);
+        if (report) {
+          float ss = sm[Lt::oRED];
 #pragma unroll
-        for (int q = 1; q < MF8_NW; ++q) ss += sm[Lt::oRED + q];
-        inf_gn = sqrtf(ss);
-        const float* t = sm + Lt::oRED + 8;
-        if (KIND == MFK_VALUE) { inf_loss = t[6] / fn; inf_ret = t[4] / fn; }
-        else { const float p_loss = -(t[0] / fn); float entropy;
-          if (KIND == MFK_CATEGORICAL) entropy = t[1] / fn;
-          else { entropy = 1.4189385332046727f;
+          for (int q = 1; q < MF8_NW; ++q) ss += sm[Lt::oRED + q];
+          inf_gn = sqrtf(ss);
+          if (KIND == MFK_VALUE) { inf_loss = t[6] * invB; inf_ret = t[4] * invB; }
+          else { const float p_loss = -(t[0] * invB); float entropy;
+            if (KIND == MFK_CATEGORICAL) entropy = t[1] * invB;
+            else { entropy = 1.4189385332046727f;
 #pragma unroll
-            for (int k = 0; k < OUT; ++k) entropy += sm[Lt::oEX + k]; }
-          inf_ent = entropy; inf_loss = a.lambda_p * p_loss + a.lambda_e * (-entropy); inf_kl = t[2] / fn; inf_adv = t[3] / fn; inf_ret = t[4] / fn; inf_clip = t[5] / fn; }
+              for (int k = 0; k < OUT; ++k) entropy += sm[Lt::oEX + k]; }
+            inf_ent = entropy; inf_loss = a.lambda_p * p_loss + a.lambda_e * (-entropy); inf_kl = t[2] * invB; inf_adv = t[3] * invB; inf_ret = t[4] * invB; inf_clip = t[5] * invB; }
+        }
       }
       if (any_bad) { inf_gn = NAN; err = CRUX_ENAN; break; }                   // training.jl:20: no update
       // ======================= Adam (Flux.update!, training.jl:21) =======================
