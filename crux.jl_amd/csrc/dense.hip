@@ -38,23 +38,30 @@ __global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) {
   const float* pa = q.A + (int64_t)(va ? ia : 0) * q.sAi;
   const float* pb = q.B + (int64_t)(vb ? jb : 0) * q.sBj;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < q.K; k0 += 16) {
-    const int kb = k0 + 4 * g;
-    float a[4], b[4];
-    if (AV) { f32x4 t = {0.f, 0.f, 0.f, 0.f}; if (va && kb < q.K) t = *(const f32x4*)(pa + kb);
+  // K loop in steps of 64: the loads of four 16-wide chunks are issued before the first MFMA, so one L2 round trip (~1 us under load) is paid per
+  // 64 k instead of per 16 (the kernel is a wave-per-tile design with no LDS staging: latency, not bandwidth, is what has to be hidden)
+  for (int k0 = 0; k0 < q.K; k0 += 64) {
+    float a[4][4], b[4][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a[r] = t[r]; }
-    else {
+    for (int u = 0; u < 4; ++u) {
+      const int kb = k0 + 16 * u + 4 * g;
+      if (AV) { f32x4 t = {0.f, 0.f, 0.f, 0.f}; if (va && kb < q.K) t = *(const f32x4*)(pa + kb);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int kk = kb + r; a[r] = (va && kk < q.K) ? pa[(int64_t)kk * q.sAk] : 0.f; } }
-    if (BV) { f32x4 t = {0.f, 0.f, 0.f, 0.f}; if (vb && kb < q.K) t = *(const f32x4*)(pb + kb);
+        for (int r = 0; r < 4; ++r) a[u][r] = t[r]; }
+      else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) b[r] = t[r]; }
-    else {
+        for (int r = 0; r < 4; ++r) { const int kk = kb + r; a[u][r] = (va && kk < q.K) ? pa[(int64_t)kk * q.sAk] : 0.f; } }
+      if (BV) { f32x4 t = {0.f, 0.f, 0.f, 0.f}; if (vb && kb < q.K) t = *(const f32x4*)(pb + kb);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int kk = kb + r; b[r] = (vb && kk < q.K) ? pb[(int64_t)kk * q.sBk] : 0.f; } }
+        for (int r = 0; r < 4; ++r) b[u][r] = t[r]; }
+      else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[r], acc, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) { const int kk = kb + r; b[u][r] = (vb && kk < q.K) ? pb[(int64_t)kk * q.sBk] : 0.f; } }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][r], b[u][r], acc, 0, 0, 0);
   }
   // D layout: reg r <-> row i0+4g+r, column j0+c
   const int j = j0 + c;

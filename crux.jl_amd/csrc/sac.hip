@@ -112,16 +112,21 @@ __global__ __launch_bounds__(256) void k_td_head(const float* __restrict__ z, co
 __global__ void k_td_info(const double* __restrict__ st, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) {
   dinfo[CRUX_INFO_LOSS] = (float)(st[0] / (double)B); dinfo[2] = (float)(st[1] / (double)B); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
 }
-// sum of squares of up to two flat gradients (norm(grads), utils.jl:49-55: sqrt of the sum of per-tensor squared norms)
-__global__ __launch_bounds__(1024) void k_sumsq2(const float* __restrict__ g1, int64_t n1, const float* __restrict__ g2, int64_t n2, double* __restrict__ out) {
-  __shared__ double red[16];
+// sum of squares of up to two flat gradients (norm(grads), utils.jl:49-55: sqrt of the sum of per-tensor squared norms): 64 blocks of partial
+// sums, combined in block order by the last block to arrive (deterministic: the combine order is fixed, only who performs it varies)
+#define SUMSQ_BLOCKS 64
+__global__ __launch_bounds__(256) void k_sumsq2(const float* __restrict__ g1, int64_t n1, const float* __restrict__ g2, int64_t n2, double* __restrict__ out /* [0] result, [1..64] partials, [65] ticket */) {
+  __shared__ double red[4]; __shared__ int last;
   double s = 0;
-  for (int64_t i = threadIdx.x; i < n1; i += 1024) s += (double)g1[i] * (double)g1[i];
-  for (int64_t i = threadIdx.x; i < n2; i += 1024) s += (double)g2[i] * (double)g2[i];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n1; i += (int64_t)SUMSQ_BLOCKS * 256) s += (double)g1[i] * (double)g1[i];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)SUMSQ_BLOCKS * 256) s += (double)g2[i] * (double)g2[i];
   s = wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) { double t = 0; for (int k = 0; k < 16; ++k) t += red[k]; out[0] = t; }
+  if (threadIdx.x == 0) { out[1 + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3]; __threadfence();
+    last = atomicAdd((unsigned int*)&out[1 + SUMSQ_BLOCKS], 1u) == SUMSQ_BLOCKS - 1; }
+  __syncthreads();
+  if (last && threadIdx.x == 0) { __threadfence(); double t = 0; for (int k = 0; k < SUMSQ_BLOCKS; ++k) t += ((volatile double*)out)[1 + k]; out[0] = t; ((volatile unsigned int*)&out[1 + SUMSQ_BLOCKS])[0] = 0u; }
 }
 __global__ void k_critic_info(const double* __restrict__ st1, const double* __restrict__ st2, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) {
   dinfo[CRUX_INFO_LOSS] = (float)(0.5 * (st1[0] / (double)B) + 0.5 * (st2[0] / (double)B));
@@ -151,10 +156,14 @@ __global__ void k_actor_grad(const float* __restrict__ sa, const float* __restri
   dmu[i] = clp * (df / s2) + abar;
   dls[i] = clp * ((df * df) / s2 - 1.f) + abar * (eps[i] * sg);
 }
-__global__ void k_rowsum(const float* __restrict__ v, int ad, int64_t B, float* __restrict__ out) {   // out[d] = sum_j v[d + ad*j], sequential like the oracle
-  const int d = blockIdx.x * blockDim.x + threadIdx.x; if (d >= ad) return;
-  float acc = 0.f; for (int64_t j = 0; j < B; ++j) acc += v[d + (int64_t)ad * j];
-  out[d] = acc;
+__global__ __launch_bounds__(256) void k_rowsum(const float* __restrict__ v, int ad, int64_t B, float* __restrict__ out) {   // out[d] = sum_j v[d + ad*j]; one block per d, fixed-order combine
+  __shared__ float red[4];
+  const int d = blockIdx.x; float acc = 0.f;
+  for (int64_t j = threadIdx.x; j < B; j += 256) acc += v[d + (int64_t)ad * j];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[d] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 __global__ void k_actor_info(const double* __restrict__ st, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) {
   dinfo[CRUX_INFO_LOSS] = (float)(st[0] / (double)B); dinfo[CRUX_INFO_ENTROPY] = (float)(-(st[1] / (double)B)); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
@@ -213,13 +222,13 @@ static int32_t finish_step(crux_ctx* c, const float* d_info, const int32_t* d_st
 int32_t crux_td_step_dense(crux_mlp* net, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out) {
   crux_ctx* c = net->ctx; const int64_t B = b->elements; const int nout = net->nd.dims[net->nd.L];
   Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * nout + 8192), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "td_step: scratch");
-  float* dy = cv.take<float>((size_t)B * nout); float* dinfo = cv.take<float>(CRUX_INFO_N); double* st = cv.take<double>(2); double* ssq = cv.take<double>(1); int32_t* status = cv.take<int32_t>(1);
-  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 4, c->stream));
+  float* dy = cv.take<float>((size_t)B * nout); float* dinfo = cv.take<float>(CRUX_INFO_N); double* st = cv.take<double>(2); double* ssq = cv.take<double>(2 + SUMSQ_BLOCKS); int32_t* status = cv.take<int32_t>(1);
+  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 6, c->stream));
   const float* S = (const float*)b->col[CRUX_COL_S]; const float* w = use_weight ? (const float*)b->col[CRUX_COL_WEIGHT] : nullptr;
   int32_t rc = crux_dense_forward(net, S, B, c->stream); if (rc) return rc;
   hipLaunchKernelGGL(k_td_head, dim3(1), dim3(256), 0, c->stream, crux_dense_act(net, net->nd.L), (const uint8_t*)b->col[CRUX_COL_A], nout, d_y, w, B, dy, st);
   rc = crux_dense_backward(net, S, B, dy, 1.0f, true, nullptr, c->stream); if (rc) return rc;
-  hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, c->stream, net->g, (int64_t)net->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+  hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, c->stream, net->g, (int64_t)net->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
   hipLaunchKernelGGL(k_td_info, dim3(1), dim3(1), 0, c->stream, st, ssq, B, dinfo);
   rc = adam_gated(net, ssq, status); if (rc) return rc;
   return finish_step(c, dinfo, status, info_out, "td_loss");
@@ -248,8 +257,8 @@ int32_t crux_sac_temp_step(crux_mlp* actor, crux_mlp* la, crux_buffer* b, float 
   crux_ctx* c = actor->ctx; int32_t rc = check_sac(c, actor, nullptr, nullptr, la, b, "sac_temp_loss"); if (rc) return rc;
   const int64_t B = b->elements; const int od = b->obs_dim, ad = b->act_dim;
   Carve cv{(char*)crux_scratch(c, 4 * (size_t)B + 4096), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "sac_temp: scratch");
-  float* lp = cv.take<float>((size_t)B); float* dinfo = cv.take<float>(CRUX_INFO_N); double* ssq = cv.take<double>(1); int32_t* st = cv.take<int32_t>(1);
-  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 3, c->stream));
+  float* lp = cv.take<float>((size_t)B); float* dinfo = cv.take<float>(CRUX_INFO_N); double* ssq = cv.take<double>(2 + SUMSQ_BLOCKS); int32_t* st = cv.take<int32_t>(1);
+  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 5, c->stream));
   const float* S = (const float*)b->col[CRUX_COL_S];
   rc = crux_dense_forward(actor, S, B, c->stream); if (rc) return rc;
   hipLaunchKernelGGL(k_gauss_explore, dim3(nblk(B)), dim3(256), 0, c->stream, crux_dense_act(actor, actor->nd.L), actor->p + actor->nd.xoff, S, od, ad, B, seed, counter, (float*)nullptr, lp, (float*)nullptr);
@@ -265,8 +274,8 @@ static int32_t q_step_impl(crux_mlp* q1, crux_mlp* q2, crux_buffer* b, const flo
   const int64_t B = b->elements; const int od = b->obs_dim, ad = b->act_dim; const int nq = q2 ? 2 : 1;
   Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (od + ad + 1) + 8192), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "%s: scratch", who);
   float* sa = cv.take<float>((size_t)B * (od + ad)); float* dy = cv.take<float>((size_t)B); float* dinfo = cv.take<float>(CRUX_INFO_N);
-  double* st1 = cv.take<double>(2); double* st2 = cv.take<double>(2); double* ssq = cv.take<double>(1); int32_t* st = cv.take<int32_t>(1);
-  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 5, c->stream));
+  double* st1 = cv.take<double>(2); double* st2 = cv.take<double>(2); double* ssq = cv.take<double>(2 + SUMSQ_BLOCKS); int32_t* st = cv.take<int32_t>(1);
+  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 7, c->stream));
   const float* w = use_weight ? (const float*)b->col[CRUX_COL_WEIGHT] : nullptr;
   hipLaunchKernelGGL(k_concat_sa, dim3(nblk(B * (od + ad))), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_S], (const float*)b->col[CRUX_COL_A], od, ad, B, sa);
   crux_mlp* qs[2] = {q1, q2}; double* sts[2] = {st1, st2};
@@ -275,7 +284,7 @@ static int32_t q_step_impl(crux_mlp* q1, crux_mlp* q2, crux_buffer* b, const flo
     hipLaunchKernelGGL(k_q_head, dim3(1), dim3(256), 0, c->stream, crux_dense_act(qs[t], qs[t]->nd.L), d_y, w, B, nq == 2 ? 0.5f : 1.0f, dy, sts[t]);
     rc = crux_dense_backward(qs[t], sa, B, dy, 1.0f, true, nullptr, c->stream); if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, c->stream, q1->g, (int64_t)q1->nd.n_params, q2 ? q2->g : (const float*)nullptr, (int64_t)(q2 ? q2->nd.n_params : 0), ssq);
+  hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, c->stream, q1->g, (int64_t)q1->nd.n_params, q2 ? q2->g : (const float*)nullptr, (int64_t)(q2 ? q2->nd.n_params : 0), ssq);
   hipLaunchKernelGGL(k_critic_info, dim3(1), dim3(1), 0, c->stream, st1, nq == 2 ? st2 : st1, ssq, B, dinfo);   // single Q: 0.5 l + 0.5 l = l
   rc = adam_gated(q1, ssq, st); if (rc) return rc;
   if (q2) { rc = adam_gated(q2, ssq, st); if (rc) return rc; }
@@ -315,8 +324,8 @@ int32_t crux_dpg_actor_step(crux_mlp* actor, crux_mlp* q, crux_buffer* b, float*
   if (actor->nd.L < 1 || actor->nd.dims[0] != od || actor->nd.dims[actor->nd.L] != ad) return crux_fail(c, CRUX_EINVAL, "ddpg_actor_loss: actor must map %d -> %d", od, ad);
   Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (2 * sd + ad + 1) + 8192), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "ddpg_actor: scratch");
   float* sa = cv.take<float>((size_t)B * sd); float* dsa = cv.take<float>((size_t)B * sd); float* da = cv.take<float>((size_t)B * ad); float* dy = cv.take<float>((size_t)B);
-  float* dinfo = cv.take<float>(CRUX_INFO_N); double* ssq = cv.take<double>(1); int32_t* st = cv.take<int32_t>(1);
-  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 3, c->stream));
+  float* dinfo = cv.take<float>(CRUX_INFO_N); double* ssq = cv.take<double>(2 + SUMSQ_BLOCKS); int32_t* st = cv.take<int32_t>(1);
+  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 5, c->stream));
   const float* S = (const float*)b->col[CRUX_COL_S];
   rc = crux_dense_forward(actor, S, B, c->stream); if (rc) return rc;
   hipLaunchKernelGGL(k_dpg_action, dim3(nblk(B * sd)), dim3(256), 0, c->stream, crux_dense_act(actor, actor->nd.L), S, od, ad, B, -1.f, 0.f, 0.f, 0.f, 0.f, (uint64_t)0, (uint64_t)0, sa);
@@ -325,7 +334,7 @@ int32_t crux_dpg_actor_step(crux_mlp* actor, crux_mlp* q, crux_buffer* b, float*
   rc = crux_dense_backward(q, sa, B, dy, 1.0f, false, dsa, c->stream); if (rc) return rc;                        // the critic's parameters are not trained here
   hipLaunchKernelGGL(k_slice_rows, dim3(nblk(B * ad)), dim3(256), 0, c->stream, dsa, sd, od, ad, B, da);
   rc = crux_dense_backward(actor, S, B, da, 1.0f, true, nullptr, c->stream); if (rc) return rc;
-  hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, c->stream, actor->g, (int64_t)actor->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+  hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, c->stream, actor->g, (int64_t)actor->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
   hipLaunchKernelGGL(k_mean_info, dim3(1), dim3(256), 0, c->stream, crux_dense_act(q, q->nd.L), B, -1.f, ssq, dinfo);
   rc = adam_gated(actor, ssq, st); if (rc) return rc;
   return finish_step(c, dinfo, st, info_out, "ddpg_actor_loss");
@@ -339,8 +348,8 @@ int32_t crux_sac_actor_step(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_ml
   float* sa = cv.take<float>((size_t)B * sd); float* dsa1 = cv.take<float>((size_t)B * sd); float* dsa2 = cv.take<float>((size_t)B * sd);
   float* eps = cv.take<float>((size_t)B * ad); float* dmu = cv.take<float>((size_t)B * ad); float* dls = cv.take<float>((size_t)B * ad);
   float* lp = cv.take<float>((size_t)B); float* dy1 = cv.take<float>((size_t)B); float* dy2 = cv.take<float>((size_t)B);
-  float* dinfo = cv.take<float>(CRUX_INFO_N); double* stats = cv.take<double>(2); double* ssq = cv.take<double>(1); int32_t* st = cv.take<int32_t>(1);
-  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 4, c->stream));
+  float* dinfo = cv.take<float>(CRUX_INFO_N); double* stats = cv.take<double>(2); double* ssq = cv.take<double>(2 + SUMSQ_BLOCKS); int32_t* st = cv.take<int32_t>(1);
+  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 6, c->stream));
   const float* S = (const float*)b->col[CRUX_COL_S];
   rc = crux_dense_forward(actor, S, B, c->stream); if (rc) return rc;
   float* mu = crux_dense_act(actor, actor->nd.L);
@@ -352,8 +361,8 @@ int32_t crux_sac_actor_step(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_ml
   rc = crux_dense_backward(q2, sa, B, dy2, 1.0f, false, dsa2, c->stream); if (rc) return rc;
   hipLaunchKernelGGL(k_actor_grad, dim3(nblk(B * ad)), dim3(256), 0, c->stream, sa, mu, eps, actor->p + actor->nd.xoff, dsa1, dsa2, la->p, od, ad, B, dmu, dls);
   rc = crux_dense_backward(actor, S, B, dmu, 1.0f, true, nullptr, c->stream); if (rc) return rc;
-  hipLaunchKernelGGL(k_rowsum, dim3(1), dim3(64), 0, c->stream, dls, ad, B, actor->g + actor->nd.xoff);
-  hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, c->stream, actor->g, (int64_t)actor->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+  hipLaunchKernelGGL(k_rowsum, dim3(ad), dim3(256), 0, c->stream, dls, ad, B, actor->g + actor->nd.xoff);
+  hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, c->stream, actor->g, (int64_t)actor->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
   hipLaunchKernelGGL(k_actor_info, dim3(1), dim3(1), 0, c->stream, stats, ssq, B, dinfo);
   rc = adam_gated(actor, ssq, st); if (rc) return rc;
   return finish_step(c, dinfo, st, info_out, "sac_actor_loss");
