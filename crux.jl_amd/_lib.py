@@ -148,7 +148,7 @@ NCOLS = 13
 ACTION_DISCRETE, ACTION_CONTINUOUS = 0, 1
 ENV = {"cartpole": 0, "pendulum": 1, "gridworld": 2, "synth": 3}
 HEAD = {"categorical": 0, "gaussian": 1, "greedy_q": 2, "deterministic": 3}
-LOSS = {"ppo": 0, "value_mse": 1, "a2c": 3, "reinforce": 4}
+LOSS = {"ppo": 0, "value_mse": 1, "a2c": 3, "reinforce": 4, "logpdf_bc": 5, "mse_action": 6}
 INFO = {"loss": 0, "grad_norm": 1, "entropy": 2, "kl": 3, "clip_fraction": 4, "avg_advantage": 5, "avg_return": 6,
         "batches_trained": 7, "epochs_run": 8, "q1avg": 9, "q2avg": 10, "alpha": 11}
 INFO_N = 16

@@ -810,6 +810,8 @@ def _train_cfg(pi, p, P):
 
 def _info_dict(p, raw, extra=True):
     d = {p.name + "loss": float(raw[L.INFO["loss"]]), p.name + "grad_norm": float(raw[L.INFO["grad_norm"]])}
+    if p.loss.name == "logpdf_bc":
+        d["entropy"], d["logpdf"] = float(raw[L.INFO["entropy"]]), float(raw[L.INFO["kl"]])          # info[:logpdf] = -mean(logpdf) (bc.jl:15)
     if p.loss.name in ("a2c", "reinforce"):
         for k in ("entropy", "kl"):
             d[k] = float(raw[L.INFO[k]])
@@ -929,6 +931,101 @@ def PPO(pi, S, eps=0.2, lambda_p=1.0, lambda_e=0.1, target_kl=0.012, a_opt=None,
                           c_opt=TrainingParams(loss=value_mse_loss, name="critic_", **c_opt),
                           post_batch_callback=lambda D, info: whiten_(D, "advantage"),
                           required_columns=cols, **kw)
+
+
+mse_action_loss, logpdf_bc_loss = _Loss("mse_action"), _Loss("logpdf_bc")   # src/model_free/il/bc.jl:1,10-18
+
+
+def normalize_(b, S, A):
+    """normalize!(b, S, A) (src/experience_buffer.jl:143-148): s, sp (and a for ContinuousSpace) replaced by tovec(., space) = (v - mu) / sigma (spaces.jl:25)."""
+    def tovec(v, sp):
+        mu = np.broadcast_to(np.asarray(sp.mu, np.float32), (v.shape[0],))[:, None]; sg = np.broadcast_to(np.asarray(sp.sigma, np.float32), (v.shape[0],))[:, None]
+        return ((v - mu) / sg).astype(np.float32)
+    for k in ("s", "sp"):
+        if b.haskey(k):
+            b[k] = tovec(b[k], S)
+    if isinstance(A, ContinuousSpace):
+        b["a"] = tovec(b["a"], A)
+    return b
+
+
+def split(b, fracs):
+    """split(b::ExperienceBuffer, fracs) (src/experience_buffer.jl:133-141): consecutive row ranges of sizes split_batches(length(b), fracs)."""
+    out, start = [], 0
+    extras = extra_columns(b)
+    for n in split_batches(len(b), fracs):
+        nb = ExperienceBuffer(b.S, b.A, max(int(n), 1), extras, ctx=b.ctx)
+        if n > 0:
+            nb.push_({k: b[k][:, start:start + n] for k in b.keys()})
+        out.append(nb); start += n
+    return out
+
+
+def loss_value(pi, p, P, D):
+    """loss(pi, P, D) evaluated on the whole buffer, no update (the validation error of stop_on_validation_increase, src/utils.jl:59-72)."""
+    _ensure_opt(pi, p)
+    cfg = _train_cfg(pi, p, P); n = len(D)
+    ids = np.arange(n, dtype=np.int64); raw = np.zeros(L.INFO_N, np.float32)
+    pi.ctx.check(pi.ctx.lib.crux_loss_grad(pi.h, D.h, C.byref(cfg), _vp(ids), n, _vp(raw)))
+    return float(raw[L.INFO["loss"]])
+
+
+class BatchSolver:
+    """BatchSolver(; agent, S, D_train, a_opt, P, ...) (src/model_free/batch.jl:20-36) for the actor-only case used by BC."""
+
+    def __init__(self, agent, S, D_train, a_opt, P=None, early_stopping=None, max_steps=100):
+        self.agent, self.S, self.D_train, self.a_opt, self.P = agent, S, D_train, a_opt, dict(P or {})
+        self.early_stopping, self.max_steps, self.epoch, self.history = early_stopping, int(max_steps), 0, []
+
+
+def _solve_batch(solver, mdp=None):
+    """POMDPs.solve(S::BatchSolver, mdp) (src/model_free/batch.jl:38-85): per epoch shuffle!, partition, train! per minibatch (one persistent
+    launch per epoch here), then the early-stopping test on the list of epoch infos. Note the inclusive range: a_opt.epochs + 1 epochs (:47)."""
+    A, p = actor(solver.agent.pi), solver.a_opt
+    e_total, first = p.epochs, solver.epoch
+    try:
+        p.epochs = 1
+        for solver.epoch in range(first, first + e_total + 1):
+            info = batch_train_(A, p, solver.P, solver.D_train)
+            solver.history.append({k: v for k, v in info.items() if not k.startswith("_")})
+            if solver.early_stopping and solver.early_stopping(solver.history):
+                break
+    finally:
+        p.epochs = e_total
+    return solver.agent.pi
+
+
+def stop_on_validation_increase(pi, P, D_val, p, window=5):
+    """stop_on_validation_increase(pi, P, D_val, loss; window) (src/utils.jl:59-72)."""
+    def f(infos):
+        infos[-1]["validation_error"] = loss_value(pi, p, P, D_val)
+        N = len(infos)
+        if N >= 2 * window:
+            cur = np.mean([infos[i]["validation_error"] for i in range(N - window, N)])
+            old = np.mean([infos[i]["validation_error"] for i in range(N - 2 * window, N - window)])
+            return bool(cur >= old)
+        return False
+    return f
+
+
+def BC(pi, S, D_demo, normalize_demo=True, loss=None, validation_fraction=0.3, window=100, lambda_e=1e-3, opt=None, shuffle_perm=None, **kw):
+    """BC(; pi, S, D_demo, normalize_demo, loss, validation_fraction=0.3, window=100, lambda_e=1f-3, opt) (src/model_free/il/bc.jl:37-70):
+    mse_action_loss for a ContinuousNetwork, logpdf_bc_loss otherwise; the demonstrations are normalised, shuffled once and split into
+    training / validation parts; early stopping on the validation error. shuffle_perm: optional 1-based permutation for the initial shuffle!."""
+    loss = loss or (mse_action_loss if type(pi) is ContinuousNetwork else logpdf_bc_loss)
+    A = pi.space if hasattr(pi, "space") else (DiscreteSpace(len(pi.outputs), pi.outputs) if isinstance(pi, DiscreteNetwork) else ContinuousSpace(pi.network.dims[-1]))
+    D = buffer_like(D_demo, capacity=len(D_demo)); D.push_({k: D_demo[k] for k in D_demo.keys()})      # deepcopy(D_demo) (:52)
+    if normalize_demo:
+        normalize_(D, S, A)
+    n = len(D)
+    perm = np.asarray(shuffle_perm, np.int64) if shuffle_perm is not None else np.random.default_rng(0xBC).permutation(n).astype(np.int64) + 1
+    D.shuffle_(perm)                                                                                    # shuffle!(D_demo) (:55)
+    D_train, D_val = split(D, [1 - validation_fraction, validation_fraction])                         # (:56)
+    P = {"lambda_e": lambda_e, "lambda_p": 1.0}
+    o = dict(opt or {}); o.setdefault("name", "")
+    p = TrainingParams(loss=loss, **o)
+    return BatchSolver(agent=PolicyParams(pi), S=S, D_train=D_train, a_opt=p, P=P,
+                       early_stopping=stop_on_validation_increase(pi, P, D_val, p, window=window), **kw)
 
 
 def A2C(pi, S, lambda_p=1.0, lambda_e=0.1, a_opt=None, c_opt=None, required_columns=(), **kw):
@@ -1168,6 +1265,8 @@ def TD3(pi, S, N, dN=50, pi_explore=None, a_opt=None, c_opt=None, pi_smooth=None
 _solve_on_policy = solve
 
 
-def solve(solver, mdp):  # noqa: F811
+def solve(solver, mdp=None):  # noqa: F811
     """POMDPs.solve(solver, mdp) for OnPolicySolver (on_policy.jl:80-109) and OffPolicySolver (off_policy.jl:113-150)."""
+    if isinstance(solver, BatchSolver):
+        return _solve_batch(solver, mdp)
     return _solve_off_policy(solver, mdp) if isinstance(solver, OffPolicySolver) else _solve_on_policy(solver, mdp)

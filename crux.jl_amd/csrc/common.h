@@ -90,6 +90,7 @@ struct crux_buffer {
   float* topo_total = nullptr; float* topo_prefix = nullptr;
   int32_t* order_a = nullptr;    // device [capacity] logical->physical order scratch for batch_train
   int32_t* order_b = nullptr;
+  float* aux_ones = nullptr; float* aux_zeros = nullptr;   // [capacity] constant columns (logpdf_bc_loss = a2c_loss with advantage 1, old logprob 0)
   int32_t* ord_all[2] = {nullptr, nullptr}; size_t ord_all_cap[2] = {0, 0};   // per-epoch composed orders (ints) for the actor / critic learner
   int32_t* order_c = nullptr;    // second pair for the concurrent critic learner
   int32_t* order_d = nullptr;

@@ -96,7 +96,10 @@ __global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
         if (tid < ns) {
           const int s = tid; const int64_t row = a.ids ? (int64_t)a.ids[st + c0 + s] : (int64_t)order_cur[st + c0 + s];
           const float* z = acts[L] + s * nout; float* dy = dA + s * nout;
-          if (a.loss == CRUX_LOSS_VALUE_MSE) {                                   // Flux.mse(value(pi,s), return)  ppo.jl:60
+          if (a.loss == CRUX_LOSS_MSE_ACTION) {                                  // Flux.mse(action(pi,s), a)  il/bc.jl:1: mean over act_dim x batch
+            const float* av = (const float*)a.A + row * a.ad; const float inv = invB / (float)nout;
+            for (int k = 0; k < nout; ++k) { const float d = z[k] - av[k]; s_sq += (double)(d * d) / (double)nout; dy[k] = 2.f * d * inv; }
+          } else if (a.loss == CRUX_LOSS_VALUE_MSE) {                            // Flux.mse(value(pi,s), return)  ppo.jl:60
             const float d = z[0] - a.RET[row]; s_sq += (double)(d * d); dy[0] = 2.f * d * invB;
           } else if (a.loss == CRUX_LOSS_TD_INTERNAL) {                          // td_loss utils.jl:76-87
             const uint8_t* av = (const uint8_t*)a.A + row * a.ad; float Q = 0.f;
@@ -232,6 +235,14 @@ static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const cr
   a.shuffle_seed = cfg->shuffle_seed; a.shuffle_counter = cfg->shuffle_counter;
   a.len = buf->elements; a.order_a = buf->order_a; a.order_b = buf->order_b; a.apply = 1;
   const int nout = net->nd.dims[net->nd.L];
+  if (internal_loss == CRUX_LOSS_LOGPDF_BC) {   // logpdf_bc_loss (il/bc.jl:10-18) = a2c_loss with advantage == 1, lambda_p = 1 and old logprob == 0 (so "kl" = -mean(logpdf))
+    if (!buf->aux_ones) {
+      if (hipMalloc(&buf->aux_ones, 4 * (size_t)buf->capacity) != hipSuccess || hipMalloc(&buf->aux_zeros, 4 * (size_t)buf->capacity) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "logpdf_bc_loss: constant columns");
+      std::vector<float> one((size_t)buf->capacity, 1.f);
+      HIPCHK(c, hipMemcpy(buf->aux_ones, one.data(), 4 * one.size(), hipMemcpyHostToDevice)); HIPCHK(c, hipMemset(buf->aux_zeros, 0, 4 * (size_t)buf->capacity));
+    }
+    a.ADV = buf->aux_ones; a.LP = buf->aux_zeros; a.lambda_p = 1.f; a.loss = internal_loss = CRUX_LOSS_A2C;
+  }
   if (internal_loss == CRUX_LOSS_REINFORCE) {   // reinforce_loss (reinforce.jl:4-13) = a2c_loss with the return as the weight, lambda_p = 1, no entropy term
     if (!a.RET || !a.LP) return crux_fail(c, CRUX_EINVAL, "reinforce_loss: buffer needs :return and :logprob columns");
     a.ADV = a.RET; a.lambda_p = 1.f; a.lambda_e = 0.f; a.loss = internal_loss = CRUX_LOSS_A2C;
@@ -243,6 +254,8 @@ static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const cr
     else return crux_fail(c, CRUX_EINVAL, "ppo_loss: head %d unsupported", cfg->head);
   } else if (internal_loss == CRUX_LOSS_VALUE_MSE) {
     if (!a.RET || nout != 1) return crux_fail(c, CRUX_EINVAL, "critic mse: needs a :return column and a scalar-output network");
+  } else if (internal_loss == CRUX_LOSS_MSE_ACTION) {
+    if (buf->act_kind != CRUX_ACTION_CONTINUOUS || nout != buf->act_dim) return crux_fail(c, CRUX_EINVAL, "mse_action_loss: needs a continuous action column of %d rows", nout);
   }
   if (cfg->batch_size < 1) return crux_fail(c, CRUX_EINVAL, "train!: batch_size %d", cfg->batch_size);
   return CRUX_OK;
@@ -300,7 +313,7 @@ static int32_t run_batch(crux_mlp* net, crux_buffer* buf, TrainArgs& a, int n_ep
   if (!sc) return crux_fail(c, CRUX_ENOMEM, "train!: scratch");
   a.status = (int32_t*)sc; a.epoch_infos = (float*)(sc + 256);
   HIPCHK(c, hipMemsetAsync(sc, 0, eb + 256, c->stream));
-  const int slot = CRUX_IS_PG(a.loss) ? CRUX_PROF_TRAIN_ACTOR : (a.loss == CRUX_LOSS_VALUE_MSE ? CRUX_PROF_TRAIN_CRITIC : CRUX_PROF_TD_STEP);
+  const int slot = (CRUX_IS_PG(a.loss) || a.loss == CRUX_LOSS_MSE_ACTION) ? CRUX_PROF_TRAIN_ACTOR : (a.loss == CRUX_LOSS_VALUE_MSE ? CRUX_PROF_TRAIN_CRITIC : CRUX_PROF_TD_STEP);
   int32_t rc;
   if (!a.ids && a.len < ((int64_t)1 << 31) && !getenv("CRUX_ORDERS_IN_KERNEL")) {
     int32_t* oa = nullptr; rc = build_orders(c, buf, 0, nullptr, a.shuffle_seed, a.shuffle_counter, a.perms, n_epochs, c->stream, &oa); if (rc) return rc;

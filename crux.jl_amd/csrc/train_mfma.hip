@@ -554,7 +554,7 @@ int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, h
   const NetDesc& nd = a.nd;
   if (getenv("CRUX_FORCE_GENERIC")) return CRUX_OK;
   if (nd.L != 3 || nd.dims[1] != MF_HID || nd.dims[2] != MF_HID || nd.acts[2] != CRUX_ACT_IDENTITY || nd.acts[0] != nd.acts[1]) return CRUX_OK;
-  if (a.bs > 128 || a.loss == CRUX_LOSS_TD_INTERNAL) return CRUX_OK;
+  if (a.bs > 128 || a.loss == CRUX_LOSS_TD_INTERNAL || a.loss == CRUX_LOSS_MSE_ACTION) return CRUX_OK;   // those two heads exist in the generic kernel only
   if (a.ids && a.n_ids > 128) return CRUX_OK;
   const int in = nd.dims[0], out = nd.dims[3], act = nd.acts[0];
   int kind;

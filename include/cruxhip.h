@@ -228,7 +228,10 @@ int32_t crux_first_episode_metrics(crux_buffer* buf, int32_t n_envs, int64_t T, 
 enum { CRUX_LOSS_PPO = 0      /* ppo_loss with the head's logpdf/entropy (ppo.jl:4-21)            */,
        CRUX_LOSS_VALUE_MSE = 1 /* Flux.mse(value(pi, s), return) (ppo.jl:60)                      */,
        CRUX_LOSS_A2C = 3       /* a2c_loss (a2c.jl:4-15): -lambda_p mean(logpdf .* advantage) - lambda_e mean(entropy) */,
-       CRUX_LOSS_REINFORCE = 4 /* reinforce_loss (reinforce.jl:4-13): -mean(logpdf .* return); entropy and kl are reported only */ };
+       CRUX_LOSS_REINFORCE = 4 /* reinforce_loss (reinforce.jl:4-13): -mean(logpdf .* return); entropy and kl are reported only */,
+       CRUX_LOSS_LOGPDF_BC = 5 /* logpdf_bc_loss (il/bc.jl:10-18): -mean(logpdf(pi, s, a)) - lambda_e mean(entropy); needs only :s, :a.
+                                  info: LOSS, GRAD_NORM, ENTROPY, KL = the -mean(logpdf) term (info[:logpdf])                    */,
+       CRUX_LOSS_MSE_ACTION = 6 /* mse_action_loss (il/bc.jl:1): Flux.mse(action(pi, s), a) for a ContinuousNetwork, mean over act_dim x batch */ };
 
 typedef struct {
   int32_t loss;           /* CRUX_LOSS_*                                                          */

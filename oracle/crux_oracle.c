@@ -732,7 +732,14 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
   float invB = 1.0f / (float)n;
   double sum_loss_p = 0, sum_H = 0, sum_kl = 0, sum_adv = 0, sum_ret = 0, sum_sq = 0; int64_t nclip = 0;
   float dy[64], p[64];
-  if (cfg->loss == CRUX_LOSS_VALUE_MSE) {                                      /* Flux.mse(value(pi, s), return) ppo.jl:60 */
+  if (cfg->loss == CRUX_LOSS_MSE_ACTION) {                                     /* mse_action_loss il/bc.jl:1: Flux.mse(action(pi, s), a) */
+    if (buf->act_kind != CRUX_ACTION_CONTINUOUS || nout != ad) { cc_free(net, &c); return CRUX_EINVAL; }
+    const float* A = (const float*)buf->col[CRUX_COL_A]; float inv = invB / (float)nout;
+    for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s]; fwd_col(net, S + (size_t)id * od, c.h);
+      for (int k = 0; k < nout; ++k) { float d = c.h[net->n_layers][k] - A[(size_t)id * ad + k]; sum_sq += (double)(d * d) / (double)nout; dy[k] = 2.f * d * inv; }
+      bwd_col(net, c.h, dy, net->g); }
+    info[CRUX_INFO_LOSS] = (float)(sum_sq / (double)n);
+  } else if (cfg->loss == CRUX_LOSS_VALUE_MSE) {                               /* Flux.mse(value(pi, s), return) ppo.jl:60 */
     if (nout != 1 || !(buf->mask & (1u << CRUX_COL_RETURN))) { cc_free(net, &c); return CRUX_EINVAL; }
     const float* RET = (const float*)buf->col[CRUX_COL_RETURN];
     for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s];
@@ -741,13 +748,14 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
     info[CRUX_INFO_LOSS] = (float)(sum_sq / (double)n);
   } else {                                                                     /* ppo_loss ppo.jl:4-21 */
     const float* RET = (buf->mask & (1u << CRUX_COL_RETURN)) ? (const float*)buf->col[CRUX_COL_RETURN] : NULL;
-    if (!(buf->mask & (1u << CRUX_COL_LOGPROB)) || (cfg->loss == CRUX_LOSS_REINFORCE ? !RET : !(buf->mask & (1u << CRUX_COL_ADVANTAGE)))) { cc_free(net, &c); return CRUX_EINVAL; }
-    const float* LP = (const float*)buf->col[CRUX_COL_LOGPROB]; const float* ADV = cfg->loss == CRUX_LOSS_REINFORCE ? RET : (const float*)buf->col[CRUX_COL_ADVANTAGE];
+    const int bc = cfg->loss == CRUX_LOSS_LOGPDF_BC;                            /* logpdf_bc_loss il/bc.jl:10-18: only :s and :a are read */
+    if (!bc && (!(buf->mask & (1u << CRUX_COL_LOGPROB)) || (cfg->loss == CRUX_LOSS_REINFORCE ? !RET : !(buf->mask & (1u << CRUX_COL_ADVANTAGE))))) { cc_free(net, &c); return CRUX_EINVAL; }
+    const float* LP = bc ? NULL : (const float*)buf->col[CRUX_COL_LOGPROB]; const float* ADV = bc ? NULL : (cfg->loss == CRUX_LOSS_REINFORCE ? RET : (const float*)buf->col[CRUX_COL_ADVANTAGE]);
     float lo = 1.f - cfg->eps_clip, hi = 1.f + cfg->eps_clip;
     float* gx = net->g + xoff(net); const float* ls = net->p + xoff(net);
     for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s];
       fwd_col(net, S + (size_t)id * od, c.h); const float* z = c.h[net->n_layers];
-      float A = ADV[id], oldlp = LP[id], newlp, H = 0.f;
+      float A = bc ? 1.f : ADV[id], oldlp = bc ? 0.f : LP[id], newlp, H = 0.f;
       if (cfg->head == CRUX_HEAD_CATEGORICAL) {
         if (nout != ad) { cc_free(net, &c); return CRUX_EINVAL; }
         const uint8_t* a = (const uint8_t*)buf->col[CRUX_COL_A] + (size_t)id * ad;
@@ -761,6 +769,7 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
         float g = (u <= cl) ? A : 0.f;                       /* d min(u,c)/dr: ties -> first arg; clipped branch strictly smaller => clamp' = 0 */
         float coef = g * r, lterm = (u <= cl ? u : cl), lp_ = cfg->lambda_p, le_ = cfg->lambda_e;
         if (cfg->loss == CRUX_LOSS_A2C) { coef = A; lterm = newlp * A; }                                   /* a2c.jl:6 */
+        else if (bc) { coef = 1.f; lterm = newlp; lp_ = 1.f; }                                             /* -mean(logpdf) bc.jl:12 */
         else if (cfg->loss == CRUX_LOSS_REINFORCE) { coef = RET[id]; lterm = newlp * RET[id]; lp_ = 1.f; le_ = 0.f; }   /* reinforce.jl:12 */
         sum_loss_p += (double)lterm;
         for (int k = 0; k < nout; ++k) {
@@ -779,6 +788,7 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
         float g = (u <= cl) ? A : 0.f;
         float coef = g * r, lterm = (u <= cl ? u : cl), lp_ = cfg->lambda_p;
         if (cfg->loss == CRUX_LOSS_A2C) { coef = A; lterm = newlp * A; }
+        else if (bc) { coef = 1.f; lterm = newlp; lp_ = 1.f; }
         else if (cfg->loss == CRUX_LOSS_REINFORCE) { coef = RET[id]; lterm = newlp * RET[id]; lp_ = 1.f; }
         sum_loss_p += (double)lterm;
         for (int k = 0; k < ad; ++k) { float sg = expf(ls[k]); float s2 = sg * sg; float d = a[k] - z[k];
@@ -793,7 +803,7 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
     if (cfg->head == CRUX_HEAD_CATEGORICAL) { entropy = (float)(sum_H / (double)n); e_loss = -entropy; }
     else { float Hs = 1.4189385332046727f; for (int k = 0; k < ad; ++k) Hs = Hs + ls[k]; entropy = Hs; e_loss = -Hs;   /* scalar entropy policies.jl:348 */
       if (cfg->loss != CRUX_LOSS_REINFORCE) for (int k = 0; k < ad; ++k) gx[k] += -cfg->lambda_e; }
-    info[CRUX_INFO_LOSS] = cfg->loss == CRUX_LOSS_REINFORCE ? p_loss : cfg->lambda_p * p_loss + cfg->lambda_e * e_loss;   /* ppo.jl:20, a2c.jl:14, reinforce.jl:12 */
+    info[CRUX_INFO_LOSS] = cfg->loss == CRUX_LOSS_REINFORCE ? p_loss : (bc ? 1.f : cfg->lambda_p) * p_loss + cfg->lambda_e * e_loss;   /* ppo.jl:20, a2c.jl:14, reinforce.jl:12 */
     info[CRUX_INFO_ENTROPY] = entropy; info[CRUX_INFO_KL] = (float)(sum_kl / (double)n);
     info[CRUX_INFO_CLIP_FRACTION] = (float)nclip / (float)n; info[CRUX_INFO_AVG_ADVANTAGE] = (float)(sum_adv / (double)n);
     info[CRUX_INFO_AVG_RETURN] = (float)(sum_ret / (double)n);

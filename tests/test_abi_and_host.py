@@ -75,3 +75,24 @@ def test_shard_helpers():
     with pytest.raises(ValueError):
         dist.partition_envs(10, 4, 0)
     assert len({dist.shard_seed(0, r) for r in range(8)}) == 8
+
+
+def test_bson_buffer_round_trip_host_side(tmp_path):
+    """crux.jl_amd/bson.py: writer -> reader round trip of the ExperienceBuffer dump layout (no GPU: a stand-in object with the buffer's host interface)."""
+    from crux_jl_amd import bson
+    rng = np.random.default_rng(0); n = 37
+
+    class FakeBuf:
+        next_ind = 1
+        cols = {"s": rng.normal(0, 1, (4, n)).astype(np.float32), "a": np.eye(2, dtype=bool)[:, rng.integers(0, 2, n)], "sp": rng.normal(0, 1, (4, n)).astype(np.float32),
+                "r": np.ones((1, n), np.float32), "done": rng.random((1, n)) < 0.1, "t": np.arange(1, n + 1, dtype=np.int64)[None, :]}
+        extra = {"expert_val": rng.normal(0, 1, (1, n)).astype(np.float32)}
+        def __len__(self): return n
+        def keys(self): return list(self.cols)
+        def __getitem__(self, k): return self.cols[k]
+    fb = FakeBuf(); path = str(tmp_path / "buf.bson")
+    bson.save_buffer(fb, path)
+    cols, meta = bson.read_columns(path)
+    assert meta["elements"] == n and meta["next_ind"] == 1 and meta["priority_params"] is None
+    for k, v in {**fb.cols, **fb.extra}.items():
+        assert cols[k].dtype == v.dtype and np.array_equal(cols[k], v), k

@@ -434,3 +434,35 @@ def test_dpg_oracle_gradients_match_finite_differences():
     done = ob["done"][0]; assert np.array_equal(yt[done], ob["r"][0][done])
     sa = np.vstack([ob["sp"], oa.forward(ob["sp"])]).astype(np.float32)
     assert np.abs(yt - (ob["r"][0] + np.float32(0.9) * (1 - done) * q.forward(sa)[0])).max() < 1e-5
+
+
+@pytest.mark.parametrize("case", ["logpdf_categorical", "logpdf_gaussian", "mse_action"])
+def test_bc_losses_vs_float64_autograd(case):
+    """logpdf_bc_loss / mse_action_loss (src/model_free/il/bc.jl:1-18) of the oracle vs torch float64 autograd of the reference formulas."""
+    rng = np.random.default_rng(21); n, acts = 40, ["tanh", "relu", "identity"]
+    disc = case == "logpdf_categorical"; ad = 3 if disc else 2; dims = [4, 16, 16, ad]
+    nx = ad if case == "logpdf_gaussian" else 0
+    o = O.OMlp(dims, acts, nx).init_glorot(6, 0, -0.2); o.params[:] += 0.05 * rng.standard_normal(o.n).astype(np.float32)
+    ob = O.OBuffer(4, ad, L.ACTION_DISCRETE if disc else L.ACTION_CONTINUOUS, n)          # no logprob / advantage / return columns: BC reads only s and a
+    d = {"s": rng.standard_normal((4, n)).astype(np.float32), "sp": rng.standard_normal((4, n)).astype(np.float32), "r": np.zeros((1, n), np.float32), "done": np.zeros((1, n), bool)}
+    if disc:
+        a = np.zeros((ad, n), np.bool_); a[rng.integers(0, ad, n), np.arange(n)] = True; d["a"] = a
+    else:
+        d["a"] = rng.standard_normal((ad, n)).astype(np.float32)
+    ob.push(d)
+    ids = np.arange(n, dtype=np.int64); info = np.zeros(L.INFO_N, np.float32)
+    cfg = _cfg("mse_action" if case == "mse_action" else "logpdf_bc", "categorical" if disc else ("gaussian" if nx else "deterministic"), lp=0.3, le=0.05)
+    O.chk(lib.orc_loss_grad(o.h, ob.h, C.byref(cfg), O.vpz(ids), n, O.vpz(info)))
+    p = _torch_net(o); z, off = _fwd(p, dims, acts, torch.tensor(d["s"], dtype=torch.float64)); a = torch.tensor(d["a"], dtype=torch.float64)
+    if case == "mse_action":
+        total = ((z - a) ** 2).mean()
+    else:
+        if disc:
+            pr = torch.softmax(z, 0); lp = torch.log((pr * a).sum(0)); ent = (-(pr * torch.log(pr + float(np.finfo(np.float32).eps))).sum(0)).mean()
+        else:
+            ls = p[off:off + ad]; s2 = torch.exp(ls) ** 2
+            lp = (-((a - z) ** 2) / (2 * s2[:, None]) - 0.9189385332046727 - ls[:, None]).sum(0); ent = 1.4189385332046727 + ls.sum()
+        total = 0.05 * (-ent) + (-lp.mean())                                          # lambda_p is not part of logpdf_bc_loss
+    total.backward()
+    assert abs(info[0] - total.item()) < 1e-5 * max(1, abs(total.item()))
+    assert np.abs(o.grads - p.grad.numpy()).max() < 2e-6 * max(1, np.abs(p.grad.numpy()).max())
