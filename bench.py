@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sync", action="store_true", help="exercise the multi-GPU parameter exchange even at world size 1 (testing)")
+    ap.add_argument("--replicas", type=int, default=48, help="also time S independent PPO learners (multi-seed) trained by two batched launches per iteration: the chip-level utilisation line (0 = skip)")
     ap.add_argument("--early-stop", action="store_true", help="also time the KL-early-stopping variant (target_kl=0.012)")
     args = ap.parse_args()
 
@@ -208,6 +209,33 @@ def main():
         ctx.sync(); d1 = time.perf_counter() - t1
         early = {"env_steps_per_s": args.steps * N_ENVS * T / d1, "grad_steps_per_s": nbs / d1, "grad_steps_per_iter": nbs / args.steps}
 
+    multi = None
+    if args.replicas > 1 and world == 1:
+      try:
+          Sn = args.replicas
+          probs = [build_problem(crux, cdist.shard_seed(1000, r)) for r in range(Sn)]
+          am = crux.TrainingParams(loss=crux.ppo_loss, batch_size=BATCH, epochs=EPOCHS, target_kl=None, name="actor_", shuffle_seed=5000)
+          cm = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=BATCH, epochs=EPOCHS, name="critic_", shuffle_seed=6000)
+
+          def multi_iteration(k):
+              for (pi_r, buf_r, smp_r) in probs:                                   # rollouts + GAE + whiten per replica (4.7 ms each, one stream)
+                  crux.steps_(smp_r, buf_r, Nsteps=buf_r.capacity, explore=True, i=k * buf_r.capacity, reset=True); crux.whiten_(buf_r, "advantage")
+              infos = crux.policy_gradient_training_multi([q[0] for q in probs], am, cm, P, [q[1] for q in probs])
+              return sum(i["actor_batches_trained"] + i["critic_batches_trained"] for i in infos)
+          multi_iteration(0); ctx.sync(); ctx.prof_reset(); ctx.prof_enable(True); t1 = time.perf_counter(); gsm = 0
+          n_it = max(1, min(args.steps, 2))
+          for k in range(n_it):
+              gsm += multi_iteration(1 + k)
+          ctx.sync(); d1 = time.perf_counter() - t1; ctx.prof_enable(False)
+          ms_a, n_a = ctx.prof_get("train_actor")
+          flops_a = Sn * EPOCHS * (N_ENVS * T // BATCH) * FLOP_ACTOR_STEP            # per batched actor launch
+          multi = {"replicas": Sn, "env_steps_per_s": n_it * Sn * N_ENVS * T / d1, "grad_steps_per_s": gsm / d1, "ms_per_iteration": 1e3 * d1 / n_it,
+                   "batched_actor_launch_ms": ms_a / max(1, n_a), "actor_launch_TFLOPs": flops_a / (ms_a / max(1, n_a) * 1e-3) / 1e12,
+                   "actor_launch_frac_of_f32_mfma_peak": flops_a / (ms_a / max(1, n_a) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                   "note": "S independent PPO problems (own envs, buffers, seeds); all S actors in one launch, all S critics in a concurrent one: 4 S CUs busy"}
+      except Exception as e:      # supplementary line: never let it take the headline measurement down
+        multi = {"replicas": args.replicas, "error": repr(e)}
+
     if rank == 0:
         env_steps = args.steps * N_ENVS * T * world
         ms_actor, n_actor = prof["train_actor"]
@@ -236,6 +264,8 @@ def main():
         }
         if early:
             out["early_stop"] = early
+        if multi is not None:
+            out["multi_seed"] = multi
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

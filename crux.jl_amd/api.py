@@ -900,6 +900,25 @@ def policy_gradient_training(solver, D, perms_a=None, perms_c=None):
     return info
 
 
+def policy_gradient_training_multi(pis, a_opt, c_opt, P, buffers):
+    """policy_gradient_training (src/model_free/on_policy.jl:56-78) for several independent ActorCritic / buffer pairs of equal shape (multi-seed or
+    population training) as two batched launches; replica i shuffles with shuffle_seed + i. Returns one info dict per replica."""
+    n = len(pis); ctx = buffers[0].ctx
+    for pi in pis:
+        _ensure_opt(actor(pi), a_opt); _ensure_opt(critic(pi), c_opt)
+    ca, cc = _train_cfg(actor(pis[0]), a_opt, P), _train_cfg(critic(pis[0]), c_opt, P)
+    ha = (C.c_void_p * n)(*[actor(pi).h for pi in pis]); hc = (C.c_void_p * n)(*[critic(pi).h for pi in pis]); hb = (C.c_void_p * n)(*[b.h for b in buffers])
+    ra, rc_ = np.zeros((n, L.INFO_N), np.float32), np.zeros((n, L.INFO_N), np.float32)
+    ctx.check(ctx.lib.crux_policy_gradient_training_multi(n, ha, hc, hb, C.byref(ca), C.byref(cc), _vp(ra), _vp(rc_)))
+    a_opt.shuffle_counter += int(ra[0, L.INFO["epochs_run"]]); c_opt.shuffle_counter += int(rc_[0, L.INFO["epochs_run"]])
+    out = []
+    for i in range(n):
+        d = _info_dict(a_opt, ra[i]); d.update({k: v for k, v in _info_dict(c_opt, rc_[i]).items() if k.startswith(c_opt.name)})
+        d[a_opt.name + "batches_trained"] = int(ra[i, L.INFO["batches_trained"]]); d[c_opt.name + "batches_trained"] = int(rc_[i, L.INFO["batches_trained"]])
+        out.append(d)
+    return out
+
+
 def solve(solver, mdp):
     """POMDPs.solve(S::OnPolicySolver, mdp) (src/model_free/on_policy.jl:80-109), logging left out (SURVEY #14)."""
     if solver.buffer is None:

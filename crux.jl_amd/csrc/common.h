@@ -26,6 +26,7 @@ struct crux_ctx {
   void* scratch = nullptr; size_t scratch_bytes = 0;   // reusable device scratch
   void* pinned = nullptr; size_t pinned_bytes = 0;     // reusable pinned host staging
   hipStream_t aux_stream = nullptr; hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr;   // second learner stream (actor || critic)
+  void* xmulti[2] = {nullptr, nullptr}; size_t xmulti_bytes[2] = {0, 0};   // exchange areas + argument blocks of the batched multi-learner launch
   void* xbuf[2] = {nullptr, nullptr};   // gradient exchange areas of the two-CU learner kernel, one per learner stream
 };
 

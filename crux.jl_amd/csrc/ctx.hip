@@ -83,7 +83,7 @@ int32_t crux_ctx_destroy(crux_ctx* c) {
   for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
   for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (c->scratch) (void)hipFree(c->scratch);
-  for (int k = 0; k < 2; ++k) if (c->xbuf[k]) (void)hipFree(c->xbuf[k]);
+  for (int k = 0; k < 2; ++k) { if (c->xbuf[k]) (void)hipFree(c->xbuf[k]); if (c->xmulti[k]) (void)hipFree(c->xmulti[k]); }
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->aux_ev0); (void)hipEventDestroy(c->aux_ev1); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);

@@ -10,6 +10,7 @@
 
 int32_t crux_buffer_apply_order(crux_buffer* b, const int32_t* d_order, int64_t n);
 int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream);
+int32_t crux_train_mfma_x2_launch_multi(crux_ctx* c, std::vector<TrainArgs>& as, bool* handled, hipStream_t stream);   // train_mfma_x2.hip
 
 #define TR_CH 32
 #define EPS32F 1.1920928955078125e-07f
@@ -474,6 +475,64 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   // the critic's final order already contains the actor's shuffles: one physical permutation leaves the buffer as the reference would
   if (stc[2] < 1) return CRUX_OK;
   return crux_buffer_apply_order(buf, k.ord_all ? k.ord_all + (size_t)(stc[2] - 1) * (size_t)len : (stc[3] ? buf->order_d : buf->order_c), len);
+}
+
+// policy_gradient_training for n independent (actor, critic, buffer) triples in TWO launches (all actors, all critics): multi-seed / population
+// training, the way the serially dependent learner fills the chip (each learner occupies two CUs). Same exactness conditions as the single call.
+extern "C" int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* const* actors, crux_mlp* const* critics, crux_buffer* const* bufs, const crux_train_cfg* cfg_a,
+                                                       const crux_train_cfg* cfg_c, float* info_a, float* info_c) {
+  if (n < 1 || !actors || !critics || !bufs || !cfg_a || !cfg_c) return CRUX_EINVAL;
+  crux_ctx* c = actors[0]->ctx;
+  if (!(cfg_a->target_kl < 0.f) || cfg_a->max_batches > 0 || cfg_c->max_batches > 0) return crux_fail(c, CRUX_EUNSUP, "policy_gradient_training_multi: early stopping / max_batches need the sequential single-learner call");
+  if (cfg_a->epochs < 1 || cfg_c->epochs < 1) return crux_fail(c, CRUX_EINVAL, "policy_gradient_training_multi: epochs < 1");
+  if (!c->aux_stream) {
+    int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+    if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi_p) != hipSuccess) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev1, hipEventDisableTiming));
+  }
+  const size_t ea = sizeof(float) * CRUX_INFO_N * (size_t)cfg_a->epochs, ec = sizeof(float) * CRUX_INFO_N * (size_t)cfg_c->epochs;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t stride = 512 + al(ea) + al(ec);
+  char* sc = (char*)crux_scratch(c, stride * (size_t)n + 256); if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_gradient_training_multi: scratch");
+  HIPCHK(c, hipMemsetAsync(sc, 0, stride * (size_t)n, c->stream));
+  std::vector<TrainArgs> as((size_t)n), ks((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    if (!actors[i] || !critics[i] || !bufs[i] || bufs[i]->elements <= 0) return crux_fail(c, CRUX_EINVAL, "policy_gradient_training_multi: replica %d is incomplete", i);
+    crux_train_cfg ca = *cfg_a, cc = *cfg_c; ca.shuffle_seed += (uint64_t)i; cc.shuffle_seed += (uint64_t)i;     // every replica shuffles with its own stream
+    int32_t rc = fill_args(as[i], actors[i], bufs[i], &ca, ca.loss); if (rc) return rc;
+    rc = fill_args(ks[i], critics[i], bufs[i], &cc, cc.loss); if (rc) return rc;
+    if (bufs[i]->elements != bufs[0]->elements || as[i].nd.n_params != as[0].nd.n_params || ks[i].nd.n_params != ks[0].nd.n_params) return crux_fail(c, CRUX_EINVAL, "policy_gradient_training_multi: replicas must have equal shapes");
+    char* s0 = sc + stride * (size_t)i;
+    as[i].status = (int32_t*)s0; ks[i].status = (int32_t*)(s0 + 256); as[i].epoch_infos = (float*)(s0 + 512); ks[i].epoch_infos = (float*)(s0 + 512 + al(ea));
+    ks[i].order_a = bufs[i]->order_c; ks[i].order_b = bufs[i]->order_d;
+    int32_t* oa = nullptr; int32_t* oc = nullptr; const int64_t len = bufs[i]->elements;
+    rc = build_orders(c, bufs[i], 0, nullptr, ca.shuffle_seed, ca.shuffle_counter, nullptr, ca.epochs, c->stream, &oa); if (rc) return rc;
+    rc = build_orders(c, bufs[i], 1, oa + (size_t)(ca.epochs - 1) * (size_t)len, cc.shuffle_seed, cc.shuffle_counter, nullptr, cc.epochs, c->stream, &oc); if (rc) return rc;
+    as[i].ord_all = oa; ks[i].ord_all = oc;
+  }
+  HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
+  bool handled = false;
+  int32_t rc = crux_train_mfma_x2_launch_multi(c, ks, &handled, c->aux_stream); if (rc) return rc;
+  if (!handled) return crux_fail(c, CRUX_EUNSUP, "policy_gradient_training_multi: no batched kernel for this network family / batch size");
+  HIPCHK(c, hipEventRecord(c->aux_ev1, c->aux_stream));
+  crux_prof_begin(c, CRUX_PROF_TRAIN_ACTOR);
+  rc = crux_train_mfma_x2_launch_multi(c, as, &handled, c->stream); if (rc) return rc;
+  crux_prof_end(c, CRUX_PROF_TRAIN_ACTOR);
+  if (!handled) return crux_fail(c, CRUX_EUNSUP, "policy_gradient_training_multi: no batched kernel for the actor family");
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
+  std::vector<int32_t> fin((size_t)n);
+  for (int i = 0; i < n; ++i) {   // read every status row first: crux_buffer_apply_order below may regrow the scratch block these rows live in
+    int32_t sta[4], stc[4];
+    rc = collect(c, as[i], cfg_a->epochs, info_a ? info_a + (size_t)i * CRUX_INFO_N : nullptr, nullptr, sta); if (rc) return rc;
+    rc = collect(c, ks[i], cfg_c->epochs, info_c ? info_c + (size_t)i * CRUX_INFO_N : nullptr, nullptr, stc); if (rc) return rc;
+    if (sta[0] == CRUX_ENAN || stc[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20) in replica %d", i);
+    if (sta[0] || stc[0]) return crux_fail(c, sta[0] ? sta[0] : stc[0], "learner kernel reported status %d/%d in replica %d", sta[0], stc[0], i);
+    fin[(size_t)i] = stc[2];
+  }
+  for (int i = 0; i < n; ++i)
+    if (fin[(size_t)i] >= 1) { rc = crux_buffer_apply_order(bufs[i], ks[i].ord_all + (size_t)(fin[(size_t)i] - 1) * (size_t)bufs[i]->elements, bufs[i]->elements); if (rc) return rc; }
+  return CRUX_OK;
 }
 
 // ---- off-policy pieces ------------------------------------------------------------------------------

@@ -54,13 +54,16 @@ struct MfxLayout {
 };
 
 template <int IN, int OUT, int KIND, int ACT, bool TIMING = false>
-__global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
+__global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const TrainArgs* __restrict__ multi) {
+  // multi != NULL: a batch of independent learners (multi-seed / population training) in one launch; replica r = blockIdx / 16 uses the
+  // workgroups 16r and 16r + 8 (one XCD) and its own argument block, exchange area and status row
+  const TrainArgs a = multi ? multi[blockIdx.x >> 4] : a_single;
   using Lt = MfxLayout<IN, OUT>;
   static_assert(Lt::TOTAL <= 40960, "LDS budget (160 KB) exceeded");
   constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS;
   constexpr int NACT = (OUT > 4 ? OUT : 4);
   constexpr int NT = 64 * MF8_NW;
-  if (blockIdx.x & 7) return;                       // only blockIdx 0 and 8 work: same XCD, shared L2
+  if ((blockIdx.x & 7) != ((blockIdx.x >> 4) & 7)) return;   // learner r works in blocks 16r + (r%8) and 16r + (r%8) + 8: same XCD for the pair, consecutive learners on consecutive XCDs
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
   float* part = sm + Lt::oPART + w * Lt::PART;
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a) {
   const int t_wr = (4 * g) * 16 + 4 * ((c >> 2) ^ tx_h(g)) + (c & 3);   // tile element (feature 4g [+16m+r], sample c)
   const int t_rd = c * 16 + 4 * (g ^ tx_h(c >> 2));                   // tile b128 (feature c [+16m], samples 4g..4g+3)
   const int mp0 = w; constexpr int m0 = 0;         // dW2 / W2 ownership: the four tiles (mp0 = w, m = 0..3) = rows [16w, 16w+16)
-  const int p = blockIdx.x >> 3;                    // workgroup 0 or 1 (blockIdx 0 / 8)
+  const int p = (blockIdx.x >> 3) & 1;              // workgroup 0 or 1 of this learner (blockIdx 16r / 16r + 8)
 
   auto s_master = [&](int s) -> int {
     if (s < Lt::sB1) { const int o = s & 63, i = s >> 6; return Lt::oW1R + o * Lt::W1LD + i; }
@@ -585,8 +588,51 @@ static int32_t launch_x2(crux_ctx* c, TrainArgs a, hipStream_t stream) {
   if (!c->xbuf[which]) { if (hipMalloc(&c->xbuf[which], xbytes) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "learner exchange buffer"); }
   a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * 4 * 8192);
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
-  hipLaunchKernelGGL((k_train_mfma_x2<IN, OUT, KIND, ACT, TIMING>), dim3(16), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((k_train_mfma_x2<IN, OUT, KIND, ACT, TIMING>), dim3(16), dim3(256), lds, stream, a, (const TrainArgs*)nullptr);
   return crux_launch_check(c, "k_train_mfma_x2");
+}
+
+// n independent learners in one launch (grid 16 n): argument blocks uploaded to a per-stream device array, one exchange area each
+template <int IN, int OUT, int KIND, int ACT>
+static int32_t launch_x2_multi(crux_ctx* c, std::vector<TrainArgs>& as, hipStream_t stream) {
+  using Lt = MfxLayout<IN, OUT>;
+  constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
+  static bool attr = false;
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma_x2<IN, OUT, KIND, ACT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  const int which = stream == c->stream ? 0 : 1; const size_t n = as.size();
+  constexpr size_t xbytes = sizeof(float) * 4 * 8192 + 256;
+  const size_t need = n * xbytes + n * sizeof(TrainArgs) + 256;
+  if (c->xmulti_bytes[which] < need) {
+    if (c->xmulti[which]) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(c->xmulti[which]); c->xmulti[which] = nullptr; c->xmulti_bytes[which] = 0; }
+    if (hipMalloc(&c->xmulti[which], need) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "multi-learner exchange area (%zu bytes)", need);
+    c->xmulti_bytes[which] = need;
+  }
+  char* base = (char*)c->xmulti[which];
+  for (size_t i = 0; i < n; ++i) { as[i].xbuf = (float*)(base + i * xbytes); as[i].xctr = (unsigned*)(base + i * xbytes + sizeof(float) * 4 * 8192);
+    HIPCHK(c, hipMemsetAsync(as[i].xctr, 0, 256, stream)); }
+  TrainArgs* d_args = (TrainArgs*)(base + n * xbytes);
+  HIPCHK(c, hipMemcpyAsync(d_args, as.data(), n * sizeof(TrainArgs), hipMemcpyHostToDevice, stream));
+  HIPCHK(c, hipStreamSynchronize(stream));      // `as` is pageable host memory: the copy must have left it before the caller's vector can change
+  hipLaunchKernelGGL((k_train_mfma_x2<IN, OUT, KIND, ACT, false>), dim3((unsigned)(16 * n)), dim3(256), lds, stream, as[0], (const TrainArgs*)d_args);
+  return crux_launch_check(c, "k_train_mfma_x2 (multi)");
+}
+
+int32_t crux_train_mfma_x2_launch_multi(crux_ctx* c, std::vector<TrainArgs>& as, bool* handled, hipStream_t stream) {
+  *handled = false;
+  if (as.empty() || !x2_placement_ok(c)) return CRUX_OK;
+  const TrainArgs& a = as[0];
+  const NetDesc& nd = a.nd;
+  if (nd.L != 3 || nd.dims[1] != MF_HID || nd.dims[2] != MF_HID || nd.acts[2] != CRUX_ACT_IDENTITY || nd.acts[0] != nd.acts[1] || a.ids || !a.apply || a.bs <= 64 || a.bs > 128 || a.len < a.bs) return CRUX_OK;
+  const int in = nd.dims[0], out = nd.dims[3], act = nd.acts[0];
+  const int kind = a.loss == CRUX_LOSS_VALUE_MSE ? MFK_VALUE : (a.head == CRUX_HEAD_CATEGORICAL ? MFK_CATEGORICAL : (a.head == CRUX_HEAD_GAUSSIAN ? MFK_GAUSSIAN : -1));
+  if (!(a.loss == CRUX_LOSS_VALUE_MSE || CRUX_IS_PG(a.loss)) || kind < 0) return CRUX_OK;
+#define MFXM_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_x2_multi<I, O, K, A_>(c, as, stream); }
+  MFXM_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)
+  MFXM_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)
+  MFXM_CASE(17, 6, MFK_GAUSSIAN, CRUX_ACT_TANH)
+  MFXM_CASE(17, 1, MFK_VALUE, CRUX_ACT_TANH)
+#undef MFXM_CASE
+  return CRUX_OK;
 }
 
 // Called by crux_train_mfma_launch after its shape checks, before the single-CU kernels.

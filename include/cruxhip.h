@@ -272,6 +272,11 @@ int32_t crux_batch_train(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* 
 int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* critic, crux_buffer* buf, const crux_train_cfg* cfg_actor,
                                       const crux_train_cfg* cfg_critic, const int64_t* perms_actor, const int64_t* perms_critic,
                                       float* info_actor, float* info_critic, float* epoch_infos_actor, float* epoch_infos_critic);
+/* The same for n independent (actor, critic, buffer) triples of equal shape -- multi-seed / population training -- as two batched launches
+ * (all critics || all actors; each learner on two CUs, consecutive learners on consecutive XCDs). Replica i shuffles with seed + i.
+ * Requires target_kl < 0 and max_batches = 0 (the exact-overlap condition). info_a / info_c: host [n x CRUX_INFO_N] or NULL.            */
+int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* const* actors, crux_mlp* const* critics, crux_buffer* const* bufs,
+                                            const crux_train_cfg* cfg_actor, const crux_train_cfg* cfg_critic, float* info_a, float* info_c);
 
 /* train!(pi, loss, p) (training.jl:13-25): one gradient step on explicit rows `ids` (host, 0-based)
  * of the buffer. Returns CRUX_ENAN (without updating) when the grad norm is NaN (:20).            */

@@ -61,3 +61,47 @@ def test_a2c_and_reinforce_solve_match_oracle_loop(gpu_ctx, algo):
     if algo == "a2c":
         assert np.abs(gc.get_params() - oc.params).max() < 2e-4
     assert np.isfinite(solver.history[-1]["actor_loss"]) and "kl" in solver.history[-1]
+
+
+def test_multi_seed_batched_learners_match_single_calls(gpu_ctx):
+    """crux_policy_gradient_training_multi: n independent learners in two batched launches == n single calls with the per-replica seeds (bit for bit:
+    same kernel, same arithmetic; only the launch geometry differs)."""
+    from parity import crux
+    rng = np.random.default_rng(4); n_rep, n, bs = 5, 512, 128
+    extras = ["return", "logprob", "advantage"]
+    def make(seed):
+        a = crux.DiscreteNetwork(parity.chain(parity.ACTOR_DIMS, parity.ACTS), [1, 2], seed=seed, stream=0)
+        c = crux.ContinuousNetwork(parity.chain(parity.CRITIC_DIMS, parity.ACTS), seed=seed, stream=1)
+        return crux.ActorCritic(a, c)
+    datas = []
+    for r in range(n_rep):
+        ai = rng.integers(0, 2, n)
+        datas.append({"s": rng.normal(0, 1, (4, n)).astype(np.float32), "a": np.eye(2, dtype=bool)[:, ai], "sp": rng.normal(0, 1, (4, n)).astype(np.float32), "r": np.ones((1, n), np.float32),
+                      "done": np.zeros((1, n), bool), "episode_end": np.zeros((1, n), bool), "return": rng.normal(0, 1, (1, n)).astype(np.float32),
+                      "logprob": rng.normal(-0.7, 0.05, (1, n)).astype(np.float32), "advantage": rng.normal(0, 1, (1, n)).astype(np.float32)})
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+    def run(multi):
+        pis = [make(50 + r) for r in range(n_rep)]
+        bufs = [crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), n, extras) for _ in range(n_rep)]
+        for b, d in zip(bufs, datas):
+            b.push_(d)
+        if multi:
+            a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=bs, epochs=3, name="actor_", shuffle_seed=900)
+            c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=bs, epochs=3, name="critic_", shuffle_seed=950)
+            infos = crux.policy_gradient_training_multi(pis, a_opt, c_opt, P, bufs)
+        else:
+            infos = []
+            for r in range(n_rep):
+                class _S:
+                    pass
+                sv = _S(); sv.agent = crux.PolicyParams(pis[r]); sv.P = P
+                sv.a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=bs, epochs=3, name="actor_", shuffle_seed=900 + r)
+                sv.c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=bs, epochs=3, name="critic_", shuffle_seed=950 + r)
+                infos.append(crux.policy_gradient_training(sv, bufs[r]))
+        return [(pi.A.get_params(), pi.C.get_params()) for pi in pis], [b["s"] for b in bufs], infos
+    pm, sm_, im = run(True); ps, ss, is_ = run(False)
+    for r in range(n_rep):
+        assert np.array_equal(pm[r][0], ps[r][0]) and np.array_equal(pm[r][1], ps[r][1]), r
+        assert np.array_equal(sm_[r], ss[r])                                              # the buffers end up in the same (reference) row order
+        assert im[r]["actor_loss"] == is_[r]["actor_loss"] and im[r]["critic_loss"] == is_[r]["critic_loss"]
+    assert not np.array_equal(pm[0][0], pm[1][0])
