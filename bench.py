@@ -218,8 +218,9 @@ def main():
           cm = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=BATCH, epochs=EPOCHS, name="critic_", shuffle_seed=6000)
 
           def multi_iteration(k):
-              for (pi_r, buf_r, smp_r) in probs:                                   # rollouts + GAE + whiten per replica (4.7 ms each, one stream)
-                  crux.steps_(smp_r, buf_r, Nsteps=buf_r.capacity, explore=True, i=k * buf_r.capacity, reset=True); crux.whiten_(buf_r, "advantage")
+              crux.steps_multi_([q[2] for q in probs], [q[1] for q in probs], Nsteps=probs[0][1].capacity, explore=True, i=k * probs[0][1].capacity, reset=True)   # one rollout launch for all S problems
+              for (pi_r, buf_r, smp_r) in probs:
+                  crux.whiten_(buf_r, "advantage")
               infos = crux.policy_gradient_training_multi([q[0] for q in probs], am, cm, P, [q[1] for q in probs])
               return sum(i["actor_batches_trained"] + i["critic_batches_trained"] for i in infos)
           multi_iteration(0); ctx.sync(); ctx.prof_reset(); ctx.prof_enable(True); t1 = time.perf_counter(); gsm = 0

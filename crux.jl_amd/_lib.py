@@ -99,6 +99,7 @@ SIGNATURES = {
     "crux_loss_grad": (i32, [vp, vp, P(TrainCfg), vp, i64, vp]),
     "crux_loss_grad_device_ids": (i32, [vp, vp, P(TrainCfg), vp, i64, vp]),
     "crux_adam_apply": (i32, [vp, f32]),
+    "crux_rollout_multi": (i32, [i32, vp, vp, P(RolloutCfg), vp, i64, vp, vp]),
     "crux_policy_gradient_training_multi": (i32, [i32, vp, vp, vp, P(TrainCfg), P(TrainCfg), vp, vp]),
     "crux_first_episode_metrics": (i32, [vp, i32, i64, f32, vp, vp, vp, vp]),
     "crux_dqn_target": (i32, [vp, vp, f32, vp]),

@@ -755,6 +755,26 @@ def failure(sampler, threshold=0.0, Neps=100, **kw):
     return float(np.mean(episodes_(sampler, Neps=Neps, **kw)[1]["undiscounted"] < threshold))
 
 
+def steps_multi_(samplers, buffers, Nsteps=1, explore=False, i=0, reset=False):
+    """steps! for several independent samplers of equal shape in one launch (the rollout half of a multi-seed run); GAE / returns are then
+    filled per buffer exactly as steps_ does. Returns one info dict per sampler."""
+    s0 = samplers[0]; E = s0.n_envs; n = len(samplers)
+    if Nsteps % E:
+        raise ValueError("steps!: Nsteps=%d is not a multiple of n_envs=%d" % (Nsteps, E))
+    cfg, _ = _rollout_cfg(s0, explore, reset, i)
+    he = (C.c_void_p * n)(*[s.h for s in samplers]); hp = (C.c_void_p * n)(*[actor(s.agent.pi).h for s in samplers]); hb = (C.c_void_p * n)(*[b.h for b in buffers])
+    sr, ne = np.zeros(n, np.float64), np.zeros(n, np.int64)
+    s0.ctx.check(s0.ctx.lib.crux_rollout_multi(n, he, hp, C.byref(cfg), hb, Nsteps // E, _vp(sr), _vp(ne)))
+    out = []
+    for k, (s, b) in enumerate(zip(samplers, buffers)):
+        if b.haskey("advantage") and len(b) == Nsteps:
+            fill_gae_(b, critic(s.agent.pi), s.lam, s.gamma)
+        if b.haskey("return") and len(b) == Nsteps:
+            fill_returns_(b, s.gamma)
+        out.append({"sum_r": float(sr[k]), "n_episode_end": int(ne[k]), "avg_r": float(sr[k] / ne[k]) if ne[k] else float("nan")})
+    return out
+
+
 def fill_gae_(buffer, V, lam, gamma):
     """fill_gae!(d::ExperienceBuffer, V, lambda, gamma) (src/sampler.jl:255-273)."""
     buffer.ctx.check(buffer.ctx.lib.crux_fill_gae(buffer.h, critic(V).h, float(lam), float(gamma)))

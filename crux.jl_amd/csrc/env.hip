@@ -203,9 +203,11 @@ __device__ __forceinline__ float env_wave_sum_uniform(float v) {      // the sam
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a0 + b0)));
 }
 template <int IN, int OUT, int ACT, int KIND>
-__global__ __launch_bounds__(64) void k_rollout_h64(RolloutArgs a) {
+__global__ __launch_bounds__(64) void k_rollout_h64(RolloutArgs a_single, const RolloutArgs* __restrict__ multi) {
   __shared__ __attribute__((aligned(16))) float sh[64];
-  const int e = blockIdx.x, lane = threadIdx.x;
+  // multi != NULL: the rollouts of several independent samplers (own policy, envs, buffer) in one launch; problem r = blockIdx / E
+  const RolloutArgs a = multi ? multi[blockIdx.x / a_single.E] : a_single;
+  const int e = multi ? (int)(blockIdx.x % a_single.E) : (int)blockIdx.x, lane = threadIdx.x;
   const NetDesc& nd = a.nd;
   constexpr int SD = KIND == CRUX_ENV_CARTPOLE ? 4 : 2;
   float w1[IN], w2[64], w3[OUT], b3[OUT];
@@ -347,6 +349,19 @@ static void env_dims(int kind, int so, int sa, int* obs, int* act, int* sd) {
   }
 }
 
+static void fill_rollout_args(RolloutArgs& a, crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg, crux_buffer* buf, int64_t T) {
+  a = RolloutArgs{};
+  a.nd = policy->nd; a.p = policy->p; a.kind = e->kind; a.E = e->n_envs; a.max_steps = e->max_steps; a.od = e->obs_dim; a.ad = e->act_dim; a.sd = e->state_dim;
+  a.act_kind = buf->act_kind; a.seed = e->seed; a.mu = e->mu; a.sigma = e->sigma; a.state = e->state; a.ep_len = e->ep_len; a.n_resets = e->n_resets;
+  a.steps_taken = e->steps_taken; a.svec = e->svec; a.acc = e->acc;
+  a.S = (float*)buf->col[CRUX_COL_S]; a.A = buf->col[CRUX_COL_A]; a.SP = (float*)buf->col[CRUX_COL_SP]; a.R = (float*)buf->col[CRUX_COL_R];
+  a.D = (uint8_t*)buf->col[CRUX_COL_DONE]; a.EE = (uint8_t*)buf->col[CRUX_COL_EPISODE_END];
+  a.LP = has_col(buf, CRUX_COL_LOGPROB) ? (float*)buf->col[CRUX_COL_LOGPROB] : nullptr; a.TT = has_col(buf, CRUX_COL_T) ? (int64_t*)buf->col[CRUX_COL_T] : nullptr;
+  a.II = has_col(buf, CRUX_COL_I) ? (int64_t*)buf->col[CRUX_COL_I] : nullptr; a.W = has_col(buf, CRUX_COL_WEIGHT) ? (float*)buf->col[CRUX_COL_WEIGHT] : nullptr;
+  a.RET = has_col(buf, CRUX_COL_RETURN) ? (float*)buf->col[CRUX_COL_RETURN] : nullptr; a.ADV = has_col(buf, CRUX_COL_ADVANTAGE) ? (float*)buf->col[CRUX_COL_ADVANTAGE] : nullptr;
+  a.base = buf->next_ind; a.C = buf->capacity; a.T = T; a.cfg = *cfg;
+}
+
 extern "C" {
 
 int32_t crux_env_create(crux_ctx* ctx, int32_t kind, int32_t n_envs, int32_t max_steps, float gamma, const float* obs_mu, const float* obs_sigma,
@@ -415,20 +430,11 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
   if ((cfg->head == CRUX_HEAD_GAUSSIAN || cfg->head == CRUX_HEAD_DETERMINISTIC) && (nout != e->act_dim || buf->act_kind != CRUX_ACTION_CONTINUOUS))
     return crux_fail(c, CRUX_EINVAL, "steps!: continuous head needs %d outputs and a Float32 action column", e->act_dim);
   if (cfg->head == CRUX_HEAD_GAUSSIAN && policy->nd.n_extra != e->act_dim) return crux_fail(c, CRUX_EINVAL, "steps!: GaussianPolicy needs %d logSigma extras", e->act_dim);
-  RolloutArgs a{};
-  a.nd = policy->nd; a.p = policy->p; a.kind = e->kind; a.E = e->n_envs; a.max_steps = e->max_steps; a.od = e->obs_dim; a.ad = e->act_dim; a.sd = e->state_dim;
-  a.act_kind = buf->act_kind; a.seed = e->seed; a.mu = e->mu; a.sigma = e->sigma; a.state = e->state; a.ep_len = e->ep_len; a.n_resets = e->n_resets;
-  a.steps_taken = e->steps_taken; a.svec = e->svec; a.acc = e->acc;
-  a.S = (float*)buf->col[CRUX_COL_S]; a.A = buf->col[CRUX_COL_A]; a.SP = (float*)buf->col[CRUX_COL_SP]; a.R = (float*)buf->col[CRUX_COL_R];
-  a.D = (uint8_t*)buf->col[CRUX_COL_DONE]; a.EE = (uint8_t*)buf->col[CRUX_COL_EPISODE_END];
-  a.LP = has_col(buf, CRUX_COL_LOGPROB) ? (float*)buf->col[CRUX_COL_LOGPROB] : nullptr; a.TT = has_col(buf, CRUX_COL_T) ? (int64_t*)buf->col[CRUX_COL_T] : nullptr;
-  a.II = has_col(buf, CRUX_COL_I) ? (int64_t*)buf->col[CRUX_COL_I] : nullptr; a.W = has_col(buf, CRUX_COL_WEIGHT) ? (float*)buf->col[CRUX_COL_WEIGHT] : nullptr;
-  a.RET = has_col(buf, CRUX_COL_RETURN) ? (float*)buf->col[CRUX_COL_RETURN] : nullptr; a.ADV = has_col(buf, CRUX_COL_ADVANTAGE) ? (float*)buf->col[CRUX_COL_ADVANTAGE] : nullptr;
-  a.base = buf->next_ind; a.C = buf->capacity; a.T = T; a.cfg = *cfg;
+  RolloutArgs a; fill_rollout_args(a, e, policy, cfg, buf, T);
   crux_prof_begin(c, CRUX_PROF_ROLLOUT);
   const NetDesc& pn = policy->nd;
   const bool h64 = pn.L == 3 && pn.dims[1] == 64 && pn.dims[2] == 64 && pn.acts[0] == pn.acts[1] && pn.acts[2] == CRUX_ACT_IDENTITY && !getenv("CRUX_FORCE_GENERIC");
-#define RO_CASE(I, O, A_, K) if (h64 && pn.dims[0] == I && nout == O && pn.acts[0] == A_ && e->kind == K) hipLaunchKernelGGL((k_rollout_h64<I, O, A_, K>), dim3(e->n_envs), dim3(64), 0, c->stream, a); else
+#define RO_CASE(I, O, A_, K) if (h64 && pn.dims[0] == I && nout == O && pn.acts[0] == A_ && e->kind == K) hipLaunchKernelGGL((k_rollout_h64<I, O, A_, K>), dim3(e->n_envs), dim3(64), 0, c->stream, a, (const RolloutArgs*)nullptr); else
   RO_CASE(4, 2, CRUX_ACT_RELU, CRUX_ENV_CARTPOLE)
   RO_CASE(4, 2, CRUX_ACT_TANH, CRUX_ENV_CARTPOLE)
   RO_CASE(3, 1, CRUX_ACT_RELU, CRUX_ENV_PENDULUM)
@@ -450,6 +456,45 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double sr = 0; int64_t ne = 0; for (int k = 0; k < e->n_envs; ++k) { sr += acc[2 * k]; ne += (int64_t)acc[2 * k + 1]; }
     if (sum_r) *sum_r = sr; if (n_episode_end) *n_episode_end = ne;
+  }
+  return CRUX_OK;
+}
+
+// steps! for n independent samplers of equal shape in ONE launch (multi-seed runs): problem r rolls out its own policy on its own environments into its own buffer
+int32_t crux_rollout_multi(int32_t n, crux_env* const* envs, crux_mlp* const* policies, const crux_rollout_cfg* cfg, crux_buffer* const* bufs, int64_t T, double* sum_r, int64_t* n_episode_end) {
+  if (n < 1 || !envs || !policies || !cfg || !bufs || T < 1) return CRUX_EINVAL;
+  crux_ctx* c = envs[0]->ctx; crux_env* e0 = envs[0]; const NetDesc& pn = policies[0]->nd; const int nout = pn.dims[pn.L];
+  const bool h64 = pn.L == 3 && pn.dims[1] == 64 && pn.dims[2] == 64 && pn.acts[0] == pn.acts[1] && pn.acts[2] == CRUX_ACT_IDENTITY;
+  if (!h64) return crux_fail(c, CRUX_EUNSUP, "steps! (multi): only the 64-wide register-resident rollout kernel is batched");
+  std::vector<RolloutArgs> as((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    crux_env* e = envs[i]; crux_buffer* b = bufs[i]; crux_mlp* p = policies[i];
+    if (!e || !b || !p || e->kind != e0->kind || e->n_envs != e0->n_envs || p->nd.n_params != pn.n_params || b->obs_dim != e->obs_dim || b->act_dim != e->act_dim || (int64_t)e->n_envs * T > b->capacity)
+      return crux_fail(c, CRUX_EINVAL, "steps! (multi): problem %d does not match problem 0 or its buffer is too small", i);
+    fill_rollout_args(as[(size_t)i], e, p, cfg, b, T);
+  }
+  const size_t bytes = sizeof(RolloutArgs) * (size_t)n;
+  RolloutArgs* d_args = (RolloutArgs*)crux_scratch(c, bytes + 256); if (!d_args) return crux_fail(c, CRUX_ENOMEM, "steps! (multi): scratch");
+  HIPCHK(c, hipMemcpyAsync(d_args, as.data(), bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+  const dim3 grid((unsigned)((size_t)n * (size_t)e0->n_envs));
+  crux_prof_begin(c, CRUX_PROF_ROLLOUT);
+  bool done = false;
+#define ROM_CASE(I, O, A_, K) if (!done && pn.dims[0] == I && nout == O && pn.acts[0] == A_ && e0->kind == K) { hipLaunchKernelGGL((k_rollout_h64<I, O, A_, K>), grid, dim3(64), 0, c->stream, as[0], (const RolloutArgs*)d_args); done = true; }
+  ROM_CASE(4, 2, CRUX_ACT_RELU, CRUX_ENV_CARTPOLE)
+  ROM_CASE(4, 2, CRUX_ACT_TANH, CRUX_ENV_CARTPOLE)
+  ROM_CASE(3, 1, CRUX_ACT_RELU, CRUX_ENV_PENDULUM)
+  ROM_CASE(3, 1, CRUX_ACT_TANH, CRUX_ENV_PENDULUM)
+#undef ROM_CASE
+  crux_prof_end(c, CRUX_PROF_ROLLOUT);
+  if (!done) return crux_fail(c, CRUX_EUNSUP, "steps! (multi): no batched rollout kernel for this policy / environment");
+  int32_t rc = crux_launch_check(c, "k_rollout_h64 (multi)"); if (rc) return rc;
+  for (int i = 0; i < n; ++i) { if (bufs[i]->prioritized) return crux_fail(c, CRUX_EUNSUP, "steps! (multi): prioritized buffers are not batched"); crux_buffer_ring_advance(bufs[i], (int64_t)envs[i]->n_envs * T); }
+  if (sum_r || n_episode_end) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) { std::vector<double> acc(2 * (size_t)envs[i]->n_envs);
+      HIPCHK(c, hipMemcpy(acc.data(), envs[i]->acc, 16 * (size_t)envs[i]->n_envs, hipMemcpyDeviceToHost));
+      double sr = 0; int64_t ne = 0; for (int k = 0; k < envs[i]->n_envs; ++k) { sr += acc[2 * k]; ne += (int64_t)acc[2 * k + 1]; }
+      if (sum_r) sum_r[i] = sr; if (n_episode_end) n_episode_end[i] = ne; }
   }
   return CRUX_OK;
 }

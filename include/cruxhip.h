@@ -201,6 +201,10 @@ typedef struct {
  * fill) run in one kernel. sum_r/n_episode_end feed record_avgr (ppo.jl:52-54).                 */
 int32_t crux_rollout(crux_env* env, crux_mlp* policy, const crux_rollout_cfg* cfg, crux_buffer* buf,
                      int64_t T, double* sum_r, int64_t* n_episode_end);
+/* steps! for n independent samplers of equal shape (own policy, environments, buffer, seed) in one launch -- the rollout half of a
+ * multi-seed run (see crux_policy_gradient_training_multi). sum_r / n_episode_end: host [n] or NULL.                               */
+int32_t crux_rollout_multi(int32_t n, crux_env* const* envs, crux_mlp* const* policies, const crux_rollout_cfg* cfg,
+                           crux_buffer* const* bufs, int64_t T, double* sum_r, int64_t* n_episode_end);
 
 /* test hook: apply the env dynamics once to explicit states/actions (host arrays):
  * state [state_dim x n] f64, action [act_dim x n] (Bool one-hot bytes or f32), uniforms [n] f64 for

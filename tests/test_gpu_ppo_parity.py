@@ -105,3 +105,27 @@ def test_multi_seed_batched_learners_match_single_calls(gpu_ctx):
         assert np.array_equal(sm_[r], ss[r])                                              # the buffers end up in the same (reference) row order
         assert im[r]["actor_loss"] == is_[r]["actor_loss"] and im[r]["critic_loss"] == is_[r]["critic_loss"]
     assert not np.array_equal(pm[0][0], pm[1][0])
+
+
+def test_batched_rollouts_match_single_rollouts(gpu_ctx):
+    """crux_rollout_multi == one crux_rollout per problem (same kernel; only the launch geometry differs): every column bit for bit."""
+    from parity import crux
+    n_rep, E, T = 3, 4, 48
+    def build():
+        out = []
+        for r in range(n_rep):
+            a = crux.DiscreteNetwork(parity.chain(parity.ACTOR_DIMS, parity.ACTS), [1, 2], seed=70 + r, stream=0)
+            c = crux.ContinuousNetwork(parity.chain(parity.CRITIC_DIMS, parity.ACTS), seed=70 + r, stream=1)
+            pi = crux.ActorCritic(a, c); extras = ["return", "logprob", "advantage"]
+            buf = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), E * T, extras)
+            smp = crux.Sampler(crux.CartPoleMDP(n_envs=E, seed=300 + r), pi, max_steps=30, required_columns=extras, lam=0.95)
+            out.append((pi, buf, smp))
+        return out
+    pa, pb = build(), build()
+    ia = crux.steps_multi_([q[2] for q in pa], [q[1] for q in pa], Nsteps=E * T, explore=True, i=0, reset=True)
+    ib = [crux.steps_(q[2], q[1], Nsteps=E * T, explore=True, i=0, reset=True) for q in pb]
+    for r in range(n_rep):
+        for k in pa[r][1].keys():
+            assert np.array_equal(pa[r][1][k], pb[r][1][k], equal_nan=True) if pa[r][1][k].dtype.kind == "f" else np.array_equal(pa[r][1][k], pb[r][1][k]), (r, k)
+        assert ia[r]["n_episode_end"] == ib[r]["n_episode_end"] and ia[r]["sum_r"] == ib[r]["sum_r"]
+    assert not np.array_equal(pa[0][1]["s"], pa[1][1]["s"])
