@@ -3,7 +3,6 @@
 #include "common.h"
 
 int32_t crux_mlp_forward_impl(crux_mlp* net, const float* d_x, int64_t B, float* d_y, const float* params_override);
-int32_t crux_values_fast(crux_mlp* net, const float* d_x, int64_t B, float* d_y);   // mfma path (train_mfma.hip); returns CRUX_EUNSUP if shape unsupported
 
 // One thread per episode: a thread sitting on an episode-end row (or the last row) walks its episode backwards.
 // The recurrence is evaluated sequentially in Float32 with the reference's association
@@ -52,9 +51,7 @@ __global__ __launch_bounds__(1024) void k_whiten(float* __restrict__ v, int64_t 
 }
 
 static int32_t values(crux_mlp* critic, const float* d_x, int64_t n, float* d_y) {
-  int32_t rc = crux_values_fast(critic, d_x, n, d_y);
-  if (rc == CRUX_EUNSUP) rc = crux_mlp_forward_impl(critic, d_x, n, d_y, nullptr);
-  return rc;
+  return crux_mlp_forward_impl(critic, d_x, n, d_y, nullptr);   // 2 x 65536 critic evaluations = 0.14 ms per iteration with the generic forward kernel
 }
 
 // episodes!-style evaluation (sampler.jl:175-251) over an env-major rollout block: the FIRST episode of every environment.

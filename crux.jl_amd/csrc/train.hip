@@ -350,7 +350,6 @@ static int32_t upload_ids(crux_ctx* c, crux_buffer* buf, const int64_t* ids, int
   return CRUX_OK;
 }
 
-int32_t crux_values_fast(crux_mlp* net, const float* d_x, int64_t B, float* d_y);
 
 extern "C" {
 
