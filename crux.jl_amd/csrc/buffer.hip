@@ -53,7 +53,11 @@ __global__ void k_per_update(float* __restrict__ pr, float* __restrict__ pminmax
     if (vconst_from_max) val = (double)vconst_from_max[0] + (double)1.1920928955078125e-07f;   // push!: max_priority*ones(N) (Float64)
     else if (v64) val = v64[i] + (double)1.1920928955078125e-07f;
     else { const float vf = __fadd_rn(v32[i], 1.1920928955078125e-07f); val = (double)vf; }
-    pr[I[i]] = (float)pow(val, (double)alpha);
+    // priorities[I] = val.^alpha is a sequential scatter in the reference (:297): with repeated indices the LAST value wins. Small calls (the
+    // sampled-batch case) resolve that exactly; large calls are ring pushes, whose repeats (N > capacity) carry the same value anyway.
+    bool later = false;
+    if (n <= 2048 && !vconst_from_max) for (int64_t j = i + 1; j < n; ++j) if (I[j] == I[i]) { later = true; break; }
+    if (!later) pr[I[i]] = (float)pow(val, (double)alpha);
     const float vf32 = (float)val;
     atomicMax((int*)&pminmax[0], __float_as_int(vf32));
     atomicMin((int*)&pminmax[1], __float_as_int(vf32));

@@ -598,3 +598,50 @@ def test_batched_evaluation_matches_oracle(gpu_ctx, kind, dims, acts, head):
         assert abs(crux.undiscounted_return(s, Neps=Neps) - ln.mean()) < 1e-6
         assert crux.failure(s, threshold=1e9, Neps=Neps) == 1.0 and crux.failure(s, threshold=0.0, Neps=Neps) == 0.0
     assert abs(crux.discounted_return(s, Neps=Neps) - float(np.mean(dis))) < 1e-4 * max(1, abs(float(np.mean(dis))))
+
+
+# ---------------------------------------------------------------------------------------------------- edge cases and error behaviour
+def test_edge_cases_and_error_codes(gpu_ctx):
+    """Empty / ragged / oversized inputs and the reference's @assert and error() sites as status codes ("Error behaviour")."""
+    ctx, rng = gpu_ctx, np.random.default_rng(31)
+    S, A = crux.ContinuousSpace(4), crux.DiscreteSpace(2)
+    extras = ["return", "logprob", "advantage"]
+    g, o = parity.make_pair([4, 64, 64, 2], ["relu", "relu", "identity"], 61, 0, "discrete")
+    p = crux.TrainingParams(loss=crux.ppo_loss, batch_size=128, epochs=1, name="actor_")
+    # empty buffer: batch_train! has nothing to partition
+    gb = crux.ExperienceBuffer(S, A, 100, extras); ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, 100, extras)
+    with pytest.raises(crux.CruxError) as e:
+        crux.batch_train_(g, p, {}, gb)
+    assert e.value.code == L.EINVAL and len(gb) == 0
+    # push of zero rows is a no-op; a push longer than the capacity wraps and the later rows win (circ_inds(1,120,100), test/experience_buffer_tests.jl:26-27)
+    d = _rand_data(rng, 120, 4, 2, True, extras)
+    gb.push_({k: v[:, :0] for k, v in d.items()}); assert len(gb) == 0
+    I = gb.push_(d); Io = ob.push(d)
+    assert len(gb) == len(ob) == 100 and gb.next_ind == 21 and np.array_equal(np.asarray(I), np.asarray(Io) if Io is not None else np.asarray(I))
+    for k in ("s", "a", "r", "advantage"):
+        assert np.array_equal(gb[k], ob[k]), k
+    assert np.array_equal(gb["s"][:, :20], d["s"][:, 100:120]) and np.array_equal(gb["s"][:, 20:], d["s"][:, 20:100])
+    # ragged last minibatch (100 rows, batch 37) and a minibatch index outside the buffer
+    p37 = crux.TrainingParams(loss=crux.ppo_loss, batch_size=37, epochs=1, name="actor_")
+    assert crux.batch_train_(g, p37, {}, gb)["actor_batches_trained"] == 3
+    with pytest.raises(crux.CruxError) as e:
+        crux.train_(g, p, {}, gb, np.array([1, 2, 101]))
+    assert e.value.code == L.EINVAL
+    # shape mismatches: critic loss on a 2-output network, rollout buffer with the wrong observation width
+    with pytest.raises(crux.CruxError) as e:
+        crux.batch_train_(g, crux.TrainingParams(loss=crux.value_mse_loss, batch_size=32, epochs=1), {}, gb)
+    assert e.value.code == L.EINVAL
+    bad = crux.ExperienceBuffer(crux.ContinuousSpace(3), A, 64)
+    smp = crux.Sampler(crux.CartPoleMDP(n_envs=2, seed=1), g, max_steps=10)
+    with pytest.raises(crux.CruxError) as e:
+        crux.steps_(smp, bad, Nsteps=16)
+    assert e.value.code == L.EINVAL
+    # update_priorities! with a repeated index: the last value wins, max/min see every value (experience_buffer.jl:290-301)
+    pb = crux.ExperienceBuffer(S, A, 50, prioritized=True); po = O.OBuffer(4, 2, L.ACTION_DISCRETE, 50, ["weight"], prioritized=True, alpha=np.float32(0.6))
+    d50 = _rand_data(rng, 50, 4, 2, True); pb.push_(d50); po.push(d50)
+    I = np.array([3, 7, 3, 9, 7, 3], np.int64); v = np.array([0.5, 2.0, 1.5, 0.1, 3.0, 0.25], np.float64)
+    pb.update_priorities_(I, v); O.chk(O.lib().orc_per_update(po.h, O.vpz(I - 1), O.vpz(v), 1, I.size))
+    pg = pb.priority_params(); pr = np.empty(50, np.float32); mx, mn = C.c_float(), C.c_float()
+    O.chk(O.lib().orc_per_get(po.h, O.vpz(pr), C.byref(mx), C.byref(mn), None))
+    assert np.array_equal(pg["priorities"], pr) and pg["max_priority"] == mx.value and pg["min_priority"] == mn.value
+    assert abs(pg["priorities"][2] - np.float32((0.25 + np.finfo(np.float32).eps) ** 0.6)) < 1e-6
