@@ -85,13 +85,13 @@ SYNC_EVERY = int(os.environ.get("CRUX_SYNC_EVERY", "1"))   # epochs between para
 
 
 def cpu_baseline():
-    """Oracle (CPU port of the reference algorithm, single thread) on a bounded sample of the same workload:
-    a 32-env x 128-step rollout + GAE, and 2 x 192 minibatch Adam steps (B=128); extrapolated to one full iteration."""
+    """Oracle (CPU port of the reference algorithm, single thread) on a bounded sample of the same workload (~10 s of CPU work):
+    one full 32-env x 2048-step rollout + GAE, and 2 x 8192 of the 2 x 40960 minibatch Adam steps (B=128); extrapolated to one full iteration."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as O
     from crux_jl_amd import _lib as L
     import parity
-    Ts = 128
+    Ts = T
     oa = O.OMlp(ACTOR, ACTS).init_glorot(1, 0); oc = O.OMlp(CRITIC, ACTS).init_glorot(1, 1)
     oa.adam_init(float(np.float32(3e-4))); oc.adam_init(float(np.float32(3e-4)))
     extras = ["return", "logprob", "advantage"]
@@ -101,11 +101,11 @@ def cpu_baseline():
     oe.rollout(oa, parity.rollout_cfg(), ob, Ts)
     O.chk(O.lib().orc_fill_gae(ob.h, oc.h, LAM, GAMMA)); O.chk(O.lib().orc_fill_returns(ob.h, GAMMA)); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
     t_roll = time.perf_counter() - t0
-    n_mb = 192
+    n_mb = 8192
     info = np.zeros(L.INFO_N, np.float32)
     t0 = time.perf_counter()
     for loss, head, net in (("ppo", "categorical", oa), ("value_mse", "deterministic", oc)):
-        cfg = parity.train_cfg(loss, head, BATCH, 6, -1.0, 7, 0, max_batches=n_mb)
+        cfg = parity.train_cfg(loss, head, BATCH, 16, -1.0, 7, 0, max_batches=n_mb)
         O.chk(O.lib().orc_batch_train(net.h, ob.h, C.byref(cfg), None, O.vpz(info), None))
     t_train = time.perf_counter() - t0
     per_env_step = t_roll / (N_ENVS * Ts)
