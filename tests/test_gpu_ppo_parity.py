@@ -66,7 +66,10 @@ def test_a2c_and_reinforce_solve_match_oracle_loop(gpu_ctx, algo):
 def test_multi_seed_batched_learners_match_single_calls(gpu_ctx):
     """crux_policy_gradient_training_multi: n independent learners in two batched launches == n single calls with the per-replica seeds (bit for bit:
     same kernel, same arithmetic; only the launch geometry differs)."""
+    import os
     from parity import crux
+    if os.environ.get("CRUX_MFMA_X2") == "0" or os.environ.get("CRUX_MFMA_WAVES4") or os.environ.get("CRUX_FORCE_GENERIC"):
+        pytest.skip("a debug switch routes the single calls to a different kernel than the batched launch: bitwise equality is not expected")
     rng = np.random.default_rng(4); n_rep, n, bs = 5, 512, 128
     extras = ["return", "logprob", "advantage"]
     def make(seed):
