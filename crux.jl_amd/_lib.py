@@ -148,7 +148,7 @@ COL = {"s": 0, "a": 1, "sp": 2, "r": 3, "done": 4, "episode_end": 5, "return": 6
        "weight": 9, "t": 10, "i": 11, "value": 12}
 NCOLS = 13
 ACTION_DISCRETE, ACTION_CONTINUOUS = 0, 1
-ENV = {"cartpole": 0, "pendulum": 1, "gridworld": 2, "synth": 3}
+ENV = {"cartpole": 0, "pendulum": 1, "gridworld": 2, "synth": 3, "synth_discrete": 4}
 HEAD = {"categorical": 0, "gaussian": 1, "greedy_q": 2, "deterministic": 3}
 LOSS = {"ppo": 0, "value_mse": 1, "a2c": 3, "reinforce": 4, "logpdf_bc": 5, "mse_action": 6}
 INFO = {"loss": 0, "grad_norm": 1, "entropy": 2, "kl": 3, "clip_fraction": 4, "avg_advantage": 5, "avg_return": 6,

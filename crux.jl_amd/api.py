@@ -593,9 +593,12 @@ class GymMDP:
     """Stand-in for POMDPGym's GymPOMDP(:CartPole) etc.: names a dynamics kind that runs inside the rollout kernel.
     n_envs independent-seed copies are stepped together (env-major Vector{Sampler} semantics)."""
 
-    def __init__(self, kind, n_envs=1, seed=0, discount=0.99):
+    def __init__(self, kind, n_envs=1, seed=0, discount=0.99, obs_dim=None, act_dim=None):
         self.kind, self.n_envs, self.seed, self.discount = kind, int(n_envs), int(seed), float(discount)
-        self.obs_dim, self.act_dim, self.discrete = {"cartpole": (4, 2, True), "pendulum": (3, 1, False), "gridworld": (2, 4, True)}[kind]
+        if kind in ("synth", "synth_discrete"):      # the library's synthetic dynamics (include/cruxhip.h): any obs/act width up to 32
+            self.obs_dim, self.act_dim, self.discrete = int(obs_dim), int(act_dim), kind == "synth_discrete"
+        else:
+            self.obs_dim, self.act_dim, self.discrete = {"cartpole": (4, 2, True), "pendulum": (3, 1, False), "gridworld": (2, 4, True)}[kind]
 
     def state_space(self, mu=0.0, sigma=1.0):
         """state_space(mdp; mu, sigma) (src/spaces.jl:34-43)."""
@@ -611,6 +614,11 @@ def CartPoleMDP(**kw):
 
 def PendulumMDP(**kw):
     return GymMDP("pendulum", **kw)
+
+
+def SynthMDP(obs_dim, act_dim, discrete=False, **kw):
+    """The library's synthetic environment for the LunarLander- (8 obs / 4 discrete actions) and HalfCheetah-shaped (17 obs / 6 continuous actions) configs."""
+    return GymMDP("synth_discrete" if discrete else "synth", obs_dim=obs_dim, act_dim=act_dim, **kw)
 
 
 def SimpleGridWorld(**kw):
@@ -663,8 +671,9 @@ class Sampler:
         mu = np.ascontiguousarray(np.broadcast_to(np.asarray(self.S.mu, np.float32), (od,)))
         sg = np.ascontiguousarray(np.broadcast_to(np.asarray(self.S.sigma, np.float32), (od,)))
         h = C.c_void_p()
+        synth = mdp.kind in ("synth", "synth_discrete")
         self.ctx.check(self.ctx.lib.crux_env_create(self.ctx.h, L.ENV[mdp.kind], mdp.n_envs, self.max_steps, float(self.gamma), _vp(mu), _vp(sg),
-                                                    mdp.seed, 0, 0, C.byref(h)))
+                                                    mdp.seed, mdp.obs_dim if synth else 0, mdp.act_dim if synth else 0, C.byref(h)))
         self.h = h
 
     @property
@@ -729,7 +738,7 @@ def episodes_(sampler, Neps=1, explore=False, i=0, seed_offset=0x45564C):
     environment are rolled out in parallel (one wave each) for max_steps steps; the first episode of each copy is one evaluation episode.
     Returns (data::ExperienceBuffer, metrics) with per-episode undiscounted / discounted returns, lengths and completion flags."""
     mdp = sampler.mdp
-    em = GymMDP(mdp.kind, n_envs=int(Neps), seed=mdp.seed + int(seed_offset), discount=mdp.discount)
+    em = GymMDP(mdp.kind, n_envs=int(Neps), seed=mdp.seed + int(seed_offset), discount=mdp.discount, obs_dim=mdp.obs_dim, act_dim=mdp.act_dim)
     es = Sampler(em, sampler.agent, S=sampler.S, max_steps=sampler.max_steps, required_columns=(), ctx=sampler.ctx)
     T = sampler.max_steps
     data = ExperienceBuffer(sampler.S, sampler.agent.space, int(Neps) * T, ctx=sampler.ctx)

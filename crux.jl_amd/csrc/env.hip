@@ -10,7 +10,7 @@ int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>
 void crux_buffer_ring_advance(crux_buffer* b, int64_t N);
 int32_t crux_buffer_per_on_push(crux_buffer* b, const int64_t* d_I, int64_t N);
 
-#define ENV_MAXSD 4
+#define ENV_MAXSD 32          // SYNTH keeps one Float64 per observation; CartPole 4, Pendulum / GridWorld 2
 #define ENV_MAXOBS 32
 #define PI_D 3.14159265358979323846
 
@@ -61,12 +61,32 @@ __device__ __forceinline__ void gridworld_step(const double* s, int a, double u,
   if (nx < 1 || nx > 10 || ny < 1 || ny > 10) { nx = x; ny = y; }
   sn[0] = nx; sn[1] = ny; *done = 0;
 }
-__device__ __forceinline__ void env_obs(int kind, const double* s, float* o) {
+// SYNTH: see include/cruxhip.h for the definition (the oracle's synth_step is the twin)
+__device__ __forceinline__ bool env_is_synth(int kind) { return kind == CRUX_ENV_SYNTH || kind == CRUX_ENV_SYNTH_DISCRETE; }
+__device__ __forceinline__ void synth_step(int so, int sa, bool discrete, const double* s, int ai, const float* a, double* sn, float* r, uint8_t* done) {
+  double ss = 0.0;
+  for (int i = 0; i < so; ++i) {
+    double u;
+    if (discrete) u = ((i + ai) % sa == 0) ? 1.0 : -0.25;
+    else { u = (double)a[i % sa]; if (u < -1.0) u = -1.0; if (u > 1.0) u = 1.0; }
+    sn[i] = __dadd_rn(__dmul_rn(0.9, s[i]), __dmul_rn(0.1, sin(__dadd_rn(s[(i + 1) % so], u))));
+    ss = __dadd_rn(ss, __dmul_rn(sn[i], sn[i]));
+  }
+  *r = (float)__dadd_rn(-(ss / (double)so), __dmul_rn(0.05, sn[0]));
+  *done = sn[0] > 0.9 ? 1 : 0;
+}
+__device__ __forceinline__ void env_obs(int kind, const double* s, float* o, int od = 0) {
   if (kind == CRUX_ENV_CARTPOLE) { o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3]; }
   else if (kind == CRUX_ENV_PENDULUM) { o[0] = (float)cos(s[0]); o[1] = (float)sin(s[0]); o[2] = (float)s[1]; }
+  else if (env_is_synth(kind)) { for (int i = 0; i < od; ++i) o[i] = (float)s[i]; }
   else { o[0] = (float)s[0]; o[1] = (float)s[1]; }
 }
-__device__ __forceinline__ void env_draw_initial(int kind, uint64_t seed, uint64_t n_resets, uint32_t env, double* s) {
+__device__ __forceinline__ void env_draw_initial(int kind, uint64_t seed, uint64_t n_resets, uint32_t env, double* s, int sd = 0) {
+  if (env_is_synth(kind)) {                                   // U(-0.05, 0.05)^so, two Float64 uniforms per Philox block
+    for (int i = 0; i < sd; ++i) { const crux_u32x4 x = crux_philox(seed, 16 * n_resets + (uint64_t)(i >> 1), env, CRUX_RNG_RESET);
+      const double ui = (i & 1) ? crux_u32x2_to_f64(x.v[2], x.v[3]) : crux_u32x2_to_f64(x.v[0], x.v[1]); s[i] = __dadd_rn(-0.05, __dmul_rn(0.1, ui)); }
+    return;
+  }
   const crux_u32x4 a = crux_philox(seed, 2 * n_resets, env, CRUX_RNG_RESET), b = crux_philox(seed, 2 * n_resets + 1, env, CRUX_RNG_RESET);
   const double u0 = crux_u32x2_to_f64(a.v[0], a.v[1]), u1 = crux_u32x2_to_f64(a.v[2], a.v[3]), u2 = crux_u32x2_to_f64(b.v[0], b.v[1]), u3 = crux_u32x2_to_f64(b.v[2], b.v[3]);
   if (kind == CRUX_ENV_CARTPOLE) { s[0] = __dadd_rn(-0.05, __dmul_rn(0.1, u0)); s[1] = __dadd_rn(-0.05, __dmul_rn(0.1, u1)); s[2] = __dadd_rn(-0.05, __dmul_rn(0.1, u2)); s[3] = __dadd_rn(-0.05, __dmul_rn(0.1, u3)); }
@@ -99,7 +119,7 @@ struct RolloutArgs {
 __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* z, const int od, const int ad, const int nout, const int kind, const int e,
                                              const int64_t t, const int64_t j, const bool writer, double* st, int64_t& ep_len, int64_t& n_resets,
                                              int64_t& steps_taken, double& sum_r, int64_t& nee, float* next_obs) {
-  const int sd = kind == CRUX_ENV_CARTPOLE ? 4 : 2;
+  const int sd = kind == CRUX_ENV_CARTPOLE ? 4 : (env_is_synth(kind) ? a.sd : 2);
       const uint64_t gi = a.cfg.i0 + (uint64_t)t * (uint64_t)a.E + (uint64_t)e;    // i + (j-1), env-minor (sampler.jl:161-163)
       const uint64_t ctr = (uint64_t)steps_taken;
       float logprob = NAN; int ai = 0; float aout[ENV_MAXOBS];
@@ -148,8 +168,9 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
       double sn[ENV_MAXSD]; float r; uint8_t done; float o[ENV_MAXOBS], spv[ENV_MAXOBS];
       if (kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done);
       else if (kind == CRUX_ENV_PENDULUM) pendulum_step(st, aout[0], sn, &r, &done);
+      else if (env_is_synth(kind)) synth_step(od, ad, kind == CRUX_ENV_SYNTH_DISCRETE, st, ai, aout, sn, &r, &done);
       else { const crux_u32x4 xd = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_ENVDYN); gridworld_step(st, ai, crux_u32x2_to_f64(xd.v[0], xd.v[1]), sn, &r, &done); }
-      env_obs(kind, sn, o);
+      env_obs(kind, sn, o, od);
       for (int q = 0; q < od; ++q) spv[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
       // ---- column writes (sampler.jl:101-107)
       if (writer) {
@@ -170,8 +191,8 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
       uint8_t ee = 0;
       if (done || ep_len >= a.max_steps) {
         ee = 1; ++nee;
-        env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st); n_resets += 1; ep_len = 0;
-        env_obs(kind, st, o);
+        env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st, a.sd); n_resets += 1; ep_len = 0;
+        env_obs(kind, st, o, od);
         for (int q = 0; q < od; ++q) next_obs[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
       } else {
         for (int i = 0; i < sd; ++i) st[i] = sn[i];
@@ -179,8 +200,8 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
       }
       if (a.cfg.reset_at_end && t == a.T - 1 && ep_len > 0) {                       // sampler.jl:148
         ee = 1; ++nee;
-        env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st); n_resets += 1; ep_len = 0;
-        env_obs(kind, st, o);
+        env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st, a.sd); n_resets += 1; ep_len = 0;
+        env_obs(kind, st, o, od);
         for (int q = 0; q < od; ++q) next_obs[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
       }
       if (writer) a.EE[j] = ee;
@@ -209,7 +230,7 @@ __global__ __launch_bounds__(64) void k_rollout_h64(RolloutArgs a_single, const 
   const RolloutArgs a = multi ? multi[blockIdx.x / a_single.E] : a_single;
   const int e = multi ? (int)(blockIdx.x % a_single.E) : (int)blockIdx.x, lane = threadIdx.x;
   const NetDesc& nd = a.nd;
-  constexpr int SD = KIND == CRUX_ENV_CARTPOLE ? 4 : 2;
+  constexpr int SD = KIND == CRUX_ENV_CARTPOLE ? 4 : ((KIND == CRUX_ENV_SYNTH || KIND == CRUX_ENV_SYNTH_DISCRETE) ? IN : 2);
   float w1[IN], w2[64], w3[OUT], b3[OUT];
 #pragma unroll
   for (int k = 0; k < IN; ++k) w1[k] = a.p[nd.woff[0] + lane + 64 * k];
@@ -308,12 +329,18 @@ __global__ void k_env_init(int kind, int E, int od, int sd, uint64_t seed, const
                            int64_t* n_resets, float* svec, int fresh) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  double st[ENV_MAXSD]; float o[ENV_MAXOBS];
   const int64_t nr = fresh ? 0 : n_resets[e];
+  if (env_is_synth(kind)) {                                  // straight to memory: no per-thread arrays (observation i == state i)
+    for (int i = 0; i < sd; ++i) { const crux_u32x4 x = crux_philox(seed, 16 * (uint64_t)nr + (uint64_t)(i >> 1), (uint32_t)e, CRUX_RNG_RESET);
+      const double ui = (i & 1) ? crux_u32x2_to_f64(x.v[2], x.v[3]) : crux_u32x2_to_f64(x.v[0], x.v[1]); const double xi = __dadd_rn(-0.05, __dmul_rn(0.1, ui));
+      state[(size_t)e * sd + i] = xi; svec[(size_t)e * od + i] = __fdiv_rn(__fsub_rn((float)xi, mu[i]), sigma[i]); }
+    n_resets[e] = nr + 1; ep_len[e] = 0; return;
+  }
+  double st[4]; float o[4];
   st[0] = st[1] = st[2] = st[3] = 0.0; o[0] = o[1] = o[2] = o[3] = 0.f;
   env_draw_initial(kind, seed, (uint64_t)nr, (uint32_t)e, st);
 #pragma unroll
-  for (int i = 0; i < ENV_MAXSD; ++i) if (i < sd) state[(size_t)e * sd + i] = st[i];      // static indices: keep the arrays in registers
+  for (int i = 0; i < 4; ++i) if (i < sd) state[(size_t)e * sd + i] = st[i];      // static indices: keep the arrays in registers
   n_resets[e] = nr + 1; ep_len[e] = 0;
   env_obs(kind, st, o);
 #pragma unroll
@@ -345,6 +372,7 @@ static void env_dims(int kind, int so, int sa, int* obs, int* act, int* sd) {
     case CRUX_ENV_CARTPOLE: *obs = 4; *act = 2; *sd = 4; break;
     case CRUX_ENV_PENDULUM: *obs = 3; *act = 1; *sd = 2; break;
     case CRUX_ENV_GRIDWORLD: *obs = 2; *act = 4; *sd = 2; break;
+    case CRUX_ENV_SYNTH: case CRUX_ENV_SYNTH_DISCRETE: *obs = so; *act = sa; *sd = so; break;
     default: *obs = so; *act = sa; *sd = 1; break;
   }
 }
@@ -367,7 +395,9 @@ extern "C" {
 int32_t crux_env_create(crux_ctx* ctx, int32_t kind, int32_t n_envs, int32_t max_steps, float gamma, const float* obs_mu, const float* obs_sigma,
                         uint64_t seed, int32_t synth_obs_dim, int32_t synth_act_dim, crux_env** out) {
   if (!ctx || !out) return CRUX_EINVAL;
-  if (kind != CRUX_ENV_CARTPOLE && kind != CRUX_ENV_PENDULUM && kind != CRUX_ENV_GRIDWORLD) return crux_fail(ctx, CRUX_EUNSUP, "env kind %d has no device dynamics yet", kind);
+  if (kind < CRUX_ENV_CARTPOLE || kind > CRUX_ENV_SYNTH_DISCRETE) return crux_fail(ctx, CRUX_EUNSUP, "env kind %d has no device dynamics", kind);
+  if ((kind == CRUX_ENV_SYNTH || kind == CRUX_ENV_SYNTH_DISCRETE) && (synth_obs_dim < 1 || synth_obs_dim > ENV_MAXOBS || synth_act_dim < 1 || synth_act_dim > ENV_MAXOBS))
+    return crux_fail(ctx, CRUX_EINVAL, "synthetic env: obs/act dims (%d, %d) must be in 1..%d", synth_obs_dim, synth_act_dim, ENV_MAXOBS);
   if (n_envs < 1 || max_steps < 1) return crux_fail(ctx, CRUX_EINVAL, "env_create: n_envs=%d max_steps=%d", n_envs, max_steps);
   crux_env* e = new crux_env(); e->ctx = ctx; e->kind = kind; e->n_envs = n_envs; e->max_steps = max_steps; e->gamma = gamma; e->seed = seed;
   env_dims(kind, synth_obs_dim, synth_act_dim, &e->obs_dim, &e->act_dim, &e->state_dim);
@@ -439,6 +469,8 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
   RO_CASE(4, 2, CRUX_ACT_TANH, CRUX_ENV_CARTPOLE)
   RO_CASE(3, 1, CRUX_ACT_RELU, CRUX_ENV_PENDULUM)
   RO_CASE(3, 1, CRUX_ACT_TANH, CRUX_ENV_PENDULUM)
+  RO_CASE(17, 6, CRUX_ACT_TANH, CRUX_ENV_SYNTH)       // C5-shaped: 17 obs / 6 continuous actions
+  RO_CASE(17, 6, CRUX_ACT_RELU, CRUX_ENV_SYNTH)
 #undef RO_CASE
   hipLaunchKernelGGL(k_rollout, dim3(e->n_envs), dim3(64), 0, c->stream, a);
   crux_prof_end(c, CRUX_PROF_ROLLOUT);
@@ -484,6 +516,8 @@ int32_t crux_rollout_multi(int32_t n, crux_env* const* envs, crux_mlp* const* po
   ROM_CASE(4, 2, CRUX_ACT_TANH, CRUX_ENV_CARTPOLE)
   ROM_CASE(3, 1, CRUX_ACT_RELU, CRUX_ENV_PENDULUM)
   ROM_CASE(3, 1, CRUX_ACT_TANH, CRUX_ENV_PENDULUM)
+  ROM_CASE(17, 6, CRUX_ACT_TANH, CRUX_ENV_SYNTH)
+  ROM_CASE(17, 6, CRUX_ACT_RELU, CRUX_ENV_SYNTH)
 #undef ROM_CASE
   crux_prof_end(c, CRUX_PROF_ROLLOUT);
   if (!done) return crux_fail(c, CRUX_EUNSUP, "steps! (multi): no batched rollout kernel for this policy / environment");

@@ -161,7 +161,12 @@ int32_t crux_per_get(crux_buffer* b, float* priorities /*capacity or NULL*/, flo
                      float* min_priority, float* cumsum /*len or NULL*/);
 
 /* environments + rollout (src/sampler.jl:1-173) --------------------------------------------------- */
-enum { CRUX_ENV_CARTPOLE = 0, CRUX_ENV_PENDULUM = 1, CRUX_ENV_GRIDWORLD = 2, CRUX_ENV_SYNTH = 3 };
+enum { CRUX_ENV_CARTPOLE = 0, CRUX_ENV_PENDULUM = 1, CRUX_ENV_GRIDWORLD = 2,
+       CRUX_ENV_SYNTH = 3 /* synthetic dynamics, synth_obs_dim observations, synth_act_dim continuous actions (C5-shaped: 17 / 6) */,
+       CRUX_ENV_SYNTH_DISCRETE = 4 /* the same with synth_act_dim discrete actions (C3-shaped: 8 / 4) */ };
+/* SYNTH (for the configurations whose simulators -- LunarLander, HalfCheetah -- cannot be restated): state x in R^so (Float64),
+ * observation Float32(x); u_i = clamp(a[i mod sa], -1, 1) or, for discrete action k, ((i + k) mod sa == 0 ? 1 : -0.25);
+ * x'_i = 0.9 x_i + 0.1 sin(x_{(i+1) mod so} + u_i); r = -mean(x'^2) + 0.05 x'_0; done = x'_0 > 0.9; reset x_i ~ U(-0.05, 0.05).              */
 enum { CRUX_HEAD_CATEGORICAL = 0 /* DiscreteNetwork softmax head (policies.jl:104-157)            */,
        CRUX_HEAD_GAUSSIAN = 1    /* GaussianPolicy, const logSigma extras (policies.jl:315-350)    */,
        CRUX_HEAD_GREEDY_Q = 2    /* action(::DiscreteNetwork) argmax (policies.jl:124)             */,

@@ -409,7 +409,7 @@ int32_t orc_per_get(orc_buffer* b, float* pr, float* maxp, float* minp, float* c
  * dynamics are restated from the public gymnasium definitions and pinned by the recordings under
  * examples/il/expert_data/ (tests/golden/ npz files).
  * ============================================================================================ */
-#define MAXSD 4
+#define MAXSD 32
 struct orc_env {
   int32_t kind, n_envs, max_steps, obs_dim, act_dim, state_dim;
   float gamma; float mu[32], sigma[32]; uint64_t seed;
@@ -420,7 +420,7 @@ static void env_dims(int kind, int so, int sa, int* obs, int* act, int* sd) {
   switch (kind) { case CRUX_ENV_CARTPOLE: *obs = 4; *act = 2; *sd = 4; break;
     case CRUX_ENV_PENDULUM: *obs = 3; *act = 1; *sd = 2; break;
     case CRUX_ENV_GRIDWORLD: *obs = 2; *act = 4; *sd = 2; break;
-    default: *obs = so; *act = sa; *sd = 1; break; }
+    default: *obs = so; *act = sa; *sd = so; break; }
 }
 
 /* gymnasium CartPole-v1 (classic_control/cartpole.py), float64 Euler step. one-hot index 1 (0-based)
@@ -476,10 +476,28 @@ static void gridworld_step(const double* s, int a, double u, double* sn, float* 
   if (nx < 1 || nx > 10 || ny < 1 || ny > 10) { nx = x; ny = y; }
   sn[0] = nx; sn[1] = ny; *done = 0;
 }
-static void env_obs(int kind, const double* s, float* o) {
+/* SYNTH: the library's documented synthetic environment for configurations whose simulators cannot be restated (LunarLander 8 obs /
+ * 4 discrete actions -> C3, HalfCheetah 17 obs / 6 continuous actions -> C5). State x in R^so (Float64), observation = Float32(x):
+ *   u_i  = clamp(a[i mod sa], -1, 1)                       (continuous)      |  (i + k) mod sa == 0 ? 1 : -0.25   (discrete action k)
+ *   x'_i = 0.9 x_i + 0.1 sin(x_{(i+1) mod so} + u_i);   r = -mean(x'^2) + 0.05 x'_0;   done = x'_0 > 0.9;   reset: x_i ~ U(-0.05, 0.05). */
+static void synth_step(int so, int sa, int discrete, const double* s, int ai, const float* a, double* sn, float* r, uint8_t* done) {
+  double ss = 0.0;
+  for (int i = 0; i < so; ++i) {
+    double u;
+    if (discrete) u = ((i + ai) % sa == 0) ? 1.0 : -0.25;
+    else { u = (double)a[i % sa]; if (u < -1.0) u = -1.0; if (u > 1.0) u = 1.0; }
+    sn[i] = 0.9 * s[i] + 0.1 * sin(s[(i + 1) % so] + u);
+    ss = ss + sn[i] * sn[i];
+  }
+  *r = (float)(-(ss / (double)so) + 0.05 * sn[0]);
+  *done = sn[0] > 0.9 ? 1 : 0;
+}
+static void env_obs_n(int kind, int od, const double* s, float* o) {
   if (kind == CRUX_ENV_CARTPOLE) cartpole_obs(s, o); else if (kind == CRUX_ENV_PENDULUM) pendulum_obs(s, o);
+  else if (kind == CRUX_ENV_SYNTH || kind == CRUX_ENV_SYNTH_DISCRETE) { for (int i = 0; i < od; ++i) o[i] = (float)s[i]; }
   else { o[0] = (float)s[0]; o[1] = (float)s[1]; }
 }
+static void env_obs(int kind, const double* s, float* o) { env_obs_n(kind, 0, s, o); }
 
 static void env_reset_one(orc_env* e, int k) { /* reset_sampler! src/sampler.jl:31-43 */
   double* s = e->state + (size_t)k * e->state_dim;
@@ -488,14 +506,18 @@ static void env_reset_one(orc_env* e, int k) { /* reset_sampler! src/sampler.jl:
   double u[4] = { crux_u32x2_to_f64(a.v[0], a.v[1]), crux_u32x2_to_f64(a.v[2], a.v[3]), crux_u32x2_to_f64(b.v[0], b.v[1]), crux_u32x2_to_f64(b.v[2], b.v[3]) };
   if (e->kind == CRUX_ENV_CARTPOLE) { for (int i = 0; i < 4; ++i) s[i] = -0.05 + 0.1 * u[i]; }          /* U(-0.05,0.05)^4 */
   else if (e->kind == CRUX_ENV_PENDULUM) { s[0] = -M_PI + 2.0 * M_PI * u[0]; s[1] = -1.0 + 2.0 * u[1]; } /* U(-pi,pi) x U(-1,1) */
+  else if (e->kind == CRUX_ENV_SYNTH || e->kind == CRUX_ENV_SYNTH_DISCRETE) {                               /* U(-0.05,0.05)^so: two Float64 uniforms per Philox block */
+    for (int i = 0; i < e->state_dim; ++i) { crux_u32x4 x = crux_philox(e->seed, 16 * c + (uint64_t)(i >> 1), (uint32_t)k, CRUX_RNG_RESET);
+      double ui = (i & 1) ? crux_u32x2_to_f64(x.v[2], x.v[3]) : crux_u32x2_to_f64(x.v[0], x.v[1]); s[i] = -0.05 + 0.1 * ui; } }
   else { s[0] = 1.0 + floor(10.0 * u[0]); s[1] = 1.0 + floor(10.0 * u[1]); }                              /* uniform over the 100 cells */
   e->n_resets[k] += 1; e->ep_len[k] = 0;
-  float o[32]; env_obs(e->kind, s, o);
+  float o[32]; env_obs_n(e->kind, e->obs_dim, s, o);
   for (int i = 0; i < e->obs_dim; ++i) e->svec[(size_t)k * e->obs_dim + i] = (o[i] - e->mu[i]) / e->sigma[i];   /* tovec src/spaces.jl:25 */
 }
 
 orc_env* orc_env_create(int32_t kind, int32_t n_envs, int32_t max_steps, float gamma, const float* mu, const float* sigma, uint64_t seed, int32_t so, int32_t sa) {
-  if (kind != CRUX_ENV_CARTPOLE && kind != CRUX_ENV_PENDULUM && kind != CRUX_ENV_GRIDWORLD) return NULL;
+  if (kind < CRUX_ENV_CARTPOLE || kind > CRUX_ENV_SYNTH_DISCRETE) return NULL;
+  if ((kind == CRUX_ENV_SYNTH || kind == CRUX_ENV_SYNTH_DISCRETE) && (so < 1 || so > 32 || sa < 1 || sa > 32)) return NULL;
   orc_env* e = (orc_env*)calloc(1, sizeof(orc_env));
   e->kind = kind; e->n_envs = n_envs; e->max_steps = max_steps; e->gamma = gamma; e->seed = seed;
   env_dims(kind, so, sa, &e->obs_dim, &e->act_dim, &e->state_dim);
@@ -619,8 +641,9 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
       double sn[MAXSD]; float r; uint8_t done; float o[32], spv[32];
       if (e->kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done);
       else if (e->kind == CRUX_ENV_PENDULUM) pendulum_step(st, aout[0], sn, &r, &done);
+      else if (e->kind == CRUX_ENV_SYNTH || e->kind == CRUX_ENV_SYNTH_DISCRETE) synth_step(od, ad, e->kind == CRUX_ENV_SYNTH_DISCRETE, st, ai, aout, sn, &r, &done);
       else { crux_u32x4 xd = crux_philox(e->seed, ctr, (uint32_t)k, CRUX_RNG_ENVDYN); gridworld_step(st, ai, crux_u32x2_to_f64(xd.v[0], xd.v[1]), sn, &r, &done); }
-      env_obs(e->kind, sn, o);
+      env_obs_n(e->kind, od, sn, o);
       for (int q = 0; q < od; ++q) spv[q] = (o[q] - e->mu[q]) / e->sigma[q];
       /* ---- column writes                                                       sampler.jl:100-107 */
       memcpy(S + (size_t)j * od, sv, 4 * (size_t)od);

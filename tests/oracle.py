@@ -163,8 +163,8 @@ class OBuffer:
 
 
 class OEnv:
-    def __init__(self, kind, n_envs, max_steps, gamma=0.99, seed=0, mu=None, sigma=None):
-        self.h = lib().orc_env_create(L.ENV[kind], n_envs, max_steps, gamma, vpz(mu), vpz(sigma), seed, 0, 0)
+    def __init__(self, kind, n_envs, max_steps, gamma=0.99, seed=0, mu=None, sigma=None, so=0, sa=0):
+        self.h = lib().orc_env_create(L.ENV[kind], n_envs, max_steps, gamma, vpz(mu), vpz(sigma), seed, so, sa)
         assert self.h, "oracle env kind unsupported"
         self.n_envs = n_envs
 

@@ -645,3 +645,34 @@ def test_edge_cases_and_error_codes(gpu_ctx):
     O.chk(O.lib().orc_per_get(po.h, O.vpz(pr), C.byref(mx), C.byref(mn), None))
     assert np.array_equal(pg["priorities"], pr) and pg["max_priority"] == mx.value and pg["min_priority"] == mn.value
     assert abs(pg["priorities"][2] - np.float32((0.25 + np.finfo(np.float32).eps) ** 0.6)) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["c5_gaussian", "c3_eps_greedy", "c3_categorical"])
+def test_synthetic_env_rollout_matches_oracle(gpu_ctx, case):
+    """The SYNTH dynamics (include/cruxhip.h) for the C3- (8 obs / 4 discrete actions) and C5-shaped (17 obs / 6 continuous actions) configurations."""
+    E, T, max_steps, seed = 5, 40, 16, 14
+    if case == "c5_gaussian":
+        od, ad, disc, dims, acts, kind, head = 17, 6, False, [17, 64, 64, 6], ["tanh", "tanh", "identity"], "gaussian", "gaussian"
+    else:
+        od, ad, disc, dims, acts, kind, head = 8, 4, True, [8, 32, 4], ["relu", "identity"], "discrete", "categorical" if case == "c3_categorical" else "greedy_q"
+    g, o = parity.make_pair(dims, acts, 44, 0, kind, n_extra=ad if kind == "gaussian" else 0, extra_init=-0.5)
+    mdp = crux.SynthMDP(od, ad, discrete=disc, n_envs=E, seed=seed, discount=0.98)
+    pe = crux.EpsGreedyPolicy(crux.LinearDecaySchedule(1.0, 0.1, 100), list(range(ad))) if case == "c3_eps_greedy" else None
+    smp = crux.Sampler(mdp, crux.PolicyParams(g, pi_explore=pe), max_steps=max_steps, S=crux.ContinuousSpace(od, mu=np.full(od, 0.01, np.float32), sigma=np.full(od, 0.5, np.float32)))
+    A = crux.DiscreteSpace(ad) if disc else crux.ContinuousSpace(ad)
+    extras = ["logprob"]
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(od), A, E * T, extras)
+    ob = O.OBuffer(od, ad, L.ACTION_DISCRETE if disc else L.ACTION_CONTINUOUS, E * T, extras)
+    oe = O.OEnv("synth_discrete" if disc else "synth", E, max_steps, 0.98, seed, mu=np.full(od, 0.01, np.float32), sigma=np.full(od, 0.5, np.float32), so=od, sa=ad)
+    cfg = parity.rollout_cfg(True, True, head, i0=7)
+    if case == "c3_eps_greedy":
+        cfg.eps_start, cfg.eps_stop, cfg.eps_steps = 1.0, 0.1, 100
+    gi = crux.steps_(smp, gb, Nsteps=E * T, explore=True, i=7, reset=True)
+    osr, one = oe.rollout(o, cfg, ob, T)
+    assert gi["n_episode_end"] == one and abs(gi["sum_r"] - osr) < 1e-4 * max(1, abs(osr))
+    for k in ("a", "done", "episode_end"):
+        assert np.array_equal(gb[k], ob[k]) if disc or k != "a" else np.abs(gb[k] - ob[k]).max() < 1e-5, k
+    for k in ("s", "sp", "r"):
+        assert np.abs(gb[k] - ob[k]).max() < 1e-5, k
+    st_g, el_g, nr_g = smp.state(); st_o, el_o, nr_o = oe.state()
+    assert np.array_equal(el_g, el_o) and np.array_equal(nr_g, nr_o) and np.abs(st_g - st_o).max() < 1e-9

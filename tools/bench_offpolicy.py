@@ -93,6 +93,25 @@ def main():
     steps5 = 2 * 4 * (n // 128)
     out["C5_learner"] = {"workload": "PPO 17-64-64-6 tanh Gaussian actor || 17-64-64-1 critic, 262144 rows, B=128, 4+4 epochs (synthetic rows)", "ms_per_call": 1e3 * t5,
                          "grad_steps_per_s": steps5 / t5, "us_per_actor_step": 1e6 * t5 / (steps5 / 2)}
+    # ---- C5 end to end: PPO on the synthetic 17-obs / 6-action environment, 128 envs x 2048 steps, tanh 17-64-64-6 Gaussian actor + critic, 10 + 10 epochs
+    mdp = crux.SynthMDP(17, 6, n_envs=128, seed=3, discount=0.99)
+    pi6 = crux.ActorCritic(crux.GaussianPolicy(chain([17, 64, 64, 6], acts5), np.full(6, -0.5, np.float32), seed=7), crux.ContinuousNetwork(chain([17, 64, 64, 1], acts5), seed=8))
+    cols = ["return", "logprob", "advantage"]
+    buf6 = crux.ExperienceBuffer(S, A, 128 * 2048, cols)
+    smp6 = crux.Sampler(mdp, pi6, max_steps=1000, required_columns=cols, lam=0.95)
+    sv6 = _S(); sv6.agent = crux.PolicyParams(pi6); sv6.P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.0}
+    sv6.a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=128, epochs=10, name="actor_", shuffle_seed=11)
+    sv6.c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=128, epochs=10, name="critic_", shuffle_seed=12)
+    it = [0]
+    def c5_iter():
+        it[0] += 1
+        crux.steps_(smp6, buf6, Nsteps=128 * 2048, explore=True, i=it[0] * 128 * 2048, reset=True); crux.whiten_(buf6, "advantage")
+        crux.policy_gradient_training(sv6, buf6)
+    ctx.prof_reset(); ctx.prof_enable(True)
+    t6 = timed(ctx, c5_iter, 2, warmup=1)
+    ctx.prof_enable(False)
+    out["C5_end_to_end"] = {"workload": "PPO synthetic 17 obs / 6 act, 128 envs x 2048 steps, 10 + 10 epochs of 2048 minibatches", "ms_per_iteration": 1e3 * t6,
+                            "env_steps_per_s": 128 * 2048 / t6, "grad_steps_per_s": 2 * 10 * 2048 / t6, "rollout_ms": ctx.prof_get("rollout")[0] / 3}
     print(json.dumps(out))
 
 
