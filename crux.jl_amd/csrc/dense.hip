@@ -11,7 +11,7 @@
 // working set of C3/C4 (a few hundred KB) is far below the 4 MB L2 of one XCD.
 //   forward   Y[o,s]  = act(b[o] + sum_k W[o,k] X[k,s])                 M=out N=B K=in
 //   backward  dX[k,s] = act'(X[k,s]) * sum_o W[o,k] dZ[o,s]             M=in  N=B K=out   (act' of the layer that produced X)
-//   weights   dW[o,k] = scale * sum_s dZ[o,s] X[k,s];  db[o] = scale * sum_s dZ[o,s]      M=out N=in K=B
+//   weights   dW[o,k] = scale * sum_s dZ[o,s] X[k,s];  db[o] = scale * sum_s dZ[o,s]      M=out N=in K=B   (db rides along in the first column tile)
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -23,7 +23,7 @@ struct GemmArgs {
   const float* B; int64_t sBk, sBj;      // B(k,j) = B[k*sBk + j*sBj]
   int M, N, K;
   float* C; int64_t sCj;                 // C(i,j) = C[i + j*sCj]
-  int epi; const float* bias; int act; const float* ysrc; float scale;
+  int epi; const float* bias; int act; const float* ysrc; float scale; float* gbias;
 };
 
 template <bool AV, bool BV>
@@ -38,6 +38,8 @@ __global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) {
   const float* pa = q.A + (int64_t)(va ? ia : 0) * q.sAi;
   const float* pb = q.B + (int64_t)(vb ? jb : 0) * q.sBj;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float rowsum = 0.f;                      // EPI_WGRAD, first column tile: db[i] = sum_k A(i, k) rides along (A = dZ, k = sample)
+  const bool want_rowsum = q.epi == EPI_WGRAD && j0 == 0 && q.gbias != nullptr;
   // K loop in steps of 64: the loads of four 16-wide chunks are issued before the first MFMA, so one L2 round trip (~1 us under load) is paid per
   // 64 k instead of per 16 (the kernel is a wave-per-tile design with no LDS staging: latency, not bandwidth, is what has to be hidden)
   for (int k0 = 0; k0 < q.K; k0 += 64) {
@@ -62,6 +64,16 @@ __global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) {
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][r], b[u][r], acc, 0, 0, 0);
+    if (want_rowsum) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowsum += a[u][r];
+    }
+  }
+  if (want_rowsum) {   // lanes c, c+16, c+32, c+48 hold the four k-groups of row i0+c: fixed-order combine
+    rowsum += __shfl_xor(rowsum, 16, 64); rowsum += __shfl_xor(rowsum, 32, 64);
+    if (g == 0 && va) q.gbias[ia] = q.scale * rowsum;
   }
   // D layout: reg r <-> row i0+4g+r, column j0+c
   const int j = j0 + c;
@@ -80,17 +92,6 @@ __global__ void k_act_grad(const float* __restrict__ dy, const float* __restrict
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
   dz[i] = crux_act_grad(act, y[i], dy[i]);
 }
-// db[o] = scale * sum_s dZ[o + out*s]: block = 64 outputs x 4 sample slices, fixed-order combine
-__global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dz, int out, int64_t B, float scale, float* __restrict__ gb) {
-  __shared__ float part[4][64];
-  const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6, o = blockIdx.x * 64 + ol;
-  float acc = 0.f;
-  if (o < out) for (int64_t s = sl; s < B; s += 4) acc += dz[o + (int64_t)out * s];
-  part[sl][ol] = acc;
-  __syncthreads();
-  if (sl == 0 && o < out) gb[o] = scale * (((part[0][ol] + part[1][ol]) + part[2][ol]) + part[3][ol]);
-}
-
 static inline bool vec_ok(const float* p, int64_t s_k, int64_t s_outer, int K) {
   return s_k == 1 && (K & 3) == 0 && (s_outer & 3) == 0 && (((uintptr_t)p) & 15) == 0;
 }
@@ -145,23 +146,25 @@ int32_t crux_dense_forward(crux_mlp* n, const float* d_x, int64_t B, hipStream_t
 int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st) {
   crux_ctx* c = n->ctx; const NetDesc& nd = n->nd;
   if (nd.L < 1 || !n->ws || n->ws_B < B) return crux_fail(c, CRUX_EINVAL, "backward: no cached forward pass for this batch");
-  float* dcur = ws_delta(n, 0); float* dnxt = ws_delta(n, 1);
-  { const int64_t cnt = (int64_t)nd.dims[nd.L] * B;
-    hipLaunchKernelGGL(k_act_grad, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_dy, crux_dense_act(n, nd.L), nd.acts[nd.L - 1], cnt, dcur); }
+  const float* dcur = d_dy; float* dnxt = ws_delta(n, 0); float* dspare = ws_delta(n, 1);
+  if (nd.acts[nd.L - 1] != CRUX_ACT_IDENTITY) {   // dZ_L = act'(Y_L) .* dY; an identity output layer (the usual critic / mean head) uses dY as it is
+    const int64_t cnt = (int64_t)nd.dims[nd.L] * B;
+    hipLaunchKernelGGL(k_act_grad, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_dy, crux_dense_act(n, nd.L), nd.acts[nd.L - 1], cnt, dnxt);
+    dcur = dnxt; dnxt = dspare; dspare = const_cast<float*>(dcur);
+  }
   for (int l = nd.L - 1; l >= 0; --l) {
     const int in = nd.dims[l], out = nd.dims[l + 1];
     const float* x = l == 0 ? d_x : crux_dense_act(n, l);
     if (want_g) {
       GemmArgs q{}; q.A = dcur; q.sAi = 1; q.sAk = out; q.B = x; q.sBk = in; q.sBj = 1; q.M = out; q.N = in; q.K = (int)B;
-      q.C = n->g + nd.woff[l]; q.sCj = out; q.epi = EPI_WGRAD; q.scale = gscale;
+      q.C = n->g + nd.woff[l]; q.sCj = out; q.epi = EPI_WGRAD; q.scale = gscale; q.gbias = n->g + nd.boff[l];   // db rides along in the first column tile
       int32_t rc = launch_gemm(c, q, st); if (rc) return rc;
-      hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)((out + 63) / 64)), dim3(256), 0, st, dcur, out, B, gscale, n->g + nd.boff[l]);
     }
     if (l > 0 || d_dx) {
       GemmArgs q{}; q.A = n->p + nd.woff[l]; q.sAi = out; q.sAk = 1; q.B = dcur; q.sBk = 1; q.sBj = out; q.M = in; q.N = (int)B; q.K = out;
       q.C = l > 0 ? dnxt : d_dx; q.sCj = in; q.epi = EPI_BWD_DATA; q.ysrc = l > 0 ? x : nullptr; q.act = l > 0 ? nd.acts[l - 1] : CRUX_ACT_IDENTITY;
       int32_t rc = launch_gemm(c, q, st); if (rc) return rc;
-      float* t = dcur; dcur = dnxt; dnxt = t;
+      dcur = dnxt; float* t = dnxt; dnxt = dspare; dspare = t;      // ping-pong between the two workspace buffers; d_dy itself is never written
     }
   }
   return crux_launch_check(c, "dense backward");

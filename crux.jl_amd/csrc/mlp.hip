@@ -96,9 +96,10 @@ int32_t crux_mlp_create(crux_ctx* ctx, int32_t L, const int32_t* dims, const int
   fill_desc(n->nd, L, L > 0 ? dims : dim0, acts, n_extra);
   const size_t bytes = sizeof(float) * (size_t)n->nd.n_params;
   if (hipMalloc(&n->p, bytes) != hipSuccess || hipMalloc(&n->g, bytes) != hipSuccess || hipMalloc(&n->m, bytes) != hipSuccess ||
-      hipMalloc(&n->v, bytes) != hipSuccess || hipMalloc(&n->bp, 2 * sizeof(double)) != hipSuccess) { delete n; return crux_fail(ctx, CRUX_ENOMEM, "mlp: hipMalloc failed"); }
+      hipMalloc(&n->v, bytes) != hipSuccess || hipMalloc(&n->bp, 4 * sizeof(double)) != hipSuccess)   /* [beta1^t, beta2^t, ticket of k_adam_gated, pad] */ { delete n; return crux_fail(ctx, CRUX_ENOMEM, "mlp: hipMalloc failed"); }
   HIPCHK(ctx, hipMemsetAsync(n->p, 0, bytes, ctx->stream)); HIPCHK(ctx, hipMemsetAsync(n->g, 0, bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(n->m, 0, bytes, ctx->stream)); HIPCHK(ctx, hipMemsetAsync(n->v, 0, bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(n->bp, 0, 4 * sizeof(double), ctx->stream));
   *out = n; return CRUX_OK;
 }
 

@@ -169,25 +169,28 @@ __global__ void k_actor_info(const double* __restrict__ st, const double* __rest
   dinfo[CRUX_INFO_LOSS] = (float)(st[0] / (double)B); dinfo[CRUX_INFO_ENTROPY] = (float)(-(st[1] / (double)B)); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
 }
 // Flux.update!(Adam) gated on the gradient norm: NaN => parameters untouched, status set (training.jl:20)
-__global__ void k_adam_gated(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, const double* __restrict__ bp,
-                             double eta, double b1, double b2, double eps, int64_t n, const double* __restrict__ ssq, int32_t* __restrict__ status) {
+__global__ __launch_bounds__(256) void k_adam_gated(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, double* __restrict__ bp,
+                                                    double eta, double b1, double b2, double eps, int64_t n, const double* __restrict__ ssq, int32_t* __restrict__ status) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (isnan(ssq[0])) { if (i == 0) status[0] = CRUX_ENAN; return; }
-  if (i >= n) return;
-  const double gd = (double)g[i];
-  const float mi = (float)(b1 * (double)m[i] + (1.0 - b1) * gd);
-  const float vi = (float)(b2 * (double)v[i] + ((1.0 - b2) * gd) * gd);
-  const float d = (float)((double)mi / (1.0 - bp[0]) / (sqrt((double)vi / (1.0 - bp[1])) + eps) * eta);
-  m[i] = mi; v[i] = vi; p[i] = p[i] - d;
+  if (i < n) {
+    const double gd = (double)g[i];
+    const float mi = (float)(b1 * (double)m[i] + (1.0 - b1) * gd);
+    const float vi = (float)(b2 * (double)v[i] + ((1.0 - b2) * gd) * gd);
+    const float d = (float)((double)mi / (1.0 - bp[0]) / (sqrt((double)vi / (1.0 - bp[1])) + eps) * eta);
+    m[i] = mi; v[i] = vi; p[i] = p[i] - d;
+  }
+  // the beta powers advance once every block has used them: the last block to FINISH (ticket in bp[2]) does it -- no second launch
+  __syncthreads();
+  if (threadIdx.x == 0) { __threadfence(); unsigned* ticket = (unsigned*)(bp + 2);
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) { bp[0] *= b1; bp[1] *= b2; *ticket = 0u; } }
 }
-__global__ void k_adam_advance_gated(double* bp, double b1, double b2, const double* __restrict__ ssq) { if (!isnan(ssq[0])) { bp[0] *= b1; bp[1] *= b2; } }
 
 static int32_t adam_gated(crux_mlp* n, const double* d_ssq, int32_t* d_status) {
   crux_ctx* c = n->ctx;
   if (!n->has_adam) return crux_fail(c, CRUX_EINVAL, "train!: crux_adam_init was not called on this handle");
   const int64_t cnt = n->nd.n_params;
   hipLaunchKernelGGL(k_adam_gated, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, n->p, n->g, n->m, n->v, n->bp, n->eta, n->b1, n->b2, n->eps, cnt, d_ssq, d_status);
-  hipLaunchKernelGGL(k_adam_advance_gated, dim3(1), dim3(1), 0, c->stream, n->bp, n->b1, n->b2, d_ssq);
   return crux_launch_check(c, "k_adam_gated");
 }
 
