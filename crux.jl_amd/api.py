@@ -818,8 +818,9 @@ class TrainingParams:
     (src/training.jl:1-11). early_stopping is expressed as target_kl (PPO's `infos[end][:kl] > target_kl`, ppo.jl:59)."""
 
     def __init__(self, loss, optimizer=None, batch_size=128, epochs=80, target_kl=None, name="", max_batches=math.inf,
-                 shuffle_seed=0):
+                 shuffle_seed=0, update_every=1):
         self.loss = loss
+        self.update_every = int(update_every)        # off-policy solvers: train this network every update_every-th epoch (off_policy.jl:91,96)
         self.optimizer = optimizer or Adam(np.float32(3e-4))
         self.batch_size, self.epochs, self.target_kl, self.name, self.max_batches = int(batch_size), int(epochs), target_kl, name, max_batches
         self.shuffle_seed, self.shuffle_counter = int(shuffle_seed), 0
@@ -1147,13 +1148,16 @@ def _value_training_sac(solver, D, gamma):
         ctx.check(lib.crux_sac_target(A.h, Qm.N1.h, Qm.N2.h, la.h, D.h, float(gamma), solver.noise_seed, 3 * ctr, solver._dy))           # :80
         ctx.check(lib.crux_sac_temp_step(A.h, la.h, D.h, float(solver.P["SAC_H_target"]), solver.noise_seed, 3 * ctr + 1, _vp(raw)))     # :86-88
         info.update({t_opt.name + "loss": float(raw[0]), t_opt.name + "grad_norm": float(raw[1]), "SAC alpha": float(raw[L.INFO["alpha"]])})
-        ctx.check(lib.crux_double_q_step(Q.N1.h, Q.N2.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))                  # :91-93
-        info.update({c_opt.name + "loss": float(raw[0]), c_opt.name + "grad_norm": float(raw[1]), "Q1avg": float(raw[L.INFO["q1avg"]]), "Q2avg": float(raw[L.INFO["q2avg"]])})
-        ctx.check(lib.crux_sac_actor_step(A.h, Q.N1.h, Q.N2.h, la.h, D.h, solver.noise_seed, 3 * ctr + 2, _vp(raw)))                     # :96-98
-        info.update({a_opt.name + "loss": float(raw[0]), a_opt.name + "grad_norm": float(raw[1]), "entropy": float(raw[L.INFO["entropy"]])})
-        polyak_average_(pim, pi, solver.tau)                                                           # :101
+        if epoch % c_opt.update_every == 0:                                                            # :91
+            ctx.check(lib.crux_double_q_step(Q.N1.h, Q.N2.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))              # :92
+            info.update({c_opt.name + "loss": float(raw[0]), c_opt.name + "grad_norm": float(raw[1]), "Q1avg": float(raw[L.INFO["q1avg"]]), "Q2avg": float(raw[L.INFO["q2avg"]])})
+        if epoch % a_opt.update_every == 0:                                                            # :96
+            ctx.check(lib.crux_sac_actor_step(A.h, Q.N1.h, Q.N2.h, la.h, D.h, solver.noise_seed, 3 * ctr + 2, _vp(raw)))                 # :97
+            info.update({a_opt.name + "loss": float(raw[0]), a_opt.name + "grad_norm": float(raw[1]), "entropy": float(raw[L.INFO["entropy"]])})
+            polyak_average_(pim, pi, solver.tau)                                                       # :100 (target update only when the actor trains)
         infos.append(info)
-    return {k: float(np.mean([d[k] for d in infos])) for k in infos[0]}
+    keys = {k for d in infos for k in d}
+    return {k: float(np.mean([d[k] for d in infos if k in d])) for k in keys}      # aggregate_info: mean over the dicts that have the key (logging.jl:60-66)
 
 
 def _value_training_dpg(solver, D, gamma):
@@ -1180,18 +1184,21 @@ def _value_training_dpg(solver, D, gamma):
         ctx.check(lib.crux_dpg_target(Am.h, (Qm.N1 if twin else Qm).h, Qm.N2.h if (twin and solver.target_fn == "td3") else None, D.h, float(gamma),
                                       sm.sigma if sm else -1.0, sm.eps_min if sm else 0.0, sm.eps_max if sm else 0.0, sm.a_min if sm else 0.0, sm.a_max if sm else 0.0,
                                       solver.noise_seed, ctr, solver._dy))                             # :80
-        if twin:
-            ctx.check(lib.crux_double_q_step(Q.N1.h, Q.N2.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))
-            info.update({"Q1avg": float(raw[L.INFO["q1avg"]]), "Q2avg": float(raw[L.INFO["q2avg"]])})
-        else:
-            ctx.check(lib.crux_q_step(Q.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))
-            info["Qavg"] = float(raw[L.INFO["q1avg"]])
-        info.update({c_opt.name + "loss": float(raw[0]), c_opt.name + "grad_norm": float(raw[1])})   # :91-93
-        ctx.check(lib.crux_dpg_actor_step(A.h, (Q.N1 if twin else Q).h, D.h, _vp(raw)))                 # :96-98
-        info.update({a_opt.name + "loss": float(raw[0]), a_opt.name + "grad_norm": float(raw[1])})
-        polyak_average_(pim, pi, solver.tau)                                                           # :101
+        if epoch % c_opt.update_every == 0:                                                            # :91
+            if twin:
+                ctx.check(lib.crux_double_q_step(Q.N1.h, Q.N2.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))
+                info.update({"Q1avg": float(raw[L.INFO["q1avg"]]), "Q2avg": float(raw[L.INFO["q2avg"]])})
+            else:
+                ctx.check(lib.crux_q_step(Q.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))
+                info["Qavg"] = float(raw[L.INFO["q1avg"]])
+            info.update({c_opt.name + "loss": float(raw[0]), c_opt.name + "grad_norm": float(raw[1])})   # :92
+        if epoch % a_opt.update_every == 0:                                                            # :96 (TD3's delayed policy update = a_opt.update_every)
+            ctx.check(lib.crux_dpg_actor_step(A.h, (Q.N1 if twin else Q).h, D.h, _vp(raw)))             # :97
+            info.update({a_opt.name + "loss": float(raw[0]), a_opt.name + "grad_norm": float(raw[1])})
+            polyak_average_(pim, pi, solver.tau)                                                       # :100
         infos.append(info)
-    return {k: float(np.mean([d[k] for d in infos])) for k in infos[0]}
+    keys = {k for d in infos for k in d}
+    return {k: float(np.mean([d[k] for d in infos if k in d])) for k in keys}                          # aggregate_info: mean over the dicts that have the key (logging.jl:60-66)
 
 
 def value_training(solver, D, gamma):
