@@ -118,6 +118,9 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
     sm[Lt::oW2C + i * MF8_LD + o] = v; }
   for (int q = tid; q < MF_HID * Lt::W1LD; q += NT) sm[Lt::oW1R + q] = 0.f;
   if (tid < 16) { sm[Lt::oB3 + tid] = 0.f; sm[Lt::oEX + tid] = 0.f; }
+  uint32_t my_xcc = 0;
+  if (tid == 0) { asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc)); my_xcc &= 0xf;
+    __hip_atomic_store(a.xctr + 8 + p, my_xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // checked against the peer's at the first exchange
   __syncthreads();
   for (int s = tid; s < NS; s += NT) { const bool in = s < ns_valid; const int pc = s_canon(s);
     if (in) sm[s_master(s)] = a.p[pc];
@@ -441,6 +444,9 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
           const unsigned want = 2u * (unsigned)(xstep + 1); unsigned spins = 0; bool ok = true;
           while (__hip_atomic_load(a.xctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 24) || __hip_atomic_load(a.xctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; } }   // never hang the GPU
+          if (ok && xstep == 0) {   // the unfenced exchange is only coherent inside one XCD's L2: refuse to train if the two workgroups were placed on different XCDs
+            const unsigned peer_xcc = __hip_atomic_load(a.xctr + 8 + (1 - p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (peer_xcc != my_xcc + 1u) ok = false; }
           if (!ok) __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           sm[Lt::oRED + 16] = ok ? 0.f : 1.f;
         }
