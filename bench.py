@@ -67,6 +67,9 @@ def ppo_iteration(crux, pi, buf, sampler, a_opt, c_opt, P, it, sync=None):
     class _S:
         pass
     sv = _S(); sv.agent = crux.PolicyParams(pi); sv.a_opt, sv.c_opt, sv.P = a_opt, c_opt, P
+    if sync == "native":   # the library's own RCCL path: chunks of SYNC_EVERY epochs + grouped all-reduce, all enqueued without a host sync
+        ti = crux.policy_gradient_training_synced(sv, buf, SYNC_EVERY)
+        return ti["actor_batches_trained"] + ti["critic_batches_trained"], info
     nb, e_total, k = 0, a_opt.epochs, SYNC_EVERY
     try:
         done = 0
@@ -129,6 +132,8 @@ def main():
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner on stdout) are pointed at stderr instead
+    sys.stdout.flush(); json_fd = os.dup(1); os.dup2(2, 1)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -176,6 +181,29 @@ def main():
             flat.mul_(1.0 / world)
             torch._foreach_copy_(ts, list(flat.split(sizes)))   # tensors alias library memory
             torch.cuda.current_stream().synchronize()
+
+        # preferred: the library's native communicator (RCCL dlopen'ed by libcruxhip, id shipped through torch.distributed);
+        # the torch.distributed exchange above stays as the fallback when RCCL cannot be initialised from the library
+        comm_kind = "torch.distributed all_reduce (host-synchronised per exchange)"; torch_sync = sync
+        if os.environ.get("CRUX_NATIVE_COMM", "1") != "0":
+            uid_np = np.zeros(129, np.uint8)
+            if rank == 0:
+                try:
+                    uid_np[:128] = ctx.comm_unique_id(); uid_np[128] = 1
+                except Exception as e:
+                    print("bench.py: native RCCL unavailable (%r)" % (e,), file=sys.stderr)
+            uid = torch.from_numpy(uid_np).cuda(); dist.broadcast(uid, 0); uid_np = uid.cpu().numpy()     # every rank takes part, whatever happened on rank 0
+            if uid_np[128]:
+                try:
+                    ctx.comm_init(rank, world, uid_np[:128].copy())
+                    sync = "native"; comm_kind = "libcruxhip RCCL communicator (stream-ordered grouped all-reduce)"
+                except Exception as e:
+                    print("bench.py: native RCCL communicator failed on rank %d (%r)" % (rank, e), file=sys.stderr)
+            ok = torch.tensor([1 if sync == "native" else 0], device="cuda"); dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks or none
+            if int(ok.item()) == 0 and sync == "native":
+                ctx.comm_destroy()
+            if int(ok.item()) == 0:
+                sync = torch_sync; comm_kind = "torch.distributed all_reduce (host-synchronised per exchange)"
 
     def barrier():
         ctx.sync()
@@ -252,7 +280,7 @@ def main():
             "config": {"workload": "PPO CartPole-v1 (device dynamics), DiscreteNetwork 4-64-64-2 + critic 4-64-64-1, 32 envs x 2048-step rollout per GPU, "
                                    "batch 128, 80 epochs actor + 80 epochs critic (81920 Adam steps/iter, KL early-stop off), Adam 3e-4",
                        "envs_per_gpu": N_ENVS, "rollout_T": T, "batch_size": BATCH, "epochs": EPOCHS,
-                       "parallelism": "env-shards x%d, per-epoch parameter all-reduce" % world if world > 1 else "single GPU"},
+                       "parallelism": ("env-shards x%d, parameter+Adam-moment all-reduce every %d epoch(s), %s" % (world, SYNC_EVERY, comm_kind)) if sync is not None else "single GPU"},
             "grad_steps_per_s": grad_steps / dt,
             "phase_ms_per_iter": {k: v[0] / args.steps for k, v in prof.items()},
             "rollout_env_steps_per_s": (N_ENVS * T * args.steps) / (prof["rollout"][0] * 1e-3) if prof["rollout"][0] > 0 else None,
@@ -269,7 +297,7 @@ def main():
             out["multi_seed"] = multi
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        sys.stdout.flush(); os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

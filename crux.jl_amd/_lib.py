@@ -101,6 +101,12 @@ SIGNATURES = {
     "crux_adam_apply": (i32, [vp, f32]),
     "crux_rollout_multi": (i32, [i32, vp, vp, P(RolloutCfg), vp, i64, vp, vp]),
     "crux_policy_gradient_training_multi": (i32, [i32, vp, vp, vp, P(TrainCfg), P(TrainCfg), vp, vp]),
+    "crux_policy_gradient_training_synced": (i32, [vp, vp, vp, P(TrainCfg), P(TrainCfg), i32, vp, vp]),
+    "crux_comm_unique_id": (i32, [vp, vp]),
+    "crux_comm_init": (i32, [vp, i32, i32, vp]),
+    "crux_comm_destroy": (i32, [vp]),
+    "crux_comm_size": (i32, [vp]),
+    "crux_allreduce_mean": (i32, [vp]),
     "crux_first_episode_metrics": (i32, [vp, i32, i64, f32, vp, vp, vp, vp]),
     "crux_dqn_target": (i32, [vp, vp, f32, vp]),
     "crux_td_error": (i32, [vp, vp, vp, vp]),

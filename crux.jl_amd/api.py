@@ -37,6 +37,21 @@ class Context:
             raise L.CruxError(rc, (self.lib.crux_last_error(self.h) or b"").decode())
         return rc
 
+    # ---- replica group (RCCL over xGMI, one process per GPU; cruxhip.h "multi-GPU") -------------------------------------------
+    def comm_unique_id(self):
+        """128-byte RCCL id; rank 0 creates it and ships it to the other ranks (torch.distributed.broadcast, a file, MPI ...)."""
+        b = np.zeros(128, np.uint8); self.check(self.lib.crux_comm_unique_id(self.h, _vp(b))); return b
+
+    def comm_init(self, rank, nranks, uid):
+        uid = np.ascontiguousarray(np.asarray(uid, np.uint8)); assert uid.size == 128
+        self.check(self.lib.crux_comm_init(self.h, int(rank), int(nranks), _vp(uid)))
+
+    def comm_destroy(self):
+        self.check(self.lib.crux_comm_destroy(self.h))
+
+    def comm_size(self):
+        return int(self.lib.crux_comm_size(self.h))
+
     def sync(self):
         self.check(self.lib.crux_sync(self.h))
 
@@ -928,6 +943,30 @@ def policy_gradient_training(solver, D, perms_a=None, perms_c=None):
             d = {k: v for k, v in d.items() if k.startswith(p.name)}
         info.update(d); info[p.name + "batches_trained"] = int(raw[L.INFO["batches_trained"]])
     return info
+
+
+def policy_gradient_training_synced(solver, D, sync_every=1):
+    """policy_gradient_training for environment-shard replicas: every `sync_every` epochs the replica group attached to the context
+    (Context.comm_init) averages actor/critic parameters and Adam moments with one RCCL all-reduce enqueued behind the learner kernels.
+    Without a group it equals policy_gradient_training bit for bit."""
+    A, Cn, pa, pc = actor(solver.agent.pi), critic(solver.agent.pi), solver.a_opt, solver.c_opt
+    _ensure_opt(A, pa); _ensure_opt(Cn, pc)
+    ca, cc = _train_cfg(A, pa, solver.P), _train_cfg(Cn, pc, solver.P)
+    ra, rc_ = np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32)
+    A.ctx.check(A.ctx.lib.crux_policy_gradient_training_synced(A.h, Cn.h, D.h, C.byref(ca), C.byref(cc), int(sync_every), _vp(ra), _vp(rc_)))
+    info = {}
+    for p, raw in ((pa, ra), (pc, rc_)):
+        p.shuffle_counter += int(raw[L.INFO["epochs_run"]])
+        d = _info_dict(p, raw)
+        if p is pc:
+            d = {k: v for k, v in d.items() if k.startswith(p.name)}
+        info.update(d); info[p.name + "batches_trained"] = int(raw[L.INFO["batches_trained"]])
+    return info
+
+
+def allreduce_mean_(net):
+    """average a network's parameters and Adam moments over the replica group (stream-ordered; no-op without a group)."""
+    net.ctx.check(net.ctx.lib.crux_allreduce_mean(net.h))
 
 
 def policy_gradient_training_multi(pis, a_opt, c_opt, P, buffers):

@@ -26,6 +26,7 @@ struct crux_ctx {
   void* scratch = nullptr; size_t scratch_bytes = 0;   // reusable device scratch
   void* pinned = nullptr; size_t pinned_bytes = 0;     // reusable pinned host staging
   hipStream_t aux_stream = nullptr; hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr;   // second learner stream (actor || critic)
+  void* comm = nullptr; int comm_rank = 0, comm_n = 0;   // RCCL communicator of the replica group (comm.hip)
   void* xmulti[2] = {nullptr, nullptr}; size_t xmulti_bytes[2] = {0, 0};   // exchange areas + argument blocks of the batched multi-learner launch
   void* xbuf[2] = {nullptr, nullptr};   // gradient exchange areas of the two-CU learner kernel, one per learner stream
 };
@@ -146,6 +147,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 int32_t crux_launch_check(crux_ctx* ctx, const char* what);
+int32_t crux_comm_allreduce_mean_impl(crux_ctx* c, crux_mlp* const* nets, int n_nets);   // comm.hip
 // dense.hip: differentiable Chain(Dense...) on the tile-GEMM engine
 int32_t crux_dense_forward(crux_mlp* n, const float* d_x, int64_t B, hipStream_t st);
 int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st);

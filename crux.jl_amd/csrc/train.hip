@@ -534,6 +534,67 @@ extern "C" int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* cons
   return CRUX_OK;
 }
 
+// policy_gradient_training for environment-shard replicas: the same two concurrent learner kernels, launched per chunk of
+// `sync_every` epochs; after each chunk the replicas' parameters and Adam moments are averaged with ONE grouped RCCL all-reduce enqueued on
+// the same stream -- the host does not synchronise until the last chunk is queued. Without a communicator (crux_comm_init not called, or a
+// group of 1) the all-reduce is skipped and the result is bit-identical to crux_policy_gradient_training (the epoch orders are precomposed,
+// the learner state persists in device memory between launches).
+extern "C" int32_t crux_policy_gradient_training_synced(crux_mlp* actor, crux_mlp* critic, crux_buffer* buf, const crux_train_cfg* cfg_a, const crux_train_cfg* cfg_c,
+                                                        int32_t sync_every, float* info_a, float* info_c) {
+  if (!actor || !critic || !buf || !cfg_a || !cfg_c || sync_every < 1) return CRUX_EINVAL;
+  crux_ctx* c = actor->ctx;
+  if (!(cfg_a->target_kl < 0.f) || cfg_a->max_batches > 0 || cfg_c->max_batches > 0) return crux_fail(c, CRUX_EUNSUP, "policy_gradient_training_synced: early stopping / max_batches would let replicas diverge in epoch count");
+  if (buf->elements <= 0 || cfg_a->epochs < 1 || cfg_c->epochs != cfg_a->epochs) return crux_fail(c, CRUX_EINVAL, "policy_gradient_training_synced: empty buffer, epochs < 1 or actor/critic epoch counts differ");
+  const int64_t len = buf->elements; if (len >= ((int64_t)1 << 31)) return crux_fail(c, CRUX_EUNSUP, "policy_gradient_training_synced: buffer too long");
+  if (!c->aux_stream) {
+    int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+    if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi_p) != hipSuccess) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev1, hipEventDisableTiming));
+  }
+  const int E = cfg_a->epochs, nch = (E + sync_every - 1) / sync_every;
+  TrainArgs a, k; int32_t rc = fill_args(a, actor, buf, cfg_a, cfg_a->loss); if (rc) return rc;
+  rc = fill_args(k, critic, buf, cfg_c, cfg_c->loss); if (rc) return rc;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t eb = al(sizeof(float) * CRUX_INFO_N * (size_t)E), stb = 256 * (size_t)nch;
+  char* sc = (char*)crux_scratch(c, 2 * stb + 2 * eb + 256); if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_gradient_training_synced: scratch");
+  HIPCHK(c, hipMemsetAsync(sc, 0, 2 * stb + 2 * eb, c->stream));
+  char* sta_d = sc; char* stc_d = sc + stb; float* eia = (float*)(sc + 2 * stb); float* eic = (float*)(sc + 2 * stb + eb);
+  int32_t* oa = nullptr; int32_t* oc = nullptr;
+  rc = build_orders(c, buf, 0, nullptr, cfg_a->shuffle_seed, cfg_a->shuffle_counter, nullptr, E, c->stream, &oa); if (rc) return rc;
+  rc = build_orders(c, buf, 1, oa + (size_t)(E - 1) * (size_t)len, cfg_c->shuffle_seed, cfg_c->shuffle_counter, nullptr, E, c->stream, &oc); if (rc) return rc;
+  k.order_a = buf->order_c; k.order_b = buf->order_d;
+  crux_mlp* nets[2] = {actor, critic};
+  for (int ch = 0; ch < nch; ++ch) {
+    const int e0 = ch * sync_every, ne = (E - e0 < sync_every) ? E - e0 : sync_every;
+    a.epochs = ne; k.epochs = ne; a.ord_all = oa + (size_t)e0 * (size_t)len; k.ord_all = oc + (size_t)e0 * (size_t)len;
+    a.status = (int32_t*)(sta_d + 256 * (size_t)ch); k.status = (int32_t*)(stc_d + 256 * (size_t)ch);
+    a.epoch_infos = eia + (size_t)e0 * CRUX_INFO_N; k.epoch_infos = eic + (size_t)e0 * CRUX_INFO_N;
+    HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
+    rc = launch_train(c, k, CRUX_PROF_TRAIN_CRITIC, c->aux_stream); if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->aux_ev1, c->aux_stream));
+    rc = launch_train(c, a, CRUX_PROF_TRAIN_ACTOR); if (rc) return rc;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
+    rc = crux_comm_allreduce_mean_impl(c, nets, 2); if (rc) return rc;
+  }
+  std::vector<int32_t> hs((size_t)nch * 128); std::vector<float> hi(2 * (size_t)E * CRUX_INFO_N);
+  HIPCHK(c, hipMemcpyAsync(hs.data(), sc, 2 * stb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(hi.data(), eia, sizeof(float) * CRUX_INFO_N * (size_t)E, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(hi.data() + (size_t)E * CRUX_INFO_N, eic, sizeof(float) * CRUX_INFO_N * (size_t)E, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int w = 0; w < 2; ++w) {
+    int bt = 0, er = 0;
+    for (int ch = 0; ch < nch; ++ch) { const int32_t* st = hs.data() + (size_t)w * (stb / 4) + 64 * (size_t)ch;
+      if (st[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
+      if (st[0]) return crux_fail(c, st[0], "learner kernel reported status %d in chunk %d", st[0], ch);
+      bt += st[1]; er += st[2]; }
+    float* out = w ? info_c : info_a; const float* ei = hi.data() + (size_t)w * (size_t)E * CRUX_INFO_N;
+    if (out) { for (int q = 0; q < CRUX_INFO_N; ++q) { double s = 0; for (int e = 0; e < er; ++e) s += (double)ei[(size_t)e * CRUX_INFO_N + q]; out[q] = er ? (float)(s / (double)er) : 0.f; }
+      out[CRUX_INFO_BATCHES_TRAINED] = (float)bt; out[CRUX_INFO_EPOCHS_RUN] = (float)er; }
+  }
+  return crux_buffer_apply_order(buf, oc + (size_t)(E - 1) * (size_t)len, len);
+}
+
 // ---- off-policy pieces ------------------------------------------------------------------------------
 int32_t crux_td_step(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight, float* info_out) {
   if (!net || !batch || !d_y) return CRUX_EINVAL;

@@ -287,6 +287,23 @@ int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* critic, crux_bu
 int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* const* actors, crux_mlp* const* critics, crux_buffer* const* bufs,
                                             const crux_train_cfg* cfg_actor, const crux_train_cfg* cfg_critic, float* info_a, float* info_c);
 
+/* ---- multi-GPU: environment-shard replicas, one process per GPU, RCCL over xGMI -------------------------------------
+ * The reference has no distributed path (Sampler.step!/batch_train! run in one Julia process, src/sampler.jl:137-160,
+ * src/training.jl:31-56); these entries are what a Distributed.jl / MPI.jl launcher around it would bind. Rank 0 calls
+ * crux_comm_unique_id and ships the 128 bytes to the other ranks by any means; every rank then calls crux_comm_init.
+ * crux_allreduce_mean averages a network's parameters AND Adam moments over the group, stream-ordered on the context's stream
+ * (no host synchronisation). RCCL is dlopen'ed on first use; without it these return CRUX_ERCCL and nothing else is affected.       */
+int32_t crux_comm_unique_id(crux_ctx* ctx, uint8_t* id128 /* [128] out */);
+int32_t crux_comm_init(crux_ctx* ctx, int32_t rank, int32_t nranks, const uint8_t* id128);
+int32_t crux_comm_destroy(crux_ctx* ctx);
+int32_t crux_comm_size(const crux_ctx* ctx);               /* 1 when no communicator is attached */
+int32_t crux_allreduce_mean(crux_mlp* net);
+/* policy_gradient_training (src/model_free/on_policy.jl:56-78) for replicas: the epochs run in chunks of sync_every, each chunk followed
+ * by crux_allreduce_mean(actor), (critic) on the stream. With no communicator it is bit-identical to crux_policy_gradient_training.
+ * Requires no KL early stopping / max_batches (replicas must run the same number of epochs) and equal actor/critic epoch counts.     */
+int32_t crux_policy_gradient_training_synced(crux_mlp* actor, crux_mlp* critic, crux_buffer* buf, const crux_train_cfg* cfg_a, const crux_train_cfg* cfg_c,
+                                             int32_t sync_every, float* info_a /* [CRUX_INFO_N] */, float* info_c);
+
 /* train!(pi, loss, p) (training.jl:13-25): one gradient step on explicit rows `ids` (host, 0-based)
  * of the buffer. Returns CRUX_ENAN (without updating) when the grad norm is NaN (:20).            */
 int32_t crux_train_step(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids,

@@ -132,3 +132,56 @@ def test_batched_rollouts_match_single_rollouts(gpu_ctx):
             assert np.array_equal(pa[r][1][k], pb[r][1][k], equal_nan=True) if pa[r][1][k].dtype.kind == "f" else np.array_equal(pa[r][1][k], pb[r][1][k]), (r, k)
         assert ia[r]["n_episode_end"] == ib[r]["n_episode_end"] and ia[r]["sum_r"] == ib[r]["sum_r"]
     assert not np.array_equal(pa[0][1]["s"], pa[1][1]["s"])
+
+
+@pytest.mark.gpu
+def test_synced_training_equals_plain_call_without_and_with_a_group_of_one(gpu_ctx):
+    """crux_policy_gradient_training_synced: the learner launched per chunk of `sync_every` epochs (+ the stream-ordered RCCL all-reduce of
+    parameters and Adam moments) must equal the single-launch call bit for bit when there is nothing to average: (1) no communicator,
+    (2) a real RCCL communicator of size 1 (exercises dlopen, ncclCommInitRank, the grouped all-reduce and the 1/n scaling on the GPU)."""
+    from parity import crux
+    rng = np.random.default_rng(11); n, bs, E = 640, 128, 7
+    extras = ["return", "logprob", "advantage"]
+    ai = rng.integers(0, 2, n)
+    data = {"s": rng.normal(0, 1, (4, n)).astype(np.float32), "a": np.eye(2, dtype=bool)[:, ai], "sp": rng.normal(0, 1, (4, n)).astype(np.float32), "r": np.ones((1, n), np.float32),
+            "done": np.zeros((1, n), bool), "episode_end": np.zeros((1, n), bool), "return": rng.normal(0, 1, (1, n)).astype(np.float32),
+            "logprob": rng.normal(-0.7, 0.05, (1, n)).astype(np.float32), "advantage": rng.normal(0, 1, (1, n)).astype(np.float32)}
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+
+    def run(mode, ctx):
+        a = crux.DiscreteNetwork(parity.chain(parity.ACTOR_DIMS, parity.ACTS), [1, 2], seed=3, stream=0, ctx=ctx)
+        c = crux.ContinuousNetwork(parity.chain(parity.CRITIC_DIMS, parity.ACTS), seed=3, stream=1, ctx=ctx)
+        pi = crux.ActorCritic(a, c)
+        b = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), n, extras, ctx=ctx); b.push_(data)
+
+        class _S:
+            pass
+        sv = _S(); sv.agent = crux.PolicyParams(pi); sv.P = P
+        sv.a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=bs, epochs=E, name="actor_", shuffle_seed=31)
+        sv.c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=bs, epochs=E, name="critic_", shuffle_seed=32)
+        outs = []
+        for _ in range(2):   # twice: Adam state and shuffle counters carry over
+            info = crux.policy_gradient_training(sv, b) if mode == "plain" else crux.policy_gradient_training_synced(sv, b, sync_every=3)
+            outs.append(info)
+        m, v = a.get_adam_state() if hasattr(a, "get_adam_state") else (None, None)
+        return pi.A.get_params(), pi.C.get_params(), b["s"], b["advantage"], outs, m, v
+
+    ref = run("plain", gpu_ctx)
+    got = run("synced", gpu_ctx)
+    ctx1 = crux.Context(0)
+    try:
+        ctx1.comm_init(0, 1, ctx1.comm_unique_id())
+        assert ctx1.comm_size() == 1
+        grp = run("synced", ctx1)
+    finally:
+        ctx1.comm_destroy()
+    for other in (got, grp):
+        for x, y in zip(ref[:4], other[:4]):
+            assert np.array_equal(x, y)
+        if ref[5] is not None:
+            assert np.array_equal(ref[5], other[5]) and np.array_equal(ref[6], other[6])
+        for i0, i1 in zip(ref[4], other[4]):
+            assert i0["actor_batches_trained"] == i1["actor_batches_trained"] == E * (n // bs)
+            for k in ("actor_loss", "critic_loss", "kl"):
+                if k in i0:
+                    assert np.isclose(i0[k], i1[k], rtol=1e-6, atol=1e-7)
