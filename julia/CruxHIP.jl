@@ -143,6 +143,17 @@ function Crux.policy_gradient_training(𝒮::Crux.OnPolicySolver, 𝒟::HipBuffe
     Dict("actor_loss" => ia[1], "actor_grad_norm" => ia[2], :kl => ia[4], :entropy => ia[3], "critic_loss" => ic[1], "critic_grad_norm" => ic[2])
 end
 
+# --- replica groups (one Julia process per GPU, e.g. under MPI.jl or Distributed.jl): RCCL communicator owned by the library
+comm_unique_id(c::Ctx) = (id = zeros(UInt8, 128); check(c, ccall((:crux_comm_unique_id, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}), c.h, id)); id)   # rank 0, then MPI.Bcast!(id, 0, comm)
+comm_init!(c::Ctx, rank::Integer, nranks::Integer, id::Vector{UInt8}) = check(c, ccall((:crux_comm_init, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), c.h, rank, nranks, id))
+allreduce_mean!(π::HipNetwork) = check(π.ctx, ccall((:crux_allreduce_mean, LIB), Int32, (Ptr{Cvoid},), π.h))   # parameters + Adam moments, stream-ordered
+function policy_gradient_training_synced(𝒮::Crux.OnPolicySolver, 𝒟::HipBuffer; sync_every=1)                    # on_policy.jl:56-78 for env-shard replicas
+    A, C_ = Crux.actor(𝒮.agent.π), Crux.critic(𝒮.agent.π); ia, ic = zeros(Float32, INFO_N), zeros(Float32, INFO_N)
+    check(A.ctx, ccall((:crux_policy_gradient_training_synced, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{TrainCfg}, Ref{TrainCfg}, Int32, Ptr{Float32}, Ptr{Float32}),
+                       A.h, C_.h, 𝒟.h, train_cfg(A, 𝒮.a_opt, 𝒮.𝒫), train_cfg(C_, 𝒮.c_opt, 𝒮.𝒫), sync_every, ia, ic))
+    Dict("actor_loss" => ia[1], "actor_grad_norm" => ia[2], :kl => ia[4], :entropy => ia[3], "critic_loss" => ic[1], "critic_grad_norm" => ic[2])
+end
+
 # off-policy seams (value_training, src/model_free/off_policy.jl:66-111) follow the same pattern:
 #   dqn_target  -> :crux_dqn_target      td_error -> :crux_td_error        train!(critic, td_loss)        -> :crux_td_step / :crux_q_step
 #   sac_target  -> :crux_sac_target      sac_temp_loss -> :crux_sac_temp_step    double_Q_loss -> :crux_double_q_step    sac_actor_loss -> :crux_sac_actor_step
