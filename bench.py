@@ -114,7 +114,14 @@ def cpu_baseline():
     per_env_step = t_roll / (N_ENVS * Ts)
     per_grad_step = t_train / (2 * n_mb)
     t_iter = per_env_step * N_ENVS * T + per_grad_step * 2 * EPOCHS * (N_ENVS * T // BATCH)
-    return {"value": N_ENVS * T / t_iter, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    model = "?"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return {"value": N_ENVS * T / t_iter, "unit": "env-steps/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": os.cpu_count(),
             "sample": "oracle/ (C restatement of Crux.jl, 1 thread): 32x%d-step rollout+GAE (%.2fs) and %d Adam steps at B=128 (%.2fs), extrapolated to one 65536-transition / 81920-step iteration"
                       % (Ts, t_roll, 2 * n_mb, t_train),
             "grad_steps_per_s": 1.0 / per_grad_step, "rollout_env_steps_per_s": 1.0 / per_env_step}
