@@ -134,7 +134,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sync", action="store_true", help="exercise the multi-GPU parameter exchange even at world size 1 (testing)")
-    ap.add_argument("--replicas", type=int, default=48, help="also time S independent PPO learners (multi-seed) trained by two batched launches per iteration: the chip-level utilisation line (0 = skip)")
+    ap.add_argument("--replicas", type=int, default=64, help="also time S independent PPO learners (multi-seed) trained by two batched launches per iteration: the chip-level utilisation line (0 = skip)")
+    ap.add_argument("--replicas-wide", type=int, default=128, help="second multi-seed line with one CU per learner (population > 64): the highest chip utilisation (0 = skip)")
     ap.add_argument("--early-stop", action="store_true", help="also time the KL-early-stopping variant (target_kl=0.012)")
     args = ap.parse_args()
 
@@ -245,32 +246,39 @@ def main():
         early = {"env_steps_per_s": args.steps * N_ENVS * T / d1, "grad_steps_per_s": nbs / d1, "grad_steps_per_iter": nbs / args.steps}
 
     multi = None
-    if args.replicas > 1 and world == 1:
-      try:
-          Sn = args.replicas
-          probs = [build_problem(crux, cdist.shard_seed(1000, r)) for r in range(Sn)]
-          am = crux.TrainingParams(loss=crux.ppo_loss, batch_size=BATCH, epochs=EPOCHS, target_kl=None, name="actor_", shuffle_seed=5000)
-          cm = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=BATCH, epochs=EPOCHS, name="critic_", shuffle_seed=6000)
+    def multi_seed_line(Sn):
+        try:
+            probs = [build_problem(crux, cdist.shard_seed(1000, r)) for r in range(Sn)]
+            am = crux.TrainingParams(loss=crux.ppo_loss, batch_size=BATCH, epochs=EPOCHS, target_kl=None, name="actor_", shuffle_seed=5000)
+            cm = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=BATCH, epochs=EPOCHS, name="critic_", shuffle_seed=6000)
 
-          def multi_iteration(k):
-              crux.steps_multi_([q[2] for q in probs], [q[1] for q in probs], Nsteps=probs[0][1].capacity, explore=True, i=k * probs[0][1].capacity, reset=True)   # one rollout launch for all S problems
-              for (pi_r, buf_r, smp_r) in probs:
-                  crux.whiten_(buf_r, "advantage")
-              infos = crux.policy_gradient_training_multi([q[0] for q in probs], am, cm, P, [q[1] for q in probs])
-              return sum(i["actor_batches_trained"] + i["critic_batches_trained"] for i in infos)
-          multi_iteration(0); ctx.sync(); ctx.prof_reset(); ctx.prof_enable(True); t1 = time.perf_counter(); gsm = 0
-          n_it = max(1, min(args.steps, 2))
-          for k in range(n_it):
-              gsm += multi_iteration(1 + k)
-          ctx.sync(); d1 = time.perf_counter() - t1; ctx.prof_enable(False)
-          ms_a, n_a = ctx.prof_get("train_actor")
-          flops_a = Sn * EPOCHS * (N_ENVS * T // BATCH) * FLOP_ACTOR_STEP            # per batched actor launch
-          multi = {"replicas": Sn, "env_steps_per_s": n_it * Sn * N_ENVS * T / d1, "grad_steps_per_s": gsm / d1, "ms_per_iteration": 1e3 * d1 / n_it,
-                   "batched_actor_launch_ms": ms_a / max(1, n_a), "actor_launch_TFLOPs": flops_a / (ms_a / max(1, n_a) * 1e-3) / 1e12,
-                   "actor_launch_frac_of_f32_mfma_peak": flops_a / (ms_a / max(1, n_a) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                   "note": "S independent PPO problems (own envs, buffers, seeds); all S actors in one launch, all S critics in a concurrent one: 4 S CUs busy"}
-      except Exception as e:      # supplementary line: never let it take the headline measurement down
-        multi = {"replicas": args.replicas, "error": repr(e)}
+            def multi_iteration(k):
+                crux.steps_multi_([q[2] for q in probs], [q[1] for q in probs], Nsteps=probs[0][1].capacity, explore=True, i=k * probs[0][1].capacity, reset=True)   # one rollout launch for all S problems
+                crux.whiten_multi_([q[1] for q in probs], "advantage")
+                infos = crux.policy_gradient_training_multi([q[0] for q in probs], am, cm, P, [q[1] for q in probs])
+                return sum(i["actor_batches_trained"] + i["critic_batches_trained"] for i in infos)
+            multi_iteration(0); ctx.sync(); ctx.prof_reset(); ctx.prof_enable(True); t1 = time.perf_counter(); gsm = 0
+            n_it = max(1, min(args.steps, 2))
+            for k in range(n_it):
+                gsm += multi_iteration(1 + k)
+            ctx.sync(); d1 = time.perf_counter() - t1; ctx.prof_enable(False)
+            ms_a, n_a = ctx.prof_get("train_actor")
+            flops_a = Sn * EPOCHS * (N_ENVS * T // BATCH) * FLOP_ACTOR_STEP            # per batched actor launch
+            cus = 2 if Sn <= 64 else 1
+            return {"replicas": Sn, "cus_per_learner": cus, "env_steps_per_s": n_it * Sn * N_ENVS * T / d1, "grad_steps_per_s": gsm / d1, "ms_per_iteration": 1e3 * d1 / n_it,
+                    "phase_ms_per_iteration": {k: ctx.prof_get(k)[0] / n_it for k in ("rollout", "values", "gae", "whiten", "train_actor")},
+                    "batched_actor_launch_ms": ms_a / max(1, n_a), "actor_launch_TFLOPs": flops_a / (ms_a / max(1, n_a) * 1e-3) / 1e12,
+                    "actor_launch_frac_of_f32_mfma_peak": flops_a / (ms_a / max(1, n_a) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "actor_plus_critic_frac_of_f32_mfma_peak": (flops_a + Sn * EPOCHS * (N_ENVS * T // BATCH) * FLOP_CRITIC_STEP) / (ms_a / max(1, n_a) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "note": "S independent PPO problems (own envs, buffers, seeds); all S actors in one launch, all S critics in a concurrent one: %d S CUs busy" % (2 * cus)}
+        except Exception as e:      # supplementary line: never let it take the headline measurement down
+            return {"replicas": Sn, "error": repr(e)}
+
+    multi = multi_wide = None
+    if args.replicas > 1 and world == 1:
+        multi = multi_seed_line(args.replicas)
+        if args.replicas_wide > 1:
+            multi_wide = multi_seed_line(args.replicas_wide)
 
     if rank == 0:
         env_steps = args.steps * N_ENVS * T * world
@@ -302,6 +310,8 @@ def main():
             out["early_stop"] = early
         if multi is not None:
             out["multi_seed"] = multi
+        if multi_wide is not None:
+            out["multi_seed_one_cu_per_learner"] = multi_wide
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush(); os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -102,6 +102,9 @@ SIGNATURES = {
     "crux_rollout_multi": (i32, [i32, vp, vp, P(RolloutCfg), vp, i64, vp, vp]),
     "crux_policy_gradient_training_multi": (i32, [i32, vp, vp, vp, P(TrainCfg), P(TrainCfg), vp, vp]),
     "crux_policy_gradient_training_synced": (i32, [vp, vp, vp, P(TrainCfg), P(TrainCfg), i32, vp, vp]),
+    "crux_fill_gae_multi": (i32, [i32, vp, vp, f32, f32, i32]),
+    "crux_whiten_multi": (i32, [i32, vp, i32]),
+    "crux_ctx_set_learner_cus": (i32, [vp, i32]),
     "crux_comm_unique_id": (i32, [vp, vp]),
     "crux_comm_init": (i32, [vp, i32, i32, vp]),
     "crux_comm_destroy": (i32, [vp]),

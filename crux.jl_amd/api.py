@@ -38,6 +38,10 @@ class Context:
         return rc
 
     # ---- replica group (RCCL over xGMI, one process per GPU; cruxhip.h "multi-GPU") -------------------------------------------
+    def set_learner_cus(self, cus):
+        """0 = automatic, 1 = one CU per small-MLP learner, 2 = two CUs of one XCD per learner (cruxhip.h)."""
+        self.check(self.lib.crux_ctx_set_learner_cus(self.h, int(cus)))
+
     def comm_unique_id(self):
         """128-byte RCCL id; rank 0 creates it and ships it to the other ranks (torch.distributed.broadcast, a file, MPI ...)."""
         b = np.zeros(128, np.uint8); self.check(self.lib.crux_comm_unique_id(self.h, _vp(b))); return b
@@ -790,10 +794,16 @@ def steps_multi_(samplers, buffers, Nsteps=1, explore=False, i=0, reset=False):
     sr, ne = np.zeros(n, np.float64), np.zeros(n, np.int64)
     s0.ctx.check(s0.ctx.lib.crux_rollout_multi(n, he, hp, C.byref(cfg), hb, Nsteps // E, _vp(sr), _vp(ne)))
     out = []
+    if all(b.haskey("advantage") and len(b) == Nsteps for b in buffers):     # same rule as steps_ (sampler.jl:62-63), batched over the problems
+        hc = (C.c_void_p * n)(*[critic(s.agent.pi).h for s in samplers])
+        s0.ctx.check(s0.ctx.lib.crux_fill_gae_multi(n, hb, hc, float(s0.lam), float(s0.gamma), 1 if all(b.haskey("return") for b in buffers) else 0))
+        done_gae = True
+    else:
+        done_gae = False
     for k, (s, b) in enumerate(zip(samplers, buffers)):
-        if b.haskey("advantage") and len(b) == Nsteps:
+        if not done_gae and b.haskey("advantage") and len(b) == Nsteps:
             fill_gae_(b, critic(s.agent.pi), s.lam, s.gamma)
-        if b.haskey("return") and len(b) == Nsteps:
+        if (not done_gae or not all(bb.haskey("return") for bb in buffers)) and b.haskey("return") and len(b) == Nsteps:
             fill_returns_(b, s.gamma)
         out.append({"sum_r": float(sr[k]), "n_episode_end": int(ne[k]), "avg_r": float(sr[k] / ne[k]) if ne[k] else float("nan")})
     return out
@@ -812,6 +822,12 @@ def fill_returns_(buffer, gamma):
 def whiten_(buffer, key="advantage"):
     """buffer[key] .= whiten(buffer[key]) (src/utils.jl:41-42, ppo.jl:61)."""
     buffer.ctx.check(buffer.ctx.lib.crux_whiten(buffer.h, L.COL[key]))
+
+
+def whiten_multi_(buffers, key="advantage"):
+    """whiten_ for several buffers of equal length in one launch."""
+    n = len(buffers); hb = (C.c_void_p * n)(*[b.h for b in buffers])
+    buffers[0].ctx.check(buffers[0].ctx.lib.crux_whiten_multi(n, hb, L.COL[key]))
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 // advantage.hip -- fill_gae! / fill_returns! / whiten on device columns.
 // Reference: src/sampler.jl:255-281 (GAE + returns), src/utils.jl:41-42 (whiten), episodes() src/experience_buffer.jl:194-212.
 #include "common.h"
+#include <vector>
 
 int32_t crux_mlp_forward_impl(crux_mlp* net, const float* d_x, int64_t B, float* d_y, const float* params_override);
 
@@ -9,7 +10,7 @@ int32_t crux_mlp_forward_impl(crux_mlp* net, const float* d_x, int64_t B, float*
 //   A = ((c*A + r) + ((1f0 - done)*gamma)*Vsp) - Vs        (sampler.jl:269)
 //   R = r + gamma*R                                        (sampler.jl:278)
 // so results are bit-identical to the scalar loop given the same V(s), V(sp).
-__global__ void k_gae_returns(const float* __restrict__ r, const uint8_t* __restrict__ done, const uint8_t* __restrict__ ee,
+__device__ __forceinline__ void gae_returns_body(const float* __restrict__ r, const uint8_t* __restrict__ done, const uint8_t* __restrict__ ee,
                               const float* __restrict__ Vs, const float* __restrict__ Vsp, float lambda, float gamma, int64_t n,
                               float* __restrict__ adv, float* __restrict__ ret, int32_t* __restrict__ nan_flag) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -29,9 +30,19 @@ __global__ void k_gae_returns(const float* __restrict__ r, const uint8_t* __rest
     if (bad) atomicOr(nan_flag, 1);
   }
 }
+__global__ void k_gae_returns(const float* __restrict__ r, const uint8_t* __restrict__ done, const uint8_t* __restrict__ ee,
+                              const float* __restrict__ Vs, const float* __restrict__ Vsp, float lambda, float gamma, int64_t n,
+                              float* __restrict__ adv, float* __restrict__ ret, int32_t* __restrict__ nan_flag) {
+  gae_returns_body(r, done, ee, Vs, Vsp, lambda, gamma, n, adv, ret, nan_flag);
+}
+struct GaeJob { const float* r; const uint8_t* done; const uint8_t* ee; const float* Vs; const float* Vsp; float* adv; float* ret; int32_t* flag; };
+__global__ void k_gae_returns_multi(const GaeJob* __restrict__ jobs, float lambda, float gamma, int64_t n) {     // grid.y = buffer
+  const GaeJob j = jobs[blockIdx.y];
+  gae_returns_body(j.r, j.done, j.ee, j.Vs, j.Vsp, lambda, gamma, n, j.adv, j.ret, j.flag);
+}
 
 // whiten(v) = (v .- mean(v)) ./ std(v), Bessel-corrected std; single block, deterministic tree reductions in Float64.
-__global__ __launch_bounds__(1024) void k_whiten(float* __restrict__ v, int64_t n) {
+__device__ __forceinline__ void whiten_block(float* __restrict__ v, int64_t n) {
   __shared__ double red[16];
   __shared__ float sh_mean, sh_sd;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -49,6 +60,8 @@ __global__ __launch_bounds__(1024) void k_whiten(float* __restrict__ v, int64_t 
   const float mf = sh_mean, sd = sh_sd;
   for (int64_t i = tid; i < n; i += 1024) v[i] = __fdiv_rn(__fsub_rn(v[i], mf), sd);
 }
+__global__ __launch_bounds__(1024) void k_whiten(float* __restrict__ v, int64_t n) { whiten_block(v, n); }
+__global__ __launch_bounds__(1024) void k_whiten_multi(float* const* __restrict__ vs, int64_t n) { whiten_block(vs[blockIdx.x], n); }
 
 static int32_t values(crux_mlp* critic, const float* d_x, int64_t n, float* d_y) {
   return crux_mlp_forward_impl(critic, d_x, n, d_y, nullptr);   // 2 x 65536 critic evaluations = 0.14 ms per iteration with the generic forward kernel
@@ -114,6 +127,77 @@ int32_t crux_fill_gae(crux_buffer* b, crux_mlp* critic, float lambda, float gamm
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (h) return crux_fail(c, CRUX_ENAN, "fill_gae!: NaN advantage (@assert !isnan(A))");
   return CRUX_OK;
+}
+
+// fill_gae! + fill_returns! for n buffers (the tail of a batched rollout): everything is enqueued, ONE host synchronisation reads the n NaN flags
+int32_t crux_fill_gae_multi(int32_t n, crux_buffer* const* bufs, crux_mlp* const* critics, float lambda, float gamma, int32_t with_returns) {
+  if (n < 1 || !bufs || !critics) return CRUX_EINVAL;
+  crux_ctx* c = bufs[0]->ctx; size_t vb = 0;
+  for (int i = 0; i < n; ++i) {
+    crux_buffer* b = bufs[i]; crux_mlp* critic = critics[i]; if (!b || !critic) return CRUX_EINVAL;
+    if (!has_col(b, CRUX_COL_ADVANTAGE)) return crux_fail(c, CRUX_EINVAL, "fill_gae!: buffer %d has no :advantage column", i);
+    if (with_returns && !has_col(b, CRUX_COL_RETURN)) return crux_fail(c, CRUX_EINVAL, "fill_returns!: buffer %d has no :return column", i);
+    if (critic->nd.dims[critic->nd.L] != 1 || critic->nd.dims[0] != b->obs_dim) return crux_fail(c, CRUX_EINVAL, "fill_gae!: critic must map obs(%d) -> 1 (@assert length(Vs) == 1)", b->obs_dim);
+    const size_t v = ((4 * (size_t)b->elements + 255) / 256) * 256; if (v > vb) vb = v;
+  }
+  bool same = true;
+  for (int i = 1; i < n; ++i) same = same && bufs[i]->elements == bufs[0]->elements && critics[i]->nd.n_params == critics[0]->nd.n_params && critics[i]->nd.L == critics[0]->nd.L &&
+                                     memcmp(critics[i]->nd.dims, critics[0]->nd.dims, sizeof critics[0]->nd.dims) == 0 && memcmp(critics[i]->nd.acts, critics[0]->nd.acts, sizeof critics[0]->nd.acts) == 0;
+  const size_t jb = (((sizeof(crux_fwd_job) * 2 + sizeof(GaeJob)) * (size_t)n) + 255) / 256 * 256, fb = (((size_t)n * 4 + 255) / 256) * 256;
+  char* sc = (char*)crux_scratch(c, fb + jb + (size_t)n * 2 * vb + 256); if (!sc) return crux_fail(c, CRUX_ENOMEM, "fill_gae! (multi): scratch");
+  int32_t* flags = (int32_t*)sc; char* vals = sc + fb + jb;
+  HIPCHK(c, hipMemsetAsync(flags, 0, 4 * (size_t)n, c->stream));
+  const int64_t m0 = bufs[0]->elements;
+  if (same && m0 > 0) {     // equal shapes: 2 launches for the 2 n critic evaluations and 1 for the n scans (grid.y = buffer)
+    std::vector<char> hj(jb); crux_fwd_job* fj = (crux_fwd_job*)hj.data(); GaeJob* gj = (GaeJob*)(hj.data() + sizeof(crux_fwd_job) * 2 * (size_t)n);
+    for (int i = 0; i < n; ++i) { crux_buffer* b = bufs[i]; float* Vs = (float*)(vals + (size_t)i * 2 * vb); float* Vsp = (float*)(vals + (size_t)i * 2 * vb + vb);
+      fj[2 * i] = {critics[i]->p, (const float*)b->col[CRUX_COL_S], Vs}; fj[2 * i + 1] = {critics[i]->p, (const float*)b->col[CRUX_COL_SP], Vsp};
+      gj[i] = {(const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE], (const uint8_t*)b->col[CRUX_COL_EPISODE_END], Vs, Vsp, (float*)b->col[CRUX_COL_ADVANTAGE],
+               with_returns ? (float*)b->col[CRUX_COL_RETURN] : (float*)nullptr, flags + i}; }
+    HIPCHK(c, hipMemcpyAsync(sc + fb, hj.data(), jb, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+    crux_prof_begin(c, CRUX_PROF_VALUES);
+    int32_t rcf = crux_mlp_forward_multi_impl(c, critics[0]->nd, (const crux_fwd_job*)(sc + fb), 2 * n, m0); if (rcf) return rcf;
+    crux_prof_end(c, CRUX_PROF_VALUES);
+    crux_prof_begin(c, CRUX_PROF_GAE);
+    hipLaunchKernelGGL(k_gae_returns_multi, dim3((unsigned)((m0 + 255) / 256), (unsigned)n), dim3(256), 0, c->stream, (const GaeJob*)(sc + fb + sizeof(crux_fwd_job) * 2 * (size_t)n), lambda, gamma, m0);
+    crux_prof_end(c, CRUX_PROF_GAE);
+  } else {
+  crux_prof_begin(c, CRUX_PROF_VALUES);
+  for (int i = 0; i < n; ++i) { crux_buffer* b = bufs[i]; const int64_t m = b->elements; if (m == 0) continue;
+    float* Vs = (float*)(vals + (size_t)i * 2 * vb); float* Vsp = (float*)(vals + (size_t)i * 2 * vb + vb);
+    int32_t rc = values(critics[i], (const float*)b->col[CRUX_COL_S], m, Vs); if (rc) return rc;
+    rc = values(critics[i], (const float*)b->col[CRUX_COL_SP], m, Vsp); if (rc) return rc; }
+  crux_prof_end(c, CRUX_PROF_VALUES);
+  crux_prof_begin(c, CRUX_PROF_GAE);
+  for (int i = 0; i < n; ++i) { crux_buffer* b = bufs[i]; const int64_t m = b->elements; if (m == 0) continue;
+    float* Vs = (float*)(vals + (size_t)i * 2 * vb); float* Vsp = (float*)(vals + (size_t)i * 2 * vb + vb);
+    hipLaunchKernelGGL(k_gae_returns, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE],
+                       (const uint8_t*)b->col[CRUX_COL_EPISODE_END], (const float*)Vs, (const float*)Vsp, lambda, gamma, m, (float*)b->col[CRUX_COL_ADVANTAGE],
+                       with_returns ? (float*)b->col[CRUX_COL_RETURN] : (float*)nullptr, flags + i); }
+  crux_prof_end(c, CRUX_PROF_GAE);
+  }
+  int32_t rc = crux_launch_check(c, "k_gae_returns (multi)"); if (rc) return rc;
+  std::vector<int32_t> h((size_t)n);
+  HIPCHK(c, hipMemcpyAsync(h.data(), flags, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; ++i) if (h[(size_t)i]) return crux_fail(c, CRUX_ENAN, "fill_gae!: NaN advantage in buffer %d (@assert !isnan(A))", i);
+  return CRUX_OK;
+}
+
+int32_t crux_whiten_multi(int32_t n, crux_buffer* const* bufs, int32_t key) {
+  if (n < 1 || !bufs) return CRUX_EINVAL;
+  crux_ctx* c = bufs[0]->ctx; const int64_t len = bufs[0]->elements;
+  std::vector<float*> hp((size_t)n);
+  for (int i = 0; i < n; ++i) { crux_buffer* b = bufs[i];
+    if (!b || !has_col(b, key) || col_elem(b, key) != 4 || col_rows(b, key) != 1) return crux_fail(c, CRUX_EINVAL, "whiten: column %d of buffer %d is not a 1 x N Float32 column", key, i);
+    if (b->elements != len || len < 2) return crux_fail(c, CRUX_EINVAL, "whiten (multi): buffers must hold the same number (>= 2) of elements");
+    hp[(size_t)i] = (float*)b->col[key]; }
+  float** dp = (float**)crux_scratch(c, 8 * (size_t)n + 256); if (!dp) return crux_fail(c, CRUX_ENOMEM, "whiten (multi): scratch");
+  HIPCHK(c, hipMemcpyAsync(dp, hp.data(), 8 * (size_t)n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+  crux_prof_begin(c, CRUX_PROF_WHITEN);
+  hipLaunchKernelGGL(k_whiten_multi, dim3((unsigned)n), dim3(1024), 0, c->stream, (float* const*)dp, len);
+  crux_prof_end(c, CRUX_PROF_WHITEN);
+  return crux_launch_check(c, "k_whiten_multi");
 }
 
 int32_t crux_fill_returns(crux_buffer* b, float gamma) {

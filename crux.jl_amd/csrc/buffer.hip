@@ -113,6 +113,41 @@ int32_t crux_buffer_apply_order(crux_buffer* b, const int32_t* d_order, int64_t 
   return crux_launch_check(c, "apply_order");
 }
 
+// the same for n buffers of equal shape: two launches per column (grid.y = buffer) instead of 2 n
+struct ApplyPtrs { void* col[CRUX_NCOLS]; void* tmp; const int32_t* order; };
+template <typename T>
+__global__ void k_apply_order_multi(const ApplyPtrs* __restrict__ P, int k, int64_t n, int32_t re, int back) {
+  const ApplyPtrs p = P[blockIdx.y]; if (!p.order) return;
+  T* col = (T*)p.col[k]; T* tmp = (T*)p.tmp; const int64_t total = n * re;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    if (back) col[t] = tmp[t];
+    else { const int64_t j = t / re; const int32_t e = (int32_t)(t - j * re); tmp[t] = col[(int64_t)p.order[j] * re + e]; }
+  }
+}
+int32_t crux_buffer_apply_order_multi(int32_t n, crux_buffer* const* bufs, const int32_t* const* d_orders) {
+  if (n < 1) return CRUX_OK;
+  crux_ctx* c = bufs[0]->ctx; const int64_t len = bufs[0]->elements;
+  bool same = true; for (int i = 1; i < n; ++i) same = same && bufs[i]->mask == bufs[0]->mask && bufs[i]->elements == len && bufs[i]->obs_dim == bufs[0]->obs_dim && bufs[i]->act_dim == bufs[0]->act_dim && bufs[i]->act_kind == bufs[0]->act_kind;
+  if (!same || n == 1) { for (int i = 0; i < n; ++i) if (d_orders[i]) { const int32_t rc = crux_buffer_apply_order(bufs[i], d_orders[i], bufs[i]->elements); if (rc) return rc; } return CRUX_OK; }
+  size_t maxst = 0; for (int k = 0; k < CRUX_NCOLS; ++k) if (has_col(bufs[0], k) && col_stride(bufs[0], k) > maxst) maxst = col_stride(bufs[0], k);
+  const size_t tb = (maxst * (size_t)len + 255) / 256 * 256, pb = (sizeof(ApplyPtrs) * (size_t)n + 255) / 256 * 256;
+  char* sc = (char*)crux_scratch(c, pb + tb * (size_t)n + 256); if (!sc) return crux_fail(c, CRUX_ENOMEM, "apply_order (multi): scratch");
+  std::vector<ApplyPtrs> hp((size_t)n);
+  for (int i = 0; i < n; ++i) { for (int k = 0; k < CRUX_NCOLS; ++k) hp[(size_t)i].col[k] = bufs[i]->col[k]; hp[(size_t)i].tmp = sc + pb + tb * (size_t)i; hp[(size_t)i].order = d_orders[i]; }
+  HIPCHK(c, hipMemcpyAsync(sc, hp.data(), sizeof(ApplyPtrs) * (size_t)n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < CRUX_NCOLS; ++k) {
+    if (!has_col(bufs[0], k)) continue;
+    const size_t st = col_stride(bufs[0], k);
+    for (int back = 0; back < 2; ++back) {
+      if (st % 4 == 0) { const int32_t re = (int32_t)(st / 4); unsigned gx = grid_for(len * re); if (gx > 512) gx = 512;
+        hipLaunchKernelGGL(k_apply_order_multi<uint32_t>, dim3(gx, (unsigned)n), dim3(256), 0, c->stream, (const ApplyPtrs*)sc, k, len, re, back); }
+      else { const int32_t re = (int32_t)st; unsigned gx = grid_for(len * re); if (gx > 512) gx = 512;
+        hipLaunchKernelGGL(k_apply_order_multi<uint8_t>, dim3(gx, (unsigned)n), dim3(256), 0, c->stream, (const ApplyPtrs*)sc, k, len, re, back); }
+    }
+  }
+  return crux_launch_check(c, "apply_order (multi)");
+}
+
 extern "C" {
 
 int32_t crux_buffer_create(crux_ctx* ctx, int32_t obs_dim, int32_t act_dim, int32_t act_kind, int64_t capacity, uint32_t column_mask,

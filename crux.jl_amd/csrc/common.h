@@ -26,7 +26,10 @@ struct crux_ctx {
   void* scratch = nullptr; size_t scratch_bytes = 0;   // reusable device scratch
   void* pinned = nullptr; size_t pinned_bytes = 0;     // reusable pinned host staging
   hipStream_t aux_stream = nullptr; hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr;   // second learner stream (actor || critic)
+  hipStream_t aux_rejected[8] = {}; int aux_n_rejected = 0; float aux_probe_ms = 0.f;   // candidates that shared the main stream's hardware queue (kept alive until destroy)
   void* comm = nullptr; int comm_rank = 0, comm_n = 0;   // RCCL communicator of the replica group (comm.hip)
+  void* amulti[2] = {nullptr, nullptr}; size_t amulti_bytes[2] = {0, 0};   // argument blocks of the one-CU batched learner launch
+  int learner_cus = 0;                 // 0 = automatic, 1 = one CU per learner (k_train_mfma8), 2 = two CUs (k_train_mfma_x2)
   void* xmulti[2] = {nullptr, nullptr}; size_t xmulti_bytes[2] = {0, 0};   // exchange areas + argument blocks of the batched multi-learner launch
   void* xbuf[2] = {nullptr, nullptr};   // gradient exchange areas of the two-CU learner kernel, one per learner stream
 };
@@ -147,6 +150,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 int32_t crux_launch_check(crux_ctx* ctx, const char* what);
+struct crux_fwd_job { const float* p; const float* x; float* y; };
+int32_t crux_mlp_forward_multi_impl(crux_ctx* c, const NetDesc& nd, const crux_fwd_job* d_jobs, int n_jobs, int64_t B);   // mlp.hip
 int32_t crux_comm_allreduce_mean_impl(crux_ctx* c, crux_mlp* const* nets, int n_nets);   // comm.hip
 // dense.hip: differentiable Chain(Dense...) on the tile-GEMM engine
 int32_t crux_dense_forward(crux_mlp* n, const float* d_x, int64_t B, hipStream_t st);

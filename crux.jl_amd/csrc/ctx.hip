@@ -77,14 +77,19 @@ int32_t crux_ctx_create(int32_t device_id, void* stream, crux_ctx** out) {
   return CRUX_OK;
 }
 
+int32_t crux_ctx_set_learner_cus(crux_ctx* c, int32_t cus) {
+  if (!c || cus < 0 || cus > 2) return CRUX_EINVAL;
+  c->learner_cus = cus; return CRUX_OK;
+}
 int32_t crux_ctx_destroy(crux_ctx* c) {
   if (!c) return CRUX_OK;
   (void)hipStreamSynchronize(c->stream);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
   for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (c->scratch) (void)hipFree(c->scratch);
-  for (int k = 0; k < 2; ++k) { if (c->xbuf[k]) (void)hipFree(c->xbuf[k]); if (c->xmulti[k]) (void)hipFree(c->xmulti[k]); }
+  for (int k = 0; k < 2; ++k) { if (c->xbuf[k]) (void)hipFree(c->xbuf[k]); if (c->xmulti[k]) (void)hipFree(c->xmulti[k]); if (c->amulti[k]) (void)hipFree(c->amulti[k]); }
   if (c->pinned) (void)hipHostFree(c->pinned);
+  for (int k = 0; k < c->aux_n_rejected; ++k) (void)hipStreamDestroy(c->aux_rejected[k]);
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->aux_ev0); (void)hipEventDestroy(c->aux_ev1); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;

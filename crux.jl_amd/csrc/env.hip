@@ -523,11 +523,11 @@ int32_t crux_rollout_multi(int32_t n, crux_env* const* envs, crux_mlp* const* po
   if (!done) return crux_fail(c, CRUX_EUNSUP, "steps! (multi): no batched rollout kernel for this policy / environment");
   int32_t rc = crux_launch_check(c, "k_rollout_h64 (multi)"); if (rc) return rc;
   for (int i = 0; i < n; ++i) { if (bufs[i]->prioritized) return crux_fail(c, CRUX_EUNSUP, "steps! (multi): prioritized buffers are not batched"); crux_buffer_ring_advance(bufs[i], (int64_t)envs[i]->n_envs * T); }
-  if (sum_r || n_episode_end) {
+  if (sum_r || n_episode_end) {     // n small copies enqueued on the library's stream (never the null stream), one synchronisation
+    const size_t per = 2 * (size_t)e0->n_envs; std::vector<double> acc(per * (size_t)n);
+    for (int i = 0; i < n; ++i) HIPCHK(c, hipMemcpyAsync(acc.data() + per * (size_t)i, envs[i]->acc, 8 * per, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < n; ++i) { std::vector<double> acc(2 * (size_t)envs[i]->n_envs);
-      HIPCHK(c, hipMemcpy(acc.data(), envs[i]->acc, 16 * (size_t)envs[i]->n_envs, hipMemcpyDeviceToHost));
-      double sr = 0; int64_t ne = 0; for (int k = 0; k < envs[i]->n_envs; ++k) { sr += acc[2 * k]; ne += (int64_t)acc[2 * k + 1]; }
+    for (int i = 0; i < n; ++i) { double sr = 0; int64_t ne = 0; for (int k = 0; k < e0->n_envs; ++k) { sr += acc[per * (size_t)i + 2 * k]; ne += (int64_t)acc[per * (size_t)i + 2 * k + 1]; }
       if (sum_r) sum_r[i] = sr; if (n_episode_end) n_episode_end[i] = ne; }
   }
   return CRUX_OK;

@@ -14,8 +14,7 @@ static void fill_desc(NetDesc& nd, int32_t L, const int32_t* dims, const int32_t
 
 // ---- generic forward: one block = TS samples, activations ping-pong in LDS as [sample][feature] ----
 #define FWD_TS 32
-__global__ __launch_bounds__(256) void k_mlp_forward(NetDesc nd, const float* __restrict__ p, const float* __restrict__ x,
-                                                     int64_t B, float* __restrict__ y) {
+__device__ __forceinline__ void mlp_forward_body(const NetDesc& nd, const float* __restrict__ p, const float* __restrict__ x, int64_t B, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* h0 = sm; float* h1 = sm + (size_t)nd.maxdim * FWD_TS;
   const int tid = threadIdx.x;
@@ -40,6 +39,22 @@ __global__ __launch_bounds__(256) void k_mlp_forward(NetDesc nd, const float* __
     for (int idx = tid; idx < outL * ns; idx += 256) y[s0 * outL + idx] = h0[idx];
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(256) void k_mlp_forward(NetDesc nd, const float* __restrict__ p, const float* __restrict__ x, int64_t B, float* __restrict__ y) {
+  mlp_forward_body(nd, p, x, B, y);
+}
+// the same network shape evaluated for many (parameters, input, output) triples in one launch: grid.y = job
+__global__ __launch_bounds__(256) void k_mlp_forward_multi(NetDesc nd, const crux_fwd_job* __restrict__ jobs, int64_t B) {
+  const crux_fwd_job j = jobs[blockIdx.y];
+  mlp_forward_body(nd, j.p, j.x, B, j.y);
+}
+int32_t crux_mlp_forward_multi_impl(crux_ctx* c, const NetDesc& nd, const crux_fwd_job* d_jobs, int n_jobs, int64_t B) {
+  if (n_jobs < 1 || B < 1) return CRUX_OK;
+  const size_t lds = sizeof(float) * 2 * (size_t)nd.maxdim * FWD_TS;
+  if (lds > 65536) return crux_fail(c, CRUX_EUNSUP, "mlp_forward: layer width %d exceeds the generic kernel's LDS tile", nd.maxdim);
+  int64_t nb = (B + FWD_TS - 1) / FWD_TS; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_mlp_forward_multi, dim3((unsigned)nb, (unsigned)n_jobs), dim3(256), lds, c->stream, nd, d_jobs, B);
+  return crux_launch_check(c, "k_mlp_forward_multi");
 }
 
 int32_t crux_mlp_forward_impl(crux_mlp* net, const float* d_x, int64_t B, float* d_y, const float* params_override);

@@ -9,8 +9,10 @@
 #include "train_args.h"
 
 int32_t crux_buffer_apply_order(crux_buffer* b, const int32_t* d_order, int64_t n);
+int32_t crux_buffer_apply_order_multi(int32_t n, crux_buffer* const* bufs, const int32_t* const* d_orders);
 int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream);
 int32_t crux_train_mfma_x2_launch_multi(crux_ctx* c, std::vector<TrainArgs>& as, bool* handled, hipStream_t stream);   // train_mfma_x2.hip
+int32_t crux_train_mfma8_launch_multi(crux_ctx* c, std::vector<TrainArgs>& as, bool* handled, hipStream_t stream);     // train_mfma8.hip
 
 #define TR_CH 32
 #define EPS32F 1.1920928955078125e-07f
@@ -240,7 +242,8 @@ static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const cr
     if (!buf->aux_ones) {
       if (hipMalloc(&buf->aux_ones, 4 * (size_t)buf->capacity) != hipSuccess || hipMalloc(&buf->aux_zeros, 4 * (size_t)buf->capacity) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "logpdf_bc_loss: constant columns");
       std::vector<float> one((size_t)buf->capacity, 1.f);
-      HIPCHK(c, hipMemcpy(buf->aux_ones, one.data(), 4 * one.size(), hipMemcpyHostToDevice)); HIPCHK(c, hipMemset(buf->aux_zeros, 0, 4 * (size_t)buf->capacity));
+      HIPCHK(c, hipMemcpyAsync(buf->aux_ones, one.data(), 4 * one.size(), hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipMemsetAsync(buf->aux_zeros, 0, 4 * (size_t)buf->capacity, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     a.ADV = buf->aux_ones; a.LP = buf->aux_zeros; a.lambda_p = 1.f; a.loss = internal_loss = CRUX_LOSS_A2C;
   }
@@ -270,13 +273,30 @@ __global__ void k_compose_order(const int32_t* __restrict__ prev, int32_t* __res
   out[j] = prev ? prev[src] : (int32_t)src;
 }
 // builds buf->ord_all[slot] = [n_epochs x len]; start = order the first epoch composes onto (NULL = identity = the physical row order)
-static int32_t build_orders(crux_ctx* c, crux_buffer* buf, int slot, const int32_t* start, uint64_t seed, uint64_t counter, const int64_t* d_perms, int n_epochs, hipStream_t st, int32_t** out) {
-  const int64_t len = buf->elements; const size_t need = (size_t)n_epochs * (size_t)len;
+static int32_t ensure_ord(crux_ctx* c, crux_buffer* buf, int slot, size_t need) {
   if (buf->ord_all_cap[slot] < need) {
     if (buf->ord_all[slot]) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(buf->ord_all[slot]); buf->ord_all[slot] = nullptr; buf->ord_all_cap[slot] = 0; }
     if (hipMalloc(&buf->ord_all[slot], 4 * need) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "batch_train!: %zu bytes for the epoch orders", 4 * need);
     buf->ord_all_cap[slot] = need;
   }
+  return CRUX_OK;
+}
+// the same composition for n buffers of equal length in one launch per epoch (grid.y = buffer): buffer i shuffles with seed + i; the critic
+// chain (slot 1) starts from the actor's last order
+struct OrdPtrs { int32_t* oa; int32_t* oc; };
+__global__ void k_compose_order_multi(const OrdPtrs* __restrict__ P, int slot, int e, int Ea, uint64_t seed, uint64_t counter, int64_t len) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (j >= len) return;
+  const int i = blockIdx.y;
+  const crux_perm pp = crux_perm_make(seed + (uint64_t)i, counter + (uint64_t)e, 0, (uint32_t)len);
+  const OrdPtrs p = P[i];
+  int32_t* base = slot ? p.oc : p.oa;
+  const int32_t* prev = e > 0 ? base + (size_t)(e - 1) * (size_t)len : (slot ? p.oa + (size_t)(Ea - 1) * (size_t)len : (const int32_t*)nullptr);
+  const int64_t src = (int64_t)crux_perm_at(&pp, (uint32_t)j);
+  base[(size_t)e * (size_t)len + j] = prev ? prev[src] : (int32_t)src;
+}
+static int32_t build_orders(crux_ctx* c, crux_buffer* buf, int slot, const int32_t* start, uint64_t seed, uint64_t counter, const int64_t* d_perms, int n_epochs, hipStream_t st, int32_t** out) {
+  const int64_t len = buf->elements; const size_t need = (size_t)n_epochs * (size_t)len;
+  { const int32_t rc0 = ensure_ord(c, buf, slot, need); if (rc0) return rc0; }
   const int32_t* prev = start;
   for (int e = 0; e < n_epochs; ++e) {
     int32_t* o = buf->ord_all[slot] + (size_t)e * (size_t)len;
@@ -399,6 +419,60 @@ int32_t crux_loss_grad_device_ids(crux_mlp* net, crux_buffer* buf, const crux_tr
   return launch_train(c, a, CRUX_IS_PG(a.loss) ? CRUX_PROF_TRAIN_ACTOR : CRUX_PROF_TRAIN_CRITIC);
 }
 
+// ---- the second learner stream ----------------------------------------------------------------------------------------------------
+// ROCm multiplexes HIP streams over a small pool of hardware queues (GPU_MAX_HW_QUEUES, default 4) and two streams that land on the same
+// queue serialise their kernels. Which queue a new stream gets depends on what the process created before (measured: after one null-stream
+// hipMemcpy, or after torch had made its streams, actor and critic ran back to back: 760-782 ms instead of 410-431). So the stream is
+// PROBED: two 150 us spin kernels, one per stream; if they do not overlap the candidate is parked (kept alive, so the next candidate maps
+// elsewhere) and another one is created, alternating priority levels.
+// The probe has the geometry of a batched two-CU learner launch (1024 workgroups that each claim a CU's whole LDS, 2 of every 16 stay busy):
+// single-workgroup kernels overlap even where those launches serialise.
+__global__ __launch_bounds__(256) void k_spin(long long ticks) {
+  extern __shared__ float spin_lds[];
+  const int r = blockIdx.x >> 4, q = blockIdx.x & 15;
+  if (q != ((r >> 1) & 7) && q != ((r >> 1) & 7) + 8) return;
+  if (threadIdx.x == 0) spin_lds[0] = 0.f;
+  const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static int32_t ensure_aux_stream(crux_ctx* c) {
+  if (c->aux_stream) return CRUX_OK;
+  int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+  hipEvent_t t0 = nullptr, t1 = nullptr, ej = nullptr;
+  HIPCHK(c, hipEventCreate(&t0)); HIPCHK(c, hipEventCreate(&t1)); HIPCHK(c, hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+  int clk_khz = 100000; (void)hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeWallClockRate, c->device); if (clk_khz <= 0) clk_khz = 100000;
+  const long long ticks = (long long)clk_khz * 150 / 1000;        // 150 us
+  const size_t probe_lds = 150 * 1024;
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_spin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)probe_lds));
+  float alone = 0.f;
+  for (int rep = 0; rep < 2; ++rep) {     // the probe launch alone on the main stream (first pass warms the code object)
+    HIPCHK(c, hipEventRecord(t0, c->stream)); hipLaunchKernelGGL(k_spin, dim3(1024), dim3(256), probe_lds, c->stream, ticks); HIPCHK(c, hipEventRecord(t1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipEventElapsedTime(&alone, t0, t1));
+  }
+  hipStream_t chosen = nullptr; float best = 0.f;
+  for (int attempt = 0; attempt < 6 && !chosen; ++attempt) {
+    hipStream_t s = nullptr;
+    const int prio = (attempt & 1) ? lo_p : hi_p;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio) != hipSuccess) HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    float ms = 1e9f;
+    for (int rep = 0; rep < 2; ++rep) {
+      HIPCHK(c, hipEventRecord(t0, c->stream)); HIPCHK(c, hipStreamWaitEvent(s, t0, 0));
+      hipLaunchKernelGGL(k_spin, dim3(1024), dim3(256), probe_lds, s, ticks); HIPCHK(c, hipEventRecord(ej, s));
+      hipLaunchKernelGGL(k_spin, dim3(1024), dim3(256), probe_lds, c->stream, ticks);
+      HIPCHK(c, hipStreamWaitEvent(c->stream, ej, 0)); HIPCHK(c, hipEventRecord(t1, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(s));
+      HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
+    }
+    best = ms;
+    if (ms < 1.5f * alone || attempt == 5 || getenv("CRUX_NO_STREAM_PROBE")) chosen = s;      // overlapped: about `alone`; back to back: 2 x
+    else if (c->aux_n_rejected < 8) c->aux_rejected[c->aux_n_rejected++] = s;
+  }
+  (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipEventDestroy(ej);
+  c->aux_stream = chosen; c->aux_probe_ms = best;
+  if (getenv("CRUX_STREAM_PROBE_VERBOSE")) fprintf(stderr, "[cruxhip] second learner stream: %d candidate(s) rejected, probe %.3f ms for two concurrent launches (one alone: %.3f ms)\n", c->aux_n_rejected, best, alone);
+  HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev1, hipEventDisableTiming));
+  return CRUX_OK;
+}
+
 // policy_gradient_training (src/model_free/on_policy.jl:56-78): batch_train!(actor) then batch_train!(critic) on the same buffer.
 // The two learners touch disjoint parameters, so when the actor's epoch count is known in advance (no KL early stopping, no
 // max_batches) they run CONCURRENTLY as two persistent kernels on two CUs: the critic kernel first composes the actor's epoch
@@ -428,14 +502,7 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
     return crux_batch_train(critic, buf, cfg_c, perms_c, info_c, epoch_infos_c);
   }
   if (buf->elements <= 0 || cfg_a->epochs < 1 || cfg_c->epochs < 1) return crux_fail(c, CRUX_EINVAL, "policy_gradient_training: empty buffer or epochs < 1");
-  if (!c->aux_stream) {
-    // The second learner stream gets its own priority level: ROCm multiplexes streams of one priority over a small pool of hardware
-    // queues (GPU_MAX_HW_QUEUES, default 4), and two streams that land on the same queue serialise their kernels -- measured: inside a
-    // process where torch had already created its streams the actor and critic kernels ran back to back (782 vs 431 ms per iteration).
-    int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-    if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi_p) != hipSuccess) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev1, hipEventDisableTiming));
-  }
+  { const int32_t rca = ensure_aux_stream(c); if (rca) return rca; }
   TrainArgs a, k; int32_t rc = fill_args(a, actor, buf, cfg_a, cfg_a->loss); if (rc) return rc;
   rc = fill_args(k, critic, buf, cfg_c, cfg_c->loss); if (rc) return rc;
   const int64_t len = buf->elements;
@@ -484,15 +551,11 @@ extern "C" int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* cons
   crux_ctx* c = actors[0]->ctx;
   if (!(cfg_a->target_kl < 0.f) || cfg_a->max_batches > 0 || cfg_c->max_batches > 0) return crux_fail(c, CRUX_EUNSUP, "policy_gradient_training_multi: early stopping / max_batches need the sequential single-learner call");
   if (cfg_a->epochs < 1 || cfg_c->epochs < 1) return crux_fail(c, CRUX_EINVAL, "policy_gradient_training_multi: epochs < 1");
-  if (!c->aux_stream) {
-    int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-    if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi_p) != hipSuccess) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev1, hipEventDisableTiming));
-  }
+  { const int32_t rca = ensure_aux_stream(c); if (rca) return rca; }
   const size_t ea = sizeof(float) * CRUX_INFO_N * (size_t)cfg_a->epochs, ec = sizeof(float) * CRUX_INFO_N * (size_t)cfg_c->epochs;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t stride = 512 + al(ea) + al(ec);
-  char* sc = (char*)crux_scratch(c, stride * (size_t)n + 256); if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_gradient_training_multi: scratch");
+  char* sc = (char*)crux_scratch(c, stride * (size_t)n + sizeof(OrdPtrs) * (size_t)n + 256); if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_gradient_training_multi: scratch");
   HIPCHK(c, hipMemsetAsync(sc, 0, stride * (size_t)n, c->stream));
   std::vector<TrainArgs> as((size_t)n), ks((size_t)n);
   for (int i = 0; i < n; ++i) {
@@ -504,34 +567,56 @@ extern "C" int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* cons
     char* s0 = sc + stride * (size_t)i;
     as[i].status = (int32_t*)s0; ks[i].status = (int32_t*)(s0 + 256); as[i].epoch_infos = (float*)(s0 + 512); ks[i].epoch_infos = (float*)(s0 + 512 + al(ea));
     ks[i].order_a = bufs[i]->order_c; ks[i].order_b = bufs[i]->order_d;
-    int32_t* oa = nullptr; int32_t* oc = nullptr; const int64_t len = bufs[i]->elements;
-    rc = build_orders(c, bufs[i], 0, nullptr, ca.shuffle_seed, ca.shuffle_counter, nullptr, ca.epochs, c->stream, &oa); if (rc) return rc;
-    rc = build_orders(c, bufs[i], 1, oa + (size_t)(ca.epochs - 1) * (size_t)len, cc.shuffle_seed, cc.shuffle_counter, nullptr, cc.epochs, c->stream, &oc); if (rc) return rc;
-    as[i].ord_all = oa; ks[i].ord_all = oc;
+    const int64_t len = bufs[i]->elements;
+    rc = ensure_ord(c, bufs[i], 0, (size_t)ca.epochs * (size_t)len); if (rc) return rc;
+    rc = ensure_ord(c, bufs[i], 1, (size_t)cc.epochs * (size_t)len); if (rc) return rc;
+    as[i].ord_all = bufs[i]->ord_all[0]; ks[i].ord_all = bufs[i]->ord_all[1];
+  }
+  { // every epoch order of every replica: Ea + Ec launches in all (grid.y = replica)
+    std::vector<OrdPtrs> hp((size_t)n); for (int i = 0; i < n; ++i) hp[(size_t)i] = {bufs[i]->ord_all[0], bufs[i]->ord_all[1]};
+    OrdPtrs* dp = (OrdPtrs*)(sc + stride * (size_t)n);
+    HIPCHK(c, hipMemcpyAsync(dp, hp.data(), sizeof(OrdPtrs) * (size_t)n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int64_t len = bufs[0]->elements; const dim3 grid((unsigned)((len + 255) / 256), (unsigned)n);
+    for (int e = 0; e < cfg_a->epochs; ++e) hipLaunchKernelGGL(k_compose_order_multi, grid, dim3(256), 0, c->stream, (const OrdPtrs*)dp, 0, e, cfg_a->epochs, cfg_a->shuffle_seed, cfg_a->shuffle_counter, len);
+    for (int e = 0; e < cfg_c->epochs; ++e) hipLaunchKernelGGL(k_compose_order_multi, grid, dim3(256), 0, c->stream, (const OrdPtrs*)dp, 1, e, cfg_a->epochs, cfg_c->shuffle_seed, cfg_c->shuffle_counter, len);
+    const int32_t rc2 = crux_launch_check(c, "k_compose_order_multi"); if (rc2) return rc2;
   }
   HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
+  // Two batched forms: two CUs per learner (k_train_mfma_x2, shortest iteration while 4 n CUs fit the chip) or one CU per learner
+  // (k_train_mfma8, 1.1x longer steps but half the CUs: the higher-throughput form once the population exceeds 64 = 256 CUs / 4).
+  const bool one_cu = c->learner_cus == 1 || (c->learner_cus == 0 && n > 64);
+  auto launch_many = [&](std::vector<TrainArgs>& v, hipStream_t st, bool* h) -> int32_t {
+    *h = false; int32_t r = CRUX_OK;
+    if (!one_cu) { r = crux_train_mfma_x2_launch_multi(c, v, h, st); if (r || *h) return r; }
+    return crux_train_mfma8_launch_multi(c, v, h, st);
+  };
   bool handled = false;
-  int32_t rc = crux_train_mfma_x2_launch_multi(c, ks, &handled, c->aux_stream); if (rc) return rc;
+  int32_t rc = launch_many(ks, c->aux_stream, &handled); if (rc) return rc;
   if (!handled) return crux_fail(c, CRUX_EUNSUP, "policy_gradient_training_multi: no batched kernel for this network family / batch size");
   HIPCHK(c, hipEventRecord(c->aux_ev1, c->aux_stream));
   crux_prof_begin(c, CRUX_PROF_TRAIN_ACTOR);
-  rc = crux_train_mfma_x2_launch_multi(c, as, &handled, c->stream); if (rc) return rc;
+  rc = launch_many(as, c->stream, &handled); if (rc) return rc;
   crux_prof_end(c, CRUX_PROF_TRAIN_ACTOR);
   if (!handled) return crux_fail(c, CRUX_EUNSUP, "policy_gradient_training_multi: no batched kernel for the actor family");
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
-  std::vector<int32_t> fin((size_t)n);
-  for (int i = 0; i < n; ++i) {   // read every status row first: crux_buffer_apply_order below may regrow the scratch block these rows live in
-    int32_t sta[4], stc[4];
-    rc = collect(c, as[i], cfg_a->epochs, info_a ? info_a + (size_t)i * CRUX_INFO_N : nullptr, nullptr, sta); if (rc) return rc;
-    rc = collect(c, ks[i], cfg_c->epochs, info_c ? info_c + (size_t)i * CRUX_INFO_N : nullptr, nullptr, stc); if (rc) return rc;
+  // one read-back of every status row and epoch info (crux_buffer_apply_order below may regrow the scratch block these rows live in)
+  std::vector<char> host(stride * (size_t)n);
+  HIPCHK(c, hipMemcpyAsync(host.data(), sc, host.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<const int32_t*> fin_ord((size_t)n, nullptr);
+  for (int i = 0; i < n; ++i) {
+    const char* s0 = host.data() + stride * (size_t)i;
+    const int32_t* sta = (const int32_t*)s0; const int32_t* stc = (const int32_t*)(s0 + 256);
+    const float* eia = (const float*)(s0 + 512); const float* eic = (const float*)(s0 + 512 + al(ea));
+    for (int w = 0; w < 2; ++w) { const int32_t* st = w ? stc : sta; const float* ei = w ? eic : eia; float* out = w ? info_c : info_a;
+      if (!out) continue; out += (size_t)i * CRUX_INFO_N;
+      for (int q = 0; q < CRUX_INFO_N; ++q) { double sum = 0; for (int e = 0; e < st[2]; ++e) sum += (double)ei[(size_t)e * CRUX_INFO_N + q]; out[q] = st[2] ? (float)(sum / (double)st[2]) : 0.f; }
+      out[CRUX_INFO_BATCHES_TRAINED] = (float)st[1]; out[CRUX_INFO_EPOCHS_RUN] = (float)st[2]; }
     if (sta[0] == CRUX_ENAN || stc[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20) in replica %d", i);
     if (sta[0] || stc[0]) return crux_fail(c, sta[0] ? sta[0] : stc[0], "learner kernel reported status %d/%d in replica %d", sta[0], stc[0], i);
-    fin[(size_t)i] = stc[2];
+    if (stc[2] >= 1) fin_ord[(size_t)i] = ks[i].ord_all + (size_t)(stc[2] - 1) * (size_t)bufs[i]->elements;
   }
-  for (int i = 0; i < n; ++i)
-    if (fin[(size_t)i] >= 1) { rc = crux_buffer_apply_order(bufs[i], ks[i].ord_all + (size_t)(fin[(size_t)i] - 1) * (size_t)bufs[i]->elements, bufs[i]->elements); if (rc) return rc; }
-  return CRUX_OK;
+  return crux_buffer_apply_order_multi(n, bufs, fin_ord.data());
 }
 
 // policy_gradient_training for environment-shard replicas: the same two concurrent learner kernels, launched per chunk of
@@ -546,11 +631,7 @@ extern "C" int32_t crux_policy_gradient_training_synced(crux_mlp* actor, crux_ml
   if (!(cfg_a->target_kl < 0.f) || cfg_a->max_batches > 0 || cfg_c->max_batches > 0) return crux_fail(c, CRUX_EUNSUP, "policy_gradient_training_synced: early stopping / max_batches would let replicas diverge in epoch count");
   if (buf->elements <= 0 || cfg_a->epochs < 1 || cfg_c->epochs != cfg_a->epochs) return crux_fail(c, CRUX_EINVAL, "policy_gradient_training_synced: empty buffer, epochs < 1 or actor/critic epoch counts differ");
   const int64_t len = buf->elements; if (len >= ((int64_t)1 << 31)) return crux_fail(c, CRUX_EUNSUP, "policy_gradient_training_synced: buffer too long");
-  if (!c->aux_stream) {
-    int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-    if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi_p) != hipSuccess) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev1, hipEventDisableTiming));
-  }
+  { const int32_t rca = ensure_aux_stream(c); if (rca) return rca; }
   const int E = cfg_a->epochs, nch = (E + sync_every - 1) / sync_every;
   TrainArgs a, k; int32_t rc = fill_args(a, actor, buf, cfg_a, cfg_a->loss); if (rc) return rc;
   rc = fill_args(k, critic, buf, cfg_c, cfg_c->loss); if (rc) return rc;

@@ -11,6 +11,7 @@
 //   small parameters         : 8 per-wave partial gradients in LDS, reduced and Adam-updated by 512 threads
 // VGPR budget is 256 per wave (2 waves/SIMD): weight fragments are fetched from LDS just in time instead of being held.
 // Used when its LDS layout fits in 160 KB (IN <= 16); wider inputs use the 4-wave kernel.
+#include <vector>
 #include "train_args.h"
 
 #include "mfma_helpers.h"
@@ -52,7 +53,9 @@ struct Mf8Layout {
 };
 
 template <int IN, int OUT, int KIND, int ACT>
-__global__ __launch_bounds__(512) void k_train_mfma8(TrainArgs a) {
+__global__ __launch_bounds__(512) void k_train_mfma8(TrainArgs a_single, const TrainArgs* __restrict__ multi) {
+  // multi != NULL: a batch of independent learners, one workgroup (= one CU) each: the throughput form for multi-seed / population training
+  const TrainArgs a = multi ? multi[blockIdx.x] : a_single;
   using Lt = Mf8Layout<IN, OUT>;
   static_assert(Lt::TOTAL <= 40960, "LDS budget (160 KB) exceeded");
   constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS;
@@ -488,8 +491,45 @@ static int32_t launch_one8(crux_ctx* c, const TrainArgs& a, hipStream_t stream) 
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
   static bool attr = false;
   if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma8<IN, OUT, KIND, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-  hipLaunchKernelGGL((k_train_mfma8<IN, OUT, KIND, ACT>), dim3(1), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((k_train_mfma8<IN, OUT, KIND, ACT>), dim3(1), dim3(512), lds, stream, a, (const TrainArgs*)nullptr);
   return crux_launch_check(c, "k_train_mfma8");
+}
+
+// n independent learners, one CU each (grid n): argument blocks uploaded to a per-stream device array
+template <int IN, int OUT, int KIND, int ACT>
+static int32_t launch_multi8(crux_ctx* c, std::vector<TrainArgs>& as, hipStream_t stream) {
+  using Lt = Mf8Layout<IN, OUT>;
+  constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
+  static bool attr = false;
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma8<IN, OUT, KIND, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  const int which = stream == c->stream ? 0 : 1; const size_t n = as.size(), need = n * sizeof(TrainArgs) + 256;
+  if (c->amulti_bytes[which] < need) {
+    if (c->amulti[which]) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(c->amulti[which]); c->amulti[which] = nullptr; c->amulti_bytes[which] = 0; }
+    if (hipMalloc(&c->amulti[which], need) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "multi-learner argument blocks (%zu bytes)", need);
+    c->amulti_bytes[which] = need;
+  }
+  TrainArgs* d_args = (TrainArgs*)c->amulti[which];
+  HIPCHK(c, hipMemcpyAsync(d_args, as.data(), n * sizeof(TrainArgs), hipMemcpyHostToDevice, stream));
+  HIPCHK(c, hipStreamSynchronize(stream));      // `as` is pageable host memory: the copy must have left it before the caller's vector can change
+  hipLaunchKernelGGL((k_train_mfma8<IN, OUT, KIND, ACT>), dim3((unsigned)n), dim3(512), lds, stream, as[0], (const TrainArgs*)d_args);
+  return crux_launch_check(c, "k_train_mfma8 (multi)");
+}
+
+int32_t crux_train_mfma8_launch_multi(crux_ctx* c, std::vector<TrainArgs>& as, bool* handled, hipStream_t stream) {
+  *handled = false;
+  if (as.empty()) return CRUX_OK;
+  const TrainArgs& a = as[0]; const NetDesc& nd = a.nd;
+  if (nd.L != 3 || nd.dims[1] != MF_HID || nd.dims[2] != MF_HID || nd.acts[2] != CRUX_ACT_IDENTITY || nd.acts[0] != nd.acts[1] || a.ids || !a.apply || a.bs > 128 || a.len < a.bs) return CRUX_OK;
+  const int in = nd.dims[0], out = nd.dims[3], act = nd.acts[0];
+  const int kind = a.loss == CRUX_LOSS_VALUE_MSE ? MFK_VALUE : (a.head == CRUX_HEAD_CATEGORICAL ? MFK_CATEGORICAL : (a.head == CRUX_HEAD_GAUSSIAN ? MFK_GAUSSIAN : -1));
+  if (!(a.loss == CRUX_LOSS_VALUE_MSE || CRUX_IS_PG(a.loss)) || kind < 0) return CRUX_OK;
+#define MF8M_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_multi8<I, O, K, A_>(c, as, stream); }
+  MF8M_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)
+  MF8M_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)
+  MF8M_CASE(3, 1, MFK_GAUSSIAN, CRUX_ACT_RELU)
+  MF8M_CASE(3, 1, MFK_VALUE, CRUX_ACT_RELU)
+#undef MF8M_CASE
+  return CRUX_OK;
 }
 
 // Called by crux_train_mfma_launch after its shape checks; handles the narrow-input members of the family.

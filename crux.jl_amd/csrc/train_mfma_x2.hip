@@ -63,7 +63,11 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
   constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS;
   constexpr int NACT = (OUT > 4 ? OUT : 4);
   constexpr int NT = 64 * MF8_NW;
-  if ((blockIdx.x & 7) != ((blockIdx.x >> 4) & 7)) return;   // learner r works in blocks 16r + (r%8) and 16r + (r%8) + 8: same XCD for the pair, consecutive learners on consecutive XCDs
+  // learner r works in blocks 16r + x and 16r + x + 8 with x = (r/2)%8: same XCD for the pair (workgroups go round-robin over the 8 XCDs).
+  // An XCD therefore hosts learners of both parities, whose workgroups are the (2r)-th/(2r+1)-th of that XCD's stream: measured, with
+  // x = r%8 all busy workgroups of an XCD fell on HALF of its CUs (positions = 0,1 mod 4 or 2,3 mod 4: the in-order dispatcher deals workgroups
+  // round-robin to the XCD's 4 shader arrays) and a population of 40 (20 busy workgroups per XCD on 16 CUs) ran actor and critic back to back.
+  if ((blockIdx.x & 7) != ((blockIdx.x >> 5) & 7)) return;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
   float* part = sm + Lt::oPART + w * Lt::PART;

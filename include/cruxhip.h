@@ -42,6 +42,10 @@ typedef struct crux_env crux_env;
 /* stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create a private one. */
 int32_t crux_ctx_create(int32_t device_id, void* stream, crux_ctx** out);
 int32_t crux_ctx_destroy(crux_ctx* ctx);
+/* How many CUs one small-MLP learner (batch_train!, src/training.jl:28-55) occupies: 0 = automatic (two CUs of one XCD per learner; the batched
+ * multi-learner call switches to one CU per learner above 64 learners), 1 = always one CU (k_train_mfma8), 2 = two CUs where the shape allows.
+ * The two kernels sum the minibatch gradient in different orders: results agree to fp32 tolerance, bitwise only for equal settings.              */
+int32_t crux_ctx_set_learner_cus(crux_ctx* ctx, int32_t cus);
 const char* crux_last_error(crux_ctx* ctx);
 int32_t crux_sync(crux_ctx* ctx);
 const char* crux_version(void);
@@ -284,6 +288,10 @@ int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* critic, crux_bu
 /* The same for n independent (actor, critic, buffer) triples of equal shape -- multi-seed / population training -- as two batched launches
  * (all critics || all actors; each learner on two CUs, consecutive learners on consecutive XCDs). Replica i shuffles with seed + i.
  * Requires target_kl < 0 and max_batches = 0 (the exact-overlap condition). info_a / info_c: host [n x CRUX_INFO_N] or NULL.            */
+/* fill_gae! (+ fill_returns! when with_returns) and whiten for n buffers of a multi-seed run: launches for all buffers are enqueued back to back
+ * and the NaN assertion of src/sampler.jl:270 is checked with one host synchronisation for the whole set.                                    */
+int32_t crux_fill_gae_multi(int32_t n, crux_buffer* const* bufs, crux_mlp* const* critics, float lambda, float gamma, int32_t with_returns);
+int32_t crux_whiten_multi(int32_t n, crux_buffer* const* bufs, int32_t key);
 int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* const* actors, crux_mlp* const* critics, crux_buffer* const* bufs,
                                             const crux_train_cfg* cfg_actor, const crux_train_cfg* cfg_critic, float* info_a, float* info_c);
 

@@ -132,6 +132,11 @@ def test_batched_rollouts_match_single_rollouts(gpu_ctx):
             assert np.array_equal(pa[r][1][k], pb[r][1][k], equal_nan=True) if pa[r][1][k].dtype.kind == "f" else np.array_equal(pa[r][1][k], pb[r][1][k]), (r, k)
         assert ia[r]["n_episode_end"] == ib[r]["n_episode_end"] and ia[r]["sum_r"] == ib[r]["sum_r"]
     assert not np.array_equal(pa[0][1]["s"], pa[1][1]["s"])
+    crux.whiten_multi_([q[1] for q in pa], "advantage")                 # one launch for all problems == whiten_ per buffer
+    for q in pb:
+        crux.whiten_(q[1], "advantage")
+    for r in range(n_rep):
+        assert np.array_equal(pa[r][1]["advantage"], pb[r][1]["advantage"]), r
 
 
 @pytest.mark.gpu
@@ -185,3 +190,51 @@ def test_synced_training_equals_plain_call_without_and_with_a_group_of_one(gpu_c
             for k in ("actor_loss", "critic_loss", "kl"):
                 if k in i0:
                     assert np.isclose(i0[k], i1[k], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_one_cu_population_launch_matches_single_calls_and_the_two_cu_form(gpu_ctx):
+    """Populations above 64 learners train with ONE CU per learner (k_train_mfma8 batched): bit-identical to single calls under
+    Context.set_learner_cus(1), and equal to the two-CU form (different summation order of the minibatch gradient) to fp32 tolerance."""
+    import os
+    from parity import crux
+    if os.environ.get("CRUX_MFMA_WAVES4") or os.environ.get("CRUX_FORCE_GENERIC"):
+        pytest.skip("a debug switch routes the single calls to a different kernel than the batched launch")
+    rng = np.random.default_rng(9); n_rep, n, bs, E = 66, 256, 128, 2
+    extras = ["return", "logprob", "advantage"]
+    datas = []
+    for r in range(n_rep):
+        ai = rng.integers(0, 2, n)
+        datas.append({"s": rng.normal(0, 1, (4, n)).astype(np.float32), "a": np.eye(2, dtype=bool)[:, ai], "sp": rng.normal(0, 1, (4, n)).astype(np.float32), "r": np.ones((1, n), np.float32),
+                      "done": np.zeros((1, n), bool), "episode_end": np.zeros((1, n), bool), "return": rng.normal(0, 1, (1, n)).astype(np.float32),
+                      "logprob": rng.normal(-0.7, 0.05, (1, n)).astype(np.float32), "advantage": rng.normal(0, 1, (1, n)).astype(np.float32)})
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+
+    def run(multi, cus):
+        ctx = crux.Context(0); ctx.set_learner_cus(cus)
+        pis = [crux.ActorCritic(crux.DiscreteNetwork(parity.chain(parity.ACTOR_DIMS, parity.ACTS), [1, 2], seed=80 + r, stream=0, ctx=ctx),
+                                crux.ContinuousNetwork(parity.chain(parity.CRITIC_DIMS, parity.ACTS), seed=80 + r, stream=1, ctx=ctx)) for r in range(n_rep)]
+        bufs = [crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), n, extras, ctx=ctx) for _ in range(n_rep)]
+        for b, d in zip(bufs, datas):
+            b.push_(d)
+        if multi:
+            a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=bs, epochs=E, name="actor_", shuffle_seed=700)
+            c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=bs, epochs=E, name="critic_", shuffle_seed=750)
+            crux.policy_gradient_training_multi(pis, a_opt, c_opt, P, bufs)
+        else:
+            for r in range(n_rep):
+                class _S:
+                    pass
+                sv = _S(); sv.agent = crux.PolicyParams(pis[r]); sv.P = P
+                sv.a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=bs, epochs=E, name="actor_", shuffle_seed=700 + r)
+                sv.c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=bs, epochs=E, name="critic_", shuffle_seed=750 + r)
+                crux.policy_gradient_training(sv, bufs[r])
+        return [(pi.A.get_params(), pi.C.get_params()) for pi in pis], [b["s"] for b in bufs]
+
+    pm, sm_ = run(True, 0)        # automatic: 66 > 64 learners -> one CU each
+    ps, ss = run(False, 1)        # single calls on the one-CU kernel
+    p2, s2 = run(True, 2)         # the same population forced onto the two-CU kernel
+    for r in range(n_rep):
+        assert np.array_equal(pm[r][0], ps[r][0]) and np.array_equal(pm[r][1], ps[r][1]), r
+        assert np.array_equal(sm_[r], ss[r]) and np.array_equal(sm_[r], s2[r])
+        assert np.allclose(pm[r][0], p2[r][0], rtol=0, atol=2e-5) and np.allclose(pm[r][1], p2[r][1], rtol=0, atol=2e-5), r
