@@ -1019,7 +1019,7 @@ def solve(solver, mdp):
         if solver.post_batch_callback:
             solver.post_batch_callback(D, info)                                                                   # :99
         tinfo = policy_gradient_training(solver, D)                                                               # :102
-        tinfo.update({k: v for k, v in info.items() if k == "avg_r"})
+        tinfo.update({k: v for k, v in info.items() if k not in ("sum_r", "n_episode_end")})   # avg_r (record_avgr) and whatever the callback logged
         solver.history.append(tinfo)
         i += solver.dN
     solver.i += solver.dN
@@ -1035,6 +1035,82 @@ def PPO(pi, S, eps=0.2, lambda_p=1.0, lambda_e=0.1, target_kl=0.012, a_opt=None,
                           c_opt=TrainingParams(loss=value_mse_loss, name="critic_", **c_opt),
                           post_batch_callback=lambda D, info: whiten_(D, "advantage"),
                           required_columns=cols, **kw)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# OnPolicyGAIL (src/model_free/il/on_policy_gail.jl) -- the discriminator is trained by batch_train! over TWO buffers (training.jl:28-44)
+# --------------------------------------------------------------------------------------------------------------
+gail_d_loss = _Loss("gail_d")     # gail_d_loss(GAN_BCELoss()) (on_policy_gail.jl:1-5, extras/gans.jl:7-9)
+
+
+def copy_buffer(b):
+    """deepcopy(b::ExperienceBuffer): same columns, same rows, same order."""
+    out = buffer_like(b, capacity=b.capacity)
+    if len(b):
+        out.push_(b, ids=np.arange(1, len(b) + 1))
+    return out
+
+
+def shuffle_device_(b, seed, counter):
+    """shuffle!(b) with the library's permutation stream (crux_rng.h), composed and applied on the device."""
+    b.ctx.check(b.ctx.lib.crux_buffer_shuffle(b.h, int(seed), int(counter))); return b
+
+
+def batch_train_gail_d_(Dnet, p, D_expert, D_policy, info=None):
+    """batch_train!(D, d_opt, (;), D_demo, deepcopy(D)) (on_policy_gail.jl:47, training.jl:28-55): every epoch shuffles both buffers, zips their
+    minibatch partitions (the shorter buffer ends the epoch) and takes one discriminator step per pair. Shuffle k of this TrainingParams uses
+    permutation counter 2k for the expert buffer and 2k+1 for the policy buffer. Epoch info = its last minibatch, result = mean over epochs."""
+    _ensure_opt(Dnet, p)
+    B, infos, total = p.batch_size, [], 0
+    nb = min(-(-len(D_expert) // B), -(-len(D_policy) // B))
+    stop = False
+    for _ in range(p.epochs):
+        shuffle_device_(D_expert, p.shuffle_seed, 2 * p.shuffle_counter); shuffle_device_(D_policy, p.shuffle_seed, 2 * p.shuffle_counter + 1)
+        p.shuffle_counter += 1
+        raw = np.zeros(L.INFO_N, np.float32)
+        for k in range(nb):
+            ne, npi = min(B, len(D_expert) - k * B), min(B, len(D_policy) - k * B)
+            Dnet.ctx.check(Dnet.ctx.lib.crux_gail_d_step(Dnet.h, D_expert.h, k * B, ne, D_policy.h, k * B, npi, _vp(raw)))
+            total += 1
+            if total >= p.max_batches:
+                stop = True; break
+        infos.append({p.name + "loss": float(raw[L.INFO["loss"]]), p.name + "grad_norm": float(raw[L.INFO["grad_norm"]])})
+        if stop:
+            break
+    out = {k: float(np.mean([d[k] for d in infos])) for k in infos[0]}
+    out[p.name + "batches_trained"] = total
+    if info is not None:
+        info.update(out)
+    return out
+
+
+def gail_reward_(Dnet, buf, alpha_r=0.5, Rscale=1.0):
+    """r = ar*logsigmoid(D(a,s)) - (1-ar)*logcompsigmoid(D(a,s)); buf[:r] .= r .* Rscale; returns mean(r) (on_policy_gail.jl:50-55)."""
+    m = np.zeros(1, np.float32)
+    Dnet.ctx.check(Dnet.ctx.lib.crux_gail_reward(Dnet.h, buf.h, float(alpha_r), float(Rscale), _vp(m)))
+    return float(m[0])
+
+
+def OnPolicyGAIL(pi, S, gamma, D, demo, lambda_gae=0.95, alpha_r=0.5, normalize_demo=True, solver=None, d_opt=None, Rscale=1.0, **kw):
+    """OnPolicyGAIL(; pi, S, gamma, lambda_gae, D_demo, alpha_r, normalize_demo, D::ContinuousNetwork, solver=PPO, gan_loss=GAN_BCELoss(), d_opt, Rscale)
+    (src/model_free/il/on_policy_gail.jl:26-69): PPO whose post_batch_callback trains the discriminator on (demo, copy of the fresh batch),
+    overwrites the rewards with the discriminator's, and refills GAE / returns / whitened advantages."""
+    d = dict(d_opt or {}); d.setdefault("name", "discriminator_")
+    dp = TrainingParams(loss=gail_d_loss, **d)
+    A = pi.space if hasattr(pi, "space") else ContinuousSpace(actor(pi).network.dims[-1])
+    demo = copy_buffer(demo)
+    if normalize_demo:
+        normalize_(demo, S, A)
+    sv = (solver or PPO)(pi=pi, S=S, lambda_gae=lambda_gae, **kw)
+
+    def GAIL_callback(buf, info):
+        batch_train_gail_d_(D, dp, demo, copy_buffer(buf), info=info)                    # :47
+        info["disc_reward"] = gail_reward_(D, buf, alpha_r, Rscale)                    # :50-56
+        fill_gae_(buf, sv.agent.pi, lambda_gae, gamma); fill_returns_(buf, gamma)        # :58-63
+        whiten_(buf, "advantage")                                                       # :64
+    sv.post_batch_callback = GAIL_callback
+    sv.discriminator, sv.d_opt, sv.demo = D, dp, demo
+    return sv
 
 
 mse_action_loss, logpdf_bc_loss = _Loss("mse_action"), _Loss("logpdf_bc")   # src/model_free/il/bc.jl:1,10-18

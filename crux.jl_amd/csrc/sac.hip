@@ -186,6 +186,35 @@ __global__ __launch_bounds__(256) void k_adam_gated(float* __restrict__ p, const
     if (atomicAdd(ticket, 1u) == gridDim.x - 1) { bp[0] *= b1; bp[1] *= b2; *ticket = 0u; } }
 }
 
+// ---- OnPolicyGAIL pieces (src/model_free/il/on_policy_gail.jl:1-5,49-54; src/extras/gans.jl:7-9) ---------------------------------------
+// vcat(a, s) of buffer rows [off, off + n): the ACTION first (D(x, y) convention, on_policy_gail.jl:50); one-hot Bool actions become 0/1
+__global__ void k_concat_as(const void* __restrict__ a, int a_is_u8, const float* __restrict__ s, int od, int ad, int64_t off, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n * (od + ad)) return;
+  const int64_t j = i / (od + ad); const int k = (int)(i - j * (od + ad)); const int64_t row = off + j;
+  out[i] = k < ad ? (a_is_u8 ? (((const uint8_t*)a)[row * ad + k] ? 1.f : 0.f) : ((const float*)a)[row * ad + k]) : s[row * od + (k - ad)];
+}
+__device__ __forceinline__ float logsigmoid_f(float x) { const float nx = -x; return -(log1pf(expf(-fabsf(nx))) + (nx > 0.f ? nx : 0.f)); }   // NNlib: -softplus(-x)
+// logitbinarycrossentropy heads of the two halves of the batch: columns [0, n_ex) carry label 1, [n_ex, n_ex + n_pi) label 0
+__global__ __launch_bounds__(256) void k_gail_head(const float* __restrict__ z, int64_t n_ex, int64_t n_pi, float* __restrict__ dz, double* __restrict__ stats /* [2] */) {
+  __shared__ double red[4];
+  double le = 0, lp = 0;
+  for (int64_t j = threadIdx.x; j < n_ex + n_pi; j += 256) { const float v = z[j]; const float ls = logsigmoid_f(v); const float sg = 1.f / (1.f + expf(-v));
+    if (j < n_ex) { le += (double)(-ls); dz[j] = (sg - 1.f) / (float)n_ex; } else { lp += (double)(v - ls); dz[j] = sg / (float)n_pi; } }
+  le = block_sum256(le, red); lp = block_sum256(lp, red);
+  if (threadIdx.x == 0) { stats[0] = le; stats[1] = lp; }
+}
+__global__ void k_gail_info(const double* __restrict__ st, const double* __restrict__ ssq, int64_t n_ex, int64_t n_pi, float* __restrict__ dinfo) {
+  dinfo[CRUX_INFO_LOSS] = (float)(st[0] / (double)n_ex) + (float)(st[1] / (double)n_pi); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
+}
+__global__ __launch_bounds__(256) void k_gail_reward(const float* __restrict__ z, int64_t n, float alpha_r, float rscale, float* __restrict__ r, double* __restrict__ partial) {
+  __shared__ double red[4];
+  double s = 0;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) { const float v = z[j]; const float ls = logsigmoid_f(v), lc = ls - v;
+    const float rr = alpha_r * ls - (1.f - alpha_r) * lc; s += (double)rr; r[j] = rr * rscale; }
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
 static int32_t adam_gated(crux_mlp* n, const double* d_ssq, int32_t* d_status) {
   crux_ctx* c = n->ctx;
   if (!n->has_adam) return crux_fail(c, CRUX_EINVAL, "train!: crux_adam_init was not called on this handle");
@@ -300,6 +329,48 @@ int32_t crux_double_q_step(crux_mlp* q1, crux_mlp* q2, crux_buffer* b, const flo
 int32_t crux_q_step(crux_mlp* q, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out) {
   if (!q || !b || !d_y) return CRUX_EINVAL;
   return q_step_impl(q, nullptr, b, d_y, use_weight, info_out, "td_loss");
+}
+
+int32_t crux_gail_d_step(crux_mlp* D, crux_buffer* ex, int64_t off_ex, int64_t n_ex, crux_buffer* pi, int64_t off_pi, int64_t n_pi, float* info_out) {
+  if (!D || !ex || !pi) return CRUX_EINVAL;
+  crux_ctx* c = D->ctx; const int od = ex->obs_dim, ad = ex->act_dim, sd = od + ad;
+  if (n_ex <= 0 || n_pi <= 0 || off_ex < 0 || off_pi < 0 || off_ex + n_ex > ex->elements || off_pi + n_pi > pi->elements) return crux_fail(c, CRUX_EINVAL, "gail_d_loss: row ranges outside the buffers");
+  if (pi->obs_dim != od || pi->act_dim != ad || pi->act_kind != ex->act_kind) return crux_fail(c, CRUX_EINVAL, "gail_d_loss: expert and policy buffers differ in shape");
+  if (D->nd.L < 1 || D->nd.dims[0] != sd || D->nd.dims[D->nd.L] != 1) return crux_fail(c, CRUX_EINVAL, "gail_d_loss: discriminator must map vcat(a, s) (%d) -> 1", sd);
+  const int64_t B = n_ex + n_pi;
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (sd + 1) + 8192), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "gail_d_loss: scratch");
+  float* x = cv.take<float>((size_t)B * sd); float* dz = cv.take<float>((size_t)B); float* dinfo = cv.take<float>(CRUX_INFO_N);
+  double* st2 = cv.take<double>(2); double* ssq = cv.take<double>(2 + SUMSQ_BLOCKS); int32_t* st = cv.take<int32_t>(1);
+  HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 5, c->stream));
+  const int u8 = ex->act_kind == CRUX_ACTION_DISCRETE ? 1 : 0;
+  hipLaunchKernelGGL(k_concat_as, dim3(nblk(n_ex * sd)), dim3(256), 0, c->stream, (const void*)ex->col[CRUX_COL_A], u8, (const float*)ex->col[CRUX_COL_S], od, ad, off_ex, n_ex, x);
+  hipLaunchKernelGGL(k_concat_as, dim3(nblk(n_pi * sd)), dim3(256), 0, c->stream, (const void*)pi->col[CRUX_COL_A], u8, (const float*)pi->col[CRUX_COL_S], od, ad, off_pi, n_pi, x + (size_t)n_ex * sd);
+  int32_t rc = crux_dense_forward(D, x, B, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_gail_head, dim3(1), dim3(256), 0, c->stream, crux_dense_act(D, D->nd.L), n_ex, n_pi, dz, st2);
+  rc = crux_dense_backward(D, x, B, dz, 1.0f, true, nullptr, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, c->stream, D->g, (int64_t)D->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+  hipLaunchKernelGGL(k_gail_info, dim3(1), dim3(1), 0, c->stream, st2, ssq, n_ex, n_pi, dinfo);
+  rc = adam_gated(D, ssq, st); if (rc) return rc;
+  return finish_step(c, dinfo, st, info_out, "gail_d_loss");
+}
+
+int32_t crux_gail_reward(crux_mlp* D, crux_buffer* b, float alpha_r, float rscale, float* mean_r) {
+  if (!D || !b) return CRUX_EINVAL;
+  crux_ctx* c = D->ctx; const int od = b->obs_dim, ad = b->act_dim, sd = od + ad; const int64_t n = b->elements;
+  if (n <= 0) return crux_fail(c, CRUX_EINVAL, "GAIL reward: empty buffer");
+  if (D->nd.L < 1 || D->nd.dims[0] != sd || D->nd.dims[D->nd.L] != 1) return crux_fail(c, CRUX_EINVAL, "GAIL reward: discriminator must map vcat(a, s) (%d) -> 1", sd);
+  const int nb = 64;
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)n * sd + 4096), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "GAIL reward: scratch");
+  float* x = cv.take<float>((size_t)n * sd); double* part = cv.take<double>(nb);
+  hipLaunchKernelGGL(k_concat_as, dim3(nblk(n * sd)), dim3(256), 0, c->stream, (const void*)b->col[CRUX_COL_A], b->act_kind == CRUX_ACTION_DISCRETE ? 1 : 0, (const float*)b->col[CRUX_COL_S], od, ad, (int64_t)0, n, x);
+  int32_t rc = crux_dense_forward(D, x, n, c->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_gail_reward, dim3(nb), dim3(256), 0, c->stream, crux_dense_act(D, D->nd.L), n, alpha_r, rscale, (float*)b->col[CRUX_COL_R], part);
+  rc = crux_launch_check(c, "k_gail_reward"); if (rc) return rc;
+  double h[64];
+  HIPCHK(c, hipMemcpyAsync(h, part, sizeof h, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+  double s = 0; for (int k = 0; k < nb; ++k) s += h[k];
+  if (mean_r) *mean_r = (float)(s / (double)n);
+  return CRUX_OK;
 }
 
 int32_t crux_dpg_target(crux_mlp* actor_t, crux_mlp* q1t, crux_mlp* q2t, crux_buffer* b, float gamma, float sigma, float eps_min, float eps_max, float a_min, float a_max,

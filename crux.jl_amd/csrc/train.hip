@@ -619,6 +619,19 @@ extern "C" int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* cons
   return crux_buffer_apply_order_multi(n, bufs, fin_ord.data());
 }
 
+// shuffle!(b) (src/experience_buffer.jl:118-124) with the library's own permutation stream (include/crux_rng.h: Feistel permutation keyed by
+// Philox(seed, counter)): new[:,j] = old[:,perm[j]] for every column, composed and applied on the device.
+extern "C" int32_t crux_buffer_shuffle(crux_buffer* b, uint64_t seed, uint64_t counter) {
+  if (!b) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx; const int64_t len = b->elements;
+  if (len < 2) return CRUX_OK;
+  if (len >= ((int64_t)1 << 31)) return crux_fail(c, CRUX_EUNSUP, "shuffle!: buffer too long");
+  const crux_perm pp = crux_perm_make(seed, counter, 0, (uint32_t)len);
+  hipLaunchKernelGGL(k_compose_order, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)nullptr, b->order_a, pp, (const int64_t*)nullptr, len);
+  int32_t rc = crux_launch_check(c, "k_compose_order"); if (rc) return rc;
+  return crux_buffer_apply_order(b, b->order_a, len);
+}
+
 // policy_gradient_training for environment-shard replicas: the same two concurrent learner kernels, launched per chunk of
 // `sync_every` epochs; after each chunk the replicas' parameters and Adam moments are averaged with ONE grouped RCCL all-reduce enqueued on
 // the same stream -- the host does not synchronise until the last chunk is queued. Without a communicator (crux_comm_init not called, or a

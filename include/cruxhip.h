@@ -140,6 +140,8 @@ int32_t crux_buffer_read_column(crux_buffer* b, int32_t key, void* host_out, int
 int32_t crux_buffer_write_column(crux_buffer* b, int32_t key, const void* host_in, int64_t n);
 /* shuffle!(b) with an explicit permutation (:118-124): new[:,j] = old[:,perm[j]], every column.    */
 int32_t crux_buffer_permute(crux_buffer* b, const int64_t* perm /*len*/);
+/* shuffle!(b) with the library's permutation stream (crux_rng.h: crux_perm_make(seed, counter, 0, length(b))), composed and applied on the device. */
+int32_t crux_buffer_shuffle(crux_buffer* b, uint64_t seed, uint64_t counter);
 /* get_last_N_indices (:223-229), 0-based; returns count written.                                  */
 int64_t crux_buffer_last_n_indices(const crux_buffer* b, int64_t N, int64_t* out);
 /* minibatch_copy(b, indices) (:171): gather rows to host; outs[k]==NULL skips a column.            */
@@ -362,6 +364,15 @@ int32_t crux_sac_actor_step(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_ml
 
 /* DDPG / TD3 (src/model_free/rl/ddpg.jl, td3.jl) -----------------------------------------------------------
  * actor: deterministic ContinuousNetwork s -> a; critics: ContinuousNetwork over vcat(s, a).              */
+/* OnPolicyGAIL (src/model_free/il/on_policy_gail.jl): train!(D, gail_d_loss(GAN_BCELoss())) on rows [off_ex, off_ex+n_ex) of the expert buffer
+ * and [off_pi, off_pi+n_pi) of the policy buffer: L = LBCE(D(vcat(a_ex, s_ex)), 1) + LBCE(D(vcat(a_pi, s_pi)), 0) (:1-5, src/extras/gans.jl:7-9,
+ * LBCE = Flux.Losses.logitbinarycrossentropy) -> gradient -> norm (NaN => CRUX_ENAN, no update) -> Adam. The row ranges are the zipped minibatch
+ * partitions of batch_train! over two shuffled buffers (src/training.jl:28-44). D maps act_dim + obs_dim -> 1; one-hot actions enter as 0/1.       */
+int32_t crux_gail_d_step(crux_mlp* D, crux_buffer* expert, int64_t off_ex, int64_t n_ex, crux_buffer* policy, int64_t off_pi, int64_t n_pi, float* info_out);
+/* GAIL_callback reward (:49-55): D_out = value(D, a, s); r = ar*logsigmoid(D_out) - (1-ar)*logcompsigmoid(D_out) (src/utils.jl:140-143);
+ * buffer[:r] .= r .* Rscale; *mean_r = mean(r) (info["disc_reward"]). fill_gae!/fill_returns!/whiten follow as separate calls.                      */
+int32_t crux_gail_reward(crux_mlp* D, crux_buffer* buf, float alpha_r, float rscale, float* mean_r);
+
 /* ddpg_target (ddpg.jl:6-8) when q2_targ = NULL and smooth_sigma < 0; td3_target (td3.jl:4-7) with both targets and the
  * smoothing policy GaussianNoiseExplorationPolicy(sigma; eps_min, eps_max, a_min, a_max) (policies.jl:510-514):
  * y = r + gamma (1-done) min_k Q_k^-(sp, clamp(mu^-(sp) + clamp(sigma randn, eps_min, eps_max), a_min, a_max)).          */

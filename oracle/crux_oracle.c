@@ -1123,6 +1123,45 @@ int32_t orc_dpg_actor_step(orc_mlp* actor, orc_mlp* q, orc_buffer* b, float* inf
   return orc_adam_apply(actor, 1.0f);
 }
 
+/* ---- OnPolicyGAIL pieces (src/model_free/il/on_policy_gail.jl:1-5,49-54; src/extras/gans.jl:7-9) -----------------------------------------
+ * Flux.Losses.logitbinarycrossentropy(z, y) = mean((1 - y) z - logsigmoid(z)) (Flux 0.13/0.14, third-party, restated from its docs);
+ * NNlib.logsigmoid(x) = -softplus(-x), softplus(x) = log1p(exp(-|x|)) + relu(x).                                                        */
+static float orc_logsigmoid(float x) { float nx = -x; float sp = log1pf(expf(-fabsf(nx))) + (nx > 0.f ? nx : 0.f); return -sp; }
+static void gail_input(const orc_buffer* b, int64_t j, float* out) {        /* vcat(a, s): the action first (on_policy_gail.jl:3, :50) */
+  int od = b->obs_dim, ad = b->act_dim;
+  if (b->act_kind == CRUX_ACTION_CONTINUOUS) memcpy(out, (const float*)b->col[CRUX_COL_A] + (size_t)j * ad, 4 * (size_t)ad);
+  else { const uint8_t* a = (const uint8_t*)b->col[CRUX_COL_A] + (size_t)j * ad; for (int k = 0; k < ad; ++k) out[k] = a[k] ? 1.f : 0.f; }
+  memcpy(out + ad, (const float*)b->col[CRUX_COL_S] + (size_t)j * od, 4 * (size_t)od);
+}
+/* train!(D, gail_d_loss(GAN_BCELoss())) on rows [off_ex, off_ex + n_ex) of the expert buffer and [off_pi, off_pi + n_pi) of the policy buffer:
+ * L = LBCE(D(vcat(a_ex, s_ex)), 1) + LBCE(D(vcat(a_pi, s_pi)), 0) */
+int32_t orc_gail_d_step(orc_mlp* D, orc_buffer* ex, int64_t off_ex, int64_t n_ex, orc_buffer* pi, int64_t off_pi, int64_t n_pi, float* info) {
+  int od = ex->obs_dim, ad = ex->act_dim;
+  if (n_ex <= 0 || n_pi <= 0 || off_ex < 0 || off_pi < 0 || off_ex + n_ex > ex->elements || off_pi + n_pi > pi->elements || pi->obs_dim != od || pi->act_dim != ad ||
+      pi->act_kind != ex->act_kind || D->dims[0] != od + ad || D->dims[D->n_layers] != 1) return CRUX_EINVAL;
+  for (int k = 0; k < CRUX_INFO_N; ++k) info[k] = 0.f;
+  float x[1024]; double l_ex = 0, l_pi = 0; colcache c = cc_alloc(D); memset(D->g, 0, 4 * (size_t)D->n_params);
+  for (int64_t j = 0; j < n_ex; ++j) { gail_input(ex, off_ex + j, x); fwd_col(D, x, c.h); float z = c.h[D->n_layers][0];
+    l_ex += (double)(-orc_logsigmoid(z)); float sg = 1.f / (1.f + expf(-z)); float dz = (sg - 1.f) / (float)n_ex; bwd_col_dx(D, c.h, &dz, D->g, NULL); }
+  for (int64_t j = 0; j < n_pi; ++j) { gail_input(pi, off_pi + j, x); fwd_col(D, x, c.h); float z = c.h[D->n_layers][0];
+    l_pi += (double)(z - orc_logsigmoid(z)); float sg = 1.f / (1.f + expf(-z)); float dz = sg / (float)n_pi; bwd_col_dx(D, c.h, &dz, D->g, NULL); }
+  cc_free(D, &c);
+  info[CRUX_INFO_LOSS] = (float)(l_ex / (double)n_ex) + (float)(l_pi / (double)n_pi); info[CRUX_INFO_GRAD_NORM] = (float)sqrt(sumsq_tensors(D));
+  if (isnan(info[CRUX_INFO_GRAD_NORM])) return CRUX_ENAN;
+  return orc_adam_apply(D, 1.0f);
+}
+/* GAIL_callback reward (on_policy_gail.jl:50-55): D_out = value(D, a, s); r = ar logsigmoid(D_out) - (1 - ar) logcompsigmoid(D_out); D[:r] .= r .* Rscale */
+int32_t orc_gail_reward(orc_mlp* D, orc_buffer* b, float alpha_r, float rscale, float* mean_r) {
+  int od = b->obs_dim, ad = b->act_dim; int64_t n = b->elements;
+  if (n <= 0 || D->dims[0] != od + ad || D->dims[D->n_layers] != 1) return CRUX_EINVAL;
+  float x[1024]; colcache c = cc_alloc(D); double sr = 0; float* R = (float*)b->col[CRUX_COL_R];
+  for (int64_t j = 0; j < n; ++j) { gail_input(b, j, x); fwd_col(D, x, c.h); float z = c.h[D->n_layers][0];
+    float ls = orc_logsigmoid(z), lc = ls - z; float r = alpha_r * ls - (1.f - alpha_r) * lc; sr += (double)r; R[j] = r * rscale; }
+  cc_free(D, &c);
+  if (mean_r) *mean_r = (float)(sr / (double)n);
+  return CRUX_OK;
+}
+
 /* test hooks for the randomness spec in include/crux_rng.h */
 void orc_perm(uint64_t seed, uint64_t counter, uint32_t n, int64_t* out) {
   crux_perm p = crux_perm_make(seed, counter, 0, n);

@@ -466,3 +466,38 @@ def test_bc_losses_vs_float64_autograd(case):
     total.backward()
     assert abs(info[0] - total.item()) < 1e-5 * max(1, abs(total.item()))
     assert np.abs(o.grads - p.grad.numpy()).max() < 2e-6 * max(1, np.abs(p.grad.numpy()).max())
+
+
+@pytest.mark.parametrize("disc", [False, True])
+def test_gail_discriminator_loss_and_reward_vs_float64_autograd(disc):
+    """gail_d_loss(GAN_BCELoss()) (on_policy_gail.jl:1-5, extras/gans.jl:7-9) and the GAIL reward (:50-55) of the oracle vs torch float64:
+    L = mean(-logsigmoid(D(a_ex, s_ex))) + mean(D(a_pi, s_pi) - logsigmoid(D(a_pi, s_pi))), r = ar*logsigmoid(z) - (1-ar)*(logsigmoid(z) - z)."""
+    rng = np.random.default_rng(21); od, ad, n_ex, n_pi = 3, 2, 20, 28
+    kind = L.ACTION_DISCRETE if disc else L.ACTION_CONTINUOUS
+    dims, acts = [ad + od, 16, 16, 1], ["tanh", "relu", "identity"]
+    o = O.OMlp(dims, acts).init_glorot(8, 0); o.params[:] += 0.1 * rng.standard_normal(o.n).astype(np.float32); o.adam_init(1e-3)
+    def mk(n):
+        b = O.OBuffer(od, ad, kind, n + 4)
+        a = np.eye(ad, dtype=bool)[:, rng.integers(0, ad, n + 4)] if disc else rng.uniform(-1, 1, (ad, n + 4)).astype(np.float32)
+        d = {"s": rng.normal(0, 1, (od, n + 4)).astype(np.float32), "a": a, "sp": rng.normal(0, 1, (od, n + 4)).astype(np.float32), "r": np.zeros((1, n + 4), np.float32),
+             "done": np.zeros((1, n + 4), bool), "episode_end": np.zeros((1, n + 4), bool)}
+        b.push(d); return b, d
+    bex, dex = mk(n_ex); bpi, dpi = mk(n_pi)
+    info = np.zeros(L.INFO_N, np.float32); p0 = o.params.copy()
+    O.chk(lib.orc_gail_d_step(o.h, bex.h, 2, n_ex, bpi.h, 3, n_pi, O.vpz(info)))
+    pt = torch.tensor(p0, dtype=torch.float64, requires_grad=True)
+    xe = torch.tensor(np.vstack([dex["a"][:, 2:2 + n_ex].astype(np.float64), dex["s"][:, 2:2 + n_ex]]), dtype=torch.float64)
+    xp = torch.tensor(np.vstack([dpi["a"][:, 3:3 + n_pi].astype(np.float64), dpi["s"][:, 3:3 + n_pi]]), dtype=torch.float64)
+    ze, _ = _fwd(pt, dims, acts, xe); zp, _ = _fwd(pt, dims, acts, xp)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(ze[0], torch.ones(n_ex, dtype=torch.float64)) + \
+        torch.nn.functional.binary_cross_entropy_with_logits(zp[0], torch.zeros(n_pi, dtype=torch.float64))
+    loss.backward()
+    assert abs(info[0] - loss.item()) < 1e-5 * max(1, abs(loss.item()))
+    assert np.abs(o.grads - pt.grad.numpy()).max() < 2e-6 * max(1, np.abs(pt.grad.numpy()).max())
+    assert abs(info[L.INFO["grad_norm"]] - float(np.linalg.norm(pt.grad.numpy()))) < 1e-5
+    assert not np.array_equal(o.params, p0)                       # Adam applied
+    # reward on the (updated) discriminator
+    m = np.zeros(1, np.float32); O.chk(lib.orc_gail_reward(o.h, bpi.h, 0.3, 2.0, O.vpz(m)))
+    z = torch.tensor(o.forward(np.vstack([dpi["a"].astype(np.float32), dpi["s"]]))[0].astype(np.float64))
+    ls = torch.nn.functional.logsigmoid(z); r = 0.3 * ls - 0.7 * (ls - z)
+    assert np.abs(bpi["r"][0] - 2.0 * r.numpy()).max() < 1e-5 and abs(m[0] - r.mean().item()) < 1e-5
