@@ -10,3 +10,5 @@ from . import _lib
 from ._lib import CruxError, LIB_PATH
 from .api import *  # noqa: F401,F403
 from . import api, dist
+from . import logging as logging_   # LoggerParams, log, TBLogger, readtb, log_* (src/logging.jl); named logging_ to leave the stdlib name alone
+from .logging import LoggerParams, TBLogger, readtb, aggregate_info, log

@@ -930,11 +930,12 @@ class OnPolicySolver:
     (src/model_free/on_policy.jl:31-54)."""
 
     def __init__(self, agent, S, N=1000, dN=200, max_steps=100, a_opt=None, c_opt=None, P=None, lambda_gae=0.95,
-                 required_columns=(), post_batch_callback=None, post_sample_callback=None, i=0):
+                 required_columns=(), post_batch_callback=None, post_sample_callback=None, i=0, log=None):
         self.agent, self.S, self.N, self.dN, self.max_steps = agent, S, int(N), int(dN), int(max_steps)
         self.a_opt, self.c_opt, self.P = a_opt, c_opt, P or {}
         self.lambda_gae, self.required_columns = np.float32(lambda_gae), list(required_columns)
         self.post_batch_callback, self.post_sample_callback, self.i = post_batch_callback, post_sample_callback, int(i)
+        self.log = log                         # LoggerParams (crux_jl_amd.logging) or None; sampler for the evaluation fns is set at solve time (on_policy.jl:84)
         self.buffer, self.sampler, self.history = None, None, []
 
 
@@ -1021,6 +1022,11 @@ def solve(solver, mdp):
         tinfo = policy_gradient_training(solver, D)                                                               # :102
         tinfo.update({k: v for k, v in info.items() if k not in ("sum_r", "n_episode_end")})   # avg_r (record_avgr) and whatever the callback logged
         solver.history.append(tinfo)
+        if solver.log is not None:                                                                                # :105 log(S.log, S.i + 1:S.i + S.dN, training_info, S=S)
+            from . import logging as _lg
+            if solver.log.sampler is None:
+                solver.log.sampler = s
+            _lg.log(solver.log, (i + 1, i + solver.dN), tinfo, S=solver)
         i += solver.dN
     solver.i += solver.dN
     return solver.agent.pi
@@ -1248,8 +1254,9 @@ class OffPolicySolver:
     (src/model_free/off_policy.jl:37-64). target_update defaults to polyak_average!(pi_minus, pi, 0.005) (:55)."""
 
     def __init__(self, agent, S, N=1000, dN=4, max_steps=100, c_opt=None, buffer_size=1000, buffer=None, buffer_init=None, tau=0.005,
-                 prioritized=False, weighted_loss=False, i=0, a_opt=None, param_optimizers=None, P=None, target_fn="dqn", noise_seed=0):
+                 prioritized=False, weighted_loss=False, i=0, a_opt=None, param_optimizers=None, P=None, target_fn="dqn", noise_seed=0, log=None):
         self.agent, self.S, self.N, self.dN, self.max_steps, self.c_opt, self.i = agent, S, int(N), int(dN), int(max_steps), c_opt, int(i)
+        self.log = log                         # LoggerParams (crux_jl_amd.logging) or None
         self.a_opt, self.param_optimizers, self.P, self.target_fn, self.noise_seed = a_opt, list(param_optimizers or []), dict(P or {}), target_fn, int(noise_seed)
         self.buffer = buffer if buffer is not None else ExperienceBuffer(S, agent.space, buffer_size, prioritized=prioritized)
         self.buffer_init = buffer_init if buffer_init is not None else max(c_opt.batch_size, 200)
@@ -1379,6 +1386,11 @@ def _solve_off_policy(solver, mdp):
         solver.i = i
         steps_(s, solver.buffer, Nsteps=solver.dN, explore=True, i=i)                                  # :138
         solver.history.append(value_training(solver, D, gamma))                                       # :143
+        if solver.log is not None:                                                                     # :146 log(S.log, S.i, infos..., S=S)
+            from . import logging as _lg
+            if solver.log.sampler is None:
+                solver.log.sampler = s
+            _lg.log(solver.log, (i + 1, i + solver.dN), solver.history[-1], S=solver)
         i += solver.dN
     solver.i += solver.dN
     return solver.agent.pi

@@ -96,3 +96,37 @@ def test_bson_buffer_round_trip_host_side(tmp_path):
     assert meta["elements"] == n and meta["next_ind"] == 1 and meta["priority_params"] is None
     for k, v in {**fb.cols, **fb.extra}.items():
         assert cols[k].dtype == v.dtype and np.array_equal(cols[k], v), k
+
+
+def test_tensorboard_event_files_round_trip_and_log_cadence(tmp_path):
+    """crux_jl_amd.logging: CRC-32C known answer, TFRecord/Event encoding read back by readtb (src/analysis.jl:2-13), run-directory increment,
+    elapsed() for steps and ranges (src/logging.jl:1-2), aggregate_info (:60-66), Base.log cadence and log_episode_averages (:29-57, :99-111)."""
+    from crux_jl_amd import logging as lg
+    assert lg.crc32c(b"123456789") == 0xE3069283                      # the standard CRC-32C check value
+    assert lg.elapsed(500, 500) and not lg.elapsed(501, 500) and lg.elapsed((499, 503), 500) and not lg.elapsed((501, 999), 500) and lg.elapsed((1, 1000), 500)
+    assert lg.aggregate_info([{"a": 1.0, "b": 2.0}, {"a": 3.0}]) == {"a": 2.0, "b": 2.0}
+    d = str(tmp_path / "log" / "ppo")
+    tb = lg.TBLogger(d); tb2 = lg.TBLogger(d)
+    assert tb.logdir == d and tb2.logdir == d + "_1"                  # tb_increment
+    for i in range(1, 6):
+        tb.log_value("actor_loss", 0.5 / i, step=100 * i)
+    tb.log_value("returns", [1.0, 2.0], step=7)
+    tb.close()
+    h = lg.readtb(d)
+    assert h["actor_loss"][0] == [100, 200, 300, 400, 500] and np.allclose(h["actor_loss"][1], [0.5 / i for i in range(1, 6)])
+    assert h["returns/1"] == ([7], [1.0]) and h["returns/2"] == ([7], [2.0])
+    raw = bytearray(open(tb.path, "rb").read()); raw[-6] ^= 0x40; open(tb.path, "wb").write(raw)
+    with pytest.raises(ValueError):
+        lg.readtb(d)
+
+    class Buf:                                                         # the two buffer operations log_episode_averages uses
+        cols = {"r": np.arange(10, dtype=np.float32)[None], "episode_end": np.array([[0, 0, 1, 0, 0, 0, 1, 0, 0, 1]], bool)}
+        def get_last_N_indices(self, N): return list(range(10 - N + 1, 11))
+        def __getitem__(self, k): return self.cols[k]
+    class Sv:
+        buffer = Buf()
+    p = lg.LoggerParams(dir=str(tmp_path / "run"), period=4, fns=[lg.log_episode_averages(["r"], 4)])
+    assert lg.log(p, 3, {"x": 1.0}, S=Sv()) is None                    # period not reached
+    w = lg.log(p, (5, 8), {"x": 1.0}, lambda **kw: {"y": 2.0}, S=Sv())
+    assert w == {"avg_r": (6 + 7 + 8 + 9) / 2.0, "x": 1.0, "y": 2.0}
+    assert lg.readtb(p.logger.logdir)["avg_r"] == ([8], [15.0])
