@@ -118,6 +118,7 @@ SIGNATURES = {
     "crux_td_error": (i32, [vp, vp, vp, vp]),
     "crux_softq_target": (i32, [vp, vp, f32, f32, vp]),
     "crux_td_step": (i32, [vp, vp, vp, i32, vp]),
+    "crux_td_step_with_error": (i32, [vp, vp, vp, i32, vp, vp]),
     "crux_mlp_forward_cached": (i32, [vp, vp, i64, vp]),
     "crux_mlp_backward": (i32, [vp, vp, i64, vp, f32, i32, vp]),
     "crux_sac_target": (i32, [vp, vp, vp, vp, vp, f32, u64, u64, vp]),

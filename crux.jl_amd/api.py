@@ -1358,11 +1358,12 @@ def value_training(solver, D, gamma):
             ctx.check(ctx.lib.crux_softq_target(pim.h, D.h, float(gamma), float(solver.P["alpha"]), solver._dy))   # :80  softq.jl:4-13
         else:
             ctx.check(ctx.lib.crux_dqn_target(pim.h, D.h, float(gamma), solver._dy))                    # :80  dqn.jl:4-6
-        if buf.isprioritized():                                                                        # :83
-            ctx.check(ctx.lib.crux_td_error(pi.h, D.h, solver._dy, solver._derr))
-            ctx.check(ctx.lib.crux_per_update_device(buf.h, ctx.lib.crux_buffer_indices_ptr(D.h), solver._derr, B))
         raw = np.zeros(L.INFO_N, np.float32)
-        ctx.check(ctx.lib.crux_td_step(pi.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))   # :91-93
+        if buf.isprioritized():                                                                        # :83 update_priorities!(buffer, D.indices, td_error) and :91-93 train!
+            ctx.check(ctx.lib.crux_td_step_with_error(pi.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, solver._derr, _vp(raw)))   # one forward pass for both
+            ctx.check(ctx.lib.crux_per_update_device(buf.h, ctx.lib.crux_buffer_indices_ptr(D.h), solver._derr, B))
+        else:
+            ctx.check(ctx.lib.crux_td_step(pi.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))   # :91-93
         infos.append({p.name + "loss": float(raw[0]), p.name + "grad_norm": float(raw[1]), "Qavg": float(raw[2])})
     polyak_average_(pim, pi, solver.tau)                                                               # :108
     return {k: float(np.mean([d[k] for d in infos])) for k in infos[0]}                                # aggregate_info (logging.jl:60-66)

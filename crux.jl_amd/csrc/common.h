@@ -157,5 +157,5 @@ int32_t crux_comm_allreduce_mean_impl(crux_ctx* c, crux_mlp* const* nets, int n_
 int32_t crux_dense_forward(crux_mlp* n, const float* d_x, int64_t B, hipStream_t st);
 int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st);
 float* crux_dense_act(crux_mlp* n, int l);
-int32_t crux_td_step_dense(crux_mlp* net, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out);   // sac.hip
+int32_t crux_td_step_dense(crux_mlp* net, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out, float* d_err);   // sac.hip
 #define CRUX_DENSE_MIN_WIDTH 128   // networks at least this wide go through the multi-CU dense engine

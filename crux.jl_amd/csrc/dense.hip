@@ -26,12 +26,17 @@ struct GemmArgs {
   int epi; const float* bias; int act; const float* ysrc; float scale; float* gbias;
 };
 
-template <bool AV, bool BV>
+// SPLITK: the four waves of a workgroup share ONE output tile and take a quarter of K each (combined through LDS in wave order, so the
+// result is deterministic): a 256-deep reduction then costs one L2 round trip instead of four -- these launches are latency-bound.
+template <bool AV, bool BV, bool SPLITK>
 __global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) {
+  __shared__ float part[SPLITK ? 3 * 64 * 5 : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int tm = (q.M + 15) >> 4, tn = (q.N + 15) >> 4;
-  const int tile = blockIdx.x * 4 + wv;
+  const int tile = SPLITK ? (int)blockIdx.x : (int)blockIdx.x * 4 + wv;
   if (tile >= tm * tn) return;
+  const int kper = SPLITK ? ((((q.K + 3) >> 2) + 15) & ~15) : q.K;
+  const int kbeg = SPLITK ? wv * kper : 0, kend = SPLITK ? (kbeg + kper < q.K ? kbeg + kper : q.K) : q.K;
   const int i0 = (tile % tm) << 4, j0 = (tile / tm) << 4;
   const int ia = i0 + c, jb = j0 + c;
   const bool va = ia < q.M, vb = jb < q.N;
@@ -42,23 +47,23 @@ __global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) {
   const bool want_rowsum = q.epi == EPI_WGRAD && j0 == 0 && q.gbias != nullptr;
   // K loop in steps of 64: the loads of four 16-wide chunks are issued before the first MFMA, so one L2 round trip (~1 us under load) is paid per
   // 64 k instead of per 16 (the kernel is a wave-per-tile design with no LDS staging: latency, not bandwidth, is what has to be hidden)
-  for (int k0 = 0; k0 < q.K; k0 += 64) {
+  for (int k0 = kbeg; k0 < kend; k0 += 64) {
     float a[4][4], b[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int kb = k0 + 16 * u + 4 * g;
-      if (AV) { f32x4 t = {0.f, 0.f, 0.f, 0.f}; if (va && kb < q.K) t = *(const f32x4*)(pa + kb);
+      if (AV) { f32x4 t = {0.f, 0.f, 0.f, 0.f}; if (va && kb < kend) t = *(const f32x4*)(pa + kb);
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[u][r] = t[r]; }
       else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int kk = kb + r; a[u][r] = (va && kk < q.K) ? pa[(int64_t)kk * q.sAk] : 0.f; } }
-      if (BV) { f32x4 t = {0.f, 0.f, 0.f, 0.f}; if (vb && kb < q.K) t = *(const f32x4*)(pb + kb);
+        for (int r = 0; r < 4; ++r) { const int kk = kb + r; a[u][r] = (va && kk < kend) ? pa[(int64_t)kk * q.sAk] : 0.f; } }
+      if (BV) { f32x4 t = {0.f, 0.f, 0.f, 0.f}; if (vb && kb < kend) t = *(const f32x4*)(pb + kb);
 #pragma unroll
         for (int r = 0; r < 4; ++r) b[u][r] = t[r]; }
       else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int kk = kb + r; b[u][r] = (vb && kk < q.K) ? pb[(int64_t)kk * q.sBk] : 0.f; } }
+        for (int r = 0; r < 4; ++r) { const int kk = kb + r; b[u][r] = (vb && kk < kend) ? pb[(int64_t)kk * q.sBk] : 0.f; } }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -70,6 +75,13 @@ __global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) rowsum += a[u][r];
     }
+  }
+  if (SPLITK) {        // waves 1..3 hand their partial tile (and row sum) to wave 0, which adds them in wave order
+    if (wv > 0) { float* p = part + ((wv - 1) * 64 + lane) * 5; p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2]; p[3] = acc[3]; p[4] = rowsum; }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { const float* p = part + (w * 64 + lane) * 5; acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3]; rowsum += p[4]; }
   }
   if (want_rowsum) {   // lanes c, c+16, c+32, c+48 hold the four k-groups of row i0+c: fixed-order combine
     rowsum += __shfl_xor(rowsum, 16, 64); rowsum += __shfl_xor(rowsum, 32, 64);
@@ -97,12 +109,22 @@ static inline bool vec_ok(const float* p, int64_t s_k, int64_t s_outer, int K) {
 }
 static int32_t launch_gemm(crux_ctx* c, const GemmArgs& q, hipStream_t st) {
   const int tiles = ((q.M + 15) >> 4) * ((q.N + 15) >> 4);
-  const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+  const dim3 block(256);
   const bool av = vec_ok(q.A, q.sAk, q.sAi, q.K), bv = vec_ok(q.B, q.sBk, q.sBj, q.K);
-  if (av && bv) hipLaunchKernelGGL((k_gemm16<true, true>), grid, block, 0, st, q);
-  else if (av) hipLaunchKernelGGL((k_gemm16<true, false>), grid, block, 0, st, q);
-  else if (bv) hipLaunchKernelGGL((k_gemm16<false, true>), grid, block, 0, st, q);
-  else hipLaunchKernelGGL((k_gemm16<false, false>), grid, block, 0, st, q);
+  static const bool no_split = getenv("CRUX_GEMM_NO_SPLITK") != nullptr;
+  if (q.K >= 128 && tiles <= 4096 && !no_split) {     // deep reductions: split K over the workgroup's four waves
+    const dim3 grid((unsigned)tiles);
+    if (av && bv) hipLaunchKernelGGL((k_gemm16<true, true, true>), grid, block, 0, st, q);
+    else if (av) hipLaunchKernelGGL((k_gemm16<true, false, true>), grid, block, 0, st, q);
+    else if (bv) hipLaunchKernelGGL((k_gemm16<false, true, true>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((k_gemm16<false, false, true>), grid, block, 0, st, q);
+    return crux_launch_check(c, "k_gemm16");
+  }
+  const dim3 grid((unsigned)((tiles + 3) / 4));
+  if (av && bv) hipLaunchKernelGGL((k_gemm16<true, true, false>), grid, block, 0, st, q);
+  else if (av) hipLaunchKernelGGL((k_gemm16<true, false, false>), grid, block, 0, st, q);
+  else if (bv) hipLaunchKernelGGL((k_gemm16<false, true, false>), grid, block, 0, st, q);
+  else hipLaunchKernelGGL((k_gemm16<false, false, false>), grid, block, 0, st, q);
   return crux_launch_check(c, "k_gemm16");
 }
 

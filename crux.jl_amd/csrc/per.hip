@@ -146,6 +146,18 @@ __global__ void k_gather_ring(T* __restrict__ dst, const T* __restrict__ src, co
     dst[((base + j) % C) * row_elems + e] = src[ids[j] * row_elems + e];
   }
 }
+// all columns of the sampled rows in ONE launch: a table of (dst, src, elements per row, element size) and the prefix of row widths
+struct GatherCols { void* dst[CRUX_NCOLS]; const void* src[CRUX_NCOLS]; int32_t re[CRUX_NCOLS]; int32_t esz[CRUX_NCOLS]; int32_t pre[CRUX_NCOLS + 1]; int32_t n; };
+__global__ void k_gather_ring_all(GatherCols g, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) {
+  const int32_t width = g.pre[g.n]; const int64_t total = n * width;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = t / width; const int32_t w = (int32_t)(t - j * width);
+    int k = 0; while (k + 1 < g.n && w >= g.pre[k + 1]) ++k;
+    const int32_t e = w - g.pre[k]; const int64_t d = ((base + j) % C) * g.re[k] + e, sidx = ids[j] * g.re[k] + e;
+    if (g.esz[k] == 4) ((uint32_t*)g.dst[k])[d] = ((const uint32_t*)g.src[k])[sidx];
+    else ((uint8_t*)g.dst[k])[d] = ((const uint8_t*)g.src[k])[sidx];
+  }
+}
 __global__ void k_ring_ids(int64_t* out, int64_t n, int64_t base, int64_t C) { const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (j < n) out[j] = (base + j) % C; }
 
 static unsigned gridn(int64_t total) { int64_t nb = (total + 255) / 256; if (nb < 1) nb = 1; if (nb > 8192) nb = 8192; return (unsigned)nb; }
@@ -172,14 +184,13 @@ static int32_t gather_into(crux_buffer* target, crux_buffer* source, int64_t B, 
   crux_ctx* c = target->ctx;
   const int64_t base = target->next_ind, C = target->capacity;
   crux_prof_begin(c, CRUX_PROF_GATHER);
+  GatherCols g{}; g.n = 0; g.pre[0] = 0;
   for (int k = 0; k < CRUX_NCOLS; ++k) {
     if (!has_col(target, k) || !has_col(source, k)) continue;
-    const size_t st = col_stride(target, k);
-    if (st % 4 == 0) { const int32_t re = (int32_t)(st / 4);
-      hipLaunchKernelGGL(k_gather_ring<uint32_t>, dim3(gridn(B * re)), dim3(256), 0, c->stream, (uint32_t*)target->col[k], (const uint32_t*)source->col[k], (const int64_t*)target->d_indices, B, re, base, C); }
-    else { const int32_t re = (int32_t)st;
-      hipLaunchKernelGGL(k_gather_ring<uint8_t>, dim3(gridn(B * re)), dim3(256), 0, c->stream, (uint8_t*)target->col[k], (const uint8_t*)source->col[k], (const int64_t*)target->d_indices, B, re, base, C); }
+    const size_t st = col_stride(target, k); const int q = g.n++;
+    g.dst[q] = target->col[k]; g.src[q] = source->col[k]; g.esz[q] = st % 4 == 0 ? 4 : 1; g.re[q] = (int32_t)(st % 4 == 0 ? st / 4 : st); g.pre[q + 1] = g.pre[q] + g.re[q];
   }
+  if (g.n > 0) hipLaunchKernelGGL(k_gather_ring_all, dim3(gridn(B * g.pre[g.n])), dim3(256), 0, c->stream, g, (const int64_t*)target->d_indices, B, base, C);
   crux_prof_end(c, CRUX_PROF_GATHER);
   int32_t rc = crux_launch_check(c, "k_gather_ring"); if (rc) return rc;
   if (target->prioritized) {       // buffer_like of a prioritized buffer is prioritized too (:84): push! runs update_priorities! on it

@@ -99,12 +99,12 @@ __global__ __launch_bounds__(256) void k_q_head(const float* __restrict__ Q, con
 }
 // td_loss head for a DiscreteNetwork critic (utils.jl:76-87, policies.jl:122): Q = sum(value .* onehot); dy = onehot * 2 (Q - y) w / B
 __global__ __launch_bounds__(256) void k_td_head(const float* __restrict__ z, const uint8_t* __restrict__ a, int nout, const float* __restrict__ y, const float* __restrict__ w, int64_t B,
-                                                 float* __restrict__ dy, double* __restrict__ stats /* [2] */) {
+                                                 float* __restrict__ dy, double* __restrict__ stats /* [2] */, float* __restrict__ err /* td_error(pi, D, y) of the same forward pass, or NULL */) {
   __shared__ double red[4];
   const float invB = 1.f / (float)B; double sl = 0, sq = 0;
   for (int64_t j = threadIdx.x; j < B; j += 256) { float Q = 0.f;
     for (int k = 0; k < nout; ++k) Q += z[j * nout + k] * (a[j * nout + k] ? 1.f : 0.f);
-    const float d = Q - y[j]; const float ww = w ? w[j] : 1.f; sl += (double)(d * d * ww); sq += (double)Q;
+    const float d = Q - y[j]; if (err) err[j] = fabsf(d); const float ww = w ? w[j] : 1.f; sl += (double)(d * d * ww); sq += (double)Q;
     for (int k = 0; k < nout; ++k) dy[j * nout + k] = a[j * nout + k] ? 2.f * d * ww * invB : 0.f; }
   sl = block_sum256(sl, red); sq = block_sum256(sq, red);
   if (threadIdx.x == 0) { stats[0] = sl; stats[1] = sq; }
@@ -251,14 +251,14 @@ static int32_t finish_step(crux_ctx* c, const float* d_info, const int32_t* d_st
 }
 
 // train!(critic, td_loss) for wide DiscreteNetwork critics (C3: 8-256-256-4) on the dense engine; crux_td_step (train.hip) routes here.
-int32_t crux_td_step_dense(crux_mlp* net, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out) {
+int32_t crux_td_step_dense(crux_mlp* net, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out, float* d_err) {
   crux_ctx* c = net->ctx; const int64_t B = b->elements; const int nout = net->nd.dims[net->nd.L];
   Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * nout + 8192), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "td_step: scratch");
   float* dy = cv.take<float>((size_t)B * nout); float* dinfo = cv.take<float>(CRUX_INFO_N); double* st = cv.take<double>(2); double* ssq = cv.take<double>(2 + SUMSQ_BLOCKS); int32_t* status = cv.take<int32_t>(1);
   HIPCHK(c, hipMemsetAsync(dinfo, 0, 256 * 6, c->stream));
   const float* S = (const float*)b->col[CRUX_COL_S]; const float* w = use_weight ? (const float*)b->col[CRUX_COL_WEIGHT] : nullptr;
   int32_t rc = crux_dense_forward(net, S, B, c->stream); if (rc) return rc;
-  hipLaunchKernelGGL(k_td_head, dim3(1), dim3(256), 0, c->stream, crux_dense_act(net, net->nd.L), (const uint8_t*)b->col[CRUX_COL_A], nout, d_y, w, B, dy, st);
+  hipLaunchKernelGGL(k_td_head, dim3(1), dim3(256), 0, c->stream, crux_dense_act(net, net->nd.L), (const uint8_t*)b->col[CRUX_COL_A], nout, d_y, w, B, dy, st, d_err);
   rc = crux_dense_backward(net, S, B, dy, 1.0f, true, nullptr, c->stream); if (rc) return rc;
   hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, c->stream, net->g, (int64_t)net->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
   hipLaunchKernelGGL(k_td_info, dim3(1), dim3(1), 0, c->stream, st, ssq, B, dinfo);

@@ -690,7 +690,15 @@ extern "C" int32_t crux_policy_gradient_training_synced(crux_mlp* actor, crux_ml
 }
 
 // ---- off-policy pieces ------------------------------------------------------------------------------
-int32_t crux_td_step(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight, float* info_out) {
+int32_t crux_td_error(crux_mlp* net, crux_buffer* batch, const float* d_y, float* d_err);
+static int32_t td_step_impl(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight, float* info_out, float* d_err);
+int32_t crux_td_step(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight, float* info_out) { return td_step_impl(net, batch, d_y, use_weight, info_out, nullptr); }
+// td_error(pi, D, y) (utils.jl:112) and train!(pi, td_loss) (utils.jl:76-87) evaluate the same Q(s, a) with the same parameters: one forward pass serves both
+int32_t crux_td_step_with_error(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight, float* d_err, float* info_out) {
+  if (!d_err) return CRUX_EINVAL;
+  return td_step_impl(net, batch, d_y, use_weight, info_out, d_err);
+}
+static int32_t td_step_impl(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight, float* info_out, float* d_err) {
   if (!net || !batch || !d_y) return CRUX_EINVAL;
   crux_ctx* c = net->ctx;
   if (batch->elements < 1) return crux_fail(c, CRUX_EINVAL, "td_loss: empty batch");
@@ -699,8 +707,9 @@ int32_t crux_td_step(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_
   if (net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH) {   // wide critics (C3): tile-GEMM engine over many CUs instead of the single-workgroup kernel
     if (!net->has_adam) return crux_fail(c, CRUX_EINVAL, "train!: crux_adam_init was not called for this network");
     if (net->nd.dims[0] != batch->obs_dim) return crux_fail(c, CRUX_EINVAL, "train!: network input %d != obs dim %d", net->nd.dims[0], batch->obs_dim);
-    return crux_td_step_dense(net, batch, d_y, use_weight, info_out);
+    return crux_td_step_dense(net, batch, d_y, use_weight, info_out, d_err);
   }
+  if (d_err) { const int32_t rce = crux_td_error(net, batch, d_y, d_err); if (rce) return rce; }   // narrow critics: the persistent kernel has no error output
   crux_train_cfg cfg{}; cfg.loss = CRUX_LOSS_VALUE_MSE; cfg.head = CRUX_HEAD_GREEDY_Q; cfg.batch_size = (int32_t)batch->elements; cfg.epochs = 1; cfg.target_kl = -1.f;
   TrainArgs a; int32_t rc = fill_args(a, net, batch, &cfg, CRUX_LOSS_TD_INTERNAL); if (rc) return rc;
   std::vector<int64_t> ids((size_t)batch->elements); for (size_t j = 0; j < ids.size(); ++j) ids[j] = (int64_t)j;

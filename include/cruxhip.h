@@ -337,6 +337,11 @@ int32_t crux_td_error(crux_mlp* net, crux_buffer* batch, const float* d_y, float
 /* train!(critic, td_loss) (utils.jl:76-87): one Adam step on mean((Q(s,a)-y)^2 [.* weight]).       */
 int32_t crux_td_step(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight,
                      float* info_out /* LOSS, GRAD_NORM, [2]=Qavg */);
+/* td_error(pi, D, y) (src/utils.jl:112) and train!(pi, td_loss) (:76-87) of one value_training epoch (off_policy.jl:83-93) in one call: both evaluate
+ * Q(s, a) with the same parameters, so the forward pass is shared. d_err (device, [B]) receives |Q - y| for update_priorities!; the step is
+ * identical to crux_td_step. The priorities do not enter the loss (the :weight column was written by prioritized_sample!), so updating them after
+ * the step instead of before gives the reference's result.                                                                                       */
+int32_t crux_td_step_with_error(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight, float* d_err, float* info_out);
 
 
 /* SAC (src/model_free/rl/sac.jl) -----------------------------------------------------------------------

@@ -349,7 +349,17 @@ def test_dqn_target_td_error_td_step_match_oracle(gpu_ctx, dims, acts):
             assert np.abs(gg - o.grads).max() < 1e-4 * np.abs(o.grads).max()
     dp = np.abs(g.get_params() - o.params)
     assert dp.max() < (1e-6 if max(dims) < 128 else 5e-4) and np.mean(dp > 2e-5) <= 1e-3   # Adam's first steps amplify rounding where g ~ 0 (step = lr*g/(|g|+eps))
-    ctx.free(dy); ctx.free(de)
+    # crux_td_step_with_error == crux_td_error followed by crux_td_step (one shared forward pass): bit for bit
+    g2, _ = parity.make_pair(dims, acts, 31, 0, "discrete"); g2.attach_optimizer(crux.Adam(np.float32(1e-3)))
+    g3, _ = parity.make_pair(dims, acts, 31, 0, "discrete"); g3.attach_optimizer(crux.Adam(np.float32(1e-3)))
+    de2 = ctx.alloc(4 * n); r2, r3 = np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32)
+    for _ in range(2):
+        ctx.check(ctx.lib.crux_td_error(g2.h, gb.h, dy, de)); ctx.check(ctx.lib.crux_td_step(g2.h, gb.h, dy, 1, O.vpz(r2)))
+        ctx.check(ctx.lib.crux_td_step_with_error(g3.h, gb.h, dy, 1, de2, O.vpz(r3)))
+        assert np.array_equal(ctx.d2h(de, np.empty(n, np.float32)), ctx.d2h(de2, np.empty(n, np.float32))) if max(dims) < 128 else \
+            np.abs(ctx.d2h(de, np.empty(n, np.float32)) - ctx.d2h(de2, np.empty(n, np.float32))).max() < 1e-6
+        assert np.array_equal(g2.get_params(), g3.get_params()) and np.array_equal(r2, r3)
+    ctx.free(dy); ctx.free(de); ctx.free(de2)
 
 
 # ---------------------------------------------------------------------------------------------------- full-size properties

@@ -44,9 +44,8 @@ def main():
     def dqn_epoch():
         k[0] += 1; crux.prioritized_sample_(D, buf, i=k[0])
         ctx.check(ctx.lib.crux_dqn_target(qm.h, D.h, 0.99, dy))
-        ctx.check(ctx.lib.crux_td_error(q.h, D.h, dy, de))
+        ctx.check(ctx.lib.crux_td_step_with_error(q.h, D.h, dy, 1, de, raw.ctypes.data_as(L.vp)))      # td_error + train! share the forward pass
         ctx.check(ctx.lib.crux_per_update_device(buf.h, ctx.lib.crux_buffer_indices_ptr(D.h), de, B))
-        ctx.check(ctx.lib.crux_td_step(q.h, D.h, dy, 1, raw.ctypes.data_as(L.vp)))
     def td_only():
         ctx.check(ctx.lib.crux_td_step(q.h, D.h, dy, 1, raw.ctypes.data_as(L.vp)))
     t_per, t_epoch, t_td = timed(ctx, per_only, a.steps), timed(ctx, dqn_epoch, a.steps), timed(ctx, td_only, a.steps)
