@@ -75,6 +75,7 @@ static void launch_copy_rows(crux_ctx* c, void* dst, const int64_t* d_dst_idx, c
     hipLaunchKernelGGL(k_copy_rows<uint8_t>, dim3(grid_for(n * re)), dim3(256), 0, c->stream, (uint8_t*)dst, d_dst_idx, (const uint8_t*)src, d_src_idx, n, re); }
 }
 
+extern "C" int32_t crux_buffer_indices(const crux_buffer* cb, int64_t* out, int64_t n);
 // exported to other translation units ------------------------------------------------------------------
 int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I) {
   I.resize((size_t)N);
@@ -202,7 +203,7 @@ int32_t crux_buffer_has_column(const crux_buffer* b, int32_t key) { return b && 
 
 int32_t crux_buffer_clear(crux_buffer* b) {                                            // clear! :97-104
   if (!b) return CRUX_EINVAL;
-  b->elements = 0; b->next_ind = 0; b->total_count = 0; b->indices.clear();
+  b->elements = 0; b->next_ind = 0; b->total_count = 0; b->indices.clear(); b->indices_n = 0; b->indices_stale = false;
   if (b->prioritized) {
     HIPCHK(b->ctx, hipMemsetAsync(b->priorities, 0, 4 * (size_t)b->capacity, b->ctx->stream));
     const float inf = INFINITY;                                                         // PriorityParams(N, pp) keeps max_priority, resets min
@@ -241,6 +242,7 @@ int32_t crux_buffer_push_host(crux_buffer* b, int64_t N, const void* const* cols
     }
   }
   if (b->prioritized) {
+    if (b->indices_stale) { int64_t dummy = 0; (void)crux_buffer_indices(b, &dummy, 0); }     // d_indices is about to be reused: bring the host mirror of the last sample up to date first
     HIPCHK(c, hipMemcpyAsync(b->d_indices, I.data(), 8 * (size_t)(N < C ? N : C), hipMemcpyHostToDevice, c->stream));
     int32_t rc = crux_buffer_per_on_push(b, b->d_indices, N < C ? N : C); if (rc) return rc;
   }
@@ -345,8 +347,12 @@ int32_t crux_buffer_gather_host(crux_buffer* b, const int64_t* ids, int64_t n, v
 
 int64_t* crux_buffer_indices_ptr(crux_buffer* b) { return b ? b->d_indices : nullptr; }
 
-int32_t crux_buffer_indices(const crux_buffer* b, int64_t* out, int64_t n) {
-  if (!b || !out) return CRUX_EINVAL;
+int32_t crux_buffer_indices(const crux_buffer* cb, int64_t* out, int64_t n) {
+  if (!cb || !out) return CRUX_EINVAL;
+  crux_buffer* b = const_cast<crux_buffer*>(cb);
+  if (b->indices_stale) { crux_ctx* c = b->ctx; b->indices.resize((size_t)b->indices_n);
+    HIPCHK(c, hipMemcpyAsync(b->indices.data(), b->d_indices, 8 * (size_t)b->indices_n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+    b->indices_stale = false; }
   if (n > (int64_t)b->indices.size()) n = (int64_t)b->indices.size();
   memcpy(out, b->indices.data(), 8 * (size_t)n); return CRUX_OK;
 }

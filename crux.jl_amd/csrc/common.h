@@ -86,7 +86,8 @@ struct crux_buffer {
   float* cumsum = nullptr;       // device [capacity]
   bool cumsum_valid = false;
   float* pminmax = nullptr;      // device [2]: max_priority, min_priority (un-powered, Float32 fields)
-  std::vector<int64_t> indices;  // host copy of the last sample's ids (target.indices)
+  std::vector<int64_t> indices;  // host copy of the last sample's ids (target.indices), fetched from d_indices on demand
+  int64_t indices_n = 0; bool indices_stale = false;
   int64_t* d_indices = nullptr;  // device copy [capacity]
   // pairwise-cumsum tree of Base.cumsum for the current length (built on the host once per length, see per.hip)
   int64_t topo_n = -1; int32_t topo_leaves = 0, topo_nodes = 0, topo_levels = 0;

@@ -393,7 +393,7 @@ def test_full_size_iteration_properties(gpu_ctx):
 
 
 # ---------------------------------------------------------------------------------------------------- replay sampling
-@pytest.mark.parametrize("N", [1, 5, 127, 128, 129, 1000, 100_003, 1_000_000])
+@pytest.mark.parametrize("N", [1, 5, 127, 128, 129, 1000, 100_003, 1_000_000, 3_000_001])   # the last one exceeds the LDS-resident tree pass (k_tree_lds) and takes the global-memory one
 def test_pairwise_cumsum_is_bit_exact(gpu_ctx, N):
     rng = np.random.default_rng(N)
     b = crux.ExperienceBuffer(crux.ContinuousSpace(1), crux.DiscreteSpace(2), N, prioritized=True)
