@@ -113,6 +113,7 @@ SIGNATURES = {
     "crux_comm_destroy": (i32, [vp]),
     "crux_comm_size": (i32, [vp]),
     "crux_allreduce_mean": (i32, [vp]),
+    "crux_allreduce_grads": (i32, [vp]),
     "crux_first_episode_metrics": (i32, [vp, i32, i64, f32, vp, vp, vp, vp]),
     "crux_dqn_target": (i32, [vp, vp, f32, vp]),
     "crux_td_error": (i32, [vp, vp, vp, vp]),

@@ -85,6 +85,15 @@ int32_t crux_comm_destroy(crux_ctx* c) {
   return CRUX_OK;
 }
 int32_t crux_comm_size(const crux_ctx* c) { return c && c->comm ? c->comm_n : 1; }
+// exact data-parallel step (k = 1): crux_loss_grad on the local minibatch -> crux_allreduce_grads (SUM over ranks, stream-ordered) ->
+// crux_adam_apply(net, 1/nranks): every rank applies the same update, parameters and Adam state stay replicated
+int32_t crux_allreduce_grads(crux_mlp* net) {
+  if (!net) return CRUX_EINVAL;
+  crux_ctx* c = net->ctx; if (!c->comm) return CRUX_OK;
+  RcclApi* api = rccl(c); if (!api) return CRUX_ERCCL;
+  RCCLCHK(c, api, api->AllReduce(net->g, net->g, (size_t)net->nd.n_params, ncclFloat, ncclSum, (ncclComm_t)c->comm, c->stream));
+  return CRUX_OK;
+}
 int32_t crux_allreduce_mean(crux_mlp* net) {
   if (!net) return CRUX_EINVAL;
   crux_mlp* one[1] = {net}; return crux_comm_allreduce_mean_impl(net->ctx, one, 1);

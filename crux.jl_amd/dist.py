@@ -49,6 +49,10 @@ class GradAllReducer:
         return self.tensor
 
     def __call__(self):
+        n_native = self.net.ctx.comm_size()
+        if n_native > 1:                    # the library's own RCCL communicator (Context.comm_init): stream-ordered, no host synchronisation
+            self.net.ctx.check(self.net.ctx.lib.crux_allreduce_grads(self.net.h))
+            return 1.0 / n_native
         if self.world == 1:
             return 1.0
         self.net.ctx.sync()                 # the library's stream must have produced the gradient

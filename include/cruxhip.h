@@ -308,6 +308,9 @@ int32_t crux_comm_init(crux_ctx* ctx, int32_t rank, int32_t nranks, const uint8_
 int32_t crux_comm_destroy(crux_ctx* ctx);
 int32_t crux_comm_size(const crux_ctx* ctx);               /* 1 when no communicator is attached */
 int32_t crux_allreduce_mean(crux_mlp* net);
+/* SUM all-reduce of the flat gradient left by crux_loss_grad (crux_mlp_grads_ptr), stream-ordered; follow with crux_adam_apply(net, 1/nranks):
+ * the exact data-parallel minibatch step (global batch = nranks x local batch), every rank applying the identical update.                */
+int32_t crux_allreduce_grads(crux_mlp* net);
 /* policy_gradient_training (src/model_free/on_policy.jl:56-78) for replicas: the epochs run in chunks of sync_every, each chunk followed
  * by crux_allreduce_mean(actor), (critic) on the stream. With no communicator it is bit-identical to crux_policy_gradient_training.
  * Requires no KL early stopping / max_batches (replicas must run the same number of epochs) and equal actor/critic epoch counts.     */

@@ -1,8 +1,11 @@
 """GPU parity: one PPO iteration through the C ABI vs the CPU oracle (same Philox-defined randomness)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
 import parity
+from parity import L, O
 
 pytestmark = pytest.mark.gpu
 
@@ -178,6 +181,16 @@ def test_synced_training_equals_plain_call_without_and_with_a_group_of_one(gpu_c
         ctx1.comm_init(0, 1, ctx1.comm_unique_id())
         assert ctx1.comm_size() == 1
         grp = run("synced", ctx1)
+        # crux_allreduce_grads on the group of one: a SUM over one rank leaves the gradient of crux_loss_grad as it is
+        net = crux.DiscreteNetwork(parity.chain(parity.ACTOR_DIMS, parity.ACTS), [1, 2], seed=3, stream=0, ctx=ctx1)
+        bb = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), n, extras, ctx=ctx1); bb.push_(data)
+        pp = crux.TrainingParams(loss=crux.ppo_loss, batch_size=bs, epochs=1, name="actor_"); crux.api._ensure_opt(net, pp)
+        cfg = crux.api._train_cfg(net, pp, P); ids0 = np.arange(bs, dtype=np.int64); raw = np.zeros(L.INFO_N, np.float32)
+        ctx1.check(ctx1.lib.crux_loss_grad(net.h, bb.h, C.byref(cfg), ids0.ctypes.data_as(C.c_void_p), bs, raw.ctypes.data_as(C.c_void_p)))
+        g0 = np.empty(net.n_params, np.float32); ctx1.d2h(ctx1.lib.crux_mlp_grads_ptr(net.h), g0)
+        ctx1.check(ctx1.lib.crux_allreduce_grads(net.h)); ctx1.sync()
+        g1 = np.empty(net.n_params, np.float32); ctx1.d2h(ctx1.lib.crux_mlp_grads_ptr(net.h), g1)
+        assert np.array_equal(g0, g1) and np.abs(g0).max() > 0
     finally:
         ctx1.comm_destroy()
     for other in (got, grp):
