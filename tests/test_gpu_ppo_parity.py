@@ -115,7 +115,10 @@ def test_multi_seed_batched_learners_match_single_calls(gpu_ctx):
 
 def test_batched_rollouts_match_single_rollouts(gpu_ctx):
     """crux_rollout_multi == one crux_rollout per problem (same kernel; only the launch geometry differs): every column bit for bit."""
+    import os
     from parity import crux
+    if os.environ.get("CRUX_FORCE_GENERIC"):
+        pytest.skip("the debug switch routes the single rollouts to the generic kernel, the batched launch exists for the register-resident one only")
     n_rep, E, T = 3, 4, 48
     def build():
         out = []
