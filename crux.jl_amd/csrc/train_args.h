@@ -30,3 +30,12 @@ struct TrainArgs {
   unsigned long long* dbg;   // optional phase-timing output (CRUX_MFMA_TIMING)
   float* xbuf; unsigned* xctr;   // two-CU kernel (train_mfma_x2.hip): gradient exchange slots [parity][workgroup] and {arrival counter, abort flag}
 };
+
+// The minibatch rows are device global memory. Typing the per-step loads as address_space(1) makes them global_load instead of the flat_load a
+// generic pointer compiles to: flat accesses also count on lgkmcnt, so every LDS wait after the prefetch of the next minibatch was issued
+// waited for that prefetch as well (an L2 round trip per step), and their 64-bit addresses cost extra VALU adds.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CRUX_GLOBAL_PTR(T, ptr) ((const __attribute__((address_space(1))) T*)(ptr))
+#else
+#define CRUX_GLOBAL_PTR(T, ptr) ((const T*)(ptr))
+#endif

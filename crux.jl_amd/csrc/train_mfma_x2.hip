@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
   auto fetch_index = [&](const int32_t* ord, int64_t st, int nb) {
     const int sidx = 64 * p + 16 * w + c;
     n_valid = sidx < nb ? 1 : 0;
-    n_row = n_valid ? (a.ids ? a.ids[st + sidx] : ord[st + sidx]) : 0;
+    n_row = n_valid ? (a.ids ? CRUX_GLOBAL_PTR(int32_t, a.ids)[st + sidx] : CRUX_GLOBAL_PTR(int32_t, ord)[st + sidx]) : 0;
   };
   auto fetch_data = [&]() {
     const int rowlo = n_row; p_valid = n_valid; const int64_t row = rowlo;
@@ -182,18 +182,18 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
     for (int e = 0; e < NXL; ++e) {
       const int el = lane + 64 * e; const int s = el / IN, f = el - s * IN;
       const int rs = __shfl(rowlo, s & 15, 64); const int vs = __shfl(p_valid, s & 15, 64);
-      px[e] = (el < 16 * IN && vs) ? a.S[(int64_t)rs * IN + f] : 0.f;
+      px[e] = (el < 16 * IN && vs) ? CRUX_GLOBAL_PTR(float, a.S)[(int64_t)rs * IN + f] : 0.f;
     }
     p_lp = 0.f; p_adv = 0.f; p_ret = 0.f;
 #pragma unroll
     for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
     if (lane < 16 && p_valid) {
-      if (KIND != MFK_VALUE) { p_lp = a.LP[row]; p_adv = a.ADV[row]; }
-      p_ret = a.RET ? a.RET[row] : 0.f;
-      if (KIND == MFK_CATEGORICAL) { const uint8_t* av = (const uint8_t*)a.A + row * OUT;
+      if (KIND != MFK_VALUE) { p_lp = CRUX_GLOBAL_PTR(float, a.LP)[row]; p_adv = CRUX_GLOBAL_PTR(float, a.ADV)[row]; }
+      p_ret = a.RET ? CRUX_GLOBAL_PTR(float, a.RET)[row] : 0.f;
+      if (KIND == MFK_CATEGORICAL) { const auto* av = CRUX_GLOBAL_PTR(uint8_t, a.A) + row * OUT;
 #pragma unroll
         for (int k = 0; k < OUT; ++k) p_abyte[k] = av[k]; }
-      if (KIND == MFK_GAUSSIAN) { const float* av = (const float*)a.A + row * OUT;
+      if (KIND == MFK_GAUSSIAN) { const auto* av = CRUX_GLOBAL_PTR(float, a.A) + row * OUT;
 #pragma unroll
         for (int k = 0; k < OUT; ++k) p_act[k] = av[k]; }
     }
