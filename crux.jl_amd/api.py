@@ -506,6 +506,20 @@ class ExperienceBuffer:
         self.ctx.check(self.ctx.lib.crux_buffer_push_host(self.h, N, cols, _vp(I)))
         return I + 1
 
+    def push_reservoir_(self, data, weighted=False, seed=0, counter=0):
+        """push_reservoir!(buffer, data; weighted) (:262-288) for a dict of (features, N) host arrays; row i draws Philox(seed, counter + i) (crux_rng.h)."""
+        first = next(iter(data.values())); N = np.asarray(first).shape[-1]
+        cols = (C.c_void_p * L.NCOLS)(); keep = []
+        for k, v in data.items():
+            if k not in L.COL or not self.haskey(k):
+                continue
+            arr = np.asarray(v); arr = arr.reshape(self._shape(k, N)) if arr.ndim == 1 else arr
+            if arr.shape[:-1] != self._shape(k, N)[:-1]:
+                raise L.CruxError(L.EINVAL, "push_reservoir!: column :%s has shape %s, buffer expects %s" % (k, arr.shape, self._shape(k, N)))
+            arr = np.asfortranarray(arr.astype(_np_dtype(k, self.act_kind))); keep.append(arr); cols[L.COL[k]] = arr.ctypes.data
+        self.ctx.check(self.ctx.lib.crux_buffer_push_reservoir(self.h, N, cols, 1 if weighted else 0, int(seed), int(counter)))
+        return self
+
     def shuffle_(self, perm):
         """shuffle!(b) with an explicit 1-based permutation (:118-124)."""
         p = np.ascontiguousarray(np.asarray(perm, np.int64) - 1)

@@ -252,6 +252,57 @@ int32_t crux_buffer_push_host(crux_buffer* b, int64_t N, const void* const* cols
   return CRUX_OK;
 }
 
+// push_reservoir!(buffer, data; weighted) (src/experience_buffer.jl:262-288). The per-element decisions are a sequential recurrence on
+// (length, total_count) and are taken on the host from the host-resident data (same rules and the same Philox draws as the oracle: see
+// crux_rng.h CRUX_RNG_RESERVOIR); the rows then move in two steps: the run that fills the ring through the ordinary push!, the
+// replacements (last write per slot wins, like the reference's sequential assignments) through one staged upload + one scatter launch per column.
+// Quirks kept: total_count grows by 2 per element while the buffer fills (:272 and push! :235); replaced slots keep their priorities.
+int32_t crux_buffer_push_reservoir(crux_buffer* b, int64_t N, const void* const* cols, int32_t weighted, uint64_t seed, uint64_t counter) {
+  if (!b || N < 0 || !cols) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx; if (N == 0) return CRUX_OK;
+  const float* W = (weighted && has_col(b, CRUX_COL_WEIGHT) && cols[CRUX_COL_WEIGHT]) ? (const float*)cols[CRUX_COL_WEIGHT] : nullptr;
+  std::vector<int64_t> fill; std::vector<std::pair<int64_t, int64_t>> repl;   // source rows pushed in order; (slot, source row) assignments in order
+  int64_t elements = b->elements, total = b->total_count;
+  for (int64_t i = 0; i < N; ++i) {
+    const crux_u32x4 x = crux_philox(seed, counter + (uint64_t)i, 0, CRUX_RNG_RESERVOIR);
+    if (W && crux_u32x2_to_f64(x.v[0], x.v[1]) > (double)W[i]) continue;
+    total += 1;
+    if (elements < b->capacity) { fill.push_back(i); elements += 1; total += 1; }
+    else { const uint64_t r = ((uint64_t)x.v[2] << 32) | (uint64_t)x.v[3];
+      const int64_t j = 1 + (int64_t)(((unsigned __int128)r * (unsigned __int128)(uint64_t)total) >> 64);
+      if (j <= b->capacity) repl.emplace_back(j - 1, i); }
+  }
+  if (!fill.empty()) {       // the fill phase is a run of 1-row push! calls = one push! of the accepted rows (the ring cannot wrap while it fills)
+    size_t maxst = 0; for (int k = 0; k < CRUX_NCOLS; ++k) if (has_col(b, k) && col_stride(b, k) > maxst) maxst = col_stride(b, k);
+    std::vector<std::vector<char>> stage(CRUX_NCOLS); const void* ptrs[CRUX_NCOLS];
+    for (int k = 0; k < CRUX_NCOLS; ++k) { ptrs[k] = nullptr; if (!has_col(b, k) || !cols[k]) continue; const size_t st = col_stride(b, k);
+      stage[k].resize(st * fill.size()); for (size_t q = 0; q < fill.size(); ++q) memcpy(stage[k].data() + q * st, (const char*)cols[k] + (size_t)fill[q] * st, st);
+      ptrs[k] = stage[k].data(); }
+    if (b->prioritized) {      // every 1-row push! raises max_priority by eps (update_priorities!: val = v + eps, :293-299), so the rows must go one at a time
+      for (size_t q = 0; q < fill.size(); ++q) { const void* one[CRUX_NCOLS];
+        for (int k = 0; k < CRUX_NCOLS; ++k) one[k] = ptrs[k] ? (const char*)ptrs[k] + q * col_stride(b, k) : nullptr;
+        int32_t rc = crux_buffer_push_host(b, 1, one, nullptr); if (rc) return rc; }
+    } else { int32_t rc = crux_buffer_push_host(b, (int64_t)fill.size(), ptrs, nullptr); if (rc) return rc; }
+  }
+  b->total_count = total;
+  if (!repl.empty()) {
+    std::vector<int64_t> slot_src((size_t)b->capacity, -1); for (auto& pr : repl) slot_src[(size_t)pr.first] = pr.second;     // last assignment per slot wins
+    std::vector<int64_t> dst, src; for (int64_t sidx = 0; sidx < b->capacity; ++sidx) if (slot_src[(size_t)sidx] >= 0) { dst.push_back(sidx); src.push_back(slot_src[(size_t)sidx]); }
+    const size_t n = dst.size(); size_t maxst = 0; for (int k = 0; k < CRUX_NCOLS; ++k) if (has_col(b, k) && col_stride(b, k) > maxst) maxst = col_stride(b, k);
+    const size_t ib = ((8 * n + 255) / 256) * 256;
+    char* sc = (char*)crux_scratch(c, ib + maxst * n + 256); if (!sc) return crux_fail(c, CRUX_ENOMEM, "push_reservoir!: scratch");
+    HIPCHK(c, hipMemcpyAsync(sc, dst.data(), 8 * n, hipMemcpyHostToDevice, c->stream));
+    std::vector<char> host(maxst * n);
+    for (int k = 0; k < CRUX_NCOLS; ++k) { if (!has_col(b, k) || !cols[k]) continue; const size_t st = col_stride(b, k);
+      for (size_t q = 0; q < n; ++q) memcpy(host.data() + q * st, (const char*)cols[k] + (size_t)src[q] * st, st);
+      HIPCHK(c, hipMemcpyAsync(sc + ib, host.data(), st * n, hipMemcpyHostToDevice, c->stream));
+      launch_copy_rows(c, b->col[k], (const int64_t*)sc, sc + ib, nullptr, (int64_t)n, st);
+      HIPCHK(c, hipStreamSynchronize(c->stream)); }       // `host` is reused for the next column
+    int32_t rc = crux_launch_check(c, "push_reservoir!"); if (rc) return rc;
+  }
+  return CRUX_OK;
+}
+
 int32_t crux_buffer_push_buffer(crux_buffer* dst, const crux_buffer* src, const int64_t* ids, int64_t N, int64_t* I_out) {
   if (!dst || !src || N < 0) return CRUX_EINVAL;
   crux_ctx* c = dst->ctx;

@@ -27,7 +27,8 @@ enum {
   CRUX_RNG_SAMPLE = 5,     /* replay-buffer sampling                                         */
   CRUX_RNG_SHUFFLE = 6,    /* epoch permutations                                             */
   CRUX_RNG_INIT = 7,       /* glorot-uniform parameter init                                  */
-  CRUX_RNG_RANDACT = 8     /* the random action of an eps-greedy draw                        */
+  CRUX_RNG_RANDACT = 8,    /* the random action of an eps-greedy draw                        */
+  CRUX_RNG_RESERVOIR = 9   /* push_reservoir!: v[0..1] -> rand() of the weight test, v[2..3] -> rand(1:total_count) */
 };
 
 typedef struct { uint32_t v[4]; } crux_u32x4;

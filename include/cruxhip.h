@@ -130,6 +130,10 @@ int32_t crux_buffer_column_ptr(crux_buffer* b, int32_t key, void** d_ptr);
  * "data has no key k" (skipped, :238-241). Writes the destination indices I (0-based) if I_out.   */
 int32_t crux_buffer_push_host(crux_buffer* b, int64_t n, const void* const* cols /*CRUX_NCOLS*/,
                               int64_t* I_out);
+/* push_reservoir!(buffer, data; weighted) (src/experience_buffer.jl:262-288): reservoir sampling into a full buffer. Row i of this call draws
+ * x = Philox(seed, counter + i, 0, CRUX_RNG_RESERVOIR) (crux_rng.h): rand() of the weight test from x[0..1], rand(1:total_count) from x[2..3].
+ * Kept quirks: total_count grows by 2 per element while the buffer fills (:272 + push! :235); replaced slots keep their priorities.            */
+int32_t crux_buffer_push_reservoir(crux_buffer* b, int64_t N, const void* const* cols /* [CRUX_NCOLS] host, NULL = absent */, int32_t weighted, uint64_t seed, uint64_t counter);
 /* push!(target, source, ids=ids) (:232-259): device gather of rows `ids` (host array, 0-based; NULL
  * => 0..n-1) of `src` into the ring of `dst`.                                                     */
 int32_t crux_buffer_push_buffer(crux_buffer* dst, const crux_buffer* src, const int64_t* ids, int64_t n,

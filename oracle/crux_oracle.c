@@ -241,6 +241,33 @@ int32_t orc_buffer_push_host(orc_buffer* b, int64_t N, const void* const* cols, 
   free(I); return CRUX_OK;
 }
 
+/* push_reservoir!(buffer, data; weighted) (src/experience_buffer.jl:262-288), element by element:
+ *   weighted && haskey(:weight) && rand() > weight[i]  -> skip
+ *   total_count += 1; if length < capacity: push!(buffer, element)  (which adds 1 to total_count AGAIN, :235 -- reproduced)
+ *   else j = rand(1:total_count); j <= capacity -> every column's slot j is overwritten (priorities are NOT touched on this branch)
+ * Randomness (crux_rng.h): x = Philox(seed, counter + i, 0, RESERVOIR); rand() = f64(x0,x1); rand(1:n) = 1 + floor(u64(x2,x3) * n / 2^64). */
+int32_t orc_buffer_push_reservoir(orc_buffer* b, int64_t N, const void* const* cols, int32_t weighted, uint64_t seed, uint64_t counter) {
+  if (N < 0 || !cols) return CRUX_EINVAL;
+  const float* W = (weighted && (b->mask & (1u << CRUX_COL_WEIGHT)) && cols[CRUX_COL_WEIGHT]) ? (const float*)cols[CRUX_COL_WEIGHT] : NULL;
+  for (int64_t i = 0; i < N; ++i) {
+    crux_u32x4 x = crux_philox(seed, counter + (uint64_t)i, 0, CRUX_RNG_RESERVOIR);
+    if (W && crux_u32x2_to_f64(x.v[0], x.v[1]) > (double)W[i]) continue;
+    b->total_count += 1;
+    if (b->elements < b->capacity) {
+      const void* one[CRUX_NCOLS];
+      for (int k = 0; k < CRUX_NCOLS; ++k) one[k] = ((b->mask & (1u << k)) && cols[k]) ? (const char*)cols[k] + (size_t)i * col_stride(b, k) : NULL;
+      int32_t rc = orc_buffer_push_host(b, 1, one, NULL); if (rc) return rc;
+    } else {
+      const uint64_t r = ((uint64_t)x.v[2] << 32) | (uint64_t)x.v[3];
+      const int64_t j = 1 + (int64_t)(((unsigned __int128)r * (unsigned __int128)(uint64_t)b->total_count) >> 64);
+      if (j <= b->capacity)
+        for (int k = 0; k < CRUX_NCOLS; ++k) { if (!(b->mask & (1u << k)) || !cols[k]) continue; size_t st = col_stride(b, k);
+          memcpy((char*)b->col[k] + (size_t)(j - 1) * st, (const char*)cols[k] + (size_t)i * st, st); }
+    }
+  }
+  return CRUX_OK;
+}
+
 /* push!(target, source, ids=ids): v2 = collect(view(source, ids)) is materialised BEFORE the copy
  * (:249-252), which is what makes the self-push of test/experience_buffer_tests.jl:141-146 well defined. */
 int32_t orc_buffer_push_buffer(orc_buffer* dst, const orc_buffer* src, const int64_t* ids, int64_t N, int64_t* I_out) {

@@ -40,6 +40,7 @@ _SIG = {
     "orc_sac_target": (i32, [vp, vp, vp, vp, vp, f32, u64, u64, vp]), "orc_sac_temp_step": (i32, [vp, vp, vp, f32, u64, u64, vp]),
     "orc_double_q_step": (i32, [vp, vp, vp, vp, i32, vp]), "orc_sac_actor_step": (i32, [vp, vp, vp, vp, vp, u64, u64, vp]),
     "orc_dpg_target": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, u64, u64, vp]), "orc_q_step": (i32, [vp, vp, vp, i32, vp]), "orc_dpg_actor_step": (i32, [vp, vp, vp, vp]),
+    "orc_buffer_push_reservoir": (i32, [vp, i64, P(vp), i32, u64, u64]),
     "orc_gail_d_step": (i32, [vp, vp, i64, i64, vp, i64, i64, vp]), "orc_gail_reward": (i32, [vp, vp, f32, f32, vp]),
     "orc_linear_decay": (f64, [f64, f64, i64, i64]),
     "orc_perm": (None, [u64, u64, u32, vp]), "orc_philox": (None, [u64, u64, u32, u32, vp]),
@@ -146,6 +147,16 @@ class OBuffer:
                 a = np.asfortranarray(np.asarray(v).reshape(rows, N).astype(_np_dtype(k, self.act_kind))); keep.append(a); cols[L.COL[k]] = a.ctypes.data
         I = np.empty(N, np.int64)
         chk(lib().orc_buffer_push_host(self.h, N, cols, vpz(I))); return I + 1
+
+    def push_reservoir(self, data, weighted, seed, counter):
+        N = np.asarray(next(iter(data.values()))).shape[-1]
+        from crux_jl_amd.api import _np_dtype
+        cols = (vp * L.NCOLS)(); keep = []
+        for k, v in data.items():
+            if k in L.COL and self.haskey(k):
+                rows = self.obs_dim if k in ("s", "sp") else self.act_dim if k == "a" else 1
+                a = np.asfortranarray(np.asarray(v).reshape(rows, N).astype(_np_dtype(k, self.act_kind))); keep.append(a); cols[L.COL[k]] = a.ctypes.data
+        chk(lib().orc_buffer_push_reservoir(self.h, N, cols, 1 if weighted else 0, seed, counter))
 
     def push_buffer(self, src, ids=None):
         ids0 = None if ids is None else np.ascontiguousarray(np.asarray(ids, np.int64) - 1)

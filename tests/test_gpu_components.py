@@ -686,3 +686,29 @@ def test_synthetic_env_rollout_matches_oracle(gpu_ctx, case):
         assert np.abs(gb[k] - ob[k]).max() < 1e-5, k
     st_g, el_g, nr_g = smp.state(); st_o, el_o, nr_o = oe.state()
     assert np.array_equal(el_g, el_o) and np.array_equal(nr_g, nr_o) and np.abs(st_g - st_o).max() < 1e-9
+
+
+@pytest.mark.parametrize("weighted,prioritized", [(False, False), (True, False), (False, True)])
+def test_push_reservoir_matches_oracle(gpu_ctx, weighted, prioritized):
+    """push_reservoir! (src/experience_buffer.jl:262-288): fill phase through push!, then uniform replacement with rand(1:total_count); the weight test
+    skips rows; total_count grows by 2 per element while filling (kept quirk). Every column, the counters and the priorities vs the oracle, bit for bit."""
+    rng = np.random.default_rng(17); C_, od, na = 37, 3, 2
+    extras = ["weight"] if weighted else []
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.DiscreteSpace(na), C_, extras, prioritized=prioritized)
+    ob = O.OBuffer(od, na, L.ACTION_DISCRETE, C_, extras if not prioritized else ["weight"], prioritized=prioritized)
+    ctr = 0
+    for n in (5, 20, 30, 1, 64, 200):
+        d = _rand_data(rng, n, od, na, True)
+        if weighted:
+            d["weight"] = rng.random((1, n)).astype(np.float32)
+        gb.push_reservoir_(d, weighted=weighted, seed=99, counter=ctr); ob.push_reservoir(d, weighted, 99, ctr); ctr += n
+        assert len(gb) == len(ob) and gb.total_count == O.lib().orc_buffer_total_count(ob.h) and gb.next_ind == O.lib().orc_buffer_next_ind(ob.h) + 1
+        for k in gb.keys():
+            assert np.array_equal(gb[k], ob[k]), (n, k)
+    assert len(gb) == C_ and gb.total_count > C_
+    if prioritized:
+        pg = gb.priority_params()["priorities"]; po = np.empty(C_, np.float32); mx = C.c_float(); mn = C.c_float()
+        O.chk(O.lib().orc_per_get(ob.h, O.vpz(po), C.byref(mx), C.byref(mn), None))
+        assert np.array_equal(pg, po)
+    if not weighted:      # every row of a full buffer came from one of the pushed batches, and late batches did replace early rows
+        assert len(np.unique(gb["s"], axis=1)) > 1
