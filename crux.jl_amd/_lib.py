@@ -102,6 +102,8 @@ SIGNATURES = {
     "crux_rollout_multi": (i32, [i32, vp, vp, P(RolloutCfg), vp, i64, vp, vp]),
     "crux_policy_gradient_training_multi": (i32, [i32, vp, vp, vp, P(TrainCfg), P(TrainCfg), vp, vp]),
     "crux_policy_gradient_training_synced": (i32, [vp, vp, vp, P(TrainCfg), P(TrainCfg), i32, vp, vp]),
+    "crux_mlp_set_squash": (i32, [vp, f32]),
+    "crux_mlp_get_squash": (f32, [vp]),
     "crux_buffer_push_reservoir": (i32, [vp, i64, vp, i32, u64, u64]),
     "crux_buffer_shuffle": (i32, [vp, u64, u64]),
     "crux_gail_d_step": (i32, [vp, vp, i64, i64, vp, i64, i64, vp]),

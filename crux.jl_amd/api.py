@@ -266,6 +266,17 @@ class GaussianPolicy(NetworkPolicy):
         p = self.get_params(); p[-logSigma.size:] = logSigma; self.set_params(p)
 
 
+
+class SquashedGaussianPolicy(GaussianPolicy):
+    """SquashedGaussianPolicy(mu::ContinuousNetwork, logSigma::Array, ascale=1f0) (src/policies.jl:353-400): a = ascale*tanh(mu + sigma*eps),
+    sigma = exp(clamp(logSigma, -5, 2)), logpdf with the tanh correction; the constant-logSigma form the reference's examples use
+    (examples/rl/pendulum.jl:20, half_cheetah_mujoco.jl:42). Greedy action = ascale*tanh(mu(s)) (:372)."""
+
+    def __init__(self, mu_chain, logSigma, ascale=1.0, **kw):
+        super().__init__(mu_chain, logSigma, **kw)
+        self.ascale = float(np.float32(ascale))
+        self.ctx.check(self.ctx.lib.crux_mlp_set_squash(self.h, self.ascale))
+
 class ParamVector(NetworkPolicy):
     """A bare trainable vector with its own optimiser state (ConstantLayer, src/utils.jl:31-36; P[:SAC_log_alpha], sac.jl:96):
     the crux_mlp handle with n_layers = 0."""
@@ -339,7 +350,9 @@ def clone_policy(pi):
         return ActorCritic(clone_policy(pi.A), clone_policy(pi.C))
     if isinstance(pi, DoubleNetwork):
         return DoubleNetwork(clone_policy(pi.N1), clone_policy(pi.N2))
-    if isinstance(pi, GaussianPolicy):
+    if isinstance(pi, SquashedGaussianPolicy):
+        new = SquashedGaussianPolicy(pi.network, np.zeros(pi.n_extra, np.float32), pi.ascale, ctx=pi.ctx)
+    elif isinstance(pi, GaussianPolicy):
         new = GaussianPolicy(pi.network, np.zeros(pi.n_extra, np.float32), ctx=pi.ctx)
     elif isinstance(pi, DiscreteNetwork):
         new = DiscreteNetwork(pi.network, pi.outputs, ctx=pi.ctx)

@@ -70,6 +70,7 @@ struct crux_mlp {
   double* bp = nullptr; // device: [beta1^t, beta2^t]
   double eta = 0, b1 = 0, b2 = 0, eps = 0;
   bool has_adam = false;
+  float squash = 0.f;   // > 0: SquashedGaussianPolicy with this ascale (policies.jl:353-400) wherever the Gaussian head is used
   float* ws = nullptr;  // dense-engine workspace (dense.hip): cached activations 1..L + two delta buffers, capacity ws_B samples
   int64_t ws_B = 0;
 };
@@ -151,6 +152,13 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 int32_t crux_launch_check(crux_ctx* ctx, const char* what);
+// SquashedGaussianPolicy arithmetic shared by the rollout and learner kernels (policies.jl:374-396): sigma = exp(clamp(logSigma, -5, 2));
+// correction term of the un-tanh'd action u: 2(log 2 - u - softplus(-2u)), softplus(x) = log1p(exp(-|x|)) + relu(x) (NNlib);
+// logpdf(pi, s, a) un-tanh's the stored action as atanh(clamp(a / ascale, -1 + 1f-5, 1 - 1f-5)).
+__device__ __forceinline__ float sq_softplus(float x) { return log1pf(expf(-fabsf(x))) + (x > 0.f ? x : 0.f); }
+__device__ __forceinline__ float sq_corr(float u) { return 2.f * (logf(2.0f) - u - sq_softplus(-2.f * u)); }
+__device__ __forceinline__ float sq_clampls(float ls) { return ls < -5.f ? -5.f : ls > 2.f ? 2.f : ls; }
+__device__ __forceinline__ float sq_untanh(float a, float ascale) { float t = a / ascale; const float lo = -1.0f + 1.0e-5f, hi = 1.0f - 1.0e-5f; t = t < lo ? lo : t > hi ? hi : t; return atanhf(t); }
 struct crux_fwd_job { const float* p; const float* x; float* y; };
 int32_t crux_mlp_forward_multi_impl(crux_ctx* c, const NetDesc& nd, const crux_fwd_job* d_jobs, int n_jobs, int64_t B);   // mlp.hip
 int32_t crux_comm_allreduce_mean_impl(crux_ctx* c, crux_mlp* const* nets, int n_nets);   // comm.hip

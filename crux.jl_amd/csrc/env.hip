@@ -112,6 +112,7 @@ struct RolloutArgs {
   float* S; void* A; float* SP; float* R; uint8_t* D; uint8_t* EE; float* LP; int64_t* TT; int64_t* II; float* W; float* RET; float* ADV;
   int64_t base, C, T;
   crux_rollout_cfg cfg;
+  float squash;      // SquashedGaussianPolicy ascale, 0 = GaussianPolicy
 };
 
 // Everything of step! after the policy forward (sampler.jl:73-136): action + logprob from the head, env transition, column writes,
@@ -149,6 +150,14 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
         const float* ls = a.p + a.nd.xoff; float lp = 0.f;
         for (int q = 0; q < ad; ++q) {
           const float mu = z[q];
+          if (a.squash > 0.f) {                                                   // SquashedGaussianPolicy (policies.jl:372, 388-394)
+            if (a.cfg.explore) { const float sg = expf(sq_clampls(ls[q]));
+              const float epsn = randn_f32(a.seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)e, q & 1);
+              const float u = __fadd_rn(__fmul_rn(epsn, sg), mu); const float s2 = __fmul_rn(sg, sg); const float dd = __fsub_rn(u, mu);
+              aout[q] = __fmul_rn(a.squash, tanhf(u));
+              lp = __fadd_rn(lp, __fsub_rn(__fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(dd, dd), __fmul_rn(2.f, s2)), 0.9189385332046727f), ls[q]), sq_corr(u))); }
+            else aout[q] = __fmul_rn(a.squash, tanhf(mu));
+          } else
           if (a.cfg.explore) { const float sg = expf(ls[q]);
             const float epsn = randn_f32(a.seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)e, q & 1);
             aout[q] = __fadd_rn(__fmul_rn(epsn, sg), mu); const float s2 = __fmul_rn(sg, sg); const float dd = __fsub_rn(aout[q], mu);
@@ -387,7 +396,7 @@ static void fill_rollout_args(RolloutArgs& a, crux_env* e, crux_mlp* policy, con
   a.LP = has_col(buf, CRUX_COL_LOGPROB) ? (float*)buf->col[CRUX_COL_LOGPROB] : nullptr; a.TT = has_col(buf, CRUX_COL_T) ? (int64_t*)buf->col[CRUX_COL_T] : nullptr;
   a.II = has_col(buf, CRUX_COL_I) ? (int64_t*)buf->col[CRUX_COL_I] : nullptr; a.W = has_col(buf, CRUX_COL_WEIGHT) ? (float*)buf->col[CRUX_COL_WEIGHT] : nullptr;
   a.RET = has_col(buf, CRUX_COL_RETURN) ? (float*)buf->col[CRUX_COL_RETURN] : nullptr; a.ADV = has_col(buf, CRUX_COL_ADVANTAGE) ? (float*)buf->col[CRUX_COL_ADVANTAGE] : nullptr;
-  a.base = buf->next_ind; a.C = buf->capacity; a.T = T; a.cfg = *cfg;
+  a.base = buf->next_ind; a.C = buf->capacity; a.T = T; a.cfg = *cfg; a.squash = policy->squash;
 }
 
 extern "C" {

@@ -215,6 +215,13 @@ int32_t crux_adam_set_state(crux_mlp* n, const float* m, const float* v, const d
   return CRUX_OK;
 }
 
+int32_t crux_mlp_set_squash(crux_mlp* n, float ascale) {
+  if (!n) return CRUX_EINVAL;
+  if (!(ascale >= 0.f)) return crux_fail(n->ctx, CRUX_EINVAL, "SquashedGaussianPolicy: ascale must be >= 0 (0 = plain GaussianPolicy)");
+  n->squash = ascale; return CRUX_OK;
+}
+float crux_mlp_get_squash(const crux_mlp* n) { return n ? n->squash : 0.f; }
+
 int32_t crux_adam_state_ptrs(crux_mlp* n, float** d_m, float** d_v) { if (!n) return CRUX_EINVAL; if (d_m) *d_m = n->m; if (d_v) *d_v = n->v; return CRUX_OK; }
 
 int32_t crux_adam_apply(crux_mlp* n, float grad_scale) {

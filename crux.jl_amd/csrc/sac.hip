@@ -228,6 +228,7 @@ struct Carve { char* p; size_t off; template <class T> T* take(size_t n) { T* r 
 static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 static int32_t check_sac(crux_ctx* c, crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* la, crux_buffer* b, const char* who) {
+  if (actor && actor->squash > 0.f) return crux_fail(c, CRUX_EUNSUP, "%s: SquashedGaussianPolicy actors are implemented for the on-policy learners (PPO / A2C / REINFORCE / BC) only", who);
   const int od = b->obs_dim, ad = b->act_dim;
   if (b->elements < 1) return crux_fail(c, CRUX_EINVAL, "%s: empty batch", who);
   if (b->act_kind != CRUX_ACTION_CONTINUOUS) return crux_fail(c, CRUX_EINVAL, "%s: needs a continuous action column", who);

@@ -129,14 +129,16 @@ __global__ __launch_bounds__(256) void k_train_generic(TrainArgs a) {
                 dy[k] = invB * (-a.lambda_p * g * r * dlogpi - a.lambda_e * (pk * (hk - hp))); }
             } else {                                                              // GaussianPolicy policies.jl:333-348
               const float* av = (const float*)a.A + row * a.ad; const float* ls = a.p + nd.xoff;
-              for (int k = 0; k < a.ad; ++k) { const float sg = expf(ls[k]); const float d = av[k] - z[k];
-                newlp += (-(d * d) / (2.f * sg * sg) - 0.9189385332046727f - ls[k]); }
+              const float sq = a.squash;                                         // > 0: SquashedGaussianPolicy (policies.jl:374-396)
+              for (int k = 0; k < a.ad; ++k) { const float sg = expf(sq > 0.f ? sq_clampls(ls[k]) : ls[k]); const float uk = sq > 0.f ? sq_untanh(av[k], sq) : av[k]; const float d = uk - z[k];
+                newlp += (-(d * d) / (2.f * sg * sg) - 0.9189385332046727f - ls[k]); if (sq > 0.f) newlp -= sq_corr(uk); }
               r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A;
               g = (u <= cl) ? A : 0.f; s_lossp += (double)(a2c ? newlp * A : (u <= cl ? u : cl));
               if (a2c) { g = A; r = 1.f; }
-              for (int k = 0; k < a.ad; ++k) { const float sg = expf(ls[k]); const float s2 = sg * sg; const float d = av[k] - z[k];
+              for (int k = 0; k < a.ad; ++k) { const float sg = expf(sq > 0.f ? sq_clampls(ls[k]) : ls[k]); const float s2 = sg * sg; const float uk = sq > 0.f ? sq_untanh(av[k], sq) : av[k]; const float d = uk - z[k];
+                const float inr = (sq > 0.f && !(ls[k] >= -5.f && ls[k] <= 2.f)) ? 0.f : 1.f;    // d clamp/dx
                 dy[k] = invB * (-a.lambda_p * g * r * (d / s2));
-                exs[s * a.ad + k] = invB * (-a.lambda_p * g * r * ((d * d) / s2 - 1.f)); }
+                exs[s * a.ad + k] = invB * (-a.lambda_p * g * r * (((d * d) / s2) * inr - 1.f)); }
             }
             s_H += (double)H; s_kl += (double)(oldlp - newlp); s_adv += (double)A; if (a.RET) s_ret += (double)a.RET[row];
             if (!a2c && (r > hi || r < lo)) s_clip += 1.0;
@@ -236,7 +238,7 @@ static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const cr
   a.loss = internal_loss; a.head = cfg->head; a.bs = cfg->batch_size; a.epochs = cfg->epochs; a.max_batches = cfg->max_batches;
   a.eps_clip = cfg->eps_clip; a.lambda_p = cfg->lambda_p; a.lambda_e = cfg->lambda_e; a.target_kl = cfg->target_kl;
   a.shuffle_seed = cfg->shuffle_seed; a.shuffle_counter = cfg->shuffle_counter;
-  a.len = buf->elements; a.order_a = buf->order_a; a.order_b = buf->order_b; a.apply = 1;
+  a.len = buf->elements; a.order_a = buf->order_a; a.order_b = buf->order_b; a.apply = 1; a.squash = net->squash;
   const int nout = net->nd.dims[net->nd.L];
   if (internal_loss == CRUX_LOSS_LOGPDF_BC) {   // logpdf_bc_loss (il/bc.jl:10-18) = a2c_loss with advantage == 1, lambda_p = 1 and old logprob == 0 (so "kl" = -mean(logpdf))
     if (!buf->aux_ones) {
@@ -258,6 +260,8 @@ static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const cr
     else return crux_fail(c, CRUX_EINVAL, "ppo_loss: head %d unsupported", cfg->head);
   } else if (internal_loss == CRUX_LOSS_VALUE_MSE) {
     if (!a.RET || nout != 1) return crux_fail(c, CRUX_EINVAL, "critic mse: needs a :return column and a scalar-output network");
+  } else if (internal_loss == CRUX_LOSS_MSE_ACTION && net->squash > 0.f) {
+    return crux_fail(c, CRUX_EUNSUP, "mse_action_loss through a SquashedGaussianPolicy (ascale*tanh(mu)) is not implemented");
   } else if (internal_loss == CRUX_LOSS_MSE_ACTION) {
     if (buf->act_kind != CRUX_ACTION_CONTINUOUS || nout != buf->act_dim) return crux_fail(c, CRUX_EINVAL, "mse_action_loss: needs a continuous action column of %d rows", nout);
   }

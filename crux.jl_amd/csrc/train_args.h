@@ -28,6 +28,7 @@ struct TrainArgs {
   float* epoch_infos;        // device [epochs x CRUX_INFO_N]
   int32_t* status;           // device [4]: err, batches_trained, epochs_run, final order selector
   unsigned long long* dbg;   // optional phase-timing output (CRUX_MFMA_TIMING)
+  float squash;              // SquashedGaussianPolicy ascale (0 = GaussianPolicy): actions are un-tanh'd, sigma uses clamp(logSigma, -5, 2), logpdf carries the tanh correction
   float* xbuf; unsigned* xctr;   // two-CU kernel (train_mfma_x2.hip): gradient exchange slots [parity][workgroup] and {arrival counter, abort flag}
 };
 

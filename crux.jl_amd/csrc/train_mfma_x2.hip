@@ -206,6 +206,13 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
       for (int k = 0; k < OUT; ++k) ai = p_abyte[k] ? k : ai;
       p_act[0] = (float)ai; }
     if (lane < 16) { float* q = sc + lane * Lt::SCW; q[0] = (float)p_valid; q[1] = p_lp; q[2] = p_adv; q[3] = p_ret;
+      if (KIND == MFK_GAUSSIAN) {       // SquashedGaussianPolicy: the stored action is un-tanh'd once here and the tanh correction of logpdf rides in the spare slot
+        static_assert(KIND != MFK_GAUSSIAN || ((4 + NACT) % 2 == 0), "the staging row needs its spare slot");
+        float corr = 0.f;
+        if (a.squash > 0.f) {
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) { const float u = p_valid ? sq_untanh(p_act[k], a.squash) : 0.f; corr += p_valid ? sq_corr(u) : 0.f; p_act[k] = u; } }
+        q[4 + NACT] = corr; }
 #pragma unroll
       for (int k = 0; k < NACT; ++k) q[4 + k] = p_act[k]; }
     wave_sync();
@@ -317,14 +324,18 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
           s_clip = cnt * clipv;
         } else {   // gaussian with constant log-std (policies.jl:333-348)
           float newlp = 0.f; float dd[OUT], s2[OUT];
+          float inr[OUT];
 #pragma unroll
-          for (int k = 0; k < OUT; ++k) { const float ls = sm[Lt::oEX + k]; s2[k] = __expf(-2.f * ls); dd[k] = q[4 + k] - z[k];   // s2 = 1/sigma^2 through v_exp_f32 (1 ulp)
+          for (int k = 0; k < OUT; ++k) { const float ls = sm[Lt::oEX + k]; const bool sq = a.squash > 0.f;
+            s2[k] = __expf(-2.f * (sq ? sq_clampls(ls) : ls)); dd[k] = q[4 + k] - z[k];   // s2 = 1/sigma^2 through v_exp_f32 (1 ulp); squashed: sigma = exp(clamp(logSigma, -5, 2))
+            inr[k] = (sq && !(ls >= -5.f && ls <= 2.f)) ? 0.f : 1.f;
             newlp += (-(dd[k] * dd[k]) * (0.5f * s2[k]) - 0.9189385332046727f - ls); }
+          if (a.squash > 0.f) newlp -= q[4 + NACT];
           const float r = __expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
           const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;   // a2c_loss (a2c.jl:4-15): -mean(logpdf .* A)
 #pragma unroll
           for (int k = 0; k < OUT; ++k) { dz[k] = valid ? invB * (-a.lambda_p * coef * (dd[k] * s2[k])) : 0.f;
-            dex[k] = valid ? invB * (-a.lambda_p * coef * ((dd[k] * dd[k]) * s2[k] - 1.f)) : 0.f; }
+            dex[k] = valid ? invB * (-a.lambda_p * coef * (((dd[k] * dd[k]) * s2[k]) * inr[k] - 1.f)) : 0.f; }
           s_lossp = cnt * lterm; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R; s_clip = cnt * clipv;
         }
       }

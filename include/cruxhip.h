@@ -92,6 +92,11 @@ int32_t crux_mlp_forward_host(crux_mlp* net, const float* x, int64_t B, float* y
 int32_t crux_mlp_forward_cached(crux_mlp* net, const float* d_x, int64_t B, float* d_y /* NULL = keep internal only */);
 int32_t crux_mlp_backward(crux_mlp* net, const float* d_x, int64_t B, const float* d_dy, float grad_scale,
                           int32_t want_param_grads, float* d_dx);
+/* SquashedGaussianPolicy(mu, logSigma::Array, ascale) (src/policies.jl:353-400): ascale > 0 switches the Gaussian head of this handle (rollout and
+ * the policy-gradient / BC learners) to a = ascale*tanh(mu + sigma*eps), sigma = exp(clamp(logSigma, -5, 2)), logpdf with the tanh correction and
+ * atanh(clamp(a/ascale, -1+1f-5, 1-1f-5)) for stored actions; entropy stays 1.4189385 + sum(logSigma) (:398). ascale = 0 restores GaussianPolicy. */
+int32_t crux_mlp_set_squash(crux_mlp* net, float ascale);
+float crux_mlp_get_squash(const crux_mlp* net);
 /* copyto!(to, from) (src/policies.jl:61-65) and polyak_average!(to, from, tau) (:48-59).         */
 int32_t crux_mlp_copy(crux_mlp* to, const crux_mlp* from);
 int32_t crux_polyak(crux_mlp* to, const crux_mlp* from, float tau);

@@ -25,6 +25,7 @@ struct orc_mlp {
   float *p, *g, *m, *v;
   double eta, b1, b2, eps, bp[2];
   int has_adam;
+  float squash;      /* > 0: SquashedGaussianPolicy with this ascale (policies.jl:353-400) instead of GaussianPolicy */
 };
 
 static int64_t woff(const orc_mlp* n, int l) { int64_t o = 0; for (int i = 0; i < l; ++i) o += (int64_t)n->dims[i + 1] * n->dims[i] + n->dims[i + 1]; return o; }
@@ -42,6 +43,14 @@ orc_mlp* orc_mlp_create(int32_t n_layers, const int32_t* dims, const int32_t* ac
   n->m = (float*)calloc(n->n_params, 4); n->v = (float*)calloc(n->n_params, 4);
   return n;
 }
+int32_t orc_mlp_set_squash(orc_mlp* n, float ascale) { if (!n || !(ascale >= 0.f)) return CRUX_EINVAL; n->squash = ascale; return CRUX_OK; }
+/* SquashedGaussianPolicy arithmetic (policies.jl:374-396): sigma = exp(clamp(logSigma, -5, 2)); for the un-tanh'd action u
+ *   logprob = sum_d[-(u-mu)^2/(2 sigma^2) - 0.9189385 - logSigma - 2(log 2 - u - softplus(-2u))],  softplus(x) = log1p(exp(-|x|)) + relu(x) (NNlib)
+ * logpdf(pi, s, a) uses u = atanh(clamp(a/ascale, -1+1f-5, 1-1f-5)) (:396). */
+static float sq_softplus(float x) { return log1pf(expf(-fabsf(x))) + (x > 0.f ? x : 0.f); }
+static float sq_corr(float u) { return 2.f * (logf(2.0f) - u - sq_softplus(-2.f * u)); }
+static float sq_clampls(float ls) { return ls < -5.f ? -5.f : ls > 2.f ? 2.f : ls; }
+static float sq_untanh(float a, float ascale) { float t = a / ascale; float lo = -1.0f + 1.0e-5f, hi = 1.0f - 1.0e-5f; t = t < lo ? lo : t > hi ? hi : t; return atanhf(t); }
 void orc_mlp_destroy(orc_mlp* n) { if (!n) return; free(n->p); free(n->g); free(n->m); free(n->v); free(n); }
 int64_t orc_mlp_n_params(const orc_mlp* n) { return n->n_params; }
 float* orc_mlp_params(orc_mlp* n) { return n->p; }
@@ -652,6 +661,12 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
         const float* ls = pol->p + xoff(pol); float lp = 0.f;
         for (int q = 0; q < ad; ++q) {
           float mu = z[q];
+          if (pol->squash > 0.f) {                                                              /* SquashedGaussianPolicy policies.jl:372,388-394 */
+            if (cfg->explore) { float sg = expf(sq_clampls(ls[q])); float epsn = randn_f32(e->seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)k, q & 1);
+              float u = epsn * sg + mu; float s2 = sg * sg; float dd = u - mu; aout[q] = pol->squash * tanhf(u);
+              lp = lp + (((-(dd * dd) / (2.f * s2) - 0.9189385332046727f) - ls[q]) - sq_corr(u)); }
+            else aout[q] = pol->squash * tanhf(mu);
+          } else
           if (cfg->explore) { float sg = expf(ls[q]); float epsn = randn_f32(e->seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)k, q & 1);
             aout[q] = epsn * sg + mu; float s2 = sg * sg; float dd = aout[q] - mu; lp = lp + (-(dd * dd) / (2.f * s2) - 0.9189385332046727f - ls[q]); }
           else aout[q] = mu;
@@ -831,9 +846,11 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
       } else {                                                                   /* GaussianPolicy policies.jl:333-348 */
         if (nout != ad || net->n_extra != ad) { cc_free(net, &c); return CRUX_EINVAL; }
         const float* a = (const float*)buf->col[CRUX_COL_A] + (size_t)id * ad;
-        newlp = 0.f;
-        for (int k = 0; k < ad; ++k) { float sg = expf(ls[k]); float s2 = sg * sg; float d = a[k] - z[k];
-          newlp = newlp + (-(d * d) / (2.f * s2) - 0.9189385332046727f - ls[k]); }
+        newlp = 0.f; const float sq = net->squash; float ua[64];
+        for (int k = 0; k < ad; ++k) { ua[k] = sq > 0.f ? sq_untanh(a[k], sq) : a[k];
+          float sg = expf(sq > 0.f ? sq_clampls(ls[k]) : ls[k]); float s2 = sg * sg; float d = ua[k] - z[k];
+          newlp = newlp + (-(d * d) / (2.f * s2) - 0.9189385332046727f - ls[k]);
+          if (sq > 0.f) newlp = newlp - sq_corr(ua[k]); }
         float r = expf(newlp - oldlp), u = r * A, rc = r < lo ? lo : r > hi ? hi : r, cl = rc * A;
         float g = (u <= cl) ? A : 0.f;
         float coef = g * r, lterm = (u <= cl ? u : cl), lp_ = cfg->lambda_p;
@@ -841,9 +858,10 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
         else if (bc) { coef = 1.f; lterm = newlp; lp_ = 1.f; }
         else if (cfg->loss == CRUX_LOSS_REINFORCE) { coef = RET[id]; lterm = newlp * RET[id]; lp_ = 1.f; }
         sum_loss_p += (double)lterm;
-        for (int k = 0; k < ad; ++k) { float sg = expf(ls[k]); float s2 = sg * sg; float d = a[k] - z[k];
+        for (int k = 0; k < ad; ++k) { float sg = expf(sq > 0.f ? sq_clampls(ls[k]) : ls[k]); float s2 = sg * sg; float d = ua[k] - z[k];
+          float inr = (sq > 0.f && !(ls[k] >= -5.f && ls[k] <= 2.f)) ? 0.f : 1.f;               /* d clamp(x, lo, hi)/dx = 1 inside [lo, hi], 0 outside (ChainRules) */
           dy[k] = invB * (-lp_ * coef * (d / s2));
-          gx[k] += invB * (-lp_ * coef * ((d * d) / s2 - 1.f)); }
+          gx[k] += invB * (-lp_ * coef * (((d * d) / s2) * inr - 1.f)); }
         if (cfg->loss == CRUX_LOSS_PPO && (r > hi || r < lo)) ++nclip;
       }
       sum_H += (double)H; sum_kl += (double)(oldlp - newlp); sum_adv += (double)A; if (RET) sum_ret += (double)RET[id];

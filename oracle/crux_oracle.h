@@ -117,6 +117,7 @@ int32_t orc_sac_actor_step(orc_mlp* actor, orc_mlp* q1, orc_mlp* q2, orc_mlp* lo
 int32_t orc_dpg_target(orc_mlp* actor_targ, orc_mlp* q1_targ, orc_mlp* q2_targ, orc_buffer* batch, float gamma, float sigma, float eps_min, float eps_max, float a_min, float a_max,
                        uint64_t seed, uint64_t counter, float* y);
 int32_t orc_buffer_push_reservoir(orc_buffer* b, int64_t N, const void* const* cols, int32_t weighted, uint64_t seed, uint64_t counter);
+int32_t orc_mlp_set_squash(orc_mlp* n, float ascale);
 int32_t orc_gail_d_step(orc_mlp* D, orc_buffer* ex, int64_t off_ex, int64_t n_ex, orc_buffer* pi, int64_t off_pi, int64_t n_pi, float* info);
 int32_t orc_gail_reward(orc_mlp* D, orc_buffer* b, float alpha_r, float rscale, float* mean_r);
 int32_t orc_q_step(orc_mlp* q, orc_buffer* batch, const float* y, int32_t use_weight, float* info_out);

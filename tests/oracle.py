@@ -40,6 +40,7 @@ _SIG = {
     "orc_sac_target": (i32, [vp, vp, vp, vp, vp, f32, u64, u64, vp]), "orc_sac_temp_step": (i32, [vp, vp, vp, f32, u64, u64, vp]),
     "orc_double_q_step": (i32, [vp, vp, vp, vp, i32, vp]), "orc_sac_actor_step": (i32, [vp, vp, vp, vp, vp, u64, u64, vp]),
     "orc_dpg_target": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, u64, u64, vp]), "orc_q_step": (i32, [vp, vp, vp, i32, vp]), "orc_dpg_actor_step": (i32, [vp, vp, vp, vp]),
+    "orc_mlp_set_squash": (i32, [vp, f32]),
     "orc_buffer_push_reservoir": (i32, [vp, i64, P(vp), i32, u64, u64]),
     "orc_gail_d_step": (i32, [vp, vp, i64, i64, vp, i64, i64, vp]), "orc_gail_reward": (i32, [vp, vp, f32, f32, vp]),
     "orc_linear_decay": (f64, [f64, f64, i64, i64]),

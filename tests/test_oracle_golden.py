@@ -501,3 +501,54 @@ def test_gail_discriminator_loss_and_reward_vs_float64_autograd(disc):
     z = torch.tensor(o.forward(np.vstack([dpi["a"].astype(np.float32), dpi["s"]]))[0].astype(np.float64))
     ls = torch.nn.functional.logsigmoid(z); r = 0.3 * ls - 0.7 * (ls - z)
     assert np.abs(bpi["r"][0] - 2.0 * r.numpy()).max() < 1e-5 and abs(m[0] - r.mean().item()) < 1e-5
+
+
+@pytest.mark.parametrize("loss", ["ppo", "a2c"])
+def test_squashed_gaussian_gradient_vs_float64_autograd(loss):
+    """SquashedGaussianPolicy (policies.jl:353-400) in the oracle's policy-gradient losses vs torch float64 autograd of the reference formulas:
+    logpdf(pi, s, a) = squashed_gaussian_logprob(mu(s), logSigma, atanh(clamp(a/ascale, -1+1f-5, 1-1f-5))), sigma = exp(clamp(logSigma, -5, 2)).
+    One log-std sits outside the clamp range so that its zero derivative through clamp is exercised."""
+    rng = np.random.default_rng(31); n, ad, asc = 40, 3, 2.0; dims, acts = [4, 16, 16, ad], ["tanh", "relu", "identity"]
+    o = O.OMlp(dims, acts, ad).init_glorot(9, 0, -0.3); o.params[:] += 0.05 * rng.standard_normal(o.n).astype(np.float32)
+    o.params[-ad:] = np.array([-0.3, 2.5, -1.0], np.float32)                       # 2.5 > LOG_STD_MAX
+    O.chk(lib.orc_mlp_set_squash(o.h, asc))
+    ob = O.OBuffer(4, ad, L.ACTION_CONTINUOUS, n, ["return", "logprob", "advantage"])
+    d = _fill(ob, n, rng, L.ACTION_CONTINUOUS, ad)
+    a_sq = (asc * np.tanh(rng.normal(0, 1.2, (ad, n)))).astype(np.float32); a_sq[0, 0] = asc        # one action exactly on the bound (clamped before atanh)
+    d["a"] = a_sq; ob2 = O.OBuffer(4, ad, L.ACTION_CONTINUOUS, n, ["return", "logprob", "advantage"]); ob2.push(d)
+    ids = np.arange(n, dtype=np.int64); info = np.zeros(L.INFO_N, np.float32); cfg = _cfg(loss, "gaussian", lp=0.8, le=0.05)
+    O.chk(lib.orc_loss_grad(o.h, ob2.h, C.byref(cfg), O.vpz(ids), n, O.vpz(info)))
+    p = _torch_net(o); mu, off = _fwd(p, dims, acts, torch.tensor(d["s"], dtype=torch.float64)); ls = p[off:off + ad]
+    t = torch.clamp(torch.tensor((d["a"] / np.float32(asc)).astype(np.float64)), float(np.float32(-1.0) + np.float32(1e-5)), float(np.float32(1.0) - np.float32(1e-5)))
+    u = torch.atanh(t); s2 = torch.exp(torch.clamp(ls, -5.0, 2.0)) ** 2
+    corr = 2 * (float(np.log(2.0)) - u - torch.nn.functional.softplus(-2 * u))
+    newlp = (-((u - mu) ** 2) / (2 * s2[:, None]) - 0.9189385332046727 - ls[:, None] - corr).sum(0)
+    A = torch.tensor(d["advantage"][0], dtype=torch.float64); old = torch.tensor(d["logprob"][0], dtype=torch.float64)
+    ent = 1.4189385332046727 + ls.sum()
+    if loss == "ppo":
+        r = torch.exp(newlp - old); pl = -torch.minimum(r * A, torch.clamp(r, 0.8, 1.2) * A).mean()
+    else:
+        pl = -(newlp * A).mean()
+    total = 0.8 * pl + 0.05 * (-ent); total.backward()
+    assert abs(info[0] - total.item()) < 2e-5 * max(1, abs(total.item()))
+    g = p.grad.numpy(); assert np.abs(o.grads - g).max() < 5e-6 * max(1, np.abs(g).max())
+    assert abs(info[L.INFO["kl"]] - (old - newlp).mean().item()) < 2e-5 and abs(info[L.INFO["entropy"]] - ent.item()) < 1e-6
+
+
+def test_squashed_gaussian_exploration_is_consistent_with_logpdf():
+    """test/policy_tests.jl:305-308: `a, logprob = exploration(p, s); logpdf(p, s, a) ≈ logprob` for SquashedGaussianPolicy, through the oracle's rollout
+    (a = ascale*tanh(mu + sigma*eps), logprob on the un-tanh'd action) and its learner head (which un-tanh's the stored action again); actions stay inside ±ascale."""
+    E, T, asc = 4, 40, 2.0
+    oa = O.OMlp([3, 64, 64, 1], ["relu", "relu", "identity"], 1).init_glorot(3, 0, -0.5); O.chk(lib.orc_mlp_set_squash(oa.h, asc))
+    ob = O.OBuffer(3, 1, L.ACTION_CONTINUOUS, E * T, ["return", "logprob", "advantage"])
+    oe = O.OEnv("pendulum", E, 30, 0.99, 5)
+    import parity
+    oe.rollout(oa, parity.rollout_cfg(True, True, "gaussian"), ob, T)
+    a, lp = ob["a"], ob["logprob"][0]
+    assert np.abs(a).max() <= asc and np.abs(a).max() > 0.5 and np.isfinite(lp).all()
+    # learner-side logpdf of the stored (s, a): PPO ratio r = exp(new - old) must be ~1 and kl ~0 with unchanged parameters
+    cfg = _cfg("ppo", "gaussian"); ids = np.arange(E * T, dtype=np.int64); info = np.zeros(L.INFO_N, np.float32)
+    ob.col("advantage")[...] = 1.0
+    O.chk(lib.orc_loss_grad(oa.h, ob.h, C.byref(cfg), O.vpz(ids), E * T, O.vpz(info)))
+    inner = np.abs(a[0]) < asc * (1 - 1e-3)                     # where the clamp before atanh is inactive, atanh(tanh(u)) returns u up to float rounding
+    assert inner.mean() > 0.8 and abs(info[L.INFO["kl"]]) < 5e-3 and info[L.INFO["clip_fraction"]] < 0.05
