@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcruxhip.so")
+LIB_PATH = os.environ.get("CRUXHIP_LIB") or os.path.join(_HERE, "libcruxhip.so")   # CRUXHIP_LIB: an alternative build of the same ABI (compiler-flag experiments)
 
 i32, i64, u32, u64, f32, f64, vp, cp = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double, C.c_void_p, C.c_char_p
 P = C.POINTER
