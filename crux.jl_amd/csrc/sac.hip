@@ -62,11 +62,15 @@ __global__ void k_slice_rows(const float* __restrict__ src, int ld, int off, int
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= B * rows) return;
   const int64_t j = i / rows; const int r = (int)(i - j * rows); dst[i] = src[off + r + (int64_t)ld * j];
 }
+#define SUMSQ_BLOCKS 64
+// out[0] = the 64 partials added in block order. Called by thread 0 of the single-block info kernel that follows k_sumsq2 in every step sequence
+// (stream order makes the partials visible): the earlier "last block to arrive combines" form needed two device-scope fences and took 11 us.
+__device__ __forceinline__ void ssq_finalize(const double* ssq_c) { double* ssq = const_cast<double*>(ssq_c); double t = 0; for (int k = 0; k < SUMSQ_BLOCKS; ++k) t += ssq[1 + k]; ssq[0] = t; }
 __global__ void k_mean_info(const float* __restrict__ q, int64_t B, float sign, const double* __restrict__ ssq, float* __restrict__ dinfo) {   // single thread block of 256
   __shared__ double red[4];
   double s = 0; for (int64_t j = threadIdx.x; j < B; j += 256) s += (double)q[j];
   s = wave_sum_d(s); __syncthreads(); if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s; __syncthreads();
-  if (threadIdx.x == 0) { dinfo[CRUX_INFO_LOSS] = sign * (float)((((red[0] + red[1]) + red[2]) + red[3]) / (double)B); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]); }
+  if (threadIdx.x == 0) { ssq_finalize(ssq); dinfo[CRUX_INFO_LOSS] = sign * (float)((((red[0] + red[1]) + red[2]) + red[3]) / (double)B); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]); }
 }
 
 // deterministic single-block reductions (256 threads; double accumulators like the oracle)
@@ -110,25 +114,23 @@ __global__ __launch_bounds__(256) void k_td_head(const float* __restrict__ z, co
   if (threadIdx.x == 0) { stats[0] = sl; stats[1] = sq; }
 }
 __global__ void k_td_info(const double* __restrict__ st, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) {
+  ssq_finalize(ssq);
   dinfo[CRUX_INFO_LOSS] = (float)(st[0] / (double)B); dinfo[2] = (float)(st[1] / (double)B); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
 }
 // sum of squares of up to two flat gradients (norm(grads), utils.jl:49-55: sqrt of the sum of per-tensor squared norms): 64 blocks of partial
 // sums, combined in block order by the last block to arrive (deterministic: the combine order is fixed, only who performs it varies)
-#define SUMSQ_BLOCKS 64
-__global__ __launch_bounds__(256) void k_sumsq2(const float* __restrict__ g1, int64_t n1, const float* __restrict__ g2, int64_t n2, double* __restrict__ out /* [0] result, [1..64] partials, [65] ticket */) {
-  __shared__ double red[4]; __shared__ int last;
+__global__ __launch_bounds__(256) void k_sumsq2(const float* __restrict__ g1, int64_t n1, const float* __restrict__ g2, int64_t n2, double* __restrict__ out /* [1..64] per-block partials; [0] is filled by ssq_finalize */) {
+  __shared__ double red[4];
   double s = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n1; i += (int64_t)SUMSQ_BLOCKS * 256) s += (double)g1[i] * (double)g1[i];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)SUMSQ_BLOCKS * 256) s += (double)g2[i] * (double)g2[i];
   s = wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) { out[1 + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3]; __threadfence();
-    last = atomicAdd((unsigned int*)&out[1 + SUMSQ_BLOCKS], 1u) == SUMSQ_BLOCKS - 1; }
-  __syncthreads();
-  if (last && threadIdx.x == 0) { __threadfence(); double t = 0; for (int k = 0; k < SUMSQ_BLOCKS; ++k) t += ((volatile double*)out)[1 + k]; out[0] = t; ((volatile unsigned int*)&out[1 + SUMSQ_BLOCKS])[0] = 0u; }
+  if (threadIdx.x == 0) out[1 + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 __global__ void k_critic_info(const double* __restrict__ st1, const double* __restrict__ st2, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) {
+  ssq_finalize(ssq);
   dinfo[CRUX_INFO_LOSS] = (float)(0.5 * (st1[0] / (double)B) + 0.5 * (st2[0] / (double)B));
   dinfo[CRUX_INFO_Q1AVG] = (float)(st1[1] / (double)B); dinfo[CRUX_INFO_Q2AVG] = (float)(st2[1] / (double)B);
   dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(256) void k_rowsum(const float* __restrict__ v, int
   if (threadIdx.x == 0) out[d] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 __global__ void k_actor_info(const double* __restrict__ st, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) {
+  ssq_finalize(ssq);
   dinfo[CRUX_INFO_LOSS] = (float)(st[0] / (double)B); dinfo[CRUX_INFO_ENTROPY] = (float)(-(st[1] / (double)B)); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
 }
 // Flux.update!(Adam) gated on the gradient norm: NaN => parameters untouched, status set (training.jl:20)
@@ -204,6 +207,7 @@ __global__ __launch_bounds__(256) void k_gail_head(const float* __restrict__ z, 
   if (threadIdx.x == 0) { stats[0] = le; stats[1] = lp; }
 }
 __global__ void k_gail_info(const double* __restrict__ st, const double* __restrict__ ssq, int64_t n_ex, int64_t n_pi, float* __restrict__ dinfo) {
+  ssq_finalize(ssq);
   dinfo[CRUX_INFO_LOSS] = (float)(st[0] / (double)n_ex) + (float)(st[1] / (double)n_pi); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
 }
 __global__ __launch_bounds__(256) void k_gail_reward(const float* __restrict__ z, int64_t n, float alpha_r, float rscale, float* __restrict__ r, double* __restrict__ partial) {
