@@ -43,7 +43,8 @@ typedef struct crux_env crux_env;
 int32_t crux_ctx_create(int32_t device_id, void* stream, crux_ctx** out);
 int32_t crux_ctx_destroy(crux_ctx* ctx);
 /* How many CUs one small-MLP learner (batch_train!, src/training.jl:28-55) occupies: 0 = automatic (two CUs of one XCD per learner; the batched
- * multi-learner call switches to one CU per learner above 64 learners), 1 = always one CU (k_train_mfma8), 2 = two CUs where the shape allows.
+ * multi-learner call switches to one CU per learner above 64 learners), 1 = always one CU (k_train_mfma8), 2 = two CUs where the shape allows
+ * (populations above 64 always take the one-CU form: two launches x 2 n workgroups would not be co-resident).
  * The two kernels sum the minibatch gradient in different orders: results agree to fp32 tolerance, bitwise only for equal settings.              */
 int32_t crux_ctx_set_learner_cus(crux_ctx* ctx, int32_t cus);
 const char* crux_last_error(crux_ctx* ctx);
