@@ -154,6 +154,19 @@ function policy_gradient_training_synced(𝒮::Crux.OnPolicySolver, 𝒟::HipBuf
     Dict("actor_loss" => ia[1], "actor_grad_norm" => ia[2], :kl => ia[4], :entropy => ia[3], "critic_loss" => ic[1], "critic_grad_norm" => ic[2])
 end
 
+# --- SquashedGaussianPolicy, reservoir pushes, GAIL pieces: thin wrappers over the same handles
+set_squash!(π::HipNetwork, ascale::Real) = check(π.ctx, ccall((:crux_mlp_set_squash, LIB), Int32, (Ptr{Cvoid}, Float32), π.h, Float32(ascale)))   # SquashedGaussianPolicy(μ, logΣ, ascale) (policies.jl:353-400)
+function Crux.push_reservoir!(b::HipBuffer, data::Dict{Symbol,<:AbstractArray}; weighted=false, seed=0, counter=0)                                # experience_buffer.jl:262-288
+    cols = fill(C_NULL, NCOLS); keep = Any[]
+    for (k, v) in data; haskey(COL, k) || continue; a = Array(v); push!(keep, a); cols[COL[k] + 1] = pointer(a); end
+    GC.@preserve keep check(b.ctx, ccall((:crux_buffer_push_reservoir, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}, Int32, UInt64, UInt64),
+                                         b.h, size(first(values(data)), 2), cols, weighted, seed, counter))
+end
+gail_d_step!(D::HipNetwork, ex::HipBuffer, r_ex::UnitRange, pol::HipBuffer, r_pol::UnitRange, info=zeros(Float32, INFO_N)) =                     # il/on_policy_gail.jl:1-5 under training.jl:40-44
+    (check(D.ctx, ccall((:crux_gail_d_step, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Float32}),
+                        D.h, ex.h, first(r_ex) - 1, length(r_ex), pol.h, first(r_pol) - 1, length(r_pol), info)); info)
+gail_reward!(D::HipNetwork, 𝒟::HipBuffer; αr=0.5f0, Rscale=1f0) = (m = Ref{Float32}(0); check(D.ctx, ccall((:crux_gail_reward, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Ref{Float32}), D.h, 𝒟.h, αr, Rscale, m)); m[])   # :50-55
+
 # off-policy seams (value_training, src/model_free/off_policy.jl:66-111) follow the same pattern:
 #   dqn_target  -> :crux_dqn_target      td_error -> :crux_td_error        train!(critic, td_loss)        -> :crux_td_step / :crux_q_step
 #   sac_target  -> :crux_sac_target      sac_temp_loss -> :crux_sac_temp_step    double_Q_loss -> :crux_double_q_step    sac_actor_loss -> :crux_sac_actor_step
