@@ -39,6 +39,7 @@ struct TrainCfg
 end
 @assert sizeof(RolloutCfg) == 72 && sizeof(TrainCfg) == 64
 
+const NCOLS = 13   # CRUX_NCOLS (cruxhip.h)
 const COL = Dict(:s => 0, :a => 1, :sp => 2, :r => 3, :done => 4, :episode_end => 5, :return => 6, :logprob => 7, :advantage => 8, :weight => 9, :t => 10, :i => 11, :value => 12)
 const HEAD_CATEGORICAL, HEAD_GAUSSIAN, HEAD_GREEDY_Q, HEAD_DETERMINISTIC = Int32(0), Int32(1), Int32(2), Int32(3)
 const LOSS_PPO, LOSS_VALUE_MSE, LOSS_A2C, LOSS_REINFORCE, LOSS_LOGPDF_BC, LOSS_MSE_ACTION = Int32(0), Int32(1), Int32(3), Int32(4), Int32(5), Int32(6)
