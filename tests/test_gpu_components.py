@@ -712,3 +712,52 @@ def test_push_reservoir_matches_oracle(gpu_ctx, weighted, prioritized):
         assert np.array_equal(pg, po)
     if not weighted:      # every row of a full buffer came from one of the pushed batches, and late batches did replace early rows
         assert len(np.unique(gb["s"], axis=1)) > 1
+
+
+def test_error_paths_of_the_newer_entries(gpu_ctx):
+    """Argument checks fail loudly with the documented status codes: synced training refuses early stopping, a context takes one communicator,
+    SquashedGaussianPolicy rejects a negative ascale and is refused by the SAC steps, push_reservoir! and GAIL validate shapes."""
+    ctx = crux.Context(0)
+    acts = ["relu", "relu", "identity"]
+    a = crux.DiscreteNetwork(parity.chain([4, 64, 64, 2], acts), [1, 2], seed=1, ctx=ctx); c = crux.ContinuousNetwork(parity.chain([4, 64, 64, 1], acts), seed=2, ctx=ctx)
+    buf = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), 256, ["return", "logprob", "advantage"], ctx=ctx)
+    rng = np.random.default_rng(0); d = _rand_data(rng, 256, 4, 2, True, ["return", "logprob", "advantage"]); buf.push_(d)
+
+    class _S:
+        pass
+    sv = _S(); sv.agent = crux.PolicyParams(crux.ActorCritic(a, c)); sv.P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+    sv.a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=128, epochs=2, target_kl=0.01, name="actor_")
+    sv.c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=128, epochs=2, name="critic_")
+    with pytest.raises(crux.CruxError) as e:
+        crux.policy_gradient_training_synced(sv, buf, 1)
+    assert e.value.code == L.EUNSUP                                   # replicas would diverge in epoch count
+    sv.a_opt.target_kl = None; sv.c_opt.epochs = 3
+    with pytest.raises(crux.CruxError) as e:
+        crux.policy_gradient_training_synced(sv, buf, 1)
+    assert e.value.code == L.EINVAL                                   # actor / critic epoch counts differ
+    uid = ctx.comm_unique_id(); ctx.comm_init(0, 1, uid)
+    with pytest.raises(crux.CruxError) as e:
+        ctx.comm_init(0, 1, uid)
+    assert e.value.code == L.EINVAL
+    ctx.comm_destroy(); assert ctx.comm_size() == 1
+    with pytest.raises(crux.CruxError) as e:
+        ctx.check(ctx.lib.crux_comm_init(ctx.h, 3, 2, uid.ctypes.data_as(L.vp)))
+    assert e.value.code == L.EINVAL                                   # rank outside the group
+    g = crux.SquashedGaussianPolicy(parity.chain([3, 32, 1], ["relu", "identity"]), np.zeros(1, np.float32), 2.0, ctx=ctx)
+    with pytest.raises(crux.CruxError) as e:
+        ctx.check(ctx.lib.crux_mlp_set_squash(g.h, -1.0))
+    assert e.value.code == L.EINVAL and abs(ctx.lib.crux_mlp_get_squash(g.h) - 2.0) < 1e-7
+    q1 = crux.ContinuousNetwork(parity.chain([4, 32, 1], ["relu", "identity"]), ctx=ctx); la = crux.ParamVector([0.0], ctx=ctx)
+    cb = crux.ExperienceBuffer(crux.ContinuousSpace(3), crux.ContinuousSpace(1), 64, ctx=ctx)
+    cb.push_({"s": rng.normal(0, 1, (3, 64)).astype(np.float32), "a": rng.uniform(-1, 1, (1, 64)).astype(np.float32), "sp": rng.normal(0, 1, (3, 64)).astype(np.float32),
+              "r": np.zeros((1, 64), np.float32), "done": np.zeros((1, 64), bool)})
+    dy = ctx.alloc(4 * 64)
+    with pytest.raises(crux.CruxError) as e:
+        ctx.check(ctx.lib.crux_sac_target(g.h, q1.h, q1.h, la.h, cb.h, 0.99, 0, 0, dy))
+    assert e.value.code == L.EUNSUP
+    with pytest.raises(crux.CruxError) as e:                          # discriminator must map act_dim + obs_dim -> 1
+        ctx.check(ctx.lib.crux_gail_d_step(q1.h, cb.h, 0, 32, cb.h, 0, 100, np.zeros(L.INFO_N, np.float32).ctypes.data_as(L.vp)))
+    assert e.value.code == L.EINVAL                                   # row range outside the buffer
+    with pytest.raises(crux.CruxError):
+        cb.push_reservoir_({"s": np.zeros((2, 5), np.float32)})       # wrong obs width
+    ctx.free(dy)
