@@ -1268,6 +1268,59 @@ def buffer_like(b, capacity=None):
     return ExperienceBuffer(b.S, b.A, capacity or b.capacity, extras, prioritized=b.isprioritized(), priority_params={"alpha": b.alpha, "beta": b.beta}, ctx=b.ctx)
 
 
+def episodes(b, use_done=False, episode_checker=None):
+    """episodes(b::ExperienceBuffer, use_done, episode_checker) (src/experience_buffer.jl:194-221): 1-based inclusive (start, stop) pairs from :episode_end
+    (or :t == 1 starts, or :done when asked); a trailing open episode is closed at length(b)."""
+    n = len(b)
+    if b.haskey("episode_end"):
+        ends = list(np.flatnonzero(b["episode_end"][0]) + 1); starts = [1] + [e + 1 for e in ends[:-1]]
+    elif b.haskey("t"):
+        starts = list(np.flatnonzero(b["t"][0] == 1) + 1); ends = [s_ - 1 for s_ in starts[1:]] + [n]
+    elif use_done:
+        ends = list(np.flatnonzero(b["done"][0]) + 1); starts = [1] + [e + 1 for e in ends[:-1]]
+    else:
+        raise ValueError("Need :episode_end flag or :t column to determine episodes")
+    if not ends:                                     # the reference would index an empty array here; an un-terminated buffer is one open episode
+        starts, ends = ([1], [n]) if n > 0 else ([], [])
+    elif n > 0 and ends[-1] != n:
+        starts.append(ends[-1] + 1); ends.append(n)
+    eps = [(int(a), int(z)) for a, z in zip(starts, ends)]
+    return [e for e in eps if episode_checker(b, e)] if episode_checker is not None else eps
+
+
+def hcat(*buffers, capacity=None):
+    """hcat(buffers::ExperienceBuffer...) (:106-116): a new buffer holding the rows of every argument in order (same columns required)."""
+    b0 = buffers[0]
+    for b in buffers[1:]:
+        if sorted(b.keys()) != sorted(b0.keys()):
+            raise L.CruxError(L.EINVAL, "hcat: buffers have different columns (@assert keys(data) == keys(b))")
+    n = sum(len(b) for b in buffers)
+    out = buffer_like(b0, capacity=max(1, capacity or n))
+    for b in buffers:
+        if len(b):
+            out.push_(b, ids=np.arange(1, len(b) + 1))
+    return out
+
+
+def get_episodes(b, eps):
+    """get_episodes(b, episodes) (:150-156): the rows of the listed (start, stop) episodes, concatenated."""
+    ids = np.concatenate([np.arange(a, z + 1) for a, z in eps]) if len(eps) else np.zeros(0, np.int64)
+    out = buffer_like(b, capacity=max(1, ids.size))
+    if ids.size:
+        out.push_(b, ids=ids)
+    return out
+
+
+def trim_(b, n):
+    """trim!(b, 1:n) (:158-168) as the samplers use it (sampler.jl:144,193): keep the first n rows. Returns a buffer of capacity n (the device columns
+    are fixed-size allocations, so the trimmed view is a new handle)."""
+    n = int(min(n, len(b)))
+    out = buffer_like(b, capacity=max(1, n))
+    if n:
+        out.push_(b, ids=np.arange(1, n + 1))
+    return out
+
+
 def extra_columns(b):
     """extra_columns(b) (src/experience_buffer.jl:178)."""
     return [k for k in b.keys() if k not in ("s", "a", "sp", "r", "done", "episode_end")]

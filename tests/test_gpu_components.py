@@ -761,3 +761,23 @@ def test_error_paths_of_the_newer_entries(gpu_ctx):
     with pytest.raises(crux.CruxError):
         cb.push_reservoir_({"s": np.zeros((2, 5), np.float32)})       # wrong obs width
     ctx.free(dy)
+
+
+def test_episodes_hcat_get_episodes_trim(gpu_ctx):
+    """episodes(b) (experience_buffer.jl:194-221; test/gym/sampler_tests.jl:95-100 compares it with the ranges episodes! returns), hcat (:106-116),
+    get_episodes (:150-156), trim! (:158-168) on device buffers vs the oracle's episode ranges and plain numpy slicing."""
+    rng = np.random.default_rng(23); n = 90
+    d = _rand_data(rng, n, 3, 2, True); ee = np.zeros((1, n), bool); ee[0, [9, 10, 40, 77]] = True; d["episode_end"] = ee; d["done"] = ee.copy()
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(3), crux.DiscreteSpace(2), n); ob = O.OBuffer(3, 2, L.ACTION_DISCRETE, n); gb.push_(d); ob.push(d)
+    st, en = np.zeros(n, np.int64), np.zeros(n, np.int64); ne = O.lib().orc_buffer_episodes(ob.h, O.vpz(st), O.vpz(en), n)
+    eps = crux.episodes(gb)
+    assert eps == [(int(a) + 1, int(z) + 1) for a, z in zip(st[:ne], en[:ne])] == [(1, 10), (11, 11), (12, 41), (42, 78), (79, 90)]   # the open tail is closed at length(b)
+    assert crux.episodes(gb, episode_checker=lambda b, e: e[1] - e[0] >= 5) == [(1, 10), (12, 41), (42, 78), (79, 90)]
+    sub = crux.get_episodes(gb, [eps[1], eps[3]])
+    assert len(sub) == 1 + 37 and np.array_equal(sub["s"], np.hstack([d["s"][:, 10:11], d["s"][:, 41:78]])) and np.array_equal(sub["a"], np.hstack([d["a"][:, 10:11], d["a"][:, 41:78]]))
+    both = crux.hcat(gb, sub)
+    assert len(both) == n + 38 and np.array_equal(both["r"], np.hstack([d["r"], d["r"][:, 10:11], d["r"][:, 41:78]])) and both.keys() == gb.keys()
+    t = crux.trim_(gb, 25)
+    assert len(t) == 25 and np.array_equal(t["sp"], d["sp"][:, :25]) and np.array_equal(t["episode_end"], ee[:, :25])
+    with pytest.raises(crux.CruxError):
+        crux.hcat(gb, crux.ExperienceBuffer(crux.ContinuousSpace(3), crux.DiscreteSpace(2), 4, ["return"]))
