@@ -688,6 +688,25 @@ class LinearDecaySchedule:
         return max(self.stop, self.start - i * rate)
 
 
+class MultitaskDecaySchedule:
+    """MultitaskDecaySchedule(steps, task_ids; start=1.0, stop=0.1) (src/utils.jl:128-138): a LinearDecaySchedule restarted per task, continuing
+    where the previous visit of the same task id stopped; before the first task -> start, after the last -> stop."""
+
+    def __init__(self, steps, task_ids, start=1.0, stop=0.1):
+        self.steps, self.task_ids, self.start, self.stop = int(steps), list(task_ids), float(start), float(stop)
+        self.schedule = LinearDecaySchedule(start, stop, steps)
+
+    def __call__(self, i):
+        taskindex = -(-int(i) // self.steps)                 # ceil(Int, i / steps)
+        if taskindex < 1:
+            return self.start
+        if taskindex > len(self.task_ids):
+            return self.stop
+        taskid = self.task_ids[taskindex - 1]
+        used = self.steps * sum(1 for t in self.task_ids[:taskindex - 1] if t == taskid)
+        return self.schedule(used + ((int(i) - 1) % self.steps) + 1)       # mod1(i, steps)
+
+
 class EpsGreedyPolicy:
     """ϵGreedyPolicy(eps, actions) = MixedPolicy(eps, uniform random action) (src/policies.jl:466-494)."""
 

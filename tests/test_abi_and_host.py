@@ -130,3 +130,25 @@ def test_tensorboard_event_files_round_trip_and_log_cadence(tmp_path):
     w = lg.log(p, (5, 8), {"x": 1.0}, lambda **kw: {"y": 2.0}, S=Sv())
     assert w == {"avg_r": (6 + 7 + 8 + 9) / 2.0, "x": 1.0, "y": 2.0}
     assert lg.readtb(p.logger.logdir)["avg_r"] == ([8], [15.0])
+
+
+def test_multitask_decay_schedule_reference_kats():
+    """test/util_tests.jl:55-86 verbatim: MultitaskDecaySchedule(10, [1,2,3]) restarts the linear decay per task; with task ids [1,2,1] the third
+    block continues where task 1 stopped; m(31) == 0.1, m(0) == 1."""
+    import crux_jl_amd as crux
+    l = crux.LinearDecaySchedule(1.0, 0.1, 10)
+    m = crux.MultitaskDecaySchedule(10, [1, 2, 3])
+    for i in range(1, 11):
+        assert m(i) == l(i)
+    for i in range(11, 21):
+        assert m(i) == l(i - 10)
+    for i in range(21, 31):
+        assert m(i) == l(i - 20)
+    m = crux.MultitaskDecaySchedule(10, [1, 2, 1])
+    for i in range(1, 11):
+        assert m(i) == l(i)
+    for i in range(11, 21):
+        assert m(i) == l(i - 10)
+    for i in range(21, 31):
+        assert m(i) == l(i - 10)
+    assert m(31) == 0.1 and m(0) == 1
