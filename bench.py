@@ -316,6 +316,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush(); os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
+        if sync == "native":
+            ctx.comm_destroy()                 # the library's communicator goes first, then torch's
         dist.destroy_process_group()
 
 
