@@ -81,6 +81,7 @@ SIGNATURES = {
     "crux_per_sample": (i32, [vp, vp, i64, vp, f32, u64]),
     "crux_uniform_sample": (i32, [vp, vp, i64, vp, u64]),
     "crux_per_get": (i32, [vp, vp, P(f32), P(f32), vp]),
+    "crux_buffer_set_sample_stream": (i32, [vp, u64, u32]),
     "crux_env_create": (i32, [vp, i32, i32, i32, f32, vp, vp, u64, i32, i32, P(vp)]),
     "crux_env_destroy": (i32, [vp]),
     "crux_env_obs_dim": (i32, [vp]),
@@ -92,6 +93,8 @@ SIGNATURES = {
     "crux_env_step_host": (i32, [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]),
     "crux_fill_gae": (i32, [vp, vp, f32, f32]),
     "crux_fill_returns": (i32, [vp, f32]),
+    "crux_fill_gae_rows": (i32, [vp, vp, f32, f32, i64, i64, i64, i32]),
+    "crux_fill_returns_rows": (i32, [vp, f32, i64, i64, i64, i32]),
     "crux_whiten": (i32, [vp, i32]),
     "crux_batch_train": (i32, [vp, vp, P(TrainCfg), vp, vp, vp]),
     "crux_policy_gradient_training": (i32, [vp, vp, vp, P(TrainCfg), P(TrainCfg), vp, vp, vp, vp, vp, vp]),

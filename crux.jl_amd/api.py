@@ -593,34 +593,48 @@ def capacity(b):
 SAMPLE_SEED = 0x5EED5A3F   # Philox key of the library's replay-sampling draws (fixed; the counter is the caller's `i`)
 
 
+def set_sample_stream_(source, seed=SAMPLE_SEED, stream=0):
+    """Philox key / stream of the draws that sample FROM `source` (cruxhip.h: crux_buffer_set_sample_stream)."""
+    source.ctx.check(source.ctx.lib.crux_buffer_set_sample_stream(source.h, int(seed), int(stream)))
+    source.sample_seed, source.sample_stream = int(seed), int(stream)
+
+
 def uniform_sample_(target, source, B=None, ids=None, i=0):
-    """uniform_sample!(target, source; B) (src/experience_buffer.jl:317-321). ids: optional explicit 1-based rows (else Philox)."""
+    """uniform_sample!(target, source; B) (src/experience_buffer.jl:317-321). ids: optional explicit 1-based rows (else the Philox draw with counter i)."""
     B = B or target.capacity
     ids0 = None if ids is None else np.ascontiguousarray(np.asarray(ids, np.int64) - 1)
     target.ctx.check(target.ctx.lib.crux_uniform_sample(target.h, source.h, B, _vp(ids0), int(i)))
     return target.indices[:B] + 1
 
 
-def prioritized_sample_(target, source, B=None, i=1, rands=None):
-    """prioritized_sample!(target, source; i, B) (src/experience_buffer.jl:324-349). rands: optional B Float64 uniforms."""
+def prioritized_sample_(target, source, B=None, i=1, rands=None, counter=None):
+    """prioritized_sample!(target, source; i, B) (src/experience_buffer.jl:324-349). `i` is the reference's keyword: the interaction count at which
+    the importance-sampling exponent beta(i) is evaluated (:344,346). `counter` is the Philox counter of this draw (defaults to i; the reference
+    advances Julia's global RNG instead). rands: optional B Float64 uniforms."""
     B = B or target.capacity
     r = None if rands is None else np.ascontiguousarray(rands, np.float64)
     beta = np.float32(source.beta(i))
-    target.ctx.check(target.ctx.lib.crux_per_sample(target.h, source.h, B, _vp(r), float(beta), int(i)))
+    target.ctx.check(target.ctx.lib.crux_per_sample(target.h, source.h, B, _vp(r), float(beta), int(i if counter is None else counter)))
     return target.indices[:B] + 1
 
 
-def rand_(target, *sources, i=1, fracs=None):
-    """Random.rand!(target, sources...; i, fracs) (src/experience_buffer.jl:303-315)."""
+def rand_(target, *sources, i=1, fracs=None, counter=None, seed=None):
+    """Random.rand!(target, sources...; i, fracs) (src/experience_buffer.jl:303-315). `i` goes to prioritized_sample! unchanged (beta(i), :312);
+    `counter` numbers this call's draws (defaults to i) and `seed` keys them (defaults to each source's own key). With several sources, source k
+    draws from Philox stream k, so the per-source samples are independent like the reference's successive rand calls."""
     fr = list(fracs) if fracs is not None else [1.0 / len(sources)] * len(sources)
     lens = [len(s) for s in sources]
     if any(l == 0 for l in lens):
         fr = [0.0 if l == 0 else f for f, l in zip(fr, lens)]; tot = sum(fr); fr = [f / tot for f in fr]
     batches = split_batches(target.capacity, fr)
-    for b, B in zip(sources, batches):
+    ctr = i if counter is None else counter
+    for k, (b, B) in enumerate(zip(sources, batches)):
         if B == 0:
             continue
-        prioritized_sample_(target, b, B=B, i=i) if b.isprioritized() else uniform_sample_(target, b, B=B, i=i)
+        want = (int(seed) if seed is not None else getattr(b, "sample_seed", SAMPLE_SEED), k if len(sources) > 1 else getattr(b, "sample_stream", 0))
+        if want != (getattr(b, "sample_seed", SAMPLE_SEED), getattr(b, "sample_stream", 0)):
+            set_sample_stream_(b, *want)
+        prioritized_sample_(target, b, B=B, i=i, counter=ctr) if b.isprioritized() else uniform_sample_(target, b, B=B, i=ctr)
 
 
 def split_batches(N, fracs):
@@ -773,6 +787,8 @@ def _rollout_cfg(sampler, explore, reset, i):
     else:
         cfg.head = L.HEAD[pi_on.head]
         cfg.logit_div = float(getattr(pi_on, "logit_div", 0.0))          # SoftQ: softmax(value ./ alpha) (softq.jl:53)
+        if not explore and getattr(pi_on, "always_stochastic", False):   # action(pi, s) = exploration(pi, s)[1] (policies.jl:124): sample, logprob NaN
+            cfg.explore = 2
     return cfg, pi_on
 
 
@@ -780,22 +796,34 @@ def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=N
     """steps!(sampler, buffer; Nsteps, explore, i, reset, cb) (src/sampler.jl:139-173).
 
     Nsteps counts transitions over all of the sampler's environments (Nsteps/n_envs per environment, env-major).
-    GAE / returns are filled like terminate_episode! does (:56-57) when the buffer carries those columns and holds
-    exactly this rollout (the on-policy case, buffer capacity == Nsteps). Returns the info dict (avg_r as record_avgr)."""
+    GAE / returns are filled on the block this call produced, like terminate_episode! does before push! (:53-57,148-152), whatever the
+    destination buffer's capacity or previous contents: the scans run on the ring rows the block was pushed to. Returns the info dict
+    (avg_r as record_avgr)."""
     E = sampler.n_envs
     if Nsteps % E:
         raise ValueError("steps!: Nsteps=%d is not a multiple of n_envs=%d" % (Nsteps, E))
     cfg, pi_on = _rollout_cfg(sampler, explore, reset, i)
     sr, ne = C.c_double(), C.c_int64()
+    first = buffer.next_ind - 1                                   # 0-based ring row the block starts at (push!, experience_buffer.jl:236)
     sampler.ctx.check(sampler.ctx.lib.crux_rollout(sampler.h, pi_on.h, C.byref(cfg), buffer.h, Nsteps // E, C.byref(sr), C.byref(ne)))
-    if buffer.haskey("advantage") and len(buffer) == Nsteps:
-        fill_gae_(buffer, critic(sampler.agent.pi), sampler.lam, sampler.gamma)
-    if buffer.haskey("return") and len(buffer) == Nsteps:
-        fill_returns_(buffer, sampler.gamma)
+    _fill_block(sampler, buffer, first, Nsteps, reset)
     info = {"sum_r": sr.value, "n_episode_end": ne.value, "avg_r": sr.value / ne.value if ne.value else float("nan")}
     if cb:
         cb(buffer, info)
     return info
+
+
+def _fill_block(sampler, buffer, first, Nsteps, reset):
+    """terminate_episode!'s fill_gae! / fill_returns! (src/sampler.jl:56-57) on the rows [first, first + Nsteps) mod capacity of `buffer`."""
+    if Nsteps > buffer.capacity:
+        if buffer.haskey("advantage") or buffer.haskey("return"):
+            raise L.CruxError(L.EINVAL, "steps!: a block of %d transitions does not fit the buffer (capacity %d) whose :advantage / :return columns it must fill" % (Nsteps, buffer.capacity))
+        return
+    lib = buffer.ctx.lib
+    if buffer.haskey("advantage"):
+        buffer.ctx.check(lib.crux_fill_gae_rows(buffer.h, critic(sampler.agent.pi).h, float(sampler.lam), float(sampler.gamma), int(first), int(Nsteps), int(Nsteps // sampler.n_envs), 1 if reset else 0))
+    if buffer.haskey("return"):
+        buffer.ctx.check(lib.crux_fill_returns_rows(buffer.h, float(sampler.gamma), int(first), int(Nsteps), int(Nsteps // sampler.n_envs), 1 if reset else 0))
 
 
 def episodes_(sampler, Neps=1, explore=False, i=0, seed_offset=0x45564C):
@@ -838,21 +866,20 @@ def steps_multi_(samplers, buffers, Nsteps=1, explore=False, i=0, reset=False):
     cfg, _ = _rollout_cfg(s0, explore, reset, i)
     he = (C.c_void_p * n)(*[s.h for s in samplers]); hp = (C.c_void_p * n)(*[actor(s.agent.pi).h for s in samplers]); hb = (C.c_void_p * n)(*[b.h for b in buffers])
     sr, ne = np.zeros(n, np.float64), np.zeros(n, np.int64)
+    firsts = [b.next_ind - 1 for b in buffers]
     s0.ctx.check(s0.ctx.lib.crux_rollout_multi(n, he, hp, C.byref(cfg), hb, Nsteps // E, _vp(sr), _vp(ne)))
-    out = []
-    if all(b.haskey("advantage") and len(b) == Nsteps for b in buffers):     # same rule as steps_ (sampler.jl:62-63), batched over the problems
+    if reset and all(b.haskey("advantage") and len(b) == Nsteps and b.capacity == Nsteps for b in buffers):     # every buffer IS its block: batched scans
         hc = (C.c_void_p * n)(*[critic(s.agent.pi).h for s in samplers])
-        s0.ctx.check(s0.ctx.lib.crux_fill_gae_multi(n, hb, hc, float(s0.lam), float(s0.gamma), 1 if all(b.haskey("return") for b in buffers) else 0))
-        done_gae = True
+        with_ret = all(b.haskey("return") for b in buffers)
+        s0.ctx.check(s0.ctx.lib.crux_fill_gae_multi(n, hb, hc, float(s0.lam), float(s0.gamma), 1 if with_ret else 0))
+        if not with_ret:
+            for s, b in zip(samplers, buffers):
+                if b.haskey("return"):
+                    fill_returns_(b, s.gamma)
     else:
-        done_gae = False
-    for k, (s, b) in enumerate(zip(samplers, buffers)):
-        if not done_gae and b.haskey("advantage") and len(b) == Nsteps:
-            fill_gae_(b, critic(s.agent.pi), s.lam, s.gamma)
-        if (not done_gae or not all(bb.haskey("return") for bb in buffers)) and b.haskey("return") and len(b) == Nsteps:
-            fill_returns_(b, s.gamma)
-        out.append({"sum_r": float(sr[k]), "n_episode_end": int(ne[k]), "avg_r": float(sr[k] / ne[k]) if ne[k] else float("nan")})
-    return out
+        for s, b, f in zip(samplers, buffers, firsts):
+            _fill_block(s, b, f, Nsteps, reset)
+    return [{"sum_r": float(sr[k]), "n_episode_end": int(ne[k]), "avg_r": float(sr[k] / ne[k]) if ne[k] else float("nan")} for k in range(n)]
 
 
 def fill_gae_(buffer, V, lam, gamma):
@@ -1353,13 +1380,13 @@ class OffPolicySolver:
     (src/model_free/off_policy.jl:37-64). target_update defaults to polyak_average!(pi_minus, pi, 0.005) (:55)."""
 
     def __init__(self, agent, S, N=1000, dN=4, max_steps=100, c_opt=None, buffer_size=1000, buffer=None, buffer_init=None, tau=0.005,
-                 prioritized=False, weighted_loss=False, i=0, a_opt=None, param_optimizers=None, P=None, target_fn="dqn", noise_seed=0, log=None):
+                 prioritized=False, weighted_loss=False, i=0, a_opt=None, param_optimizers=None, P=None, target_fn="dqn", noise_seed=0, log=None, sample_seed=SAMPLE_SEED):
         self.agent, self.S, self.N, self.dN, self.max_steps, self.c_opt, self.i = agent, S, int(N), int(dN), int(max_steps), c_opt, int(i)
         self.log = log                         # LoggerParams (crux_jl_amd.logging) or None
         self.a_opt, self.param_optimizers, self.P, self.target_fn, self.noise_seed = a_opt, list(param_optimizers or []), dict(P or {}), target_fn, int(noise_seed)
         self.buffer = buffer if buffer is not None else ExperienceBuffer(S, agent.space, buffer_size, prioritized=prioritized)
         self.buffer_init = buffer_init if buffer_init is not None else max(c_opt.batch_size, 200)
-        self.tau, self.weighted_loss = float(tau), bool(weighted_loss)
+        self.tau, self.weighted_loss, self.sample_seed = float(tau), bool(weighted_loss), int(sample_seed)
         self.sampler, self.batch, self.history = None, None, []
         self._dy = self._derr = None
 
@@ -1380,7 +1407,7 @@ def _value_training_sac(solver, D, gamma):
     infos, lib, raw = [], ctx.lib, np.zeros(L.INFO_N, np.float32)
     for epoch in range(c_opt.epochs):
         ctr = solver.i * c_opt.epochs + epoch                                                          # one Philox counter block per epoch
-        rand_(D, buf, i=ctr)                                                                           # :71
+        rand_(D, buf, i=solver.i, counter=ctr, seed=solver.sample_seed)                                # :71 rand!(D, buffer, i=S.i)
         info = {}
         ctx.check(lib.crux_sac_target(A.h, Qm.N1.h, Qm.N2.h, la.h, D.h, float(gamma), solver.noise_seed, 3 * ctr, solver._dy))           # :80
         ctx.check(lib.crux_sac_temp_step(A.h, la.h, D.h, float(solver.P["SAC_H_target"]), solver.noise_seed, 3 * ctr + 1, _vp(raw)))     # :86-88
@@ -1416,7 +1443,7 @@ def _value_training_dpg(solver, D, gamma):
     infos, lib, raw = [], ctx.lib, np.zeros(L.INFO_N, np.float32)
     for epoch in range(c_opt.epochs):
         ctr = solver.i * c_opt.epochs + epoch
-        rand_(D, buf, i=ctr)                                                                           # :71
+        rand_(D, buf, i=solver.i, counter=ctr, seed=solver.sample_seed)                                # :71 rand!(D, buffer, i=S.i)
         info = {}
         ctx.check(lib.crux_dpg_target(Am.h, (Qm.N1 if twin else Qm).h, Qm.N2.h if (twin and solver.target_fn == "td3") else None, D.h, float(gamma),
                                       sm.sigma if sm else -1.0, sm.eps_min if sm else 0.0, sm.eps_max if sm else 0.0, sm.a_min if sm else 0.0, sm.a_max if sm else 0.0,
@@ -1452,7 +1479,7 @@ def value_training(solver, D, gamma):
         solver._dy, solver._derr = ctx.alloc(4 * B), ctx.alloc(4 * B)
     infos = []
     for epoch in range(p.epochs):
-        rand_(D, buf, i=solver.i * p.epochs + epoch)                                                   # :71 (Philox counter unique per draw)
+        rand_(D, buf, i=solver.i, counter=solver.i * p.epochs + epoch, seed=solver.sample_seed)        # :71 rand!(D, buffer, i=S.i): beta(S.i); the Philox counter is unique per draw
         if solver.target_fn == "softq":
             ctx.check(ctx.lib.crux_softq_target(pim.h, D.h, float(gamma), float(solver.P["alpha"]), solver._dy))   # :80  softq.jl:4-13
         else:

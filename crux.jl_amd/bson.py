@@ -78,7 +78,8 @@ def read_columns(path):
     fields = node["data"]
     cols = {k: _array(v) for k, v in fields[0].items() if _array(v) is not None}
     meta = {"elements": int(fields[1]), "next_ind": int(fields[2]), "indices": _array(fields[3]) if len(fields) > 3 else None,
-            "priority_params": fields[4] if len(fields) > 4 else None}
+            "priority_params": fields[4] if len(fields) > 4 else None,
+            "total_count": int(fields[5]) if len(fields) > 5 and isinstance(fields[5], (int, np.integer)) else None}   # 6th field of the current struct (experience_buffer.jl:59); the shipped expert dumps predate it (5 fields)
     return cols, meta
 
 
@@ -96,6 +97,7 @@ def load_buffer(path, S=None, A=None, ctx=None, capacity=None):
     data.setdefault("episode_end", np.zeros((1, n), bool))
     buf.push_(data)
     buf.extra = {k: v[:, :n] for k, v in cols.items() if k not in api.L.COL}
+    buf.loaded_total_count = meta["total_count"] if meta["total_count"] is not None else n      # push_reservoir! continues from the stored count
     return buf
 
 
@@ -154,7 +156,8 @@ def save_buffer(buf, path, extra=None):
                           "body": {"tag": "unionall", "var": {"tag": "backref", "ref": 3},
                                    "body": {"tag": "datatype", "name": ["Core", "Array"], "params": [{"tag": "backref", "ref": 2}, {"tag": "backref", "ref": 3}]}}}]}
     doc = {"data": {"tag": "struct", "type": ebtype,
-                    "data": [{k: _arr(v) for k, v in cols.items()}, int(n), int(buf.next_ind), _arr(np.zeros(0, np.int64)), None]},
+                    "data": [{k: _arr(v) for k, v in cols.items()}, int(n), int(buf.next_ind), _arr(np.zeros(0, np.int64)), None,
+                             int(getattr(buf, "total_count", n))]},      # data, elements, next_ind, indices, priority_params, total_count (experience_buffer.jl:53-60)
            "_backrefs": [_dt("TypeVar"), _typevar("T"), _typevar("N")]}
     with open(path, "wb") as f:
         f.write(_emit(doc))

@@ -10,22 +10,37 @@ int32_t crux_mlp_forward_impl(crux_mlp* net, const float* d_x, int64_t B, float*
 //   A = ((c*A + r) + ((1f0 - done)*gamma)*Vsp) - Vs        (sampler.jl:269)
 //   R = r + gamma*R                                        (sampler.jl:278)
 // so results are bit-identical to the scalar loop given the same V(s), V(sp).
+// Row k of the scanned block lives at physical row (first + k) mod cap (a ring range; first = 0, cap = n for a whole buffer); Vs / Vsp are
+// indexed by k. close_last: the block's last row terminates an episode even without :episode_end (episodes(d) closes a trailing episode at
+// length(d), experience_buffer.jl:207-211; steps!(reset=true) sets the flag itself); otherwise the trailing open rows get 0 -- the values
+// mdp_data initialised them with in the reference's fresh `data` block, which terminate_episode! never reached (sampler.jl:53-57,140-148).
 __device__ __forceinline__ void gae_returns_body(const float* __restrict__ r, const uint8_t* __restrict__ done, const uint8_t* __restrict__ ee,
                               const float* __restrict__ Vs, const float* __restrict__ Vsp, float lambda, float gamma, int64_t n,
-                              float* __restrict__ adv, float* __restrict__ ret, int32_t* __restrict__ nan_flag) {
+                              float* __restrict__ adv, float* __restrict__ ret, int32_t* __restrict__ nan_flag,
+                              int64_t first = 0, int64_t cap = 0, int close_last = 1, int64_t seg = 0) {
+  if (cap <= 0) cap = n;
+  if (seg <= 0) seg = n;        // env-major blocks: rows [e*seg, (e+1)*seg) belong to environment e and no episode crosses that boundary
+  auto phys = [&](int64_t k) -> int64_t { const int64_t q = first + k; return q >= cap ? q - cap : q; };
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    if (!(ee[i] || i == n - 1)) continue;
+    const bool closed = ee[phys(i)];
+    if (!(closed || i == n - 1 || (i + 1) % seg == 0)) continue;
+    const int64_t k0 = (i / seg) * seg;     // first row of this environment's segment
+    if (!closed && !close_last) {          // trailing rows of an episode that is still open at the end of the segment
+      for (int64_t k = i; k >= k0 && !ee[phys(k)]; --k) { if (adv) adv[phys(k)] = 0.f; if (ret) ret[phys(k)] = 0.f; }
+      continue;
+    }
     float A = 0.f, R = 0.f; const float c = __fmul_rn(lambda, gamma);
     bool bad = false;
-    for (int64_t k = i; k >= 0 && (k == i || !ee[k]); --k) {
-      const float rk = r[k];
+    for (int64_t k = i; k >= k0 && (k == i || !ee[phys(k)]); --k) {
+      const int64_t q = phys(k);
+      const float rk = r[q];
       if (adv) {
         const float t2 = __fadd_rn(__fmul_rn(c, A), rk);
-        const float t3 = __fmul_rn(__fmul_rn(__fsub_rn(1.f, done[k] ? 1.f : 0.f), gamma), Vsp[k]);
+        const float t3 = __fmul_rn(__fmul_rn(__fsub_rn(1.f, done[q] ? 1.f : 0.f), gamma), Vsp[k]);
         A = __fsub_rn(__fadd_rn(t2, t3), Vs[k]);
-        adv[k] = A; bad |= isnan(A);
+        adv[q] = A; bad |= isnan(A);
       }
-      if (ret) { R = __fadd_rn(rk, __fmul_rn(gamma, R)); ret[k] = R; }
+      if (ret) { R = __fadd_rn(rk, __fmul_rn(gamma, R)); ret[q] = R; }
     }
     if (bad) atomicOr(nan_flag, 1);
   }
@@ -34,6 +49,11 @@ __global__ void k_gae_returns(const float* __restrict__ r, const uint8_t* __rest
                               const float* __restrict__ Vs, const float* __restrict__ Vsp, float lambda, float gamma, int64_t n,
                               float* __restrict__ adv, float* __restrict__ ret, int32_t* __restrict__ nan_flag) {
   gae_returns_body(r, done, ee, Vs, Vsp, lambda, gamma, n, adv, ret, nan_flag);
+}
+__global__ void k_gae_returns_rows(const float* __restrict__ r, const uint8_t* __restrict__ done, const uint8_t* __restrict__ ee,
+                                   const float* __restrict__ Vs, const float* __restrict__ Vsp, float lambda, float gamma, int64_t n,
+                                   float* __restrict__ adv, float* __restrict__ ret, int32_t* __restrict__ nan_flag, int64_t first, int64_t cap, int close_last, int64_t seg) {
+  gae_returns_body(r, done, ee, Vs, Vsp, lambda, gamma, n, adv, ret, nan_flag, first, cap, close_last, seg);
 }
 struct GaeJob { const float* r; const uint8_t* done; const uint8_t* ee; const float* Vs; const float* Vsp; float* adv; float* ret; int32_t* flag; };
 __global__ void k_gae_returns_multi(const GaeJob* __restrict__ jobs, float lambda, float gamma, int64_t n) {     // grid.y = buffer
@@ -198,6 +218,57 @@ int32_t crux_whiten_multi(int32_t n, crux_buffer* const* bufs, int32_t key) {
   hipLaunchKernelGGL(k_whiten_multi, dim3((unsigned)n), dim3(1024), 0, c->stream, (float* const*)dp, len);
   crux_prof_end(c, CRUX_PROF_WHITEN);
   return crux_launch_check(c, "k_whiten_multi");
+}
+
+// fill_gae!(data, ep, V, lambda, gamma) / fill_returns!(data, ep, gamma) as terminate_episode! applies them to the block a steps! call just
+// produced (sampler.jl:53-57,140-148), on the ring rows [first_row, first_row + n_rows) mod capacity that the block was pushed to.
+int32_t crux_fill_gae_rows(crux_buffer* b, crux_mlp* critic, float lambda, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last) {
+  if (!b || !critic) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx;
+  if (!has_col(b, CRUX_COL_ADVANTAGE)) return crux_fail(c, CRUX_EINVAL, "fill_gae!: buffer has no :advantage column");
+  if (critic->nd.dims[critic->nd.L] != 1 || critic->nd.dims[0] != b->obs_dim) return crux_fail(c, CRUX_EINVAL, "fill_gae!: critic must map obs(%d) -> 1 (@assert length(Vs) == 1)", b->obs_dim);
+  const int64_t C = b->capacity, n = n_rows;
+  if (first_row < 0 || first_row >= C || n < 0 || n > C) return crux_fail(c, CRUX_EINVAL, "fill_gae!: rows [%lld, +%lld) outside the ring of %lld", (long long)first_row, (long long)n, (long long)C);
+  if (n == 0) return CRUX_OK;
+  const size_t vb = ((4 * (size_t)n + 255) / 256) * 256;
+  char* sc = (char*)crux_scratch(c, 2 * vb + 256);
+  if (!sc) return crux_fail(c, CRUX_ENOMEM, "fill_gae!: scratch");
+  float* Vs = (float*)sc; float* Vsp = (float*)(sc + vb); int32_t* flag = (int32_t*)(sc + 2 * vb);
+  HIPCHK(c, hipMemsetAsync(flag, 0, 4, c->stream));
+  const int64_t n1 = first_row + n <= C ? n : C - first_row, n2 = n - n1; const int od = b->obs_dim;
+  crux_prof_begin(c, CRUX_PROF_VALUES);
+  int32_t rc = values(critic, (const float*)b->col[CRUX_COL_S] + first_row * od, n1, Vs); if (rc) return rc;
+  rc = values(critic, (const float*)b->col[CRUX_COL_SP] + first_row * od, n1, Vsp); if (rc) return rc;
+  if (n2 > 0) { rc = values(critic, (const float*)b->col[CRUX_COL_S], n2, Vs + n1); if (rc) return rc;
+    rc = values(critic, (const float*)b->col[CRUX_COL_SP], n2, Vsp + n1); if (rc) return rc; }
+  crux_prof_end(c, CRUX_PROF_VALUES);
+  crux_prof_begin(c, CRUX_PROF_GAE);
+  hipLaunchKernelGGL(k_gae_returns_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE],
+                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], (const float*)Vs, (const float*)Vsp, lambda, gamma, n, (float*)b->col[CRUX_COL_ADVANTAGE], (float*)nullptr, flag,
+                     first_row, C, close_last ? 1 : 0, rows_per_env);
+  crux_prof_end(c, CRUX_PROF_GAE);
+  rc = crux_launch_check(c, "k_gae_returns_rows"); if (rc) return rc;
+  int32_t h = 0;
+  HIPCHK(c, hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (h) return crux_fail(c, CRUX_ENAN, "fill_gae!: NaN advantage (@assert !isnan(A))");
+  return CRUX_OK;
+}
+int32_t crux_fill_returns_rows(crux_buffer* b, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last) {
+  if (!b) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx;
+  if (!has_col(b, CRUX_COL_RETURN)) return crux_fail(c, CRUX_EINVAL, "fill_returns!: buffer has no :return column");
+  const int64_t C = b->capacity, n = n_rows;
+  if (first_row < 0 || first_row >= C || n < 0 || n > C) return crux_fail(c, CRUX_EINVAL, "fill_returns!: rows [%lld, +%lld) outside the ring of %lld", (long long)first_row, (long long)n, (long long)C);
+  if (n == 0) return CRUX_OK;
+  int32_t* flag = (int32_t*)crux_scratch(c, 256);
+  if (!flag) return crux_fail(c, CRUX_ENOMEM, "fill_returns!: scratch");
+  crux_prof_begin(c, CRUX_PROF_GAE);
+  hipLaunchKernelGGL(k_gae_returns_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE],
+                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], (const float*)nullptr, (const float*)nullptr, 0.f, gamma, n, (float*)nullptr, (float*)b->col[CRUX_COL_RETURN], flag,
+                     first_row, C, close_last ? 1 : 0, rows_per_env);
+  crux_prof_end(c, CRUX_PROF_GAE);
+  return crux_launch_check(c, "k_gae_returns_rows");
 }
 
 int32_t crux_fill_returns(crux_buffer* b, float gamma) {

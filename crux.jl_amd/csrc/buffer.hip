@@ -45,8 +45,8 @@ __global__ void k_fill_f32_idx(float* p, const int64_t* idx, float v, int64_t n)
 // update_priorities! (:290-301): val = v + eps(Float32); priorities[I] = val^alpha; max/min track the
 // un-powered val (Float32 fields). Positive floats order like their bit patterns, so atomicMax/Min on
 // the int view reproduce the sequential max/min exactly.
-__global__ void k_per_update(float* __restrict__ pr, float* __restrict__ pminmax, const int64_t* __restrict__ I,
-                             const double* __restrict__ v64, const float* __restrict__ v32, const float* __restrict__ vconst_from_max,
+__global__ void k_per_update(float* __restrict__ pr, float* pminmax, const int64_t* __restrict__ I,
+                             const double* __restrict__ v64, const float* __restrict__ v32, const float* vconst_from_max,
                              float alpha, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double val;
@@ -90,9 +90,12 @@ void crux_buffer_ring_advance(crux_buffer* b, int64_t N) {   // :256-257
 // priorities of freshly pushed rows (:254); d_I device index array
 int32_t crux_buffer_per_on_push(crux_buffer* b, const int64_t* d_I, int64_t N) {
   if (!b->prioritized || N <= 0) return CRUX_OK;
-  // all pushed rows get max_priority; the kernel reads pminmax[0] live, which this update can only re-set to itself
+  // all pushed rows get (max_priority + eps)^alpha with max_priority read ONCE before the update (push!: update_priorities!(b, I, max_priority*ones(N)),
+  // experience_buffer.jl:254): the value is snapshotted into pminmax[2] by a stream-ordered copy, because the kernel's atomicMax raises
+  // pminmax[0] to Float32(m + eps) while other waves are still reading it (for m in [1,2) that is the next float up)
+  HIPCHK(b->ctx, hipMemcpyAsync(b->pminmax + 2, b->pminmax, 4, hipMemcpyDeviceToDevice, b->ctx->stream));
   hipLaunchKernelGGL(k_per_update, dim3(grid_for(N)), dim3(256), 0, b->ctx->stream, b->priorities, b->pminmax, d_I, (const double*)nullptr,
-                     (const float*)nullptr, (const float*)b->pminmax, b->alpha, N);
+                     (const float*)nullptr, (const float*)(b->pminmax + 2), b->alpha, N);
   b->cumsum_valid = false;
   return crux_launch_check(b->ctx, "k_per_update(push)");
 }
@@ -173,7 +176,7 @@ int32_t crux_buffer_create(crux_ctx* ctx, int32_t obs_dim, int32_t act_dim, int3
       hipMalloc(&b->order_c, 4 * (size_t)capacity) != hipSuccess || hipMalloc(&b->order_d, 4 * (size_t)capacity) != hipSuccess) { crux_buffer_destroy(b); return crux_fail(ctx, CRUX_ENOMEM, "buffer_create: index arrays"); }
   if (b->prioritized) {
     if (hipMalloc(&b->priorities, 4 * (size_t)capacity) != hipSuccess || hipMalloc(&b->cumsum, 4 * (size_t)capacity) != hipSuccess ||
-        hipMalloc(&b->pminmax, 8) != hipSuccess) { crux_buffer_destroy(b); return crux_fail(ctx, CRUX_ENOMEM, "buffer_create: priorities"); }
+        hipMalloc(&b->pminmax, 16) != hipSuccess) { crux_buffer_destroy(b); return crux_fail(ctx, CRUX_ENOMEM, "buffer_create: priorities"); }
     HIPCHK(ctx, hipMemsetAsync(b->priorities, 0, 4 * (size_t)capacity, ctx->stream));
     const float mm[2] = {1.0f, INFINITY};                                              // PriorityParams :38-50
     HIPCHK(ctx, hipMemcpyAsync(b->pminmax, mm, 8, hipMemcpyHostToDevice, ctx->stream));

@@ -90,6 +90,7 @@ struct crux_buffer {
   std::vector<int64_t> indices;  // host copy of the last sample's ids (target.indices), fetched from d_indices on demand
   int64_t indices_n = 0; bool indices_stale = false;
   int64_t* d_indices = nullptr;  // device copy [capacity]
+  uint64_t sample_seed = 0x5EED5A3Full; uint32_t sample_stream = 0;   // Philox key / stream of the draws that sample FROM this buffer
   // pairwise-cumsum tree of Base.cumsum for the current length (built on the host once per length, see per.hip)
   int64_t topo_n = -1; int32_t topo_leaves = 0, topo_nodes = 0, topo_levels = 0;
   int32_t* topo_leaf_start = nullptr; int32_t* topo_leaf_len = nullptr; int32_t* topo_leaf_node = nullptr;

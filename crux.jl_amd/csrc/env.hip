@@ -187,6 +187,7 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
         else { float* A = (float*)a.A + (size_t)j * ad; for (int q = 0; q < ad; ++q) A[q] = aout[q]; }
         for (int q = 0; q < od; ++q) a.SP[(size_t)j * od + q] = spv[q];
         a.R[j] = r; a.D[j] = done;
+        if (a.cfg.explore == 2) logprob = NAN;      // action(pi, s) of an always_stochastic policy: exploration(pi, s)[1] with logprob NaN (policies.jl:124, sampler.jl:73)
         if (a.LP) a.LP[j] = logprob;
         if (a.TT) a.TT[j] = ep_len + 1;
         if (a.II) a.II[j] = (int64_t)gi + 1;

@@ -145,14 +145,14 @@ __global__ void k_cumsum_tiny(const float* v, int64_t n, float* c) { if (threadI
 
 // stratified search + importance weights (:335-347)
 __global__ void k_per_search(const float* __restrict__ cs, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B,
-                             const double* __restrict__ rands, uint64_t seed, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) {
+                             const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= B) return;
   const float ptot = cs[N - 1];
   const float dp = ptot / (float)B;
   double u;
   if (rands) u = rands[j];
-  else { const crux_u32x4 x = crux_philox(seed, ictr * (uint64_t)B + (uint64_t)j, 0, CRUX_RNG_SAMPLE); u = crux_u32x2_to_f64(x.v[0], x.v[1]); }
+  else { const crux_u32x4 x = crux_philox(seed, ictr * (uint64_t)B + (uint64_t)j, stream, CRUX_RNG_SAMPLE); u = crux_u32x2_to_f64(x.v[0], x.v[1]); }
   const double key = ((double)(j + 1) + u - 1.0) * (double)dp;
   int64_t lo = 0, hi = N;
   while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if ((double)cs[mid] < key) lo = mid + 1; else hi = mid; }
@@ -162,10 +162,10 @@ __global__ void k_per_search(const float* __restrict__ cs, const float* __restri
   const float max_w = powf(pmin * (float)N, -beta);
   weight[lo] = powf(((float)N * pr[lo]) / ptot, beta) / max_w;
 }
-__global__ void k_uniform_ids(int64_t N, int64_t B, uint64_t seed, uint64_t ictr, int64_t* ids) {
+__global__ void k_uniform_ids(int64_t N, int64_t B, uint64_t seed, uint32_t stream, uint64_t ictr, int64_t* ids) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= B) return;
-  const crux_u32x4 x = crux_philox(seed, ictr * (uint64_t)B + (uint64_t)j, 0, CRUX_RNG_SAMPLE);
+  const crux_u32x4 x = crux_philox(seed, ictr * (uint64_t)B + (uint64_t)j, stream, CRUX_RNG_SAMPLE);
   ids[j] = (int64_t)(((uint64_t)x.v[0] * (uint64_t)N) >> 32);
 }
 // gather rows src[ids[j]] into the ring of dst at (base + j) % C
@@ -255,7 +255,7 @@ int32_t crux_per_sample(crux_buffer* target, crux_buffer* source, int64_t B, con
     HIPCHK(c, hipMemcpyAsync(d_r, rands, 8 * (size_t)B, hipMemcpyHostToDevice, c->stream)); }
   crux_prof_begin(c, CRUX_PROF_PER_SEARCH);
   hipLaunchKernelGGL(k_per_search, dim3(gridn(B)), dim3(256), 0, c->stream, source->cumsum, source->priorities, source->pminmax, N, B, (const double*)d_r,
-                     (uint64_t)0x5EED5A3Full, i, beta, target->d_indices, (float*)source->col[CRUX_COL_WEIGHT]);
+                     source->sample_seed, source->sample_stream, i, beta, target->d_indices, (float*)source->col[CRUX_COL_WEIGHT]);
   crux_prof_end(c, CRUX_PROF_PER_SEARCH);
   rc = crux_launch_check(c, "k_per_search"); if (rc) return rc;
   return gather_into(target, source, B, true);
@@ -269,8 +269,14 @@ int32_t crux_uniform_sample(crux_buffer* target, crux_buffer* source, int64_t B,
   if (target->obs_dim != source->obs_dim || target->act_dim != source->act_dim || target->act_kind != source->act_kind) return crux_fail(c, CRUX_EINVAL, "uniform_sample!: column shapes differ");
   if (ids) { for (int64_t j = 0; j < B; ++j) if (ids[j] < 0 || ids[j] >= N) return crux_fail(c, CRUX_EINVAL, "uniform_sample!: id %lld out of range", (long long)ids[j]);
     HIPCHK(c, hipMemcpyAsync(target->d_indices, ids, 8 * (size_t)B, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
-  else hipLaunchKernelGGL(k_uniform_ids, dim3(gridn(B)), dim3(256), 0, c->stream, N, B, (uint64_t)0x5EED5A3Full, i, target->d_indices);
+  else hipLaunchKernelGGL(k_uniform_ids, dim3(gridn(B)), dim3(256), 0, c->stream, N, B, source->sample_seed, source->sample_stream, i, target->d_indices);
   return gather_into(target, source, B, true);
+}
+
+// Philox key and stream of the sampling draws taken FROM this buffer (rand!, experience_buffer.jl:303-315 draws each source independently)
+int32_t crux_buffer_set_sample_stream(crux_buffer* source, uint64_t seed, uint32_t stream) {
+  if (!source) return CRUX_EINVAL;
+  source->sample_seed = seed; source->sample_stream = stream; return CRUX_OK;
 }
 
 int32_t crux_per_get(crux_buffer* b, float* priorities, float* max_priority, float* min_priority, float* cumsum) {

@@ -173,6 +173,9 @@ int32_t crux_per_sample(crux_buffer* target, crux_buffer* source, int64_t B, con
 /* uniform_sample!(target, source; B) (:317-321): `ids` host array or NULL => Philox draw.          */
 int32_t crux_uniform_sample(crux_buffer* target, crux_buffer* source, int64_t B, const int64_t* ids,
                             uint64_t i);
+/* The Philox draws of both samplers are crux_philox(seed, i*B + j, stream, CRUX_RNG_SAMPLE) (crux_rng.h) with the SOURCE buffer's key and stream
+ * (defaults 0x5EED5A3F, 0): rand!(target, sources...) (:303-315) samples every source with an independent draw, so sources get distinct streams. */
+int32_t crux_buffer_set_sample_stream(crux_buffer* source, uint64_t seed, uint32_t stream);
 int32_t crux_per_get(crux_buffer* b, float* priorities /*capacity or NULL*/, float* max_priority,
                      float* min_priority, float* cumsum /*len or NULL*/);
 
@@ -201,7 +204,8 @@ int32_t crux_env_get_state(crux_env* env, double* state, int64_t* episode_length
 int32_t crux_env_state_dim(const crux_env* env);
 
 typedef struct {
-  int32_t explore;        /* steps!(...; explore=) (:139)                                          */
+  int32_t explore;        /* steps!(...; explore=) (:139); 2 = explore=false with an always_stochastic policy:
+                             action(pi, s) = exploration(pi, s)[1] (policies.jl:124), logprob stored as NaN       */
   int32_t reset_at_end;   /* steps!(...; reset=)   (:148)                                          */
   int32_t head;           /* CRUX_HEAD_*                                                           */
   /* MixedPolicy / eps-greedy (policies.jl:466-494): eps(i)=max(stop, start - i*(start-stop)/steps)
@@ -239,6 +243,14 @@ int32_t crux_env_step_host(crux_ctx* ctx, int32_t kind, int64_t n, const double*
 int32_t crux_fill_gae(crux_buffer* b, crux_mlp* critic, float lambda, float gamma);
 /* fill_returns! for every episode of the buffer (sampler.jl:275-281).                             */
 int32_t crux_fill_returns(crux_buffer* b, float gamma);
+/* fill_gae!(data, ep, ...) / fill_returns!(data, ep, gamma) as terminate_episode! applies them to the block a steps! call produced (sampler.jl:53-57):
+ * the same scans restricted to the ring rows [first_row, first_row + n_rows) mod capacity the block was pushed to, whatever else the buffer holds.
+ * close_last = steps!(...; reset=true) (:148): the block's last row closes an episode; otherwise the rows of an episode still open at the end of
+ * the block get 0, the value mdp_data gave them in the reference's fresh `data` (experience_buffer.jl:14-16).
+ * rows_per_env: env-major blocks hold environment e in rows [e*rows_per_env, (e+1)*rows_per_env) of the block; episodes never cross that boundary
+ * (0 = the block is one environment's).                                                                                                          */
+int32_t crux_fill_gae_rows(crux_buffer* b, crux_mlp* critic, float lambda, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last);
+int32_t crux_fill_returns_rows(crux_buffer* b, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last);
 /* b[key] .= whiten(b[key]) (utils.jl:41-42; PPO post_batch_callback ppo.jl:61). Bessel-corrected. */
 int32_t crux_whiten(crux_buffer* b, int32_t key);
 

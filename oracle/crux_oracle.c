@@ -174,6 +174,7 @@ struct orc_buffer {
   int prioritized; float alpha;
   float* priorities; float* cumsum; int cumsum_valid; float max_priority, min_priority;
   int64_t* indices; int64_t n_indices;
+  uint32_t sample_stream;   /* Philox stream of the draws that sample FROM this buffer (crux_buffer_set_sample_stream) */
 };
 
 static int col_elem(const orc_buffer* b, int k) {
@@ -405,7 +406,7 @@ int32_t orc_per_sample(orc_buffer* target, orc_buffer* source, int64_t B, const 
   for (int64_t j = 0; j < B; ++j) {
     double u;
     if (rands) u = rands[j];
-    else { crux_u32x4 x = crux_philox(seed, i * (uint64_t)B + (uint64_t)j, 0, CRUX_RNG_SAMPLE); u = crux_u32x2_to_f64(x.v[0], x.v[1]); }
+    else { crux_u32x4 x = crux_philox(seed, i * (uint64_t)B + (uint64_t)j, source->sample_stream, CRUX_RNG_SAMPLE); u = crux_u32x2_to_f64(x.v[0], x.v[1]); }
     double key = ((double)(j + 1) + u - 1.0) * (double)dp;                      /* :340 (j + rands[j] - 1) * dp */
     int64_t idx = searchsortedfirst_f32_f64(source->cumsum, N, key);
     if (idx >= N) idx = N - 1;   /* the reference would index out of bounds; clamp and document */
@@ -425,12 +426,14 @@ int32_t orc_uniform_sample(orc_buffer* target, orc_buffer* source, int64_t B, co
   if (N <= 0 || B <= 0 || B > target->capacity) return CRUX_EINVAL;
   for (int64_t j = 0; j < B; ++j) {
     if (ids) target->indices[j] = ids[j];
-    else { crux_u32x4 x = crux_philox(seed, i * (uint64_t)B + (uint64_t)j, 0, CRUX_RNG_SAMPLE);
+    else { crux_u32x4 x = crux_philox(seed, i * (uint64_t)B + (uint64_t)j, source->sample_stream, CRUX_RNG_SAMPLE);
       target->indices[j] = (int64_t)(((uint64_t)x.v[0] * (uint64_t)N) >> 32); }
   }
   target->n_indices = B;
   return orc_buffer_push_buffer(target, source, target->indices, B, NULL);
 }
+
+int32_t orc_buffer_set_sample_stream(orc_buffer* b, uint32_t stream) { b->sample_stream = stream; return CRUX_OK; }
 
 int32_t orc_per_get(orc_buffer* b, float* pr, float* maxp, float* minp, float* cs) {
   if (!b->prioritized) return CRUX_EINVAL;
@@ -693,6 +696,7 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
       else memcpy((float*)buf->col[CRUX_COL_A] + (size_t)j * ad, aout, 4 * (size_t)ad);
       memcpy(SP + (size_t)j * od, spv, 4 * (size_t)od);
       R[j] = r; D[j] = done; EE[j] = 0;
+      if (cfg->explore == 2) logprob = NAN;   /* action(pi, s) of an always_stochastic policy = exploration(pi, s)[1] (policies.jl:124), logprob NaN (sampler.jl:73) */
       if (LP) LP[j] = logprob;
       if (TT) TT[j] = e->ep_len[k] + 1;
       if (II) II[j] = (int64_t)gi + 1;

@@ -70,6 +70,7 @@ void orc_circ_inds(int64_t start0, int64_t n, int64_t C, int64_t* out);
 int32_t orc_per_update(orc_buffer* b, const int64_t* I, const void* v, int32_t v_is_f64, int64_t n);
 int32_t orc_per_sample(orc_buffer* target, orc_buffer* source, int64_t B, const double* rands, float beta, uint64_t i, uint64_t seed);
 int32_t orc_uniform_sample(orc_buffer* target, orc_buffer* source, int64_t B, const int64_t* ids, uint64_t i, uint64_t seed);
+int32_t orc_buffer_set_sample_stream(orc_buffer* b, uint32_t stream);
 int32_t orc_per_get(orc_buffer* b, float* priorities, float* max_priority, float* min_priority, float* cumsum);
 void orc_pairwise_cumsum_f32(const float* v, int64_t n, float* out);
 

@@ -28,7 +28,7 @@ _SIG = {
     "orc_buffer_indices": (i32, [vp, vp, i64]), "orc_buffer_episodes": (i64, [vp, vp, vp, i64]), "orc_split_batches": (None, [i64, vp, i32, vp]),
     "orc_circ_inds": (None, [i64, i64, i64, vp]), "orc_per_update": (i32, [vp, vp, vp, i32, i64]),
     "orc_per_sample": (i32, [vp, vp, i64, vp, f32, u64, u64]), "orc_uniform_sample": (i32, [vp, vp, i64, vp, u64, u64]),
-    "orc_per_get": (i32, [vp, vp, P(f32), P(f32), vp]), "orc_pairwise_cumsum_f32": (None, [vp, i64, vp]),
+    "orc_per_get": (i32, [vp, vp, P(f32), P(f32), vp]), "orc_buffer_set_sample_stream": (i32, [vp, u32]), "orc_pairwise_cumsum_f32": (None, [vp, i64, vp]),
     "orc_env_create": (vp, [i32, i32, i32, f32, vp, vp, u64, i32, i32]), "orc_env_destroy": (None, [vp]), "orc_env_obs_dim": (i32, [vp]),
     "orc_env_act_dim": (i32, [vp]), "orc_env_state_dim": (i32, [vp]), "orc_env_reset": (i32, [vp]), "orc_env_get_state": (i32, [vp, vp, vp, vp]),
     "orc_rollout": (i32, [vp, vp, P(L.RolloutCfg), vp, i64, P(f64), P(i64)]), "orc_env_step_host": (i32, [i32, i64, vp, vp, vp, vp, vp, vp, vp]),

@@ -65,24 +65,45 @@ def compare_buffers(gb, ob, keys=None, atol=2e-5, rtol=1e-4):
     return out
 
 
-def ppo_iteration_parity(n_envs=4, T=64, batch_size=32, epochs=2, seed=3, max_steps=50, target_kl=-1.0, gamma=0.99, lam=0.95, pair=False):
+FAMILIES = {
+    # name: (obs, act, discrete, actor dims, critic dims, activations, policy kind, head, oracle env kind)
+    "cartpole": (4, 2, True, ACTOR_DIMS, CRITIC_DIMS, ACTS, "discrete", "categorical", "cartpole"),
+    # C5-shaped (BASELINE configs[4]): 17 observations / 6 continuous actions, tanh 17->64->64->6 GaussianPolicy + critic, SYNTH dynamics (cruxhip.h)
+    "synth_c5": (17, 6, False, [17, 64, 64, 6], [17, 64, 64, 1], ["tanh", "tanh", "identity"], "gaussian", "gaussian", "synth"),
+}
+
+
+def param_tol(steps):
+    """Stated bound on |theta_gpu - theta_oracle| (abs, parameters are O(0.1-1)) after `steps` consecutive Adam steps of the persistent learner
+    kernels against the oracle's Float64-Adam restatement: 1e-6 up to 64 steps, then growing linearly with the step count (each step adds at
+    most a few f32 ulps of lr-sized updates: v_rcp/v_sqrt bias corrections and MFMA-vs-scalar summation order), 4e-9 per step beyond 64."""
+    return 1e-6 + 4e-9 * max(0, steps - 64)
+
+
+def ppo_iteration_parity(n_envs=4, T=64, batch_size=32, epochs=2, seed=3, max_steps=50, target_kl=-1.0, gamma=0.99, lam=0.95, pair=False,
+                         family="cartpole", logsigma=-0.5):
     """One full PPO iteration (rollout -> GAE/returns -> whiten -> actor batch_train! -> critic batch_train!) on the GPU
     and in the oracle with the same Philox-defined randomness; returns the differences."""
+    od, ad, disc, adims, cdims, acts, kind, head, okind = FAMILIES[family]
     N = n_envs * T
     extras = ["return", "logprob", "advantage"]
-    ga, oa = make_pair(ACTOR_DIMS, ACTS, seed, 0, "discrete")
-    gc, oc = make_pair(CRITIC_DIMS, ACTS, seed, 1)
+    ga, oa = make_pair(adims, acts, seed, 0, kind, n_extra=0 if disc else ad, extra_init=logsigma)
+    gc, oc = make_pair(cdims, acts, seed, 1)
     res = {"init_params_equal": bool(np.array_equal(ga.get_params(), oa.params) and np.array_equal(gc.get_params(), oc.params))}
-    S, A = crux.ContinuousSpace(4), crux.DiscreteSpace(2)
+    S, A = crux.ContinuousSpace(od), (crux.DiscreteSpace(ad) if disc else crux.ContinuousSpace(ad))
     gb = crux.ExperienceBuffer(S, A, N, extras)
-    ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, N, extras)
-    mdp = crux.CartPoleMDP(n_envs=n_envs, seed=seed, discount=gamma)
+    ob = O.OBuffer(od, ad, L.ACTION_DISCRETE if disc else L.ACTION_CONTINUOUS, N, extras)
+    if family == "cartpole":
+        mdp = crux.CartPoleMDP(n_envs=n_envs, seed=seed, discount=gamma)
+        oe = O.OEnv("cartpole", n_envs, max_steps, gamma, seed)
+    else:
+        mdp = crux.SynthMDP(od, ad, discrete=disc, n_envs=n_envs, seed=seed, discount=gamma)
+        oe = O.OEnv(okind, n_envs, max_steps, gamma, seed, so=od, sa=ad)
     pi = crux.ActorCritic(ga, gc)
     gs = crux.Sampler(mdp, pi, max_steps=max_steps, required_columns=extras, lam=lam)
-    oe = O.OEnv("cartpole", n_envs, max_steps, gamma, seed)
     # rollout
     ginfo = crux.steps_(gs, gb, Nsteps=N, explore=True, i=0, reset=True)
-    osr, one = oe.rollout(oa, rollout_cfg(), ob, T)
+    osr, one = oe.rollout(oa, rollout_cfg(head=head), ob, T)
     O.chk(O.lib().orc_fill_gae(ob.h, oc.h, lam, gamma)); O.chk(O.lib().orc_fill_returns(ob.h, gamma))
     res["rollout"] = compare_buffers(gb, ob)
     res["sum_r"] = (ginfo["sum_r"], osr); res["n_episode_end"] = (ginfo["n_episode_end"], one)
@@ -102,7 +123,7 @@ def ppo_iteration_parity(n_envs=4, T=64, batch_size=32, epochs=2, seed=3, max_st
     else:
         gi = crux.batch_train_(ga, a_opt, P, gb)
     oinfo = np.zeros(L.INFO_N, np.float32)
-    cfg_a = train_cfg("ppo", "categorical", batch_size, epochs, target_kl, seed + 100)
+    cfg_a = train_cfg("ppo", head, batch_size, epochs, target_kl, seed + 100)
     O.chk(O.lib().orc_batch_train(oa.h, ob.h, C.byref(cfg_a), None, O.vpz(oinfo), None))
     res["actor_param_maxdiff"] = float(np.abs(ga.get_params() - oa.params).max())
     res["actor_info"] = {k: (gi.get(k if k in gi else "actor_" + k), float(oinfo[L.INFO[k]])) for k in ("loss", "grad_norm", "kl", "entropy")}
@@ -115,15 +136,24 @@ def ppo_iteration_parity(n_envs=4, T=64, batch_size=32, epochs=2, seed=3, max_st
     O.chk(O.lib().orc_batch_train(oc.h, ob.h, C.byref(cfg_c), None, O.vpz(oinfo2), None))
     res["critic_param_maxdiff"] = float(np.abs(gc.get_params() - oc.params).max())
     res["critic_info"] = {"loss": (gi2["critic_loss"], float(oinfo2[0])), "grad_norm": (gi2["critic_grad_norm"], float(oinfo2[1]))}
+    res["critic_batches"] = (gi2["critic_batches_trained"], int(oinfo2[L.INFO["batches_trained"]]))
+    # tolerances: integer / Bool columns bit-exact; observations and rewards come out of the float64 dynamics and round
+    # identically (<= 1 ulp of O(1) values); log-probabilities differ by the exp/log implementations (<= 2e-6); advantages / returns are
+    # T-long recurrences over critic values whose MFMA-free but differently ordered dot products differ by ~1e-6 relative: 2e-5 abs on O(10).
+    res["param_tol"] = (param_tol(res["actor_batches"][1]), param_tol(res["critic_batches"][1]))
     ok = res["init_params_equal"]
-    ok &= all(v == 0 for k, v in res["rollout"].items() if k in ("a", "done", "episode_end"))
-    ok &= all(v < 2e-4 for k, v in res["rollout"].items() if k in ("s", "sp", "r", "logprob", "advantage", "return"))
-    ok &= res["whiten"]["advantage"] < 2e-4
-    ok &= res["actor_param_maxdiff"] < 2e-4 and res["critic_param_maxdiff"] < 2e-4
-    ok &= res["actor_batches"][0] == res["actor_batches"][1]
+    ok &= all(v == 0 for k, v in res["rollout"].items() if k in ("a", "done", "episode_end")) if disc else all(v == 0 for k, v in res["rollout"].items() if k in ("done", "episode_end"))
+    ok &= all(v < 2e-6 for k, v in res["rollout"].items() if k in ("s", "sp", "r") or (k == "a" and not disc))
+    ok &= res["rollout"]["logprob"] < 4e-6 and res["rollout"]["advantage"] < 5e-5 and res["rollout"]["return"] < 5e-5
+    ok &= res["whiten"]["advantage"] < 2e-5
+    ok &= res["actor_param_maxdiff"] < res["param_tol"][0] and res["critic_param_maxdiff"] < res["param_tol"][1]
+    ok &= res["actor_batches"][0] == res["actor_batches"][1] and res["critic_batches"][0] == res["critic_batches"][1]
+    for k in ("loss", "grad_norm", "kl", "entropy"):
+        g_, o_ = res["actor_info"][k]
+        ok &= abs(g_ - o_) < 2e-5 * max(1.0, abs(o_))
     res["order_after_critic"] = compare_buffers(gb, ob, ["s", "a", "advantage"])
-    ok &= res["order_after_critic"]["a"] == 0 and res["order_after_critic"]["s"] < 2e-5
+    ok &= (res["order_after_critic"]["a"] == 0 if disc else res["order_after_critic"]["a"] < 2e-6) and res["order_after_critic"]["s"] < 2e-6
     if not pair:
-        ok &= res["order_after_actor"]["a"] == 0 and res["order_after_actor"]["s"] < 2e-5
+        ok &= (res["order_after_actor"]["a"] == 0 if disc else res["order_after_actor"]["a"] < 2e-6) and res["order_after_actor"]["s"] < 2e-6
     res["ok"] = bool(ok)
     return res

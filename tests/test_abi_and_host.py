@@ -84,6 +84,7 @@ def test_bson_buffer_round_trip_host_side(tmp_path):
 
     class FakeBuf:
         next_ind = 1
+        total_count = 2 * n - 3                       # not equal to elements: push_reservoir! counts what it has SEEN (experience_buffer.jl:262-288)
         cols = {"s": rng.normal(0, 1, (4, n)).astype(np.float32), "a": np.eye(2, dtype=bool)[:, rng.integers(0, 2, n)], "sp": rng.normal(0, 1, (4, n)).astype(np.float32),
                 "r": np.ones((1, n), np.float32), "done": rng.random((1, n)) < 0.1, "t": np.arange(1, n + 1, dtype=np.int64)[None, :]}
         extra = {"expert_val": rng.normal(0, 1, (1, n)).astype(np.float32)}
@@ -93,7 +94,9 @@ def test_bson_buffer_round_trip_host_side(tmp_path):
     fb = FakeBuf(); path = str(tmp_path / "buf.bson")
     bson.save_buffer(fb, path)
     cols, meta = bson.read_columns(path)
-    assert meta["elements"] == n and meta["next_ind"] == 1 and meta["priority_params"] is None
+    assert meta["elements"] == n and meta["next_ind"] == 1 and meta["priority_params"] is None and meta["total_count"] == 2 * n - 3
+    # struct field count = the reference's ExperienceBuffer (data, elements, next_ind, indices, priority_params, total_count; experience_buffer.jl:53-60)
+    assert len(bson._parse(open(path, "rb").read())["data"]["data"]) == 6
     for k, v in {**fb.cols, **fb.extra}.items():
         assert cols[k].dtype == v.dtype and np.array_equal(cols[k], v), k
 

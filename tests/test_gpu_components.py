@@ -511,6 +511,7 @@ def test_dqn_solve_matches_oracle_loop(gpu_ctx, prioritized):
                 O.chk(O.lib().orc_td_error(o.h, obt.h, O.vpz(y), O.vpz(err))); O.chk(O.lib().orc_buffer_indices(obt.h, O.vpz(ids), B))
                 O.chk(O.lib().orc_per_update(ob.h, O.vpz(ids), O.vpz(err), 0, B))
             O.chk(O.lib().orc_td_step(o.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+            last_losses = ([] if ep == 0 else last_losses) + [float(info[0])]
         O.chk(O.lib().orc_polyak(ot.h, o.h, 0.005))
         i += dN
     assert solver.i == i and len(buf) == len(ob)
@@ -518,7 +519,8 @@ def test_dqn_solve_matches_oracle_loop(gpu_ctx, prioritized):
         assert np.array_equal(buf[k], ob[k]), k                                          # same trajectories into the same ring slots
     assert np.abs(g.get_params() - o.params).max() < 2e-5
     assert np.abs(solver.agent.pi_minus.get_params() - ot.params).max() < 2e-5
-    assert abs(solver.history[-1]["critic_loss"] - info[0]) < 1e-3 * max(1, abs(info[0])) or True
+    ref_loss = float(np.mean(last_losses))                                              # aggregate_info over the last value_training call's epochs (logging.jl:60-66)
+    assert abs(solver.history[-1]["critic_loss"] - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
     if prioritized:
         pg = buf.priority_params(); pr = np.empty(cap, np.float32); mx, mn = C.c_float(), C.c_float()
         O.chk(O.lib().orc_per_get(ob.h, O.vpz(pr), C.byref(mx), C.byref(mn), None))
@@ -573,6 +575,7 @@ def test_softq_target_and_solve_match_oracle(gpu_ctx):
             O.chk(O.lib().orc_uniform_sample(obt.h, ob.h, B, None, i * dN + ep, crux.api.SAMPLE_SEED))
             O.chk(O.lib().orc_softq_target(ot.h, obt.h, 0.95, alpha, O.vpz(y)))
             O.chk(O.lib().orc_td_step(o.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+            last_losses = ([] if ep == 0 else last_losses) + [float(info[0])]
         O.chk(O.lib().orc_polyak(ot.h, o.h, 0.005))
         i += dN
     assert solver.i == i and len(solver.buffer) == len(ob)

@@ -1,0 +1,129 @@
+"""GPU parity for the round-2 host/ABI fixes: block-local GAE fill in a larger ring, push!'s max_priority snapshot, rand!'s beta(i) and
+per-source draws, action() of always_stochastic policies."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity
+from parity import L, O, crux
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("reset", [True, False])
+def test_steps_fills_gae_on_the_pushed_block_of_a_larger_ring(gpu_ctx, reset):
+    """steps! computes GAE / returns on the fresh rollout block before push! (src/sampler.jl:53-57,140-152), whatever the destination holds:
+    three rollouts of 4 envs x 24 steps into a ring of 250 rows (the third wraps) must equal the oracle's per-block fill, and the rows of
+    earlier blocks must keep their values."""
+    E, T, seed, cap = 4, 24, 6, 250
+    N = E * T
+    extras = ["return", "logprob", "advantage"]
+    ga, oa = parity.make_pair(parity.ACTOR_DIMS, parity.ACTS, seed, 0, "discrete")
+    gc, oc = parity.make_pair(parity.CRITIC_DIMS, parity.ACTS, seed, 1)
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), cap, extras)
+    gs = crux.Sampler(crux.CartPoleMDP(n_envs=E, seed=seed), crux.ActorCritic(ga, gc), max_steps=15, required_columns=extras, lam=0.95)
+    oe = O.OEnv("cartpole", E, 15, 0.99, seed)
+    ring = {k: np.zeros((1, cap), np.float32) for k in ("advantage", "return")}
+    ee_ring = np.zeros(cap, bool)
+    for it in range(3):
+        first = gb.next_ind - 1
+        crux.steps_(gs, gb, Nsteps=N, explore=True, i=it * N, reset=reset)
+        ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, N, extras)          # the reference's fresh `data` block
+        cfg = parity.rollout_cfg(True, reset, "categorical", i0=it * N)
+        oe.rollout(oa, cfg, ob, T)
+        ee = ob["episode_end"][0].copy()
+        adv, ret = np.zeros(N, np.float32), np.zeros(N, np.float32)
+        # per-environment segments: terminate_episode! fills the episodes that ended inside the block; open tails stay 0 (mdp_data zeros)
+        Vs, Vsp = oc.forward(ob["s"])[0], oc.forward(ob["sp"])[0]
+        r, done_u8 = np.ascontiguousarray(ob["r"][0]), np.ascontiguousarray(ob["done"][0]).view(np.uint8)
+        Vs, Vsp = np.ascontiguousarray(Vs), np.ascontiguousarray(Vsp)
+        for e in range(E):
+            lo = e * T; start = lo
+            for j in range(lo, lo + T):
+                if ee[j]:
+                    O.lib().orc_gae_range(O.vpz(r), O.vpz(done_u8), O.vpz(Vs), O.vpz(Vsp), start, j, 0.95, 0.99, O.vpz(adv))
+                    O.lib().orc_returns_range(O.vpz(r), start, j, 0.99, O.vpz(ret))
+                    start = j + 1
+        idx = (first + np.arange(N)) % cap
+        ring["advantage"][0, idx] = adv; ring["return"][0, idx] = ret; ee_ring[idx] = ee
+        n = len(gb)
+        assert np.array_equal(gb["episode_end"][0][idx[idx < n]], ee[idx < n])
+        assert np.abs(gb["advantage"][0] - ring["advantage"][0, :n]).max() < 5e-5, it
+        assert np.abs(gb["return"][0] - ring["return"][0, :n]).max() < 5e-5, it
+    assert len(gb) == cap and gb.next_ind - 1 == (3 * N) % cap
+
+
+def test_push_gives_every_new_row_the_same_snapshotted_max_priority(gpu_ctx):
+    """push!: update_priorities!(b, I, max_priority*ones(N)) (src/experience_buffer.jl:254): all N rows get (m + eps)^alpha for the m read BEFORE the
+    call, and max_priority rises once per push -- bit-exact against the oracle over repeated large pushes (many waves racing on the atomic max)."""
+    rng = np.random.default_rng(3); cap, n = 200_000, 60_000
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(2), crux.DiscreteSpace(2), cap, prioritized=True)
+    ob = O.OBuffer(2, 2, L.ACTION_DISCRETE, cap, ["weight"], prioritized=True, alpha=np.float32(0.6))
+    for rep in range(5):
+        d = {"s": rng.normal(0, 1, (2, n)).astype(np.float32), "sp": rng.normal(0, 1, (2, n)).astype(np.float32), "a": np.eye(2, dtype=bool)[:, rng.integers(0, 2, n)],
+             "r": np.ones((1, n), np.float32), "done": np.zeros((1, n), bool)}
+        I = gb.push_(d); ob.push(d)
+        pg = gb.priority_params(); pr = np.empty(cap, np.float32); mx, mn = C.c_float(), C.c_float()
+        O.chk(O.lib().orc_per_get(ob.h, O.vpz(pr), C.byref(mx), C.byref(mn), None))
+        assert np.unique(pg["priorities"][I - 1]).size == 1                  # one value for the whole push
+        assert np.array_equal(pg["priorities"], pr) and pg["max_priority"] == mx.value and pg["min_priority"] == mn.value, rep
+
+
+def test_rand_evaluates_beta_at_i_and_draws_sources_independently(gpu_ctx):
+    """rand!(target, sources...; i) (src/experience_buffer.jl:303-315): beta(i) with the caller's i (not the draw counter), and each source gets its own draw."""
+    rng = np.random.default_rng(8); n = 400
+    S, A = crux.ContinuousSpace(1), crux.DiscreteSpace(2)
+    calls = []
+    def beta(i):
+        calls.append(i); return 0.4 + 0.001 * i
+    def filled(prioritized, pp=None):
+        b = crux.ExperienceBuffer(S, A, n, prioritized=prioritized, priority_params=pp)
+        b.push_({"s": np.arange(n, dtype=np.float32)[None, :], "sp": np.zeros((1, n), np.float32), "a": np.eye(2, dtype=bool)[:, rng.integers(0, 2, n)],
+                 "r": np.zeros((1, n), np.float32), "done": np.zeros((1, n), bool)})
+        return b
+    src = filled(True, {"alpha": 0.6, "beta": beta})
+    src.update_priorities_(np.arange(1, n + 1), rng.random(n).astype(np.float32) + 0.1)
+    tgt = crux.buffer_like(src, capacity=64)
+    crux.rand_(tgt, src, i=123, counter=999_999)
+    assert calls and set(calls) == {123}
+    osrc = O.OBuffer(1, 2, L.ACTION_DISCRETE, n, ["weight"], prioritized=True, alpha=np.float32(0.6)); otgt = O.OBuffer(1, 2, L.ACTION_DISCRETE, 64, ["weight"], prioritized=True, alpha=np.float32(0.6))
+    osrc.push({k: src[k] for k in ("s", "sp", "a", "r", "done")})
+    # replay the identical update on the oracle (same rng stream)
+    rng2 = np.random.default_rng(8); rng2.integers(0, 2, n); v = rng2.random(n).astype(np.float32) + 0.1
+    O.chk(O.lib().orc_per_update(osrc.h, O.vpz(np.arange(n, dtype=np.int64)), O.vpz(v), 0, n))
+    O.chk(O.lib().orc_per_sample(otgt.h, osrc.h, 64, None, np.float32(0.4 + 0.123), 999_999, crux.api.SAMPLE_SEED))
+    oi = np.empty(64, np.int64); O.chk(O.lib().orc_buffer_indices(otgt.h, O.vpz(oi), 64))
+    assert np.array_equal(tgt.indices[:64], oi)
+    assert np.allclose(src["weight"], osrc["weight"], rtol=2e-6, atol=0)
+    # two uniform sources of equal length: before the fix both halves held the same row numbers
+    u1, u2 = filled(False), filled(False)
+    t2 = crux.ExperienceBuffer(S, A, 128)
+    crux.rand_(t2, u1, u2, i=5)
+    rows = t2["s"][0]
+    assert not np.array_equal(rows[:64], rows[64:])
+    o1 = O.OBuffer(1, 2, L.ACTION_DISCRETE, n); o2 = O.OBuffer(1, 2, L.ACTION_DISCRETE, n); ot = O.OBuffer(1, 2, L.ACTION_DISCRETE, 128)
+    o1.push({k: u1[k] for k in ("s", "sp", "a", "r", "done")}); o2.push({k: u2[k] for k in ("s", "sp", "a", "r", "done")})
+    O.chk(O.lib().orc_buffer_set_sample_stream(o1.h, 0)); O.chk(O.lib().orc_buffer_set_sample_stream(o2.h, 1))
+    O.chk(O.lib().orc_uniform_sample(ot.h, o1.h, 64, None, 5, crux.api.SAMPLE_SEED)); O.chk(O.lib().orc_uniform_sample(ot.h, o2.h, 64, None, 5, crux.api.SAMPLE_SEED))
+    assert np.array_equal(t2["s"], ot["s"])
+
+
+def test_action_of_an_always_stochastic_policy_samples_with_nan_logprob(gpu_ctx):
+    """action(pi::DiscreteNetwork, s) = always_stochastic ? exploration(pi, s)[1] : argmax (src/policies.jl:124); step! stores logprob NaN for
+    explore=false (src/sampler.jl:73). SoftQ's evaluation rollouts go through this path."""
+    E, T, seed = 6, 20, 12
+    g, o = parity.make_pair([4, 32, 2], ["relu", "identity"], seed, 0, "discrete")
+    g.always_stochastic, g.logit_div = True, 0.7
+    extras = ["logprob"]
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), E * T, extras)
+    ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, E * T, extras)
+    gs = crux.Sampler(crux.CartPoleMDP(n_envs=E, seed=seed), g, max_steps=50)
+    crux.steps_(gs, gb, Nsteps=E * T, explore=False, i=0, reset=True)
+    cfg = parity.rollout_cfg(False, True, "categorical"); cfg.explore = 2; cfg.logit_div = 0.7
+    O.OEnv("cartpole", E, 50, 0.99, seed).rollout(o, cfg, ob, T)
+    assert np.array_equal(gb["a"], ob["a"]) and np.isnan(gb["logprob"]).all() and np.isnan(ob["logprob"]).all()
+    greedy = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), E * T, extras)
+    g.always_stochastic = False
+    crux.steps_(crux.Sampler(crux.CartPoleMDP(n_envs=E, seed=seed), g, max_steps=50), greedy, Nsteps=E * T, explore=False, i=0, reset=True)
+    assert not np.array_equal(greedy["a"], gb["a"])                       # sampling differs from argmax on this seed
