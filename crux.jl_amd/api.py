@@ -56,6 +56,22 @@ class Context:
     def comm_size(self):
         return int(self.lib.crux_comm_size(self.h))
 
+    # ---- replica group with direct peer slots: in-kernel SUM all-reduce of every minibatch gradient over xGMI (cruxhip.h) ----------------
+    def peer_export(self):
+        """64-byte IPC handle of this context's peer region; every rank ships its handle to every other rank."""
+        b = np.zeros(64, np.uint8); self.check(self.lib.crux_peer_export(self.h, _vp(b))); return b
+
+    def peer_attach(self, rank, nranks, handles):
+        """handles: (nranks, 64) uint8, row r = rank r's peer_export(). All ranks must have attached before any of them trains."""
+        h = np.ascontiguousarray(np.asarray(handles, np.uint8).reshape(int(nranks), 64))
+        self.check(self.lib.crux_peer_attach(self.h, int(rank), int(nranks), _vp(h)))
+
+    def peer_detach(self):
+        self.check(self.lib.crux_peer_detach(self.h))
+
+    def peer_size(self):
+        return int(self.lib.crux_peer_size(self.h))
+
     def sync(self):
         self.check(self.lib.crux_sync(self.h))
 
@@ -91,6 +107,15 @@ class Context:
         if self.h:
             self.lib.crux_ctx_destroy(self.h)
             self.h = None
+
+
+def peer_attach_local(contexts):
+    """Wire the contexts of ONE process into a replica group (contexts[r] = rank r): a multi-GPU single-process host, or replicas sharing a device."""
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    rc = contexts[0].lib.crux_peer_attach_local(arr, len(contexts))
+    for c in contexts:
+        if rc != 0:
+            c.check(rc)
 
 
 def default_context():
@@ -226,6 +251,11 @@ class NetworkPolicy:
         m, v, bp = np.empty(self.n_params, np.float32), np.empty(self.n_params, np.float32), np.empty(2, np.float64)
         self.ctx.check(self.ctx.lib.crux_adam_get_state(self.h, _vp(m), _vp(v), _vp(bp)))
         return m, v, bp
+
+    def set_adam_state(self, m, v, beta_pow):
+        """Load Adam's (m, v, [beta1^t, beta2^t]) -- the IdDict entry Flux keeps per parameter array (checkpoint restore, parity tests)."""
+        m, v, bp = np.ascontiguousarray(m, np.float32), np.ascontiguousarray(v, np.float32), np.ascontiguousarray(beta_pow, np.float64)
+        self.ctx.check(self.ctx.lib.crux_adam_set_state(self.h, _vp(m), _vp(v), _vp(bp)))
 
     def __del__(self):
         try:

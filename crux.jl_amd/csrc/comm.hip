@@ -94,6 +94,89 @@ int32_t crux_allreduce_grads(crux_mlp* net) {
   RCCLCHK(c, api, api->AllReduce(net->g, net->g, (size_t)net->nd.n_params, ncclFloat, ncclSum, (ncclComm_t)c->comm, c->stream));
   return CRUX_OK;
 }
+// ---- replica group with direct peer slots ------------------------------------------------------------------------------------------
+// The exchange step of the data-parallel path: a SUM all-reduce of the flattened minibatch gradient (C5 actor: 22.8 KB) before
+// Adam, every minibatch. At that size a ring/tree collective is pure latency, and the learner is a persistent kernel that cannot return to
+// the host between steps, so the all-reduce is done BY the kernel: every rank owns a fine-grained region; rank r writes its local gradient
+// into slot [parity][r] of every peer's region over xGMI (one hop, fully connected), raises flag[r] there, waits for the N-1 flags in its own
+// region and adds the N contributions in rank order -- every rank forms the same sum bit for bit, so parameters and Adam state stay
+// replicated without ever being exchanged. These entries only set the regions up; the protocol itself is in train_mfma_x2.hip.
+int32_t crux_make_streams_concurrent(crux_ctx* const* ctxs, int n);   // train.hip
+int crux_x2_placement_ok(crux_ctx* c);                                  // train_mfma_x2.hip
+static int32_t peer_region(crux_ctx* c) {
+  if (c->peer_local) return CRUX_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  void* p = nullptr;
+  if (!getenv("CRUX_PEER_COARSE") && hipExtMallocWithFlags(&p, CRUX_PX_BYTES, hipDeviceMallocFinegrained) == hipSuccess) c->peer_fine = true;
+  else { (void)hipGetLastError(); c->peer_fine = false; if (hipMalloc(&p, CRUX_PX_BYTES) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "peer region (%zu bytes)", (size_t)CRUX_PX_BYTES); }
+  HIPCHK(c, hipMemset(p, 0, CRUX_PX_BYTES));
+  HIPCHK(c, hipDeviceSynchronize());
+  c->peer_local = p; return CRUX_OK;
+}
+// a new group starts from exchange 0 with clean flags (a previous group may have ended on a timeout); legal because no peer writes here before
+// every rank has attached
+static int32_t peer_reset(crux_ctx* c) {
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemset(c->peer_local, 0, CRUX_PX_BYTES)); HIPCHK(c, hipDeviceSynchronize()); return CRUX_OK;
+}
+static int32_t peer_upload_table(crux_ctx* c) {
+  if (!c->peer_tab) { if (hipMalloc(&c->peer_tab, sizeof(float*) * 2 * CRUX_PX_MAXR) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "peer table"); }
+  float* h[2 * CRUX_PX_MAXR] = {};
+  for (int w = 0; w < 2; ++w) for (int r = 0; r < c->peer_n; ++r) h[w * CRUX_PX_MAXR + r] = (float*)c->peer_ptr[r] + (size_t)w * CRUX_PX_STREAM_FLOATS;
+  HIPCHK(c, hipMemcpy(c->peer_tab, h, sizeof h, hipMemcpyHostToDevice));
+  return CRUX_OK;
+}
+int32_t crux_peer_export(crux_ctx* c, uint8_t* handle64) {
+  if (!c || !handle64) return CRUX_EINVAL;
+  if (c->peer_n > 1) return crux_fail(c, CRUX_EINVAL, "peer_export: this context is attached to a group (detach first)");
+  int32_t rc = peer_region(c); if (rc) return rc;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  hipIpcMemHandle_t h; HIPCHK(c, hipIpcGetMemHandle(&h, c->peer_local));
+  memcpy(handle64, &h, 64); return CRUX_OK;
+}
+int32_t crux_peer_attach(crux_ctx* c, int32_t rank, int32_t nranks, const uint8_t* handles) {
+  if (!c || !handles || nranks < 1 || nranks > CRUX_PX_MAXR || rank < 0 || rank >= nranks) return CRUX_EINVAL;
+  if (c->peer_n > 1) return crux_fail(c, CRUX_EINVAL, "peer_attach: already attached");
+  int32_t rc = peer_region(c); if (rc) return rc;
+  rc = peer_reset(c); if (rc) return rc;
+  int ndev = 0; (void)hipGetDeviceCount(&ndev);
+  for (int d = 0; d < ndev; ++d) if (d != c->device) { (void)hipDeviceEnablePeerAccess(d, 0); (void)hipGetLastError(); }   // best effort: already enabled / not visible are both fine
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) { c->peer_ptr[r] = c->peer_local; c->peer_ipc[r] = false; continue; }
+    hipIpcMemHandle_t h; memcpy(&h, handles + 64 * (size_t)r, 64); void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { for (int q = 0; q < r; ++q) if (c->peer_ipc[q]) { (void)hipIpcCloseMemHandle(c->peer_ptr[q]); c->peer_ipc[q] = false; }
+      return crux_fail(c, CRUX_EHIP, "peer_attach: hipIpcOpenMemHandle for rank %d failed: %s", r, hipGetErrorString(e)); }
+    c->peer_ptr[r] = p; c->peer_ipc[r] = true;
+  }
+  (void)crux_x2_placement_ok(c);
+  c->peer_rank = rank; c->peer_n = nranks; return peer_upload_table(c);
+}
+// the same wiring for contexts of ONE process (a multi-GPU single-process host, or several replicas on one device): ctxs[r] is rank r
+int32_t crux_peer_attach_local(crux_ctx* const* ctxs, int32_t n) {
+  if (!ctxs || n < 1 || n > CRUX_PX_MAXR) return CRUX_EINVAL;
+  for (int r = 0; r < n; ++r) { if (!ctxs[r]) return CRUX_EINVAL; if (ctxs[r]->peer_n > 1) return crux_fail(ctxs[r], CRUX_EINVAL, "peer_attach_local: rank %d is already attached", r);
+    int32_t rc = peer_region(ctxs[r]); if (rc) return rc; rc = peer_reset(ctxs[r]); if (rc) return rc; }
+  for (int r = 0; r < n; ++r) { crux_ctx* c = ctxs[r];
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int q = 0; q < n; ++q) { if (ctxs[q]->device != c->device) { (void)hipDeviceEnablePeerAccess(ctxs[q]->device, 0); (void)hipGetLastError(); }
+      c->peer_ptr[q] = ctxs[q]->peer_local; c->peer_ipc[q] = false; }
+    c->peer_rank = r; c->peer_n = n;
+    const int32_t rc = peer_upload_table(c); if (rc) return rc; }
+  for (int r = 0; r < n; ++r) { HIPCHK(ctxs[r], hipSetDevice(ctxs[r]->device)); (void)crux_x2_placement_ok(ctxs[r]); }
+  const int32_t rcs = crux_make_streams_concurrent(ctxs, n);        // replicas sharing a device: every learner stream on its own hardware queue
+  if (rcs) { for (int r = 0; r < n; ++r) { ctxs[r]->peer_n = 0; ctxs[r]->peer_rank = 0; } return rcs; }
+  return CRUX_OK;
+}
+int32_t crux_peer_detach(crux_ctx* c) {
+  if (!c) return CRUX_EINVAL;
+  (void)hipStreamSynchronize(c->stream); if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+  for (int r = 0; r < CRUX_PX_MAXR; ++r) { if (c->peer_ipc[r]) (void)hipIpcCloseMemHandle(c->peer_ptr[r]); c->peer_ipc[r] = false; c->peer_ptr[r] = nullptr; }
+  c->peer_n = 0; c->peer_rank = 0; return CRUX_OK;
+}
+int32_t crux_peer_size(const crux_ctx* c) { return c && c->peer_n > 1 ? c->peer_n : 1; }
+int32_t crux_peer_rank(const crux_ctx* c) { return c && c->peer_n > 1 ? c->peer_rank : 0; }
+
 int32_t crux_allreduce_mean(crux_mlp* net) {
   if (!net) return CRUX_EINVAL;
   crux_mlp* one[1] = {net}; return crux_comm_allreduce_mean_impl(net->ctx, one, 1);

@@ -32,7 +32,25 @@ struct crux_ctx {
   int learner_cus = 0;                 // 0 = automatic, 1 = one CU per learner (k_train_mfma8), 2 = two CUs (k_train_mfma_x2)
   void* xmulti[2] = {nullptr, nullptr}; size_t xmulti_bytes[2] = {0, 0};   // exchange areas + argument blocks of the batched multi-learner launch
   void* xbuf[2] = {nullptr, nullptr};   // gradient exchange areas of the two-CU learner kernel, one per learner stream
+  // replica group with direct peer slots (comm.hip "peer"): every rank owns one fine-grained region that its peers write their minibatch
+  // gradients into over xGMI; peer_ptr[r] is rank r's region as mapped here (own region for r == peer_rank)
+  int peer_n = 0, peer_rank = 0; void* peer_local = nullptr; void* peer_ptr[8] = {}; bool peer_ipc[8] = {}; bool peer_fine = false;
+  float** peer_tab = nullptr;   // device [2 learner streams][8]: region base of every rank for that stream (what the kernel indexes)
 };
+
+// Layout of a peer region (floats unless noted), per learner stream w in {0,1} at w * CRUX_PX_STREAM_FLOATS:
+//   slots   [parity 2][source rank 8][CRUX_PX_SLOT]   the source's local gradient sum + statistics of one minibatch step
+//   flags   uint64 [8] at CRUX_PX_FLAGS, 64-byte stride   flag[src] = number of exchanges whose data src has completely written here
+//   abort   uint32 at CRUX_PX_ABORT                        set by any rank that gave up waiting
+//   count   uint64 at CRUX_PX_COUNT                        exchanges done so far on this stream (local bookkeeping: slot parity and flag values
+//                                                          continue across launches, so the double buffering argument holds across them too)
+#define CRUX_PX_MAXR 8
+#define CRUX_PX_SLOT 8192
+#define CRUX_PX_FLAGS (2 * CRUX_PX_MAXR * CRUX_PX_SLOT)
+#define CRUX_PX_ABORT (CRUX_PX_FLAGS + 16 * CRUX_PX_MAXR)
+#define CRUX_PX_COUNT (CRUX_PX_ABORT + 16)
+#define CRUX_PX_STREAM_FLOATS (CRUX_PX_COUNT + 16)
+#define CRUX_PX_BYTES (2 * CRUX_PX_STREAM_FLOATS * sizeof(float))
 
 int32_t crux_fail(crux_ctx* ctx, int32_t code, const char* fmt, ...);
 void* crux_scratch(crux_ctx* ctx, size_t bytes);       // grows; contents undefined

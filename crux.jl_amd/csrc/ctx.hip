@@ -89,6 +89,9 @@ int32_t crux_ctx_destroy(crux_ctx* c) {
   if (c->scratch) (void)hipFree(c->scratch);
   for (int k = 0; k < 2; ++k) { if (c->xbuf[k]) (void)hipFree(c->xbuf[k]); if (c->xmulti[k]) (void)hipFree(c->xmulti[k]); if (c->amulti[k]) (void)hipFree(c->amulti[k]); }
   if (c->pinned) (void)hipHostFree(c->pinned);
+  for (int r = 0; r < 8; ++r) if (c->peer_ipc[r]) (void)hipIpcCloseMemHandle(c->peer_ptr[r]);
+  if (c->peer_local) (void)hipFree(c->peer_local);
+  if (c->peer_tab) (void)hipFree(c->peer_tab);
   for (int k = 0; k < c->aux_n_rejected; ++k) (void)hipStreamDestroy(c->aux_rejected[k]);
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->aux_ev0); (void)hipEventDestroy(c->aux_ev1); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);

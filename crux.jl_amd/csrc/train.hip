@@ -317,7 +317,12 @@ static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_
   if (!stream) stream = c->stream;
   const bool prof = stream == c->stream;      // HIP-event timing is kept on the context's main stream
   if (prof) crux_prof_begin(c, prof_slot);
+  // a replica group is attached (comm.hip "peer"): the per-minibatch gradient all-reduce lives in the two-CU kernels only; a learner that would
+  // update its parameters through any other kernel is refused rather than trained un-synchronised (gradient-only / single-step calls stay local)
+  a.need_px = (c->peer_n > 1 && a.apply && !a.ids) ? 1 : 0;
   int32_t rc = crux_train_mfma_launch(c, a, &handled, stream);
+  if (rc) return rc;
+  if (a.need_px && !handled) return crux_fail(c, CRUX_EUNSUP, "batch_train! with a replica group attached needs the two-CU learner kernels (IN->64->64->OUT of the supported families, batch 65..128): this learner would run un-synchronised");
   if (!handled) {
     const size_t lds = generic_lds_bytes(a.nd);
     if (lds > 160 * 1024 - 64) return crux_fail(c, CRUX_EUNSUP, "train!: network too wide for the generic learner kernel (%zu B of LDS)", lds);
@@ -474,6 +479,62 @@ static int32_t ensure_aux_stream(crux_ctx* c) {
   c->aux_stream = chosen; c->aux_probe_ms = best;
   if (getenv("CRUX_STREAM_PROBE_VERBOSE")) fprintf(stderr, "[cruxhip] second learner stream: %d candidate(s) rejected, probe %.3f ms for two concurrent launches (one alone: %.3f ms)\n", c->aux_n_rejected, best, alone);
   HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev1, hipEventDisableTiming));
+  return CRUX_OK;
+}
+
+// Replicas that share ONE device (crux_peer_attach_local with several contexts on a device): their persistent learner kernels wait for each other
+// inside the kernel, so every learner stream of every such context must sit on its own hardware queue -- two kernels on one queue run back to
+// back and the first would wait for the second forever (until its timeout). Streams are probed pairwise like the second learner stream above and
+// replaced (the rejected ones parked) until all of them overlap. Contexts on different devices need nothing of this.
+static int32_t probe_pair_ms(crux_ctx* c, hipStream_t s0, hipStream_t s1, long long ticks, size_t lds, float* ms) {
+  hipEvent_t t0 = nullptr, t1 = nullptr, ej = nullptr;
+  HIPCHK(c, hipEventCreate(&t0)); HIPCHK(c, hipEventCreate(&t1)); HIPCHK(c, hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+  for (int rep = 0; rep < 2; ++rep) {
+    HIPCHK(c, hipEventRecord(t0, s0)); HIPCHK(c, hipStreamWaitEvent(s1, t0, 0));
+    hipLaunchKernelGGL(k_spin, dim3(16), dim3(256), lds, s1, ticks); HIPCHK(c, hipEventRecord(ej, s1));
+    hipLaunchKernelGGL(k_spin, dim3(16), dim3(256), lds, s0, ticks);
+    HIPCHK(c, hipStreamWaitEvent(s0, ej, 0)); HIPCHK(c, hipEventRecord(t1, s0));
+    HIPCHK(c, hipStreamSynchronize(s0)); HIPCHK(c, hipStreamSynchronize(s1));
+    HIPCHK(c, hipEventElapsedTime(ms, t0, t1));
+  }
+  (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipEventDestroy(ej);
+  return CRUX_OK;
+}
+int32_t crux_make_streams_concurrent(crux_ctx* const* ctxs, int n) {
+  std::vector<hipStream_t> ok_streams; std::vector<crux_ctx*> owner;
+  for (int r = 0; r < n; ++r) {
+    crux_ctx* c = ctxs[r];
+    bool shares = false; for (int q = 0; q < n; ++q) if (q != r && ctxs[q]->device == c->device) shares = true;
+    if (!shares) continue;
+    HIPCHK(c, hipSetDevice(c->device));
+    { const int32_t rca = ensure_aux_stream(c); if (rca) return rca; }
+    int clk_khz = 100000; (void)hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeWallClockRate, c->device); if (clk_khz <= 0) clk_khz = 100000;
+    const long long ticks = (long long)clk_khz * 150 / 1000; const size_t lds = 150 * 1024;
+    float alone = 0.15f;
+    { hipEvent_t t0 = nullptr, t1 = nullptr; HIPCHK(c, hipEventCreate(&t0)); HIPCHK(c, hipEventCreate(&t1));
+      HIPCHK(c, hipFuncSetAttribute((const void*)k_spin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      for (int rep = 0; rep < 2; ++rep) { HIPCHK(c, hipEventRecord(t0, c->stream)); hipLaunchKernelGGL(k_spin, dim3(16), dim3(256), lds, c->stream, ticks); HIPCHK(c, hipEventRecord(t1, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipEventElapsedTime(&alone, t0, t1)); }
+      (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); }
+    for (int which = 0; which < 2; ++which) {
+      hipStream_t* sp = which ? &c->aux_stream : &c->stream;
+      for (int attempt = 0; attempt < 8; ++attempt) {
+        bool all = true;
+        for (size_t k = 0; k < ok_streams.size() && all; ++k) { if (owner[k]->device != c->device) continue;
+          float ms = 0.f; const int32_t rc = probe_pair_ms(c, ok_streams[k], *sp, ticks, lds, &ms); if (rc) return rc;
+          if (ms > 1.6f * alone) all = false; }          // two 150 us spins: about `alone` when overlapped, 2 x back to back
+        if (all) break;
+        if (which == 0 && !c->own_stream) return crux_fail(c, CRUX_EUNSUP, "peer_attach_local: the caller's stream of replica %d shares a hardware queue with another replica's learner stream", r);
+        if (attempt == 7) return crux_fail(c, CRUX_EHIP, "peer_attach_local: could not place the learner streams of replica %d on their own hardware queues (raise GPU_MAX_HW_QUEUES)", r);
+        HIPCHK(c, hipStreamSynchronize(*sp));
+        if (c->aux_n_rejected < 8) c->aux_rejected[c->aux_n_rejected++] = *sp;      // parked, destroyed with the context: the next stream maps elsewhere
+        hipStream_t s = nullptr; int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, (attempt & 1) ? lo_p : hi_p) != hipSuccess) HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        *sp = s;
+      }
+      ok_streams.push_back(*sp); owner.push_back(c);
+    }
+  }
   return CRUX_OK;
 }
 

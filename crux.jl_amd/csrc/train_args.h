@@ -30,6 +30,10 @@ struct TrainArgs {
   unsigned long long* dbg;   // optional phase-timing output (CRUX_MFMA_TIMING)
   float squash;              // SquashedGaussianPolicy ascale (0 = GaussianPolicy): actions are un-tanh'd, sigma uses clamp(logSigma, -5, 2), logpdf carries the tanh correction
   float* xbuf; unsigned* xctr;   // two-CU kernel (train_mfma_x2.hip): gradient exchange slots [parity][workgroup] and {arrival counter, abort flag}
+  // replica group (comm.hip "peer"): SUM all-reduce of the minibatch gradient over px_n GPUs inside the persistent kernel, between the pullback
+  // (training.jl:18) and Flux.update! (:21). px_tab[r] = rank r's slot region for THIS learner stream as mapped in this process.
+  int32_t need_px;           // host-side: a replica group is attached and this launch updates parameters -> only the two-CU kernel may take it
+  int32_t px_n, px_rank; float* const* px_tab;   // px_tab: device table [px_n] of the ranks' region bases for this learner stream (own region at px_rank)
 };
 
 // The minibatch rows are device global memory. Typing the per-step loads as address_space(1) makes them global_load instead of the flat_load a

@@ -574,7 +574,8 @@ int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, h
     return CRUX_OK;
   }
   { static const bool four = getenv("CRUX_MFMA_WAVES4") != nullptr;   // A/B switch: force the 4-wave kernel
-    if (!four && c->learner_cus != 1) { const int32_t rcx = crux_train_mfma_x2_launch(c, a, kind, handled, stream); if (rcx || *handled) return rcx; }
+    if (!four && (c->learner_cus != 1 || a.need_px)) { const int32_t rcx = crux_train_mfma_x2_launch(c, a, kind, handled, stream); if (rcx || *handled) return rcx; }
+    if (a.need_px) return CRUX_OK;      // not covered by the two-CU kernel: the caller refuses (no un-synchronised training)
     if (!four) { const int32_t rc = crux_train_mfma8_launch(c, a, kind, handled, stream); if (rc || *handled) return rc; } }
   if (a.squash > 0.f) return CRUX_OK;     // SquashedGaussianPolicy: implemented in the 8-wave / two-CU kernels and the generic one, not in this 4-wave fallback
 #define MF_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_one<I, O, K, A_>(c, a, stream); }

@@ -146,6 +146,10 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
   long long total_batches = 0; int epochs_run = 0, err = 0; bool stop = false;
   bool staged = false;                              // the next minibatch is already in this wave's LDS staging tiles
   long long xstep = 0;                              // exchanges done so far (the counter target and the slot parity)
+  // replica group (comm.hip "peer"): exchanges done on this learner stream before this launch -- slot parity and flag values continue across launches
+  float* const px_mine = a.px_n > 1 ? a.px_tab[a.px_rank] : nullptr;
+  const unsigned long long px0 = a.px_n > 1 ? *(const unsigned long long*)(px_mine + CRUX_PX_COUNT) : 0ull;
+  const float px_inv = a.px_n > 1 ? 1.0f / (float)a.px_n : 1.0f;
   constexpr int XSLOT = 4096 + NSI * NT + 16;
   float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
   const int n_epochs = a.ids ? 1 : a.epochs;
@@ -279,18 +283,22 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
 
       MX_T(3);
       // ======================= layer 3 (VALU) + loss head =======================
-      f32x4 w3[OUT][4];
+      // W3 fragments: kept in registers across the head for narrow outputs (32 VGPRs at OUT = 2); for wider heads (OUT = 6: 96 VGPRs, which made the
+      // 17->64->64->6 kernels spill) they are re-read from LDS in the backward pass instead (conflict-free b128 reads)
+      constexpr bool W3_REG = OUT <= 2;
+      f32x4 w3[W3_REG ? OUT : 1][4];
+      if (W3_REG) {
 #pragma unroll
-      for (int o = 0; o < OUT; ++o)
+        for (int o = 0; o < OUT; ++o)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) w3[o][m] = *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 16 * m + 4 * g];
+          for (int m = 0; m < 4; ++m) w3[o][m] = *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 16 * m + 4 * g]; }
       float z[OUT];
 #pragma unroll
       for (int o = 0; o < OUT; ++o) { float acc = 0.f;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m) { const f32x4 wv = W3_REG ? w3[W3_REG ? o : 0][m] : *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 16 * m + 4 * g];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc = fmaf(w3[o][m][r], h2[m][r], acc);
+          for (int r = 0; r < 4; ++r) acc = fmaf(wv[r], h2[m][r], acc); }
         z[o] = g4_sum(acc) + sm[Lt::oB3 + o]; }
       float dz[OUT], dex[OUT];
       float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f;
@@ -349,13 +357,19 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
 #pragma unroll
           for (int r = 0; r < 4; ++r) pv[4 * m + r] = dz[o] * h2[m][r];
         part[Lt::pW3 + o * MF_HID + 16 * (c >> 2) + 4 * g + (c & 3)] = row16_reduce_scatter(pv, c); }
+      { f32x4 d2[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m) d2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { float d0 = 0.f;
+        for (int o = 0; o < OUT; ++o)          // same fma order over o as before: d = fma(w3[o], dz[o], d)
 #pragma unroll
-          for (int o = 0; o < OUT; ++o) d0 = fmaf(w3[o][m][r], dz[o], d0);
-          h2[m][r] = actg<ACT>(h2[m][r], d0); }
+          for (int m = 0; m < 4; ++m) { const f32x4 wv = W3_REG ? w3[W3_REG ? o : 0][m] : *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 16 * m + 4 * g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d2[m][r] = fmaf(wv[r], dz[o], d2[m][r]); }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h2[m][r] = actg<ACT>(h2[m][r], d2[m][r]); }
       { constexpr int NV = 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0);
         float mv[((NV + 15) / 16) * 16];
 #pragma unroll
@@ -480,7 +494,96 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
         for (int mm = 0; mm < 4; ++mm) gW2[mm] += pw[mm];      // a+b == b+a bitwise: both workgroups hold the same total
 #pragma unroll
         for (int k = 0; k < NSI; ++k) gs[k] += pg[k];
-        if (tid >= NT - 8 && tid < NT - 1) sm[Lt::oRED + 8 + (tid - (NT - 8))] = stat_loc + ps;
+        float stat_tot = stat_loc + ps;
+        if (a.px_n > 1) {
+          // ---- SUM all-reduce of the local gradient over the replica group, between the pullback (training.jl:18) and Flux.update! (:21) ----
+          // Both workgroups hold the same local total. They share the writes (peer i of the N-1 goes to workgroup i & 1): the total and the seven
+          // statistics sums go into slot [parity][my rank] of the peer's region, a system-scope release makes them visible, then flag[my rank]
+          // there is raised to the exchange number. Both workgroups then wait for the N-1 flags in the OWN region and add the N contributions in
+          // rank order, so every workgroup of every rank forms the same sum bit for bit.
+          const unsigned long long xg = px0 + (unsigned long long)xstep;       // number of this exchange on this learner stream
+          const int par = (int)(xg & 1ull);
+          { int pi_ = 0;
+            for (int r = 0; r < a.px_n; ++r) {
+              if (r == a.px_rank) { if (p != 0) continue; }          // own slot of the own region (workgroup 0): the sum below reads all N slots alike
+              else if ((pi_++ & 1) != p) continue;
+              float* dst = a.px_tab[r] + (size_t)(par * CRUX_PX_MAXR + a.px_rank) * CRUX_PX_SLOT;
+#pragma unroll
+              for (int mm = 0; mm < 4; ++mm) *(f32x4*)&dst[tid * 16 + 4 * mm] = gW2[mm];
+#pragma unroll
+              for (int k = 0; k < NSI; ++k) dst[4096 + tid + NT * k] = gs[k];
+              if (tid >= NT - 8 && tid < NT - 1) dst[4096 + NSI * NT + (tid - (NT - 8))] = stat_tot; } }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                         // system scope: this wave's slot stores are performed at the peers
+          __syncthreads();
+          if (tid == 0) {
+            int pi_ = 0;
+            for (int r = 0; r < a.px_n; ++r) { if (r == a.px_rank) continue;
+              if ((pi_++ & 1) != p) continue;
+              __hip_atomic_store((unsigned long long*)(a.px_tab[r] + CRUX_PX_FLAGS) + 8 * a.px_rank, xg + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+            bool ok = true; const long long t0 = wall_clock64();                // 100 MHz: a missing peer becomes CRUX_EHIP after ~30 s instead of a hung GPU
+            unsigned* abortw = (unsigned*)(px_mine + CRUX_PX_ABORT);
+            for (int r = 0; r < a.px_n && ok; ++r) { if (r == a.px_rank) continue;
+              const unsigned long long* fl = (const unsigned long long*)(px_mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
+              while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
+            if (!ok) { for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            sm[Lt::oRED + 16] = ok ? 0.f : 1.f;
+          }
+          __syncthreads();
+          if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; break; }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                         // system scope: nothing read below is older than the flags
+          // the N slots are read two at a time (all loads of a pair in flight together) and added in rank order
+          auto px_load = [&](int r, f32x4 (&vW)[4], float (&vS)[NSI], float& vT) {
+            const float* src = px_mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT;
+#pragma unroll
+            for (int k = 0; k < NSI; ++k) vS[k] = __hip_atomic_load(src + 4096 + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            vT = 0.f;
+            if (tid >= NT - 8 && tid < NT - 1) vT = __hip_atomic_load(src + 4096 + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\tglobal_load_dwordx4 %2, %4, off offset:32 sc0 sc1\n\t"
+                         "global_load_dwordx4 %3, %4, off offset:48 sc0 sc1"
+                         : "=&v"(vW[0]), "=&v"(vW[1]), "=&v"(vW[2]), "=&v"(vW[3]) : "v"(src + tid * 16) : "memory");
+          };
+          for (int r = 0; r < a.px_n; r += 2) {
+            f32x4 vA[4], vB[4]; float sA[NSI], sB[NSI]; float tA = 0.f, tB = 0.f;
+            const bool two = r + 1 < a.px_n;
+            px_load(r, vA, sA, tA);
+            if (two) px_load(r + 1, vB, sB, tB);
+            else {
+#pragma unroll
+              for (int mm = 0; mm < 4; ++mm) vB[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int k = 0; k < NSI; ++k) sB[k] = 0.f; }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(vA[0]), "+v"(vA[1]), "+v"(vA[2]), "+v"(vA[3]), "+v"(vB[0]), "+v"(vB[1]), "+v"(vB[2]), "+v"(vB[3]) :: "memory");
+            if (r == 0) {
+#pragma unroll
+              for (int mm = 0; mm < 4; ++mm) gW2[mm] = vA[mm];
+#pragma unroll
+              for (int k = 0; k < NSI; ++k) gs[k] = sA[k];
+              stat_tot = tA;
+            } else {
+#pragma unroll
+              for (int mm = 0; mm < 4; ++mm) gW2[mm] += vA[mm];
+#pragma unroll
+              for (int k = 0; k < NSI; ++k) gs[k] += sA[k];
+              stat_tot += tA;
+            }
+            if (two) {
+#pragma unroll
+              for (int mm = 0; mm < 4; ++mm) gW2[mm] += vB[mm];
+#pragma unroll
+              for (int k = 0; k < NSI; ++k) gs[k] += sB[k];
+              stat_tot += tB;
+            }
+          }
+          // mean over the group: global minibatch = px_n x nb samples, every rank's partial was already divided by nb
+#pragma unroll
+          for (int mm = 0; mm < 4; ++mm) gW2[mm] = gW2[mm] * px_inv;
+#pragma unroll
+          for (int k = 0; k < NSI; ++k) gs[k] = gs[k] * px_inv;
+          stat_tot = stat_tot * px_inv;
+        }
+        if (tid >= NT - 8 && tid < NT - 1) sm[Lt::oRED + 8 + (tid - (NT - 8))] = stat_tot;
         xstep += 1;
       }
       float ssq = 0.f; int bad = 0;
@@ -568,6 +671,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
     for (int s = tid; s < ns_valid; s += NT) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; }
   }
   if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(4 * p + w) * 16 + k] = tacc[k]; }
+  if (tid == 0 && p == 0 && a.px_n > 1) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)xstep;
   if (tid == 0 && (p == 0 || err)) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     a.bp[0] = bp1; a.bp[1] = bp2;
@@ -582,7 +686,11 @@ __global__ void k_xcc_probe(uint32_t* out) {
   uint32_t id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
   if (threadIdx.x == 0) out[blockIdx.x] = id & 0xf;
 }
-static int x2_placement_ok(crux_ctx* c) {
+extern "C" int crux_x2_placement_ok(crux_ctx* c);
+static int x2_placement_ok(crux_ctx* c) { return crux_x2_placement_ok(c); }
+// also called when a replica group is attached: the probe ends in a hipFree, which waits for the whole device -- it must not run for the first time
+// while a peer replica on the same device already spins in its learner kernel
+extern "C" int crux_x2_placement_ok(crux_ctx* c) {
   static int cached = -1;
   if (cached >= 0) return cached;
   cached = 0;
@@ -613,6 +721,7 @@ static int32_t launch_x2(crux_ctx* c, TrainArgs a, hipStream_t stream) {
   constexpr size_t xbytes = sizeof(float) * 4 * 8192 + 256;
   if (!c->xbuf[which]) { if (hipMalloc(&c->xbuf[which], xbytes) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "learner exchange buffer"); }
   a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * 4 * 8192);
+  if (c->peer_n > 1) { a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR; }
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
   hipLaunchKernelGGL((k_train_mfma_x2<IN, OUT, KIND, ACT, TIMING>), dim3(16), dim3(256), lds, stream, a, (const TrainArgs*)nullptr);
   return crux_launch_check(c, "k_train_mfma_x2");

@@ -333,6 +333,23 @@ int32_t crux_allreduce_mean(crux_mlp* net);
 /* SUM all-reduce of the flat gradient left by crux_loss_grad (crux_mlp_grads_ptr), stream-ordered; follow with crux_adam_apply(net, 1/nranks):
  * the exact data-parallel minibatch step (global batch = nranks x local batch), every rank applying the identical update.                */
 int32_t crux_allreduce_grads(crux_mlp* net);
+/* Replica group with direct peer slots -- the exact data-parallel step of SURVEY 8(e): with a group attached, every minibatch step of
+ * crux_batch_train / crux_policy_gradient_training SUM-all-reduces the flattened local gradient (and the loss / KL statistics) over the group
+ * INSIDE the persistent learner kernel, between the pullback (src/training.jl:18) and Flux.update! (:21), and applies Adam to sum / nranks:
+ * nranks replicas with local minibatches of B reproduce one learner with minibatches of nranks x B (up to the summation order), and all replicas
+ * hold bit-identical parameters and Adam state at every step. Transport: every rank's gradient is written straight into a slot of each peer's
+ * fine-grained region over xGMI (hipIpc-mapped; one hop on the fully connected node) and summed locally in rank order. KL early stopping and
+ * max_batches work (every rank sees the same global statistics). Needs the two-CU learner kernels (IN->64->64->OUT, batch 65..128), equal buffer
+ * lengths on all ranks, and every rank making the same sequence of training calls.
+ *   crux_peer_export  allocates this context's region and returns its 64-byte IPC handle; ship the handles of all ranks to all ranks;
+ *   crux_peer_attach  maps the peers' regions (handles: [nranks][64], own entry ignored). All ranks must have attached before any trains.
+ *   crux_peer_attach_local wires contexts of one process directly (ctxs[r] = rank r), e.g. two replicas on one device.                         */
+int32_t crux_peer_export(crux_ctx* ctx, uint8_t* handle64);
+int32_t crux_peer_attach(crux_ctx* ctx, int32_t rank, int32_t nranks, const uint8_t* handles);
+int32_t crux_peer_attach_local(crux_ctx* const* ctxs, int32_t n);
+int32_t crux_peer_detach(crux_ctx* ctx);
+int32_t crux_peer_size(const crux_ctx* ctx);               /* 1 when no group is attached */
+int32_t crux_peer_rank(const crux_ctx* ctx);
 /* policy_gradient_training (src/model_free/on_policy.jl:56-78) for replicas: the epochs run in chunks of sync_every, each chunk followed
  * by crux_allreduce_mean(actor), (critic) on the stream. With no communicator it is bit-identical to crux_policy_gradient_training.
  * Requires no KL early stopping / max_batches (replicas must run the same number of epochs) and equal actor/critic epoch counts.     */

@@ -15,7 +15,9 @@ pytestmark = pytest.mark.gpu
 
 def test_c2_full_size_iteration_replays_oracle(gpu_ctx):
     """configs[1]: PPO CartPole 4->64->64->2 (+ critic), 32 envs x 2048 steps, batch 128: rollout + GAE + returns + whiten + 2 full epochs of
-    actor and critic batch_train! (1 024 Adam steps each) through crux_policy_gradient_training (the two concurrent persistent kernels)."""
+    actor and critic batch_train! (1 024 Adam steps each) through crux_policy_gradient_training (the two concurrent persistent kernels).
+    Rollout, GAE, returns, whitening, row order: the tolerances of parity.ppo_iteration_parity. Free-running learners after 1 024 steps: step counts,
+    training statistics within 2 %, parameters inside the chaos envelope; their arithmetic is pinned by the teacher-forced window tests below."""
     res = parity.ppo_iteration_parity(n_envs=32, T=2048, batch_size=128, epochs=2, seed=1234, max_steps=500, pair=True)
     print({k: v for k, v in res.items() if k != "ok"})
     assert res["actor_batches"] == (1024, 1024) and res["critic_batches"] == (1024, 1024)
@@ -31,42 +33,79 @@ def test_c5_full_size_shard_iteration_replays_oracle(gpu_ctx):
     assert res["ok"], res
 
 
-@pytest.mark.parametrize("which", ["actor", "critic"])
-def test_persistent_learner_drift_over_4096_steps(gpu_ctx, which):
-    """8 epochs x 512 minibatches = 4 096 consecutive Adam steps in ONE launch of the two-CU persistent kernel (v_rcp/v_sqrt Adam in f32) vs the
-    oracle (Flux's per-element Float64 Adam): the difference must stay inside the stated growth law at every checkpoint."""
-    E, T, bs, seed = 32, 2048, 128, 4321
-    N = E * T
+def _c2_training_set(seed, E=32, T=2048):
+    """the oracle's own C2 rollout + GAE + returns + whitened advantages as host columns (identical inputs for both sides)."""
     extras = ["return", "logprob", "advantage"]
     ga, oa = parity.make_pair(parity.ACTOR_DIMS, parity.ACTS, seed, 0, "discrete")
     gc, oc = parity.make_pair(parity.CRITIC_DIMS, parity.ACTS, seed, 1)
-    ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, N, extras)
-    oe = O.OEnv("cartpole", E, 500, 0.99, seed)
-    oe.rollout(oa, parity.rollout_cfg(), ob, T)
+    ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, E * T, extras)
+    O.OEnv("cartpole", E, 500, 0.99, seed).rollout(oa, parity.rollout_cfg(), ob, T)
     O.chk(O.lib().orc_fill_gae(ob.h, oc.h, 0.95, 0.99)); O.chk(O.lib().orc_fill_returns(ob.h, 0.99)); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
-    data0 = {k: ob[k] for k in ob.keys()}                      # identical inputs on both sides: the test isolates the learner
+    return {k: ob[k] for k in ob.keys()}, (ga, oa), (gc, oc)
+
+
+@pytest.mark.parametrize("which", ["actor", "critic"])
+def test_c2_learner_teacher_forced_windows_over_4096_steps(gpu_ctx, which):
+    """The persistent two-CU kernel against the oracle's Float64-Adam restatement along 8 epochs x 512 minibatches = 4 096 consecutive steps of
+    configs[1]: every 128 steps (and at the late, large-moment states) the kernel restarts from the oracle's exact state and must reproduce its
+    next 16 steps to parity.window_tol (2e-7 from step 256 on). This bounds the kernel's arithmetic error at every point of a long run without comparing two chaotic
+    trajectories (tests/parity.py explains why free-running relu/PPO learners decorrelate)."""
+    data0, (ga, oa), (gc, oc) = _c2_training_set(4321)
     g, o = (ga, oa) if which == "actor" else (gc, oc)
     loss, head = ("ppo", "categorical") if which == "actor" else ("value_mse", "deterministic")
-    o.adam_init(float(np.float32(3e-4)))
-    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
-    p0 = g.get_params().copy()
-    # the oracle advances epoch by epoch (shuffle counter e, like one 8-epoch batch_train!) and is snapshotted after 1, 2, 4, 8 epochs;
-    # the GPU runs 1, 2, 4 and 8 epochs from the same start, each as ONE persistent launch
-    oinfo = np.zeros(L.INFO_N, np.float32); o_snap = {}
-    for e in range(8):
-        cfg = parity.train_cfg(loss, head, bs, 1, -1.0, 900, counter=e)
-        O.chk(O.lib().orc_batch_train(o.h, ob.h, C.byref(cfg), None, O.vpz(oinfo), None))
-        if e + 1 in (1, 2, 4, 8):
-            o_snap[e + 1] = o.params.copy()
+    starts = list(range(0, 4096, 128)) + [4096 - 16, 2048 - 16]
+    out, _ = parity.learner_window_parity(g, o, data0, 4, 2, True, loss, head, 128, 8, starts, 16)
+    print(which, "windows (start, W, max |dtheta|):", out)
+    assert len(out) == len(set(starts))
+    assert all(d < parity.window_tol(st) for st, _, d in out), out
+
+
+@pytest.mark.parametrize("which", ["actor", "critic"])
+def test_c5_learner_teacher_forced_windows(gpu_ctx, which):
+    """configs[4] learners (tanh 17->64->64->6 GaussianPolicy with trainable logSigma / 17->64->64->1 critic, the two-CU kernels of the 17-wide family)
+    on one GPU's 128-env x 2048-step shard: 16-step teacher-forced windows every 128 steps of a 2 048-step epoch."""
+    od, ad, E, T, seed = 17, 6, 128, 2048, 31
+    extras = ["return", "logprob", "advantage"]
+    ga, oa = parity.make_pair([17, 64, 64, 6], ["tanh", "tanh", "identity"], seed, 0, "gaussian", n_extra=6, extra_init=-0.5)
+    gc, oc = parity.make_pair([17, 64, 64, 1], ["tanh", "tanh", "identity"], seed, 1)
+    ob = O.OBuffer(od, ad, L.ACTION_CONTINUOUS, E * T, extras)
+    O.OEnv("synth", E, 1000, 0.99, seed, so=od, sa=ad).rollout(oa, parity.rollout_cfg(head="gaussian"), ob, T)
+    O.chk(O.lib().orc_fill_gae(ob.h, oc.h, 0.95, 0.99)); O.chk(O.lib().orc_fill_returns(ob.h, 0.99)); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
+    data0 = {k: ob[k] for k in ob.keys()}
+    g, o = (ga, oa) if which == "actor" else (gc, oc)
+    loss, head = ("ppo", "gaussian") if which == "actor" else ("value_mse", "deterministic")
+    starts = list(range(0, 2048, 128)) + [2048 - 16]
+    out, _ = parity.learner_window_parity(g, o, data0, od, ad, False, loss, head, 128, 1, starts, 16)
+    print("c5", which, "windows (start, W, max |dtheta|):", out)
+    assert len(out) == len(set(starts))
+    assert all(d < parity.window_tol(st) for st, _, d in out), out
+
+
+def test_smooth_learner_free_running_drift_over_4096_steps(gpu_ctx):
+    """Free-running 4 096 consecutive steps (2 epochs x 2 048 minibatches, ONE persistent launch) of the tanh 17->64->64->1 critic on the C5-shaped
+    shard: no kinks, no clipping -- the map is smooth, so the f32 v_rcp/v_sqrt Adam and MFMA summation order must stay inside param_tol(steps)
+    of the oracle's Float64 Adam without any re-synchronisation."""
+    od, ad, E, T, seed = 17, 6, 128, 2048, 99
+    extras = ["return", "logprob", "advantage"]
+    ga, oa = parity.make_pair([17, 64, 64, 6], ["tanh", "tanh", "identity"], seed, 0, "gaussian", n_extra=6, extra_init=-0.5)
+    gc, oc = parity.make_pair([17, 64, 64, 1], ["tanh", "tanh", "identity"], seed, 1)
+    ob = O.OBuffer(od, ad, L.ACTION_CONTINUOUS, E * T, extras)
+    O.OEnv("synth", E, 1000, 0.99, seed, so=od, sa=ad).rollout(oa, parity.rollout_cfg(head="gaussian"), ob, T)
+    O.chk(O.lib().orc_fill_gae(ob.h, oc.h, 0.95, 0.99)); O.chk(O.lib().orc_fill_returns(ob.h, 0.99))
+    data0 = {k: ob[k] for k in ob.keys()}
     worst = []
-    for n_ep in (1, 2, 4, 8):
-        g.set_params(p0)
-        src = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), N, extras); src.push_(data0)
-        opt = crux.TrainingParams(loss=crux.ppo_loss if which == "actor" else crux.value_mse_loss, batch_size=bs, epochs=n_ep, name=which + "_", shuffle_seed=900)
-        inf = crux.batch_train_(g, opt, P, src)                 # a fresh TrainingParams attaches a fresh Adam state (m = v = 0, beta powers reset)
-        steps = n_ep * (N // bs)
-        assert inf[which + "_batches_trained"] == steps
-        worst.append((steps, float(np.abs(g.get_params() - o_snap[n_ep]).max()), parity.param_tol(steps)))
-    print(which, "drift (steps, max |dtheta|, bound):", worst)
+    p0 = gc.get_params().copy()
+    for n_ep in (1, 2):
+        gc.set_params(p0); oc.params[:] = p0; oc.adam_init(float(np.float32(3e-4)))
+        src_o = O.OBuffer(od, ad, L.ACTION_CONTINUOUS, E * T, extras); src_o.push(data0)
+        src_g = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.ContinuousSpace(ad), E * T, extras); src_g.push_(data0)
+        opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=128, epochs=n_ep, name="critic_", shuffle_seed=55)
+        inf = crux.batch_train_(gc, opt, {}, src_g)
+        oi = np.zeros(L.INFO_N, np.float32); cfg = parity.train_cfg("value_mse", "deterministic", 128, n_ep, -1.0, 55)
+        O.chk(O.lib().orc_batch_train(oc.h, src_o.h, C.byref(cfg), None, O.vpz(oi), None))
+        steps = n_ep * 2048
+        assert inf["critic_batches_trained"] == steps
+        worst.append((steps, float(np.abs(gc.get_params() - oc.params).max()), parity.param_tol(steps)))
+    print("smooth critic free-running drift (steps, max |dtheta|, bound):", worst)
     for steps, d, tol in worst:
         assert d < tol, worst

@@ -1,0 +1,157 @@
+"""The multi-GPU exchange step on ONE GPU: two contexts on device 0, wired into a replica group of two (crux_peer_attach_local), run the persistent
+learner kernels concurrently; every minibatch step SUM-all-reduces the local gradients through the peer-slot protocol of train_mfma_x2.hip (the same
+code path N processes on N GPUs take, with hipIpc-mapped regions instead of same-process pointers). SURVEY 8(e): k = 1 must reproduce the single
+learner on the concatenated batch -- here the oracle with minibatches of 2 x 128 = 256 rows."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import parity
+from parity import L, O, crux
+
+pytestmark = pytest.mark.gpu
+
+
+def _shard(seed, E=8, T=128):
+    extras = ["return", "logprob", "advantage"]
+    _, oa = parity.make_pair(parity.ACTOR_DIMS, parity.ACTS, 50, 0, "discrete")
+    _, oc = parity.make_pair(parity.CRITIC_DIMS, parity.ACTS, 50, 1)
+    ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, E * T, extras)
+    O.OEnv("cartpole", E, 60, 0.99, seed).rollout(oa, parity.rollout_cfg(), ob, T)
+    O.chk(O.lib().orc_fill_gae(ob.h, oc.h, 0.95, 0.99)); O.chk(O.lib().orc_fill_returns(ob.h, 0.99)); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
+    return {k: ob[k] for k in ob.keys()}
+
+
+def _interleave(shards, bs):
+    """row (rank r, position j) of the global buffer: minibatch j // bs holds [bs rows of rank 0 | bs rows of rank 1 | ...]."""
+    R, N = len(shards), shards[0]["s"].shape[1]
+    pos = np.empty((R, N), np.int64)
+    for r in range(R):
+        j = np.arange(N); pos[r] = (j // bs) * (R * bs) + r * bs + (j % bs)
+    out = {}
+    for k in shards[0]:
+        rows = shards[0][k].shape[0]; a = np.empty((rows, R * N), shards[0][k].dtype, order="F")
+        for r in range(R):
+            a[:, pos[r]] = shards[r][k]
+        out[k] = a
+    return out, pos
+
+
+@pytest.fixture()
+def two_contexts(gpu_ctx):
+    c1 = crux.Context(0)
+    crux.peer_attach_local([gpu_ctx, c1])
+    yield gpu_ctx, c1
+    gpu_ctx.peer_detach(); c1.peer_detach(); c1.close()
+
+
+def _run_threads(fns):
+    errs = [None] * len(fns)
+    def wrap(i):
+        try:
+            fns[i]()
+        except Exception as e:      # noqa: BLE001
+            errs[i] = e
+    ts = [threading.Thread(target=wrap, args=(i,)) for i in range(len(fns))]
+    [t.start() for t in ts]; [t.join(120) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a replica did not return"
+    for e in errs:
+        if e is not None:
+            raise e
+
+
+@pytest.mark.parametrize("which", ["actor", "critic"])
+def test_two_replicas_equal_the_single_learner_on_the_concatenated_batch(two_contexts, which):
+    ctxs = two_contexts; bs, epochs = 128, 2
+    shards = [_shard(200), _shard(201)]
+    N = shards[0]["s"].shape[1]; extras = ["return", "logprob", "advantage"]
+    dims = parity.ACTOR_DIMS if which == "actor" else parity.CRITIC_DIMS
+    loss, head = ("ppo", "categorical") if which == "actor" else ("value_mse", "deterministic")
+    rng = np.random.default_rng(5)
+    perms = [np.stack([rng.permutation(N) for _ in range(epochs)]) for _ in range(2)]          # every replica shuffles its own shard (0-based)
+    nets, bufs = [], []
+    for r, ctx in enumerate(ctxs):
+        ch = parity.chain(dims, parity.ACTS)
+        g = crux.DiscreteNetwork(ch, [1, 2], ctx=ctx, seed=77, stream=3) if which == "actor" else crux.ContinuousNetwork(ch, ctx=ctx, seed=77, stream=3)
+        b = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), N, extras, ctx=ctx); b.push_(shards[r])
+        nets.append(g); bufs.append(b)
+    assert np.array_equal(nets[0].get_params(), nets[1].get_params())
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+    infos = [None, None]
+    def make(r):
+        def f():
+            opt = crux.TrainingParams(loss=crux.ppo_loss if which == "actor" else crux.value_mse_loss, batch_size=bs, epochs=epochs, name="n_")
+            infos[r] = crux.batch_train_(nets[r], opt, P, bufs[r], perms=perms[r] + 1)
+        return f
+    _run_threads([make(0), make(1)])
+    p0, p1 = nets[0].get_params(), nets[1].get_params()
+    assert np.array_equal(p0, p1)                                                    # replicas never diverge: identical sums, identical Adam
+    m0, v0, bp0 = nets[0].adam_state(); m1, v1, bp1 = nets[1].adam_state()
+    assert np.array_equal(m0, m1) and np.array_equal(v0, v1) and np.array_equal(bp0, bp1)
+    assert infos[0]["n_batches_trained"] == infos[1]["n_batches_trained"] == epochs * (N // bs)
+    assert infos[0]["n_loss"] == infos[1]["n_loss"] and infos[0]["n_grad_norm"] == infos[1]["n_grad_norm"]     # the statistics are global
+    # ---- the oracle: ONE learner, minibatches of 256 = [128 rows of replica 0 | 128 rows of replica 1]
+    glob, pos = _interleave(shards, bs)
+    ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, 2 * N, extras); ob.push(glob)
+    o = O.OMlp(dims, parity.ACTS).init_glorot(77, 3).adam_init(float(np.float32(3e-4)))
+    assert np.array_equal(o.params, crux.ContinuousNetwork(parity.chain(dims, parity.ACTS), ctx=ctxs[0], seed=77, stream=3).get_params())
+    gperm = np.empty((epochs, 2 * N), np.int64)
+    for e in range(epochs):
+        for r in range(2):
+            gperm[e, pos[r]] = pos[r][perms[r][e]]                                    # new[pos(r, j)] = old[pos(r, perm_r[j])]
+    cfg = parity.train_cfg(loss, head, 2 * bs, epochs, -1.0, 0)
+    oi = np.zeros(L.INFO_N, np.float32)
+    O.chk(O.lib().orc_batch_train(o.h, ob.h, C.byref(cfg), O.vpz(gperm), O.vpz(oi), None))
+    d = float(np.abs(p0 - o.params).max())
+    print(which, "two replicas vs concatenated-batch oracle after %d steps: max |dtheta| = %.3g" % (epochs * (N // bs), d), "loss", infos[0]["n_loss"], float(oi[0]))
+    assert d < parity.window_tol(0)
+    assert abs(infos[0]["n_loss"] - float(oi[0])) < 2e-5 * max(1.0, abs(float(oi[0])))
+    assert abs(infos[0]["n_grad_norm"] - float(oi[1])) < 2e-5 * max(1.0, abs(float(oi[1])))
+
+
+def test_policy_gradient_training_of_two_replicas_with_kl_early_stopping(two_contexts):
+    """actor and critic of both replicas (four persistent kernels, two exchange streams per replica) through crux_policy_gradient_training; the KL
+    statistic is all-reduced with the gradient, so both replicas stop at the same minibatch and stay bit-identical."""
+    ctxs = two_contexts; bs = 128
+    shards = [_shard(300), _shard(301)]
+    N = shards[0]["s"].shape[1]; extras = ["return", "logprob", "advantage"]
+    sv, bufs = [], []
+    for r, ctx in enumerate(ctxs):
+        a = crux.DiscreteNetwork(parity.chain(parity.ACTOR_DIMS, parity.ACTS), [1, 2], ctx=ctx, seed=9, stream=0)
+        c = crux.ContinuousNetwork(parity.chain(parity.CRITIC_DIMS, parity.ACTS), ctx=ctx, seed=9, stream=1)
+        b = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), N, extras, ctx=ctx); b.push_(shards[r])
+        class _S:
+            pass
+        s = _S(); s.agent = crux.PolicyParams(crux.ActorCritic(a, c)); s.P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+        s.a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=bs, epochs=6, target_kl=0.004, name="actor_", shuffle_seed=40 + r)
+        s.c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=bs, epochs=3, name="critic_", shuffle_seed=60 + r)
+        sv.append(s); bufs.append(b)
+    for tk in (0.004, None):           # sequential path with early stopping, then the concurrent actor || critic path
+        infos = [None, None]
+        for s in sv:
+            s.a_opt.target_kl = tk
+        def make(r):
+            def f():
+                infos[r] = crux.policy_gradient_training(sv[r], bufs[r])
+            return f
+        _run_threads([make(0), make(1)])
+        A0, A1 = sv[0].agent.pi.A, sv[1].agent.pi.A; C0, C1 = sv[0].agent.pi.C, sv[1].agent.pi.C
+        assert np.array_equal(A0.get_params(), A1.get_params()) and np.array_equal(C0.get_params(), C1.get_params())
+        assert infos[0]["actor_batches_trained"] == infos[1]["actor_batches_trained"] and infos[0]["kl"] == infos[1]["kl"]
+        if tk is not None:
+            assert infos[0]["actor_batches_trained"] < 6 * (N // bs)              # the KL stop fired (on the same minibatch in both replicas)
+        else:
+            assert infos[0]["actor_batches_trained"] == 6 * (N // bs) and infos[0]["critic_batches_trained"] == 3 * (N // bs)
+
+
+def test_unsupported_shape_with_a_group_attached_is_refused(two_contexts):
+    """the exchange lives in the two-CU kernels: a learner they do not cover must fail loudly instead of training un-synchronised."""
+    ctx = two_contexts[0]
+    g = crux.ContinuousNetwork(parity.chain([4, 32, 1], ["relu", "identity"]), ctx=ctx)
+    d = _shard(400, E=2, T=64)
+    b = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), 128, ["return", "logprob", "advantage"], ctx=ctx); b.push_(d)
+    with pytest.raises(crux.CruxError) as e:
+        crux.batch_train_(g, crux.TrainingParams(loss=crux.value_mse_loss, batch_size=32, epochs=1), {}, b)
+    assert e.value.code == L.EUNSUP
