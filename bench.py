@@ -1,24 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- PPO actor-learner hot path on MI355X (BASELINE.json configs[1]).
+"""bench.py -- the PPO actor-learner hot path on MI355X (BASELINE.json configs[1]; `--workload c5` = configs[4]'s per-GPU shard).
 
-One "step" = one full PPO iteration on synthetic CartPole shards: 32 envs x 2048-step rollout (65 536 transitions,
-policy forward + env dynamics + SoA column writes in one kernel), GAE/returns, advantage whitening, then
-batch_train! for the actor (ppo_loss) and the critic (mse): 80 epochs x 512 minibatches of 128 each, i.e. exactly
-81 920 sequential Adam steps per iteration (KL early stopping is OFF in the timed configuration so no work is skipped;
-the early-stopping variant is reported separately under "early_stop").
+One "step" = one full PPO iteration on one GPU's environment shard: E envs x 2048-step rollout (policy forward + env dynamics + SoA column
+writes in one kernel), GAE / returns, advantage whitening, then batch_train! for the actor (ppo_loss) and the critic (mse): 80 epochs x
+(E x 2048 / 128) minibatches of 128 each -- for C2 (E = 32) exactly 81 920 sequential Adam steps per iteration. KL early stopping is OFF in the
+timed configuration so no work is skipped (the early-stopping variant is reported separately under "early_stop").
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c5] [--sync grad|params]
 
-N>1: launched by torch.distributed.run, one rank per GPU; every rank owns an independent-seed shard of 32 envs (weak
-scaling) and the replicas exchange parameters + Adam moments with an all-reduce (RCCL over xGMI) after every epoch.
+N > 1: one rank per GPU (the script re-launches itself under torch.distributed.run when it was started plainly); every rank owns an
+independent-seed shard of E envs (weak scaling) and the replicas exchange GRADIENTS: every minibatch step SUM-all-reduces the flattened local
+gradient over the N GPUs inside the persistent learner kernel (peer slots over xGMI, include/cruxhip.h "replica group"), Adam runs on the mean
+-- N replicas with minibatches of 128 are one learner with minibatches of N x 128, parameters stay bit-identical on all ranks (checked after
+the timed region). `--sync params` selects the older periodic form (parameters + Adam moments averaged by RCCL every epoch).
 Rank 0 prints ONE JSON line.
 """
 import os as _os
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: keep the two learner streams on separate hardware queues next to torch/RCCL streams
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,50 +31,66 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_ENVS, T, BATCH, EPOCHS, MAX_STEPS = 32, 2048, 128, 80, 500
+T, BATCH, EPOCHS = 2048, 128, 80
 GAMMA, LAM = 0.99, 0.95
-ACTOR, CRITIC, ACTS = [4, 64, 64, 2], [4, 64, 64, 1], ["relu", "relu", "identity"]
-# algorithmic work per unit (SURVEY.md 8d / DESIGN.md)
-FLOP_ACTOR_STEP = 6 * BATCH * (4 * 64 + 64 * 64 + 64 * 2)     # 3.44 MFLOP: fwd 2*B*P + bwd 4*B*P (P = weight count)
-FLOP_CRITIC_STEP = 6 * BATCH * (4 * 64 + 64 * 64 + 64 * 1)    # 3.39 MFLOP
 PEAK_F32_MFMA_TFLOPS = 157.3                                  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+# workloads: BASELINE.json configs[1] (the metric's config) and configs[4] (per-GPU shard; SYNTH 17/6 dynamics stand in for HalfCheetah, cruxhip.h)
+WORKLOADS = {
+    "c2": dict(n_envs=32, obs=4, act=2, discrete=True, actor=[4, 64, 64, 2], critic=[4, 64, 64, 1], acts=["relu", "relu", "identity"], max_steps=500, lambda_e=0.1,
+               name="PPO CartPole-v1 (device dynamics), DiscreteNetwork 4-64-64-2 + critic 4-64-64-1, 32 envs x 2048-step rollout per GPU"),
+    "c5": dict(n_envs=128, obs=17, act=6, discrete=False, actor=[17, 64, 64, 6], critic=[17, 64, 64, 1], acts=["tanh", "tanh", "identity"], max_steps=1000, lambda_e=0.0,
+               name="PPO on the HalfCheetah-shaped synthetic env (17 obs / 6 act), tanh GaussianPolicy 17-64-64-6 + critic 17-64-64-1, 128 envs x 2048-step rollout per GPU"),
+}
+N_ENVS, MAX_STEPS, ACTOR, CRITIC, ACTS = 32, 500, WORKLOADS["c2"]["actor"], WORKLOADS["c2"]["critic"], WORKLOADS["c2"]["acts"]   # C2 names used by tests/
 
 
-def chain(crux, dims):
-    return crux.Chain(*[crux.Dense(dims[i], dims[i + 1], ACTS[i]) for i in range(3)])
+def flop_step(dims, batch=BATCH):
+    """algorithmic flops of one learner step: forward 2 B P + backward 4 B P, P = weight count."""
+    return 6 * batch * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
 
 
-def build_problem(crux, seed, n_envs=N_ENVS, T_=T):
-    S, A = crux.ContinuousSpace(4), crux.DiscreteSpace(2)
-    actor = crux.DiscreteNetwork(chain(crux, ACTOR), [1, 2], seed=1, stream=0)
-    critic = crux.ContinuousNetwork(chain(crux, CRITIC), seed=1, stream=1)
+FLOP_ACTOR_STEP, FLOP_CRITIC_STEP = flop_step(ACTOR), flop_step(CRITIC)     # 3.44 / 3.39 MFLOP
+
+
+def chain(crux, dims, acts=ACTS):
+    return crux.Chain(*[crux.Dense(dims[i], dims[i + 1], acts[i]) for i in range(len(acts))])
+
+
+def build_problem(crux, seed, n_envs=None, T_=T, workload="c2"):
+    w = WORKLOADS[workload]; n_envs = n_envs or w["n_envs"]
+    S = crux.ContinuousSpace(w["obs"]); A = crux.DiscreteSpace(w["act"]) if w["discrete"] else crux.ContinuousSpace(w["act"])
+    if w["discrete"]:
+        actor = crux.DiscreteNetwork(chain(crux, w["actor"], w["acts"]), list(range(1, w["act"] + 1)), seed=1, stream=0)
+        mdp = crux.CartPoleMDP(n_envs=n_envs, seed=seed, discount=GAMMA)
+    else:
+        actor = crux.GaussianPolicy(chain(crux, w["actor"], w["acts"]), np.full(w["act"], -0.5, np.float32), seed=1, stream=0)
+        mdp = crux.SynthMDP(w["obs"], w["act"], n_envs=n_envs, seed=seed, discount=GAMMA)
+    critic = crux.ContinuousNetwork(chain(crux, w["critic"], w["acts"]), seed=1, stream=1)
     pi = crux.ActorCritic(actor, critic)
     extras = ["return", "logprob", "advantage"]
     buf = crux.ExperienceBuffer(S, A, n_envs * T_, extras)
-    mdp = crux.CartPoleMDP(n_envs=n_envs, seed=seed, discount=GAMMA)
-    sampler = crux.Sampler(mdp, pi, max_steps=MAX_STEPS, required_columns=extras, lam=LAM)
+    sampler = crux.Sampler(mdp, pi, max_steps=w["max_steps"], required_columns=extras, lam=LAM)
     return pi, buf, sampler
 
 
+class _Solver:      # the fields policy_gradient_training reads from an OnPolicySolver
+    def __init__(self, crux, pi, a_opt, c_opt, P):
+        self.agent, self.a_opt, self.c_opt, self.P = crux.PolicyParams(pi), a_opt, c_opt, P
+
+
 def ppo_iteration(crux, pi, buf, sampler, a_opt, c_opt, P, it, sync=None):
-    n = len(buf) if len(buf) else buf.capacity
     info = crux.steps_(sampler, buf, Nsteps=buf.capacity, explore=True, i=it * buf.capacity, reset=True)
     crux.whiten_(buf, "advantage")
-    if sync is None:
-        class _S:       # the fields policy_gradient_training reads from an OnPolicySolver
-            pass
-        sv = _S(); sv.agent = crux.PolicyParams(pi); sv.a_opt, sv.c_opt, sv.P = a_opt, c_opt, P
-        ti = crux.policy_gradient_training(sv, buf)            # on_policy.jl:56-78 (actor then critic; overlapped when exact)
+    sv = _Solver(crux, pi, a_opt, c_opt, P)
+    if sync is None or sync == "grad":
+        # single GPU, or a replica group with peer slots attached to the context: the SAME call -- with a group every minibatch step of the two
+        # persistent kernels all-reduces its gradient over the GPUs (on_policy.jl:56-78 / training.jl:13-25 with the exchange between :18 and :21)
+        ti = crux.policy_gradient_training(sv, buf)
         return ti["actor_batches_trained"] + ti["critic_batches_trained"], info
-    # multi-GPU: one persistent launch per learner per `sync_every` epochs (actor || critic concurrently, as above), then the replicas'
-    # parameters and Adam moments are averaged with ONE all-reduce ("periodic" exchange of north_star; every epoch by default)
-    class _S:
-        pass
-    sv = _S(); sv.agent = crux.PolicyParams(pi); sv.a_opt, sv.c_opt, sv.P = a_opt, c_opt, P
-    if sync == "native":   # the library's own RCCL path: chunks of SYNC_EVERY epochs + grouped all-reduce, all enqueued without a host sync
+    if sync == "native":   # periodic parameter averaging by the library's RCCL communicator: chunks of SYNC_EVERY epochs + grouped all-reduce, enqueued without a host sync
         ti = crux.policy_gradient_training_synced(sv, buf, SYNC_EVERY)
         return ti["actor_batches_trained"] + ti["critic_batches_trained"], info
-    nb, e_total, k = 0, a_opt.epochs, SYNC_EVERY
+    nb, e_total, k = 0, a_opt.epochs, SYNC_EVERY       # torch.distributed fallback of the periodic form (host-synchronised per exchange)
     try:
         done = 0
         while done < e_total:
@@ -84,36 +104,10 @@ def ppo_iteration(crux, pi, buf, sampler, a_opt, c_opt, P, it, sync=None):
     return nb, info
 
 
-SYNC_EVERY = int(os.environ.get("CRUX_SYNC_EVERY", "1"))   # epochs between parameter exchanges in the multi-GPU path
+SYNC_EVERY = int(os.environ.get("CRUX_SYNC_EVERY", "1"))   # epochs between parameter exchanges in the `--sync params` path
 
 
-def cpu_baseline():
-    """Oracle (CPU port of the reference algorithm, single thread) on a bounded sample of the same workload (~10 s of CPU work):
-    one full 32-env x 2048-step rollout + GAE, and 2 x 8192 of the 2 x 40960 minibatch Adam steps (B=128); extrapolated to one full iteration."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle as O
-    from crux_jl_amd import _lib as L
-    import parity
-    Ts = T
-    oa = O.OMlp(ACTOR, ACTS).init_glorot(1, 0); oc = O.OMlp(CRITIC, ACTS).init_glorot(1, 1)
-    oa.adam_init(float(np.float32(3e-4))); oc.adam_init(float(np.float32(3e-4)))
-    extras = ["return", "logprob", "advantage"]
-    ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, N_ENVS * Ts, extras)
-    oe = O.OEnv("cartpole", N_ENVS, MAX_STEPS, GAMMA, 0)
-    t0 = time.perf_counter()
-    oe.rollout(oa, parity.rollout_cfg(), ob, Ts)
-    O.chk(O.lib().orc_fill_gae(ob.h, oc.h, LAM, GAMMA)); O.chk(O.lib().orc_fill_returns(ob.h, GAMMA)); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
-    t_roll = time.perf_counter() - t0
-    n_mb = 8192
-    info = np.zeros(L.INFO_N, np.float32)
-    t0 = time.perf_counter()
-    for loss, head, net in (("ppo", "categorical", oa), ("value_mse", "deterministic", oc)):
-        cfg = parity.train_cfg(loss, head, BATCH, 16, -1.0, 7, 0, max_batches=n_mb)
-        O.chk(O.lib().orc_batch_train(net.h, ob.h, C.byref(cfg), None, O.vpz(info), None))
-    t_train = time.perf_counter() - t0
-    per_env_step = t_roll / (N_ENVS * Ts)
-    per_grad_step = t_train / (2 * n_mb)
-    t_iter = per_env_step * N_ENVS * T + per_grad_step * 2 * EPOCHS * (N_ENVS * T // BATCH)
+def host_cpu():
     model = "?"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -121,10 +115,178 @@ def cpu_baseline():
                 model = ln.split(":", 1)[1].strip(); break
     except OSError:
         pass
-    return {"value": N_ENVS * T / t_iter, "unit": "env-steps/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": os.cpu_count(),
-            "sample": "oracle/ (C restatement of Crux.jl, 1 thread): 32x%d-step rollout+GAE (%.2fs) and %d Adam steps at B=128 (%.2fs), extrapolated to one 65536-transition / 81920-step iteration"
-                      % (Ts, t_roll, 2 * n_mb, t_train),
-            "grad_steps_per_s": 1.0 / per_grad_step, "rollout_env_steps_per_s": 1.0 / per_env_step}
+    return model, os.cpu_count()
+
+
+def cpu_baseline(workload="c2"):
+    """Oracle (CPU restatement of the reference algorithm, the faithful analogue of the single-threaded reference) on a bounded sample of the same
+    workload (~10-20 s of CPU work): a rollout + GAE of all E envs over T_s steps and n_mb Adam steps per learner at B = 128; scaled to one full
+    iteration. When oracle/libcruxoracle_omp.so exists (the OpenMP env-parallel / batch-parallel variant on all host cores), it is timed too."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from crux_jl_amd import _lib as L
+    import parity
+    w = WORKLOADS[workload]; E = w["n_envs"]
+    Ts = T if workload == "c2" else 256
+    n_mb = 8192 if workload == "c2" else 2048
+    kind = L.ACTION_DISCRETE if w["discrete"] else L.ACTION_CONTINUOUS
+    head = "categorical" if w["discrete"] else "gaussian"
+    extras = ["return", "logprob", "advantage"]
+
+    def run(lib_sel):
+        O.select(lib_sel)
+        oa = O.OMlp(w["actor"], w["acts"], 0 if w["discrete"] else w["act"]).init_glorot(1, 0, -0.5); oc = O.OMlp(w["critic"], w["acts"]).init_glorot(1, 1)
+        oa.adam_init(float(np.float32(3e-4))); oc.adam_init(float(np.float32(3e-4)))
+        ob = O.OBuffer(w["obs"], w["act"], kind, E * Ts, extras)
+        oe = O.OEnv("cartpole" if workload == "c2" else "synth", E, w["max_steps"], GAMMA, 0, so=w["obs"] if workload != "c2" else 0, sa=w["act"] if workload != "c2" else 0)
+        t0 = time.perf_counter()
+        oe.rollout(oa, parity.rollout_cfg(head=head), ob, Ts)
+        O.chk(O.lib().orc_fill_gae(ob.h, oc.h, LAM, GAMMA)); O.chk(O.lib().orc_fill_returns(ob.h, GAMMA)); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
+        t_roll = time.perf_counter() - t0
+        info = np.zeros(L.INFO_N, np.float32)
+        t0 = time.perf_counter()
+        for loss, hd, net in (("ppo", head, oa), ("value_mse", "deterministic", oc)):
+            cfg = parity.train_cfg(loss, hd, BATCH, 64, -1.0, 7, 0, max_batches=n_mb, le=w["lambda_e"])
+            O.chk(O.lib().orc_batch_train(net.h, ob.h, C.byref(cfg), None, O.vpz(info), None))
+        t_train = time.perf_counter() - t0
+        return t_roll / (E * Ts), t_train / (2 * n_mb), t_roll, t_train
+    per_env_step, per_grad_step, t_roll, t_train = run("scalar")
+    steps_iter = 2 * EPOCHS * (E * T // BATCH)
+    t_iter = per_env_step * E * T + per_grad_step * steps_iter
+    model, ncpu = host_cpu()
+    out = {"value": E * T / t_iter, "unit": "env-steps/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": ncpu,
+           "sample": "oracle/ (C restatement of Crux.jl, 1 thread): %dx%d-step rollout+GAE (%.2fs) and %d Adam steps at B=128 (%.2fs), scaled to one %d-transition / %d-step iteration"
+                     % (E, Ts, t_roll, 2 * n_mb, t_train, E * T, steps_iter),
+           "grad_steps_per_s": 1.0 / per_grad_step, "rollout_env_steps_per_s": 1.0 / per_env_step}
+    if O.have("omp"):
+        try:
+            pe, pg, tr, tt = run("omp")
+            nthr = int(O.lib().orc_omp_threads())
+            out["openmp_all_cores"] = {"value": E * T / (pe * E * T + pg * steps_iter), "unit": "env-steps/s", "cores": nthr, "grad_steps_per_s": 1.0 / pg, "rollout_env_steps_per_s": 1.0 / pe,
+                                       "sample": "oracle built with -fopenmp (environments in parallel for the rollout, minibatch samples in parallel inside a learner step): same sample, %.2fs + %.2fs" % (tr, tt)}
+        except Exception as e:      # noqa: BLE001  (supplementary)
+            out["openmp_all_cores"] = {"error": repr(e)}
+        O.select("scalar")
+    ref = julia_reference_probe()
+    if ref:
+        out["julia_reference"] = ref
+    return out
+
+
+def julia_reference_probe():
+    """when a `julia` with Crux installed exists on the box, time the reference itself (bench/crux_ref.jl); otherwise say why not."""
+    import shutil
+    jl = shutil.which("julia")
+    if not jl:
+        return {"available": False, "why": "no `julia` binary on this box (the reference is pure Julia; it cannot be timed here)"}
+    script = os.path.join(ROOT, "julia", "crux_ref_bench.jl")
+    try:
+        r = subprocess.run([jl, "--project=" + os.path.join(ROOT, "julia"), script], capture_output=True, text=True, timeout=900)
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                d = json.loads(ln); d["available"] = True; return d
+        return {"available": False, "why": "julia ran but printed no result (Crux.jl not installed?): " + (r.stderr or r.stdout)[-300:]}
+    except Exception as e:      # noqa: BLE001
+        return {"available": False, "why": repr(e)}
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` started plainly: become the launcher (one rank per GPU on this node, rendezvous on 127.0.0.1)."""
+    port = os.environ.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def setup_group(args, crux, ctx, rank, world, local):
+    """Attach this rank to the replica group. Preference order, each level agreed by ALL ranks (a MIN all-reduce) before it is used:
+    (1) peer slots: in-kernel per-minibatch gradient all-reduce over xGMI (exact data parallelism)   [--sync grad]
+    (2) the library's RCCL communicator: parameters + Adam moments averaged every SYNC_EVERY epochs   [--sync params, or fallback]
+    (3) torch.distributed all-reduce of the same tensors (host-synchronised)                         [last resort]"""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", local) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+    def all_agree(flag):
+        t = torch.tensor([1 if flag else 0], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MIN); return int(t.item()) == 1
+
+    if args.sync == "grad":
+        ok, handles = True, None
+        try:
+            mine = torch.from_numpy(ctx.peer_export().copy()).to(dev)
+        except Exception as e:      # noqa: BLE001
+            print("bench.py: rank %d cannot export a peer region (%r)" % (rank, e), file=sys.stderr); ok = False; mine = torch.zeros(64, dtype=torch.uint8, device=dev)
+        gathered = [torch.zeros(64, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        if all_agree(ok):
+            try:
+                handles = np.stack([g.cpu().numpy() for g in gathered]); ctx.peer_attach(rank, world, handles)
+            except Exception as e:      # noqa: BLE001
+                print("bench.py: rank %d cannot attach the peer regions (%r)" % (rank, e), file=sys.stderr); ok = False
+            if all_agree(ok):
+                dist.barrier()      # every rank has attached before any of them trains (cruxhip.h)
+                return "grad", "per-minibatch SUM all-reduce of the gradient inside the persistent learner kernel (peer slots over xGMI, hipIpc-mapped)"
+            try:
+                ctx.peer_detach()
+            except Exception:       # noqa: BLE001
+                pass
+        print("bench.py: peer-slot gradient exchange unavailable, falling back to periodic parameter averaging", file=sys.stderr)
+
+    wrapped = {}
+
+    def torch_sync(nets):   # average parameters and Adam moments of all networks across ranks
+        key = tuple(id(n) for n in nets)
+        if key not in wrapped:
+            lib, ts = ctx.lib, []
+
+            def wrap(ptr, n):
+                class _I:
+                    __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+                return torch.as_tensor(_I(), device="cuda:%d" % local)
+            for net in nets:
+                pm, pv = C.c_void_p(), C.c_void_p()
+                ctx.check(lib.crux_adam_state_ptrs(net.h, C.byref(pm), C.byref(pv)))
+                ts += [wrap(lib.crux_mlp_params_ptr(net.h), net.n_params), wrap(pm.value, net.n_params), wrap(pv.value, net.n_params)]
+            wrapped[key] = (ts, [t.numel() for t in ts])
+        ts, sizes = wrapped[key]
+        ctx.sync()                                   # the library's streams produced the values
+        flat = torch.cat(ts)
+        if dist.get_backend() != "nccl":
+            h = flat.cpu(); dist.all_reduce(h, op=dist.ReduceOp.SUM); flat.copy_(h)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / world)
+        torch._foreach_copy_(ts, list(flat.split(sizes)))   # tensors alias library memory
+        torch.cuda.current_stream().synchronize()
+
+    if os.environ.get("CRUX_NATIVE_COMM", "1") != "0" and dist.get_backend() == "nccl":
+        uid_np = np.zeros(129, np.uint8)
+        if rank == 0:
+            try:
+                uid_np[:128] = ctx.comm_unique_id(); uid_np[128] = 1
+            except Exception as e:      # noqa: BLE001
+                print("bench.py: native RCCL unavailable (%r)" % (e,), file=sys.stderr)
+        uid = torch.from_numpy(uid_np).to(dev); dist.broadcast(uid, 0); uid_np = uid.cpu().numpy()     # every rank takes part, whatever happened on rank 0
+        ok = False
+        if uid_np[128]:
+            try:
+                ctx.comm_init(rank, world, uid_np[:128].copy()); ok = True
+            except Exception as e:      # noqa: BLE001
+                print("bench.py: native RCCL communicator failed on rank %d (%r)" % (rank, e), file=sys.stderr)
+        if all_agree(ok):
+            return "native", "parameters + Adam moments averaged every %d epoch(s) by the library's RCCL communicator (stream-ordered grouped all-reduce)" % SYNC_EVERY
+        if ok:
+            ctx.comm_destroy()
+    return torch_sync, "parameters + Adam moments averaged every %d epoch(s) by a torch.distributed all_reduce (host-synchronised)" % SYNC_EVERY
+
+
+def params_digest(nets):
+    """order-independent exact digest of the replicated state (parameters + Adam moments): equal on all ranks iff the replicas are bit-identical."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in nets:
+        h.update(n.get_params().tobytes()); m, v, bp = n.adam_state(); h.update(m.tobytes()); h.update(v.tobytes()); h.update(bp.tobytes())
+    return np.frombuffer(h.digest()[:8], np.int64)[0]
 
 
 def main():
@@ -132,91 +294,57 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2", help="c2 = BASELINE configs[1] (the metric's config, default); c5 = configs[4]'s per-GPU shard")
+    ap.add_argument("--sync", choices=["grad", "params"], default="grad", help="multi-GPU exchange: grad = per-minibatch gradient all-reduce inside the learner kernel (exact); params = periodic parameter averaging (RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-sync", action="store_true", help="exercise the multi-GPU parameter exchange even at world size 1 (testing)")
+    ap.add_argument("--force-sync", action="store_true", help="exercise the multi-GPU path even at world size 1 (testing)")
+    ap.add_argument("--same-device", action="store_true", help="testing on a 1-GPU box: all ranks use device 0 (gloo rendezvous; the peer regions are still exchanged through hipIpc between the processes)")
     ap.add_argument("--replicas", type=int, default=64, help="also time S independent PPO learners (multi-seed) trained by two batched launches per iteration: the chip-level utilisation line (0 = skip)")
     ap.add_argument("--replicas-wide", type=int, default=128, help="second multi-seed line with one CU per learner (population > 64): the highest chip utilisation (0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the supplementary configs (C5 shard, off-policy lines)")
     ap.add_argument("--early-stop", action="store_true", help="also time the KL-early-stopping variant (target_kl=0.012)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_device:
+        local = 0
     # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner on stdout) are pointed at stderr instead
     sys.stdout.flush(); json_fd = os.dup(1); os.dup2(2, 1)
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = torch = None
     if world > 1 or args.force_sync:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import crux_jl_amd as crux
     from crux_jl_amd import dist as cdist
     ctx = crux.Context(local)
     crux.set_default_context(ctx)
-    pi, buf, sampler = build_problem(crux, cdist.shard_seed(0, rank))
-    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+    wl = WORKLOADS[args.workload]; E = wl["n_envs"]
+    pi, buf, sampler = build_problem(crux, cdist.shard_seed(0, rank), workload=args.workload)
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": wl["lambda_e"]}
     a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=BATCH, epochs=EPOCHS, target_kl=None, name="actor_", shuffle_seed=100 + rank)
     c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=BATCH, epochs=EPOCHS, name="critic_", shuffle_seed=200 + rank)
 
-    sync = None
+    sync, comm_kind = None, "single GPU"
     if world > 1 or args.force_sync:
-        wrapped = {}
-
-        def sync(nets):   # average parameters and Adam moments of all networks across ranks: one RCCL all-reduce over xGMI
-            key = tuple(id(n) for n in nets)
-            if key not in wrapped:
-                lib, ts = ctx.lib, []
-
-                def wrap(ptr, n):
-                    class _I:
-                        __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
-                    return torch.as_tensor(_I(), device="cuda:%d" % local)
-                for net in nets:
-                    pm, pv = C.c_void_p(), C.c_void_p()
-                    ctx.check(lib.crux_adam_state_ptrs(net.h, C.byref(pm), C.byref(pv)))
-                    ts += [wrap(lib.crux_mlp_params_ptr(net.h), net.n_params), wrap(pm.value, net.n_params), wrap(pv.value, net.n_params)]
-                wrapped[key] = (ts, [t.numel() for t in ts])
-            ts, sizes = wrapped[key]
-            ctx.sync()                                   # the library's streams produced the values
-            flat = torch.cat(ts)                         # 6 x ~18 KB -> one 110 KB message (latency-bound either way on xGMI)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.mul_(1.0 / world)
-            torch._foreach_copy_(ts, list(flat.split(sizes)))   # tensors alias library memory
-            torch.cuda.current_stream().synchronize()
-
-        # preferred: the library's native communicator (RCCL dlopen'ed by libcruxhip, id shipped through torch.distributed);
-        # the torch.distributed exchange above stays as the fallback when RCCL cannot be initialised from the library
-        comm_kind = "torch.distributed all_reduce (host-synchronised per exchange)"; torch_sync = sync
-        if os.environ.get("CRUX_NATIVE_COMM", "1") != "0":
-            uid_np = np.zeros(129, np.uint8)
-            if rank == 0:
-                try:
-                    uid_np[:128] = ctx.comm_unique_id(); uid_np[128] = 1
-                except Exception as e:
-                    print("bench.py: native RCCL unavailable (%r)" % (e,), file=sys.stderr)
-            uid = torch.from_numpy(uid_np).cuda(); dist.broadcast(uid, 0); uid_np = uid.cpu().numpy()     # every rank takes part, whatever happened on rank 0
-            if uid_np[128]:
-                try:
-                    ctx.comm_init(rank, world, uid_np[:128].copy())
-                    sync = "native"; comm_kind = "libcruxhip RCCL communicator (stream-ordered grouped all-reduce)"
-                except Exception as e:
-                    print("bench.py: native RCCL communicator failed on rank %d (%r)" % (rank, e), file=sys.stderr)
-            ok = torch.tensor([1 if sync == "native" else 0], device="cuda"); dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks or none
-            if int(ok.item()) == 0 and sync == "native":
-                ctx.comm_destroy()
-            if int(ok.item()) == 0:
-                sync = torch_sync; comm_kind = "torch.distributed all_reduce (host-synchronised per exchange)"
+        sync, comm_kind = setup_group(args, crux, ctx, rank, world, local)
 
     def barrier():
         ctx.sync()
         if dist is not None:
-            dist.barrier(); torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
 
     it = 0
     for _ in range(args.warmup):
@@ -231,9 +359,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ctx.prof_enable(False)
+    replicas_identical = None
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dt = float(tmax.item())
-        gs = torch.tensor([grad_steps], dtype=torch.float64, device="cuda"); dist.all_reduce(gs); grad_steps = int(gs.item())
+        tdev = torch.device("cuda", local) if dist.get_backend() == "nccl" else torch.device("cpu")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dt = float(tmax.item())
+        gs = torch.tensor([grad_steps], dtype=torch.float64, device=tdev); dist.all_reduce(gs); grad_steps = int(gs.item())
+        dg = torch.tensor([int(params_digest((pi.A, pi.C)))], dtype=torch.int64, device=tdev)
+        lo, hi = dg.clone(), dg.clone(); dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(int(lo.item()) == int(hi.item()))
 
     prof = {k: ctx.prof_get(k) for k in ("rollout", "values", "gae", "whiten", "train_actor", "train_critic")}
     early = None
@@ -243,19 +376,19 @@ def main():
         for _ in range(args.steps):
             nb, _i = ppo_iteration(crux, pi, buf, sampler, a_es, c_opt, P, it); it += 1; nbs += nb
         ctx.sync(); d1 = time.perf_counter() - t1
-        early = {"env_steps_per_s": args.steps * N_ENVS * T / d1, "grad_steps_per_s": nbs / d1, "grad_steps_per_iter": nbs / args.steps}
+        early = {"env_steps_per_s": args.steps * E * T / d1, "grad_steps_per_s": nbs / d1, "grad_steps_per_iter": nbs / args.steps}
 
-    multi = None
     def multi_seed_line(Sn):
         try:
             probs = [build_problem(crux, cdist.shard_seed(1000, r)) for r in range(Sn)]
             am = crux.TrainingParams(loss=crux.ppo_loss, batch_size=BATCH, epochs=EPOCHS, target_kl=None, name="actor_", shuffle_seed=5000)
             cm = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=BATCH, epochs=EPOCHS, name="critic_", shuffle_seed=6000)
+            P2 = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
 
             def multi_iteration(k):
                 crux.steps_multi_([q[2] for q in probs], [q[1] for q in probs], Nsteps=probs[0][1].capacity, explore=True, i=k * probs[0][1].capacity, reset=True)   # one rollout launch for all S problems
                 crux.whiten_multi_([q[1] for q in probs], "advantage")
-                infos = crux.policy_gradient_training_multi([q[0] for q in probs], am, cm, P, [q[1] for q in probs])
+                infos = crux.policy_gradient_training_multi([q[0] for q in probs], am, cm, P2, [q[1] for q in probs])
                 return sum(i["actor_batches_trained"] + i["critic_batches_trained"] for i in infos)
             multi_iteration(0); ctx.sync(); ctx.prof_reset(); ctx.prof_enable(True); t1 = time.perf_counter(); gsm = 0
             n_it = max(1, min(args.steps, 2))
@@ -263,61 +396,76 @@ def main():
                 gsm += multi_iteration(1 + k)
             ctx.sync(); d1 = time.perf_counter() - t1; ctx.prof_enable(False)
             ms_a, n_a = ctx.prof_get("train_actor")
-            flops_a = Sn * EPOCHS * (N_ENVS * T // BATCH) * FLOP_ACTOR_STEP            # per batched actor launch
+            steps_l = EPOCHS * (N_ENVS * T // BATCH)
+            flops_all = Sn * steps_l * (FLOP_ACTOR_STEP + FLOP_CRITIC_STEP) * n_it          # every learner step of every replica in the timed region
             cus = 2 if Sn <= 64 else 1
             return {"replicas": Sn, "cus_per_learner": cus, "env_steps_per_s": n_it * Sn * N_ENVS * T / d1, "grad_steps_per_s": gsm / d1, "ms_per_iteration": 1e3 * d1 / n_it,
                     "phase_ms_per_iteration": {k: ctx.prof_get(k)[0] / n_it for k in ("rollout", "values", "gae", "whiten", "train_actor")},
-                    "batched_actor_launch_ms": ms_a / max(1, n_a), "actor_launch_TFLOPs": flops_a / (ms_a / max(1, n_a) * 1e-3) / 1e12,
-                    "actor_launch_frac_of_f32_mfma_peak": flops_a / (ms_a / max(1, n_a) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                    "actor_plus_critic_frac_of_f32_mfma_peak": (flops_a + Sn * EPOCHS * (N_ENVS * T // BATCH) * FLOP_CRITIC_STEP) / (ms_a / max(1, n_a) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                    "note": "S independent PPO problems (own envs, buffers, seeds); all S actors in one launch, all S critics in a concurrent one: %d S CUs busy" % (2 * cus)}
-        except Exception as e:      # supplementary line: never let it take the headline measurement down
+                    "batched_actor_launch_ms": ms_a / max(1, n_a),
+                    "end_to_end_TFLOPs": flops_all / d1 / 1e12, "end_to_end_frac_of_f32_mfma_peak": flops_all / d1 / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "learner_launches_frac_of_f32_mfma_peak": Sn * steps_l * (FLOP_ACTOR_STEP + FLOP_CRITIC_STEP) / (ms_a / max(1, n_a) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "note": "S independent PPO problems (own envs, buffers, seeds); all S actors in one launch, all S critics in a concurrent one: %d S CUs busy. end_to_end = all learner flops / wall time of whole iterations (rollout, GAE, order composition included); learner_launches = the same flops / duration of the concurrent actor||critic launches" % (2 * cus)}
+        except Exception as e:      # noqa: BLE001  supplementary line: never let it take the headline measurement down
             return {"replicas": Sn, "error": repr(e)}
 
-    multi = multi_wide = None
-    if args.replicas > 1 and world == 1:
-        multi = multi_seed_line(args.replicas)
-        if args.replicas_wide > 1:
-            multi_wide = multi_seed_line(args.replicas_wide)
+    multi = multi_wide = extra = None
+    if world == 1 and not args.force_sync and args.workload == "c2":
+        if args.replicas > 1:
+            multi = multi_seed_line(args.replicas)
+            if args.replicas_wide > 1:
+                multi_wide = multi_seed_line(args.replicas_wide)
+        if not args.no_extra:
+            try:
+                import bench_extra
+                extra = bench_extra.run(crux, ctx, cpu=not args.no_cpu_baseline)
+            except Exception as e:      # noqa: BLE001
+                extra = {"error": repr(e)}
 
     if rank == 0:
-        env_steps = args.steps * N_ENVS * T * world
+        env_steps = args.steps * E * T * world
         ms_actor, n_actor = prof["train_actor"]
         launches_per_iter = max(1, n_actor // max(1, args.steps))
-        steps_per_launch = EPOCHS * (N_ENVS * T // BATCH) / launches_per_iter
+        steps_per_launch = EPOCHS * (E * T // BATCH) / launches_per_iter
         avg_launch_s = (ms_actor / max(1, n_actor)) * 1e-3
-        achieved = FLOP_ACTOR_STEP * steps_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        fa = flop_step(wl["actor"])
+        achieved = fa * steps_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         out = {
-            "metric": "env-steps/sec + grad-steps/sec, PPO 2048x32 rollout",
+            "metric": "env-steps/sec + grad-steps/sec, PPO 2048x32 rollout" if args.workload == "c2" else "env-steps/sec + grad-steps/sec, PPO 2048x128 rollout (C5 shard)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "PPO CartPole-v1 (device dynamics), DiscreteNetwork 4-64-64-2 + critic 4-64-64-1, 32 envs x 2048-step rollout per GPU, "
-                                   "batch 128, 80 epochs actor + 80 epochs critic (81920 Adam steps/iter, KL early-stop off), Adam 3e-4",
-                       "envs_per_gpu": N_ENVS, "rollout_T": T, "batch_size": BATCH, "epochs": EPOCHS,
-                       "parallelism": ("env-shards x%d, parameter+Adam-moment all-reduce every %d epoch(s), %s" % (world, SYNC_EVERY, comm_kind)) if sync is not None else "single GPU"},
+            "config": {"workload": wl["name"] + ", batch 128, 80 epochs actor + 80 epochs critic (%d Adam steps/iter, KL early-stop off), Adam 3e-4" % (2 * EPOCHS * (E * T // BATCH)),
+                       "envs_per_gpu": E, "rollout_T": T, "batch_size": BATCH, "epochs": EPOCHS,
+                       "parallelism": ("env-shards x%d (global minibatch %d): %s" % (world, world * BATCH, comm_kind)) if sync is not None else "single GPU"},
             "grad_steps_per_s": grad_steps / dt,
             "phase_ms_per_iter": {k: v[0] / args.steps for k, v in prof.items()},
-            "rollout_env_steps_per_s": (N_ENVS * T * args.steps) / (prof["rollout"][0] * 1e-3) if prof["rollout"][0] > 0 else None,
+            "rollout_env_steps_per_s": (E * T * args.steps) / (prof["rollout"][0] * 1e-3) if prof["rollout"][0] > 0 else None,
             "roofline": {"kernel": "batch_train! actor (persistent fwd+ppo_loss+bwd+Adam)", "bound": "mfma", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": 16.6e6 if world == 1 else None,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": 16.6e6 if (world == 1 and args.workload == "c2") else None,
                          "traffic_note": "HBM-side bytes per actor launch from rocprofv3 --pmc FETCH_SIZE (13.86 MB) + WRITE_SIZE (2.70 MB), separate passes of this command (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.txt); a recorded constant, not re-measured in this run. Algorithmic minibatch bytes per launch are 136 MB (40960 x 3328 B): the 3.4 MB buffer is re-read from L2/MALL, and the 1.6 GB/launch of gradient exchange between the two workgroups stays inside one XCD's L2",
                          "avg_launch_ms": avg_launch_s * 1e3, "grad_steps_per_launch": steps_per_launch,
                          "us_per_grad_step": avg_launch_s * 1e6 / steps_per_launch if steps_per_launch else None,
-                         "note": "81920 serially dependent 3.4-MFLOP steps: each learner step is split over two CUs of one XCD (gradient exchange through the shared L2), actor and critic run concurrently -> 4 CUs busy; per-CU f32 MFMA peak is 0.614 TFLOP/s"},
+                         "note": "serially dependent %.2f-MFLOP steps: each learner step is split over two CUs of one XCD (gradient exchange through the shared L2), actor and critic run concurrently -> 4 CUs busy; per-CU f32 MFMA peak is 0.614 TFLOP/s" % (fa / 1e6)},
         }
+        if replicas_identical is not None:
+            out["replicas_bit_identical_after_run"] = replicas_identical
         if early:
             out["early_stop"] = early
         if multi is not None:
             out["multi_seed"] = multi
         if multi_wide is not None:
             out["multi_seed_one_cu_per_learner"] = multi_wide
+        if extra is not None:
+            out["other_configs"] = extra
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.workload)
         sys.stdout.flush(); os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
+        barrier()
         if sync == "native":
             ctx.comm_destroy()                 # the library's communicator goes first, then torch's
+        if sync == "grad":
+            ctx.peer_detach()
         dist.destroy_process_group()
 
 

@@ -48,6 +48,15 @@ _SIG = {
 }
 
 _lib = None
+_libs = {}
+OMP_PATH = os.path.join(ROOT, "oracle", "libcruxoracle_omp.so")      # the same restatement built with -fopenmp (bench.py's all-cores CPU baseline only)
+
+
+def _load(path):
+    l = C.CDLL(path)
+    for name, (res, args) in _SIG.items():
+        fn = getattr(l, name); fn.restype = res; fn.argtypes = args
+    return l
 
 
 def lib():
@@ -55,10 +64,21 @@ def lib():
     if _lib is None:
         if not os.path.exists(ORACLE_PATH):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-        _lib = C.CDLL(ORACLE_PATH)
-        for name, (res, args) in _SIG.items():
-            fn = getattr(_lib, name); fn.restype = res; fn.argtypes = args
+        _lib = _libs["scalar"] = _load(ORACLE_PATH)
     return _lib
+
+
+def have(which):
+    return which == "scalar" or (which == "omp" and os.path.exists(OMP_PATH))
+
+
+def select(which):
+    """switch the library the wrappers below bind to ("scalar" = the parity oracle, "omp" = its OpenMP build); objects made before a switch stay with their library's handles and must not be mixed."""
+    global _lib
+    lib()
+    if which not in _libs:
+        _libs[which] = _load(OMP_PATH); _libs[which].orc_omp_threads.restype = C.c_int32
+    _lib = _libs[which]
 
 
 def vpz(a):
