@@ -76,6 +76,7 @@ static void launch_copy_rows(crux_ctx* c, void* dst, const int64_t* d_dst_idx, c
 }
 
 extern "C" int32_t crux_buffer_indices(const crux_buffer* cb, int64_t* out, int64_t n);
+int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool from_push);   // per.hip: priorities of these elements changed
 // exported to other translation units ------------------------------------------------------------------
 int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I) {
   I.resize((size_t)N);
@@ -96,8 +97,8 @@ int32_t crux_buffer_per_on_push(crux_buffer* b, const int64_t* d_I, int64_t N) {
   HIPCHK(b->ctx, hipMemcpyAsync(b->pminmax + 2, b->pminmax, 4, hipMemcpyDeviceToDevice, b->ctx->stream));
   hipLaunchKernelGGL(k_per_update, dim3(grid_for(N)), dim3(256), 0, b->ctx->stream, b->priorities, b->pminmax, d_I, (const double*)nullptr,
                      (const float*)nullptr, (const float*)(b->pminmax + 2), b->alpha, N);
-  b->cumsum_valid = false;
-  return crux_launch_check(b->ctx, "k_per_update(push)");
+  { const int32_t rc = crux_launch_check(b->ctx, "k_per_update(push)"); if (rc) return rc; }
+  return crux_per_touched(b, d_I, N, true);
 }
 // physical permutation of every column by a device int32 order: new[:,j] = old[:,order[j]]
 int32_t crux_buffer_apply_order(crux_buffer* b, const int32_t* d_order, int64_t n) {
@@ -212,7 +213,7 @@ int32_t crux_buffer_clear(crux_buffer* b) {                                     
     const float inf = INFINITY;                                                         // PriorityParams(N, pp) keeps max_priority, resets min
     HIPCHK(b->ctx, hipMemcpyAsync(b->pminmax + 1, &inf, 4, hipMemcpyHostToDevice, b->ctx->stream));
     HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
-    b->cumsum_valid = false;
+    b->cumsum_valid = false; b->per_full_dirty = true;
   }
   return CRUX_OK;
 }
@@ -427,8 +428,9 @@ int32_t crux_per_update(crux_buffer* b, const int64_t* I, const void* v, int32_t
                      v_is_f64 ? (const double*)(sc + ib) : (const double*)nullptr, v_is_f64 ? (const float*)nullptr : (const float*)(sc + ib),
                      (const float*)nullptr, b->alpha, n);
   int32_t rc = crux_launch_check(c, "k_per_update"); if (rc) return rc;
+  { bool in_tree = true; for (int64_t j = 0; j < n; ++j) in_tree = in_tree && I[j] < b->elements;      // rows beyond length(b) are outside the current tree
+    if (!in_tree) { b->per_full_dirty = true; b->cumsum_valid = false; } else { rc = crux_per_touched(b, (const int64_t*)sc, n, false); if (rc) return rc; } }                     // :299 cumsum_valid = false; only the touched leaves are re-summed
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  b->cumsum_valid = false;                                                               // :299
   return CRUX_OK;
 }
 
@@ -438,8 +440,8 @@ int32_t crux_per_update_device(crux_buffer* b, const int64_t* d_ids, const float
   if (n == 0) return CRUX_OK;
   hipLaunchKernelGGL(k_per_update, dim3(grid_for(n)), dim3(256), 0, b->ctx->stream, b->priorities, b->pminmax, d_ids, (const double*)nullptr, d_v,
                      (const float*)nullptr, b->alpha, n);
-  b->cumsum_valid = false;
-  return crux_launch_check(b->ctx, "k_per_update(device)");
+  { const int32_t rc = crux_launch_check(b->ctx, "k_per_update(device)"); if (rc) return rc; }
+  return crux_per_touched(b, d_ids, n, false);
 }
 
 }  // extern "C"

@@ -44,6 +44,7 @@ struct crux_ctx {
 //   abort   uint32 at CRUX_PX_ABORT                        set by any rank that gave up waiting
 //   count   uint64 at CRUX_PX_COUNT                        exchanges done so far on this stream (local bookkeeping: slot parity and flag values
 //                                                          continue across launches, so the double buffering argument holds across them too)
+#define CRUX_PER_PMAX 24   // deepest pairwise-cumsum tree handled incrementally (N < 128 * 2^24)
 #define CRUX_PX_MAXR 8
 #define CRUX_PX_SLOT 8192
 #define CRUX_PX_FLAGS (2 * CRUX_PX_MAXR * CRUX_PX_SLOT)
@@ -114,6 +115,14 @@ struct crux_buffer {
   int32_t* topo_leaf_start = nullptr; int32_t* topo_leaf_len = nullptr; int32_t* topo_leaf_node = nullptr;
   int32_t* topo_left = nullptr; int32_t* topo_right = nullptr; int32_t* topo_level_off = nullptr;   // nodes sorted by level
   float* topo_total = nullptr; float* topo_prefix = nullptr;
+  // incremental maintenance (per.hip): `cumsum` holds the leaf-LOCAL running sums; c[i] = prefix[leaf(i)] + cumsum[i]. After update_priorities! only the
+  // touched leaves are re-summed (k_leaf_refresh); the node totals / prefixes are re-derived by the LDS tree pass at the next sample.
+  int32_t* topo_leaf_of = nullptr;      // device [N]: node id of the leaf holding element i (i >= 1)
+  int32_t* topo_node_start = nullptr; int32_t* topo_node_len = nullptr;   // device [nodes]: element range of every node
+  int32_t* topo_path = nullptr;         // device [nodes][CRUX_PER_PMAX]: for a leaf, the left siblings met on the way down from the root (top-down order, -1 = went left)
+  int32_t* topo_anc = nullptr;          // device [nodes][CRUX_PER_PMAX]: for a leaf, its ancestors bottom-up (-1 past the root)
+  int32_t* topo_depth = nullptr;        // device [nodes]: level of the node (root 0)
+  int64_t per_run_n = -1; bool per_full_dirty = true;
   int32_t* order_a = nullptr;    // device [capacity] logical->physical order scratch for batch_train
   int32_t* order_b = nullptr;
   float* aux_ones = nullptr; float* aux_zeros = nullptr;   // [capacity] constant columns (logpdf_bc_loss = a2c_loss with advantage 1, old logprob 0)

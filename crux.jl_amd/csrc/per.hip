@@ -10,6 +10,13 @@
 //   k_leaf_scan     one thread per leaf: c[i] = prefix + running leaf sum              (streams N floats in, N out)
 // followed by k_per_search (Float64 key against the Float32 cumsum, :335-340), the IS weights (:343-347) and the row gather.
 // The tree shape depends only on N and is built on the host once per buffer length.
+//
+// Incremental form (the reference rescans all N priorities per gradient step, :329-332; its abandoned sum-tree is at :48,:334-336): the cumsum is
+// never materialised. `cumsum[i]` holds the running sum INSIDE i's leaf and c[i] = prefix[leaf(i)] + cumsum[i] is formed when the search probes
+// it -- the same two Float32 additions in the same order as accumulate_pairwise! performs (c[i] = op(s, s_)). update_priorities! re-sums only the
+// leaves it touched (k_leaf_refresh: <= 127 elements each), the next sample re-derives node totals and prefixes with the LDS tree pass over the
+// ~N/95 leaves' nodes, and searchsortedfirst probes exactly the elements the reference's binary search would. Per sampled step at N = 1 M:
+// <= 128 x 127 x 8 B of leaf traffic + 170 KB of tree nodes + 20 KB of probes instead of 8 MB.
 #include "common.h"
 #include <algorithm>
 
@@ -27,11 +34,11 @@ static int32_t topo_rec(TopoBuild& t, int64_t i1, int64_t n, int lvl) {
 }
 
 static void topo_free(crux_buffer* b) {
-  int32_t** ps[] = {&b->topo_leaf_start, &b->topo_leaf_len, &b->topo_leaf_node, &b->topo_left, &b->topo_right, &b->topo_level_off};
+  int32_t** ps[] = {&b->topo_leaf_start, &b->topo_leaf_len, &b->topo_leaf_node, &b->topo_left, &b->topo_right, &b->topo_level_off, &b->topo_leaf_of, &b->topo_node_start, &b->topo_node_len, &b->topo_path, &b->topo_anc, &b->topo_depth};
   for (auto p : ps) if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (b->topo_total) { (void)hipFree(b->topo_total); b->topo_total = nullptr; }
   if (b->topo_prefix) { (void)hipFree(b->topo_prefix); b->topo_prefix = nullptr; }
-  b->topo_n = -1;
+  b->topo_n = -1; b->per_run_n = -1; b->per_full_dirty = true;
 }
 void crux_buffer_topo_free(crux_buffer* b) { topo_free(b); }
 
@@ -60,7 +67,22 @@ static int32_t topo_ensure(crux_buffer* b, int64_t N) {
   auto up = [&](int32_t** d, const std::vector<int32_t>& h) -> bool {
     if (hipMalloc(d, 4 * h.size()) != hipSuccess) return false;
     return hipMemcpyAsync(*d, h.data(), 4 * h.size(), hipMemcpyHostToDevice, c->stream) == hipSuccess; };
-  if (!up(&b->topo_leaf_start, ls) || !up(&b->topo_leaf_len, ll) || !up(&b->topo_leaf_node, ln) || !up(&b->topo_left, L) || !up(&b->topo_right, R) || !up(&b->topo_level_off, lvl_off) ||
+  std::vector<int32_t> nstart(nn), nlen(nn), leaf_of((size_t)N, 0);
+  for (int k = 0; k < nn; ++k) { const int i = order[k]; nstart[k] = t.start[i]; nlen[k] = t.len[i];
+    if (t.left[i] < 0) for (int e = t.start[i]; e < t.start[i] + t.len[i]; ++e) leaf_of[(size_t)e] = k; }
+  // per-leaf root paths for the incremental form: parent links from the (level-sorted) child links, then for every leaf the ancestors bottom-up and,
+  // top-down, the left sibling passed whenever the path turns right (prefix(leaf) = v[1] + those totals, added in that order: _accumulate_pairwise!'s s)
+  std::vector<int32_t> par(nn, -1), depth(nn, 0), path((size_t)nn * CRUX_PER_PMAX, -1), anc((size_t)nn * CRUX_PER_PMAX, -1);
+  for (int k = 0; k < nn; ++k) { if (L[k] >= 0) { par[L[k]] = k; par[R[k]] = k; } depth[k] = t.level[order[k]]; }
+  bool deep = false;
+  for (int k = 0; k < nn; ++k) { if (L[k] >= 0) continue;
+    if (depth[k] > CRUX_PER_PMAX) { deep = true; continue; }
+    int a = 0; for (int q = par[k]; q >= 0; q = par[q]) anc[(size_t)k * CRUX_PER_PMAX + a++] = q;
+    int cur = k; for (int d = depth[k] - 1; d >= 0; --d) { const int pq = par[cur]; path[(size_t)k * CRUX_PER_PMAX + d] = (R[pq] == cur) ? L[pq] : -1; cur = pq; } }
+  b->per_full_dirty = true; (void)deep;
+  if (!up(&b->topo_path, path) || !up(&b->topo_anc, anc) || !up(&b->topo_depth, depth) ||
+      !up(&b->topo_leaf_start, ls) || !up(&b->topo_leaf_len, ll) || !up(&b->topo_leaf_node, ln) || !up(&b->topo_left, L) || !up(&b->topo_right, R) || !up(&b->topo_level_off, lvl_off) ||
+      !up(&b->topo_leaf_of, leaf_of) || !up(&b->topo_node_start, nstart) || !up(&b->topo_node_len, nlen) ||
       hipMalloc(&b->topo_total, 4 * (size_t)nn) != hipSuccess || hipMalloc(&b->topo_prefix, 4 * (size_t)nn) != hipSuccess) { topo_free(b); return crux_fail(c, CRUX_ENOMEM, "cumsum tree"); }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   b->topo_n = N; b->topo_leaves = nl; b->topo_nodes = nn; b->topo_levels = maxlvl + 1;
@@ -99,7 +121,7 @@ __global__ __launch_bounds__(1024) void k_tree(const int32_t* __restrict__ left,
 // the same two passes with every node's total and prefix held in LDS (2 x 4 B x nodes <= 150 KB, i.e. up to ~2.4 M elements): the 2 x levels
 // dependent steps cost an LDS round trip each instead of an L2 round trip (20 us -> ~4 us at N = 1 M); the arithmetic and its order are unchanged
 __global__ __launch_bounds__(1024) void k_tree_lds(const int32_t* __restrict__ left, const int32_t* __restrict__ right, const int32_t* __restrict__ lvl_off, int nlev, int nn,
-                                                   const float* __restrict__ total, float* __restrict__ prefix, const float* __restrict__ v) {
+                                                   float* __restrict__ total, float* __restrict__ prefix, const float* __restrict__ v) {
   extern __shared__ float tl[];
   float* tot = tl; float* pre = tl + nn;
   const int t = threadIdx.x;
@@ -125,7 +147,7 @@ __global__ __launch_bounds__(1024) void k_tree_lds(const int32_t* __restrict__ l
     for (int i = 0; i < NPT; ++i) { const int k = t + 1024 * i; if (k >= lo && k < hi && lft[i] >= 0) { const float s = pre[k]; pre[lft[i]] = s; pre[rgt[i]] = s + tot[lft[i]]; } }
     __syncthreads();
   }
-  for (int k = t; k < nn; k += 1024) prefix[k] = pre[k];
+  for (int k = t; k < nn; k += 1024) { prefix[k] = pre[k]; total[k] = tot[k]; }     // internal totals stay resident: k_tree_touch updates them along touched paths
 }
 __global__ __launch_bounds__(LEAF_BLK) void k_leaf_scan(const float* __restrict__ v, const int32_t* __restrict__ lstart, const int32_t* __restrict__ llen,
                                                         const int32_t* __restrict__ lnode, int nl, const float* __restrict__ prefix, float* __restrict__ c) {
@@ -135,32 +157,117 @@ __global__ __launch_bounds__(LEAF_BLK) void k_leaf_scan(const float* __restrict_
   const int base = lstart[l0], cnt = lstart[lend] + llen[lend] - base;
   for (int i = t; i < cnt; i += LEAF_BLK) sm[i] = v[base + i];
   __syncthreads();
-  if (l < nl) { const int o = lstart[l] - base, n = llen[l]; const float s = prefix[lnode[l]]; float s_ = sm[o]; sm[o] = s + s_;
-    for (int i = 1; i < n; ++i) { s_ = s_ + sm[o + i]; sm[o + i] = s + s_; } }
+  if (l < nl) { const int o = lstart[l] - base, n = llen[l]; float s_ = sm[o];          // the running sum s_ of _accumulate_pairwise!'s leaf loop; c[i] = op(s, s_) is formed at probe time
+    for (int i = 1; i < n; ++i) { s_ = s_ + sm[o + i]; sm[o + i] = s_; } }
   __syncthreads();
   for (int i = t; i < cnt; i += LEAF_BLK) c[base + i] = sm[i];
   if (blockIdx.x == 0 && t == 0) c[0] = v[0];
 }
+// update_priorities! touched element ids[j]: re-sum its leaf (running sums + total). One 64-lane block per touched element; duplicates write identical values.
+__global__ __launch_bounds__(64) void k_leaf_refresh(const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of,
+                                                      const int32_t* __restrict__ nstart, const int32_t* __restrict__ nlen, float* __restrict__ run, float* __restrict__ total) {
+  __shared__ float sm[LEAF_MAX + 1];
+  const int64_t e = ids[blockIdx.x];
+  if (e == 0) { if (threadIdx.x == 0) run[0] = v[0]; return; }       // element 1 of the reference is the seed s_ = v[1], outside the tree
+  const int node = leaf_of[e], o = nstart[node], len = nlen[node];
+  for (int i = threadIdx.x; i < len; i += 64) sm[i] = v[o + i];
+  __syncthreads();
+  if (threadIdx.x == 0) { float s_ = sm[0]; for (int i = 1; i < len; ++i) { s_ = s_ + sm[i]; sm[i] = s_; } total[node] = s_; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < len; i += 64) run[o + i] = sm[i];
+}
+// After k_leaf_refresh: node totals along the touched leaves' root paths, bottom-up level by level (s_ = rec(left); s_ += rec(right)). One workgroup;
+// thread q follows touched element q. Nodes shared by several paths are written by several threads with the same value.
+__global__ __launch_bounds__(1024) void k_tree_touch(const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of, const int32_t* __restrict__ anc,
+                                                      const int32_t* __restrict__ depth, const int32_t* __restrict__ left, const int32_t* __restrict__ right, int nlev, float* __restrict__ total) {
+  // thread q < 1024 follows touched element q (+1024, ...: calls with more than 1024 touched elements take the slow loop below). The root path and the
+  // child links of its nodes are static, so they are fetched once, before the level loop: each level then costs ONE round trip (the two child totals)
+  if (n <= 1024) {
+    const int64_t q = threadIdx.x; int d = 0; int an[CRUX_PER_PMAX], lf[CRUX_PER_PMAX], rg[CRUX_PER_PMAX];
+    const int64_t e = q < n ? ids[q] : 0;
+    if (e != 0) { const int leaf = leaf_of[e]; d = depth[leaf];
+      const int4* pa = (const int4*)(anc + (size_t)leaf * CRUX_PER_PMAX);
+#pragma unroll
+      for (int k = 0; k < CRUX_PER_PMAX / 4; ++k) { const int4 x = pa[k]; an[4 * k] = x.x; an[4 * k + 1] = x.y; an[4 * k + 2] = x.z; an[4 * k + 3] = x.w; }
+#pragma unroll
+      for (int k = 0; k < CRUX_PER_PMAX; ++k) { lf[k] = an[k] >= 0 ? left[an[k]] : 0; rg[k] = an[k] >= 0 ? right[an[k]] : 0; } }
+    for (int lv = nlev - 2; lv >= 0; --lv) {          // parents at level lv are complete once the level below is
+      const int k = d - 1 - lv;
+      if (e != 0 && k >= 0) {
+        int a = 0, l = 0, r = 0;
+#pragma unroll
+        for (int z = 0; z < CRUX_PER_PMAX; ++z) if (z == k) { a = an[z]; l = lf[z]; r = rg[z]; }
+        total[a] = total[l] + total[r]; }
+      __threadfence_block(); __syncthreads();
+    }
+    return;
+  }
+  for (int lv = nlev - 2; lv >= 0; --lv) {
+    for (int64_t q = threadIdx.x; q < n; q += 1024) { const int64_t e = ids[q]; if (e == 0) continue;
+      const int leaf = leaf_of[e]; const int k = depth[leaf] - 1 - lv;
+      if (k >= 0) { const int a = anc[(size_t)leaf * CRUX_PER_PMAX + k]; total[a] = total[left[a]] + total[right[a]]; } }
+    __threadfence_block(); __syncthreads();
+  }
+}
+// prefix of leaf node `leaf` = _accumulate_pairwise!'s s at that leaf: v[1], then + total(left sibling) at every right turn of the root path, top-down
+__device__ __forceinline__ float leaf_prefix(const float* __restrict__ v, const float* __restrict__ total, const int32_t* __restrict__ path, int leaf) {
+  int sib[CRUX_PER_PMAX]; float tv[CRUX_PER_PMAX];
+  const int4* pp = (const int4*)(path + (size_t)leaf * CRUX_PER_PMAX);
+#pragma unroll
+  for (int q = 0; q < CRUX_PER_PMAX / 4; ++q) { const int4 x = pp[q]; sib[4 * q] = x.x; sib[4 * q + 1] = x.y; sib[4 * q + 2] = x.z; sib[4 * q + 3] = x.w; }
+#pragma unroll
+  for (int q = 0; q < CRUX_PER_PMAX; ++q) tv[q] = sib[q] >= 0 ? total[sib[q]] : 0.f;
+  float s = v[0];
+#pragma unroll
+  for (int q = 0; q < CRUX_PER_PMAX; ++q) if (sib[q] >= 0) s = s + tv[q];
+  return s;
+}
+// cumsum(priorities) as the reference would hold it, materialised for crux_per_get: c[i] = prefix(leaf(i)) + run[i]
+__global__ void k_materialize_cumsum(const float* __restrict__ run, const float* __restrict__ v, const float* __restrict__ total, const int32_t* __restrict__ path, const int32_t* __restrict__ leaf_of, int64_t N, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = i == 0 ? run[0] : leaf_prefix(v, total, path, leaf_of[i]) + run[i];
+}
 __global__ void k_cumsum_tiny(const float* v, int64_t n, float* c) { if (threadIdx.x == 0 && blockIdx.x == 0) { if (n >= 1) c[0] = v[0]; } }
 
 // stratified search + importance weights (:335-347)
-__global__ void k_per_search(const float* __restrict__ cs, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B,
+// One WAVE per stratum. searchsortedfirst (:340) is a chain of ~log2(N) dependent probes, and each probe of the un-materialised cumsum costs a
+// memory round trip (leaf_of[mid] and run[mid] together, then prefix[leaf]); evaluated by one thread that is 20 serial round trips. The wave
+// evaluates SIX levels of the binary search at once: lane L (1..63, heap order) assumes the outcomes spelled by the bits of L below its leading one,
+// derives the (lo, hi) interval that path would have produced and probes its midpoint; a ballot then replays the real search over the 63 answers.
+// The probes and comparisons are exactly those of the sequential search, so the result is the reference's index even where rounding makes the
+// cumsum locally non-monotone; 20 levels cost 4 round trips instead of 20.
+__global__ __launch_bounds__(256) void k_per_search(const float* __restrict__ run, const float* __restrict__ total, const int32_t* __restrict__ path, const int32_t* __restrict__ leaf_of, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B,
                              const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= B) return;
-  const float ptot = cs[N - 1];
+  auto cs = [&](int64_t i) -> float { return (i == 0 || N < 2) ? run[i] : leaf_prefix(pr, total, path, leaf_of[i]) + run[i]; };    // cumsum[i] exactly as accumulate_pairwise! forms it
+  const float ptot = cs(N - 1);
   const float dp = ptot / (float)B;
   double u;
   if (rands) u = rands[j];
   else { const crux_u32x4 x = crux_philox(seed, ictr * (uint64_t)B + (uint64_t)j, stream, CRUX_RNG_SAMPLE); u = crux_u32x2_to_f64(x.v[0], x.v[1]); }
   const double key = ((double)(j + 1) + u - 1.0) * (double)dp;
   int64_t lo = 0, hi = N;
-  while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if ((double)cs[mid] < key) lo = mid + 1; else hi = mid; }
+  const int depth = lane ? 31 - __builtin_clz((unsigned)lane) : 0;          // lane 1 is the root (depth 0)
+  while (lo < hi) {
+    int64_t l = lo, h = hi; bool valid = lane != 0;
+    for (int b = depth - 1; b >= 0 && valid; --b) { if (!(l < h)) { valid = false; break; } const int64_t m = l + ((h - l) >> 1); if ((lane >> b) & 1) l = m + 1; else h = m; }
+    valid = valid && l < h;
+    bool less = false;
+    if (valid) { const int64_t m = l + ((h - l) >> 1); less = (double)cs(m) < key; }
+    const unsigned long long lt = __ballot(less);
+    int node = 1;
+#pragma unroll
+    for (int step = 0; step < 6; ++step) { if (!(lo < hi)) break; const int64_t mid = lo + ((hi - lo) >> 1); const int bit = (int)((lt >> node) & 1ull); if (bit) lo = mid + 1; else hi = mid; node = 2 * node + bit; }
+  }
   if (lo >= N) lo = N - 1;       // the reference would index out of bounds here
-  ids[j] = lo;
-  const float pmin = pminmax[1] / ptot;
-  const float max_w = powf(pmin * (float)N, -beta);
-  weight[lo] = powf(((float)N * pr[lo]) / ptot, beta) / max_w;
+  if (lane == 0) {
+    ids[j] = lo;
+    const float pmin = pminmax[1] / ptot;
+    const float max_w = powf(pmin * (float)N, -beta);
+    weight[lo] = powf(((float)N * pr[lo]) / ptot, beta) / max_w;
+  }
 }
 __global__ void k_uniform_ids(int64_t N, int64_t B, uint64_t seed, uint32_t stream, uint64_t ictr, int64_t* ids) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -201,19 +308,34 @@ static int32_t ensure_cumsum(crux_buffer* s, int64_t N) {
   if (N < 2) hipLaunchKernelGGL(k_cumsum_tiny, dim3(1), dim3(1), 0, c->stream, s->priorities, N, s->cumsum);
   else {
     const int nb = (s->topo_leaves + LEAF_BLK - 1) / LEAF_BLK;
-    hipLaunchKernelGGL(k_leaf_totals, dim3(nb), dim3(LEAF_BLK), 0, c->stream, s->priorities, s->topo_leaf_start, s->topo_leaf_len, s->topo_leaf_node, s->topo_leaves, s->topo_total);
-    const size_t tree_lds = 8 * (size_t)s->topo_nodes;
-    if (tree_lds <= 150 * 1024) {
-      static bool attr = false;
-      if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_tree_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
-      hipLaunchKernelGGL(k_tree_lds, dim3(1), dim3(1024), tree_lds, c->stream, s->topo_left, s->topo_right, s->topo_level_off, s->topo_levels, s->topo_nodes, (const float*)s->topo_total, s->topo_prefix, s->priorities);
-    } else
-    hipLaunchKernelGGL(k_tree, dim3(1), dim3(1024), 0, c->stream, s->topo_left, s->topo_right, s->topo_level_off, s->topo_levels, s->topo_total, s->topo_prefix, s->priorities);
-    hipLaunchKernelGGL(k_leaf_scan, dim3(nb), dim3(LEAF_BLK), 0, c->stream, s->priorities, s->topo_leaf_start, s->topo_leaf_len, s->topo_leaf_node, s->topo_leaves, s->topo_prefix, s->cumsum);
+    const bool full = s->per_full_dirty || s->per_run_n != N || s->topo_levels > CRUX_PER_PMAX;      // otherwise leaves and root paths were re-summed when they were touched (crux_per_touched)
+    if (full) {
+      hipLaunchKernelGGL(k_leaf_totals, dim3(nb), dim3(LEAF_BLK), 0, c->stream, s->priorities, s->topo_leaf_start, s->topo_leaf_len, s->topo_leaf_node, s->topo_leaves, s->topo_total);
+      const size_t tree_lds = 8 * (size_t)s->topo_nodes;
+      if (tree_lds <= 150 * 1024) {
+        static bool attr = false;
+        if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_tree_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+        hipLaunchKernelGGL(k_tree_lds, dim3(1), dim3(1024), tree_lds, c->stream, s->topo_left, s->topo_right, s->topo_level_off, s->topo_levels, s->topo_nodes, s->topo_total, s->topo_prefix, s->priorities);
+      } else
+      hipLaunchKernelGGL(k_tree, dim3(1), dim3(1024), 0, c->stream, s->topo_left, s->topo_right, s->topo_level_off, s->topo_levels, s->topo_total, s->topo_prefix, s->priorities);
+      hipLaunchKernelGGL(k_leaf_scan, dim3(nb), dim3(LEAF_BLK), 0, c->stream, s->priorities, s->topo_leaf_start, s->topo_leaf_len, s->topo_leaf_node, s->topo_leaves, s->topo_prefix, s->cumsum);
+    }
+    s->per_full_dirty = false; s->per_run_n = N;
   }
   crux_prof_end(c, CRUX_PROF_PER_SCAN);
   s->cumsum_valid = true;
   return crux_launch_check(c, "per scan");
+}
+// called by every path that changes priorities (update_priorities!, push!'s max-priority rows): d_ids = the touched elements (device, int64)
+int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool from_push) {
+  b->cumsum_valid = false;
+  if (n <= 0) return CRUX_OK;
+  if (from_push && b->elements < b->capacity) { b->per_full_dirty = true; return CRUX_OK; }   // the ring is still growing: the rows may lie beyond the current tree
+  if (b->per_full_dirty || b->topo_n < 2 || b->per_run_n != b->topo_n || b->topo_n != b->elements || n > 4096 || !d_ids) { b->per_full_dirty = true; return CRUX_OK; }
+  if (b->topo_levels > CRUX_PER_PMAX) { b->per_full_dirty = true; return CRUX_OK; }
+  hipLaunchKernelGGL(k_leaf_refresh, dim3((unsigned)n), dim3(64), 0, b->ctx->stream, b->priorities, d_ids, n, b->topo_leaf_of, b->topo_node_start, b->topo_node_len, b->cumsum, b->topo_total);
+  hipLaunchKernelGGL(k_tree_touch, dim3(1), dim3(1024), 0, b->ctx->stream, d_ids, n, b->topo_leaf_of, b->topo_anc, b->topo_depth, b->topo_left, b->topo_right, b->topo_levels, b->topo_total);
+  return crux_launch_check(b->ctx, "k_leaf_refresh");
 }
 
 // push!(target, source, ids=device ids) (:232-259): gather B rows into target's ring; target.indices mirrors the ids
@@ -254,7 +376,7 @@ int32_t crux_per_sample(crux_buffer* target, crux_buffer* source, int64_t B, con
   if (rands) { d_r = (double*)crux_scratch(c, 8 * (size_t)B + 256); if (!d_r) return crux_fail(c, CRUX_ENOMEM, "prioritized_sample!: scratch");
     HIPCHK(c, hipMemcpyAsync(d_r, rands, 8 * (size_t)B, hipMemcpyHostToDevice, c->stream)); }
   crux_prof_begin(c, CRUX_PROF_PER_SEARCH);
-  hipLaunchKernelGGL(k_per_search, dim3(gridn(B)), dim3(256), 0, c->stream, source->cumsum, source->priorities, source->pminmax, N, B, (const double*)d_r,
+  hipLaunchKernelGGL(k_per_search, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, c->stream, source->cumsum, source->topo_total, source->topo_path, source->topo_leaf_of, source->priorities, source->pminmax, N, B, (const double*)d_r,
                      source->sample_seed, source->sample_stream, i, beta, target->d_indices, (float*)source->col[CRUX_COL_WEIGHT]);
   crux_prof_end(c, CRUX_PROF_PER_SEARCH);
   rc = crux_launch_check(c, "k_per_search"); if (rc) return rc;
@@ -284,7 +406,10 @@ int32_t crux_per_get(crux_buffer* b, float* priorities, float* max_priority, flo
   crux_ctx* c = b->ctx;
   if (!b->prioritized) return crux_fail(c, CRUX_EINVAL, "buffer is not prioritized");
   if (cumsum && b->elements > 0) { int32_t rc = ensure_cumsum(b, b->elements); if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(cumsum, b->cumsum, 4 * (size_t)b->elements, hipMemcpyDeviceToHost, c->stream)); }
+    const int64_t N = b->elements; float* tmp = (float*)crux_scratch(c, 4 * (size_t)N + 256); if (!tmp) return crux_fail(c, CRUX_ENOMEM, "per_get: scratch");
+    if (N < 2) HIPCHK(c, hipMemcpyAsync(tmp, b->cumsum, 4 * (size_t)N, hipMemcpyDeviceToDevice, c->stream));
+    else hipLaunchKernelGGL(k_materialize_cumsum, dim3(gridn(N)), dim3(256), 0, c->stream, b->cumsum, b->priorities, b->topo_total, b->topo_path, b->topo_leaf_of, N, tmp);
+    HIPCHK(c, hipMemcpyAsync(cumsum, tmp, 4 * (size_t)N, hipMemcpyDeviceToHost, c->stream)); }
   float mm[2];
   HIPCHK(c, hipMemcpyAsync(mm, b->pminmax, 8, hipMemcpyDeviceToHost, c->stream));
   if (priorities) HIPCHK(c, hipMemcpyAsync(priorities, b->priorities, 4 * (size_t)b->capacity, hipMemcpyDeviceToHost, c->stream));

@@ -519,12 +519,13 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
             int pi_ = 0;
             for (int r = 0; r < a.px_n; ++r) { if (r == a.px_rank) continue;
               if ((pi_++ & 1) != p) continue;
-              __hip_atomic_store((unsigned long long*)(a.px_tab[r] + CRUX_PX_FLAGS) + 8 * a.px_rank, xg + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+              // relaxed: every wave fenced its own slot stores (system-scope release) BEFORE the barrier above, so they are performed at the peer already
+              __hip_atomic_store((unsigned long long*)(a.px_tab[r] + CRUX_PX_FLAGS) + 8 * a.px_rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
             bool ok = true; const long long t0 = wall_clock64();                // 100 MHz: a missing peer becomes CRUX_EHIP after ~30 s instead of a hung GPU
             unsigned* abortw = (unsigned*)(px_mine + CRUX_PX_ABORT);
             for (int r = 0; r < a.px_n && ok; ++r) { if (r == a.px_rank) continue;
               const unsigned long long* fl = (const unsigned long long*)(px_mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
-              while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(2);
+              while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);      // the acquire is the fence after the barrier below
                 if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
             if (!ok) { for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
               __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
