@@ -1417,6 +1417,7 @@ class OffPolicySolver:
         self.buffer = buffer if buffer is not None else ExperienceBuffer(S, agent.space, buffer_size, prioritized=prioritized)
         self.buffer_init = buffer_init if buffer_init is not None else max(c_opt.batch_size, 200)
         self.tau, self.weighted_loss, self.sample_seed = float(tau), bool(weighted_loss), int(sample_seed)
+        self.fused_epochs = True              # value_training epochs through crux_dqn_epoch / crux_sac_epoch (one fused launch each for wide networks)
         self.sampler, self.batch, self.history = None, None, []
         self._dy = self._derr = None
 
@@ -1437,15 +1438,29 @@ def _value_training_sac(solver, D, gamma):
     infos, lib, raw = [], ctx.lib, np.zeros(L.INFO_N, np.float32)
     for epoch in range(c_opt.epochs):
         ctr = solver.i * c_opt.epochs + epoch                                                          # one Philox counter block per epoch
+        upd_c, upd_a = epoch % c_opt.update_every == 0, epoch % a_opt.update_every == 0                # :91, :96
+        if solver.fused_epochs:
+            # the whole epoch (:71-100) as one fused launch (cruxhip.h: crux_sac_epoch); same pieces, order and draws as the branch below
+            _set_stream_for(buf, solver.sample_seed)
+            rt, rq, ra = np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32)
+            ctx.check(lib.crux_sac_epoch(A.h, Q.N1.h, Q.N2.h, pim.A.h, Qm.N1.h, Qm.N2.h, la.h, buf.h, D.h, float(gamma), float(solver.P["SAC_H_target"]), float(solver.tau),
+                                         1 if solver.weighted_loss else 0, 1 if upd_c else 0, 1 if upd_a else 0, ctr, solver.noise_seed, 3 * ctr, _vp(rt), _vp(rq), _vp(ra)))
+            info = {t_opt.name + "loss": float(rt[0]), t_opt.name + "grad_norm": float(rt[1]), "SAC alpha": float(rt[L.INFO["alpha"]])}
+            if upd_c:
+                info.update({c_opt.name + "loss": float(rq[0]), c_opt.name + "grad_norm": float(rq[1]), "Q1avg": float(rq[L.INFO["q1avg"]]), "Q2avg": float(rq[L.INFO["q2avg"]])})
+            if upd_a:
+                info.update({a_opt.name + "loss": float(ra[0]), a_opt.name + "grad_norm": float(ra[1]), "entropy": float(ra[L.INFO["entropy"]])})
+            infos.append(info)
+            continue
         rand_(D, buf, i=solver.i, counter=ctr, seed=solver.sample_seed)                                # :71 rand!(D, buffer, i=S.i)
         info = {}
         ctx.check(lib.crux_sac_target(A.h, Qm.N1.h, Qm.N2.h, la.h, D.h, float(gamma), solver.noise_seed, 3 * ctr, solver._dy))           # :80
         ctx.check(lib.crux_sac_temp_step(A.h, la.h, D.h, float(solver.P["SAC_H_target"]), solver.noise_seed, 3 * ctr + 1, _vp(raw)))     # :86-88
         info.update({t_opt.name + "loss": float(raw[0]), t_opt.name + "grad_norm": float(raw[1]), "SAC alpha": float(raw[L.INFO["alpha"]])})
-        if epoch % c_opt.update_every == 0:                                                            # :91
+        if upd_c:                                                                                      # :91
             ctx.check(lib.crux_double_q_step(Q.N1.h, Q.N2.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))              # :92
             info.update({c_opt.name + "loss": float(raw[0]), c_opt.name + "grad_norm": float(raw[1]), "Q1avg": float(raw[L.INFO["q1avg"]]), "Q2avg": float(raw[L.INFO["q2avg"]])})
-        if epoch % a_opt.update_every == 0:                                                            # :96
+        if upd_a:                                                                                      # :96
             ctx.check(lib.crux_sac_actor_step(A.h, Q.N1.h, Q.N2.h, la.h, D.h, solver.noise_seed, 3 * ctr + 2, _vp(raw)))                 # :97
             info.update({a_opt.name + "loss": float(raw[0]), a_opt.name + "grad_norm": float(raw[1]), "entropy": float(raw[L.INFO["entropy"]])})
             polyak_average_(pim, pi, solver.tau)                                                       # :100 (target update only when the actor trains)
@@ -1495,6 +1510,11 @@ def _value_training_dpg(solver, D, gamma):
     return {k: float(np.mean([d[k] for d in infos if k in d])) for k in keys}                          # aggregate_info: mean over the dicts that have the key (logging.jl:60-66)
 
 
+def _set_stream_for(buf, seed):
+    if seed is not None and int(seed) != getattr(buf, "sample_seed", SAMPLE_SEED):
+        set_sample_stream_(buf, int(seed), getattr(buf, "sample_stream", 0))
+
+
 def value_training(solver, D, gamma):
     """value_training(S, D, gamma) (src/model_free/off_policy.jl:66-111) for the critic-only (DQN) case: per epoch
     rand! -> dqn_target -> [update_priorities!(td_error)] -> train!(td_loss); then target_update once (:108)."""
@@ -1508,13 +1528,21 @@ def value_training(solver, D, gamma):
     if solver._dy is None:
         solver._dy, solver._derr = ctx.alloc(4 * B), ctx.alloc(4 * B)
     infos = []
+    fused = solver.target_fn == "dqn" and solver.fused_epochs
     for epoch in range(p.epochs):
+        raw = np.zeros(L.INFO_N, np.float32)
+        if fused:
+            # the whole epoch (:71-93) in one C call -- one fused launch for wide networks (cruxhip.h: crux_dqn_epoch); same steps, same order, same draws
+            _set_stream_for(buf, solver.sample_seed)
+            beta = float(np.float32(buf.beta(solver.i))) if buf.isprioritized() else 0.0                   # rand!(D, buffer, i=S.i): beta(S.i)
+            ctx.check(ctx.lib.crux_dqn_epoch(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs + epoch, _vp(raw)))
+            infos.append({p.name + "loss": float(raw[0]), p.name + "grad_norm": float(raw[1]), "Qavg": float(raw[2])})
+            continue
         rand_(D, buf, i=solver.i, counter=solver.i * p.epochs + epoch, seed=solver.sample_seed)        # :71 rand!(D, buffer, i=S.i): beta(S.i); the Philox counter is unique per draw
         if solver.target_fn == "softq":
             ctx.check(ctx.lib.crux_softq_target(pim.h, D.h, float(gamma), float(solver.P["alpha"]), solver._dy))   # :80  softq.jl:4-13
         else:
             ctx.check(ctx.lib.crux_dqn_target(pim.h, D.h, float(gamma), solver._dy))                    # :80  dqn.jl:4-6
-        raw = np.zeros(L.INFO_N, np.float32)
         if buf.isprioritized():                                                                        # :83 update_priorities!(buffer, D.indices, td_error) and :91-93 train!
             ctx.check(ctx.lib.crux_td_step_with_error(pi.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, solver._derr, _vp(raw)))   # one forward pass for both
             ctx.check(ctx.lib.crux_per_update_device(buf.h, ctx.lib.crux_buffer_indices_ptr(D.h), solver._derr, B))

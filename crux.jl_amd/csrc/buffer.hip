@@ -2,6 +2,8 @@
 // Reference: src/experience_buffer.jl (mdp_data :4-35, ExperienceBuffer :53-80, shuffle! :118-124,
 // minibatch :170-171, get_last_N_indices :223-229, push! :232-259, update_priorities! :290-301).
 #include "common.h"
+#include "exec.h"
+#include "ops_small.h"
 
 void crux_buffer_topo_free(crux_buffer* b);
 
@@ -47,22 +49,7 @@ __global__ void k_fill_f32_idx(float* p, const int64_t* idx, float v, int64_t n)
 // the int view reproduce the sequential max/min exactly.
 __global__ void k_per_update(float* __restrict__ pr, float* pminmax, const int64_t* __restrict__ I,
                              const double* __restrict__ v64, const float* __restrict__ v32, const float* vconst_from_max,
-                             float alpha, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double val;
-    if (vconst_from_max) val = (double)vconst_from_max[0] + (double)1.1920928955078125e-07f;   // push!: max_priority*ones(N) (Float64)
-    else if (v64) val = v64[i] + (double)1.1920928955078125e-07f;
-    else { const float vf = __fadd_rn(v32[i], 1.1920928955078125e-07f); val = (double)vf; }
-    // priorities[I] = val.^alpha is a sequential scatter in the reference (:297): with repeated indices the LAST value wins. Small calls (the
-    // sampled-batch case) resolve that exactly; large calls are ring pushes, whose repeats (N > capacity) carry the same value anyway.
-    bool later = false;
-    if (n <= 2048 && !vconst_from_max) for (int64_t j = i + 1; j < n; ++j) if (I[j] == I[i]) { later = true; break; }
-    if (!later) pr[I[i]] = (float)pow(val, (double)alpha);
-    const float vf32 = (float)val;
-    atomicMax((int*)&pminmax[0], __float_as_int(vf32));
-    atomicMin((int*)&pminmax[1], __float_as_int(vf32));
-  }
-}
+                             float alpha, int64_t n) { PerUpdateOp::run(blockIdx.x, gridDim.x, pr, pminmax, I, v64, v32, vconst_from_max, alpha, n); }
 
 static unsigned grid_for(int64_t total) { int64_t nb = (total + 255) / 256; if (nb < 1) nb = 1; if (nb > 8192) nb = 8192; return (unsigned)nb; }
 
@@ -94,9 +81,9 @@ int32_t crux_buffer_per_on_push(crux_buffer* b, const int64_t* d_I, int64_t N) {
   // all pushed rows get (max_priority + eps)^alpha with max_priority read ONCE before the update (push!: update_priorities!(b, I, max_priority*ones(N)),
   // experience_buffer.jl:254): the value is snapshotted into pminmax[2] by a stream-ordered copy, because the kernel's atomicMax raises
   // pminmax[0] to Float32(m + eps) while other waves are still reading it (for m in [1,2) that is the next float up)
-  HIPCHK(b->ctx, hipMemcpyAsync(b->pminmax + 2, b->pminmax, 4, hipMemcpyDeviceToDevice, b->ctx->stream));
-  hipLaunchKernelGGL(k_per_update, dim3(grid_for(N)), dim3(256), 0, b->ctx->stream, b->priorities, b->pminmax, d_I, (const double*)nullptr,
-                     (const float*)nullptr, (const float*)(b->pminmax + 2), b->alpha, N);
+  if (crux_exec_recording(b->ctx)) crux_exec_push<CopyF32Op, OP_COPY_F32>(b->ctx, 1u, b->pminmax + 2, (const float*)b->pminmax, (int64_t)1);
+  else HIPCHK(b->ctx, hipMemcpyAsync(b->pminmax + 2, b->pminmax, 4, hipMemcpyDeviceToDevice, b->ctx->stream));
+  CRUX_RUN(b->ctx, PerUpdateOp, OP_PER_UPDATE, k_per_update, grid_for(N), 256, b->ctx->stream, b->priorities, b->pminmax, d_I, (const double*)nullptr, (const float*)nullptr, (const float*)(b->pminmax + 2), b->alpha, N);
   { const int32_t rc = crux_launch_check(b->ctx, "k_per_update(push)"); if (rc) return rc; }
   return crux_per_touched(b, d_I, N, true);
 }
@@ -424,9 +411,7 @@ int32_t crux_per_update(crux_buffer* b, const int64_t* I, const void* v, int32_t
   HIPCHK(c, hipMemcpyAsync(sc, I, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(sc + ib, v, vb, hipMemcpyHostToDevice, c->stream));
   // duplicate indices: the reference loop lets the last write win; values for duplicated rows are equal in every call site
-  hipLaunchKernelGGL(k_per_update, dim3(grid_for(n)), dim3(256), 0, c->stream, b->priorities, b->pminmax, (const int64_t*)sc,
-                     v_is_f64 ? (const double*)(sc + ib) : (const double*)nullptr, v_is_f64 ? (const float*)nullptr : (const float*)(sc + ib),
-                     (const float*)nullptr, b->alpha, n);
+  CRUX_RUN(c, PerUpdateOp, OP_PER_UPDATE, k_per_update, grid_for(n), 256, c->stream, b->priorities, b->pminmax, (const int64_t*)sc, v_is_f64 ? (const double*)(sc + ib) : (const double*)nullptr, v_is_f64 ? (const float*)nullptr : (const float*)(sc + ib), (const float*)nullptr, b->alpha, n);
   int32_t rc = crux_launch_check(c, "k_per_update"); if (rc) return rc;
   { bool in_tree = true; for (int64_t j = 0; j < n; ++j) in_tree = in_tree && I[j] < b->elements;      // rows beyond length(b) are outside the current tree
     if (!in_tree) { b->per_full_dirty = true; b->cumsum_valid = false; } else { rc = crux_per_touched(b, (const int64_t*)sc, n, false); if (rc) return rc; } }                     // :299 cumsum_valid = false; only the touched leaves are re-summed
@@ -438,8 +423,7 @@ int32_t crux_per_update_device(crux_buffer* b, const int64_t* d_ids, const float
   if (!b || !d_ids || !d_v || n < 0) return CRUX_EINVAL;
   if (!b->prioritized) return crux_fail(b->ctx, CRUX_EINVAL, "update_priorities!: buffer is not prioritized");
   if (n == 0) return CRUX_OK;
-  hipLaunchKernelGGL(k_per_update, dim3(grid_for(n)), dim3(256), 0, b->ctx->stream, b->priorities, b->pminmax, d_ids, (const double*)nullptr, d_v,
-                     (const float*)nullptr, b->alpha, n);
+  CRUX_RUN(b->ctx, PerUpdateOp, OP_PER_UPDATE, k_per_update, grid_for(n), 256, b->ctx->stream, b->priorities, b->pminmax, d_ids, (const double*)nullptr, d_v, (const float*)nullptr, b->alpha, n);
   { const int32_t rc = crux_launch_check(b->ctx, "k_per_update(device)"); if (rc) return rc; }
   return crux_per_touched(b, d_ids, n, false);
 }

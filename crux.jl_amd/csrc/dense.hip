@@ -13,6 +13,7 @@
 //   backward  dX[k,s] = act'(X[k,s]) * sum_o W[o,k] dZ[o,s]             M=in  N=B K=out   (act' of the layer that produced X)
 //   weights   dW[o,k] = scale * sum_s dZ[o,s] X[k,s];  db[o] = scale * sum_s dZ[o,s]      M=out N=in K=B   (db rides along in the first column tile)
 #include "common.h"
+#include "exec.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -29,11 +30,11 @@ struct GemmArgs {
 // SPLITK: the four waves of a workgroup share ONE output tile and take a quarter of K each (combined through LDS in wave order, so the
 // result is deterministic): a 256-deep reduction then costs one L2 round trip instead of four -- these launches are latency-bound.
 template <bool AV, bool BV, bool SPLITK>
-__global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) {
+struct Gemm16 { static __device__ __forceinline__ void run(const unsigned bid_, const GemmArgs& q) {
   __shared__ float part[SPLITK ? 3 * 64 * 5 : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int tm = (q.M + 15) >> 4, tn = (q.N + 15) >> 4;
-  const int tile = SPLITK ? (int)blockIdx.x : (int)blockIdx.x * 4 + wv;
+  const int tile = SPLITK ? (int)bid_ : (int)bid_ * 4 + wv;
   if (tile >= tm * tn) return;
   const int kper = SPLITK ? ((((q.K + 3) >> 2) + 15) & ~15) : q.K;
   const int kbeg = SPLITK ? wv * kper : 0, kend = SPLITK ? (kbeg + kper < q.K ? kbeg + kper : q.K) : q.K;
@@ -97,13 +98,23 @@ __global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) {
     else if (q.epi == EPI_BWD_DATA) { if (q.ysrc) v = crux_act_grad(q.act, q.ysrc[ci], v); }
     else v *= q.scale;
     q.C[ci] = v; }
-}
+} };
+template <bool AV, bool BV, bool SPLITK>
+__global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) { Gemm16<AV, BV, SPLITK>::run(blockIdx.x, q); }
+// the executor's form (exec.hip): the variant is data
+struct GemmOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, GemmArgs q, int variant) {
+  switch (variant) {
+    case 0: Gemm16<false, false, false>::run(bid_, q); break; case 1: Gemm16<true, false, false>::run(bid_, q); break;
+    case 2: Gemm16<false, true, false>::run(bid_, q); break;  case 3: Gemm16<true, true, false>::run(bid_, q); break;
+    case 4: Gemm16<false, false, true>::run(bid_, q); break;  case 5: Gemm16<true, false, true>::run(bid_, q); break;
+    case 6: Gemm16<false, true, true>::run(bid_, q); break;   default: Gemm16<true, true, true>::run(bid_, q); break; } } };
 
 // dZ = act'(Y) .* dY for the output layer
-__global__ void k_act_grad(const float* __restrict__ dy, const float* __restrict__ y, int act, int64_t n, float* __restrict__ dz) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+struct ActGradOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ dy, const float* __restrict__ y, int act, int64_t n, float* __restrict__ dz) {
+  const int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x; if (i >= n) return;
   dz[i] = crux_act_grad(act, y[i], dy[i]);
-}
+} };
+__global__ void k_act_grad(const float* __restrict__ dy, const float* __restrict__ y, int act, int64_t n, float* __restrict__ dz) { ActGradOp::run(blockIdx.x, gridDim.x, dy, y, act, n, dz); }
 static inline bool vec_ok(const float* p, int64_t s_k, int64_t s_outer, int K) {
   return s_k == 1 && (K & 3) == 0 && (s_outer & 3) == 0 && (((uintptr_t)p) & 15) == 0;
 }
@@ -112,6 +123,11 @@ static int32_t launch_gemm(crux_ctx* c, const GemmArgs& q, hipStream_t st) {
   const dim3 block(256);
   const bool av = vec_ok(q.A, q.sAk, q.sAi, q.K), bv = vec_ok(q.B, q.sBk, q.sBj, q.K);
   static const bool no_split = getenv("CRUX_GEMM_NO_SPLITK") != nullptr;
+  if (crux_exec_recording(c)) {                       // fused sequence (exec.hip): the same tile bodies, run by the persistent executor
+    const bool split = q.K >= 128 && tiles <= 4096 && !no_split;
+    crux_exec_push<GemmOp, OP_GEMM>(c, (unsigned)(split ? tiles : (tiles + 3) / 4), q, (int)((av ? 1 : 0) | (bv ? 2 : 0) | (split ? 4 : 0)));
+    return CRUX_OK;
+  }
   if (q.K >= 128 && tiles <= 4096 && !no_split) {     // deep reductions: split K over the workgroup's four waves
     const dim3 grid((unsigned)tiles);
     if (av && bv) hipLaunchKernelGGL((k_gemm16<true, true, true>), grid, block, 0, st, q);
@@ -171,7 +187,7 @@ int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const floa
   const float* dcur = d_dy; float* dnxt = ws_delta(n, 0); float* dspare = ws_delta(n, 1);
   if (nd.acts[nd.L - 1] != CRUX_ACT_IDENTITY) {   // dZ_L = act'(Y_L) .* dY; an identity output layer (the usual critic / mean head) uses dY as it is
     const int64_t cnt = (int64_t)nd.dims[nd.L] * B;
-    hipLaunchKernelGGL(k_act_grad, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_dy, crux_dense_act(n, nd.L), nd.acts[nd.L - 1], cnt, dnxt);
+    CRUX_RUN(c, ActGradOp, OP_ACT_GRAD, k_act_grad, (unsigned)((cnt + 255) / 256), 256, st, d_dy, crux_dense_act(n, nd.L), nd.acts[nd.L - 1], cnt, dnxt);
     dcur = dnxt; dnxt = dspare; dspare = const_cast<float*>(dcur);
   }
   for (int l = nd.L - 1; l >= 0; --l) {

@@ -2,6 +2,8 @@
 // Reference: Flux Chain/Dense wrapped by ContinuousNetwork / DiscreteNetwork (src/policies.jl:68-157),
 // polyak_average! (src/policies.jl:48-59), Flux.update!(Adam) (src/training.jl:21).
 #include "common.h"
+#include "exec.h"
+#include "ops_small.h"
 
 static void fill_desc(NetDesc& nd, int32_t L, const int32_t* dims, const int32_t* acts, int32_t n_extra) {
   nd.L = L; int off = 0; nd.maxdim = 0;
@@ -77,12 +79,7 @@ __global__ void k_glorot(NetDesc nd, float* p, uint64_t seed, uint32_t stream, f
   }
 }
 
-__global__ void k_polyak(float* __restrict__ to, const float* __restrict__ from, float tau, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float omt = __fsub_rn(1.0f, tau);
-  to[i] = __fadd_rn(__fmul_rn(tau, from[i]), __fmul_rn(omt, to[i]));   // tau .* from .+ (1f0 - tau) .* to, no contraction
-}
+__global__ void k_polyak(float* __restrict__ to, const float* __restrict__ from, float tau, int64_t n) { PolyakOp::run(blockIdx.x, gridDim.x, to, from, tau, n); }
 
 // Flux.Optimise.Adam apply! with Float64 scalar fields: each broadcast evaluated in Float64 per element,
 // rounded to Float32 on store.
@@ -182,7 +179,7 @@ int32_t crux_polyak(crux_mlp* to, const crux_mlp* from, float tau) {
   if (!to || !from) return CRUX_EINVAL;
   if (to->nd.n_params != from->nd.n_params) return crux_fail(to->ctx, CRUX_EINVAL, "polyak_average!: parameter counts differ");
   const int64_t n = to->nd.n_params;
-  hipLaunchKernelGGL(k_polyak, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, to->ctx->stream, to->p, from->p, tau, n);
+  CRUX_RUN(to->ctx, PolyakOp, OP_POLYAK, k_polyak, (unsigned)((n + 255) / 256), 256, to->ctx->stream, to->p, from->p, tau, n);
   return crux_launch_check(to->ctx, "k_polyak");
 }
 

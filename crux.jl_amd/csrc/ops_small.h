@@ -1,0 +1,45 @@
+// ops_small.h -- device bodies of small kernels that live in buffer.hip / train.hip / mlp.hip and are ALSO executed by the fused-step executor
+// (exec.hip) as ops: one definition, two callers. Reference lines are cited at the kernels' home files.
+#pragma once
+#include "common.h"
+
+struct PerUpdateOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, float* __restrict__ pr, float* pminmax, const int64_t* __restrict__ I,
+                             const double* __restrict__ v64, const float* __restrict__ v32, const float* vconst_from_max,
+                             float alpha, int64_t n) {
+  for (int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x; i < n; i += (int64_t)nb_ * blockDim.x) {
+    double val;
+    if (vconst_from_max) val = (double)vconst_from_max[0] + (double)1.1920928955078125e-07f;   // push!: max_priority*ones(N) (Float64)
+    else if (v64) val = v64[i] + (double)1.1920928955078125e-07f;
+    else { const float vf = __fadd_rn(v32[i], 1.1920928955078125e-07f); val = (double)vf; }
+    // priorities[I] = val.^alpha is a sequential scatter in the reference (:297): with repeated indices the LAST value wins. Small calls (the
+    // sampled-batch case) resolve that exactly; large calls are ring pushes, whose repeats (N > capacity) carry the same value anyway.
+    bool later = false;
+    if (n <= 2048 && !vconst_from_max) for (int64_t j = i + 1; j < n; ++j) if (I[j] == I[i]) { later = true; break; }
+    if (!later) pr[I[i]] = (float)pow(val, (double)alpha);
+    const float vf32 = (float)val;
+    atomicMax((int*)&pminmax[0], __float_as_int(vf32));
+    atomicMin((int*)&pminmax[1], __float_as_int(vf32));
+  }
+} };
+struct DqnTargetOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ q, int nout, const float* __restrict__ r, const uint8_t* __restrict__ done, float gamma, int64_t n, float* __restrict__ y) {
+#pragma clang fp contract(off)      // the reference evaluates r .+ gamma .* (1 .- done) .* q un-fused; train.hip is not built with -ffp-contract=off
+  const int64_t s = (int64_t)bid_ * blockDim.x + threadIdx.x; if (s >= n) return;
+  float mx = q[s * nout]; for (int k = 1; k < nout; ++k) mx = q[s * nout + k] > mx ? q[s * nout + k] : mx;
+  const float nd = 1.f - (done[s] ? 1.f : 0.f); const float gn = gamma * nd; const float t = gn * mx; y[s] = r[s] + t;      // plain operators: the pragma above governs them (the __f*_rn intrinsics are inline functions compiled under the unit's own contraction mode)
+   // r .+ gamma .* (1 .- done) .* max  (dqn.jl:5)
+} };
+struct TdErrorOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ q, int nout, const uint8_t* __restrict__ a, const float* __restrict__ y, int64_t n, float* __restrict__ err) {
+#pragma clang fp contract(off)      // the reference evaluates r .+ gamma .* (1 .- done) .* q un-fused; train.hip is not built with -ffp-contract=off
+  const int64_t s = (int64_t)bid_ * blockDim.x + threadIdx.x; if (s >= n) return;
+  float Q = 0.f; for (int k = 0; k < nout; ++k) { const float t = q[s * nout + k] * (a[s * nout + k] ? 1.f : 0.f); Q = Q + t; }
+  err[s] = fabsf(Q - y[s]);
+} };
+struct PolyakOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, float* __restrict__ to, const float* __restrict__ from, float tau, int64_t n) {
+  const int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float omt = __fsub_rn(1.0f, tau);
+  to[i] = __fadd_rn(__fmul_rn(tau, from[i]), __fmul_rn(omt, to[i]));   // tau .* from .+ (1f0 - tau) .* to, no contraction
+} };
+struct CopyF32Op { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x; i < n; i += (int64_t)nb_ * blockDim.x) dst[i] = src[i];
+} };

@@ -18,6 +18,7 @@
 // ~N/95 leaves' nodes, and searchsortedfirst probes exactly the elements the reference's binary search would. Per sampled step at N = 1 M:
 // <= 128 x 127 x 8 B of leaf traffic + 170 KB of tree nodes + 20 KB of probes instead of 8 MB.
 #include "common.h"
+#include "exec.h"
 #include <algorithm>
 
 int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I);
@@ -164,25 +165,27 @@ __global__ __launch_bounds__(LEAF_BLK) void k_leaf_scan(const float* __restrict_
   if (blockIdx.x == 0 && t == 0) c[0] = v[0];
 }
 // update_priorities! touched element ids[j]: re-sum its leaf (running sums + total). One 64-lane block per touched element; duplicates write identical values.
-__global__ __launch_bounds__(64) void k_leaf_refresh(const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of,
+struct LeafRefreshOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of,
                                                       const int32_t* __restrict__ nstart, const int32_t* __restrict__ nlen, float* __restrict__ run, float* __restrict__ total) {
   __shared__ float sm[LEAF_MAX + 1];
-  const int64_t e = ids[blockIdx.x];
+  const int64_t e = ids[bid_];
   if (e == 0) { if (threadIdx.x == 0) run[0] = v[0]; return; }       // element 1 of the reference is the seed s_ = v[1], outside the tree
   const int node = leaf_of[e], o = nstart[node], len = nlen[node];
-  for (int i = threadIdx.x; i < len; i += 64) sm[i] = v[o + i];
+  for (int i = threadIdx.x; i < len; i += (int)blockDim.x) sm[i] = v[o + i];
   __syncthreads();
   if (threadIdx.x == 0) { float s_ = sm[0]; for (int i = 1; i < len; ++i) { s_ = s_ + sm[i]; sm[i] = s_; } total[node] = s_; }
   __syncthreads();
-  for (int i = threadIdx.x; i < len; i += 64) run[o + i] = sm[i];
-}
+  for (int i = threadIdx.x; i < len; i += (int)blockDim.x) run[o + i] = sm[i];
+} };
+__global__ __launch_bounds__(64) void k_leaf_refresh(const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of,
+                                                      const int32_t* __restrict__ nstart, const int32_t* __restrict__ nlen, float* __restrict__ run, float* __restrict__ total) { LeafRefreshOp::run(blockIdx.x, gridDim.x, v, ids, n, leaf_of, nstart, nlen, run, total); }
 // After k_leaf_refresh: node totals along the touched leaves' root paths, bottom-up level by level (s_ = rec(left); s_ += rec(right)). One workgroup;
 // thread q follows touched element q. Nodes shared by several paths are written by several threads with the same value.
-__global__ __launch_bounds__(1024) void k_tree_touch(const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of, const int32_t* __restrict__ anc,
+struct TreeTouchOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of, const int32_t* __restrict__ anc,
                                                       const int32_t* __restrict__ depth, const int32_t* __restrict__ left, const int32_t* __restrict__ right, int nlev, float* __restrict__ total) {
   // thread q < 1024 follows touched element q (+1024, ...: calls with more than 1024 touched elements take the slow loop below). The root path and the
   // child links of its nodes are static, so they are fetched once, before the level loop: each level then costs ONE round trip (the two child totals)
-  if (n <= 1024) {
+  if (n <= (int64_t)blockDim.x) {
     const int64_t q = threadIdx.x; int d = 0; int an[CRUX_PER_PMAX], lf[CRUX_PER_PMAX], rg[CRUX_PER_PMAX];
     const int64_t e = q < n ? ids[q] : 0;
     if (e != 0) { const int leaf = leaf_of[e]; d = depth[leaf];
@@ -203,12 +206,14 @@ __global__ __launch_bounds__(1024) void k_tree_touch(const int64_t* __restrict__
     return;
   }
   for (int lv = nlev - 2; lv >= 0; --lv) {
-    for (int64_t q = threadIdx.x; q < n; q += 1024) { const int64_t e = ids[q]; if (e == 0) continue;
+    for (int64_t q = threadIdx.x; q < n; q += blockDim.x) { const int64_t e = ids[q]; if (e == 0) continue;
       const int leaf = leaf_of[e]; const int k = depth[leaf] - 1 - lv;
       if (k >= 0) { const int a = anc[(size_t)leaf * CRUX_PER_PMAX + k]; total[a] = total[left[a]] + total[right[a]]; } }
     __threadfence_block(); __syncthreads();
   }
-}
+} };
+__global__ __launch_bounds__(1024) void k_tree_touch(const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of, const int32_t* __restrict__ anc,
+                                                      const int32_t* __restrict__ depth, const int32_t* __restrict__ left, const int32_t* __restrict__ right, int nlev, float* __restrict__ total) { TreeTouchOp::run(blockIdx.x, gridDim.x, ids, n, leaf_of, anc, depth, left, right, nlev, total); }
 // prefix of leaf node `leaf` = _accumulate_pairwise!'s s at that leaf: v[1], then + total(left sibling) at every right turn of the root path, top-down
 __device__ __forceinline__ float leaf_prefix(const float* __restrict__ v, const float* __restrict__ total, const int32_t* __restrict__ path, int leaf) {
   int sib[CRUX_PER_PMAX]; float tv[CRUX_PER_PMAX];
@@ -236,10 +241,10 @@ __global__ void k_cumsum_tiny(const float* v, int64_t n, float* c) { if (threadI
 // derives the (lo, hi) interval that path would have produced and probes its midpoint; a ballot then replays the real search over the 63 answers.
 // The probes and comparisons are exactly those of the sequential search, so the result is the reference's index even where rounding makes the
 // cumsum locally non-monotone; 20 levels cost 4 round trips instead of 20.
-__global__ __launch_bounds__(256) void k_per_search(const float* __restrict__ run, const float* __restrict__ total, const int32_t* __restrict__ path, const int32_t* __restrict__ leaf_of, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B,
+struct PerSearchOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ run, const float* __restrict__ total, const int32_t* __restrict__ path, const int32_t* __restrict__ leaf_of, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B,
                              const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) {
   const int lane = threadIdx.x & 63;
-  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t j = (int64_t)bid_ * 4 + (threadIdx.x >> 6);
   if (j >= B) return;
   auto cs = [&](int64_t i) -> float { return (i == 0 || N < 2) ? run[i] : leaf_prefix(pr, total, path, leaf_of[i]) + run[i]; };    // cumsum[i] exactly as accumulate_pairwise! forms it
   const float ptot = cs(N - 1);
@@ -268,13 +273,16 @@ __global__ __launch_bounds__(256) void k_per_search(const float* __restrict__ ru
     const float max_w = powf(pmin * (float)N, -beta);
     weight[lo] = powf(((float)N * pr[lo]) / ptot, beta) / max_w;
   }
-}
-__global__ void k_uniform_ids(int64_t N, int64_t B, uint64_t seed, uint32_t stream, uint64_t ictr, int64_t* ids) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+} };
+__global__ __launch_bounds__(256) void k_per_search(const float* __restrict__ run, const float* __restrict__ total, const int32_t* __restrict__ path, const int32_t* __restrict__ leaf_of, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B,
+                             const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) { PerSearchOp::run(blockIdx.x, gridDim.x, run, total, path, leaf_of, pr, pminmax, N, B, rands, seed, stream, ictr, beta, ids, weight); }
+struct UniformIdsOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, int64_t N, int64_t B, uint64_t seed, uint32_t stream, uint64_t ictr, int64_t* ids) {
+  const int64_t j = (int64_t)bid_ * blockDim.x + threadIdx.x;
   if (j >= B) return;
   const crux_u32x4 x = crux_philox(seed, ictr * (uint64_t)B + (uint64_t)j, stream, CRUX_RNG_SAMPLE);
   ids[j] = (int64_t)(((uint64_t)x.v[0] * (uint64_t)N) >> 32);
-}
+} };
+__global__ void k_uniform_ids(int64_t N, int64_t B, uint64_t seed, uint32_t stream, uint64_t ictr, int64_t* ids) { UniformIdsOp::run(blockIdx.x, gridDim.x, N, B, seed, stream, ictr, ids); }
 // gather rows src[ids[j]] into the ring of dst at (base + j) % C
 template <typename T>
 __global__ void k_gather_ring(T* __restrict__ dst, const T* __restrict__ src, const int64_t* __restrict__ ids, int64_t n, int32_t row_elems, int64_t base, int64_t C) {
@@ -286,17 +294,19 @@ __global__ void k_gather_ring(T* __restrict__ dst, const T* __restrict__ src, co
 }
 // all columns of the sampled rows in ONE launch: a table of (dst, src, elements per row, element size) and the prefix of row widths
 struct GatherCols { void* dst[CRUX_NCOLS]; const void* src[CRUX_NCOLS]; int32_t re[CRUX_NCOLS]; int32_t esz[CRUX_NCOLS]; int32_t pre[CRUX_NCOLS + 1]; int32_t n; };
-__global__ void k_gather_ring_all(GatherCols g, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) {
+struct GatherRingAllOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, GatherCols g, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) {
   const int32_t width = g.pre[g.n]; const int64_t total = n * width;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t t = (int64_t)bid_ * blockDim.x + threadIdx.x; t < total; t += (int64_t)nb_ * blockDim.x) {
     const int64_t j = t / width; const int32_t w = (int32_t)(t - j * width);
     int k = 0; while (k + 1 < g.n && w >= g.pre[k + 1]) ++k;
     const int32_t e = w - g.pre[k]; const int64_t d = ((base + j) % C) * g.re[k] + e, sidx = ids[j] * g.re[k] + e;
     if (g.esz[k] == 4) ((uint32_t*)g.dst[k])[d] = ((const uint32_t*)g.src[k])[sidx];
     else ((uint8_t*)g.dst[k])[d] = ((const uint8_t*)g.src[k])[sidx];
   }
-}
-__global__ void k_ring_ids(int64_t* out, int64_t n, int64_t base, int64_t C) { const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (j < n) out[j] = (base + j) % C; }
+} };
+__global__ void k_gather_ring_all(GatherCols g, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) { GatherRingAllOp::run(blockIdx.x, gridDim.x, g, ids, n, base, C); }
+struct RingIdsOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, int64_t* out, int64_t n, int64_t base, int64_t C) { const int64_t j = (int64_t)bid_ * blockDim.x + threadIdx.x; if (j < n) out[j] = (base + j) % C; } };
+__global__ void k_ring_ids(int64_t* out, int64_t n, int64_t base, int64_t C) { RingIdsOp::run(blockIdx.x, gridDim.x, out, n, base, C); }
 
 static unsigned gridn(int64_t total) { int64_t nb = (total + 255) / 256; if (nb < 1) nb = 1; if (nb > 8192) nb = 8192; return (unsigned)nb; }
 
@@ -326,6 +336,10 @@ static int32_t ensure_cumsum(crux_buffer* s, int64_t N) {
   s->cumsum_valid = true;
   return crux_launch_check(c, "per scan");
 }
+int32_t crux_per_prepare(crux_buffer* source) {      // exec.hip: bring the tree up to date BEFORE a recording starts (a full rebuild launches plain kernels)
+  if (!source->prioritized || source->elements < 1) return CRUX_OK;
+  return ensure_cumsum(source, source->elements);
+}
 // called by every path that changes priorities (update_priorities!, push!'s max-priority rows): d_ids = the touched elements (device, int64)
 int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool from_push) {
   b->cumsum_valid = false;
@@ -333,8 +347,8 @@ int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool f
   if (from_push && b->elements < b->capacity) { b->per_full_dirty = true; return CRUX_OK; }   // the ring is still growing: the rows may lie beyond the current tree
   if (b->per_full_dirty || b->topo_n < 2 || b->per_run_n != b->topo_n || b->topo_n != b->elements || n > 4096 || !d_ids) { b->per_full_dirty = true; return CRUX_OK; }
   if (b->topo_levels > CRUX_PER_PMAX) { b->per_full_dirty = true; return CRUX_OK; }
-  hipLaunchKernelGGL(k_leaf_refresh, dim3((unsigned)n), dim3(64), 0, b->ctx->stream, b->priorities, d_ids, n, b->topo_leaf_of, b->topo_node_start, b->topo_node_len, b->cumsum, b->topo_total);
-  hipLaunchKernelGGL(k_tree_touch, dim3(1), dim3(1024), 0, b->ctx->stream, d_ids, n, b->topo_leaf_of, b->topo_anc, b->topo_depth, b->topo_left, b->topo_right, b->topo_levels, b->topo_total);
+  CRUX_RUN(b->ctx, LeafRefreshOp, OP_LEAF_REFRESH, k_leaf_refresh, (unsigned)n, 64, b->ctx->stream, b->priorities, d_ids, n, b->topo_leaf_of, b->topo_node_start, b->topo_node_len, b->cumsum, b->topo_total);
+  CRUX_RUN(b->ctx, TreeTouchOp, OP_TREE_TOUCH, k_tree_touch, 1, 1024, b->ctx->stream, d_ids, n, b->topo_leaf_of, b->topo_anc, b->topo_depth, b->topo_left, b->topo_right, b->topo_levels, b->topo_total);
   return crux_launch_check(b->ctx, "k_leaf_refresh");
 }
 
@@ -349,12 +363,12 @@ static int32_t gather_into(crux_buffer* target, crux_buffer* source, int64_t B, 
     const size_t st = col_stride(target, k); const int q = g.n++;
     g.dst[q] = target->col[k]; g.src[q] = source->col[k]; g.esz[q] = st % 4 == 0 ? 4 : 1; g.re[q] = (int32_t)(st % 4 == 0 ? st / 4 : st); g.pre[q + 1] = g.pre[q] + g.re[q];
   }
-  if (g.n > 0) hipLaunchKernelGGL(k_gather_ring_all, dim3(gridn(B * g.pre[g.n])), dim3(256), 0, c->stream, g, (const int64_t*)target->d_indices, B, base, C);
+  if (g.n > 0) CRUX_RUN(c, GatherRingAllOp, OP_GATHER_RING_ALL, k_gather_ring_all, gridn(B * g.pre[g.n]), 256, c->stream, g, (const int64_t*)target->d_indices, B, base, C);
   crux_prof_end(c, CRUX_PROF_GATHER);
   int32_t rc = crux_launch_check(c, "k_gather_ring"); if (rc) return rc;
   if (target->prioritized) {       // buffer_like of a prioritized buffer is prioritized too (:84): push! runs update_priorities! on it
     int64_t* ring = (int64_t*)crux_scratch(c, 8 * (size_t)B + 256); if (!ring) return crux_fail(c, CRUX_ENOMEM, "sample: scratch");
-    hipLaunchKernelGGL(k_ring_ids, dim3(gridn(B)), dim3(256), 0, c->stream, ring, B, base, C);
+    CRUX_RUN(c, RingIdsOp, OP_RING_IDS, k_ring_ids, gridn(B), 256, c->stream, ring, B, base, C);
     rc = crux_buffer_per_on_push(target, ring, B); if (rc) return rc;
   }
   if (fetch_indices) { target->indices_n = B; target->indices_stale = true; }   // crux_buffer_indices copies them out when (if) the host asks: no synchronisation per sample
@@ -376,8 +390,7 @@ int32_t crux_per_sample(crux_buffer* target, crux_buffer* source, int64_t B, con
   if (rands) { d_r = (double*)crux_scratch(c, 8 * (size_t)B + 256); if (!d_r) return crux_fail(c, CRUX_ENOMEM, "prioritized_sample!: scratch");
     HIPCHK(c, hipMemcpyAsync(d_r, rands, 8 * (size_t)B, hipMemcpyHostToDevice, c->stream)); }
   crux_prof_begin(c, CRUX_PROF_PER_SEARCH);
-  hipLaunchKernelGGL(k_per_search, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, c->stream, source->cumsum, source->topo_total, source->topo_path, source->topo_leaf_of, source->priorities, source->pminmax, N, B, (const double*)d_r,
-                     source->sample_seed, source->sample_stream, i, beta, target->d_indices, (float*)source->col[CRUX_COL_WEIGHT]);
+  CRUX_RUN(c, PerSearchOp, OP_PER_SEARCH, k_per_search, (unsigned)((B + 3) / 4), 256, c->stream, source->cumsum, source->topo_total, source->topo_path, source->topo_leaf_of, source->priorities, source->pminmax, N, B, (const double*)d_r, source->sample_seed, source->sample_stream, i, beta, target->d_indices, (float*)source->col[CRUX_COL_WEIGHT]);
   crux_prof_end(c, CRUX_PROF_PER_SEARCH);
   rc = crux_launch_check(c, "k_per_search"); if (rc) return rc;
   return gather_into(target, source, B, true);
@@ -391,7 +404,7 @@ int32_t crux_uniform_sample(crux_buffer* target, crux_buffer* source, int64_t B,
   if (target->obs_dim != source->obs_dim || target->act_dim != source->act_dim || target->act_kind != source->act_kind) return crux_fail(c, CRUX_EINVAL, "uniform_sample!: column shapes differ");
   if (ids) { for (int64_t j = 0; j < B; ++j) if (ids[j] < 0 || ids[j] >= N) return crux_fail(c, CRUX_EINVAL, "uniform_sample!: id %lld out of range", (long long)ids[j]);
     HIPCHK(c, hipMemcpyAsync(target->d_indices, ids, 8 * (size_t)B, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
-  else hipLaunchKernelGGL(k_uniform_ids, dim3(gridn(B)), dim3(256), 0, c->stream, N, B, source->sample_seed, source->sample_stream, i, target->d_indices);
+  else CRUX_RUN(c, UniformIdsOp, OP_UNIFORM_IDS, k_uniform_ids, gridn(B), 256, c->stream, N, B, source->sample_seed, source->sample_stream, i, target->d_indices);
   return gather_into(target, source, B, true);
 }
 

@@ -7,6 +7,8 @@
 // parameters / moments stay in global memory (L2 resident). It is the correctness baseline and the fallback for shapes
 // the MFMA kernel (train_mfma.hip) does not cover. Both implement the same TrainArgs contract.
 #include "train_args.h"
+#include "exec.h"
+#include "ops_small.h"
 
 int32_t crux_buffer_apply_order(crux_buffer* b, const int32_t* d_order, int64_t n);
 int32_t crux_buffer_apply_order_multi(int32_t n, crux_buffer* const* bufs, const int32_t* const* d_orders);
@@ -790,11 +792,7 @@ static int32_t td_step_impl(crux_mlp* net, crux_buffer* batch, const float* d_y,
 // ---- dqn_target / td_error -----------------------------------------------------------------------------
 int32_t crux_mlp_forward_impl(crux_mlp* net, const float* d_x, int64_t B, float* d_y, const float* params_override);
 
-__global__ void k_dqn_target(const float* __restrict__ q, int nout, const float* __restrict__ r, const uint8_t* __restrict__ done, float gamma, int64_t n, float* __restrict__ y) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (s >= n) return;
-  float mx = q[s * nout]; for (int k = 1; k < nout; ++k) mx = q[s * nout + k] > mx ? q[s * nout + k] : mx;
-  y[s] = __fadd_rn(r[s], __fmul_rn(__fmul_rn(gamma, __fsub_rn(1.f, done[s] ? 1.f : 0.f)), mx));   // r .+ gamma .* (1 .- done) .* max  (dqn.jl:5)
-}
+__global__ void k_dqn_target(const float* __restrict__ q, int nout, const float* __restrict__ r, const uint8_t* __restrict__ done, float gamma, int64_t n, float* __restrict__ y) { DqnTargetOp::run(blockIdx.x, gridDim.x, q, nout, r, done, gamma, n, y); }
 __global__ void k_softq_target(const float* __restrict__ q, int nout, const float* __restrict__ r, const uint8_t* __restrict__ done, float gamma, float alpha, int64_t n, float* __restrict__ y) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (s >= n) return;
   float mx = __fdiv_rn(q[s * nout], alpha); for (int k = 1; k < nout; ++k) { const float v = __fdiv_rn(q[s * nout + k], alpha); mx = v > mx ? v : mx; }
@@ -802,11 +800,7 @@ __global__ void k_softq_target(const float* __restrict__ q, int nout, const floa
   const float sv = __fmul_rn(alpha, __fadd_rn(mx, logf(sum)));                                   // soft_value = alpha .* logsumexp(value ./ alpha) (softq.jl:1)
   y[s] = __fadd_rn(r[s], __fmul_rn(__fmul_rn(gamma, __fsub_rn(1.f, done[s] ? 1.f : 0.f)), sv));
 }
-__global__ void k_td_error(const float* __restrict__ q, int nout, const uint8_t* __restrict__ a, const float* __restrict__ y, int64_t n, float* __restrict__ err) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (s >= n) return;
-  float Q = 0.f; for (int k = 0; k < nout; ++k) Q = __fadd_rn(Q, __fmul_rn(q[s * nout + k], a[s * nout + k] ? 1.f : 0.f));
-  err[s] = fabsf(__fsub_rn(Q, y[s]));
-}
+__global__ void k_td_error(const float* __restrict__ q, int nout, const uint8_t* __restrict__ a, const float* __restrict__ y, int64_t n, float* __restrict__ err) { TdErrorOp::run(blockIdx.x, gridDim.x, q, nout, a, y, n, err); }
 
 extern "C" {
 
@@ -818,7 +812,7 @@ int32_t crux_dqn_target(crux_mlp* tn, crux_buffer* batch, float gamma, float* d_
   int32_t rc;
   if (tn->nd.maxdim >= CRUX_DENSE_MIN_WIDTH) { rc = crux_dense_forward(tn, (const float*)batch->col[CRUX_COL_SP], n, c->stream); if (rc) return rc; q = crux_dense_act(tn, tn->nd.L); }
   else { rc = crux_mlp_forward_impl(tn, (const float*)batch->col[CRUX_COL_SP], n, q, nullptr); if (rc) return rc; }
-  hipLaunchKernelGGL(k_dqn_target, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, q, nout, (const float*)batch->col[CRUX_COL_R], (const uint8_t*)batch->col[CRUX_COL_DONE], gamma, n, d_y);
+  CRUX_RUN(c, DqnTargetOp, OP_DQN_TARGET, k_dqn_target, (unsigned)((n + 255) / 256), 256, c->stream, q, nout, (const float*)batch->col[CRUX_COL_R], (const uint8_t*)batch->col[CRUX_COL_DONE], gamma, n, d_y);
   return crux_launch_check(c, "k_dqn_target");
 }
 
@@ -844,7 +838,7 @@ int32_t crux_td_error(crux_mlp* net, crux_buffer* batch, const float* d_y, float
   int32_t rc;
   if (net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH) { rc = crux_dense_forward(net, (const float*)batch->col[CRUX_COL_S], n, c->stream); if (rc) return rc; q = crux_dense_act(net, net->nd.L); }
   else { rc = crux_mlp_forward_impl(net, (const float*)batch->col[CRUX_COL_S], n, q, nullptr); if (rc) return rc; }
-  hipLaunchKernelGGL(k_td_error, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, q, nout, (const uint8_t*)batch->col[CRUX_COL_A], d_y, n, d_err);
+  CRUX_RUN(c, TdErrorOp, OP_TD_ERROR, k_td_error, (unsigned)((n + 255) / 256), 256, c->stream, q, nout, (const uint8_t*)batch->col[CRUX_COL_A], d_y, n, d_err);
   return crux_launch_check(c, "k_td_error");
 }
 

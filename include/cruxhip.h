@@ -386,6 +386,22 @@ int32_t crux_td_step(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_
 int32_t crux_td_step_with_error(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight, float* d_err, float* info_out);
 
 
+/* One epoch of value_training (src/model_free/off_policy.jl:69-93) for the DQN family: rand!(batch, source; i) (:71, uniform or prioritized with
+ * exponent beta) -> y = dqn_target(target_net, batch) (:80) -> when source is prioritized td_error (:83, shares the forward pass of the step) and
+ * update_priorities!(source, batch.indices, td_error) -> train!(net, td_loss[, weight]) (:91-93). Results equal the separate calls
+ * (crux_per_sample / crux_uniform_sample, crux_dqn_target, crux_td_step[_with_error], crux_per_update_device) in that order. For networks at least 128
+ * wide the ~25 kernels of the epoch run as ONE persistent launch (csrc/exec.hip: the kernel bodies are executed op by op by 64 workgroups on one
+ * XCD with L2 counter barriers between dependent ops), which is what makes the step latency- instead of launch-bound. info_out: LOSS, GRAD_NORM, [2] = Qavg. */
+int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
+                       uint64_t sample_counter, float* info_out);
+/* One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl:4-52,94-104) as one fused launch: rand! -> sac_target ->
+ * train!(log_alpha, sac_temp_loss) -> [update_critic: train!(critic, double_Q_loss)] -> [update_actor: train!(actor, sac_actor_loss), then
+ * polyak_average!(target, online, tau) for the actor (when actor_targ != NULL) and both critics (:100)]. The three exploration draws use noise counters
+ * noise_counter0, +1, +2 like the separate calls. info_*: host [CRUX_INFO_N] each (NULL = not wanted).                                            */
+int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_mlp* log_alpha,
+                       crux_buffer* source, crux_buffer* batch, float gamma, float H_target, float tau, int32_t use_weight, int32_t update_critic, int32_t update_actor,
+                       uint64_t sample_counter, uint64_t noise_seed, uint64_t noise_counter0, float* info_temp, float* info_critic, float* info_actor);
+
 /* SAC (src/model_free/rl/sac.jl) -----------------------------------------------------------------------
  * actor: GaussianPolicy handle (mean network + n_extra = act_dim trainable logSigma, policies.jl:315-348);
  * critic: DoubleNetwork = two ContinuousNetwork handles over vcat(s, a) (policies.jl:96,162-187); log_alpha:

@@ -127,3 +127,42 @@ def test_action_of_an_always_stochastic_policy_samples_with_nan_logprob(gpu_ctx)
     g.always_stochastic = False
     crux.steps_(crux.Sampler(crux.CartPoleMDP(n_envs=E, seed=seed), g, max_steps=50), greedy, Nsteps=E * T, explore=False, i=0, reset=True)
     assert not np.array_equal(greedy["a"], gb["a"])                       # sampling differs from argmax on this seed
+
+
+@pytest.mark.parametrize("prioritized", [True, False])
+def test_fused_dqn_epoch_equals_the_separate_calls(gpu_ctx, prioritized):
+    """crux_dqn_epoch (one fused launch per value_training epoch for wide networks, csrc/exec.hip) against the same epoch made of separate calls:
+    same samples, same priorities, same parameters, bit for bit (the op bodies are shared)."""
+    def run(fused):
+        S, A = crux.ContinuousSpace(8), crux.DiscreteSpace(4)
+        q = crux.DiscreteNetwork(parity.chain([8, 256, 256, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=3)
+        mdp = crux.SynthMDP(8, 4, discrete=True, n_envs=1, seed=5, discount=0.97)
+        sv = crux.DQN(q, S, N=600, dN=4, buffer_size=2000, prioritized=prioritized, buffer_init=400, max_steps=40, c_opt={"batch_size": 128})
+        sv.fused_epochs = fused
+        crux.solve(sv, mdp)
+        pp = sv.buffer.priority_params() if prioritized else None
+        return q.get_params(), sv.agent.pi_minus.get_params(), sv.buffer["s"], pp, sv.history
+    pa, ta, sa, ppa, ha = run(True); pb, tb, sb, ppb, hb = run(False)
+    assert np.array_equal(sa, sb)
+    assert np.array_equal(pa, pb) and np.array_equal(ta, tb), (np.abs(pa - pb).max(), np.abs(ta - tb).max())      # the op bodies are shared: bit for bit
+    if prioritized:
+        assert np.allclose(ppa["priorities"], ppb["priorities"], rtol=1e-5, atol=1e-7) and abs(ppa["max_priority"] - ppb["max_priority"]) < 1e-5
+    assert abs(ha[-1]["critic_loss"] - hb[-1]["critic_loss"]) < 1e-5 * max(1.0, abs(hb[-1]["critic_loss"]))
+
+
+def test_fused_sac_epoch_equals_the_separate_calls(gpu_ctx):
+    """crux_sac_epoch (rand! -> sac_target -> temperature -> twin critics -> actor -> polyak as one fused launch) against the separate calls."""
+    def run(fused):
+        S = crux.ContinuousSpace(3)
+        acts = ["relu", "relu", "identity"]
+        pi = crux.ActorCritic(crux.GaussianPolicy(parity.chain([3, 256, 256, 1], acts), np.zeros(1, np.float32), seed=2),
+                              crux.DoubleNetwork(crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], acts), seed=3), crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], acts), seed=4)))
+        sv = crux.SAC(pi, S, N=420, dN=6, buffer_size=1000, buffer_init=300, max_steps=50, c_opt={"batch_size": 256}, a_opt={"batch_size": 256}, SAC_alpha_opt={"batch_size": 256})
+        sv.fused_epochs = fused
+        crux.solve(sv, crux.PendulumMDP(n_envs=1, seed=8))
+        return [n.get_params() for n in (pi.A, pi.C.N1, pi.C.N2, sv.agent.pi_minus.C.N1, sv.P["SAC_log_alpha"])], sv.history
+    a, ha = run(True); b, hb = run(False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y), np.abs(x - y).max()
+    for k in ("critic_loss", "actor_loss", "temp_loss", "SAC alpha"):
+        assert abs(ha[-1][k] - hb[-1][k]) < 1e-5 * max(1.0, abs(hb[-1][k])), k
