@@ -1,0 +1,211 @@
+"""Off-policy configs of BASELINE.json on one MI355X, each with a roofline and the oracle's CPU baseline on a bounded sample of the same workload
+(imported by bench_extra.py; `python bench_offpolicy.py [--steps K]` prints the same dict on its own).
+
+  c3  configs[2]: DQN + prioritized replay (1 M transitions), 8-256-256-4, B = 128: one value_training epoch =
+      prioritized_sample! -> dqn_target -> td_error -> update_priorities! -> train!(td_loss)              (crux_dqn_epoch, one fused launch)
+  c4  configs[3]: SAC, GaussianPolicy 3-256-256-1 + twin Q 4-256-256-1, B = 256: one epoch =
+      rand! -> sac_target -> temperature step -> twin-critic step -> actor step -> polyak                 (crux_sac_epoch, one fused launch)
+  c1  configs[0]: DQN on SimpleGridWorld, 2-8-4, N = 100 000, dN = 4, B = 128 (the README example), whole solve
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PEAK_F32_MFMA_TFLOPS, PEAK_HBM_GBS = 157.3, 8000.0
+# algorithmic flops: C3 step = train fwd+bwd (6) + target fwd (2) + td_error fwd (2, shared with the train forward here but counted as the reference does) per sample and weight
+C3_W = 8 * 256 + 256 * 256 + 256 * 4
+C3_FLOP = (6 + 2 + 2) * 128 * C3_W                       # 87.8 MFLOP
+C4_ACTOR_W, C4_Q_W = 3 * 256 + 256 * 256 + 256 * 1, 4 * 256 + 256 * 256 + 256 * 1
+C4_FLOP = 256 * 2 * (6 * 2 * C4_Q_W / 2 + (6 * C4_ACTOR_W + 4 * 2 * C4_Q_W) / 2 + (2 * C4_ACTOR_W + 2 * 2 * C4_Q_W) / 2 + 2 * C4_ACTOR_W / 2)   # ~0.58 GFLOP (MAC counts of SURVEY 8d x 2)
+
+
+def _chain(crux, dims, acts):
+    return crux.Chain(*[crux.Dense(dims[i], dims[i + 1], acts[i]) for i in range(len(acts))])
+
+
+def _timed(ctx, fn, steps, warmup=5):
+    for _ in range(warmup):
+        fn()
+    ctx.sync(); t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    ctx.sync(); return (time.perf_counter() - t0) / steps
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from crux_jl_amd import _lib as L
+    return O, L
+
+
+def c3(crux, ctx, cpu=True, steps=300):
+    from crux_jl_amd import _lib as L
+    rng = np.random.default_rng(0); N, B = 1_000_000, 128
+    S, A = crux.ContinuousSpace(8), crux.DiscreteSpace(4)
+    buf = crux.ExperienceBuffer(S, A, N, prioritized=True); D = crux.buffer_like(buf, capacity=B)
+    chunk = 100_000
+    for _ in range(N // chunk):
+        a_id = rng.integers(0, 4, chunk)
+        buf.push_({"s": rng.normal(0, 1, (8, chunk)).astype(np.float32), "a": np.eye(4, dtype=bool)[:, a_id], "sp": rng.normal(0, 1, (8, chunk)).astype(np.float32),
+                   "r": rng.normal(0, 1, (1, chunk)).astype(np.float32), "done": rng.random((1, chunk)) < 0.01, "episode_end": np.zeros((1, chunk), bool)})
+    buf.update_priorities_(np.arange(1, N + 1), (np.abs(rng.normal(0, 1, N)) + 1e-3).astype(np.float32))
+    q = crux.DiscreteNetwork(_chain(crux, [8, 256, 256, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=1)
+    qm = crux.clone_policy(q); q.attach_optimizer(crux.Adam(np.float32(1e-3)))
+    raw = np.zeros(L.INFO_N, np.float32); k = [0]
+
+    def epoch():
+        k[0] += 1
+        ctx.check(ctx.lib.crux_dqn_epoch(q.h, qm.h, buf.h, D.h, 0.99, 1, 0.5, k[0], raw.ctypes.data_as(L.vp)))
+    t = _timed(ctx, epoch, steps)
+    ach = C3_FLOP / t / 1e12
+    # bytes the replay sampling moves per epoch with the incremental tree (per.hip): <= 128 touched leaves re-summed (read + write, <= 127 x 4 B each),
+    # their root paths, 128 x 20 probes of (leaf id, running sum, 24 path ids, <= 24 totals), the 128-row gather (78 B/row read + write)
+    per_bytes = 128 * 127 * 8 + 128 * 14 * 12 + 128 * 20 * (4 + 4 + 96 + 56) + 2 * 128 * 78
+    out = {"workload": "DQN + prioritized replay, 8-256-256-4, buffer 1 M, B = 128: one value_training epoch (prioritized_sample! + dqn_target + td_error + update_priorities! + train!)",
+           "grad_steps_per_s": 1.0 / t, "per_samples_per_s": B / t, "us_per_epoch": 1e6 * t, "fused_launches_per_epoch": 1,
+           "roofline": {"kernel": "k_exec (fused epoch: 10 tile-GEMM ops + heads + Adam + replay ops)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        "algorithmic_MFLOP_per_epoch": C3_FLOP / 1e6, "note": "latency-bound: ~25 dependent ops per epoch on 32 CUs of one XCD with 1.3 us L2 barriers between them"},
+           "replay_sampling": {"bytes_per_epoch_incremental": per_bytes, "bytes_per_epoch_full_rescan": 8 * N, "bound": "hbm", "note": "the reference's cumsum(priorities) per gradient step (4 MB read + 4 MB write at N = 1 M) is replaced by re-summing the touched leaves and their root paths; sample indices stay bit-exact"}}
+    if cpu:
+        O, L2 = _oracle()
+        n_o = 200_000                                     # bounded sample: the oracle's O(N) rescan per step at a 5x smaller buffer, scaled linearly in N for the scan part
+        ob = O.OBuffer(8, 4, L2.ACTION_DISCRETE, n_o, ["weight"], prioritized=True, alpha=np.float32(0.6)); od = O.OBuffer(8, 4, L2.ACTION_DISCRETE, B, ["weight"], prioritized=True, alpha=np.float32(0.6))
+        a_id = rng.integers(0, 4, n_o)
+        ob.push({"s": rng.normal(0, 1, (8, n_o)).astype(np.float32), "a": np.eye(4, dtype=bool)[:, a_id], "sp": rng.normal(0, 1, (8, n_o)).astype(np.float32),
+                 "r": rng.normal(0, 1, (1, n_o)).astype(np.float32), "done": rng.random((1, n_o)) < 0.01})
+        v = (np.abs(rng.normal(0, 1, n_o)) + 1e-3).astype(np.float32)
+        O.chk(O.lib().orc_per_update(ob.h, O.vpz(np.arange(n_o, dtype=np.int64)), O.vpz(v), 0, n_o))
+        oq = O.OMlp([8, 256, 256, 4], ["relu", "relu", "identity"]).init_glorot(1).adam_init(1e-3); ot = O.OMlp([8, 256, 256, 4], ["relu", "relu", "identity"]).init_glorot(1)
+        y = np.empty(B, np.float32); err = np.empty(B, np.float32); ids = np.empty(B, np.int64); info = np.zeros(L2.INFO_N, np.float32)
+        n_ep = 40; t_scan = t_rest = 0.0
+        for e in range(n_ep):
+            t0 = time.perf_counter(); O.chk(O.lib().orc_per_sample(od.h, ob.h, B, None, 0.5, e + 1, 0x5EED5A3F)); t1 = time.perf_counter()
+            O.chk(O.lib().orc_dqn_target(ot.h, od.h, 0.99, O.vpz(y))); O.chk(O.lib().orc_td_error(oq.h, od.h, O.vpz(y), O.vpz(err)))
+            O.chk(O.lib().orc_buffer_indices(od.h, O.vpz(ids), B)); O.chk(O.lib().orc_per_update(ob.h, O.vpz(ids), O.vpz(err), 0, B))
+            O.chk(O.lib().orc_td_step(oq.h, od.h, O.vpz(y), 1, O.vpz(info))); t2 = time.perf_counter()
+            t_scan += t1 - t0; t_rest += t2 - t1
+        t_cpu = (t_scan / n_ep) * (N / n_o) + t_rest / n_ep
+        import bench
+        model, ncpu = bench.host_cpu()
+        out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "grad-steps/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": ncpu,
+                               "sample": "oracle/ (1 thread): %d epochs at a %d-row buffer (cumsum rescan %.2f ms/epoch scaled x%d to 1 M rows, networks + update %.2f ms/epoch)" % (n_ep, n_o, 1e3 * t_scan / n_ep, N // n_o, 1e3 * t_rest / n_ep)}
+    return out
+
+
+def c4(crux, ctx, cpu=True, steps=200):
+    from crux_jl_amd import _lib as L
+    rng = np.random.default_rng(1); B, n = 256, 100_000
+    S, A = crux.ContinuousSpace(3), crux.ContinuousSpace(1)
+    buf = crux.ExperienceBuffer(S, A, n); D = crux.buffer_like(buf, capacity=B)
+    data = {"s": rng.normal(0, 1, (3, n)).astype(np.float32), "a": rng.uniform(-2, 2, (1, n)).astype(np.float32), "sp": rng.normal(0, 1, (3, n)).astype(np.float32),
+            "r": rng.normal(-1, 1, (1, n)).astype(np.float32), "done": np.zeros((1, n), bool), "episode_end": np.zeros((1, n), bool)}
+    buf.push_(data)
+    acts = ["relu", "relu", "identity"]
+    pi = crux.ActorCritic(crux.GaussianPolicy(_chain(crux, [3, 256, 256, 1], acts), np.zeros(1, np.float32), seed=2),
+                          crux.DoubleNetwork(crux.ContinuousNetwork(_chain(crux, [4, 256, 256, 1], acts), seed=3), crux.ContinuousNetwork(_chain(crux, [4, 256, 256, 1], acts), seed=4)))
+    opt = {"batch_size": B, "optimizer": crux.Adam(np.float32(3e-4))}
+    solver = crux.SAC(pi, S, N=10**9, dN=1, c_opt=dict(opt), a_opt=dict(opt), SAC_alpha_opt=dict(opt), buffer=buf)
+    solver.batch = D
+
+    def epoch():
+        solver.i += 1; crux.value_training(solver, D, np.float32(0.99))
+    t = _timed(ctx, epoch, steps)
+    ach = C4_FLOP / t / 1e12
+    out = {"workload": "SAC, GaussianPolicy 3-256-256-1 + twin Q 4-256-256-1, B = 256: one value_training epoch (rand! + sac_target + temperature, twin-critic and actor steps + polyak)",
+           "epochs_per_s": 1.0 / t, "grad_steps_per_s": 3.0 / t, "us_per_epoch": 1e6 * t, "fused_launches_per_epoch": 1,
+           "roofline": {"kernel": "k_exec (fused epoch: ~40 tile-GEMM ops + heads + 4 Adam + polyak)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        "algorithmic_GFLOP_per_epoch": C4_FLOP / 1e9, "note": "latency-bound: ~70 dependent ops per epoch on one XCD"}}
+    if cpu:
+        O, L2 = _oracle()
+        n_o = 20_000
+        ob = O.OBuffer(3, 1, L2.ACTION_CONTINUOUS, n_o); od = O.OBuffer(3, 1, L2.ACTION_CONTINUOUS, B)
+        ob.push({k: v[:, :n_o] for k, v in data.items() if k != "episode_end"})
+        oa = O.OMlp([3, 256, 256, 1], acts, 1).init_glorot(2).adam_init(float(np.float32(3e-4)))
+        q1, q2 = (O.OMlp([4, 256, 256, 1], acts).init_glorot(s).adam_init(float(np.float32(3e-4))) for s in (3, 4))
+        t1n, t2n = (O.OMlp([4, 256, 256, 1], acts).init_glorot(s) for s in (3, 4))
+        la = O.OMlp([0], [], 1); la.params[:] = 0.0; la.adam_init(float(np.float32(3e-4)))
+        y = np.empty(B, np.float32); info = np.zeros(L2.INFO_N, np.float32); n_ep = 20
+        t0 = time.perf_counter()
+        for e in range(n_ep):
+            O.chk(O.lib().orc_uniform_sample(od.h, ob.h, B, None, e + 1, 0x5EED5A3F))
+            O.chk(O.lib().orc_sac_target(oa.h, t1n.h, t2n.h, la.h, od.h, 0.99, 0, 3 * e, O.vpz(y)))
+            O.chk(O.lib().orc_sac_temp_step(oa.h, la.h, od.h, -1.0, 0, 3 * e + 1, O.vpz(info)))
+            O.chk(O.lib().orc_double_q_step(q1.h, q2.h, od.h, O.vpz(y), 0, O.vpz(info)))
+            O.chk(O.lib().orc_sac_actor_step(oa.h, q1.h, q2.h, la.h, od.h, 0, 3 * e + 2, O.vpz(info)))
+            for tn, qn in ((t1n, q1), (t2n, q2)):
+                O.chk(O.lib().orc_polyak(tn.h, qn.h, 0.005))
+        t_cpu = (time.perf_counter() - t0) / n_ep
+        import bench
+        model, ncpu = bench.host_cpu()
+        out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "epochs/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": ncpu,
+                               "sample": "oracle/ (1 thread): %d full epochs at B = 256 (%.1f ms/epoch)" % (n_ep, 1e3 * t_cpu)}
+    return out
+
+
+def c1(crux, ctx, cpu=True, N=100_000):
+    """configs[0], the README example: DQN on SimpleGridWorld(10x10, tprob .7), 2-8-4 relu network, N = 100 000 interactions, dN = 4, buffer 1000, B = 128,
+    eps-greedy 1 -> 0.1 over N/2 (src/model_free/rl/dqn.jl:27-46, README). Whole solve(), evaluation/logging off."""
+    S = crux.ContinuousSpace(2)
+    q = crux.DiscreteNetwork(_chain(crux, [2, 8, 4], ["relu", "identity"]), [1, 2, 3, 4], seed=1)
+    sv = crux.DQN(q, S, N=N, dN=4, max_steps=100, c_opt={"batch_size": 128})
+    mdp = crux.SimpleGridWorld(n_envs=1, seed=0)
+    ctx.sync(); t0 = time.perf_counter()
+    crux.solve(sv, mdp)
+    ctx.sync(); t = time.perf_counter() - t0
+    n_grad = len(sv.history) * 4
+    out = {"workload": "DQN on SimpleGridWorld (README example): 2-8-4, N = %d, dN = 4, buffer 1000, B = 128, whole solve()" % N,
+           "seconds": t, "env_steps_per_s": N / t, "grad_steps_per_s": n_grad / t,
+           "roofline": {"kernel": "k_exec / small-network learner", "bound": "hbm", "achieved": n_grad * 128 * 19 / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": n_grad * 128 * 19 / t / 1e9 / PEAK_HBM_GBS,
+                        "note": "19 B per sampled transition x 128 per gradient step; a 60-parameter network: pure latency, nominally HBM-bound"}}
+    if cpu:
+        out["cpu_baseline"] = c1_cpu(N=20_000)
+    return out
+
+
+def c1_cpu(N=20_000):
+    O, L = _oracle()
+    import parity
+    import bench
+    B, cap, dN = 128, 1000, 4
+    o = O.OMlp([2, 8, 4], ["relu", "identity"]).init_glorot(1).adam_init(1e-3); ot = O.OMlp([2, 8, 4], ["relu", "identity"]).init_glorot(1)
+    ob = O.OBuffer(2, 4, L.ACTION_DISCRETE, cap); obt = O.OBuffer(2, 4, L.ACTION_DISCRETE, B)
+    oe = O.OEnv("gridworld", 1, 100, 0.95, 0)
+    cfg = parity.rollout_cfg(True, False, "greedy_q"); cfg.eps_start, cfg.eps_stop, cfg.eps_steps = 1.0, 0.1, N // 2
+    y = np.empty(B, np.float32); info = np.zeros(L.INFO_N, np.float32)
+    t0 = time.perf_counter()
+    cfg.i0 = 200; oe.rollout(o, cfg, ob, 200)
+    i = 200
+    while i <= N - dN:
+        cfg.i0 = i; oe.rollout(o, cfg, ob, dN)
+        for ep in range(dN):
+            O.chk(O.lib().orc_uniform_sample(obt.h, ob.h, B, None, i * dN + ep, 0x5EED5A3F))
+            O.chk(O.lib().orc_dqn_target(ot.h, obt.h, 0.95, O.vpz(y)))
+            O.chk(O.lib().orc_td_step(o.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+        O.chk(O.lib().orc_polyak(ot.h, o.h, 0.005))
+        i += dN
+    t = time.perf_counter() - t0
+    model, ncpu = bench.host_cpu()
+    return {"value": N / t, "unit": "env-steps/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": ncpu,
+            "sample": "oracle/ (1 thread): the same solve loop for N = %d (%.2f s)" % (N, t)}
+
+
+def run(crux, ctx, cpu=True):
+    out = {}
+    for name, fn in (("c3_dqn_per", c3), ("c4_sac", c4), ("c1_dqn_gridworld", c1)):
+        try:
+            t0 = time.perf_counter(); out[name] = fn(crux, ctx, cpu); out[name]["bench_seconds"] = time.perf_counter() - t0
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": repr(e)}
+    return out
+
+
+if __name__ == "__main__":
+    import crux_jl_amd as crux
+    print(json.dumps(run(crux, crux.default_context(), cpu="--no-cpu" not in sys.argv)))

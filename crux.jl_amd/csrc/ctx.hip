@@ -15,7 +15,11 @@ int32_t crux_launch_check(crux_ctx* ctx, const char* what) {
   return CRUX_OK;
 }
 
+bool crux_exec_recording(const crux_ctx* c);          // exec.hip
+void* crux_exec_scratch(crux_ctx* c, size_t bytes);
 void* crux_scratch(crux_ctx* ctx, size_t bytes) {
+  // while a fused sequence is being recorded (exec.hip) the pieces' scratch blocks must not alias: ops of different pieces may share a phase
+  if (crux_exec_recording(ctx)) return crux_exec_scratch(ctx, bytes);
   if (bytes <= ctx->scratch_bytes) return ctx->scratch;
   if (ctx->scratch) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
   size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;

@@ -30,14 +30,17 @@ struct GemmArgs {
 // SPLITK: the four waves of a workgroup share ONE output tile and take a quarter of K each (combined through LDS in wave order, so the
 // result is deterministic): a 256-deep reduction then costs one L2 round trip instead of four -- these launches are latency-bound.
 template <bool AV, bool BV, bool SPLITK>
-struct Gemm16 { static __device__ __forceinline__ void run(const unsigned bid_, const GemmArgs& q) {
+struct Gemm16 { static __device__ __forceinline__ void run(const unsigned bid_, const GemmArgs& q, const int quart = 0) {
   __shared__ float part[SPLITK ? 3 * 64 * 5 : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int tm = (q.M + 15) >> 4, tn = (q.N + 15) >> 4;
   const int tile = SPLITK ? (int)bid_ : (int)bid_ * 4 + wv;
   if (tile >= tm * tn) return;
-  const int kper = SPLITK ? ((((q.K + 3) >> 2) + 15) & ~15) : q.K;
-  const int kbeg = SPLITK ? wv * kper : 0, kend = SPLITK ? (kbeg + kper < q.K ? kbeg + kper : q.K) : q.K;
+  // The reduction over K is DEFINED in four quarters of kper = ceil16(ceil(K / 4)) whenever the split-K form applies (K >= 128): quarter sums are
+  // formed separately and added in order ((q0 + q1) + q2) + q3. SPLITK gives one quarter to each wave of the workgroup (one L2 round trip for the
+  // whole depth: the stand-alone launches); `quart` lets ONE wave walk the four quarters (four tiles per workgroup: what the fused executor prefers on
+  // its 32 CUs). Both produce the same bits.
+  const int kper = (SPLITK || quart) ? ((((q.K + 3) >> 2) + 15) & ~15) : q.K;
   const int i0 = (tile % tm) << 4, j0 = (tile / tm) << 4;
   const int ia = i0 + c, jb = j0 + c;
   const bool va = ia < q.M, vb = jb < q.N;
@@ -46,10 +49,15 @@ struct Gemm16 { static __device__ __forceinline__ void run(const unsigned bid_, 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float rowsum = 0.f;                      // EPI_WGRAD, first column tile: db[i] = sum_k A(i, k) rides along (A = dZ, k = sample)
   const bool want_rowsum = q.epi == EPI_WGRAD && j0 == 0 && q.gbias != nullptr;
+  const int nparts = (!SPLITK && quart) ? 4 : 1;
+  for (int part = 0; part < nparts; ++part) {
+  const int kbeg = SPLITK ? wv * kper : (quart ? part * kper : 0), kend = (SPLITK || quart) ? (kbeg + kper < q.K ? kbeg + kper : q.K) : q.K;
+  f32x4 pacc = {0.f, 0.f, 0.f, 0.f}; float prow = 0.f;
   // K loop in steps of 64: the loads of four 16-wide chunks are issued before the first MFMA, so one L2 round trip (~1 us under load) is paid per
-  // 64 k instead of per 16 (the kernel is a wave-per-tile design with no LDS staging: latency, not bandwidth, is what has to be hidden)
-  for (int k0 = kbeg; k0 < kend; k0 += 64) {
-    float a[4][4], b[4][4];
+  // 64 k instead of per 16 (the kernel is a wave-per-tile design with no LDS staging: latency, not bandwidth, is what has to be hidden). The loads of
+  // step k0 + 64 are in flight while the MFMAs of step k0 run (two register sets, loop unrolled by two): a 256-deep reduction walked by one wave costs
+  // about one round trip instead of four. The accumulation order (k ascending) is unchanged.
+  auto load = [&](const int k0, float (&a)[4][4], float (&b)[4][4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int kb = k0 + 16 * u + 4 * g;
@@ -65,17 +73,31 @@ struct Gemm16 { static __device__ __forceinline__ void run(const unsigned bid_, 
       else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int kk = kb + r; b[u][r] = (vb && kk < kend) ? pb[(int64_t)kk * q.sBk] : 0.f; } }
-    }
+    } };
+  auto compute = [&](const float (&a)[4][4], const float (&b)[4][4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][r], b[u][r], acc, 0, 0, 0);
+      for (int r = 0; r < 4; ++r) pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][r], b[u][r], pacc, 0, 0, 0);
     if (want_rowsum) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rowsum += a[u][r];
+        for (int r = 0; r < 4; ++r) prow += a[u][r];
+    } };
+  if (kbeg < kend) {
+    float a0[4][4], b0[4][4], a1[4][4], b1[4][4];
+    int k0 = kbeg; load(k0, a0, b0);
+    for (;;) {
+      bool more = k0 + 64 < kend; if (more) load(k0 + 64, a1, b1);
+      compute(a0, b0);
+      if (!more) break; k0 += 64;
+      more = k0 + 64 < kend; if (more) load(k0 + 64, a0, b0);
+      compute(a1, b1);
+      if (!more) break; k0 += 64;
     }
+  }
+  if (part == 0) { acc = pacc; rowsum = prow; } else { acc[0] += pacc[0]; acc[1] += pacc[1]; acc[2] += pacc[2]; acc[3] += pacc[3]; rowsum += prow; }
   }
   if (SPLITK) {        // waves 1..3 hand their partial tile (and row sum) to wave 0, which adds them in wave order
     if (wv > 0) { float* p = part + ((wv - 1) * 64 + lane) * 5; p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2]; p[3] = acc[3]; p[4] = rowsum; }
@@ -103,9 +125,10 @@ template <bool AV, bool BV, bool SPLITK>
 __global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) { Gemm16<AV, BV, SPLITK>::run(blockIdx.x, q); }
 // the executor's form (exec.hip): the variant is data
 struct GemmOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, GemmArgs q, int variant) {
-  switch (variant) {
-    case 0: Gemm16<false, false, false>::run(bid_, q); break; case 1: Gemm16<true, false, false>::run(bid_, q); break;
-    case 2: Gemm16<false, true, false>::run(bid_, q); break;  case 3: Gemm16<true, true, false>::run(bid_, q); break;
+  const int quart = (variant >> 3) & 1;       // bit 0 AV, bit 1 BV, bit 2 split-K over the workgroup's waves, bit 3 the four K quarters walked by one wave
+  switch (variant & 7) {
+    case 0: Gemm16<false, false, false>::run(bid_, q, quart); break; case 1: Gemm16<true, false, false>::run(bid_, q, quart); break;
+    case 2: Gemm16<false, true, false>::run(bid_, q, quart); break;  case 3: Gemm16<true, true, false>::run(bid_, q, quart); break;
     case 4: Gemm16<false, false, true>::run(bid_, q); break;  case 5: Gemm16<true, false, true>::run(bid_, q); break;
     case 6: Gemm16<false, true, true>::run(bid_, q); break;   default: Gemm16<true, true, true>::run(bid_, q); break; } } };
 
@@ -124,8 +147,10 @@ static int32_t launch_gemm(crux_ctx* c, const GemmArgs& q, hipStream_t st) {
   const bool av = vec_ok(q.A, q.sAk, q.sAi, q.K), bv = vec_ok(q.B, q.sBk, q.sBj, q.K);
   static const bool no_split = getenv("CRUX_GEMM_NO_SPLITK") != nullptr;
   if (crux_exec_recording(c)) {                       // fused sequence (exec.hip): the same tile bodies, run by the persistent executor
-    const bool split = q.K >= 128 && tiles <= 4096 && !no_split;
-    crux_exec_push<GemmOp, OP_GEMM>(c, (unsigned)(split ? tiles : (tiles + 3) / 4), q, (int)((av ? 1 : 0) | (bv ? 2 : 0) | (split ? 4 : 0)));
+    // the stand-alone launch would split K over the four waves of a workgroup here; on the executor's 32 CUs one round of fat blocks beats several rounds of
+    // thin ones, so up to 32 tiles keep the split form and larger GEMMs give each wave a whole tile with the K quarters walked in order (same bits)
+    const bool deep = q.K >= 128 && tiles <= 4096 && !no_split, split = deep && tiles <= 32;
+    crux_exec_push<GemmOp, OP_GEMM>(c, (unsigned)(split ? tiles : (tiles + 3) / 4), q, (int)((av ? 1 : 0) | (bv ? 2 : 0) | (split ? 4 : 0) | ((deep && !split) ? 8 : 0)));
     return CRUX_OK;
   }
   if (q.K >= 128 && tiles <= 4096 && !no_split) {     // deep reductions: split K over the workgroup's four waves

@@ -14,7 +14,7 @@
 enum {
   OP_GEMM = 1, OP_ACT_GRAD, OP_GAUSS_EXPLORE, OP_CONCAT_SA, OP_SAC_TARGET, OP_DPG_ACTION, OP_DPG_TARGET, OP_FILL, OP_SLICE_ROWS, OP_MEAN_INFO, OP_TEMP_HEAD,
   OP_Q_HEAD, OP_TD_HEAD, OP_TD_INFO, OP_SUMSQ2, OP_CRITIC_INFO, OP_ACTOR_HEAD, OP_ACTOR_GRAD, OP_ROWSUM, OP_ACTOR_INFO, OP_ADAM_GATED,
-  OP_PER_SEARCH, OP_UNIFORM_IDS, OP_GATHER_RING_ALL, OP_RING_IDS, OP_LEAF_REFRESH, OP_TREE_TOUCH, OP_PER_UPDATE, OP_DQN_TARGET, OP_TD_ERROR, OP_POLYAK, OP_COPY_F32
+  OP_PER_SEARCH, OP_UNIFORM_IDS, OP_GATHER_RING_ALL, OP_RING_IDS, OP_LEAF_REFRESH, OP_TREE_TOUCH, OP_PER_UPDATE, OP_DQN_TARGET, OP_TD_ERROR, OP_POLYAK, OP_COPY_F32, OP_ADAM_ADVANCE
 };
 
 #define CRUX_EXEC_ARG_BYTES 432
@@ -47,7 +47,7 @@ struct ExecRec {
   void* d_ops = nullptr; size_t d_ops_cap = 0;                     // device copy of the op list
   unsigned* d_ctr = nullptr;                                       // device: barrier counter, abort flag
   void* h_stage = nullptr; size_t h_stage_cap = 0;                 // pinned staging of the op list and of the read-backs
-  size_t scratch_floor = 0;
+  size_t scratch_floor = 0, scratch_off = 0;                       // scratch requests made while recording are carved one after the other from the pre-sized block
 };
 bool crux_exec_recording(const crux_ctx* c);
 int32_t crux_exec_begin(crux_ctx* c);                 // start recording on this context (the launch sites below push ops instead of launching)

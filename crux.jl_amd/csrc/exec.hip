@@ -2,6 +2,7 @@
 // (offpolicy_unit.hip includes dense.hip, sac.hip, per.hip and this file, so that one translation unit sees every op body).
 #include "exec.h"
 #include "ops_small.h"
+#include <algorithm>
 
 #define EXEC_G 64                 // workgroups of the persistent launch, all on one XCD (32 CUs x 2)
 #define EXEC_SMALL_BYTES (256 * 1024)
@@ -10,73 +11,127 @@ int32_t crux_x2_placement_ok_c(crux_ctx* c);
 
 // ---- device: the interpreter ------------------------------------------------------------------------------------------------------------
 template <class Op> __device__ __forceinline__ void exec_dispatch(const ExecOp* op, unsigned bid) {
-  const OpPack<Op> p = *(const OpPack<Op>*)op->args;        // uniform address: scalar loads
-  exec_apply<Op>(bid, op->nblocks, p);
+  // the record sits in LDS (staged one op ahead by k_exec). Its words are moved to SCALAR registers (v_readfirstlane): arguments that arrive in vector
+  // registers turn every pointer computation and every uniform branch of the body into per-lane work (the tile GEMM ran 3x slower that way)
+  constexpr int NW = (int)((sizeof(OpPack<Op>) + 3) / 4);
+  uint32_t w[NW]; const uint32_t* src = (const uint32_t*)op->args;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) w[i] = __builtin_amdgcn_readfirstlane(src[i]);
+  OpPack<Op> p; __builtin_memcpy(&p, w, sizeof p);
+  exec_apply<Op>(bid, __builtin_amdgcn_readfirstlane(op->nblocks), p);
 }
 // Counter barrier between workgroups that sit behind ONE L2 (the learner kernels' exchange, tools/xcu_barrier_bench.hip): stores are write-through
 // to the L2, so s_waitcnt + one relaxed agent-scope atomic is the release; the acquire side drops this CU's L1 and scalar cache.
-__device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned target) {
+// Flag barrier between workgroups that sit behind ONE L2. Workgroup w publishes the phase number in ITS OWN word (plain store: the vector L1 is
+// write-through); one wave then polls all G words with a single coalesced L1-bypassing load per try. No atomics: G arrivals on one address are
+// serialised by the L2 (2.4 us per barrier with 64 workgroups, tools/dbg_nops.py). ctr[0..255] = arrival words, ctr[256] = abort flag.
+__device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigned G, unsigned phase, int flags) {
   __shared__ int ok_s;
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's stores are in the L2
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) { __hip_atomic_store(ctr + wg, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     unsigned spins = 0; int ok = 1;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) { __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 255u) == 0u && (spins > (1u << 23) || __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { ok = 0; break; } }   // never hang the GPU
-    if (!ok) __hip_atomic_store(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ok_s = ok;
+    for (;;) {
+      bool here = true;
+      for (unsigned q = threadIdx.x; q < G; q += 64) here = here && __hip_atomic_load(ctr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase;
+      if (__ballot(!here) == 0ull) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 255u) == 0u && (spins > (1u << 22) || __hip_atomic_load(ctr + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { ok = 0; break; }      // never hang the GPU
+    }
+    if (threadIdx.x == 0) { if (!ok) __hip_atomic_store(ctr + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok_s = ok; }
   }
   __syncthreads();
-  asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // acquire side: drop THIS CU's vector L1 (buffer_inv sc0, workgroup scope in the ISA's terms: the L2 behind it is shared by the whole XCD and needs nothing)
+  // and its scalar cache. The agent-scope form (sc1) also walks the L2 and cost 17 us per barrier with 64 workgroups (tools/dbg_nops.py)
+  if (!(flags & 1)) { if (flags & 4) asm volatile("buffer_inv sc1" ::: "memory"); else asm volatile("buffer_inv sc0" ::: "memory"); }
+  if (!(flags & 2)) asm volatile("s_dcache_inv" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   return ok_s != 0;
 }
-__global__ __launch_bounds__(256) void k_exec(const ExecOp* __restrict__ ops, int nops, unsigned* ctr, int xcd, int32_t* status) {
+#define EXEC_SWITCH(DISPATCH) \
+      switch (kid) { \
+        case OP_GEMM: DISPATCH<GemmOp>(op, b); break; \
+        case OP_ACT_GRAD: DISPATCH<ActGradOp>(op, b); break; \
+        case OP_GAUSS_EXPLORE: DISPATCH<GaussExploreOp>(op, b); break; \
+        case OP_CONCAT_SA: DISPATCH<ConcatSaOp>(op, b); break; \
+        case OP_SAC_TARGET: DISPATCH<SacTargetOp>(op, b); break; \
+        case OP_DPG_ACTION: DISPATCH<DpgActionOp>(op, b); break; \
+        case OP_DPG_TARGET: DISPATCH<DpgTargetOp>(op, b); break; \
+        case OP_FILL: DISPATCH<FillOp>(op, b); break; \
+        case OP_SLICE_ROWS: DISPATCH<SliceRowsOp>(op, b); break; \
+        case OP_MEAN_INFO: DISPATCH<MeanInfoOp>(op, b); break; \
+        case OP_TEMP_HEAD: DISPATCH<TempHeadOp>(op, b); break; \
+        case OP_Q_HEAD: DISPATCH<QHeadOp>(op, b); break; \
+        case OP_TD_HEAD: DISPATCH<TdHeadOp>(op, b); break; \
+        case OP_TD_INFO: DISPATCH<TdInfoOp>(op, b); break; \
+        case OP_SUMSQ2: DISPATCH<Sumsq2Op>(op, b); break; \
+        case OP_CRITIC_INFO: DISPATCH<CriticInfoOp>(op, b); break; \
+        case OP_ACTOR_HEAD: DISPATCH<ActorHeadOp>(op, b); break; \
+        case OP_ACTOR_GRAD: DISPATCH<ActorGradOp>(op, b); break; \
+        case OP_ROWSUM: DISPATCH<RowsumOp>(op, b); break; \
+        case OP_ACTOR_INFO: DISPATCH<ActorInfoOp>(op, b); break; \
+        case OP_ADAM_GATED: DISPATCH<AdamGatedOp>(op, b); break; \
+        case OP_PER_SEARCH: DISPATCH<PerSearchOp>(op, b); break; \
+        case OP_UNIFORM_IDS: DISPATCH<UniformIdsOp>(op, b); break; \
+        case OP_GATHER_RING_ALL: DISPATCH<GatherRingAllOp>(op, b); break; \
+        case OP_RING_IDS: DISPATCH<RingIdsOp>(op, b); break; \
+        case OP_LEAF_REFRESH: DISPATCH<LeafRefreshOp>(op, b); break; \
+        case OP_TREE_TOUCH: DISPATCH<TreeTouchOp>(op, b); break; \
+        case OP_PER_UPDATE: DISPATCH<PerUpdateOp>(op, b); break; \
+        case OP_DQN_TARGET: DISPATCH<DqnTargetOp>(op, b); break; \
+        case OP_TD_ERROR: DISPATCH<TdErrorOp>(op, b); break; \
+        case OP_POLYAK: DISPATCH<PolyakOp>(op, b); break; \
+        case OP_COPY_F32: DISPATCH<CopyF32Op>(op, b); break; \
+        case OP_ADAM_ADVANCE: DISPATCH<AdamAdvanceOp>(op, b); break; \
+        default: break; \
+      }
+
+// the same dispatch with the record read straight from global memory at a uniform address (scalar loads): the one-launch-per-phase form below
+template <class Op> __device__ __forceinline__ void exec_dispatch_g(const ExecOp* op, unsigned bid) {
+  const OpPack<Op> p = *(const OpPack<Op>*)op->args;
+  exec_apply<Op>(bid, op->nblocks, p);
+}
+// One PHASE of a recorded sequence as one launch over the whole chip: block x of the grid belongs to the op whose block range contains x. The ops of a
+// phase do not depend on each other, the dependency between phases is the kernel boundary -- no in-kernel barrier, no coherence question, all 256 CUs.
+// A fused epoch then costs (number of phases) launches instead of (number of kernels): 13 instead of 25 for a DQN epoch, ~35 instead of ~75 for SAC.
+__global__ __launch_bounds__(256) void k_phase(const ExecOp* __restrict__ ops, int n) {
+  unsigned b = blockIdx.x; int o = 0;
+  while (o + 1 < n && b >= ops[o].nblocks) { b -= ops[o].nblocks; ++o; }
+  const ExecOp* op = ops + o; const int kid = op->kid;
+  EXEC_SWITCH(exec_dispatch_g)
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_exec(const ExecOp* __restrict__ ops, int nops, unsigned* ctr, int xcd, int32_t* status, int flags) {
   if (xcd >= 0 && (int)(blockIdx.x & 7) != xcd) return;
   const unsigned wg = xcd >= 0 ? blockIdx.x >> 3 : blockIdx.x, G = xcd >= 0 ? gridDim.x >> 3 : gridDim.x;
-  unsigned phase = 0;
+  // op records are staged through LDS one op ahead: the 448-byte record of op o+1 is fetched while op o runs and its barrier is waited for, so
+  // dispatch reads its arguments from LDS instead of paying two dependent L2 round trips per op (1.5 us measured, tools/dbg_nops.py)
+  __shared__ ExecOp op_s[2];
+  constexpr int OPW = (int)(sizeof(ExecOp) / 4);
+  if ((int)threadIdx.x < OPW && nops > 0) ((uint32_t*)&op_s[0])[threadIdx.x] = ((const uint32_t*)&ops[0])[threadIdx.x];
+  __syncthreads();
+  unsigned phase = 0, off = 0;
   for (int o = 0; o < nops; ++o) {
-    const ExecOp* op = ops + o;
-    const int kid = op->kid; const unsigned nb = op->nblocks;
-    for (unsigned b = wg; b < nb; b += G) {
-      switch (kid) {
-        case OP_GEMM: exec_dispatch<GemmOp>(op, b); break;
-        case OP_ACT_GRAD: exec_dispatch<ActGradOp>(op, b); break;
-        case OP_GAUSS_EXPLORE: exec_dispatch<GaussExploreOp>(op, b); break;
-        case OP_CONCAT_SA: exec_dispatch<ConcatSaOp>(op, b); break;
-        case OP_SAC_TARGET: exec_dispatch<SacTargetOp>(op, b); break;
-        case OP_DPG_ACTION: exec_dispatch<DpgActionOp>(op, b); break;
-        case OP_DPG_TARGET: exec_dispatch<DpgTargetOp>(op, b); break;
-        case OP_FILL: exec_dispatch<FillOp>(op, b); break;
-        case OP_SLICE_ROWS: exec_dispatch<SliceRowsOp>(op, b); break;
-        case OP_MEAN_INFO: exec_dispatch<MeanInfoOp>(op, b); break;
-        case OP_TEMP_HEAD: exec_dispatch<TempHeadOp>(op, b); break;
-        case OP_Q_HEAD: exec_dispatch<QHeadOp>(op, b); break;
-        case OP_TD_HEAD: exec_dispatch<TdHeadOp>(op, b); break;
-        case OP_TD_INFO: exec_dispatch<TdInfoOp>(op, b); break;
-        case OP_SUMSQ2: exec_dispatch<Sumsq2Op>(op, b); break;
-        case OP_CRITIC_INFO: exec_dispatch<CriticInfoOp>(op, b); break;
-        case OP_ACTOR_HEAD: exec_dispatch<ActorHeadOp>(op, b); break;
-        case OP_ACTOR_GRAD: exec_dispatch<ActorGradOp>(op, b); break;
-        case OP_ROWSUM: exec_dispatch<RowsumOp>(op, b); break;
-        case OP_ACTOR_INFO: exec_dispatch<ActorInfoOp>(op, b); break;
-        case OP_ADAM_GATED: exec_dispatch<AdamGatedOp>(op, b); break;
-        case OP_PER_SEARCH: exec_dispatch<PerSearchOp>(op, b); break;
-        case OP_UNIFORM_IDS: exec_dispatch<UniformIdsOp>(op, b); break;
-        case OP_GATHER_RING_ALL: exec_dispatch<GatherRingAllOp>(op, b); break;
-        case OP_RING_IDS: exec_dispatch<RingIdsOp>(op, b); break;
-        case OP_LEAF_REFRESH: exec_dispatch<LeafRefreshOp>(op, b); break;
-        case OP_TREE_TOUCH: exec_dispatch<TreeTouchOp>(op, b); break;
-        case OP_PER_UPDATE: exec_dispatch<PerUpdateOp>(op, b); break;
-        case OP_DQN_TARGET: exec_dispatch<DqnTargetOp>(op, b); break;
-        case OP_TD_ERROR: exec_dispatch<TdErrorOp>(op, b); break;
-        case OP_POLYAK: exec_dispatch<PolyakOp>(op, b); break;
-        case OP_COPY_F32: exec_dispatch<CopyF32Op>(op, b); break;
-        default: break;
-      }
+    const ExecOp* op = &op_s[o & 1];
+    uint32_t nxt = 0;
+    if ((int)threadIdx.x < OPW && o + 1 < nops) nxt = ((const uint32_t*)&ops[o + 1])[threadIdx.x];
+    const int kid = __builtin_amdgcn_readfirstlane(op->kid); const unsigned nb = __builtin_amdgcn_readfirstlane(op->nblocks);
+    unsigned long long* tdbg = (unsigned long long*)(ctr + 1024);          // CRUX_EXEC_FLAGS & 8: per-op timestamps of workgroups 0 and 1 (s_memtime, 100 MHz)
+    if ((flags & 8) && wg < 2 && threadIdx.x == 0 && o < 512) tdbg[(wg * 512 + o) * 3 + 0] = __builtin_amdgcn_s_memtime();
+    // blocks are dealt to the workgroups round-robin over the whole PHASE (ops without a barrier between them), not per op: a phase made of a
+    // one-block op and two GEMMs then keeps 1 + 16 + 32 different workgroups busy instead of giving workgroup 0 a block of each
+    const unsigned b0 = (wg + G - off) % G;
+    for (unsigned b = b0; b < nb; b += G) {
+      EXEC_SWITCH(exec_dispatch)
       __syncthreads();                                   // the bodies' static LDS is reused by the next block / op of this workgroup
     }
-    if (op->barrier) { phase += 1; if (!exec_barrier(ctr, phase * G)) { if (threadIdx.x == 0 && wg == 0) status[0] = CRUX_EHIP; return; } }
+    const int bar = __builtin_amdgcn_readfirstlane(op->barrier);
+    if ((flags & 8) && wg < 2 && threadIdx.x == 0 && o < 512) tdbg[(wg * 512 + o) * 3 + 1] = __builtin_amdgcn_s_memtime();
+    if ((int)threadIdx.x < OPW && o + 1 < nops) ((uint32_t*)&op_s[(o + 1) & 1])[threadIdx.x] = nxt;
+    off = bar ? 0u : (off + nb) % G;
+    if (bar) { phase += 1; if (!exec_barrier(ctr, wg, G, phase, flags)) { if (threadIdx.x == 0 && wg == 0) status[0] = CRUX_EHIP; return; } }
+    else __syncthreads();
+    if ((flags & 8) && wg < 2 && threadIdx.x == 0 && o < 512) tdbg[(wg * 512 + o) * 3 + 2] = __builtin_amdgcn_s_memtime();
   }
 }
 
@@ -88,9 +143,9 @@ int32_t crux_exec_begin(crux_ctx* c) {
   ExecRec* r = rec_of(c);
   if (r->active) return crux_fail(c, CRUX_EINVAL, "executor: a recording is already open on this context");
   if (!r->small) { if (hipMalloc(&r->small, EXEC_SMALL_BYTES) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "executor: small region"); r->small_cap = EXEC_SMALL_BYTES; }
-  if (!r->d_ctr) { if (hipMalloc(&r->d_ctr, 256) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "executor: barrier counter"); }
+  if (!r->d_ctr) { if (hipMalloc(&r->d_ctr, 65536) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "executor: barrier counter"); }
   if (!crux_scratch(c, (size_t)32 << 20)) return crux_fail(c, CRUX_ENOMEM, "executor: scratch");     // pre-sized: the scratch block must not move while pointers into it are recorded
-  r->scratch_floor = c->scratch_bytes;
+  r->scratch_floor = c->scratch_bytes; r->scratch_off = 0;
   r->ops.clear(); r->readbacks.clear(); r->small_off = 0; r->active = true;
   return CRUX_OK;
 }
@@ -98,6 +153,11 @@ void crux_exec_abort(crux_ctx* c) { if (c->rec) { ExecRec* r = rec_of(c); r->act
 ExecOp* crux_exec_new_op(crux_ctx* c, int kid, unsigned nblocks) {
   ExecRec* r = rec_of(c); r->ops.emplace_back(); ExecOp* op = &r->ops.back();
   op->kid = kid; op->nblocks = nblocks; op->barrier = 1; op->pad = 0; return op;
+}
+void* crux_exec_scratch(crux_ctx* c, size_t bytes) {
+  ExecRec* r = rec_of(c); bytes = (bytes + 255) / 256 * 256;
+  if (r->scratch_off + bytes > r->scratch_floor) return nullptr;
+  void* p = (char*)c->scratch + r->scratch_off; r->scratch_off += bytes; return p;
 }
 void* crux_exec_small(crux_ctx* c, size_t bytes) {
   ExecRec* r = rec_of(c); bytes = (bytes + 255) / 256 * 256;
@@ -112,8 +172,18 @@ int32_t crux_exec_zero(crux_ctx* c, void* d_ptr, size_t bytes, hipStream_t st) {
   crux_exec_push<FillOp, OP_FILL>(c, (unsigned)((n + 255) / 256), (float*)d_ptr, 0.f, n);
   return CRUX_OK;
 }
-// ops i and i+1 .. may run in the same phase (no barrier between them) when the caller knows they are independent
-static void exec_no_barrier_before_last(crux_ctx* c, int count) { ExecRec* r = rec_of(c); const size_t n = r->ops.size(); for (int k = 0; k < count && (size_t)k + 2 <= n; ++k) r->ops[n - 2 - k].barrier = 0; }
+// Phases: ops that do not depend on each other share a barrier. The caller assigns every recorded op a phase number (non-decreasing along every
+// dependency chain); the list is stably sorted by phase and only the last op of a phase keeps its barrier.
+static size_t exec_mark(crux_ctx* c) { return rec_of(c)->ops.size(); }
+static int32_t exec_schedule(crux_ctx* c, const std::vector<int>& phase) {
+  ExecRec* r = rec_of(c); const size_t n = r->ops.size();
+  if (phase.size() != n) return crux_fail(c, CRUX_EHIP, "executor: %zu phase tags for %zu ops", phase.size(), n);
+  std::vector<size_t> idx(n); for (size_t i = 0; i < n; ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return phase[a] < phase[b]; });
+  std::vector<ExecOp> out(n);
+  for (size_t k = 0; k < n; ++k) { out[k] = r->ops[idx[k]]; out[k].barrier = (k + 1 == n || phase[idx[k + 1]] != phase[idx[k]]) ? 1 : 0; }
+  r->ops.swap(out); return CRUX_OK;
+}
 
 int32_t crux_exec_run(crux_ctx* c) {
   ExecRec* r = rec_of(c);
@@ -129,22 +199,35 @@ int32_t crux_exec_run(crux_ctx* c) {
     r->ops.back().barrier = 0;
     memcpy(r->h_stage, r->ops.data(), ob);
     HIPCHK(c, hipMemcpyAsync(r->d_ops, r->h_stage, ob, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(r->d_ctr, 0, 256, c->stream));
-    static const int one_xcd = getenv("CRUX_EXEC_CHIP") ? 0 : 1;
+    HIPCHK(c, hipMemsetAsync(r->d_ctr, 0, 2048, c->stream));
+    static const bool persistent = getenv("CRUX_EXEC_PERSISTENT") != nullptr;
+    if (!persistent) {
+      // default: one launch per phase over the whole chip (see k_phase). Measured against the persistent one-XCD form (CRUX_EXEC_PERSISTENT=1): the latter
+      // saves the launches but runs every op on 32 CUs behind one L2 and pays ~2 us per barrier; DESIGN 4.3 has the numbers.
+      size_t i0 = 0;
+      while (i0 < nops) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += r->ops[i1].nblocks; if (r->ops[i1].barrier || i1 + 1 == nops) break; ++i1; }
+        if (blocks) hipLaunchKernelGGL(k_phase, dim3(blocks), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops + i0, (int)(i1 - i0 + 1));
+        i0 = i1 + 1; }
+    } else {
     // the counter barrier relies on one shared L2: all workgroups on XCD 0 (workgroup i of a grid lands on XCD i mod 8, verified by the placement probe)
-    const int xcd = (one_xcd && crux_x2_placement_ok_c(c)) ? 0 : -2;
+    const int xcd = crux_x2_placement_ok_c(c) ? 0 : -2;
     if (xcd == -2) return crux_fail(c, CRUX_EUNSUP, "executor: workgroups are not placed round-robin over the XCDs on this device");
     static const int g_env = getenv("CRUX_EXEC_G") ? atoi(getenv("CRUX_EXEC_G")) : 0;
     const int G = (g_env >= 1 && g_env <= 128) ? g_env : EXEC_G;
-    hipLaunchKernelGGL(k_exec, dim3(G * 8), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops, (int)nops, r->d_ctr, xcd, (int32_t*)(r->d_ctr + 8));
+    hipLaunchKernelGGL(k_exec, dim3(G * 8), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops, (int)nops, r->d_ctr, xcd, (int32_t*)(r->d_ctr + 264), getenv("CRUX_EXEC_FLAGS") ? atoi(getenv("CRUX_EXEC_FLAGS")) : 0);
+    }
     rc = crux_launch_check(c, "k_exec"); if (rc) return rc;
     char* hb = (char*)r->h_stage + ob;
     for (size_t k = 0; k < r->readbacks.size(); ++k) { char* h = hb + k * (sizeof(float) * CRUX_INFO_N + 16);
       HIPCHK(c, hipMemcpyAsync(h, r->readbacks[k].d_info, sizeof(float) * CRUX_INFO_N, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipMemcpyAsync(h + sizeof(float) * CRUX_INFO_N, r->readbacks[k].d_status, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream)); }
     int32_t* hst = (int32_t*)(hb + rb);
-    HIPCHK(c, hipMemcpyAsync(hst, r->d_ctr + 8, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hst, r->d_ctr + 264, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (getenv("CRUX_EXEC_FLAGS") && (atoi(getenv("CRUX_EXEC_FLAGS")) & 8)) { static int shown = 0; if (shown++ == 3) {
+        std::vector<unsigned long long> tt(2 * 512 * 3); (void)hipMemcpy(tt.data(), r->d_ctr + 1024, tt.size() * 8, hipMemcpyDeviceToHost);
+        for (size_t o = 0; o < nops && o < 512; ++o) fprintf(stderr, "[exec-t] op %2zu kid %2d blocks %3u bar %d | wg0 body %6.2f us barrier %6.2f us | wg1 body %6.2f barrier %6.2f\n", o, r->ops[o].kid, r->ops[o].nblocks, r->ops[o].barrier,
+          (tt[o * 3 + 1] - tt[o * 3]) / 100.0, (tt[o * 3 + 2] - tt[o * 3 + 1]) / 100.0, (tt[(512 + o) * 3 + 1] - tt[(512 + o) * 3]) / 100.0, (tt[(512 + o) * 3 + 2] - tt[(512 + o) * 3 + 1]) / 100.0); } }
     if (*hst) return crux_fail(c, *hst, "executor: the fused launch reported status %d (a workgroup did not reach a barrier)", *hst);
     for (size_t k = 0; k < r->readbacks.size(); ++k) { const char* h = hb + k * (sizeof(float) * CRUX_INFO_N + 16);
       if (r->readbacks[k].host_info) memcpy(r->readbacks[k].host_info, h, sizeof(float) * CRUX_INFO_N);
@@ -189,15 +272,38 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
     if (eager_mask & bit) { if (crux_exec_recording(c)) return crux_exec_run(c); return CRUX_OK; }
     if (!crux_exec_recording(c)) return crux_exec_begin(c); return CRUX_OK; };
   auto bail = [&](int32_t e) { if (fuse) crux_exec_abort(c); return e; };
+  // Phase plan of the fused epoch (L = number of Dense layers): the target network's forward chain runs beside the online network's, the replay
+  // bookkeeping beside the backward chain.    0 search | 1 gather, ring ids, zero-fill | 2+k forward layer k (both nets; + push! priorities of the batch)
+  //   2+L dqn_target | 3+L td head | 4+L+j backward of layer L-1-j (weight + data gradient; + update_priorities!, leaf re-sum, root paths) | then norm, info, Adam
+  std::vector<int> ph; bool plan_ok = true; const int Ld = net->nd.L;
+  auto tag = [&](size_t from, auto&& rule) { if (!fuse || !crux_exec_recording(c)) return; ExecRec* r = rec_of(c); int g = 0;
+    for (size_t i = from; i < r->ops.size(); ++i) { const int p = rule(r->ops[i].kid, g); if (p < 0) plan_ok = false; ph.push_back(p < 0 ? 0 : p); } };
   rc = piece(1); if (rc) return bail(rc);
+  size_t m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
   rc = per ? crux_per_sample(batch, source, B, nullptr, beta, sample_counter) : crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
+  tag(m, [&](int kid, int&) { return (kid == OP_PER_SEARCH || kid == OP_UNIFORM_IDS) ? 0 : (kid == OP_GATHER_RING_ALL || kid == OP_RING_IDS || kid == OP_COPY_F32) ? 1 : kid == OP_PER_UPDATE ? 2 : -1; });
   rc = piece(2); if (rc) return bail(rc);
+  m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
   rc = crux_dqn_target(target_net, batch, gamma, d_y); if (rc) return bail(rc);
+  tag(m, [&](int kid, int& g) { return kid == OP_GEMM ? (g < Ld ? 2 + g++ : -1) : kid == OP_DQN_TARGET ? 2 + Ld : -1; });
   rc = piece(4); if (rc) return bail(rc);
+  m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
+  auto td_rule = [&](int kid, int& g) {      // g counts the GEMMs: Ld forward, then (weight, data) pairs from the last layer down, the first layer has no data gradient
+    if (kid == OP_FILL) return 1;
+    if (kid == OP_GEMM) { const int k = g++; if (k < Ld) return 2 + k; const int j = (k - Ld) / 2; return j < Ld ? 4 + Ld + j : -1; }
+    if (kid == OP_TD_HEAD) return 3 + Ld;
+    if (kid == OP_SUMSQ2) return 4 + 2 * Ld; if (kid == OP_TD_INFO || kid == OP_ADAM_GATED) return 5 + 2 * Ld; if (kid == OP_ADAM_ADVANCE) return 6 + 2 * Ld;
+    return -1; };
   if (per) { rc = crux_td_step_with_error(net, batch, d_y, use_weight, d_err, info_out); if (rc) return bail(rc);
+    tag(m, td_rule);
     rc = piece(8); if (rc) return bail(rc);
-    rc = crux_per_update_device(source, batch->d_indices, d_err, B); if (rc) return bail(rc); }
-  else { rc = crux_td_step(net, batch, d_y, use_weight, info_out); if (rc) return bail(rc); }
+    m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
+    rc = crux_per_update_device(source, batch->d_indices, d_err, B); if (rc) return bail(rc);
+    tag(m, [&](int kid, int&) { return kid == OP_PER_UPDATE ? 4 + Ld : kid == OP_LEAF_REFRESH ? 5 + Ld : kid == OP_TREE_TOUCH ? 6 + Ld : -1; }); }
+  else { rc = crux_td_step(net, batch, d_y, use_weight, info_out); if (rc) return bail(rc); tag(m, td_rule); }
+  if (fuse && crux_exec_recording(c) && plan_ok && !eager_mask && !getenv("CRUX_EXEC_NO_PHASES") && target_net->nd.L == Ld && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
+  if (fuse && getenv("CRUX_EXEC_VERBOSE")) { ExecRec* r = rec_of(c); int nbar = 0; for (auto& o : r->ops) nbar += o.barrier; fprintf(stderr, "[exec] dqn_epoch: %zu ops, %d barriers, plan_ok=%d tags=%zu\n", r->ops.size(), nbar, (int)plan_ok, ph.size());
+    for (auto& o : r->ops) fprintf(stderr, "   kid %d blocks %u barrier %d\n", o.kid, o.nblocks, o.barrier); }
   return (fuse && crux_exec_recording(c)) ? crux_exec_run(c) : CRUX_OK;
 }
 
@@ -222,16 +328,51 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
       c->epoch_tmp_bytes = 16 * (size_t)B + 4096; if (hipMalloc(&c->epoch_tmp, c->epoch_tmp_bytes) != hipSuccess) { c->epoch_tmp = nullptr; c->epoch_tmp_bytes = 0; return crux_fail(c, CRUX_ENOMEM, "sac_epoch: targets"); } }
     d_y = (float*)c->epoch_tmp; }
   auto bail = [&](int32_t e) { if (fuse) crux_exec_abort(c); return e; };
+  // Phase plan (LA = layers of the actor, LQ = of a critic; X = 3 + LA + LQ, Y = X + 4 + LQ). Chains that touch different networks run side by side:
+  //   0 ids | 1 gather, zero-fills | 2.. actor(sp) forward ; vcat(s, a) ; Q1 || Q2 forward on (s, a) | 2+LA exploration at sp | 3+LA.. target Q1 || Q2 ; actor(s) forward
+  //   X sac_target ; exploration at s | X+1 critic heads ; temperature head | X+2.. critic backward (weight || data gradient, both critics) ; Adam(log_alpha) | .. norm | info, Adam(Q1), Adam(Q2)
+  //   Y.. actor(s) forward | exploration | Q1 || Q2 forward | actor head | Q1 || Q2 input gradients | reverse of exploration | actor backward ; logSigma row sums | norm | info, Adam | polyak
+  // The order inside every chain is the reference's (temperature before critic before actor: each sees the parameters the previous step left).
+  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, X = 3 + LA + LQ, Y = X + 4 + LQ;
+  if (LA != LQ || q2->nd.L != LQ || q1_targ->nd.L != LQ || q2_targ->nd.L != LQ) plan_ok = false;
+  auto tag = [&](size_t from, auto&& rule) { if (!fuse) return; ExecRec* r = rec_of(c); int g = 0;
+    for (size_t i = from; i < r->ops.size(); ++i) { const int p = rule(r->ops[i].kid, g); if (p < 0) plan_ok = false; ph.push_back(p < 0 ? 0 : p); } };
+  size_t m = fuse ? exec_mark(c) : 0;
   rc = crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
+  tag(m, [&](int kid, int&) { return kid == OP_UNIFORM_IDS ? 0 : kid == OP_GATHER_RING_ALL ? 1 : -1; });
+  m = fuse ? exec_mark(c) : 0;
   rc = crux_sac_target(actor, q1_targ, q2_targ, log_alpha, batch, gamma, noise_seed, noise_counter0, d_y); if (rc) return bail(rc);
+  tag(m, [&](int kid, int& g) { if (kid == OP_GEMM) { const int k = g++; return k < LA ? 2 + k : 3 + LA + (k - LA) % LQ; }
+    return kid == OP_GAUSS_EXPLORE ? 2 + LA : kid == OP_SAC_TARGET ? X : -1; });
+  m = fuse ? exec_mark(c) : 0;
   rc = crux_sac_temp_step(actor, log_alpha, batch, H_target, noise_seed, noise_counter0 + 1, info_temp); if (rc) return bail(rc);
-  if (update_critic) { rc = crux_double_q_step(q1, q2, batch, d_y, use_weight, info_critic); if (rc) return bail(rc); }
+  tag(m, [&](int kid, int& g) { if (kid == OP_FILL) return 1; if (kid == OP_GEMM) { const int k = g++; return k < LA ? 3 + LA + k : -1; }
+    return kid == OP_GAUSS_EXPLORE ? X : kid == OP_TEMP_HEAD ? X + 1 : kid == OP_ADAM_GATED ? X + 2 : kid == OP_ADAM_ADVANCE ? X + 3 : -1; });
+  if (update_critic) {
+    m = fuse ? exec_mark(c) : 0;
+    rc = crux_double_q_step(q1, q2, batch, d_y, use_weight, info_critic); if (rc) return bail(rc);
+    tag(m, [&](int kid, int& g) {      // per critic: LQ forward GEMMs, head, then (weight, data) pairs from the last layer down (the first layer has no data gradient)
+      if (kid == OP_FILL) return 1; if (kid == OP_CONCAT_SA) return 2;
+      if (kid == OP_GEMM) { const int k = (g++) % (3 * LQ - 1); return k < LQ ? 3 + k : X + 2 + (k - LQ) / 2; }
+      return kid == OP_Q_HEAD ? X + 1 : kid == OP_SUMSQ2 ? X + 2 + LQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 + LQ : kid == OP_ADAM_ADVANCE ? X + 4 + LQ : -1; });
+  }
   if (update_actor) {
+    m = fuse ? exec_mark(c) : 0;
     rc = crux_sac_actor_step(actor, q1, q2, log_alpha, batch, noise_seed, noise_counter0 + 2, info_actor); if (rc) return bail(rc);
+    tag(m, [&](int kid, int& g) {      // GEMMs: LA actor forward, LQ + LQ critic forwards, LQ + LQ critic input gradients, then the actor's (weight, data) pairs
+      if (kid == OP_FILL) return 1;
+      if (kid == OP_GEMM) { const int k = g++; if (k < LA) return Y + k; if (k < LA + 2 * LQ) return Y + LA + 1 + (k - LA) % LQ;
+        if (k < LA + 4 * LQ) return Y + LA + 2 + LQ + (k - LA - 2 * LQ) % LQ; return Y + LA + 3 + 2 * LQ + (k - LA - 4 * LQ) / 2; }
+      return kid == OP_GAUSS_EXPLORE ? Y + LA : kid == OP_ACTOR_HEAD ? Y + LA + 1 + LQ : kid == OP_ACTOR_GRAD ? Y + LA + 2 + 2 * LQ : kid == OP_ROWSUM ? Y + LA + 3 + 2 * LQ :
+             kid == OP_SUMSQ2 ? Y + 2 * LA + 3 + 2 * LQ : (kid == OP_ACTOR_INFO || kid == OP_ADAM_GATED) ? Y + 2 * LA + 4 + 2 * LQ : kid == OP_ADAM_ADVANCE ? Y + 2 * LA + 5 + 2 * LQ : -1; });
+    m = fuse ? exec_mark(c) : 0;
     if (actor_targ) { rc = crux_polyak(actor_targ, actor, tau); if (rc) return bail(rc); }
     rc = crux_polyak(q1_targ, q1, tau); if (rc) return bail(rc);
     rc = crux_polyak(q2_targ, q2, tau); if (rc) return bail(rc);
+    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + 2 * LA + 5 + 2 * LQ : -1; });
   }
+  if (fuse && plan_ok && !getenv("CRUX_EXEC_NO_PHASES") && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
+  if (fuse && getenv("CRUX_EXEC_VERBOSE")) { ExecRec* r = rec_of(c); int nbar = 0; for (auto& o : r->ops) nbar += o.barrier; fprintf(stderr, "[exec] sac_epoch: %zu ops, %d phases, plan_ok=%d\n", r->ops.size(), nbar, (int)plan_ok); }
   return fuse ? crux_exec_run(c) : CRUX_OK;
 }
 }  // extern "C"
@@ -246,4 +387,18 @@ extern "C" int32_t crux_debug_exec_forward(crux_mlp* net, const float* d_x, int6
   HIPCHK(c, hipMemcpyAsync(d_y, crux_dense_act(net, net->nd.L), sizeof(float) * (size_t)net->nd.dims[net->nd.L] * (size_t)B, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return CRUX_OK;
+}
+
+// test hook: n dependent trivial ops (a 256-float fill each): the executor's per-op overhead (dispatch + barrier)
+extern "C" int32_t crux_debug_exec_nops(crux_ctx* c, int32_t n, int32_t blocks) {
+  int32_t rc = crux_exec_begin(c); if (rc) return rc;
+  float* p = (float*)crux_exec_small(c, 4 * 256 * (size_t)(blocks > 0 ? blocks : 1));
+  for (int k = 0; k < n; ++k) crux_exec_push<FillOp, OP_FILL>(c, (unsigned)(blocks > 0 ? blocks : 1), p, (float)k, (int64_t)256 * (blocks > 0 ? blocks : 1));
+  return crux_exec_run(c);
+}
+// test hook: the forward pass of `net` recorded `reps` times (dependent ops): per-op cost of the tile GEMM inside the executor
+extern "C" int32_t crux_debug_exec_forward_reps(crux_mlp* net, const float* d_x, int64_t B, int32_t reps) {
+  crux_ctx* c = net->ctx; int32_t rc = crux_exec_begin(c); if (rc) return rc;
+  for (int k = 0; k < reps; ++k) { rc = crux_dense_forward(net, d_x, B, c->stream); if (rc) { crux_exec_abort(c); return rc; } }
+  return crux_exec_run(c);
 }

@@ -167,17 +167,25 @@ __global__ __launch_bounds__(LEAF_BLK) void k_leaf_scan(const float* __restrict_
 // update_priorities! touched element ids[j]: re-sum its leaf (running sums + total). One 64-lane block per touched element; duplicates write identical values.
 struct LeafRefreshOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of,
                                                       const int32_t* __restrict__ nstart, const int32_t* __restrict__ nlen, float* __restrict__ run, float* __restrict__ total) {
-  __shared__ float sm[LEAF_MAX + 1];
-  const int64_t e = ids[bid_];
-  if (e == 0) { if (threadIdx.x == 0) run[0] = v[0]; return; }       // element 1 of the reference is the seed s_ = v[1], outside the tree
+  // one WAVE per touched element (4 per 256-thread block): lane l holds v[o + l] and v[o + 64 + l]; the running sum s_ = s_ + v[i] is inherently serial, so
+  // it walks the lanes with v_readlane (a few cycles per element) instead of a chain of dependent LDS reads, and lane i keeps the i-th running sum
+  const int lane = threadIdx.x & 63; const int64_t q = (int64_t)bid_ * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (q >= n) return;
+  const int64_t e = ids[q];
+  if (e == 0) { if (lane == 0) run[0] = v[0]; return; }       // element 1 of the reference is the seed s_ = v[1], outside the tree
   const int node = leaf_of[e], o = nstart[node], len = nlen[node];
-  for (int i = threadIdx.x; i < len; i += (int)blockDim.x) sm[i] = v[o + i];
-  __syncthreads();
-  if (threadIdx.x == 0) { float s_ = sm[0]; for (int i = 1; i < len; ++i) { s_ = s_ + sm[i]; sm[i] = s_; } total[node] = s_; }
-  __syncthreads();
-  for (int i = threadIdx.x; i < len; i += (int)blockDim.x) run[o + i] = sm[i];
+  const float x0 = lane < len ? v[o + lane] : 0.f, x1 = 64 + lane < len ? v[o + 64 + lane] : 0.f;
+  float s_ = 0.f, r0 = 0.f, r1 = 0.f;
+  for (int i = 0; i < len; ++i) {
+    const float xi = __builtin_bit_cast(float, i < 64 ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, x0), i) : __builtin_amdgcn_readlane(__builtin_bit_cast(int, x1), i - 64));   // v_readlane (a __shfl here becomes an LDS-crossbar ds_bpermute: ~120 cycles per element)
+    s_ = i == 0 ? xi : s_ + xi;
+    if (i < 64) { if (lane == i) r0 = s_; } else { if (lane == i - 64) r1 = s_; }
+  }
+  if (lane < len) run[o + lane] = r0;
+  if (64 + lane < len) run[o + 64 + lane] = r1;
+  if (lane == 0) total[node] = s_;
 } };
-__global__ __launch_bounds__(64) void k_leaf_refresh(const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of,
+__global__ __launch_bounds__(256) void k_leaf_refresh(const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of,
                                                       const int32_t* __restrict__ nstart, const int32_t* __restrict__ nlen, float* __restrict__ run, float* __restrict__ total) { LeafRefreshOp::run(blockIdx.x, gridDim.x, v, ids, n, leaf_of, nstart, nlen, run, total); }
 // After k_leaf_refresh: node totals along the touched leaves' root paths, bottom-up level by level (s_ = rec(left); s_ += rec(right)). One workgroup;
 // thread q follows touched element q. Nodes shared by several paths are written by several threads with the same value.
@@ -295,13 +303,17 @@ __global__ void k_gather_ring(T* __restrict__ dst, const T* __restrict__ src, co
 // all columns of the sampled rows in ONE launch: a table of (dst, src, elements per row, element size) and the prefix of row widths
 struct GatherCols { void* dst[CRUX_NCOLS]; const void* src[CRUX_NCOLS]; int32_t re[CRUX_NCOLS]; int32_t esz[CRUX_NCOLS]; int32_t pre[CRUX_NCOLS + 1]; int32_t n; };
 struct GatherRingAllOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, GatherCols g, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) {
-  const int32_t width = g.pre[g.n]; const int64_t total = n * width;
+  // the column table is indexed per element: held in LDS (a by-value struct indexed at run time lives in scratch memory: 8 us for an 11-block gather)
+  __shared__ GatherCols gs;
+  { const uint32_t* src = (const uint32_t*)&g; uint32_t* dst = (uint32_t*)&gs; for (int i = threadIdx.x; i < (int)(sizeof(GatherCols) / 4); i += blockDim.x) dst[i] = src[i]; }
+  __syncthreads();
+  const int32_t width = gs.pre[gs.n]; const int64_t total = n * width; const int ncol = gs.n;
   for (int64_t t = (int64_t)bid_ * blockDim.x + threadIdx.x; t < total; t += (int64_t)nb_ * blockDim.x) {
     const int64_t j = t / width; const int32_t w = (int32_t)(t - j * width);
-    int k = 0; while (k + 1 < g.n && w >= g.pre[k + 1]) ++k;
-    const int32_t e = w - g.pre[k]; const int64_t d = ((base + j) % C) * g.re[k] + e, sidx = ids[j] * g.re[k] + e;
-    if (g.esz[k] == 4) ((uint32_t*)g.dst[k])[d] = ((const uint32_t*)g.src[k])[sidx];
-    else ((uint8_t*)g.dst[k])[d] = ((const uint8_t*)g.src[k])[sidx];
+    int k = 0; while (k + 1 < ncol && w >= gs.pre[k + 1]) ++k;
+    const int32_t e = w - gs.pre[k]; const int64_t d = ((base + j) % C) * gs.re[k] + e, sidx = ids[j] * gs.re[k] + e;
+    if (gs.esz[k] == 4) ((uint32_t*)gs.dst[k])[d] = ((const uint32_t*)gs.src[k])[sidx];
+    else ((uint8_t*)gs.dst[k])[d] = ((const uint8_t*)gs.src[k])[sidx];
   }
 } };
 __global__ void k_gather_ring_all(GatherCols g, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) { GatherRingAllOp::run(blockIdx.x, gridDim.x, g, ids, n, base, C); }
@@ -347,7 +359,7 @@ int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool f
   if (from_push && b->elements < b->capacity) { b->per_full_dirty = true; return CRUX_OK; }   // the ring is still growing: the rows may lie beyond the current tree
   if (b->per_full_dirty || b->topo_n < 2 || b->per_run_n != b->topo_n || b->topo_n != b->elements || n > 4096 || !d_ids) { b->per_full_dirty = true; return CRUX_OK; }
   if (b->topo_levels > CRUX_PER_PMAX) { b->per_full_dirty = true; return CRUX_OK; }
-  CRUX_RUN(b->ctx, LeafRefreshOp, OP_LEAF_REFRESH, k_leaf_refresh, (unsigned)n, 64, b->ctx->stream, b->priorities, d_ids, n, b->topo_leaf_of, b->topo_node_start, b->topo_node_len, b->cumsum, b->topo_total);
+  CRUX_RUN(b->ctx, LeafRefreshOp, OP_LEAF_REFRESH, k_leaf_refresh, (unsigned)((n + 3) / 4), 256, b->ctx->stream, b->priorities, d_ids, n, b->topo_leaf_of, b->topo_node_start, b->topo_node_len, b->cumsum, b->topo_total);
   CRUX_RUN(b->ctx, TreeTouchOp, OP_TREE_TOUCH, k_tree_touch, 1, 1024, b->ctx->stream, d_ids, n, b->topo_leaf_of, b->topo_anc, b->topo_depth, b->topo_left, b->topo_right, b->topo_levels, b->topo_total);
   return crux_launch_check(b->ctx, "k_leaf_refresh");
 }

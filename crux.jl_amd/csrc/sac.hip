@@ -201,23 +201,31 @@ struct ActorInfoOp { static __device__ __forceinline__ void run(const unsigned b
 __global__ void k_actor_info(const double* __restrict__ st, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) { ActorInfoOp::run(blockIdx.x, gridDim.x, st, ssq, B, dinfo); }
 // Flux.update!(Adam) gated on the gradient norm: NaN => parameters untouched, status set (training.jl:20)
 struct AdamGatedOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, double* __restrict__ bp,
-                                                    double eta, double b1, double b2, double eps, int64_t n, const double* __restrict__ ssq, int32_t* __restrict__ status) {
-  const int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x;
-  if (isnan(ssq[0])) { if (i == 0) status[0] = CRUX_ENAN; return; }
-  if (i < n) {
+                                                    double eta, double b1, double b2, double eps, int64_t n, const double* __restrict__ ssq, int32_t* __restrict__ status, int advance, int from_partials) {
+  // from_partials (fused executor): the 64 partials of k_sumsq2 are added here, in the order ssq_finalize adds them, so that the info op -- which writes ssq[0] --
+  // can share this op's phase instead of preceding it by a barrier
+  double sq;
+  if (!from_partials) sq = ssq[0]; else { sq = 0; for (int k = 0; k < SUMSQ_BLOCKS; ++k) sq += ssq[1 + k]; }
+  if (isnan(sq)) { if (bid_ == 0 && threadIdx.x == 0) status[0] = CRUX_ENAN; return; }
+  const double c1 = 1.0 - bp[0], c2 = 1.0 - bp[1];
+  for (int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x; i < n; i += (int64_t)nb_ * blockDim.x) {     // element-wise: any grid gives the same result
     const double gd = (double)g[i];
     const float mi = (float)(b1 * (double)m[i] + (1.0 - b1) * gd);
     const float vi = (float)(b2 * (double)v[i] + ((1.0 - b2) * gd) * gd);
-    const float d = (float)((double)mi / (1.0 - bp[0]) / (sqrt((double)vi / (1.0 - bp[1])) + eps) * eta);
+    const float d = (float)((double)mi / c1 / (sqrt((double)vi / c2) + eps) * eta);
     m[i] = mi; v[i] = vi; p[i] = p[i] - d;
   }
+  if (!advance) return;      // the fused executor advances the beta powers with AdamAdvanceOp in the next phase instead
   // the beta powers advance once every block has used them: the last block to FINISH (ticket in bp[2]) does it -- no second launch
   __syncthreads();
   if (threadIdx.x == 0) { __threadfence(); unsigned* ticket = (unsigned*)(bp + 2);
     if (atomicAdd(ticket, 1u) == nb_ - 1) { bp[0] *= b1; bp[1] *= b2; *ticket = 0u; } }
 } };
 __global__ __launch_bounds__(256) void k_adam_gated(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, double* __restrict__ bp,
-                                                    double eta, double b1, double b2, double eps, int64_t n, const double* __restrict__ ssq, int32_t* __restrict__ status) { AdamGatedOp::run(blockIdx.x, gridDim.x, p, g, m, v, bp, eta, b1, b2, eps, n, ssq, status); }
+                                                    double eta, double b1, double b2, double eps, int64_t n, const double* __restrict__ ssq, int32_t* __restrict__ status, int advance, int from_partials) { AdamGatedOp::run(blockIdx.x, gridDim.x, p, g, m, v, bp, eta, b1, b2, eps, n, ssq, status, advance, from_partials); }
+struct AdamAdvanceOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, double* __restrict__ bp, double b1, double b2, const double* __restrict__ ssq) {
+  if (bid_ == 0 && threadIdx.x == 0 && !isnan(ssq[0])) { bp[0] *= b1; bp[1] *= b2; }      // ssq[0] was written by the info op one phase earlier
+} };
 
 // ---- OnPolicyGAIL pieces (src/model_free/il/on_policy_gail.jl:1-5,49-54; src/extras/gans.jl:7-9) ---------------------------------------
 // vcat(a, s) of buffer rows [off, off + n): the ACTION first (D(x, y) convention, on_policy_gail.jl:50); one-hot Bool actions become 0/1
@@ -253,11 +261,18 @@ struct GailRewardOp { static __device__ __forceinline__ void run(const unsigned 
 } };
 __global__ __launch_bounds__(256) void k_gail_reward(const float* __restrict__ z, int64_t n, float alpha_r, float rscale, float* __restrict__ r, double* __restrict__ partial) { GailRewardOp::run(blockIdx.x, gridDim.x, z, n, alpha_r, rscale, r, partial); }
 
-static int32_t adam_gated(crux_mlp* n, const double* d_ssq, int32_t* d_status) {
+// partials: the squared norm arrives as k_sumsq2's per-block partials in d_ssq[1..] (finalised by the info op into d_ssq[0]); false: d_ssq[0] was written directly
+static int32_t adam_gated(crux_mlp* n, const double* d_ssq, int32_t* d_status, bool partials = true) {
   crux_ctx* c = n->ctx;
   if (!n->has_adam) return crux_fail(c, CRUX_EINVAL, "train!: crux_adam_init was not called on this handle");
   const int64_t cnt = n->nd.n_params;
-  CRUX_RUN(c, AdamGatedOp, OP_ADAM_GATED, k_adam_gated, (unsigned)((cnt + 255) / 256), 256, c->stream, n->p, n->g, n->m, n->v, n->bp, n->eta, n->b1, n->b2, n->eps, cnt, d_ssq, d_status);
+  if (crux_exec_recording(c)) {      // fused sequence: at most one round of blocks, beta powers advanced by a one-thread op of the next phase (no device-scope fence per block)
+    const unsigned nbk = (unsigned)((cnt + 255) / 256);
+    crux_exec_push<AdamGatedOp, OP_ADAM_GATED>(c, nbk < 64u ? nbk : 64u, n->p, (const float*)n->g, n->m, n->v, n->bp, n->eta, n->b1, n->b2, n->eps, cnt, d_ssq, d_status, 0, partials ? 1 : 0);
+    crux_exec_push<AdamAdvanceOp, OP_ADAM_ADVANCE>(c, 1u, n->bp, n->b1, n->b2, d_ssq);
+    return CRUX_OK;
+  }
+  CRUX_RUN(c, AdamGatedOp, OP_ADAM_GATED, k_adam_gated, (unsigned)((cnt + 255) / 256), 256, c->stream, n->p, n->g, n->m, n->v, n->bp, n->eta, n->b1, n->b2, n->eps, cnt, d_ssq, d_status, 1, 0);
   return crux_launch_check(c, "k_adam_gated");
 }
 
@@ -343,7 +358,7 @@ int32_t crux_sac_temp_step(crux_mlp* actor, crux_mlp* la, crux_buffer* b, float 
   CRUX_RUN(c, GaussExploreOp, OP_GAUSS_EXPLORE, k_gauss_explore, nblk(B), 256, c->stream, crux_dense_act(actor, actor->nd.L), actor->p + actor->nd.xoff, S, od, ad, B, seed, counter, (float*)nullptr, lp, (float*)nullptr);
   { const int32_t rz = crux_exec_zero(c, la->g, sizeof(float) * (size_t)la->nd.n_params, c->stream); if (rz) return rz; }
   CRUX_RUN(c, TempHeadOp, OP_TEMP_HEAD, k_temp_head, 1, 256, c->stream, lp, B, H_target, la->p, la->g, dinfo, ssq);
-  rc = adam_gated(la, ssq, st); if (rc) return rc;
+  rc = adam_gated(la, ssq, st, false); if (rc) return rc;
   return finish_step(c, dinfo, st, info_out, "sac_temp_loss");
 }
 
@@ -351,8 +366,9 @@ static int32_t q_step_impl(crux_mlp* q1, crux_mlp* q2, crux_buffer* b, const flo
   crux_ctx* c = q1->ctx; int32_t rc = check_sac(c, nullptr, q1, q2, nullptr, b, who); if (rc) return rc;
   if (use_weight && !has_col(b, CRUX_COL_WEIGHT)) return crux_fail(c, CRUX_EINVAL, "%s(weight=:weight): batch has no :weight column", who);
   const int64_t B = b->elements; const int od = b->obs_dim, ad = b->act_dim; const int nq = q2 ? 2 : 1;
-  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (od + ad + 1) + 8192), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "%s: scratch", who);
-  float* sa = cv.take<float>((size_t)B * (od + ad)); float* dy = cv.take<float>((size_t)B); Carve sv = small_carve(c, cv, 256 * 7); if (!sv.p) return crux_fail(c, CRUX_ENOMEM, "%s: executor region", who);
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (od + ad + 2) + 8192), 0}; if (!cv.p) return crux_fail(c, CRUX_ENOMEM, "%s: scratch", who);
+  float* sa = cv.take<float>((size_t)B * (od + ad)); float* dys[2] = {cv.take<float>((size_t)B), cv.take<float>((size_t)B)};      // one dL/dQ per critic: the two chains may run side by side (exec.hip)
+  Carve sv = small_carve(c, cv, 256 * 7); if (!sv.p) return crux_fail(c, CRUX_ENOMEM, "%s: executor region", who);
   float* dinfo = sv.take<float>(CRUX_INFO_N);
   double* st1 = sv.take<double>(2); double* st2 = sv.take<double>(2); double* ssq = sv.take<double>(2 + SUMSQ_BLOCKS); int32_t* st = sv.take<int32_t>(1);
   { const int32_t rz = crux_exec_zero(c, dinfo, 256 * 7, c->stream); if (rz) return rz; }
@@ -361,8 +377,8 @@ static int32_t q_step_impl(crux_mlp* q1, crux_mlp* q2, crux_buffer* b, const flo
   crux_mlp* qs[2] = {q1, q2}; double* sts[2] = {st1, st2};
   for (int t = 0; t < nq; ++t) {
     rc = crux_dense_forward(qs[t], sa, B, c->stream); if (rc) return rc;
-    CRUX_RUN(c, QHeadOp, OP_Q_HEAD, k_q_head, 1, 256, c->stream, crux_dense_act(qs[t], qs[t]->nd.L), d_y, w, B, nq == 2 ? 0.5f : 1.0f, dy, sts[t]);
-    rc = crux_dense_backward(qs[t], sa, B, dy, 1.0f, true, nullptr, c->stream); if (rc) return rc;
+    CRUX_RUN(c, QHeadOp, OP_Q_HEAD, k_q_head, 1, 256, c->stream, crux_dense_act(qs[t], qs[t]->nd.L), d_y, w, B, nq == 2 ? 0.5f : 1.0f, dys[t], sts[t]);
+    rc = crux_dense_backward(qs[t], sa, B, dys[t], 1.0f, true, nullptr, c->stream); if (rc) return rc;
   }
   CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, q1->g, (int64_t)q1->nd.n_params, q2 ? q2->g : (const float*)nullptr, (int64_t)(q2 ? q2->nd.n_params : 0), ssq);
   CRUX_RUN(c, CriticInfoOp, OP_CRITIC_INFO, k_critic_info, 1, 1, c->stream, st1, nq == 2 ? st2 : st1, ssq, B, dinfo);   // single Q: 0.5 l + 0.5 l = l
