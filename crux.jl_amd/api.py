@@ -1553,6 +1553,32 @@ def value_training(solver, D, gamma):
     return {k: float(np.mean([d[k] for d in infos])) for k in infos[0]}                                # aggregate_info (logging.jl:60-66)
 
 
+def _solve_small_dqn(solver, D, s, gamma, i, stop):
+    """The iterations i, i + dN, ..., stop of solve(::OffPolicySolver) for a small DQN as a few launches of the one-workgroup solve kernel (cruxhip.h:
+    crux_dqn_small_solve); returns the first iteration index it did NOT run (== i when the configuration needs the call-by-call loop)."""
+    pe, pi, buf = solver.agent.pi_explore, solver.agent.pi, solver.buffer
+    if not (solver.fused_epochs and solver.target_fn == "dqn" and solver.log is None and isinstance(pe, EpsGreedyPolicy) and isinstance(pi, DiscreteNetwork)
+            and not buf.isprioritized() and not solver.weighted_loss and max(pi.network.dims) < 128 and D.capacity <= 256 and s.n_envs <= 4 and solver.dN % s.n_envs == 0 and i <= stop):
+        return i
+    p, ctx = solver.c_opt, buf.ctx
+    _ensure_opt(pi, p); _set_stream_for(buf, solver.sample_seed)
+    cfg, pi_on = _rollout_cfg(s, True, False, i)
+    n_total = (stop - i) // solver.dN + 1
+    while n_total > 0:
+        n = min(n_total, 8192)
+        infos = np.zeros((n, p.epochs, L.INFO_N), np.float32); sr, ne = C.c_double(), C.c_int64()
+        rc = ctx.lib.crux_dqn_small_solve(pi.h, solver.agent.pi_minus.h, s.h, C.byref(cfg), buf.h, D.h, n, solver.dN, p.epochs, float(gamma), float(solver.tau), 0, int(i), _vp(infos), C.byref(sr), C.byref(ne))
+        if rc == L.EUNSUP:
+            return i
+        ctx.check(rc)
+        for k in range(n):
+            solver.history.append({p.name + "loss": float(np.mean([float(x) for x in infos[k, :, 0]])), p.name + "grad_norm": float(np.mean([float(x) for x in infos[k, :, 1]])),
+                                   "Qavg": float(np.mean([float(x) for x in infos[k, :, 2]]))})
+        i += n * solver.dN; n_total -= n
+        solver.i = i - solver.dN
+    return i
+
+
 def _solve_off_policy(solver, mdp):
     """POMDPs.solve(S::OffPolicySolver, mdp) (src/model_free/off_policy.jl:113-150), logging left out."""
     gamma = np.float32(discount(mdp))
@@ -1567,6 +1593,7 @@ def _solve_off_policy(solver, mdp):
         steps_(s, solver.buffer, Nsteps=nfill, explore=True, i=solver.i)
     i = solver.i
     stop = istart + solver.N - solver.dN
+    i = _solve_small_dqn(solver, D, s, gamma, i, stop)                                                 # whole iterations in one launch where the configuration allows it
     while i <= stop:                                                                                   # :133
         solver.i = i
         steps_(s, solver.buffer, Nsteps=solver.dN, explore=True, i=i)                                  # :138

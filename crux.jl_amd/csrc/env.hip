@@ -5,6 +5,9 @@
 // tovec whitening (src/spaces.jl:25). Environment dynamics restate gymnasium's classic_control definitions
 // (the reference reaches them through POMDPGym/PyCall, src/sampler.jl:93).
 #include "common.h"
+#include "train_generic.h"
+#include "mlp_forward.h"
+#include "ops_small.h"
 
 int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I);
 void crux_buffer_ring_advance(crux_buffer* b, int64_t N);
@@ -291,10 +294,10 @@ __global__ __launch_bounds__(64) void k_rollout_h64(RolloutArgs a_single, const 
 
 // one wave (64 lanes) per environment; lanes split the output units of each Dense layer, lane 0 runs the
 // head, the dynamics and the bookkeeping. Environments never synchronise with each other.
-__global__ __launch_bounds__(64) void k_rollout(RolloutArgs a) {
-  __shared__ float hbuf[2][1024];
-  __shared__ float sh_misc[ENV_MAXOBS + 8];
-  const int e = blockIdx.x, lane = threadIdx.x;
+// The body is a device function of ONE wave (its LDS traffic is ordered by a wave barrier, not a workgroup barrier), so that the small-network
+// solve kernel below can run it on one of its waves.
+#define RO_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+__device__ __forceinline__ void rollout_generic_wave(const RolloutArgs& a, const int e, const int lane, float (*hbuf)[1024], float* sh_misc) {
   const NetDesc& nd = a.nd;
   const int od = a.od, ad = a.ad, nout = nd.dims[nd.L];
   double st[ENV_MAXSD]; int64_t ep_len = 0, n_resets = 0, steps_taken = 0; double sum_r = 0.0; int64_t nee = 0;
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(64) void k_rollout(RolloutArgs a) {
     ep_len = a.ep_len[e]; n_resets = a.n_resets[e]; steps_taken = a.steps_taken[e];
   }
   if (lane < od) hbuf[0][lane] = a.svec[(size_t)e * od + lane];
-  __syncthreads();
+  RO_WAVE_SYNC();
   for (int64_t t = 0; t < a.T; ++t) {
     const int64_t j = (a.base + (int64_t)e * a.T + t) % a.C;
     // current observation -> S column (sampler.jl:100)
@@ -318,14 +321,14 @@ __global__ __launch_bounds__(64) void k_rollout(RolloutArgs a) {
         for (int k = 0; k < in; ++k) accv = fmaf(Wl[o + out * k], hbuf[cur][k], accv);
         hbuf[cur ^ 1][o] = crux_act(act, accv + bl[o]);
       }
-      __syncthreads();
+      RO_WAVE_SYNC();
       cur ^= 1;
     }
     // (the observation in hbuf[0] was already stored to the S column, so the ping-pong may overwrite it)
     if (lane == 0) rollout_tail(a, hbuf[cur], od, ad, nout, a.kind, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
-    __syncthreads();
+    RO_WAVE_SYNC();
     if (lane < od) hbuf[0][lane] = sh_misc[lane];
-    __syncthreads();
+    RO_WAVE_SYNC();
   }
   if (lane == 0) {
     for (int i = 0; i < a.sd; ++i) a.state[(size_t)e * a.sd + i] = st[i];
@@ -333,6 +336,89 @@ __global__ __launch_bounds__(64) void k_rollout(RolloutArgs a) {
     a.acc[2 * e] = sum_r; a.acc[2 * e + 1] = (double)nee;
   }
   if (lane < od) a.svec[(size_t)e * od + lane] = hbuf[0][lane];
+}
+
+__global__ __launch_bounds__(64) void k_rollout(RolloutArgs a) {
+  __shared__ float hbuf[2][1024];
+  __shared__ float sh_misc[ENV_MAXOBS + 8];
+  rollout_generic_wave(a, blockIdx.x, threadIdx.x, hbuf, sh_misc);
+}
+
+// ---- the whole off-policy solve loop of a small network in ONE launch ------------------------------------------------------------------------
+// solve(::OffPolicySolver) (src/model_free/off_policy.jl:133-147) for the DQN family on networks that fit one workgroup (the README example: DQN on
+// SimpleGridWorld, 2-8-4, dN = 4, B = 128): per iteration steps!(dN) -> dN epochs of {rand! (uniform) -> dqn_target -> train!(td_loss)} ->
+// polyak_average!. Launched piece by piece this is ~10 kernels and several host round trips per gradient step for a few hundred flops of work. Here
+// one workgroup runs `iters` iterations back to back: wave e steps environment e (the generic rollout body above), then all four waves run the epochs
+// (the uniform draw and gather, the target network through mlp_forward_run, the step through train_generic_run -- the bodies the separate calls
+// use, so the results are the same bits), then the target update. Per-epoch info rows are left in device memory for the host to average.
+struct SmallSolveArgs {
+  RolloutArgs ro;                 // steps! of dN transitions per iteration into the replay ring (base / cfg.i0 advance in the kernel)
+  TrainArgs tr;                   // train!(pi, td_loss) on the B rows of the staging buffer (explicit rows 0..B-1)
+  NetDesc ndt; float* pt;         // pi_minus
+  // staging buffer <- replay buffer gather table (rand!: push!(target, source, ids))
+  void* gdst[CRUX_NCOLS]; const void* gsrc[CRUX_NCOLS]; int32_t gre[CRUX_NCOLS]; int32_t gesz[CRUX_NCOLS]; int32_t gn;
+  const float* bSP; const float* bR; const uint8_t* bD;     // staging columns the target reads
+  int64_t* bidx;                  // staging buffer's indices (device)
+  float* qtmp; float* y;          // [nout x B], [B]
+  int64_t elements, next, C;      // replay ring state at the first iteration
+  int32_t B, epochs, iters, dN, E;
+  float gamma, tau;
+  uint64_t sample_seed; uint32_t sample_stream; uint64_t i0;
+  float* infos;                   // [iters x epochs x 4]: loss, grad norm, Qavg, status
+  int32_t* status;
+  int32_t lds_train, lds_fwd;     // floats
+};
+__global__ __launch_bounds__(256) void k_dqn_small_solve(SmallSolveArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ double red[4];
+  __shared__ int32_t st_s[16];
+  float* sm_train = sm; float* sm_fwd = sm + q.lds_train; float* sm_ro = sm_fwd + q.lds_fwd;      // rollout: per wave hbuf[2][1024] + misc
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nout = q.ndt.dims[q.ndt.L], npar = q.tr.nd.n_params, B = q.B;
+  float* P = q.tr.p; float* G = q.tr.g; float* M = q.tr.m; float* V = q.tr.v; float* PT = q.pt; double* BP = q.tr.bp;
+  const float* bS = q.tr.S; const void* bA = q.tr.A; const float* bSP = q.bSP; const float* bR = q.bR; const uint8_t* bD = q.bD; float* Y = q.y; float* QT = q.qtmp; const int32_t* IDS = q.tr.ids;
+  if (tid < 16) st_s[tid] = 0;
+  __syncthreads();
+  int64_t elements = q.elements, next = q.next; int err = 0;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#define SS_T(k_) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k_] += tn_ - tl; tl = tn_; } while (0)
+  for (int it = 0; it < q.iters && !err; ++it) {
+    const uint64_t si = q.i0 + (uint64_t)it * (uint64_t)q.dN;             // S.i of this iteration (off_policy.jl:134)
+    // ---- steps!(sampler, buffer, Nsteps = dN, explore = true, i = S.i) (:138)
+    if (wv < q.E) { RolloutArgs ro = q.ro; ro.base = next; ro.cfg.i0 = si; ro.p = P;
+      rollout_generic_wave(ro, wv, lane, (float (*)[1024])(sm_ro + (size_t)wv * (2 * 1024 + ENV_MAXOBS + 8)), sm_ro + (size_t)wv * (2 * 1024 + ENV_MAXOBS + 8) + 2 * 1024); }
+    next = (next + q.dN) % q.C; elements = elements + q.dN < q.C ? elements + q.dN : q.C;
+    __threadfence_block(); __syncthreads(); SS_T(0);
+    // ---- value_training (:66-111)
+    for (int ep = 0; ep < q.epochs; ++ep) {
+      const uint64_t ictr = si * (uint64_t)q.epochs + (uint64_t)ep;
+      // rand!(D, buffer): uniform_sample! (experience_buffer.jl:317-321) with the library's Philox draw (per.hip k_uniform_ids), then the row gather
+      for (int j = tid; j < B; j += 256) { const crux_u32x4 x = crux_philox(q.sample_seed, ictr * (uint64_t)B + (uint64_t)j, q.sample_stream, CRUX_RNG_SAMPLE);
+        q.bidx[j] = (int64_t)(((uint64_t)x.v[0] * (uint64_t)elements) >> 32); }
+      __threadfence_block(); __syncthreads(); SS_T(1);
+      for (int k = 0; k < q.gn; ++k) { const int re = q.gre[k];
+        for (int t = tid; t < B * re; t += 256) { const int j = t / re, e2 = t - j * re; const int64_t sidx = q.bidx[j] * re + e2;
+          if (q.gesz[k] == 4) ((uint32_t*)q.gdst[k])[t] = ((const uint32_t*)q.gsrc[k])[sidx];
+          else ((uint8_t*)q.gdst[k])[t] = ((const uint8_t*)q.gsrc[k])[sidx]; } }
+      __threadfence_block(); __syncthreads(); SS_T(2);
+      // y = dqn_target(pi_minus, D) (dqn.jl:4-6)
+      mlp_forward_run(q.ndt, PT, bSP, B, QT, sm_fwd, 0u, 1u);
+      __threadfence_block(); __syncthreads();
+      for (unsigned b = 0; b * 256u < (unsigned)B; ++b) DqnTargetOp::run(b, 1u, QT, nout, bR, bD, q.gamma, (int64_t)B, Y);
+      __threadfence_block(); __syncthreads(); SS_T(3);
+      // train!(pi, td_loss) (training.jl:13-25)
+      { TrainArgs tr = q.tr; tr.p = P; tr.g = G; tr.m = M; tr.v = V; tr.bp = BP; tr.S = bS; tr.A = bA; tr.Y = Y; tr.ids = IDS; tr.status = st_s;
+        tr.epoch_infos = q.infos + ((size_t)it * q.epochs + ep) * CRUX_INFO_N; train_generic_run(tr, sm_train, red); }
+      __threadfence_block(); __syncthreads(); SS_T(4);
+      if (st_s[0] != 0) { err = st_s[0]; break; }
+    }
+    if (err) break;
+    // target_update: polyak_average!(pi_minus, pi, tau) (:108, policies.jl:48-59)
+    { const float omt = __fsub_rn(1.0f, q.tau);
+      for (int i = tid; i < npar; i += 256) PT[i] = __fadd_rn(__fmul_rn(q.tau, P[i]), __fmul_rn(omt, PT[i])); }
+    __threadfence_block(); __syncthreads();
+  }
+  if (tid == 0) { q.status[0] = st_s[0]; q.status[8] = err; for (int z = 0; z < 8; ++z) ((unsigned long long*)(q.status + 16))[z] = tacc[z]; }
 }
 
 __global__ void k_env_init(int kind, int E, int od, int sd, uint64_t seed, const float* mu, const float* sigma, double* state, int64_t* ep_len,
@@ -570,3 +656,67 @@ int32_t crux_env_step_host(crux_ctx* c, int32_t kind, int64_t n, const double* s
 }
 
 }  // extern "C"
+
+// solve(::OffPolicySolver) for a small DQN (see k_dqn_small_solve). Preconditions (CRUX_EUNSUP otherwise, the caller then loops piece by piece): uniform replay,
+// batch capacity == B <= 256, at most 4 environments, dN a multiple of them, both networks narrower than the dense engine's threshold, a rollout that the
+// generic kernel would run. infos: host [iters x epochs x CRUX_INFO_N] (loss, grad norm, [2] = Qavg per epoch).
+extern "C" int32_t crux_dqn_small_solve(crux_mlp* net, crux_mlp* target_net, crux_env* e, const crux_rollout_cfg* cfg, crux_buffer* source, crux_buffer* batch,
+                                        int32_t iters, int32_t dN, int32_t epochs, float gamma, float tau, int32_t use_weight, uint64_t i0, float* infos, double* sum_r, int64_t* n_episode_end) {
+  if (!net || !target_net || !e || !cfg || !source || !batch || iters < 1 || dN < 1 || epochs < 1) return CRUX_EINVAL;
+  crux_ctx* c = net->ctx; const int64_t B = batch->capacity; const int E = e->n_envs;
+  const NetDesc& pn = net->nd;
+  const bool h64 = pn.L == 3 && pn.dims[1] == 64 && pn.dims[2] == 64 && pn.acts[0] == pn.acts[1] && pn.acts[2] == CRUX_ACT_IDENTITY;
+  if (source->prioritized || batch->prioritized || B > 256 || B < 1 || E > 4 || dN % E || pn.maxdim >= CRUX_DENSE_MIN_WIDTH || target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH || h64 ||
+      target_net->nd.n_params != pn.n_params || !net->has_adam || cfg->head != CRUX_HEAD_GREEDY_Q || source->act_kind != CRUX_ACTION_DISCRETE || pn.dims[pn.L] != source->act_dim || dN > source->capacity || use_weight)
+    return crux_fail(c, CRUX_EUNSUP, "dqn_small_solve: configuration outside the one-launch solve kernel");
+  if (source->obs_dim != e->obs_dim || source->act_dim != e->act_dim || batch->obs_dim != source->obs_dim || batch->act_dim != source->act_dim || pn.dims[0] != e->obs_dim) return crux_fail(c, CRUX_EINVAL, "dqn_small_solve: shapes of env / buffers / network differ");
+  SmallSolveArgs q{};
+  fill_rollout_args(q.ro, e, net, cfg, source, dN / E);
+  // train!(pi, td_loss) on rows 0..B-1 of the staging buffer (the ids live in the staging buffer's order scratch)
+  TrainArgs& a = q.tr; memset(&a, 0, sizeof a);
+  a.nd = net->nd; a.p = net->p; a.g = net->g; a.m = net->m; a.v = net->v; a.bp = net->bp; a.eta = net->eta; a.b1 = net->b1; a.b2 = net->b2; a.eps = net->eps;
+  a.S = (const float*)batch->col[CRUX_COL_S]; a.A = batch->col[CRUX_COL_A]; a.od = batch->obs_dim; a.ad = batch->act_dim; a.act_kind = batch->act_kind;
+  a.loss = CRUX_LOSS_TD_INTERNAL; a.head = CRUX_HEAD_GREEDY_Q; a.bs = (int32_t)B; a.epochs = 1; a.max_batches = 0; a.target_kl = -1.f; a.len = B; a.apply = 1;
+  a.order_a = batch->order_a; a.order_b = batch->order_b;
+  const size_t nout = (size_t)pn.dims[pn.L];
+  const size_t small = 4 * ((size_t)B * nout + (size_t)B) + 4 * (size_t)B + 2048;
+  char* sc = (char*)crux_scratch(c, small + sizeof(float) * CRUX_INFO_N * (size_t)iters * (size_t)epochs + 4096); if (!sc) return crux_fail(c, CRUX_ENOMEM, "dqn_small_solve: scratch");
+  int32_t* d_ids = (int32_t*)sc; q.qtmp = (float*)(sc + ((4 * (size_t)B + 255) / 256) * 256); q.y = q.qtmp + B * nout; q.status = (int32_t*)(q.y + B); q.infos = (float*)(sc + ((small + 255) / 256) * 256);
+  { std::vector<int32_t> h((size_t)B); for (int64_t j = 0; j < B; ++j) h[(size_t)j] = (int32_t)j;
+    HIPCHK(c, hipMemcpyAsync(d_ids, h.data(), 4 * (size_t)B, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipMemsetAsync(q.status, 0, 256, c->stream));
+    HIPCHK(c, hipMemsetAsync(q.infos, 0, sizeof(float) * CRUX_INFO_N * (size_t)iters * (size_t)epochs, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+  a.ids = d_ids; a.n_ids = B; a.Y = q.y; a.Wt = nullptr; a.status = q.status;
+  q.ndt = target_net->nd; q.pt = target_net->p;
+  q.gn = 0; for (int k = 0; k < CRUX_NCOLS; ++k) { if (!has_col(batch, k) || !has_col(source, k)) continue; const size_t st = col_stride(batch, k); const int z = q.gn++;
+    q.gdst[z] = batch->col[k]; q.gsrc[z] = source->col[k]; q.gesz[z] = st % 4 == 0 ? 4 : 1; q.gre[z] = (int32_t)(st % 4 == 0 ? st / 4 : st);
+  }
+  q.bSP = (const float*)batch->col[CRUX_COL_SP]; q.bR = (const float*)batch->col[CRUX_COL_R]; q.bD = (const uint8_t*)batch->col[CRUX_COL_DONE]; q.bidx = batch->d_indices;
+  q.elements = source->elements; q.next = source->next_ind; q.C = source->capacity; q.B = (int32_t)B; q.epochs = epochs; q.iters = iters; q.dN = dN; q.E = E;
+  q.gamma = gamma; q.tau = tau; q.sample_seed = source->sample_seed; q.sample_stream = source->sample_stream; q.i0 = i0;
+  size_t fl = 0; for (int l = 0; l <= pn.L; ++l) fl += (size_t)pn.dims[l] * 32; fl += 2 * (size_t)pn.maxdim * 32 + 32 * (size_t)(pn.n_extra > 0 ? pn.n_extra : 1);     // = generic_lds_bytes (train.hip)
+  q.lds_train = (int32_t)((fl + 63) / 64 * 64); q.lds_fwd = (int32_t)(2 * (size_t)target_net->nd.maxdim * FWD_TS);
+  size_t lds = sizeof(float) * ((size_t)q.lds_train + (size_t)q.lds_fwd + (size_t)E * (2 * 1024 + ENV_MAXOBS + 8));
+  if (lds > 150 * 1024) return crux_fail(c, CRUX_EUNSUP, "dqn_small_solve: %zu bytes of LDS", lds);
+  static size_t attr_set = 0;
+  if (lds > attr_set) { HIPCHK(c, hipFuncSetAttribute((const void*)k_dqn_small_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = lds; }
+  crux_prof_begin(c, CRUX_PROF_TD_STEP);
+  hipLaunchKernelGGL(k_dqn_small_solve, dim3(1), dim3(256), lds, c->stream, q);
+  crux_prof_end(c, CRUX_PROF_TD_STEP);
+  int32_t rc = crux_launch_check(c, "k_dqn_small_solve"); if (rc) return rc;
+  int32_t hst9[9] = {0}; int32_t hst[2];
+  HIPCHK(c, hipMemcpyAsync(hst9, q.status, sizeof hst9, hipMemcpyDeviceToHost, c->stream));
+  if (infos) HIPCHK(c, hipMemcpyAsync(infos, q.infos, sizeof(float) * CRUX_INFO_N * (size_t)iters * (size_t)epochs, hipMemcpyDeviceToHost, c->stream));
+  std::vector<double> acc(2 * (size_t)E);
+  HIPCHK(c, hipMemcpyAsync(acc.data(), e->acc, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // host-side bookkeeping of the rings (push!, experience_buffer.jl:256-257) and of the staging buffer's sample state
+  for (int it = 0; it < iters; ++it) crux_buffer_ring_advance(source, dN);
+  batch->elements = B; batch->next_ind = 0; batch->total_count += (int64_t)B * epochs * iters; batch->indices_n = B; batch->indices_stale = true;
+  if (sum_r || n_episode_end) { double sr = 0; int64_t ne = 0; for (int k = 0; k < E; ++k) { sr += acc[2 * k]; ne += (int64_t)acc[2 * k + 1]; } if (sum_r) *sum_r = sr; if (n_episode_end) *n_episode_end = ne; }
+  hst[0] = hst9[0]; hst[1] = hst9[8];
+  if (getenv("CRUX_SMALL_SOLVE_TIMING")) { unsigned long long tt[8]; (void)hipMemcpy(tt, q.status + 16, sizeof tt, hipMemcpyDeviceToHost); unsigned long long tot = 0; for (auto v : tt) tot += v;
+    fprintf(stderr, "[small-solve] rollout %.1f%% ids %.1f%% gather %.1f%% target %.1f%% train %.1f%%\n", 100.0 * tt[0] / tot, 100.0 * tt[1] / tot, 100.0 * tt[2] / tot, 100.0 * tt[3] / tot, 100.0 * tt[4] / tot); }
+  if (hst[1] == CRUX_ENAN || hst[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
+  if (hst[1]) return crux_fail(c, hst[1], "small solve kernel reported status %d", hst[1]);
+  return CRUX_OK;
+}

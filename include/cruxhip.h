@@ -402,6 +402,16 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
                        crux_buffer* source, crux_buffer* batch, float gamma, float H_target, float tau, int32_t use_weight, int32_t update_critic, int32_t update_actor,
                        uint64_t sample_counter, uint64_t noise_seed, uint64_t noise_counter0, float* info_temp, float* info_critic, float* info_actor);
 
+/* solve(::OffPolicySolver) (src/model_free/off_policy.jl:133-147) for a DQN on a SMALL network (the README example: SimpleGridWorld, 2-8-4), `iters` iterations
+ * in ONE launch: per iteration steps!(sampler, buffer, Nsteps = dN, explore = true, i = S.i) (:138), then value_training (:66-111): dN.. `epochs` epochs of
+ * rand! (uniform) -> dqn_target -> train!(td_loss), then polyak_average!(target_net, net, tau) (:108). One workgroup runs the loop; the bodies are the ones
+ * the separate calls use (crux_rollout's generic kernel, crux_uniform_sample, crux_dqn_target, crux_td_step, crux_polyak), so the results are the same bits.
+ * CRUX_EUNSUP when the configuration needs the call-by-call loop (prioritized replay, weighted loss, batch > 256 rows, > 4 environments, wide or 64-64 networks).
+ * i0 = S.i of the first iteration; infos: host [iters x epochs x CRUX_INFO_N] (LOSS, GRAD_NORM, [2] = Qavg of every epoch).                       */
+int32_t crux_dqn_small_solve(crux_mlp* net, crux_mlp* target_net, crux_env* env, const crux_rollout_cfg* cfg, crux_buffer* source, crux_buffer* batch,
+                             int32_t iters, int32_t dN, int32_t epochs, float gamma, float tau, int32_t use_weight, uint64_t i0, float* infos,
+                             double* sum_r, int64_t* n_episode_end);
+
 /* SAC (src/model_free/rl/sac.jl) -----------------------------------------------------------------------
  * actor: GaussianPolicy handle (mean network + n_extra = act_dim trainable logSigma, policies.jl:315-348);
  * critic: DoubleNetwork = two ContinuousNetwork handles over vcat(s, a) (policies.jl:96,162-187); log_alpha:

@@ -166,3 +166,27 @@ def test_fused_sac_epoch_equals_the_separate_calls(gpu_ctx):
         assert np.array_equal(x, y), np.abs(x - y).max()
     for k in ("critic_loss", "actor_loss", "temp_loss", "SAC alpha"):
         assert abs(ha[-1][k] - hb[-1][k]) < 1e-5 * max(1.0, abs(hb[-1][k])), k
+
+
+def test_small_dqn_solve_in_one_launch_equals_the_call_by_call_loop(gpu_ctx):
+    """The README example's shape (DQN on SimpleGridWorld, 2-8-4, dN = 4, B = 128, buffer 1000): crux_dqn_small_solve runs whole solve iterations in one
+    workgroup with the bodies of the separate calls -- replay buffer, staging batch, both networks, Adam state and the per-iteration infos must be the
+    same bits as the call-by-call loop."""
+    def run(fast):
+        q = crux.DiscreteNetwork(parity.chain([2, 8, 4], ["relu", "identity"]), [1, 2, 3, 4], seed=1)
+        sv = crux.DQN(q, crux.ContinuousSpace(2), N=1600, dN=4, max_steps=100, c_opt={"batch_size": 128})
+        sv.fused_epochs = fast
+        crux.solve(sv, crux.SimpleGridWorld(n_envs=1, seed=3))
+        m, v, bp = q.adam_state()
+        return q.get_params(), sv.agent.pi_minus.get_params(), m, v, bp, {k: sv.buffer[k] for k in ("s", "a", "sp", "r", "done")}, {k: sv.batch[k] for k in ("s", "a", "r")}, sv.history, sv.i, sv.sampler.state()
+    a, b = run(True), run(False)
+    for x, y in zip(a[:5], b[:5]):
+        assert np.array_equal(x, y)
+    for d1, d2 in ((a[5], b[5]), (a[6], b[6])):
+        for k in d1:
+            assert np.array_equal(d1[k], d2[k]), k
+    assert len(a[7]) == len(b[7]) == (1600 - 200) // 4 and a[8] == b[8]
+    for h1, h2 in zip(a[7], b[7]):
+        assert h1 == h2
+    for x, y in zip(a[9], b[9]):
+        assert np.array_equal(x, y)
