@@ -500,13 +500,13 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
           // Both workgroups hold the same local total. They share the writes (peer i of the N-1 goes to workgroup i & 1): the total and the seven
           // statistics sums go into slot [parity][my rank] of the peer's region, a system-scope release makes them visible, then flag[my rank]
           // there is raised to the exchange number. Both workgroups then wait for the N-1 flags in the OWN region and add the N contributions in
-          // rank order, so every workgroup of every rank forms the same sum bit for bit.
+          // rank order -- the own one from registers (nothing orders workgroup 1 after a store of workgroup 0, so it is never read back from a
+          // slot), the others from the slots -- so every workgroup of every rank forms the same sum bit for bit.
           const unsigned long long xg = px0 + (unsigned long long)xstep;       // number of this exchange on this learner stream
           const int par = (int)(xg & 1ull);
           { int pi_ = 0;
             for (int r = 0; r < a.px_n; ++r) {
-              if (r == a.px_rank) { if (p != 0) continue; }          // own slot of the own region (workgroup 0): the sum below reads all N slots alike
-              else if ((pi_++ & 1) != p) continue;
+              if (r == a.px_rank || (pi_++ & 1) != p) continue;
               float* dst = a.px_tab[r] + (size_t)(par * CRUX_PX_MAXR + a.px_rank) * CRUX_PX_SLOT;
 #pragma unroll
               for (int mm = 0; mm < 4; ++mm) *(f32x4*)&dst[tid * 16 + 4 * mm] = gW2[mm];
@@ -534,8 +534,19 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
           __syncthreads();
           if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; break; }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                         // system scope: nothing read below is older than the flags
-          // the N slots are read two at a time (all loads of a pair in flight together) and added in rank order
+          // the N - 1 slots are read two ranks at a time (all loads of a pair in flight together) and added in rank order
+          f32x4 oW[4]; float oS[NSI]; const float oT = stat_tot;
+#pragma unroll
+          for (int mm = 0; mm < 4; ++mm) oW[mm] = gW2[mm];
+#pragma unroll
+          for (int k = 0; k < NSI; ++k) oS[k] = gs[k];
           auto px_load = [&](int r, f32x4 (&vW)[4], float (&vS)[NSI], float& vT) {
+            if (r == a.px_rank) {
+#pragma unroll
+              for (int mm = 0; mm < 4; ++mm) vW[mm] = oW[mm];
+#pragma unroll
+              for (int k = 0; k < NSI; ++k) vS[k] = oS[k];
+              vT = oT; return; }
             const float* src = px_mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT;
 #pragma unroll
             for (int k = 0; k < NSI; ++k) vS[k] = __hip_atomic_load(src + 4096 + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
