@@ -12,6 +12,16 @@
 #include <string.h>
 #include <stdio.h>
 
+#ifdef _OPENMP          /* libcruxoracle_omp.so: the all-cores CPU baseline of bench.py. The parity oracle is built WITHOUT -fopenmp. */
+#include <omp.h>
+#define ORC_STR_(x) #x
+#define ORC_OMP(x) _Pragma(ORC_STR_(x))
+int32_t orc_omp_threads(void) { return (int32_t)omp_get_max_threads(); }
+#else
+#define ORC_OMP(x)
+int32_t orc_omp_threads(void) { return 1; }
+#endif
+
 #define MAXL 8
 static const float EPS32 = 1.1920928955078125e-07f; /* eps(Float32) */
 
@@ -94,10 +104,12 @@ static colcache cc_alloc(const orc_mlp* n) { colcache c; memset(&c, 0, sizeof c)
 static void cc_free(const orc_mlp* n, colcache* c) { for (int l = 0; l <= n->n_layers; ++l) free(c->h[l]); }
 
 int32_t orc_mlp_forward(orc_mlp* n, const float* x, int64_t B, float* y) {
-  colcache c = cc_alloc(n);
   int in = n->dims[0], out = n->dims[n->n_layers];
-  for (int64_t s = 0; s < B; ++s) { fwd_col(n, x + s * in, c.h); memcpy(y + s * out, c.h[n->n_layers], 4 * (size_t)out); }
-  cc_free(n, &c);
+  ORC_OMP(omp parallel if (B >= 256))       /* the OpenMP build (bench.py's all-cores baseline) spreads the columns; the parity build runs this block once */
+  { colcache c = cc_alloc(n);
+    ORC_OMP(omp for schedule(static))
+    for (int64_t s = 0; s < B; ++s) { fwd_col(n, x + s * in, c.h); memcpy(y + s * out, c.h[n->n_layers], 4 * (size_t)out); }
+    cc_free(n, &c); }
   return CRUX_OK;
 }
 
@@ -628,9 +640,11 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
   float* RET = (buf->mask & (1u << CRUX_COL_RETURN)) ? (float*)buf->col[CRUX_COL_RETURN] : NULL;
   float* ADV = (buf->mask & (1u << CRUX_COL_ADVANTAGE)) ? (float*)buf->col[CRUX_COL_ADVANTAGE] : NULL;
   double sr = 0.0; int64_t nee = 0;
-  colcache c = cc_alloc(pol);
-  float p[64], aout[64];
+  /* environments are independent (own state, own Philox streams, own rows of the ring): the OpenMP build steps them on all cores */
+  ORC_OMP(omp parallel for schedule(dynamic, 1) reduction(+ : sr, nee))
   for (int k = 0; k < E; ++k) {
+    colcache c = cc_alloc(pol);
+    float p[64], aout[64];
     double* st = e->state + (size_t)k * e->state_dim; float* sv = e->svec + (size_t)k * od;
     for (int64_t t = 0; t < T; ++t) {
       int64_t j = I[(int64_t)k * T + t];
@@ -712,8 +726,8 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
     if (cfg->reset_at_end && e->ep_len[k] > 0) {                                               /* sampler.jl:148 */
       int64_t j = I[(int64_t)k * T + T - 1]; if (!EE[j]) { EE[j] = 1; ++nee; } env_reset_one(e, k);
     }
+    cc_free(pol, &c);
   }
-  cc_free(pol, &c);
   per_on_push(buf, I, N);
   ring_advance(buf, N);
   if (sum_r) *sum_r = sr; if (n_ee) *n_ee = nee;
@@ -796,37 +810,51 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
   if (net->dims[0] != od || n <= 0) return CRUX_EINVAL;
   memset(net->g, 0, 4 * (size_t)net->n_params);
   for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
-  colcache c = cc_alloc(net);
   const float* S = (const float*)buf->col[CRUX_COL_S];
   float invB = 1.0f / (float)n;
   double sum_loss_p = 0, sum_H = 0, sum_kl = 0, sum_adv = 0, sum_ret = 0, sum_sq = 0; int64_t nclip = 0;
-  float dy[64], p[64];
+  /* The sample loops below run once, in order, into net->g in the parity build. The OpenMP build gives every thread a slice of the minibatch and a
+   * private gradient that is added to net->g at the end (sample-parallel inside one step: the steps themselves are serially dependent). */
+#ifdef _OPENMP
+  const int nthr = n >= 32 ? (omp_get_max_threads() < (int)(n / 8) ? omp_get_max_threads() : (int)(n / 8)) : 1;
+#define LG_BEGIN ORC_OMP(omp parallel num_threads(nthr) reduction(+ : sum_loss_p, sum_H, sum_kl, sum_adv, sum_ret, sum_sq, nclip)) \
+  { colcache c = cc_alloc(net); float dy[64], p[64]; (void)p; float* gl = nthr > 1 ? (float*)calloc((size_t)net->n_params, 4) : net->g; ORC_OMP(omp for schedule(static))
+#define LG_END if (gl != net->g) { ORC_OMP(omp critical) { for (int64_t i_ = 0; i_ < net->n_params; ++i_) net->g[i_] += gl[i_]; } free(gl); } cc_free(net, &c); }
+#else
+#define LG_BEGIN { colcache c = cc_alloc(net); float dy[64], p[64]; (void)p; float* gl = net->g;
+#define LG_END cc_free(net, &c); }
+#endif
   if (cfg->loss == CRUX_LOSS_MSE_ACTION) {                                     /* mse_action_loss il/bc.jl:1: Flux.mse(action(pi, s), a) */
-    if (buf->act_kind != CRUX_ACTION_CONTINUOUS || nout != ad) { cc_free(net, &c); return CRUX_EINVAL; }
+    if (buf->act_kind != CRUX_ACTION_CONTINUOUS || nout != ad) return CRUX_EINVAL;
     const float* A = (const float*)buf->col[CRUX_COL_A]; float inv = invB / (float)nout;
+    LG_BEGIN
     for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s]; fwd_col(net, S + (size_t)id * od, c.h);
       for (int k = 0; k < nout; ++k) { float d = c.h[net->n_layers][k] - A[(size_t)id * ad + k]; sum_sq += (double)(d * d) / (double)nout; dy[k] = 2.f * d * inv; }
-      bwd_col(net, c.h, dy, net->g); }
+      bwd_col(net, c.h, dy, gl); }
+    LG_END
     info[CRUX_INFO_LOSS] = (float)(sum_sq / (double)n);
   } else if (cfg->loss == CRUX_LOSS_VALUE_MSE) {                               /* Flux.mse(value(pi, s), return) ppo.jl:60 */
-    if (nout != 1 || !(buf->mask & (1u << CRUX_COL_RETURN))) { cc_free(net, &c); return CRUX_EINVAL; }
+    if (nout != 1 || !(buf->mask & (1u << CRUX_COL_RETURN))) return CRUX_EINVAL;
     const float* RET = (const float*)buf->col[CRUX_COL_RETURN];
+    LG_BEGIN
     for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s];
       fwd_col(net, S + (size_t)id * od, c.h); float d = c.h[net->n_layers][0] - RET[id];
-      sum_sq += (double)(d * d); dy[0] = 2.f * d * invB; bwd_col(net, c.h, dy, net->g); }
+      sum_sq += (double)(d * d); dy[0] = 2.f * d * invB; bwd_col(net, c.h, dy, gl); }
+    LG_END
     info[CRUX_INFO_LOSS] = (float)(sum_sq / (double)n);
   } else {                                                                     /* ppo_loss ppo.jl:4-21 */
     const float* RET = (buf->mask & (1u << CRUX_COL_RETURN)) ? (const float*)buf->col[CRUX_COL_RETURN] : NULL;
     const int bc = cfg->loss == CRUX_LOSS_LOGPDF_BC;                            /* logpdf_bc_loss il/bc.jl:10-18: only :s and :a are read */
-    if (!bc && (!(buf->mask & (1u << CRUX_COL_LOGPROB)) || (cfg->loss == CRUX_LOSS_REINFORCE ? !RET : !(buf->mask & (1u << CRUX_COL_ADVANTAGE))))) { cc_free(net, &c); return CRUX_EINVAL; }
+    if (!bc && (!(buf->mask & (1u << CRUX_COL_LOGPROB)) || (cfg->loss == CRUX_LOSS_REINFORCE ? !RET : !(buf->mask & (1u << CRUX_COL_ADVANTAGE))))) return CRUX_EINVAL;
+    if (nout != ad || (cfg->head != CRUX_HEAD_CATEGORICAL && net->n_extra != ad)) return CRUX_EINVAL;
     const float* LP = bc ? NULL : (const float*)buf->col[CRUX_COL_LOGPROB]; const float* ADV = bc ? NULL : (cfg->loss == CRUX_LOSS_REINFORCE ? RET : (const float*)buf->col[CRUX_COL_ADVANTAGE]);
     float lo = 1.f - cfg->eps_clip, hi = 1.f + cfg->eps_clip;
-    float* gx = net->g + xoff(net); const float* ls = net->p + xoff(net);
-    for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s];
+    const float* ls = net->p + xoff(net);
+    LG_BEGIN
+    for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s]; float* gx = gl + xoff(net);
       fwd_col(net, S + (size_t)id * od, c.h); const float* z = c.h[net->n_layers];
       float A = bc ? 1.f : ADV[id], oldlp = bc ? 0.f : LP[id], newlp, H = 0.f;
       if (cfg->head == CRUX_HEAD_CATEGORICAL) {
-        if (nout != ad) { cc_free(net, &c); return CRUX_EINVAL; }
         const uint8_t* a = (const uint8_t*)buf->col[CRUX_COL_A] + (size_t)id * ad;
         softmax_col(z, nout, p);
         float q = 0.f; for (int k = 0; k < nout; ++k) q = q + p[k] * (a[k] ? 1.f : 0.f);        /* sum(probs .* a_oh) policies.jl:135 */
@@ -848,7 +876,6 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
         }
         if (cfg->loss == CRUX_LOSS_PPO && (r > hi || r < lo)) ++nclip;
       } else {                                                                   /* GaussianPolicy policies.jl:333-348 */
-        if (nout != ad || net->n_extra != ad) { cc_free(net, &c); return CRUX_EINVAL; }
         const float* a = (const float*)buf->col[CRUX_COL_A] + (size_t)id * ad;
         newlp = 0.f; const float sq = net->squash; float ua[64];
         for (int k = 0; k < ad; ++k) { ua[k] = sq > 0.f ? sq_untanh(a[k], sq) : a[k];
@@ -869,8 +896,10 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
         if (cfg->loss == CRUX_LOSS_PPO && (r > hi || r < lo)) ++nclip;
       }
       sum_H += (double)H; sum_kl += (double)(oldlp - newlp); sum_adv += (double)A; if (RET) sum_ret += (double)RET[id];
-      bwd_col(net, c.h, dy, net->g);
+      bwd_col(net, c.h, dy, gl);
     }
+    LG_END
+    float* gx = net->g + xoff(net);
     float p_loss = (float)(-(sum_loss_p / (double)n)), e_loss, entropy;
     if (cfg->head == CRUX_HEAD_CATEGORICAL) { entropy = (float)(sum_H / (double)n); e_loss = -entropy; }
     else { float Hs = 1.4189385332046727f; for (int k = 0; k < ad; ++k) Hs = Hs + ls[k]; entropy = Hs; e_loss = -Hs;   /* scalar entropy policies.jl:348 */
@@ -889,8 +918,9 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
   }
   if (net->n_extra) { double sx = 0; for (int i = 0; i < net->n_extra; ++i) sx += (double)net->g[xoff(net) + i] * net->g[xoff(net) + i]; float nx = (float)sqrt(sx); tot += (double)nx * nx; }
   info[CRUX_INFO_GRAD_NORM] = (float)sqrt(tot);
-  cc_free(net, &c);
   return CRUX_OK;
+#undef LG_BEGIN
+#undef LG_END
 }
 
 int32_t orc_loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids, int64_t n, float* info) { return loss_grad(net, buf, cfg, ids, n, info); }

@@ -124,6 +124,7 @@ int32_t orc_gail_reward(orc_mlp* D, orc_buffer* b, float alpha_r, float rscale, 
 int32_t orc_q_step(orc_mlp* q, orc_buffer* batch, const float* y, int32_t use_weight, float* info_out);
 int32_t orc_dpg_actor_step(orc_mlp* actor, orc_mlp* q, orc_buffer* batch, float* info_out);
 
+int32_t orc_omp_threads(void);   /* 1 in the parity build; the OpenMP build's thread count (bench.py's all-cores baseline only) */
 void orc_perm(uint64_t seed, uint64_t counter, uint32_t n, int64_t* out);
 void orc_philox(uint64_t seed, uint64_t counter, uint32_t stream, uint32_t purpose, uint32_t* out4);
 
