@@ -947,17 +947,113 @@ a2c_loss = _Loss("a2c")            # src/model_free/rl/a2c.jl:4-15
 reinforce_loss = _Loss("reinforce")  # src/model_free/rl/reinforce.jl:4-13
 
 
+class CustomLoss(_Loss):
+    """A user-written loss in the `loss` field of TrainingParams (src/training.jl:2) for losses outside the library's closed list. The reference
+    differentiates `loss(pi, P, D)` with Zygote (training.jl:16-18); here the user supplies the one piece Zygote would derive, d(loss)/d(network
+    output), and the library supplies the pullback through the network (crux_mlp_forward_cached / crux_mlp_backward on the MFMA dense engine):
+
+        fn(y, D, P) -> (loss, dloss_dy)  or  (loss, dloss_dy, info_dict)
+
+    y = value(pi, D[:s]) as a host array [out x B]; D = minibatch(D, indices) as a dict of host arrays; dloss_dy has y's shape. Host-mediated (one
+    round trip per minibatch): the escape hatch, not the fast path."""
+
+    def __init__(self, fn, name="custom"):
+        super().__init__(name)
+        self.fn = fn
+
+
 class TrainingParams:
-    """TrainingParams(; loss, optimizer=Adam(3f-4), batch_size=128, epochs=80, early_stopping, name, max_batches)
-    (src/training.jl:1-11). early_stopping is expressed as target_kl (PPO's `infos[end][:kl] > target_kl`, ppo.jl:59)."""
+    """TrainingParams(; loss, optimizer=Adam(3f-4), regularizer, batch_size=128, epochs=80, early_stopping, name, max_batches)
+    (src/training.jl:1-11). PPO's early_stopping (`infos[end][:kl] > target_kl`, ppo.jl:59) is expressed as target_kl and runs inside the
+    persistent learner kernel. The function-valued seams of the reference take the host-driven path of _train_seam / _batch_train_seam:
+    regularizer(theta) -> (value, gradient) over the flat parameter vector (training.jl:4,13: loss + regularizer(pi)); early_stopping(infos) ->
+    Bool over the per-epoch info dicts (:8,46,49); loss = CustomLoss(fn)."""
 
     def __init__(self, loss, optimizer=None, batch_size=128, epochs=80, target_kl=None, name="", max_batches=math.inf,
-                 shuffle_seed=0, update_every=1):
+                 shuffle_seed=0, update_every=1, regularizer=None, early_stopping=None):
         self.loss = loss
+        self.regularizer, self.early_stopping = regularizer, early_stopping
         self.update_every = int(update_every)        # off-policy solvers: train this network every update_every-th epoch (off_policy.jl:91,96)
         self.optimizer = optimizer or Adam(np.float32(3e-4))
         self.batch_size, self.epochs, self.target_kl, self.name, self.max_batches = int(batch_size), int(epochs), target_kl, name, max_batches
         self.shuffle_seed, self.shuffle_counter = int(shuffle_seed), 0
+
+
+def _uses_seam(p):
+    return isinstance(p.loss, CustomLoss) or getattr(p, "regularizer", None) is not None or getattr(p, "early_stopping", None) is not None
+
+
+def _train_seam(pi, p, P, D, ids0, info):
+    """train!(pi, loss + regularizer, p) (src/training.jl:13-25) with the function-valued pieces evaluated on the host:
+    pullback (:16-18) = library loss gradient (crux_loss_grad) or, for a CustomLoss, crux_mlp_forward_cached -> fn -> crux_mlp_backward;
+    the regularizer's gradient is added to the flat gradient; norm / NaN check (:19-20); Flux.update! = crux_adam_apply (:21)."""
+    ctx, lib = pi.ctx, pi.ctx.lib
+    n = pi.n_params; extra = {}
+    if isinstance(p.loss, CustomLoss):
+        mb = D.minibatch(ids0 + 1); x = np.asfortranarray(mb["s"], dtype=np.float32); B = x.shape[1]; out = pi.network.dims[-1]
+        d_x, d_y = ctx.alloc(x.nbytes), ctx.alloc(4 * out * B)
+        try:
+            ctx.h2d(d_x, x)
+            ctx.check(lib.crux_mlp_forward_cached(pi.h, d_x, B, d_y))
+            y = np.empty((out, B), np.float32, order="F"); ctx.d2h(d_y, y)
+            res = p.loss.fn(y, mb, P)
+            l, dy = float(res[0]), np.asfortranarray(res[1], dtype=np.float32)
+            if len(res) > 2:
+                extra = dict(res[2])
+            if dy.shape != y.shape:
+                raise ValueError("CustomLoss: dloss_dy must have the shape of the network output %r" % (y.shape,))
+            ctx.h2d(d_y, dy)
+            ctx.check(lib.crux_mlp_backward(pi.h, d_x, B, d_y, 1.0, 1, None))
+        finally:
+            ctx.free(d_x); ctx.free(d_y)
+        raw = None
+    else:
+        raw = np.zeros(L.INFO_N, np.float32); cfg = _train_cfg(pi, p, P)
+        ctx.check(lib.crux_loss_grad(pi.h, D.h, C.byref(cfg), _vp(ids0), ids0.size, _vp(raw)))
+        l = float(raw[L.INFO["loss"]])
+    g = np.empty(n, np.float32); ctx.d2h(lib.crux_mlp_grads_ptr(pi.h), g)
+    if p.regularizer is not None:
+        rv, rg = p.regularizer(pi.get_params())
+        l = float(np.float32(l) + np.float32(rv)); g = (g + np.asarray(rg, np.float32).reshape(-1)).astype(np.float32)
+        ctx.h2d(lib.crux_mlp_grads_ptr(pi.h), g)
+    gnorm = float(np.float32(np.sqrt(np.sum(g.astype(np.float64) ** 2))))
+    if math.isnan(gnorm):
+        raise L.CruxError(L.ENAN, "NaN detected! Loss: %r" % l)                                   # training.jl:20
+    ctx.check(lib.crux_adam_apply(pi.h, 1.0))
+    if raw is not None:
+        info.update(_info_dict(p, raw))
+    info.update(extra)
+    info[p.name + "loss"], info[p.name + "grad_norm"] = l, gnorm
+    return info
+
+
+def _batch_train_seam(pi, p, P, D, info, perms):
+    """batch_train! (src/training.jl:28-55) driven from the host, for TrainingParams with a CustomLoss, a regularizer or an early_stopping closure:
+    epochs x (shuffle!, partition(1:length(D), batch_size), train!), max_batches (:45,50), early_stopping over the aggregated infos (:46,49; the
+    aliased info dict makes aggregate_info(minibatch_infos) the latest minibatch's)."""
+    infos, total, N = [], 0, len(D)
+    stop_fn = p.early_stopping or ((lambda infos_: infos_[-1].get("kl", 0.0) > p.target_kl) if p.target_kl is not None else (lambda infos_: False))
+    maxb = math.inf if p.max_batches in (None, math.inf) else int(p.max_batches)
+    cur = {}
+    for ep in range(p.epochs):
+        if perms is not None:
+            D.shuffle_(np.asarray(perms[ep], np.int64))
+        else:
+            shuffle_device_(D, p.shuffle_seed, p.shuffle_counter); p.shuffle_counter += 1
+        for st in range(0, N, p.batch_size):
+            ids0 = np.arange(st, min(N, st + p.batch_size), dtype=np.int64)
+            cur = _train_seam(pi, p, P, D, ids0, cur)
+            total += 1
+            if total >= maxb or stop_fn(infos + [dict(cur)]):
+                break
+        infos.append(dict(cur))
+        if stop_fn(infos) or total >= maxb:
+            break
+    info = info if info is not None else {}
+    agg = {k: float(np.mean([d[k] for d in infos])) for k in infos[0]} if infos else {}
+    info.update(agg)
+    info[p.name + "batches_trained"] = total; info["_epochs_run"] = len(infos)
+    return info
 
 
 def _train_cfg(pi, p, P):
@@ -995,6 +1091,8 @@ def train_(pi, p, P, D, indices, info=None):
     Raises CruxError(ENAN) like `error("NaN detected!")` (:20)."""
     _ensure_opt(pi, p)
     ids = np.ascontiguousarray(np.asarray(indices, np.int64) - 1)
+    if _uses_seam(p):
+        return _train_seam(pi, p, P, D, ids, info if info is not None else {})
     raw = np.zeros(L.INFO_N, np.float32)
     cfg = _train_cfg(pi, p, P)
     pi.ctx.check(pi.ctx.lib.crux_train_step(pi.h, D.h, C.byref(cfg), _vp(ids), ids.size, _vp(raw)))
@@ -1007,6 +1105,8 @@ def batch_train_(pi, p, P, D, info=None, perms=None):
     """batch_train!(pi, p, P, D; info) (src/training.jl:28-55): epochs x (shuffle!, partition, train!) with max_batches and
     early stopping, as ONE persistent kernel. perms: optional (epochs, len) 1-based permutations (else Philox)."""
     _ensure_opt(pi, p)
+    if _uses_seam(p):
+        return _batch_train_seam(pi, p, P, D, info, perms)
     cfg = _train_cfg(pi, p, P)
     pp = None
     if perms is not None:

@@ -3,6 +3,7 @@
 # NOT executed in this repository's build environment (no Julia toolchain there); the tested twin of every call below is the
 # ctypes binding crux.jl_amd/_lib.py + crux.jl_amd/api.py, which uses the same symbols, argument order and struct layouts.
 # Every method cites the Crux.jl definition it overloads (paths relative to the Crux.jl repository root).
+# `julia julia/check_syntax.jl` parses this file (Meta.parseall) without loading Crux -- the CI-style check for boxes that have a julia binary.
 module CruxHIP
 
 using Crux, Flux, POMDPs
@@ -77,14 +78,14 @@ attach!(π::HipNetwork, o::Flux.Optimise.Adam) = check(π.ctx, ccall((:crux_adam
 
 # ---------------------------------------------------------------------------------------------------- buffer
 mutable struct HipBuffer                                                       # stands in for ExperienceBuffer{CuArray} (src/experience_buffer.jl:53-80)
-    ctx::Ctx; h::Ptr{Cvoid}; obs_dim::Int; act_dim::Int; discrete::Bool; keys::Vector{Symbol}
+    ctx::Ctx; h::Ptr{Cvoid}; obs_dim::Int; act_dim::Int; discrete::Bool; keys::Vector{Symbol}; prioritized::Bool; β
 end
-function HipBuffer(ctx::Ctx, S, A, capacity::Integer, extras=Symbol[]; prioritized=false, α=0.6f0)
+function HipBuffer(ctx::Ctx, S, A, capacity::Integer, extras=Symbol[]; prioritized=false, α=0.6f0, β=Crux.LinearDecaySchedule(0.5f0, 1f0, 10_000))   # PriorityParams (:38-50)
     mask = UInt32(0); for k in extras; mask |= UInt32(1) << COL[k]; end
     r = Ref{Ptr{Cvoid}}(C_NULL); disc = A isa Crux.DiscreteSpace
     check(ctx, ccall((:crux_buffer_create, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Int64, UInt32, Int32, Float32, Ref{Ptr{Cvoid}}),
                      ctx.h, prod(Crux.dim(S)), prod(Crux.dim(A)), disc ? 0 : 1, capacity, mask, prioritized, α, r))
-    b = HipBuffer(ctx, r[], prod(Crux.dim(S)), prod(Crux.dim(A)), disc, [:s, :a, :sp, :r, :done, :episode_end, extras...])
+    b = HipBuffer(ctx, r[], prod(Crux.dim(S)), prod(Crux.dim(A)), disc, [:s, :a, :sp, :r, :done, :episode_end, extras...], prioritized, β)
     finalizer(x -> ccall((:crux_buffer_destroy, LIB), Int32, (Ptr{Cvoid},), x.h), b); b
 end
 Base.length(b::HipBuffer) = Int(ccall((:crux_buffer_len, LIB), Int64, (Ptr{Cvoid},), b.h))
@@ -108,14 +109,43 @@ function HipSampler(ctx::Ctx, kind::Integer, agent; n_envs=1, max_steps=100, γ=
                      ctx.h, kind, n_envs, max_steps, γ, μ, σ, seed, 0, 0, r))
     HipSampler(ctx, r[], agent, n_envs, max_steps, γ, λ)
 end
+# exploration configuration of the agent -> the fields of crux_rollout_cfg (cruxhip.h): the device rollout evaluates them per step, like
+# exploration(π_explore, s; π_on, i) does (src/sampler.jl:73, src/policies.jl:474-514)
+function explore_fields(π_explore)
+    eps_start, eps_stop, eps_steps = 0.0, 0.0, Int64(0)
+    σ, ϵmin, ϵmax, amin, amax = -1f0, -Inf32, Inf32, -Inf32, Inf32
+    if π_explore isa Crux.MixedPolicy                                   # ϵGreedyPolicy(ϵ, actions) = MixedPolicy(ϵ, ObjectCategorical) (policies.jl:471-472)
+        sched = π_explore.ϵ
+        if sched isa Crux.LinearDecaySchedule                           # src/utils.jl:115-126
+            eps_start, eps_stop, eps_steps = Float64(sched.start), Float64(sched.stop), Int64(sched.steps)
+        else                                                            # a constant ϵ: MixedPolicy(ϵ::Real, policy) wraps it as (i) -> ϵ
+            e = Float64(sched(0)); e == Float64(sched(10^9)) || error("ϵ schedule $(typeof(sched)) has no device form (LinearDecaySchedule or a constant)")
+            eps_start, eps_stop, eps_steps = e, e, Int64(1)
+        end
+    elseif π_explore isa Crux.GaussianNoiseExplorationPolicy            # policies.jl:498-514
+        σ = Float32(π_explore.σ(0)); σ == Float32(π_explore.σ(10^9)) || error("a σ schedule needs one crux_rollout call per value of σ(i)")
+        ϵmin, ϵmax, amin, amax = π_explore.ϵ_min, π_explore.ϵ_max, π_explore.a_min[1], π_explore.a_max[1]
+    elseif !isnothing(π_explore)
+        error("exploration policy $(typeof(π_explore)) has no device form")
+    end
+    (eps_start, eps_stop, eps_steps, σ, ϵmin, ϵmax, amin, amax)
+end
 function Crux.steps!(s::HipSampler, b::HipBuffer; Nsteps=1, explore=false, i=0, reset=false, cb=(D) -> nothing, kw...)   # src/sampler.jl:139-173
     π = Crux.actor(s.agent.π)
-    cfg = RolloutCfg(explore, reset, π.head, 0.0, 0.0, 0, -1f0, -Inf32, Inf32, -Inf32, Inf32, 0f0, i)
+    e0, e1, en, σ, ϵmin, ϵmax, amin, amax = explore ? explore_fields(s.agent.π_explore) : explore_fields(nothing)
+    # explore = 2: action(π, s) of an always_stochastic DiscreteNetwork samples but records logprob NaN (policies.jl:124, sampler.jl:73)
+    mode = explore ? Int32(1) : (hasproperty(π, :always_stochastic) && π.always_stochastic ? Int32(2) : Int32(0))
+    cfg = RolloutCfg(mode, reset, π.head, e0, e1, en, σ, ϵmin, ϵmax, amin, amax, 0f0, i)
     sr = Ref{Float64}(0); ne = Ref{Int64}(0)
+    first = ccall((:crux_buffer_next_ind, LIB), Int64, (Ptr{Cvoid},), b.h)
     check(s.ctx, ccall((:crux_rollout, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{RolloutCfg}, Ptr{Cvoid}, Int64, Ref{Float64}, Ref{Int64}),
                        s.h, π.h, cfg, b.h, Nsteps ÷ s.n_envs, sr, ne))
-    haskey(b, :advantage) && Crux.fill_gae!(b, Crux.critic(s.agent.π), s.λ, s.γ)          # terminate_episode! (:56-57)
-    haskey(b, :return) && Crux.fill_returns!(b, s.γ)
+    # terminate_episode! (:53-69) fills advantage / return per finished episode of the rows just written: the block entry points take the ring
+    # position of the block, so a buffer larger than one batch is handled like the reference handles it (rows outside the block are not touched)
+    T = Nsteps ÷ s.n_envs
+    haskey(b, :advantage) && check(b.ctx, ccall((:crux_fill_gae_rows, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Int64, Int64, Int64, Int32),
+                                                b.h, Crux.critic(s.agent.π).h, s.λ, s.γ, first, Nsteps, T, reset))
+    haskey(b, :return) && check(b.ctx, ccall((:crux_fill_returns_rows, LIB), Int32, (Ptr{Cvoid}, Float32, Int64, Int64, Int64, Int32), b.h, s.γ, first, Nsteps, T, reset))
     cb(b); Dict("avg_r" => sr[] / ne[])
 end
 Crux.fill_gae!(b::HipBuffer, V::HipNetwork, λ::Float32, γ::Float32) = check(b.ctx, ccall((:crux_fill_gae, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32), b.h, V.h, λ, γ))   # :255-273
@@ -125,11 +155,21 @@ whiten!(b::HipBuffer, k::Symbol=:advantage) = check(b.ctx, ccall((:crux_whiten, 
 # ---------------------------------------------------------------------------------------------------- learner
 loss_id(f) = f === Crux.ppo_loss ? LOSS_PPO : f === Crux.a2c_loss ? LOSS_A2C : f === Crux.reinforce_loss ? LOSS_REINFORCE : f === Crux.logpdf_bc_loss ? LOSS_LOGPDF_BC :
              f === Crux.mse_action_loss ? LOSS_MSE_ACTION : LOSS_VALUE_MSE      # the critic loss of PPO/A2C is an anonymous mse closure (ppo.jl:60)
-function train_cfg(π::HipNetwork, p::Crux.TrainingParams, 𝒫; target_kl=-1f0, seed=0, counter=0)
+# PPO's KL early stop lives in a closure, `early_stopping = (infos) -> (infos[end][:kl] > target_kl)` (ppo.jl:59): the number cannot be read back from
+# the TrainingParams, so the solver constructor below records it here and batch_train! / policy_gradient_training look it up (keyword overrides).
+const TARGET_KL = IdDict{Any,Float32}()
+target_kl_of(p) = get(TARGET_KL, p, -1f0)
+"""PPO(...) with the learners on the device: Crux.PPO's own constructor (ppo.jl:40-66) + the target_kl it captured, remembered for the kernel."""
+function HipPPO(; target_kl=0.012f0, kwargs...)
+    𝒮 = Crux.PPO(; target_kl=target_kl, kwargs...)
+    TARGET_KL[𝒮.a_opt] = Float32(target_kl)
+    𝒮
+end
+function train_cfg(π::HipNetwork, p::Crux.TrainingParams, 𝒫; target_kl=target_kl_of(p), seed=0, counter=0)
     TrainCfg(loss_id(p.loss), π.head, p.batch_size, p.epochs, isinf(p.max_batches) ? 0 : Int64(p.max_batches),
              get(𝒫, :ϵ, 0.2f0), get(𝒫, :λp, 1f0), get(𝒫, :λe, 0.1f0), target_kl, seed, counter, 0, 0)
 end
-function Crux.batch_train!(π::HipNetwork, p::Crux.TrainingParams, 𝒫, 𝒟::HipBuffer; info=Dict(), target_kl=-1f0, seed=0, counter=0)   # src/training.jl:28-55
+function Crux.batch_train!(π::HipNetwork, p::Crux.TrainingParams, 𝒫, 𝒟::HipBuffer; info=Dict(), target_kl=target_kl_of(p), seed=0, counter=0)   # src/training.jl:28-55
     out = zeros(Float32, INFO_N)
     check(π.ctx, ccall((:crux_batch_train, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{TrainCfg}, Ptr{Int64}, Ptr{Float32}, Ptr{Float32}),
                        π.h, 𝒟.h, train_cfg(π, p, 𝒫; target_kl, seed, counter), C_NULL, out, C_NULL))
@@ -140,7 +180,7 @@ function Crux.policy_gradient_training(𝒮::Crux.OnPolicySolver, 𝒟::HipBuffe
     A, C_ = Crux.actor(𝒮.agent.π), Crux.critic(𝒮.agent.π); ia, ic = zeros(Float32, INFO_N), zeros(Float32, INFO_N)
     check(A.ctx, ccall((:crux_policy_gradient_training, LIB), Int32,
                        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{TrainCfg}, Ref{TrainCfg}, Ptr{Int64}, Ptr{Int64}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
-                       A.h, C_.h, 𝒟.h, train_cfg(A, 𝒮.a_opt, 𝒮.𝒫; target_kl=get(𝒮.𝒫, :target_kl, -1f0)), train_cfg(C_, 𝒮.c_opt, 𝒮.𝒫), C_NULL, C_NULL, ia, ic, C_NULL, C_NULL))
+                       A.h, C_.h, 𝒟.h, train_cfg(A, 𝒮.a_opt, 𝒮.𝒫), train_cfg(C_, 𝒮.c_opt, 𝒮.𝒫), C_NULL, C_NULL, ia, ic, C_NULL, C_NULL))
     Dict("actor_loss" => ia[1], "actor_grad_norm" => ia[2], :kl => ia[4], :entropy => ia[3], "critic_loss" => ic[1], "critic_grad_norm" => ic[2])
 end
 
@@ -168,10 +208,110 @@ gail_d_step!(D::HipNetwork, ex::HipBuffer, r_ex::UnitRange, pol::HipBuffer, r_po
                         D.h, ex.h, first(r_ex) - 1, length(r_ex), pol.h, first(r_pol) - 1, length(r_pol), info)); info)
 gail_reward!(D::HipNetwork, 𝒟::HipBuffer; αr=0.5f0, Rscale=1f0) = (m = Ref{Float32}(0); check(D.ctx, ccall((:crux_gail_reward, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Ref{Float32}), D.h, 𝒟.h, αr, Rscale, m)); m[])   # :50-55
 
-# off-policy seams (value_training, src/model_free/off_policy.jl:66-111) follow the same pattern:
-#   dqn_target  -> :crux_dqn_target      td_error -> :crux_td_error        train!(critic, td_loss)        -> :crux_td_step / :crux_q_step
-#   sac_target  -> :crux_sac_target      sac_temp_loss -> :crux_sac_temp_step    double_Q_loss -> :crux_double_q_step    sac_actor_loss -> :crux_sac_actor_step
-#   ddpg/td3    -> :crux_dpg_target, :crux_dpg_actor_step                  softq_target  -> :crux_softq_target
-#   rand!       -> :crux_uniform_sample / :crux_per_sample                 episodes!     -> :crux_rollout over Neps fresh envs + :crux_first_episode_metrics
+# ---------------------------------------------------------------------------------------------------- replica groups over xGMI peer slots
+# The exact multi-GPU algorithm (SURVEY 8e): every minibatch step of the persistent learner SUM-all-reduces the gradient between back(1f0) and
+# Flux.update! (training.jl:18,21) through peer-mapped slots -- no host call per step. One process per GPU: export, exchange the 64-byte handles
+# (MPI.Allgather or any side channel), attach; crux_batch_train / crux_policy_gradient_training then synchronise by themselves.
+peer_export(c::Ctx) = (h = zeros(UInt8, 64); check(c, ccall((:crux_peer_export, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}), c.h, h)); h)
+peer_attach!(c::Ctx, rank::Integer, nranks::Integer, handles::Vector{UInt8}) = check(c, ccall((:crux_peer_attach, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), c.h, rank, nranks, handles))
+peer_detach!(c::Ctx) = check(c, ccall((:crux_peer_detach, LIB), Int32, (Ptr{Cvoid},), c.h))
+
+# ---------------------------------------------------------------------------------------------------- off-policy: value_training and its pieces
+# src/model_free/off_policy.jl:66-111. 𝒟 is the staging HipBuffer of batch_size rows, 𝒮.buffer the replay HipBuffer.
+device_vec(c::Ctx, n) = (r = Ref{Ptr{Cvoid}}(C_NULL); check(c, ccall((:crux_device_alloc, LIB), Int32, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), c.h, 4n, r)); r[])
+device_free(c::Ctx, p) = ccall((:crux_device_free, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), c.h, p)
+
+Crux.isprioritized(b::HipBuffer) = b.prioritized                                                                                    # experience_buffer.jl:84
+function Crux.uniform_sample!(t::HipBuffer, s::HipBuffer; B=Int(ccall((:crux_buffer_capacity, LIB), Int64, (Ptr{Cvoid},), t.h)), i=1)   # :317-321
+    check(t.ctx, ccall((:crux_uniform_sample, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Int64}, UInt64), t.h, s.h, B, C_NULL, i))
+end
+function Crux.prioritized_sample!(t::HipBuffer, s::HipBuffer; B=Int(ccall((:crux_buffer_capacity, LIB), Int64, (Ptr{Cvoid},), t.h)), i=1)   # :324-349
+    β = Float32(s.β(i))                                                                                                             # priority_params.β(i) (:331)
+    check(t.ctx, ccall((:crux_per_sample, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Float32, UInt64), t.h, s.h, B, C_NULL, β, i))
+end
+function Base.rand!(t::HipBuffer, sources::HipBuffer...; i=1, fracs=ones(Float32, length(sources)) ./ length(sources))              # :303-315
+    ccall((:crux_buffer_clear, LIB), Int32, (Ptr{Cvoid},), t.h)
+    lens = Crux.split_batches(Int(ccall((:crux_buffer_capacity, LIB), Int64, (Ptr{Cvoid},), t.h)), fracs)
+    for (k, (b, B)) in enumerate(zip(sources, lens))
+        check(t.ctx, ccall((:crux_buffer_set_sample_stream, LIB), Int32, (Ptr{Cvoid}, UInt64, UInt32), b.h, 0x5EED5A3F, k - 1))     # independent draws per source
+        Crux.isprioritized(b) ? Crux.prioritized_sample!(t, b; B, i) : Crux.uniform_sample!(t, b; B, i)
+    end
+end
+
+# targets and losses: every device call is the reference's closure of the same name
+struct DeviceTarget; p::Ptr{Cvoid}; n::Int; end                                     # y stays on the device between target_fn and the losses
+dqn_target(π⁻::HipNetwork, 𝒫, 𝒟::HipBuffer, γ; y=device_vec(π⁻.ctx, length(𝒟)), kw...) =                                           # rl/dqn.jl:4-6
+    (check(π⁻.ctx, ccall((:crux_dqn_target, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Ptr{Cvoid}), π⁻.h, 𝒟.h, γ, y)); DeviceTarget(y, length(𝒟)))
+softq_target(α) = (π⁻::HipNetwork, 𝒫, 𝒟::HipBuffer, γ; y=device_vec(π⁻.ctx, length(𝒟)), kw...) ->                                   # rl/softq.jl:4-13
+    (check(π⁻.ctx, ccall((:crux_softq_target, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Ptr{Cvoid}), π⁻.h, 𝒟.h, γ, α, y)); DeviceTarget(y, length(𝒟)))
+function td_step!(π::HipNetwork, 𝒟::HipBuffer, y::DeviceTarget; weighted=false, err=C_NULL, info=zeros(Float32, INFO_N))            # train!(critic, td_loss) utils.jl:76-87 (+ td_error :112)
+    check(π.ctx, ccall((:crux_td_step_with_error, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Float32}), π.h, 𝒟.h, y.p, weighted, err, info)); info
+end
+
+"""One epoch of value_training for the DQN family (off_policy.jl:69-93) as one fused call: rand! -> dqn_target -> td_error / update_priorities! ->
+train!(critic, td_loss). `i` is 𝒮.i; the sample counter makes every epoch of every iteration draw fresh rows."""
+function dqn_epoch!(𝒮, 𝒟::HipBuffer, γ, epoch)
+    π, π⁻ = 𝒮.agent.π, 𝒮.agent.π⁻; info = zeros(Float32, INFO_N)
+    β = Crux.isprioritized(𝒮.buffer) ? Float32(𝒮.buffer.β(𝒮.i)) : 0f0
+    check(π.ctx, ccall((:crux_dqn_epoch, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Int32, Float32, UInt64, Ptr{Float32}),
+                       π.h, π⁻.h, 𝒮.buffer.h, 𝒟.h, γ, Crux.isprioritized(𝒮.buffer), β, 𝒮.i * 𝒮.c_opt.epochs + epoch - 1, info))
+    Dict("critic_loss" => info[1], "critic_grad_norm" => info[2], "Qavg" => info[3])
+end
+"""One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl:4-52,94-104) as one fused call."""
+function sac_epoch!(𝒮, 𝒟::HipBuffer, γ, epoch; noise_seed=0)
+    A, Q = Crux.actor(𝒮.agent.π), Crux.critic(𝒮.agent.π); A⁻, Q⁻ = Crux.actor(𝒮.agent.π⁻), Crux.critic(𝒮.agent.π⁻)
+    it, ic, ia = zeros(Float32, INFO_N), zeros(Float32, INFO_N), zeros(Float32, INFO_N); ctr = 𝒮.i * 𝒮.c_opt.epochs + epoch - 1
+    check(A.ctx, ccall((:crux_sac_epoch, LIB), Int32,
+                       (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Float32, Int32, Int32, Int32,
+                        UInt64, UInt64, UInt64, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                       A.h, Q.N1.h, Q.N2.h, C_NULL, Q⁻.N1.h, Q⁻.N2.h, 𝒮.𝒫[:SAC_log_α].h, 𝒮.buffer.h, 𝒟.h, γ, 𝒮.𝒫[:SAC_H_target], 0.005f0,
+                       Crux.isprioritized(𝒮.buffer), (epoch - 1) % 𝒮.c_opt.update_every == 0, (epoch - 1) % 𝒮.a_opt.update_every == 0,
+                       ctr, noise_seed, 3ctr, it, ic, ia))
+    Dict("SAC alpha" => it[3], "critic_loss" => ic[1], "actor_loss" => ia[1], "entropy" => ia[3])
+end
+function Crux.value_training(𝒮::Crux.OffPolicySolver, 𝒟::HipBuffer, γ)                                                             # off_policy.jl:66-111
+    fused = haskey(𝒮.𝒫, :SAC_log_α) ? sac_epoch! : dqn_epoch!
+    infos = [fused(𝒮, 𝒟, γ, epoch) for epoch in 1:𝒮.c_opt.epochs]
+    isnothing(𝒮.a_opt) && Crux.polyak_average!(𝒮.agent.π⁻, 𝒮.agent.π, 0.005f0)                                                     # :108 with the default target_update
+    Crux.aggregate_info(infos)
+end
+# The unfused pieces for solvers that compose their own epoch (DDPG / TD3 / custom param_optimizers) follow the same pattern:
+#   sac_target -> :crux_sac_target   sac_temp_loss -> :crux_sac_temp_step   double_Q_loss -> :crux_double_q_step   sac_actor_loss -> :crux_sac_actor_step
+#   ddpg/td3   -> :crux_dpg_target, :crux_q_step, :crux_dpg_actor_step      episodes! -> :crux_rollout over Neps fresh envs + :crux_first_episode_metrics
+# solve(::OffPolicySolver) for a small DQN (the README example) in one launch: :crux_dqn_small_solve (off_policy.jl:133-147).
+
+# ---------------------------------------------------------------------------------------------------- user-written losses and the regularizer
+# The reference differentiates ANY loss(π, 𝒫, 𝒟) with Zygote (training.jl:16-18). The library's fast paths cover a closed list (loss_id above);
+# everything else composes the explicit pullback: forward with cached activations -> the user's d(loss)/d(output) -> parameter gradients ->
+# + the regularizer's gradient (training.jl:13) -> Flux.update!. Tested twin: crux.jl_amd/api.py `CustomLoss`, tests/test_gpu_seams.py.
+"""train!(π, loss, p) for a loss given as `f(y, mb) -> (l, dl_dy)`, y = value(π, mb[:s]) (training.jl:13-25). `mb` is a Dict of host arrays."""
+function train_custom!(π::HipNetwork, f, p::Crux.TrainingParams, mb::Dict; regularizer_grad=nothing, info=Dict())
+    c = π.ctx; x = Float32.(mb[:s]); B = size(x, 2); out = Int(π.dims[end])
+    d_x, d_y = device_vec(c, length(x)), device_vec(c, out * B)
+    try
+        check(c, ccall((:crux_memcpy_h2d, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Int64), c.h, d_x, x, sizeof(x)))
+        check(c, ccall((:crux_mlp_forward_cached, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}), π.h, d_x, B, d_y))
+        y = Matrix{Float32}(undef, out, B)
+        check(c, ccall((:crux_memcpy_d2h, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}, Int64), c.h, y, d_y, sizeof(y)))
+        l, dy = f(y, mb); dy = Float32.(dy)                                                                                        # the piece Zygote would derive
+        check(c, ccall((:crux_memcpy_h2d, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Int64), c.h, d_y, dy, sizeof(dy)))
+        check(c, ccall((:crux_mlp_backward, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Float32, Int32, Ptr{Cvoid}), π.h, d_x, B, d_y, 1f0, 1, C_NULL))
+        g = Vector{Float32}(undef, n_params(π)); gp = ccall((:crux_mlp_grads_ptr, LIB), Ptr{Cvoid}, (Ptr{Cvoid},), π.h)
+        check(c, ccall((:crux_memcpy_d2h, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}, Int64), c.h, g, gp, sizeof(g)))
+        if !isnothing(regularizer_grad)                                                                                            # p.regularizer(π) and its gradient w.r.t. θ
+            rv, rg = regularizer_grad(Flux.params(π)); l += rv; g .+= rg
+            check(c, ccall((:crux_memcpy_h2d, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Int64), c.h, gp, g, sizeof(g)))
+        end
+        gnorm = sqrt(sum(abs2, Float64.(g))); isnan(gnorm) && error("NaN detected! Loss: $l")                                      # training.jl:19-20
+        check(c, ccall((:crux_adam_apply, LIB), Int32, (Ptr{Cvoid}, Float32), π.h, 1f0))                                           # Flux.update! (:21)
+        info[string(p.name, "loss")] = l; info[string(p.name, "grad_norm")] = Float32(gnorm); info
+    finally
+        device_free(c, d_x); device_free(c, d_y)
+    end
+end
+# example: a Huber critic loss with an L2 penalty
+#   huber(y, mb) = (d = y .- mb[:return]; a = abs.(d); (mean(ifelse.(a .< 1, 0.5f0 .* d .^ 2, a .- 0.5f0)), clamp.(d, -1, 1) ./ length(d)))
+#   l2(θ; λ=1f-4) = (λ * sum(abs2, θ), 2λ .* θ)
+#   train_custom!(V, huber, 𝒮.c_opt, minibatch(𝒟, 1:128); regularizer_grad=l2)
 
 end # module
