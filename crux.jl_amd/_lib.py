@@ -20,11 +20,18 @@ class RolloutCfg(C.Structure):
                 ("a_min", f32), ("a_max", f32), ("logit_div", f32), ("i0", u64)]
 
 
+class Lagrange(C.Structure):
+    """crux_lagrange (include/cruxhip.h): LagrangePPO's penalty controller -- hyper-parameters, PID state, last values."""
+    _fields_ = [("target_cost", f32), ("penalty_max", f32), ("Ki_max", f32), ("Ki", f32), ("Kp", f32), ("Kd", f32), ("ema_alpha", C.c_double),
+                ("I", f32), ("Jc_prev", f32), ("smooth_delta", f32), ("smooth_Jc", f32),
+                ("penalty", f32), ("cur_cost", f32), ("deriv_term", f32), ("reserved", f32)]
+
+
 class TrainCfg(C.Structure):
     """crux_train_cfg (include/cruxhip.h)."""
     _fields_ = [("loss", i32), ("head", i32), ("batch_size", i32), ("epochs", i32), ("max_batches", i64),
                 ("eps_clip", f32), ("lambda_p", f32), ("lambda_e", f32), ("target_kl", f32), ("shuffle_seed", u64),
-                ("shuffle_counter", u64), ("sync_every", i32), ("reserved", i32)]
+                ("shuffle_counter", u64), ("sync_every", i32), ("target_col", i32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/cruxhip.h appears here (checked by tests).
@@ -100,6 +107,11 @@ SIGNATURES = {
     "crux_fill_returns_rows": (i32, [vp, f32, i64, i64, i64, i32]),
     "crux_whiten": (i32, [vp, i32]),
     "crux_batch_train": (i32, [vp, vp, P(TrainCfg), vp, vp, vp]),
+    "crux_batch_train_lagrange": (i32, [vp, vp, P(TrainCfg), P(Lagrange), vp, vp, vp]),
+    "crux_fill_gae_keys": (i32, [vp, vp, f32, f32, i32, i32]),
+    "crux_fill_returns_keys": (i32, [vp, f32, i32, i32]),
+    "crux_fill_gae_rows_keys": (i32, [vp, vp, f32, f32, i64, i64, i64, i32, i32, i32]),
+    "crux_fill_returns_rows_keys": (i32, [vp, f32, i64, i64, i64, i32, i32, i32]),
     "crux_policy_gradient_training": (i32, [vp, vp, vp, P(TrainCfg), P(TrainCfg), vp, vp, vp, vp, vp, vp]),
     "crux_train_step": (i32, [vp, vp, P(TrainCfg), vp, i64, vp]),
     "crux_loss_grad": (i32, [vp, vp, P(TrainCfg), vp, i64, vp]),
@@ -170,14 +182,14 @@ def load():
 OK, EINVAL, ENAN, EHIP, ERCCL, ENOMEM, EUNSUP = 0, -1, -2, -3, -4, -5, -6
 ACT = {"identity": 0, "relu": 1, "tanh": 2}
 COL = {"s": 0, "a": 1, "sp": 2, "r": 3, "done": 4, "episode_end": 5, "return": 6, "logprob": 7, "advantage": 8,
-       "weight": 9, "t": 10, "i": 11, "value": 12}
-NCOLS = 13
+       "weight": 9, "t": 10, "i": 11, "value": 12, "cost": 13, "cost_advantage": 14, "cost_return": 15}
+NCOLS = 16
 ACTION_DISCRETE, ACTION_CONTINUOUS = 0, 1
 ENV = {"cartpole": 0, "pendulum": 1, "gridworld": 2, "synth": 3, "synth_discrete": 4}
 HEAD = {"categorical": 0, "gaussian": 1, "greedy_q": 2, "deterministic": 3}
-LOSS = {"ppo": 0, "value_mse": 1, "a2c": 3, "reinforce": 4, "logpdf_bc": 5, "mse_action": 6}
+LOSS = {"ppo": 0, "value_mse": 1, "a2c": 3, "reinforce": 4, "logpdf_bc": 5, "mse_action": 6, "lagrange_ppo": 7}
 INFO = {"loss": 0, "grad_norm": 1, "entropy": 2, "kl": 3, "clip_fraction": 4, "avg_advantage": 5, "avg_return": 6,
-        "batches_trained": 7, "epochs_run": 8, "q1avg": 9, "q2avg": 10, "alpha": 11}
+        "batches_trained": 7, "epochs_run": 8, "q1avg": 9, "q2avg": 10, "alpha": 11, "penalty": 12, "cur_cost": 13, "cost_loss": 14, "p_loss": 15}
 INFO_N = 16
 PROF = {"rollout": 0, "values": 1, "gae": 2, "whiten": 3, "train_actor": 4, "train_critic": 5, "per_scan": 6,
         "per_search": 7, "gather": 8, "td_step": 9}

@@ -412,7 +412,7 @@ class Adam:
 # --------------------------------------------------------------------------------------------------------------
 # experience buffer (src/experience_buffer.jl)
 # --------------------------------------------------------------------------------------------------------------
-_F32_KEYS = ["return", "logprob", "advantage", "value"]
+_F32_KEYS = ["return", "logprob", "advantage", "value", "cost", "cost_advantage", "cost_return"]
 
 
 def _np_dtype(key, act_kind):
@@ -769,9 +769,10 @@ class GaussianNoiseExplorationPolicy:
 class Sampler:
     """Sampler(mdp, agent; max_steps, required_columns, lambda, S) (src/sampler.jl:1-29) for mdp.n_envs environments."""
 
-    def __init__(self, mdp, agent, S=None, max_steps=100, required_columns=(), lam=float("nan"), ctx=None):
+    def __init__(self, mdp, agent, S=None, max_steps=100, required_columns=(), lam=float("nan"), ctx=None, Vc=None):
         self.ctx = ctx or default_context()
         self.mdp = mdp
+        self.Vc = Vc                             # cost value network (Sampler.Vc, src/sampler.jl:20): fill_gae!(..., source=:cost, target=:cost_advantage) (:65)
         self.agent = agent if isinstance(agent, PolicyParams) else PolicyParams(agent)
         self.S = S or mdp.state_space()
         self.max_steps, self.required_columns = int(max_steps), list(required_columns)
@@ -846,7 +847,7 @@ def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=N
 def _fill_block(sampler, buffer, first, Nsteps, reset):
     """terminate_episode!'s fill_gae! / fill_returns! (src/sampler.jl:56-57) on the rows [first, first + Nsteps) mod capacity of `buffer`."""
     if Nsteps > buffer.capacity:
-        if buffer.haskey("advantage") or buffer.haskey("return"):
+        if buffer.haskey("advantage") or buffer.haskey("return") or buffer.haskey("cost_advantage") or buffer.haskey("cost_return"):
             raise L.CruxError(L.EINVAL, "steps!: a block of %d transitions does not fit the buffer (capacity %d) whose :advantage / :return columns it must fill" % (Nsteps, buffer.capacity))
         return
     lib = buffer.ctx.lib
@@ -854,6 +855,15 @@ def _fill_block(sampler, buffer, first, Nsteps, reset):
         buffer.ctx.check(lib.crux_fill_gae_rows(buffer.h, critic(sampler.agent.pi).h, float(sampler.lam), float(sampler.gamma), int(first), int(Nsteps), int(Nsteps // sampler.n_envs), 1 if reset else 0))
     if buffer.haskey("return"):
         buffer.ctx.check(lib.crux_fill_returns_rows(buffer.h, float(sampler.gamma), int(first), int(Nsteps), int(Nsteps // sampler.n_envs), 1 if reset else 0))
+    # cost constraints (sampler.jl:65-66)
+    if buffer.haskey("cost_advantage"):
+        if sampler.Vc is None:
+            raise L.CruxError(L.EINVAL, "steps!: the buffer has a :cost_advantage column but the sampler has no Vc")
+        buffer.ctx.check(lib.crux_fill_gae_rows_keys(buffer.h, sampler.Vc.h, float(sampler.lam), float(sampler.gamma), int(first), int(Nsteps), int(Nsteps // sampler.n_envs),
+                                                     1 if reset else 0, L.COL["cost"], L.COL["cost_advantage"]))
+    if buffer.haskey("cost_return"):
+        buffer.ctx.check(lib.crux_fill_returns_rows_keys(buffer.h, float(sampler.gamma), int(first), int(Nsteps), int(Nsteps // sampler.n_envs), 1 if reset else 0,
+                                                         L.COL["cost"], L.COL["cost_return"]))
 
 
 def episodes_(sampler, Neps=1, explore=False, i=0, seed_offset=0x45564C):
@@ -945,6 +955,8 @@ ppo_loss = _Loss("ppo")            # src/model_free/rl/ppo.jl:4-21
 value_mse_loss = _Loss("value_mse")  # (pi, P, D) -> Flux.mse(value(pi, D[:s]), D[:return])  ppo.jl:60
 a2c_loss = _Loss("a2c")            # src/model_free/rl/a2c.jl:4-15
 reinforce_loss = _Loss("reinforce")  # src/model_free/rl/reinforce.jl:4-13
+lagrange_ppo_loss = _Loss("lagrange_ppo")   # src/model_free/rl/ppo.jl:70-131; P carries the penalty controller ("lagrange": _lib.Lagrange)
+cost_value_mse_loss = _Loss("cost_value_mse")   # (pi, P, D) -> Flux.mse(value(pi, D[:s]), D[:cost_return]) (ppo.jl:210)
 
 
 class CustomLoss(_Loss):
@@ -1058,7 +1070,10 @@ def _batch_train_seam(pi, p, P, D, info, perms):
 
 def _train_cfg(pi, p, P):
     cfg = L.TrainCfg()
-    cfg.loss = L.LOSS[p.loss.name]
+    if p.loss.name == "cost_value_mse":              # Flux.mse(value(pi, D[:s]), D[:cost_return]) (ppo.jl:210): the critic loss against another column
+        cfg.loss, cfg.target_col = L.LOSS["value_mse"], L.COL["cost_return"]
+    else:
+        cfg.loss = L.LOSS[p.loss.name]
     cfg.head = L.HEAD.get(getattr(pi, "head", "deterministic"), 3)
     cfg.batch_size, cfg.epochs = p.batch_size, p.epochs
     cfg.max_batches = 0 if p.max_batches in (None, math.inf) else int(p.max_batches)
@@ -1075,8 +1090,11 @@ def _info_dict(p, raw, extra=True):
     if p.loss.name in ("a2c", "reinforce"):
         for k in ("entropy", "kl"):
             d[k] = float(raw[L.INFO[k]])
-    if p.loss.name == "ppo":
+    if p.loss.name in ("ppo", "lagrange_ppo"):
         for k in ("entropy", "kl", "clip_fraction", "avg_advantage", "avg_return"):
+            d[k] = float(raw[L.INFO[k]])
+    if p.loss.name == "lagrange_ppo":                                                  # info["penalty"], ["cur_cost"], ["cost_loss"], ["p_loss"] (ppo.jl:111-127)
+        for k in ("penalty", "cur_cost", "cost_loss", "p_loss"):
             d[k] = float(raw[L.INFO[k]])
     return d
 
@@ -1115,7 +1133,10 @@ def batch_train_(pi, p, P, D, info=None, perms=None):
             raise ValueError("batch_train!: perms must have shape (epochs, length(D))")
     raw = np.zeros(L.INFO_N, np.float32)
     ep = np.zeros((p.epochs, L.INFO_N), np.float32)
-    pi.ctx.check(pi.ctx.lib.crux_batch_train(pi.h, D.h, C.byref(cfg), _vp(pp), _vp(raw), _vp(ep)))
+    if p.loss.name == "lagrange_ppo":
+        pi.ctx.check(pi.ctx.lib.crux_batch_train_lagrange(pi.h, D.h, C.byref(cfg), C.byref(P["lagrange"]), _vp(pp), _vp(raw), _vp(ep)))
+    else:
+        pi.ctx.check(pi.ctx.lib.crux_batch_train(pi.h, D.h, C.byref(cfg), _vp(pp), _vp(raw), _vp(ep)))
     p.shuffle_counter += int(raw[L.INFO["epochs_run"]])
     info = info if info is not None else {}
     info.update(_info_dict(p, raw))
@@ -1133,7 +1154,8 @@ class OnPolicySolver:
     (src/model_free/on_policy.jl:31-54)."""
 
     def __init__(self, agent, S, N=1000, dN=200, max_steps=100, a_opt=None, c_opt=None, P=None, lambda_gae=0.95,
-                 required_columns=(), post_batch_callback=None, post_sample_callback=None, i=0, log=None):
+                 required_columns=(), post_batch_callback=None, post_sample_callback=None, i=0, log=None, Vc=None, cost_opt=None):
+        self.Vc, self.cost_opt = Vc, cost_opt      # cost constraints: a separate value network and its TrainingParams (on_policy.jl:50-53)
         self.agent, self.S, self.N, self.dN, self.max_steps = agent, S, int(N), int(dN), int(max_steps)
         self.a_opt, self.c_opt, self.P = a_opt, c_opt, P or {}
         self.lambda_gae, self.required_columns = np.float32(lambda_gae), list(required_columns)
@@ -1149,6 +1171,15 @@ def policy_gradient_training(solver, D, perms_a=None, perms_c=None):
     A, Cn, pa, pc = actor(solver.agent.pi), critic(solver.agent.pi), solver.a_opt, solver.c_opt
     if pc is None:
         return batch_train_(A, pa, solver.P, D, info=info, perms=perms_a)
+    if pa.loss.name == "lagrange_ppo" or getattr(solver, "cost_opt", None) is not None or _uses_seam(pa) or _uses_seam(pc):
+        # the sequential form of on_policy.jl:63-76: actor, critic, then the cost critic (the penalty controller rides in the actor's learner kernel)
+        batch_train_(A, pa, solver.P, D, info=info, perms=perms_a)
+        ci = batch_train_(Cn, pc, solver.P, D, info={}, perms=perms_c)
+        info.update({k: v for k, v in ci.items() if k.startswith(pc.name)})
+        if getattr(solver, "cost_opt", None) is not None:
+            vi = batch_train_(solver.Vc, solver.cost_opt, solver.P, D, info={})
+            info.update({k: v for k, v in vi.items() if k.startswith(solver.cost_opt.name)})
+        return info
     _ensure_opt(A, pa); _ensure_opt(Cn, pc)
     ca, cc = _train_cfg(A, pa, solver.P), _train_cfg(Cn, pc, solver.P)
     ra, rc_ = np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32)
@@ -1213,7 +1244,7 @@ def solve(solver, mdp):
     if solver.buffer is None:
         solver.buffer = ExperienceBuffer(solver.S, solver.agent.space, solver.dN, solver.required_columns)
         solver.sampler = Sampler(mdp, solver.agent, S=solver.S, required_columns=solver.required_columns, lam=solver.lambda_gae,
-                                 max_steps=solver.max_steps)
+                                 max_steps=solver.max_steps, Vc=getattr(solver, "Vc", None))
     D, s = solver.buffer, solver.sampler
     stop = solver.i + solver.N - solver.dN
     i = solver.i
@@ -1242,6 +1273,23 @@ def PPO(pi, S, eps=0.2, lambda_p=1.0, lambda_e=0.1, target_kl=0.012, a_opt=None,
     return OnPolicySolver(agent=PolicyParams(pi), S=S, P={"eps": eps, "lambda_p": lambda_p, "lambda_e": lambda_e},
                           a_opt=TrainingParams(loss=ppo_loss, target_kl=target_kl, name="actor_", **a_opt),
                           c_opt=TrainingParams(loss=value_mse_loss, name="critic_", **c_opt),
+                          post_batch_callback=lambda D, info: whiten_(D, "advantage"),
+                          required_columns=cols, **kw)
+
+
+def LagrangePPO(pi, Vc, S, eps=0.2, lambda_p=1.0, lambda_e=0.1, lambda_gae=0.95, target_kl=0.012, target_cost=0.025, penalty_scale=1.0, penalty_max=math.inf,
+                Ki_max=10.0, Ki=1e-3, Kp=1.0, Kd=0.0, ema_alpha=0.95, a_opt=None, c_opt=None, cost_opt=None, required_columns=(), **kw):
+    """LagrangePPO(; pi::ActorCritic, Vc::ContinuousNetwork, ...) (src/model_free/rl/ppo.jl:138-215): PPO whose actor loss carries a PID-controlled cost
+    penalty (lagrange_ppo_loss, :70-131), a cost critic Vc regressed on :cost_return, and the cost columns filled by the sampler (sampler.jl:65-66,114).
+    The controller's state (I, Jc_prev, smooth_delta, smooth_Jc: the one-element arrays of P, :192-201) lives in P["lagrange"]."""
+    a_opt, c_opt, cost_opt = dict(a_opt or {}), dict(c_opt or {}), dict(cost_opt or {})
+    lag = L.Lagrange(); lag.target_cost, lag.penalty_max, lag.Ki_max, lag.Ki, lag.Kp, lag.Kd, lag.ema_alpha = target_cost, penalty_max, Ki_max, Ki, Kp, Kd, ema_alpha
+    cols = list(dict.fromkeys(list(required_columns) + ["return", "advantage", "logprob", "cost_advantage", "cost", "cost_return"]))
+    return OnPolicySolver(agent=PolicyParams(pi), S=S, P={"eps": eps, "lambda_p": lambda_p, "lambda_e": lambda_e, "lagrange": lag, "penalty_scale": penalty_scale},
+                          Vc=Vc, lambda_gae=lambda_gae,
+                          a_opt=TrainingParams(loss=lagrange_ppo_loss, target_kl=target_kl, name="actor_", **a_opt),
+                          c_opt=TrainingParams(loss=value_mse_loss, name="critic_", **c_opt),
+                          cost_opt=TrainingParams(loss=cost_value_mse_loss, name="cost_critic_", **cost_opt),
                           post_batch_callback=lambda D, info: whiten_(D, "advantage"),
                           required_columns=cols, **kw)
 

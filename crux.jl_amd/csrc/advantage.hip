@@ -102,6 +102,9 @@ __global__ void k_first_episode_metrics(const float* __restrict__ r, const uint8
   und[e] = u; dis[e] = d; len[e] = stop + 1;
 }
 
+// a Float32 one-row column that exists (fill_gae!/fill_returns! `source=` / `target=` keywords, sampler.jl:65-66,255,275)
+static bool f32_scalar_col(const crux_buffer* b, int k) { return (k == CRUX_COL_R || has_col(b, k)) && col_rows(b, k) == 1 && col_elem(b, k) == 4; }
+
 extern "C" {
 
 int32_t crux_first_episode_metrics(crux_buffer* b, int32_t n_envs, int64_t T, float gamma, float* undisc, float* disc, int64_t* length, uint8_t* complete) {
@@ -122,10 +125,10 @@ int32_t crux_first_episode_metrics(crux_buffer* b, int32_t n_envs, int64_t T, fl
   return CRUX_OK;
 }
 
-int32_t crux_fill_gae(crux_buffer* b, crux_mlp* critic, float lambda, float gamma) {
+int32_t crux_fill_gae_keys(crux_buffer* b, crux_mlp* critic, float lambda, float gamma, int32_t source, int32_t target) {
   if (!b || !critic) return CRUX_EINVAL;
   crux_ctx* c = b->ctx;
-  if (!has_col(b, CRUX_COL_ADVANTAGE)) return crux_fail(c, CRUX_EINVAL, "fill_gae!: buffer has no :advantage column");
+  if (!f32_scalar_col(b, source) || !f32_scalar_col(b, target)) return crux_fail(c, CRUX_EINVAL, "fill_gae!: buffer lacks the source / target column (%d -> %d)", source, target);
   if (critic->nd.dims[critic->nd.L] != 1 || critic->nd.dims[0] != b->obs_dim) return crux_fail(c, CRUX_EINVAL, "fill_gae!: critic must map obs(%d) -> 1 (@assert length(Vs) == 1)", b->obs_dim);
   const int64_t n = b->elements; if (n == 0) return CRUX_OK;
   const size_t vb = ((4 * (size_t)n + 255) / 256) * 256;
@@ -138,8 +141,8 @@ int32_t crux_fill_gae(crux_buffer* b, crux_mlp* critic, float lambda, float gamm
   rc = values(critic, (const float*)b->col[CRUX_COL_SP], n, Vsp); if (rc) return rc;
   crux_prof_end(c, CRUX_PROF_VALUES);
   crux_prof_begin(c, CRUX_PROF_GAE);
-  hipLaunchKernelGGL(k_gae_returns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE],
-                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], Vs, Vsp, lambda, gamma, n, (float*)b->col[CRUX_COL_ADVANTAGE], (float*)nullptr, flag);
+  hipLaunchKernelGGL(k_gae_returns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[source], (const uint8_t*)b->col[CRUX_COL_DONE],
+                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], Vs, Vsp, lambda, gamma, n, (float*)b->col[target], (float*)nullptr, flag);
   crux_prof_end(c, CRUX_PROF_GAE);
   rc = crux_launch_check(c, "k_gae_returns"); if (rc) return rc;
   int32_t h = 0;
@@ -148,6 +151,7 @@ int32_t crux_fill_gae(crux_buffer* b, crux_mlp* critic, float lambda, float gamm
   if (h) return crux_fail(c, CRUX_ENAN, "fill_gae!: NaN advantage (@assert !isnan(A))");
   return CRUX_OK;
 }
+int32_t crux_fill_gae(crux_buffer* b, crux_mlp* critic, float lambda, float gamma) { return crux_fill_gae_keys(b, critic, lambda, gamma, CRUX_COL_R, CRUX_COL_ADVANTAGE); }
 
 // fill_gae! + fill_returns! for n buffers (the tail of a batched rollout): everything is enqueued, ONE host synchronisation reads the n NaN flags
 int32_t crux_fill_gae_multi(int32_t n, crux_buffer* const* bufs, crux_mlp* const* critics, float lambda, float gamma, int32_t with_returns) {
@@ -222,10 +226,10 @@ int32_t crux_whiten_multi(int32_t n, crux_buffer* const* bufs, int32_t key) {
 
 // fill_gae!(data, ep, V, lambda, gamma) / fill_returns!(data, ep, gamma) as terminate_episode! applies them to the block a steps! call just
 // produced (sampler.jl:53-57,140-148), on the ring rows [first_row, first_row + n_rows) mod capacity that the block was pushed to.
-int32_t crux_fill_gae_rows(crux_buffer* b, crux_mlp* critic, float lambda, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last) {
+int32_t crux_fill_gae_rows_keys(crux_buffer* b, crux_mlp* critic, float lambda, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last, int32_t source, int32_t target) {
   if (!b || !critic) return CRUX_EINVAL;
   crux_ctx* c = b->ctx;
-  if (!has_col(b, CRUX_COL_ADVANTAGE)) return crux_fail(c, CRUX_EINVAL, "fill_gae!: buffer has no :advantage column");
+  if (!f32_scalar_col(b, source) || !f32_scalar_col(b, target)) return crux_fail(c, CRUX_EINVAL, "fill_gae!: buffer lacks the source / target column (%d -> %d)", source, target);
   if (critic->nd.dims[critic->nd.L] != 1 || critic->nd.dims[0] != b->obs_dim) return crux_fail(c, CRUX_EINVAL, "fill_gae!: critic must map obs(%d) -> 1 (@assert length(Vs) == 1)", b->obs_dim);
   const int64_t C = b->capacity, n = n_rows;
   if (first_row < 0 || first_row >= C || n < 0 || n > C) return crux_fail(c, CRUX_EINVAL, "fill_gae!: rows [%lld, +%lld) outside the ring of %lld", (long long)first_row, (long long)n, (long long)C);
@@ -243,8 +247,8 @@ int32_t crux_fill_gae_rows(crux_buffer* b, crux_mlp* critic, float lambda, float
     rc = values(critic, (const float*)b->col[CRUX_COL_SP], n2, Vsp + n1); if (rc) return rc; }
   crux_prof_end(c, CRUX_PROF_VALUES);
   crux_prof_begin(c, CRUX_PROF_GAE);
-  hipLaunchKernelGGL(k_gae_returns_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE],
-                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], (const float*)Vs, (const float*)Vsp, lambda, gamma, n, (float*)b->col[CRUX_COL_ADVANTAGE], (float*)nullptr, flag,
+  hipLaunchKernelGGL(k_gae_returns_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[source], (const uint8_t*)b->col[CRUX_COL_DONE],
+                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], (const float*)Vs, (const float*)Vsp, lambda, gamma, n, (float*)b->col[target], (float*)nullptr, flag,
                      first_row, C, close_last ? 1 : 0, rows_per_env);
   crux_prof_end(c, CRUX_PROF_GAE);
   rc = crux_launch_check(c, "k_gae_returns_rows"); if (rc) return rc;
@@ -254,36 +258,39 @@ int32_t crux_fill_gae_rows(crux_buffer* b, crux_mlp* critic, float lambda, float
   if (h) return crux_fail(c, CRUX_ENAN, "fill_gae!: NaN advantage (@assert !isnan(A))");
   return CRUX_OK;
 }
-int32_t crux_fill_returns_rows(crux_buffer* b, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last) {
+int32_t crux_fill_gae_rows(crux_buffer* b, crux_mlp* critic, float lambda, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last) { return crux_fill_gae_rows_keys(b, critic, lambda, gamma, first_row, n_rows, rows_per_env, close_last, CRUX_COL_R, CRUX_COL_ADVANTAGE); }
+int32_t crux_fill_returns_rows_keys(crux_buffer* b, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last, int32_t source, int32_t target) {
   if (!b) return CRUX_EINVAL;
   crux_ctx* c = b->ctx;
-  if (!has_col(b, CRUX_COL_RETURN)) return crux_fail(c, CRUX_EINVAL, "fill_returns!: buffer has no :return column");
+  if (!f32_scalar_col(b, source) || !f32_scalar_col(b, target)) return crux_fail(c, CRUX_EINVAL, "fill_returns!: buffer lacks the source / target column (%d -> %d)", source, target);
   const int64_t C = b->capacity, n = n_rows;
   if (first_row < 0 || first_row >= C || n < 0 || n > C) return crux_fail(c, CRUX_EINVAL, "fill_returns!: rows [%lld, +%lld) outside the ring of %lld", (long long)first_row, (long long)n, (long long)C);
   if (n == 0) return CRUX_OK;
   int32_t* flag = (int32_t*)crux_scratch(c, 256);
   if (!flag) return crux_fail(c, CRUX_ENOMEM, "fill_returns!: scratch");
   crux_prof_begin(c, CRUX_PROF_GAE);
-  hipLaunchKernelGGL(k_gae_returns_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE],
-                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], (const float*)nullptr, (const float*)nullptr, 0.f, gamma, n, (float*)nullptr, (float*)b->col[CRUX_COL_RETURN], flag,
+  hipLaunchKernelGGL(k_gae_returns_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[source], (const uint8_t*)b->col[CRUX_COL_DONE],
+                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], (const float*)nullptr, (const float*)nullptr, 0.f, gamma, n, (float*)nullptr, (float*)b->col[target], flag,
                      first_row, C, close_last ? 1 : 0, rows_per_env);
   crux_prof_end(c, CRUX_PROF_GAE);
   return crux_launch_check(c, "k_gae_returns_rows");
 }
+int32_t crux_fill_returns_rows(crux_buffer* b, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last) { return crux_fill_returns_rows_keys(b, gamma, first_row, n_rows, rows_per_env, close_last, CRUX_COL_R, CRUX_COL_RETURN); }
 
-int32_t crux_fill_returns(crux_buffer* b, float gamma) {
+int32_t crux_fill_returns_keys(crux_buffer* b, float gamma, int32_t source, int32_t target) {
   if (!b) return CRUX_EINVAL;
   crux_ctx* c = b->ctx;
-  if (!has_col(b, CRUX_COL_RETURN)) return crux_fail(c, CRUX_EINVAL, "fill_returns!: buffer has no :return column");
+  if (!f32_scalar_col(b, source) || !f32_scalar_col(b, target)) return crux_fail(c, CRUX_EINVAL, "fill_returns!: buffer lacks the source / target column (%d -> %d)", source, target);
   const int64_t n = b->elements; if (n == 0) return CRUX_OK;
   int32_t* flag = (int32_t*)crux_scratch(c, 256);
   if (!flag) return crux_fail(c, CRUX_ENOMEM, "fill_returns!: scratch");
   crux_prof_begin(c, CRUX_PROF_GAE);
-  hipLaunchKernelGGL(k_gae_returns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_R], (const uint8_t*)b->col[CRUX_COL_DONE],
-                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], (const float*)nullptr, (const float*)nullptr, 0.f, gamma, n, (float*)nullptr, (float*)b->col[CRUX_COL_RETURN], flag);
+  hipLaunchKernelGGL(k_gae_returns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[source], (const uint8_t*)b->col[CRUX_COL_DONE],
+                     (const uint8_t*)b->col[CRUX_COL_EPISODE_END], (const float*)nullptr, (const float*)nullptr, 0.f, gamma, n, (float*)nullptr, (float*)b->col[target], flag);
   crux_prof_end(c, CRUX_PROF_GAE);
   return crux_launch_check(c, "k_gae_returns");
 }
+int32_t crux_fill_returns(crux_buffer* b, float gamma) { return crux_fill_returns_keys(b, gamma, CRUX_COL_R, CRUX_COL_RETURN); }
 
 int32_t crux_whiten(crux_buffer* b, int32_t key) {
   if (!b) return CRUX_EINVAL;

@@ -78,6 +78,13 @@ __device__ __forceinline__ void synth_step(int so, int sa, bool discrete, const 
   *r = (float)__dadd_rn(-(ss / (double)so), __dmul_rn(0.05, sn[0]));
   *done = sn[0] > 0.9 ? 1 : 0;
 }
+// the cost channel of the restated environments (include/cruxhip.h): info["cost"] of the step that reached s' (sampler.jl:65-66,114)
+__device__ __forceinline__ float env_cost(int kind, int so, const double* sn) {
+  if (env_is_synth(kind)) { const double x = sn[1 % so]; return (float)__dmul_rn(25.0, __dmul_rn(x, x)); }
+  if (kind == CRUX_ENV_CARTPOLE) return fabs(sn[2]) > 0.05 ? 1.f : 0.f;
+  if (kind == CRUX_ENV_PENDULUM) return fabs(sn[1]) > 4.0 ? 1.f : 0.f;
+  return 0.f;
+}
 __device__ __forceinline__ void env_obs(int kind, const double* s, float* o, int od = 0) {
   if (kind == CRUX_ENV_CARTPOLE) { o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3]; }
   else if (kind == CRUX_ENV_PENDULUM) { o[0] = (float)cos(s[0]); o[1] = (float)sin(s[0]); o[2] = (float)s[1]; }
@@ -113,6 +120,7 @@ struct RolloutArgs {
   const float* mu; const float* sigma;
   double* state; int64_t* ep_len; int64_t* n_resets; int64_t* steps_taken; float* svec; double* acc;
   float* S; void* A; float* SP; float* R; uint8_t* D; uint8_t* EE; float* LP; int64_t* TT; int64_t* II; float* W; float* RET; float* ADV;
+  float* COST; float* CADV; float* CRET;      // :cost, :cost_advantage, :cost_return (cost-constrained solvers; NULL = absent)
   int64_t base, C, T;
   crux_rollout_cfg cfg;
   float squash;      // SquashedGaussianPolicy ascale, 0 = GaussianPolicy
@@ -197,6 +205,9 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
         if (a.W) a.W[j] = 1.0f;
         if (a.RET) a.RET[j] = 0.f;
         if (a.ADV) a.ADV[j] = 0.f;
+        if (a.COST) a.COST[j] = env_cost(kind, od, sn);                              // data[:cost][1,j] = info["cost"] (sampler.jl:114)
+        if (a.CADV) a.CADV[j] = 0.f;
+        if (a.CRET) a.CRET[j] = 0.f;
       }
       sum_r += (double)r; steps_taken += 1;
       // ---- episode bookkeeping (sampler.jl:130-136; terminate_episode! :53-69)
@@ -483,6 +494,8 @@ static void fill_rollout_args(RolloutArgs& a, crux_env* e, crux_mlp* policy, con
   a.LP = has_col(buf, CRUX_COL_LOGPROB) ? (float*)buf->col[CRUX_COL_LOGPROB] : nullptr; a.TT = has_col(buf, CRUX_COL_T) ? (int64_t*)buf->col[CRUX_COL_T] : nullptr;
   a.II = has_col(buf, CRUX_COL_I) ? (int64_t*)buf->col[CRUX_COL_I] : nullptr; a.W = has_col(buf, CRUX_COL_WEIGHT) ? (float*)buf->col[CRUX_COL_WEIGHT] : nullptr;
   a.RET = has_col(buf, CRUX_COL_RETURN) ? (float*)buf->col[CRUX_COL_RETURN] : nullptr; a.ADV = has_col(buf, CRUX_COL_ADVANTAGE) ? (float*)buf->col[CRUX_COL_ADVANTAGE] : nullptr;
+  a.COST = has_col(buf, CRUX_COL_COST) ? (float*)buf->col[CRUX_COL_COST] : nullptr; a.CADV = has_col(buf, CRUX_COL_COST_ADVANTAGE) ? (float*)buf->col[CRUX_COL_COST_ADVANTAGE] : nullptr;
+  a.CRET = has_col(buf, CRUX_COL_COST_RETURN) ? (float*)buf->col[CRUX_COL_COST_RETURN] : nullptr;
   a.base = buf->next_ind; a.C = buf->capacity; a.T = T; a.cfg = *cfg; a.squash = policy->squash;
 }
 

@@ -17,7 +17,7 @@ enum {
   OP_PER_SEARCH, OP_UNIFORM_IDS, OP_GATHER_RING_ALL, OP_RING_IDS, OP_LEAF_REFRESH, OP_TREE_TOUCH, OP_PER_UPDATE, OP_DQN_TARGET, OP_TD_ERROR, OP_POLYAK, OP_COPY_F32, OP_ADAM_ADVANCE
 };
 
-#define CRUX_EXEC_ARG_BYTES 432
+#define CRUX_EXEC_ARG_BYTES 496
 struct ExecOp { int32_t kid; uint32_t nblocks; int32_t barrier; int32_t pad; alignas(8) unsigned char args[CRUX_EXEC_ARG_BYTES]; };
 
 // ---- argument packs: the parameters of XOp::run after (bid, nblocks), stored by value in declaration order --------------------------------

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_phase(const ExecOp* __restrict__ ops, i
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_exec(const ExecOp* __restrict__ ops, int nops, unsigned* ctr, int xcd, int32_t* status, int flags) {
   if (xcd >= 0 && (int)(blockIdx.x & 7) != xcd) return;
   const unsigned wg = xcd >= 0 ? blockIdx.x >> 3 : blockIdx.x, G = xcd >= 0 ? gridDim.x >> 3 : gridDim.x;
-  // op records are staged through LDS one op ahead: the 448-byte record of op o+1 is fetched while op o runs and its barrier is waited for, so
+  // op records are staged through LDS one op ahead: the 512-byte record of op o+1 is fetched while op o runs and its barrier is waited for, so
   // dispatch reads its arguments from LDS instead of paying two dependent L2 round trips per op (1.5 us measured, tools/dbg_nops.py)
   __shared__ ExecOp op_s[2];
   constexpr int OPW = (int)(sizeof(ExecOp) / 4);

@@ -65,6 +65,11 @@ static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const cr
     else if (cfg->head == CRUX_HEAD_GAUSSIAN) { if (nout != buf->act_dim || buf->act_kind != CRUX_ACTION_CONTINUOUS || net->nd.n_extra != buf->act_dim) return crux_fail(c, CRUX_EINVAL, "ppo_loss: gaussian head needs %d means + %d logSigma extras over a Float32 action column", buf->act_dim, buf->act_dim); }
     else return crux_fail(c, CRUX_EINVAL, "ppo_loss: head %d unsupported", cfg->head);
   } else if (internal_loss == CRUX_LOSS_VALUE_MSE) {
+    if (cfg->target_col > 0) {          // Flux.mse(value(pi, s), D[:cost_return]) (ppo.jl:210)
+      const int k = cfg->target_col;
+      if (!has_col(buf, k) || col_rows(buf, k) != 1 || col_elem(buf, k) != 4) return crux_fail(c, CRUX_EINVAL, "critic mse: target column %d is not a Float32 row of this buffer", k);
+      a.RET = (const float*)buf->col[k];
+    }
     if (!a.RET || nout != 1) return crux_fail(c, CRUX_EINVAL, "critic mse: needs a :return column and a scalar-output network");
   } else if (internal_loss == CRUX_LOSS_MSE_ACTION && net->squash > 0.f) {
     return crux_fail(c, CRUX_EUNSUP, "mse_action_loss through a SquashedGaussianPolicy (ascale*tanh(mu)) is not implemented");
@@ -205,6 +210,34 @@ int32_t crux_batch_train(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* 
   }
   rc = run_batch(net, buf, a, cfg->epochs, info_out, epoch_infos, true);
   if (d_perms) { (void)hipStreamSynchronize(c->stream); (void)hipFree(d_perms); }
+  return rc;
+}
+
+// batch_train!(actor, a_opt, P, D) with lagrange_ppo_loss (rl/ppo.jl:70-131,208): ppo_loss's learner with the PID state riding in the kernel
+int32_t crux_batch_train_lagrange(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, crux_lagrange* lag, const int64_t* perms, float* info_out, float* epoch_infos) {
+  if (!net || !buf || !cfg || !lag) return CRUX_EINVAL;
+  crux_ctx* c = net->ctx;
+  if (cfg->loss != CRUX_LOSS_LAGRANGE_PPO) return crux_fail(c, CRUX_EINVAL, "batch_train! (lagrange): cfg.loss must be CRUX_LOSS_LAGRANGE_PPO");
+  if (buf->elements <= 0 || cfg->epochs < 1) return crux_fail(c, CRUX_EINVAL, "batch_train! (lagrange): empty buffer or epochs %d", cfg->epochs);
+  if (!has_col(buf, CRUX_COL_COST) || !has_col(buf, CRUX_COL_COST_ADVANTAGE)) return crux_fail(c, CRUX_EINVAL, "lagrange_ppo_loss: buffer needs :cost and :cost_advantage columns (ppo.jl:211)");
+  if (c->peer_n > 1) return crux_fail(c, CRUX_EUNSUP, "lagrange_ppo_loss with a replica group attached: the penalty update is not part of the exchange yet");
+  TrainArgs a; int32_t rc = fill_args(a, net, buf, cfg, CRUX_LOSS_PPO); if (rc) return rc;
+  if (!c->lag_dev) { if (hipMalloc(&c->lag_dev, 256) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "lagrange state"); }
+  HIPCHK(c, hipMemcpyAsync(c->lag_dev, lag, sizeof *lag, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));         // `lag` is caller memory
+  a.lag = (crux_lagrange*)c->lag_dev; a.COST = (const float*)buf->col[CRUX_COL_COST]; a.CADV = (const float*)buf->col[CRUX_COL_COST_ADVANTAGE]; a.EE = (const uint8_t*)buf->col[CRUX_COL_EPISODE_END];
+  int64_t* d_perms = nullptr;
+  if (perms) {
+    const int64_t len = buf->elements;
+    for (int64_t i = 0; i < (int64_t)cfg->epochs * len; ++i) if (perms[i] < 0 || perms[i] >= len) return crux_fail(c, CRUX_EINVAL, "batch_train!: perms[%lld] out of range", (long long)i);
+    if (hipMalloc(&d_perms, 8 * (size_t)cfg->epochs * (size_t)len) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "batch_train!: perms");
+    if (hipMemcpyAsync(d_perms, perms, 8 * (size_t)cfg->epochs * (size_t)len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipFree(d_perms); return crux_fail(c, CRUX_EHIP, "batch_train!: perms upload"); }
+    a.perms = d_perms;
+  }
+  rc = run_batch(net, buf, a, cfg->epochs, info_out, epoch_infos, true);
+  (void)hipMemcpyAsync(lag, c->lag_dev, sizeof *lag, hipMemcpyDeviceToHost, c->stream);     // the state advanced by the minibatches that ran (also after CRUX_ENAN, like the reference's P)
+  (void)hipStreamSynchronize(c->stream);
+  if (d_perms) (void)hipFree(d_perms);
   return rc;
 }
 

@@ -39,6 +39,10 @@ __device__ __forceinline__ void train_generic_run(const TrainArgs& a, float* sm,
   float info[CRUX_INFO_N];
 #pragma unroll
   for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
+  // lagrange_ppo_loss: every thread carries an identical copy of the PID state (ppo.jl:192-201)
+  const bool lagr = a.lag != nullptr;
+  crux_lagrange lg{}; if (lagr) lg = *a.lag;
+  float pen = 0.f;
 
   const int n_epochs = a.ids ? 1 : a.epochs;
   if (!a.ids && !a.ord_all) { for (int64_t j = tid; j < a.len; j += 256) order_cur[j] = (int32_t)j; __syncthreads(); }
@@ -68,7 +72,21 @@ __device__ __forceinline__ void train_generic_run(const TrainArgs& a, float* sm,
       const int nb = (int)((total_rows - st) < a.bs ? (total_rows - st) : a.bs);
       const float invB = 1.0f / (float)nb;
       for (int i = tid; i < nd.n_params; i += 256) a.g[i] = 0.f;
-      double s_lossp = 0, s_H = 0, s_kl = 0, s_adv = 0, s_ret = 0, s_clip = 0, s_sq = 0, s_q = 0;
+      double s_lossp = 0, s_H = 0, s_kl = 0, s_adv = 0, s_ret = 0, s_clip = 0, s_sq = 0, s_q = 0, s_cost = 0;
+      if (lagr) {   // the penalty update inside the loss (ppo.jl:80-116): it reads only the minibatch's :cost and :episode_end, so it runs ahead of the passes
+        double sc_ = 0.0, ne_ = 0.0;
+        for (int i = tid; i < nb; i += 256) { const int64_t row = a.ids ? (int64_t)a.ids[st + i] : (int64_t)order_cur[st + i]; sc_ += (double)a.COST[row]; ne_ += a.EE[row] ? 1.0 : 0.0; }
+        const double t_sc = block_sum_d(sc_, red, tid), t_ne = block_sum_d(ne_, red, tid);
+        const float Jc = (float)t_sc / (float)t_ne;                                   // sum(D[:cost]) / sum(D[:episode_end]) (:86): Float32 / Int
+        const float dl = Jc - lg.target_cost;                                         // :91
+        { const float x = lg.I + lg.Ki * dl; lg.I = x > lg.Ki_max ? lg.Ki_max : (x < 0.f ? 0.f : x); }             // :94 clamp(I + Ki*Delta, 0, Ki_max)
+        lg.smooth_delta = (float)(lg.ema_alpha * (double)lg.smooth_delta + (1.0 - lg.ema_alpha) * (double)dl);      // :98 (Float64 arithmetic, Float32 store)
+        lg.smooth_Jc = (float)(lg.ema_alpha * (double)lg.smooth_Jc + (1.0 - lg.ema_alpha) * (double)Jc);            // :99
+        { const float x = lg.smooth_Jc - lg.Jc_prev; lg.deriv_term = (x != x) ? x : (x > 0.f ? x : 0.f); }           // :102 max(0, .) keeps NaN
+        lg.Jc_prev = lg.smooth_Jc;                                                    // :105
+        { const float x = (lg.Kp * lg.smooth_delta + lg.I) + lg.Kd * lg.deriv_term; pen = x > lg.penalty_max ? lg.penalty_max : (x < 0.f ? 0.f : x); }   // :108
+        lg.penalty = pen; lg.cur_cost = Jc;
+      }
       for (int c0 = 0; c0 < nb; c0 += TR_CH) {
         const int ns = (nb - c0) < TR_CH ? (nb - c0) : TR_CH;
         // ---- gather the chunk's observations (minibatch view, experience_buffer.jl:170)
@@ -114,10 +132,13 @@ __device__ __forceinline__ void train_generic_run(const TrainArgs& a, float* sm,
               r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A;
               g = (u <= cl) ? A : 0.f; s_lossp += (double)(a2c ? newlp * A : (u <= cl ? u : cl));
               if (a2c) { g = A; r = 1.f; }                                        // a2c_loss (a2c.jl:4-15): d(-mean(logpdf .* A)); clip statistics off below
-              for (int k = 0; k < nout; ++k) { const float pk = expf(z[k] - mx) / sum; const float lg = logf(pk + EPS32F);
-                const float hk = -lg - pk / (pk + EPS32F);
+              float gcr = 0.f;                                                    // lagrange: d/dr of max(r Ac, clamp(r) Ac) times r (ppo.jl:119)
+              if (lagr) { const float Ac = a.CADV[row]; const float uc = r * Ac, clc = rc * Ac; s_cost += (double)(uc >= clc ? uc : clc); gcr = (uc >= clc ? Ac : 0.f) * r; }
+              for (int k = 0; k < nout; ++k) { const float pk = expf(z[k] - mx) / sum; const float lgk = logf(pk + EPS32F);
+                const float hk = -lgk - pk / (pk + EPS32F);
                 const float dlogpi = pk * ((av[k] ? 1.f : 0.f) / q) - pk;
-                dy[k] = invB * (-a.lambda_p * g * r * dlogpi - a.lambda_e * (pk * (hk - hp))); }
+                const float base = -a.lambda_p * g * r * dlogpi - a.lambda_e * (pk * (hk - hp));
+                dy[k] = lagr ? invB * ((base + pen * gcr * dlogpi) / (1.f + pen)) : invB * base; }
             } else {                                                              // GaussianPolicy policies.jl:333-348
               const float* av = (const float*)a.A + row * a.ad; const float* ls = a.p + nd.xoff;
               const float sq = a.squash;                                         // > 0: SquashedGaussianPolicy (policies.jl:374-396)
@@ -126,10 +147,13 @@ __device__ __forceinline__ void train_generic_run(const TrainArgs& a, float* sm,
               r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A;
               g = (u <= cl) ? A : 0.f; s_lossp += (double)(a2c ? newlp * A : (u <= cl ? u : cl));
               if (a2c) { g = A; r = 1.f; }
+              float cf = -a.lambda_p * g * r;                                     // coefficient of d logpdf in d loss
+              if (lagr) { const float Ac = a.CADV[row]; const float uc = r * Ac, clc = rc * Ac; s_cost += (double)(uc >= clc ? uc : clc);
+                cf = (cf + pen * ((uc >= clc ? Ac : 0.f) * r)) / (1.f + pen); }
               for (int k = 0; k < a.ad; ++k) { const float sg = expf(sq > 0.f ? sq_clampls(ls[k]) : ls[k]); const float s2 = sg * sg; const float uk = sq > 0.f ? sq_untanh(av[k], sq) : av[k]; const float d = uk - z[k];
                 const float inr = (sq > 0.f && !(ls[k] >= -5.f && ls[k] <= 2.f)) ? 0.f : 1.f;    // d clamp/dx
-                dy[k] = invB * (-a.lambda_p * g * r * (d / s2));
-                exs[s * a.ad + k] = invB * (-a.lambda_p * g * r * (((d * d) / s2) * inr - 1.f)); }
+                dy[k] = invB * (cf * (d / s2));
+                exs[s * a.ad + k] = invB * (cf * (((d * d) / s2) * inr - 1.f)); }
             }
             s_H += (double)H; s_kl += (double)(oldlp - newlp); s_adv += (double)A; if (a.RET) s_ret += (double)a.RET[row];
             if (!a2c && (r > hi || r < lo)) s_clip += 1.0;
@@ -161,13 +185,14 @@ __device__ __forceinline__ void train_generic_run(const TrainArgs& a, float* sm,
           float* t = dcur; dcur = dnxt; dnxt = t;
         }
       }
-      if (CRUX_IS_PG(a.loss) && a.head == CRUX_HEAD_GAUSSIAN && tid < a.ad) a.g[nd.xoff + tid] += -a.lambda_e;   // d(-le*H)/dlogSigma, H scalar
+      if (CRUX_IS_PG(a.loss) && a.head == CRUX_HEAD_GAUSSIAN && tid < a.ad) a.g[nd.xoff + tid] += lagr ? -a.lambda_e / (1.f + pen) : -a.lambda_e;   // d(-le*H)/dlogSigma, H scalar
       // ---- reductions: stats and grad norm (utils.jl:49-55)
       double ssq = 0.0; for (int i = tid; i < nd.n_params; i += 256) { const double gi = (double)a.g[i]; ssq += gi * gi; }
       const double t_ssq = block_sum_d(ssq, red, tid);
       const double t_lossp = block_sum_d(s_lossp, red, tid), t_H = block_sum_d(s_H, red, tid), t_kl = block_sum_d(s_kl, red, tid);
       const double t_adv = block_sum_d(s_adv, red, tid), t_ret = block_sum_d(s_ret, red, tid), t_clip = block_sum_d(s_clip, red, tid);
       const double t_sq = block_sum_d(s_sq, red, tid), t_q = block_sum_d(s_q, red, tid);
+      const double t_cost = lagr ? block_sum_d(s_cost, red, tid) : 0.0;
       const float gnorm = (float)sqrt(t_ssq);
 #pragma unroll
       for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
@@ -177,6 +202,9 @@ __device__ __forceinline__ void train_generic_run(const TrainArgs& a, float* sm,
         else { float Hs = 1.4189385332046727f; for (int k = 0; k < a.ad; ++k) Hs += a.p[nd.xoff + k]; entropy = Hs; e_loss = -Hs; }
         info[CRUX_INFO_LOSS] = a.lambda_p * p_loss + a.lambda_e * e_loss; info[CRUX_INFO_ENTROPY] = entropy; info[CRUX_INFO_KL] = (float)(t_kl / (double)nb);
         info[CRUX_INFO_CLIP_FRACTION] = (float)t_clip / (float)nb; info[CRUX_INFO_AVG_ADVANTAGE] = (float)(t_adv / (double)nb); info[CRUX_INFO_AVG_RETURN] = (float)(t_ret / (double)nb);
+        if (lagr) { const float cost_loss = pen * (float)(t_cost / (double)nb);                                    // ppo.jl:119
+          info[CRUX_INFO_LOSS] = ((a.lambda_p * p_loss + a.lambda_e * e_loss) + cost_loss) / (1.f + pen);           // :131
+          info[CRUX_INFO_PENALTY] = pen; info[CRUX_INFO_CUR_COST] = lg.cur_cost; info[CRUX_INFO_COST_LOSS] = cost_loss; info[CRUX_INFO_P_LOSS] = a.lambda_p * p_loss; }
       } else { info[CRUX_INFO_LOSS] = (float)(t_sq / (double)nb); if (a.loss == CRUX_LOSS_TD_INTERNAL) info[2] = (float)(t_q / (double)nb); }
       info[CRUX_INFO_GRAD_NORM] = gnorm;
       if (isnan(gnorm)) { err = CRUX_ENAN; break; }                            // training.jl:20 -- no update
@@ -205,6 +233,7 @@ __device__ __forceinline__ void train_generic_run(const TrainArgs& a, float* sm,
   if (tid == 0) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     a.bp[0] = bp1; a.bp[1] = bp2;
+    if (lagr) *a.lag = lg;
   }
 }
 

@@ -550,6 +550,7 @@ int32_t crux_train_mfma8_launch(crux_ctx* c, const TrainArgs& a, int kind, bool*
 int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream);   // train_mfma_x2.hip
 
 int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream) {
+  if (a.lag) { *handled = false; return CRUX_OK; }     // lagrange_ppo_loss: the penalty controller lives in the generic learner body only
   *handled = false;
   const NetDesc& nd = a.nd;
   if (getenv("CRUX_FORCE_GENERIC")) return CRUX_OK;

@@ -115,7 +115,9 @@ int32_t crux_adam_state_ptrs(crux_mlp* net, float** d_m, float** d_v);
  * device arrays (SoA across keys; one transition's features contiguous within a key).           */
 enum { CRUX_COL_S = 0, CRUX_COL_A = 1, CRUX_COL_SP = 2, CRUX_COL_R = 3, CRUX_COL_DONE = 4,
        CRUX_COL_EPISODE_END = 5, CRUX_COL_RETURN = 6, CRUX_COL_LOGPROB = 7, CRUX_COL_ADVANTAGE = 8,
-       CRUX_COL_WEIGHT = 9, CRUX_COL_T = 10, CRUX_COL_I = 11, CRUX_COL_VALUE = 12, CRUX_NCOLS = 13 };
+       CRUX_COL_WEIGHT = 9, CRUX_COL_T = 10, CRUX_COL_I = 11, CRUX_COL_VALUE = 12,
+       /* cost-constrained solvers (LagrangePPO, rl/ppo.jl:211): info["cost"] of the step (sampler.jl:114), its GAE under the cost critic Vc and its return (:65-66) */
+       CRUX_COL_COST = 13, CRUX_COL_COST_ADVANTAGE = 14, CRUX_COL_COST_RETURN = 15, CRUX_NCOLS = 16 };
 enum { CRUX_ACTION_DISCRETE = 0 /* Bool one-hot, 1 byte each (src/spaces.jl:18,24) */,
        CRUX_ACTION_CONTINUOUS = 1 /* Float32 */ };
 /* column_mask: bit k set => optional column k present (S,A,SP,R,DONE,EPISODE_END always are).   */
@@ -185,7 +187,9 @@ enum { CRUX_ENV_CARTPOLE = 0, CRUX_ENV_PENDULUM = 1, CRUX_ENV_GRIDWORLD = 2,
        CRUX_ENV_SYNTH_DISCRETE = 4 /* the same with synth_act_dim discrete actions (C3-shaped: 8 / 4) */ };
 /* SYNTH (for the configurations whose simulators -- LunarLander, HalfCheetah -- cannot be restated): state x in R^so (Float64),
  * observation Float32(x); u_i = clamp(a[i mod sa], -1, 1) or, for discrete action k, ((i + k) mod sa == 0 ? 1 : -0.25);
- * x'_i = 0.9 x_i + 0.1 sin(x_{(i+1) mod so} + u_i); r = -mean(x'^2) + 0.05 x'_0; done = x'_0 > 0.9; reset x_i ~ U(-0.05, 0.05).              */
+ * x'_i = 0.9 x_i + 0.1 sin(x_{(i+1) mod so} + u_i); r = -mean(x'^2) + 0.05 x'_0; done = x'_0 > 0.9; reset x_i ~ U(-0.05, 0.05).
+ * Cost channel (the info["cost"] a safety-gym style mdp returns from @gen, sampler.jl:65-66,114), written to the :cost column when the buffer has one:
+ * SYNTH 25 x'_{1 mod so}^2 (Float32 of the Float64 product); CartPole 1 when the pole angle |theta'| > 0.05 rad else 0; Pendulum 1 when |thetadot'| > 4 else 0; GridWorld 0.  */
 enum { CRUX_HEAD_CATEGORICAL = 0 /* DiscreteNetwork softmax head (policies.jl:104-157)            */,
        CRUX_HEAD_GAUSSIAN = 1    /* GaussianPolicy, const logSigma extras (policies.jl:315-350)    */,
        CRUX_HEAD_GREEDY_Q = 2    /* action(::DiscreteNetwork) argmax (policies.jl:124)             */,
@@ -251,6 +255,13 @@ int32_t crux_fill_returns(crux_buffer* b, float gamma);
  * (0 = the block is one environment's).                                                                                                          */
 int32_t crux_fill_gae_rows(crux_buffer* b, crux_mlp* critic, float lambda, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last);
 int32_t crux_fill_returns_rows(crux_buffer* b, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last);
+/* the `source=` / `target=` keywords of fill_gae! / fill_returns! (sampler.jl:255,275), as terminate_episode! uses them for cost constraints (:65-66):
+ * fill_gae!(data, ep, Vc, lambda, gamma, source=:cost, target=:cost_advantage), fill_returns!(data, ep, gamma, source=:cost, target=:cost_return).
+ * source / target: CRUX_COL_* of Float32 one-row columns.                                                                                         */
+int32_t crux_fill_gae_keys(crux_buffer* b, crux_mlp* critic, float lambda, float gamma, int32_t source, int32_t target);
+int32_t crux_fill_returns_keys(crux_buffer* b, float gamma, int32_t source, int32_t target);
+int32_t crux_fill_gae_rows_keys(crux_buffer* b, crux_mlp* critic, float lambda, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last, int32_t source, int32_t target);
+int32_t crux_fill_returns_rows_keys(crux_buffer* b, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last, int32_t source, int32_t target);
 /* b[key] .= whiten(b[key]) (utils.jl:41-42; PPO post_batch_callback ppo.jl:61). Bessel-corrected. */
 int32_t crux_whiten(crux_buffer* b, int32_t key);
 
@@ -268,7 +279,8 @@ enum { CRUX_LOSS_PPO = 0      /* ppo_loss with the head's logpdf/entropy (ppo.jl
        CRUX_LOSS_REINFORCE = 4 /* reinforce_loss (reinforce.jl:4-13): -mean(logpdf .* return); entropy and kl are reported only */,
        CRUX_LOSS_LOGPDF_BC = 5 /* logpdf_bc_loss (il/bc.jl:10-18): -mean(logpdf(pi, s, a)) - lambda_e mean(entropy); needs only :s, :a.
                                   info: LOSS, GRAD_NORM, ENTROPY, KL = the -mean(logpdf) term (info[:logpdf])                    */,
-       CRUX_LOSS_MSE_ACTION = 6 /* mse_action_loss (il/bc.jl:1): Flux.mse(action(pi, s), a) for a ContinuousNetwork, mean over act_dim x batch */ };
+       CRUX_LOSS_MSE_ACTION = 6 /* mse_action_loss (il/bc.jl:1): Flux.mse(action(pi, s), a) for a ContinuousNetwork, mean over act_dim x batch */,
+       CRUX_LOSS_LAGRANGE_PPO = 7 /* lagrange_ppo_loss (rl/ppo.jl:70-131): only through crux_batch_train_lagrange (it carries the PID state) */ };
 
 typedef struct {
   int32_t loss;           /* CRUX_LOSS_*                                                          */
@@ -283,14 +295,16 @@ typedef struct {
   uint64_t shuffle_seed;  /* Philox key for epoch permutations when perms==NULL                    */
   uint64_t shuffle_counter; /* first epoch's permutation counter (advanced by the caller)          */
   int32_t sync_every;     /* multi-GPU: host-level gradient exchange period in minibatches (0=off) */
-  int32_t reserved;
+  int32_t target_col;     /* CRUX_LOSS_VALUE_MSE: the Float32 column the value is regressed on; 0 = :return (ppo.jl:60), CRUX_COL_COST_RETURN for LagrangePPO's cost critic (ppo.jl:210) */
 } crux_train_cfg;
 
 /* info keys written by train!/batch_train! (training.jl:22-23,53; ppo.jl:13-19).                   */
 enum { CRUX_INFO_LOSS = 0, CRUX_INFO_GRAD_NORM = 1, CRUX_INFO_ENTROPY = 2, CRUX_INFO_KL = 3,
        CRUX_INFO_CLIP_FRACTION = 4, CRUX_INFO_AVG_ADVANTAGE = 5, CRUX_INFO_AVG_RETURN = 6,
        CRUX_INFO_BATCHES_TRAINED = 7, CRUX_INFO_EPOCHS_RUN = 8, CRUX_INFO_Q1AVG = 9, CRUX_INFO_Q2AVG = 10,
-       CRUX_INFO_ALPHA = 11 /* "SAC alpha" (sac.jl:47) */, CRUX_INFO_N = 16 };
+       CRUX_INFO_ALPHA = 11 /* "SAC alpha" (sac.jl:47) */,
+       /* lagrange_ppo_loss (ppo.jl:111-127): info["penalty"], info["cur_cost"], info["cost_loss"], info["p_loss"] (= lambda_p * p_loss) */
+       CRUX_INFO_PENALTY = 12, CRUX_INFO_CUR_COST = 13, CRUX_INFO_COST_LOSS = 14, CRUX_INFO_P_LOSS = 15, CRUX_INFO_N = 16 };
 
 /* batch_train!(pi, p, P, D) (training.jl:28-55): epochs x (shuffle!, partition, train!) with
  * max_batches and early stopping (incl. the aliased-info semantics), executed by
@@ -358,6 +372,24 @@ int32_t crux_policy_gradient_training_synced(crux_mlp* actor, crux_mlp* critic, 
 
 /* train!(pi, loss, p) (training.jl:13-25): one gradient step on explicit rows `ids` (host, 0-based)
  * of the buffer. Returns CRUX_ENAN (without updating) when the grad norm is NaN (:20).            */
+/* LagrangePPO (rl/ppo.jl:70-215): batch_train!(actor, a_opt, P, D) with loss = lagrange_ppo_loss. The loss runs a PID controller on the minibatch's
+ * average episode cost EVERY time it is evaluated (ppo.jl:80-116, inside ignore_derivatives): Jc = sum(D[:cost]) / sum(D[:episode_end]) over the
+ * minibatch, Delta = Jc - target_cost, I = clamp(I + Ki Delta, 0, Ki_max), exponential smoothing of Delta and Jc with ema_alpha, derivative term
+ * max(0, smooth_Jc - Jc_prev), penalty = clamp(Kp smooth_Delta + I + Kd d, 0, penalty_max); then
+ *   loss = (lambda_p p_loss + lambda_e e_loss + penalty mean(max(r Ac, clamp(r, 1-eps, 1+eps) Ac))) / (1 + penalty),  Ac = D[:cost_advantage].
+ * The one-element arrays the reference keeps in P (I, Jc_prev, smooth_Delta, smooth_Jc, ppo.jl:192-201) are the state fields below: read at the
+ * start of the call, advanced once per executed minibatch inside the persistent learner kernel, written back at the end. The buffer needs
+ * :logprob, :advantage, :cost, :cost_advantage. info adds CRUX_INFO_PENALTY / CUR_COST / COST_LOSS / P_LOSS of the last minibatch of each epoch.
+ * A minibatch without an episode end makes Jc Inf or NaN exactly as in the reference (a NaN loss is CRUX_ENAN, training.jl:20).                  */
+typedef struct {
+  float target_cost, penalty_max, Ki_max, Ki, Kp, Kd;     /* LagrangePPO keywords (ppo.jl:167-176); penalty_max may be INFINITY                  */
+  double ema_alpha;                                         /* Float64 in the reference (0.95): the smoothing is evaluated in Float64, stored Float32 */
+  float I, Jc_prev, smooth_delta, smooth_Jc;                /* state                                                                                */
+  float penalty, cur_cost, deriv_term, reserved;            /* out: values of the last executed minibatch (info["penalty"], ["cur_cost"], ["deriv_term"]) */
+} crux_lagrange;
+int32_t crux_batch_train_lagrange(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, crux_lagrange* lag, const int64_t* perms,
+                                  float* info_out, float* epoch_infos);
+
 int32_t crux_train_step(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids,
                         int64_t n, float* info_out);
 /* gradient only (no optimiser step): writes the flat gradient to crux_mlp_grads_ptr(net); used by

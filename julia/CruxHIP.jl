@@ -36,12 +36,12 @@ end
 struct TrainCfg
     loss::Int32; head::Int32; batch_size::Int32; epochs::Int32; max_batches::Int64
     eps_clip::Float32; lambda_p::Float32; lambda_e::Float32; target_kl::Float32
-    shuffle_seed::UInt64; shuffle_counter::UInt64; sync_every::Int32; reserved::Int32
+    shuffle_seed::UInt64; shuffle_counter::UInt64; sync_every::Int32; target_col::Int32
 end
 @assert sizeof(RolloutCfg) == 72 && sizeof(TrainCfg) == 64
 
-const NCOLS = 13   # CRUX_NCOLS (cruxhip.h)
-const COL = Dict(:s => 0, :a => 1, :sp => 2, :r => 3, :done => 4, :episode_end => 5, :return => 6, :logprob => 7, :advantage => 8, :weight => 9, :t => 10, :i => 11, :value => 12)
+const NCOLS = 16   # CRUX_NCOLS (cruxhip.h)
+const COL = Dict(:s => 0, :a => 1, :sp => 2, :r => 3, :done => 4, :episode_end => 5, :return => 6, :logprob => 7, :advantage => 8, :weight => 9, :t => 10, :i => 11, :value => 12, :cost => 13, :cost_advantage => 14, :cost_return => 15)
 const HEAD_CATEGORICAL, HEAD_GAUSSIAN, HEAD_GREEDY_Q, HEAD_DETERMINISTIC = Int32(0), Int32(1), Int32(2), Int32(3)
 const LOSS_PPO, LOSS_VALUE_MSE, LOSS_A2C, LOSS_REINFORCE, LOSS_LOGPDF_BC, LOSS_MSE_ACTION = Int32(0), Int32(1), Int32(3), Int32(4), Int32(5), Int32(6)
 const INFO_N = 16
@@ -91,7 +91,7 @@ end
 Base.length(b::HipBuffer) = Int(ccall((:crux_buffer_len, LIB), Int64, (Ptr{Cvoid},), b.h))
 Base.haskey(b::HipBuffer, k::Symbol) = k in b.keys
 function Base.push!(b::HipBuffer, data::Dict{Symbol,<:AbstractArray})          # src/experience_buffer.jl:232-259; returns the 1-based ring indices
-    cols = fill(C_NULL, 13); keep = Any[]
+    cols = fill(C_NULL, NCOLS); keep = Any[]
     for (k, v) in data; haskey(COL, k) || continue; a = collect(v); push!(keep, a); cols[COL[k] + 1] = pointer(a); end
     N = size(first(values(data)), 2); I = Vector{Int64}(undef, N)
     GC.@preserve keep check(b.ctx, ccall((:crux_buffer_push_host, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}, Ptr{Int64}), b.h, N, cols, I))
@@ -207,6 +207,26 @@ gail_d_step!(D::HipNetwork, ex::HipBuffer, r_ex::UnitRange, pol::HipBuffer, r_po
     (check(D.ctx, ccall((:crux_gail_d_step, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Float32}),
                         D.h, ex.h, first(r_ex) - 1, length(r_ex), pol.h, first(r_pol) - 1, length(r_pol), info)); info)
 gail_reward!(D::HipNetwork, 𝒟::HipBuffer; αr=0.5f0, Rscale=1f0) = (m = Ref{Float32}(0); check(D.ctx, ccall((:crux_gail_reward, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Ref{Float32}), D.h, 𝒟.h, αr, Rscale, m)); m[])   # :50-55
+
+# ---------------------------------------------------------------------------------------------------- LagrangePPO (rl/ppo.jl:70-215)
+# isbits mirror of crux_lagrange (64 bytes): hyper-parameters, the PID state the reference keeps in one-element arrays of 𝒫 (:192-201), last values
+mutable struct Lagrange
+    target_cost::Float32; penalty_max::Float32; Ki_max::Float32; Ki::Float32; Kp::Float32; Kd::Float32; ema_α::Float64
+    I::Float32; Jc_prev::Float32; smooth_Δ::Float32; smooth_Jc::Float32; penalty::Float32; cur_cost::Float32; deriv_term::Float32; reserved::Float32
+end
+Lagrange(𝒫) = Lagrange(𝒫[:target_cost], 𝒫[:penalty_max], 𝒫[:Ki_max], 𝒫[:Ki], 𝒫[:Kp], 𝒫[:Kd], 𝒫[:ema_α], 𝒫[:I][1], 𝒫[:Jc_prev][1], 𝒫[:smooth_Δ][1], 𝒫[:smooth_Jc][1], 0, 0, 0, 0)
+const LOSS_LAGRANGE_PPO = Int32(7)
+"""batch_train!(actor, a_opt, 𝒫, 𝒟) with lagrange_ppo_loss: the penalty controller (ppo.jl:80-116) runs once per minibatch inside the learner kernel;
+its state is copied back into 𝒫's arrays afterwards. The sampler side: HipBuffer with :cost, :cost_advantage, :cost_return and steps! filling them
+through crux_fill_gae_rows_keys / crux_fill_returns_rows_keys with Vc (sampler.jl:65-66); the cost critic: TrainCfg.target_col = COL[:cost_return]."""
+function batch_train_lagrange!(π::HipNetwork, p::Crux.TrainingParams, 𝒫, 𝒟::HipBuffer; info=Dict(), target_kl=target_kl_of(p), seed=0, counter=0)
+    lag = Lagrange(𝒫); out = zeros(Float32, INFO_N); c0 = train_cfg(π, p, 𝒫; target_kl, seed, counter)
+    cfg = TrainCfg(LOSS_LAGRANGE_PPO, c0.head, c0.batch_size, c0.epochs, c0.max_batches, c0.eps_clip, c0.lambda_p, c0.lambda_e, c0.target_kl, c0.shuffle_seed, c0.shuffle_counter, 0, 0)
+    check(π.ctx, ccall((:crux_batch_train_lagrange, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{TrainCfg}, Ref{Lagrange}, Ptr{Int64}, Ptr{Float32}, Ptr{Float32}), π.h, 𝒟.h, cfg, lag, C_NULL, out, C_NULL))
+    𝒫[:I][1], 𝒫[:Jc_prev][1], 𝒫[:smooth_Δ][1], 𝒫[:smooth_Jc][1] = lag.I, lag.Jc_prev, lag.smooth_Δ, lag.smooth_Jc
+    info["penalty"], info["cur_cost"], info["cost_loss"], info["p_loss"] = out[13], out[14], out[15], out[16]
+    info[string(p.name, "loss")] = out[1]; info[:kl] = out[4]; info[:entropy] = out[3]; info
+end
 
 # ---------------------------------------------------------------------------------------------------- replica groups over xGMI peer slots
 # The exact multi-GPU algorithm (SURVEY 8e): every minibatch step of the persistent learner SUM-all-reduces the gradient between back(1f0) and

@@ -543,6 +543,13 @@ static void synth_step(int so, int sa, int discrete, const double* s, int ai, co
   *r = (float)(-(ss / (double)so) + 0.05 * sn[0]);
   *done = sn[0] > 0.9 ? 1 : 0;
 }
+/* the cost channel of the restated environments (include/cruxhip.h): info["cost"] of the step that reached s' (sampler.jl:65-66,114) */
+static float env_cost(int kind, int so, const double* sn) {
+  if (kind == CRUX_ENV_SYNTH || kind == CRUX_ENV_SYNTH_DISCRETE) { double x = sn[1 % so]; return (float)(25.0 * (x * x)); }
+  if (kind == CRUX_ENV_CARTPOLE) return fabs(sn[2]) > 0.05 ? 1.f : 0.f;
+  if (kind == CRUX_ENV_PENDULUM) return fabs(sn[1]) > 4.0 ? 1.f : 0.f;
+  return 0.f;
+}
 static void env_obs_n(int kind, int od, const double* s, float* o) {
   if (kind == CRUX_ENV_CARTPOLE) cartpole_obs(s, o); else if (kind == CRUX_ENV_PENDULUM) pendulum_obs(s, o);
   else if (kind == CRUX_ENV_SYNTH || kind == CRUX_ENV_SYNTH_DISCRETE) { for (int i = 0; i < od; ++i) o[i] = (float)s[i]; }
@@ -639,6 +646,9 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
   float* W = (buf->mask & (1u << CRUX_COL_WEIGHT)) ? (float*)buf->col[CRUX_COL_WEIGHT] : NULL;
   float* RET = (buf->mask & (1u << CRUX_COL_RETURN)) ? (float*)buf->col[CRUX_COL_RETURN] : NULL;
   float* ADV = (buf->mask & (1u << CRUX_COL_ADVANTAGE)) ? (float*)buf->col[CRUX_COL_ADVANTAGE] : NULL;
+  float* COST = (buf->mask & (1u << CRUX_COL_COST)) ? (float*)buf->col[CRUX_COL_COST] : NULL;
+  float* CADV = (buf->mask & (1u << CRUX_COL_COST_ADVANTAGE)) ? (float*)buf->col[CRUX_COL_COST_ADVANTAGE] : NULL;
+  float* CRET = (buf->mask & (1u << CRUX_COL_COST_RETURN)) ? (float*)buf->col[CRUX_COL_COST_RETURN] : NULL;
   double sr = 0.0; int64_t nee = 0;
   /* environments are independent (own state, own Philox streams, own rows of the ring): the OpenMP build steps them on all cores */
   ORC_OMP(omp parallel for schedule(dynamic, 1) reduction(+ : sr, nee))
@@ -716,6 +726,8 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
       if (II) II[j] = (int64_t)gi + 1;
       if (W) W[j] = 1.0f;             /* fresh mdp_data :weight is ones (experience_buffer.jl:17-19) */
       if (RET) RET[j] = 0.f; if (ADV) ADV[j] = 0.f;
+      if (COST) COST[j] = env_cost(e->kind, od, sn);                                             /* data[:cost][1,j] = info["cost"] sampler.jl:114 */
+      if (CADV) CADV[j] = 0.f; if (CRET) CRET[j] = 0.f;
       sr += (double)r;
       e->steps_taken[k] += 1;
       /* ---- episode bookkeeping                                                 sampler.jl:130-136 */
@@ -754,19 +766,21 @@ void orc_returns_range(const float* r, int64_t start, int64_t stop, float gamma,
   float acc = 0.f; for (int64_t i = stop; i >= start; --i) { acc = r[i] + gamma * acc; ret[i] = acc; }
 }
 
-int32_t orc_fill_gae(orc_buffer* b, orc_mlp* critic, float lambda, float gamma) { /* :255-260 over episodes(d) */
-  if (!(b->mask & (1u << CRUX_COL_ADVANTAGE))) return CRUX_EINVAL;
+/* source= / target= keywords (sampler.jl:255): fill_gae!(data, ep, Vc, lambda, gamma, source=:cost, target=:cost_advantage) (:65) */
+int32_t orc_fill_gae_keys(orc_buffer* b, orc_mlp* critic, float lambda, float gamma, int32_t source, int32_t target) { /* :255-260 over episodes(d) */
+  if (!(b->mask & (1u << target)) || (source != CRUX_COL_R && !(b->mask & (1u << source)))) return CRUX_EINVAL;
   int64_t n = b->elements; if (n == 0) return CRUX_OK;
   float* Vs = (float*)malloc(4 * (size_t)n); float* Vsp = (float*)malloc(4 * (size_t)n);
   int vo = critic->dims[critic->n_layers]; if (vo != 1) { free(Vs); free(Vsp); return CRUX_EINVAL; }   /* @assert length(Vs)==1 :268 */
   orc_mlp_forward(critic, (float*)b->col[CRUX_COL_S], n, Vs); orc_mlp_forward(critic, (float*)b->col[CRUX_COL_SP], n, Vsp);
   int64_t* st = (int64_t*)malloc(8 * (size_t)n); int64_t* en = (int64_t*)malloc(8 * (size_t)n);
   int64_t ne = orc_buffer_episodes(b, st, en, n);
-  float* adv = (float*)b->col[CRUX_COL_ADVANTAGE]; int32_t rc = CRUX_OK;
-  for (int64_t k = 0; k < ne; ++k) orc_gae_range((float*)b->col[CRUX_COL_R], (uint8_t*)b->col[CRUX_COL_DONE], Vs, Vsp, st[k], en[k], lambda, gamma, adv);
+  float* adv = (float*)b->col[target]; int32_t rc = CRUX_OK;
+  for (int64_t k = 0; k < ne; ++k) orc_gae_range((float*)b->col[source], (uint8_t*)b->col[CRUX_COL_DONE], Vs, Vsp, st[k], en[k], lambda, gamma, adv);
   for (int64_t i = 0; i < n; ++i) if (isnan(adv[i])) rc = CRUX_ENAN;                              /* @assert !isnan(A) :270 */
   free(Vs); free(Vsp); free(st); free(en); return rc;
 }
+int32_t orc_fill_gae(orc_buffer* b, orc_mlp* critic, float lambda, float gamma) { return orc_fill_gae_keys(b, critic, lambda, gamma, CRUX_COL_R, CRUX_COL_ADVANTAGE); }
 /* episodes! metrics (sampler.jl:175-251) for the first episode of each env of an env-major n_envs x T block */
 int32_t orc_first_episode_metrics(orc_buffer* b, int32_t n_envs, int64_t T, float gamma, float* und, float* dis, int64_t* len, uint8_t* complete) {
   if ((int64_t)n_envs * T != b->elements) return CRUX_EINVAL;
@@ -780,14 +794,15 @@ int32_t orc_first_episode_metrics(orc_buffer* b, int32_t n_envs, int64_t T, floa
     if (und) und[e] = u; if (dis) dis[e] = d; if (len) len[e] = stop + 1; }
   return CRUX_OK;
 }
-int32_t orc_fill_returns(orc_buffer* b, float gamma) {
-  if (!(b->mask & (1u << CRUX_COL_RETURN))) return CRUX_EINVAL;
+int32_t orc_fill_returns_keys(orc_buffer* b, float gamma, int32_t source, int32_t target) {   /* fill_returns!(...; source=:cost, target=:cost_return) (:66,275) */
+  if (!(b->mask & (1u << target)) || (source != CRUX_COL_R && !(b->mask & (1u << source)))) return CRUX_EINVAL;
   int64_t n = b->elements; if (n == 0) return CRUX_OK;
   int64_t* st = (int64_t*)malloc(8 * (size_t)n); int64_t* en = (int64_t*)malloc(8 * (size_t)n);
   int64_t ne = orc_buffer_episodes(b, st, en, n);
-  for (int64_t k = 0; k < ne; ++k) orc_returns_range((float*)b->col[CRUX_COL_R], st[k], en[k], gamma, (float*)b->col[CRUX_COL_RETURN]);
+  for (int64_t k = 0; k < ne; ++k) orc_returns_range((float*)b->col[source], st[k], en[k], gamma, (float*)b->col[target]);
   free(st); free(en); return CRUX_OK;
 }
+int32_t orc_fill_returns(orc_buffer* b, float gamma) { return orc_fill_returns_keys(b, gamma, CRUX_COL_R, CRUX_COL_RETURN); }
 /* whiten(v) = (v .- mean(v)) ./ std(v)  utils.jl:41-42; [3P] Statistics.std is Bessel-corrected; the
  * reductions are evaluated in Float64 here and rounded to Float32 (Julia uses pairwise Float32). */
 int32_t orc_whiten(orc_buffer* b, int32_t key) {
@@ -805,6 +820,24 @@ int32_t orc_whiten(orc_buffer* b, int32_t key) {
  * learner                                src/training.jl:13-55, src/model_free/rl/ppo.jl:4-21,59-60
  * ============================================================================================ */
 /* loss + flat gradient on rows ids[0..n) ; info per training.jl:22-23 / ppo.jl:13-19. */
+/* lagrange_ppo_loss's penalty controller (rl/ppo.jl:80-116), run inside the loss on every evaluation; state = the one-element arrays of P (:192-201) */
+static crux_lagrange* g_lag = NULL;
+static float clamp_jl(float x, float lo, float hi) { return x > hi ? hi : (x < lo ? lo : x); }     /* Base.clamp: NaN passes through */
+static float lagrange_penalty(crux_lagrange* L, const orc_buffer* buf, const int64_t* ids, int64_t n) {
+  const float* COST = (const float*)buf->col[CRUX_COL_COST]; const uint8_t* EE = (const uint8_t*)buf->col[CRUX_COL_EPISODE_END];
+  double sc = 0.0; int64_t ne = 0; for (int64_t s = 0; s < n; ++s) { sc += (double)COST[ids[s]]; ne += EE[ids[s]] ? 1 : 0; }
+  float Jc = (float)sc / (float)ne;                                                              /* :86 sum(D[:cost]) / sum(D[:episode_end]); Float32 sum restated through Float64 */
+  float dl = Jc - L->target_cost;                                                                 /* :91 */
+  L->I = clamp_jl(L->I + L->Ki * dl, 0.f, L->Ki_max);                                             /* :94 */
+  L->smooth_delta = (float)(L->ema_alpha * (double)L->smooth_delta + (1.0 - L->ema_alpha) * (double)dl);   /* :98, ema_alpha is Float64 */
+  L->smooth_Jc = (float)(L->ema_alpha * (double)L->smooth_Jc + (1.0 - L->ema_alpha) * (double)Jc);         /* :99 */
+  { float x = L->smooth_Jc - L->Jc_prev; L->deriv_term = (x != x) ? x : (x > 0.f ? x : 0.f); }    /* :102 max(0, x): NaN if x is NaN */
+  L->Jc_prev = L->smooth_Jc;                                                                      /* :105 */
+  L->penalty = clamp_jl((L->Kp * L->smooth_delta + L->I) + L->Kd * L->deriv_term, 0.f, L->penalty_max);   /* :108 */
+  L->cur_cost = Jc;
+  return L->penalty;
+}
+
 static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg, const int64_t* ids, int64_t n, float* info) {
   int od = buf->obs_dim, ad = buf->act_dim, nout = net->dims[net->n_layers];
   if (net->dims[0] != od || n <= 0) return CRUX_EINVAL;
@@ -812,12 +845,12 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
   for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
   const float* S = (const float*)buf->col[CRUX_COL_S];
   float invB = 1.0f / (float)n;
-  double sum_loss_p = 0, sum_H = 0, sum_kl = 0, sum_adv = 0, sum_ret = 0, sum_sq = 0; int64_t nclip = 0;
+  double sum_loss_p = 0, sum_H = 0, sum_kl = 0, sum_adv = 0, sum_ret = 0, sum_sq = 0, sum_cost = 0; int64_t nclip = 0;
   /* The sample loops below run once, in order, into net->g in the parity build. The OpenMP build gives every thread a slice of the minibatch and a
    * private gradient that is added to net->g at the end (sample-parallel inside one step: the steps themselves are serially dependent). */
 #ifdef _OPENMP
   const int nthr = n >= 32 ? (omp_get_max_threads() < (int)(n / 8) ? omp_get_max_threads() : (int)(n / 8)) : 1;
-#define LG_BEGIN ORC_OMP(omp parallel num_threads(nthr) reduction(+ : sum_loss_p, sum_H, sum_kl, sum_adv, sum_ret, sum_sq, nclip)) \
+#define LG_BEGIN ORC_OMP(omp parallel num_threads(nthr) reduction(+ : sum_loss_p, sum_H, sum_kl, sum_adv, sum_ret, sum_sq, sum_cost, nclip)) \
   { colcache c = cc_alloc(net); float dy[64], p[64]; (void)p; float* gl = nthr > 1 ? (float*)calloc((size_t)net->n_params, 4) : net->g; ORC_OMP(omp for schedule(static))
 #define LG_END if (gl != net->g) { ORC_OMP(omp critical) { for (int64_t i_ = 0; i_ < net->n_params; ++i_) net->g[i_] += gl[i_]; } free(gl); } cc_free(net, &c); }
 #else
@@ -834,8 +867,9 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
     LG_END
     info[CRUX_INFO_LOSS] = (float)(sum_sq / (double)n);
   } else if (cfg->loss == CRUX_LOSS_VALUE_MSE) {                               /* Flux.mse(value(pi, s), return) ppo.jl:60 */
-    if (nout != 1 || !(buf->mask & (1u << CRUX_COL_RETURN))) return CRUX_EINVAL;
-    const float* RET = (const float*)buf->col[CRUX_COL_RETURN];
+    const int tk = cfg->target_col > 0 ? cfg->target_col : CRUX_COL_RETURN;      /* D[:return] (ppo.jl:60) or D[:cost_return] (:210) */
+    if (nout != 1 || !(buf->mask & (1u << tk))) return CRUX_EINVAL;
+    const float* RET = (const float*)buf->col[tk];
     LG_BEGIN
     for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s];
       fwd_col(net, S + (size_t)id * od, c.h); float d = c.h[net->n_layers][0] - RET[id];
@@ -850,6 +884,9 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
     const float* LP = bc ? NULL : (const float*)buf->col[CRUX_COL_LOGPROB]; const float* ADV = bc ? NULL : (cfg->loss == CRUX_LOSS_REINFORCE ? RET : (const float*)buf->col[CRUX_COL_ADVANTAGE]);
     float lo = 1.f - cfg->eps_clip, hi = 1.f + cfg->eps_clip;
     const float* ls = net->p + xoff(net);
+    const int lagr = cfg->loss == CRUX_LOSS_LAGRANGE_PPO; float pen = 0.f; const float* CADV = NULL;
+    if (lagr) { if (!g_lag || !(buf->mask & (1u << CRUX_COL_COST)) || !(buf->mask & (1u << CRUX_COL_COST_ADVANTAGE))) return CRUX_EINVAL;
+      CADV = (const float*)buf->col[CRUX_COL_COST_ADVANTAGE]; pen = lagrange_penalty(g_lag, buf, ids, n); }
     LG_BEGIN
     for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s]; float* gx = gl + xoff(net);
       fwd_col(net, S + (size_t)id * od, c.h); const float* z = c.h[net->n_layers];
@@ -869,12 +906,15 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
         else if (bc) { coef = 1.f; lterm = newlp; lp_ = 1.f; }                                             /* -mean(logpdf) bc.jl:12 */
         else if (cfg->loss == CRUX_LOSS_REINFORCE) { coef = RET[id]; lterm = newlp * RET[id]; lp_ = 1.f; le_ = 0.f; }   /* reinforce.jl:12 */
         sum_loss_p += (double)lterm;
+        float gcr = 0.f;                                           /* lagrange: d/dr max(r Ac, clamp(r) Ac) times r (ppo.jl:119) */
+        if (lagr) { float Ac = CADV[id], uc = r * Ac, clc = rc * Ac; sum_cost += (double)(uc >= clc ? uc : clc); gcr = (uc >= clc ? Ac : 0.f) * r; }
         for (int k = 0; k < nout; ++k) {
           float dlogpi = p[k] * ((a[k] ? 1.f : 0.f) / q) - p[k];   /* = y_k - p_k for one-hot y */
           float dH = p[k] * (hk[k] - hp);
-          dy[k] = invB * (-lp_ * coef * dlogpi - le_ * dH);
+          float base = -lp_ * coef * dlogpi - le_ * dH;
+          dy[k] = lagr ? invB * ((base + pen * gcr * dlogpi) / (1.f + pen)) : invB * base;    /* (...) / (1 + penalty) (:131) */
         }
-        if (cfg->loss == CRUX_LOSS_PPO && (r > hi || r < lo)) ++nclip;
+        if ((cfg->loss == CRUX_LOSS_PPO || lagr) && (r > hi || r < lo)) ++nclip;
       } else {                                                                   /* GaussianPolicy policies.jl:333-348 */
         const float* a = (const float*)buf->col[CRUX_COL_A] + (size_t)id * ad;
         newlp = 0.f; const float sq = net->squash; float ua[64];
@@ -889,11 +929,14 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
         else if (bc) { coef = 1.f; lterm = newlp; lp_ = 1.f; }
         else if (cfg->loss == CRUX_LOSS_REINFORCE) { coef = RET[id]; lterm = newlp * RET[id]; lp_ = 1.f; }
         sum_loss_p += (double)lterm;
+        float cf = -lp_ * coef;                                                                  /* coefficient of d logpdf in d loss */
+        if (lagr) { float Ac = CADV[id], uc = r * Ac, clc = rc * Ac; sum_cost += (double)(uc >= clc ? uc : clc);
+          cf = (cf + pen * ((uc >= clc ? Ac : 0.f) * r)) / (1.f + pen); }
         for (int k = 0; k < ad; ++k) { float sg = expf(sq > 0.f ? sq_clampls(ls[k]) : ls[k]); float s2 = sg * sg; float d = ua[k] - z[k];
           float inr = (sq > 0.f && !(ls[k] >= -5.f && ls[k] <= 2.f)) ? 0.f : 1.f;               /* d clamp(x, lo, hi)/dx = 1 inside [lo, hi], 0 outside (ChainRules) */
-          dy[k] = invB * (-lp_ * coef * (d / s2));
-          gx[k] += invB * (-lp_ * coef * (((d * d) / s2) * inr - 1.f)); }
-        if (cfg->loss == CRUX_LOSS_PPO && (r > hi || r < lo)) ++nclip;
+          dy[k] = invB * (cf * (d / s2));
+          gx[k] += invB * (cf * (((d * d) / s2) * inr - 1.f)); }
+        if ((cfg->loss == CRUX_LOSS_PPO || lagr) && (r > hi || r < lo)) ++nclip;
       }
       sum_H += (double)H; sum_kl += (double)(oldlp - newlp); sum_adv += (double)A; if (RET) sum_ret += (double)RET[id];
       bwd_col(net, c.h, dy, gl);
@@ -903,11 +946,14 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
     float p_loss = (float)(-(sum_loss_p / (double)n)), e_loss, entropy;
     if (cfg->head == CRUX_HEAD_CATEGORICAL) { entropy = (float)(sum_H / (double)n); e_loss = -entropy; }
     else { float Hs = 1.4189385332046727f; for (int k = 0; k < ad; ++k) Hs = Hs + ls[k]; entropy = Hs; e_loss = -Hs;   /* scalar entropy policies.jl:348 */
-      if (cfg->loss != CRUX_LOSS_REINFORCE) for (int k = 0; k < ad; ++k) gx[k] += -cfg->lambda_e; }
+      if (cfg->loss != CRUX_LOSS_REINFORCE) for (int k = 0; k < ad; ++k) gx[k] += lagr ? -cfg->lambda_e / (1.f + pen) : -cfg->lambda_e; }
     info[CRUX_INFO_LOSS] = cfg->loss == CRUX_LOSS_REINFORCE ? p_loss : (bc ? 1.f : cfg->lambda_p) * p_loss + cfg->lambda_e * e_loss;   /* ppo.jl:20, a2c.jl:14, reinforce.jl:12 */
     info[CRUX_INFO_ENTROPY] = entropy; info[CRUX_INFO_KL] = (float)(sum_kl / (double)n);
     info[CRUX_INFO_CLIP_FRACTION] = (float)nclip / (float)n; info[CRUX_INFO_AVG_ADVANTAGE] = (float)(sum_adv / (double)n);
     info[CRUX_INFO_AVG_RETURN] = (float)(sum_ret / (double)n);
+    if (lagr) { float cost_loss = pen * (float)(sum_cost / (double)n);                                              /* ppo.jl:119 */
+      info[CRUX_INFO_LOSS] = ((cfg->lambda_p * p_loss + cfg->lambda_e * e_loss) + cost_loss) / (1.f + pen);          /* :131 */
+      info[CRUX_INFO_PENALTY] = pen; info[CRUX_INFO_CUR_COST] = g_lag->cur_cost; info[CRUX_INFO_COST_LOSS] = cost_loss; info[CRUX_INFO_P_LOSS] = cfg->lambda_p * p_loss; }
   }
   /* norm(grad) utils.jl:49-55: 2-norm of the per-tensor 2-norms */
   double tot = 0;
@@ -962,6 +1008,12 @@ int32_t orc_batch_train(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg
   info_out[CRUX_INFO_BATCHES_TRAINED] = (float)total; info_out[CRUX_INFO_EPOCHS_RUN] = (float)epochs_run;         /* :53 */
   free(perm); free(ids);
   return CRUX_OK;
+}
+
+/* batch_train!(actor, a_opt, P, D) with lagrange_ppo_loss (rl/ppo.jl:70-131,208): the PID state in *lag advances once per executed minibatch */
+int32_t orc_batch_train_lagrange(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg, crux_lagrange* lag, const int64_t* perms, float* info_out, float* epoch_infos) {
+  if (!lag || cfg->loss != CRUX_LOSS_LAGRANGE_PPO) return CRUX_EINVAL;
+  g_lag = lag; int32_t rc = orc_batch_train(net, buf, cfg, perms, info_out, epoch_infos); g_lag = NULL; return rc;
 }
 
 /* ============================================================================================

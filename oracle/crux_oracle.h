@@ -91,6 +91,8 @@ int32_t orc_env_step_host(int32_t kind, int64_t n, const double* state, const vo
 /* advantage pipeline */
 int32_t orc_fill_gae(orc_buffer* b, orc_mlp* critic, float lambda, float gamma);
 int32_t orc_fill_returns(orc_buffer* b, float gamma);
+int32_t orc_fill_gae_keys(orc_buffer* b, orc_mlp* critic, float lambda, float gamma, int32_t source, int32_t target);
+int32_t orc_fill_returns_keys(orc_buffer* b, float gamma, int32_t source, int32_t target);
 int32_t orc_whiten(orc_buffer* b, int32_t key);
 /* fill_gae! on one explicit range with given V(s), V(sp) (sampler.jl:262-273) -- KAT helper. */
 void orc_gae_range(const float* r, const uint8_t* done, const float* Vs, const float* Vsp, int64_t start, int64_t stop,
@@ -124,6 +126,7 @@ int32_t orc_gail_reward(orc_mlp* D, orc_buffer* b, float alpha_r, float rscale, 
 int32_t orc_q_step(orc_mlp* q, orc_buffer* batch, const float* y, int32_t use_weight, float* info_out);
 int32_t orc_dpg_actor_step(orc_mlp* actor, orc_mlp* q, orc_buffer* batch, float* info_out);
 
+int32_t orc_batch_train_lagrange(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cfg, crux_lagrange* lag, const int64_t* perms, float* info_out, float* epoch_infos);
 int32_t orc_omp_threads(void);   /* 1 in the parity build; the OpenMP build's thread count (bench.py's all-cores baseline only) */
 void orc_perm(uint64_t seed, uint64_t counter, uint32_t n, int64_t* out);
 void orc_philox(uint64_t seed, uint64_t counter, uint32_t stream, uint32_t purpose, uint32_t* out4);
