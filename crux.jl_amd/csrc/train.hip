@@ -135,6 +135,14 @@ static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_
   if (rc) return rc;
   if (a.need_px && !handled) return crux_fail(c, CRUX_EUNSUP, "batch_train! with a replica group attached needs the two-CU learner kernels (IN->64->64->OUT of the supported families, batch 65..128): this learner would run un-synchronised");
   if (!handled) {
+    // the generic learner is one workgroup of scalar loops: right for tiny networks and single steps, ~60x slower per minibatch than the MFMA family
+    // on anything 64 wide -- say so once instead of silently falling off the cliff
+    if (!a.ids && a.apply && a.nd.n_params >= 2048 && !a.lag && !getenv("CRUX_FORCE_GENERIC") && !getenv("CRUX_QUIET")) {
+      static bool warned = false;
+      if (!warned) { warned = true; char shape[128]; int o = 0; for (int l = 0; l <= a.nd.L && o < 100; ++l) o += snprintf(shape + o, sizeof shape - o, l ? "-%d" : "%d", a.nd.dims[l]);
+        fprintf(stderr, "[cruxhip] batch_train!: network %s (batch %d) is outside the MFMA learner family (IN-64-64-OUT with IN in {3,4,8,17}, batch <= 128, PPO / A2C / value losses); "
+                        "running the generic single-workgroup learner, roughly 60x slower per minibatch. (CRUX_QUIET=1 silences this.)\n", shape, a.bs); }
+    }
     const size_t lds = generic_lds_bytes(a.nd);
     if (lds > 160 * 1024 - 64) return crux_fail(c, CRUX_EUNSUP, "train!: network too wide for the generic learner kernel (%zu B of LDS)", lds);
     static size_t attr_set = 0;

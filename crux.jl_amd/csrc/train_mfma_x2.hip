@@ -733,7 +733,7 @@ static int32_t launch_x2(crux_ctx* c, TrainArgs a, hipStream_t stream) {
   constexpr size_t xbytes = sizeof(float) * 4 * 8192 + 256;
   if (!c->xbuf[which]) { if (hipMalloc(&c->xbuf[which], xbytes) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "learner exchange buffer"); }
   a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * 4 * 8192);
-  if (c->peer_n > 1) { a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR; }
+  if (c->peer_n > 1 && a.need_px) { a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR; }     // local calls (single steps, gradients) never exchange
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
   hipLaunchKernelGGL((k_train_mfma_x2<IN, OUT, KIND, ACT, TIMING>), dim3(16), dim3(256), lds, stream, a, (const TrainArgs*)nullptr);
   return crux_launch_check(c, "k_train_mfma_x2");
@@ -783,10 +783,13 @@ int32_t crux_train_mfma_x2_launch_multi(crux_ctx* c, std::vector<TrainArgs>& as,
 }
 
 // Called by crux_train_mfma_launch after its shape checks, before the single-CU kernels.
-int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream) {
+// any_mode = false: only full minibatch loops of 65..128 rows (where two CUs pay); true: also single steps, gradient-only calls and small minibatches
+// (workgroup 1 then idles on empty tiles) -- used for the shapes that have no one-CU instantiation.
+int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream, bool any_mode) {
   *handled = false;
   static const bool off = getenv("CRUX_MFMA_X2") && getenv("CRUX_MFMA_X2")[0] == '0';
-  if (off || a.ids || !a.apply || a.bs <= 64 || a.len < a.bs) return CRUX_OK;     // single steps and small batches stay on one CU
+  if (off) return CRUX_OK;
+  if (!any_mode && (a.ids || !a.apply || a.bs <= 64 || a.len < a.bs)) return CRUX_OK;     // single steps and small batches stay on one CU when it has the shape
   if (!x2_placement_ok(c)) return CRUX_OK;
   const int in = a.nd.dims[0], out = a.nd.dims[3], act = a.nd.acts[0];
   if (getenv("CRUX_MFMA_TIMING") && in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) {
@@ -810,6 +813,8 @@ int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, boo
   MFX_CASE(17, 6, MFK_GAUSSIAN, CRUX_ACT_TANH)
   MFX_CASE(17, 1, MFK_VALUE, CRUX_ACT_RELU)          // C5 critic
   MFX_CASE(17, 1, MFK_VALUE, CRUX_ACT_TANH)
+  MFX_CASE(8, 4, MFK_CATEGORICAL, CRUX_ACT_RELU)     // 8 observations / 4 discrete actions (LunarLander-shaped, the C3 environment under an on-policy learner)
+  MFX_CASE(8, 1, MFK_VALUE, CRUX_ACT_RELU)
 #undef MFX_CASE
   return CRUX_OK;
 }

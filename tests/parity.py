@@ -70,6 +70,10 @@ FAMILIES = {
     "cartpole": (4, 2, True, ACTOR_DIMS, CRITIC_DIMS, ACTS, "discrete", "categorical", "cartpole"),
     # C5-shaped (BASELINE configs[4]): 17 observations / 6 continuous actions, tanh 17->64->64->6 GaussianPolicy + critic, SYNTH dynamics (cruxhip.h)
     "synth_c5": (17, 6, False, [17, 64, 64, 6], [17, 64, 64, 1], ["tanh", "tanh", "identity"], "gaussian", "gaussian", "synth"),
+    # 8 observations / 4 discrete actions (the C3 environment's shape) under the on-policy learner: 8->64->64->4 DiscreteNetwork + critic
+    "synth_8_4": (8, 4, True, [8, 64, 64, 4], [8, 64, 64, 1], ACTS, "discrete", "categorical", "synth_discrete"),
+    # outside the MFMA family (32-wide hidden layers): the generic learner
+    "synth_8_4_h32": (8, 4, True, [8, 32, 32, 4], [8, 32, 32, 1], ACTS, "discrete", "categorical", "synth_discrete"),
 }
 
 

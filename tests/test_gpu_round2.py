@@ -190,3 +190,23 @@ def test_small_dqn_solve_in_one_launch_equals_the_call_by_call_loop(gpu_ctx):
         assert h1 == h2
     for x, y in zip(a[9], b[9]):
         assert np.array_equal(x, y)
+
+
+# ---------------------------------------------------------------------------------------------------- the fast learner's shape list
+@pytest.mark.parametrize("bs,T", [(128, 64), (48, 32)])
+def test_8_64_64_4_runs_on_the_mfma_learner_and_matches_the_oracle(gpu_ctx, capfd, bs, T):
+    """8->64->64->4 used to fall to the generic learner without a word; it is an instantiation of the two-CU kernel now (full minibatches) and of its
+    any-mode form (small minibatches, the single steps of the window tests)."""
+    res = parity.ppo_iteration_parity(n_envs=8, T=T, batch_size=bs, epochs=2, seed=13, family="synth_8_4", pair=(bs == 128))
+    assert res["ok"], res
+    assert "outside the MFMA learner family" not in capfd.readouterr().err
+
+
+def test_generic_fallback_is_announced_once(gpu_ctx, capfd):
+    """a 32-wide network trains on the generic single-workgroup learner: correct (parity below) and announced, once per process"""
+    res = parity.ppo_iteration_parity(n_envs=8, T=32, batch_size=64, epochs=1, seed=14, family="synth_8_4_h32")
+    assert res["ok"], res
+    err = capfd.readouterr().err
+    assert err.count("outside the MFMA learner family") <= 1                      # at most once (another test of this process may have triggered it first)
+    parity.ppo_iteration_parity(n_envs=8, T=32, batch_size=64, epochs=1, seed=15, family="synth_8_4_h32")
+    assert "outside the MFMA learner family" not in capfd.readouterr().err
