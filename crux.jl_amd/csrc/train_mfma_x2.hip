@@ -467,7 +467,8 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
         MX_T(10);
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(a.xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // arrive (one atomic per workgroup: per-wave arrivals measured slower, 9.37 vs 9.19 us)
-        // the ~1 us until the other workgroup arrives is spent staging the NEXT minibatch (rows prefetched a step ago; x/scalar tiles are free after B_a)
+        // the ~1 us until the other workgroup arrives is spent staging the NEXT minibatch (rows prefetched a step ago; x/scalar tiles are free after B_a).
+        // (Staging before the s_waitcnt instead, inside the store acknowledgement latency, measured slower: 8.85 vs 8.76 us per step.)
         if (st + a.bs < total_rows) { stage(); staged = true; }
         if (tid == 0) {
           const unsigned want = 2u * (unsigned)(xstep + 1); unsigned spins = 0; bool ok = true;
@@ -556,17 +557,23 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
                          "global_load_dwordx4 %3, %4, off offset:48 sc0 sc1"
                          : "=&v"(vW[0]), "=&v"(vW[1]), "=&v"(vW[2]), "=&v"(vW[3]) : "v"(src + tid * 16) : "memory");
           };
-          for (int r = 0; r < a.px_n; r += 2) {
-            f32x4 vA[4], vB[4]; float sA[NSI], sB[NSI]; float tA = 0.f, tB = 0.f;
-            const bool two = r + 1 < a.px_n;
+          // wide heads (OUT > 2) are at the 512-register limit: they take the ranks one at a time (16 + NSI fewer live registers), the others in pairs
+          constexpr int PXS = (OUT <= 2) ? 2 : 1;
+          for (int r = 0; r < a.px_n; r += PXS) {
+            f32x4 vA[4], vB[PXS == 2 ? 4 : 1]; float sA[NSI], sB[PXS == 2 ? NSI : 1]; float tA = 0.f, tB = 0.f;
+            const bool two = PXS == 2 && r + 1 < a.px_n;
             px_load(r, vA, sA, tA);
-            if (two) px_load(r + 1, vB, sB, tB);
-            else {
+            if constexpr (PXS == 2) {
+              if (two) px_load(r + 1, (f32x4 (&)[4])vB, (float (&)[NSI])sB, tB);
+              else {
 #pragma unroll
-              for (int mm = 0; mm < 4; ++mm) vB[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int mm = 0; mm < 4; ++mm) vB[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-              for (int k = 0; k < NSI; ++k) sB[k] = 0.f; }
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(vA[0]), "+v"(vA[1]), "+v"(vA[2]), "+v"(vA[3]), "+v"(vB[0]), "+v"(vB[1]), "+v"(vB[2]), "+v"(vB[3]) :: "memory");
+                for (int k = 0; k < NSI; ++k) sB[k] = 0.f; }
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(vA[0]), "+v"(vA[1]), "+v"(vA[2]), "+v"(vA[3]), "+v"(vB[0]), "+v"(vB[1]), "+v"(vB[2]), "+v"(vB[3]) :: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(vA[0]), "+v"(vA[1]), "+v"(vA[2]), "+v"(vA[3]) :: "memory");
+            }
             if (r == 0) {
 #pragma unroll
               for (int mm = 0; mm < 4; ++mm) gW2[mm] = vA[mm];
@@ -580,12 +587,14 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
               for (int k = 0; k < NSI; ++k) gs[k] += sA[k];
               stat_tot += tA;
             }
-            if (two) {
+            if constexpr (PXS == 2) {
+              if (two) {
 #pragma unroll
-              for (int mm = 0; mm < 4; ++mm) gW2[mm] += vB[mm];
+                for (int mm = 0; mm < 4; ++mm) gW2[mm] += vB[mm];
 #pragma unroll
-              for (int k = 0; k < NSI; ++k) gs[k] += sB[k];
-              stat_tot += tB;
+                for (int k = 0; k < NSI; ++k) gs[k] += sB[k];
+                stat_tot += tB;
+              }
             }
           }
           // mean over the group: global minibatch = px_n x nb samples, every rank's partial was already divided by nb
@@ -792,15 +801,15 @@ int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, boo
   if (!any_mode && (a.ids || !a.apply || a.bs <= 64 || a.len < a.bs)) return CRUX_OK;     // single steps and small batches stay on one CU when it has the shape
   if (!x2_placement_ok(c)) return CRUX_OK;
   const int in = a.nd.dims[0], out = a.nd.dims[3], act = a.nd.acts[0];
-  if (getenv("CRUX_MFMA_TIMING") && in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) {
+  if (getenv("CRUX_MFMA_TIMING") && ((in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) || (in == 17 && out == 6 && kind == MFK_GAUSSIAN && act == CRUX_ACT_TANH))) {
     static unsigned long long* dbg = nullptr;
     if (!dbg) { if (hipMalloc(&dbg, 128 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
     TrainArgs b = a; b.dbg = dbg; *handled = true;
-    int32_t rc = launch_x2<4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU, true>(c, b, stream); if (rc) return rc;
+    int32_t rc = in == 4 ? launch_x2<4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU, true>(c, b, stream) : launch_x2<17, 6, MFK_GAUSSIAN, CRUX_ACT_TANH, true>(c, b, stream); if (rc) return rc;
     unsigned long long h[128]; HIPCHK(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, stream)); HIPCHK(c, hipStreamSynchronize(stream));
     static const char* nm[16] = {"loop+prefetch", "stage", "fwdL1+T1", "fwdL2", "L3+head", "dW3+dZ2+stats+T2", "dH1", "dZ1+db+dW1", "wait B_a", "dW2", "reduce+store", "exchange wait",
                                  "load peer+total+ssq", "wait B_or", "info+adam", "wait B_b"};
-    for (int w = 0; w < 8; ++w) { fprintf(stderr, "[x2-timing] wg %d wave %d:", w >> 2, w & 3); unsigned long long tot = 0; for (int k = 0; k < 16; ++k) tot += h[w * 16 + k];
+    for (int w = 0; w < 8; w += 4) { fprintf(stderr, "[x2-timing] %d-%d wg %d wave %d:", in, out, w >> 2, w & 3); unsigned long long tot = 0; for (int k = 0; k < 16; ++k) tot += h[w * 16 + k];
       for (int k = 0; k < 16; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[w * 16 + k] / (double)tot); fprintf(stderr, " total=%llu\n", tot); }
     return CRUX_OK;
   }
