@@ -162,8 +162,12 @@ def cpu_baseline(workload="c2"):
         try:
             pe, pg, tr, tt = run("omp")
             nthr = int(O.lib().orc_omp_threads())
-            out["openmp_all_cores"] = {"value": E * T / (pe * E * T + pg * steps_iter), "unit": "env-steps/s", "cores": nthr, "grad_steps_per_s": 1.0 / pg, "rollout_env_steps_per_s": 1.0 / pe,
-                                       "sample": "oracle built with -fopenmp (environments in parallel for the rollout, minibatch samples in parallel inside a learner step): same sample, %.2fs + %.2fs" % (tr, tt)}
+            used = max(min(nthr, E), min(nthr, BATCH // 8))
+            out["openmp_all_cores"] = {"value": E * T / (pe * E * T + pg * steps_iter), "unit": "env-steps/s", "cores": used, "host_threads_available": nthr,
+                                       "grad_steps_per_s": 1.0 / pg, "rollout_env_steps_per_s": 1.0 / pe,
+                                       "sample": "oracle built with -fopenmp: one thread per environment in the rollout (%d), %d threads over the samples of a minibatch inside a learner step "
+                                                 "(the steps themselves are serially dependent; more threads than B/8 only add reduction cost): same sample, %.2fs + %.2fs"
+                                                 % (min(nthr, E), min(nthr, BATCH // 8), tr, tt)}
         except Exception as e:      # noqa: BLE001  (supplementary)
             out["openmp_all_cores"] = {"error": repr(e)}
         O.select("scalar")
@@ -442,7 +446,7 @@ def main():
             "rollout_env_steps_per_s": (E * T * args.steps) / (prof["rollout"][0] * 1e-3) if prof["rollout"][0] > 0 else None,
             "roofline": {"kernel": "batch_train! actor (persistent fwd+ppo_loss+bwd+Adam)", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": 16.6e6 if (world == 1 and args.workload == "c2") else None,
-                         "traffic_note": "HBM-side bytes per actor launch from rocprofv3 --pmc FETCH_SIZE (13.86 MB) + WRITE_SIZE (2.70 MB), separate passes of this command (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.txt); a recorded constant, not re-measured in this run. Algorithmic minibatch bytes per launch are 136 MB (40960 x 3328 B): the 3.4 MB buffer is re-read from L2/MALL, and the 1.6 GB/launch of gradient exchange between the two workgroups stays inside one XCD's L2",
+                         "traffic_note": "HBM-side bytes per actor launch from rocprofv3 --pmc FETCH_SIZE (13.86 MB) + WRITE_SIZE (2.70 MB), separate passes of this command (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.txt); a recorded constant, not re-measured in this run. Algorithmic minibatch bytes per launch are 136 MB (40960 x 3328 B): the 3.4 MB buffer is re-read from L2/MALL, and the 1.6 GB/launch of gradient exchange between the two workgroups stays inside one XCD's L2",
                          "avg_launch_ms": avg_launch_s * 1e3, "grad_steps_per_launch": steps_per_launch,
                          "us_per_grad_step": avg_launch_s * 1e6 / steps_per_launch if steps_per_launch else None,
                          "note": "serially dependent %.2f-MFLOP steps: each learner step is split over two CUs of one XCD (gradient exchange through the shared L2), actor and critic run concurrently -> 4 CUs busy; per-CU f32 MFMA peak is 0.614 TFLOP/s" % (fa / 1e6)},
