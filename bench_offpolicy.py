@@ -69,9 +69,9 @@ def c3(crux, ctx, cpu=True, steps=300):
     # their root paths, 128 x 20 probes of (leaf id, running sum, 24 path ids, <= 24 totals), the 128-row gather (78 B/row read + write)
     per_bytes = 128 * 127 * 8 + 128 * 14 * 12 + 128 * 20 * (4 + 4 + 96 + 56) + 2 * 128 * 78
     out = {"workload": "DQN + prioritized replay, 8-256-256-4, buffer 1 M, B = 128: one value_training epoch (prioritized_sample! + dqn_target + td_error + update_priorities! + train!)",
-           "grad_steps_per_s": 1.0 / t, "per_samples_per_s": B / t, "us_per_epoch": 1e6 * t, "fused_launches_per_epoch": 1,
-           "roofline": {"kernel": "k_exec (fused epoch: 10 tile-GEMM ops + heads + Adam + replay ops)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                        "algorithmic_MFLOP_per_epoch": C3_FLOP / 1e6, "note": "latency-bound: ~25 dependent ops per epoch on 32 CUs of one XCD with 1.3 us L2 barriers between them"},
+           "grad_steps_per_s": 1.0 / t, "per_samples_per_s": B / t, "us_per_epoch": 1e6 * t, "launches_per_epoch": 13,
+           "roofline": {"kernel": "k_phase (crux_dqn_epoch: the epoch's ~25 recorded ops -- 10 tile GEMMs, heads, Adam, replay ops -- run as 13 phase launches over the whole chip)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        "algorithmic_MFLOP_per_epoch": C3_FLOP / 1e6, "note": "latency-bound: 13 dependent launches of ~5 us plus their CPU enqueue cost; independent ops share a launch. The persistent one-XCD form (CRUX_EXEC_PERSISTENT=1, 1.3 us L2 barriers) measured slower"},
            "replay_sampling": {"bytes_per_epoch_incremental": per_bytes, "bytes_per_epoch_full_rescan": 8 * N, "bound": "hbm", "note": "the reference's cumsum(priorities) per gradient step (4 MB read + 4 MB write at N = 1 M) is replaced by re-summing the touched leaves and their root paths; sample indices stay bit-exact"}}
     if cpu:
         O, L2 = _oracle()
@@ -119,9 +119,9 @@ def c4(crux, ctx, cpu=True, steps=200):
     t = _timed(ctx, epoch, steps)
     ach = C4_FLOP / t / 1e12
     out = {"workload": "SAC, GaussianPolicy 3-256-256-1 + twin Q 4-256-256-1, B = 256: one value_training epoch (rand! + sac_target + temperature, twin-critic and actor steps + polyak)",
-           "epochs_per_s": 1.0 / t, "grad_steps_per_s": 3.0 / t, "us_per_epoch": 1e6 * t, "fused_launches_per_epoch": 1,
-           "roofline": {"kernel": "k_exec (fused epoch: ~40 tile-GEMM ops + heads + 4 Adam + polyak)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                        "algorithmic_GFLOP_per_epoch": C4_FLOP / 1e9, "note": "latency-bound: ~70 dependent ops per epoch on one XCD"}}
+           "epochs_per_s": 1.0 / t, "grad_steps_per_s": 3.0 / t, "us_per_epoch": 1e6 * t, "launches_per_epoch": 34,
+           "roofline": {"kernel": "k_phase (crux_sac_epoch: ~70 recorded ops -- ~40 tile GEMMs, heads, 4 Adam updates, polyak -- run as 34 phase launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        "algorithmic_GFLOP_per_epoch": C4_FLOP / 1e9, "note": "latency-bound: 34 dependent launches per epoch (Q1 || Q2 and the target critics share phases)"}}
     if cpu:
         O, L2 = _oracle()
         n_o = 20_000
@@ -162,7 +162,7 @@ def c1(crux, ctx, cpu=True, N=100_000):
     n_grad = len(sv.history) * 4
     out = {"workload": "DQN on SimpleGridWorld (README example): 2-8-4, N = %d, dN = 4, buffer 1000, B = 128, whole solve()" % N,
            "seconds": t, "env_steps_per_s": N / t, "grad_steps_per_s": n_grad / t,
-           "roofline": {"kernel": "k_exec / small-network learner", "bound": "hbm", "achieved": n_grad * 128 * 19 / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": n_grad * 128 * 19 / t / 1e9 / PEAK_HBM_GBS,
+           "roofline": {"kernel": "k_dqn_small_solve (the whole solve loop in one launch of one workgroup)", "bound": "hbm", "achieved": n_grad * 128 * 19 / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": n_grad * 128 * 19 / t / 1e9 / PEAK_HBM_GBS,
                         "note": "19 B per sampled transition x 128 per gradient step; a 60-parameter network: pure latency, nominally HBM-bound"}}
     if cpu:
         out["cpu_baseline"] = c1_cpu(N=20_000)

@@ -53,7 +53,9 @@ struct MfxLayout {
   static constexpr int TOTAL = oRED + 32;
 };
 
-template <int IN, int OUT, int KIND, int ACT, bool TIMING = false>
+// PX: the replica-group form (per-minibatch gradient all-reduce over the peer slots). A separate instantiation, so that the single-GPU kernel carries
+// neither the branch nor the live registers of the exchange (with a run-time test the C2 actor step was 3.6 % slower: 8.75 vs 8.44 us).
+template <int IN, int OUT, int KIND, int ACT, bool TIMING = false, bool PX = false>
 __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const TrainArgs* __restrict__ multi) {
   // multi != NULL: a batch of independent learners (multi-seed / population training) in one launch; replica r = blockIdx / 16 uses the
   // workgroups 16r and 16r + 8 (one XCD) and its own argument block, exchange area and status row
@@ -147,9 +149,9 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
   bool staged = false;                              // the next minibatch is already in this wave's LDS staging tiles
   long long xstep = 0;                              // exchanges done so far (the counter target and the slot parity)
   // replica group (comm.hip "peer"): exchanges done on this learner stream before this launch -- slot parity and flag values continue across launches
-  float* const px_mine = a.px_n > 1 ? a.px_tab[a.px_rank] : nullptr;
-  const unsigned long long px0 = a.px_n > 1 ? *(const unsigned long long*)(px_mine + CRUX_PX_COUNT) : 0ull;
-  const float px_inv = a.px_n > 1 ? 1.0f / (float)a.px_n : 1.0f;
+  float* const px_mine = PX ? a.px_tab[a.px_rank] : nullptr;
+  const unsigned long long px0 = PX ? *(const unsigned long long*)(px_mine + CRUX_PX_COUNT) : 0ull;
+  const float px_inv = PX ? 1.0f / (float)a.px_n : 1.0f;
   constexpr int XSLOT = 4096 + NSI * NT + 16;
   float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
   const int n_epochs = a.ids ? 1 : a.epochs;
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
 #pragma unroll
         for (int k = 0; k < NSI; ++k) gs[k] += pg[k];
         float stat_tot = stat_loc + ps;
-        if (a.px_n > 1) {
+        if constexpr (PX) {
           // ---- SUM all-reduce of the local gradient over the replica group, between the pullback (training.jl:18) and Flux.update! (:21) ----
           // Both workgroups hold the same local total. They share the writes (peer i of the N-1 goes to workgroup i & 1): the total and the seven
           // statistics sums go into slot [parity][my rank] of the peer's region, a system-scope release makes them visible, then flag[my rank]
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
     for (int s = tid; s < ns_valid; s += NT) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; }
   }
   if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(4 * p + w) * 16 + k] = tacc[k]; }
-  if (tid == 0 && p == 0 && a.px_n > 1) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)xstep;
+  if (PX && tid == 0 && p == 0) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)xstep;
   if (tid == 0 && (p == 0 || err)) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     a.bp[0] = bp1; a.bp[1] = bp2;
@@ -730,22 +732,29 @@ extern "C" int crux_x2_placement_ok(crux_ctx* c) {
   return cached;
 }
 
+template <int IN, int OUT, int KIND, int ACT, bool TIMING, bool PX>
+static int32_t launch_x2_form(crux_ctx* c, const TrainArgs& a, size_t lds, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma_x2<IN, OUT, KIND, ACT, TIMING, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_train_mfma_x2<IN, OUT, KIND, ACT, TIMING, PX>), dim3(16), dim3(256), lds, stream, a, (const TrainArgs*)nullptr);
+  return crux_launch_check(c, "k_train_mfma_x2");
+}
 template <int IN, int OUT, int KIND, int ACT, bool TIMING = false>
 static int32_t launch_x2(crux_ctx* c, TrainArgs a, hipStream_t stream) {
   using Lt = MfxLayout<IN, OUT>;
   static_assert(Lt::FITS, "x2 layout must fit");
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
-  static bool attr = false;
-  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma_x2<IN, OUT, KIND, ACT, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
   // exchange area: one per stream the learners run on (actor || critic use the context's two streams concurrently)
   const int which = stream == c->stream ? 0 : 1;
   constexpr size_t xbytes = sizeof(float) * 4 * 8192 + 256;
   if (!c->xbuf[which]) { if (hipMalloc(&c->xbuf[which], xbytes) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "learner exchange buffer"); }
   a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * 4 * 8192);
-  if (c->peer_n > 1 && a.need_px) { a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR; }     // local calls (single steps, gradients) never exchange
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
-  hipLaunchKernelGGL((k_train_mfma_x2<IN, OUT, KIND, ACT, TIMING>), dim3(16), dim3(256), lds, stream, a, (const TrainArgs*)nullptr);
-  return crux_launch_check(c, "k_train_mfma_x2");
+  if (c->peer_n > 1 && a.need_px) {     // local calls (single steps, gradients) never exchange
+    a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
+    return launch_x2_form<IN, OUT, KIND, ACT, false, true>(c, a, lds, stream);
+  }
+  return launch_x2_form<IN, OUT, KIND, ACT, TIMING, false>(c, a, lds, stream);
 }
 
 // n independent learners in one launch (grid 16 n): argument blocks uploaded to a per-stream device array, one exchange area each

@@ -421,9 +421,10 @@ int32_t crux_td_step_with_error(crux_mlp* net, crux_buffer* batch, const float* 
 /* One epoch of value_training (src/model_free/off_policy.jl:69-93) for the DQN family: rand!(batch, source; i) (:71, uniform or prioritized with
  * exponent beta) -> y = dqn_target(target_net, batch) (:80) -> when source is prioritized td_error (:83, shares the forward pass of the step) and
  * update_priorities!(source, batch.indices, td_error) -> train!(net, td_loss[, weight]) (:91-93). Results equal the separate calls
- * (crux_per_sample / crux_uniform_sample, crux_dqn_target, crux_td_step[_with_error], crux_per_update_device) in that order. For networks at least 128
- * wide the ~25 kernels of the epoch run as ONE persistent launch (csrc/exec.hip: the kernel bodies are executed op by op by 64 workgroups on one
- * XCD with L2 counter barriers between dependent ops), which is what makes the step latency- instead of launch-bound. info_out: LOSS, GRAD_NORM, [2] = Qavg. */
+ * (crux_per_sample / crux_uniform_sample, crux_dqn_target, crux_td_step[_with_error], crux_per_update_device) in that order, bit for bit. For networks
+ * at least 128 wide the ~25 kernel bodies of the epoch are recorded as ops and run by the executor (csrc/exec.hip): ops that do not depend on each
+ * other share a launch (13 phase launches over the whole chip instead of ~25, info rows read back once), or -- CRUX_EXEC_PERSISTENT=1 -- by ONE
+ * persistent launch on one XCD with L2 counter barriers between dependent ops. info_out: LOSS, GRAD_NORM, [2] = Qavg.                             */
 int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
                        uint64_t sample_counter, float* info_out);
 /* One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl:4-52,94-104) as one fused launch: rand! -> sac_target ->
