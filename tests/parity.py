@@ -87,7 +87,7 @@ FAMILIES = {
 # (param_tol), and by the training statistics where it is not.
 def window_tol(start):
     """abs bound on |theta_gpu - theta_oracle| (parameters O(0.1-1)) after a 16-step teacher-forced window that starts `start` steps into training.
-    Measured on MI355X (profiles/r02_parity_windows.txt): 3e-8 .. 6e-8 (one ulp of the larger weights) for every window from step 256 on, in all four
+    Measured on MI355X (profiles/r02_parity_measurements.txt): 3e-8 .. 6e-8 (one ulp of the larger weights) for every window from step 256 on, in all four
     learner families; during Adam's first steps v is tiny, the update lr*m/(sqrt(v)+eps) amplifies a last-bit gradient difference and a relu kink can
     flip inside the window (measured up to 1.4e-5 at step 128)."""
     return 5e-5 if start < 256 else 2e-7
