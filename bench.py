@@ -343,6 +343,27 @@ def main():
     sync, comm_kind = None, "single GPU"
     if world > 1 or args.force_sync:
         sync, comm_kind = setup_group(args, crux, ctx, rank, world, local)
+        if sync == "grad":
+            # probe: a few minibatches through the in-kernel exchange before anything is timed. A rank whose peers never answer gets CRUX_EHIP from the kernel's own
+            # timeout (and raises the abort word for the others); if ANY rank failed, all ranks drop to periodic parameter averaging with fresh learners.
+            ok = True
+            try:
+                pa = crux.TrainingParams(loss=crux.ppo_loss, batch_size=BATCH, epochs=1, target_kl=None, name="actor_", shuffle_seed=900 + rank, max_batches=8)
+                pc = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=BATCH, epochs=1, name="critic_", shuffle_seed=950 + rank, max_batches=8)
+                ppo_iteration(crux, pi, buf, sampler, pa, pc, P, 0, sync); ctx.sync()
+            except Exception as e:      # noqa: BLE001
+                ok = False; print("bench.py: rank %d: the peer-slot exchange failed its probe (%r)" % (rank, e), file=sys.stderr)
+            tdev0 = torch.device("cuda", local) if dist.get_backend() == "nccl" else torch.device("cpu")
+            flag = torch.tensor([1 if ok else 0], device=tdev0); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                try:
+                    ctx.peer_detach()
+                except Exception:       # noqa: BLE001
+                    pass
+                args.sync = "params"
+                pi, buf, sampler = build_problem(crux, cdist.shard_seed(0, rank), workload=args.workload)
+                sync, comm_kind = setup_group(args, crux, ctx, rank, world, local)
+                comm_kind += " [fallback: the in-kernel peer-slot gradient exchange failed its probe iteration on at least one rank]"
 
     def barrier():
         ctx.sync()
