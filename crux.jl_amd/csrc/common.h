@@ -37,6 +37,7 @@ struct crux_ctx {
   int peer_n = 0, peer_rank = 0; void* peer_local = nullptr; void* peer_ptr[8] = {}; bool peer_ipc[8] = {}; bool peer_fine = false;
   void* rec = nullptr;                 // ExecRec* (exec.h): the fused-step executor's recording state
   void* lag_dev = nullptr;        // device copy of crux_lagrange for crux_batch_train_lagrange
+  void* dense_tmp = nullptr; size_t dense_tmp_bytes = 0;   // minibatch staging of the dense-engine on-policy learner (train_dense.hip)
   void* epoch_tmp = nullptr; size_t epoch_tmp_bytes = 0;   // targets / td errors of the un-fused epoch path
   float** peer_tab = nullptr;   // device [2 learner streams][8]: region base of every rank for that stream (what the kernel indexes)
 };

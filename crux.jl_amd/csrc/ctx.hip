@@ -97,6 +97,7 @@ int32_t crux_ctx_destroy(crux_ctx* c) {
   if (c->peer_local) (void)hipFree(c->peer_local);
   if (c->peer_tab) (void)hipFree(c->peer_tab);
   if (c->lag_dev) (void)hipFree(c->lag_dev);
+  if (c->dense_tmp) (void)hipFree(c->dense_tmp);
   for (int k = 0; k < c->aux_n_rejected; ++k) (void)hipStreamDestroy(c->aux_rejected[k]);
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->aux_ev0); (void)hipEventDestroy(c->aux_ev1); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);

@@ -206,6 +206,7 @@ struct AdamGatedOp { static __device__ __forceinline__ void run(const unsigned b
   // can share this op's phase instead of preceding it by a barrier
   double sq;
   if (!from_partials) sq = ssq[0]; else { sq = 0; for (int k = 0; k < SUMSQ_BLOCKS; ++k) sq += ssq[1 + k]; }
+  if (status[0] == CRUX_ENAN) return;      // an earlier step of this launch sequence already stopped with "NaN detected!": no further updates (training.jl:20)
   if (isnan(sq)) { if (bid_ == 0 && threadIdx.x == 0) status[0] = CRUX_ENAN; return; }
   const double c1 = 1.0 - bp[0], c2 = 1.0 - bp[1];
   for (int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x; i < n; i += (int64_t)nb_ * blockDim.x) {     // element-wise: any grid gives the same result

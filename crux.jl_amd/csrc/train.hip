@@ -44,7 +44,7 @@ static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const cr
   a.loss = internal_loss; a.head = cfg->head; a.bs = cfg->batch_size; a.epochs = cfg->epochs; a.max_batches = cfg->max_batches;
   a.eps_clip = cfg->eps_clip; a.lambda_p = cfg->lambda_p; a.lambda_e = cfg->lambda_e; a.target_kl = cfg->target_kl;
   a.shuffle_seed = cfg->shuffle_seed; a.shuffle_counter = cfg->shuffle_counter;
-  a.len = buf->elements; a.order_a = buf->order_a; a.order_b = buf->order_b; a.apply = 1; a.squash = net->squash;
+  a.len = buf->elements; a.order_a = buf->order_a; a.order_b = buf->order_b; a.apply = 1; a.squash = net->squash; a.host_net = net;
   const int nout = net->nd.dims[net->nd.L];
   if (internal_loss == CRUX_LOSS_LOGPDF_BC) {   // logpdf_bc_loss (il/bc.jl:10-18) = a2c_loss with advantage == 1, lambda_p = 1 and old logprob == 0 (so "kl" = -mean(logpdf))
     if (!buf->aux_ones) {
@@ -123,6 +123,8 @@ static int32_t build_orders(crux_ctx* c, crux_buffer* buf, int slot, const int32
   return crux_launch_check(c, "k_compose_order");
 }
 
+bool crux_train_dense_eligible(const TrainArgs& a, size_t generic_lds, bool force_generic);     // train_dense.hip
+int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a);
 static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_t stream = nullptr) {
   bool handled = false;
   if (!stream) stream = c->stream;
@@ -134,14 +136,20 @@ static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_
   int32_t rc = crux_train_mfma_launch(c, a, &handled, stream);
   if (rc) return rc;
   if (a.need_px && !handled) return crux_fail(c, CRUX_EUNSUP, "batch_train! with a replica group attached needs the two-CU learner kernels (IN->64->64->OUT of the supported families, batch 65..128): this learner would run un-synchronised");
+  if (!handled && stream == c->stream && crux_train_dense_eligible(a, generic_lds_bytes(a.nd), getenv("CRUX_FORCE_GENERIC") != nullptr)) {
+    // outside the register-resident family: the MFMA dense engine, one chain of tile GEMMs per minibatch (train_dense.hip)
+    rc = crux_train_dense_run(c, a);
+    if (prof) crux_prof_end(c, prof_slot);
+    return rc;
+  }
   if (!handled) {
     // the generic learner is one workgroup of scalar loops: right for tiny networks and single steps, ~60x slower per minibatch than the MFMA family
     // on anything 64 wide -- say so once instead of silently falling off the cliff
     if (!a.ids && a.apply && a.nd.n_params >= 2048 && !a.lag && !getenv("CRUX_FORCE_GENERIC") && !getenv("CRUX_QUIET")) {
       static bool warned = false;
       if (!warned) { warned = true; char shape[128]; int o = 0; for (int l = 0; l <= a.nd.L && o < 100; ++l) o += snprintf(shape + o, sizeof shape - o, l ? "-%d" : "%d", a.nd.dims[l]);
-        fprintf(stderr, "[cruxhip] batch_train!: network %s (batch %d) is outside the MFMA learner family (IN-64-64-OUT with IN in {3,4,8,17}, batch <= 128, PPO / A2C / value losses); "
-                        "running the generic single-workgroup learner, roughly 60x slower per minibatch. (CRUX_QUIET=1 silences this.)\n", shape, a.bs); }
+        fprintf(stderr, "[cruxhip] batch_train!: network %s (batch %d, loss %d) is outside the MFMA learner family (IN-64-64-OUT with IN in {3,4,8,17}, batch <= 128) and not a case of the "
+                        "dense-engine learner (PPO / A2C / value losses): running the generic single-workgroup learner, 40-1000x slower per minibatch. (CRUX_QUIET=1 silences this.)\n", shape, a.bs, a.loss); }
     }
     const size_t lds = generic_lds_bytes(a.nd);
     if (lds > 160 * 1024 - 64) return crux_fail(c, CRUX_EUNSUP, "train!: network too wide for the generic learner kernel (%zu B of LDS)", lds);
@@ -408,7 +416,9 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
                                                  const int64_t* perms_a, const int64_t* perms_c, float* info_a, float* info_c, float* epoch_infos_a, float* epoch_infos_c) {
   if (!actor || !critic || !buf || !cfg_a || !cfg_c) return CRUX_EINVAL;
   crux_ctx* c = actor->ctx;
-  const bool exact = cfg_a->target_kl < 0.f && cfg_a->max_batches <= 0 && !getenv("CRUX_SEQUENTIAL_LEARNERS");
+  bool exact = cfg_a->target_kl < 0.f && cfg_a->max_batches <= 0 && !getenv("CRUX_SEQUENTIAL_LEARNERS");
+  { auto mfma_family = [](const crux_mlp* n) { const NetDesc& d = n->nd; return d.L == 3 && d.dims[1] == 64 && d.dims[2] == 64; };
+    if (!mfma_family(actor) || !mfma_family(critic)) exact = false; }     // dense-engine / generic learners run one after the other on the main stream
   if (!exact) {
     int32_t rc = crux_batch_train(actor, buf, cfg_a, perms_a, info_a, epoch_infos_a); if (rc) return rc;
     return crux_batch_train(critic, buf, cfg_c, perms_c, info_c, epoch_infos_c);

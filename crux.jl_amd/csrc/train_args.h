@@ -36,6 +36,7 @@ struct TrainArgs {
   int32_t px_n, px_rank; float* const* px_tab;   // px_tab: device table [px_n] of the ranks' region bases for this learner stream (own region at px_rank)
   // lagrange_ppo_loss (rl/ppo.jl:70-131): device copy of crux_lagrange (hyper-parameters + PID state), the cost columns; NULL = plain ppo_loss
   crux_lagrange* lag; const float* COST; const float* CADV; const uint8_t* EE;
+  void* host_net;            // host-side: the crux_mlp this block was filled from (the dense-engine learner drives its GEMM workspace); never read on the device
 };
 
 // The minibatch rows are device global memory. Typing the per-step loads as address_space(1) makes them global_load instead of the flat_load a

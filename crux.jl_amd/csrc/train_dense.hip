@@ -1,0 +1,166 @@
+// train_dense.hip -- batch_train! / train! (src/training.jl:13-55) for networks OUTSIDE the register-resident IN-64-64-OUT family, on the MFMA dense engine.
+//
+// The persistent learner kernels keep a whole 64-wide network in one or two compute units; everything else used to fall to the generic single-workgroup
+// learner (scalar loops, ~0.5 ms per minibatch at 64 wide) or, beyond its LDS budget (hidden widths of 256), was refused. Here a minibatch step is the chain
+//   gather the minibatch's observations through the composed shuffle order -> Chain forward (tile GEMMs, dense.hip) -> loss head (ppo_loss / a2c_loss /
+//   critic mse: d(loss)/d(output), statistics, logSigma gradient) -> pullback (tile GEMMs) -> norm(grad), NaN check -> Flux.update! (gated Adam)
+// of ~13 stream-ordered launches, driven from the host over epochs x minibatches like the reference's loop. The host synchronises once per epoch (the
+// epoch's info row, training.jl:48), or once per minibatch when KL early stopping or max_batches need a decision (training.jl:45-46). NaN: the gated Adam
+// leaves the parameters alone and every later step of the launch finds the status set and does the same (training.jl:20: error, no update).
+// Compiled inside offpolicy_unit.hip (uses the heads' helpers of sac.hip).
+#include "train_args.h"
+#ifndef EPS32F
+#define EPS32F 1.1920928955078125e-07f
+#endif
+#define CRUX_MAXEXTRA 64      // logSigma entries a Gaussian head may carry here (act_dim <= 64, as in check_sac)
+
+__global__ void k_gather_obs(const float* __restrict__ S, int od, const int32_t* __restrict__ rows, int64_t nb, float* __restrict__ x) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= nb * od) return;
+  const int64_t s = i / od; const int k = (int)(i - s * od);
+  x[i] = S[(int64_t)rows[s] * od + k];
+}
+
+struct PgHeadArgs {
+  const float* z; int nout; const int32_t* rows; int64_t nb;
+  const void* A; int ad; const float* LP; const float* ADV; const float* RET;
+  int loss, head; float lo, hi, lambda_p, lambda_e, squash;
+  const float* ls;       // logSigma (p + xoff) for the Gaussian head
+  float* dy;             // [nout x nb]
+  float* gx;             // g + xoff: d(loss)/d(logSigma)
+  double* stats;         // [8]: sum of the clipped surrogate terms, entropy, kl, advantage, return, clip count, squared error, -
+};
+// ppo_loss (ppo.jl:4-21) / a2c_loss (a2c.jl:4-15) / Flux.mse(value, return) (ppo.jl:60): one thread per sample, the arithmetic of the generic learner's head
+__global__ __launch_bounds__(256) void k_pg_head(PgHeadArgs q) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x; const float invB = 1.0f / (float)q.nb; const bool a2c = q.loss == CRUX_LOSS_A2C;
+  double s_lossp = 0, s_H = 0, s_kl = 0, s_adv = 0, s_ret = 0, s_clip = 0, s_sq = 0;
+  double exg[CRUX_MAXEXTRA];
+  const bool gauss = CRUX_IS_PG(q.loss) && q.head == CRUX_HEAD_GAUSSIAN;
+  if (gauss) for (int k = 0; k < q.ad; ++k) exg[k] = 0.0;
+  for (int64_t s = tid; s < q.nb; s += 256) {
+    const int64_t row = q.rows[s]; const float* z = q.z + s * q.nout; float* dy = q.dy + s * q.nout;
+    if (q.loss == CRUX_LOSS_VALUE_MSE) { const float R = q.RET[row]; const float d = z[0] - R; s_sq += (double)(d * d); s_ret += (double)R; dy[0] = 2.f * d * invB; continue; }
+    const float A = q.ADV[row], oldlp = q.LP[row]; float newlp = 0.f, H = 0.f, r, g;
+    if (q.head == CRUX_HEAD_CATEGORICAL) {
+      const uint8_t* av = (const uint8_t*)q.A + row * q.ad;
+      float mx = z[0]; for (int k = 1; k < q.nout; ++k) mx = z[k] > mx ? z[k] : mx;
+      float sum = 0.f; for (int k = 0; k < q.nout; ++k) sum += expf(z[k] - mx);
+      float qq = 0.f, hp = 0.f;
+      for (int k = 0; k < q.nout; ++k) { const float pk = expf(z[k] - mx) / sum; qq += pk * (av[k] ? 1.f : 0.f);
+        const float lg = logf(pk + EPS32F); H -= pk * lg; hp += (-lg - pk / (pk + EPS32F)) * pk; }
+      newlp = logf(qq);
+      r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, q.lo), q.hi), cl = rc * A;
+      g = (u <= cl) ? A : 0.f; s_lossp += (double)(a2c ? newlp * A : (u <= cl ? u : cl));
+      if (a2c) { g = A; r = 1.f; }
+      for (int k = 0; k < q.nout; ++k) { const float pk = expf(z[k] - mx) / sum; const float lg = logf(pk + EPS32F); const float hk = -lg - pk / (pk + EPS32F);
+        const float dlogpi = pk * ((av[k] ? 1.f : 0.f) / qq) - pk;
+        dy[k] = invB * (-q.lambda_p * g * r * dlogpi - q.lambda_e * (pk * (hk - hp))); }
+    } else {                                                                        // GaussianPolicy / SquashedGaussianPolicy (policies.jl:333-348,374-396)
+      const float* av = (const float*)q.A + row * q.ad; const float sq = q.squash;
+      for (int k = 0; k < q.ad; ++k) { const float sg = expf(sq > 0.f ? sq_clampls(q.ls[k]) : q.ls[k]); const float uk = sq > 0.f ? sq_untanh(av[k], sq) : av[k]; const float d = uk - z[k];
+        newlp += (-(d * d) / (2.f * sg * sg) - 0.9189385332046727f - q.ls[k]); if (sq > 0.f) newlp -= sq_corr(uk); }
+      r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, q.lo), q.hi), cl = rc * A;
+      g = (u <= cl) ? A : 0.f; s_lossp += (double)(a2c ? newlp * A : (u <= cl ? u : cl));
+      if (a2c) { g = A; r = 1.f; }
+      for (int k = 0; k < q.ad; ++k) { const float sg = expf(sq > 0.f ? sq_clampls(q.ls[k]) : q.ls[k]); const float s2 = sg * sg; const float uk = sq > 0.f ? sq_untanh(av[k], sq) : av[k]; const float d = uk - z[k];
+        const float inr = (sq > 0.f && !(q.ls[k] >= -5.f && q.ls[k] <= 2.f)) ? 0.f : 1.f;
+        dy[k] = invB * (-q.lambda_p * g * r * (d / s2));
+        exg[k] += (double)(invB * (-q.lambda_p * g * r * (((d * d) / s2) * inr - 1.f))); }
+    }
+    s_H += (double)H; s_kl += (double)(oldlp - newlp); s_adv += (double)A; if (q.RET) s_ret += (double)q.RET[row];
+    if (!a2c && (r > q.hi || r < q.lo)) s_clip += 1.0;
+  }
+  const double t0 = block_sum256(s_lossp, red), t1 = block_sum256(s_H, red), t2 = block_sum256(s_kl, red), t3 = block_sum256(s_adv, red);
+  const double t4 = block_sum256(s_ret, red), t5 = block_sum256(s_clip, red), t6 = block_sum256(s_sq, red);
+  if (tid == 0) { q.stats[0] = t0; q.stats[1] = t1; q.stats[2] = t2; q.stats[3] = t3; q.stats[4] = t4; q.stats[5] = t5; q.stats[6] = t6; }
+  if (gauss) for (int k = 0; k < q.ad; ++k) { const double t = block_sum256(exg[k], red); if (tid == 0) q.gx[k] = (float)t + (-q.lambda_e); }     // + d(-lambda_e * H)/dlogSigma, H = const + sum(logSigma)
+}
+__global__ void k_pg_info(const double* __restrict__ st, const double* __restrict__ ssq, int64_t nb, int loss, int head, float lambda_p, float lambda_e, const float* __restrict__ ls, int ad,
+                          float* __restrict__ dinfo) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ssq_finalize(ssq);
+  for (int k = 0; k < CRUX_INFO_N; ++k) dinfo[k] = 0.f;
+  if (CRUX_IS_PG(loss)) {
+    const float p_loss = (float)(-(st[0] / (double)nb)); float entropy, e_loss;
+    if (head == CRUX_HEAD_CATEGORICAL) { entropy = (float)(st[1] / (double)nb); e_loss = -entropy; }
+    else { float Hs = 1.4189385332046727f; for (int k = 0; k < ad; ++k) Hs += ls[k]; entropy = Hs; e_loss = -Hs; }
+    dinfo[CRUX_INFO_LOSS] = lambda_p * p_loss + lambda_e * e_loss; dinfo[CRUX_INFO_ENTROPY] = entropy; dinfo[CRUX_INFO_KL] = (float)(st[2] / (double)nb);
+    dinfo[CRUX_INFO_CLIP_FRACTION] = (float)st[5] / (float)nb; dinfo[CRUX_INFO_AVG_ADVANTAGE] = (float)(st[3] / (double)nb); dinfo[CRUX_INFO_AVG_RETURN] = (float)(st[4] / (double)nb);
+  } else dinfo[CRUX_INFO_LOSS] = (float)(st[6] / (double)nb);
+  dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
+}
+
+__global__ void k_nan_status(const double* __restrict__ ssq, int32_t* __restrict__ status) { if (isnan(ssq[0])) status[0] = CRUX_ENAN; }   // gradient-only calls: the NaN check of training.jl:20 without the update
+
+// which learners take this path (called by launch_train after the MFMA family declined)
+bool crux_train_dense_eligible(const TrainArgs& a, size_t generic_lds, bool force_generic) {
+  if (!a.host_net || a.lag || !(a.ids || a.ord_all)) return false;
+  if (!(CRUX_IS_PG(a.loss) || a.loss == CRUX_LOSS_VALUE_MSE)) return false;
+  if (CRUX_IS_PG(a.loss) && a.head != CRUX_HEAD_CATEGORICAL && a.head != CRUX_HEAD_GAUSSIAN) return false;
+  if (a.nd.L < 1 || a.nd.n_extra > CRUX_MAXEXTRA) return false;
+  if (generic_lds > 160 * 1024 - 64) return true;                                   // the generic learner cannot hold it at all
+  return !force_generic && a.nd.n_params >= 512 && a.bs >= 32 && !a.ids;            // single steps and tiny networks (the README's 2-8-4) stay on the one-launch generic learner
+}
+
+int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a) {
+  crux_mlp* net = (crux_mlp*)a.host_net; const NetDesc& nd = net->nd; const int nout = nd.dims[nd.L], od = nd.dims[0];
+  const int64_t total_rows = a.ids ? a.n_ids : a.len; const int n_epochs = a.ids ? 1 : a.epochs;
+  const int64_t bmax = total_rows < a.bs ? total_rows : a.bs;
+  // a block of the context that nothing else carves (the caller's status / info rows live in the scratch block)
+  { const size_t need = 4 * (size_t)bmax * (size_t)(od + nout) + 256 * 8 + 4096;
+    if (c->dense_tmp_bytes < need) { if (c->dense_tmp) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->dense_tmp); c->dense_tmp = nullptr; c->dense_tmp_bytes = 0; }
+      if (hipMalloc(&c->dense_tmp, 2 * need) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "batch_train! (dense): %zu bytes of staging", 2 * need);
+      c->dense_tmp_bytes = 2 * need; } }
+  Carve cv{(char*)c->dense_tmp, 0};
+  float* x = cv.take<float>((size_t)bmax * od); float* dy = cv.take<float>((size_t)bmax * nout);
+  float* dinfo = cv.take<float>(CRUX_INFO_N); double* st = cv.take<double>(8); double* ssq = cv.take<double>(2 + SUMSQ_BLOCKS); int32_t* status = cv.take<int32_t>(4);
+  HIPCHK(c, hipMemsetAsync(status, 0, 16, c->stream));
+  float* hinfo = (float*)crux_pinned(c, sizeof(float) * CRUX_INFO_N + 16); if (!hinfo) return crux_fail(c, CRUX_ENOMEM, "batch_train! (dense): pinned staging");
+  const bool pg = CRUX_IS_PG(a.loss); const bool step_sync = (pg && a.target_kl >= 0.f);
+  long long total_batches = 0; int epochs_run = 0, err = 0; bool stop = false;
+  std::vector<float> ei((size_t)CRUX_INFO_N * (size_t)n_epochs, 0.f);
+  auto read_info = [&]() -> int32_t {
+    HIPCHK(c, hipMemcpyAsync(hinfo, dinfo, sizeof(float) * CRUX_INFO_N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hinfo + CRUX_INFO_N, status, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int32_t s; memcpy(&s, hinfo + CRUX_INFO_N, sizeof s); if (s == CRUX_ENAN) err = CRUX_ENAN;
+    return CRUX_OK;
+  };
+  for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
+    const int32_t* order = a.ids ? a.ids : a.ord_all + (size_t)ep * (size_t)a.len;
+    bool fresh = false;                      // hinfo holds the info row of the latest minibatch
+    for (int64_t s0 = 0; s0 < total_rows; s0 += a.bs) {                                                    // partition(1:len, batch_size) (training.jl:40)
+      const int64_t nb = (total_rows - s0) < a.bs ? (total_rows - s0) : a.bs;
+      hipLaunchKernelGGL(k_gather_obs, dim3((unsigned)((nb * od + 255) / 256)), dim3(256), 0, c->stream, a.S, od, order + s0, nb, x);
+      int32_t rc = crux_dense_forward(net, x, nb, c->stream); if (rc) return rc;
+      PgHeadArgs q{}; q.z = crux_dense_act(net, nd.L); q.nout = nout; q.rows = order + s0; q.nb = nb; q.A = a.A; q.ad = a.ad; q.LP = a.LP; q.ADV = a.ADV; q.RET = a.RET;
+      q.loss = a.loss; q.head = a.head; q.lo = 1.f - a.eps_clip; q.hi = 1.f + a.eps_clip; q.lambda_p = a.lambda_p; q.lambda_e = a.lambda_e; q.squash = a.squash;
+      q.ls = net->p + nd.xoff; q.dy = dy; q.gx = net->g + nd.xoff; q.stats = st;
+      hipLaunchKernelGGL(k_pg_head, dim3(1), dim3(256), 0, c->stream, q);
+      rc = crux_dense_backward(net, x, nb, dy, 1.0f, true, nullptr, c->stream); if (rc) return rc;
+      hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, c->stream, (const float*)net->g, (int64_t)nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+      hipLaunchKernelGGL(k_pg_info, dim3(1), dim3(1), 0, c->stream, (const double*)st, (const double*)ssq, nb, a.loss, a.head, a.lambda_p, a.lambda_e, (const float*)(net->p + nd.xoff), a.ad, dinfo);
+      if (a.apply) { rc = adam_gated(net, ssq, status); if (rc) return rc; }
+      else hipLaunchKernelGGL(k_nan_status, dim3(1), dim3(1), 0, c->stream, (const double*)ssq, status);
+      total_batches += 1; fresh = false;
+      const bool last = s0 + a.bs >= total_rows, capped = a.max_batches > 0 && total_batches >= a.max_batches;
+      if (step_sync || capped || last) { rc = read_info(); if (rc) return rc; fresh = true; }
+      if (err) break;
+      if (capped) break;                                                                                  // training.jl:45
+      if (step_sync && hinfo[CRUX_INFO_KL] > a.target_kl) break;                                          // :46
+    }
+    if (err) break;
+    if (!fresh) { const int32_t rc = read_info(); if (rc) return rc; if (err) break; }
+    memcpy(&ei[(size_t)ep * CRUX_INFO_N], hinfo, sizeof(float) * CRUX_INFO_N);                            // aggregate_info(minibatch_infos) == the latest minibatch's (App. A-Q3)
+    epochs_run += 1;
+    if (pg && a.target_kl >= 0.f && hinfo[CRUX_INFO_KL] > a.target_kl) stop = true;                       // :49
+    if (a.max_batches > 0 && total_batches >= a.max_batches) stop = true;                                 // :50
+  }
+  // status row and epoch infos where the persistent kernels leave them (run_batch / collect read them back)
+  if (err && epochs_run == 0) { ei[CRUX_INFO_LOSS] = hinfo[CRUX_INFO_LOSS]; ei[CRUX_INFO_GRAD_NORM] = NAN; }
+  int32_t hst[4] = {err, (int32_t)total_batches, epochs_run, 0};
+  HIPCHK(c, hipMemcpyAsync(a.status, hst, sizeof hst, hipMemcpyHostToDevice, c->stream));
+  if (a.epoch_infos) HIPCHK(c, hipMemcpyAsync(a.epoch_infos, ei.data(), sizeof(float) * ei.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));            // hst / ei are stack / heap memory of this call
+  return crux_launch_check(c, "batch_train! (dense)");
+}
