@@ -145,7 +145,7 @@ static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_
   if (!handled) {
     // the generic learner is one workgroup of scalar loops: right for tiny networks and single steps, ~60x slower per minibatch than the MFMA family
     // on anything 64 wide -- say so once instead of silently falling off the cliff
-    if (!a.ids && a.apply && a.nd.n_params >= 2048 && !a.lag && !getenv("CRUX_FORCE_GENERIC") && !getenv("CRUX_QUIET")) {
+    if (!a.ids && a.apply && a.nd.n_params >= 2048 && !getenv("CRUX_FORCE_GENERIC") && !getenv("CRUX_QUIET")) {
       static bool warned = false;
       if (!warned) { warned = true; char shape[128]; int o = 0; for (int l = 0; l <= a.nd.L && o < 100; ++l) o += snprintf(shape + o, sizeof shape - o, l ? "-%d" : "%d", a.nd.dims[l]);
         fprintf(stderr, "[cruxhip] batch_train!: network %s (batch %d, loss %d) is outside the MFMA learner family (IN-64-64-OUT with IN in {3,4,8,17}, batch <= 128) and not a case of the "

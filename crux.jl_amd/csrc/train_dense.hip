@@ -27,19 +27,45 @@ struct PgHeadArgs {
   const float* ls;       // logSigma (p + xoff) for the Gaussian head
   float* dy;             // [nout x nb]
   float* gx;             // g + xoff: d(loss)/d(logSigma)
-  double* stats;         // [8]: sum of the clipped surrogate terms, entropy, kl, advantage, return, clip count, squared error, -
+  double* stats;         // [8]: sum of the clipped surrogate terms, entropy, kl, advantage, return, clip count, squared error, lagrange cost terms
+  const crux_lagrange* lag; const float* CADV;      // lagrange_ppo_loss (ppo.jl:70-131): penalty of THIS minibatch (written by k_lagrange_pid) and D[:cost_advantage]; NULL = plain ppo_loss
 };
+// the penalty update inside lagrange_ppo_loss (ppo.jl:80-116), once per evaluation of the loss: one block sums the minibatch's :cost and :episode_end and
+// thread 0 advances the controller -- the arithmetic of the generic learner's in-kernel version (train_generic.h) and of the oracle
+__global__ __launch_bounds__(256) void k_lagrange_pid(crux_lagrange* __restrict__ lgp, const float* __restrict__ COST, const uint8_t* __restrict__ EE, const int32_t* __restrict__ rows, int64_t nb) {
+  __shared__ double red[4];
+  double sc_ = 0.0, ne_ = 0.0;
+  for (int64_t i = threadIdx.x; i < nb; i += 256) { const int64_t row = rows[i]; sc_ += (double)COST[row]; ne_ += EE[row] ? 1.0 : 0.0; }
+  const double t_sc = block_sum256(sc_, red), t_ne = block_sum256(ne_, red);
+  if (threadIdx.x != 0) return;
+  crux_lagrange lg = *lgp;
+  const float Jc = (float)t_sc / (float)t_ne;
+  const float dl = Jc - lg.target_cost;
+  { const float x = lg.I + lg.Ki * dl; lg.I = x > lg.Ki_max ? lg.Ki_max : (x < 0.f ? 0.f : x); }
+  lg.smooth_delta = (float)(lg.ema_alpha * (double)lg.smooth_delta + (1.0 - lg.ema_alpha) * (double)dl);
+  lg.smooth_Jc = (float)(lg.ema_alpha * (double)lg.smooth_Jc + (1.0 - lg.ema_alpha) * (double)Jc);
+  { const float x = lg.smooth_Jc - lg.Jc_prev; lg.deriv_term = (x != x) ? x : (x > 0.f ? x : 0.f); }
+  lg.Jc_prev = lg.smooth_Jc;
+  { const float x = (lg.Kp * lg.smooth_delta + lg.I) + lg.Kd * lg.deriv_term; lg.penalty = x > lg.penalty_max ? lg.penalty_max : (x < 0.f ? 0.f : x); }
+  lg.cur_cost = Jc;
+  *lgp = lg;
+}
 // ppo_loss (ppo.jl:4-21) / a2c_loss (a2c.jl:4-15) / Flux.mse(value, return) (ppo.jl:60): one thread per sample, the arithmetic of the generic learner's head
 __global__ __launch_bounds__(256) void k_pg_head(PgHeadArgs q) {
   __shared__ double red[4];
   const int tid = threadIdx.x; const float invB = 1.0f / (float)q.nb; const bool a2c = q.loss == CRUX_LOSS_A2C;
-  double s_lossp = 0, s_H = 0, s_kl = 0, s_adv = 0, s_ret = 0, s_clip = 0, s_sq = 0;
+  double s_lossp = 0, s_H = 0, s_kl = 0, s_adv = 0, s_ret = 0, s_clip = 0, s_sq = 0, s_cost = 0;
+  const bool lagr = q.lag != nullptr; const float pen = lagr ? q.lag->penalty : 0.f;
   double exg[CRUX_MAXEXTRA];
   const bool gauss = CRUX_IS_PG(q.loss) && q.head == CRUX_HEAD_GAUSSIAN;
   if (gauss) for (int k = 0; k < q.ad; ++k) exg[k] = 0.0;
   for (int64_t s = tid; s < q.nb; s += 256) {
     const int64_t row = q.rows[s]; const float* z = q.z + s * q.nout; float* dy = q.dy + s * q.nout;
     if (q.loss == CRUX_LOSS_VALUE_MSE) { const float R = q.RET[row]; const float d = z[0] - R; s_sq += (double)(d * d); s_ret += (double)R; dy[0] = 2.f * d * invB; continue; }
+    if (q.loss == CRUX_LOSS_MSE_ACTION) {                                            // Flux.mse(action(pi, s), a) (il/bc.jl:1): mean over act_dim x batch
+      const float* av = (const float*)q.A + row * q.ad; const float inv = invB / (float)q.nout;
+      for (int k = 0; k < q.nout; ++k) { const float d = z[k] - av[k]; s_sq += (double)(d * d) / (double)q.nout; dy[k] = 2.f * d * inv; }
+      continue; }
     const float A = q.ADV[row], oldlp = q.LP[row]; float newlp = 0.f, H = 0.f, r, g;
     if (q.head == CRUX_HEAD_CATEGORICAL) {
       const uint8_t* av = (const uint8_t*)q.A + row * q.ad;
@@ -52,9 +78,12 @@ __global__ __launch_bounds__(256) void k_pg_head(PgHeadArgs q) {
       r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, q.lo), q.hi), cl = rc * A;
       g = (u <= cl) ? A : 0.f; s_lossp += (double)(a2c ? newlp * A : (u <= cl ? u : cl));
       if (a2c) { g = A; r = 1.f; }
+      float gcr = 0.f;
+      if (lagr) { const float Ac = q.CADV[row]; const float uc = r * Ac, clc = rc * Ac; s_cost += (double)(uc >= clc ? uc : clc); gcr = (uc >= clc ? Ac : 0.f) * r; }
       for (int k = 0; k < q.nout; ++k) { const float pk = expf(z[k] - mx) / sum; const float lg = logf(pk + EPS32F); const float hk = -lg - pk / (pk + EPS32F);
         const float dlogpi = pk * ((av[k] ? 1.f : 0.f) / qq) - pk;
-        dy[k] = invB * (-q.lambda_p * g * r * dlogpi - q.lambda_e * (pk * (hk - hp))); }
+        const float base = -q.lambda_p * g * r * dlogpi - q.lambda_e * (pk * (hk - hp));
+        dy[k] = lagr ? invB * ((base + pen * gcr * dlogpi) / (1.f + pen)) : invB * base; }
     } else {                                                                        // GaussianPolicy / SquashedGaussianPolicy (policies.jl:333-348,374-396)
       const float* av = (const float*)q.A + row * q.ad; const float sq = q.squash;
       for (int k = 0; k < q.ad; ++k) { const float sg = expf(sq > 0.f ? sq_clampls(q.ls[k]) : q.ls[k]); const float uk = sq > 0.f ? sq_untanh(av[k], sq) : av[k]; const float d = uk - z[k];
@@ -62,21 +91,23 @@ __global__ __launch_bounds__(256) void k_pg_head(PgHeadArgs q) {
       r = expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, q.lo), q.hi), cl = rc * A;
       g = (u <= cl) ? A : 0.f; s_lossp += (double)(a2c ? newlp * A : (u <= cl ? u : cl));
       if (a2c) { g = A; r = 1.f; }
+      float cf = -q.lambda_p * g * r;
+      if (lagr) { const float Ac = q.CADV[row]; const float uc = r * Ac, clc = rc * Ac; s_cost += (double)(uc >= clc ? uc : clc); cf = (cf + pen * ((uc >= clc ? Ac : 0.f) * r)) / (1.f + pen); }
       for (int k = 0; k < q.ad; ++k) { const float sg = expf(sq > 0.f ? sq_clampls(q.ls[k]) : q.ls[k]); const float s2 = sg * sg; const float uk = sq > 0.f ? sq_untanh(av[k], sq) : av[k]; const float d = uk - z[k];
         const float inr = (sq > 0.f && !(q.ls[k] >= -5.f && q.ls[k] <= 2.f)) ? 0.f : 1.f;
-        dy[k] = invB * (-q.lambda_p * g * r * (d / s2));
-        exg[k] += (double)(invB * (-q.lambda_p * g * r * (((d * d) / s2) * inr - 1.f))); }
+        dy[k] = invB * (cf * (d / s2));
+        exg[k] += (double)(invB * (cf * (((d * d) / s2) * inr - 1.f))); }
     }
     s_H += (double)H; s_kl += (double)(oldlp - newlp); s_adv += (double)A; if (q.RET) s_ret += (double)q.RET[row];
     if (!a2c && (r > q.hi || r < q.lo)) s_clip += 1.0;
   }
   const double t0 = block_sum256(s_lossp, red), t1 = block_sum256(s_H, red), t2 = block_sum256(s_kl, red), t3 = block_sum256(s_adv, red);
-  const double t4 = block_sum256(s_ret, red), t5 = block_sum256(s_clip, red), t6 = block_sum256(s_sq, red);
-  if (tid == 0) { q.stats[0] = t0; q.stats[1] = t1; q.stats[2] = t2; q.stats[3] = t3; q.stats[4] = t4; q.stats[5] = t5; q.stats[6] = t6; }
-  if (gauss) for (int k = 0; k < q.ad; ++k) { const double t = block_sum256(exg[k], red); if (tid == 0) q.gx[k] = (float)t + (-q.lambda_e); }     // + d(-lambda_e * H)/dlogSigma, H = const + sum(logSigma)
+  const double t4 = block_sum256(s_ret, red), t5 = block_sum256(s_clip, red), t6 = block_sum256(s_sq, red), t7 = block_sum256(s_cost, red);
+  if (tid == 0) { q.stats[0] = t0; q.stats[1] = t1; q.stats[2] = t2; q.stats[3] = t3; q.stats[4] = t4; q.stats[5] = t5; q.stats[6] = t6; q.stats[7] = t7; }
+  if (gauss) for (int k = 0; k < q.ad; ++k) { const double t = block_sum256(exg[k], red); if (tid == 0) q.gx[k] = (float)t + (lagr ? -q.lambda_e / (1.f + pen) : -q.lambda_e); }     // + d(-lambda_e * H)/dlogSigma, H = const + sum(logSigma)
 }
 __global__ void k_pg_info(const double* __restrict__ st, const double* __restrict__ ssq, int64_t nb, int loss, int head, float lambda_p, float lambda_e, const float* __restrict__ ls, int ad,
-                          float* __restrict__ dinfo) {
+                          float* __restrict__ dinfo, const crux_lagrange* __restrict__ lag) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   ssq_finalize(ssq);
   for (int k = 0; k < CRUX_INFO_N; ++k) dinfo[k] = 0.f;
@@ -86,6 +117,9 @@ __global__ void k_pg_info(const double* __restrict__ st, const double* __restric
     else { float Hs = 1.4189385332046727f; for (int k = 0; k < ad; ++k) Hs += ls[k]; entropy = Hs; e_loss = -Hs; }
     dinfo[CRUX_INFO_LOSS] = lambda_p * p_loss + lambda_e * e_loss; dinfo[CRUX_INFO_ENTROPY] = entropy; dinfo[CRUX_INFO_KL] = (float)(st[2] / (double)nb);
     dinfo[CRUX_INFO_CLIP_FRACTION] = (float)st[5] / (float)nb; dinfo[CRUX_INFO_AVG_ADVANTAGE] = (float)(st[3] / (double)nb); dinfo[CRUX_INFO_AVG_RETURN] = (float)(st[4] / (double)nb);
+    if (lag) { const float pen = lag->penalty; const float cost_loss = pen * (float)(st[7] / (double)nb);                    // ppo.jl:119,131
+      dinfo[CRUX_INFO_LOSS] = ((lambda_p * p_loss + lambda_e * e_loss) + cost_loss) / (1.f + pen);
+      dinfo[CRUX_INFO_PENALTY] = pen; dinfo[CRUX_INFO_CUR_COST] = lag->cur_cost; dinfo[CRUX_INFO_COST_LOSS] = cost_loss; dinfo[CRUX_INFO_P_LOSS] = lambda_p * p_loss; }
   } else dinfo[CRUX_INFO_LOSS] = (float)(st[6] / (double)nb);
   dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
 }
@@ -94,8 +128,8 @@ __global__ void k_nan_status(const double* __restrict__ ssq, int32_t* __restrict
 
 // which learners take this path (called by launch_train after the MFMA family declined)
 bool crux_train_dense_eligible(const TrainArgs& a, size_t generic_lds, bool force_generic) {
-  if (!a.host_net || a.lag || !(a.ids || a.ord_all)) return false;
-  if (!(CRUX_IS_PG(a.loss) || a.loss == CRUX_LOSS_VALUE_MSE)) return false;
+  if (!a.host_net || !(a.ids || a.ord_all)) return false;
+  if (!(CRUX_IS_PG(a.loss) || a.loss == CRUX_LOSS_VALUE_MSE || (a.loss == CRUX_LOSS_MSE_ACTION && a.squash == 0.f))) return false;
   if (CRUX_IS_PG(a.loss) && a.head != CRUX_HEAD_CATEGORICAL && a.head != CRUX_HEAD_GAUSSIAN) return false;
   if (a.nd.L < 1 || a.nd.n_extra > CRUX_MAXEXTRA) return false;
   if (generic_lds > 160 * 1024 - 64) return true;                                   // the generic learner cannot hold it at all
@@ -133,13 +167,14 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a) {
       const int64_t nb = (total_rows - s0) < a.bs ? (total_rows - s0) : a.bs;
       hipLaunchKernelGGL(k_gather_obs, dim3((unsigned)((nb * od + 255) / 256)), dim3(256), 0, c->stream, a.S, od, order + s0, nb, x);
       int32_t rc = crux_dense_forward(net, x, nb, c->stream); if (rc) return rc;
-      PgHeadArgs q{}; q.z = crux_dense_act(net, nd.L); q.nout = nout; q.rows = order + s0; q.nb = nb; q.A = a.A; q.ad = a.ad; q.LP = a.LP; q.ADV = a.ADV; q.RET = a.RET;
+      if (a.lag) hipLaunchKernelGGL(k_lagrange_pid, dim3(1), dim3(256), 0, c->stream, a.lag, a.COST, a.EE, order + s0, nb);
+      PgHeadArgs q{}; q.lag = a.lag; q.CADV = a.CADV; q.z = crux_dense_act(net, nd.L); q.nout = nout; q.rows = order + s0; q.nb = nb; q.A = a.A; q.ad = a.ad; q.LP = a.LP; q.ADV = a.ADV; q.RET = a.RET;
       q.loss = a.loss; q.head = a.head; q.lo = 1.f - a.eps_clip; q.hi = 1.f + a.eps_clip; q.lambda_p = a.lambda_p; q.lambda_e = a.lambda_e; q.squash = a.squash;
       q.ls = net->p + nd.xoff; q.dy = dy; q.gx = net->g + nd.xoff; q.stats = st;
       hipLaunchKernelGGL(k_pg_head, dim3(1), dim3(256), 0, c->stream, q);
       rc = crux_dense_backward(net, x, nb, dy, 1.0f, true, nullptr, c->stream); if (rc) return rc;
       hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, c->stream, (const float*)net->g, (int64_t)nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
-      hipLaunchKernelGGL(k_pg_info, dim3(1), dim3(1), 0, c->stream, (const double*)st, (const double*)ssq, nb, a.loss, a.head, a.lambda_p, a.lambda_e, (const float*)(net->p + nd.xoff), a.ad, dinfo);
+      hipLaunchKernelGGL(k_pg_info, dim3(1), dim3(1), 0, c->stream, (const double*)st, (const double*)ssq, nb, a.loss, a.head, a.lambda_p, a.lambda_e, (const float*)(net->p + nd.xoff), a.ad, dinfo, (const crux_lagrange*)a.lag);
       if (a.apply) { rc = adam_gated(net, ssq, status); if (rc) return rc; }
       else hipLaunchKernelGGL(k_nan_status, dim3(1), dim3(1), 0, c->stream, (const double*)ssq, status);
       total_batches += 1; fresh = false;
