@@ -974,6 +974,19 @@ class CustomLoss(_Loss):
         self.fn = fn
 
 
+class ParamLoss(_Loss):
+    """A user-written loss over a bare parameter vector (a `param_optimizers` entry, on_policy.jl:59-61 / off_policy.jl:86-88: `batch_train!(θs, p_opt, P, D, π_loss=agent.π)`):
+
+        fn(theta, D, P, pi) -> (loss, dloss_dtheta)  or  (loss, dloss_dtheta, info_dict)
+
+    theta = the ParamVector's values (host copy), D = minibatch(D, indices) as a dict of host arrays, pi = the agent's policy (for value(pi, ...) on the host
+    side of the loss). There is no network between the parameters and the loss, so the gradient the user returns IS the pullback."""
+
+    def __init__(self, fn, name="param"):
+        super().__init__(name)
+        self.fn = fn
+
+
 class TrainingParams:
     """TrainingParams(; loss, optimizer=Adam(3f-4), regularizer, batch_size=128, epochs=80, early_stopping, name, max_batches)
     (src/training.jl:1-11). PPO's early_stopping (`infos[end][:kl] > target_kl`, ppo.jl:59) is expressed as target_kl and runs inside the
@@ -992,7 +1005,7 @@ class TrainingParams:
 
 
 def _uses_seam(p):
-    return isinstance(p.loss, CustomLoss) or getattr(p, "regularizer", None) is not None or getattr(p, "early_stopping", None) is not None
+    return isinstance(p.loss, (CustomLoss, ParamLoss)) or getattr(p, "regularizer", None) is not None or getattr(p, "early_stopping", None) is not None
 
 
 def _train_seam(pi, p, P, D, ids0, info):
@@ -1001,7 +1014,16 @@ def _train_seam(pi, p, P, D, ids0, info):
     the regularizer's gradient is added to the flat gradient; norm / NaN check (:19-20); Flux.update! = crux_adam_apply (:21)."""
     ctx, lib = pi.ctx, pi.ctx.lib
     n = pi.n_params; extra = {}
-    if isinstance(p.loss, CustomLoss):
+    if isinstance(p.loss, ParamLoss):                                      # a bare vector: the user's gradient is the pullback
+        res = p.loss.fn(pi.get_params(), D.minibatch(ids0 + 1), P, getattr(p, "pi_loss", None))
+        l, g0 = float(res[0]), np.ascontiguousarray(np.asarray(res[1], np.float32).reshape(-1))
+        if len(res) > 2:
+            extra = dict(res[2])
+        if g0.size != n:
+            raise ValueError("ParamLoss: the gradient must have %d entries" % n)
+        ctx.h2d(lib.crux_mlp_grads_ptr(pi.h), g0)
+        raw = None
+    elif isinstance(p.loss, CustomLoss):
         mb = D.minibatch(ids0 + 1); x = np.asfortranarray(mb["s"], dtype=np.float32); B = x.shape[1]; out = pi.network.dims[-1]
         d_x, d_y = ctx.alloc(x.nbytes), ctx.alloc(4 * out * B)
         try:
@@ -1154,8 +1176,9 @@ class OnPolicySolver:
     (src/model_free/on_policy.jl:31-54)."""
 
     def __init__(self, agent, S, N=1000, dN=200, max_steps=100, a_opt=None, c_opt=None, P=None, lambda_gae=0.95,
-                 required_columns=(), post_batch_callback=None, post_sample_callback=None, i=0, log=None, Vc=None, cost_opt=None):
+                 required_columns=(), post_batch_callback=None, post_sample_callback=None, i=0, log=None, Vc=None, cost_opt=None, param_optimizers=None):
         self.Vc, self.cost_opt = Vc, cost_opt      # cost constraints: a separate value network and its TrainingParams (on_policy.jl:50-53)
+        self.param_optimizers = list(param_optimizers or [])     # [(ParamVector, TrainingParams(loss=ParamLoss(...)))]: trained before the actor (on_policy.jl:59-61)
         self.agent, self.S, self.N, self.dN, self.max_steps = agent, S, int(N), int(dN), int(max_steps)
         self.a_opt, self.c_opt, self.P = a_opt, c_opt, P or {}
         self.lambda_gae, self.required_columns = np.float32(lambda_gae), list(required_columns)
@@ -1168,6 +1191,10 @@ def policy_gradient_training(solver, D, perms_a=None, perms_c=None):
     """policy_gradient_training(S, D) (src/model_free/on_policy.jl:56-78): actor batch_train!, then critic batch_train!.
     One C call: the two persistent learner kernels overlap on two CUs whenever that is exact (see cruxhip.h)."""
     info = {}
+    for theta, p_opt in getattr(solver, "param_optimizers", []):                                       # on_policy.jl:59-61: batch_train!(θs, p_opt, P, D, π_loss=agent.π)
+        p_opt.pi_loss = solver.agent.pi
+        pi_ = batch_train_(theta, p_opt, solver.P, D, info={})
+        info.update({k: v for k, v in pi_.items() if not k.startswith("_")})
     A, Cn, pa, pc = actor(solver.agent.pi), critic(solver.agent.pi), solver.a_opt, solver.c_opt
     if pc is None:
         return batch_train_(A, pa, solver.P, D, info=info, perms=perms_a)

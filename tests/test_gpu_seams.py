@@ -107,3 +107,40 @@ def test_user_loss_nan_raises_like_the_reference(gpu_ctx):
     with pytest.raises(crux.CruxError) as e:
         crux.train_(g, crux.TrainingParams(loss=bad, batch_size=32, epochs=1), {}, gb, np.arange(1, 33))
     assert e.value.code == L.ENAN and np.array_equal(before, g.get_params())                      # training.jl:20: no update
+
+
+def test_param_optimizers_train_a_bare_vector_before_the_actor(gpu_ctx):
+    """`param_optimizers` (on_policy.jl:59-61): batch_train!(θs, p_opt, P, D, π_loss=agent.π) for entries that are bare parameter vectors, e.g. a
+    multiplier trained by dual ascent on a constraint estimated from the minibatch; the oracle twin applies Flux's Adam to the same gradients."""
+    ctx = gpu_ctx; bs = 96
+    gb, ob = _filled(ctx, seed=39); N = len(gb)
+    lam = crux.ParamVector(np.array([0.5, -0.25], np.float32), ctx=ctx)
+    olam = O.OMlp([0], [], 2); olam.params[:] = np.array([0.5, -0.25], np.float32); olam.adam_init(float(np.float32(1e-2)))
+    seen = []
+    def dual(theta, D, P, pi):          # maximise theta[0] * (mean |advantage| - 0.5) - theta[1]^2: gradient of the negated objective
+        c = float(np.mean(np.abs(D["advantage"]))) - P["budget"]
+        seen.append(pi is not None)
+        return -theta[0] * c + theta[1] ** 2, np.array([-c, 2 * theta[1]], np.float32), {"constraint": c}
+    g, _ = parity.make_pair(parity.ACTOR_DIMS, parity.ACTS, 12, 0, "discrete"); gc, _ = parity.make_pair(parity.CRITIC_DIMS, parity.ACTS, 12, 1)
+    class _S:
+        pass
+    s = _S(); s.agent = crux.PolicyParams(crux.ActorCritic(g, gc)); s.P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1, "budget": 0.5}
+    s.a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=bs, epochs=1, name="actor_", shuffle_seed=1)
+    s.c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=bs, epochs=1, name="critic_", shuffle_seed=2)
+    p_lam = crux.TrainingParams(loss=crux.ParamLoss(dual), optimizer=crux.Adam(np.float32(1e-2)), batch_size=bs, epochs=2, name="lambda_", shuffle_seed=3)
+    s.param_optimizers = [(lam, p_lam)]
+    before = g.get_params()
+    info = crux.policy_gradient_training(s, gb)
+    assert all(seen) and len(seen) == 2 * (N // bs) and "lambda_loss" in info and "constraint" in info and "actor_loss" in info
+    assert not np.array_equal(before, g.get_params())                                    # the actor trained after the parameter step
+    # oracle twin: the same shuffles (library permutation stream), the same minibatch means, Flux's Adam
+    perm = np.empty(N, np.int64); adv = ob["advantage"][0].copy()
+    for ep in range(2):
+        O.lib().orc_perm(3, ep, N, O.vpz(perm)); adv = adv[perm]
+        for st in range(0, N, bs):
+            c = float(np.mean(np.abs(adv[st:st + bs]))) - 0.5
+            th = olam.params.copy(); olam.grads[:] = np.array([-c, 2 * th[1]], np.float32)
+            O.chk(O.lib().orc_adam_apply(olam.h, 1.0))
+    d = float(np.abs(lam.get_params() - olam.params).max())
+    print("param_optimizers: multiplier after %d steps: %s vs oracle %s (max diff %.3g)" % (2 * (N // bs), lam.get_params(), olam.params, d))
+    assert d < 1e-6
