@@ -155,3 +155,106 @@ def test_unsupported_shape_with_a_group_attached_is_refused(two_contexts):
     with pytest.raises(crux.CruxError) as e:
         crux.batch_train_(g, crux.TrainingParams(loss=crux.value_mse_loss, batch_size=32, epochs=1), {}, b)
     assert e.value.code == L.EUNSUP
+
+
+@pytest.mark.parametrize("R,which", [(3, "actor"), (4, "critic"), (4, "actor")])
+def test_more_than_two_replicas_sum_in_rank_order(gpu_ctx, R, which):
+    """N = 3 (an unpaired last rank in the slot loop) and N = 4 (peers shared between the two workgroups of a learner) on one GPU: R persistent learners spin
+    concurrently, every step adds R contributions in rank order; all replicas stay bit-identical and equal the oracle's single learner on R x 128 rows."""
+    extra = [crux.Context(0) for _ in range(R - 1)]
+    ctxs = [gpu_ctx] + extra
+    try:
+        crux.peer_attach_local(ctxs)
+        bs, epochs = 128, 1
+        shards = [_shard(500 + r, E=4, T=128) for r in range(R)]
+        N = shards[0]["s"].shape[1]; extras = ["return", "logprob", "advantage"]
+        dims = parity.ACTOR_DIMS if which == "actor" else parity.CRITIC_DIMS
+        loss, head = ("ppo", "categorical") if which == "actor" else ("value_mse", "deterministic")
+        rng = np.random.default_rng(7)
+        perms = [np.stack([rng.permutation(N) for _ in range(epochs)]) for _ in range(R)]
+        nets, bufs = [], []
+        for r, ctx in enumerate(ctxs):
+            ch = parity.chain(dims, parity.ACTS)
+            g = crux.DiscreteNetwork(ch, [1, 2], ctx=ctx, seed=78, stream=3) if which == "actor" else crux.ContinuousNetwork(ch, ctx=ctx, seed=78, stream=3)
+            b = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), N, extras, ctx=ctx); b.push_(shards[r])
+            nets.append(g); bufs.append(b)
+        P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+        def make(r):
+            def f():
+                opt = crux.TrainingParams(loss=crux.ppo_loss if which == "actor" else crux.value_mse_loss, batch_size=bs, epochs=epochs, name="n_")
+                crux.batch_train_(nets[r], opt, P, bufs[r], perms=perms[r] + 1)
+            return f
+        _run_threads([make(r) for r in range(R)])
+        ps = [n.get_params() for n in nets]
+        for r in range(1, R):
+            assert np.array_equal(ps[0], ps[r]), "replica %d diverged" % r
+        glob, pos = _interleave(shards, bs)
+        ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, R * N, extras); ob.push(glob)
+        o = O.OMlp(dims, parity.ACTS).init_glorot(78, 3).adam_init(float(np.float32(3e-4)))
+        gperm = np.empty((epochs, R * N), np.int64)
+        for e in range(epochs):
+            for r in range(R):
+                gperm[e, pos[r]] = pos[r][perms[r][e]]
+        cfg = parity.train_cfg(loss, head, R * bs, epochs, -1.0, 0); oi = np.zeros(L.INFO_N, np.float32)
+        O.chk(O.lib().orc_batch_train(o.h, ob.h, C.byref(cfg), O.vpz(gperm), O.vpz(oi), None))
+        d = float(np.abs(ps[0] - o.params).max())
+        print(which, "%d replicas vs the concatenated-batch oracle after %d steps: max |dtheta| = %.3g" % (R, epochs * (N // bs), d))
+        assert d < parity.window_tol(0)
+    finally:
+        for c in ctxs:
+            try:
+                c.peer_detach()
+            except Exception:       # noqa: BLE001
+                pass
+        for c in extra:
+            c.close()
+
+
+def test_three_replicas_of_the_c5_actor(gpu_ctx):
+    """the wide-head (17 -> 64 -> 64 -> 6, tanh, Gaussian) form of the exchange, which takes the peer slots one rank at a time: 3 replicas == the oracle on 3 x 128 rows"""
+    R, bs, E, T = 3, 128, 4, 128
+    od, ad, disc, adims, cdims, acts, kind, head, okind = parity.FAMILIES["synth_c5"]
+    extras = ["return", "logprob", "advantage"]
+    def shard(seed):
+        _, oa = parity.make_pair(adims, acts, 50, 0, kind, n_extra=ad, extra_init=-0.5); _, oc = parity.make_pair(cdims, acts, 50, 1)
+        ob = O.OBuffer(od, ad, L.ACTION_CONTINUOUS, E * T, extras)
+        O.OEnv(okind, E, 60, 0.99, seed, so=od, sa=ad).rollout(oa, parity.rollout_cfg(head=head), ob, T)
+        O.chk(O.lib().orc_fill_gae(ob.h, oc.h, 0.95, 0.99)); O.chk(O.lib().orc_fill_returns(ob.h, 0.99)); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
+        return {k: ob[k] for k in ob.keys()}
+    extra = [crux.Context(0) for _ in range(R - 1)]; ctxs = [gpu_ctx] + extra
+    try:
+        crux.peer_attach_local(ctxs)
+        shards = [shard(600 + r) for r in range(R)]; N = E * T
+        rng = np.random.default_rng(9); perms = [rng.permutation(N)[None, :] for _ in range(R)]
+        nets, bufs = [], []
+        for r, ctx in enumerate(ctxs):
+            g = crux.GaussianPolicy(parity.chain(adims, acts), np.full(ad, -0.5, np.float32), ctx=ctx, seed=79, stream=3)
+            b = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.ContinuousSpace(ad), N, extras, ctx=ctx); b.push_(shards[r])
+            nets.append(g); bufs.append(b)
+        P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.0}
+        def make(r):
+            def f():
+                crux.batch_train_(nets[r], crux.TrainingParams(loss=crux.ppo_loss, batch_size=bs, epochs=1, name="n_"), P, bufs[r], perms=perms[r] + 1)
+            return f
+        _run_threads([make(r) for r in range(R)])
+        ps = [n.get_params() for n in nets]
+        assert np.array_equal(ps[0], ps[1]) and np.array_equal(ps[0], ps[2])
+        glob, pos = _interleave(shards, bs)
+        ob = O.OBuffer(od, ad, L.ACTION_CONTINUOUS, R * N, extras); ob.push(glob)
+        o = O.OMlp(adims, acts, ad).init_glorot(79, 3, -0.5).adam_init(float(np.float32(3e-4)))
+        gperm = np.empty((1, R * N), np.int64)
+        for r in range(R):
+            gperm[0, pos[r]] = pos[r][perms[r][0]]
+        cfg = parity.train_cfg("ppo", "gaussian", R * bs, 1, -1.0, 0, le=0.0); oi = np.zeros(L.INFO_N, np.float32)
+        O.chk(O.lib().orc_batch_train(o.h, ob.h, C.byref(cfg), O.vpz(gperm), O.vpz(oi), None))
+        d = float(np.abs(ps[0] - o.params).max())
+        print("c5 actor, 3 replicas vs the concatenated-batch oracle after %d steps: max |dtheta| = %.3g" % (N // bs, d))
+        assert d < parity.window_tol(0)
+    finally:
+        for c in ctxs:
+            try:
+                c.peer_detach()
+            except Exception:       # noqa: BLE001
+                pass
+        for c in extra:
+            c.close()
