@@ -175,7 +175,7 @@ int32_t crux_buffer_create(crux_ctx* ctx, int32_t obs_dim, int32_t act_dim, int3
 
 int32_t crux_buffer_destroy(crux_buffer* b) {
   if (!b) return CRUX_OK;
-  (void)hipStreamSynchronize(b->ctx->stream);
+  crux_sync_before_free(b->ctx);
   crux_buffer_topo_free(b);
   for (int k = 0; k < CRUX_NCOLS; ++k) if (b->col[k]) (void)hipFree(b->col[k]);
   if (b->priorities) (void)hipFree(b->priorities); if (b->cumsum) (void)hipFree(b->cumsum); if (b->pminmax) (void)hipFree(b->pminmax);

@@ -162,17 +162,21 @@ int32_t crux_peer_attach_local(crux_ctx* const* ctxs, int32_t n) {
     for (int q = 0; q < n; ++q) { if (ctxs[q]->device != c->device) { (void)hipDeviceEnablePeerAccess(ctxs[q]->device, 0); (void)hipGetLastError(); }
       c->peer_ptr[q] = ctxs[q]->peer_local; c->peer_ipc[q] = false; }
     c->peer_rank = r; c->peer_n = n;
+    { bool same = false; for (int q = 0; q < n; ++q) if (q != r && ctxs[q]->device == c->device) same = true;       // device-wide waits (hipFree) would deadlock against the peer's spinning kernel
+      if (same && !c->peer_same_device) { c->peer_same_device = true; crux_same_device_group_enter(); } }
     const int32_t rc = peer_upload_table(c); if (rc) return rc; }
   for (int r = 0; r < n; ++r) { HIPCHK(ctxs[r], hipSetDevice(ctxs[r]->device)); (void)crux_x2_placement_ok(ctxs[r]); }
   const int32_t rcs = crux_make_streams_concurrent(ctxs, n);        // replicas sharing a device: every learner stream on its own hardware queue
-  if (rcs) { for (int r = 0; r < n; ++r) { ctxs[r]->peer_n = 0; ctxs[r]->peer_rank = 0; } return rcs; }
+  if (rcs) { for (int r = 0; r < n; ++r) { ctxs[r]->peer_n = 0; ctxs[r]->peer_rank = 0; if (ctxs[r]->peer_same_device) { ctxs[r]->peer_same_device = false; crux_same_device_group_leave(); } } return rcs; }
   return CRUX_OK;
 }
 int32_t crux_peer_detach(crux_ctx* c) {
   if (!c) return CRUX_EINVAL;
   (void)hipStreamSynchronize(c->stream); if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
   for (int r = 0; r < CRUX_PX_MAXR; ++r) { if (c->peer_ipc[r]) (void)hipIpcCloseMemHandle(c->peer_ptr[r]); c->peer_ipc[r] = false; c->peer_ptr[r] = nullptr; }
-  c->peer_n = 0; c->peer_rank = 0; return CRUX_OK;
+  c->peer_n = 0; c->peer_rank = 0;
+  if (c->peer_same_device) { c->peer_same_device = false; crux_same_device_group_leave(); }      // the last member to leave frees the parked blocks
+  return CRUX_OK;
 }
 int32_t crux_peer_size(const crux_ctx* c) { return c && c->peer_n > 1 ? c->peer_n : 1; }
 int32_t crux_peer_rank(const crux_ctx* c) { return c && c->peer_n > 1 ? c->peer_rank : 0; }

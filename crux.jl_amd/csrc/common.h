@@ -36,6 +36,9 @@ struct crux_ctx {
   // gradients into over xGMI; peer_ptr[r] is rank r's region as mapped here (own region for r == peer_rank)
   int peer_n = 0, peer_rank = 0; void* peer_local = nullptr; void* peer_ptr[8] = {}; bool peer_ipc[8] = {}; bool peer_fine = false;
   void* rec = nullptr;                 // ExecRec* (exec.h): the fused-step executor's recording state
+  // replica group with another context of THIS process on the same device (crux_peer_attach_local): hipFree waits for the whole device, i.e. for the peer's
+  // spinning learner kernel, which waits for this replica -- blocks that must be re-allocated while the group is attached are parked instead and freed at detach
+  bool peer_same_device = false;
   void* lag_dev = nullptr;        // device copy of crux_lagrange for crux_batch_train_lagrange
   void* dense_tmp = nullptr; size_t dense_tmp_bytes = 0;   // minibatch staging of the dense-engine on-policy learner (train_dense.hip)
   void* epoch_tmp = nullptr; size_t epoch_tmp_bytes = 0;   // targets / td errors of the un-fused epoch path
@@ -60,6 +63,16 @@ struct crux_ctx {
 int32_t crux_fail(crux_ctx* ctx, int32_t code, const char* fmt, ...);
 void* crux_scratch(crux_ctx* ctx, size_t bytes);       // grows; contents undefined
 void* crux_pinned(crux_ctx* ctx, size_t bytes);
+// hipFree waits for the whole device. While contexts of this process form a replica group on ONE device (crux_peer_attach_local: tests, single-GPU
+// development), a learner kernel of one replica spins until the others answer -- a device-wide wait issued by another host thread (a growing scratch block,
+// or a finalizer of the host language's garbage collector destroying an unrelated handle) would wait for that kernel and stop the thread the kernel is
+// waiting for. Every hipFree of the library therefore goes through crux_hip_free: a plain hipFree normally, parked until the last same-device group detaches otherwise.
+hipError_t crux_hip_free(void* p);
+void crux_same_device_group_enter();
+void crux_same_device_group_leave();
+#define hipFree(p) crux_hip_free((void*)(p))
+void crux_sync_before_free(crux_ctx* ctx);           // hipStreamSynchronize(ctx->stream) unless a same-device group exists (then the frees are parked anyway and the stream may hold a spinning learner)
+void crux_free_device(crux_ctx* ctx, void* p);      // stream-synchronised free (parked like every free while a same-device group exists)
 void crux_prof_begin(crux_ctx* ctx, int slot);
 void crux_prof_end(crux_ctx* ctx, int slot);
 

@@ -17,11 +17,34 @@ int32_t crux_launch_check(crux_ctx* ctx, const char* what) {
 
 bool crux_exec_recording(const crux_ctx* c);          // exec.hip
 void* crux_exec_scratch(crux_ctx* c, size_t bytes);
+#undef hipFree
+#include <atomic>
+#include <mutex>
+static std::atomic<int> g_same_device_members{0};      // contexts of this process currently attached to a replica group that shares a device
+static std::mutex g_parked_mu; static std::vector<void*> g_parked;
+hipError_t crux_hip_free(void* p) {
+  if (!p) return hipSuccess;
+  if (g_same_device_members.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(g_parked_mu); g_parked.push_back(p); return hipSuccess; }
+  return hipFree(p);
+}
+void crux_same_device_group_enter() { g_same_device_members.fetch_add(1, std::memory_order_acq_rel); }
+void crux_same_device_group_leave() {
+  if (g_same_device_members.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+  std::vector<void*> v; { std::lock_guard<std::mutex> lk(g_parked_mu); v.swap(g_parked); }
+  for (void* p : v) (void)hipFree(p);
+}
+#define hipFree(p) crux_hip_free((void*)(p))
+void crux_sync_before_free(crux_ctx* ctx) { if (g_same_device_members.load(std::memory_order_acquire) == 0) (void)hipStreamSynchronize(ctx->stream); }
+void crux_free_device(crux_ctx* ctx, void* p) {
+  if (!p) return;
+  crux_sync_before_free(ctx);
+  (void)hipFree(p);
+}
 void* crux_scratch(crux_ctx* ctx, size_t bytes) {
   // while a fused sequence is being recorded (exec.hip) the pieces' scratch blocks must not alias: ops of different pieces may share a phase
   if (crux_exec_recording(ctx)) return crux_exec_scratch(ctx, bytes);
   if (bytes <= ctx->scratch_bytes) return ctx->scratch;
-  if (ctx->scratch) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+  if (ctx->scratch) { crux_free_device(ctx, ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
   size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
   if (hipMalloc(&ctx->scratch, want) != hipSuccess) { ctx->scratch = nullptr; return nullptr; }
   ctx->scratch_bytes = want;
@@ -97,6 +120,7 @@ int32_t crux_ctx_destroy(crux_ctx* c) {
   if (c->peer_local) (void)hipFree(c->peer_local);
   if (c->peer_tab) (void)hipFree(c->peer_tab);
   if (c->lag_dev) (void)hipFree(c->lag_dev);
+  if (c->peer_same_device) { c->peer_same_device = false; crux_same_device_group_leave(); }
   if (c->dense_tmp) (void)hipFree(c->dense_tmp);
   for (int k = 0; k < c->aux_n_rejected; ++k) (void)hipStreamDestroy(c->aux_rejected[k]);
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->aux_ev0); (void)hipEventDestroy(c->aux_ev1); }
@@ -115,7 +139,7 @@ int32_t crux_device_alloc(crux_ctx* c, int64_t bytes, void** out) {
   if (hipMalloc(out, (size_t)bytes) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "device_alloc(%lld) failed", (long long)bytes);
   return CRUX_OK;
 }
-int32_t crux_device_free(crux_ctx* c, void* p) { if (!c) return CRUX_EINVAL; if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); } return CRUX_OK; }
+int32_t crux_device_free(crux_ctx* c, void* p) { if (!c) return CRUX_EINVAL; if (p) { crux_sync_before_free(c); (void)hipFree(p); } return CRUX_OK; }
 int32_t crux_memcpy_h2d(crux_ctx* c, void* d_dst, const void* src, int64_t bytes) {
   if (!c || bytes < 0) return CRUX_EINVAL; if (bytes == 0) return CRUX_OK;
   HIPCHK(c, hipMemcpyAsync(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return CRUX_OK;

@@ -432,6 +432,144 @@ __global__ __launch_bounds__(256) void k_dqn_small_solve(SmallSolveArgs q) {
   if (tid == 0) { q.status[0] = st_s[0]; q.status[8] = err; for (int z = 0; z < 8; ++z) ((unsigned long long*)(q.status + 16))[z] = tacc[z]; }
 }
 
+typedef float f32x4_env __attribute__((ext_vector_type(4)));
+// ---- the same solve loop for a TINY network, wave-resident ----------------------------------------------------------------------------------
+// The README example's DQN (SimpleGridWorld, 2 -> 8 -> 4, 60 parameters, B = 128) is a few hundred flops per gradient step: in k_dqn_small_solve the step
+// still cost 68 us, almost all of it workgroup barriers and Float64 block reductions of the shape-generic learner body -- one host core does the step in
+// 21 us. Here ONE wave owns the whole problem: parameter i, its Adam moments and the target network's copy live in lane i's registers and are broadcast with
+// v_readlane; the replay ring is mirrored in LDS (the rollout body still writes the global columns, the new rows are copied over after each steps!);
+// lane j evaluates samples j and j + 64 of the minibatch (target network, Q network, td_loss and the per-sample parameter gradients in registers), the
+// 60 x 64 partial gradients are transposed through LDS so that lane i adds parameter i's contributions in lane order, and applies Flux's Adam (Float64 per
+// element, like the generic body). No workgroup barrier exists in the loop. Same mathematics as the call-by-call loop with a different (fixed) summation
+// order of the minibatch gradient: parity against the oracle is to float tolerance (tests/test_gpu_components.py: the solve loop keeps the oracle's
+// trajectories and replay contents exactly, the networks to 1e-5), not bit-identity with k_dqn_small_solve, which stays as the shape-generic form.
+template <int IN, int H, int OUT>
+__global__ __launch_bounds__(64) void k_dqn_tiny_solve(SmallSolveArgs q) {
+  constexpr int NP = H * IN + H + OUT * H + OUT, oW1 = 0, oB1 = H * IN, oW2 = oB1 + H, oB2 = oW2 + OUT * H;
+  static_assert(NP <= 64 && OUT == 4, "one parameter per lane; the one-hot action row is read as one 32-bit word");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x; const int B = q.B; const int64_t C = q.C;
+  float* sm_ro = sm;                                                   // rollout body: hbuf[2][1024] + misc
+  float* mS = sm_ro + (2 * 1024 + ENV_MAXOBS + 8);                     // ring mirror: S [C x IN], SP [C x IN], R [C], A (action index) [C], D [C]
+  float* mSP = mS + C * IN; float* mR = mSP + C * IN; int32_t* mA = (int32_t*)(mR + C); int32_t* mD = mA + C;
+  float* red = (float*)(mD + C);                                       // [NP][64] transpose buffer
+  const float* gS = q.ro.S; const float* gSP = q.ro.SP; const float* gR = q.ro.R; const uint8_t* gA = (const uint8_t*)q.ro.A; const uint8_t* gD = q.ro.D;
+  auto mirror_row = [&](int64_t row) {
+    for (int k = 0; k < IN; ++k) { mS[row * IN + k] = gS[row * IN + k]; mSP[row * IN + k] = gSP[row * IN + k]; }
+    mR[row] = gR[row]; int ai = 0; for (int k = 0; k < OUT; ++k) ai = gA[row * OUT + k] ? k : ai; mA[row] = ai; mD[row] = gD[row] ? 1 : 0;
+  };
+  for (int64_t row = lane; row < q.elements; row += 64) mirror_row(row);
+  float p = lane < NP ? q.tr.p[lane] : 0.f, pt = lane < NP ? q.pt[lane] : 0.f, am = lane < NP ? q.tr.m[lane] : 0.f, av = lane < NP ? q.tr.v[lane] : 0.f;
+  double bp1 = q.tr.bp[0], bp2 = q.tr.bp[1];
+  int64_t elements = q.elements, next = q.next; int err = 0;
+  const float invB = 1.0f / (float)B;
+  auto W = [&](float reg, int i) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, reg), i)); };   // parameter i, wave-uniform
+  auto forward = [&](float reg, const float (&x)[IN], float (&h)[H], float (&o)[OUT]) {
+#pragma unroll
+    for (int j = 0; j < H; ++j) { float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < IN; ++k) acc = fmaf(W(reg, oW1 + j + H * k), x[k], acc);
+      const float z = acc + W(reg, oB1 + j); h[j] = z > 0.f ? z : 0.f; }
+#pragma unroll
+    for (int j = 0; j < OUT; ++j) { float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < H; ++k) acc = fmaf(W(reg, oW2 + j + OUT * k), h[k], acc);
+      o[j] = acc + W(reg, oB2 + j); }
+  };
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  for (int it = 0; it < q.iters && !err; ++it) {
+    const uint64_t si = q.i0 + (uint64_t)it * (uint64_t)q.dN;
+    // ---- steps!(sampler, buffer, Nsteps = dN, explore = true, i = S.i): the generic rollout body with theta read from global memory
+    if (lane < NP) q.tr.p[lane] = p;
+    __threadfence();
+    { RolloutArgs ro = q.ro; ro.base = next; ro.cfg.i0 = si; rollout_generic_wave(ro, 0, lane, (float (*)[1024])sm_ro, sm_ro + 2 * 1024); }
+    __threadfence();
+    if (lane < q.dN) mirror_row((next + lane) % C);
+    next = (next + q.dN) % C; elements = elements + q.dN < C ? elements + q.dN : C;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    for (int ep = 0; ep < q.epochs; ++ep) {
+      const uint64_t ictr = si * (uint64_t)q.epochs + (uint64_t)ep;
+      float g[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) g[k] = 0.f;
+      double s_sq = 0.0, s_q = 0.0;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int j = lane + 64 * half;
+        if (j < B) {
+          // rand!(D, buffer): uniform_sample! with the library's Philox draw (per.hip k_uniform_ids)
+          const crux_u32x4 xr = crux_philox(q.sample_seed, ictr * (uint64_t)B + (uint64_t)j, q.sample_stream, CRUX_RNG_SAMPLE);
+          const int64_t row = (int64_t)(((uint64_t)xr.v[0] * (uint64_t)elements) >> 32);
+          q.bidx[j] = row;
+          float x[IN], xp[IN];
+#pragma unroll
+          for (int k = 0; k < IN; ++k) { x[k] = mS[row * IN + k]; xp[k] = mSP[row * IN + k]; }
+          const float r = mR[row]; const int ai = mA[row]; const float nd = 1.f - (mD[row] ? 1.f : 0.f);
+          // y = dqn_target(pi_minus, D) (dqn.jl:4-6): r + gamma (1 - done) max_a Q-(sp, a), un-fused
+          float h[H], o[OUT]; forward(pt, xp, h, o);
+          float mx = o[0];
+#pragma unroll
+          for (int k = 1; k < OUT; ++k) mx = o[k] > mx ? o[k] : mx;
+          const float gn = q.gamma * nd; const float tt = gn * mx; const float y = r + tt;
+          // td_loss (utils.jl:76-87): mean((Q(s, a) - y)^2) and its pullback
+          forward(p, x, h, o);
+          float Q = 0.f;
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) Q += o[k] * (k == ai ? 1.f : 0.f);
+          const float d = Q - y; s_sq += (double)(d * d); s_q += (double)Q;
+          float dq[OUT], dh[H];
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) dq[k] = (k == ai) ? 2.f * d * 1.f * invB : 0.f;
+#pragma unroll
+          for (int k = 0; k < H; ++k) { float acc = 0.f;
+#pragma unroll
+            for (int oo = 0; oo < OUT; ++oo) { g[oW2 + oo + OUT * k] = fmaf(dq[oo], h[k], g[oW2 + oo + OUT * k]); acc = fmaf(W(p, oW2 + oo + OUT * k), dq[oo], acc); }
+            dh[k] = h[k] > 0.f ? acc : 0.f; }                                                                   // relu'(0) = 0
+#pragma unroll
+          for (int oo = 0; oo < OUT; ++oo) g[oB2 + oo] += dq[oo];
+#pragma unroll
+          for (int k = 0; k < IN; ++k)
+#pragma unroll
+            for (int oo = 0; oo < H; ++oo) g[oW1 + oo + H * k] = fmaf(dh[oo], x[k], g[oW1 + oo + H * k]);
+#pragma unroll
+          for (int oo = 0; oo < H; ++oo) g[oB1 + oo] += dh[oo];
+        }
+      }
+      // transpose: lane i adds parameter i's 64 partials in lane order
+#pragma unroll
+      for (int k = 0; k < NP; ++k) red[k * 64 + lane] = g[k];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+      float gi = 0.f;
+      if (lane < NP) {
+#pragma unroll
+        for (int l4 = 0; l4 < 16; ++l4) { const f32x4_env v4 = *(const f32x4_env*)&red[lane * 64 + 4 * l4]; gi = ((((gi + v4[0]) + v4[1]) + v4[2]) + v4[3]); } }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+      const double t_ssq = wave_sum_d(lane < NP ? (double)gi * (double)gi : 0.0), t_sq = wave_sum_d(s_sq), t_q = wave_sum_d(s_q);
+      const float gnorm = (float)sqrt(t_ssq);
+      if (lane == 0) { float* e = q.infos + ((size_t)it * q.epochs + ep) * CRUX_INFO_N;
+        e[CRUX_INFO_LOSS] = (float)(t_sq / (double)B); e[CRUX_INFO_GRAD_NORM] = gnorm; e[2] = (float)(t_q / (double)B); }
+      if (isnan(gnorm)) { err = CRUX_ENAN; break; }                                                               // training.jl:20 -- no update
+      if (lane < NP) {   // Flux.update!(Adam) (training.jl:21), Float64 per element like the reference
+        const double gd = (double)gi; const double b1 = q.tr.b1, b2 = q.tr.b2;
+        const float mi = (float)(b1 * (double)am + (1.0 - b1) * gd);
+        const float vi = (float)(b2 * (double)av + ((1.0 - b2) * gd) * gd);
+        const float dd = (float)((double)mi / (1.0 - bp1) / (sqrt((double)vi / (1.0 - bp2)) + q.tr.eps) * q.tr.eta);
+        am = mi; av = vi; p = p - dd; }
+      bp1 *= q.tr.b1; bp2 *= q.tr.b2;
+    }
+    if (err) break;
+    { const float omt = __fsub_rn(1.0f, q.tau); pt = __fadd_rn(__fmul_rn(q.tau, p), __fmul_rn(omt, pt)); }          // polyak_average!(pi_minus, pi, tau) (:108)
+  }
+  // ---- leave everything where the call-by-call loop leaves it: networks, Adam state, and the staging batch = the last minibatch drawn
+  if (lane < NP) { q.tr.p[lane] = p; q.pt[lane] = pt; q.tr.m[lane] = am; q.tr.v[lane] = av; q.tr.g[lane] = 0.f; }
+  __threadfence();
+  for (int k = 0; k < q.gn; ++k) { const int re = q.gre[k];
+    for (int t = lane; t < B * re; t += 64) { const int j = t / re, e2 = t - j * re; const int64_t sidx = q.bidx[j] * re + e2;
+      if (q.gesz[k] == 4) ((uint32_t*)q.gdst[k])[t] = ((const uint32_t*)q.gsrc[k])[sidx];
+      else ((uint8_t*)q.gdst[k])[t] = ((const uint8_t*)q.gsrc[k])[sidx]; } }
+  if (lane == 0) { q.tr.bp[0] = bp1; q.tr.bp[1] = bp2; q.status[0] = err; q.status[8] = err; }
+}
+
 __global__ void k_env_init(int kind, int E, int od, int sd, uint64_t seed, const float* mu, const float* sigma, double* state, int64_t* ep_len,
                            int64_t* n_resets, float* svec, int fresh) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -529,7 +667,7 @@ int32_t crux_env_create(crux_ctx* ctx, int32_t kind, int32_t n_envs, int32_t max
 
 int32_t crux_env_destroy(crux_env* e) {
   if (!e) return CRUX_OK;
-  (void)hipStreamSynchronize(e->ctx->stream);
+  crux_sync_before_free(e->ctx);
   (void)hipFree(e->mu); (void)hipFree(e->sigma); (void)hipFree(e->state); (void)hipFree(e->ep_len); (void)hipFree(e->n_resets);
   (void)hipFree(e->steps_taken); (void)hipFree(e->svec); (void)hipFree(e->acc);
   delete e; return CRUX_OK;
@@ -710,10 +848,18 @@ extern "C" int32_t crux_dqn_small_solve(crux_mlp* net, crux_mlp* target_net, cru
   q.lds_train = (int32_t)((fl + 63) / 64 * 64); q.lds_fwd = (int32_t)(2 * (size_t)target_net->nd.maxdim * FWD_TS);
   size_t lds = sizeof(float) * ((size_t)q.lds_train + (size_t)q.lds_fwd + (size_t)E * (2 * 1024 + ENV_MAXOBS + 8));
   if (lds > 150 * 1024) return crux_fail(c, CRUX_EUNSUP, "dqn_small_solve: %zu bytes of LDS", lds);
-  static size_t attr_set = 0;
-  if (lds > attr_set) { HIPCHK(c, hipFuncSetAttribute((const void*)k_dqn_small_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = lds; }
+  // the README shape (2 -> 8 -> 4, relu, one environment, B <= 128) with a ring that fits LDS: the wave-resident kernel
+  const size_t tiny_lds = sizeof(float) * ((size_t)(2 * 1024 + ENV_MAXOBS + 8) + (size_t)source->capacity * (2 * 2 + 3) + 60 * 64) + 64;
+  const bool tiny = pn.L == 2 && pn.dims[0] == 2 && pn.dims[1] == 8 && pn.dims[2] == 4 && pn.acts[0] == CRUX_ACT_RELU && pn.acts[1] == CRUX_ACT_IDENTITY && pn.n_extra == 0 &&
+                    target_net->nd.L == 2 && target_net->nd.dims[1] == 8 && target_net->nd.acts[0] == CRUX_ACT_RELU && E == 1 && B <= 128 && dN <= 64 && tiny_lds <= 60 * 1024 &&
+                    !getenv("CRUX_SMALL_SOLVE_GENERIC");
   crux_prof_begin(c, CRUX_PROF_TD_STEP);
-  hipLaunchKernelGGL(k_dqn_small_solve, dim3(1), dim3(256), lds, c->stream, q);
+  if (tiny) hipLaunchKernelGGL((k_dqn_tiny_solve<2, 8, 4>), dim3(1), dim3(64), tiny_lds, c->stream, q);
+  else {
+    static size_t attr_set = 0;
+    if (lds > attr_set) { HIPCHK(c, hipFuncSetAttribute((const void*)k_dqn_small_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = lds; }
+    hipLaunchKernelGGL(k_dqn_small_solve, dim3(1), dim3(256), lds, c->stream, q);
+  }
   crux_prof_end(c, CRUX_PROF_TD_STEP);
   int32_t rc = crux_launch_check(c, "k_dqn_small_solve"); if (rc) return rc;
   int32_t hst9[9] = {0}; int32_t hst[2];

@@ -94,7 +94,7 @@ int32_t crux_mlp_create(crux_ctx* ctx, int32_t L, const int32_t* dims, const int
 
 int32_t crux_mlp_destroy(crux_mlp* n) {
   if (!n) return CRUX_OK;
-  (void)hipStreamSynchronize(n->ctx->stream);
+  crux_sync_before_free(n->ctx);
   (void)hipFree(n->p); (void)hipFree(n->g); (void)hipFree(n->m); (void)hipFree(n->v); (void)hipFree(n->bp); if (n->ws) (void)hipFree(n->ws);
   delete n; return CRUX_OK;
 }

@@ -90,7 +90,7 @@ __global__ void k_compose_order(const int32_t* __restrict__ prev, int32_t* __res
 // builds buf->ord_all[slot] = [n_epochs x len]; start = order the first epoch composes onto (NULL = identity = the physical row order)
 static int32_t ensure_ord(crux_ctx* c, crux_buffer* buf, int slot, size_t need) {
   if (buf->ord_all_cap[slot] < need) {
-    if (buf->ord_all[slot]) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(buf->ord_all[slot]); buf->ord_all[slot] = nullptr; buf->ord_all_cap[slot] = 0; }
+    if (buf->ord_all[slot]) { if (!c->peer_same_device) HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(buf->ord_all[slot]); buf->ord_all[slot] = nullptr; buf->ord_all_cap[slot] = 0; }
     if (hipMalloc(&buf->ord_all[slot], 4 * need) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "batch_train!: %zu bytes for the epoch orders", 4 * need);
     buf->ord_all_cap[slot] = need;
   }
@@ -177,7 +177,7 @@ static int32_t run_batch(crux_mlp* net, crux_buffer* buf, TrainArgs& a, int n_ep
     a.ord_all = oa;
   }
   rc = launch_train(c, a, slot); if (rc) return rc;
-  int32_t st[4]; std::vector<float> ei((size_t)CRUX_INFO_N * (size_t)(n_epochs > 0 ? n_epochs : 1));
+  int32_t st[8]; std::vector<float> ei((size_t)CRUX_INFO_N * (size_t)(n_epochs > 0 ? n_epochs : 1));
   HIPCHK(c, hipMemcpyAsync(st, a.status, sizeof st, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(ei.data(), a.epoch_infos, eb, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -192,6 +192,8 @@ static int32_t run_batch(crux_mlp* net, crux_buffer* buf, TrainArgs& a, int n_ep
   }
   if (epoch_infos) memcpy(epoch_infos, ei.data(), sizeof(float) * CRUX_INFO_N * (size_t)st[2]);
   if (st[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
+  if (st[0] == CRUX_EHIP) return crux_fail(c, st[0], "learner kernel stopped: %s", st[4] == 2 ? "its two workgroups were placed on different XCDs (concurrent dispatches interleaved them)" :
+                                     st[4] == 3 ? "a replica of the group did not answer within the timeout or raised the abort word" : "its second workgroup never arrived at the exchange");
   if (st[0]) return crux_fail(c, st[0], "learner kernel reported status %d", st[0]);
   return CRUX_OK;
 }

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
   AdamK ak; ak.b1 = (float)a.b1; ak.b2 = (float)a.b2; ak.omb1 = (float)(1.0 - a.b1); ak.omb2 = (float)(1.0 - a.b2); ak.eps = (float)a.eps; ak.eta = (float)a.eta;
 
   int32_t* order_cur = a.order_a; int32_t* order_nxt = a.order_b;
-  long long total_batches = 0; int epochs_run = 0, err = 0; bool stop = false;
+  long long total_batches = 0; int epochs_run = 0, err = 0, why_failed = 0; bool stop = false;
   bool staged = false;                              // the next minibatch is already in this wave's LDS staging tiles
   long long xstep = 0;                              // exchanges done so far (the counter target and the slot parity)
   // replica group (comm.hip "peer"): exchanges done on this learner stream before this launch -- slot parity and flag values continue across launches
@@ -476,14 +476,16 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
           const unsigned want = 2u * (unsigned)(xstep + 1); unsigned spins = 0; bool ok = true;
           while (__hip_atomic_load(a.xctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 24) || __hip_atomic_load(a.xctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; } }   // never hang the GPU
+          float why = ok ? 0.f : 1.f;                                   // 1: the other workgroup never arrived (or raised the abort word)
           if (ok && xstep == 0) {   // the unfenced exchange is only coherent inside one XCD's L2: refuse to train if the two workgroups were placed on different XCDs
             const unsigned peer_xcc = __hip_atomic_load(a.xctr + 8 + (1 - p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (peer_xcc != my_xcc + 1u) ok = false; }
-          if (!ok) __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          sm[Lt::oRED + 16] = ok ? 0.f : 1.f;
+            if (peer_xcc != my_xcc + 1u) { ok = false; why = 2.f; } }       // 2: the two workgroups of this learner sit on different XCDs
+          if (!ok) { __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (PX) for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // the replicas stop waiting for this one
+          sm[Lt::oRED + 16] = why;
         }
         __syncthreads();
-        if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; break; }
+        if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; why_failed = (int)sm[Lt::oRED + 16]; break; }
         MX_T(11);
         f32x4 pw[4]; float pg[NSI]; float ps = 0.f;
         // all loads of the peer's slot are in flight together (one L2 round trip): the dword loads first, then the b128 block whose wait covers them
@@ -532,10 +534,10 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
                 if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
             if (!ok) { for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
               __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            sm[Lt::oRED + 16] = ok ? 0.f : 1.f;
+            sm[Lt::oRED + 16] = ok ? 0.f : 3.f;                         // 3: a replica of the group did not answer within the timeout, or raised the abort word
           }
           __syncthreads();
-          if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; break; }
+          if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; why_failed = (int)sm[Lt::oRED + 16]; break; }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                         // system scope: nothing read below is older than the flags
           // the N - 1 slots are read two ranks at a time (all loads of a pair in flight together) and added in rank order
           f32x4 oW[4]; float oS[NSI]; const float oT = stat_tot;
@@ -697,6 +699,7 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
   if (PX && tid == 0 && p == 0) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)xstep;
   if (tid == 0 && (p == 0 || err)) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
+    if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 local workgroup missing, 2 workgroups on different XCDs, 3 replica group timeout / abort
     a.bp[0] = bp1; a.bp[1] = bp2;
     if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = inf_loss; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
   }

@@ -440,6 +440,8 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
  * in ONE launch: per iteration steps!(sampler, buffer, Nsteps = dN, explore = true, i = S.i) (:138), then value_training (:66-111): dN.. `epochs` epochs of
  * rand! (uniform) -> dqn_target -> train!(td_loss), then polyak_average!(target_net, net, tau) (:108). One workgroup runs the loop; the bodies are the ones
  * the separate calls use (crux_rollout's generic kernel, crux_uniform_sample, crux_dqn_target, crux_td_step, crux_polyak), so the results are the same bits.
+ * The README shape itself (2-8-4, one environment, B <= 128, a ring that fits LDS) runs wave-resident (parameters in lane registers, replay ring mirrored in LDS; the
+ * minibatch gradient is summed in a fixed but different order, so that form agrees with the separate calls to float tolerance instead of bit for bit).
  * CRUX_EUNSUP when the configuration needs the call-by-call loop (prioritized replay, weighted loss, batch > 256 rows, > 4 environments, wide or 64-64 networks).
  * i0 = S.i of the first iteration; infos: host [iters x epochs x CRUX_INFO_N] (LOSS, GRAD_NORM, [2] = Qavg of every epoch).                       */
 int32_t crux_dqn_small_solve(crux_mlp* net, crux_mlp* target_net, crux_env* env, const crux_rollout_cfg* cfg, crux_buffer* source, crux_buffer* batch,

@@ -3,6 +3,7 @@ learner kernels concurrently; every minibatch step SUM-all-reduces the local gra
 code path N processes on N GPUs take, with hipIpc-mapped regions instead of same-process pointers). SURVEY 8(e): k = 1 must reproduce the single
 learner on the concatenated batch -- here the oracle with minibatches of 2 x 128 = 256 rows."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -55,7 +56,12 @@ def _run_threads(fns):
         except Exception as e:      # noqa: BLE001
             errs[i] = e
     ts = [threading.Thread(target=wrap, args=(i,)) for i in range(len(fns))]
+    import faulthandler, sys
+    faulthandler.dump_traceback_later(20, file=sys.stderr)          # a group that has not finished after 20 s is stuck: show where every thread is
     [t.start() for t in ts]; [t.join(120) for t in ts]
+    faulthandler.cancel_dump_traceback_later()
+    if any(e is not None for e in errs):
+        print("replica errors:", [repr(e)[:160] if e is not None else None for e in errs], file=sys.stderr)
     assert not any(t.is_alive() for t in ts), "a replica did not return"
     for e in errs:
         if e is not None:
@@ -157,7 +163,10 @@ def test_unsupported_shape_with_a_group_attached_is_refused(two_contexts):
     assert e.value.code == L.EUNSUP
 
 
-@pytest.mark.parametrize("R,which", [(3, "actor"), (4, "critic"), (4, "actor")])
+_RS = [(3, "actor"), (3, "critic"), (4, "critic"), (4, "actor")]
+
+
+@pytest.mark.parametrize("R,which", _RS)
 def test_more_than_two_replicas_sum_in_rank_order(gpu_ctx, R, which):
     """N = 3 (an unpaired last rank in the slot loop) and N = 4 (peers shared between the two workgroups of a learner) on one GPU: R persistent learners spin
     concurrently, every step adds R contributions in rank order; all replicas stay bit-identical and equal the oracle's single learner on R x 128 rows."""

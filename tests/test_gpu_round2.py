@@ -168,10 +168,11 @@ def test_fused_sac_epoch_equals_the_separate_calls(gpu_ctx):
         assert abs(ha[-1][k] - hb[-1][k]) < 1e-5 * max(1.0, abs(hb[-1][k])), k
 
 
-def test_small_dqn_solve_in_one_launch_equals_the_call_by_call_loop(gpu_ctx):
-    """The README example's shape (DQN on SimpleGridWorld, 2-8-4, dN = 4, B = 128, buffer 1000): crux_dqn_small_solve runs whole solve iterations in one
-    workgroup with the bodies of the separate calls -- replay buffer, staging batch, both networks, Adam state and the per-iteration infos must be the
-    same bits as the call-by-call loop."""
+def test_small_dqn_solve_in_one_launch_equals_the_call_by_call_loop(gpu_ctx, monkeypatch):
+    """The README example's shape (DQN on SimpleGridWorld, 2-8-4, dN = 4, B = 128, buffer 1000): the shape-generic form of crux_dqn_small_solve runs whole solve
+    iterations in one workgroup with the bodies of the separate calls -- replay buffer, staging batch, both networks, Adam state and the per-iteration infos must
+    be the same bits as the call-by-call loop. (CRUX_SMALL_SOLVE_GENERIC: this shape would otherwise take the wave-resident kernel, tested below.)"""
+    monkeypatch.setenv("CRUX_SMALL_SOLVE_GENERIC", "1")
     def run(fast):
         q = crux.DiscreteNetwork(parity.chain([2, 8, 4], ["relu", "identity"]), [1, 2, 3, 4], seed=1)
         sv = crux.DQN(q, crux.ContinuousSpace(2), N=1600, dN=4, max_steps=100, c_opt={"batch_size": 128})
@@ -188,6 +189,33 @@ def test_small_dqn_solve_in_one_launch_equals_the_call_by_call_loop(gpu_ctx):
     assert len(a[7]) == len(b[7]) == (1600 - 200) // 4 and a[8] == b[8]
     for h1, h2 in zip(a[7], b[7]):
         assert h1 == h2
+    for x, y in zip(a[9], b[9]):
+        assert np.array_equal(x, y)
+
+
+def test_wave_resident_tiny_dqn_solve_follows_the_call_by_call_loop(gpu_ctx):
+    """k_dqn_tiny_solve (one wave owns the README problem: parameters in lane registers, replay ring mirrored in LDS) against the call-by-call loop: a different
+    but fixed summation order of the minibatch gradient, so the comparison is to tolerance -- the trajectories (greedy actions of nearly equal Q-networks) and the
+    replay contents must still be identical, the networks within 1e-5 over 350 iterations = 1 400 gradient steps."""
+    def run(fast):
+        q = crux.DiscreteNetwork(parity.chain([2, 8, 4], ["relu", "identity"]), [1, 2, 3, 4], seed=1)
+        sv = crux.DQN(q, crux.ContinuousSpace(2), N=1600, dN=4, max_steps=100, c_opt={"batch_size": 128})
+        sv.fused_epochs = fast
+        crux.solve(sv, crux.SimpleGridWorld(n_envs=1, seed=3))
+        m, v, bp = q.adam_state()
+        return q.get_params(), sv.agent.pi_minus.get_params(), m, v, bp, {k: sv.buffer[k] for k in ("s", "a", "sp", "r", "done")}, {k: sv.batch[k] for k in ("s", "a", "r")}, sv.history, sv.i, sv.sampler.state()
+    a, b = run(True), run(False)
+    for k in a[5]:
+        assert np.array_equal(a[5][k], b[5][k]), k                      # same transitions in the same ring slots
+    for k in a[6]:
+        assert np.array_equal(a[6][k], b[6][k]), k                      # the staging batch holds the last minibatch drawn
+    d = [float(np.abs(x - y).max()) for x, y in zip(a[:4], b[:4])]
+    print("tiny solve vs call-by-call after 1400 gradient steps: max |dtheta| %.3g, target %.3g, m %.3g, v %.3g" % tuple(d))
+    assert d[0] < 1e-5 and d[1] < 1e-5 and np.array_equal(a[4], b[4])
+    assert len(a[7]) == len(b[7]) and a[8] == b[8]
+    for h1, h2 in zip(a[7], b[7]):
+        for k in h1:
+            assert abs(h1[k] - h2[k]) <= 1e-4 * max(1.0, abs(h2[k])), k
     for x, y in zip(a[9], b[9]):
         assert np.array_equal(x, y)
 
