@@ -58,19 +58,20 @@ def c3(crux, ctx, cpu=True, steps=300):
     buf.update_priorities_(np.arange(1, N + 1), (np.abs(rng.normal(0, 1, N)) + 1e-3).astype(np.float32))
     q = crux.DiscreteNetwork(_chain(crux, [8, 256, 256, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=1)
     qm = crux.clone_policy(q); q.attach_optimizer(crux.Adam(np.float32(1e-3)))
-    raw = np.zeros(L.INFO_N, np.float32); k = [0]
+    EP = 4                                     # value_training runs c_opt.epochs = dN = 4 epochs per solve iteration (rl/dqn.jl): one chained call
+    raw = np.zeros((EP, L.INFO_N), np.float32); k = [0]
 
-    def epoch():
-        k[0] += 1
-        ctx.check(ctx.lib.crux_dqn_epoch(q.h, qm.h, buf.h, D.h, 0.99, 1, 0.5, k[0], raw.ctypes.data_as(L.vp)))
-    t = _timed(ctx, epoch, steps)
+    def iteration():
+        k[0] += EP
+        ctx.check(ctx.lib.crux_dqn_epochs(q.h, qm.h, buf.h, D.h, 0.99, 1, 0.5, k[0], EP, raw.ctypes.data_as(L.vp)))
+    t = _timed(ctx, iteration, max(1, steps // EP)) / EP
     ach = C3_FLOP / t / 1e12
     # bytes the replay sampling moves per epoch with the incremental tree (per.hip): <= 128 touched leaves re-summed (read + write, <= 127 x 4 B each),
     # their root paths, 128 x 20 probes of (leaf id, running sum, 24 path ids, <= 24 totals), the 128-row gather (78 B/row read + write)
     per_bytes = 128 * 127 * 8 + 128 * 14 * 12 + 128 * 20 * (4 + 4 + 96 + 56) + 2 * 128 * 78
-    out = {"workload": "DQN + prioritized replay, 8-256-256-4, buffer 1 M, B = 128: one value_training epoch (prioritized_sample! + dqn_target + td_error + update_priorities! + train!)",
+    out = {"workload": "DQN + prioritized replay, 8-256-256-4, buffer 1 M, B = 128: value_training epochs (prioritized_sample! + dqn_target + td_error + update_priorities! + train!), 4 per solve iteration in one chained call",
            "grad_steps_per_s": 1.0 / t, "per_samples_per_s": B / t, "us_per_epoch": 1e6 * t, "launches_per_epoch": 13,
-           "roofline": {"kernel": "k_phase (crux_dqn_epoch: the epoch's ~25 recorded ops -- 10 tile GEMMs, heads, Adam, replay ops -- run as 13 phase launches over the whole chip)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+           "roofline": {"kernel": "k_phase (crux_dqn_epochs: every epoch's ~25 recorded ops -- 10 tile GEMMs, heads, Adam, replay ops -- run as 13 phase launches over the whole chip)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                         "algorithmic_MFLOP_per_epoch": C3_FLOP / 1e6, "note": "latency-bound: 13 dependent launches of ~5 us plus their CPU enqueue cost; independent ops share a launch. The persistent one-XCD form (CRUX_EXEC_PERSISTENT=1, 1.3 us L2 barriers) measured slower"},
            "replay_sampling": {"bytes_per_epoch_incremental": per_bytes, "bytes_per_epoch_full_rescan": 8 * N, "bound": "hbm", "note": "the reference's cumsum(priorities) per gradient step (4 MB read + 4 MB write at N = 1 M) is replaced by re-summing the touched leaves and their root paths; sample indices stay bit-exact"}}
     if cpu:
@@ -111,16 +112,17 @@ def c4(crux, ctx, cpu=True, steps=200):
     pi = crux.ActorCritic(crux.GaussianPolicy(_chain(crux, [3, 256, 256, 1], acts), np.zeros(1, np.float32), seed=2),
                           crux.DoubleNetwork(crux.ContinuousNetwork(_chain(crux, [4, 256, 256, 1], acts), seed=3), crux.ContinuousNetwork(_chain(crux, [4, 256, 256, 1], acts), seed=4)))
     opt = {"batch_size": B, "optimizer": crux.Adam(np.float32(3e-4))}
-    solver = crux.SAC(pi, S, N=10**9, dN=1, c_opt=dict(opt), a_opt=dict(opt), SAC_alpha_opt=dict(opt), buffer=buf)
+    EP = 50                                    # SAC's dN = 50: value_training runs c_opt.epochs = 50 epochs per solve iteration (rl/sac.jl), chained 8 at a time
+    solver = crux.SAC(pi, S, N=10**9, dN=EP, c_opt=dict(opt), a_opt=dict(opt), SAC_alpha_opt=dict(opt), buffer=buf)
     solver.batch = D
 
-    def epoch():
-        solver.i += 1; crux.value_training(solver, D, np.float32(0.99))
-    t = _timed(ctx, epoch, steps)
+    def iteration():
+        solver.i += EP; crux.value_training(solver, D, np.float32(0.99))
+    t = _timed(ctx, iteration, max(1, steps // EP), warmup=1) / EP
     ach = C4_FLOP / t / 1e12
-    out = {"workload": "SAC, GaussianPolicy 3-256-256-1 + twin Q 4-256-256-1, B = 256: one value_training epoch (rand! + sac_target + temperature, twin-critic and actor steps + polyak)",
+    out = {"workload": "SAC, GaussianPolicy 3-256-256-1 + twin Q 4-256-256-1, B = 256: value_training epochs (rand! + sac_target + temperature, twin-critic and actor steps + polyak), 50 per solve iteration chained 8 at a time",
            "epochs_per_s": 1.0 / t, "grad_steps_per_s": 3.0 / t, "us_per_epoch": 1e6 * t, "launches_per_epoch": 34,
-           "roofline": {"kernel": "k_phase (crux_sac_epoch: ~70 recorded ops -- ~40 tile GEMMs, heads, 4 Adam updates, polyak -- run as 34 phase launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+           "roofline": {"kernel": "k_phase (crux_sac_epochs: per epoch ~70 recorded ops -- ~40 tile GEMMs, heads, 4 Adam updates, polyak -- run as 34 phase launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                         "algorithmic_GFLOP_per_epoch": C4_FLOP / 1e9, "note": "latency-bound: 34 dependent launches per epoch (Q1 || Q2 and the target critics share phases)"}}
     if cpu:
         O, L2 = _oracle()

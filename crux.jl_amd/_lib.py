@@ -91,6 +91,8 @@ SIGNATURES = {
     "crux_buffer_set_sample_stream": (i32, [vp, u64, u32]),
     "crux_dqn_small_solve": (i32, [vp, vp, vp, P(RolloutCfg), vp, vp, i32, i32, i32, f32, f32, i32, u64, vp, P(f64), P(i64)]),
     "crux_dqn_epoch": (i32, [vp, vp, vp, vp, f32, i32, f32, u64, vp]),
+    "crux_dqn_epochs": (i32, [vp, vp, vp, vp, f32, i32, f32, u64, i32, vp]),
+    "crux_sac_epochs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i32, i32, u64, u64, u64, vp, vp, vp]),
     "crux_sac_epoch": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, u64, u64, u64, vp, vp, vp]),
     "crux_env_create": (i32, [vp, i32, i32, i32, f32, vp, vp, u64, i32, i32, P(vp)]),
     "crux_env_destroy": (i32, [vp]),

@@ -1611,10 +1611,26 @@ def _value_training_sac(solver, D, gamma):
     if solver._dy is None:
         solver._dy = ctx.alloc(4 * B)
     infos, lib, raw = [], ctx.lib, np.zeros(L.INFO_N, np.float32)
-    for epoch in range(c_opt.epochs):
+    if solver.fused_epochs:
+        # the whole epoch loop (:69-104) in one C call: chains of up to 8 epochs per recorded list, no host round trip between them (cruxhip.h: crux_sac_epochs);
+        # same pieces, order and draws as the epoch-by-epoch branch below
+        _set_stream_for(buf, solver.sample_seed)
+        n = c_opt.epochs; ctr0 = solver.i * n
+        rt, rq, ra = (np.zeros((n, L.INFO_N), np.float32) for _ in range(3))
+        ctx.check(lib.crux_sac_epochs(A.h, Q.N1.h, Q.N2.h, pim.A.h, Qm.N1.h, Qm.N2.h, la.h, buf.h, D.h, float(gamma), float(solver.P["SAC_H_target"]), float(solver.tau),
+                                      1 if solver.weighted_loss else 0, 0, n, int(c_opt.update_every), int(a_opt.update_every), ctr0, solver.noise_seed, 3 * ctr0,
+                                      _vp(rt), _vp(rq), _vp(ra)))
+        for epoch in range(n):
+            info = {t_opt.name + "loss": float(rt[epoch, 0]), t_opt.name + "grad_norm": float(rt[epoch, 1]), "SAC alpha": float(rt[epoch, L.INFO["alpha"]])}
+            if epoch % c_opt.update_every == 0:
+                info.update({c_opt.name + "loss": float(rq[epoch, 0]), c_opt.name + "grad_norm": float(rq[epoch, 1]), "Q1avg": float(rq[epoch, L.INFO["q1avg"]]), "Q2avg": float(rq[epoch, L.INFO["q2avg"]])})
+            if epoch % a_opt.update_every == 0:
+                info.update({a_opt.name + "loss": float(ra[epoch, 0]), a_opt.name + "grad_norm": float(ra[epoch, 1]), "entropy": float(ra[epoch, L.INFO["entropy"]])})
+            infos.append(info)
+    for epoch in range(0 if solver.fused_epochs else c_opt.epochs):
         ctr = solver.i * c_opt.epochs + epoch                                                          # one Philox counter block per epoch
         upd_c, upd_a = epoch % c_opt.update_every == 0, epoch % a_opt.update_every == 0                # :91, :96
-        if solver.fused_epochs:
+        if False:
             # the whole epoch (:71-100) as one fused launch (cruxhip.h: crux_sac_epoch); same pieces, order and draws as the branch below
             _set_stream_for(buf, solver.sample_seed)
             rt, rq, ra = np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32)
@@ -1704,15 +1720,16 @@ def value_training(solver, D, gamma):
         solver._dy, solver._derr = ctx.alloc(4 * B), ctx.alloc(4 * B)
     infos = []
     fused = solver.target_fn == "dqn" and solver.fused_epochs
-    for epoch in range(p.epochs):
+    if fused:
+        # the whole epoch loop (:69-93) in one C call: for wide networks all c_opt.epochs epochs are recorded into one list and run without a host round trip
+        # between them (cruxhip.h: crux_dqn_epochs); same steps, same order, same draws as the separate calls below
+        _set_stream_for(buf, solver.sample_seed)
+        beta = float(np.float32(buf.beta(solver.i))) if buf.isprioritized() else 0.0                       # rand!(D, buffer, i=S.i): beta(S.i)
+        raws = np.zeros((p.epochs, L.INFO_N), np.float32)
+        ctx.check(ctx.lib.crux_dqn_epochs(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, _vp(raws)))
+        infos = [{p.name + "loss": float(r[0]), p.name + "grad_norm": float(r[1]), "Qavg": float(r[2])} for r in raws]
+    for epoch in range(0 if fused else p.epochs):
         raw = np.zeros(L.INFO_N, np.float32)
-        if fused:
-            # the whole epoch (:71-93) in one C call -- one fused launch for wide networks (cruxhip.h: crux_dqn_epoch); same steps, same order, same draws
-            _set_stream_for(buf, solver.sample_seed)
-            beta = float(np.float32(buf.beta(solver.i))) if buf.isprioritized() else 0.0                   # rand!(D, buffer, i=S.i): beta(S.i)
-            ctx.check(ctx.lib.crux_dqn_epoch(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs + epoch, _vp(raw)))
-            infos.append({p.name + "loss": float(raw[0]), p.name + "grad_norm": float(raw[1]), "Qavg": float(raw[2])})
-            continue
         rand_(D, buf, i=solver.i, counter=solver.i * p.epochs + epoch, seed=solver.sample_seed)        # :71 rand!(D, buffer, i=S.i): beta(S.i); the Philox counter is unique per draw
         if solver.target_fn == "softq":
             ctx.check(ctx.lib.crux_softq_target(pim.h, D.h, float(gamma), float(solver.P["alpha"]), solver._dy))   # :80  softq.jl:4-13

@@ -48,6 +48,9 @@ struct ExecRec {
   unsigned* d_ctr = nullptr;                                       // device: barrier counter, abort flag
   void* h_stage = nullptr; size_t h_stage_cap = 0;                 // pinned staging of the op list and of the read-backs
   size_t scratch_floor = 0, scratch_off = 0;                       // scratch requests made while recording are carved one after the other from the pre-sized block
+  // chained epochs (crux_dqn_epochs / crux_sac_epochs): several value_training epochs recorded into ONE list, scheduled and run once -- no host round trip between
+  // the epochs of an iteration. While `chain` is set the per-epoch entry points append their phase tags (offset by chain_base) instead of scheduling and running.
+  bool chain = false, chain_ok = true; int chain_base = 0; std::vector<int> chain_tags;
 };
 bool crux_exec_recording(const crux_ctx* c);
 int32_t crux_exec_begin(crux_ctx* c);                 // start recording on this context (the launch sites below push ops instead of launching)

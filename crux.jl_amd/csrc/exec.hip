@@ -147,6 +147,7 @@ int32_t crux_exec_begin(crux_ctx* c) {
   if (!crux_scratch(c, (size_t)32 << 20)) return crux_fail(c, CRUX_ENOMEM, "executor: scratch");     // pre-sized: the scratch block must not move while pointers into it are recorded
   r->scratch_floor = c->scratch_bytes; r->scratch_off = 0;
   r->ops.clear(); r->readbacks.clear(); r->small_off = 0; r->active = true;
+  r->chain_tags.clear(); r->chain_base = 0; r->chain_ok = true;
   return CRUX_OK;
 }
 void crux_exec_abort(crux_ctx* c) { if (c->rec) { ExecRec* r = rec_of(c); r->active = false; r->ops.clear(); r->readbacks.clear(); } }
@@ -276,10 +277,11 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
   // bookkeeping beside the backward chain.    0 search | 1 gather, ring ids, zero-fill | 2+k forward layer k (both nets; + push! priorities of the batch)
   //   2+L dqn_target | 3+L td head | 4+L+j backward of layer L-1-j (weight + data gradient; + update_priorities!, leaf re-sum, root paths) | then norm, info, Adam
   std::vector<int> ph; bool plan_ok = true; const int Ld = net->nd.L;
-  auto tag = [&](size_t from, auto&& rule) { if (!fuse || !crux_exec_recording(c)) return; ExecRec* r = rec_of(c); int g = 0;
-    for (size_t i = from; i < r->ops.size(); ++i) { const int p = rule(r->ops[i].kid, g); if (p < 0) plan_ok = false; ph.push_back(p < 0 ? 0 : p); } };
+  auto tag = [&](size_t from, auto&& rule) { if (!fuse || !crux_exec_recording(c)) return; ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
+    for (size_t i = from; i < r->ops.size(); ++i) { const int p = rule(r->ops[i].kid, g); if (p < 0) plan_ok = false; ph.push_back((p < 0 ? 0 : p) + base); } };
   rc = piece(1); if (rc) return bail(rc);
-  size_t m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
+  const size_t ops0 = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;      // first op of THIS epoch (a chained recording already holds the earlier epochs)
+  size_t m = ops0;
   rc = per ? crux_per_sample(batch, source, B, nullptr, beta, sample_counter) : crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
   tag(m, [&](int kid, int&) { return (kid == OP_PER_SEARCH || kid == OP_UNIFORM_IDS) ? 0 : (kid == OP_GATHER_RING_ALL || kid == OP_RING_IDS || kid == OP_COPY_F32) ? 1 : kid == OP_PER_UPDATE ? 2 : -1; });
   rc = piece(2); if (rc) return bail(rc);
@@ -301,10 +303,48 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
     rc = crux_per_update_device(source, batch->d_indices, d_err, B); if (rc) return bail(rc);
     tag(m, [&](int kid, int&) { return kid == OP_PER_UPDATE ? 4 + Ld : kid == OP_LEAF_REFRESH ? 5 + Ld : kid == OP_TREE_TOUCH ? 6 + Ld : -1; }); }
   else { rc = crux_td_step(net, batch, d_y, use_weight, info_out); if (rc) return bail(rc); tag(m, td_rule); }
+  if (fuse && crux_exec_recording(c) && rec_of(c)->chain) {     // chained: the caller (crux_dqn_epochs) schedules and runs the whole list
+    ExecRec* r = rec_of(c);
+    if (!(plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 7 + 2 * Ld;
+    return CRUX_OK;
+  }
   if (fuse && crux_exec_recording(c) && plan_ok && !eager_mask && !getenv("CRUX_EXEC_NO_PHASES") && target_net->nd.L == Ld && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
   if (fuse && getenv("CRUX_EXEC_VERBOSE")) { ExecRec* r = rec_of(c); int nbar = 0; for (auto& o : r->ops) nbar += o.barrier; fprintf(stderr, "[exec] dqn_epoch: %zu ops, %d barriers, plan_ok=%d tags=%zu\n", r->ops.size(), nbar, (int)plan_ok, ph.size());
     for (auto& o : r->ops) fprintf(stderr, "   kid %d blocks %u barrier %d\n", o.kid, o.nblocks, o.barrier); }
   return (fuse && crux_exec_recording(c)) ? crux_exec_run(c) : CRUX_OK;
+}
+
+// value_training's epoch loop (off_policy.jl:69: `for epoch in 1:c_opt.epochs`) for the DQN family as ONE recorded list: the n epochs are recorded back to back, the
+// phases of epoch e follow those of epoch e - 1, and the host uploads, launches and reads back once. Epoch e draws with sample counter sample_counter0 + e; beta is
+// the iteration's (rand!(…, i = S.i)). infos: host [n x CRUX_INFO_N]. Falls back to n single-epoch calls wherever an epoch cannot be chained (narrow networks, a
+// priority tree that needs a full rebuild between epochs).
+int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
+                        uint64_t sample_counter0, int32_t n_epochs, float* infos) {
+  if (!net || !target_net || !source || !batch || n_epochs < 1) return CRUX_EINVAL;
+  crux_ctx* c = net->ctx;
+  const bool fuse = net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && !getenv("CRUX_NO_FUSED_EPOCH") && !getenv("CRUX_EXEC_NO_PHASES") &&
+                    !getenv("CRUX_EXEC_EAGER_MASK") && !getenv("CRUX_NO_CHAINED_EPOCHS");
+  auto flush = [&]() -> int32_t {
+    if (!crux_exec_recording(c)) return CRUX_OK;
+    ExecRec* r = rec_of(c); r->chain = false;
+    if (r->chain_ok && r->chain_tags.size() == r->ops.size()) { const int32_t rs = exec_schedule(c, r->chain_tags); if (rs) { crux_exec_abort(c); return rs; } }
+    return crux_exec_run(c);
+  };
+  int32_t rc = CRUX_OK; int in_chain = 0;
+  for (int e = 0; e < n_epochs; ++e) {
+    float* info_e = infos ? infos + (size_t)e * CRUX_INFO_N : nullptr;
+    if (!fuse) { rc = crux_dqn_epoch(net, target_net, source, batch, gamma, use_weight, beta, sample_counter0 + (uint64_t)e, info_e); if (rc) return rc; continue; }
+    // a priority tree that needs a plain rebuild (the ring is still filling, or a bulk change) cannot be refreshed inside a recording: run what is recorded first
+    if (in_chain && ((source->prioritized && source->per_full_dirty) || in_chain >= 8)) { rc = flush(); in_chain = 0; if (rc) return rc; }
+    if (!in_chain) { if (source->prioritized) { rc = crux_per_prepare(source); if (rc) return rc; }
+      rc = crux_exec_begin(c); if (rc) return rc; }
+    rec_of(c)->chain = true;
+    rc = crux_dqn_epoch(net, target_net, source, batch, gamma, use_weight, beta, sample_counter0 + (uint64_t)e, info_e);
+    if (rc) { if (c->rec) rec_of(c)->chain = false; crux_exec_abort(c); return rc; }
+    ++in_chain;
+  }
+  return fuse ? flush() : rc;
 }
 
 int32_t crux_sac_target(crux_mlp* actor, crux_mlp* q1t, crux_mlp* q2t, crux_mlp* la, crux_buffer* b, float gamma, uint64_t seed, uint64_t counter, float* d_y);
@@ -322,7 +362,8 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   if (source->prioritized) return crux_fail(c, CRUX_EUNSUP, "sac_epoch: prioritized replay over a DoubleNetwork critic is not defined (td_error, src/utils.jl:112)");
   const bool fuse = !getenv("CRUX_NO_FUSED_EPOCH");
   int32_t rc; float* d_y = nullptr;
-  if (fuse) { rc = crux_exec_begin(c); if (rc) return rc; d_y = (float*)crux_exec_small(c, 4 * (size_t)B);
+  if (fuse) { if (!crux_exec_recording(c)) { rc = crux_exec_begin(c); if (rc) return rc; }       // a chained recording (crux_sac_epochs) is already open
+    d_y = (float*)crux_exec_small(c, 4 * (size_t)B);
     if (!d_y) { crux_exec_abort(c); return crux_fail(c, CRUX_EUNSUP, "sac_epoch: batch of %lld rows exceeds the executor's region", (long long)B); } }
   else { if (c->epoch_tmp_bytes < 4 * (size_t)B + 256) { if (c->epoch_tmp) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->epoch_tmp); }
       c->epoch_tmp_bytes = 16 * (size_t)B + 4096; if (hipMalloc(&c->epoch_tmp, c->epoch_tmp_bytes) != hipSuccess) { c->epoch_tmp = nullptr; c->epoch_tmp_bytes = 0; return crux_fail(c, CRUX_ENOMEM, "sac_epoch: targets"); } }
@@ -335,9 +376,10 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   // The order inside every chain is the reference's (temperature before critic before actor: each sees the parameters the previous step left).
   std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, X = 3 + LA + LQ, Y = X + 4 + LQ;
   if (LA != LQ || q2->nd.L != LQ || q1_targ->nd.L != LQ || q2_targ->nd.L != LQ) plan_ok = false;
-  auto tag = [&](size_t from, auto&& rule) { if (!fuse) return; ExecRec* r = rec_of(c); int g = 0;
-    for (size_t i = from; i < r->ops.size(); ++i) { const int p = rule(r->ops[i].kid, g); if (p < 0) plan_ok = false; ph.push_back(p < 0 ? 0 : p); } };
-  size_t m = fuse ? exec_mark(c) : 0;
+  auto tag = [&](size_t from, auto&& rule) { if (!fuse) return; ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
+    for (size_t i = from; i < r->ops.size(); ++i) { const int p = rule(r->ops[i].kid, g); if (p < 0) plan_ok = false; ph.push_back((p < 0 ? 0 : p) + base); } };
+  const size_t ops0 = fuse ? exec_mark(c) : 0;
+  size_t m = ops0;
   rc = crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
   tag(m, [&](int kid, int&) { return kid == OP_UNIFORM_IDS ? 0 : kid == OP_GATHER_RING_ALL ? 1 : -1; });
   m = fuse ? exec_mark(c) : 0;
@@ -371,9 +413,48 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
     rc = crux_polyak(q2_targ, q2, tau); if (rc) return bail(rc);
     tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + 2 * LA + 5 + 2 * LQ : -1; });
   }
+  if (fuse && rec_of(c)->chain) {      // chained: crux_sac_epochs schedules and runs the whole list
+    ExecRec* r = rec_of(c);
+    if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + 2 * LA + 6 + 2 * LQ;
+    return CRUX_OK;
+  }
   if (fuse && plan_ok && !getenv("CRUX_EXEC_NO_PHASES") && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
   if (fuse && getenv("CRUX_EXEC_VERBOSE")) { ExecRec* r = rec_of(c); int nbar = 0; for (auto& o : r->ops) nbar += o.barrier; fprintf(stderr, "[exec] sac_epoch: %zu ops, %d phases, plan_ok=%d\n", r->ops.size(), nbar, (int)plan_ok); }
   return fuse ? crux_exec_run(c) : CRUX_OK;
+}
+
+// value_training's epoch loop with SAC's pieces (off_policy.jl:69-104; SAC's c_opt.epochs = dN = 50, rl/sac.jl) in chains of up to 8 epochs per recorded list.
+// Epoch e (global index epoch0 + e within the iteration) trains the critic when (epoch0 + e) % critic_every == 0 and the actor (then the target update) when
+// (epoch0 + e) % actor_every == 0 (:91,96); it draws with sample counter sample_counter0 + e and noise counters noise_counter0 + 3 e .. + 2. infos_*: host [n x CRUX_INFO_N].
+int32_t crux_sac_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_mlp* log_alpha,
+                        crux_buffer* source, crux_buffer* batch, float gamma, float H_target, float tau, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
+                        int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0,
+                        float* infos_temp, float* infos_critic, float* infos_actor) {
+  if (!actor || n_epochs < 1 || critic_every < 1 || actor_every < 1) return CRUX_EINVAL;
+  crux_ctx* c = actor->ctx;
+  const bool fuse = !getenv("CRUX_NO_FUSED_EPOCH") && !getenv("CRUX_EXEC_NO_PHASES") && !getenv("CRUX_NO_CHAINED_EPOCHS");
+  auto flush = [&]() -> int32_t {
+    if (!crux_exec_recording(c)) return CRUX_OK;
+    ExecRec* r = rec_of(c); r->chain = false;
+    if (r->chain_ok && r->chain_tags.size() == r->ops.size()) { const int32_t rs = exec_schedule(c, r->chain_tags); if (rs) { crux_exec_abort(c); return rs; } }
+    return crux_exec_run(c);
+  };
+  int32_t rc = CRUX_OK; int in_chain = 0;
+  for (int e = 0; e < n_epochs; ++e) {
+    const int ge = epoch0 + e; const int32_t uc = ge % critic_every == 0, ua = ge % actor_every == 0;
+    float* it = infos_temp ? infos_temp + (size_t)e * CRUX_INFO_N : nullptr; float* ic = infos_critic ? infos_critic + (size_t)e * CRUX_INFO_N : nullptr; float* ia = infos_actor ? infos_actor + (size_t)e * CRUX_INFO_N : nullptr;
+    if (fuse) {
+      if (in_chain >= 8) { rc = flush(); in_chain = 0; if (rc) return rc; }
+      if (!in_chain) { rc = crux_exec_begin(c); if (rc) return rc; }
+      rec_of(c)->chain = true;
+    }
+    rc = crux_sac_epoch(actor, q1, q2, actor_targ, q1_targ, q2_targ, log_alpha, source, batch, gamma, H_target, tau, use_weight, uc, ua,
+                        sample_counter0 + (uint64_t)e, noise_seed, noise_counter0 + 3ull * (uint64_t)e, it, ic, ia);
+    if (rc) { if (fuse && c->rec) { rec_of(c)->chain = false; crux_exec_abort(c); } return rc; }
+    if (fuse) ++in_chain;
+  }
+  return fuse ? flush() : rc;
 }
 }  // extern "C"
 

@@ -428,6 +428,11 @@ int32_t crux_td_step_with_error(crux_mlp* net, crux_buffer* batch, const float* 
  * persistent launch on one XCD with L2 counter barriers between dependent ops. info_out: LOSS, GRAD_NORM, [2] = Qavg.                             */
 int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
                        uint64_t sample_counter, float* info_out);
+/* The epoch loop of value_training (off_policy.jl:69: `for epoch in 1:c_opt.epochs`; DQN's c_opt.epochs = dN, rl/dqn.jl) as ONE recorded list: n_epochs epochs back to
+ * back, one upload, 13 phase launches per epoch, one read-back -- no host round trip between the epochs of an iteration (~60 us each). Epoch e draws with sample counter
+ * sample_counter0 + e; infos: host [n_epochs x CRUX_INFO_N]. Same results as n_epochs calls of crux_dqn_epoch.                                         */
+int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
+                        uint64_t sample_counter0, int32_t n_epochs, float* infos);
 /* One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl:4-52,94-104) as one fused launch: rand! -> sac_target ->
  * train!(log_alpha, sac_temp_loss) -> [update_critic: train!(critic, double_Q_loss)] -> [update_actor: train!(actor, sac_actor_loss), then
  * polyak_average!(target, online, tau) for the actor (when actor_targ != NULL) and both critics (:100)]. The three exploration draws use noise counters
@@ -435,6 +440,15 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
 int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_mlp* log_alpha,
                        crux_buffer* source, crux_buffer* batch, float gamma, float H_target, float tau, int32_t use_weight, int32_t update_critic, int32_t update_actor,
                        uint64_t sample_counter, uint64_t noise_seed, uint64_t noise_counter0, float* info_temp, float* info_critic, float* info_actor);
+
+/* The epoch loop of value_training with SAC's pieces in chains of up to 8 epochs per recorded list (SAC's c_opt.epochs = dN = 50, rl/sac.jl): epoch e has global index
+ * epoch0 + e within the iteration, trains the critic when that index % critic_every == 0 and the actor (+ target update) when % actor_every == 0 (off_policy.jl:91,96),
+ * draws with sample counter sample_counter0 + e and noise counters noise_counter0 + 3 e (+1, +2). infos_*: host [n_epochs x CRUX_INFO_N] (NULL = not wanted). Same
+ * results as n_epochs calls of crux_sac_epoch.                                                                                                          */
+int32_t crux_sac_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_mlp* log_alpha,
+                        crux_buffer* source, crux_buffer* batch, float gamma, float H_target, float tau, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
+                        int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0,
+                        float* infos_temp, float* infos_critic, float* infos_actor);
 
 /* solve(::OffPolicySolver) (src/model_free/off_policy.jl:133-147) for a DQN on a SMALL network (the README example: SimpleGridWorld, 2-8-4), `iters` iterations
  * in ONE launch: per iteration steps!(sampler, buffer, Nsteps = dN, explore = true, i = S.i) (:138), then value_training (:66-111): dN.. `epochs` epochs of

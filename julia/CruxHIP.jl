@@ -289,6 +289,8 @@ function sac_epoch!(𝒮, 𝒟::HipBuffer, γ, epoch; noise_seed=0)
                        ctr, noise_seed, 3ctr, it, ic, ia))
     Dict("SAC alpha" => it[3], "critic_loss" => ic[1], "actor_loss" => ia[1], "entropy" => ia[3])
 end
+# (crux_dqn_epochs / crux_sac_epochs record the whole `for epoch in 1:c_opt.epochs` loop into one list -- no host round trip between the epochs; same arguments plus the
+#  epoch count and, for SAC, the update_every periods. The per-epoch form below is the readable one.)
 function Crux.value_training(𝒮::Crux.OffPolicySolver, 𝒟::HipBuffer, γ)                                                             # off_policy.jl:66-111
     fused = haskey(𝒮.𝒫, :SAC_log_α) ? sac_epoch! : dqn_epoch!
     infos = [fused(𝒮, 𝒟, γ, epoch) for epoch in 1:𝒮.c_opt.epochs]

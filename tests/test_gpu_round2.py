@@ -247,3 +247,59 @@ def test_wide_policies_train_on_the_dense_engine_and_match_the_oracle(gpu_ctx, c
     res = parity.ppo_iteration_parity(n_envs=8, T=64, batch_size=bs, epochs=2, seed=23, family=family, target_kl=kl, pair=(kl < 0))
     assert res["ok"], res
     assert "outside the MFMA learner family" not in capfd.readouterr().err
+
+
+def test_chained_dqn_epochs_equal_single_epoch_calls(gpu_ctx):
+    """crux_dqn_epochs (the c_opt.epochs epochs of one value_training recorded into one list, no host round trip between them) == the same epochs as
+    separate crux_dqn_epoch calls: sampled rows, priorities, networks and infos, bit for bit -- with prioritized replay on a FULL ring (incremental tree
+    refresh inside the chain) and on a ring that is still filling (the chain is cut where the tree needs a plain rebuild)."""
+    def run(chained, fill):
+        rng = np.random.default_rng(3); N, B = 20_000, 128
+        S, A = crux.ContinuousSpace(8), crux.DiscreteSpace(4)
+        buf = crux.ExperienceBuffer(S, A, N, prioritized=True); D = crux.buffer_like(buf, capacity=B)
+        n0 = N if fill else N // 2
+        a = np.zeros((4, n0), bool); a[rng.integers(0, 4, n0), np.arange(n0)] = True
+        buf.push_({"s": rng.normal(0, 1, (8, n0)).astype(np.float32), "a": a, "sp": rng.normal(0, 1, (8, n0)).astype(np.float32), "r": rng.normal(0, 1, (1, n0)).astype(np.float32),
+                   "done": rng.random((1, n0)) < 0.02, "episode_end": np.zeros((1, n0), bool)})
+        buf.update_priorities_(np.arange(1, n0 + 1), (np.abs(rng.normal(0, 1, n0)) + 1e-3).astype(np.float32))
+        q = crux.DiscreteNetwork(parity.chain([8, 256, 256, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=5)
+        qm = crux.clone_policy(q); q.attach_optimizer(crux.Adam(np.float32(1e-3)))
+        ctx = q.ctx; infos = np.zeros((6, L.INFO_N), np.float32); rows = []
+        if chained:
+            ctx.check(ctx.lib.crux_dqn_epochs(q.h, qm.h, buf.h, D.h, 0.99, 1, 0.6, 40, 6, O.vpz(infos)))
+        else:
+            for e in range(6):
+                ctx.check(ctx.lib.crux_dqn_epoch(q.h, qm.h, buf.h, D.h, 0.99, 1, 0.6, 40 + e, O.vpz(infos[e])))
+        return q.get_params(), buf.priority_params()["priorities"], D.indices.copy(), D["s"], infos
+    for fill in (True, False):
+        a, b = run(True, fill), run(False, fill)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), fill
+
+
+def test_chained_sac_epochs_equal_single_epoch_calls(gpu_ctx):
+    """crux_sac_epochs (chains of up to 8 epochs per recorded list, update_every handled per epoch) == crux_sac_epoch called epoch by epoch, bit for bit;
+    11 epochs = one full chain + a partial one, critic every epoch, actor + target update every second epoch."""
+    def run(chained):
+        rng = np.random.default_rng(4); B, n = 256, 5000
+        S, A = crux.ContinuousSpace(3), crux.ContinuousSpace(1)
+        buf = crux.ExperienceBuffer(S, A, n); D = crux.buffer_like(buf, capacity=B)
+        buf.push_({"s": rng.normal(0, 1, (3, n)).astype(np.float32), "a": rng.uniform(-2, 2, (1, n)).astype(np.float32), "sp": rng.normal(0, 1, (3, n)).astype(np.float32),
+                   "r": rng.normal(-1, 1, (1, n)).astype(np.float32), "done": rng.random((1, n)) < 0.02, "episode_end": np.zeros((1, n), bool)})
+        acts = ["relu", "relu", "identity"]
+        nets = [crux.GaussianPolicy(parity.chain([3, 256, 256, 1], acts), np.zeros(1, np.float32), seed=2)] + \
+               [crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], acts), seed=s) for s in (3, 4, 3, 4)]
+        la = crux.ParamVector(np.zeros(1, np.float32))
+        for net in nets[:3] + [la]:
+            net.attach_optimizer(crux.Adam(np.float32(3e-4)))
+        a, q1, q2, t1, t2 = nets; ctx = a.ctx; E = 11
+        it, ic, ia = (np.zeros((E, L.INFO_N), np.float32) for _ in range(3))
+        if chained:
+            ctx.check(ctx.lib.crux_sac_epochs(a.h, q1.h, q2.h, None, t1.h, t2.h, la.h, buf.h, D.h, 0.99, -1.0, 0.005, 0, 0, E, 1, 2, 70, 9, 210, O.vpz(it), O.vpz(ic), O.vpz(ia)))
+        else:
+            for e in range(E):
+                ctx.check(ctx.lib.crux_sac_epoch(a.h, q1.h, q2.h, None, t1.h, t2.h, la.h, buf.h, D.h, 0.99, -1.0, 0.005, 0, 1, 1 if e % 2 == 0 else 0, 70 + e, 9, 210 + 3 * e,
+                                                 O.vpz(it[e]), O.vpz(ic[e]), O.vpz(ia[e])))
+        return [n_.get_params() for n_ in nets + [la]] + [it, ic, ia[::2]]
+    for x, y in zip(run(True), run(False)):
+        assert np.array_equal(x, y)
