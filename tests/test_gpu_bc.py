@@ -75,6 +75,6 @@ def test_bc_losses_and_solve_match_oracle(gpu_ctx, tmp_path, case):
     gv = [h["validation_error"] for h in solver.history]
     assert np.allclose(gv, ves, rtol=2e-4, atol=1e-6), (gv, ves)
     assert np.abs(g.get_params() - o.params).max() < 5e-5
-    assert abs(solver.history[-1]["loss"] - info[0]) < 2e-4 * max(1.0, abs(info[0]))
+    assert abs(solver.history[-1]["loss"] - info[0]) < 2e-6 * max(1.0, abs(info[0]))
     if loss == "logpdf_bc":
         assert "logpdf" in solver.history[-1] and "entropy" in solver.history[-1]

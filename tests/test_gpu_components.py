@@ -188,7 +188,7 @@ def test_rollout_matches_oracle(gpu_ctx, case, hidden):
         cfg.i0 = i0
         info = crux.steps_(gs, gb, Nsteps=N, explore=bool(cfg.explore), i=i0, reset=bool(cfg.reset_at_end))
         osr, one = oe.rollout(o, cfg, ob, N // E)
-        assert info["n_episode_end"] == one and abs(info["sum_r"] - osr) < 1e-3 * max(1, abs(osr))
+        assert info["n_episode_end"] == one and abs(info["sum_r"] - osr) < 1e-5 * max(1, abs(osr))
     diff = parity.compare_buffers(gb, ob)
     for k in ("done", "episode_end", "t", "i"):
         if k in diff:
@@ -303,7 +303,7 @@ def test_batch_train_early_stop_perms_and_ragged(gpu_ctx, monkeypatch, force_gen
     cfg2 = parity.train_cfg("ppo", "categorical", 32, 5, 0.01, 5)
     O.chk(O.lib().orc_batch_train(o.h, ob.h, C.byref(cfg2), None, O.vpz(oinfo), None))
     assert info2["actor_batches_trained"] == int(oinfo[L.INFO["batches_trained"]]) and info2["_epochs_run"] == int(oinfo[L.INFO["epochs_run"]]) == 1
-    assert info2["kl"] > 0.01 and abs(info2["kl"] - oinfo[L.INFO["kl"]]) < 1e-3
+    assert info2["kl"] > 0.01 and abs(info2["kl"] - oinfo[L.INFO["kl"]]) < 1e-5
     # (c) max_batches
     p3 = crux.TrainingParams(loss=crux.ppo_loss, batch_size=32, epochs=5, name="actor_", max_batches=13, shuffle_seed=9); g.optimizer = None
     info3 = crux.batch_train_(g, p3, P, gb)

@@ -31,7 +31,7 @@ def test_squashed_rollout_matches_oracle(gpu_ctx, hidden, explore):
     oe = O.OEnv("pendulum", E, 30, 0.99, 8)
     info = crux.steps_(gs, gb, Nsteps=E * T, explore=explore, i=0, reset=True)
     osr, one = oe.rollout(o, parity.rollout_cfg(explore, True, "gaussian"), ob, T)
-    assert info["n_episode_end"] == one and abs(info["sum_r"] - osr) < 1e-3 * max(1, abs(osr))
+    assert info["n_episode_end"] == one and abs(info["sum_r"] - osr) < 1e-5 * max(1, abs(osr))
     a = gb["a"]; assert np.abs(a).max() <= ASC and np.abs(a - ob["a"]).max() < 2e-5
     for k in ("s", "sp", "r"):
         assert np.abs(gb[k] - ob[k]).max() < 1e-4 * max(1, np.abs(ob[k]).max()), k
@@ -82,15 +82,15 @@ def test_squashed_learner_matches_oracle(gpu_ctx, monkeypatch, cus, force_generi
     ctx.check(ctx.lib.crux_loss_grad(g.h, gb.h, C.byref(tc), O.vpz(mb), bs, O.vpz(raw)))
     O.chk(O.lib().orc_loss_grad(o.h, ob.h, C.byref(cfg), O.vpz(mb), bs, O.vpz(oi)))
     gg = np.empty(o.n, np.float32); ctx.d2h(ctx.lib.crux_mlp_grads_ptr(g.h), gg)
-    assert np.abs(gg - o.grads).max() < 2e-4 * max(1.0, np.abs(o.grads).max())
+    assert np.abs(gg - o.grads).max() < 5e-6 * max(1.0, np.abs(o.grads).max())        # measured 4e-7 of the gradient's scale
     for k in ("loss", "grad_norm", "kl", "entropy", "clip_fraction"):
-        assert abs(raw[L.INFO[k]] - oi[L.INFO[k]]) < 2e-4 * max(1.0, abs(oi[L.INFO[k]])), k
+        assert abs(raw[L.INFO[k]] - oi[L.INFO[k]]) < 2e-6 * max(1.0, abs(oi[L.INFO[k]])), k
     # batch_train!: 2 epochs of the persistent learner
     info = crux.batch_train_(g, p, P, gb); oinfo = np.zeros(L.INFO_N, np.float32)
     O.chk(O.lib().orc_batch_train(o.h, ob.h, C.byref(cfg), None, O.vpz(oinfo), None))
     assert info["actor_batches_trained"] == int(oinfo[L.INFO["batches_trained"]])
     dp = np.abs(g.get_params() - o.params)
-    assert dp.max() < 5e-4 and np.mean(dp > 3e-5) <= 2e-3, (dp.max(), np.mean(dp > 3e-5))
+    assert dp.max() < 5e-6 and np.mean(dp > 3e-5) <= 2e-3, (dp.max(), np.mean(dp > 3e-5))
     assert abs(info["actor_loss"] - oinfo[0]) < 2e-3 * max(1, abs(oinfo[0]))
 
 
