@@ -113,9 +113,10 @@ def peer_attach_local(contexts):
     """Wire the contexts of ONE process into a replica group (contexts[r] = rank r): a multi-GPU single-process host, or replicas sharing a device."""
     arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
     rc = contexts[0].lib.crux_peer_attach_local(arr, len(contexts))
-    for c in contexts:
-        if rc != 0:
-            c.check(rc)
+    if rc != 0:      # the library records the reason on the context that failed, not necessarily the first one
+        msgs = [(c.lib.crux_last_error(c.h) or b"").decode() for c in contexts]
+        hit = [m for m in msgs if "peer_attach" in m or "hardware queue" in m] or msgs
+        raise L.CruxError(rc, hit[-1])
 
 
 def default_context():

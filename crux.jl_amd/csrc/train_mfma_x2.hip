@@ -561,43 +561,41 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
                          "global_load_dwordx4 %3, %4, off offset:48 sc0 sc1"
                          : "=&v"(vW[0]), "=&v"(vW[1]), "=&v"(vW[2]), "=&v"(vW[3]) : "v"(src + tid * 16) : "memory");
           };
-          // wide heads (OUT > 2) are at the 512-register limit: they take the ranks one at a time (16 + NSI fewer live registers), the others in pairs
-          constexpr int PXS = (OUT <= 2) ? 2 : 1;
-          for (int r = 0; r < a.px_n; r += PXS) {
-            f32x4 vA[4], vB[PXS == 2 ? 4 : 1]; float sA[NSI], sB[PXS == 2 ? NSI : 1]; float tA = 0.f, tB = 0.f;
-            const bool two = PXS == 2 && r + 1 < a.px_n;
-            px_load(r, vA, sA, tA);
-            if constexpr (PXS == 2) {
-              if (two) px_load(r + 1, (f32x4 (&)[4])vB, (float (&)[NSI])sB, tB);
-              else {
+          // The slots are read PXS ranks at a time -- all loads of a batch in flight together, one round trip to the fine-grained region per batch -- and added in
+          // rank order. Narrow heads have the registers for four at a time (8 replicas = two round trips); wide heads (OUT > 2) sit at the 512-register limit
+          // and take the ranks one at a time (16 + NSI live registers per slot in flight).
+          constexpr int PXS = (OUT <= 2) ? 4 : 1;
+          for (int r0 = 0; r0 < a.px_n; r0 += PXS) {
+            f32x4 vW[PXS][4]; float vS[PXS][NSI]; float vT[PXS];
 #pragma unroll
-                for (int mm = 0; mm < 4; ++mm) vB[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < PXS; ++q) {
+              if (r0 + q < a.px_n) px_load(r0 + q, vW[q], vS[q], vT[q]);
+              else { vT[q] = 0.f;
 #pragma unroll
-                for (int k = 0; k < NSI; ++k) sB[k] = 0.f; }
-              asm volatile("s_waitcnt vmcnt(0)" : "+v"(vA[0]), "+v"(vA[1]), "+v"(vA[2]), "+v"(vA[3]), "+v"(vB[0]), "+v"(vB[1]), "+v"(vB[2]), "+v"(vB[3]) :: "memory");
+                for (int mm = 0; mm < 4; ++mm) vW[q][mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < NSI; ++k) vS[q][k] = 0.f; } }
+            if constexpr (PXS == 4) {
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(vW[0][0]), "+v"(vW[0][1]), "+v"(vW[0][2]), "+v"(vW[0][3]), "+v"(vW[1][0]), "+v"(vW[1][1]), "+v"(vW[1][2]), "+v"(vW[1][3]),
+                                                  "+v"(vW[2][0]), "+v"(vW[2][1]), "+v"(vW[2][2]), "+v"(vW[2][3]), "+v"(vW[3][0]), "+v"(vW[3][1]), "+v"(vW[3][2]), "+v"(vW[3][3]) :: "memory");
             } else {
-              asm volatile("s_waitcnt vmcnt(0)" : "+v"(vA[0]), "+v"(vA[1]), "+v"(vA[2]), "+v"(vA[3]) :: "memory");
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(vW[0][0]), "+v"(vW[0][1]), "+v"(vW[0][2]), "+v"(vW[0][3]) :: "memory");
             }
-            if (r == 0) {
 #pragma unroll
-              for (int mm = 0; mm < 4; ++mm) gW2[mm] = vA[mm];
+            for (int q = 0; q < PXS; ++q) {
+              if (r0 + q >= a.px_n) break;
+              if (r0 + q == 0) {
 #pragma unroll
-              for (int k = 0; k < NSI; ++k) gs[k] = sA[k];
-              stat_tot = tA;
-            } else {
+                for (int mm = 0; mm < 4; ++mm) gW2[mm] = vW[q][mm];
 #pragma unroll
-              for (int mm = 0; mm < 4; ++mm) gW2[mm] += vA[mm];
+                for (int k = 0; k < NSI; ++k) gs[k] = vS[q][k];
+                stat_tot = vT[q];
+              } else {
 #pragma unroll
-              for (int k = 0; k < NSI; ++k) gs[k] += sA[k];
-              stat_tot += tA;
-            }
-            if constexpr (PXS == 2) {
-              if (two) {
+                for (int mm = 0; mm < 4; ++mm) gW2[mm] += vW[q][mm];
 #pragma unroll
-                for (int mm = 0; mm < 4; ++mm) gW2[mm] += vB[mm];
-#pragma unroll
-                for (int k = 0; k < NSI; ++k) gs[k] += sB[k];
-                stat_tot += tB;
+                for (int k = 0; k < NSI; ++k) gs[k] += vS[q][k];
+                stat_tot += vT[q];
               }
             }
           }
