@@ -578,6 +578,8 @@ __global__ __launch_bounds__(256) void k_train_mfma_x2(TrainArgs a_single, const
             if constexpr (PXS == 4) {
               asm volatile("s_waitcnt vmcnt(0)" : "+v"(vW[0][0]), "+v"(vW[0][1]), "+v"(vW[0][2]), "+v"(vW[0][3]), "+v"(vW[1][0]), "+v"(vW[1][1]), "+v"(vW[1][2]), "+v"(vW[1][3]),
                                                   "+v"(vW[2][0]), "+v"(vW[2][1]), "+v"(vW[2][2]), "+v"(vW[2][3]), "+v"(vW[3][0]), "+v"(vW[3][1]), "+v"(vW[3][2]), "+v"(vW[3][3]) :: "memory");
+            } else if constexpr (PXS == 2) {
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(vW[0][0]), "+v"(vW[0][1]), "+v"(vW[0][2]), "+v"(vW[0][3]), "+v"(vW[1][0]), "+v"(vW[1][1]), "+v"(vW[1][2]), "+v"(vW[1][3]) :: "memory");
             } else {
               asm volatile("s_waitcnt vmcnt(0)" : "+v"(vW[0][0]), "+v"(vW[0][1]), "+v"(vW[0][2]), "+v"(vW[0][3]) :: "memory");
             }
