@@ -1593,7 +1593,7 @@ class OffPolicySolver:
         self.buffer = buffer if buffer is not None else ExperienceBuffer(S, agent.space, buffer_size, prioritized=prioritized)
         self.buffer_init = buffer_init if buffer_init is not None else max(c_opt.batch_size, 200)
         self.tau, self.weighted_loss, self.sample_seed = float(tau), bool(weighted_loss), int(sample_seed)
-        self.fused_epochs = True              # value_training epochs through crux_dqn_epoch / crux_sac_epoch (one fused launch each for wide networks)
+        self.fused_epochs = True              # value_training's epoch loop through crux_dqn_epochs / crux_sac_epochs (recorded op lists run by the executor for wide networks)
         self.sampler, self.batch, self.history = None, None, []
         self._dy = self._derr = None
 
@@ -1631,19 +1631,6 @@ def _value_training_sac(solver, D, gamma):
     for epoch in range(0 if solver.fused_epochs else c_opt.epochs):
         ctr = solver.i * c_opt.epochs + epoch                                                          # one Philox counter block per epoch
         upd_c, upd_a = epoch % c_opt.update_every == 0, epoch % a_opt.update_every == 0                # :91, :96
-        if False:
-            # the whole epoch (:71-100) as one fused launch (cruxhip.h: crux_sac_epoch); same pieces, order and draws as the branch below
-            _set_stream_for(buf, solver.sample_seed)
-            rt, rq, ra = np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32)
-            ctx.check(lib.crux_sac_epoch(A.h, Q.N1.h, Q.N2.h, pim.A.h, Qm.N1.h, Qm.N2.h, la.h, buf.h, D.h, float(gamma), float(solver.P["SAC_H_target"]), float(solver.tau),
-                                         1 if solver.weighted_loss else 0, 1 if upd_c else 0, 1 if upd_a else 0, ctr, solver.noise_seed, 3 * ctr, _vp(rt), _vp(rq), _vp(ra)))
-            info = {t_opt.name + "loss": float(rt[0]), t_opt.name + "grad_norm": float(rt[1]), "SAC alpha": float(rt[L.INFO["alpha"]])}
-            if upd_c:
-                info.update({c_opt.name + "loss": float(rq[0]), c_opt.name + "grad_norm": float(rq[1]), "Q1avg": float(rq[L.INFO["q1avg"]]), "Q2avg": float(rq[L.INFO["q2avg"]])})
-            if upd_a:
-                info.update({a_opt.name + "loss": float(ra[0]), a_opt.name + "grad_norm": float(ra[1]), "entropy": float(ra[L.INFO["entropy"]])})
-            infos.append(info)
-            continue
         rand_(D, buf, i=solver.i, counter=ctr, seed=solver.sample_seed)                                # :71 rand!(D, buffer, i=S.i)
         info = {}
         ctx.check(lib.crux_sac_target(A.h, Qm.N1.h, Qm.N2.h, la.h, D.h, float(gamma), solver.noise_seed, 3 * ctr, solver._dy))           # :80

@@ -433,7 +433,7 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
  * sample_counter0 + e; infos: host [n_epochs x CRUX_INFO_N]. Same results as n_epochs calls of crux_dqn_epoch.                                         */
 int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
                         uint64_t sample_counter0, int32_t n_epochs, float* infos);
-/* One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl:4-52,94-104) as one fused launch: rand! -> sac_target ->
+/* One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl:4-52,94-104) as one recorded op list (34 phase launches, see crux_dqn_epoch): rand! -> sac_target ->
  * train!(log_alpha, sac_temp_loss) -> [update_critic: train!(critic, double_Q_loss)] -> [update_actor: train!(actor, sac_actor_loss), then
  * polyak_average!(target, online, tau) for the actor (when actor_targ != NULL) and both critics (:100)]. The three exploration draws use noise counters
  * noise_counter0, +1, +2 like the separate calls. info_*: host [CRUX_INFO_N] each (NULL = not wanted).                                            */
