@@ -107,7 +107,7 @@ static int32_t peer_region(crux_ctx* c) {
   if (c->peer_local) return CRUX_OK;
   HIPCHK(c, hipSetDevice(c->device));
   void* p = nullptr;
-  if (!getenv("CRUX_PEER_COARSE") && hipExtMallocWithFlags(&p, CRUX_PX_BYTES, hipDeviceMallocFinegrained) == hipSuccess) c->peer_fine = true;
+  if (hipExtMallocWithFlags(&p, CRUX_PX_BYTES, hipDeviceMallocFinegrained) == hipSuccess) c->peer_fine = true;
   else { (void)hipGetLastError(); c->peer_fine = false; if (hipMalloc(&p, CRUX_PX_BYTES) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "peer region (%zu bytes)", (size_t)CRUX_PX_BYTES); }
   HIPCHK(c, hipMemset(p, 0, CRUX_PX_BYTES));
   HIPCHK(c, hipDeviceSynchronize());

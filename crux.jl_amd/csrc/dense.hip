@@ -145,7 +145,7 @@ static int32_t launch_gemm(crux_ctx* c, const GemmArgs& q, hipStream_t st) {
   const int tiles = ((q.M + 15) >> 4) * ((q.N + 15) >> 4);
   const dim3 block(256);
   const bool av = vec_ok(q.A, q.sAk, q.sAi, q.K), bv = vec_ok(q.B, q.sBk, q.sBj, q.K);
-  static const bool no_split = getenv("CRUX_GEMM_NO_SPLITK") != nullptr;
+  constexpr bool no_split = false;
   if (crux_exec_recording(c)) {                       // fused sequence (exec.hip): the same tile bodies, run by the persistent executor
     // the stand-alone launch would split K over the four waves of a workgroup here; on the executor's 32 CUs one round of fat blocks beats several rounds of
     // thin ones, so up to 32 tiles keep the split form and larger GEMMs give each wave a whole tile with the K quarters walked in order (same bits)

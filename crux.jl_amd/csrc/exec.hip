@@ -213,9 +213,8 @@ int32_t crux_exec_run(crux_ctx* c) {
     // the counter barrier relies on one shared L2: all workgroups on XCD 0 (workgroup i of a grid lands on XCD i mod 8, verified by the placement probe)
     const int xcd = crux_x2_placement_ok_c(c) ? 0 : -2;
     if (xcd == -2) return crux_fail(c, CRUX_EUNSUP, "executor: workgroups are not placed round-robin over the XCDs on this device");
-    static const int g_env = getenv("CRUX_EXEC_G") ? atoi(getenv("CRUX_EXEC_G")) : 0;
-    const int G = (g_env >= 1 && g_env <= 128) ? g_env : EXEC_G;
-    hipLaunchKernelGGL(k_exec, dim3(G * 8), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops, (int)nops, r->d_ctr, xcd, (int32_t*)(r->d_ctr + 264), getenv("CRUX_EXEC_FLAGS") ? atoi(getenv("CRUX_EXEC_FLAGS")) : 0);
+    const int G = EXEC_G;
+    hipLaunchKernelGGL(k_exec, dim3(G * 8), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops, (int)nops, r->d_ctr, xcd, (int32_t*)(r->d_ctr + 264), 0);
     }
     rc = crux_launch_check(c, "k_exec"); if (rc) return rc;
     char* hb = (char*)r->h_stage + ob;
@@ -225,10 +224,6 @@ int32_t crux_exec_run(crux_ctx* c) {
     int32_t* hst = (int32_t*)(hb + rb);
     HIPCHK(c, hipMemcpyAsync(hst, r->d_ctr + 264, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (getenv("CRUX_EXEC_FLAGS") && (atoi(getenv("CRUX_EXEC_FLAGS")) & 8)) { static int shown = 0; if (shown++ == 3) {
-        std::vector<unsigned long long> tt(2 * 512 * 3); (void)hipMemcpy(tt.data(), r->d_ctr + 1024, tt.size() * 8, hipMemcpyDeviceToHost);
-        for (size_t o = 0; o < nops && o < 512; ++o) fprintf(stderr, "[exec-t] op %2zu kid %2d blocks %3u bar %d | wg0 body %6.2f us barrier %6.2f us | wg1 body %6.2f barrier %6.2f\n", o, r->ops[o].kid, r->ops[o].nblocks, r->ops[o].barrier,
-          (tt[o * 3 + 1] - tt[o * 3]) / 100.0, (tt[o * 3 + 2] - tt[o * 3 + 1]) / 100.0, (tt[(512 + o) * 3 + 1] - tt[(512 + o) * 3]) / 100.0, (tt[(512 + o) * 3 + 2] - tt[(512 + o) * 3 + 1]) / 100.0); } }
     if (*hst) return crux_fail(c, *hst, "executor: the fused launch reported status %d (a workgroup did not reach a barrier)", *hst);
     for (size_t k = 0; k < r->readbacks.size(); ++k) { const char* h = hb + k * (sizeof(float) * CRUX_INFO_N + 16);
       if (r->readbacks[k].host_info) memcpy(r->readbacks[k].host_info, h, sizeof(float) * CRUX_INFO_N);
@@ -268,7 +263,7 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
     if (c->epoch_tmp_bytes < 8 * (size_t)B + 512) { if (sc2) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(sc2); }
       c->epoch_tmp_bytes = 16 * (size_t)B + 4096; if (hipMalloc(&c->epoch_tmp, c->epoch_tmp_bytes) != hipSuccess) { c->epoch_tmp = nullptr; c->epoch_tmp_bytes = 0; return crux_fail(c, CRUX_ENOMEM, "dqn_epoch: targets"); } sc2 = (char*)c->epoch_tmp; }
     d_y = (float*)sc2; d_err = (float*)(sc2 + ((4 * (size_t)B + 255) / 256) * 256); }
-  static const int eager_mask = getenv("CRUX_EXEC_EAGER_MASK") ? atoi(getenv("CRUX_EXEC_EAGER_MASK")) : 0;      // debugging: run piece k outside the fused launch
+  constexpr int eager_mask = 0;
   auto piece = [&](int bit) -> int32_t { if (!fuse) return CRUX_OK;
     if (eager_mask & bit) { if (crux_exec_recording(c)) return crux_exec_run(c); return CRUX_OK; }
     if (!crux_exec_recording(c)) return crux_exec_begin(c); return CRUX_OK; };
@@ -309,9 +304,7 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
     r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 7 + 2 * Ld;
     return CRUX_OK;
   }
-  if (fuse && crux_exec_recording(c) && plan_ok && !eager_mask && !getenv("CRUX_EXEC_NO_PHASES") && target_net->nd.L == Ld && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
-  if (fuse && getenv("CRUX_EXEC_VERBOSE")) { ExecRec* r = rec_of(c); int nbar = 0; for (auto& o : r->ops) nbar += o.barrier; fprintf(stderr, "[exec] dqn_epoch: %zu ops, %d barriers, plan_ok=%d tags=%zu\n", r->ops.size(), nbar, (int)plan_ok, ph.size());
-    for (auto& o : r->ops) fprintf(stderr, "   kid %d blocks %u barrier %d\n", o.kid, o.nblocks, o.barrier); }
+  if (fuse && crux_exec_recording(c) && plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
   return (fuse && crux_exec_recording(c)) ? crux_exec_run(c) : CRUX_OK;
 }
 
@@ -323,8 +316,8 @@ int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source
                         uint64_t sample_counter0, int32_t n_epochs, float* infos) {
   if (!net || !target_net || !source || !batch || n_epochs < 1) return CRUX_EINVAL;
   crux_ctx* c = net->ctx;
-  const bool fuse = net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && !getenv("CRUX_NO_FUSED_EPOCH") && !getenv("CRUX_EXEC_NO_PHASES") &&
-                    !getenv("CRUX_EXEC_EAGER_MASK") && !getenv("CRUX_NO_CHAINED_EPOCHS");
+  const bool fuse = net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && !getenv("CRUX_NO_FUSED_EPOCH") &&
+                    !getenv("CRUX_NO_CHAINED_EPOCHS");
   auto flush = [&]() -> int32_t {
     if (!crux_exec_recording(c)) return CRUX_OK;
     ExecRec* r = rec_of(c); r->chain = false;
@@ -419,8 +412,7 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
     r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + 2 * LA + 6 + 2 * LQ;
     return CRUX_OK;
   }
-  if (fuse && plan_ok && !getenv("CRUX_EXEC_NO_PHASES") && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
-  if (fuse && getenv("CRUX_EXEC_VERBOSE")) { ExecRec* r = rec_of(c); int nbar = 0; for (auto& o : r->ops) nbar += o.barrier; fprintf(stderr, "[exec] sac_epoch: %zu ops, %d phases, plan_ok=%d\n", r->ops.size(), nbar, (int)plan_ok); }
+  if (fuse && plan_ok && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
   return fuse ? crux_exec_run(c) : CRUX_OK;
 }
 
@@ -433,7 +425,7 @@ int32_t crux_sac_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* a
                         float* infos_temp, float* infos_critic, float* infos_actor) {
   if (!actor || n_epochs < 1 || critic_every < 1 || actor_every < 1) return CRUX_EINVAL;
   crux_ctx* c = actor->ctx;
-  const bool fuse = !getenv("CRUX_NO_FUSED_EPOCH") && !getenv("CRUX_EXEC_NO_PHASES") && !getenv("CRUX_NO_CHAINED_EPOCHS");
+  const bool fuse = !getenv("CRUX_NO_FUSED_EPOCH") && !getenv("CRUX_NO_CHAINED_EPOCHS");
   auto flush = [&]() -> int32_t {
     if (!crux_exec_recording(c)) return CRUX_OK;
     ExecRec* r = rec_of(c); r->chain = false;

@@ -172,7 +172,7 @@ static int32_t run_batch(crux_mlp* net, crux_buffer* buf, TrainArgs& a, int n_ep
   HIPCHK(c, hipMemsetAsync(sc, 0, eb + 256, c->stream));
   const int slot = (CRUX_IS_PG(a.loss) || a.loss == CRUX_LOSS_MSE_ACTION) ? CRUX_PROF_TRAIN_ACTOR : (a.loss == CRUX_LOSS_VALUE_MSE ? CRUX_PROF_TRAIN_CRITIC : CRUX_PROF_TD_STEP);
   int32_t rc;
-  if (!a.ids && a.len < ((int64_t)1 << 31) && !getenv("CRUX_ORDERS_IN_KERNEL")) {
+  if (!a.ids && a.len < ((int64_t)1 << 31)) {
     int32_t* oa = nullptr; rc = build_orders(c, buf, 0, nullptr, a.shuffle_seed, a.shuffle_counter, a.perms, n_epochs, c->stream, &oa); if (rc) return rc;
     a.ord_all = oa;
   }
@@ -329,12 +329,11 @@ static int32_t ensure_aux_stream(crux_ctx* c) {
       HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
     }
     best = ms;
-    if (ms < 1.5f * alone || attempt == 5 || getenv("CRUX_NO_STREAM_PROBE")) chosen = s;      // overlapped: about `alone`; back to back: 2 x
+    if (ms < 1.5f * alone || attempt == 5) chosen = s;      // overlapped: about `alone`; back to back: 2 x
     else if (c->aux_n_rejected < 8) c->aux_rejected[c->aux_n_rejected++] = s;
   }
   (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipEventDestroy(ej);
   c->aux_stream = chosen; c->aux_probe_ms = best;
-  if (getenv("CRUX_STREAM_PROBE_VERBOSE")) fprintf(stderr, "[cruxhip] second learner stream: %d candidate(s) rejected, probe %.3f ms for two concurrent launches (one alone: %.3f ms)\n", c->aux_n_rejected, best, alone);
   HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->aux_ev1, hipEventDisableTiming));
   return CRUX_OK;
 }
@@ -418,7 +417,7 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
                                                  const int64_t* perms_a, const int64_t* perms_c, float* info_a, float* info_c, float* epoch_infos_a, float* epoch_infos_c) {
   if (!actor || !critic || !buf || !cfg_a || !cfg_c) return CRUX_EINVAL;
   crux_ctx* c = actor->ctx;
-  bool exact = cfg_a->target_kl < 0.f && cfg_a->max_batches <= 0 && !getenv("CRUX_SEQUENTIAL_LEARNERS");
+  bool exact = cfg_a->target_kl < 0.f && cfg_a->max_batches <= 0;
   { auto mfma_family = [](const crux_mlp* n) { const NetDesc& d = n->nd; return d.L == 3 && d.dims[1] == 64 && d.dims[2] == 64; };
     if (!mfma_family(actor) || !mfma_family(critic)) exact = false; }     // dense-engine / generic learners run one after the other on the main stream
   if (!exact) {
@@ -445,7 +444,7 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   a.perms = d_pa; k.perms = d_pc;
   k.order_a = buf->order_c; k.order_b = buf->order_d;
   k.pre_epochs = cfg_a->epochs; k.pre_seed = cfg_a->shuffle_seed; k.pre_counter = cfg_a->shuffle_counter; k.pre_perms = d_pa;
-  if (len < ((int64_t)1 << 31) && !getenv("CRUX_ORDERS_IN_KERNEL")) {   // all epoch orders ahead of time; the critic's chain starts from the actor's last order
+  if (len < ((int64_t)1 << 31)) {   // all epoch orders ahead of time; the critic's chain starts from the actor's last order
     int32_t* oa = nullptr; int32_t* oc = nullptr;
     rc = build_orders(c, buf, 0, nullptr, cfg_a->shuffle_seed, cfg_a->shuffle_counter, d_pa, cfg_a->epochs, c->stream, &oa); if (rc) return rc;
     rc = build_orders(c, buf, 1, oa + (size_t)(cfg_a->epochs - 1) * (size_t)len, cfg_c->shuffle_seed, cfg_c->shuffle_counter, d_pc, cfg_c->epochs, c->stream, &oc); if (rc) return rc;
