@@ -149,7 +149,9 @@ static int32_t launch_gemm(crux_ctx* c, const GemmArgs& q, hipStream_t st) {
   if (crux_exec_recording(c)) {                       // fused sequence (exec.hip): the same tile bodies, run by the persistent executor
     // the stand-alone launch would split K over the four waves of a workgroup here; on the executor's 32 CUs one round of fat blocks beats several rounds of
     // thin ones, so up to 32 tiles keep the split form and larger GEMMs give each wave a whole tile with the K quarters walked in order (same bits)
-    const bool deep = q.K >= 128 && tiles <= 4096 && !no_split, split = deep && tiles <= 32;
+    // (the persistent one-XCD executor prefers fat blocks; the default phase launches run over the whole chip like the stand-alone launches and split whenever those do)
+    static const bool persistent = getenv("CRUX_EXEC_PERSISTENT") != nullptr;
+    const bool deep = q.K >= 128 && tiles <= 4096 && !no_split, split = deep && (!persistent || tiles <= 32);
     crux_exec_push<GemmOp, OP_GEMM>(c, (unsigned)(split ? tiles : (tiles + 3) / 4), q, (int)((av ? 1 : 0) | (bv ? 2 : 0) | (split ? 4 : 0) | ((deep && !split) ? 8 : 0)));
     return CRUX_OK;
   }

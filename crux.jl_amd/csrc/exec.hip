@@ -272,8 +272,13 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
   // bookkeeping beside the backward chain.    0 search | 1 gather, ring ids, zero-fill | 2+k forward layer k (both nets; + push! priorities of the batch)
   //   2+L dqn_target | 3+L td head | 4+L+j backward of layer L-1-j (weight + data gradient; + update_priorities!, leaf re-sum, root paths) | then norm, info, Adam
   std::vector<int> ph; bool plan_ok = true; const int Ld = net->nd.L;
+  // chained epochs (crux_dqn_epochs): the sampling of epoch e + 1 (phase 0: search / uniform ids, phase 1: gather, ring ids, fills) touches nothing that the last three
+  // phases of epoch e (norm | info + Adam | beta-power advance) read or write -- the batch rows and the sampled ids were last read by the first-layer weight gradient and
+  // the tree refresh one phase earlier -- so it runs BESIDE them: phases 0 and 1 of a later epoch are tagged as the previous epoch's last-but-two and last-but-one, and
+  // its remaining phases close up by two. The replay chain (leaf refresh -> root paths -> search -> gather) then hides the optimizer tail instead of following it.
   auto tag = [&](size_t from, auto&& rule) { if (!fuse || !crux_exec_recording(c)) return; ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
-    for (size_t i = from; i < r->ops.size(); ++i) { const int p = rule(r->ops[i].kid, g); if (p < 0) plan_ok = false; ph.push_back((p < 0 ? 0 : p) + base); } };
+    for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { plan_ok = false; p = 0; }
+      ph.push_back(base > 0 ? (p < 2 ? base - 3 + p : base + p - 2) : p); } };
   rc = piece(1); if (rc) return bail(rc);
   const size_t ops0 = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;      // first op of THIS epoch (a chained recording already holds the earlier epochs)
   size_t m = ops0;
@@ -301,7 +306,7 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
   if (fuse && crux_exec_recording(c) && rec_of(c)->chain) {     // chained: the caller (crux_dqn_epochs) schedules and runs the whole list
     ExecRec* r = rec_of(c);
     if (!(plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 7 + 2 * Ld;
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += (r->chain_base > 0 ? 5 : 7) + 2 * Ld;
     return CRUX_OK;
   }
   if (fuse && crux_exec_recording(c) && plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
@@ -369,8 +374,11 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   // The order inside every chain is the reference's (temperature before critic before actor: each sees the parameters the previous step left).
   std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, X = 3 + LA + LQ, Y = X + 4 + LQ;
   if (LA != LQ || q2->nd.L != LQ || q1_targ->nd.L != LQ || q2_targ->nd.L != LQ) plan_ok = false;
+  // chained epochs: phases 0 (ids) and 1 (gather, fills) of a later epoch run beside the previous epoch's last three phases (actor norm | info + Adam | advance + polyak,
+  // none of which reads the batch), the rest closes up by two -- see crux_dqn_epoch
   auto tag = [&](size_t from, auto&& rule) { if (!fuse) return; ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
-    for (size_t i = from; i < r->ops.size(); ++i) { const int p = rule(r->ops[i].kid, g); if (p < 0) plan_ok = false; ph.push_back((p < 0 ? 0 : p) + base); } };
+    for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { plan_ok = false; p = 0; }
+      ph.push_back(base > 0 ? (p < 2 ? base - 3 + p : base + p - 2) : p); } };
   const size_t ops0 = fuse ? exec_mark(c) : 0;
   size_t m = ops0;
   rc = crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
@@ -409,7 +417,7 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   if (fuse && rec_of(c)->chain) {      // chained: crux_sac_epochs schedules and runs the whole list
     ExecRec* r = rec_of(c);
     if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + 2 * LA + 6 + 2 * LQ;
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + 2 * LA + 6 + 2 * LQ - (r->chain_base > 0 ? 2 : 0);
     return CRUX_OK;
   }
   if (fuse && plan_ok && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
