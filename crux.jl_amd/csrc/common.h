@@ -130,15 +130,10 @@ struct crux_buffer {
   // pairwise-cumsum tree of Base.cumsum for the current length (built on the host once per length, see per.hip)
   int64_t topo_n = -1; int32_t topo_leaves = 0, topo_nodes = 0, topo_levels = 0;
   int32_t* topo_leaf_start = nullptr; int32_t* topo_leaf_len = nullptr; int32_t* topo_leaf_node = nullptr;
-  int32_t* topo_left = nullptr; int32_t* topo_right = nullptr; int32_t* topo_level_off = nullptr;   // nodes sorted by level
+  int32_t* topo_left = nullptr; int32_t* topo_right = nullptr; int32_t* topo_level_off = nullptr;   // heap-numbered nodes (root 1, children 2k / 2k + 1); level l = [2^l, 2^(l+1))
   float* topo_total = nullptr; float* topo_prefix = nullptr;
   // incremental maintenance (per.hip): `cumsum` holds the leaf-LOCAL running sums; c[i] = prefix[leaf(i)] + cumsum[i]. After update_priorities! only the
   // touched leaves are re-summed (k_leaf_refresh); the node totals / prefixes are re-derived by the LDS tree pass at the next sample.
-  int32_t* topo_leaf_of = nullptr;      // device [N]: node id of the leaf holding element i (i >= 1)
-  int32_t* topo_node_start = nullptr; int32_t* topo_node_len = nullptr;   // device [nodes]: element range of every node
-  int32_t* topo_path = nullptr;         // device [nodes][CRUX_PER_PMAX]: for a leaf, the left siblings met on the way down from the root (top-down order, -1 = went left)
-  int32_t* topo_anc = nullptr;          // device [nodes][CRUX_PER_PMAX]: for a leaf, its ancestors bottom-up (-1 past the root)
-  int32_t* topo_depth = nullptr;        // device [nodes]: level of the node (root 0)
   int64_t per_run_n = -1; bool per_full_dirty = true;
   int32_t* order_a = nullptr;    // device [capacity] logical->physical order scratch for batch_train
   int32_t* order_b = nullptr;

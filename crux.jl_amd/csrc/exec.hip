@@ -275,10 +275,12 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
   // chained epochs (crux_dqn_epochs): the sampling of epoch e + 1 (phase 0: search / uniform ids, phase 1: gather, ring ids, fills) touches nothing that the last three
   // phases of epoch e (norm | info + Adam | beta-power advance) read or write -- the batch rows and the sampled ids were last read by the first-layer weight gradient and
   // the tree refresh one phase earlier -- so it runs BESIDE them: phases 0 and 1 of a later epoch are tagged as the previous epoch's last-but-two and last-but-one, and
-  // its remaining phases close up by two. The replay chain (leaf refresh -> root paths -> search -> gather) then hides the optimizer tail instead of following it.
+  // its remaining phases close up by THREE: the first forward layer of epoch e + 1 shares a launch with the beta-power advance of epoch e (the last phase, which writes
+  // the two powers only; Adam of epoch e + 1 reads them nine phases later). The replay chain (leaf refresh -> root paths -> search -> gather) then hides the optimizer
+  // tail instead of following it: 13 phases, 10 launches per chained epoch.
   auto tag = [&](size_t from, auto&& rule) { if (!fuse || !crux_exec_recording(c)) return; ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
     for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { plan_ok = false; p = 0; }
-      ph.push_back(base > 0 ? (p < 2 ? base - 3 + p : base + p - 2) : p); } };
+      ph.push_back(base > 0 ? (p < 2 ? base - 3 + p : base + p - 3) : p); } };
   rc = piece(1); if (rc) return bail(rc);
   const size_t ops0 = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;      // first op of THIS epoch (a chained recording already holds the earlier epochs)
   size_t m = ops0;
@@ -306,7 +308,7 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
   if (fuse && crux_exec_recording(c) && rec_of(c)->chain) {     // chained: the caller (crux_dqn_epochs) schedules and runs the whole list
     ExecRec* r = rec_of(c);
     if (!(plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += (r->chain_base > 0 ? 5 : 7) + 2 * Ld;
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += (r->chain_base > 0 ? 4 : 7) + 2 * Ld;
     return CRUX_OK;
   }
   if (fuse && crux_exec_recording(c) && plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }

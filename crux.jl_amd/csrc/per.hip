@@ -26,16 +26,18 @@ void crux_buffer_ring_advance(crux_buffer* b, int64_t N);
 int32_t crux_buffer_per_on_push(crux_buffer* b, const int64_t* d_I, int64_t N);
 
 // ---- host: shape of accumulate_pairwise!(add_sum, c, v[2:n]) ----------------------------------------------------------
-struct TopoBuild { std::vector<int32_t> left, right, level, start, len; };
-static int32_t topo_rec(TopoBuild& t, int64_t i1, int64_t n, int lvl) {
-  const int32_t id = (int32_t)t.left.size();
-  t.left.push_back(-1); t.right.push_back(-1); t.level.push_back(lvl); t.start.push_back((int32_t)i1); t.len.push_back((int32_t)n);
-  if (n >= 128) { const int64_t n2 = n >> 1; const int32_t l = topo_rec(t, i1, n2, lvl + 1); const int32_t r = topo_rec(t, i1 + n2, n - n2, lvl + 1); t.left[id] = l; t.right[id] = r; }
-  return id;
+// Nodes carry HEAP numbers (root 1, children 2k and 2k + 1, level l in [2^l, 2^(l+1))). The recursion halves n -> (n >> 1, n - (n >> 1)) until n < 128, so sizes
+// inside a level differ by at most one and leaves sit on the last two levels only: the numbering is sparse on the last level (holes have no links and are never
+// referenced). What it buys: the leaf of an element, its root path and the left siblings along it follow from N by integer arithmetic (leaf_locate below), so
+// the per-step kernels (search, leaf refresh, root paths) read no topology table at all -- each table lookup was a dependent ~1 us round trip to L2 / HBM.
+struct TopoBuild { std::vector<int32_t> id, level, start, len; std::vector<char> leaf; };
+static void topo_rec(TopoBuild& t, int64_t i1, int64_t n, int lvl, int32_t id) {
+  t.id.push_back(id); t.level.push_back(lvl); t.start.push_back((int32_t)i1); t.len.push_back((int32_t)n); t.leaf.push_back(n < 128);
+  if (n >= 128) { const int64_t n2 = n >> 1; topo_rec(t, i1, n2, lvl + 1, 2 * id); topo_rec(t, i1 + n2, n - n2, lvl + 1, 2 * id + 1); }
 }
 
 static void topo_free(crux_buffer* b) {
-  int32_t** ps[] = {&b->topo_leaf_start, &b->topo_leaf_len, &b->topo_leaf_node, &b->topo_left, &b->topo_right, &b->topo_level_off, &b->topo_leaf_of, &b->topo_node_start, &b->topo_node_len, &b->topo_path, &b->topo_anc, &b->topo_depth};
+  int32_t** ps[] = {&b->topo_leaf_start, &b->topo_leaf_len, &b->topo_leaf_node, &b->topo_left, &b->topo_right, &b->topo_level_off};
   for (auto p : ps) if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (b->topo_total) { (void)hipFree(b->topo_total); b->topo_total = nullptr; }
   if (b->topo_prefix) { (void)hipFree(b->topo_prefix); b->topo_prefix = nullptr; }
@@ -49,45 +51,35 @@ static int32_t topo_ensure(crux_buffer* b, int64_t N) {
   (void)hipStreamSynchronize(c->stream);
   topo_free(b);
   if (N < 2) { b->topo_n = N; b->topo_leaves = b->topo_nodes = b->topo_levels = 0; return CRUX_OK; }
-  TopoBuild t; topo_rec(t, 1, N - 1, 0);
-  const int nn = (int)t.left.size(); int maxlvl = 0; for (int v : t.level) if (v > maxlvl) maxlvl = v;
-  // renumber nodes so that each level is contiguous (level 0 first)
-  std::vector<int32_t> order(nn), newid(nn), lvl_off(maxlvl + 2, 0);
-  for (int i = 0; i < nn; ++i) lvl_off[t.level[i] + 1]++;
-  for (int l = 0; l <= maxlvl; ++l) lvl_off[l + 1] += lvl_off[l];
-  { std::vector<int32_t> cur(lvl_off.begin(), lvl_off.end() - 1); for (int i = 0; i < nn; ++i) { newid[i] = cur[t.level[i]]++; order[newid[i]] = i; } }
-  std::vector<int32_t> L(nn), R(nn), ls, ll, ln;
-  for (int k = 0; k < nn; ++k) { const int i = order[k]; L[k] = t.left[i] >= 0 ? newid[t.left[i]] : -1; R[k] = t.right[i] >= 0 ? newid[t.right[i]] : -1;
-    if (t.left[i] < 0) { ls.push_back(t.start[i]); ll.push_back(t.len[i]); ln.push_back(k); } }
-  const int nl = (int)ls.size();
-  { // leaves in memory order: a block of LEAF_BLK consecutive leaves then covers one contiguous span of the vector
-    std::vector<int32_t> idx(nl); for (int i = 0; i < nl; ++i) idx[i] = i;
-    std::sort(idx.begin(), idx.end(), [&](int a, int b2) { return ls[a] < ls[b2]; });
-    std::vector<int32_t> a(nl), b2(nl), c2(nl); for (int i = 0; i < nl; ++i) { a[i] = ls[idx[i]]; b2[i] = ll[idx[i]]; c2[i] = ln[idx[i]]; }
-    ls.swap(a); ll.swap(b2); ln.swap(c2); }
+  TopoBuild t; topo_rec(t, 1, N - 1, 0, 1);
+  int maxlvl = 0; for (int v : t.level) if (v > maxlvl) maxlvl = v;
+  if (maxlvl > 28) return crux_fail(c, CRUX_EINVAL, "cumsum tree: %lld elements are more than the heap numbering holds", (long long)N);
+  const int nn = 1 << (maxlvl + 1);                       // heap slots 0 .. 2^(levels) - 1 (slot 0 unused)
+  std::vector<int32_t> L(nn, -1), R(nn, -1), lvl_off(maxlvl + 2), ls, ll, ln;
+  for (int l = 0; l <= maxlvl + 1; ++l) lvl_off[l] = 1 << l;
+  for (size_t i = 0; i < t.id.size(); ++i) { const int k = t.id[i];
+    if (t.leaf[i]) { ls.push_back(t.start[i]); ll.push_back(t.len[i]); ln.push_back(k); } else { L[k] = 2 * k; R[k] = 2 * k + 1; } }
+  const int nl = (int)ls.size();            // the pre-order walk meets the leaves in memory order: a block of LEAF_BLK consecutive leaves covers one contiguous span of the vector
   auto up = [&](int32_t** d, const std::vector<int32_t>& h) -> bool {
     if (hipMalloc(d, 4 * h.size()) != hipSuccess) return false;
     return hipMemcpyAsync(*d, h.data(), 4 * h.size(), hipMemcpyHostToDevice, c->stream) == hipSuccess; };
-  std::vector<int32_t> nstart(nn), nlen(nn), leaf_of((size_t)N, 0);
-  for (int k = 0; k < nn; ++k) { const int i = order[k]; nstart[k] = t.start[i]; nlen[k] = t.len[i];
-    if (t.left[i] < 0) for (int e = t.start[i]; e < t.start[i] + t.len[i]; ++e) leaf_of[(size_t)e] = k; }
-  // per-leaf root paths for the incremental form: parent links from the (level-sorted) child links, then for every leaf the ancestors bottom-up and,
-  // top-down, the left sibling passed whenever the path turns right (prefix(leaf) = v[1] + those totals, added in that order: _accumulate_pairwise!'s s)
-  std::vector<int32_t> par(nn, -1), depth(nn, 0), path((size_t)nn * CRUX_PER_PMAX, -1), anc((size_t)nn * CRUX_PER_PMAX, -1);
-  for (int k = 0; k < nn; ++k) { if (L[k] >= 0) { par[L[k]] = k; par[R[k]] = k; } depth[k] = t.level[order[k]]; }
-  bool deep = false;
-  for (int k = 0; k < nn; ++k) { if (L[k] >= 0) continue;
-    if (depth[k] > CRUX_PER_PMAX) { deep = true; continue; }
-    int a = 0; for (int q = par[k]; q >= 0; q = par[q]) anc[(size_t)k * CRUX_PER_PMAX + a++] = q;
-    int cur = k; for (int d = depth[k] - 1; d >= 0; --d) { const int pq = par[cur]; path[(size_t)k * CRUX_PER_PMAX + d] = (R[pq] == cur) ? L[pq] : -1; cur = pq; } }
-  b->per_full_dirty = true; (void)deep;
-  if (!up(&b->topo_path, path) || !up(&b->topo_anc, anc) || !up(&b->topo_depth, depth) ||
-      !up(&b->topo_leaf_start, ls) || !up(&b->topo_leaf_len, ll) || !up(&b->topo_leaf_node, ln) || !up(&b->topo_left, L) || !up(&b->topo_right, R) || !up(&b->topo_level_off, lvl_off) ||
-      !up(&b->topo_leaf_of, leaf_of) || !up(&b->topo_node_start, nstart) || !up(&b->topo_node_len, nlen) ||
-      hipMalloc(&b->topo_total, 4 * (size_t)nn) != hipSuccess || hipMalloc(&b->topo_prefix, 4 * (size_t)nn) != hipSuccess) { topo_free(b); return crux_fail(c, CRUX_ENOMEM, "cumsum tree"); }
+  b->per_full_dirty = true;
+  if (!up(&b->topo_leaf_start, ls) || !up(&b->topo_leaf_len, ll) || !up(&b->topo_leaf_node, ln) || !up(&b->topo_left, L) || !up(&b->topo_right, R) || !up(&b->topo_level_off, lvl_off) ||
+      hipMalloc(&b->topo_total, 4 * (size_t)nn) != hipSuccess || hipMalloc(&b->topo_prefix, 4 * (size_t)nn) != hipSuccess ||
+      hipMemsetAsync(b->topo_total, 0, 4 * (size_t)nn, c->stream) != hipSuccess || hipMemsetAsync(b->topo_prefix, 0, 4 * (size_t)nn, c->stream) != hipSuccess) { topo_free(b); return crux_fail(c, CRUX_ENOMEM, "cumsum tree"); }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   b->topo_n = N; b->topo_leaves = nl; b->topo_nodes = nn; b->topo_levels = maxlvl + 1;
   return CRUX_OK;
+}
+
+// device twin of topo_rec's descent: the leaf holding element e (1 <= e < N): heap number, level, first element and length. `nlev` = levels of the tree
+// (uniform): the loop runs nlev - 1 times for every lane with predicated updates -- branch-free (a data-dependent `while` costs an exec-mask branch per level).
+struct LeafLoc { int id, depth, start, len; };
+__device__ __forceinline__ LeafLoc leaf_locate(int64_t N, int64_t e, int nlev) {
+  int i1 = 1, n = (int)(N - 1), id = 1, d = 0; const int ee = (int)e;
+  for (int it = 0; it < nlev - 1; ++it) { const bool sp = n >= 128; const int n2 = n >> 1; const bool rt = sp && ee >= i1 + n2;
+    i1 += rt ? n2 : 0; n = sp ? (rt ? n - n2 : n2) : n; id = sp ? 2 * id + (rt ? 1 : 0) : id; d += sp ? 1 : 0; }
+  return LeafLoc{id, d, i1, n};
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------------------------
@@ -112,7 +104,7 @@ __global__ __launch_bounds__(1024) void k_tree(const int32_t* __restrict__ left,
     for (int k = lvl_off[lv] + t; k < lvl_off[lv + 1]; k += 1024) if (left[k] >= 0) total[k] = total[left[k]] + total[right[k]];
     __syncthreads();
   }
-  if (t == 0) prefix[0] = v[0];                        // accumulate_pairwise!: s_ = v[1]; rec(c, v, s_, 2, n-1)
+  if (t == 0) prefix[1] = v[0];                        // accumulate_pairwise!: s_ = v[1]; rec(c, v, s_, 2, n-1)  (the root is heap slot 1)
   __syncthreads();
   for (int lv = 0; lv < nlev; ++lv) {                 // left gets s, right gets s + s_left
     for (int k = lvl_off[lv] + t; k < lvl_off[lv + 1]; k += 1024) if (left[k] >= 0) { const float s = prefix[k]; prefix[left[k]] = s; prefix[right[k]] = s + total[left[k]]; }
@@ -140,7 +132,7 @@ __global__ __launch_bounds__(1024) void k_tree_lds(const int32_t* __restrict__ l
     for (int i = 0; i < NPT; ++i) { const int k = t + 1024 * i; if (k >= lo && k < hi && lft[i] >= 0) tot[k] = tot[lft[i]] + tot[rgt[i]]; }
     __syncthreads();
   }
-  if (t == 0) pre[0] = v[0];
+  if (t == 0) pre[1] = v[0];
   __syncthreads();
   for (int lv = 0; lv < nlev; ++lv) {
     const int lo = lvl_off[lv], hi = lvl_off[lv + 1];
@@ -164,117 +156,113 @@ __global__ __launch_bounds__(LEAF_BLK) void k_leaf_scan(const float* __restrict_
   for (int i = t; i < cnt; i += LEAF_BLK) c[base + i] = sm[i];
   if (blockIdx.x == 0 && t == 0) c[0] = v[0];
 }
-// update_priorities! touched element ids[j]: re-sum its leaf (running sums + total). One 64-lane block per touched element; duplicates write identical values.
-struct LeafRefreshOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of,
-                                                      const int32_t* __restrict__ nstart, const int32_t* __restrict__ nlen, float* __restrict__ run, float* __restrict__ total) {
+// update_priorities! touched element ids[j]: re-sum its leaf (running sums + total). One wave per touched element; duplicates write identical values.
+struct LeafRefreshOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev,
+                                                      float* __restrict__ run, float* __restrict__ total) {
   // one WAVE per touched element (4 per 256-thread block): lane l holds v[o + l] and v[o + 64 + l]; the running sum s_ = s_ + v[i] is inherently serial, so
-  // it walks the lanes with v_readlane (a few cycles per element) instead of a chain of dependent LDS reads, and lane i keeps the i-th running sum
+  // it walks the lanes with v_readlane (constant lane numbers, fully unrolled: readlane + add + select per element, no branch) and lane i keeps the i-th
+  // running sum. Lanes past the leaf's end hold +0, which leaves the (positive) sum unchanged bit for bit. The leaf follows from the element number by
+  // arithmetic on wave-uniform values: ids -> v is the only dependent pair of memory round trips.
   const int lane = threadIdx.x & 63; const int64_t q = (int64_t)bid_ * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q >= n) return;
-  const int64_t e = ids[q];
+  const int e = __builtin_amdgcn_readfirstlane((int)ids[q]);
   if (e == 0) { if (lane == 0) run[0] = v[0]; return; }       // element 1 of the reference is the seed s_ = v[1], outside the tree
-  const int node = leaf_of[e], o = nstart[node], len = nlen[node];
+  const LeafLoc lf = leaf_locate(N, e, nlev); const int node = lf.id, o = lf.start, len = lf.len;
   const float x0 = lane < len ? v[o + lane] : 0.f, x1 = 64 + lane < len ? v[o + 64 + lane] : 0.f;
   float s_ = 0.f, r0 = 0.f, r1 = 0.f;
-  for (int i = 0; i < len; ++i) {
-    const float xi = __builtin_bit_cast(float, i < 64 ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, x0), i) : __builtin_amdgcn_readlane(__builtin_bit_cast(int, x1), i - 64));   // v_readlane (a __shfl here becomes an LDS-crossbar ds_bpermute: ~120 cycles per element)
-    s_ = i == 0 ? xi : s_ + xi;
-    if (i < 64) { if (lane == i) r0 = s_; } else { if (lane == i - 64) r1 = s_; }
+#pragma unroll
+  for (int i = 0; i < 64; ++i) { const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x0), i)); s_ = i == 0 ? xi : s_ + xi; r0 = lane == i ? s_ : r0; }
+  if (len > 64) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) { const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x1), i)); s_ = s_ + xi; r1 = lane == i ? s_ : r1; }
   }
   if (lane < len) run[o + lane] = r0;
   if (64 + lane < len) run[o + 64 + lane] = r1;
   if (lane == 0) total[node] = s_;
 } };
-__global__ __launch_bounds__(256) void k_leaf_refresh(const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of,
-                                                      const int32_t* __restrict__ nstart, const int32_t* __restrict__ nlen, float* __restrict__ run, float* __restrict__ total) { LeafRefreshOp::run(blockIdx.x, gridDim.x, v, ids, n, leaf_of, nstart, nlen, run, total); }
+__global__ __launch_bounds__(256) void k_leaf_refresh(const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev, float* __restrict__ run, float* __restrict__ total) { LeafRefreshOp::run(blockIdx.x, gridDim.x, v, ids, n, N, nlev, run, total); }
 // After k_leaf_refresh: node totals along the touched leaves' root paths, bottom-up level by level (s_ = rec(left); s_ += rec(right)). One workgroup;
-// thread q follows touched element q. Nodes shared by several paths are written by several threads with the same value.
-struct TreeTouchOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of, const int32_t* __restrict__ anc,
-                                                      const int32_t* __restrict__ depth, const int32_t* __restrict__ left, const int32_t* __restrict__ right, int nlev, float* __restrict__ total) {
-  // thread q < 1024 follows touched element q (+1024, ...: calls with more than 1024 touched elements take the slow loop below). The root path and the
-  // child links of its nodes are static, so they are fetched once, before the level loop: each level then costs ONE round trip (the two child totals)
-  if (n <= (int64_t)blockDim.x) {
-    const int64_t q = threadIdx.x; int d = 0; int an[CRUX_PER_PMAX], lf[CRUX_PER_PMAX], rg[CRUX_PER_PMAX];
-    const int64_t e = q < n ? ids[q] : 0;
-    if (e != 0) { const int leaf = leaf_of[e]; d = depth[leaf];
-      const int4* pa = (const int4*)(anc + (size_t)leaf * CRUX_PER_PMAX);
-#pragma unroll
-      for (int k = 0; k < CRUX_PER_PMAX / 4; ++k) { const int4 x = pa[k]; an[4 * k] = x.x; an[4 * k + 1] = x.y; an[4 * k + 2] = x.z; an[4 * k + 3] = x.w; }
-#pragma unroll
-      for (int k = 0; k < CRUX_PER_PMAX; ++k) { lf[k] = an[k] >= 0 ? left[an[k]] : 0; rg[k] = an[k] >= 0 ? right[an[k]] : 0; } }
-    for (int lv = nlev - 2; lv >= 0; --lv) {          // parents at level lv are complete once the level below is
-      const int k = d - 1 - lv;
-      if (e != 0 && k >= 0) {
-        int a = 0, l = 0, r = 0;
-#pragma unroll
-        for (int z = 0; z < CRUX_PER_PMAX; ++z) if (z == k) { a = an[z]; l = lf[z]; r = rg[z]; }
-        total[a] = total[l] + total[r]; }
+// thread q follows touched element q. Nodes shared by several paths are written by several threads with the same value. The ancestor of leaf L (level d) at
+// level lv is L >> (d - lv) and its children are 2a and 2a + 1: each level costs ONE round trip (the two child totals), nothing is looked up.
+struct TreeTouchOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev, float* __restrict__ total) {
+  if (n <= (int64_t)blockDim.x) {                   // the usual case (a minibatch of touched elements): the descent is done once, before the level loop
+    const int64_t e = (int64_t)threadIdx.x < n ? ids[threadIdx.x] : 0;
+    const LeafLoc lf = leaf_locate(N, e > 0 ? e : 1, nlev);
+    for (int lv = nlev - 2; lv >= 0; --lv) {
+      if (e != 0 && lf.depth - 1 - lv >= 0) { const int a = lf.id >> (lf.depth - lv); total[a] = total[2 * a] + total[2 * a + 1]; }
       __threadfence_block(); __syncthreads();
     }
     return;
   }
-  for (int lv = nlev - 2; lv >= 0; --lv) {
+  for (int lv = nlev - 2; lv >= 0; --lv) {          // parents at level lv are complete once the level below is
     for (int64_t q = threadIdx.x; q < n; q += blockDim.x) { const int64_t e = ids[q]; if (e == 0) continue;
-      const int leaf = leaf_of[e]; const int k = depth[leaf] - 1 - lv;
-      if (k >= 0) { const int a = anc[(size_t)leaf * CRUX_PER_PMAX + k]; total[a] = total[left[a]] + total[right[a]]; } }
+      const LeafLoc lf = leaf_locate(N, e, nlev);
+      if (lf.depth - 1 - lv >= 0) { const int a = lf.id >> (lf.depth - lv); total[a] = total[2 * a] + total[2 * a + 1]; } }
     __threadfence_block(); __syncthreads();
   }
 } };
-__global__ __launch_bounds__(1024) void k_tree_touch(const int64_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ leaf_of, const int32_t* __restrict__ anc,
-                                                      const int32_t* __restrict__ depth, const int32_t* __restrict__ left, const int32_t* __restrict__ right, int nlev, float* __restrict__ total) { TreeTouchOp::run(blockIdx.x, gridDim.x, ids, n, leaf_of, anc, depth, left, right, nlev, total); }
-// prefix of leaf node `leaf` = _accumulate_pairwise!'s s at that leaf: v[1], then + total(left sibling) at every right turn of the root path, top-down
-__device__ __forceinline__ float leaf_prefix(const float* __restrict__ v, const float* __restrict__ total, const int32_t* __restrict__ path, int leaf) {
-  int sib[CRUX_PER_PMAX]; float tv[CRUX_PER_PMAX];
-  const int4* pp = (const int4*)(path + (size_t)leaf * CRUX_PER_PMAX);
+__global__ __launch_bounds__(1024) void k_tree_touch(const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev, float* __restrict__ total) { TreeTouchOp::run(blockIdx.x, gridDim.x, ids, n, N, nlev, total); }
+// prefix of a leaf = _accumulate_pairwise!'s s at that leaf: v[1], then + total(left sibling) at every right turn of the root path, top-down. The node of the path
+// at level q is id >> (depth - q); it is a right child when odd and its left sibling is the slot before it. Branch-free: a left turn (or a level below the leaf)
+// reads slot 0 of the totals, which holds +0 and leaves the positive sum unchanged bit for bit. All loads are independent (one round trip).
+__device__ __forceinline__ float leaf_prefix(const float* __restrict__ v, const float* __restrict__ total, const LeafLoc lf, int nlev) {
+  float tv[CRUX_PER_PMAX];
 #pragma unroll
-  for (int q = 0; q < CRUX_PER_PMAX / 4; ++q) { const int4 x = pp[q]; sib[4 * q] = x.x; sib[4 * q + 1] = x.y; sib[4 * q + 2] = x.z; sib[4 * q + 3] = x.w; }
-#pragma unroll
-  for (int q = 0; q < CRUX_PER_PMAX; ++q) tv[q] = sib[q] >= 0 ? total[sib[q]] : 0.f;
+  for (int q = 1; q <= CRUX_PER_PMAX; ++q) { tv[q - 1] = 0.f;
+    if (q < nlev) { const int sh = lf.depth - q; const int node = sh >= 0 ? lf.id >> sh : 0; tv[q - 1] = total[(node & 1) ? node - 1 : 0]; } }
   float s = v[0];
 #pragma unroll
-  for (int q = 0; q < CRUX_PER_PMAX; ++q) if (sib[q] >= 0) s = s + tv[q];
+  for (int q = 1; q <= CRUX_PER_PMAX; ++q) if (q < nlev) s = s + tv[q - 1];
   return s;
 }
 // cumsum(priorities) as the reference would hold it, materialised for crux_per_get: c[i] = prefix(leaf(i)) + run[i]
-__global__ void k_materialize_cumsum(const float* __restrict__ run, const float* __restrict__ v, const float* __restrict__ total, const int32_t* __restrict__ path, const int32_t* __restrict__ leaf_of, int64_t N, float* __restrict__ out) {
+__global__ void k_materialize_cumsum(const float* __restrict__ run, const float* __restrict__ v, const float* __restrict__ total, int64_t N, int nlev, float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = i == 0 ? run[0] : leaf_prefix(v, total, path, leaf_of[i]) + run[i];
+    out[i] = i == 0 ? run[0] : leaf_prefix(v, total, leaf_locate(N, i, nlev), nlev) + run[i];
 }
 __global__ void k_cumsum_tiny(const float* v, int64_t n, float* c) { if (threadIdx.x == 0 && blockIdx.x == 0) { if (n >= 1) c[0] = v[0]; } }
 
 // stratified search + importance weights (:335-347)
 // One WAVE per stratum. searchsortedfirst (:340) is a chain of ~log2(N) dependent probes, and each probe of the un-materialised cumsum costs a
-// memory round trip (leaf_of[mid] and run[mid] together, then prefix[leaf]); evaluated by one thread that is 20 serial round trips. The wave
-// evaluates SIX levels of the binary search at once: lane L (1..63, heap order) assumes the outcomes spelled by the bits of L below its leading one,
-// derives the (lo, hi) interval that path would have produced and probes its midpoint; a ballot then replays the real search over the 63 answers.
+// memory round trip (run[mid] and the sibling totals of mid's root path together -- the path itself is arithmetic); evaluated by one thread that is 20 serial
+// round trips. The wave evaluates SIX levels of the binary search at once: lane L (1..63, heap order) assumes the outcomes spelled by the bits of L below its
+// leading one, derives the (lo, hi) interval that path would have produced and probes its midpoint; a ballot then replays the real search over the 63 answers.
 // The probes and comparisons are exactly those of the sequential search, so the result is the reference's index even where rounding makes the
-// cumsum locally non-monotone; 20 levels cost 4 round trips instead of 20.
-struct PerSearchOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ run, const float* __restrict__ total, const int32_t* __restrict__ path, const int32_t* __restrict__ leaf_of, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B,
+// cumsum locally non-monotone; 20 levels cost 4 round trips instead of 20. Lane 0, idle in that scheme, fetches cumsum[N] (the total the stratum width is
+// derived from) in the FIRST round, beside the probes, so the total costs no round trip of its own. The interval bookkeeping is predicated, not branched, and
+// the real (lo, hi) live in scalar registers.
+struct PerSearchOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ run, const float* __restrict__ total, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B, int nlev,
                              const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) {
   const int lane = threadIdx.x & 63;
   const int64_t j = (int64_t)bid_ * 4 + (threadIdx.x >> 6);
   if (j >= B) return;
-  auto cs = [&](int64_t i) -> float { return (i == 0 || N < 2) ? run[i] : leaf_prefix(pr, total, path, leaf_of[i]) + run[i]; };    // cumsum[i] exactly as accumulate_pairwise! forms it
-  const float ptot = cs(N - 1);
-  const float dp = ptot / (float)B;
+  const int Ni = (int)N;
+  auto cs = [&](int i) -> float { return (i == 0 || Ni < 2) ? run[i] : leaf_prefix(pr, total, leaf_locate(N, i, nlev), nlev) + run[i]; };    // cumsum[i] exactly as accumulate_pairwise! forms it
   double u;
   if (rands) u = rands[j];
   else { const crux_u32x4 x = crux_philox(seed, ictr * (uint64_t)B + (uint64_t)j, stream, CRUX_RNG_SAMPLE); u = crux_u32x2_to_f64(x.v[0], x.v[1]); }
-  const double key = ((double)(j + 1) + u - 1.0) * (double)dp;
-  int64_t lo = 0, hi = N;
-  const int depth = lane ? 31 - __builtin_clz((unsigned)lane) : 0;          // lane 1 is the root (depth 0)
+  float ptot = 0.f; double key = 0.0; bool first = true;
+  int lo = 0, hi = Ni;
+  const int dl = lane ? 31 - __builtin_clz((unsigned)lane) : 0;          // lane 1 is the root (depth 0)
   while (lo < hi) {
-    int64_t l = lo, h = hi; bool valid = lane != 0;
-    for (int b = depth - 1; b >= 0 && valid; --b) { if (!(l < h)) { valid = false; break; } const int64_t m = l + ((h - l) >> 1); if ((lane >> b) & 1) l = m + 1; else h = m; }
+    int l = lo, h = hi; bool valid = lane != 0;
+#pragma unroll
+    for (int b = 5; b >= 0; --b) { const bool act = valid && b < dl, ok = l < h; const int m = l + ((h - l) >> 1); const bool bit = ((lane >> b) & 1) != 0;
+      valid = valid && (!act || ok); const bool upd = act && ok; l = (upd && bit) ? m + 1 : l; h = (upd && !bit) ? m : h; }
     valid = valid && l < h;
-    bool less = false;
-    if (valid) { const int64_t m = l + ((h - l) >> 1); less = (double)cs(m) < key; }
+    const bool want_tot = first && lane == 0;
+    float cv = 0.f;
+    if (valid || want_tot) cv = cs(want_tot ? Ni - 1 : l + ((h - l) >> 1));
+    if (first) { ptot = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cv)));
+      const float dp = ptot / (float)B; key = ((double)(j + 1) + u - 1.0) * (double)dp; first = false; }
+    const bool less = valid && (double)cv < key;
     const unsigned long long lt = __ballot(less);
     int node = 1;
 #pragma unroll
-    for (int step = 0; step < 6; ++step) { if (!(lo < hi)) break; const int64_t mid = lo + ((hi - lo) >> 1); const int bit = (int)((lt >> node) & 1ull); if (bit) lo = mid + 1; else hi = mid; node = 2 * node + bit; }
+    for (int step = 0; step < 6; ++step) { if (!(lo < hi)) break; const int mid = lo + ((hi - lo) >> 1); const int bit = (int)((lt >> node) & 1ull); if (bit) lo = mid + 1; else hi = mid; node = 2 * node + bit; }
+    lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
   }
-  if (lo >= N) lo = N - 1;       // the reference would index out of bounds here
+  if (lo >= Ni) lo = Ni - 1;       // the reference would index out of bounds here
   if (lane == 0) {
     ids[j] = lo;
     const float pmin = pminmax[1] / ptot;
@@ -282,8 +270,8 @@ struct PerSearchOp { static __device__ __forceinline__ void run(const unsigned b
     weight[lo] = powf(((float)N * pr[lo]) / ptot, beta) / max_w;
   }
 } };
-__global__ __launch_bounds__(256) void k_per_search(const float* __restrict__ run, const float* __restrict__ total, const int32_t* __restrict__ path, const int32_t* __restrict__ leaf_of, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B,
-                             const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) { PerSearchOp::run(blockIdx.x, gridDim.x, run, total, path, leaf_of, pr, pminmax, N, B, rands, seed, stream, ictr, beta, ids, weight); }
+__global__ __launch_bounds__(256) void k_per_search(const float* __restrict__ run, const float* __restrict__ total, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B, int nlev,
+                             const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) { PerSearchOp::run(blockIdx.x, gridDim.x, run, total, pr, pminmax, N, B, nlev, rands, seed, stream, ictr, beta, ids, weight); }
 struct UniformIdsOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, int64_t N, int64_t B, uint64_t seed, uint32_t stream, uint64_t ictr, int64_t* ids) {
   const int64_t j = (int64_t)bid_ * blockDim.x + threadIdx.x;
   if (j >= B) return;
@@ -359,8 +347,8 @@ int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool f
   if (from_push && b->elements < b->capacity) { b->per_full_dirty = true; return CRUX_OK; }   // the ring is still growing: the rows may lie beyond the current tree
   if (b->per_full_dirty || b->topo_n < 2 || b->per_run_n != b->topo_n || b->topo_n != b->elements || n > 4096 || !d_ids) { b->per_full_dirty = true; return CRUX_OK; }
   if (b->topo_levels > CRUX_PER_PMAX) { b->per_full_dirty = true; return CRUX_OK; }
-  CRUX_RUN(b->ctx, LeafRefreshOp, OP_LEAF_REFRESH, k_leaf_refresh, (unsigned)((n + 3) / 4), 256, b->ctx->stream, b->priorities, d_ids, n, b->topo_leaf_of, b->topo_node_start, b->topo_node_len, b->cumsum, b->topo_total);
-  CRUX_RUN(b->ctx, TreeTouchOp, OP_TREE_TOUCH, k_tree_touch, 1, 1024, b->ctx->stream, d_ids, n, b->topo_leaf_of, b->topo_anc, b->topo_depth, b->topo_left, b->topo_right, b->topo_levels, b->topo_total);
+  CRUX_RUN(b->ctx, LeafRefreshOp, OP_LEAF_REFRESH, k_leaf_refresh, (unsigned)((n + 3) / 4), 256, b->ctx->stream, b->priorities, d_ids, n, b->topo_n, b->topo_levels, b->cumsum, b->topo_total);
+  CRUX_RUN(b->ctx, TreeTouchOp, OP_TREE_TOUCH, k_tree_touch, 1, 1024, b->ctx->stream, d_ids, n, b->topo_n, b->topo_levels, b->topo_total);
   return crux_launch_check(b->ctx, "k_leaf_refresh");
 }
 
@@ -402,7 +390,7 @@ int32_t crux_per_sample(crux_buffer* target, crux_buffer* source, int64_t B, con
   if (rands) { d_r = (double*)crux_scratch(c, 8 * (size_t)B + 256); if (!d_r) return crux_fail(c, CRUX_ENOMEM, "prioritized_sample!: scratch");
     HIPCHK(c, hipMemcpyAsync(d_r, rands, 8 * (size_t)B, hipMemcpyHostToDevice, c->stream)); }
   crux_prof_begin(c, CRUX_PROF_PER_SEARCH);
-  CRUX_RUN(c, PerSearchOp, OP_PER_SEARCH, k_per_search, (unsigned)((B + 3) / 4), 256, c->stream, source->cumsum, source->topo_total, source->topo_path, source->topo_leaf_of, source->priorities, source->pminmax, N, B, (const double*)d_r, source->sample_seed, source->sample_stream, i, beta, target->d_indices, (float*)source->col[CRUX_COL_WEIGHT]);
+  CRUX_RUN(c, PerSearchOp, OP_PER_SEARCH, k_per_search, (unsigned)((B + 3) / 4), 256, c->stream, source->cumsum, source->topo_total, source->priorities, source->pminmax, N, B, source->topo_levels, (const double*)d_r, source->sample_seed, source->sample_stream, i, beta, target->d_indices, (float*)source->col[CRUX_COL_WEIGHT]);
   crux_prof_end(c, CRUX_PROF_PER_SEARCH);
   rc = crux_launch_check(c, "k_per_search"); if (rc) return rc;
   return gather_into(target, source, B, true);
@@ -433,7 +421,7 @@ int32_t crux_per_get(crux_buffer* b, float* priorities, float* max_priority, flo
   if (cumsum && b->elements > 0) { int32_t rc = ensure_cumsum(b, b->elements); if (rc) return rc;
     const int64_t N = b->elements; float* tmp = (float*)crux_scratch(c, 4 * (size_t)N + 256); if (!tmp) return crux_fail(c, CRUX_ENOMEM, "per_get: scratch");
     if (N < 2) HIPCHK(c, hipMemcpyAsync(tmp, b->cumsum, 4 * (size_t)N, hipMemcpyDeviceToDevice, c->stream));
-    else hipLaunchKernelGGL(k_materialize_cumsum, dim3(gridn(N)), dim3(256), 0, c->stream, b->cumsum, b->priorities, b->topo_total, b->topo_path, b->topo_leaf_of, N, tmp);
+    else hipLaunchKernelGGL(k_materialize_cumsum, dim3(gridn(N)), dim3(256), 0, c->stream, b->cumsum, b->priorities, b->topo_total, N, b->topo_levels, tmp);
     HIPCHK(c, hipMemcpyAsync(cumsum, tmp, 4 * (size_t)N, hipMemcpyDeviceToHost, c->stream)); }
   float mm[2];
   HIPCHK(c, hipMemcpyAsync(mm, b->pminmax, 8, hipMemcpyDeviceToHost, c->stream));
