@@ -18,7 +18,7 @@ enum {
 };
 
 #define CRUX_EXEC_ARG_BYTES 496
-struct ExecOp { int32_t kid; uint32_t nblocks; int32_t barrier; int32_t pad; alignas(8) unsigned char args[CRUX_EXEC_ARG_BYTES]; };
+struct ExecOp { int32_t kid; uint32_t nblocks; int32_t barrier; int32_t abytes; alignas(8) unsigned char args[CRUX_EXEC_ARG_BYTES]; };   // abytes: size of the packed arguments actually used
 
 // ---- argument packs: the parameters of XOp::run after (bid, nblocks), stored by value in declaration order --------------------------------
 template <class... T> struct ArgPack;
@@ -66,7 +66,7 @@ template <class Op, int KID, class... A> inline void crux_exec_push(crux_ctx* c,
   static_assert(std::is_trivially_copyable<P>::value, "op arguments must be plain data");
   ExecOp* op = crux_exec_new_op(c, KID, nblocks);
   P p(a...);
-  memcpy(op->args, &p, sizeof p);
+  memcpy(op->args, &p, sizeof p); op->abytes = (int32_t)sizeof p;
 }
 // a launch site: record when the context is recording, launch otherwise. NT = threads per block of the stand-alone launch (the executor always runs 256).
 #define CRUX_RUN(c, OpT, KID, kernel, nblocks, NT, stream, ...)                                                            \

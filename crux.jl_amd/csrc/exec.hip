@@ -101,6 +101,42 @@ __global__ __launch_bounds__(256) void k_phase(const ExecOp* __restrict__ ops, i
   const ExecOp* op = ops + o; const int kid = op->kid;
   EXEC_SWITCH(exec_dispatch_g)
 }
+// The same phase with its op records INSIDE the kernel arguments (<= 8 ops, <= 3.8 KB of packed arguments: every phase of the DQN / SAC epochs). With the records in
+// global memory a workgroup walks block counts -> body id -> arguments -> the op's own data: three dependent scalar loads from memory the host copy has just written
+// (cold in every cache) before the first useful load, ~4 us of a one-block phase's 6. The kernel-argument segment is read once, by independent scalar loads, so the
+// chain is arguments -> data, as in a stand-alone launch.
+// The argument struct comes in three sizes (the host copies it on every launch: with 4 KB per launch the enqueue, not the GPU, paced a SAC epoch).
+#define PHASEK_MAXOPS 8
+template <int BYTES> struct PhaseK { int32_t n; int32_t pad; int32_t kid[PHASEK_MAXOPS]; uint32_t nblocks[PHASEK_MAXOPS]; uint32_t off[PHASEK_MAXOPS]; alignas(16) unsigned char args[BYTES]; };
+static_assert(sizeof(PhaseK<3840>) <= 4096, "HIP kernel arguments are limited to 4 KB");
+struct KOp { const unsigned char* args; unsigned nblocks; };
+template <class Op> __device__ __forceinline__ void exec_dispatch_k(const KOp* op, unsigned bid) {
+  const OpPack<Op> p = *(const OpPack<Op>*)op->args;
+  exec_apply<Op>(bid, op->nblocks, p);
+}
+template <int BYTES>
+__global__ __launch_bounds__(256) void k_phase_k(PhaseK<BYTES> by_value) {
+  // read through the kernel-argument segment pointer, not through the by-value parameter: indexing the parameter at a run-time offset would make the compiler
+  // copy the aggregate to private memory first
+  const PhaseK<BYTES>* pk = (const PhaseK<BYTES>*)__builtin_amdgcn_kernarg_segment_ptr();
+  unsigned b = blockIdx.x; int o = 0; const int n = pk->n;
+#pragma unroll
+  for (int q = 0; q < PHASEK_MAXOPS - 1; ++q) { const unsigned nb = pk->nblocks[q]; const bool adv = o == q && q + 1 < n && b >= nb; b -= adv ? nb : 0u; o += adv ? 1 : 0; }
+  const int kid = pk->kid[o]; const KOp kop{pk->args + pk->off[o], pk->nblocks[o]}; const KOp* op = &kop;
+  EXEC_SWITCH(exec_dispatch_k)
+}
+// host: pack ops [i0, i1] of a recording into a PhaseK<BYTES>; false when they do not fit
+template <int BYTES> static bool phasek_launch(const std::vector<ExecOp>& ops, size_t i0, size_t i1, unsigned blocks, hipStream_t st) {
+  PhaseK<BYTES> pk; pk.n = 0; pk.pad = 0; size_t used = 0;
+  for (size_t i = i0; i <= i1; ++i) { const ExecOp& e = ops[i]; if (!e.nblocks) continue;
+    const size_t raw = (size_t)(e.abytes > 0 ? e.abytes : CRUX_EXEC_ARG_BYTES), ab = (raw + 15) & ~(size_t)15;
+    if (pk.n >= PHASEK_MAXOPS || used + ab > (size_t)BYTES) return false;
+    pk.kid[pk.n] = e.kid; pk.nblocks[pk.n] = e.nblocks; pk.off[pk.n] = (uint32_t)used; memcpy(pk.args + used, e.args, raw); used += ab; pk.n++; }
+  if (pk.n == 0) return false;
+  for (int q = pk.n; q < PHASEK_MAXOPS; ++q) { pk.kid[q] = 0; pk.nblocks[q] = 0; pk.off[q] = 0; }
+  hipLaunchKernelGGL(k_phase_k<BYTES>, dim3(blocks), dim3(256), 0, st, pk);
+  return true;
+}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_exec(const ExecOp* __restrict__ ops, int nops, unsigned* ctr, int xcd, int32_t* status, int flags) {
   if (xcd >= 0 && (int)(blockIdx.x & 7) != xcd) return;
   const unsigned wg = xcd >= 0 ? blockIdx.x >> 3 : blockIdx.x, G = xcd >= 0 ? gridDim.x >> 3 : gridDim.x;
@@ -153,7 +189,7 @@ int32_t crux_exec_begin(crux_ctx* c) {
 void crux_exec_abort(crux_ctx* c) { if (c->rec) { ExecRec* r = rec_of(c); r->active = false; r->ops.clear(); r->readbacks.clear(); } }
 ExecOp* crux_exec_new_op(crux_ctx* c, int kid, unsigned nblocks) {
   ExecRec* r = rec_of(c); r->ops.emplace_back(); ExecOp* op = &r->ops.back();
-  op->kid = kid; op->nblocks = nblocks; op->barrier = 1; op->pad = 0; return op;
+  op->kid = kid; op->nblocks = nblocks; op->barrier = 1; op->abytes = 0; return op;
 }
 void* crux_exec_scratch(crux_ctx* c, size_t bytes) {
   ExecRec* r = rec_of(c); bytes = (bytes + 255) / 256 * 256;
@@ -207,7 +243,11 @@ int32_t crux_exec_run(crux_ctx* c) {
       // saves the launches but runs every op on 32 CUs behind one L2 and pays ~2 us per barrier; DESIGN 4.3 has the numbers.
       size_t i0 = 0;
       while (i0 < nops) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += r->ops[i1].nblocks; if (r->ops[i1].barrier || i1 + 1 == nops) break; ++i1; }
-        if (blocks) hipLaunchKernelGGL(k_phase, dim3(blocks), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops + i0, (int)(i1 - i0 + 1));
+        if (blocks) {
+          // the phase's records travel in the kernel arguments when they fit (see k_phase_k); zero-block ops are dropped there
+          if (!phasek_launch<384>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<1024>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<3840>(r->ops, i0, i1, blocks, c->stream))
+            hipLaunchKernelGGL(k_phase, dim3(blocks), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops + i0, (int)(i1 - i0 + 1));
+        }
         i0 = i1 + 1; }
     } else {
     // the counter barrier relies on one shared L2: all workgroups on XCD 0 (workgroup i of a grid lands on XCD i mod 8, verified by the placement probe)
@@ -372,15 +412,16 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   // Phase plan (LA = layers of the actor, LQ = of a critic; X = 3 + LA + LQ, Y = X + 4 + LQ). Chains that touch different networks run side by side:
   //   0 ids | 1 gather, zero-fills | 2.. actor(sp) forward ; vcat(s, a) ; Q1 || Q2 forward on (s, a) | 2+LA exploration at sp | 3+LA.. target Q1 || Q2 ; actor(s) forward
   //   X sac_target ; exploration at s | X+1 critic heads ; temperature head | X+2.. critic backward (weight || data gradient, both critics) ; Adam(log_alpha) | .. norm | info, Adam(Q1), Adam(Q2)
-  //   Y.. actor(s) forward | exploration | Q1 || Q2 forward | actor head | Q1 || Q2 input gradients | reverse of exploration | actor backward ; logSigma row sums | norm | info, Adam | polyak
+  //   X+1.. actor(s) forward of the ACTOR step, exploration (beside the critic's backward) | Y.. Q1 || Q2 forward | actor head | Q1 || Q2 input gradients | reverse of exploration | actor backward ; logSigma row sums | norm | info, Adam | polyak
   // The order inside every chain is the reference's (temperature before critic before actor: each sees the parameters the previous step left).
   std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, X = 3 + LA + LQ, Y = X + 4 + LQ;
-  if (LA != LQ || q2->nd.L != LQ || q1_targ->nd.L != LQ || q2_targ->nd.L != LQ) plan_ok = false;
-  // chained epochs: phases 0 (ids) and 1 (gather, fills) of a later epoch run beside the previous epoch's last three phases (actor norm | info + Adam | advance + polyak,
-  // none of which reads the batch), the rest closes up by two -- see crux_dqn_epoch
+  if (LA != LQ || q2->nd.L != LQ || q1_targ->nd.L != LQ || q2_targ->nd.L != LQ) plan_ok = false;       // (the early actor forward needs X + 1 + LA < Y, i.e. LA < LQ + 3)
+  // chained epochs: phases 0 (ids) and 1 (gather, fills) of a later epoch run beside the previous epoch's actor norm and info + Adam (neither reads the batch), and its
+  // phase 2 (actor(sp) forward, vcat(s, a): online networks only) beside the previous epoch's advance + polyak, which writes beta powers and TARGET networks: the rest
+  // closes up by three -- see crux_dqn_epoch
   auto tag = [&](size_t from, auto&& rule) { if (!fuse) return; ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
     for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { plan_ok = false; p = 0; }
-      ph.push_back(base > 0 ? (p < 2 ? base - 3 + p : base + p - 2) : p); } };
+      ph.push_back(base > 0 ? (p < 2 ? base - 3 + p : base + p - 3) : p); } };
   const size_t ops0 = fuse ? exec_mark(c) : 0;
   size_t m = ops0;
   rc = crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
@@ -406,20 +447,22 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
     rc = crux_sac_actor_step(actor, q1, q2, log_alpha, batch, noise_seed, noise_counter0 + 2, info_actor); if (rc) return bail(rc);
     tag(m, [&](int kid, int& g) {      // GEMMs: LA actor forward, LQ + LQ critic forwards, LQ + LQ critic input gradients, then the actor's (weight, data) pairs
       if (kid == OP_FILL) return 1;
-      if (kid == OP_GEMM) { const int k = g++; if (k < LA) return Y + k; if (k < LA + 2 * LQ) return Y + LA + 1 + (k - LA) % LQ;
-        if (k < LA + 4 * LQ) return Y + LA + 2 + LQ + (k - LA - 2 * LQ) % LQ; return Y + LA + 3 + 2 * LQ + (k - LA - 4 * LQ) / 2; }
-      return kid == OP_GAUSS_EXPLORE ? Y + LA : kid == OP_ACTOR_HEAD ? Y + LA + 1 + LQ : kid == OP_ACTOR_GRAD ? Y + LA + 2 + 2 * LQ : kid == OP_ROWSUM ? Y + LA + 3 + 2 * LQ :
-             kid == OP_SUMSQ2 ? Y + 2 * LA + 3 + 2 * LQ : (kid == OP_ACTOR_INFO || kid == OP_ADAM_GATED) ? Y + 2 * LA + 4 + 2 * LQ : kid == OP_ADAM_ADVANCE ? Y + 2 * LA + 5 + 2 * LQ : -1; });
+      // the actor's own forward pass and its exploration draw depend on neither the critic update nor the temperature: they run beside the critic's head / backward
+      // phases (X + 1 ..), after the temperature step's last read of the actor's activations (its exploration at X)
+      if (kid == OP_GEMM) { const int k = g++; if (k < LA) return X + 1 + k; if (k < LA + 2 * LQ) return Y + (k - LA) % LQ;
+        if (k < LA + 4 * LQ) return Y + 1 + LQ + (k - LA - 2 * LQ) % LQ; return Y + 2 + 2 * LQ + (k - LA - 4 * LQ) / 2; }
+      return kid == OP_GAUSS_EXPLORE ? X + 1 + LA : kid == OP_ACTOR_HEAD ? Y + LQ : kid == OP_ACTOR_GRAD ? Y + 1 + 2 * LQ : kid == OP_ROWSUM ? Y + 2 + 2 * LQ :
+             kid == OP_SUMSQ2 ? Y + LA + 2 + 2 * LQ : (kid == OP_ACTOR_INFO || kid == OP_ADAM_GATED) ? Y + LA + 3 + 2 * LQ : kid == OP_ADAM_ADVANCE ? Y + LA + 4 + 2 * LQ : -1; });
     m = fuse ? exec_mark(c) : 0;
     if (actor_targ) { rc = crux_polyak(actor_targ, actor, tau); if (rc) return bail(rc); }
     rc = crux_polyak(q1_targ, q1, tau); if (rc) return bail(rc);
     rc = crux_polyak(q2_targ, q2, tau); if (rc) return bail(rc);
-    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + 2 * LA + 5 + 2 * LQ : -1; });
+    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + LA + 4 + 2 * LQ : -1; });
   }
   if (fuse && rec_of(c)->chain) {      // chained: crux_sac_epochs schedules and runs the whole list
     ExecRec* r = rec_of(c);
     if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + 2 * LA + 6 + 2 * LQ - (r->chain_base > 0 ? 2 : 0);
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + LA + 5 + 2 * LQ - (r->chain_base > 0 ? 3 : 0);
     return CRUX_OK;
   }
   if (fuse && plan_ok && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }

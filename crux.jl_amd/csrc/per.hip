@@ -12,11 +12,11 @@
 // The tree shape depends only on N and is built on the host once per buffer length.
 //
 // Incremental form (the reference rescans all N priorities per gradient step, :329-332; its abandoned sum-tree is at :48,:334-336): the cumsum is
-// never materialised. `cumsum[i]` holds the running sum INSIDE i's leaf and c[i] = prefix[leaf(i)] + cumsum[i] is formed when the search probes
-// it -- the same two Float32 additions in the same order as accumulate_pairwise! performs (c[i] = op(s, s_)). update_priorities! re-sums only the
-// leaves it touched (k_leaf_refresh: <= 127 elements each), the next sample re-derives node totals and prefixes with the LDS tree pass over the
-// ~N/95 leaves' nodes, and searchsortedfirst probes exactly the elements the reference's binary search would. Per sampled step at N = 1 M:
-// <= 128 x 127 x 8 B of leaf traffic + 170 KB of tree nodes + 20 KB of probes instead of 8 MB.
+// never materialised. `cumsum[i]` holds the running sum INSIDE i's leaf and c[i] = prefix(leaf(i)) + cumsum[i] is formed when the search probes
+// it -- the same Float32 additions in the same order as accumulate_pairwise! performs (c[i] = op(s, s_)). update_priorities! re-sums only the
+// leaves it touched (k_leaf_refresh: <= 127 elements each) and the node totals on their root paths (k_tree_touch); prefix(leaf) = v[1] + the totals of the
+// left siblings passed on the way down, added top-down, is formed per probe from those totals. searchsortedfirst probes exactly the elements the reference's
+// binary search would. Per sampled step at N = 1 M: <= 128 x 127 x 8 B of leaf traffic + a few KB of node totals and probes instead of 8 MB.
 #include "common.h"
 #include "exec.h"
 #include <algorithm>
