@@ -58,7 +58,7 @@ def c5(crux, ctx, cpu=True):
     out = {"workload": bench.WORKLOADS["c5"]["name"] + ", batch 128, 80 + 80 epochs (%d Adam steps/iter)" % (2 * steps_l), "n_gpus": 1,
            "env_steps_per_s": E * T / t, "grad_steps_per_s": 2 * steps_l / t, "ms_per_iteration": 1e3 * t,
            "phase_ms": {k: ctx.prof_get(k)[0] for k in ("rollout", "values", "gae", "whiten", "train_actor")},
-           "roofline": {"kernel": "batch_train! actor, k_train_mfma_x2<17,6,GAUSSIAN,tanh>", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "roofline": {"kernel": "batch_train! actor, k_train_mfma<17,6,GAUSSIAN,tanh,4,2>", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "us_per_grad_step": ms_a / max(1, n_a) * 1e3 / steps_l, "allreduce_payload_bytes": 4 * pi.A.n_params,
                         "note": "one serially dependent learner on two CUs; %.2f MFLOP per step" % (fa / 1e6)}}
     if cpu:

@@ -29,7 +29,7 @@ struct crux_ctx {
   hipStream_t aux_rejected[8] = {}; int aux_n_rejected = 0; float aux_probe_ms = 0.f;   // candidates that shared the main stream's hardware queue (kept alive until destroy)
   void* comm = nullptr; int comm_rank = 0, comm_n = 0;   // RCCL communicator of the replica group (comm.hip)
   void* amulti[2] = {nullptr, nullptr}; size_t amulti_bytes[2] = {0, 0};   // argument blocks of the one-CU batched learner launch
-  int learner_cus = 0;                 // 0 = automatic, 1 = one CU per learner (k_train_mfma8), 2 = two CUs (k_train_mfma_x2)
+  int learner_cus = 0;                 // 0 = automatic, 1 = one CU per learner (k_train_mfma<...,8,1>), 2 = two CUs (k_train_mfma<...,4,2>)
   void* xmulti[2] = {nullptr, nullptr}; size_t xmulti_bytes[2] = {0, 0};   // exchange areas + argument blocks of the batched multi-learner launch
   void* xbuf[2] = {nullptr, nullptr};   // gradient exchange areas of the two-CU learner kernel, one per learner stream
   // replica group with direct peer slots (comm.hip "peer"): every rank owns one fine-grained region that its peers write their minibatch

@@ -506,8 +506,8 @@ extern "C" int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* cons
   }
   HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
-  // Two batched forms: two CUs per learner (k_train_mfma_x2, shortest iteration while 4 n CUs fit the chip) or one CU per learner
-  // (k_train_mfma8, 1.1x longer steps but half the CUs: the higher-throughput form once the population exceeds 64 = 256 CUs / 4).
+  // Two batched forms: two CUs per learner (k_train_mfma<...,4,2>, shortest iteration while 4 n CUs fit the chip) or one CU per learner
+  // (k_train_mfma<...,8,1>, 1.1x longer steps but half the CUs: the higher-throughput form once the population exceeds 64 = 256 CUs / 4).
   // more than 64 two-CU learners per launch pair would not be co-resident (2 launches x 2 n workgroups > 256 CUs): a workgroup could then spin on a
   // peer that is waiting for its CU, so that size always takes the one-CU form
   const bool one_cu = c->learner_cus == 1 || n > 64;

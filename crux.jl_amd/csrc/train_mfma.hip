@@ -1,13 +1,13 @@
 // train_mfma.hip -- dispatch of batch_train! / train! (src/training.jl:13-55) onto the MFMA learner kernels of the IN->64->64->OUT family.
 //
-// Two kernels share one mathematical formulation (documented in train_mfma8.hip / train_mfma_x2.hip): exact-f32 v_mfma_f32_16x16x4_f32 GEMMs for the
+// ONE kernel template (train_mfma_kernel.h: k_train_mfma<IN, OUT, KIND, ACT, NW, NWG, ...>) in two forms: exact-f32 v_mfma_f32_16x16x4_f32 GEMMs for the
 // 64-wide layers, the last layer and the loss head on the VALU, the 64x64 weight gradient model-parallel over waves with theta / m / v of W2 living
 // in the owning wave's registers for the whole launch.
-//   * k_train_mfma_x2 (train_mfma_x2.hip): one learner on TWO compute units of an XCD; minibatches of 65..128 rows (the batch_train! fast path),
-//     and -- for the shapes the one-CU kernel does not instantiate -- also single steps, gradient-only calls and small minibatches.
-//   * k_train_mfma8 (train_mfma8.hip): one learner on ONE compute unit with 8 waves; narrow inputs (IN <= 4), any minibatch up to 128 rows,
+//   * <NW = 4, NWG = 2> (train_mfma_x2.hip): one learner on TWO compute units of an XCD; minibatches of 65..128 rows (the batch_train! fast path),
+//     and -- for the shapes the one-CU form does not instantiate -- also single steps, gradient-only calls and small minibatches.
+//   * <NW = 8, NWG = 1> (train_mfma8.hip): one learner on ONE compute unit with 8 waves; narrow inputs (IN <= 4), any minibatch up to 128 rows,
 //     single steps (train!, crux_loss_grad), and the population launches where compute units are the scarce resource.
-// (A third, 4-wave one-CU kernel lived here until round 2; every case it served is now taken by the two above.)
+// (Round 1 had three separate copies of the step body -- a 4-wave one-CU kernel, the 8-wave one and the two-CU one; they are this one template now.)
 #include "train_args.h"
 
 #include "mfma_helpers.h"

@@ -1,5 +1,5 @@
 """The multi-GPU exchange step on ONE GPU: two contexts on device 0, wired into a replica group of two (crux_peer_attach_local), run the persistent
-learner kernels concurrently; every minibatch step SUM-all-reduces the local gradients through the peer-slot protocol of train_mfma_x2.hip (the same
+learner kernels concurrently; every minibatch step SUM-all-reduces the local gradients through the peer-slot protocol of train_mfma_kernel.h (the same
 code path N processes on N GPUs take, with hipIpc-mapped regions instead of same-process pointers). SURVEY 8(e): k = 1 must reproduce the single
 learner on the concatenated batch -- here the oracle with minibatches of 2 x 128 = 256 rows."""
 import ctypes as C

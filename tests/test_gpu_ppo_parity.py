@@ -210,7 +210,7 @@ def test_synced_training_equals_plain_call_without_and_with_a_group_of_one(gpu_c
 
 @pytest.mark.gpu
 def test_one_cu_population_launch_matches_single_calls_and_the_two_cu_form(gpu_ctx):
-    """Populations above 64 learners train with ONE CU per learner (k_train_mfma8 batched): bit-identical to single calls under
+    """Populations above 64 learners train with ONE CU per learner (the one-CU form of k_train_mfma, batched): bit-identical to single calls under
     Context.set_learner_cus(1), and equal to the two-CU form (different summation order of the minibatch gradient) to fp32 tolerance."""
     import os
     from parity import crux
