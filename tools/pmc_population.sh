@@ -27,6 +27,6 @@ for k, d in agg.items():
     if "SQ_WAVE_CYCLES" in m and "SQ_WAVES" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m and m["SQ_WAVES"] > 0:
         T = 4.0 * m["SQ_WAVE_CYCLES"] / m["SQ_WAVES"]          # cycles one wave (= the launch) lasted; SQ_WAVE_CYCLES counts quad-cycles
         print("   launch duration %.0f cycles; matrix pipe busy %.1f %% of (1024 SIMDs x duration), %.1f %% of the SIMDs that hosted a wave" % (
-            T, 100.0 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * T), 100.0 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["SQ_WAVES"] / (2 if "mfma8" in k else 1) * T)))
+            T, 100.0 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * T), 100.0 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["SQ_WAVES"] / (2 if ", 8, 1," in k else 1) * T)))
 PY
 rm -rf $OUT
