@@ -1665,7 +1665,25 @@ def _value_training_dpg(solver, D, gamma):
         solver._dy = ctx.alloc(4 * B)
     sm = solver.P.get("pi_smooth") if solver.target_fn == "td3" else None
     infos, lib, raw = [], ctx.lib, np.zeros(L.INFO_N, np.float32)
-    for epoch in range(c_opt.epochs):
+    fused = solver.fused_epochs and (not twin or solver.target_fn == "td3")
+    if fused:
+        # the whole epoch loop (:69-104) in one C call: chains of up to 8 epochs per recorded list (cruxhip.h: crux_dpg_epochs); same pieces, order and draws as below
+        _set_stream_for(buf, solver.sample_seed)
+        n = c_opt.epochs; ctr0 = solver.i * n
+        rq, ra = (np.zeros((n, L.INFO_N), np.float32) for _ in range(2))
+        ctx.check(lib.crux_dpg_epochs(A.h, (Q.N1 if twin else Q).h, Q.N2.h if twin else None, Am.h, (Qm.N1 if twin else Qm).h, Qm.N2.h if twin else None, buf.h, D.h,
+                                      float(gamma), float(solver.tau), sm.sigma if sm else -1.0, sm.eps_min if sm else 0.0, sm.eps_max if sm else 0.0, sm.a_min if sm else 0.0,
+                                      sm.a_max if sm else 0.0, 1 if solver.weighted_loss else 0, 0, n, int(c_opt.update_every), int(a_opt.update_every), ctr0,
+                                      solver.noise_seed, ctr0, _vp(rq), _vp(ra)))
+        for epoch in range(n):
+            info = {}
+            if epoch % c_opt.update_every == 0:
+                info.update({"Q1avg": float(rq[epoch, L.INFO["q1avg"]]), "Q2avg": float(rq[epoch, L.INFO["q2avg"]])} if twin else {"Qavg": float(rq[epoch, L.INFO["q1avg"]])})
+                info.update({c_opt.name + "loss": float(rq[epoch, 0]), c_opt.name + "grad_norm": float(rq[epoch, 1])})
+            if epoch % a_opt.update_every == 0:
+                info.update({a_opt.name + "loss": float(ra[epoch, 0]), a_opt.name + "grad_norm": float(ra[epoch, 1])})
+            infos.append(info)
+    for epoch in range(0 if fused else c_opt.epochs):
         ctr = solver.i * c_opt.epochs + epoch
         rand_(D, buf, i=solver.i, counter=ctr, seed=solver.sample_seed)                                # :71 rand!(D, buffer, i=S.i)
         info = {}

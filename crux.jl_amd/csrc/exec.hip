@@ -391,6 +391,10 @@ int32_t crux_sac_target(crux_mlp* actor, crux_mlp* q1t, crux_mlp* q2t, crux_mlp*
 int32_t crux_sac_temp_step(crux_mlp* actor, crux_mlp* la, crux_buffer* b, float H_target, uint64_t seed, uint64_t counter, float* info_out);
 int32_t crux_double_q_step(crux_mlp* q1, crux_mlp* q2, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out);
 int32_t crux_sac_actor_step(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* la, crux_buffer* b, uint64_t seed, uint64_t counter, float* info_out);
+int32_t crux_q_step(crux_mlp* q, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out);
+int32_t crux_dpg_target(crux_mlp* actor_t, crux_mlp* q1t, crux_mlp* q2t, crux_buffer* b, float gamma, float sigma, float eps_min, float eps_max, float a_min, float a_max,
+                        uint64_t seed, uint64_t counter, float* d_y);
+int32_t crux_dpg_actor_step(crux_mlp* actor, crux_mlp* q, crux_buffer* b, float* info_out);
 
 // One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl): rand! -> sac_target -> train!(log_alpha, sac_temp_loss) ->
 // [train!(critic, double_Q_loss)] -> [train!(actor, sac_actor_loss) -> polyak_average!(pi_minus, pi, tau)] as ONE fused launch.
@@ -500,6 +504,104 @@ int32_t crux_sac_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* a
     if (fuse) ++in_chain;
   }
   return fuse ? flush() : rc;
+}
+
+// One epoch of value_training with DDPG's / TD3's pieces (off_policy.jl:69-104; rl/ddpg.jl, rl/td3.jl): rand! -> ddpg_target | td3_target -> [train!(critic, td_loss |
+// double_Q_loss)] -> [train!(actor, -mean(Q(s, mu(s)))) -> polyak_average!] recorded as one list. q2 / q2_targ = NULL: single critic (DDPG); q2 with q2_targ = NULL:
+// twin critics trained against a single-target (not used by the reference's solvers).
+static int32_t dpg_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_buffer* source, crux_buffer* batch,
+                         float gamma, float tau, float sigma, float eps_min, float eps_max, float a_min, float a_max, int32_t use_weight, int32_t update_critic, int32_t update_actor,
+                         uint64_t sample_counter, uint64_t noise_seed, uint64_t noise_counter, float* info_critic, float* info_actor) {
+  crux_ctx* c = actor->ctx; const int64_t B = batch->capacity;
+  if (source->prioritized) return crux_fail(c, CRUX_EUNSUP, "dpg_epoch: DDPG / TD3 with a prioritized buffer is not wired up");
+  int32_t rc;
+  if (!crux_exec_recording(c)) { rc = crux_exec_begin(c); if (rc) return rc; }
+  float* d_y = (float*)crux_exec_small(c, 4 * (size_t)B);
+  if (!d_y) { crux_exec_abort(c); return crux_fail(c, CRUX_EUNSUP, "dpg_epoch: batch of %lld rows exceeds the executor's region", (long long)B); }
+  auto bail = [&](int32_t e) { crux_exec_abort(c); return e; };
+  // Phase plan (LA = layers of the actor, LQ = of a critic; X = 3 + LA + LQ, Y = X + 4 + LQ), chains that touch different networks side by side:
+  //   0 ids | 1 gather, fills | 2.. target actor(sp) forward ; vcat(s, a) ; actor(s) forward of the ACTOR step | 2+LA target action (+ smoothing noise) ; mu(s) -> vcat(s, mu(s))
+  //   3+LA.. target Q1 || Q2 forward (and, from 3: Q1 || Q2 forward on (s, a)) | X target | X+1 critic heads | X+2.. critic backward | norm | info, Adam | advance
+  //   Y.. Q(s, mu(s)) forward | its input gradient | slice | actor backward | norm | info, Adam | advance, polyak
+  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, X = 3 + LA + LQ, Y = X + 4 + LQ;
+  const int ag = actor->nd.acts[LA - 1] != CRUX_ACT_IDENTITY ? 1 : 0;
+  if (LA != LQ || actor_targ->nd.L != LA || q1_targ->nd.L != LQ || (q2 && q2->nd.L != LQ) || (q2_targ && q2_targ->nd.L != LQ)) plan_ok = false;
+  // chained epochs: the sampling of epoch e + 1 beside the actor's norm and info + Adam of epoch e; its phase 2 reads the TARGET actor, which polyak (last phase) writes,
+  // so the rest closes up by two only
+  auto tag = [&](size_t from, auto&& rule) { ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
+    for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { if (getenv("CRUX_VERBOSE")) fprintf(stderr, "[cruxhip] dpg_epoch: op kind %d has no phase in the plan\n", r->ops[i].kid); plan_ok = false; p = 0; }
+      ph.push_back(base > 0 ? (p < 2 ? base - 3 + p : base + p - 2) : p); } };
+  const size_t ops0 = exec_mark(c);
+  size_t m = ops0;
+  rc = crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
+  tag(m, [&](int kid, int&) { return kid == OP_UNIFORM_IDS ? 0 : kid == OP_GATHER_RING_ALL ? 1 : -1; });
+  m = exec_mark(c);
+  rc = crux_dpg_target(actor_targ, q1_targ, q2_targ, batch, gamma, sigma, eps_min, eps_max, a_min, a_max, noise_seed, noise_counter, d_y); if (rc) return bail(rc);
+  tag(m, [&](int kid, int& g) { if (kid == OP_GEMM) { const int k = g++; return k < LA ? 2 + k : 3 + LA + (k - LA) % LQ; }
+    return kid == OP_DPG_ACTION ? 2 + LA : kid == OP_DPG_TARGET ? X : -1; });
+  if (update_critic) {
+    m = exec_mark(c);
+    rc = q2 ? crux_double_q_step(q1, q2, batch, d_y, use_weight, info_critic) : crux_q_step(q1, batch, d_y, use_weight, info_critic); if (rc) return bail(rc);
+    tag(m, [&](int kid, int& g) {      // per critic: LQ forward GEMMs, head, then (weight, data) pairs from the last layer down (the first layer has no data gradient)
+      if (kid == OP_FILL) return 1; if (kid == OP_CONCAT_SA) return 2;
+      if (kid == OP_GEMM) { const int k = (g++) % (3 * LQ - 1); return k < LQ ? 3 + k : X + 2 + (k - LQ) / 2; }
+      return kid == OP_Q_HEAD ? X + 1 : kid == OP_SUMSQ2 ? X + 2 + LQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 + LQ : kid == OP_ADAM_ADVANCE ? X + 4 + LQ : -1; });
+  }
+  if (update_actor) {
+    m = exec_mark(c);
+    rc = crux_dpg_actor_step(actor, q1, batch, info_actor); if (rc) return bail(rc);
+    tag(m, [&](int kid, int& g) {      // GEMMs: LA actor forward, LQ critic forward, LQ critic input gradients, then the actor's (weight, data) pairs
+      if (kid == OP_FILL) return 1;      // the info / status rows and the constant dQ = -1 / B
+      if (kid == OP_GEMM) { const int k = g++; if (k < LA) return 2 + k; if (k < LA + LQ) return Y + (k - LA); if (k < LA + 2 * LQ) return Y + LQ + (k - LA - LQ);
+        return Y + 2 * LQ + 1 + ag + (k - LA - 2 * LQ) / 2; }
+      if (kid == OP_ACT_GRAD) return ag ? Y + 2 * LQ + 1 : -1;      // dZ = act'(mu) .* dmu of a bounded (tanh) action head, between the slice and the actor's backward GEMMs
+      return kid == OP_DPG_ACTION ? 2 + LA : kid == OP_SLICE_ROWS ? Y + 2 * LQ : kid == OP_SUMSQ2 ? Y + 2 * LQ + 1 + ag + LA : (kid == OP_MEAN_INFO || kid == OP_ADAM_GATED) ? Y + 2 * LQ + 2 + ag + LA :
+             kid == OP_ADAM_ADVANCE ? Y + 2 * LQ + 3 + ag + LA : -1; });
+    m = exec_mark(c);
+    rc = crux_polyak(actor_targ, actor, tau); if (rc) return bail(rc);
+    rc = crux_polyak(q1_targ, q1, tau); if (rc) return bail(rc);
+    if (q2 && q2_targ) { rc = crux_polyak(q2_targ, q2, tau); if (rc) return bail(rc); }
+    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + 2 * LQ + 3 + ag + LA : -1; });
+  }
+  ExecRec* r = rec_of(c);
+  if (r->chain) {
+    if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + 2 * LQ + 4 + ag + LA - (r->chain_base > 0 ? 2 : 0);
+    return CRUX_OK;
+  }
+  if (plan_ok && ph.size() == r->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
+  return crux_exec_run(c);
+}
+
+// value_training's epoch loop with DDPG's / TD3's pieces in chains of up to 8 epochs per recorded list (see crux_sac_epochs). sigma < 0: no target-policy smoothing
+// (DDPG); otherwise TD3's clamp(a' + clamp(sigma randn, eps_min, eps_max), a_min, a_max) with noise counters noise_counter0 + e. infos_*: host [n x CRUX_INFO_N].
+int32_t crux_dpg_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_buffer* source, crux_buffer* batch,
+                        float gamma, float tau, float sigma, float eps_min, float eps_max, float a_min, float a_max, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
+                        int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0, float* infos_critic, float* infos_actor) {
+  if (!actor || !q1 || !actor_targ || !q1_targ || !source || !batch || n_epochs < 1 || critic_every < 1 || actor_every < 1) return CRUX_EINVAL;
+  crux_ctx* c = actor->ctx;
+  const bool chain = !getenv("CRUX_NO_CHAINED_EPOCHS");
+  auto flush = [&]() -> int32_t {
+    if (!crux_exec_recording(c)) return CRUX_OK;
+    ExecRec* r = rec_of(c); r->chain = false;
+    if (r->chain_ok && r->chain_tags.size() == r->ops.size()) { const int32_t rs = exec_schedule(c, r->chain_tags); if (rs) { crux_exec_abort(c); return rs; } }
+    return crux_exec_run(c);
+  };
+  int32_t rc = CRUX_OK; int in_chain = 0;
+  for (int e = 0; e < n_epochs; ++e) {
+    const int ge = epoch0 + e; const int32_t uc = ge % critic_every == 0, ua = ge % actor_every == 0;
+    float* ic = infos_critic ? infos_critic + (size_t)e * CRUX_INFO_N : nullptr; float* ia = infos_actor ? infos_actor + (size_t)e * CRUX_INFO_N : nullptr;
+    if (chain) {
+      if (in_chain >= 8) { rc = flush(); in_chain = 0; if (rc) return rc; }
+      if (!in_chain) { rc = crux_exec_begin(c); if (rc) return rc; }
+      rec_of(c)->chain = true;
+    }
+    rc = dpg_epoch(actor, q1, q2, actor_targ, q1_targ, q2_targ, source, batch, gamma, tau, sigma, eps_min, eps_max, a_min, a_max, use_weight, uc, ua,
+                   sample_counter0 + (uint64_t)e, noise_seed, noise_counter0 + (uint64_t)e, ic, ia);
+    if (rc) { if (chain && c->rec) { rec_of(c)->chain = false; crux_exec_abort(c); } return rc; }
+    if (chain) ++in_chain;
+  }
+  return chain ? flush() : rc;
 }
 }  // extern "C"
 

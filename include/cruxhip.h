@@ -450,6 +450,16 @@ int32_t crux_sac_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* a
                         int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0,
                         float* infos_temp, float* infos_critic, float* infos_actor);
 
+/* The epoch loop of value_training with DDPG's / TD3's pieces (off_policy.jl:69-104 with rl/ddpg.jl:4-11, rl/td3.jl:4-12) in chains of up to 8 epochs per recorded list:
+ * rand! -> ddpg_target | td3_target -> [train!(critic, td_loss | double_Q_loss)] -> [train!(actor, -mean(Q(s, mu(s)))) -> polyak_average!(pi_minus, pi, tau)].
+ * q2 = q2_targ = NULL: one critic (DDPG). sigma < 0: no target-policy smoothing; otherwise TD3's clamp(a' + clamp(sigma randn, eps_min, eps_max), a_min, a_max) drawn with
+ * noise counter noise_counter0 + e. Epoch e has global index epoch0 + e, trains the critic when that index % critic_every == 0 and the actor (+ target update) when
+ * % actor_every == 0 (TD3's delayed policy update). Same results as the call-by-call sequence crux_uniform_sample, crux_dpg_target, crux_q_step | crux_double_q_step,
+ * crux_dpg_actor_step, crux_polyak.                                                                                                                       */
+int32_t crux_dpg_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_buffer* source, crux_buffer* batch,
+                        float gamma, float tau, float sigma, float eps_min, float eps_max, float a_min, float a_max, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
+                        int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0, float* infos_critic, float* infos_actor);
+
 /* solve(::OffPolicySolver) (src/model_free/off_policy.jl:133-147) for a DQN on a SMALL network (the README example: SimpleGridWorld, 2-8-4), `iters` iterations
  * in ONE launch: per iteration steps!(sampler, buffer, Nsteps = dN, explore = true, i = S.i) (:138), then value_training (:66-111): dN.. `epochs` epochs of
  * rand! (uniform) -> dqn_target -> train!(td_loss), then polyak_average!(target_net, net, tau) (:108). One workgroup runs the loop; the bodies are the ones

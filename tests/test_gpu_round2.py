@@ -168,6 +168,30 @@ def test_fused_sac_epoch_equals_the_separate_calls(gpu_ctx):
         assert abs(ha[-1][k] - hb[-1][k]) < 1e-5 * max(1.0, abs(hb[-1][k])), k
 
 
+@pytest.mark.parametrize("algo", ["ddpg", "td3"])
+def test_fused_dpg_epochs_equal_the_separate_calls(gpu_ctx, algo):
+    """crux_dpg_epochs (rand! -> ddpg_target | td3_target -> critic(s) -> [actor -> polyak], chained, phases shared between the chains) against the call-by-call
+    value_training; TD3 with its delayed policy update (a_opt.update_every = 2)."""
+    def run(fused):
+        S = crux.ContinuousSpace(3); twin = algo == "td3"
+        acts = ["relu", "relu", "identity"]
+        q = lambda sd: crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], acts), seed=sd)      # noqa: E731
+        pi = crux.ActorCritic(crux.ContinuousNetwork(parity.chain([3, 256, 256, 1], ["relu", "relu", "tanh"]), seed=2), crux.DoubleNetwork(q(3), q(4)) if twin else q(3))
+        ctor = crux.TD3 if twin else crux.DDPG
+        a_opt = {"batch_size": 128, "update_every": 2} if twin else {"batch_size": 128}
+        sv = ctor(pi, S, N=200, dN=10, buffer_size=1000, buffer_init=140, max_steps=50, c_opt={"batch_size": 128, "epochs": 10}, a_opt=a_opt, noise_seed=5,
+                  pi_explore=crux.GaussianNoiseExplorationPolicy(0.3, a_min=-1.0, a_max=1.0))
+        sv.fused_epochs = fused
+        crux.solve(sv, crux.PendulumMDP(n_envs=1, seed=8))
+        nets = [pi.A, sv.agent.pi_minus.A] + ([pi.C.N1, pi.C.N2, sv.agent.pi_minus.C.N1, sv.agent.pi_minus.C.N2] if twin else [pi.C, sv.agent.pi_minus.C])
+        return [n.get_params() for n in nets], sv.history
+    a, ha = run(True); b, hb = run(False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y), np.abs(x - y).max()
+    for k in ("critic_loss", "actor_loss"):
+        assert abs(ha[-1][k] - hb[-1][k]) < 1e-5 * max(1.0, abs(hb[-1][k])), k
+
+
 def test_small_dqn_solve_in_one_launch_equals_the_call_by_call_loop(gpu_ctx, monkeypatch):
     """The README example's shape (DQN on SimpleGridWorld, 2-8-4, dN = 4, B = 128, buffer 1000): the shape-generic form of crux_dqn_small_solve runs whole solve
     iterations in one workgroup with the bodies of the separate calls -- replay buffer, staging batch, both networks, Adam state and the per-iteration infos must
