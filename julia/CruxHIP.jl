@@ -289,9 +289,25 @@ function sac_epoch!(𝒮, 𝒟::HipBuffer, γ, epoch; noise_seed=0)
                        ctr, noise_seed, 3ctr, it, ic, ia))
     Dict("SAC alpha" => it[3], "critic_loss" => ic[1], "actor_loss" => ia[1], "entropy" => ia[3])
 end
-# (crux_dqn_epochs / crux_sac_epochs record the whole `for epoch in 1:c_opt.epochs` loop into one list -- no host round trip between the epochs; same arguments plus the
-#  epoch count and, for SAC, the update_every periods. The per-epoch form below is the readable one.)
+"""The epoch loop of value_training with DDPG's / TD3's pieces (off_policy.jl:69-104, rl/ddpg.jl:4-26, rl/td3.jl:4-12) as one chained call: `smooth` is TD3's
+target-policy smoothing (σ, ϵmin, ϵmax, amin, amax) or `nothing` (DDPG); a DoubleNetwork critic selects the twin form."""
+function dpg_epochs!(𝒮, 𝒟::HipBuffer, γ; smooth=nothing, noise_seed=0)
+    A, Q = Crux.actor(𝒮.agent.π), Crux.critic(𝒮.agent.π); A⁻, Q⁻ = Crux.actor(𝒮.agent.π⁻), Crux.critic(𝒮.agent.π⁻)
+    twin = hasproperty(Q, :N1); n = 𝒮.c_opt.epochs; ic, ia = zeros(Float32, INFO_N, n), zeros(Float32, INFO_N, n); ctr0 = 𝒮.i * n
+    σ, ϵmin, ϵmax, amin, amax = isnothing(smooth) ? (-1f0, 0f0, 0f0, 0f0, 0f0) : Float32.(smooth)
+    check(A.ctx, ccall((:crux_dpg_epochs, LIB), Int32,
+                       (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Float32, Float32, Float32, Float32, Float32,
+                        Int32, Int32, Int32, Int32, Int32, UInt64, UInt64, UInt64, Ptr{Float32}, Ptr{Float32}),
+                       A.h, twin ? Q.N1.h : Q.h, twin ? Q.N2.h : C_NULL, A⁻.h, twin ? Q⁻.N1.h : Q⁻.h, twin ? Q⁻.N2.h : C_NULL, 𝒮.buffer.h, 𝒟.h, γ, 0.005f0, σ, ϵmin, ϵmax, amin, amax,
+                       false, 0, n, 𝒮.c_opt.update_every, 𝒮.a_opt.update_every, ctr0, noise_seed, ctr0, ic, ia))
+    [Dict("critic_loss" => ic[1, e], "critic_grad_norm" => ic[2, e], "actor_loss" => ia[1, e], "actor_grad_norm" => ia[2, e]) for e in 1:n]
+end
+# (crux_dqn_epochs / crux_sac_epochs record the whole `for epoch in 1:c_opt.epochs` loop into one list in the same way -- no host round trip between the epochs; same
+#  arguments as the per-epoch calls plus the epoch count and, for SAC, the update_every periods. The per-epoch form below is the readable one.)
 function Crux.value_training(𝒮::Crux.OffPolicySolver, 𝒟::HipBuffer, γ)                                                             # off_policy.jl:66-111
+    if !isnothing(𝒮.a_opt) && !haskey(𝒮.𝒫, :SAC_log_α)                                                                             # DDPG / TD3: actor + critic, no temperature
+        return Crux.aggregate_info(dpg_epochs!(𝒮, 𝒟, γ; smooth=get(𝒮.𝒫, :π_smooth_params, nothing)))
+    end
     fused = haskey(𝒮.𝒫, :SAC_log_α) ? sac_epoch! : dqn_epoch!
     infos = [fused(𝒮, 𝒟, γ, epoch) for epoch in 1:𝒮.c_opt.epochs]
     isnothing(𝒮.a_opt) && Crux.polyak_average!(𝒮.agent.π⁻, 𝒮.agent.π, 0.005f0)                                                     # :108 with the default target_update
@@ -299,7 +315,7 @@ function Crux.value_training(𝒮::Crux.OffPolicySolver, 𝒟::HipBuffer, γ)   
 end
 # The unfused pieces for solvers that compose their own epoch (DDPG / TD3 / custom param_optimizers) follow the same pattern:
 #   sac_target -> :crux_sac_target   sac_temp_loss -> :crux_sac_temp_step   double_Q_loss -> :crux_double_q_step   sac_actor_loss -> :crux_sac_actor_step
-#   ddpg/td3   -> :crux_dpg_target, :crux_q_step, :crux_dpg_actor_step      episodes! -> :crux_rollout over Neps fresh envs + :crux_first_episode_metrics
+#   ddpg/td3   -> :crux_dpg_target, :crux_q_step, :crux_dpg_actor_step (fused: dpg_epochs! above)      episodes! -> :crux_rollout over Neps fresh envs + :crux_first_episode_metrics
 # solve(::OffPolicySolver) for a small DQN (the README example) in one launch: :crux_dqn_small_solve (off_policy.jl:133-147).
 
 # ---------------------------------------------------------------------------------------------------- user-written losses and the regularizer
