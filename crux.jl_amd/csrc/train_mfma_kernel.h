@@ -573,9 +573,9 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
                          : "=&v"(vW[0]), "=&v"(vW[1]), "=&v"(vW[2]), "=&v"(vW[3]) : "v"(src + tid * 16) : "memory");
           };
           // The slots are read PXS ranks at a time -- all loads of a batch in flight together, one round trip to the fine-grained region per batch -- and added in
-          // rank order. Narrow heads have the registers for four at a time (8 replicas = two round trips); wide heads (OUT > 2) sit at the 512-register limit
-          // and take the ranks one at a time (16 + NSI live registers per slot in flight).
-          constexpr int PXS = (OUT <= 2) ? 4 : 1;
+          // rank order. Heads of up to four outputs have the registers for four at a time (8 replicas = two round trips); the six-output heads sit at the
+          // 512-register limit and take two (16 + NSI live registers per slot in flight; with four the step loop spills, with two only prologue / epilogue values do).
+          constexpr int PXS = (OUT <= 4) ? 4 : 2;
           for (int r0 = 0; r0 < a.px_n; r0 += PXS) {
             f32x4 vW[PXS][4]; float vS[PXS][NSI]; float vT[PXS];
 #pragma unroll
