@@ -176,7 +176,8 @@ def test_fused_dpg_epochs_equal_the_separate_calls(gpu_ctx, algo):
         S = crux.ContinuousSpace(3); twin = algo == "td3"
         acts = ["relu", "relu", "identity"]
         q = lambda sd: crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], acts), seed=sd)      # noqa: E731
-        pi = crux.ActorCritic(crux.ContinuousNetwork(parity.chain([3, 256, 256, 1], ["relu", "relu", "tanh"]), seed=2), crux.DoubleNetwork(q(3), q(4)) if twin else q(3))
+        # TD3 with a bounded (tanh) action head, DDPG with a linear one: the two shapes of the actor's backward chain in the phase plan
+        pi = crux.ActorCritic(crux.ContinuousNetwork(parity.chain([3, 256, 256, 1], ["relu", "relu", "tanh" if twin else "identity"]), seed=2), crux.DoubleNetwork(q(3), q(4)) if twin else q(3))
         ctor = crux.TD3 if twin else crux.DDPG
         a_opt = {"batch_size": 128, "update_every": 2} if twin else {"batch_size": 128}
         sv = ctor(pi, S, N=200, dN=10, buffer_size=1000, buffer_init=140, max_steps=50, c_opt={"batch_size": 128, "epochs": 10}, a_opt=a_opt, noise_seed=5,
