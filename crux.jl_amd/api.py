@@ -1725,14 +1725,17 @@ def value_training(solver, D, gamma):
     if solver._dy is None:
         solver._dy, solver._derr = ctx.alloc(4 * B), ctx.alloc(4 * B)
     infos = []
-    fused = solver.target_fn == "dqn" and solver.fused_epochs
+    fused = solver.target_fn in ("dqn", "softq") and solver.fused_epochs
     if fused:
         # the whole epoch loop (:69-93) in one C call: for wide networks all c_opt.epochs epochs are recorded into one list and run without a host round trip
         # between them (cruxhip.h: crux_dqn_epochs); same steps, same order, same draws as the separate calls below
         _set_stream_for(buf, solver.sample_seed)
         beta = float(np.float32(buf.beta(solver.i))) if buf.isprioritized() else 0.0                       # rand!(D, buffer, i=S.i): beta(S.i)
         raws = np.zeros((p.epochs, L.INFO_N), np.float32)
-        ctx.check(ctx.lib.crux_dqn_epochs(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, _vp(raws)))
+        if solver.target_fn == "softq":      # softq_target(alpha) in place of dqn_target (rl/softq.jl:4-13)
+            ctx.check(ctx.lib.crux_softq_epochs(pi.h, pim.h, buf.h, D.h, float(gamma), float(solver.P["alpha"]), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, _vp(raws)))
+        else:
+            ctx.check(ctx.lib.crux_dqn_epochs(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, _vp(raws)))
         infos = [{p.name + "loss": float(r[0]), p.name + "grad_norm": float(r[1]), "Qavg": float(r[2])} for r in raws]
     for epoch in range(0 if fused else p.epochs):
         raw = np.zeros(L.INFO_N, np.float32)

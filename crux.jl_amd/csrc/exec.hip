@@ -84,6 +84,7 @@ __device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigne
         case OP_POLYAK: DISPATCH<PolyakOp>(op, b); break; \
         case OP_COPY_F32: DISPATCH<CopyF32Op>(op, b); break; \
         case OP_ADAM_ADVANCE: DISPATCH<AdamAdvanceOp>(op, b); break; \
+        case OP_SOFTQ_TARGET: DISPATCH<SoftqTargetOp>(op, b); break; \
         default: break; \
       }
 
@@ -278,10 +279,28 @@ int32_t crux_x2_placement_ok_c(crux_ctx* c) { return crux_x2_placement_ok(c); }
 
 // ---- fused value_training epochs ------------------------------------------------------------------------------------------------------------
 int32_t crux_per_prepare(crux_buffer* source);      // per.hip: any full rebuild of the cumsum tree happens before the recording starts
+// softq_target(alpha) (rl/softq.jl:4-13). Lives in this translation unit so that the stand-alone kernel and the executor's phase kernel are compiled under the same
+// floating-point contraction setting (exp / log are inlined library code: the two forms must agree bit for bit).
+int32_t crux_mlp_forward_impl(crux_mlp* net, const float* d_x, int64_t B, float* d_y, const float* params_override);
+__global__ void k_softq_target(const float* __restrict__ q, int nout, const float* __restrict__ r, const uint8_t* __restrict__ done, float gamma, float alpha, int64_t n, float* __restrict__ y) { SoftqTargetOp::run(blockIdx.x, gridDim.x, q, nout, r, done, gamma, alpha, n, y); }
+extern "C" int32_t crux_softq_target(crux_mlp* tn, crux_buffer* batch, float gamma, float alpha, float* d_y) {
+  if (!tn || !batch || !d_y) return CRUX_EINVAL;
+  crux_ctx* c = tn->ctx; const int64_t n = batch->elements; if (n == 0) return CRUX_OK;
+  if (!(alpha > 0.f)) return crux_fail(c, CRUX_EINVAL, "softq_target: alpha must be positive");
+  const int nout = tn->nd.dims[tn->nd.L];
+  float* q = (float*)crux_scratch(c, 4 * (size_t)n * nout + 256); if (!q) return crux_fail(c, CRUX_ENOMEM, "softq_target: scratch");
+  int32_t rc;
+  if (tn->nd.maxdim >= CRUX_DENSE_MIN_WIDTH) { rc = crux_dense_forward(tn, (const float*)batch->col[CRUX_COL_SP], n, c->stream); if (rc) return rc; q = crux_dense_act(tn, tn->nd.L); }
+  else { rc = crux_mlp_forward_impl(tn, (const float*)batch->col[CRUX_COL_SP], n, q, nullptr); if (rc) return rc; }
+  CRUX_RUN(c, SoftqTargetOp, OP_SOFTQ_TARGET, k_softq_target, (unsigned)((n + 255) / 256), 256, c->stream, q, nout, (const float*)batch->col[CRUX_COL_R], (const uint8_t*)batch->col[CRUX_COL_DONE], gamma, alpha, n, d_y);
+  return crux_launch_check(c, "k_softq_target");
+}
+
 extern "C" {
 int32_t crux_per_sample(crux_buffer* target, crux_buffer* source, int64_t B, const double* rands, float beta, uint64_t i);
 int32_t crux_uniform_sample(crux_buffer* target, crux_buffer* source, int64_t B, const int64_t* ids, uint64_t i);
 int32_t crux_dqn_target(crux_mlp* tn, crux_buffer* batch, float gamma, float* d_y);
+int32_t crux_softq_target(crux_mlp* tn, crux_buffer* batch, float gamma, float alpha, float* d_y);
 int32_t crux_td_step(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight, float* info_out);
 int32_t crux_td_step_with_error(crux_mlp* net, crux_buffer* batch, const float* d_y, int32_t use_weight, float* d_err, float* info_out);
 int32_t crux_per_update_device(crux_buffer* b, const int64_t* d_ids, const float* d_v, int64_t n);
@@ -290,7 +309,7 @@ int32_t crux_polyak(crux_mlp* to, const crux_mlp* from, float tau);
 // One epoch of value_training for the DQN family (src/model_free/off_policy.jl:69-93 with dqn_target, rl/dqn.jl:4-6): rand!(batch, source; i) ->
 // y = target(pi_minus, batch) -> [td_error -> update_priorities!(source, batch.indices, .)] -> train!(pi, td_loss). Networks at least
 // CRUX_DENSE_MIN_WIDTH wide run the whole epoch as ONE fused launch; narrower ones take the same steps one call at a time.
-int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
+static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float softq_alpha, int32_t use_weight, float beta,
                        uint64_t sample_counter, float* info_out) {
   if (!net || !target_net || !source || !batch) return CRUX_EINVAL;
   crux_ctx* c = net->ctx; const int64_t B = batch->capacity;
@@ -328,8 +347,8 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
   tag(m, [&](int kid, int&) { return (kid == OP_PER_SEARCH || kid == OP_UNIFORM_IDS) ? 0 : (kid == OP_GATHER_RING_ALL || kid == OP_RING_IDS || kid == OP_COPY_F32) ? 1 : kid == OP_PER_UPDATE ? 2 : -1; });
   rc = piece(2); if (rc) return bail(rc);
   m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
-  rc = crux_dqn_target(target_net, batch, gamma, d_y); if (rc) return bail(rc);
-  tag(m, [&](int kid, int& g) { return kid == OP_GEMM ? (g < Ld ? 2 + g++ : -1) : kid == OP_DQN_TARGET ? 2 + Ld : -1; });
+  rc = softq_alpha > 0.f ? crux_softq_target(target_net, batch, gamma, softq_alpha, d_y) : crux_dqn_target(target_net, batch, gamma, d_y); if (rc) return bail(rc);      // softq_target(alpha) (rl/softq.jl:4-13) | dqn_target (rl/dqn.jl:4-6)
+  tag(m, [&](int kid, int& g) { return kid == OP_GEMM ? (g < Ld ? 2 + g++ : -1) : (kid == OP_DQN_TARGET || kid == OP_SOFTQ_TARGET) ? 2 + Ld : -1; });
   rc = piece(4); if (rc) return bail(rc);
   m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
   auto td_rule = [&](int kid, int& g) {      // g counts the GEMMs: Ld forward, then (weight, data) pairs from the last layer down, the first layer has no data gradient
@@ -355,12 +374,15 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
   return (fuse && crux_exec_recording(c)) ? crux_exec_run(c) : CRUX_OK;
 }
 
+int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
+                       uint64_t sample_counter, float* info_out) { return dqn_epoch_impl(net, target_net, source, batch, gamma, 0.f, use_weight, beta, sample_counter, info_out); }
+
 // value_training's epoch loop (off_policy.jl:69: `for epoch in 1:c_opt.epochs`) for the DQN family as ONE recorded list: the n epochs are recorded back to back, the
 // phases of epoch e follow those of epoch e - 1, and the host uploads, launches and reads back once. Epoch e draws with sample counter sample_counter0 + e; beta is
 // the iteration's (rand!(…, i = S.i)). infos: host [n x CRUX_INFO_N]. Falls back to n single-epoch calls wherever an epoch cannot be chained (narrow networks, a
 // priority tree that needs a full rebuild between epochs).
-int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
-                        uint64_t sample_counter0, int32_t n_epochs, float* infos) {
+static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float softq_alpha, int32_t use_weight, float beta,
+                               uint64_t sample_counter0, int32_t n_epochs, float* infos) {
   if (!net || !target_net || !source || !batch || n_epochs < 1) return CRUX_EINVAL;
   crux_ctx* c = net->ctx;
   const bool fuse = net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && !getenv("CRUX_NO_FUSED_EPOCH") &&
@@ -374,17 +396,27 @@ int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source
   int32_t rc = CRUX_OK; int in_chain = 0;
   for (int e = 0; e < n_epochs; ++e) {
     float* info_e = infos ? infos + (size_t)e * CRUX_INFO_N : nullptr;
-    if (!fuse) { rc = crux_dqn_epoch(net, target_net, source, batch, gamma, use_weight, beta, sample_counter0 + (uint64_t)e, info_e); if (rc) return rc; continue; }
+    if (!fuse) { rc = dqn_epoch_impl(net, target_net, source, batch, gamma, softq_alpha, use_weight, beta, sample_counter0 + (uint64_t)e, info_e); if (rc) return rc; continue; }
     // a priority tree that needs a plain rebuild (the ring is still filling, or a bulk change) cannot be refreshed inside a recording: run what is recorded first
     if (in_chain && ((source->prioritized && source->per_full_dirty) || in_chain >= 8)) { rc = flush(); in_chain = 0; if (rc) return rc; }
     if (!in_chain) { if (source->prioritized) { rc = crux_per_prepare(source); if (rc) return rc; }
       rc = crux_exec_begin(c); if (rc) return rc; }
     rec_of(c)->chain = true;
-    rc = crux_dqn_epoch(net, target_net, source, batch, gamma, use_weight, beta, sample_counter0 + (uint64_t)e, info_e);
+    rc = dqn_epoch_impl(net, target_net, source, batch, gamma, softq_alpha, use_weight, beta, sample_counter0 + (uint64_t)e, info_e);
     if (rc) { if (c->rec) rec_of(c)->chain = false; crux_exec_abort(c); return rc; }
     ++in_chain;
   }
   return fuse ? flush() : rc;
+}
+int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
+                        uint64_t sample_counter0, int32_t n_epochs, float* infos) {
+  return dqn_epochs_impl(net, target_net, source, batch, gamma, 0.f, use_weight, beta, sample_counter0, n_epochs, infos);
+}
+// the same loop with softq_target(alpha) (rl/softq.jl:4-13) in place of dqn_target: SoftQ's value_training
+int32_t crux_softq_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
+                          uint64_t sample_counter0, int32_t n_epochs, float* infos) {
+  if (!(alpha > 0.f)) return CRUX_EINVAL;
+  return dqn_epochs_impl(net, target_net, source, batch, gamma, alpha, use_weight, beta, sample_counter0, n_epochs, infos);
 }
 
 int32_t crux_sac_target(crux_mlp* actor, crux_mlp* q1t, crux_mlp* q2t, crux_mlp* la, crux_buffer* b, float gamma, uint64_t seed, uint64_t counter, float* d_y);

@@ -39,6 +39,14 @@ struct DqnTargetOp { static __device__ __forceinline__ void run(const unsigned b
   const float nd = 1.f - (done[s] ? 1.f : 0.f); const float gn = gamma * nd; const float t = gn * mx; y[s] = r[s] + t;      // plain operators: the pragma above governs them (the __f*_rn intrinsics are inline functions compiled under the unit's own contraction mode)
    // r .+ gamma .* (1 .- done) .* max  (dqn.jl:5)
 } };
+struct SoftqTargetOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ q, int nout, const float* __restrict__ r, const uint8_t* __restrict__ done, float gamma, float alpha, int64_t n, float* __restrict__ y) {
+#pragma clang fp contract(off)      // softq_target(alpha) (rl/softq.jl:1-13): r .+ gamma .* (1 .- done) .* (alpha .* logsumexp(Q ./ alpha)), un-fused
+  const int64_t s = (int64_t)bid_ * blockDim.x + threadIdx.x; if (s >= n) return;
+  float mx = q[s * nout] / alpha; for (int k = 1; k < nout; ++k) { const float v = q[s * nout + k] / alpha; mx = v > mx ? v : mx; }
+  float sum = 0.f; for (int k = 0; k < nout; ++k) sum = sum + expf(q[s * nout + k] / alpha - mx);
+  const float lse = mx + logf(sum); const float sv = alpha * lse;                                 // soft_value (softq.jl:1)
+  const float nd = 1.f - (done[s] ? 1.f : 0.f); const float gn = gamma * nd; const float t = gn * sv; y[s] = r[s] + t;
+} };
 struct TdErrorOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ q, int nout, const uint8_t* __restrict__ a, const float* __restrict__ y, int64_t n, float* __restrict__ err) {
 #pragma clang fp contract(off)      // the reference evaluates r .+ gamma .* (1 .- done) .* q un-fused; train.hip is not built with -ffp-contract=off
   const int64_t s = (int64_t)bid_ * blockDim.x + threadIdx.x; if (s >= n) return;

@@ -649,13 +649,6 @@ static int32_t td_step_impl(crux_mlp* net, crux_buffer* batch, const float* d_y,
 int32_t crux_mlp_forward_impl(crux_mlp* net, const float* d_x, int64_t B, float* d_y, const float* params_override);
 
 __global__ void k_dqn_target(const float* __restrict__ q, int nout, const float* __restrict__ r, const uint8_t* __restrict__ done, float gamma, int64_t n, float* __restrict__ y) { DqnTargetOp::run(blockIdx.x, gridDim.x, q, nout, r, done, gamma, n, y); }
-__global__ void k_softq_target(const float* __restrict__ q, int nout, const float* __restrict__ r, const uint8_t* __restrict__ done, float gamma, float alpha, int64_t n, float* __restrict__ y) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (s >= n) return;
-  float mx = __fdiv_rn(q[s * nout], alpha); for (int k = 1; k < nout; ++k) { const float v = __fdiv_rn(q[s * nout + k], alpha); mx = v > mx ? v : mx; }
-  float sum = 0.f; for (int k = 0; k < nout; ++k) sum = __fadd_rn(sum, expf(__fdiv_rn(q[s * nout + k], alpha) - mx));
-  const float sv = __fmul_rn(alpha, __fadd_rn(mx, logf(sum)));                                   // soft_value = alpha .* logsumexp(value ./ alpha) (softq.jl:1)
-  y[s] = __fadd_rn(r[s], __fmul_rn(__fmul_rn(gamma, __fsub_rn(1.f, done[s] ? 1.f : 0.f)), sv));
-}
 __global__ void k_td_error(const float* __restrict__ q, int nout, const uint8_t* __restrict__ a, const float* __restrict__ y, int64_t n, float* __restrict__ err) { TdErrorOp::run(blockIdx.x, gridDim.x, q, nout, a, y, n, err); }
 
 extern "C" {
@@ -670,19 +663,6 @@ int32_t crux_dqn_target(crux_mlp* tn, crux_buffer* batch, float gamma, float* d_
   else { rc = crux_mlp_forward_impl(tn, (const float*)batch->col[CRUX_COL_SP], n, q, nullptr); if (rc) return rc; }
   CRUX_RUN(c, DqnTargetOp, OP_DQN_TARGET, k_dqn_target, (unsigned)((n + 255) / 256), 256, c->stream, q, nout, (const float*)batch->col[CRUX_COL_R], (const uint8_t*)batch->col[CRUX_COL_DONE], gamma, n, d_y);
   return crux_launch_check(c, "k_dqn_target");
-}
-
-int32_t crux_softq_target(crux_mlp* tn, crux_buffer* batch, float gamma, float alpha, float* d_y) {
-  if (!tn || !batch || !d_y) return CRUX_EINVAL;
-  crux_ctx* c = tn->ctx; const int64_t n = batch->elements; if (n == 0) return CRUX_OK;
-  if (!(alpha > 0.f)) return crux_fail(c, CRUX_EINVAL, "softq_target: alpha must be positive");
-  const int nout = tn->nd.dims[tn->nd.L];
-  float* q = (float*)crux_scratch(c, 4 * (size_t)n * nout + 256); if (!q) return crux_fail(c, CRUX_ENOMEM, "softq_target: scratch");
-  int32_t rc;
-  if (tn->nd.maxdim >= CRUX_DENSE_MIN_WIDTH) { rc = crux_dense_forward(tn, (const float*)batch->col[CRUX_COL_SP], n, c->stream); if (rc) return rc; q = crux_dense_act(tn, tn->nd.L); }
-  else { rc = crux_mlp_forward_impl(tn, (const float*)batch->col[CRUX_COL_SP], n, q, nullptr); if (rc) return rc; }
-  hipLaunchKernelGGL(k_softq_target, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, q, nout, (const float*)batch->col[CRUX_COL_R], (const uint8_t*)batch->col[CRUX_COL_DONE], gamma, alpha, n, d_y);
-  return crux_launch_check(c, "k_softq_target");
 }
 
 int32_t crux_td_error(crux_mlp* net, crux_buffer* batch, const float* d_y, float* d_err) {

@@ -433,6 +433,9 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
  * sample_counter0 + e; infos: host [n_epochs x CRUX_INFO_N]. Same results as n_epochs calls of crux_dqn_epoch.                                         */
 int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
                         uint64_t sample_counter0, int32_t n_epochs, float* infos);
+/* The same epoch loop with softq_target(alpha) (rl/softq.jl:4-13) in place of dqn_target: value_training of the SoftQ solver (rl/softq.jl:31-58).             */
+int32_t crux_softq_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
+                          uint64_t sample_counter0, int32_t n_epochs, float* infos);
 /* One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl:4-52,94-104) as one recorded op list (34 phase launches, see crux_dqn_epoch): rand! -> sac_target ->
  * train!(log_alpha, sac_temp_loss) -> [update_critic: train!(critic, double_Q_loss)] -> [update_actor: train!(actor, sac_actor_loss), then
  * polyak_average!(target, online, tau) for the actor (when actor_targ != NULL) and both critics (:100)]. The three exploration draws use noise counters

@@ -302,7 +302,7 @@ function dpg_epochs!(𝒮, 𝒟::HipBuffer, γ; smooth=nothing, noise_seed=0)
                        false, 0, n, 𝒮.c_opt.update_every, 𝒮.a_opt.update_every, ctr0, noise_seed, ctr0, ic, ia))
     [Dict("critic_loss" => ic[1, e], "critic_grad_norm" => ic[2, e], "actor_loss" => ia[1, e], "actor_grad_norm" => ia[2, e]) for e in 1:n]
 end
-# (crux_dqn_epochs / crux_sac_epochs record the whole `for epoch in 1:c_opt.epochs` loop into one list in the same way -- no host round trip between the epochs; same
+# (crux_dqn_epochs / crux_softq_epochs / crux_sac_epochs record the whole `for epoch in 1:c_opt.epochs` loop into one list in the same way -- no host round trip between the epochs; same
 #  arguments as the per-epoch calls plus the epoch count and, for SAC, the update_every periods. The per-epoch form below is the readable one.)
 function Crux.value_training(𝒮::Crux.OffPolicySolver, 𝒟::HipBuffer, γ)                                                             # off_policy.jl:66-111
     if !isnothing(𝒮.a_opt) && !haskey(𝒮.𝒫, :SAC_log_α)                                                                             # DDPG / TD3: actor + critic, no temperature

@@ -168,6 +168,20 @@ def test_fused_sac_epoch_equals_the_separate_calls(gpu_ctx):
         assert abs(ha[-1][k] - hb[-1][k]) < 1e-5 * max(1.0, abs(hb[-1][k])), k
 
 
+def test_fused_softq_epochs_equal_the_separate_calls(gpu_ctx):
+    """crux_softq_epochs: the DQN epoch chain with softq_target(alpha) (rl/softq.jl:4-13) in place of dqn_target, against the call-by-call value_training."""
+    def run(fused):
+        S = crux.ContinuousSpace(8)
+        q = crux.DiscreteNetwork(parity.chain([8, 256, 256, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=3)
+        sv = crux.SoftQ(q, S, N=560, dN=4, alpha=0.5, buffer_size=2000, buffer_init=400, max_steps=40, c_opt={"batch_size": 128})
+        sv.fused_epochs = fused
+        crux.solve(sv, crux.SynthMDP(8, 4, discrete=True, n_envs=1, seed=5, discount=0.97))
+        return q.get_params(), sv.agent.pi_minus.get_params(), sv.buffer["s"], sv.history
+    pa, ta, sa, ha = run(True); pb, tb, sb, hb = run(False)
+    assert np.array_equal(sa, sb) and np.array_equal(pa, pb) and np.array_equal(ta, tb), (np.abs(pa - pb).max(), np.abs(ta - tb).max())
+    assert abs(ha[-1]["critic_loss"] - hb[-1]["critic_loss"]) < 1e-5 * max(1.0, abs(hb[-1]["critic_loss"]))
+
+
 @pytest.mark.parametrize("algo", ["ddpg", "td3"])
 def test_fused_dpg_epochs_equal_the_separate_calls(gpu_ctx, algo):
     """crux_dpg_epochs (rand! -> ddpg_target | td3_target -> critic(s) -> [actor -> polyak], chained, phases shared between the chains) against the call-by-call
