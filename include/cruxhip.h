@@ -429,14 +429,14 @@ int32_t crux_td_step_with_error(crux_mlp* net, crux_buffer* batch, const float* 
 int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
                        uint64_t sample_counter, float* info_out);
 /* The epoch loop of value_training (off_policy.jl:69: `for epoch in 1:c_opt.epochs`; DQN's c_opt.epochs = dN, rl/dqn.jl) as ONE recorded list: n_epochs epochs back to
- * back, one upload, 13 phase launches per epoch, one read-back -- no host round trip between the epochs of an iteration (~60 us each). Epoch e draws with sample counter
+ * back, one upload, 10 phase launches per chained epoch (13 phases; the next epoch's sampling and first layer share launches with the optimizer tail), one read-back -- no host round trip between the epochs of an iteration (~60 us each). Epoch e draws with sample counter
  * sample_counter0 + e; infos: host [n_epochs x CRUX_INFO_N]. Same results as n_epochs calls of crux_dqn_epoch.                                         */
 int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
                         uint64_t sample_counter0, int32_t n_epochs, float* infos);
 /* The same epoch loop with softq_target(alpha) (rl/softq.jl:4-13) in place of dqn_target: value_training of the SoftQ solver (rl/softq.jl:31-58).             */
 int32_t crux_softq_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
                           uint64_t sample_counter0, int32_t n_epochs, float* infos);
-/* One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl:4-52,94-104) as one recorded op list (34 phase launches, see crux_dqn_epoch): rand! -> sac_target ->
+/* One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl:4-52,94-104) as one recorded op list (30 phases, see crux_dqn_epoch): rand! -> sac_target ->
  * train!(log_alpha, sac_temp_loss) -> [update_critic: train!(critic, double_Q_loss)] -> [update_actor: train!(actor, sac_actor_loss), then
  * polyak_average!(target, online, tau) for the actor (when actor_targ != NULL) and both critics (:100)]. The three exploration draws use noise counters
  * noise_counter0, +1, +2 like the separate calls. info_*: host [CRUX_INFO_N] each (NULL = not wanted).                                            */
