@@ -88,6 +88,16 @@ __device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigne
         default: break; \
       }
 
+// the ops that may run as the sequential tail of a one-block op (the loss heads that consume a target): a small switch of its own, so that the main dispatch stays
+// straight-line (with the full switch inside a loop every phase ran ~1 us longer)
+#define EXEC_SWITCH_TAIL(DISPATCH) \
+      switch (kid) { \
+        case OP_TD_HEAD: DISPATCH<TdHeadOp>(op, b); break; \
+        case OP_Q_HEAD: DISPATCH<QHeadOp>(op, b); break; \
+        default: break; \
+      }
+
+
 // the same dispatch with the record read straight from global memory at a uniform address (scalar loads): the one-launch-per-phase form below
 template <class Op> __device__ __forceinline__ void exec_dispatch_g(const ExecOp* op, unsigned bid) {
   const OpPack<Op> p = *(const OpPack<Op>*)op->args;
@@ -97,10 +107,14 @@ template <class Op> __device__ __forceinline__ void exec_dispatch_g(const ExecOp
 // phase do not depend on each other, the dependency between phases is the kernel boundary -- no in-kernel barrier, no coherence question, all 256 CUs.
 // A fused epoch then costs (number of phases) launches instead of (number of kernels): 13 instead of 25 for a DQN epoch, 30 instead of ~75 for SAC (10 / 27 per epoch inside a chain).
 __global__ __launch_bounds__(256) void k_phase(const ExecOp* __restrict__ ops, int n) {
+  // ops flagged sequential (barrier bit 1) own no blocks: they run in the block of the op before them, after it (see k_phase_k)
   unsigned b = blockIdx.x; int o = 0;
-  while (o + 1 < n && b >= ops[o].nblocks) { b -= ops[o].nblocks; ++o; }
-  const ExecOp* op = ops + o; const int kid = op->kid;
-  EXEC_SWITCH(exec_dispatch_g)
+  for (;;) { const unsigned nb = (ops[o].barrier & 2) ? 0u : ops[o].nblocks; if (o + 1 < n && b >= nb) { b -= nb; ++o; } else break; }
+  { const ExecOp* op = ops + o; const int kid = op->kid;
+    EXEC_SWITCH(exec_dispatch_g) }
+  while (o + 1 < n && (ops[o + 1].barrier & 2)) { __threadfence(); __syncthreads(); ++o; b = 0;
+    const ExecOp* op = ops + o; const int kid = op->kid;
+    EXEC_SWITCH_TAIL(exec_dispatch_g) }
 }
 // The same phase with its op records INSIDE the kernel arguments (<= 8 ops, <= 3.8 KB of packed arguments: every phase of the DQN / SAC epochs). With the records in
 // global memory a workgroup walks block counts -> body id -> arguments -> the op's own data: three dependent scalar loads from memory the host copy has just written
@@ -108,6 +122,7 @@ __global__ __launch_bounds__(256) void k_phase(const ExecOp* __restrict__ ops, i
 // chain is arguments -> data, as in a stand-alone launch.
 // The argument struct comes in three sizes (the host copies it on every launch: with 4 KB per launch the enqueue, not the GPU, paced a SAC epoch).
 #define PHASEK_MAXOPS 8
+#define PHASEK_SEQ 0x10000
 template <int BYTES> struct PhaseK { int32_t n; int32_t pad; int32_t kid[PHASEK_MAXOPS]; uint32_t nblocks[PHASEK_MAXOPS]; uint32_t off[PHASEK_MAXOPS]; alignas(16) unsigned char args[BYTES]; };
 static_assert(sizeof(PhaseK<3840>) <= 4096, "HIP kernel arguments are limited to 4 KB");
 struct KOp { const unsigned char* args; unsigned nblocks; };
@@ -123,8 +138,14 @@ __global__ __launch_bounds__(256) void k_phase_k(PhaseK<BYTES> by_value) {
   unsigned b = blockIdx.x; int o = 0; const int n = pk->n;
 #pragma unroll
   for (int q = 0; q < PHASEK_MAXOPS - 1; ++q) { const unsigned nb = pk->nblocks[q]; const bool adv = o == q && q + 1 < n && b >= nb; b -= adv ? nb : 0u; o += adv ? 1 : 0; }
-  const int kid = pk->kid[o]; const KOp kop{pk->args + pk->off[o], pk->nblocks[o]}; const KOp* op = &kop;
-  EXEC_SWITCH(exec_dispatch_k)
+  // Sequential ops (kid flagged PHASEK_SEQ; block count 0 in the table above, so no block starts on them) run in the block of the op before them, after it: a one-block
+  // op whose only consumer is another one-block op (target -> loss head) shares its launch instead of paying a kernel boundary (~5 us) for a 128-float hand-over.
+  // Same compute unit, write-through L1: the fence + workgroup barrier make the first op's global stores visible to the second.
+  { const int kid = pk->kid[o]; const KOp kop{pk->args + pk->off[o], pk->nblocks[o]}; const KOp* op = &kop;
+    EXEC_SWITCH(exec_dispatch_k) }
+  while (o + 1 < n && (pk->kid[o + 1] & PHASEK_SEQ)) { __threadfence(); __syncthreads(); ++o; b = 0;
+    const int kid = pk->kid[o] & (PHASEK_SEQ - 1); const KOp kop{pk->args + pk->off[o], 1u}; const KOp* op = &kop;
+    EXEC_SWITCH_TAIL(exec_dispatch_k) }
 }
 // host: pack ops [i0, i1] of a recording into a PhaseK<BYTES>; false when they do not fit
 template <int BYTES> static bool phasek_launch(const std::vector<ExecOp>& ops, size_t i0, size_t i1, unsigned blocks, hipStream_t st) {
@@ -132,7 +153,8 @@ template <int BYTES> static bool phasek_launch(const std::vector<ExecOp>& ops, s
   for (size_t i = i0; i <= i1; ++i) { const ExecOp& e = ops[i]; if (!e.nblocks) continue;
     const size_t raw = (size_t)(e.abytes > 0 ? e.abytes : CRUX_EXEC_ARG_BYTES), ab = (raw + 15) & ~(size_t)15;
     if (pk.n >= PHASEK_MAXOPS || used + ab > (size_t)BYTES) return false;
-    pk.kid[pk.n] = e.kid; pk.nblocks[pk.n] = e.nblocks; pk.off[pk.n] = (uint32_t)used; memcpy(pk.args + used, e.args, raw); used += ab; pk.n++; }
+    const bool seq = (e.barrier & 2) != 0;
+    pk.kid[pk.n] = e.kid | (seq ? PHASEK_SEQ : 0); pk.nblocks[pk.n] = seq ? 0u : e.nblocks; pk.off[pk.n] = (uint32_t)used; memcpy(pk.args + used, e.args, raw); used += ab; pk.n++; }
   if (pk.n == 0) return false;
   for (int q = pk.n; q < PHASEK_MAXOPS; ++q) { pk.kid[q] = 0; pk.nblocks[q] = 0; pk.off[q] = 0; }
   hipLaunchKernelGGL(k_phase_k<BYTES>, dim3(blocks), dim3(256), 0, st, pk);
@@ -162,7 +184,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       EXEC_SWITCH(exec_dispatch)
       __syncthreads();                                   // the bodies' static LDS is reused by the next block / op of this workgroup
     }
-    const int bar = __builtin_amdgcn_readfirstlane(op->barrier);
+    const int bar = __builtin_amdgcn_readfirstlane(op->barrier) & 1;
     if ((flags & 8) && wg < 2 && threadIdx.x == 0 && o < 512) tdbg[(wg * 512 + o) * 3 + 1] = __builtin_amdgcn_s_memtime();
     if ((int)threadIdx.x < OPW && o + 1 < nops) ((uint32_t*)&op_s[(o + 1) & 1])[threadIdx.x] = nxt;
     off = bar ? 0u : (off + nb) % G;
@@ -213,15 +235,22 @@ int32_t crux_exec_zero(crux_ctx* c, void* d_ptr, size_t bytes, hipStream_t st) {
 // Phases: ops that do not depend on each other share a barrier. The caller assigns every recorded op a phase number (non-decreasing along every
 // dependency chain); the list is stably sorted by phase and only the last op of a phase keeps its barrier.
 static size_t exec_mark(crux_ctx* c) { return rec_of(c)->ops.size(); }
+// Tags are 4 * phase + sub: sub 0 = an ordinary op of the phase; sub 1 = head of a sequential group, sorted behind the ordinary ops; sub 2 = runs in the block of
+// the op sorted before it, after it (both must be one-block ops: the caller only tags such pairs -- PH_SEQ_HEAD / PH_SEQ_TAIL below).
 static int32_t exec_schedule(crux_ctx* c, const std::vector<int>& phase) {
   ExecRec* r = rec_of(c); const size_t n = r->ops.size();
   if (phase.size() != n) return crux_fail(c, CRUX_EHIP, "executor: %zu phase tags for %zu ops", phase.size(), n);
   std::vector<size_t> idx(n); for (size_t i = 0; i < n; ++i) idx[i] = i;
   std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return phase[a] < phase[b]; });
   std::vector<ExecOp> out(n);
-  for (size_t k = 0; k < n; ++k) { out[k] = r->ops[idx[k]]; out[k].barrier = (k + 1 == n || phase[idx[k + 1]] != phase[idx[k]]) ? 1 : 0; }
+  for (size_t k = 0; k < n; ++k) { out[k] = r->ops[idx[k]]; out[k].barrier = (k + 1 == n || (phase[idx[k + 1]] >> 2) != (phase[idx[k]] >> 2)) ? 1 : 0;
+    if ((phase[idx[k]] & 3) == 2) { if (k == 0 || (phase[idx[k - 1]] >> 2) != (phase[idx[k]] >> 2) || out[k].nblocks != 1 || out[k - 1].nblocks != 1) return crux_fail(c, CRUX_EHIP, "executor: a sequential op without a one-block predecessor in its phase");
+      out[k].barrier |= 2; } }
   r->ops.swap(out); return CRUX_OK;
 }
+#define PH_SEQ_HEAD (1 << 12)
+#define PH_SEQ_TAIL (2 << 12)
+static inline int ph_tag(int p_mapped, int sub) { return 4 * p_mapped + sub; }
 
 int32_t crux_exec_run(crux_ctx* c) {
   ExecRec* r = rec_of(c);
@@ -234,7 +263,7 @@ int32_t crux_exec_run(crux_ctx* c) {
     const size_t ob = nops * sizeof(ExecOp), rb = r->readbacks.size() * (sizeof(float) * CRUX_INFO_N + 16), need_h = ob + rb + 64;
     if (r->d_ops_cap < ob) { if (r->d_ops) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(r->d_ops); } r->d_ops_cap = ob * 2 + 4096; if (hipMalloc(&r->d_ops, r->d_ops_cap) != hipSuccess) { r->d_ops = nullptr; r->d_ops_cap = 0; return crux_fail(c, CRUX_ENOMEM, "executor: op list"); } }
     if (r->h_stage_cap < need_h) { if (r->h_stage) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(r->h_stage); } r->h_stage_cap = need_h * 2 + 4096; if (hipHostMalloc(&r->h_stage, r->h_stage_cap, hipHostMallocDefault) != hipSuccess) { r->h_stage = nullptr; r->h_stage_cap = 0; return crux_fail(c, CRUX_ENOMEM, "executor: staging"); } }
-    r->ops.back().barrier = 0;
+    r->ops.back().barrier &= 2;
     memcpy(r->h_stage, r->ops.data(), ob);
     HIPCHK(c, hipMemcpyAsync(r->d_ops, r->h_stage, ob, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(r->d_ctr, 0, 2048, c->stream));
@@ -243,7 +272,7 @@ int32_t crux_exec_run(crux_ctx* c) {
       // default: one launch per phase over the whole chip (see k_phase). Measured against the persistent one-XCD form (CRUX_EXEC_PERSISTENT=1): the latter
       // saves the launches but runs every op on 32 CUs behind one L2 and pays ~2 us per barrier; DESIGN 4.3 has the numbers.
       size_t i0 = 0;
-      while (i0 < nops) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += r->ops[i1].nblocks; if (r->ops[i1].barrier || i1 + 1 == nops) break; ++i1; }
+      while (i0 < nops) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += (r->ops[i1].barrier & 2) ? 0u : r->ops[i1].nblocks; if ((r->ops[i1].barrier & 1) || i1 + 1 == nops) break; ++i1; }
         if (blocks) {
           // the phase's records travel in the kernel arguments when they fit (see k_phase_k); zero-block ops are dropped there
           if (!phasek_launch<384>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<1024>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<3840>(r->ops, i0, i1, blocks, c->stream))
@@ -339,7 +368,11 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   // tail instead of following it: 13 phases, 10 launches per chained epoch.
   auto tag = [&](size_t from, auto&& rule) { if (!fuse || !crux_exec_recording(c)) return; ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
     for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { plan_ok = false; p = 0; }
-      ph.push_back(base > 0 ? (p < 2 ? base - 3 + p : base + p - 3) : p); } };
+      const int sub = p >> 12; p &= 4095;
+      ph.push_back(ph_tag(base > 0 ? (p < 2 ? base - 3 + p : base + p - 3) : p, sub)); } };
+  // the target (one block at B <= 256) and the loss head (one block) are a sequential pair: the head runs in the target's block, right after it, and every later
+  // phase moves up by one (sq). Not in the persistent one-XCD form, whose workgroups walk the ops of a phase in lockstep.
+  const int sq = (B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;
   rc = piece(1); if (rc) return bail(rc);
   const size_t ops0 = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;      // first op of THIS epoch (a chained recording already holds the earlier epochs)
   size_t m = ops0;
@@ -348,26 +381,26 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   rc = piece(2); if (rc) return bail(rc);
   m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
   rc = softq_alpha > 0.f ? crux_softq_target(target_net, batch, gamma, softq_alpha, d_y) : crux_dqn_target(target_net, batch, gamma, d_y); if (rc) return bail(rc);      // softq_target(alpha) (rl/softq.jl:4-13) | dqn_target (rl/dqn.jl:4-6)
-  tag(m, [&](int kid, int& g) { return kid == OP_GEMM ? (g < Ld ? 2 + g++ : -1) : (kid == OP_DQN_TARGET || kid == OP_SOFTQ_TARGET) ? 2 + Ld : -1; });
+  tag(m, [&](int kid, int& g) { return kid == OP_GEMM ? (g < Ld ? 2 + g++ : -1) : (kid == OP_DQN_TARGET || kid == OP_SOFTQ_TARGET) ? (2 + Ld) | (sq ? PH_SEQ_HEAD : 0) : -1; });
   rc = piece(4); if (rc) return bail(rc);
   m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
   auto td_rule = [&](int kid, int& g) {      // g counts the GEMMs: Ld forward, then (weight, data) pairs from the last layer down, the first layer has no data gradient
     if (kid == OP_FILL) return 1;
-    if (kid == OP_GEMM) { const int k = g++; if (k < Ld) return 2 + k; const int j = (k - Ld) / 2; return j < Ld ? 4 + Ld + j : -1; }
-    if (kid == OP_TD_HEAD) return 3 + Ld;
-    if (kid == OP_SUMSQ2) return 4 + 2 * Ld; if (kid == OP_TD_INFO || kid == OP_ADAM_GATED) return 5 + 2 * Ld; if (kid == OP_ADAM_ADVANCE) return 6 + 2 * Ld;
+    if (kid == OP_GEMM) { const int k = g++; if (k < Ld) return 2 + k; const int j = (k - Ld) / 2; return j < Ld ? 4 + Ld + j - sq : -1; }
+    if (kid == OP_TD_HEAD) return sq ? ((2 + Ld) | PH_SEQ_TAIL) : 3 + Ld;
+    if (kid == OP_SUMSQ2) return 4 + 2 * Ld - sq; if (kid == OP_TD_INFO || kid == OP_ADAM_GATED) return 5 + 2 * Ld - sq; if (kid == OP_ADAM_ADVANCE) return 6 + 2 * Ld - sq;
     return -1; };
   if (per) { rc = crux_td_step_with_error(net, batch, d_y, use_weight, d_err, info_out); if (rc) return bail(rc);
     tag(m, td_rule);
     rc = piece(8); if (rc) return bail(rc);
     m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
     rc = crux_per_update_device(source, batch->d_indices, d_err, B); if (rc) return bail(rc);
-    tag(m, [&](int kid, int&) { return kid == OP_PER_UPDATE ? 4 + Ld : kid == OP_LEAF_REFRESH ? 5 + Ld : kid == OP_TREE_TOUCH ? 6 + Ld : -1; }); }
+    tag(m, [&](int kid, int&) { return kid == OP_PER_UPDATE ? 4 + Ld - sq : kid == OP_LEAF_REFRESH ? 5 + Ld - sq : kid == OP_TREE_TOUCH ? 6 + Ld - sq : -1; }); }
   else { rc = crux_td_step(net, batch, d_y, use_weight, info_out); if (rc) return bail(rc); tag(m, td_rule); }
   if (fuse && crux_exec_recording(c) && rec_of(c)->chain) {     // chained: the caller (crux_dqn_epochs) schedules and runs the whole list
     ExecRec* r = rec_of(c);
     if (!(plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += (r->chain_base > 0 ? 4 : 7) + 2 * Ld;
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += (r->chain_base > 0 ? 4 : 7) + 2 * Ld - sq;
     return CRUX_OK;
   }
   if (fuse && crux_exec_recording(c) && plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
@@ -450,14 +483,18 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   //   X sac_target ; exploration at s | X+1 critic heads ; temperature head | X+2.. critic backward (weight || data gradient, both critics) ; Adam(log_alpha) | .. norm | info, Adam(Q1), Adam(Q2)
   //   X+1.. actor(s) forward of the ACTOR step, exploration (beside the critic's backward) | Y.. Q1 || Q2 forward | actor head | Q1 || Q2 input gradients | reverse of exploration | actor backward ; logSigma row sums | norm | info, Adam | polyak
   // The order inside every chain is the reference's (temperature before critic before actor: each sees the parameters the previous step left).
-  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, X = 3 + LA + LQ, Y = X + 4 + LQ;
+  // sq: sac_target (one block at B <= 256) and the critic heads (one block each) form a sequential group in ONE block of phase X when the critics train; the critic
+  // chain and everything behind it (Y ..) then sit one phase earlier. The temperature chain (X .. X + 3) is independent of it.
+  const int sq = (update_critic && B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;
+  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, X = 3 + LA + LQ, Y = X + 4 + LQ - sq;
   if (LA != LQ || q2->nd.L != LQ || q1_targ->nd.L != LQ || q2_targ->nd.L != LQ) plan_ok = false;       // (the early actor forward needs X + 1 + LA < Y, i.e. LA < LQ + 3)
   // chained epochs: phases 0 (ids) and 1 (gather, fills) of a later epoch run beside the previous epoch's actor norm and info + Adam (neither reads the batch), and its
   // phase 2 (actor(sp) forward, vcat(s, a): online networks only) beside the previous epoch's advance + polyak, which writes beta powers and TARGET networks: the rest
   // closes up by three -- see crux_dqn_epoch
   auto tag = [&](size_t from, auto&& rule) { if (!fuse) return; ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
     for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { plan_ok = false; p = 0; }
-      ph.push_back(base > 0 ? (p < 2 ? base - 3 + p : base + p - 3) : p); } };
+      const int sub = p >> 12; p &= 4095;
+      ph.push_back(ph_tag(base > 0 ? (p < 2 ? base - 3 + p : base + p - 3) : p, sub)); } };
   const size_t ops0 = fuse ? exec_mark(c) : 0;
   size_t m = ops0;
   rc = crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
@@ -465,7 +502,7 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   m = fuse ? exec_mark(c) : 0;
   rc = crux_sac_target(actor, q1_targ, q2_targ, log_alpha, batch, gamma, noise_seed, noise_counter0, d_y); if (rc) return bail(rc);
   tag(m, [&](int kid, int& g) { if (kid == OP_GEMM) { const int k = g++; return k < LA ? 2 + k : 3 + LA + (k - LA) % LQ; }
-    return kid == OP_GAUSS_EXPLORE ? 2 + LA : kid == OP_SAC_TARGET ? X : -1; });
+    return kid == OP_GAUSS_EXPLORE ? 2 + LA : kid == OP_SAC_TARGET ? X | (sq ? PH_SEQ_HEAD : 0) : -1; });
   m = fuse ? exec_mark(c) : 0;
   rc = crux_sac_temp_step(actor, log_alpha, batch, H_target, noise_seed, noise_counter0 + 1, info_temp); if (rc) return bail(rc);
   tag(m, [&](int kid, int& g) { if (kid == OP_FILL) return 1; if (kid == OP_GEMM) { const int k = g++; return k < LA ? 3 + LA + k : -1; }
@@ -475,8 +512,8 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
     rc = crux_double_q_step(q1, q2, batch, d_y, use_weight, info_critic); if (rc) return bail(rc);
     tag(m, [&](int kid, int& g) {      // per critic: LQ forward GEMMs, head, then (weight, data) pairs from the last layer down (the first layer has no data gradient)
       if (kid == OP_FILL) return 1; if (kid == OP_CONCAT_SA) return 2;
-      if (kid == OP_GEMM) { const int k = (g++) % (3 * LQ - 1); return k < LQ ? 3 + k : X + 2 + (k - LQ) / 2; }
-      return kid == OP_Q_HEAD ? X + 1 : kid == OP_SUMSQ2 ? X + 2 + LQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 + LQ : kid == OP_ADAM_ADVANCE ? X + 4 + LQ : -1; });
+      if (kid == OP_GEMM) { const int k = (g++) % (3 * LQ - 1); return k < LQ ? 3 + k : X + 2 - sq + (k - LQ) / 2; }
+      return kid == OP_Q_HEAD ? (sq ? (X | PH_SEQ_TAIL) : X + 1) : kid == OP_SUMSQ2 ? X + 2 - sq + LQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 - sq + LQ : kid == OP_ADAM_ADVANCE ? X + 4 - sq + LQ : -1; });
   }
   if (update_actor) {
     m = fuse ? exec_mark(c) : 0;
@@ -555,14 +592,16 @@ static int32_t dpg_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* 
   //   0 ids | 1 gather, fills | 2.. target actor(sp) forward ; vcat(s, a) ; actor(s) forward of the ACTOR step | 2+LA target action (+ smoothing noise) ; mu(s) -> vcat(s, mu(s))
   //   3+LA.. target Q1 || Q2 forward (and, from 3: Q1 || Q2 forward on (s, a)) | X target | X+1 critic heads | X+2.. critic backward | norm | info, Adam | advance
   //   Y.. Q(s, mu(s)) forward | its input gradient | slice | actor backward | norm | info, Adam | advance, polyak
-  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, X = 3 + LA + LQ, Y = X + 4 + LQ;
+  const int sq = (update_critic && B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;      // target + critic head(s) as a sequential one-block group (see crux_sac_epoch)
+  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, X = 3 + LA + LQ, Y = X + 4 + LQ - sq;
   const int ag = actor->nd.acts[LA - 1] != CRUX_ACT_IDENTITY ? 1 : 0;
   if (LA != LQ || actor_targ->nd.L != LA || q1_targ->nd.L != LQ || (q2 && q2->nd.L != LQ) || (q2_targ && q2_targ->nd.L != LQ)) plan_ok = false;
   // chained epochs: the sampling of epoch e + 1 beside the actor's norm and info + Adam of epoch e; its phase 2 reads the TARGET actor, which polyak (last phase) writes,
   // so the rest closes up by two only
   auto tag = [&](size_t from, auto&& rule) { ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
     for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { if (getenv("CRUX_VERBOSE")) fprintf(stderr, "[cruxhip] dpg_epoch: op kind %d has no phase in the plan\n", r->ops[i].kid); plan_ok = false; p = 0; }
-      ph.push_back(base > 0 ? (p < 2 ? base - 3 + p : base + p - 2) : p); } };
+      const int sub = p >> 12; p &= 4095;
+      ph.push_back(ph_tag(base > 0 ? (p < 2 ? base - 3 + p : base + p - 2) : p, sub)); } };
   const size_t ops0 = exec_mark(c);
   size_t m = ops0;
   rc = crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
@@ -570,14 +609,14 @@ static int32_t dpg_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* 
   m = exec_mark(c);
   rc = crux_dpg_target(actor_targ, q1_targ, q2_targ, batch, gamma, sigma, eps_min, eps_max, a_min, a_max, noise_seed, noise_counter, d_y); if (rc) return bail(rc);
   tag(m, [&](int kid, int& g) { if (kid == OP_GEMM) { const int k = g++; return k < LA ? 2 + k : 3 + LA + (k - LA) % LQ; }
-    return kid == OP_DPG_ACTION ? 2 + LA : kid == OP_DPG_TARGET ? X : -1; });
+    return kid == OP_DPG_ACTION ? 2 + LA : kid == OP_DPG_TARGET ? X | (sq ? PH_SEQ_HEAD : 0) : -1; });
   if (update_critic) {
     m = exec_mark(c);
     rc = q2 ? crux_double_q_step(q1, q2, batch, d_y, use_weight, info_critic) : crux_q_step(q1, batch, d_y, use_weight, info_critic); if (rc) return bail(rc);
     tag(m, [&](int kid, int& g) {      // per critic: LQ forward GEMMs, head, then (weight, data) pairs from the last layer down (the first layer has no data gradient)
       if (kid == OP_FILL) return 1; if (kid == OP_CONCAT_SA) return 2;
-      if (kid == OP_GEMM) { const int k = (g++) % (3 * LQ - 1); return k < LQ ? 3 + k : X + 2 + (k - LQ) / 2; }
-      return kid == OP_Q_HEAD ? X + 1 : kid == OP_SUMSQ2 ? X + 2 + LQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 + LQ : kid == OP_ADAM_ADVANCE ? X + 4 + LQ : -1; });
+      if (kid == OP_GEMM) { const int k = (g++) % (3 * LQ - 1); return k < LQ ? 3 + k : X + 2 - sq + (k - LQ) / 2; }
+      return kid == OP_Q_HEAD ? (sq ? (X | PH_SEQ_TAIL) : X + 1) : kid == OP_SUMSQ2 ? X + 2 - sq + LQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 - sq + LQ : kid == OP_ADAM_ADVANCE ? X + 4 - sq + LQ : -1; });
   }
   if (update_actor) {
     m = exec_mark(c);
