@@ -12,7 +12,7 @@ import csv, sys
 w = sys.argv[1]
 rows = [r for r in csv.DictReader(open("/tmp/pt_%s/t_kernel_trace.csv" % w)) if "k_phase" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-n = {"c3": 10, "c4": 27}[w]
+n = {"c3": 9, "c4": 26}[w]
 mid = rows[len(rows) // 2: len(rows) // 2 + 2 * n]
 print("== %s: %d consecutive phase launches from the middle of the run (kernel, grid threads, duration us, gap before us)" % (w, len(mid)))
 prev = None; tot = 0.0
