@@ -17,7 +17,6 @@ int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, boo
 
 int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream) {
   *handled = false;
-  if (a.lag) return CRUX_OK;     // lagrange_ppo_loss: the penalty controller lives in the generic learner body only
   const NetDesc& nd = a.nd;
   if (getenv("CRUX_FORCE_GENERIC")) return CRUX_OK;      // parity tests run the same cases through the generic learner
   if (nd.L != 3 || nd.dims[1] != MF_HID || nd.dims[2] != MF_HID || nd.acts[2] != CRUX_ACT_IDENTITY || nd.acts[0] != nd.acts[1]) return CRUX_OK;
@@ -28,6 +27,9 @@ int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, h
   else if (a.head == CRUX_HEAD_CATEGORICAL) kind = MFK_CATEGORICAL;
   else if (a.head == CRUX_HEAD_GAUSSIAN) kind = MFK_GAUSSIAN;
   else return CRUX_OK;
+  // 0. lagrange_ppo_loss (ppo.jl:70-131): the penalty controller and the cost term exist in the two-CU form only (its own instantiations, any call shape)
+  if (a.lag) { if (kind == MFK_VALUE || a.loss != CRUX_LOSS_PPO) return CRUX_OK;      // (crux_batch_train_lagrange passes the PPO head with the controller attached)
+    return crux_train_mfma_x2_launch(c, a, kind, handled, stream, /*any_mode=*/true); }
   // 1. the two-CU kernel for full minibatch loops (and whenever a replica group needs its in-kernel exchange)
   if (c->learner_cus != 1 || a.need_px) { const int32_t rc = crux_train_mfma_x2_launch(c, a, kind, handled, stream, /*any_mode=*/false); if (rc || *handled) return rc; }
   if (a.need_px) return CRUX_OK;      // not covered by the two-CU kernel: the caller refuses (no un-synchronised training)

@@ -60,10 +60,13 @@ struct MfLayout {
 
 // PX: the replica-group form (per-minibatch gradient all-reduce over the peer slots). A separate instantiation, so that the single-GPU kernel carries
 // neither the branch nor the live registers of the exchange (with a run-time test the C2 actor step was 3.6 % slower: 8.75 vs 8.44 us).
-template <int IN, int OUT, int KIND, int ACT, int NW, int NWG, bool TIMING = false, bool PX = false>
+// LAG: lagrange_ppo_loss (ppo.jl:70-131) -- the PID penalty controller advanced once per minibatch inside the kernel and the cost-advantage term of the loss.
+// A separate instantiation (two-CU form only), so that the plain kernels carry none of it.
+template <int IN, int OUT, int KIND, int ACT, int NW, int NWG, bool TIMING = false, bool PX = false, bool LAG = false>
 __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, const TrainArgs* __restrict__ multi) {
   static_assert((NW == 4 && NWG == 2) || (NW == 8 && NWG == 1), "forms: two workgroups of four waves, or one of eight");
   static_assert(NWG == 2 || !PX, "the replica-group exchange lives in the two-CU form");
+  static_assert(!LAG || (NWG == 2 && !PX && KIND != MFK_VALUE), "lagrange_ppo_loss: two-CU form, policy heads");
   constexpr int MF8_NW = NW;
   constexpr int WT = 16 / NW;                        // 16x16 tiles of W2 (and of its gradient, Adam state) owned by a wave
   // multi != NULL: a batch of independent learners (multi-seed / population training) in one launch. Two-CU form: replica r = blockIdx / 16 uses the
@@ -153,6 +156,11 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
   const float lo = 1.f - a.eps_clip, hi = 1.f + a.eps_clip;
   const bool a2c = a.loss == CRUX_LOSS_A2C;
   AdamK ak; ak.b1 = (float)a.b1; ak.b2 = (float)a.b2; ak.omb1 = (float)(1.0 - a.b1); ak.omb2 = (float)(1.0 - a.b2); ak.eps = (float)a.eps; ak.eta = (float)a.eta;
+  // lagrange_ppo_loss: every thread carries an identical copy of the PID state (ppo.jl:192-201); the minibatch's :cost / :episode_end / :cost_advantage are staged
+  // in LDS next to the observation tiles (all 128 rows of the minibatch in BOTH workgroups: each advances the controller on its own, bit for bit alike)
+  __shared__ float lag_cost[LAG ? 128 : 1], lag_ee[LAG ? 128 : 1], lag_cadv[LAG ? NW * 16 : 1];
+  crux_lagrange lg{}; float pen = 0.f; float inf_pen = 0.f, inf_cur = 0.f, inf_closs = 0.f, inf_ploss = 0.f;
+  if constexpr (LAG) lg = *a.lag;
 
   int32_t* order_cur = a.order_a; int32_t* order_nxt = a.order_b;
   long long total_batches = 0; int epochs_run = 0, err = 0, why_failed = 0; bool stop = false;
@@ -189,10 +197,12 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
 #pragma unroll
   for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
   int n_row = 0, n_valid = 0;
+  int n_row2 = -1; float p_cost2 = 0.f, p_ee2 = 0.f, p_cadv = 0.f;      // LAG: row tid of the whole minibatch (both halves), its :cost and :episode_end; :cost_advantage of the own sample
   auto fetch_index = [&](const int32_t* ord, int64_t st, int nb) {
     const int sidx = (NWG == 2 ? 64 * p : 0) + 16 * w + c;
     n_valid = sidx < nb ? 1 : 0;
     n_row = n_valid ? (a.ids ? CRUX_GLOBAL_PTR(int32_t, a.ids)[st + sidx] : CRUX_GLOBAL_PTR(int32_t, ord)[st + sidx]) : 0;
+    if constexpr (LAG) n_row2 = tid < nb ? (a.ids ? CRUX_GLOBAL_PTR(int32_t, a.ids)[st + tid] : CRUX_GLOBAL_PTR(int32_t, ord)[st + tid]) : -1;
   };
   auto fetch_data = [&]() {
     const int rowlo = n_row; p_valid = n_valid; const int64_t row = rowlo;
@@ -201,6 +211,8 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
 #pragma unroll
     for (int e = 0; e < NXL; ++e) px[e] = ((lane & 3) * NXL + e < IN && vs) ? xrow[e] : 0.f;
     p_lp = 0.f; p_adv = 0.f; p_ret = 0.f;
+    if constexpr (LAG) { p_cost2 = n_row2 >= 0 ? CRUX_GLOBAL_PTR(float, a.COST)[n_row2] : 0.f; p_ee2 = (n_row2 >= 0 && CRUX_GLOBAL_PTR(uint8_t, a.EE)[n_row2]) ? 1.f : 0.f;
+      p_cadv = (lane < 16 && p_valid) ? CRUX_GLOBAL_PTR(float, a.CADV)[row] : 0.f; }
 #pragma unroll
     for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
     if (lane < 16 && p_valid) {
@@ -221,6 +233,7 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
 #pragma unroll
       for (int k = 0; k < OUT; ++k) ai = p_abyte[k] ? k : ai;
       p_act[0] = (float)ai; }
+    if constexpr (LAG) { if (tid < 128) { lag_cost[tid] = p_cost2; lag_ee[tid] = p_ee2; } if (lane < 16) lag_cadv[w * 16 + lane] = p_cadv; }
     if (lane < 16) { float* q = sc + lane * Lt::SCW; q[0] = (float)p_valid; q[1] = p_lp; q[2] = p_adv; q[3] = p_ret;
       if (KIND == MFK_GAUSSIAN) {       // SquashedGaussianPolicy: the stored action is un-tanh'd once here and the tanh correction of logpdf rides in the spare slot
         static_assert(KIND != MFK_GAUSSIAN || ((4 + NACT) % 2 == 0), "the staging row needs its spare slot");
@@ -251,8 +264,24 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
       const float invB = 1.0f / (float)nb;
       ak.c1 = __builtin_amdgcn_rcpf((float)(1.0 - bp1)); ak.c2 = __builtin_amdgcn_rcpf((float)(1.0 - bp2));
       MX_T(0);
+      const bool staged_now = !staged;
       if (!staged) stage();                        // normally done already, inside the previous step's exchange wait
       staged = false;
+      if constexpr (LAG) {   // the penalty update inside the loss (ppo.jl:80-116), once per evaluation: sums of the minibatch's :cost and :episode_end, then the controller
+        if (staged_now) __syncthreads();            // the first minibatch of an epoch is staged here, not under the previous step's barriers (uniform: staged is)
+        double sc_ = (double)lag_cost[lane] + (double)lag_cost[lane + 64], ne_ = (double)lag_ee[lane] + (double)lag_ee[lane + 64];      // Float32 terms: any summation order gives the same Float64 sum
+#pragma unroll
+        for (int o_ = 32; o_ >= 1; o_ >>= 1) { sc_ += __shfl_xor(sc_, o_, 64); ne_ += __shfl_xor(ne_, o_, 64); }
+        const float Jc = (float)sc_ / (float)ne_;                                      // :84-88
+        const float dl = Jc - lg.target_cost;                                         // :91
+        { const float x = lg.I + lg.Ki * dl; lg.I = x > lg.Ki_max ? lg.Ki_max : (x < 0.f ? 0.f : x); }             // :94 clamp(I + Ki*Delta, 0, Ki_max)
+        lg.smooth_delta = (float)(lg.ema_alpha * (double)lg.smooth_delta + (1.0 - lg.ema_alpha) * (double)dl);      // :98 (Float64 arithmetic, Float32 store)
+        lg.smooth_Jc = (float)(lg.ema_alpha * (double)lg.smooth_Jc + (1.0 - lg.ema_alpha) * (double)Jc);            // :99
+        { const float x = lg.smooth_Jc - lg.Jc_prev; lg.deriv_term = (x != x) ? x : (x > 0.f ? x : 0.f); }           // :102 max(0, .) keeps NaN
+        lg.Jc_prev = lg.smooth_Jc;                                                    // :105
+        { const float x = (lg.Kp * lg.smooth_delta + lg.I) + lg.Kd * lg.deriv_term; pen = x > lg.penalty_max ? lg.penalty_max : (x < 0.f ? 0.f : x); }   // :108
+        lg.penalty = pen; lg.cur_cost = Jc;
+      }
       if (st + a.bs < total_rows) fetch_data();
       { const int64_t st2 = st + 2 * (int64_t)a.bs; const int nb2 = st2 < total_rows ? (int)((total_rows - st2) < a.bs ? (total_rows - st2) : a.bs) : 0;
         fetch_index(order_cur, st2 < total_rows ? st2 : 0, nb2); }
@@ -313,7 +342,7 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
           for (int r = 0; r < 4; ++r) acc = fmaf(wv[r], h2[m][r], acc); }
         z[o] = g4_sum(acc) + sm[Lt::oB3 + o]; }
       float dz[OUT], dex[OUT];
-      float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f;
+      float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f, s_cost = 0.f;
       {
         const float* q = sc + c * Lt::SCW;
         const bool valid = q[0] != 0.f; const float oldlp = q[1], A = q[2], R = q[3];
@@ -337,9 +366,12 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
           const float newlp = __logf(pa); const float r = __expf(newlp - oldlp);
           const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
           const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;   // a2c_loss (a2c.jl:4-15): -mean(logpdf .* A)
+          float gcr = 0.f;                                                          // lagrange: d/dr of max(r Ac, clamp(r) Ac) times r (ppo.jl:119)
+          if constexpr (LAG) { const float Ac = lag_cadv[w * 16 + c]; const float uc = r * Ac, clc = rc * Ac; s_cost = cnt * (uc >= clc ? uc : clc); gcr = (uc >= clc ? Ac : 0.f) * r; }
 #pragma unroll
           for (int k = 0; k < OUT; ++k) { const float dlogpi = ((k == ai) ? 1.f : 0.f) - pk[k];
-            dz[k] = valid ? invB * (-a.lambda_p * coef * dlogpi - a.lambda_e * (pk[k] * (hk[k] - hp))) : 0.f; }
+            const float base = -a.lambda_p * coef * dlogpi - a.lambda_e * (pk[k] * (hk[k] - hp));
+            dz[k] = !valid ? 0.f : (LAG ? invB * ((base + pen * gcr * dlogpi) / (1.f + pen)) : invB * base); }
           s_lossp = cnt * lterm; s_H = cnt * H; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R;
           s_clip = cnt * clipv;
         } else {   // gaussian with constant log-std (policies.jl:333-348)
@@ -353,9 +385,12 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
           if (a.squash > 0.f) newlp -= q[4 + NACT];
           const float r = __expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
           const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;   // a2c_loss (a2c.jl:4-15): -mean(logpdf .* A)
+          float cf = -a.lambda_p * coef;
+          if constexpr (LAG) { const float Ac = lag_cadv[w * 16 + c]; const float uc = r * Ac, clc = rc * Ac; s_cost = cnt * (uc >= clc ? uc : clc);
+            cf = (cf + pen * ((uc >= clc ? Ac : 0.f) * r)) / (1.f + pen); }
 #pragma unroll
-          for (int k = 0; k < OUT; ++k) { dz[k] = valid ? invB * (-a.lambda_p * coef * (dd[k] * s2[k])) : 0.f;
-            dex[k] = valid ? invB * (-a.lambda_p * coef * (((dd[k] * dd[k]) * s2[k]) * inr[k] - 1.f)) : 0.f; }
+          for (int k = 0; k < OUT; ++k) { dz[k] = valid ? invB * (cf * (dd[k] * s2[k])) : 0.f;
+            dex[k] = valid ? invB * (cf * (((dd[k] * dd[k]) * s2[k]) * inr[k] - 1.f)) : 0.f; }
           s_lossp = cnt * lterm; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R; s_clip = cnt * clipv;
         }
       }
@@ -382,13 +417,14 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int r = 0; r < 4; ++r) h2[m][r] = actg<ACT>(h2[m][r], d2[m][r]); }
-      { constexpr int NV = 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0);
+      { constexpr int NVB = 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0), NV = NVB + (LAG ? 1 : 0);
         float mv[((NV + 15) / 16) * 16];
 #pragma unroll
         for (int k = 0; k < ((NV + 15) / 16) * 16; ++k) mv[k] = 0.f;
         mv[0] = s_lossp; mv[1] = s_H; mv[2] = s_kl; mv[3] = s_adv; mv[4] = s_ret; mv[5] = s_clip; mv[6] = s_sq;
 #pragma unroll
         for (int o = 0; o < OUT; ++o) { mv[7 + o] = dz[o]; if (KIND == MFK_GAUSSIAN) mv[7 + OUT + o] = dex[o]; }
+        if constexpr (LAG) mv[NVB] = s_cost;             // the cost term of the loss rides behind the head's gradient sums
 #pragma unroll
         for (int ch = 0; ch < (NV + 15) / 16; ++ch) { float cv[16];
 #pragma unroll
@@ -464,10 +500,14 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
 #pragma unroll
           for (int q = 1; q < MF8_NW; ++q) gsum += sm[po + q * Lt::PART]; }
         gs[k] = gsum; }
+      constexpr int stat_hi = LAG ? NT : NT - 1;          // lanes NT - 8 .. carry the statistics sums (7, and the cost term of lagrange_ppo_loss)
       float stat_loc = 0.f;
       if (tid >= NT - 8 && tid < NT - 1) { const int k = tid - (NT - 8); stat_loc = sm[Lt::oPART + Lt::pST + k];   // stat sums, by 7 lanes of the last wave
 #pragma unroll
         for (int q = 1; q < MF8_NW; ++q) stat_loc += sm[Lt::oPART + q * Lt::PART + Lt::pST + k]; }
+      if constexpr (LAG) { if (tid == NT - 1) { constexpr int pc_ = Lt::pMISC + 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0); stat_loc = sm[Lt::oPART + pc_];
+#pragma unroll
+          for (int q = 1; q < MF8_NW; ++q) stat_loc += sm[Lt::oPART + q * Lt::PART + pc_]; } }
       float stat_tot = stat_loc;
       // ---- exchange the partial gradients with the other workgroup through the shared L2 (see the header) ----
       if constexpr (NWG == 2) { float* mine = a.xbuf + (size_t)(((int)(xstep & 1) * 2 + p)) * XSLOT; const float* peer = a.xbuf + (size_t)(((int)(xstep & 1) * 2 + (1 - p))) * XSLOT;
@@ -475,7 +515,7 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
         for (int mm = 0; mm < 4; ++mm) *(f32x4*)&mine[tid * 16 + 4 * mm] = gW2[mm];
 #pragma unroll
         for (int k = 0; k < NSI; ++k) mine[4096 + tid + NT * k] = gs[k];
-        if (tid >= NT - 8 && tid < NT - 1) mine[4096 + NSI * NT + (tid - (NT - 8))] = stat_loc;
+        if (tid >= NT - 8 && tid < stat_hi) mine[4096 + NSI * NT + (tid - (NT - 8))] = stat_loc;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this lane has reached the L2
         MX_T(10);
         __syncthreads();
@@ -502,7 +542,7 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
         // all loads of the peer's slot are in flight together (one L2 round trip): the dword loads first, then the b128 block whose wait covers them
 #pragma unroll
         for (int k = 0; k < NSI; ++k) pg[k] = __hip_atomic_load(peer + 4096 + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid >= NT - 8 && tid < NT - 1) ps = __hip_atomic_load(peer + 4096 + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid >= NT - 8 && tid < stat_hi) ps = __hip_atomic_load(peer + 4096 + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
                      "global_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(pw[0]), "=&v"(pw[1]), "=&v"(pw[2]), "=&v"(pw[3]) : "v"(peer + tid * 16) : "memory");
@@ -528,7 +568,7 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
               for (int mm = 0; mm < 4; ++mm) *(f32x4*)&dst[tid * 16 + 4 * mm] = gW2[mm];
 #pragma unroll
               for (int k = 0; k < NSI; ++k) dst[4096 + tid + NT * k] = gs[k];
-              if (tid >= NT - 8 && tid < NT - 1) dst[4096 + NSI * NT + (tid - (NT - 8))] = stat_tot; } }
+              if (tid >= NT - 8 && tid < stat_hi) dst[4096 + NSI * NT + (tid - (NT - 8))] = stat_tot; } }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                         // system scope: this wave's slot stores are performed at the peers
           __syncthreads();
           if (tid == 0) {
@@ -567,7 +607,7 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
 #pragma unroll
             for (int k = 0; k < NSI; ++k) vS[k] = __hip_atomic_load(src + 4096 + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             vT = 0.f;
-            if (tid >= NT - 8 && tid < NT - 1) vT = __hip_atomic_load(src + 4096 + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid >= NT - 8 && tid < stat_hi) vT = __hip_atomic_load(src + 4096 + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\tglobal_load_dwordx4 %2, %4, off offset:32 sc0 sc1\n\t"
                          "global_load_dwordx4 %3, %4, off offset:48 sc0 sc1"
                          : "=&v"(vW[0]), "=&v"(vW[1]), "=&v"(vW[2]), "=&v"(vW[3]) : "v"(src + tid * 16) : "memory");
@@ -621,11 +661,11 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
         }
         xstep += 1;
       }
-      if (tid >= NT - 8 && tid < NT - 1) sm[Lt::oRED + 8 + (tid - (NT - 8))] = stat_tot;
+      if (tid >= NT - 8 && tid < stat_hi) sm[Lt::oRED + 8 + (tid - (NT - 8))] = stat_tot;
       float ssq = 0.f; int bad = 0;
 #pragma unroll
       for (int k = 0; k < NSI; ++k) if (so_ok[k]) {
-        if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += -a.lambda_e;
+        if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += LAG ? -a.lambda_e / (1.f + pen) : -a.lambda_e;      // d(-lambda_e H)/dlogSigma, H = const + sum(logSigma); lagrange: the whole loss is divided by 1 + penalty
         ssq += gs[k] * gs[k]; bad |= isnan(gs[k]) ? 1 : 0; }
 #pragma unroll
       for (int mm = 0; mm < WT; ++mm)
@@ -654,7 +694,10 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
             else { entropy = 1.4189385332046727f;
 #pragma unroll
               for (int k = 0; k < OUT; ++k) entropy += sm[Lt::oEX + k]; }
-            inf_ent = entropy; inf_loss = a.lambda_p * p_loss + a.lambda_e * (-entropy); inf_kl = t[2] * invB; inf_adv = t[3] * invB; inf_ret = t[4] * invB; inf_clip = t[5] * invB; }
+            inf_ent = entropy; inf_loss = a.lambda_p * p_loss + a.lambda_e * (-entropy); inf_kl = t[2] * invB; inf_adv = t[3] * invB; inf_ret = t[4] * invB; inf_clip = t[5] * invB;
+            if constexpr (LAG) { const float cost_loss = pen * (t[7] * invB);                                        // ppo.jl:119
+              inf_loss = ((a.lambda_p * p_loss + a.lambda_e * (-entropy)) + cost_loss) / (1.f + pen);                   // :131
+              inf_pen = pen; inf_cur = lg.cur_cost; inf_closs = cost_loss; inf_ploss = a.lambda_p * p_loss; } }
         }
       }
       if (any_bad) { inf_gn = NAN; err = CRUX_ENAN; break; }                   // training.jl:20: no update
@@ -691,7 +734,8 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
     if (tid == 0 && p == 0 && a.epoch_infos) { float* e = a.epoch_infos + (size_t)ep * CRUX_INFO_N;   // aggregate_info(minibatch_infos) == last minibatch (Q3)
       for (int k = 0; k < CRUX_INFO_N; ++k) e[k] = 0.f;
       e[CRUX_INFO_LOSS] = inf_loss; e[CRUX_INFO_GRAD_NORM] = inf_gn;
-      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = inf_ent; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = inf_clip; e[CRUX_INFO_AVG_ADVANTAGE] = inf_adv; e[CRUX_INFO_AVG_RETURN] = inf_ret; } }
+      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = inf_ent; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = inf_clip; e[CRUX_INFO_AVG_ADVANTAGE] = inf_adv; e[CRUX_INFO_AVG_RETURN] = inf_ret; }
+      if constexpr (LAG) { e[CRUX_INFO_PENALTY] = inf_pen; e[CRUX_INFO_CUR_COST] = inf_cur; e[CRUX_INFO_COST_LOSS] = inf_closs; e[CRUX_INFO_P_LOSS] = inf_ploss; } }
     epochs_run += 1;
     if (a.target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > a.target_kl) stop = true;   // :49
     if (a.max_batches > 0 && total_batches >= a.max_batches) stop = true;               // :50
@@ -712,6 +756,7 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 local workgroup missing, 2 workgroups on different XCDs, 3 replica group timeout / abort
     a.bp[0] = bp1; a.bp[1] = bp2;
+    if constexpr (LAG) { if (p == 0) *a.lag = lg; }
     if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = inf_loss; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
   }
 }

@@ -31,11 +31,11 @@ extern "C" int crux_x2_placement_ok(crux_ctx* c) {
   return cached;
 }
 
-template <int IN, int OUT, int KIND, int ACT, bool TIMING, bool PX>
+template <int IN, int OUT, int KIND, int ACT, bool TIMING, bool PX, bool LAG = false>
 static int32_t launch_x2_form(crux_ctx* c, const TrainArgs& a, size_t lds, hipStream_t stream) {
   static bool attr = false;
-  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<IN, OUT, KIND, ACT, 4, 2, TIMING, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-  hipLaunchKernelGGL((k_train_mfma<IN, OUT, KIND, ACT, 4, 2, TIMING, PX>), dim3(16), dim3(256), lds, stream, a, (const TrainArgs*)nullptr);
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<IN, OUT, KIND, ACT, 4, 2, TIMING, PX, LAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_train_mfma<IN, OUT, KIND, ACT, 4, 2, TIMING, PX, LAG>), dim3(16), dim3(256), lds, stream, a, (const TrainArgs*)nullptr);
   return crux_launch_check(c, "k_train_mfma<4,2>");
 }
 template <int IN, int OUT, int KIND, int ACT, bool TIMING = false>
@@ -53,6 +53,7 @@ static int32_t launch_x2(crux_ctx* c, TrainArgs a, hipStream_t stream) {
     a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
     return launch_x2_form<IN, OUT, KIND, ACT, false, true>(c, a, lds, stream);
   }
+  if constexpr (KIND != MFK_VALUE && !TIMING) { if (a.lag) return launch_x2_form<IN, OUT, KIND, ACT, false, false, true>(c, a, lds, stream); }      // lagrange_ppo_loss (ppo.jl:70-131)
   return launch_x2_form<IN, OUT, KIND, ACT, TIMING, false>(c, a, lds, stream);
 }
 
@@ -109,6 +110,16 @@ int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, boo
   if (!any_mode && (a.ids || !a.apply || a.bs <= 64 || a.len < a.bs)) return CRUX_OK;     // single steps and small batches stay on one CU when it has the shape
   if (!x2_placement_ok(c)) return CRUX_OK;
   const int in = a.nd.dims[0], out = a.nd.dims[3], act = a.nd.acts[0];
+  if (a.lag) {     // lagrange_ppo_loss: its own instantiations, for the shapes below; replica groups and every other shape stay on the dense-engine learner
+    if (c->peer_n > 1 && a.need_px) return CRUX_OK;
+#define MFXL_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_x2<I, O, K, A_>(c, a, stream); }
+    MFXL_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)
+    MFXL_CASE(8, 4, MFK_CATEGORICAL, CRUX_ACT_RELU)
+    MFXL_CASE(3, 1, MFK_GAUSSIAN, CRUX_ACT_RELU)
+    MFXL_CASE(17, 6, MFK_GAUSSIAN, CRUX_ACT_TANH)
+#undef MFXL_CASE
+    return CRUX_OK;
+  }
   if (getenv("CRUX_MFMA_TIMING") && ((in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) || (in == 17 && out == 6 && kind == MFK_GAUSSIAN && act == CRUX_ACT_TANH))) {
     static unsigned long long* dbg = nullptr;
     if (!dbg) { if (hipMalloc(&dbg, 128 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
