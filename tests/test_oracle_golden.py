@@ -384,6 +384,77 @@ def test_sac_target_restatement_against_numpy():
     assert np.array_equal(y[done], ob["r"][0][done])
 
 
+def _noise(seed, counter, ad, B):
+    """the standard normal draws of exploration(pi, s) as include/crux_rng.h defines them (purpose 2 = CRUX_RNG_NOISE, Box-Muller on two 53-bit uniforms)"""
+    eps = np.empty((ad, B)); out4 = (C.c_uint32 * 4)()
+    for j in range(B):
+        for d in range(ad):
+            O.lib().orc_philox(seed, counter, j * ad + d, 2, out4)
+            u1 = (((out4[0] << 32) | out4[1]) >> 11) * 1.1102230246251565e-16
+            u2 = (((out4[2] << 32) | out4[3]) >> 11) * 1.1102230246251565e-16
+            eps[d, j] = np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+    return eps
+
+
+def test_sac_losses_vs_float64_autograd():
+    """The SAC twins of the oracle against torch float64 autograd of the reference formulas written out independently: sac_actor_loss (sac.jl:34-40: the
+    reparameterised action and its logpdf both carry gradient), double_Q_loss (utils.jl:89-96) and sac_temp_loss (sac.jl:45-52). Pins R26 beyond the
+    finite-difference self-check above."""
+    rng = np.random.default_rng(8)
+    oa, o1, o2, ola, ob, B = _sac_oracle_setup(rng)
+    od, ad = 3, 2; adims, qdims, aacts, qacts = [od, 16, ad], [od + ad, 16, 1], ["tanh", "identity"], ["tanh", "identity"]
+    info, ol = np.zeros(L.INFO_N, np.float32), O.lib()
+    S = torch.tensor(ob["s"], dtype=torch.float64)
+    # ---- actor
+    O.chk(ol.orc_sac_actor_step(oa.h, o1.h, o2.h, ola.h, ob.h, 5, 9, O.vpz(info))); ga, la = oa.grads.copy(), float(info[L.INFO["loss"]])
+    pa, p1, p2 = _torch_net(oa), _torch_net(o1), _torch_net(o2); alpha = float(np.exp(np.float64(ola.params[0])))
+    mu, off = _fwd(pa, adims, aacts, S); ls = pa[off:off + ad]; eps = torch.tensor(_noise(5, 9, ad, B), dtype=torch.float64)
+    a = mu + torch.exp(ls)[:, None] * eps                                                                   # exploration(pi, s): policies.jl:338-344
+    lp = (-((a - mu) ** 2) / (2 * torch.exp(ls)[:, None] ** 2) - 0.9189385332046727 - ls[:, None]).sum(0)     # gaussian_logpdf (:333-336)
+    sa = torch.cat([S, a], 0)
+    q = torch.minimum(_fwd(p1, qdims, qacts, sa)[0][0], _fwd(p2, qdims, qacts, sa)[0][0])
+    loss = (alpha * lp - q).mean(); loss.backward()                                                          # sac.jl:39
+    assert abs(la - loss.item()) < 1e-5 * max(1.0, abs(loss.item()))
+    assert np.abs(ga - pa.grad.numpy()).max() < 3e-6 * max(1.0, np.abs(pa.grad.numpy()).max())
+    assert abs(float(info[L.INFO["entropy"]]) - (-lp.mean().item())) < 1e-5                                    # sac.jl:36-38 logs -mean(logpdf)
+    # ---- critics
+    y = rng.normal(0, 1, B).astype(np.float32)
+    O.chk(ol.orc_double_q_step(o1.h, o2.h, ob.h, O.vpz(y), 0, O.vpz(info))); g1, g2, lc = o1.grads.copy(), o2.grads.copy(), float(info[L.INFO["loss"]])
+    p1, p2 = _torch_net(o1), _torch_net(o2); sa0 = torch.tensor(np.vstack([ob["s"], ob["a"]]), dtype=torch.float64); yt = torch.tensor(y, dtype=torch.float64)
+    l = 0.5 * (((_fwd(p1, qdims, qacts, sa0)[0][0] - yt) ** 2).mean() + ((_fwd(p2, qdims, qacts, sa0)[0][0] - yt) ** 2).mean()); l.backward()   # utils.jl:89-96
+    assert abs(lc - l.item()) < 1e-5 * max(1.0, abs(l.item()))
+    assert np.abs(g1 - p1.grad.numpy()).max() < 3e-6 * max(1.0, np.abs(p1.grad.numpy()).max()) and np.abs(g2 - p2.grad.numpy()).max() < 3e-6 * max(1.0, np.abs(p2.grad.numpy()).max())
+    # ---- temperature (sac.jl:45-52): -mean(alpha * (logpdf + H_target)), alpha = exp(log_alpha), logpdf held constant
+    O.chk(ol.orc_sac_temp_step(oa.h, ola.h, ob.h, -2.0, 5, 10, O.vpz(info))); gl, lt = float(ola.grads[0]), float(info[L.INFO["loss"]])
+    pa = _torch_net(oa); mu, off = _fwd(pa, adims, aacts, S); ls = pa[off:off + ad].detach(); eps = torch.tensor(_noise(5, 10, ad, B), dtype=torch.float64)
+    a = mu.detach() + torch.exp(ls)[:, None] * eps
+    lp = (-((a - mu.detach()) ** 2) / (2 * torch.exp(ls)[:, None] ** 2) - 0.9189385332046727 - ls[:, None]).sum(0)
+    log_alpha = torch.tensor(np.float64(ola.params[0]), requires_grad=True)
+    lt_ref = -(torch.exp(log_alpha) * (lp + (-2.0))).mean(); lt_ref.backward()
+    assert abs(lt - lt_ref.item()) < 1e-5 * max(1.0, abs(lt_ref.item())) and abs(gl - log_alpha.grad.item()) < 3e-6 * max(1.0, abs(log_alpha.grad.item()))
+
+
+def test_dpg_losses_vs_float64_autograd():
+    """ddpg_actor_loss (-mean(Q(s, mu(s))), ddpg.jl:26) and td_loss over vcat(s, a) (utils.jl:76-87) of the oracle against torch float64 autograd."""
+    rng = np.random.default_rng(18); od, ad, B = 3, 2, 24
+    adims, qdims, aacts, qacts = [od, 16, ad], [od + ad, 16, 1], ["relu", "tanh"], ["tanh", "identity"]
+    oa = O.OMlp(adims, aacts).init_glorot(4, 0); q = O.OMlp(qdims, qacts).init_glorot(4, 1)
+    oa.params[:] += 0.1 * rng.standard_normal(oa.n).astype(np.float32)
+    ob = O.OBuffer(od, ad, L.ACTION_CONTINUOUS, B)
+    ob.push({"s": rng.normal(0, 1, (od, B)).astype(np.float32), "a": rng.uniform(-1, 1, (ad, B)).astype(np.float32), "sp": rng.normal(0, 1, (od, B)).astype(np.float32),
+             "r": rng.normal(0, 1, (1, B)).astype(np.float32), "done": rng.random((1, B)) < 0.2, "episode_end": np.zeros((1, B), bool)})
+    oa.adam_init(0.0); q.adam_init(0.0)
+    info, ol = np.zeros(L.INFO_N, np.float32), O.lib()
+    O.chk(ol.orc_dpg_actor_step(oa.h, q.h, ob.h, O.vpz(info))); ga, la = oa.grads.copy(), float(info[0])
+    pa, pq = _torch_net(oa), _torch_net(q); S = torch.tensor(ob["s"], dtype=torch.float64)
+    l = -(_fwd(pq, qdims, qacts, torch.cat([S, _fwd(pa, adims, aacts, S)[0]], 0))[0][0]).mean(); l.backward()
+    assert abs(la - l.item()) < 1e-5 * max(1.0, abs(l.item())) and np.abs(ga - pa.grad.numpy()).max() < 3e-6 * max(1.0, np.abs(pa.grad.numpy()).max())
+    y = rng.normal(0, 1, B).astype(np.float32)
+    O.chk(ol.orc_q_step(q.h, ob.h, O.vpz(y), 0, O.vpz(info))); gq, lq = q.grads.copy(), float(info[0])
+    pq = _torch_net(q); l = ((_fwd(pq, qdims, qacts, torch.tensor(np.vstack([ob["s"], ob["a"]]), dtype=torch.float64))[0][0] - torch.tensor(y, dtype=torch.float64)) ** 2).mean(); l.backward()
+    assert abs(lq - l.item()) < 1e-5 * max(1.0, abs(l.item())) and np.abs(gq - pq.grad.numpy()).max() < 3e-6 * max(1.0, np.abs(pq.grad.numpy()).max())
+
+
 @pytest.mark.parametrize("loss", ["a2c", "reinforce"])
 @pytest.mark.parametrize("head", ["categorical", "gaussian"])
 def test_a2c_reinforce_gradients_vs_float64_autograd(loss, head):
