@@ -94,3 +94,39 @@ def test_lagrange_gradient_matches_finite_differences_of_the_loss():
             lp, _ = _loss_at(net, ob, cfg, lag0, ids, tp); lm, _ = _loss_at(net, ob, cfg, lag0, ids, tm)
             fd = (lp - lm) / (2 * h); worst = max(worst, abs(fd - g[i]) / max(1e-3, abs(fd), abs(g[i])))
         assert worst < 0.03, worst                          # Float32 loss values: ~1e-7 / 1e-3 of noise per difference; kinks of min / max / clamp are measure-zero
+
+
+def test_lagrange_loss_and_gradient_vs_float64_autograd():
+    """lagrange_ppo_loss (ppo.jl:70-131) written out independently in torch float64 and differentiated by autograd, for both heads: the surrogate with the
+    cost-advantage term, max instead of min for the cost (a cost is to be decreased), the penalty held constant (ignore_derivatives, :80), the whole sum
+    divided by 1 + penalty (:131). The penalty itself comes from julia_pid above."""
+    import pytest
+    torch = pytest.importorskip("torch")
+    for disc in (True, False):
+        rng = np.random.default_rng(15 + disc); od, ad, N = 3, 2, 48
+        ob = _buffer(rng, od, ad, N, disc)
+        dims, acts = [od, 6, ad], ["tanh", "identity"]
+        net = O.OMlp(dims, acts, 0 if disc else ad).init_glorot(7, 0, -0.3).adam_init(0.0)
+        cfg = L.TrainCfg(); cfg.loss, cfg.head, cfg.batch_size, cfg.epochs = L.LOSS["lagrange_ppo"], L.HEAD["categorical" if disc else "gaussian"], N, 1
+        cfg.eps_clip, cfg.lambda_p, cfg.lambda_e, cfg.target_kl = 0.2, 1.0, 0.1, -1.0
+        lag0 = _lag(target_cost=0.1, Kp=2.0)
+        loss, g = _loss_at(net, ob, cfg, lag0, np.arange(N, dtype=np.int64), net.params.copy())
+        hp = {"target_cost": f32(0.1), "Ki": f32(1e-3), "Ki_max": f32(10.0), "Kp": f32(2.0), "Kd": f32(0.0), "ema": 0.95, "penalty_max": f32(np.inf)}
+        _, pen, _, _ = julia_pid((f32(0), f32(0), f32(0), f32(0)), hp, ob["cost"][0], ob["episode_end"][0])
+        pen = float(pen)
+        p = torch.tensor(net.params.copy(), dtype=torch.float64, requires_grad=True)
+        off = 0; h = torch.tensor(ob["s"], dtype=torch.float64)
+        for l in range(len(acts)):
+            i, o = dims[l], dims[l + 1]; W = p[off:off + i * o].reshape(i, o).T; off += i * o; b = p[off:off + o]; off += o
+            h = W @ h + b[:, None]; h = torch.tanh(h) if acts[l] == "tanh" else h
+        z = h; a = torch.tensor(ob["a"].astype(np.float64)); A = torch.tensor(ob["advantage"][0].astype(np.float64)); Ac = torch.tensor(ob["cost_advantage"][0].astype(np.float64))
+        old = torch.tensor(ob["logprob"][0].astype(np.float64))
+        if disc:
+            pr = torch.softmax(z, 0); newlp = torch.log((pr * a).sum(0)); ent = (-(pr * torch.log(pr + float(np.finfo(np.float32).eps))).sum(0)).mean()
+        else:
+            ls = p[off:off + ad]; newlp = (-((a - z) ** 2) / (2 * torch.exp(ls)[:, None] ** 2) - 0.9189385332046727 - ls[:, None]).sum(0); ent = 1.4189385332046727 + ls.sum()
+        r = torch.exp(newlp - old); rc = torch.clamp(r, 0.8, 1.2)
+        p_loss = -torch.minimum(r * A, rc * A).mean(); c_loss = torch.maximum(r * Ac, rc * Ac).mean()
+        total = (1.0 * p_loss + 0.1 * (-ent) + pen * c_loss) / (1.0 + pen); total.backward()
+        assert abs(loss - total.item()) < 2e-5 * max(1.0, abs(total.item())), (disc, loss, total.item())
+        assert np.abs(g - p.grad.numpy()).max() < 5e-6 * max(1.0, np.abs(p.grad.numpy()).max()), (disc, np.abs(g - p.grad.numpy()).max())
