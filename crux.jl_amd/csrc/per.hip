@@ -237,7 +237,21 @@ struct PerSearchOp { static __device__ __forceinline__ void run(const unsigned b
   const int64_t j = (int64_t)bid_ * 4 + (threadIdx.x >> 6);
   if (j >= B) return;
   const int Ni = (int)N;
-  auto cs = [&](int i) -> float { return (i == 0 || Ni < 2) ? run[i] : leaf_prefix(pr, total, leaf_locate(N, i, nlev), nlev) + run[i]; };    // cumsum[i] exactly as accumulate_pairwise! forms it
+  // cumsum[i] exactly as accumulate_pairwise! forms it: the descent to i's leaf and the sibling totals of its root path in ONE pass (leaf_locate + leaf_prefix fused:
+  // the left sibling of a right turn is the slot before the child just entered), all loads independent
+  auto cs = [&](int i) -> float {
+    const float ri = run[i];
+    if (i == 0 || Ni < 2) return ri;
+    int i1 = 1, n = Ni - 1, id = 1; float tv[CRUX_PER_PMAX];
+#pragma unroll
+    for (int it = 0; it < CRUX_PER_PMAX; ++it) { tv[it] = 0.f;
+      if (it < nlev - 1) { const bool sp = n >= 128; const int n2 = n >> 1; const bool rt = sp && i >= i1 + n2;
+        i1 += rt ? n2 : 0; n = sp ? (rt ? n - n2 : n2) : n; id = sp ? 2 * id + (rt ? 1 : 0) : id;
+        tv[it] = total[rt ? id - 1 : 0]; } }
+    float sacc = pr[0];
+#pragma unroll
+    for (int it = 0; it < CRUX_PER_PMAX; ++it) if (it < nlev - 1) sacc = sacc + tv[it];
+    return sacc + ri; };
   double u;
   if (rands) u = rands[j];
   else { const crux_u32x4 x = crux_philox(seed, ictr * (uint64_t)B + (uint64_t)j, stream, CRUX_RNG_SAMPLE); u = crux_u32x2_to_f64(x.v[0], x.v[1]); }
