@@ -204,10 +204,13 @@ struct AdamGatedOp { static __device__ __forceinline__ void run(const unsigned b
                                                     double eta, double b1, double b2, double eps, int64_t n, const double* __restrict__ ssq, int32_t* __restrict__ status, int advance, int from_partials) {
   // from_partials (fused executor): the 64 partials of k_sumsq2 are added here, in the order ssq_finalize adds them, so that the info op -- which writes ssq[0] --
   // can share this op's phase instead of preceding it by a barrier
-  double sq;
-  if (!from_partials) sq = ssq[0]; else { sq = 0; for (int k = 0; k < SUMSQ_BLOCKS; ++k) sq += ssq[1 + k]; }
+  // The gate only asks whether the norm is NaN. The partials are sums of squares (no cancellation), so their sum is NaN exactly when one of them is: each lane
+  // looks at its own partials and the wave votes -- instead of every thread adding all 64 in ssq_finalize's order (64 loads + 64 dependent Float64 adds per thread)
+  bool bad;
+  if (!from_partials) bad = isnan(ssq[0]);
+  else { bool b_ = false; for (int k = (int)(threadIdx.x & 63); k < SUMSQ_BLOCKS; k += 64) b_ = b_ || isnan(ssq[1 + k]); bad = __ballot(b_) != 0ull; }
   if (status[0] == CRUX_ENAN) return;      // an earlier step of this launch sequence already stopped with "NaN detected!": no further updates (training.jl:20)
-  if (isnan(sq)) { if (bid_ == 0 && threadIdx.x == 0) status[0] = CRUX_ENAN; return; }
+  if (bad) { if (bid_ == 0 && threadIdx.x == 0) status[0] = CRUX_ENAN; return; }
   const double c1 = 1.0 - bp[0], c2 = 1.0 - bp[1];
   for (int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x; i < n; i += (int64_t)nb_ * blockDim.x) {     // element-wise: any grid gives the same result
     const double gd = (double)g[i];
