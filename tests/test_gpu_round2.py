@@ -150,14 +150,16 @@ def test_fused_dqn_epoch_equals_the_separate_calls(gpu_ctx, prioritized):
     assert abs(ha[-1]["critic_loss"] - hb[-1]["critic_loss"]) < 1e-5 * max(1.0, abs(hb[-1]["critic_loss"]))
 
 
-def test_fused_sac_epoch_equals_the_separate_calls(gpu_ctx):
-    """crux_sac_epoch (rand! -> sac_target -> temperature -> twin critics -> actor -> polyak as one fused launch) against the separate calls."""
+@pytest.mark.parametrize("B", [256, 512])
+def test_fused_sac_epoch_equals_the_separate_calls(gpu_ctx, B):
+    """crux_sac_epoch (rand! -> sac_target -> temperature -> twin critics -> actor -> polyak as one fused launch) against the separate calls. B = 256: the target and
+    the critic heads are one-block ops and share a block (sequential group); B = 512: the target spans two blocks and keeps its own phase."""
     def run(fused):
         S = crux.ContinuousSpace(3)
         acts = ["relu", "relu", "identity"]
         pi = crux.ActorCritic(crux.GaussianPolicy(parity.chain([3, 256, 256, 1], acts), np.zeros(1, np.float32), seed=2),
                               crux.DoubleNetwork(crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], acts), seed=3), crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], acts), seed=4)))
-        sv = crux.SAC(pi, S, N=420, dN=6, buffer_size=1000, buffer_init=300, max_steps=50, c_opt={"batch_size": 256}, a_opt={"batch_size": 256}, SAC_alpha_opt={"batch_size": 256})
+        sv = crux.SAC(pi, S, N=420 + 2 * B, dN=6, buffer_size=2000, buffer_init=300 + 2 * B, max_steps=50, c_opt={"batch_size": B}, a_opt={"batch_size": B}, SAC_alpha_opt={"batch_size": B})
         sv.fused_epochs = fused
         crux.solve(sv, crux.PendulumMDP(n_envs=1, seed=8))
         return [n.get_params() for n in (pi.A, pi.C.N1, pi.C.N2, sv.agent.pi_minus.C.N1, sv.P["SAC_log_alpha"])], sv.history
