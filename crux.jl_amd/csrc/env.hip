@@ -459,6 +459,10 @@ __global__ __launch_bounds__(64) void k_dqn_tiny_solve(SmallSolveArgs q) {
     mR[row] = gR[row]; int ai = 0; for (int k = 0; k < OUT; ++k) ai = gA[row * OUT + k] ? k : ai; mA[row] = ai; mD[row] = gD[row] ? 1 : 0;
   };
   for (int64_t row = lane; row < q.elements; row += 64) mirror_row(row);
+  __shared__ float th_s[64]; __shared__ double st_s[ENV_MAXSD]; __shared__ int64_t cnt_s[3]; __shared__ float sv_s[ENV_MAXOBS]; __shared__ double acc_s[2];
+  if (lane == 0) { for (int i = 0; i < q.ro.sd; ++i) st_s[i] = q.ro.state[i];
+    cnt_s[0] = q.ro.ep_len[0]; cnt_s[1] = q.ro.n_resets[0]; cnt_s[2] = q.ro.steps_taken[0]; acc_s[0] = q.ro.acc[0]; acc_s[1] = q.ro.acc[1]; }
+  if (lane < q.ro.od) sv_s[lane] = q.ro.svec[lane];
   float p = lane < NP ? q.tr.p[lane] : 0.f, pt = lane < NP ? q.pt[lane] : 0.f, am = lane < NP ? q.tr.m[lane] : 0.f, av = lane < NP ? q.tr.v[lane] : 0.f;
   double bp1 = q.tr.bp[0], bp2 = q.tr.bp[1];
   int64_t elements = q.elements, next = q.next; int err = 0;
@@ -477,16 +481,23 @@ __global__ __launch_bounds__(64) void k_dqn_tiny_solve(SmallSolveArgs q) {
       o[j] = acc + W(reg, oB2 + j); }
   };
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();      // phase shares (CRUX_SMALL_SOLVE_TIMING): rollout | sample + forward / backward | transpose-reduce | statistics + Adam
+#define TS_T(k_) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k_] += tn_ - tl; tl = tn_; } while (0)
   for (int it = 0; it < q.iters && !err; ++it) {
     const uint64_t si = q.i0 + (uint64_t)it * (uint64_t)q.dN;
-    // ---- steps!(sampler, buffer, Nsteps = dN, explore = true, i = S.i): the generic rollout body with theta read from global memory
-    if (lane < NP) q.tr.p[lane] = p;
-    __threadfence();
-    { RolloutArgs ro = q.ro; ro.base = next; ro.cfg.i0 = si; rollout_generic_wave(ro, 0, lane, (float (*)[1024])sm_ro, sm_ro + 2 * 1024); }
+    // ---- steps!(sampler, buffer, Nsteps = dN, explore = true, i = S.i): the generic rollout body, with theta and the sampler's state (env state, episode
+    // counters, current observation) pointed at LDS copies -- read from global memory they cost a dependent L2 round trip per layer and per call (the rollout was
+    // 2/3 of the solve); the buffer columns it writes stay in global memory, where the call-by-call loop leaves them
+    if (lane < NP) th_s[lane] = p;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    { RolloutArgs ro = q.ro; ro.base = next; ro.cfg.i0 = si;
+      ro.p = th_s; ro.state = st_s; ro.ep_len = &cnt_s[0]; ro.n_resets = &cnt_s[1]; ro.steps_taken = &cnt_s[2]; ro.svec = sv_s; ro.acc = acc_s;
+      rollout_generic_wave(ro, 0, lane, (float (*)[1024])sm_ro, sm_ro + 2 * 1024); }
     __threadfence();
     if (lane < q.dN) mirror_row((next + lane) % C);
     next = (next + q.dN) % C; elements = elements + q.dN < C ? elements + q.dN : C;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    TS_T(0);
     for (int ep = 0; ep < q.epochs; ++ep) {
       const uint64_t ictr = si * (uint64_t)q.epochs + (uint64_t)ep;
       float g[NP];
@@ -535,6 +546,7 @@ __global__ __launch_bounds__(64) void k_dqn_tiny_solve(SmallSolveArgs q) {
           for (int oo = 0; oo < H; ++oo) g[oB1 + oo] += dh[oo];
         }
       }
+      TS_T(1);
       // transpose: lane i adds parameter i's 64 partials in lane order
 #pragma unroll
       for (int k = 0; k < NP; ++k) red[k * 64 + lane] = g[k];
@@ -544,6 +556,7 @@ __global__ __launch_bounds__(64) void k_dqn_tiny_solve(SmallSolveArgs q) {
 #pragma unroll
         for (int l4 = 0; l4 < 16; ++l4) { const f32x4_env v4 = *(const f32x4_env*)&red[lane * 64 + 4 * l4]; gi = ((((gi + v4[0]) + v4[1]) + v4[2]) + v4[3]); } }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+      TS_T(2);
       const double t_ssq = wave_sum_d(lane < NP ? (double)gi * (double)gi : 0.0), t_sq = wave_sum_d(s_sq), t_q = wave_sum_d(s_q);
       const float gnorm = (float)sqrt(t_ssq);
       if (lane == 0) { float* e = q.infos + ((size_t)it * q.epochs + ep) * CRUX_INFO_N;
@@ -556,18 +569,23 @@ __global__ __launch_bounds__(64) void k_dqn_tiny_solve(SmallSolveArgs q) {
         const float dd = (float)((double)mi / (1.0 - bp1) / (sqrt((double)vi / (1.0 - bp2)) + q.tr.eps) * q.tr.eta);
         am = mi; av = vi; p = p - dd; }
       bp1 *= q.tr.b1; bp2 *= q.tr.b2;
+      TS_T(4);
     }
     if (err) break;
     { const float omt = __fsub_rn(1.0f, q.tau); pt = __fadd_rn(__fmul_rn(q.tau, p), __fmul_rn(omt, pt)); }          // polyak_average!(pi_minus, pi, tau) (:108)
   }
   // ---- leave everything where the call-by-call loop leaves it: networks, Adam state, and the staging batch = the last minibatch drawn
   if (lane < NP) { q.tr.p[lane] = p; q.pt[lane] = pt; q.tr.m[lane] = am; q.tr.v[lane] = av; q.tr.g[lane] = 0.f; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  if (lane == 0) { for (int i = 0; i < q.ro.sd; ++i) q.ro.state[i] = st_s[i];           // the sampler's state back where the call-by-call loop keeps it
+    q.ro.ep_len[0] = cnt_s[0]; q.ro.n_resets[0] = cnt_s[1]; q.ro.steps_taken[0] = cnt_s[2]; q.ro.acc[0] = acc_s[0]; q.ro.acc[1] = acc_s[1]; }
+  if (lane < q.ro.od) q.ro.svec[lane] = sv_s[lane];
   __threadfence();
   for (int k = 0; k < q.gn; ++k) { const int re = q.gre[k];
     for (int t = lane; t < B * re; t += 64) { const int j = t / re, e2 = t - j * re; const int64_t sidx = q.bidx[j] * re + e2;
       if (q.gesz[k] == 4) ((uint32_t*)q.gdst[k])[t] = ((const uint32_t*)q.gsrc[k])[sidx];
       else ((uint8_t*)q.gdst[k])[t] = ((const uint8_t*)q.gsrc[k])[sidx]; } }
-  if (lane == 0) { q.tr.bp[0] = bp1; q.tr.bp[1] = bp2; q.status[0] = err; q.status[8] = err; }
+  if (lane == 0) { q.tr.bp[0] = bp1; q.tr.bp[1] = bp2; q.status[0] = err; q.status[8] = err; for (int z = 0; z < 8; ++z) ((unsigned long long*)(q.status + 16))[z] = tacc[z]; }
 }
 
 __global__ void k_env_init(int kind, int E, int od, int sd, uint64_t seed, const float* mu, const float* sigma, double* state, int64_t* ep_len,
@@ -874,7 +892,7 @@ extern "C" int32_t crux_dqn_small_solve(crux_mlp* net, crux_mlp* target_net, cru
   if (sum_r || n_episode_end) { double sr = 0; int64_t ne = 0; for (int k = 0; k < E; ++k) { sr += acc[2 * k]; ne += (int64_t)acc[2 * k + 1]; } if (sum_r) *sum_r = sr; if (n_episode_end) *n_episode_end = ne; }
   hst[0] = hst9[0]; hst[1] = hst9[8];
   if (getenv("CRUX_SMALL_SOLVE_TIMING")) { unsigned long long tt[8]; (void)hipMemcpy(tt, q.status + 16, sizeof tt, hipMemcpyDeviceToHost); unsigned long long tot = 0; for (auto v : tt) tot += v;
-    fprintf(stderr, "[small-solve] rollout %.1f%% ids %.1f%% gather %.1f%% target %.1f%% train %.1f%%\n", 100.0 * tt[0] / tot, 100.0 * tt[1] / tot, 100.0 * tt[2] / tot, 100.0 * tt[3] / tot, 100.0 * tt[4] / tot); }
+    fprintf(stderr, "[small-solve] rollout %.1f%% ids (tiny kernel: sample + forward / backward) %.1f%% gather (tiny: transpose-reduce) %.1f%% target %.1f%% train (tiny: statistics + Adam) %.1f%%\n", 100.0 * tt[0] / tot, 100.0 * tt[1] / tot, 100.0 * tt[2] / tot, 100.0 * tt[3] / tot, 100.0 * tt[4] / tot); }
   if (hst[1] == CRUX_ENAN || hst[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
   if (hst[1]) return crux_fail(c, hst[1], "small solve kernel reported status %d", hst[1]);
   return CRUX_OK;
