@@ -164,7 +164,7 @@ def c1(crux, ctx, cpu=True, N=100_000):
     n_grad = len(sv.history) * 4
     out = {"workload": "DQN on SimpleGridWorld (README example): 2-8-4, N = %d, dN = 4, buffer 1000, B = 128, whole solve()" % N,
            "seconds": t, "env_steps_per_s": N / t, "grad_steps_per_s": n_grad / t,
-           "roofline": {"kernel": "k_dqn_tiny_solve<2,8,4> (the whole solve loop in one launch of ONE wave: parameters in lane registers, replay ring in LDS)", "bound": "hbm", "achieved": n_grad * 128 * 19 / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": n_grad * 128 * 19 / t / 1e9 / PEAK_HBM_GBS,
+           "roofline": {"kernel": "k_dqn_tiny_solve<2,8,4> (the whole solve loop in one launch of ONE wave: parameters and the GridWorld sampler in lane registers, replay ring in LDS)", "bound": "hbm", "achieved": n_grad * 128 * 19 / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": n_grad * 128 * 19 / t / 1e9 / PEAK_HBM_GBS,
                         "note": "19 B per sampled transition x 128 per gradient step; a 60-parameter network: pure latency, nominally HBM-bound"}}
     if cpu:
         out["cpu_baseline"] = c1_cpu(N=20_000)

@@ -481,6 +481,12 @@ __global__ __launch_bounds__(64) void k_dqn_tiny_solve(SmallSolveArgs q) {
       o[j] = acc + W(reg, oB2 + j); }
   };
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  const bool grid = q.ro.kind == CRUX_ENV_GRIDWORLD && q.ro.od == IN && q.ro.ad == OUT;
+  double gst[ENV_MAXSD]; float gx[IN]; int64_t g_ep_len = cnt_s[0], g_n_resets = cnt_s[1], g_steps_taken = cnt_s[2], g_nee = 0; double g_sum_r = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) gst[i] = st_s[i];
+#pragma unroll
+  for (int k = 0; k < IN; ++k) gx[k] = sv_s[k];
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();      // phase shares (CRUX_SMALL_SOLVE_TIMING): rollout | sample + forward / backward | transpose-reduce | statistics + Adam
 #define TS_T(k_) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k_] += tn_ - tl; tl = tn_; } while (0)
   for (int it = 0; it < q.iters && !err; ++it) {
@@ -488,11 +494,31 @@ __global__ __launch_bounds__(64) void k_dqn_tiny_solve(SmallSolveArgs q) {
     // ---- steps!(sampler, buffer, Nsteps = dN, explore = true, i = S.i): the generic rollout body, with theta and the sampler's state (env state, episode
     // counters, current observation) pointed at LDS copies -- read from global memory they cost a dependent L2 round trip per layer and per call (the rollout was
     // 2/3 of the solve); the buffer columns it writes stay in global memory, where the call-by-call loop leaves them
+    if (grid) {
+      // SimpleGridWorld (the README example): the whole sampler lives in registers, every lane carrying an identical copy like the 64-wide rollout kernel does. The
+      // policy forward reads theta from the lane registers (the arithmetic order of the generic body: fma over k ascending, + bias, relu), and the tail runs with
+      // compile-time environment kind and dimensions, so that its per-step arrays are registers -- called with run-time dimensions they are private memory and
+      // a step cost 7.4 us (2/3 of the whole solve).
+      RolloutArgs ro = q.ro; ro.base = next; ro.cfg.i0 = si; g_sum_r = 0.0; g_nee = 0;
+      for (int64_t t = 0; t < ro.T; ++t) {
+        const int64_t j = (ro.base + t) % ro.C;
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < IN; ++k) ro.S[(size_t)j * IN + k] = gx[k]; }
+        float h[H], z[OUT]; forward(p, gx, h, z);
+        float nx[ENV_MAXOBS];
+        rollout_tail(ro, z, IN, OUT, OUT, CRUX_ENV_GRIDWORLD, 0, t, j, lane == 0, gst, g_ep_len, g_n_resets, g_steps_taken, g_sum_r, g_nee, nx);
+#pragma unroll
+        for (int k = 0; k < IN; ++k) gx[k] = nx[k];
+      }
+    } else {
     if (lane < NP) th_s[lane] = p;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
     { RolloutArgs ro = q.ro; ro.base = next; ro.cfg.i0 = si;
       ro.p = th_s; ro.state = st_s; ro.ep_len = &cnt_s[0]; ro.n_resets = &cnt_s[1]; ro.steps_taken = &cnt_s[2]; ro.svec = sv_s; ro.acc = acc_s;
       rollout_generic_wave(ro, 0, lane, (float (*)[1024])sm_ro, sm_ro + 2 * 1024); }
+    }
+    TS_T(5);
     __threadfence();
     if (lane < q.dN) mirror_row((next + lane) % C);
     next = (next + q.dN) % C; elements = elements + q.dN < C ? elements + q.dN : C;
@@ -576,6 +602,9 @@ __global__ __launch_bounds__(64) void k_dqn_tiny_solve(SmallSolveArgs q) {
   }
   // ---- leave everything where the call-by-call loop leaves it: networks, Adam state, and the staging batch = the last minibatch drawn
   if (lane < NP) { q.tr.p[lane] = p; q.pt[lane] = pt; q.tr.m[lane] = am; q.tr.v[lane] = av; q.tr.g[lane] = 0.f; }
+  if (grid && lane == 0) { st_s[0] = gst[0]; st_s[1] = gst[1]; cnt_s[0] = g_ep_len; cnt_s[1] = g_n_resets; cnt_s[2] = g_steps_taken; acc_s[0] = g_sum_r; acc_s[1] = (double)g_nee;
+#pragma unroll
+    for (int k = 0; k < IN; ++k) sv_s[k] = gx[k]; }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   if (lane == 0) { for (int i = 0; i < q.ro.sd; ++i) q.ro.state[i] = st_s[i];           // the sampler's state back where the call-by-call loop keeps it
     q.ro.ep_len[0] = cnt_s[0]; q.ro.n_resets[0] = cnt_s[1]; q.ro.steps_taken[0] = cnt_s[2]; q.ro.acc[0] = acc_s[0]; q.ro.acc[1] = acc_s[1]; }
@@ -892,7 +921,7 @@ extern "C" int32_t crux_dqn_small_solve(crux_mlp* net, crux_mlp* target_net, cru
   if (sum_r || n_episode_end) { double sr = 0; int64_t ne = 0; for (int k = 0; k < E; ++k) { sr += acc[2 * k]; ne += (int64_t)acc[2 * k + 1]; } if (sum_r) *sum_r = sr; if (n_episode_end) *n_episode_end = ne; }
   hst[0] = hst9[0]; hst[1] = hst9[8];
   if (getenv("CRUX_SMALL_SOLVE_TIMING")) { unsigned long long tt[8]; (void)hipMemcpy(tt, q.status + 16, sizeof tt, hipMemcpyDeviceToHost); unsigned long long tot = 0; for (auto v : tt) tot += v;
-    fprintf(stderr, "[small-solve] rollout %.1f%% ids (tiny kernel: sample + forward / backward) %.1f%% gather (tiny: transpose-reduce) %.1f%% target %.1f%% train (tiny: statistics + Adam) %.1f%%\n", 100.0 * tt[0] / tot, 100.0 * tt[1] / tot, 100.0 * tt[2] / tot, 100.0 * tt[3] / tot, 100.0 * tt[4] / tot); }
+    fprintf(stderr, "[small-solve] rollout %.1f%% ids (tiny kernel: sample + forward / backward) %.1f%% gather (tiny: transpose-reduce) %.1f%% target %.1f%% train (tiny: statistics + Adam) %.1f%%\n", 100.0 * tt[0] / tot, 100.0 * tt[1] / tot, 100.0 * tt[2] / tot, 100.0 * tt[3] / tot, 100.0 * tt[4] / tot); fprintf(stderr, "[small-solve] tiny: rollout body %.1f%%, fence + mirror %.1f%%\n", 100.0 * tt[5] / tot, 100.0 * tt[0] / tot); }
   if (hst[1] == CRUX_ENAN || hst[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
   if (hst[1]) return crux_fail(c, hst[1], "small solve kernel reported status %d", hst[1]);
   return CRUX_OK;
