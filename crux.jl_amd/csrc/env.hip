@@ -308,16 +308,22 @@ __global__ __launch_bounds__(64) void k_rollout_h64(RolloutArgs a_single, const 
 // The body is a device function of ONE wave (its LDS traffic is ordered by a wave barrier, not a workgroup barrier), so that the small-network
 // solve kernel below can run it on one of its waves.
 #define RO_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// NT = threads sharing the body: 64 (one wave, ordered by a wave barrier) or 256 (one workgroup per environment, ordered by __syncthreads: the wide-network rollout
+// kernel below -- with 256-wide layers one wave needed 117 us per step). Thread 0 runs the tail either way; the layer arithmetic (fma over k ascending, + bias,
+// activation) is the same, so the results are.
+template <int NT = 64>
 __device__ __forceinline__ void rollout_generic_wave(const RolloutArgs& a, const int e, const int lane, float (*hbuf)[1024], float* sh_misc) {
+#define RO_SYNC() do { if (NT == 64) { RO_WAVE_SYNC(); } else { __syncthreads(); } } while (0)
   const NetDesc& nd = a.nd;
   const int od = a.od, ad = a.ad, nout = nd.dims[nd.L];
   double st[ENV_MAXSD]; int64_t ep_len = 0, n_resets = 0, steps_taken = 0; double sum_r = 0.0; int64_t nee = 0;
   if (lane == 0) {
-    for (int i = 0; i < a.sd; ++i) st[i] = a.state[(size_t)e * a.sd + i];
+#pragma unroll
+    for (int i = 0; i < ENV_MAXSD; ++i) if (i < a.sd) st[i] = a.state[(size_t)e * a.sd + i];      // constant indices: the state array stays in registers
     ep_len = a.ep_len[e]; n_resets = a.n_resets[e]; steps_taken = a.steps_taken[e];
   }
   if (lane < od) hbuf[0][lane] = a.svec[(size_t)e * od + lane];
-  RO_WAVE_SYNC();
+  RO_SYNC();
   for (int64_t t = 0; t < a.T; ++t) {
     const int64_t j = (a.base + (int64_t)e * a.T + t) % a.C;
     // current observation -> S column (sampler.jl:100)
@@ -327,22 +333,36 @@ __device__ __forceinline__ void rollout_generic_wave(const RolloutArgs& a, const
     for (int l = 0; l < nd.L; ++l) {
       const int in = nd.dims[l], out = nd.dims[l + 1], act = nd.acts[l];
       const float* Wl = a.p + nd.woff[l]; const float* bl = a.p + nd.boff[l];
-      for (int o = lane; o < out; o += 64) {
-        float accv = 0.f;
-        for (int k = 0; k < in; ++k) accv = fmaf(Wl[o + out * k], hbuf[cur][k], accv);
+      for (int o = lane; o < out; o += NT) {
+        float accv = 0.f; int k = 0;
+        for (; k + 8 <= in; k += 8) {          // eight independent weight loads in flight; the fma chain keeps its order
+          float wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) wv[u] = Wl[o + out * (k + u)];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) accv = fmaf(wv[u], hbuf[cur][k + u], accv); }
+        for (; k < in; ++k) accv = fmaf(Wl[o + out * k], hbuf[cur][k], accv);
         hbuf[cur ^ 1][o] = crux_act(act, accv + bl[o]);
       }
-      RO_WAVE_SYNC();
+      RO_SYNC();
       cur ^= 1;
     }
     // (the observation in hbuf[0] was already stored to the S column, so the ping-pong may overwrite it)
-    if (lane == 0) rollout_tail(a, hbuf[cur], od, ad, nout, a.kind, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
-    RO_WAVE_SYNC();
+    // the tail with compile-time kind and dimensions for the restated environments (its per-step arrays are then registers; with run-time dimensions they are
+    // private memory and the step costs ~3x more), the run-time form for everything else (SYNTH envs of any width)
+    if (lane == 0) {
+      if (a.kind == CRUX_ENV_CARTPOLE && od == 4 && ad == 2 && nout == 2) rollout_tail(a, hbuf[cur], 4, 2, 2, CRUX_ENV_CARTPOLE, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
+      else if (a.kind == CRUX_ENV_GRIDWORLD && od == 2 && ad == 4 && nout == 4) rollout_tail(a, hbuf[cur], 2, 4, 4, CRUX_ENV_GRIDWORLD, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
+      else if (a.kind == CRUX_ENV_PENDULUM && od == 3 && ad == 1 && nout == 1) rollout_tail(a, hbuf[cur], 3, 1, 1, CRUX_ENV_PENDULUM, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
+      else rollout_tail(a, hbuf[cur], od, ad, nout, a.kind, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
+    }
+    RO_SYNC();
     if (lane < od) hbuf[0][lane] = sh_misc[lane];
-    RO_WAVE_SYNC();
+    RO_SYNC();
   }
   if (lane == 0) {
-    for (int i = 0; i < a.sd; ++i) a.state[(size_t)e * a.sd + i] = st[i];
+#pragma unroll
+    for (int i = 0; i < ENV_MAXSD; ++i) if (i < a.sd) a.state[(size_t)e * a.sd + i] = st[i];
     a.ep_len[e] = ep_len; a.n_resets[e] = n_resets; a.steps_taken[e] = steps_taken;
     a.acc[2 * e] = sum_r; a.acc[2 * e + 1] = (double)nee;
   }
@@ -353,6 +373,13 @@ __global__ __launch_bounds__(64) void k_rollout(RolloutArgs a) {
   __shared__ float hbuf[2][1024];
   __shared__ float sh_misc[ENV_MAXOBS + 8];
   rollout_generic_wave(a, blockIdx.x, threadIdx.x, hbuf, sh_misc);
+}
+// one WORKGROUP of 256 threads per environment: thread o evaluates output unit o of a layer (weights W[o + out k] coalesced over the threads, the previous layer
+// broadcast from LDS), thread 0 runs the head, the dynamics and the bookkeeping. For policies with layers of 128 units or more.
+__global__ __launch_bounds__(256) void k_rollout_wide(RolloutArgs a) {
+  __shared__ float hbuf[2][1024];
+  __shared__ float sh_misc[ENV_MAXOBS + 8];
+  rollout_generic_wave<256>(a, blockIdx.x, threadIdx.x, hbuf, sh_misc);
 }
 
 // ---- the whole off-policy solve loop of a small network in ONE launch ------------------------------------------------------------------------
@@ -766,7 +793,8 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
   RO_CASE(17, 6, CRUX_ACT_TANH, CRUX_ENV_SYNTH)       // C5-shaped: 17 obs / 6 continuous actions
   RO_CASE(17, 6, CRUX_ACT_RELU, CRUX_ENV_SYNTH)
 #undef RO_CASE
-  hipLaunchKernelGGL(k_rollout, dim3(e->n_envs), dim3(64), 0, c->stream, a);
+  if (policy->nd.maxdim >= 128) hipLaunchKernelGGL(k_rollout_wide, dim3(e->n_envs), dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_rollout, dim3(e->n_envs), dim3(64), 0, c->stream, a);
   crux_prof_end(c, CRUX_PROF_ROLLOUT);
   int32_t rc = crux_launch_check(c, "k_rollout"); if (rc) return rc;
   if (buf->prioritized) {

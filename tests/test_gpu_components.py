@@ -165,7 +165,7 @@ def _rollout_pair(kind, head, n_envs, T, cap, extras, explore=True, reset=True, 
     return g, o, gb, ob, gs, oe, cfg
 
 
-@pytest.mark.parametrize("hidden", [32, 64])      # 64 -> register-resident k_rollout_h64, 32 -> generic k_rollout
+@pytest.mark.parametrize("hidden", [32, 64, 160])      # 64 -> register-resident k_rollout_h64, 32 -> generic one-wave k_rollout, 160 -> k_rollout_wide (a workgroup per environment)
 @pytest.mark.parametrize("case", ["ppo_cartpole", "greedy_eval", "eps_greedy_offpolicy", "pendulum_gaussian", "pendulum_noise"])
 def test_rollout_matches_oracle(gpu_ctx, case, hidden):
     if case == "ppo_cartpole":
