@@ -130,6 +130,11 @@ template <class Op> __device__ __forceinline__ void exec_dispatch_k(const KOp* o
   const OpPack<Op> p = *(const OpPack<Op>*)op->args;
   exec_apply<Op>(bid, op->nblocks, p);
 }
+// the gather's column table (456 bytes) is read where it lies in the kernel arguments instead of travelling by value (see GatherRingAllOp::run_ptr)
+template <> __device__ __forceinline__ void exec_dispatch_k<GatherRingAllOp>(const KOp* op, unsigned bid) {
+  using P = OpPack<GatherRingAllOp>; const P* pp = (const P*)op->args;
+  GatherRingAllOp::run_ptr(bid, op->nblocks, &pp->head, pp->tail.head, pp->tail.tail.head, pp->tail.tail.tail.head, pp->tail.tail.tail.tail.head);
+}
 template <int BYTES>
 __global__ __launch_bounds__(256) void k_phase_k(PhaseK<BYTES> by_value) {
   // read through the kernel-argument segment pointer, not through the by-value parameter: indexing the parameter at a run-time offset would make the compiler

@@ -304,20 +304,25 @@ __global__ void k_gather_ring(T* __restrict__ dst, const T* __restrict__ src, co
 }
 // all columns of the sampled rows in ONE launch: a table of (dst, src, elements per row, element size) and the prefix of row widths
 struct GatherCols { void* dst[CRUX_NCOLS]; const void* src[CRUX_NCOLS]; int32_t re[CRUX_NCOLS]; int32_t esz[CRUX_NCOLS]; int32_t pre[CRUX_NCOLS + 1]; int32_t n; };
-struct GatherRingAllOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, GatherCols g, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) {
-  // the column table is indexed per element: held in LDS (a by-value struct indexed at run time lives in scratch memory: 8 us for an 11-block gather)
-  __shared__ GatherCols gs;
-  { const uint32_t* src = (const uint32_t*)&g; uint32_t* dst = (uint32_t*)&gs; for (int i = threadIdx.x; i < (int)(sizeof(GatherCols) / 4); i += blockDim.x) dst[i] = src[i]; }
-  __syncthreads();
-  const int32_t width = gs.pre[gs.n]; const int64_t total = n * width; const int ncol = gs.n;
-  for (int64_t t = (int64_t)bid_ * blockDim.x + threadIdx.x; t < total; t += (int64_t)nb_ * blockDim.x) {
-    const int64_t j = t / width; const int32_t w = (int32_t)(t - j * width);
-    int k = 0; while (k + 1 < ncol && w >= gs.pre[k + 1]) ++k;
-    const int32_t e = w - gs.pre[k]; const int64_t d = ((base + j) % C) * gs.re[k] + e, sidx = ids[j] * gs.re[k] + e;
-    if (gs.esz[k] == 4) ((uint32_t*)gs.dst[k])[d] = ((const uint32_t*)gs.src[k])[sidx];
-    else ((uint8_t*)gs.dst[k])[d] = ((const uint8_t*)gs.src[k])[sidx];
+struct GatherRingAllOp {
+  // the column table is indexed per element: held in LDS (a by-value struct indexed at run time lives in scratch memory: 8 us for an 11-block gather). run_ptr takes
+  // the table WHERE IT LIES (the executor's kernel-argument record): copied from there to LDS without a private copy in between -- passed by value through the
+  // executor's argument pack it put 464 bytes of scratch into every phase launch.
+  static __device__ __forceinline__ void run_ptr(const unsigned bid_, const unsigned nb_, const GatherCols* gp, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) {
+    __shared__ GatherCols gs;
+    { const uint32_t* src = (const uint32_t*)gp; uint32_t* dst = (uint32_t*)&gs; for (int i = threadIdx.x; i < (int)(sizeof(GatherCols) / 4); i += blockDim.x) dst[i] = src[i]; }
+    __syncthreads();
+    const int32_t width = gs.pre[gs.n]; const int64_t total = n * width; const int ncol = gs.n;
+    for (int64_t t = (int64_t)bid_ * blockDim.x + threadIdx.x; t < total; t += (int64_t)nb_ * blockDim.x) {
+      const int64_t j = t / width; const int32_t w = (int32_t)(t - j * width);
+      int k = 0; while (k + 1 < ncol && w >= gs.pre[k + 1]) ++k;
+      const int32_t e = w - gs.pre[k]; const int64_t d = ((base + j) % C) * gs.re[k] + e, sidx = ids[j] * gs.re[k] + e;
+      if (gs.esz[k] == 4) ((uint32_t*)gs.dst[k])[d] = ((const uint32_t*)gs.src[k])[sidx];
+      else ((uint8_t*)gs.dst[k])[d] = ((const uint8_t*)gs.src[k])[sidx];
+    }
   }
-} };
+  static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, GatherCols g, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) { run_ptr(bid_, nb_, &g, ids, n, base, C); }
+};
 __global__ void k_gather_ring_all(GatherCols g, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) { GatherRingAllOp::run(blockIdx.x, gridDim.x, g, ids, n, base, C); }
 struct RingIdsOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, int64_t* out, int64_t n, int64_t base, int64_t C) { const int64_t j = (int64_t)bid_ * blockDim.x + threadIdx.x; if (j < n) out[j] = (base + j) % C; } };
 __global__ void k_ring_ids(int64_t* out, int64_t n, int64_t base, int64_t C) { RingIdsOp::run(blockIdx.x, gridDim.x, out, n, base, C); }
