@@ -30,8 +30,8 @@ struct GemmArgs {
 // SPLITK: the four waves of a workgroup share ONE output tile and take a quarter of K each (combined through LDS in wave order, so the
 // result is deterministic): a 256-deep reduction then costs one L2 round trip instead of four -- these launches are latency-bound.
 template <bool AV, bool BV, bool SPLITK>
-struct Gemm16 { static __device__ __forceinline__ void run(const unsigned bid_, const GemmArgs& q, const int quart = 0) {
-  __shared__ float part[SPLITK ? 3 * 64 * 5 : 1];
+#define GEMM16_PART (3 * 64 * 5)      // floats of LDS the split-K combine needs (waves 1..3 hand 4 + 1 values per lane to wave 0); ONE buffer, owned by the caller
+struct Gemm16 { static __device__ __forceinline__ void run(const unsigned bid_, const GemmArgs& q, float* part, const int quart = 0) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int tm = (q.M + 15) >> 4, tn = (q.N + 15) >> 4;
   const int tile = SPLITK ? (int)bid_ : (int)bid_ * 4 + wv;
@@ -122,15 +122,16 @@ struct Gemm16 { static __device__ __forceinline__ void run(const unsigned bid_, 
     q.C[ci] = v; }
 } };
 template <bool AV, bool BV, bool SPLITK>
-__global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) { Gemm16<AV, BV, SPLITK>::run(blockIdx.x, q); }
+__global__ __launch_bounds__(256) void k_gemm16(GemmArgs q) { __shared__ float part[SPLITK ? GEMM16_PART : 1]; Gemm16<AV, BV, SPLITK>::run(blockIdx.x, q, part); }
 // the executor's form (exec.hip): the variant is data
 struct GemmOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, GemmArgs q, int variant) {
+  __shared__ float part[GEMM16_PART];         // one combine buffer for all variants (a static array per template instantiation cost the phase kernel 15 KB of LDS)
   const int quart = (variant >> 3) & 1;       // bit 0 AV, bit 1 BV, bit 2 split-K over the workgroup's waves, bit 3 the four K quarters walked by one wave
   switch (variant & 7) {
-    case 0: Gemm16<false, false, false>::run(bid_, q, quart); break; case 1: Gemm16<true, false, false>::run(bid_, q, quart); break;
-    case 2: Gemm16<false, true, false>::run(bid_, q, quart); break;  case 3: Gemm16<true, true, false>::run(bid_, q, quart); break;
-    case 4: Gemm16<false, false, true>::run(bid_, q); break;  case 5: Gemm16<true, false, true>::run(bid_, q); break;
-    case 6: Gemm16<false, true, true>::run(bid_, q); break;   default: Gemm16<true, true, true>::run(bid_, q); break; } } };
+    case 0: Gemm16<false, false, false>::run(bid_, q, part, quart); break; case 1: Gemm16<true, false, false>::run(bid_, q, part, quart); break;
+    case 2: Gemm16<false, true, false>::run(bid_, q, part, quart); break;  case 3: Gemm16<true, true, false>::run(bid_, q, part, quart); break;
+    case 4: Gemm16<false, false, true>::run(bid_, q, part); break;  case 5: Gemm16<true, false, true>::run(bid_, q, part); break;
+    case 6: Gemm16<false, true, true>::run(bid_, q, part); break;   default: Gemm16<true, true, true>::run(bid_, q, part); break; } } };
 
 // dZ = act'(Y) .* dY for the output layer
 struct ActGradOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ dy, const float* __restrict__ y, int act, int64_t n, float* __restrict__ dz) {

@@ -6,9 +6,9 @@
 struct PerUpdateOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, float* __restrict__ pr, float* pminmax, const int64_t* __restrict__ I,
                              const double* __restrict__ v64, const float* __restrict__ v32, const float* vconst_from_max,
                              float alpha, int64_t n) {
-  __shared__ int64_t ids_s[2048];          // small calls: the "last write wins" scan over the ids runs out of LDS (from global memory it cost 27 us for n = 128)
+  __shared__ int64_t ids_s[512];           // small calls (a sampled minibatch): the "last write wins" scan over the ids runs out of LDS (from global memory it cost 27 us for n = 128)
   bool sorted_ids = false;
-  if (n <= 2048 && !vconst_from_max) { for (int64_t j = threadIdx.x; j < n; j += blockDim.x) ids_s[j] = I[j]; __syncthreads();
+  if (n <= 512 && !vconst_from_max) { for (int64_t j = threadIdx.x; j < n; j += blockDim.x) ids_s[j] = I[j]; __syncthreads();
     int ok = 1; for (int64_t j = threadIdx.x; j + 1 < n; j += blockDim.x) ok &= ids_s[j] <= ids_s[j + 1] ? 1 : 0;
     sorted_ids = __syncthreads_and(ok) != 0; }          // stratified samples arrive in ascending order: duplicates are then neighbours
   int wmax = (int)0x80000000, wmin = 0x7fffffff;
@@ -20,7 +20,7 @@ struct PerUpdateOp { static __device__ __forceinline__ void run(const unsigned b
     // priorities[I] = val.^alpha is a sequential scatter in the reference (:297): with repeated indices the LAST value wins. Small calls (the
     // sampled-batch case) resolve that exactly; large calls are ring pushes, whose repeats (N > capacity) carry the same value anyway.
     bool later = false;
-    if (n <= 2048 && !vconst_from_max) { const int64_t me = ids_s[i];
+    if (n <= 512 && !vconst_from_max) { const int64_t me = ids_s[i];
       if (sorted_ids) later = i + 1 < n && ids_s[i + 1] == me;
       else for (int64_t j = i + 1; j < n; ++j) if (ids_s[j] == me) { later = true; break; } }
     if (!later) pr[I[i]] = (float)pow(val, (double)alpha);
