@@ -824,7 +824,7 @@ def _rollout_cfg(sampler, explore, reset, i):
     return cfg, pi_on
 
 
-def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=None):
+def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=None, want_info=True):
     """steps!(sampler, buffer; Nsteps, explore, i, reset, cb) (src/sampler.jl:139-173).
 
     Nsteps counts transitions over all of the sampler's environments (Nsteps/n_envs per environment, env-major).
@@ -837,6 +837,10 @@ def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=N
     cfg, pi_on = _rollout_cfg(sampler, explore, reset, i)
     sr, ne = C.c_double(), C.c_int64()
     first = buffer.next_ind - 1                                   # 0-based ring row the block starts at (push!, experience_buffer.jl:236)
+    if not want_info and cb is None:      # callers that do not look at the rewards (the off-policy solve loop): the rollout stays asynchronous, no read-back to wait for
+        sampler.ctx.check(sampler.ctx.lib.crux_rollout(sampler.h, pi_on.h, C.byref(cfg), buffer.h, Nsteps // E, None, None))
+        _fill_block(sampler, buffer, first, Nsteps, reset)
+        return {}
     sampler.ctx.check(sampler.ctx.lib.crux_rollout(sampler.h, pi_on.h, C.byref(cfg), buffer.h, Nsteps // E, C.byref(sr), C.byref(ne)))
     _fill_block(sampler, buffer, first, Nsteps, reset)
     info = {"sum_r": sr.value, "n_episode_end": ne.value, "avg_r": sr.value / ne.value if ne.value else float("nan")}
@@ -1791,13 +1795,13 @@ def _solve_off_policy(solver, mdp):
     nfill = max(0, solver.buffer_init - len(solver.buffer))                                            # :122
     if nfill > 0:
         solver.i += nfill                                                                              # :125 (Q12: advanced BEFORE sampling)
-        steps_(s, solver.buffer, Nsteps=nfill, explore=True, i=solver.i)
+        steps_(s, solver.buffer, Nsteps=nfill, explore=True, i=solver.i, want_info=False)
     i = solver.i
     stop = istart + solver.N - solver.dN
     i = _solve_small_dqn(solver, D, s, gamma, i, stop)                                                 # whole iterations in one launch where the configuration allows it
     while i <= stop:                                                                                   # :133
         solver.i = i
-        steps_(s, solver.buffer, Nsteps=solver.dN, explore=True, i=i)                                  # :138
+        steps_(s, solver.buffer, Nsteps=solver.dN, explore=True, i=i, want_info=False)                # :138 (its info is not used by this loop)
         solver.history.append(value_training(solver, D, gamma))                                       # :143
         if solver.log is not None:                                                                     # :146 log(S.log, S.i, infos..., S=S)
             from . import logging as _lg

@@ -12,6 +12,7 @@
 int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I);
 void crux_buffer_ring_advance(crux_buffer* b, int64_t N);
 int32_t crux_buffer_per_on_push(crux_buffer* b, const int64_t* d_I, int64_t N);
+int32_t crux_buffer_ring_ids_device(crux_buffer* b, int64_t N, int64_t* d_out);
 
 #define ENV_MAXSD 32          // SYNTH keeps one Float64 per observation; CartPole 4, Pendulum / GridWorld 2
 #define ENV_MAXOBS 32
@@ -797,11 +798,9 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
   else hipLaunchKernelGGL(k_rollout, dim3(e->n_envs), dim3(64), 0, c->stream, a);
   crux_prof_end(c, CRUX_PROF_ROLLOUT);
   int32_t rc = crux_launch_check(c, "k_rollout"); if (rc) return rc;
-  if (buf->prioritized) {
-    std::vector<int64_t> I; crux_buffer_ring_indices(buf, N, I);
-    HIPCHK(c, hipMemcpyAsync(buf->d_indices, I.data(), 8 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+  if (buf->prioritized) {      // push!: the new rows get max_priority (experience_buffer.jl:254); their ring rows are formed on the device, nothing to wait for
+    rc = crux_buffer_ring_ids_device(buf, N, buf->d_indices); if (rc) return rc;
     rc = crux_buffer_per_on_push(buf, buf->d_indices, N); if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   crux_buffer_ring_advance(buf, N);
   if (sum_r || n_episode_end) {

@@ -327,6 +327,12 @@ __global__ void k_gather_ring_all(GatherCols g, const int64_t* __restrict__ ids,
 struct RingIdsOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, int64_t* out, int64_t n, int64_t base, int64_t C) { const int64_t j = (int64_t)bid_ * blockDim.x + threadIdx.x; if (j < n) out[j] = (base + j) % C; } };
 __global__ void k_ring_ids(int64_t* out, int64_t n, int64_t base, int64_t C) { RingIdsOp::run(blockIdx.x, gridDim.x, out, n, base, C); }
 
+// the ring rows of the next N pushed transitions, mod1.(next_ind : next_ind + N - 1, C) (experience_buffer.jl:236), written on the device: no host vector, no copy to wait for
+int32_t crux_buffer_ring_ids_device(crux_buffer* b, int64_t N, int64_t* d_out) {
+  if (N <= 0) return CRUX_OK;
+  hipLaunchKernelGGL(k_ring_ids, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, b->ctx->stream, d_out, N, b->next_ind, b->capacity);
+  return crux_launch_check(b->ctx, "k_ring_ids");
+}
 static unsigned gridn(int64_t total) { int64_t nb = (total + 255) / 256; if (nb < 1) nb = 1; if (nb > 8192) nb = 8192; return (unsigned)nb; }
 
 static int32_t ensure_cumsum(crux_buffer* s, int64_t N) {
