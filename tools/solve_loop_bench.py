@@ -14,8 +14,8 @@ def dqn(iters):
     sv = crux.DQN(q, S, N=1200 + 4 * iters, dN=4, buffer_size=100000, prioritized=True, buffer_init=1200, max_steps=200, c_opt={"batch_size": 128})
     mdp = crux.SynthMDP(8, 4, discrete=True, n_envs=1, seed=5, discount=0.99)
     sv.N = 1200 + 4 * 50; crux.solve(sv, mdp); sv.buffer.ctx.sync()
-    t0 = time.perf_counter(); sv.N = sv.i + 4 * iters; crux.solve(sv, mdp); sv.buffer.ctx.sync()
-    return 1e6 * (time.perf_counter() - t0) / iters
+    t0 = time.perf_counter(); i0 = sv.i; sv.N = sv.i + 4 * iters; crux.solve(sv, mdp); sv.buffer.ctx.sync()
+    return 1e6 * (time.perf_counter() - t0) / ((sv.i - i0) // 4)
 
 def sac(iters):
     S = crux.ContinuousSpace(3)
@@ -24,8 +24,8 @@ def sac(iters):
     sv = crux.SAC(pi, S, N=1000 + 50 * iters, dN=50, buffer_size=100000, buffer_init=1000, max_steps=200, c_opt={"batch_size": 256}, a_opt={"batch_size": 256}, SAC_alpha_opt={"batch_size": 256})
     mdp = crux.PendulumMDP(n_envs=1, seed=8)
     sv.N = 1000 + 50 * 2; crux.solve(sv, mdp); sv.buffer.ctx.sync()
-    t0 = time.perf_counter(); sv.N = sv.i + 50 * iters; crux.solve(sv, mdp); sv.buffer.ctx.sync()
-    return 1e6 * (time.perf_counter() - t0) / iters
+    t0 = time.perf_counter(); i0 = sv.i; sv.N = sv.i + 50 * iters; crux.solve(sv, mdp); sv.buffer.ctx.sync()
+    return 1e6 * (time.perf_counter() - t0) / ((sv.i - i0) // 50)
 
 print("DQN + PER solve: %.0f us per iteration (4 env steps + 4 epochs)" % dqn(400))
 print("SAC solve: %.0f us per iteration (50 env steps + 50 epochs)" % sac(20))
