@@ -280,7 +280,8 @@ int32_t crux_exec_run(crux_ctx* c) {
       while (i0 < nops) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += (r->ops[i1].barrier & 2) ? 0u : r->ops[i1].nblocks; if ((r->ops[i1].barrier & 1) || i1 + 1 == nops) break; ++i1; }
         if (blocks) {
           // the phase's records travel in the kernel arguments when they fit (see k_phase_k); zero-block ops are dropped there
-          if (!phasek_launch<384>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<1024>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<3840>(r->ops, i0, i1, blocks, c->stream))
+          const bool no_kernarg = getenv("CRUX_EXEC_NO_KERNARG") != nullptr;      // tests: every phase through the global-record form
+          if (no_kernarg || (!phasek_launch<384>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<1024>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<3840>(r->ops, i0, i1, blocks, c->stream)))
             hipLaunchKernelGGL(k_phase, dim3(blocks), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops + i0, (int)(i1 - i0 + 1));
         }
         i0 = i1 + 1; }

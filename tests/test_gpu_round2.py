@@ -290,6 +290,23 @@ def test_wide_policies_train_on_the_dense_engine_and_match_the_oracle(gpu_ctx, c
     assert "outside the MFMA learner family" not in capfd.readouterr().err
 
 
+def test_phase_records_in_global_memory_give_the_same_epochs(gpu_ctx, monkeypatch):
+    """The executor launches a phase with its op records inside the kernel arguments (k_phase_k) when they fit, through a device copy of the records (k_phase)
+    otherwise; CRUX_EXEC_NO_KERNARG forces the second form for every phase -- sequential one-block groups included -- and the SAC epochs must not change."""
+    def run():
+        S = crux.ContinuousSpace(3); acts = ["relu", "relu", "identity"]
+        pi = crux.ActorCritic(crux.GaussianPolicy(parity.chain([3, 256, 256, 1], acts), np.zeros(1, np.float32), seed=2),
+                              crux.DoubleNetwork(crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], acts), seed=3), crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], acts), seed=4)))
+        sv = crux.SAC(pi, S, N=420, dN=6, buffer_size=1000, buffer_init=300, max_steps=50, c_opt={"batch_size": 256}, a_opt={"batch_size": 256}, SAC_alpha_opt={"batch_size": 256})
+        crux.solve(sv, crux.PendulumMDP(n_envs=1, seed=8))
+        return [n.get_params() for n in (pi.A, pi.C.N1, pi.C.N2, sv.agent.pi_minus.C.N1, sv.P["SAC_log_alpha"])]
+    a = run()
+    monkeypatch.setenv("CRUX_EXEC_NO_KERNARG", "1")
+    b = run()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y), np.abs(x - y).max()
+
+
 def test_chained_dqn_epochs_equal_single_epoch_calls(gpu_ctx):
     """crux_dqn_epochs (the c_opt.epochs epochs of one value_training recorded into one list, no host round trip between them) == the same epochs as
     separate crux_dqn_epoch calls: sampled rows, priorities, networks and infos, bit for bit -- with prioritized replay on a FULL ring (incremental tree
