@@ -466,8 +466,8 @@ def main():
             "phase_ms_per_iter": {k: v[0] / args.steps for k, v in prof.items()},
             "rollout_env_steps_per_s": (E * T * args.steps) / (prof["rollout"][0] * 1e-3) if prof["rollout"][0] > 0 else None,
             "roofline": {"kernel": "batch_train! actor (persistent fwd+ppo_loss+bwd+Adam)", "bound": "mfma", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": 31.0e6 if (world == 1 and args.workload == "c2") else None,
-                         "traffic_note": "HBM-side bytes per actor launch from rocprofv3 --pmc FETCH_SIZE (14.13 MB reported) and --pmc WRITE_SIZE (2.70 MB), separate passes of this command (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.txt), corrected as the microarchitecture guide prescribes and as calibrated here on a 2 GiB stream (tools/fetch_calib.hip -> profiles/r02_fetch_calibration.txt): FETCH_SIZE tallies 128-byte requests at 64 B, so reads = 2 x 14.13 MB, writes are exact: 31.0 MB. A recorded constant, not re-measured in this run. Algorithmic minibatch bytes per launch are 136 MB (40960 x 3328 B): the 3.4 MB buffer is re-read from L2/MALL, and the 1.6 GB/launch of gradient exchange between the two workgroups stays inside one XCD's L2",
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": 30.9e6 if (world == 1 and args.workload == "c2") else None,
+                         "traffic_note": "HBM-side bytes per actor launch from rocprofv3 --pmc FETCH_SIZE (14.08 MB reported) and --pmc WRITE_SIZE (2.70 MB), separate passes of this command (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.txt), corrected as the microarchitecture guide prescribes and as calibrated here on a 2 GiB stream (tools/fetch_calib.hip -> profiles/r02_fetch_calibration.txt): FETCH_SIZE tallies 128-byte requests at 64 B, so reads = 2 x 14.08 MB, writes are exact: 30.9 MB. A recorded constant, not re-measured in this run. Algorithmic minibatch bytes per launch are 136 MB (40960 x 3328 B): the 3.4 MB buffer is re-read from L2/MALL, and the 1.6 GB/launch of gradient exchange between the two workgroups stays inside one XCD's L2",
                          "avg_launch_ms": avg_launch_s * 1e3, "grad_steps_per_launch": steps_per_launch,
                          "us_per_grad_step": avg_launch_s * 1e6 / steps_per_launch if steps_per_launch else None,
                          "note": "serially dependent %.2f-MFLOP steps: each learner step is split over two CUs of one XCD (gradient exchange through the shared L2), actor and critic run concurrently -> 4 CUs busy; per-CU f32 MFMA peak is 0.614 TFLOP/s" % (fa / 1e6)},
