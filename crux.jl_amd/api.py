@@ -662,10 +662,15 @@ def rand_(target, *sources, i=1, fracs=None, counter=None, seed=None):
     for k, (b, B) in enumerate(zip(sources, batches)):
         if B == 0:
             continue
-        want = (int(seed) if seed is not None else getattr(b, "sample_seed", SAMPLE_SEED), k if len(sources) > 1 else getattr(b, "sample_stream", 0))
-        if want != (getattr(b, "sample_seed", SAMPLE_SEED), getattr(b, "sample_stream", 0)):
+        had = (getattr(b, "sample_seed", SAMPLE_SEED), getattr(b, "sample_stream", 0))
+        want = (int(seed) if seed is not None else had[0], k if len(sources) > 1 else had[1])
+        if want != had:
             set_sample_stream_(b, *want)
-        prioritized_sample_(target, b, B=B, i=i, counter=ctr) if b.isprioritized() else uniform_sample_(target, b, B=B, i=ctr)
+        try:
+            prioritized_sample_(target, b, B=B, i=i, counter=ctr) if b.isprioritized() else uniform_sample_(target, b, B=B, i=ctr)
+        finally:
+            if want != had:      # the re-keying is this call's only: a later single-source draw from b uses b's own (seed, stream) again
+                set_sample_stream_(b, *had)
 
 
 def split_batches(N, fracs):

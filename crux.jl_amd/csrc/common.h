@@ -70,6 +70,7 @@ void* crux_pinned(crux_ctx* ctx, size_t bytes);
 hipError_t crux_hip_free(void* p);
 void crux_same_device_group_enter();
 void crux_same_device_group_leave();
+void crux_exec_destroy(crux_ctx* ctx);                 // exec.hip: frees the fused-step executor's device / pinned blocks
 #define hipFree(p) crux_hip_free((void*)(p))
 void crux_sync_before_free(crux_ctx* ctx);           // hipStreamSynchronize(ctx->stream) unless a same-device group exists (then the frees are parked anyway and the stream may hold a spinning learner)
 void crux_free_device(crux_ctx* ctx, void* p);      // stream-synchronised free (parked like every free while a same-device group exists)

@@ -214,6 +214,16 @@ int32_t crux_exec_begin(crux_ctx* c) {
   r->chain_tags.clear(); r->chain_base = 0; r->chain_ok = true;
   return CRUX_OK;
 }
+// frees everything a context's executor ever allocated (called by crux_ctx_destroy after the stream has drained)
+void crux_exec_destroy(crux_ctx* c) {
+  if (!c || !c->rec) return;
+  ExecRec* r = rec_of(c);
+  if (r->small) (void)hipFree(r->small);
+  if (r->d_ctr) (void)hipFree(r->d_ctr);
+  if (r->d_ops) (void)hipFree(r->d_ops);
+  if (r->h_stage) (void)hipHostFree(r->h_stage);
+  delete r; c->rec = nullptr;
+}
 void crux_exec_abort(crux_ctx* c) { if (c->rec) { ExecRec* r = rec_of(c); r->active = false; r->ops.clear(); r->readbacks.clear(); } }
 ExecOp* crux_exec_new_op(crux_ctx* c, int kid, unsigned nblocks) {
   ExecRec* r = rec_of(c); r->ops.emplace_back(); ExecOp* op = &r->ops.back();
@@ -249,7 +259,10 @@ static int32_t exec_schedule(crux_ctx* c, const std::vector<int>& phase) {
   std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return phase[a] < phase[b]; });
   std::vector<ExecOp> out(n);
   for (size_t k = 0; k < n; ++k) { out[k] = r->ops[idx[k]]; out[k].barrier = (k + 1 == n || (phase[idx[k + 1]] >> 2) != (phase[idx[k]] >> 2)) ? 1 : 0;
-    if ((phase[idx[k]] & 3) == 2) { if (k == 0 || (phase[idx[k - 1]] >> 2) != (phase[idx[k]] >> 2) || out[k].nblocks != 1 || out[k - 1].nblocks != 1) return crux_fail(c, CRUX_EHIP, "executor: a sequential op without a one-block predecessor in its phase");
+    if ((phase[idx[k]] & 3) == 2) {
+      // the in-block tail switch (EXEC_SWITCH_TAIL) knows these bodies only: anything else would be skipped silently
+      if (out[k].kid != OP_TD_HEAD && out[k].kid != OP_Q_HEAD) return crux_fail(c, CRUX_EHIP, "executor: op %d cannot run as a sequential tail", out[k].kid);
+      if (k == 0 || (phase[idx[k - 1]] >> 2) != (phase[idx[k]] >> 2) || out[k].nblocks != 1 || out[k - 1].nblocks != 1) return crux_fail(c, CRUX_EHIP, "executor: a sequential op without a one-block predecessor in its phase");
       out[k].barrier |= 2; } }
   r->ops.swap(out); return CRUX_OK;
 }
@@ -372,10 +385,14 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   // its remaining phases close up by THREE: the first forward layer of epoch e + 1 shares a launch with the beta-power advance of epoch e (the last phase, which writes
   // the two powers only; Adam of epoch e + 1 reads them nine phases later). The replay chain (leaf refresh -> root paths -> search -> gather) then hides the optimizer
   // tail instead of following it: 13 phases, 10 launches per chained epoch.
+  // The overlap is bounded by the replay tree: update_priorities! -> leaf re-sum -> root paths of epoch e sit at phases 4+L-sq .. 6+L-sq and read batch->d_indices / write
+  // the tree total, which the search of epoch e + 1 (phase 4+2L-sq with the full overlap of three) rewrites and probes. With fewer than three Dense layers the backward
+  // chain is too short to cover them, so the overlap shrinks to L phases there (search(e + 1) strictly after the root paths of e).
+  const int ov = (per && Ld < 3) ? (Ld < 1 ? 1 : Ld) : 3;
   auto tag = [&](size_t from, auto&& rule) { if (!fuse || !crux_exec_recording(c)) return; ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
     for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { plan_ok = false; p = 0; }
       const int sub = p >> 12; p &= 4095;
-      ph.push_back(ph_tag(base > 0 ? (p < 2 ? base - 3 + p : base + p - 3) : p, sub)); } };
+      ph.push_back(ph_tag(base > 0 ? (p < 2 ? base - ov + p : base + p - ov) : p, sub)); } };
   // the target (one block at B <= 256) and the loss head (one block) are a sequential pair: the head runs in the target's block, right after it, and every later
   // phase moves up by one (sq). Not in the persistent one-XCD form, whose workgroups walk the ops of a phase in lockstep.
   const int sq = (B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;
@@ -406,7 +423,7 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   if (fuse && crux_exec_recording(c) && rec_of(c)->chain) {     // chained: the caller (crux_dqn_epochs) schedules and runs the whole list
     ExecRec* r = rec_of(c);
     if (!(plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += (r->chain_base > 0 ? 4 : 7) + 2 * Ld - sq;
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += (r->chain_base > 0 ? 7 - ov : 7) + 2 * Ld - sq;
     return CRUX_OK;
   }
   if (fuse && crux_exec_recording(c) && plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }

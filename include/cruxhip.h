@@ -166,7 +166,9 @@ int32_t crux_buffer_indices(const crux_buffer* b, int64_t* out, int64_t n);
 /* prioritized replay (src/experience_buffer.jl:38-50,290-301,324-349) ---------------------------- */
 /* update_priorities!(b, I, v): v Float64 (v_is_f64=1) or Float32.                                 */
 int32_t crux_per_update(crux_buffer* b, const int64_t* I, const void* v, int32_t v_is_f64, int64_t n);
-/* same with device-resident ids (int64) and Float32 values (the td-error path, off_policy.jl:83).   */
+/* same with device-resident ids (int64) and Float32 values (the td-error path, off_policy.jl:83). Duplicate ids: the reference's scalar loop lets the LAST
+ * occurrence win (:296-298); that order is reproduced exactly for n <= 512. For 512 < n the winner among duplicates is unspecified -- harmless when duplicated
+ * ids carry equal values, which holds for td_error of the same row (the only caller inside the library); pass unique ids or equal values otherwise. */
 int32_t crux_per_update_device(crux_buffer* b, const int64_t* d_ids, const float* d_v, int64_t n);
 /* prioritized_sample!(target, source; i, B): `rands` = B Float64 uniforms (NULL => Philox draw with
  * counter `i`). Writes ids into target.indices, IS weights into source[:weight], gathers rows.     */

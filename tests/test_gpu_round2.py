@@ -307,20 +307,24 @@ def test_phase_records_in_global_memory_give_the_same_epochs(gpu_ctx, monkeypatc
         assert np.array_equal(x, y), np.abs(x - y).max()
 
 
-def test_chained_dqn_epochs_equal_single_epoch_calls(gpu_ctx):
+@pytest.mark.parametrize("dims", [[8, 256, 256, 4], [8, 256, 4], [128, 4]], ids=["L3", "L2", "L1"])
+def test_chained_dqn_epochs_equal_single_epoch_calls(gpu_ctx, dims):
     """crux_dqn_epochs (the c_opt.epochs epochs of one value_training recorded into one list, no host round trip between them) == the same epochs as
     separate crux_dqn_epoch calls: sampled rows, priorities, networks and infos, bit for bit -- with prioritized replay on a FULL ring (incremental tree
-    refresh inside the chain) and on a ring that is still filling (the chain is cut where the tree needs a plain rebuild)."""
+    refresh inside the chain) and on a ring that is still filling (the chain is cut where the tree needs a plain rebuild). Networks of two and of one Dense layer
+    have a backward chain shorter than the replay-tree refresh: the overlap of neighbouring epochs shrinks there (exec.hip `ov`; ADVICE r2: with the full overlap the
+    search of epoch e + 1 raced the root-path refresh of epoch e)."""
+    no = dims[0]
     def run(chained, fill):
         rng = np.random.default_rng(3); N, B = 20_000, 128
-        S, A = crux.ContinuousSpace(8), crux.DiscreteSpace(4)
+        S, A = crux.ContinuousSpace(no), crux.DiscreteSpace(4)
         buf = crux.ExperienceBuffer(S, A, N, prioritized=True); D = crux.buffer_like(buf, capacity=B)
         n0 = N if fill else N // 2
         a = np.zeros((4, n0), bool); a[rng.integers(0, 4, n0), np.arange(n0)] = True
-        buf.push_({"s": rng.normal(0, 1, (8, n0)).astype(np.float32), "a": a, "sp": rng.normal(0, 1, (8, n0)).astype(np.float32), "r": rng.normal(0, 1, (1, n0)).astype(np.float32),
+        buf.push_({"s": rng.normal(0, 1, (no, n0)).astype(np.float32), "a": a, "sp": rng.normal(0, 1, (no, n0)).astype(np.float32), "r": rng.normal(0, 1, (1, n0)).astype(np.float32),
                    "done": rng.random((1, n0)) < 0.02, "episode_end": np.zeros((1, n0), bool)})
         buf.update_priorities_(np.arange(1, n0 + 1), (np.abs(rng.normal(0, 1, n0)) + 1e-3).astype(np.float32))
-        q = crux.DiscreteNetwork(parity.chain([8, 256, 256, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=5)
+        q = crux.DiscreteNetwork(parity.chain(dims, ["relu"] * (len(dims) - 2) + ["identity"]), [1, 2, 3, 4], seed=5)
         qm = crux.clone_policy(q); q.attach_optimizer(crux.Adam(np.float32(1e-3)))
         ctx = q.ctx; infos = np.zeros((6, L.INFO_N), np.float32); rows = []
         if chained:
