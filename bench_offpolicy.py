@@ -176,7 +176,7 @@ def c1_cpu(N=20_000):
     import parity
     import bench
     B, cap, dN = 128, 1000, 4
-    o = O.OMlp([2, 8, 4], ["relu", "identity"]).init_glorot(1).adam_init(1e-3); ot = O.OMlp([2, 8, 4], ["relu", "identity"]).init_glorot(1)
+    o = O.OMlp([2, 8, 4], ["relu", "identity"]).init_glorot(1).adam_init(float(np.float32(3e-4))); ot = O.OMlp([2, 8, 4], ["relu", "identity"]).init_glorot(1)
     ob = O.OBuffer(2, 4, L.ACTION_DISCRETE, cap); obt = O.OBuffer(2, 4, L.ACTION_DISCRETE, B)
     oe = O.OEnv("gridworld", 1, 100, 0.95, 0)
     cfg = parity.rollout_cfg(True, False, "greedy_q"); cfg.eps_start, cfg.eps_stop, cfg.eps_steps = 1.0, 0.1, N // 2

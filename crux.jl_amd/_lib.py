@@ -196,7 +196,7 @@ INFO = {"loss": 0, "grad_norm": 1, "entropy": 2, "kl": 3, "clip_fraction": 4, "a
         "batches_trained": 7, "epochs_run": 8, "q1avg": 9, "q2avg": 10, "alpha": 11, "penalty": 12, "cur_cost": 13, "cost_loss": 14, "p_loss": 15}
 INFO_N = 16
 PROF = {"rollout": 0, "values": 1, "gae": 2, "whiten": 3, "train_actor": 4, "train_critic": 5, "per_scan": 6,
-        "per_search": 7, "gather": 8, "td_step": 9}
+        "per_search": 7, "gather": 8, "td_step": 9, "tiny_solve": 10}
 
 
 class CruxError(RuntimeError):

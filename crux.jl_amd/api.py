@@ -1591,20 +1591,62 @@ td_loss = _Loss("td")                # td_loss() (src/utils.jl:76-87)
 
 
 class OffPolicySolver:
-    """OffPolicySolver(; agent, S, N, dN=4, max_steps=100, c_opt, buffer_size=1000, buffer, buffer_init, target_fn, target_update)
-    (src/model_free/off_policy.jl:37-64). target_update defaults to polyak_average!(pi_minus, pi, 0.005) (:55)."""
+    """OffPolicySolver(; agent, S, N, dN=4, max_steps=100, c_opt, buffer_size=1000, buffer, buffer_init, target_fn, target_update, priority_fn,
+    post_sample_callback, post_batch_callback, pre_train_callback, extra_buffers, buffer_fractions) (src/model_free/off_policy.jl:37-64).
+
+    The function-valued fields (:53-63) accept what the reference accepts:
+      target_fn            a built-in name ("dqn", "softq", "sac", "ddpg", "td3": the fused device paths) or a callable (pi_minus, P, D, gamma; i) -> y of B
+                           Float32 targets (:56, called at :80)
+      priority_fn          None = td_error (utils.jl:112, :60) or a callable (pi, P, D, y) -> B non-negative values (:83)
+      target_update        None = polyak_average!(pi_minus, pi, tau) (:55) or a callable (pi_minus, pi; i=None) (:100, :108)
+      post_sample_callback (D; S, info) after every steps! with the freshly sampled rows as a dict of host arrays; columns the callback modifies are written
+                           back into the ring (:50, :125, :138)
+      post_batch_callback  (D; S, info) after every rand! with the staging buffer (:53, :77)
+      pre_train_callback   (S; info) once per iteration before value_training (:54, :140)
+      extra_buffers / buffer_fractions   further sources of rand! and the share of the minibatch each source gets (:62-63, :71)
+    A solver whose seams are all built-ins runs the fused epoch chains; any callable (or an extra buffer) selects the call-by-call form of the same loop, in
+    which every piece is its own C call and the callables run on the host between them -- the analogue of the reference calling user code between Flux calls."""
 
     def __init__(self, agent, S, N=1000, dN=4, max_steps=100, c_opt=None, buffer_size=1000, buffer=None, buffer_init=None, tau=0.005,
-                 prioritized=False, weighted_loss=False, i=0, a_opt=None, param_optimizers=None, P=None, target_fn="dqn", noise_seed=0, log=None, sample_seed=SAMPLE_SEED):
+                 prioritized=False, weighted_loss=False, i=0, a_opt=None, param_optimizers=None, P=None, target_fn="dqn", noise_seed=0, log=None, sample_seed=SAMPLE_SEED,
+                 target_update=None, priority_fn=None, post_sample_callback=None, post_batch_callback=None, pre_train_callback=None, extra_buffers=(),
+                 buffer_fractions=None, required_columns=()):
         self.agent, self.S, self.N, self.dN, self.max_steps, self.c_opt, self.i = agent, S, int(N), int(dN), int(max_steps), c_opt, int(i)
         self.log = log                         # LoggerParams (crux_jl_amd.logging) or None
         self.a_opt, self.param_optimizers, self.P, self.target_fn, self.noise_seed = a_opt, list(param_optimizers or []), dict(P or {}), target_fn, int(noise_seed)
-        self.buffer = buffer if buffer is not None else ExperienceBuffer(S, agent.space, buffer_size, prioritized=prioritized)
+        self.buffer = buffer if buffer is not None else ExperienceBuffer(S, agent.space, buffer_size, list(required_columns), prioritized=prioritized)
         self.buffer_init = buffer_init if buffer_init is not None else max(c_opt.batch_size, 200)
         self.tau, self.weighted_loss, self.sample_seed = float(tau), bool(weighted_loss), int(sample_seed)
+        self.target_update, self.priority_fn = target_update, priority_fn
+        self.post_sample_callback, self.post_batch_callback, self.pre_train_callback = post_sample_callback, post_batch_callback, pre_train_callback
+        self.extra_buffers = list(extra_buffers)
+        self.buffer_fractions = list(buffer_fractions) if buffer_fractions is not None else ([1.0] if not self.extra_buffers else None)
+        if self.extra_buffers and (self.buffer_fractions is None or len(self.buffer_fractions) != 1 + len(self.extra_buffers)):
+            raise ValueError("buffer_fractions needs one entry per source: the buffer and every extra buffer (off_policy.jl:62-63)")
         self.fused_epochs = True              # value_training's epoch loop through crux_dqn_epochs / crux_sac_epochs (recorded op lists run by the executor for wide networks)
         self.sampler, self.batch, self.history = None, None, []
         self._dy = self._derr = None
+
+    def custom_seams(self):
+        """True when a function-valued field is not the built-in: value_training then runs call by call with the callables on the host."""
+        return (callable(self.target_fn) or self.priority_fn is not None or self.target_update is not None or self.post_batch_callback is not None
+                or bool(self.extra_buffers))
+
+    def _sources(self):
+        return [self.buffer] + self.extra_buffers
+
+    def _rand(self, D, counter):
+        """rand!(D, S.buffer, S.extra_buffers...; fracs=S.buffer_fractions, i=S.i) (:71)"""
+        rand_(D, *self._sources(), i=self.i, fracs=self.buffer_fractions if self.extra_buffers else None, counter=counter, seed=self.sample_seed)
+
+    def _update_target(self, final=False):
+        """S.target_update(pi_minus, pi) (:100) / S.target_update(pi_minus, pi, i = S.i + 1 : S.i + dN) (:108)"""
+        if self.target_update is None:
+            polyak_average_(self.agent.pi_minus, self.agent.pi, self.tau)
+        elif final:
+            self.target_update(self.agent.pi_minus, self.agent.pi, i=range(self.i + 1, self.i + self.dN + 1))
+        else:
+            self.target_update(self.agent.pi_minus, self.agent.pi)
 
 
 def _value_training_sac(solver, D, gamma):
@@ -1621,7 +1663,8 @@ def _value_training_sac(solver, D, gamma):
     if solver._dy is None:
         solver._dy = ctx.alloc(4 * B)
     infos, lib, raw = [], ctx.lib, np.zeros(L.INFO_N, np.float32)
-    if solver.fused_epochs:
+    fused = solver.fused_epochs and not solver.custom_seams()
+    if fused:
         # the whole epoch loop (:69-104) in one C call: chains of up to 8 epochs per recorded list, no host round trip between them (cruxhip.h: crux_sac_epochs);
         # same pieces, order and draws as the epoch-by-epoch branch below
         _set_stream_for(buf, solver.sample_seed)
@@ -1637,12 +1680,17 @@ def _value_training_sac(solver, D, gamma):
             if epoch % a_opt.update_every == 0:
                 info.update({a_opt.name + "loss": float(ra[epoch, 0]), a_opt.name + "grad_norm": float(ra[epoch, 1]), "entropy": float(ra[epoch, L.INFO["entropy"]])})
             infos.append(info)
-    for epoch in range(0 if solver.fused_epochs else c_opt.epochs):
+    for epoch in range(0 if fused else c_opt.epochs):
         ctr = solver.i * c_opt.epochs + epoch                                                          # one Philox counter block per epoch
         upd_c, upd_a = epoch % c_opt.update_every == 0, epoch % a_opt.update_every == 0                # :91, :96
-        rand_(D, buf, i=solver.i, counter=ctr, seed=solver.sample_seed)                                # :71 rand!(D, buffer, i=S.i)
+        solver._rand(D, ctr)                                                                           # :71 rand!(D, buffer, extra_buffers...; fracs, i=S.i)
         info = {}
-        ctx.check(lib.crux_sac_target(A.h, Qm.N1.h, Qm.N2.h, la.h, D.h, float(gamma), solver.noise_seed, 3 * ctr, solver._dy))           # :80
+        if solver.post_batch_callback is not None:
+            solver.post_batch_callback(D, S=solver, info=info)                                         # :77
+        if callable(solver.target_fn):
+            _upload_target(solver, D, solver.target_fn(pim, solver.P, D, gamma, i=solver.i))           # :80 with the caller's target
+        else:
+            ctx.check(lib.crux_sac_target(A.h, Qm.N1.h, Qm.N2.h, la.h, D.h, float(gamma), solver.noise_seed, 3 * ctr, solver._dy))       # :80
         ctx.check(lib.crux_sac_temp_step(A.h, la.h, D.h, float(solver.P["SAC_H_target"]), solver.noise_seed, 3 * ctr + 1, _vp(raw)))     # :86-88
         info.update({t_opt.name + "loss": float(raw[0]), t_opt.name + "grad_norm": float(raw[1]), "SAC alpha": float(raw[L.INFO["alpha"]])})
         if upd_c:                                                                                      # :91
@@ -1651,7 +1699,7 @@ def _value_training_sac(solver, D, gamma):
         if upd_a:                                                                                      # :96
             ctx.check(lib.crux_sac_actor_step(A.h, Q.N1.h, Q.N2.h, la.h, D.h, solver.noise_seed, 3 * ctr + 2, _vp(raw)))                 # :97
             info.update({a_opt.name + "loss": float(raw[0]), a_opt.name + "grad_norm": float(raw[1]), "entropy": float(raw[L.INFO["entropy"]])})
-            polyak_average_(pim, pi, solver.tau)                                                       # :100 (target update only when the actor trains)
+            solver._update_target()                                                                    # :100 (target update only when the actor trains)
         infos.append(info)
     keys = {k for d in infos for k in d}
     return {k: float(np.mean([d[k] for d in infos if k in d])) for k in keys}      # aggregate_info: mean over the dicts that have the key (logging.jl:60-66)
@@ -1674,7 +1722,7 @@ def _value_training_dpg(solver, D, gamma):
         solver._dy = ctx.alloc(4 * B)
     sm = solver.P.get("pi_smooth") if solver.target_fn == "td3" else None
     infos, lib, raw = [], ctx.lib, np.zeros(L.INFO_N, np.float32)
-    fused = solver.fused_epochs and (not twin or solver.target_fn == "td3")
+    fused = solver.fused_epochs and (not twin or solver.target_fn == "td3") and not solver.custom_seams()
     if fused:
         # the whole epoch loop (:69-104) in one C call: chains of up to 8 epochs per recorded list (cruxhip.h: crux_dpg_epochs); same pieces, order and draws as below
         _set_stream_for(buf, solver.sample_seed)
@@ -1694,8 +1742,10 @@ def _value_training_dpg(solver, D, gamma):
             infos.append(info)
     for epoch in range(0 if fused else c_opt.epochs):
         ctr = solver.i * c_opt.epochs + epoch
-        rand_(D, buf, i=solver.i, counter=ctr, seed=solver.sample_seed)                                # :71 rand!(D, buffer, i=S.i)
+        solver._rand(D, ctr)                                                                           # :71 rand!(D, buffer, extra_buffers...; fracs, i=S.i)
         info = {}
+        if solver.post_batch_callback is not None:
+            solver.post_batch_callback(D, S=solver, info=info)                                         # :77
         ctx.check(lib.crux_dpg_target(Am.h, (Qm.N1 if twin else Qm).h, Qm.N2.h if (twin and solver.target_fn == "td3") else None, D.h, float(gamma),
                                       sm.sigma if sm else -1.0, sm.eps_min if sm else 0.0, sm.eps_max if sm else 0.0, sm.a_min if sm else 0.0, sm.a_max if sm else 0.0,
                                       solver.noise_seed, ctr, solver._dy))                             # :80
@@ -1710,7 +1760,7 @@ def _value_training_dpg(solver, D, gamma):
         if epoch % a_opt.update_every == 0:                                                            # :96 (TD3's delayed policy update = a_opt.update_every)
             ctx.check(lib.crux_dpg_actor_step(A.h, (Q.N1 if twin else Q).h, D.h, _vp(raw)))             # :97
             info.update({a_opt.name + "loss": float(raw[0]), a_opt.name + "grad_norm": float(raw[1])})
-            polyak_average_(pim, pi, solver.tau)                                                       # :100
+            solver._update_target()                                                                    # :100
         infos.append(info)
     keys = {k for d in infos for k in d}
     return {k: float(np.mean([d[k] for d in infos if k in d])) for k in keys}                          # aggregate_info: mean over the dicts that have the key (logging.jl:60-66)
@@ -1721,10 +1771,19 @@ def _set_stream_for(buf, seed):
         set_sample_stream_(buf, int(seed), getattr(buf, "sample_stream", 0))
 
 
+def _upload_target(solver, D, y):
+    """the targets a user target_fn returned (1 x B or B Float32, like the reference's y) into the device block the loss heads read"""
+    y = np.ascontiguousarray(np.asarray(y, np.float32).reshape(-1))
+    if y.size != D.capacity:
+        raise ValueError("target_fn returned %d targets for a batch of %d" % (y.size, D.capacity))
+    solver.buffer.ctx.h2d(solver._dy, y)
+    return y
+
+
 def value_training(solver, D, gamma):
     """value_training(S, D, gamma) (src/model_free/off_policy.jl:66-111) for the critic-only (DQN) case: per epoch
-    rand! -> dqn_target -> [update_priorities!(td_error)] -> train!(td_loss); then target_update once (:108)."""
-    if solver.target_fn == "sac":
+    rand! -> post_batch_callback -> target_fn -> [update_priorities!(priority_fn)] -> train!(td_loss); then target_update once (:108)."""
+    if solver.target_fn == "sac" or (callable(solver.target_fn) and solver.a_opt is not None and isinstance(solver.agent.pi.A, GaussianPolicy)):
         return _value_training_sac(solver, D, gamma)
     if solver.target_fn in ("ddpg", "td3"):
         return _value_training_dpg(solver, D, gamma)
@@ -1734,7 +1793,7 @@ def value_training(solver, D, gamma):
     if solver._dy is None:
         solver._dy, solver._derr = ctx.alloc(4 * B), ctx.alloc(4 * B)
     infos = []
-    fused = solver.target_fn in ("dqn", "softq") and solver.fused_epochs
+    fused = solver.target_fn in ("dqn", "softq") and solver.fused_epochs and not solver.custom_seams()
     if fused:
         # the whole epoch loop (:69-93) in one C call: for wide networks all c_opt.epochs epochs are recorded into one list and run without a host round trip
         # between them (cruxhip.h: crux_dqn_epochs); same steps, same order, same draws as the separate calls below
@@ -1747,27 +1806,41 @@ def value_training(solver, D, gamma):
             ctx.check(ctx.lib.crux_dqn_epochs(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, _vp(raws)))
         infos = [{p.name + "loss": float(r[0]), p.name + "grad_norm": float(r[1]), "Qavg": float(r[2])} for r in raws]
     for epoch in range(0 if fused else p.epochs):
-        raw = np.zeros(L.INFO_N, np.float32)
-        rand_(D, buf, i=solver.i, counter=solver.i * p.epochs + epoch, seed=solver.sample_seed)        # :71 rand!(D, buffer, i=S.i): beta(S.i); the Philox counter is unique per draw
-        if solver.target_fn == "softq":
+        raw = np.zeros(L.INFO_N, np.float32); info = {}
+        solver._rand(D, solver.i * p.epochs + epoch)                                                   # :71 rand!(D, buffer, extra_buffers...; fracs, i=S.i): beta(S.i); the Philox counter is unique per draw
+        if solver.post_batch_callback is not None:
+            solver.post_batch_callback(D, S=solver, info=info)                                         # :77
+        y_host = None
+        if callable(solver.target_fn):
+            y_host = _upload_target(solver, D, solver.target_fn(pim, solver.P, D, gamma, i=solver.i))  # :80 with the caller's target
+        elif solver.target_fn == "softq":
             ctx.check(ctx.lib.crux_softq_target(pim.h, D.h, float(gamma), float(solver.P["alpha"]), solver._dy))   # :80  softq.jl:4-13
         else:
             ctx.check(ctx.lib.crux_dqn_target(pim.h, D.h, float(gamma), solver._dy))                    # :80  dqn.jl:4-6
-        if buf.isprioritized():                                                                        # :83 update_priorities!(buffer, D.indices, td_error) and :91-93 train!
+        if buf.isprioritized() and solver.priority_fn is not None:                                     # :83 with the caller's priority function
+            if y_host is None:
+                y_host = np.empty(B, np.float32); ctx.d2h(solver._dy, y_host)
+            v = np.ascontiguousarray(np.asarray(solver.priority_fn(pi, solver.P, D, y_host), np.float32).reshape(-1))
+            buf.update_priorities_(D.indices[:B] + 1, v)
+            ctx.check(ctx.lib.crux_td_step(pi.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))   # :91-93
+        elif buf.isprioritized():                                                                      # :83 update_priorities!(buffer, D.indices, td_error) and :91-93 train!
             ctx.check(ctx.lib.crux_td_step_with_error(pi.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, solver._derr, _vp(raw)))   # one forward pass for both
             ctx.check(ctx.lib.crux_per_update_device(buf.h, ctx.lib.crux_buffer_indices_ptr(D.h), solver._derr, B))
         else:
             ctx.check(ctx.lib.crux_td_step(pi.h, D.h, solver._dy, 1 if solver.weighted_loss else 0, _vp(raw)))   # :91-93
-        infos.append({p.name + "loss": float(raw[0]), p.name + "grad_norm": float(raw[1]), "Qavg": float(raw[2])})
-    polyak_average_(pim, pi, solver.tau)                                                               # :108
-    return {k: float(np.mean([d[k] for d in infos])) for k in infos[0]}                                # aggregate_info (logging.jl:60-66)
+        info.update({p.name + "loss": float(raw[0]), p.name + "grad_norm": float(raw[1]), "Qavg": float(raw[2])})
+        infos.append(info)
+    solver._update_target(final=True)                                                                  # :108
+    keys = {k for d in infos for k in d}
+    return {k: float(np.mean([d[k] for d in infos if k in d])) for k in keys}                          # aggregate_info: mean over the dicts that have the key (logging.jl:60-66)
 
 
 def _solve_small_dqn(solver, D, s, gamma, i, stop):
     """The iterations i, i + dN, ..., stop of solve(::OffPolicySolver) for a small DQN as a few launches of the one-workgroup solve kernel (cruxhip.h:
     crux_dqn_small_solve); returns the first iteration index it did NOT run (== i when the configuration needs the call-by-call loop)."""
     pe, pi, buf = solver.agent.pi_explore, solver.agent.pi, solver.buffer
-    if not (solver.fused_epochs and solver.target_fn == "dqn" and solver.log is None and isinstance(pe, EpsGreedyPolicy) and isinstance(pi, DiscreteNetwork)
+    if not (solver.fused_epochs and solver.target_fn == "dqn" and not solver.custom_seams() and solver.post_sample_callback is None and solver.pre_train_callback is None
+            and solver.log is None and isinstance(pe, EpsGreedyPolicy) and isinstance(pi, DiscreteNetwork)
             and not buf.isprioritized() and not solver.weighted_loss and max(pi.network.dims) < 128 and D.capacity <= 256 and s.n_envs <= 4 and solver.dN % s.n_envs == 0 and i <= stop):
         return i
     p, ctx = solver.c_opt, buf.ctx
@@ -1789,6 +1862,21 @@ def _solve_small_dqn(solver, D, s, gamma, i, stop):
     return i
 
 
+def _post_sample(solver, n, info):
+    """steps!(...; cb = D -> S.post_sample_callback(D, S=S, info=info)) (off_policy.jl:125,138; sampler.jl:151): the callback sees the n rows this steps!
+    produced (host copies of the ring's newest rows, oldest first) and whatever it changes in them is written back into the ring."""
+    if solver.post_sample_callback is None:
+        return
+    buf = solver.buffer
+    ids = np.asarray(buf.get_last_N_indices(n), np.int64)       # 1-based ring rows of this steps!, oldest first
+    rows = buf.minibatch(ids)
+    before = {k: v.copy() for k, v in rows.items()}
+    solver.post_sample_callback(rows, S=solver, info=info)
+    for k, v in rows.items():
+        if not np.array_equal(v, before[k], equal_nan=(v.dtype.kind == "f")):
+            col = buf[k]; col[..., ids - 1] = v; buf[k] = col
+
+
 def _solve_off_policy(solver, mdp):
     """POMDPs.solve(S::OffPolicySolver, mdp) (src/model_free/off_policy.jl:113-150), logging left out."""
     gamma = np.float32(discount(mdp))
@@ -1801,13 +1889,19 @@ def _solve_off_policy(solver, mdp):
     if nfill > 0:
         solver.i += nfill                                                                              # :125 (Q12: advanced BEFORE sampling)
         steps_(s, solver.buffer, Nsteps=nfill, explore=True, i=solver.i, want_info=False)
+        _post_sample(solver, nfill, {})
     i = solver.i
     stop = istart + solver.N - solver.dN
     i = _solve_small_dqn(solver, D, s, gamma, i, stop)                                                 # whole iterations in one launch where the configuration allows it
     while i <= stop:                                                                                   # :133
         solver.i = i
         steps_(s, solver.buffer, Nsteps=solver.dN, explore=True, i=i, want_info=False)                # :138 (its info is not used by this loop)
+        it_info = {}
+        _post_sample(solver, solver.dN, it_info)                                                      # :138 cb = D -> S.post_sample_callback(D, S=S, info=info)
+        if solver.pre_train_callback is not None:
+            solver.pre_train_callback(solver, info=it_info)                                           # :140
         solver.history.append(value_training(solver, D, gamma))                                       # :143
+        solver.history[-1].update({k: v for k, v in it_info.items() if k not in solver.history[-1]})  # :146 log(..., training_info, info)
         if solver.log is not None:                                                                     # :146 log(S.log, S.i, infos..., S=S)
             from . import logging as _lg
             if solver.log.sampler is None:

@@ -927,14 +927,14 @@ extern "C" int32_t crux_dqn_small_solve(crux_mlp* net, crux_mlp* target_net, cru
   const bool tiny = pn.L == 2 && pn.dims[0] == 2 && pn.dims[1] == 8 && pn.dims[2] == 4 && pn.acts[0] == CRUX_ACT_RELU && pn.acts[1] == CRUX_ACT_IDENTITY && pn.n_extra == 0 &&
                     target_net->nd.L == 2 && target_net->nd.dims[1] == 8 && target_net->nd.acts[0] == CRUX_ACT_RELU && E == 1 && B <= 128 && dN <= 64 && tiny_lds <= 60 * 1024 &&
                     !getenv("CRUX_SMALL_SOLVE_GENERIC");
-  crux_prof_begin(c, CRUX_PROF_TD_STEP);
+  crux_prof_begin(c, tiny ? CRUX_PROF_TINY_SOLVE : CRUX_PROF_TD_STEP);
   if (tiny) hipLaunchKernelGGL((k_dqn_tiny_solve<2, 8, 4>), dim3(1), dim3(64), tiny_lds, c->stream, q);
   else {
     static size_t attr_set = 0;
     if (lds > attr_set) { HIPCHK(c, hipFuncSetAttribute((const void*)k_dqn_small_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = lds; }
     hipLaunchKernelGGL(k_dqn_small_solve, dim3(1), dim3(256), lds, c->stream, q);
   }
-  crux_prof_end(c, CRUX_PROF_TD_STEP);
+  crux_prof_end(c, tiny ? CRUX_PROF_TINY_SOLVE : CRUX_PROF_TD_STEP);
   int32_t rc = crux_launch_check(c, "k_dqn_small_solve"); if (rc) return rc;
   int32_t hst9[9] = {0}; int32_t hst[2];
   HIPCHK(c, hipMemcpyAsync(hst9, q.status, sizeof hst9, hipMemcpyDeviceToHost, c->stream));

@@ -60,7 +60,8 @@ int32_t crux_memcpy_d2h(crux_ctx* ctx, void* dst, const void* d_src, int64_t byt
 /* kernel timing on the context's stream (HIP events). slot = one of CRUX_PROF_*.                */
 enum { CRUX_PROF_ROLLOUT = 0, CRUX_PROF_VALUES = 1, CRUX_PROF_GAE = 2, CRUX_PROF_WHITEN = 3,
        CRUX_PROF_TRAIN_ACTOR = 4, CRUX_PROF_TRAIN_CRITIC = 5, CRUX_PROF_PER_SCAN = 6,
-       CRUX_PROF_PER_SEARCH = 7, CRUX_PROF_GATHER = 8, CRUX_PROF_TD_STEP = 9, CRUX_PROF_NSLOTS = 16 };
+       CRUX_PROF_PER_SEARCH = 7, CRUX_PROF_GATHER = 8, CRUX_PROF_TD_STEP = 9,
+       CRUX_PROF_TINY_SOLVE = 10 /* launches of the wave-resident k_dqn_tiny_solve (the README shape) */, CRUX_PROF_NSLOTS = 16 };
 int32_t crux_prof_enable(crux_ctx* ctx, int32_t on);
 int32_t crux_prof_reset(crux_ctx* ctx);
 /* returns accumulated milliseconds and launch count for a slot (synchronises the stream). */

@@ -161,7 +161,9 @@ const TARGET_KL = IdDict{Any,Float32}()
 target_kl_of(p) = get(TARGET_KL, p, -1f0)
 """PPO(...) with the learners on the device: Crux.PPO's own constructor (ppo.jl:40-66) + the target_kl it captured, remembered for the kernel."""
 function HipPPO(; target_kl=0.012f0, kwargs...)
-    𝒮 = Crux.PPO(; target_kl=target_kl, kwargs...)
+    # post_batch_callback: PPO's own `𝒟[:advantage] .= whiten(𝒟[:advantage])` (ppo.jl:61) works on a HipBuffer through ColumnRef (a host round trip of the column);
+    # this replaces it by the device kernel of the same arithmetic. A splatted keyword given twice takes the later value, so a caller's own callback still wins.
+    𝒮 = Crux.PPO(; target_kl=target_kl, post_batch_callback=(𝒟; kw...) -> (𝒟 isa HipBuffer ? whiten!(𝒟, :advantage) : (𝒟[:advantage] .= Crux.whiten(𝒟[:advantage]))), kwargs...)
     TARGET_KL[𝒮.a_opt] = Float32(target_kl)
     𝒮
 end
@@ -351,5 +353,118 @@ end
 #   huber(y, mb) = (d = y .- mb[:return]; a = abs.(d); (mean(ifelse.(a .< 1, 0.5f0 .* d .^ 2, a .- 0.5f0)), clamp.(d, -1, 1) ./ length(d)))
 #   l2(θ; λ=1f-4) = (λ * sum(abs2, θ), 2λ .* θ)
 #   train_custom!(V, huber, 𝒮.c_opt, minibatch(𝒟, 1:128); regularizer_grad=l2)
+
+# ---------------------------------------------------------------------------------------------------- the solve entry seam
+# The reference's `solve` builds its own buffer and sampler from the policy's device (src/model_free/on_policy.jl:80-85, off_policy.jl:113-117, src/devices.jl:1-8):
+#     𝒟 = ExperienceBuffer(𝒮.S, 𝒮.agent.space, 𝒮.ΔN, 𝒮.required_columns, device=device(𝒮.agent.π));   s = Sampler(mdp, 𝒮.agent, ...)
+# Neither constructor can be re-pointed by dispatch (keyword arguments do not dispatch, and re-defining the methods would replace Crux's own), so the hook is `solve` itself,
+# on the ENVIRONMENT argument: an `HipMDP` names one of the library's device environments, and `solve(𝒮, ::HipMDP)` below is the reference's loop with the device buffer and
+# sampler in the two places where the reference constructs the host ones. Everything inside the loop dispatches on HipSampler / HipBuffer / HipNetwork:
+#     steps!(::HipSampler, ::HipBuffer)                     (this file)  <- sampler.jl:139-173
+#     𝒮.post_batch_callback(𝒟::HipBuffer)                    getindex / setindex! / `.=` on a HipBuffer column (this file; PPO's whiten callback, ppo.jl:61, runs unchanged)
+#     policy_gradient_training(::OnPolicySolver, ::HipBuffer) (this file) <- on_policy.jl:56-78
+#     value_training(::OffPolicySolver, ::HipBuffer, γ)       (this file) <- off_policy.jl:66-111
+# `solve(𝒮, mdp)` with a plain POMDPs environment is untouched and stays on the CPU path.
+"""An environment that lives in the rollout kernel (cruxhip.h CRUX_ENV_*): `kind` 0 CartPole-v1, 1 Pendulum-v1, 2 SimpleGridWorld, 3/4 the synthetic dynamics;
+`n_envs` independent-seed copies are stepped together (env-major, SURVEY §8a R7). `host` optionally keeps the POMDPs model for evaluation loggers."""
+struct HipMDP{M} <: POMDPs.MDP{Vector{Float32},Any}
+    ctx::Ctx; kind::Int32; n_envs::Int; seed::UInt64; γ::Float32; host::M
+end
+HipMDP(ctx::Ctx, kind::Integer; n_envs=1, seed=0, γ=0.99f0, host=nothing) = HipMDP(ctx, Int32(kind), Int(n_envs), UInt64(seed), Float32(γ), host)
+POMDPs.discount(m::HipMDP) = m.γ
+HipSampler(m::HipMDP, agent; S=nothing, max_steps=100, λ=NaN32, kw...) = HipSampler(m.ctx, m.kind, agent; n_envs=m.n_envs, max_steps=max_steps, γ=m.γ, λ=λ, S=S, seed=m.seed)
+
+# device(π) (src/devices.jl:1-8, policies.jl:28): a marker the reference's `device(𝒮.agent.π)` call sites can receive
+hip(x) = x
+Crux.device(π::HipNetwork) = hip
+Crux.device(π::Crux.ActorCritic{<:HipNetwork}) = hip
+ctx_of(π::HipNetwork) = π.ctx
+ctx_of(π) = ctx_of(Crux.actor(π))
+# the greedy action for evaluation samplers (policies.jl:124,96): argmax over the outputs of a categorical / Q head, the network output otherwise
+function POMDPs.action(π::HipNetwork, s::AbstractVector)
+    y = vec(POMDPs.value(π, reshape(Float32.(s), :, 1)))
+    (π.head == HEAD_CATEGORICAL || π.head == HEAD_GREEDY_Q) && !isnothing(π.outputs) ? π.outputs[argmax(y)] : y
+end
+Crux.action_space(π::HipNetwork) = isnothing(π.outputs) ? Crux.ContinuousSpace(Int(π.dims[end])) : Crux.DiscreteSpace(length(π.outputs), π.outputs)
+
+# ---- columns of a HipBuffer as the callbacks of the reference use them: 𝒟[:r], 𝒟[:advantage] .= whiten(𝒟[:advantage]) (ppo.jl:44,61)
+col_eltype(b::HipBuffer, k::Symbol) = k in (:done, :episode_end) ? Bool : k === :a && b.discrete ? Bool : k in (:t, :i) ? Int64 : Float32
+col_rows(b::HipBuffer, k::Symbol) = k in (:s, :sp) ? b.obs_dim : k === :a ? b.act_dim : 1
+function Base.getindex(b::HipBuffer, k::Symbol)                                  # b[key] = view(b.data[key], :, 1:length(b)) (experience_buffer.jl:176) -- a host copy here
+    n = length(b); out = Matrix{col_eltype(b, k)}(undef, col_rows(b, k), n)
+    check(b.ctx, ccall((:crux_buffer_read_column, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64), b.h, COL[k], out, n)); out
+end
+function Base.setindex!(b::HipBuffer, v, k::Symbol)
+    n = length(b); a = Matrix{col_eltype(b, k)}(undef, col_rows(b, k), n); a .= v
+    check(b.ctx, ccall((:crux_buffer_write_column, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64), b.h, COL[k], a, n)); v
+end
+struct ColumnRef; b::HipBuffer; k::Symbol; end                                  # the left-hand side of `𝒟[k] .= rhs`
+Base.dotview(b::HipBuffer, k::Symbol) = ColumnRef(b, k)
+Base.Broadcast.materialize!(dest::ColumnRef, bc::Base.Broadcast.Broadcasted) = (dest.b[dest.k] = Base.Broadcast.materialize(bc); dest)
+Base.Broadcast.materialize!(dest::ColumnRef, x::AbstractArray) = (dest.b[dest.k] = x; dest)
+Crux.capacity(b::HipBuffer) = Int(ccall((:crux_buffer_capacity, LIB), Int64, (Ptr{Cvoid},), b.h))
+Crux.extra_columns(b::HipBuffer) = [k for k in b.keys if !(k in (:s, :a, :sp, :r, :done, :episode_end))]   # experience_buffer.jl:178
+"""buffer_like(b; capacity) (experience_buffer.jl:82-85) for the staging buffer of an off-policy solver"""
+hip_buffer_like(b::HipBuffer, S, A; capacity) = HipBuffer(b.ctx, S, A, capacity, Crux.extra_columns(b); prioritized=b.prioritized, β=b.β)
+"""The replay buffer of an OffPolicySolver on the device: the solver's constructor made a host ExperienceBuffer (off_policy.jl:58); its rows (if any) move over once."""
+function to_hip(ctx::Ctx, b::Crux.ExperienceBuffer, S, A)
+    extras = [k for k in keys(b.data) if !(k in (:s, :a, :sp, :r, :done, :episode_end))]
+    h = HipBuffer(ctx, S, A, Crux.capacity(b), extras; prioritized=Crux.isprioritized(b))
+    length(b) > 0 && push!(h, Dict{Symbol,AbstractArray}(k => collect(b[k]) for k in keys(b.data)))
+    h
+end
+to_hip(ctx::Ctx, b::HipBuffer, S, A) = b
+
+"""solve(𝒮::OnPolicySolver, mdp) (src/model_free/on_policy.jl:80-109) for a device environment. Requires 𝒮.agent.π = ActorCritic(HipNetwork, HipNetwork)."""
+function POMDPs.solve(𝒮::Crux.OnPolicySolver, mdp::HipMDP)
+    ctx = ctx_of(𝒮.agent.π)
+    𝒟 = HipBuffer(ctx, 𝒮.S, 𝒮.agent.space, 𝒮.ΔN, Symbol[𝒮.required_columns...])                                # :82  ExperienceBuffer(...; device=device(π))
+    γ, λ = Float32(POMDPs.discount(mdp)), 𝒮.λ_gae                                                               # :83
+    s = HipSampler(mdp, 𝒮.agent; S=𝒮.S, λ=λ, max_steps=𝒮.max_steps)                                            # :84  Sampler(mdp, 𝒮.agent, ...)
+    evaluating = !isnothing(𝒮.log) && !isnothing(mdp.host)                                                      # the reference's loggers roll out on a host Sampler (logging.jl:73)
+    evaluating && isnothing(𝒮.log.sampler) && (𝒮.log.sampler = Crux.Sampler(mdp.host, 𝒮.agent, S=𝒮.S, max_steps=𝒮.max_steps))   # :85
+    evaluating && Crux.log(𝒮.log, 𝒮.i, 𝒮=𝒮)                                                                    # :88
+    for 𝒮.i = range(𝒮.i, stop=𝒮.i + 𝒮.N - 𝒮.ΔN, step=𝒮.ΔN)                                                     # :91
+        info = Dict()
+        Crux.steps!(s, 𝒟, Nsteps=𝒮.ΔN, explore=true, i=𝒮.i, reset=true, cb=(D) -> 𝒮.post_sample_callback(D, info=info, 𝒮=𝒮))       # :96  -> steps!(::HipSampler, ::HipBuffer)
+        𝒮.post_batch_callback(𝒟, info=info, 𝒮=𝒮)                                                                # :99  PPO: 𝒟[:advantage] .= whiten(𝒟[:advantage]) through ColumnRef
+        training_info = Crux.policy_gradient_training(𝒮, 𝒟)                                                    # :102 -> policy_gradient_training(::OnPolicySolver, ::HipBuffer)
+        evaluating && Crux.log(𝒮.log, 𝒮.i + 1:𝒮.i + 𝒮.ΔN, training_info, info, 𝒮=𝒮)                             # :105
+    end
+    𝒮.i += 𝒮.ΔN                                                                                                 # :107
+    𝒮.agent.π
+end
+
+"""solve(𝒮::OffPolicySolver, mdp) (src/model_free/off_policy.jl:113-150) for a device environment. Requires HipNetwork policies in 𝒮.agent (π, π⁻)."""
+function POMDPs.solve(𝒮::Crux.OffPolicySolver, mdp::HipMDP)
+    ctx = ctx_of(𝒮.agent.π)
+    𝒮.buffer = to_hip(ctx, 𝒮.buffer, 𝒮.S, 𝒮.agent.space)                                                        # the replay ring the constructor made (:58), on the device
+    𝒟 = hip_buffer_like(𝒮.buffer, 𝒮.S, 𝒮.agent.space; capacity=𝒮.c_opt.batch_size)                              # :115 buffer_like(𝒮.buffer, capacity=batch_size, device=device(π))
+    γ = Float32(POMDPs.discount(mdp))                                                                           # :116
+    s = HipSampler(mdp, 𝒮.agent; S=𝒮.S, max_steps=𝒮.max_steps)                                                 # :117 Sampler(mdp, 𝒮.agent, ...)
+    evaluating = !isnothing(𝒮.log) && !isnothing(mdp.host)
+    evaluating && isnothing(𝒮.log.sampler) && (𝒮.log.sampler = Crux.Sampler(mdp.host, 𝒮.agent, S=𝒮.S, max_steps=𝒮.max_steps))   # :118
+    info = Dict()
+    Nfill = max(0, 𝒮.buffer_init - length(𝒮.buffer)); istart = 𝒮.i                                              # :122-123
+    if Nfill > 0
+        𝒮.i += Nfill                                                                                            # :125
+        Crux.steps!(s, 𝒮.buffer, Nsteps=Nfill, explore=true, i=𝒮.i, cb=(D) -> 𝒮.post_sample_callback(D, 𝒮=𝒮, info=info))             # :126
+    end
+    evaluating && Crux.log(𝒮.log, 𝒮.i, info, 𝒮=𝒮)                                                              # :130
+    for 𝒮.i in range(𝒮.i, stop=istart + 𝒮.N - 𝒮.ΔN, step=𝒮.ΔN)                                                 # :133
+        info = Dict()
+        Crux.steps!(s, 𝒮.buffer, Nsteps=𝒮.ΔN, explore=true, i=𝒮.i, cb=(D) -> 𝒮.post_sample_callback(D, 𝒮=𝒮, info=info))            # :138
+        𝒮.pre_train_callback(𝒮, info=info)                                                                      # :140
+        training_info = Crux.value_training(𝒮, 𝒟, γ)                                                            # :143 -> value_training(::OffPolicySolver, ::HipBuffer, γ)
+        evaluating && Crux.log(𝒮.log, 𝒮.i + 1:𝒮.i + 𝒮.ΔN, training_info, info, 𝒮=𝒮)                             # :146
+    end
+    𝒮.i += 𝒮.ΔN                                                                                                 # :148
+    𝒮.agent.π
+end
+# What a user writes (README / examples/rl/cartpole.jl, three changed lines -- the environment and the two networks):
+#     ctx = CruxHIP.Ctx(0); mdp = CruxHIP.HipMDP(ctx, 0; n_envs=32, host=GymPOMDP(:CartPole))
+#     A() = CruxHIP.HipNetwork(ctx, DiscreteNetwork(Chain(Dense(4, 64, relu), Dense(64, 64, relu), Dense(64, 2)), [1, 2]))
+#     V() = CruxHIP.HipNetwork(ctx, ContinuousNetwork(Chain(Dense(4, 64, relu), Dense(64, 64, relu), Dense(64, 1))))
+#     solve(CruxHIP.HipPPO(π=ActorCritic(A(), V()), S=state_space(mdp.host), N=65536 * 20, ΔN=65536), mdp)      # dispatches to the method above
 
 end # module

@@ -1,0 +1,271 @@
+"""GPU parity added in round 3: the README example (BASELINE configs[0]) through the kernel bench.py times for it, against the oracle's solve loop;
+function-valued seams of OffPolicySolver; teacher-forced windows of the off-policy learners at the C4 dimensions."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity
+from parity import L, O, crux
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_readme_dqn(N, dN=4, B=128, cap=1000, init=200, seed_net=1, seed_env=0, max_steps=100):
+    """The oracle's restatement of solve(::OffPolicySolver) (off_policy.jl:113-150, :66-111) for DQN on SimpleGridWorld at the README's shapes
+    (the loop bench_offpolicy.c1_cpu times as the CPU baseline of configs[0])."""
+    o = O.OMlp([2, 8, 4], ["relu", "identity"]).init_glorot(seed_net).adam_init(float(np.float32(3e-4)))      # TrainingParams default Adam(3f-4) (training.jl:3)
+    ot = O.OMlp([2, 8, 4], ["relu", "identity"]).init_glorot(seed_net)
+    ob = O.OBuffer(2, 4, L.ACTION_DISCRETE, cap); obt = O.OBuffer(2, 4, L.ACTION_DISCRETE, B)
+    oe = O.OEnv("gridworld", 1, max_steps, 0.95, seed_env)
+    cfg = parity.rollout_cfg(True, False, "greedy_q"); cfg.eps_start, cfg.eps_stop, cfg.eps_steps = 1.0, 0.1, N // 2
+    y = np.empty(B, np.float32); info = np.zeros(L.INFO_N, np.float32); losses = []
+    cfg.i0 = init; oe.rollout(o, cfg, ob, init)
+    i = init
+    while i <= N - dN:
+        cfg.i0 = i; oe.rollout(o, cfg, ob, dN)
+        ep_losses = []
+        for ep in range(dN):
+            O.chk(O.lib().orc_uniform_sample(obt.h, ob.h, B, None, i * dN + ep, crux.api.SAMPLE_SEED))
+            O.chk(O.lib().orc_dqn_target(ot.h, obt.h, 0.95, O.vpz(y)))
+            O.chk(O.lib().orc_td_step(o.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+            ep_losses.append(float(info[0]))
+        O.chk(O.lib().orc_polyak(ot.h, o.h, 0.005))
+        losses.append(float(np.mean(ep_losses)))
+        i += dN
+    return o, ot, ob, obt, losses, i
+
+
+def test_readme_dqn_gridworld_tiny_solve_kernel_matches_the_oracle_loop(gpu_ctx):
+    """BASELINE configs[0] at the README's shapes (one environment, B = 128, ring of 1000, 2-8-4 relu network, dN = 4, eps 1 -> 0.1 over N/2) for 320
+    iterations of solve: crux.solve takes the wave-resident k_dqn_tiny_solve<2,8,4> -- the kernel bench.py times for this config (asserted through its
+    profiling slot) -- and must follow the ORACLE's loop: the same trajectories into the same ring slots (bit-exact), the same last staging batch, and the
+    networks within a float tolerance after 1 280 Adam steps (the minibatch gradient is summed in another order than the oracle's scalar loop)."""
+    N = 200 + 4 * 320
+    S = crux.ContinuousSpace(2)
+    q = crux.DiscreteNetwork(parity.chain([2, 8, 4], ["relu", "identity"]), [1, 2, 3, 4], seed=1)
+    sv = crux.DQN(q, S, N=N, dN=4, max_steps=100, c_opt={"batch_size": 128})
+    ctx = q.ctx
+    ctx.prof_enable(True); ctx.prof_reset()
+    crux.solve(sv, crux.SimpleGridWorld(n_envs=1, seed=0))
+    ms, n_tiny = ctx.prof_get("tiny_solve"); _, n_other = ctx.prof_get("td_step")
+    ctx.prof_enable(False)
+    assert n_tiny >= 1 and n_other == 0, (n_tiny, n_other)            # the timed kernel of configs[0] ran, and nothing else trained
+    o, ot, ob, obt, losses, i_end = _oracle_readme_dqn(N)
+    assert sv.i == i_end and len(sv.buffer) == len(ob) == 1000 and len(sv.history) == len(losses) == 320
+    for k in ("s", "a", "sp", "r", "done"):
+        assert np.array_equal(sv.buffer[k], ob[k]), k                                         # eps-greedy trajectories incl. every greedy argmax, ring wrap
+    assert np.array_equal(sv.batch["s"], obt["s"]) and np.array_equal(sv.batch["r"], obt["r"])          # the last uniform sample and its gather
+    dq, dt = np.abs(q.get_params() - o.params).max(), np.abs(sv.agent.pi_minus.get_params() - ot.params).max()
+    print("README DQN, 320 iterations: max |dtheta| %.3g (Q) %.3g (target)" % (dq, dt))
+    assert dq < 1e-6 and dt < 1e-6, (dq, dt)          # measured 7.1e-8 / 6.0e-8 (profiles/r03_parity_measurements.txt)
+    gl = np.array([h["critic_loss"] for h in sv.history]); ol = np.array(losses)
+    assert np.abs(gl - ol).max() < 1e-4 * max(1.0, np.abs(ol).max())
+
+
+# ---------------------------------------------------------------------------------------------------- teacher-forced windows of the off-policy learners (C4 dims)
+def _replay_source(rng, od, ad, n):
+    data = {"s": rng.normal(0, 1, (od, n)).astype(np.float32), "a": rng.uniform(-2, 2, (ad, n)).astype(np.float32), "sp": rng.normal(0, 1, (od, n)).astype(np.float32),
+            "r": rng.normal(-1, 1, (1, n)).astype(np.float32), "done": rng.random((1, n)) < 0.02, "episode_end": np.zeros((1, n), bool)}
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.ContinuousSpace(ad), n); gb.push_(data)
+    ob = O.OBuffer(od, ad, L.ACTION_CONTINUOUS, n); ob.push(data)
+    return gb, ob
+
+
+def _inject(pairs):
+    """the oracle's parameters and Adam state (m, v, beta powers) of this moment into the GPU twins"""
+    for g, o, trained in pairs:
+        g.set_params(o.params.copy())
+        if trained:
+            g.set_adam_state(*o.adam_state())
+
+
+# 10 x the largest measured window difference (profiles/r03_parity_measurements.txt): windows that start inside Adam's first steps (v ~ 0: lr m / (sqrt(v) + eps)
+# amplifies a last-bit difference of the gradient) measured 2.5e-7 ... 7.6e-7, windows further along the trajectory 1.5e-8 ... 2.5e-7
+OFFPOLICY_WINDOW_TOL = {0: 8e-6, "later": 2.5e-6}
+
+
+@pytest.mark.parametrize("algo", ["sac", "ddpg", "td3"])
+def test_offpolicy_teacher_forced_windows_at_c4_dims(gpu_ctx, algo):
+    """BASELINE configs[3] dimensions (actor 3-256-256-1, critics 4-256-256-1, B = 256, Adam 3e-4 / 1e-3, polyak 0.005): the oracle runs 208 value_training epochs
+    (off_policy.jl:69-104) from a 5 000-row ring; at epochs 0, 64, 128 and 200 the GPU networks get the oracle's exact state of that moment (parameters, Adam moments and
+    beta powers, target networks, log alpha) and replay the next 8 epochs through the product path (crux_sac_epochs / crux_dpg_epochs: the chained executor epochs that
+    solve() and bench.py run). The learner map is chaotic over hundreds of steps (relu kinks, Adam's normalisation), so this -- not the first steps from zero moments --
+    is what pins the arithmetic of the off-policy dense engine along a trajectory."""
+    ctx, rng = gpu_ctx, np.random.default_rng(17)
+    B, n, od, ad, nseed, gamma, tau = 256, 5000, 3, 1, 9, 0.99, 0.005
+    starts, W, total = (0, 64, 128, 200), 8, 208
+    gbuf, obuf = _replay_source(rng, od, ad, n)
+    D = crux.buffer_like(gbuf, capacity=B); oD = O.OBuffer(od, ad, L.ACTION_CONTINUOUS, B)
+    acts = ["relu", "relu", "identity"]; adims, qdims = [3, 256, 256, 1], [4, 256, 256, 1]
+    sac, twin = algo == "sac", algo in ("sac", "td3")
+    if sac:
+        ga, oa = parity.make_pair(adims, acts, 5, 0, "gaussian", n_extra=1, extra_init=0.0)
+    else:
+        ga, oa = parity.make_pair(adims, ["relu", "relu", "tanh"], 5, 0)
+    g1, o1 = parity.make_pair(qdims, acts, 5, 1); g2, o2 = parity.make_pair(qdims, acts, 5, 2)
+    g1t, o1t = parity.make_pair(qdims, acts, 5, 1); g2t, o2t = parity.make_pair(qdims, acts, 5, 2)
+    gat, oat = (None, None) if sac else parity.make_pair(adims, ["relu", "relu", "tanh"], 5, 0)
+    gla = crux.ParamVector([0.0], ctx=ctx); ola = O.OMlp([0], [], 1); ola.params[:] = 0.0
+    lr = float(np.float32(3e-4 if sac else 1e-3))
+    trained = [(ga, oa), (g1, o1)] + ([(g2, o2)] if twin else []) + ([(gla, ola)] if sac else [])
+    for g, o in trained:
+        g.attach_optimizer(crux.Adam(np.float32(lr))); o.adam_init(lr)
+    targets = [(g1t, o1t)] + ([(g2t, o2t)] if twin else []) + ([] if sac else [(gat, oat)])
+    pairs = [(g, o, True) for g, o in trained] + [(g, o, False) for g, o in targets]
+    sm = (np.float32(0.1), -0.5, 0.5, -1.0, 1.0) if algo == "td3" else (-1.0, 0.0, 0.0, 0.0, 0.0)
+    ol, y, info = O.lib(), np.empty(B, np.float32), np.zeros(L.INFO_N, np.float32)
+    pending, out = {}, []
+    for e in range(total):
+        if e in starts:
+            _inject(pairs)
+            if sac:
+                ctx.check(ctx.lib.crux_sac_epochs(ga.h, g1.h, g2.h, None, g1t.h, g2t.h, gla.h, gbuf.h, D.h, gamma, -1.0, tau, 0, 0, W, 1, 1, e, nseed, 3 * e, None, None, None))
+            else:
+                ctx.check(ctx.lib.crux_dpg_epochs(ga.h, g1.h, g2.h if twin else None, gat.h, g1t.h, g2t.h if twin else None, gbuf.h, D.h, gamma, tau, *[float(x) for x in sm], 0, 0, W,
+                                                  1, 2 if algo == "td3" else 1, e, nseed, e, None, None))
+            pending[e + W] = [g.get_params() for g, _, _ in pairs]
+        O.chk(ol.orc_uniform_sample(oD.h, obuf.h, B, None, e, crux.api.SAMPLE_SEED))
+        if sac:
+            O.chk(ol.orc_sac_target(oa.h, o1t.h, o2t.h, ola.h, oD.h, gamma, nseed, 3 * e, O.vpz(y)))
+            O.chk(ol.orc_sac_temp_step(oa.h, ola.h, oD.h, -1.0, nseed, 3 * e + 1, O.vpz(info)))
+            O.chk(ol.orc_double_q_step(o1.h, o2.h, oD.h, O.vpz(y), 0, O.vpz(info)))
+            O.chk(ol.orc_sac_actor_step(oa.h, o1.h, o2.h, ola.h, oD.h, nseed, 3 * e + 2, O.vpz(info)))
+            for t, s in ((o1t, o1), (o2t, o2)):
+                O.chk(ol.orc_polyak(t.h, s.h, tau))
+        else:
+            O.chk(ol.orc_dpg_target(oat.h, o1t.h, o2t.h if algo == "td3" else None, oD.h, gamma, *sm, nseed, e, O.vpz(y)))
+            if twin:
+                O.chk(ol.orc_double_q_step(o1.h, o2.h, oD.h, O.vpz(y), 0, O.vpz(info)))
+            else:
+                O.chk(ol.orc_q_step(o1.h, oD.h, O.vpz(y), 0, O.vpz(info)))
+            if algo != "td3" or e % 2 == 0:          # TD3's delayed policy update (a_opt.update_every = 2): actor step and target update together (off_policy.jl:96-100)
+                O.chk(ol.orc_dpg_actor_step(oa.h, o1.h, oD.h, O.vpz(info)))
+                for t, s in ((oat, oa), (o1t, o1)) + (((o2t, o2),) if twin else ()):
+                    O.chk(ol.orc_polyak(t.h, s.h, tau))
+        if e + 1 in pending:
+            gp = pending.pop(e + 1)
+            out.append((e + 1 - W, [float(np.abs(x - o.params).max()) for x, (_, o, _) in zip(gp, pairs)]))
+    print("off-policy windows %s (start, max |dtheta| per network): %s" % (algo, out))
+    assert len(out) == len(starts)
+    for st, d in out:
+        assert max(d) < OFFPOLICY_WINDOW_TOL[0 if st == 0 else "later"], (st, d)
+
+
+# ---------------------------------------------------------------------------------------------------- function-valued seams of OffPolicySolver (off_policy.jl:53-63)
+def test_offpolicy_user_target_two_sources_and_callbacks_match_the_oracle_loop(gpu_ctx):
+    """solve(::OffPolicySolver) with the reference's function-valued fields set by the caller: target_fn (a double-DQN target evaluated by user code from pi and pi_minus),
+    target_update (polyak with the caller's tau), extra_buffers + buffer_fractions (rand! over two sources, 3/4 + 1/4 of the minibatch), and the three callbacks. The
+    solver leaves the fused chains for the call-by-call loop; the ORACLE's loop with the same user functions must give the same ring, the same staging batch and the same
+    networks."""
+    E, dN, B, N, cap, seed, max_steps = 1, 4, 32, 72, 96, 4, 20
+    dims, acts = [2, 16, 4], ["relu", "identity"]
+    g, o = parity.make_pair(dims, acts, 43, 0, "discrete", outputs=[1, 2, 3, 4])
+    S, A = crux.ContinuousSpace(2), crux.DiscreteSpace(4)
+    rng = np.random.default_rng(6); nx = 50
+    ax = np.zeros((4, nx), bool); ax[rng.integers(0, 4, nx), np.arange(nx)] = True
+    xdata = {"s": rng.integers(1, 11, (2, nx)).astype(np.float32), "a": ax, "sp": rng.integers(1, 11, (2, nx)).astype(np.float32), "r": rng.normal(0, 1, (1, nx)).astype(np.float32),
+             "done": rng.random((1, nx)) < 0.1, "episode_end": np.zeros((1, nx), bool)}
+    gx = crux.ExperienceBuffer(S, A, nx); gx.push_(xdata)
+    ox = O.OBuffer(2, 4, L.ACTION_DISCRETE, nx); ox.push(xdata)
+    calls = {"sample": 0, "batch": 0, "pre": 0, "rows": 0}
+
+    def ddqn_target(fwd_online, fwd_target, D, gamma):
+        sp, r, done = D["sp"], D["r"][0], D["done"][0]
+        qo, qt = fwd_online(sp), fwd_target(sp)
+        return (r + np.float32(gamma) * (1.0 - done.astype(np.float32)) * qt[np.argmax(qo, axis=0), np.arange(sp.shape[1])]).astype(np.float32)
+
+    def target_fn(pim, P, D, gamma, i=0):
+        return ddqn_target(g.forward, pim.forward, D, gamma)
+
+    def target_update(pim, pi, i=None):
+        crux.polyak_average_(pim, pi, 0.02)
+
+    def post_sample(D, S=None, info=None):
+        calls["sample"] += 1; calls["rows"] += D["s"].shape[1]; info["seen"] = 1.0
+
+    def post_batch(D, S=None, info=None):
+        calls["batch"] += 1; info["batch_r"] = float(D["r"].mean())
+
+    def pre_train(S, info=None):
+        calls["pre"] += 1
+
+    sv = crux.DQN(g, S, N=N, dN=dN, c_opt={"batch_size": B, "optimizer": crux.Adam(np.float32(1e-3))}, buffer_size=cap, buffer_init=B, max_steps=max_steps,
+                  target_fn=target_fn, target_update=target_update, extra_buffers=[gx], buffer_fractions=[0.75, 0.25],
+                  post_sample_callback=post_sample, post_batch_callback=post_batch, pre_train_callback=pre_train)
+    assert sv.custom_seams()
+    crux.solve(sv, crux.SimpleGridWorld(n_envs=E, seed=seed))
+    n_it = (N - B) // dN + 1 - 0
+    # ---- the same loop on the oracle
+    ot = O.OMlp(dims, acts); O.chk(O.lib().orc_mlp_copy(ot.h, o.h)); o.adam_init(float(np.float32(1e-3)))
+    ob = O.OBuffer(2, 4, L.ACTION_DISCRETE, cap); obt = O.OBuffer(2, 4, L.ACTION_DISCRETE, B)
+    oe = O.OEnv("gridworld", E, max_steps, 0.95, seed)
+    cfg = parity.rollout_cfg(True, False, "greedy_q"); cfg.eps_start, cfg.eps_stop, cfg.eps_steps = 1.0, 0.1, N // 2
+    O.chk(O.lib().orc_buffer_set_sample_stream(ob.h, 0)); O.chk(O.lib().orc_buffer_set_sample_stream(ox.h, 1))
+    i = B; cfg.i0 = i; oe.rollout(o, cfg, ob, B)
+    info = np.zeros(L.INFO_N, np.float32); its = 0
+    while i <= N - dN:
+        cfg.i0 = i; oe.rollout(o, cfg, ob, dN)
+        for ep in range(dN):
+            ctr = i * dN + ep
+            O.chk(O.lib().orc_uniform_sample(obt.h, ob.h, 24, None, ctr, crux.api.SAMPLE_SEED)); O.chk(O.lib().orc_uniform_sample(obt.h, ox.h, 8, None, ctr, crux.api.SAMPLE_SEED))
+            y = ddqn_target(o.forward, ot.forward, obt, 0.95)
+            O.chk(O.lib().orc_td_step(o.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+        O.chk(O.lib().orc_polyak(ot.h, o.h, 0.02))
+        i += dN; its += 1
+    assert sv.i == i and len(sv.history) == its
+    assert calls["pre"] == its and calls["batch"] == its * dN and calls["sample"] == its + 1 and calls["rows"] == B + its * dN
+    assert "batch_r" in sv.history[-1] and sv.history[-1]["seen"] == 1.0                      # callback infos reach the iteration's info like log(...) gets them (:146)
+    for k in ("s", "a", "sp", "r", "done"):
+        assert np.array_equal(sv.buffer[k], ob[k]), k
+        assert np.array_equal(sv.batch[k], obt[k]), k                                        # 24 rows of the ring + 8 of the extra buffer, in that order
+    dq, dt = np.abs(g.get_params() - o.params).max(), np.abs(sv.agent.pi_minus.get_params() - ot.params).max()
+    print("user-target DQN over two sources: max |dtheta| %.3g / %.3g" % (dq, dt))
+    assert dq < 2e-6 and dt < 2e-6, (dq, dt)
+
+
+def test_offpolicy_user_priority_fn_and_sample_callback_write_back(gpu_ctx):
+    """priority_fn (off_policy.jl:60,83) supplied by the caller on a prioritized ring, and a post_sample_callback that relabels rewards in place (the GAIL-style use of
+    the callback, :50): priorities, relabelled rewards and networks against the oracle's loop."""
+    E, dN, B, N, cap, seed, max_steps = 1, 4, 16, 40, 64, 9, 20
+    dims, acts = [2, 8, 4], ["relu", "identity"]
+    g, o = parity.make_pair(dims, acts, 47, 0, "discrete", outputs=[1, 2, 3, 4])
+    S = crux.ContinuousSpace(2)
+
+    def prio(fwd, D, y):
+        q = fwd(D["s"]); qa = (q * D["a"]).sum(axis=0)
+        return (np.abs(qa - y) + np.float32(0.5)).astype(np.float32)
+
+    def relabel(D, S=None, info=None):
+        D["r"][...] = D["r"] * np.float32(0.5) - np.float32(0.25)
+
+    sv = crux.DQN(g, S, N=N, dN=dN, c_opt={"batch_size": B, "optimizer": crux.Adam(np.float32(1e-3))}, buffer_size=cap, buffer_init=B, max_steps=max_steps, prioritized=True,
+                  priority_fn=lambda pi, P, D, y: prio(pi.forward, D, y), post_sample_callback=relabel)
+    crux.solve(sv, crux.SimpleGridWorld(n_envs=E, seed=seed))
+    ot = O.OMlp(dims, acts); O.chk(O.lib().orc_mlp_copy(ot.h, o.h)); o.adam_init(float(np.float32(1e-3)))
+    ob = O.OBuffer(2, 4, L.ACTION_DISCRETE, cap, ["weight"], prioritized=True, alpha=np.float32(0.6)); obt = O.OBuffer(2, 4, L.ACTION_DISCRETE, B, ["weight"], prioritized=True, alpha=np.float32(0.6))
+    oe = O.OEnv("gridworld", E, max_steps, 0.95, seed)
+    cfg = parity.rollout_cfg(True, False, "greedy_q"); cfg.eps_start, cfg.eps_stop, cfg.eps_steps = 1.0, 0.1, N // 2
+    y, ids, info = np.empty(B, np.float32), np.empty(B, np.int64), np.zeros(L.INFO_N, np.float32)
+
+    def orelabel(n):
+        last = np.empty(n, np.int64); k = O.lib().orc_buffer_last_n_indices(ob.h, n, O.vpz(last)); assert k == n
+        r = ob.col("r"); r[0, last] = r[0, last] * np.float32(0.5) - np.float32(0.25)
+
+    i = B; cfg.i0 = i; oe.rollout(o, cfg, ob, B); orelabel(B)
+    while i <= N - dN:
+        cfg.i0 = i; oe.rollout(o, cfg, ob, dN); orelabel(dN)
+        for ep in range(dN):
+            O.chk(O.lib().orc_per_sample(obt.h, ob.h, B, None, 0.5, i * dN + ep, crux.api.SAMPLE_SEED))
+            O.chk(O.lib().orc_dqn_target(ot.h, obt.h, 0.95, O.vpz(y)))
+            O.chk(O.lib().orc_buffer_indices(obt.h, O.vpz(ids), B))
+            v = prio(o.forward, obt, y)
+            O.chk(O.lib().orc_per_update(ob.h, O.vpz(ids), O.vpz(v), 0, B))
+            O.chk(O.lib().orc_td_step(o.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+        O.chk(O.lib().orc_polyak(ot.h, o.h, 0.005))
+        i += dN
+    assert np.array_equal(sv.buffer["s"], ob["s"]) and np.abs(sv.buffer["r"] - ob["r"]).max() == 0.0
+    pg = sv.buffer.priority_params(); pr = np.empty(cap, np.float32); mx, mn = C.c_float(), C.c_float()
+    O.chk(O.lib().orc_per_get(ob.h, O.vpz(pr), C.byref(mx), C.byref(mn), None))
+    assert np.allclose(pg["priorities"], pr, rtol=2e-5, atol=1e-6) and abs(pg["max_priority"] - mx.value) < 1e-5
+    assert np.abs(g.get_params() - o.params).max() < 2e-6

@@ -72,12 +72,19 @@ def _grads(net, ctx):
 
 
 def _step_close(g, o, ctx, lr=1e-3):
-    """After one train!: gradients agree to 1e-4 of their scale; parameters agree except where Adam's first steps amplify rounding
-    (step = lr*g/(|g|+1e-8) is discontinuous at g = 0): at most 0.1 % of the entries may differ by more than 2e-5, none by more than lr/2."""
+    """After one train! from (nearly) zero Adam moments: gradients agree to 6e-6 of their scale; parameters agree except where Adam's first steps amplify
+    rounding (step = lr*g/(|g|+1e-8) is discontinuous at g = 0): at most 0.02 % of the entries may differ by more than 2e-6, none by more than 5e-5
+    (10 x the measured extremes; the arithmetic along a trajectory is pinned by the teacher-forced windows of tests/test_gpu_round3.py)."""
     gg, og = _grads(g, ctx), o.grads
-    ok = np.abs(gg - og).max() <= 1e-4 * max(np.abs(og).max(), 1e-6)
+    gd = np.abs(gg - og).max() / max(np.abs(og).max(), 1e-6)
+    ok = gd <= 6e-6                                      # measured <= 6.3e-7 over all cases (profiles/r03_parity_measurements.txt)
     d = np.abs(g.get_params() - o.params)
-    return bool(ok and d.max() < 0.5 * lr and np.mean(d > 2e-5) <= 1e-3)
+    _MEAS["grad_rel"] = max(_MEAS.get("grad_rel", 0.0), float(gd)); _MEAS["param_max"] = max(_MEAS.get("param_max", 0.0), float(d.max()))
+    _MEAS["frac_gt_2e-6"] = max(_MEAS.get("frac_gt_2e-6", 0.0), float(np.mean(d > 2e-6)))
+    return bool(ok and d.max() < 5e-5 and np.mean(d > 2e-6) <= 2e-4)      # measured: max 5.1e-6, 1.4e-5 of the entries above 2e-6
+
+
+_MEAS = {}
 
 
 def _sac_pair(od, ad, hidden, q_act, a_acts, seed, ctx):
@@ -121,6 +128,7 @@ def test_sac_steps_match_oracle(gpu_ctx, od, ad, hidden, q_act, a_acts, B):
     gi, oi = np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32)
 
     def close(a, b, tol=1e-4):
+        _MEAS["info_rel"] = max(_MEAS.get("info_rel", 0.0), abs(a - b) / max(1.0, abs(b)))
         return abs(a - b) <= tol * max(1.0, abs(b))
 
     for rep in range(3):                                               # three epochs: Adam state and beta powers advance
@@ -145,6 +153,7 @@ def test_sac_steps_match_oracle(gpu_ctx, od, ad, hidden, q_act, a_acts, B):
         assert _step_close(ga, oa, ctx)
     m, v, bp = ga.adam_state(); mo, vo, bpo = oa.adam_state()
     assert np.allclose(bp, bpo) and np.abs(m - mo).max() < 1e-5
+    print("sac steps measured:", {k: "%.3g" % x for k, x in _MEAS.items()}, "targets |dy| rel: see assert")
     ctx.free(d_y)
 
 
