@@ -284,6 +284,85 @@ def setup_group(args, crux, ctx, rank, world, local):
     return torch_sync, "parameters + Adam moments averaged every %d epoch(s) by a torch.distributed all_reduce (host-synchronised)" % SYNC_EVERY
 
 
+def run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P):
+    """The first thing a multi-GPU run should do on new hardware: exercise the in-kernel exchange across the REAL devices before anything is timed.
+    (1) identical shards: every rank trains on the same rows, so the SUM over ranks / N equals each rank's own gradient up to the rounding of (N - 1) additions -- the
+        group must reproduce an un-grouped learner of a second context on rank 0 (bit for bit at N = 2, where g + g and the division by two are exact), and a lost,
+        torn or stale slot read shows up as a different sum;
+    (2) distinct shards: 64 minibatch steps per learner, the replicas' parameters and Adam state must be bit-identical afterwards;
+    (3) flag-wait histograms of (2), one per rank: how long each learner workgroup waited for the slowest peer per exchange;
+    (4) the library's own RCCL communicator (crux_comm_init, crux_allreduce_grads -- ncclAllReduce over xGMI): a known vector summed over the ranks.
+    Returns the dict that goes into the JSON line under "selftest" (rank 0 gathers)."""
+    tdev = torch.device("cuda", local) if dist.get_backend() == "nccl" else torch.device("cpu")
+    res = {"world": world}
+
+    def gather_obj(o):
+        out = [None] * world; dist.all_gather_object(out, o); return out
+
+    def short_opts(seed, nb):
+        return (crux.TrainingParams(loss=crux.ppo_loss, batch_size=BATCH, epochs=1, target_kl=None, name="actor_", shuffle_seed=seed, max_batches=nb),
+                crux.TrainingParams(loss=crux.value_mse_loss, batch_size=BATCH, epochs=1, name="critic_", shuffle_seed=seed + 50, max_batches=nb))
+
+    # (1) identical shards, same shuffle on every rank
+    pi1, buf1, smp1 = build_problem(crux, cdist.shard_seed(7, 0), workload=args.workload)
+    pa, pc = short_opts(700, 16)
+    ppo_iteration(crux, pi1, buf1, smp1, pa, pc, P, 0, "grad"); ctx.sync()
+    mine = np.concatenate([pi1.A.get_params(), pi1.C.get_params()])
+    allp = gather_obj(mine)
+    res["identical_shards_replicas_equal"] = bool(all(np.array_equal(allp[0], x) for x in allp))
+    if rank == 0:
+        ctx2 = crux.Context(local); prev = crux.default_context(); crux.set_default_context(ctx2)      # an un-grouped learner on the same device
+        try:
+            pi2, buf2, smp2 = build_problem(crux, cdist.shard_seed(7, 0), workload=args.workload)
+            pa2, pc2 = short_opts(700, 16)
+            ppo_iteration(crux, pi2, buf2, smp2, pa2, pc2, P, 0, None); ctx2.sync()
+            ref = np.concatenate([pi2.A.get_params(), pi2.C.get_params()])
+            res["identical_shards_max_abs_diff_vs_single_learner"] = float(np.abs(ref - mine).max())
+            res["identical_shards_ok"] = bool(np.array_equal(ref, mine)) if world == 2 else bool(np.abs(ref - mine).max() < 1e-5)
+        finally:
+            crux.set_default_context(prev)
+    # (2) + (3) distinct shards, histograms on
+    ctx.peer_wait_hist(reset=True); ctx.peer_hist_enable(True)
+    pi3, buf3, smp3 = build_problem(crux, cdist.shard_seed(11, rank), workload=args.workload)
+    pa, pc = short_opts(800 + rank, 64)
+    ppo_iteration(crux, pi3, buf3, smp3, pa, pc, P, 0, "grad"); ctx.sync()
+    ctx.peer_hist_enable(False)
+    dg = gather_obj(int(params_digest((pi3.A, pi3.C))))
+    res["distinct_shards_replicas_bit_identical"] = bool(len(set(dg)) == 1)
+    hist = ctx.peer_wait_hist(reset=True)
+
+    def fmt(h):      # {"<= 0.64 us": n, ...} for the non-empty log2 bins of 10 ns ticks
+        return {"<%.2fus" % (10e-3 * 2 ** (b + 1)): int(n) for b, n in enumerate(h) if n}
+    res["flag_wait_hist_per_rank"] = gather_obj({"actor_wg0": fmt(hist[0, 0]), "actor_wg1": fmt(hist[0, 1]), "critic_wg0": fmt(hist[1, 0]), "critic_wg1": fmt(hist[1, 1])})
+    # (4) RCCL through the library's communicator
+    rc = {"ok": False}
+    try:
+        if args.same_device:
+            raise RuntimeError("skipped: all ranks share one device (--same-device), RCCL needs one device per rank")
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            uid[:] = ctx.comm_unique_id()
+        t = torch.from_numpy(uid).to(tdev); dist.broadcast(t, 0); uid = t.cpu().numpy().copy()
+        ctx.comm_init(rank, world, uid)
+        net = pi3.A; n = net.n_params
+        g = (np.arange(n, dtype=np.float32) % 97 + 1.0) * np.float32(rank + 1)
+        ctx.h2d(ctx.lib.crux_mlp_grads_ptr(net.h), g)
+        ctx.check(ctx.lib.crux_allreduce_grads(net.h)); ctx.sync()
+        out = np.empty(n, np.float32); ctx.d2h(ctx.lib.crux_mlp_grads_ptr(net.h), out)
+        want = (np.arange(n, dtype=np.float32) % 97 + 1.0) * np.float32(world * (world + 1) / 2)
+        rc = {"ok": bool(np.array_equal(out, want)), "floats": int(n), "backend": "RCCL ncclAllReduce(sum, f32) issued by libcruxhip on its own stream"}
+        ctx.comm_destroy()
+    except Exception as e:      # noqa: BLE001
+        rc = {"ok": False, "error": repr(e)}
+    res["rccl_allreduce_per_rank"] = gather_obj(rc)
+    ok = res["identical_shards_replicas_equal"] and res["distinct_shards_replicas_bit_identical"] and (args.same_device or all(r.get("ok") for r in res["rccl_allreduce_per_rank"]))
+    flag = torch.tensor([1 if (ok and res.get("identical_shards_ok", True)) else 0], device=tdev); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    res["passed"] = bool(int(flag.item()) == 1)
+    if rank == 0:
+        print("bench.py selftest: %s" % json.dumps(res), file=sys.stderr)
+    return res
+
+
 def params_digest(nets):
     """order-independent exact digest of the replicated state (parameters + Adam moments): equal on all ranks iff the replicas are bit-identical."""
     import hashlib
@@ -307,6 +386,9 @@ def main():
     ap.add_argument("--replicas-wide", type=int, default=128, help="second multi-seed line with one CU per learner (population > 64): the highest chip utilisation (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the supplementary configs (C5 shard, off-policy lines)")
     ap.add_argument("--early-stop", action="store_true", help="also time the KL-early-stopping variant (target_kl=0.012)")
+    ap.add_argument("--selftest", action="store_true", help="N > 1: before timing, check the in-kernel gradient exchange across the real devices (identical shards on every rank must "
+                    "reproduce an un-grouped learner; distinct shards must leave the replicas bit-identical), print per-rank flag-wait histograms, and run a 2..N-rank RCCL all-reduce "
+                    "through the library's communicator (crux_comm_init / crux_allreduce_grads)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -370,6 +452,10 @@ def main():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+
+    selftest = None
+    if args.selftest and dist is not None and sync == "grad":
+        selftest = run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P)
 
     it = 0
     for _ in range(args.warmup):
@@ -474,6 +560,8 @@ def main():
         }
         if replicas_identical is not None:
             out["replicas_bit_identical_after_run"] = replicas_identical
+        if selftest is not None:
+            out["selftest"] = selftest
         if early:
             out["early_stop"] = early
         if multi is not None:

@@ -31,7 +31,7 @@ class TrainCfg(C.Structure):
     """crux_train_cfg (include/cruxhip.h)."""
     _fields_ = [("loss", i32), ("head", i32), ("batch_size", i32), ("epochs", i32), ("max_batches", i64),
                 ("eps_clip", f32), ("lambda_p", f32), ("lambda_e", f32), ("target_kl", f32), ("shuffle_seed", u64),
-                ("shuffle_counter", u64), ("sync_every", i32), ("target_col", i32)]
+                ("shuffle_counter", u64), ("reserved0", i32), ("target_col", i32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/cruxhip.h appears here (checked by tests).
@@ -138,7 +138,7 @@ SIGNATURES = {
     "crux_comm_destroy": (i32, [vp]),
     "crux_comm_size": (i32, [vp]),
     "crux_peer_export": (i32, [vp, vp]), "crux_peer_attach": (i32, [vp, i32, i32, vp]), "crux_peer_attach_local": (i32, [P(vp), i32]),
-    "crux_peer_detach": (i32, [vp]), "crux_peer_size": (i32, [vp]), "crux_peer_rank": (i32, [vp]),
+    "crux_peer_detach": (i32, [vp]), "crux_peer_hist_enable": (i32, [vp, i32]), "crux_peer_wait_hist": (i32, [vp, vp, i32]), "crux_peer_size": (i32, [vp]), "crux_peer_rank": (i32, [vp]),
     "crux_allreduce_mean": (i32, [vp]),
     "crux_allreduce_grads": (i32, [vp]),
     "crux_first_episode_metrics": (i32, [vp, i32, i64, f32, vp, vp, vp, vp]),

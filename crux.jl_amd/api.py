@@ -72,6 +72,14 @@ class Context:
     def peer_size(self):
         return int(self.lib.crux_peer_size(self.h))
 
+    def peer_hist_enable(self, on=True):
+        """record, per learner workgroup, how long every in-kernel exchange waited for the slowest peer's flag (cruxhip.h: crux_peer_hist_enable)"""
+        self.check(self.lib.crux_peer_hist_enable(self.h, 1 if on else 0))
+
+    def peer_wait_hist(self, reset=True):
+        """uint32 [2 learner streams][2 workgroups][32]: log2 bins of the flag waits in 10 ns ticks"""
+        out = np.zeros((2, 2, 32), np.uint32); self.check(self.lib.crux_peer_wait_hist(self.h, _vp(out), 1 if reset else 0)); return out
+
     def sync(self):
         self.check(self.lib.crux_sync(self.h))
 

@@ -107,8 +107,12 @@ static int32_t peer_region(crux_ctx* c) {
   if (c->peer_local) return CRUX_OK;
   HIPCHK(c, hipSetDevice(c->device));
   void* p = nullptr;
-  if (hipExtMallocWithFlags(&p, CRUX_PX_BYTES, hipDeviceMallocFinegrained) == hipSuccess) c->peer_fine = true;
-  else { (void)hipGetLastError(); c->peer_fine = false; if (hipMalloc(&p, CRUX_PX_BYTES) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "peer region (%zu bytes)", (size_t)CRUX_PX_BYTES); }
+  // The slots are written by peers over xGMI and read by a kernel that is already running: only a fine-grained region is coherent for that. A coarse-grained
+  // hipMalloc block would look fine behind one L2 and serve stale slots across devices, so there is no fallback: no fine-grained memory, no replica group.
+  const hipError_t ef = hipExtMallocWithFlags(&p, CRUX_PX_BYTES, hipDeviceMallocFinegrained);
+  if (ef != hipSuccess) { (void)hipGetLastError(); c->peer_fine = false;
+    return crux_fail(c, CRUX_EHIP, "peer region: fine-grained device memory is unavailable (hipExtMallocWithFlags: %s); replica groups need it for in-kernel coherence across devices", hipGetErrorString(ef)); }
+  c->peer_fine = true;
   HIPCHK(c, hipMemset(p, 0, CRUX_PX_BYTES));
   HIPCHK(c, hipDeviceSynchronize());
   c->peer_local = p; return CRUX_OK;
@@ -176,6 +180,18 @@ int32_t crux_peer_detach(crux_ctx* c) {
   for (int r = 0; r < CRUX_PX_MAXR; ++r) { if (c->peer_ipc[r]) (void)hipIpcCloseMemHandle(c->peer_ptr[r]); c->peer_ipc[r] = false; c->peer_ptr[r] = nullptr; }
   c->peer_n = 0; c->peer_rank = 0;
   if (c->peer_same_device) { c->peer_same_device = false; crux_same_device_group_leave(); }      // the last member to leave frees the parked blocks
+  return CRUX_OK;
+}
+// flag-wait histogram of the in-kernel exchange (diagnostics of a multi-GPU run): while enabled, lane 0 of each learner workgroup bins the time it waited for the
+// slowest peer's flag of every exchange, log2 of 10 ns ticks (bin b: [2^b, 2^(b+1)) x 10 ns). out: uint32 [2 learner streams][2 workgroups][32].
+int32_t crux_peer_hist_enable(crux_ctx* c, int32_t on) { if (!c) return CRUX_EINVAL; c->peer_hist = on != 0; return CRUX_OK; }
+int32_t crux_peer_wait_hist(crux_ctx* c, uint32_t* out128, int32_t reset) {
+  if (!c || !out128) return CRUX_EINVAL;
+  if (!c->peer_local) { memset(out128, 0, 128 * sizeof(uint32_t)); return CRUX_OK; }
+  (void)hipStreamSynchronize(c->stream); if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+  for (int w = 0; w < 2; ++w) { float* h = (float*)c->peer_local + (size_t)w * CRUX_PX_STREAM_FLOATS + CRUX_PX_HIST;
+    HIPCHK(c, hipMemcpy(out128 + 64 * w, h, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(c, hipMemset(h, 0, 64 * sizeof(uint32_t))); }
   return CRUX_OK;
 }
 int32_t crux_peer_size(const crux_ctx* c) { return c && c->peer_n > 1 ? c->peer_n : 1; }

@@ -34,6 +34,7 @@ struct crux_ctx {
   void* xbuf[2] = {nullptr, nullptr};   // gradient exchange areas of the two-CU learner kernel, one per learner stream
   // replica group with direct peer slots (comm.hip "peer"): every rank owns one fine-grained region that its peers write their minibatch
   // gradients into over xGMI; peer_ptr[r] is rank r's region as mapped here (own region for r == peer_rank)
+  bool peer_hist = false;              // record the per-step flag waits of the replica-group exchange (crux_peer_hist_enable)
   int peer_n = 0, peer_rank = 0; void* peer_local = nullptr; void* peer_ptr[8] = {}; bool peer_ipc[8] = {}; bool peer_fine = false;
   void* rec = nullptr;                 // ExecRec* (exec.h): the fused-step executor's recording state
   // replica group with another context of THIS process on the same device (crux_peer_attach_local): hipFree waits for the whole device, i.e. for the peer's
@@ -57,7 +58,8 @@ struct crux_ctx {
 #define CRUX_PX_FLAGS (2 * CRUX_PX_MAXR * CRUX_PX_SLOT)
 #define CRUX_PX_ABORT (CRUX_PX_FLAGS + 16 * CRUX_PX_MAXR)
 #define CRUX_PX_COUNT (CRUX_PX_ABORT + 16)
-#define CRUX_PX_STREAM_FLOATS (CRUX_PX_COUNT + 16)
+#define CRUX_PX_HIST (CRUX_PX_COUNT + 16)       // uint32 [2 workgroups][32]: log2 histogram of the flag waits in 10 ns ticks (crux_peer_wait_hist; filled only while enabled)
+#define CRUX_PX_STREAM_FLOATS (CRUX_PX_HIST + 64)
 #define CRUX_PX_BYTES (2 * CRUX_PX_STREAM_FLOATS * sizeof(float))
 
 int32_t crux_fail(crux_ctx* ctx, int32_t code, const char* fmt, ...);

@@ -50,7 +50,7 @@ static int32_t launch_x2(crux_ctx* c, TrainArgs a, hipStream_t stream) {
   a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * 4 * 8192);
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
   if (c->peer_n > 1 && a.need_px) {     // local calls (single steps, gradients) never exchange
-    a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
+    a.px_hist = c->peer_hist ? 1 : 0; a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
     return launch_x2_form<IN, OUT, KIND, ACT, false, true>(c, a, lds, stream);
   }
   if constexpr (KIND != MFK_VALUE && !TIMING) { if (a.lag) return launch_x2_form<IN, OUT, KIND, ACT, false, false, true>(c, a, lds, stream); }      // lagrange_ppo_loss (ppo.jl:70-131)

@@ -297,7 +297,8 @@ typedef struct {
   float target_kl;        /* early_stopping = infos[end][:kl] > target_kl (ppo.jl:59); <0 => off   */
   uint64_t shuffle_seed;  /* Philox key for epoch permutations when perms==NULL                    */
   uint64_t shuffle_counter; /* first epoch's permutation counter (advanced by the caller)          */
-  int32_t sync_every;     /* multi-GPU: host-level gradient exchange period in minibatches (0=off) */
+  int32_t reserved0;      /* must be 0. (Was `sync_every`, never read: replica groups exchange the gradient EVERY minibatch inside the learner kernel, crux_peer_*; the
+                             periodic alternative -- parameters + Adam moments averaged every k epochs -- takes its period as an argument of crux_policy_gradient_training_synced.) */
   int32_t target_col;     /* CRUX_LOSS_VALUE_MSE: the Float32 column the value is regressed on; 0 = :return (ppo.jl:60), CRUX_COL_COST_RETURN for LagrangePPO's cost critic (ppo.jl:210) */
 } crux_train_cfg;
 
@@ -365,6 +366,10 @@ int32_t crux_peer_export(crux_ctx* ctx, uint8_t* handle64);
 int32_t crux_peer_attach(crux_ctx* ctx, int32_t rank, int32_t nranks, const uint8_t* handles);
 int32_t crux_peer_attach_local(crux_ctx* const* ctxs, int32_t n);
 int32_t crux_peer_detach(crux_ctx* ctx);
+/* diagnostics of the in-kernel exchange: while enabled every learner workgroup bins how long it waited for the slowest peer's flag at each exchange
+ * (log2 bins of 10 ns ticks). out: uint32 [2 learner streams][2 workgroups][32]; reset != 0 clears the bins after reading.                       */
+int32_t crux_peer_hist_enable(crux_ctx* ctx, int32_t on);
+int32_t crux_peer_wait_hist(crux_ctx* ctx, uint32_t* out128, int32_t reset);
 int32_t crux_peer_size(const crux_ctx* ctx);               /* 1 when no group is attached */
 int32_t crux_peer_rank(const crux_ctx* ctx);
 /* policy_gradient_training (src/model_free/on_policy.jl:56-78) for replicas: the epochs run in chunks of sync_every, each chunk followed

@@ -36,7 +36,7 @@ end
 struct TrainCfg
     loss::Int32; head::Int32; batch_size::Int32; epochs::Int32; max_batches::Int64
     eps_clip::Float32; lambda_p::Float32; lambda_e::Float32; target_kl::Float32
-    shuffle_seed::UInt64; shuffle_counter::UInt64; sync_every::Int32; target_col::Int32
+    shuffle_seed::UInt64; shuffle_counter::UInt64; reserved0::Int32; target_col::Int32
 end
 @assert sizeof(RolloutCfg) == 72 && sizeof(TrainCfg) == 64
 
