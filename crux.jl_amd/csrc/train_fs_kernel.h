@@ -1,0 +1,614 @@
+// train_fs_kernel.h -- the persistent batch_train! kernel of the register-resident IN->64->64->OUT family in its FEATURE-SPLIT form (round 3; src/training.jl:13-55,
+// ppo.jl:4-21,59-60, Flux Adam). Same arithmetic pieces as train_mfma_kernel.h, another decomposition of one minibatch step:
+//
+//   * a 16-sample tile of the minibatch belongs to a PAIR of waves (t, h), h in {0, 1}: wave h computes the hidden features [32h, 32h + 32) of the second layer, of its
+//     gradient and of the first layer's gradient -- half of the 64x64 MFMA work (forward 32, dH1 32 instead of 64 each) and half of the per-feature VALU / LDS work of the
+//     tile. The first layer (IN <= 17 inputs: 4..20 MFMAs) is evaluated by both waves, so the second layer needs no exchange; the pair meets twice per step through LDS:
+//     the partial logits z (OUT values per sample) before the loss head, and the other half of dZ2 (A operand of dH1 = W2' dZ2) after it;
+//   * NWG workgroups (compute units of ONE XCD) share the 128 samples: NWG = 2 -> 64 samples = 4 tiles = 8 waves per workgroup (two waves per SIMD),
+//     NWG = 4 -> 32 samples = 2 tiles = 4 waves per workgroup (one wave per SIMD, four compute units per learner). Per wave and step: 4 (L1) + 32 (L2) + 32 (dW2)
+//     + 32 (dH1) + 8 (dW1) = 108 MFMAs against 212 in the sample-split form -- the step loop is instruction-issue bound, and this halves the per-feature
+//     instruction stream of a wave;
+//   * the 64x64 weight gradient stays model-parallel over the waves of a workgroup (16 / NW tiles of W2 with theta, m, v in the owning wave's registers); it is formed
+//     BEFORE dH1 and its partial sums leave for the other workgroups' L2 slots at once, so the store acknowledgement is covered by the rest of the backward pass;
+//   * the NWG partial gradients are exchanged once per step through the shared L2 exactly like the two-CU form does (plain stores, s_waitcnt, one agent-scope arrival
+//     counter, sc1 loads) and added in workgroup order by everyone: bit-identical totals, Adam updates and early-stopping decisions in all workgroups.
+// Covers full minibatch loops (batch_train! with Adam, 65..128 rows per minibatch) of the plain policy-gradient / critic losses; single steps, gradient-only calls,
+// replica groups and lagrange_ppo_loss stay on train_mfma_kernel.h.
+#pragma once
+#include "train_args.h"
+
+#include "mfma_helpers.h"
+
+#define FS_LD 72
+__device__ __forceinline__ int fs_tx(int q) { return (4 - q) & 3; }   // {0,3,2,1}
+
+template <int IN, int OUT, int NWG>
+struct FsLayout {
+  static constexpr int NW = 16 / NWG, TILES = NW / 2, NT = 64 * NW;
+  static constexpr int KS0 = (IN + 3) / 4, IP = KS0 * 4, JT = (IN + 15) / 16, XP = IP + 2, W1LD = IP + 2;
+  static constexpr int SCW = (4 + (OUT > 4 ? OUT : 4)) | 1;
+  static constexpr int ZW = OUT;                                                          // partial logits per (tile, half, g, sample)
+  // flat index spaces of the small parameters (everything but W2): s = thread-owned index, c = canonical (Flux.params) index, p = index inside a tile's partial block
+  static constexpr int sW1 = 0, sB1 = MF_HID * IN, sB2 = sB1 + MF_HID, sW3 = sB2 + MF_HID, sB3 = sW3 + MF_HID * OUT, sEX = sB3 + OUT, NS = sEX + 16;
+  static constexpr int cW1 = 0, cB1 = MF_HID * IN, cW2 = cB1 + MF_HID, cB2 = cW2 + MF_HID * MF_HID, cW3 = cB2 + MF_HID, cB3 = cW3 + MF_HID * OUT, cEX = cB3 + OUT;
+  static constexpr int W1ROWS = IP < 16 * JT ? IP : 16 * JT;
+  static constexpr int pW1 = 0, pB1 = pW1 + W1ROWS * FS_LD, pB2 = pB1 + MF_HID, pW3 = pB2 + MF_HID, pMISC = pW3 + OUT * MF_HID;
+  static constexpr int pST = pMISC, pB3 = pMISC + 7, pEX = pB3 + OUT;
+  static constexpr int PART = ((pMISC + 48 + 3) / 4) * 4;
+  static constexpr int NSP = ((NS + 3) / 4) * 4;
+  static constexpr int TILE = MF_HID * 16;
+  static constexpr int oW2R = 0, oW2C = oW2R + MF_HID * FS_LD, oW1R = oW2C + MF_HID * FS_LD;
+  static constexpr int oB1 = oW1R + MF_HID * W1LD, oB2 = oB1 + MF_HID, oW3R = oB2 + MF_HID, oB3 = oW3R + OUT * MF_HID, oEX = oB3 + 16;
+  static constexpr int oMS = ((oEX + 16 + 3) / 4) * 4, oVS = oMS + NSP;
+  static constexpr int oT1 = oVS + NSP, oT2 = oT1 + TILES * TILE;
+  static constexpr int oD2X = oT2 + TILES * TILE;                         // [tile][half][2][64 lanes] f32x4: the dZ2 half of a wave in A-operand layout, for its partner
+  static constexpr int oZP = oD2X + TILES * 2 * 2 * 256;                  // [tile][half][g 4][sample 16][ZW]
+  static constexpr int oPART = ((oZP + TILES * 2 * 64 * ZW + 3) / 4) * 4; // [tile][PART]
+  static constexpr int oXS = oPART + TILES * PART;
+  static constexpr int oSC = oXS + TILES * 16 * XP;
+  static constexpr int oRED = oSC + TILES * 16 * SCW;                     // [0,8): per-wave sum of squares; [8,15): reduced stat sums; [16]: abort flag
+  static constexpr int TOTAL = oRED + 32;
+  static constexpr int NSI = (NS + NT - 1) / NT;
+  static constexpr int XSLOT = ((4096 + NSI * NT + 16 + 3) / 4) * 4;      // floats per exchange slot
+  static_assert(TOTAL <= 40960, "LDS budget (160 KB) exceeded");
+  static_assert(XSLOT <= 8192, "exchange slot");
+};
+
+template <int IN, int OUT, int KIND, int ACT, int NWG, bool TIMING = false>
+__global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
+  static_assert(NWG == 2 || NWG == 4, "two workgroups of eight waves, or four of four");
+  using Lt = FsLayout<IN, OUT, NWG>;
+  constexpr int NW = Lt::NW, TILES = Lt::TILES, NT = Lt::NT, WT = 16 / NW;
+  constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS, NSI = Lt::NSI, XSLOT = Lt::XSLOT;
+  constexpr int NACT = (OUT > 4 ? OUT : 4);
+  if ((blockIdx.x & 7) != 0) return;                 // the NWG workgroups of the learner: blocks 0, 8, 16, 24 -> one XCD (consecutive workgroups go round-robin over the 8 XCDs)
+  const int p = (int)(blockIdx.x >> 3);              // workgroup 0 .. NWG-1 of this learner
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
+  const int t = w >> 1, h = w & 1;                   // sample tile of the workgroup, feature half
+  float* part = sm + Lt::oPART + t * Lt::PART;
+  float* xs = sm + Lt::oXS + t * 16 * XP;
+  float* sc = sm + Lt::oSC + t * 16 * Lt::SCW;
+  float* T1 = sm + Lt::oT1 + t * Lt::TILE;
+  float* T2 = sm + Lt::oT2 + t * Lt::TILE;
+  const int n_extra = (KIND == MFK_GAUSSIAN) ? OUT : 0;
+  unsigned long long tacc[16]; unsigned long long tlast = 0;
+  if (TIMING) { for (int k = 0; k < 16; ++k) tacc[k] = 0; tlast = __builtin_amdgcn_s_memtime(); }
+#define FS_T(ph) do { if (TIMING) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
+  const int t_wr = (4 * g) * 16 + 4 * ((c >> 2) ^ fs_tx(g)) + (c & 3);   // tile element (feature 4g [+16m+r], sample c)
+  const int t_rd = c * 16 + 4 * (g ^ fs_tx(c >> 2));                    // tile b128 (feature c [+16m], samples 4g..4g+3)
+  // dW2 / W2 ownership: four waves own the tiles (mp0 = w, m = 0..3) = rows [16w, 16w+16); eight waves the tiles (mp0, m0) and (mp0, m0 + 1)
+  const int mp0 = NW == 4 ? w : (w >> 1), m0 = NW == 4 ? 0 : 2 * (w & 1);
+
+  auto s_master = [&](int s) -> int {
+    if (s < Lt::sB1) { const int o = s & 63, i = s >> 6; return Lt::oW1R + o * Lt::W1LD + i; }
+    if (s < Lt::sB2) return Lt::oB1 + (s - Lt::sB1);
+    if (s < Lt::sW3) return Lt::oB2 + (s - Lt::sB2);
+    if (s < Lt::sB3) { const int q = s - Lt::sW3; const int o = q % OUT, i = q / OUT; return Lt::oW3R + o * MF_HID + i; }
+    if (s < Lt::sEX) return Lt::oB3 + (s - Lt::sB3);
+    return Lt::oEX + (s - Lt::sEX);
+  };
+  auto s_canon = [&](int s) -> int {
+    if (s < Lt::sB1) return Lt::cW1 + s;
+    if (s < Lt::sB2) return Lt::cB1 + (s - Lt::sB1);
+    if (s < Lt::sW3) return Lt::cB2 + (s - Lt::sB2);
+    if (s < Lt::sB3) return Lt::cW3 + (s - Lt::sW3);
+    if (s < Lt::sEX) return Lt::cB3 + (s - Lt::sB3);
+    return Lt::cEX + (s - Lt::sEX);
+  };
+  auto s_part = [&](int s) -> int {
+    if (s < Lt::sB1) { const int o = s & 63, i = s >> 6; return Lt::pW1 + i * FS_LD + o; }
+    if (s < Lt::sB2) return Lt::pB1 + (s - Lt::sB1);
+    if (s < Lt::sW3) return Lt::pB2 + (s - Lt::sB2);
+    if (s < Lt::sB3) { const int q = s - Lt::sW3; const int o = q % OUT, i = q / OUT; return Lt::pW3 + o * MF_HID + i; }
+    if (s < Lt::sEX) return Lt::pB3 + (s - Lt::sB3);
+    return Lt::pEX + (s - Lt::sEX);
+  };
+  const int ns_valid = Lt::sEX + n_extra;
+  int so_part[NSI], so_master[NSI]; bool so_ok[NSI], so_ex[NSI];
+#pragma unroll
+  for (int k = 0; k < NSI; ++k) { const int s = tid + NT * k; so_ok[k] = s < ns_valid; so_ex[k] = s >= Lt::sEX;
+    so_part[k] = so_ok[k] ? s_part(s) : 0; so_master[k] = so_ok[k] ? s_master(s) : 0; }
+
+  // ---- load parameters and Adam state --------------------------------------------------------------------------
+  for (int q = tid; q < MF_HID * MF_HID; q += NT) { const int o = q & 63, i = q >> 6; const float v = a.p[Lt::cW2 + q];
+    sm[Lt::oW2R + o * FS_LD + i] = v; sm[Lt::oW2C + i * FS_LD + o] = v; }
+  for (int q = tid; q < MF_HID * Lt::W1LD; q += NT) sm[Lt::oW1R + q] = 0.f;
+  if (tid < 16) { sm[Lt::oB3 + tid] = 0.f; sm[Lt::oEX + tid] = 0.f; }
+  for (int q = tid; q < TILES * Lt::PART; q += NT) sm[Lt::oPART + q] = 0.f;
+  uint32_t my_xcc = 0;
+  if (tid == 0) { asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc)); my_xcc &= 0xf;
+    __hip_atomic_store(a.xctr + 8 + p, my_xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // checked against the peers' at the first exchange
+  __syncthreads();
+  for (int s = tid; s < NS; s += NT) { const bool in = s < ns_valid; const int pc = s_canon(s);
+    if (in) sm[s_master(s)] = a.p[pc];
+    sm[Lt::oMS + s] = in ? a.m[pc] : 0.f; sm[Lt::oVS + s] = in ? a.v[pc] : 0.f; }
+  for (int q = tid; q < TILES * 16 * XP; q += NT) sm[Lt::oXS + q] = 0.f;
+  // owned W2 tiles, D layout: reg r of tile mm <-> W2[o = 16 mp0 + 4g + r][i = 16 (m0+mm) + c]
+  f32x4 tW2[WT], mW2[WT], vW2[WT];
+#pragma unroll
+  for (int mm = 0; mm < WT; ++mm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + MF_HID * (16 * (m0 + mm) + c);
+      tW2[mm][r] = a.p[pc]; mW2[mm][r] = a.m[pc]; vW2[mm][r] = a.v[pc]; }
+  double bp1 = a.bp[0], bp2 = a.bp[1];
+  const float lo = 1.f - a.eps_clip, hi = 1.f + a.eps_clip;
+  const bool a2c = a.loss == CRUX_LOSS_A2C;
+  AdamK ak; ak.b1 = (float)a.b1; ak.b2 = (float)a.b2; ak.omb1 = (float)(1.0 - a.b1); ak.omb2 = (float)(1.0 - a.b2); ak.eps = (float)a.eps; ak.eta = (float)a.eta;
+
+  int32_t* order_cur = a.order_a; int32_t* order_nxt = a.order_b;
+  long long total_batches = 0; int epochs_run = 0, err = 0, why_failed = 0; bool stop = false;
+  bool staged = false;
+  long long xstep = 0;
+  float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
+  const int n_epochs = a.epochs;
+  if (!a.ord_all) { for (int64_t j = tid; j < a.len; j += NT) order_cur[j] = (int32_t)j; }
+  if (!a.ord_all && a.pre_epochs > 0) {
+    __syncthreads();
+    for (int pe = 0; pe < a.pre_epochs; ++pe) {
+      if (a.pre_perms) { for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[a.pre_perms[(int64_t)pe * a.len + j]]; }
+      else { const crux_perm pp = crux_perm_make(a.pre_seed, a.pre_counter + (uint64_t)pe, 0, (uint32_t)a.len);
+        for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[crux_perm_at(&pp, (uint32_t)j)]; }
+      __syncthreads();
+      int32_t* tq = order_cur; order_cur = order_nxt; order_nxt = tq;
+    }
+  }
+  __syncthreads();
+  const int64_t total_rows = a.len;
+
+  // ---- minibatch prefetch (HBM/L2 -> registers) and staging (registers -> the tile's LDS rows) ----------------
+  // The pair shares the work: wave h = 0 fetches and stages the observation rows (four lanes per sample), wave h = 1 the scalars (logprob, advantage, return, action).
+  constexpr int NXL = (IN + 3) / 4;
+  float px[NXL]; float p_lp = 0.f, p_adv = 0.f, p_ret = 0.f; float p_act[NACT]; int p_valid = 0; uint8_t p_abyte[OUT];
+#pragma unroll
+  for (int k = 0; k < OUT; ++k) p_abyte[k] = 0;
+#pragma unroll
+  for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
+#pragma unroll
+  for (int e = 0; e < NXL; ++e) px[e] = 0.f;
+  int n_row = 0, n_valid = 0;
+  auto fetch_index = [&](const int32_t* ord, int64_t st, int nb) {
+    const int sidx = 8 * NW * p + 16 * t + c;
+    n_valid = sidx < nb ? 1 : 0;
+    n_row = n_valid ? CRUX_GLOBAL_PTR(int32_t, ord)[st + sidx] : 0;
+  };
+  auto fetch_data = [&]() {
+    const int rowlo = n_row; p_valid = n_valid; const int64_t row = rowlo;
+    if (h == 0) {
+      const int rs = __shfl(rowlo, lane >> 2, 64), vs = __shfl(p_valid, lane >> 2, 64);      // lanes 0..15 hold the rows of samples 0..15
+      const float* xrow = CRUX_GLOBAL_PTR(float, a.S) + (int64_t)rs * IN + (lane & 3) * NXL;
+#pragma unroll
+      for (int e = 0; e < NXL; ++e) px[e] = ((lane & 3) * NXL + e < IN && vs) ? xrow[e] : 0.f;
+    } else {
+      p_lp = 0.f; p_adv = 0.f; p_ret = 0.f;
+#pragma unroll
+      for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
+      if (lane < 16 && p_valid) {
+        if (KIND != MFK_VALUE) { p_lp = CRUX_GLOBAL_PTR(float, a.LP)[row]; p_adv = CRUX_GLOBAL_PTR(float, a.ADV)[row]; }
+        p_ret = a.RET ? CRUX_GLOBAL_PTR(float, a.RET)[row] : 0.f;
+        if (KIND == MFK_CATEGORICAL) { const auto* av = CRUX_GLOBAL_PTR(uint8_t, a.A) + row * OUT;
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) p_abyte[k] = av[k]; }
+        if (KIND == MFK_GAUSSIAN) { const auto* av = CRUX_GLOBAL_PTR(float, a.A) + row * OUT;
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) p_act[k] = av[k]; }
+      }
+    }
+  };
+  auto stage = [&]() {
+    if (h == 0) {
+#pragma unroll
+      for (int e = 0; e < NXL; ++e) { const int f = (lane & 3) * NXL + e; if (f < IN) xs[(lane >> 2) * XP + f] = px[e]; }
+    } else {
+      if (KIND == MFK_CATEGORICAL) { int ai = 0;
+#pragma unroll
+        for (int k = 0; k < OUT; ++k) ai = p_abyte[k] ? k : ai;
+        p_act[0] = (float)ai; }
+      if (lane < 16) { float* q = sc + lane * Lt::SCW; q[0] = (float)p_valid; q[1] = p_lp; q[2] = p_adv; q[3] = p_ret;
+        if (KIND == MFK_GAUSSIAN) {       // SquashedGaussianPolicy: the stored action is un-tanh'd once here and the tanh correction of logpdf rides in the spare slot
+          static_assert(KIND != MFK_GAUSSIAN || ((4 + NACT) % 2 == 0), "the staging row needs its spare slot");
+          float corr = 0.f;
+          if (a.squash > 0.f) {
+#pragma unroll
+            for (int k = 0; k < OUT; ++k) { const float u = p_valid ? sq_untanh(p_act[k], a.squash) : 0.f; corr += p_valid ? sq_corr(u) : 0.f; p_act[k] = u; } }
+          q[4 + NACT] = corr; }
+#pragma unroll
+        for (int k = 0; k < NACT; ++k) q[4 + k] = p_act[k]; }
+    }
+  };
+
+  for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
+    if (a.ord_all) order_cur = const_cast<int32_t*>(a.ord_all) + (size_t)ep * (size_t)a.len;   // shuffle orders composed ahead of time by k_compose_order
+    else {   // shuffle!(D) as an index composition (experience_buffer.jl:118-124)
+      if (a.perms) { for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[a.perms[(int64_t)ep * a.len + j]]; }
+      else { const crux_perm pp = crux_perm_make(a.shuffle_seed, a.shuffle_counter + (uint64_t)ep, 0, (uint32_t)a.len);
+        for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[crux_perm_at(&pp, (uint32_t)j)]; }
+      __syncthreads();
+      int32_t* tq = order_cur; order_cur = order_nxt; order_nxt = tq;
+    }
+    staged = false;
+    { const int nb0 = (int)(total_rows < a.bs ? total_rows : a.bs); fetch_index(order_cur, 0, nb0); fetch_data();
+      const int64_t st1 = a.bs; const int nb1 = st1 < total_rows ? (int)((total_rows - st1) < a.bs ? (total_rows - st1) : a.bs) : 0; fetch_index(order_cur, st1 < total_rows ? st1 : 0, nb1); }
+    for (int64_t st = 0; st < total_rows; st += a.bs) {
+      const int nb = (int)((total_rows - st) < a.bs ? (total_rows - st) : a.bs);
+      const float invB = 1.0f / (float)nb;
+      ak.c1 = __builtin_amdgcn_rcpf((float)(1.0 - bp1)); ak.c2 = __builtin_amdgcn_rcpf((float)(1.0 - bp2));
+      FS_T(0);
+      if (!staged) { stage(); __syncthreads(); }     // the first minibatch of an epoch; every other one was staged inside the previous step's exchange wait (barriers follow it there)
+      staged = false;
+      if (st + a.bs < total_rows) fetch_data();
+      { const int64_t st2 = st + 2 * (int64_t)a.bs; const int nb2 = st2 < total_rows ? (int)((total_rows - st2) < a.bs ? (total_rows - st2) : a.bs) : 0;
+        fetch_index(order_cur, st2 < total_rows ? st2 : 0, nb2); }
+
+      FS_T(1);
+      // ======================= forward, C orientation: D[feature 16m+4g+r][sample c] =======================
+      float xB[KS0];
+#pragma unroll
+      for (int ks = 0; ks < KS0; ++ks) xB[ks] = xs[c * XP + 4 * ks + g];
+      f32x4 h1[4];                                   // the WHOLE first layer in both waves of the pair
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { f32x4 acc = *(const f32x4*)&sm[Lt::oB1 + 16 * m + 4 * g];
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm[Lt::oW1R + (16 * m + c) * Lt::W1LD + 4 * ks + g], xB[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = actf<ACT>(acc[r]);
+        h1[m] = acc; }
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)                 // the tile's H1 rows of this wave's half (the partner writes the others): B operand of dW2, relu' mask of dZ1
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T1[t_wr + (16 * (2 * h + mm) + r) * 16] = (h ? (mm ? h1[3][r] : h1[2][r]) : (mm ? h1[1][r] : h1[0][r]));
+      FS_T(2);
+      f32x4 h2[2];                                   // second layer: output features [32h, 32h + 32)
+      { f32x4 acc0 = *(const f32x4*)&sm[Lt::oB2 + 32 * h + 4 * g], acc1 = *(const f32x4*)&sm[Lt::oB2 + 32 * h + 16 + 4 * g];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { const f32x4 wv0 = *(const f32x4*)&sm[Lt::oW2R + (32 * h + c) * FS_LD + 16 * m + 4 * g];
+          const f32x4 wv1 = *(const f32x4*)&sm[Lt::oW2R + (32 * h + 16 + c) * FS_LD + 16 * m + 4 * g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv0[r], h1[m][r], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv1[r], h1[m][r], acc1, 0, 0, 0); } }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc0[r] = actf<ACT>(acc0[r]); acc1[r] = actf<ACT>(acc1[r]); }
+        h2[0] = acc0; h2[1] = acc1; }
+
+      FS_T(3);
+      // ======================= layer 3 (VALU): partial logits over this wave's 32 features, exchanged inside the pair =======================
+      f32x4 w3[OUT <= 2 ? OUT : 1][2];
+      constexpr bool W3_REG = OUT <= 2;
+      if (W3_REG) {
+#pragma unroll
+        for (int o = 0; o < OUT; ++o)
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) w3[o][mm] = *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 32 * h + 16 * mm + 4 * g]; }
+      float zp[OUT];
+#pragma unroll
+      for (int o = 0; o < OUT; ++o) { float acc = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) { const f32x4 wv = W3_REG ? w3[W3_REG ? o : 0][mm] : *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 32 * h + 16 * mm + 4 * g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = fmaf(wv[r], h2[mm][r], acc); }
+        zp[o] = g4_sum(acc); }
+      { float* zq = sm + Lt::oZP + ((t * 2 + h) * 64 + lane) * Lt::ZW;      // every lane its own slot (the four g rows hold the same value): no cross-lane read needed
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) zq[o] = zp[o]; }
+      __syncthreads();   // ---- B_z: partial logits of both halves are visible
+      float z[OUT];
+      { const float* zo = sm + Lt::oZP + ((t * 2 + (1 - h)) * 64 + lane) * Lt::ZW;
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) { const float other = zo[o]; z[o] = (h ? other + zp[o] : zp[o] + other) + sm[Lt::oB3 + o]; } }      // (half 0 + half 1) + b: the same bits in both waves
+      // ======================= loss head (identical in both waves of the pair) =======================
+      float dz[OUT], dex[OUT];
+      float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f;
+      {
+        const float* q = sc + c * Lt::SCW;
+        const bool valid = q[0] != 0.f; const float oldlp = q[1], A = q[2], R = q[3];
+        const float cnt = (valid && g == 0) ? 1.f : 0.f;    // every sample is replicated in the 4 g-groups (and in both waves: only wave h = 0 reports statistics)
+#pragma unroll
+        for (int k = 0; k < OUT; ++k) dex[k] = 0.f;
+        if (KIND == MFK_VALUE) {
+          const float d = z[0] - R; dz[0] = valid ? 2.f * d * invB : 0.f; s_sq = cnt * d * d; s_ret = cnt * R;
+        } else if (KIND == MFK_CATEGORICAL) {
+          const int ai = (int)q[4];
+          float mx = z[0];
+#pragma unroll
+          for (int k = 1; k < OUT; ++k) mx = fmaxf(mx, z[k]);
+          float pk[OUT], hk[OUT]; float sum = 0.f;
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) { pk[k] = __expf(z[k] - mx); sum += pk[k]; }
+          const float inv = __builtin_amdgcn_rcpf(sum); float pa = 0.f, H = 0.f, hp = 0.f;
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) { pk[k] *= inv; pa = (k == ai) ? pk[k] : pa; const float pe = pk[k] + EPS32F; const float lg = __logf(pe); H -= pk[k] * lg;
+            hk[k] = -lg - pk[k] * __builtin_amdgcn_rcpf(pe); hp += hk[k] * pk[k]; }
+          const float newlp = __logf(pa); const float r = __expf(newlp - oldlp);
+          const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
+          const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;   // a2c_loss (a2c.jl:4-15): -mean(logpdf .* A)
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) { const float dlogpi = ((k == ai) ? 1.f : 0.f) - pk[k];
+            const float base = -a.lambda_p * coef * dlogpi - a.lambda_e * (pk[k] * (hk[k] - hp));
+            dz[k] = !valid ? 0.f : invB * base; }
+          s_lossp = cnt * lterm; s_H = cnt * H; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R;
+          s_clip = cnt * clipv;
+        } else {   // gaussian with constant log-std (policies.jl:333-348)
+          float newlp = 0.f; float dd[OUT], s2[OUT];
+          float inr[OUT];
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) { const float ls = sm[Lt::oEX + k]; const bool sq = a.squash > 0.f;
+            s2[k] = __expf(-2.f * (sq ? sq_clampls(ls) : ls)); dd[k] = q[4 + k] - z[k];
+            inr[k] = (sq && !(ls >= -5.f && ls <= 2.f)) ? 0.f : 1.f;
+            newlp += (-(dd[k] * dd[k]) * (0.5f * s2[k]) - 0.9189385332046727f - ls); }
+          if (a.squash > 0.f) newlp -= q[4 + NACT];
+          const float r = __expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
+          const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;
+          const float cf = -a.lambda_p * coef;
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) { dz[k] = valid ? invB * (cf * (dd[k] * s2[k])) : 0.f;
+            dex[k] = valid ? invB * (cf * (((dd[k] * dd[k]) * s2[k]) * inr[k] - 1.f)) : 0.f; }
+          s_lossp = cnt * lterm; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R; s_clip = cnt * clipv;
+        }
+      }
+
+      FS_T(4);
+      // ======================= backward, own samples, own feature half =======================
+      // dW3 rows of this half: sum over the 16 samples of dz[o] * h2[feature]; two outputs share one 16-value reduce-scatter (8 features each)
+#pragma unroll
+      for (int o2 = 0; o2 < (OUT + 1) / 2; ++o2) { float pv[16];
+#pragma unroll
+        for (int oo = 0; oo < 2; ++oo)
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[8 * oo + 4 * mm + r] = (2 * o2 + oo < OUT) ? dz[(2 * o2 + oo < OUT) ? 2 * o2 + oo : 0] * h2[mm][r] : 0.f;
+        const float sred = row16_reduce_scatter(pv, c);      // lane c: output 2 o2 + (c >> 3), feature 32h + 16 ((c >> 2) & 1) + 4g + (c & 3)
+        const int oo = c >> 3;
+        if (2 * o2 + oo < OUT) part[Lt::pW3 + (2 * o2 + oo) * MF_HID + 32 * h + 16 * ((c >> 2) & 1) + 4 * g + (c & 3)] = sred; }
+      { f32x4 d2[2];
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) d2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < OUT; ++o)
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) { const f32x4 wv = W3_REG ? w3[W3_REG ? o : 0][mm] : *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 32 * h + 16 * mm + 4 * g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d2[mm][r] = fmaf(wv[r], dz[o], d2[mm][r]); }
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h2[mm][r] = actg<ACT>(h2[mm][r], d2[mm][r]); }       // h2 now holds dZ2 of this half
+      if (h == 0) {      // statistics and the head's own gradient sums (db3, dlogSigma): once per tile
+        constexpr int NV = 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0);
+        float mv[((NV + 15) / 16) * 16];
+#pragma unroll
+        for (int k = 0; k < ((NV + 15) / 16) * 16; ++k) mv[k] = 0.f;
+        mv[0] = s_lossp; mv[1] = s_H; mv[2] = s_kl; mv[3] = s_adv; mv[4] = s_ret; mv[5] = s_clip; mv[6] = s_sq;
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) { mv[7 + o] = dz[o]; if (KIND == MFK_GAUSSIAN) mv[7 + OUT + o] = dex[o]; }
+#pragma unroll
+        for (int ch = 0; ch < (NV + 15) / 16; ++ch) { float cv[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) cv[k] = mv[16 * ch + k];
+          const float tq = row16_reduce_scatter(cv, c);
+          if (g == 0) part[Lt::pMISC + 16 * ch + c] = tq; } }
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T2[t_wr + (16 * (2 * h + mm) + r) * 16] = h2[mm][r];
+      { float* dq = sm + Lt::oD2X + ((t * 2 + h) * 2) * 256 + lane * 4;     // the same values in A-operand (register) layout for the partner's dH1
+        *(f32x4*)&dq[0] = h2[0]; *(f32x4*)&dq[256] = h2[1]; }
+      FS_T(5);
+      __syncthreads();   // ---- B_1: T1 / T2 tiles of the workgroup and the dZ2 halves are visible
+      FS_T(6);
+      // ======================= this wave's dW2 tiles over the workgroup's samples, sent to the exchange slots at once =======================
+      f32x4 gW2[WT];
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm) gW2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ws = 0; ws < TILES; ++ws) {
+        const float* t2 = sm + Lt::oT2 + ws * Lt::TILE; const float* t1 = sm + Lt::oT1 + ws * Lt::TILE;
+        const f32x4 av = *(const f32x4*)&t2[t_rd + 256 * mp0];          // A[i=c -> o=16mp0+c][k -> sample 4g+r]
+#pragma unroll
+        for (int mm = 0; mm < WT; ++mm) { const f32x4 bv = *(const f32x4*)&t1[t_rd + 256 * (m0 + mm)];   // B[k -> sample][j=c -> i]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gW2[mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], gW2[mm], 0, 0, 0); }
+      }
+      float* mine = a.xbuf + (size_t)(((int)(xstep & 1) * NWG + p)) * XSLOT;
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm) *(f32x4*)&mine[tid * (4 * WT) + 4 * mm] = gW2[mm];      // acknowledged long before the s_waitcnt below
+      FS_T(7);
+      // dH1 (R) for the h1 features [32h, 32h + 32) = dZ2 (C regs as A: [i=c -> sample][k -> f' = 16mp+4g+r]) x W2 (B: W2[f'][f = 16m+c] = W2C[f][f']); K = all 64 dZ2 features:
+      // the own half from registers, the partner's from its A-layout copy
+      f32x4 dz1r[2];
+      { const float* dq = sm + Lt::oD2X + ((t * 2 + (1 - h)) * 2) * 256 + lane * 4;
+        f32x4 av[4]; av[0] = h2[0]; av[1] = h2[1]; av[2] = *(const f32x4*)&dq[0]; av[3] = *(const f32x4*)&dq[256];      // own half (features 32h + 16 mm ..), then the partner's (32 (1-h) + 16 mm ..)
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int fo = 32 * ((q >> 1) ? 1 - h : h) + 16 * (q & 1);      // dZ2 feature block of this k step
+          const f32x4 wv0 = *(const f32x4*)&sm[Lt::oW2C + (32 * h + c) * FS_LD + fo + 4 * g];
+          const f32x4 wv1 = *(const f32x4*)&sm[Lt::oW2C + (32 * h + 16 + c) * FS_LD + fo + 4 * g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][r], wv0[r], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][r], wv1[r], acc1, 0, 0, 0); } }
+        dz1r[0] = acc0; dz1r[1] = acc1; }
+      FS_T(8);
+      // dZ1 (R)[sample 4g+r][f = 16m+c] = act'(H1 R) .* dH1 (R), m = 2h + mm; bias gradients of both hidden layers for this half
+      float gb1[2], gb2[2];
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) { float sb1 = 0.f, sb2 = 0.f;
+        const f32x4 h1r = *(const f32x4*)&T1[t_rd + 256 * (2 * h + mm)];
+        const f32x4 d2 = *(const f32x4*)&T2[t_rd + 256 * (2 * h + mm)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = actg<ACT>(h1r[r], dz1r[mm][r]); dz1r[mm][r] = d; sb1 += d; sb2 += d2[r]; }
+        gb1[mm] = g4_sum(sb1); gb2[mm] = g4_sum(sb2); }
+      if (g == 0) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) { part[Lt::pB1 + 32 * h + 16 * mm + c] = gb1[mm]; part[Lt::pB2 + 32 * h + 16 * mm + c] = gb2[mm]; } }
+      // dW1 partial: A = dZ1 (R) [i=c -> o=16m+c][k -> sample 4g+r], B = X (R) [k -> sample][j=c -> input 16jt+c]
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt) {
+        float xR[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xR[r] = (16 * jt + c < IP) ? xs[(4 * g + r) * XP + 16 * jt + c] : 0.f;
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) { f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1r[mm][r], xR[r], acc, 0, 0, 0);
+          if (16 * jt + c < Lt::W1ROWS) *(f32x4*)&part[Lt::pW1 + (16 * jt + c) * FS_LD + 32 * h + 16 * mm + 4 * g] = acc; }
+      }
+      FS_T(9);
+      __syncthreads();   // ---- B_2: the small partial gradients of every tile are visible
+      // small parameters: add the tiles' partials of this workgroup
+      float gs[NSI];
+#pragma unroll
+      for (int k = 0; k < NSI; ++k) { float gsum = 0.f;
+        if (so_ok[k]) { const int po = Lt::oPART + so_part[k];
+          gsum = sm[po];
+#pragma unroll
+          for (int q = 1; q < TILES; ++q) gsum += sm[po + q * Lt::PART]; }
+        gs[k] = gsum; }
+      float stat_loc = 0.f;
+      if (tid >= NT - 8 && tid < NT - 1) { const int k = tid - (NT - 8); stat_loc = sm[Lt::oPART + Lt::pST + k];   // stat sums, by 7 lanes of the last wave
+#pragma unroll
+        for (int q = 1; q < TILES; ++q) stat_loc += sm[Lt::oPART + q * Lt::PART + Lt::pST + k]; }
+      float stat_tot = stat_loc;
+      // ---- exchange the partial gradients with the other workgroups through the shared L2 ----
+      {
+#pragma unroll
+        for (int k = 0; k < NSI; ++k) mine[4096 + tid + NT * k] = gs[k];
+        if (tid >= NT - 8 && tid < NT - 1) mine[4096 + NSI * NT + (tid - (NT - 8))] = stat_loc;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this lane has reached the L2 (the dW2 partials left before dH1: long acknowledged)
+        FS_T(10);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(a.xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // second arrival: the small partials are in the L2 too
+        // the wait for the slowest workgroup is spent staging the NEXT minibatch (rows prefetched a step ago; the tiles' x / scalar rows are free after B_2)
+        if (st + a.bs < total_rows) { stage(); staged = true; }
+        if (tid == 0) {
+          const unsigned want = (unsigned)NWG * (unsigned)(xstep + 1); unsigned spins = 0; bool ok = true;
+          while (__hip_atomic_load(a.xctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24) || __hip_atomic_load(a.xctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; } }   // never hang the GPU
+          float why = ok ? 0.f : 1.f;                                   // 1: a workgroup never arrived (or raised the abort word)
+          if (ok && xstep == 0) {   // the unfenced exchange is only coherent inside one XCD's L2
+            for (int q = 0; q < NWG; ++q) { const unsigned peer_xcc = __hip_atomic_load(a.xctr + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (peer_xcc != my_xcc + 1u) { ok = false; why = 2.f; } } }   // 2: the workgroups of this learner sit on different XCDs
+          if (!ok) __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sm[Lt::oRED + 16] = why;
+        }
+        __syncthreads();
+        if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; why_failed = (int)sm[Lt::oRED + 16]; break; }
+        FS_T(11);
+        // The total is formed as (s0 + s1) + (s2 + s3): a workgroup adds its own contribution (registers) to its pair partner's slot -- a + b == b + a bitwise, so both
+        // partners hold the same pair sum --, the other pair's two slots in index order, and then the two pair sums, again a commutative add: the same bits in all four
+        // workgroups without reading the own slot back and without any selection by p. Two workgroups: own + peer.
+        // (A two-phase form -- the dW2 partials, 89 % of a slot, announced by a counter of their own and loaded before the second arrival -- was measured and dropped: the
+        //  exchange is a chain of L2 round trips, not a bandwidth problem, and every variant added a round trip: 7.19 / 7.59 us per step against 7.10 us.)
+        constexpr int NLD = NWG - 1;
+        f32x4 pw[NLD][WT]; float pg[NLD][NSI]; float ps[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) { const int q = j == 0 ? (p ^ 1) : ((p ^ 2) & 2) + (j - 1);      // partner, then the other pair's first and second workgroup
+          const float* peer = a.xbuf + (size_t)(((int)(xstep & 1) * NWG + q)) * XSLOT;
+#pragma unroll
+          for (int k = 0; k < NSI; ++k) pg[j][k] = __hip_atomic_load(peer + 4096 + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ps[j] = 0.f;
+          if (tid >= NT - 8 && tid < NT - 1) ps[j] = __hip_atomic_load(peer + 4096 + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(pw[j][mm]) : "v"(peer + tid * (4 * WT) + 4 * mm) : "memory"); }
+        if constexpr (NWG == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pw[0][0]), "+v"(pw[0][1]) :: "memory");
+        else { asm volatile("s_waitcnt vmcnt(0)" : "+v"(pw[0][0]), "+v"(pw[0][1]), "+v"(pw[0][2]), "+v"(pw[0][3]), "+v"(pw[1][0]), "+v"(pw[1][1]), "+v"(pw[1][2]), "+v"(pw[1][3]) :: "memory");
+          asm volatile("" : "+v"(pw[2][0]), "+v"(pw[2][1]), "+v"(pw[2][2]), "+v"(pw[2][3]) :: "memory"); }
+        if constexpr (NWG == 2) {
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) gW2[mm] += pw[0][mm];
+#pragma unroll
+          for (int k = 0; k < NSI; ++k) gs[k] += pg[0][k];
+          stat_tot = stat_loc + ps[0];
+        } else {
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) gW2[mm] = (gW2[mm] + pw[0][mm]) + (pw[1][mm] + pw[2][mm]);
+#pragma unroll
+          for (int k = 0; k < NSI; ++k) gs[k] = (gs[k] + pg[0][k]) + (pg[1][k] + pg[2][k]);
+          stat_tot = (stat_loc + ps[0]) + (ps[1] + ps[2]);
+        }
+        xstep += 1;
+      }
+      if (tid >= NT - 8 && tid < NT - 1) sm[Lt::oRED + 8 + (tid - (NT - 8))] = stat_tot;
+      float ssq = 0.f; int bad = 0;
+#pragma unroll
+      for (int k = 0; k < NSI; ++k) if (so_ok[k]) {
+        if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += -a.lambda_e;      // d(-lambda_e H)/dlogSigma, H = const + sum(logSigma)
+        ssq += gs[k] * gs[k]; bad |= isnan(gs[k]) ? 1 : 0; }
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssq += gW2[mm][r] * gW2[mm][r]; bad |= isnan(gW2[mm][r]) ? 1 : 0; }
+      ssq = wave_sum(ssq);
+      if (lane == 0) sm[Lt::oRED + w] = ssq;
+      FS_T(12);
+      const int any_bad = __syncthreads_or(bad);   // ---- B_or (also publishes RED)
+      FS_T(13);
+      // minibatch info (training.jl:22-23, ppo.jl:13-19); identical in every thread; only the epoch's last minibatch (or the one that stops the loop) is ever reported
+      { const float* tq = sm + Lt::oRED + 8;
+        if (KIND != MFK_VALUE && a.target_kl >= 0.f) inf_kl = tq[2] * invB;
+        const bool report = any_bad || st + a.bs >= total_rows || (a.max_batches > 0 && total_batches + 1 >= a.max_batches) ||
+                            (KIND != MFK_VALUE && a.target_kl >= 0.f && inf_kl > a.target_kl);
+        if (report) {
+          float ss = sm[Lt::oRED];
+#pragma unroll
+          for (int q = 1; q < NW; ++q) ss += sm[Lt::oRED + q];
+          inf_gn = sqrtf(ss);
+          if (KIND == MFK_VALUE) { inf_loss = tq[6] * invB; inf_ret = tq[4] * invB; }
+          else { const float p_loss = -(tq[0] * invB); float entropy;
+            if (KIND == MFK_CATEGORICAL) entropy = tq[1] * invB;
+            else { entropy = 1.4189385332046727f;
+#pragma unroll
+              for (int k = 0; k < OUT; ++k) entropy += sm[Lt::oEX + k]; }
+            inf_ent = entropy; inf_loss = a.lambda_p * p_loss + a.lambda_e * (-entropy); inf_kl = tq[2] * invB; inf_adv = tq[3] * invB; inf_ret = tq[4] * invB; inf_clip = tq[5] * invB; }
+        }
+      }
+      if (any_bad) { inf_gn = NAN; err = CRUX_ENAN; break; }                   // training.jl:20: no update
+      // ======================= Adam (Flux.update!, training.jl:21) =======================
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float m_ = mW2[mm][r], v_ = vW2[mm][r]; const float d = adam1(gW2[mm][r], m_, v_, ak);
+          mW2[mm][r] = m_; vW2[mm][r] = v_; tW2[mm][r] -= d;
+          sm[Lt::oW2R + (16 * mp0 + 4 * g + r) * FS_LD + 16 * (m0 + mm) + c] = tW2[mm][r]; }
+        *(f32x4*)&sm[Lt::oW2C + (16 * (m0 + mm) + c) * FS_LD + 16 * mp0 + 4 * g] = tW2[mm]; }
+#pragma unroll
+      for (int k = 0; k < NSI; ++k) { const int s = tid + NT * k;
+        if (so_ok[k]) { float m_ = sm[Lt::oMS + s], v_ = sm[Lt::oVS + s]; const float d = adam1(gs[k], m_, v_, ak);
+          sm[Lt::oMS + s] = m_; sm[Lt::oVS + s] = v_; const int mo = so_master[k]; sm[mo] = sm[mo] - d; } }
+      bp1 *= a.b1; bp2 *= a.b2;
+      FS_T(14);
+      __syncthreads();   // ---- B_b: masters updated; tiles and partials may be overwritten
+      FS_T(15);
+      total_batches += 1;
+      if (a.max_batches > 0 && total_batches >= a.max_batches) break;          // training.jl:45
+      if (a.target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > a.target_kl) break;   // :46
+    }
+    if (err) break;
+    if (tid == 0 && p == 0 && a.epoch_infos) { float* e = a.epoch_infos + (size_t)ep * CRUX_INFO_N;   // aggregate_info(minibatch_infos) == last minibatch (Q3)
+      for (int k = 0; k < CRUX_INFO_N; ++k) e[k] = 0.f;
+      e[CRUX_INFO_LOSS] = inf_loss; e[CRUX_INFO_GRAD_NORM] = inf_gn;
+      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = inf_ent; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = inf_clip; e[CRUX_INFO_AVG_ADVANTAGE] = inf_adv; e[CRUX_INFO_AVG_RETURN] = inf_ret; } }
+    epochs_run += 1;
+    if (a.target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > a.target_kl) stop = true;   // :49
+    if (a.max_batches > 0 && total_batches >= a.max_batches) stop = true;               // :50
+  }
+  // ---- write back parameters and Adam state --------------------------------------------------------------------
+  __syncthreads();
+  if (p == 0) {
+#pragma unroll
+    for (int mm = 0; mm < WT; ++mm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + MF_HID * (16 * (m0 + mm) + c);
+        a.p[pc] = tW2[mm][r]; a.m[pc] = mW2[mm][r]; a.v[pc] = vW2[mm][r]; }
+    for (int s = tid; s < ns_valid; s += NT) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; }
+  }
+  if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(NW * p + w) * 16 + k] = tacc[k]; }
+  if (tid == 0 && (p == 0 || err)) {
+    a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
+    if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs
+    a.bp[0] = bp1; a.bp[1] = bp2;
+    if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = inf_loss; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
+  }
+#undef FS_T
+}

@@ -45,9 +45,9 @@ static int32_t launch_x2(crux_ctx* c, TrainArgs a, hipStream_t stream) {
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
   // exchange area: one per stream the learners run on (actor || critic use the context's two streams concurrently)
   const int which = stream == c->stream ? 0 : 1;
-  constexpr size_t xbytes = sizeof(float) * 4 * 8192 + 256;
+  constexpr size_t xbytes = sizeof(float) * CRUX_XBUF_FLOATS + 256;
   if (!c->xbuf[which]) { if (hipMalloc(&c->xbuf[which], xbytes) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "learner exchange buffer"); }
-  a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * 4 * 8192);
+  a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * CRUX_XBUF_FLOATS);
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
   if (c->peer_n > 1 && a.need_px) {     // local calls (single steps, gradients) never exchange
     a.px_hist = c->peer_hist ? 1 : 0; a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
@@ -103,8 +103,10 @@ int32_t crux_train_mfma_x2_launch_multi(crux_ctx* c, std::vector<TrainArgs>& as,
 // Called by crux_train_mfma_launch after its shape checks, before the single-CU kernels.
 // any_mode = false: only full minibatch loops of 65..128 rows (where two CUs pay); true: also single steps, gradient-only calls and small minibatches
 // (workgroup 1 then idles on empty tiles) -- used for the shapes that have no one-CU instantiation.
+int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream);      // train_fs.hip: the feature-split form
 int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream, bool any_mode) {
   *handled = false;
+  { const int32_t rc = crux_train_fs_launch(c, a, kind, handled, stream); if (rc || *handled) return rc; }
   static const bool off = getenv("CRUX_MFMA_X2") && getenv("CRUX_MFMA_X2")[0] == '0';
   if (off) return CRUX_OK;
   if (!any_mode && (a.ids || !a.apply || a.bs <= 64 || a.len < a.bs)) return CRUX_OK;     // single steps and small batches stay on one CU when it has the shape

@@ -66,9 +66,11 @@ def test_a2c_and_reinforce_solve_match_oracle_loop(gpu_ctx, algo):
     assert np.isfinite(solver.history[-1]["actor_loss"]) and "kl" in solver.history[-1]
 
 
-def test_multi_seed_batched_learners_match_single_calls(gpu_ctx):
+def test_multi_seed_batched_learners_match_single_calls(gpu_ctx, monkeypatch):
     """crux_policy_gradient_training_multi: n independent learners in two batched launches == n single calls with the per-replica seeds (bit for bit:
-    same kernel, same arithmetic; only the launch geometry differs)."""
+    same kernel, same arithmetic; only the launch geometry differs). The population launch runs the sample-split two-CU kernel, so the single calls are kept on
+    it too (CRUX_FS=0: the feature-split form sums a minibatch gradient in another order)."""
+    monkeypatch.setenv("CRUX_FS", "0")
     import os
     from parity import crux
     if os.environ.get("CRUX_MFMA_X2") == "0" or os.environ.get("CRUX_MFMA_WAVES4") or os.environ.get("CRUX_FORCE_GENERIC"):
