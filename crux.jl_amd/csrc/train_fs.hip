@@ -4,14 +4,21 @@
 
 extern "C" int crux_x2_placement_ok(crux_ctx* c);      // train_mfma_x2.hip: workgroups i and i + 8 of a grid share an XCD (probed once per process)
 
-template <int IN, int OUT, int KIND, int ACT, int NWG, bool TIMING>
+template <int IN, int OUT, int KIND, int ACT, int NWG, bool HELP, bool TIMING>
 static int32_t launch_fs_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
-  using Lt = FsLayout<IN, OUT, NWG>;
+  using Lt = FsLayout<IN, OUT, NWG, HELP>;
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
   static bool attr = false;
-  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs<IN, OUT, KIND, ACT, NWG, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-  hipLaunchKernelGGL((k_train_fs<IN, OUT, KIND, ACT, NWG, TIMING>), dim3(8 * NWG), dim3(Lt::NT), lds, stream, a);
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING>), dim3(8 * NWG), dim3(Lt::NT), lds, stream, a);
   return crux_launch_check(c, "k_train_fs");
+}
+// form: 2 = two workgroups of eight waves; 4 = four workgroups of four waves; 8 = four workgroups of four compute + four helper waves
+template <int IN, int OUT, int KIND, int ACT, bool TIMING>
+static int32_t launch_fs_pick(crux_ctx* c, TrainArgs& a, int form, hipStream_t stream) {
+  if (form == 2) return launch_fs_form<IN, OUT, KIND, ACT, 2, false, TIMING>(c, a, stream);
+  if (form == 4) return launch_fs_form<IN, OUT, KIND, ACT, 4, false, TIMING>(c, a, stream);
+  return launch_fs_form<IN, OUT, KIND, ACT, 4, true, TIMING>(c, a, stream);
 }
 template <int IN, int OUT, int KIND, int ACT>
 static int32_t launch_fs(crux_ctx* c, TrainArgs a, int nwg, bool timing, hipStream_t stream) {
@@ -22,18 +29,20 @@ static int32_t launch_fs(crux_ctx* c, TrainArgs a, int nwg, bool timing, hipStre
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
   if (timing) {
     static unsigned long long* dbg = nullptr;
-    if (!dbg) { if (hipMalloc(&dbg, 256 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
+    if (!dbg) { if (hipMalloc(&dbg, 512 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
     a.dbg = dbg;
-    int32_t rc = nwg == 2 ? launch_fs_form<IN, OUT, KIND, ACT, 2, true>(c, a, stream) : launch_fs_form<IN, OUT, KIND, ACT, 4, true>(c, a, stream); if (rc) return rc;
-    unsigned long long h[256]; HIPCHK(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, stream)); HIPCHK(c, hipStreamSynchronize(stream));
+    int32_t rc = launch_fs_pick<IN, OUT, KIND, ACT, true>(c, a, nwg, stream); if (rc) return rc;
+    unsigned long long h[512]; HIPCHK(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, stream)); HIPCHK(c, hipStreamSynchronize(stream));
     static const char* nm[16] = {"loop+prefetch", "stage", "fwdL1+T1", "fwdL2", "L3+z-exchange+head", "dW3+dZ2+stats+T2", "wait B_1", "dW2+send", "dH1", "dZ1+db+dW1", "B_2+reduce+store", "exchange wait",
                                  "load slots+total+ssq", "wait B_or", "info+adam", "wait B_b"};
-    const int nw = 16 / nwg;
-    for (int w = 0; w < 16; w += nw) { fprintf(stderr, "[fs-timing] %d-%d wg %d wave 0:", IN, OUT, w / nw); unsigned long long tot = 0; for (int k = 0; k < 16; ++k) tot += h[w * 16 + k];
+    const int nw = nwg == 8 ? 8 : 16 / nwg, ntot = nwg == 2 ? 16 : (nwg == 4 ? 16 : 32);
+    if (nwg == 8) { fprintf(stderr, "[fs-timing] %d-%d wg 0 helper wave 4:", IN, OUT); unsigned long long tot = 0; for (int k = 0; k < 16; ++k) tot += h[4 * 16 + k];
+      for (int k = 0; k < 16; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[4 * 16 + k] / (double)tot); fprintf(stderr, " total=%llu\n", tot); }
+    for (int w = 0; w < ntot; w += nw) { fprintf(stderr, "[fs-timing] %d-%d wg %d wave 0:", IN, OUT, w / nw); unsigned long long tot = 0; for (int k = 0; k < 16; ++k) tot += h[w * 16 + k];
       for (int k = 0; k < 16; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[w * 16 + k] / (double)tot); fprintf(stderr, " total=%llu\n", tot); }
     return CRUX_OK;
   }
-  return nwg == 2 ? launch_fs_form<IN, OUT, KIND, ACT, 2, false>(c, a, stream) : launch_fs_form<IN, OUT, KIND, ACT, 4, false>(c, a, stream);
+  return launch_fs_pick<IN, OUT, KIND, ACT, false>(c, a, nwg, stream);
 }
 
 // Called by crux_train_mfma_x2_launch for the plain learners (no replica group, no lagrange loss, no explicit ids). CRUX_FS=0 switches the form off (the sample-split
@@ -45,12 +54,20 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* ha
   if (mode == 0) return CRUX_OK;
   if (a.ids || !a.apply || a.bs <= 64 || a.bs > 128 || a.len < a.bs || a.lag || a.need_px) return CRUX_OK;
   if (!crux_x2_placement_ok(c)) return CRUX_OK;
-  const int nwg = nwg_env == 2 || nwg_env == 4 ? nwg_env : CRUX_FS_DEFAULT_WG;
+  const int nwg = nwg_env == 2 || nwg_env == 4 || nwg_env == 8 ? nwg_env : CRUX_FS_DEFAULT_WG;      // 8 = four workgroups with helper waves
   const bool timing = getenv("CRUX_MFMA_TIMING") != nullptr;
   const int in = a.nd.dims[0], out = a.nd.dims[3], act = a.nd.acts[0];
 #define FS_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_fs<I, O, K, A_>(c, a, nwg, timing, stream); }
   FS_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)     // C2 actor  (PPO CartPole)
   FS_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)           // C2 critic
+  FS_CASE(3, 1, MFK_GAUSSIAN, CRUX_ACT_RELU)        // Pendulum actor
+  FS_CASE(3, 1, MFK_VALUE, CRUX_ACT_RELU)           // Pendulum critic
+  FS_CASE(17, 6, MFK_GAUSSIAN, CRUX_ACT_RELU)       // C5 actor  (PPO HalfCheetah-shaped, 17 obs / 6 act)
+  FS_CASE(17, 6, MFK_GAUSSIAN, CRUX_ACT_TANH)
+  FS_CASE(17, 1, MFK_VALUE, CRUX_ACT_RELU)          // C5 critic
+  FS_CASE(17, 1, MFK_VALUE, CRUX_ACT_TANH)
+  FS_CASE(8, 4, MFK_CATEGORICAL, CRUX_ACT_RELU)     // 8 observations / 4 discrete actions (LunarLander-shaped)
+  FS_CASE(8, 1, MFK_VALUE, CRUX_ACT_RELU)
 #undef FS_CASE
   return CRUX_OK;
 }

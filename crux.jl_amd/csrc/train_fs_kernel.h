@@ -23,9 +23,11 @@
 #define FS_LD 72
 __device__ __forceinline__ int fs_tx(int q) { return (4 - q) & 3; }   // {0,3,2,1}
 
-template <int IN, int OUT, int NWG>
+template <int IN, int OUT, int NWG, bool HELP = false>
 struct FsLayout {
-  static constexpr int NW = 16 / NWG, TILES = NW / 2, NT = 64 * NW;
+  static constexpr int NWC = 16 / NWG, TILES = NWC / 2;                    // compute waves (a pair per 16-sample tile)
+  static constexpr int NW = HELP ? 2 * NWC : NWC, NT = 64 * NW;            // + as many helper waves: owners of half the W2 tiles, and the minibatch staging
+  static constexpr int NXB = HELP ? 2 : 1;                                 // staging rows are double-buffered when the helpers stage the next minibatch during the step
   static constexpr int KS0 = (IN + 3) / 4, IP = KS0 * 4, JT = (IN + 15) / 16, XP = IP + 2, W1LD = IP + 2;
   static constexpr int SCW = (4 + (OUT > 4 ? OUT : 4)) | 1;
   static constexpr int ZW = OUT;                                                          // partial logits per (tile, half, g, sample)
@@ -46,8 +48,8 @@ struct FsLayout {
   static constexpr int oZP = oD2X + TILES * 2 * 2 * 256;                  // [tile][half][g 4][sample 16][ZW]
   static constexpr int oPART = ((oZP + TILES * 2 * 64 * ZW + 3) / 4) * 4; // [tile][PART]
   static constexpr int oXS = oPART + TILES * PART;
-  static constexpr int oSC = oXS + TILES * 16 * XP;
-  static constexpr int oRED = oSC + TILES * 16 * SCW;                     // [0,8): per-wave sum of squares; [8,15): reduced stat sums; [16]: abort flag
+  static constexpr int oSC = oXS + NXB * TILES * 16 * XP;
+  static constexpr int oRED = oSC + NXB * TILES * 16 * SCW;                     // [0,8): per-wave sum of squares; [8,15): reduced stat sums; [16]: abort flag
   static constexpr int TOTAL = oRED + 32;
   static constexpr int NSI = (NS + NT - 1) / NT;
   static constexpr int XSLOT = ((4096 + NSI * NT + 16 + 3) / 4) * 4;      // floats per exchange slot
@@ -55,21 +57,29 @@ struct FsLayout {
   static_assert(XSLOT <= 8192, "exchange slot");
 };
 
-template <int IN, int OUT, int KIND, int ACT, int NWG, bool TIMING = false>
-__global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
-  static_assert(NWG == 2 || NWG == 4, "two workgroups of eight waves, or four of four");
-  using Lt = FsLayout<IN, OUT, NWG>;
-  constexpr int NW = Lt::NW, TILES = Lt::TILES, NT = Lt::NT, WT = 16 / NW;
+template <int IN, int OUT, int KIND, int ACT, int NWG, bool HELP = false, bool TIMING = false>
+__global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(TrainArgs a) {
+  static_assert(NWG == 2 || NWG == 4, "two workgroups of eight waves, or four of four (+ four helper waves)");
+  static_assert(!HELP || NWG == 4, "helper waves: the four-workgroup form");
+  using Lt = FsLayout<IN, OUT, NWG, HELP>;
+  constexpr int NW = Lt::NW, NWC = Lt::NWC, TILES = Lt::TILES, NT = Lt::NT, WT = 16 / NW;
   constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS, NSI = Lt::NSI, XSLOT = Lt::XSLOT;
   constexpr int NACT = (OUT > 4 ? OUT : 4);
   if ((blockIdx.x & 7) != 0) return;                 // the NWG workgroups of the learner: blocks 0, 8, 16, 24 -> one XCD (consecutive workgroups go round-robin over the 8 XCDs)
   const int p = (int)(blockIdx.x >> 3);              // workgroup 0 .. NWG-1 of this learner
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-  const int t = w >> 1, h = w & 1;                   // sample tile of the workgroup, feature half
+  // Helper waves (HELP): waves NWC .. 2 NWC - 1 have no tile. They own half of the W2 tiles (dW2, its exchange, Adam: the per-lane share of a wave halves and two waves
+  // per SIMD interleave their instruction streams) and they prefetch and stage the NEXT minibatch while the compute waves run the forward pass.
+  const bool cw = !HELP || w < NWC;                  // compute wave
+  const int wt = HELP ? (w & (NWC - 1)) : w;         // (tile, half) role: of the tile work for a compute wave, of the staging work for a helper
+  const int t = wt >> 1, h = wt & 1;                 // sample tile of the workgroup, feature half
+  const bool sw = HELP ? !cw : true;                 // this wave prefetches / stages minibatch rows
   float* part = sm + Lt::oPART + t * Lt::PART;
-  float* xs = sm + Lt::oXS + t * 16 * XP;
+  float* xs = sm + Lt::oXS + t * 16 * XP;            // (+ buffer offset when double-buffered)
   float* sc = sm + Lt::oSC + t * 16 * Lt::SCW;
+  constexpr int XSB = TILES * 16 * XP, SCB = TILES * 16 * Lt::SCW;      // one staging buffer
+  int xcur = 0;                                      // buffer the current minibatch sits in
   float* T1 = sm + Lt::oT1 + t * Lt::TILE;
   float* T2 = sm + Lt::oT2 + t * Lt::TILE;
   const int n_extra = (KIND == MFK_GAUSSIAN) ? OUT : 0;
@@ -80,6 +90,7 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
   const int t_rd = c * 16 + 4 * (g ^ fs_tx(c >> 2));                    // tile b128 (feature c [+16m], samples 4g..4g+3)
   // dW2 / W2 ownership: four waves own the tiles (mp0 = w, m = 0..3) = rows [16w, 16w+16); eight waves the tiles (mp0, m0) and (mp0, m0 + 1)
   const int mp0 = NW == 4 ? w : (w >> 1), m0 = NW == 4 ? 0 : 2 * (w & 1);
+  (void)sw; (void)xcur;
 
   auto s_master = [&](int s) -> int {
     if (s < Lt::sB1) { const int o = s & 63, i = s >> 6; return Lt::oW1R + o * Lt::W1LD + i; }
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
   for (int s = tid; s < NS; s += NT) { const bool in = s < ns_valid; const int pc = s_canon(s);
     if (in) sm[s_master(s)] = a.p[pc];
     sm[Lt::oMS + s] = in ? a.m[pc] : 0.f; sm[Lt::oVS + s] = in ? a.v[pc] : 0.f; }
-  for (int q = tid; q < TILES * 16 * XP; q += NT) sm[Lt::oXS + q] = 0.f;
+  for (int q = tid; q < Lt::NXB * TILES * 16 * XP; q += NT) sm[Lt::oXS + q] = 0.f;
   // owned W2 tiles, D layout: reg r of tile mm <-> W2[o = 16 mp0 + 4g + r][i = 16 (m0+mm) + c]
   f32x4 tW2[WT], mW2[WT], vW2[WT];
 #pragma unroll
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
   for (int e = 0; e < NXL; ++e) px[e] = 0.f;
   int n_row = 0, n_valid = 0;
   auto fetch_index = [&](const int32_t* ord, int64_t st, int nb) {
-    const int sidx = 8 * NW * p + 16 * t + c;
+    const int sidx = 8 * NWC * p + 16 * t + c;
     n_valid = sidx < nb ? 1 : 0;
     n_row = n_valid ? CRUX_GLOBAL_PTR(int32_t, ord)[st + sidx] : 0;
   };
@@ -196,16 +207,17 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
       }
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int buf) {
+    float* xs_ = xs + buf * XSB; float* sc_ = sc + buf * SCB;
     if (h == 0) {
 #pragma unroll
-      for (int e = 0; e < NXL; ++e) { const int f = (lane & 3) * NXL + e; if (f < IN) xs[(lane >> 2) * XP + f] = px[e]; }
+      for (int e = 0; e < NXL; ++e) { const int f = (lane & 3) * NXL + e; if (f < IN) xs_[(lane >> 2) * XP + f] = px[e]; }
     } else {
       if (KIND == MFK_CATEGORICAL) { int ai = 0;
 #pragma unroll
         for (int k = 0; k < OUT; ++k) ai = p_abyte[k] ? k : ai;
         p_act[0] = (float)ai; }
-      if (lane < 16) { float* q = sc + lane * Lt::SCW; q[0] = (float)p_valid; q[1] = p_lp; q[2] = p_adv; q[3] = p_ret;
+      if (lane < 16) { float* q = sc_ + lane * Lt::SCW; q[0] = (float)p_valid; q[1] = p_lp; q[2] = p_adv; q[3] = p_ret;
         if (KIND == MFK_GAUSSIAN) {       // SquashedGaussianPolicy: the stored action is un-tanh'd once here and the tanh correction of logpdf rides in the spare slot
           static_assert(KIND != MFK_GAUSSIAN || ((4 + NACT) % 2 == 0), "the staging row needs its spare slot");
           float corr = 0.f;
@@ -228,25 +240,32 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
       int32_t* tq = order_cur; order_cur = order_nxt; order_nxt = tq;
     }
     staged = false;
-    { const int nb0 = (int)(total_rows < a.bs ? total_rows : a.bs); fetch_index(order_cur, 0, nb0); fetch_data();
+    if (sw) { const int nb0 = (int)(total_rows < a.bs ? total_rows : a.bs); fetch_index(order_cur, 0, nb0); fetch_data();
       const int64_t st1 = a.bs; const int nb1 = st1 < total_rows ? (int)((total_rows - st1) < a.bs ? (total_rows - st1) : a.bs) : 0; fetch_index(order_cur, st1 < total_rows ? st1 : 0, nb1); }
     for (int64_t st = 0; st < total_rows; st += a.bs) {
       const int nb = (int)((total_rows - st) < a.bs ? (total_rows - st) : a.bs);
       const float invB = 1.0f / (float)nb;
       ak.c1 = __builtin_amdgcn_rcpf((float)(1.0 - bp1)); ak.c2 = __builtin_amdgcn_rcpf((float)(1.0 - bp2));
       FS_T(0);
-      if (!staged) { stage(); __syncthreads(); }     // the first minibatch of an epoch; every other one was staged inside the previous step's exchange wait (barriers follow it there)
+      if (!staged) { if (sw) stage(HELP ? xcur : 0); __syncthreads(); }     // the first minibatch of an epoch; every other one was staged during the previous step (barriers follow it there)
       staged = false;
-      if (st + a.bs < total_rows) fetch_data();
-      { const int64_t st2 = st + 2 * (int64_t)a.bs; const int nb2 = st2 < total_rows ? (int)((total_rows - st2) < a.bs ? (total_rows - st2) : a.bs) : 0;
+      if (sw) {
+        if (st + a.bs < total_rows) fetch_data();
+        const int64_t st2 = st + 2 * (int64_t)a.bs; const int nb2 = st2 < total_rows ? (int)((total_rows - st2) < a.bs ? (total_rows - st2) : a.bs) : 0;
         fetch_index(order_cur, st2 < total_rows ? st2 : 0, nb2); }
+      const float* xs_c = xs + (HELP ? xcur * XSB : 0); const float* sc_c = sc + (HELP ? xcur * SCB : 0);      // the current minibatch's rows
 
       FS_T(1);
       // ======================= forward, C orientation: D[feature 16m+4g+r][sample c] =======================
+      f32x4 h1[4];                                   // the WHOLE first layer in both waves of the pair
+      f32x4 h2[2];                                   // second layer: output features [32h, 32h + 32)
+      constexpr bool W3_REG = OUT <= 2;
+      f32x4 w3[OUT <= 2 ? OUT : 1][2];
+      float zp[OUT];
+      if (cw) {
       float xB[KS0];
 #pragma unroll
-      for (int ks = 0; ks < KS0; ++ks) xB[ks] = xs[c * XP + 4 * ks + g];
-      f32x4 h1[4];                                   // the WHOLE first layer in both waves of the pair
+      for (int ks = 0; ks < KS0; ++ks) xB[ks] = xs_c[c * XP + 4 * ks + g];
 #pragma unroll
       for (int m = 0; m < 4; ++m) { f32x4 acc = *(const f32x4*)&sm[Lt::oB1 + 16 * m + 4 * g];
 #pragma unroll
@@ -259,7 +278,6 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) T1[t_wr + (16 * (2 * h + mm) + r) * 16] = (h ? (mm ? h1[3][r] : h1[2][r]) : (mm ? h1[1][r] : h1[0][r]));
       FS_T(2);
-      f32x4 h2[2];                                   // second layer: output features [32h, 32h + 32)
       { f32x4 acc0 = *(const f32x4*)&sm[Lt::oB2 + 32 * h + 4 * g], acc1 = *(const f32x4*)&sm[Lt::oB2 + 32 * h + 16 + 4 * g];
 #pragma unroll
         for (int m = 0; m < 4; ++m) { const f32x4 wv0 = *(const f32x4*)&sm[Lt::oW2R + (32 * h + c) * FS_LD + 16 * m + 4 * g];
@@ -273,14 +291,11 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
 
       FS_T(3);
       // ======================= layer 3 (VALU): partial logits over this wave's 32 features, exchanged inside the pair =======================
-      f32x4 w3[OUT <= 2 ? OUT : 1][2];
-      constexpr bool W3_REG = OUT <= 2;
       if (W3_REG) {
 #pragma unroll
         for (int o = 0; o < OUT; ++o)
 #pragma unroll
           for (int mm = 0; mm < 2; ++mm) w3[o][mm] = *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 32 * h + 16 * mm + 4 * g]; }
-      float zp[OUT];
 #pragma unroll
       for (int o = 0; o < OUT; ++o) { float acc = 0.f;
 #pragma unroll
@@ -291,16 +306,19 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
       { float* zq = sm + Lt::oZP + ((t * 2 + h) * 64 + lane) * Lt::ZW;      // every lane its own slot (the four g rows hold the same value): no cross-lane read needed
 #pragma unroll
         for (int o = 0; o < OUT; ++o) zq[o] = zp[o]; }
+      }      // compute waves
       __syncthreads();   // ---- B_z: partial logits of both halves are visible
+      if (HELP && !cw && st + a.bs < total_rows) stage(xcur ^ 1);      // helpers: the NEXT minibatch (rows requested at the top of this step) goes into the other staging buffer
+      float dz[OUT], dex[OUT];
+      float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f;
+      if (cw) {
       float z[OUT];
       { const float* zo = sm + Lt::oZP + ((t * 2 + (1 - h)) * 64 + lane) * Lt::ZW;
 #pragma unroll
         for (int o = 0; o < OUT; ++o) { const float other = zo[o]; z[o] = (h ? other + zp[o] : zp[o] + other) + sm[Lt::oB3 + o]; } }      // (half 0 + half 1) + b: the same bits in both waves
       // ======================= loss head (identical in both waves of the pair) =======================
-      float dz[OUT], dex[OUT];
-      float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f;
       {
-        const float* q = sc + c * Lt::SCW;
+        const float* q = sc_c + c * Lt::SCW;
         const bool valid = q[0] != 0.f; const float oldlp = q[1], A = q[2], R = q[3];
         const float cnt = (valid && g == 0) ? 1.f : 0.f;    // every sample is replicated in the 4 g-groups (and in both waves: only wave h = 0 reports statistics)
 #pragma unroll
@@ -394,6 +412,7 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
         for (int r = 0; r < 4; ++r) T2[t_wr + (16 * (2 * h + mm) + r) * 16] = h2[mm][r];
       { float* dq = sm + Lt::oD2X + ((t * 2 + h) * 2) * 256 + lane * 4;     // the same values in A-operand (register) layout for the partner's dH1
         *(f32x4*)&dq[0] = h2[0]; *(f32x4*)&dq[256] = h2[1]; }
+      }      // compute waves
       FS_T(5);
       __syncthreads();   // ---- B_1: T1 / T2 tiles of the workgroup and the dZ2 halves are visible
       FS_T(6);
@@ -416,6 +435,7 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
       FS_T(7);
       // dH1 (R) for the h1 features [32h, 32h + 32) = dZ2 (C regs as A: [i=c -> sample][k -> f' = 16mp+4g+r]) x W2 (B: W2[f'][f = 16m+c] = W2C[f][f']); K = all 64 dZ2 features:
       // the own half from registers, the partner's from its A-layout copy
+      if (cw) {
       f32x4 dz1r[2];
       { const float* dq = sm + Lt::oD2X + ((t * 2 + (1 - h)) * 2) * 256 + lane * 4;
         f32x4 av[4]; av[0] = h2[0]; av[1] = h2[1]; av[2] = *(const f32x4*)&dq[0]; av[3] = *(const f32x4*)&dq[256];      // own half (features 32h + 16 mm ..), then the partner's (32 (1-h) + 16 mm ..)
@@ -446,13 +466,14 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
       for (int jt = 0; jt < JT; ++jt) {
         float xR[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xR[r] = (16 * jt + c < IP) ? xs[(4 * g + r) * XP + 16 * jt + c] : 0.f;
+        for (int r = 0; r < 4; ++r) xR[r] = (16 * jt + c < IP) ? xs_c[(4 * g + r) * XP + 16 * jt + c] : 0.f;
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) { f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1r[mm][r], xR[r], acc, 0, 0, 0);
           if (16 * jt + c < Lt::W1ROWS) *(f32x4*)&part[Lt::pW1 + (16 * jt + c) * FS_LD + 32 * h + 16 * mm + 4 * g] = acc; }
       }
+      }      // compute waves
       FS_T(9);
       __syncthreads();   // ---- B_2: the small partial gradients of every tile are visible
       // small parameters: add the tiles' partials of this workgroup
@@ -479,7 +500,7 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(a.xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // second arrival: the small partials are in the L2 too
         // the wait for the slowest workgroup is spent staging the NEXT minibatch (rows prefetched a step ago; the tiles' x / scalar rows are free after B_2)
-        if (st + a.bs < total_rows) { stage(); staged = true; }
+        if (st + a.bs < total_rows) { if (!HELP) stage(0); staged = true; }      // (with helper waves the next minibatch is staged already)
         if (tid == 0) {
           const unsigned want = (unsigned)NWG * (unsigned)(xstep + 1); unsigned spins = 0; bool ok = true;
           while (__hip_atomic_load(a.xctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(1);
@@ -511,9 +532,11 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
 #pragma unroll
           for (int mm = 0; mm < WT; ++mm)
             asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(pw[j][mm]) : "v"(peer + tid * (4 * WT) + 4 * mm) : "memory"); }
-        if constexpr (NWG == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pw[0][0]), "+v"(pw[0][1]) :: "memory");
-        else { asm volatile("s_waitcnt vmcnt(0)" : "+v"(pw[0][0]), "+v"(pw[0][1]), "+v"(pw[0][2]), "+v"(pw[0][3]), "+v"(pw[1][0]), "+v"(pw[1][1]), "+v"(pw[1][2]), "+v"(pw[1][3]) :: "memory");
-          asm volatile("" : "+v"(pw[2][0]), "+v"(pw[2][1]), "+v"(pw[2][2]), "+v"(pw[2][3]) :: "memory"); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) asm volatile("" : "+v"(pw[j][mm]));      // (asm statements keep their order: every use of a loaded value follows the wait)
         if constexpr (NWG == 2) {
 #pragma unroll
           for (int mm = 0; mm < WT; ++mm) gW2[mm] += pw[0][mm];
@@ -579,6 +602,7 @@ __global__ __launch_bounds__(64 * (16 / NWG)) void k_train_fs(TrainArgs a) {
       bp1 *= a.b1; bp2 *= a.b2;
       FS_T(14);
       __syncthreads();   // ---- B_b: masters updated; tiles and partials may be overwritten
+      if (HELP) xcur ^= 1;
       FS_T(15);
       total_batches += 1;
       if (a.max_batches > 0 && total_batches >= a.max_batches) break;          // training.jl:45
