@@ -194,6 +194,42 @@ def julia_reference_probe():
         return {"available": False, "why": repr(e)}
 
 
+TRAFFIC_RECORDED = {"c2": 33.1e6, "c5": 9.94e9}      # bytes per actor launch: profiles/r03_pmc_traffic.txt (2 x 13.89 MB FETCH_SIZE + 5.34 MB WRITE_SIZE), r03_pmc_traffic_c5.txt (2 x 4 961 MB + 20.8 MB: the 27 MB C5 buffer does not fit an XCD's 4 MB L2, and a gathered 68-byte observation row / 24-byte action row / 4-byte scalar costs whole 64..128-byte sectors: 60.7 KB per step against 13.3 KB algorithmic)
+
+
+def measure_traffic(workload):
+    """HBM-side bytes of ONE actor launch, measured now: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes of a one-iteration child run of this script
+    (MI355X_MICROARCH.md: no trace domains next to --pmc). FETCH_SIZE tallies 128-byte requests at 64 B (calibrated on a 2 GiB stream, profiles/r02_fetch_calibration.txt),
+    both counters are reported in KB: traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024."""
+    import csv, glob, shutil, tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="crux_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0",
+               "--no-cpu-baseline", "--replicas", "0", "--replicas-wide", "0", "--no-extra", "--workload", workload]
+        try:
+            subprocess.run(cmd, capture_output=True, timeout=600, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            per = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    kn = r["Kernel_Name"].split("(")[0]
+                    if r["Counter_Name"] != ctr or "k_train" not in kn or "<" not in kn:
+                        continue
+                    targs = kn[kn.index("<") + 1:].split(",")
+                    if len(targs) > 2 and targs[2].strip() != "2":       # template arguments <IN, OUT, KIND, ...>: KIND 2 is the critic (value head)
+                        per.append(float(r["Counter_Value"]))
+            if not per:
+                return None, "no learner kernel in the %s pass" % ctr
+            vals[ctr] = sum(per) / len(per)
+        except Exception as e:      # noqa: BLE001
+            return None, repr(e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "measured in this run: FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB per actor launch" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"])
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` started plainly: become the launcher (one rank per GPU on this node, rendezvous on 127.0.0.1)."""
     port = os.environ.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
@@ -386,6 +422,8 @@ def main():
     ap.add_argument("--replicas-wide", type=int, default=128, help="second multi-seed line with one CU per learner (population > 64): the highest chip utilisation (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the supplementary configs (C5 shard, off-policy lines)")
     ap.add_argument("--early-stop", action="store_true", help="also time the KL-early-stopping variant (target_kl=0.012)")
+    ap.add_argument("--measure-traffic", action="store_true", help="N = 1: re-measure roofline.traffic in this run -- two child passes of this script under rocprofv3 --pmc FETCH_SIZE / "
+                    "--pmc WRITE_SIZE (separate passes, no trace domains), corrected as the microarchitecture guide prescribes; otherwise the recorded constant of profiles/ is reported")
     ap.add_argument("--selftest", action="store_true", help="N > 1: before timing, check the in-kernel gradient exchange across the real devices (identical shards on every rank must "
                     "reproduce an un-grouped learner; distinct shards must leave the replicas bit-identical), print per-rank flag-wait histograms, and run a 2..N-rank RCCL all-reduce "
                     "through the library's communicator (crux_comm_init / crux_allreduce_grads)")
@@ -532,6 +570,13 @@ def main():
             except Exception as e:      # noqa: BLE001
                 extra = {"error": repr(e)}
 
+    traffic, traffic_how = (TRAFFIC_RECORDED.get(args.workload) if world == 1 else None), "recorded constant (profiles/r03_pmc_traffic*.txt), not re-measured in this run; --measure-traffic re-measures it"
+    if rank == 0 and world == 1 and args.measure_traffic:
+        tv, how = measure_traffic(args.workload)
+        if tv is not None:
+            traffic, traffic_how = tv, how
+        else:
+            traffic_how += " [--measure-traffic failed: %s]" % how
     if rank == 0:
         env_steps = args.steps * E * T * world
         ms_actor, n_actor = prof["train_actor"]
@@ -551,12 +596,12 @@ def main():
             "grad_steps_per_s": grad_steps / dt,
             "phase_ms_per_iter": {k: v[0] / args.steps for k, v in prof.items()},
             "rollout_env_steps_per_s": (E * T * args.steps) / (prof["rollout"][0] * 1e-3) if prof["rollout"][0] > 0 else None,
-            "roofline": {"kernel": "batch_train! actor (persistent fwd+ppo_loss+bwd+Adam)", "bound": "mfma", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": 30.9e6 if (world == 1 and args.workload == "c2") else None,
-                         "traffic_note": "HBM-side bytes per actor launch from rocprofv3 --pmc FETCH_SIZE (14.08 MB reported) and --pmc WRITE_SIZE (2.70 MB), separate passes of this command (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.txt), corrected as the microarchitecture guide prescribes and as calibrated here on a 2 GiB stream (tools/fetch_calib.hip -> profiles/r02_fetch_calibration.txt): FETCH_SIZE tallies 128-byte requests at 64 B, so reads = 2 x 14.08 MB, writes are exact: 30.9 MB. A recorded constant, not re-measured in this run. Algorithmic minibatch bytes per launch are 136 MB (40960 x 3328 B): the 3.4 MB buffer is re-read from L2/MALL, and the 1.6 GB/launch of gradient exchange between the two workgroups stays inside one XCD's L2",
+            "roofline": {"kernel": "batch_train! actor (k_train_fs: persistent fwd + ppo_loss + bwd + gradient exchange + Adam, 40 960 steps per launch)", "bound": "mfma", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM-side bytes per actor launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes; FETCH_SIZE tallies 128-byte requests at 64 B, calibrated in profiles/r02_fetch_calibration.txt). " + traffic_how + ". Algorithmic minibatch bytes per launch are %.0f MB (%d steps x %d B): the buffer is re-read from L2/MALL, and the per-step gradient exchange between the learner's workgroups (4 x 18 KB written, 3 x 18 KB read per workgroup and step) stays inside one XCD's L2" % (steps_per_launch * BATCH * (4 * wl["obs"] + (wl["act"] if wl["discrete"] else 4 * wl["act"]) + 8) / 1e6, int(steps_per_launch), BATCH * (4 * wl["obs"] + (wl["act"] if wl["discrete"] else 4 * wl["act"]) + 8)),
                          "avg_launch_ms": avg_launch_s * 1e3, "grad_steps_per_launch": steps_per_launch,
                          "us_per_grad_step": avg_launch_s * 1e6 / steps_per_launch if steps_per_launch else None,
-                         "note": "serially dependent %.2f-MFLOP steps: each learner step is split over two CUs of one XCD (gradient exchange through the shared L2), actor and critic run concurrently -> 4 CUs busy; per-CU f32 MFMA peak is 0.614 TFLOP/s" % (fa / 1e6)},
+                         "note": "serially dependent %.2f-MFLOP steps: each learner step is split over FOUR CUs of one XCD (k_train_fs: feature-split wave pairs per 16-sample tile + helper waves, gradient exchange through the shared L2), actor and critic run concurrently -> 8 CUs busy; per-CU f32 MFMA peak is 0.614 TFLOP/s, so frac is structurally <= 4/256" % (fa / 1e6)},
         }
         if replicas_identical is not None:
             out["replicas_bit_identical_after_run"] = replicas_identical
@@ -570,6 +615,15 @@ def main():
             out["multi_seed_one_cu_per_learner"] = multi_wide
         if extra is not None:
             out["other_configs"] = extra
+            # the other BASELINE configs' headline numbers as short top-level keys (the driver's parsed record carries them)
+            def _g(name, key):
+                v = extra.get(name) if isinstance(extra, dict) else None
+                return v.get(key) if isinstance(v, dict) else None
+            out["c1_dqn_gridworld_env_steps_per_s"] = _g("c1_dqn_gridworld", "env_steps_per_s"); out["c1_dqn_gridworld_seconds_N100k"] = _g("c1_dqn_gridworld", "seconds")
+            out["c3_dqn_per_us_per_epoch"] = _g("c3_dqn_per", "us_per_epoch"); out["c3_dqn_per_grad_steps_per_s"] = _g("c3_dqn_per", "grad_steps_per_s")
+            out["c4_sac_us_per_epoch"] = _g("c4_sac", "us_per_epoch")
+            out["c5_shard_env_steps_per_s"] = _g("c5_shard", "env_steps_per_s")
+            out["c5_shard_us_per_grad_step"] = (extra.get("c5_shard", {}).get("roofline", {}) or {}).get("us_per_grad_step") if isinstance(extra, dict) else None
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         sys.stdout.flush(); os.write(json_fd, (json.dumps(out) + "\n").encode())

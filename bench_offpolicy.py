@@ -96,7 +96,17 @@ def c3(crux, ctx, cpu=True, steps=300):
         import bench
         model, ncpu = bench.host_cpu()
         out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "grad-steps/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": ncpu,
-                               "sample": "oracle/ (1 thread): %d epochs at a %d-row buffer (cumsum rescan %.2f ms/epoch scaled x%d to 1 M rows, networks + update %.2f ms/epoch)" % (n_ep, n_o, 1e3 * t_scan / n_ep, N // n_o, 1e3 * t_rest / n_ep)}
+                               "sample": "oracle/ (1 thread): %d epochs at a %d-row buffer (cumsum rescan %.2f ms/epoch scaled x%d to 1 M rows, networks + update %.2f ms/epoch)" % (n_ep, n_o, 1e3 * t_scan / n_ep, N // n_o, 1e3 * t_rest / n_ep),
+                               "note": "the port's Dense products are scalar triple loops (no BLAS, no SIMD intrinsics): ~4 GFLOP/s. The reference calls Flux -> OpenBLAS sgemm, an order of magnitude faster per core on these 256-wide layers; see blas_gemm_leg"}
+        try:
+            bl = blas_leg([([8, 256, 256, 4], 3, 1)], B, None)      # train forward + target forward + td_error forward, one backward
+            scan = (t_scan / n_ep) * (N / n_o)
+            out["cpu_baseline"]["blas_gemm_leg"] = {"gemm_s_one_thread": bl["one_thread_s"], "gemm_s_all_threads": bl["all_threads_s"], "cumsum_rescan_s": scan,
+                                                    "grad_steps_per_s_lower_bound_one_thread": (1.0 / (bl["one_thread_s"] + scan)) if bl["one_thread_s"] else None,
+                                                    "grad_steps_per_s_lower_bound_all_threads": 1.0 / (bl["all_threads_s"] + scan),
+                                                    "note": "the epoch's matrix products through numpy / OpenBLAS sgemm + the oracle's measured cumsum rescan; elementwise work excluded (an upper bound on a BLAS-backed host's rate)"}
+        except Exception as e:      # noqa: BLE001
+            out["cpu_baseline"]["blas_gemm_leg"] = {"error": repr(e)}
     return out
 
 
@@ -147,7 +157,17 @@ def c4(crux, ctx, cpu=True, steps=200):
         import bench
         model, ncpu = bench.host_cpu()
         out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "epochs/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": ncpu,
-                               "sample": "oracle/ (1 thread): %d full epochs at B = 256 (%.1f ms/epoch)" % (n_ep, 1e3 * t_cpu)}
+                               "sample": "oracle/ (1 thread): %d full epochs at B = 256 (%.1f ms/epoch)" % (n_ep, 1e3 * t_cpu),
+                               "note": "the port's Dense products are scalar triple loops (no BLAS): the reference's Flux -> OpenBLAS path is roughly an order of magnitude faster per core; see blas_gemm_leg"}
+        try:
+            # critics: train fwd+bwd x2, target fwd x2, actor-loss fwd x2 + bwd (data gradient) x2; actor: target fwd, temperature fwd, train fwd + bwd
+            bl = blas_leg([([4, 256, 256, 1], 6, 4), ([3, 256, 256, 1], 3, 1)], B, None)
+            out["cpu_baseline"]["blas_gemm_leg"] = {"gemm_s_one_thread": bl["one_thread_s"], "gemm_s_all_threads": bl["all_threads_s"],
+                                                    "epochs_per_s_upper_bound_one_thread": (1.0 / bl["one_thread_s"]) if bl["one_thread_s"] else None,
+                                                    "epochs_per_s_upper_bound_all_threads": 1.0 / bl["all_threads_s"],
+                                                    "note": "the epoch's matrix products through numpy / OpenBLAS sgemm; elementwise work, sampling and Adam excluded (an upper bound on a BLAS-backed host's rate)"}
+        except Exception as e:      # noqa: BLE001
+            out["cpu_baseline"]["blas_gemm_leg"] = {"error": repr(e)}
     return out
 
 
@@ -196,6 +216,34 @@ def c1_cpu(N=20_000):
     model, ncpu = bench.host_cpu()
     return {"value": N / t, "unit": "env-steps/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": ncpu,
             "sample": "oracle/ (1 thread): the same solve loop for N = %d (%.2f s)" % (N, t)}
+
+
+def blas_leg(nets, B, passes):
+    """What a BLAS-backed host does with the SAME matrix products (the reference runs Flux -> OpenBLAS sgemm; the oracle port is a scalar triple loop): every Dense
+    product of `passes` = [(dims, n_forward, n_backward)] at batch B through numpy's sgemm, one thread and all threads. Elementwise work (activations, heads, Adam) is left
+    out, so this is a LOWER bound on a BLAS-backed epoch -- reported next to the port so that the port's number is not read as the speed of the reference's arithmetic."""
+    rng = np.random.default_rng(0); ops = []
+    for dims, nf, nb in nets:
+        for l in range(len(dims) - 1):
+            i, o = dims[l], dims[l + 1]
+            W = rng.normal(0, 1, (o, i)).astype(np.float32); X = rng.normal(0, 1, (i, B)).astype(np.float32); D = rng.normal(0, 1, (o, B)).astype(np.float32)
+            ops += [(W, X)] * nf + ([(D, X.T.copy())] * nb) + ([(W.T.copy(), D)] * nb if l > 0 else [])
+    def once():
+        for A_, B_ in ops:
+            A_ @ B_
+    def timed(n=30):
+        once(); t0 = time.perf_counter()
+        for _ in range(n):
+            once()
+        return (time.perf_counter() - t0) / n
+    out = {"all_threads_s": timed()}
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            out["one_thread_s"] = timed()
+    except Exception:       # noqa: BLE001
+        out["one_thread_s"] = None
+    return out
 
 
 def run(crux, ctx, cpu=True):
