@@ -21,12 +21,27 @@ static int32_t launch_fs_pick(crux_ctx* c, TrainArgs& a, int form, hipStream_t s
   return launch_fs_form<IN, OUT, KIND, ACT, 4, true, TIMING>(c, a, stream);
 }
 template <int IN, int OUT, int KIND, int ACT>
+static int32_t launch_fs_px(crux_ctx* c, TrainArgs& a, hipStream_t stream) {      // replica group: four workgroups with helper waves, the in-kernel all-reduce over the peer slots
+  using Lt = FsLayout<IN, OUT, 4, true>;
+  constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
+  static bool attr = false;
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs<IN, OUT, KIND, ACT, 4, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_train_fs<IN, OUT, KIND, ACT, 4, true, false, true>), dim3(32), dim3(Lt::NT), lds, stream, a);
+  return crux_launch_check(c, "k_train_fs (replica group)");
+}
+template <int IN, int OUT, int KIND, int ACT>
 static int32_t launch_fs(crux_ctx* c, TrainArgs a, int nwg, bool timing, hipStream_t stream) {
   const int which = stream == c->stream ? 0 : 1;
   constexpr size_t xfloats = (size_t)CRUX_XBUF_FLOATS;
   if (!c->xbuf[which]) { if (hipMalloc(&c->xbuf[which], sizeof(float) * xfloats + 256) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "learner exchange buffer"); }
   a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * xfloats);
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
+  a.xcd = which;      // actor / critic (the context's two learner streams) behind different L2s. (Replicas sharing a device stay on the same XCD pair: spreading them over XCDs
+                      // sent their flag / slot traffic across L2s and measured 15.5 against 12.9 us per step on one GPU.)
+  if (c->peer_n > 1 && a.need_px) {
+    a.px_hist = c->peer_hist ? 1 : 0; a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
+    return launch_fs_px<IN, OUT, KIND, ACT>(c, a, stream);
+  }
   if (timing) {
     static unsigned long long* dbg = nullptr;
     if (!dbg) { if (hipMalloc(&dbg, 512 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
@@ -52,7 +67,7 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* ha
   const int mode = [] { const char* e = getenv("CRUX_FS"); return e ? atoi(e) : 1; }();            // read per call: tests switch the form inside one process
   const int nwg_env = [] { const char* e = getenv("CRUX_FS_WG"); return e ? atoi(e) : 0; }();
   if (mode == 0) return CRUX_OK;
-  if (a.ids || !a.apply || a.bs <= 64 || a.bs > 128 || a.len < a.bs || a.lag || a.need_px) return CRUX_OK;
+  if (a.ids || !a.apply || a.bs <= 64 || a.bs > 128 || a.len < a.bs || a.lag) return CRUX_OK;
   if (!crux_x2_placement_ok(c)) return CRUX_OK;
   const int nwg = nwg_env == 2 || nwg_env == 4 || nwg_env == 8 ? nwg_env : CRUX_FS_DEFAULT_WG;      // 8 = four workgroups with helper waves
   const bool timing = getenv("CRUX_MFMA_TIMING") != nullptr;

@@ -57,7 +57,9 @@ struct FsLayout {
   static_assert(XSLOT <= 8192, "exchange slot");
 };
 
-template <int IN, int OUT, int KIND, int ACT, int NWG, bool HELP = false, bool TIMING = false>
+// PX: the replica-group form (comm.hip "peer"): after the workgroups have formed the local total, the N replicas SUM-all-reduce it through peer-mapped slots inside the same step,
+// between the pullback (training.jl:18) and Flux.update! (:21) -- the protocol of train_mfma_kernel.h with the peers shared among four workgroups instead of two.
+template <int IN, int OUT, int KIND, int ACT, int NWG, bool HELP = false, bool TIMING = false, bool PX = false>
 __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(TrainArgs a) {
   static_assert(NWG == 2 || NWG == 4, "two workgroups of eight waves, or four of four (+ four helper waves)");
   static_assert(!HELP || NWG == 4, "helper waves: the four-workgroup form");
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   constexpr int NW = Lt::NW, NWC = Lt::NWC, TILES = Lt::TILES, NT = Lt::NT, WT = 16 / NW;
   constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS, NSI = Lt::NSI, XSLOT = Lt::XSLOT;
   constexpr int NACT = (OUT > 4 ? OUT : 4);
-  if ((blockIdx.x & 7) != 0) return;                 // the NWG workgroups of the learner: blocks 0, 8, 16, 24 -> one XCD (consecutive workgroups go round-robin over the 8 XCDs)
+  if ((int)(blockIdx.x & 7) != a.xcd) return;        // the NWG workgroups of the learner: blocks x, x + 8, x + 16, x + 24 -> one XCD (consecutive workgroups go round-robin over the 8 XCDs)
   const int p = (int)(blockIdx.x >> 3);              // workgroup 0 .. NWG-1 of this learner
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
@@ -153,6 +155,10 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   bool staged = false;
   long long xstep = 0;
   float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
+  // replica group: exchanges done on this learner stream before this launch -- slot parity and flag values continue across launches
+  float* const px_mine = PX ? a.px_tab[a.px_rank] : nullptr;
+  const unsigned long long px0 = PX ? *(const unsigned long long*)(px_mine + CRUX_PX_COUNT) : 0ull;
+  const float px_inv = PX ? 1.0f / (float)a.px_n : 1.0f;
   const int n_epochs = a.epochs;
   if (!a.ord_all) { for (int64_t j = tid; j < a.len; j += NT) order_cur[j] = (int32_t)j; }
   if (!a.ord_all && a.pre_epochs > 0) {
@@ -550,6 +556,103 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
           for (int k = 0; k < NSI; ++k) gs[k] = (gs[k] + pg[0][k]) + (pg[1][k] + pg[2][k]);
           stat_tot = (stat_loc + ps[0]) + (ps[1] + ps[2]);
         }
+        if constexpr (PX) {
+          // ---- SUM all-reduce of the local gradient over the replica group. All NWG workgroups hold the same local total. They share the writes (peer i of the N-1 goes to
+          // workgroup i mod NWG): the total and the seven statistics sums go into slot [parity][my rank] of the peer's region, a system-scope release makes them visible, then
+          // flag[my rank] there is raised to the exchange number. Every workgroup then waits for the N-1 flags in the OWN region and adds the N contributions in rank order -- the
+          // own one from registers, the others from the slots -- so every workgroup of every rank forms the same sum bit for bit.
+          const unsigned long long xg = px0 + (unsigned long long)xstep;       // number of this exchange on this learner stream
+          const int par = (int)(xg & 1ull);
+          { int pi_ = 0;
+            for (int r = 0; r < a.px_n; ++r) {
+              if (r == a.px_rank || (pi_++ % NWG) != p) continue;
+              float* dst = a.px_tab[r] + (size_t)(par * CRUX_PX_MAXR + a.px_rank) * CRUX_PX_SLOT;
+#pragma unroll
+              for (int mm = 0; mm < WT; ++mm) *(f32x4*)&dst[tid * (4 * WT) + 4 * mm] = gW2[mm];
+#pragma unroll
+              for (int k = 0; k < NSI; ++k) dst[4096 + tid + NT * k] = gs[k];
+              if (tid >= NT - 8 && tid < NT - 1) dst[4096 + NSI * NT + (tid - (NT - 8))] = stat_tot; } }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                         // system scope: this wave's slot stores are performed at the peers
+          __syncthreads();
+          if (tid == 0) {
+            int pi_ = 0;
+            for (int r = 0; r < a.px_n; ++r) { if (r == a.px_rank) continue;
+              if ((pi_++ % NWG) != p) continue;
+              __hip_atomic_store((unsigned long long*)(a.px_tab[r] + CRUX_PX_FLAGS) + 8 * a.px_rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            bool ok = true; const long long t0 = wall_clock64();                // 100 MHz: a missing peer becomes CRUX_EHIP after ~30 s instead of a hung GPU
+            unsigned* abortw = (unsigned*)(px_mine + CRUX_PX_ABORT);
+            for (int r = 0; r < a.px_n && ok; ++r) { if (r == a.px_rank) continue;
+              const unsigned long long* fl = (const unsigned long long*)(px_mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
+              while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
+            if (!ok) { for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (a.px_hist) {      // how long this workgroup waited for the slowest peer's flag (10 ns ticks, log2 bins; workgroups 0 and 1 report)
+              const unsigned long long dtk = (unsigned long long)(wall_clock64() - t0) | 1ull;
+              if (p < 2) { unsigned* hb = (unsigned*)(px_mine + CRUX_PX_HIST) + 32 * p + (63 - __builtin_clzll(dtk) > 31 ? 31 : 63 - __builtin_clzll(dtk)); *hb = *hb + 1u; } }
+            sm[Lt::oRED + 16] = ok ? 0.f : 3.f;                         // 3: a replica of the group did not answer within the timeout, or raised the abort word
+          }
+          __syncthreads();
+          if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; why_failed = (int)sm[Lt::oRED + 16]; break; }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                         // system scope: nothing read below is older than the flags
+          f32x4 oW[WT]; float oS[NSI]; const float oT = stat_tot;
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) oW[mm] = gW2[mm];
+#pragma unroll
+          for (int k = 0; k < NSI; ++k) oS[k] = gs[k];
+          // the slots are read PXS ranks at a time (all loads of a batch in flight together: one round trip to the fine-grained region per batch) and added in rank order;
+          // the six-output heads sit at the 256-register limit of two waves per SIMD and take one rank at a time (two spilled 14 registers)
+          constexpr int PXS = OUT <= 4 ? 2 : 1;
+          for (int r0 = 0; r0 < a.px_n; r0 += PXS) {
+            f32x4 vW[PXS][WT]; float vS[PXS][NSI]; float vT[PXS];
+#pragma unroll
+            for (int q = 0; q < PXS; ++q) {
+              const int r = r0 + q;
+              if (r < a.px_n && r != a.px_rank) {
+                const float* src = px_mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT;
+#pragma unroll
+                for (int k = 0; k < NSI; ++k) vS[q][k] = __hip_atomic_load(src + 4096 + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                vT[q] = 0.f;
+                if (tid >= NT - 8 && tid < NT - 1) vT[q] = __hip_atomic_load(src + 4096 + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+                for (int mm = 0; mm < WT; ++mm)
+                  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(vW[q][mm]) : "v"(src + tid * (4 * WT) + 4 * mm) : "memory");
+              } else {      // the own contribution (registers: nothing orders another workgroup's read after a store of this one, so it is never read back), or past the last rank
+                vT[q] = r < a.px_n ? oT : 0.f;
+#pragma unroll
+                for (int mm = 0; mm < WT; ++mm) vW[q][mm] = r < a.px_n ? oW[mm] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < NSI; ++k) vS[q][k] = r < a.px_n ? oS[k] : 0.f; } }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < PXS; ++q)
+#pragma unroll
+              for (int mm = 0; mm < WT; ++mm) asm volatile("" : "+v"(vW[q][mm]));
+#pragma unroll
+            for (int q = 0; q < PXS; ++q) {
+              if (r0 + q >= a.px_n) break;
+              if (r0 + q == 0) {
+#pragma unroll
+                for (int mm = 0; mm < WT; ++mm) gW2[mm] = vW[q][mm];
+#pragma unroll
+                for (int k = 0; k < NSI; ++k) gs[k] = vS[q][k];
+                stat_tot = vT[q];
+              } else {
+#pragma unroll
+                for (int mm = 0; mm < WT; ++mm) gW2[mm] += vW[q][mm];
+#pragma unroll
+                for (int k = 0; k < NSI; ++k) gs[k] += vS[q][k];
+                stat_tot += vT[q];
+              }
+            }
+          }
+          // mean over the group: global minibatch = px_n x nb samples, every rank's partial was already divided by nb
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) gW2[mm] = gW2[mm] * px_inv;
+#pragma unroll
+          for (int k = 0; k < NSI; ++k) gs[k] = gs[k] * px_inv;
+          stat_tot = stat_tot * px_inv;
+        }
         xstep += 1;
       }
       if (tid >= NT - 8 && tid < NT - 1) sm[Lt::oRED + 8 + (tid - (NT - 8))] = stat_tot;
@@ -628,9 +731,10 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
     for (int s = tid; s < ns_valid; s += NT) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; }
   }
   if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(NW * p + w) * 16 + k] = tacc[k]; }
+  if (PX && tid == 0 && p == 0) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)xstep;
   if (tid == 0 && (p == 0 || err)) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
-    if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs
+    if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 3 replica group timeout / abort
     a.bp[0] = bp1; a.bp[1] = bp2;
     if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = inf_loss; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
   }
