@@ -369,7 +369,8 @@ def run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P):
 
     def fmt(h):      # {"<= 0.64 us": n, ...} for the non-empty log2 bins of 10 ns ticks
         return {"<%.2fus" % (10e-3 * 2 ** (b + 1)): int(n) for b, n in enumerate(h) if n}
-    res["flag_wait_hist_per_rank"] = gather_obj({"actor_wg0": fmt(hist[0, 0]), "actor_wg1": fmt(hist[0, 1]), "critic_wg0": fmt(hist[1, 0]), "critic_wg1": fmt(hist[1, 1])})
+    # (the short max_batches runs of this selftest train actor and critic back to back on learner stream 0; the timed iterations run them concurrently on streams 0 and 1)
+    res["flag_wait_hist_per_rank"] = gather_obj({"stream0_wg0": fmt(hist[0, 0]), "stream0_wg1": fmt(hist[0, 1]), "stream1_wg0": fmt(hist[1, 0]), "stream1_wg1": fmt(hist[1, 1])})
     # (4) RCCL through the library's communicator
     rc = {"ok": False}
     try:

@@ -42,7 +42,8 @@ static int32_t launch_fs(crux_ctx* c, TrainArgs a, int nwg, bool timing, hipStre
     a.px_hist = c->peer_hist ? 1 : 0; a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
     return launch_fs_px<IN, OUT, KIND, ACT>(c, a, stream);
   }
-  if (timing) {
+  constexpr bool HAS_TIMING = (IN == 4 && (OUT == 2 || OUT == 1)) || (IN == 17 && ACT == CRUX_ACT_TANH);      // the in-kernel phase timers are instantiated for the C2 / C5 learners only
+  if constexpr (HAS_TIMING) if (timing) {
     static unsigned long long* dbg = nullptr;
     if (!dbg) { if (hipMalloc(&dbg, 512 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
     a.dbg = dbg;
@@ -83,6 +84,8 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* ha
   FS_CASE(17, 1, MFK_VALUE, CRUX_ACT_TANH)
   FS_CASE(8, 4, MFK_CATEGORICAL, CRUX_ACT_RELU)     // 8 observations / 4 discrete actions (LunarLander-shaped)
   FS_CASE(8, 1, MFK_VALUE, CRUX_ACT_RELU)
+  FS_CASE(2, 1, MFK_GAUSSIAN, CRUX_ACT_RELU)        // the reference's own Pendulum examples observe (theta, theta_dot): 2 inputs (examples/rl/pendulum.jl)
+  FS_CASE(2, 1, MFK_VALUE, CRUX_ACT_RELU)
 #undef FS_CASE
   return CRUX_OK;
 }

@@ -75,6 +75,8 @@ FAMILIES = {
     # outside the register-resident family, on the MFMA dense engine (train_dense.hip): 128- and 256-wide policies
     "synth_8_4_h128": (8, 4, True, [8, 128, 128, 4], [8, 128, 128, 1], ACTS, "discrete", "categorical", "synth_discrete"),
     "synth_c5_h256": (17, 6, False, [17, 256, 256, 6], [17, 256, 256, 1], ["tanh", "tanh", "identity"], "gaussian", "gaussian", "synth"),
+    # the reference's own Pendulum examples observe (theta, theta_dot): 2 inputs, one continuous action (examples/rl/pendulum.jl), here on the SYNTH dynamics
+    "synth_2_1": (2, 1, False, [2, 64, 64, 1], [2, 64, 64, 1], ACTS, "gaussian", "gaussian", "synth"),
     # outside the MFMA family (32-wide hidden layers): the generic learner
     "synth_8_4_h32": (8, 4, True, [8, 32, 32, 4], [8, 32, 32, 1], ACTS, "discrete", "categorical", "synth_discrete"),
 }

@@ -269,3 +269,23 @@ def test_offpolicy_user_priority_fn_and_sample_callback_write_back(gpu_ctx):
     O.chk(O.lib().orc_per_get(ob.h, O.vpz(pr), C.byref(mx), C.byref(mn), None))
     assert np.allclose(pg["priorities"], pr, rtol=2e-5, atol=1e-6) and abs(pg["max_priority"] - mx.value) < 1e-5
     assert np.abs(g.get_params() - o.params).max() < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------- the feature-split learner kernel (train_fs_kernel.h)
+@pytest.mark.parametrize("form", ["2", "4", "8"])
+@pytest.mark.parametrize("family", ["cartpole", "synth_c5"])
+def test_feature_split_learner_forms_match_the_oracle(gpu_ctx, monkeypatch, capfd, form, family):
+    """k_train_fs in its three forms (CRUX_FS_WG: 2 = two compute units x eight waves, 4 = four x four, 8 = four x (four compute + four helper waves), the default)
+    through a whole PPO iteration -- rollout, GAE, whiten, actor || critic batch_train! of 2 epochs x 8 minibatches of 128 -- against the oracle: the same bounds as
+    the sample-split kernel's (tests/parity.py), whatever the decomposition of a step."""
+    monkeypatch.setenv("CRUX_FS_WG", form)
+    res = parity.ppo_iteration_parity(n_envs=8, T=128, batch_size=128, epochs=2, seed=21, family=family, pair=True)
+    assert res["ok"], res
+    assert "outside the MFMA learner family" not in capfd.readouterr().err
+
+
+def test_two_input_pendulum_shape_runs_on_the_feature_split_learner(gpu_ctx, capfd):
+    """2->64->64->1 Gaussian actor + critic (the reference's own Pendulum networks, examples/rl/pendulum.jl): an instantiation of the feature-split kernel."""
+    res = parity.ppo_iteration_parity(n_envs=8, T=128, batch_size=128, epochs=2, seed=5, family="synth_2_1", pair=True)
+    assert res["ok"], res
+    assert "outside the MFMA learner family" not in capfd.readouterr().err
