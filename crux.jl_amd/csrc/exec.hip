@@ -303,7 +303,15 @@ int32_t crux_exec_run(crux_ctx* c) {
     const int xcd = crux_x2_placement_ok_c(c) ? 0 : -2;
     if (xcd == -2) return crux_fail(c, CRUX_EUNSUP, "executor: workgroups are not placed round-robin over the XCDs on this device");
     const int G = EXEC_G;
-    hipLaunchKernelGGL(k_exec, dim3(G * 8), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops, (int)nops, r->d_ctr, xcd, (int32_t*)(r->d_ctr + 264), 0);
+    const int xflags = getenv("CRUX_EXEC_FLAGS") ? atoi(getenv("CRUX_EXEC_FLAGS")) : 0;      // 8: per-op timestamps of workgroups 0 and 1, printed below
+    hipLaunchKernelGGL(k_exec, dim3(G * 8), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops, (int)nops, r->d_ctr, xcd, (int32_t*)(r->d_ctr + 264), xflags);
+    if (xflags & 8) { static int dumps = 0;
+      std::vector<unsigned long long> tb(2 * 512 * 3); HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpy(tb.data(), r->d_ctr + 1024, tb.size() * 8, hipMemcpyDeviceToHost));
+      if (dumps++ == 3) { double tw = 0, tbar = 0; const size_t nn = nops < 512 ? nops : 512;
+        for (size_t o = 0; o < nn; ++o) { const double w0 = (tb[o * 3 + 1] - tb[o * 3]) * 1e-3, b0 = (tb[o * 3 + 2] - tb[o * 3 + 1]) * 1e-3; tw += w0; tbar += b0;      // s_memtime ticks are shader cycles (~2 GHz)
+          fprintf(stderr, "[k_exec] op %3zu kid %2d blocks %4u barrier %d  work %7.2f kcycles  wait %7.2f kcycles\n", o, r->ops[o].kid, r->ops[o].nblocks, r->ops[o].barrier, w0, b0); }
+        fprintf(stderr, "[k_exec] %zu ops: work %.1f kcycles, barrier / wait %.1f kcycles (workgroup 0; shader cycles, ~0.5 ns each)\n", nn, tw, tbar); } }
     }
     rc = crux_launch_check(c, "k_exec"); if (rc) return rc;
     char* hb = (char*)r->h_stage + ob;
