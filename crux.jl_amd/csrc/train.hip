@@ -418,7 +418,8 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   if (!actor || !critic || !buf || !cfg_a || !cfg_c) return CRUX_EINVAL;
   crux_ctx* c = actor->ctx;
   bool exact = cfg_a->target_kl < 0.f && cfg_a->max_batches <= 0;
-  { auto mfma_family = [](const crux_mlp* n) { const NetDesc& d = n->nd; return d.L == 3 && d.dims[1] == 64 && d.dims[2] == 64; };
+  { const bool fs_on = !(getenv("CRUX_FS") && atoi(getenv("CRUX_FS")) == 0) && cfg_a->batch_size > 64 && cfg_a->batch_size <= 128;      // the feature-split kernel also takes a 32-wide second layer
+    auto mfma_family = [fs_on](const crux_mlp* n) { const NetDesc& d = n->nd; return d.L == 3 && d.dims[1] == 64 && (d.dims[2] == 64 || (d.dims[2] == 32 && fs_on)); };
     if (!mfma_family(actor) || !mfma_family(critic)) exact = false; }     // dense-engine / generic learners run one after the other on the main stream
   if (!exact) {
     int32_t rc = crux_batch_train(actor, buf, cfg_a, perms_a, info_a, epoch_infos_a); if (rc) return rc;

@@ -23,8 +23,12 @@
 #define FS_LD 72
 __device__ __forceinline__ int fs_tx(int q) { return (4 - q) & 3; }   // {0,3,2,1}
 
-template <int IN, int OUT, int NWG, bool HELP = false>
+// H2: width of the second hidden layer, 64 or 32 (the first is MF_HID = 64): the reference's HalfCheetah PPO networks are 17-64-32-6 / 17-64-32-1
+// (examples/rl/half_cheetah_mujoco.jl:33-38); a wave's half of the layer is then ONE 16-feature tile instead of two.
+template <int IN, int OUT, int NWG, bool HELP = false, int H2 = 64>
 struct FsLayout {
+  static_assert(H2 == 64 || H2 == 32, "second hidden layer: 64 or 32 units");
+  static constexpr int MH = H2 / 32, NT2 = H2 / 16, HH = H2 / 2, W2N = H2 * MF_HID;      // 16-feature tiles per half / per layer, features per half, elements of W2
   static constexpr int NWC = 16 / NWG, TILES = NWC / 2;                    // compute waves (a pair per 16-sample tile)
   static constexpr int NW = HELP ? 2 * NWC : NWC, NT = 64 * NW;            // + as many helper waves: owners of half the W2 tiles, and the minibatch staging
   static constexpr int NXB = HELP ? 2 : 1;                                 // staging rows are double-buffered when the helpers stage the next minibatch during the step
@@ -32,39 +36,42 @@ struct FsLayout {
   static constexpr int SCW = (4 + (OUT > 4 ? OUT : 4)) | 1;
   static constexpr int ZW = OUT;                                                          // partial logits per (tile, half, g, sample)
   // flat index spaces of the small parameters (everything but W2): s = thread-owned index, c = canonical (Flux.params) index, p = index inside a tile's partial block
-  static constexpr int sW1 = 0, sB1 = MF_HID * IN, sB2 = sB1 + MF_HID, sW3 = sB2 + MF_HID, sB3 = sW3 + MF_HID * OUT, sEX = sB3 + OUT, NS = sEX + 16;
-  static constexpr int cW1 = 0, cB1 = MF_HID * IN, cW2 = cB1 + MF_HID, cB2 = cW2 + MF_HID * MF_HID, cW3 = cB2 + MF_HID, cB3 = cW3 + MF_HID * OUT, cEX = cB3 + OUT;
+  static constexpr int sW1 = 0, sB1 = MF_HID * IN, sB2 = sB1 + MF_HID, sW3 = sB2 + H2, sB3 = sW3 + H2 * OUT, sEX = sB3 + OUT, NS = sEX + 16;
+  static constexpr int cW1 = 0, cB1 = MF_HID * IN, cW2 = cB1 + MF_HID, cB2 = cW2 + W2N, cW3 = cB2 + H2, cB3 = cW3 + H2 * OUT, cEX = cB3 + OUT;
   static constexpr int W1ROWS = IP < 16 * JT ? IP : 16 * JT;
-  static constexpr int pW1 = 0, pB1 = pW1 + W1ROWS * FS_LD, pB2 = pB1 + MF_HID, pW3 = pB2 + MF_HID, pMISC = pW3 + OUT * MF_HID;
+  static constexpr int pW1 = 0, pB1 = pW1 + W1ROWS * FS_LD, pB2 = pB1 + MF_HID, pW3 = pB2 + H2, pMISC = pW3 + OUT * H2;
   static constexpr int pST = pMISC, pB3 = pMISC + 7, pEX = pB3 + OUT;
   static constexpr int PART = ((pMISC + 48 + 3) / 4) * 4;
   static constexpr int NSP = ((NS + 3) / 4) * 4;
-  static constexpr int TILE = MF_HID * 16;
-  static constexpr int oW2R = 0, oW2C = oW2R + MF_HID * FS_LD, oW1R = oW2C + MF_HID * FS_LD;
-  static constexpr int oB1 = oW1R + MF_HID * W1LD, oB2 = oB1 + MF_HID, oW3R = oB2 + MF_HID, oB3 = oW3R + OUT * MF_HID, oEX = oB3 + 16;
+  static constexpr int TILE = MF_HID * 16, TILE2 = H2 * 16;
+  static constexpr int oW2R = 0, oW2C = oW2R + H2 * FS_LD, oW1R = oW2C + MF_HID * FS_LD;      // W2R: [H2 rows o][i], W2C: [64 rows i][o]
+  static constexpr int oB1 = oW1R + MF_HID * W1LD, oB2 = oB1 + MF_HID, oW3R = oB2 + H2, oB3 = oW3R + OUT * H2, oEX = oB3 + 16;
   static constexpr int oMS = ((oEX + 16 + 3) / 4) * 4, oVS = oMS + NSP;
   static constexpr int oT1 = oVS + NSP, oT2 = oT1 + TILES * TILE;
-  static constexpr int oD2X = oT2 + TILES * TILE;                         // [tile][half][2][64 lanes] f32x4: the dZ2 half of a wave in A-operand layout, for its partner
-  static constexpr int oZP = oD2X + TILES * 2 * 2 * 256;                  // [tile][half][g 4][sample 16][ZW]
+  static constexpr int oD2X = oT2 + TILES * TILE2;                        // [tile][half][MH][64 lanes] f32x4: the dZ2 half of a wave in A-operand layout, for its partner
+  static constexpr int oZP = oD2X + TILES * 2 * MH * 256;                 // [tile][half][g 4][sample 16][ZW]
   static constexpr int oPART = ((oZP + TILES * 2 * 64 * ZW + 3) / 4) * 4; // [tile][PART]
   static constexpr int oXS = oPART + TILES * PART;
   static constexpr int oSC = oXS + NXB * TILES * 16 * XP;
   static constexpr int oRED = oSC + NXB * TILES * 16 * SCW;                     // [0,8): per-wave sum of squares; [8,15): reduced stat sums; [16]: abort flag
   static constexpr int TOTAL = oRED + 32;
   static constexpr int NSI = (NS + NT - 1) / NT;
-  static constexpr int XSLOT = ((4096 + NSI * NT + 16 + 3) / 4) * 4;      // floats per exchange slot
+  static constexpr int XSLOT = ((W2N + NSI * NT + 16 + 3) / 4) * 4;       // floats per exchange slot
   static_assert(TOTAL <= 40960, "LDS budget (160 KB) exceeded");
   static_assert(XSLOT <= 8192, "exchange slot");
 };
 
 // PX: the replica-group form (comm.hip "peer"): after the workgroups have formed the local total, the N replicas SUM-all-reduce it through peer-mapped slots inside the same step,
 // between the pullback (training.jl:18) and Flux.update! (:21) -- the protocol of train_mfma_kernel.h with the peers shared among four workgroups instead of two.
-template <int IN, int OUT, int KIND, int ACT, int NWG, bool HELP = false, bool TIMING = false, bool PX = false>
+// ACT / ACT2: activations of the first / second hidden layer (the reference's critic of that example has no activation on its second layer).
+template <int IN, int OUT, int KIND, int ACT, int NWG, bool HELP = false, bool TIMING = false, bool PX = false, int H2 = 64, int ACT2 = ACT>
 __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(TrainArgs a) {
   static_assert(NWG == 2 || NWG == 4, "two workgroups of eight waves, or four of four (+ four helper waves)");
   static_assert(!HELP || NWG == 4, "helper waves: the four-workgroup form");
-  using Lt = FsLayout<IN, OUT, NWG, HELP>;
-  constexpr int NW = Lt::NW, NWC = Lt::NWC, TILES = Lt::TILES, NT = Lt::NT, WT = 16 / NW;
+  using Lt = FsLayout<IN, OUT, NWG, HELP, H2>;
+  constexpr int NW = Lt::NW, NWC = Lt::NWC, TILES = Lt::TILES, NT = Lt::NT, MH = Lt::MH, HH = Lt::HH, W2N = Lt::W2N;
+  constexpr int WT = (Lt::NT2 * 4) / NW;             // 16x16 tiles of W2 (H2/16 x 4 of them) owned by a wave
+  static_assert(WT >= 1 && WT * NW == Lt::NT2 * 4, "W2 tiles must divide over the waves");
   constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS, NSI = Lt::NSI, XSLOT = Lt::XSLOT;
   constexpr int NACT = (OUT > 4 ? OUT : 4);
   if ((int)(blockIdx.x & 7) != a.xcd) return;        // the NWG workgroups of the learner: blocks x, x + 8, x + 16, x + 24 -> one XCD (consecutive workgroups go round-robin over the 8 XCDs)
@@ -83,22 +90,22 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   constexpr int XSB = TILES * 16 * XP, SCB = TILES * 16 * Lt::SCW;      // one staging buffer
   int xcur = 0;                                      // buffer the current minibatch sits in
   float* T1 = sm + Lt::oT1 + t * Lt::TILE;
-  float* T2 = sm + Lt::oT2 + t * Lt::TILE;
+  float* T2 = sm + Lt::oT2 + t * Lt::TILE2;
   const int n_extra = (KIND == MFK_GAUSSIAN) ? OUT : 0;
   unsigned long long tacc[16]; unsigned long long tlast = 0;
   if (TIMING) { for (int k = 0; k < 16; ++k) tacc[k] = 0; tlast = __builtin_amdgcn_s_memtime(); }
 #define FS_T(ph) do { if (TIMING) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
   const int t_wr = (4 * g) * 16 + 4 * ((c >> 2) ^ fs_tx(g)) + (c & 3);   // tile element (feature 4g [+16m+r], sample c)
   const int t_rd = c * 16 + 4 * (g ^ fs_tx(c >> 2));                    // tile b128 (feature c [+16m], samples 4g..4g+3)
-  // dW2 / W2 ownership: four waves own the tiles (mp0 = w, m = 0..3) = rows [16w, 16w+16); eight waves the tiles (mp0, m0) and (mp0, m0 + 1)
-  const int mp0 = NW == 4 ? w : (w >> 1), m0 = NW == 4 ? 0 : 2 * (w & 1);
+  // dW2 / W2 ownership: tile (mp, m) = rows [16mp, 16mp+16) x columns [16m, 16m+16), numbered 4 mp + m; wave w owns the WT tiles from number w WT on (same mp)
+  const int mp0 = (w * WT) >> 2, m0 = (w * WT) & 3;
   (void)sw; (void)xcur;
 
   auto s_master = [&](int s) -> int {
     if (s < Lt::sB1) { const int o = s & 63, i = s >> 6; return Lt::oW1R + o * Lt::W1LD + i; }
     if (s < Lt::sB2) return Lt::oB1 + (s - Lt::sB1);
     if (s < Lt::sW3) return Lt::oB2 + (s - Lt::sB2);
-    if (s < Lt::sB3) { const int q = s - Lt::sW3; const int o = q % OUT, i = q / OUT; return Lt::oW3R + o * MF_HID + i; }
+    if (s < Lt::sB3) { const int q = s - Lt::sW3; const int o = q % OUT, i = q / OUT; return Lt::oW3R + o * H2 + i; }
     if (s < Lt::sEX) return Lt::oB3 + (s - Lt::sB3);
     return Lt::oEX + (s - Lt::sEX);
   };
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
     if (s < Lt::sB1) { const int o = s & 63, i = s >> 6; return Lt::pW1 + i * FS_LD + o; }
     if (s < Lt::sB2) return Lt::pB1 + (s - Lt::sB1);
     if (s < Lt::sW3) return Lt::pB2 + (s - Lt::sB2);
-    if (s < Lt::sB3) { const int q = s - Lt::sW3; const int o = q % OUT, i = q / OUT; return Lt::pW3 + o * MF_HID + i; }
+    if (s < Lt::sB3) { const int q = s - Lt::sW3; const int o = q % OUT, i = q / OUT; return Lt::pW3 + o * H2 + i; }
     if (s < Lt::sEX) return Lt::pB3 + (s - Lt::sB3);
     return Lt::pEX + (s - Lt::sEX);
   };
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
     so_part[k] = so_ok[k] ? s_part(s) : 0; so_master[k] = so_ok[k] ? s_master(s) : 0; }
 
   // ---- load parameters and Adam state --------------------------------------------------------------------------
-  for (int q = tid; q < MF_HID * MF_HID; q += NT) { const int o = q & 63, i = q >> 6; const float v = a.p[Lt::cW2 + q];
+  for (int q = tid; q < W2N; q += NT) { const int o = q % H2, i = q / H2; const float v = a.p[Lt::cW2 + q];
     sm[Lt::oW2R + o * FS_LD + i] = v; sm[Lt::oW2C + i * FS_LD + o] = v; }
   for (int q = tid; q < MF_HID * Lt::W1LD; q += NT) sm[Lt::oW1R + q] = 0.f;
   if (tid < 16) { sm[Lt::oB3 + tid] = 0.f; sm[Lt::oEX + tid] = 0.f; }
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 #pragma unroll
   for (int mm = 0; mm < WT; ++mm)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + MF_HID * (16 * (m0 + mm) + c);
+    for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + H2 * (16 * (m0 + mm) + c);
       tW2[mm][r] = a.p[pc]; mW2[mm][r] = a.m[pc]; vW2[mm][r] = a.v[pc]; }
   double bp1 = a.bp[0], bp2 = a.bp[1];
   const float lo = 1.f - a.eps_clip, hi = 1.f + a.eps_clip;
@@ -264,9 +271,9 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
       FS_T(1);
       // ======================= forward, C orientation: D[feature 16m+4g+r][sample c] =======================
       f32x4 h1[4];                                   // the WHOLE first layer in both waves of the pair
-      f32x4 h2[2];                                   // second layer: output features [32h, 32h + 32)
+      f32x4 h2[MH];                                  // second layer: output features [HH h, HH h + HH)
       constexpr bool W3_REG = OUT <= 2;
-      f32x4 w3[OUT <= 2 ? OUT : 1][2];
+      f32x4 w3[OUT <= 2 ? OUT : 1][MH];
       float zp[OUT];
       if (cw) {
       float xB[KS0];
@@ -284,16 +291,22 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 #pragma unroll
         for (int r = 0; r < 4; ++r) T1[t_wr + (16 * (2 * h + mm) + r) * 16] = (h ? (mm ? h1[3][r] : h1[2][r]) : (mm ? h1[1][r] : h1[0][r]));
       FS_T(2);
-      { f32x4 acc0 = *(const f32x4*)&sm[Lt::oB2 + 32 * h + 4 * g], acc1 = *(const f32x4*)&sm[Lt::oB2 + 32 * h + 16 + 4 * g];
+      { f32x4 acc[MH];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { const f32x4 wv0 = *(const f32x4*)&sm[Lt::oW2R + (32 * h + c) * FS_LD + 16 * m + 4 * g];
-          const f32x4 wv1 = *(const f32x4*)&sm[Lt::oW2R + (32 * h + 16 + c) * FS_LD + 16 * m + 4 * g];
+        for (int mm = 0; mm < MH; ++mm) acc[mm] = *(const f32x4*)&sm[Lt::oB2 + HH * h + 16 * mm + 4 * g];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv0[r], h1[m][r], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv1[r], h1[m][r], acc1, 0, 0, 0); } }
+        for (int m = 0; m < 4; ++m) { f32x4 wv[MH];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { acc0[r] = actf<ACT>(acc0[r]); acc1[r] = actf<ACT>(acc1[r]); }
-        h2[0] = acc0; h2[1] = acc1; }
+          for (int mm = 0; mm < MH; ++mm) wv[mm] = *(const f32x4*)&sm[Lt::oW2R + (HH * h + 16 * mm + c) * FS_LD + 16 * m + 4 * g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mm = 0; mm < MH; ++mm) acc[mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[mm][r], h1[m][r], acc[mm], 0, 0, 0); }      // MH independent accumulator chains
+#pragma unroll
+        for (int mm = 0; mm < MH; ++mm) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mm][r] = actf<ACT2>(acc[mm][r]);
+          h2[mm] = acc[mm]; } }
 
       FS_T(3);
       // ======================= layer 3 (VALU): partial logits over this wave's 32 features, exchanged inside the pair =======================
@@ -301,11 +314,11 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 #pragma unroll
         for (int o = 0; o < OUT; ++o)
 #pragma unroll
-          for (int mm = 0; mm < 2; ++mm) w3[o][mm] = *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 32 * h + 16 * mm + 4 * g]; }
+          for (int mm = 0; mm < MH; ++mm) w3[o][mm] = *(const f32x4*)&sm[Lt::oW3R + o * H2 + HH * h + 16 * mm + 4 * g]; }
 #pragma unroll
       for (int o = 0; o < OUT; ++o) { float acc = 0.f;
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm) { const f32x4 wv = W3_REG ? w3[W3_REG ? o : 0][mm] : *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 32 * h + 16 * mm + 4 * g];
+        for (int mm = 0; mm < MH; ++mm) { const f32x4 wv = W3_REG ? w3[W3_REG ? o : 0][mm] : *(const f32x4*)&sm[Lt::oW3R + o * H2 + HH * h + 16 * mm + 4 * g];
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc = fmaf(wv[r], h2[mm][r], acc); }
         zp[o] = g4_sum(acc); }
@@ -373,31 +386,32 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 
       FS_T(4);
       // ======================= backward, own samples, own feature half =======================
-      // dW3 rows of this half: sum over the 16 samples of dz[o] * h2[feature]; two outputs share one 16-value reduce-scatter (8 features each)
+      // dW3 rows of this half: sum over the 16 samples of dz[o] * h2[feature]; PER outputs share one 16-value reduce-scatter (4 MH features each per lane row)
+      constexpr int FPL = 4 * MH, PER = 16 / FPL;
 #pragma unroll
-      for (int o2 = 0; o2 < (OUT + 1) / 2; ++o2) { float pv[16];
+      for (int o2 = 0; o2 < (OUT + PER - 1) / PER; ++o2) { float pv[16];
 #pragma unroll
-        for (int oo = 0; oo < 2; ++oo)
+        for (int oo = 0; oo < PER; ++oo)
 #pragma unroll
-          for (int mm = 0; mm < 2; ++mm)
+          for (int mm = 0; mm < MH; ++mm)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pv[8 * oo + 4 * mm + r] = (2 * o2 + oo < OUT) ? dz[(2 * o2 + oo < OUT) ? 2 * o2 + oo : 0] * h2[mm][r] : 0.f;
-        const float sred = row16_reduce_scatter(pv, c);      // lane c: output 2 o2 + (c >> 3), feature 32h + 16 ((c >> 2) & 1) + 4g + (c & 3)
-        const int oo = c >> 3;
-        if (2 * o2 + oo < OUT) part[Lt::pW3 + (2 * o2 + oo) * MF_HID + 32 * h + 16 * ((c >> 2) & 1) + 4 * g + (c & 3)] = sred; }
-      { f32x4 d2[2];
+            for (int r = 0; r < 4; ++r) pv[FPL * oo + 4 * mm + r] = (PER * o2 + oo < OUT) ? dz[(PER * o2 + oo < OUT) ? PER * o2 + oo : 0] * h2[mm][r] : 0.f;
+        const float sred = row16_reduce_scatter(pv, c);      // lane c: output PER o2 + c / FPL, feature HH h + 16 ((c >> 2) & (MH - 1)) + 4g + (c & 3)
+        const int oo = c / FPL;
+        if (PER * o2 + oo < OUT) part[Lt::pW3 + (PER * o2 + oo) * H2 + HH * h + 16 * ((c >> 2) & (MH - 1)) + 4 * g + (c & 3)] = sred; }
+      { f32x4 d2[MH];
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm) d2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mm = 0; mm < MH; ++mm) d2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int o = 0; o < OUT; ++o)
 #pragma unroll
-          for (int mm = 0; mm < 2; ++mm) { const f32x4 wv = W3_REG ? w3[W3_REG ? o : 0][mm] : *(const f32x4*)&sm[Lt::oW3R + o * MF_HID + 32 * h + 16 * mm + 4 * g];
+          for (int mm = 0; mm < MH; ++mm) { const f32x4 wv = W3_REG ? w3[W3_REG ? o : 0][mm] : *(const f32x4*)&sm[Lt::oW3R + o * H2 + HH * h + 16 * mm + 4 * g];
 #pragma unroll
             for (int r = 0; r < 4; ++r) d2[mm][r] = fmaf(wv[r], dz[o], d2[mm][r]); }
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
+        for (int mm = 0; mm < MH; ++mm)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h2[mm][r] = actg<ACT>(h2[mm][r], d2[mm][r]); }       // h2 now holds dZ2 of this half
+          for (int r = 0; r < 4; ++r) h2[mm][r] = actg<ACT2>(h2[mm][r], d2[mm][r]); }       // h2 now holds dZ2 of this half
       if (h == 0) {      // statistics and the head's own gradient sums (db3, dlogSigma): once per tile
         constexpr int NV = 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0);
         float mv[((NV + 15) / 16) * 16];
@@ -413,11 +427,12 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
           const float tq = row16_reduce_scatter(cv, c);
           if (g == 0) part[Lt::pMISC + 16 * ch + c] = tq; } }
 #pragma unroll
-      for (int mm = 0; mm < 2; ++mm)
+      for (int mm = 0; mm < MH; ++mm)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T2[t_wr + (16 * (2 * h + mm) + r) * 16] = h2[mm][r];
-      { float* dq = sm + Lt::oD2X + ((t * 2 + h) * 2) * 256 + lane * 4;     // the same values in A-operand (register) layout for the partner's dH1
-        *(f32x4*)&dq[0] = h2[0]; *(f32x4*)&dq[256] = h2[1]; }
+        for (int r = 0; r < 4; ++r) T2[t_wr + (16 * (MH * h + mm) + r) * 16] = h2[mm][r];
+      { float* dq = sm + Lt::oD2X + ((t * 2 + h) * MH) * 256 + lane * 4;     // the same values in A-operand (register) layout for the partner's dH1
+#pragma unroll
+        for (int mm = 0; mm < MH; ++mm) *(f32x4*)&dq[256 * mm] = h2[mm]; }
       }      // compute waves
       FS_T(5);
       __syncthreads();   // ---- B_1: T1 / T2 tiles of the workgroup and the dZ2 halves are visible
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
       for (int mm = 0; mm < WT; ++mm) gW2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ws = 0; ws < TILES; ++ws) {
-        const float* t2 = sm + Lt::oT2 + ws * Lt::TILE; const float* t1 = sm + Lt::oT1 + ws * Lt::TILE;
+        const float* t2 = sm + Lt::oT2 + ws * Lt::TILE2; const float* t1 = sm + Lt::oT1 + ws * Lt::TILE;
         const f32x4 av = *(const f32x4*)&t2[t_rd + 256 * mp0];          // A[i=c -> o=16mp0+c][k -> sample 4g+r]
 #pragma unroll
         for (int mm = 0; mm < WT; ++mm) { const f32x4 bv = *(const f32x4*)&t1[t_rd + 256 * (m0 + mm)];   // B[k -> sample][j=c -> i]
@@ -443,11 +458,13 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
       // the own half from registers, the partner's from its A-layout copy
       if (cw) {
       f32x4 dz1r[2];
-      { const float* dq = sm + Lt::oD2X + ((t * 2 + (1 - h)) * 2) * 256 + lane * 4;
-        f32x4 av[4]; av[0] = h2[0]; av[1] = h2[1]; av[2] = *(const f32x4*)&dq[0]; av[3] = *(const f32x4*)&dq[256];      // own half (features 32h + 16 mm ..), then the partner's (32 (1-h) + 16 mm ..)
+      { const float* dq = sm + Lt::oD2X + ((t * 2 + (1 - h)) * MH) * 256 + lane * 4;
+        f32x4 av[2 * MH];      // own half (dZ2 features HH h + 16 mm ..), then the partner's (HH (1-h) + 16 mm ..)
+#pragma unroll
+        for (int mm = 0; mm < MH; ++mm) { av[mm] = h2[mm]; av[MH + mm] = *(const f32x4*)&dq[256 * mm]; }
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int fo = 32 * ((q >> 1) ? 1 - h : h) + 16 * (q & 1);      // dZ2 feature block of this k step
+        for (int q = 0; q < 2 * MH; ++q) { const int fo = HH * ((q >= MH) ? 1 - h : h) + 16 * (q % MH);      // dZ2 feature block of this k step
           const f32x4 wv0 = *(const f32x4*)&sm[Lt::oW2C + (32 * h + c) * FS_LD + fo + 4 * g];
           const f32x4 wv1 = *(const f32x4*)&sm[Lt::oW2C + (32 * h + 16 + c) * FS_LD + fo + 4 * g];
 #pragma unroll
@@ -456,17 +473,24 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
         dz1r[0] = acc0; dz1r[1] = acc1; }
       FS_T(8);
       // dZ1 (R)[sample 4g+r][f = 16m+c] = act'(H1 R) .* dH1 (R), m = 2h + mm; bias gradients of both hidden layers for this half
-      float gb1[2], gb2[2];
+      float gb1[2], gb2[MH];
 #pragma unroll
-      for (int mm = 0; mm < 2; ++mm) { float sb1 = 0.f, sb2 = 0.f;
+      for (int mm = 0; mm < 2; ++mm) { float sb1 = 0.f;
         const f32x4 h1r = *(const f32x4*)&T1[t_rd + 256 * (2 * h + mm)];
-        const f32x4 d2 = *(const f32x4*)&T2[t_rd + 256 * (2 * h + mm)];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float d = actg<ACT>(h1r[r], dz1r[mm][r]); dz1r[mm][r] = d; sb1 += d; sb2 += d2[r]; }
-        gb1[mm] = g4_sum(sb1); gb2[mm] = g4_sum(sb2); }
+        for (int r = 0; r < 4; ++r) { const float d = actg<ACT>(h1r[r], dz1r[mm][r]); dz1r[mm][r] = d; sb1 += d; }
+        gb1[mm] = g4_sum(sb1); }
+#pragma unroll
+      for (int mm = 0; mm < MH; ++mm) { float sb2 = 0.f;
+        const f32x4 d2 = *(const f32x4*)&T2[t_rd + 256 * (MH * h + mm)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sb2 += d2[r];
+        gb2[mm] = g4_sum(sb2); }
       if (g == 0) {
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm) { part[Lt::pB1 + 32 * h + 16 * mm + c] = gb1[mm]; part[Lt::pB2 + 32 * h + 16 * mm + c] = gb2[mm]; } }
+        for (int mm = 0; mm < 2; ++mm) part[Lt::pB1 + 32 * h + 16 * mm + c] = gb1[mm];
+#pragma unroll
+        for (int mm = 0; mm < MH; ++mm) part[Lt::pB2 + HH * h + 16 * mm + c] = gb2[mm]; }
       // dW1 partial: A = dZ1 (R) [i=c -> o=16m+c][k -> sample 4g+r], B = X (R) [k -> sample][j=c -> input 16jt+c]
 #pragma unroll
       for (int jt = 0; jt < JT; ++jt) {
@@ -499,8 +523,8 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
       // ---- exchange the partial gradients with the other workgroups through the shared L2 ----
       {
 #pragma unroll
-        for (int k = 0; k < NSI; ++k) mine[4096 + tid + NT * k] = gs[k];
-        if (tid >= NT - 8 && tid < NT - 1) mine[4096 + NSI * NT + (tid - (NT - 8))] = stat_loc;
+        for (int k = 0; k < NSI; ++k) mine[W2N + tid + NT * k] = gs[k];
+        if (tid >= NT - 8 && tid < NT - 1) mine[W2N + NSI * NT + (tid - (NT - 8))] = stat_loc;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this lane has reached the L2 (the dW2 partials left before dH1: long acknowledged)
         FS_T(10);
         __syncthreads();
@@ -532,9 +556,9 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
         for (int j = 0; j < NLD; ++j) { const int q = j == 0 ? (p ^ 1) : ((p ^ 2) & 2) + (j - 1);      // partner, then the other pair's first and second workgroup
           const float* peer = a.xbuf + (size_t)(((int)(xstep & 1) * NWG + q)) * XSLOT;
 #pragma unroll
-          for (int k = 0; k < NSI; ++k) pg[j][k] = __hip_atomic_load(peer + 4096 + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int k = 0; k < NSI; ++k) pg[j][k] = __hip_atomic_load(peer + W2N + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ps[j] = 0.f;
-          if (tid >= NT - 8 && tid < NT - 1) ps[j] = __hip_atomic_load(peer + 4096 + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (tid >= NT - 8 && tid < NT - 1) ps[j] = __hip_atomic_load(peer + W2N + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
           for (int mm = 0; mm < WT; ++mm)
             asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(pw[j][mm]) : "v"(peer + tid * (4 * WT) + 4 * mm) : "memory"); }
@@ -570,8 +594,8 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 #pragma unroll
               for (int mm = 0; mm < WT; ++mm) *(f32x4*)&dst[tid * (4 * WT) + 4 * mm] = gW2[mm];
 #pragma unroll
-              for (int k = 0; k < NSI; ++k) dst[4096 + tid + NT * k] = gs[k];
-              if (tid >= NT - 8 && tid < NT - 1) dst[4096 + NSI * NT + (tid - (NT - 8))] = stat_tot; } }
+              for (int k = 0; k < NSI; ++k) dst[W2N + tid + NT * k] = gs[k];
+              if (tid >= NT - 8 && tid < NT - 1) dst[W2N + NSI * NT + (tid - (NT - 8))] = stat_tot; } }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                         // system scope: this wave's slot stores are performed at the peers
           __syncthreads();
           if (tid == 0) {
@@ -611,9 +635,9 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
               if (r < a.px_n && r != a.px_rank) {
                 const float* src = px_mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT;
 #pragma unroll
-                for (int k = 0; k < NSI; ++k) vS[q][k] = __hip_atomic_load(src + 4096 + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int k = 0; k < NSI; ++k) vS[q][k] = __hip_atomic_load(src + W2N + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 vT[q] = 0.f;
-                if (tid >= NT - 8 && tid < NT - 1) vT[q] = __hip_atomic_load(src + 4096 + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (tid >= NT - 8 && tid < NT - 1) vT[q] = __hip_atomic_load(src + W2N + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
                 for (int mm = 0; mm < WT; ++mm)
                   asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(vW[q][mm]) : "v"(src + tid * (4 * WT) + 4 * mm) : "memory");
@@ -726,7 +750,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 #pragma unroll
     for (int mm = 0; mm < WT; ++mm)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + MF_HID * (16 * (m0 + mm) + c);
+      for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + H2 * (16 * (m0 + mm) + c);
         a.p[pc] = tW2[mm][r]; a.m[pc] = mW2[mm][r]; a.v[pc] = vW2[mm][r]; }
     for (int s = tid; s < ns_valid; s += NT) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; }
   }

@@ -15,10 +15,13 @@
 int32_t crux_train_mfma8_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream);   // train_mfma8.hip
 int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream, bool any_mode);   // train_mfma_x2.hip
 
+int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream);      // train_fs.hip: the feature-split form (its own shape test: IN -> 64 -> {64, 32} -> OUT)
 int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream) {
   *handled = false;
   const NetDesc& nd = a.nd;
   if (getenv("CRUX_FORCE_GENERIC")) return CRUX_OK;      // parity tests run the same cases through the generic learner
+  // 0. full minibatch loops (with or without a replica group): the feature-split kernel on four compute units
+  { const int32_t rc = crux_train_fs_launch(c, a, handled, stream); if (rc || *handled) return rc; }
   if (nd.L != 3 || nd.dims[1] != MF_HID || nd.dims[2] != MF_HID || nd.acts[2] != CRUX_ACT_IDENTITY || nd.acts[0] != nd.acts[1]) return CRUX_OK;
   if (a.bs > 128 || a.loss == CRUX_LOSS_TD_INTERNAL || a.loss == CRUX_LOSS_MSE_ACTION) return CRUX_OK;   // those two heads exist in the generic kernel only
   if (a.ids && a.n_ids > 128) return CRUX_OK;

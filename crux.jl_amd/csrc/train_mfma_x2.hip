@@ -103,10 +103,8 @@ int32_t crux_train_mfma_x2_launch_multi(crux_ctx* c, std::vector<TrainArgs>& as,
 // Called by crux_train_mfma_launch after its shape checks, before the single-CU kernels.
 // any_mode = false: only full minibatch loops of 65..128 rows (where two CUs pay); true: also single steps, gradient-only calls and small minibatches
 // (workgroup 1 then idles on empty tiles) -- used for the shapes that have no one-CU instantiation.
-int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream);      // train_fs.hip: the feature-split form
 int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream, bool any_mode) {
   *handled = false;
-  { const int32_t rc = crux_train_fs_launch(c, a, kind, handled, stream); if (rc || *handled) return rc; }
   static const bool off = getenv("CRUX_MFMA_X2") && getenv("CRUX_MFMA_X2")[0] == '0';
   if (off) return CRUX_OK;
   if (!any_mode && (a.ids || !a.apply || a.bs <= 64 || a.len < a.bs)) return CRUX_OK;     // single steps and small batches stay on one CU when it has the shape

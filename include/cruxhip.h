@@ -46,7 +46,7 @@ int32_t crux_ctx_destroy(crux_ctx* ctx);
  * multi-learner call switches to one CU per learner above 64 learners), 1 = always one CU (k_train_mfma8), 2 = two CUs where the shape allows
  * (populations above 64 always take the one-CU form: two launches x 2 n workgroups would not be co-resident).
  * The two kernels sum the minibatch gradient in different orders: results agree to fp32 tolerance, bitwise only for equal settings.              */
-int32_t crux_ctx_set_learner_cus(crux_ctx* ctx, int32_t cus);
+int32_t crux_ctx_set_learner_cus(crux_ctx* ctx, int32_t cus);   /* 0 (default): automatic = the feature-split kernel on four CUs for full batch_train! loops, else the two- / one-CU kernels */
 const char* crux_last_error(crux_ctx* ctx);
 int32_t crux_sync(crux_ctx* ctx);
 const char* crux_version(void);

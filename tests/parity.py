@@ -15,6 +15,9 @@ import oracle as O  # noqa: E402
 ACTOR_DIMS, CRITIC_DIMS, ACTS = [4, 64, 64, 2], [4, 64, 64, 1], ["relu", "relu", "identity"]
 
 
+CRITIC_ACTS = {"cheetah_ref": ["tanh", "identity", "identity"]}      # families whose critic has other activations than the actor
+
+
 def chain(dims, acts):
     return crux.Chain(*[crux.Dense(dims[i], dims[i + 1], acts[i]) for i in range(len(acts))])
 
@@ -77,6 +80,8 @@ FAMILIES = {
     "synth_c5_h256": (17, 6, False, [17, 256, 256, 6], [17, 256, 256, 1], ["tanh", "tanh", "identity"], "gaussian", "gaussian", "synth"),
     # the reference's own Pendulum examples observe (theta, theta_dot): 2 inputs, one continuous action (examples/rl/pendulum.jl), here on the SYNTH dynamics
     "synth_2_1": (2, 1, False, [2, 64, 64, 1], [2, 64, 64, 1], ACTS, "gaussian", "gaussian", "synth"),
+    # the reference's HalfCheetah PPO networks (examples/rl/half_cheetah_mujoco.jl:33-38): mu = 17 -tanh-> 64 -tanh-> 32 -> 6, V = 17 -tanh-> 64 -> 32 -> 1 (CRITIC_ACTS below)
+    "cheetah_ref": (17, 6, False, [17, 64, 32, 6], [17, 64, 32, 1], ["tanh", "tanh", "identity"], "gaussian", "gaussian", "synth"),
     # outside the MFMA family (32-wide hidden layers): the generic learner
     "synth_8_4_h32": (8, 4, True, [8, 32, 32, 4], [8, 32, 32, 1], ACTS, "discrete", "categorical", "synth_discrete"),
 }
@@ -147,10 +152,11 @@ def ppo_iteration_parity(n_envs=4, T=64, batch_size=32, epochs=2, seed=3, max_st
     """One full PPO iteration (rollout -> GAE/returns -> whiten -> actor batch_train! -> critic batch_train!) on the GPU
     and in the oracle with the same Philox-defined randomness; returns the differences."""
     od, ad, disc, adims, cdims, acts, kind, head, okind = FAMILIES[family]
+    cacts = CRITIC_ACTS.get(family, acts)
     N = n_envs * T
     extras = ["return", "logprob", "advantage"]
     ga, oa = make_pair(adims, acts, seed, 0, kind, n_extra=0 if disc else ad, extra_init=logsigma)
-    gc, oc = make_pair(cdims, acts, seed, 1)
+    gc, oc = make_pair(cdims, cacts, seed, 1)
     res = {"init_params_equal": bool(np.array_equal(ga.get_params(), oa.params) and np.array_equal(gc.get_params(), oc.params))}
     S, A = crux.ContinuousSpace(od), (crux.DiscreteSpace(ad) if disc else crux.ContinuousSpace(ad))
     gb = crux.ExperienceBuffer(S, A, N, extras)

@@ -289,3 +289,13 @@ def test_two_input_pendulum_shape_runs_on_the_feature_split_learner(gpu_ctx, cap
     res = parity.ppo_iteration_parity(n_envs=8, T=128, batch_size=128, epochs=2, seed=5, family="synth_2_1", pair=True)
     assert res["ok"], res
     assert "outside the MFMA learner family" not in capfd.readouterr().err
+
+
+def test_reference_half_cheetah_ppo_networks_run_on_the_feature_split_learner(gpu_ctx, capfd):
+    """The networks of the reference's own HalfCheetah PPO example (examples/rl/half_cheetah_mujoco.jl:33-38): mu = 17 -tanh-> 64 -tanh-> 32 -> 6 with a trainable logSigma,
+    V = 17 -tanh-> 64 -> 32 -> 1 (no activation on its second layer). A 32-wide second hidden layer and per-layer activations are instantiations of k_train_fs (a wave's half of
+    the layer is one 16-feature tile); a whole PPO iteration against the oracle."""
+    res = parity.ppo_iteration_parity(n_envs=8, T=128, batch_size=128, epochs=2, seed=9, family="cheetah_ref", pair=True)
+    assert res["ok"], res
+    err = capfd.readouterr().err
+    assert "outside the MFMA learner family" not in err and "generic" not in err
