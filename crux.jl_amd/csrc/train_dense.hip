@@ -124,6 +124,54 @@ __global__ void k_pg_info(const double* __restrict__ st, const double* __restric
   dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
 }
 
+// Replica group (comm.hip "peer") for the dense-engine learner: the SUM all-reduce of the flat minibatch gradient (and of the head's eight statistics sums) between the pullback
+// (training.jl:18) and Flux.update! (:21) as ONE launch of one workgroup, in chunks of a peer slot: chunk k is exchange number x0 + k of this learner stream -- written into
+// slot [parity][my rank] of every peer, system-scope release, flag, wait for the N - 1 flags in the own region, acquire, add the N contributions in rank order (the own one from
+// the gradient buffer itself) and scale by 1/N: the protocol of the persistent kernels (train_mfma_kernel.h), driven from a stand-alone kernel. Every rank forms the same sums bit
+// for bit, so parameters, Adam state and the host's early-stopping decisions stay replicated.
+#define PXF_CHUNK (CRUX_PX_SLOT - 16)
+__global__ __launch_bounds__(1024) void k_px_allreduce_flat(float* __restrict__ g, int64_t n, double* __restrict__ st, float* const* __restrict__ px_tab, int rank, int N, int32_t* __restrict__ status) {
+  __shared__ int ok_s;
+  const int tid = threadIdx.x;
+  float* const mine = px_tab[rank];
+  const unsigned long long x0 = *(const unsigned long long*)(mine + CRUX_PX_COUNT);
+  const float inv = 1.0f / (float)N;
+  const int nchunks = (int)((n + PXF_CHUNK - 1) / PXF_CHUNK);
+  for (int k = 0; k < nchunks; ++k) {
+    const unsigned long long xg = x0 + (unsigned long long)k; const int par = (int)(xg & 1ull);
+    const int64_t off = (int64_t)k * PXF_CHUNK; const int len = (int)((n - off) < PXF_CHUNK ? (n - off) : PXF_CHUNK);
+    for (int r = 0; r < N; ++r) { if (r == rank) continue;
+      float* dst = px_tab[r] + (size_t)(par * CRUX_PX_MAXR + rank) * CRUX_PX_SLOT;
+      for (int i = tid; i < len; i += 1024) dst[i] = g[off + i];
+      if (k == 0 && tid < 8) dst[PXF_CHUNK + tid] = (float)st[tid]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (tid == 0) {
+      for (int r = 0; r < N; ++r) if (r != rank) __hip_atomic_store((unsigned long long*)(px_tab[r] + CRUX_PX_FLAGS) + 8 * rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      bool ok = true; const long long t0 = wall_clock64(); unsigned* abortw = (unsigned*)(mine + CRUX_PX_ABORT);
+      for (int r = 0; r < N && ok; ++r) { if (r == rank) continue;
+        const unsigned long long* fl = (const unsigned long long*)(mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
+        while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
+          if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
+      if (!ok) for (int r = 0; r < N; ++r) __hip_atomic_store((unsigned*)(px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      ok_s = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!ok_s) { if (tid == 0) status[0] = CRUX_EHIP; return; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    for (int i = tid; i < len; i += 1024) { float acc = 0.f;
+      for (int r = 0; r < N; ++r) { const float v = r == rank ? g[off + i] : __hip_atomic_load(mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        acc = r == 0 ? v : acc + v; }
+      g[off + i] = acc * inv; }
+    if (k == 0 && tid < 8) { float acc = 0.f;
+      for (int r = 0; r < N; ++r) { const float v = r == rank ? (float)st[tid] : __hip_atomic_load(mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT + PXF_CHUNK + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        acc = r == 0 ? v : acc + v; }
+      st[tid] = (double)(acc * inv); }
+    __syncthreads();
+  }
+  if (tid == 0) *(unsigned long long*)(mine + CRUX_PX_COUNT) = x0 + (unsigned long long)nchunks;
+}
+
 __global__ void k_nan_status(const double* __restrict__ ssq, int32_t* __restrict__ status) { if (isnan(ssq[0])) status[0] = CRUX_ENAN; }   // gradient-only calls: the NaN check of training.jl:20 without the update
 
 // which learners take this path (called by launch_train after the MFMA family declined)
@@ -157,7 +205,7 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a) {
     HIPCHK(c, hipMemcpyAsync(hinfo, dinfo, sizeof(float) * CRUX_INFO_N, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(hinfo + CRUX_INFO_N, status, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int32_t s; memcpy(&s, hinfo + CRUX_INFO_N, sizeof s); if (s == CRUX_ENAN) err = CRUX_ENAN;
+    int32_t s; memcpy(&s, hinfo + CRUX_INFO_N, sizeof s); if (s == CRUX_ENAN || s == CRUX_EHIP) err = s;
     return CRUX_OK;
   };
   for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
@@ -173,6 +221,8 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a) {
       q.ls = net->p + nd.xoff; q.dy = dy; q.gx = net->g + nd.xoff; q.stats = st;
       hipLaunchKernelGGL(k_pg_head, dim3(1), dim3(256), 0, c->stream, q);
       rc = crux_dense_backward(net, x, nb, dy, 1.0f, true, nullptr, c->stream); if (rc) return rc;
+      if (a.need_px && c->peer_n > 1)      // replica group: the gradient (and the statistics) of the GLOBAL minibatch, the same bits on every rank
+        hipLaunchKernelGGL(k_px_allreduce_flat, dim3(1), dim3(1024), 0, c->stream, net->g, (int64_t)nd.n_params, st, (float* const*)c->peer_tab, c->peer_rank, c->peer_n, status);
       hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, c->stream, (const float*)net->g, (int64_t)nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
       hipLaunchKernelGGL(k_pg_info, dim3(1), dim3(1), 0, c->stream, (const double*)st, (const double*)ssq, nb, a.loss, a.head, a.lambda_p, a.lambda_e, (const float*)(net->p + nd.xoff), a.ad, dinfo, (const crux_lagrange*)a.lag);
       if (a.apply) { rc = adam_gated(net, ssq, status); if (rc) return rc; }

@@ -270,3 +270,55 @@ def test_three_replicas_of_the_c5_actor(gpu_ctx):
                 pass
         for c in extra:
             c.close()
+
+
+@pytest.mark.parametrize("which", ["actor", "critic"])
+def test_dense_engine_learner_under_a_replica_group_equals_the_concatenated_batch_oracle(two_contexts, which):
+    """replica groups for the shapes the dense engine serves. 8->128->128->4 PPO actor / 8->128->128->1 critic (outside the register-resident family: ~13
+    launches per minibatch, train_dense.hip) under a group of two: the flat gradient (18 180 floats = three slot-sized chunks) and the head's statistics are SUM-all-reduced
+    by k_px_allreduce_flat between the pullback and the gated Adam. Two replicas with minibatches of 128 must take the steps of ONE oracle learner on minibatches of 256 and
+    stay bit-identical to each other."""
+    ctxs = two_contexts; bs, epochs, N = 128, 2, 512
+    rng = np.random.default_rng(31); extras = ["return", "logprob", "advantage"]
+    def shard():
+        ai = rng.integers(0, 4, N)
+        return {"s": rng.normal(0, 1, (8, N)).astype(np.float32), "a": np.eye(4, dtype=bool)[:, ai], "sp": rng.normal(0, 1, (8, N)).astype(np.float32), "r": np.ones((1, N), np.float32),
+                "done": np.zeros((1, N), bool), "episode_end": np.zeros((1, N), bool), "return": rng.normal(0, 1, (1, N)).astype(np.float32),
+                "logprob": rng.normal(-1.4, 0.05, (1, N)).astype(np.float32), "advantage": rng.normal(0, 1, (1, N)).astype(np.float32)}
+    shards = [shard(), shard()]
+    dims = [8, 128, 128, 4] if which == "actor" else [8, 128, 128, 1]
+    loss, head = ("ppo", "categorical") if which == "actor" else ("value_mse", "deterministic")
+    perms = [np.stack([rng.permutation(N) for _ in range(epochs)]) for _ in range(2)]
+    nets, bufs = [], []
+    for r, ctx in enumerate(ctxs):
+        ch = parity.chain(dims, parity.ACTS)
+        g = crux.DiscreteNetwork(ch, [1, 2, 3, 4], ctx=ctx, seed=78, stream=3) if which == "actor" else crux.ContinuousNetwork(ch, ctx=ctx, seed=78, stream=3)
+        b = crux.ExperienceBuffer(crux.ContinuousSpace(8), crux.DiscreteSpace(4), N, extras, ctx=ctx); b.push_(shards[r])
+        nets.append(g); bufs.append(b)
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+    infos = [None, None]
+    def make(r):
+        def f():
+            opt = crux.TrainingParams(loss=crux.ppo_loss if which == "actor" else crux.value_mse_loss, batch_size=bs, epochs=epochs, name="n_")
+            infos[r] = crux.batch_train_(nets[r], opt, P, bufs[r], perms=perms[r] + 1)
+        return f
+    _run_threads([make(0), make(1)])
+    p0, p1 = nets[0].get_params(), nets[1].get_params()
+    assert np.array_equal(p0, p1)
+    m0, v0, bp0 = nets[0].adam_state(); m1, v1, bp1 = nets[1].adam_state()
+    assert np.array_equal(m0, m1) and np.array_equal(v0, v1) and np.array_equal(bp0, bp1)
+    assert infos[0]["n_loss"] == infos[1]["n_loss"] and infos[0]["n_grad_norm"] == infos[1]["n_grad_norm"]
+    glob, pos = _interleave(shards, bs)
+    ob = O.OBuffer(8, 4, L.ACTION_DISCRETE, 2 * N, extras); ob.push(glob)
+    o = O.OMlp(dims, parity.ACTS).init_glorot(78, 3).adam_init(float(np.float32(3e-4)))
+    gperm = np.empty((epochs, 2 * N), np.int64)
+    for e in range(epochs):
+        for r in range(2):
+            gperm[e, pos[r]] = pos[r][perms[r][e]]
+    cfg = parity.train_cfg(loss, head, 2 * bs, epochs, -1.0, 0)
+    oi = np.zeros(L.INFO_N, np.float32)
+    O.chk(O.lib().orc_batch_train(o.h, ob.h, C.byref(cfg), O.vpz(gperm), O.vpz(oi), None))
+    d = float(np.abs(p0 - o.params).max())
+    print(which, "dense-engine learner, two replicas vs concatenated-batch oracle after %d steps: max |dtheta| = %.3g" % (epochs * (N // bs), d), "loss", infos[0]["n_loss"], float(oi[0]))
+    assert d < 2e-6            # measured 4.5e-8 (actor) / 1.5e-8 (critic) after 8 steps
+    assert abs(infos[0]["n_loss"] - float(oi[0])) < 2e-5 * max(1.0, abs(float(oi[0])))
