@@ -5,14 +5,14 @@
 
 extern "C" int crux_x2_placement_ok(crux_ctx* c);      // train_mfma_x2.hip: workgroups i and i + 8 of a grid share an XCD (probed once per process)
 
-template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, int NWG, bool HELP, bool TIMING, bool PX>
+template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, int NWG, bool HELP, bool TIMING, bool PX, bool LAG = false>
 static int32_t launch_fs_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
-  using Lt = FsLayout<IN, OUT, NWG, HELP, H2>;
+  using Lt = FsLayout<IN, OUT, NWG, HELP, H2, LAG>;
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
   static bool attr = false;
-  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING, PX, H2, ACT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-  hipLaunchKernelGGL((k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING, PX, H2, ACT2>), dim3(8 * NWG), dim3(Lt::NT), lds, stream, a);
-  return crux_launch_check(c, PX ? "k_train_fs (replica group)" : "k_train_fs");
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING, PX, H2, ACT2, LAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING, PX, H2, ACT2, LAG>), dim3(8 * NWG), dim3(Lt::NT), lds, stream, a);
+  return crux_launch_check(c, PX ? "k_train_fs (replica group)" : LAG ? "k_train_fs (lagrange_ppo_loss)" : "k_train_fs");
 }
 // form: 2 = two workgroups of eight waves; 4 = four workgroups of four waves; 8 = four workgroups of four compute + four helper waves (the only form of the 32-wide second layer)
 template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, bool TIMING>
@@ -36,6 +36,10 @@ static int32_t launch_fs(crux_ctx* c, TrainArgs a, int form, bool timing, hipStr
     a.px_hist = c->peer_hist ? 1 : 0; a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
     return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, true, false, true>(c, a, stream);
   }
+  if constexpr (KIND != MFK_VALUE && H2 == 64 && ACT2 == ACT && ((IN == 4 && OUT == 2) || (IN == 8 && OUT == 4) || (IN == 3 && OUT == 1) || (IN == 17 && OUT == 6 && ACT == CRUX_ACT_TANH))) {
+    if (a.lag) return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, true, false, false, true>(c, a, stream);      // lagrange_ppo_loss (ppo.jl:70-131): the helper-wave form with the penalty controller
+  }
+  if (a.lag) return crux_fail(c, CRUX_EINVAL, "k_train_fs: no lagrange instantiation for this shape");
   constexpr bool HAS_TIMING = H2 == 64 && ACT2 == ACT && ((IN == 4 && (OUT == 2 || OUT == 1)) || (IN == 17 && ACT == CRUX_ACT_TANH));      // the in-kernel phase timers are instantiated for the C2 / C5 learners only
   if constexpr (HAS_TIMING) if (timing) {
     static unsigned long long* dbg = nullptr;
@@ -66,7 +70,7 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hip
   if (c->learner_cus != 0 && !a.need_px) return CRUX_OK;      // crux_ctx_set_learner_cus(1 | 2): the caller asked for the one- / two-CU kernels (population runs)
   const NetDesc& nd = a.nd;
   if (nd.L != 3 || nd.dims[1] != MF_HID || (nd.dims[2] != 64 && nd.dims[2] != 32) || nd.acts[2] != CRUX_ACT_IDENTITY) return CRUX_OK;
-  if (a.ids || !a.apply || a.bs <= 64 || a.bs > 128 || a.len < a.bs || a.lag) return CRUX_OK;
+  if (a.ids || !a.apply || a.bs <= 64 || a.bs > 128 || a.len < a.bs) return CRUX_OK;
   int kind;
   if (a.loss == CRUX_LOSS_VALUE_MSE) kind = MFK_VALUE;
   else if (!CRUX_IS_PG(a.loss)) return CRUX_OK;
@@ -74,9 +78,16 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hip
   else if (a.head == CRUX_HEAD_GAUSSIAN) kind = MFK_GAUSSIAN;
   else return CRUX_OK;
   if (!crux_x2_placement_ok(c)) return CRUX_OK;
+  const int in = nd.dims[0], h2 = nd.dims[2], out = nd.dims[3], act = nd.acts[0], act2 = nd.acts[1];
+  if (a.lag) {     // lagrange_ppo_loss (crux_batch_train_lagrange passes the PPO head with the controller attached): the helper-wave form, one replica, the shapes instantiated in launch_fs;
+                   // everything else stays with the two-CU kernel / the dense-engine learner
+    if (kind == MFK_VALUE || a.loss != CRUX_LOSS_PPO || (c->peer_n > 1 && a.need_px) || (form_env != 0 && form_env != 8) || h2 != 64 || act2 != act) return CRUX_OK;
+    const bool shape = (in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) || (in == 8 && out == 4 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) ||
+                       (in == 3 && out == 1 && kind == MFK_GAUSSIAN && act == CRUX_ACT_RELU) || (in == 17 && out == 6 && kind == MFK_GAUSSIAN && act == CRUX_ACT_TANH);
+    if (!shape) return CRUX_OK;
+  }
   const int form = form_env == 2 || form_env == 4 || form_env == 8 ? form_env : CRUX_FS_DEFAULT_WG;      // 8 = four workgroups with helper waves
   const bool timing = getenv("CRUX_MFMA_TIMING") != nullptr;
-  const int in = nd.dims[0], h2 = nd.dims[2], out = nd.dims[3], act = nd.acts[0], act2 = nd.acts[1];
 #define FS_CASE2(I, O, K, A1, H, A2) if (in == I && out == O && kind == K && act == A1 && h2 == H && act2 == A2) { *handled = true; return launch_fs<I, O, K, A1, H, A2>(c, a, form, timing, stream); }
 #define FS_CASE(I, O, K, A_) FS_CASE2(I, O, K, A_, 64, A_)
   FS_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)     // C2 actor  (PPO CartPole)

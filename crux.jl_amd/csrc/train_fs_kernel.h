@@ -13,8 +13,8 @@
 //     BEFORE dH1 and its partial sums leave for the other workgroups' L2 slots at once, so the store acknowledgement is covered by the rest of the backward pass;
 //   * the NWG partial gradients are exchanged once per step through the shared L2 exactly like the two-CU form does (plain stores, s_waitcnt, one agent-scope arrival
 //     counter, sc1 loads) and added in workgroup order by everyone: bit-identical totals, Adam updates and early-stopping decisions in all workgroups.
-// Covers full minibatch loops (batch_train! with Adam, 65..128 rows per minibatch) of the plain policy-gradient / critic losses; single steps, gradient-only calls,
-// replica groups and lagrange_ppo_loss stay on train_mfma_kernel.h.
+// Covers full minibatch loops (batch_train! with Adam, 65..128 rows per minibatch) of the plain policy-gradient / critic losses, of lagrange_ppo_loss (LAG) and of replica
+// groups (PX); single steps and gradient-only calls stay on train_mfma_kernel.h.
 #pragma once
 #include "train_args.h"
 
@@ -25,7 +25,7 @@ __device__ __forceinline__ int fs_tx(int q) { return (4 - q) & 3; }   // {0,3,2,
 
 // H2: width of the second hidden layer, 64 or 32 (the first is MF_HID = 64): the reference's HalfCheetah PPO networks are 17-64-32-6 / 17-64-32-1
 // (examples/rl/half_cheetah_mujoco.jl:33-38); a wave's half of the layer is then ONE 16-feature tile instead of two.
-template <int IN, int OUT, int NWG, bool HELP = false, int H2 = 64>
+template <int IN, int OUT, int NWG, bool HELP = false, int H2 = 64, bool LAG = false>
 struct FsLayout {
   static_assert(H2 == 64 || H2 == 32, "second hidden layer: 64 or 32 units");
   static constexpr int MH = H2 / 32, NT2 = H2 / 16, HH = H2 / 2, W2N = H2 * MF_HID;      // 16-feature tiles per half / per layer, features per half, elements of W2
@@ -33,7 +33,7 @@ struct FsLayout {
   static constexpr int NW = HELP ? 2 * NWC : NWC, NT = 64 * NW;            // + as many helper waves: owners of half the W2 tiles, and the minibatch staging
   static constexpr int NXB = HELP ? 2 : 1;                                 // staging rows are double-buffered when the helpers stage the next minibatch during the step
   static constexpr int KS0 = (IN + 3) / 4, IP = KS0 * 4, JT = (IN + 15) / 16, XP = IP + 2, W1LD = IP + 2;
-  static constexpr int SCW = (4 + (OUT > 4 ? OUT : 4)) | 1;
+  static constexpr int SCW = ((4 + (OUT > 4 ? OUT : 4)) | 1) + (LAG ? 2 : 0);      // lagrange_ppo_loss: :cost_advantage of the sample rides in the last slot
   static constexpr int ZW = OUT;                                                          // partial logits per (tile, half, g, sample)
   // flat index spaces of the small parameters (everything but W2): s = thread-owned index, c = canonical (Flux.params) index, p = index inside a tile's partial block
   static constexpr int sW1 = 0, sB1 = MF_HID * IN, sB2 = sB1 + MF_HID, sW3 = sB2 + H2, sB3 = sW3 + H2 * OUT, sEX = sB3 + OUT, NS = sEX + 16;
@@ -54,7 +54,9 @@ struct FsLayout {
   static constexpr int oXS = oPART + TILES * PART;
   static constexpr int oSC = oXS + NXB * TILES * 16 * XP;
   static constexpr int oRED = oSC + NXB * TILES * 16 * SCW;                     // [0,8): per-wave sum of squares; [8,15): reduced stat sums; [16]: abort flag
-  static constexpr int TOTAL = oRED + 32;
+  static constexpr int oLAG = oRED + 32;                                        // lagrange_ppo_loss: [buffer][cost 128 | episode_end 128] of the WHOLE minibatch
+  static constexpr int oLGS = oLAG + (LAG ? 2 * 256 : 0);                       // [wave][8]: the controller's state, one copy per wave (every wave advances its own, identically)
+  static constexpr int TOTAL = oLGS + (LAG ? 8 * NW : 0);
   static constexpr int NSI = (NS + NT - 1) / NT;
   static constexpr int XSLOT = ((W2N + NSI * NT + 16 + 3) / 4) * 4;       // floats per exchange slot
   static_assert(TOTAL <= 40960, "LDS budget (160 KB) exceeded");
@@ -64,16 +66,20 @@ struct FsLayout {
 // PX: the replica-group form (comm.hip "peer"): after the workgroups have formed the local total, the N replicas SUM-all-reduce it through peer-mapped slots inside the same step,
 // between the pullback (training.jl:18) and Flux.update! (:21) -- the protocol of train_mfma_kernel.h with the peers shared among four workgroups instead of two.
 // ACT / ACT2: activations of the first / second hidden layer (the reference's critic of that example has no activation on its second layer).
-template <int IN, int OUT, int KIND, int ACT, int NWG, bool HELP = false, bool TIMING = false, bool PX = false, int H2 = 64, int ACT2 = ACT>
+// LAG: lagrange_ppo_loss (ppo.jl:70-131) -- the PID penalty controller advanced once per minibatch inside the kernel (every thread, from the staged :cost / :episode_end
+// columns of the whole minibatch) and the cost-advantage term of the loss; helper-wave form.
+template <int IN, int OUT, int KIND, int ACT, int NWG, bool HELP = false, bool TIMING = false, bool PX = false, int H2 = 64, int ACT2 = ACT, bool LAG = false>
 __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(TrainArgs a) {
   static_assert(NWG == 2 || NWG == 4, "two workgroups of eight waves, or four of four (+ four helper waves)");
   static_assert(!HELP || NWG == 4, "helper waves: the four-workgroup form");
-  using Lt = FsLayout<IN, OUT, NWG, HELP, H2>;
+  static_assert(!LAG || (HELP && !PX && KIND != MFK_VALUE), "lagrange_ppo_loss: helper-wave form, policy heads, one replica");
+  using Lt = FsLayout<IN, OUT, NWG, HELP, H2, LAG>;
   constexpr int NW = Lt::NW, NWC = Lt::NWC, TILES = Lt::TILES, NT = Lt::NT, MH = Lt::MH, HH = Lt::HH, W2N = Lt::W2N;
   constexpr int WT = (Lt::NT2 * 4) / NW;             // 16x16 tiles of W2 (H2/16 x 4 of them) owned by a wave
   static_assert(WT >= 1 && WT * NW == Lt::NT2 * 4, "W2 tiles must divide over the waves");
   constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS, NSI = Lt::NSI, XSLOT = Lt::XSLOT;
   constexpr int NACT = (OUT > 4 ? OUT : 4);
+  constexpr int STAT_HI = LAG ? 64 * Lt::NW : 64 * Lt::NW - 1;
   if ((int)(blockIdx.x & 7) != a.xcd) return;        // the NWG workgroups of the learner: blocks x, x + 8, x + 16, x + 24 -> one XCD (consecutive workgroups go round-robin over the 8 XCDs)
   const int p = (int)(blockIdx.x >> 3);              // workgroup 0 .. NWG-1 of this learner
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -162,6 +168,10 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   bool staged = false;
   long long xstep = 0;
   float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
+  float inf_pen = 0.f, inf_cur = 0.f, inf_closs = 0.f, inf_ploss = 0.f;
+  float pen = 0.f;                                     // lagrange_ppo_loss: the penalty of the current minibatch; the controller's state sits in LDS, one copy per wave
+  float* lgs = sm + Lt::oLGS + 8 * w;                  // [I, smooth_delta, smooth_Jc, Jc_prev, deriv_term, penalty, cur_cost]
+  if constexpr (LAG) { if (lane == 0) { lgs[0] = a.lag->I; lgs[1] = a.lag->smooth_delta; lgs[2] = a.lag->smooth_Jc; lgs[3] = a.lag->Jc_prev; lgs[4] = a.lag->deriv_term; lgs[5] = a.lag->penalty; lgs[6] = a.lag->cur_cost; } }
   // replica group: exchanges done on this learner stream before this launch -- slot parity and flag values continue across launches
   float* const px_mine = PX ? a.px_tab[a.px_rank] : nullptr;
   const unsigned long long px0 = PX ? *(const unsigned long long*)(px_mine + CRUX_PX_COUNT) : 0ull;
@@ -192,23 +202,28 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 #pragma unroll
   for (int e = 0; e < NXL; ++e) px[e] = 0.f;
   int n_row = 0, n_valid = 0;
+  const int lt = tid - 64 * NWC;                       // LAG: helper thread lt < 128 carries row lt of the whole minibatch (its :cost and :episode_end)
+  int n_row2 = -1; float p_cost2 = 0.f, p_ee2 = 0.f, p_cadv = 0.f;
   auto fetch_index = [&](const int32_t* ord, int64_t st, int nb) {
     const int sidx = 8 * NWC * p + 16 * t + c;
     n_valid = sidx < nb ? 1 : 0;
     n_row = n_valid ? CRUX_GLOBAL_PTR(int32_t, ord)[st + sidx] : 0;
+    if constexpr (LAG) n_row2 = (lt >= 0 && lt < nb) ? CRUX_GLOBAL_PTR(int32_t, ord)[st + lt] : -1;
   };
   auto fetch_data = [&]() {
     const int rowlo = n_row; p_valid = n_valid; const int64_t row = rowlo;
+    if constexpr (LAG) { p_cost2 = n_row2 >= 0 ? CRUX_GLOBAL_PTR(float, a.COST)[n_row2] : 0.f; p_ee2 = (n_row2 >= 0 && CRUX_GLOBAL_PTR(uint8_t, a.EE)[n_row2]) ? 1.f : 0.f; }
     if (h == 0) {
       const int rs = __shfl(rowlo, lane >> 2, 64), vs = __shfl(p_valid, lane >> 2, 64);      // lanes 0..15 hold the rows of samples 0..15
       const float* xrow = CRUX_GLOBAL_PTR(float, a.S) + (int64_t)rs * IN + (lane & 3) * NXL;
 #pragma unroll
       for (int e = 0; e < NXL; ++e) px[e] = ((lane & 3) * NXL + e < IN && vs) ? xrow[e] : 0.f;
     } else {
-      p_lp = 0.f; p_adv = 0.f; p_ret = 0.f;
+      p_lp = 0.f; p_adv = 0.f; p_ret = 0.f; p_cadv = 0.f;
 #pragma unroll
       for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
       if (lane < 16 && p_valid) {
+        if constexpr (LAG) p_cadv = CRUX_GLOBAL_PTR(float, a.CADV)[row];
         if (KIND != MFK_VALUE) { p_lp = CRUX_GLOBAL_PTR(float, a.LP)[row]; p_adv = CRUX_GLOBAL_PTR(float, a.ADV)[row]; }
         p_ret = a.RET ? CRUX_GLOBAL_PTR(float, a.RET)[row] : 0.f;
         if (KIND == MFK_CATEGORICAL) { const auto* av = CRUX_GLOBAL_PTR(uint8_t, a.A) + row * OUT;
@@ -222,6 +237,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   };
   auto stage = [&](int buf) {
     float* xs_ = xs + buf * XSB; float* sc_ = sc + buf * SCB;
+    if constexpr (LAG) { if (lt >= 0 && lt < 128) { sm[Lt::oLAG + 256 * buf + lt] = p_cost2; sm[Lt::oLAG + 256 * buf + 128 + lt] = p_ee2; } }
     if (h == 0) {
 #pragma unroll
       for (int e = 0; e < NXL; ++e) { const int f = (lane & 3) * NXL + e; if (f < IN) xs_[(lane >> 2) * XP + f] = px[e]; }
@@ -231,6 +247,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
         for (int k = 0; k < OUT; ++k) ai = p_abyte[k] ? k : ai;
         p_act[0] = (float)ai; }
       if (lane < 16) { float* q = sc_ + lane * Lt::SCW; q[0] = (float)p_valid; q[1] = p_lp; q[2] = p_adv; q[3] = p_ret;
+        if constexpr (LAG) q[Lt::SCW - 1] = p_cadv;
         if (KIND == MFK_GAUSSIAN) {       // SquashedGaussianPolicy: the stored action is un-tanh'd once here and the tanh correction of logpdf rides in the spare slot
           static_assert(KIND != MFK_GAUSSIAN || ((4 + NACT) % 2 == 0), "the staging row needs its spare slot");
           float corr = 0.f;
@@ -262,6 +279,22 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
       FS_T(0);
       if (!staged) { if (sw) stage(HELP ? xcur : 0); __syncthreads(); }     // the first minibatch of an epoch; every other one was staged during the previous step (barriers follow it there)
       staged = false;
+      if constexpr (LAG) {   // the penalty update inside the loss (ppo.jl:80-116), once per evaluation: sums of the minibatch's :cost and :episode_end, then the controller
+        const float* lc = sm + Lt::oLAG + 256 * xcur;
+        double sc_ = (double)lc[lane] + (double)lc[lane + 64], ne_ = (double)lc[128 + lane] + (double)lc[128 + lane + 64];      // Float32 terms: any summation order gives the same Float64 sum
+#pragma unroll
+        for (int o_ = 32; o_ >= 1; o_ >>= 1) { sc_ += __shfl_xor(sc_, o_, 64); ne_ += __shfl_xor(ne_, o_, 64); }
+        const crux_lagrange* L = a.lag;              // the keywords: uniform (scalar) loads
+        const float Jc = (float)sc_ / (float)ne_;                                      // :84-88
+        const float dl = Jc - L->target_cost;                                         // :91
+        float I_ = lgs[0], sd_ = lgs[1], sj_ = lgs[2]; const float jp_ = lgs[3];
+        { const float x = I_ + L->Ki * dl; I_ = x > L->Ki_max ? L->Ki_max : (x < 0.f ? 0.f : x); }                   // :94 clamp(I + Ki*Delta, 0, Ki_max)
+        sd_ = (float)(L->ema_alpha * (double)sd_ + (1.0 - L->ema_alpha) * (double)dl);                             // :98 (Float64 arithmetic, Float32 store)
+        sj_ = (float)(L->ema_alpha * (double)sj_ + (1.0 - L->ema_alpha) * (double)Jc);                             // :99
+        float dt_; { const float x = sj_ - jp_; dt_ = (x != x) ? x : (x > 0.f ? x : 0.f); }                          // :102 max(0, .) keeps NaN
+        { const float x = (L->Kp * sd_ + I_) + L->Kd * dt_; pen = x > L->penalty_max ? L->penalty_max : (x < 0.f ? 0.f : x); }   // :108
+        if (lane == 0) { lgs[0] = I_; lgs[1] = sd_; lgs[2] = sj_; lgs[3] = sj_ /* Jc_prev = smooth_Jc, :105 */; lgs[4] = dt_; lgs[5] = pen; lgs[6] = Jc; }
+      }
       if (sw) {
         if (st + a.bs < total_rows) fetch_data();
         const int64_t st2 = st + 2 * (int64_t)a.bs; const int nb2 = st2 < total_rows ? (int)((total_rows - st2) < a.bs ? (total_rows - st2) : a.bs) : 0;
@@ -329,7 +362,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
       __syncthreads();   // ---- B_z: partial logits of both halves are visible
       if (HELP && !cw && st + a.bs < total_rows) stage(xcur ^ 1);      // helpers: the NEXT minibatch (rows requested at the top of this step) goes into the other staging buffer
       float dz[OUT], dex[OUT];
-      float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f;
+      float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f, s_cost = 0.f;
       if (cw) {
       float z[OUT];
       { const float* zo = sm + Lt::oZP + ((t * 2 + (1 - h)) * 64 + lane) * Lt::ZW;
@@ -359,10 +392,12 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
           const float newlp = __logf(pa); const float r = __expf(newlp - oldlp);
           const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
           const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;   // a2c_loss (a2c.jl:4-15): -mean(logpdf .* A)
+          float gcr = 0.f;                                                          // lagrange: d/dr of max(r Ac, clamp(r) Ac) times r (ppo.jl:119)
+          if constexpr (LAG) { const float Ac = q[Lt::SCW - 1]; const float uc = r * Ac, clc = rc * Ac; s_cost = cnt * (uc >= clc ? uc : clc); gcr = (uc >= clc ? Ac : 0.f) * r; }
 #pragma unroll
           for (int k = 0; k < OUT; ++k) { const float dlogpi = ((k == ai) ? 1.f : 0.f) - pk[k];
             const float base = -a.lambda_p * coef * dlogpi - a.lambda_e * (pk[k] * (hk[k] - hp));
-            dz[k] = !valid ? 0.f : invB * base; }
+            dz[k] = !valid ? 0.f : (LAG ? invB * ((base + pen * gcr * dlogpi) / (1.f + pen)) : invB * base); }
           s_lossp = cnt * lterm; s_H = cnt * H; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R;
           s_clip = cnt * clipv;
         } else {   // gaussian with constant log-std (policies.jl:333-348)
@@ -376,7 +411,9 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
           if (a.squash > 0.f) newlp -= q[4 + NACT];
           const float r = __expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
           const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;
-          const float cf = -a.lambda_p * coef;
+          float cf = -a.lambda_p * coef;
+          if constexpr (LAG) { const float Ac = q[Lt::SCW - 1]; const float uc = r * Ac, clc = rc * Ac; s_cost = cnt * (uc >= clc ? uc : clc);
+            cf = (cf + pen * ((uc >= clc ? Ac : 0.f) * r)) / (1.f + pen); }
 #pragma unroll
           for (int k = 0; k < OUT; ++k) { dz[k] = valid ? invB * (cf * (dd[k] * s2[k])) : 0.f;
             dex[k] = valid ? invB * (cf * (((dd[k] * dd[k]) * s2[k]) * inr[k] - 1.f)) : 0.f; }
@@ -413,13 +450,14 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 #pragma unroll
           for (int r = 0; r < 4; ++r) h2[mm][r] = actg<ACT2>(h2[mm][r], d2[mm][r]); }       // h2 now holds dZ2 of this half
       if (h == 0) {      // statistics and the head's own gradient sums (db3, dlogSigma): once per tile
-        constexpr int NV = 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0);
+        constexpr int NVB = 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0), NV = NVB + (LAG ? 1 : 0);
         float mv[((NV + 15) / 16) * 16];
 #pragma unroll
         for (int k = 0; k < ((NV + 15) / 16) * 16; ++k) mv[k] = 0.f;
         mv[0] = s_lossp; mv[1] = s_H; mv[2] = s_kl; mv[3] = s_adv; mv[4] = s_ret; mv[5] = s_clip; mv[6] = s_sq;
 #pragma unroll
         for (int o = 0; o < OUT; ++o) { mv[7 + o] = dz[o]; if (KIND == MFK_GAUSSIAN) mv[7 + OUT + o] = dex[o]; }
+        if constexpr (LAG) mv[NVB] = s_cost;             // the cost term of the loss rides behind the head's gradient sums
 #pragma unroll
         for (int ch = 0; ch < (NV + 15) / 16; ++ch) { float cv[16];
 #pragma unroll
@@ -516,15 +554,16 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
           for (int q = 1; q < TILES; ++q) gsum += sm[po + q * Lt::PART]; }
         gs[k] = gsum; }
       float stat_loc = 0.f;
-      if (tid >= NT - 8 && tid < NT - 1) { const int k = tid - (NT - 8); stat_loc = sm[Lt::oPART + Lt::pST + k];   // stat sums, by 7 lanes of the last wave
+      if (tid >= NT - 8 && tid < STAT_HI) { const int k = tid - (NT - 8);      // stat sums, by 7 lanes of the last wave (8 with the cost term of lagrange_ppo_loss)
+        const int ko = (LAG && k == 7) ? Lt::pMISC + 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0) : Lt::pST + k; stat_loc = sm[Lt::oPART + ko];
 #pragma unroll
-        for (int q = 1; q < TILES; ++q) stat_loc += sm[Lt::oPART + q * Lt::PART + Lt::pST + k]; }
+        for (int q = 1; q < TILES; ++q) stat_loc += sm[Lt::oPART + q * Lt::PART + ko]; }
       float stat_tot = stat_loc;
       // ---- exchange the partial gradients with the other workgroups through the shared L2 ----
       {
 #pragma unroll
         for (int k = 0; k < NSI; ++k) mine[W2N + tid + NT * k] = gs[k];
-        if (tid >= NT - 8 && tid < NT - 1) mine[W2N + NSI * NT + (tid - (NT - 8))] = stat_loc;
+        if (tid >= NT - 8 && tid < STAT_HI) mine[W2N + NSI * NT + (tid - (NT - 8))] = stat_loc;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this lane has reached the L2 (the dW2 partials left before dH1: long acknowledged)
         FS_T(10);
         __syncthreads();
@@ -558,7 +597,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 #pragma unroll
           for (int k = 0; k < NSI; ++k) pg[j][k] = __hip_atomic_load(peer + W2N + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ps[j] = 0.f;
-          if (tid >= NT - 8 && tid < NT - 1) ps[j] = __hip_atomic_load(peer + W2N + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (tid >= NT - 8 && tid < STAT_HI) ps[j] = __hip_atomic_load(peer + W2N + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
           for (int mm = 0; mm < WT; ++mm)
             asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(pw[j][mm]) : "v"(peer + tid * (4 * WT) + 4 * mm) : "memory"); }
@@ -595,7 +634,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
               for (int mm = 0; mm < WT; ++mm) *(f32x4*)&dst[tid * (4 * WT) + 4 * mm] = gW2[mm];
 #pragma unroll
               for (int k = 0; k < NSI; ++k) dst[W2N + tid + NT * k] = gs[k];
-              if (tid >= NT - 8 && tid < NT - 1) dst[W2N + NSI * NT + (tid - (NT - 8))] = stat_tot; } }
+              if (tid >= NT - 8 && tid < STAT_HI) dst[W2N + NSI * NT + (tid - (NT - 8))] = stat_tot; } }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                         // system scope: this wave's slot stores are performed at the peers
           __syncthreads();
           if (tid == 0) {
@@ -637,7 +676,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 #pragma unroll
                 for (int k = 0; k < NSI; ++k) vS[q][k] = __hip_atomic_load(src + W2N + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 vT[q] = 0.f;
-                if (tid >= NT - 8 && tid < NT - 1) vT[q] = __hip_atomic_load(src + W2N + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (tid >= NT - 8 && tid < STAT_HI) vT[q] = __hip_atomic_load(src + W2N + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
                 for (int mm = 0; mm < WT; ++mm)
                   asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(vW[q][mm]) : "v"(src + tid * (4 * WT) + 4 * mm) : "memory");
@@ -679,11 +718,11 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
         }
         xstep += 1;
       }
-      if (tid >= NT - 8 && tid < NT - 1) sm[Lt::oRED + 8 + (tid - (NT - 8))] = stat_tot;
+      if (tid >= NT - 8 && tid < STAT_HI) sm[Lt::oRED + 8 + (tid - (NT - 8))] = stat_tot;
       float ssq = 0.f; int bad = 0;
 #pragma unroll
       for (int k = 0; k < NSI; ++k) if (so_ok[k]) {
-        if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += -a.lambda_e;      // d(-lambda_e H)/dlogSigma, H = const + sum(logSigma)
+        if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += LAG ? -a.lambda_e / (1.f + pen) : -a.lambda_e;      // d(-lambda_e H)/dlogSigma, H = const + sum(logSigma); lagrange: the whole loss is divided by 1 + penalty
         ssq += gs[k] * gs[k]; bad |= isnan(gs[k]) ? 1 : 0; }
 #pragma unroll
       for (int mm = 0; mm < WT; ++mm)
@@ -710,7 +749,10 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
             else { entropy = 1.4189385332046727f;
 #pragma unroll
               for (int k = 0; k < OUT; ++k) entropy += sm[Lt::oEX + k]; }
-            inf_ent = entropy; inf_loss = a.lambda_p * p_loss + a.lambda_e * (-entropy); inf_kl = tq[2] * invB; inf_adv = tq[3] * invB; inf_ret = tq[4] * invB; inf_clip = tq[5] * invB; }
+            inf_ent = entropy; inf_loss = a.lambda_p * p_loss + a.lambda_e * (-entropy); inf_kl = tq[2] * invB; inf_adv = tq[3] * invB; inf_ret = tq[4] * invB; inf_clip = tq[5] * invB;
+            if constexpr (LAG) { const float cost_loss = pen * (tq[7] * invB);                                        // ppo.jl:119
+              inf_loss = ((a.lambda_p * p_loss + a.lambda_e * (-entropy)) + cost_loss) / (1.f + pen);                   // :131
+              inf_pen = pen; inf_cur = lgs[6]; inf_closs = cost_loss; inf_ploss = a.lambda_p * p_loss; } }
         }
       }
       if (any_bad) { inf_gn = NAN; err = CRUX_ENAN; break; }                   // training.jl:20: no update
@@ -739,7 +781,8 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
     if (tid == 0 && p == 0 && a.epoch_infos) { float* e = a.epoch_infos + (size_t)ep * CRUX_INFO_N;   // aggregate_info(minibatch_infos) == last minibatch (Q3)
       for (int k = 0; k < CRUX_INFO_N; ++k) e[k] = 0.f;
       e[CRUX_INFO_LOSS] = inf_loss; e[CRUX_INFO_GRAD_NORM] = inf_gn;
-      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = inf_ent; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = inf_clip; e[CRUX_INFO_AVG_ADVANTAGE] = inf_adv; e[CRUX_INFO_AVG_RETURN] = inf_ret; } }
+      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = inf_ent; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = inf_clip; e[CRUX_INFO_AVG_ADVANTAGE] = inf_adv; e[CRUX_INFO_AVG_RETURN] = inf_ret; }
+      if constexpr (LAG) { e[CRUX_INFO_PENALTY] = inf_pen; e[CRUX_INFO_CUR_COST] = inf_cur; e[CRUX_INFO_COST_LOSS] = inf_closs; e[CRUX_INFO_P_LOSS] = inf_ploss; } }
     epochs_run += 1;
     if (a.target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > a.target_kl) stop = true;   // :49
     if (a.max_batches > 0 && total_batches >= a.max_batches) stop = true;               // :50
@@ -760,6 +803,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 3 replica group timeout / abort
     a.bp[0] = bp1; a.bp[1] = bp2;
+    if constexpr (LAG) { if (p == 0) { a.lag->I = lgs[0]; a.lag->smooth_delta = lgs[1]; a.lag->smooth_Jc = lgs[2]; a.lag->Jc_prev = lgs[3]; a.lag->deriv_term = lgs[4]; a.lag->penalty = lgs[5]; a.lag->cur_cost = lgs[6]; } }
     if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = inf_loss; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
   }
 #undef FS_T

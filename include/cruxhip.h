@@ -389,7 +389,7 @@ int32_t crux_policy_gradient_training_synced(crux_mlp* actor, crux_mlp* critic, 
  *   loss = (lambda_p p_loss + lambda_e e_loss + penalty mean(max(r Ac, clamp(r, 1-eps, 1+eps) Ac))) / (1 + penalty),  Ac = D[:cost_advantage].
  * The one-element arrays the reference keeps in P (I, Jc_prev, smooth_Delta, smooth_Jc, ppo.jl:192-201) are the state fields below: read at the
  * start of the call, advanced on the device once per executed minibatch (a one-block kernel ahead of the loss head on the dense-engine learner; inside
- * the generic learner kernel for tiny networks), written back at the end. The buffer needs
+ * the generic learner kernel for tiny networks, inside the register-resident kernels for the 64-wide actors), written back at the end. The buffer needs
  * :logprob, :advantage, :cost, :cost_advantage. info adds CRUX_INFO_PENALTY / CUR_COST / COST_LOSS / P_LOSS of the last minibatch of each epoch.
  * A minibatch without an episode end makes Jc Inf or NaN exactly as in the reference (a NaN loss is CRUX_ENAN, training.jl:20).                  */
 typedef struct {

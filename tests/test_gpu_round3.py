@@ -299,3 +299,13 @@ def test_reference_half_cheetah_ppo_networks_run_on_the_feature_split_learner(gp
     assert res["ok"], res
     err = capfd.readouterr().err
     assert "outside the MFMA learner family" not in err and "generic" not in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cartpole", "synth17"])
+def test_lagrange_two_cu_form_still_matches_the_oracle(gpu_ctx, monkeypatch, kind):
+    """lagrange_ppo_loss with full minibatches runs on the feature-split kernel's LAG instantiation by default (tests/test_gpu_lagrange.py, bs = 128); with CRUX_FS=0 the same
+    call takes the two-CU kernel's (train_mfma_kernel.h) -- both against the oracle, same bounds."""
+    import test_gpu_lagrange as TL
+    monkeypatch.setenv("CRUX_FS", "0")
+    TL.test_lagrange_batch_train_matches_oracle(gpu_ctx, kind, 128)
