@@ -51,6 +51,11 @@ struct ExecRec {
   // chained epochs (crux_dqn_epochs / crux_sac_epochs): several value_training epochs recorded into ONE list, scheduled and run once -- no host round trip between
   // the epochs of an iteration. While `chain` is set the per-epoch entry points append their phase tags (offset by chain_base) instead of scheduling and running.
   bool chain = false, chain_ok = true; int chain_base = 0; std::vector<int> chain_tags;
+  // the two-kernel persistent form of the DQN-family epochs (dqn_persist.h): first op of every recorded epoch; what crux_exec_run launches instead of the phases
+  std::vector<size_t> epoch_marks;
+  struct Dqp { bool on = false; int in = 0, out = 0, bt = 0, n_epochs = 0; void* net = nullptr; void* tnet = nullptr; void* batch = nullptr; float gamma = 0.f; bool use_weight = false; float* d_err = nullptr;
+               std::vector<int32_t> tab; } dqp;
+  void* dqp_buf = nullptr;                                          // device: learner barrier words, flags, tables, exchange areas
 };
 bool crux_exec_recording(const crux_ctx* c);
 int32_t crux_exec_begin(crux_ctx* c);                 // start recording on this context (the launch sites below push ops instead of launching)

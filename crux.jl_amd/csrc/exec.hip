@@ -44,7 +44,9 @@ __device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigne
   __syncthreads();
   // acquire side: drop THIS CU's vector L1 (buffer_inv sc0, workgroup scope in the ISA's terms: the L2 behind it is shared by the whole XCD and needs nothing)
   // and its scalar cache. The agent-scope form (sc1) also walks the L2 and cost 17 us per barrier with 64 workgroups (tools/dbg_nops.py)
-  if (!(flags & 1)) { if (flags & 4) asm volatile("buffer_inv sc1" ::: "memory"); else asm volatile("buffer_inv sc0" ::: "memory"); }
+  // (round 3: the agent-scope form. `buffer_inv sc0` is a workgroup-scope invalidate and leaves the L1 as it is -- a re-read of a line this CU had cached before another
+  //  CU rewrote it returned the OLD data (found with dqn_persist.h's kernels, whose second epoch re-reads the batch rows); flag 1 = the caller reads with L1-bypassing loads)
+  if (!(flags & 1)) asm volatile("buffer_inv sc1" ::: "memory");
   if (!(flags & 2)) asm volatile("s_dcache_inv" ::: "memory");
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   return ok_s != 0;
@@ -103,6 +105,21 @@ template <class Op> __device__ __forceinline__ void exec_dispatch_g(const ExecOp
   const OpPack<Op> p = *(const OpPack<Op>*)op->args;
   exec_apply<Op>(bid, op->nblocks, p);
 }
+// the replay ops alone (dqn_persist.h: k_dqn_replay); the gather's column table is read where it lies
+#define EXEC_SWITCH_REPLAY(DISPATCH) \
+      switch (kid) { \
+        case OP_FILL: DISPATCH<FillOp>(op, b); break; \
+        case OP_PER_SEARCH: DISPATCH<PerSearchOp>(op, b); break; \
+        case OP_UNIFORM_IDS: DISPATCH<UniformIdsOp>(op, b); break; \
+        case OP_GATHER_RING_ALL: { using P_ = OpPack<GatherRingAllOp>; const P_* pp = (const P_*)op->args; \
+          GatherRingAllOp::run_ptr(b, op->nblocks, &pp->head, pp->tail.head, pp->tail.tail.head, pp->tail.tail.tail.head, pp->tail.tail.tail.tail.head); } break; \
+        case OP_RING_IDS: DISPATCH<RingIdsOp>(op, b); break; \
+        case OP_LEAF_REFRESH: DISPATCH<LeafRefreshOp>(op, b); break; \
+        case OP_TREE_TOUCH: DISPATCH<TreeTouchOp>(op, b); break; \
+        case OP_PER_UPDATE: DISPATCH<PerUpdateOp>(op, b); break; \
+        case OP_COPY_F32: DISPATCH<CopyF32Op>(op, b); break; \
+        default: break; \
+      }
 // One PHASE of a recorded sequence as one launch over the whole chip: block x of the grid belongs to the op whose block range contains x. The ops of a
 // phase do not depend on each other, the dependency between phases is the kernel boundary -- no in-kernel barrier, no coherence question, all 256 CUs.
 // A fused epoch then costs (number of phases) launches instead of (number of kernels): 13 instead of 25 for a DQN epoch, 30 instead of ~75 for SAC (10 / 27 per epoch inside a chain).
@@ -199,8 +216,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+#include "dqn_persist.h"
+
 // ---- host: recording -------------------------------------------------------------------------------------------------------------------
 static ExecRec* rec_of(crux_ctx* c) { return (ExecRec*)c->rec; }
+extern "C" int32_t crux_ensure_aux_stream(crux_ctx* c);      // train.hip: a second stream on its own hardware queue (probed)
+
+// The persistent two-kernel form of a recorded chain of DQN-family epochs (dqn_persist.h). The recording holds every op of every epoch; the learner's ops (tile GEMMs,
+// target, head, norm, info, Adam) are replaced by k_dqn_learn, the replay ops are handed to k_dqn_replay grouped into the stages the two kernels synchronise on.
+#define DQP_BUF_BYTES ((size_t)6 << 20)
+struct DqpBuf { static constexpr size_t oCtrL = 0, oFlags = 2048, oSsq = 2304, oTab = 4096, oPtr = 4096 + 32768, oG = 65536, oZ = oG + 32768, oP = oZ + 262144, oMV = oP + ((size_t)DQP_G * 128 * 256 * 4), oDbg = oMV + (1 << 20), oWT = oDbg + 16384; };      // oWT: 16 x 16 KB      // oMV: 16 x 2 x <= 4360 floats = 558 KB
+template <int IN, int OUT, int BT> static int32_t dqp_launch_learn(crux_ctx* c, const DqpArgs& a, hipStream_t st) {
+  constexpr size_t lds = sizeof(float) * (size_t)DqpL<IN, OUT, BT>::TOTAL;
+  static bool attr = false;
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_dqn_learn<IN, OUT, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_dqn_learn<IN, OUT, BT>), dim3(8 * DQP_G), dim3(256), lds, st, a);
+  return crux_launch_check(c, "k_dqn_learn");
+}
+static bool dqp_shape(int in, int out, int64_t B) { return ((in == 8 && out == 4) || (in == 4 && out == 2)) && (B == 128 || B == 64); }
+static int32_t dqp_build(ExecRec* r) {        // the replay table; CRUX_EUNSUP when the recording holds something the two kernels do not know
+  ExecRec::Dqp& d = r->dqp; const int n = d.n_epochs; if (n < 1 || (int)r->epoch_marks.size() != n || (int)r->readbacks.size() != n) return CRUX_EUNSUP;
+  d.tab.assign(4 * (size_t)n, 0);
+  for (int e = 0; e < n; ++e) {
+    const size_t i0 = r->epoch_marks[e], i1 = e + 1 < n ? r->epoch_marks[e + 1] : r->ops.size();
+    std::vector<std::pair<int, int>> A, Cs; bool head = false;      // (phase, op index)
+    for (size_t i = i0; i < i1; ++i) { const int kid = r->ops[i].kid;
+      switch (kid) {
+        case OP_PER_SEARCH: case OP_UNIFORM_IDS: A.push_back({0, (int)i}); break;
+        case OP_GATHER_RING_ALL: case OP_RING_IDS: case OP_COPY_F32: case OP_FILL: if (head) return CRUX_EUNSUP; A.push_back({1, (int)i}); break;
+        case OP_PER_UPDATE: if (head) Cs.push_back({0, (int)i}); else A.push_back({2, (int)i}); break;
+        case OP_LEAF_REFRESH: if (!head) return CRUX_EUNSUP; Cs.push_back({1, (int)i}); break;
+        case OP_TREE_TOUCH: if (!head) return CRUX_EUNSUP; Cs.push_back({2, (int)i}); break;
+        case OP_TD_HEAD: head = true; break;
+        case OP_GEMM: case OP_DQN_TARGET: case OP_SUMSQ2: case OP_TD_INFO: case OP_ADAM_GATED: case OP_ADAM_ADVANCE: break;      // the learner kernel's work
+        default: return CRUX_EUNSUP; } }
+    if (!head || A.empty()) return CRUX_EUNSUP;
+    auto emit = [&](std::vector<std::pair<int, int>>& v, int slot) {
+      std::stable_sort(v.begin(), v.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
+      const int32_t at = (int32_t)d.tab.size(); d.tab[4 * e + slot] = at; d.tab[4 * e + slot + 1] = (int32_t)v.size();
+      for (size_t k = 0; k < v.size(); ++k) { d.tab.push_back(v[k].second); d.tab.push_back((k + 1 == v.size() || v[k + 1].first != v[k].first) ? 1 : 0); } };
+    emit(A, 0); emit(Cs, 2);
+  }
+  return d.tab.size() * 4 <= 32768 ? CRUX_OK : CRUX_EUNSUP;
+}
+static int32_t dqp_launch(crux_ctx* c, ExecRec* r) {      // inside crux_exec_run: the op list is uploaded, d_ctr is zeroed
+  ExecRec::Dqp& d = r->dqp; crux_mlp* net = (crux_mlp*)d.net; crux_mlp* tn = (crux_mlp*)d.tnet; crux_buffer* b = (crux_buffer*)d.batch;
+  const int n = d.n_epochs; char* buf = (char*)r->dqp_buf;
+  std::vector<void*> ptrs(2 * (size_t)n);
+  for (int e = 0; e < n; ++e) { ptrs[e] = (void*)r->readbacks[e].d_info; ptrs[n + e] = (void*)r->readbacks[e].d_status; }
+  if (ptrs.size() * sizeof(void*) > 16384) return crux_fail(c, CRUX_EINVAL, "dqn epochs: chain of %d epochs", n);
+  HIPCHK(c, hipMemsetAsync(buf, 0, 4096, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf + DqpBuf::oTab, d.tab.data(), d.tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf + DqpBuf::oPtr, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, c->stream));
+  DqpArgs a{}; a.p = net->p; a.m = net->m; a.v = net->v; a.bp = net->bp; a.pt = tn->p;
+  for (int l = 0; l < 3; ++l) { a.woff[l] = net->nd.woff[l]; a.boff[l] = net->nd.boff[l]; }
+  a.eta = net->eta; a.b1 = net->b1; a.b2 = net->b2; a.eps = net->eps;
+  a.S = (const float*)b->col[CRUX_COL_S]; a.SP = (const float*)b->col[CRUX_COL_SP]; a.A = (const uint8_t*)b->col[CRUX_COL_A]; a.R = (const float*)b->col[CRUX_COL_R];
+  a.DONE = (const uint8_t*)b->col[CRUX_COL_DONE]; a.W = d.use_weight ? (const float*)b->col[CRUX_COL_WEIGHT] : nullptr;
+  a.gamma = d.gamma; a.n_epochs = n; a.err = d.d_err;
+  a.dinfo = (float* const*)(buf + DqpBuf::oPtr); a.dstatus = (int32_t* const*)(buf + DqpBuf::oPtr + n * sizeof(void*));
+  a.zbuf = (float*)(buf + DqpBuf::oZ); a.pbuf = (float*)(buf + DqpBuf::oP); a.gbuf = (float*)(buf + DqpBuf::oG); a.mv2 = (float*)(buf + DqpBuf::oMV); a.wtg = (float*)(buf + DqpBuf::oWT); a.ssq = (double*)(buf + DqpBuf::oSsq);
+  a.ctrL = (unsigned*)(buf + DqpBuf::oCtrL); a.flags = (unsigned*)(buf + DqpBuf::oFlags); a.status = (int32_t*)(r->d_ctr + 264); a.xcd = 0;
+  a.dbg = getenv("CRUX_DQP_DEBUG") ? (unsigned long long*)(buf + DqpBuf::oDbg) : nullptr; if (a.dbg) HIPCHK(c, hipMemsetAsync(a.dbg, 0, 8192, c->stream));
+  // the replay kernel first, on the second stream (its own hardware queue): it samples epoch 0 while the learner loads its parameters
+  HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
+  hipLaunchKernelGGL(k_dqn_replay, dim3(8 * DQP_R), dim3(256), 0, c->aux_stream, (const ExecOp*)r->d_ops, (const int32_t*)(buf + DqpBuf::oTab), n, r->d_ctr, a.flags, a.xcd, a.status, a.dbg);
+  HIPCHK(c, hipEventRecord(c->aux_ev1, c->aux_stream));
+  int32_t rc = CRUX_EUNSUP;
+  if (d.in == 8 && d.out == 4 && d.bt == 8) rc = dqp_launch_learn<8, 4, 8>(c, a, c->stream);
+  else if (d.in == 8 && d.out == 4 && d.bt == 4) rc = dqp_launch_learn<8, 4, 4>(c, a, c->stream);
+  else if (d.in == 4 && d.out == 2 && d.bt == 8) rc = dqp_launch_learn<4, 2, 8>(c, a, c->stream);
+  else if (d.in == 4 && d.out == 2 && d.bt == 4) rc = dqp_launch_learn<4, 2, 4>(c, a, c->stream);
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
+  if (getenv("CRUX_DQP_DEBUG")) { HIPCHK(c, hipStreamSynchronize(c->stream)); unsigned h[1024]; HIPCHK(c, hipMemcpy(h, buf, 4096, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[dqp] rc %d n %d flags %u %u %u  ctrL", rc, n, h[512], h[513], h[514]); for (int q = 0; q < 16; ++q) fprintf(stderr, " %u", h[q]); fprintf(stderr, " abort %u  ssq", h[256]);
+    const double* sq = (const double*)(h + 576); for (int q = 0; q < 16; ++q) fprintf(stderr, " %.3g", sq[q]); { unsigned hc[300]; (void)hipMemcpy(hc, r->d_ctr, 1200, hipMemcpyDeviceToHost); fprintf(stderr, "  ctrR"); for (int q = 0; q < 32; ++q) fprintf(stderr, " %u", hc[q]); fprintf(stderr, " abortR %u st %d whyL %d whyR %d claims %u %u", hc[256], (int)hc[264], (int)hc[265], (int)hc[266], h[516], h[517]); }
+    fprintf(stderr, "  xcc L"); for (int q = 0; q < 16; ++q) fprintf(stderr, " %u", h[512 + 16 + q]); fprintf(stderr, " R"); for (int q = 0; q < 32; ++q) fprintf(stderr, " %u", h[512 + 32 + q]); fprintf(stderr, "  tab"); for (size_t q = 0; q < d.tab.size() && q < 40; ++q) fprintf(stderr, " %d", d.tab[q]); fprintf(stderr, "\n");
+    static int dumps = 0; if (dumps++ == 2) { unsigned long long t[1024]; HIPCHK(c, hipMemcpy(t, buf + DqpBuf::oDbg, 8192, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[dqp] learner wg 0 (us since its start; ~2.04 GHz ticks; after the start stamp, per epoch: batch ready | forward | barrier b | z loaded | sync | head | stats | acked | sync | dW3 dZ2 P dW2 | barrier c | dH1 dW1 | barrier d | Adam):"); for (int q = 0; q < 512 && t[q]; ++q) fprintf(stderr, " %.1f", (double)(t[q] - t[0]) / 2040.0);
+      fprintf(stderr, "\n[dqp] replay wg 0 (us since the LEARNER's start):"); for (int q = 512; q < 1024 && t[q]; ++q) fprintf(stderr, " %.1f", ((double)t[q] - (double)t[0]) / 2040.0); fprintf(stderr, "\n"); } }
+  return rc;
+}
 bool crux_exec_recording(const crux_ctx* c) { return c && c->rec && ((const ExecRec*)c->rec)->active; }
 int32_t crux_exec_begin(crux_ctx* c) {
   if (!c->rec) c->rec = new ExecRec();
@@ -211,7 +307,7 @@ int32_t crux_exec_begin(crux_ctx* c) {
   if (!crux_scratch(c, (size_t)32 << 20)) return crux_fail(c, CRUX_ENOMEM, "executor: scratch");     // pre-sized: the scratch block must not move while pointers into it are recorded
   r->scratch_floor = c->scratch_bytes; r->scratch_off = 0;
   r->ops.clear(); r->readbacks.clear(); r->small_off = 0; r->active = true;
-  r->chain_tags.clear(); r->chain_base = 0; r->chain_ok = true;
+  r->chain_tags.clear(); r->chain_base = 0; r->chain_ok = true; r->epoch_marks.clear(); r->dqp.on = false;
   return CRUX_OK;
 }
 // frees everything a context's executor ever allocated (called by crux_ctx_destroy after the stream has drained)
@@ -222,6 +318,7 @@ void crux_exec_destroy(crux_ctx* c) {
   if (r->d_ctr) (void)hipFree(r->d_ctr);
   if (r->d_ops) (void)hipFree(r->d_ops);
   if (r->h_stage) (void)hipHostFree(r->h_stage);
+  if (r->dqp_buf) (void)hipFree(r->dqp_buf);
   delete r; c->rec = nullptr;
 }
 void crux_exec_abort(crux_ctx* c) { if (c->rec) { ExecRec* r = rec_of(c); r->active = false; r->ops.clear(); r->readbacks.clear(); } }
@@ -286,7 +383,8 @@ int32_t crux_exec_run(crux_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(r->d_ops, r->h_stage, ob, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(r->d_ctr, 0, 2048, c->stream));
     static const bool persistent = getenv("CRUX_EXEC_PERSISTENT") != nullptr;
-    if (!persistent) {
+    if (r->dqp.on) { r->dqp.on = false; rc = dqp_launch(c, r); if (rc) return rc; }
+    else if (!persistent) {
       // default: one launch per phase over the whole chip (see k_phase). Measured against the persistent one-XCD form (CRUX_EXEC_PERSISTENT=1): the latter
       // saves the launches but runs every op on 32 CUs behind one L2 and pays ~2 us per barrier; DESIGN 4.3 has the numbers.
       size_t i0 = 0;
@@ -406,6 +504,7 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   const int sq = (B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;
   rc = piece(1); if (rc) return bail(rc);
   const size_t ops0 = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;      // first op of THIS epoch (a chained recording already holds the earlier epochs)
+  if (fuse && crux_exec_recording(c) && rec_of(c)->chain) rec_of(c)->epoch_marks.push_back(ops0);
   size_t m = ops0;
   rc = per ? crux_per_sample(batch, source, B, nullptr, beta, sample_counter) : crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
   tag(m, [&](int kid, int&) { return (kid == OP_PER_SEARCH || kid == OP_UNIFORM_IDS) ? 0 : (kid == OP_GATHER_RING_ALL || kid == OP_RING_IDS || kid == OP_COPY_F32) ? 1 : kid == OP_PER_UPDATE ? 2 : -1; });
@@ -451,9 +550,29 @@ static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer*
   crux_ctx* c = net->ctx;
   const bool fuse = net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && !getenv("CRUX_NO_FUSED_EPOCH") &&
                     !getenv("CRUX_NO_CHAINED_EPOCHS");
+  // 256-wide networks of the shapes dqn_persist.h instantiates: the whole chain as two persistent kernels. OPT-IN (CRUX_DQN_PERSIST=1): correct (tests/test_gpu_round3.py)
+  // but measured SLOWER than the phase launches in round 3 -- 113-125 us against 73-79 us per C3 epoch (DESIGN 4.3 has the in-kernel timeline) -- so the default stays
+  // with the phases.
+  const int64_t Bc = batch->capacity;
+  const bool persist = fuse && softq_alpha == 0.f && net->nd.L == 3 && target_net->nd.L == 3 && net->nd.dims[1] == 256 && net->nd.dims[2] == 256 && target_net->nd.dims[1] == 256 && target_net->nd.dims[2] == 256 &&
+                       net->nd.dims[0] == target_net->nd.dims[0] && net->nd.dims[3] == target_net->nd.dims[3] && dqp_shape(net->nd.dims[0], net->nd.dims[3], Bc) &&
+                       net->nd.acts[0] == CRUX_ACT_RELU && net->nd.acts[1] == CRUX_ACT_RELU && net->nd.acts[2] == CRUX_ACT_IDENTITY &&
+                       target_net->nd.acts[0] == CRUX_ACT_RELU && target_net->nd.acts[1] == CRUX_ACT_RELU && target_net->nd.acts[2] == CRUX_ACT_IDENTITY &&
+                       net->has_adam && batch->obs_dim == net->nd.dims[0] && batch->act_kind == CRUX_ACTION_DISCRETE && batch->act_dim == net->nd.dims[3] && (!use_weight || has_col(batch, CRUX_COL_WEIGHT)) &&
+                       (getenv("CRUX_DQN_PERSIST") && getenv("CRUX_DQN_PERSIST")[0] == '1') && !c->dqp_broken && crux_x2_placement_ok_c(c);
   auto flush = [&]() -> int32_t {
     if (!crux_exec_recording(c)) return CRUX_OK;
     ExecRec* r = rec_of(c); r->chain = false;
+    if (persist) {
+      ExecRec::Dqp& d = r->dqp; d.in = net->nd.dims[0]; d.out = net->nd.dims[3]; d.bt = (int)(Bc / 16); d.n_epochs = (int)r->epoch_marks.size(); d.net = net; d.tnet = target_net; d.batch = batch;
+      d.gamma = gamma; d.use_weight = use_weight != 0; d.d_err = source->prioritized ? (float*)((char*)c->epoch_tmp + ((4 * (size_t)Bc + 255) / 256) * 256) : nullptr;
+      int32_t rp = dqp_build(r);
+      if (!rp) rp = crux_ensure_aux_stream(c);
+      if (!rp && !r->dqp_buf && hipMalloc(&r->dqp_buf, DQP_BUF_BYTES) != hipSuccess) { r->dqp_buf = nullptr; rp = CRUX_ENOMEM; }
+      if (!rp) { d.on = true; const int32_t rr = crux_exec_run(c);
+        if (rr == CRUX_EHIP) c->dqp_broken = true;      // a wait timed out (the two kernels did not run side by side): later chains take the phase launches
+        return rr; }
+    }
     if (r->chain_ok && r->chain_tags.size() == r->ops.size()) { const int32_t rs = exec_schedule(c, r->chain_tags); if (rs) { crux_exec_abort(c); return rs; } }
     return crux_exec_run(c);
   };

@@ -339,6 +339,8 @@ static int32_t ensure_aux_stream(crux_ctx* c) {
   return CRUX_OK;
 }
 
+int32_t crux_ensure_aux_stream(crux_ctx* c) { return ensure_aux_stream(c); }      // exec.hip: the replay kernel of dqn_persist.h runs beside the learner kernel
+
 // Replicas that share ONE device (crux_peer_attach_local with several contexts on a device): their persistent learner kernels wait for each other
 // inside the kernel, so every learner stream of every such context must sit on its own hardware queue -- two kernels on one queue run back to
 // back and the first would wait for the second forever (until its timeout). Streams are probed pairwise like the second learner stream above and

@@ -309,3 +309,39 @@ def test_lagrange_two_cu_form_still_matches_the_oracle(gpu_ctx, monkeypatch, kin
     import test_gpu_lagrange as TL
     monkeypatch.setenv("CRUX_FS", "0")
     TL.test_lagrange_batch_train_matches_oracle(gpu_ctx, kind, 128)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per", [True, False], ids=["prioritized", "uniform"])
+@pytest.mark.parametrize("B", [128, 64])
+def test_persistent_dqn_kernels_match_the_phase_launches(gpu_ctx, monkeypatch, per, B):
+    """CRUX_DQN_PERSIST=1 (dqn_persist.h: the value_training epochs of an 8-256-256-4 DQN as two persistent kernels behind one L2 -- learner and replay -- one launch each per
+    crux_dqn_epochs call) against the default phase launches from the same state, six epochs in one chain: replay indices and the sampled rows bit for bit, priorities, parameters
+    and infos to f32 rounding. The persistent learner sums in another order (per-tile sequential k, partials over workgroups) and evaluates Adam in f32, so the bound is a
+    tolerance: measured |dtheta| <= 3.9e-6 (the first Adam step from zero moments, where g / (|g| + eps) amplifies last-bit differences of tiny gradients), priorities 1.6e-6,
+    losses 1e-7 relative (tools/dqp_dev.py prints them)."""
+    no, na, N, n_ep = 8, 4, 20_000, 6
+
+    def run(persist):
+        monkeypatch.setenv("CRUX_DQN_PERSIST", "1" if persist else "0")
+        rng = np.random.default_rng(3)
+        S, A = crux.ContinuousSpace(no), crux.DiscreteSpace(na)
+        buf = crux.ExperienceBuffer(S, A, N, prioritized=per); D = crux.buffer_like(buf, capacity=B)
+        a = np.zeros((na, N), bool); a[rng.integers(0, na, N), np.arange(N)] = True
+        buf.push_({"s": rng.normal(0, 1, (no, N)).astype(np.float32), "a": a, "sp": rng.normal(0, 1, (no, N)).astype(np.float32), "r": rng.normal(0, 1, (1, N)).astype(np.float32),
+                   "done": rng.random((1, N)) < 0.02, "episode_end": np.zeros((1, N), bool)})
+        if per:
+            buf.update_priorities_(np.arange(1, N + 1), (np.abs(rng.normal(0, 1, N)) + 1e-3).astype(np.float32))
+        q = crux.DiscreteNetwork(parity.chain([no, 256, 256, na], ["relu", "relu", "identity"]), list(range(1, na + 1)), seed=5)
+        qm = crux.clone_policy(q); q.attach_optimizer(crux.Adam(np.float32(1e-3)))
+        infos = np.zeros((n_ep, L.INFO_N), np.float32)
+        q.ctx.check(q.ctx.lib.crux_dqn_epochs(q.h, qm.h, buf.h, D.h, 0.99, 1 if per else 0, 0.6, 40, n_ep, O.vpz(infos)))
+        pr = buf.priority_params()["priorities"] if per else np.zeros(1, np.float32)
+        return q.get_params(), pr, D.indices.copy(), D["s"], infos
+    a, b = run(True), run(False)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])                       # the same minibatch in the last epoch: the whole replay chain agreed
+    dth, dpr = float(np.abs(a[0] - b[0]).max()), float(np.abs(a[1] - b[1]).max())
+    print("persistent DQN kernels vs phase launches (%s, B = %d): |dtheta| %.3g, |dpriority| %.3g" % ("PER" if per else "uniform", B, dth, dpr))
+    assert dth < 2e-5 and dpr < 2e-5
+    for k in (L.INFO["loss"], L.INFO["grad_norm"], 2):
+        assert np.allclose(a[4][:, k], b[4][:, k], rtol=2e-6, atol=1e-7), (k, a[4][:, k], b[4][:, k])
