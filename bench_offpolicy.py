@@ -110,6 +110,25 @@ def c3(crux, ctx, cpu=True, steps=300):
     return out
 
 
+def c3_solve(crux, ctx, iters=600, ring=200_000):
+    """Whole solve(DQN + prioritized replay) iterations at the C3 shapes (steps! of dN = 4 environment steps with eps-greedy exploration, push! with max priority, four
+    value_training epochs, polyak): the iteration loop enqueues every chain without waiting for it (crux_dqn_epochs_async) -- wall time per iteration."""
+    mdp = crux.SynthMDP(8, 4, discrete=True, n_envs=1, seed=3)
+    q = crux.DiscreteNetwork(_chain(crux, [8, 256, 256, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=1)
+    out = {}
+    for asyn in (True, False):
+        sv = crux.DQN(q, crux.ContinuousSpace(8), N=4 * 50, dN=4, buffer_size=ring, buffer_init=ring, prioritized=True, weighted_loss=True, max_steps=200,
+                      c_opt={"batch_size": 128, "optimizer": crux.Adam(np.float32(1e-3))})
+        sv.async_training = asyn
+        crux.solve(sv, mdp); ctx.sync()                          # ring fill + warm-up
+        sv.N = 4 * iters
+        t0 = time.perf_counter(); crux.solve(sv, mdp); ctx.sync(); t = time.perf_counter() - t0
+        out["us_per_iteration" if asyn else "us_per_iteration_synchronous_loop"] = 1e6 * t / iters
+    out["env_steps_per_s"] = 4 / (out["us_per_iteration"] * 1e-6)
+    out["workload"] = "solve(DQN + PER), 8-256-256-4, B = 128, dN = 4, ring %d (full), synthetic 8-observation / 4-action environment: %d iterations" % (ring, iters)
+    return out
+
+
 def c4(crux, ctx, cpu=True, steps=200):
     from crux_jl_amd import _lib as L
     rng = np.random.default_rng(1); B, n = 256, 100_000
@@ -253,6 +272,10 @@ def run(crux, ctx, cpu=True):
             t0 = time.perf_counter(); out[name] = fn(crux, ctx, cpu); out[name]["bench_seconds"] = time.perf_counter() - t0
         except Exception as e:      # noqa: BLE001
             out[name] = {"error": repr(e)}
+    try:
+        t0 = time.perf_counter(); out["c3_dqn_per"]["solve"] = c3_solve(crux, ctx); out["c3_dqn_per"]["solve"]["bench_seconds"] = time.perf_counter() - t0
+    except Exception as e:      # noqa: BLE001
+        out.setdefault("c3_dqn_per", {})["solve"] = {"error": repr(e)}
     return out
 
 

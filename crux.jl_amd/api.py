@@ -1632,8 +1632,41 @@ class OffPolicySolver:
         if self.extra_buffers and (self.buffer_fractions is None or len(self.buffer_fractions) != 1 + len(self.extra_buffers)):
             raise ValueError("buffer_fractions needs one entry per source: the buffer and every extra buffer (off_policy.jl:62-63)")
         self.fused_epochs = True              # value_training's epoch loop through crux_dqn_epochs / crux_sac_epochs (recorded op lists run by the executor for wide networks)
-        self.sampler, self.batch, self.history = None, None, []
+        self.sampler, self.batch, self._history = None, None, []
         self._dy = self._derr = None
+        # solve() without the host in the loop (cruxhip.h: crux_dqn_epochs_async): the epochs' info rows stay on the device until somebody looks at `history`
+        self.async_training = True
+        self._dinfos, self._dinfos_rows, self._dinfos_used, self._pending = None, 0, 0, []      # device ring of info rows; (history index, first row, epochs, name) not yet fetched
+
+    @property
+    def history(self):
+        """One info dict per iteration (the `training_info` the reference logs at off_policy.jl:146). Iterations that ran through the asynchronous chain are fetched
+        from the device here, on first access: one synchronisation for all of them. A NaN loss raises the reference's "NaN detected!" (training.jl:20) at that point."""
+        self._resolve_history()
+        return self._history
+
+    @history.setter
+    def history(self, v):
+        self._resolve_history(); self._history = v
+
+    def _resolve_history(self):
+        if not self._pending:
+            return
+        ctx = self.buffer.ctx
+        rows = np.zeros((self._dinfos_used, L.INFO_N), np.float32)
+        ctx.sync(); ctx.d2h(self._dinfos, rows)
+        pend, self._pending, self._dinfos_used = self._pending, [], 0
+        bad = None
+        for hi, r0, n, name, extra in pend:
+            raws = rows[r0:r0 + n]
+            infos = [{name + "loss": float(r[0]), name + "grad_norm": float(r[1]), "Qavg": float(r[2])} for r in raws]
+            d = {k: float(np.mean([x[k] for x in infos])) for k in infos[0]}
+            d.update({k: v for k, v in extra.items() if k not in d})
+            self._history[hi] = d
+            if bad is None and np.isnan(raws[:, 1]).any():
+                bad = hi
+        if bad is not None:
+            raise L.CruxError(L.ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20) in td_loss, iteration %d of this solve (asynchronous chain: reported when the infos were fetched)" % bad)
 
     def custom_seams(self):
         """True when a function-valued field is not the built-in: value_training then runs call by call with the callables on the host."""
@@ -1808,6 +1841,21 @@ def value_training(solver, D, gamma):
         _set_stream_for(buf, solver.sample_seed)
         beta = float(np.float32(buf.beta(solver.i))) if buf.isprioritized() else 0.0                       # rand!(D, buffer, i=S.i): beta(S.i)
         raws = np.zeros((p.epochs, L.INFO_N), np.float32)
+        if solver.target_fn == "dqn" and getattr(solver, "_async_now", False):
+            # no host in the loop: the chain is enqueued and the info rows stay on the device (OffPolicySolver.history fetches them)
+            if solver._dinfos is None or solver._dinfos_used + p.epochs > solver._dinfos_rows:
+                solver._resolve_history()
+                if solver._dinfos is None:
+                    solver._dinfos_rows = max(4096, 8 * p.epochs); solver._dinfos = ctx.alloc(4 * L.INFO_N * solver._dinfos_rows)
+            rc = ctx.lib.crux_dqn_epochs_async(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs,
+                                               C.c_void_p(int(solver._dinfos if not hasattr(solver._dinfos, "value") else solver._dinfos.value) + 4 * L.INFO_N * solver._dinfos_used))
+            if rc == L.OK:
+                pend = (solver._dinfos_used, p.epochs, p.name); solver._dinfos_used += p.epochs
+                solver._update_target(final=True)                                                          # :108
+                return _PendingInfo(*pend)
+            if rc != L.EUNSUP:
+                ctx.check(rc)
+            solver._async_now = False                  # narrow networks: the synchronous entry point from here on
         if solver.target_fn == "softq":      # softq_target(alpha) in place of dqn_target (rl/softq.jl:4-13)
             ctx.check(ctx.lib.crux_softq_epochs(pi.h, pim.h, buf.h, D.h, float(gamma), float(solver.P["alpha"]), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, _vp(raws)))
         else:
@@ -1841,6 +1889,12 @@ def value_training(solver, D, gamma):
     solver._update_target(final=True)                                                                  # :108
     keys = {k for d in infos for k in d}
     return {k: float(np.mean([d[k] for d in infos if k in d])) for k in keys}                          # aggregate_info: mean over the dicts that have the key (logging.jl:60-66)
+
+
+class _PendingInfo:
+    """value_training's info of an iteration whose chain is still on its way (crux_dqn_epochs_async): rows [row0, row0 + n) of the solver's device info ring."""
+    def __init__(self, row0, n, name):
+        self.row0, self.n, self.name = row0, n, name
 
 
 def _solve_small_dqn(solver, D, s, gamma, i, stop):
@@ -1905,11 +1959,18 @@ def _solve_off_policy(solver, mdp):
         solver.i = i
         steps_(s, solver.buffer, Nsteps=solver.dN, explore=True, i=i, want_info=False)                # :138 (its info is not used by this loop)
         it_info = {}
+        # asynchronous chains when nothing on the host looks at an iteration's result before the next one starts: no logger, no callbacks, built-in seams
+        solver._async_now = (solver.async_training and solver.log is None and solver.post_sample_callback is None and solver.pre_train_callback is None
+                             and not solver.custom_seams() and solver.fused_epochs and getattr(solver, "_async_now", True))
         _post_sample(solver, solver.dN, it_info)                                                      # :138 cb = D -> S.post_sample_callback(D, S=S, info=info)
         if solver.pre_train_callback is not None:
             solver.pre_train_callback(solver, info=it_info)                                           # :140
-        solver.history.append(value_training(solver, D, gamma))                                       # :143
-        solver.history[-1].update({k: v for k, v in it_info.items() if k not in solver.history[-1]})  # :146 log(..., training_info, info)
+        tinfo = value_training(solver, D, gamma)                                                      # :143
+        if isinstance(tinfo, _PendingInfo):          # the chain was only enqueued: the host goes on to the next iteration, `history` fetches the rows when asked
+            solver._history.append(None); solver._pending.append((len(solver._history) - 1, tinfo.row0, tinfo.n, tinfo.name, dict(it_info)))
+        else:
+            solver._history.append(tinfo)
+            solver._history[-1].update({k: v for k, v in it_info.items() if k not in solver._history[-1]})  # :146 log(..., training_info, info)
         if solver.log is not None:                                                                     # :146 log(S.log, S.i, infos..., S=S)
             from . import logging as _lg
             if solver.log.sampler is None:
@@ -1917,6 +1978,7 @@ def _solve_off_policy(solver, mdp):
             _lg.log(solver.log, (i + 1, i + solver.dN), solver.history[-1], S=solver)
         i += solver.dN
     solver.i += solver.dN
+    solver._resolve_history()                  # one synchronisation at the end: the infos of the asynchronous iterations, and their NaN check
     return solver.agent.pi
 
 

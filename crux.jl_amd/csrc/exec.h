@@ -56,6 +56,10 @@ struct ExecRec {
   struct Dqp { bool on = false; int in = 0, out = 0, bt = 0, n_epochs = 0; void* net = nullptr; void* tnet = nullptr; void* batch = nullptr; float gamma = 0.f; bool use_weight = false; float* d_err = nullptr;
                std::vector<int32_t> tab; } dqp;
   void* dqp_buf = nullptr;                                          // device: learner barrier words, flags, tables, exchange areas
+  // asynchronous runs (crux_dqn_epochs_async): no read-back, no host synchronisation -- the info rows are copied to a caller-owned device array by ops of the list itself.
+  // The op list is uploaded from a ring of pinned staging buffers, so the host may record and enqueue up to three chains ahead of the one the device is running.
+  bool async = false;
+  void* h_ring[4] = {nullptr, nullptr, nullptr, nullptr}; size_t h_ring_cap[4] = {0, 0, 0, 0}; void* h_ring_ev[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned h_ring_next = 0;
 };
 bool crux_exec_recording(const crux_ctx* c);
 int32_t crux_exec_begin(crux_ctx* c);                 // start recording on this context (the launch sites below push ops instead of launching)

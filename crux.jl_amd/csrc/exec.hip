@@ -319,6 +319,7 @@ void crux_exec_destroy(crux_ctx* c) {
   if (r->d_ops) (void)hipFree(r->d_ops);
   if (r->h_stage) (void)hipHostFree(r->h_stage);
   if (r->dqp_buf) (void)hipFree(r->dqp_buf);
+  for (int k = 0; k < 4; ++k) { if (r->h_ring[k]) (void)hipHostFree(r->h_ring[k]); if (r->h_ring_ev[k]) (void)hipEventDestroy((hipEvent_t)r->h_ring_ev[k]); }
   delete r; c->rec = nullptr;
 }
 void crux_exec_abort(crux_ctx* c) { if (c->rec) { ExecRec* r = rec_of(c); r->active = false; r->ops.clear(); r->readbacks.clear(); } }
@@ -377,10 +378,25 @@ int32_t crux_exec_run(crux_ctx* c) {
   if (nops) {
     const size_t ob = nops * sizeof(ExecOp), rb = r->readbacks.size() * (sizeof(float) * CRUX_INFO_N + 16), need_h = ob + rb + 64;
     if (r->d_ops_cap < ob) { if (r->d_ops) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(r->d_ops); } r->d_ops_cap = ob * 2 + 4096; if (hipMalloc(&r->d_ops, r->d_ops_cap) != hipSuccess) { r->d_ops = nullptr; r->d_ops_cap = 0; return crux_fail(c, CRUX_ENOMEM, "executor: op list"); } }
+    const bool async = r->async; r->async = false;
+    void* stage = nullptr;
+    if (async) {      // a staging buffer of its own for this chain: the previous chains' uploads may not have executed yet
+      const unsigned k = r->h_ring_next++ & 3u;
+      if (!r->h_ring_ev[k]) { hipEvent_t ev; HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); r->h_ring_ev[k] = ev; }
+      else HIPCHK(c, hipEventSynchronize((hipEvent_t)r->h_ring_ev[k]));      // the upload that last used this buffer (four chains ago) has run
+      if (r->h_ring_cap[k] < ob) { if (r->h_ring[k]) (void)hipHostFree(r->h_ring[k]); r->h_ring_cap[k] = ob * 2 + 4096;
+        if (hipHostMalloc(&r->h_ring[k], r->h_ring_cap[k], hipHostMallocDefault) != hipSuccess) { r->h_ring[k] = nullptr; r->h_ring_cap[k] = 0; return crux_fail(c, CRUX_ENOMEM, "executor: staging ring"); } }
+      stage = r->h_ring[k];
+      r->ops.back().barrier &= 2;
+      memcpy(stage, r->ops.data(), ob);
+      HIPCHK(c, hipMemcpyAsync(r->d_ops, stage, ob, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipEventRecord((hipEvent_t)r->h_ring_ev[k], c->stream));
+    } else {
     if (r->h_stage_cap < need_h) { if (r->h_stage) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(r->h_stage); } r->h_stage_cap = need_h * 2 + 4096; if (hipHostMalloc(&r->h_stage, r->h_stage_cap, hipHostMallocDefault) != hipSuccess) { r->h_stage = nullptr; r->h_stage_cap = 0; return crux_fail(c, CRUX_ENOMEM, "executor: staging"); } }
     r->ops.back().barrier &= 2;
     memcpy(r->h_stage, r->ops.data(), ob);
     HIPCHK(c, hipMemcpyAsync(r->d_ops, r->h_stage, ob, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(r->d_ctr, 0, 2048, c->stream));
     static const bool persistent = getenv("CRUX_EXEC_PERSISTENT") != nullptr;
     if (r->dqp.on) { r->dqp.on = false; rc = dqp_launch(c, r); if (rc) return rc; }
@@ -412,6 +428,7 @@ int32_t crux_exec_run(crux_ctx* c) {
         fprintf(stderr, "[k_exec] %zu ops: work %.1f kcycles, barrier / wait %.1f kcycles (workgroup 0; shader cycles, ~0.5 ns each)\n", nn, tw, tbar); } }
     }
     rc = crux_launch_check(c, "k_exec"); if (rc) return rc;
+    if (async) { r->ops.clear(); r->readbacks.clear(); return CRUX_OK; }      // nothing is read back: the list itself copied the info rows where the caller wants them
     char* hb = (char*)r->h_stage + ob;
     for (size_t k = 0; k < r->readbacks.size(); ++k) { char* h = hb + k * (sizeof(float) * CRUX_INFO_N + 16);
       HIPCHK(c, hipMemcpyAsync(h, r->readbacks[k].d_info, sizeof(float) * CRUX_INFO_N, hipMemcpyDeviceToHost, c->stream));
@@ -545,7 +562,7 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
 // the iteration's (rand!(…, i = S.i)). infos: host [n x CRUX_INFO_N]. Falls back to n single-epoch calls wherever an epoch cannot be chained (narrow networks, a
 // priority tree that needs a full rebuild between epochs).
 static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float softq_alpha, int32_t use_weight, float beta,
-                               uint64_t sample_counter0, int32_t n_epochs, float* infos) {
+                               uint64_t sample_counter0, int32_t n_epochs, float* infos, float* d_infos_async = nullptr) {
   if (!net || !target_net || !source || !batch || n_epochs < 1) return CRUX_EINVAL;
   crux_ctx* c = net->ctx;
   const bool fuse = net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && !getenv("CRUX_NO_FUSED_EPOCH") &&
@@ -574,12 +591,14 @@ static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer*
         return rr; }
     }
     if (r->chain_ok && r->chain_tags.size() == r->ops.size()) { const int32_t rs = exec_schedule(c, r->chain_tags); if (rs) { crux_exec_abort(c); return rs; } }
+    r->async = d_infos_async != nullptr;
     return crux_exec_run(c);
   };
   int32_t rc = CRUX_OK; int in_chain = 0;
   for (int e = 0; e < n_epochs; ++e) {
     float* info_e = infos ? infos + (size_t)e * CRUX_INFO_N : nullptr;
-    if (!fuse) { rc = dqn_epoch_impl(net, target_net, source, batch, gamma, softq_alpha, use_weight, beta, sample_counter0 + (uint64_t)e, info_e); if (rc) return rc; continue; }
+    if (!fuse) { if (d_infos_async) return CRUX_EUNSUP;      // narrow networks run call by call with a read-back per epoch: the caller takes the synchronous entry point
+      rc = dqn_epoch_impl(net, target_net, source, batch, gamma, softq_alpha, use_weight, beta, sample_counter0 + (uint64_t)e, info_e); if (rc) return rc; continue; }
     // a priority tree that needs a plain rebuild (the ring is still filling, or a bulk change) cannot be refreshed inside a recording: run what is recorded first
     if (in_chain && ((source->prioritized && source->per_full_dirty) || in_chain >= 8)) { rc = flush(); in_chain = 0; if (rc) return rc; }
     if (!in_chain) { if (source->prioritized) { rc = crux_per_prepare(source); if (rc) return rc; }
@@ -587,6 +606,11 @@ static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer*
     rec_of(c)->chain = true;
     rc = dqn_epoch_impl(net, target_net, source, batch, gamma, softq_alpha, use_weight, beta, sample_counter0 + (uint64_t)e, info_e);
     if (rc) { if (c->rec) rec_of(c)->chain = false; crux_exec_abort(c); return rc; }
+    if (d_infos_async) {      // the epoch's info row goes to the caller's device array, copied in the epoch's last phase (one phase after the info op wrote it)
+      ExecRec* r = rec_of(c);
+      crux_exec_push<CopyF32Op, OP_COPY_F32>(c, 1u, d_infos_async + (size_t)e * CRUX_INFO_N, (const float*)r->readbacks.back().d_info, (int64_t)CRUX_INFO_N);
+      int tmax = 0; for (size_t k = r->epoch_marks.empty() ? 0 : r->epoch_marks.back(); k < r->chain_tags.size(); ++k) tmax = std::max(tmax, r->chain_tags[k] & ~3);      // the epoch's last phase (the beta-power advance)
+      r->chain_tags.push_back(tmax); }
     ++in_chain;
   }
   return fuse ? flush() : rc;
@@ -596,6 +620,16 @@ int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source
   return dqn_epochs_impl(net, target_net, source, batch, gamma, 0.f, use_weight, beta, sample_counter0, n_epochs, infos);
 }
 // the same loop with softq_target(alpha) (rl/softq.jl:4-13) in place of dqn_target: SoftQ's value_training
+// The same chain WITHOUT the host: nothing is read back and nothing is waited for; the info row of epoch e lands in d_infos[e] (device, [n_epochs x CRUX_INFO_N]) when
+// the device gets there. For the iteration loop of solve(::OffPolicySolver) (off_policy.jl:133-147): the host records and enqueues the next iteration's steps! and
+// value_training while the device runs this one. A NaN gradient norm shows as a NaN in the info row (the update is skipped on the device as always, training.jl:20);
+// CRUX_EUNSUP for networks that do not take the recorded form (the caller uses crux_dqn_epochs).
+int32_t crux_dqn_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
+                              uint64_t sample_counter0, int32_t n_epochs, float* d_infos) {
+  if (!d_infos) return CRUX_EINVAL;
+  if (!net || !target_net || net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || target_net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || getenv("CRUX_NO_FUSED_EPOCH") || getenv("CRUX_NO_CHAINED_EPOCHS")) return CRUX_EUNSUP;
+  return dqn_epochs_impl(net, target_net, source, batch, gamma, 0.f, use_weight, beta, sample_counter0, n_epochs, nullptr, d_infos);
+}
 int32_t crux_softq_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
                           uint64_t sample_counter0, int32_t n_epochs, float* infos) {
   if (!(alpha > 0.f)) return CRUX_EINVAL;

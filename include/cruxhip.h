@@ -444,6 +444,14 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
 int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
                         uint64_t sample_counter0, int32_t n_epochs, float* infos);
 /* The same epoch loop with softq_target(alpha) (rl/softq.jl:4-13) in place of dqn_target: value_training of the SoftQ solver (rl/softq.jl:31-58).             */
+/* crux_dqn_epochs without the host in the loop: nothing is read back, nothing is waited for. The info row of epoch e (LOSS, GRAD_NORM, [2] = Qavg) is copied
+ * to d_infos[e * CRUX_INFO_N] (DEVICE memory, n_epochs rows) by the recorded list itself; the caller fetches the rows when it wants them (crux_ctx_sync +
+ * crux_memcpy_d2h). Meant for the iteration loop of solve(::OffPolicySolver) (off_policy.jl:133-147): the host records and enqueues iteration k + 1 (steps!,
+ * value_training, target update) while the device runs iteration k -- up to three chains ahead. A NaN gradient norm skips the update on the device as always
+ * (training.jl:20) and shows as NaN in the row; the "NaN detected!" error is the caller's to raise when it reads the rows. CRUX_EUNSUP: the networks do not take
+ * the recorded form (narrower than the dense engine's minimum width) -- use crux_dqn_epochs.                                                               */
+int32_t crux_dqn_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
+                              uint64_t sample_counter0, int32_t n_epochs, float* d_infos);
 int32_t crux_softq_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
                           uint64_t sample_counter0, int32_t n_epochs, float* infos);
 /* One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl:4-52,94-104) as one recorded op list (30 phases, see crux_dqn_epoch): rand! -> sac_target ->

@@ -345,3 +345,23 @@ def test_persistent_dqn_kernels_match_the_phase_launches(gpu_ctx, monkeypatch, p
     assert dth < 2e-5 and dpr < 2e-5
     for k in (L.INFO["loss"], L.INFO["grad_norm"], 2):
         assert np.allclose(a[4][:, k], b[4][:, k], rtol=2e-6, atol=1e-7), (k, a[4][:, k], b[4][:, k])
+
+
+@pytest.mark.gpu
+def test_asynchronous_solve_loop_equals_the_synchronous_one(gpu_ctx):
+    """solve(::OffPolicySolver) for a wide DQN enqueues every iteration's chain without waiting for it (crux_dqn_epochs_async: no read-back, the info rows stay in a device
+    ring until `history` is read) -- VERDICT r2 #5, "the host out of the solve loop". Same ring, priorities, networks and per-iteration infos as the loop that synchronises
+    after every value_training call, bit for bit; the ring is still filling for the first iterations (chains cut at plain tree rebuilds) and full afterwards."""
+    def run(asyn):
+        S = crux.ContinuousSpace(8)
+        q = crux.DiscreteNetwork(parity.chain([8, 256, 256, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=3)
+        mdp = crux.SynthMDP(8, 4, discrete=True, n_envs=1, seed=5, discount=0.97)
+        sv = crux.DQN(q, S, N=1200, dN=4, buffer_size=1000, prioritized=True, weighted_loss=True, buffer_init=400, max_steps=40, c_opt={"batch_size": 128})
+        sv.async_training = asyn
+        crux.solve(sv, mdp)
+        assert (len(sv._pending) == 0) and all(h is not None for h in sv._history)
+        return q.get_params(), sv.agent.pi_minus.get_params(), sv.buffer["s"], sv.buffer.priority_params()["priorities"], np.array([[h["critic_loss"], h["critic_grad_norm"], h["Qavg"]] for h in sv.history])
+    a, b = run(True), run(False)
+    assert len(a[4]) == len(b[4]) >= 150
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
