@@ -136,7 +136,7 @@ static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_
   int32_t rc = crux_train_mfma_launch(c, a, &handled, stream);
   if (rc) return rc;
   const bool dense_ok = !handled && stream == c->stream && crux_train_dense_eligible(a, generic_lds_bytes(a.nd), getenv("CRUX_FORCE_GENERIC") != nullptr);
-  if (a.need_px && !handled && (!dense_ok || a.lag)) return crux_fail(c, CRUX_EUNSUP, "batch_train! with a replica group attached needs a learner with the gradient exchange (the register-resident kernels, or the dense-engine learner for other Chain(Dense...) shapes; not lagrange_ppo_loss): this learner would run un-synchronised");
+  if (a.need_px && !handled && !dense_ok) return crux_fail(c, CRUX_EUNSUP, "batch_train! with a replica group attached needs a learner with the gradient exchange (the register-resident kernels, or the dense-engine learner for other Chain(Dense...) shapes; not lagrange_ppo_loss): this learner would run un-synchronised");
   if (dense_ok) {
     // outside the register-resident family: the MFMA dense engine, one chain of tile GEMMs per minibatch (train_dense.hip)
     rc = crux_train_dense_run(c, a);
@@ -239,7 +239,7 @@ int32_t crux_batch_train_lagrange(crux_mlp* net, crux_buffer* buf, const crux_tr
   if (cfg->loss != CRUX_LOSS_LAGRANGE_PPO) return crux_fail(c, CRUX_EINVAL, "batch_train! (lagrange): cfg.loss must be CRUX_LOSS_LAGRANGE_PPO");
   if (buf->elements <= 0 || cfg->epochs < 1) return crux_fail(c, CRUX_EINVAL, "batch_train! (lagrange): empty buffer or epochs %d", cfg->epochs);
   if (!has_col(buf, CRUX_COL_COST) || !has_col(buf, CRUX_COL_COST_ADVANTAGE)) return crux_fail(c, CRUX_EINVAL, "lagrange_ppo_loss: buffer needs :cost and :cost_advantage columns (ppo.jl:211)");
-  if (c->peer_n > 1) return crux_fail(c, CRUX_EUNSUP, "lagrange_ppo_loss with a replica group attached: the penalty update is not part of the exchange yet");
+  // (a replica group attached: the launch falls through to the dense-engine learner, whose controller step exchanges the cost sums -- train_dense.hip: k_lagrange_pid)
   TrainArgs a; int32_t rc = fill_args(a, net, buf, cfg, CRUX_LOSS_PPO); if (rc) return rc;
   if (!c->lag_dev) { if (hipMalloc(&c->lag_dev, 256) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "lagrange state"); }
   HIPCHK(c, hipMemcpyAsync(c->lag_dev, lag, sizeof *lag, hipMemcpyHostToDevice, c->stream));

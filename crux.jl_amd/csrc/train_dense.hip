@@ -32,12 +32,40 @@ struct PgHeadArgs {
 };
 // the penalty update inside lagrange_ppo_loss (ppo.jl:80-116), once per evaluation of the loss: one block sums the minibatch's :cost and :episode_end and
 // thread 0 advances the controller -- the arithmetic of the generic learner's in-kernel version (train_generic.h) and of the oracle
-__global__ __launch_bounds__(256) void k_lagrange_pid(crux_lagrange* __restrict__ lgp, const float* __restrict__ COST, const uint8_t* __restrict__ EE, const int32_t* __restrict__ rows, int64_t nb) {
+// Under a replica group (px_tab != NULL, N > 1) the minibatch is the GLOBAL one (ppo.jl:84-88 sums over the whole D): the two Float64 sums of every rank travel bit for bit
+// (four 32-bit words) through one exchange of the peer slots -- the protocol of k_px_allreduce_flat below -- and every rank adds them in rank order, so all replicas advance
+// identical controllers.
+__global__ __launch_bounds__(256) void k_lagrange_pid(crux_lagrange* __restrict__ lgp, const float* __restrict__ COST, const uint8_t* __restrict__ EE, const int32_t* __restrict__ rows, int64_t nb,
+                                                      float* const* __restrict__ px_tab, int rank, int N, int32_t* __restrict__ status) {
   __shared__ double red[4];
   double sc_ = 0.0, ne_ = 0.0;
   for (int64_t i = threadIdx.x; i < nb; i += 256) { const int64_t row = rows[i]; sc_ += (double)COST[row]; ne_ += EE[row] ? 1.0 : 0.0; }
-  const double t_sc = block_sum256(sc_, red), t_ne = block_sum256(ne_, red);
+  double t_sc = block_sum256(sc_, red), t_ne = block_sum256(ne_, red);
   if (threadIdx.x != 0) return;
+  if (px_tab && N > 1) {
+    float* const mine = px_tab[rank];
+    const unsigned long long xg = *(const unsigned long long*)(mine + CRUX_PX_COUNT); const int par = (int)(xg & 1ull);
+    const unsigned long long w0 = __builtin_bit_cast(unsigned long long, t_sc), w1 = __builtin_bit_cast(unsigned long long, t_ne);
+    for (int r = 0; r < N; ++r) { if (r == rank) continue;
+      unsigned long long* dst = (unsigned long long*)(px_tab[r] + (size_t)(par * CRUX_PX_MAXR + rank) * CRUX_PX_SLOT);
+      __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    for (int r = 0; r < N; ++r) if (r != rank) __hip_atomic_store((unsigned long long*)(px_tab[r] + CRUX_PX_FLAGS) + 8 * rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    bool ok = true; const long long t0 = wall_clock64(); unsigned* abortw = (unsigned*)(mine + CRUX_PX_ABORT);
+    for (int r = 0; r < N && ok; ++r) { if (r == rank) continue;
+      const unsigned long long* fl = (const unsigned long long*)(mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
+      while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
+    if (!ok) { for (int r = 0; r < N; ++r) __hip_atomic_store((unsigned*)(px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); status[0] = CRUX_EHIP; return; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    double g_sc = 0.0, g_ne = 0.0;
+    for (int r = 0; r < N; ++r) { double a_ = t_sc, b_ = t_ne;
+      if (r != rank) { const unsigned long long* src = (const unsigned long long*)(mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT);
+        a_ = __builtin_bit_cast(double, __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); b_ = __builtin_bit_cast(double, __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
+      g_sc = r == 0 ? a_ : g_sc + a_; g_ne = r == 0 ? b_ : g_ne + b_; }
+    t_sc = g_sc; t_ne = g_ne;
+    *(unsigned long long*)(mine + CRUX_PX_COUNT) = xg + 1ull;
+  }
   crux_lagrange lg = *lgp;
   const float Jc = (float)t_sc / (float)t_ne;
   const float dl = Jc - lg.target_cost;
@@ -215,7 +243,7 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a) {
       const int64_t nb = (total_rows - s0) < a.bs ? (total_rows - s0) : a.bs;
       hipLaunchKernelGGL(k_gather_obs, dim3((unsigned)((nb * od + 255) / 256)), dim3(256), 0, c->stream, a.S, od, order + s0, nb, x);
       int32_t rc = crux_dense_forward(net, x, nb, c->stream); if (rc) return rc;
-      if (a.lag) hipLaunchKernelGGL(k_lagrange_pid, dim3(1), dim3(256), 0, c->stream, a.lag, a.COST, a.EE, order + s0, nb);
+      if (a.lag) hipLaunchKernelGGL(k_lagrange_pid, dim3(1), dim3(256), 0, c->stream, a.lag, a.COST, a.EE, order + s0, nb, (float* const*)((a.need_px && c->peer_n > 1) ? c->peer_tab : nullptr), c->peer_rank, c->peer_n, status);
       PgHeadArgs q{}; q.lag = a.lag; q.CADV = a.CADV; q.z = crux_dense_act(net, nd.L); q.nout = nout; q.rows = order + s0; q.nb = nb; q.A = a.A; q.ad = a.ad; q.LP = a.LP; q.ADV = a.ADV; q.RET = a.RET;
       q.loss = a.loss; q.head = a.head; q.lo = 1.f - a.eps_clip; q.hi = 1.f + a.eps_clip; q.lambda_p = a.lambda_p; q.lambda_e = a.lambda_e; q.squash = a.squash;
       q.ls = net->p + nd.xoff; q.dy = dy; q.gx = net->g + nd.xoff; q.stats = st;

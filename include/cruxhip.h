@@ -359,7 +359,8 @@ int32_t crux_allreduce_grads(crux_mlp* net);
  * fine-grained region over xGMI (hipIpc-mapped; one hop on the fully connected node) and summed locally in rank order. KL early stopping and
  * max_batches work (every rank sees the same global statistics). Learners with the exchange: the register-resident kernels (IN->64->{64,32}->OUT, batch
  * 65..128: inside the persistent launch) and the dense-engine learner of every other Chain(Dense...) shape (one exchange launch per minibatch between the pullback
- * and the gated Adam, the flat gradient in slot-sized chunks); anything else (the generic one-workgroup learner, lagrange_ppo_loss) returns CRUX_EUNSUP while a
+ * and the gated Adam, the flat gradient in slot-sized chunks; lagrange_ppo_loss always takes this learner under a group: the controller step first exchanges the
+ * minibatch's cost sums, so every replica advances the same controller on the global minibatch); the generic one-workgroup learner returns CRUX_EUNSUP while a
  * group is attached rather than training un-synchronised. Needs equal buffer lengths on all ranks and every rank making the same sequence of training calls.
  *   crux_peer_export  allocates this context's region and returns its 64-byte IPC handle; ship the handles of all ranks to all ranks;
  *   crux_peer_attach  maps the peers' regions (handles: [nranks][64], own entry ignored). All ranks must have attached before any trains.

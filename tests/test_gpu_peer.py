@@ -322,3 +322,59 @@ def test_dense_engine_learner_under_a_replica_group_equals_the_concatenated_batc
     print(which, "dense-engine learner, two replicas vs concatenated-batch oracle after %d steps: max |dtheta| = %.3g" % (epochs * (N // bs), d), "loss", infos[0]["n_loss"], float(oi[0]))
     assert d < 2e-6            # measured 4.5e-8 (actor) / 1.5e-8 (critic) after 8 steps
     assert abs(infos[0]["n_loss"] - float(oi[0])) < 2e-5 * max(1.0, abs(float(oi[0])))
+
+
+@pytest.mark.parametrize("dims", [[8, 128, 128, 4], [4, 64, 64, 2]], ids=["128wide", "cartpole64"])
+def test_lagrange_ppo_under_a_replica_group_equals_the_concatenated_batch_oracle(two_contexts, dims):
+    """LagrangePPO with a group attached (refused until round 3). lagrange_ppo_loss runs its PID penalty controller on the minibatch's average episode cost EVERY time it is
+    evaluated (ppo.jl:80-116); under a group the minibatch is the global one, so the two Float64 sums (cost, episode ends) of every rank are exchanged bit for bit through the
+    peer slots before the controller step (train_dense.hip: k_lagrange_pid), then the gradient and the statistics as for ppo_loss. Two replicas with minibatches of 128 must take
+    the steps of ONE oracle learner on minibatches of 256 -- parameters, controller state, infos -- and stay bit-identical to each other. The 64-wide actor, which runs on the
+    register-resident lagrange kernels without a group, takes the dense-engine learner with one."""
+    import test_gpu_lagrange as TL
+    ctxs = two_contexts; bs, epochs, N = 128, 2, 512; od, na = dims[0], dims[-1]
+    rng = np.random.default_rng(41); extras = ["return", "logprob", "advantage", "cost", "cost_advantage", "cost_return"]
+    def shard():
+        ai = rng.integers(0, na, N)
+        return {"s": rng.normal(0, 1, (od, N)).astype(np.float32), "a": np.eye(na, dtype=bool)[:, ai], "sp": rng.normal(0, 1, (od, N)).astype(np.float32), "r": np.ones((1, N), np.float32),
+                "done": np.zeros((1, N), bool), "episode_end": rng.random((1, N)) < 0.1, "return": rng.normal(0, 1, (1, N)).astype(np.float32),
+                "logprob": rng.normal(-np.log(na), 0.05, (1, N)).astype(np.float32), "advantage": rng.normal(0, 1, (1, N)).astype(np.float32),
+                "cost": (rng.random((1, N)) < 0.3).astype(np.float32), "cost_advantage": rng.normal(0, 1, (1, N)).astype(np.float32), "cost_return": rng.normal(1, 0.3, (1, N)).astype(np.float32)}
+    shards = [shard(), shard()]
+    perms = [np.stack([rng.permutation(N) for _ in range(epochs)]) for _ in range(2)]
+    nets, bufs, lags, infos = [], [], [], [None, None]
+    for r, ctx in enumerate(ctxs):
+        g = crux.DiscreteNetwork(parity.chain(dims, parity.ACTS), list(range(1, na + 1)), ctx=ctx, seed=79, stream=3)
+        b = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.DiscreteSpace(na), N, extras, ctx=ctx); b.push_(shards[r])
+        nets.append(g); bufs.append(b); lags.append(TL._lag())
+    def make(r):
+        def f():
+            P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1, "lagrange": lags[r]}
+            infos[r] = crux.batch_train_(nets[r], crux.TrainingParams(loss=crux.lagrange_ppo_loss, batch_size=bs, epochs=epochs, name="actor_"), P, bufs[r], perms=perms[r] + 1)
+        return f
+    olag = TL._copy_lag(lags[0])
+    _run_threads([make(0), make(1)])
+    p0, p1 = nets[0].get_params(), nets[1].get_params()
+    assert np.array_equal(p0, p1)
+    for f in ("I", "Jc_prev", "smooth_delta", "smooth_Jc", "penalty", "cur_cost", "deriv_term"):
+        assert getattr(lags[0], f) == getattr(lags[1], f), f
+    glob, pos = _interleave(shards, bs)
+    ob = O.OBuffer(od, na, L.ACTION_DISCRETE, 2 * N, extras); ob.push(glob)
+    o = O.OMlp(dims, parity.ACTS).init_glorot(79, 3).adam_init(float(np.float32(3e-4)))
+    gperm = np.empty((epochs, 2 * N), np.int64)
+    for e in range(epochs):
+        for r in range(2):
+            gperm[e, pos[r]] = pos[r][perms[r][e]]
+    cfg = parity.train_cfg("lagrange_ppo", "categorical", 2 * bs, epochs, -1.0, 0)
+    oi = np.zeros(L.INFO_N, np.float32); oe_ = np.zeros((epochs, L.INFO_N), np.float32)
+    O.chk(O.lib().orc_batch_train_lagrange(o.h, ob.h, C.byref(cfg), C.byref(olag), O.vpz(gperm), O.vpz(oi), O.vpz(oe_)))
+    d = float(np.abs(p0 - o.params).max())
+    print(dims, "lagrange_ppo_loss, two replicas vs concatenated-batch oracle after %d steps: max |dtheta| = %.3g; penalty %.6g / %.6g" % (epochs * (N // bs), d, lags[0].penalty, olag.penalty))
+    assert d < 2e-6
+    for f in ("I", "Jc_prev", "smooth_delta", "smooth_Jc", "penalty", "cur_cost", "deriv_term"):
+        a, b = getattr(lags[0], f), getattr(olag, f)
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (f, a, b)
+    assert lags[0].penalty > 0.0
+    for k in ("loss", "penalty", "cur_cost", "cost_loss", "p_loss"):
+        a, b = float(infos[0][k if k in infos[0] else "actor_" + k]), float(oi[L.INFO[k]])
+        assert abs(a - b) < 2e-5 * max(1.0, abs(b)), (k, a, b)
