@@ -21,8 +21,7 @@ def run(persist, n_ep, per=True, B=128, N=20_000, no=8, na=4):
     ctx = q.ctx; infos = np.zeros((n_ep, L.INFO_N), np.float32)
     ctx.check(ctx.lib.crux_dqn_epochs(q.h, qm.h, buf.h, D.h, 0.99, 1 if per else 0, 0.6, 40, n_ep, infos.ctypes.data_as(L.vp)))
     pr = buf.priority_params()["priorities"] if per else np.zeros(1)
-    ids = D.indices.copy(); exp = buf["s"][:, ids - 1] if ids.min() >= 1 else buf["s"][:, ids]
-    print("   self-check persist=%d: rows vs source rows at ids: %.3g (ids min %d)" % (persist, np.abs(D["s"] - exp).max(), ids.min()))
+    ids = D.indices.copy()
     return q.get_params(), pr, ids, D["s"], infos
 
 import sys as _s
