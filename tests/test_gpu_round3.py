@@ -393,3 +393,41 @@ def test_lagrange_loss_on_the_feature_split_kernel_at_rollout_size(gpu_ctx, kind
     for f in ("I", "smooth_delta", "smooth_Jc", "penalty", "cur_cost"):
         a, b = getattr(glag, f), getattr(olag, f)
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (f, a, b)
+
+
+@pytest.mark.gpu
+def test_learner_dispatch_over_random_shapes_matches_the_oracle(gpu_ctx):
+    """Which kernel trains a network is decided by its shape (feature-split / two-CU / one-CU register-resident kernels, the dense engine, the generic one-workgroup learner),
+    and every shape list is closed. Twenty random Chain(Dense, Dense, Dense) learners -- inputs 2..20, hidden widths in and out of the 64-wide family, 1..6 outputs, relu /
+    tanh / mixed activations, categorical / Gaussian / critic heads, minibatches of 32..200 -- each replay two teacher-forced windows of four minibatch steps from the oracle's
+    state (steps 2..5 and 9..12 of its trajectory): whatever kernel the dispatch picks must land on the oracle's parameters."""
+    rng = np.random.default_rng(2026)
+    hid = [(64, 64), (64, 32), (32, 32), (128, 128), (48, 48), (64, 16), (256, 64), (64, 64), (64, 64)]
+    worst = 0.0
+    for case in range(20):
+        od = int(rng.choice([2, 3, 4, 5, 8, 17, 20])); h1, h2 = hid[int(rng.integers(len(hid)))]; kind = ["categorical", "gaussian", "value"][int(rng.integers(3))]
+        ad = int(rng.choice([2, 4, 6])) if kind == "categorical" else int(rng.choice([1, 2, 6]))
+        out = 1 if kind == "value" else ad
+        a1, a2 = [("relu", "relu"), ("tanh", "tanh"), ("tanh", "identity"), ("relu", "tanh")][int(rng.integers(4))]
+        bs = int(rng.choice([32, 64, 100, 128, 200])); N = bs * 14
+        disc = kind == "categorical"
+        if disc:
+            ai = rng.integers(0, ad, N); act = np.eye(ad, dtype=bool)[:, ai]
+        else:
+            act = rng.normal(0, 0.7, (ad, N)).astype(np.float32)
+        data0 = {"s": rng.normal(0, 1, (od, N)).astype(np.float32), "a": act, "sp": rng.normal(0, 1, (od, N)).astype(np.float32), "r": np.ones((1, N), np.float32),
+                 "done": np.zeros((1, N), bool), "episode_end": np.zeros((1, N), bool), "return": rng.normal(0, 1, (1, N)).astype(np.float32),
+                 "logprob": rng.normal(-1.2, 0.05, (1, N)).astype(np.float32), "advantage": rng.normal(0, 1, (1, N)).astype(np.float32)}
+        dims, acts = [od, h1, h2, out], [a1, a2, "identity"]
+        if kind == "categorical":
+            g, o = parity.make_pair(dims, acts, 300 + case, 0, "discrete"); loss, head = "ppo", "categorical"
+        elif kind == "gaussian":
+            g, o = parity.make_pair(dims, acts, 300 + case, 0, "gaussian", n_extra=ad, extra_init=-0.5); loss, head = "ppo", "gaussian"
+        else:
+            g, o = parity.make_pair(dims, acts, 300 + case, 0); loss, head = "value_mse", "deterministic"
+        res, _ = parity.learner_window_parity(g, o, data0, od, ad, disc, loss, head, bs, 1, [2, 9], 4, seed=700 + case)
+        assert len(res) == 2, (case, dims, acts, kind, bs, res)
+        for start, W, d in res:
+            worst = max(worst, d)
+            assert d < 2e-6, (case, dims, acts, kind, bs, start, d)          # measured: worst 3e-8 over the twenty shapes
+    print("learner dispatch over 20 random shapes: worst window |dtheta| = %.3g" % worst)
