@@ -172,9 +172,11 @@ __global__ __launch_bounds__(1024) void k_px_allreduce_flat(float* __restrict__ 
       float* dst = px_tab[r] + (size_t)(par * CRUX_PX_MAXR + rank) * CRUX_PX_SLOT;
       for (int i = tid; i < len; i += 1024) dst[i] = g[off + i];
       if (k == 0 && tid < 8) dst[PXF_CHUNK + tid] = (float)st[tid]; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its slot stores, then ONE lane issues the system-scope release and drains it before the flags
     __syncthreads();
     if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       for (int r = 0; r < N; ++r) if (r != rank) __hip_atomic_store((unsigned long long*)(px_tab[r] + CRUX_PX_FLAGS) + 8 * rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       bool ok = true; const long long t0 = wall_clock64(); unsigned* abortw = (unsigned*)(mine + CRUX_PX_ABORT);
       for (int r = 0; r < N && ok; ++r) { if (r == rank) continue;
@@ -183,10 +185,10 @@ __global__ __launch_bounds__(1024) void k_px_allreduce_flat(float* __restrict__ 
           if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
       if (!ok) for (int r = 0; r < N; ++r) __hip_atomic_store((unsigned*)(px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       ok_s = ok ? 1 : 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // one lane: drops the L1 (the slot loads are system-scope atomic loads and pass it anyway)
     }
     __syncthreads();
     if (!ok_s) { if (tid == 0) status[0] = CRUX_EHIP; return; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     for (int i = tid; i < len; i += 1024) { float acc = 0.f;
       for (int r = 0; r < N; ++r) { const float v = r == rank ? g[off + i] : __hip_atomic_load(mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         acc = r == 0 ? v : acc + v; }

@@ -635,9 +635,14 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 #pragma unroll
               for (int k = 0; k < NSI; ++k) dst[W2N + tid + NT * k] = gs[k];
               if (tid >= NT - 8 && tid < STAT_HI) dst[W2N + NSI * NT + (tid - (NT - 8))] = stat_tot; } }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                         // system scope: this wave's slot stores are performed at the peers
+          // release, the hand-off recipe of the CDNA guides: every wave drains its own slot stores, the workgroup meets, ONE lane issues the system-scope release
+          // (buffer_wbl2 sc0 sc1 covers the whole L2, whoever wrote the lines) and drains it before the flags go out -- one L2 write-back per workgroup and step
+          // instead of one per wave
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
           if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             int pi_ = 0;
             for (int r = 0; r < a.px_n; ++r) { if (r == a.px_rank) continue;
               if ((pi_++ % NWG) != p) continue;
@@ -654,10 +659,10 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
               const unsigned long long dtk = (unsigned long long)(wall_clock64() - t0) | 1ull;
               if (p < 2) { unsigned* hb = (unsigned*)(px_mine + CRUX_PX_HIST) + 32 * p + (63 - __builtin_clzll(dtk) > 31 ? 31 : 63 - __builtin_clzll(dtk)); *hb = *hb + 1u; } }
             sm[Lt::oRED + 16] = ok ? 0.f : 3.f;                         // 3: a replica of the group did not answer within the timeout, or raised the abort word
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                       // system scope, one lane: drops this compute unit's L1 (the slot loads below bypass it anyway: sc0 sc1)
           }
           __syncthreads();
           if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; why_failed = (int)sm[Lt::oRED + 16]; break; }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                         // system scope: nothing read below is older than the flags
           f32x4 oW[WT]; float oS[NSI]; const float oT = stat_tot;
 #pragma unroll
           for (int mm = 0; mm < WT; ++mm) oW[mm] = gW2[mm];

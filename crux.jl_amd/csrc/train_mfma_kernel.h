@@ -569,13 +569,15 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
 #pragma unroll
               for (int k = 0; k < NSI; ++k) dst[4096 + tid + NT * k] = gs[k];
               if (tid >= NT - 8 && tid < stat_hi) dst[4096 + NSI * NT + (tid - (NT - 8))] = stat_tot; } }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                         // system scope: this wave's slot stores are performed at the peers
-          __syncthreads();
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // every wave drains its own slot stores; the workgroup meets; ONE lane issues the system-scope
+          __syncthreads();                                                      // release (the L2 write-back covers the lines of all waves) and drains it before the flags go out
           if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             int pi_ = 0;
             for (int r = 0; r < a.px_n; ++r) { if (r == a.px_rank) continue;
               if ((pi_++ & 1) != p) continue;
-              // relaxed: every wave fenced its own slot stores (system-scope release) BEFORE the barrier above, so they are performed at the peer already
+              // relaxed: the release above covers the slot stores of every wave (all drained before the barrier)
               __hip_atomic_store((unsigned long long*)(a.px_tab[r] + CRUX_PX_FLAGS) + 8 * a.px_rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
             bool ok = true; const long long t0 = wall_clock64();                // 100 MHz: a missing peer becomes CRUX_EHIP after ~30 s instead of a hung GPU
             unsigned* abortw = (unsigned*)(px_mine + CRUX_PX_ABORT);
@@ -590,10 +592,10 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
               unsigned* hb = (unsigned*)(px_mine + CRUX_PX_HIST) + 32 * p + (63 - __builtin_clzll(dtk) > 31 ? 31 : 63 - __builtin_clzll(dtk));
               *hb = *hb + 1u; }
             sm[Lt::oRED + 16] = ok ? 0.f : 3.f;                         // 3: a replica of the group did not answer within the timeout, or raised the abort word
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                       // system scope, one lane (the slot loads below are sc0 sc1 and pass the L1 anyway)
           }
           __syncthreads();
           if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; why_failed = (int)sm[Lt::oRED + 16]; break; }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                         // system scope: nothing read below is older than the flags
           // the N - 1 slots are read two ranks at a time (all loads of a pair in flight together) and added in rank order
           f32x4 oW[4]; float oS[NSI]; const float oT = stat_tot;
 #pragma unroll
