@@ -623,7 +623,9 @@ def main():
             out["c1_dqn_gridworld_env_steps_per_s"] = _g("c1_dqn_gridworld", "env_steps_per_s"); out["c1_dqn_gridworld_seconds_N100k"] = _g("c1_dqn_gridworld", "seconds")
             out["c3_dqn_per_us_per_epoch"] = _g("c3_dqn_per", "us_per_epoch"); out["c3_dqn_per_grad_steps_per_s"] = _g("c3_dqn_per", "grad_steps_per_s")
             out["c3_solve_us_per_iteration"] = (_g("c3_dqn_per", "solve") or {}).get("us_per_iteration")
+            out["c3_dqn_per_us_per_epoch_async_chains"] = _g("c3_dqn_per", "us_per_epoch_async_chains")
             out["c4_sac_us_per_epoch"] = _g("c4_sac", "us_per_epoch")
+            out["c4_sac_us_per_epoch_async_chains"] = _g("c4_sac", "us_per_epoch_async_chains")
             out["c5_shard_env_steps_per_s"] = _g("c5_shard", "env_steps_per_s")
             out["c5_shard_us_per_grad_step"] = (extra.get("c5_shard", {}).get("roofline", {}) or {}).get("us_per_grad_step") if isinstance(extra, dict) else None
         if not args.no_cpu_baseline and world == 1:

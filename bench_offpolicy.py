@@ -65,12 +65,19 @@ def c3(crux, ctx, cpu=True, steps=300):
         k[0] += EP
         ctx.check(ctx.lib.crux_dqn_epochs(q.h, qm.h, buf.h, D.h, 0.99, 1, 0.5, k[0], EP, raw.ctypes.data_as(L.vp)))
     t = _timed(ctx, iteration, max(1, steps // EP)) / EP
+    # the same chains through the entry point solve() uses (crux_dqn_epochs_async: no read-back, no synchronisation between the calls -- the host records chain k + 1
+    # while the device runs chain k): what an epoch costs when the host is out of the loop
+    d_rows = ctx.alloc(4 * L.INFO_N * EP)
+    def iteration_async():
+        k[0] += EP
+        ctx.check(ctx.lib.crux_dqn_epochs_async(q.h, qm.h, buf.h, D.h, 0.99, 1, 0.5, k[0], EP, d_rows))
+    t_async = _timed(ctx, iteration_async, max(1, steps // EP)) / EP
     ach = C3_FLOP / t / 1e12
     # bytes the replay sampling moves per epoch with the incremental tree (per.hip): <= 128 touched leaves re-summed (read + write, <= 127 x 4 B each),
     # their root paths, 128 x 20 probes of (leaf id, running sum, 24 path ids, <= 24 totals), the 128-row gather (78 B/row read + write)
     per_bytes = 128 * 127 * 8 + 128 * 14 * 12 + 128 * 20 * (4 + 4 + 96 + 56) + 2 * 128 * 78
     out = {"workload": "DQN + prioritized replay, 8-256-256-4, buffer 1 M, B = 128: value_training epochs (prioritized_sample! + dqn_target + td_error + update_priorities! + train!), 4 per solve iteration in one chained call",
-           "grad_steps_per_s": 1.0 / t, "per_samples_per_s": B / t, "us_per_epoch": 1e6 * t, "launches_per_epoch": 9,
+           "grad_steps_per_s": 1.0 / t, "per_samples_per_s": B / t, "us_per_epoch": 1e6 * t, "us_per_epoch_async_chains": 1e6 * t_async, "launches_per_epoch": 9,
            "roofline": {"kernel": "k_phase (crux_dqn_epochs: every epoch's ~25 recorded ops -- 10 tile GEMMs, heads, Adam, replay ops -- run as 13 phases, 9 launches per epoch in a chain: the next epoch's sampling and first layer run beside the optimizer tail; op records travel in the kernel arguments)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                         "algorithmic_MFLOP_per_epoch": C3_FLOP / 1e6, "note": "latency-bound: 9 dependent launches of ~5.2 us (the kernel-to-kernel dependency cost of the device: a one-block phase runs 2.5 us when nothing precedes it); independent ops share a launch. The persistent one-XCD form (CRUX_EXEC_PERSISTENT=1, 1.3 us L2 barriers) measured slower"},
            "replay_sampling": {"bytes_per_epoch_incremental": per_bytes, "bytes_per_epoch_full_rescan": 8 * N, "bound": "hbm", "note": "the reference's cumsum(priorities) per gradient step (4 MB read + 4 MB write at N = 1 M) is replaced by re-summing the touched leaves and their root paths; sample indices stay bit-exact"}}
@@ -148,9 +155,13 @@ def c4(crux, ctx, cpu=True, steps=200):
     def iteration():
         solver.i += EP; crux.value_training(solver, D, np.float32(0.99))
     t = _timed(ctx, iteration, max(1, steps // EP), warmup=1) / EP
+    def iteration_async():      # the entry point solve() uses: chains enqueued without read-back or synchronisation (the infos stay in the solver's device ring)
+        solver.i += EP; solver._async_now = True; crux.value_training(solver, D, np.float32(0.99))
+    t_async = _timed(ctx, iteration_async, max(1, steps // EP), warmup=1) / EP
+    solver._resolve_history()
     ach = C4_FLOP / t / 1e12
     out = {"workload": "SAC, GaussianPolicy 3-256-256-1 + twin Q 4-256-256-1, B = 256: value_training epochs (rand! + sac_target + temperature, twin-critic and actor steps + polyak), 50 per solve iteration chained 8 at a time",
-           "epochs_per_s": 1.0 / t, "grad_steps_per_s": 3.0 / t, "us_per_epoch": 1e6 * t, "launches_per_epoch": 26,
+           "epochs_per_s": 1.0 / t, "grad_steps_per_s": 3.0 / t, "us_per_epoch": 1e6 * t, "us_per_epoch_async_chains": 1e6 * t_async, "launches_per_epoch": 26,
            "roofline": {"kernel": "k_phase (crux_sac_epochs: per epoch ~70 recorded ops -- ~40 tile GEMMs, heads, 4 Adam updates, polyak -- run as 30 phases, 26 launches per epoch in a chain)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                         "algorithmic_GFLOP_per_epoch": C4_FLOP / 1e9, "note": "latency-bound: 26 dependent launches of ~5.2 us per epoch (Q1 || Q2, the target critics, the temperature step and the actor's own forward pass share phases with the critic chain)"}}
     if cpu:

@@ -1657,16 +1657,17 @@ class OffPolicySolver:
         ctx.sync(); ctx.d2h(self._dinfos, rows)
         pend, self._pending, self._dinfos_used = self._pending, [], 0
         bad = None
-        for hi, r0, n, name, extra in pend:
+        for hi, r0, n, decode, extra in pend:
             raws = rows[r0:r0 + n]
-            infos = [{name + "loss": float(r[0]), name + "grad_norm": float(r[1]), "Qavg": float(r[2])} for r in raws]
-            d = {k: float(np.mean([x[k] for x in infos])) for k in infos[0]}
+            infos, nan = decode(raws)
+            keys = {k for x in infos for k in x}
+            d = {k: float(np.mean([x[k] for x in infos if k in x])) for k in keys}                       # aggregate_info: mean over the dicts that have the key (logging.jl:60-66)
             d.update({k: v for k, v in extra.items() if k not in d})
             self._history[hi] = d
-            if bad is None and np.isnan(raws[:, 1]).any():
+            if bad is None and nan:
                 bad = hi
         if bad is not None:
-            raise L.CruxError(L.ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20) in td_loss, iteration %d of this solve (asynchronous chain: reported when the infos were fetched)" % bad)
+            raise L.CruxError(L.ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20) in iteration %d of this solve (asynchronous chain: reported when the infos were fetched)" % bad)
 
     def custom_seams(self):
         """True when a function-valued field is not the built-in: value_training then runs call by call with the callables on the host."""
@@ -1710,6 +1711,28 @@ def _value_training_sac(solver, D, gamma):
         # same pieces, order and draws as the epoch-by-epoch branch below
         _set_stream_for(buf, solver.sample_seed)
         n = c_opt.epochs; ctr0 = solver.i * n
+        if getattr(solver, "_async_now", False):
+            d_rows, row0 = _info_ring(solver, ctx, 3 * n)
+            rc = lib.crux_sac_epochs_async(A.h, Q.N1.h, Q.N2.h, pim.A.h, Qm.N1.h, Qm.N2.h, la.h, buf.h, D.h, float(gamma), float(solver.P["SAC_H_target"]), float(solver.tau),
+                                           1 if solver.weighted_loss else 0, 0, n, int(c_opt.update_every), int(a_opt.update_every), ctr0, solver.noise_seed, 3 * ctr0, d_rows)
+            if rc == L.OK:
+                ce, ae, tn, cn, an = int(c_opt.update_every), int(a_opt.update_every), t_opt.name, c_opt.name, a_opt.name
+                def decode(raws):
+                    out, nan = [], False
+                    for epoch in range(len(raws) // 3):
+                        rt_, rq_, ra_ = raws[3 * epoch], raws[3 * epoch + 1], raws[3 * epoch + 2]
+                        info = {tn + "loss": float(rt_[0]), tn + "grad_norm": float(rt_[1]), "SAC alpha": float(rt_[L.INFO["alpha"]])}; nan = nan or bool(np.isnan(rt_[1]))
+                        if epoch % ce == 0:
+                            info.update({cn + "loss": float(rq_[0]), cn + "grad_norm": float(rq_[1]), "Q1avg": float(rq_[L.INFO["q1avg"]]), "Q2avg": float(rq_[L.INFO["q2avg"]])}); nan = nan or bool(np.isnan(rq_[1]))
+                        if epoch % ae == 0:
+                            info.update({an + "loss": float(ra_[0]), an + "grad_norm": float(ra_[1]), "entropy": float(ra_[L.INFO["entropy"]])}); nan = nan or bool(np.isnan(ra_[1]))
+                        out.append(info)
+                    return out, nan
+                solver._dinfos_used += 3 * n
+                return _PendingInfo(row0, 3 * n, decode)
+            if rc != L.EUNSUP:
+                ctx.check(rc)
+            solver._async_now = False
         rt, rq, ra = (np.zeros((n, L.INFO_N), np.float32) for _ in range(3))
         ctx.check(lib.crux_sac_epochs(A.h, Q.N1.h, Q.N2.h, pim.A.h, Qm.N1.h, Qm.N2.h, la.h, buf.h, D.h, float(gamma), float(solver.P["SAC_H_target"]), float(solver.tau),
                                       1 if solver.weighted_loss else 0, 0, n, int(c_opt.update_every), int(a_opt.update_every), ctr0, solver.noise_seed, 3 * ctr0,
@@ -1843,16 +1866,15 @@ def value_training(solver, D, gamma):
         raws = np.zeros((p.epochs, L.INFO_N), np.float32)
         if solver.target_fn == "dqn" and getattr(solver, "_async_now", False):
             # no host in the loop: the chain is enqueued and the info rows stay on the device (OffPolicySolver.history fetches them)
-            if solver._dinfos is None or solver._dinfos_used + p.epochs > solver._dinfos_rows:
-                solver._resolve_history()
-                if solver._dinfos is None:
-                    solver._dinfos_rows = max(4096, 8 * p.epochs); solver._dinfos = ctx.alloc(4 * L.INFO_N * solver._dinfos_rows)
-            rc = ctx.lib.crux_dqn_epochs_async(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs,
-                                               C.c_void_p(int(solver._dinfos if not hasattr(solver._dinfos, "value") else solver._dinfos.value) + 4 * L.INFO_N * solver._dinfos_used))
+            d_rows, _row0 = _info_ring(solver, ctx, p.epochs)
+            rc = ctx.lib.crux_dqn_epochs_async(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, d_rows)
             if rc == L.OK:
-                pend = (solver._dinfos_used, p.epochs, p.name); solver._dinfos_used += p.epochs
+                name = p.name; row0 = _row0
+                def decode(raws):
+                    return [{name + "loss": float(r[0]), name + "grad_norm": float(r[1]), "Qavg": float(r[2])} for r in raws], bool(np.isnan(raws[:, 1]).any())
+                pend = _PendingInfo(row0, p.epochs, decode); solver._dinfos_used += p.epochs
                 solver._update_target(final=True)                                                          # :108
-                return _PendingInfo(*pend)
+                return pend
             if rc != L.EUNSUP:
                 ctx.check(rc)
             solver._async_now = False                  # narrow networks: the synchronous entry point from here on
@@ -1891,10 +1913,20 @@ def value_training(solver, D, gamma):
     return {k: float(np.mean([d[k] for d in infos if k in d])) for k in keys}                          # aggregate_info: mean over the dicts that have the key (logging.jl:60-66)
 
 
+def _info_ring(solver, ctx, nrows):
+    """nrows rows of the solver's device info ring (fetching what is pending when it is full); returns the device address of the first one and its row index"""
+    if solver._dinfos is None or solver._dinfos_used + nrows > solver._dinfos_rows:
+        solver._resolve_history()
+        if solver._dinfos is None or nrows > solver._dinfos_rows:
+            solver._dinfos_rows = max(4096, 8 * nrows); solver._dinfos = ctx.alloc(4 * L.INFO_N * solver._dinfos_rows)
+    base = solver._dinfos.value if hasattr(solver._dinfos, "value") else int(solver._dinfos)
+    return C.c_void_p(base + 4 * L.INFO_N * solver._dinfos_used), solver._dinfos_used
+
+
 class _PendingInfo:
     """value_training's info of an iteration whose chain is still on its way (crux_dqn_epochs_async): rows [row0, row0 + n) of the solver's device info ring."""
-    def __init__(self, row0, n, name):
-        self.row0, self.n, self.name = row0, n, name
+    def __init__(self, row0, n, decode):
+        self.row0, self.n, self.decode = row0, n, decode      # decode(rows) -> (list of per-epoch info dicts, any NaN norm)
 
 
 def _solve_small_dqn(solver, D, s, gamma, i, stop):
@@ -1967,7 +1999,7 @@ def _solve_off_policy(solver, mdp):
             solver.pre_train_callback(solver, info=it_info)                                           # :140
         tinfo = value_training(solver, D, gamma)                                                      # :143
         if isinstance(tinfo, _PendingInfo):          # the chain was only enqueued: the host goes on to the next iteration, `history` fetches the rows when asked
-            solver._history.append(None); solver._pending.append((len(solver._history) - 1, tinfo.row0, tinfo.n, tinfo.name, dict(it_info)))
+            solver._history.append(None); solver._pending.append((len(solver._history) - 1, tinfo.row0, tinfo.n, tinfo.decode, dict(it_info)))
         else:
             solver._history.append(tinfo)
             solver._history[-1].update({k: v for k, v in it_info.items() if k not in solver._history[-1]})  # :146 log(..., training_info, info)

@@ -182,6 +182,15 @@ template <int BYTES> static bool phasek_launch(const std::vector<ExecOp>& ops, s
   hipLaunchKernelGGL(k_phase_k<BYTES>, dim3(blocks), dim3(256), 0, st, pk);
   return true;
 }
+// would phasek_launch<3840> take ops [i0, i1]? (the same packing rules, nothing launched)
+static bool phasek_fits(const std::vector<ExecOp>& ops, size_t i0, size_t i1) {
+  int n = 0; size_t used = 0;
+  for (size_t i = i0; i <= i1; ++i) { const ExecOp& e = ops[i]; if (!e.nblocks) continue;
+    const size_t raw = (size_t)(e.abytes > 0 ? e.abytes : CRUX_EXEC_ARG_BYTES), ab = (raw + 15) & ~(size_t)15;
+    if (n >= PHASEK_MAXOPS || used + ab > (size_t)3840) return false;
+    used += ab; ++n; }
+  return n > 0;
+}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_exec(const ExecOp* __restrict__ ops, int nops, unsigned* ctr, int xcd, int32_t* status, int flags) {
   if (xcd >= 0 && (int)(blockIdx.x & 7) != xcd) return;
   const unsigned wg = xcd >= 0 ? blockIdx.x >> 3 : blockIdx.x, G = xcd >= 0 ? gridDim.x >> 3 : gridDim.x;
@@ -380,7 +389,17 @@ int32_t crux_exec_run(crux_ctx* c) {
     if (r->d_ops_cap < ob) { if (r->d_ops) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(r->d_ops); } r->d_ops_cap = ob * 2 + 4096; if (hipMalloc(&r->d_ops, r->d_ops_cap) != hipSuccess) { r->d_ops = nullptr; r->d_ops_cap = 0; return crux_fail(c, CRUX_ENOMEM, "executor: op list"); } }
     const bool async = r->async; r->async = false;
     void* stage = nullptr;
-    if (async) {      // a staging buffer of its own for this chain: the previous chains' uploads may not have executed yet
+    r->ops.back().barrier &= 2;
+    // an asynchronous chain whose phases all travel in kernel arguments needs neither the device copy of the list nor the zeroed counters (no persistent form, no status
+    // read-back): two stream operations less between chains (they sit IN the stream there, ~15 us per chain)
+    bool lean = false;
+    if (async && !r->dqp.on && !getenv("CRUX_EXEC_PERSISTENT") && !getenv("CRUX_EXEC_NO_KERNARG")) { lean = true;
+      size_t i0 = 0;
+      while (i0 < nops && lean) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += (r->ops[i1].barrier & 2) ? 0u : r->ops[i1].nblocks; if ((r->ops[i1].barrier & 1) || i1 + 1 == nops) break; ++i1; }
+        if (blocks && !phasek_fits(r->ops, i0, i1)) lean = false;
+        i0 = i1 + 1; } }
+    if (lean) { /* nothing to upload */ }
+    else if (async) {      // a staging buffer of its own for this chain: the previous chains' uploads may not have executed yet
       const unsigned k = r->h_ring_next++ & 3u;
       if (!r->h_ring_ev[k]) { hipEvent_t ev; HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); r->h_ring_ev[k] = ev; }
       else HIPCHK(c, hipEventSynchronize((hipEvent_t)r->h_ring_ev[k]));      // the upload that last used this buffer (four chains ago) has run
@@ -397,7 +416,7 @@ int32_t crux_exec_run(crux_ctx* c) {
     memcpy(r->h_stage, r->ops.data(), ob);
     HIPCHK(c, hipMemcpyAsync(r->d_ops, r->h_stage, ob, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(r->d_ctr, 0, 2048, c->stream));
+    if (!lean) HIPCHK(c, hipMemsetAsync(r->d_ctr, 0, 2048, c->stream));
     static const bool persistent = getenv("CRUX_EXEC_PERSISTENT") != nullptr;
     if (r->dqp.on) { r->dqp.on = false; rc = dqp_launch(c, r); if (rc) return rc; }
     else if (!persistent) {
@@ -729,17 +748,19 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
 // value_training's epoch loop with SAC's pieces (off_policy.jl:69-104; SAC's c_opt.epochs = dN = 50, rl/sac.jl) in chains of up to 8 epochs per recorded list.
 // Epoch e (global index epoch0 + e within the iteration) trains the critic when (epoch0 + e) % critic_every == 0 and the actor (then the target update) when
 // (epoch0 + e) % actor_every == 0 (:91,96); it draws with sample counter sample_counter0 + e and noise counters noise_counter0 + 3 e .. + 2. infos_*: host [n x CRUX_INFO_N].
-int32_t crux_sac_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_mlp* log_alpha,
+static int32_t sac_epochs_impl(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_mlp* log_alpha,
                         crux_buffer* source, crux_buffer* batch, float gamma, float H_target, float tau, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
                         int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0,
-                        float* infos_temp, float* infos_critic, float* infos_actor) {
+                        float* infos_temp, float* infos_critic, float* infos_actor, float* d_infos_async) {
   if (!actor || n_epochs < 1 || critic_every < 1 || actor_every < 1) return CRUX_EINVAL;
   crux_ctx* c = actor->ctx;
   const bool fuse = !getenv("CRUX_NO_FUSED_EPOCH") && !getenv("CRUX_NO_CHAINED_EPOCHS");
+  if (d_infos_async && !fuse) return CRUX_EUNSUP;
   auto flush = [&]() -> int32_t {
     if (!crux_exec_recording(c)) return CRUX_OK;
     ExecRec* r = rec_of(c); r->chain = false;
     if (r->chain_ok && r->chain_tags.size() == r->ops.size()) { const int32_t rs = exec_schedule(c, r->chain_tags); if (rs) { crux_exec_abort(c); return rs; } }
+    r->async = d_infos_async != nullptr;
     return crux_exec_run(c);
   };
   int32_t rc = CRUX_OK; int in_chain = 0;
@@ -751,12 +772,37 @@ int32_t crux_sac_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* a
       if (!in_chain) { rc = crux_exec_begin(c); if (rc) return rc; }
       rec_of(c)->chain = true;
     }
+    const size_t rb0 = fuse ? rec_of(c)->readbacks.size() : 0, tg0 = fuse ? rec_of(c)->chain_tags.size() : 0;
     rc = crux_sac_epoch(actor, q1, q2, actor_targ, q1_targ, q2_targ, log_alpha, source, batch, gamma, H_target, tau, use_weight, uc, ua,
                         sample_counter0 + (uint64_t)e, noise_seed, noise_counter0 + 3ull * (uint64_t)e, it, ic, ia);
     if (rc) { if (fuse && c->rec) { rec_of(c)->chain = false; crux_exec_abort(c); } return rc; }
+    if (d_infos_async) {      // the epoch's info rows (temperature, [critics], [actor] -- the order the steps ran in) go to rows 3 e .. 3 e + 2 of the caller's device array, copied in the epoch's last phase
+      ExecRec* r = rec_of(c);
+      if (r->readbacks.size() != rb0 + 1 + (uc ? 1 : 0) + (ua ? 1 : 0) || r->chain_tags.size() != r->ops.size()) { r->chain = false; crux_exec_abort(c); return crux_fail(c, CRUX_EHIP, "sac epochs (async): unexpected recording"); }
+      int tmax = 0; for (size_t k = tg0; k < r->chain_tags.size(); ++k) tmax = std::max(tmax, r->chain_tags[k] & ~3);
+      size_t q = rb0; const int slot_of[3] = {0, uc ? 1 : -1, ua ? 2 : -1};
+      for (int sl = 0; sl < 3; ++sl) { if (slot_of[sl] < 0) continue;
+        crux_exec_push<CopyF32Op, OP_COPY_F32>(c, 1u, d_infos_async + ((size_t)e * 3 + sl) * CRUX_INFO_N, (const float*)r->readbacks[q++].d_info, (int64_t)CRUX_INFO_N);
+        r->chain_tags.push_back(tmax); } }
     if (fuse) ++in_chain;
   }
   return fuse ? flush() : rc;
+}
+int32_t crux_sac_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_mlp* log_alpha,
+                        crux_buffer* source, crux_buffer* batch, float gamma, float H_target, float tau, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
+                        int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0,
+                        float* infos_temp, float* infos_critic, float* infos_actor) {
+  return sac_epochs_impl(actor, q1, q2, actor_targ, q1_targ, q2_targ, log_alpha, source, batch, gamma, H_target, tau, use_weight, epoch0, n_epochs, critic_every, actor_every,
+                         sample_counter0, noise_seed, noise_counter0, infos_temp, infos_critic, infos_actor, nullptr);
+}
+// crux_sac_epochs without the host in the loop (see crux_dqn_epochs_async): d_infos is DEVICE memory, [n_epochs][3][CRUX_INFO_N] = temperature | critics | actor rows of every
+// epoch (rows of steps an epoch skipped -- critic_every / actor_every -- are left as they were).
+int32_t crux_sac_epochs_async(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_mlp* log_alpha,
+                              crux_buffer* source, crux_buffer* batch, float gamma, float H_target, float tau, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
+                              int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0, float* d_infos) {
+  if (!d_infos) return CRUX_EINVAL;
+  return sac_epochs_impl(actor, q1, q2, actor_targ, q1_targ, q2_targ, log_alpha, source, batch, gamma, H_target, tau, use_weight, epoch0, n_epochs, critic_every, actor_every,
+                         sample_counter0, noise_seed, noise_counter0, nullptr, nullptr, nullptr, d_infos);
 }
 
 // One epoch of value_training with DDPG's / TD3's pieces (off_policy.jl:69-104; rl/ddpg.jl, rl/td3.jl): rand! -> ddpg_target | td3_target -> [train!(critic, td_loss |

@@ -471,6 +471,11 @@ int32_t crux_sac_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* a
                         crux_buffer* source, crux_buffer* batch, float gamma, float H_target, float tau, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
                         int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0,
                         float* infos_temp, float* infos_critic, float* infos_actor);
+/* The same chains without the host in the loop (see crux_dqn_epochs_async): nothing is read back or waited for; d_infos is DEVICE memory, [n_epochs][3][CRUX_INFO_N] =
+ * the temperature | critic | actor info rows of every epoch, copied there by the recorded lists themselves (rows of steps an epoch skips stay untouched).          */
+int32_t crux_sac_epochs_async(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_mlp* log_alpha,
+                              crux_buffer* source, crux_buffer* batch, float gamma, float H_target, float tau, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
+                              int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0, float* d_infos);
 
 /* The epoch loop of value_training with DDPG's / TD3's pieces (off_policy.jl:69-104 with rl/ddpg.jl:4-11, rl/td3.jl:4-12) in chains of up to 8 epochs per recorded list:
  * rand! -> ddpg_target | td3_target -> [train!(critic, td_loss | double_Q_loss)] -> [train!(actor, -mean(Q(s, mu(s)))) -> polyak_average!(pi_minus, pi, tau)].

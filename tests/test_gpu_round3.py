@@ -431,3 +431,23 @@ def test_learner_dispatch_over_random_shapes_matches_the_oracle(gpu_ctx):
             worst = max(worst, d)
             assert d < 2e-6, (case, dims, acts, kind, bs, start, d)          # measured: worst 3e-8 over the twenty shapes
     print("learner dispatch over 20 random shapes: worst window |dtheta| = %.3g" % worst)
+
+
+@pytest.mark.gpu
+def test_asynchronous_sac_solve_loop_equals_the_synchronous_one(gpu_ctx):
+    """The same for SAC (crux_sac_epochs_async: three info rows per epoch -- temperature, critics, actor -- copied to the device ring by the recorded lists): networks, target
+    critics, temperature and the per-iteration infos bit for bit against the loop that reads back after every chain."""
+    def run(asyn):
+        S = crux.ContinuousSpace(3); acts = ["relu", "relu", "identity"]
+        pi = crux.ActorCritic(crux.GaussianPolicy(parity.chain([3, 256, 256, 1], acts), np.zeros(1, np.float32), seed=2),
+                              crux.DoubleNetwork(crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], acts), seed=3), crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], acts), seed=4)))
+        sv = crux.SAC(pi, S, N=360, dN=12, buffer_size=1000, buffer_init=300, max_steps=50, c_opt={"batch_size": 256}, a_opt={"batch_size": 256}, SAC_alpha_opt={"batch_size": 256})
+        sv.async_training = asyn
+        crux.solve(sv, crux.PendulumMDP(n_envs=1, seed=8))
+        keys = sorted(sv.history[-1])
+        return [n.get_params() for n in (pi.A, pi.C.N1, pi.C.N2, sv.agent.pi_minus.C.N1, sv.P["SAC_log_alpha"])], np.array([[h[k] for k in keys] for h in sv.history]), keys
+    (pa, ha, ka), (pb, hb, kb) = run(True), run(False)
+    assert ka == kb and len(ha) == len(hb) >= 4 and "SAC alpha" in ka and "critic_loss" in ka and "actor_loss" in ka
+    for x, y in zip(pa, pb):
+        assert np.array_equal(x, y)
+    assert np.array_equal(ha, hb)
