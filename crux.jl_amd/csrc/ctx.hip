@@ -123,6 +123,7 @@ int32_t crux_ctx_destroy(crux_ctx* c) {
   if (c->peer_same_device) { c->peer_same_device = false; crux_same_device_group_leave(); }
   if (c->dense_tmp) (void)hipFree(c->dense_tmp);
   if (c->epoch_tmp) (void)hipFree(c->epoch_tmp);
+  if (c->epoch_rows) (void)hipFree(c->epoch_rows);
   crux_exec_destroy(c);
   for (int k = 0; k < c->aux_n_rejected; ++k) (void)hipStreamDestroy(c->aux_rejected[k]);
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->aux_ev0); (void)hipEventDestroy(c->aux_ev1); }
