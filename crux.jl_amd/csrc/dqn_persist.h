@@ -3,7 +3,7 @@
 // utils.jl:76-87; Flux Adam; prioritized_sample! / update_priorities! experience_buffer.jl:291-349). Included by exec.hip (the off-policy translation unit).
 //
 //   k_dqn_learn   16 workgroups = 16 compute units. Workgroup p OWNS the second hidden layer's features F_p = [16 p, 16 p + 16): the rows W2[F_p, :] with their Adam
-//                 state (gradients, m, v in registers in the MFMA D layout, theta in LDS), b2[F_p], the columns W3[:, F_p]; the first layer (IN <= 16 inputs) is
+//                 state (gradient tiles in registers in the MFMA D layout, theta in LDS, m and v in global memory, touched once per epoch), b2[F_p], the columns W3[:, F_p]; the first layer (IN <= 16 inputs) is
 //                 evaluated -- and updated -- redundantly by every workgroup, so the forward pass of BOTH networks (online on s, target on s') up to its slice of H2
 //                 needs no exchange at all: every wave owns one 16-sample tile from the input to H2. Three exchanges per epoch go through the shared L2 (plain
 //                 stores, s_waitcnt, flag barrier -- the protocol of the on-policy learner kernels):
@@ -11,7 +11,7 @@
 //                   (c) the partial input gradients of the second layer, P_p = W2[F_p, :]' dZ2[F_p, :] (B x 256), of which workgroup q sums the slice F_q;
 //                   (d) the first layer's gradient rows dW1[F_p, :], db1[F_p] and the partial sums of squares (the norm gates Adam, training.jl:20).
 //                 H1 is kept for 64 samples at a time (LDS) and recomputed for the weight gradient of the second layer (two MFMAs per tile).
-//   k_dqn_replay  32 workgroups running the RECORDED replay ops of the same epochs (exec.h records; the bodies are per.hip's and ops_small.h's): stratified
+//   k_dqn_replay  16 workgroups (DQP_R; they must leave 16 compute units of the XCD to the learner, see STATUS) running the RECORDED replay ops of the same epochs (exec.h records; the bodies are per.hip's and ops_small.h's): stratified
 //                 search, row gather, push! of the batch buffer, and -- once the learner has published the td errors of epoch e -- update_priorities!, leaf re-sum
 //                 and root paths, all of it beside the learner's backward pass and optimizer step of epoch e.
 // The two kernels meet through two counters: batch_ready (replay -> learner: the minibatch of epoch e is in the batch buffer) and td_ready (learner -> replay: the
