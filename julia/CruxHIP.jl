@@ -305,7 +305,9 @@ function dpg_epochs!(𝒮, 𝒟::HipBuffer, γ; smooth=nothing, noise_seed=0)
     [Dict("critic_loss" => ic[1, e], "critic_grad_norm" => ic[2, e], "actor_loss" => ia[1, e], "actor_grad_norm" => ia[2, e]) for e in 1:n]
 end
 # (crux_dqn_epochs / crux_softq_epochs / crux_sac_epochs record the whole `for epoch in 1:c_opt.epochs` loop into one list in the same way -- no host round trip between the epochs; same
-#  arguments as the per-epoch calls plus the epoch count and, for SAC, the update_every periods. The per-epoch form below is the readable one.)
+#  arguments as the per-epoch calls plus the epoch count and, for SAC, the update_every periods. The per-epoch form below is the readable one.
+#  crux_dqn_epochs_async / crux_sac_epochs_async enqueue the same chains without read-back or synchronisation -- the info rows land in a device vector the caller fetches when
+#  `log` fires: with them the iteration loop of `solve` (off_policy.jl:133-147) never waits for the device; crux.jl_amd/api.py `_solve_off_policy` is the tested twin.)
 function Crux.value_training(𝒮::Crux.OffPolicySolver, 𝒟::HipBuffer, γ)                                                             # off_policy.jl:66-111
     if !isnothing(𝒮.a_opt) && !haskey(𝒮.𝒫, :SAC_log_α)                                                                             # DDPG / TD3: actor + critic, no temperature
         return Crux.aggregate_info(dpg_epochs!(𝒮, 𝒟, γ; smooth=get(𝒮.𝒫, :π_smooth_params, nothing)))
