@@ -43,6 +43,7 @@ struct crux_ctx {
   // spinning learner kernel, which waits for this replica -- blocks that must be re-allocated while the group is attached are parked instead and freed at detach
   bool peer_same_device = false;
   void* lag_dev = nullptr;        // device copy of crux_lagrange for crux_batch_train_lagrange
+  void* dense_tmp2 = nullptr; size_t dense_tmp2_bytes = 0; void* dense_pinned2 = nullptr;   // the same for a chain on the second learner stream
   void* dense_tmp = nullptr; size_t dense_tmp_bytes = 0;   // minibatch staging of the dense-engine on-policy learner (train_dense.hip)
   void* epoch_tmp = nullptr; size_t epoch_tmp_bytes = 0;   // targets / td errors of the un-fused epoch path
   void* epoch_rows = nullptr; size_t epoch_rows_bytes = 0;      // device info rows of a multi-chain epochs call (exec.hip: one synchronisation per call)

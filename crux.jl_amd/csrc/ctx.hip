@@ -122,6 +122,8 @@ int32_t crux_ctx_destroy(crux_ctx* c) {
   if (c->lag_dev) (void)hipFree(c->lag_dev);
   if (c->peer_same_device) { c->peer_same_device = false; crux_same_device_group_leave(); }
   if (c->dense_tmp) (void)hipFree(c->dense_tmp);
+  if (c->dense_tmp2) (void)hipFree(c->dense_tmp2);
+  if (c->dense_pinned2) (void)hipHostFree(c->dense_pinned2);
   if (c->epoch_tmp) (void)hipFree(c->epoch_tmp);
   if (c->epoch_rows) (void)hipFree(c->epoch_rows);
   crux_exec_destroy(c);

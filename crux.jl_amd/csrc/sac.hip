@@ -266,8 +266,8 @@ struct GailRewardOp { static __device__ __forceinline__ void run(const unsigned 
 __global__ __launch_bounds__(256) void k_gail_reward(const float* __restrict__ z, int64_t n, float alpha_r, float rscale, float* __restrict__ r, double* __restrict__ partial) { GailRewardOp::run(blockIdx.x, gridDim.x, z, n, alpha_r, rscale, r, partial); }
 
 // partials: the squared norm arrives as k_sumsq2's per-block partials in d_ssq[1..] (finalised by the info op into d_ssq[0]); false: d_ssq[0] was written directly
-static int32_t adam_gated(crux_mlp* n, const double* d_ssq, int32_t* d_status, bool partials = true) {
-  crux_ctx* c = n->ctx;
+static int32_t adam_gated(crux_mlp* n, const double* d_ssq, int32_t* d_status, bool partials = true, hipStream_t strm = nullptr) {
+  crux_ctx* c = n->ctx; if (!strm) strm = c->stream;
   if (!n->has_adam) return crux_fail(c, CRUX_EINVAL, "train!: crux_adam_init was not called on this handle");
   const int64_t cnt = n->nd.n_params;
   if (crux_exec_recording(c)) {      // fused sequence: at most one round of blocks, beta powers advanced by a one-thread op of the next phase (no device-scope fence per block)
@@ -276,7 +276,7 @@ static int32_t adam_gated(crux_mlp* n, const double* d_ssq, int32_t* d_status, b
     crux_exec_push<AdamAdvanceOp, OP_ADAM_ADVANCE>(c, 1u, n->bp, n->b1, n->b2, d_ssq);
     return CRUX_OK;
   }
-  CRUX_RUN(c, AdamGatedOp, OP_ADAM_GATED, k_adam_gated, (unsigned)((cnt + 255) / 256), 256, c->stream, n->p, n->g, n->m, n->v, n->bp, n->eta, n->b1, n->b2, n->eps, cnt, d_ssq, d_status, 1, 0);
+  CRUX_RUN(c, AdamGatedOp, OP_ADAM_GATED, k_adam_gated, (unsigned)((cnt + 255) / 256), 256, strm, n->p, n->g, n->m, n->v, n->bp, n->eta, n->b1, n->b2, n->eps, cnt, d_ssq, d_status, 1, 0);
   return crux_launch_check(c, "k_adam_gated");
 }
 

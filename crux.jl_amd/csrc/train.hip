@@ -7,6 +7,7 @@
 // parameters / moments stay in global memory (L2 resident). It is the correctness baseline and the fallback for shapes
 // the MFMA kernel (train_mfma.hip) does not cover. Both implement the same TrainArgs contract.
 #include "train_args.h"
+#include <thread>
 #include "exec.h"
 #include "ops_small.h"
 
@@ -124,7 +125,7 @@ static int32_t build_orders(crux_ctx* c, crux_buffer* buf, int slot, const int32
 }
 
 bool crux_train_dense_eligible(const TrainArgs& a, size_t generic_lds, bool force_generic);     // train_dense.hip
-int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a);
+int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a, hipStream_t strm = nullptr, int which = 0);
 static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_t stream = nullptr) {
   bool handled = false;
   if (!stream) stream = c->stream;
@@ -416,6 +417,54 @@ static int32_t collect(crux_ctx* c, const TrainArgs& a, int n_epochs, float* inf
   return CRUX_OK;
 }
 
+// policy_gradient_training (on_policy.jl:56-78) for two learners of the dense engine: the actor's chain of launches on the main stream from the calling thread, the critic's on the
+// second learner stream from a second host thread (each chain is ~13 dependent launches per minibatch: launch-bound, the two queues interleave on the device). The shuffle orders of
+// all epochs of both learners are composed first, exactly as for the register-resident pair below; CRUX_EUNSUP = not this case (the caller runs them one after the other).
+static int32_t dense_pair(crux_mlp* actor, crux_mlp* critic, crux_buffer* buf, const crux_train_cfg* cfg_a, const crux_train_cfg* cfg_c,
+                          const int64_t* perms_a, const int64_t* perms_c, float* info_a, float* info_c, float* epoch_infos_a, float* epoch_infos_c) {
+  crux_ctx* c = actor->ctx;
+  if (buf->elements <= 0 || cfg_a->epochs < 1 || cfg_c->epochs < 1 || cfg_c->target_kl >= 0.f || cfg_c->max_batches > 0) return CRUX_EUNSUP;
+  const int64_t len = buf->elements; if (len >= ((int64_t)1 << 31)) return CRUX_EUNSUP;
+  TrainArgs a, k; int32_t rc = fill_args(a, actor, buf, cfg_a, cfg_a->loss); if (rc) return rc;
+  rc = fill_args(k, critic, buf, cfg_c, cfg_c->loss); if (rc) return rc;
+  a.ord_all = (const int32_t*)1; k.ord_all = (const int32_t*)1;      // (placeholders for the eligibility test: the orders are built below)
+  if (!crux_train_dense_eligible(a, generic_lds_bytes(a.nd), false) || !crux_train_dense_eligible(k, generic_lds_bytes(k.nd), false)) return CRUX_EUNSUP;
+  a.ord_all = nullptr; k.ord_all = nullptr;
+  { const int32_t rca = ensure_aux_stream(c); if (rca) return rca; }
+  const size_t ea = sizeof(float) * CRUX_INFO_N * (size_t)cfg_a->epochs, ec = sizeof(float) * CRUX_INFO_N * (size_t)cfg_c->epochs;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t pa = perms_a ? al(8 * (size_t)cfg_a->epochs * (size_t)len) : 0, pc = perms_c ? al(8 * (size_t)cfg_c->epochs * (size_t)len) : 0;
+  char* sc = (char*)crux_scratch(c, 512 + al(ea) + al(ec) + pa + pc + 256);
+  if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_gradient_training: scratch");
+  a.status = (int32_t*)sc; k.status = (int32_t*)(sc + 256); a.epoch_infos = (float*)(sc + 512); k.epoch_infos = (float*)(sc + 512 + al(ea));
+  HIPCHK(c, hipMemsetAsync(sc, 0, 512 + al(ea) + al(ec), c->stream));
+  int64_t* d_pa = nullptr; int64_t* d_pc = nullptr;
+  if (perms_a) { d_pa = (int64_t*)(sc + 512 + al(ea) + al(ec)); for (int64_t i = 0; i < (int64_t)cfg_a->epochs * len; ++i) if (perms_a[i] < 0 || perms_a[i] >= len) return crux_fail(c, CRUX_EINVAL, "perms_a[%lld] out of range", (long long)i);
+    HIPCHK(c, hipMemcpyAsync(d_pa, perms_a, 8 * (size_t)cfg_a->epochs * (size_t)len, hipMemcpyHostToDevice, c->stream)); }
+  if (perms_c) { d_pc = (int64_t*)(sc + 512 + al(ea) + al(ec) + pa); for (int64_t i = 0; i < (int64_t)cfg_c->epochs * len; ++i) if (perms_c[i] < 0 || perms_c[i] >= len) return crux_fail(c, CRUX_EINVAL, "perms_c[%lld] out of range", (long long)i);
+    HIPCHK(c, hipMemcpyAsync(d_pc, perms_c, 8 * (size_t)cfg_c->epochs * (size_t)len, hipMemcpyHostToDevice, c->stream)); }
+  int32_t* oa = nullptr; int32_t* oc = nullptr;
+  rc = build_orders(c, buf, 0, nullptr, cfg_a->shuffle_seed, cfg_a->shuffle_counter, d_pa, cfg_a->epochs, c->stream, &oa); if (rc) return rc;
+  rc = build_orders(c, buf, 1, oa + (size_t)(cfg_a->epochs - 1) * (size_t)len, cfg_c->shuffle_seed, cfg_c->shuffle_counter, d_pc, cfg_c->epochs, c->stream, &oc); if (rc) return rc;
+  a.ord_all = oa; k.ord_all = oc; a.need_px = 0; k.need_px = 0;
+  HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
+  int32_t rck = CRUX_OK; const int dev = c->device;
+  std::thread th([&]() { (void)hipSetDevice(dev); rck = crux_train_dense_run(c, k, c->aux_stream, 1); });
+  crux_prof_begin(c, CRUX_PROF_TRAIN_ACTOR);
+  const int32_t rca = crux_train_dense_run(c, a, c->stream, 0);
+  crux_prof_end(c, CRUX_PROF_TRAIN_ACTOR);
+  th.join();
+  if (rca) return rca; if (rck) return rck;
+  int32_t sta[4], stc[4];
+  rc = collect(c, a, cfg_a->epochs, info_a, epoch_infos_a, sta); if (rc) return rc;
+  rc = collect(c, k, cfg_c->epochs, info_c, epoch_infos_c, stc); if (rc) return rc;
+  if (sta[0] == CRUX_ENAN || stc[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
+  if (sta[0] || stc[0]) return crux_fail(c, sta[0] ? sta[0] : stc[0], "learner reported status %d/%d", sta[0], stc[0]);
+  if (stc[2] < 1) return CRUX_OK;
+  return crux_buffer_apply_order(buf, k.ord_all + (size_t)(stc[2] - 1) * (size_t)len, len);
+}
+
 extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* critic, crux_buffer* buf, const crux_train_cfg* cfg_a, const crux_train_cfg* cfg_c,
                                                  const int64_t* perms_a, const int64_t* perms_c, float* info_a, float* info_c, float* epoch_infos_a, float* epoch_infos_c) {
   if (!actor || !critic || !buf || !cfg_a || !cfg_c) return CRUX_EINVAL;
@@ -423,7 +472,13 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   bool exact = cfg_a->target_kl < 0.f && cfg_a->max_batches <= 0;
   { const bool fs_on = !(getenv("CRUX_FS") && atoi(getenv("CRUX_FS")) == 0) && cfg_a->batch_size > 64 && cfg_a->batch_size <= 128;      // the feature-split kernel also takes a 32-wide second layer
     auto mfma_family = [fs_on](const crux_mlp* n) { const NetDesc& d = n->nd; return d.L == 3 && d.dims[1] == 64 && (d.dims[2] == 64 || (d.dims[2] == 32 && fs_on)); };
-    if (!mfma_family(actor) || !mfma_family(critic)) exact = false; }     // dense-engine / generic learners run one after the other on the main stream
+    if (!mfma_family(actor) || !mfma_family(critic)) {
+      // outside the register-resident family: two dense-engine chains (train_dense.hip), one per learner stream, driven by two host threads -- same condition as above
+      // (no early stopping, no minibatch cap: the critic's shuffle chain can be composed ahead of the actor's run), no replica group, CRUX_DENSE_PAIR=0 switches it off
+      if (exact && c->peer_n <= 1 && !(getenv("CRUX_DENSE_PAIR") && getenv("CRUX_DENSE_PAIR")[0] == '0') && !getenv("CRUX_FORCE_GENERIC")) {
+        const int32_t rcd = dense_pair(actor, critic, buf, cfg_a, cfg_c, perms_a, perms_c, info_a, info_c, epoch_infos_a, epoch_infos_c);
+        if (rcd != CRUX_EUNSUP) return rcd; }
+      exact = false; } }     // otherwise dense-engine / generic learners run one after the other on the main stream
   if (!exact) {
     int32_t rc = crux_batch_train(actor, buf, cfg_a, perms_a, info_a, epoch_infos_a); if (rc) return rc;
     return crux_batch_train(critic, buf, cfg_c, perms_c, info_c, epoch_infos_c);

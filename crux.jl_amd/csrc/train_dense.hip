@@ -214,27 +214,32 @@ bool crux_train_dense_eligible(const TrainArgs& a, size_t generic_lds, bool forc
   return !force_generic && a.nd.n_params >= 512 && a.bs >= 32 && !a.ids;            // single steps and tiny networks (the README's 2-8-4) stay on the one-launch generic learner
 }
 
-int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a) {
+// `strm` / `which`: the stream the chain runs on and the resource set it uses (0: the context's main stream; 1: the second learner stream -- policy_gradient_training runs the
+// critic's chain there, from a second host thread, beside the actor's: both chains are launch-bound, two queues interleave them on the device).
+int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a, hipStream_t strm, int which) {
+  if (!strm) strm = c->stream;
+  void*& dtmp = which ? c->dense_tmp2 : c->dense_tmp; size_t& dtmp_bytes = which ? c->dense_tmp2_bytes : c->dense_tmp_bytes;
   crux_mlp* net = (crux_mlp*)a.host_net; const NetDesc& nd = net->nd; const int nout = nd.dims[nd.L], od = nd.dims[0];
   const int64_t total_rows = a.ids ? a.n_ids : a.len; const int n_epochs = a.ids ? 1 : a.epochs;
   const int64_t bmax = total_rows < a.bs ? total_rows : a.bs;
   // a block of the context that nothing else carves (the caller's status / info rows live in the scratch block)
   { const size_t need = 4 * (size_t)bmax * (size_t)(od + nout) + 256 * 8 + 4096;
-    if (c->dense_tmp_bytes < need) { if (c->dense_tmp) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->dense_tmp); c->dense_tmp = nullptr; c->dense_tmp_bytes = 0; }
-      if (hipMalloc(&c->dense_tmp, 2 * need) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "batch_train! (dense): %zu bytes of staging", 2 * need);
-      c->dense_tmp_bytes = 2 * need; } }
-  Carve cv{(char*)c->dense_tmp, 0};
+    if (dtmp_bytes < need) { if (dtmp) { HIPCHK(c, hipStreamSynchronize(strm)); (void)hipFree(dtmp); dtmp = nullptr; dtmp_bytes = 0; }
+      if (hipMalloc(&dtmp, 2 * need) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "batch_train! (dense): %zu bytes of staging", 2 * need);
+      dtmp_bytes = 2 * need; } }
+  Carve cv{(char*)dtmp, 0};
   float* x = cv.take<float>((size_t)bmax * od); float* dy = cv.take<float>((size_t)bmax * nout);
   float* dinfo = cv.take<float>(CRUX_INFO_N); double* st = cv.take<double>(8); double* ssq = cv.take<double>(2 + SUMSQ_BLOCKS); int32_t* status = cv.take<int32_t>(4);
-  HIPCHK(c, hipMemsetAsync(status, 0, 16, c->stream));
-  float* hinfo = (float*)crux_pinned(c, sizeof(float) * CRUX_INFO_N + 16); if (!hinfo) return crux_fail(c, CRUX_ENOMEM, "batch_train! (dense): pinned staging");
+  HIPCHK(c, hipMemsetAsync(status, 0, 16, strm));
+  if (which && !c->dense_pinned2 && hipHostMalloc(&c->dense_pinned2, 256, hipHostMallocDefault) != hipSuccess) { c->dense_pinned2 = nullptr; return crux_fail(c, CRUX_ENOMEM, "batch_train! (dense): pinned staging"); }
+  float* hinfo = which ? (float*)c->dense_pinned2 : (float*)crux_pinned(c, sizeof(float) * CRUX_INFO_N + 16); if (!hinfo) return crux_fail(c, CRUX_ENOMEM, "batch_train! (dense): pinned staging");
   const bool pg = CRUX_IS_PG(a.loss); const bool step_sync = (pg && a.target_kl >= 0.f);
   long long total_batches = 0; int epochs_run = 0, err = 0; bool stop = false;
   std::vector<float> ei((size_t)CRUX_INFO_N * (size_t)n_epochs, 0.f);
   auto read_info = [&]() -> int32_t {
-    HIPCHK(c, hipMemcpyAsync(hinfo, dinfo, sizeof(float) * CRUX_INFO_N, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hinfo + CRUX_INFO_N, status, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(hinfo, dinfo, sizeof(float) * CRUX_INFO_N, hipMemcpyDeviceToHost, strm));
+    HIPCHK(c, hipMemcpyAsync(hinfo + CRUX_INFO_N, status, sizeof(int32_t), hipMemcpyDeviceToHost, strm));
+    HIPCHK(c, hipStreamSynchronize(strm));
     int32_t s; memcpy(&s, hinfo + CRUX_INFO_N, sizeof s); if (s == CRUX_ENAN || s == CRUX_EHIP) err = s;
     return CRUX_OK;
   };
@@ -243,20 +248,20 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a) {
     bool fresh = false;                      // hinfo holds the info row of the latest minibatch
     for (int64_t s0 = 0; s0 < total_rows; s0 += a.bs) {                                                    // partition(1:len, batch_size) (training.jl:40)
       const int64_t nb = (total_rows - s0) < a.bs ? (total_rows - s0) : a.bs;
-      hipLaunchKernelGGL(k_gather_obs, dim3((unsigned)((nb * od + 255) / 256)), dim3(256), 0, c->stream, a.S, od, order + s0, nb, x);
-      int32_t rc = crux_dense_forward(net, x, nb, c->stream); if (rc) return rc;
-      if (a.lag) hipLaunchKernelGGL(k_lagrange_pid, dim3(1), dim3(256), 0, c->stream, a.lag, a.COST, a.EE, order + s0, nb, (float* const*)((a.need_px && c->peer_n > 1) ? c->peer_tab : nullptr), c->peer_rank, c->peer_n, status);
+      hipLaunchKernelGGL(k_gather_obs, dim3((unsigned)((nb * od + 255) / 256)), dim3(256), 0, strm, a.S, od, order + s0, nb, x);
+      int32_t rc = crux_dense_forward(net, x, nb, strm); if (rc) return rc;
+      if (a.lag) hipLaunchKernelGGL(k_lagrange_pid, dim3(1), dim3(256), 0, strm, a.lag, a.COST, a.EE, order + s0, nb, (float* const*)((a.need_px && c->peer_n > 1) ? c->peer_tab + which * CRUX_PX_MAXR : nullptr), c->peer_rank, c->peer_n, status);
       PgHeadArgs q{}; q.lag = a.lag; q.CADV = a.CADV; q.z = crux_dense_act(net, nd.L); q.nout = nout; q.rows = order + s0; q.nb = nb; q.A = a.A; q.ad = a.ad; q.LP = a.LP; q.ADV = a.ADV; q.RET = a.RET;
       q.loss = a.loss; q.head = a.head; q.lo = 1.f - a.eps_clip; q.hi = 1.f + a.eps_clip; q.lambda_p = a.lambda_p; q.lambda_e = a.lambda_e; q.squash = a.squash;
       q.ls = net->p + nd.xoff; q.dy = dy; q.gx = net->g + nd.xoff; q.stats = st;
-      hipLaunchKernelGGL(k_pg_head, dim3(1), dim3(256), 0, c->stream, q);
-      rc = crux_dense_backward(net, x, nb, dy, 1.0f, true, nullptr, c->stream); if (rc) return rc;
+      hipLaunchKernelGGL(k_pg_head, dim3(1), dim3(256), 0, strm, q);
+      rc = crux_dense_backward(net, x, nb, dy, 1.0f, true, nullptr, strm); if (rc) return rc;
       if (a.need_px && c->peer_n > 1)      // replica group: the gradient (and the statistics) of the GLOBAL minibatch, the same bits on every rank
-        hipLaunchKernelGGL(k_px_allreduce_flat, dim3(1), dim3(1024), 0, c->stream, net->g, (int64_t)nd.n_params, st, (float* const*)c->peer_tab, c->peer_rank, c->peer_n, status);
-      hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, c->stream, (const float*)net->g, (int64_t)nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
-      hipLaunchKernelGGL(k_pg_info, dim3(1), dim3(1), 0, c->stream, (const double*)st, (const double*)ssq, nb, a.loss, a.head, a.lambda_p, a.lambda_e, (const float*)(net->p + nd.xoff), a.ad, dinfo, (const crux_lagrange*)a.lag);
-      if (a.apply) { rc = adam_gated(net, ssq, status); if (rc) return rc; }
-      else hipLaunchKernelGGL(k_nan_status, dim3(1), dim3(1), 0, c->stream, (const double*)ssq, status);
+        hipLaunchKernelGGL(k_px_allreduce_flat, dim3(1), dim3(1024), 0, strm, net->g, (int64_t)nd.n_params, st, (float* const*)(c->peer_tab + which * CRUX_PX_MAXR), c->peer_rank, c->peer_n, status);
+      hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, strm, (const float*)net->g, (int64_t)nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+      hipLaunchKernelGGL(k_pg_info, dim3(1), dim3(1), 0, strm, (const double*)st, (const double*)ssq, nb, a.loss, a.head, a.lambda_p, a.lambda_e, (const float*)(net->p + nd.xoff), a.ad, dinfo, (const crux_lagrange*)a.lag);
+      if (a.apply) { rc = adam_gated(net, ssq, status, true, strm); if (rc) return rc; }
+      else hipLaunchKernelGGL(k_nan_status, dim3(1), dim3(1), 0, strm, (const double*)ssq, status);
       total_batches += 1; fresh = false;
       const bool last = s0 + a.bs >= total_rows, capped = a.max_batches > 0 && total_batches >= a.max_batches;
       if (step_sync || capped || last) { rc = read_info(); if (rc) return rc; fresh = true; }
@@ -274,8 +279,8 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a) {
   // status row and epoch infos where the persistent kernels leave them (run_batch / collect read them back)
   if (err && epochs_run == 0) { ei[CRUX_INFO_LOSS] = hinfo[CRUX_INFO_LOSS]; ei[CRUX_INFO_GRAD_NORM] = NAN; }
   int32_t hst[4] = {err, (int32_t)total_batches, epochs_run, 0};
-  HIPCHK(c, hipMemcpyAsync(a.status, hst, sizeof hst, hipMemcpyHostToDevice, c->stream));
-  if (a.epoch_infos) HIPCHK(c, hipMemcpyAsync(a.epoch_infos, ei.data(), sizeof(float) * ei.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));            // hst / ei are stack / heap memory of this call
+  HIPCHK(c, hipMemcpyAsync(a.status, hst, sizeof hst, hipMemcpyHostToDevice, strm));
+  if (a.epoch_infos) HIPCHK(c, hipMemcpyAsync(a.epoch_infos, ei.data(), sizeof(float) * ei.size(), hipMemcpyHostToDevice, strm));
+  HIPCHK(c, hipStreamSynchronize(strm));            // hst / ei are stack / heap memory of this call
   return crux_launch_check(c, "batch_train! (dense)");
 }

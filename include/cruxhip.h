@@ -323,7 +323,8 @@ int32_t crux_batch_train(crux_mlp* net, crux_buffer* buf, const crux_train_cfg* 
 /* policy_gradient_training(S, D) (src/model_free/on_policy.jl:56-78): batch_train!(actor) then batch_train!(critic) on one
  * buffer. Results are those of the sequential reference order; when the actor's epoch count is fixed in advance (target_kl < 0,
  * no max_batches) the two persistent learner kernels run concurrently on two CUs (the critic composes the actor's shuffles
- * into its starting order), otherwise they run back to back. */
+ * into its starting order), otherwise they run back to back. Learners of the dense engine (shapes outside the register-resident family) run their
+ * two chains of launches side by side under the same condition: the critic's on the second learner stream, driven by a second host thread. */
 int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* critic, crux_buffer* buf, const crux_train_cfg* cfg_actor,
                                       const crux_train_cfg* cfg_critic, const int64_t* perms_actor, const int64_t* perms_critic,
                                       float* info_actor, float* info_critic, float* epoch_infos_actor, float* epoch_infos_critic);
