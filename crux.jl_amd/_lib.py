@@ -97,6 +97,7 @@ SIGNATURES = {
     "crux_sac_epochs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i32, i32, u64, u64, u64, vp, vp, vp]),
     "crux_sac_epochs_async": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i32, i32, u64, u64, u64, vp]),
     "crux_dpg_epochs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, i32, i32, i32, u64, u64, u64, vp, vp]),
+    "crux_dpg_epochs_async": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, i32, i32, i32, u64, u64, u64, vp]),
     "crux_sac_epoch": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, u64, u64, u64, vp, vp, vp]),
     "crux_env_create": (i32, [vp, i32, i32, i32, f32, vp, vp, u64, i32, i32, P(vp)]),
     "crux_env_destroy": (i32, [vp]),

@@ -1791,6 +1791,30 @@ def _value_training_dpg(solver, D, gamma):
         # the whole epoch loop (:69-104) in one C call: chains of up to 8 epochs per recorded list (cruxhip.h: crux_dpg_epochs); same pieces, order and draws as below
         _set_stream_for(buf, solver.sample_seed)
         n = c_opt.epochs; ctr0 = solver.i * n
+        if getattr(solver, "_async_now", False):
+            d_rows, row0 = _info_ring(solver, ctx, 2 * n)
+            rc = lib.crux_dpg_epochs_async(A.h, (Q.N1 if twin else Q).h, Q.N2.h if twin else None, Am.h, (Qm.N1 if twin else Qm).h, Qm.N2.h if twin else None, buf.h, D.h,
+                                           float(gamma), float(solver.tau), sm.sigma if sm else -1.0, sm.eps_min if sm else 0.0, sm.eps_max if sm else 0.0, sm.a_min if sm else 0.0,
+                                           sm.a_max if sm else 0.0, 1 if solver.weighted_loss else 0, 0, n, int(c_opt.update_every), int(a_opt.update_every), ctr0,
+                                           solver.noise_seed, ctr0, d_rows)
+            if rc == L.OK:
+                ce, ae, cn, an, tw = int(c_opt.update_every), int(a_opt.update_every), c_opt.name, a_opt.name, twin
+                def decode(raws):
+                    out, nan = [], False
+                    for epoch in range(len(raws) // 2):
+                        rq_, ra_ = raws[2 * epoch], raws[2 * epoch + 1]; info = {}
+                        if epoch % ce == 0:
+                            info.update({"Q1avg": float(rq_[L.INFO["q1avg"]]), "Q2avg": float(rq_[L.INFO["q2avg"]])} if tw else {"Qavg": float(rq_[L.INFO["q1avg"]])})
+                            info.update({cn + "loss": float(rq_[0]), cn + "grad_norm": float(rq_[1])}); nan = nan or bool(np.isnan(rq_[1]))
+                        if epoch % ae == 0:
+                            info.update({an + "loss": float(ra_[0]), an + "grad_norm": float(ra_[1])}); nan = nan or bool(np.isnan(ra_[1]))
+                        out.append(info)
+                    return out, nan
+                solver._dinfos_used += 2 * n
+                return _PendingInfo(row0, 2 * n, decode)
+            if rc != L.EUNSUP:
+                ctx.check(rc)
+            solver._async_now = False
         rq, ra = (np.zeros((n, L.INFO_N), np.float32) for _ in range(2))
         ctx.check(lib.crux_dpg_epochs(A.h, (Q.N1 if twin else Q).h, Q.N2.h if twin else None, Am.h, (Qm.N1 if twin else Qm).h, Qm.N2.h if twin else None, buf.h, D.h,
                                       float(gamma), float(solver.tau), sm.sigma if sm else -1.0, sm.eps_min if sm else 0.0, sm.eps_max if sm else 0.0, sm.a_min if sm else 0.0,

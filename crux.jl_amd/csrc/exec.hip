@@ -937,6 +937,14 @@ static int32_t dpg_epochs_impl(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux
   }
   return chain ? flush() : rc;
 }
+// crux_dpg_epochs without the host in the loop (see crux_dqn_epochs_async): d_infos is DEVICE memory, [n_epochs][2][CRUX_INFO_N] = critic | actor rows of every epoch
+int32_t crux_dpg_epochs_async(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_buffer* source, crux_buffer* batch,
+                              float gamma, float tau, float sigma, float eps_min, float eps_max, float a_min, float a_max, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
+                              int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0, float* d_infos) {
+  if (!d_infos) return CRUX_EINVAL;
+  return dpg_epochs_impl(actor, q1, q2, actor_targ, q1_targ, q2_targ, source, batch, gamma, tau, sigma, eps_min, eps_max, a_min, a_max, use_weight, epoch0, n_epochs, critic_every, actor_every,
+                         sample_counter0, noise_seed, noise_counter0, nullptr, nullptr, d_infos);
+}
 int32_t crux_dpg_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_buffer* source, crux_buffer* batch,
                         float gamma, float tau, float sigma, float eps_min, float eps_max, float a_min, float a_max, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
                         int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0, float* infos_critic, float* infos_actor) {

@@ -487,6 +487,10 @@ int32_t crux_sac_epochs_async(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_
 int32_t crux_dpg_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_buffer* source, crux_buffer* batch,
                         float gamma, float tau, float sigma, float eps_min, float eps_max, float a_min, float a_max, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
                         int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0, float* infos_critic, float* infos_actor);
+/* The same chains without the host in the loop (see crux_dqn_epochs_async): d_infos is DEVICE memory, [n_epochs][2][CRUX_INFO_N] = critic | actor rows.      */
+int32_t crux_dpg_epochs_async(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_buffer* source, crux_buffer* batch,
+                        float gamma, float tau, float sigma, float eps_min, float eps_max, float a_min, float a_max, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
+                        int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0, float* d_infos);
 
 /* solve(::OffPolicySolver) (src/model_free/off_policy.jl:133-147) for a DQN on a SMALL network (the README example: SimpleGridWorld, 2-8-4), `iters` iterations
  * in ONE launch: per iteration steps!(sampler, buffer, Nsteps = dN, explore = true, i = S.i) (:138), then value_training (:66-111): dN.. `epochs` epochs of

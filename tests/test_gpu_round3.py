@@ -451,3 +451,28 @@ def test_asynchronous_sac_solve_loop_equals_the_synchronous_one(gpu_ctx):
     for x, y in zip(pa, pb):
         assert np.array_equal(x, y)
     assert np.array_equal(ha, hb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["ddpg", "td3"])
+def test_asynchronous_dpg_solve_loop_equals_the_synchronous_one(gpu_ctx, algo):
+    """The same for DDPG / TD3 (crux_dpg_epochs_async: two info rows per epoch, critic | actor; TD3 trains its actor every second epoch, whose rows are skipped)."""
+    twin = algo == "td3"
+    def run(asyn):
+        S = crux.ContinuousSpace(3)
+        q = lambda s: crux.ContinuousNetwork(parity.chain([4, 256, 256, 1], ["relu", "relu", "identity"]), seed=s)
+        pi = crux.ActorCritic(crux.ContinuousNetwork(parity.chain([3, 256, 256, 1], ["relu", "relu", "tanh" if twin else "identity"]), seed=2), crux.DoubleNetwork(q(3), q(4)) if twin else q(3))
+        ctor = crux.TD3 if twin else crux.DDPG
+        a_opt = {"batch_size": 128, "update_every": 2} if twin else {"batch_size": 128}
+        sv = ctor(pi, S, N=200, dN=10, buffer_size=1000, buffer_init=140, max_steps=50, c_opt={"batch_size": 128, "epochs": 10}, a_opt=a_opt, noise_seed=5,
+                  pi_explore=crux.GaussianNoiseExplorationPolicy(0.3, a_min=-1.0, a_max=1.0))
+        sv.async_training = asyn
+        crux.solve(sv, crux.PendulumMDP(n_envs=1, seed=8))
+        nets = [pi.A, sv.agent.pi_minus.A] + ([pi.C.N1, pi.C.N2, sv.agent.pi_minus.C.N1, sv.agent.pi_minus.C.N2] if twin else [pi.C, sv.agent.pi_minus.C])
+        keys = sorted(sv.history[-1])
+        return [n.get_params() for n in nets], np.array([[h[k] for k in keys] for h in sv.history]), keys
+    (pa, ha, ka), (pb, hb, kb) = run(True), run(False)
+    assert ka == kb and "critic_loss" in ka and "actor_loss" in ka and len(ha) == len(hb) >= 4
+    for x, y in zip(pa, pb):
+        assert np.array_equal(x, y)
+    assert np.array_equal(ha, hb)
