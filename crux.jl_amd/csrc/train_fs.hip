@@ -15,9 +15,11 @@ static int32_t launch_fs_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
   return crux_launch_check(c, PX ? "k_train_fs (replica group)" : LAG ? "k_train_fs (lagrange_ppo_loss)" : "k_train_fs");
 }
 // form: 2 = two workgroups of eight waves; 4 = four workgroups of four waves; 8 = four workgroups of four compute + four helper waves (the only form of the 32-wide second layer)
+// (the shapes added in round 3 for the standard Gym tasks -- IN > 17 or not one of the benchmark shapes -- are instantiated in the default form only: FS_LITE)
+template <int IN, int OUT> constexpr bool FS_LITE = !((IN == 4 && (OUT == 2 || OUT == 1)) || (IN == 3 && OUT == 1) || (IN == 17 && (OUT == 6 || OUT == 1)) || (IN == 8 && (OUT == 4 || OUT == 1)) || (IN == 2 && OUT == 1));
 template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, bool TIMING>
 static int32_t launch_fs_pick(crux_ctx* c, TrainArgs& a, int form, hipStream_t stream) {
-  if constexpr (H2 == 64 && ACT2 == ACT) {
+  if constexpr (H2 == 64 && ACT2 == ACT && !FS_LITE<IN, OUT>) {
     if (form == 2) return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 2, false, TIMING, false>(c, a, stream);
     if (form == 4) return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, false, TIMING, false>(c, a, stream);
   }
@@ -102,6 +104,13 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hip
   FS_CASE(8, 1, MFK_VALUE, CRUX_ACT_RELU)
   FS_CASE(2, 1, MFK_GAUSSIAN, CRUX_ACT_RELU)        // the reference's own Pendulum examples observe (theta, theta_dot): 2 inputs (examples/rl/pendulum.jl)
   FS_CASE(2, 1, MFK_VALUE, CRUX_ACT_RELU)
+  // standard Gym shapes (default form + replica-group form only): Acrobot 6 / 3, MountainCar 2 / 3, LunarLanderContinuous 8 / 2, Hopper 11 / 3, BipedalWalker 24 / 4, Ant 27 / 8
+  FS_CASE(6, 3, MFK_CATEGORICAL, CRUX_ACT_RELU)  FS_CASE(6, 1, MFK_VALUE, CRUX_ACT_RELU)
+  FS_CASE(2, 3, MFK_CATEGORICAL, CRUX_ACT_RELU)
+  FS_CASE(8, 2, MFK_GAUSSIAN, CRUX_ACT_RELU)     FS_CASE(8, 2, MFK_GAUSSIAN, CRUX_ACT_TANH)     FS_CASE(8, 1, MFK_VALUE, CRUX_ACT_TANH)
+  FS_CASE(11, 3, MFK_GAUSSIAN, CRUX_ACT_RELU)    FS_CASE(11, 3, MFK_GAUSSIAN, CRUX_ACT_TANH)    FS_CASE(11, 1, MFK_VALUE, CRUX_ACT_RELU)   FS_CASE(11, 1, MFK_VALUE, CRUX_ACT_TANH)
+  FS_CASE(24, 4, MFK_GAUSSIAN, CRUX_ACT_RELU)    FS_CASE(24, 4, MFK_GAUSSIAN, CRUX_ACT_TANH)    FS_CASE(24, 1, MFK_VALUE, CRUX_ACT_RELU)   FS_CASE(24, 1, MFK_VALUE, CRUX_ACT_TANH)
+  FS_CASE(27, 8, MFK_GAUSSIAN, CRUX_ACT_RELU)    FS_CASE(27, 8, MFK_GAUSSIAN, CRUX_ACT_TANH)    FS_CASE(27, 1, MFK_VALUE, CRUX_ACT_RELU)   FS_CASE(27, 1, MFK_VALUE, CRUX_ACT_TANH)
   // the reference's HalfCheetah PPO networks (examples/rl/half_cheetah_mujoco.jl:33-38): mu = 17 -tanh-> 64 -tanh-> 32 -> 6, V = 17 -tanh-> 64 -> 32 -> 1 (no activation on V's second layer)
   FS_CASE2(17, 6, MFK_GAUSSIAN, CRUX_ACT_TANH, 32, CRUX_ACT_TANH)
   FS_CASE2(17, 1, MFK_VALUE, CRUX_ACT_TANH, 32, CRUX_ACT_IDENTITY)

@@ -476,3 +476,32 @@ def test_asynchronous_dpg_solve_loop_equals_the_synchronous_one(gpu_ctx, algo):
     for x, y in zip(pa, pb):
         assert np.array_equal(x, y)
     assert np.array_equal(ha, hb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("od,ad,kind,act", [(6, 3, "categorical", "relu"), (2, 3, "categorical", "relu"), (8, 2, "gaussian", "tanh"), (11, 3, "gaussian", "tanh"), (24, 4, "gaussian", "relu"),
+                                            (27, 8, "gaussian", "tanh"), (27, 8, "value", "tanh"), (24, 4, "value", "relu"), (6, 3, "value", "relu")])
+def test_gym_shapes_on_the_feature_split_kernel(gpu_ctx, capfd, od, ad, kind, act):
+    """The standard Gym observation / action sizes added to k_train_fs's dispatch in round 3 (Acrobot 6 / 3, MountainCar 2 / 3, LunarLanderContinuous 8 / 2, Hopper 11 / 3,
+    BipedalWalker 24 / 4, Ant 27 / 8; 64-64 hidden): two teacher-forced windows of eight full-minibatch steps each against the oracle (B = 128: the feature-split kernel;
+    CRUX_FS=0 would send these shapes to the dense engine)."""
+    rng = np.random.default_rng(77 + od + ad); bs = 128; N = bs * 20; disc = kind == "categorical"
+    if disc:
+        ai = rng.integers(0, ad, N); actn = np.eye(ad, dtype=bool)[:, ai]
+    else:
+        actn = rng.normal(0, 0.7, (ad, N)).astype(np.float32)
+    data0 = {"s": rng.normal(0, 1, (od, N)).astype(np.float32), "a": actn, "sp": rng.normal(0, 1, (od, N)).astype(np.float32), "r": np.ones((1, N), np.float32),
+             "done": np.zeros((1, N), bool), "episode_end": np.zeros((1, N), bool), "return": rng.normal(0, 1, (1, N)).astype(np.float32),
+             "logprob": rng.normal(-1.2, 0.05, (1, N)).astype(np.float32), "advantage": rng.normal(0, 1, (1, N)).astype(np.float32)}
+    out = 1 if kind == "value" else ad; dims, acts = [od, 64, 64, out], [act, act, "identity"]
+    if kind == "categorical":
+        g, o = parity.make_pair(dims, acts, 400 + od, 0, "discrete"); loss, head = "ppo", "categorical"
+    elif kind == "gaussian":
+        g, o = parity.make_pair(dims, acts, 400 + od, 0, "gaussian", n_extra=ad, extra_init=-0.5); loss, head = "ppo", "gaussian"
+    else:
+        g, o = parity.make_pair(dims, acts, 400 + od, 0); loss, head = "value_mse", "deterministic"
+    res, _ = parity.learner_window_parity(g, o, data0, od, ad, disc, loss, head, bs, 1, [2, 11], 8, seed=800 + od)
+    assert len(res) == 2
+    for start, W, d in res:
+        assert d < 2e-6, (start, d)
+    assert "outside the MFMA learner family" not in capfd.readouterr().err
