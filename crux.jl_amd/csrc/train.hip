@@ -136,11 +136,11 @@ static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_
   a.need_px = (c->peer_n > 1 && a.apply && !a.ids) ? 1 : 0;
   int32_t rc = crux_train_mfma_launch(c, a, &handled, stream);
   if (rc) return rc;
-  const bool dense_ok = !handled && stream == c->stream && crux_train_dense_eligible(a, generic_lds_bytes(a.nd), getenv("CRUX_FORCE_GENERIC") != nullptr);
+  const bool dense_ok = !handled && crux_train_dense_eligible(a, generic_lds_bytes(a.nd), getenv("CRUX_FORCE_GENERIC") != nullptr);      // (on the second learner stream too: its own resource set)
   if (a.need_px && !handled && !dense_ok) return crux_fail(c, CRUX_EUNSUP, "batch_train! with a replica group attached needs a learner with the gradient exchange (the register-resident kernels, or the dense-engine learner for other Chain(Dense...) shapes; not lagrange_ppo_loss): this learner would run un-synchronised");
   if (dense_ok) {
     // outside the register-resident family: the MFMA dense engine, one chain of tile GEMMs per minibatch (train_dense.hip)
-    rc = crux_train_dense_run(c, a);
+    rc = crux_train_dense_run(c, a, stream, stream == c->stream ? 0 : 1);
     if (prof) crux_prof_end(c, prof_slot);
     return rc;
   }

@@ -82,6 +82,8 @@ FAMILIES = {
     "synth_2_1": (2, 1, False, [2, 64, 64, 1], [2, 64, 64, 1], ACTS, "gaussian", "gaussian", "synth"),
     # the reference's HalfCheetah PPO networks (examples/rl/half_cheetah_mujoco.jl:33-38): mu = 17 -tanh-> 64 -tanh-> 32 -> 6, V = 17 -tanh-> 64 -> 32 -> 1 (CRITIC_ACTS below)
     "cheetah_ref": (17, 6, False, [17, 64, 32, 6], [17, 64, 32, 1], ["tanh", "tanh", "identity"], "gaussian", "gaussian", "synth"),
+    # 64-wide but with no instantiation in the register-resident kernels (5 observations / 3 actions): the dense engine, also on the second learner stream of a pair
+    "synth_5_3": (5, 3, True, [5, 64, 64, 3], [5, 64, 64, 1], ACTS, "discrete", "categorical", "synth_discrete"),
     # outside the MFMA family (32-wide hidden layers): the generic learner
     "synth_8_4_h32": (8, 4, True, [8, 32, 32, 4], [8, 32, 32, 1], ACTS, "discrete", "categorical", "synth_discrete"),
 }

@@ -505,3 +505,13 @@ def test_gym_shapes_on_the_feature_split_kernel(gpu_ctx, capfd, od, ad, kind, ac
     for start, W, d in res:
         assert d < 2e-6, (start, d)
     assert "outside the MFMA learner family" not in capfd.readouterr().err
+
+
+@pytest.mark.gpu
+def test_a_64_wide_shape_without_an_instantiation_takes_the_dense_engine_on_both_learner_streams(gpu_ctx, capfd):
+    """policy_gradient_training treats every 64-wide pair as the register-resident family and launches the critic on the second learner stream; a shape none of those kernels
+    instantiates (5 observations / 3 actions) used to fall to the generic one-workgroup learner there (the dense engine was bound to the main stream). It now takes the dense
+    engine on either stream: oracle parity of the whole iteration, and no "outside the MFMA learner family" announcement."""
+    res = parity.ppo_iteration_parity(n_envs=8, T=64, batch_size=128, epochs=2, seed=19, family="synth_5_3", pair=True)
+    assert res["ok"], res
+    assert "outside the MFMA learner family" not in capfd.readouterr().err
