@@ -94,6 +94,7 @@ SIGNATURES = {
     "crux_dqn_epochs": (i32, [vp, vp, vp, vp, f32, i32, f32, u64, i32, vp]),
     "crux_dqn_epochs_async": (i32, [vp, vp, vp, vp, f32, i32, f32, u64, i32, vp]),
     "crux_softq_epochs": (i32, [vp, vp, vp, vp, f32, f32, i32, f32, u64, i32, vp]),
+    "crux_softq_epochs_async": (i32, [vp, vp, vp, vp, f32, f32, i32, f32, u64, i32, vp]),
     "crux_sac_epochs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i32, i32, u64, u64, u64, vp, vp, vp]),
     "crux_sac_epochs_async": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i32, i32, u64, u64, u64, vp]),
     "crux_dpg_epochs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, i32, i32, i32, u64, u64, u64, vp, vp]),

@@ -1888,10 +1888,13 @@ def value_training(solver, D, gamma):
         _set_stream_for(buf, solver.sample_seed)
         beta = float(np.float32(buf.beta(solver.i))) if buf.isprioritized() else 0.0                       # rand!(D, buffer, i=S.i): beta(S.i)
         raws = np.zeros((p.epochs, L.INFO_N), np.float32)
-        if solver.target_fn == "dqn" and getattr(solver, "_async_now", False):
+        if getattr(solver, "_async_now", False):
             # no host in the loop: the chain is enqueued and the info rows stay on the device (OffPolicySolver.history fetches them)
             d_rows, _row0 = _info_ring(solver, ctx, p.epochs)
-            rc = ctx.lib.crux_dqn_epochs_async(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, d_rows)
+            if solver.target_fn == "softq":
+                rc = ctx.lib.crux_softq_epochs_async(pi.h, pim.h, buf.h, D.h, float(gamma), float(solver.P["alpha"]), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, d_rows)
+            else:
+                rc = ctx.lib.crux_dqn_epochs_async(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, d_rows)
             if rc == L.OK:
                 name = p.name; row0 = _row0
                 def decode(raws):

@@ -649,6 +649,12 @@ int32_t crux_dqn_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   if (!net || !target_net || net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || target_net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || getenv("CRUX_NO_FUSED_EPOCH") || getenv("CRUX_NO_CHAINED_EPOCHS")) return CRUX_EUNSUP;
   return dqn_epochs_impl(net, target_net, source, batch, gamma, 0.f, use_weight, beta, sample_counter0, n_epochs, nullptr, d_infos);
 }
+int32_t crux_softq_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
+                                uint64_t sample_counter0, int32_t n_epochs, float* d_infos) {      // crux_softq_epochs without the host in the loop (see crux_dqn_epochs_async)
+  if (!d_infos || !(alpha > 0.f)) return CRUX_EINVAL;
+  if (!net || !target_net || net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || target_net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || getenv("CRUX_NO_FUSED_EPOCH") || getenv("CRUX_NO_CHAINED_EPOCHS")) return CRUX_EUNSUP;
+  return dqn_epochs_impl(net, target_net, source, batch, gamma, alpha, use_weight, beta, sample_counter0, n_epochs, nullptr, d_infos);
+}
 int32_t crux_softq_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
                           uint64_t sample_counter0, int32_t n_epochs, float* infos) {
   if (!(alpha > 0.f)) return CRUX_EINVAL;

@@ -456,6 +456,8 @@ int32_t crux_dqn_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
                               uint64_t sample_counter0, int32_t n_epochs, float* d_infos);
 int32_t crux_softq_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
                           uint64_t sample_counter0, int32_t n_epochs, float* infos);
+int32_t crux_softq_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
+                          uint64_t sample_counter0, int32_t n_epochs, float* d_infos);      /* the same without the host in the loop (see crux_dqn_epochs_async) */
 /* One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl:4-52,94-104) as one recorded op list (30 phases, see crux_dqn_epoch): rand! -> sac_target ->
  * train!(log_alpha, sac_temp_loss) -> [update_critic: train!(critic, double_Q_loss)] -> [update_actor: train!(actor, sac_actor_loss), then
  * polyak_average!(target, online, tau) for the actor (when actor_targ != NULL) and both critics (:100)]. The three exploration draws use noise counters
