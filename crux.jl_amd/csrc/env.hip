@@ -145,7 +145,7 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
           const double u = crux_u32x2_to_f64(x.v[0], x.v[1]);
           if (u < eps) { const crux_u32x4 y = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_RANDACT); ai = (int)(((uint64_t)y.v[0] * (uint64_t)nout) >> 32); }
           else ai = greedy;
-          logprob = (float)log(eps * (1.0 / (double)nout) + (1.0 - eps));
+          if (a.LP) logprob = (float)log(eps * (1.0 / (double)nout) + (1.0 - eps));      // (a Float64 log per step: only where a :logprob column takes it)
         } else {
           float pr[ENV_MAXOBS];
           const float ldiv = a.cfg.logit_div > 0.f ? a.cfg.logit_div : 1.f;                       // softmax(value ./ alpha) (softq.jl:53)
