@@ -126,6 +126,7 @@ static int32_t build_orders(crux_ctx* c, crux_buffer* buf, int slot, const int32
 
 bool crux_train_dense_eligible(const TrainArgs& a, size_t generic_lds, bool force_generic);     // train_dense.hip
 int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a, hipStream_t strm = nullptr, int which = 0);
+int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream, bool probe);      // train_fs.hip
 static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_t stream = nullptr) {
   bool handled = false;
   if (!stream) stream = c->stream;
@@ -472,7 +473,13 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   bool exact = cfg_a->target_kl < 0.f && cfg_a->max_batches <= 0;
   { const bool fs_on = !(getenv("CRUX_FS") && atoi(getenv("CRUX_FS")) == 0) && cfg_a->batch_size > 64 && cfg_a->batch_size <= 128;      // the feature-split kernel also takes a 32-wide second layer
     auto mfma_family = [fs_on](const crux_mlp* n) { const NetDesc& d = n->nd; return d.L == 3 && d.dims[1] == 64 && (d.dims[2] == 64 || (d.dims[2] == 32 && fs_on)); };
-    if (!mfma_family(actor) || !mfma_family(critic)) {
+    bool family = mfma_family(actor) && mfma_family(critic);
+    if (family && exact && fs_on && c->learner_cus == 0 && buf->elements >= cfg_a->batch_size && cfg_a->batch_size == cfg_c->batch_size) {      // 64 wide, but does a register-resident kernel instantiate these shapes?
+      TrainArgs pa, pk; bool ha = false, hk = false;
+      if (!fill_args(pa, actor, buf, cfg_a, cfg_a->loss) && !fill_args(pk, critic, buf, cfg_c, cfg_c->loss)) { pa.need_px = pk.need_px = (c->peer_n > 1) ? 1 : 0;
+        (void)crux_train_fs_launch(c, pa, &ha, c->stream, true); (void)crux_train_fs_launch(c, pk, &hk, c->stream, true);
+        if (!ha || !hk) family = false; } }      // no: the dense engine's pair below instead of one learner after the other
+    if (!family) {
       // outside the register-resident family: two dense-engine chains (train_dense.hip), one per learner stream, driven by two host threads -- same condition as above
       // (no early stopping, no minibatch cap: the critic's shuffle chain can be composed ahead of the actor's run), no replica group, CRUX_DENSE_PAIR=0 switches it off
       if (exact && c->peer_n <= 1 && !(getenv("CRUX_DENSE_PAIR") && getenv("CRUX_DENSE_PAIR")[0] == '0') && !getenv("CRUX_FORCE_GENERIC")) {

@@ -64,7 +64,8 @@ static int32_t launch_fs(crux_ctx* c, TrainArgs a, int form, bool timing, hipStr
 // Called first by crux_train_mfma_launch (train_mfma.hip) with its own shape test: IN -> 64 -> {64, 32} -> OUT, identity output layer, full minibatch loops with Adam, the plain
 // policy-gradient / critic losses; replica groups take the PX instantiation. CRUX_FS=0 switches the form off (the sample-split two-CU kernel, or the dense engine for the 32-wide
 // second layer, then run), CRUX_FS_WG=2|4|8 picks the form.
-int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream) {
+// probe: only answer whether this call would be taken (policy_gradient_training asks before it commits a pair of learners to the two learner streams)
+int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream, bool probe) {
   *handled = false;
   const int mode = [] { const char* e = getenv("CRUX_FS"); return e ? atoi(e) : 1; }();            // read per call: tests switch the form inside one process
   const int form_env = [] { const char* e = getenv("CRUX_FS_WG"); return e ? atoi(e) : 0; }();
@@ -90,7 +91,7 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hip
   }
   const int form = form_env == 2 || form_env == 4 || form_env == 8 ? form_env : CRUX_FS_DEFAULT_WG;      // 8 = four workgroups with helper waves
   const bool timing = getenv("CRUX_MFMA_TIMING") != nullptr;
-#define FS_CASE2(I, O, K, A1, H, A2) if (in == I && out == O && kind == K && act == A1 && h2 == H && act2 == A2) { *handled = true; return launch_fs<I, O, K, A1, H, A2>(c, a, form, timing, stream); }
+#define FS_CASE2(I, O, K, A1, H, A2) if (in == I && out == O && kind == K && act == A1 && h2 == H && act2 == A2) { *handled = true; if (probe) return CRUX_OK; return launch_fs<I, O, K, A1, H, A2>(c, a, form, timing, stream); }
 #define FS_CASE(I, O, K, A_) FS_CASE2(I, O, K, A_, 64, A_)
   FS_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)     // C2 actor  (PPO CartPole)
   FS_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)           // C2 critic
