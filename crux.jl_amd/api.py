@@ -1219,11 +1219,27 @@ def policy_gradient_training(solver, D, perms_a=None, perms_c=None):
     if pa.loss.name == "lagrange_ppo" or getattr(solver, "cost_opt", None) is not None or _uses_seam(pa) or _uses_seam(pc):
         # the sequential form of on_policy.jl:63-76: actor, critic, then the cost critic (the penalty controller rides in the actor's learner kernel)
         batch_train_(A, pa, solver.P, D, info=info, perms=perms_a)
+        po = getattr(solver, "cost_opt", None)
+        if (po is not None and perms_c is None and not _uses_seam(pc) and not _uses_seam(po) and pc.target_kl is None and po.target_kl is None
+                and pc.max_batches == math.inf and po.max_batches == math.inf):
+            # the critic and the cost critic (on_policy.jl:66-76) as ONE pair call: two learners whose shuffle chains follow each other, run side by side where that is exact
+            # (crux_policy_gradient_training is not tied to an actor: the second learner's order chain starts from the first one's last order)
+            Vc = solver.Vc
+            _ensure_opt(Cn, pc); _ensure_opt(Vc, po)
+            cc, cv = _train_cfg(Cn, pc, solver.P), _train_cfg(Vc, po, solver.P)
+            rc_, rv = np.zeros(L.INFO_N, np.float32), np.zeros(L.INFO_N, np.float32)
+            ec, ev = np.zeros((pc.epochs, L.INFO_N), np.float32), np.zeros((po.epochs, L.INFO_N), np.float32)
+            Cn.ctx.check(Cn.ctx.lib.crux_policy_gradient_training(Cn.h, Vc.h, D.h, C.byref(cc), C.byref(cv), None, None, _vp(rc_), _vp(rv), _vp(ec), _vp(ev)))
+            for p, raw in ((pc, rc_), (po, rv)):
+                p.shuffle_counter += int(raw[L.INFO["epochs_run"]])
+                d = {k: v for k, v in _info_dict(p, raw).items() if k.startswith(p.name)}
+                info.update(d); info[p.name + "batches_trained"] = int(raw[L.INFO["batches_trained"]])
+            return info
         ci = batch_train_(Cn, pc, solver.P, D, info={}, perms=perms_c)
         info.update({k: v for k, v in ci.items() if k.startswith(pc.name)})
-        if getattr(solver, "cost_opt", None) is not None:
-            vi = batch_train_(solver.Vc, solver.cost_opt, solver.P, D, info={})
-            info.update({k: v for k, v in vi.items() if k.startswith(solver.cost_opt.name)})
+        if po is not None:
+            vi = batch_train_(solver.Vc, po, solver.P, D, info={})
+            info.update({k: v for k, v in vi.items() if k.startswith(po.name)})
         return info
     _ensure_opt(A, pa); _ensure_opt(Cn, pc)
     ca, cc = _train_cfg(A, pa, solver.P), _train_cfg(Cn, pc, solver.P)
