@@ -156,7 +156,7 @@ def c4(crux, ctx, cpu=True, steps=200):
         solver.i += EP; crux.value_training(solver, D, np.float32(0.99))
     t = _timed(ctx, iteration, max(1, steps // EP), warmup=1) / EP
     def iteration_async():      # the entry point solve() uses: chains enqueued without read-back or synchronisation (the infos stay in the solver's device ring)
-        solver.i += EP; solver._async_now = True; crux.value_training(solver, D, np.float32(0.99))
+        solver.i += EP; crux.value_training_async(solver, D, np.float32(0.99))
     t_async = _timed(ctx, iteration_async, max(1, steps // EP), warmup=1) / EP
     solver._resolve_history()
     ach = C4_FLOP / t / 1e12

@@ -1652,6 +1652,7 @@ class OffPolicySolver:
         self._dy = self._derr = None
         # solve() without the host in the loop (cruxhip.h: crux_dqn_epochs_async): the epochs' info rows stay on the device until somebody looks at `history`
         self.async_training = True
+        self._async_now = self._async_unsupported = self._async_fell_back = False
         self._dinfos, self._dinfos_rows, self._dinfos_used, self._pending = None, 0, 0, []      # device ring of info rows; (history index, first row, epochs, name) not yet fetched
 
     @property
@@ -1748,7 +1749,7 @@ def _value_training_sac(solver, D, gamma):
                 return _PendingInfo(row0, 3 * n, decode)
             if rc != L.EUNSUP:
                 ctx.check(rc)
-            solver._async_now = False
+            solver._async_now = False; solver._async_fell_back = True
         rt, rq, ra = (np.zeros((n, L.INFO_N), np.float32) for _ in range(3))
         ctx.check(lib.crux_sac_epochs(A.h, Q.N1.h, Q.N2.h, pim.A.h, Qm.N1.h, Qm.N2.h, la.h, buf.h, D.h, float(gamma), float(solver.P["SAC_H_target"]), float(solver.tau),
                                       1 if solver.weighted_loss else 0, 0, n, int(c_opt.update_every), int(a_opt.update_every), ctr0, solver.noise_seed, 3 * ctr0,
@@ -1830,7 +1831,7 @@ def _value_training_dpg(solver, D, gamma):
                 return _PendingInfo(row0, 2 * n, decode)
             if rc != L.EUNSUP:
                 ctx.check(rc)
-            solver._async_now = False
+            solver._async_now = False; solver._async_fell_back = True
         rq, ra = (np.zeros((n, L.INFO_N), np.float32) for _ in range(2))
         ctx.check(lib.crux_dpg_epochs(A.h, (Q.N1 if twin else Q).h, Q.N2.h if twin else None, Am.h, (Qm.N1 if twin else Qm).h, Qm.N2.h if twin else None, buf.h, D.h,
                                       float(gamma), float(solver.tau), sm.sigma if sm else -1.0, sm.eps_min if sm else 0.0, sm.eps_max if sm else 0.0, sm.a_min if sm else 0.0,
@@ -1920,7 +1921,7 @@ def value_training(solver, D, gamma):
                 return pend
             if rc != L.EUNSUP:
                 ctx.check(rc)
-            solver._async_now = False                  # narrow networks: the synchronous entry point from here on
+            solver._async_now = False; solver._async_fell_back = True      # narrow networks: the synchronous entry point from here on
         if solver.target_fn == "softq":      # softq_target(alpha) in place of dqn_target (rl/softq.jl:4-13)
             ctx.check(ctx.lib.crux_softq_epochs(pi.h, pim.h, buf.h, D.h, float(gamma), float(solver.P["alpha"]), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, _vp(raws)))
         else:
@@ -1956,12 +1957,33 @@ def value_training(solver, D, gamma):
     return {k: float(np.mean([d[k] for d in infos if k in d])) for k in keys}                          # aggregate_info: mean over the dicts that have the key (logging.jl:60-66)
 
 
+def value_training_async(solver, D, gamma):
+    """value_training without the host in the loop, for callers outside solve() (benchmarks): the chain is enqueued, its info rows stay in the solver's device ring and
+    are registered as pending, so `solver.history` (or `_resolve_history`) fetches them later. Falls back to the synchronous call (returns the info dict) where the
+    asynchronous entry point does not apply."""
+    solver._async_now = solver.async_training and not solver._async_unsupported
+    try:
+        tinfo = value_training(solver, D, gamma)
+    finally:
+        solver._async_unsupported = solver._async_unsupported or solver._async_fell_back
+        solver._async_now = False
+    if isinstance(tinfo, _PendingInfo):
+        solver._history.append(None); solver._pending.append((len(solver._history) - 1, tinfo.row0, tinfo.n, tinfo.decode, {}))
+    else:
+        solver._history.append(tinfo)
+    return tinfo
+
+
 def _info_ring(solver, ctx, nrows):
     """nrows rows of the solver's device info ring (fetching what is pending when it is full); returns the device address of the first one and its row index"""
     if solver._dinfos is None or solver._dinfos_used + nrows > solver._dinfos_rows:
         solver._resolve_history()
+        solver._dinfos_used = 0                    # whatever was pending has been fetched; rows handed to callers that never registered them (ADVICE r3) are dropped
         if solver._dinfos is None or nrows > solver._dinfos_rows:
+            ctx.sync()                             # chains already enqueued may still write the old ring
             solver._dinfos_rows = max(4096, 8 * nrows); solver._dinfos = ctx.alloc(4 * L.INFO_N * solver._dinfos_rows)
+    if solver._dinfos_used + nrows > solver._dinfos_rows:
+        raise RuntimeError("info ring: %d rows requested, %d of %d in use" % (nrows, solver._dinfos_used, solver._dinfos_rows))
     base = solver._dinfos.value if hasattr(solver._dinfos, "value") else int(solver._dinfos)
     return C.c_void_p(base + 4 * L.INFO_N * solver._dinfos_used), solver._dinfos_used
 
@@ -2036,11 +2058,15 @@ def _solve_off_policy(solver, mdp):
         it_info = {}
         # asynchronous chains when nothing on the host looks at an iteration's result before the next one starts: no logger, no callbacks, built-in seams
         solver._async_now = (solver.async_training and solver.log is None and solver.post_sample_callback is None and solver.pre_train_callback is None
-                             and not solver.custom_seams() and solver.fused_epochs and getattr(solver, "_async_now", True))
+                             and not solver.custom_seams() and solver.fused_epochs and not getattr(solver, "_async_unsupported", False))
         _post_sample(solver, solver.dN, it_info)                                                      # :138 cb = D -> S.post_sample_callback(D, S=S, info=info)
         if solver.pre_train_callback is not None:
             solver.pre_train_callback(solver, info=it_info)                                           # :140
-        tinfo = value_training(solver, D, gamma)                                                      # :143
+        try:
+            tinfo = value_training(solver, D, gamma)                                                  # :143
+        finally:
+            solver._async_unsupported = solver._async_unsupported or solver._async_fell_back      # CRUX_EUNSUP once: the synchronous entry point from here on
+            solver._async_now = False              # the request covers this call only: a later direct value_training(solver, ...) gets the info dict
         if isinstance(tinfo, _PendingInfo):          # the chain was only enqueued: the host goes on to the next iteration, `history` fetches the rows when asked
             solver._history.append(None); solver._pending.append((len(solver._history) - 1, tinfo.row0, tinfo.n, tinfo.decode, dict(it_info)))
         else:
