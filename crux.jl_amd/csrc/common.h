@@ -212,7 +212,11 @@ int32_t crux_mlp_forward_multi_impl(crux_ctx* c, const NetDesc& nd, const crux_f
 int32_t crux_comm_allreduce_mean_impl(crux_ctx* c, crux_mlp* const* nets, int n_nets);   // comm.hip
 // dense.hip: differentiable Chain(Dense...) on the tile-GEMM engine
 int32_t crux_dense_forward(crux_mlp* n, const float* d_x, int64_t B, hipStream_t st);
-int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st);
+// Layer 0's weight / bias gradient left as four quarter partials by Dgrad2W1Op (dense_fused.h) for up to two networks: Sumsq2Op, the reader that follows every pullback
+// of a train! step, forms and stores the final values while it sums the squares. part == nullptr: nothing deferred for that network.
+struct Sumsq2Fix { const float* part[2]; int32_t out1[2], in0[2], woff[2], boff[2]; float scale[2]; };
+// defer (slot of a Sumsq2Fix the caller passes to the Sumsq2Op that follows, or NULL): permits the fused pullback of layers 1 / 0, whose layer-0 gradient is completed by that op
+int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st, Sumsq2Fix* defer = nullptr, int defer_slot = 0);
 float* crux_dense_act(crux_mlp* n, int l);
 int32_t crux_td_step_dense(crux_mlp* net, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out, float* d_err);   // sac.hip
 #define CRUX_DENSE_MIN_WIDTH 128   // networks at least this wide go through the multi-CU dense engine

@@ -133,6 +133,12 @@ struct GemmOp { static __device__ __forceinline__ void run(const unsigned bid_, 
     case 4: Gemm16<false, false, true>::run(bid_, q, part); break;  case 5: Gemm16<true, false, true>::run(bid_, q, part); break;
     case 6: Gemm16<false, true, true>::run(bid_, q, part); break;   default: Gemm16<true, true, true>::run(bid_, q, part); break; } } };
 
+#include "dense_fused.h"
+// CRUX_DENSE_FUSED=0: every layer through its own Gemm16 launch (the round-3 chains; tests compare the two forms bit for bit). Read once.
+static bool dense_fused_on() { static const bool on = !(getenv("CRUX_DENSE_FUSED") && getenv("CRUX_DENSE_FUSED")[0] == '0'); return on; }
+bool crux_dense_fwd_fused(const crux_mlp* n) { return dense_fused_on() && df_fwd12_ok(n->nd); }                      // layers 0 + 1 in one launch (exec.hip's phase plans ask)
+bool crux_dense_bwd_fused(const crux_mlp* n, int64_t B) { return dense_fused_on() && df_bwd_ok(n->nd, B); }        // layer 1's dW beside (layer 1's dX -> layer 0's dW) in one phase
+
 // dZ = act'(Y) .* dY for the output layer
 struct ActGradOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ dy, const float* __restrict__ y, int act, int64_t n, float* __restrict__ dz) {
   const int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x; if (i >= n) return;
@@ -180,12 +186,17 @@ static int32_t ensure_ws(crux_mlp* n, int64_t B) {
   int64_t cap = 256; while (cap < B) cap *= 2;
   size_t tot = 0; for (int l = 1; l <= n->nd.L; ++l) tot += (size_t)n->nd.dims[l] * (size_t)cap;
   tot += 2 * (size_t)n->nd.maxdim * (size_t)cap;
+  if (n->nd.L >= 2) tot += 4 * (size_t)n->nd.dims[1] * (size_t)(n->nd.dims[0] + 4);      // quarter partials of layer 0's gradient (Dgrad2W1Op)
   if (hipMalloc(&n->ws, sizeof(float) * tot + 64) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "dense workspace: hipMalloc(%zu) failed", sizeof(float) * tot);
   n->ws_B = cap; return CRUX_OK;
 }
 float* crux_dense_act(crux_mlp* n, int l) {   // l in 1..L
   size_t off = 0; for (int q = 1; q < l; ++q) off += (size_t)n->nd.dims[q] * (size_t)n->ws_B;
   return n->ws + off;
+}
+static float* ws_part(crux_mlp* n) {      // behind the two delta buffers
+  size_t off = 0; for (int q = 1; q <= n->nd.L; ++q) off += (size_t)n->nd.dims[q] * (size_t)n->ws_B;
+  return n->ws + off + 2 * (size_t)n->nd.maxdim * (size_t)n->ws_B;
 }
 static float* ws_delta(crux_mlp* n, int which) {
   size_t off = 0; for (int q = 1; q <= n->nd.L; ++q) off += (size_t)n->nd.dims[q] * (size_t)n->ws_B;
@@ -197,8 +208,15 @@ int32_t crux_dense_forward(crux_mlp* n, const float* d_x, int64_t B, hipStream_t
   if (nd.L < 1) return crux_fail(c, CRUX_EINVAL, "forward: the handle has no layers");
   if (B < 1 || B > (1 << 20)) return crux_fail(c, CRUX_EINVAL, "forward: batch %lld out of range", (long long)B);
   int32_t rc = ensure_ws(n, B); if (rc) return rc;
-  const float* x = d_x;
-  for (int l = 0; l < nd.L; ++l) {
+  const float* x = d_x; int l0 = 0;
+  if (crux_dense_fwd_fused(n)) {      // layers 0 and 1 as one launch (dense_fused.h)
+    Fwd12Args a{}; a.W1 = n->p + nd.woff[0]; a.b1 = n->p + nd.boff[0]; a.W2 = n->p + nd.woff[1]; a.b2 = n->p + nd.boff[1]; a.x = d_x; a.H1 = crux_dense_act(n, 1); a.H2 = crux_dense_act(n, 2);
+    a.in0 = nd.dims[0]; a.out1 = nd.dims[1]; a.out2 = nd.dims[2]; a.B = (int32_t)B; a.act1 = nd.acts[0]; a.act2 = nd.acts[1];
+    CRUX_RUN(c, Fwd12Op, OP_FWD12, k_fwd12, df_fwd12_blocks(nd, B), 256, st, a);
+    rc = crux_launch_check(c, "k_fwd12"); if (rc) return rc;
+    x = a.H2; l0 = 2;
+  }
+  for (int l = l0; l < nd.L; ++l) {
     const int in = nd.dims[l], out = nd.dims[l + 1];
     GemmArgs q{}; q.A = n->p + nd.woff[l]; q.sAi = 1; q.sAk = out; q.B = x; q.sBk = 1; q.sBj = in; q.M = out; q.N = (int)B; q.K = in;
     q.C = crux_dense_act(n, l + 1); q.sCj = out; q.epi = EPI_FWD; q.bias = n->p + nd.boff[l]; q.act = nd.acts[l];
@@ -209,7 +227,7 @@ int32_t crux_dense_forward(crux_mlp* n, const float* d_x, int64_t B, hipStream_t
 }
 
 // Reverse pass after crux_dense_forward(n, d_x, B) with the same d_x. d_dy [out_L x B] is not modified.
-int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st) {
+int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st, Sumsq2Fix* defer, int defer_slot) {
   crux_ctx* c = n->ctx; const NetDesc& nd = n->nd;
   if (nd.L < 1 || !n->ws || n->ws_B < B) return crux_fail(c, CRUX_EINVAL, "backward: no cached forward pass for this batch");
   const float* dcur = d_dy; float* dnxt = ws_delta(n, 0); float* dspare = ws_delta(n, 1);
@@ -218,9 +236,24 @@ int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const floa
     CRUX_RUN(c, ActGradOp, OP_ACT_GRAD, k_act_grad, (unsigned)((cnt + 255) / 256), 256, st, d_dy, crux_dense_act(n, nd.L), nd.acts[nd.L - 1], cnt, dnxt);
     dcur = dnxt; dnxt = dspare; dspare = const_cast<float*>(dcur);
   }
+  // with parameter gradients the fused pair leaves layer 0's gradient as quarter partials: only where the caller runs Sumsq2Op next (defer); input-gradient chains need no such reader
+  const bool fused = crux_dense_bwd_fused(n, B) && (!want_g || defer != nullptr);
   for (int l = nd.L - 1; l >= 0; --l) {
     const int in = nd.dims[l], out = nd.dims[l + 1];
     const float* x = l == 0 ? d_x : crux_dense_act(n, l);
+    if (fused && l == 1) {      // layers 1 and 0 together (dense_fused.h): dW1' = dcur X1' | dX1 = act0'(X1) .* (W1'' dcur) -> layer 0's dW, db inside the same workgroups
+      if (want_g) { Wgrad2Args w{}; w.dZ = dcur; w.X = x; w.dW = n->g + nd.woff[1]; w.db = n->g + nd.boff[1]; w.scale = gscale; w.out = out; w.in = in; w.B = (int32_t)B;
+        CRUX_RUN(c, Wgrad2Op, OP_WGRAD2, k_wgrad2, (unsigned)((out >> 5) * (in >> 5)), 256, st, w); }
+      Dgrad2Args a{}; a.W2 = n->p + nd.woff[1]; a.dZ2 = dcur; a.H1 = x; a.x = d_x; a.part = ws_part(n); a.dZ1 = d_dx ? dnxt : nullptr;
+      a.in0 = nd.dims[0]; a.out1 = in; a.out2 = out; a.B = (int32_t)B; a.act0 = nd.acts[0]; a.want_g = want_g ? 1 : 0;
+      CRUX_RUN(c, Dgrad2W1Op, OP_DGRAD2W1, k_dgrad2w1, (unsigned)((in >> 4) * 4), 256, st, a);
+      if (want_g) { defer->part[defer_slot] = a.part; defer->out1[defer_slot] = in; defer->in0[defer_slot] = nd.dims[0]; defer->woff[defer_slot] = nd.woff[0]; defer->boff[defer_slot] = nd.boff[0]; defer->scale[defer_slot] = gscale; }
+      if (d_dx) {                // the input gradient of layer 0 from the dZ of layer 0 the fused op left in the workspace
+        GemmArgs q{}; q.A = n->p + nd.woff[0]; q.sAi = in; q.sAk = 1; q.B = dnxt; q.sBk = 1; q.sBj = in; q.M = nd.dims[0]; q.N = (int)B; q.K = in;
+        q.C = d_dx; q.sCj = nd.dims[0]; q.epi = EPI_BWD_DATA; q.ysrc = nullptr; q.act = CRUX_ACT_IDENTITY;
+        int32_t rc = launch_gemm(c, q, st); if (rc) return rc; }
+      break;
+    }
     if (want_g) {
       GemmArgs q{}; q.A = dcur; q.sAi = 1; q.sAk = out; q.B = x; q.sBk = in; q.sBj = 1; q.M = out; q.N = in; q.K = (int)B;
       q.C = n->g + nd.woff[l]; q.sCj = out; q.epi = EPI_WGRAD; q.scale = gscale; q.gbias = n->g + nd.boff[l];   // db rides along in the first column tile

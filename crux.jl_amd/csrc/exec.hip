@@ -87,6 +87,9 @@ __device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigne
         case OP_COPY_F32: DISPATCH<CopyF32Op>(op, b); break; \
         case OP_ADAM_ADVANCE: DISPATCH<AdamAdvanceOp>(op, b); break; \
         case OP_SOFTQ_TARGET: DISPATCH<SoftqTargetOp>(op, b); break; \
+        case OP_FWD12: DISPATCH<Fwd12Op>(op, b); break; \
+        case OP_WGRAD2: DISPATCH<Wgrad2Op>(op, b); break; \
+        case OP_DGRAD2W1: if constexpr (EXEC_HEAVY) { DISPATCH<Dgrad2W1Op>(op, b); } break; \
         default: break; \
       }
 
@@ -96,6 +99,7 @@ __device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigne
       switch (kid) { \
         case OP_TD_HEAD: DISPATCH<TdHeadOp>(op, b); break; \
         case OP_Q_HEAD: DISPATCH<QHeadOp>(op, b); break; \
+        case OP_PER_UPDATE: DISPATCH<PerUpdateOp>(op, b); break; \
         default: break; \
       }
 
@@ -123,7 +127,10 @@ template <class Op> __device__ __forceinline__ void exec_dispatch_g(const ExecOp
 // One PHASE of a recorded sequence as one launch over the whole chip: block x of the grid belongs to the op whose block range contains x. The ops of a
 // phase do not depend on each other, the dependency between phases is the kernel boundary -- no in-kernel barrier, no coherence question, all 256 CUs.
 // A fused epoch then costs (number of phases) launches instead of (number of kernels): 13 instead of 25 for a DQN epoch, 30 instead of ~75 for SAC (10 / 27 per epoch inside a chain).
+// EXEC_HEAVY: the register-hungry op bodies (Dgrad2W1Op: ~300 VGPRs) are compiled into the HEAVY instantiations only; a phase without such an op runs the light
+// kernel (~100 VGPRs: four workgroups per CU instead of one -- a phase of 500-800 light blocks then takes one round over the chip instead of three)
 __global__ __launch_bounds__(256) void k_phase(const ExecOp* __restrict__ ops, int n) {
+  constexpr bool EXEC_HEAVY = true;
   // ops flagged sequential (barrier bit 1) own no blocks: they run in the block of the op before them, after it (see k_phase_k)
   unsigned b = blockIdx.x; int o = 0;
   for (;;) { const unsigned nb = (ops[o].barrier & 2) ? 0u : ops[o].nblocks; if (o + 1 < n && b >= nb) { b -= nb; ++o; } else break; }
@@ -152,7 +159,7 @@ template <> __device__ __forceinline__ void exec_dispatch_k<GatherRingAllOp>(con
   using P = OpPack<GatherRingAllOp>; const P* pp = (const P*)op->args;
   GatherRingAllOp::run_ptr(bid, op->nblocks, &pp->head, pp->tail.head, pp->tail.tail.head, pp->tail.tail.tail.head, pp->tail.tail.tail.tail.head);
 }
-template <int BYTES>
+template <int BYTES, bool EXEC_HEAVY>
 __global__ __launch_bounds__(256) void k_phase_k(PhaseK<BYTES> by_value) {
   // read through the kernel-argument segment pointer, not through the by-value parameter: indexing the parameter at a run-time offset would make the compiler
   // copy the aggregate to private memory first
@@ -179,7 +186,9 @@ template <int BYTES> static bool phasek_launch(const std::vector<ExecOp>& ops, s
     pk.kid[pk.n] = e.kid | (seq ? PHASEK_SEQ : 0); pk.nblocks[pk.n] = seq ? 0u : e.nblocks; pk.off[pk.n] = (uint32_t)used; memcpy(pk.args + used, e.args, raw); used += ab; pk.n++; }
   if (pk.n == 0) return false;
   for (int q = pk.n; q < PHASEK_MAXOPS; ++q) { pk.kid[q] = 0; pk.nblocks[q] = 0; pk.off[q] = 0; }
-  hipLaunchKernelGGL(k_phase_k<BYTES>, dim3(blocks), dim3(256), 0, st, pk);
+  bool heavy = false; for (int q = 0; q < pk.n; ++q) heavy = heavy || (pk.kid[q] & (PHASEK_SEQ - 1)) == OP_DGRAD2W1;
+  if (heavy) hipLaunchKernelGGL((k_phase_k<BYTES, true>), dim3(blocks), dim3(256), 0, st, pk);
+  else hipLaunchKernelGGL((k_phase_k<BYTES, false>), dim3(blocks), dim3(256), 0, st, pk);
   return true;
 }
 // would phasek_launch<3840> take ops [i0, i1]? (the same packing rules, nothing launched)
@@ -191,7 +200,8 @@ static bool phasek_fits(const std::vector<ExecOp>& ops, size_t i0, size_t i1) {
     used += ab; ++n; }
   return n > 0;
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_exec(const ExecOp* __restrict__ ops, int nops, unsigned* ctr, int xcd, int32_t* status, int flags) {
+__global__ __launch_bounds__(256) void k_exec(const ExecOp* __restrict__ ops, int nops, unsigned* ctr, int xcd, int32_t* status, int flags) {
+  constexpr bool EXEC_HEAVY = true;
   if (xcd >= 0 && (int)(blockIdx.x & 7) != xcd) return;
   const unsigned wg = xcd >= 0 ? blockIdx.x >> 3 : blockIdx.x, G = xcd >= 0 ? gridDim.x >> 3 : gridDim.x;
   // op records are staged through LDS one op ahead: the 512-byte record of op o+1 is fetched while op o runs and its barrier is waited for, so
@@ -257,7 +267,7 @@ static int32_t dqp_build(ExecRec* r) {        // the replay table; CRUX_EUNSUP w
         case OP_LEAF_REFRESH: if (!head) return CRUX_EUNSUP; Cs.push_back({1, (int)i}); break;
         case OP_TREE_TOUCH: if (!head) return CRUX_EUNSUP; Cs.push_back({2, (int)i}); break;
         case OP_TD_HEAD: head = true; break;
-        case OP_GEMM: case OP_DQN_TARGET: case OP_SUMSQ2: case OP_TD_INFO: case OP_ADAM_GATED: case OP_ADAM_ADVANCE: break;      // the learner kernel's work
+        case OP_GEMM: case OP_FWD12: case OP_WGRAD2: case OP_DGRAD2W1: case OP_DQN_TARGET: case OP_SUMSQ2: case OP_TD_INFO: case OP_ADAM_GATED: case OP_ADAM_ADVANCE: break;      // the learner kernel's work
         default: return CRUX_EUNSUP; } }
     if (!head || A.empty()) return CRUX_EUNSUP;
     auto emit = [&](std::vector<std::pair<int, int>>& v, int slot) {
@@ -368,11 +378,18 @@ static int32_t exec_schedule(crux_ctx* c, const std::vector<int>& phase) {
   for (size_t k = 0; k < n; ++k) { out[k] = r->ops[idx[k]]; out[k].barrier = (k + 1 == n || (phase[idx[k + 1]] >> 2) != (phase[idx[k]] >> 2)) ? 1 : 0;
     if ((phase[idx[k]] & 3) == 2) {
       // the in-block tail switch (EXEC_SWITCH_TAIL) knows these bodies only: anything else would be skipped silently
-      if (out[k].kid != OP_TD_HEAD && out[k].kid != OP_Q_HEAD) return crux_fail(c, CRUX_EHIP, "executor: op %d cannot run as a sequential tail", out[k].kid);
+      if (out[k].kid != OP_TD_HEAD && out[k].kid != OP_Q_HEAD && out[k].kid != OP_PER_UPDATE) return crux_fail(c, CRUX_EHIP, "executor: op %d cannot run as a sequential tail", out[k].kid);
       if (k == 0 || (phase[idx[k - 1]] >> 2) != (phase[idx[k]] >> 2) || out[k].nblocks != 1 || out[k - 1].nblocks != 1) return crux_fail(c, CRUX_EHIP, "executor: a sequential op without a one-block predecessor in its phase");
       out[k].barrier |= 2; } }
   r->ops.swap(out); return CRUX_OK;
 }
+// launches of the dense engine inside a recorded chain: a tile GEMM, or one of the fused block kernels of dense_fused.h (round 4). The phase plans below count THESE
+// in recording order; a network's forward pass is nf of them (nf = L, or L - 1 when layers 0 + 1 are one Fwd12Op), its pullback with parameter gradients 2 L - 1
+// (weight + data gradient per layer, no data gradient for layer 0) in L phases -- or 2 (L - 1) in L - 1 phases when Wgrad2Op || Dgrad2W1Op take layers 1 and 0 together.
+static inline bool is_mm(int kid) { return kid == OP_GEMM || kid == OP_FWD12 || kid == OP_WGRAD2 || kid == OP_DGRAD2W1; }
+struct NetPlan { int nf, nbops, nb; };
+static inline NetPlan net_plan(const crux_mlp* n, int64_t B) { const int L = n->nd.L; const bool ff = crux_dense_fwd_fused(n), fb = crux_dense_bwd_fused(n, B);
+  return NetPlan{ff ? L - 1 : L, fb ? 2 * (L - 1) : 2 * L - 1, fb ? L - 1 : L}; }
 #define PH_SEQ_HEAD (1 << 12)
 #define PH_SEQ_TAIL (2 << 12)
 static inline int ph_tag(int p_mapped, int sub) { return 4 * p_mapped + sub; }
@@ -530,14 +547,25 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   // The overlap is bounded by the replay tree: update_priorities! -> leaf re-sum -> root paths of epoch e sit at phases 4+L-sq .. 6+L-sq and read batch->d_indices / write
   // the tree total, which the search of epoch e + 1 (phase 4+2L-sq with the full overlap of three) rewrites and probes. With fewer than three Dense layers the backward
   // chain is too short to cover them, so the overlap shrinks to L phases there (search(e + 1) strictly after the root paths of e).
-  const int ov = (per && Ld < 3) ? (Ld < 1 ? 1 : Ld) : 3;
+  // Round 4 (dense_fused.h): a network whose first two layers run as ONE forward launch (Fwd12Op) has nf = Ld - 1 forward launches, and one whose layer-1 / layer-0
+  // pullback runs as one phase (Wgrad2Op || Dgrad2W1Op) nb = Ld - 1 backward phases; the plan below is written in nf, nb. With the sequential group (sq) the replay
+  // chain starts INSIDE the head's block: update_priorities! is a second sequential tail behind the td head (one block, reads the head's td errors), so the leaf
+  // re-sum and the root paths sit at 3 + nf and 4 + nf, and the search of epoch e + 1 (phase 7 + nf + nb - sq - ov of this epoch) stays behind the root paths as long
+  // as ov <= nb + 1; without the group the chain is update | leaf | paths at 4 + nf - sq .., and ov <= nb as before.
+  const bool ffw = crux_dense_fwd_fused(net), fbw = crux_dense_bwd_fused(net, B);
+  const int nf = ffw ? Ld - 1 : Ld, nb = fbw ? Ld - 1 : Ld;
+  const int sq0 = (B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;
+  const bool tailp = per && sq0 == 1;
+  const int ovmax = tailp ? nb + 1 : nb;
+  const int ov = per ? (ovmax < 1 ? 1 : (ovmax < 3 ? ovmax : 3)) : 3;
   auto tag = [&](size_t from, auto&& rule) { if (!fuse || !crux_exec_recording(c)) return; ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
     for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { plan_ok = false; p = 0; }
       const int sub = p >> 12; p &= 4095;
       ph.push_back(ph_tag(base > 0 ? (p < 2 ? base - ov + p : base + p - ov) : p, sub)); } };
   // the target (one block at B <= 256) and the loss head (one block) are a sequential pair: the head runs in the target's block, right after it, and every later
   // phase moves up by one (sq). Not in the persistent one-XCD form, whose workgroups walk the ops of a phase in lockstep.
-  const int sq = (B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;
+  const int sq = sq0;
+  if (crux_dense_fwd_fused(target_net) != ffw) plan_ok = false;
   rc = piece(1); if (rc) return bail(rc);
   const size_t ops0 = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;      // first op of THIS epoch (a chained recording already holds the earlier epochs)
   if (fuse && crux_exec_recording(c) && rec_of(c)->chain) rec_of(c)->epoch_marks.push_back(ops0);
@@ -547,26 +575,30 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   rc = piece(2); if (rc) return bail(rc);
   m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
   rc = softq_alpha > 0.f ? crux_softq_target(target_net, batch, gamma, softq_alpha, d_y) : crux_dqn_target(target_net, batch, gamma, d_y); if (rc) return bail(rc);      // softq_target(alpha) (rl/softq.jl:4-13) | dqn_target (rl/dqn.jl:4-6)
-  tag(m, [&](int kid, int& g) { return kid == OP_GEMM ? (g < Ld ? 2 + g++ : -1) : (kid == OP_DQN_TARGET || kid == OP_SOFTQ_TARGET) ? (2 + Ld) | (sq ? PH_SEQ_HEAD : 0) : -1; });
+  tag(m, [&](int kid, int& g) { if (kid == OP_FWD12) { g = 1; return 2; }
+    return kid == OP_GEMM ? (g < nf ? 2 + g++ : -1) : (kid == OP_DQN_TARGET || kid == OP_SOFTQ_TARGET) ? (2 + nf) | (sq ? PH_SEQ_HEAD : 0) : -1; });
   rc = piece(4); if (rc) return bail(rc);
   m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
   auto td_rule = [&](int kid, int& g) {      // g counts the GEMMs: Ld forward, then (weight, data) pairs from the last layer down, the first layer has no data gradient
     if (kid == OP_FILL) return 1;
-    if (kid == OP_GEMM) { const int k = g++; if (k < Ld) return 2 + k; const int j = (k - Ld) / 2; return j < Ld ? 4 + Ld + j - sq : -1; }
-    if (kid == OP_TD_HEAD) return sq ? ((2 + Ld) | PH_SEQ_TAIL) : 3 + Ld;
-    if (kid == OP_SUMSQ2) return 4 + 2 * Ld - sq; if (kid == OP_TD_INFO || kid == OP_ADAM_GATED) return 5 + 2 * Ld - sq; if (kid == OP_ADAM_ADVANCE) return 6 + 2 * Ld - sq;
+    if (kid == OP_FWD12) { g = 1; return 2; }
+    if (kid == OP_GEMM) { const int k = g++; if (k < nf) return 2 + k; const int j = (k - nf) / 2; return j < nb ? 4 + nf + j - sq : -1; }
+    if (kid == OP_WGRAD2 || kid == OP_DGRAD2W1) return 3 + nf + nb - sq;      // the last backward phase: layer 1's dW beside layer 1's dX -> layer 0's dW
+    if (kid == OP_TD_HEAD) return sq ? ((2 + nf) | PH_SEQ_TAIL) : 3 + nf;
+    if (kid == OP_SUMSQ2) return 4 + nf + nb - sq; if (kid == OP_TD_INFO || kid == OP_ADAM_GATED) return 5 + nf + nb - sq; if (kid == OP_ADAM_ADVANCE) return 6 + nf + nb - sq;
     return -1; };
   if (per) { rc = crux_td_step_with_error(net, batch, d_y, use_weight, d_err, info_out); if (rc) return bail(rc);
     tag(m, td_rule);
     rc = piece(8); if (rc) return bail(rc);
     m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
     rc = crux_per_update_device(source, batch->d_indices, d_err, B); if (rc) return bail(rc);
-    tag(m, [&](int kid, int&) { return kid == OP_PER_UPDATE ? 4 + Ld - sq : kid == OP_LEAF_REFRESH ? 5 + Ld - sq : kid == OP_TREE_TOUCH ? 6 + Ld - sq : -1; }); }
+    tag(m, [&](int kid, int&) { if (tailp) return kid == OP_PER_UPDATE ? ((2 + nf) | PH_SEQ_TAIL) : kid == OP_LEAF_REFRESH ? 3 + nf : kid == OP_TREE_TOUCH ? 4 + nf : -1;
+      return kid == OP_PER_UPDATE ? 4 + nf - sq : kid == OP_LEAF_REFRESH ? 5 + nf - sq : kid == OP_TREE_TOUCH ? 6 + nf - sq : -1; }); }
   else { rc = crux_td_step(net, batch, d_y, use_weight, info_out); if (rc) return bail(rc); tag(m, td_rule); }
   if (fuse && crux_exec_recording(c) && rec_of(c)->chain) {     // chained: the caller (crux_dqn_epochs) schedules and runs the whole list
     ExecRec* r = rec_of(c);
     if (!(plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += (r->chain_base > 0 ? 7 - ov : 7) + 2 * Ld - sq;
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += (r->chain_base > 0 ? 7 - ov : 7) + nf + nb - sq;
     return CRUX_OK;
   }
   if (fuse && crux_exec_recording(c) && plan_ok && !eager_mask && target_net->nd.L == Ld && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
@@ -695,8 +727,12 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   // sq: sac_target (one block at B <= 256) and the critic heads (one block each) form a sequential group in ONE block of phase X when the critics train; the critic
   // chain and everything behind it (Y ..) then sit one phase earlier. The temperature chain (X .. X + 3) is independent of it.
   const int sq = (update_critic && B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;
-  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, X = 3 + LA + LQ, Y = X + 4 + LQ - sq;
-  if (LA != LQ || q2->nd.L != LQ || q1_targ->nd.L != LQ || q2_targ->nd.L != LQ) plan_ok = false;       // (the early actor forward needs X + 1 + LA < Y, i.e. LA < LQ + 3)
+  // Round 4: written in launches -- FA / FQ forward launches of the actor / a critic, BQ / BA phases of a pullback with parameter gradients (BQo ops per critic), LQ phases
+  // of a critic's input-gradient chain; with the fused block kernels FA = FQ = L - 1 and BQ = BA = L - 1 (net_plan above), otherwise all equal L as in round 3.
+  const NetPlan pa = net_plan(actor, B), pq = net_plan(q1, B);
+  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, FA = pa.nf, FQ = pq.nf, BQ = pq.nb, BQo = pq.nbops, BA = pa.nb, X = 3 + FA + FQ, Y = X + 4 + BQ - sq;
+  if (LA != LQ || q2->nd.L != LQ || q1_targ->nd.L != LQ || q2_targ->nd.L != LQ) plan_ok = false;       // (the early actor forward needs X + 1 + FA < Y)
+  { const NetPlan p2 = net_plan(q2, B), t1 = net_plan(q1_targ, B), t2 = net_plan(q2_targ, B); if (p2.nf != FQ || p2.nb != BQ || t1.nf != FQ || t2.nf != FQ || FA != FQ) plan_ok = false; }
   // chained epochs: phases 0 (ids) and 1 (gather, fills) of a later epoch run beside the previous epoch's actor norm and info + Adam (neither reads the batch), and its
   // phase 2 (actor(sp) forward, vcat(s, a): online networks only) beside the previous epoch's advance + polyak, which writes beta powers and TARGET networks: the rest
   // closes up by three -- see crux_dqn_epoch
@@ -710,19 +746,19 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   tag(m, [&](int kid, int&) { return kid == OP_UNIFORM_IDS ? 0 : kid == OP_GATHER_RING_ALL ? 1 : -1; });
   m = fuse ? exec_mark(c) : 0;
   rc = crux_sac_target(actor, q1_targ, q2_targ, log_alpha, batch, gamma, noise_seed, noise_counter0, d_y); if (rc) return bail(rc);
-  tag(m, [&](int kid, int& g) { if (kid == OP_GEMM) { const int k = g++; return k < LA ? 2 + k : 3 + LA + (k - LA) % LQ; }
-    return kid == OP_GAUSS_EXPLORE ? 2 + LA : kid == OP_SAC_TARGET ? X | (sq ? PH_SEQ_HEAD : 0) : -1; });
+  tag(m, [&](int kid, int& g) { if (is_mm(kid)) { const int k = g++; return k < FA ? 2 + k : 3 + FA + (k - FA) % FQ; }
+    return kid == OP_GAUSS_EXPLORE ? 2 + FA : kid == OP_SAC_TARGET ? X | (sq ? PH_SEQ_HEAD : 0) : -1; });
   m = fuse ? exec_mark(c) : 0;
   rc = crux_sac_temp_step(actor, log_alpha, batch, H_target, noise_seed, noise_counter0 + 1, info_temp); if (rc) return bail(rc);
-  tag(m, [&](int kid, int& g) { if (kid == OP_FILL) return 1; if (kid == OP_GEMM) { const int k = g++; return k < LA ? 3 + LA + k : -1; }
+  tag(m, [&](int kid, int& g) { if (kid == OP_FILL) return 1; if (is_mm(kid)) { const int k = g++; return k < FA ? 3 + FA + k : -1; }
     return kid == OP_GAUSS_EXPLORE ? X : kid == OP_TEMP_HEAD ? X + 1 : kid == OP_ADAM_GATED ? X + 2 : kid == OP_ADAM_ADVANCE ? X + 3 : -1; });
   if (update_critic) {
     m = fuse ? exec_mark(c) : 0;
     rc = crux_double_q_step(q1, q2, batch, d_y, use_weight, info_critic); if (rc) return bail(rc);
     tag(m, [&](int kid, int& g) {      // per critic: LQ forward GEMMs, head, then (weight, data) pairs from the last layer down (the first layer has no data gradient)
       if (kid == OP_FILL) return 1; if (kid == OP_CONCAT_SA) return 2;
-      if (kid == OP_GEMM) { const int k = (g++) % (3 * LQ - 1); return k < LQ ? 3 + k : X + 2 - sq + (k - LQ) / 2; }
-      return kid == OP_Q_HEAD ? (sq ? (X | PH_SEQ_TAIL) : X + 1) : kid == OP_SUMSQ2 ? X + 2 - sq + LQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 - sq + LQ : kid == OP_ADAM_ADVANCE ? X + 4 - sq + LQ : -1; });
+      if (is_mm(kid)) { const int k = (g++) % (FQ + BQo); return k < FQ ? 3 + k : X + 2 - sq + (k - FQ) / 2; }
+      return kid == OP_Q_HEAD ? (sq ? (X | PH_SEQ_TAIL) : X + 1) : kid == OP_SUMSQ2 ? X + 2 - sq + BQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 - sq + BQ : kid == OP_ADAM_ADVANCE ? X + 4 - sq + BQ : -1; });
   }
   if (update_actor) {
     m = fuse ? exec_mark(c) : 0;
@@ -731,20 +767,20 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
       if (kid == OP_FILL) return 1;
       // the actor's own forward pass and its exploration draw depend on neither the critic update nor the temperature: they run beside the critic's head / backward
       // phases (X + 1 ..), after the temperature step's last read of the actor's activations (its exploration at X)
-      if (kid == OP_GEMM) { const int k = g++; if (k < LA) return X + 1 + k; if (k < LA + 2 * LQ) return Y + (k - LA) % LQ;
-        if (k < LA + 4 * LQ) return Y + 1 + LQ + (k - LA - 2 * LQ) % LQ; return Y + 2 + 2 * LQ + (k - LA - 4 * LQ) / 2; }
-      return kid == OP_GAUSS_EXPLORE ? X + 1 + LA : kid == OP_ACTOR_HEAD ? Y + LQ : kid == OP_ACTOR_GRAD ? Y + 1 + 2 * LQ : kid == OP_ROWSUM ? Y + 2 + 2 * LQ :
-             kid == OP_SUMSQ2 ? Y + LA + 2 + 2 * LQ : (kid == OP_ACTOR_INFO || kid == OP_ADAM_GATED) ? Y + LA + 3 + 2 * LQ : kid == OP_ADAM_ADVANCE ? Y + LA + 4 + 2 * LQ : -1; });
+      if (is_mm(kid)) { const int k = g++; if (k < FA) return X + 1 + k; if (k < FA + 2 * FQ) return Y + (k - FA) % FQ;
+        if (k < FA + 2 * FQ + 2 * LQ) return Y + 1 + FQ + (k - FA - 2 * FQ) % LQ; return Y + 2 + FQ + LQ + (k - FA - 2 * FQ - 2 * LQ) / 2; }
+      return kid == OP_GAUSS_EXPLORE ? X + 1 + FA : kid == OP_ACTOR_HEAD ? Y + FQ : kid == OP_ACTOR_GRAD ? Y + 1 + FQ + LQ : kid == OP_ROWSUM ? Y + 2 + FQ + LQ :
+             kid == OP_SUMSQ2 ? Y + BA + 2 + FQ + LQ : (kid == OP_ACTOR_INFO || kid == OP_ADAM_GATED) ? Y + BA + 3 + FQ + LQ : kid == OP_ADAM_ADVANCE ? Y + BA + 4 + FQ + LQ : -1; });
     m = fuse ? exec_mark(c) : 0;
     if (actor_targ) { rc = crux_polyak(actor_targ, actor, tau); if (rc) return bail(rc); }
     rc = crux_polyak(q1_targ, q1, tau); if (rc) return bail(rc);
     rc = crux_polyak(q2_targ, q2, tau); if (rc) return bail(rc);
-    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + LA + 4 + 2 * LQ : -1; });
+    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + BA + 4 + FQ + LQ : -1; });
   }
   if (fuse && rec_of(c)->chain) {      // chained: crux_sac_epochs schedules and runs the whole list
     ExecRec* r = rec_of(c);
     if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + LA + 5 + 2 * LQ - (r->chain_base > 0 ? 3 : 0);
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + BA + 5 + FQ + LQ - (r->chain_base > 0 ? 3 : 0);
     return CRUX_OK;
   }
   if (fuse && plan_ok && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
@@ -850,9 +886,11 @@ static int32_t dpg_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* 
   //   3+LA.. target Q1 || Q2 forward (and, from 3: Q1 || Q2 forward on (s, a)) | X target | X+1 critic heads | X+2.. critic backward | norm | info, Adam | advance
   //   Y.. Q(s, mu(s)) forward | its input gradient | slice | actor backward | norm | info, Adam | advance, polyak
   const int sq = (update_critic && B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;      // target + critic head(s) as a sequential one-block group (see crux_sac_epoch)
-  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, X = 3 + LA + LQ, Y = X + 4 + LQ - sq;
+  const NetPlan pa = net_plan(actor, B), pq = net_plan(q1, B);      // launches per pass (see crux_sac_epoch)
+  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, FA = pa.nf, FQ = pq.nf, BQ = pq.nb, BQo = pq.nbops, BA = pa.nb, X = 3 + FA + FQ, Y = X + 4 + BQ - sq;
   const int ag = actor->nd.acts[LA - 1] != CRUX_ACT_IDENTITY ? 1 : 0;
   if (LA != LQ || actor_targ->nd.L != LA || q1_targ->nd.L != LQ || (q2 && q2->nd.L != LQ) || (q2_targ && q2_targ->nd.L != LQ)) plan_ok = false;
+  if (FA != FQ || net_plan(actor_targ, B).nf != FA || net_plan(q1_targ, B).nf != FQ || (q2 && (net_plan(q2, B).nf != FQ || net_plan(q2, B).nb != BQ)) || (q2_targ && net_plan(q2_targ, B).nf != FQ)) plan_ok = false;
   // chained epochs: the sampling of epoch e + 1 beside the actor's norm and info + Adam of epoch e; its phase 2 reads the TARGET actor, which polyak (last phase) writes,
   // so the rest closes up by two only
   auto tag = [&](size_t from, auto&& rule) { ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
@@ -865,36 +903,36 @@ static int32_t dpg_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* 
   tag(m, [&](int kid, int&) { return kid == OP_UNIFORM_IDS ? 0 : kid == OP_GATHER_RING_ALL ? 1 : -1; });
   m = exec_mark(c);
   rc = crux_dpg_target(actor_targ, q1_targ, q2_targ, batch, gamma, sigma, eps_min, eps_max, a_min, a_max, noise_seed, noise_counter, d_y); if (rc) return bail(rc);
-  tag(m, [&](int kid, int& g) { if (kid == OP_GEMM) { const int k = g++; return k < LA ? 2 + k : 3 + LA + (k - LA) % LQ; }
-    return kid == OP_DPG_ACTION ? 2 + LA : kid == OP_DPG_TARGET ? X | (sq ? PH_SEQ_HEAD : 0) : -1; });
+  tag(m, [&](int kid, int& g) { if (is_mm(kid)) { const int k = g++; return k < FA ? 2 + k : 3 + FA + (k - FA) % FQ; }
+    return kid == OP_DPG_ACTION ? 2 + FA : kid == OP_DPG_TARGET ? X | (sq ? PH_SEQ_HEAD : 0) : -1; });
   if (update_critic) {
     m = exec_mark(c);
     rc = q2 ? crux_double_q_step(q1, q2, batch, d_y, use_weight, info_critic) : crux_q_step(q1, batch, d_y, use_weight, info_critic); if (rc) return bail(rc);
     tag(m, [&](int kid, int& g) {      // per critic: LQ forward GEMMs, head, then (weight, data) pairs from the last layer down (the first layer has no data gradient)
       if (kid == OP_FILL) return 1; if (kid == OP_CONCAT_SA) return 2;
-      if (kid == OP_GEMM) { const int k = (g++) % (3 * LQ - 1); return k < LQ ? 3 + k : X + 2 - sq + (k - LQ) / 2; }
-      return kid == OP_Q_HEAD ? (sq ? (X | PH_SEQ_TAIL) : X + 1) : kid == OP_SUMSQ2 ? X + 2 - sq + LQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 - sq + LQ : kid == OP_ADAM_ADVANCE ? X + 4 - sq + LQ : -1; });
+      if (is_mm(kid)) { const int k = (g++) % (FQ + BQo); return k < FQ ? 3 + k : X + 2 - sq + (k - FQ) / 2; }
+      return kid == OP_Q_HEAD ? (sq ? (X | PH_SEQ_TAIL) : X + 1) : kid == OP_SUMSQ2 ? X + 2 - sq + BQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 - sq + BQ : kid == OP_ADAM_ADVANCE ? X + 4 - sq + BQ : -1; });
   }
   if (update_actor) {
     m = exec_mark(c);
     rc = crux_dpg_actor_step(actor, q1, batch, info_actor); if (rc) return bail(rc);
     tag(m, [&](int kid, int& g) {      // GEMMs: LA actor forward, LQ critic forward, LQ critic input gradients, then the actor's (weight, data) pairs
       if (kid == OP_FILL) return 1;      // the info / status rows and the constant dQ = -1 / B
-      if (kid == OP_GEMM) { const int k = g++; if (k < LA) return 2 + k; if (k < LA + LQ) return Y + (k - LA); if (k < LA + 2 * LQ) return Y + LQ + (k - LA - LQ);
-        return Y + 2 * LQ + 1 + ag + (k - LA - 2 * LQ) / 2; }
-      if (kid == OP_ACT_GRAD) return ag ? Y + 2 * LQ + 1 : -1;      // dZ = act'(mu) .* dmu of a bounded (tanh) action head, between the slice and the actor's backward GEMMs
-      return kid == OP_DPG_ACTION ? 2 + LA : kid == OP_SLICE_ROWS ? Y + 2 * LQ : kid == OP_SUMSQ2 ? Y + 2 * LQ + 1 + ag + LA : (kid == OP_MEAN_INFO || kid == OP_ADAM_GATED) ? Y + 2 * LQ + 2 + ag + LA :
-             kid == OP_ADAM_ADVANCE ? Y + 2 * LQ + 3 + ag + LA : -1; });
+      if (is_mm(kid)) { const int k = g++; if (k < FA) return 2 + k; if (k < FA + FQ) return Y + (k - FA); if (k < FA + FQ + LQ) return Y + FQ + (k - FA - FQ);
+        return Y + FQ + LQ + 1 + ag + (k - FA - FQ - LQ) / 2; }
+      if (kid == OP_ACT_GRAD) return ag ? Y + FQ + LQ + 1 : -1;      // dZ = act'(mu) .* dmu of a bounded (tanh) action head, between the slice and the actor's backward GEMMs
+      return kid == OP_DPG_ACTION ? 2 + FA : kid == OP_SLICE_ROWS ? Y + FQ + LQ : kid == OP_SUMSQ2 ? Y + FQ + LQ + 1 + ag + BA : (kid == OP_MEAN_INFO || kid == OP_ADAM_GATED) ? Y + FQ + LQ + 2 + ag + BA :
+             kid == OP_ADAM_ADVANCE ? Y + FQ + LQ + 3 + ag + BA : -1; });
     m = exec_mark(c);
     rc = crux_polyak(actor_targ, actor, tau); if (rc) return bail(rc);
     rc = crux_polyak(q1_targ, q1, tau); if (rc) return bail(rc);
     if (q2 && q2_targ) { rc = crux_polyak(q2_targ, q2, tau); if (rc) return bail(rc); }
-    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + 2 * LQ + 3 + ag + LA : -1; });
+    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + FQ + LQ + 3 + ag + BA : -1; });
   }
   ExecRec* r = rec_of(c);
   if (r->chain) {
     if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + 2 * LQ + 4 + ag + LA - (r->chain_base > 0 ? 2 : 0);
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + FQ + LQ + 4 + ag + BA - (r->chain_base > 0 ? 2 : 0);
     return CRUX_OK;
   }
   if (plan_ok && ph.size() == r->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }

@@ -138,17 +138,31 @@ struct TdInfoOp { static __device__ __forceinline__ void run(const unsigned bid_
 __global__ void k_td_info(const double* __restrict__ st, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) { TdInfoOp::run(blockIdx.x, gridDim.x, st, ssq, B, dinfo); }
 // sum of squares of up to two flat gradients (norm(grads), utils.jl:49-55: sqrt of the sum of per-tensor squared norms): 64 blocks of partial
 // sums, combined in block order by the last block to arrive (deterministic: the combine order is fixed, only who performs it varies)
-struct Sumsq2Op { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ g1, int64_t n1, const float* __restrict__ g2, int64_t n2, double* __restrict__ out /* [1..64] per-block partials; [0] is filled by ssq_finalize */) {
+// Layer-0 gradient entries a fused pullback left as quarter partials (Sumsq2Fix, common.h): element i of flat gradient `slot` is formed here -- the additions Gemm16's
+// split-K combine would have done, in its order -- and stored, by the one thread that sums its square.
+__device__ __forceinline__ float ssq_elem(float* g, int64_t i, const Sumsq2Fix& fx, int slot) {
+  const float* part = fx.part[slot];
+  if (!part) return g[i];
+  const int out1 = fx.out1[slot], in0 = fx.in0[slot], ps = in0 + 4; const int64_t w0 = fx.woff[slot], b0 = fx.boff[slot], qs = (int64_t)out1 * ps;
+  if (i >= w0 && i < w0 + (int64_t)out1 * in0) { const int64_t e = i - w0; const int f = (int)(e % out1), qc = (int)(e / out1); const float* p = part + (int64_t)f * ps + qc;
+    const float v = (((p[0] + p[qs]) + p[2 * qs]) + p[3 * qs]) * fx.scale[slot]; g[i] = v; return v; }
+  if (i >= b0 && i < b0 + out1) { const int f = (int)(i - b0); const float* p = part + (int64_t)f * ps + in0; float R[4];
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) R[gg] = ((p[gg] + p[qs + gg]) + p[2 * qs + gg]) + p[3 * qs + gg];
+    const float v = fx.scale[slot] * ((R[0] + R[1]) + (R[2] + R[3])); g[i] = v; return v; }
+  return g[i];
+}
+struct Sumsq2Op { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, float* __restrict__ g1, int64_t n1, float* __restrict__ g2, int64_t n2, double* __restrict__ out /* [1..64] per-block partials; [0] is filled by ssq_finalize */, Sumsq2Fix fx) {
   __shared__ double red[4];
   double s = 0;
-  for (int64_t i = (int64_t)bid_ * 256 + threadIdx.x; i < n1; i += (int64_t)SUMSQ_BLOCKS * 256) s += (double)g1[i] * (double)g1[i];
-  for (int64_t i = (int64_t)bid_ * 256 + threadIdx.x; i < n2; i += (int64_t)SUMSQ_BLOCKS * 256) s += (double)g2[i] * (double)g2[i];
+  for (int64_t i = (int64_t)bid_ * 256 + threadIdx.x; i < n1; i += (int64_t)SUMSQ_BLOCKS * 256) { const double v = (double)ssq_elem(g1, i, fx, 0); s += v * v; }
+  for (int64_t i = (int64_t)bid_ * 256 + threadIdx.x; i < n2; i += (int64_t)SUMSQ_BLOCKS * 256) { const double v = (double)ssq_elem(g2, i, fx, 1); s += v * v; }
   s = wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) out[1 + bid_] = ((red[0] + red[1]) + red[2]) + red[3];
 } };
-__global__ __launch_bounds__(256) void k_sumsq2(const float* __restrict__ g1, int64_t n1, const float* __restrict__ g2, int64_t n2, double* __restrict__ out /* [1..64] per-block partials; [0] is filled by ssq_finalize */) { Sumsq2Op::run(blockIdx.x, gridDim.x, g1, n1, g2, n2, out); }
+__global__ __launch_bounds__(256) void k_sumsq2(float* __restrict__ g1, int64_t n1, float* __restrict__ g2, int64_t n2, double* __restrict__ out /* [1..64] per-block partials; [0] is filled by ssq_finalize */, Sumsq2Fix fx) { Sumsq2Op::run(blockIdx.x, gridDim.x, g1, n1, g2, n2, out, fx); }
 struct CriticInfoOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const double* __restrict__ st1, const double* __restrict__ st2, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) { if (threadIdx.x != 0) return;
   ssq_finalize(ssq);
   dinfo[CRUX_INFO_LOSS] = (float)(0.5 * (st1[0] / (double)B) + 0.5 * (st2[0] / (double)B));
@@ -325,8 +339,9 @@ int32_t crux_td_step_dense(crux_mlp* net, crux_buffer* b, const float* d_y, int3
   const float* S = (const float*)b->col[CRUX_COL_S]; const float* w = use_weight ? (const float*)b->col[CRUX_COL_WEIGHT] : nullptr;
   int32_t rc = crux_dense_forward(net, S, B, c->stream); if (rc) return rc;
   CRUX_RUN(c, TdHeadOp, OP_TD_HEAD, k_td_head, 1, 256, c->stream, crux_dense_act(net, net->nd.L), (const uint8_t*)b->col[CRUX_COL_A], nout, d_y, w, B, dy, st, d_err);
-  rc = crux_dense_backward(net, S, B, dy, 1.0f, true, nullptr, c->stream); if (rc) return rc;
-  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, net->g, (int64_t)net->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+  Sumsq2Fix fx{};
+  rc = crux_dense_backward(net, S, B, dy, 1.0f, true, nullptr, c->stream, &fx, 0); if (rc) return rc;
+  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, net->g, (int64_t)net->nd.n_params, (float*)nullptr, (int64_t)0, ssq, fx);
   CRUX_RUN(c, TdInfoOp, OP_TD_INFO, k_td_info, 1, 1, c->stream, st, ssq, B, dinfo);
   rc = adam_gated(net, ssq, status); if (rc) return rc;
   return finish_step(c, dinfo, status, info_out, "td_loss");
@@ -378,13 +393,13 @@ static int32_t q_step_impl(crux_mlp* q1, crux_mlp* q2, crux_buffer* b, const flo
   { const int32_t rz = crux_exec_zero(c, dinfo, 256 * 7, c->stream); if (rz) return rz; }
   const float* w = use_weight ? (const float*)b->col[CRUX_COL_WEIGHT] : nullptr;
   CRUX_RUN(c, ConcatSaOp, OP_CONCAT_SA, k_concat_sa, nblk(B * (od + ad)), 256, c->stream, (const float*)b->col[CRUX_COL_S], (const float*)b->col[CRUX_COL_A], od, ad, B, sa);
-  crux_mlp* qs[2] = {q1, q2}; double* sts[2] = {st1, st2};
+  crux_mlp* qs[2] = {q1, q2}; double* sts[2] = {st1, st2}; Sumsq2Fix fx{};
   for (int t = 0; t < nq; ++t) {
     rc = crux_dense_forward(qs[t], sa, B, c->stream); if (rc) return rc;
     CRUX_RUN(c, QHeadOp, OP_Q_HEAD, k_q_head, 1, 256, c->stream, crux_dense_act(qs[t], qs[t]->nd.L), d_y, w, B, nq == 2 ? 0.5f : 1.0f, dys[t], sts[t]);
-    rc = crux_dense_backward(qs[t], sa, B, dys[t], 1.0f, true, nullptr, c->stream); if (rc) return rc;
+    rc = crux_dense_backward(qs[t], sa, B, dys[t], 1.0f, true, nullptr, c->stream, &fx, t); if (rc) return rc;
   }
-  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, q1->g, (int64_t)q1->nd.n_params, q2 ? q2->g : (const float*)nullptr, (int64_t)(q2 ? q2->nd.n_params : 0), ssq);
+  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, q1->g, (int64_t)q1->nd.n_params, q2 ? q2->g : (float*)nullptr, (int64_t)(q2 ? q2->nd.n_params : 0), ssq, fx);
   CRUX_RUN(c, CriticInfoOp, OP_CRITIC_INFO, k_critic_info, 1, 1, c->stream, st1, nq == 2 ? st2 : st1, ssq, B, dinfo);   // single Q: 0.5 l + 0.5 l = l
   rc = adam_gated(q1, ssq, st); if (rc) return rc;
   if (q2) { rc = adam_gated(q2, ssq, st); if (rc) return rc; }
@@ -416,7 +431,7 @@ int32_t crux_gail_d_step(crux_mlp* D, crux_buffer* ex, int64_t off_ex, int64_t n
   int32_t rc = crux_dense_forward(D, x, B, c->stream); if (rc) return rc;
   hipLaunchKernelGGL(k_gail_head, dim3(1), dim3(256), 0, c->stream, crux_dense_act(D, D->nd.L), n_ex, n_pi, dz, st2);
   rc = crux_dense_backward(D, x, B, dz, 1.0f, true, nullptr, c->stream); if (rc) return rc;
-  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, D->g, (int64_t)D->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, D->g, (int64_t)D->nd.n_params, (float*)nullptr, (int64_t)0, ssq, Sumsq2Fix{});
   hipLaunchKernelGGL(k_gail_info, dim3(1), dim3(1), 0, c->stream, st2, ssq, n_ex, n_pi, dinfo);
   rc = adam_gated(D, ssq, st); if (rc) return rc;
   return finish_step(c, dinfo, st, info_out, "gail_d_loss");
@@ -475,8 +490,9 @@ int32_t crux_dpg_actor_step(crux_mlp* actor, crux_mlp* q, crux_buffer* b, float*
   CRUX_RUN(c, FillOp, OP_FILL, k_fill, nblk(B), 256, c->stream, dy, -1.f / (float)B, B);                    // d(-mean(Q))/dQ
   rc = crux_dense_backward(q, sa, B, dy, 1.0f, false, dsa, c->stream); if (rc) return rc;                        // the critic's parameters are not trained here
   CRUX_RUN(c, SliceRowsOp, OP_SLICE_ROWS, k_slice_rows, nblk(B * ad), 256, c->stream, dsa, sd, od, ad, B, da);
-  rc = crux_dense_backward(actor, S, B, da, 1.0f, true, nullptr, c->stream); if (rc) return rc;
-  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, actor->g, (int64_t)actor->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+  Sumsq2Fix fx{};
+  rc = crux_dense_backward(actor, S, B, da, 1.0f, true, nullptr, c->stream, &fx, 0); if (rc) return rc;
+  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, actor->g, (int64_t)actor->nd.n_params, (float*)nullptr, (int64_t)0, ssq, fx);
   CRUX_RUN(c, MeanInfoOp, OP_MEAN_INFO, k_mean_info, 1, 256, c->stream, crux_dense_act(q, q->nd.L), B, -1.f, ssq, dinfo);
   rc = adam_gated(actor, ssq, st); if (rc) return rc;
   return finish_step(c, dinfo, st, info_out, "ddpg_actor_loss");
@@ -503,9 +519,10 @@ int32_t crux_sac_actor_step(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_ml
   rc = crux_dense_backward(q1, sa, B, dy1, 1.0f, false, dsa1, c->stream); if (rc) return rc;     // gradient w.r.t. vcat(s, a) only: the Q parameters are not trained here
   rc = crux_dense_backward(q2, sa, B, dy2, 1.0f, false, dsa2, c->stream); if (rc) return rc;
   CRUX_RUN(c, ActorGradOp, OP_ACTOR_GRAD, k_actor_grad, nblk(B * ad), 256, c->stream, sa, mu, eps, actor->p + actor->nd.xoff, dsa1, dsa2, la->p, od, ad, B, dmu, dls);
-  rc = crux_dense_backward(actor, S, B, dmu, 1.0f, true, nullptr, c->stream); if (rc) return rc;
+  Sumsq2Fix fx{};
+  rc = crux_dense_backward(actor, S, B, dmu, 1.0f, true, nullptr, c->stream, &fx, 0); if (rc) return rc;
   CRUX_RUN(c, RowsumOp, OP_ROWSUM, k_rowsum, ad, 256, c->stream, dls, ad, B, actor->g + actor->nd.xoff);
-  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, actor->g, (int64_t)actor->nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, actor->g, (int64_t)actor->nd.n_params, (float*)nullptr, (int64_t)0, ssq, fx);
   CRUX_RUN(c, ActorInfoOp, OP_ACTOR_INFO, k_actor_info, 1, 1, c->stream, stats, ssq, B, dinfo);
   rc = adam_gated(actor, ssq, st); if (rc) return rc;
   return finish_step(c, dinfo, st, info_out, "sac_actor_loss");

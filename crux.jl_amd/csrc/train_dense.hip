@@ -258,7 +258,7 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a, hipStream_t strm, int wh
       rc = crux_dense_backward(net, x, nb, dy, 1.0f, true, nullptr, strm); if (rc) return rc;
       if (a.need_px && c->peer_n > 1)      // replica group: the gradient (and the statistics) of the GLOBAL minibatch, the same bits on every rank
         hipLaunchKernelGGL(k_px_allreduce_flat, dim3(1), dim3(1024), 0, strm, net->g, (int64_t)nd.n_params, st, (float* const*)(c->peer_tab + which * CRUX_PX_MAXR), c->peer_rank, c->peer_n, status);
-      hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, strm, (const float*)net->g, (int64_t)nd.n_params, (const float*)nullptr, (int64_t)0, ssq);
+      hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, strm, (float*)net->g, (int64_t)nd.n_params, (float*)nullptr, (int64_t)0, ssq, Sumsq2Fix{});
       hipLaunchKernelGGL(k_pg_info, dim3(1), dim3(1), 0, strm, (const double*)st, (const double*)ssq, nb, a.loss, a.head, a.lambda_p, a.lambda_e, (const float*)(net->p + nd.xoff), a.ad, dinfo, (const crux_lagrange*)a.lag);
       if (a.apply) { rc = adam_gated(net, ssq, status, true, strm); if (rc) return rc; }
       else hipLaunchKernelGGL(k_nan_status, dim3(1), dim3(1), 0, strm, (const double*)ssq, status);

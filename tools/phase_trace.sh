@@ -1,8 +1,8 @@
 #!/bin/bash
 # Phase durations of the chained off-policy epochs (C3: tools/c3_trace.py, C4: tools/c4_trace.py) from a rocprofv3 kernel trace:
 # per launch its grid, duration and the idle gap before it, for one epoch in the middle of the run, plus the kernel-stats summary.
-# Output: gpurun_out/r02/offpolicy_phase_trace.txt (copied to profiles/r02_offpolicy_phase_trace.txt)
-R=$PWD; OUT=$R/gpurun_out/r02; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+# Output: gpurun_out/r04/offpolicy_phase_trace.txt (copied to profiles/r02_offpolicy_phase_trace.txt)
+R=$PWD; OUT=$R/gpurun_out/r04; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 : > $OUT/offpolicy_phase_trace.txt
 for w in c3 c4; do
   rm -rf /tmp/pt_$w
@@ -12,7 +12,7 @@ import csv, sys
 w = sys.argv[1]
 rows = [r for r in csv.DictReader(open("/tmp/pt_%s/t_kernel_trace.csv" % w)) if "k_phase" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-n = {"c3": 9, "c4": 26}[w]
+n = {"c3": int(__import__("os").environ.get("C3_N", 7)), "c4": int(__import__("os").environ.get("C4_N", 26))}[w]
 mid = rows[len(rows) // 2: len(rows) // 2 + 2 * n]
 print("== %s: %d consecutive phase launches from the middle of the run (kernel, grid threads, duration us, gap before us)" % (w, len(mid)))
 prev = None; tot = 0.0
