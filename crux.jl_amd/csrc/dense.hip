@@ -137,7 +137,10 @@ struct GemmOp { static __device__ __forceinline__ void run(const unsigned bid_, 
 // CRUX_DENSE_FUSED=0: every layer through its own Gemm16 launch (the round-3 chains; tests compare the two forms bit for bit). Read once.
 static bool dense_fused_on() { static const bool on = !(getenv("CRUX_DENSE_FUSED") && getenv("CRUX_DENSE_FUSED")[0] == '0'); return on; }
 bool crux_dense_fwd_fused(const crux_mlp* n) { return dense_fused_on() && df_fwd12_ok(n->nd); }                      // layers 0 + 1 in one launch (exec.hip's phase plans ask)
-bool crux_dense_bwd_fused(const crux_mlp* n, int64_t B) { return dense_fused_on() && df_bwd_ok(n->nd, B); }        // layer 1's dW beside (layer 1's dX -> layer 0's dW) in one phase
+bool crux_dense_bwd_fused(const crux_mlp* n, int64_t B) { return dense_fused_on() && df_bwd_ok(n->nd, B); }
+bool crux_dense_bwd_fused3(const crux_mlp* n, int64_t B) {      // + the output layer's data gradient folded into the pair: the whole pullback of a three-layer network is ONE phase
+  static const bool on3 = !(getenv("CRUX_DENSE_FUSED") && getenv("CRUX_DENSE_FUSED")[0] == '2');      // CRUX_DENSE_FUSED=2: the pair without the folded output layer (tests)
+  return on3 && crux_dense_bwd_fused(n, B) && n->nd.L == 3 && (n->nd.dims[3] == 1 || n->nd.dims[3] == 4) && n->nd.acts[2] == CRUX_ACT_IDENTITY; }        // layer 1's dW beside (layer 1's dX -> layer 0's dW) in one phase
 
 // dZ = act'(Y) .* dY for the output layer
 struct ActGradOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ dy, const float* __restrict__ y, int act, int64_t n, float* __restrict__ dz) {
@@ -238,13 +241,23 @@ int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const floa
   }
   // with parameter gradients the fused pair leaves layer 0's gradient as quarter partials: only where the caller runs Sumsq2Op next (defer); input-gradient chains need no such reader
   const bool fused = crux_dense_bwd_fused(n, B) && (!want_g || defer != nullptr);
+  // three layers with a narrow identity output layer: its data gradient (K = out <= 4) is formed inside the consumers' panel staging (DzSrc) -- no launch, no dZ buffer
+  const bool fused3 = fused && crux_dense_bwd_fused3(n, B);
   for (int l = nd.L - 1; l >= 0; --l) {
     const int in = nd.dims[l], out = nd.dims[l + 1];
     const float* x = l == 0 ? d_x : crux_dense_act(n, l);
+    if (fused3 && l == 2) {      // the output layer: its weight gradient only (same phase as the fused pair below)
+      if (want_g) { GemmArgs q{}; q.A = dcur; q.sAi = 1; q.sAk = out; q.B = x; q.sBk = in; q.sBj = 1; q.M = out; q.N = in; q.K = (int)B;
+        q.C = n->g + nd.woff[l]; q.sCj = out; q.epi = EPI_WGRAD; q.scale = gscale; q.gbias = n->g + nd.boff[l];
+        int32_t rc = launch_gemm(c, q, st); if (rc) return rc; }
+      continue;
+    }
     if (fused && l == 1) {      // layers 1 and 0 together (dense_fused.h): dW1' = dcur X1' | dX1 = act0'(X1) .* (W1'' dcur) -> layer 0's dW, db inside the same workgroups
-      if (want_g) { Wgrad2Args w{}; w.dZ = dcur; w.X = x; w.dW = n->g + nd.woff[1]; w.db = n->g + nd.boff[1]; w.scale = gscale; w.out = out; w.in = in; w.B = (int32_t)B;
+      DzSrc z{}; const float* dz1 = dcur;
+      if (fused3) { z.W3 = n->p + nd.woff[2]; z.dZ3 = dcur; z.out3 = nd.dims[3]; z.act = nd.acts[1]; dz1 = crux_dense_act(n, 2); }      // dcur is still dZ of the output layer; the operand pointer becomes H2
+      if (want_g) { Wgrad2Args w{}; w.z = z; w.dZ = dz1; w.X = x; w.dW = n->g + nd.woff[1]; w.db = n->g + nd.boff[1]; w.scale = gscale; w.out = out; w.in = in; w.B = (int32_t)B;
         CRUX_RUN(c, Wgrad2Op, OP_WGRAD2, k_wgrad2, (unsigned)((out >> 5) * (in >> 5)), 256, st, w); }
-      Dgrad2Args a{}; a.W2 = n->p + nd.woff[1]; a.dZ2 = dcur; a.H1 = x; a.x = d_x; a.part = ws_part(n); a.dZ1 = d_dx ? dnxt : nullptr;
+      Dgrad2Args a{}; a.z = z; a.W2 = n->p + nd.woff[1]; a.dZ2 = dz1; a.H1 = x; a.x = d_x; a.part = ws_part(n); a.dZ1 = d_dx ? dnxt : nullptr;
       a.in0 = nd.dims[0]; a.out1 = in; a.out2 = out; a.B = (int32_t)B; a.act0 = nd.acts[0]; a.want_g = want_g ? 1 : 0;
       CRUX_RUN(c, Dgrad2W1Op, OP_DGRAD2W1, k_dgrad2w1, (unsigned)((in >> 4) * 4), 256, st, a);
       if (want_g) { defer->part[defer_slot] = a.part; defer->out1[defer_slot] = in; defer->in0[defer_slot] = nd.dims[0]; defer->woff[defer_slot] = nd.woff[0]; defer->boff[defer_slot] = nd.boff[0]; defer->scale[defer_slot] = gscale; }

@@ -83,7 +83,16 @@ static inline bool df_fwd12_ok(const NetDesc& nd) {
 static inline unsigned df_fwd12_blocks(const NetDesc& nd, int64_t B) { return (unsigned)((nd.dims[2] >> 4) * ((B + 15) >> 4)); }
 
 // ---- weight gradient of a wide layer: dW[i, k] = scale * sum_s dZ[i, s] X[k, s]; db[i] = scale * sum_s dZ[i, s] ----------------------------------
-struct Wgrad2Args { const float* dZ; const float* X; float* dW; float* db; float scale; int32_t out, in, B; };
+// dZ of the layer under a narrow output layer (out3 <= 4), formed where it is consumed instead of by a launch of its own: dZ[o, s] = act'(H[o, s]) * sum_q W3[q, o] dZ3[q, s].
+// The sum is Gemm16's chain for K = out3 <= 4 (one MFMA slice per q, lane group 0 only): fmaf in q-ascending order from +0. W3 == nullptr: the operand is dZ itself.
+struct DzSrc { const float* W3; const float* dZ3; int32_t out3, act; };
+template <int O3> __device__ __forceinline__ float df_dz(const DzSrc& z, float h, const float (&w)[O3], const float (&d)[O3]) {
+  float v = 0.f;
+#pragma unroll
+  for (int q = 0; q < O3; ++q) v = fmaf(w[q], d[q], v);      // (w is zero past out3: the term adds +-0)
+  return crux_act_grad(z.act, h, v);
+}
+struct Wgrad2Args { const float* dZ; const float* X; float* dW; float* db; float scale; int32_t out, in, B; DzSrc z; };      // z.W3 != nullptr: dZ points at H (the layer's own output) and the gradient is formed on the fly
 struct Wgrad2Op { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, Wgrad2Args q) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int tI = q.out >> 5; const int bi = (int)bid_ % tI, bk = (int)bid_ / tI; const int I0 = bi << 5, K0 = bk << 5;
@@ -96,13 +105,42 @@ struct Wgrad2Op { static __device__ __forceinline__ void run(const unsigned bid_
   f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; float rows[4] = {0.f, 0.f, 0.f, 0.f};
   // both halves of both panels are fetched before the first use (one memory round trip per block)
   const int i4 = (threadIdx.x & 7) << 2, sr = threadIdx.x >> 3;
+  float w3[4][4], d3[2][4][4], mks[2][4];
+  const float* W3 = q.z.W3 ? q.z.W3 : q.X; const float* D3 = q.z.W3 ? q.z.dZ3 : q.X; const int o3 = q.z.W3 ? q.z.out3 : 1;      // (no folding: harmless loads of valid addresses, results unused)
+  const bool o4 = o3 == 4;      // crux_dense_bwd_fused3: out3 is 1 or 4
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) w3[e][qq] = 0.f;
+  if (o4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const f32x4 t = *(const f32x4*)(W3 + 4 * (I0 + i4 + e));
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) w3[e][qq] = t[qq]; }
+  } else { const f32x4 t = *(const f32x4*)(W3 + I0 + i4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w3[e][0] = t[e]; }
   f32x4 ta[2][4], tb[2][4];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int p = 0; p < 4; ++p) { const int sl = sr + 32 * p, s = h * half_k + sl; const bool v = h < nhalf && sl < half_k && s < K; const int sc = v ? s : 0;      // clamped address + select
       const float mk = v ? 1.f : 0.f;      // unconditional loads; rows past the end are zeroed on the dZ side by a multiplication (see Fwd12Op)
-      ta[h][p] = *(const f32x4*)(q.dZ + (I0 + i4) + (int64_t)q.out * sc) * mk; tb[h][p] = *(const f32x4*)(q.X + (K0 + i4) + (int64_t)q.in * sc); }
+      ta[h][p] = *(const f32x4*)(q.dZ + (I0 + i4) + (int64_t)q.out * sc); tb[h][p] = *(const f32x4*)(q.X + (K0 + i4) + (int64_t)q.in * sc); mks[h][p] = mk;
+      d3[h][p][1] = d3[h][p][2] = d3[h][p][3] = 0.f;
+      if (o4) { const f32x4 t = *(const f32x4*)(D3 + 4 * sc);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) d3[h][p][qq] = t[qq]; }
+      else d3[h][p][0] = D3[sc]; }
+  // (the loads above are all in flight before the first of them is used: the folded gradient is formed in a second pass)
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (q.z.W3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ta[h][p][e] = df_dz<4>(q.z, ta[h][p][e], w3[e], d3[h][p]); }
+      ta[h][p] = ta[h][p] * mks[h][p]; }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (h >= nhalf) break;
@@ -147,9 +185,11 @@ __global__ __launch_bounds__(256) void k_wgrad2(Wgrad2Args q) { Wgrad2Op::run(bl
 // whoever reads the gradient next: Sumsq2Op (sac.hip), which every train! step runs right after the pullback, forms and stores dW1 / db1 from the four partials as it
 // sums the squares. Both operand panels are staged through LDS with row-contiguous 16-byte loads (a lane-per-sample fragment load touches sixteen half-used cache
 // lines per instruction: the texture path, not latency, bounded the first version of this kernel), all issued before the first use.
-struct Dgrad2Args { const float* W2; const float* dZ2; const float* H1; const float* x; float* part; float* dZ1; int32_t in0, out1, out2, B, act0, want_g; };
+struct Dgrad2Args { const float* W2; const float* dZ2; const float* H1; const float* x; float* part; float* dZ1; int32_t in0, out1, out2, B, act0, want_g; DzSrc z; };      // z.W3 != nullptr: dZ2 points at H2 (see Wgrad2Args)
 #define DF_PART_STRIDE(in0) ((in0) + 4)      // per feature: in0 partial dW entries + 4 partial row sums (lane groups g = 0..3)
-struct Dgrad2W1Op { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, Dgrad2Args q) {
+// O3: the widest output layer whose data gradient the instantiation can fold in (DzSrc): 1 (critics, value heads; also "no folding") or 4. Two instantiations because the
+// folded operands live in registers until the panels are written: 16 of them at O3 = 1, 64 at O3 = 4 -- and the register count decides how many workgroups share a CU.
+template <int O3> struct Dgrad2W1OpT { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, Dgrad2Args q) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int nF = q.out1 >> 4; const int F0 = ((int)bid_ % nF) << 4, sb = (int)bid_ / nF;      // sb = the quarter of the samples
   const int K = q.out2, kper = K >> 2, half_k = K >> 1;                // df_bwd_ok: K in {128, 192, 256}
@@ -159,6 +199,28 @@ struct Dgrad2W1Op { static __device__ __forceinline__ void run(const unsigned bi
   // all global loads first: both halves of the weight rows (16 x K) and of the quarter's dZ2 columns (<= 64 x K), H1 of this wave's tile, x of the quarter (wave 0)
   const int col4 = (threadIdx.x & 31) << 2, row8 = threadIdx.x >> 5;   // 32 threads per half row of <= 128 floats, 8 rows per pass
   f32x4 wl[2][2], zl[2][8];
+  float w3[2][4][O3], d3[8][O3];      // folded output layer (DzSrc): W3[q, o] of this thread's four features per half, dZ3[q, s] of its eight samples -- 16-byte loads
+  { const float* W3 = q.z.W3 ? q.z.W3 : q.W2; const float* D3 = q.z.W3 ? q.z.dZ3 : q.W2;      // (no folding: harmless loads of valid addresses, results unused)
+    const int ccz = col4 < half_k ? col4 : 0;
+    if (O3 == 1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { const f32x4 t = *(const f32x4*)(W3 + h * half_k + ccz);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w3[h][e][0] = t[e]; }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) { const int sl = row8 + 8 * p; d3[p][0] = D3[sl < S ? S0 + sl : 0]; }
+    } else {      // out3 == 4 (crux_dense_bwd_fused3)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const f32x4 t = *(const f32x4*)(W3 + 4 * (h * half_k + ccz + e));
+#pragma unroll
+          for (int qq = 0; qq < O3; ++qq) w3[h][e][qq] = t[qq & 3]; }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) { const int sl = row8 + 8 * p; const f32x4 t = *(const f32x4*)(D3 + 4 * (sl < S ? S0 + sl : 0));
+#pragma unroll
+        for (int qq = 0; qq < O3; ++qq) d3[p][qq] = t[qq & 3]; }
+    } }
 #pragma unroll
   for (int h = 0; h < 2; ++h) { const int cc = col4 < half_k ? col4 : 0;
 #pragma unroll
@@ -167,21 +229,24 @@ struct Dgrad2W1Op { static __device__ __forceinline__ void run(const unsigned bi
     for (int p = 0; p < 8; ++p) { const int sl = row8 + 8 * p; const int s = sl < S ? S0 + sl : 0; zl[h][p] = *(const f32x4*)(q.dZ2 + h * half_k + cc + (int64_t)q.out2 * s); } }      // (rows past the quarter re-read sample 0 and are never stored)
   const int st = S0 + 16 * wv + c; const bool vt = 16 * wv < S, vs = vt && st < S1;      // this wave's tile and sample
   const f32x4 y = *(const f32x4*)(q.H1 + F0 + 4 * g + (int64_t)q.out1 * (vs ? st : 0));
-  float xf[2][4][4];
+  float xf[1][4][4];      // (df_bwd_ok: in0 <= 16 -- one input tile)
 #pragma unroll
-  for (int tq = 0; tq < 2; ++tq)
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xf[0][u][r] = 0.f;
+  if (wv == 0 && q.want_g) {      // (one wave forms the quarter's partial chain; inside the branch the loads are still back to back)
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xf[tq][u][r] = 0.f;
-  if (wv == 0 && q.want_g) {      // (one wave forms the quarter's partial chain; inside the branch the loads are still back to back)
+      for (int r = 0; r < 4; ++r) { const int qc = c, s = S0 + 16 * u + 4 * g + r; const bool v = qc < q.in0 && s < S1;
+        xf[0][u][r] = q.x[(v ? qc : 0) + (int64_t)q.in0 * (v ? s : 0)] * (v ? 1.f : 0.f); } }      // unconditional load, zeroed by a multiplication (see Fwd12Op)
+  if (q.z.W3) {
 #pragma unroll
-    for (int tq = 0; tq < 2; ++tq)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int p = 0; p < 8; ++p)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int qc = 16 * tq + c, s = S0 + 16 * u + 4 * g + r; const bool v = qc < q.in0 && s < S1;
-          xf[tq][u][r] = q.x[(v ? qc : 0) + (int64_t)q.in0 * (v ? s : 0)] * (v ? 1.f : 0.f); } }      // unconditional load, zeroed by a multiplication (see Fwd12Op)
+        for (int e = 0; e < 4; ++e) zl[h][p][e] = df_dz<O3>(q.z, zl[h][p][e], w3[h][e], d3[p]); }
   f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -222,7 +287,7 @@ struct Dgrad2W1Op { static __device__ __forceinline__ void run(const unsigned bi
   // the quarter's partial chain of layer 0's weight gradient: M = 16, N = in0, K = the quarter's samples (Gemm16: 16-groups ascending)
   float* prow_out = q.part + (int64_t)sb * q.out1 * DF_PART_STRIDE(q.in0);
 #pragma unroll
-  for (int tq = 0; tq < 2; ++tq) { if (16 * tq < q.in0) {
+  for (int tq = 0; tq < 1; ++tq) { if (16 * tq < q.in0) {
     f32x4 pa = {0.f, 0.f, 0.f, 0.f}; float prow = 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) { if (16 * u < kperb) { const f32x4 av = *(const f32x4*)(Zs + c * ZP + 16 * u + 4 * g);
@@ -235,8 +300,9 @@ struct Dgrad2W1Op { static __device__ __forceinline__ void run(const unsigned bi
     if (tq == 0) prow_out[(int64_t)(F0 + c) * DF_PART_STRIDE(q.in0) + q.in0 + g] = prow;      // lane (c, g): the partial row sum of feature F0 + c over this quarter's k = 16 u + 4 g + r
   } }
 } };
+struct Dgrad2W1Op { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, Dgrad2Args q) { if (q.z.W3 && q.z.out3 > 1) Dgrad2W1OpT<4>::run(bid_, nb_, q); else Dgrad2W1OpT<1>::run(bid_, nb_, q); } };      // (the op type the recorder packs; stand-alone launches)
 __global__ __launch_bounds__(256) void k_dgrad2w1(Dgrad2Args q) { Dgrad2W1Op::run(blockIdx.x, gridDim.x, q); }
 // the pair (Wgrad2Op on layer 1, Dgrad2W1Op through layer 1 into layer 0) applies to: a narrow input, layer widths in whole 32-blocks, K = out2 in {128, 192, 256}, 128 <= B <= 256
 static inline bool df_bwd_ok(const NetDesc& nd, int64_t B) {
-  return nd.L >= 2 && nd.dims[0] <= 32 && nd.dims[1] >= 32 && (nd.dims[1] & 31) == 0 && (nd.dims[2] == 128 || nd.dims[2] == 192 || nd.dims[2] == 256) && B >= 128 && B <= 256;
+  return nd.L >= 2 && nd.dims[0] <= 16 && nd.dims[1] >= 32 && (nd.dims[1] & 31) == 0 && (nd.dims[2] == 128 || nd.dims[2] == 192 || nd.dims[2] == 256) && B >= 128 && B <= 256;
 }

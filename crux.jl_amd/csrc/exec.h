@@ -15,10 +15,11 @@ enum {
   OP_GEMM = 1, OP_ACT_GRAD, OP_GAUSS_EXPLORE, OP_CONCAT_SA, OP_SAC_TARGET, OP_DPG_ACTION, OP_DPG_TARGET, OP_FILL, OP_SLICE_ROWS, OP_MEAN_INFO, OP_TEMP_HEAD,
   OP_Q_HEAD, OP_TD_HEAD, OP_TD_INFO, OP_SUMSQ2, OP_CRITIC_INFO, OP_ACTOR_HEAD, OP_ACTOR_GRAD, OP_ROWSUM, OP_ACTOR_INFO, OP_ADAM_GATED,
   OP_PER_SEARCH, OP_UNIFORM_IDS, OP_GATHER_RING_ALL, OP_RING_IDS, OP_LEAF_REFRESH, OP_TREE_TOUCH, OP_PER_UPDATE, OP_DQN_TARGET, OP_TD_ERROR, OP_POLYAK, OP_COPY_F32, OP_ADAM_ADVANCE, OP_SOFTQ_TARGET,
-  OP_FWD12, OP_WGRAD2, OP_DGRAD2W1      // dense_fused.h (round 4)
+  OP_FWD12, OP_WGRAD2, OP_DGRAD2W1,     // dense_fused.h (round 4)
+  OP_PER_SAMPLE                        // per.hip: search + gather of one row per wave (round 4)
 };
 
-#define CRUX_EXEC_ARG_BYTES 496
+#define CRUX_EXEC_ARG_BYTES 624
 struct ExecOp { int32_t kid; uint32_t nblocks; int32_t barrier; int32_t abytes; alignas(8) unsigned char args[CRUX_EXEC_ARG_BYTES]; };   // abytes: size of the packed arguments actually used
 
 // ---- argument packs: the parameters of XOp::run after (bid, nblocks), stored by value in declaration order --------------------------------

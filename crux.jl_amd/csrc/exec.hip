@@ -87,9 +87,10 @@ __device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigne
         case OP_COPY_F32: DISPATCH<CopyF32Op>(op, b); break; \
         case OP_ADAM_ADVANCE: DISPATCH<AdamAdvanceOp>(op, b); break; \
         case OP_SOFTQ_TARGET: DISPATCH<SoftqTargetOp>(op, b); break; \
+        case OP_PER_SAMPLE: PerSampleGatherOp::run_ptr(b, op->nblocks, (const PerSampleArgs*)op->args); break; \
         case OP_FWD12: DISPATCH<Fwd12Op>(op, b); break; \
         case OP_WGRAD2: DISPATCH<Wgrad2Op>(op, b); break; \
-        case OP_DGRAD2W1: if constexpr (EXEC_HEAVY) { DISPATCH<Dgrad2W1Op>(op, b); } break; \
+        case OP_DGRAD2W1: if constexpr (EXEC_HEAVY == 1) { DISPATCH<Dgrad2W1OpT<1>>(op, b); } else if constexpr (EXEC_HEAVY == 2) { DISPATCH<Dgrad2W1Op>(op, b); } break; \
         default: break; \
       }
 
@@ -130,7 +131,7 @@ template <class Op> __device__ __forceinline__ void exec_dispatch_g(const ExecOp
 // EXEC_HEAVY: the register-hungry op bodies (Dgrad2W1Op: ~300 VGPRs) are compiled into the HEAVY instantiations only; a phase without such an op runs the light
 // kernel (~100 VGPRs: four workgroups per CU instead of one -- a phase of 500-800 light blocks then takes one round over the chip instead of three)
 __global__ __launch_bounds__(256) void k_phase(const ExecOp* __restrict__ ops, int n) {
-  constexpr bool EXEC_HEAVY = true;
+  constexpr int EXEC_HEAVY = 2;
   // ops flagged sequential (barrier bit 1) own no blocks: they run in the block of the op before them, after it (see k_phase_k)
   unsigned b = blockIdx.x; int o = 0;
   for (;;) { const unsigned nb = (ops[o].barrier & 2) ? 0u : ops[o].nblocks; if (o + 1 < n && b >= nb) { b -= nb; ++o; } else break; }
@@ -159,7 +160,7 @@ template <> __device__ __forceinline__ void exec_dispatch_k<GatherRingAllOp>(con
   using P = OpPack<GatherRingAllOp>; const P* pp = (const P*)op->args;
   GatherRingAllOp::run_ptr(bid, op->nblocks, &pp->head, pp->tail.head, pp->tail.tail.head, pp->tail.tail.tail.head, pp->tail.tail.tail.tail.head);
 }
-template <int BYTES, bool EXEC_HEAVY>
+template <int BYTES, int EXEC_HEAVY>
 __global__ __launch_bounds__(256) void k_phase_k(PhaseK<BYTES> by_value) {
   // read through the kernel-argument segment pointer, not through the by-value parameter: indexing the parameter at a run-time offset would make the compiler
   // copy the aggregate to private memory first
@@ -186,9 +187,11 @@ template <int BYTES> static bool phasek_launch(const std::vector<ExecOp>& ops, s
     pk.kid[pk.n] = e.kid | (seq ? PHASEK_SEQ : 0); pk.nblocks[pk.n] = seq ? 0u : e.nblocks; pk.off[pk.n] = (uint32_t)used; memcpy(pk.args + used, e.args, raw); used += ab; pk.n++; }
   if (pk.n == 0) return false;
   for (int q = pk.n; q < PHASEK_MAXOPS; ++q) { pk.kid[q] = 0; pk.nblocks[q] = 0; pk.off[q] = 0; }
-  bool heavy = false; for (int q = 0; q < pk.n; ++q) heavy = heavy || (pk.kid[q] & (PHASEK_SEQ - 1)) == OP_DGRAD2W1;
-  if (heavy) hipLaunchKernelGGL((k_phase_k<BYTES, true>), dim3(blocks), dim3(256), 0, st, pk);
-  else hipLaunchKernelGGL((k_phase_k<BYTES, false>), dim3(blocks), dim3(256), 0, st, pk);
+  int heavy = 0;      // 0: no Dgrad2W1Op in the phase; 1: its O3 = 1 form (critics / no folded output layer); 2: the O3 = 4 form
+  for (int q = 0; q < pk.n; ++q) if ((pk.kid[q] & (PHASEK_SEQ - 1)) == OP_DGRAD2W1) { Dgrad2Args a; memcpy(&a, pk.args + pk.off[q], sizeof a); heavy = std::max(heavy, (a.z.W3 && a.z.out3 > 1) ? 2 : 1); }
+  if (heavy == 2) hipLaunchKernelGGL((k_phase_k<BYTES, 2>), dim3(blocks), dim3(256), 0, st, pk);
+  else if (heavy == 1) hipLaunchKernelGGL((k_phase_k<BYTES, 1>), dim3(blocks), dim3(256), 0, st, pk);
+  else hipLaunchKernelGGL((k_phase_k<BYTES, 0>), dim3(blocks), dim3(256), 0, st, pk);
   return true;
 }
 // would phasek_launch<3840> take ops [i0, i1]? (the same packing rules, nothing launched)
@@ -201,7 +204,7 @@ static bool phasek_fits(const std::vector<ExecOp>& ops, size_t i0, size_t i1) {
   return n > 0;
 }
 __global__ __launch_bounds__(256) void k_exec(const ExecOp* __restrict__ ops, int nops, unsigned* ctr, int xcd, int32_t* status, int flags) {
-  constexpr bool EXEC_HEAVY = true;
+  constexpr int EXEC_HEAVY = 2;
   if (xcd >= 0 && (int)(blockIdx.x & 7) != xcd) return;
   const unsigned wg = xcd >= 0 ? blockIdx.x >> 3 : blockIdx.x, G = xcd >= 0 ? gridDim.x >> 3 : gridDim.x;
   // op records are staged through LDS one op ahead: the 512-byte record of op o+1 is fetched while op o runs and its barrier is waited for, so
@@ -261,7 +264,7 @@ static int32_t dqp_build(ExecRec* r) {        // the replay table; CRUX_EUNSUP w
     std::vector<std::pair<int, int>> A, Cs; bool head = false;      // (phase, op index)
     for (size_t i = i0; i < i1; ++i) { const int kid = r->ops[i].kid;
       switch (kid) {
-        case OP_PER_SEARCH: case OP_UNIFORM_IDS: A.push_back({0, (int)i}); break;
+        case OP_PER_SEARCH: case OP_UNIFORM_IDS: case OP_PER_SAMPLE: A.push_back({0, (int)i}); break;
         case OP_GATHER_RING_ALL: case OP_RING_IDS: case OP_COPY_F32: case OP_FILL: if (head) return CRUX_EUNSUP; A.push_back({1, (int)i}); break;
         case OP_PER_UPDATE: if (head) Cs.push_back({0, (int)i}); else A.push_back({2, (int)i}); break;
         case OP_LEAF_REFRESH: if (!head) return CRUX_EUNSUP; Cs.push_back({1, (int)i}); break;
@@ -387,9 +390,11 @@ static int32_t exec_schedule(crux_ctx* c, const std::vector<int>& phase) {
 // in recording order; a network's forward pass is nf of them (nf = L, or L - 1 when layers 0 + 1 are one Fwd12Op), its pullback with parameter gradients 2 L - 1
 // (weight + data gradient per layer, no data gradient for layer 0) in L phases -- or 2 (L - 1) in L - 1 phases when Wgrad2Op || Dgrad2W1Op take layers 1 and 0 together.
 static inline bool is_mm(int kid) { return kid == OP_GEMM || kid == OP_FWD12 || kid == OP_WGRAD2 || kid == OP_DGRAD2W1; }
-struct NetPlan { int nf, nbops, nb; };
-static inline NetPlan net_plan(const crux_mlp* n, int64_t B) { const int L = n->nd.L; const bool ff = crux_dense_fwd_fused(n), fb = crux_dense_bwd_fused(n, B);
-  return NetPlan{ff ? L - 1 : L, fb ? 2 * (L - 1) : 2 * L - 1, fb ? L - 1 : L}; }
+// With the output layer's data gradient folded into the pair (three layers, out <= 4: crux_dense_bwd_fused3) the whole pullback is ONE phase of three launches
+// (output-layer dW, Wgrad2Op, Dgrad2W1Op), and an input-gradient chain is two (Dgrad2W1Op, layer 0's data gradient).
+struct NetPlan { int nf, nbops, nb, dq; bool one; int stage(int k) const { return one ? 0 : k / 2; } };
+static inline NetPlan net_plan(const crux_mlp* n, int64_t B) { const int L = n->nd.L; const bool ff = crux_dense_fwd_fused(n), fb = crux_dense_bwd_fused(n, B), f3 = crux_dense_bwd_fused3(n, B);
+  return NetPlan{ff ? L - 1 : L, f3 ? 3 : fb ? 2 * (L - 1) : 2 * L - 1, f3 ? 1 : fb ? L - 1 : L, f3 ? 2 : L, f3}; }
 #define PH_SEQ_HEAD (1 << 12)
 #define PH_SEQ_TAIL (2 << 12)
 static inline int ph_tag(int p_mapped, int sub) { return 4 * p_mapped + sub; }
@@ -552,11 +557,14 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   // chain starts INSIDE the head's block: update_priorities! is a second sequential tail behind the td head (one block, reads the head's td errors), so the leaf
   // re-sum and the root paths sit at 3 + nf and 4 + nf, and the search of epoch e + 1 (phase 7 + nf + nb - sq - ov of this epoch) stays behind the root paths as long
   // as ov <= nb + 1; without the group the chain is update | leaf | paths at 4 + nf - sq .., and ov <= nb as before.
-  const bool ffw = crux_dense_fwd_fused(net), fbw = crux_dense_bwd_fused(net, B);
-  const int nf = ffw ? Ld - 1 : Ld, nb = fbw ? Ld - 1 : Ld;
+  const NetPlan pn = net_plan(net, B); const bool ffw = crux_dense_fwd_fused(net);
+  const int nf = pn.nf, nb = pn.nb;
   const int sq0 = (B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;
   const bool tailp = per && sq0 == 1;
-  const int ovmax = tailp ? nb + 1 : nb;
+  // sph: with the search and the gather in one launch (PerSampleGatherOp) the sampling of an epoch is phase 1 alone, so the search of epoch e + 1 sits one phase later and the
+  // overlap may be one deeper
+  const int sph = (per && crux_per_fused_gather() && !c->per_split_sample) ? 1 : 0;
+  const int ovmax = (tailp ? nb + 1 : nb) + sph;
   const int ov = per ? (ovmax < 1 ? 1 : (ovmax < 3 ? ovmax : 3)) : 3;
   auto tag = [&](size_t from, auto&& rule) { if (!fuse || !crux_exec_recording(c)) return; ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
     for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { plan_ok = false; p = 0; }
@@ -571,7 +579,7 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   if (fuse && crux_exec_recording(c) && rec_of(c)->chain) rec_of(c)->epoch_marks.push_back(ops0);
   size_t m = ops0;
   rc = per ? crux_per_sample(batch, source, B, nullptr, beta, sample_counter) : crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
-  tag(m, [&](int kid, int&) { return (kid == OP_PER_SEARCH || kid == OP_UNIFORM_IDS) ? 0 : (kid == OP_GATHER_RING_ALL || kid == OP_RING_IDS || kid == OP_COPY_F32) ? 1 : kid == OP_PER_UPDATE ? 2 : -1; });
+  tag(m, [&](int kid, int&) { return (kid == OP_PER_SEARCH || kid == OP_UNIFORM_IDS) ? 0 : (kid == OP_PER_SAMPLE || kid == OP_GATHER_RING_ALL || kid == OP_RING_IDS || kid == OP_COPY_F32) ? 1 : kid == OP_PER_UPDATE ? 2 : -1; });
   rc = piece(2); if (rc) return bail(rc);
   m = fuse && crux_exec_recording(c) ? exec_mark(c) : 0;
   rc = softq_alpha > 0.f ? crux_softq_target(target_net, batch, gamma, softq_alpha, d_y) : crux_dqn_target(target_net, batch, gamma, d_y); if (rc) return bail(rc);      // softq_target(alpha) (rl/softq.jl:4-13) | dqn_target (rl/dqn.jl:4-6)
@@ -582,7 +590,7 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   auto td_rule = [&](int kid, int& g) {      // g counts the GEMMs: Ld forward, then (weight, data) pairs from the last layer down, the first layer has no data gradient
     if (kid == OP_FILL) return 1;
     if (kid == OP_FWD12) { g = 1; return 2; }
-    if (kid == OP_GEMM) { const int k = g++; if (k < nf) return 2 + k; const int j = (k - nf) / 2; return j < nb ? 4 + nf + j - sq : -1; }
+    if (kid == OP_GEMM) { const int k = g++; if (k < nf) return 2 + k; const int j = pn.stage(k - nf); return j < nb ? 4 + nf + j - sq : -1; }
     if (kid == OP_WGRAD2 || kid == OP_DGRAD2W1) return 3 + nf + nb - sq;      // the last backward phase: layer 1's dW beside layer 1's dX -> layer 0's dW
     if (kid == OP_TD_HEAD) return sq ? ((2 + nf) | PH_SEQ_TAIL) : 3 + nf;
     if (kid == OP_SUMSQ2) return 4 + nf + nb - sq; if (kid == OP_TD_INFO || kid == OP_ADAM_GATED) return 5 + nf + nb - sq; if (kid == OP_ADAM_ADVANCE) return 6 + nf + nb - sq;
@@ -646,6 +654,8 @@ static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer*
     return crux_exec_run(c);
   };
   int32_t rc = CRUX_OK; int in_chain = 0;
+  struct SplitGuard { crux_ctx* c; bool old; ~SplitGuard() { c->per_split_sample = old; } } split_guard{c, c->per_split_sample};
+  if (persist) c->per_split_sample = true;
   for (int e = 0; e < n_epochs; ++e) {
     float* info_e = infos ? infos + (size_t)e * CRUX_INFO_N : nullptr;
     if (!fuse) { if (d_infos_async) return CRUX_EUNSUP;      // narrow networks run call by call with a read-back per epoch: the caller takes the synchronous entry point
@@ -730,9 +740,9 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   // Round 4: written in launches -- FA / FQ forward launches of the actor / a critic, BQ / BA phases of a pullback with parameter gradients (BQo ops per critic), LQ phases
   // of a critic's input-gradient chain; with the fused block kernels FA = FQ = L - 1 and BQ = BA = L - 1 (net_plan above), otherwise all equal L as in round 3.
   const NetPlan pa = net_plan(actor, B), pq = net_plan(q1, B);
-  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, FA = pa.nf, FQ = pq.nf, BQ = pq.nb, BQo = pq.nbops, BA = pa.nb, X = 3 + FA + FQ, Y = X + 4 + BQ - sq;
+  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, FA = pa.nf, FQ = pq.nf, BQ = pq.nb, BQo = pq.nbops, BA = pa.nb, DQ = pq.dq, X = 3 + FA + FQ, Y = X + 4 + BQ - sq;
   if (LA != LQ || q2->nd.L != LQ || q1_targ->nd.L != LQ || q2_targ->nd.L != LQ) plan_ok = false;       // (the early actor forward needs X + 1 + FA < Y)
-  { const NetPlan p2 = net_plan(q2, B), t1 = net_plan(q1_targ, B), t2 = net_plan(q2_targ, B); if (p2.nf != FQ || p2.nb != BQ || t1.nf != FQ || t2.nf != FQ || FA != FQ) plan_ok = false; }
+  { const NetPlan p2 = net_plan(q2, B), t1 = net_plan(q1_targ, B), t2 = net_plan(q2_targ, B); if (p2.nf != FQ || p2.nb != BQ || p2.one != pq.one || t1.nf != FQ || t2.nf != FQ || FA != FQ) plan_ok = false; }
   // chained epochs: phases 0 (ids) and 1 (gather, fills) of a later epoch run beside the previous epoch's actor norm and info + Adam (neither reads the batch), and its
   // phase 2 (actor(sp) forward, vcat(s, a): online networks only) beside the previous epoch's advance + polyak, which writes beta powers and TARGET networks: the rest
   // closes up by three -- see crux_dqn_epoch
@@ -757,7 +767,7 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
     rc = crux_double_q_step(q1, q2, batch, d_y, use_weight, info_critic); if (rc) return bail(rc);
     tag(m, [&](int kid, int& g) {      // per critic: LQ forward GEMMs, head, then (weight, data) pairs from the last layer down (the first layer has no data gradient)
       if (kid == OP_FILL) return 1; if (kid == OP_CONCAT_SA) return 2;
-      if (is_mm(kid)) { const int k = (g++) % (FQ + BQo); return k < FQ ? 3 + k : X + 2 - sq + (k - FQ) / 2; }
+      if (is_mm(kid)) { const int k = (g++) % (FQ + BQo); return k < FQ ? 3 + k : X + 2 - sq + pq.stage(k - FQ); }
       return kid == OP_Q_HEAD ? (sq ? (X | PH_SEQ_TAIL) : X + 1) : kid == OP_SUMSQ2 ? X + 2 - sq + BQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 - sq + BQ : kid == OP_ADAM_ADVANCE ? X + 4 - sq + BQ : -1; });
   }
   if (update_actor) {
@@ -768,19 +778,19 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
       // the actor's own forward pass and its exploration draw depend on neither the critic update nor the temperature: they run beside the critic's head / backward
       // phases (X + 1 ..), after the temperature step's last read of the actor's activations (its exploration at X)
       if (is_mm(kid)) { const int k = g++; if (k < FA) return X + 1 + k; if (k < FA + 2 * FQ) return Y + (k - FA) % FQ;
-        if (k < FA + 2 * FQ + 2 * LQ) return Y + 1 + FQ + (k - FA - 2 * FQ) % LQ; return Y + 2 + FQ + LQ + (k - FA - 2 * FQ - 2 * LQ) / 2; }
-      return kid == OP_GAUSS_EXPLORE ? X + 1 + FA : kid == OP_ACTOR_HEAD ? Y + FQ : kid == OP_ACTOR_GRAD ? Y + 1 + FQ + LQ : kid == OP_ROWSUM ? Y + 2 + FQ + LQ :
-             kid == OP_SUMSQ2 ? Y + BA + 2 + FQ + LQ : (kid == OP_ACTOR_INFO || kid == OP_ADAM_GATED) ? Y + BA + 3 + FQ + LQ : kid == OP_ADAM_ADVANCE ? Y + BA + 4 + FQ + LQ : -1; });
+        if (k < FA + 2 * FQ + 2 * DQ) return Y + 1 + FQ + (k - FA - 2 * FQ) % DQ; return Y + 2 + FQ + DQ + pa.stage(k - FA - 2 * FQ - 2 * DQ); }
+      return kid == OP_GAUSS_EXPLORE ? X + 1 + FA : kid == OP_ACTOR_HEAD ? Y + FQ : kid == OP_ACTOR_GRAD ? Y + 1 + FQ + DQ : kid == OP_ROWSUM ? Y + 2 + FQ + DQ :
+             kid == OP_SUMSQ2 ? Y + BA + 2 + FQ + DQ : (kid == OP_ACTOR_INFO || kid == OP_ADAM_GATED) ? Y + BA + 3 + FQ + DQ : kid == OP_ADAM_ADVANCE ? Y + BA + 4 + FQ + DQ : -1; });
     m = fuse ? exec_mark(c) : 0;
     if (actor_targ) { rc = crux_polyak(actor_targ, actor, tau); if (rc) return bail(rc); }
     rc = crux_polyak(q1_targ, q1, tau); if (rc) return bail(rc);
     rc = crux_polyak(q2_targ, q2, tau); if (rc) return bail(rc);
-    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + BA + 4 + FQ + LQ : -1; });
+    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + BA + 4 + FQ + DQ : -1; });
   }
   if (fuse && rec_of(c)->chain) {      // chained: crux_sac_epochs schedules and runs the whole list
     ExecRec* r = rec_of(c);
     if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + BA + 5 + FQ + LQ - (r->chain_base > 0 ? 3 : 0);
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + BA + 5 + FQ + DQ - (r->chain_base > 0 ? 3 : 0);
     return CRUX_OK;
   }
   if (fuse && plan_ok && ph.size() == rec_of(c)->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
@@ -887,7 +897,7 @@ static int32_t dpg_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* 
   //   Y.. Q(s, mu(s)) forward | its input gradient | slice | actor backward | norm | info, Adam | advance, polyak
   const int sq = (update_critic && B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;      // target + critic head(s) as a sequential one-block group (see crux_sac_epoch)
   const NetPlan pa = net_plan(actor, B), pq = net_plan(q1, B);      // launches per pass (see crux_sac_epoch)
-  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, FA = pa.nf, FQ = pq.nf, BQ = pq.nb, BQo = pq.nbops, BA = pa.nb, X = 3 + FA + FQ, Y = X + 4 + BQ - sq;
+  std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, FA = pa.nf, FQ = pq.nf, BQ = pq.nb, BQo = pq.nbops, BA = pa.nb, DQ = pq.dq, X = 3 + FA + FQ, Y = X + 4 + BQ - sq;
   const int ag = actor->nd.acts[LA - 1] != CRUX_ACT_IDENTITY ? 1 : 0;
   if (LA != LQ || actor_targ->nd.L != LA || q1_targ->nd.L != LQ || (q2 && q2->nd.L != LQ) || (q2_targ && q2_targ->nd.L != LQ)) plan_ok = false;
   if (FA != FQ || net_plan(actor_targ, B).nf != FA || net_plan(q1_targ, B).nf != FQ || (q2 && (net_plan(q2, B).nf != FQ || net_plan(q2, B).nb != BQ)) || (q2_targ && net_plan(q2_targ, B).nf != FQ)) plan_ok = false;
@@ -910,7 +920,7 @@ static int32_t dpg_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* 
     rc = q2 ? crux_double_q_step(q1, q2, batch, d_y, use_weight, info_critic) : crux_q_step(q1, batch, d_y, use_weight, info_critic); if (rc) return bail(rc);
     tag(m, [&](int kid, int& g) {      // per critic: LQ forward GEMMs, head, then (weight, data) pairs from the last layer down (the first layer has no data gradient)
       if (kid == OP_FILL) return 1; if (kid == OP_CONCAT_SA) return 2;
-      if (is_mm(kid)) { const int k = (g++) % (FQ + BQo); return k < FQ ? 3 + k : X + 2 - sq + (k - FQ) / 2; }
+      if (is_mm(kid)) { const int k = (g++) % (FQ + BQo); return k < FQ ? 3 + k : X + 2 - sq + pq.stage(k - FQ); }
       return kid == OP_Q_HEAD ? (sq ? (X | PH_SEQ_TAIL) : X + 1) : kid == OP_SUMSQ2 ? X + 2 - sq + BQ : (kid == OP_CRITIC_INFO || kid == OP_ADAM_GATED) ? X + 3 - sq + BQ : kid == OP_ADAM_ADVANCE ? X + 4 - sq + BQ : -1; });
   }
   if (update_actor) {
@@ -918,21 +928,21 @@ static int32_t dpg_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* 
     rc = crux_dpg_actor_step(actor, q1, batch, info_actor); if (rc) return bail(rc);
     tag(m, [&](int kid, int& g) {      // GEMMs: LA actor forward, LQ critic forward, LQ critic input gradients, then the actor's (weight, data) pairs
       if (kid == OP_FILL) return 1;      // the info / status rows and the constant dQ = -1 / B
-      if (is_mm(kid)) { const int k = g++; if (k < FA) return 2 + k; if (k < FA + FQ) return Y + (k - FA); if (k < FA + FQ + LQ) return Y + FQ + (k - FA - FQ);
-        return Y + FQ + LQ + 1 + ag + (k - FA - FQ - LQ) / 2; }
-      if (kid == OP_ACT_GRAD) return ag ? Y + FQ + LQ + 1 : -1;      // dZ = act'(mu) .* dmu of a bounded (tanh) action head, between the slice and the actor's backward GEMMs
-      return kid == OP_DPG_ACTION ? 2 + FA : kid == OP_SLICE_ROWS ? Y + FQ + LQ : kid == OP_SUMSQ2 ? Y + FQ + LQ + 1 + ag + BA : (kid == OP_MEAN_INFO || kid == OP_ADAM_GATED) ? Y + FQ + LQ + 2 + ag + BA :
-             kid == OP_ADAM_ADVANCE ? Y + FQ + LQ + 3 + ag + BA : -1; });
+      if (is_mm(kid)) { const int k = g++; if (k < FA) return 2 + k; if (k < FA + FQ) return Y + (k - FA); if (k < FA + FQ + DQ) return Y + FQ + (k - FA - FQ);
+        return Y + FQ + DQ + 1 + ag + pa.stage(k - FA - FQ - DQ); }
+      if (kid == OP_ACT_GRAD) return ag ? Y + FQ + DQ + 1 : -1;      // dZ = act'(mu) .* dmu of a bounded (tanh) action head, between the slice and the actor's backward GEMMs
+      return kid == OP_DPG_ACTION ? 2 + FA : kid == OP_SLICE_ROWS ? Y + FQ + DQ : kid == OP_SUMSQ2 ? Y + FQ + DQ + 1 + ag + BA : (kid == OP_MEAN_INFO || kid == OP_ADAM_GATED) ? Y + FQ + DQ + 2 + ag + BA :
+             kid == OP_ADAM_ADVANCE ? Y + FQ + DQ + 3 + ag + BA : -1; });
     m = exec_mark(c);
     rc = crux_polyak(actor_targ, actor, tau); if (rc) return bail(rc);
     rc = crux_polyak(q1_targ, q1, tau); if (rc) return bail(rc);
     if (q2 && q2_targ) { rc = crux_polyak(q2_targ, q2, tau); if (rc) return bail(rc); }
-    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + FQ + LQ + 3 + ag + BA : -1; });
+    tag(m, [&](int kid, int&) { return kid == OP_POLYAK ? Y + FQ + DQ + 3 + ag + BA : -1; });
   }
   ExecRec* r = rec_of(c);
   if (r->chain) {
     if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + FQ + LQ + 4 + ag + BA - (r->chain_base > 0 ? 2 : 0);
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += Y + FQ + DQ + 4 + ag + BA - (r->chain_base > 0 ? 2 : 0);
     return CRUX_OK;
   }
   if (plan_ok && ph.size() == r->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }

@@ -231,11 +231,10 @@ __global__ void k_cumsum_tiny(const float* v, int64_t n, float* c) { if (threadI
 // cumsum locally non-monotone; 20 levels cost 4 round trips instead of 20. Lane 0, idle in that scheme, fetches cumsum[N] (the total the stratum width is
 // derived from) in the FIRST round, beside the probes, so the total costs no round trip of its own. The interval bookkeeping is predicated, not branched, and
 // the real (lo, hi) live in scalar registers.
-struct PerSearchOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ run, const float* __restrict__ total, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B, int nlev,
-                             const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) {
+// the search of ONE stratum j by the calling wave (all 64 lanes); returns the sampled index (wave-uniform) and, through w_out, its importance weight
+__device__ __forceinline__ int per_search_wave(const int64_t j, const float* __restrict__ run, const float* __restrict__ total, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B, int nlev,
+                             const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight, float* w_out) {
   const int lane = threadIdx.x & 63;
-  const int64_t j = (int64_t)bid_ * 4 + (threadIdx.x >> 6);
-  if (j >= B) return;
   const int Ni = (int)N;
   // cumsum[i] exactly as accumulate_pairwise! forms it: the descent to i's leaf and the sibling totals of its root path in ONE pass (leaf_locate + leaf_prefix fused:
   // the left sibling of a right turn is the slot before the child just entered), all loads independent
@@ -277,12 +276,22 @@ struct PerSearchOp { static __device__ __forceinline__ void run(const unsigned b
     lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
   }
   if (lo >= Ni) lo = Ni - 1;       // the reference would index out of bounds here
+  float w = 0.f;
   if (lane == 0) {
     ids[j] = lo;
     const float pmin = pminmax[1] / ptot;
     const float max_w = powf(pmin * (float)N, -beta);
-    weight[lo] = powf(((float)N * pr[lo]) / ptot, beta) / max_w;
+    w = powf(((float)N * pr[lo]) / ptot, beta) / max_w;
+    weight[lo] = w;
   }
+  *w_out = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w)));
+  return lo;
+}
+struct PerSearchOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ run, const float* __restrict__ total, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B, int nlev,
+                             const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) {
+  const int64_t j = (int64_t)bid_ * 4 + (threadIdx.x >> 6);
+  if (j >= B) return;
+  float w; (void)per_search_wave(j, run, total, pr, pminmax, N, B, nlev, rands, seed, stream, ictr, beta, ids, weight, &w);
 } };
 __global__ __launch_bounds__(256) void k_per_search(const float* __restrict__ run, const float* __restrict__ total, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B, int nlev,
                              const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) { PerSearchOp::run(blockIdx.x, gridDim.x, run, total, pr, pminmax, N, B, nlev, rands, seed, stream, ictr, beta, ids, weight); }
@@ -324,6 +333,31 @@ struct GatherRingAllOp {
   static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, GatherCols g, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) { run_ptr(bid_, nb_, &g, ids, n, base, C); }
 };
 __global__ void k_gather_ring_all(GatherCols g, const int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C) { GatherRingAllOp::run(blockIdx.x, gridDim.x, g, ids, n, base, C); }
+// prioritized_sample! of one row per WAVE, search and gather in ONE launch (round 4): the wave that found stratum j's index copies that row into the batch ring right away --
+// the sampled ids no longer cross a kernel boundary between `searchsortedfirst` and `push!(target, source, ids)` (experience_buffer.jl:340,348). The row's :weight entry is
+// the value the wave has just computed (the source column is written too, as before; the copy takes it from the register instead of reading it back).
+struct PerSampleArgs { const float* run; const float* total; const float* pr; const float* pminmax; int64_t N, B; const double* rands; uint64_t seed, ictr; int64_t* ids; float* weight; int64_t base, C;
+                       int32_t nlev; uint32_t stream; float beta; int32_t pad; GatherCols g; };
+struct PerSampleGatherOp {
+  static __device__ __forceinline__ void run_ptr(const unsigned bid_, const unsigned nb_, const PerSampleArgs* a) {
+    __shared__ GatherCols gs2;
+    { const uint32_t* src = (const uint32_t*)&a->g; uint32_t* dst = (uint32_t*)&gs2; for (int i = threadIdx.x; i < (int)(sizeof(GatherCols) / 4); i += blockDim.x) dst[i] = src[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63; const int64_t j = (int64_t)bid_ * 4 + (threadIdx.x >> 6); const int64_t B = a->B;
+    if (j >= B) return;
+    float* const weight = a->weight; float w;
+    const int lo = per_search_wave(j, a->run, a->total, a->pr, a->pminmax, a->N, B, a->nlev, a->rands, a->seed, a->stream, a->ictr, a->beta, a->ids, weight, &w);
+    const int32_t width = gs2.pre[gs2.n]; const int ncol = gs2.n; const int64_t drow = (a->base + j) % a->C;
+    for (int32_t t = lane; t < width; t += 64) {
+      int k = 0; while (k + 1 < ncol && t >= gs2.pre[k + 1]) ++k;
+      const int32_t e = t - gs2.pre[k]; const int64_t d = drow * gs2.re[k] + e, sidx = (int64_t)lo * gs2.re[k] + e;
+      if (gs2.esz[k] == 4) { uint32_t v = ((const uint32_t*)gs2.src[k])[sidx]; if (gs2.src[k] == (const void*)weight) v = __builtin_bit_cast(uint32_t, w); ((uint32_t*)gs2.dst[k])[d] = v; }
+      else ((uint8_t*)gs2.dst[k])[d] = ((const uint8_t*)gs2.src[k])[sidx];
+    }
+  }
+  static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, PerSampleArgs a) { run_ptr(bid_, nb_, &a); }
+};
+__global__ __launch_bounds__(256) void k_per_sample_gather(PerSampleArgs a) { PerSampleGatherOp::run_ptr(blockIdx.x, gridDim.x, (const PerSampleArgs*)__builtin_amdgcn_kernarg_segment_ptr()); }      // (the table is read where it lies: no private copy)
 struct RingIdsOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, int64_t* out, int64_t n, int64_t base, int64_t C) { const int64_t j = (int64_t)bid_ * blockDim.x + threadIdx.x; if (j < n) out[j] = (base + j) % C; } };
 __global__ void k_ring_ids(int64_t* out, int64_t n, int64_t base, int64_t C) { RingIdsOp::run(blockIdx.x, gridDim.x, out, n, base, C); }
 
@@ -378,17 +412,21 @@ int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool f
 }
 
 // push!(target, source, ids=device ids) (:232-259): gather B rows into target's ring; target.indices mirrors the ids
-static int32_t gather_into(crux_buffer* target, crux_buffer* source, int64_t B, bool fetch_indices) {
-  crux_ctx* c = target->ctx;
-  const int64_t base = target->next_ind, C = target->capacity;
-  crux_prof_begin(c, CRUX_PROF_GATHER);
-  GatherCols g{}; g.n = 0; g.pre[0] = 0;
+bool crux_per_fused_gather() { static const bool on = !(getenv("CRUX_PER_FUSED_GATHER") && getenv("CRUX_PER_FUSED_GATHER")[0] == '0'); return on; }      // 0: search and gather as two launches (tests compare)
+static void gather_table(crux_buffer* target, crux_buffer* source, GatherCols& g) {
+  g = GatherCols{}; g.n = 0; g.pre[0] = 0;
   for (int k = 0; k < CRUX_NCOLS; ++k) {
     if (!has_col(target, k) || !has_col(source, k)) continue;
     const size_t st = col_stride(target, k); const int q = g.n++;
     g.dst[q] = target->col[k]; g.src[q] = source->col[k]; g.esz[q] = st % 4 == 0 ? 4 : 1; g.re[q] = (int32_t)(st % 4 == 0 ? st / 4 : st); g.pre[q + 1] = g.pre[q] + g.re[q];
   }
-  if (g.n > 0) CRUX_RUN(c, GatherRingAllOp, OP_GATHER_RING_ALL, k_gather_ring_all, gridn(B * g.pre[g.n]), 256, c->stream, g, (const int64_t*)target->d_indices, B, base, C);
+}
+static int32_t gather_into(crux_buffer* target, crux_buffer* source, int64_t B, bool fetch_indices, bool rows_done = false) {
+  crux_ctx* c = target->ctx;
+  const int64_t base = target->next_ind, C = target->capacity;
+  crux_prof_begin(c, CRUX_PROF_GATHER);
+  GatherCols g; gather_table(target, source, g);
+  if (g.n > 0 && !rows_done) CRUX_RUN(c, GatherRingAllOp, OP_GATHER_RING_ALL, k_gather_ring_all, gridn(B * g.pre[g.n]), 256, c->stream, g, (const int64_t*)target->d_indices, B, base, C);
   crux_prof_end(c, CRUX_PROF_GATHER);
   int32_t rc = crux_launch_check(c, "k_gather_ring"); if (rc) return rc;
   if (target->prioritized) {       // buffer_like of a prioritized buffer is prioritized too (:84): push! runs update_priorities! on it
@@ -414,7 +452,17 @@ int32_t crux_per_sample(crux_buffer* target, crux_buffer* source, int64_t B, con
   double* d_r = nullptr;
   if (rands) { d_r = (double*)crux_scratch(c, 8 * (size_t)B + 256); if (!d_r) return crux_fail(c, CRUX_ENOMEM, "prioritized_sample!: scratch");
     HIPCHK(c, hipMemcpyAsync(d_r, rands, 8 * (size_t)B, hipMemcpyHostToDevice, c->stream)); }
+  const bool fuse_gather = crux_per_fused_gather() && !c->per_split_sample;
   crux_prof_begin(c, CRUX_PROF_PER_SEARCH);
+  if (fuse_gather) {
+    PerSampleArgs a{}; a.run = source->cumsum; a.total = source->topo_total; a.pr = source->priorities; a.pminmax = source->pminmax; a.N = N; a.B = B; a.nlev = source->topo_levels; a.rands = d_r;
+    a.seed = source->sample_seed; a.stream = source->sample_stream; a.ictr = i; a.beta = beta; a.ids = target->d_indices; a.weight = (float*)source->col[CRUX_COL_WEIGHT]; a.base = target->next_ind; a.C = target->capacity;
+    gather_table(target, source, a.g);
+    CRUX_RUN(c, PerSampleGatherOp, OP_PER_SAMPLE, k_per_sample_gather, (unsigned)((B + 3) / 4), 256, c->stream, a);
+    crux_prof_end(c, CRUX_PROF_PER_SEARCH);
+    rc = crux_launch_check(c, "k_per_sample_gather"); if (rc) return rc;
+    return gather_into(target, source, B, true, /*rows_done=*/true);
+  }
   CRUX_RUN(c, PerSearchOp, OP_PER_SEARCH, k_per_search, (unsigned)((B + 3) / 4), 256, c->stream, source->cumsum, source->topo_total, source->priorities, source->pminmax, N, B, source->topo_levels, (const double*)d_r, source->sample_seed, source->sample_stream, i, beta, target->d_indices, (float*)source->col[CRUX_COL_WEIGHT]);
   crux_prof_end(c, CRUX_PROF_PER_SEARCH);
   rc = crux_launch_check(c, "k_per_search"); if (rc) return rc;
