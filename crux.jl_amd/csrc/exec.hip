@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_phase(const ExecOp* __restrict__ ops, i
 // (cold in every cache) before the first useful load, ~4 us of a one-block phase's 6. The kernel-argument segment is read once, by independent scalar loads, so the
 // chain is arguments -> data, as in a stand-alone launch.
 // The argument struct comes in three sizes (the host copies it on every launch: with 4 KB per launch the enqueue, not the GPU, paced a SAC epoch).
-#define PHASEK_MAXOPS 8
+#define PHASEK_MAXOPS 14
 #define PHASEK_SEQ 0x10000
 template <int BYTES> struct PhaseK { int32_t n; int32_t pad; int32_t kid[PHASEK_MAXOPS]; uint32_t nblocks[PHASEK_MAXOPS]; uint32_t off[PHASEK_MAXOPS]; alignas(16) unsigned char args[BYTES]; };
 static_assert(sizeof(PhaseK<3840>) <= 4096, "HIP kernel arguments are limited to 4 KB");
