@@ -47,6 +47,7 @@ struct crux_ctx {
   void* dense_tmp = nullptr; size_t dense_tmp_bytes = 0;   // minibatch staging of the dense-engine on-policy learner (train_dense.hip)
   void* epoch_tmp = nullptr; size_t epoch_tmp_bytes = 0;   // targets / td errors of the un-fused epoch path
   void* epoch_rows = nullptr; size_t epoch_rows_bytes = 0;      // device info rows of a multi-chain epochs call (exec.hip: one synchronisation per call)
+  unsigned* spec_abort = nullptr;   // host-pinned word a speculatively started critic learner polls once per epoch (train.hip: policy_gradient_training under KL early stopping)
   bool per_split_sample = false;   // prioritized_sample! as two launches (search | gather) while set: the two persistent kernels of dqn_persist.h replay them as separate stages
   bool dqp_broken = false;      // the two persistent kernels of dqn_persist.h did not run side by side once: the phase launches from then on
   float** peer_tab = nullptr;   // device [2 learner streams][8]: region base of every rank for that stream (what the kernel indexes)

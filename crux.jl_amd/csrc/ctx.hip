@@ -126,6 +126,7 @@ int32_t crux_ctx_destroy(crux_ctx* c) {
   if (c->dense_pinned2) (void)hipHostFree(c->dense_pinned2);
   if (c->epoch_tmp) (void)hipFree(c->epoch_tmp);
   if (c->epoch_rows) (void)hipFree(c->epoch_rows);
+  if (c->spec_abort) (void)hipHostFree(c->spec_abort);
   crux_exec_destroy(c);
   for (int k = 0; k < c->aux_n_rejected; ++k) (void)hipStreamDestroy(c->aux_rejected[k]);
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->aux_ev0); (void)hipEventDestroy(c->aux_ev1); }

@@ -471,14 +471,23 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   if (!actor || !critic || !buf || !cfg_a || !cfg_c) return CRUX_EINVAL;
   crux_ctx* c = actor->ctx;
   bool exact = cfg_a->target_kl < 0.f && cfg_a->max_batches <= 0;
+  // KL early stopping (the reference's default PPO, rl/ppo.jl:59): the actor's epoch count e is not known in advance, and the critic's row order is the actor's e shuffles
+  // composed with its own. The critic is started SPECULATIVELY beside the actor on the order for "the actor runs all its epochs" (parameters and Adam state saved first);
+  // when the actor's kernel reports an earlier stop, the critic is told to leave at its next epoch boundary (TrainArgs.spec_abort), restored, and run on the order
+  // composed for e shuffles -- exactly the sequential result either way, never slower than actor-then-critic by more than one critic epoch, twice as fast when the
+  // actor does not stop. CRUX_SPEC_PAIR=0: the sequential order.
+  bool spec = !exact && cfg_a->target_kl >= 0.f && cfg_a->max_batches <= 0 && cfg_c->max_batches <= 0 && CRUX_IS_PG(cfg_a->loss) && cfg_c->loss == CRUX_LOSS_VALUE_MSE && c->peer_n <= 1 &&
+              buf->elements < ((int64_t)1 << 31) && !(getenv("CRUX_SPEC_PAIR") && getenv("CRUX_SPEC_PAIR")[0] == '0');
   { const bool fs_on = !(getenv("CRUX_FS") && atoi(getenv("CRUX_FS")) == 0) && cfg_a->batch_size > 64 && cfg_a->batch_size <= 128;      // the feature-split kernel also takes a 32-wide second layer
     auto mfma_family = [fs_on](const crux_mlp* n) { const NetDesc& d = n->nd; return d.L == 3 && d.dims[1] == 64 && (d.dims[2] == 64 || (d.dims[2] == 32 && fs_on)); };
     bool family = mfma_family(actor) && mfma_family(critic);
-    if (family && exact && fs_on && c->learner_cus == 0 && buf->elements >= cfg_a->batch_size && cfg_a->batch_size == cfg_c->batch_size) {      // 64 wide, but does a register-resident kernel instantiate these shapes?
+    if (family && (exact || spec) && fs_on && c->learner_cus == 0 && buf->elements >= cfg_a->batch_size && cfg_a->batch_size == cfg_c->batch_size) {      // 64 wide, but does a register-resident kernel instantiate these shapes?
       TrainArgs pa, pk; bool ha = false, hk = false;
       if (!fill_args(pa, actor, buf, cfg_a, cfg_a->loss) && !fill_args(pk, critic, buf, cfg_c, cfg_c->loss)) { pa.need_px = pk.need_px = (c->peer_n > 1) ? 1 : 0;
         (void)crux_train_fs_launch(c, pa, &ha, c->stream, true); (void)crux_train_fs_launch(c, pk, &hk, c->stream, true);
         if (!ha || !hk) family = false; } }      // no: the dense engine's pair below instead of one learner after the other
+    else spec = false;                           // (the abort latch lives in the feature-split kernel only)
+    if (!family) spec = false;
     if (!family) {
       // outside the register-resident family: two dense-engine chains (train_dense.hip), one per learner stream, driven by two host threads -- same condition as above
       // (no early stopping, no minibatch cap: the critic's shuffle chain can be composed ahead of the actor's run), no replica group, CRUX_DENSE_PAIR=0 switches it off
@@ -486,7 +495,7 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
         const int32_t rcd = dense_pair(actor, critic, buf, cfg_a, cfg_c, perms_a, perms_c, info_a, info_c, epoch_infos_a, epoch_infos_c);
         if (rcd != CRUX_EUNSUP) return rcd; }
       exact = false; } }     // otherwise dense-engine / generic learners run one after the other on the main stream
-  if (!exact) {
+  if (!exact && !spec) {
     int32_t rc = crux_batch_train(actor, buf, cfg_a, perms_a, info_a, epoch_infos_a); if (rc) return rc;
     return crux_batch_train(critic, buf, cfg_c, perms_c, info_c, epoch_infos_c);
   }
@@ -498,7 +507,8 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   const size_t ea = sizeof(float) * CRUX_INFO_N * (size_t)cfg_a->epochs, ec = sizeof(float) * CRUX_INFO_N * (size_t)cfg_c->epochs;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t pa = perms_a ? al(8 * (size_t)cfg_a->epochs * (size_t)len) : 0, pc = perms_c ? al(8 * (size_t)cfg_c->epochs * (size_t)len) : 0;
-  char* sc = (char*)crux_scratch(c, 512 + al(ea) + al(ec) + pa + pc + 256);
+  const size_t np_c = (size_t)critic->nd.n_params, snap = spec ? al(3 * 4 * np_c + 64) : 0;      // speculative start: the critic's parameters, Adam moments and beta powers as they are now
+  char* sc = (char*)crux_scratch(c, 512 + al(ea) + al(ec) + pa + pc + snap + 256);
   if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_gradient_training: scratch");
   a.status = (int32_t*)sc; k.status = (int32_t*)(sc + 256); a.epoch_infos = (float*)(sc + 512); k.epoch_infos = (float*)(sc + 512 + al(ea));
   HIPCHK(c, hipMemsetAsync(sc, 0, 512 + al(ea) + al(ec), c->stream));
@@ -507,6 +517,15 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
     HIPCHK(c, hipMemcpyAsync(d_pa, perms_a, 8 * (size_t)cfg_a->epochs * (size_t)len, hipMemcpyHostToDevice, c->stream)); }
   if (perms_c) { d_pc = (int64_t*)(sc + 512 + al(ea) + al(ec) + pa); for (int64_t i = 0; i < (int64_t)cfg_c->epochs * len; ++i) if (perms_c[i] < 0 || perms_c[i] >= len) return crux_fail(c, CRUX_EINVAL, "perms_c[%lld] out of range", (long long)i);
     HIPCHK(c, hipMemcpyAsync(d_pc, perms_c, 8 * (size_t)cfg_c->epochs * (size_t)len, hipMemcpyHostToDevice, c->stream)); }
+  float* snap_p = nullptr;
+  if (spec) {
+    snap_p = (float*)(sc + 512 + al(ea) + al(ec) + pa + pc);
+    HIPCHK(c, hipMemcpyAsync(snap_p, critic->p, 4 * np_c, hipMemcpyDeviceToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(snap_p + np_c, critic->m, 4 * np_c, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(snap_p + 2 * np_c, critic->v, 4 * np_c, hipMemcpyDeviceToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(snap_p + 3 * np_c, critic->bp, 16, hipMemcpyDeviceToDevice, c->stream));
+    if (!c->spec_abort) { if (hipHostMalloc((void**)&c->spec_abort, 64, hipHostMallocMapped) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "policy_gradient_training: pinned abort word"); }
+    *(volatile unsigned*)c->spec_abort = 0u;
+    void* dptr = nullptr; HIPCHK(c, hipHostGetDevicePointer(&dptr, c->spec_abort, 0)); k.spec_abort = (const unsigned*)dptr;
+  }
   a.perms = d_pa; k.perms = d_pc;
   k.order_a = buf->order_c; k.order_b = buf->order_d;
   k.pre_epochs = cfg_a->epochs; k.pre_seed = cfg_a->shuffle_seed; k.pre_counter = cfg_a->shuffle_counter; k.pre_perms = d_pa;
@@ -521,9 +540,29 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   rc = launch_train(c, k, CRUX_PROF_TRAIN_CRITIC, c->aux_stream); if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->aux_ev1, c->aux_stream));
   rc = launch_train(c, a, CRUX_PROF_TRAIN_ACTOR); if (rc) return rc;
-  HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
   int32_t sta[4], stc[4];
-  rc = collect(c, a, cfg_a->epochs, info_a, epoch_infos_a, sta); if (rc) return rc;
+  if (spec) {
+    rc = collect(c, a, cfg_a->epochs, info_a, epoch_infos_a, sta);      // waits for the ACTOR only
+    const bool wrong = !rc && sta[0] == 0 && sta[2] < cfg_a->epochs;      // the actor stopped after sta[2] epochs: the critic was started on the order of cfg_a->epochs shuffles
+    if (rc || sta[0] || wrong) { *(volatile unsigned*)c->spec_abort = 1u; (void)hipStreamSynchronize(c->aux_stream); *(volatile unsigned*)c->spec_abort = 0u; }
+    if (rc || sta[0] || wrong) {      // undo the critic's speculative steps (an actor that failed: the reference throws inside the actor's batch_train!, the critic never trains)
+      HIPCHK(c, hipMemcpyAsync(critic->p, snap_p, 4 * np_c, hipMemcpyDeviceToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(critic->m, snap_p + np_c, 4 * np_c, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(critic->v, snap_p + 2 * np_c, 4 * np_c, hipMemcpyDeviceToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(critic->bp, snap_p + 3 * np_c, 16, hipMemcpyDeviceToDevice, c->stream)); }
+    if (rc || sta[0]) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (rc) return rc;
+    if (sta[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
+    if (sta[0]) return crux_fail(c, sta[0], "learner kernel reported status %d", sta[0]);
+    if (wrong) {
+      HIPCHK(c, hipMemsetAsync(k.status, 0, 256, c->stream)); HIPCHK(c, hipMemsetAsync(k.epoch_infos, 0, ec, c->stream));
+      int32_t* oc = nullptr;
+      rc = build_orders(c, buf, 1, sta[2] >= 1 ? a.ord_all + (size_t)(sta[2] - 1) * (size_t)len : nullptr, cfg_c->shuffle_seed, cfg_c->shuffle_counter, d_pc, cfg_c->epochs, c->stream, &oc); if (rc) return rc;
+      k.ord_all = oc; k.spec_abort = nullptr; k.pre_epochs = sta[2];
+      rc = launch_train(c, k, CRUX_PROF_TRAIN_CRITIC); if (rc) return rc;
+    } else HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
+  } else {
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
+    rc = collect(c, a, cfg_a->epochs, info_a, epoch_infos_a, sta); if (rc) return rc;
+  }
   rc = collect(c, k, cfg_c->epochs, info_c, epoch_infos_c, stc); if (rc) return rc;
   if (sta[0] == CRUX_ENAN || stc[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
   if (sta[0] || stc[0]) return crux_fail(c, sta[0] ? sta[0] : stc[0], "learner kernel reported status %d/%d", sta[0], stc[0]);

@@ -3,6 +3,7 @@
 #include "common.h"
 
 #define CRUX_LOSS_TD_INTERNAL 2
+#define CRUX_TRAIN_ABORTED (-99)   // status[0] of a learner launch that left at an epoch boundary because its speculative start order turned out wrong (never crosses the ABI)
 #define CRUX_IS_PG(l) ((l) == CRUX_LOSS_PPO || (l) == CRUX_LOSS_A2C)   // policy-gradient losses share the head, statistics and KL early stopping   // td_loss (src/utils.jl:76-87); reached through crux_td_step
 
 struct TrainArgs {
@@ -38,6 +39,9 @@ struct TrainArgs {
   int32_t px_n, px_rank; float* const* px_tab;   // px_tab: device table [px_n] of the ranks' region bases for this learner stream (own region at px_rank)
   // lagrange_ppo_loss (rl/ppo.jl:70-131): device copy of crux_lagrange (hyper-parameters + PID state), the cost columns; NULL = plain ppo_loss
   crux_lagrange* lag; const float* COST; const float* CADV; const uint8_t* EE;
+  // speculative launch (train.hip: policy_gradient_training with KL early stopping): host-pinned word the kernel looks at once per epoch; non-zero = leave at this epoch
+  // boundary with status CRUX_TRAIN_ABORTED (decided once for all workgroups of the learner through a latch in xctr). NULL = never.
+  const unsigned* spec_abort;
   void* host_net;            // host-side: the crux_mlp this block was filled from (the dense-engine learner drives its GEMM workspace); never read on the device
 };
 

@@ -261,6 +261,19 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   };
 
   for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
+    if (a.spec_abort) {      // a speculative run (train_args.h): thread 0 of every workgroup ORs what it reads from the host's word into an L2 latch, all wait until all have (one
+                             // arrival counter, NWG per epoch), then everyone reads the latch: the same decision in every workgroup, whenever the host's store lands
+      if (tid == 0) {
+        const unsigned r = __hip_atomic_load(a.spec_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        (void)__hip_atomic_fetch_or(a.xctr + 16, r ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        (void)__hip_atomic_fetch_add(a.xctr + 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (unsigned)NWG * (unsigned)(ep + 1); unsigned spins = 0;
+        while (__hip_atomic_load(a.xctr + 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 24)) break; }
+        sm[Lt::oRED + 17] = __hip_atomic_load(a.xctr + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f; }
+      __syncthreads();
+      if (sm[Lt::oRED + 17] != 0.f) { err = CRUX_TRAIN_ABORTED; break; }
+    }
     if (a.ord_all) order_cur = const_cast<int32_t*>(a.ord_all) + (size_t)ep * (size_t)a.len;   // shuffle orders composed ahead of time by k_compose_order
     else {   // shuffle!(D) as an index composition (experience_buffer.jl:118-124)
       if (a.perms) { for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[a.perms[(int64_t)ep * a.len + j]]; }
