@@ -171,6 +171,19 @@ def cpu_baseline(workload="c2"):
         except Exception as e:      # noqa: BLE001  (supplementary)
             out["openmp_all_cores"] = {"error": repr(e)}
         O.select("scalar")
+    try:      # what a BLAS-backed host (Flux -> OpenBLAS sgemm, the reference's arithmetic) does with the same matrix products: a lower bound on its step time
+        import bench_offpolicy
+        bl = bench_offpolicy.blas_leg([(list(w["actor"]), 1, 1), (list(w["critic"]), 1, 1)], BATCH, None)      # one actor + one critic step: forward + pullback each
+        pair = 2.0
+        out["blas_gemm_leg"] = {"gemm_s_per_step_one_thread": (bl["one_thread_s"] / pair) if bl["one_thread_s"] else None, "gemm_s_per_step_all_threads": bl["all_threads_s"] / pair,
+                                "grad_steps_per_s_upper_bound_one_thread": (pair / bl["one_thread_s"]) if bl["one_thread_s"] else None,
+                                "grad_steps_per_s_upper_bound_all_threads": pair / bl["all_threads_s"],
+                                "env_steps_per_s_upper_bound_one_thread": (E * T / (per_env_step * E * T + steps_iter * bl["one_thread_s"] / pair)) if bl["one_thread_s"] else None,
+                                "note": "the Dense products of one actor + one critic minibatch step (forward + pullback, B = 128) through numpy / OpenBLAS sgemm; elementwise work, the loss head, Zygote's tape and Adam excluded: "
+                                        "an UPPER bound on a BLAS-backed host's Adam-step rate, next to the scalar port so that the port's number is not read as the speed of the reference's arithmetic "
+                                        "(the env-steps bound takes the port's rollout time and this step time)"}
+    except Exception as e:      # noqa: BLE001
+        out["blas_gemm_leg"] = {"error": repr(e)}
     ref = julia_reference_probe()
     if ref:
         out["julia_reference"] = ref
@@ -208,7 +221,7 @@ def measure_traffic(workload):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="crux_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0",
-               "--no-cpu-baseline", "--replicas", "0", "--replicas-wide", "0", "--no-extra", "--workload", workload]
+               "--no-cpu-baseline", "--replicas", "0", "--replicas-wide", "0", "--no-extra", "--no-measure-traffic", "--no-early-stop", "--workload", workload]
         try:
             subprocess.run(cmd, capture_output=True, timeout=600, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
             per = []
@@ -422,8 +435,10 @@ def main():
     ap.add_argument("--replicas", type=int, default=64, help="also time S independent PPO learners (multi-seed) trained by two batched launches per iteration: the chip-level utilisation line (0 = skip)")
     ap.add_argument("--replicas-wide", type=int, default=128, help="second multi-seed line with one CU per learner (population > 64): the highest chip utilisation (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the supplementary configs (C5 shard, off-policy lines)")
-    ap.add_argument("--early-stop", action="store_true", help="also time the KL-early-stopping variant (target_kl=0.012)")
-    ap.add_argument("--measure-traffic", action="store_true", help="N = 1: re-measure roofline.traffic in this run -- two child passes of this script under rocprofv3 --pmc FETCH_SIZE / "
+    ap.add_argument("--early-stop", dest="early_stop", action="store_true", default=True, help="also time the KL-early-stopping variant (target_kl = 0.012, the reference's default PPO, rl/ppo.jl:40-65); on by default at N = 1 (BASELINE.md section 3: the metric is reported with KL early stopping on, and with it off)")
+    ap.add_argument("--no-early-stop", dest="early_stop", action="store_false")
+    ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false", help="keep the recorded roofline.traffic constant instead of re-measuring it (the default run measures when rocprofv3 is on PATH)")
+    ap.add_argument("--measure-traffic", action="store_true", default=True, help="N = 1: re-measure roofline.traffic in this run -- two child passes of this script under rocprofv3 --pmc FETCH_SIZE / "
                     "--pmc WRITE_SIZE (separate passes, no trace domains), corrected as the microarchitecture guide prescribes; otherwise the recorded constant of profiles/ is reported")
     ap.add_argument("--selftest", action="store_true", help="N > 1: before timing, check the in-kernel gradient exchange across the real devices (identical shards on every rank must "
                     "reproduce an un-grouped learner; distinct shards must leave the replicas bit-identical), print per-rank flag-wait histograms, and run a 2..N-rank RCCL all-reduce "
@@ -526,7 +541,9 @@ def main():
         for _ in range(args.steps):
             nb, _i = ppo_iteration(crux, pi, buf, sampler, a_es, c_opt, P, it); it += 1; nbs += nb
         ctx.sync(); d1 = time.perf_counter() - t1
-        early = {"env_steps_per_s": args.steps * E * T / d1, "grad_steps_per_s": nbs / d1, "grad_steps_per_iter": nbs / args.steps}
+        early = {"env_steps_per_s": args.steps * E * T / d1, "grad_steps_per_s": nbs / d1, "grad_steps_per_iter": nbs / args.steps, "ms_per_iteration": 1e3 * d1 / args.steps, "target_kl": 0.012,
+                 "note": "the reference's default PPO (KL early stopping, rl/ppo.jl:59): the actor stops after the epoch whose last minibatch has kl > target_kl; the critic learner is started speculatively beside the actor "
+                         "and re-run on the right shuffle order when the actor stopped early (csrc/train.hip) -- bit-identical to actor-then-critic either way. The policy of this leg has already been trained by the timed iterations above."}
 
     def multi_seed_line(Sn):
         try:
@@ -571,13 +588,13 @@ def main():
             except Exception as e:      # noqa: BLE001
                 extra = {"error": repr(e)}
 
-    traffic, traffic_how = (TRAFFIC_RECORDED.get(args.workload) if world == 1 else None), "recorded constant (profiles/r03_pmc_traffic*.txt), not re-measured in this run; --measure-traffic re-measures it"
+    traffic, traffic_how = (TRAFFIC_RECORDED.get(args.workload) if world == 1 else None), "RECORDED constant (profiles/r03_pmc_traffic*.txt), not measured in this run"
     if rank == 0 and world == 1 and args.measure_traffic:
         tv, how = measure_traffic(args.workload)
         if tv is not None:
             traffic, traffic_how = tv, how
         else:
-            traffic_how += " [--measure-traffic failed: %s]" % how
+            traffic_how += " [the in-run measurement (two child passes under rocprofv3 --pmc) was not possible: %s]" % how
     if rank == 0:
         env_steps = args.steps * E * T * world
         ms_actor, n_actor = prof["train_actor"]
@@ -598,7 +615,7 @@ def main():
             "phase_ms_per_iter": {k: v[0] / args.steps for k, v in prof.items()},
             "rollout_env_steps_per_s": (E * T * args.steps) / (prof["rollout"][0] * 1e-3) if prof["rollout"][0] > 0 else None,
             "roofline": {"kernel": "batch_train! actor (k_train_fs: persistent fwd + ppo_loss + bwd + gradient exchange + Adam, 40 960 steps per launch)", "bound": "mfma", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "frac_of_occupied_cus": achieved / (PEAK_F32_MFMA_TFLOPS * 4.0 / 256.0), "occupied_cus": 4, "traffic": traffic,
                          "traffic_note": "HBM-side bytes per actor launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes; FETCH_SIZE tallies 128-byte requests at 64 B, calibrated in profiles/r02_fetch_calibration.txt). " + traffic_how + ". Algorithmic minibatch bytes per launch are %.0f MB (%d steps x %d B): the buffer is re-read from L2/MALL, and the per-step gradient exchange between the learner's workgroups (4 x 18 KB written, 3 x 18 KB read per workgroup and step) stays inside one XCD's L2" % (steps_per_launch * BATCH * (4 * wl["obs"] + (wl["act"] if wl["discrete"] else 4 * wl["act"]) + 8) / 1e6, int(steps_per_launch), BATCH * (4 * wl["obs"] + (wl["act"] if wl["discrete"] else 4 * wl["act"]) + 8)),
                          "avg_launch_ms": avg_launch_s * 1e3, "grad_steps_per_launch": steps_per_launch,
                          "us_per_grad_step": avg_launch_s * 1e6 / steps_per_launch if steps_per_launch else None,
@@ -609,7 +626,7 @@ def main():
         if selftest is not None:
             out["selftest"] = selftest
         if early:
-            out["early_stop"] = early
+            out["early_stop"] = early; out["early_stop_env_steps_per_s"] = early["env_steps_per_s"]; out["early_stop_grad_steps_per_s"] = early["grad_steps_per_s"]
         if multi is not None:
             out["multi_seed"] = multi
         if multi_wide is not None:
