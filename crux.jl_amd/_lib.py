@@ -151,6 +151,8 @@ SIGNATURES = {
     "crux_softq_target": (i32, [vp, vp, f32, f32, vp]),
     "crux_td_step": (i32, [vp, vp, vp, i32, vp]),
     "crux_td_step_with_error": (i32, [vp, vp, vp, i32, vp, vp]),
+    "crux_importance_weight_rows": (i32, [vp, vp, i32, i64, i64]),
+    "crux_fill_importance_weights_rows": (i32, [vp, i64, i64, i64, i32]),
     "crux_mlp_forward_cached": (i32, [vp, vp, i64, vp]),
     "crux_mlp_backward": (i32, [vp, vp, i64, vp, f32, i32, vp]),
     "crux_sac_target": (i32, [vp, vp, vp, vp, vp, f32, u64, u64, vp]),
@@ -190,8 +192,9 @@ def load():
 OK, EINVAL, ENAN, EHIP, ERCCL, ENOMEM, EUNSUP = 0, -1, -2, -3, -4, -5, -6
 ACT = {"identity": 0, "relu": 1, "tanh": 2}
 COL = {"s": 0, "a": 1, "sp": 2, "r": 3, "done": 4, "episode_end": 5, "return": 6, "logprob": 7, "advantage": 8,
-       "weight": 9, "t": 10, "i": 11, "value": 12, "cost": 13, "cost_advantage": 14, "cost_return": 15}
-NCOLS = 16
+       "weight": 9, "t": 10, "i": 11, "value": 12, "cost": 13, "cost_advantage": 14, "cost_return": 15,
+       "importance_weight": 16, "fwd_importance_weight": 17, "rev_importance_weight": 18, "cum_importance_weight": 19, "traj_importance_weight": 20}
+NCOLS = 21
 ACTION_DISCRETE, ACTION_CONTINUOUS = 0, 1
 ENV = {"cartpole": 0, "pendulum": 1, "gridworld": 2, "synth": 3, "synth_discrete": 4}
 HEAD = {"categorical": 0, "gaussian": 1, "greedy_q": 2, "deterministic": 3}

@@ -404,8 +404,9 @@ def clone_policy(pi):
 class PolicyParams:
     """PolicyParams(pi; space, pi_explore, pi_minus) (src/policies.jl:12-19)."""
 
-    def __init__(self, pi, space=None, pi_explore=None, pi_minus=None):
+    def __init__(self, pi, space=None, pi_explore=None, pi_minus=None, pa=None):
         self.pi, self.pi_explore, self.pi_minus = pi, pi_explore if pi_explore is not None else pi, pi_minus
+        self.pa = pa                                   # nominal action policy (policies.jl:17): the reference distribution of :importance_weight (sampler.jl:108-111)
         a = actor(pi)
         self.space = space or (DiscreteSpace(len(a.outputs), a.outputs) if isinstance(a, DiscreteNetwork) else ContinuousSpace(a.network.dims[-1]))
 
@@ -421,7 +422,8 @@ class Adam:
 # --------------------------------------------------------------------------------------------------------------
 # experience buffer (src/experience_buffer.jl)
 # --------------------------------------------------------------------------------------------------------------
-_F32_KEYS = ["return", "logprob", "advantage", "value", "cost", "cost_advantage", "cost_return"]
+_F32_KEYS = ["return", "logprob", "advantage", "value", "cost", "cost_advantage", "cost_return",
+             "importance_weight", "fwd_importance_weight", "rev_importance_weight", "cum_importance_weight", "traj_importance_weight"]      # the last five start at 1 (experience_buffer.jl:17-19)
 
 
 def _np_dtype(key, act_kind):
@@ -442,9 +444,9 @@ def mdp_data(S, A, capacity, extras=()):
          "sp": np.zeros((od, capacity), np.float32, order="F"), "r": np.zeros((1, capacity), np.float32, order="F"),
          "done": np.zeros((1, capacity), np.bool_, order="F"), "episode_end": np.zeros((1, capacity), np.bool_, order="F")}
     for k in extras:
-        if k in _F32_KEYS:
+        if k in _F32_KEYS and not k.endswith("importance_weight"):
             d[k] = np.zeros((1, capacity), np.float32, order="F")
-        elif k == "weight":
+        elif k == "weight" or k.endswith("importance_weight"):      # :17-19 fill(one(R), 1, capacity)
             d[k] = np.ones((1, capacity), np.float32, order="F")
         elif k in ("t", "i"):
             d[k] = np.zeros((1, capacity), np.int64, order="F")
@@ -783,9 +785,10 @@ class GaussianNoiseExplorationPolicy:
 class Sampler:
     """Sampler(mdp, agent; max_steps, required_columns, lambda, S) (src/sampler.jl:1-29) for mdp.n_envs environments."""
 
-    def __init__(self, mdp, agent, S=None, max_steps=100, required_columns=(), lam=float("nan"), ctx=None, Vc=None):
+    def __init__(self, mdp, agent, S=None, max_steps=100, required_columns=(), lam=float("nan"), ctx=None, Vc=None, traj_weight_fn=None):
         self.ctx = ctx or default_context()
         self.mdp = mdp
+        self.traj_weight_fn = traj_weight_fn     # weight of a trajectory (Sampler.traj_weight_fn, src/sampler.jl:21): (agent, data, ep) -> the :traj_importance_weight of the episode's rows (:62)
         self.Vc = Vc                             # cost value network (Sampler.Vc, src/sampler.jl:20): fill_gae!(..., source=:cost, target=:cost_advantage) (:65)
         self.agent = agent if isinstance(agent, PolicyParams) else PolicyParams(agent)
         self.S = S or mdp.state_space()
@@ -837,8 +840,9 @@ def _rollout_cfg(sampler, explore, reset, i):
     return cfg, pi_on
 
 
-def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=None, want_info=True):
-    """steps!(sampler, buffer; Nsteps, explore, i, reset, cb) (src/sampler.jl:139-173).
+def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=None, want_info=True, store=None):
+    """steps!(sampler, buffer; Nsteps, explore, i, reset, cb, store) (src/sampler.jl:139-173). `store`: a list that receives a host copy of the block's columns after the
+    callback ran on them (`!isnothing(store) && push!(store, data)`, :151 -- the solvers' interaction_storage).
 
     Nsteps counts transitions over all of the sampler's environments (Nsteps/n_envs per environment, env-major).
     GAE / returns are filled on the block this call produced, like terminate_episode! does before push! (:53-57,148-152), whatever the
@@ -850,7 +854,7 @@ def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=N
     cfg, pi_on = _rollout_cfg(sampler, explore, reset, i)
     sr, ne = C.c_double(), C.c_int64()
     first = buffer.next_ind - 1                                   # 0-based ring row the block starts at (push!, experience_buffer.jl:236)
-    if not want_info and cb is None:      # callers that do not look at the rewards (the off-policy solve loop): the rollout stays asynchronous, no read-back to wait for
+    if not want_info and cb is None and store is None:      # callers that do not look at the rewards (the off-policy solve loop): the rollout stays asynchronous, no read-back to wait for
         sampler.ctx.check(sampler.ctx.lib.crux_rollout(sampler.h, pi_on.h, C.byref(cfg), buffer.h, Nsteps // E, None, None))
         _fill_block(sampler, buffer, first, Nsteps, reset)
         return {}
@@ -859,6 +863,8 @@ def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=N
     info = {"sum_r": sr.value, "n_episode_end": ne.value, "avg_r": sr.value / ne.value if ne.value else float("nan")}
     if cb:
         cb(buffer, info)
+    if store is not None:                                         # :151, after the callback, before push!(buffer, data): the block as the reference's `data` Dict
+        store.append(buffer.minibatch((first + np.arange(Nsteps)) % buffer.capacity + 1))
     return info
 
 
@@ -873,6 +879,9 @@ def _fill_block(sampler, buffer, first, Nsteps, reset):
         buffer.ctx.check(lib.crux_fill_gae_rows(buffer.h, critic(sampler.agent.pi).h, float(sampler.lam), float(sampler.gamma), int(first), int(Nsteps), int(Nsteps // sampler.n_envs), 1 if reset else 0))
     if buffer.haskey("return"):
         buffer.ctx.check(lib.crux_fill_returns_rows(buffer.h, float(sampler.gamma), int(first), int(Nsteps), int(Nsteps // sampler.n_envs), 1 if reset else 0))
+    # importance weights: the per-step ratio against the nominal action policy (step!, sampler.jl:108-111), then its running products per episode (:58-62, 283-308)
+    if buffer.haskey("importance_weight") or any(buffer.haskey(k) for k in ("fwd_importance_weight", "cum_importance_weight", "rev_importance_weight", "traj_importance_weight")):
+        _fill_importance_weights(sampler, buffer, first, Nsteps, reset)
     # cost constraints (sampler.jl:65-66)
     if buffer.haskey("cost_advantage"):
         if sampler.Vc is None:
@@ -882,6 +891,38 @@ def _fill_block(sampler, buffer, first, Nsteps, reset):
     if buffer.haskey("cost_return"):
         buffer.ctx.check(lib.crux_fill_returns_rows_keys(buffer.h, float(sampler.gamma), int(first), int(Nsteps), int(Nsteps // sampler.n_envs), 1 if reset else 0,
                                                          L.COL["cost"], L.COL["cost_return"]))
+
+
+def _fill_importance_weights(sampler, buffer, first, Nsteps, reset):
+    lib, ctx = buffer.ctx.lib, buffer.ctx
+    if buffer.haskey("importance_weight"):
+        pa = getattr(sampler.agent, "pa", None)
+        if pa is None:
+            raise L.CruxError(L.EINVAL, "steps!: the buffer has an :importance_weight column but the agent has no nominal action policy `pa` (sampler.jl:109)")
+        if not buffer.haskey("logprob"):
+            raise L.CruxError(L.EINVAL, "steps!: :importance_weight needs the :logprob column of the exploration policy (sampler.jl:110)")
+        head = L.HEAD["categorical"] if isinstance(pa, DiscreteNetwork) else L.HEAD["gaussian"]
+        C_ = buffer.capacity; n1 = min(Nsteps, C_ - first)
+        ctx.check(lib.crux_importance_weight_rows(buffer.h, pa.h, head, int(first), int(n1)))
+        if n1 < Nsteps:
+            ctx.check(lib.crux_importance_weight_rows(buffer.h, pa.h, head, 0, int(Nsteps - n1)))
+    if any(buffer.haskey(k) for k in ("fwd_importance_weight", "cum_importance_weight", "rev_importance_weight")):
+        ctx.check(lib.crux_fill_importance_weights_rows(buffer.h, int(first), int(Nsteps), int(Nsteps // sampler.n_envs), 1 if reset else 0))
+    if buffer.haskey("traj_importance_weight"):
+        # data[:traj_importance_weight][1, ep] .= sampler.traj_weight_fn(sampler.agent, data, ep) (sampler.jl:62): a host function of the episode's rows
+        fn = getattr(sampler, "traj_weight_fn", None)
+        if fn is None:
+            raise L.CruxError(L.EINVAL, "steps!: the buffer has a :traj_importance_weight column but the sampler has no traj_weight_fn (sampler.jl:21,62)")
+        C_ = buffer.capacity; ids = (first + np.arange(Nsteps)) % C_ + 1
+        rows = buffer.minibatch(ids); ee = rows["episode_end"].reshape(-1).astype(bool); seg = Nsteps // sampler.n_envs
+        out = rows["traj_importance_weight"].reshape(-1).copy(); start = 0
+        for j in range(Nsteps):
+            last_of_seg = (j + 1) % seg == 0
+            if ee[j] or (last_of_seg and reset):
+                ep = np.arange(start, j + 1); out[ep] = np.float32(fn(sampler.agent, rows, ep)); start = j + 1
+            elif last_of_seg:
+                out[start:j + 1] = 1.0; start = j + 1          # an episode left open: the fresh data block's ones
+        col = buffer["traj_importance_weight"]; col[..., ids - 1] = out; buffer["traj_importance_weight"] = col
 
 
 def episodes_(sampler, Neps=1, explore=False, i=0, seed_offset=0x45564C):
@@ -1194,7 +1235,8 @@ class OnPolicySolver:
     (src/model_free/on_policy.jl:31-54)."""
 
     def __init__(self, agent, S, N=1000, dN=200, max_steps=100, a_opt=None, c_opt=None, P=None, lambda_gae=0.95,
-                 required_columns=(), post_batch_callback=None, post_sample_callback=None, i=0, log=None, Vc=None, cost_opt=None, param_optimizers=None):
+                 required_columns=(), post_batch_callback=None, post_sample_callback=None, i=0, log=None, Vc=None, cost_opt=None, param_optimizers=None, interaction_storage=None):
+        self.interaction_storage = interaction_storage      # a list: every steps! block is appended to it (on_policy.jl:44,96)
         self.Vc, self.cost_opt = Vc, cost_opt      # cost constraints: a separate value network and its TrainingParams (on_policy.jl:50-53)
         self.param_optimizers = list(param_optimizers or [])     # [(ParamVector, TrainingParams(loss=ParamLoss(...)))]: trained before the actor (on_policy.jl:59-61)
         self.agent, self.S, self.N, self.dN, self.max_steps = agent, S, int(N), int(dN), int(max_steps)
@@ -1307,11 +1349,16 @@ def solve(solver, mdp):
         solver.sampler = Sampler(mdp, solver.agent, S=solver.S, required_columns=solver.required_columns, lam=solver.lambda_gae,
                                  max_steps=solver.max_steps, Vc=getattr(solver, "Vc", None))
     D, s = solver.buffer, solver.sampler
+    if solver.log is not None:                                                                                    # :84, :88 log the pre-train performance: log(S.log, S.i, S=S)
+        from . import logging as _lg
+        if solver.log.sampler is None:
+            solver.log.sampler = s
+        _lg.log(solver.log, solver.i, S=solver)
     stop = solver.i + solver.N - solver.dN
     i = solver.i
     while i <= stop:
         solver.i = i
-        info = steps_(s, D, Nsteps=solver.dN, explore=True, i=i, reset=True, cb=solver.post_sample_callback)     # :96
+        info = steps_(s, D, Nsteps=solver.dN, explore=True, i=i, reset=True, cb=solver.post_sample_callback, store=getattr(solver, "interaction_storage", None))     # :96
         if solver.post_batch_callback:
             solver.post_batch_callback(D, info)                                                                   # :99
         tinfo = policy_gradient_training(solver, D)                                                               # :102
@@ -1634,7 +1681,8 @@ class OffPolicySolver:
     def __init__(self, agent, S, N=1000, dN=4, max_steps=100, c_opt=None, buffer_size=1000, buffer=None, buffer_init=None, tau=0.005,
                  prioritized=False, weighted_loss=False, i=0, a_opt=None, param_optimizers=None, P=None, target_fn="dqn", noise_seed=0, log=None, sample_seed=SAMPLE_SEED,
                  target_update=None, priority_fn=None, post_sample_callback=None, post_batch_callback=None, pre_train_callback=None, extra_buffers=(),
-                 buffer_fractions=None, required_columns=()):
+                 buffer_fractions=None, required_columns=(), interaction_storage=None):
+        self.interaction_storage = interaction_storage      # a list: every steps! block is appended to it (off_policy.jl:18,49,126,138)
         self.agent, self.S, self.N, self.dN, self.max_steps, self.c_opt, self.i = agent, S, int(N), int(dN), int(max_steps), c_opt, int(i)
         self.log = log                         # LoggerParams (crux_jl_amd.logging) or None
         self.a_opt, self.param_optimizers, self.P, self.target_fn, self.noise_seed = a_opt, list(param_optimizers or []), dict(P or {}), target_fn, int(noise_seed)
@@ -1999,7 +2047,7 @@ def _solve_small_dqn(solver, D, s, gamma, i, stop):
     crux_dqn_small_solve); returns the first iteration index it did NOT run (== i when the configuration needs the call-by-call loop)."""
     pe, pi, buf = solver.agent.pi_explore, solver.agent.pi, solver.buffer
     if not (solver.fused_epochs and solver.target_fn == "dqn" and not solver.custom_seams() and solver.post_sample_callback is None and solver.pre_train_callback is None
-            and solver.log is None and isinstance(pe, EpsGreedyPolicy) and isinstance(pi, DiscreteNetwork)
+            and solver.log is None and solver.interaction_storage is None and isinstance(pe, EpsGreedyPolicy) and isinstance(pi, DiscreteNetwork)
             and not buf.isprioritized() and not solver.weighted_loss and max(pi.network.dims) < 128 and D.capacity <= 256 and s.n_envs <= 4 and solver.dN % s.n_envs == 0 and i <= stop):
         return i
     p, ctx = solver.c_opt, buf.ctx
@@ -2045,21 +2093,36 @@ def _solve_off_policy(solver, mdp):
     D, s = solver.batch, solver.sampler
     istart = solver.i
     nfill = max(0, solver.buffer_init - len(solver.buffer))                                            # :122
+    fill_info = {}
     if nfill > 0:
         solver.i += nfill                                                                              # :125 (Q12: advanced BEFORE sampling)
-        steps_(s, solver.buffer, Nsteps=nfill, explore=True, i=solver.i, want_info=False)
-        _post_sample(solver, nfill, {})
+        if solver.interaction_storage is not None:      # :126 store=S.interaction_storage: the block goes to the storage after the callback, like the reference's `data`
+            first = solver.buffer.next_ind - 1
+            steps_(s, solver.buffer, Nsteps=nfill, explore=True, i=solver.i, want_info=False)
+            _post_sample(solver, nfill, fill_info)
+            solver.interaction_storage.append(solver.buffer.minibatch((first + np.arange(nfill)) % solver.buffer.capacity + 1))
+        else:
+            steps_(s, solver.buffer, Nsteps=nfill, explore=True, i=solver.i, want_info=False)
+            _post_sample(solver, nfill, fill_info)
+    if solver.log is not None:                                                                         # :130 log the pre-train performance: log(S.log, S.i, info, S=S)
+        from . import logging as _lg
+        if solver.log.sampler is None:
+            solver.log.sampler = s
+        _lg.log(solver.log, solver.i, fill_info, S=solver)
     i = solver.i
     stop = istart + solver.N - solver.dN
     i = _solve_small_dqn(solver, D, s, gamma, i, stop)                                                 # whole iterations in one launch where the configuration allows it
     while i <= stop:                                                                                   # :133
         solver.i = i
+        first_ = solver.buffer.next_ind - 1
         steps_(s, solver.buffer, Nsteps=solver.dN, explore=True, i=i, want_info=False)                # :138 (its info is not used by this loop)
         it_info = {}
         # asynchronous chains when nothing on the host looks at an iteration's result before the next one starts: no logger, no callbacks, built-in seams
         solver._async_now = (solver.async_training and solver.log is None and solver.post_sample_callback is None and solver.pre_train_callback is None
-                             and not solver.custom_seams() and solver.fused_epochs and not getattr(solver, "_async_unsupported", False))
+                             and not solver.custom_seams() and solver.fused_epochs and not getattr(solver, "_async_unsupported", False) and solver.interaction_storage is None)
         _post_sample(solver, solver.dN, it_info)                                                      # :138 cb = D -> S.post_sample_callback(D, S=S, info=info)
+        if solver.interaction_storage is not None:                                                    # :138 store=S.interaction_storage (after the callback, sampler.jl:150-151)
+            solver.interaction_storage.append(solver.buffer.minibatch((first_ + np.arange(solver.dN)) % solver.buffer.capacity + 1))
         if solver.pre_train_callback is not None:
             solver.pre_train_callback(solver, info=it_info)                                           # :140
         try:

@@ -305,3 +305,75 @@ int32_t crux_whiten(crux_buffer* b, int32_t key) {
 }
 
 }  // extern "C"
+
+// ---- importance-weight columns (src/sampler.jl:58-62,108-111,283-308) ------------------------------------------------------------------------
+// exp.(logpdf(pa, s, a) .- logprob): z = the nominal policy's outputs of the rows [nout x n]
+__global__ void k_importance_weight(const float* __restrict__ z, int nout, const void* __restrict__ act, int act_kind, const float* __restrict__ ls, const float* __restrict__ lp, int64_t n, float* __restrict__ iw) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (j >= n) return;
+  float nom;
+  if (act_kind == CRUX_ACTION_DISCRETE) {      // categorical_logpdf (policies.jl:128-135): log(sum(softmax(z) .* onehot))
+    const uint8_t* a = (const uint8_t*)act + j * nout; const float* zz = z + j * nout;
+    float mx = zz[0]; for (int k = 1; k < nout; ++k) mx = zz[k] > mx ? zz[k] : mx;
+    float sum = 0.f; for (int k = 0; k < nout; ++k) sum = __fadd_rn(sum, expf(__fsub_rn(zz[k], mx)));
+    float q = 0.f; for (int k = 0; k < nout; ++k) q = __fadd_rn(q, __fmul_rn(__fdiv_rn(expf(__fsub_rn(zz[k], mx)), sum), a[k] ? 1.f : 0.f));
+    nom = logf(q);
+  } else {                                     // gaussian_logpdf (policies.jl:333-336)
+    const float* a = (const float*)act + j * nout; const float* mu = z + j * nout; nom = 0.f;
+    for (int d = 0; d < nout; ++d) { const float sg = expf(ls[d]), s2 = __fmul_rn(sg, sg), df = __fsub_rn(a[d], mu[d]);
+      nom = __fadd_rn(nom, __fsub_rn(__fsub_rn(-(__fmul_rn(df, df)) / __fmul_rn(2.f, s2), 0.9189385332046727f), ls[d])); }
+  }
+  iw[j] = expf(__fsub_rn(nom, lp[j]));
+}
+// one thread per episode (the one sitting on its last row), as gae_returns_body: rev walks the episode backwards, fwd forwards, cum is the product of the whole episode
+__global__ void k_importance_fills(const float* __restrict__ iw, const uint8_t* __restrict__ ee, int64_t n, float* __restrict__ fwd, float* __restrict__ cum, float* __restrict__ rev,
+                                   int64_t first, int64_t cap, int close_last, int64_t seg) {
+  if (cap <= 0) cap = n;
+  if (seg <= 0) seg = n;
+  auto phys = [&](int64_t k) -> int64_t { const int64_t q = first + k; return q >= cap ? q - cap : q; };
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool closed = ee[phys(i)];
+    if (!(closed || i == n - 1 || (i + 1) % seg == 0)) continue;
+    const int64_t k0 = (i / seg) * seg;
+    int64_t start = i; while (start > k0 && !ee[phys(start - 1)]) --start;
+    if (!closed && !close_last) {            // an episode still open at the end of the segment: terminate_episode! never reached it, the fresh data block holds ones
+      for (int64_t k = start; k <= i; ++k) { const int64_t q = phys(k); if (fwd) fwd[q] = 1.f; if (cum) cum[q] = 1.f; if (rev) rev[q] = 1.f; }
+      continue;
+    }
+    float w = 1.f;
+    if (rev) for (int64_t k = i; k >= start; --k) { const int64_t q = phys(k); w = __fmul_rn(iw[q], w); rev[q] = w; }      // :301-308
+    w = 1.f;
+    for (int64_t k = start; k <= i; ++k) { const int64_t q = phys(k); w = __fmul_rn(iw[q], w); if (fwd) fwd[q] = w; }     // :283-290
+    if (cum) for (int64_t k = start; k <= i; ++k) cum[phys(k)] = w;                                                          // :292-299
+  }
+}
+extern "C" int32_t crux_importance_weight_rows(crux_buffer* b, crux_mlp* nominal, int32_t head, int64_t first_row, int64_t n_rows) {
+  if (!b || !nominal) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx;
+  if (!has_col(b, CRUX_COL_IMPORTANCE_WEIGHT) || !has_col(b, CRUX_COL_LOGPROB)) return crux_fail(c, CRUX_EINVAL, "importance_weight: the buffer needs :importance_weight and :logprob columns");
+  if (n_rows == 0) return CRUX_OK;
+  if (first_row < 0 || n_rows < 0 || first_row + n_rows > b->capacity) return crux_fail(c, CRUX_EINVAL, "importance_weight: rows [%lld, %lld) outside the buffer (a wrapped range takes two calls)", (long long)first_row, (long long)(first_row + n_rows));
+  const int nout = nominal->nd.dims[nominal->nd.L];
+  const bool disc = b->act_kind == CRUX_ACTION_DISCRETE;
+  if (nominal->nd.dims[0] != b->obs_dim || nout != b->act_dim || (disc ? head != CRUX_HEAD_CATEGORICAL : (head != CRUX_HEAD_GAUSSIAN || nominal->nd.n_extra != nout)))
+    return crux_fail(c, CRUX_EINVAL, "importance_weight: the nominal policy must map obs(%d) -> %d with a %s head", b->obs_dim, b->act_dim, disc ? "categorical" : "Gaussian (logSigma extras)");
+  if (nominal->squash > 0.f) return crux_fail(c, CRUX_EUNSUP, "importance_weight: SquashedGaussianPolicy nominal policies are not wired up");
+  float* z = (float*)crux_scratch(c, 4 * (size_t)n_rows * nout + 256); if (!z) return crux_fail(c, CRUX_ENOMEM, "importance_weight: scratch");
+  int32_t rc = crux_mlp_forward_impl(nominal, (const float*)b->col[CRUX_COL_S] + (size_t)first_row * b->obs_dim, n_rows, z, nullptr); if (rc) return rc;
+  const char* act = (const char*)b->col[CRUX_COL_A] + (size_t)first_row * col_stride(b, CRUX_COL_A);
+  hipLaunchKernelGGL(k_importance_weight, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, (const float*)z, nout, (const void*)act, b->act_kind, disc ? (const float*)nullptr : (const float*)(nominal->p + nominal->nd.xoff),
+                     (const float*)b->col[CRUX_COL_LOGPROB] + first_row, n_rows, (float*)b->col[CRUX_COL_IMPORTANCE_WEIGHT] + first_row);
+  return crux_launch_check(c, "k_importance_weight");
+}
+extern "C" int32_t crux_fill_importance_weights_rows(crux_buffer* b, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last) {
+  if (!b) return CRUX_EINVAL;
+  crux_ctx* c = b->ctx;
+  const bool hf = has_col(b, CRUX_COL_FWD_IMPORTANCE_WEIGHT), hc = has_col(b, CRUX_COL_CUM_IMPORTANCE_WEIGHT), hr = has_col(b, CRUX_COL_REV_IMPORTANCE_WEIGHT);
+  if (!hf && !hc && !hr) return CRUX_OK;
+  if (!has_col(b, CRUX_COL_IMPORTANCE_WEIGHT)) return crux_fail(c, CRUX_EINVAL, "fill_*_importance_weight!: the buffer has no :importance_weight column (@assert haskey(data, :importance_weight), sampler.jl:284)");
+  if (n_rows == 0) return CRUX_OK;
+  if (first_row < 0 || first_row >= b->capacity || n_rows < 0 || n_rows > b->capacity) return crux_fail(c, CRUX_EINVAL, "fill_*_importance_weight!: rows out of range");
+  hipLaunchKernelGGL(k_importance_fills, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, (const float*)b->col[CRUX_COL_IMPORTANCE_WEIGHT], (const uint8_t*)b->col[CRUX_COL_EPISODE_END], n_rows,
+                     hf ? (float*)b->col[CRUX_COL_FWD_IMPORTANCE_WEIGHT] : (float*)nullptr, hc ? (float*)b->col[CRUX_COL_CUM_IMPORTANCE_WEIGHT] : (float*)nullptr, hr ? (float*)b->col[CRUX_COL_REV_IMPORTANCE_WEIGHT] : (float*)nullptr,
+                     first_row, b->capacity, close_last, rows_per_env);
+  return crux_launch_check(c, "k_importance_fills");
+}

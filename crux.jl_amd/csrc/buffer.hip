@@ -156,7 +156,7 @@ int32_t crux_buffer_create(crux_ctx* ctx, int32_t obs_dim, int32_t act_dim, int3
     const size_t bytes = col_stride(b, k) * (size_t)capacity;
     if (hipMalloc(&b->col[k], bytes) != hipSuccess) { crux_buffer_destroy(b); return crux_fail(ctx, CRUX_ENOMEM, "buffer_create: hipMalloc(%zu) failed", bytes); }
     HIPCHK(ctx, hipMemsetAsync(b->col[k], 0, bytes, ctx->stream));
-    if (k == CRUX_COL_WEIGHT) hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(capacity)), dim3(256), 0, ctx->stream, (float*)b->col[k], 1.0f, capacity);   // :17-19
+    if (CRUX_COL_INIT_ONE(k)) hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(capacity)), dim3(256), 0, ctx->stream, (float*)b->col[k], 1.0f, capacity);   // :17-19
   }
   b->prioritized = prioritized != 0; b->alpha = alpha;
   if (hipMalloc(&b->d_indices, sizeof(int64_t) * (size_t)capacity) != hipSuccess || hipMalloc(&b->order_a, 4 * (size_t)capacity) != hipSuccess ||

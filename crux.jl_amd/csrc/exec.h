@@ -19,7 +19,7 @@ enum {
   OP_PER_SAMPLE                        // per.hip: search + gather of one row per wave (round 4)
 };
 
-#define CRUX_EXEC_ARG_BYTES 624
+#define CRUX_EXEC_ARG_BYTES 768
 struct ExecOp { int32_t kid; uint32_t nblocks; int32_t barrier; int32_t abytes; alignas(8) unsigned char args[CRUX_EXEC_ARG_BYTES]; };   // abytes: size of the packed arguments actually used
 
 // ---- argument packs: the parameters of XOp::run after (bid, nblocks), stored by value in declaration order --------------------------------

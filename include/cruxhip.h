@@ -118,7 +118,12 @@ enum { CRUX_COL_S = 0, CRUX_COL_A = 1, CRUX_COL_SP = 2, CRUX_COL_R = 3, CRUX_COL
        CRUX_COL_EPISODE_END = 5, CRUX_COL_RETURN = 6, CRUX_COL_LOGPROB = 7, CRUX_COL_ADVANTAGE = 8,
        CRUX_COL_WEIGHT = 9, CRUX_COL_T = 10, CRUX_COL_I = 11, CRUX_COL_VALUE = 12,
        /* cost-constrained solvers (LagrangePPO, rl/ppo.jl:211): info["cost"] of the step (sampler.jl:114), its GAE under the cost critic Vc and its return (:65-66) */
-       CRUX_COL_COST = 13, CRUX_COL_COST_ADVANTAGE = 14, CRUX_COL_COST_RETURN = 15, CRUX_NCOLS = 16 };
+       CRUX_COL_COST = 13, CRUX_COL_COST_ADVANTAGE = 14, CRUX_COL_COST_RETURN = 15,
+       /* importance-weight columns (experience_buffer.jl:17-19: Float32, initialised to ONE like :weight): the per-step ratio exp(logpdf(pa, s, a) - logprob) of the nominal
+        * action policy `pa` (sampler.jl:108-111) and its running products over the episode, filled by terminate_episode! (sampler.jl:58-62,283-308) */
+       CRUX_COL_IMPORTANCE_WEIGHT = 16, CRUX_COL_FWD_IMPORTANCE_WEIGHT = 17, CRUX_COL_REV_IMPORTANCE_WEIGHT = 18, CRUX_COL_CUM_IMPORTANCE_WEIGHT = 19, CRUX_COL_TRAJ_IMPORTANCE_WEIGHT = 20,
+       CRUX_NCOLS = 21 };
+#define CRUX_COL_INIT_ONE(k) ((k) == CRUX_COL_WEIGHT || ((k) >= CRUX_COL_IMPORTANCE_WEIGHT && (k) <= CRUX_COL_TRAJ_IMPORTANCE_WEIGHT))
 enum { CRUX_ACTION_DISCRETE = 0 /* Bool one-hot, 1 byte each (src/spaces.jl:18,24) */,
        CRUX_ACTION_CONTINUOUS = 1 /* Float32 */ };
 /* column_mask: bit k set => optional column k present (S,A,SP,R,DONE,EPISODE_END always are).   */
@@ -263,6 +268,13 @@ int32_t crux_fill_returns_rows(crux_buffer* b, float gamma, int64_t first_row, i
  * source / target: CRUX_COL_* of Float32 one-row columns.                                                                                         */
 int32_t crux_fill_gae_keys(crux_buffer* b, crux_mlp* critic, float lambda, float gamma, int32_t source, int32_t target);
 int32_t crux_fill_returns_keys(crux_buffer* b, float gamma, int32_t source, int32_t target);
+/* :importance_weight of buffer rows [first_row, first_row + n_rows) (no ring wrap): exp.(logpdf(pa, s, a) .- logprob) with the nominal action policy `pa`
+ * (step!, src/sampler.jl:108-111; head = CRUX_HEAD_CATEGORICAL | CRUX_HEAD_GAUSSIAN as in crux_train_cfg; needs :logprob and :importance_weight). */
+int32_t crux_importance_weight_rows(crux_buffer* b, crux_mlp* nominal, int32_t head, int64_t first_row, int64_t n_rows);
+/* fill_fwd_importance_weight! / fill_cum_importance_weight! / fill_rev_importance_weight! (src/sampler.jl:283-308) over the episodes of a block of rows, for
+ * whichever of the three columns the buffer has (terminate_episode!, :58-60); block geometry as crux_fill_gae_rows. Rows of an episode left open at the end of a
+ * segment keep the value mdp_data gave them (1). */
+int32_t crux_fill_importance_weights_rows(crux_buffer* b, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last);
 int32_t crux_fill_gae_rows_keys(crux_buffer* b, crux_mlp* critic, float lambda, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last, int32_t source, int32_t target);
 int32_t crux_fill_returns_rows_keys(crux_buffer* b, float gamma, int64_t first_row, int64_t n_rows, int64_t rows_per_env, int32_t close_last, int32_t source, int32_t target);
 /* b[key] .= whiten(b[key]) (utils.jl:41-42; PPO post_batch_callback ppo.jl:61). Bessel-corrected. */

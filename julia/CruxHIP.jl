@@ -40,8 +40,9 @@ struct TrainCfg
 end
 @assert sizeof(RolloutCfg) == 72 && sizeof(TrainCfg) == 64
 
-const NCOLS = 16   # CRUX_NCOLS (cruxhip.h)
-const COL = Dict(:s => 0, :a => 1, :sp => 2, :r => 3, :done => 4, :episode_end => 5, :return => 6, :logprob => 7, :advantage => 8, :weight => 9, :t => 10, :i => 11, :value => 12, :cost => 13, :cost_advantage => 14, :cost_return => 15)
+const NCOLS = 21   # CRUX_NCOLS (cruxhip.h)
+const COL = Dict(:s => 0, :a => 1, :sp => 2, :r => 3, :done => 4, :episode_end => 5, :return => 6, :logprob => 7, :advantage => 8, :weight => 9, :t => 10, :i => 11, :value => 12, :cost => 13, :cost_advantage => 14, :cost_return => 15,
+                 :importance_weight => 16, :fwd_importance_weight => 17, :rev_importance_weight => 18, :cum_importance_weight => 19, :traj_importance_weight => 20)
 const HEAD_CATEGORICAL, HEAD_GAUSSIAN, HEAD_GREEDY_Q, HEAD_DETERMINISTIC = Int32(0), Int32(1), Int32(2), Int32(3)
 const LOSS_PPO, LOSS_VALUE_MSE, LOSS_A2C, LOSS_REINFORCE, LOSS_LOGPDF_BC, LOSS_MSE_ACTION = Int32(0), Int32(1), Int32(3), Int32(4), Int32(5), Int32(6)
 const INFO_N = 16
@@ -146,6 +147,14 @@ function Crux.steps!(s::HipSampler, b::HipBuffer; Nsteps=1, explore=false, i=0, 
     haskey(b, :advantage) && check(b.ctx, ccall((:crux_fill_gae_rows, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Int64, Int64, Int64, Int32),
                                                 b.h, Crux.critic(s.agent.π).h, s.λ, s.γ, first, Nsteps, T, reset))
     haskey(b, :return) && check(b.ctx, ccall((:crux_fill_returns_rows, LIB), Int32, (Ptr{Cvoid}, Float32, Int64, Int64, Int64, Int32), b.h, s.γ, first, Nsteps, T, reset))
+    # importance weights (:58-62, 108-111): the per-step ratio against the nominal action policy agent.pa, then its running products per episode
+    if haskey(b, :importance_weight)
+        pa = s.agent.pa; head = pa isa DiscreteNetwork ? Int32(0) : Int32(1); C = capacity(b); n1 = min(Nsteps, C - first)
+        check(b.ctx, ccall((:crux_importance_weight_rows, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64, Int64), b.h, pa.h, head, first, n1))
+        n1 < Nsteps && check(b.ctx, ccall((:crux_importance_weight_rows, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64, Int64), b.h, pa.h, head, 0, Nsteps - n1))
+    end
+    (haskey(b, :fwd_importance_weight) || haskey(b, :cum_importance_weight) || haskey(b, :rev_importance_weight)) &&
+        check(b.ctx, ccall((:crux_fill_importance_weights_rows, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int64, Int32), b.h, first, Nsteps, T, reset))
     cb(b); Dict("avg_r" => sr[] / ne[])
 end
 Crux.fill_gae!(b::HipBuffer, V::HipNetwork, λ::Float32, γ::Float32) = check(b.ctx, ccall((:crux_fill_gae, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32), b.h, V.h, λ, γ))   # :255-273

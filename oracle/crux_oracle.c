@@ -206,7 +206,7 @@ orc_buffer* orc_buffer_create(int32_t obs_dim, int32_t act_dim, int32_t act_kind
   if (prioritized) b->mask |= 1u << CRUX_COL_WEIGHT;            /* experience_buffer.jl:71 */
   for (int k = 0; k < CRUX_NCOLS; ++k) if (b->mask & (1u << k)) {
     b->col[k] = calloc((size_t)capacity, col_stride(b, k));
-    if (k == CRUX_COL_WEIGHT) for (int64_t i = 0; i < capacity; ++i) ((float*)b->col[k])[i] = 1.0f;   /* :17-19 ones */
+    if (CRUX_COL_INIT_ONE(k)) for (int64_t i = 0; i < capacity; ++i) ((float*)b->col[k])[i] = 1.0f;   /* :17-19 ones */
   }
   b->prioritized = prioritized; b->alpha = alpha;
   if (prioritized) { b->priorities = (float*)calloc((size_t)capacity, 4); b->cumsum = (float*)calloc((size_t)capacity, 4);
@@ -803,6 +803,39 @@ int32_t orc_fill_returns_keys(orc_buffer* b, float gamma, int32_t source, int32_
   free(st); free(en); return CRUX_OK;
 }
 int32_t orc_fill_returns(orc_buffer* b, float gamma) { return orc_fill_returns_keys(b, gamma, CRUX_COL_R, CRUX_COL_RETURN); }
+/* :importance_weight of every row: exp.(logpdf(pa, s, a) .- logprob) with the nominal action policy pa (step!, sampler.jl:108-111);
+ * categorical_logpdf policies.jl:128-135, gaussian_logpdf :333-336 */
+int32_t orc_importance_weight(orc_buffer* b, orc_mlp* nominal, int32_t head) {
+  if (!(b->mask & (1u << CRUX_COL_IMPORTANCE_WEIGHT)) || !(b->mask & (1u << CRUX_COL_LOGPROB))) return CRUX_EINVAL;
+  const int od = b->obs_dim, ad = b->act_dim, nout = nominal->dims[nominal->n_layers]; if (nout != ad || nominal->dims[0] != od) return CRUX_EINVAL;
+  colcache c = cc_alloc(nominal); float p[64]; if (nout > 64) { cc_free(nominal, &c); return CRUX_EINVAL; }
+  const float* S = (const float*)b->col[CRUX_COL_S]; const float* LP = (const float*)b->col[CRUX_COL_LOGPROB]; float* IW = (float*)b->col[CRUX_COL_IMPORTANCE_WEIGHT];
+  for (int64_t j = 0; j < b->elements; ++j) {
+    fwd_col(nominal, S + (size_t)j * od, c.h); const float* z = c.h[nominal->n_layers]; float nom;
+    if (head == CRUX_HEAD_CATEGORICAL) { const uint8_t* a = (const uint8_t*)b->col[CRUX_COL_A] + (size_t)j * ad;
+      softmax_col(z, nout, p); float q = 0.f; for (int k = 0; k < nout; ++k) q = q + p[k] * (a[k] ? 1.f : 0.f); nom = logf(q); }
+    else { const float* a = (const float*)b->col[CRUX_COL_A] + (size_t)j * ad; const float* ls = nominal->p + xoff(nominal); nom = 0.f;
+      for (int d = 0; d < ad; ++d) { float sg = expf(ls[d]), s2 = sg * sg, df = a[d] - z[d]; nom = nom + ((-(df * df) / (2.f * s2) - 0.9189385332046727f) - ls[d]); } }
+    IW[j] = expf(nom - LP[j]);
+  }
+  cc_free(nominal, &c); return CRUX_OK;
+}
+/* fill_fwd_importance_weight! / fill_cum_importance_weight! / fill_rev_importance_weight! (sampler.jl:283-308) over episodes(b), as terminate_episode! calls them (:58-60) */
+int32_t orc_fill_importance_weights(orc_buffer* b) {
+  if (!(b->mask & (1u << CRUX_COL_IMPORTANCE_WEIGHT))) return CRUX_EINVAL;                       /* @assert haskey(data, :importance_weight) */
+  int64_t n = b->elements; if (n == 0) return CRUX_OK;
+  const float* iw = (const float*)b->col[CRUX_COL_IMPORTANCE_WEIGHT];
+  float* fwd = (b->mask & (1u << CRUX_COL_FWD_IMPORTANCE_WEIGHT)) ? (float*)b->col[CRUX_COL_FWD_IMPORTANCE_WEIGHT] : NULL;
+  float* cum = (b->mask & (1u << CRUX_COL_CUM_IMPORTANCE_WEIGHT)) ? (float*)b->col[CRUX_COL_CUM_IMPORTANCE_WEIGHT] : NULL;
+  float* rev = (b->mask & (1u << CRUX_COL_REV_IMPORTANCE_WEIGHT)) ? (float*)b->col[CRUX_COL_REV_IMPORTANCE_WEIGHT] : NULL;
+  int64_t* st = (int64_t*)malloc(8 * (size_t)n); int64_t* en = (int64_t*)malloc(8 * (size_t)n);
+  int64_t ne = orc_buffer_episodes(b, st, en, n);
+  for (int64_t k = 0; k < ne; ++k) { float w;
+    if (fwd) { w = 1.f; for (int64_t i = st[k]; i <= en[k]; ++i) { w = iw[i] * w; fwd[i] = w; } }                    /* :283-290 */
+    if (cum) { w = 1.f; for (int64_t i = st[k]; i <= en[k]; ++i) w = iw[i] * w; for (int64_t i = st[k]; i <= en[k]; ++i) cum[i] = w; }   /* :292-299 */
+    if (rev) { w = 1.f; for (int64_t i = en[k]; i >= st[k]; --i) { w = iw[i] * w; rev[i] = w; } } }                  /* :301-308 */
+  free(st); free(en); return CRUX_OK;
+}
 /* whiten(v) = (v .- mean(v)) ./ std(v)  utils.jl:41-42; [3P] Statistics.std is Bessel-corrected; the
  * reductions are evaluated in Float64 here and rounded to Float32 (Julia uses pairwise Float32). */
 int32_t orc_whiten(orc_buffer* b, int32_t key) {

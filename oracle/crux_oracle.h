@@ -91,6 +91,8 @@ int32_t orc_env_step_host(int32_t kind, int64_t n, const double* state, const vo
 /* advantage pipeline */
 int32_t orc_fill_gae(orc_buffer* b, orc_mlp* critic, float lambda, float gamma);
 int32_t orc_fill_returns(orc_buffer* b, float gamma);
+int32_t orc_importance_weight(orc_buffer* b, orc_mlp* nominal, int32_t head);      /* sampler.jl:108-111 */
+int32_t orc_fill_importance_weights(orc_buffer* b);                                 /* sampler.jl:58-60,283-308 */
 int32_t orc_fill_gae_keys(orc_buffer* b, orc_mlp* critic, float lambda, float gamma, int32_t source, int32_t target);
 int32_t orc_fill_returns_keys(orc_buffer* b, float gamma, int32_t source, int32_t target);
 int32_t orc_whiten(orc_buffer* b, int32_t key);

