@@ -181,6 +181,7 @@ int32_t crux_buffer_destroy(crux_buffer* b) {
   if (b->priorities) (void)hipFree(b->priorities); if (b->cumsum) (void)hipFree(b->cumsum); if (b->pminmax) (void)hipFree(b->pminmax);
   if (b->d_indices) (void)hipFree(b->d_indices); if (b->order_a) (void)hipFree(b->order_a); if (b->order_b) (void)hipFree(b->order_b);
   if (b->order_c) (void)hipFree(b->order_c); if (b->order_d) (void)hipFree(b->order_d);
+  if (b->pack) (void)hipFree(b->pack);
   for (int q = 0; q < 2; ++q) if (b->ord_all[q]) (void)hipFree(b->ord_all[q]);
   if (b->aux_ones) (void)hipFree(b->aux_ones); if (b->aux_zeros) (void)hipFree(b->aux_zeros);
   delete b; return CRUX_OK;

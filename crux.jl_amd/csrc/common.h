@@ -149,6 +149,7 @@ struct crux_buffer {
   int32_t* order_b = nullptr;
   float* aux_ones = nullptr; float* aux_zeros = nullptr;   // [capacity] constant columns (logpdf_bc_loss = a2c_loss with advantage 1, old logprob 0)
   int32_t* ord_all[2] = {nullptr, nullptr}; size_t ord_all_cap[2] = {0, 0};   // per-epoch composed orders (ints) for the actor / critic learner
+  float* pack = nullptr; size_t pack_floats = 0;   // packed learner rows (train.hip: ensure_pack), capacity x stride floats
   int32_t* order_c = nullptr;    // second pair for the concurrent critic learner
   int32_t* order_d = nullptr;
 };

@@ -125,6 +125,49 @@ static int32_t build_orders(crux_ctx* c, crux_buffer* buf, int slot, const int32
 }
 
 bool crux_train_dense_eligible(const TrainArgs& a, size_t generic_lds, bool force_generic);     // train_dense.hip
+// ---- packed learner rows --------------------------------------------------------------------------------------------------------------------
+// One line per transition with everything a policy-gradient / critic minibatch step reads of it: [s | action | logprob | advantage | return], padded to a power of two of
+// floats (C2: 8 floats = 32 B, C5: 32 floats = 128 B). Written once per batch_train! call (the columns do not change while the learners run; :advantage was whitened before);
+// the feature-split kernel then fetches ONE line per sample through the composed shuffle order instead of four to five scattered pieces.
+__global__ void k_pack_rows(const float* __restrict__ S, const void* __restrict__ A, int act_kind, const float* __restrict__ LP, const float* __restrict__ ADV, const float* __restrict__ RET,
+                            int od, int ad, int64_t n, int stride, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; const int64_t row = t / stride; const int e = (int)(t - row * stride);
+  if (row >= n) return;
+  const int na = act_kind == CRUX_ACTION_DISCRETE ? 1 : ad;
+  float v = 0.f;
+  if (e < od) v = S[row * od + e];
+  else if (e < od + na) { if (act_kind == CRUX_ACTION_DISCRETE) { int ai = 0; const uint8_t* a = (const uint8_t*)A + row * ad; for (int k = 0; k < ad; ++k) ai = a[k] ? k : ai; v = (float)ai; }      // the index the kernel's staging derives from the one-hot bytes
+                          else v = ((const float*)A)[row * ad + (e - od)]; }
+  else if (e == od + na) v = LP ? LP[row] : 0.f;
+  else if (e == od + na + 1) v = ADV ? ADV[row] : 0.f;
+  else if (e == od + na + 2) v = RET ? RET[row] : 0.f;
+  out[t] = v;
+}
+// builds buf->pack for the rows [0, elements) on `st`; fills the PACK fields of `a` (and of `k` when given: actor and critic share the lines). Skipped (PACK stays NULL) for
+// shapes whose row would not fit 64 floats, custom column selections (the critic against :cost_return) and CRUX_PACK_ROWS=0.
+static int32_t ensure_pack(crux_ctx* c, crux_buffer* buf, hipStream_t st, TrainArgs& a, TrainArgs* k) {
+  if (getenv("CRUX_PACK_ROWS") && getenv("CRUX_PACK_ROWS")[0] == '0') return CRUX_OK;
+  const int od = buf->obs_dim, ad = buf->act_dim, na = buf->act_kind == CRUX_ACTION_DISCRETE ? 1 : ad; const int need = od + na + 3;
+  if (need > 64 || a.lag || a.ids) return CRUX_OK;
+  const float* ret = has_col(buf, CRUX_COL_RETURN) ? (const float*)buf->col[CRUX_COL_RETURN] : nullptr;
+  if ((a.RET && a.RET != ret) || (k && k->RET && k->RET != ret)) return CRUX_OK;      // a learner regresses on another column (:cost_return)
+  int stride = 8; while (stride < need) stride *= 2;
+  const size_t fl = (size_t)buf->capacity * (size_t)stride;
+  if (buf->pack_floats < fl) { if (buf->pack) { crux_sync_before_free(c); (void)hipFree(buf->pack); buf->pack = nullptr; buf->pack_floats = 0; }
+    if (hipMalloc(&buf->pack, 4 * fl) != hipSuccess) { buf->pack = nullptr; return CRUX_OK; }      // no memory for the copy: the SoA gather still works
+    buf->pack_floats = fl; }
+  const int64_t n = buf->elements, tot = n * stride;
+  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)buf->col[CRUX_COL_S], (const void*)buf->col[CRUX_COL_A], buf->act_kind,
+                     has_col(buf, CRUX_COL_LOGPROB) ? (const float*)buf->col[CRUX_COL_LOGPROB] : (const float*)nullptr, has_col(buf, CRUX_COL_ADVANTAGE) ? (const float*)buf->col[CRUX_COL_ADVANTAGE] : (const float*)nullptr, ret,
+                     od, ad, n, stride, buf->pack);
+  TrainArgs* both[2] = {&a, k};
+  for (int q = 0; q < 2; ++q) { TrainArgs* t = both[q]; if (!t) continue;
+    // (a learner whose :logprob / :advantage columns were substituted -- logpdf_bc_loss, reinforce_loss -- keeps the SoA gather)
+    const bool plain = (t->LP == nullptr || t->LP == (const float*)buf->col[CRUX_COL_LOGPROB]) && (t->ADV == nullptr || (has_col(buf, CRUX_COL_ADVANTAGE) && t->ADV == (const float*)buf->col[CRUX_COL_ADVANTAGE]));
+    if (!plain && t->loss != CRUX_LOSS_VALUE_MSE) continue;
+    t->PACK = buf->pack; t->pack_stride = stride; t->pack_act = od; t->pack_lp = od + na; }
+  return crux_launch_check(c, "k_pack_rows");
+}
 int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a, hipStream_t strm = nullptr, int which = 0);
 int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream, bool probe);      // train_fs.hip
 static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_t stream = nullptr) {
@@ -179,6 +222,7 @@ static int32_t run_batch(crux_mlp* net, crux_buffer* buf, TrainArgs& a, int n_ep
     int32_t* oa = nullptr; rc = build_orders(c, buf, 0, nullptr, a.shuffle_seed, a.shuffle_counter, a.perms, n_epochs, c->stream, &oa); if (rc) return rc;
     a.ord_all = oa;
   }
+  if (!a.ids) { rc = ensure_pack(c, buf, c->stream, a, nullptr); if (rc) return rc; }
   rc = launch_train(c, a, slot); if (rc) return rc;
   int32_t st[8]; std::vector<float> ei((size_t)CRUX_INFO_N * (size_t)(n_epochs > 0 ? n_epochs : 1));
   HIPCHK(c, hipMemcpyAsync(st, a.status, sizeof st, hipMemcpyDeviceToHost, c->stream));
@@ -535,6 +579,7 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
     rc = build_orders(c, buf, 1, oa + (size_t)(cfg_a->epochs - 1) * (size_t)len, cfg_c->shuffle_seed, cfg_c->shuffle_counter, d_pc, cfg_c->epochs, c->stream, &oc); if (rc) return rc;
     a.ord_all = oa; k.ord_all = oc;
   }
+  rc = ensure_pack(c, buf, c->stream, a, &k); if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
   rc = launch_train(c, k, CRUX_PROF_TRAIN_CRITIC, c->aux_stream); if (rc) return rc;

@@ -39,6 +39,10 @@ struct TrainArgs {
   int32_t px_n, px_rank; float* const* px_tab;   // px_tab: device table [px_n] of the ranks' region bases for this learner stream (own region at px_rank)
   // lagrange_ppo_loss (rl/ppo.jl:70-131): device copy of crux_lagrange (hyper-parameters + PID state), the cost columns; NULL = plain ppo_loss
   crux_lagrange* lag; const float* COST; const float* CADV; const uint8_t* EE;
+  // packed learner rows (train.hip: ensure_pack): [s (od) | action (index, or ad floats) | logprob | advantage | return] of every buffer row in ONE line of
+  // pack_stride floats (a power of two), written once per batch_train! call. NULL = gather the pieces from the SoA columns (68 / 24 / 4 / 4-byte pieces cost a sector each:
+  // 60.7 KB of memory-side traffic per C5 minibatch step against 13.3 KB algorithmic).
+  const float* PACK; int32_t pack_stride, pack_act, pack_lp;
   // speculative launch (train.hip: policy_gradient_training with KL early stopping): host-pinned word the kernel looks at once per epoch; non-zero = leave at this epoch
   // boundary with status CRUX_TRAIN_ABORTED (decided once for all workgroups of the learner through a latch in xctr). NULL = never.
   const unsigned* spec_abort;

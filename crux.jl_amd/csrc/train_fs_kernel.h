@@ -215,13 +215,24 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
     if constexpr (LAG) { p_cost2 = n_row2 >= 0 ? CRUX_GLOBAL_PTR(float, a.COST)[n_row2] : 0.f; p_ee2 = (n_row2 >= 0 && CRUX_GLOBAL_PTR(uint8_t, a.EE)[n_row2]) ? 1.f : 0.f; }
     if (h == 0) {
       const int rs = __shfl(rowlo, lane >> 2, 64), vs = __shfl(p_valid, lane >> 2, 64);      // lanes 0..15 hold the rows of samples 0..15
-      const float* xrow = CRUX_GLOBAL_PTR(float, a.S) + (int64_t)rs * IN + (lane & 3) * NXL;
+      const float* xrow = a.PACK ? CRUX_GLOBAL_PTR(float, a.PACK) + (int64_t)rs * a.pack_stride + (lane & 3) * NXL : CRUX_GLOBAL_PTR(float, a.S) + (int64_t)rs * IN + (lane & 3) * NXL;
 #pragma unroll
       for (int e = 0; e < NXL; ++e) px[e] = ((lane & 3) * NXL + e < IN && vs) ? xrow[e] : 0.f;
     } else {
       p_lp = 0.f; p_adv = 0.f; p_ret = 0.f; p_cadv = 0.f;
 #pragma unroll
       for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
+      if (a.PACK && !LAG) {      // the sample's scalars and action from its packed line (the observation half of the same line goes to wave h = 0)
+        if (lane < 16 && p_valid) { const float* q = CRUX_GLOBAL_PTR(float, a.PACK) + row * a.pack_stride;
+          if (KIND != MFK_VALUE) { p_lp = q[a.pack_lp]; p_adv = q[a.pack_lp + 1]; }
+          p_ret = q[a.pack_lp + 2];
+          if (KIND == MFK_CATEGORICAL) { const int ai = (int)q[a.pack_act];
+#pragma unroll
+            for (int k = 0; k < OUT; ++k) p_abyte[k] = k == ai ? 1 : 0; }
+          if (KIND == MFK_GAUSSIAN) {
+#pragma unroll
+            for (int k = 0; k < OUT; ++k) p_act[k] = q[a.pack_act + k]; } }
+      } else
       if (lane < 16 && p_valid) {
         if constexpr (LAG) p_cadv = CRUX_GLOBAL_PTR(float, a.CADV)[row];
         if (KIND != MFK_VALUE) { p_lp = CRUX_GLOBAL_PTR(float, a.LP)[row]; p_adv = CRUX_GLOBAL_PTR(float, a.ADV)[row]; }

@@ -276,6 +276,6 @@ def test_solve_writes_tensorboard_events_at_the_logger_period(gpu_ctx, tmp_path)
     sv = crux.PPO(crux.ActorCritic(a, c), crux.ContinuousSpace(4), N=N, dN=dN, max_steps=40, a_opt={"epochs": 1}, c_opt={"epochs": 1}, log=logp)
     crux.solve(sv, crux.CartPoleMDP(n_envs=4, seed=1))
     h = lg.readtb(logp.logger.logdir)
-    assert h["actor_loss"][0] == [512, 1024] and h["undiscounted_return"][0] == [512, 1024] and sorted(set(h["avg_r"][0])) == [512, 1024]   # avg_r: record_avgr (ppo.jl:46) and log_episode_averages both write it, as in the reference
+    assert h["actor_loss"][0] == [512, 1024] and h["undiscounted_return"][0] == [0, 512, 1024] and sorted(set(h["avg_r"][0]) - {0}) == [512, 1024]   # step 0: the pre-train log(S.log, S.i, S=S) of on_policy.jl:88 (evaluation closures only);   # avg_r: record_avgr (ppo.jl:46) and log_episode_averages both write it, as in the reference
     assert np.isclose(h["actor_loss"][1][-1], sv.history[-1]["actor_loss"]) and all(1.0 <= v <= 40.0 for v in h["undiscounted_return"][1])
-    assert all(np.isfinite(v) and 1.0 <= v <= 40.0 for v in h["avg_r"][1])          # CartPole: reward 1 per step, episodes of 1..max_steps steps
+    assert all(np.isfinite(v) and 1.0 <= v <= 40.0 for i_, v in zip(h["avg_r"][0], h["avg_r"][1]) if i_ > 0)          # CartPole: reward 1 per step, episodes of 1..max_steps steps
