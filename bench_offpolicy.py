@@ -161,9 +161,9 @@ def c4(crux, ctx, cpu=True, steps=200):
     solver._resolve_history()
     ach = C4_FLOP / t / 1e12
     out = {"workload": "SAC, GaussianPolicy 3-256-256-1 + twin Q 4-256-256-1, B = 256: value_training epochs (rand! + sac_target + temperature, twin-critic and actor steps + polyak), 50 per solve iteration chained 8 at a time",
-           "epochs_per_s": 1.0 / t, "grad_steps_per_s": 3.0 / t, "us_per_epoch": 1e6 * t, "us_per_epoch_async_chains": 1e6 * t_async, "launches_per_epoch": 17,
-           "roofline": {"kernel": "k_phase_k (crux_sac_epochs: an epoch is 17 dependent launches in a chain; every three-layer forward pass is 2 launches (layers 0+1 fused in registers, output layer), every pullback ONE phase (output-layer dW | LDS-staged layer-1 dW | quarter-split layer-1 dX with the output layer\'s data gradient folded in -> layer-0 partials completed by the norm op), a critic input-gradient chain 2; round 3: 26 launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                        "algorithmic_GFLOP_per_epoch": C4_FLOP / 1e9, "note": "latency-bound: 17 dependent launches of 5-9 us per epoch (Q1 || Q2, the target critics, the temperature step and the actor\'s own forward pass share phases with the critic chain)"}}
+           "epochs_per_s": 1.0 / t, "grad_steps_per_s": 3.0 / t, "us_per_epoch": 1e6 * t, "us_per_epoch_async_chains": 1e6 * t_async, "launches_per_epoch": 14,
+           "roofline": {"kernel": "k_phase_k (crux_sac_epochs: an epoch is 14 dependent launches in a chain (sac_epoch_tiles, csrc/exec.hip: 17 phases, three of them beside the previous epoch's tail); layers 0+1 of every forward pass are one register-fused launch, the output layers run inside per-16-sample-tile ops together with what follows them (exploration, sac_target + both critic heads, the actor head, the reverse of exploration), every pullback is ONE phase (output-layer dW | LDS-staged layer-1 dW | quarter-split layer-1 dX with the output layer\'s data gradient folded in -> layer-0 partials completed by the norm op), a critic input-gradient chain 2; round 3: 26 launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        "algorithmic_GFLOP_per_epoch": C4_FLOP / 1e9, "note": "latency-bound: 14 dependent launches of 5.5-11 us per epoch (Q1 || Q2, the target critics, the temperature step and the actor\'s own forward pass share phases with the critic chain)"}}
     if cpu:
         O, L2 = _oracle()
         n_o = 20_000

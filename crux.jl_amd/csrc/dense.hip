@@ -229,6 +229,29 @@ int32_t crux_dense_forward(crux_mlp* n, const float* d_x, int64_t B, hipStream_t
   return CRUX_OK;
 }
 
+// pieces of the passes for callers that fuse the output layer into an op of their own (exec.hip: the fused SAC epoch):
+// layers 0 + 1 only (the caller's op evaluates the output layer from crux_dense_act(n, 2))
+int32_t crux_dense_forward12(crux_mlp* n, const float* d_x, int64_t B, hipStream_t st) {
+  crux_ctx* c = n->ctx; const NetDesc& nd = n->nd;
+  if (!crux_dense_fwd_fused(n) || nd.L != 3) return crux_fail(c, CRUX_EUNSUP, "forward12: not a fused three-layer shape");
+  int32_t rc = ensure_ws(n, B); if (rc) return rc;
+  Fwd12Args a{}; a.W1 = n->p + nd.woff[0]; a.b1 = n->p + nd.boff[0]; a.W2 = n->p + nd.woff[1]; a.b2 = n->p + nd.boff[1]; a.x = d_x; a.H1 = crux_dense_act(n, 1); a.H2 = crux_dense_act(n, 2);
+  a.in0 = nd.dims[0]; a.out1 = nd.dims[1]; a.out2 = nd.dims[2]; a.B = (int32_t)B; a.act1 = nd.acts[0]; a.act2 = nd.acts[1];
+  CRUX_RUN(c, Fwd12Op, OP_FWD12, k_fwd12, df_fwd12_blocks(nd, B), 256, st, a);
+  return crux_launch_check(c, "k_fwd12");
+}
+// the input-gradient chain down to layer 0's dZ (the caller's op applies layer 0's weights): returns the buffer [dims[1] x B] Dgrad2W1Op fills
+int32_t crux_dense_dgrad_to_dz1(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, const float** d_dz1, hipStream_t st) {
+  crux_ctx* c = n->ctx; const NetDesc& nd = n->nd;
+  if (!crux_dense_bwd_fused3(n, B) || !n->ws || n->ws_B < B) return crux_fail(c, CRUX_EUNSUP, "dgrad_to_dz1: not a fused three-layer shape with a cached forward pass");
+  DzSrc z{}; z.W3 = n->p + nd.woff[2]; z.dZ3 = d_dy; z.out3 = nd.dims[3]; z.act = nd.acts[1];
+  Dgrad2Args a{}; a.z = z; a.W2 = n->p + nd.woff[1]; a.dZ2 = crux_dense_act(n, 2); a.H1 = crux_dense_act(n, 1); a.x = d_x; a.part = ws_part(n); a.dZ1 = ws_delta(n, 0);
+  a.in0 = nd.dims[0]; a.out1 = nd.dims[1]; a.out2 = nd.dims[2]; a.B = (int32_t)B; a.act0 = nd.acts[0]; a.want_g = 0;
+  CRUX_RUN(c, Dgrad2W1Op, OP_DGRAD2W1, k_dgrad2w1, (unsigned)((nd.dims[1] >> 4) * 4), 256, st, a);
+  *d_dz1 = a.dZ1;
+  return crux_launch_check(c, "k_dgrad2w1");
+}
+
 // Reverse pass after crux_dense_forward(n, d_x, B) with the same d_x. d_dy [out_L x B] is not modified.
 int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st, Sumsq2Fix* defer, int defer_slot) {
   crux_ctx* c = n->ctx; const NetDesc& nd = n->nd;

@@ -88,6 +88,12 @@ __device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigne
         case OP_ADAM_ADVANCE: DISPATCH<AdamAdvanceOp>(op, b); break; \
         case OP_SOFTQ_TARGET: DISPATCH<SoftqTargetOp>(op, b); break; \
         case OP_PER_SAMPLE: PerSampleGatherOp::run_ptr(b, op->nblocks, (const PerSampleArgs*)op->args); break; \
+        case OP_ACTOR_EXPLORE_TILE: DISPATCH<ActorExploreTileOp>(op, b); break; \
+        case OP_SAC_CRITIC_TILE: DISPATCH<SacCriticTileOp>(op, b); break; \
+        case OP_CRITIC_INFO2: DISPATCH<CriticInfo2Op>(op, b); break; \
+        case OP_SAC_ACTOR_TILE: DISPATCH<SacActorTileOp>(op, b); break; \
+        case OP_ACTOR_INFO2: DISPATCH<ActorInfo2Op>(op, b); break; \
+        case OP_CRITIC_DX_TILE: DISPATCH<CriticDxActorGradTileOp>(op, b); break; \
         case OP_FWD12: DISPATCH<Fwd12Op>(op, b); break; \
         case OP_WGRAD2: DISPATCH<Wgrad2Op>(op, b); break; \
         case OP_DGRAD2W1: if constexpr (EXEC_HEAVY == 1) { DISPATCH<Dgrad2W1OpT<1>>(op, b); } else if constexpr (EXEC_HEAVY == 2) { DISPATCH<Dgrad2W1Op>(op, b); } break; \
@@ -712,6 +718,136 @@ int32_t crux_dpg_target(crux_mlp* actor_t, crux_mlp* q1t, crux_mlp* q2t, crux_bu
                         uint64_t seed, uint64_t counter, float* d_y);
 int32_t crux_dpg_actor_step(crux_mlp* actor, crux_mlp* q, crux_buffer* b, float* info_out);
 
+// The SAC epoch on the fused block kernels and the per-sample-tile ops of sac_fused.h (round 4): 17 phases, 14 launches per epoch inside a chain (round 3: 30 / 26).
+//   0 ids | 1 gather, zero-fills | 2 actor(s') layers 0+1 ; vcat(s, a) | 3 actor(s') output layer + exploration -> (s', a'), log pi ; Q1, Q2 (s, a) layers 0+1
+//   4 target Q1, Q2 (s', a') layers 0+1 ; actor(s) layers 0+1 | 5 the four critic output layers + sac_target + both double_Q_loss heads ; actor(s) output layer + the TWO
+//   exploration draws of the temperature and the actor step (same means: the temperature step leaves the actor untouched) | 6 critic pullbacks (one phase each network) ;
+//   temperature head | 7 norm ; Adam(log alpha) | 8 info, Adam(Q1), Adam(Q2) | 9 Q1, Q2 (s, a~) layers 0+1 | 10 their output layers + sac_actor_loss head
+//   11 critic input gradients down to layer 0's dZ | 12 layer 0's W' dZ + reverse of exploration | 13 actor pullback ; logSigma row sums | 14 norm | 15 info, Adam | 16 advance, polyak
+// The order inside every chain is the reference's (temperature, critic and actor each see what the previous step left; sac_target reads log alpha BEFORE the temperature
+// update lands, the actor head after). Same arithmetic as the generic recording below (tools/fused_check.py compares the two bit for bit); false = not this case.
+static bool sac_tile_case(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* q1t, crux_mlp* q2t, crux_buffer* source, crux_buffer* batch, int32_t uc, int32_t ua) {
+  const bool on = !(getenv("CRUX_SAC_TILE_OPS") && getenv("CRUX_SAC_TILE_OPS")[0] == '0') && !getenv("CRUX_EXEC_PERSISTENT") && !getenv("CRUX_NO_FUSED_EPOCH");      // (read per call: tests switch forms inside one process)
+  if (!on || !uc || !ua || source->prioritized) return false;
+  const int64_t B = batch->capacity; crux_mlp* all[5] = {actor, q1, q2, q1t, q2t};
+  for (crux_mlp* n : all) { if (n->nd.L != 3 || !crux_dense_fwd_fused(n) || n->nd.acts[2] != CRUX_ACT_IDENTITY || n->nd.dims[2] != actor->nd.dims[2]) return false; }
+  if (!crux_dense_bwd_fused3(actor, B) || !crux_dense_bwd_fused3(q1, B) || !crux_dense_bwd_fused3(q2, B)) return false;
+  if (batch->act_dim > 4 || batch->obs_dim + batch->act_dim > 16 || actor->nd.dims[3] != batch->act_dim || q1->nd.dims[3] != 1 || q2->nd.dims[3] != 1) return false;
+  if (q1t->nd.dims[3] != 1 || q2t->nd.dims[3] != 1 || q1->nd.dims[0] != batch->obs_dim + batch->act_dim) return false;
+  return true;
+}
+static int32_t sac_epoch_tiles(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1t, crux_mlp* q2t, crux_mlp* la, crux_buffer* source, crux_buffer* batch,
+                               float gamma, float H_target, float tau, int32_t use_weight, uint64_t sample_counter, uint64_t noise_seed, uint64_t noise_counter0,
+                               float* info_temp, float* info_critic, float* info_actor) {
+  crux_ctx* c = actor->ctx; const int64_t B = batch->capacity; const int od = batch->obs_dim, ad = batch->act_dim, sd = od + ad, K = actor->nd.dims[2];
+  int32_t rc = CRUX_OK;
+  if (use_weight && !has_col(batch, CRUX_COL_WEIGHT)) return crux_fail(c, CRUX_EINVAL, "double_Q_loss(weight=:weight): batch has no :weight column");
+  if (!crux_exec_recording(c)) { rc = crux_exec_begin(c); if (rc) return rc; }
+  auto bail = [&](int32_t e) { crux_exec_abort(c); return e; };
+  ExecRec* r = rec_of(c); const int base = r->chain ? r->chain_base : 0; std::vector<int> ph; bool plan_ok = true;
+  size_t m = exec_mark(c); const size_t ops0 = m;
+  auto sect = [&](auto&& rule) { for (size_t i = m; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid); if (p < 0) { plan_ok = false; p = 0; }
+      ph.push_back(ph_tag(base > 0 ? base + p - 3 : p, 0)); } m = r->ops.size(); };
+  auto only = [&](int p) { sect([p](int) { return p; }); };
+  // buffers of this epoch (scratch of the recording: live until the list has run)
+  float* y = (float*)crux_exec_small(c, 4 * (size_t)B); if (!y) return bail(crux_fail(c, CRUX_EUNSUP, "sac_epoch: batch of %lld rows exceeds the executor's region", (long long)B));
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (3 * sd + 3 * ad + 12) + 65536), 0}; if (!cv.p) return bail(crux_fail(c, CRUX_ENOMEM, "sac_epoch: scratch"));
+  float* sa_c = cv.take<float>((size_t)B * sd); float* sa_t = cv.take<float>((size_t)B * sd); float* sa_a = cv.take<float>((size_t)B * sd);
+  float* lp_t = cv.take<float>((size_t)B); float* lp_temp = cv.take<float>((size_t)B); float* lp_a = cv.take<float>((size_t)B); float* eps = cv.take<float>((size_t)B * ad);
+  float* dy1 = cv.take<float>((size_t)B); float* dy2 = cv.take<float>((size_t)B); float* t1 = cv.take<float>((size_t)B); float* t2 = cv.take<float>((size_t)B);
+  float* da1 = cv.take<float>((size_t)B); float* da2 = cv.take<float>((size_t)B); float* ta = cv.take<float>((size_t)B); float* dmu = cv.take<float>((size_t)B * ad); float* dls = cv.take<float>((size_t)B * ad);
+  // info rows / statistics / status words of the three steps
+  Carve st_{(char*)crux_exec_small(c, 256 * 5), 0}, sc_{(char*)crux_exec_small(c, 256 * 5), 0}, sa_{(char*)crux_exec_small(c, 256 * 5), 0};
+  if (!st_.p || !sc_.p || !sa_.p) return bail(crux_fail(c, CRUX_ENOMEM, "sac_epoch: executor region"));
+  float* it = st_.take<float>(CRUX_INFO_N); double* ssq_t = st_.take<double>(2 + SUMSQ_BLOCKS); int32_t* stt = st_.take<int32_t>(1);
+  float* ic = sc_.take<float>(CRUX_INFO_N); double* ssq_c = sc_.take<double>(2 + SUMSQ_BLOCKS); int32_t* stc = sc_.take<int32_t>(1);
+  float* ia = sa_.take<float>(CRUX_INFO_N); double* ssq_a = sa_.take<double>(2 + SUMSQ_BLOCKS); int32_t* sta = sa_.take<int32_t>(1);
+  const float* S = (const float*)batch->col[CRUX_COL_S]; const float* SP = (const float*)batch->col[CRUX_COL_SP];
+  const float* ls = actor->p + actor->nd.xoff; const float* w = use_weight ? (const float*)batch->col[CRUX_COL_WEIGHT] : nullptr;
+  auto l3 = [&](crux_mlp* n, bool store) { const NetDesc& nd = n->nd; return TileSet{n->p + nd.woff[2], n->p + nd.boff[2], crux_dense_act(n, 2), store ? crux_dense_act(n, 3) : nullptr}; };
+  const unsigned nt = (unsigned)((B + 15) / 16);
+  // 0, 1: rand!
+  rc = crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
+  sect([](int kid) { return kid == OP_UNIFORM_IDS ? 0 : kid == OP_GATHER_RING_ALL ? 1 : -1; });
+  rc = check_sac(c, actor, q1, q2, la, batch, "sac_epoch"); if (rc) return bail(rc);
+  rc = crux_exec_zero(c, it, 256 * 5, c->stream); if (!rc) rc = crux_exec_zero(c, ic, 256 * 5, c->stream); if (!rc) rc = crux_exec_zero(c, ia, 256 * 5, c->stream);
+  if (!rc) rc = crux_exec_zero(c, la->g, sizeof(float) * (size_t)la->nd.n_params, c->stream); if (rc) return bail(rc);
+  only(1);
+  // 2
+  rc = crux_dense_forward12(actor, SP, B, c->stream); if (rc) return bail(rc);
+  CRUX_RUN(c, ConcatSaOp, OP_CONCAT_SA, k_concat_sa, nblk(B * sd), 256, c->stream, S, (const float*)batch->col[CRUX_COL_A], od, ad, B, sa_c);
+  only(2);
+  // 3
+  { ActorExploreArgs a{}; a.mu = l3(actor, true); a.ls = ls; a.s = SP; a.od = od; a.ad = ad; a.K = K; a.B = (int32_t)B; a.n_cfg = 1; a.seed = noise_seed; a.cfg[0] = ExploreCfg{noise_counter0, sa_t, lp_t, nullptr};
+    crux_exec_push<ActorExploreTileOp, OP_ACTOR_EXPLORE_TILE>(c, nt, a); }
+  rc = crux_dense_forward12(q1, sa_c, B, c->stream); if (!rc) rc = crux_dense_forward12(q2, sa_c, B, c->stream); if (rc) return bail(rc);
+  only(3);
+  // 4
+  rc = crux_dense_forward12(q1t, sa_t, B, c->stream); if (!rc) rc = crux_dense_forward12(q2t, sa_t, B, c->stream); if (!rc) rc = crux_dense_forward12(actor, S, B, c->stream); if (rc) return bail(rc);
+  only(4);
+  // 5
+  { SacCriticArgs a{}; a.q1t = l3(q1t, true); a.q2t = l3(q2t, true); a.q1 = l3(q1, true); a.q2 = l3(q2, true); a.r = (const float*)batch->col[CRUX_COL_R]; a.done = (const uint8_t*)batch->col[CRUX_COL_DONE];
+    a.lp = lp_t; a.log_alpha = la->p; a.w = w; a.gamma = gamma; a.scale = 0.5f; a.K = K; a.B = (int32_t)B; a.y = y; a.dy1 = dy1; a.dy2 = dy2; a.term1 = t1; a.term2 = t2;
+    crux_exec_push<SacCriticTileOp, OP_SAC_CRITIC_TILE>(c, nt, a); }
+  { ActorExploreArgs a{}; a.mu = l3(actor, true); a.ls = ls; a.s = S; a.od = od; a.ad = ad; a.K = K; a.B = (int32_t)B; a.n_cfg = 1; a.seed = noise_seed;      // the two draws side by side (each re-evaluates the output layer: 8 MFMAs)
+    a.cfg[0] = ExploreCfg{noise_counter0 + 1, nullptr, lp_temp, nullptr}; crux_exec_push<ActorExploreTileOp, OP_ACTOR_EXPLORE_TILE>(c, nt, a);
+    a.cfg[0] = ExploreCfg{noise_counter0 + 2, sa_a, lp_a, eps}; crux_exec_push<ActorExploreTileOp, OP_ACTOR_EXPLORE_TILE>(c, nt, a); }
+  only(5);
+  // 6
+  Sumsq2Fix fxc{}, fxa{};
+  rc = crux_dense_backward(q1, sa_c, B, dy1, 1.0f, true, nullptr, c->stream, &fxc, 0); if (!rc) rc = crux_dense_backward(q2, sa_c, B, dy2, 1.0f, true, nullptr, c->stream, &fxc, 1); if (rc) return bail(rc);
+  CRUX_RUN(c, TempHeadOp, OP_TEMP_HEAD, k_temp_head, 1, 256, c->stream, (const float*)lp_temp, B, H_target, (const float*)la->p, la->g, it, ssq_t);
+  only(6);
+  // 7 (+ 8: the advance of log alpha's beta powers)
+  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, q1->g, (int64_t)q1->nd.n_params, q2->g, (int64_t)q2->nd.n_params, ssq_c, fxc);
+  rc = adam_gated(la, ssq_t, stt, false); if (rc) return bail(rc);
+  sect([](int kid) { return kid == OP_ADAM_ADVANCE ? 8 : 7; });
+  // 8 (+ 9: the critics' advances)
+  crux_exec_push<CriticInfo2Op, OP_CRITIC_INFO2>(c, 1u, (const float*)t1, (const float*)crux_dense_act(q1, 3), (const float*)t2, (const float*)crux_dense_act(q2, 3), (const double*)ssq_c, B, ic);
+  rc = adam_gated(q1, ssq_c, stc); if (!rc) rc = adam_gated(q2, ssq_c, stc); if (rc) return bail(rc);
+  sect([](int kid) { return kid == OP_ADAM_ADVANCE ? 9 : 8; });
+  // 9
+  rc = crux_dense_forward12(q1, sa_a, B, c->stream); if (!rc) rc = crux_dense_forward12(q2, sa_a, B, c->stream); if (rc) return bail(rc);
+  only(9);
+  // 10
+  { SacActorArgs a{}; a.q1 = l3(q1, true); a.q2 = l3(q2, true); a.lp = lp_a; a.log_alpha = la->p; a.K = K; a.B = (int32_t)B; a.dy1 = da1; a.dy2 = da2; a.term = ta;
+    crux_exec_push<SacActorTileOp, OP_SAC_ACTOR_TILE>(c, nt, a); }
+  only(10);
+  // 11
+  const float* dz1a = nullptr; const float* dz1b = nullptr;
+  rc = crux_dense_dgrad_to_dz1(q1, sa_a, B, da1, &dz1a, c->stream); if (!rc) rc = crux_dense_dgrad_to_dz1(q2, sa_a, B, da2, &dz1b, c->stream); if (rc) return bail(rc);
+  only(11);
+  // 12
+  { CriticDxArgs a{}; a.c1 = TileSet{q1->p + q1->nd.woff[0], nullptr, dz1a, nullptr}; a.c2 = TileSet{q2->p + q2->nd.woff[0], nullptr, dz1b, nullptr};
+    a.sa = sa_a; a.mu = crux_dense_act(actor, 3); a.eps = eps; a.ls = ls; a.log_alpha = la->p; a.od = od; a.ad = ad; a.K = q1->nd.dims[1]; a.B = (int32_t)B; a.dmu = dmu; a.dls = dls;
+    crux_exec_push<CriticDxActorGradTileOp, OP_CRITIC_DX_TILE>(c, nt, a); }
+  only(12);
+  // 13
+  rc = crux_dense_backward(actor, S, B, dmu, 1.0f, true, nullptr, c->stream, &fxa, 0); if (rc) return bail(rc);
+  CRUX_RUN(c, RowsumOp, OP_ROWSUM, k_rowsum, ad, 256, c->stream, (const float*)dls, ad, B, actor->g + actor->nd.xoff);
+  only(13);
+  // 14
+  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, actor->g, (int64_t)actor->nd.n_params, (float*)nullptr, (int64_t)0, ssq_a, fxa);
+  only(14);
+  // 15 (+ 16)
+  crux_exec_push<ActorInfo2Op, OP_ACTOR_INFO2>(c, 1u, (const float*)ta, (const float*)lp_a, (const double*)ssq_a, B, ia);
+  rc = adam_gated(actor, ssq_a, sta); if (rc) return bail(rc);
+  sect([](int kid) { return kid == OP_ADAM_ADVANCE ? 16 : 15; });
+  if (actor_targ) { rc = crux_polyak(actor_targ, actor, tau); if (rc) return bail(rc); }
+  rc = crux_polyak(q1t, q1, tau); if (!rc) rc = crux_polyak(q2t, q2, tau); if (rc) return bail(rc);
+  only(16);
+  // the steps' read-backs in the order they ran (temperature, critics, actor), as the generic recording registers them
+  crux_exec_add_readback(c, info_temp, it, stt, "sac_temp_loss"); crux_exec_add_readback(c, info_critic, ic, stc, "double_Q_loss"); crux_exec_add_readback(c, info_actor, ia, sta, "sac_actor_loss");
+  // phases 0 / 1 of a chained epoch overlap the previous epoch's norm / info + Adam, phase 2 its advance + polyak: base + p - 3 for every p (see crux_sac_epoch)
+  if (r->chain) {
+    if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 17 - (r->chain_base > 0 ? 3 : 0);
+    return CRUX_OK;
+  }
+  if (plan_ok && ph.size() == r->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
+  return crux_exec_run(c);
+}
+
 // One epoch of value_training with SAC's pieces (off_policy.jl:69-104, rl/sac.jl): rand! -> sac_target -> train!(log_alpha, sac_temp_loss) ->
 // [train!(critic, double_Q_loss)] -> [train!(actor, sac_actor_loss) -> polyak_average!(pi_minus, pi, tau)] as ONE fused launch.
 int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* actor_targ, crux_mlp* q1_targ, crux_mlp* q2_targ, crux_mlp* log_alpha,
@@ -720,6 +856,8 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   if (!actor || !q1 || !q2 || !q1_targ || !q2_targ || !log_alpha || !source || !batch) return CRUX_EINVAL;
   crux_ctx* c = actor->ctx; const int64_t B = batch->capacity;
   if (source->prioritized) return crux_fail(c, CRUX_EUNSUP, "sac_epoch: prioritized replay over a DoubleNetwork critic is not defined (td_error, src/utils.jl:112)");
+  if (c->rec && rec_of(c)->chain && sac_tile_case(actor, q1, q2, q1_targ, q2_targ, source, batch, update_critic, update_actor))      // chained epochs of the C4 family: the tile ops (14 launches per epoch)
+    return sac_epoch_tiles(actor, q1, q2, actor_targ, q1_targ, q2_targ, log_alpha, source, batch, gamma, H_target, tau, use_weight, sample_counter, noise_seed, noise_counter0, info_temp, info_critic, info_actor);
   const bool fuse = !getenv("CRUX_NO_FUSED_EPOCH");
   int32_t rc; float* d_y = nullptr;
   if (fuse) { if (!crux_exec_recording(c)) { rc = crux_exec_begin(c); if (rc) return rc; }       // a chained recording (crux_sac_epochs) is already open

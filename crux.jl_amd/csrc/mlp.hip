@@ -156,7 +156,10 @@ int32_t crux_polyak(crux_mlp* to, const crux_mlp* from, float tau) {
   if (!to || !from) return CRUX_EINVAL;
   if (to->nd.n_params != from->nd.n_params) return crux_fail(to->ctx, CRUX_EINVAL, "polyak_average!: parameter counts differ");
   const int64_t n = to->nd.n_params;
-  CRUX_RUN(to->ctx, PolyakOp, OP_POLYAK, k_polyak, (unsigned)((n + 255) / 256), 256, to->ctx->stream, to->p, from->p, tau, n);
+  // inside a recorded chain the three polyak updates of an epoch share a phase with other ops: 64 grid-striding blocks each instead of n / 256 (a phase of > 768 blocks takes
+  // two rounds over the chip)
+  const unsigned nbk = (unsigned)((n + 255) / 256);
+  CRUX_RUN(to->ctx, PolyakOp, OP_POLYAK, k_polyak, crux_exec_recording(to->ctx) ? (nbk < 64u ? nbk : 64u) : nbk, 256, to->ctx->stream, to->p, from->p, tau, n);
   return crux_launch_check(to->ctx, "k_polyak");
 }
 

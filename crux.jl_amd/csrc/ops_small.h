@@ -54,10 +54,9 @@ struct TdErrorOp { static __device__ __forceinline__ void run(const unsigned bid
   err[s] = fabsf(Q - y[s]);
 } };
 struct PolyakOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, float* __restrict__ to, const float* __restrict__ from, float tau, int64_t n) {
-  const int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x;
-  if (i >= n) return;
   const float omt = __fsub_rn(1.0f, tau);
-  to[i] = __fadd_rn(__fmul_rn(tau, from[i]), __fmul_rn(omt, to[i]));   // tau .* from .+ (1f0 - tau) .* to, no contraction
+  for (int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x; i < n; i += (int64_t)nb_ * blockDim.x)      // element-wise: any grid gives the same result
+    to[i] = __fadd_rn(__fmul_rn(tau, from[i]), __fmul_rn(omt, to[i]));   // tau .* from .+ (1f0 - tau) .* to, no contraction
 } };
 struct CopyF32Op { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
   for (int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x; i < n; i += (int64_t)nb_ * blockDim.x) dst[i] = src[i];

@@ -245,6 +245,8 @@ struct AdamAdvanceOp { static __device__ __forceinline__ void run(const unsigned
   if (bid_ == 0 && threadIdx.x == 0 && !isnan(ssq[0])) { bp[0] *= b1; bp[1] *= b2; }      // ssq[0] was written by the info op one phase earlier
 } };
 
+#include "sac_fused.h"
+
 // ---- OnPolicyGAIL pieces (src/model_free/il/on_policy_gail.jl:1-5,49-54; src/extras/gans.jl:7-9) ---------------------------------------
 // vcat(a, s) of buffer rows [off, off + n): the ACTION first (D(x, y) convention, on_policy_gail.jl:50); one-hot Bool actions become 0/1
 struct ConcatAsOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const void* __restrict__ a, int a_is_u8, const float* __restrict__ s, int od, int ad, int64_t off, int64_t n, float* __restrict__ out) {

@@ -57,7 +57,7 @@ if __name__ == "__main__":
     for what in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["dqn", "dqn128", "sac", "td3", "ddpg"]):
         res = []
         for f in ("0", "1"):
-            env = dict(os.environ, CRUX_DENSE_FUSED=f, CRUX_PER_FUSED_GATHER=f); path = "/tmp/fc_%s_%s.npz" % (what, f)      # "0": the round-3 chains (per-layer launches, search and gather apart)
+            env = dict(os.environ, CRUX_DENSE_FUSED=f, CRUX_PER_FUSED_GATHER=f, CRUX_SAC_TILE_OPS=f); path = "/tmp/fc_%s_%s.npz" % (what, f)      # "0": the round-3 chains (per-layer launches, search and gather apart)
             r = subprocess.run([sys.executable, __file__, what, path], env=env, capture_output=True, text=True)
             if r.returncode: print(what, "fused=" + f, "FAILED\n", r.stderr[-1500:]); bad += 1; res = None; break
             res.append(np.load(path))
