@@ -77,9 +77,9 @@ def c3(crux, ctx, cpu=True, steps=300):
     # their root paths, 128 x 20 probes of (leaf id, running sum, 24 path ids, <= 24 totals), the 128-row gather (78 B/row read + write)
     per_bytes = 128 * 127 * 8 + 128 * 14 * 12 + 128 * 20 * (4 + 4 + 96 + 56) + 2 * 128 * 78
     out = {"workload": "DQN + prioritized replay, 8-256-256-4, buffer 1 M, B = 128: value_training epochs (prioritized_sample! + dqn_target + td_error + update_priorities! + train!), 4 per solve iteration in one chained call",
-           "grad_steps_per_s": 1.0 / t, "per_samples_per_s": B / t, "us_per_epoch": 1e6 * t, "us_per_epoch_async_chains": 1e6 * t_async, "launches_per_epoch": 6,
-           "roofline": {"kernel": "k_phase_k (crux_dqn_epochs: an epoch is 6 dependent launches in a chain -- [layers 0+1 of Q and Q-target as one fused block kernel | beta-power advance of the previous epoch] [output layers] [dqn_target + td head + update_priorities! in one block] [the whole pullback: output-layer dW, LDS-staged layer-1 dW, quarter-split layer-1 dX -> layer-0 partials | leaf re-sums] [gradient norm (completes the layer-0 gradient) | root paths] [Adam | prioritized search + gather of the next epoch in one launch]; round 3: 9 launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                        "algorithmic_MFLOP_per_epoch": C3_FLOP / 1e6, "note": "latency-bound: 6 dependent launches; a launch that follows its predecessor back to back costs ~5 us whatever it holds, the prioritized search (four dependent probe rounds into a 4 MB running-sum array) ~15 us"},
+           "grad_steps_per_s": 1.0 / t, "per_samples_per_s": B / t, "us_per_epoch": 1e6 * t, "us_per_epoch_async_chains": 1e6 * t_async, "launches_per_epoch": 5,
+           "roofline": {"kernel": "k_phase_k (crux_dqn_epochs -> dqn_epoch_tiles, csrc/exec.hip: an epoch is FIVE dependent launches in a chain -- [layers 0+1 of Q and Q-target as one register-fused block kernel | beta-power advance of the previous epoch] [both output layers + dqn_target + td head + update_priorities! per 16-sample tile] [the whole pullback: output-layer dW, LDS-staged layer-1 dW, quarter-split layer-1 dX -> layer-0 partials | leaf re-sums] [gradient norm (completes the layer-0 gradient) | root paths] [Adam | prioritized search + gather of the next epoch in one launch]; round 3: 9 launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        "algorithmic_MFLOP_per_epoch": C3_FLOP / 1e6, "note": "latency-bound: 5 dependent launches; a launch that follows its predecessor back to back costs ~5 us whatever it holds, the prioritized search (four dependent probe rounds into a 4 MB running-sum array) ~15 us"},
            "replay_sampling": {"bytes_per_epoch_incremental": per_bytes, "bytes_per_epoch_full_rescan": 8 * N, "bound": "hbm", "note": "the reference's cumsum(priorities) per gradient step (4 MB read + 4 MB write at N = 1 M) is replaced by re-summing the touched leaves and their root paths; sample indices stay bit-exact"}}
     if cpu:
         O, L2 = _oracle()

@@ -94,6 +94,8 @@ __device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigne
         case OP_SAC_ACTOR_TILE: DISPATCH<SacActorTileOp>(op, b); break; \
         case OP_ACTOR_INFO2: DISPATCH<ActorInfo2Op>(op, b); break; \
         case OP_CRITIC_DX_TILE: DISPATCH<CriticDxActorGradTileOp>(op, b); break; \
+        case OP_DQN_TD_TILE: DISPATCH<DqnTdTileOp>(op, b); break; \
+        case OP_TD_INFO2: DISPATCH<TdInfo2Op>(op, b); break; \
         case OP_FWD12: DISPATCH<Fwd12Op>(op, b); break; \
         case OP_WGRAD2: DISPATCH<Wgrad2Op>(op, b); break; \
         case OP_DGRAD2W1: if constexpr (EXEC_HEAVY == 1) { DISPATCH<Dgrad2W1OpT<1>>(op, b); } else if constexpr (EXEC_HEAVY == 2) { DISPATCH<Dgrad2W1Op>(op, b); } break; \
@@ -524,6 +526,64 @@ int32_t crux_td_step_with_error(crux_mlp* net, crux_buffer* batch, const float* 
 int32_t crux_per_update_device(crux_buffer* b, const int64_t* d_ids, const float* d_v, int64_t n);
 int32_t crux_polyak(crux_mlp* to, const crux_mlp* from, float tau);
 
+// The DQN-family epoch on the fused block kernels and DqnTdTileOp (sac_fused.h, round 4): 8 phases, FIVE launches per epoch inside a chain (round 3: 13 / 9).
+//   0 [uniform ids] | 1 prioritized search + gather in one launch (or the gather), zero-fills | 2 layers 0+1 of Q(s) and Q-(s') | 3 both output layers + target + td head +
+//   update_priorities! per 16-sample tile | 4 the whole pullback ; leaf re-sums | 5 norm ; root paths | 6 info, Adam | 7 beta-power advance
+// In a chain the sampling of epoch e + 1 (phases 0, 1) sits beside the norm and Adam of epoch e -- after the root paths of phase 5 --, its phase 2 beside the advance.
+static bool dqn_tile_case(crux_mlp* net, crux_mlp* tnet, crux_buffer* source, crux_buffer* batch) {
+  const bool on = !(getenv("CRUX_SAC_TILE_OPS") && getenv("CRUX_SAC_TILE_OPS")[0] == '0') && !getenv("CRUX_EXEC_PERSISTENT") && !getenv("CRUX_NO_FUSED_EPOCH") && !getenv("CRUX_NO_CHAINED_EPOCHS");
+  const int64_t B = batch->capacity; crux_ctx* c = net->ctx;
+  if (!on || c->per_split_sample || !net->has_adam) return false;
+  if (source->prioritized && !crux_per_fused_gather()) return false;
+  crux_mlp* both[2] = {net, tnet};
+  for (crux_mlp* n : both) if (n->nd.L != 3 || !crux_dense_fwd_fused(n) || n->nd.acts[2] != CRUX_ACT_IDENTITY || n->nd.dims[2] != net->nd.dims[2] || n->nd.dims[3] != net->nd.dims[3] || n->nd.dims[0] != batch->obs_dim) return false;
+  if (!crux_dense_bwd_fused3(net, B)) return false;
+  return batch->act_kind == CRUX_ACTION_DISCRETE && batch->act_dim == net->nd.dims[3] && net->nd.dims[3] <= 4;
+}
+static int32_t dqn_epoch_tiles(crux_mlp* net, crux_mlp* tnet, crux_buffer* source, crux_buffer* batch, float gamma, float softq_alpha, int32_t use_weight, float beta,
+                               uint64_t sample_counter, float* info_out, float* d_y, float* d_err) {
+  crux_ctx* c = net->ctx; const int64_t B = batch->capacity; const bool per = source->prioritized; const int nout = net->nd.dims[3], K = net->nd.dims[2];
+  ExecRec* r = rec_of(c); const int base = r->chain_base; std::vector<int> ph; bool plan_ok = true; int32_t rc;
+  auto bail = [&](int32_t e) { crux_exec_abort(c); return e; };
+  size_t m = exec_mark(c); const size_t ops0 = m; r->epoch_marks.push_back(ops0);
+  auto sect = [&](auto&& rule) { for (size_t i = m; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid); if (p < 0) { plan_ok = false; p = 0; }
+      ph.push_back(ph_tag(base > 0 ? base + p - 3 : p, 0)); } m = r->ops.size(); };
+  auto only = [&](int p) { sect([p](int) { return p; }); };
+  if (use_weight && !has_col(batch, CRUX_COL_WEIGHT)) return bail(crux_fail(c, CRUX_EINVAL, "td_loss(weight=:weight): batch has no :weight column"));
+  rc = per ? crux_per_sample(batch, source, B, nullptr, beta, sample_counter) : crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
+  sect([](int kid) { return kid == OP_UNIFORM_IDS ? 0 : (kid == OP_PER_SAMPLE || kid == OP_GATHER_RING_ALL || kid == OP_RING_IDS || kid == OP_COPY_F32) ? 1 : kid == OP_PER_UPDATE ? 2 : -1; });
+  Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (nout + 2) + 8192), 0}; if (!cv.p) return bail(crux_fail(c, CRUX_ENOMEM, "dqn_epoch: scratch"));
+  float* dy = cv.take<float>((size_t)B * nout); float* term = cv.take<float>((size_t)B); float* qsel = cv.take<float>((size_t)B);
+  Carve sv{(char*)crux_exec_small(c, 256 * 5), 0}; if (!sv.p) return bail(crux_fail(c, CRUX_ENOMEM, "dqn_epoch: executor region"));
+  float* dinfo = sv.take<float>(CRUX_INFO_N); double* ssq = sv.take<double>(2 + SUMSQ_BLOCKS); int32_t* status = sv.take<int32_t>(1);
+  rc = crux_exec_zero(c, dinfo, 256 * 5, c->stream); if (rc) return bail(rc);
+  only(1);
+  const float* S = (const float*)batch->col[CRUX_COL_S]; const float* SP = (const float*)batch->col[CRUX_COL_SP];
+  rc = crux_dense_forward12(net, S, B, c->stream); if (!rc) rc = crux_dense_forward12(tnet, SP, B, c->stream); if (rc) return bail(rc);
+  only(2);
+  { DqnTdArgs a{}; auto l3 = [&](crux_mlp* n) { const NetDesc& nd = n->nd; return TileSet{n->p + nd.woff[2], n->p + nd.boff[2], crux_dense_act(n, 2), crux_dense_act(n, 3)}; };
+    a.qt = l3(tnet); a.q = l3(net); a.r = (const float*)batch->col[CRUX_COL_R]; a.done = (const uint8_t*)batch->col[CRUX_COL_DONE]; a.a = (const uint8_t*)batch->col[CRUX_COL_A];
+    a.w = use_weight ? (const float*)batch->col[CRUX_COL_WEIGHT] : nullptr; a.gamma = gamma; a.softq_alpha = softq_alpha; a.nout = nout; a.K = K; a.B = (int32_t)B;
+    a.y = d_y; a.dy = dy; a.err = per ? d_err : nullptr; a.term = term; a.qsel = qsel;
+    a.per = per ? 1 : 0; a.pr = source->priorities; a.pminmax = source->pminmax; a.ids = batch->d_indices; a.per_alpha = source->alpha;
+    crux_exec_push<DqnTdTileOp, OP_DQN_TD_TILE>(c, (unsigned)((B + 15) / 16), a); }
+  only(3);
+  Sumsq2Fix fx{};
+  rc = crux_dense_backward(net, S, B, dy, 1.0f, true, nullptr, c->stream, &fx, 0); if (rc) return bail(rc);
+  only(4);
+  if (per) { rc = crux_per_touched(source, batch->d_indices, B, false); if (rc) return bail(rc);
+    sect([](int kid) { return kid == OP_LEAF_REFRESH ? 4 : kid == OP_TREE_TOUCH ? 5 : -1; }); }
+  CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, net->g, (int64_t)net->nd.n_params, (float*)nullptr, (int64_t)0, ssq, fx);
+  only(5);
+  crux_exec_push<TdInfo2Op, OP_TD_INFO2>(c, 1u, (const float*)term, (const float*)qsel, (const double*)ssq, B, dinfo);
+  rc = adam_gated(net, ssq, status); if (rc) return bail(rc);
+  sect([](int kid) { return kid == OP_ADAM_ADVANCE ? 7 : 6; });
+  crux_exec_add_readback(c, info_out, dinfo, status, "td_loss");
+  if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
+  r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 8 - (r->chain_base > 0 ? 3 : 0);
+  return CRUX_OK;
+}
+
 // One epoch of value_training for the DQN family (src/model_free/off_policy.jl:69-93 with dqn_target, rl/dqn.jl:4-6): rand!(batch, source; i) ->
 // y = target(pi_minus, batch) -> [td_error -> update_priorities!(source, batch.indices, .)] -> train!(pi, td_loss). Networks at least
 // CRUX_DENSE_MIN_WIDTH wide run the whole epoch as ONE fused launch; narrower ones take the same steps one call at a time.
@@ -540,6 +600,8 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
     if (c->epoch_tmp_bytes < 8 * (size_t)B + 512) { if (sc2) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(sc2); }
       c->epoch_tmp_bytes = 16 * (size_t)B + 4096; if (hipMalloc(&c->epoch_tmp, c->epoch_tmp_bytes) != hipSuccess) { c->epoch_tmp = nullptr; c->epoch_tmp_bytes = 0; return crux_fail(c, CRUX_ENOMEM, "dqn_epoch: targets"); } sc2 = (char*)c->epoch_tmp; }
     d_y = (float*)sc2; d_err = (float*)(sc2 + ((4 * (size_t)B + 255) / 256) * 256); }
+  if (fuse && c->rec && rec_of(c)->chain && crux_exec_recording(c) && dqn_tile_case(net, target_net, source, batch))      // chained epochs of the C3 family: the tile op (5 launches per epoch)
+    return dqn_epoch_tiles(net, target_net, source, batch, gamma, softq_alpha, use_weight, beta, sample_counter, info_out, d_y, d_err);
   constexpr int eager_mask = 0;
   auto piece = [&](int bit) -> int32_t { if (!fuse) return CRUX_OK;
     if (eager_mask & bit) { if (crux_exec_recording(c)) return crux_exec_run(c); return CRUX_OK; }

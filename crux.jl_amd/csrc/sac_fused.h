@@ -157,3 +157,60 @@ struct CriticDxActorGradTileOp { static __device__ __forceinline__ void run(cons
   q.dmu[i] = clp * (df / s2) + abar;
   q.dls[i] = clp * ((df * df) / s2 - 1.f) + abar * (q.eps[i] * sg);
 } };
+
+// ---- DQN family: both output layers + dqn_target | softq_target + td_loss head + td_error + update_priorities! of the tile's samples ------------------------------------------
+// (rl/dqn.jl:4-6, rl/softq.jl:1-13, utils.jl:76-87,112, experience_buffer.jl:290-301). update_priorities! distributes over the tiles: a sample's new priority needs its own
+// td error and the id list only (a repeated id keeps its LAST value: the id list decides, as in PerUpdateOp), max / min priority are atomics.
+struct DqnTdArgs { TileSet qt, q; const float* r; const uint8_t* done; const uint8_t* a; const float* w; float gamma, softq_alpha; int32_t nout, K, B;
+                   float* y; float* dy; float* err; float* term; float* qsel;
+                   float* pr; float* pminmax; const int64_t* ids; float per_alpha; int32_t per; };
+struct DqnTdTileOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, DqnTdArgs q) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4; const int j0 = (int)bid_ << 4;
+  int64_t* ids_s = (int64_t*)(df_lds + TILE_PART_FLOATS(2));
+  if (q.per) for (int64_t j = threadIdx.x; j < q.B; j += 256) ids_s[j] = q.ids[j];      // (visible after the helper's workgroup barrier)
+  const TileSet sets[2] = {q.qt, q.q}; f32x4 z[2];
+  tile_splitk<2, false>(sets, q.nout, q.K, q.B, j0, df_lds, z);
+  if (wv > 0) return;
+  bool sorted_ids = true;
+  if (q.per) { bool ok = true; for (int64_t j = lane; j + 1 < q.B; j += 64) ok = ok && ids_s[j] <= ids_s[j + 1]; sorted_ids = __ballot(!ok) == 0ull; }      // stratified samples arrive in ascending order
+  const int64_t j = j0 + c; const bool mine = g == 0 && j < q.B;      // nout <= 4: lane c of group 0 holds the nout outputs of both networks for sample j0 + c
+  int wmax = (int)0x80000000, wmin = 0x7fffffff;
+  if (mine) {
+    float yv;
+    if (q.softq_alpha > 0.f) { const float al = q.softq_alpha;      // SoftqTargetOp
+      float mx = z[0][0] / al; for (int k = 1; k < q.nout; ++k) { const float v = z[0][k] / al; mx = v > mx ? v : mx; }
+      float sum = 0.f; for (int k = 0; k < q.nout; ++k) sum = sum + expf(z[0][k] / al - mx);
+      const float lse = mx + logf(sum); const float sv = al * lse;
+      const float nd = 1.f - (q.done[j] ? 1.f : 0.f); const float gn = q.gamma * nd; const float t = gn * sv; yv = q.r[j] + t; }
+    else {                                                             // DqnTargetOp
+      float mx = z[0][0]; for (int k = 1; k < q.nout; ++k) mx = z[0][k] > mx ? z[0][k] : mx;
+      const float nd = 1.f - (q.done[j] ? 1.f : 0.f); const float gn = q.gamma * nd; const float t = gn * mx; yv = q.r[j] + t; }
+    q.y[j] = yv;
+    const float invB = 1.f / (float)q.B; const uint8_t* a = q.a + j * q.nout;      // TdHeadOp
+    float Q = 0.f; for (int k = 0; k < q.nout; ++k) Q += z[1][k] * (a[k] ? 1.f : 0.f);
+    const float d = Q - yv; const float ww = q.w ? q.w[j] : 1.f;
+    if (q.err) q.err[j] = fabsf(d);
+    q.term[j] = d * d * ww; q.qsel[j] = Q;
+    for (int k = 0; k < q.nout; ++k) q.dy[j * q.nout + k] = a[k] ? 2.f * d * ww * invB : 0.f;
+    if (q.per) {                                                        // PerUpdateOp on (ids[j], |d|)
+      const float vf = __fadd_rn(fabsf(d), 1.1920928955078125e-07f); const double val = (double)vf; const int64_t me = ids_s[j];
+      bool later = false;
+      if (sorted_ids) later = j + 1 < q.B && ids_s[j + 1] == me;
+      else for (int64_t t = j + 1; t < q.B; ++t) if (ids_s[t] == me) { later = true; break; }
+      if (!later) q.pr[me] = (float)pow(val, (double)q.per_alpha);
+      wmax = __float_as_int(vf); wmin = __float_as_int(vf); }
+  }
+  if (q.per) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { wmax = max(wmax, __shfl_xor(wmax, o, 64)); wmin = min(wmin, __shfl_xor(wmin, o, 64)); }
+    if (lane == 0 && wmax != (int)0x80000000) { atomicMax((int*)&q.pminmax[0], wmax); atomicMin((int*)&q.pminmax[1], wmin); } }
+} };
+struct TdInfo2Op { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ term, const float* __restrict__ qsel, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) {
+  __shared__ double red[4];
+  double sl = 0, sq = 0;
+  for (int64_t j = threadIdx.x; j < B; j += 256) { sl += (double)term[j]; sq += (double)qsel[j]; }      // TdHeadOp's block sums
+  sl = block_sum256(sl, red); sq = block_sum256(sq, red);
+  if (threadIdx.x != 0) return;
+  ssq_finalize(ssq);
+  dinfo[CRUX_INFO_LOSS] = (float)(sl / (double)B); dinfo[2] = (float)(sq / (double)B); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
+} };
