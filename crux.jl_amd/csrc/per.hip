@@ -231,7 +231,16 @@ __global__ void k_cumsum_tiny(const float* v, int64_t n, float* c) { if (threadI
 // cumsum locally non-monotone; 20 levels cost 4 round trips instead of 20. Lane 0, idle in that scheme, fetches cumsum[N] (the total the stratum width is
 // derived from) in the FIRST round, beside the probes, so the total costs no round trip of its own. The interval bookkeeping is predicated, not branched, and
 // the real (lo, hi) live in scalar registers.
-// the search of ONE stratum j by the calling wave (all 64 lanes); returns the sampled index (wave-uniform) and, through w_out, its importance weight
+// the search of ONE stratum j by the calling wave (all 64 lanes); returns the sampled index (wave-uniform) and, through w_out, cumsum[N] (ptot)
+// importance weight of the sampled index (:343-347), lane 0 only; writes ids[j] and the source's :weight entry
+__device__ __forceinline__ float per_weight_lane0(const int64_t j, const int lo, const float ptot, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) {
+  ids[j] = lo;
+  const float pmin = pminmax[1] / ptot;
+  const float max_w = powf(pmin * (float)N, -beta);
+  const float w = powf(((float)N * pr[lo]) / ptot, beta) / max_w;
+  weight[lo] = w;
+  return w;
+}
 __device__ __forceinline__ int per_search_wave(const int64_t j, const float* __restrict__ run, const float* __restrict__ total, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B, int nlev,
                              const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight, float* w_out) {
   const int lane = threadIdx.x & 63;
@@ -256,42 +265,42 @@ __device__ __forceinline__ int per_search_wave(const int64_t j, const float* __r
   else { const crux_u32x4 x = crux_philox(seed, ictr * (uint64_t)B + (uint64_t)j, stream, CRUX_RNG_SAMPLE); u = crux_u32x2_to_f64(x.v[0], x.v[1]); }
   float ptot = 0.f; double key = 0.0; bool first = true;
   int lo = 0, hi = Ni;
-  const int dl = lane ? 31 - __builtin_clz((unsigned)lane) : 0;          // lane 1 is the root (depth 0)
+  // Round 4: SEVEN levels per round -- every lane carries two nodes of the speculation tree (heap numbers lane and lane + 64; node 1 is the root) -- so that the 20 levels of
+  // a search over 1 M elements take three dependent memory round trips (7 + 7 + 6) instead of four (6 + 6 + 6 + 2); the probes and comparisons are still exactly those of
+  // the sequential search.
   while (lo < hi) {
-    int l = lo, h = hi; bool valid = lane != 0;
+    float cvs[2]; bool valids[2];
 #pragma unroll
-    for (int b = 5; b >= 0; --b) { const bool act = valid && b < dl, ok = l < h; const int m = l + ((h - l) >> 1); const bool bit = ((lane >> b) & 1) != 0;
-      valid = valid && (!act || ok); const bool upd = act && ok; l = (upd && bit) ? m + 1 : l; h = (upd && !bit) ? m : h; }
-    valid = valid && l < h;
-    const bool want_tot = first && lane == 0;
-    float cv = 0.f;
-    if (valid || want_tot) cv = cs(want_tot ? Ni - 1 : l + ((h - l) >> 1));
-    if (first) { ptot = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cv)));
+    for (int pnode = 0; pnode < 2; ++pnode) {
+      const int nd = lane + 64 * pnode; const int dl = nd ? 31 - __builtin_clz((unsigned)nd) : 0;          // node 1 is the root (depth 0)
+      int l = lo, h = hi; bool valid = nd != 0;
+#pragma unroll
+      for (int b = 5; b >= 0; --b) { const bool act = valid && b < dl, ok = l < h; const int m = l + ((h - l) >> 1); const bool bit = ((nd >> b) & 1) != 0;
+        valid = valid && (!act || ok); const bool upd = act && ok; l = (upd && bit) ? m + 1 : l; h = (upd && !bit) ? m : h; }
+      valid = valid && l < h;
+      const bool want_tot = first && nd == 0;
+      float cv = 0.f;
+      if (valid || want_tot) cv = cs(want_tot ? Ni - 1 : l + ((h - l) >> 1));
+      cvs[pnode] = cv; valids[pnode] = valid; }
+    if (first) { ptot = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cvs[0])));
       const float dp = ptot / (float)B; key = ((double)(j + 1) + u - 1.0) * (double)dp; first = false; }
-    const bool less = valid && (double)cv < key;
-    const unsigned long long lt = __ballot(less);
+    const unsigned long long lt0 = __ballot(valids[0] && (double)cvs[0] < key), lt1 = __ballot(valids[1] && (double)cvs[1] < key);
     int node = 1;
 #pragma unroll
-    for (int step = 0; step < 6; ++step) { if (!(lo < hi)) break; const int mid = lo + ((hi - lo) >> 1); const int bit = (int)((lt >> node) & 1ull); if (bit) lo = mid + 1; else hi = mid; node = 2 * node + bit; }
+    for (int step = 0; step < 7; ++step) { if (!(lo < hi)) break; const int mid = lo + ((hi - lo) >> 1);
+      const int bit = (int)(((node < 64 ? lt0 >> node : lt1 >> (node - 64))) & 1ull); if (bit) lo = mid + 1; else hi = mid; node = 2 * node + bit; }
     lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
   }
   if (lo >= Ni) lo = Ni - 1;       // the reference would index out of bounds here
-  float w = 0.f;
-  if (lane == 0) {
-    ids[j] = lo;
-    const float pmin = pminmax[1] / ptot;
-    const float max_w = powf(pmin * (float)N, -beta);
-    w = powf(((float)N * pr[lo]) / ptot, beta) / max_w;
-    weight[lo] = w;
-  }
-  *w_out = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w)));
+  *w_out = ptot;      // (the total the stratum width came from: the caller forms the importance weight, per_weight_lane0 below)
   return lo;
 }
 struct PerSearchOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ run, const float* __restrict__ total, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B, int nlev,
                              const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) {
   const int64_t j = (int64_t)bid_ * 4 + (threadIdx.x >> 6);
   if (j >= B) return;
-  float w; (void)per_search_wave(j, run, total, pr, pminmax, N, B, nlev, rands, seed, stream, ictr, beta, ids, weight, &w);
+  float ptot; const int lo = per_search_wave(j, run, total, pr, pminmax, N, B, nlev, rands, seed, stream, ictr, beta, ids, weight, &ptot);
+  if ((threadIdx.x & 63) == 0) (void)per_weight_lane0(j, lo, ptot, pr, pminmax, N, beta, ids, weight);
 } };
 __global__ __launch_bounds__(256) void k_per_search(const float* __restrict__ run, const float* __restrict__ total, const float* __restrict__ pr, const float* __restrict__ pminmax, int64_t N, int64_t B, int nlev,
                              const double* __restrict__ rands, uint64_t seed, uint32_t stream, uint64_t ictr, float beta, int64_t* __restrict__ ids, float* __restrict__ weight) { PerSearchOp::run(blockIdx.x, gridDim.x, run, total, pr, pminmax, N, B, nlev, rands, seed, stream, ictr, beta, ids, weight); }
@@ -345,10 +354,18 @@ struct PerSampleGatherOp {
     __syncthreads();
     const int lane = threadIdx.x & 63; const int64_t j = (int64_t)bid_ * 4 + (threadIdx.x >> 6); const int64_t B = a->B;
     if (j >= B) return;
-    float* const weight = a->weight; float w;
-    const int lo = per_search_wave(j, a->run, a->total, a->pr, a->pminmax, a->N, B, a->nlev, a->rands, a->seed, a->stream, a->ictr, a->beta, a->ids, weight, &w);
+    float* const weight = a->weight; float ptot;
+    const int lo = per_search_wave(j, a->run, a->total, a->pr, a->pminmax, a->N, B, a->nlev, a->rands, a->seed, a->stream, a->ictr, a->beta, a->ids, weight, &ptot);
     const int32_t width = gs2.pre[gs2.n]; const int ncol = gs2.n; const int64_t drow = (a->base + j) % a->C;
-    for (int32_t t = lane; t < width; t += 64) {
+    // the row's loads go out BEFORE lane 0 forms the importance weight (a dependent load of priorities[lo] and two powf): one memory round trip for both
+    uint32_t v0 = 0; int k0 = -1; int64_t d0 = 0; bool byte0 = false;
+    if (lane < width) { int k = 0; while (k + 1 < ncol && lane >= gs2.pre[k + 1]) ++k;
+      const int32_t e = lane - gs2.pre[k]; d0 = drow * gs2.re[k] + e; const int64_t sidx = (int64_t)lo * gs2.re[k] + e; k0 = k; byte0 = gs2.esz[k] != 4;
+      v0 = byte0 ? (uint32_t)((const uint8_t*)gs2.src[k])[sidx] : ((const uint32_t*)gs2.src[k])[sidx]; }
+    float w = 0.f; if (lane == 0) w = per_weight_lane0(j, lo, ptot, a->pr, a->pminmax, a->N, a->beta, a->ids, weight);
+    w = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w)));
+    if (k0 >= 0) { if (byte0) ((uint8_t*)gs2.dst[k0])[d0] = (uint8_t)v0; else ((uint32_t*)gs2.dst[k0])[d0] = gs2.src[k0] == (const void*)weight ? __builtin_bit_cast(uint32_t, w) : v0; }
+    for (int32_t t = lane + 64; t < width; t += 64) {      // (rows wider than 64 elements)
       int k = 0; while (k + 1 < ncol && t >= gs2.pre[k + 1]) ++k;
       const int32_t e = t - gs2.pre[k]; const int64_t d = drow * gs2.re[k] + e, sidx = (int64_t)lo * gs2.re[k] + e;
       if (gs2.esz[k] == 4) { uint32_t v = ((const uint32_t*)gs2.src[k])[sidx]; if (gs2.src[k] == (const void*)weight) v = __builtin_bit_cast(uint32_t, w); ((uint32_t*)gs2.dst[k])[d] = v; }

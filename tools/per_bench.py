@@ -2,10 +2,10 @@ import sys, time, numpy as np
 import os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R)
 import crux_jl_amd as crux
 ctx=crux.default_context(); rng=np.random.default_rng(0)
-N,B=1_000_000,128
+N,B=int(os.environ.get("PER_N", 1_000_000)),128
 S,A=crux.ContinuousSpace(8),crux.DiscreteSpace(4)
 buf=crux.ExperienceBuffer(S,A,N,prioritized=True); D=crux.buffer_like(buf,capacity=B)
-chunk=100_000
+chunk=min(100_000, N)
 for _ in range(N//chunk):
     a_id=rng.integers(0,4,chunk)
     buf.push_({"s":rng.normal(0,1,(8,chunk)).astype(np.float32),"a":np.eye(4,dtype=bool)[:,a_id],"sp":rng.normal(0,1,(8,chunk)).astype(np.float32),"r":rng.normal(0,1,(1,chunk)).astype(np.float32),"done":rng.random((1,chunk))<0.01,"episode_end":np.zeros((1,chunk),bool)})
