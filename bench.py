@@ -385,6 +385,18 @@ def run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P):
     # (the short max_batches runs of this selftest train actor and critic back to back on learner stream 0; the timed iterations run them concurrently on streams 0 and 1)
     res["flag_wait_hist_per_rank"] = gather_obj({"stream0_wg0": fmt(hist[0, 0]), "stream0_wg1": fmt(hist[0, 1]), "stream1_wg0": fmt(hist[1, 0]), "stream1_wg1": fmt(hist[1, 1])})
     # (4) RCCL through the library's communicator
+    rc = rccl_check(ctx, dist, torch, rank, world, tdev, args, pi3.A)
+    res["rccl_allreduce_per_rank"] = gather_obj(rc)
+    ok = res["identical_shards_replicas_equal"] and res["distinct_shards_replicas_bit_identical"] and (args.same_device or all(r.get("ok") for r in res["rccl_allreduce_per_rank"]))
+    flag = torch.tensor([1 if (ok and res.get("identical_shards_ok", True)) else 0], device=tdev); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    res["passed"] = bool(int(flag.item()) == 1)
+    if rank == 0:
+        print("bench.py selftest: %s" % json.dumps(res), file=sys.stderr)
+    return res
+
+
+def rccl_check(ctx, dist, torch, rank, world, tdev, args, net):
+    """the library's own RCCL communicator (crux_comm_init, crux_allreduce_grads -- ncclAllReduce over xGMI): a known vector summed over the ranks, checked exactly."""
     rc = {"ok": False}
     try:
         if args.same_device:
@@ -394,7 +406,7 @@ def run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P):
             uid[:] = ctx.comm_unique_id()
         t = torch.from_numpy(uid).to(tdev); dist.broadcast(t, 0); uid = t.cpu().numpy().copy()
         ctx.comm_init(rank, world, uid)
-        net = pi3.A; n = net.n_params
+        n = net.n_params
         g = (np.arange(n, dtype=np.float32) % 97 + 1.0) * np.float32(rank + 1)
         ctx.h2d(ctx.lib.crux_mlp_grads_ptr(net.h), g)
         ctx.check(ctx.lib.crux_allreduce_grads(net.h)); ctx.sync()
@@ -404,13 +416,20 @@ def run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P):
         ctx.comm_destroy()
     except Exception as e:      # noqa: BLE001
         rc = {"ok": False, "error": repr(e)}
-    res["rccl_allreduce_per_rank"] = gather_obj(rc)
-    ok = res["identical_shards_replicas_equal"] and res["distinct_shards_replicas_bit_identical"] and (args.same_device or all(r.get("ok") for r in res["rccl_allreduce_per_rank"]))
-    flag = torch.tensor([1 if (ok and res.get("identical_shards_ok", True)) else 0], device=tdev); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    res["passed"] = bool(int(flag.item()) == 1)
-    if rank == 0:
-        print("bench.py selftest: %s" % json.dumps(res), file=sys.stderr)
-    return res
+    return rc
+
+
+def wait_percentiles(hist):
+    """per-rank summary of the in-kernel flag waits (crux_peer_wait_hist: log2 bins of 10 ns ticks, [2 learner streams][2 workgroups][32]): the UPPER edge of the bin that holds the
+    p-th percentile, in microseconds, over both streams and workgroups of this rank."""
+    h = np.asarray(hist, np.int64).reshape(-1, 32).sum(axis=0); n = int(h.sum())
+    if n == 0:
+        return {"n": 0}
+    cum = np.cumsum(h); out = {"n": n}
+    for name, q in (("p50", 0.50), ("p90", 0.90), ("p99", 0.99), ("max", 1.0)):
+        b = int(np.searchsorted(cum, q * n)) if q < 1.0 else int(np.nonzero(h)[0][-1])
+        out[name + "_us"] = 10e-3 * 2 ** (min(b, 31) + 1)
+    return out
 
 
 def params_digest(nets):
@@ -429,6 +448,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2", help="c2 = BASELINE configs[1] (the metric's config, default); c5 = configs[4]'s per-GPU shard")
     ap.add_argument("--sync", choices=["grad", "params"], default="grad", help="multi-GPU exchange: grad = per-minibatch gradient all-reduce inside the learner kernel (exact); params = periodic parameter averaging (RCCL)")
+    ap.add_argument("--sync-every", type=int, default=1, help="--sync grad: 1 = the gradient is exchanged every minibatch inside the learner kernel (exact: equals one learner on the concatenated batch); "
+                    "k > 1 = the in-kernel PERIODIC form: local Adam steps, theta / m / v averaged through the peer slots after every k-th step (crux_peer_set_sync_every; k must divide the minibatches of an epoch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sync", action="store_true", help="exercise the multi-GPU path even at world size 1 (testing)")
     ap.add_argument("--same-device", action="store_true", help="testing on a 1-GPU box: all ranks use device 0 (gloo rendezvous; the peer regions are still exchanged through hipIpc between the processes)")
@@ -477,6 +498,7 @@ def main():
     c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=BATCH, epochs=EPOCHS, name="critic_", shuffle_seed=200 + rank)
 
     sync, comm_kind = None, "single GPU"
+    requested_sync = args.sync
     if world > 1 or args.force_sync:
         sync, comm_kind = setup_group(args, crux, ctx, rank, world, local)
         if sync == "grad":
@@ -511,9 +533,14 @@ def main():
     if args.selftest and dist is not None and sync == "grad":
         selftest = run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P)
 
+    if sync == "grad" and args.sync_every > 1:
+        ctx.peer_set_sync_every(args.sync_every)      # (after the probe / selftest: their max_batches runs need the per-step form)
+        comm_kind = "in-kernel PERIODIC exchange: local Adam steps, theta / m / v averaged through the peer slots after every %d-th minibatch inside the persistent learner kernel" % args.sync_every
     it = 0
     for _ in range(args.warmup):
         ppo_iteration(crux, pi, buf, sampler, a_opt, c_opt, P, it, sync); it += 1
+    if sync == "grad":
+        ctx.peer_wait_hist(reset=True); ctx.peer_hist_enable(True)      # lane 0 of two workgroups reads the wall clock around its flag wait: no measurable cost
     barrier()
     ctx.prof_reset(); ctx.prof_enable(True)
     t0 = time.perf_counter()
@@ -532,6 +559,25 @@ def main():
         dg = torch.tensor([int(params_digest((pi.A, pi.C)))], dtype=torch.int64, device=tdev)
         lo, hi = dg.clone(), dg.clone(); dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_identical = bool(int(lo.item()) == int(hi.item()))
+
+    exchange = None
+    if dist is not None:
+        tdev = torch.device("cuda", local) if dist.get_backend() == "nccl" else torch.device("cpu")
+        mine = {"rank": rank}
+        if sync == "grad":
+            ctx.peer_hist_enable(False); mine.update(wait_percentiles(ctx.peer_wait_hist(reset=True)))
+        waits = [None] * world; dist.all_gather_object(waits, mine)
+        # RCCL as the library drives it: the params/native form used it in the timed region; otherwise one checked all-reduce through crux_comm_init / crux_allreduce_grads now
+        if sync == "native":
+            rccl = [{"ok": True, "how": "the timed region ran on the library's RCCL communicator"}] * world
+        else:
+            r1 = rccl_check(ctx, dist, torch, rank, world, tdev, args, pi.A); rccl = [None] * world; dist.all_gather_object(rccl, r1)
+        exchange = {"kind": ("peer_slots_grad_every_step" if args.sync_every <= 1 else "peer_slots_periodic_k%d" % args.sync_every) if sync == "grad" else ("rccl_params_every_%d_epochs" % SYNC_EVERY if sync == "native" else "torch_allreduce_params_every_%d_epochs" % SYNC_EVERY),
+                    "requested": "grad" if requested_sync == "grad" else "params", "fell_back": bool(requested_sync == "grad" and sync != "grad"),
+                    "sync_every_minibatches": args.sync_every if sync == "grad" else None,
+                    "flag_wait_per_rank": waits if sync == "grad" else None,
+                    "flag_wait_note": "upper edge (us) of the log2 bin holding the percentile of the per-exchange wait for the slowest peer's flag, both learner streams, workgroups 0 and 1 of every learner",
+                    "rccl_ranks": int(sum(1 for r in rccl if r and r.get("ok"))), "rccl_detail": rccl[0] if rccl else None}
 
     prof = {k: ctx.prof_get(k) for k in ("rollout", "values", "gae", "whiten", "train_actor", "train_critic")}
     early = None
@@ -623,6 +669,8 @@ def main():
         }
         if replicas_identical is not None:
             out["replicas_bit_identical_after_run"] = replicas_identical
+        if exchange is not None:
+            out["exchange"] = exchange; out["rccl_ranks"] = exchange["rccl_ranks"]; out["exchange_kind"] = exchange["kind"]
         if selftest is not None:
             out["selftest"] = selftest
         if early:

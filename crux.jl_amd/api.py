@@ -72,6 +72,13 @@ class Context:
     def peer_size(self):
         return int(self.lib.crux_peer_size(self.h))
 
+    def peer_set_sync_every(self, k):
+        """k = 1: gradient exchange every minibatch (the exact form); k > 1: local Adam steps, theta / m / v averaged in the learner kernel after every k-th (cruxhip.h: crux_peer_set_sync_every)"""
+        self.check(self.lib.crux_peer_set_sync_every(self.h, int(k)))
+
+    def peer_sync_every(self):
+        return int(self.lib.crux_peer_sync_every(self.h))
+
     def peer_hist_enable(self, on=True):
         """record, per learner workgroup, how long every in-kernel exchange waited for the slowest peer's flag (cruxhip.h: crux_peer_hist_enable)"""
         self.check(self.lib.crux_peer_hist_enable(self.h, 1 if on else 0))

@@ -36,6 +36,7 @@ struct crux_ctx {
   void* xbuf[2] = {nullptr, nullptr};   // gradient exchange areas of the two-CU learner kernel, one per learner stream
   // replica group with direct peer slots (comm.hip "peer"): every rank owns one fine-grained region that its peers write their minibatch
   // gradients into over xGMI; peer_ptr[r] is rank r's region as mapped here (own region for r == peer_rank)
+  int peer_every = 1;                  // crux_peer_set_sync_every: 1 = gradient exchange every minibatch; k > 1 = local Adam steps, theta / m / v averaged after every k-th
   bool peer_hist = false;              // record the per-step flag waits of the replica-group exchange (crux_peer_hist_enable)
   int peer_n = 0, peer_rank = 0; void* peer_local = nullptr; void* peer_ptr[8] = {}; bool peer_ipc[8] = {}; bool peer_fine = false;
   void* rec = nullptr;                 // ExecRec* (exec.h): the fused-step executor's recording state
@@ -61,7 +62,8 @@ struct crux_ctx {
 //                                                          continue across launches, so the double buffering argument holds across them too)
 #define CRUX_PER_PMAX 24   // deepest pairwise-cumsum tree handled incrementally (N < 128 * 2^24)
 #define CRUX_PX_MAXR 8
-#define CRUX_PX_SLOT 8192
+#define CRUX_PX_SEC 8192                        // one payload section (a gradient, or one of theta / m / v in the periodic form)
+#define CRUX_PX_SLOT (3 * CRUX_PX_SEC)
 #define CRUX_PX_FLAGS (2 * CRUX_PX_MAXR * CRUX_PX_SLOT)
 #define CRUX_PX_ABORT (CRUX_PX_FLAGS + 16 * CRUX_PX_MAXR)
 #define CRUX_PX_COUNT (CRUX_PX_ABORT + 16)

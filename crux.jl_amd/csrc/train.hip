@@ -178,6 +178,15 @@ static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_
   // a replica group is attached (comm.hip "peer"): the per-minibatch gradient all-reduce lives in the two-CU kernels only; a learner that would
   // update its parameters through any other kernel is refused rather than trained un-synchronised (gradient-only / single-step calls stay local)
   a.need_px = (c->peer_n > 1 && a.apply && !a.ids) ? 1 : 0;
+  a.px_every = 1;
+  if (a.need_px && c->peer_every > 1) {      // periodic form: k_train_fs<..., PX> only, and only where every replica provably takes the same number of steps
+    bool fs = false; int32_t prc = crux_train_fs_launch(c, a, &fs, stream, /*probe=*/true); if (prc) return prc;
+    if (!fs) return crux_fail(c, CRUX_EUNSUP, "peer sync_every = %d: the periodic exchange lives in the register-resident learner kernels (IN-64-{64,32}-OUT, 64 < batch <= 128); this learner has the per-step gradient exchange only", c->peer_every);
+    if (a.target_kl >= 0.f || a.max_batches > 0) return crux_fail(c, CRUX_EINVAL, "peer sync_every = %d: no KL early stopping / max_batches (the replicas' statistics are local between exchanges)", c->peer_every);
+    const int64_t nmb = (a.len + a.bs - 1) / a.bs;
+    if (nmb % c->peer_every != 0) return crux_fail(c, CRUX_EINVAL, "peer sync_every = %d must divide the %lld minibatches of an epoch (every call returns with identical replicas)", c->peer_every, (long long)nmb);
+    a.px_every = c->peer_every;
+  }
   int32_t rc = crux_train_mfma_launch(c, a, &handled, stream);
   if (rc) return rc;
   const bool dense_ok = !handled && crux_train_dense_eligible(a, generic_lds_bytes(a.nd), getenv("CRUX_FORCE_GENERIC") != nullptr);      // (on the second learner stream too: its own resource set)

@@ -5,14 +5,14 @@
 
 extern "C" int crux_x2_placement_ok(crux_ctx* c);      // train_mfma_x2.hip: workgroups i and i + 8 of a grid share an XCD (probed once per process)
 
-template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, int NWG, bool HELP, bool TIMING, bool PX, bool LAG = false>
+template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, int NWG, bool HELP, bool TIMING, bool PX, bool LAG = false, bool PXK = false>
 static int32_t launch_fs_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
   using Lt = FsLayout<IN, OUT, NWG, HELP, H2, LAG>;
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
   static bool attr = false;
-  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING, PX, H2, ACT2, LAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-  hipLaunchKernelGGL((k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING, PX, H2, ACT2, LAG>), dim3(8 * NWG), dim3(Lt::NT), lds, stream, a);
-  return crux_launch_check(c, PX ? "k_train_fs (replica group)" : LAG ? "k_train_fs (lagrange_ppo_loss)" : "k_train_fs");
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING, PX, H2, ACT2, LAG, PXK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING, PX, H2, ACT2, LAG, PXK>), dim3(8 * NWG), dim3(Lt::NT), lds, stream, a);
+  return crux_launch_check(c, PXK ? "k_train_fs (replica group, periodic form)" : PX ? "k_train_fs (replica group)" : LAG ? "k_train_fs (lagrange_ppo_loss)" : "k_train_fs");
 }
 // form: 2 = two workgroups of eight waves; 4 = four workgroups of four waves; 8 = four workgroups of four compute + four helper waves (the only form of the 32-wide second layer)
 // (the shapes added in round 3 for the standard Gym tasks -- IN > 17 or not one of the benchmark shapes -- are instantiated in the default form only: FS_LITE)
@@ -36,6 +36,7 @@ static int32_t launch_fs(crux_ctx* c, TrainArgs a, int form, bool timing, hipStr
                       // sent their flag / slot traffic across L2s and measured 15.5 against 12.9 us per step on one GPU.)
   if (c->peer_n > 1 && a.need_px) {      // replica group: four workgroups with helper waves, the in-kernel all-reduce over the peer slots
     a.px_hist = c->peer_hist ? 1 : 0; a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
+    if (a.px_every > 1) return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, true, false, true, false, true>(c, a, stream);      // periodic form: local Adam steps, theta / m / v averaged every k-th
     return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, true, false, true>(c, a, stream);
   }
   if constexpr (KIND != MFK_VALUE && H2 == 64 && ACT2 == ACT && ((IN == 4 && OUT == 2) || (IN == 8 && OUT == 4) || (IN == 3 && OUT == 1) || (IN == 17 && OUT == 6 && ACT == CRUX_ACT_TANH))) {

@@ -16,6 +16,7 @@
 // Covers full minibatch loops (batch_train! with Adam, 65..128 rows per minibatch) of the plain policy-gradient / critic losses, of lagrange_ppo_loss (LAG) and of replica
 // groups (PX); single steps and gradient-only calls stay on train_mfma_kernel.h.
 #pragma once
+#include <type_traits>
 #include "train_args.h"
 
 #include "mfma_helpers.h"
@@ -68,11 +69,13 @@ struct FsLayout {
 // ACT / ACT2: activations of the first / second hidden layer (the reference's critic of that example has no activation on its second layer).
 // LAG: lagrange_ppo_loss (ppo.jl:70-131) -- the PID penalty controller advanced once per minibatch inside the kernel (every thread, from the staged :cost / :episode_end
 // columns of the whole minibatch) and the cost-advantage term of the loss; helper-wave form.
-template <int IN, int OUT, int KIND, int ACT, int NWG, bool HELP = false, bool TIMING = false, bool PX = false, int H2 = 64, int ACT2 = ACT, bool LAG = false>
+template <int IN, int OUT, int KIND, int ACT, int NWG, bool HELP = false, bool TIMING = false, bool PX = false, int H2 = 64, int ACT2 = ACT, bool LAG = false, bool PXK = false>
 __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(TrainArgs a) {
   static_assert(NWG == 2 || NWG == 4, "two workgroups of eight waves, or four of four (+ four helper waves)");
   static_assert(!HELP || NWG == 4, "helper waves: the four-workgroup form");
   static_assert(!LAG || (HELP && !PX && KIND != MFK_VALUE), "lagrange_ppo_loss: helper-wave form, policy heads, one replica");
+  static_assert(!PXK || PX, "PXK: the periodic form of the replica group");
+  static_assert(!PX || FsLayout<IN, OUT, NWG, HELP, H2, LAG>::W2N + FsLayout<IN, OUT, NWG, HELP, H2, LAG>::NSI * FsLayout<IN, OUT, NWG, HELP, H2, LAG>::NT + 8 <= CRUX_PX_SEC, "a payload section must fit CRUX_PX_SEC");
   using Lt = FsLayout<IN, OUT, NWG, HELP, H2, LAG>;
   constexpr int NW = Lt::NW, NWC = Lt::NWC, TILES = Lt::TILES, NT = Lt::NT, MH = Lt::MH, HH = Lt::HH, W2N = Lt::W2N;
   constexpr int WT = (Lt::NT2 * 4) / NW;             // 16x16 tiles of W2 (H2/16 x 4 of them) owned by a wave
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   int32_t* order_cur = a.order_a; int32_t* order_nxt = a.order_b;
   long long total_batches = 0; int epochs_run = 0, err = 0, why_failed = 0; bool stop = false;
   bool staged = false;
-  long long xstep = 0;
+  long long xstep = 0, pxc = 0;      // pxc: replica-group exchanges of this launch (one per step, or three per k-th step in the periodic form)
   float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
   float inf_pen = 0.f, inf_cur = 0.f, inf_closs = 0.f, inf_ploss = 0.f;
   float pen = 0.f;                                     // lagrange_ppo_loss: the penalty of the current minibatch; the controller's state sits in LDS, one copy per wave
@@ -582,6 +585,118 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
         const int ko = (LAG && k == 7) ? Lt::pMISC + 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0) : Lt::pST + k; stat_loc = sm[Lt::oPART + ko];
 #pragma unroll
         for (int q = 1; q < TILES; ++q) stat_loc += sm[Lt::oPART + q * Lt::PART + ko]; }
+      // ---- replica group: mean over the group of NSEC payload sections (W2-tile registers + the small parameters' registers) and one statistics word, the same bits on every
+      // workgroup of every rank. Per-step form: ONE section, the minibatch gradient and its statistics. Periodic form (PXK): THREE sections -- theta, m, v after every k-th Adam
+      // step -- in ONE exchange (one release, one flag round trip). Returns false when a replica did not answer (err / why_failed are set).
+      // All NWG workgroups hold the same local values. They share the writes (peer i of the N-1 goes to workgroup i mod NWG): the sections go into slot [parity][my rank] of the
+      // peer's region, a system-scope release makes them visible, then flag[my rank] there is raised to the exchange number. Every workgroup then waits for the N-1 flags in the
+      // OWN region and adds the N contributions in rank order -- the own one from registers, the others from the slots -- so every workgroup of every rank forms the same sum.
+      auto px_allreduce_mean = [&](auto nsec_c, f32x4* const (&Wp)[3], float* const (&Sp)[3], float& xT) -> bool {
+          constexpr int NSEC = decltype(nsec_c)::value;
+          const unsigned long long xg = px0 + (unsigned long long)pxc;       // number of this exchange on this learner stream
+          const int par = (int)(xg & 1ull);
+          { int pi_ = 0;
+            for (int r = 0; r < a.px_n; ++r) {
+              if (r == a.px_rank || (pi_++ % NWG) != p) continue;
+              float* dst0 = a.px_tab[r] + (size_t)(par * CRUX_PX_MAXR + a.px_rank) * CRUX_PX_SLOT;
+#pragma unroll
+              for (int sec = 0; sec < NSEC; ++sec) { float* dst = dst0 + sec * CRUX_PX_SEC;
+#pragma unroll
+                for (int mm = 0; mm < WT; ++mm) *(f32x4*)&dst[tid * (4 * WT) + 4 * mm] = Wp[sec][mm];
+#pragma unroll
+                for (int k = 0; k < NSI; ++k) dst[W2N + tid + NT * k] = Sp[sec][k]; }
+              if (tid >= NT - 8 && tid < STAT_HI) dst0[W2N + NSI * NT + (tid - (NT - 8))] = xT; } }
+          // release, the hand-off recipe of the CDNA guides: every wave drains its own slot stores, the workgroup meets, ONE lane issues the system-scope release
+          // (buffer_wbl2 sc0 sc1 covers the whole L2, whoever wrote the lines) and drains it before the flags go out -- one L2 write-back per workgroup and exchange
+          // instead of one per wave
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int pi_ = 0;
+            for (int r = 0; r < a.px_n; ++r) { if (r == a.px_rank) continue;
+              if ((pi_++ % NWG) != p) continue;
+              __hip_atomic_store((unsigned long long*)(a.px_tab[r] + CRUX_PX_FLAGS) + 8 * a.px_rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            bool ok = true; const long long t0 = wall_clock64();                // 100 MHz: a missing peer becomes CRUX_EHIP after ~30 s instead of a hung GPU
+            unsigned* abortw = (unsigned*)(px_mine + CRUX_PX_ABORT);
+            for (int r = 0; r < a.px_n && ok; ++r) { if (r == a.px_rank) continue;
+              const unsigned long long* fl = (const unsigned long long*)(px_mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
+              while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
+            if (!ok) { for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (a.px_hist) {      // how long this workgroup waited for the slowest peer's flag (10 ns ticks, log2 bins; workgroups 0 and 1 report)
+              const unsigned long long dtk = (unsigned long long)(wall_clock64() - t0) | 1ull;
+              if (p < 2) { unsigned* hb = (unsigned*)(px_mine + CRUX_PX_HIST) + 32 * p + (63 - __builtin_clzll(dtk) > 31 ? 31 : 63 - __builtin_clzll(dtk)); *hb = *hb + 1u; } }
+            sm[Lt::oRED + 16] = ok ? 0.f : 3.f;                         // 3: a replica of the group did not answer within the timeout, or raised the abort word
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                       // system scope, one lane: drops this compute unit's L1 (the slot loads below bypass it anyway: sc0 sc1)
+          }
+          __syncthreads();
+          if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; why_failed = (int)sm[Lt::oRED + 16]; return false; }
+          // the slots are read PXS ranks at a time (all loads of a batch in flight together: one round trip to the fine-grained region per batch) and added in rank order;
+          // the six-output heads sit at the 256-register limit of two waves per SIMD and take one rank at a time (two spilled 14 registers)
+          constexpr int PXS = OUT <= 4 ? 2 : 1;
+#pragma unroll
+          for (int sec = 0; sec < NSEC; ++sec) {
+            f32x4 oW[WT]; float oS[NSI]; const float oT = xT;
+#pragma unroll
+            for (int mm = 0; mm < WT; ++mm) oW[mm] = Wp[sec][mm];
+#pragma unroll
+            for (int k = 0; k < NSI; ++k) oS[k] = Sp[sec][k];
+            for (int r0 = 0; r0 < a.px_n; r0 += PXS) {
+              f32x4 vW[PXS][WT]; float vS[PXS][NSI]; float vT[PXS];
+#pragma unroll
+              for (int q = 0; q < PXS; ++q) {
+                const int r = r0 + q;
+                if (r < a.px_n && r != a.px_rank) {
+                  const float* src0 = px_mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT; const float* src = src0 + sec * CRUX_PX_SEC;
+#pragma unroll
+                  for (int k = 0; k < NSI; ++k) vS[q][k] = __hip_atomic_load(src + W2N + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                  vT[q] = 0.f;
+                  if (sec == 0 && tid >= NT - 8 && tid < STAT_HI) vT[q] = __hip_atomic_load(src0 + W2N + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+                  for (int mm = 0; mm < WT; ++mm)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(vW[q][mm]) : "v"(src + tid * (4 * WT) + 4 * mm) : "memory");
+                } else {      // the own contribution (registers: nothing orders another workgroup's read after a store of this one, so it is never read back), or past the last rank
+                  vT[q] = r < a.px_n ? oT : 0.f;
+#pragma unroll
+                  for (int mm = 0; mm < WT; ++mm) vW[q][mm] = r < a.px_n ? oW[mm] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                  for (int k = 0; k < NSI; ++k) vS[q][k] = r < a.px_n ? oS[k] : 0.f; } }
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+              for (int q = 0; q < PXS; ++q)
+#pragma unroll
+                for (int mm = 0; mm < WT; ++mm) asm volatile("" : "+v"(vW[q][mm]));
+#pragma unroll
+              for (int q = 0; q < PXS; ++q) {
+                if (r0 + q >= a.px_n) break;
+                if (r0 + q == 0) {
+#pragma unroll
+                  for (int mm = 0; mm < WT; ++mm) Wp[sec][mm] = vW[q][mm];
+#pragma unroll
+                  for (int k = 0; k < NSI; ++k) Sp[sec][k] = vS[q][k];
+                  if (sec == 0) xT = vT[q];
+                } else {
+#pragma unroll
+                  for (int mm = 0; mm < WT; ++mm) Wp[sec][mm] += vW[q][mm];
+#pragma unroll
+                  for (int k = 0; k < NSI; ++k) Sp[sec][k] += vS[q][k];
+                  if (sec == 0) xT += vT[q];
+                }
+              }
+            }
+            // mean over the group (gradient: global minibatch = px_n x nb samples, every rank's partial was already divided by nb)
+#pragma unroll
+            for (int mm = 0; mm < WT; ++mm) Wp[sec][mm] = Wp[sec][mm] * px_inv;
+#pragma unroll
+            for (int k = 0; k < NSI; ++k) Sp[sec][k] = Sp[sec][k] * px_inv;
+          }
+          xT = xT * px_inv;
+          pxc += 1;
+          return true;
+      };
       float stat_tot = stat_loc;
       // ---- exchange the partial gradients with the other workgroups through the shared L2 ----
       {
@@ -643,107 +758,9 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
           for (int k = 0; k < NSI; ++k) gs[k] = (gs[k] + pg[0][k]) + (pg[1][k] + pg[2][k]);
           stat_tot = (stat_loc + ps[0]) + (ps[1] + ps[2]);
         }
-        if constexpr (PX) {
-          // ---- SUM all-reduce of the local gradient over the replica group. All NWG workgroups hold the same local total. They share the writes (peer i of the N-1 goes to
-          // workgroup i mod NWG): the total and the seven statistics sums go into slot [parity][my rank] of the peer's region, a system-scope release makes them visible, then
-          // flag[my rank] there is raised to the exchange number. Every workgroup then waits for the N-1 flags in the OWN region and adds the N contributions in rank order -- the
-          // own one from registers, the others from the slots -- so every workgroup of every rank forms the same sum bit for bit.
-          const unsigned long long xg = px0 + (unsigned long long)xstep;       // number of this exchange on this learner stream
-          const int par = (int)(xg & 1ull);
-          { int pi_ = 0;
-            for (int r = 0; r < a.px_n; ++r) {
-              if (r == a.px_rank || (pi_++ % NWG) != p) continue;
-              float* dst = a.px_tab[r] + (size_t)(par * CRUX_PX_MAXR + a.px_rank) * CRUX_PX_SLOT;
-#pragma unroll
-              for (int mm = 0; mm < WT; ++mm) *(f32x4*)&dst[tid * (4 * WT) + 4 * mm] = gW2[mm];
-#pragma unroll
-              for (int k = 0; k < NSI; ++k) dst[W2N + tid + NT * k] = gs[k];
-              if (tid >= NT - 8 && tid < STAT_HI) dst[W2N + NSI * NT + (tid - (NT - 8))] = stat_tot; } }
-          // release, the hand-off recipe of the CDNA guides: every wave drains its own slot stores, the workgroup meets, ONE lane issues the system-scope release
-          // (buffer_wbl2 sc0 sc1 covers the whole L2, whoever wrote the lines) and drains it before the flags go out -- one L2 write-back per workgroup and step
-          // instead of one per wave
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            int pi_ = 0;
-            for (int r = 0; r < a.px_n; ++r) { if (r == a.px_rank) continue;
-              if ((pi_++ % NWG) != p) continue;
-              __hip_atomic_store((unsigned long long*)(a.px_tab[r] + CRUX_PX_FLAGS) + 8 * a.px_rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-            bool ok = true; const long long t0 = wall_clock64();                // 100 MHz: a missing peer becomes CRUX_EHIP after ~30 s instead of a hung GPU
-            unsigned* abortw = (unsigned*)(px_mine + CRUX_PX_ABORT);
-            for (int r = 0; r < a.px_n && ok; ++r) { if (r == a.px_rank) continue;
-              const unsigned long long* fl = (const unsigned long long*)(px_mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
-              while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
-            if (!ok) { for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-              __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            if (a.px_hist) {      // how long this workgroup waited for the slowest peer's flag (10 ns ticks, log2 bins; workgroups 0 and 1 report)
-              const unsigned long long dtk = (unsigned long long)(wall_clock64() - t0) | 1ull;
-              if (p < 2) { unsigned* hb = (unsigned*)(px_mine + CRUX_PX_HIST) + 32 * p + (63 - __builtin_clzll(dtk) > 31 ? 31 : 63 - __builtin_clzll(dtk)); *hb = *hb + 1u; } }
-            sm[Lt::oRED + 16] = ok ? 0.f : 3.f;                         // 3: a replica of the group did not answer within the timeout, or raised the abort word
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                       // system scope, one lane: drops this compute unit's L1 (the slot loads below bypass it anyway: sc0 sc1)
-          }
-          __syncthreads();
-          if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; why_failed = (int)sm[Lt::oRED + 16]; break; }
-          f32x4 oW[WT]; float oS[NSI]; const float oT = stat_tot;
-#pragma unroll
-          for (int mm = 0; mm < WT; ++mm) oW[mm] = gW2[mm];
-#pragma unroll
-          for (int k = 0; k < NSI; ++k) oS[k] = gs[k];
-          // the slots are read PXS ranks at a time (all loads of a batch in flight together: one round trip to the fine-grained region per batch) and added in rank order;
-          // the six-output heads sit at the 256-register limit of two waves per SIMD and take one rank at a time (two spilled 14 registers)
-          constexpr int PXS = OUT <= 4 ? 2 : 1;
-          for (int r0 = 0; r0 < a.px_n; r0 += PXS) {
-            f32x4 vW[PXS][WT]; float vS[PXS][NSI]; float vT[PXS];
-#pragma unroll
-            for (int q = 0; q < PXS; ++q) {
-              const int r = r0 + q;
-              if (r < a.px_n && r != a.px_rank) {
-                const float* src = px_mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT;
-#pragma unroll
-                for (int k = 0; k < NSI; ++k) vS[q][k] = __hip_atomic_load(src + W2N + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                vT[q] = 0.f;
-                if (tid >= NT - 8 && tid < STAT_HI) vT[q] = __hip_atomic_load(src + W2N + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#pragma unroll
-                for (int mm = 0; mm < WT; ++mm)
-                  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(vW[q][mm]) : "v"(src + tid * (4 * WT) + 4 * mm) : "memory");
-              } else {      // the own contribution (registers: nothing orders another workgroup's read after a store of this one, so it is never read back), or past the last rank
-                vT[q] = r < a.px_n ? oT : 0.f;
-#pragma unroll
-                for (int mm = 0; mm < WT; ++mm) vW[q][mm] = r < a.px_n ? oW[mm] : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < NSI; ++k) vS[q][k] = r < a.px_n ? oS[k] : 0.f; } }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int q = 0; q < PXS; ++q)
-#pragma unroll
-              for (int mm = 0; mm < WT; ++mm) asm volatile("" : "+v"(vW[q][mm]));
-#pragma unroll
-            for (int q = 0; q < PXS; ++q) {
-              if (r0 + q >= a.px_n) break;
-              if (r0 + q == 0) {
-#pragma unroll
-                for (int mm = 0; mm < WT; ++mm) gW2[mm] = vW[q][mm];
-#pragma unroll
-                for (int k = 0; k < NSI; ++k) gs[k] = vS[q][k];
-                stat_tot = vT[q];
-              } else {
-#pragma unroll
-                for (int mm = 0; mm < WT; ++mm) gW2[mm] += vW[q][mm];
-#pragma unroll
-                for (int k = 0; k < NSI; ++k) gs[k] += vS[q][k];
-                stat_tot += vT[q];
-              }
-            }
-          }
-          // mean over the group: global minibatch = px_n x nb samples, every rank's partial was already divided by nb
-#pragma unroll
-          for (int mm = 0; mm < WT; ++mm) gW2[mm] = gW2[mm] * px_inv;
-#pragma unroll
-          for (int k = 0; k < NSI; ++k) gs[k] = gs[k] * px_inv;
-          stat_tot = stat_tot * px_inv;
+        if constexpr (PX && !PXK) {
+          f32x4* const Wp[3] = {gW2, nullptr, nullptr}; float* const Sp[3] = {gs, nullptr, nullptr};
+          if (!px_allreduce_mean(std::integral_constant<int, 1>{}, Wp, Sp, stat_tot)) break;
         }
         xstep += 1;
       }
@@ -798,6 +815,26 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
         if (so_ok[k]) { float m_ = sm[Lt::oMS + s], v_ = sm[Lt::oVS + s]; const float d = adam1(gs[k], m_, v_, ak);
           sm[Lt::oMS + s] = m_; sm[Lt::oVS + s] = v_; const int mo = so_master[k]; sm[mo] = sm[mo] - d; } }
       bp1 *= a.b1; bp2 *= a.b2;
+      if constexpr (PX && PXK) {
+        // ---- periodic form (crux_peer_set_sync_every(k > 1)): between exchanges every replica takes LOCAL Adam steps on its own shard; after every k-th step the group averages
+        // theta, m and v (sum in rank order x 1/N: the same bits everywhere, so the replicas leave the exchange identical). One exchange per k steps instead of k.
+        if ((total_batches + 1) % a.px_every == 0) {
+          float sT[NSI], sM[NSI], sV[NSI]; float dummy = 0.f;
+#pragma unroll
+          for (int k = 0; k < NSI; ++k) { const int s = tid + NT * k; const bool ok_ = so_ok[k];
+            sT[k] = ok_ ? sm[so_master[k]] : 0.f; sM[k] = ok_ ? sm[Lt::oMS + s] : 0.f; sV[k] = ok_ ? sm[Lt::oVS + s] : 0.f; }
+          f32x4* const Wp[3] = {tW2, mW2, vW2}; float* const Sp[3] = {sT, sM, sV};
+          if (!px_allreduce_mean(std::integral_constant<int, 3>{}, Wp, Sp, dummy)) break;
+#pragma unroll
+          for (int k = 0; k < NSI; ++k) { const int s = tid + NT * k;
+            if (so_ok[k]) { sm[so_master[k]] = sT[k]; sm[Lt::oMS + s] = sM[k]; sm[Lt::oVS + s] = sV[k]; } }
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) {      // the LDS copies of W2 follow the averaged registers
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm[Lt::oW2R + (16 * mp0 + 4 * g + r) * FS_LD + 16 * (m0 + mm) + c] = tW2[mm][r];
+            *(f32x4*)&sm[Lt::oW2C + (16 * (m0 + mm) + c) * FS_LD + 16 * mp0 + 4 * g] = tW2[mm]; }
+        }
+      }
       FS_T(14);
       __syncthreads();   // ---- B_b: masters updated; tiles and partials may be overwritten
       if (HELP) xcur ^= 1;
@@ -827,7 +864,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
     for (int s = tid; s < ns_valid; s += NT) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; }
   }
   if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(NW * p + w) * 16 + k] = tacc[k]; }
-  if (PX && tid == 0 && p == 0) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)xstep;
+  if (PX && tid == 0 && p == 0) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)pxc;
   if (tid == 0 && (p == 0 || err)) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 3 replica group timeout / abort

@@ -71,3 +71,39 @@ def train_minibatch_synced(pi, p, P, D, ids0, reducer, cfg_builder):
     scale = reducer()
     pi.ctx.check(pi.ctx.lib.crux_adam_apply(pi.h, float(scale)))
     return raw
+
+
+def sync_due(steps_taken, k):
+    """periodic form (crux_peer_set_sync_every(k), bench.py --sync-every k): the replicas average theta, m, v after every k-th minibatch step; k = 1 is the per-step gradient exchange."""
+    return k > 1 and steps_taken > 0 and steps_taken % k == 0
+
+
+class StateAverager:
+    """Host-side twin of the in-kernel periodic exchange (train_fs_kernel.h): replaces every float32 array by its mean over the ranks, in place -- SUM all-reduce, then x float32(1 / N),
+    the kernel's arithmetic (at N = 2 the sum is order-free, so the result is bit-identical to the kernel's rank-ordered sum). `arrays` are numpy float32 arrays on the host."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def __call__(self, arrays):
+        if self.world == 1:
+            return
+        inv = np.float32(1.0) / np.float32(self.world)
+        for a in arrays:
+            t = self.torch.from_numpy(a)                 # aliases the array
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            a *= inv
+
+
+def train_periodic(local_step, state_arrays, n_steps, k, averager):
+    """n_steps local minibatch steps (local_step(i) trains on this rank's shard only), the replicated state averaged after every k-th: the schedule the learner kernel runs under
+    crux_peer_set_sync_every(k). Returns the number of exchanges."""
+    n_sync = 0
+    for i in range(n_steps):
+        local_step(i)
+        if sync_due(i + 1, k):
+            averager(state_arrays()); n_sync += 1
+    return n_sync

@@ -384,6 +384,12 @@ int32_t crux_peer_attach_local(crux_ctx* const* ctxs, int32_t n);
 int32_t crux_peer_detach(crux_ctx* ctx);
 /* diagnostics of the in-kernel exchange: while enabled every learner workgroup bins how long it waited for the slowest peer's flag at each exchange
  * (log2 bins of 10 ns ticks). out: uint32 [2 learner streams][2 workgroups][32]; reset != 0 clears the bins after reading.                       */
+/* periodic form (Crux.jl itself is single-process: this extends SURVEY 8(e)'s k > 1 row into the kernel): k = 1 (default) exchanges the minibatch gradient every step and equals
+ * the single learner on the concatenated batch; k > 1 lets every replica take local Adam steps on its shard and averages theta, m and v (sum in rank order x 1/N) after every
+ * k-th step inside the persistent kernel -- 3 exchanges per k steps instead of k. Needs the register-resident learner family, no KL early stopping / max_batches, and k must
+ * divide the minibatches per epoch so that every call returns with identical replicas; other calls fail with CRUX_EUNSUP / CRUX_EINVAL.                                        */
+int32_t crux_peer_set_sync_every(crux_ctx* ctx, int32_t k);
+int32_t crux_peer_sync_every(const crux_ctx* ctx);
 int32_t crux_peer_hist_enable(crux_ctx* ctx, int32_t on);
 int32_t crux_peer_wait_hist(crux_ctx* ctx, uint32_t* out128, int32_t reset);
 int32_t crux_peer_size(const crux_ctx* ctx);               /* 1 when no group is attached */

@@ -161,6 +161,14 @@ int32_t orc_adam_get_state(orc_mlp* n, float* m, float* v, double* bp) {
   if (bp) { bp[0] = n->bp[0]; bp[1] = n->bp[1]; }
   return CRUX_OK;
 }
+/* test infrastructure for the replica group's periodic form (local SGD twin): overwrite the Adam moments (the beta powers are kept when bp == NULL) */
+int32_t orc_adam_set_state(orc_mlp* n, const float* m, const float* v, const double* bp) {
+  if (!n->has_adam) return CRUX_EINVAL;
+  if (m) memcpy(n->m, m, 4 * (size_t)n->n_params);
+  if (v) memcpy(n->v, v, 4 * (size_t)n->n_params);
+  if (bp) { n->bp[0] = bp[0]; n->bp[1] = bp[1]; }
+  return CRUX_OK;
+}
 int32_t orc_adam_apply(orc_mlp* n, float grad_scale) {
   if (!n->has_adam) return CRUX_EINVAL;
   for (int64_t i = 0; i < n->n_params; ++i) {

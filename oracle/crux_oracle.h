@@ -40,6 +40,7 @@ int32_t orc_mlp_copy(orc_mlp* to, const orc_mlp* from);
 int32_t orc_polyak(orc_mlp* to, const orc_mlp* from, float tau);
 int32_t orc_adam_init(orc_mlp* net, double eta, double beta1, double beta2, double eps);
 int32_t orc_adam_get_state(orc_mlp* net, float* m, float* v, double* beta_pow);
+int32_t orc_adam_set_state(orc_mlp* net, const float* m, const float* v, const double* beta_pow);
 int32_t orc_adam_apply(orc_mlp* net, float grad_scale);
 
 /* buffer */

@@ -19,7 +19,7 @@ _SIG = {
     "orc_mlp_create": (vp, [i32, P(i32), P(i32), i32]), "orc_mlp_destroy": (None, [vp]), "orc_mlp_n_params": (i64, [vp]),
     "orc_mlp_params": (P(f32), [vp]), "orc_mlp_grads": (P(f32), [vp]), "orc_mlp_init_glorot": (i32, [vp, u64, u32, f32]),
     "orc_mlp_forward": (i32, [vp, vp, i64, vp]), "orc_mlp_copy": (i32, [vp, vp]), "orc_polyak": (i32, [vp, vp, f32]),
-    "orc_adam_init": (i32, [vp, f64, f64, f64, f64]), "orc_adam_get_state": (i32, [vp, vp, vp, vp]), "orc_adam_apply": (i32, [vp, f32]),
+    "orc_adam_init": (i32, [vp, f64, f64, f64, f64]), "orc_adam_get_state": (i32, [vp, vp, vp, vp]), "orc_adam_set_state": (i32, [vp, vp, vp, vp]), "orc_adam_apply": (i32, [vp, f32]),
     "orc_buffer_create": (vp, [i32, i32, i32, i64, u32, i32, f32]), "orc_buffer_destroy": (None, [vp]), "orc_buffer_len": (i64, [vp]),
     "orc_buffer_capacity": (i64, [vp]), "orc_buffer_next_ind": (i64, [vp]), "orc_buffer_total_count": (i64, [vp]),
     "orc_buffer_has_column": (i32, [vp, i32]), "orc_buffer_clear": (i32, [vp]), "orc_buffer_column_info": (i32, [vp, i32, P(i32), P(i32)]),
@@ -121,6 +121,10 @@ class OMlp:
     def adam_state(self):
         m, v, bp = np.empty(self.n, np.float32), np.empty(self.n, np.float32), np.empty(2, np.float64)
         chk(lib().orc_adam_get_state(self.h, vpz(m), vpz(v), vpz(bp))); return m, v, bp
+
+    def set_adam_state(self, m, v):
+        m, v = np.ascontiguousarray(m, np.float32), np.ascontiguousarray(v, np.float32)
+        chk(lib().orc_adam_set_state(self.h, vpz(m), vpz(v), None)); return self
 
     def __del__(self):
         try:

@@ -65,3 +65,59 @@ def test_two_rank_gradient_allreduce_matches_concatenated_batch():
         ids = np.arange(128, dtype=np.int64); info = np.zeros(L.INFO_N, np.float32)
         O.chk(O.lib().orc_train_step(net.h, big.h, C.byref(cfg), O.vpz(ids), 128, O.vpz(info)))
     assert np.abs(net.params - out[0]).max() < 1e-6
+
+
+def _worker_periodic(rank, world, port, out, k, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from crux_jl_amd import dist as cdist
+    n = 64
+    O, L, net, buf, cfg = _make(100 + rank, n)
+    ids = np.arange(n, dtype=np.int64); info = np.zeros(L.INFO_N, np.float32)
+    mv = {}
+
+    def local_step(i):
+        O.chk(O.lib().orc_train_step(net.h, buf.h, C.byref(cfg), O.vpz(ids), n, O.vpz(info)))
+
+    def state():
+        mv["m"], mv["v"], _ = net.adam_state(); return [net.params, mv["m"], mv["v"]]        # net.params aliases the oracle's buffer; m / v are copies, written back below
+
+    class Avg(cdist.StateAverager):
+        def __call__(self, arrays):
+            super().__call__(arrays); net.set_adam_state(arrays[1], arrays[2])
+    n_sync = cdist.train_periodic(local_step, state, steps, k, Avg())
+    m, v, bp = net.adam_state()
+    out[rank] = (net.params.copy(), m, v, n_sync)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [4])
+def test_two_rank_periodic_form_matches_the_local_sgd_twin(k):
+    """k = 4 (SURVEY 8e's k > 1 row; the in-kernel form is tests/test_gpu_peer.py::test_periodic_form_equals_the_local_sgd_twin): two gloo ranks take local oracle steps on their own
+    shards and average theta, m, v after every 4th through dist.StateAverager; a single process running both learners with numpy's (a + b) * 0.5 must give the same bits."""
+    steps = 8
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager(); out = mgr.dict()
+    port = 30500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker_periodic, args=(r, 2, port, out, k, steps)) for r in range(2)]
+    [p.start() for p in procs]; [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for j in range(3):
+        assert np.array_equal(out[0][j], out[1][j])          # replicas leave every exchange bit-identical
+    assert out[0][3] == out[1][3] == steps // k
+    twins = [_make(100 + r, 64) for r in range(2)]
+    ids = np.arange(64, dtype=np.int64)
+    for i in range(steps):
+        for O, L, net, buf, cfg in twins:
+            info = np.zeros(L.INFO_N, np.float32)
+            O.chk(O.lib().orc_train_step(net.h, buf.h, C.byref(cfg), O.vpz(ids), 64, O.vpz(info)))
+        if (i + 1) % k == 0:
+            nets = [t[2] for t in twins]; st = [n.adam_state() for n in nets]
+            th = (nets[0].params + nets[1].params) * np.float32(0.5); m = (st[0][0] + st[1][0]) * np.float32(0.5); v = (st[0][1] + st[1][1]) * np.float32(0.5)
+            for n in nets:
+                n.params[:] = th; n.set_adam_state(m, v)
+    tm, tv, _ = twins[0][2].adam_state()
+    assert np.array_equal(twins[0][2].params, out[0][0]) and np.array_equal(tm, out[0][1]) and np.array_equal(tv, out[0][2])
+    # and local steps really diverge between exchanges: the per-step form gives different parameters
+    from crux_jl_amd import dist as cdist
+    assert not cdist.sync_due(4, 1) and cdist.sync_due(4, 4) and not cdist.sync_due(5, 4) and not cdist.sync_due(0, 4)
