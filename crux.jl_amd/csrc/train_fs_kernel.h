@@ -636,63 +636,74 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
           if (sm[Lt::oRED + 16] != 0.f) { err = CRUX_EHIP; why_failed = (int)sm[Lt::oRED + 16]; return false; }
           // the slots are read PXS ranks at a time (all loads of a batch in flight together: one round trip to the fine-grained region per batch) and added in rank order;
           // the six-output heads sit at the 256-register limit of two waves per SIMD and take one rank at a time (two spilled 14 registers)
-          constexpr int PXS = OUT <= 4 ? 2 : 1;
+          constexpr int PXS = (OUT <= 4 && NSEC == 1) ? 2 : 1;      // (the three-section exchange of the periodic form has all sections of ONE rank in flight together)
+          f32x4 oW[NSEC][WT]; float oS[NSEC][NSI]; const float oT = xT;
 #pragma unroll
           for (int sec = 0; sec < NSEC; ++sec) {
-            f32x4 oW[WT]; float oS[NSI]; const float oT = xT;
 #pragma unroll
-            for (int mm = 0; mm < WT; ++mm) oW[mm] = Wp[sec][mm];
+            for (int mm = 0; mm < WT; ++mm) oW[sec][mm] = Wp[sec][mm];
 #pragma unroll
-            for (int k = 0; k < NSI; ++k) oS[k] = Sp[sec][k];
-            for (int r0 = 0; r0 < a.px_n; r0 += PXS) {
-              f32x4 vW[PXS][WT]; float vS[PXS][NSI]; float vT[PXS];
+            for (int k = 0; k < NSI; ++k) oS[sec][k] = Sp[sec][k]; }
+          for (int r0 = 0; r0 < a.px_n; r0 += PXS) {
+            f32x4 vW[NSEC][PXS][WT]; float vS[NSEC][PXS][NSI]; float vT[PXS];
 #pragma unroll
-              for (int q = 0; q < PXS; ++q) {
-                const int r = r0 + q;
-                if (r < a.px_n && r != a.px_rank) {
-                  const float* src0 = px_mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT; const float* src = src0 + sec * CRUX_PX_SEC;
+            for (int q = 0; q < PXS; ++q) {
+              const int r = r0 + q;
+              if (r < a.px_n && r != a.px_rank) {
+                const float* src0 = px_mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT;
+                vT[q] = 0.f;
+                if (tid >= NT - 8 && tid < STAT_HI) vT[q] = __hip_atomic_load(src0 + W2N + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
-                  for (int k = 0; k < NSI; ++k) vS[q][k] = __hip_atomic_load(src + W2N + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                  vT[q] = 0.f;
-                  if (sec == 0 && tid >= NT - 8 && tid < STAT_HI) vT[q] = __hip_atomic_load(src0 + W2N + NSI * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int sec = 0; sec < NSEC; ++sec) { const float* src = src0 + sec * CRUX_PX_SEC;
+#pragma unroll
+                  for (int k = 0; k < NSI; ++k) vS[sec][q][k] = __hip_atomic_load(src + W2N + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
                   for (int mm = 0; mm < WT; ++mm)
-                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(vW[q][mm]) : "v"(src + tid * (4 * WT) + 4 * mm) : "memory");
-                } else {      // the own contribution (registers: nothing orders another workgroup's read after a store of this one, so it is never read back), or past the last rank
-                  vT[q] = r < a.px_n ? oT : 0.f;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(vW[sec][q][mm]) : "v"(src + tid * (4 * WT) + 4 * mm) : "memory"); }
+              } else {      // the own contribution (registers: nothing orders another workgroup's read after a store of this one, so it is never read back), or past the last rank
+                vT[q] = r < a.px_n ? oT : 0.f;
 #pragma unroll
-                  for (int mm = 0; mm < WT; ++mm) vW[q][mm] = r < a.px_n ? oW[mm] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int sec = 0; sec < NSEC; ++sec) {
 #pragma unroll
-                  for (int k = 0; k < NSI; ++k) vS[q][k] = r < a.px_n ? oS[k] : 0.f; } }
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  for (int mm = 0; mm < WT; ++mm) vW[sec][q][mm] = r < a.px_n ? oW[sec][mm] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                  for (int k = 0; k < NSI; ++k) vS[sec][q][k] = r < a.px_n ? oS[sec][k] : 0.f; } } }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int sec = 0; sec < NSEC; ++sec)
 #pragma unroll
               for (int q = 0; q < PXS; ++q)
 #pragma unroll
-                for (int mm = 0; mm < WT; ++mm) asm volatile("" : "+v"(vW[q][mm]));
+                for (int mm = 0; mm < WT; ++mm) asm volatile("" : "+v"(vW[sec][q][mm]));
 #pragma unroll
-              for (int q = 0; q < PXS; ++q) {
-                if (r0 + q >= a.px_n) break;
-                if (r0 + q == 0) {
+            for (int q = 0; q < PXS; ++q) {
+              if (r0 + q >= a.px_n) break;
+              if (r0 + q == 0) {
 #pragma unroll
-                  for (int mm = 0; mm < WT; ++mm) Wp[sec][mm] = vW[q][mm];
+                for (int sec = 0; sec < NSEC; ++sec) {
 #pragma unroll
-                  for (int k = 0; k < NSI; ++k) Sp[sec][k] = vS[q][k];
-                  if (sec == 0) xT = vT[q];
-                } else {
+                  for (int mm = 0; mm < WT; ++mm) Wp[sec][mm] = vW[sec][q][mm];
 #pragma unroll
-                  for (int mm = 0; mm < WT; ++mm) Wp[sec][mm] += vW[q][mm];
+                  for (int k = 0; k < NSI; ++k) Sp[sec][k] = vS[sec][q][k]; }
+                xT = vT[q];
+              } else {
 #pragma unroll
-                  for (int k = 0; k < NSI; ++k) Sp[sec][k] += vS[q][k];
-                  if (sec == 0) xT += vT[q];
-                }
+                for (int sec = 0; sec < NSEC; ++sec) {
+#pragma unroll
+                  for (int mm = 0; mm < WT; ++mm) Wp[sec][mm] += vW[sec][q][mm];
+#pragma unroll
+                  for (int k = 0; k < NSI; ++k) Sp[sec][k] += vS[sec][q][k]; }
+                xT += vT[q];
               }
             }
-            // mean over the group (gradient: global minibatch = px_n x nb samples, every rank's partial was already divided by nb)
+          }
+          // mean over the group (gradient: global minibatch = px_n x nb samples, every rank's partial was already divided by nb)
+#pragma unroll
+          for (int sec = 0; sec < NSEC; ++sec) {
 #pragma unroll
             for (int mm = 0; mm < WT; ++mm) Wp[sec][mm] = Wp[sec][mm] * px_inv;
 #pragma unroll
-            for (int k = 0; k < NSI; ++k) Sp[sec][k] = Sp[sec][k] * px_inv;
-          }
+            for (int k = 0; k < NSI; ++k) Sp[sec][k] = Sp[sec][k] * px_inv; }
           xT = xT * px_inv;
           pxc += 1;
           return true;
