@@ -221,7 +221,9 @@ int32_t crux_dense_forward(crux_mlp* n, const float* d_x, int64_t B, hipStream_t
 // of a train! step, forms and stores the final values while it sums the squares. part == nullptr: nothing deferred for that network.
 struct Sumsq2Fix { const float* part[2]; int32_t out1[2], in0[2], woff[2], boff[2]; float scale[2]; };
 // defer (slot of a Sumsq2Fix the caller passes to the Sumsq2Op that follows, or NULL): permits the fused pullback of layers 1 / 0, whose layer-0 gradient is completed by that op
-int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st, Sumsq2Fix* defer = nullptr, int defer_slot = 0);
+// nanflags (or NULL): [0] |= 1 when a gradient value stored by the pullback is NaN, [1] |= 1 when a deferred layer-0 partial is not finite (its final sum may be NaN): what
+// AdamSelfOp (sac.hip) gates on, so that Adam shares the phase of the norm instead of following it
+int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st, Sumsq2Fix* defer = nullptr, int defer_slot = 0, int32_t* nanflags = nullptr);
 float* crux_dense_act(crux_mlp* n, int l);
 int32_t crux_td_step_dense(crux_mlp* net, crux_buffer* b, const float* d_y, int32_t use_weight, float* info_out, float* d_err);   // sac.hip
 #define CRUX_DENSE_MIN_WIDTH 128   // networks at least this wide go through the multi-CU dense engine

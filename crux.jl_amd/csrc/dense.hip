@@ -25,6 +25,7 @@ struct GemmArgs {
   int M, N, K;
   float* C; int64_t sCj;                 // C(i,j) = C[i + j*sCj]
   int epi; const float* bias; int act; const float* ysrc; float scale; float* gbias;
+  int32_t* nf;                           // EPI_WGRAD: nf[0] |= 1 when a value this launch stores is NaN (the self-gated Adam of the fused epochs, sac.hip AdamSelfOp); may be NULL
 };
 
 // SPLITK: the four waves of a workgroup share ONE output tile and take a quarter of K each (combined through LDS in wave order, so the
@@ -108,7 +109,7 @@ struct Gemm16 { static __device__ __forceinline__ void run(const unsigned bid_, 
   }
   if (want_rowsum) {   // lanes c, c+16, c+32, c+48 hold the four k-groups of row i0+c: fixed-order combine
     rowsum += __shfl_xor(rowsum, 16, 64); rowsum += __shfl_xor(rowsum, 32, 64);
-    if (g == 0 && va) q.gbias[ia] = q.scale * rowsum;
+    if (g == 0 && va) { const float bv = q.scale * rowsum; q.gbias[ia] = bv; if (q.nf && bv != bv) atomicOr((int*)q.nf, 1); }
   }
   // D layout: reg r <-> row i0+4g+r, column j0+c
   const int j = j0 + c;
@@ -118,7 +119,7 @@ struct Gemm16 { static __device__ __forceinline__ void run(const unsigned bid_, 
     const int64_t ci = (int64_t)i + (int64_t)j * q.sCj; float v = acc[r];
     if (q.epi == EPI_FWD) v = crux_act(q.act, v + q.bias[i]);
     else if (q.epi == EPI_BWD_DATA) { if (q.ysrc) v = crux_act_grad(q.act, q.ysrc[ci], v); }
-    else v *= q.scale;
+    else { v *= q.scale; if (q.nf && v != v) atomicOr((int*)q.nf, 1); }
     q.C[ci] = v; }
 } };
 template <bool AV, bool BV, bool SPLITK>
@@ -253,7 +254,7 @@ int32_t crux_dense_dgrad_to_dz1(crux_mlp* n, const float* d_x, int64_t B, const 
 }
 
 // Reverse pass after crux_dense_forward(n, d_x, B) with the same d_x. d_dy [out_L x B] is not modified.
-int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st, Sumsq2Fix* defer, int defer_slot) {
+int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const float* d_dy, float gscale, bool want_g, float* d_dx, hipStream_t st, Sumsq2Fix* defer, int defer_slot, int32_t* nanflags) {
   crux_ctx* c = n->ctx; const NetDesc& nd = n->nd;
   if (nd.L < 1 || !n->ws || n->ws_B < B) return crux_fail(c, CRUX_EINVAL, "backward: no cached forward pass for this batch");
   const float* dcur = d_dy; float* dnxt = ws_delta(n, 0); float* dspare = ws_delta(n, 1);
@@ -271,17 +272,17 @@ int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const floa
     const float* x = l == 0 ? d_x : crux_dense_act(n, l);
     if (fused3 && l == 2) {      // the output layer: its weight gradient only (same phase as the fused pair below)
       if (want_g) { GemmArgs q{}; q.A = dcur; q.sAi = 1; q.sAk = out; q.B = x; q.sBk = in; q.sBj = 1; q.M = out; q.N = in; q.K = (int)B;
-        q.C = n->g + nd.woff[l]; q.sCj = out; q.epi = EPI_WGRAD; q.scale = gscale; q.gbias = n->g + nd.boff[l];
+        q.C = n->g + nd.woff[l]; q.sCj = out; q.epi = EPI_WGRAD; q.scale = gscale; q.gbias = n->g + nd.boff[l]; q.nf = nanflags;
         int32_t rc = launch_gemm(c, q, st); if (rc) return rc; }
       continue;
     }
     if (fused && l == 1) {      // layers 1 and 0 together (dense_fused.h): dW1' = dcur X1' | dX1 = act0'(X1) .* (W1'' dcur) -> layer 0's dW, db inside the same workgroups
       DzSrc z{}; const float* dz1 = dcur;
       if (fused3) { z.W3 = n->p + nd.woff[2]; z.dZ3 = dcur; z.out3 = nd.dims[3]; z.act = nd.acts[1]; dz1 = crux_dense_act(n, 2); }      // dcur is still dZ of the output layer; the operand pointer becomes H2
-      if (want_g) { Wgrad2Args w{}; w.z = z; w.dZ = dz1; w.X = x; w.dW = n->g + nd.woff[1]; w.db = n->g + nd.boff[1]; w.scale = gscale; w.out = out; w.in = in; w.B = (int32_t)B;
+      if (want_g) { Wgrad2Args w{}; w.z = z; w.dZ = dz1; w.X = x; w.dW = n->g + nd.woff[1]; w.db = n->g + nd.boff[1]; w.scale = gscale; w.out = out; w.in = in; w.B = (int32_t)B; w.nf = nanflags;
         CRUX_RUN(c, Wgrad2Op, OP_WGRAD2, k_wgrad2, (unsigned)((out >> 5) * (in >> 5)), 256, st, w); }
       Dgrad2Args a{}; a.z = z; a.W2 = n->p + nd.woff[1]; a.dZ2 = dz1; a.H1 = x; a.x = d_x; a.part = ws_part(n); a.dZ1 = d_dx ? dnxt : nullptr;
-      a.in0 = nd.dims[0]; a.out1 = in; a.out2 = out; a.B = (int32_t)B; a.act0 = nd.acts[0]; a.want_g = want_g ? 1 : 0;
+      a.in0 = nd.dims[0]; a.out1 = in; a.out2 = out; a.B = (int32_t)B; a.act0 = nd.acts[0]; a.want_g = want_g ? 1 : 0; a.nf = nanflags;
       CRUX_RUN(c, Dgrad2W1Op, OP_DGRAD2W1, k_dgrad2w1, (unsigned)((in >> 4) * 4), 256, st, a);
       if (want_g) { defer->part[defer_slot] = a.part; defer->out1[defer_slot] = in; defer->in0[defer_slot] = nd.dims[0]; defer->woff[defer_slot] = nd.woff[0]; defer->boff[defer_slot] = nd.boff[0]; defer->scale[defer_slot] = gscale; }
       if (d_dx) {                // the input gradient of layer 0 from the dZ of layer 0 the fused op left in the workspace
@@ -292,7 +293,7 @@ int32_t crux_dense_backward(crux_mlp* n, const float* d_x, int64_t B, const floa
     }
     if (want_g) {
       GemmArgs q{}; q.A = dcur; q.sAi = 1; q.sAk = out; q.B = x; q.sBk = in; q.sBj = 1; q.M = out; q.N = in; q.K = (int)B;
-      q.C = n->g + nd.woff[l]; q.sCj = out; q.epi = EPI_WGRAD; q.scale = gscale; q.gbias = n->g + nd.boff[l];   // db rides along in the first column tile
+      q.C = n->g + nd.woff[l]; q.sCj = out; q.epi = EPI_WGRAD; q.scale = gscale; q.gbias = n->g + nd.boff[l]; q.nf = nanflags;   // db rides along in the first column tile
       int32_t rc = launch_gemm(c, q, st); if (rc) return rc;
     }
     if (l > 0 || d_dx) {

@@ -92,7 +92,7 @@ template <int O3> __device__ __forceinline__ float df_dz(const DzSrc& z, float h
   for (int q = 0; q < O3; ++q) v = fmaf(w[q], d[q], v);      // (w is zero past out3: the term adds +-0)
   return crux_act_grad(z.act, h, v);
 }
-struct Wgrad2Args { const float* dZ; const float* X; float* dW; float* db; float scale; int32_t out, in, B; DzSrc z; };      // z.W3 != nullptr: dZ points at H (the layer's own output) and the gradient is formed on the fly
+struct Wgrad2Args { const float* dZ; const float* X; float* dW; float* db; float scale; int32_t out, in, B; DzSrc z; int32_t* nf; };      // z.W3 != nullptr: dZ points at H (the layer's own output) and the gradient is formed on the fly
 struct Wgrad2Op { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, Wgrad2Args q) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int tI = q.out >> 5; const int bi = (int)bid_ % tI, bk = (int)bid_ / tI; const int I0 = bi << 5, K0 = bk << 5;
@@ -168,12 +168,14 @@ struct Wgrad2Op { static __device__ __forceinline__ void run(const unsigned bid_
   if (quartered) {
 #pragma unroll
     for (int p = 1; p < 4; ++p) { t[0] += acc[p][0]; t[1] += acc[p][1]; t[2] += acc[p][2]; t[3] += acc[p][3]; rowsum += rows[p]; } }
-  if (want_rowsum) { rowsum += __shfl_xor(rowsum, 16, 64); rowsum += __shfl_xor(rowsum, 32, 64); if (g == 0) q.db[I0 + 16 * mtw + c] = q.scale * rowsum; }
+  bool bad = false;
+  if (want_rowsum) { rowsum += __shfl_xor(rowsum, 16, 64); rowsum += __shfl_xor(rowsum, 32, 64); if (g == 0) { const float bv = q.scale * rowsum; q.db[I0 + 16 * mtw + c] = bv; bad = bv != bv; } }
   const int i = I0 + 16 * mtw + 4 * g, kc = K0 + 16 * ntw + c;
   f32x4 o;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = t[r] * q.scale;
+  for (int r = 0; r < 4; ++r) { o[r] = t[r] * q.scale; bad = bad || o[r] != o[r]; }
   *(f32x4*)(q.dW + i + (int64_t)q.out * kc) = o;
+  if (q.nf && bad) atomicOr((int*)q.nf, 1);
 } };
 __global__ __launch_bounds__(256) void k_wgrad2(Wgrad2Args q) { Wgrad2Op::run(blockIdx.x, gridDim.x, q); }
 
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void k_wgrad2(Wgrad2Args q) { Wgrad2Op::run(bl
 // whoever reads the gradient next: Sumsq2Op (sac.hip), which every train! step runs right after the pullback, forms and stores dW1 / db1 from the four partials as it
 // sums the squares. Both operand panels are staged through LDS with row-contiguous 16-byte loads (a lane-per-sample fragment load touches sixteen half-used cache
 // lines per instruction: the texture path, not latency, bounded the first version of this kernel), all issued before the first use.
-struct Dgrad2Args { const float* W2; const float* dZ2; const float* H1; const float* x; float* part; float* dZ1; int32_t in0, out1, out2, B, act0, want_g; DzSrc z; };      // z.W3 != nullptr: dZ2 points at H2 (see Wgrad2Args)
+struct Dgrad2Args { const float* W2; const float* dZ2; const float* H1; const float* x; float* part; float* dZ1; int32_t in0, out1, out2, B, act0, want_g; DzSrc z; int32_t* nf; };      // z.W3 != nullptr: dZ2 points at H2 (see Wgrad2Args)
 #define DF_PART_STRIDE(in0) ((in0) + 4)      // per feature: in0 partial dW entries + 4 partial row sums (lane groups g = 0..3)
 // O3: the widest output layer whose data gradient the instantiation can fold in (DzSrc): 1 (critics, value heads; also "no folding") or 4. Two instantiations because the
 // folded operands live in registers until the panels are written: 16 of them at O3 = 1, 64 at O3 = 4 -- and the register count decides how many workgroups share a CU.
@@ -294,9 +296,11 @@ template <int O3> struct Dgrad2W1OpT { static __device__ __forceinline__ void ru
 #pragma unroll
       for (int r = 0; r < 4; ++r) { pa = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], xf[tq][u][r], pa, 0, 0, 0); if (tq == 0) prow += av[r]; } } }
     const int qc = 16 * tq + c;
+    bool odd = !(fabsf(prow) <= 3.4028234664e38f);                     // a partial that is not finite: the final sum may be NaN (AdamSelfOp then looks at the sums themselves)
     if (qc < q.in0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) prow_out[(int64_t)(F0 + 4 * g + r) * DF_PART_STRIDE(q.in0) + qc] = pa[r]; }
+      for (int r = 0; r < 4; ++r) { prow_out[(int64_t)(F0 + 4 * g + r) * DF_PART_STRIDE(q.in0) + qc] = pa[r]; odd = odd || !(fabsf(pa[r]) <= 3.4028234664e38f); } }
+    if (q.nf && odd) atomicOr((int*)q.nf + 1, 1);
     if (tq == 0) prow_out[(int64_t)(F0 + c) * DF_PART_STRIDE(q.in0) + q.in0 + g] = prow;      // lane (c, g): the partial row sum of feature F0 + c over this quarter's k = 16 u + 4 g + r
   } }
 } };

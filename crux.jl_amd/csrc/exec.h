@@ -17,7 +17,8 @@ enum {
   OP_PER_SEARCH, OP_UNIFORM_IDS, OP_GATHER_RING_ALL, OP_RING_IDS, OP_LEAF_REFRESH, OP_TREE_TOUCH, OP_PER_UPDATE, OP_DQN_TARGET, OP_TD_ERROR, OP_POLYAK, OP_COPY_F32, OP_ADAM_ADVANCE, OP_SOFTQ_TARGET,
   OP_FWD12, OP_WGRAD2, OP_DGRAD2W1,     // dense_fused.h (round 4)
   OP_PER_SAMPLE,                       // per.hip: search + gather of one row per wave (round 4)
-  OP_ACTOR_EXPLORE_TILE, OP_SAC_CRITIC_TILE, OP_CRITIC_INFO2, OP_SAC_ACTOR_TILE, OP_ACTOR_INFO2, OP_CRITIC_DX_TILE, OP_DQN_TD_TILE, OP_TD_INFO2      // sac_fused.h (round 4)
+  OP_ACTOR_EXPLORE_TILE, OP_SAC_CRITIC_TILE, OP_CRITIC_INFO2, OP_SAC_ACTOR_TILE, OP_ACTOR_INFO2, OP_CRITIC_DX_TILE, OP_DQN_TD_TILE, OP_TD_INFO2,     // sac_fused.h (round 4)
+  OP_ADAM_SELF, OP_ADAM_ADVANCE_SELF   // sac.hip: Adam gated on the producers' NaN flags, in the phase of the norm (round 4)
 };
 
 #define CRUX_EXEC_ARG_BYTES 768

@@ -86,6 +86,8 @@ __device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigne
         case OP_POLYAK: DISPATCH<PolyakOp>(op, b); break; \
         case OP_COPY_F32: DISPATCH<CopyF32Op>(op, b); break; \
         case OP_ADAM_ADVANCE: DISPATCH<AdamAdvanceOp>(op, b); break; \
+        case OP_ADAM_SELF: DISPATCH<AdamSelfOp>(op, b); break; \
+        case OP_ADAM_ADVANCE_SELF: DISPATCH<AdamAdvanceSelfOp>(op, b); break; \
         case OP_SOFTQ_TARGET: DISPATCH<SoftqTargetOp>(op, b); break; \
         case OP_PER_SAMPLE: PerSampleGatherOp::run_ptr(b, op->nblocks, (const PerSampleArgs*)op->args); break; \
         case OP_ACTOR_EXPLORE_TILE: DISPATCH<ActorExploreTileOp>(op, b); break; \
@@ -278,7 +280,7 @@ static int32_t dqp_build(ExecRec* r) {        // the replay table; CRUX_EUNSUP w
         case OP_LEAF_REFRESH: if (!head) return CRUX_EUNSUP; Cs.push_back({1, (int)i}); break;
         case OP_TREE_TOUCH: if (!head) return CRUX_EUNSUP; Cs.push_back({2, (int)i}); break;
         case OP_TD_HEAD: head = true; break;
-        case OP_GEMM: case OP_FWD12: case OP_WGRAD2: case OP_DGRAD2W1: case OP_DQN_TARGET: case OP_SUMSQ2: case OP_TD_INFO: case OP_ADAM_GATED: case OP_ADAM_ADVANCE: break;      // the learner kernel's work
+        case OP_GEMM: case OP_FWD12: case OP_WGRAD2: case OP_DGRAD2W1: case OP_DQN_TARGET: case OP_SUMSQ2: case OP_TD_INFO: case OP_ADAM_GATED: case OP_ADAM_ADVANCE: case OP_ADAM_SELF: case OP_ADAM_ADVANCE_SELF: break;      // the learner kernel's work
         default: return CRUX_EUNSUP; } }
     if (!head || A.empty()) return CRUX_EUNSUP;
     auto emit = [&](std::vector<std::pair<int, int>>& v, int slot) {
@@ -544,19 +546,24 @@ static int32_t dqn_epoch_tiles(crux_mlp* net, crux_mlp* tnet, crux_buffer* sourc
                                uint64_t sample_counter, float* info_out, float* d_y, float* d_err) {
   crux_ctx* c = net->ctx; const int64_t B = batch->capacity; const bool per = source->prioritized; const int nout = net->nd.dims[3], K = net->nd.dims[2];
   ExecRec* r = rec_of(c); const int base = r->chain_base; std::vector<int> ph; bool plan_ok = true; int32_t rc;
+  // Phases: 0 uniform ids | 1 search + gather / gather | 2 forward (both nets) | 3 td tile (+ update_priorities!) | 4 pullback (+ leaf re-sum) | 5 norm, Adam (AdamSelfOp), root paths |
+  // 6 info, beta-power advance. Chained: the sampling of epoch e + 1 runs beside the tail of epoch e -- uniform replay: ids | gather beside 4 | 5 (the gather rewrites the batch
+  // rows the pullback read: not before 5), forward beside 6 (after Adam): FOUR launches per epoch; prioritized replay: the search needs this epoch's root paths (5), so it runs
+  // beside 6 and the forward opens a launch of its own: five.
+  const int ov = per ? 2 : 3;
   auto bail = [&](int32_t e) { crux_exec_abort(c); return e; };
   size_t m = exec_mark(c); const size_t ops0 = m; r->epoch_marks.push_back(ops0);
   auto sect = [&](auto&& rule) { for (size_t i = m; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid); if (p < 0) { plan_ok = false; p = 0; }
-      ph.push_back(ph_tag(base > 0 ? base + p - 3 : p, 0)); } m = r->ops.size(); };
+      ph.push_back(ph_tag(base > 0 ? base + p - ov : p, 0)); } m = r->ops.size(); };
   auto only = [&](int p) { sect([p](int) { return p; }); };
   if (use_weight && !has_col(batch, CRUX_COL_WEIGHT)) return bail(crux_fail(c, CRUX_EINVAL, "td_loss(weight=:weight): batch has no :weight column"));
   rc = per ? crux_per_sample(batch, source, B, nullptr, beta, sample_counter) : crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
   sect([](int kid) { return kid == OP_UNIFORM_IDS ? 0 : (kid == OP_PER_SAMPLE || kid == OP_GATHER_RING_ALL || kid == OP_RING_IDS || kid == OP_COPY_F32) ? 1 : kid == OP_PER_UPDATE ? 2 : -1; });
   Carve cv{(char*)crux_scratch(c, 4 * (size_t)B * (nout + 2) + 8192), 0}; if (!cv.p) return bail(crux_fail(c, CRUX_ENOMEM, "dqn_epoch: scratch"));
   float* dy = cv.take<float>((size_t)B * nout); float* term = cv.take<float>((size_t)B); float* qsel = cv.take<float>((size_t)B);
-  Carve sv{(char*)crux_exec_small(c, 256 * 5), 0}; if (!sv.p) return bail(crux_fail(c, CRUX_ENOMEM, "dqn_epoch: executor region"));
-  float* dinfo = sv.take<float>(CRUX_INFO_N); double* ssq = sv.take<double>(2 + SUMSQ_BLOCKS); int32_t* status = sv.take<int32_t>(1);
-  rc = crux_exec_zero(c, dinfo, 256 * 5, c->stream); if (rc) return bail(rc);
+  Carve sv{(char*)crux_exec_small(c, 256 * 6), 0}; if (!sv.p) return bail(crux_fail(c, CRUX_ENOMEM, "dqn_epoch: executor region"));
+  float* dinfo = sv.take<float>(CRUX_INFO_N); double* ssq = sv.take<double>(2 + SUMSQ_BLOCKS); int32_t* status = sv.take<int32_t>(1); int32_t* nanf = sv.take<int32_t>(2);
+  rc = crux_exec_zero(c, dinfo, 256 * 6, c->stream); if (rc) return bail(rc);
   only(1);
   const float* S = (const float*)batch->col[CRUX_COL_S]; const float* SP = (const float*)batch->col[CRUX_COL_SP];
   rc = crux_dense_forward12(net, S, B, c->stream); if (!rc) rc = crux_dense_forward12(tnet, SP, B, c->stream); if (rc) return bail(rc);
@@ -569,18 +576,19 @@ static int32_t dqn_epoch_tiles(crux_mlp* net, crux_mlp* tnet, crux_buffer* sourc
     crux_exec_push<DqnTdTileOp, OP_DQN_TD_TILE>(c, (unsigned)((B + 15) / 16), a); }
   only(3);
   Sumsq2Fix fx{};
-  rc = crux_dense_backward(net, S, B, dy, 1.0f, true, nullptr, c->stream, &fx, 0); if (rc) return bail(rc);
+  rc = crux_dense_backward(net, S, B, dy, 1.0f, true, nullptr, c->stream, &fx, 0, nanf); if (rc) return bail(rc);
   only(4);
   if (per) { rc = crux_per_touched(source, batch->d_indices, B, false); if (rc) return bail(rc);
     sect([](int kid) { return kid == OP_LEAF_REFRESH ? 4 : kid == OP_TREE_TOUCH ? 5 : -1; }); }
+  // 5: the norm (for the info row) and, beside it, Adam gated on the producers' NaN flags (AdamSelfOp, sac.hip) | 6: info, beta-power advance
   CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, net->g, (int64_t)net->nd.n_params, (float*)nullptr, (int64_t)0, ssq, fx);
-  only(5);
+  rc = adam_self(net, nanf, status, fx, 0); if (rc) return bail(rc);
+  sect([](int kid) { return kid == OP_ADAM_ADVANCE_SELF ? 6 : 5; });
   crux_exec_push<TdInfo2Op, OP_TD_INFO2>(c, 1u, (const float*)term, (const float*)qsel, (const double*)ssq, B, dinfo);
-  rc = adam_gated(net, ssq, status); if (rc) return bail(rc);
-  sect([](int kid) { return kid == OP_ADAM_ADVANCE ? 7 : 6; });
+  only(6);
   crux_exec_add_readback(c, info_out, dinfo, status, "td_loss");
   if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-  r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 8 - (r->chain_base > 0 ? 3 : 0);
+  r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 7 - (r->chain_base > 0 ? ov : 0);
   return CRUX_OK;
 }
 
@@ -735,11 +743,12 @@ static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer*
     rec_of(c)->chain = true;
     rc = dqn_epoch_impl(net, target_net, source, batch, gamma, softq_alpha, use_weight, beta, sample_counter0 + (uint64_t)e, info_e);
     if (rc) { if (c->rec) rec_of(c)->chain = false; crux_exec_abort(c); return rc; }
+    const bool tiles = dqn_tile_case(net, target_net, source, batch) && !getenv("CRUX_NO_FUSED_EPOCH");
     if (d_infos_async) {      // the epoch's info row goes to the caller's device array, copied in the epoch's last phase (one phase after the info op wrote it)
       ExecRec* r = rec_of(c);
       crux_exec_push<CopyF32Op, OP_COPY_F32>(c, 1u, d_infos_async + (size_t)e * CRUX_INFO_N, (const float*)r->readbacks.back().d_info, (int64_t)CRUX_INFO_N);
       int tmax = 0; for (size_t k = r->epoch_marks.empty() ? 0 : r->epoch_marks.back(); k < r->chain_tags.size(); ++k) tmax = std::max(tmax, r->chain_tags[k] & ~3);      // the epoch's last phase (the beta-power advance)
-      r->chain_tags.push_back(tmax); }
+      r->chain_tags.push_back(tmax + (tiles ? 4 : 0)); }      // (tile plan: the info op sits IN the epoch's last phase -- the copy joins the launch after it)
     ++in_chain;
   }
   return fuse ? flush() : rc;
@@ -819,11 +828,11 @@ static int32_t sac_epoch_tiles(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux
   float* dy1 = cv.take<float>((size_t)B); float* dy2 = cv.take<float>((size_t)B); float* t1 = cv.take<float>((size_t)B); float* t2 = cv.take<float>((size_t)B);
   float* da1 = cv.take<float>((size_t)B); float* da2 = cv.take<float>((size_t)B); float* ta = cv.take<float>((size_t)B); float* dmu = cv.take<float>((size_t)B * ad); float* dls = cv.take<float>((size_t)B * ad);
   // info rows / statistics / status words of the three steps
-  Carve st_{(char*)crux_exec_small(c, 256 * 5), 0}, sc_{(char*)crux_exec_small(c, 256 * 5), 0}, sa_{(char*)crux_exec_small(c, 256 * 5), 0};
+  Carve st_{(char*)crux_exec_small(c, 256 * 5), 0}, sc_{(char*)crux_exec_small(c, 256 * 6), 0}, sa_{(char*)crux_exec_small(c, 256 * 6), 0};
   if (!st_.p || !sc_.p || !sa_.p) return bail(crux_fail(c, CRUX_ENOMEM, "sac_epoch: executor region"));
   float* it = st_.take<float>(CRUX_INFO_N); double* ssq_t = st_.take<double>(2 + SUMSQ_BLOCKS); int32_t* stt = st_.take<int32_t>(1);
-  float* ic = sc_.take<float>(CRUX_INFO_N); double* ssq_c = sc_.take<double>(2 + SUMSQ_BLOCKS); int32_t* stc = sc_.take<int32_t>(1);
-  float* ia = sa_.take<float>(CRUX_INFO_N); double* ssq_a = sa_.take<double>(2 + SUMSQ_BLOCKS); int32_t* sta = sa_.take<int32_t>(1);
+  float* ic = sc_.take<float>(CRUX_INFO_N); double* ssq_c = sc_.take<double>(2 + SUMSQ_BLOCKS); int32_t* stc = sc_.take<int32_t>(1); int32_t* nfc = sc_.take<int32_t>(2);
+  float* ia = sa_.take<float>(CRUX_INFO_N); double* ssq_a = sa_.take<double>(2 + SUMSQ_BLOCKS); int32_t* sta = sa_.take<int32_t>(1); int32_t* nfa = sa_.take<int32_t>(2);
   const float* S = (const float*)batch->col[CRUX_COL_S]; const float* SP = (const float*)batch->col[CRUX_COL_SP];
   const float* ls = actor->p + actor->nd.xoff; const float* w = use_weight ? (const float*)batch->col[CRUX_COL_WEIGHT] : nullptr;
   auto l3 = [&](crux_mlp* n, bool store) { const NetDesc& nd = n->nd; return TileSet{n->p + nd.woff[2], n->p + nd.boff[2], crux_dense_act(n, 2), store ? crux_dense_act(n, 3) : nullptr}; };
@@ -832,7 +841,7 @@ static int32_t sac_epoch_tiles(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux
   rc = crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
   sect([](int kid) { return kid == OP_UNIFORM_IDS ? 0 : kid == OP_GATHER_RING_ALL ? 1 : -1; });
   rc = check_sac(c, actor, q1, q2, la, batch, "sac_epoch"); if (rc) return bail(rc);
-  rc = crux_exec_zero(c, it, 256 * 5, c->stream); if (!rc) rc = crux_exec_zero(c, ic, 256 * 5, c->stream); if (!rc) rc = crux_exec_zero(c, ia, 256 * 5, c->stream);
+  rc = crux_exec_zero(c, it, 256 * 5, c->stream); if (!rc) rc = crux_exec_zero(c, ic, 256 * 6, c->stream); if (!rc) rc = crux_exec_zero(c, ia, 256 * 6, c->stream);
   if (!rc) rc = crux_exec_zero(c, la->g, sizeof(float) * (size_t)la->nd.n_params, c->stream); if (rc) return bail(rc);
   only(1);
   // 2
@@ -857,53 +866,50 @@ static int32_t sac_epoch_tiles(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux
   only(5);
   // 6
   Sumsq2Fix fxc{}, fxa{};
-  rc = crux_dense_backward(q1, sa_c, B, dy1, 1.0f, true, nullptr, c->stream, &fxc, 0); if (!rc) rc = crux_dense_backward(q2, sa_c, B, dy2, 1.0f, true, nullptr, c->stream, &fxc, 1); if (rc) return bail(rc);
+  rc = crux_dense_backward(q1, sa_c, B, dy1, 1.0f, true, nullptr, c->stream, &fxc, 0, nfc); if (!rc) rc = crux_dense_backward(q2, sa_c, B, dy2, 1.0f, true, nullptr, c->stream, &fxc, 1, nfc); if (rc) return bail(rc);
   CRUX_RUN(c, TempHeadOp, OP_TEMP_HEAD, k_temp_head, 1, 256, c->stream, (const float*)lp_temp, B, H_target, (const float*)la->p, la->g, it, ssq_t);
   only(6);
-  // 7 (+ 8: the advance of log alpha's beta powers)
+  // 7: the critics' norm (for the info row) and, beside it, their Adam steps gated on the pullback's NaN flags (AdamSelfOp, sac.hip); log alpha's step (+ 8: the advances)
   CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, q1->g, (int64_t)q1->nd.n_params, q2->g, (int64_t)q2->nd.n_params, ssq_c, fxc);
-  rc = adam_gated(la, ssq_t, stt, false); if (rc) return bail(rc);
-  sect([](int kid) { return kid == OP_ADAM_ADVANCE ? 8 : 7; });
-  // 8 (+ 9: the critics' advances)
+  rc = adam_self(q1, nfc, stc, fxc, 0); if (!rc) rc = adam_self(q2, nfc, stc, fxc, 1); if (!rc) rc = adam_gated(la, ssq_t, stt, false); if (rc) return bail(rc);
+  sect([](int kid) { return (kid == OP_ADAM_ADVANCE || kid == OP_ADAM_ADVANCE_SELF) ? 8 : 7; });
+  // 8: critic info | the updated critics' first two layers on (s, a ~ pi)
   crux_exec_push<CriticInfo2Op, OP_CRITIC_INFO2>(c, 1u, (const float*)t1, (const float*)crux_dense_act(q1, 3), (const float*)t2, (const float*)crux_dense_act(q2, 3), (const double*)ssq_c, B, ic);
-  rc = adam_gated(q1, ssq_c, stc); if (!rc) rc = adam_gated(q2, ssq_c, stc); if (rc) return bail(rc);
-  sect([](int kid) { return kid == OP_ADAM_ADVANCE ? 9 : 8; });
-  // 9
   rc = crux_dense_forward12(q1, sa_a, B, c->stream); if (!rc) rc = crux_dense_forward12(q2, sa_a, B, c->stream); if (rc) return bail(rc);
-  only(9);
-  // 10
+  only(8);
+  // 9
   { SacActorArgs a{}; a.q1 = l3(q1, true); a.q2 = l3(q2, true); a.lp = lp_a; a.log_alpha = la->p; a.K = K; a.B = (int32_t)B; a.dy1 = da1; a.dy2 = da2; a.term = ta;
     crux_exec_push<SacActorTileOp, OP_SAC_ACTOR_TILE>(c, nt, a); }
-  only(10);
-  // 11
+  only(9);
+  // 10
   const float* dz1a = nullptr; const float* dz1b = nullptr;
   rc = crux_dense_dgrad_to_dz1(q1, sa_a, B, da1, &dz1a, c->stream); if (!rc) rc = crux_dense_dgrad_to_dz1(q2, sa_a, B, da2, &dz1b, c->stream); if (rc) return bail(rc);
-  only(11);
-  // 12
+  only(10);
+  // 11
   { CriticDxArgs a{}; a.c1 = TileSet{q1->p + q1->nd.woff[0], nullptr, dz1a, nullptr}; a.c2 = TileSet{q2->p + q2->nd.woff[0], nullptr, dz1b, nullptr};
     a.sa = sa_a; a.mu = crux_dense_act(actor, 3); a.eps = eps; a.ls = ls; a.log_alpha = la->p; a.od = od; a.ad = ad; a.K = q1->nd.dims[1]; a.B = (int32_t)B; a.dmu = dmu; a.dls = dls;
     crux_exec_push<CriticDxActorGradTileOp, OP_CRITIC_DX_TILE>(c, nt, a); }
+  only(11);
+  // 12
+  rc = crux_dense_backward(actor, S, B, dmu, 1.0f, true, nullptr, c->stream, &fxa, 0, nfa); if (rc) return bail(rc);
+  CRUX_RUN(c, RowsumOp, OP_ROWSUM, k_rowsum, ad, 256, c->stream, (const float*)dls, ad, B, actor->g + actor->nd.xoff, nfa);
   only(12);
-  // 13
-  rc = crux_dense_backward(actor, S, B, dmu, 1.0f, true, nullptr, c->stream, &fxa, 0); if (rc) return bail(rc);
-  CRUX_RUN(c, RowsumOp, OP_ROWSUM, k_rowsum, ad, 256, c->stream, (const float*)dls, ad, B, actor->g + actor->nd.xoff);
-  only(13);
-  // 14
+  // 13: the actor's norm | its Adam step (self-gated)
   CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, actor->g, (int64_t)actor->nd.n_params, (float*)nullptr, (int64_t)0, ssq_a, fxa);
-  only(14);
-  // 15 (+ 16)
+  rc = adam_self(actor, nfa, sta, fxa, 0); if (rc) return bail(rc);
+  sect([](int kid) { return kid == OP_ADAM_ADVANCE_SELF ? 14 : 13; });
+  // 14: actor info, polyak
   crux_exec_push<ActorInfo2Op, OP_ACTOR_INFO2>(c, 1u, (const float*)ta, (const float*)lp_a, (const double*)ssq_a, B, ia);
-  rc = adam_gated(actor, ssq_a, sta); if (rc) return bail(rc);
-  sect([](int kid) { return kid == OP_ADAM_ADVANCE ? 16 : 15; });
   if (actor_targ) { rc = crux_polyak(actor_targ, actor, tau); if (rc) return bail(rc); }
   rc = crux_polyak(q1t, q1, tau); if (!rc) rc = crux_polyak(q2t, q2, tau); if (rc) return bail(rc);
-  only(16);
+  only(14);
   // the steps' read-backs in the order they ran (temperature, critics, actor), as the generic recording registers them
   crux_exec_add_readback(c, info_temp, it, stt, "sac_temp_loss"); crux_exec_add_readback(c, info_critic, ic, stc, "double_Q_loss"); crux_exec_add_readback(c, info_actor, ia, sta, "sac_actor_loss");
-  // phases 0 / 1 of a chained epoch overlap the previous epoch's norm / info + Adam, phase 2 its advance + polyak: base + p - 3 for every p (see crux_sac_epoch)
+  // phases 0 / 1 of a chained epoch (ids | gather, fills) overlap the previous epoch's actor pullback (12: the gather rewrites the batch rows it read -- not before 13) and
+  // norm + Adam (13), phase 2 (the new actor's forward on s') its info + advance + polyak (14): base + p - 3 for every p. 15 phases, 12 launches per chained epoch.
   if (r->chain) {
     if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 17 - (r->chain_base > 0 ? 3 : 0);
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 15 - (r->chain_base > 0 ? 3 : 0);
     return CRUX_OK;
   }
   if (plan_ok && ph.size() == r->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
@@ -1028,6 +1034,7 @@ static int32_t sac_epochs_impl(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux
     rc = crux_sac_epoch(actor, q1, q2, actor_targ, q1_targ, q2_targ, log_alpha, source, batch, gamma, H_target, tau, use_weight, uc, ua,
                         sample_counter0 + (uint64_t)e, noise_seed, noise_counter0 + 3ull * (uint64_t)e, it, ic, ia);
     if (rc) { if (fuse && c->rec) { rec_of(c)->chain = false; crux_exec_abort(c); } return rc; }
+    const bool tiles = fuse && sac_tile_case(actor, q1, q2, q1_targ, q2_targ, source, batch, uc, ua);
     if (d_infos_async) {      // the epoch's info rows (temperature, [critics], [actor] -- the order the steps ran in) go to rows 3 e .. 3 e + 2 of the caller's device array, copied in the epoch's last phase
       ExecRec* r = rec_of(c);
       if (r->readbacks.size() != rb0 + 1 + (uc ? 1 : 0) + (ua ? 1 : 0) || r->chain_tags.size() != r->ops.size()) { r->chain = false; crux_exec_abort(c); return crux_fail(c, CRUX_EHIP, "sac epochs (async): unexpected recording"); }
@@ -1035,7 +1042,7 @@ static int32_t sac_epochs_impl(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux
       size_t q = rb0; const int slot_of[3] = {0, uc ? 1 : -1, ua ? 2 : -1};
       for (int sl = 0; sl < 3; ++sl) { if (slot_of[sl] < 0) continue;
         crux_exec_push<CopyF32Op, OP_COPY_F32>(c, 1u, d_infos_async + ((size_t)e * 3 + sl) * CRUX_INFO_N, (const float*)r->readbacks[q++].d_info, (int64_t)CRUX_INFO_N);
-        r->chain_tags.push_back(tmax); } }
+        r->chain_tags.push_back(tmax + (tiles ? 4 : 0)); } }      // (tile plans: the actor's info op sits IN the epoch's last phase -- the copy joins the launch after it, the next epoch's third)
     if (fuse) ++in_chain;
   }
   return fuse ? flush() : rc;

@@ -198,16 +198,16 @@ struct ActorGradOp { static __device__ __forceinline__ void run(const unsigned b
 __global__ void k_actor_grad(const float* __restrict__ sa, const float* __restrict__ mu, const float* __restrict__ eps, const float* __restrict__ ls,
                              const float* __restrict__ dsa1, const float* __restrict__ dsa2, const float* __restrict__ log_alpha, int od, int ad, int64_t B,
                              float* __restrict__ dmu, float* __restrict__ dls) { ActorGradOp::run(blockIdx.x, gridDim.x, sa, mu, eps, ls, dsa1, dsa2, log_alpha, od, ad, B, dmu, dls); }
-struct RowsumOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ v, int ad, int64_t B, float* __restrict__ out) {   // out[d] = sum_j v[d + ad*j]; one block per d, fixed-order combine
+struct RowsumOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ v, int ad, int64_t B, float* __restrict__ out, int32_t* __restrict__ nf = nullptr) {   // out[d] = sum_j v[d + ad*j]; one block per d, fixed-order combine
   __shared__ float red[4];
   const int d = bid_; float acc = 0.f;
   for (int64_t j = threadIdx.x; j < B; j += 256) acc += v[d + (int64_t)ad * j];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) out[d] = ((red[0] + red[1]) + red[2]) + red[3];
+  if (threadIdx.x == 0) { const float r_ = ((red[0] + red[1]) + red[2]) + red[3]; out[d] = r_; if (nf && r_ != r_) atomicOr((int*)nf, 1); }
 } };
-__global__ __launch_bounds__(256) void k_rowsum(const float* __restrict__ v, int ad, int64_t B, float* __restrict__ out) { RowsumOp::run(blockIdx.x, gridDim.x, v, ad, B, out); }
+__global__ __launch_bounds__(256) void k_rowsum(const float* __restrict__ v, int ad, int64_t B, float* __restrict__ out, int32_t* __restrict__ nf) { RowsumOp::run(blockIdx.x, gridDim.x, v, ad, B, out, nf); }
 struct ActorInfoOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const double* __restrict__ st, const double* __restrict__ ssq, int64_t B, float* __restrict__ dinfo) { if (threadIdx.x != 0) return;
   ssq_finalize(ssq);
   dinfo[CRUX_INFO_LOSS] = (float)(st[0] / (double)B); dinfo[CRUX_INFO_ENTROPY] = (float)(-(st[1] / (double)B)); dinfo[CRUX_INFO_GRAD_NORM] = (float)sqrt(ssq[0]);
@@ -244,6 +244,56 @@ __global__ __launch_bounds__(256) void k_adam_gated(float* __restrict__ p, const
 struct AdamAdvanceOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, double* __restrict__ bp, double b1, double b2, const double* __restrict__ ssq) {
   if (bid_ == 0 && threadIdx.x == 0 && !isnan(ssq[0])) { bp[0] *= b1; bp[1] *= b2; }      // ssq[0] was written by the info op one phase earlier
 } };
+
+// ---- the self-gated form (round 4, the tile plans of exec.hip): Adam in the SAME phase as the norm ------------------------------------------------------------------
+// training.jl:20 skips the update when the gradient norm is NaN -- exactly when a gradient element is NaN (the norm is a Float64 sum of squares: no overflow, no
+// cancellation). The producers of the gradient raise flags[0] when a value they store is NaN (Gemm16's EPI_WGRAD epilogue, Wgrad2Op, RowsumOp) and flags[1] when a deferred
+// layer-0 partial is not finite (Dgrad2W1Op: the final sum of four partials may then be NaN -- Inf - Inf -- without any partial being NaN). AdamSelfOp gates on flags[0] and,
+// in the flags[1] case only, on the deferred sums themselves, which every block then forms and inspects; so the update needs no reduced norm and can run beside Sumsq2Op
+// (which still forms the norm for the info row) instead of one dependent launch after it. Deferred layer-0 entries are formed here as Sumsq2Op forms them (ssq_elem: the same
+// additions; both store the same value).
+__device__ __forceinline__ bool adam_self_bad(const int32_t* __restrict__ flags, const Sumsq2Fix& fx, int slot) {
+  bool bad = flags[0] != 0;
+  if (flags[1] != 0 && fx.part[slot]) {      // rare: look at the sums
+    const int out1 = fx.out1[slot], in0 = fx.in0[slot], ps = in0 + 4; const int64_t qs = (int64_t)out1 * ps; const float* part = fx.part[slot]; bool b_ = false;
+    for (int64_t e = threadIdx.x; e < (int64_t)out1 * in0; e += blockDim.x) { const int f = (int)(e % out1), qc = (int)(e / out1); const float* p = part + (int64_t)f * ps + qc;
+      const float v = (((p[0] + p[qs]) + p[2 * qs]) + p[3 * qs]) * fx.scale[slot]; b_ = b_ || v != v; }
+    for (int f = threadIdx.x; f < out1; f += blockDim.x) { const float* p = part + (int64_t)f * ps + in0; float R[4];
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) R[gg] = ((p[gg] + p[qs + gg]) + p[2 * qs + gg]) + p[3 * qs + gg];
+      const float v = fx.scale[slot] * ((R[0] + R[1]) + (R[2] + R[3])); b_ = b_ || v != v; }
+    bad = __syncthreads_or(b_ ? 1 : 0) != 0 || bad;
+  }
+  return bad;
+}
+struct AdamSelfOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, const double* __restrict__ bp,
+                                                   double eta, double b1, double b2, double eps, int64_t n, const int32_t* __restrict__ flags, int32_t* __restrict__ status, Sumsq2Fix fx, int slot) {
+  const bool bad = adam_self_bad(flags, fx, slot);
+  if (status[0] == CRUX_ENAN) return;      // an earlier step of this launch sequence already stopped with "NaN detected!" (training.jl:20)
+  if (bad) { if (bid_ == 0 && threadIdx.x == 0) status[0] = CRUX_ENAN; return; }
+  const double c1 = 1.0 - bp[0], c2 = 1.0 - bp[1];
+  for (int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x; i < n; i += (int64_t)nb_ * blockDim.x) {
+    const double gd = (double)ssq_elem(g, i, fx, slot);
+    const float mi = (float)(b1 * (double)m[i] + (1.0 - b1) * gd);
+    const float vi = (float)(b2 * (double)v[i] + ((1.0 - b2) * gd) * gd);
+    const float d = (float)((double)mi / c1 / (sqrt((double)vi / c2) + eps) * eta);
+    m[i] = mi; v[i] = vi; p[i] = p[i] - d;
+  }
+} };
+// the beta powers advance one phase later (every block of AdamSelfOp has used them), on the same evidence
+struct AdamAdvanceSelfOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, double* __restrict__ bp, double b1, double b2, const int32_t* __restrict__ flags, Sumsq2Fix fx, int slot) {
+  const bool bad = adam_self_bad(flags, fx, slot);
+  if (bid_ == 0 && threadIdx.x == 0 && !bad) { bp[0] *= b1; bp[1] *= b2; }
+} };
+static int32_t adam_self(crux_mlp* n, const int32_t* d_flags, int32_t* d_status, const Sumsq2Fix& fx, int slot) {      // recorded sequences only
+  crux_ctx* c = n->ctx;
+  if (!n->has_adam) return crux_fail(c, CRUX_EINVAL, "train!: crux_adam_init was not called on this handle");
+  if (!crux_exec_recording(c)) return crux_fail(c, CRUX_EHIP, "adam_self: outside a recording");
+  const int64_t cnt = n->nd.n_params; const unsigned nbk = (unsigned)((cnt + 255) / 256);
+  crux_exec_push<AdamSelfOp, OP_ADAM_SELF>(c, nbk < 64u ? nbk : 64u, n->p, n->g, n->m, n->v, (const double*)n->bp, n->eta, n->b1, n->b2, n->eps, cnt, d_flags, d_status, fx, slot);
+  crux_exec_push<AdamAdvanceSelfOp, OP_ADAM_ADVANCE_SELF>(c, 1u, n->bp, n->b1, n->b2, d_flags, fx, slot);
+  return CRUX_OK;
+}
 
 #include "sac_fused.h"
 
@@ -523,7 +573,7 @@ int32_t crux_sac_actor_step(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_ml
   CRUX_RUN(c, ActorGradOp, OP_ACTOR_GRAD, k_actor_grad, nblk(B * ad), 256, c->stream, sa, mu, eps, actor->p + actor->nd.xoff, dsa1, dsa2, la->p, od, ad, B, dmu, dls);
   Sumsq2Fix fx{};
   rc = crux_dense_backward(actor, S, B, dmu, 1.0f, true, nullptr, c->stream, &fx, 0); if (rc) return rc;
-  CRUX_RUN(c, RowsumOp, OP_ROWSUM, k_rowsum, ad, 256, c->stream, dls, ad, B, actor->g + actor->nd.xoff);
+  CRUX_RUN(c, RowsumOp, OP_ROWSUM, k_rowsum, ad, 256, c->stream, dls, ad, B, actor->g + actor->nd.xoff, (int32_t*)nullptr);
   CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, actor->g, (int64_t)actor->nd.n_params, (float*)nullptr, (int64_t)0, ssq, fx);
   CRUX_RUN(c, ActorInfoOp, OP_ACTOR_INFO, k_actor_info, 1, 1, c->stream, stats, ssq, B, dinfo);
   rc = adam_gated(actor, ssq, st); if (rc) return rc;

@@ -175,3 +175,26 @@ def test_relu_critic_free_running_4096_steps_statistics(gpu_ctx):
 
 
 RELU_CRITIC_LOSS_TOL, RELU_CRITIC_GNORM_TOL = 2e-3, 0.15      # measured x 10: per-epoch loss within 1.8e-4 relative, gradient norm of the epoch's last minibatch within 1.5e-2 (profiles/r04_parity_measurements.txt); the generic bound of tests/parity.py is 2 %
+
+
+@pytest.mark.parametrize("prioritized", [True, False])
+def test_chained_tile_epochs_report_nan_and_update_nothing(gpu_ctx, prioritized):
+    """training.jl:20 in the chained C3 epochs (exec.hip dqn_epoch_tiles): there Adam runs BESIDE the norm, gated on the NaN flags the pullback's kernels raise (AdamSelfOp, sac.hip).
+    NaN rewards -> NaN targets -> NaN gradients: the call reports CRUX_ENAN, parameters, Adam moments and beta powers are untouched."""
+    ctx, rng = gpu_ctx, np.random.default_rng(4); N, B = 4096, 128
+    S, A = crux.ContinuousSpace(8), crux.DiscreteSpace(4)
+    buf = crux.ExperienceBuffer(S, A, N, prioritized=prioritized, ctx=ctx); D = crux.buffer_like(buf, capacity=B)
+    a = np.zeros((4, N), bool); a[rng.integers(0, 4, N), np.arange(N)] = True
+    buf.push_({"s": rng.normal(0, 1, (8, N)).astype(np.float32), "a": a, "sp": rng.normal(0, 1, (8, N)).astype(np.float32), "r": np.full((1, N), np.nan, np.float32),
+               "done": np.zeros((1, N), bool), "episode_end": np.zeros((1, N), bool)})
+    if prioritized:
+        buf.update_priorities_(np.arange(1, N + 1), (np.abs(rng.normal(0, 1, N)) + 1e-3).astype(np.float32))
+    q = crux.DiscreteNetwork(parity.chain([8, 256, 256, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=5, ctx=ctx)
+    qm = crux.clone_policy(q); q.attach_optimizer(crux.Adam(np.float32(1e-3)))
+    before = q.get_params(); infos = np.zeros((4, L.INFO_N), np.float32)
+    with pytest.raises(crux.CruxError) as e:
+        ctx.check(ctx.lib.crux_dqn_epochs(q.h, qm.h, buf.h, D.h, 0.99, 1 if prioritized else 0, 0.6, 40, 4, infos.ctypes.data_as(L.vp)))
+    assert e.value.code == L.ENAN
+    assert np.array_equal(q.get_params(), before)
+    m, v, bp = q.adam_state()
+    assert not m.any() and not v.any() and np.allclose(bp, [0.9, 0.999])

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/pmc
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --replicas 0 --replicas-wide 0 --no-extra $BENCH_ARGS"   # BENCH_ARGS="--workload c5": the C5 shard
+CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --replicas 0 --replicas-wide 0 --no-extra --no-measure-traffic --no-early-stop $BENCH_ARGS"   # BENCH_ARGS="--workload c5": the C5 shard
 i=0
 for set in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \

@@ -2,7 +2,7 @@
 # HBM-side traffic of the learner kernels: FETCH_SIZE and WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md, HBM section).
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out/pmc_traffic; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --replicas 0 --replicas-wide 0 --no-extra $BENCH_ARGS"   # BENCH_ARGS="--workload c5": the C5 shard
+CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --replicas 0 --replicas-wide 0 --no-extra --no-measure-traffic --no-early-stop $BENCH_ARGS"   # BENCH_ARGS="--workload c5": the C5 shard
 for c in FETCH_SIZE WRITE_SIZE; do timeout 400 rocprofv3 --pmc $c --output-format csv -d $OUT/$c -o p -- $CMD > $OUT/$c.log 2>&1; done
 python - <<PY
 import csv, glob, collections
