@@ -63,7 +63,7 @@ static void launch_copy_rows(crux_ctx* c, void* dst, const int64_t* d_dst_idx, c
 }
 
 extern "C" int32_t crux_buffer_indices(const crux_buffer* cb, int64_t* out, int64_t n);
-int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool from_push);   // per.hip: priorities of these elements changed
+int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool from_push, unsigned* ticket = nullptr);   // per.hip: priorities of these elements changed
 // exported to other translation units ------------------------------------------------------------------
 int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I) {
   I.resize((size_t)N);

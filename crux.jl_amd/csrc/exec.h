@@ -18,6 +18,7 @@ enum {
   OP_FWD12, OP_WGRAD2, OP_DGRAD2W1,     // dense_fused.h (round 4)
   OP_PER_SAMPLE,                       // per.hip: search + gather of one row per wave (round 4)
   OP_ACTOR_EXPLORE_TILE, OP_SAC_CRITIC_TILE, OP_CRITIC_INFO2, OP_SAC_ACTOR_TILE, OP_ACTOR_INFO2, OP_CRITIC_DX_TILE, OP_DQN_TD_TILE, OP_TD_INFO2,     // sac_fused.h (round 4)
+  OP_LEAF_TOUCH,                       // per.hip: leaf re-sum + root paths in one launch (round 4)
   OP_ADAM_SELF, OP_ADAM_ADVANCE_SELF   // sac.hip: Adam gated on the producers' NaN flags, in the phase of the norm (round 4)
 };
 

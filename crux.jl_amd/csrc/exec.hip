@@ -80,6 +80,7 @@ __device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigne
         case OP_RING_IDS: DISPATCH<RingIdsOp>(op, b); break; \
         case OP_LEAF_REFRESH: DISPATCH<LeafRefreshOp>(op, b); break; \
         case OP_TREE_TOUCH: DISPATCH<TreeTouchOp>(op, b); break; \
+        case OP_LEAF_TOUCH: DISPATCH<LeafTouchOp>(op, b); break; \
         case OP_PER_UPDATE: DISPATCH<PerUpdateOp>(op, b); break; \
         case OP_DQN_TARGET: DISPATCH<DqnTargetOp>(op, b); break; \
         case OP_TD_ERROR: DISPATCH<TdErrorOp>(op, b); break; \
@@ -546,11 +547,11 @@ static int32_t dqn_epoch_tiles(crux_mlp* net, crux_mlp* tnet, crux_buffer* sourc
                                uint64_t sample_counter, float* info_out, float* d_y, float* d_err) {
   crux_ctx* c = net->ctx; const int64_t B = batch->capacity; const bool per = source->prioritized; const int nout = net->nd.dims[3], K = net->nd.dims[2];
   ExecRec* r = rec_of(c); const int base = r->chain_base; std::vector<int> ph; bool plan_ok = true; int32_t rc;
-  // Phases: 0 uniform ids | 1 search + gather / gather | 2 forward (both nets) | 3 td tile (+ update_priorities!) | 4 pullback (+ leaf re-sum) | 5 norm, Adam (AdamSelfOp), root paths |
-  // 6 info, beta-power advance. Chained: the sampling of epoch e + 1 runs beside the tail of epoch e -- uniform replay: ids | gather beside 4 | 5 (the gather rewrites the batch
-  // rows the pullback read: not before 5), forward beside 6 (after Adam): FOUR launches per epoch; prioritized replay: the search needs this epoch's root paths (5), so it runs
-  // beside 6 and the forward opens a launch of its own: five.
-  const int ov = per ? 2 : 3;
+  // Phases: 0 uniform ids | 1 search + gather / gather | 2 forward (both nets) | 3 td tile (+ update_priorities!) | 4 pullback || leaf re-sum -> root paths (LeafTouchOp) |
+  // 5 norm || Adam (AdamSelfOp) | 6 info, beta-power advance. Chained: the sampling of epoch e + 1 runs beside the tail of epoch e -- ids beside 4, search + gather beside 5 (the
+  // replay tree is complete after 4; the gather rewrites the batch rows the pullback read: not before 5), forward beside 6 (after Adam): FOUR launches per epoch.
+  const bool touch_split = per && (B > 256 || source->per_full_dirty);      // (root paths as an op of their own in 5: the search then waits one launch longer)
+  const int ov = touch_split ? 2 : 3;
   auto bail = [&](int32_t e) { crux_exec_abort(c); return e; };
   size_t m = exec_mark(c); const size_t ops0 = m; r->epoch_marks.push_back(ops0);
   auto sect = [&](auto&& rule) { for (size_t i = m; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid); if (p < 0) { plan_ok = false; p = 0; }
@@ -578,8 +579,8 @@ static int32_t dqn_epoch_tiles(crux_mlp* net, crux_mlp* tnet, crux_buffer* sourc
   Sumsq2Fix fx{};
   rc = crux_dense_backward(net, S, B, dy, 1.0f, true, nullptr, c->stream, &fx, 0, nanf); if (rc) return bail(rc);
   only(4);
-  if (per) { rc = crux_per_touched(source, batch->d_indices, B, false); if (rc) return bail(rc);
-    sect([](int kid) { return kid == OP_LEAF_REFRESH ? 4 : kid == OP_TREE_TOUCH ? 5 : -1; }); }
+  if (per) { rc = crux_per_touched(source, batch->d_indices, B, false, (unsigned*)(nanf + 2)); if (rc) return bail(rc);      // leaves + root paths as one op beside the pullback (LeafTouchOp)
+    sect([](int kid) { return (kid == OP_LEAF_TOUCH || kid == OP_LEAF_REFRESH) ? 4 : kid == OP_TREE_TOUCH ? 5 : -1; }); }
   // 5: the norm (for the info row) and, beside it, Adam gated on the producers' NaN flags (AdamSelfOp, sac.hip) | 6: info, beta-power advance
   CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, net->g, (int64_t)net->nd.n_params, (float*)nullptr, (int64_t)0, ssq, fx);
   rc = adam_self(net, nanf, status, fx, 0); if (rc) return bail(rc);

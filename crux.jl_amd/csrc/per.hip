@@ -201,6 +201,21 @@ struct TreeTouchOp { static __device__ __forceinline__ void run(const unsigned b
     __threadfence_block(); __syncthreads();
   }
 } };
+// LeafRefreshOp and TreeTouchOp in ONE launch (the chained C3 epochs, exec.hip dqn_epoch_tiles): every workgroup re-sums its leaves, publishes them (device-scope release) and takes
+// a ticket; the workgroup that draws the last ticket -- all leaves are then visible to it -- walks the root paths. The root paths so leave the launch of the pullback they sit
+// beside, and the next epoch's search can follow one launch earlier. `ticket` is a zeroed word; n <= 256 touched elements.
+struct LeafTouchOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev,
+                                                    float* __restrict__ run, float* __restrict__ total, unsigned* __restrict__ ticket) {
+  __shared__ int last_;
+  LeafRefreshOp::run(bid_, nb_, v, ids, n, N, nlev, run, total);
+  __syncthreads();
+  if (threadIdx.x == 0) { __threadfence(); last_ = atomicAdd(ticket, 1u) == nb_ - 1u ? 1 : 0; }
+  __syncthreads();
+  if (!last_) return;
+  __threadfence();
+  TreeTouchOp::run(0u, 1u, ids, n, N, nlev, total);
+} };
+__global__ __launch_bounds__(256) void k_leaf_touch(const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev, float* __restrict__ run, float* __restrict__ total, unsigned* __restrict__ ticket) { LeafTouchOp::run(blockIdx.x, gridDim.x, v, ids, n, N, nlev, run, total, ticket); }
 __global__ __launch_bounds__(1024) void k_tree_touch(const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev, float* __restrict__ total) { TreeTouchOp::run(blockIdx.x, gridDim.x, ids, n, N, nlev, total); }
 // prefix of a leaf = _accumulate_pairwise!'s s at that leaf: v[1], then + total(left sibling) at every right turn of the root path, top-down. The node of the path
 // at level q is id >> (depth - q); it is a right child when odd and its left sibling is the slot before it. Branch-free: a left turn (or a level below the leaf)
@@ -417,12 +432,13 @@ int32_t crux_per_prepare(crux_buffer* source) {      // exec.hip: bring the tree
   return ensure_cumsum(source, source->elements);
 }
 // called by every path that changes priorities (update_priorities!, push!'s max-priority rows): d_ids = the touched elements (device, int64)
-int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool from_push) {
+int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool from_push, unsigned* ticket) {      // ticket (a zeroed device word, recordings only): leaves and root paths as ONE op (LeafTouchOp)
   b->cumsum_valid = false;
   if (n <= 0) return CRUX_OK;
   if (from_push && b->elements < b->capacity) { b->per_full_dirty = true; return CRUX_OK; }   // the ring is still growing: the rows may lie beyond the current tree
   if (b->per_full_dirty || b->topo_n < 2 || b->per_run_n != b->topo_n || b->topo_n != b->elements || n > 4096 || !d_ids) { b->per_full_dirty = true; return CRUX_OK; }
   if (b->topo_levels > CRUX_PER_PMAX) { b->per_full_dirty = true; return CRUX_OK; }
+  if (ticket && n <= 256 && crux_exec_recording(b->ctx)) { crux_exec_push<LeafTouchOp, OP_LEAF_TOUCH>(b->ctx, (unsigned)((n + 3) / 4), (const float*)b->priorities, d_ids, n, (int64_t)b->topo_n, (int)b->topo_levels, b->cumsum, b->topo_total, ticket); return CRUX_OK; }
   CRUX_RUN(b->ctx, LeafRefreshOp, OP_LEAF_REFRESH, k_leaf_refresh, (unsigned)((n + 3) / 4), 256, b->ctx->stream, b->priorities, d_ids, n, b->topo_n, b->topo_levels, b->cumsum, b->topo_total);
   CRUX_RUN(b->ctx, TreeTouchOp, OP_TREE_TOUCH, k_tree_touch, 1, 1024, b->ctx->stream, d_ids, n, b->topo_n, b->topo_levels, b->topo_total);
   return crux_launch_check(b->ctx, "k_leaf_refresh");
