@@ -77,9 +77,9 @@ def c3(crux, ctx, cpu=True, steps=300):
     # their root paths, 128 x 20 probes of (leaf id, running sum, 24 path ids, <= 24 totals), the 128-row gather (78 B/row read + write)
     per_bytes = 128 * 127 * 8 + 128 * 14 * 12 + 128 * 20 * (4 + 4 + 96 + 56) + 2 * 128 * 78
     out = {"workload": "DQN + prioritized replay, 8-256-256-4, buffer 1 M, B = 128: value_training epochs (prioritized_sample! + dqn_target + td_error + update_priorities! + train!), 4 per solve iteration in one chained call",
-           "grad_steps_per_s": 1.0 / t, "per_samples_per_s": B / t, "us_per_epoch": 1e6 * t, "us_per_epoch_async_chains": 1e6 * t_async, "launches_per_epoch": 5,
-           "roofline": {"kernel": "k_phase_k (crux_dqn_epochs -> dqn_epoch_tiles, csrc/exec.hip: an epoch is FIVE dependent launches in a chain -- [layers 0+1 of Q and Q-target as one register-fused block kernel | beta-power advance of the previous epoch] [both output layers + dqn_target + td head + update_priorities! per 16-sample tile] [the whole pullback: output-layer dW, LDS-staged layer-1 dW, quarter-split layer-1 dX -> layer-0 partials | leaf re-sums] [gradient norm (completes the layer-0 gradient) | root paths] [Adam | prioritized search + gather of the next epoch in one launch]; round 3: 9 launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                        "algorithmic_MFLOP_per_epoch": C3_FLOP / 1e6, "note": "latency-bound: 5 dependent launches; a launch that follows its predecessor back to back costs ~5 us whatever it holds, the prioritized search (four dependent probe rounds into a 4 MB running-sum array) ~15 us"},
+           "grad_steps_per_s": 1.0 / t, "per_samples_per_s": B / t, "us_per_epoch": 1e6 * t, "us_per_epoch_async_chains": 1e6 * t_async, "launches_per_epoch": 4,
+           "roofline": {"kernel": "k_phase_k (crux_dqn_epochs -> dqn_epoch_tiles, csrc/exec.hip: an epoch is FOUR dependent launches in a chain -- [layers 0+1 of Q and Q-target as one register-fused block kernel | info + beta-power advance of the previous epoch] [both output layers + dqn_target + td head + update_priorities! per 16-sample tile] [the whole pullback: output-layer dW, LDS-staged layer-1 dW, quarter-split layer-1 dX -> layer-0 partials | leaf re-sums -> root paths by the workgroup that draws the last ticket] [gradient norm | Adam gated on the pullback's NaN flags | prioritized search + gather of the next epoch]; round 3: 9 launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        "algorithmic_MFLOP_per_epoch": C3_FLOP / 1e6, "note": "latency-bound: 4 dependent launches; a launch that follows its predecessor back to back costs ~5 us whatever it holds, the prioritized search + gather (three dependent probe rounds into a 4 MB running-sum array, then the row) ~12 us more"},
            "replay_sampling": {"bytes_per_epoch_incremental": per_bytes, "bytes_per_epoch_full_rescan": 8 * N, "bound": "hbm", "note": "the reference's cumsum(priorities) per gradient step (4 MB read + 4 MB write at N = 1 M) is replaced by re-summing the touched leaves and their root paths; sample indices stay bit-exact"}}
     if cpu:
         O, L2 = _oracle()
@@ -161,9 +161,9 @@ def c4(crux, ctx, cpu=True, steps=200):
     solver._resolve_history()
     ach = C4_FLOP / t / 1e12
     out = {"workload": "SAC, GaussianPolicy 3-256-256-1 + twin Q 4-256-256-1, B = 256: value_training epochs (rand! + sac_target + temperature, twin-critic and actor steps + polyak), 50 per solve iteration chained 8 at a time",
-           "epochs_per_s": 1.0 / t, "grad_steps_per_s": 3.0 / t, "us_per_epoch": 1e6 * t, "us_per_epoch_async_chains": 1e6 * t_async, "launches_per_epoch": 14,
-           "roofline": {"kernel": "k_phase_k (crux_sac_epochs: an epoch is 14 dependent launches in a chain (sac_epoch_tiles, csrc/exec.hip: 17 phases, three of them beside the previous epoch's tail); layers 0+1 of every forward pass are one register-fused launch, the output layers run inside per-16-sample-tile ops together with what follows them (exploration, sac_target + both critic heads, the actor head, the reverse of exploration), every pullback is ONE phase (output-layer dW | LDS-staged layer-1 dW | quarter-split layer-1 dX with the output layer\'s data gradient folded in -> layer-0 partials completed by the norm op), a critic input-gradient chain 2; round 3: 26 launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                        "algorithmic_GFLOP_per_epoch": C4_FLOP / 1e9, "note": "latency-bound: 14 dependent launches of 5.5-11 us per epoch (Q1 || Q2, the target critics, the temperature step and the actor\'s own forward pass share phases with the critic chain)"}}
+           "epochs_per_s": 1.0 / t, "grad_steps_per_s": 3.0 / t, "us_per_epoch": 1e6 * t, "us_per_epoch_async_chains": 1e6 * t_async, "launches_per_epoch": 12,
+           "roofline": {"kernel": "k_phase_k (crux_sac_epochs: an epoch is 12 dependent launches in a chain (sac_epoch_tiles, csrc/exec.hip: 15 phases, three of them beside the previous epoch's tail; Adam runs beside the gradient norm, gated on the NaN flags the pullback's kernels raise); layers 0+1 of every forward pass are one register-fused launch, the output layers run inside per-16-sample-tile ops together with what follows them (exploration, sac_target + both critic heads, the actor head, the reverse of exploration), every pullback is ONE phase (output-layer dW | LDS-staged layer-1 dW | quarter-split layer-1 dX with the output layer\'s data gradient folded in -> layer-0 partials completed by the norm op), a critic input-gradient chain 2; round 3: 26 launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        "algorithmic_GFLOP_per_epoch": C4_FLOP / 1e9, "note": "latency-bound: 12 dependent launches of 5.5-11 us per epoch (Q1 || Q2, the target critics, the temperature step and the actor\'s own forward pass share phases with the critic chain)"}}
     if cpu:
         O, L2 = _oracle()
         n_o = 20_000

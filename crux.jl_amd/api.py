@@ -124,6 +124,11 @@ class Context:
             self.h = None
 
 
+def reload_switches():
+    """re-read the CRUX_* environment switches (the library reads them when a context is created; cruxhip.h: crux_reload_switches)"""
+    L.load().crux_reload_switches()
+
+
 def peer_attach_local(contexts):
     """Wire the contexts of ONE process into a replica group (contexts[r] = rank r): a multi-GPU single-process host, or replicas sharing a device."""
     arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])

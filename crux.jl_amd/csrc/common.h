@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include <cstring>
+#include "switches.h"
 #include <cstdio>
 #include <cmath>
 #include "../../include/cruxhip.h"

@@ -86,7 +86,13 @@ static void prof_resolve(crux_ctx* ctx) {
   ctx->pending.clear();
 }
 
+// the CRUX_* switches: one snapshot per process (switches.h)
+static CruxSwitches g_sw; static bool g_sw_loaded = false;
+const CruxSwitches& crux_sw() { if (!g_sw_loaded) { g_sw = crux_switches_read(); g_sw_loaded = true; } return g_sw; }
+
 extern "C" {
+
+int32_t crux_reload_switches(void) { g_sw = crux_switches_read(); g_sw_loaded = true; return CRUX_OK; }
 
 const char* crux_version(void) { return "cruxhip 0.1 (gfx950)"; }
 
@@ -96,6 +102,7 @@ int32_t crux_ctx_create(int32_t device_id, void* stream, crux_ctx** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return CRUX_EHIP;
   if (hipSetDevice(device_id) != hipSuccess) return CRUX_EHIP;
+  crux_reload_switches();      // the environment switches are read here, once per context creation, never on a launch path
   crux_ctx* c = new crux_ctx();
   c->device = device_id;
   if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }

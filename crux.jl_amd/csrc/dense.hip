@@ -136,11 +136,11 @@ struct GemmOp { static __device__ __forceinline__ void run(const unsigned bid_, 
 
 #include "dense_fused.h"
 // CRUX_DENSE_FUSED=0: every layer through its own Gemm16 launch (the round-3 chains; tests compare the two forms bit for bit). Read once.
-static bool dense_fused_on() { static const bool on = !(getenv("CRUX_DENSE_FUSED") && getenv("CRUX_DENSE_FUSED")[0] == '0'); return on; }
+static bool dense_fused_on() { return crux_sw().dense_fused != 0; }
 bool crux_dense_fwd_fused(const crux_mlp* n) { return dense_fused_on() && df_fwd12_ok(n->nd); }                      // layers 0 + 1 in one launch (exec.hip's phase plans ask)
 bool crux_dense_bwd_fused(const crux_mlp* n, int64_t B) { return dense_fused_on() && df_bwd_ok(n->nd, B); }
 bool crux_dense_bwd_fused3(const crux_mlp* n, int64_t B) {      // + the output layer's data gradient folded into the pair: the whole pullback of a three-layer network is ONE phase
-  static const bool on3 = !(getenv("CRUX_DENSE_FUSED") && getenv("CRUX_DENSE_FUSED")[0] == '2');      // CRUX_DENSE_FUSED=2: the pair without the folded output layer (tests)
+  const bool on3 = crux_sw().dense_fused != 2;      // CRUX_DENSE_FUSED=2: the pair without the folded output layer (tests)
   return on3 && crux_dense_bwd_fused(n, B) && n->nd.L == 3 && (n->nd.dims[3] == 1 || n->nd.dims[3] == 4) && n->nd.acts[2] == CRUX_ACT_IDENTITY; }        // layer 1's dW beside (layer 1's dX -> layer 0's dW) in one phase
 
 // dZ = act'(Y) .* dY for the output layer
@@ -161,7 +161,7 @@ static int32_t launch_gemm(crux_ctx* c, const GemmArgs& q, hipStream_t st) {
     // the stand-alone launch would split K over the four waves of a workgroup here; on the executor's 32 CUs one round of fat blocks beats several rounds of
     // thin ones, so up to 32 tiles keep the split form and larger GEMMs give each wave a whole tile with the K quarters walked in order (same bits)
     // (the persistent one-XCD executor prefers fat blocks; the default phase launches run over the whole chip like the stand-alone launches and split whenever those do)
-    static const bool persistent = getenv("CRUX_EXEC_PERSISTENT") != nullptr;
+    const bool persistent = crux_sw().exec_persistent;
     const bool deep = q.K >= 128 && tiles <= 4096 && !no_split, split = deep && (!persistent || tiles <= 32);
     crux_exec_push<GemmOp, OP_GEMM>(c, (unsigned)(split ? tiles : (tiles + 3) / 4), q, (int)((av ? 1 : 0) | (bv ? 2 : 0) | (split ? 4 : 0) | ((deep && !split) ? 8 : 0)));
     return CRUX_OK;

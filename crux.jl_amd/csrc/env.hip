@@ -785,7 +785,7 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
   RolloutArgs a; fill_rollout_args(a, e, policy, cfg, buf, T);
   crux_prof_begin(c, CRUX_PROF_ROLLOUT);
   const NetDesc& pn = policy->nd;
-  const bool h64 = pn.L == 3 && pn.dims[1] == 64 && pn.dims[2] == 64 && pn.acts[0] == pn.acts[1] && pn.acts[2] == CRUX_ACT_IDENTITY && !getenv("CRUX_FORCE_GENERIC");
+  const bool h64 = pn.L == 3 && pn.dims[1] == 64 && pn.dims[2] == 64 && pn.acts[0] == pn.acts[1] && pn.acts[2] == CRUX_ACT_IDENTITY && !crux_sw().force_generic;
 #define RO_CASE(I, O, A_, K) if (h64 && pn.dims[0] == I && nout == O && pn.acts[0] == A_ && e->kind == K) hipLaunchKernelGGL((k_rollout_h64<I, O, A_, K>), dim3(e->n_envs), dim3(64), 0, c->stream, a, (const RolloutArgs*)nullptr); else
   RO_CASE(4, 2, CRUX_ACT_RELU, CRUX_ENV_CARTPOLE)
   RO_CASE(4, 2, CRUX_ACT_TANH, CRUX_ENV_CARTPOLE)
@@ -926,7 +926,7 @@ extern "C" int32_t crux_dqn_small_solve(crux_mlp* net, crux_mlp* target_net, cru
   const size_t tiny_lds = sizeof(float) * ((size_t)(2 * 1024 + ENV_MAXOBS + 8) + (size_t)source->capacity * (2 * 2 + 3) + 60 * 64) + 64;
   const bool tiny = pn.L == 2 && pn.dims[0] == 2 && pn.dims[1] == 8 && pn.dims[2] == 4 && pn.acts[0] == CRUX_ACT_RELU && pn.acts[1] == CRUX_ACT_IDENTITY && pn.n_extra == 0 &&
                     target_net->nd.L == 2 && target_net->nd.dims[1] == 8 && target_net->nd.acts[0] == CRUX_ACT_RELU && E == 1 && B <= 128 && dN <= 64 && tiny_lds <= 60 * 1024 &&
-                    !getenv("CRUX_SMALL_SOLVE_GENERIC");
+                    !crux_sw().small_solve_generic;
   crux_prof_begin(c, tiny ? CRUX_PROF_TINY_SOLVE : CRUX_PROF_TD_STEP);
   if (tiny) hipLaunchKernelGGL((k_dqn_tiny_solve<2, 8, 4>), dim3(1), dim3(64), tiny_lds, c->stream, q);
   else {
@@ -947,7 +947,7 @@ extern "C" int32_t crux_dqn_small_solve(crux_mlp* net, crux_mlp* target_net, cru
   batch->elements = B; batch->next_ind = 0; batch->total_count += (int64_t)B * epochs * iters; batch->indices_n = B; batch->indices_stale = true;
   if (sum_r || n_episode_end) { double sr = 0; int64_t ne = 0; for (int k = 0; k < E; ++k) { sr += acc[2 * k]; ne += (int64_t)acc[2 * k + 1]; } if (sum_r) *sum_r = sr; if (n_episode_end) *n_episode_end = ne; }
   hst[0] = hst9[0]; hst[1] = hst9[8];
-  if (getenv("CRUX_SMALL_SOLVE_TIMING")) { unsigned long long tt[8]; (void)hipMemcpy(tt, q.status + 16, sizeof tt, hipMemcpyDeviceToHost); unsigned long long tot = 0; for (auto v : tt) tot += v;
+  if (crux_sw().small_solve_timing) { unsigned long long tt[8]; (void)hipMemcpy(tt, q.status + 16, sizeof tt, hipMemcpyDeviceToHost); unsigned long long tot = 0; for (auto v : tt) tot += v;
     fprintf(stderr, "[small-solve] rollout %.1f%% ids (tiny kernel: sample + forward / backward) %.1f%% gather (tiny: transpose-reduce) %.1f%% target %.1f%% train (tiny: statistics + Adam) %.1f%%\n", 100.0 * tt[0] / tot, 100.0 * tt[1] / tot, 100.0 * tt[2] / tot, 100.0 * tt[3] / tot, 100.0 * tt[4] / tot); fprintf(stderr, "[small-solve] tiny: rollout body %.1f%%, fence + mirror %.1f%%\n", 100.0 * tt[5] / tot, 100.0 * tt[0] / tot); }
   if (hst[1] == CRUX_ENAN || hst[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
   if (hst[1]) return crux_fail(c, hst[1], "small solve kernel reported status %d", hst[1]);

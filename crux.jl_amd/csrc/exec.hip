@@ -310,7 +310,7 @@ static int32_t dqp_launch(crux_ctx* c, ExecRec* r) {      // inside crux_exec_ru
   a.dinfo = (float* const*)(buf + DqpBuf::oPtr); a.dstatus = (int32_t* const*)(buf + DqpBuf::oPtr + n * sizeof(void*));
   a.zbuf = (float*)(buf + DqpBuf::oZ); a.pbuf = (float*)(buf + DqpBuf::oP); a.gbuf = (float*)(buf + DqpBuf::oG); a.mv2 = (float*)(buf + DqpBuf::oMV); a.wtg = (float*)(buf + DqpBuf::oWT); a.ssq = (double*)(buf + DqpBuf::oSsq);
   a.ctrL = (unsigned*)(buf + DqpBuf::oCtrL); a.flags = (unsigned*)(buf + DqpBuf::oFlags); a.status = (int32_t*)(r->d_ctr + 264); a.xcd = 0;
-  a.dbg = getenv("CRUX_DQP_DEBUG") ? (unsigned long long*)(buf + DqpBuf::oDbg) : nullptr; if (a.dbg) HIPCHK(c, hipMemsetAsync(a.dbg, 0, 8192, c->stream));
+  a.dbg = crux_sw().dqp_debug ? (unsigned long long*)(buf + DqpBuf::oDbg) : nullptr; if (a.dbg) HIPCHK(c, hipMemsetAsync(a.dbg, 0, 8192, c->stream));
   // the replay kernel first, on the second stream (its own hardware queue): it samples epoch 0 while the learner loads its parameters
   HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
   hipLaunchKernelGGL(k_dqn_replay, dim3(8 * DQP_R), dim3(256), 0, c->aux_stream, (const ExecOp*)r->d_ops, (const int32_t*)(buf + DqpBuf::oTab), n, r->d_ctr, a.flags, a.xcd, a.status, a.dbg);
@@ -321,7 +321,7 @@ static int32_t dqp_launch(crux_ctx* c, ExecRec* r) {      // inside crux_exec_ru
   else if (d.in == 4 && d.out == 2 && d.bt == 8) rc = dqp_launch_learn<4, 2, 8>(c, a, c->stream);
   else if (d.in == 4 && d.out == 2 && d.bt == 4) rc = dqp_launch_learn<4, 2, 4>(c, a, c->stream);
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
-  if (getenv("CRUX_DQP_DEBUG")) { HIPCHK(c, hipStreamSynchronize(c->stream)); unsigned h[1024]; HIPCHK(c, hipMemcpy(h, buf, 4096, hipMemcpyDeviceToHost));
+  if (crux_sw().dqp_debug) { HIPCHK(c, hipStreamSynchronize(c->stream)); unsigned h[1024]; HIPCHK(c, hipMemcpy(h, buf, 4096, hipMemcpyDeviceToHost));
     fprintf(stderr, "[dqp] rc %d n %d flags %u %u %u  ctrL", rc, n, h[512], h[513], h[514]); for (int q = 0; q < 16; ++q) fprintf(stderr, " %u", h[q]); fprintf(stderr, " abort %u  ssq", h[256]);
     const double* sq = (const double*)(h + 576); for (int q = 0; q < 16; ++q) fprintf(stderr, " %.3g", sq[q]); { unsigned hc[300]; (void)hipMemcpy(hc, r->d_ctr, 1200, hipMemcpyDeviceToHost); fprintf(stderr, "  ctrR"); for (int q = 0; q < 32; ++q) fprintf(stderr, " %u", hc[q]); fprintf(stderr, " abortR %u st %d whyL %d whyR %d claims %u %u", hc[256], (int)hc[264], (int)hc[265], (int)hc[266], h[516], h[517]); }
     fprintf(stderr, "  xcc L"); for (int q = 0; q < 16; ++q) fprintf(stderr, " %u", h[512 + 16 + q]); fprintf(stderr, " R"); for (int q = 0; q < 32; ++q) fprintf(stderr, " %u", h[512 + 32 + q]); fprintf(stderr, "  tab"); for (size_t q = 0; q < d.tab.size() && q < 40; ++q) fprintf(stderr, " %d", d.tab[q]); fprintf(stderr, "\n");
@@ -426,7 +426,7 @@ int32_t crux_exec_run(crux_ctx* c) {
     // an asynchronous chain whose phases all travel in kernel arguments needs neither the device copy of the list nor the zeroed counters (no persistent form, no status
     // read-back): two stream operations less between chains (they sit IN the stream there, ~15 us per chain)
     bool lean = false;
-    if (async && !r->dqp.on && !getenv("CRUX_EXEC_PERSISTENT") && !getenv("CRUX_EXEC_NO_KERNARG")) { lean = true;
+    if (async && !r->dqp.on && !crux_sw().exec_persistent && !crux_sw().exec_no_kernarg) { lean = true;
       size_t i0 = 0;
       while (i0 < nops && lean) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += (r->ops[i1].barrier & 2) ? 0u : r->ops[i1].nblocks; if ((r->ops[i1].barrier & 1) || i1 + 1 == nops) break; ++i1; }
         if (blocks && !phasek_fits(r->ops, i0, i1)) lean = false;
@@ -450,7 +450,7 @@ int32_t crux_exec_run(crux_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(r->d_ops, r->h_stage, ob, hipMemcpyHostToDevice, c->stream));
     }
     if (!lean) HIPCHK(c, hipMemsetAsync(r->d_ctr, 0, 2048, c->stream));
-    static const bool persistent = getenv("CRUX_EXEC_PERSISTENT") != nullptr;
+    const bool persistent = crux_sw().exec_persistent;
     if (r->dqp.on) { r->dqp.on = false; rc = dqp_launch(c, r); if (rc) return rc; }
     else if (!persistent) {
       // default: one launch per phase over the whole chip (see k_phase). Measured against the persistent one-XCD form (CRUX_EXEC_PERSISTENT=1): the latter
@@ -459,7 +459,7 @@ int32_t crux_exec_run(crux_ctx* c) {
       while (i0 < nops) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += (r->ops[i1].barrier & 2) ? 0u : r->ops[i1].nblocks; if ((r->ops[i1].barrier & 1) || i1 + 1 == nops) break; ++i1; }
         if (blocks) {
           // the phase's records travel in the kernel arguments when they fit (see k_phase_k); zero-block ops are dropped there
-          const bool no_kernarg = getenv("CRUX_EXEC_NO_KERNARG") != nullptr;      // tests: every phase through the global-record form
+          const bool no_kernarg = crux_sw().exec_no_kernarg;      // tests: every phase through the global-record form
           if (no_kernarg || (!phasek_launch<384>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<1024>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<3840>(r->ops, i0, i1, blocks, c->stream)))
             hipLaunchKernelGGL(k_phase, dim3(blocks), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops + i0, (int)(i1 - i0 + 1));
         }
@@ -469,7 +469,7 @@ int32_t crux_exec_run(crux_ctx* c) {
     const int xcd = crux_x2_placement_ok_c(c) ? 0 : -2;
     if (xcd == -2) return crux_fail(c, CRUX_EUNSUP, "executor: workgroups are not placed round-robin over the XCDs on this device");
     const int G = EXEC_G;
-    const int xflags = getenv("CRUX_EXEC_FLAGS") ? atoi(getenv("CRUX_EXEC_FLAGS")) : 0;      // 8: per-op timestamps of workgroups 0 and 1, printed below
+    const int xflags = crux_sw().exec_flags;      // 8: per-op timestamps of workgroups 0 and 1, printed below
     hipLaunchKernelGGL(k_exec, dim3(G * 8), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops, (int)nops, r->d_ctr, xcd, (int32_t*)(r->d_ctr + 264), xflags);
     if (xflags & 8) { static int dumps = 0;
       std::vector<unsigned long long> tb(2 * 512 * 3); HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -534,7 +534,7 @@ int32_t crux_polyak(crux_mlp* to, const crux_mlp* from, float tau);
 //   update_priorities! per 16-sample tile | 4 the whole pullback ; leaf re-sums | 5 norm ; root paths | 6 info, Adam | 7 beta-power advance
 // In a chain the sampling of epoch e + 1 (phases 0, 1) sits beside the norm and Adam of epoch e -- after the root paths of phase 5 --, its phase 2 beside the advance.
 static bool dqn_tile_case(crux_mlp* net, crux_mlp* tnet, crux_buffer* source, crux_buffer* batch) {
-  const bool on = !(getenv("CRUX_SAC_TILE_OPS") && getenv("CRUX_SAC_TILE_OPS")[0] == '0') && !getenv("CRUX_EXEC_PERSISTENT") && !getenv("CRUX_NO_FUSED_EPOCH") && !getenv("CRUX_NO_CHAINED_EPOCHS");
+  const bool on = crux_sw().sac_tile_ops && !crux_sw().exec_persistent && !crux_sw().no_fused_epoch && !crux_sw().no_chained_epochs;
   const int64_t B = batch->capacity; crux_ctx* c = net->ctx;
   if (!on || c->per_split_sample || !net->has_adam) return false;
   if (source->prioritized && !crux_per_fused_gather()) return false;
@@ -601,7 +601,7 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   if (!net || !target_net || !source || !batch) return CRUX_EINVAL;
   crux_ctx* c = net->ctx; const int64_t B = batch->capacity;
   const bool per = source->prioritized;
-  const bool fuse = net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && !getenv("CRUX_NO_FUSED_EPOCH");
+  const bool fuse = net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && !crux_sw().no_fused_epoch;
   int32_t rc;
   if (per) { rc = crux_per_prepare(source); if (rc) return rc; }
   float* d_y = nullptr; float* d_err = nullptr;
@@ -636,7 +636,7 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   // as ov <= nb + 1; without the group the chain is update | leaf | paths at 4 + nf - sq .., and ov <= nb as before.
   const NetPlan pn = net_plan(net, B); const bool ffw = crux_dense_fwd_fused(net);
   const int nf = pn.nf, nb = pn.nb;
-  const int sq0 = (B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;
+  const int sq0 = (B <= 256 && !crux_sw().exec_persistent) ? 1 : 0;
   const bool tailp = per && sq0 == 1;
   // sph: with the search and the gather in one launch (PerSampleGatherOp) the sampling of an epoch is phase 1 alone, so the search of epoch e + 1 sits one phase later and the
   // overlap may be one deeper
@@ -701,8 +701,8 @@ static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer*
                                uint64_t sample_counter0, int32_t n_epochs, float* infos, float* d_infos_async = nullptr) {
   if (!net || !target_net || !source || !batch || n_epochs < 1) return CRUX_EINVAL;
   crux_ctx* c = net->ctx;
-  const bool fuse = net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && !getenv("CRUX_NO_FUSED_EPOCH") &&
-                    !getenv("CRUX_NO_CHAINED_EPOCHS");
+  const bool fuse = net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && !crux_sw().no_fused_epoch &&
+                    !crux_sw().no_chained_epochs;
   // 256-wide networks of the shapes dqn_persist.h instantiates: the whole chain as two persistent kernels. OPT-IN (CRUX_DQN_PERSIST=1): correct (tests/test_gpu_round3.py)
   // but measured SLOWER than the phase launches in round 3 -- 113-125 us against 73-79 us per C3 epoch (DESIGN 4.3 has the in-kernel timeline) -- so the default stays
   // with the phases.
@@ -712,7 +712,7 @@ static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer*
                        net->nd.acts[0] == CRUX_ACT_RELU && net->nd.acts[1] == CRUX_ACT_RELU && net->nd.acts[2] == CRUX_ACT_IDENTITY &&
                        target_net->nd.acts[0] == CRUX_ACT_RELU && target_net->nd.acts[1] == CRUX_ACT_RELU && target_net->nd.acts[2] == CRUX_ACT_IDENTITY &&
                        net->has_adam && batch->obs_dim == net->nd.dims[0] && batch->act_kind == CRUX_ACTION_DISCRETE && batch->act_dim == net->nd.dims[3] && (!use_weight || has_col(batch, CRUX_COL_WEIGHT)) &&
-                       (getenv("CRUX_DQN_PERSIST") && getenv("CRUX_DQN_PERSIST")[0] == '1') && !c->dqp_broken && crux_x2_placement_ok_c(c);
+                       crux_sw().dqn_persist && !c->dqp_broken && crux_x2_placement_ok_c(c);
   auto flush = [&]() -> int32_t {
     if (!crux_exec_recording(c)) return CRUX_OK;
     ExecRec* r = rec_of(c); r->chain = false;
@@ -744,7 +744,7 @@ static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer*
     rec_of(c)->chain = true;
     rc = dqn_epoch_impl(net, target_net, source, batch, gamma, softq_alpha, use_weight, beta, sample_counter0 + (uint64_t)e, info_e);
     if (rc) { if (c->rec) rec_of(c)->chain = false; crux_exec_abort(c); return rc; }
-    const bool tiles = dqn_tile_case(net, target_net, source, batch) && !getenv("CRUX_NO_FUSED_EPOCH");
+    const bool tiles = dqn_tile_case(net, target_net, source, batch) && !crux_sw().no_fused_epoch;
     if (d_infos_async) {      // the epoch's info row goes to the caller's device array, copied in the epoch's last phase (one phase after the info op wrote it)
       ExecRec* r = rec_of(c);
       crux_exec_push<CopyF32Op, OP_COPY_F32>(c, 1u, d_infos_async + (size_t)e * CRUX_INFO_N, (const float*)r->readbacks.back().d_info, (int64_t)CRUX_INFO_N);
@@ -766,13 +766,13 @@ int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source
 int32_t crux_dqn_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
                               uint64_t sample_counter0, int32_t n_epochs, float* d_infos) {
   if (!d_infos) return CRUX_EINVAL;
-  if (!net || !target_net || net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || target_net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || getenv("CRUX_NO_FUSED_EPOCH") || getenv("CRUX_NO_CHAINED_EPOCHS")) return CRUX_EUNSUP;
+  if (!net || !target_net || net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || target_net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || crux_sw().no_fused_epoch || crux_sw().no_chained_epochs) return CRUX_EUNSUP;
   return dqn_epochs_impl(net, target_net, source, batch, gamma, 0.f, use_weight, beta, sample_counter0, n_epochs, nullptr, d_infos);
 }
 int32_t crux_softq_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
                                 uint64_t sample_counter0, int32_t n_epochs, float* d_infos) {      // crux_softq_epochs without the host in the loop (see crux_dqn_epochs_async)
   if (!d_infos || !(alpha > 0.f)) return CRUX_EINVAL;
-  if (!net || !target_net || net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || target_net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || getenv("CRUX_NO_FUSED_EPOCH") || getenv("CRUX_NO_CHAINED_EPOCHS")) return CRUX_EUNSUP;
+  if (!net || !target_net || net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || target_net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || crux_sw().no_fused_epoch || crux_sw().no_chained_epochs) return CRUX_EUNSUP;
   return dqn_epochs_impl(net, target_net, source, batch, gamma, alpha, use_weight, beta, sample_counter0, n_epochs, nullptr, d_infos);
 }
 int32_t crux_softq_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
@@ -799,7 +799,7 @@ int32_t crux_dpg_actor_step(crux_mlp* actor, crux_mlp* q, crux_buffer* b, float*
 // The order inside every chain is the reference's (temperature, critic and actor each see what the previous step left; sac_target reads log alpha BEFORE the temperature
 // update lands, the actor head after). Same arithmetic as the generic recording below (tools/fused_check.py compares the two bit for bit); false = not this case.
 static bool sac_tile_case(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* q1t, crux_mlp* q2t, crux_buffer* source, crux_buffer* batch, int32_t uc, int32_t ua) {
-  const bool on = !(getenv("CRUX_SAC_TILE_OPS") && getenv("CRUX_SAC_TILE_OPS")[0] == '0') && !getenv("CRUX_EXEC_PERSISTENT") && !getenv("CRUX_NO_FUSED_EPOCH");      // (read per call: tests switch forms inside one process)
+  const bool on = crux_sw().sac_tile_ops && !crux_sw().exec_persistent && !crux_sw().no_fused_epoch;      // (read per call: tests switch forms inside one process)
   if (!on || !uc || !ua || source->prioritized) return false;
   const int64_t B = batch->capacity; crux_mlp* all[5] = {actor, q1, q2, q1t, q2t};
   for (crux_mlp* n : all) { if (n->nd.L != 3 || !crux_dense_fwd_fused(n) || n->nd.acts[2] != CRUX_ACT_IDENTITY || n->nd.dims[2] != actor->nd.dims[2]) return false; }
@@ -927,7 +927,7 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   if (source->prioritized) return crux_fail(c, CRUX_EUNSUP, "sac_epoch: prioritized replay over a DoubleNetwork critic is not defined (td_error, src/utils.jl:112)");
   if (c->rec && rec_of(c)->chain && sac_tile_case(actor, q1, q2, q1_targ, q2_targ, source, batch, update_critic, update_actor))      // chained epochs of the C4 family: the tile ops (14 launches per epoch)
     return sac_epoch_tiles(actor, q1, q2, actor_targ, q1_targ, q2_targ, log_alpha, source, batch, gamma, H_target, tau, use_weight, sample_counter, noise_seed, noise_counter0, info_temp, info_critic, info_actor);
-  const bool fuse = !getenv("CRUX_NO_FUSED_EPOCH");
+  const bool fuse = !crux_sw().no_fused_epoch;
   int32_t rc; float* d_y = nullptr;
   if (fuse) { if (!crux_exec_recording(c)) { rc = crux_exec_begin(c); if (rc) return rc; }       // a chained recording (crux_sac_epochs) is already open
     d_y = (float*)crux_exec_small(c, 4 * (size_t)B);
@@ -943,7 +943,7 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   // The order inside every chain is the reference's (temperature before critic before actor: each sees the parameters the previous step left).
   // sq: sac_target (one block at B <= 256) and the critic heads (one block each) form a sequential group in ONE block of phase X when the critics train; the critic
   // chain and everything behind it (Y ..) then sit one phase earlier. The temperature chain (X .. X + 3) is independent of it.
-  const int sq = (update_critic && B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;
+  const int sq = (update_critic && B <= 256 && !crux_sw().exec_persistent) ? 1 : 0;
   // Round 4: written in launches -- FA / FQ forward launches of the actor / a critic, BQ / BA phases of a pullback with parameter gradients (BQo ops per critic), LQ phases
   // of a critic's input-gradient chain; with the fused block kernels FA = FQ = L - 1 and BQ = BA = L - 1 (net_plan above), otherwise all equal L as in round 3.
   const NetPlan pa = net_plan(actor, B), pq = net_plan(q1, B);
@@ -1013,7 +1013,7 @@ static int32_t sac_epochs_impl(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux
                         float* infos_temp, float* infos_critic, float* infos_actor, float* d_infos_async) {
   if (!actor || n_epochs < 1 || critic_every < 1 || actor_every < 1) return CRUX_EINVAL;
   crux_ctx* c = actor->ctx;
-  const bool fuse = !getenv("CRUX_NO_FUSED_EPOCH") && !getenv("CRUX_NO_CHAINED_EPOCHS");
+  const bool fuse = !crux_sw().no_fused_epoch && !crux_sw().no_chained_epochs;
   if (d_infos_async && !fuse) return CRUX_EUNSUP;
   auto flush = [&]() -> int32_t {
     if (!crux_exec_recording(c)) return CRUX_OK;
@@ -1055,7 +1055,7 @@ int32_t crux_sac_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* a
   // More than one chain (n_epochs > 8): the chains run back to back without a read-back between them -- the asynchronous form with the info rows in a device block of the
   // context -- and the host synchronises ONCE, at the end of the call: the device no longer idles while the host reads back, records and uploads the next chain
   // (C4, 50 epochs per call: 180 -> ~155 us per epoch). Same results; a NaN gradient norm is reported from the rows.
-  if (actor && n_epochs > 8 && critic_every >= 1 && actor_every >= 1 && !getenv("CRUX_NO_FUSED_EPOCH") && !getenv("CRUX_NO_CHAINED_EPOCHS") && !getenv("CRUX_SYNC_CHAINS")) {
+  if (actor && n_epochs > 8 && critic_every >= 1 && actor_every >= 1 && !crux_sw().no_fused_epoch && !crux_sw().no_chained_epochs && !crux_sw().sync_chains) {
     crux_ctx* c = actor->ctx; const size_t need = sizeof(float) * 3 * CRUX_INFO_N * (size_t)n_epochs;
     if (c->epoch_rows_bytes < need) { if (c->epoch_rows) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->epoch_rows); c->epoch_rows = nullptr; c->epoch_rows_bytes = 0; }
       if (hipMalloc(&c->epoch_rows, 2 * need) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "sac epochs: info rows"); c->epoch_rows_bytes = 2 * need; }
@@ -1103,7 +1103,7 @@ static int32_t dpg_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* 
   //   0 ids | 1 gather, fills | 2.. target actor(sp) forward ; vcat(s, a) ; actor(s) forward of the ACTOR step | 2+LA target action (+ smoothing noise) ; mu(s) -> vcat(s, mu(s))
   //   3+LA.. target Q1 || Q2 forward (and, from 3: Q1 || Q2 forward on (s, a)) | X target | X+1 critic heads | X+2.. critic backward | norm | info, Adam | advance
   //   Y.. Q(s, mu(s)) forward | its input gradient | slice | actor backward | norm | info, Adam | advance, polyak
-  const int sq = (update_critic && B <= 256 && !getenv("CRUX_EXEC_PERSISTENT")) ? 1 : 0;      // target + critic head(s) as a sequential one-block group (see crux_sac_epoch)
+  const int sq = (update_critic && B <= 256 && !crux_sw().exec_persistent) ? 1 : 0;      // target + critic head(s) as a sequential one-block group (see crux_sac_epoch)
   const NetPlan pa = net_plan(actor, B), pq = net_plan(q1, B);      // launches per pass (see crux_sac_epoch)
   std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, FA = pa.nf, FQ = pq.nf, BQ = pq.nb, BQo = pq.nbops, BA = pa.nb, DQ = pq.dq, X = 3 + FA + FQ, Y = X + 4 + BQ - sq;
   const int ag = actor->nd.acts[LA - 1] != CRUX_ACT_IDENTITY ? 1 : 0;
@@ -1112,7 +1112,7 @@ static int32_t dpg_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* 
   // chained epochs: the sampling of epoch e + 1 beside the actor's norm and info + Adam of epoch e; its phase 2 reads the TARGET actor, which polyak (last phase) writes,
   // so the rest closes up by two only
   auto tag = [&](size_t from, auto&& rule) { ExecRec* r = rec_of(c); int g = 0; const int base = r->chain ? r->chain_base : 0;
-    for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { if (getenv("CRUX_VERBOSE")) fprintf(stderr, "[cruxhip] dpg_epoch: op kind %d has no phase in the plan\n", r->ops[i].kid); plan_ok = false; p = 0; }
+    for (size_t i = from; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid, g); if (p < 0) { if (crux_sw().verbose) fprintf(stderr, "[cruxhip] dpg_epoch: op kind %d has no phase in the plan\n", r->ops[i].kid); plan_ok = false; p = 0; }
       const int sub = p >> 12; p &= 4095;
       ph.push_back(ph_tag(base > 0 ? (p < 2 ? base - 3 + p : base + p - 2) : p, sub)); } };
   const size_t ops0 = exec_mark(c);
@@ -1165,7 +1165,7 @@ static int32_t dpg_epochs_impl(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux
                         float* d_infos_async) {
   if (!actor || !q1 || !actor_targ || !q1_targ || !source || !batch || n_epochs < 1 || critic_every < 1 || actor_every < 1) return CRUX_EINVAL;
   crux_ctx* c = actor->ctx;
-  const bool chain = !getenv("CRUX_NO_CHAINED_EPOCHS");
+  const bool chain = !crux_sw().no_chained_epochs;
   if (d_infos_async && !chain) return CRUX_EUNSUP;
   auto flush = [&]() -> int32_t {
     if (!crux_exec_recording(c)) return CRUX_OK;
@@ -1211,7 +1211,7 @@ int32_t crux_dpg_epochs(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* a
                         float gamma, float tau, float sigma, float eps_min, float eps_max, float a_min, float a_max, int32_t use_weight, int32_t epoch0, int32_t n_epochs,
                         int32_t critic_every, int32_t actor_every, uint64_t sample_counter0, uint64_t noise_seed, uint64_t noise_counter0, float* infos_critic, float* infos_actor) {
   // several chains per call: run back to back, one synchronisation at the end of the call (see crux_sac_epochs)
-  if (actor && n_epochs > 8 && critic_every >= 1 && actor_every >= 1 && !getenv("CRUX_NO_CHAINED_EPOCHS") && !getenv("CRUX_SYNC_CHAINS")) {
+  if (actor && n_epochs > 8 && critic_every >= 1 && actor_every >= 1 && !crux_sw().no_chained_epochs && !crux_sw().sync_chains) {
     crux_ctx* c = actor->ctx; const size_t need = sizeof(float) * 2 * CRUX_INFO_N * (size_t)n_epochs;
     if (c->epoch_rows_bytes < need) { if (c->epoch_rows) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->epoch_rows); c->epoch_rows = nullptr; c->epoch_rows_bytes = 0; }
       if (hipMalloc(&c->epoch_rows, 2 * need) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "dpg epochs: info rows"); c->epoch_rows_bytes = 2 * need; }

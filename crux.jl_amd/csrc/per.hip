@@ -445,7 +445,7 @@ int32_t crux_per_touched(crux_buffer* b, const int64_t* d_ids, int64_t n, bool f
 }
 
 // push!(target, source, ids=device ids) (:232-259): gather B rows into target's ring; target.indices mirrors the ids
-bool crux_per_fused_gather() { static const bool on = !(getenv("CRUX_PER_FUSED_GATHER") && getenv("CRUX_PER_FUSED_GATHER")[0] == '0'); return on; }      // 0: search and gather as two launches (tests compare)
+bool crux_per_fused_gather() { return crux_sw().per_fused_gather; }      // 0: search and gather as two launches (tests compare)
 static void gather_table(crux_buffer* target, crux_buffer* source, GatherCols& g) {
   g = GatherCols{}; g.n = 0; g.pre[0] = 0;
   for (int k = 0; k < CRUX_NCOLS; ++k) {

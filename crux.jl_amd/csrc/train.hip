@@ -146,7 +146,7 @@ __global__ void k_pack_rows(const float* __restrict__ S, const void* __restrict_
 // builds buf->pack for the rows [0, elements) on `st`; fills the PACK fields of `a` (and of `k` when given: actor and critic share the lines). Skipped (PACK stays NULL) for
 // shapes whose row would not fit 64 floats, custom column selections (the critic against :cost_return) and CRUX_PACK_ROWS=0.
 static int32_t ensure_pack(crux_ctx* c, crux_buffer* buf, hipStream_t st, TrainArgs& a, TrainArgs* k) {
-  if (getenv("CRUX_PACK_ROWS") && getenv("CRUX_PACK_ROWS")[0] == '0') return CRUX_OK;
+  if (!crux_sw().pack_rows) return CRUX_OK;
   const int od = buf->obs_dim, ad = buf->act_dim, na = buf->act_kind == CRUX_ACTION_DISCRETE ? 1 : ad; const int need = od + na + 3;
   if (need > 64 || a.lag || a.ids) return CRUX_OK;
   const float* ret = has_col(buf, CRUX_COL_RETURN) ? (const float*)buf->col[CRUX_COL_RETURN] : nullptr;
@@ -189,7 +189,7 @@ static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_
   }
   int32_t rc = crux_train_mfma_launch(c, a, &handled, stream);
   if (rc) return rc;
-  const bool dense_ok = !handled && crux_train_dense_eligible(a, generic_lds_bytes(a.nd), getenv("CRUX_FORCE_GENERIC") != nullptr);      // (on the second learner stream too: its own resource set)
+  const bool dense_ok = !handled && crux_train_dense_eligible(a, generic_lds_bytes(a.nd), crux_sw().force_generic);      // (on the second learner stream too: its own resource set)
   if (a.need_px && !handled && !dense_ok) return crux_fail(c, CRUX_EUNSUP, "batch_train! with a replica group attached needs a learner with the gradient exchange (the register-resident kernels, or the dense-engine learner for other Chain(Dense...) shapes; not lagrange_ppo_loss): this learner would run un-synchronised");
   if (dense_ok) {
     // outside the register-resident family: the MFMA dense engine, one chain of tile GEMMs per minibatch (train_dense.hip)
@@ -200,7 +200,7 @@ static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_
   if (!handled) {
     // the generic learner is one workgroup of scalar loops: right for tiny networks and single steps, ~60x slower per minibatch than the MFMA family
     // on anything 64 wide -- say so once instead of silently falling off the cliff
-    if (!a.ids && a.apply && a.nd.n_params >= 2048 && !getenv("CRUX_FORCE_GENERIC") && !getenv("CRUX_QUIET")) {
+    if (!a.ids && a.apply && a.nd.n_params >= 2048 && !crux_sw().force_generic && !crux_sw().quiet) {
       static bool warned = false;
       if (!warned) { warned = true; char shape[128]; int o = 0; for (int l = 0; l <= a.nd.L && o < 100; ++l) o += snprintf(shape + o, sizeof shape - o, l ? "-%d" : "%d", a.nd.dims[l]);
         fprintf(stderr, "[cruxhip] batch_train!: network %s (batch %d, loss %d) is outside the MFMA learner family (IN-64-64-OUT with IN in {3,4,8,17}, batch <= 128) and not a case of the "
@@ -530,8 +530,8 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   // composed for e shuffles -- exactly the sequential result either way, never slower than actor-then-critic by more than one critic epoch, twice as fast when the
   // actor does not stop. CRUX_SPEC_PAIR=0: the sequential order.
   bool spec = !exact && cfg_a->target_kl >= 0.f && cfg_a->max_batches <= 0 && cfg_c->max_batches <= 0 && CRUX_IS_PG(cfg_a->loss) && cfg_c->loss == CRUX_LOSS_VALUE_MSE && c->peer_n <= 1 &&
-              buf->elements < ((int64_t)1 << 31) && !(getenv("CRUX_SPEC_PAIR") && getenv("CRUX_SPEC_PAIR")[0] == '0');
-  { const bool fs_on = !(getenv("CRUX_FS") && atoi(getenv("CRUX_FS")) == 0) && cfg_a->batch_size > 64 && cfg_a->batch_size <= 128;      // the feature-split kernel also takes a 32-wide second layer
+              buf->elements < ((int64_t)1 << 31) && crux_sw().spec_pair;
+  { const bool fs_on = (crux_sw().fs != 0) && cfg_a->batch_size > 64 && cfg_a->batch_size <= 128;      // the feature-split kernel also takes a 32-wide second layer
     auto mfma_family = [fs_on](const crux_mlp* n) { const NetDesc& d = n->nd; return d.L == 3 && d.dims[1] == 64 && (d.dims[2] == 64 || (d.dims[2] == 32 && fs_on)); };
     bool family = mfma_family(actor) && mfma_family(critic);
     if (family && (exact || spec) && fs_on && c->learner_cus == 0 && buf->elements >= cfg_a->batch_size && cfg_a->batch_size == cfg_c->batch_size) {      // 64 wide, but does a register-resident kernel instantiate these shapes?
@@ -544,7 +544,7 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
     if (!family) {
       // outside the register-resident family: two dense-engine chains (train_dense.hip), one per learner stream, driven by two host threads -- same condition as above
       // (no early stopping, no minibatch cap: the critic's shuffle chain can be composed ahead of the actor's run), no replica group, CRUX_DENSE_PAIR=0 switches it off
-      if (exact && c->peer_n <= 1 && !(getenv("CRUX_DENSE_PAIR") && getenv("CRUX_DENSE_PAIR")[0] == '0') && !getenv("CRUX_FORCE_GENERIC")) {
+      if (exact && c->peer_n <= 1 && crux_sw().dense_pair && !crux_sw().force_generic) {
         const int32_t rcd = dense_pair(actor, critic, buf, cfg_a, cfg_c, perms_a, perms_c, info_a, info_c, epoch_infos_a, epoch_infos_c);
         if (rcd != CRUX_EUNSUP) return rcd; }
       exact = false; } }     // otherwise dense-engine / generic learners run one after the other on the main stream

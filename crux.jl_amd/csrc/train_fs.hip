@@ -68,8 +68,8 @@ static int32_t launch_fs(crux_ctx* c, TrainArgs a, int form, bool timing, hipStr
 // probe: only answer whether this call would be taken (policy_gradient_training asks before it commits a pair of learners to the two learner streams)
 int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream, bool probe) {
   *handled = false;
-  const int mode = [] { const char* e = getenv("CRUX_FS"); return e ? atoi(e) : 1; }();            // read per call: tests switch the form inside one process
-  const int form_env = [] { const char* e = getenv("CRUX_FS_WG"); return e ? atoi(e) : 0; }();
+  const int mode = crux_sw().fs;            // read per call: tests switch the form inside one process
+  const int form_env = crux_sw().fs_wg;
   if (mode == 0) return CRUX_OK;
   if (c->learner_cus != 0 && !a.need_px) return CRUX_OK;      // crux_ctx_set_learner_cus(1 | 2): the caller asked for the one- / two-CU kernels (population runs)
   const NetDesc& nd = a.nd;
@@ -91,7 +91,7 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hip
     if (!shape) return CRUX_OK;
   }
   const int form = form_env == 2 || form_env == 4 || form_env == 8 ? form_env : CRUX_FS_DEFAULT_WG;      // 8 = four workgroups with helper waves
-  const bool timing = getenv("CRUX_MFMA_TIMING") != nullptr;
+  const bool timing = crux_sw().mfma_timing;
 #define FS_CASE2(I, O, K, A1, H, A2) if (in == I && out == O && kind == K && act == A1 && h2 == H && act2 == A2) { *handled = true; if (probe) return CRUX_OK; return launch_fs<I, O, K, A1, H, A2>(c, a, form, timing, stream); }
 #define FS_CASE(I, O, K, A_) FS_CASE2(I, O, K, A_, 64, A_)
   FS_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)     // C2 actor  (PPO CartPole)

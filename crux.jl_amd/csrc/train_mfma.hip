@@ -19,7 +19,7 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hip
 int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream) {
   *handled = false;
   const NetDesc& nd = a.nd;
-  if (getenv("CRUX_FORCE_GENERIC")) return CRUX_OK;      // parity tests run the same cases through the generic learner
+  if (crux_sw().force_generic) return CRUX_OK;      // parity tests run the same cases through the generic learner
   // 0. full minibatch loops (with or without a replica group): the feature-split kernel on four compute units
   { const int32_t rc = crux_train_fs_launch(c, a, handled, stream); if (rc || *handled) return rc; }
   if (nd.L != 3 || nd.dims[1] != MF_HID || nd.dims[2] != MF_HID || nd.acts[2] != CRUX_ACT_IDENTITY || nd.acts[0] != nd.acts[1]) return CRUX_OK;

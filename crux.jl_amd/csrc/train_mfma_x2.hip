@@ -27,7 +27,7 @@ extern "C" int crux_x2_placement_ok(crux_ctx* c) {
   }
   (void)hipFree(d);
   cached = ok ? 1 : 0;
-  if (!ok && getenv("CRUX_VERBOSE")) fprintf(stderr, "[cruxhip] workgroups are not placed round-robin over XCDs: two-CU learner kernel disabled\n");
+  if (!ok && crux_sw().verbose) fprintf(stderr, "[cruxhip] workgroups are not placed round-robin over XCDs: two-CU learner kernel disabled\n");
   return cached;
 }
 
@@ -105,7 +105,7 @@ int32_t crux_train_mfma_x2_launch_multi(crux_ctx* c, std::vector<TrainArgs>& as,
 // (workgroup 1 then idles on empty tiles) -- used for the shapes that have no one-CU instantiation.
 int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream, bool any_mode) {
   *handled = false;
-  static const bool off = getenv("CRUX_MFMA_X2") && getenv("CRUX_MFMA_X2")[0] == '0';
+  const bool off = !crux_sw().mfma_x2;
   if (off) return CRUX_OK;
   if (!any_mode && (a.ids || !a.apply || a.bs <= 64 || a.len < a.bs)) return CRUX_OK;     // single steps and small batches stay on one CU when it has the shape
   if (!x2_placement_ok(c)) return CRUX_OK;
@@ -120,7 +120,7 @@ int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, boo
 #undef MFXL_CASE
     return CRUX_OK;
   }
-  if (getenv("CRUX_MFMA_TIMING") && ((in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) || (in == 17 && out == 6 && kind == MFK_GAUSSIAN && act == CRUX_ACT_TANH))) {
+  if (crux_sw().mfma_timing && ((in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) || (in == 17 && out == 6 && kind == MFK_GAUSSIAN && act == CRUX_ACT_TANH))) {
     static unsigned long long* dbg = nullptr;
     if (!dbg) { if (hipMalloc(&dbg, 128 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
     TrainArgs b = a; b.dbg = dbg; *handled = true;

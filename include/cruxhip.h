@@ -41,6 +41,9 @@ typedef struct crux_env crux_env;
 /* lifecycle --------------------------------------------------------------------------------- */
 /* stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create a private one. */
 int32_t crux_ctx_create(int32_t device_id, void* stream, crux_ctx** out);
+/* The CRUX_* environment switches (development / test knobs) are read when a context is created, into one process-wide snapshot; a process that
+ * changes one afterwards calls this to have it take effect. */
+int32_t crux_reload_switches(void);
 int32_t crux_ctx_destroy(crux_ctx* ctx);
 /* How many CUs one small-MLP learner (batch_train!, src/training.jl:28-55) occupies: 0 = automatic (two CUs of one XCD per learner; the batched
  * multi-learner call switches to one CU per learner above 64 learners), 1 = always one CU (k_train_mfma8), 2 = two CUs where the shape allows

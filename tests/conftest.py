@@ -19,3 +19,36 @@ def gpu_ctx():
     """A libcruxhip context on device 0. GPU tests FAIL (not skip) when the HIP library or device is missing."""
     import crux_jl_amd as crux
     return crux.default_context()
+
+
+def _reload_switches():
+    """the library reads its CRUX_* switches when a context is created (csrc/switches.h); a test that changes one mid-process has them re-read"""
+    try:
+        import crux_jl_amd as crux
+        crux.reload_switches()
+    except Exception:       # noqa: BLE001  (CPU-only run: no library to tell)
+        pass
+
+
+@pytest.fixture
+def monkeypatch():
+    """pytest's monkeypatch, with setenv / delenv of a CRUX_* variable followed by crux_reload_switches() (and once more after the undo)."""
+    from _pytest.monkeypatch import MonkeyPatch
+    mp = MonkeyPatch()
+
+    class _MP:
+        def setenv(self, k, v, *a, **kw):
+            mp.setenv(k, v, *a, **kw)
+            if k.startswith("CRUX_"):
+                _reload_switches()
+
+        def delenv(self, k, *a, **kw):
+            mp.delenv(k, *a, **kw)
+            if k.startswith("CRUX_"):
+                _reload_switches()
+
+        def __getattr__(self, n):
+            return getattr(mp, n)
+    yield _MP()
+    mp.undo()
+    _reload_switches()

@@ -6,6 +6,6 @@ import dense_learner_bench as d
 
 if __name__ == "__main__":
     for fs in ("1", "0"):
-        os.environ["CRUX_FS"] = fs
+        os.environ["CRUX_FS"] = fs; d.crux.reload_switches()
         r = d.run([17, 64, 32, 6], ["tanh", "tanh", "identity"], False, 17, 6, E=32, T=512, epochs=4)
         print("17-64-32-6 tanh Gaussian actor, CRUX_FS=%s (%s): actor %.2f us/step, critic (17-64-32-1 tanh tanh) %.2f us/step" % (fs, "feature-split kernel" if fs == "1" else "dense engine", r["actor"], r["critic"]))

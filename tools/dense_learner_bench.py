@@ -7,9 +7,9 @@ import crux_jl_amd as crux
 
 def run(dims_a, acts, disc, od, ad, E=32, T=512, bs=128, epochs=2, force_generic=False):
     if force_generic:
-        os.environ["CRUX_FORCE_GENERIC"] = "1"
+        os.environ["CRUX_FORCE_GENERIC"] = "1"; crux.reload_switches()
     else:
-        os.environ.pop("CRUX_FORCE_GENERIC", None)
+        os.environ.pop("CRUX_FORCE_GENERIC", None); crux.reload_switches()
     ch = crux.Chain(*[crux.Dense(dims_a[i], dims_a[i + 1], acts[i]) for i in range(len(acts))])
     A = crux.DiscreteNetwork(ch, list(range(1, ad + 1)), seed=1) if disc else crux.GaussianPolicy(ch, np.full(ad, -0.5, np.float32), seed=1)
     cd = dims_a[:-1] + [1]

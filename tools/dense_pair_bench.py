@@ -24,7 +24,7 @@ class _Solver:          # the fields policy_gradient_training reads
 sv = _Solver(); sv.agent = _Agent(); sv.agent.pi = crux.ActorCritic(A, Cn); sv.a_opt, sv.c_opt, sv.P, sv.param_optimizers = a_opt, c_opt, P, []
 ctx = buf.ctx
 for mode in ("1", "0", "1", "0"):
-    os.environ["CRUX_DENSE_PAIR"] = mode
+    os.environ["CRUX_DENSE_PAIR"] = mode; crux.reload_switches()
     ctx.sync(); t0 = time.perf_counter(); info = crux.policy_gradient_training(sv, buf); ctx.sync(); dt = time.perf_counter() - t0
     steps = info["actor_batches_trained"]
     print("CRUX_DENSE_PAIR=%s width %d: %.1f us per (actor + critic) minibatch step, %d steps each, actor loss %.6f critic loss %.6f" % (mode, W, 1e6 * dt / steps, steps, info["actor_loss"], info["critic_loss"]), flush=True)

@@ -8,7 +8,7 @@ import ctypes as C
 
 def chain(dims, acts): return crux.Chain(*[crux.Dense(dims[i], dims[i + 1], acts[i]) for i in range(len(acts))])
 def run(persist, n_ep, per=True, B=128, N=20_000, no=8, na=4):
-    os.environ["CRUX_DQN_PERSIST"] = "1" if persist else "0"
+    os.environ["CRUX_DQN_PERSIST"] = "1" if persist else "0"; crux.reload_switches()
     rng = np.random.default_rng(3)
     S, A = crux.ContinuousSpace(no), crux.DiscreteSpace(na)
     buf = crux.ExperienceBuffer(S, A, N, prioritized=per); D = crux.buffer_like(buf, capacity=B)
