@@ -17,11 +17,15 @@ static int32_t launch_fs_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
 // form: 2 = two workgroups of eight waves; 4 = four workgroups of four waves; 8 = four workgroups of four compute + four helper waves (the only form of the 32-wide second layer)
 // (the shapes added in round 3 for the standard Gym tasks -- IN > 17 or not one of the benchmark shapes -- are instantiated in the default form only: FS_LITE)
 template <int IN, int OUT> constexpr bool FS_LITE = !((IN == 4 && (OUT == 2 || OUT == 1)) || (IN == 3 && OUT == 1) || (IN == 17 && (OUT == 6 || OUT == 1)) || (IN == 8 && (OUT == 4 || OUT == 1)) || (IN == 2 && OUT == 1));
+template <int IN, int OUT> constexpr bool FS_WIDE_HEAD = IN == 27 && OUT == 8;
 template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, bool TIMING>
 static int32_t launch_fs_pick(crux_ctx* c, TrainArgs& a, int form, hipStream_t stream) {
   if constexpr (H2 == 64 && ACT2 == ACT && !FS_LITE<IN, OUT>) {
     if (form == 2) return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 2, false, TIMING, false>(c, a, stream);
     if (form == 4) return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, false, TIMING, false>(c, a, stream);
+  }
+  if constexpr (H2 == 64 && ACT2 == ACT && FS_WIDE_HEAD<IN, OUT> && !TIMING) {      // wide Gaussian heads (Ant 27 / 8): four waves per workgroup have 512 registers each, the helper-wave form spilled 52
+    if (form == 4 || form == 0) return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, false, false, false>(c, a, stream);
   }
   return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, true, TIMING, false>(c, a, stream);
 }
