@@ -336,8 +336,8 @@ def setup_group(args, crux, ctx, rank, world, local):
 def run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P):
     """The first thing a multi-GPU run should do on new hardware: exercise the in-kernel exchange across the REAL devices before anything is timed.
     (1) identical shards: every rank trains on the same rows, so the SUM over ranks / N equals each rank's own gradient up to the rounding of (N - 1) additions -- the
-        group must reproduce an un-grouped learner of a second context on rank 0 (bit for bit at N = 2, where g + g and the division by two are exact), and a lost,
-        torn or stale slot read shows up as a different sum;
+        group must reproduce an un-grouped learner of a second context on rank 0 (to 1e-6 at N = 2, where g + g and the division by two are exact and only the two
+        compilations of the step differ in the last place; bit equality is reported separately), and a lost, torn or stale slot read shows up as a different sum;
     (2) distinct shards: 64 minibatch steps per learner, the replicas' parameters and Adam state must be bit-identical afterwards;
     (3) flag-wait histograms of (2), one per rank: how long each learner workgroup waited for the slowest peer per exchange;
     (4) the library's own RCCL communicator (crux_comm_init, crux_allreduce_grads -- ncclAllReduce over xGMI): a known vector summed over the ranks.
@@ -367,7 +367,10 @@ def run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P):
             ppo_iteration(crux, pi2, buf2, smp2, pa2, pc2, P, 0, None); ctx2.sync()
             ref = np.concatenate([pi2.A.get_params(), pi2.C.get_params()])
             res["identical_shards_max_abs_diff_vs_single_learner"] = float(np.abs(ref - mine).max())
-            res["identical_shards_ok"] = bool(np.array_equal(ref, mine)) if world == 2 else bool(np.abs(ref - mine).max() < 1e-5)
+            # (N = 2: g + g and the division by two are exact, so any difference comes from the two compilations of the step -- the group's kernel is another instantiation of
+            #  k_train_fs than the un-grouped learner's, and the compiler's FMA contraction may differ in the last place; a lost, torn or stale slot read is orders larger)
+            res["identical_shards_bit_identical_to_single_learner"] = bool(np.array_equal(ref, mine))
+            res["identical_shards_ok"] = bool(np.abs(ref - mine).max() < (1e-6 if world == 2 else 1e-5))
         finally:
             crux.set_default_context(prev)
     # (2) + (3) distinct shards, histograms on
