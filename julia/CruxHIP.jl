@@ -246,6 +246,9 @@ end
 peer_export(c::Ctx) = (h = zeros(UInt8, 64); check(c, ccall((:crux_peer_export, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}), c.h, h)); h)
 peer_attach!(c::Ctx, rank::Integer, nranks::Integer, handles::Vector{UInt8}) = check(c, ccall((:crux_peer_attach, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), c.h, rank, nranks, handles))
 peer_detach!(c::Ctx) = check(c, ccall((:crux_peer_detach, LIB), Int32, (Ptr{Cvoid},), c.h))
+# periodic form (round 4): k = 1 exchanges the gradient every minibatch (exact); k > 1: local Adam steps, theta / m / v averaged in the kernel after every k-th
+peer_set_sync_every!(c::Ctx, k::Integer) = check(c, ccall((:crux_peer_set_sync_every, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, k))
+reload_switches!() = ccall((:crux_reload_switches, LIB), Int32, ())      # after changing a CRUX_* switch inside a running process
 
 # ---------------------------------------------------------------------------------------------------- off-policy: value_training and its pieces
 # src/model_free/off_policy.jl:66-111. 𝒟 is the staging HipBuffer of batch_size rows, 𝒮.buffer the replay HipBuffer.
