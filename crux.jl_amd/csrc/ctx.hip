@@ -5,7 +5,7 @@
 int32_t crux_fail(crux_ctx* ctx, int32_t code, const char* fmt, ...) {
   char buf[1024];
   va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-  if (ctx) ctx->err = buf;
+  if (ctx) { static std::mutex mu; std::lock_guard<std::mutex> lk(mu); ctx->err = buf; }      // (dense_pair drives two learner chains of one context from two host threads: ADVICE r3)
   return code;
 }
 

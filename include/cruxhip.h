@@ -463,7 +463,12 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
                        uint64_t sample_counter, float* info_out);
 /* The epoch loop of value_training (off_policy.jl:69: `for epoch in 1:c_opt.epochs`; DQN's c_opt.epochs = dN, rl/dqn.jl) as ONE recorded list: n_epochs epochs back to
  * back, one upload, 10 phase launches per chained epoch (13 phases; the next epoch's sampling and first layer share launches with the optimizer tail), one read-back -- no host round trip between the epochs of an iteration (~60 us each). Epoch e draws with sample counter
- * sample_counter0 + e; infos: host [n_epochs x CRUX_INFO_N]. Same results as n_epochs calls of crux_dqn_epoch.                                         */
+ * sample_counter0 + e; infos: host [n_epochs x CRUX_INFO_N]. Same results as n_epochs calls of crux_dqn_epoch.
+ * Round 4: networks of the C3 family (L = 3, hidden 128 / 192 / 256, out <= 4) take the tile plan -- 4 launches per chained epoch (exec.hip dqn_epoch_tiles).
+ * NaN (training.jl:20 "NaN detected!"): the step that sees it and every later step of the SAME network in the chain leave parameters and Adam state untouched (the status word
+ * gates them on the device), but the chain itself runs to its end -- sampling, target-network updates and steps of OTHER networks continue -- and CRUX_ENAN is reported when the
+ * chain's rows are read back (at the latest at the end of the call; the *_async forms report it when the caller resolves the info rows). The reference stops at the first NaN
+ * step; a caller that needs that state should use the per-epoch entry points.                                                                                       */
 int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
                         uint64_t sample_counter0, int32_t n_epochs, float* infos);
 /* The same epoch loop with softq_target(alpha) (rl/softq.jl:4-13) in place of dqn_target: value_training of the SoftQ solver (rl/softq.jl:31-58).             */
