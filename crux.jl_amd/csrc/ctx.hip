@@ -1,6 +1,7 @@
 // ctx.hip -- context lifecycle, error reporting, scratch memory, HIP-event kernel timing.
 #include "common.h"
 #include <cstdarg>
+#include <mutex>
 
 int32_t crux_fail(crux_ctx* ctx, int32_t code, const char* fmt, ...) {
   char buf[1024];
