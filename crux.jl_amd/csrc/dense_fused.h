@@ -29,9 +29,7 @@ struct Fwd12Op { static __device__ __forceinline__ void run(const unsigned bid_,
   // Latency, not bandwidth, bounds these blocks (a global load is a 1-2 us round trip here: the weights were just rewritten by Adam on other XCDs): every global
   // load of the wave -- observations, layer-0 weight fragments and biases, its layer-1 weight fragments -- is issued before the first use.
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  // block -> (feature tile bi, sample tile bj): the sample tile varies fastest, so that with 8 | tJ all feature tiles of sample tile j sit on XCD j mod 8 (workgroups are dealt
-  // round-robin over the XCDs) -- what lets a per-sample-tile consumer follow in the same launch behind ONE L2 (the executor's ticket tails, exec.hip k_phase_k)
-  const int tJ = (q.B + 15) >> 4; const int bj = (int)bid_ % tJ, bi = (int)bid_ / tJ; const int i0 = bi << 4, j0 = bj << 4;
+  const int tI = q.out2 >> 4; const int bi = (int)bid_ % tI, bj = (int)bid_ / tI; const int i0 = bi << 4, j0 = bj << 4;
   const int K = q.out1, kper = K >> 2, ng = kper >> 4;          // df_fwd12_ok: K in {128, 192, 256} -> kper = df_kper(K) = K / 4, 2..4 sixteen-groups per quarter
   const int s = j0 + c; const bool vs = s < q.B; const bool u1 = q.in0 > 16; const int sc = vs ? s : q.B - 1;
   float xb[2][4];

@@ -23,10 +23,7 @@ enum {
 };
 
 #define CRUX_EXEC_ARG_BYTES 768
-// barrier: bit 0 = last op of its phase; bit 1 = sequential tail (runs in the one block of the op before it); bit 2 = TICKET tail: a per-16-sample-tile op that owns no blocks --
-// the workgroup of a ticket PRODUCER (bit 3: the Fwd12Op launches of the phase) that draws the last ticket of sample tile j runs it for tile j (round 4, exec.hip k_phase_k).
-// aux: producer = its blocks per sample tile; ticket tail = its tile count. tk / tk_expect: the phase's ticket words (zeroed by the epoch's fills) and the tickets per tile.
-struct ExecOp { int32_t kid; uint32_t nblocks; int32_t barrier; int32_t abytes; uint32_t aux; uint32_t tk_expect; unsigned* tk; alignas(8) unsigned char args[CRUX_EXEC_ARG_BYTES]; };   // abytes: size of the packed arguments actually used
+struct ExecOp { int32_t kid; uint32_t nblocks; int32_t barrier; int32_t abytes; alignas(8) unsigned char args[CRUX_EXEC_ARG_BYTES]; };   // abytes: size of the packed arguments actually used
 
 // ---- argument packs: the parameters of XOp::run after (bid, nblocks), stored by value in declaration order --------------------------------
 template <class... T> struct ArgPack;

@@ -116,25 +116,10 @@ __device__ __forceinline__ bool exec_barrier(unsigned* ctr, unsigned wg, unsigne
       }
 
 
-// the per-sample-tile ops that may run as TICKET tails of the phase's Fwd12Op launches (see k_phase_k)
-#define EXEC_SWITCH_TICKET(DISPATCH) \
-      switch (kid) { \
-        case OP_DQN_TD_TILE: DISPATCH<DqnTdTileOp>(op, b); break; \
-        case OP_ACTOR_EXPLORE_TILE: DISPATCH<ActorExploreTileOp>(op, b); break; \
-        case OP_SAC_CRITIC_TILE: DISPATCH<SacCriticTileOp>(op, b); break; \
-        case OP_SAC_ACTOR_TILE: DISPATCH<SacActorTileOp>(op, b); break; \
-        default: break; \
-      }
-static inline bool exec_ticket_tail_ok(int kid) { return kid == OP_DQN_TD_TILE || kid == OP_ACTOR_EXPLORE_TILE || kid == OP_SAC_CRITIC_TILE || kid == OP_SAC_ACTOR_TILE; }
-
 // the same dispatch with the record read straight from global memory at a uniform address (scalar loads): the one-launch-per-phase form below
 template <class Op> __device__ __forceinline__ void exec_dispatch_g(const ExecOp* op, unsigned bid) {
   const OpPack<Op> p = *(const OpPack<Op>*)op->args;
   exec_apply<Op>(bid, op->nblocks, p);
-}
-template <class Op> __device__ __forceinline__ void exec_dispatch_gt(const ExecOp* op, unsigned bid) {      // a ticket tail: its tile count rides in aux (nblocks counts no blocks of the grid)
-  const OpPack<Op> p = *(const OpPack<Op>*)op->args;
-  exec_apply<Op>(bid, op->aux, p);
 }
 // the replay ops alone (dqn_persist.h: k_dqn_replay); the gather's column table is read where it lies
 #define EXEC_SWITCH_REPLAY(DISPATCH) \
@@ -160,21 +145,9 @@ __global__ __launch_bounds__(256) void k_phase(const ExecOp* __restrict__ ops, i
   constexpr int EXEC_HEAVY = 2;
   // ops flagged sequential (barrier bit 1) own no blocks: they run in the block of the op before them, after it (see k_phase_k)
   unsigned b = blockIdx.x; int o = 0;
-  for (;;) { const unsigned nb = (ops[o].barrier & 6) ? 0u : ops[o].nblocks; if (o + 1 < n && b >= nb) { b -= nb; ++o; } else break; }
+  for (;;) { const unsigned nb = (ops[o].barrier & 2) ? 0u : ops[o].nblocks; if (o + 1 < n && b >= nb) { b -= nb; ++o; } else break; }
   { const ExecOp* op = ops + o; const int kid = op->kid;
     EXEC_SWITCH(exec_dispatch_g) }
-  if (ops[o].barrier & 8) {      // ticket producer (see k_phase_k)
-    __shared__ int last_g; const unsigned j = b % ops[o].aux;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) last_g = __hip_atomic_fetch_add(ops[o].tk + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ops[o].tk_expect - 1u ? 1 : 0;
-    __syncthreads();
-    if (!last_g) return;
-    asm volatile("buffer_inv sc0" ::: "memory");
-    for (int q = 0; q < n; ++q) if (ops[q].barrier & 4) { ExecOp tmp_hdr; (void)tmp_hdr; b = j; const ExecOp* op = ops + q; const int kid = op->kid;
-      EXEC_SWITCH_TICKET(exec_dispatch_gt) __syncthreads(); }
-    return;
-  }
   while (o + 1 < n && (ops[o + 1].barrier & 2)) { __threadfence(); __syncthreads(); ++o; b = 0;
     const ExecOp* op = ops + o; const int kid = op->kid;
     EXEC_SWITCH_TAIL(exec_dispatch_g) }
@@ -186,9 +159,8 @@ __global__ __launch_bounds__(256) void k_phase(const ExecOp* __restrict__ ops, i
 // The argument struct comes in three sizes (the host copies it on every launch: with 4 KB per launch the enqueue, not the GPU, paced a SAC epoch).
 #define PHASEK_MAXOPS 14
 #define PHASEK_SEQ 0x10000
-#define PHASEK_TICKET 0x20000
-template <int BYTES> struct PhaseK { int32_t n; uint32_t tk_expect; unsigned* tk; int32_t kid[PHASEK_MAXOPS]; uint32_t nblocks[PHASEK_MAXOPS]; uint32_t off[PHASEK_MAXOPS]; uint32_t aux[PHASEK_MAXOPS]; alignas(16) unsigned char args[BYTES]; };
-static_assert(sizeof(PhaseK<3808>) <= 4096, "HIP kernel arguments are limited to 4 KB");
+template <int BYTES> struct PhaseK { int32_t n; int32_t pad; int32_t kid[PHASEK_MAXOPS]; uint32_t nblocks[PHASEK_MAXOPS]; uint32_t off[PHASEK_MAXOPS]; alignas(16) unsigned char args[BYTES]; };
+static_assert(sizeof(PhaseK<3840>) <= 4096, "HIP kernel arguments are limited to 4 KB");
 struct KOp { const unsigned char* args; unsigned nblocks; };
 template <class Op> __device__ __forceinline__ void exec_dispatch_k(const KOp* op, unsigned bid) {
   const OpPack<Op> p = *(const OpPack<Op>*)op->args;
@@ -212,42 +184,20 @@ __global__ __launch_bounds__(256) void k_phase_k(PhaseK<BYTES> by_value) {
   // Same compute unit, write-through L1: the fence + workgroup barrier make the first op's global stores visible to the second.
   { const int kid = pk->kid[o]; const KOp kop{pk->args + pk->off[o], pk->nblocks[o]}; const KOp* op = &kop;
     EXEC_SWITCH(exec_dispatch_k) }
-  // Ticket tails (kid flagged PHASEK_TICKET, no blocks of their own): per-16-sample-tile ops that consume what the phase's Fwd12Op launches (aux != 0: the number of sample
-  // tiles; block b of such an op works on sample tile b mod aux) produce for that tile. The producers come FIRST in the phase's block order and 8 | aux, so every workgroup of
-  // sample tile j sits on XCD j mod 8 (round-robin dealing, probed: crux_x2_placement_ok) -- behind ONE L2. A producer drains its stores (they are in that L2 then), the workgroup
-  // meets and draws a ticket of its sample tile; the workgroup that draws the last one runs the tails for j, reading the tiles from the shared L2. No workgroup waits for another,
-  // no cache is written back or walked (a device-scope release / acquire per producer measured 2x SLOWER than the separate launches it replaced: buffer_wbl2 / buffer_inv sc1
-  // walk the L2), and a [forward | tile op] pair costs one launch instead of two (~5.2 us each back to back).
-  if (pk->tk != nullptr && pk->aux[o] != 0u && !(pk->kid[o] & (PHASEK_TICKET | PHASEK_SEQ))) {
-    __shared__ int last_k; const unsigned j = b % pk->aux[o];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores of the tile have reached the L2 its consumers share
-    __syncthreads();
-    if (threadIdx.x == 0) last_k = __hip_atomic_fetch_add(pk->tk + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pk->tk_expect - 1u ? 1 : 0;
-    __syncthreads();
-    if (!last_k) return;
-    asm volatile("buffer_inv sc0" ::: "memory");          // (L1 only: nothing of these tiles can be in this compute unit's L1 from before the launch, but cheap)
-#pragma unroll 1
-    for (int q = 0; q < n; ++q) if (pk->kid[q] & PHASEK_TICKET) { b = j;
-      const int kid = pk->kid[q] & (PHASEK_SEQ - 1); const KOp kop{pk->args + pk->off[q], pk->aux[q]}; const KOp* op = &kop;
-      EXEC_SWITCH_TICKET(exec_dispatch_k) __syncthreads(); }
-    return;
-  }
   while (o + 1 < n && (pk->kid[o + 1] & PHASEK_SEQ)) { __threadfence(); __syncthreads(); ++o; b = 0;
     const int kid = pk->kid[o] & (PHASEK_SEQ - 1); const KOp kop{pk->args + pk->off[o], 1u}; const KOp* op = &kop;
     EXEC_SWITCH_TAIL(exec_dispatch_k) }
 }
 // host: pack ops [i0, i1] of a recording into a PhaseK<BYTES>; false when they do not fit
 template <int BYTES> static bool phasek_launch(const std::vector<ExecOp>& ops, size_t i0, size_t i1, unsigned blocks, hipStream_t st) {
-  PhaseK<BYTES> pk; pk.n = 0; pk.tk_expect = 0; pk.tk = nullptr; size_t used = 0;
+  PhaseK<BYTES> pk; pk.n = 0; pk.pad = 0; size_t used = 0;
   for (size_t i = i0; i <= i1; ++i) { const ExecOp& e = ops[i]; if (!e.nblocks) continue;
     const size_t raw = (size_t)(e.abytes > 0 ? e.abytes : CRUX_EXEC_ARG_BYTES), ab = (raw + 15) & ~(size_t)15;
     if (pk.n >= PHASEK_MAXOPS || used + ab > (size_t)BYTES) return false;
-    const bool seq = (e.barrier & 2) != 0, tkt = (e.barrier & 4) != 0, prod = (e.barrier & 8) != 0;
-    pk.kid[pk.n] = e.kid | (seq ? PHASEK_SEQ : 0) | (tkt ? PHASEK_TICKET : 0); pk.nblocks[pk.n] = (seq || tkt) ? 0u : e.nblocks; pk.off[pk.n] = (uint32_t)used;
-    pk.aux[pk.n] = tkt ? e.nblocks : prod ? e.aux : 0u; if (prod) { pk.tk = e.tk; pk.tk_expect = e.tk_expect; }
-    memcpy(pk.args + used, e.args, raw); used += ab; pk.n++; }
+    const bool seq = (e.barrier & 2) != 0;
+    pk.kid[pk.n] = e.kid | (seq ? PHASEK_SEQ : 0); pk.nblocks[pk.n] = seq ? 0u : e.nblocks; pk.off[pk.n] = (uint32_t)used; memcpy(pk.args + used, e.args, raw); used += ab; pk.n++; }
   if (pk.n == 0) return false;
-  for (int q = pk.n; q < PHASEK_MAXOPS; ++q) { pk.kid[q] = 0; pk.nblocks[q] = 0; pk.off[q] = 0; pk.aux[q] = 0; }
+  for (int q = pk.n; q < PHASEK_MAXOPS; ++q) { pk.kid[q] = 0; pk.nblocks[q] = 0; pk.off[q] = 0; }
   int heavy = 0;      // 0: no Dgrad2W1Op in the phase; 1: its O3 = 1 form (critics / no folded output layer); 2: the O3 = 4 form
   for (int q = 0; q < pk.n; ++q) if ((pk.kid[q] & (PHASEK_SEQ - 1)) == OP_DGRAD2W1) { Dgrad2Args a; memcpy(&a, pk.args + pk.off[q], sizeof a); heavy = std::max(heavy, (a.z.W3 && a.z.out3 > 1) ? 2 : 1); }
   if (heavy == 2) hipLaunchKernelGGL((k_phase_k<BYTES, 2>), dim3(blocks), dim3(256), 0, st, pk);
@@ -255,12 +205,12 @@ template <int BYTES> static bool phasek_launch(const std::vector<ExecOp>& ops, s
   else hipLaunchKernelGGL((k_phase_k<BYTES, 0>), dim3(blocks), dim3(256), 0, st, pk);
   return true;
 }
-// would phasek_launch<3808> take ops [i0, i1]? (the same packing rules, nothing launched)
+// would phasek_launch<3840> take ops [i0, i1]? (the same packing rules, nothing launched)
 static bool phasek_fits(const std::vector<ExecOp>& ops, size_t i0, size_t i1) {
   int n = 0; size_t used = 0;
   for (size_t i = i0; i <= i1; ++i) { const ExecOp& e = ops[i]; if (!e.nblocks) continue;
     const size_t raw = (size_t)(e.abytes > 0 ? e.abytes : CRUX_EXEC_ARG_BYTES), ab = (raw + 15) & ~(size_t)15;
-    if (n >= PHASEK_MAXOPS || used + ab > (size_t)3808) return false;
+    if (n >= PHASEK_MAXOPS || used + ab > (size_t)3840) return false;
     used += ab; ++n; }
   return n > 0;
 }
@@ -408,7 +358,7 @@ void crux_exec_destroy(crux_ctx* c) {
 void crux_exec_abort(crux_ctx* c) { if (c->rec) { ExecRec* r = rec_of(c); r->active = false; r->ops.clear(); r->readbacks.clear(); } }
 ExecOp* crux_exec_new_op(crux_ctx* c, int kid, unsigned nblocks) {
   ExecRec* r = rec_of(c); r->ops.emplace_back(); ExecOp* op = &r->ops.back();
-  op->kid = kid; op->nblocks = nblocks; op->barrier = 1; op->abytes = 0; op->aux = 0; op->tk_expect = 0; op->tk = nullptr; return op;
+  op->kid = kid; op->nblocks = nblocks; op->barrier = 1; op->abytes = 0; return op;
 }
 void* crux_exec_scratch(crux_ctx* c, size_t bytes) {
   ExecRec* r = rec_of(c); bytes = (bytes + 255) / 256 * 256;
@@ -444,27 +394,7 @@ static int32_t exec_schedule(crux_ctx* c, const std::vector<int>& phase) {
       // the in-block tail switch (EXEC_SWITCH_TAIL) knows these bodies only: anything else would be skipped silently
       if (out[k].kid != OP_TD_HEAD && out[k].kid != OP_Q_HEAD && out[k].kid != OP_PER_UPDATE) return crux_fail(c, CRUX_EHIP, "executor: op %d cannot run as a sequential tail", out[k].kid);
       if (k == 0 || (phase[idx[k - 1]] >> 2) != (phase[idx[k]] >> 2) || out[k].nblocks != 1 || out[k - 1].nblocks != 1) return crux_fail(c, CRUX_EHIP, "executor: a sequential op without a one-block predecessor in its phase");
-      out[k].barrier |= 2; }
-    if ((phase[idx[k]] & 3) == 3) {      // ticket tail: owns no blocks; the phase's Fwd12Op launches are its producers (k_phase_k)
-      if (!exec_ticket_tail_ok(out[k].kid) || !out[k].tk) return crux_fail(c, CRUX_EHIP, "executor: op %d cannot run as a ticket tail", out[k].kid);
-      out[k].barrier |= 4; } }
-  // ticket groups: one per phase -- every Fwd12Op of a phase that holds ticket tails is a producer; tickets per sample tile = the producers' blocks per tile
-  for (size_t a = 0; a < n; ) { size_t b = a; while (!(out[b].barrier & 1) && b + 1 < n) ++b;
-    unsigned* tk = nullptr; bool any = false, same = true; unsigned ntiles = 0;
-    for (size_t k = a; k <= b; ++k) if (out[k].barrier & 4) { if (any && (out[k].tk != tk || out[k].nblocks != ntiles)) same = false; any = true; tk = out[k].tk; ntiles = out[k].nblocks; }
-    if (any) {
-      if (!same) return crux_fail(c, CRUX_EHIP, "executor: the ticket tails of a phase must share their ticket words and tile count");
-      unsigned expect = 0;
-      for (size_t k = a; k <= b; ++k) if (out[k].kid == OP_FWD12 && !(out[k].barrier & 6)) { Fwd12Args fa; memcpy(&fa, out[k].args, sizeof fa);
-        const unsigned per = (unsigned)(fa.out2 >> 4); if (!per || out[k].nblocks != per * ntiles) return crux_fail(c, CRUX_EHIP, "executor: a ticket producer does not cover the tails' %u sample tiles", ntiles);
-        out[k].aux = ntiles; out[k].barrier |= 8; expect += per; }
-      if (!expect || (ntiles & 7u)) return crux_fail(c, CRUX_EHIP, "executor: ticket tails need producers in their phase and a multiple of 8 sample tiles (%u)", ntiles);
-      for (size_t k = a; k <= b; ++k) if (out[k].barrier & 8) { out[k].tk = tk; out[k].tk_expect = expect; }
-      // producers first: their blocks then start at a multiple of 8 in the phase's block order (block count of a producer = tiles x 8 | ntiles)
-      const bool last_bit = (out[b].barrier & 1) != 0; out[b].barrier &= ~1;
-      std::stable_partition(out.begin() + (long)a, out.begin() + (long)b + 1, [](const ExecOp& e) { return (e.barrier & 8) != 0; });
-      if (last_bit) out[b].barrier |= 1; }
-    a = b + 1; }
+      out[k].barrier |= 2; } }
   r->ops.swap(out); return CRUX_OK;
 }
 // launches of the dense engine inside a recorded chain: a tile GEMM, or one of the fused block kernels of dense_fused.h (round 4). The phase plans below count THESE
@@ -478,7 +408,6 @@ static inline NetPlan net_plan(const crux_mlp* n, int64_t B) { const int L = n->
   return NetPlan{ff ? L - 1 : L, f3 ? 3 : fb ? 2 * (L - 1) : 2 * L - 1, f3 ? 1 : fb ? L - 1 : L, f3 ? 2 : L, f3}; }
 #define PH_SEQ_HEAD (1 << 12)
 #define PH_SEQ_TAIL (2 << 12)
-#define PH_TICKET (3 << 12)
 static inline int ph_tag(int p_mapped, int sub) { return 4 * p_mapped + sub; }
 
 int32_t crux_exec_run(crux_ctx* c) {
@@ -493,13 +422,13 @@ int32_t crux_exec_run(crux_ctx* c) {
     if (r->d_ops_cap < ob) { if (r->d_ops) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(r->d_ops); } r->d_ops_cap = ob * 2 + 4096; if (hipMalloc(&r->d_ops, r->d_ops_cap) != hipSuccess) { r->d_ops = nullptr; r->d_ops_cap = 0; return crux_fail(c, CRUX_ENOMEM, "executor: op list"); } }
     const bool async = r->async; r->async = false;
     void* stage = nullptr;
-    r->ops.back().barrier &= ~1;
+    r->ops.back().barrier &= 2;
     // an asynchronous chain whose phases all travel in kernel arguments needs neither the device copy of the list nor the zeroed counters (no persistent form, no status
     // read-back): two stream operations less between chains (they sit IN the stream there, ~15 us per chain)
     bool lean = false;
     if (async && !r->dqp.on && !crux_sw().exec_persistent && !crux_sw().exec_no_kernarg) { lean = true;
       size_t i0 = 0;
-      while (i0 < nops && lean) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += (r->ops[i1].barrier & 6) ? 0u : r->ops[i1].nblocks; if ((r->ops[i1].barrier & 1) || i1 + 1 == nops) break; ++i1; }
+      while (i0 < nops && lean) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += (r->ops[i1].barrier & 2) ? 0u : r->ops[i1].nblocks; if ((r->ops[i1].barrier & 1) || i1 + 1 == nops) break; ++i1; }
         if (blocks && !phasek_fits(r->ops, i0, i1)) lean = false;
         i0 = i1 + 1; } }
     if (lean) { /* nothing to upload */ }
@@ -510,13 +439,13 @@ int32_t crux_exec_run(crux_ctx* c) {
       if (r->h_ring_cap[k] < ob) { if (r->h_ring[k]) (void)hipHostFree(r->h_ring[k]); r->h_ring_cap[k] = ob * 2 + 4096;
         if (hipHostMalloc(&r->h_ring[k], r->h_ring_cap[k], hipHostMallocDefault) != hipSuccess) { r->h_ring[k] = nullptr; r->h_ring_cap[k] = 0; return crux_fail(c, CRUX_ENOMEM, "executor: staging ring"); } }
       stage = r->h_ring[k];
-      r->ops.back().barrier &= ~1;
+      r->ops.back().barrier &= 2;
       memcpy(stage, r->ops.data(), ob);
       HIPCHK(c, hipMemcpyAsync(r->d_ops, stage, ob, hipMemcpyHostToDevice, c->stream));
       HIPCHK(c, hipEventRecord((hipEvent_t)r->h_ring_ev[k], c->stream));
     } else {
     if (r->h_stage_cap < need_h) { if (r->h_stage) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(r->h_stage); } r->h_stage_cap = need_h * 2 + 4096; if (hipHostMalloc(&r->h_stage, r->h_stage_cap, hipHostMallocDefault) != hipSuccess) { r->h_stage = nullptr; r->h_stage_cap = 0; return crux_fail(c, CRUX_ENOMEM, "executor: staging"); } }
-    r->ops.back().barrier &= ~1;
+    r->ops.back().barrier &= 2;
     memcpy(r->h_stage, r->ops.data(), ob);
     HIPCHK(c, hipMemcpyAsync(r->d_ops, r->h_stage, ob, hipMemcpyHostToDevice, c->stream));
     }
@@ -527,11 +456,11 @@ int32_t crux_exec_run(crux_ctx* c) {
       // default: one launch per phase over the whole chip (see k_phase). Measured against the persistent one-XCD form (CRUX_EXEC_PERSISTENT=1): the latter
       // saves the launches but runs every op on 32 CUs behind one L2 and pays ~2 us per barrier; DESIGN 4.3 has the numbers.
       size_t i0 = 0;
-      while (i0 < nops) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += (r->ops[i1].barrier & 6) ? 0u : r->ops[i1].nblocks; if ((r->ops[i1].barrier & 1) || i1 + 1 == nops) break; ++i1; }
+      while (i0 < nops) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += (r->ops[i1].barrier & 2) ? 0u : r->ops[i1].nblocks; if ((r->ops[i1].barrier & 1) || i1 + 1 == nops) break; ++i1; }
         if (blocks) {
           // the phase's records travel in the kernel arguments when they fit (see k_phase_k); zero-block ops are dropped there
           const bool no_kernarg = crux_sw().exec_no_kernarg;      // tests: every phase through the global-record form
-          if (no_kernarg || (!phasek_launch<384>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<1024>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<3808>(r->ops, i0, i1, blocks, c->stream)))
+          if (no_kernarg || (!phasek_launch<384>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<1024>(r->ops, i0, i1, blocks, c->stream) && !phasek_launch<3840>(r->ops, i0, i1, blocks, c->stream)))
             hipLaunchKernelGGL(k_phase, dim3(blocks), dim3(256), 0, c->stream, (const ExecOp*)r->d_ops + i0, (int)(i1 - i0 + 1));
         }
         i0 = i1 + 1; }
@@ -618,16 +547,15 @@ static int32_t dqn_epoch_tiles(crux_mlp* net, crux_mlp* tnet, crux_buffer* sourc
                                uint64_t sample_counter, float* info_out, float* d_y, float* d_err) {
   crux_ctx* c = net->ctx; const int64_t B = batch->capacity; const bool per = source->prioritized; const int nout = net->nd.dims[3], K = net->nd.dims[2];
   ExecRec* r = rec_of(c); const int base = r->chain_base; std::vector<int> ph; bool plan_ok = true; int32_t rc;
-  // Phases: 0 uniform ids | 1 search + gather / gather | 2 forward (both nets) -> td tile (+ update_priorities!) as the forward launches' TICKET tail | 3 pullback || leaf re-sum ->
-  // root paths (LeafTouchOp) | 4 norm || Adam (AdamSelfOp) | 5 info, beta-power advance. Chained: the sampling of epoch e + 1 runs beside the tail of epoch e -- ids beside 3,
-  // search + gather beside 4 (the replay tree is complete after 3; the gather rewrites the batch rows the pullback read: not before 4), forward + td beside 5 (after Adam):
-  // THREE launches per epoch.
+  // Phases: 0 uniform ids | 1 search + gather / gather | 2 forward (both nets) | 3 td tile (+ update_priorities!) | 4 pullback || leaf re-sum -> root paths (LeafTouchOp) |
+  // 5 norm || Adam (AdamSelfOp) | 6 info, beta-power advance. Chained: the sampling of epoch e + 1 runs beside the tail of epoch e -- ids beside 4, search + gather beside 5 (the
+  // replay tree is complete after 4; the gather rewrites the batch rows the pullback read: not before 5), forward beside 6 (after Adam): FOUR launches per epoch.
   const bool touch_split = per && (B > 256 || source->per_full_dirty);      // (root paths as an op of their own in 5: the search then waits one launch longer)
   const int ov = touch_split ? 2 : 3;
   auto bail = [&](int32_t e) { crux_exec_abort(c); return e; };
   size_t m = exec_mark(c); const size_t ops0 = m; r->epoch_marks.push_back(ops0);
   auto sect = [&](auto&& rule) { for (size_t i = m; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid); if (p < 0) { plan_ok = false; p = 0; }
-      const int sub = p >> 12; p &= 4095; ph.push_back(ph_tag(base > 0 ? base + p - ov : p, sub)); } m = r->ops.size(); };
+      ph.push_back(ph_tag(base > 0 ? base + p - ov : p, 0)); } m = r->ops.size(); };
   auto only = [&](int p) { sect([p](int) { return p; }); };
   if (use_weight && !has_col(batch, CRUX_COL_WEIGHT)) return bail(crux_fail(c, CRUX_EINVAL, "td_loss(weight=:weight): batch has no :weight column"));
   rc = per ? crux_per_sample(batch, source, B, nullptr, beta, sample_counter) : crux_uniform_sample(batch, source, B, nullptr, sample_counter); if (rc) return bail(rc);
@@ -646,22 +574,22 @@ static int32_t dqn_epoch_tiles(crux_mlp* net, crux_mlp* tnet, crux_buffer* sourc
     a.w = use_weight ? (const float*)batch->col[CRUX_COL_WEIGHT] : nullptr; a.gamma = gamma; a.softq_alpha = softq_alpha; a.nout = nout; a.K = K; a.B = (int32_t)B;
     a.y = d_y; a.dy = dy; a.err = per ? d_err : nullptr; a.term = term; a.qsel = qsel;
     a.per = per ? 1 : 0; a.pr = source->priorities; a.pminmax = source->pminmax; a.ids = batch->d_indices; a.per_alpha = source->alpha;
-    crux_exec_push<DqnTdTileOp, OP_DQN_TD_TILE>(c, (unsigned)((B + 15) / 16), a); r->ops.back().tk = (unsigned*)(nanf + 8); }      // (nanf[8 .. 8 + B / 16): the tiles' ticket words, zeroed with the info row)
-  only(2 | PH_TICKET);
+    crux_exec_push<DqnTdTileOp, OP_DQN_TD_TILE>(c, (unsigned)((B + 15) / 16), a); }
+  only(3);
   Sumsq2Fix fx{};
   rc = crux_dense_backward(net, S, B, dy, 1.0f, true, nullptr, c->stream, &fx, 0, nanf); if (rc) return bail(rc);
-  only(3);
+  only(4);
   if (per) { rc = crux_per_touched(source, batch->d_indices, B, false, (unsigned*)(nanf + 2)); if (rc) return bail(rc);      // leaves + root paths as one op beside the pullback (LeafTouchOp)
-    sect([](int kid) { return (kid == OP_LEAF_TOUCH || kid == OP_LEAF_REFRESH) ? 3 : kid == OP_TREE_TOUCH ? 4 : -1; }); }
-  // 4: the norm (for the info row) and, beside it, Adam gated on the producers' NaN flags (AdamSelfOp, sac.hip) | 5: info, beta-power advance
+    sect([](int kid) { return (kid == OP_LEAF_TOUCH || kid == OP_LEAF_REFRESH) ? 4 : kid == OP_TREE_TOUCH ? 5 : -1; }); }
+  // 5: the norm (for the info row) and, beside it, Adam gated on the producers' NaN flags (AdamSelfOp, sac.hip) | 6: info, beta-power advance
   CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, net->g, (int64_t)net->nd.n_params, (float*)nullptr, (int64_t)0, ssq, fx);
   rc = adam_self(net, nanf, status, fx, 0); if (rc) return bail(rc);
-  sect([](int kid) { return kid == OP_ADAM_ADVANCE_SELF ? 5 : 4; });
+  sect([](int kid) { return kid == OP_ADAM_ADVANCE_SELF ? 6 : 5; });
   crux_exec_push<TdInfo2Op, OP_TD_INFO2>(c, 1u, (const float*)term, (const float*)qsel, (const double*)ssq, B, dinfo);
-  only(5);
+  only(6);
   crux_exec_add_readback(c, info_out, dinfo, status, "td_loss");
   if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-  r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 6 - (r->chain_base > 0 ? ov : 0);
+  r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 7 - (r->chain_base > 0 ? ov : 0);
   return CRUX_OK;
 }
 
@@ -891,7 +819,7 @@ static int32_t sac_epoch_tiles(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux
   ExecRec* r = rec_of(c); const int base = r->chain ? r->chain_base : 0; std::vector<int> ph; bool plan_ok = true;
   size_t m = exec_mark(c); const size_t ops0 = m;
   auto sect = [&](auto&& rule) { for (size_t i = m; i < r->ops.size(); ++i) { int p = rule(r->ops[i].kid); if (p < 0) { plan_ok = false; p = 0; }
-      const int sub = p >> 12; p &= 4095; ph.push_back(ph_tag(base > 0 ? base + p - 3 : p, sub)); } m = r->ops.size(); };
+      ph.push_back(ph_tag(base > 0 ? base + p - 3 : p, 0)); } m = r->ops.size(); };
   auto only = [&](int p) { sect([p](int) { return p; }); };
   // buffers of this epoch (scratch of the recording: live until the list has run)
   float* y = (float*)crux_exec_small(c, 4 * (size_t)B); if (!y) return bail(crux_fail(c, CRUX_EUNSUP, "sac_epoch: batch of %lld rows exceeds the executor's region", (long long)B));
@@ -917,73 +845,72 @@ static int32_t sac_epoch_tiles(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux
   rc = crux_exec_zero(c, it, 256 * 5, c->stream); if (!rc) rc = crux_exec_zero(c, ic, 256 * 6, c->stream); if (!rc) rc = crux_exec_zero(c, ia, 256 * 6, c->stream);
   if (!rc) rc = crux_exec_zero(c, la->g, sizeof(float) * (size_t)la->nd.n_params, c->stream); if (rc) return bail(rc);
   only(1);
-  // Per-16-sample-tile ops run as TICKET tails of the forward launches that feed them (exec.hip k_phase_k): the workgroup that completes sample tile j's last forward tile
-  // runs the tile op for j -- a [forward | tile op] pair is one launch. Ticket words (zeroed with the actor's info row): three groups of nt.
-  unsigned* tkA = (unsigned*)(nfa + 8); unsigned* tkB = (unsigned*)(nfa + 24); unsigned* tkC = (unsigned*)(nfa + 40);
-  if (nt > 16) return bail(crux_fail(c, CRUX_EUNSUP, "sac_epoch (tile plan): batch of %lld rows", (long long)B));
-  // 2: the actor's first two layers on s' -> [exploration on s' (sa_t, lp_t)] | vcat(s, a)
+  // 2
   rc = crux_dense_forward12(actor, SP, B, c->stream); if (rc) return bail(rc);
   CRUX_RUN(c, ConcatSaOp, OP_CONCAT_SA, k_concat_sa, nblk(B * sd), 256, c->stream, S, (const float*)batch->col[CRUX_COL_A], od, ad, B, sa_c);
   only(2);
+  // 3
   { ActorExploreArgs a{}; a.mu = l3(actor, true); a.ls = ls; a.s = SP; a.od = od; a.ad = ad; a.K = K; a.B = (int32_t)B; a.n_cfg = 1; a.seed = noise_seed; a.cfg[0] = ExploreCfg{noise_counter0, sa_t, lp_t, nullptr};
-    crux_exec_push<ActorExploreTileOp, OP_ACTOR_EXPLORE_TILE>(c, nt, a); r->ops.back().tk = tkA; }
-  only(2 | PH_TICKET);
-  // 3: Q1, Q2 on (s, a) | the target critics on (s', a') | the actor on s -> [sac_target + both critic heads | the two exploration draws on s]
-  rc = crux_dense_forward12(q1, sa_c, B, c->stream); if (!rc) rc = crux_dense_forward12(q2, sa_c, B, c->stream);
-  if (!rc) rc = crux_dense_forward12(q1t, sa_t, B, c->stream); if (!rc) rc = crux_dense_forward12(q2t, sa_t, B, c->stream); if (!rc) rc = crux_dense_forward12(actor, S, B, c->stream); if (rc) return bail(rc);
+    crux_exec_push<ActorExploreTileOp, OP_ACTOR_EXPLORE_TILE>(c, nt, a); }
+  rc = crux_dense_forward12(q1, sa_c, B, c->stream); if (!rc) rc = crux_dense_forward12(q2, sa_c, B, c->stream); if (rc) return bail(rc);
   only(3);
+  // 4
+  rc = crux_dense_forward12(q1t, sa_t, B, c->stream); if (!rc) rc = crux_dense_forward12(q2t, sa_t, B, c->stream); if (!rc) rc = crux_dense_forward12(actor, S, B, c->stream); if (rc) return bail(rc);
+  only(4);
+  // 5
   { SacCriticArgs a{}; a.q1t = l3(q1t, true); a.q2t = l3(q2t, true); a.q1 = l3(q1, true); a.q2 = l3(q2, true); a.r = (const float*)batch->col[CRUX_COL_R]; a.done = (const uint8_t*)batch->col[CRUX_COL_DONE];
     a.lp = lp_t; a.log_alpha = la->p; a.w = w; a.gamma = gamma; a.scale = 0.5f; a.K = K; a.B = (int32_t)B; a.y = y; a.dy1 = dy1; a.dy2 = dy2; a.term1 = t1; a.term2 = t2;
-    crux_exec_push<SacCriticTileOp, OP_SAC_CRITIC_TILE>(c, nt, a); r->ops.back().tk = tkB; }
-  { ActorExploreArgs a{}; a.mu = l3(actor, true); a.ls = ls; a.s = S; a.od = od; a.ad = ad; a.K = K; a.B = (int32_t)B; a.n_cfg = 1; a.seed = noise_seed;      // the two draws (each re-evaluates the output layer: 8 MFMAs)
-    a.cfg[0] = ExploreCfg{noise_counter0 + 1, nullptr, lp_temp, nullptr}; crux_exec_push<ActorExploreTileOp, OP_ACTOR_EXPLORE_TILE>(c, nt, a); r->ops.back().tk = tkB;
-    a.cfg[0] = ExploreCfg{noise_counter0 + 2, sa_a, lp_a, eps}; crux_exec_push<ActorExploreTileOp, OP_ACTOR_EXPLORE_TILE>(c, nt, a); r->ops.back().tk = tkB; }
-  only(3 | PH_TICKET);
-  // 4
+    crux_exec_push<SacCriticTileOp, OP_SAC_CRITIC_TILE>(c, nt, a); }
+  { ActorExploreArgs a{}; a.mu = l3(actor, true); a.ls = ls; a.s = S; a.od = od; a.ad = ad; a.K = K; a.B = (int32_t)B; a.n_cfg = 1; a.seed = noise_seed;      // the two draws side by side (each re-evaluates the output layer: 8 MFMAs)
+    a.cfg[0] = ExploreCfg{noise_counter0 + 1, nullptr, lp_temp, nullptr}; crux_exec_push<ActorExploreTileOp, OP_ACTOR_EXPLORE_TILE>(c, nt, a);
+    a.cfg[0] = ExploreCfg{noise_counter0 + 2, sa_a, lp_a, eps}; crux_exec_push<ActorExploreTileOp, OP_ACTOR_EXPLORE_TILE>(c, nt, a); }
+  only(5);
+  // 6
   Sumsq2Fix fxc{}, fxa{};
   rc = crux_dense_backward(q1, sa_c, B, dy1, 1.0f, true, nullptr, c->stream, &fxc, 0, nfc); if (!rc) rc = crux_dense_backward(q2, sa_c, B, dy2, 1.0f, true, nullptr, c->stream, &fxc, 1, nfc); if (rc) return bail(rc);
   CRUX_RUN(c, TempHeadOp, OP_TEMP_HEAD, k_temp_head, 1, 256, c->stream, (const float*)lp_temp, B, H_target, (const float*)la->p, la->g, it, ssq_t);
-  only(4);
-  // 5: the critics' norm (for the info row) and, beside it, their Adam steps gated on the pullback's NaN flags (AdamSelfOp, sac.hip); log alpha's step (+ 6: the advances)
+  only(6);
+  // 7: the critics' norm (for the info row) and, beside it, their Adam steps gated on the pullback's NaN flags (AdamSelfOp, sac.hip); log alpha's step (+ 8: the advances)
   CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, q1->g, (int64_t)q1->nd.n_params, q2->g, (int64_t)q2->nd.n_params, ssq_c, fxc);
   rc = adam_self(q1, nfc, stc, fxc, 0); if (!rc) rc = adam_self(q2, nfc, stc, fxc, 1); if (!rc) rc = adam_gated(la, ssq_t, stt, false); if (rc) return bail(rc);
-  sect([](int kid) { return (kid == OP_ADAM_ADVANCE || kid == OP_ADAM_ADVANCE_SELF) ? 6 : 5; });
-  // 6: critic info | the updated critics' first two layers on (s, a ~ pi) -> [the actor head]
+  sect([](int kid) { return (kid == OP_ADAM_ADVANCE || kid == OP_ADAM_ADVANCE_SELF) ? 8 : 7; });
+  // 8: critic info | the updated critics' first two layers on (s, a ~ pi)
   crux_exec_push<CriticInfo2Op, OP_CRITIC_INFO2>(c, 1u, (const float*)t1, (const float*)crux_dense_act(q1, 3), (const float*)t2, (const float*)crux_dense_act(q2, 3), (const double*)ssq_c, B, ic);
   rc = crux_dense_forward12(q1, sa_a, B, c->stream); if (!rc) rc = crux_dense_forward12(q2, sa_a, B, c->stream); if (rc) return bail(rc);
-  only(6);
+  only(8);
+  // 9
   { SacActorArgs a{}; a.q1 = l3(q1, true); a.q2 = l3(q2, true); a.lp = lp_a; a.log_alpha = la->p; a.K = K; a.B = (int32_t)B; a.dy1 = da1; a.dy2 = da2; a.term = ta;
-    crux_exec_push<SacActorTileOp, OP_SAC_ACTOR_TILE>(c, nt, a); r->ops.back().tk = tkC; }
-  only(6 | PH_TICKET);
-  // 7
+    crux_exec_push<SacActorTileOp, OP_SAC_ACTOR_TILE>(c, nt, a); }
+  only(9);
+  // 10
   const float* dz1a = nullptr; const float* dz1b = nullptr;
   rc = crux_dense_dgrad_to_dz1(q1, sa_a, B, da1, &dz1a, c->stream); if (!rc) rc = crux_dense_dgrad_to_dz1(q2, sa_a, B, da2, &dz1b, c->stream); if (rc) return bail(rc);
-  only(7);
-  // 8
+  only(10);
+  // 11
   { CriticDxArgs a{}; a.c1 = TileSet{q1->p + q1->nd.woff[0], nullptr, dz1a, nullptr}; a.c2 = TileSet{q2->p + q2->nd.woff[0], nullptr, dz1b, nullptr};
     a.sa = sa_a; a.mu = crux_dense_act(actor, 3); a.eps = eps; a.ls = ls; a.log_alpha = la->p; a.od = od; a.ad = ad; a.K = q1->nd.dims[1]; a.B = (int32_t)B; a.dmu = dmu; a.dls = dls;
     crux_exec_push<CriticDxActorGradTileOp, OP_CRITIC_DX_TILE>(c, nt, a); }
-  only(8);
-  // 9
+  only(11);
+  // 12
   rc = crux_dense_backward(actor, S, B, dmu, 1.0f, true, nullptr, c->stream, &fxa, 0, nfa); if (rc) return bail(rc);
   CRUX_RUN(c, RowsumOp, OP_ROWSUM, k_rowsum, ad, 256, c->stream, (const float*)dls, ad, B, actor->g + actor->nd.xoff, nfa);
-  only(9);
-  // 10: the actor's norm | its Adam step (self-gated)
+  only(12);
+  // 13: the actor's norm | its Adam step (self-gated)
   CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, actor->g, (int64_t)actor->nd.n_params, (float*)nullptr, (int64_t)0, ssq_a, fxa);
   rc = adam_self(actor, nfa, sta, fxa, 0); if (rc) return bail(rc);
-  sect([](int kid) { return kid == OP_ADAM_ADVANCE_SELF ? 11 : 10; });
-  // 11: actor info, polyak
+  sect([](int kid) { return kid == OP_ADAM_ADVANCE_SELF ? 14 : 13; });
+  // 14: actor info, polyak
   crux_exec_push<ActorInfo2Op, OP_ACTOR_INFO2>(c, 1u, (const float*)ta, (const float*)lp_a, (const double*)ssq_a, B, ia);
   if (actor_targ) { rc = crux_polyak(actor_targ, actor, tau); if (rc) return bail(rc); }
   rc = crux_polyak(q1t, q1, tau); if (!rc) rc = crux_polyak(q2t, q2, tau); if (rc) return bail(rc);
-  only(11);
+  only(14);
   // the steps' read-backs in the order they ran (temperature, critics, actor), as the generic recording registers them
   crux_exec_add_readback(c, info_temp, it, stt, "sac_temp_loss"); crux_exec_add_readback(c, info_critic, ic, stc, "double_Q_loss"); crux_exec_add_readback(c, info_actor, ia, sta, "sac_actor_loss");
-  // phases 0 / 1 of a chained epoch (ids | gather, fills) overlap the previous epoch's actor pullback (9: the gather rewrites the batch rows it read -- not before 10) and
-  // norm + Adam (10), phase 2 (the new actor's forward on s' and its exploration tail) its info + advance + polyak (11): base + p - 3 for every p. 12 phases, 9 launches per chained epoch.
+  // phases 0 / 1 of a chained epoch (ids | gather, fills) overlap the previous epoch's actor pullback (12: the gather rewrites the batch rows it read -- not before 13) and
+  // norm + Adam (13), phase 2 (the new actor's forward on s') its info + advance + polyak (14): base + p - 3 for every p. 15 phases, 12 launches per chained epoch.
   if (r->chain) {
     if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
-    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 12 - (r->chain_base > 0 ? 3 : 0);
+    r->chain_tags.insert(r->chain_tags.end(), ph.begin(), ph.end()); r->chain_base += 15 - (r->chain_base > 0 ? 3 : 0);
     return CRUX_OK;
   }
   if (plan_ok && ph.size() == r->ops.size()) { rc = exec_schedule(c, ph); if (rc) return bail(rc); }
