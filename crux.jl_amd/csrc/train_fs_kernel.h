@@ -274,6 +274,8 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
     }
   };
 
+  if (!PX && tid == 0) {      // this workgroup's SUSPECT words (B_or elision below), both slot parities: a launch that ended on a suspect step must not slow the next one down
+    a.xbuf[(size_t)(0 * NWG + p) * XSLOT + W2N + NSI * NT + 12] = 0.f; a.xbuf[(size_t)(1 * NWG + p) * XSLOT + W2N + NSI * NT + 12] = 0.f; }
   for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
     if (a.spec_abort) {      // a speculative run (train_args.h): thread 0 of every workgroup ORs what it reads from the host's word into an L2 latch, all wait until all have (one
                              // arrival counter, NWG per epoch), then everyone reads the latch: the same decision in every workgroup, whenever the host's store lands
@@ -518,6 +520,18 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
       float* mine = a.xbuf + (size_t)(((int)(xstep & 1) * NWG + p)) * XSLOT;
 #pragma unroll
       for (int mm = 0; mm < WT; ++mm) *(f32x4*)&mine[tid * (4 * WT) + 4 * mm] = gW2[mm];      // acknowledged long before the s_waitcnt below
+      // B_or elision (round 4): the norm barrier below exists for three things -- the "gradient is NaN" consensus, the KL statistic for early stopping, the per-wave sums of
+      // squares of a REPORTED step. A total can only be NaN when a workgroup's partial is NaN or huge (four partials of magnitude <= 1e30 cannot overflow): a thread that sees
+      // such a partial raises its workgroup's SUSPECT word in the exchange slot, every thread reads the four words (and the four KL partial sums) beside the partials, and all
+      // threads of all workgroups take the barrier only on a suspect, reporting or KL-stopping step -- the same decision everywhere. (Not in replica groups: there the
+      // statistics come back from the group exchange in the stat lanes only.)
+      constexpr bool ELIDE = !PX; constexpr int SUS = W2N + NSI * NT + 12, KLW = W2N + NSI * NT + 2;
+      bool odd = false;
+      if constexpr (ELIDE) {
+#pragma unroll
+        for (int mm = 0; mm < WT; ++mm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) odd = odd || !(fabsf(gW2[mm][r]) <= 1e30f); }
       FS_T(7);
       // dH1 (R) for the h1 features [32h, 32h + 32) = dZ2 (C regs as A: [i=c -> sample][k -> f' = 16mp+4g+r]) x W2 (B: W2[f'][f = 16m+c] = W2C[f][f']); K = all 64 dZ2 features:
       // the own half from registers, the partner's from its A-layout copy
@@ -708,12 +722,16 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
           pxc += 1;
           return true;
       };
-      float stat_tot = stat_loc;
+      float stat_tot = stat_loc; bool suspect = true; float kl_tot = 0.f;
       // ---- exchange the partial gradients with the other workgroups through the shared L2 ----
       {
 #pragma unroll
         for (int k = 0; k < NSI; ++k) mine[W2N + tid + NT * k] = gs[k];
         if (tid >= NT - 8 && tid < STAT_HI) mine[W2N + NSI * NT + (tid - (NT - 8))] = stat_loc;
+        if constexpr (ELIDE) {
+#pragma unroll
+          for (int k = 0; k < NSI; ++k) odd = odd || !(fabsf(gs[k]) <= 1e30f);
+          if (odd) mine[SUS] = 1.f; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this lane has reached the L2 (the dW2 partials left before dH1: long acknowledged)
         FS_T(10);
         __syncthreads();
@@ -740,10 +758,12 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
         // (A two-phase form -- the dW2 partials, 89 % of a slot, announced by a counter of their own and loaded before the second arrival -- was measured and dropped: the
         //  exchange is a chain of L2 round trips, not a bandwidth problem, and every variant added a round trip: 7.19 / 7.59 us per step against 7.10 us.)
         constexpr int NLD = NWG - 1;
-        f32x4 pw[NLD][WT]; float pg[NLD][NSI]; float ps[NLD];
+        f32x4 pw[NLD][WT]; float pg[NLD][NSI]; float ps[NLD]; float psus[NLD + 1], pkl[NLD + 1];
+        if constexpr (ELIDE) { psus[NLD] = __hip_atomic_load(mine + SUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pkl[NLD] = __hip_atomic_load(mine + KLW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #pragma unroll
         for (int j = 0; j < NLD; ++j) { const int q = j == 0 ? (p ^ 1) : ((p ^ 2) & 2) + (j - 1);      // partner, then the other pair's first and second workgroup
           const float* peer = a.xbuf + (size_t)(((int)(xstep & 1) * NWG + q)) * XSLOT;
+          if constexpr (ELIDE) { psus[j] = __hip_atomic_load(peer + SUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pkl[j] = __hip_atomic_load(peer + KLW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #pragma unroll
           for (int k = 0; k < NSI; ++k) pg[j][k] = __hip_atomic_load(peer + W2N + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ps[j] = 0.f;
@@ -762,12 +782,14 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
 #pragma unroll
           for (int k = 0; k < NSI; ++k) gs[k] += pg[0][k];
           stat_tot = stat_loc + ps[0];
+          if constexpr (ELIDE) { suspect = psus[0] != 0.f || psus[1] != 0.f; kl_tot = pkl[1] + pkl[0]; }
         } else {
 #pragma unroll
           for (int mm = 0; mm < WT; ++mm) gW2[mm] = (gW2[mm] + pw[0][mm]) + (pw[1][mm] + pw[2][mm]);
 #pragma unroll
           for (int k = 0; k < NSI; ++k) gs[k] = (gs[k] + pg[0][k]) + (pg[1][k] + pg[2][k]);
           stat_tot = (stat_loc + ps[0]) + (ps[1] + ps[2]);
+          if constexpr (ELIDE) { suspect = psus[0] != 0.f || psus[1] != 0.f || psus[2] != 0.f || psus[3] != 0.f; kl_tot = (pkl[3] + pkl[0]) + (pkl[1] + pkl[2]); }      // (the stat lanes' own additions)
         }
         if constexpr (PX && !PXK) {
           f32x4* const Wp[3] = {gW2, nullptr, nullptr}; float* const Sp[3] = {gs, nullptr, nullptr};
@@ -779,22 +801,29 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
       float ssq = 0.f; int bad = 0;
 #pragma unroll
       for (int k = 0; k < NSI; ++k) if (so_ok[k]) {
-        if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += LAG ? -a.lambda_e / (1.f + pen) : -a.lambda_e;      // d(-lambda_e H)/dlogSigma, H = const + sum(logSigma); lagrange: the whole loss is divided by 1 + penalty
-        ssq += gs[k] * gs[k]; bad |= isnan(gs[k]) ? 1 : 0; }
+        if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += LAG ? -a.lambda_e / (1.f + pen) : -a.lambda_e; }      // d(-lambda_e H)/dlogSigma, H = const + sum(logSigma); lagrange: the whole loss is divided by 1 + penalty
+      bool need_bar = true; float kl_now = 0.f;
+      if constexpr (ELIDE) { kl_now = kl_tot * invB;
+        need_bar = suspect || st + a.bs >= total_rows || (a.max_batches > 0 && total_batches + 1 >= a.max_batches) || (KIND != MFK_VALUE && a.target_kl >= 0.f && kl_now > a.target_kl); }
+      int any_bad = 0;
+      if (need_bar) {      // (uniform over the learner's workgroups: every term is the same in all of them)
 #pragma unroll
-      for (int mm = 0; mm < WT; ++mm)
+        for (int k = 0; k < NSI; ++k) if (so_ok[k]) { ssq += gs[k] * gs[k]; bad |= isnan(gs[k]) ? 1 : 0; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ssq += gW2[mm][r] * gW2[mm][r]; bad |= isnan(gW2[mm][r]) ? 1 : 0; }
-      ssq = wave_sum(ssq);
-      if (lane == 0) sm[Lt::oRED + w] = ssq;
-      FS_T(12);
-      const int any_bad = __syncthreads_or(bad);   // ---- B_or (also publishes RED)
+        for (int mm = 0; mm < WT; ++mm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { ssq += gW2[mm][r] * gW2[mm][r]; bad |= isnan(gW2[mm][r]) ? 1 : 0; }
+        ssq = wave_sum(ssq);
+        if (lane == 0) sm[Lt::oRED + w] = ssq;
+        FS_T(12);
+        any_bad = __syncthreads_or(bad);   // ---- B_or (also publishes RED)
+      }
       FS_T(13);
       // minibatch info (training.jl:22-23, ppo.jl:13-19); identical in every thread; only the epoch's last minibatch (or the one that stops the loop) is ever reported
       { const float* tq = sm + Lt::oRED + 8;
-        if (KIND != MFK_VALUE && a.target_kl >= 0.f) inf_kl = tq[2] * invB;
-        const bool report = any_bad || st + a.bs >= total_rows || (a.max_batches > 0 && total_batches + 1 >= a.max_batches) ||
-                            (KIND != MFK_VALUE && a.target_kl >= 0.f && inf_kl > a.target_kl);
+        if (KIND != MFK_VALUE && a.target_kl >= 0.f) inf_kl = need_bar ? tq[2] * invB : kl_now;
+        const bool report = need_bar && (any_bad || st + a.bs >= total_rows || (a.max_batches > 0 && total_batches + 1 >= a.max_batches) ||
+                            (KIND != MFK_VALUE && a.target_kl >= 0.f && inf_kl > a.target_kl));
         if (report) {
           float ss = sm[Lt::oRED];
 #pragma unroll
