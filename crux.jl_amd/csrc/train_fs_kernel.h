@@ -736,6 +736,8 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
         FS_T(10);
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(a.xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // second arrival: the small partials are in the L2 too
+        // (Arrival and polling per WAVE -- no workgroup barrier before the arrival, none to pass the news on -- was measured and dropped: 32 waves adding to and polling one L2
+        //  word, 6.80 us per step against 6.18; C5 9.38 against 8.54.)
         // the wait for the slowest workgroup is spent staging the NEXT minibatch (rows prefetched a step ago; the tiles' x / scalar rows are free after B_2)
         if (st + a.bs < total_rows) { if (!HELP) stage(0); staged = true; }      // (with helper waves the next minibatch is staged already)
         if (tid == 0) {
