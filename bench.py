@@ -207,7 +207,7 @@ def julia_reference_probe():
         return {"available": False, "why": repr(e)}
 
 
-TRAFFIC_RECORDED = {"c2": 35.3e6, "c5": 2.817e9}      # bytes per actor launch: profiles/r03_pmc_traffic.txt (2 x 13.89 MB FETCH_SIZE + 5.34 MB WRITE_SIZE), r03_pmc_traffic_c5.txt (2 x 4 961 MB + 20.8 MB: the 27 MB C5 buffer does not fit an XCD's 4 MB L2, and a gathered 68-byte observation row / 24-byte action row / 4-byte scalar costs whole 64..128-byte sectors: 60.7 KB per step against 13.3 KB algorithmic)
+TRAFFIC_RECORDED = {"c2": 35.3e6, "c5": 2.817e9}      # bytes per actor launch: profiles/r04_pmc_traffic.txt (2 x 14.57 MB FETCH_SIZE + 5.34 MB WRITE_SIZE), r04_pmc_traffic_c5.txt (2 x 1 364 MB + 22.2 MB: 17.2 KB per step with the packed learner rows)
 
 
 def measure_traffic(workload):
