@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
     }
   };
 
-  if (!PX && tid == 0) {      // this workgroup's SUSPECT words (B_or elision below), both slot parities: a launch that ended on a suspect step must not slow the next one down
+  if ((!PX || PXK) && tid == 0) {      // this workgroup's SUSPECT words (B_or elision below), both slot parities: a launch that ended on a suspect step must not slow the next one down
     a.xbuf[(size_t)(0 * NWG + p) * XSLOT + W2N + NSI * NT + 12] = 0.f; a.xbuf[(size_t)(1 * NWG + p) * XSLOT + W2N + NSI * NT + 12] = 0.f; }
   for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
     if (a.spec_abort) {      // a speculative run (train_args.h): thread 0 of every workgroup ORs what it reads from the host's word into an L2 latch, all wait until all have (one
@@ -525,7 +525,8 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
       // such a partial raises its workgroup's SUSPECT word in the exchange slot, every thread reads the four words (and the four KL partial sums) beside the partials, and all
       // threads of all workgroups take the barrier only on a suspect, reporting or KL-stopping step -- the same decision everywhere. (Not in replica groups: there the
       // statistics come back from the group exchange in the stat lanes only.)
-      constexpr bool ELIDE = !PX; constexpr int SUS = W2N + NSI * NT + 12, KLW = W2N + NSI * NT + 2;
+      constexpr bool ELIDE = !PX || PXK;      // (the periodic form of a replica group runs on LOCAL gradients and statistics between its exchanges, like a single learner)
+      constexpr int SUS = W2N + NSI * NT + 12, KLW = W2N + NSI * NT + 2;
       bool odd = false;
       if constexpr (ELIDE) {
 #pragma unroll
