@@ -422,6 +422,20 @@ def rccl_check(ctx, dist, torch, rank, world, tdev, args, net):
     return rc
 
 
+def guarded(fn, seconds):
+    """fn() in a daemon thread: (result or None, still running?) -- for checks that must not be able to take the measurement down with them"""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn()
+        except Exception as e:      # noqa: BLE001
+            box["e"] = repr(e)
+    t = threading.Thread(target=run, daemon=True); t.start(); t.join(seconds)
+    return box.get("r"), t.is_alive()
+
+
 def wait_percentiles(hist):
     """per-rank summary of the in-kernel flag waits (crux_peer_wait_hist: log2 bins of 10 ns ticks, [2 learner streams][2 workgroups][32]): the UPPER edge of the bin that holds the
     p-th percentile, in microseconds, over both streams and workgroups of this rank."""
@@ -563,7 +577,7 @@ def main():
         lo, hi = dg.clone(), dg.clone(); dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_identical = bool(int(lo.item()) == int(hi.item()))
 
-    exchange = None
+    exchange = None; rccl_hung = False
     if dist is not None:
         tdev = torch.device("cuda", local) if dist.get_backend() == "nccl" else torch.device("cpu")
         mine = {"rank": rank}
@@ -574,7 +588,12 @@ def main():
         if sync == "native":
             rccl = [{"ok": True, "how": "the timed region ran on the library's RCCL communicator"}] * world
         else:
-            r1 = rccl_check(ctx, dist, torch, rank, world, tdev, args, pi.A); rccl = [None] * world; dist.all_gather_object(rccl, r1)
+            # under a watchdog: the timed numbers above must reach the JSON line whatever a second communicator does on a machine this was never run on
+            def _rccl():
+                r1 = rccl_check(ctx, dist, torch, rank, world, tdev, args, pi.A); got = [None] * world; dist.all_gather_object(got, r1); return got
+            rccl, rccl_hung = guarded(_rccl, 120.0)
+            if rccl is None:
+                rccl = [{"ok": False, "error": "the RCCL check did not return within 120 s" if rccl_hung else "the RCCL check raised"}] * world
         exchange = {"kind": ("peer_slots_grad_every_step" if args.sync_every <= 1 else "peer_slots_periodic_k%d" % args.sync_every) if sync == "grad" else ("rccl_params_every_%d_epochs" % SYNC_EVERY if sync == "native" else "torch_allreduce_params_every_%d_epochs" % SYNC_EVERY),
                     "requested": "grad" if requested_sync == "grad" else "params", "fell_back": bool(requested_sync == "grad" and sync != "grad"),
                     "sync_every_minibatches": args.sync_every if sync == "grad" else None,
@@ -699,6 +718,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         sys.stdout.flush(); os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist is not None and rccl_hung:
+        os._exit(0)            # a thread of this process sits in a collective that never returned: the line is out, leave without the group's tear-down
     if dist is not None:
         barrier()
         if sync == "native":
