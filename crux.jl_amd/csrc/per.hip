@@ -365,12 +365,16 @@ struct PerSampleArgs { const float* run; const float* total; const float* pr; co
 struct PerSampleGatherOp {
   static __device__ __forceinline__ void run_ptr(const unsigned bid_, const unsigned nb_, const PerSampleArgs* a) {
     __shared__ GatherCols gs2;
-    { const uint32_t* src = (const uint32_t*)&a->g; uint32_t* dst = (uint32_t*)&gs2; for (int i = threadIdx.x; i < (int)(sizeof(GatherCols) / 4); i += blockDim.x) dst[i] = src[i]; }
-    __syncthreads();
+    // the column table (456 bytes of the kernel arguments) is only needed by the gather: its loads are issued now, the LDS copy and the barrier come AFTER the search, so the
+    // table's round trip hides behind the search's three instead of preceding them
+    static_assert(sizeof(GatherCols) / 4 <= 256, "one table word per thread");
+    const uint32_t tabw = threadIdx.x < sizeof(GatherCols) / 4 ? ((const uint32_t*)&a->g)[threadIdx.x] : 0u;
     const int lane = threadIdx.x & 63; const int64_t j = (int64_t)bid_ * 4 + (threadIdx.x >> 6); const int64_t B = a->B;
+    float* const weight = a->weight; float ptot = 0.f; int lo = 0;
+    if (j < B) lo = per_search_wave(j, a->run, a->total, a->pr, a->pminmax, a->N, B, a->nlev, a->rands, a->seed, a->stream, a->ictr, a->beta, a->ids, weight, &ptot);
+    if (threadIdx.x < sizeof(GatherCols) / 4) ((uint32_t*)&gs2)[threadIdx.x] = tabw;
+    __syncthreads();
     if (j >= B) return;
-    float* const weight = a->weight; float ptot;
-    const int lo = per_search_wave(j, a->run, a->total, a->pr, a->pminmax, a->N, B, a->nlev, a->rands, a->seed, a->stream, a->ictr, a->beta, a->ids, weight, &ptot);
     const int32_t width = gs2.pre[gs2.n]; const int ncol = gs2.n; const int64_t drow = (a->base + j) % a->C;
     // the row's loads go out BEFORE lane 0 forms the importance weight (a dependent load of priorities[lo] and two powf): one memory round trip for both
     uint32_t v0 = 0; int k0 = -1; int64_t d0 = 0; bool byte0 = false;
