@@ -275,6 +275,44 @@ def test_policy_gradient_training_of_two_replicas_with_kl_early_stopping(two_con
             assert infos[0]["actor_batches_trained"] == 6 * (N // bs) and infos[0]["critic_batches_trained"] == 3 * (N // bs)
 
 
+def test_policy_gradient_training_of_two_replicas_in_the_periodic_form(two_contexts):
+    """crux_policy_gradient_training under crux_peer_set_sync_every(8): actor and critic of both replicas train concurrently (four persistent kernels, periodic exchanges on both
+    learner streams) and leave the call bit-identical across the replicas; KL early stopping is refused in this form (the statistics are local between exchanges)."""
+    ctxs = two_contexts; bs = 128
+    shards = [_shard(310), _shard(311)]
+    N = shards[0]["s"].shape[1]; extras = ["return", "logprob", "advantage"]
+    sv, bufs = [], []
+    for r, ctx in enumerate(ctxs):
+        ctx.peer_set_sync_every(8)
+        a = crux.DiscreteNetwork(parity.chain(parity.ACTOR_DIMS, parity.ACTS), [1, 2], ctx=ctx, seed=9, stream=0)
+        c = crux.ContinuousNetwork(parity.chain(parity.CRITIC_DIMS, parity.ACTS), ctx=ctx, seed=9, stream=1)
+        b = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), N, extras, ctx=ctx); b.push_(shards[r])
+        class _S:
+            pass
+        s = _S(); s.agent = crux.PolicyParams(crux.ActorCritic(a, c)); s.P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+        s.a_opt = crux.TrainingParams(loss=crux.ppo_loss, batch_size=bs, epochs=4, target_kl=None, name="actor_", shuffle_seed=40 + r)
+        s.c_opt = crux.TrainingParams(loss=crux.value_mse_loss, batch_size=bs, epochs=4, name="critic_", shuffle_seed=60 + r)
+        sv.append(s); bufs.append(b)
+    try:
+        infos = [None, None]
+        def make(r):
+            def f():
+                infos[r] = crux.policy_gradient_training(sv[r], bufs[r])
+            return f
+        _run_threads([make(0), make(1)])
+        A0, A1 = sv[0].agent.pi.A, sv[1].agent.pi.A; C0, C1 = sv[0].agent.pi.C, sv[1].agent.pi.C
+        assert np.array_equal(A0.get_params(), A1.get_params()) and np.array_equal(C0.get_params(), C1.get_params())
+        assert all(np.array_equal(x, y) for x, y in zip(A0.adam_state(), A1.adam_state()))
+        assert infos[0]["actor_batches_trained"] == infos[1]["actor_batches_trained"] == 4 * (N // bs)
+        sv[0].a_opt.target_kl = 0.004
+        with pytest.raises(crux.CruxError) as e:
+            crux.policy_gradient_training(sv[0], bufs[0])
+        assert e.value.code == L.EINVAL
+    finally:
+        for ctx in ctxs:
+            ctx.peer_set_sync_every(1)
+
+
 def test_unsupported_shape_with_a_group_attached_is_refused(two_contexts):
     """the exchange lives in the two-CU kernels: a learner they do not cover must fail loudly instead of training un-synchronised."""
     ctx = two_contexts[0]
