@@ -151,6 +151,29 @@ def test_two_replicas_on_identical_shards_reproduce_the_ungrouped_learner(two_co
         c3.close()
 
 
+def _group(gpu_ctx, R, attempts=5):
+    """R contexts on device 0 wired into a replica group. Four replicas need all eight hardware queues (a learner and an auxiliary stream each): crux_peer_attach_local sometimes
+    cannot place them and says so -- fresh contexts get fresh streams, so the attach is retried; if the placement never works the test is skipped with the library's message."""
+    last = None
+    for _ in range(attempts):
+        extra = [crux.Context(0) for _ in range(R - 1)]; ctxs = [gpu_ctx] + extra
+        try:
+            crux.peer_attach_local(ctxs)
+            return ctxs, extra
+        except crux.CruxError as e:
+            last = e
+            for c in ctxs:
+                try:
+                    c.peer_detach()
+                except Exception:       # noqa: BLE001
+                    pass
+            for c in extra:
+                c.close()
+            if "hardware queue" not in str(e):
+                raise
+    pytest.skip("no placement of %d replicas on the device's hardware queues after %d attempts: %s" % (R, attempts, last))
+
+
 def _local_sgd_twin(R, shards, perms, dims, loss, head, bs, epochs, k, seed, stream):
     """the oracle twin of the in-kernel periodic form: R oracle learners, each on its own shard and shuffle, take k local minibatch steps (training.jl:40-43 on the composed shuffle order), then theta, m and v are replaced by the mean over the replicas -- float32 sum in rank order times float32(1 / R), the kernel's arithmetic."""
     N = shards[0]["s"].shape[1]; extras = ["return", "logprob", "advantage"]; nmb = N // bs
@@ -182,17 +205,15 @@ def _local_sgd_twin(R, shards, perms, dims, loss, head, bs, epochs, k, seed, str
     return os_[0]
 
 
-_PERIODIC = [(2, 8, "actor"), (2, 8, "critic"), (2, 4, "actor"), (3, 4, "critic")] + ([(2, 2, "actor"), (2, 4, "critic"), (2, 2, "critic"), (3, 4, "actor"), (3, 8, "actor")] if os.environ.get("CRUX_TEST_PERIODIC_ALL") else []) + ([(4, 4, "critic"), (4, 8, "actor")] if os.environ.get("CRUX_TEST_FOUR_REPLICAS") else [])
+_PERIODIC = [(2, 8, "actor"), (2, 8, "critic"), (2, 4, "actor"), (3, 4, "critic"), (4, 4, "critic")] + ([(2, 2, "actor"), (2, 4, "critic"), (2, 2, "critic"), (3, 4, "actor"), (3, 8, "actor")] if os.environ.get("CRUX_TEST_PERIODIC_ALL") else []) + ([(4, 4, "critic"), (4, 8, "actor")] if os.environ.get("CRUX_TEST_FOUR_REPLICAS") else [])
 
 
 @pytest.mark.parametrize("R,k,which", _PERIODIC)
 def test_periodic_form_equals_the_local_sgd_twin(gpu_ctx, R, k, which):
     """crux_peer_set_sync_every(k > 1): R persistent learners take LOCAL Adam steps on their shards and average theta, m, v through the peer slots after every k-th step inside
     the kernel (train_fs_kernel.h). Replicas must leave every call bit-identical; the oracle's local-SGD twin bounds the values (VERDICT r3 #3: within 1e-6)."""
-    extra = [crux.Context(0) for _ in range(R - 1)]
-    ctxs = [gpu_ctx] + extra
+    ctxs, extra = _group(gpu_ctx, R)
     try:
-        crux.peer_attach_local(ctxs)
         for c in ctxs:
             c.peer_set_sync_every(k)
         bs, epochs = 128, 2
@@ -325,19 +346,17 @@ def test_unsupported_shape_with_a_group_attached_is_refused(two_contexts):
 
 
 # Four replicas on ONE device need a learner and an auxiliary stream per context = all eight hardware queues (GPU_MAX_HW_QUEUES = 8; larger values do not help): now and
-# then crux_peer_attach_local cannot find such a placement in its eight attempts and reports it. N = 4 therefore runs on request (CRUX_TEST_FOUR_REPLICAS=1; the
-# exchange itself is covered at N = 4 by tools/peer_stress.py); N = 3 covers the unpaired last rank and the split of the peers between a learner's two workgroups.
-_RS = [(3, "actor"), (3, "critic")] + ([(4, "critic"), (4, "actor")] if os.environ.get("CRUX_TEST_FOUR_REPLICAS") else [])
+# then crux_peer_attach_local cannot find such a placement in its eight attempts and reports it: _group retries with fresh contexts (round 4: N = 4 runs by default, the
+# exchange is also covered at N = 4 by tools/peer_stress.py); N = 3 covers the unpaired last rank and the split of the peers between a learner's two workgroups.
+_RS = [(3, "actor"), (3, "critic"), (4, "critic")] + ([(4, "actor")] if os.environ.get("CRUX_TEST_FOUR_REPLICAS") else [])
 
 
 @pytest.mark.parametrize("R,which", _RS)
 def test_more_than_two_replicas_sum_in_rank_order(gpu_ctx, R, which):
     """N = 3 (an unpaired last rank in the slot loop) and N = 4 (peers shared between the two workgroups of a learner) on one GPU: R persistent learners spin
     concurrently, every step adds R contributions in rank order; all replicas stay bit-identical and equal the oracle's single learner on R x 128 rows."""
-    extra = [crux.Context(0) for _ in range(R - 1)]
-    ctxs = [gpu_ctx] + extra
+    ctxs, extra = _group(gpu_ctx, R)
     try:
-        crux.peer_attach_local(ctxs)
         bs, epochs = 128, 1
         shards = [_shard(500 + r, E=4, T=128) for r in range(R)]
         N = shards[0]["s"].shape[1]; extras = ["return", "logprob", "advantage"]
