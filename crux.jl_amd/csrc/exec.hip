@@ -261,7 +261,7 @@ extern "C" int32_t crux_ensure_aux_stream(crux_ctx* c);      // train.hip: a sec
 struct DqpBuf { static constexpr size_t oCtrL = 0, oFlags = 2048, oSsq = 2304, oTab = 4096, oPtr = 4096 + 32768, oG = 65536, oZ = oG + 32768, oP = oZ + 262144, oMV = oP + ((size_t)DQP_G * 128 * 256 * 4), oDbg = oMV + (1 << 20), oWT = oDbg + 16384; };      // oWT: 16 x 16 KB      // oMV: 16 x 2 x <= 4360 floats = 558 KB
 template <int IN, int OUT, int BT> static int32_t dqp_launch_learn(crux_ctx* c, const DqpArgs& a, hipStream_t st) {
   constexpr size_t lds = sizeof(float) * (size_t)DqpL<IN, OUT, BT>::TOTAL;
-  static bool attr = false;
+  static bool attr_dev[16] = {}; bool& attr = attr_dev[c->device & 15];      // (per device: a second device in the process sets the attribute for itself)
   if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_dqn_learn<IN, OUT, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
   hipLaunchKernelGGL((k_dqn_learn<IN, OUT, BT>), dim3(8 * DQP_G), dim3(256), lds, st, a);
   return crux_launch_check(c, "k_dqn_learn");

@@ -418,7 +418,7 @@ static int32_t ensure_cumsum(crux_buffer* s, int64_t N) {
       hipLaunchKernelGGL(k_leaf_totals, dim3(nb), dim3(LEAF_BLK), 0, c->stream, s->priorities, s->topo_leaf_start, s->topo_leaf_len, s->topo_leaf_node, s->topo_leaves, s->topo_total);
       const size_t tree_lds = 8 * (size_t)s->topo_nodes;
       if (tree_lds <= 150 * 1024) {
-        static bool attr = false;
+        static bool attr_dev[16] = {}; bool& attr = attr_dev[c->device & 15];      // (per device: a second device in the process sets the attribute for itself)
         if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_tree_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
         hipLaunchKernelGGL(k_tree_lds, dim3(1), dim3(1024), tree_lds, c->stream, s->topo_left, s->topo_right, s->topo_level_off, s->topo_levels, s->topo_nodes, s->topo_total, s->topo_prefix, s->priorities);
       } else

@@ -9,7 +9,7 @@ template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, int NWG, bool HE
 static int32_t launch_fs_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
   using Lt = FsLayout<IN, OUT, NWG, HELP, H2, LAG>;
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
-  static bool attr = false;
+  static bool attr_dev[16] = {}; bool& attr = attr_dev[c->device & 15];      // (per device: a second device in the process sets the attribute for itself)
   if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING, PX, H2, ACT2, LAG, PXK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
   hipLaunchKernelGGL((k_train_fs<IN, OUT, KIND, ACT, NWG, HELP, TIMING, PX, H2, ACT2, LAG, PXK>), dim3(8 * NWG), dim3(Lt::NT), lds, stream, a);
   return crux_launch_check(c, PXK ? "k_train_fs (replica group, periodic form)" : PX ? "k_train_fs (replica group)" : LAG ? "k_train_fs (lagrange_ppo_loss)" : "k_train_fs");

@@ -8,7 +8,7 @@ template <int IN, int OUT, int KIND, int ACT>
 static int32_t launch_one8(crux_ctx* c, const TrainArgs& a, hipStream_t stream) {
   using Lt = MfLayout<IN, OUT, 8>;
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
-  static bool attr = false;
+  static bool attr_dev[16] = {}; bool& attr = attr_dev[c->device & 15];      // (per device: a second device in the process sets the attribute for itself)
   if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<IN, OUT, KIND, ACT, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
   hipLaunchKernelGGL((k_train_mfma<IN, OUT, KIND, ACT, 8, 1>), dim3(1), dim3(512), lds, stream, a, (const TrainArgs*)nullptr);
   return crux_launch_check(c, "k_train_mfma<8,1>");
@@ -19,7 +19,7 @@ template <int IN, int OUT, int KIND, int ACT>
 static int32_t launch_multi8(crux_ctx* c, std::vector<TrainArgs>& as, hipStream_t stream) {
   using Lt = MfLayout<IN, OUT, 8>;
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
-  static bool attr = false;
+  static bool attr_dev[16] = {}; bool& attr = attr_dev[c->device & 15];      // (per device: a second device in the process sets the attribute for itself)
   if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<IN, OUT, KIND, ACT, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
   const int which = stream == c->stream ? 0 : 1; const size_t n = as.size(), need = n * sizeof(TrainArgs) + 256;
   if (c->amulti_bytes[which] < need) {

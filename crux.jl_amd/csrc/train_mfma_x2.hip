@@ -33,7 +33,7 @@ extern "C" int crux_x2_placement_ok(crux_ctx* c) {
 
 template <int IN, int OUT, int KIND, int ACT, bool TIMING, bool PX, bool LAG = false>
 static int32_t launch_x2_form(crux_ctx* c, const TrainArgs& a, size_t lds, hipStream_t stream) {
-  static bool attr = false;
+  static bool attr_dev[16] = {}; bool& attr = attr_dev[c->device & 15];      // (per device: a second device in the process sets the attribute for itself)
   if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<IN, OUT, KIND, ACT, 4, 2, TIMING, PX, LAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
   hipLaunchKernelGGL((k_train_mfma<IN, OUT, KIND, ACT, 4, 2, TIMING, PX, LAG>), dim3(16), dim3(256), lds, stream, a, (const TrainArgs*)nullptr);
   return crux_launch_check(c, "k_train_mfma<4,2>");
@@ -62,7 +62,7 @@ template <int IN, int OUT, int KIND, int ACT>
 static int32_t launch_x2_multi(crux_ctx* c, std::vector<TrainArgs>& as, hipStream_t stream) {
   using Lt = MfLayout<IN, OUT, 4>;
   constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
-  static bool attr = false;
+  static bool attr_dev[16] = {}; bool& attr = attr_dev[c->device & 15];      // (per device: a second device in the process sets the attribute for itself)
   if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<IN, OUT, KIND, ACT, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
   const int which = stream == c->stream ? 0 : 1; const size_t n = as.size();
   constexpr size_t xbytes = sizeof(float) * 4 * 8192 + 256;
