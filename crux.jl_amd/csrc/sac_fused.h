@@ -169,6 +169,12 @@ struct DqnTdTileOp { static __device__ __forceinline__ void run(const unsigned b
   int64_t* ids_s = (int64_t*)(df_lds + TILE_PART_FLOATS(2));
   if (q.per) for (int64_t j = threadIdx.x; j < q.B; j += 256) ids_s[j] = q.ids[j];      // (visible after the helper's workgroup barrier)
   const TileSet sets[2] = {q.qt, q.q}; f32x4 z[2];
+  // the sample's reward, done flag, action row and weight are loaded BEFORE the output layers (one round trip together with their operands instead of one more after them)
+  const int64_t jp = j0 + c < q.B ? j0 + c : q.B - 1;
+  const float r_p = q.r[jp]; const uint8_t done_p = q.done[jp]; const float w_p = q.w ? q.w[jp] : 1.f;
+  uint8_t a_p[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a_p[k] = q.a[jp * q.nout + (k < q.nout ? k : 0)];
   tile_splitk<2, false>(sets, q.nout, q.K, q.B, j0, df_lds, z);
   if (wv > 0) return;
   bool sorted_ids = true;
@@ -181,17 +187,20 @@ struct DqnTdTileOp { static __device__ __forceinline__ void run(const unsigned b
       float mx = z[0][0] / al; for (int k = 1; k < q.nout; ++k) { const float v = z[0][k] / al; mx = v > mx ? v : mx; }
       float sum = 0.f; for (int k = 0; k < q.nout; ++k) sum = sum + expf(z[0][k] / al - mx);
       const float lse = mx + logf(sum); const float sv = al * lse;
-      const float nd = 1.f - (q.done[j] ? 1.f : 0.f); const float gn = q.gamma * nd; const float t = gn * sv; yv = q.r[j] + t; }
+      const float nd = 1.f - (done_p ? 1.f : 0.f); const float gn = q.gamma * nd; const float t = gn * sv; yv = r_p + t; }
     else {                                                             // DqnTargetOp
       float mx = z[0][0]; for (int k = 1; k < q.nout; ++k) mx = z[0][k] > mx ? z[0][k] : mx;
-      const float nd = 1.f - (q.done[j] ? 1.f : 0.f); const float gn = q.gamma * nd; const float t = gn * mx; yv = q.r[j] + t; }
+      const float nd = 1.f - (done_p ? 1.f : 0.f); const float gn = q.gamma * nd; const float t = gn * mx; yv = r_p + t; }
     q.y[j] = yv;
-    const float invB = 1.f / (float)q.B; const uint8_t* a = q.a + j * q.nout;      // TdHeadOp
-    float Q = 0.f; for (int k = 0; k < q.nout; ++k) Q += z[1][k] * (a[k] ? 1.f : 0.f);
-    const float d = Q - yv; const float ww = q.w ? q.w[j] : 1.f;
+    const float invB = 1.f / (float)q.B; const uint8_t* a = a_p;      // TdHeadOp
+    float Q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < q.nout) Q += z[1][k] * (a[k] ? 1.f : 0.f);
+    const float d = Q - yv; const float ww = w_p;
     if (q.err) q.err[j] = fabsf(d);
     q.term[j] = d * d * ww; q.qsel[j] = Q;
-    for (int k = 0; k < q.nout; ++k) q.dy[j * q.nout + k] = a[k] ? 2.f * d * ww * invB : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < q.nout) q.dy[j * q.nout + k] = a[k] ? 2.f * d * ww * invB : 0.f;
     if (q.per) {                                                        // PerUpdateOp on (ids[j], |d|)
       const float vf = __fadd_rn(fabsf(d), 1.1920928955078125e-07f); const double val = (double)vf; const int64_t me = ids_s[j];
       bool later = false;
