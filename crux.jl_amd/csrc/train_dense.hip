@@ -255,10 +255,13 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a, hipStream_t strm, int wh
       q.loss = a.loss; q.head = a.head; q.lo = 1.f - a.eps_clip; q.hi = 1.f + a.eps_clip; q.lambda_p = a.lambda_p; q.lambda_e = a.lambda_e; q.squash = a.squash;
       q.ls = net->p + nd.xoff; q.dy = dy; q.gx = net->g + nd.xoff; q.stats = st;
       hipLaunchKernelGGL(k_pg_head, dim3(1), dim3(256), 0, strm, q);
-      rc = crux_dense_backward(net, x, nb, dy, 1.0f, true, nullptr, strm); if (rc) return rc;
-      if (a.need_px && c->peer_n > 1)      // replica group: the gradient (and the statistics) of the GLOBAL minibatch, the same bits on every rank
+      // (round 4) the fused pullback of layers 1 / 0 where it applies (dense_fused.h: three launches instead of five); it leaves layer 0's gradient as quarter partials that
+      // k_sumsq2 completes -- not in a replica group, whose flat all-reduce reads the whole gradient before the norm
+      const bool group = a.need_px && c->peer_n > 1; Sumsq2Fix fx{};
+      rc = crux_dense_backward(net, x, nb, dy, 1.0f, true, nullptr, strm, group ? nullptr : &fx, 0); if (rc) return rc;
+      if (group)      // replica group: the gradient (and the statistics) of the GLOBAL minibatch, the same bits on every rank
         hipLaunchKernelGGL(k_px_allreduce_flat, dim3(1), dim3(1024), 0, strm, net->g, (int64_t)nd.n_params, st, (float* const*)(c->peer_tab + which * CRUX_PX_MAXR), c->peer_rank, c->peer_n, status);
-      hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, strm, (float*)net->g, (int64_t)nd.n_params, (float*)nullptr, (int64_t)0, ssq, Sumsq2Fix{});
+      hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, strm, (float*)net->g, (int64_t)nd.n_params, (float*)nullptr, (int64_t)0, ssq, fx);
       hipLaunchKernelGGL(k_pg_info, dim3(1), dim3(1), 0, strm, (const double*)st, (const double*)ssq, nb, a.loss, a.head, a.lambda_p, a.lambda_e, (const float*)(net->p + nd.xoff), a.ad, dinfo, (const crux_lagrange*)a.lag);
       if (a.apply) { rc = adam_gated(net, ssq, status, true, strm); if (rc) return rc; }
       else hipLaunchKernelGGL(k_nan_status, dim3(1), dim3(1), 0, strm, (const double*)ssq, status);
