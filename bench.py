@@ -273,7 +273,10 @@ def setup_group(args, crux, ctx, rank, world, local):
         dist.all_gather(gathered, mine)
         if all_agree(ok):
             try:
-                handles = np.stack([g.cpu().numpy() for g in gathered]); ctx.peer_attach(rank, world, handles)
+                handles = np.stack([g.cpu().numpy() for g in gathered])
+                if args.inject_attach_failure:      # testing the ladder below: the peers' handles are corrupted, hipIpcOpenMemHandle refuses them on every rank
+                    handles = handles ^ np.uint8(0x5A)
+                ctx.peer_attach(rank, world, handles)
             except Exception as e:      # noqa: BLE001
                 print("bench.py: rank %d cannot attach the peer regions (%r)" % (rank, e), file=sys.stderr); ok = False
             if all_agree(ok):
@@ -336,8 +339,9 @@ def setup_group(args, crux, ctx, rank, world, local):
 def run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P):
     """The first thing a multi-GPU run should do on new hardware: exercise the in-kernel exchange across the REAL devices before anything is timed.
     (1) identical shards: every rank trains on the same rows, so the SUM over ranks / N equals each rank's own gradient up to the rounding of (N - 1) additions -- the
-        group must reproduce an un-grouped learner of a second context on rank 0 (to 1e-6 at N = 2, where g + g and the division by two are exact and only the two
-        compilations of the step differ in the last place; bit equality is reported separately), and a lost, torn or stale slot read shows up as a different sum;
+        group must reproduce a GROUP OF ONE on a second context of rank 0 (crux_peer_attach with nranks = 1: the same instantiation of the learner kernel, no peer) BIT FOR BIT
+        at N = 2, where g + g and the halving are exact (1e-5 for N > 2), and an un-grouped learner -- another compilation of the step -- to 1e-6; a lost, torn or stale slot
+        read shows up as a different sum;
     (2) distinct shards: 64 minibatch steps per learner, the replicas' parameters and Adam state must be bit-identical afterwards;
     (3) flag-wait histograms of (2), one per rank: how long each learner workgroup waited for the slowest peer per exchange;
     (4) the library's own RCCL communicator (crux_comm_init, crux_allreduce_grads -- ncclAllReduce over xGMI): a known vector summed over the ranks.
@@ -360,17 +364,26 @@ def run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P):
     allp = gather_obj(mine)
     res["identical_shards_replicas_equal"] = bool(all(np.array_equal(allp[0], x) for x in allp))
     if rank == 0:
-        ctx2 = crux.Context(local); prev = crux.default_context(); crux.set_default_context(ctx2)      # an un-grouped learner on the same device
+        ctx2 = crux.Context(local); prev = crux.default_context(); crux.set_default_context(ctx2)      # a second context on the same device
         try:
-            pi2, buf2, smp2 = build_problem(crux, cdist.shard_seed(7, 0), workload=args.workload)
-            pa2, pc2 = short_opts(700, 16)
-            ppo_iteration(crux, pi2, buf2, smp2, pa2, pc2, P, 0, None); ctx2.sync()
-            ref = np.concatenate([pi2.A.get_params(), pi2.C.get_params()])
-            res["identical_shards_max_abs_diff_vs_single_learner"] = float(np.abs(ref - mine).max())
-            # (N = 2: g + g and the division by two are exact, so any difference comes from the two compilations of the step -- the group's kernel is another instantiation of
-            #  k_train_fs than the un-grouped learner's, and the compiler's FMA contraction may differ in the last place; a lost, torn or stale slot read is orders larger)
-            res["identical_shards_bit_identical_to_single_learner"] = bool(np.array_equal(ref, mine))
-            res["identical_shards_ok"] = bool(np.abs(ref - mine).max() < (1e-6 if world == 2 else 1e-5))
+            refs = {}
+            for form in ("group_of_one", "ungrouped"):
+                if form == "group_of_one":
+                    ctx2.peer_attach(0, 1, ctx2.peer_export()[None, :])      # the replica-group instantiation of the learner kernel with no peer
+                pi2, buf2, smp2 = build_problem(crux, cdist.shard_seed(7, 0), workload=args.workload)
+                pa2, pc2 = short_opts(700, 16)
+                ppo_iteration(crux, pi2, buf2, smp2, pa2, pc2, P, 0, None); ctx2.sync()
+                refs[form] = np.concatenate([pi2.A.get_params(), pi2.C.get_params()])
+                if form == "group_of_one":
+                    ctx2.peer_detach()
+            res["identical_shards_max_abs_diff_vs_single_learner"] = float(np.abs(refs["ungrouped"] - mine).max())
+            res["identical_shards_max_abs_diff_vs_group_of_one"] = float(np.abs(refs["group_of_one"] - mine).max())
+            # (N = 2: g + g and the division by two are exact, so the group of one -- same kernel instantiation -- must be reproduced bit for bit; the un-grouped learner is another
+            #  instantiation of k_train_fs whose FMA contraction may differ in the last place. A lost, torn or stale slot read is orders larger than either.)
+            res["identical_shards_bit_identical_to_group_of_one"] = bool(np.array_equal(refs["group_of_one"], mine))
+            res["identical_shards_bit_identical_to_single_learner"] = bool(np.array_equal(refs["ungrouped"], mine))
+            res["identical_shards_ok"] = bool((res["identical_shards_bit_identical_to_group_of_one"] if world == 2 else res["identical_shards_max_abs_diff_vs_group_of_one"] < 1e-5)
+                                              and res["identical_shards_max_abs_diff_vs_single_learner"] < (1e-6 if world == 2 else 1e-5))
         finally:
             crux.set_default_context(prev)
     # (2) + (3) distinct shards, histograms on
@@ -478,6 +491,7 @@ def main():
     ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false", help="keep the recorded roofline.traffic constant instead of re-measuring it (the default run measures when rocprofv3 is on PATH)")
     ap.add_argument("--measure-traffic", action="store_true", default=True, help="N = 1: re-measure roofline.traffic in this run -- two child passes of this script under rocprofv3 --pmc FETCH_SIZE / "
                     "--pmc WRITE_SIZE (separate passes, no trace domains), corrected as the microarchitecture guide prescribes; otherwise the recorded constant of profiles/ is reported")
+    ap.add_argument("--inject-attach-failure", action="store_true", help="testing: corrupt the peers' IPC handles so that crux_peer_attach fails on every rank and the fallback ladder is taken")
     ap.add_argument("--selftest", action="store_true", help="N > 1: before timing, check the in-kernel gradient exchange across the real devices (identical shards on every rank must "
                     "reproduce an un-grouped learner; distinct shards must leave the replicas bit-identical), print per-rank flag-wait histograms, and run a 2..N-rank RCCL all-reduce "
                     "through the library's communicator (crux_comm_init / crux_allreduce_grads)")

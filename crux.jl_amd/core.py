@@ -66,6 +66,10 @@ class Context:
         """k = 1: gradient exchange every minibatch (the exact form); k > 1: local Adam steps, theta / m / v averaged in the learner kernel after every k-th (cruxhip.h: crux_peer_set_sync_every)"""
         self.check(self.lib.crux_peer_set_sync_every(self.h, int(k)))
 
+    def peer_set_timeout_ms(self, ms):
+        """in-kernel flag-wait timeout of one exchange (default 30 s): a rank whose peer died gets CruxError(EHIP) after this long instead of a hung GPU"""
+        self.check(self.lib.crux_peer_set_timeout_ms(self.h, int(ms)))
+
     def peer_sync_every(self):
         return int(self.lib.crux_peer_sync_every(self.h))
 
@@ -873,8 +877,9 @@ def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=N
 def _fill_block(sampler, buffer, first, Nsteps, reset):
     """terminate_episode!'s fill_gae! / fill_returns! (src/sampler.jl:56-57) on the rows [first, first + Nsteps) mod capacity of `buffer`."""
     if Nsteps > buffer.capacity:
-        if buffer.haskey("advantage") or buffer.haskey("return") or buffer.haskey("cost_advantage") or buffer.haskey("cost_return"):
-            raise L.CruxError(L.EINVAL, "steps!: a block of %d transitions does not fit the buffer (capacity %d) whose :advantage / :return columns it must fill" % (Nsteps, buffer.capacity))
+        filled = ("advantage", "return", "cost_advantage", "cost_return", "importance_weight", "fwd_importance_weight", "cum_importance_weight", "rev_importance_weight", "traj_importance_weight")
+        if any(buffer.haskey(k) for k in filled):
+            raise L.CruxError(L.EINVAL, "steps!: a block of %d transitions does not fit the buffer (capacity %d) whose %s column(s) it must fill" % (Nsteps, buffer.capacity, " / ".join(":" + k for k in filled if buffer.haskey(k))))
         return
     lib = buffer.ctx.lib
     if buffer.haskey("advantage"):
@@ -903,6 +908,8 @@ def _fill_importance_weights(sampler, buffer, first, Nsteps, reset):
             raise L.CruxError(L.EINVAL, "steps!: the buffer has an :importance_weight column but the agent has no nominal action policy `pa` (sampler.jl:109)")
         if not buffer.haskey("logprob"):
             raise L.CruxError(L.EINVAL, "steps!: :importance_weight needs the :logprob column of the exploration policy (sampler.jl:110)")
+        if float(getattr(pa, "logit_div", 0.0) or 0.0) != 0.0:      # the reference evaluates logpdf(pa, s, a) through pa's own logit_conversion (policies.jl:128-135); the kernel knows the plain softmax only
+            raise L.CruxError(L.EUNSUP, "steps!: :importance_weight with a nominal DiscreteNetwork whose logit conversion is not the plain softmax (logit_div = %g) is not supported" % pa.logit_div)
         head = L.HEAD["categorical"] if isinstance(pa, DiscreteNetwork) else L.HEAD["gaussian"]
         C_ = buffer.capacity; n1 = min(Nsteps, C_ - first)
         ctx.check(lib.crux_importance_weight_rows(buffer.h, pa.h, head, int(first), int(n1)))

@@ -132,7 +132,7 @@ static int32_t peer_upload_table(crux_ctx* c) {
 }
 int32_t crux_peer_export(crux_ctx* c, uint8_t* handle64) {
   if (!c || !handle64) return CRUX_EINVAL;
-  if (c->peer_n > 1) return crux_fail(c, CRUX_EINVAL, "peer_export: this context is attached to a group (detach first)");
+  if (crux_grouped(c)) return crux_fail(c, CRUX_EINVAL, "peer_export: this context is attached to a group (detach first)");
   int32_t rc = peer_region(c); if (rc) return rc;
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
   hipIpcMemHandle_t h; HIPCHK(c, hipIpcGetMemHandle(&h, c->peer_local));
@@ -140,7 +140,7 @@ int32_t crux_peer_export(crux_ctx* c, uint8_t* handle64) {
 }
 int32_t crux_peer_attach(crux_ctx* c, int32_t rank, int32_t nranks, const uint8_t* handles) {
   if (!c || !handles || nranks < 1 || nranks > CRUX_PX_MAXR || rank < 0 || rank >= nranks) return CRUX_EINVAL;
-  if (c->peer_n > 1) return crux_fail(c, CRUX_EINVAL, "peer_attach: already attached");
+  if (crux_grouped(c)) return crux_fail(c, CRUX_EINVAL, "peer_attach: already attached");
   int32_t rc = peer_region(c); if (rc) return rc;
   rc = peer_reset(c); if (rc) return rc;
   int ndev = 0; (void)hipGetDeviceCount(&ndev);
@@ -149,12 +149,14 @@ int32_t crux_peer_attach(crux_ctx* c, int32_t rank, int32_t nranks, const uint8_
     if (r == rank) { c->peer_ptr[r] = c->peer_local; c->peer_ipc[r] = false; continue; }
     hipIpcMemHandle_t h; memcpy(&h, handles + 64 * (size_t)r, 64); void* p = nullptr;
     const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
-    if (e != hipSuccess) { for (int q = 0; q < r; ++q) if (c->peer_ipc[q]) { (void)hipIpcCloseMemHandle(c->peer_ptr[q]); c->peer_ipc[q] = false; }
+    if (e != hipSuccess) { (void)hipGetLastError();      // (reported below; a sticky error would fail the next kernel launch check of this thread)
+      for (int q = 0; q < r; ++q) if (c->peer_ipc[q]) { (void)hipIpcCloseMemHandle(c->peer_ptr[q]); c->peer_ipc[q] = false; }
       return crux_fail(c, CRUX_EHIP, "peer_attach: hipIpcOpenMemHandle for rank %d failed: %s", r, hipGetErrorString(e)); }
     c->peer_ptr[r] = p; c->peer_ipc[r] = true;
   }
   (void)crux_x2_placement_ok(c);
-  c->peer_rank = rank; c->peer_n = nranks; return peer_upload_table(c);
+  c->peer_rank = rank; c->peer_n = nranks; c->peer_solo = nranks == 1;      // nranks == 1: a group of one (the replica-group kernels with no peer: the bit-exact reference of a group on identical shards)
+  return peer_upload_table(c);
 }
 // the same wiring for contexts of ONE process (a multi-GPU single-process host, or several replicas on one device): ctxs[r] is rank r
 int32_t crux_peer_attach_local(crux_ctx* const* ctxs, int32_t n) {
@@ -178,7 +180,7 @@ int32_t crux_peer_detach(crux_ctx* c) {
   if (!c) return CRUX_EINVAL;
   (void)hipStreamSynchronize(c->stream); if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
   for (int r = 0; r < CRUX_PX_MAXR; ++r) { if (c->peer_ipc[r]) (void)hipIpcCloseMemHandle(c->peer_ptr[r]); c->peer_ipc[r] = false; c->peer_ptr[r] = nullptr; }
-  c->peer_n = 0; c->peer_rank = 0;
+  c->peer_n = 0; c->peer_rank = 0; c->peer_solo = false;
   if (c->peer_same_device) { c->peer_same_device = false; crux_same_device_group_leave(); }      // the last member to leave frees the parked blocks
   return CRUX_OK;
 }
@@ -188,6 +190,10 @@ int32_t crux_peer_detach(crux_ctx* c) {
 // averages theta, m and v inside the persistent learner kernel (train_fs_kernel.h). k = 1 (default) is the exact form: the gradient is exchanged every minibatch.
 int32_t crux_peer_set_sync_every(crux_ctx* c, int32_t k) { if (!c) return CRUX_EINVAL; if (k < 1 || k > 65536) return crux_fail(c, CRUX_EINVAL, "peer_set_sync_every: k = %d", k); c->peer_every = k; return CRUX_OK; }
 int32_t crux_peer_sync_every(const crux_ctx* c) { return c ? c->peer_every : 1; }
+// how long a learner workgroup waits for a peer's flag of ONE exchange before it gives up: the launch then ends with CRUX_EHIP ("a replica of the group did not answer") and
+// raises the abort word of every peer, instead of hanging the GPU behind a rank that died. Default 30 000 ms.
+int32_t crux_peer_set_timeout_ms(crux_ctx* c, int32_t ms) { if (!c) return CRUX_EINVAL; if (ms < 1 || ms > 600000) return crux_fail(c, CRUX_EINVAL, "peer_set_timeout_ms: %d ms (1 .. 600 000)", ms);
+  c->peer_timeout_ticks = (long long)ms * 100000ll; return CRUX_OK; }
 int32_t crux_peer_hist_enable(crux_ctx* c, int32_t on) { if (!c) return CRUX_EINVAL; c->peer_hist = on != 0; return CRUX_OK; }
 int32_t crux_peer_wait_hist(crux_ctx* c, uint32_t* out128, int32_t reset) {
   if (!c || !out128) return CRUX_EINVAL;

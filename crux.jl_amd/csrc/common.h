@@ -39,6 +39,8 @@ struct crux_ctx {
   // gradients into over xGMI; peer_ptr[r] is rank r's region as mapped here (own region for r == peer_rank)
   int peer_every = 1;                  // crux_peer_set_sync_every: 1 = gradient exchange every minibatch; k > 1 = local Adam steps, theta / m / v averaged after every k-th
   bool peer_hist = false;              // record the per-step flag waits of the replica-group exchange (crux_peer_hist_enable)
+  bool peer_solo = false;              // crux_peer_attach(ctx, 0, 1, ...): a group of ONE -- the replica-group instantiations of the learner kernels with no peer (the reference form bit-exact group results are compared with)
+  long long peer_timeout_ticks = 3000000000ll;   // in-kernel flag-wait timeout of the replica-group exchange in 10 ns ticks (crux_peer_set_timeout_ms; default 30 s)
   int peer_n = 0, peer_rank = 0; void* peer_local = nullptr; void* peer_ptr[8] = {}; bool peer_ipc[8] = {}; bool peer_fine = false;
   void* rec = nullptr;                 // ExecRec* (exec.h): the fused-step executor's recording state
   // replica group with another context of THIS process on the same device (crux_peer_attach_local): hipFree waits for the whole device, i.e. for the peer's
@@ -72,6 +74,7 @@ struct crux_ctx {
 #define CRUX_PX_STREAM_FLOATS (CRUX_PX_HIST + 64)
 #define CRUX_PX_BYTES (2 * CRUX_PX_STREAM_FLOATS * sizeof(float))
 
+static inline bool crux_grouped(const crux_ctx* c) { return c->peer_n > 1 || c->peer_solo; }      // a replica group is attached (a group of one included)
 int32_t crux_fail(crux_ctx* ctx, int32_t code, const char* fmt, ...);
 void* crux_scratch(crux_ctx* ctx, size_t bytes);       // grows; contents undefined
 void* crux_pinned(crux_ctx* ctx, size_t bytes);
@@ -92,6 +95,7 @@ void crux_prof_end(crux_ctx* ctx, int slot);
 #define HIPCHK(ctx, expr)                                                                       \
   do {                                                                                          \
     hipError_t e__ = (expr);                                                                    \
+    if (e__ != hipSuccess) (void)hipGetLastError();   /* reported here: must not resurface as the "launch error" of the next kernel (crux_launch_check) */ \
     if (e__ != hipSuccess) return crux_fail((ctx), CRUX_EHIP, "%s failed: %s (%s:%d)", #expr,    \
                                             hipGetErrorString(e__), __FILE__, __LINE__);        \
   } while (0)

@@ -3,10 +3,11 @@
 #include <cstdarg>
 #include <mutex>
 
+static std::mutex& crux_err_mu() { static std::mutex mu; return mu; }      // writers (crux_fail) and the reader (crux_last_error) of every context's message
 int32_t crux_fail(crux_ctx* ctx, int32_t code, const char* fmt, ...) {
   char buf[1024];
   va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-  if (ctx) { static std::mutex mu; std::lock_guard<std::mutex> lk(mu); ctx->err = buf; }      // (dense_pair drives two learner chains of one context from two host threads: ADVICE r3)
+  if (ctx) { std::lock_guard<std::mutex> lk(crux_err_mu()); ctx->err = buf; }      // (dense_pair drives two learner chains of one context from two host threads: ADVICE r3)
   return code;
 }
 
@@ -88,12 +89,19 @@ static void prof_resolve(crux_ctx* ctx) {
 }
 
 // the CRUX_* switches: one snapshot per process (switches.h)
-static CruxSwitches g_sw; static bool g_sw_loaded = false;
-const CruxSwitches& crux_sw() { if (!g_sw_loaded) { g_sw = crux_switches_read(); g_sw_loaded = true; } return g_sw; }
+// One process-wide snapshot, published through an atomic pointer: read from the environment on FIRST use and by crux_reload_switches() only -- creating another context
+// does not change the switches under contexts that are already running. Superseded snapshots are kept (a launch path may still hold a reference; a few hundred bytes each).
+static std::atomic<const CruxSwitches*> g_sw{nullptr};
+const CruxSwitches& crux_sw() {
+  const CruxSwitches* s = g_sw.load(std::memory_order_acquire);
+  if (!s) { const CruxSwitches* fresh = new CruxSwitches(crux_switches_read()); const CruxSwitches* expect = nullptr;
+    if (g_sw.compare_exchange_strong(expect, fresh, std::memory_order_acq_rel)) s = fresh; else { delete fresh; s = expect; } }
+  return *s;
+}
 
 extern "C" {
 
-int32_t crux_reload_switches(void) { g_sw = crux_switches_read(); g_sw_loaded = true; return CRUX_OK; }
+int32_t crux_reload_switches(void) { g_sw.store(new CruxSwitches(crux_switches_read()), std::memory_order_release); return CRUX_OK; }
 
 const char* crux_version(void) { return "cruxhip 0.1 (gfx950)"; }
 
@@ -103,7 +111,7 @@ int32_t crux_ctx_create(int32_t device_id, void* stream, crux_ctx** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return CRUX_EHIP;
   if (hipSetDevice(device_id) != hipSuccess) return CRUX_EHIP;
-  crux_reload_switches();      // the environment switches are read here, once per context creation, never on a launch path
+  (void)crux_sw();             // the environment switches are read on first use (normally here, by the process's first context), never on a launch path; crux_reload_switches() re-reads
   crux_ctx* c = new crux_ctx();
   c->device = device_id;
   if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
@@ -143,7 +151,10 @@ int32_t crux_ctx_destroy(crux_ctx* c) {
   return CRUX_OK;
 }
 
-const char* crux_last_error(crux_ctx* c) { return c ? c->err.c_str() : "no context"; }
+const char* crux_last_error(crux_ctx* c) {      // a copy taken under the writers' lock, valid until this thread's next call
+  if (!c) return "no context";
+  static thread_local std::string copy; { std::lock_guard<std::mutex> lk(crux_err_mu()); copy = c->err; } return copy.c_str();
+}
 
 int32_t crux_sync(crux_ctx* c) { if (!c) return CRUX_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); return CRUX_OK; }
 

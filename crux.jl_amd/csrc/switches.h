@@ -1,4 +1,4 @@
-// switches.h -- the CRUX_* environment switches (development / test knobs; DESIGN.md lists them). They are read ONCE, when a context is created (crux_ctx_create calls
+// switches.h -- the CRUX_* environment switches (development / test knobs; DESIGN.md lists them). They are read ONCE, on first use (normally when the first context is created; also by
 // crux_reload_switches), into one process-wide snapshot that every launch site consults: no getenv on any launch path. A test that changes a switch inside one process
 // calls crux_reload_switches() (cruxhip.h) afterwards.
 #pragma once

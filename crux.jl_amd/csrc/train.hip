@@ -36,6 +36,7 @@ static int32_t fill_args(TrainArgs& a, crux_mlp* net, crux_buffer* buf, const cr
   if (!net->has_adam) return crux_fail(c, CRUX_EINVAL, "train!: crux_adam_init was not called for this network");
   if (net->nd.dims[0] != buf->obs_dim) return crux_fail(c, CRUX_EINVAL, "train!: network input %d != obs dim %d", net->nd.dims[0], buf->obs_dim);
   memset(&a, 0, sizeof a);
+  a.px_timeout = net->ctx->peer_timeout_ticks;
   a.nd = net->nd; a.p = net->p; a.g = net->g; a.m = net->m; a.v = net->v; a.bp = net->bp; a.eta = net->eta; a.b1 = net->b1; a.b2 = net->b2; a.eps = net->eps;
   a.S = (const float*)buf->col[CRUX_COL_S]; a.A = buf->col[CRUX_COL_A];
   a.LP = has_col(buf, CRUX_COL_LOGPROB) ? (const float*)buf->col[CRUX_COL_LOGPROB] : nullptr;
@@ -177,7 +178,8 @@ static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_
   if (prof) crux_prof_begin(c, prof_slot);
   // a replica group is attached (comm.hip "peer"): the per-minibatch gradient all-reduce lives in the two-CU kernels only; a learner that would
   // update its parameters through any other kernel is refused rather than trained un-synchronised (gradient-only / single-step calls stay local)
-  a.need_px = (c->peer_n > 1 && a.apply && !a.ids) ? 1 : 0;
+  a.need_px = (crux_grouped(c) && a.apply && !a.ids) ? 1 : 0;
+  a.px_timeout = c->peer_timeout_ticks;
   a.px_every = 1;
   if (a.need_px && c->peer_every > 1) {      // periodic form: k_train_fs<..., PX> only, and only where every replica provably takes the same number of steps
     bool fs = false; int32_t prc = crux_train_fs_launch(c, a, &fs, stream, /*probe=*/true); if (prc) return prc;
@@ -249,7 +251,8 @@ static int32_t run_batch(crux_mlp* net, crux_buffer* buf, TrainArgs& a, int n_ep
   if (epoch_infos) memcpy(epoch_infos, ei.data(), sizeof(float) * CRUX_INFO_N * (size_t)st[2]);
   if (st[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
   if (st[0] == CRUX_EHIP) return crux_fail(c, st[0], "learner kernel stopped: %s", st[4] == 2 ? "its two workgroups were placed on different XCDs (concurrent dispatches interleaved them)" :
-                                     st[4] == 3 ? "a replica of the group did not answer within the timeout or raised the abort word" : "its second workgroup never arrived at the exchange");
+                                     st[4] == 3 ? "a replica of the group did not answer within the timeout or raised the abort word" :
+                                     st[4] == 4 ? "a workgroup never arrived at the abort-latch consensus of a speculatively started learner" : "its second workgroup never arrived at the exchange");
   if (st[0]) return crux_fail(c, st[0], "learner kernel reported status %d", st[0]);
   return CRUX_OK;
 }
@@ -529,14 +532,14 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   // when the actor's kernel reports an earlier stop, the critic is told to leave at its next epoch boundary (TrainArgs.spec_abort), restored, and run on the order
   // composed for e shuffles -- exactly the sequential result either way, never slower than actor-then-critic by more than one critic epoch, twice as fast when the
   // actor does not stop. CRUX_SPEC_PAIR=0: the sequential order.
-  bool spec = !exact && cfg_a->target_kl >= 0.f && cfg_a->max_batches <= 0 && cfg_c->max_batches <= 0 && CRUX_IS_PG(cfg_a->loss) && cfg_c->loss == CRUX_LOSS_VALUE_MSE && c->peer_n <= 1 &&
+  bool spec = !exact && cfg_a->target_kl >= 0.f && cfg_a->max_batches <= 0 && cfg_c->max_batches <= 0 && CRUX_IS_PG(cfg_a->loss) && cfg_c->loss == CRUX_LOSS_VALUE_MSE && !crux_grouped(c) &&
               buf->elements < ((int64_t)1 << 31) && crux_sw().spec_pair;
   { const bool fs_on = (crux_sw().fs != 0) && cfg_a->batch_size > 64 && cfg_a->batch_size <= 128;      // the feature-split kernel also takes a 32-wide second layer
     auto mfma_family = [fs_on](const crux_mlp* n) { const NetDesc& d = n->nd; return d.L == 3 && d.dims[1] == 64 && (d.dims[2] == 64 || (d.dims[2] == 32 && fs_on)); };
     bool family = mfma_family(actor) && mfma_family(critic);
     if (family && (exact || spec) && fs_on && c->learner_cus == 0 && buf->elements >= cfg_a->batch_size && cfg_a->batch_size == cfg_c->batch_size) {      // 64 wide, but does a register-resident kernel instantiate these shapes?
       TrainArgs pa, pk; bool ha = false, hk = false;
-      if (!fill_args(pa, actor, buf, cfg_a, cfg_a->loss) && !fill_args(pk, critic, buf, cfg_c, cfg_c->loss)) { pa.need_px = pk.need_px = (c->peer_n > 1) ? 1 : 0;
+      if (!fill_args(pa, actor, buf, cfg_a, cfg_a->loss) && !fill_args(pk, critic, buf, cfg_c, cfg_c->loss)) { pa.need_px = pk.need_px = crux_grouped(c) ? 1 : 0;
         (void)crux_train_fs_launch(c, pa, &ha, c->stream, true); (void)crux_train_fs_launch(c, pk, &hk, c->stream, true);
         if (!ha || !hk) family = false; } }      // no: the dense engine's pair below instead of one learner after the other
     else spec = false;                           // (the abort latch lives in the feature-split kernel only)
@@ -544,7 +547,7 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
     if (!family) {
       // outside the register-resident family: two dense-engine chains (train_dense.hip), one per learner stream, driven by two host threads -- same condition as above
       // (no early stopping, no minibatch cap: the critic's shuffle chain can be composed ahead of the actor's run), no replica group, CRUX_DENSE_PAIR=0 switches it off
-      if (exact && c->peer_n <= 1 && crux_sw().dense_pair && !crux_sw().force_generic) {
+      if (exact && !crux_grouped(c) && crux_sw().dense_pair && !crux_sw().force_generic) {
         const int32_t rcd = dense_pair(actor, critic, buf, cfg_a, cfg_c, perms_a, perms_c, info_a, info_c, epoch_infos_a, epoch_infos_c);
         if (rcd != CRUX_EUNSUP) return rcd; }
       exact = false; } }     // otherwise dense-engine / generic learners run one after the other on the main stream
@@ -592,31 +595,47 @@ extern "C" int32_t crux_policy_gradient_training(crux_mlp* actor, crux_mlp* crit
   HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
   rc = launch_train(c, k, CRUX_PROF_TRAIN_CRITIC, c->aux_stream); if (rc) return rc;
-  HIPCHK(c, hipEventRecord(c->aux_ev1, c->aux_stream));
-  rc = launch_train(c, a, CRUX_PROF_TRAIN_ACTOR); if (rc) return rc;
+  // From here on the critic's kernel runs on aux_stream and reads status / snapshot blocks of the shared scratch: EVERY exit before it has been waited for goes through
+  // unwind() -- a speculative critic is told to leave (abort word), the stream is drained, and the critic's parameters / Adam state are put back as they were.
+  bool critic_in_flight = true;
+  auto restore_critic = [&]() -> bool {
+    return hipMemcpyAsync(critic->p, snap_p, 4 * np_c, hipMemcpyDeviceToDevice, c->stream) == hipSuccess && hipMemcpyAsync(critic->m, snap_p + np_c, 4 * np_c, hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
+           hipMemcpyAsync(critic->v, snap_p + 2 * np_c, 4 * np_c, hipMemcpyDeviceToDevice, c->stream) == hipSuccess && hipMemcpyAsync(critic->bp, snap_p + 3 * np_c, 16, hipMemcpyDeviceToDevice, c->stream) == hipSuccess; };
+  auto unwind = [&](int32_t code) -> int32_t {
+    if (critic_in_flight) {
+      if (spec) *(volatile unsigned*)c->spec_abort = 1u;
+      (void)hipStreamSynchronize(c->aux_stream);
+      if (spec) { *(volatile unsigned*)c->spec_abort = 0u; (void)restore_critic(); }
+      critic_in_flight = false; }
+    (void)hipStreamSynchronize(c->stream); (void)hipGetLastError();
+    return code; };
+#define PGT_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { (void)hipGetLastError(); return unwind(crux_fail(c, CRUX_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__)); } } while (0)
+  PGT_HIP(hipEventRecord(c->aux_ev1, c->aux_stream));
+  rc = launch_train(c, a, CRUX_PROF_TRAIN_ACTOR); if (rc) return unwind(rc);
   int32_t sta[4], stc[4];
   if (spec) {
     rc = collect(c, a, cfg_a->epochs, info_a, epoch_infos_a, sta);      // waits for the ACTOR only
     const bool wrong = !rc && sta[0] == 0 && sta[2] < cfg_a->epochs;      // the actor stopped after sta[2] epochs: the critic was started on the order of cfg_a->epochs shuffles
-    if (rc || sta[0] || wrong) { *(volatile unsigned*)c->spec_abort = 1u; (void)hipStreamSynchronize(c->aux_stream); *(volatile unsigned*)c->spec_abort = 0u; }
-    if (rc || sta[0] || wrong) {      // undo the critic's speculative steps (an actor that failed: the reference throws inside the actor's batch_train!, the critic never trains)
-      HIPCHK(c, hipMemcpyAsync(critic->p, snap_p, 4 * np_c, hipMemcpyDeviceToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(critic->m, snap_p + np_c, 4 * np_c, hipMemcpyDeviceToDevice, c->stream));
-      HIPCHK(c, hipMemcpyAsync(critic->v, snap_p + 2 * np_c, 4 * np_c, hipMemcpyDeviceToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(critic->bp, snap_p + 3 * np_c, 16, hipMemcpyDeviceToDevice, c->stream)); }
-    if (rc || sta[0]) HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (rc) return rc;
-    if (sta[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
-    if (sta[0]) return crux_fail(c, sta[0], "learner kernel reported status %d", sta[0]);
+    if (rc || sta[0] || wrong) {      // stop the critic and undo its speculative steps (an actor that failed: the reference throws inside the actor's batch_train!, the critic never trains)
+      *(volatile unsigned*)c->spec_abort = 1u; (void)hipStreamSynchronize(c->aux_stream); *(volatile unsigned*)c->spec_abort = 0u; critic_in_flight = false;
+      if (!restore_critic()) { (void)hipGetLastError(); return unwind(crux_fail(c, CRUX_EHIP, "policy_gradient_training: restoring the critic's snapshot failed")); } }
+    if (rc || sta[0]) PGT_HIP(hipStreamSynchronize(c->stream));
+    if (rc) return unwind(rc);
+    if (sta[0] == CRUX_ENAN) return unwind(crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)"));
+    if (sta[0]) return unwind(crux_fail(c, sta[0], "learner kernel reported status %d", sta[0]));
     if (wrong) {
-      HIPCHK(c, hipMemsetAsync(k.status, 0, 256, c->stream)); HIPCHK(c, hipMemsetAsync(k.epoch_infos, 0, ec, c->stream));
+      PGT_HIP(hipMemsetAsync(k.status, 0, 256, c->stream)); PGT_HIP(hipMemsetAsync(k.epoch_infos, 0, ec, c->stream));
       int32_t* oc = nullptr;
-      rc = build_orders(c, buf, 1, sta[2] >= 1 ? a.ord_all + (size_t)(sta[2] - 1) * (size_t)len : nullptr, cfg_c->shuffle_seed, cfg_c->shuffle_counter, d_pc, cfg_c->epochs, c->stream, &oc); if (rc) return rc;
+      rc = build_orders(c, buf, 1, sta[2] >= 1 ? a.ord_all + (size_t)(sta[2] - 1) * (size_t)len : nullptr, cfg_c->shuffle_seed, cfg_c->shuffle_counter, d_pc, cfg_c->epochs, c->stream, &oc); if (rc) return unwind(rc);
       k.ord_all = oc; k.spec_abort = nullptr; k.pre_epochs = sta[2];
-      rc = launch_train(c, k, CRUX_PROF_TRAIN_CRITIC); if (rc) return rc;
-    } else HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
+      rc = launch_train(c, k, CRUX_PROF_TRAIN_CRITIC); if (rc) return unwind(rc);
+    } else PGT_HIP(hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
   } else {
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
-    rc = collect(c, a, cfg_a->epochs, info_a, epoch_infos_a, sta); if (rc) return rc;
+    PGT_HIP(hipStreamWaitEvent(c->stream, c->aux_ev1, 0));
+    rc = collect(c, a, cfg_a->epochs, info_a, epoch_infos_a, sta); if (rc) return unwind(rc);
   }
+  critic_in_flight = false;      // (the main stream now waits for the critic: collect() below synchronises it)
+#undef PGT_HIP
   rc = collect(c, k, cfg_c->epochs, info_c, epoch_infos_c, stc); if (rc) return rc;
   if (sta[0] == CRUX_ENAN || stc[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20)");
   if (sta[0] || stc[0]) return crux_fail(c, sta[0] ? sta[0] : stc[0], "learner kernel reported status %d/%d", sta[0], stc[0]);

@@ -37,6 +37,7 @@ struct TrainArgs {
   int32_t xcd;               // feature-split kernel: the XCD (blockIdx mod 8) whose compute units this learner takes -- actor and critic (and same-device replicas) sit behind different L2s
   int32_t px_hist;           // 1: lane 0 of each workgroup bins its flag wait of every exchange into the own region's histogram (CRUX_PX_HIST)
   int32_t px_every;          // <= 1: the gradient is exchanged every minibatch; k > 1: local Adam steps, theta / m / v are averaged after every k-th (crux_peer_set_sync_every)
+  long long px_timeout;      // flag-wait timeout of one exchange in 10 ns wall-clock ticks (crux_peer_set_timeout_ms): a missing peer becomes CRUX_EHIP instead of a hung GPU
   int32_t px_n, px_rank; float* const* px_tab;   // px_tab: device table [px_n] of the ranks' region bases for this learner stream (own region at px_rank)
   // lagrange_ppo_loss (rl/ppo.jl:70-131): device copy of crux_lagrange (hyper-parameters + PID state), the cost columns; NULL = plain ppo_loss
   crux_lagrange* lag; const float* COST; const float* CADV; const uint8_t* EE;

@@ -36,7 +36,7 @@ struct PgHeadArgs {
 // (four 32-bit words) through one exchange of the peer slots -- the protocol of k_px_allreduce_flat below -- and every rank adds them in rank order, so all replicas advance
 // identical controllers.
 __global__ __launch_bounds__(256) void k_lagrange_pid(crux_lagrange* __restrict__ lgp, const float* __restrict__ COST, const uint8_t* __restrict__ EE, const int32_t* __restrict__ rows, int64_t nb,
-                                                      float* const* __restrict__ px_tab, int rank, int N, int32_t* __restrict__ status) {
+                                                      float* const* __restrict__ px_tab, int rank, int N, int32_t* __restrict__ status, long long tmo) {
   __shared__ double red[4];
   double sc_ = 0.0, ne_ = 0.0;
   for (int64_t i = threadIdx.x; i < nb; i += 256) { const int64_t row = rows[i]; sc_ += (double)COST[row]; ne_ += EE[row] ? 1.0 : 0.0; }
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_lagrange_pid(crux_lagrange* __restrict_
     for (int r = 0; r < N && ok; ++r) { if (r == rank) continue;
       const unsigned long long* fl = (const unsigned long long*)(mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
       while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
+        if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > tmo || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
     if (!ok) { for (int r = 0; r < N; ++r) __hip_atomic_store((unsigned*)(px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); status[0] = CRUX_EHIP; return; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     double g_sc = 0.0, g_ne = 0.0;
@@ -158,7 +158,7 @@ __global__ void k_pg_info(const double* __restrict__ st, const double* __restric
 // the gradient buffer itself) and scale by 1/N: the protocol of the persistent kernels (train_mfma_kernel.h), driven from a stand-alone kernel. Every rank forms the same sums bit
 // for bit, so parameters, Adam state and the host's early-stopping decisions stay replicated.
 #define PXF_CHUNK (CRUX_PX_SLOT - 16)
-__global__ __launch_bounds__(1024) void k_px_allreduce_flat(float* __restrict__ g, int64_t n, double* __restrict__ st, float* const* __restrict__ px_tab, int rank, int N, int32_t* __restrict__ status) {
+__global__ __launch_bounds__(1024) void k_px_allreduce_flat(float* __restrict__ g, int64_t n, double* __restrict__ st, float* const* __restrict__ px_tab, int rank, int N, int32_t* __restrict__ status, long long tmo) {
   __shared__ int ok_s;
   const int tid = threadIdx.x;
   float* const mine = px_tab[rank];
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(1024) void k_px_allreduce_flat(float* __restrict__ 
       for (int r = 0; r < N && ok; ++r) { if (r == rank) continue;
         const unsigned long long* fl = (const unsigned long long*)(mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
         while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
-          if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
+          if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > tmo || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
       if (!ok) for (int r = 0; r < N; ++r) __hip_atomic_store((unsigned*)(px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       ok_s = ok ? 1 : 0;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // one lane: drops the L1 (the slot loads are system-scope atomic loads and pass it anyway)
@@ -250,7 +250,7 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a, hipStream_t strm, int wh
       const int64_t nb = (total_rows - s0) < a.bs ? (total_rows - s0) : a.bs;
       hipLaunchKernelGGL(k_gather_obs, dim3((unsigned)((nb * od + 255) / 256)), dim3(256), 0, strm, a.S, od, order + s0, nb, x);
       int32_t rc = crux_dense_forward(net, x, nb, strm); if (rc) return rc;
-      if (a.lag) hipLaunchKernelGGL(k_lagrange_pid, dim3(1), dim3(256), 0, strm, a.lag, a.COST, a.EE, order + s0, nb, (float* const*)((a.need_px && c->peer_n > 1) ? c->peer_tab + which * CRUX_PX_MAXR : nullptr), c->peer_rank, c->peer_n, status);
+      if (a.lag) hipLaunchKernelGGL(k_lagrange_pid, dim3(1), dim3(256), 0, strm, a.lag, a.COST, a.EE, order + s0, nb, (float* const*)((a.need_px && c->peer_n > 1) ? c->peer_tab + which * CRUX_PX_MAXR : nullptr), c->peer_rank, c->peer_n, status, c->peer_timeout_ticks);
       PgHeadArgs q{}; q.lag = a.lag; q.CADV = a.CADV; q.z = crux_dense_act(net, nd.L); q.nout = nout; q.rows = order + s0; q.nb = nb; q.A = a.A; q.ad = a.ad; q.LP = a.LP; q.ADV = a.ADV; q.RET = a.RET;
       q.loss = a.loss; q.head = a.head; q.lo = 1.f - a.eps_clip; q.hi = 1.f + a.eps_clip; q.lambda_p = a.lambda_p; q.lambda_e = a.lambda_e; q.squash = a.squash;
       q.ls = net->p + nd.xoff; q.dy = dy; q.gx = net->g + nd.xoff; q.stats = st;
@@ -260,7 +260,7 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a, hipStream_t strm, int wh
       const bool group = a.need_px && c->peer_n > 1; Sumsq2Fix fx{};
       rc = crux_dense_backward(net, x, nb, dy, 1.0f, true, nullptr, strm, group ? nullptr : &fx, 0); if (rc) return rc;
       if (group)      // replica group: the gradient (and the statistics) of the GLOBAL minibatch, the same bits on every rank
-        hipLaunchKernelGGL(k_px_allreduce_flat, dim3(1), dim3(1024), 0, strm, net->g, (int64_t)nd.n_params, st, (float* const*)(c->peer_tab + which * CRUX_PX_MAXR), c->peer_rank, c->peer_n, status);
+        hipLaunchKernelGGL(k_px_allreduce_flat, dim3(1), dim3(1024), 0, strm, net->g, (int64_t)nd.n_params, st, (float* const*)(c->peer_tab + which * CRUX_PX_MAXR), c->peer_rank, c->peer_n, status, c->peer_timeout_ticks);
       hipLaunchKernelGGL(k_sumsq2, dim3(SUMSQ_BLOCKS), dim3(256), 0, strm, (float*)net->g, (int64_t)nd.n_params, (float*)nullptr, (int64_t)0, ssq, fx);
       hipLaunchKernelGGL(k_pg_info, dim3(1), dim3(1), 0, strm, (const double*)st, (const double*)ssq, nb, a.loss, a.head, a.lambda_p, a.lambda_e, (const float*)(net->p + nd.xoff), a.ad, dinfo, (const crux_lagrange*)a.lag);
       if (a.apply) { rc = adam_gated(net, ssq, status, true, strm); if (rc) return rc; }

@@ -38,7 +38,7 @@ static int32_t launch_fs(crux_ctx* c, TrainArgs a, int form, bool timing, hipStr
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
   a.xcd = which;      // actor / critic (the context's two learner streams) behind different L2s. (Replicas sharing a device stay on the same XCD pair: spreading them over XCDs
                       // sent their flag / slot traffic across L2s and measured 15.5 against 12.9 us per step on one GPU.)
-  if (c->peer_n > 1 && a.need_px) {      // replica group: four workgroups with helper waves, the in-kernel all-reduce over the peer slots
+  if (crux_grouped(c) && a.need_px) {      // replica group: four workgroups with helper waves, the in-kernel all-reduce over the peer slots
     a.px_hist = c->peer_hist ? 1 : 0; a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
     if (a.px_every > 1) return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, true, false, true, false, true>(c, a, stream);      // periodic form: local Adam steps, theta / m / v averaged every k-th
     return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, true, false, true>(c, a, stream);
@@ -89,7 +89,7 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hip
   const int in = nd.dims[0], h2 = nd.dims[2], out = nd.dims[3], act = nd.acts[0], act2 = nd.acts[1];
   if (a.lag) {     // lagrange_ppo_loss (crux_batch_train_lagrange passes the PPO head with the controller attached): the helper-wave form, one replica, the shapes instantiated in launch_fs;
                    // everything else stays with the two-CU kernel / the dense-engine learner
-    if (kind == MFK_VALUE || a.loss != CRUX_LOSS_PPO || (c->peer_n > 1 && a.need_px) || (form_env != 0 && form_env != 8) || h2 != 64 || act2 != act) return CRUX_OK;
+    if (kind == MFK_VALUE || a.loss != CRUX_LOSS_PPO || (crux_grouped(c) && a.need_px) || (form_env != 0 && form_env != 8) || h2 != 64 || act2 != act) return CRUX_OK;
     const bool shape = (in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) || (in == 8 && out == 4 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) ||
                        (in == 3 && out == 1 && kind == MFK_GAUSSIAN && act == CRUX_ACT_RELU) || (in == 17 && out == 6 && kind == MFK_GAUSSIAN && act == CRUX_ACT_TANH);
     if (!shape) return CRUX_OK;

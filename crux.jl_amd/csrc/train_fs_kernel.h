@@ -285,10 +285,15 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         (void)__hip_atomic_fetch_add(a.xctr + 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned want = (unsigned)NWG * (unsigned)(ep + 1); unsigned spins = 0;
-        while (__hip_atomic_load(a.xctr + 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 24)) break; }
-        sm[Lt::oRED + 17] = __hip_atomic_load(a.xctr + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f; }
+        bool late = false;
+        while (__hip_atomic_load(a.xctr + 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 24)) { late = true; break; } }
+        // a workgroup that never arrived: the consensus cannot be formed. Leave with an error of its own (never "continue on whatever the latch says now" -- the others may read
+        // something else) and raise the latch and the learner's abort word, so that every workgroup that still comes by leaves too instead of waiting at the next gradient exchange.
+        if (late) { (void)__hip_atomic_fetch_or(a.xctr + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        sm[Lt::oRED + 17] = late ? 2.f : (__hip_atomic_load(a.xctr + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f); }
       __syncthreads();
-      if (sm[Lt::oRED + 17] != 0.f) { err = CRUX_TRAIN_ABORTED; break; }
+      if (sm[Lt::oRED + 17] == 2.f) { err = CRUX_EHIP; why_failed = 4; break; }
+      if (sm[Lt::oRED + 17] != 0.f) { err = CRUX_TRAIN_ABORTED; break; }      // (the critic's result is valid only when the latch was never set: the host discards or restores it otherwise)
     }
     if (a.ord_all) order_cur = const_cast<int32_t*>(a.ord_all) + (size_t)ep * (size_t)a.len;   // shuffle orders composed ahead of time by k_compose_order
     else {   // shuffle!(D) as an index composition (experience_buffer.jl:118-124)
@@ -638,7 +643,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
             for (int r = 0; r < a.px_n && ok; ++r) { if (r == a.px_rank) continue;
               const unsigned long long* fl = (const unsigned long long*)(px_mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
               while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > 3000000000ll || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
+                if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > a.px_timeout || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
             if (!ok) { for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
               __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             if (a.px_hist) {      // how long this workgroup waited for the slowest peer's flag (10 ns ticks, log2 bins; workgroups 0 and 1 report)
@@ -910,7 +915,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   if (PX && tid == 0 && p == 0) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)pxc;
   if (tid == 0 && (p == 0 || err)) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
-    if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 3 replica group timeout / abort
+    if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 3 replica group timeout / abort, 4 a workgroup missed the abort-latch consensus of a speculative run
     a.bp[0] = bp1; a.bp[1] = bp2;
     if constexpr (LAG) { if (p == 0) { a.lag->I = lgs[0]; a.lag->smooth_delta = lgs[1]; a.lag->smooth_Jc = lgs[2]; a.lag->Jc_prev = lgs[3]; a.lag->deriv_term = lgs[4]; a.lag->penalty = lgs[5]; a.lag->cur_cost = lgs[6]; } }
     if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = inf_loss; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }

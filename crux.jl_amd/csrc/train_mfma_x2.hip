@@ -49,7 +49,7 @@ static int32_t launch_x2(crux_ctx* c, TrainArgs a, hipStream_t stream) {
   if (!c->xbuf[which]) { if (hipMalloc(&c->xbuf[which], xbytes) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "learner exchange buffer"); }
   a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * CRUX_XBUF_FLOATS);
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
-  if (c->peer_n > 1 && a.need_px) {     // local calls (single steps, gradients) never exchange
+  if (crux_grouped(c) && a.need_px) {     // local calls (single steps, gradients) never exchange
     a.px_hist = c->peer_hist ? 1 : 0; a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
     return launch_x2_form<IN, OUT, KIND, ACT, false, true>(c, a, lds, stream);
   }
@@ -111,7 +111,7 @@ int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, boo
   if (!x2_placement_ok(c)) return CRUX_OK;
   const int in = a.nd.dims[0], out = a.nd.dims[3], act = a.nd.acts[0];
   if (a.lag) {     // lagrange_ppo_loss: its own instantiations, for the shapes below; replica groups and every other shape stay on the dense-engine learner
-    if (c->peer_n > 1 && a.need_px) return CRUX_OK;
+    if (crux_grouped(c) && a.need_px) return CRUX_OK;
 #define MFXL_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_x2<I, O, K, A_>(c, a, stream); }
     MFXL_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)
     MFXL_CASE(8, 4, MFK_CATEGORICAL, CRUX_ACT_RELU)

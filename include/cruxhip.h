@@ -41,8 +41,8 @@ typedef struct crux_env crux_env;
 /* lifecycle --------------------------------------------------------------------------------- */
 /* stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create a private one. */
 int32_t crux_ctx_create(int32_t device_id, void* stream, crux_ctx** out);
-/* The CRUX_* environment switches (development / test knobs) are read when a context is created, into one process-wide snapshot; a process that
- * changes one afterwards calls this to have it take effect. */
+/* The CRUX_* environment switches (development / test knobs) are read ONCE per process, when its first context is created, into one snapshot (creating further
+ * contexts does not re-read them under the ones already running); a process that changes one afterwards calls this to have it take effect. */
 int32_t crux_reload_switches(void);
 int32_t crux_ctx_destroy(crux_ctx* ctx);
 /* How many CUs one small-MLP learner (batch_train!, src/training.jl:28-55) occupies: 0 = automatic (two CUs of one XCD per learner; the batched
@@ -380,7 +380,9 @@ int32_t crux_allreduce_grads(crux_mlp* net);
  * group is attached rather than training un-synchronised. Needs equal buffer lengths on all ranks and every rank making the same sequence of training calls.
  *   crux_peer_export  allocates this context's region and returns its 64-byte IPC handle; ship the handles of all ranks to all ranks;
  *   crux_peer_attach  maps the peers' regions (handles: [nranks][64], own entry ignored). All ranks must have attached before any trains.
- *   crux_peer_attach_local wires contexts of one process directly (ctxs[r] = rank r), e.g. two replicas on one device.                         */
+ *   crux_peer_attach_local wires contexts of one process directly (ctxs[r] = rank r), e.g. two replicas on one device.
+ *   nranks = 1 is a group of ONE: the learner runs the replica-group instantiation of its kernel with no peer (sum of one contribution x 1/1). It is the reference
+ *   a group on identical shards is compared with bit for bit (N = 2: g + g and the halving are exact), which the un-grouped kernel -- another compilation -- is not.      */
 int32_t crux_peer_export(crux_ctx* ctx, uint8_t* handle64);
 int32_t crux_peer_attach(crux_ctx* ctx, int32_t rank, int32_t nranks, const uint8_t* handles);
 int32_t crux_peer_attach_local(crux_ctx* const* ctxs, int32_t n);
@@ -393,6 +395,9 @@ int32_t crux_peer_detach(crux_ctx* ctx);
  * divide the minibatches per epoch so that every call returns with identical replicas; other calls fail with CRUX_EUNSUP / CRUX_EINVAL.                                        */
 int32_t crux_peer_set_sync_every(crux_ctx* ctx, int32_t k);
 int32_t crux_peer_sync_every(const crux_ctx* ctx);
+/* how long a learner workgroup waits for a peer's flag of ONE exchange before it gives up (default 30 000 ms; 1 .. 600 000): the training call then returns CRUX_EHIP and
+ * the abort word of every peer is raised, so the surviving ranks of a group whose member died leave their kernels too instead of hanging the GPU.                      */
+int32_t crux_peer_set_timeout_ms(crux_ctx* ctx, int32_t ms);
 int32_t crux_peer_hist_enable(crux_ctx* ctx, int32_t on);
 int32_t crux_peer_wait_hist(crux_ctx* ctx, uint32_t* out128, int32_t reset);
 int32_t crux_peer_size(const crux_ctx* ctx);               /* 1 when no group is attached */
