@@ -38,6 +38,8 @@ class TrainCfg(C.Structure):
 SIGNATURES = {
     "crux_ctx_create": (i32, [i32, vp, P(vp)]),
     "crux_ctx_destroy": (i32, [vp]),
+    "crux_policy_explore": (i32, [vp, P(RolloutCfg), i32, vp, u64, vp, vp, vp]),
+    "crux_steps_push": (i32, [vp, i64, P(vp), i64, i32, vp, f32, f32, vp, vp, i32, P(i64)]),
     "crux_last_error": (cp, [vp]),
     "crux_sync": (i32, [vp]),
     "crux_version": (cp, []),

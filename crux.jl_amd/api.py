@@ -19,11 +19,11 @@ from . import _lib as L   # noqa: F401
 from .core import *   # noqa: F401,F403
 from .core import (  # noqa: F401
     ActorCritic, Adam, CartPoleMDP, Chain, Context, ContinuousNetwork, ContinuousSpace, CustomLoss, Dense, DiscreteNetwork, DiscreteSpace, DoubleNetwork, EpsGreedyPolicy,
-    ExperienceBuffer, GaussianNoiseExplorationPolicy, GaussianPolicy, GymMDP, LinearDecaySchedule, MultitaskDecaySchedule, NetworkPolicy, ParamLoss, ParamVector, PendulumMDP,
+    ExperienceBuffer, GaussianNoiseExplorationPolicy, GaussianPolicy, GymMDP, HostMDP, LinearDecaySchedule, MultitaskDecaySchedule, NetworkPolicy, ParamLoss, ParamVector, PendulumMDP,
     PolicyParams, SAMPLE_SEED, Sampler, SimpleGridWorld, SquashedGaussianPolicy, SynthMDP, TrainingParams, _F32_KEYS, _Loss, _batch_train_seam, _ensure_opt, _fill_block,
     _fill_importance_weights, _info_dict, _leaves, _np_dtype, _rollout_cfg, _train_cfg, _train_seam, _uses_seam, _vp, a2c_loss, actor, batch_train_, buffer_like, capacity,
     clone_policy, copy_buffer, copyto_, cost_value_mse_loss, critic, default_context, dim, discount, discounted_return, episodes, episodes_, extra_columns, failure, fill_gae_,
-    fill_returns_, get_episodes, hcat, lagrange_ppo_loss, mdp_data, normalize_, peer_attach_local, polyak_average_, ppo_loss, prioritized_sample_, rand_, reinforce_loss,
+    fill_returns_, get_episodes, hcat, lagrange_ppo_loss, mdp_data, normalize_, peer_attach_local, policy_explore, polyak_average_, ppo_loss, prioritized_sample_, rand_, reinforce_loss,
     reload_switches, set_default_context, set_sample_stream_, shuffle_device_, split, split_batches, steps_, steps_multi_, train_, trim_, undiscounted_return, uniform_sample_,
     value, value_mse_loss, whiten_, whiten_multi_)
 from .on_policy import *   # noqa: F401,F403

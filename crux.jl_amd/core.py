@@ -739,6 +739,34 @@ def SimpleGridWorld(**kw):
     return GymMDP("gridworld", **kw)
 
 
+class HostMDP:
+    """An mdp that exists only on the HOST -- any POMDPs.jl-style generative model (LunarLander, MuJoCo, a user's simulator) -- as n_envs independent copies the CALLER steps.
+    The reference's step! calls `sp, r = @gen(:sp,:r)(mdp, s, a)`, `isterminal(mdp, sp)`, `convert_s(AbstractArray, sp, mdp)` (src/sampler.jl:89-97) and reset_sampler!
+    draws `rand(initialstate(mdp))` (:31-43) on whatever mdp the user handed to solve; this class carries those four functions:
+
+        initialstate(e, n_resets) -> s            rand(initialstate(mdp)) for copy e; n_resets = episodes copy e has started so far (for seeded environments)
+        gen(e, s, a, n_steps)     -> (sp, r) | (sp, r, info)      @gen(:sp,:r)(mdp, s, a[; info]); a = the action index (DiscreteSpace, 0-based) or the Float32 action vector;
+                                                   n_steps = steps copy e has taken so far; info["cost"] feeds the :cost column (:114)
+        isterminal(sp)            -> bool
+        observation(s)            -> (obs_dim,) array           convert_s(AbstractArray, s, mdp)
+
+    The policy forward, exploration draws, log-probabilities (crux_policy_explore) and the buffer write with the GAE / return / importance-weight fills (crux_steps_push) run on
+    the device; the Sampler state (s, svec, episode_length, was_reset) stays here, as it stays in Julia in the reference."""
+
+    kind = "host"
+
+    def __init__(self, initialstate, gen, isterminal, observation, obs_dim, act_dim, discrete, n_envs=1, seed=0, discount=0.99):
+        self.initialstate, self.gen, self.isterminal, self.observation = initialstate, gen, isterminal, observation
+        self.obs_dim, self.act_dim, self.discrete = int(obs_dim), int(act_dim), bool(discrete)
+        self.n_envs, self.seed, self.discount = int(n_envs), int(seed), float(discount)
+
+    def state_space(self, mu=0.0, sigma=1.0):
+        return ContinuousSpace(self.obs_dim, np.float32, mu, sigma)
+
+    def action_space(self):
+        return DiscreteSpace(self.act_dim) if self.discrete else ContinuousSpace(self.act_dim)
+
+
 def discount(mdp):
     return mdp.discount
 
@@ -803,6 +831,16 @@ class Sampler:
         od = mdp.obs_dim
         mu = np.ascontiguousarray(np.broadcast_to(np.asarray(self.S.mu, np.float32), (od,)))
         sg = np.ascontiguousarray(np.broadcast_to(np.asarray(self.S.sigma, np.float32), (od,)))
+        self.h = None
+        if isinstance(mdp, HostMDP):      # caller-stepped environments: the Sampler fields of src/sampler.jl:1-22 live here, one entry per copy
+            E = mdp.n_envs
+            self._mu, self._sigma = mu, sg
+            self.s = [None] * E; self.svec = np.zeros((od, E), np.float32, order="F")
+            self.episode_length = np.zeros(E, np.int64); self.n_resets = np.zeros(E, np.int64); self.steps_taken = np.zeros(E, np.int64); self.was_reset = np.zeros(E, np.bool_)
+            for e in range(E):
+                self._reset_one(e)
+            self.was_reset[:] = False      # (a fresh Sampler has was_reset = false, sampler.jl:14)
+            return
         h = C.c_void_p()
         synth = mdp.kind in ("synth", "synth_discrete")
         self.ctx.check(self.ctx.lib.crux_env_create(self.ctx.h, L.ENV[mdp.kind], mdp.n_envs, self.max_steps, float(self.gamma), _vp(mu), _vp(sg),
@@ -812,6 +850,18 @@ class Sampler:
     @property
     def n_envs(self):
         return self.mdp.n_envs
+
+    def _tovec(self, o):
+        """tovec(v, S::ContinuousSpace) = (v .- mu) ./ sigma in Float32 (src/spaces.jl:25)"""
+        return (np.asarray(o, np.float32).reshape(-1) - self._mu) / self._sigma
+
+    def _reset_one(self, e):
+        """reset_sampler! (src/sampler.jl:31-43) of copy e of a HostMDP"""
+        if self.was_reset[e]:
+            return
+        self.s[e] = self.mdp.initialstate(e, int(self.n_resets[e])); self.n_resets[e] += 1
+        self.svec[:, e] = self._tovec(self.mdp.observation(self.s[e]))
+        self.episode_length[e] = 0; self.was_reset[e] = True
 
     def state(self):
         sd = int(self.ctx.lib.crux_env_state_dim(self.h)); E = self.n_envs
@@ -858,6 +908,8 @@ def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=N
     if Nsteps % E:
         raise ValueError("steps!: Nsteps=%d is not a multiple of n_envs=%d" % (Nsteps, E))
     cfg, pi_on = _rollout_cfg(sampler, explore, reset, i)
+    if isinstance(sampler.mdp, HostMDP):
+        return _steps_host(sampler, buffer, Nsteps, cfg, pi_on, explore, i, reset, cb, store)
     sr, ne = C.c_double(), C.c_int64()
     first = buffer.next_ind - 1                                   # 0-based ring row the block starts at (push!, experience_buffer.jl:236)
     if not want_info and cb is None and store is None:      # callers that do not look at the rewards (the off-policy solve loop): the rollout stays asynchronous, no read-back to wait for
@@ -872,6 +924,88 @@ def steps_(sampler, buffer=None, Nsteps=1, explore=False, i=0, reset=False, cb=N
     if store is not None:                                         # :151, after the callback, before push!(buffer, data): the block as the reference's `data` Dict
         store.append(buffer.minibatch((first + np.arange(Nsteps)) % buffer.capacity + 1))
     return info
+
+
+def policy_explore(pi, cfg, svec, seed, steps_taken):
+    """crux_policy_explore (cruxhip.h): `a, logprob = exploration(pi_explore, svec; pi_on, i)` / `(action(pi, svec), NaN)` (src/sampler.jl:73) for the columns of svec at once.
+    Returns (actions [act_dim x E] Bool one-hot or Float32, logprob [E])."""
+    svec = np.asfortranarray(svec, np.float32); E = svec.shape[1]; nout = pi.network.dims[-1]
+    disc = cfg.head in (L.HEAD["categorical"], L.HEAD["greedy_q"])
+    a = np.zeros((nout, E), np.bool_ if disc else np.float32, order="F"); lp = np.empty(E, np.float32)
+    st = np.ascontiguousarray(steps_taken, np.int64)
+    pi.ctx.check(pi.ctx.lib.crux_policy_explore(pi.h, C.byref(cfg), E, _vp(svec), int(seed), _vp(st), _vp(a), _vp(lp)))
+    return a, lp
+
+
+def _steps_host(sampler, buffer, Nsteps, cfg, pi_on, explore, i, reset, cb, store):
+    """steps! / step! (src/sampler.jl:71-155) for the copies of a HostMDP, statement by statement; the block is env-major like the device rollout (copy e owns rows
+    [e*T, (e+1)*T), == hcat of E single-Sampler rollouts) and the interaction counter env-minor (i + t*E + e, :161-163)."""
+    mdp = sampler.mdp; E = sampler.n_envs; T = Nsteps // E
+    A = mdp.action_space()
+    cols = list(sampler.required_columns)
+    if buffer is not None:
+        cols = [k for k in buffer.keys() if k not in ("s", "a", "sp", "r", "done", "episode_end")]
+    data = mdp_data(sampler.S, A, Nsteps, cols)                                   # :140
+    sum_r, n_ee = 0.0, 0
+    for t in range(T):
+        cfg.i0 = int(i) + t * E
+        a_all, lp_all = policy_explore(pi_on, cfg, sampler.svec, mdp.seed, sampler.steps_taken)      # :73 for all copies
+        for e in range(E):
+            j = e * T + t
+            sampler.was_reset[e] = False                                            # :72
+            a = int(np.argmax(a_all[:, e])) if mdp.discrete else a_all[:, e].copy()
+            out = mdp.gen(e, sampler.s[e], a, int(sampler.steps_taken[e]))          # :93-94  sp, r = @gen(:sp,:r)(mdp, s, a; info)
+            sp, r = out[0], out[1]; info = out[2] if len(out) > 2 else {}
+            spvec = sampler._tovec(mdp.observation(sp))                             # :95-96
+            done = bool(mdp.isterminal(sp))                                         # :97
+            data["s"][:, j] = sampler.svec[:, e]; data["a"][:, j] = a_all[:, e]; data["sp"][:, j] = spvec      # :100-102
+            data["r"][0, j] = np.float32(r); data["done"][0, j] = done                                            # :103-104
+            if "logprob" in data:
+                data["logprob"][0, j] = lp_all[e]                                   # :107
+            if "t" in data:
+                data["t"][0, j] = sampler.episode_length[e] + 1                     # :112
+            if "i" in data:
+                data["i"][0, j] = int(i) + t * E + e + 1                            # :113
+            if "cost" in data:
+                data["cost"][0, j] = np.float32(info["cost"])                       # :114
+            sum_r += float(np.float32(r)); sampler.steps_taken[e] += 1
+            sampler.episode_length[e] += 1                                          # :130
+            if done or sampler.episode_length[e] >= sampler.max_steps:              # :131-132  terminate_episode!: the cut here, the fills after the push (crux_steps_push)
+                data["episode_end"][0, j] = True; n_ee += 1
+                sampler._reset_one(e)
+            else:
+                sampler.s[e] = sp; sampler.svec[:, e] = spvec                       # :134-135
+    if reset:                                                                       # :148  reset && terminate_episode!(sampler, data, Nsteps), per copy
+        for e in range(E):
+            j = e * T + T - 1
+            if not data["episode_end"][0, j]:
+                data["episode_end"][0, j] = True; n_ee += 1
+            sampler._reset_one(e)
+    info_out = {"sum_r": sum_r, "n_episode_end": n_ee, "avg_r": sum_r / n_ee if n_ee else float("nan")}
+    if buffer is None:
+        return data
+    first = buffer.next_ind - 1
+    pa = getattr(sampler.agent, "pa", None) if buffer.haskey("importance_weight") else None
+    if buffer.haskey("importance_weight") and pa is None:
+        raise L.CruxError(L.EINVAL, "steps!: the buffer has an :importance_weight column but the agent has no nominal action policy `pa` (sampler.jl:109)")
+    if pa is not None and float(getattr(pa, "logit_div", 0.0) or 0.0) != 0.0:
+        raise L.CruxError(L.EUNSUP, "steps!: :importance_weight with a nominal DiscreteNetwork whose logit conversion is not the plain softmax is not supported")
+    ptrs = (C.c_void_p * L.NCOLS)(); keep = []
+    for k, v in data.items():
+        arr = np.asfortranarray(v); keep.append(arr); ptrs[L.COL[k]] = arr.ctypes.data
+    cr = critic(sampler.agent.pi) if buffer.haskey("advantage") else None
+    fr = C.c_int64()
+    buffer.ctx.check(buffer.ctx.lib.crux_steps_push(buffer.h, int(Nsteps), ptrs, int(T), 1 if reset else 0, cr.h if cr is not None else None, float(sampler.lam), float(sampler.gamma),
+                                                    sampler.Vc.h if sampler.Vc is not None else None, pa.h if pa is not None else None,
+                                                    (L.HEAD["categorical"] if isinstance(pa, DiscreteNetwork) else L.HEAD["gaussian"]) if pa is not None else 0, C.byref(fr)))
+    assert fr.value == first
+    if buffer.haskey("traj_importance_weight"):
+        _fill_traj_weights(sampler, buffer, first, Nsteps, reset)
+    if cb:
+        cb(buffer, info_out)
+    if store is not None:
+        store.append(buffer.minibatch((first + np.arange(Nsteps)) % buffer.capacity + 1))
+    return info_out
 
 
 def _fill_block(sampler, buffer, first, Nsteps, reset):
@@ -918,6 +1052,11 @@ def _fill_importance_weights(sampler, buffer, first, Nsteps, reset):
     if any(buffer.haskey(k) for k in ("fwd_importance_weight", "cum_importance_weight", "rev_importance_weight")):
         ctx.check(lib.crux_fill_importance_weights_rows(buffer.h, int(first), int(Nsteps), int(Nsteps // sampler.n_envs), 1 if reset else 0))
     if buffer.haskey("traj_importance_weight"):
+        _fill_traj_weights(sampler, buffer, first, Nsteps, reset)
+
+
+def _fill_traj_weights(sampler, buffer, first, Nsteps, reset):
+    if True:
         # data[:traj_importance_weight][1, ep] .= sampler.traj_weight_fn(sampler.agent, data, ep) (sampler.jl:62): a host function of the episode's rows
         fn = getattr(sampler, "traj_weight_fn", None)
         if fn is None:

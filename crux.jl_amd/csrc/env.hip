@@ -127,15 +127,13 @@ struct RolloutArgs {
   float squash;      // SquashedGaussianPolicy ascale, 0 = GaussianPolicy
 };
 
-// Everything of step! after the policy forward (sampler.jl:73-136): action + logprob from the head, env transition, column writes,
-// episode bookkeeping. `writer` lanes store to the buffer; all callers advance identical copies of the sampler state.
-__device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* z, const int od, const int ad, const int nout, const int kind, const int e,
-                                             const int64_t t, const int64_t j, const bool writer, double* st, int64_t& ep_len, int64_t& n_resets,
-                                             int64_t& steps_taken, double& sum_r, int64_t& nee, float* next_obs) {
-  const int sd = kind == CRUX_ENV_CARTPOLE ? 4 : (env_is_synth(kind) ? a.sd : 2);
-      const uint64_t gi = a.cfg.i0 + (uint64_t)t * (uint64_t)a.E + (uint64_t)e;    // i + (j-1), env-minor (sampler.jl:161-163)
-      const uint64_t ctr = (uint64_t)steps_taken;
-      float logprob = NAN; int ai = 0; float aout[ENV_MAXOBS];
+// exploration(pi_explore, svec; pi_on, i) / action(pi, svec) (sampler.jl:73; policies.jl:124-144, 338-344, 372-394, 466-494, 499-514) given the network outputs z of ONE
+// observation: the action (aout: one-hot floats for the discrete heads, the action vector otherwise; ai: the discrete index) and its log-probability. Every draw is
+// crux_philox(seed, f(ctr), stream = e, purpose) with ctr = the number of steps sampler e has taken so far -- shared by the rollout kernels (device environments) and
+// k_policy_explore (caller-stepped environments, crux_policy_explore), so the two produce the same actions from the same observations.
+__device__ __forceinline__ void rollout_head(const RolloutArgs& a, const float* z, const int ad, const int nout, const int e, const uint64_t gi, const uint64_t ctr,
+                                             float* aout, int& ai, float& logprob) {
+      logprob = NAN; ai = 0;
       if (a.cfg.head == CRUX_HEAD_CATEGORICAL || a.cfg.head == CRUX_HEAD_GREEDY_Q) {
         int greedy = 0; for (int q = 1; q < nout; ++q) if (z[q] > z[greedy]) greedy = q;
         if (!a.cfg.explore) ai = greedy;
@@ -185,6 +183,18 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
             av = av < a.cfg.a_min ? a.cfg.a_min : av > a.cfg.a_max ? a.cfg.a_max : av; }
           aout[q] = av; }
       }
+      if (a.cfg.explore == 2) logprob = NAN;      // action(pi, s) of an always_stochastic policy: exploration(pi, s)[1] with logprob NaN (policies.jl:124, sampler.jl:73)
+}
+// Everything of step! after the policy forward (sampler.jl:73-136): action + logprob from the head, env transition, column writes,
+// episode bookkeeping. `writer` lanes store to the buffer; all callers advance identical copies of the sampler state.
+__device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* z, const int od, const int ad, const int nout, const int kind, const int e,
+                                             const int64_t t, const int64_t j, const bool writer, double* st, int64_t& ep_len, int64_t& n_resets,
+                                             int64_t& steps_taken, double& sum_r, int64_t& nee, float* next_obs) {
+  const int sd = kind == CRUX_ENV_CARTPOLE ? 4 : (env_is_synth(kind) ? a.sd : 2);
+      const uint64_t gi = a.cfg.i0 + (uint64_t)t * (uint64_t)a.E + (uint64_t)e;    // i + (j-1), env-minor (sampler.jl:161-163)
+      const uint64_t ctr = (uint64_t)steps_taken;
+      float logprob; int ai; float aout[ENV_MAXOBS];
+      rollout_head(a, z, ad, nout, e, gi, ctr, aout, ai, logprob);
       // ---- env transition (sampler.jl:93-97)
       double sn[ENV_MAXSD]; float r; uint8_t done; float o[ENV_MAXOBS], spv[ENV_MAXOBS];
       if (kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done);
@@ -199,7 +209,6 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
         else { float* A = (float*)a.A + (size_t)j * ad; for (int q = 0; q < ad; ++q) A[q] = aout[q]; }
         for (int q = 0; q < od; ++q) a.SP[(size_t)j * od + q] = spv[q];
         a.R[j] = r; a.D[j] = done;
-        if (a.cfg.explore == 2) logprob = NAN;      // action(pi, s) of an always_stochastic policy: exploration(pi, s)[1] with logprob NaN (policies.jl:124, sampler.jl:73)
         if (a.LP) a.LP[j] = logprob;
         if (a.TT) a.TT[j] = ep_len + 1;
         if (a.II) a.II[j] = (int64_t)gi + 1;
@@ -248,6 +257,25 @@ __device__ __forceinline__ float env_wave_sum_uniform(float v) {      // the sam
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(b0));
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a0 + b0)));
 }
+// the forward pass of the register-resident IN-64-64-OUT policy on ONE observation, by one wave: lane j holds row j of W1 / W2 and column j of W3. Layers 1 and 2 are fma chains over
+// k ascending (+ bias, activation), layer 3 a product per lane summed over the wave in one fixed order. Shared by k_rollout_h64 and k_explore_h64 (same bits from the same observation).
+template <int IN, int OUT, int ACT>
+__device__ __forceinline__ void h64_forward(const float (&w1)[IN], const float (&w2)[64], const float (&w3)[OUT], const float (&b3)[OUT], const float b1, const float b2,
+                                            const float (&x)[IN], float* sh, const int lane, float (&z)[OUT]) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < IN; ++k) acc = fmaf(w1[k], x[k], acc);
+    sh[lane] = crux_act(ACT, acc + b1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    acc = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) { const float4 hv = *(const float4*)&sh[4 * k4];
+      acc = fmaf(w2[4 * k4], hv.x, acc); acc = fmaf(w2[4 * k4 + 1], hv.y, acc); acc = fmaf(w2[4 * k4 + 2], hv.z, acc); acc = fmaf(w2[4 * k4 + 3], hv.w, acc); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const float h2 = crux_act(ACT, acc + b2);
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) z[o] = env_wave_sum_uniform(w3[o] * h2) + b3[o];
+}
 template <int IN, int OUT, int ACT, int KIND>
 __global__ __launch_bounds__(64) void k_rollout_h64(RolloutArgs a_single, const RolloutArgs* __restrict__ multi) {
   __shared__ __attribute__((aligned(16))) float sh[64];
@@ -276,20 +304,8 @@ __global__ __launch_bounds__(64) void k_rollout_h64(RolloutArgs a_single, const 
 #pragma unroll
       for (int k = 0; k < IN; ++k) a.S[(size_t)j * IN + k] = x[k];
     }
-    float acc = 0.f;
-#pragma unroll
-    for (int k = 0; k < IN; ++k) acc = fmaf(w1[k], x[k], acc);
-    sh[lane] = crux_act(ACT, acc + b1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    acc = 0.f;
-#pragma unroll
-    for (int k4 = 0; k4 < 16; ++k4) { const float4 hv = *(const float4*)&sh[4 * k4];
-      acc = fmaf(w2[4 * k4], hv.x, acc); acc = fmaf(w2[4 * k4 + 1], hv.y, acc); acc = fmaf(w2[4 * k4 + 2], hv.z, acc); acc = fmaf(w2[4 * k4 + 3], hv.w, acc); }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    const float h2 = crux_act(ACT, acc + b2);
     float z[OUT];
-#pragma unroll
-    for (int o = 0; o < OUT; ++o) z[o] = env_wave_sum_uniform(w3[o] * h2) + b3[o];
+    h64_forward<IN, OUT, ACT>(w1, w2, w3, b3, b1, b2, x, sh, lane, z);
     rollout_tail(a, z, IN, OUT, OUT, KIND, e, t, j, lane == 0, st, ep_len, n_resets, steps_taken, sum_r, nee, nx);
 #pragma unroll
     for (int k = 0; k < IN; ++k) x[k] = nx[k];
@@ -312,6 +328,31 @@ __global__ __launch_bounds__(64) void k_rollout_h64(RolloutArgs a_single, const 
 // NT = threads sharing the body: 64 (one wave, ordered by a wave barrier) or 256 (one workgroup per environment, ordered by __syncthreads: the wide-network rollout
 // kernel below -- with 256-wide layers one wave needed 117 us per step). Thread 0 runs the tail either way; the layer arithmetic (fma over k ascending, + bias,
 // activation) is the same, so the results are.
+// Chain(Dense...) on ONE observation held in hbuf[0] (sampler.jl:73 -> policies.jl:94,120) by NT threads: thread o evaluates output unit o (fma over k ascending, + bias,
+// activation); returns the index of the hbuf half that holds the outputs. Shared by the generic rollout kernels and k_explore_generic.
+template <int NT>
+__device__ __forceinline__ int rollout_generic_forward(const RolloutArgs& a, const int lane, float (*hbuf)[1024]) {
+    const NetDesc& nd = a.nd;
+    int cur = 0;
+    for (int l = 0; l < nd.L; ++l) {
+      const int in = nd.dims[l], out = nd.dims[l + 1], act = nd.acts[l];
+      const float* Wl = a.p + nd.woff[l]; const float* bl = a.p + nd.boff[l];
+      for (int o = lane; o < out; o += NT) {
+        float accv = 0.f; int k = 0;
+        for (; k + 8 <= in; k += 8) {          // eight independent weight loads in flight; the fma chain keeps its order
+          float wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) wv[u] = Wl[o + out * (k + u)];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) accv = fmaf(wv[u], hbuf[cur][k + u], accv); }
+        for (; k < in; ++k) accv = fmaf(Wl[o + out * k], hbuf[cur][k], accv);
+        hbuf[cur ^ 1][o] = crux_act(act, accv + bl[o]);
+      }
+      if (NT == 64) { RO_WAVE_SYNC(); } else { __syncthreads(); }
+      cur ^= 1;
+    }
+    return cur;
+}
 template <int NT = 64>
 __device__ __forceinline__ void rollout_generic_wave(const RolloutArgs& a, const int e, const int lane, float (*hbuf)[1024], float* sh_misc) {
 #define RO_SYNC() do { if (NT == 64) { RO_WAVE_SYNC(); } else { __syncthreads(); } } while (0)
@@ -330,24 +371,7 @@ __device__ __forceinline__ void rollout_generic_wave(const RolloutArgs& a, const
     // current observation -> S column (sampler.jl:100)
     if (lane < od) a.S[(size_t)j * od + lane] = hbuf[0][lane];
     // ---- policy forward: Chain(Dense...) on a batch of one (sampler.jl:73 -> policies.jl:94,120)
-    int cur = 0;
-    for (int l = 0; l < nd.L; ++l) {
-      const int in = nd.dims[l], out = nd.dims[l + 1], act = nd.acts[l];
-      const float* Wl = a.p + nd.woff[l]; const float* bl = a.p + nd.boff[l];
-      for (int o = lane; o < out; o += NT) {
-        float accv = 0.f; int k = 0;
-        for (; k + 8 <= in; k += 8) {          // eight independent weight loads in flight; the fma chain keeps its order
-          float wv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) wv[u] = Wl[o + out * (k + u)];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) accv = fmaf(wv[u], hbuf[cur][k + u], accv); }
-        for (; k < in; ++k) accv = fmaf(Wl[o + out * k], hbuf[cur][k], accv);
-        hbuf[cur ^ 1][o] = crux_act(act, accv + bl[o]);
-      }
-      RO_SYNC();
-      cur ^= 1;
-    }
+    const int cur = rollout_generic_forward<NT>(a, lane, hbuf);
     // (the observation in hbuf[0] was already stored to the S column, so the ping-pong may overwrite it)
     // the tail with compile-time kind and dimensions for the restated environments (its per-step arrays are then registers; with run-time dimensions they are
     // private memory and the step costs ~3x more), the run-time form for everything else (SYNTH envs of any width)
@@ -381,6 +405,49 @@ __global__ __launch_bounds__(256) void k_rollout_wide(RolloutArgs a) {
   __shared__ float hbuf[2][1024];
   __shared__ float sh_misc[ENV_MAXOBS + 8];
   rollout_generic_wave<256>(a, blockIdx.x, threadIdx.x, hbuf, sh_misc);
+}
+
+// ---- caller-stepped environments: step! with an arbitrary mdp on the host (sampler.jl:71-137) ----------------------------------------------------------------
+// The reference's step! calls @gen(:sp,:r)(mdp, s, a) on whatever mdp the user handed to solve (sampler.jl:89-97). For environments that only exist on the host the
+// device part of a step is the policy: exploration(pi_explore, svec; pi_on, i) / action(pi, svec) (sampler.jl:73) for the E current observations at once --
+// a.svec = observations [od x E], a.steps_taken = draws each sampler has made so far, a.cfg.i0 = the interaction counter of sampler 0; outputs a.A (one-hot bytes or
+// Float32 [ad x E]) and a.LP [E]. The forward pass and the head are the rollout kernels' own (h64_forward / rollout_generic_forward, rollout_head): a caller that steps the
+// restated CartPole on the host gets the transitions crux_rollout produces, bit for bit (tests/test_gpu_host_env.py).
+__device__ __forceinline__ void explore_store(const RolloutArgs& a, const int e, const int ad, const float* aout, const float logprob) {
+  if (a.act_kind == CRUX_ACTION_DISCRETE) { uint8_t* A = (uint8_t*)a.A + (size_t)e * ad; for (int q = 0; q < ad; ++q) A[q] = aout[q] != 0.f; }
+  else { float* A = (float*)a.A + (size_t)e * ad; for (int q = 0; q < ad; ++q) A[q] = aout[q]; }
+  a.LP[e] = logprob;
+}
+template <int IN, int OUT, int ACT>
+__global__ __launch_bounds__(64) void k_explore_h64(RolloutArgs a) {
+  __shared__ __attribute__((aligned(16))) float sh[64];
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const NetDesc& nd = a.nd;
+  float w1[IN], w2[64], w3[OUT], b3[OUT], x[IN], z[OUT];
+#pragma unroll
+  for (int k = 0; k < IN; ++k) w1[k] = a.p[nd.woff[0] + lane + 64 * k];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) w2[k] = a.p[nd.woff[1] + lane + 64 * k];
+#pragma unroll
+  for (int o = 0; o < OUT; ++o) { w3[o] = a.p[nd.woff[2] + o + OUT * lane]; b3[o] = a.p[nd.boff[2] + o]; }
+  const float b1 = a.p[nd.boff[0] + lane], b2 = a.p[nd.boff[1] + lane];
+#pragma unroll
+  for (int k = 0; k < IN; ++k) x[k] = a.svec[(size_t)e * IN + k];
+  h64_forward<IN, OUT, ACT>(w1, w2, w3, b3, b1, b2, x, sh, lane, z);
+  float aout[ENV_MAXOBS]; int ai; float logprob;
+  rollout_head(a, z, OUT, OUT, e, a.cfg.i0 + (uint64_t)e, (uint64_t)a.steps_taken[e], aout, ai, logprob);
+  if (lane == 0) explore_store(a, e, OUT, aout, logprob);
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void k_explore_generic(RolloutArgs a) {
+  __shared__ float hbuf[2][1024];
+  const int e = blockIdx.x, lane = threadIdx.x, od = a.od, nout = a.nd.dims[a.nd.L];
+  if (lane < od) hbuf[0][lane] = a.svec[(size_t)e * od + lane];
+  if (NT == 64) { RO_WAVE_SYNC(); } else { __syncthreads(); }
+  const int cur = rollout_generic_forward<NT>(a, lane, hbuf);
+  if (lane == 0) { float aout[ENV_MAXOBS]; int ai; float logprob;
+    rollout_head(a, hbuf[cur], a.ad, nout, e, a.cfg.i0 + (uint64_t)e, (uint64_t)a.steps_taken[e], aout, ai, logprob);
+    explore_store(a, e, a.ad, aout, logprob); }
 }
 
 // ---- the whole off-policy solve loop of a small network in ONE launch ------------------------------------------------------------------------
@@ -814,6 +881,69 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
 }
 
 // steps! for n independent samplers of equal shape in ONE launch (multi-seed runs): problem r rolls out its own policy on its own environments into its own buffer
+// exploration(pi_explore, svec; pi_on, i) / action(pi, svec) of step! (sampler.jl:73) for n_envs caller-stepped samplers at once: see k_explore_* above.
+int32_t crux_policy_explore(crux_mlp* policy, const crux_rollout_cfg* cfg, int32_t n_envs, const float* obs, uint64_t seed, const int64_t* steps_taken,
+                            void* actions_out, float* logprob_out) {
+  if (!policy || !cfg || !obs || !actions_out || n_envs < 1) return CRUX_EINVAL;
+  crux_ctx* c = policy->ctx; const NetDesc& pn = policy->nd;
+  if (pn.L < 1) return crux_fail(c, CRUX_EINVAL, "policy_explore: the policy has no layers");
+  const int od = pn.dims[0], nout = pn.dims[pn.L];
+  if (od > ENV_MAXOBS || nout > ENV_MAXOBS) return crux_fail(c, CRUX_EUNSUP, "policy_explore: observation / action widths (%d, %d) above %d", od, nout, ENV_MAXOBS);
+  if (pn.maxdim > 1024) return crux_fail(c, CRUX_EUNSUP, "policy_explore: layer width %d > 1024", pn.maxdim);
+  if (cfg->head < CRUX_HEAD_CATEGORICAL || cfg->head > CRUX_HEAD_DETERMINISTIC) return crux_fail(c, CRUX_EINVAL, "policy_explore: head %d", cfg->head);
+  if (cfg->head == CRUX_HEAD_GAUSSIAN && pn.n_extra != nout) return crux_fail(c, CRUX_EINVAL, "policy_explore: GaussianPolicy needs %d logSigma extras", nout);
+  const bool disc = cfg->head == CRUX_HEAD_CATEGORICAL || cfg->head == CRUX_HEAD_GREEDY_Q;
+  const size_t E = (size_t)n_envs, b_obs = (4 * E * od + 255) / 256 * 256, b_st = (8 * E + 255) / 256 * 256, b_act = (E * nout * (disc ? 1 : 4) + 255) / 256 * 256, b_lp = (4 * E + 255) / 256 * 256;
+  char* sc = (char*)crux_scratch(c, b_obs + b_st + b_act + b_lp); if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_explore: scratch");
+  RolloutArgs a = RolloutArgs{};
+  a.nd = pn; a.p = policy->p; a.E = n_envs; a.od = od; a.ad = nout; a.act_kind = disc ? CRUX_ACTION_DISCRETE : CRUX_ACTION_CONTINUOUS; a.seed = seed;
+  a.svec = (float*)sc; a.steps_taken = (int64_t*)(sc + b_obs); a.A = sc + b_obs + b_st; a.LP = (float*)(sc + b_obs + b_st + b_act); a.cfg = *cfg; a.squash = policy->squash;
+  HIPCHK(c, hipMemcpyAsync(a.svec, obs, 4 * E * od, hipMemcpyHostToDevice, c->stream));
+  if (steps_taken) HIPCHK(c, hipMemcpyAsync(a.steps_taken, steps_taken, 8 * E, hipMemcpyHostToDevice, c->stream));
+  else HIPCHK(c, hipMemsetAsync(a.steps_taken, 0, 8 * E, c->stream));
+  // the arithmetic of the rollout kernel that serves this policy shape (crux_rollout: the register-resident form for the instantiated IN-64-64-OUT shapes, else the generic one)
+  const bool h64 = pn.L == 3 && pn.dims[1] == 64 && pn.dims[2] == 64 && pn.acts[0] == pn.acts[1] && pn.acts[2] == CRUX_ACT_IDENTITY && !crux_sw().force_generic;
+#define EX_CASE(I, O, A_) if (h64 && od == I && nout == O && pn.acts[0] == A_) hipLaunchKernelGGL((k_explore_h64<I, O, A_>), dim3(n_envs), dim3(64), 0, c->stream, a); else
+  EX_CASE(4, 2, CRUX_ACT_RELU) EX_CASE(4, 2, CRUX_ACT_TANH) EX_CASE(3, 1, CRUX_ACT_RELU) EX_CASE(3, 1, CRUX_ACT_TANH) EX_CASE(17, 6, CRUX_ACT_TANH) EX_CASE(17, 6, CRUX_ACT_RELU)
+#undef EX_CASE
+  if (pn.maxdim >= 128) hipLaunchKernelGGL(k_explore_generic<256>, dim3(n_envs), dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_explore_generic<64>, dim3(n_envs), dim3(64), 0, c->stream, a);
+  int32_t rc = crux_launch_check(c, "k_explore"); if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(actions_out, a.A, E * nout * (disc ? 1 : 4), hipMemcpyDeviceToHost, c->stream));
+  if (logprob_out) HIPCHK(c, hipMemcpyAsync(logprob_out, a.LP, 4 * E, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CRUX_OK;
+}
+
+// the tail of steps! for a block the CALLER stepped (sampler.jl:139-155): push!(buffer, data) of the n transitions (ring write, experience_buffer.jl:232-259) and, on the ring rows
+// just written, what terminate_episode! ran on the reference's `data` before the push (sampler.jl:53-66): fill_gae! / fill_returns!, the importance-weight products, the cost
+// advantage / return -- for whichever of those columns the buffer has. cols[CRUX_COL_EPISODE_END] carries the caller's episode cuts (done, max_steps, the reset at the end).
+int32_t crux_steps_push(crux_buffer* buf, int64_t n, const void* const* cols, int64_t rows_per_env, int32_t close_last, crux_mlp* critic, float lambda, float gamma,
+                        crux_mlp* cost_critic, crux_mlp* nominal, int32_t nominal_head, int64_t* first_row_out) {
+  if (!buf || !cols || n < 0) return CRUX_EINVAL;
+  crux_ctx* c = buf->ctx;
+  if (n > buf->capacity && (has_col(buf, CRUX_COL_ADVANTAGE) || has_col(buf, CRUX_COL_RETURN) || has_col(buf, CRUX_COL_COST_ADVANTAGE) || has_col(buf, CRUX_COL_COST_RETURN) ||
+                            has_col(buf, CRUX_COL_FWD_IMPORTANCE_WEIGHT) || has_col(buf, CRUX_COL_CUM_IMPORTANCE_WEIGHT) || has_col(buf, CRUX_COL_REV_IMPORTANCE_WEIGHT) || (nominal && has_col(buf, CRUX_COL_IMPORTANCE_WEIGHT))))
+    return crux_fail(c, CRUX_EINVAL, "steps!: a block of %lld transitions does not fit the buffer (capacity %lld) whose advantage / return / importance-weight columns it must fill", (long long)n, (long long)buf->capacity);
+  if (!cols[CRUX_COL_EPISODE_END]) return crux_fail(c, CRUX_EINVAL, "steps_push: the block needs its :episode_end column (the caller's Sampler cuts the episodes: sampler.jl:130-136,148)");
+  const int64_t first = buf->next_ind;
+  if (first_row_out) *first_row_out = first;
+  int32_t rc = crux_buffer_push_host(buf, n, cols, nullptr); if (rc) return rc;
+  if (n == 0 || n > buf->capacity) return CRUX_OK;
+  if (has_col(buf, CRUX_COL_ADVANTAGE)) { if (!critic) return crux_fail(c, CRUX_EINVAL, "steps_push: the buffer has an :advantage column but no critic was given (fill_gae!, sampler.jl:56)");
+    rc = crux_fill_gae_rows(buf, critic, lambda, gamma, first, n, rows_per_env, close_last); if (rc) return rc; }
+  if (has_col(buf, CRUX_COL_RETURN)) { rc = crux_fill_returns_rows(buf, gamma, first, n, rows_per_env, close_last); if (rc) return rc; }
+  if (nominal && has_col(buf, CRUX_COL_IMPORTANCE_WEIGHT)) {      // step! wrote exp(logpdf(pa, s, a) - logprob) per row (sampler.jl:108-111): the same on the pushed rows (a wrapped block takes two ranges)
+    const int64_t n1 = n < buf->capacity - first ? n : buf->capacity - first;
+    rc = crux_importance_weight_rows(buf, nominal, nominal_head, first, n1); if (rc) return rc;
+    if (n1 < n) { rc = crux_importance_weight_rows(buf, nominal, nominal_head, 0, n - n1); if (rc) return rc; } }
+  rc = crux_fill_importance_weights_rows(buf, first, n, rows_per_env, close_last); if (rc) return rc;
+  if (has_col(buf, CRUX_COL_COST_ADVANTAGE)) { if (!cost_critic) return crux_fail(c, CRUX_EINVAL, "steps_push: the buffer has a :cost_advantage column but no cost critic (Sampler.Vc, sampler.jl:65)");
+    rc = crux_fill_gae_rows_keys(buf, cost_critic, lambda, gamma, first, n, rows_per_env, close_last, CRUX_COL_COST, CRUX_COL_COST_ADVANTAGE); if (rc) return rc; }
+  if (has_col(buf, CRUX_COL_COST_RETURN)) { rc = crux_fill_returns_rows_keys(buf, gamma, first, n, rows_per_env, close_last, CRUX_COL_COST, CRUX_COL_COST_RETURN); if (rc) return rc; }
+  return CRUX_OK;
+}
+
 int32_t crux_rollout_multi(int32_t n, crux_env* const* envs, crux_mlp* const* policies, const crux_rollout_cfg* cfg, crux_buffer* const* bufs, int64_t T, double* sum_r, int64_t* n_episode_end) {
   if (n < 1 || !envs || !policies || !cfg || !bufs || T < 1) return CRUX_EINVAL;
   crux_ctx* c = envs[0]->ctx; crux_env* e0 = envs[0]; const NetDesc& pn = policies[0]->nd; const int nout = pn.dims[pn.L];

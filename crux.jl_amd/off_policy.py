@@ -408,7 +408,7 @@ def _solve_small_dqn(solver, D, s, gamma, i, stop):
     """The iterations i, i + dN, ..., stop of solve(::OffPolicySolver) for a small DQN as a few launches of the one-workgroup solve kernel (cruxhip.h:
     crux_dqn_small_solve); returns the first iteration index it did NOT run (== i when the configuration needs the call-by-call loop)."""
     pe, pi, buf = solver.agent.pi_explore, solver.agent.pi, solver.buffer
-    if not (solver.fused_epochs and solver.target_fn == "dqn" and not solver.custom_seams() and solver.post_sample_callback is None and solver.pre_train_callback is None
+    if not (s.h is not None and solver.fused_epochs and solver.target_fn == "dqn" and not solver.custom_seams() and solver.post_sample_callback is None and solver.pre_train_callback is None
             and solver.log is None and solver.interaction_storage is None and isinstance(pe, EpsGreedyPolicy) and isinstance(pi, DiscreteNetwork)
             and not buf.isprioritized() and not solver.weighted_loss and max(pi.network.dims) < 128 and D.capacity <= 256 and s.n_envs <= 4 and solver.dN % s.n_envs == 0 and i <= stop):
         return i

@@ -132,7 +132,7 @@ def policy_gradient_training_multi(pis, a_opt, c_opt, P, buffers):
 
 
 def solve(solver, mdp):
-    """POMDPs.solve(S::OnPolicySolver, mdp) (src/model_free/on_policy.jl:80-109), logging left out (SURVEY #14)."""
+    """POMDPs.solve(S::OnPolicySolver, mdp) (src/model_free/on_policy.jl:80-109), with the pre-train and per-iteration log points (:84,:88,:105; crux.jl_amd/logging.py)."""
     if solver.buffer is None:
         solver.buffer = ExperienceBuffer(solver.S, solver.agent.space, solver.dN, solver.required_columns)
         solver.sampler = Sampler(mdp, solver.agent, S=solver.S, required_columns=solver.required_columns, lam=solver.lambda_gae,

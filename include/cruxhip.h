@@ -246,6 +246,30 @@ int32_t crux_rollout(crux_env* env, crux_mlp* policy, const crux_rollout_cfg* cf
 int32_t crux_rollout_multi(int32_t n, crux_env* const* envs, crux_mlp* const* policies, const crux_rollout_cfg* cfg,
                            crux_buffer* const* bufs, int64_t T, double* sum_r, int64_t* n_episode_end);
 
+/* Caller-stepped environments: step! with an ARBITRARY mdp (src/sampler.jl:71-137). The reference's step! calls @gen(:sp,:r)(mdp, s, a) on whatever POMDPs.jl mdp the user
+ * handed to solve (:89-97); an mdp that only exists on the host keeps its Sampler (state s, svec, episode_length, was_reset -- sampler.jl:1-22) in the host language and
+ * uses these two entry points for the device part of steps!:
+ *
+ * crux_policy_explore = the first line of step! (:73) for n_envs samplers at once:
+ *     a, logprob = explore ? exploration(agent.pi_explore, svec; pi_on = agent.pi, i = i) : (action(agent.pi, svec), NaN)
+ *   policy / cfg: as crux_rollout (cfg->head, explore, eps_*, noise_*, logit_div; cfg->i0 = the interaction counter `i` of sampler 0 in this step, sampler e uses i0 + e
+ *   -- steps!(::Vector{Sampler}) numbers them env-minor, sampler.jl:161-163; reset_at_end is ignored). obs: host [obs_dim x n_envs], the samplers' svec (already tovec'd,
+ *   src/spaces.jl:25). Draws: crux_philox(seed, f(steps_taken[e]), stream = e, purpose) exactly as the rollout kernel draws them for its sampler e after steps_taken[e] steps
+ *   (crux_rng.h; steps_taken: host [n_envs], NULL = zeros), so a caller that steps one of the restated environments itself reproduces crux_rollout's buffer bit for bit.
+ *   actions_out: host [act_dim x n_envs], Bool one-hot bytes for the discrete heads (CATEGORICAL / GREEDY_Q), Float32 otherwise; logprob_out: host [n_envs] or NULL
+ *   (NaN where the reference stores NaN). Synchronous (it returns host data).
+ *
+ * crux_steps_push = the tail of steps! (:148-155) for the block the caller stepped: push!(buffer, data) (experience_buffer.jl:232-259) of n = n_envs x T transitions,
+ *   env-major (environment e in rows [e*rows_per_env, (e+1)*rows_per_env) of the block), then -- on the ring rows just written -- what terminate_episode! did to `data`
+ *   (:53-66): fill_gae!(critic, lambda, gamma) / fill_returns!(gamma), :importance_weight = exp(logpdf(nominal, s, a) - logprob) (:108-111; nominal NULL = the caller
+ *   supplied the column) and its fwd / cum / rev products, fill_gae! / fill_returns! on :cost with cost_critic -- each only if the buffer has the column.
+ *   cols: host columns as crux_buffer_push_host, :episode_end included (the caller's Sampler cuts episodes: done, max_steps, and the reset at the end of the block);
+ *   close_last = steps!(...; reset=true). first_row_out (optional): 0-based ring row of the block's first transition.                                                */
+int32_t crux_policy_explore(crux_mlp* policy, const crux_rollout_cfg* cfg, int32_t n_envs, const float* obs, uint64_t seed, const int64_t* steps_taken,
+                            void* actions_out, float* logprob_out);
+int32_t crux_steps_push(crux_buffer* buf, int64_t n, const void* const* cols /*CRUX_NCOLS*/, int64_t rows_per_env, int32_t close_last, crux_mlp* critic, float lambda, float gamma,
+                        crux_mlp* cost_critic, crux_mlp* nominal, int32_t nominal_head, int64_t* first_row_out);
+
 /* test hook: apply the env dynamics once to explicit states/actions (host arrays):
  * state [state_dim x n] f64, action [act_dim x n] (Bool one-hot bytes or f32), uniforms [n] f64 for
  * stochastic envs or NULL; out: next state, obs(sp) [obs_dim x n] f32, r f32, done u8.            */

@@ -637,6 +637,59 @@ static float randn_f32(uint64_t seed, uint64_t ctr, uint32_t stream, int which) 
 }
 
 /* steps!(samplers, buffer; Nsteps=T, explore, reset, i) src/sampler.jl:139-173, env-major. */
+/* exploration(pi_explore, svec; pi_on, i) / action(pi, svec) (sampler.jl:73) given the network outputs z of ONE observation: the action (aout: one-hot floats for the
+ * discrete heads, the action vector otherwise; *ai_out the discrete index) and its log-probability. Draws: crux_philox(seed, f(ctr), stream, purpose), ctr = steps the sampler
+ * has taken (crux_rng.h). Shared by orc_rollout and orc_policy_explore (the twin of crux_policy_explore, cruxhip.h). */
+static void policy_head(const orc_mlp* pol, const crux_rollout_cfg* cfg, const float* z, int nout, int ad, uint64_t seed, uint64_t ctr, uint32_t k, uint64_t gi,
+                        float* aout, int* ai_out, float* logprob_out) {
+  float p[64]; float logprob = NAN; int ai = 0;
+      if (cfg->head == CRUX_HEAD_CATEGORICAL || cfg->head == CRUX_HEAD_GREEDY_Q) {
+        int greedy = 0; for (int q = 1; q < nout; ++q) if (z[q] > z[greedy]) greedy = q;      /* argmax, first on ties (policies.jl:124) */
+        if (!cfg->explore) ai = greedy;
+        else if (cfg->eps_steps > 0 || cfg->head == CRUX_HEAD_GREEDY_Q) {                       /* MixedPolicy policies.jl:474-494 */
+          double eps = cfg->eps_steps > 0 ? orc_linear_decay(cfg->eps_start, cfg->eps_stop, cfg->eps_steps, (int64_t)gi) : 0.0;
+          crux_u32x4 x = crux_philox(seed, ctr, k, CRUX_RNG_ACTION);
+          double u = crux_u32x2_to_f64(x.v[0], x.v[1]);
+          if (u < eps) { crux_u32x4 y = crux_philox(seed, ctr, k, CRUX_RNG_RANDACT); ai = (int)(((uint64_t)y.v[0] * (uint64_t)nout) >> 32); }
+          else ai = greedy;
+          /* p1 = eps*exp(logpdf(ObjectCategorical)) = eps/n ; p2 = 1-eps ; log(p1+p2) (policies.jl:485-493) */
+          logprob = (float)log(eps * (1.0 / (double)nout) + (1.0 - eps));
+        } else {                                                                                 /* DiscreteNetwork exploration policies.jl:137-142 */
+          if (cfg->logit_div > 0.f) { float zs[64]; for (int q = 0; q < nout; ++q) zs[q] = z[q] / cfg->logit_div; softmax_col(zs, nout, p); }   /* softmax(value ./ alpha) softq.jl:53 */
+          else softmax_col(z, nout, p);
+          crux_u32x4 x = crux_philox(seed, ctr, k, CRUX_RNG_ACTION);
+          float draw = crux_u32_to_f32(x.v[0]);
+          /* [3P] Distributions rand(::DiscreteNonParametric): cp=p[1]; while cp <= draw && i<n: cp += p[++i] */
+          float cp = p[0]; ai = 0; while (cp <= draw && ai < nout - 1) { ai += 1; cp = cp + p[ai]; }
+          logprob = logf(p[ai]);                                                                  /* categorical_logpdf policies.jl:135 */
+        }
+        for (int q = 0; q < ad; ++q) aout[q] = (q == ai) ? 1.f : 0.f;
+      } else if (cfg->head == CRUX_HEAD_GAUSSIAN) {                                              /* GaussianPolicy policies.jl:338-344 */
+        const float* ls = pol->p + xoff(pol); float lp = 0.f;
+        for (int q = 0; q < ad; ++q) {
+          float mu = z[q];
+          if (pol->squash > 0.f) {                                                              /* SquashedGaussianPolicy policies.jl:372,388-394 */
+            if (cfg->explore) { float sg = expf(sq_clampls(ls[q])); float epsn = randn_f32(seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), k, q & 1);
+              float u = epsn * sg + mu; float s2 = sg * sg; float dd = u - mu; aout[q] = pol->squash * tanhf(u);
+              lp = lp + (((-(dd * dd) / (2.f * s2) - 0.9189385332046727f) - ls[q]) - sq_corr(u)); }
+            else aout[q] = pol->squash * tanhf(mu);
+          } else
+          if (cfg->explore) { float sg = expf(ls[q]); float epsn = randn_f32(seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), k, q & 1);
+            aout[q] = epsn * sg + mu; float s2 = sg * sg; float dd = aout[q] - mu; lp = lp + (-(dd * dd) / (2.f * s2) - 0.9189385332046727f - ls[q]); }
+          else aout[q] = mu;
+        }
+        logprob = cfg->explore ? lp : NAN;
+      } else {                                                                                   /* DETERMINISTIC (+ GaussianNoiseExplorationPolicy policies.jl:510-514) */
+        for (int q = 0; q < ad; ++q) { float a = z[q];
+          if (cfg->explore && cfg->noise_sigma >= 0.f) { float n0 = randn_f32(seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), k, q & 1) * cfg->noise_sigma;
+            n0 = n0 < cfg->noise_eps_min ? cfg->noise_eps_min : n0 > cfg->noise_eps_max ? cfg->noise_eps_max : n0; a = a + n0;
+            a = a < cfg->a_min ? cfg->a_min : a > cfg->a_max ? cfg->a_max : a; }
+          aout[q] = a; }
+      }
+  if (cfg->explore == 2) logprob = NAN;   /* action(pi, s) of an always_stochastic policy = exploration(pi, s)[1] (policies.jl:124), logprob NaN (sampler.jl:73) */
+  *ai_out = ai; *logprob_out = logprob;
+}
+
 int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_buffer* buf, int64_t T, double* sum_r, int64_t* n_ee) {
   int E = e->n_envs, od = e->obs_dim, ad = e->act_dim;
   int64_t N = (int64_t)E * T, C = buf->capacity;
@@ -662,7 +715,7 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
   ORC_OMP(omp parallel for schedule(dynamic, 1) reduction(+ : sr, nee))
   for (int k = 0; k < E; ++k) {
     colcache c = cc_alloc(pol);
-    float p[64], aout[64];
+    float aout[64];
     double* st = e->state + (size_t)k * e->state_dim; float* sv = e->svec + (size_t)k * od;
     for (int64_t t = 0; t < T; ++t) {
       int64_t j = I[(int64_t)k * T + t];
@@ -670,50 +723,8 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
       uint64_t ctr = (uint64_t)e->steps_taken[k];
       /* ---- action + logprob: exploration(pi_explore, svec) / action(pi, svec)   sampler.jl:73 */
       fwd_col(pol, sv, c.h); const float* z = c.h[pol->n_layers];
-      float logprob = NAN; int ai = 0;
-      if (cfg->head == CRUX_HEAD_CATEGORICAL || cfg->head == CRUX_HEAD_GREEDY_Q) {
-        int greedy = 0; for (int q = 1; q < nout; ++q) if (z[q] > z[greedy]) greedy = q;      /* argmax, first on ties (policies.jl:124) */
-        if (!cfg->explore) ai = greedy;
-        else if (cfg->eps_steps > 0 || cfg->head == CRUX_HEAD_GREEDY_Q) {                       /* MixedPolicy policies.jl:474-494 */
-          double eps = cfg->eps_steps > 0 ? orc_linear_decay(cfg->eps_start, cfg->eps_stop, cfg->eps_steps, (int64_t)gi) : 0.0;
-          crux_u32x4 x = crux_philox(e->seed, ctr, (uint32_t)k, CRUX_RNG_ACTION);
-          double u = crux_u32x2_to_f64(x.v[0], x.v[1]);
-          if (u < eps) { crux_u32x4 y = crux_philox(e->seed, ctr, (uint32_t)k, CRUX_RNG_RANDACT); ai = (int)(((uint64_t)y.v[0] * (uint64_t)nout) >> 32); }
-          else ai = greedy;
-          /* p1 = eps*exp(logpdf(ObjectCategorical)) = eps/n ; p2 = 1-eps ; log(p1+p2) (policies.jl:485-493) */
-          logprob = (float)log(eps * (1.0 / (double)nout) + (1.0 - eps));
-        } else {                                                                                 /* DiscreteNetwork exploration policies.jl:137-142 */
-          if (cfg->logit_div > 0.f) { float zs[64]; for (int q = 0; q < nout; ++q) zs[q] = z[q] / cfg->logit_div; softmax_col(zs, nout, p); }   /* softmax(value ./ alpha) softq.jl:53 */
-          else softmax_col(z, nout, p);
-          crux_u32x4 x = crux_philox(e->seed, ctr, (uint32_t)k, CRUX_RNG_ACTION);
-          float draw = crux_u32_to_f32(x.v[0]);
-          /* [3P] Distributions rand(::DiscreteNonParametric): cp=p[1]; while cp <= draw && i<n: cp += p[++i] */
-          float cp = p[0]; ai = 0; while (cp <= draw && ai < nout - 1) { ai += 1; cp = cp + p[ai]; }
-          logprob = logf(p[ai]);                                                                  /* categorical_logpdf policies.jl:135 */
-        }
-        for (int q = 0; q < ad; ++q) aout[q] = (q == ai) ? 1.f : 0.f;
-      } else if (cfg->head == CRUX_HEAD_GAUSSIAN) {                                              /* GaussianPolicy policies.jl:338-344 */
-        const float* ls = pol->p + xoff(pol); float lp = 0.f;
-        for (int q = 0; q < ad; ++q) {
-          float mu = z[q];
-          if (pol->squash > 0.f) {                                                              /* SquashedGaussianPolicy policies.jl:372,388-394 */
-            if (cfg->explore) { float sg = expf(sq_clampls(ls[q])); float epsn = randn_f32(e->seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)k, q & 1);
-              float u = epsn * sg + mu; float s2 = sg * sg; float dd = u - mu; aout[q] = pol->squash * tanhf(u);
-              lp = lp + (((-(dd * dd) / (2.f * s2) - 0.9189385332046727f) - ls[q]) - sq_corr(u)); }
-            else aout[q] = pol->squash * tanhf(mu);
-          } else
-          if (cfg->explore) { float sg = expf(ls[q]); float epsn = randn_f32(e->seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)k, q & 1);
-            aout[q] = epsn * sg + mu; float s2 = sg * sg; float dd = aout[q] - mu; lp = lp + (-(dd * dd) / (2.f * s2) - 0.9189385332046727f - ls[q]); }
-          else aout[q] = mu;
-        }
-        logprob = cfg->explore ? lp : NAN;
-      } else {                                                                                   /* DETERMINISTIC (+ GaussianNoiseExplorationPolicy policies.jl:510-514) */
-        for (int q = 0; q < ad; ++q) { float a = z[q];
-          if (cfg->explore && cfg->noise_sigma >= 0.f) { float n0 = randn_f32(e->seed, ctr * (uint64_t)((ad + 1) / 2) + (uint64_t)(q / 2), (uint32_t)k, q & 1) * cfg->noise_sigma;
-            n0 = n0 < cfg->noise_eps_min ? cfg->noise_eps_min : n0 > cfg->noise_eps_max ? cfg->noise_eps_max : n0; a = a + n0;
-            a = a < cfg->a_min ? cfg->a_min : a > cfg->a_max ? cfg->a_max : a; }
-          aout[q] = a; }
-      }
+      float logprob; int ai;
+      policy_head(pol, cfg, z, nout, ad, e->seed, ctr, (uint32_t)k, gi, aout, &ai, &logprob);
       /* ---- env transition @gen(:sp,:r) + isterminal                            sampler.jl:93-97 */
       double sn[MAXSD]; float r; uint8_t done; float o[32], spv[32];
       if (e->kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done);
@@ -728,7 +739,6 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
       else memcpy((float*)buf->col[CRUX_COL_A] + (size_t)j * ad, aout, 4 * (size_t)ad);
       memcpy(SP + (size_t)j * od, spv, 4 * (size_t)od);
       R[j] = r; D[j] = done; EE[j] = 0;
-      if (cfg->explore == 2) logprob = NAN;   /* action(pi, s) of an always_stochastic policy = exploration(pi, s)[1] (policies.jl:124), logprob NaN (sampler.jl:73) */
       if (LP) LP[j] = logprob;
       if (TT) TT[j] = e->ep_len[k] + 1;
       if (II) II[j] = (int64_t)gi + 1;
@@ -752,6 +762,24 @@ int32_t orc_rollout(orc_env* e, orc_mlp* pol, const crux_rollout_cfg* cfg, orc_b
   ring_advance(buf, N);
   if (sum_r) *sum_r = sr; if (n_ee) *n_ee = nee;
   free(I);
+  return CRUX_OK;
+}
+
+/* crux_policy_explore (cruxhip.h): the first line of step! (sampler.jl:73) for n_envs caller-stepped samplers -- the policy forward on each observation column, then the head. */
+int32_t orc_policy_explore(orc_mlp* pol, const crux_rollout_cfg* cfg, int32_t n_envs, const float* obs, uint64_t seed, const int64_t* steps_taken, void* actions_out, float* logprob_out) {
+  if (!pol || !cfg || !obs || !actions_out || n_envs < 1) return CRUX_EINVAL;
+  int od = pol->dims[0], nout = pol->dims[pol->n_layers];
+  int disc = cfg->head == CRUX_HEAD_CATEGORICAL || cfg->head == CRUX_HEAD_GREEDY_Q;
+  colcache c = cc_alloc(pol);
+  for (int k = 0; k < n_envs; ++k) {
+    float aout[64]; int ai; float logprob;
+    fwd_col(pol, obs + (size_t)k * od, c.h);
+    policy_head(pol, cfg, c.h[pol->n_layers], nout, nout, seed, steps_taken ? (uint64_t)steps_taken[k] : 0, (uint32_t)k, cfg->i0 + (uint64_t)k, aout, &ai, &logprob);
+    if (disc) { uint8_t* A = (uint8_t*)actions_out + (size_t)k * nout; for (int q = 0; q < nout; ++q) A[q] = aout[q] != 0.f; }
+    else memcpy((float*)actions_out + (size_t)k * nout, aout, 4 * (size_t)nout);
+    if (logprob_out) logprob_out[k] = logprob;
+  }
+  cc_free(pol, &c);
   return CRUX_OK;
 }
 

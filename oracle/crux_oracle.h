@@ -86,6 +86,7 @@ int32_t orc_env_reset(orc_env* env);
 int32_t orc_env_get_state(orc_env* env, double* state, int64_t* episode_length, int64_t* n_resets);
 int32_t orc_rollout(orc_env* env, orc_mlp* policy, const crux_rollout_cfg* cfg, orc_buffer* buf, int64_t T,
                     double* sum_r, int64_t* n_episode_end);
+int32_t orc_policy_explore(orc_mlp* policy, const crux_rollout_cfg* cfg, int32_t n_envs, const float* obs, uint64_t seed, const int64_t* steps_taken, void* actions_out, float* logprob_out);   /* sampler.jl:73 for caller-stepped samplers */
 int32_t orc_env_step_host(int32_t kind, int64_t n, const double* state, const void* action, const double* uniforms,
                           double* next_state, float* obs, float* r, uint8_t* done);
 

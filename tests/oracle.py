@@ -31,7 +31,7 @@ _SIG = {
     "orc_per_get": (i32, [vp, vp, P(f32), P(f32), vp]), "orc_buffer_set_sample_stream": (i32, [vp, u32]), "orc_pairwise_cumsum_f32": (None, [vp, i64, vp]),
     "orc_env_create": (vp, [i32, i32, i32, f32, vp, vp, u64, i32, i32]), "orc_env_destroy": (None, [vp]), "orc_env_obs_dim": (i32, [vp]),
     "orc_env_act_dim": (i32, [vp]), "orc_env_state_dim": (i32, [vp]), "orc_env_reset": (i32, [vp]), "orc_env_get_state": (i32, [vp, vp, vp, vp]),
-    "orc_rollout": (i32, [vp, vp, P(L.RolloutCfg), vp, i64, P(f64), P(i64)]), "orc_env_step_host": (i32, [i32, i64, vp, vp, vp, vp, vp, vp, vp]),
+    "orc_rollout": (i32, [vp, vp, P(L.RolloutCfg), vp, i64, P(f64), P(i64)]), "orc_policy_explore": (i32, [vp, P(L.RolloutCfg), i32, vp, u64, vp, vp, vp]), "orc_env_step_host": (i32, [i32, i64, vp, vp, vp, vp, vp, vp, vp]),
     "orc_fill_gae": (i32, [vp, vp, f32, f32]), "orc_fill_returns": (i32, [vp, f32]), "orc_importance_weight": (i32, [vp, vp, i32]), "orc_fill_importance_weights": (i32, [vp]), "orc_whiten": (i32, [vp, i32]),
     "orc_fill_gae_keys": (i32, [vp, vp, f32, f32, i32, i32]), "orc_fill_returns_keys": (i32, [vp, f32, i32, i32]),
     "orc_batch_train_lagrange": (i32, [vp, vp, P(L.TrainCfg), P(L.Lagrange), vp, vp, vp]),
