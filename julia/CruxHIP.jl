@@ -6,7 +6,7 @@
 # `julia julia/check_syntax.jl` parses this file (Meta.parseall) without loading Crux -- the CI-style check for boxes that have a julia binary.
 module CruxHIP
 
-using Crux, Flux, POMDPs
+using Crux, Flux, POMDPs, Statistics
 
 const LIB = get(ENV, "CRUXHIP_LIB", joinpath(@__DIR__, "..", "crux.jl_amd", "libcruxhip.so"))
 
@@ -98,17 +98,22 @@ function Base.push!(b::HipBuffer, data::Dict{Symbol,<:AbstractArray})          #
     GC.@preserve keep check(b.ctx, ccall((:crux_buffer_push_host, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}, Ptr{Int64}), b.h, N, cols, I))
     I .+ 1                                                                     # indices cross the ABI 0-based
 end
+Crux.shuffle!(b::HipBuffer; seed=0, counter=0) = check(b.ctx, ccall((:crux_buffer_shuffle, LIB), Int32, (Ptr{Cvoid}, UInt64, UInt64), b.h, seed, counter))   # :118-124 with the library's permutation stream
+function priorities(b::HipBuffer)                                              # b.priorities, b.max_priority, b.min_priority (:38-50) as host values
+    pr = Vector{Float32}(undef, Crux.capacity(b)); mx = Ref{Float32}(0); mn = Ref{Float32}(0)
+    check(b.ctx, ccall((:crux_per_get, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ref{Float32}, Ref{Float32}, Ptr{Float32}), b.h, pr, mx, mn, C_NULL)); (pr, mx[], mn[])
+end
 function Crux.update_priorities!(b::HipBuffer, I::AbstractVector{<:Integer}, v::AbstractVector)   # :290-301
     check(b.ctx, ccall((:crux_per_update, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cvoid}, Int32, Int64), b.h, Int64.(I) .- 1, Float64.(v), 1, length(I)))
 end
 
 # ---------------------------------------------------------------------------------------------------- sampler / advantage pipeline
-mutable struct HipSampler; ctx::Ctx; h::Ptr{Cvoid}; agent; n_envs::Int; max_steps::Int; γ::Float32; λ::Float32; end
-function HipSampler(ctx::Ctx, kind::Integer, agent; n_envs=1, max_steps=100, γ=0.99f0, λ=NaN32, S=nothing, seed=0)   # kind: 0 CartPole-v1, 1 Pendulum-v1, 2 SimpleGridWorld
+mutable struct HipSampler; ctx::Ctx; h::Ptr{Cvoid}; agent; n_envs::Int; max_steps::Int; γ::Float32; λ::Float32; Vc; end      # Vc: the cost value network (Sampler.Vc, sampler.jl:17)
+function HipSampler(ctx::Ctx, kind::Integer, agent; n_envs=1, max_steps=100, γ=0.99f0, λ=NaN32, S=nothing, seed=0, Vc=nothing)   # kind: 0 CartPole-v1, 1 Pendulum-v1, 2 SimpleGridWorld
     μ = isnothing(S) ? C_NULL : Float32.(S.μ); σ = isnothing(S) ? C_NULL : Float32.(S.σ); r = Ref{Ptr{Cvoid}}(C_NULL)
     check(ctx, ccall((:crux_env_create, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Float32, Ptr{Float32}, Ptr{Float32}, UInt64, Int32, Int32, Ref{Ptr{Cvoid}}),
                      ctx.h, kind, n_envs, max_steps, γ, μ, σ, seed, 0, 0, r))
-    HipSampler(ctx, r[], agent, n_envs, max_steps, γ, λ)
+    HipSampler(ctx, r[], agent, n_envs, max_steps, γ, λ, Vc)
 end
 # exploration configuration of the agent -> the fields of crux_rollout_cfg (cruxhip.h): the device rollout evaluates them per step, like
 # exploration(π_explore, s; π_on, i) does (src/sampler.jl:73, src/policies.jl:474-514)
@@ -155,11 +160,90 @@ function Crux.steps!(s::HipSampler, b::HipBuffer; Nsteps=1, explore=false, i=0, 
     end
     (haskey(b, :fwd_importance_weight) || haskey(b, :cum_importance_weight) || haskey(b, :rev_importance_weight)) &&
         check(b.ctx, ccall((:crux_fill_importance_weights_rows, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int64, Int32), b.h, first, Nsteps, T, reset))
+    # cost constraints (:65-66): fill_gae!(data, ep, Vc, λ, γ, source=:cost, target=:cost_advantage), fill_returns!(data, ep, γ, source=:cost, target=:cost_return)
+    haskey(b, :cost_advantage) && check(b.ctx, ccall((:crux_fill_gae_rows_keys, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Int64, Int64, Int64, Int32, Int32, Int32),
+                                                     b.h, s.Vc.h, s.λ, s.γ, first, Nsteps, T, reset, COL[:cost], COL[:cost_advantage]))
+    haskey(b, :cost_return) && check(b.ctx, ccall((:crux_fill_returns_rows_keys, LIB), Int32, (Ptr{Cvoid}, Float32, Int64, Int64, Int64, Int32, Int32, Int32),
+                                                  b.h, s.γ, first, Nsteps, T, reset, COL[:cost], COL[:cost_return]))
     cb(b); Dict("avg_r" => sr[] / ne[])
+end
+
+# ---------------------------------------------------------------------------------------------------- steps! with ANY POMDPs.jl mdp (caller-stepped environments)
+# A plain Crux.Sampler -- whatever `mdp` the user handed to solve: LunarLander, MuJoCo, a custom @gen -- filling a HipBuffer with HipNetwork policies. The Sampler struct, its
+# state (s, svec, episode_length, was_reset) and the @gen call stay exactly the reference's (sampler.jl:1-43, 89-97); the device does the first line of step! (:73) for the
+# sampler's observation -- crux_policy_explore: policy forward, exploration draw, logprob -- and the tail of steps! (:148-155) -- crux_steps_push: push! + terminate_episode!'s
+# fills on the rows just written. `samplers` may be one Sampler or the Vector{Sampler} the reference builds for a vector of mdps (sampler.jl:27-29); the block is env-major
+# (sampler e owns rows (e-1)*T+1 : e*T, SURVEY §8a R7), the interaction counter env-minor (:161-163). Draw streams: sampler e = Philox stream e-1 of `seed`, counter = the
+# steps that sampler has taken (kept here in STEPS_TAKEN).
+const STEPS_TAKEN = IdDict{Any,Int64}()
+function policy_explore(π::HipNetwork, cfg::RolloutCfg, svec::Matrix{Float32}; seed=0, steps=zeros(Int64, size(svec, 2)))
+    E = size(svec, 2); nout = Int(π.dims[end]); disc = π.head == HEAD_CATEGORICAL || cfg.head == HEAD_GREEDY_Q
+    a = disc ? zeros(Bool, nout, E) : zeros(Float32, nout, E); lp = Vector{Float32}(undef, E)
+    check(π.ctx, ccall((:crux_policy_explore, LIB), Int32, (Ptr{Cvoid}, Ref{RolloutCfg}, Int32, Ptr{Float32}, UInt64, Ptr{Int64}, Ptr{Cvoid}, Ptr{Float32}),
+                       π.h, cfg, E, svec, seed, steps, a, lp))
+    a, lp
+end
+function Crux.steps!(samplers::Union{Crux.Sampler,Vector{<:Crux.Sampler}}, b::HipBuffer; Nsteps=1, explore=false, i=0, reset=false, cb=(D) -> nothing, seed=0, kw...)
+    ss = samplers isa Crux.Sampler ? [samplers] : samplers; E = length(ss); T = Nsteps ÷ E; s1 = ss[1]
+    π = Crux.actor(s1.agent.π)
+    e0, e1, en, σ, ϵmin, ϵmax, amin, amax = explore ? explore_fields(s1.agent.π_explore) : explore_fields(nothing)
+    mode = explore ? Int32(1) : (hasproperty(π, :always_stochastic) && π.always_stochastic ? Int32(2) : Int32(0))
+    head = explore && s1.agent.π_explore isa Crux.MixedPolicy ? HEAD_GREEDY_Q : explore && s1.agent.π_explore isa Crux.GaussianNoiseExplorationPolicy ? HEAD_DETERMINISTIC : π.head
+    data = Crux.mdp_data(s1.S, s1.agent.space, Nsteps, Crux.extra_columns(b))                                       # :140
+    for t in 1:T
+        cfg = RolloutCfg(mode, 0, head, e0, e1, en, σ, ϵmin, ϵmax, amin, amax, 0f0, i + (t - 1) * E)
+        svec = reduce(hcat, [Float32.(vec(s.svec)) for s in ss]); steps = Int64[get(STEPS_TAKEN, s, 0) for s in ss]
+        A, LP = policy_explore(π, cfg, svec; seed, steps)                                                           # :73 for all samplers
+        for (e, s) in enumerate(ss)
+            j = (e - 1) * T + t
+            s.was_reset = false                                                                                     # :72
+            a = π.head == HEAD_CATEGORICAL || head == HEAD_GREEDY_Q ? π.outputs[argmax(A[:, e])] : (size(A, 1) == 1 ? A[1, e] : A[:, e])
+            info = Dict(); kwargs = haskey(data, :cost) ? (info=info,) : ()
+            sp, r = POMDPs.@gen(:sp, :r)(s.mdp, s.s, a; kwargs...)                                                   # :93  (POMDPs with observations: :90-91, the same two lines)
+            spvec = Crux.tovec(POMDPs.convert_s(AbstractArray, sp, s.mdp), s.S)                                     # :95-96
+            done = POMDPs.isterminal(s.mdp, sp)                                                                     # :97
+            Crux.bslice(data[:s], j:j) .= s.svec; data[:a][:, j:j] .= Crux.tovec(a, s.agent.space); Crux.bslice(data[:sp], j:j) .= spvec   # :100-102
+            data[:r][1, j] = r; data[:done][1, j] = done                                                            # :103-104
+            haskey(data, :logprob) && (data[:logprob][:, j] .= LP[e])                                               # :107
+            haskey(data, :t) && (data[:t][1, j] = s.episode_length + 1)                                             # :112
+            haskey(data, :i) && (data[:i][1, j] = i + (t - 1) * E + e)                                              # :113
+            haskey(data, :cost) && (data[:cost][1, j] = info["cost"])                                               # :114
+            STEPS_TAKEN[s] = get(STEPS_TAKEN, s, 0) + 1
+            s.episode_length += 1                                                                                   # :130
+            if done || s.episode_length >= s.max_steps                                                              # :131-132: the cut here, terminate_episode!'s fills after the push
+                data[:episode_end][1, j] = true; Crux.reset_sampler!(s)
+            else
+                s.s = sp; s.svec = spvec                                                                            # :134-135
+            end
+        end
+    end
+    if reset                                                                                                        # :148
+        for (e, s) in enumerate(ss); data[:episode_end][1, e * T] = true; Crux.reset_sampler!(s); end
+    end
+    cols = fill(C_NULL, NCOLS); keep = Any[]
+    for (k, v) in data; haskey(COL, k) || continue; a = collect(v); push!(keep, a); cols[COL[k] + 1] = pointer(a); end
+    V = haskey(b, :advantage) ? Crux.critic(s1.agent.π).h : C_NULL; Vc = haskey(b, :cost_advantage) ? s1.Vc.h : C_NULL
+    pa = haskey(b, :importance_weight) ? s1.agent.pa : nothing; first = Ref{Int64}(0)
+    GC.@preserve keep check(b.ctx, ccall((:crux_steps_push, LIB), Int32,
+                                         (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}, Int64, Int32, Ptr{Cvoid}, Float32, Float32, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Int64}),
+                                         b.h, Nsteps, cols, T, reset, V, s1.λ, s1.γ, Vc, isnothing(pa) ? C_NULL : pa.h, isnothing(pa) ? Int32(0) : pa.head, first))
+    cb(b); data
 end
 Crux.fill_gae!(b::HipBuffer, V::HipNetwork, λ::Float32, γ::Float32) = check(b.ctx, ccall((:crux_fill_gae, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32), b.h, V.h, λ, γ))   # :255-273
 Crux.fill_returns!(b::HipBuffer, γ::Float32) = check(b.ctx, ccall((:crux_fill_returns, LIB), Int32, (Ptr{Cvoid}, Float32), b.h, γ))                                                  # :275-281
 whiten!(b::HipBuffer, k::Symbol=:advantage) = check(b.ctx, ccall((:crux_whiten, LIB), Int32, (Ptr{Cvoid}, Int32), b.h, COL[k]))                                                      # src/utils.jl:41-42 via ppo.jl:61
+
+# evaluation: undiscounted_return / discounted_return / failure (sampler.jl:202-251) over Neps episodes = a rollout of Neps freshly reset device environments for max_steps
+# steps into an empty buffer, then the first episode of every environment
+function episode_metrics(s::HipSampler, b::HipBuffer; explore=false)
+    E = s.n_envs; und, dis = Vector{Float32}(undef, E), Vector{Float32}(undef, E); len = Vector{Int64}(undef, E); complete = Vector{UInt8}(undef, E)
+    ccall((:crux_buffer_clear, LIB), Int32, (Ptr{Cvoid},), b.h); ccall((:crux_env_reset, LIB), Int32, (Ptr{Cvoid},), s.h)
+    Crux.steps!(s, b; Nsteps=E * s.max_steps, explore=explore)
+    check(b.ctx, ccall((:crux_first_episode_metrics, LIB), Int32, (Ptr{Cvoid}, Int32, Int64, Float32, Ptr{Float32}, Ptr{Float32}, Ptr{Int64}, Ptr{UInt8}), b.h, E, s.max_steps, s.γ, und, dis, len, complete))
+    (undiscounted=und, discounted=dis, length=len, complete=complete .!= 0)
+end
+Crux.undiscounted_return(s::HipSampler, b::HipBuffer; kw...) = Statistics.mean(episode_metrics(s, b; kw...).undiscounted)      # :202-212
+Crux.discounted_return(s::HipSampler, b::HipBuffer; kw...) = Statistics.mean(episode_metrics(s, b; kw...).discounted)          # :214-232
 
 # ---------------------------------------------------------------------------------------------------- learner
 loss_id(f) = f === Crux.ppo_loss ? LOSS_PPO : f === Crux.a2c_loss ? LOSS_A2C : f === Crux.reinforce_loss ? LOSS_REINFORCE : f === Crux.logpdf_bc_loss ? LOSS_LOGPDF_BC :
@@ -248,6 +332,14 @@ peer_attach!(c::Ctx, rank::Integer, nranks::Integer, handles::Vector{UInt8}) = c
 peer_detach!(c::Ctx) = check(c, ccall((:crux_peer_detach, LIB), Int32, (Ptr{Cvoid},), c.h))
 # periodic form (round 4): k = 1 exchanges the gradient every minibatch (exact); k > 1: local Adam steps, theta / m / v averaged in the kernel after every k-th
 peer_set_sync_every!(c::Ctx, k::Integer) = check(c, ccall((:crux_peer_set_sync_every, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, k))
+peer_set_timeout_ms!(c::Ctx, ms::Integer) = check(c, ccall((:crux_peer_set_timeout_ms, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, ms))   # a rank whose peer died gets CRUX_EHIP after this long instead of a hung GPU
+# multi-seed / population training: n independent (actor, critic, buffer) triples in two batched launches (on_policy.jl:56-78 per triple)
+function policy_gradient_training_multi(𝒮::Crux.OnPolicySolver, actors::Vector{HipNetwork}, critics::Vector{HipNetwork}, bufs::Vector{HipBuffer})
+    n = length(actors); ia, ic = zeros(Float32, INFO_N, n), zeros(Float32, INFO_N, n)
+    check(actors[1].ctx, ccall((:crux_policy_gradient_training_multi, LIB), Int32, (Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ref{TrainCfg}, Ref{TrainCfg}, Ptr{Float32}, Ptr{Float32}),
+                               n, [a.h for a in actors], [c.h for c in critics], [b.h for b in bufs], train_cfg(actors[1], 𝒮.a_opt, 𝒮.𝒫), train_cfg(critics[1], 𝒮.c_opt, 𝒮.𝒫), ia, ic))
+    [Dict("actor_loss" => ia[1, k], :kl => ia[4, k], "critic_loss" => ic[1, k]) for k in 1:n]
+end
 reload_switches!() = ccall((:crux_reload_switches, LIB), Int32, ())      # after changing a CRUX_* switch inside a running process
 
 # ---------------------------------------------------------------------------------------------------- off-policy: value_training and its pieces
@@ -316,18 +408,85 @@ function dpg_epochs!(𝒮, 𝒟::HipBuffer, γ; smooth=nothing, noise_seed=0)
                        false, 0, n, 𝒮.c_opt.update_every, 𝒮.a_opt.update_every, ctr0, noise_seed, ctr0, ic, ia))
     [Dict("critic_loss" => ic[1, e], "critic_grad_norm" => ic[2, e], "actor_loss" => ia[1, e], "actor_grad_norm" => ia[2, e]) for e in 1:n]
 end
-# (crux_dqn_epochs / crux_softq_epochs / crux_sac_epochs record the whole `for epoch in 1:c_opt.epochs` loop into one list in the same way -- no host round trip between the epochs; same
-#  arguments as the per-epoch calls plus the epoch count and, for SAC, the update_every periods. The per-epoch form below is the readable one.
-#  crux_dqn_epochs_async / crux_sac_epochs_async enqueue the same chains without read-back or synchronisation -- the info rows land in a device vector the caller fetches when
-#  `log` fires: with them the iteration loop of `solve` (off_policy.jl:133-147) never waits for the device; crux.jl_amd/api.py `_solve_off_policy` is the tested twin.)
-function Crux.value_training(𝒮::Crux.OffPolicySolver, 𝒟::HipBuffer, γ)                                                             # off_policy.jl:66-111
-    if !isnothing(𝒮.a_opt) && !haskey(𝒮.𝒫, :SAC_log_α)                                                                             # DDPG / TD3: actor + critic, no temperature
-        return Crux.aggregate_info(dpg_epochs!(𝒮, 𝒟, γ; smooth=get(𝒮.𝒫, :π_smooth_params, nothing)))
+# value_training (off_policy.jl:66-111) through the CHAINED epoch calls -- the paths bench.py times. crux_*_epochs_async record the whole `for epoch in 1:c_opt.epochs` loop
+# into lists of up to 8 epochs and enqueue them without read-back or synchronisation: the info rows land in device memory, and the iteration loop of `solve`
+# (off_policy.jl:133-147) never waits for the device. The rows are fetched (one crux_sync + one copy) only when somebody looks: `resolve` below, called by `solve` when a
+# logger is attached and at the end. crux_*_epochs are the same chains with the read-back inside the call (one synchronisation per call). The per-epoch
+# functions above are the readable form of one epoch. Tested twin: crux.jl_amd/off_policy.py `value_training` / `_solve_off_policy` (tests/test_gpu_round3.py: async == sync, bit for bit).
+mutable struct PendingInfo                       # value_training's info of an iteration whose chain is still on its way
+    ctx::Ctx; d_rows::Ptr{Cvoid}; n_epochs::Int; rows_per_epoch::Int; decode::Function; value
+end
+function resolve(p::PendingInfo)                 # aggregate_info of the epoch rows (off_policy.jl:110), "NaN detected!" (training.jl:20) raised here for the asynchronous chains
+    isnothing(p.value) || return p.value
+    rows = Array{Float32}(undef, INFO_N, p.rows_per_epoch, p.n_epochs)
+    check(p.ctx, ccall((:crux_sync, LIB), Int32, (Ptr{Cvoid},), p.ctx.h))
+    check(p.ctx, ccall((:crux_memcpy_d2h, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}, Int64), p.ctx.h, rows, p.d_rows, sizeof(rows)))
+    device_free(p.ctx, p.d_rows)
+    any(isnan, rows[2, :, :]) && error("NaN detected! (grad norm is NaN, src/training.jl:20)")
+    p.value = Crux.aggregate_info([p.decode(rows[:, :, e]) for e in 1:p.n_epochs])
+end
+resolve(d::AbstractDict) = d
+const EUNSUP = Int32(-6)
+function Crux.value_training(𝒮::Crux.OffPolicySolver, 𝒟::HipBuffer, γ; async=isnothing(𝒮.log), noise_seed=0)                       # off_policy.jl:66-111
+    n = 𝒮.c_opt.epochs; ctx = 𝒟.ctx; per = Int32(Crux.isprioritized(𝒮.buffer)); β = per == 1 ? Float32(𝒮.buffer.β(𝒮.i)) : 0f0; ctr0 = UInt64(𝒮.i * n)
+    sac = haskey(𝒮.𝒫, :SAC_log_α); dpg = !isnothing(𝒮.a_opt) && !sac; softq = haskey(𝒮.𝒫, :alpha) && !sac && !dpg
+    rows_per_epoch = sac ? 3 : dpg ? 2 : 1
+    d_rows = async ? device_vec(ctx, INFO_N * rows_per_epoch * n) : C_NULL
+    if sac
+        A, Q = Crux.actor(𝒮.agent.π), Crux.critic(𝒮.agent.π); Q⁻ = Crux.critic(𝒮.agent.π⁻)
+        decode = r -> Dict("SAC alpha" => r[3, 1], "critic_loss" => r[1, 2], "actor_loss" => r[1, 3], "entropy" => r[3, 3])
+        lα, H, ce, ae = 𝒮.𝒫[:SAC_log_α].h, Float32(𝒮.𝒫[:SAC_H_target]), Int32(𝒮.c_opt.update_every), Int32(𝒮.a_opt.update_every)
+        if async
+            rc = ccall((:crux_sac_epochs_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Float32,
+                                                             Int32, Int32, Int32, Int32, Int32, UInt64, UInt64, UInt64, Ptr{Cvoid}),
+                       A.h, Q.N1.h, Q.N2.h, C_NULL, Q⁻.N1.h, Q⁻.N2.h, lα, 𝒮.buffer.h, 𝒟.h, γ, H, 0.005f0, per, 0, n, ce, ae, ctr0, noise_seed, 3ctr0, d_rows)
+            rc == EUNSUP || (check(ctx, rc); return PendingInfo(ctx, d_rows, n, 3, decode, nothing))
+            device_free(ctx, d_rows)
+        end
+        it, ic, ia = zeros(Float32, INFO_N, n), zeros(Float32, INFO_N, n), zeros(Float32, INFO_N, n)
+        check(ctx, ccall((:crux_sac_epochs, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Float32,
+                                                           Int32, Int32, Int32, Int32, Int32, UInt64, UInt64, UInt64, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                         A.h, Q.N1.h, Q.N2.h, C_NULL, Q⁻.N1.h, Q⁻.N2.h, lα, 𝒮.buffer.h, 𝒟.h, γ, H, 0.005f0, per, 0, n, ce, ae, ctr0, noise_seed, 3ctr0, it, ic, ia))
+        return Crux.aggregate_info([decode(hcat(it[:, e], ic[:, e], ia[:, e])) for e in 1:n])
+    elseif dpg
+        A, Q = Crux.actor(𝒮.agent.π), Crux.critic(𝒮.agent.π); A⁻, Q⁻ = Crux.actor(𝒮.agent.π⁻), Crux.critic(𝒮.agent.π⁻); twin = hasproperty(Q, :N1)
+        smooth = get(𝒮.𝒫, :π_smooth_params, nothing); σ, ϵmin, ϵmax, amin, amax = isnothing(smooth) ? (-1f0, 0f0, 0f0, 0f0, 0f0) : Float32.(smooth)
+        decode = r -> Dict("critic_loss" => r[1, 1], "critic_grad_norm" => r[2, 1], "actor_loss" => r[1, 2], "actor_grad_norm" => r[2, 2])
+        q1, q2, q1⁻, q2⁻ = twin ? Q.N1.h : Q.h, twin ? Q.N2.h : C_NULL, twin ? Q⁻.N1.h : Q⁻.h, twin ? Q⁻.N2.h : C_NULL
+        if async
+            rc = ccall((:crux_dpg_epochs_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Float32, Float32, Float32, Float32, Float32,
+                                                             Int32, Int32, Int32, Int32, Int32, UInt64, UInt64, UInt64, Ptr{Cvoid}),
+                       A.h, q1, q2, A⁻.h, q1⁻, q2⁻, 𝒮.buffer.h, 𝒟.h, γ, 0.005f0, σ, ϵmin, ϵmax, amin, amax, 0, 0, n, 𝒮.c_opt.update_every, 𝒮.a_opt.update_every, ctr0, noise_seed, ctr0, d_rows)
+            rc == EUNSUP || (check(ctx, rc); return PendingInfo(ctx, d_rows, n, 2, decode, nothing))
+            device_free(ctx, d_rows)
+        end
+        return Crux.aggregate_info(dpg_epochs!(𝒮, 𝒟, γ; smooth, noise_seed))
     end
-    fused = haskey(𝒮.𝒫, :SAC_log_α) ? sac_epoch! : dqn_epoch!
-    infos = [fused(𝒮, 𝒟, γ, epoch) for epoch in 1:𝒮.c_opt.epochs]
-    isnothing(𝒮.a_opt) && Crux.polyak_average!(𝒮.agent.π⁻, 𝒮.agent.π, 0.005f0)                                                     # :108 with the default target_update
-    Crux.aggregate_info(infos)
+    π, π⁻ = 𝒮.agent.π, 𝒮.agent.π⁻                                                                                                   # DQN / SoftQ: one critic, polyak inside the chain
+    decode = r -> Dict("critic_loss" => r[1, 1], "critic_grad_norm" => r[2, 1], "Qavg" => r[3, 1])
+    infos = zeros(Float32, INFO_N, n)
+    if softq
+        α = Float32(𝒮.𝒫[:alpha])
+        if async
+            rc = ccall((:crux_softq_epochs_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Int32, Float32, UInt64, Int32, Ptr{Cvoid}),
+                       π.h, π⁻.h, 𝒮.buffer.h, 𝒟.h, γ, α, per, β, ctr0, n, d_rows)
+            rc == EUNSUP || (check(ctx, rc); return PendingInfo(ctx, d_rows, n, 1, decode, nothing))
+            device_free(ctx, d_rows)
+        end
+        check(ctx, ccall((:crux_softq_epochs, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Int32, Float32, UInt64, Int32, Ptr{Float32}),
+                         π.h, π⁻.h, 𝒮.buffer.h, 𝒟.h, γ, α, per, β, ctr0, n, infos))
+    else
+        if async
+            rc = ccall((:crux_dqn_epochs_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Int32, Float32, UInt64, Int32, Ptr{Cvoid}),
+                       π.h, π⁻.h, 𝒮.buffer.h, 𝒟.h, γ, per, β, ctr0, n, d_rows)
+            rc == EUNSUP || (check(ctx, rc); Crux.polyak_average!(π⁻, π, 0.005f0); return PendingInfo(ctx, d_rows, n, 1, decode, nothing))
+            device_free(ctx, d_rows)
+        end
+        check(ctx, ccall((:crux_dqn_epochs, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Int32, Float32, UInt64, Int32, Ptr{Float32}),
+                         π.h, π⁻.h, 𝒮.buffer.h, 𝒟.h, γ, per, β, ctr0, n, infos))
+    end
+    Crux.polyak_average!(π⁻, π, 0.005f0)                                                                                           # :108 with the default target_update (stream-ordered behind the chain)
+    Crux.aggregate_info([decode(infos[:, e:e]) for e in 1:n])
 end
 # The unfused pieces for solvers that compose their own epoch (DDPG / TD3 / custom param_optimizers) follow the same pattern:
 #   sac_target -> :crux_sac_target   sac_temp_loss -> :crux_sac_temp_step   double_Q_loss -> :crux_double_q_step   sac_actor_loss -> :crux_sac_actor_step
@@ -469,9 +628,11 @@ function POMDPs.solve(𝒮::Crux.OffPolicySolver, mdp::HipMDP)
         info = Dict()
         Crux.steps!(s, 𝒮.buffer, Nsteps=𝒮.ΔN, explore=true, i=𝒮.i, cb=(D) -> 𝒮.post_sample_callback(D, 𝒮=𝒮, info=info))            # :138
         𝒮.pre_train_callback(𝒮, info=info)                                                                      # :140
-        training_info = Crux.value_training(𝒮, 𝒟, γ)                                                            # :143 -> value_training(::OffPolicySolver, ::HipBuffer, γ)
-        evaluating && Crux.log(𝒮.log, 𝒮.i + 1:𝒮.i + 𝒮.ΔN, training_info, info, 𝒮=𝒮)                             # :146
+        training_info = Crux.value_training(𝒮, 𝒟, γ)                                                            # :143 -> value_training(::OffPolicySolver, ::HipBuffer, γ): the asynchronous chains when nobody logs
+        evaluating && Crux.log(𝒮.log, 𝒮.i + 1:𝒮.i + 𝒮.ΔN, resolve(training_info), info, 𝒮=𝒮)                    # :146
+        last_info = training_info
     end
+    @isdefined(last_info) && resolve(last_info)                                                                 # one synchronisation per solve: also where "NaN detected!" surfaces for the asynchronous chains
     𝒮.i += 𝒮.ΔN                                                                                                 # :148
     𝒮.agent.π
 end
