@@ -57,7 +57,9 @@ template <int ACT> __device__ __forceinline__ float actg(float y, float d) { ret
 // the f32 evaluation differs from the reference's per-element Float64 evaluation by < 1e-7 relative in the step).
 struct AdamK { float b1, b2, omb1, omb2, eps, eta, c1, c2; };
 __device__ __forceinline__ float adam1(float g, float& m, float& v, const AdamK& k) {
-  m = k.b1 * m + k.omb1 * g; v = k.b2 * v + (k.omb2 * g) * g;
+  // (explicit fma: which of the two products of `b1 m + (1 - b1) g` the compiler fuses into the addition otherwise differs from one kernel instantiation to the next, and with it
+  //  the last bit of m and v -- the forms of the learner kernel are meant to be bit-identical to each other)
+  m = fmaf(k.b1, m, k.omb1 * g); v = fmaf(k.b2, v, (k.omb2 * g) * g);
   return (m * k.c1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * k.c2) + k.eps) * k.eta;
 }
 

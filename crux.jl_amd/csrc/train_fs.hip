@@ -4,6 +4,7 @@
 #include "train_fs_kernel.h"
 
 extern "C" int crux_x2_placement_ok(crux_ctx* c);      // train_mfma_x2.hip: workgroups i and i + 8 of a grid share an XCD (probed once per process)
+int32_t crux_train_fs2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream, bool probe);      // train_fs2.hip: the role-specialised form (round 5)
 
 template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, int NWG, bool HELP, bool TIMING, bool PX, bool LAG = false, bool PXK = false>
 static int32_t launch_fs_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
@@ -94,6 +95,11 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hip
                        (in == 3 && out == 1 && kind == MFK_GAUSSIAN && act == CRUX_ACT_RELU) || (in == 17 && out == 6 && kind == MFK_GAUSSIAN && act == CRUX_ACT_TANH);
     if (!shape) return CRUX_OK;
   }
+  // round 5: the plain learners (no replica group, no lagrange_ppo_loss, no explicitly requested older form) take the role-specialised kernel k_train_fs2 -- the same arithmetic,
+  // bit-identical parameters, the W2 exchange / Adam in the helper waves beside the compute waves' backward pass. CRUX_FS2=0 keeps k_train_fs.
+  if (crux_sw().fs2 && form_env == 0 && !a.lag && !(crux_grouped(c) && a.need_px)) {
+    const int32_t rc2 = crux_train_fs2_launch(c, a, kind, handled, stream, probe);
+    if (rc2 || *handled) return rc2; }
   const int form = form_env == 2 || form_env == 4 || form_env == 8 ? form_env : CRUX_FS_DEFAULT_WG;      // 8 = four workgroups with helper waves
   const bool timing = crux_sw().mfma_timing;
 #define FS_CASE2(I, O, K, A1, H, A2) if (in == I && out == O && kind == K && act == A1 && h2 == H && act2 == A2) { *handled = true; if (probe) return CRUX_OK; return launch_fs<I, O, K, A1, H, A2>(c, a, form, timing, stream); }

@@ -1,0 +1,79 @@
+// train_fs2.hip -- dispatch of the role-specialised form of the register-resident learner kernel (train_fs2_kernel.h: k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2>): the plain
+// policy-gradient / critic losses of full batch_train! loops (src/training.jl:28-55) on every IN->64->{64,32}->OUT shape k_train_fs serves, on four compute units of one XCD
+// with four compute + four helper waves each. Called by crux_train_fs_launch (train_fs.hip) for the launches that are neither a replica group, nor lagrange_ppo_loss, nor one of
+// the explicitly requested older forms (CRUX_FS_WG); CRUX_FS2=0 keeps k_train_fs for them too.
+#include "train_fs2_kernel.h"
+
+template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, bool TIMING>
+static int32_t launch_fs2_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
+  using Lt = Fs2Layout<IN, OUT, H2>;
+  constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
+  static bool attr_dev[16] = {}; bool& attr = attr_dev[c->device & 15];
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING>), dim3(32), dim3(512), lds, stream, a);
+  return crux_launch_check(c, "k_train_fs2");
+}
+template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2>
+static int32_t launch_fs2(crux_ctx* c, TrainArgs a, bool timing, hipStream_t stream) {
+  const int which = stream == c->stream ? 0 : 1;
+  constexpr size_t xfloats = (size_t)CRUX_XBUF_FLOATS;
+  if (!c->xbuf[which]) { if (hipMalloc(&c->xbuf[which], sizeof(float) * xfloats + 256) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "learner exchange buffer"); }
+  a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * xfloats);
+  HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
+  a.xcd = which;      // actor / critic (the context's two learner streams) behind different L2s
+  constexpr bool HAS_TIMING = H2 == 64 && ACT2 == ACT && ((IN == 4 && (OUT == 2 || OUT == 1)) || (IN == 17 && ACT == CRUX_ACT_TANH));      // the in-kernel phase timers are instantiated for the C2 / C5 learners only
+  if constexpr (HAS_TIMING) if (timing) {
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) { if (hipMalloc(&dbg, 512 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
+    a.dbg = dbg;
+    int32_t rc = launch_fs2_form<IN, OUT, KIND, ACT, H2, ACT2, true>(c, a, stream); if (rc) return rc;
+    unsigned long long h[512]; HIPCHK(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, stream)); HIPCHK(c, hipStreamSynchronize(stream));
+    static const char* nc[16] = {"loop", "wait staged", "fwdL1+T1", "fwdL2", "L3+pair barrier+head", "dW3+dZ2+stats+T2", "wait B_1", "dH1", "dZ1+db+dW1", "B_2+reduce+store+drain", "arrival 2+wait",
+                                 "load small+total", "adam small", "wait B_b", "report+exit", "-"};
+    static const char* nh[16] = {"loop", "fetch", "stage next", "wait B_1", "dW2+send+drain", "arrival 1+wait", "load W2 slots+total", "ssq+backup+adam W2", "wait B_b", "exit", "-", "-", "-", "-", "-", "-"};
+    for (int wg = 0; wg < 4; ++wg) for (int w : {0, 4}) { const char** nm = w == 0 ? nc : nh;
+      fprintf(stderr, "[fs2-timing] %d-%d wg %d %s wave %d:", IN, OUT, wg, w == 0 ? "compute" : "helper", w); unsigned long long tot = 0; for (int k = 0; k < 16; ++k) tot += h[(8 * wg + w) * 16 + k];
+      for (int k = 0; k < 16; ++k) if (nm[k][0] != '-') fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[(8 * wg + w) * 16 + k] / (double)tot);
+      fprintf(stderr, " total=%llu\n", tot); }
+    return CRUX_OK;
+  }
+  return launch_fs2_form<IN, OUT, KIND, ACT, H2, ACT2, false>(c, a, stream);
+}
+
+// the shape list of crux_train_fs_launch (train_fs.hip), which has already tested the call (full minibatch loops with Adam, 64 < batch <= 128, plain PG / critic loss, no group)
+int32_t crux_train_fs2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream, bool probe) {
+  *handled = false;
+  const NetDesc& nd = a.nd;
+  const int in = nd.dims[0], h2 = nd.dims[2], out = nd.dims[3], act = nd.acts[0], act2 = nd.acts[1];
+  const bool timing = crux_sw().mfma_timing;
+#define FS2_CASE2(I, O, K, A1, H, A2) if (in == I && out == O && kind == K && act == A1 && h2 == H && act2 == A2) { *handled = true; if (probe) return CRUX_OK; return launch_fs2<I, O, K, A1, H, A2>(c, a, timing, stream); }
+#define FS2_CASE(I, O, K, A_) FS2_CASE2(I, O, K, A_, 64, A_)
+  FS2_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)     // C2 actor  (PPO CartPole)
+  FS2_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)           // C2 critic
+  FS2_CASE(17, 6, MFK_GAUSSIAN, CRUX_ACT_TANH)       // C5 actor  (PPO HalfCheetah-shaped, 17 obs / 6 act)
+  FS2_CASE(17, 1, MFK_VALUE, CRUX_ACT_TANH)          // C5 critic
+#ifndef CRUX_FS2_MINIMAL
+  FS2_CASE(3, 1, MFK_GAUSSIAN, CRUX_ACT_RELU)        // Pendulum actor
+  FS2_CASE(3, 1, MFK_VALUE, CRUX_ACT_RELU)           // Pendulum critic
+  FS2_CASE(17, 6, MFK_GAUSSIAN, CRUX_ACT_RELU)
+  FS2_CASE(17, 1, MFK_VALUE, CRUX_ACT_RELU)
+  FS2_CASE(8, 4, MFK_CATEGORICAL, CRUX_ACT_RELU)     // 8 observations / 4 discrete actions (LunarLander-shaped)
+  FS2_CASE(8, 1, MFK_VALUE, CRUX_ACT_RELU)
+  FS2_CASE(2, 1, MFK_GAUSSIAN, CRUX_ACT_RELU)        // the reference's own Pendulum examples observe (theta, theta_dot): 2 inputs (examples/rl/pendulum.jl)
+  FS2_CASE(2, 1, MFK_VALUE, CRUX_ACT_RELU)
+  // standard Gym shapes: Acrobot 6 / 3, MountainCar 2 / 3, LunarLanderContinuous 8 / 2, Hopper 11 / 3, BipedalWalker 24 / 4, Ant 27 / 8
+  FS2_CASE(6, 3, MFK_CATEGORICAL, CRUX_ACT_RELU)  FS2_CASE(6, 1, MFK_VALUE, CRUX_ACT_RELU)
+  FS2_CASE(2, 3, MFK_CATEGORICAL, CRUX_ACT_RELU)
+  FS2_CASE(8, 2, MFK_GAUSSIAN, CRUX_ACT_RELU)     FS2_CASE(8, 2, MFK_GAUSSIAN, CRUX_ACT_TANH)     FS2_CASE(8, 1, MFK_VALUE, CRUX_ACT_TANH)
+  FS2_CASE(11, 3, MFK_GAUSSIAN, CRUX_ACT_RELU)    FS2_CASE(11, 3, MFK_GAUSSIAN, CRUX_ACT_TANH)    FS2_CASE(11, 1, MFK_VALUE, CRUX_ACT_RELU)   FS2_CASE(11, 1, MFK_VALUE, CRUX_ACT_TANH)
+  FS2_CASE(24, 4, MFK_GAUSSIAN, CRUX_ACT_RELU)    FS2_CASE(24, 4, MFK_GAUSSIAN, CRUX_ACT_TANH)    FS2_CASE(24, 1, MFK_VALUE, CRUX_ACT_RELU)   FS2_CASE(24, 1, MFK_VALUE, CRUX_ACT_TANH)
+  FS2_CASE(27, 8, MFK_GAUSSIAN, CRUX_ACT_RELU)    FS2_CASE(27, 8, MFK_GAUSSIAN, CRUX_ACT_TANH)    FS2_CASE(27, 1, MFK_VALUE, CRUX_ACT_RELU)   FS2_CASE(27, 1, MFK_VALUE, CRUX_ACT_TANH)
+  // the reference's HalfCheetah PPO networks (examples/rl/half_cheetah_mujoco.jl:33-38): mu = 17 -tanh-> 64 -tanh-> 32 -> 6, V = 17 -tanh-> 64 -> 32 -> 1
+  FS2_CASE2(17, 6, MFK_GAUSSIAN, CRUX_ACT_TANH, 32, CRUX_ACT_TANH)
+  FS2_CASE2(17, 1, MFK_VALUE, CRUX_ACT_TANH, 32, CRUX_ACT_IDENTITY)
+  FS2_CASE2(17, 1, MFK_VALUE, CRUX_ACT_TANH, 32, CRUX_ACT_TANH)
+#endif
+#undef FS2_CASE
+#undef FS2_CASE2
+  return CRUX_OK;
+}

@@ -1,0 +1,783 @@
+// train_fs2_kernel.h -- the persistent batch_train! kernel of the register-resident IN->64->{64,32}->OUT family, ROLE-SPECIALISED form (round 5; src/training.jl:13-55,
+// ppo.jl:4-21,59-60, Flux Adam). Same decomposition of a minibatch step over four compute units of one XCD as train_fs_kernel.h (feature-split wave pairs per 16-sample
+// tile, four helper waves per workgroup) and the same arithmetic in the same order -- parameters, Adam moments and statistics come out bit-identical to k_train_fs --, but
+// the two kinds of waves no longer walk through one instruction stream:
+//
+//   COMPUTE waves (0..3)                                        HELPER waves (4..7)
+//   forward L1, L2, partial logits                              prefetch minibatch k+2's row indices, k+1's rows; stage minibatch k+1
+//   -- pair barrier (LDS) --
+//   loss head, dW3 / db3 partials, dZ2 -> T2 tiles
+//   ============================== B_1 (s_barrier): H1 / dZ2 tiles of the workgroup are visible ==============================
+//   dH1, dZ1, db1, db2, dW1 partials                            dW2 of ALL sixteen W2 tiles (four per wave), partials -> exchange slot
+//   -- compute barrier (LDS) --                                 drain stores, helper barrier (LDS), ARRIVAL 1, wait for the four workgroups
+//   small partials -> exchange slot, drain, compute barrier     load the three peers' W2 partials, total, Adam on W2 (theta, m, v in registers),
+//   ARRIVAL 2, wait, load the peers' small partials, total,     new W2 -> the LDS masters
+//   Adam on the small parameters (LDS masters)
+//   ============================== B_b (s_barrier): masters updated ==========================================================
+//
+// What this buys over k_train_fs: (1) the exchange of the W2 gradient -- 89 % of the bytes, and with them the slot loads, the total and the Adam update of W2 --
+// runs in the helper waves WHILE the compute waves are still in the backward pass (dH1 / dZ1 / dW1) and in their own, small exchange: two chains of L2 round trips side by
+// side instead of one after the other; (2) each role is its own code path, so the register allocation is the maximum of the two roles, not their union: the compute waves
+// no longer carry W2's theta / m / v / gradient / peer tiles, the helpers no activations -- no instantiation spills (the 17-64-64-6 forms of k_train_fs spill 25..140);
+// (3) the per-step barriers of the whole workgroup go from five to two; pairs and roles meet through LDS counters.
+// NaN semantics (training.jl:20): a total can only be NaN when a partial is NaN or huge; such a SUSPECT step is decided by the whole workgroup after B_b -- the helpers, who
+// have applied Adam to W2 by then, put their pre-step state back first -- so a NaN step leaves every parameter as it was, exactly as in k_train_fs.
+// Covers the plain policy-gradient / critic losses of full minibatch loops (65..128 rows); replica groups (PX), lagrange_ppo_loss and the other forms stay on k_train_fs.
+#pragma once
+#include "train_fs_kernel.h"
+
+template <int IN, int OUT, int H2>
+struct Fs2Layout : FsLayout<IN, OUT, 4, true, H2, false> {
+  using B = FsLayout<IN, OUT, 4, true, H2, false>;
+  static constexpr int NTC = 256;                                   // compute threads = helper threads
+  static constexpr int NSC = (B::NS + NTC - 1) / NTC;               // small parameters per compute thread
+  static constexpr int WTH = B::NT2;                                // W2 tiles per helper wave (NT2 x 4 tiles over four waves)
+  static constexpr int xW2 = 0, xSM = B::W2N, xST = xSM + NSC * NTC, xSUS1 = xST + 8, xSUS2 = xST + 9;      // exchange slot: W2 partials | small partials | 8 stat sums | suspect words
+  static constexpr int XSLOT2 = ((xST + 16 + 3) / 4) * 4;
+  static_assert(XSLOT2 <= 8192, "exchange slot");
+  // LDS words behind the reduction area (oRED .. oRED + 32): group-barrier counters and step flags
+  // cPAIR + t: the two waves of tile t, once per step; cCOMP: the four compute waves, three times per step; cHELP: the four helper waves, once per step;
+  // fH1 / fP1: steps whose ARRIVAL 1 has been issued / whose phase 1 is complete (helper leader -> everyone); fSUS: this step is suspect; fERR: why the exchange failed (sticky)
+  static constexpr int cPAIR = B::oRED + 24, cCOMP = B::oRED + 26, cHELP = B::oRED + 27, fH1 = B::oRED + 28, fP1 = B::oRED + 29, fSUS = B::oRED + 30, fERR = B::oRED + 31;
+};
+
+// meeting point of a subset of the workgroup's waves: one LDS counter, monotonic over the launch (target = members x number of uses so far). A wave's LDS operations execute in
+// order, so everything it wrote before the add is in the LDS before the add is.
+__device__ __forceinline__ void fs2_group_barrier(float* word, unsigned target, int lane) {
+  unsigned* cnt = (unsigned*)word;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(0);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void fs2_flag_set(float* word, unsigned v) { __hip_atomic_store((unsigned*)word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ unsigned fs2_flag_get(const float* word) { return __hip_atomic_load((const unsigned*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void fs2_flag_wait(const float* word, unsigned target) {
+  while (fs2_flag_get(word) < target) __builtin_amdgcn_s_sleep(0);
+  asm volatile("" ::: "memory");
+}
+
+template <int IN, int OUT, int KIND, int ACT, int H2 = 64, int ACT2 = ACT, bool TIMING = false>
+__global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
+  using Lt = Fs2Layout<IN, OUT, H2>;
+  constexpr int NWG = 4, NWC = 4, TILES = 2, NT = 512, NTC = 256, MH = Lt::MH, HH = Lt::HH, W2N = Lt::W2N, NW = 8;
+  constexpr int WT = Lt::WTH;                       // W2 tiles of a helper wave
+  constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS, NSC = Lt::NSC, XSLOT = Lt::XSLOT2;
+  constexpr int NACT = (OUT > 4 ? OUT : 4);
+  if ((int)(blockIdx.x & 7) != a.xcd) return;        // the four workgroups of the learner: blocks x, x + 8, x + 16, x + 24 -> one XCD
+  const int p = (int)(blockIdx.x >> 3);
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
+  const bool cw = w < NWC;                           // compute wave
+  const int wt = w & (NWC - 1);                      // (tile, half) role: of the tile work for a compute wave, of the staging work for a helper
+  const int t = wt >> 1, h = wt & 1;
+  const int ct = tid & (NTC - 1);                    // index inside the role's 256 threads
+  float* part = sm + Lt::oPART + t * Lt::PART;
+  float* xs = sm + Lt::oXS + t * 16 * XP;
+  float* sc = sm + Lt::oSC + t * 16 * Lt::SCW;
+  constexpr int XSB = TILES * 16 * XP, SCB = TILES * 16 * Lt::SCW;
+  int xcur = 0;
+  float* T1 = sm + Lt::oT1 + t * Lt::TILE;
+  float* T2 = sm + Lt::oT2 + t * Lt::TILE2;
+  const int n_extra = (KIND == MFK_GAUSSIAN) ? OUT : 0;
+  unsigned long long tacc[16]; unsigned long long tlast = 0;
+  if (TIMING) { for (int k = 0; k < 16; ++k) tacc[k] = 0; tlast = __builtin_amdgcn_s_memtime(); }
+#define FS2_T(ph) do { if (TIMING) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
+  const int t_wr = (4 * g) * 16 + 4 * ((c >> 2) ^ fs_tx(g)) + (c & 3);
+  const int t_rd = c * 16 + 4 * (g ^ fs_tx(c >> 2));
+  const int hw = w - NWC;                            // helper wave 0..3 (negative for compute waves: never used there)
+  const int mp0 = ((hw < 0 ? 0 : hw) * WT) >> 2, m0 = ((hw < 0 ? 0 : hw) * WT) & 3;      // W2 tiles (mp0, m0 .. m0 + WT - 1) of a helper wave
+
+  auto s_master = [&](int s) -> int {
+    if (s < Lt::sB1) { const int o = s & 63, i = s >> 6; return Lt::oW1R + o * Lt::W1LD + i; }
+    if (s < Lt::sB2) return Lt::oB1 + (s - Lt::sB1);
+    if (s < Lt::sW3) return Lt::oB2 + (s - Lt::sB2);
+    if (s < Lt::sB3) { const int q = s - Lt::sW3; const int o = q % OUT, i = q / OUT; return Lt::oW3R + o * H2 + i; }
+    if (s < Lt::sEX) return Lt::oB3 + (s - Lt::sB3);
+    return Lt::oEX + (s - Lt::sEX);
+  };
+  auto s_canon = [&](int s) -> int {
+    if (s < Lt::sB1) return Lt::cW1 + s;
+    if (s < Lt::sB2) return Lt::cB1 + (s - Lt::sB1);
+    if (s < Lt::sW3) return Lt::cB2 + (s - Lt::sB2);
+    if (s < Lt::sB3) return Lt::cW3 + (s - Lt::sW3);
+    if (s < Lt::sEX) return Lt::cB3 + (s - Lt::sB3);
+    return Lt::cEX + (s - Lt::sEX);
+  };
+  auto s_part = [&](int s) -> int {
+    if (s < Lt::sB1) { const int o = s & 63, i = s >> 6; return Lt::pW1 + i * FS_LD + o; }
+    if (s < Lt::sB2) return Lt::pB1 + (s - Lt::sB1);
+    if (s < Lt::sW3) return Lt::pB2 + (s - Lt::sB2);
+    if (s < Lt::sB3) { const int q = s - Lt::sW3; const int o = q % OUT, i = q / OUT; return Lt::pW3 + o * H2 + i; }
+    if (s < Lt::sEX) return Lt::pB3 + (s - Lt::sB3);
+    return Lt::pEX + (s - Lt::sEX);
+  };
+  const int ns_valid = Lt::sEX + n_extra;
+
+  // ---- load parameters and Adam state (all 512 threads) ------------------------------------------------------------
+  for (int q = tid; q < W2N; q += NT) { const int o = q % H2, i = q / H2; const float v = a.p[Lt::cW2 + q];
+    sm[Lt::oW2R + o * FS_LD + i] = v; sm[Lt::oW2C + i * FS_LD + o] = v; }
+  for (int q = tid; q < MF_HID * Lt::W1LD; q += NT) sm[Lt::oW1R + q] = 0.f;
+  if (tid < 16) { sm[Lt::oB3 + tid] = 0.f; sm[Lt::oEX + tid] = 0.f; }
+  if (tid < 32) sm[Lt::oRED + tid] = 0.f;            // statistics, group-barrier counters and step flags start from zero
+  for (int q = tid; q < TILES * Lt::PART; q += NT) sm[Lt::oPART + q] = 0.f;
+  uint32_t my_xcc = 0;
+  if (tid == 0) { asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc)); my_xcc &= 0xf;
+    __hip_atomic_store(a.xctr + 8 + p, my_xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __syncthreads();
+  for (int s = tid; s < NS; s += NT) { const bool in = s < ns_valid; const int pc = s_canon(s);
+    if (in) sm[s_master(s)] = a.p[pc];
+    sm[Lt::oMS + s] = in ? a.m[pc] : 0.f; sm[Lt::oVS + s] = in ? a.v[pc] : 0.f; }
+  for (int q = tid; q < Lt::NXB * TILES * 16 * XP; q += NT) sm[Lt::oXS + q] = 0.f;
+  double bp1 = a.bp[0], bp2 = a.bp[1];
+  const float lo = 1.f - a.eps_clip, hi = 1.f + a.eps_clip;
+  const bool a2c = a.loss == CRUX_LOSS_A2C;
+  AdamK ak; ak.b1 = (float)a.b1; ak.b2 = (float)a.b2; ak.omb1 = (float)(1.0 - a.b1); ak.omb2 = (float)(1.0 - a.b2); ak.eps = (float)a.eps; ak.eta = (float)a.eta;
+  const double db1 = a.b1, db2 = a.b2;
+  const float lambda_p = a.lambda_p, lambda_e = a.lambda_e, target_kl = a.target_kl, squash = a.squash;
+  const long long max_batches = a.max_batches;
+  const int bs = a.bs;
+
+  int32_t* order_cur = a.order_a; int32_t* order_nxt = a.order_b;
+  long long total_batches = 0; int epochs_run = 0, err = 0, why_failed = 0; bool stop = false;
+  bool staged = false;
+  unsigned xstep = 0;                                // exchanges of this launch: every group-barrier target and both arrival counters are multiples of xstep + 1
+  float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
+  const int n_epochs = a.epochs;
+  if (!a.ord_all) { for (int64_t j = tid; j < a.len; j += NT) order_cur[j] = (int32_t)j; }
+  if (!a.ord_all && a.pre_epochs > 0) {
+    __syncthreads();
+    for (int pe = 0; pe < a.pre_epochs; ++pe) {
+      if (a.pre_perms) { for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[a.pre_perms[(int64_t)pe * a.len + j]]; }
+      else { const crux_perm pp = crux_perm_make(a.pre_seed, a.pre_counter + (uint64_t)pe, 0, (uint32_t)a.len);
+        for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[crux_perm_at(&pp, (uint32_t)j)]; }
+      __syncthreads();
+      int32_t* tq = order_cur; order_cur = order_nxt; order_nxt = tq;
+    }
+  }
+  __syncthreads();
+  const int64_t total_rows = a.len;
+  if (tid == 0) { a.xbuf[(size_t)(0 * NWG + p) * XSLOT + Lt::xSUS1] = 0.f; a.xbuf[(size_t)(0 * NWG + p) * XSLOT + Lt::xSUS2] = 0.f;      // this workgroup's SUSPECT words, both parities
+    a.xbuf[(size_t)(1 * NWG + p) * XSLOT + Lt::xSUS1] = 0.f; a.xbuf[(size_t)(1 * NWG + p) * XSLOT + Lt::xSUS2] = 0.f; }
+
+  // what the minibatch loops of both roles share. Only the epoch's last minibatch, or the one that ends the loop, is ever reported (training.jl:22-23, 45-53).
+  auto static_report = [&](int64_t st) -> bool { return st + bs >= total_rows || (max_batches > 0 && total_batches + 1 >= max_batches); };
+  // the end of a minibatch step after B_b, identical in every thread of the workgroup (its inputs are LDS words published before the barrier): the KL statistic and the loop exits.
+  // false = the minibatch loop ends here.
+  auto step_exit = [&](float invB, bool any_bad) -> bool {
+    if (KIND != MFK_VALUE && target_kl >= 0.f) inf_kl = sm[Lt::oRED + 8 + 2] * invB;
+    if (any_bad) { inf_gn = NAN; err = CRUX_ENAN; return false; }                     // training.jl:20: no update
+    total_batches += 1;
+    if (max_batches > 0 && total_batches >= max_batches) return false;                // training.jl:45
+    if (target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > target_kl) return false;    // :46
+    return true;
+  };
+  // both roles run the same epoch prologue (same barriers): the speculative-run consensus of k_train_fs and the epoch's shuffle order. false = leave the epoch loop.
+  auto epoch_prologue = [&](int ep) -> bool {
+    if (a.spec_abort) {
+      if (tid == 0) {
+        const unsigned r = __hip_atomic_load(a.spec_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        (void)__hip_atomic_fetch_or(a.xctr + 16, r ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        (void)__hip_atomic_fetch_add(a.xctr + 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (unsigned)NWG * (unsigned)(ep + 1); unsigned spins = 0; bool late = false;
+        while (__hip_atomic_load(a.xctr + 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 24)) { late = true; break; } }
+        if (late) { (void)__hip_atomic_fetch_or(a.xctr + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        sm[Lt::oRED + 17] = late ? 2.f : (__hip_atomic_load(a.xctr + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f); }
+      __syncthreads();
+      if (sm[Lt::oRED + 17] == 2.f) { err = CRUX_EHIP; why_failed = 4; return false; }
+      if (sm[Lt::oRED + 17] != 0.f) { err = CRUX_TRAIN_ABORTED; return false; }
+    }
+    if (a.ord_all) order_cur = const_cast<int32_t*>(a.ord_all) + (size_t)ep * (size_t)a.len;   // shuffle orders composed ahead of time by k_compose_order
+    else {   // shuffle!(D) as an index composition (experience_buffer.jl:118-124)
+      if (a.perms) { for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[a.perms[(int64_t)ep * a.len + j]]; }
+      else { const crux_perm pp = crux_perm_make(a.shuffle_seed, a.shuffle_counter + (uint64_t)ep, 0, (uint32_t)a.len);
+        for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[crux_perm_at(&pp, (uint32_t)j)]; }
+      __syncthreads();
+      int32_t* tq = order_cur; order_cur = order_nxt; order_nxt = tq;
+    }
+    return true;
+  };
+  auto epoch_epilogue = [&](int ep) {
+    if (tid == 0 && p == 0 && a.epoch_infos) { float* e = a.epoch_infos + (size_t)ep * CRUX_INFO_N;   // aggregate_info(minibatch_infos) == last minibatch (Q3)
+      for (int k = 0; k < CRUX_INFO_N; ++k) e[k] = 0.f;
+      e[CRUX_INFO_LOSS] = inf_loss; e[CRUX_INFO_GRAD_NORM] = inf_gn;
+      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = inf_ent; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = inf_clip; e[CRUX_INFO_AVG_ADVANTAGE] = inf_adv; e[CRUX_INFO_AVG_RETURN] = inf_ret; } }
+    epochs_run += 1;
+    if (target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > target_kl) stop = true;   // training.jl:49
+    if (max_batches > 0 && total_batches >= max_batches) stop = true;               // :50
+  };
+
+  if (cw) {
+    // =====================================================================================================================================================
+    // COMPUTE WAVES
+    // =====================================================================================================================================================
+    int so_part[NSC], so_master[NSC]; bool so_ok[NSC], so_ex[NSC];
+#pragma unroll
+    for (int k = 0; k < NSC; ++k) { const int s = ct + NTC * k; so_ok[k] = s < ns_valid; so_ex[k] = s >= Lt::sEX;
+      so_part[k] = so_ok[k] ? s_part(s) : 0; so_master[k] = so_ok[k] ? s_master(s) : 0; }
+    for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
+      if (!epoch_prologue(ep)) break;
+      staged = false;
+      for (int64_t st = 0; st < total_rows; st += bs) {
+        const int nb = (int)((total_rows - st) < bs ? (total_rows - st) : bs);
+        const float invB = 1.0f / (float)nb;
+        ak.c1 = __builtin_amdgcn_rcpf((float)(1.0 - bp1)); ak.c2 = __builtin_amdgcn_rcpf((float)(1.0 - bp2));
+        FS2_T(0);
+        if (!staged) __syncthreads();      // the first minibatch of an epoch is staged by the helpers before this barrier; every other one during the previous step
+        staged = false;
+        const float* xs_c = xs + xcur * XSB; const float* sc_c = sc + xcur * SCB;
+        FS2_T(1);
+        // ======================= forward, C orientation: D[feature 16m+4g+r][sample c] =======================
+        f32x4 h1[4]; f32x4 h2[MH];
+        constexpr bool W3_REG = OUT <= 2;
+        f32x4 w3[OUT <= 2 ? OUT : 1][MH];
+        float zp[OUT];
+        {
+          float xB[KS0];
+#pragma unroll
+          for (int ks = 0; ks < KS0; ++ks) xB[ks] = xs_c[c * XP + 4 * ks + g];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { f32x4 acc = *(const f32x4*)&sm[Lt::oB1 + 16 * m + 4 * g];
+#pragma unroll
+            for (int ks = 0; ks < KS0; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm[Lt::oW1R + (16 * m + c) * Lt::W1LD + 4 * ks + g], xB[ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = actf<ACT>(acc[r]);
+            h1[m] = acc; }
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T1[t_wr + (16 * (2 * h + mm) + r) * 16] = (h ? (mm ? h1[3][r] : h1[2][r]) : (mm ? h1[1][r] : h1[0][r]));
+          FS2_T(2);
+          { f32x4 acc[MH];
+#pragma unroll
+            for (int mm = 0; mm < MH; ++mm) acc[mm] = *(const f32x4*)&sm[Lt::oB2 + HH * h + 16 * mm + 4 * g];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { f32x4 wv[MH];
+#pragma unroll
+              for (int mm = 0; mm < MH; ++mm) wv[mm] = *(const f32x4*)&sm[Lt::oW2R + (HH * h + 16 * mm + c) * FS_LD + 16 * m + 4 * g];
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mm = 0; mm < MH; ++mm) acc[mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[mm][r], h1[m][r], acc[mm], 0, 0, 0); }
+#pragma unroll
+            for (int mm = 0; mm < MH; ++mm) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[mm][r] = actf<ACT2>(acc[mm][r]);
+              h2[mm] = acc[mm]; } }
+          FS2_T(3);
+          if (W3_REG) {
+#pragma unroll
+            for (int o = 0; o < OUT; ++o)
+#pragma unroll
+              for (int mm = 0; mm < MH; ++mm) w3[o][mm] = *(const f32x4*)&sm[Lt::oW3R + o * H2 + HH * h + 16 * mm + 4 * g]; }
+#pragma unroll
+          for (int o = 0; o < OUT; ++o) { float acc = 0.f;
+#pragma unroll
+            for (int mm = 0; mm < MH; ++mm) { const f32x4 wv = W3_REG ? w3[W3_REG ? o : 0][mm] : *(const f32x4*)&sm[Lt::oW3R + o * H2 + HH * h + 16 * mm + 4 * g];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc = fmaf(wv[r], h2[mm][r], acc); }
+            zp[o] = g4_sum(acc); }
+          { float* zq = sm + Lt::oZP + ((t * 2 + h) * 64 + lane) * Lt::ZW;
+#pragma unroll
+            for (int o = 0; o < OUT; ++o) zq[o] = zp[o]; }
+        }
+        fs2_group_barrier(sm + Lt::cPAIR + t, 2u * (xstep + 1u), lane);      // ---- B_z: the pair's partial logits are visible (the two waves of the tile only)
+        float dz[OUT], dex[OUT];
+        float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f;
+        {
+          float z[OUT];
+          { const float* zo = sm + Lt::oZP + ((t * 2 + (1 - h)) * 64 + lane) * Lt::ZW;
+#pragma unroll
+            for (int o = 0; o < OUT; ++o) { const float other = zo[o]; z[o] = (h ? other + zp[o] : zp[o] + other) + sm[Lt::oB3 + o]; } }
+          // ======================= loss head (identical in both waves of the pair) =======================
+          {
+            const float* q = sc_c + c * Lt::SCW;
+            const bool valid = q[0] != 0.f; const float oldlp = q[1], A = q[2], R = q[3];
+            const float cnt = (valid && g == 0) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < OUT; ++k) dex[k] = 0.f;
+            if (KIND == MFK_VALUE) {
+              const float d = z[0] - R; dz[0] = valid ? 2.f * d * invB : 0.f; s_sq = cnt * d * d; s_ret = cnt * R;
+            } else if (KIND == MFK_CATEGORICAL) {
+              const int ai = (int)q[4];
+              float mx = z[0];
+#pragma unroll
+              for (int k = 1; k < OUT; ++k) mx = fmaxf(mx, z[k]);
+              float pk[OUT], hk[OUT]; float sum = 0.f;
+#pragma unroll
+              for (int k = 0; k < OUT; ++k) { pk[k] = __expf(z[k] - mx); sum += pk[k]; }
+              const float inv = __builtin_amdgcn_rcpf(sum); float pa = 0.f, H = 0.f, hp = 0.f;
+#pragma unroll
+              for (int k = 0; k < OUT; ++k) { pk[k] *= inv; pa = (k == ai) ? pk[k] : pa; const float pe = pk[k] + EPS32F; const float lg = __logf(pe); H -= pk[k] * lg;
+                hk[k] = -lg - pk[k] * __builtin_amdgcn_rcpf(pe); hp += hk[k] * pk[k]; }
+              const float newlp = __logf(pa); const float r = __expf(newlp - oldlp);
+              const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
+              const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;
+#pragma unroll
+              for (int k = 0; k < OUT; ++k) { const float dlogpi = ((k == ai) ? 1.f : 0.f) - pk[k];
+                const float base = -lambda_p * coef * dlogpi - lambda_e * (pk[k] * (hk[k] - hp));
+                dz[k] = !valid ? 0.f : invB * base; }
+              s_lossp = cnt * lterm; s_H = cnt * H; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R;
+              s_clip = cnt * clipv;
+            } else {   // gaussian with constant log-std (policies.jl:333-348)
+              float newlp = 0.f; float dd[OUT], s2[OUT];
+              float inr[OUT];
+#pragma unroll
+              for (int k = 0; k < OUT; ++k) { const float ls = sm[Lt::oEX + k]; const bool sq = squash > 0.f;
+                s2[k] = __expf(-2.f * (sq ? sq_clampls(ls) : ls)); dd[k] = q[4 + k] - z[k];
+                inr[k] = (sq && !(ls >= -5.f && ls <= 2.f)) ? 0.f : 1.f;
+                newlp += (-(dd[k] * dd[k]) * (0.5f * s2[k]) - 0.9189385332046727f - ls); }
+              if (squash > 0.f) newlp -= q[4 + NACT];
+              const float r = __expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
+              const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;
+              const float cf = -lambda_p * coef;
+#pragma unroll
+              for (int k = 0; k < OUT; ++k) { dz[k] = valid ? invB * (cf * (dd[k] * s2[k])) : 0.f;
+                dex[k] = valid ? invB * (cf * (((dd[k] * dd[k]) * s2[k]) * inr[k] - 1.f)) : 0.f; }
+              s_lossp = cnt * lterm; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R; s_clip = cnt * clipv;
+            }
+          }
+          FS2_T(4);
+          // ======================= backward, own samples, own feature half =======================
+          constexpr int FPL = 4 * MH, PER = 16 / FPL;
+#pragma unroll
+          for (int o2 = 0; o2 < (OUT + PER - 1) / PER; ++o2) { float pv[16];
+#pragma unroll
+            for (int oo = 0; oo < PER; ++oo)
+#pragma unroll
+              for (int mm = 0; mm < MH; ++mm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[FPL * oo + 4 * mm + r] = (PER * o2 + oo < OUT) ? dz[(PER * o2 + oo < OUT) ? PER * o2 + oo : 0] * h2[mm][r] : 0.f;
+            const float sred = row16_reduce_scatter(pv, c);
+            const int oo = c / FPL;
+            if (PER * o2 + oo < OUT) part[Lt::pW3 + (PER * o2 + oo) * H2 + HH * h + 16 * ((c >> 2) & (MH - 1)) + 4 * g + (c & 3)] = sred; }
+          { f32x4 d2[MH];
+#pragma unroll
+            for (int mm = 0; mm < MH; ++mm) d2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < OUT; ++o)
+#pragma unroll
+              for (int mm = 0; mm < MH; ++mm) { const f32x4 wv = W3_REG ? w3[W3_REG ? o : 0][mm] : *(const f32x4*)&sm[Lt::oW3R + o * H2 + HH * h + 16 * mm + 4 * g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d2[mm][r] = fmaf(wv[r], dz[o], d2[mm][r]); }
+#pragma unroll
+            for (int mm = 0; mm < MH; ++mm)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) h2[mm][r] = actg<ACT2>(h2[mm][r], d2[mm][r]); }       // h2 now holds dZ2 of this half
+          if (h == 0) {
+            constexpr int NV = 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0);
+            float mv[((NV + 15) / 16) * 16];
+#pragma unroll
+            for (int k = 0; k < ((NV + 15) / 16) * 16; ++k) mv[k] = 0.f;
+            mv[0] = s_lossp; mv[1] = s_H; mv[2] = s_kl; mv[3] = s_adv; mv[4] = s_ret; mv[5] = s_clip; mv[6] = s_sq;
+#pragma unroll
+            for (int o = 0; o < OUT; ++o) { mv[7 + o] = dz[o]; if (KIND == MFK_GAUSSIAN) mv[7 + OUT + o] = dex[o]; }
+#pragma unroll
+            for (int ch = 0; ch < (NV + 15) / 16; ++ch) { float cv[16];
+#pragma unroll
+              for (int k = 0; k < 16; ++k) cv[k] = mv[16 * ch + k];
+              const float tq = row16_reduce_scatter(cv, c);
+              if (g == 0) part[Lt::pMISC + 16 * ch + c] = tq; } }
+#pragma unroll
+          for (int mm = 0; mm < MH; ++mm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T2[t_wr + (16 * (MH * h + mm) + r) * 16] = h2[mm][r];
+          { float* dq = sm + Lt::oD2X + ((t * 2 + h) * MH) * 256 + lane * 4;
+#pragma unroll
+            for (int mm = 0; mm < MH; ++mm) *(f32x4*)&dq[256 * mm] = h2[mm]; }
+        }
+        FS2_T(5);
+        __syncthreads();   // ---- B_1: T1 / T2 tiles of the workgroup and the dZ2 halves are visible (the helpers start dW2)
+        FS2_T(6);
+        // dH1 (R) for the h1 features [32h, 32h + 32)
+        f32x4 dz1r[2];
+        { const float* dq = sm + Lt::oD2X + ((t * 2 + (1 - h)) * MH) * 256 + lane * 4;
+          f32x4 av[2 * MH];
+#pragma unroll
+          for (int mm = 0; mm < MH; ++mm) { av[mm] = h2[mm]; av[MH + mm] = *(const f32x4*)&dq[256 * mm]; }
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 2 * MH; ++q) { const int fo = HH * ((q >= MH) ? 1 - h : h) + 16 * (q % MH);
+            const f32x4 wv0 = *(const f32x4*)&sm[Lt::oW2C + (32 * h + c) * FS_LD + fo + 4 * g];
+            const f32x4 wv1 = *(const f32x4*)&sm[Lt::oW2C + (32 * h + 16 + c) * FS_LD + fo + 4 * g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][r], wv0[r], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][r], wv1[r], acc1, 0, 0, 0); } }
+          dz1r[0] = acc0; dz1r[1] = acc1; }
+        FS2_T(7);
+        float gb1[2], gb2[MH];
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) { float sb1 = 0.f;
+          const f32x4 h1r = *(const f32x4*)&T1[t_rd + 256 * (2 * h + mm)];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float d = actg<ACT>(h1r[r], dz1r[mm][r]); dz1r[mm][r] = d; sb1 += d; }
+          gb1[mm] = g4_sum(sb1); }
+#pragma unroll
+        for (int mm = 0; mm < MH; ++mm) { float sb2 = 0.f;
+          const f32x4 d2 = *(const f32x4*)&T2[t_rd + 256 * (MH * h + mm)];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sb2 += d2[r];
+          gb2[mm] = g4_sum(sb2); }
+        if (g == 0) {
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) part[Lt::pB1 + 32 * h + 16 * mm + c] = gb1[mm];
+#pragma unroll
+          for (int mm = 0; mm < MH; ++mm) part[Lt::pB2 + HH * h + 16 * mm + c] = gb2[mm]; }
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+          float xR[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xR[r] = (16 * jt + c < IP) ? xs_c[(4 * g + r) * XP + 16 * jt + c] : 0.f;
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) { f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1r[mm][r], xR[r], acc, 0, 0, 0);
+            if (16 * jt + c < Lt::W1ROWS) *(f32x4*)&part[Lt::pW1 + (16 * jt + c) * FS_LD + 32 * h + 16 * mm + 4 * g] = acc; }
+        }
+        FS2_T(8);
+        fs2_group_barrier(sm + Lt::cCOMP, (unsigned)NWC * (3u * xstep + 1u), lane);   // ---- B_2: the small partial gradients of both tiles are visible (compute waves only)
+        float gs[NSC];
+#pragma unroll
+        for (int k = 0; k < NSC; ++k) { float gsum = 0.f;
+          if (so_ok[k]) { const int po = Lt::oPART + so_part[k];
+            gsum = sm[po];
+#pragma unroll
+            for (int q = 1; q < TILES; ++q) gsum += sm[po + q * Lt::PART]; }
+          gs[k] = gsum; }
+        float stat_loc = 0.f;
+        const bool stat_lane = ct >= NTC - 8 && ct < NTC - 1;      // stat sums, by 7 lanes of the last compute wave
+        if (stat_lane) { const int ko = Lt::pST + (ct - (NTC - 8)); stat_loc = sm[Lt::oPART + ko];
+#pragma unroll
+          for (int q = 1; q < TILES; ++q) stat_loc += sm[Lt::oPART + q * Lt::PART + ko]; }
+        float* mine = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + p)) * XSLOT;
+        bool odd = false;
+#pragma unroll
+        for (int k = 0; k < NSC; ++k) { mine[Lt::xSM + ct + NTC * k] = gs[k]; odd = odd || !(fabsf(gs[k]) <= 1e30f); }
+        if (stat_lane) mine[Lt::xST + (ct - (NTC - 8))] = stat_loc;
+        if (odd) mine[Lt::xSUS2] = 1.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this lane has reached the L2
+        FS2_T(9);
+        fs2_group_barrier(sm + Lt::cCOMP, (unsigned)NWC * (3u * xstep + 2u), lane);   // all compute waves' stores are acknowledged
+        if (tid == 0) {
+          fs2_flag_wait(sm + Lt::fH1, xstep + 1u);          // ARRIVAL 2 follows this workgroup's ARRIVAL 1: a full second counter says the W2 partials (and their suspect words) are out too
+          (void)__hip_atomic_fetch_add(a.xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned want = (unsigned)NWG * (xstep + 1u); unsigned spins = 0; bool ok = true;
+          while (__hip_atomic_load(a.xctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24) || __hip_atomic_load(a.xctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; } }   // never hang the GPU
+          unsigned why = ok ? 0u : 1u;
+          if (ok && xstep == 0u) {   // the unfenced exchange is only coherent inside one XCD's L2
+            for (int q = 0; q < NWG; ++q) { const unsigned peer_xcc = __hip_atomic_load(a.xctr + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (peer_xcc != my_xcc + 1u) { ok = false; why = 2u; } } }
+          if (!ok) { __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fs2_flag_set(sm + Lt::fERR, why); }
+        }
+        fs2_group_barrier(sm + Lt::cCOMP, (unsigned)NWC * (3u * xstep + 3u), lane);   // the end of the wait (or its failure) reaches the other compute waves
+        FS2_T(10);
+        const bool failed = fs2_flag_get(sm + Lt::fERR) != 0u;
+        float stat_tot = stat_loc; bool suspect = true; float kl_tot = 0.f;
+        if (!failed) {
+          constexpr int NLD = NWG - 1;
+          float pg[NLD][NSC]; float ps[NLD]; float psus[2 * NLD + 2], pkl[NLD + 1];
+          psus[2 * NLD] = __hip_atomic_load(mine + Lt::xSUS1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); psus[2 * NLD + 1] = __hip_atomic_load(mine + Lt::xSUS2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pkl[NLD] = __hip_atomic_load(mine + Lt::xST + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int j = 0; j < NLD; ++j) { const int q = j == 0 ? (p ^ 1) : ((p ^ 2) & 2) + (j - 1);      // partner, then the other pair's first and second workgroup
+            const float* peer = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + q)) * XSLOT;
+            psus[2 * j] = __hip_atomic_load(peer + Lt::xSUS1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); psus[2 * j + 1] = __hip_atomic_load(peer + Lt::xSUS2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pkl[j] = __hip_atomic_load(peer + Lt::xST + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < NSC; ++k) pg[j][k] = __hip_atomic_load(peer + Lt::xSM + ct + NTC * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ps[j] = 0.f;
+            if (stat_lane) ps[j] = __hip_atomic_load(peer + Lt::xST + (ct - (NTC - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) gs[k] = (gs[k] + pg[0][k]) + (pg[1][k] + pg[2][k]);
+          stat_tot = (stat_loc + ps[0]) + (ps[1] + ps[2]);
+          suspect = false;
+#pragma unroll
+          for (int j = 0; j < 2 * NLD + 2; ++j) suspect = suspect || psus[j] != 0.f;
+          kl_tot = (pkl[3] + pkl[0]) + (pkl[1] + pkl[2]);
+        }
+        if (stat_lane) sm[Lt::oRED + 8 + (ct - (NTC - 8))] = stat_tot;
+#pragma unroll
+        for (int k = 0; k < NSC; ++k) if (so_ok[k]) {
+          if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += -lambda_e; }      // d(-lambda_e H)/dlogSigma, H = const + sum(logSigma)
+        const float kl_now = kl_tot * invB;
+        const bool maybe_report = suspect || static_report(st) || (KIND != MFK_VALUE && target_kl >= 0.f && kl_now > target_kl);
+        float ssq = 0.f;
+        if (maybe_report) {      // the norm of a reported step (the helpers add their W2 share every step); the report itself is formed after B_b
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) if (so_ok[k]) ssq += gs[k] * gs[k];
+          ssq = wave_sum(ssq);
+          if (lane == 0) sm[Lt::oRED + w] = ssq; }
+        float ent_pre = 1.4189385332046727f;               // entropy of a Gaussian policy as the loss saw it: the report follows the update of logSigma below
+        if (KIND == MFK_GAUSSIAN && maybe_report) {
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) ent_pre += sm[Lt::oEX + k]; }
+        FS2_T(11);
+        // ======================= Adam on the small parameters (Flux.update!, training.jl:21) -- not on a suspect step: that one is decided after B_b =======================
+        auto adam_small = [&]() {
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) { const int s = ct + NTC * k;
+            if (so_ok[k]) { float m_ = sm[Lt::oMS + s], v_ = sm[Lt::oVS + s]; const float d = adam1(gs[k], m_, v_, ak);
+              sm[Lt::oMS + s] = m_; sm[Lt::oVS + s] = v_; const int mo = so_master[k]; sm[mo] = sm[mo] - d; } } };
+        if (!suspect && !failed) adam_small();
+        if (tid == 0) fs2_flag_set(sm + Lt::fSUS, suspect ? 1u : 0u);
+        FS2_T(12);
+        __syncthreads();   // ---- B_b: masters updated (W2 by the helpers); tiles and partials may be overwritten
+        FS2_T(13);
+        { const unsigned why = fs2_flag_get(sm + Lt::fERR); if (why != 0u) { err = CRUX_EHIP; why_failed = (int)why; break; } }
+        int any_bad = 0;
+        if (suspect) {      // the whole workgroup decides (the helpers have put their pre-step W2 state back): NaN -> no update, error (training.jl:20); otherwise the update now
+          int bad = 0;
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) if (so_ok[k]) bad |= isnan(gs[k]) ? 1 : 0;
+          any_bad = __syncthreads_or(bad);
+          if (!any_bad) { adam_small(); __syncthreads(); }
+        }
+        // minibatch info (training.jl:22-23, ppo.jl:13-19): identical in every compute thread
+        { const float* tq = sm + Lt::oRED + 8;
+          const bool report = any_bad || static_report(st) || (KIND != MFK_VALUE && target_kl >= 0.f && tq[2] * invB > target_kl);
+          if (report) {
+            float ss = sm[Lt::oRED];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) ss += sm[Lt::oRED + q];
+            inf_gn = sqrtf(ss);
+            if (KIND == MFK_VALUE) { inf_loss = tq[6] * invB; inf_ret = tq[4] * invB; }
+            else { const float p_loss = -(tq[0] * invB); const float entropy = KIND == MFK_CATEGORICAL ? tq[1] * invB : ent_pre;
+              inf_ent = entropy; inf_loss = lambda_p * p_loss + lambda_e * (-entropy); inf_kl = tq[2] * invB; inf_adv = tq[3] * invB; inf_ret = tq[4] * invB; inf_clip = tq[5] * invB; } } }
+        const bool go = step_exit(invB, any_bad != 0);
+        if (!any_bad) { bp1 *= db1; bp2 *= db2; }
+        xcur ^= 1; xstep += 1u; staged = st + bs < total_rows;
+        FS2_T(14);
+        if (!go) break;
+      }
+      if (err) break;
+      epoch_epilogue(ep);
+    }
+  } else {
+    // =====================================================================================================================================================
+    // HELPER WAVES: the whole W2 path of the step (dW2, its exchange, total, Adam) and the minibatch prefetch / staging
+    // =====================================================================================================================================================
+    // owned W2 tiles, D layout: reg r of tile mm <-> W2[o = 16 mp0 + 4g + r][i = 16 (m0+mm) + c]
+    f32x4 tW2[WT], mW2[WT], vW2[WT];
+#pragma unroll
+    for (int mm = 0; mm < WT; ++mm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + H2 * (16 * (m0 + mm) + c);
+        tW2[mm][r] = a.p[pc]; mW2[mm][r] = a.m[pc]; vW2[mm][r] = a.v[pc]; }
+    // ---- minibatch prefetch (HBM/L2 -> registers) and staging (registers -> the tile's LDS rows): wave h = 0 of a tile role fetches and stages the observation rows (four
+    // lanes per sample), wave h = 1 the scalars (logprob, advantage, return, action) -- the helper part of k_train_fs, unchanged
+    constexpr int NXL = (IN + 3) / 4;
+    float px[NXL]; float p_lp = 0.f, p_adv = 0.f, p_ret = 0.f; float p_act[NACT]; int p_valid = 0; uint8_t p_abyte[OUT];
+#pragma unroll
+    for (int k = 0; k < OUT; ++k) p_abyte[k] = 0;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < NXL; ++e) px[e] = 0.f;
+    int n_row = 0, n_valid = 0;
+    auto fetch_index = [&](const int32_t* ord, int64_t st, int nb) {
+      const int sidx = 8 * NWC * p + 16 * t + c;
+      n_valid = sidx < nb ? 1 : 0;
+      n_row = n_valid ? CRUX_GLOBAL_PTR(int32_t, ord)[st + sidx] : 0;
+    };
+    auto fetch_data = [&]() {
+      const int rowlo = n_row; p_valid = n_valid; const int64_t row = rowlo;
+      if (h == 0) {
+        const int rs = __shfl(rowlo, lane >> 2, 64), vs = __shfl(p_valid, lane >> 2, 64);
+        const float* xrow = a.PACK ? CRUX_GLOBAL_PTR(float, a.PACK) + (int64_t)rs * a.pack_stride + (lane & 3) * NXL : CRUX_GLOBAL_PTR(float, a.S) + (int64_t)rs * IN + (lane & 3) * NXL;
+#pragma unroll
+        for (int e = 0; e < NXL; ++e) px[e] = ((lane & 3) * NXL + e < IN && vs) ? xrow[e] : 0.f;
+      } else {
+        p_lp = 0.f; p_adv = 0.f; p_ret = 0.f;
+#pragma unroll
+        for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
+        if (a.PACK) {
+          if (lane < 16 && p_valid) { const float* q = CRUX_GLOBAL_PTR(float, a.PACK) + row * a.pack_stride;
+            if (KIND != MFK_VALUE) { p_lp = q[a.pack_lp]; p_adv = q[a.pack_lp + 1]; }
+            p_ret = q[a.pack_lp + 2];
+            if (KIND == MFK_CATEGORICAL) { const int ai = (int)q[a.pack_act];
+#pragma unroll
+              for (int k = 0; k < OUT; ++k) p_abyte[k] = k == ai ? 1 : 0; }
+            if (KIND == MFK_GAUSSIAN) {
+#pragma unroll
+              for (int k = 0; k < OUT; ++k) p_act[k] = q[a.pack_act + k]; } }
+        } else
+        if (lane < 16 && p_valid) {
+          if (KIND != MFK_VALUE) { p_lp = CRUX_GLOBAL_PTR(float, a.LP)[row]; p_adv = CRUX_GLOBAL_PTR(float, a.ADV)[row]; }
+          p_ret = a.RET ? CRUX_GLOBAL_PTR(float, a.RET)[row] : 0.f;
+          if (KIND == MFK_CATEGORICAL) { const auto* av = CRUX_GLOBAL_PTR(uint8_t, a.A) + row * OUT;
+#pragma unroll
+            for (int k = 0; k < OUT; ++k) p_abyte[k] = av[k]; }
+          if (KIND == MFK_GAUSSIAN) { const auto* av = CRUX_GLOBAL_PTR(float, a.A) + row * OUT;
+#pragma unroll
+            for (int k = 0; k < OUT; ++k) p_act[k] = av[k]; }
+        }
+      }
+    };
+    auto stage = [&](int buf) {
+      float* xs_ = xs + buf * XSB; float* sc_ = sc + buf * SCB;
+      if (h == 0) {
+#pragma unroll
+        for (int e = 0; e < NXL; ++e) { const int f = (lane & 3) * NXL + e; if (f < IN) xs_[(lane >> 2) * XP + f] = px[e]; }
+      } else {
+        if (KIND == MFK_CATEGORICAL) { int ai = 0;
+#pragma unroll
+          for (int k = 0; k < OUT; ++k) ai = p_abyte[k] ? k : ai;
+          p_act[0] = (float)ai; }
+        if (lane < 16) { float* q = sc_ + lane * Lt::SCW; q[0] = (float)p_valid; q[1] = p_lp; q[2] = p_adv; q[3] = p_ret;
+          if (KIND == MFK_GAUSSIAN) {
+            static_assert(KIND != MFK_GAUSSIAN || ((4 + NACT) % 2 == 0), "the staging row needs its spare slot");
+            float corr = 0.f;
+            if (squash > 0.f) {
+#pragma unroll
+              for (int k = 0; k < OUT; ++k) { const float u = p_valid ? sq_untanh(p_act[k], squash) : 0.f; corr += p_valid ? sq_corr(u) : 0.f; p_act[k] = u; } }
+            q[4 + NACT] = corr; }
+#pragma unroll
+          for (int k = 0; k < NACT; ++k) q[4 + k] = p_act[k]; }
+      }
+    };
+    auto adam_w2 = [&](const f32x4 (&gT)[WT]) {      // Flux.update! on the owned tiles; the new weights go to both LDS layouts of W2
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float m_ = mW2[mm][r], v_ = vW2[mm][r]; const float d = adam1(gT[mm][r], m_, v_, ak);
+          mW2[mm][r] = m_; vW2[mm][r] = v_; tW2[mm][r] -= d;
+          sm[Lt::oW2R + (16 * mp0 + 4 * g + r) * FS_LD + 16 * (m0 + mm) + c] = tW2[mm][r]; }
+        *(f32x4*)&sm[Lt::oW2C + (16 * (m0 + mm) + c) * FS_LD + 16 * mp0 + 4 * g] = tW2[mm]; } };
+
+    for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
+      if (!epoch_prologue(ep)) break;
+      staged = false;
+      { const int nb0 = (int)(total_rows < bs ? total_rows : bs); fetch_index(order_cur, 0, nb0); fetch_data();
+        const int64_t st1 = bs; const int nb1 = st1 < total_rows ? (int)((total_rows - st1) < bs ? (total_rows - st1) : bs) : 0; fetch_index(order_cur, st1 < total_rows ? st1 : 0, nb1); }
+      for (int64_t st = 0; st < total_rows; st += bs) {
+        const int nb = (int)((total_rows - st) < bs ? (total_rows - st) : bs);
+        const float invB = 1.0f / (float)nb;
+        ak.c1 = __builtin_amdgcn_rcpf((float)(1.0 - bp1)); ak.c2 = __builtin_amdgcn_rcpf((float)(1.0 - bp2));
+        FS2_T(0);
+        if (!staged) { stage(xcur); __syncthreads(); }      // the first minibatch of an epoch
+        staged = false;
+        // rows of the NEXT minibatch (their indices came a step ago) and the indices of the one after it; the next minibatch goes into the other staging buffer, which the
+        // compute waves left at the end of the previous step
+        if (st + bs < total_rows) fetch_data();
+        { const int64_t st2 = st + 2 * (int64_t)bs; const int nb2 = st2 < total_rows ? (int)((total_rows - st2) < bs ? (total_rows - st2) : bs) : 0;
+          fetch_index(order_cur, st2 < total_rows ? st2 : 0, nb2); }
+        FS2_T(1);
+        if (st + bs < total_rows) stage(xcur ^ 1);
+        FS2_T(2);
+        __syncthreads();   // ---- B_1: T1 / T2 tiles of the workgroup are visible
+        FS2_T(3);
+        // ======================= dW2 of this wave's tiles over the workgroup's samples, sent to the exchange slot at once =======================
+        f32x4 gW2[WT];
+#pragma unroll
+        for (int mm = 0; mm < WT; ++mm) gW2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ws = 0; ws < TILES; ++ws) {
+          const float* t2 = sm + Lt::oT2 + ws * Lt::TILE2; const float* t1 = sm + Lt::oT1 + ws * Lt::TILE;
+          const f32x4 av = *(const f32x4*)&t2[t_rd + 256 * mp0];          // A[i=c -> o=16mp0+c][k -> sample 4g+r]
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) { const f32x4 bv = *(const f32x4*)&t1[t_rd + 256 * (m0 + mm)];   // B[k -> sample][j=c -> i]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gW2[mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], gW2[mm], 0, 0, 0); }
+        }
+        float* mine = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + p)) * XSLOT;
+        bool odd = false;
+#pragma unroll
+        for (int mm = 0; mm < WT; ++mm) { *(f32x4*)&mine[Lt::xW2 + ct * (4 * WT) + 4 * mm] = gW2[mm];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) odd = odd || !(fabsf(gW2[mm][r]) <= 1e30f); }
+        if (odd) mine[Lt::xSUS1] = 1.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this lane has reached the L2 (and the prefetched rows are in)
+        FS2_T(4);
+        fs2_group_barrier(sm + Lt::cHELP, (unsigned)NWC * (xstep + 1u), lane);      // all helper waves' stores are acknowledged
+        if (ct == 0) {
+          (void)__hip_atomic_fetch_add(a.xctr + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ARRIVAL 1
+          fs2_flag_set(sm + Lt::fH1, xstep + 1u);
+          const unsigned want = (unsigned)NWG * (xstep + 1u); unsigned spins = 0; bool ok = true;
+          while (__hip_atomic_load(a.xctr + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24) || __hip_atomic_load(a.xctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; } }   // never hang the GPU
+          if (!ok) { __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (fs2_flag_get(sm + Lt::fERR) == 0u) fs2_flag_set(sm + Lt::fERR, 1u); }
+          fs2_flag_set(sm + Lt::fP1, xstep + 1u);
+        }
+        fs2_flag_wait(sm + Lt::fP1, xstep + 1u);      // phase 1 is complete (or has failed): every workgroup's W2 partials are in the L2
+        FS2_T(5);
+        const bool failed = fs2_flag_get(sm + Lt::fERR) != 0u;
+        if (!failed) {
+          constexpr int NLD = NWG - 1;
+          f32x4 pw[NLD][WT];
+#pragma unroll
+          for (int j = 0; j < NLD; ++j) { const int q = j == 0 ? (p ^ 1) : ((p ^ 2) & 2) + (j - 1);      // partner, then the other pair's first and second workgroup
+            const float* peer = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + q)) * XSLOT;
+#pragma unroll
+            for (int mm = 0; mm < WT; ++mm)
+              asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(pw[j][mm]) : "v"(peer + Lt::xW2 + ct * (4 * WT) + 4 * mm) : "memory"); }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < NLD; ++j)
+#pragma unroll
+            for (int mm = 0; mm < WT; ++mm) asm volatile("" : "+v"(pw[j][mm]));      // (asm statements keep their order: every use of a loaded value follows the wait)
+          // (s0 + s1) + (s2 + s3): own + partner, the other pair in index order, then the two pair sums -- the same bits in all four workgroups (train_fs_kernel.h)
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) gW2[mm] = (gW2[mm] + pw[0][mm]) + (pw[1][mm] + pw[2][mm]);
+        }
+        FS2_T(6);
+        { float ssq = 0.f;      // this wave's share of the gradient norm, every step (whether the step reports is the compute waves' knowledge)
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ssq += gW2[mm][r] * gW2[mm][r];
+          ssq = wave_sum(ssq);
+          if (lane == 0) sm[Lt::oRED + w] = ssq; }
+        // the state before this step's update: a suspect step (decided after B_b, with the small parameters' news) is undone first
+        f32x4 tW2o[WT], mW2o[WT], vW2o[WT];
+#pragma unroll
+        for (int mm = 0; mm < WT; ++mm) { tW2o[mm] = tW2[mm]; mW2o[mm] = mW2[mm]; vW2o[mm] = vW2[mm]; }
+        fs2_flag_wait(sm + Lt::cCOMP, (unsigned)NWC * (3u * xstep + 1u));      // the compute waves have passed B_2: nobody reads the W2 masters (dH1) any more
+        if (!failed) adam_w2(gW2);
+        FS2_T(7);
+        __syncthreads();   // ---- B_b: masters updated
+        FS2_T(8);
+        { const unsigned why = fs2_flag_get(sm + Lt::fERR); if (why != 0u) { err = CRUX_EHIP; why_failed = (int)why; break; } }
+        int any_bad = 0;
+        if (fs2_flag_get(sm + Lt::fSUS) != 0u) {      // suspect step: back to the pre-step state, then the workgroup decides
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) { tW2[mm] = tW2o[mm]; mW2[mm] = mW2o[mm]; vW2[mm] = vW2o[mm]; }
+          int bad = 0;
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bad |= isnan(gW2[mm][r]) ? 1 : 0;
+          any_bad = __syncthreads_or(bad);
+          if (!any_bad) { adam_w2(gW2); __syncthreads(); }
+        }
+        const bool go = step_exit(invB, any_bad != 0);
+        if (!any_bad) { bp1 *= db1; bp2 *= db2; }
+        xcur ^= 1; xstep += 1u; staged = st + bs < total_rows;
+        FS2_T(9);
+        if (!go) break;
+      }
+      if (err) break;
+      epoch_epilogue(ep);
+    }
+    // ---- write back W2 and its Adam state --------------------------------------------------------------------
+    if (p == 0) {
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + H2 * (16 * (m0 + mm) + c);
+          a.p[pc] = tW2[mm][r]; a.m[pc] = mW2[mm][r]; a.v[pc] = vW2[mm][r]; }
+    }
+  }
+  // ---- write back the small parameters and the launch status ------------------------------------------------------
+  __syncthreads();
+  if (p == 0) { for (int s = tid; s < ns_valid; s += NT) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; } }
+  if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(NW * p + w) * 16 + k] = tacc[k]; }
+  if (tid == 0 && (p == 0 || err)) {
+    a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
+    if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 4 a workgroup missed the abort-latch consensus
+    a.bp[0] = bp1; a.bp[1] = bp2;
+    if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = inf_loss; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
+  }
+#undef FS2_T
+}
