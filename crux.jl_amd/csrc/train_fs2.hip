@@ -19,7 +19,7 @@ static int32_t launch_fs2(crux_ctx* c, TrainArgs a, bool timing, hipStream_t str
   constexpr size_t xfloats = (size_t)CRUX_XBUF_FLOATS;
   if (!c->xbuf[which]) { if (hipMalloc(&c->xbuf[which], sizeof(float) * xfloats + 256) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "learner exchange buffer"); }
   a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * xfloats);
-  HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
+  HIPCHK(c, hipMemsetAsync(c->xbuf[which], 0, sizeof(float) * xfloats + 256, stream));      // counters AND slots: the granules' step tags start from zero (a stale tag must never look like this launch's)
   a.xcd = which;      // actor / critic (the context's two learner streams) behind different L2s
   constexpr bool HAS_TIMING = H2 == 64 && ACT2 == ACT && ((IN == 4 && (OUT == 2 || OUT == 1)) || (IN == 17 && ACT == CRUX_ACT_TANH));      // the in-kernel phase timers are instantiated for the C2 / C5 learners only
   if constexpr (HAS_TIMING) if (timing) {
@@ -28,9 +28,10 @@ static int32_t launch_fs2(crux_ctx* c, TrainArgs a, bool timing, hipStream_t str
     a.dbg = dbg;
     int32_t rc = launch_fs2_form<IN, OUT, KIND, ACT, H2, ACT2, true>(c, a, stream); if (rc) return rc;
     unsigned long long h[512]; HIPCHK(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, stream)); HIPCHK(c, hipStreamSynchronize(stream));
-    static const char* nc[16] = {"loop", "wait staged", "fwdL1+T1", "fwdL2", "L3+pair barrier+head", "dW3+dZ2+stats+T2", "wait B_1", "dH1", "dZ1+db+dW1", "B_2+reduce+store+drain", "arrival 2+wait",
-                                 "load small+total", "adam small", "wait B_b", "report+exit", "-"};
-    static const char* nh[16] = {"loop", "fetch", "stage next", "wait B_1", "dW2+send+drain", "arrival 1+wait", "load W2 slots+total", "ssq+backup+adam W2", "wait B_b", "exit", "-", "-", "-", "-", "-", "-"};
+    static const char* nc[16] = {"loop", "wait staged", "fwdL1+T1", "fwdL2", "L3+pair barrier+head", "dW3+dZ2+stats+T2", "wait B_1", "dW2+send+dH1", "dZ1+db+dW1", "B_2+reduce+granules", "wait P1",
+                                 "W2 loads+granule poll", "drain loads", "totals+adam W2+ssq", "adam small", "B_b+report+exit"};
+    static const char* nh[16] = {"loop", "fetch", "stage next", "wait B_1", "dW2+send+drain", "arrival 1+wait(leader)", "-", "-", "-", "wait B_2+reduce+granules", "wait P1",
+                                 "W2 loads+granule poll", "drain loads", "totals+adam W2+ssq", "adam small", "B_b+exit"};
     for (int wg = 0; wg < 4; ++wg) for (int w : {0, 4}) { const char** nm = w == 0 ? nc : nh;
       fprintf(stderr, "[fs2-timing] %d-%d wg %d %s wave %d:", IN, OUT, wg, w == 0 ? "compute" : "helper", w); unsigned long long tot = 0; for (int k = 0; k < 16; ++k) tot += h[(8 * wg + w) * 16 + k];
       for (int k = 0; k < 16; ++k) if (nm[k][0] != '-') fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[(8 * wg + w) * 16 + k] / (double)tot);

@@ -1,27 +1,31 @@
 // train_fs2_kernel.h -- the persistent batch_train! kernel of the register-resident IN->64->{64,32}->OUT family, ROLE-SPECIALISED form (round 5; src/training.jl:13-55,
 // ppo.jl:4-21,59-60, Flux Adam). Same decomposition of a minibatch step over four compute units of one XCD as train_fs_kernel.h (feature-split wave pairs per 16-sample
-// tile, four helper waves per workgroup) and the same arithmetic in the same order -- parameters, Adam moments and statistics come out bit-identical to k_train_fs --, but
-// the two kinds of waves no longer walk through one instruction stream:
+// tile, four helper waves per workgroup, every wave owning two 16x16 tiles of W2) and the same arithmetic in the same order -- parameters, Adam moments and statistics come out
+// bit-identical to k_train_fs --, but with two changes to how a step ends (40 % of a k_train_fs step is its tail, a chain of L2 round trips):
 //
 //   COMPUTE waves (0..3)                                        HELPER waves (4..7)
 //   forward L1, L2, partial logits                              prefetch minibatch k+2's row indices, k+1's rows; stage minibatch k+1
 //   -- pair barrier (LDS) --
 //   loss head, dW3 / db3 partials, dZ2 -> T2 tiles
 //   ============================== B_1 (s_barrier): H1 / dZ2 tiles of the workgroup are visible ==============================
-//   dH1, dZ1, db1, db2, dW1 partials                            dW2 of ALL sixteen W2 tiles (four per wave), partials -> exchange slot
-//   -- compute barrier (LDS) --                                 drain stores, helper barrier (LDS), ARRIVAL 1, wait for the four workgroups
-//   small partials -> exchange slot, drain, compute barrier     load the three peers' W2 partials, total, Adam on W2 (theta, m, v in registers),
-//   ARRIVAL 2, wait, load the peers' small partials, total,     new W2 -> the LDS masters
-//   Adam on the small parameters (LDS masters)
+//   dW2 of the own two tiles -> exchange slot                   dW2 of the own two tiles -> exchange slot, drain the stores
+//   dH1; the stores are acknowledged by now: tell the leader    leader: all eight waves' stores acknowledged -> ARRIVAL 1 -> wait for the four workgroups -> P1
+//   dZ1, db1, db2, dW1 partials                                 P1: load the three peers' partials of the own tiles, total, Adam (theta, m, v in registers)
+//   -- compute barrier (LDS) --
+//   small partials -> 8-byte {value, step} GRANULES in the slot
+//   P1: load the peers' partials of the own W2 tiles; poll the peers' granules (the tag is the flag: ONE round trip)
+//   W2 total + Adam, small total + Adam
 //   ============================== B_b (s_barrier): masters updated ==========================================================
 //
-// What this buys over k_train_fs: (1) the exchange of the W2 gradient -- 89 % of the bytes, and with them the slot loads, the total and the Adam update of W2 --
-// runs in the helper waves WHILE the compute waves are still in the backward pass (dH1 / dZ1 / dW1) and in their own, small exchange: two chains of L2 round trips side by
-// side instead of one after the other; (2) each role is its own code path, so the register allocation is the maximum of the two roles, not their union: the compute waves
-// no longer carry W2's theta / m / v / gradient / peer tiles, the helpers no activations -- no instantiation spills (the 17-64-64-6 forms of k_train_fs spill 25..140);
-// (3) the per-step barriers of the whole workgroup go from five to two; pairs and roles meet through LDS counters.
-// NaN semantics (training.jl:20): a total can only be NaN when a partial is NaN or huge; such a SUSPECT step is decided by the whole workgroup after B_b -- the helpers, who
-// have applied Adam to W2 by then, put their pre-step state back first -- so a NaN step leaves every parameter as it was, exactly as in k_train_fs.
+//   (1) the W2 partials (89 % of the bytes) leave right after dW2 as before, but their hand-shake (drain, arrival counter, wait) is now run by the helper leader WHILE the
+//       compute waves are in dH1 / dZ1 / dW1: when the small partials are ready, the peers' W2 partials are known to be in the L2 already;
+//   (2) the small partials, the last bytes of the step, travel as data-tagged granules -- store, then poll the peers' granules until the tag is the step's: one L2 round trip
+//       where the flag protocol needs three (drain, arrival + wait, load);
+//   (3) each role is its own code path: the register allocation is the maximum of the two roles, not their union -- no instantiation spills;
+//   (4) two workgroup barriers per step instead of five; pairs and roles meet through LDS counters.
+// NaN semantics (training.jl:20: a NaN gradient norm is an error BEFORE the update): every thread forms the totals of its own elements in every workgroup; one that finds a
+// NaN total marks the step SUSPECT in LDS; after B_b the whole workgroup puts the pre-step state back (W2 from registers, the small parameters from the values read for Adam)
+// and leaves with CRUX_ENAN -- a NaN step leaves every parameter as it was, exactly as in k_train_fs. The same totals, hence the same decision, in all four workgroups.
 // Covers the plain policy-gradient / critic losses of full minibatch loops (65..128 rows); replica groups (PX), lagrange_ppo_loss and the other forms stay on k_train_fs.
 #pragma once
 #include "train_fs_kernel.h"
@@ -30,15 +34,16 @@ template <int IN, int OUT, int H2>
 struct Fs2Layout : FsLayout<IN, OUT, 4, true, H2, false> {
   using B = FsLayout<IN, OUT, 4, true, H2, false>;
   static constexpr int NTC = 256;                                   // compute threads = helper threads
-  static constexpr int NSC = (B::NS + NTC - 1) / NTC;               // small parameters per compute thread
-  static constexpr int WTH = B::NT2;                                // W2 tiles per helper wave (NT2 x 4 tiles over four waves)
-  static constexpr int xW2 = 0, xSM = B::W2N, xST = xSM + NSC * NTC, xSUS1 = xST + 8, xSUS2 = xST + 9;      // exchange slot: W2 partials | small partials | 8 stat sums | suspect words
-  static constexpr int XSLOT2 = ((xST + 16 + 3) / 4) * 4;
-  static_assert(XSLOT2 <= 8192, "exchange slot");
+  static constexpr int NSC = (B::NS + 511) / 512;                   // small parameters per thread (all 512 threads share them, as in k_train_fs)
+  static constexpr int WT2 = (B::NT2 * 4) / 8;                      // W2 tiles per wave (all eight waves own tiles)
+  static constexpr int NGR = NSC * 512 + 8;                         // granules of a slot: the small partials, then the 7 statistics sums
+  static constexpr int xW2 = 0, xGR = B::W2N;                       // exchange slot: W2 partials [thread][WT2][4] | granules {value, step} of the small partials and statistics
+  static constexpr int XSLOT2 = ((xGR + 2 * NGR + 3) / 4) * 4;
+  static_assert(2 * 4 * XSLOT2 <= CRUX_XBUF_FLOATS, "exchange area");
   // LDS words behind the reduction area (oRED .. oRED + 32): group-barrier counters and step flags
-  // cPAIR + t: the two waves of tile t, once per step; cCOMP: the four compute waves, three times per step; cHELP: the four helper waves, once per step;
-  // fH1 / fP1: steps whose ARRIVAL 1 has been issued / whose phase 1 is complete (helper leader -> everyone); fSUS: this step is suspect; fERR: why the exchange failed (sticky)
-  static constexpr int cPAIR = B::oRED + 24, cCOMP = B::oRED + 26, cHELP = B::oRED + 27, fH1 = B::oRED + 28, fP1 = B::oRED + 29, fSUS = B::oRED + 30, fERR = B::oRED + 31;
+  // cACK: waves whose W2 stores are acknowledged (eight per step); cPAIR + t: the two waves of tile t, once per step; cCOMP: the four compute waves, once per step;
+  // fP1: steps whose phase 1 is complete (helper leader -> everyone); fSUS: the last suspect step; fERR: why the exchange failed (sticky)
+  static constexpr int cACK = B::oRED + 18, cPAIR = B::oRED + 24, cCOMP = B::oRED + 26, fP1 = B::oRED + 29, fSUS = B::oRED + 30, fERR = B::oRED + 31;
 };
 
 // meeting point of a subset of the workgroup's waves: one LDS counter, monotonic over the launch (target = members x number of uses so far). A wave's LDS operations execute in
@@ -61,7 +66,7 @@ template <int IN, int OUT, int KIND, int ACT, int H2 = 64, int ACT2 = ACT, bool 
 __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   using Lt = Fs2Layout<IN, OUT, H2>;
   constexpr int NWG = 4, NWC = 4, TILES = 2, NT = 512, NTC = 256, MH = Lt::MH, HH = Lt::HH, W2N = Lt::W2N, NW = 8;
-  constexpr int WT = Lt::WTH;                       // W2 tiles of a helper wave
+  constexpr int WT = Lt::WT2;                       // 16x16 tiles of W2 owned by a wave (all eight waves own tiles)
   constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS, NSC = Lt::NSC, XSLOT = Lt::XSLOT2;
   constexpr int NACT = (OUT > 4 ? OUT : 4);
   if ((int)(blockIdx.x & 7) != a.xcd) return;        // the four workgroups of the learner: blocks x, x + 8, x + 16, x + 24 -> one XCD
@@ -85,8 +90,8 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
 #define FS2_T(ph) do { if (TIMING) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
   const int t_wr = (4 * g) * 16 + 4 * ((c >> 2) ^ fs_tx(g)) + (c & 3);
   const int t_rd = c * 16 + 4 * (g ^ fs_tx(c >> 2));
-  const int hw = w - NWC;                            // helper wave 0..3 (negative for compute waves: never used there)
-  const int mp0 = ((hw < 0 ? 0 : hw) * WT) >> 2, m0 = ((hw < 0 ? 0 : hw) * WT) & 3;      // W2 tiles (mp0, m0 .. m0 + WT - 1) of a helper wave
+  // dW2 / W2 ownership: tile (mp, m) = rows [16mp, 16mp+16) x columns [16m, 16m+16), numbered 4 mp + m; wave w owns the WT tiles from number w WT on (same mp)
+  const int mp0 = (w * WT) >> 2, m0 = (w * WT) & 3;
 
   auto s_master = [&](int s) -> int {
     if (s < Lt::sB1) { const int o = s & 63, i = s >> 6; return Lt::oW1R + o * Lt::W1LD + i; }
@@ -157,8 +162,6 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   }
   __syncthreads();
   const int64_t total_rows = a.len;
-  if (tid == 0) { a.xbuf[(size_t)(0 * NWG + p) * XSLOT + Lt::xSUS1] = 0.f; a.xbuf[(size_t)(0 * NWG + p) * XSLOT + Lt::xSUS2] = 0.f;      // this workgroup's SUSPECT words, both parities
-    a.xbuf[(size_t)(1 * NWG + p) * XSLOT + Lt::xSUS1] = 0.f; a.xbuf[(size_t)(1 * NWG + p) * XSLOT + Lt::xSUS2] = 0.f; }
 
   // what the minibatch loops of both roles share. Only the epoch's last minibatch, or the one that ends the loop, is ever reported (training.jl:22-23, 45-53).
   auto static_report = [&](int64_t st) -> bool { return st + bs >= total_rows || (max_batches > 0 && total_batches + 1 >= max_batches); };
@@ -208,14 +211,181 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     if (max_batches > 0 && total_batches >= max_batches) stop = true;               // :50
   };
 
+  // ---- the W2 path of a step, the same in both roles: every wave owns WT tiles (theta, m, v in registers; D layout: reg r of tile mm <-> W2[o = 16 mp0 + 4g + r][i = 16 (m0+mm) + c])
+  f32x4 tW2[WT], mW2[WT], vW2[WT];
+#pragma unroll
+  for (int mm = 0; mm < WT; ++mm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + H2 * (16 * (m0 + mm) + c);
+      tW2[mm][r] = a.p[pc]; mW2[mm][r] = a.m[pc]; vW2[mm][r] = a.v[pc]; }
+  // dW2 of the own tiles over the workgroup's samples, sent to the exchange slot at once (the acknowledgement hides under what follows)
+  auto dw2_send = [&](f32x4 (&gW2)[WT]) {
+#pragma unroll
+    for (int mm = 0; mm < WT; ++mm) gW2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ws = 0; ws < TILES; ++ws) {
+      const float* t2 = sm + Lt::oT2 + ws * Lt::TILE2; const float* t1 = sm + Lt::oT1 + ws * Lt::TILE;
+      const f32x4 av = *(const f32x4*)&t2[t_rd + 256 * mp0];          // A[i=c -> o=16mp0+c][k -> sample 4g+r]
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm) { const f32x4 bv = *(const f32x4*)&t1[t_rd + 256 * (m0 + mm)];   // B[k -> sample][j=c -> i]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gW2[mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], gW2[mm], 0, 0, 0); }
+    }
+    float* mine = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + p)) * XSLOT;
+#pragma unroll
+    for (int mm = 0; mm < WT; ++mm) *(f32x4*)&mine[Lt::xW2 + tid * (4 * WT) + 4 * mm] = gW2[mm];
+  };
+  // the three peers' partials of the own tiles: issue the loads (phase 1 is complete: they are in the L2) ...
+  auto w2_loads = [&](f32x4 (&pw)[NWG - 1][WT]) {
+#pragma unroll
+    for (int j = 0; j < NWG - 1; ++j) { const int q = j == 0 ? (p ^ 1) : ((p ^ 2) & 2) + (j - 1);      // partner, then the other pair's first and second workgroup
+      const float* peer = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + q)) * XSLOT;
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm)
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(pw[j][mm]) : "v"(peer + Lt::xW2 + tid * (4 * WT) + 4 * mm) : "memory"); }
+  };
+  // ... and, once they are in (the caller has waited), the total (s0 + s1) + (s2 + s3) -- own + partner, the other pair in index order, then the two pair sums: the same bits
+  // in all four workgroups (train_fs_kernel.h) --, the suspect test over the four contributions and this wave's share of the gradient norm
+  auto w2_total = [&](f32x4 (&gW2)[WT], f32x4 (&pw)[NWG - 1][WT], bool want_ssq, float& ssq, bool& bad) {
+#pragma unroll
+    for (int j = 0; j < NWG - 1; ++j)
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm) asm volatile("" : "+v"(pw[j][mm]));      // (asm statements keep their order: every use of a loaded value follows the wait)
+#pragma unroll
+    for (int mm = 0; mm < WT; ++mm) {
+      gW2[mm] = (gW2[mm] + pw[0][mm]) + (pw[1][mm] + pw[2][mm]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bad = bad || isnan(gW2[mm][r]);
+      if (want_ssq) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ssq += gW2[mm][r] * gW2[mm][r]; } }
+  };
+  auto adam_w2 = [&](const f32x4 (&gT)[WT]) {      // Flux.update! on the owned tiles; the new weights go to both LDS layouts of W2
+#pragma unroll
+    for (int mm = 0; mm < WT; ++mm) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { float m_ = mW2[mm][r], v_ = vW2[mm][r]; const float d = adam1(gT[mm][r], m_, v_, ak);
+        mW2[mm][r] = m_; vW2[mm][r] = v_; tW2[mm][r] -= d;
+        sm[Lt::oW2R + (16 * mp0 + 4 * g + r) * FS_LD + 16 * (m0 + mm) + c] = tW2[mm][r]; }
+      *(f32x4*)&sm[Lt::oW2C + (16 * (m0 + mm) + c) * FS_LD + 16 * mp0 + 4 * g] = tW2[mm]; } };
+  // the small parameters (everything but W2), shared by all 512 threads
+  int so_part[NSC], so_master[NSC]; bool so_ok[NSC], so_ex[NSC];
+#pragma unroll
+  for (int k = 0; k < NSC; ++k) { const int s = tid + NT * k; so_ok[k] = s < ns_valid; so_ex[k] = s >= Lt::sEX;
+    so_part[k] = so_ok[k] ? s_part(s) : 0; so_master[k] = so_ok[k] ? s_master(s) : 0; }
+  const bool stat_lane = tid >= NT - 8 && tid < NT - 1;      // stat sums, by 7 lanes of the last wave
+  // ---- the end of a step in every wave, once the workgroup's small partials are in LDS (B_2): the small partials leave as granules; the peers' W2 partials (phase 1 complete)
+  // and granules come in; totals, Adam, B_b; suspect steps. false = the launch ends here (err is set).
+  long long st_now = 0;      // the minibatch loops set it: first row of the current minibatch
+  auto step_tail = [&](const unsigned tag, f32x4 (&gW2)[WT], int& any_bad) -> bool {
+    float gs[NSC];
+#pragma unroll
+    for (int k = 0; k < NSC; ++k) { float gsum = 0.f;
+      if (so_ok[k]) { const int po = Lt::oPART + so_part[k];
+        gsum = sm[po];
+#pragma unroll
+        for (int q = 1; q < TILES; ++q) gsum += sm[po + q * Lt::PART]; }
+      gs[k] = gsum; }
+    float stat_loc = 0.f;
+    if (stat_lane) { const int ko = Lt::pST + (tid - (NT - 8)); stat_loc = sm[Lt::oPART + ko];
+#pragma unroll
+      for (int q = 1; q < TILES; ++q) stat_loc += sm[Lt::oPART + q * Lt::PART + ko]; }
+    // the small partials travel as granules: {value, step} in ONE naturally aligned 8-byte store -- the tag is the flag
+    float* mine = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + p)) * XSLOT;
+    // (a PLAIN store: it writes through the L1 and KEEPS the line in this XCD's L2, where the peers' sc1 loads find it; sc1 / volatile stores would drop it to the fabric)
+    auto gran_put = [&](int gi, float v) { typedef unsigned u32x2 __attribute__((ext_vector_type(2))); u32x2 gq; gq.x = __builtin_bit_cast(unsigned, v); gq.y = tag;
+      *(u32x2*)(mine + Lt::xGR + 2 * gi) = gq; };
+#pragma unroll
+    for (int k = 0; k < NSC; ++k) gran_put(tid + NT * k, gs[k]);
+    if (stat_lane) gran_put(NSC * NT + (tid - (NT - 8)), stat_loc);
+    FS2_T(9);
+    fs2_flag_wait(sm + Lt::fP1, tag);           // phase 1 is complete (or has failed): every workgroup's W2 partials are in the L2
+    FS2_T(10);
+    bool failed = fs2_flag_get(sm + Lt::fERR) != 0u;
+    f32x4 pw[NWG - 1][WT];
+    if (!failed) w2_loads(pw);
+    // poll the peers' granules: the same loads again until every tag is this step's
+    constexpr int NLD = NWG - 1;
+    float pg[NLD][NSC]; float ps[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) { ps[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NSC; ++k) pg[j][k] = 0.f; }
+    if (!failed) {
+      unsigned spins = 0;
+      for (;;) {
+        unsigned long long gv[NLD][NSC], gst[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) { const int q = j == 0 ? (p ^ 1) : ((p ^ 2) & 2) + (j - 1);
+          const float* peer = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + q)) * XSLOT + Lt::xGR;
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) gv[j][k] = __hip_atomic_load((const unsigned long long*)(peer + 2 * (tid + NT * k)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gst[j] = ((unsigned long long)tag << 32);
+          if (stat_lane) gst[j] = __hip_atomic_load((const unsigned long long*)(peer + 2 * (NSC * NT + (tid - (NT - 8)))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        bool all_in = true;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) { all_in = all_in && (unsigned)(gst[j] >> 32) == tag; ps[j] = __builtin_bit_cast(float, (unsigned)gst[j]);
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) { all_in = all_in && (unsigned)(gv[j][k] >> 32) == tag; pg[j][k] = __builtin_bit_cast(float, (unsigned)gv[j][k]); } }
+        if (__all(all_in ? 1 : 0)) break;
+        if ((++spins & 255u) == 0u && (spins > (1u << 22) || __hip_atomic_load(a.xctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {      // never hang the GPU
+          __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (fs2_flag_get(sm + Lt::fERR) == 0u) fs2_flag_set(sm + Lt::fERR, 1u); failed = true; break; }
+      }
+    }
+    FS2_T(11);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FS2_T(12);
+    float ssq = 0.f; bool bad_tot = false;
+    const bool want_ssq = static_report((int64_t)st_now) || (KIND != MFK_VALUE && target_kl >= 0.f);      // only a step that may report needs the gradient norm
+    f32x4 tW2o[WT], mW2o[WT], vW2o[WT];      // the state before this step's update: a suspect step (known after B_b) is undone first
+#pragma unroll
+    for (int mm = 0; mm < WT; ++mm) { tW2o[mm] = tW2[mm]; mW2o[mm] = mW2[mm]; vW2o[mm] = vW2[mm]; }
+    float th_o[NSC], m_o[NSC], v_o[NSC];
+    float stat_tot = stat_loc;
+    if (!failed) {
+      w2_total(gW2, pw, want_ssq, ssq, bad_tot);
+      adam_w2(gW2);                            // (every compute wave is past B_2: nobody reads the W2 masters any more)
+#pragma unroll
+      for (int k = 0; k < NSC; ++k) { gs[k] = (gs[k] + pg[0][k]) + (pg[1][k] + pg[2][k]); bad_tot = bad_tot || (so_ok[k] && isnan(gs[k])); }
+      if (bad_tot) fs2_flag_set(sm + Lt::fSUS, tag);
+      stat_tot = (stat_loc + ps[0]) + (ps[1] + ps[2]);
+    }
+    if (stat_lane) sm[Lt::oRED + 8 + (tid - (NT - 8))] = stat_tot;
+#pragma unroll
+    for (int k = 0; k < NSC; ++k) if (so_ok[k]) {
+      if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += -lambda_e;       // d(-lambda_e H)/dlogSigma, H = const + sum(logSigma)
+      if (want_ssq) ssq += gs[k] * gs[k]; }
+    if (want_ssq) { ssq = wave_sum(ssq);
+      if (lane == 0) sm[Lt::oRED + w] = ssq; }      // this wave's share of the gradient norm (the report is formed after B_b)
+    FS2_T(13);
+    // Adam on the small parameters (Flux.update!, training.jl:21); the values read here are what a suspect step is put back to
+    auto adam_small = [&]() {
+#pragma unroll
+      for (int k = 0; k < NSC; ++k) { const int s = tid + NT * k;
+        if (so_ok[k]) { float m_ = sm[Lt::oMS + s], v_ = sm[Lt::oVS + s]; const int mo = so_master[k]; const float th = sm[mo];
+          m_o[k] = m_; v_o[k] = v_; th_o[k] = th;
+          const float d = adam1(gs[k], m_, v_, ak);
+          sm[Lt::oMS + s] = m_; sm[Lt::oVS + s] = v_; sm[mo] = th - d; } } };
+    if (!failed) adam_small();
+    FS2_T(14);
+    __syncthreads();   // ---- B_b: masters updated; tiles and partials may be overwritten
+    { const unsigned why = fs2_flag_get(sm + Lt::fERR); if (why != 0u) { err = CRUX_EHIP; why_failed = (int)why; return false; } }
+    any_bad = 0;
+    if (fs2_flag_get(sm + Lt::fSUS) == tag) {      // a thread of this workgroup found a NaN total: every thread back to its pre-step state (training.jl:20: error, no update)
+#pragma unroll
+      for (int k = 0; k < NSC; ++k) { const int s = tid + NT * k;
+        if (so_ok[k]) { sm[Lt::oMS + s] = m_o[k]; sm[Lt::oVS + s] = v_o[k]; sm[so_master[k]] = th_o[k]; } }
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm) { tW2[mm] = tW2o[mm]; mW2[mm] = mW2o[mm]; vW2[mm] = vW2o[mm]; }
+      any_bad = 1;
+    }
+    return true;
+  };
+
   if (cw) {
     // =====================================================================================================================================================
     // COMPUTE WAVES
     // =====================================================================================================================================================
-    int so_part[NSC], so_master[NSC]; bool so_ok[NSC], so_ex[NSC];
-#pragma unroll
-    for (int k = 0; k < NSC; ++k) { const int s = ct + NTC * k; so_ok[k] = s < ns_valid; so_ex[k] = s >= Lt::sEX;
-      so_part[k] = so_ok[k] ? s_part(s) : 0; so_master[k] = so_ok[k] ? s_master(s) : 0; }
     for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
       if (!epoch_prologue(ep)) break;
       staged = false;
@@ -285,6 +455,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         fs2_group_barrier(sm + Lt::cPAIR + t, 2u * (xstep + 1u), lane);      // ---- B_z: the pair's partial logits are visible (the two waves of the tile only)
         float dz[OUT], dex[OUT];
         float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f;
+        float ent_pre = 1.4189385332046727f;
         {
           float z[OUT];
           { const float* zo = sm + Lt::oZP + ((t * 2 + (1 - h)) * 64 + lane) * Lt::ZW;
@@ -339,6 +510,9 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
             }
           }
           FS2_T(4);
+          if (KIND == MFK_GAUSSIAN) {      // the entropy of the report, 1.4189385 + sum(logSigma), as the loss saw it (this step's Adam on logSigma comes after B_1)
+#pragma unroll
+            for (int k = 0; k < OUT; ++k) ent_pre += sm[Lt::oEX + k]; }
           // ======================= backward, own samples, own feature half =======================
           constexpr int FPL = 4 * MH, PER = 16 / FPL;
 #pragma unroll
@@ -388,8 +562,10 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
             for (int mm = 0; mm < MH; ++mm) *(f32x4*)&dq[256 * mm] = h2[mm]; }
         }
         FS2_T(5);
-        __syncthreads();   // ---- B_1: T1 / T2 tiles of the workgroup and the dZ2 halves are visible (the helpers start dW2)
+        __syncthreads();   // ---- B_1: T1 / T2 tiles of the workgroup and the dZ2 halves are visible
         FS2_T(6);
+        f32x4 gW2[WT];
+        dw2_send(gW2);
         // dH1 (R) for the h1 features [32h, 32h + 32)
         f32x4 dz1r[2];
         { const float* dq = sm + Lt::oD2X + ((t * 2 + (1 - h)) * MH) * 256 + lane * 4;
@@ -405,6 +581,8 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
             for (int r = 0; r < 4; ++r) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][r], wv0[r], acc0, 0, 0, 0);
               acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][r], wv1[r], acc1, 0, 0, 0); } }
           dz1r[0] = acc0; dz1r[1] = acc1; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dW2 stores left before dH1: acknowledged by now -- tell the helper leader (phase 1)
+        if (lane == 0) (void)__hip_atomic_fetch_add((unsigned*)(sm + Lt::cACK), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         FS2_T(7);
         float gb1[2], gb2[MH];
 #pragma unroll
@@ -436,106 +614,13 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
             if (16 * jt + c < Lt::W1ROWS) *(f32x4*)&part[Lt::pW1 + (16 * jt + c) * FS_LD + 32 * h + 16 * mm + 4 * g] = acc; }
         }
         FS2_T(8);
-        fs2_group_barrier(sm + Lt::cCOMP, (unsigned)NWC * (3u * xstep + 1u), lane);   // ---- B_2: the small partial gradients of both tiles are visible (compute waves only)
-        float gs[NSC];
-#pragma unroll
-        for (int k = 0; k < NSC; ++k) { float gsum = 0.f;
-          if (so_ok[k]) { const int po = Lt::oPART + so_part[k];
-            gsum = sm[po];
-#pragma unroll
-            for (int q = 1; q < TILES; ++q) gsum += sm[po + q * Lt::PART]; }
-          gs[k] = gsum; }
-        float stat_loc = 0.f;
-        const bool stat_lane = ct >= NTC - 8 && ct < NTC - 1;      // stat sums, by 7 lanes of the last compute wave
-        if (stat_lane) { const int ko = Lt::pST + (ct - (NTC - 8)); stat_loc = sm[Lt::oPART + ko];
-#pragma unroll
-          for (int q = 1; q < TILES; ++q) stat_loc += sm[Lt::oPART + q * Lt::PART + ko]; }
-        float* mine = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + p)) * XSLOT;
-        bool odd = false;
-#pragma unroll
-        for (int k = 0; k < NSC; ++k) { mine[Lt::xSM + ct + NTC * k] = gs[k]; odd = odd || !(fabsf(gs[k]) <= 1e30f); }
-        if (stat_lane) mine[Lt::xST + (ct - (NTC - 8))] = stat_loc;
-        if (odd) mine[Lt::xSUS2] = 1.f;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this lane has reached the L2
-        FS2_T(9);
-        fs2_group_barrier(sm + Lt::cCOMP, (unsigned)NWC * (3u * xstep + 2u), lane);   // all compute waves' stores are acknowledged
-        if (tid == 0) {
-          fs2_flag_wait(sm + Lt::fH1, xstep + 1u);          // ARRIVAL 2 follows this workgroup's ARRIVAL 1: a full second counter says the W2 partials (and their suspect words) are out too
-          (void)__hip_atomic_fetch_add(a.xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned want = (unsigned)NWG * (xstep + 1u); unsigned spins = 0; bool ok = true;
-          while (__hip_atomic_load(a.xctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24) || __hip_atomic_load(a.xctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; } }   // never hang the GPU
-          unsigned why = ok ? 0u : 1u;
-          if (ok && xstep == 0u) {   // the unfenced exchange is only coherent inside one XCD's L2
-            for (int q = 0; q < NWG; ++q) { const unsigned peer_xcc = __hip_atomic_load(a.xctr + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (peer_xcc != my_xcc + 1u) { ok = false; why = 2u; } } }
-          if (!ok) { __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fs2_flag_set(sm + Lt::fERR, why); }
-        }
-        fs2_group_barrier(sm + Lt::cCOMP, (unsigned)NWC * (3u * xstep + 3u), lane);   // the end of the wait (or its failure) reaches the other compute waves
-        FS2_T(10);
-        const bool failed = fs2_flag_get(sm + Lt::fERR) != 0u;
-        float stat_tot = stat_loc; bool suspect = true; float kl_tot = 0.f;
-        if (!failed) {
-          constexpr int NLD = NWG - 1;
-          float pg[NLD][NSC]; float ps[NLD]; float psus[2 * NLD + 2], pkl[NLD + 1];
-          psus[2 * NLD] = __hip_atomic_load(mine + Lt::xSUS1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); psus[2 * NLD + 1] = __hip_atomic_load(mine + Lt::xSUS2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          pkl[NLD] = __hip_atomic_load(mine + Lt::xST + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-          for (int j = 0; j < NLD; ++j) { const int q = j == 0 ? (p ^ 1) : ((p ^ 2) & 2) + (j - 1);      // partner, then the other pair's first and second workgroup
-            const float* peer = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + q)) * XSLOT;
-            psus[2 * j] = __hip_atomic_load(peer + Lt::xSUS1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); psus[2 * j + 1] = __hip_atomic_load(peer + Lt::xSUS2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pkl[j] = __hip_atomic_load(peer + Lt::xST + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int k = 0; k < NSC; ++k) pg[j][k] = __hip_atomic_load(peer + Lt::xSM + ct + NTC * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ps[j] = 0.f;
-            if (stat_lane) ps[j] = __hip_atomic_load(peer + Lt::xST + (ct - (NTC - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#pragma unroll
-          for (int k = 0; k < NSC; ++k) gs[k] = (gs[k] + pg[0][k]) + (pg[1][k] + pg[2][k]);
-          stat_tot = (stat_loc + ps[0]) + (ps[1] + ps[2]);
-          suspect = false;
-#pragma unroll
-          for (int j = 0; j < 2 * NLD + 2; ++j) suspect = suspect || psus[j] != 0.f;
-          kl_tot = (pkl[3] + pkl[0]) + (pkl[1] + pkl[2]);
-        }
-        if (stat_lane) sm[Lt::oRED + 8 + (ct - (NTC - 8))] = stat_tot;
-#pragma unroll
-        for (int k = 0; k < NSC; ++k) if (so_ok[k]) {
-          if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += -lambda_e; }      // d(-lambda_e H)/dlogSigma, H = const + sum(logSigma)
-        const float kl_now = kl_tot * invB;
-        const bool maybe_report = suspect || static_report(st) || (KIND != MFK_VALUE && target_kl >= 0.f && kl_now > target_kl);
-        float ssq = 0.f;
-        if (maybe_report) {      // the norm of a reported step (the helpers add their W2 share every step); the report itself is formed after B_b
-#pragma unroll
-          for (int k = 0; k < NSC; ++k) if (so_ok[k]) ssq += gs[k] * gs[k];
-          ssq = wave_sum(ssq);
-          if (lane == 0) sm[Lt::oRED + w] = ssq; }
-        float ent_pre = 1.4189385332046727f;               // entropy of a Gaussian policy as the loss saw it: the report follows the update of logSigma below
-        if (KIND == MFK_GAUSSIAN && maybe_report) {
-#pragma unroll
-          for (int k = 0; k < OUT; ++k) ent_pre += sm[Lt::oEX + k]; }
-        FS2_T(11);
-        // ======================= Adam on the small parameters (Flux.update!, training.jl:21) -- not on a suspect step: that one is decided after B_b =======================
-        auto adam_small = [&]() {
-#pragma unroll
-          for (int k = 0; k < NSC; ++k) { const int s = ct + NTC * k;
-            if (so_ok[k]) { float m_ = sm[Lt::oMS + s], v_ = sm[Lt::oVS + s]; const float d = adam1(gs[k], m_, v_, ak);
-              sm[Lt::oMS + s] = m_; sm[Lt::oVS + s] = v_; const int mo = so_master[k]; sm[mo] = sm[mo] - d; } } };
-        if (!suspect && !failed) adam_small();
-        if (tid == 0) fs2_flag_set(sm + Lt::fSUS, suspect ? 1u : 0u);
-        FS2_T(12);
-        __syncthreads();   // ---- B_b: masters updated (W2 by the helpers); tiles and partials may be overwritten
-        FS2_T(13);
-        { const unsigned why = fs2_flag_get(sm + Lt::fERR); if (why != 0u) { err = CRUX_EHIP; why_failed = (int)why; break; } }
-        int any_bad = 0;
-        if (suspect) {      // the whole workgroup decides (the helpers have put their pre-step W2 state back): NaN -> no update, error (training.jl:20); otherwise the update now
-          int bad = 0;
-#pragma unroll
-          for (int k = 0; k < NSC; ++k) if (so_ok[k]) bad |= isnan(gs[k]) ? 1 : 0;
-          any_bad = __syncthreads_or(bad);
-          if (!any_bad) { adam_small(); __syncthreads(); }
-        }
-        // minibatch info (training.jl:22-23, ppo.jl:13-19): identical in every compute thread
-        { const float* tq = sm + Lt::oRED + 8;
+        fs2_group_barrier(sm + Lt::cCOMP, (unsigned)NWC * (xstep + 1u), lane);   // ---- B_2: the small partial gradients of both tiles are visible (compute waves only)
+        const unsigned tag = xstep + 1u;
+        int any_bad = 0; st_now = st;
+        if (!step_tail(tag, gW2, any_bad)) break;
+        // minibatch info (training.jl:22-23, ppo.jl:13-19): identical in every compute thread; only the epoch's last minibatch (or the one that stops the loop) is ever reported
+        if (any_bad || static_report(st) || (KIND != MFK_VALUE && target_kl >= 0.f)) {
+          const float* tq = sm + Lt::oRED + 8;
           const bool report = any_bad || static_report(st) || (KIND != MFK_VALUE && target_kl >= 0.f && tq[2] * invB > target_kl);
           if (report) {
             float ss = sm[Lt::oRED];
@@ -544,11 +629,11 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
             inf_gn = sqrtf(ss);
             if (KIND == MFK_VALUE) { inf_loss = tq[6] * invB; inf_ret = tq[4] * invB; }
             else { const float p_loss = -(tq[0] * invB); const float entropy = KIND == MFK_CATEGORICAL ? tq[1] * invB : ent_pre;
-              inf_ent = entropy; inf_loss = lambda_p * p_loss + lambda_e * (-entropy); inf_kl = tq[2] * invB; inf_adv = tq[3] * invB; inf_ret = tq[4] * invB; inf_clip = tq[5] * invB; } } }
+              inf_ent = entropy; inf_loss = fmaf(lambda_p, p_loss, lambda_e * (-entropy)); inf_kl = tq[2] * invB; inf_adv = tq[3] * invB; inf_ret = tq[4] * invB; inf_clip = tq[5] * invB; } } }
         const bool go = step_exit(invB, any_bad != 0);
         if (!any_bad) { bp1 *= db1; bp2 *= db2; }
         xcur ^= 1; xstep += 1u; staged = st + bs < total_rows;
-        FS2_T(14);
+        FS2_T(15);
         if (!go) break;
       }
       if (err) break;
@@ -558,13 +643,6 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     // =====================================================================================================================================================
     // HELPER WAVES: the whole W2 path of the step (dW2, its exchange, total, Adam) and the minibatch prefetch / staging
     // =====================================================================================================================================================
-    // owned W2 tiles, D layout: reg r of tile mm <-> W2[o = 16 mp0 + 4g + r][i = 16 (m0+mm) + c]
-    f32x4 tW2[WT], mW2[WT], vW2[WT];
-#pragma unroll
-    for (int mm = 0; mm < WT; ++mm)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + H2 * (16 * (m0 + mm) + c);
-        tW2[mm][r] = a.p[pc]; mW2[mm][r] = a.m[pc]; vW2[mm][r] = a.v[pc]; }
     // ---- minibatch prefetch (HBM/L2 -> registers) and staging (registers -> the tile's LDS rows): wave h = 0 of a tile role fetches and stages the observation rows (four
     // lanes per sample), wave h = 1 the scalars (logprob, advantage, return, action) -- the helper part of k_train_fs, unchanged
     constexpr int NXL = (IN + 3) / 4;
@@ -637,14 +715,6 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
           for (int k = 0; k < NACT; ++k) q[4 + k] = p_act[k]; }
       }
     };
-    auto adam_w2 = [&](const f32x4 (&gT)[WT]) {      // Flux.update! on the owned tiles; the new weights go to both LDS layouts of W2
-#pragma unroll
-      for (int mm = 0; mm < WT; ++mm) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { float m_ = mW2[mm][r], v_ = vW2[mm][r]; const float d = adam1(gT[mm][r], m_, v_, ak);
-          mW2[mm][r] = m_; vW2[mm][r] = v_; tW2[mm][r] -= d;
-          sm[Lt::oW2R + (16 * mp0 + 4 * g + r) * FS_LD + 16 * (m0 + mm) + c] = tW2[mm][r]; }
-        *(f32x4*)&sm[Lt::oW2C + (16 * (m0 + mm) + c) * FS_LD + 16 * mp0 + 4 * g] = tW2[mm]; } };
 
     for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
       if (!epoch_prologue(ep)) break;
@@ -668,109 +738,49 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         FS2_T(2);
         __syncthreads();   // ---- B_1: T1 / T2 tiles of the workgroup are visible
         FS2_T(3);
-        // ======================= dW2 of this wave's tiles over the workgroup's samples, sent to the exchange slot at once =======================
+        // ======================= dW2 of this wave's tiles, then phase 1 of the exchange: the hand-shake for the W2 partials of ALL eight waves =======================
+        const unsigned tag = xstep + 1u;
         f32x4 gW2[WT];
-#pragma unroll
-        for (int mm = 0; mm < WT; ++mm) gW2[mm] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ws = 0; ws < TILES; ++ws) {
-          const float* t2 = sm + Lt::oT2 + ws * Lt::TILE2; const float* t1 = sm + Lt::oT1 + ws * Lt::TILE;
-          const f32x4 av = *(const f32x4*)&t2[t_rd + 256 * mp0];          // A[i=c -> o=16mp0+c][k -> sample 4g+r]
-#pragma unroll
-          for (int mm = 0; mm < WT; ++mm) { const f32x4 bv = *(const f32x4*)&t1[t_rd + 256 * (m0 + mm)];   // B[k -> sample][j=c -> i]
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gW2[mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], gW2[mm], 0, 0, 0); }
-        }
-        float* mine = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + p)) * XSLOT;
-        bool odd = false;
-#pragma unroll
-        for (int mm = 0; mm < WT; ++mm) { *(f32x4*)&mine[Lt::xW2 + ct * (4 * WT) + 4 * mm] = gW2[mm];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) odd = odd || !(fabsf(gW2[mm][r]) <= 1e30f); }
-        if (odd) mine[Lt::xSUS1] = 1.f;
+        dw2_send(gW2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this lane has reached the L2 (and the prefetched rows are in)
+        if (lane == 0) (void)__hip_atomic_fetch_add((unsigned*)(sm + Lt::cACK), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         FS2_T(4);
-        fs2_group_barrier(sm + Lt::cHELP, (unsigned)NWC * (xstep + 1u), lane);      // all helper waves' stores are acknowledged
         if (ct == 0) {
+          fs2_flag_wait(sm + Lt::cACK, (unsigned)NW * tag);        // all eight waves' W2 stores are acknowledged (the compute waves report after dH1)
           (void)__hip_atomic_fetch_add(a.xctr + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ARRIVAL 1
-          fs2_flag_set(sm + Lt::fH1, xstep + 1u);
-          const unsigned want = (unsigned)NWG * (xstep + 1u); unsigned spins = 0; bool ok = true;
+          const unsigned want = (unsigned)NWG * tag; unsigned spins = 0; bool ok = true;
           while (__hip_atomic_load(a.xctr + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 24) || __hip_atomic_load(a.xctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; } }   // never hang the GPU
-          if (!ok) { __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (fs2_flag_get(sm + Lt::fERR) == 0u) fs2_flag_set(sm + Lt::fERR, 1u); }
-          fs2_flag_set(sm + Lt::fP1, xstep + 1u);
+          unsigned why = ok ? 0u : 1u;                                // 1: a workgroup never arrived (or raised the abort word)
+          if (ok && xstep == 0u) {   // the unfenced exchange is only coherent inside one XCD's L2
+            uint32_t xcc = 0; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 0xf;
+            for (int q = 0; q < NWG; ++q) { const unsigned peer_xcc = __hip_atomic_load(a.xctr + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (peer_xcc != xcc + 1u) { ok = false; why = 2u; } } }   // 2: the workgroups of this learner sit on different XCDs
+          if (!ok) { __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (fs2_flag_get(sm + Lt::fERR) == 0u) fs2_flag_set(sm + Lt::fERR, why); }
+          fs2_flag_set(sm + Lt::fP1, tag);
         }
-        fs2_flag_wait(sm + Lt::fP1, xstep + 1u);      // phase 1 is complete (or has failed): every workgroup's W2 partials are in the L2
         FS2_T(5);
-        const bool failed = fs2_flag_get(sm + Lt::fERR) != 0u;
-        if (!failed) {
-          constexpr int NLD = NWG - 1;
-          f32x4 pw[NLD][WT];
-#pragma unroll
-          for (int j = 0; j < NLD; ++j) { const int q = j == 0 ? (p ^ 1) : ((p ^ 2) & 2) + (j - 1);      // partner, then the other pair's first and second workgroup
-            const float* peer = a.xbuf + (size_t)(((int)(xstep & 1u) * NWG + q)) * XSLOT;
-#pragma unroll
-            for (int mm = 0; mm < WT; ++mm)
-              asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(pw[j][mm]) : "v"(peer + Lt::xW2 + ct * (4 * WT) + 4 * mm) : "memory"); }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int j = 0; j < NLD; ++j)
-#pragma unroll
-            for (int mm = 0; mm < WT; ++mm) asm volatile("" : "+v"(pw[j][mm]));      // (asm statements keep their order: every use of a loaded value follows the wait)
-          // (s0 + s1) + (s2 + s3): own + partner, the other pair in index order, then the two pair sums -- the same bits in all four workgroups (train_fs_kernel.h)
-#pragma unroll
-          for (int mm = 0; mm < WT; ++mm) gW2[mm] = (gW2[mm] + pw[0][mm]) + (pw[1][mm] + pw[2][mm]);
-        }
-        FS2_T(6);
-        { float ssq = 0.f;      // this wave's share of the gradient norm, every step (whether the step reports is the compute waves' knowledge)
-#pragma unroll
-          for (int mm = 0; mm < WT; ++mm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ssq += gW2[mm][r] * gW2[mm][r];
-          ssq = wave_sum(ssq);
-          if (lane == 0) sm[Lt::oRED + w] = ssq; }
-        // the state before this step's update: a suspect step (decided after B_b, with the small parameters' news) is undone first
-        f32x4 tW2o[WT], mW2o[WT], vW2o[WT];
-#pragma unroll
-        for (int mm = 0; mm < WT; ++mm) { tW2o[mm] = tW2[mm]; mW2o[mm] = mW2[mm]; vW2o[mm] = vW2[mm]; }
-        fs2_flag_wait(sm + Lt::cCOMP, (unsigned)NWC * (3u * xstep + 1u));      // the compute waves have passed B_2: nobody reads the W2 masters (dH1) any more
-        if (!failed) adam_w2(gW2);
-        FS2_T(7);
-        __syncthreads();   // ---- B_b: masters updated
-        FS2_T(8);
-        { const unsigned why = fs2_flag_get(sm + Lt::fERR); if (why != 0u) { err = CRUX_EHIP; why_failed = (int)why; break; } }
-        int any_bad = 0;
-        if (fs2_flag_get(sm + Lt::fSUS) != 0u) {      // suspect step: back to the pre-step state, then the workgroup decides
-#pragma unroll
-          for (int mm = 0; mm < WT; ++mm) { tW2[mm] = tW2o[mm]; mW2[mm] = mW2o[mm]; vW2[mm] = vW2o[mm]; }
-          int bad = 0;
-#pragma unroll
-          for (int mm = 0; mm < WT; ++mm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bad |= isnan(gW2[mm][r]) ? 1 : 0;
-          any_bad = __syncthreads_or(bad);
-          if (!any_bad) { adam_w2(gW2); __syncthreads(); }
-        }
+        fs2_flag_wait(sm + Lt::cCOMP, (unsigned)NWC * tag);      // the compute waves have passed B_2: the small partials of both tiles are in LDS, nobody reads the W2 masters (dH1) any more
+        int any_bad = 0; st_now = st;
+        if (!step_tail(tag, gW2, any_bad)) break;
         const bool go = step_exit(invB, any_bad != 0);
         if (!any_bad) { bp1 *= db1; bp2 *= db2; }
         xcur ^= 1; xstep += 1u; staged = st + bs < total_rows;
-        FS2_T(9);
+        FS2_T(15);
         if (!go) break;
       }
       if (err) break;
       epoch_epilogue(ep);
     }
-    // ---- write back W2 and its Adam state --------------------------------------------------------------------
-    if (p == 0) {
-#pragma unroll
-      for (int mm = 0; mm < WT; ++mm)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + H2 * (16 * (m0 + mm) + c);
-          a.p[pc] = tW2[mm][r]; a.m[pc] = mW2[mm][r]; a.v[pc] = vW2[mm][r]; }
-    }
   }
-  // ---- write back the small parameters and the launch status ------------------------------------------------------
+  // ---- write back parameters, Adam state and the launch status ------------------------------------------------------
   __syncthreads();
+  if (p == 0) {
+#pragma unroll
+    for (int mm = 0; mm < WT; ++mm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + H2 * (16 * (m0 + mm) + c);
+        a.p[pc] = tW2[mm][r]; a.m[pc] = mW2[mm][r]; a.v[pc] = vW2[mm][r]; } }
   if (p == 0) { for (int s = tid; s < ns_valid; s += NT) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; } }
   if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(NW * p + w) * 16 + k] = tacc[k]; }
   if (tid == 0 && (p == 0 || err)) {

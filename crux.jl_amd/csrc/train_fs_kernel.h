@@ -843,7 +843,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
             else { entropy = 1.4189385332046727f;
 #pragma unroll
               for (int k = 0; k < OUT; ++k) entropy += sm[Lt::oEX + k]; }
-            inf_ent = entropy; inf_loss = a.lambda_p * p_loss + a.lambda_e * (-entropy); inf_kl = tq[2] * invB; inf_adv = tq[3] * invB; inf_ret = tq[4] * invB; inf_clip = tq[5] * invB;
+            inf_ent = entropy; inf_loss = fmaf(a.lambda_p, p_loss, a.lambda_e * (-entropy));      /* (explicit fma: the same bits in every form of the kernel) */ inf_kl = tq[2] * invB; inf_adv = tq[3] * invB; inf_ret = tq[4] * invB; inf_clip = tq[5] * invB;
             if constexpr (LAG) { const float cost_loss = pen * (tq[7] * invB);                                        // ppo.jl:119
               inf_loss = ((a.lambda_p * p_loss + a.lambda_e * (-entropy)) + cost_loss) / (1.f + pen);                   // :131
               inf_pen = pen; inf_cur = lgs[6]; inf_closs = cost_loss; inf_ploss = a.lambda_p * p_loss; } }
