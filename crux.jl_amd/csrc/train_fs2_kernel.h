@@ -140,11 +140,12 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   AdamK ak; ak.b1 = (float)a.b1; ak.b2 = (float)a.b2; ak.omb1 = (float)(1.0 - a.b1); ak.omb2 = (float)(1.0 - a.b2); ak.eps = (float)a.eps; ak.eta = (float)a.eta;
   const double db1 = a.b1, db2 = a.b2;
   const float lambda_p = a.lambda_p, lambda_e = a.lambda_e, target_kl = a.target_kl, squash = a.squash;
-  const long long max_batches = a.max_batches;
+  // 32-bit loop control (the dispatcher sends only buffers below 2^30 rows and launches below 2^31 steps here): 64-bit counters cost SGPR pairs the wide heads do not have
+  const int max_batches = a.max_batches > 0 && a.max_batches < 0x7fffffffll ? (int)a.max_batches : 0;
   const int bs = a.bs;
 
   int32_t* order_cur = a.order_a; int32_t* order_nxt = a.order_b;
-  long long total_batches = 0; int epochs_run = 0, err = 0, why_failed = 0; bool stop = false;
+  int total_batches = 0; int epochs_run = 0, err = 0, why_failed = 0; bool stop = false;
   bool staged = false;
   unsigned xstep = 0;                                // exchanges of this launch: every group-barrier target and both arrival counters are multiples of xstep + 1
   float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
@@ -161,10 +162,10 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     }
   }
   __syncthreads();
-  const int64_t total_rows = a.len;
+  const int total_rows = (int)a.len;
 
   // what the minibatch loops of both roles share. Only the epoch's last minibatch, or the one that ends the loop, is ever reported (training.jl:22-23, 45-53).
-  auto static_report = [&](int64_t st) -> bool { return st + bs >= total_rows || (max_batches > 0 && total_batches + 1 >= max_batches); };
+  auto static_report = [&](int st) -> bool { return st + bs >= total_rows || (max_batches > 0 && total_batches + 1 >= max_batches); };
   // the end of a minibatch step after B_b, identical in every thread of the workgroup (its inputs are LDS words published before the barrier): the KL statistic and the loop exits.
   // false = the minibatch loop ends here.
   auto step_exit = [&](float invB, bool any_bad) -> bool {
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   const bool stat_lane = tid >= NT - 8 && tid < NT - 1;      // stat sums, by 7 lanes of the last wave
   // ---- the end of a step in every wave, once the workgroup's small partials are in LDS (B_2): the small partials leave as granules; the peers' W2 partials (phase 1 complete)
   // and granules come in; totals, Adam, B_b; suspect steps. false = the launch ends here (err is set).
-  long long st_now = 0;      // the minibatch loops set it: first row of the current minibatch
+  int st_now = 0;      // the minibatch loops set it: first row of the current minibatch
   auto step_tail = [&](const unsigned tag, f32x4 (&gW2)[WT], int& any_bad) -> bool {
     float gs[NSC];
 #pragma unroll
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FS2_T(12);
     float ssq = 0.f; bool bad_tot = false;
-    const bool want_ssq = static_report((int64_t)st_now) || (KIND != MFK_VALUE && target_kl >= 0.f);      // only a step that may report needs the gradient norm
+    const bool want_ssq = static_report(st_now) || (KIND != MFK_VALUE && target_kl >= 0.f);      // only a step that may report needs the gradient norm
     f32x4 tW2o[WT], mW2o[WT], vW2o[WT];      // the state before this step's update: a suspect step (known after B_b) is undone first
 #pragma unroll
     for (int mm = 0; mm < WT; ++mm) { tW2o[mm] = tW2[mm]; mW2o[mm] = mW2[mm]; vW2o[mm] = vW2[mm]; }
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
       if (!epoch_prologue(ep)) break;
       staged = false;
-      for (int64_t st = 0; st < total_rows; st += bs) {
+      for (int st = 0; st < total_rows; st += bs) {
         const int nb = (int)((total_rows - st) < bs ? (total_rows - st) : bs);
         const float invB = 1.0f / (float)nb;
         ak.c1 = __builtin_amdgcn_rcpf((float)(1.0 - bp1)); ak.c2 = __builtin_amdgcn_rcpf((float)(1.0 - bp2));
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
 #pragma unroll
     for (int e = 0; e < NXL; ++e) px[e] = 0.f;
     int n_row = 0, n_valid = 0;
-    auto fetch_index = [&](const int32_t* ord, int64_t st, int nb) {
+    auto fetch_index = [&](const int32_t* ord, int st, int nb) {
       const int sidx = 8 * NWC * p + 16 * t + c;
       n_valid = sidx < nb ? 1 : 0;
       n_row = n_valid ? CRUX_GLOBAL_PTR(int32_t, ord)[st + sidx] : 0;
@@ -720,8 +721,8 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
       if (!epoch_prologue(ep)) break;
       staged = false;
       { const int nb0 = (int)(total_rows < bs ? total_rows : bs); fetch_index(order_cur, 0, nb0); fetch_data();
-        const int64_t st1 = bs; const int nb1 = st1 < total_rows ? (int)((total_rows - st1) < bs ? (total_rows - st1) : bs) : 0; fetch_index(order_cur, st1 < total_rows ? st1 : 0, nb1); }
-      for (int64_t st = 0; st < total_rows; st += bs) {
+        const int st1 = bs; const int nb1 = st1 < total_rows ? (int)((total_rows - st1) < bs ? (total_rows - st1) : bs) : 0; fetch_index(order_cur, st1 < total_rows ? st1 : 0, nb1); }
+      for (int st = 0; st < total_rows; st += bs) {
         const int nb = (int)((total_rows - st) < bs ? (total_rows - st) : bs);
         const float invB = 1.0f / (float)nb;
         ak.c1 = __builtin_amdgcn_rcpf((float)(1.0 - bp1)); ak.c2 = __builtin_amdgcn_rcpf((float)(1.0 - bp2));
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         // rows of the NEXT minibatch (their indices came a step ago) and the indices of the one after it; the next minibatch goes into the other staging buffer, which the
         // compute waves left at the end of the previous step
         if (st + bs < total_rows) fetch_data();
-        { const int64_t st2 = st + 2 * (int64_t)bs; const int nb2 = st2 < total_rows ? (int)((total_rows - st2) < bs ? (total_rows - st2) : bs) : 0;
+        { const int st2 = st + 2 * bs; const int nb2 = st2 < total_rows ? (int)((total_rows - st2) < bs ? (total_rows - st2) : bs) : 0;
           fetch_index(order_cur, st2 < total_rows ? st2 : 0, nb2); }
         FS2_T(1);
         if (st + bs < total_rows) stage(xcur ^ 1);
@@ -776,10 +777,14 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   // ---- write back parameters, Adam state and the launch status ------------------------------------------------------
   __syncthreads();
   if (p == 0) {
+    // (the element addresses are formed again from a laundered thread index: shared with the loads at the top of the kernel, the compiler kept the 64-bit addresses alive
+    //  across the whole launch -- in scratch, at the 256-register limit of the wide heads)
+    int tid2 = tid; asm volatile("" : "+v"(tid2));
+    const int lane2 = tid2 & 63, w2_ = tid2 >> 6, c2 = lane2 & 15, g2 = lane2 >> 4, mp2 = (w2_ * WT) >> 2, m2 = (w2_ * WT) & 3;
 #pragma unroll
     for (int mm = 0; mm < WT; ++mm)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp0 + 4 * g + r) + H2 * (16 * (m0 + mm) + c);
+      for (int r = 0; r < 4; ++r) { const int pc = Lt::cW2 + (16 * mp2 + 4 * g2 + r) + H2 * (16 * (m2 + mm) + c2);
         a.p[pc] = tW2[mm][r]; a.m[pc] = mW2[mm][r]; a.v[pc] = vW2[mm][r]; } }
   if (p == 0) { for (int s = tid; s < ns_valid; s += NT) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; } }
   if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(NW * p + w) * 16 + k] = tacc[k]; }
