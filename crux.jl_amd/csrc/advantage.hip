@@ -61,24 +61,53 @@ __global__ void k_gae_returns_multi(const GaeJob* __restrict__ jobs, float lambd
   gae_returns_body(j.r, j.done, j.ee, j.Vs, j.Vsp, lambda, gamma, n, j.adv, j.ret, j.flag);
 }
 
-// whiten(v) = (v .- mean(v)) ./ std(v), Bessel-corrected std; single block, deterministic tree reductions in Float64.
+// whiten(v) = (v .- mean(v)) ./ std(v) (utils.jl:41-42) with Julia's own Float32 reductions: Statistics.mean = sum(A) / length(A), Statistics.std = sqrt(centralize_sumabs2(A, m) / (n - 1)),
+// both through Base.mapreduce_impl's pairwise scheme (reduce.jl; pairwise_blocksize = 1024): a range of at most 1024 elements is summed from the left, a longer one is split at
+// ifirst + (ilast - ifirst) >> 1 and the halves are added. One block: thread 0 walks the recursion once to list the leaves, thread i sums leaf i from the left, thread 0 walks it
+// again to add the leaf sums in the tree's order -- the oracle's orc_jl_mean_f32 / orc_jl_std_f32 bit for bit (round 5; the Float64 tree sums before agreed with the oracle, not with Julia).
+#define JLW_MAXLEAF 4096        // leaves of one reduction: n up to ~2 M elements (an on-policy buffer); larger columns are refused by the host
+struct JlFrame { int64_t a, b; float v1; int st; };
+__device__ __forceinline__ float jlw_term(float x, bool centred, float m) { if (!centred) return x; const float d = __fsub_rn(x, m); return __fmul_rn(d, d); }
+__device__ float jlw_reduce(const float* __restrict__ v, int64_t n, bool centred, float m, int32_t* leaf_lo, float* leaf_sum, int* n_leaf) {      // leaves are contiguous: leaf q = [leaf_lo[q], leaf_lo[q + 1])
+  const int tid = threadIdx.x;
+  if (tid == 0) {      // the leaves of mapreduce_impl(f, +, A, 1, n, 1024) in the order the recursion visits them
+    JlFrame stk[48]; int sp = 0, nl = 0; stk[sp++] = JlFrame{0, n - 1, 0.f, 0};
+    while (sp) { JlFrame f = stk[sp - 1];
+      if (f.b - f.a < 1024) { leaf_lo[nl] = (int32_t)f.a; ++nl; --sp; continue; }
+      const int64_t mid = f.a + ((f.b - f.a) >> 1);
+      if (f.st == 0) { stk[sp - 1].st = 1; stk[sp++] = JlFrame{f.a, mid, 0.f, 0}; continue; }
+      if (f.st == 1) { stk[sp - 1].st = 2; stk[sp++] = JlFrame{mid + 1, f.b, 0.f, 0}; continue; }
+      --sp; }
+    leaf_lo[nl] = (int32_t)n; *n_leaf = nl; }
+  __syncthreads();
+  const int nl = *n_leaf;
+  for (int q = tid; q < nl; q += 1024) { const int64_t lo = leaf_lo[q], hi = (int64_t)leaf_lo[q + 1] - 1;      // v = f(a1) + f(a2); v += f(a3); ... (reduce.jl, the sequential portion)
+    float acc = jlw_term(v[lo], centred, m);
+    for (int64_t i = lo + 1; i <= hi; ++i) acc = __fadd_rn(acc, jlw_term(v[i], centred, m));
+    leaf_sum[q] = acc; }
+  __syncthreads();
+  __shared__ float result;
+  if (tid == 0) {      // op(v1, v2) up the same tree
+    JlFrame stk[48]; int sp = 0, nx = 0; float ret = 0.f; stk[sp++] = JlFrame{0, n - 1, 0.f, 0};
+    while (sp) { JlFrame f = stk[sp - 1];
+      if (f.b - f.a < 1024) { ret = leaf_sum[nx++]; --sp; continue; }
+      const int64_t mid = f.a + ((f.b - f.a) >> 1);
+      if (f.st == 0) { stk[sp - 1].st = 1; stk[sp++] = JlFrame{f.a, mid, 0.f, 0}; continue; }
+      if (f.st == 1) { stk[sp - 1].v1 = ret; stk[sp - 1].st = 2; stk[sp++] = JlFrame{mid + 1, f.b, 0.f, 0}; continue; }
+      ret = __fadd_rn(f.v1, ret); --sp; }
+    result = ret; }
+  __syncthreads();
+  const float r = result;
+  __syncthreads();
+  return r;
+}
 __device__ __forceinline__ void whiten_block(float* __restrict__ v, int64_t n) {
-  __shared__ double red[16];
-  __shared__ float sh_mean, sh_sd;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  double s = 0.0;
-  for (int64_t i = tid; i < n; i += 1024) s += (double)v[i];
-  s = wave_sum_d(s); if (lane == 0) red[wid] = s; __syncthreads();
-  if (tid == 0) { double t = 0; for (int w = 0; w < 16; ++w) t += red[w]; sh_mean = (float)(t / (double)n); }
-  __syncthreads();
-  const double mean = (double)sh_mean;
-  double ss = 0.0;
-  for (int64_t i = tid; i < n; i += 1024) { const double d = (double)v[i] - mean; ss += d * d; }
-  ss = wave_sum_d(ss); __syncthreads(); if (lane == 0) red[wid] = ss; __syncthreads();
-  if (tid == 0) { double t = 0; for (int w = 0; w < 16; ++w) t += red[w]; sh_sd = (float)sqrt(t / (double)(n - 1)); }
-  __syncthreads();
-  const float mf = sh_mean, sd = sh_sd;
-  for (int64_t i = tid; i < n; i += 1024) v[i] = __fdiv_rn(__fsub_rn(v[i], mf), sd);
+  __shared__ int32_t leaf_lo[JLW_MAXLEAF + 1];
+  __shared__ float leaf_sum[JLW_MAXLEAF];
+  __shared__ int n_leaf;
+  const float mean = __fdiv_rn(jlw_reduce(v, n, false, 0.f, leaf_lo, leaf_sum, &n_leaf), (float)n);                 // sum(A) / length(A)
+  const float sd = sqrtf(__fdiv_rn(jlw_reduce(v, n, true, mean, leaf_lo, leaf_sum, &n_leaf), (float)(n - 1)));        // sqrt(centralize_sumabs2(A, m) / (n - 1))
+  for (int64_t i = threadIdx.x; i < n; i += 1024) v[i] = __fdiv_rn(__fsub_rn(v[i], mean), sd);
 }
 __global__ __launch_bounds__(1024) void k_whiten(float* __restrict__ v, int64_t n) { whiten_block(v, n); }
 __global__ __launch_bounds__(1024) void k_whiten_multi(float* const* __restrict__ vs, int64_t n) { whiten_block(vs[blockIdx.x], n); }
@@ -298,6 +327,7 @@ int32_t crux_whiten(crux_buffer* b, int32_t key) {
   if (!has_col(b, key) || col_elem(b, key) != 4 || col_rows(b, key) != 1) return crux_fail(c, CRUX_EINVAL, "whiten: column %d is not a 1 x N Float32 column", key);
   const int64_t n = b->elements;
   if (n < 2) return crux_fail(c, CRUX_EINVAL, "whiten: need at least 2 elements");
+  if (n > (int64_t)JLW_MAXLEAF * 512) return crux_fail(c, CRUX_EUNSUP, "whiten: %lld elements (the pairwise reduction is laid out for at most %d leaves)", (long long)n, JLW_MAXLEAF);
   crux_prof_begin(c, CRUX_PROF_WHITEN);
   hipLaunchKernelGGL(k_whiten, dim3(1), dim3(1024), 0, c->stream, (float*)b->col[key], n);
   crux_prof_end(c, CRUX_PROF_WHITEN);

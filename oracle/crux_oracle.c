@@ -872,15 +872,28 @@ int32_t orc_fill_importance_weights(orc_buffer* b) {
     if (rev) { w = 1.f; for (int64_t i = en[k]; i >= st[k]; --i) { w = iw[i] * w; rev[i] = w; } } }                  /* :301-308 */
   free(st); free(en); return CRUX_OK;
 }
-/* whiten(v) = (v .- mean(v)) ./ std(v)  utils.jl:41-42; [3P] Statistics.std is Bessel-corrected; the
- * reductions are evaluated in Float64 here and rounded to Float32 (Julia uses pairwise Float32). */
+/* [3P] Julia's reductions over a Float32 array, restated from Base (reduce.jl: mapreduce_impl, pairwise_blocksize = 1024) and Statistics (mean = sum(A) / length(A);
+ * var(A; corrected = true) = centralize_sumabs2(A, mean(A)) / (n - 1), the same pairwise scheme over abs2(x - m); std = sqrt(var)): a range of at most 1024 elements is
+ * summed from the left, `v = a1 + a2; v += a3; ...`, a longer one is split at ifirst + (ilast - ifirst) >> 1 and the two halves are added -- all in Float32.
+ * (Base marks the inner loop @simd, which lets LLVM re-associate it by vector lane on the machine Julia runs on; the left-to-right order is the scalar semantics.) */
+static float jl_mapreduce_f32(const float* a, int64_t ifirst, int64_t ilast, int centred, float m) {      /* 0-based, inclusive */
+#define JL_F(x) (centred ? ((x) - m) * ((x) - m) : (x))
+  if (ifirst == ilast) return JL_F(a[ifirst]);
+  if (ilast - ifirst < 1024) { float v = JL_F(a[ifirst]) + JL_F(a[ifirst + 1]); for (int64_t i = ifirst + 2; i <= ilast; ++i) v = v + JL_F(a[i]); return v; }
+  int64_t imid = ifirst + ((ilast - ifirst) >> 1);
+  float v1 = jl_mapreduce_f32(a, ifirst, imid, centred, m), v2 = jl_mapreduce_f32(a, imid + 1, ilast, centred, m);
+  return v1 + v2;
+#undef JL_F
+}
+float orc_jl_sum_f32(const float* a, int64_t n) { return n <= 0 ? 0.f : jl_mapreduce_f32(a, 0, n - 1, 0, 0.f); }
+float orc_jl_mean_f32(const float* a, int64_t n) { return orc_jl_sum_f32(a, n) / (float)n; }                       /* Statistics.mean: sum(A) / length(A), Float32 / Int */
+float orc_jl_std_f32(const float* a, int64_t n) {                                                                    /* Statistics.std, corrected */
+  float m = orc_jl_mean_f32(a, n); return sqrtf(jl_mapreduce_f32(a, 0, n - 1, 1, m) / (float)(n - 1)); }
+/* whiten(v) = (v .- mean(v)) ./ std(v)  utils.jl:41-42, with Julia's own reductions (above) */
 int32_t orc_whiten(orc_buffer* b, int32_t key) {
   if (!orc_buffer_has_column(b, key) || col_elem(b, key) != 4 || col_rows(b, key) != 1) return CRUX_EINVAL;
   float* v = (float*)b->col[key]; int64_t n = b->elements; if (n < 2) return CRUX_EINVAL;
-  double s = 0; for (int64_t i = 0; i < n; ++i) s += v[i];
-  float mean = (float)(s / (double)n);
-  double ss = 0; for (int64_t i = 0; i < n; ++i) { double d = (double)v[i] - (double)mean; ss += d * d; }
-  float sd = (float)sqrt(ss / (double)(n - 1));
+  float mean = orc_jl_mean_f32(v, n), sd = orc_jl_std_f32(v, n);
   for (int64_t i = 0; i < n; ++i) v[i] = (v[i] - mean) / sd;
   return CRUX_OK;
 }
@@ -914,12 +927,15 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
   for (int q = 0; q < CRUX_INFO_N; ++q) info[q] = 0.f;
   const float* S = (const float*)buf->col[CRUX_COL_S];
   float invB = 1.0f / (float)n;
-  double sum_loss_p = 0, sum_H = 0, sum_kl = 0, sum_adv = 0, sum_ret = 0, sum_sq = 0, sum_cost = 0; int64_t nclip = 0;
+  /* the per-sample terms of every mean the loss reports: reduced at the end the way Julia's mean does (orc_jl_mean_f32) */
+  const int64_t nsq = n * (cfg->loss == CRUX_LOSS_MSE_ACTION ? (int64_t)nout : 1);
+  float* T_ = (float*)calloc((size_t)(6 * n + nsq), 4);
+  float* T_lp = T_; float* T_H = T_ + n; float* T_kl = T_ + 2 * n; float* T_adv = T_ + 3 * n; float* T_ret = T_ + 4 * n; float* T_cost = T_ + 5 * n; float* T_sq = T_ + 6 * n; int64_t nclip = 0;
   /* The sample loops below run once, in order, into net->g in the parity build. The OpenMP build gives every thread a slice of the minibatch and a
    * private gradient that is added to net->g at the end (sample-parallel inside one step: the steps themselves are serially dependent). */
 #ifdef _OPENMP
   const int nthr = n >= 32 ? (omp_get_max_threads() < (int)(n / 8) ? omp_get_max_threads() : (int)(n / 8)) : 1;
-#define LG_BEGIN ORC_OMP(omp parallel num_threads(nthr) reduction(+ : sum_loss_p, sum_H, sum_kl, sum_adv, sum_ret, sum_sq, sum_cost, nclip)) \
+#define LG_BEGIN ORC_OMP(omp parallel num_threads(nthr) reduction(+ : nclip)) \
   { colcache c = cc_alloc(net); float dy[64], p[64]; (void)p; float* gl = nthr > 1 ? (float*)calloc((size_t)net->n_params, 4) : net->g; ORC_OMP(omp for schedule(static))
 #define LG_END if (gl != net->g) { ORC_OMP(omp critical) { for (int64_t i_ = 0; i_ < net->n_params; ++i_) net->g[i_] += gl[i_]; } free(gl); } cc_free(net, &c); }
 #else
@@ -927,34 +943,34 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
 #define LG_END cc_free(net, &c); }
 #endif
   if (cfg->loss == CRUX_LOSS_MSE_ACTION) {                                     /* mse_action_loss il/bc.jl:1: Flux.mse(action(pi, s), a) */
-    if (buf->act_kind != CRUX_ACTION_CONTINUOUS || nout != ad) return CRUX_EINVAL;
+    if (buf->act_kind != CRUX_ACTION_CONTINUOUS || nout != ad) { free(T_); return CRUX_EINVAL; }
     const float* A = (const float*)buf->col[CRUX_COL_A]; float inv = invB / (float)nout;
     LG_BEGIN
     for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s]; fwd_col(net, S + (size_t)id * od, c.h);
-      for (int k = 0; k < nout; ++k) { float d = c.h[net->n_layers][k] - A[(size_t)id * ad + k]; sum_sq += (double)(d * d) / (double)nout; dy[k] = 2.f * d * inv; }
+      for (int k = 0; k < nout; ++k) { float d = c.h[net->n_layers][k] - A[(size_t)id * ad + k]; T_sq[s * nout + k] = d * d; dy[k] = 2.f * d * inv; }      /* Flux.mse: mean(abs2.(yhat .- y)) over all nout x n elements, column-major */
       bwd_col(net, c.h, dy, gl); }
     LG_END
-    info[CRUX_INFO_LOSS] = (float)(sum_sq / (double)n);
+    info[CRUX_INFO_LOSS] = orc_jl_mean_f32(T_sq, nsq);
   } else if (cfg->loss == CRUX_LOSS_VALUE_MSE) {                               /* Flux.mse(value(pi, s), return) ppo.jl:60 */
     const int tk = cfg->target_col > 0 ? cfg->target_col : CRUX_COL_RETURN;      /* D[:return] (ppo.jl:60) or D[:cost_return] (:210) */
-    if (nout != 1 || !(buf->mask & (1u << tk))) return CRUX_EINVAL;
+    if (nout != 1 || !(buf->mask & (1u << tk))) { free(T_); return CRUX_EINVAL; }
     const float* RET = (const float*)buf->col[tk];
     LG_BEGIN
     for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s];
       fwd_col(net, S + (size_t)id * od, c.h); float d = c.h[net->n_layers][0] - RET[id];
-      sum_sq += (double)(d * d); dy[0] = 2.f * d * invB; bwd_col(net, c.h, dy, gl); }
+      T_sq[s] = d * d; dy[0] = 2.f * d * invB; bwd_col(net, c.h, dy, gl); }
     LG_END
-    info[CRUX_INFO_LOSS] = (float)(sum_sq / (double)n);
+    info[CRUX_INFO_LOSS] = orc_jl_mean_f32(T_sq, n);
   } else {                                                                     /* ppo_loss ppo.jl:4-21 */
     const float* RET = (buf->mask & (1u << CRUX_COL_RETURN)) ? (const float*)buf->col[CRUX_COL_RETURN] : NULL;
     const int bc = cfg->loss == CRUX_LOSS_LOGPDF_BC;                            /* logpdf_bc_loss il/bc.jl:10-18: only :s and :a are read */
-    if (!bc && (!(buf->mask & (1u << CRUX_COL_LOGPROB)) || (cfg->loss == CRUX_LOSS_REINFORCE ? !RET : !(buf->mask & (1u << CRUX_COL_ADVANTAGE))))) return CRUX_EINVAL;
-    if (nout != ad || (cfg->head != CRUX_HEAD_CATEGORICAL && net->n_extra != ad)) return CRUX_EINVAL;
+    if (!bc && (!(buf->mask & (1u << CRUX_COL_LOGPROB)) || (cfg->loss == CRUX_LOSS_REINFORCE ? !RET : !(buf->mask & (1u << CRUX_COL_ADVANTAGE))))) { free(T_); return CRUX_EINVAL; }
+    if (nout != ad || (cfg->head != CRUX_HEAD_CATEGORICAL && net->n_extra != ad)) { free(T_); return CRUX_EINVAL; }
     const float* LP = bc ? NULL : (const float*)buf->col[CRUX_COL_LOGPROB]; const float* ADV = bc ? NULL : (cfg->loss == CRUX_LOSS_REINFORCE ? RET : (const float*)buf->col[CRUX_COL_ADVANTAGE]);
     float lo = 1.f - cfg->eps_clip, hi = 1.f + cfg->eps_clip;
     const float* ls = net->p + xoff(net);
     const int lagr = cfg->loss == CRUX_LOSS_LAGRANGE_PPO; float pen = 0.f; const float* CADV = NULL;
-    if (lagr) { if (!g_lag || !(buf->mask & (1u << CRUX_COL_COST)) || !(buf->mask & (1u << CRUX_COL_COST_ADVANTAGE))) return CRUX_EINVAL;
+    if (lagr) { if (!g_lag || !(buf->mask & (1u << CRUX_COL_COST)) || !(buf->mask & (1u << CRUX_COL_COST_ADVANTAGE))) { free(T_); return CRUX_EINVAL; }
       CADV = (const float*)buf->col[CRUX_COL_COST_ADVANTAGE]; pen = lagrange_penalty(g_lag, buf, ids, n); }
     LG_BEGIN
     for (int64_t s = 0; s < n; ++s) { int64_t id = ids[s]; float* gx = gl + xoff(net);
@@ -974,9 +990,9 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
         if (cfg->loss == CRUX_LOSS_A2C) { coef = A; lterm = newlp * A; }                                   /* a2c.jl:6 */
         else if (bc) { coef = 1.f; lterm = newlp; lp_ = 1.f; }                                             /* -mean(logpdf) bc.jl:12 */
         else if (cfg->loss == CRUX_LOSS_REINFORCE) { coef = RET[id]; lterm = newlp * RET[id]; lp_ = 1.f; le_ = 0.f; }   /* reinforce.jl:12 */
-        sum_loss_p += (double)lterm;
+        T_lp[s] = lterm;
         float gcr = 0.f;                                           /* lagrange: d/dr max(r Ac, clamp(r) Ac) times r (ppo.jl:119) */
-        if (lagr) { float Ac = CADV[id], uc = r * Ac, clc = rc * Ac; sum_cost += (double)(uc >= clc ? uc : clc); gcr = (uc >= clc ? Ac : 0.f) * r; }
+        if (lagr) { float Ac = CADV[id], uc = r * Ac, clc = rc * Ac; T_cost[s] = (uc >= clc ? uc : clc); gcr = (uc >= clc ? Ac : 0.f) * r; }
         for (int k = 0; k < nout; ++k) {
           float dlogpi = p[k] * ((a[k] ? 1.f : 0.f) / q) - p[k];   /* = y_k - p_k for one-hot y */
           float dH = p[k] * (hk[k] - hp);
@@ -997,9 +1013,9 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
         if (cfg->loss == CRUX_LOSS_A2C) { coef = A; lterm = newlp * A; }
         else if (bc) { coef = 1.f; lterm = newlp; lp_ = 1.f; }
         else if (cfg->loss == CRUX_LOSS_REINFORCE) { coef = RET[id]; lterm = newlp * RET[id]; lp_ = 1.f; }
-        sum_loss_p += (double)lterm;
+        T_lp[s] = lterm;
         float cf = -lp_ * coef;                                                                  /* coefficient of d logpdf in d loss */
-        if (lagr) { float Ac = CADV[id], uc = r * Ac, clc = rc * Ac; sum_cost += (double)(uc >= clc ? uc : clc);
+        if (lagr) { float Ac = CADV[id], uc = r * Ac, clc = rc * Ac; T_cost[s] = (uc >= clc ? uc : clc);
           cf = (cf + pen * ((uc >= clc ? Ac : 0.f) * r)) / (1.f + pen); }
         for (int k = 0; k < ad; ++k) { float sg = expf(sq > 0.f ? sq_clampls(ls[k]) : ls[k]); float s2 = sg * sg; float d = ua[k] - z[k];
           float inr = (sq > 0.f && !(ls[k] >= -5.f && ls[k] <= 2.f)) ? 0.f : 1.f;               /* d clamp(x, lo, hi)/dx = 1 inside [lo, hi], 0 outside (ChainRules) */
@@ -1007,20 +1023,20 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
           gx[k] += invB * (cf * (((d * d) / s2) * inr - 1.f)); }
         if ((cfg->loss == CRUX_LOSS_PPO || lagr) && (r > hi || r < lo)) ++nclip;
       }
-      sum_H += (double)H; sum_kl += (double)(oldlp - newlp); sum_adv += (double)A; if (RET) sum_ret += (double)RET[id];
+      T_H[s] = H; T_kl[s] = oldlp - newlp; T_adv[s] = A; if (RET) T_ret[s] = RET[id];
       bwd_col(net, c.h, dy, gl);
     }
     LG_END
     float* gx = net->g + xoff(net);
-    float p_loss = (float)(-(sum_loss_p / (double)n)), e_loss, entropy;
-    if (cfg->head == CRUX_HEAD_CATEGORICAL) { entropy = (float)(sum_H / (double)n); e_loss = -entropy; }
+    float p_loss = -orc_jl_mean_f32(T_lp, n), e_loss, entropy;
+    if (cfg->head == CRUX_HEAD_CATEGORICAL) { entropy = orc_jl_mean_f32(T_H, n); e_loss = -entropy; }
     else { float Hs = 1.4189385332046727f; for (int k = 0; k < ad; ++k) Hs = Hs + ls[k]; entropy = Hs; e_loss = -Hs;   /* scalar entropy policies.jl:348 */
       if (cfg->loss != CRUX_LOSS_REINFORCE) for (int k = 0; k < ad; ++k) gx[k] += lagr ? -cfg->lambda_e / (1.f + pen) : -cfg->lambda_e; }
     info[CRUX_INFO_LOSS] = cfg->loss == CRUX_LOSS_REINFORCE ? p_loss : (bc ? 1.f : cfg->lambda_p) * p_loss + cfg->lambda_e * e_loss;   /* ppo.jl:20, a2c.jl:14, reinforce.jl:12 */
-    info[CRUX_INFO_ENTROPY] = entropy; info[CRUX_INFO_KL] = (float)(sum_kl / (double)n);
-    info[CRUX_INFO_CLIP_FRACTION] = (float)nclip / (float)n; info[CRUX_INFO_AVG_ADVANTAGE] = (float)(sum_adv / (double)n);
-    info[CRUX_INFO_AVG_RETURN] = (float)(sum_ret / (double)n);
-    if (lagr) { float cost_loss = pen * (float)(sum_cost / (double)n);                                              /* ppo.jl:119 */
+    info[CRUX_INFO_ENTROPY] = entropy; info[CRUX_INFO_KL] = orc_jl_mean_f32(T_kl, n);
+    info[CRUX_INFO_CLIP_FRACTION] = (float)nclip / (float)n; info[CRUX_INFO_AVG_ADVANTAGE] = orc_jl_mean_f32(T_adv, n);
+    info[CRUX_INFO_AVG_RETURN] = orc_jl_mean_f32(T_ret, n);
+    if (lagr) { float cost_loss = pen * orc_jl_mean_f32(T_cost, n);                                              /* ppo.jl:119 */
       info[CRUX_INFO_LOSS] = ((cfg->lambda_p * p_loss + cfg->lambda_e * e_loss) + cost_loss) / (1.f + pen);          /* :131 */
       info[CRUX_INFO_PENALTY] = pen; info[CRUX_INFO_CUR_COST] = g_lag->cur_cost; info[CRUX_INFO_COST_LOSS] = cost_loss; info[CRUX_INFO_P_LOSS] = cfg->lambda_p * p_loss; }
   }
@@ -1033,6 +1049,7 @@ static int32_t loss_grad(orc_mlp* net, orc_buffer* buf, const crux_train_cfg* cf
   }
   if (net->n_extra) { double sx = 0; for (int i = 0; i < net->n_extra; ++i) sx += (double)net->g[xoff(net) + i] * net->g[xoff(net) + i]; float nx = (float)sqrt(sx); tot += (double)nx * nx; }
   info[CRUX_INFO_GRAD_NORM] = (float)sqrt(tot);
+  free(T_);
   return CRUX_OK;
 #undef LG_BEGIN
 #undef LG_END

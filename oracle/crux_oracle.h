@@ -98,6 +98,9 @@ int32_t orc_fill_importance_weights(orc_buffer* b);                             
 int32_t orc_fill_gae_keys(orc_buffer* b, orc_mlp* critic, float lambda, float gamma, int32_t source, int32_t target);
 int32_t orc_fill_returns_keys(orc_buffer* b, float gamma, int32_t source, int32_t target);
 int32_t orc_whiten(orc_buffer* b, int32_t key);
+float orc_jl_sum_f32(const float* a, int64_t n);    /* [3P] Base.mapreduce_impl(identity, +, ...): pairwise above 1024 elements, left to right below, Float32 */
+float orc_jl_mean_f32(const float* a, int64_t n);   /* Statistics.mean */
+float orc_jl_std_f32(const float* a, int64_t n);    /* Statistics.std (corrected) */
 /* fill_gae! on one explicit range with given V(s), V(sp) (sampler.jl:262-273) -- KAT helper. */
 void orc_gae_range(const float* r, const uint8_t* done, const float* Vs, const float* Vsp, int64_t start, int64_t stop,
                    float lambda, float gamma, float* adv);

@@ -46,6 +46,7 @@ _SIG = {
     "orc_buffer_push_reservoir": (i32, [vp, i64, P(vp), i32, u64, u64]),
     "orc_gail_d_step": (i32, [vp, vp, i64, i64, vp, i64, i64, vp]), "orc_gail_reward": (i32, [vp, vp, f32, f32, vp]),
     "orc_linear_decay": (f64, [f64, f64, i64, i64]),
+    "orc_jl_sum_f32": (f32, [vp, i64]), "orc_jl_mean_f32": (f32, [vp, i64]), "orc_jl_std_f32": (f32, [vp, i64]),
     "orc_perm": (None, [u64, u64, u32, vp]), "orc_philox": (None, [u64, u64, u32, u32, vp]),
 }
 

@@ -218,11 +218,25 @@ def test_gae_returns_whiten_match_oracle_on_random_episodes(gpu_ctx):
     assert np.abs(gb["advantage"] - ob["advantage"]).max() < 5e-5       # depends on V(s) (fp32 GEMM tolerance)
     crux.whiten_(gb, "advantage"); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
     a = gb["advantage"][0]
-    assert np.abs(a - ob["advantage"][0]).max() < 2e-5 and abs(a.mean()) < 1e-5 and abs(a.std(ddof=1) - 1) < 1e-5
+    assert np.abs(a - ob["advantage"][0]).max() < 2e-5 and abs(a.mean()) < 1e-5 and abs(a.std(ddof=1) - 1) < 1e-5      # (different inputs: the advantages above agree to 5e-5; identical inputs whiten bit for bit, below)
     gb["r"] = np.full((1, n), np.nan, np.float32)
     with pytest.raises(crux.CruxError) as e:
         crux.fill_gae_(gb, gc, 0.95, 0.99)
     assert e.value.code == L.ENAN                                       # @assert !isnan(A)
+
+
+@pytest.mark.parametrize("n", [2, 1000, 1480, 1025, 65536, 100003, 262144])
+def test_whiten_is_julias_pairwise_float32_bit_for_bit(gpu_ctx, n):
+    """whiten(v) = (v .- mean(v)) ./ std(v) (utils.jl:41-42) with Statistics.mean / std as Julia evaluates them on a Float32 vector (Base's pairwise sum, block 1024): the
+    kernel and the oracle agree on every bit of the whitened column, for lengths on both sides of the block size and off the powers of two"""
+    rng = np.random.default_rng(n); extras = ["return", "logprob", "advantage"]
+    gb = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), n, extras); ob = O.OBuffer(4, 2, L.ACTION_DISCRETE, n, extras)
+    d = _rand_data(rng, n, 4, 2, True, extras); d["advantage"] = (rng.standard_normal((1, n)) * 2.5 + 0.3).astype(np.float32)
+    gb.push_(d); ob.push(d)
+    crux.whiten_(gb, "advantage"); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
+    assert np.array_equal(gb["advantage"].view(np.uint32), ob["advantage"].view(np.uint32))
+    a = gb["advantage"][0].astype(np.float64)
+    assert abs(a.mean()) < 1e-5 and abs(a.std(ddof=1) - 1) < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------------- learner

@@ -108,6 +108,41 @@ def test_pairwise_cumsum_matches_float64_and_leaf_form():
 
 
 # ---- GAE / returns KAT derived from src/sampler.jl:262-281 ----------------------------------------
+def _jl_mapreduce(a, f=lambda x: x):
+    """Base.mapreduce_impl(f, +, A, ifirst, ilast, 1024) (reduce.jl) spelled out independently in numpy Float32 scalars: at most 1024 elements from the left, otherwise split at
+    ifirst + (ilast - ifirst) >> 1"""
+    def rec(i0, i1):
+        if i0 == i1:
+            return np.float32(f(a[i0]))
+        if i1 - i0 < 1024:
+            v = np.float32(f(a[i0])) + np.float32(f(a[i0 + 1]))
+            for i in range(i0 + 2, i1 + 1):
+                v = np.float32(v + np.float32(f(a[i])))
+            return v
+        mid = i0 + ((i1 - i0) >> 1)
+        return np.float32(rec(i0, mid) + rec(mid + 1, i1))
+    return rec(0, len(a) - 1)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 1000, 1024, 1025, 2049, 3000, 65536, 100003])
+def test_julia_order_reductions(n):
+    """[3P] the oracle's mean / std are Julia's: Statistics.mean = sum(A) / length(A) with Base's pairwise Float32 sum (block 1024), Statistics.std =
+    sqrt(centralize_sumabs2(A, m) / (n - 1)) with the same scheme -- not a Float64 accumulation rounded at the end"""
+    rng = np.random.default_rng(n); a = (rng.standard_normal(n) * 3 + 0.7).astype(np.float32)
+    s = _jl_mapreduce(a)
+    assert np.float32(O.lib().orc_jl_sum_f32(O.vpz(a), n)) == s
+    m = np.float32(s / np.float32(n))
+    assert np.float32(O.lib().orc_jl_mean_f32(O.vpz(a), n)) == m
+    if n >= 2:
+        ss = _jl_mapreduce(a, lambda x: np.float32(np.float32(x - m) * np.float32(x - m)))
+        assert np.float32(O.lib().orc_jl_std_f32(O.vpz(a), n)) == np.float32(np.sqrt(np.float32(ss / np.float32(n - 1))))
+    if n >= 65536:      # and it is not the left-to-right Float32 sum, nor the Float64 sum rounded (what the oracle did before round 5) -- the three differ at this length
+        seq = np.float32(0)
+        for x in a[:4096]:
+            seq = np.float32(seq + x)
+        assert abs(float(s) - float(a.astype(np.float64).sum())) < 1e-3 * np.sqrt(n)
+
+
 def test_gae_and_returns_kat():
     r = np.full(5, 6, np.float32); d = np.ones(5, np.uint8); V = np.zeros(5, np.float32); adv = np.zeros(5, np.float32); ret = np.zeros(5, np.float32)
     lib.orc_gae_range(O.vpz(r), O.vpz(d), O.vpz(V), O.vpz(V), 0, 4, 0.9, 0.7, O.vpz(adv))
