@@ -447,7 +447,7 @@ def _post_sample(solver, n, info):
 
 
 def _solve_off_policy(solver, mdp):
-    """POMDPs.solve(S::OffPolicySolver, mdp) (src/model_free/off_policy.jl:113-150), logging left out."""
+    """POMDPs.solve(S::OffPolicySolver, mdp) (src/model_free/off_policy.jl:113-150), with the log points of :130 and :146 (crux.jl_amd/logging.py)."""
     gamma = np.float32(discount(mdp))
     if solver.batch is None:
         solver.batch = buffer_like(solver.buffer, capacity=solver.c_opt.batch_size)                     # :115
