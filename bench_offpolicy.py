@@ -117,17 +117,25 @@ def c3(crux, ctx, cpu=True, steps=300):
     return out
 
 
-def c3_solve(crux, ctx, iters=600, ring=200_000):
-    """Whole solve(DQN + prioritized replay) iterations at the C3 shapes (steps! of dN = 4 environment steps with eps-greedy exploration, push! with max priority, four
-    value_training epochs, polyak): the iteration loop enqueues every chain without waiting for it (crux_dqn_epochs_async) -- wall time per iteration."""
+def c3_solve(crux, ctx, iters=600, ring=1_000_000):
+    """Whole solve(DQN + prioritized replay) iterations at the C3 shapes and at the ring size BASELINE names (1 M transitions, full): steps! of dN = 4 environment steps with
+    eps-greedy exploration, push! with max priority, four value_training epochs, polyak. The iteration loop enqueues every chain without waiting for it (crux_dqn_epochs_async) --
+    wall time per iteration. The ring is filled once with synthetic transitions and a non-trivial priority landscape (a 1 M-step rollout of one environment would only add
+    seconds to the run; the iterations timed afterwards are the same)."""
     mdp = crux.SynthMDP(8, 4, discrete=True, n_envs=1, seed=3)
     q = crux.DiscreteNetwork(_chain(crux, [8, 256, 256, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=1)
     out = {}
+    rng = np.random.default_rng(5)
+    d = {"s": rng.standard_normal((8, ring)).astype(np.float32), "sp": rng.standard_normal((8, ring)).astype(np.float32), "r": rng.standard_normal((1, ring)).astype(np.float32),
+         "done": rng.random((1, ring)) < 0.05, "episode_end": rng.random((1, ring)) < 0.05}
+    a = np.zeros((4, ring), np.bool_); a[rng.integers(0, 4, ring), np.arange(ring)] = True; d["a"] = a
+    I = rng.choice(ring, ring // 5, replace=False).astype(np.int64); v = np.abs(rng.standard_normal(I.size)) + 1e-3
     for asyn in (True, False):
-        sv = crux.DQN(q, crux.ContinuousSpace(8), N=4 * 50, dN=4, buffer_size=ring, buffer_init=ring, prioritized=True, weighted_loss=True, max_steps=200,
+        buf = crux.ExperienceBuffer(crux.ContinuousSpace(8), crux.DiscreteSpace(4), ring, prioritized=True); buf.push_(d); buf.update_priorities_(I + 1, v)
+        sv = crux.DQN(q, crux.ContinuousSpace(8), N=4 * 50, dN=4, buffer=buf, buffer_init=ring, prioritized=True, weighted_loss=True, max_steps=200,
                       c_opt={"batch_size": 128, "optimizer": crux.Adam(np.float32(1e-3))})
         sv.async_training = asyn
-        crux.solve(sv, mdp); ctx.sync()                          # ring fill + warm-up
+        crux.solve(sv, mdp); ctx.sync()                          # warm-up
         sv.N = 4 * iters
         t0 = time.perf_counter(); crux.solve(sv, mdp); ctx.sync(); t = time.perf_counter() - t0
         out["us_per_iteration" if asyn else "us_per_iteration_synchronous_loop"] = 1e6 * t / iters

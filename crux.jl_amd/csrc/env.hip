@@ -67,8 +67,35 @@ __device__ __forceinline__ void gridworld_step(const double* s, int a, double u,
 }
 // SYNTH: see include/cruxhip.h for the definition (the oracle's synth_step is the twin)
 __device__ __forceinline__ bool env_is_synth(int kind) { return kind == CRUX_ENV_SYNTH || kind == CRUX_ENV_SYNTH_DISCRETE; }
-__device__ __forceinline__ void synth_step(int so, int sa, bool discrete, const double* s, int ai, const float* a, double* sn, float* r, uint8_t* done) {
+__device__ __forceinline__ void env_writelane(uint32_t& dst, const uint32_t uniform_v, const int l) {      // dst[lane l] = the (wave-uniform) value
+  const int sv = __builtin_amdgcn_readfirstlane((int)uniform_v);
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sv), "n"(l));
+}
+__device__ __forceinline__ double env_readlane_f64(const double v, const int l) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+// par_lane >= 0: the whole wave executes this with identical arguments in every lane (the register-resident rollout kernels); lane i evaluates element i -- the Float64 sin
+// is the cost of the step -- and the elements are collected with v_readlane (so, sa compile-time there). The same operations per element: the same bits.
+__device__ __forceinline__ void synth_step(int so, int sa, bool discrete, const double* s, int ai, const float* a, double* sn, float* r, uint8_t* done, const int par_lane = -1) {
   double ss = 0.0;
+  if (par_lane >= 0) {
+    // lane i takes s[i] and s[i+1] with v_writelane (a select chain over the lane id is turned into an indexed load of the state array, which then lives in scratch)
+    uint32_t il = 0, ih = 0, jl = 0, jh = 0; double u = 0.0;
+#pragma unroll
+    for (int i = 0; i < so; ++i) { const uint64_t bi = __builtin_bit_cast(uint64_t, s[i]), bj = __builtin_bit_cast(uint64_t, s[(i + 1) % so]);
+      env_writelane(il, (uint32_t)bi, i); env_writelane(ih, (uint32_t)(bi >> 32), i); env_writelane(jl, (uint32_t)bj, i); env_writelane(jh, (uint32_t)(bj >> 32), i); }
+    const double si = __builtin_bit_cast(double, ((uint64_t)ih << 32) | il), sj = __builtin_bit_cast(double, ((uint64_t)jh << 32) | jl);
+    const int ii = par_lane < so ? par_lane : 0;
+    if (discrete) u = ((ii + ai) % sa == 0) ? 1.0 : -0.25;
+    else { float av = a[0];
+#pragma unroll
+      for (int q = 0; q < sa; ++q) if (ii % sa == q) av = a[q]; u = (double)av; if (u < -1.0) u = -1.0; if (u > 1.0) u = 1.0; }
+    const double mine = __dadd_rn(__dmul_rn(0.9, si), __dmul_rn(0.1, sin(__dadd_rn(sj, u))));
+#pragma unroll
+    for (int i = 0; i < so; ++i) { sn[i] = env_readlane_f64(mine, i); ss = __dadd_rn(ss, __dmul_rn(sn[i], sn[i])); }
+  } else
   for (int i = 0; i < so; ++i) {
     double u;
     if (discrete) u = ((i + ai) % sa == 0) ? 1.0 : -0.25;
@@ -189,8 +216,8 @@ __device__ __forceinline__ void rollout_head(const RolloutArgs& a, const float* 
 // episode bookkeeping. `writer` lanes store to the buffer; all callers advance identical copies of the sampler state.
 __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* z, const int od, const int ad, const int nout, const int kind, const int e,
                                              const int64_t t, const int64_t j, const bool writer, double* st, int64_t& ep_len, int64_t& n_resets,
-                                             int64_t& steps_taken, double& sum_r, int64_t& nee, float* next_obs) {
-  const int sd = kind == CRUX_ENV_CARTPOLE ? 4 : (env_is_synth(kind) ? a.sd : 2);
+                                             int64_t& steps_taken, double& sum_r, int64_t& nee, float* next_obs, const int par_lane = -1) {
+  const int sd = kind == CRUX_ENV_CARTPOLE ? 4 : (env_is_synth(kind) ? od : 2);      // (SYNTH keeps one Float64 per observation: a compile-time od makes the state array registers)
       const uint64_t gi = a.cfg.i0 + (uint64_t)t * (uint64_t)a.E + (uint64_t)e;    // i + (j-1), env-minor (sampler.jl:161-163)
       const uint64_t ctr = (uint64_t)steps_taken;
       float logprob; int ai; float aout[ENV_MAXOBS];
@@ -199,7 +226,7 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
       double sn[ENV_MAXSD]; float r; uint8_t done; float o[ENV_MAXOBS], spv[ENV_MAXOBS];
       if (kind == CRUX_ENV_CARTPOLE) cartpole_step(st, ai, sn, &r, &done);
       else if (kind == CRUX_ENV_PENDULUM) pendulum_step(st, aout[0], sn, &r, &done);
-      else if (env_is_synth(kind)) synth_step(od, ad, kind == CRUX_ENV_SYNTH_DISCRETE, st, ai, aout, sn, &r, &done);
+      else if (env_is_synth(kind)) synth_step(od, ad, kind == CRUX_ENV_SYNTH_DISCRETE, st, ai, aout, sn, &r, &done, par_lane);
       else { const crux_u32x4 xd = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_ENVDYN); gridworld_step(st, ai, crux_u32x2_to_f64(xd.v[0], xd.v[1]), sn, &r, &done); }
       env_obs(kind, sn, o, od);
       for (int q = 0; q < od; ++q) spv[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
@@ -225,7 +252,7 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
       uint8_t ee = 0;
       if (done || ep_len >= a.max_steps) {
         ee = 1; ++nee;
-        env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st, a.sd); n_resets += 1; ep_len = 0;
+        env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st, sd); n_resets += 1; ep_len = 0;
         env_obs(kind, st, o, od);
         for (int q = 0; q < od; ++q) next_obs[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
       } else {
@@ -234,7 +261,7 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
       }
       if (a.cfg.reset_at_end && t == a.T - 1 && ep_len > 0) {                       // sampler.jl:148
         ee = 1; ++nee;
-        env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st, a.sd); n_resets += 1; ep_len = 0;
+        env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st, sd); n_resets += 1; ep_len = 0;
         env_obs(kind, st, o, od);
         for (int q = 0; q < od; ++q) next_obs[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
       }
@@ -306,7 +333,7 @@ __global__ __launch_bounds__(64) void k_rollout_h64(RolloutArgs a_single, const 
     }
     float z[OUT];
     h64_forward<IN, OUT, ACT>(w1, w2, w3, b3, b1, b2, x, sh, lane, z);
-    rollout_tail(a, z, IN, OUT, OUT, KIND, e, t, j, lane == 0, st, ep_len, n_resets, steps_taken, sum_r, nee, nx);
+    rollout_tail(a, z, IN, OUT, OUT, KIND, e, t, j, lane == 0, st, ep_len, n_resets, steps_taken, sum_r, nee, nx, lane);
 #pragma unroll
     for (int k = 0; k < IN; ++k) x[k] = nx[k];
   }
@@ -339,6 +366,13 @@ __device__ __forceinline__ int rollout_generic_forward(const RolloutArgs& a, con
       const float* Wl = a.p + nd.woff[l]; const float* bl = a.p + nd.boff[l];
       for (int o = lane; o < out; o += NT) {
         float accv = 0.f; int k = 0;
+        if (NT > 64) {                         // wide layers (one workgroup per environment): 32 independent weight loads in flight -- a batch-1 layer is a chain of L2 round trips,
+          for (; k + 32 <= in; k += 32) {      // and its length is in / (loads in flight); the fma chain keeps its order, so the result keeps its bits
+            float wv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) wv[u] = Wl[o + out * (k + u)];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) accv = fmaf(wv[u], hbuf[cur][k + u], accv); } }
         for (; k + 8 <= in; k += 8) {          // eight independent weight loads in flight; the fma chain keeps its order
           float wv[8];
 #pragma unroll
@@ -379,6 +413,7 @@ __device__ __forceinline__ void rollout_generic_wave(const RolloutArgs& a, const
       if (a.kind == CRUX_ENV_CARTPOLE && od == 4 && ad == 2 && nout == 2) rollout_tail(a, hbuf[cur], 4, 2, 2, CRUX_ENV_CARTPOLE, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
       else if (a.kind == CRUX_ENV_GRIDWORLD && od == 2 && ad == 4 && nout == 4) rollout_tail(a, hbuf[cur], 2, 4, 4, CRUX_ENV_GRIDWORLD, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
       else if (a.kind == CRUX_ENV_PENDULUM && od == 3 && ad == 1 && nout == 1) rollout_tail(a, hbuf[cur], 3, 1, 1, CRUX_ENV_PENDULUM, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
+      else if (a.kind == CRUX_ENV_SYNTH_DISCRETE && od == 8 && ad == 4 && nout == 4) rollout_tail(a, hbuf[cur], 8, 4, 4, CRUX_ENV_SYNTH_DISCRETE, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
       else rollout_tail(a, hbuf[cur], od, ad, nout, a.kind, e, t, j, true, st, ep_len, n_resets, steps_taken, sum_r, nee, sh_misc);
     }
     RO_SYNC();
@@ -405,6 +440,135 @@ __global__ __launch_bounds__(256) void k_rollout_wide(RolloutArgs a) {
   __shared__ float hbuf[2][1024];
   __shared__ float sh_misc[ENV_MAXOBS + 8];
   rollout_generic_wave<256>(a, blockIdx.x, threadIdx.x, hbuf, sh_misc);
+}
+
+// ---- register-resident WIDE policy: IN -> H -> H -> OUT with H = 256 or 128 (the off-policy configurations C3 / C4: 8->256->256->4, 3->256->256->1) -------------------------
+// One workgroup of 256 threads (one wave per SIMD: up to 512 registers per thread) per environment. Thread o keeps row o of W1 and of W2 -- H weights of the second layer -- in
+// registers for the whole launch and evaluates unit o of both hidden layers with the generic kernels' arithmetic (fma over k ascending, + bias, activation: the same bits); the
+// output layer's weights sit in LDS. A batch-1 layer streamed from the L2 is a chain of H / (loads in flight) round trips per step (k_rollout_wide: 20 us per step at H = 256);
+// from registers it is H fma. steps!(sampler, buffer; Nsteps = dN) of an off-policy solve calls this with T = dN = 4..50 steps per launch.
+__device__ __forceinline__ void env_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // LDS traffic only: does not wait for the column stores
+__device__ __forceinline__ float env_readlane(const float v, const int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+// acc = fma(w[i], h[L0 + i], acc) for i = 0..7, h[l] = lane l of hreg: v_readlane into a scalar register, v_fmac with it as the scalar operand (the product commutes: the bits
+// of fmaf(w, h, acc)). Written out because the scheduler, left alone, hoists every v_readlane of a layer and then spills the scalar registers they fill.
+template <int L0>
+__device__ __forceinline__ void env_rl_fma8(float& acc, const float hreg, const float w0, const float w1, const float w2, const float w3, const float w4, const float w5,
+                                            const float w6, const float w7) {
+  int t0, t1;
+  asm volatile("v_readlane_b32 %[t0], %[h], %[l0]\n\tv_readlane_b32 %[t1], %[h], %[l1]\n\t"
+               "v_fmac_f32_e32 %[acc], %[t0], %[w0]\n\tv_readlane_b32 %[t0], %[h], %[l2]\n\t"
+               "v_fmac_f32_e32 %[acc], %[t1], %[w1]\n\tv_readlane_b32 %[t1], %[h], %[l3]\n\t"
+               "v_fmac_f32_e32 %[acc], %[t0], %[w2]\n\tv_readlane_b32 %[t0], %[h], %[l4]\n\t"
+               "v_fmac_f32_e32 %[acc], %[t1], %[w3]\n\tv_readlane_b32 %[t1], %[h], %[l5]\n\t"
+               "v_fmac_f32_e32 %[acc], %[t0], %[w4]\n\tv_readlane_b32 %[t0], %[h], %[l6]\n\t"
+               "v_fmac_f32_e32 %[acc], %[t1], %[w5]\n\tv_readlane_b32 %[t1], %[h], %[l7]\n\t"
+               "v_fmac_f32_e32 %[acc], %[t0], %[w6]\n\tv_fmac_f32_e32 %[acc], %[t1], %[w7]"
+               : [acc] "+v"(acc), [t0] "=&s"(t0), [t1] "=&s"(t1)
+               : [h] "v"(hreg), [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [w4] "v"(w4), [w5] "v"(w5), [w6] "v"(w6), [w7] "v"(w7),
+                 [l0] "n"(L0), [l1] "n"(L0 + 1), [l2] "n"(L0 + 2), [l3] "n"(L0 + 3), [l4] "n"(L0 + 4), [l5] "n"(L0 + 5), [l6] "n"(L0 + 6), [l7] "n"(L0 + 7));
+}
+template <int H, int K0 = 0>
+__device__ __forceinline__ void env_rl_layer(float& acc, const float (&hr)[H / 64], const float (&w)[H]) {
+  if constexpr (K0 < H) {
+    env_rl_fma8<(K0 & 63)>(acc, hr[K0 >> 6], w[K0], w[K0 + 1], w[K0 + 2], w[K0 + 3], w[K0 + 4], w[K0 + 5], w[K0 + 6], w[K0 + 7]);
+    env_rl_layer<H, K0 + 8>(acc, hr, w);
+  }
+}
+template <int H, int K0 = 0>
+__device__ __forceinline__ void env_rl_layer_lds(float& acc, const float (&hr)[H / 64], const float* wrow) {      // the weights of the row from LDS, 32 at a time
+  if constexpr (K0 < H) {
+    float4 wv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wv[q] = *(const float4*)&wrow[K0 + 4 * q];
+    env_rl_fma8<(K0 & 63)>(acc, hr[K0 >> 6], wv[0].x, wv[0].y, wv[0].z, wv[0].w, wv[1].x, wv[1].y, wv[1].z, wv[1].w);
+    env_rl_fma8<((K0 + 8) & 63)>(acc, hr[K0 >> 6], wv[2].x, wv[2].y, wv[2].z, wv[2].w, wv[3].x, wv[3].y, wv[3].z, wv[3].w);
+    env_rl_fma8<((K0 + 16) & 63)>(acc, hr[K0 >> 6], wv[4].x, wv[4].y, wv[4].z, wv[4].w, wv[5].x, wv[5].y, wv[5].z, wv[5].w);
+    env_rl_fma8<((K0 + 24) & 63)>(acc, hr[K0 >> 6], wv[6].x, wv[6].y, wv[6].z, wv[6].w, wv[7].x, wv[7].y, wv[7].z, wv[7].w);
+    env_rl_layer_lds<H, K0 + 32>(acc, hr, wrow);
+  }
+}
+template <int H>
+__global__ __launch_bounds__(256) void k_rollout_res(RolloutArgs a) {
+  __shared__ __attribute__((aligned(16))) float hb[2][H];      // the hidden activations of the two layers
+  __shared__ __attribute__((aligned(16))) float w3s[ENV_MAXOBS * (H + 4)];      // row o of W3 contiguous (+4: the nout rows start in different banks)
+  __shared__ float xin[ENV_MAXOBS];
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const NetDesc& nd = a.nd; const int od = a.od, nout = nd.dims[3];
+  const bool on = tid < H;
+  float w1[8], w2[H];      // (obs_dim <= 8 for the shapes dispatched here)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w1[k] = (on && k < od) ? a.p[nd.woff[0] + tid + H * k] : 0.f;
+#pragma unroll
+  for (int k = 0; k < H; ++k) w2[k] = on ? a.p[nd.woff[1] + tid + H * k] : 0.f;
+  const float b1 = on ? a.p[nd.boff[0] + tid] : 0.f, b2 = on ? a.p[nd.boff[1] + tid] : 0.f;
+  for (int q = tid; q < nout * H; q += 256) w3s[(q % nout) * (H + 4) + q / nout] = a.p[nd.woff[2] + q];      // W3[o + nout k] in the flat vector -> row o
+  const int row3 = lane < nout ? lane : 0;
+  const float b3 = a.p[nd.boff[2] + row3];
+  const int act1 = nd.acts[0], act2 = nd.acts[1], act3 = nd.acts[2];
+  // wave 0 carries the sampler state, identically in every lane (the head, the dynamics and the bookkeeping are evaluated redundantly; lane 0 writes)
+  double st[ENV_MAXSD]; int64_t ep_len = 0, n_resets = 0, steps_taken = 0; double sum_r = 0.0; int64_t nee = 0;
+  if (tid < 64) {
+#pragma unroll
+    for (int i = 0; i < ENV_MAXSD; ++i) if (i < a.sd) st[i] = a.state[(size_t)e * a.sd + i];
+    ep_len = a.ep_len[e]; n_resets = a.n_resets[e]; steps_taken = a.steps_taken[e]; }
+  if (tid < od) xin[tid] = a.svec[(size_t)e * od + tid];
+  __syncthreads();
+#ifdef CRUX_RES_TIMING
+  long long tk[6] = {0, 0, 0, 0, 0, 0}, t0 = wall_clock64(), t1;
+#define RT(i) { t1 = wall_clock64(); tk[i] += t1 - t0; t0 = t1; }
+#else
+#define RT(i)
+#endif
+  int64_t j = (a.base + (int64_t)e * a.T) % a.C;      // the ring row of step t: (base + e T + t) % C, advanced instead of divided
+  for (int64_t t = 0; t < a.T; ++t, j = j + 1 == a.C ? 0 : j + 1) {
+    if (tid < od) a.S[(size_t)j * od + tid] = xin[tid];      // current observation -> S column (sampler.jl:100)
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < od) acc = fmaf(w1[k], xin[k], acc);
+    if (on) hb[0][tid] = crux_act(act1, acc + b1);
+    env_lds_barrier();
+    RT(0)
+    // layer 2: the H activations sit H / 64 per lane; v_readlane broadcasts h[k] as the scalar operand of the fma (an LDS broadcast read per k is a round trip per k)
+    float hr[H / 64];
+#pragma unroll
+    for (int c = 0; c < H / 64; ++c) hr[c] = hb[0][lane + 64 * c];
+    acc = 0.f;
+    env_rl_layer<H>(acc, hr, w2);
+    if (on) hb[1][tid] = crux_act(act2, acc + b2);
+    env_lds_barrier();
+    RT(1)
+    if (tid < 64) {      // wave 0: the output layer (lane o = unit o; the other lanes repeat unit 0), then everything of step! after the forward pass
+#pragma unroll
+      for (int c = 0; c < H / 64; ++c) hr[c] = hb[1][lane + 64 * c];
+      float z = 0.f;
+      env_rl_layer_lds<H>(z, hr, &w3s[row3 * (H + 4)]);
+      z = crux_act(act3, z + b3);
+      RT(2)
+      float zz[4], nx[ENV_MAXOBS];
+      // (the host dispatches here only for these two environment shapes)
+      if (a.kind == CRUX_ENV_PENDULUM) { zz[0] = env_readlane(z, 0);
+        rollout_tail(a, zz, 3, 1, 1, CRUX_ENV_PENDULUM, e, t, j, tid == 0, st, ep_len, n_resets, steps_taken, sum_r, nee, nx, lane);
+        if (tid == 0) { xin[0] = nx[0]; xin[1] = nx[1]; xin[2] = nx[2]; } }
+      else { zz[0] = env_readlane(z, 0); zz[1] = env_readlane(z, 1); zz[2] = env_readlane(z, 2); zz[3] = env_readlane(z, 3);
+        rollout_tail(a, zz, 8, 4, 4, CRUX_ENV_SYNTH_DISCRETE, e, t, j, tid == 0, st, ep_len, n_resets, steps_taken, sum_r, nee, nx, lane);
+        if (tid == 0) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xin[q] = nx[q]; } }
+      RT(3)
+    }
+    env_lds_barrier();
+    RT(4)
+  }
+#ifdef CRUX_RES_TIMING
+  if (tid == 0 && e == 0) printf("[res-timing] T=%lld ticks: l1 %lld l2 %lld l3 %lld tail %lld bar %lld\n", (long long)a.T, tk[0], tk[1], tk[2], tk[3], tk[4]);
+#endif
+#undef RT
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < ENV_MAXSD; ++i) if (i < a.sd) a.state[(size_t)e * a.sd + i] = st[i];
+    a.ep_len[e] = ep_len; a.n_resets[e] = n_resets; a.steps_taken[e] = steps_taken;
+    a.acc[2 * e] = sum_r; a.acc[2 * e + 1] = (double)nee; }
+  if (tid < od) a.svec[(size_t)e * od + tid] = xin[tid];
 }
 
 // ---- caller-stepped environments: step! with an arbitrary mdp on the host (sampler.jl:71-137) ----------------------------------------------------------------
@@ -861,7 +1025,13 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
   RO_CASE(17, 6, CRUX_ACT_TANH, CRUX_ENV_SYNTH)       // C5-shaped: 17 obs / 6 continuous actions
   RO_CASE(17, 6, CRUX_ACT_RELU, CRUX_ENV_SYNTH)
 #undef RO_CASE
-  if (policy->nd.maxdim >= 128) hipLaunchKernelGGL(k_rollout_wide, dim3(e->n_envs), dim3(256), 0, c->stream, a);
+  // wide two-hidden-layer policies (C3 / C4): the register-resident kernel when the launch is long enough to pay for loading W2 into registers (a step costs 8 round trips
+  // streamed; the load costs 8 once) -- always, from two steps on
+  if (pn.L == 3 && pn.dims[1] == pn.dims[2] && (pn.dims[1] == 256 || pn.dims[1] == 128) && T >= 2 && !crux_sw().force_generic &&
+      ((e->kind == CRUX_ENV_PENDULUM && e->obs_dim == 3 && e->act_dim == 1 && nout == 1) || (e->kind == CRUX_ENV_SYNTH_DISCRETE && e->obs_dim == 8 && e->act_dim == 4 && nout == 4))) {
+    if (pn.dims[1] == 256) hipLaunchKernelGGL(k_rollout_res<256>, dim3(e->n_envs), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_rollout_res<128>, dim3(e->n_envs), dim3(256), 0, c->stream, a); }
+  else if (policy->nd.maxdim >= 128) hipLaunchKernelGGL(k_rollout_wide, dim3(e->n_envs), dim3(256), 0, c->stream, a);
   else hipLaunchKernelGGL(k_rollout, dim3(e->n_envs), dim3(64), 0, c->stream, a);
   crux_prof_end(c, CRUX_PROF_ROLLOUT);
   int32_t rc = crux_launch_check(c, "k_rollout"); if (rc) return rc;

@@ -11,7 +11,14 @@ mdp = crux.SynthMDP(8, 4, discrete=True, n_envs=1, seed=3)
 S = crux.ContinuousSpace(8)
 q = crux.DiscreteNetwork(chain([8, 256, 256, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=1)
 iters = int(os.environ.get("C3S_ITERS", "600"))
-sv = crux.DQN(q, S, N=4 * iters, dN=4, buffer_size=N_BUF, buffer_init=N_BUF, prioritized=True, weighted_loss=True, max_steps=200,
+buf = None
+if os.environ.get("C3S_PREFILL"):      # fill the ring with synthetic transitions instead of a rollout of N_BUF steps
+    rng = np.random.default_rng(5)
+    d = {"s": rng.standard_normal((8, N_BUF)).astype(np.float32), "sp": rng.standard_normal((8, N_BUF)).astype(np.float32), "r": rng.standard_normal((1, N_BUF)).astype(np.float32),
+         "done": rng.random((1, N_BUF)) < 0.05, "episode_end": rng.random((1, N_BUF)) < 0.05}
+    a = np.zeros((4, N_BUF), np.bool_); a[rng.integers(0, 4, N_BUF), np.arange(N_BUF)] = True; d["a"] = a
+    buf = crux.ExperienceBuffer(S, crux.DiscreteSpace(4), N_BUF, prioritized=True); buf.push_(d)
+sv = crux.DQN(q, S, N=4 * iters, dN=4, buffer_size=N_BUF, buffer=buf, buffer_init=N_BUF, prioritized=True, weighted_loss=True, max_steps=200,
               c_opt={"batch_size": 128, "optimizer": crux.Adam(np.float32(1e-3))})
 ctx = q.ctx
 t0 = time.perf_counter(); crux.solve(sv, mdp); ctx.sync(); t1 = time.perf_counter()          # first call: fills the ring (buffer_init) + iterations
