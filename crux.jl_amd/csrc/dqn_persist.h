@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_dqn_learn(DqpArgs a) {
     // (everything another compute unit wrote -- batch rows, the exchange areas -- is read with L1-bypassing loads below: a CU's vector L1 is never refreshed by other
     //  CUs' stores, and the agent-scope invalidate costs ~1.5 us per use)
     for (int q = tid; q < B * IN; q += 256) { const int s = q / IN, k = q - s * IN; sm[L::oX + s * XLD + k] = NT(&a.S[q]); sm[L::oXP + s * XLD + k] = NT(&a.SP[q]); }
-    if (IN < L::IP) { for (int q = tid; q < B * (L::IP - IN); q += 256) { const int s = q / (L::IP - IN), k = IN + q % (L::IP - IN); sm[L::oXP + s * XLD + k] = 0.f; } }      // (the union is reused: the pad columns of s' again)
+    if constexpr (IN < L::IP) { for (int q = tid; q < B * (L::IP - IN); q += 256) { const int s = q / (L::IP - IN), k = IN + q % (L::IP - IN); sm[L::oXP + s * XLD + k] = 0.f; } }      // (the union is reused: the pad columns of s' again)
     float rr = 0.f, ww = 1.f; unsigned amask = 0, dn = 0;
     if (tid < B) { rr = NT(&a.R[tid]); dn = NT(&a.DONE[tid]); ww = a.W ? NT(&a.W[tid]) : 1.f;
 #pragma unroll

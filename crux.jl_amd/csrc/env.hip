@@ -13,6 +13,7 @@ int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>
 void crux_buffer_ring_advance(crux_buffer* b, int64_t N);
 int32_t crux_buffer_per_on_push(crux_buffer* b, const int64_t* d_I, int64_t N);
 int32_t crux_buffer_ring_ids_device(crux_buffer* b, int64_t N, int64_t* d_out);
+bool crux_per_push_fused(crux_buffer* b, int64_t n, int64_t* d_ids);
 
 #define ENV_MAXSD 32          // SYNTH keeps one Float64 per observation; CartPole 4, Pendulum / GridWorld 2
 #define ENV_MAXOBS 32
@@ -1036,8 +1037,10 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
   crux_prof_end(c, CRUX_PROF_ROLLOUT);
   int32_t rc = crux_launch_check(c, "k_rollout"); if (rc) return rc;
   if (buf->prioritized) {      // push!: the new rows get max_priority (experience_buffer.jl:254); their ring rows are formed on the device, nothing to wait for
-    rc = crux_buffer_ring_ids_device(buf, N, buf->d_indices); if (rc) return rc;
-    rc = crux_buffer_per_on_push(buf, buf->d_indices, N); if (rc) return rc;
+    if (crux_per_push_fused(buf, N, buf->d_indices)) { rc = crux_launch_check(c, "k_push_touch"); if (rc) return rc; }      // a few rows: the whole bookkeeping as one launch
+    else {
+      rc = crux_buffer_ring_ids_device(buf, N, buf->d_indices); if (rc) return rc;
+      rc = crux_buffer_per_on_push(buf, buf->d_indices, N); if (rc) return rc; }
   }
   crux_buffer_ring_advance(buf, N);
   if (sum_r || n_episode_end) {

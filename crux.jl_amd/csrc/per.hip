@@ -19,6 +19,7 @@
 // binary search would. Per sampled step at N = 1 M: <= 128 x 127 x 8 B of leaf traffic + a few KB of node totals and probes instead of 8 MB.
 #include "common.h"
 #include "exec.h"
+#include "ops_small.h"
 #include <algorithm>
 
 int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I);
@@ -217,6 +218,37 @@ struct LeafTouchOp { static __device__ __forceinline__ void run(const unsigned b
 } };
 __global__ __launch_bounds__(256) void k_leaf_touch(const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev, float* __restrict__ run, float* __restrict__ total, unsigned* __restrict__ ticket) { LeafTouchOp::run(blockIdx.x, gridDim.x, v, ids, n, N, nlev, run, total, ticket); }
 __global__ __launch_bounds__(1024) void k_tree_touch(const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev, float* __restrict__ total) { TreeTouchOp::run(blockIdx.x, gridDim.x, ids, n, N, nlev, total); }
+// push!'s priority bookkeeping for n <= 256 freshly written ring rows as ONE launch of one workgroup (an off-policy solve pushes dN = 4..50 rows per iteration; as separate launches --
+// ring rows, max-priority snapshot, update_priorities!, leaf re-sum, root paths -- it was five kernel boundaries of ~5 us for a few hundred bytes of work): ids[j] = (base + j) % C
+// (experience_buffer.jl:236), priorities[ids] = (max_priority + eps)^alpha with max_priority read once before (:254, :290-301), and -- touch != 0: the tree is in its incremental
+// state (crux_per_touched) -- the touched leaves' running sums and the totals along their root paths. The bodies are the stand-alone kernels' own, run back to back in one
+// compute unit (write-through L1: fence + workgroup barrier order them).
+__global__ __launch_bounds__(1024) void k_push_touch(int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C, float* pr, float* pminmax, float alpha, int64_t N, int nlev,
+                                                     float* run, float* total, int touch) {
+  if (threadIdx.x == 0) pminmax[2] = pminmax[0];
+  if ((int64_t)threadIdx.x < n) ids[threadIdx.x] = (base + (int64_t)threadIdx.x) % C;
+  __threadfence_block(); __syncthreads();
+  PerUpdateOp::run(0u, 1u, pr, pminmax, ids, (const double*)nullptr, (const float*)nullptr, (const float*)(pminmax + 2), alpha, n);
+  if (!touch) return;
+  __threadfence_block(); __syncthreads();
+  for (unsigned b = 0; (int64_t)b * (blockDim.x >> 6) < n; ++b) LeafRefreshOp::run(b, 1u, pr, ids, n, N, nlev, run, total);
+  __threadfence_block(); __syncthreads();
+  TreeTouchOp::run(0u, 1u, ids, n, N, nlev, total);
+}
+// host side of k_push_touch: false when the call is not of that shape (the caller then runs the separate steps)
+bool crux_per_push_fused(crux_buffer* b, int64_t n, int64_t* d_ids) {
+  if (!b->prioritized || n < 1 || n > 256 || !d_ids || crux_exec_recording(b->ctx) || !crux_sw().push_fused) return false;
+  // the conditions of crux_per_touched(from_push = true), evaluated before the ring advances
+  int touch = 1;
+  if (b->elements < b->capacity) touch = 0;
+  else if (b->per_full_dirty || b->topo_n < 2 || b->per_run_n != b->topo_n || b->topo_n != b->elements || b->topo_levels > CRUX_PER_PMAX) touch = 0;
+  hipLaunchKernelGGL(k_push_touch, dim3(1), dim3(1024), 0, b->ctx->stream, d_ids, n, b->next_ind, b->capacity, b->priorities, b->pminmax, b->alpha, (int64_t)b->topo_n, (int)b->topo_levels,
+                     b->cumsum, b->topo_total, touch);
+  b->cumsum_valid = false;
+  if (!touch) b->per_full_dirty = true;
+  return true;
+}
+
 // prefix of a leaf = _accumulate_pairwise!'s s at that leaf: v[1], then + total(left sibling) at every right turn of the root path, top-down. The node of the path
 // at level q is id >> (depth - q); it is a right child when odd and its left sibling is the slot before it. Branch-free: a left turn (or a level below the leaf)
 // reads slot 0 of the totals, which holds +0 and leaves the positive sum unchanged bit for bit. All loads are independent (one round trip).

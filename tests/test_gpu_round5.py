@@ -154,3 +154,28 @@ def test_c3_solve_on_the_one_million_row_prioritized_ring(gpu_ctx, forced):
               % (first_idx_diff, first_row_diff, np.mean(gl[-20:]), np.mean(ol[-20:])))
         assert first_idx_diff is None or first_idx_diff >= 2
         assert abs(np.mean(gl[-20:]) - np.mean(ol[-20:])) < 0.5 * max(np.mean(gl[-20:]), np.mean(ol[-20:])) and np.isfinite(g.get_params()).all()
+
+
+def _small_per_solve(N=4096, iters=24, dN=4, seed=5):
+    """a DQN + PER solve on a FULL ring of N rows (the incremental tree, crux_per_touched): parameters, priorities, the materialised cumsum and the sampled ids afterwards"""
+    rng = np.random.default_rng(17); od, ad, B = 8, 4, 64
+    g, _ = parity.make_pair([8, 256, 256, 4], ["relu", "relu", "identity"], 23, 0, "discrete")
+    S, A = crux.ContinuousSpace(od), crux.DiscreteSpace(ad)
+    buf = crux.ExperienceBuffer(S, A, N, prioritized=True)
+    d = {"s": rng.standard_normal((od, N)).astype(np.float32), "sp": rng.standard_normal((od, N)).astype(np.float32), "r": rng.standard_normal((1, N)).astype(np.float32),
+         "done": rng.random((1, N)) < 0.05, "episode_end": rng.random((1, N)) < 0.05}
+    a = np.zeros((ad, N), np.bool_); a[rng.integers(0, ad, N), np.arange(N)] = True; d["a"] = a
+    buf.push_(d)
+    sv = crux.DQN(g, S, N=dN * iters, dN=dN, buffer=buf, buffer_init=N, prioritized=True, weighted_loss=True, max_steps=50, c_opt={"batch_size": B, "optimizer": crux.Adam(np.float32(1e-3))})
+    crux.solve(sv, crux.SynthMDP(8, 4, discrete=True, n_envs=1, seed=seed))
+    pp = buf.priority_params()
+    return g.get_params(), pp["priorities"][:N].copy(), buf.cumsum()[:N].copy(), float(pp["max_priority"]), float(pp["min_priority"]), sv.batch.indices[:B].copy(), buf["s"].copy()
+
+
+def test_push_bookkeeping_as_one_launch_equals_the_separate_launches(gpu_ctx, monkeypatch):
+    """push!'s priority bookkeeping for the dN rows of an off-policy iteration (ring rows, max-priority snapshot, update_priorities!, leaf re-sum, root paths: k_push_touch, one
+    launch) against CRUX_PUSH_FUSED=0 (the five separate launches): everything a solve leaves behind, bit for bit."""
+    monkeypatch.setenv("CRUX_PUSH_FUSED", "0"); ref = _small_per_solve()
+    monkeypatch.delenv("CRUX_PUSH_FUSED"); got = _small_per_solve()
+    for x, y, name in zip(ref, got, ("params", "priorities", "cumsum", "max_priority", "min_priority", "indices", "s")):
+        assert np.array_equal(np.asarray(x), np.asarray(y)), name
