@@ -8,12 +8,15 @@
 #include "train_generic.h"
 #include "mlp_forward.h"
 #include "ops_small.h"
+#include "per_tree.h"
 
 int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I);
 void crux_buffer_ring_advance(crux_buffer* b, int64_t N);
 int32_t crux_buffer_per_on_push(crux_buffer* b, const int64_t* d_I, int64_t N);
 int32_t crux_buffer_ring_ids_device(crux_buffer* b, int64_t N, int64_t* d_out);
 bool crux_per_push_fused(crux_buffer* b, int64_t n, int64_t* d_ids);
+bool crux_per_push_plan(crux_buffer* b, int64_t n, int* touch);
+void crux_per_push_done(crux_buffer* b, int touch);
 
 #define ENV_MAXSD 32          // SYNTH keeps one Float64 per observation; CartPole 4, Pendulum / GridWorld 2
 #define ENV_MAXOBS 32
@@ -153,6 +156,8 @@ struct RolloutArgs {
   int64_t base, C, T;
   crux_rollout_cfg cfg;
   float squash;      // SquashedGaussianPolicy ascale, 0 = GaussianPolicy
+  // push!'s priority bookkeeping finished by the rollout launch itself (k_rollout_res with one environment; per_tree.h: push_touch_block); pt_pr == NULL: not asked for
+  int64_t* pt_ids; float* pt_pr; float* pt_pminmax; float* pt_run; float* pt_total; float pt_alpha; int32_t pt_nlev, pt_touch; int64_t pt_N;
 };
 
 // exploration(pi_explore, svec; pi_on, i) / action(pi, svec) (sampler.jl:73; policies.jl:124-144, 338-344, 372-394, 466-494, 499-514) given the network outputs z of ONE
@@ -494,6 +499,9 @@ __global__ __launch_bounds__(256) void k_rollout_res(RolloutArgs a) {
   __shared__ __attribute__((aligned(16))) float w3s[ENV_MAXOBS * (H + 4)];      // row o of W3 contiguous (+4: the nout rows start in different banks)
   __shared__ float xin[ENV_MAXOBS];
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+#ifdef CRUX_RES_TIMING
+  const long long t_entry = wall_clock64();
+#endif
   const NetDesc& nd = a.nd; const int od = a.od, nout = nd.dims[3];
   const bool on = tid < H;
   float w1[8], w2[H];      // (obs_dim <= 8 for the shapes dispatched here)
@@ -561,6 +569,7 @@ __global__ __launch_bounds__(256) void k_rollout_res(RolloutArgs a) {
     RT(4)
   }
 #ifdef CRUX_RES_TIMING
+  if (tid == 0 && e == 0) printf("[res-timing] prologue %lld\n", t0 - t_entry - tk[0] - tk[1] - tk[2] - tk[3] - tk[4]);
   if (tid == 0 && e == 0) printf("[res-timing] T=%lld ticks: l1 %lld l2 %lld l3 %lld tail %lld bar %lld\n", (long long)a.T, tk[0], tk[1], tk[2], tk[3], tk[4]);
 #endif
 #undef RT
@@ -570,6 +579,14 @@ __global__ __launch_bounds__(256) void k_rollout_res(RolloutArgs a) {
     a.ep_len[e] = ep_len; a.n_resets[e] = n_resets; a.steps_taken[e] = steps_taken;
     a.acc[2 * e] = sum_r; a.acc[2 * e + 1] = (double)nee; }
   if (tid < od) a.svec[(size_t)e * od + tid] = xin[tid];
+  // the T rows just written get the maximal priority (experience_buffer.jl:254), in this launch (one environment: the rows are this workgroup's)
+#ifdef CRUX_RES_TIMING
+  const long long tp0 = wall_clock64();
+#endif
+  if (a.pt_pr) push_touch_block(a.pt_ids, a.T, a.base, a.C, a.pt_pr, a.pt_pminmax, a.pt_alpha, a.pt_N, a.pt_nlev, a.pt_run, a.pt_total, a.pt_touch);
+#ifdef CRUX_RES_TIMING
+  if (tid == 0 && e == 0) printf("[res-timing] push %lld ticks (touch %d)\n", wall_clock64() - tp0, a.pt_touch);
+#endif
 }
 
 // ---- caller-stepped environments: step! with an arbitrary mdp on the host (sampler.jl:71-137) ----------------------------------------------------------------
@@ -1018,6 +1035,7 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
   crux_prof_begin(c, CRUX_PROF_ROLLOUT);
   const NetDesc& pn = policy->nd;
   const bool h64 = pn.L == 3 && pn.dims[1] == 64 && pn.dims[2] == 64 && pn.acts[0] == pn.acts[1] && pn.acts[2] == CRUX_ACT_IDENTITY && !crux_sw().force_generic;
+  bool push_done = false; int pt_touch = 0;
 #define RO_CASE(I, O, A_, K) if (h64 && pn.dims[0] == I && nout == O && pn.acts[0] == A_ && e->kind == K) hipLaunchKernelGGL((k_rollout_h64<I, O, A_, K>), dim3(e->n_envs), dim3(64), 0, c->stream, a, (const RolloutArgs*)nullptr); else
   RO_CASE(4, 2, CRUX_ACT_RELU, CRUX_ENV_CARTPOLE)
   RO_CASE(4, 2, CRUX_ACT_TANH, CRUX_ENV_CARTPOLE)
@@ -1030,13 +1048,17 @@ int32_t crux_rollout(crux_env* e, crux_mlp* policy, const crux_rollout_cfg* cfg,
   // streamed; the load costs 8 once) -- always, from two steps on
   if (pn.L == 3 && pn.dims[1] == pn.dims[2] && (pn.dims[1] == 256 || pn.dims[1] == 128) && T >= 2 && !crux_sw().force_generic &&
       ((e->kind == CRUX_ENV_PENDULUM && e->obs_dim == 3 && e->act_dim == 1 && nout == 1) || (e->kind == CRUX_ENV_SYNTH_DISCRETE && e->obs_dim == 8 && e->act_dim == 4 && nout == 4))) {
+    if (e->n_envs == 1 && crux_per_push_plan(buf, N, &pt_touch)) { push_done = true;
+      a.pt_ids = buf->d_indices; a.pt_pr = buf->priorities; a.pt_pminmax = buf->pminmax; a.pt_run = buf->cumsum; a.pt_total = buf->topo_total; a.pt_alpha = buf->alpha;
+      a.pt_nlev = (int32_t)buf->topo_levels; a.pt_touch = pt_touch; a.pt_N = (int64_t)buf->topo_n; }
     if (pn.dims[1] == 256) hipLaunchKernelGGL(k_rollout_res<256>, dim3(e->n_envs), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL(k_rollout_res<128>, dim3(e->n_envs), dim3(256), 0, c->stream, a); }
   else if (policy->nd.maxdim >= 128) hipLaunchKernelGGL(k_rollout_wide, dim3(e->n_envs), dim3(256), 0, c->stream, a);
   else hipLaunchKernelGGL(k_rollout, dim3(e->n_envs), dim3(64), 0, c->stream, a);
   crux_prof_end(c, CRUX_PROF_ROLLOUT);
   int32_t rc = crux_launch_check(c, "k_rollout"); if (rc) return rc;
-  if (buf->prioritized) {      // push!: the new rows get max_priority (experience_buffer.jl:254); their ring rows are formed on the device, nothing to wait for
+  if (push_done) crux_per_push_done(buf, pt_touch);
+  else if (buf->prioritized) {      // push!: the new rows get max_priority (experience_buffer.jl:254); their ring rows are formed on the device, nothing to wait for
     if (crux_per_push_fused(buf, N, buf->d_indices)) { rc = crux_launch_check(c, "k_push_touch"); if (rc) return rc; }      // a few rows: the whole bookkeeping as one launch
     else {
       rc = crux_buffer_ring_ids_device(buf, N, buf->d_indices); if (rc) return rc;

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "exec.h"
 #include "ops_small.h"
+#include "per_tree.h"
 #include <algorithm>
 
 int32_t crux_buffer_ring_indices(crux_buffer* b, int64_t N, std::vector<int64_t>& I);
@@ -71,16 +72,6 @@ static int32_t topo_ensure(crux_buffer* b, int64_t N) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   b->topo_n = N; b->topo_leaves = nl; b->topo_nodes = nn; b->topo_levels = maxlvl + 1;
   return CRUX_OK;
-}
-
-// device twin of topo_rec's descent: the leaf holding element e (1 <= e < N): heap number, level, first element and length. `nlev` = levels of the tree
-// (uniform): the loop runs nlev - 1 times for every lane with predicated updates -- branch-free (a data-dependent `while` costs an exec-mask branch per level).
-struct LeafLoc { int id, depth, start, len; };
-__device__ __forceinline__ LeafLoc leaf_locate(int64_t N, int64_t e, int nlev) {
-  int i1 = 1, n = (int)(N - 1), id = 1, d = 0; const int ee = (int)e;
-  for (int it = 0; it < nlev - 1; ++it) { const bool sp = n >= 128; const int n2 = n >> 1; const bool rt = sp && ee >= i1 + n2;
-    i1 += rt ? n2 : 0; n = sp ? (rt ? n - n2 : n2) : n; id = sp ? 2 * id + (rt ? 1 : 0) : id; d += sp ? 1 : 0; }
-  return LeafLoc{id, d, i1, n};
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------------------------
@@ -157,51 +148,7 @@ __global__ __launch_bounds__(LEAF_BLK) void k_leaf_scan(const float* __restrict_
   for (int i = t; i < cnt; i += LEAF_BLK) c[base + i] = sm[i];
   if (blockIdx.x == 0 && t == 0) c[0] = v[0];
 }
-// update_priorities! touched element ids[j]: re-sum its leaf (running sums + total). One wave per touched element; duplicates write identical values.
-struct LeafRefreshOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev,
-                                                      float* __restrict__ run, float* __restrict__ total) {
-  // one WAVE per touched element (4 per 256-thread block): lane l holds v[o + l] and v[o + 64 + l]; the running sum s_ = s_ + v[i] is inherently serial, so
-  // it walks the lanes with v_readlane (constant lane numbers, fully unrolled: readlane + add + select per element, no branch) and lane i keeps the i-th
-  // running sum. Lanes past the leaf's end hold +0, which leaves the (positive) sum unchanged bit for bit. The leaf follows from the element number by
-  // arithmetic on wave-uniform values: ids -> v is the only dependent pair of memory round trips.
-  const int lane = threadIdx.x & 63; const int64_t q = (int64_t)bid_ * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (q >= n) return;
-  const int e = __builtin_amdgcn_readfirstlane((int)ids[q]);
-  if (e == 0) { if (lane == 0) run[0] = v[0]; return; }       // element 1 of the reference is the seed s_ = v[1], outside the tree
-  const LeafLoc lf = leaf_locate(N, e, nlev); const int node = lf.id, o = lf.start, len = lf.len;
-  const float x0 = lane < len ? v[o + lane] : 0.f, x1 = 64 + lane < len ? v[o + 64 + lane] : 0.f;
-  float s_ = 0.f, r0 = 0.f, r1 = 0.f;
-#pragma unroll
-  for (int i = 0; i < 64; ++i) { const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x0), i)); s_ = i == 0 ? xi : s_ + xi; r0 = lane == i ? s_ : r0; }
-  if (len > 64) {
-#pragma unroll
-    for (int i = 0; i < 64; ++i) { const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x1), i)); s_ = s_ + xi; r1 = lane == i ? s_ : r1; }
-  }
-  if (lane < len) run[o + lane] = r0;
-  if (64 + lane < len) run[o + 64 + lane] = r1;
-  if (lane == 0) total[node] = s_;
-} };
 __global__ __launch_bounds__(256) void k_leaf_refresh(const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev, float* __restrict__ run, float* __restrict__ total) { LeafRefreshOp::run(blockIdx.x, gridDim.x, v, ids, n, N, nlev, run, total); }
-// After k_leaf_refresh: node totals along the touched leaves' root paths, bottom-up level by level (s_ = rec(left); s_ += rec(right)). One workgroup;
-// thread q follows touched element q. Nodes shared by several paths are written by several threads with the same value. The ancestor of leaf L (level d) at
-// level lv is L >> (d - lv) and its children are 2a and 2a + 1: each level costs ONE round trip (the two child totals), nothing is looked up.
-struct TreeTouchOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev, float* __restrict__ total) {
-  if (n <= (int64_t)blockDim.x) {                   // the usual case (a minibatch of touched elements): the descent is done once, before the level loop
-    const int64_t e = (int64_t)threadIdx.x < n ? ids[threadIdx.x] : 0;
-    const LeafLoc lf = leaf_locate(N, e > 0 ? e : 1, nlev);
-    for (int lv = nlev - 2; lv >= 0; --lv) {
-      if (e != 0 && lf.depth - 1 - lv >= 0) { const int a = lf.id >> (lf.depth - lv); total[a] = total[2 * a] + total[2 * a + 1]; }
-      __threadfence_block(); __syncthreads();
-    }
-    return;
-  }
-  for (int lv = nlev - 2; lv >= 0; --lv) {          // parents at level lv are complete once the level below is
-    for (int64_t q = threadIdx.x; q < n; q += blockDim.x) { const int64_t e = ids[q]; if (e == 0) continue;
-      const LeafLoc lf = leaf_locate(N, e, nlev);
-      if (lf.depth - 1 - lv >= 0) { const int a = lf.id >> (lf.depth - lv); total[a] = total[2 * a] + total[2 * a + 1]; } }
-    __threadfence_block(); __syncthreads();
-  }
-} };
 // LeafRefreshOp and TreeTouchOp in ONE launch (the chained C3 epochs, exec.hip dqn_epoch_tiles): every workgroup re-sums its leaves, publishes them (device-scope release) and takes
 // a ticket; the workgroup that draws the last ticket -- all leaves are then visible to it -- walks the root paths. The root paths so leave the launch of the pullback they sit
 // beside, and the next epoch's search can follow one launch earlier. `ticket` is a zeroed word; n <= 256 touched elements.
@@ -218,34 +165,23 @@ struct LeafTouchOp { static __device__ __forceinline__ void run(const unsigned b
 } };
 __global__ __launch_bounds__(256) void k_leaf_touch(const float* __restrict__ v, const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev, float* __restrict__ run, float* __restrict__ total, unsigned* __restrict__ ticket) { LeafTouchOp::run(blockIdx.x, gridDim.x, v, ids, n, N, nlev, run, total, ticket); }
 __global__ __launch_bounds__(1024) void k_tree_touch(const int64_t* __restrict__ ids, int64_t n, int64_t N, int nlev, float* __restrict__ total) { TreeTouchOp::run(blockIdx.x, gridDim.x, ids, n, N, nlev, total); }
-// push!'s priority bookkeeping for n <= 256 freshly written ring rows as ONE launch of one workgroup (an off-policy solve pushes dN = 4..50 rows per iteration; as separate launches --
-// ring rows, max-priority snapshot, update_priorities!, leaf re-sum, root paths -- it was five kernel boundaries of ~5 us for a few hundred bytes of work): ids[j] = (base + j) % C
-// (experience_buffer.jl:236), priorities[ids] = (max_priority + eps)^alpha with max_priority read once before (:254, :290-301), and -- touch != 0: the tree is in its incremental
-// state (crux_per_touched) -- the touched leaves' running sums and the totals along their root paths. The bodies are the stand-alone kernels' own, run back to back in one
-// compute unit (write-through L1: fence + workgroup barrier order them).
 __global__ __launch_bounds__(1024) void k_push_touch(int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C, float* pr, float* pminmax, float alpha, int64_t N, int nlev,
-                                                     float* run, float* total, int touch) {
-  if (threadIdx.x == 0) pminmax[2] = pminmax[0];
-  if ((int64_t)threadIdx.x < n) ids[threadIdx.x] = (base + (int64_t)threadIdx.x) % C;
-  __threadfence_block(); __syncthreads();
-  PerUpdateOp::run(0u, 1u, pr, pminmax, ids, (const double*)nullptr, (const float*)nullptr, (const float*)(pminmax + 2), alpha, n);
-  if (!touch) return;
-  __threadfence_block(); __syncthreads();
-  for (unsigned b = 0; (int64_t)b * (blockDim.x >> 6) < n; ++b) LeafRefreshOp::run(b, 1u, pr, ids, n, N, nlev, run, total);
-  __threadfence_block(); __syncthreads();
-  TreeTouchOp::run(0u, 1u, ids, n, N, nlev, total);
+                                                     float* run, float* total, int touch) { push_touch_block(ids, n, base, C, pr, pminmax, alpha, N, nlev, run, total, touch); }
+// host side of push_touch_block. crux_per_push_plan: is this push of that shape, and is the tree in its incremental state (the conditions of crux_per_touched(from_push = true),
+// evaluated before the ring advances)? crux_per_push_done: the host flags after the launch that ran it (k_push_touch, or the rollout kernel that finished with it).
+bool crux_per_push_plan(crux_buffer* b, int64_t n, int* touch) {
+  if (!b->prioritized || n < 1 || n > 256 || !b->d_indices || crux_exec_recording(b->ctx) || !crux_sw().push_fused) return false;
+  *touch = 1;
+  if (b->elements < b->capacity) *touch = 0;
+  else if (b->per_full_dirty || b->topo_n < 2 || b->per_run_n != b->topo_n || b->topo_n != b->elements || b->topo_levels > CRUX_PER_PMAX) *touch = 0;
+  return true;
 }
-// host side of k_push_touch: false when the call is not of that shape (the caller then runs the separate steps)
+void crux_per_push_done(crux_buffer* b, int touch) { b->cumsum_valid = false; if (!touch) b->per_full_dirty = true; }
 bool crux_per_push_fused(crux_buffer* b, int64_t n, int64_t* d_ids) {
-  if (!b->prioritized || n < 1 || n > 256 || !d_ids || crux_exec_recording(b->ctx) || !crux_sw().push_fused) return false;
-  // the conditions of crux_per_touched(from_push = true), evaluated before the ring advances
-  int touch = 1;
-  if (b->elements < b->capacity) touch = 0;
-  else if (b->per_full_dirty || b->topo_n < 2 || b->per_run_n != b->topo_n || b->topo_n != b->elements || b->topo_levels > CRUX_PER_PMAX) touch = 0;
+  int touch = 0; if (!d_ids || !crux_per_push_plan(b, n, &touch)) return false;
   hipLaunchKernelGGL(k_push_touch, dim3(1), dim3(1024), 0, b->ctx->stream, d_ids, n, b->next_ind, b->capacity, b->priorities, b->pminmax, b->alpha, (int64_t)b->topo_n, (int)b->topo_levels,
                      b->cumsum, b->topo_total, touch);
-  b->cumsum_valid = false;
-  if (!touch) b->per_full_dirty = true;
+  crux_per_push_done(b, touch);
   return true;
 }
 
