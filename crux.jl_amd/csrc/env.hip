@@ -222,7 +222,9 @@ __device__ __forceinline__ void rollout_head(const RolloutArgs& a, const float* 
 // episode bookkeeping. `writer` lanes store to the buffer; all callers advance identical copies of the sampler state.
 __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* z, const int od, const int ad, const int nout, const int kind, const int e,
                                              const int64_t t, const int64_t j, const bool writer, double* st, int64_t& ep_len, int64_t& n_resets,
-                                             int64_t& steps_taken, double& sum_r, int64_t& nee, float* next_obs, const int par_lane = -1) {
+                                             int64_t& steps_taken, double& sum_r, int64_t& nee, float* next_obs, const int par_lane = -1,
+                                             const float* mu_cached = nullptr, const float* sigma_cached = nullptr) {
+  const float* mu = mu_cached ? mu_cached : a.mu; const float* sg = sigma_cached ? sigma_cached : a.sigma;      // (a kernel may hold the observation normalisation in LDS / registers)
   const int sd = kind == CRUX_ENV_CARTPOLE ? 4 : (env_is_synth(kind) ? od : 2);      // (SYNTH keeps one Float64 per observation: a compile-time od makes the state array registers)
       const uint64_t gi = a.cfg.i0 + (uint64_t)t * (uint64_t)a.E + (uint64_t)e;    // i + (j-1), env-minor (sampler.jl:161-163)
       const uint64_t ctr = (uint64_t)steps_taken;
@@ -235,7 +237,7 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
       else if (env_is_synth(kind)) synth_step(od, ad, kind == CRUX_ENV_SYNTH_DISCRETE, st, ai, aout, sn, &r, &done, par_lane);
       else { const crux_u32x4 xd = crux_philox(a.seed, ctr, (uint32_t)e, CRUX_RNG_ENVDYN); gridworld_step(st, ai, crux_u32x2_to_f64(xd.v[0], xd.v[1]), sn, &r, &done); }
       env_obs(kind, sn, o, od);
-      for (int q = 0; q < od; ++q) spv[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
+      for (int q = 0; q < od; ++q) spv[q] = __fdiv_rn(__fsub_rn(o[q], mu[q]), sg[q]);
       // ---- column writes (sampler.jl:101-107)
       if (writer) {
         if (a.act_kind == CRUX_ACTION_DISCRETE) { uint8_t* A = (uint8_t*)a.A + (size_t)j * ad; for (int q = 0; q < ad; ++q) A[q] = aout[q] != 0.f; }
@@ -260,7 +262,7 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
         ee = 1; ++nee;
         env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st, sd); n_resets += 1; ep_len = 0;
         env_obs(kind, st, o, od);
-        for (int q = 0; q < od; ++q) next_obs[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
+        for (int q = 0; q < od; ++q) next_obs[q] = __fdiv_rn(__fsub_rn(o[q], mu[q]), sg[q]);
       } else {
         for (int i = 0; i < sd; ++i) st[i] = sn[i];
         for (int q = 0; q < od; ++q) next_obs[q] = spv[q];
@@ -269,7 +271,7 @@ __device__ __forceinline__ void rollout_tail(const RolloutArgs& a, const float* 
         ee = 1; ++nee;
         env_draw_initial(kind, a.seed, (uint64_t)n_resets, (uint32_t)e, st, sd); n_resets += 1; ep_len = 0;
         env_obs(kind, st, o, od);
-        for (int q = 0; q < od; ++q) next_obs[q] = __fdiv_rn(__fsub_rn(o[q], a.mu[q]), a.sigma[q]);
+        for (int q = 0; q < od; ++q) next_obs[q] = __fdiv_rn(__fsub_rn(o[q], mu[q]), sg[q]);
       }
       if (writer) a.EE[j] = ee;
 }
@@ -496,8 +498,8 @@ __device__ __forceinline__ void env_rl_layer_lds(float& acc, const float (&hr)[H
 template <int H>
 __global__ __launch_bounds__(256) void k_rollout_res(RolloutArgs a) {
   __shared__ __attribute__((aligned(16))) float hb[2][H];      // the hidden activations of the two layers
-  __shared__ __attribute__((aligned(16))) float w3s[ENV_MAXOBS * (H + 4)];      // row o of W3 contiguous (+4: the nout rows start in different banks)
-  __shared__ float xin[ENV_MAXOBS];
+  __shared__ __attribute__((aligned(16))) float w3s[4 * (H + 4)];      // row o of W3 contiguous (+4: the nout <= 4 rows start in different banks)
+  __shared__ float xin[ENV_MAXOBS], smu[8], ssg[8];
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
 #ifdef CRUX_RES_TIMING
   const long long t_entry = wall_clock64();
@@ -507,6 +509,8 @@ __global__ __launch_bounds__(256) void k_rollout_res(RolloutArgs a) {
   float w1[8], w2[H];      // (obs_dim <= 8 for the shapes dispatched here)
 #pragma unroll
   for (int k = 0; k < 8; ++k) w1[k] = (on && k < od) ? a.p[nd.woff[0] + tid + H * k] : 0.f;
+  // (element by element: 256-byte loads per wave, ~64 KB in flight per compute unit -- 10 us for the 256 KB of H = 256. Wider pieces dealt to their owners through LDS need the
+  //  registers twice or > 64 KB of staging to keep enough bytes in flight; measured slower within the static 64 KB)
 #pragma unroll
   for (int k = 0; k < H; ++k) w2[k] = on ? a.p[nd.woff[1] + tid + H * k] : 0.f;
   const float b1 = on ? a.p[nd.boff[0] + tid] : 0.f, b2 = on ? a.p[nd.boff[1] + tid] : 0.f;
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(256) void k_rollout_res(RolloutArgs a) {
 #pragma unroll
     for (int i = 0; i < ENV_MAXSD; ++i) if (i < a.sd) st[i] = a.state[(size_t)e * a.sd + i];
     ep_len = a.ep_len[e]; n_resets = a.n_resets[e]; steps_taken = a.steps_taken[e]; }
-  if (tid < od) xin[tid] = a.svec[(size_t)e * od + tid];
+  if (tid < od) { xin[tid] = a.svec[(size_t)e * od + tid]; smu[tid] = a.mu[tid]; ssg[tid] = a.sigma[tid]; }
   __syncthreads();
 #ifdef CRUX_RES_TIMING
   long long tk[6] = {0, 0, 0, 0, 0, 0}, t0 = wall_clock64(), t1;
@@ -556,10 +560,10 @@ __global__ __launch_bounds__(256) void k_rollout_res(RolloutArgs a) {
       float zz[4], nx[ENV_MAXOBS];
       // (the host dispatches here only for these two environment shapes)
       if (a.kind == CRUX_ENV_PENDULUM) { zz[0] = env_readlane(z, 0);
-        rollout_tail(a, zz, 3, 1, 1, CRUX_ENV_PENDULUM, e, t, j, tid == 0, st, ep_len, n_resets, steps_taken, sum_r, nee, nx, lane);
+        rollout_tail(a, zz, 3, 1, 1, CRUX_ENV_PENDULUM, e, t, j, tid == 0, st, ep_len, n_resets, steps_taken, sum_r, nee, nx, lane, smu, ssg);
         if (tid == 0) { xin[0] = nx[0]; xin[1] = nx[1]; xin[2] = nx[2]; } }
       else { zz[0] = env_readlane(z, 0); zz[1] = env_readlane(z, 1); zz[2] = env_readlane(z, 2); zz[3] = env_readlane(z, 3);
-        rollout_tail(a, zz, 8, 4, 4, CRUX_ENV_SYNTH_DISCRETE, e, t, j, tid == 0, st, ep_len, n_resets, steps_taken, sum_r, nee, nx, lane);
+        rollout_tail(a, zz, 8, 4, 4, CRUX_ENV_SYNTH_DISCRETE, e, t, j, tid == 0, st, ep_len, n_resets, steps_taken, sum_r, nee, nx, lane, smu, ssg);
         if (tid == 0) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) xin[q] = nx[q]; } }
