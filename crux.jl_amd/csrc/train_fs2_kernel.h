@@ -44,6 +44,9 @@ struct Fs2Layout : FsLayout<IN, OUT, 4, true, H2, false> {
   // cACK: waves whose W2 stores are acknowledged (eight per step); cPAIR + t: the two waves of tile t, once per step; cCOMP: the four compute waves, once per step;
   // fP1: steps whose phase 1 is complete (helper leader -> everyone); fSUS: the last suspect step; fERR: why the exchange failed (sticky)
   static constexpr int cACK = B::oRED + 18, cPAIR = B::oRED + 24, cCOMP = B::oRED + 26, fP1 = B::oRED + 29, fSUS = B::oRED + 30, fERR = B::oRED + 31;
+  // the reported minibatch's info (training.jl:22-23), kept by thread 0 -- its only reader (epoch_infos) -- in free words of the same area instead of six registers per thread
+  // that would stay live across the whole launch: loss, grad norm, entropy, clip fraction, avg advantage, avg return (the KL stays in a register: every thread's loop exit reads it)
+  static constexpr int iLOSS = B::oRED + 19, iGN = B::oRED + 20, iENT = B::oRED + 21, iCLIP = B::oRED + 22, iADV = B::oRED + 23, iRET = B::oRED + 27;
 };
 
 // meeting point of a subset of the workgroup's waves: one LDS counter, monotonic over the launch (target = members x number of uses so far). A wave's LDS operations execute in
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   int total_batches = 0; int epochs_run = 0, err = 0, why_failed = 0; bool stop = false;
   bool staged = false;
   unsigned xstep = 0;                                // exchanges of this launch: every group-barrier target and both arrival counters are multiples of xstep + 1
-  float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
+  float inf_kl = 0.f;
   const int n_epochs = a.epochs;
   if (!a.ord_all) { for (int64_t j = tid; j < a.len; j += NT) order_cur[j] = (int32_t)j; }
   if (!a.ord_all && a.pre_epochs > 0) {
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   // false = the minibatch loop ends here.
   auto step_exit = [&](float invB, bool any_bad) -> bool {
     if (KIND != MFK_VALUE && target_kl >= 0.f) inf_kl = sm[Lt::oRED + 8 + 2] * invB;
-    if (any_bad) { inf_gn = NAN; err = CRUX_ENAN; return false; }                     // training.jl:20: no update
+    if (any_bad) { if (tid == 0) sm[Lt::iGN] = NAN; err = CRUX_ENAN; return false; }      // training.jl:20: no update
     total_batches += 1;
     if (max_batches > 0 && total_batches >= max_batches) return false;                // training.jl:45
     if (target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > target_kl) return false;    // :46
@@ -205,8 +208,8 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   auto epoch_epilogue = [&](int ep) {
     if (tid == 0 && p == 0 && a.epoch_infos) { float* e = a.epoch_infos + (size_t)ep * CRUX_INFO_N;   // aggregate_info(minibatch_infos) == last minibatch (Q3)
       for (int k = 0; k < CRUX_INFO_N; ++k) e[k] = 0.f;
-      e[CRUX_INFO_LOSS] = inf_loss; e[CRUX_INFO_GRAD_NORM] = inf_gn;
-      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = inf_ent; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = inf_clip; e[CRUX_INFO_AVG_ADVANTAGE] = inf_adv; e[CRUX_INFO_AVG_RETURN] = inf_ret; } }
+      e[CRUX_INFO_LOSS] = sm[Lt::iLOSS]; e[CRUX_INFO_GRAD_NORM] = sm[Lt::iGN];
+      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = sm[Lt::iENT]; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = sm[Lt::iCLIP]; e[CRUX_INFO_AVG_ADVANTAGE] = sm[Lt::iADV]; e[CRUX_INFO_AVG_RETURN] = sm[Lt::iRET]; } }
     epochs_run += 1;
     if (target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > target_kl) stop = true;   // training.jl:49
     if (max_batches > 0 && total_batches >= max_batches) stop = true;               // :50
@@ -627,10 +630,11 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
             float ss = sm[Lt::oRED];
 #pragma unroll
             for (int q = 1; q < NW; ++q) ss += sm[Lt::oRED + q];
-            inf_gn = sqrtf(ss);
-            if (KIND == MFK_VALUE) { inf_loss = tq[6] * invB; inf_ret = tq[4] * invB; }
-            else { const float p_loss = -(tq[0] * invB); const float entropy = KIND == MFK_CATEGORICAL ? tq[1] * invB : ent_pre;
-              inf_ent = entropy; inf_loss = fmaf(lambda_p, p_loss, lambda_e * (-entropy)); inf_kl = tq[2] * invB; inf_adv = tq[3] * invB; inf_ret = tq[4] * invB; inf_clip = tq[5] * invB; } } }
+            if (KIND != MFK_VALUE) inf_kl = tq[2] * invB;
+            if (tid == 0) { sm[Lt::iGN] = sqrtf(ss);
+              if (KIND == MFK_VALUE) { sm[Lt::iLOSS] = tq[6] * invB; sm[Lt::iRET] = tq[4] * invB; }
+              else { const float p_loss = -(tq[0] * invB); const float entropy = KIND == MFK_CATEGORICAL ? tq[1] * invB : ent_pre;
+                sm[Lt::iENT] = entropy; sm[Lt::iLOSS] = fmaf(lambda_p, p_loss, lambda_e * (-entropy)); sm[Lt::iADV] = tq[3] * invB; sm[Lt::iRET] = tq[4] * invB; sm[Lt::iCLIP] = tq[5] * invB; } } } }
         const bool go = step_exit(invB, any_bad != 0);
         if (!any_bad) { bp1 *= db1; bp2 *= db2; }
         xcur ^= 1; xstep += 1u; staged = st + bs < total_rows;
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 4 a workgroup missed the abort-latch consensus
     a.bp[0] = bp1; a.bp[1] = bp2;
-    if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = inf_loss; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
+    if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = sm[Lt::iLOSS]; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
   }
 #undef FS2_T
 }

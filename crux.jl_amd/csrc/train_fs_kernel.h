@@ -170,8 +170,12 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   long long total_batches = 0; int epochs_run = 0, err = 0, why_failed = 0; bool stop = false;
   bool staged = false;
   long long xstep = 0, pxc = 0;      // pxc: replica-group exchanges of this launch (one per step, or three per k-th step in the periodic form)
-  float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
-  float inf_pen = 0.f, inf_cur = 0.f, inf_closs = 0.f, inf_ploss = 0.f;
+  // the reported minibatch's info (training.jl:22-23) is kept by thread 0 -- its only reader (epoch_infos) -- in free words of the reduction area, not in registers of every
+  // thread that would stay live across the whole launch (k_train_fs2 has the measurement: ~30 VGPRs and every spill of the wide heads); the KL stays a register: the loop exits read it
+  constexpr int iLOSS = Lt::oRED + 18, iGN = Lt::oRED + 19, iENT = Lt::oRED + 20, iCLIP = Lt::oRED + 21, iADV = Lt::oRED + 22, iRET = Lt::oRED + 23,
+                iPEN = Lt::oRED + 24, iCUR = Lt::oRED + 25, iCLOSS = Lt::oRED + 26, iPLOSS = Lt::oRED + 27;
+  if (threadIdx.x == 0) { for (int k = 18; k < 28; ++k) sm[Lt::oRED + k] = 0.f; }
+  float inf_kl = 0.f;
   float pen = 0.f;                                     // lagrange_ppo_loss: the penalty of the current minibatch; the controller's state sits in LDS, one copy per wave
   float* lgs = sm + Lt::oLGS + 8 * w;                  // [I, smooth_delta, smooth_Jc, Jc_prev, deriv_term, penalty, cur_cost]
   if constexpr (LAG) { if (lane == 0) { lgs[0] = a.lag->I; lgs[1] = a.lag->smooth_delta; lgs[2] = a.lag->smooth_Jc; lgs[3] = a.lag->Jc_prev; lgs[4] = a.lag->deriv_term; lgs[5] = a.lag->penalty; lgs[6] = a.lag->cur_cost; } }
@@ -836,20 +840,23 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
           float ss = sm[Lt::oRED];
 #pragma unroll
           for (int q = 1; q < NW; ++q) ss += sm[Lt::oRED + q];
-          inf_gn = sqrtf(ss);
-          if (KIND == MFK_VALUE) { inf_loss = tq[6] * invB; inf_ret = tq[4] * invB; }
+          if (KIND != MFK_VALUE) inf_kl = tq[2] * invB;
+          if (tid == 0) {
+          sm[iGN] = sqrtf(ss);
+          if (KIND == MFK_VALUE) { sm[iLOSS] = tq[6] * invB; sm[iRET] = tq[4] * invB; }
           else { const float p_loss = -(tq[0] * invB); float entropy;
             if (KIND == MFK_CATEGORICAL) entropy = tq[1] * invB;
             else { entropy = 1.4189385332046727f;
 #pragma unroll
               for (int k = 0; k < OUT; ++k) entropy += sm[Lt::oEX + k]; }
-            inf_ent = entropy; inf_loss = fmaf(a.lambda_p, p_loss, a.lambda_e * (-entropy));      /* (explicit fma: the same bits in every form of the kernel) */ inf_kl = tq[2] * invB; inf_adv = tq[3] * invB; inf_ret = tq[4] * invB; inf_clip = tq[5] * invB;
+            sm[iENT] = entropy; sm[iLOSS] = fmaf(a.lambda_p, p_loss, a.lambda_e * (-entropy));      /* (explicit fma: the same bits in every form of the kernel) */ sm[iADV] = tq[3] * invB; sm[iRET] = tq[4] * invB; sm[iCLIP] = tq[5] * invB;
             if constexpr (LAG) { const float cost_loss = pen * (tq[7] * invB);                                        // ppo.jl:119
-              inf_loss = ((a.lambda_p * p_loss + a.lambda_e * (-entropy)) + cost_loss) / (1.f + pen);                   // :131
-              inf_pen = pen; inf_cur = lgs[6]; inf_closs = cost_loss; inf_ploss = a.lambda_p * p_loss; } }
+              sm[iLOSS] = ((a.lambda_p * p_loss + a.lambda_e * (-entropy)) + cost_loss) / (1.f + pen);                  // :131
+              sm[iPEN] = pen; sm[iCUR] = lgs[6]; sm[iCLOSS] = cost_loss; sm[iPLOSS] = a.lambda_p * p_loss; } }
+          }
         }
       }
-      if (any_bad) { inf_gn = NAN; err = CRUX_ENAN; break; }                   // training.jl:20: no update
+      if (any_bad) { if (tid == 0) sm[iGN] = NAN; err = CRUX_ENAN; break; }      // training.jl:20: no update
       // ======================= Adam (Flux.update!, training.jl:21) =======================
 #pragma unroll
       for (int mm = 0; mm < WT; ++mm) {
@@ -894,9 +901,9 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
     if (err) break;
     if (tid == 0 && p == 0 && a.epoch_infos) { float* e = a.epoch_infos + (size_t)ep * CRUX_INFO_N;   // aggregate_info(minibatch_infos) == last minibatch (Q3)
       for (int k = 0; k < CRUX_INFO_N; ++k) e[k] = 0.f;
-      e[CRUX_INFO_LOSS] = inf_loss; e[CRUX_INFO_GRAD_NORM] = inf_gn;
-      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = inf_ent; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = inf_clip; e[CRUX_INFO_AVG_ADVANTAGE] = inf_adv; e[CRUX_INFO_AVG_RETURN] = inf_ret; }
-      if constexpr (LAG) { e[CRUX_INFO_PENALTY] = inf_pen; e[CRUX_INFO_CUR_COST] = inf_cur; e[CRUX_INFO_COST_LOSS] = inf_closs; e[CRUX_INFO_P_LOSS] = inf_ploss; } }
+      e[CRUX_INFO_LOSS] = sm[iLOSS]; e[CRUX_INFO_GRAD_NORM] = sm[iGN];
+      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = sm[iENT]; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = sm[iCLIP]; e[CRUX_INFO_AVG_ADVANTAGE] = sm[iADV]; e[CRUX_INFO_AVG_RETURN] = sm[iRET]; }
+      if constexpr (LAG) { e[CRUX_INFO_PENALTY] = sm[iPEN]; e[CRUX_INFO_CUR_COST] = sm[iCUR]; e[CRUX_INFO_COST_LOSS] = sm[iCLOSS]; e[CRUX_INFO_P_LOSS] = sm[iPLOSS]; } }
     epochs_run += 1;
     if (a.target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > a.target_kl) stop = true;   // :49
     if (a.max_batches > 0 && total_batches >= a.max_batches) stop = true;               // :50
@@ -918,7 +925,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
     if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 3 replica group timeout / abort, 4 a workgroup missed the abort-latch consensus of a speculative run
     a.bp[0] = bp1; a.bp[1] = bp2;
     if constexpr (LAG) { if (p == 0) { a.lag->I = lgs[0]; a.lag->smooth_delta = lgs[1]; a.lag->smooth_Jc = lgs[2]; a.lag->Jc_prev = lgs[3]; a.lag->deriv_term = lgs[4]; a.lag->penalty = lgs[5]; a.lag->cur_cost = lgs[6]; } }
-    if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = inf_loss; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
+    if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = sm[iLOSS]; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
   }
 #undef FS_T
 }

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
   // lagrange_ppo_loss: every thread carries an identical copy of the PID state (ppo.jl:192-201); the minibatch's :cost / :episode_end / :cost_advantage are staged
   // in LDS next to the observation tiles (all 128 rows of the minibatch in BOTH workgroups: each advances the controller on its own, bit for bit alike)
   __shared__ float lag_cost[LAG ? 128 : 1], lag_ee[LAG ? 128 : 1], lag_cadv[LAG ? NW * 16 : 1];
-  crux_lagrange lg{}; float pen = 0.f; float inf_pen = 0.f, inf_cur = 0.f, inf_closs = 0.f, inf_ploss = 0.f;
+  crux_lagrange lg{}; float pen = 0.f;
   if constexpr (LAG) lg = *a.lag;
 
   int32_t* order_cur = a.order_a; int32_t* order_nxt = a.order_b;
@@ -171,7 +171,12 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
   const unsigned long long px0 = PX ? *(const unsigned long long*)(px_mine + CRUX_PX_COUNT) : 0ull;
   const float px_inv = PX ? 1.0f / (float)a.px_n : 1.0f;
   constexpr int XSLOT = 4096 + NSI * NT + 16;
-  float inf_loss = 0.f, inf_gn = 0.f, inf_ent = 0.f, inf_kl = 0.f, inf_clip = 0.f, inf_adv = 0.f, inf_ret = 0.f;
+  // the reported minibatch's info (training.jl:22-23) is kept by thread 0 -- its only reader (epoch_infos) -- in free words of the reduction area, not in registers of every
+  // thread that would stay live across the whole launch (k_train_fs2 has the measurement: ~30 VGPRs); the KL stays a register: the loop exits read it
+  constexpr int iLOSS = Lt::oRED + 18, iGN = Lt::oRED + 19, iENT = Lt::oRED + 20, iCLIP = Lt::oRED + 21, iADV = Lt::oRED + 22, iRET = Lt::oRED + 23,
+                iPEN = Lt::oRED + 24, iCUR = Lt::oRED + 25, iCLOSS = Lt::oRED + 26, iPLOSS = Lt::oRED + 27;
+  if (threadIdx.x == 0) { for (int k = 18; k < 28; ++k) sm[Lt::oRED + k] = 0.f; }
+  float inf_kl = 0.f;
   const int n_epochs = a.ids ? 1 : a.epochs;
   if (!a.ids && !a.ord_all) { for (int64_t j = tid; j < a.len; j += NT) order_cur[j] = (int32_t)j; }
   if (!a.ids && !a.ord_all && a.pre_epochs > 0) {
@@ -693,20 +698,23 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
           float ss = sm[Lt::oRED];
 #pragma unroll
           for (int q = 1; q < MF8_NW; ++q) ss += sm[Lt::oRED + q];
-          inf_gn = sqrtf(ss);
-          if (KIND == MFK_VALUE) { inf_loss = t[6] * invB; inf_ret = t[4] * invB; }
+          if (KIND != MFK_VALUE) inf_kl = t[2] * invB;
+          if (tid == 0) {
+          sm[iGN] = sqrtf(ss);
+          if (KIND == MFK_VALUE) { sm[iLOSS] = t[6] * invB; sm[iRET] = t[4] * invB; }
           else { const float p_loss = -(t[0] * invB); float entropy;
             if (KIND == MFK_CATEGORICAL) entropy = t[1] * invB;
             else { entropy = 1.4189385332046727f;
 #pragma unroll
               for (int k = 0; k < OUT; ++k) entropy += sm[Lt::oEX + k]; }
-            inf_ent = entropy; inf_loss = a.lambda_p * p_loss + a.lambda_e * (-entropy); inf_kl = t[2] * invB; inf_adv = t[3] * invB; inf_ret = t[4] * invB; inf_clip = t[5] * invB;
+            sm[iENT] = entropy; sm[iLOSS] = a.lambda_p * p_loss + a.lambda_e * (-entropy); sm[iADV] = t[3] * invB; sm[iRET] = t[4] * invB; sm[iCLIP] = t[5] * invB;
             if constexpr (LAG) { const float cost_loss = pen * (t[7] * invB);                                        // ppo.jl:119
-              inf_loss = ((a.lambda_p * p_loss + a.lambda_e * (-entropy)) + cost_loss) / (1.f + pen);                   // :131
-              inf_pen = pen; inf_cur = lg.cur_cost; inf_closs = cost_loss; inf_ploss = a.lambda_p * p_loss; } }
+              sm[iLOSS] = ((a.lambda_p * p_loss + a.lambda_e * (-entropy)) + cost_loss) / (1.f + pen);                  // :131
+              sm[iPEN] = pen; sm[iCUR] = lg.cur_cost; sm[iCLOSS] = cost_loss; sm[iPLOSS] = a.lambda_p * p_loss; } }
+          }
         }
       }
-      if (any_bad) { inf_gn = NAN; err = CRUX_ENAN; break; }                   // training.jl:20: no update
+      if (any_bad) { if (tid == 0) sm[iGN] = NAN; err = CRUX_ENAN; break; }      // training.jl:20: no update
       // ======================= Adam (Flux.update!, training.jl:21) =======================
       if (a.apply) {
 #pragma unroll
@@ -739,9 +747,9 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
     if (err) break;
     if (tid == 0 && p == 0 && a.epoch_infos) { float* e = a.epoch_infos + (size_t)ep * CRUX_INFO_N;   // aggregate_info(minibatch_infos) == last minibatch (Q3)
       for (int k = 0; k < CRUX_INFO_N; ++k) e[k] = 0.f;
-      e[CRUX_INFO_LOSS] = inf_loss; e[CRUX_INFO_GRAD_NORM] = inf_gn;
-      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = inf_ent; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = inf_clip; e[CRUX_INFO_AVG_ADVANTAGE] = inf_adv; e[CRUX_INFO_AVG_RETURN] = inf_ret; }
-      if constexpr (LAG) { e[CRUX_INFO_PENALTY] = inf_pen; e[CRUX_INFO_CUR_COST] = inf_cur; e[CRUX_INFO_COST_LOSS] = inf_closs; e[CRUX_INFO_P_LOSS] = inf_ploss; } }
+      e[CRUX_INFO_LOSS] = sm[iLOSS]; e[CRUX_INFO_GRAD_NORM] = sm[iGN];
+      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = sm[iENT]; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = sm[iCLIP]; e[CRUX_INFO_AVG_ADVANTAGE] = sm[iADV]; e[CRUX_INFO_AVG_RETURN] = sm[iRET]; }
+      if constexpr (LAG) { e[CRUX_INFO_PENALTY] = sm[iPEN]; e[CRUX_INFO_CUR_COST] = sm[iCUR]; e[CRUX_INFO_COST_LOSS] = sm[iCLOSS]; e[CRUX_INFO_P_LOSS] = sm[iPLOSS]; } }
     epochs_run += 1;
     if (a.target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > a.target_kl) stop = true;   // :49
     if (a.max_batches > 0 && total_batches >= a.max_batches) stop = true;               // :50
@@ -763,7 +771,7 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
     if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 local workgroup missing, 2 workgroups on different XCDs, 3 replica group timeout / abort
     a.bp[0] = bp1; a.bp[1] = bp2;
     if constexpr (LAG) { if (p == 0) *a.lag = lg; }
-    if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = inf_loss; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
+    if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = sm[iLOSS]; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
   }
 }
 
