@@ -696,12 +696,12 @@ def main():
             "grad_steps_per_s": grad_steps / dt,
             "phase_ms_per_iter": {k: v[0] / args.steps for k, v in prof.items()},
             "rollout_env_steps_per_s": (E * T * args.steps) / (prof["rollout"][0] * 1e-3) if prof["rollout"][0] > 0 else None,
-            "roofline": {"kernel": "batch_train! actor (k_train_fs: persistent fwd + ppo_loss + bwd + gradient exchange + Adam, 40 960 steps per launch)", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "batch_train! actor (k_train_fs2, the role-specialised form of the feature-split learner: persistent fwd + ppo_loss + bwd + gradient exchange + Adam, 40 960 steps per launch; replica groups and lagrange_ppo_loss run k_train_fs)", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "frac_of_occupied_cus": achieved / (PEAK_F32_MFMA_TFLOPS * 4.0 / 256.0), "occupied_cus": 4, "traffic": traffic,
                          "traffic_note": "HBM-side bytes per actor launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes; FETCH_SIZE tallies 128-byte requests at 64 B, calibrated in profiles/r02_fetch_calibration.txt). " + traffic_how + ". Algorithmic minibatch bytes per launch are %.0f MB (%d steps x %d B): the buffer is re-read from L2/MALL, and the per-step gradient exchange between the learner's workgroups (4 x 18 KB written, 3 x 18 KB read per workgroup and step) stays inside one XCD's L2" % (steps_per_launch * BATCH * (4 * wl["obs"] + (wl["act"] if wl["discrete"] else 4 * wl["act"]) + 8) / 1e6, int(steps_per_launch), BATCH * (4 * wl["obs"] + (wl["act"] if wl["discrete"] else 4 * wl["act"]) + 8)),
                          "avg_launch_ms": avg_launch_s * 1e3, "grad_steps_per_launch": steps_per_launch,
                          "us_per_grad_step": avg_launch_s * 1e6 / steps_per_launch if steps_per_launch else None,
-                         "note": "serially dependent %.2f-MFLOP steps: each learner step is split over FOUR CUs of one XCD (k_train_fs: feature-split wave pairs per 16-sample tile + helper waves, gradient exchange through the shared L2), actor and critic run concurrently -> 8 CUs busy; per-CU f32 MFMA peak is 0.614 TFLOP/s, so frac is structurally <= 4/256" % (fa / 1e6)},
+                         "note": "serially dependent %.2f-MFLOP steps: each learner step is split over FOUR CUs of one XCD (k_train_fs2: four compute waves -- feature-split pairs per 16-sample tile -- and four helper waves per workgroup with code paths of their own; gradient exchange through the shared L2, the W2 partials handed over by the helper leader while the compute waves finish the first-layer pullback), actor and critic run concurrently -> 8 CUs busy; per-CU f32 MFMA peak is 0.614 TFLOP/s, so frac is structurally <= 4/256" % (fa / 1e6)},
         }
         if replicas_identical is not None:
             out["replicas_bit_identical_after_run"] = replicas_identical

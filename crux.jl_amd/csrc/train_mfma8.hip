@@ -55,6 +55,21 @@ int32_t crux_train_mfma8_launch_multi(crux_ctx* c, std::vector<TrainArgs>& as, b
 int32_t crux_train_mfma8_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream) {
   *handled = false;
   const int in = a.nd.dims[0], out = a.nd.dims[3], act = a.nd.acts[0];
+  if (crux_sw().mfma_timing && in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) {      // CRUX_MFMA_TIMING=1: per-phase s_memtime totals of the C2 actor (development)
+    using Lt = MfLayout<4, 2, 8>; constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) { if (hipMalloc(&dbg, 128 * 8) != hipSuccess) return crux_fail(c, CRUX_ENOMEM, "timing buffer"); }
+    TrainArgs b = a; b.dbg = dbg; *handled = true;
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_train_mfma<4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU, 8, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_train_mfma<4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU, 8, 1, true>), dim3(1), dim3(512), lds, stream, b, (const TrainArgs*)nullptr);
+    int32_t rc = crux_launch_check(c, "k_train_mfma<8,1,timing>"); if (rc) return rc;
+    unsigned long long h[128]; HIPCHK(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, stream)); HIPCHK(c, hipStreamSynchronize(stream));
+    static const char* nm[16] = {"loop+prefetch", "stage", "fwdL1+T1", "fwdL2", "L3+head", "dW3+dZ2+stats+T2", "dH1", "dZ1+db+dW1", "wait B_a", "dW2", "reduce+store", "exchange wait",
+                                 "load peer+total+ssq", "wait B_or", "info+adam", "wait B_b"};
+    for (int w = 0; w < 8; w += 3) { fprintf(stderr, "[one-cu-timing] wave %d:", w); unsigned long long tot = 0; for (int k = 0; k < 16; ++k) tot += h[w * 16 + k];
+      for (int k = 0; k < 16; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[w * 16 + k] / (double)tot); fprintf(stderr, " total=%llu\n", tot); }
+    return CRUX_OK;
+  }
 #define MF8_CASE(I, O, K, A_) if (in == I && out == O && kind == K && act == A_) { *handled = true; return launch_one8<I, O, K, A_>(c, a, stream); }
   MF8_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)     // C2 actor  (PPO CartPole)
   MF8_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)           // C2 critic

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timeline of whole solve(DQN + PER) iterations at the C3 shapes (1 M-row ring): rocprofv3 kernel trace of tools/c3_solve_bench.py; prints, for two iterations from the middle of the
 # run, every launch with its duration and the idle gap before it. Output: gpurun_out/r05/c3_solve_trace.txt
-R=$PWD; OUT=$R/gpurun_out/r05; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+R=$PWD; OUT=$R/gpurun_out/${ROUND:-r05}; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/c3s
 C3S_BUF=1000000 C3S_ITERS=300 C3S_PREFILL=1 timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/c3s -o t -- python $R/tools/c3_solve_bench.py > /tmp/c3s.log 2>&1
 python - > $OUT/c3_solve_trace.txt <<'PY'

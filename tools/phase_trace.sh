@@ -1,8 +1,8 @@
 #!/bin/bash
 # Phase durations of the chained off-policy epochs (C3: tools/c3_trace.py, C4: tools/c4_trace.py) from a rocprofv3 kernel trace:
 # per launch its grid, duration and the idle gap before it, for one epoch in the middle of the run, plus the kernel-stats summary.
-# Output: gpurun_out/r04/offpolicy_phase_trace.txt (copied to profiles/r02_offpolicy_phase_trace.txt)
-R=$PWD; OUT=$R/gpurun_out/r04; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+# Output: gpurun_out/$ROUND/offpolicy_phase_trace.txt (copied to profiles/<round>_offpolicy_phase_trace.txt)
+R=$PWD; OUT=$R/gpurun_out/${ROUND:-r05}; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 : > $OUT/offpolicy_phase_trace.txt
 for w in c3 c4; do
   rm -rf /tmp/pt_$w
