@@ -207,7 +207,7 @@ def julia_reference_probe():
         return {"available": False, "why": repr(e)}
 
 
-TRAFFIC_RECORDED = {"c2": 35.3e6, "c5": 2.817e9}      # bytes per actor launch: profiles/r04_pmc_traffic.txt (2 x 14.57 MB FETCH_SIZE + 5.34 MB WRITE_SIZE), r04_pmc_traffic_c5.txt (2 x 1 364 MB + 22.2 MB: 17.2 KB per step with the packed learner rows)
+TRAFFIC_RECORDED = {"c2": 39.97e6, "c5": 2.832e9}      # bytes per actor launch: profiles/r05_pmc_traffic.txt (2 x 16 828 KB FETCH_SIZE + 5 374 KB WRITE_SIZE), r05_pmc_traffic_c5.txt (2 x 1 372 560 KB + 20 809 KB: 17.3 KB per step with the packed learner rows)
 
 
 def measure_traffic(workload):
@@ -670,7 +670,7 @@ def main():
             except Exception as e:      # noqa: BLE001
                 extra = {"error": repr(e)}
 
-    traffic, traffic_how = (TRAFFIC_RECORDED.get(args.workload) if world == 1 else None), "RECORDED constant (profiles/r04_pmc_traffic*.txt), not measured in this run"
+    traffic, traffic_how = (TRAFFIC_RECORDED.get(args.workload) if world == 1 else None), "RECORDED constant (profiles/r05_pmc_traffic*.txt), not measured in this run"
     if rank == 0 and world == 1 and args.measure_traffic:
         tv, how = measure_traffic(args.workload)
         if tv is not None:

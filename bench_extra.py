@@ -60,7 +60,7 @@ def c5(crux, ctx, cpu=True):
            "phase_ms": {k: ctx.prof_get(k)[0] for k in ("rollout", "values", "gae", "whiten", "train_actor")},
            "roofline": {"kernel": "batch_train! actor, k_train_fs2<17,6,GAUSSIAN,tanh> (4 workgroups x (4 compute + 4 helper waves))", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "frac_of_occupied_cus": ach / (PEAK_F32_MFMA_TFLOPS * 4.0 / 256.0), "occupied_cus": 4, "us_per_grad_step": ms_a / max(1, n_a) * 1e3 / steps_l, "allreduce_payload_bytes": 4 * pi.A.n_params,
-                        "traffic": 2.816e9, "traffic_note": "RECORDED constant (profiles/r04_pmc_traffic_c5.txt: 2 x FETCH_SIZE + WRITE_SIZE per 163 840-step actor launch = 17.2 KB per step against 13.3 KB of algorithmic minibatch bytes; `python bench.py --workload c5` measures it in the run). Round 3 read 60.7 KB per step: a gathered 68-byte observation row, 24-byte action row and 4-byte scalars cost a sector each; the learners now fetch ONE 128-byte packed line per sample (s | a | logprob | advantage | return, written once per batch_train! call)",
+                        "traffic": 2.832e9, "traffic_note": "RECORDED constant (profiles/r05_pmc_traffic_c5.txt: 2 x FETCH_SIZE + WRITE_SIZE per 163 840-step actor launch = 17.3 KB per step against 13.3 KB of algorithmic minibatch bytes; `python bench.py --workload c5` measures it in the run). Round 3 read 60.7 KB per step: a gathered 68-byte observation row, 24-byte action row and 4-byte scalars cost a sector each; the learners now fetch ONE 128-byte packed line per sample (s | a | logprob | advantage | return, written once per batch_train! call)",
                         "note": "one serially dependent learner on four CUs of one XCD (feature-split wave pairs + helper waves); %.2f MFLOP per step" % (fa / 1e6)}}
     if cpu:
         out["cpu_baseline"] = bench.cpu_baseline("c5")
