@@ -253,6 +253,9 @@ __global__ __launch_bounds__(256) void k_exec(const ExecOp* __restrict__ ops, in
 
 // ---- host: recording -------------------------------------------------------------------------------------------------------------------
 static ExecRec* rec_of(crux_ctx* c) { return (ExecRec*)c->rec; }
+// CRUX_EXEC_PERSISTENT (development): the one-XCD persistent executor k_exec, for recordings that are run one at a time and waited for. Chained epochs ignore the switch: their
+// op tags assume the phase plan (sequential one-block groups, tile ops), and an asynchronous chain could not read k_exec's status word back.
+static bool exec_persistent_on(crux_ctx* c) { const ExecRec* r = (const ExecRec*)c->rec; return crux_sw().exec_persistent && !(r && r->chain); }
 extern "C" int32_t crux_ensure_aux_stream(crux_ctx* c);      // train.hip: a second stream on its own hardware queue (probed)
 
 // The persistent two-kernel form of a recorded chain of DQN-family epochs (dqn_persist.h). The recording holds every op of every epoch; the learner's ops (tile GEMMs,
@@ -426,7 +429,7 @@ int32_t crux_exec_run(crux_ctx* c) {
     // an asynchronous chain whose phases all travel in kernel arguments needs neither the device copy of the list nor the zeroed counters (no persistent form, no status
     // read-back): two stream operations less between chains (they sit IN the stream there, ~15 us per chain)
     bool lean = false;
-    if (async && !r->dqp.on && !crux_sw().exec_persistent && !crux_sw().exec_no_kernarg) { lean = true;
+    if (async && !r->dqp.on && !crux_sw().exec_no_kernarg) { lean = true;
       size_t i0 = 0;
       while (i0 < nops && lean) { size_t i1 = i0; unsigned blocks = 0; for (;;) { blocks += (r->ops[i1].barrier & 2) ? 0u : r->ops[i1].nblocks; if ((r->ops[i1].barrier & 1) || i1 + 1 == nops) break; ++i1; }
         if (blocks && !phasek_fits(r->ops, i0, i1)) lean = false;
@@ -450,7 +453,9 @@ int32_t crux_exec_run(crux_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(r->d_ops, r->h_stage, ob, hipMemcpyHostToDevice, c->stream));
     }
     if (!lean) HIPCHK(c, hipMemsetAsync(r->d_ctr, 0, 2048, c->stream));
-    const bool persistent = crux_sw().exec_persistent;
+    // CRUX_EXEC_PERSISTENT (development): the one-XCD persistent executor, for synchronous calls only -- its status word (a workgroup that does not reach a barrier: the grid was
+    // not co-resident, which the register-heavy block kernels of round 4 cause) is read back by the synchronous path; an asynchronous chain would go on with garbage
+    const bool persistent = crux_sw().exec_persistent && !r->async && r->chain_tags.empty();      // (a chained recording carries op tags)
     if (r->dqp.on) { r->dqp.on = false; rc = dqp_launch(c, r); if (rc) return rc; }
     else if (!persistent) {
       // default: one launch per phase over the whole chip (see k_phase). Measured against the persistent one-XCD form (CRUX_EXEC_PERSISTENT=1): the latter
@@ -534,7 +539,7 @@ int32_t crux_polyak(crux_mlp* to, const crux_mlp* from, float tau);
 //   update_priorities! per 16-sample tile | 4 the whole pullback ; leaf re-sums | 5 norm ; root paths | 6 info, Adam | 7 beta-power advance
 // In a chain the sampling of epoch e + 1 (phases 0, 1) sits beside the norm and Adam of epoch e -- after the root paths of phase 5 --, its phase 2 beside the advance.
 static bool dqn_tile_case(crux_mlp* net, crux_mlp* tnet, crux_buffer* source, crux_buffer* batch) {
-  const bool on = crux_sw().sac_tile_ops && !crux_sw().exec_persistent && !crux_sw().no_fused_epoch && !crux_sw().no_chained_epochs;
+  const bool on = crux_sw().sac_tile_ops && !exec_persistent_on(net->ctx) && !crux_sw().no_fused_epoch && !crux_sw().no_chained_epochs;
   const int64_t B = batch->capacity; crux_ctx* c = net->ctx;
   if (!on || c->per_split_sample || !net->has_adam) return false;
   if (source->prioritized && !crux_per_fused_gather()) return false;
@@ -636,7 +641,7 @@ static int32_t dqn_epoch_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   // as ov <= nb + 1; without the group the chain is update | leaf | paths at 4 + nf - sq .., and ov <= nb as before.
   const NetPlan pn = net_plan(net, B); const bool ffw = crux_dense_fwd_fused(net);
   const int nf = pn.nf, nb = pn.nb;
-  const int sq0 = (B <= 256 && !crux_sw().exec_persistent) ? 1 : 0;
+  const int sq0 = (B <= 256 && !exec_persistent_on(c)) ? 1 : 0;
   const bool tailp = per && sq0 == 1;
   // sph: with the search and the gather in one launch (PerSampleGatherOp) the sampling of an epoch is phase 1 alone, so the search of epoch e + 1 sits one phase later and the
   // overlap may be one deeper
@@ -799,7 +804,7 @@ int32_t crux_dpg_actor_step(crux_mlp* actor, crux_mlp* q, crux_buffer* b, float*
 // The order inside every chain is the reference's (temperature, critic and actor each see what the previous step left; sac_target reads log alpha BEFORE the temperature
 // update lands, the actor head after). Same arithmetic as the generic recording below (tools/fused_check.py compares the two bit for bit); false = not this case.
 static bool sac_tile_case(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* q1t, crux_mlp* q2t, crux_buffer* source, crux_buffer* batch, int32_t uc, int32_t ua) {
-  const bool on = crux_sw().sac_tile_ops && !crux_sw().exec_persistent && !crux_sw().no_fused_epoch;      // (read per call: tests switch forms inside one process)
+  const bool on = crux_sw().sac_tile_ops && !exec_persistent_on(actor->ctx) && !crux_sw().no_fused_epoch;      // (read per call: tests switch forms inside one process)
   if (!on || !uc || !ua || source->prioritized) return false;
   const int64_t B = batch->capacity; crux_mlp* all[5] = {actor, q1, q2, q1t, q2t};
   for (crux_mlp* n : all) { if (n->nd.L != 3 || !crux_dense_fwd_fused(n) || n->nd.acts[2] != CRUX_ACT_IDENTITY || n->nd.dims[2] != actor->nd.dims[2]) return false; }
@@ -943,7 +948,7 @@ int32_t crux_sac_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* ac
   // The order inside every chain is the reference's (temperature before critic before actor: each sees the parameters the previous step left).
   // sq: sac_target (one block at B <= 256) and the critic heads (one block each) form a sequential group in ONE block of phase X when the critics train; the critic
   // chain and everything behind it (Y ..) then sit one phase earlier. The temperature chain (X .. X + 3) is independent of it.
-  const int sq = (update_critic && B <= 256 && !crux_sw().exec_persistent) ? 1 : 0;
+  const int sq = (update_critic && B <= 256 && !exec_persistent_on(c)) ? 1 : 0;
   // Round 4: written in launches -- FA / FQ forward launches of the actor / a critic, BQ / BA phases of a pullback with parameter gradients (BQo ops per critic), LQ phases
   // of a critic's input-gradient chain; with the fused block kernels FA = FQ = L - 1 and BQ = BA = L - 1 (net_plan above), otherwise all equal L as in round 3.
   const NetPlan pa = net_plan(actor, B), pq = net_plan(q1, B);
@@ -1103,7 +1108,7 @@ static int32_t dpg_epoch(crux_mlp* actor, crux_mlp* q1, crux_mlp* q2, crux_mlp* 
   //   0 ids | 1 gather, fills | 2.. target actor(sp) forward ; vcat(s, a) ; actor(s) forward of the ACTOR step | 2+LA target action (+ smoothing noise) ; mu(s) -> vcat(s, mu(s))
   //   3+LA.. target Q1 || Q2 forward (and, from 3: Q1 || Q2 forward on (s, a)) | X target | X+1 critic heads | X+2.. critic backward | norm | info, Adam | advance
   //   Y.. Q(s, mu(s)) forward | its input gradient | slice | actor backward | norm | info, Adam | advance, polyak
-  const int sq = (update_critic && B <= 256 && !crux_sw().exec_persistent) ? 1 : 0;      // target + critic head(s) as a sequential one-block group (see crux_sac_epoch)
+  const int sq = (update_critic && B <= 256 && !exec_persistent_on(c)) ? 1 : 0;      // target + critic head(s) as a sequential one-block group (see crux_sac_epoch)
   const NetPlan pa = net_plan(actor, B), pq = net_plan(q1, B);      // launches per pass (see crux_sac_epoch)
   std::vector<int> ph; bool plan_ok = true; const int LA = actor->nd.L, LQ = q1->nd.L, FA = pa.nf, FQ = pq.nf, BQ = pq.nb, BQo = pq.nbops, BA = pa.nb, DQ = pq.dq, X = 3 + FA + FQ, Y = X + 4 + BQ - sq;
   const int ag = actor->nd.acts[LA - 1] != CRUX_ACT_IDENTITY ? 1 : 0;

@@ -49,10 +49,11 @@ def test_on_policy_switch_forms_are_bit_identical(gpu_ctx, monkeypatch, switch, 
 
 
 @pytest.mark.parametrize("switch,value", [("CRUX_NO_CHAINED_EPOCHS", "1"), ("CRUX_NO_FUSED_EPOCH", "1"), ("CRUX_SYNC_CHAINS", "1"), ("CRUX_EXEC_PERSISTENT", "1")],
-                         ids=["no_chained_epochs", "no_fused_epoch", "sync_chains", "exec_persistent"])
+                         ids=["no_chained_epochs", "no_fused_epoch", "sync_chains", "exec_persistent_is_ignored_by_asynchronous_chains"])
 def test_off_policy_switch_forms_are_bit_identical(gpu_ctx, monkeypatch, switch, value):
     """a DQN + prioritized-replay solve on a full ring (8-256-256-4, 24 iterations of 4 steps + 4 epochs): the epochs call by call / one recording per epoch / chains with a
-    read-back after each / the one-XCD persistent executor, against the default chained phase launches"""
+    read-back after each, against the default chained phase launches. CRUX_EXEC_PERSISTENT (the one-XCD persistent executor, development) applies to synchronous calls only: an
+    asynchronous chain cannot read its status word back, so solve's chains must ignore it."""
     monkeypatch.setenv(switch, value); ref = _small_per_solve()
     monkeypatch.delenv(switch); got = _small_per_solve()
     _same(ref, got, ("params", "priorities", "cumsum", "max_priority", "min_priority", "indices", "s"))
