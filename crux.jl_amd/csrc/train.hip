@@ -98,19 +98,6 @@ static int32_t ensure_ord(crux_ctx* c, crux_buffer* buf, int slot, size_t need) 
   }
   return CRUX_OK;
 }
-// the same composition for n buffers of equal length in one launch per epoch (grid.y = buffer): buffer i shuffles with seed + i; the critic
-// chain (slot 1) starts from the actor's last order
-struct OrdPtrs { int32_t* oa; int32_t* oc; };
-__global__ void k_compose_order_multi(const OrdPtrs* __restrict__ P, int slot, int e, int Ea, uint64_t seed, uint64_t counter, int64_t len) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (j >= len) return;
-  const int i = blockIdx.y;
-  const crux_perm pp = crux_perm_make(seed + (uint64_t)i, counter + (uint64_t)e, 0, (uint32_t)len);
-  const OrdPtrs p = P[i];
-  int32_t* base = slot ? p.oc : p.oa;
-  const int32_t* prev = e > 0 ? base + (size_t)(e - 1) * (size_t)len : (slot ? p.oa + (size_t)(Ea - 1) * (size_t)len : (const int32_t*)nullptr);
-  const int64_t src = (int64_t)crux_perm_at(&pp, (uint32_t)j);
-  base[(size_t)e * (size_t)len + j] = prev ? prev[src] : (int32_t)src;
-}
 static int32_t build_orders(crux_ctx* c, crux_buffer* buf, int slot, const int32_t* start, uint64_t seed, uint64_t counter, const int64_t* d_perms, int n_epochs, hipStream_t st, int32_t** out) {
   const int64_t len = buf->elements; const size_t need = (size_t)n_epochs * (size_t)len;
   { const int32_t rc0 = ensure_ord(c, buf, slot, need); if (rc0) return rc0; }
@@ -656,7 +643,7 @@ extern "C" int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* cons
   const size_t ea = sizeof(float) * CRUX_INFO_N * (size_t)cfg_a->epochs, ec = sizeof(float) * CRUX_INFO_N * (size_t)cfg_c->epochs;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t stride = 512 + al(ea) + al(ec);
-  char* sc = (char*)crux_scratch(c, stride * (size_t)n + sizeof(OrdPtrs) * (size_t)n + 256); if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_gradient_training_multi: scratch");
+  char* sc = (char*)crux_scratch(c, stride * (size_t)n + 256); if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_gradient_training_multi: scratch");
   HIPCHK(c, hipMemsetAsync(sc, 0, stride * (size_t)n, c->stream));
   std::vector<TrainArgs> as((size_t)n), ks((size_t)n);
   for (int i = 0; i < n; ++i) {
@@ -668,19 +655,12 @@ extern "C" int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* cons
     char* s0 = sc + stride * (size_t)i;
     as[i].status = (int32_t*)s0; ks[i].status = (int32_t*)(s0 + 256); as[i].epoch_infos = (float*)(s0 + 512); ks[i].epoch_infos = (float*)(s0 + 512 + al(ea));
     ks[i].order_a = bufs[i]->order_c; ks[i].order_b = bufs[i]->order_d;
-    const int64_t len = bufs[i]->elements;
-    rc = ensure_ord(c, bufs[i], 0, (size_t)ca.epochs * (size_t)len); if (rc) return rc;
-    rc = ensure_ord(c, bufs[i], 1, (size_t)cc.epochs * (size_t)len); if (rc) return rc;
-    as[i].ord_all = bufs[i]->ord_all[0]; ks[i].ord_all = bufs[i]->ord_all[1];
-  }
-  { // every epoch order of every replica: Ea + Ec launches in all (grid.y = replica)
-    std::vector<OrdPtrs> hp((size_t)n); for (int i = 0; i < n; ++i) hp[(size_t)i] = {bufs[i]->ord_all[0], bufs[i]->ord_all[1]};
-    OrdPtrs* dp = (OrdPtrs*)(sc + stride * (size_t)n);
-    HIPCHK(c, hipMemcpyAsync(dp, hp.data(), sizeof(OrdPtrs) * (size_t)n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int64_t len = bufs[0]->elements; const dim3 grid((unsigned)((len + 255) / 256), (unsigned)n);
-    for (int e = 0; e < cfg_a->epochs; ++e) hipLaunchKernelGGL(k_compose_order_multi, grid, dim3(256), 0, c->stream, (const OrdPtrs*)dp, 0, e, cfg_a->epochs, cfg_a->shuffle_seed, cfg_a->shuffle_counter, len);
-    for (int e = 0; e < cfg_c->epochs; ++e) hipLaunchKernelGGL(k_compose_order_multi, grid, dim3(256), 0, c->stream, (const OrdPtrs*)dp, 1, e, cfg_a->epochs, cfg_c->shuffle_seed, cfg_c->shuffle_counter, len);
-    const int32_t rc2 = crux_launch_check(c, "k_compose_order_multi"); if (rc2) return rc2;
+    // shuffle!(D) per epoch as an index composition INSIDE the learner kernels (every learner composes its own order with its own 512 threads: ~8 us per epoch, all learners at
+    // once); the critic first replays the actor's epochs (the reference shuffles the same buffer on through both batch_train! calls). Composed ahead of time -- (Ea + Ec)
+    // launches over all replicas -- the orders took 9 ms of a 128-seed iteration and 2 x 80 x 256 KB of memory per replica (5.4 GB at 128 seeds); inside the kernels the
+    // random gather costs about as much (~100 us per epoch and learner: 423 -> 431 ms per launch), so this is a memory saving, not a speed-up (iteration 472 ms either way).
+    as[i].ord_all = nullptr; ks[i].ord_all = nullptr;
+    ks[i].pre_epochs = ca.epochs; ks[i].pre_seed = ca.shuffle_seed; ks[i].pre_counter = ca.shuffle_counter; ks[i].pre_perms = nullptr;
   }
   HIPCHK(c, hipEventRecord(c->aux_ev0, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_ev0, 0));
@@ -717,7 +697,7 @@ extern "C" int32_t crux_policy_gradient_training_multi(int32_t n, crux_mlp* cons
       out[CRUX_INFO_BATCHES_TRAINED] = (float)st[1]; out[CRUX_INFO_EPOCHS_RUN] = (float)st[2]; }
     if (sta[0] == CRUX_ENAN || stc[0] == CRUX_ENAN) return crux_fail(c, CRUX_ENAN, "NaN detected! (grad norm is NaN, src/training.jl:20) in replica %d", i);
     if (sta[0] || stc[0]) return crux_fail(c, sta[0] ? sta[0] : stc[0], "learner kernel reported status %d/%d in replica %d", sta[0], stc[0], i);
-    if (stc[2] >= 1) fin_ord[(size_t)i] = ks[i].ord_all + (size_t)(stc[2] - 1) * (size_t)bufs[i]->elements;
+    if (stc[2] >= 1) fin_ord[(size_t)i] = stc[3] ? bufs[i]->order_d : bufs[i]->order_c;      // the critic's last epoch order = the buffer's final arrangement
   }
   return crux_buffer_apply_order_multi(n, bufs, fin_ord.data());
 }
