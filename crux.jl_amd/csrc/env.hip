@@ -587,7 +587,8 @@ __global__ __launch_bounds__(256) void k_rollout_res(RolloutArgs a) {
 #ifdef CRUX_RES_TIMING
   const long long tp0 = wall_clock64();
 #endif
-  if (a.pt_pr) push_touch_block(a.pt_ids, a.T, a.base, a.C, a.pt_pr, a.pt_pminmax, a.pt_alpha, a.pt_N, a.pt_nlev, a.pt_run, a.pt_total, a.pt_touch);
+  if (a.pt_pr) { if (a.pt_touch && a.T <= PUSH_SMALL_MAX && a.T <= a.C) push_touch_small(a.pt_ids, (int)a.T, a.base, a.C, a.pt_pr, a.pt_pminmax, a.pt_alpha, a.pt_N, a.pt_nlev, a.pt_run, a.pt_total);
+    else push_touch_block(a.pt_ids, a.T, a.base, a.C, a.pt_pr, a.pt_pminmax, a.pt_alpha, a.pt_N, a.pt_nlev, a.pt_run, a.pt_total, a.pt_touch); }
 #ifdef CRUX_RES_TIMING
   if (tid == 0 && e == 0) printf("[res-timing] push %lld ticks (touch %d)\n", wall_clock64() - tp0, a.pt_touch);
 #endif

@@ -177,8 +177,14 @@ bool crux_per_push_plan(crux_buffer* b, int64_t n, int* touch) {
   return true;
 }
 void crux_per_push_done(crux_buffer* b, int touch) { b->cumsum_valid = false; if (!touch) b->per_full_dirty = true; }
+// (the one-round-trip form of a handful of rows keeps a root path's sibling totals in registers: its own launch bounds, so that it does not spill under the 1024-thread cap)
+__global__ __launch_bounds__(256) void k_push_touch_small(int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C, float* pr, float* pminmax, float alpha, int64_t N, int nlev,
+                                                          float* run, float* total) { push_touch_small(ids, (int)n, base, C, pr, pminmax, alpha, N, nlev, run, total); }
 bool crux_per_push_fused(crux_buffer* b, int64_t n, int64_t* d_ids) {
   int touch = 0; if (!d_ids || !crux_per_push_plan(b, n, &touch)) return false;
+  if (touch && n <= PUSH_SMALL_MAX && n <= b->capacity)
+    hipLaunchKernelGGL(k_push_touch_small, dim3(1), dim3(256), 0, b->ctx->stream, d_ids, n, b->next_ind, b->capacity, b->priorities, b->pminmax, b->alpha, (int64_t)b->topo_n, (int)b->topo_levels, b->cumsum, b->topo_total);
+  else
   hipLaunchKernelGGL(k_push_touch, dim3(1), dim3(1024), 0, b->ctx->stream, d_ids, n, b->next_ind, b->capacity, b->priorities, b->pminmax, b->alpha, (int64_t)b->topo_n, (int)b->topo_levels,
                      b->cumsum, b->topo_total, touch);
   crux_per_push_done(b, touch);

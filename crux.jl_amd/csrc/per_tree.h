@@ -153,7 +153,7 @@ __device__ __forceinline__ void push_touch_small(int64_t* __restrict__ ids, cons
 }
 __device__ __forceinline__ void push_touch_block(int64_t* __restrict__ ids, int64_t n, int64_t base, int64_t C, float* pr, float* pminmax, float alpha, int64_t N, int nlev,
                                                  float* run, float* total, int touch) {
-  if (touch && n <= PUSH_SMALL_MAX && n <= C) { push_touch_small(ids, (int)n, base, C, pr, pminmax, alpha, N, nlev, run, total); return; }
+  // (a handful of rows with the tree in its incremental state take push_touch_small: the rollout kernel calls it directly, crux_per_push_fused launches k_push_touch_small)
   if (threadIdx.x == 0) pminmax[2] = pminmax[0];
   if ((int64_t)threadIdx.x < n) ids[threadIdx.x] = (base + (int64_t)threadIdx.x) % C;
   __threadfence_block(); __syncthreads();
