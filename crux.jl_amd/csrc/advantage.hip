@@ -83,7 +83,13 @@ __device__ float jlw_reduce(const float* __restrict__ v, int64_t n, bool centred
   const int nl = *n_leaf;
   for (int q = tid; q < nl; q += 1024) { const int64_t lo = leaf_lo[q], hi = (int64_t)leaf_lo[q + 1] - 1;      // v = f(a1) + f(a2); v += f(a3); ... (reduce.jl, the sequential portion)
     float acc = jlw_term(v[lo], centred, m);
-    for (int64_t i = lo + 1; i <= hi; ++i) acc = __fadd_rn(acc, jlw_term(v[i], centred, m));
+    int64_t i = lo + 1;
+    for (; i + 15 <= hi; i += 16) { float x[16];      // 16 loads in flight, then the 16 additions in order (the sum itself is a serial chain; one load per addition made it a memory round trip each)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = v[i + k];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc = __fadd_rn(acc, jlw_term(x[k], centred, m)); }
+    for (; i <= hi; ++i) acc = __fadd_rn(acc, jlw_term(v[i], centred, m));
     leaf_sum[q] = acc; }
   __syncthreads();
   __shared__ float result;
