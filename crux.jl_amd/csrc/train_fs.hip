@@ -95,9 +95,9 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hip
                        (in == 3 && out == 1 && kind == MFK_GAUSSIAN && act == CRUX_ACT_RELU) || (in == 17 && out == 6 && kind == MFK_GAUSSIAN && act == CRUX_ACT_TANH);
     if (!shape) return CRUX_OK;
   }
-  // round 5: the plain learners (no replica group, no lagrange_ppo_loss, no explicitly requested older form) take the role-specialised kernel k_train_fs2 -- the same arithmetic,
-  // bit-identical parameters, the W2 exchange / Adam in the helper waves beside the compute waves' backward pass. CRUX_FS2=0 keeps k_train_fs.
-  if (crux_sw().fs2 && form_env == 0 && !a.lag && !(crux_grouped(c) && a.need_px) && a.len < (1ll << 30) && (long long)a.epochs * ((a.len + a.bs - 1) / a.bs) < 0x7fffffffll) {
+  // round 5: the plain learners (no lagrange_ppo_loss, no explicitly requested older form) take the role-specialised kernel k_train_fs2 -- the same arithmetic, bit-identical
+  // parameters, the W2 hand-over in the helper waves beside the compute waves' backward pass --, replica groups too on the shapes train_fs2.hip instantiates. CRUX_FS2=0 keeps k_train_fs.
+  if (crux_sw().fs2 && form_env == 0 && !a.lag && a.len < (1ll << 30) && (long long)a.epochs * ((a.len + a.bs - 1) / a.bs) < 0x7fffffffll) {
     const int32_t rc2 = crux_train_fs2_launch(c, a, kind, handled, stream, probe);
     if (rc2 || *handled) return rc2; }
   const int form = form_env == 2 || form_env == 4 || form_env == 8 ? form_env : CRUX_FS_DEFAULT_WG;      // 8 = four workgroups with helper waves

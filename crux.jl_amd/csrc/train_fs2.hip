@@ -1,18 +1,23 @@
 // train_fs2.hip -- dispatch of the role-specialised form of the register-resident learner kernel (train_fs2_kernel.h: k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2>): the plain
 // policy-gradient / critic losses of full batch_train! loops (src/training.jl:28-55) on every IN->64->{64,32}->OUT shape k_train_fs serves, on four compute units of one XCD
-// with four compute + four helper waves each. Called by crux_train_fs_launch (train_fs.hip) for the launches that are neither a replica group, nor lagrange_ppo_loss, nor one of
-// the explicitly requested older forms (CRUX_FS_WG); CRUX_FS2=0 keeps k_train_fs for them too.
+// with four compute + four helper waves each. Called by crux_train_fs_launch (train_fs.hip) for the launches that are neither lagrange_ppo_loss nor one of the explicitly
+// requested older forms (CRUX_FS_WG); replica groups on the C2 / C5 shapes (PX / PXK instantiations); CRUX_FS2=0 keeps k_train_fs for all of them.
 #include "train_fs2_kernel.h"
 
-template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, bool TIMING>
+template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, bool TIMING, bool PX = false, bool PXK = false>
 static int32_t launch_fs2_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
   using Lt = Fs2Layout<IN, OUT, H2>;
-  constexpr size_t lds = sizeof(float) * (size_t)Lt::TOTAL;
+  constexpr size_t lds = sizeof(float) * (size_t)(PX && Lt::BK_FITS ? Lt::TOTAL_BK : Lt::TOTAL);
   static bool attr_dev[16] = {}; bool& attr = attr_dev[c->device & 15];
-  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-  hipLaunchKernelGGL((k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING>), dim3(32), dim3(512), lds, stream, a);
-  return crux_launch_check(c, "k_train_fs2");
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING, PX, PXK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING, PX, PXK>), dim3(32), dim3(512), lds, stream, a);
+  return crux_launch_check(c, PXK ? "k_train_fs2 (replica group, periodic form)" : PX ? "k_train_fs2 (replica group)" : "k_train_fs2");
 }
+// the shapes whose replica-group forms (PX / PXK) are instantiated in the role-specialised kernel: the learners of BASELINE's configurations (C2: PPO CartPole, C5: the
+// HalfCheetah-shaped shard); every other shape of a replica group stays on k_train_fs
+template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2> constexpr bool FS2_HAS_PX = H2 == 64 && ACT2 == ACT &&
+  ((IN == 4 && ACT == CRUX_ACT_RELU && ((OUT == 2 && KIND == MFK_CATEGORICAL) || (OUT == 1 && KIND == MFK_VALUE))) ||
+   (IN == 17 && ACT == CRUX_ACT_TANH && ((OUT == 6 && KIND == MFK_GAUSSIAN) || (OUT == 1 && KIND == MFK_VALUE))));
 template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2>
 static int32_t launch_fs2(crux_ctx* c, TrainArgs a, bool timing, hipStream_t stream) {
   const int which = stream == c->stream ? 0 : 1;
@@ -21,6 +26,11 @@ static int32_t launch_fs2(crux_ctx* c, TrainArgs a, bool timing, hipStream_t str
   a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * xfloats);
   HIPCHK(c, hipMemsetAsync(c->xbuf[which], 0, sizeof(float) * xfloats + 256, stream));      // counters AND slots: the granules' step tags start from zero (a stale tag must never look like this launch's)
   a.xcd = which;      // actor / critic (the context's two learner streams) behind different L2s
+  if constexpr (FS2_HAS_PX<IN, OUT, KIND, ACT, H2, ACT2>) if (crux_grouped(c) && a.need_px) {      // replica group: the in-kernel all-reduce over the peer slots (comm.hip)
+    a.px_hist = c->peer_hist ? 1 : 0; a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
+    if (a.px_every > 1) return launch_fs2_form<IN, OUT, KIND, ACT, H2, ACT2, false, true, true>(c, a, stream);      // periodic form: local Adam steps, theta / m / v averaged every k-th
+    return launch_fs2_form<IN, OUT, KIND, ACT, H2, ACT2, false, true, false>(c, a, stream);
+  }
   constexpr bool HAS_TIMING = H2 == 64 && ACT2 == ACT && ((IN == 4 && (OUT == 2 || OUT == 1)) || (IN == 17 && ACT == CRUX_ACT_TANH));      // the in-kernel phase timers are instantiated for the C2 / C5 learners only
   if constexpr (HAS_TIMING) if (timing) {
     static unsigned long long* dbg = nullptr;
@@ -47,7 +57,9 @@ int32_t crux_train_fs2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* h
   const NetDesc& nd = a.nd;
   const int in = nd.dims[0], h2 = nd.dims[2], out = nd.dims[3], act = nd.acts[0], act2 = nd.acts[1];
   const bool timing = crux_sw().mfma_timing;
-#define FS2_CASE2(I, O, K, A1, H, A2) if (in == I && out == O && kind == K && act == A1 && h2 == H && act2 == A2) { *handled = true; if (probe) return CRUX_OK; return launch_fs2<I, O, K, A1, H, A2>(c, a, timing, stream); }
+  const bool grouped = crux_grouped(c) && a.need_px;
+#define FS2_CASE2(I, O, K, A1, H, A2) if (in == I && out == O && kind == K && act == A1 && h2 == H && act2 == A2) { if (grouped && !FS2_HAS_PX<I, O, K, A1, H, A2>) return CRUX_OK; \
+    *handled = true; if (probe) return CRUX_OK; return launch_fs2<I, O, K, A1, H, A2>(c, a, timing, stream); }
 #define FS2_CASE(I, O, K, A_) FS2_CASE2(I, O, K, A_, 64, A_)
   FS2_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)     // C2 actor  (PPO CartPole)
   FS2_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)           // C2 critic

@@ -26,7 +26,8 @@
 // NaN semantics (training.jl:20: a NaN gradient norm is an error BEFORE the update): every thread forms the totals of its own elements in every workgroup; one that finds a
 // NaN total marks the step SUSPECT in LDS; after B_b the whole workgroup puts the pre-step state back (W2 from registers, the small parameters from the values read for Adam)
 // and leaves with CRUX_ENAN -- a NaN step leaves every parameter as it was, exactly as in k_train_fs. The same totals, hence the same decision, in all four workgroups.
-// Covers the plain policy-gradient / critic losses of full minibatch loops (65..128 rows); replica groups (PX), lagrange_ppo_loss and the other forms stay on k_train_fs.
+// Covers the plain policy-gradient / critic losses of full minibatch loops (65..128 rows), alone or as a member of a replica group (PX: the group's all-reduce of the minibatch
+// gradient between the totals and Adam; PXK: local steps, theta / m / v averaged every k-th -- the exchange of train_fs_kernel.h, same bits); lagrange_ppo_loss stays on k_train_fs.
 #pragma once
 #include "train_fs_kernel.h"
 
@@ -40,6 +41,10 @@ struct Fs2Layout : FsLayout<IN, OUT, 4, true, H2, false> {
   static constexpr int xW2 = 0, xGR = B::W2N;                       // exchange slot: W2 partials [thread][WT2][4] | granules {value, step} of the small partials and statistics
   static constexpr int XSLOT2 = ((xGR + 2 * NGR + 3) / 4) * 4;
   static_assert(2 * 4 * XSLOT2 <= CRUX_XBUF_FLOATS, "exchange area");
+  // every thread's copy of its W2 theta / m / v from before the step's Adam (what a suspect step is put back to): in registers (plain learners: the LDS form measured 3 %
+  // slower, 5.58 against 5.40 us per C2 step), in LDS in the replica-group forms, whose exchange needs the 24 registers (no spills in the C5 PX / PXK forms)
+  static constexpr bool BK_FITS = B::TOTAL + 3 * B::W2N <= 40960;
+  static constexpr int oBK = B::TOTAL, TOTAL_BK = B::TOTAL + 3 * B::W2N;
   // LDS words behind the reduction area (oRED .. oRED + 32): group-barrier counters and step flags
   // cACK: waves whose W2 stores are acknowledged (eight per step); cPAIR + t: the two waves of tile t, once per step; cCOMP: the four compute waves, once per step;
   // fP1: steps whose phase 1 is complete (helper leader -> everyone); fSUS: the last suspect step; fERR: why the exchange failed (sticky)
@@ -65,13 +70,16 @@ __device__ __forceinline__ void fs2_flag_wait(const float* word, unsigned target
   asm volatile("" ::: "memory");
 }
 
-template <int IN, int OUT, int KIND, int ACT, int H2 = 64, int ACT2 = ACT, bool TIMING = false>
+template <int IN, int OUT, int KIND, int ACT, int H2 = 64, int ACT2 = ACT, bool TIMING = false, bool PX = false, bool PXK = false>
 __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
+  static_assert(!PXK || PX, "PXK: the periodic form of the replica group");
+  static_assert(!PX || FsLayout<IN, OUT, 4, true, H2, false>::W2N + Fs2Layout<IN, OUT, H2>::NSC * 512 + 8 <= CRUX_PX_SEC, "a payload section must fit CRUX_PX_SEC");
   using Lt = Fs2Layout<IN, OUT, H2>;
   constexpr int NWG = 4, NWC = 4, TILES = 2, NT = 512, NTC = 256, MH = Lt::MH, HH = Lt::HH, W2N = Lt::W2N, NW = 8;
   constexpr int WT = Lt::WT2;                       // 16x16 tiles of W2 owned by a wave (all eight waves own tiles)
   constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS, NSC = Lt::NSC, XSLOT = Lt::XSLOT2;
   constexpr int NACT = (OUT > 4 ? OUT : 4);
+  constexpr bool BK_LDS = PX && Lt::BK_FITS;
   if ((int)(blockIdx.x & 7) != a.xcd) return;        // the four workgroups of the learner: blocks x, x + 8, x + 16, x + 24 -> one XCD
   const int p = (int)(blockIdx.x >> 3);
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -249,15 +257,18 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(pw[j][mm]) : "v"(peer + Lt::xW2 + tid * (4 * WT) + 4 * mm) : "memory"); }
   };
   // ... and, once they are in (the caller has waited), the total (s0 + s1) + (s2 + s3) -- own + partner, the other pair in index order, then the two pair sums: the same bits
-  // in all four workgroups (train_fs_kernel.h) --, the suspect test over the four contributions and this wave's share of the gradient norm
-  auto w2_total = [&](f32x4 (&gW2)[WT], f32x4 (&pw)[NWG - 1][WT], bool want_ssq, float& ssq, bool& bad) {
+  // in all four workgroups (train_fs_kernel.h)
+  auto w2_total = [&](f32x4 (&gW2)[WT], f32x4 (&pw)[NWG - 1][WT]) {
 #pragma unroll
     for (int j = 0; j < NWG - 1; ++j)
 #pragma unroll
       for (int mm = 0; mm < WT; ++mm) asm volatile("" : "+v"(pw[j][mm]));      // (asm statements keep their order: every use of a loaded value follows the wait)
 #pragma unroll
+    for (int mm = 0; mm < WT; ++mm) gW2[mm] = (gW2[mm] + pw[0][mm]) + (pw[1][mm] + pw[2][mm]);
+  };
+  auto w2_check = [&](const f32x4 (&gW2)[WT], bool want_ssq, float& ssq, bool& bad) {      // the suspect test over the totals and this wave's share of the gradient norm
+#pragma unroll
     for (int mm = 0; mm < WT; ++mm) {
-      gW2[mm] = (gW2[mm] + pw[0][mm]) + (pw[1][mm] + pw[2][mm]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) bad = bad || isnan(gW2[mm][r]);
       if (want_ssq) {
@@ -278,6 +289,126 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   for (int k = 0; k < NSC; ++k) { const int s = tid + NT * k; so_ok[k] = s < ns_valid; so_ex[k] = s >= Lt::sEX;
     so_part[k] = so_ok[k] ? s_part(s) : 0; so_master[k] = so_ok[k] ? s_master(s) : 0; }
   const bool stat_lane = tid >= NT - 8 && tid < NT - 1;      // stat sums, by 7 lanes of the last wave
+  // ---- replica group (comm.hip "peer"; the exchange of train_fs_kernel.h): mean over the group of NSEC payload sections (the W2-tile registers + the small parameters'
+  // registers of every thread) and one statistics word, the same bits on every workgroup of every rank. Per-step form: ONE section, the minibatch gradient and its statistics;
+  // periodic form (PXK): THREE sections -- theta, m, v after every k-th Adam step -- in one exchange. All four workgroups hold the same local values and share the writes (peer i
+  // of the N-1 goes to workgroup i mod 4): the sections go into slot [parity][my rank] of the peer's region, one lane issues the system-scope release and raises flag[my rank]
+  // there; every workgroup then waits for the N-1 flags in the OWN region and adds the N contributions in rank order. Called by all 512 threads (two workgroup barriers).
+  // 0 = done, 1 = a replica did not answer or this learner had already failed (fERR is set), 2 = skipped: the step is suspect (a NaN total: the launch ends with CRUX_ENAN).
+  float* const px_mine = PX ? a.px_tab[a.px_rank] : nullptr;
+  const unsigned long long px0 = PX ? *(const unsigned long long*)(px_mine + CRUX_PX_COUNT) : 0ull;
+  const float px_inv = PX ? 1.0f / (float)a.px_n : 1.0f;
+  int pxc = 0;
+  auto px_allreduce_mean = [&](auto nsec_c, f32x4* const (&Wp)[3], float* const (&Sp)[3], float& xT, const bool failed, const unsigned tag, const bool check_suspect) -> int {
+    constexpr int NSEC = decltype(nsec_c)::value;
+    const unsigned long long xg = px0 + (unsigned long long)pxc;       // number of this exchange on this learner stream
+    const int par = (int)(xg & 1ull);
+    if (!failed) { int pi_ = 0;
+      for (int r = 0; r < a.px_n; ++r) {
+        if (r == a.px_rank || (pi_++ % NWG) != p) continue;
+        float* dst0 = a.px_tab[r] + (size_t)(par * CRUX_PX_MAXR + a.px_rank) * CRUX_PX_SLOT;
+#pragma unroll
+        for (int sec = 0; sec < NSEC; ++sec) { float* dst = dst0 + sec * CRUX_PX_SEC;
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) *(f32x4*)&dst[tid * (4 * WT) + 4 * mm] = Wp[sec][mm];
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) dst[W2N + tid + NT * k] = Sp[sec][k]; }
+        if (stat_lane) dst0[W2N + NSC * NT + (tid - (NT - 8))] = xT; } }
+    // release, the hand-off recipe of the CDNA guides: every wave drains its own slot stores, the workgroup meets, ONE lane issues the system-scope release and drains it
+    // before the flags go out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      unsigned* abortw = (unsigned*)(px_mine + CRUX_PX_ABORT);
+      const bool dead = fs2_flag_get(sm + Lt::fERR) != 0u, sus = check_suspect && fs2_flag_get(sm + Lt::fSUS) == tag;
+      bool ok = !dead && !sus;
+      if (ok) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int pi_ = 0;
+        for (int r = 0; r < a.px_n; ++r) { if (r == a.px_rank) continue;
+          if ((pi_++ % NWG) != p) continue;
+          __hip_atomic_store((unsigned long long*)(a.px_tab[r] + CRUX_PX_FLAGS) + 8 * a.px_rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        const long long t0 = wall_clock64();                // 100 MHz: a missing peer becomes CRUX_EHIP after the timeout instead of a hung GPU
+        for (int r = 0; r < a.px_n && ok; ++r) { if (r == a.px_rank) continue;
+          const unsigned long long* fl = (const unsigned long long*)(px_mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
+          while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > a.px_timeout || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
+        if (!ok) fs2_flag_set(sm + Lt::fERR, 3u);            // 3: a replica of the group did not answer within the timeout, or raised the abort word
+        if (a.px_hist) {      // how long this workgroup waited for the slowest peer's flag (10 ns ticks, log2 bins; workgroups 0 and 1 report)
+          const unsigned long long dtk = (unsigned long long)(wall_clock64() - t0) | 1ull;
+          if (p < 2) { unsigned* hb = (unsigned*)(px_mine + CRUX_PX_HIST) + 32 * p + (63 - __builtin_clzll(dtk) > 31 ? 31 : 63 - __builtin_clzll(dtk)); *hb = *hb + 1u; } }
+      }
+      if (!ok) {      // this learner leaves the group (failure, or a NaN step): the peers must not wait for it
+        for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!sus || dead) __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                       // system scope, one lane: drops this compute unit's L1 (the slot loads below bypass it anyway: sc0 sc1)
+    }
+    __syncthreads();
+    if (fs2_flag_get(sm + Lt::fERR) != 0u) return 1;
+    if (check_suspect && fs2_flag_get(sm + Lt::fSUS) == tag) return 2;
+    // the slots are read one rank at a time (all loads of a rank in flight together) and added in rank order; the own contribution comes from the registers
+    f32x4 oW[NSEC][WT]; float oS[NSEC][NSC]; const float oT = xT;
+#pragma unroll
+    for (int sec = 0; sec < NSEC; ++sec) {
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm) oW[sec][mm] = Wp[sec][mm];
+#pragma unroll
+      for (int k = 0; k < NSC; ++k) oS[sec][k] = Sp[sec][k]; }
+    for (int r = 0; r < a.px_n; ++r) {
+      f32x4 vW[NSEC][WT]; float vS[NSEC][NSC]; float vT = 0.f;
+      if (r != a.px_rank) {
+        const float* src0 = px_mine + (size_t)(par * CRUX_PX_MAXR + r) * CRUX_PX_SLOT;
+        if (stat_lane) vT = __hip_atomic_load(src0 + W2N + NSC * NT + (tid - (NT - 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int sec = 0; sec < NSEC; ++sec) { const float* src = src0 + sec * CRUX_PX_SEC;
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) vS[sec][k] = __hip_atomic_load(src + W2N + tid + NT * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm)
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(vW[sec][mm]) : "v"(src + tid * (4 * WT) + 4 * mm) : "memory"); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int sec = 0; sec < NSEC; ++sec)
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) asm volatile("" : "+v"(vW[sec][mm]));
+      } else {      // the own contribution (registers: nothing orders another workgroup's read after a store of this one, so it is never read back)
+        vT = oT;
+#pragma unroll
+        for (int sec = 0; sec < NSEC; ++sec) {
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) vW[sec][mm] = oW[sec][mm];
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) vS[sec][k] = oS[sec][k]; } }
+      if (r == 0) {
+#pragma unroll
+        for (int sec = 0; sec < NSEC; ++sec) {
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) Wp[sec][mm] = vW[sec][mm];
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) Sp[sec][k] = vS[sec][k]; }
+        xT = vT;
+      } else {
+#pragma unroll
+        for (int sec = 0; sec < NSEC; ++sec) {
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) Wp[sec][mm] += vW[sec][mm];
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) Sp[sec][k] += vS[sec][k]; }
+        xT += vT;
+      }
+    }
+    // mean over the group (gradient: global minibatch = px_n x nb samples, every rank's partial was already divided by nb)
+#pragma unroll
+    for (int sec = 0; sec < NSEC; ++sec) {
+#pragma unroll
+      for (int mm = 0; mm < WT; ++mm) Wp[sec][mm] = Wp[sec][mm] * px_inv;
+#pragma unroll
+      for (int k = 0; k < NSC; ++k) Sp[sec][k] = Sp[sec][k] * px_inv; }
+    xT = xT * px_inv;
+    pxc += 1;
+    return 0;
+  };
   // ---- the end of a step in every wave, once the workgroup's small partials are in LDS (B_2): the small partials leave as granules; the peers' W2 partials (phase 1 complete)
   // and granules come in; totals, Adam, B_b; suspect steps. false = the launch ends here (err is set).
   int st_now = 0;      // the minibatch loops set it: first row of the current minibatch
@@ -341,13 +472,33 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     FS2_T(12);
     float ssq = 0.f; bool bad_tot = false;
     const bool want_ssq = static_report(st_now) || (KIND != MFK_VALUE && target_kl >= 0.f);      // only a step that may report needs the gradient norm
-    f32x4 tW2o[WT], mW2o[WT], vW2o[WT];      // the state before this step's update: a suspect step (known after B_b) is undone first
+    f32x4 tW2o[BK_LDS ? 1 : WT], mW2o[BK_LDS ? 1 : WT], vW2o[BK_LDS ? 1 : WT];      // the state before this step's update: a suspect step (known after B_b) is undone first
+    float* const bk = sm + Lt::oBK + 4 * tid;      // (LDS form: [theta | m | v][tile][thread] x 16 B)
 #pragma unroll
-    for (int mm = 0; mm < WT; ++mm) { tW2o[mm] = tW2[mm]; mW2o[mm] = mW2[mm]; vW2o[mm] = vW2[mm]; }
+    for (int mm = 0; mm < WT; ++mm) {
+      if constexpr (BK_LDS) { *(f32x4*)&bk[4 * NT * mm] = tW2[mm]; *(f32x4*)&bk[4 * NT * (WT + mm)] = mW2[mm]; *(f32x4*)&bk[4 * NT * (2 * WT + mm)] = vW2[mm]; }
+      else { tW2o[mm] = tW2[mm]; mW2o[mm] = mW2[mm]; vW2o[mm] = vW2[mm]; } }
     float th_o[NSC], m_o[NSC], v_o[NSC];
     float stat_tot = stat_loc;
-    if (!failed) {
-      w2_total(gW2, pw, want_ssq, ssq, bad_tot);
+    if constexpr (PX && !PXK) {
+      if (!failed) {
+        w2_total(gW2, pw);
+#pragma unroll
+        for (int k = 0; k < NSC; ++k) gs[k] = (gs[k] + pg[0][k]) + (pg[1][k] + pg[2][k]);
+        stat_tot = (stat_loc + ps[0]) + (ps[1] + ps[2]);
+      }
+      // the group's all-reduce of the minibatch gradient and its statistics, between the pullback (training.jl:18) and Flux.update! (:21)
+      f32x4* const Wp[3] = {gW2, nullptr, nullptr}; float* const Sp[3] = {gs, nullptr, nullptr};
+      if (px_allreduce_mean(std::integral_constant<int, 1>{}, Wp, Sp, stat_tot, failed, tag, false) != 0) failed = true;
+      if (!failed) {
+        w2_check(gW2, want_ssq, ssq, bad_tot);
+        adam_w2(gW2);                            // (every compute wave is past B_2: nobody reads the W2 masters any more)
+#pragma unroll
+        for (int k = 0; k < NSC; ++k) bad_tot = bad_tot || (so_ok[k] && isnan(gs[k]));
+        if (bad_tot) fs2_flag_set(sm + Lt::fSUS, tag);
+      }
+    } else if (!failed) {
+      w2_total(gW2, pw); w2_check(gW2, want_ssq, ssq, bad_tot);
       adam_w2(gW2);                            // (every compute wave is past B_2: nobody reads the W2 masters any more)
 #pragma unroll
       for (int k = 0; k < NSC; ++k) { gs[k] = (gs[k] + pg[0][k]) + (pg[1][k] + pg[2][k]); bad_tot = bad_tot || (so_ok[k] && isnan(gs[k])); }
@@ -371,6 +522,28 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
           const float d = adam1(gs[k], m_, v_, ak);
           sm[Lt::oMS + s] = m_; sm[Lt::oVS + s] = v_; sm[mo] = th - d; } } };
     if (!failed) adam_small();
+    if constexpr (PX && PXK) {
+      // ---- periodic form (crux_peer_set_sync_every(k > 1)): between exchanges every replica takes LOCAL Adam steps on its own shard; after every k-th step the group averages
+      // theta, m and v (sum in rank order x 1/N: the same bits everywhere, so the replicas leave the exchange identical). One exchange per k steps instead of k.
+      if ((total_batches + 1) % a.px_every == 0) {
+        float sT[NSC], sM[NSC], sV[NSC]; float dummy = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSC; ++k) { const int s = tid + NT * k; const bool ok_ = so_ok[k] && !failed;
+          sT[k] = ok_ ? sm[so_master[k]] : 0.f; sM[k] = ok_ ? sm[Lt::oMS + s] : 0.f; sV[k] = ok_ ? sm[Lt::oVS + s] : 0.f; }
+        f32x4* const Wp[3] = {tW2, mW2, vW2}; float* const Sp[3] = {sT, sM, sV};
+        const int rc = px_allreduce_mean(std::integral_constant<int, 3>{}, Wp, Sp, dummy, failed, tag, true);
+        if (rc == 1) failed = true;
+        if (rc == 0) {
+#pragma unroll
+          for (int k = 0; k < NSC; ++k) { const int s = tid + NT * k;
+            if (so_ok[k]) { sm[so_master[k]] = sT[k]; sm[Lt::oMS + s] = sM[k]; sm[Lt::oVS + s] = sV[k]; } }
+#pragma unroll
+          for (int mm = 0; mm < WT; ++mm) {      // the LDS copies of W2 follow the averaged registers
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm[Lt::oW2R + (16 * mp0 + 4 * g + r) * FS_LD + 16 * (m0 + mm) + c] = tW2[mm][r];
+            *(f32x4*)&sm[Lt::oW2C + (16 * (m0 + mm) + c) * FS_LD + 16 * mp0 + 4 * g] = tW2[mm]; } }
+      }
+    }
     FS2_T(14);
     __syncthreads();   // ---- B_b: masters updated; tiles and partials may be overwritten
     { const unsigned why = fs2_flag_get(sm + Lt::fERR); if (why != 0u) { err = CRUX_EHIP; why_failed = (int)why; return false; } }
@@ -380,7 +553,9 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
       for (int k = 0; k < NSC; ++k) { const int s = tid + NT * k;
         if (so_ok[k]) { sm[Lt::oMS + s] = m_o[k]; sm[Lt::oVS + s] = v_o[k]; sm[so_master[k]] = th_o[k]; } }
 #pragma unroll
-      for (int mm = 0; mm < WT; ++mm) { tW2[mm] = tW2o[mm]; mW2[mm] = mW2o[mm]; vW2[mm] = vW2o[mm]; }
+      for (int mm = 0; mm < WT; ++mm) {
+        if constexpr (BK_LDS) { tW2[mm] = *(const f32x4*)&bk[4 * NT * mm]; mW2[mm] = *(const f32x4*)&bk[4 * NT * (WT + mm)]; vW2[mm] = *(const f32x4*)&bk[4 * NT * (2 * WT + mm)]; }
+        else { tW2[mm] = tW2o[mm]; mW2[mm] = mW2o[mm]; vW2[mm] = vW2o[mm]; } }
       any_bad = 1;
     }
     return true;
@@ -792,9 +967,10 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         a.p[pc] = tW2[mm][r]; a.m[pc] = mW2[mm][r]; a.v[pc] = vW2[mm][r]; } }
   if (p == 0) { for (int s = tid; s < ns_valid; s += NT) { const int pc = s_canon(s); a.p[pc] = sm[s_master(s)]; a.m[pc] = sm[Lt::oMS + s]; a.v[pc] = sm[Lt::oVS + s]; } }
   if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(NW * p + w) * 16 + k] = tacc[k]; }
+  if (PX && tid == 0 && p == 0) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)pxc;
   if (tid == 0 && (p == 0 || err)) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
-    if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 4 a workgroup missed the abort-latch consensus
+    if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 3 replica group timeout / abort, 4 a workgroup missed the abort-latch consensus
     a.bp[0] = bp1; a.bp[1] = bp2;
     if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = sm[Lt::iLOSS]; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
   }

@@ -130,3 +130,67 @@ def test_fs2_nan_step_is_an_error_and_leaves_the_parameters_of_the_step_before(g
     net = _nets(family)[which]; clean = _shard(family, 902, 8, 128); b = _buffer(family, clean)
     crux.batch_train_(net, crux.TrainingParams(loss=loss, batch_size=128, epochs=1, max_batches=2, name="n_"), P, b, perms=perm[None, :] + 1)
     assert _same_bits(got["fs2"], got["fs"]) and _same_bits(got["fs2"][:3], _state(net)[:3])
+
+
+@pytest.mark.parametrize("family,k", [("cartpole", 1), ("cartpole", 4), ("synth_c5", 1), ("synth_c5", 4)])
+def test_fs2_replica_group_forms_against_those_of_fs(gpu_ctx, monkeypatch, family, k):
+    """k_train_fs2<..., PX> / <..., PX, PXK> (round 5: the replica-group exchange inside the role-specialised kernel, C2 and C5 shapes) against the same forms of k_train_fs
+    (CRUX_FS2=0): two contexts on one device wired into a group of two (crux_peer_attach_local), distinct shards, per-step all-reduce (k = 1) and the periodic form (k = 4).
+    Same sums in the same order: the two replicas of a group must leave the same bits. Between the two kernels the last place may differ -- the PX instantiations of
+    k_train_fs contract the loss head's a * b + c differently from its plain form (ADVICE r4 #4), which the plain k_train_fs2 is bit-identical to -- so: 16 steps within 2e-7."""
+    import threading
+    od, ad, disc = parity.FAMILIES[family][:3]
+    shards = [_shard(family, 910, 8, 128), _shard(family, 911, 8, 128)]
+    N = shards[0]["s"].shape[1]; epochs = 2
+    rng = np.random.default_rng(12); perms = [np.stack([rng.permutation(N) for _ in range(epochs)]) for _ in range(2)]
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1 if disc else 0.0}
+    c1 = crux.Context(0); ctxs = [gpu_ctx, c1]
+    out = {}
+    try:
+        crux.peer_attach_local(ctxs)
+        for c in ctxs:
+            c.peer_set_sync_every(k)
+        for form in ("fs2", "fs"):
+            monkeypatch.setenv("CRUX_FS2", "1" if form == "fs2" else "0")
+            res = []
+            for which in (0, 1):
+                nets, bufs = [], []
+                for r, ctx in enumerate(ctxs):
+                    ch = parity.chain(parity.FAMILIES[family][3 + which], parity.FAMILIES[family][5] if which == 0 else parity.CRITIC_ACTS.get(family, parity.FAMILIES[family][5]))
+                    if which == 1:
+                        g = crux.ContinuousNetwork(ch, ctx=ctx, seed=83, stream=3)
+                    elif disc:
+                        g = crux.DiscreteNetwork(ch, list(range(1, ad + 1)), ctx=ctx, seed=83, stream=3)
+                    else:
+                        g = crux.GaussianPolicy(ch, np.full(ad, -0.5, np.float32), ctx=ctx, seed=83, stream=3)
+                    b = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.DiscreteSpace(ad) if disc else crux.ContinuousSpace(ad), N, ["return", "logprob", "advantage"], ctx=ctx); b.push_(shards[r])
+                    nets.append(g); bufs.append(b)
+                errs = [None, None]; infos = [None, None]
+                def run(r):
+                    try:
+                        opt = crux.TrainingParams(loss=crux.ppo_loss if which == 0 else crux.value_mse_loss, batch_size=128, epochs=epochs, name="n_")
+                        infos[r] = crux.batch_train_(nets[r], opt, P, bufs[r], perms=perms[r] + 1)
+                    except Exception as e:      # noqa: BLE001
+                        errs[r] = e
+                ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]; [t.start() for t in ts]; [t.join(120) for t in ts]
+                assert not any(t.is_alive() for t in ts), "a replica did not return"
+                for e in errs:
+                    if e is not None:
+                        raise e
+                st = [_state(n) for n in nets]
+                assert _same_bits(st[0], st[1])                       # the replicas of a group never diverge
+                res.append((st[0], infos[0]))
+            out[form] = res
+        for (s2, i2), (s1, i1) in zip(out["fs2"], out["fs"]):
+            assert i2["n_batches_trained"] == i1["n_batches_trained"] == epochs * (N // 128)
+            d = [float(np.abs(x - y).max() / max(1.0, float(np.abs(y).max()))) for x, y in zip(s2[:3], s1[:3])]
+            print("fs2 vs fs replica-group form, %s k=%d: max |dtheta| %.3g |dm| %.3g |dv| %.3g (relative to the largest entry)" % (family, k, *d))
+            assert max(d) < 2e-7 and np.array_equal(s2[3], s1[3])
+            assert abs(i2["n_loss"] - i1["n_loss"]) <= 2e-6 * max(1.0, abs(i1["n_loss"]))
+    finally:
+        for c in ctxs:
+            try:
+                c.peer_set_sync_every(1); c.peer_detach()
+            except Exception:       # noqa: BLE001
+                pass
+        c1.close()
