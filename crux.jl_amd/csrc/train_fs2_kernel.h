@@ -439,6 +439,22 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     bool failed = fs2_flag_get(sm + Lt::fERR) != 0u;
     f32x4 pw[NWG - 1][WT];
     if (!failed) w2_loads(pw);
+    float ssq = 0.f; bool bad_tot = false;
+    const bool want_ssq = static_report(st_now) || (KIND != MFK_VALUE && target_kl >= 0.f);      // only a step that may report needs the gradient norm
+    f32x4 tW2o[BK_LDS ? 1 : WT], mW2o[BK_LDS ? 1 : WT], vW2o[BK_LDS ? 1 : WT];      // the state before this step's update: a suspect step (known after B_b) is undone first
+    float* const bk = sm + Lt::oBK + 4 * tid;      // (LDS form: [theta | m | v][tile][thread] x 16 B)
+#pragma unroll
+    for (int mm = 0; mm < WT; ++mm) {
+      if constexpr (BK_LDS) { *(f32x4*)&bk[4 * NT * mm] = tW2[mm]; *(f32x4*)&bk[4 * NT * (WT + mm)] = mW2[mm]; *(f32x4*)&bk[4 * NT * (2 * WT + mm)] = vW2[mm]; }
+      else { tW2o[mm] = tW2[mm]; mW2o[mm] = mW2[mm]; vW2o[mm] = vW2[mm]; } }
+    // the W2 update BEFORE the peers' small granules are asked for: those left a moment ago and need an L2 hop (polls that come back stale only keep the load path busy),
+    // the W2 partials (phase 1 complete) are in the L2 already -- same box: C2 5.40 -> 5.396, C5 7.61 -> 7.50 us per step. (The per-step replica-group form needs both totals
+    // before its exchange.)
+    constexpr bool W2_FIRST = !(PX && !PXK);
+    if constexpr (W2_FIRST) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!failed) { w2_total(gW2, pw); w2_check(gW2, want_ssq, ssq, bad_tot); adam_w2(gW2); }      // (every compute wave is past B_2: nobody reads the W2 masters any more)
+    }
     // poll the peers' granules: the same loads again until every tag is this step's
     constexpr int NLD = NWG - 1;
     float pg[NLD][NSC]; float ps[NLD];
@@ -470,14 +486,6 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     FS2_T(11);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FS2_T(12);
-    float ssq = 0.f; bool bad_tot = false;
-    const bool want_ssq = static_report(st_now) || (KIND != MFK_VALUE && target_kl >= 0.f);      // only a step that may report needs the gradient norm
-    f32x4 tW2o[BK_LDS ? 1 : WT], mW2o[BK_LDS ? 1 : WT], vW2o[BK_LDS ? 1 : WT];      // the state before this step's update: a suspect step (known after B_b) is undone first
-    float* const bk = sm + Lt::oBK + 4 * tid;      // (LDS form: [theta | m | v][tile][thread] x 16 B)
-#pragma unroll
-    for (int mm = 0; mm < WT; ++mm) {
-      if constexpr (BK_LDS) { *(f32x4*)&bk[4 * NT * mm] = tW2[mm]; *(f32x4*)&bk[4 * NT * (WT + mm)] = mW2[mm]; *(f32x4*)&bk[4 * NT * (2 * WT + mm)] = vW2[mm]; }
-      else { tW2o[mm] = tW2[mm]; mW2o[mm] = mW2[mm]; vW2o[mm] = vW2[mm]; } }
     float th_o[NSC], m_o[NSC], v_o[NSC];
     float stat_tot = stat_loc;
     if constexpr (PX && !PXK) {
@@ -498,8 +506,8 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         if (bad_tot) fs2_flag_set(sm + Lt::fSUS, tag);
       }
     } else if (!failed) {
-      w2_total(gW2, pw); w2_check(gW2, want_ssq, ssq, bad_tot);
-      adam_w2(gW2);                            // (every compute wave is past B_2: nobody reads the W2 masters any more)
+      if constexpr (!W2_FIRST) { w2_total(gW2, pw); w2_check(gW2, want_ssq, ssq, bad_tot);
+        adam_w2(gW2); }                          // (every compute wave is past B_2: nobody reads the W2 masters any more)
 #pragma unroll
       for (int k = 0; k < NSC; ++k) { gs[k] = (gs[k] + pg[0][k]) + (pg[1][k] + pg[2][k]); bad_tot = bad_tot || (so_ok[k] && isnan(gs[k])); }
       if (bad_tot) fs2_flag_set(sm + Lt::fSUS, tag);
