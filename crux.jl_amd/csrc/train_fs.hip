@@ -19,6 +19,11 @@ static int32_t launch_fs_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
 // (the shapes added in round 3 for the standard Gym tasks -- IN > 17 or not one of the benchmark shapes -- are instantiated in the default form only: FS_LITE)
 template <int IN, int OUT> constexpr bool FS_LITE = !((IN == 4 && (OUT == 2 || OUT == 1)) || (IN == 3 && OUT == 1) || (IN == 17 && (OUT == 6 || OUT == 1)) || (IN == 8 && (OUT == 4 || OUT == 1)) || (IN == 2 && OUT == 1));
 template <int IN, int OUT> constexpr bool FS_WIDE_HEAD = IN == 27 && OUT == 8;
+// replica-group forms (PX / PXK) of THIS kernel: the shapes k_train_fs2 does not take as a group (24 / 27 inputs) and the C2 / C5 learners, on which the two kernels are
+// compared (tests/test_gpu_fs2.py) and CRUX_FS2=0 still runs a group; every other shape of a group is k_train_fs2's
+template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2> constexpr bool FS_HAS_PX = IN >= 24 || (H2 == 64 && ACT2 == ACT &&
+  ((IN == 4 && ACT == CRUX_ACT_RELU && ((OUT == 2 && KIND == MFK_CATEGORICAL) || (OUT == 1 && KIND == MFK_VALUE))) ||
+   (IN == 17 && ACT == CRUX_ACT_TANH && ((OUT == 6 && KIND == MFK_GAUSSIAN) || (OUT == 1 && KIND == MFK_VALUE)))));
 template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, bool TIMING>
 static int32_t launch_fs_pick(crux_ctx* c, TrainArgs& a, int form, hipStream_t stream) {
   if constexpr (H2 == 64 && ACT2 == ACT && !FS_LITE<IN, OUT>) {
@@ -39,7 +44,7 @@ static int32_t launch_fs(crux_ctx* c, TrainArgs a, int form, bool timing, hipStr
   HIPCHK(c, hipMemsetAsync(a.xctr, 0, 256, stream));
   a.xcd = which;      // actor / critic (the context's two learner streams) behind different L2s. (Replicas sharing a device stay on the same XCD pair: spreading them over XCDs
                       // sent their flag / slot traffic across L2s and measured 15.5 against 12.9 us per step on one GPU.)
-  if (crux_grouped(c) && a.need_px) {      // replica group: four workgroups with helper waves, the in-kernel all-reduce over the peer slots
+  if constexpr (FS_HAS_PX<IN, OUT, KIND, ACT, H2, ACT2>) if (crux_grouped(c) && a.need_px) {      // replica group: four workgroups with helper waves, the in-kernel all-reduce over the peer slots
     a.px_hist = c->peer_hist ? 1 : 0; a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
     if (a.px_every > 1) return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, true, false, true, false, true>(c, a, stream);      // periodic form: local Adam steps, theta / m / v averaged every k-th
     return launch_fs_form<IN, OUT, KIND, ACT, H2, ACT2, 4, true, false, true>(c, a, stream);
@@ -102,7 +107,9 @@ int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hip
     if (rc2 || *handled) return rc2; }
   const int form = form_env == 2 || form_env == 4 || form_env == 8 ? form_env : CRUX_FS_DEFAULT_WG;      // 8 = four workgroups with helper waves
   const bool timing = crux_sw().mfma_timing;
-#define FS_CASE2(I, O, K, A1, H, A2) if (in == I && out == O && kind == K && act == A1 && h2 == H && act2 == A2) { *handled = true; if (probe) return CRUX_OK; return launch_fs<I, O, K, A1, H, A2>(c, a, form, timing, stream); }
+  const bool grouped = crux_grouped(c) && a.need_px;
+#define FS_CASE2(I, O, K, A1, H, A2) if (in == I && out == O && kind == K && act == A1 && h2 == H && act2 == A2) { if (grouped && !FS_HAS_PX<I, O, K, A1, H, A2>) return CRUX_OK; \
+    *handled = true; if (probe) return CRUX_OK; return launch_fs<I, O, K, A1, H, A2>(c, a, form, timing, stream); }
 #define FS_CASE(I, O, K, A_) FS_CASE2(I, O, K, A_, 64, A_)
   FS_CASE(4, 2, MFK_CATEGORICAL, CRUX_ACT_RELU)     // C2 actor  (PPO CartPole)
   FS_CASE(4, 1, MFK_VALUE, CRUX_ACT_RELU)           // C2 critic

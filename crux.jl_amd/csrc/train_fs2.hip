@@ -1,7 +1,7 @@
 // train_fs2.hip -- dispatch of the role-specialised form of the register-resident learner kernel (train_fs2_kernel.h: k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2>): the plain
 // policy-gradient / critic losses of full batch_train! loops (src/training.jl:28-55) on every IN->64->{64,32}->OUT shape k_train_fs serves, on four compute units of one XCD
 // with four compute + four helper waves each. Called by crux_train_fs_launch (train_fs.hip) for the launches that are neither lagrange_ppo_loss nor one of the explicitly
-// requested older forms (CRUX_FS_WG); replica groups on the C2 / C5 shapes (PX / PXK instantiations); CRUX_FS2=0 keeps k_train_fs for all of them.
+// requested older forms (CRUX_FS_WG), replica groups included (PX / PXK instantiations; the 24- / 27-input shapes of a group stay on k_train_fs); CRUX_FS2=0 keeps k_train_fs.
 #include "train_fs2_kernel.h"
 
 template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, bool TIMING, bool PX = false, bool PXK = false>
@@ -13,11 +13,9 @@ static int32_t launch_fs2_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL((k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING, PX, PXK>), dim3(32), dim3(512), lds, stream, a);
   return crux_launch_check(c, PXK ? "k_train_fs2 (replica group, periodic form)" : PX ? "k_train_fs2 (replica group)" : "k_train_fs2");
 }
-// the shapes whose replica-group forms (PX / PXK) are instantiated in the role-specialised kernel: the learners of BASELINE's configurations (C2: PPO CartPole, C5: the
-// HalfCheetah-shaped shard); every other shape of a replica group stays on k_train_fs
-template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2> constexpr bool FS2_HAS_PX = H2 == 64 && ACT2 == ACT &&
-  ((IN == 4 && ACT == CRUX_ACT_RELU && ((OUT == 2 && KIND == MFK_CATEGORICAL) || (OUT == 1 && KIND == MFK_VALUE))) ||
-   (IN == 17 && ACT == CRUX_ACT_TANH && ((OUT == 6 && KIND == MFK_GAUSSIAN) || (OUT == 1 && KIND == MFK_VALUE))));
+// the shapes whose replica-group forms (PX / PXK) are instantiated in the role-specialised kernel: every shape whose W2 backups fit into LDS beside the kernel's own
+// 113..132 KB (all but the 24- and 27-input ones, which spill without them and stay on k_train_fs)
+template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2> constexpr bool FS2_HAS_PX = IN < 24 && Fs2Layout<IN, OUT, H2>::BK_FITS;
 template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2>
 static int32_t launch_fs2(crux_ctx* c, TrainArgs a, bool timing, hipStream_t stream) {
   const int which = stream == c->stream ? 0 : 1;

@@ -13,8 +13,9 @@
 //   dZ1, db1, db2, dW1 partials                                 P1: load the three peers' partials of the own tiles, total, Adam (theta, m, v in registers)
 //   -- compute barrier (LDS) --
 //   small partials -> 8-byte {value, step} GRANULES in the slot
-//   P1: load the peers' partials of the own W2 tiles; poll the peers' granules (the tag is the flag: ONE round trip)
-//   W2 total + Adam, small total + Adam
+//   P1: load the peers' partials of the own W2 tiles -> W2 total + Adam (the small granules are still on their way)
+//   poll the peers' granules (the tag is the flag: ONE round trip) -> small total + Adam
+//   (replica group, PX: the group's all-reduce of the totals sits between the totals and Adam; PXK: its theta / m / v average after every k-th Adam step)
 //   ============================== B_b (s_barrier): masters updated ==========================================================
 //
 //   (1) the W2 partials (89 % of the bytes) leave right after dW2 as before, but their hand-shake (drain, arrival counter, wait) is now run by the helper leader WHILE the

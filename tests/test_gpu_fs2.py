@@ -194,3 +194,62 @@ def test_fs2_replica_group_forms_against_those_of_fs(gpu_ctx, monkeypatch, famil
             except Exception:       # noqa: BLE001
                 pass
         c1.close()
+
+
+@pytest.mark.parametrize("family,k", [("synth_8_4", 1), ("synth_8_4", 4), ("cheetah_ref", 1), ("cheetah_ref", 4), ("synth_2_1", 1)])
+def test_fs2_group_of_two_on_identical_shards_equals_a_group_of_one(gpu_ctx, family, k):
+    """The other shapes of the family as members of a replica group (k_train_fs2<..., PX / PXK>; k_train_fs has no group forms for them any more): two replicas with the SAME
+    rows and shuffles -- g + g and the division by two are exact, the average of two identical theta / m / v is that theta / m / v -- must leave exactly the bits a group of
+    ONE leaves (same instantiation, same code path)."""
+    import threading
+    od, ad, disc = parity.FAMILIES[family][:3]
+    shard = _shard(family, 920, 8, 128); N = shard["s"].shape[1]; epochs = 2
+    rng = np.random.default_rng(13); perms = np.stack([rng.permutation(N) for _ in range(epochs)])
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1 if disc else 0.0}
+    def run_group(ctxs):
+        crux.peer_attach_local(ctxs)
+        try:
+            for c in ctxs:
+                c.peer_set_sync_every(k)
+            res = []
+            for which in (0, 1):
+                nets, bufs = [], []
+                for ctx in ctxs:
+                    ch = parity.chain(parity.FAMILIES[family][3 + which], parity.FAMILIES[family][5] if which == 0 else parity.CRITIC_ACTS.get(family, parity.FAMILIES[family][5]))
+                    if which == 1:
+                        g = crux.ContinuousNetwork(ch, ctx=ctx, seed=85, stream=3)
+                    elif disc:
+                        g = crux.DiscreteNetwork(ch, list(range(1, ad + 1)), ctx=ctx, seed=85, stream=3)
+                    else:
+                        g = crux.GaussianPolicy(ch, np.full(ad, -0.5, np.float32), ctx=ctx, seed=85, stream=3)
+                    b = crux.ExperienceBuffer(crux.ContinuousSpace(od), crux.DiscreteSpace(ad) if disc else crux.ContinuousSpace(ad), N, ["return", "logprob", "advantage"], ctx=ctx); b.push_(shard)
+                    nets.append(g); bufs.append(b)
+                errs = [None] * len(ctxs)
+                def run(r):
+                    try:
+                        crux.batch_train_(nets[r], crux.TrainingParams(loss=crux.ppo_loss if which == 0 else crux.value_mse_loss, batch_size=128, epochs=epochs, name="n_"), P, bufs[r], perms=perms + 1)
+                    except Exception as e:      # noqa: BLE001
+                        errs[r] = e
+                ts = [threading.Thread(target=run, args=(r,)) for r in range(len(ctxs))]; [t.start() for t in ts]; [t.join(120) for t in ts]
+                assert not any(t.is_alive() for t in ts), "a replica did not return"
+                for e in errs:
+                    if e is not None:
+                        raise e
+                st = [_state(n) for n in nets]
+                for x in st[1:]:
+                    assert _same_bits(st[0], x)
+                res.append(st[0])
+            return res
+        finally:
+            for c in ctxs:
+                try:
+                    c.peer_set_sync_every(1); c.peer_detach()
+                except Exception:       # noqa: BLE001
+                    pass
+    c1 = crux.Context(0)
+    try:
+        two = run_group([gpu_ctx, c1]); one = run_group([gpu_ctx])
+    finally:
+        c1.close()
+    for s2, s1 in zip(two, one):
+        assert _same_bits(s2, s1), "max |dtheta| = %.3g" % float(np.abs(s2[0] - s1[0]).max())
