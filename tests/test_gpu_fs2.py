@@ -253,3 +253,49 @@ def test_fs2_group_of_two_on_identical_shards_equals_a_group_of_one(gpu_ctx, fam
         c1.close()
     for s2, s1 in zip(two, one):
         assert _same_bits(s2, s1), "max |dtheta| = %.3g" % float(np.abs(s2[0] - s1[0]).max())
+
+
+@pytest.mark.parametrize("k", [1, 4])
+def test_fs2_replica_group_nan_step(gpu_ctx, k):
+    """training.jl:20 inside a replica group (k_train_fs2<..., PX / PXK>). Per-step form: the NaN arrives in every replica's group mean at the same step, so BOTH fail with
+    CRUX_ENAN and keep the identical state of the step before. Periodic form: the gradients are local between exchanges -- the replica that met the NaN fails with CRUX_ENAN
+    (state of its step before), skips the exchange and raises its peers' abort words, so the other replica leaves with CRUX_EHIP instead of waiting for the timeout."""
+    import threading
+    family = "cartpole"; shards = [_shard(family, 930, 8, 128), _shard(family, 931, 8, 128)]
+    N = shards[0]["s"].shape[1]; perm = np.random.default_rng(2).permutation(N)
+    shards[1]["s"] = shards[1]["s"].copy(); shards[1]["s"][0, perm[2 * 128 + 5]] = np.nan          # replica 1's third minibatch picks the poisoned row up
+    P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
+    c1 = crux.Context(0); ctxs = [gpu_ctx, c1]
+    try:
+        crux.peer_attach_local(ctxs)
+        for c in ctxs:
+            c.peer_set_sync_every(k)
+        nets, bufs = [], []
+        for r, ctx in enumerate(ctxs):
+            g = crux.DiscreteNetwork(parity.chain(parity.FAMILIES[family][3], parity.FAMILIES[family][5]), [1, 2], ctx=ctx, seed=87, stream=3)
+            b = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), N, ["return", "logprob", "advantage"], ctx=ctx); b.push_(shards[r])
+            nets.append(g); bufs.append(b)
+        errs = [None, None]
+        def run(r):
+            try:
+                crux.batch_train_(nets[r], crux.TrainingParams(loss=crux.ppo_loss, batch_size=128, epochs=1, name="n_"), P, bufs[r], perms=perm[None, :] + 1)
+            except crux.CruxError as e:
+                errs[r] = e
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]; [t.start() for t in ts]; [t.join(120) for t in ts]
+        assert not any(t.is_alive() for t in ts), "a replica did not return"
+        assert errs[1] is not None and errs[1].code == L.ENAN
+        st = [_state(n) for n in nets]
+        if k == 1:
+            assert errs[0] is not None and errs[0].code == L.ENAN
+            assert _same_bits(st[0], st[1])
+            assert not np.isnan(st[0][0]).any() and float(st[0][3][0]) == pytest.approx(0.9 ** 3)      # two clean steps taken: beta1^(t+1) with t = 2
+        else:
+            assert errs[0] is not None and errs[0].code == L.EHIP
+            assert not np.isnan(st[1][0]).any() and float(st[1][3][0]) == pytest.approx(0.9 ** 3)
+    finally:
+        for c in ctxs:
+            try:
+                c.peer_set_sync_every(1); c.peer_detach()
+            except Exception:       # noqa: BLE001
+                pass
+        c1.close()
