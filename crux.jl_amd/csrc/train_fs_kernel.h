@@ -920,6 +920,8 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   }
   if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(NW * p + w) * 16 + k] = tacc[k]; }
   if (PX && tid == 0 && p == 0) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)pxc;
+  if constexpr (PX && PXK) {      // periodic form: a replica that leaves on a NaN step between two exchanges will not show up at the next one -- its peers must not wait for the timeout
+    if (tid == 0 && p == 0 && err == CRUX_ENAN) { for (int r = 0; r < a.px_n; ++r) if (r != a.px_rank) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }
   if (tid == 0 && (p == 0 || err)) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 3 replica group timeout / abort, 4 a workgroup missed the abort-latch consensus of a speculative run

@@ -255,12 +255,13 @@ def test_fs2_group_of_two_on_identical_shards_equals_a_group_of_one(gpu_ctx, fam
         assert _same_bits(s2, s1), "max |dtheta| = %.3g" % float(np.abs(s2[0] - s1[0]).max())
 
 
-@pytest.mark.parametrize("k", [1, 4])
-def test_fs2_replica_group_nan_step(gpu_ctx, k):
+@pytest.mark.parametrize("form,k", [("fs2", 1), ("fs2", 4), ("fs", 4)])
+def test_fs2_replica_group_nan_step(gpu_ctx, monkeypatch, form, k):
     """training.jl:20 inside a replica group (k_train_fs2<..., PX / PXK>). Per-step form: the NaN arrives in every replica's group mean at the same step, so BOTH fail with
     CRUX_ENAN and keep the identical state of the step before. Periodic form: the gradients are local between exchanges -- the replica that met the NaN fails with CRUX_ENAN
     (state of its step before), skips the exchange and raises its peers' abort words, so the other replica leaves with CRUX_EHIP instead of waiting for the timeout."""
     import threading
+    monkeypatch.setenv("CRUX_FS2", "1" if form == "fs2" else "0")
     family = "cartpole"; shards = [_shard(family, 930, 8, 128), _shard(family, 931, 8, 128)]
     N = shards[0]["s"].shape[1]; perm = np.random.default_rng(2).permutation(N)
     shards[1]["s"] = shards[1]["s"].copy(); shards[1]["s"][0, perm[2 * 128 + 5]] = np.nan          # replica 1's third minibatch picks the poisoned row up
