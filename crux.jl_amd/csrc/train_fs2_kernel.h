@@ -555,9 +555,10 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     }
     FS2_T(14);
     __syncthreads();   // ---- B_b: masters updated; tiles and partials may be overwritten
-    { const unsigned why = fs2_flag_get(sm + Lt::fERR); if (why != 0u) { err = CRUX_EHIP; why_failed = (int)why; return false; } }
+    const unsigned why = fs2_flag_get(sm + Lt::fERR), sus = fs2_flag_get(sm + Lt::fSUS);      // (both reads in flight together: one LDS round trip)
+    if (why != 0u) { err = CRUX_EHIP; why_failed = (int)why; return false; }
     any_bad = 0;
-    if (fs2_flag_get(sm + Lt::fSUS) == tag) {      // a thread of this workgroup found a NaN total: every thread back to its pre-step state (training.jl:20: error, no update)
+    if (sus == tag) {      // a thread of this workgroup found a NaN total: every thread back to its pre-step state (training.jl:20: error, no update)
 #pragma unroll
       for (int k = 0; k < NSC; ++k) { const int s = tid + NT * k;
         if (so_ok[k]) { sm[Lt::oMS + s] = m_o[k]; sm[Lt::oVS + s] = v_o[k]; sm[so_master[k]] = th_o[k]; } }
