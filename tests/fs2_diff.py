@@ -1,7 +1,7 @@
-"""development aid: k_train_fs2 against k_train_fs (CRUX_FS2=0) after a few minibatch steps, difference per parameter block (W1 b1 W2 b2 W3 b3 extra)"""
+"""development aid (test infrastructure: it builds its shards with the oracle, like the tests): k_train_fs2 against k_train_fs (CRUX_FS2=0) after a few minibatch steps, difference per parameter block (W1 b1 W2 b2 W3 b3 extra)"""
 import os, sys, subprocess, json
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import test_gpu_fs2 as T
     from parity import crux

@@ -1,4 +1,4 @@
-"""stress of the in-kernel replica exchange on ONE GPU: R contexts, actor || critic persistent learners per replica, thousands of minibatch steps;
+"""(test infrastructure: it builds its shards with the oracle, like the tests) stress of the in-kernel replica exchange on ONE GPU: R contexts, actor || critic persistent learners per replica, thousands of minibatch steps;
 the replicas must end bit-identical (any lost or torn slot read shows up as a divergence)."""
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -347,7 +347,7 @@ def test_unsupported_shape_with_a_group_attached_is_refused(two_contexts):
 
 # Four replicas on ONE device need a learner and an auxiliary stream per context = all eight hardware queues (GPU_MAX_HW_QUEUES = 8; larger values do not help): now and
 # then crux_peer_attach_local cannot find such a placement in its eight attempts and reports it: _group retries with fresh contexts (round 4: N = 4 runs by default, the
-# exchange is also covered at N = 4 by tools/peer_stress.py); N = 3 covers the unpaired last rank and the split of the peers between a learner's two workgroups.
+# exchange is also covered at N = 4 by tests/peer_stress.py); N = 3 covers the unpaired last rank and the split of the peers between a learner's two workgroups.
 _RS = [(3, "actor"), (3, "critic"), (4, "critic")] + ([(4, "actor")] if os.environ.get("CRUX_TEST_FOUR_REPLICAS") else [])
 
 
