@@ -251,6 +251,9 @@ def relaunch_under_torchrun(args):
     return subprocess.call(cmd)
 
 
+PROBE = {}      # the rendezvous probe's waits of this rank (setup_group), reported in the JSON line
+
+
 def setup_group(args, crux, ctx, rank, world, local):
     """Attach this rank to the replica group. Preference order, each level agreed by ALL ranks (a MIN all-reduce) before it is used:
     (1) peer slots: in-kernel per-minibatch gradient all-reduce over xGMI (exact data parallelism)   [--sync grad]
@@ -281,7 +284,22 @@ def setup_group(args, crux, ctx, rank, world, local):
                 print("bench.py: rank %d cannot attach the peer regions (%r)" % (rank, e), file=sys.stderr); ok = False
             if all_agree(ok):
                 dist.barrier()      # every rank has attached before any of them trains (cruxhip.h)
-                return "grad", "per-minibatch SUM all-reduce of the gradient inside the persistent learner kernel (peer slots over xGMI, hipIpc-mapped)"
+                # the rendezvous probe (crux_peer_probe, collective): do the ranks' kernels answer each other at the speed the in-kernel exchange assumes? A few us per
+                # rendezvous on one device, ~10 us over xGMI; milliseconds when the device's hardware queues are time-sliced (too many ranks on ONE GPU: 100 x slower
+                # iterations, profiles/r06_same_device_oversubscription.txt) -- such a group is refused here instead of being timed.
+                limit_us = 250.0 if args.same_device else 1000.0
+                try:
+                    ctx.peer_set_budget_ms(60000)
+                    PROBE["us"] = ctx.peer_probe(rounds=256, first_bound_ms=5000, round_bound_ms=50); ok = max(PROBE["us"][1], PROBE["us"][3]) <= limit_us
+                    if not ok:
+                        print("bench.py: rank %d: rendezvous probe too slow: %r us (limit %.0f)" % (rank, PROBE["us"], limit_us), file=sys.stderr)
+                except Exception as e:      # noqa: BLE001
+                    print("bench.py: rank %d: rendezvous probe failed (%r)" % (rank, e), file=sys.stderr); ok = False
+                if all_agree(ok):
+                    return "grad", "per-minibatch SUM all-reduce of the gradient inside the persistent learner kernel (peer slots over xGMI, hipIpc-mapped)"
+                if args.same_device:
+                    raise SystemExit("bench.py --same-device: the %d ranks' learner kernels do not run side by side on this one device (rendezvous probe, us: %r; co-resident kernels "
+                                     "meet in a few us): its hardware queues are time-sliced. Refusing to time a group that waits a scheduling quantum per exchange; use fewer ranks." % (world, PROBE.get("us")))
             try:
                 ctx.peer_detach()
             except Exception:       # noqa: BLE001
@@ -612,6 +630,8 @@ def main():
                     "requested": "grad" if requested_sync == "grad" else "params", "fell_back": bool(requested_sync == "grad" and sync != "grad"),
                     "sync_every_minibatches": args.sync_every if sync == "grad" else None,
                     "flag_wait_per_rank": waits if sync == "grad" else None,
+                    "rendezvous_probe_us": {"first_round_stream0": PROBE["us"][0], "slowest_later_round_stream0": PROBE["us"][1], "first_round_stream1": PROBE["us"][2], "slowest_later_round_stream1": PROBE["us"][3],
+                                            "note": "crux_peer_probe on rank 0: 256 rendezvous through the peer regions before anything is timed; the first round absorbs the launch skew between the ranks"} if PROBE.get("us") else None,
                     "flag_wait_note": "upper edge (us) of the log2 bin holding the percentile of the per-exchange wait for the slowest peer's flag, both learner streams, workgroups 0 and 1 of every learner",
                     "rccl_ranks": int(sum(1 for r in rccl if r and r.get("ok"))), "rccl_detail": rccl[0] if rccl else None}
 

@@ -144,7 +144,7 @@ SIGNATURES = {
     "crux_comm_destroy": (i32, [vp]),
     "crux_comm_size": (i32, [vp]),
     "crux_peer_export": (i32, [vp, vp]), "crux_peer_attach": (i32, [vp, i32, i32, vp]), "crux_peer_attach_local": (i32, [P(vp), i32]),
-    "crux_peer_detach": (i32, [vp]), "crux_peer_hist_enable": (i32, [vp, i32]), "crux_peer_set_sync_every": (i32, [vp, i32]), "crux_reload_switches": (i32, []), "crux_peer_sync_every": (i32, [vp]), "crux_peer_set_timeout_ms": (i32, [vp, i32]), "crux_peer_wait_hist": (i32, [vp, vp, i32]), "crux_peer_size": (i32, [vp]), "crux_peer_rank": (i32, [vp]),
+    "crux_peer_detach": (i32, [vp]), "crux_peer_hist_enable": (i32, [vp, i32]), "crux_peer_set_sync_every": (i32, [vp, i32]), "crux_reload_switches": (i32, []), "crux_peer_sync_every": (i32, [vp]), "crux_peer_set_timeout_ms": (i32, [vp, i32]), "crux_peer_set_budget_ms": (i32, [vp, i32]), "crux_peer_abort": (i32, [vp]), "crux_peer_abort_clear": (i32, [vp]), "crux_abort_all": (i32, []), "crux_peer_abort_reason": (i32, [vp, vp]), "crux_peer_probe": (i32, [vp, i32, i32, i32, vp]), "crux_peer_wait_hist": (i32, [vp, vp, i32]), "crux_peer_size": (i32, [vp]), "crux_peer_rank": (i32, [vp]),
     "crux_allreduce_mean": (i32, [vp]),
     "crux_allreduce_grads": (i32, [vp]),
     "crux_first_episode_metrics": (i32, [vp, i32, i64, f32, vp, vp, vp, vp]),

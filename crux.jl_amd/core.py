@@ -70,6 +70,25 @@ class Context:
         """in-kernel flag-wait timeout of one exchange (default 30 s): a rank whose peer died gets CruxError(EHIP) after this long instead of a hung GPU"""
         self.check(self.lib.crux_peer_set_timeout_ms(self.h, int(ms)))
 
+    def peer_set_budget_ms(self, ms):
+        """what the flag waits of ONE learner launch may add up to (default 60 s; 0 = no budget): replicas that answer, but a scheduling quantum late (cruxhip.h)"""
+        self.check(self.lib.crux_peer_set_budget_ms(self.h, int(ms)))
+
+    def peer_abort(self):
+        """call this context's replica-group launches off from the host (no GPU work; any thread): they return CruxError(EHIP) within ~100 us"""
+        self.lib.crux_peer_abort(self.h)
+
+    def peer_abort_clear(self):
+        self.lib.crux_peer_abort_clear(self.h)
+
+    def peer_abort_reason(self):
+        """the abort words of this rank's region, one per learner stream: 0 none, 1 timeout, 2 budget, 3 passed on, 4 host, 5 a peer left on a NaN step"""
+        out = np.zeros(2, np.int32); self.check(self.lib.crux_peer_abort_reason(self.h, _vp(out))); return [int(x) for x in out]
+
+    def peer_probe(self, rounds=64, first_bound_ms=2000, round_bound_ms=20):
+        """COLLECTIVE rendezvous probe (cruxhip.h: crux_peer_probe): [first-round wait, longest later wait] in us for learner stream 0, then 1; CruxError(EHIP) if the replicas did not meet"""
+        out = np.zeros(4, np.float32); self.check(self.lib.crux_peer_probe(self.h, int(rounds), int(first_bound_ms), int(round_bound_ms), _vp(out))); return [float(x) for x in out]
+
     def peer_sync_every(self):
         return int(self.lib.crux_peer_sync_every(self.h))
 
@@ -121,6 +140,11 @@ class Context:
 def reload_switches():
     """re-read the CRUX_* environment switches (the library reads them when a context is created; cruxhip.h: crux_reload_switches)"""
     L.load().crux_reload_switches()
+
+
+def abort_all():
+    """raise the host abort word of every live context of this process (cruxhip.h: crux_abort_all): replica-group launches waiting for a peer return CruxError(EHIP). For watchdogs."""
+    return int(L.load().crux_abort_all())
 
 
 def peer_attach_local(contexts):

@@ -246,6 +246,7 @@ int32_t crux_fill_gae_multi(int32_t n, crux_buffer* const* bufs, crux_mlp* const
 int32_t crux_whiten_multi(int32_t n, crux_buffer* const* bufs, int32_t key) {
   if (n < 1 || !bufs) return CRUX_EINVAL;
   crux_ctx* c = bufs[0]->ctx; const int64_t len = bufs[0]->elements;
+  if (len > (int64_t)JLW_MAXLEAF * 512) return crux_fail(c, CRUX_EUNSUP, "whiten (multi): %lld elements per buffer (the pairwise reduction is laid out for at most %d leaves)", (long long)len, JLW_MAXLEAF);      // the same bound as crux_whiten: k_whiten_multi keeps the leaf tables in LDS
   std::vector<float*> hp((size_t)n);
   for (int i = 0; i < n; ++i) { crux_buffer* b = bufs[i];
     if (!b || !has_col(b, key) || col_elem(b, key) != 4 || col_rows(b, key) != 1) return crux_fail(c, CRUX_EINVAL, "whiten: column %d of buffer %d is not a 1 x N Float32 column", key, i);

@@ -41,6 +41,11 @@ struct crux_ctx {
   bool peer_hist = false;              // record the per-step flag waits of the replica-group exchange (crux_peer_hist_enable)
   bool peer_solo = false;              // crux_peer_attach(ctx, 0, 1, ...): a group of ONE -- the replica-group instantiations of the learner kernels with no peer (the reference form bit-exact group results are compared with)
   long long peer_timeout_ticks = 3000000000ll;   // in-kernel flag-wait timeout of the replica-group exchange in 10 ns ticks (crux_peer_set_timeout_ms; default 30 s)
+  long long peer_budget_ticks = 6000000000ll;    // what the flag waits of ONE learner launch may add up to (crux_peer_set_budget_ms; default 60 s): bounds a group whose replicas answer, but slowly
+  unsigned* peer_host = nullptr;                 // host-pinned, device-mapped block: word 0 = the abort word the kernels' slow path polls (crux_peer_abort), words 16.. = results of crux_peer_probe
+  void* peer_host_dev = nullptr;                 // its device address
+  unsigned long long peer_probe_base = 0;        // rendezvous rounds announced so far (every rank of a group calls crux_peer_probe the same number of times)
+  bool peer_probe_bad = false;                   // a probe failed: the ranks' round counters may differ until the next attach
   int peer_n = 0, peer_rank = 0; void* peer_local = nullptr; void* peer_ptr[8] = {}; bool peer_ipc[8] = {}; bool peer_fine = false;
   void* rec = nullptr;                 // ExecRec* (exec.h): the fused-step executor's recording state
   // replica group with another context of THIS process on the same device (crux_peer_attach_local): hipFree waits for the whole device, i.e. for the peer's
@@ -60,9 +65,12 @@ struct crux_ctx {
 // Layout of a peer region (floats unless noted), per learner stream w in {0,1} at w * CRUX_PX_STREAM_FLOATS:
 //   slots   [parity 2][source rank 8][CRUX_PX_SLOT]   the source's local gradient sum + statistics of one minibatch step
 //   flags   uint64 [8] at CRUX_PX_FLAGS, 64-byte stride   flag[src] = number of exchanges whose data src has completely written here
-//   abort   uint32 at CRUX_PX_ABORT                        set by any rank that gave up waiting
+//   abort   uint32 at CRUX_PX_ABORT                        set by any rank that gave up waiting: the bound that ended its wait (peer_wait.h: 1 timeout, 2 launch budget,
+//                                                          3 passed on, 4 its host called the launch off) or 5 = it left on a NaN step. TERMINAL for the group: cleared by
+//                                                          the next crux_peer_attach* only (a rank that left holds other parameters than its peers)
 //   count   uint64 at CRUX_PX_COUNT                        exchanges done so far on this stream (local bookkeeping: slot parity and flag values
 //                                                          continue across launches, so the double buffering argument holds across them too)
+//   waited / habort / budget / probe                       the bounds of peer_wait.h and the rendezvous probe (below)
 #define CRUX_PER_PMAX 24   // deepest pairwise-cumsum tree handled incrementally (N < 128 * 2^24)
 #define CRUX_PX_MAXR 8
 #define CRUX_PX_SEC 8192                        // one payload section (a gradient, or one of theta / m / v in the periodic form)
@@ -71,7 +79,11 @@ struct crux_ctx {
 #define CRUX_PX_ABORT (CRUX_PX_FLAGS + 16 * CRUX_PX_MAXR)
 #define CRUX_PX_COUNT (CRUX_PX_ABORT + 16)
 #define CRUX_PX_HIST (CRUX_PX_COUNT + 16)       // uint32 [2 workgroups][32]: log2 histogram of the flag waits in 10 ns ticks (crux_peer_wait_hist; filled only while enabled)
-#define CRUX_PX_STREAM_FLOATS (CRUX_PX_HIST + 64)
+#define CRUX_PX_WAITED (CRUX_PX_HIST + 64)     // uint32 [8] (+ 8 spare): per workgroup, what is left of the current launch's wait budget in 1.28 us units (peer_wait.h, bound 2)
+#define CRUX_PX_HABORT (CRUX_PX_WAITED + 16)   // device pointer (8 bytes) of the owning context's HOST-pinned abort word (crux_peer_abort), written at attach
+#define CRUX_PX_BUDGET (CRUX_PX_HABORT + 2)    // int64: the per-launch wait budget in ticks (crux_peer_set_budget_ms), written at attach
+#define CRUX_PX_PROBE (CRUX_PX_BUDGET + 14)    // uint64 [8] at 64-byte stride: probe[src] = rendezvous rounds src has announced here (crux_peer_probe)
+#define CRUX_PX_STREAM_FLOATS (CRUX_PX_PROBE + 16 * CRUX_PX_MAXR)
 #define CRUX_PX_BYTES (2 * CRUX_PX_STREAM_FLOATS * sizeof(float))
 
 static inline bool crux_grouped(const crux_ctx* c) { return c->peer_n > 1 || c->peer_solo; }      // a replica group is attached (a group of one included)

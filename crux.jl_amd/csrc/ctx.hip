@@ -99,7 +99,18 @@ const CruxSwitches& crux_sw() {
   return *s;
 }
 
+// every live context of the process (crux_abort_all: a watchdog that does not know which contexts a stuck call involves)
+static std::mutex g_ctx_mu; static std::vector<crux_ctx*> g_ctxs;
+
 extern "C" {
+
+// raises the host abort word of EVERY live context (crux_peer_abort): replica-group launches of this process that are waiting for a peer return CRUX_EHIP within a
+// slow-path poll (~100 us). No GPU work, no lock a training call holds: callable from a watchdog thread while the main thread sits in a training call.
+int32_t crux_abort_all(void) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu); int n = 0;
+  for (crux_ctx* c : g_ctxs) if (c->peer_host) { __atomic_store_n(&c->peer_host[0], 1u, __ATOMIC_RELEASE); ++n; }
+  return n;
+}
 
 int32_t crux_reload_switches(void) { g_sw.store(new CruxSwitches(crux_switches_read()), std::memory_order_release); return CRUX_OK; }
 
@@ -116,6 +127,7 @@ int32_t crux_ctx_create(int32_t device_id, void* stream, crux_ctx** out) {
   c->device = device_id;
   if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
   else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRUX_EHIP; } c->own_stream = true; }
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.push_back(c); }
   *out = c;
   return CRUX_OK;
 }
@@ -126,6 +138,7 @@ int32_t crux_ctx_set_learner_cus(crux_ctx* c, int32_t cus) {
 }
 int32_t crux_ctx_destroy(crux_ctx* c) {
   if (!c) return CRUX_OK;
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); for (size_t i = 0; i < g_ctxs.size(); ++i) if (g_ctxs[i] == c) { g_ctxs.erase(g_ctxs.begin() + (long)i); break; } }
   (void)hipStreamSynchronize(c->stream);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.second.first); (void)hipEventDestroy(p.second.second); }
   for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -143,6 +156,7 @@ int32_t crux_ctx_destroy(crux_ctx* c) {
   if (c->epoch_tmp) (void)hipFree(c->epoch_tmp);
   if (c->epoch_rows) (void)hipFree(c->epoch_rows);
   if (c->spec_abort) (void)hipHostFree(c->spec_abort);
+  if (c->peer_host) (void)hipHostFree(c->peer_host);
   crux_exec_destroy(c);
   for (int k = 0; k < c->aux_n_rejected; ++k) (void)hipStreamDestroy(c->aux_rejected[k]);
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->aux_ev0); (void)hipEventDestroy(c->aux_ev1); }

@@ -1126,11 +1126,15 @@ int32_t crux_steps_push(crux_buffer* buf, int64_t n, const void* const* cols, in
                             has_col(buf, CRUX_COL_FWD_IMPORTANCE_WEIGHT) || has_col(buf, CRUX_COL_CUM_IMPORTANCE_WEIGHT) || has_col(buf, CRUX_COL_REV_IMPORTANCE_WEIGHT) || (nominal && has_col(buf, CRUX_COL_IMPORTANCE_WEIGHT))))
     return crux_fail(c, CRUX_EINVAL, "steps!: a block of %lld transitions does not fit the buffer (capacity %lld) whose advantage / return / importance-weight columns it must fill", (long long)n, (long long)buf->capacity);
   if (!cols[CRUX_COL_EPISODE_END]) return crux_fail(c, CRUX_EINVAL, "steps_push: the block needs its :episode_end column (the caller's Sampler cuts the episodes: sampler.jl:130-136,148)");
+  // every argument is checked BEFORE the ring moves: a failed call must not leave pushed rows whose advantage / return columns hold stale data
+  if (n > 0 && n <= buf->capacity) {
+    if (has_col(buf, CRUX_COL_ADVANTAGE) && !critic) return crux_fail(c, CRUX_EINVAL, "steps_push: the buffer has an :advantage column but no critic was given (fill_gae!, sampler.jl:56)");
+    if (has_col(buf, CRUX_COL_COST_ADVANTAGE) && !cost_critic) return crux_fail(c, CRUX_EINVAL, "steps_push: the buffer has a :cost_advantage column but no cost critic (Sampler.Vc, sampler.jl:65)"); }
   const int64_t first = buf->next_ind;
   if (first_row_out) *first_row_out = first;
   int32_t rc = crux_buffer_push_host(buf, n, cols, nullptr); if (rc) return rc;
   if (n == 0 || n > buf->capacity) return CRUX_OK;
-  if (has_col(buf, CRUX_COL_ADVANTAGE)) { if (!critic) return crux_fail(c, CRUX_EINVAL, "steps_push: the buffer has an :advantage column but no critic was given (fill_gae!, sampler.jl:56)");
+  if (has_col(buf, CRUX_COL_ADVANTAGE)) {
     rc = crux_fill_gae_rows(buf, critic, lambda, gamma, first, n, rows_per_env, close_last); if (rc) return rc; }
   if (has_col(buf, CRUX_COL_RETURN)) { rc = crux_fill_returns_rows(buf, gamma, first, n, rows_per_env, close_last); if (rc) return rc; }
   if (nominal && has_col(buf, CRUX_COL_IMPORTANCE_WEIGHT)) {      // step! wrote exp(logpdf(pa, s, a) - logprob) per row (sampler.jl:108-111): the same on the pushed rows (a wrapped block takes two ranges)
@@ -1138,7 +1142,7 @@ int32_t crux_steps_push(crux_buffer* buf, int64_t n, const void* const* cols, in
     rc = crux_importance_weight_rows(buf, nominal, nominal_head, first, n1); if (rc) return rc;
     if (n1 < n) { rc = crux_importance_weight_rows(buf, nominal, nominal_head, 0, n - n1); if (rc) return rc; } }
   rc = crux_fill_importance_weights_rows(buf, first, n, rows_per_env, close_last); if (rc) return rc;
-  if (has_col(buf, CRUX_COL_COST_ADVANTAGE)) { if (!cost_critic) return crux_fail(c, CRUX_EINVAL, "steps_push: the buffer has a :cost_advantage column but no cost critic (Sampler.Vc, sampler.jl:65)");
+  if (has_col(buf, CRUX_COL_COST_ADVANTAGE)) {
     rc = crux_fill_gae_rows_keys(buf, cost_critic, lambda, gamma, first, n, rows_per_env, close_last, CRUX_COL_COST, CRUX_COL_COST_ADVANTAGE); if (rc) return rc; }
   if (has_col(buf, CRUX_COL_COST_RETURN)) { rc = crux_fill_returns_rows_keys(buf, gamma, first, n, rows_per_env, close_last, CRUX_COL_COST, CRUX_COL_COST_RETURN); if (rc) return rc; }
   return CRUX_OK;

@@ -9,6 +9,7 @@
 // leaves the parameters alone and every later step of the launch finds the status set and does the same (training.jl:20: error, no update).
 // Compiled inside offpolicy_unit.hip (uses the heads' helpers of sac.hip).
 #include "train_args.h"
+#include "peer_wait.h"
 #ifndef EPS32F
 #define EPS32F 1.1920928955078125e-07f
 #endif
@@ -51,12 +52,9 @@ __global__ __launch_bounds__(256) void k_lagrange_pid(crux_lagrange* __restrict_
       __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     for (int r = 0; r < N; ++r) if (r != rank) __hip_atomic_store((unsigned long long*)(px_tab[r] + CRUX_PX_FLAGS) + 8 * rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    bool ok = true; const long long t0 = wall_clock64(); unsigned* abortw = (unsigned*)(mine + CRUX_PX_ABORT);
-    for (int r = 0; r < N && ok; ++r) { if (r == rank) continue;
-      const unsigned long long* fl = (const unsigned long long*)(mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
-      while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > tmo || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
-    if (!ok) { for (int r = 0; r < N; ++r) __hip_atomic_store((unsigned*)(px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); status[0] = CRUX_EHIP; return; }
+    const long long t0 = wall_clock64();
+    const unsigned gave_up = px_wait_peers(mine, N, rank, xg + 1ull, t0, tmo, 0, false);      // (one exchange per launch: the per-launch budget does not apply, the other bounds of peer_wait.h do)
+    if (gave_up) { px_raise_abort(px_tab, N, gave_up); status[0] = CRUX_EHIP; status[1] = 16 + (int)gave_up; return; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     double g_sc = 0.0, g_ne = 0.0;
     for (int r = 0; r < N; ++r) { double a_ = t_sc, b_ = t_ne;
@@ -178,12 +176,9 @@ __global__ __launch_bounds__(1024) void k_px_allreduce_flat(float* __restrict__ 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       for (int r = 0; r < N; ++r) if (r != rank) __hip_atomic_store((unsigned long long*)(px_tab[r] + CRUX_PX_FLAGS) + 8 * rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      bool ok = true; const long long t0 = wall_clock64(); unsigned* abortw = (unsigned*)(mine + CRUX_PX_ABORT);
-      for (int r = 0; r < N && ok; ++r) { if (r == rank) continue;
-        const unsigned long long* fl = (const unsigned long long*)(mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
-        while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
-          if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > tmo || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
-      if (!ok) for (int r = 0; r < N; ++r) __hip_atomic_store((unsigned*)(px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const long long t0 = wall_clock64();
+      const unsigned gave_up = px_wait_peers(mine, N, rank, xg + 1ull, t0, tmo, 0, false); const bool ok = gave_up == 0u;
+      if (!ok) { px_raise_abort(px_tab, N, gave_up); status[1] = 16 + (int)gave_up; }
       ok_s = ok ? 1 : 0;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // one lane: drops the L1 (the slot loads are system-scope atomic loads and pass it anyway)
     }
@@ -234,13 +229,13 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a, hipStream_t strm, int wh
   if (which && !c->dense_pinned2 && hipHostMalloc(&c->dense_pinned2, 256, hipHostMallocDefault) != hipSuccess) { c->dense_pinned2 = nullptr; return crux_fail(c, CRUX_ENOMEM, "batch_train! (dense): pinned staging"); }
   float* hinfo = which ? (float*)c->dense_pinned2 : (float*)crux_pinned(c, sizeof(float) * CRUX_INFO_N + 16); if (!hinfo) return crux_fail(c, CRUX_ENOMEM, "batch_train! (dense): pinned staging");
   const bool pg = CRUX_IS_PG(a.loss); const bool step_sync = (pg && a.target_kl >= 0.f);
-  long long total_batches = 0; int epochs_run = 0, err = 0; bool stop = false;
+  long long total_batches = 0; int epochs_run = 0, err = 0, why = 0; bool stop = false;      // why: 16 + the bound that ended a replica-group wait (peer_wait.h)
   std::vector<float> ei((size_t)CRUX_INFO_N * (size_t)n_epochs, 0.f);
   auto read_info = [&]() -> int32_t {
     HIPCHK(c, hipMemcpyAsync(hinfo, dinfo, sizeof(float) * CRUX_INFO_N, hipMemcpyDeviceToHost, strm));
-    HIPCHK(c, hipMemcpyAsync(hinfo + CRUX_INFO_N, status, sizeof(int32_t), hipMemcpyDeviceToHost, strm));
+    HIPCHK(c, hipMemcpyAsync(hinfo + CRUX_INFO_N, status, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, strm));
     HIPCHK(c, hipStreamSynchronize(strm));
-    int32_t s; memcpy(&s, hinfo + CRUX_INFO_N, sizeof s); if (s == CRUX_ENAN || s == CRUX_EHIP) err = s;
+    int32_t s[2]; memcpy(s, hinfo + CRUX_INFO_N, sizeof s); if (s[0] == CRUX_ENAN || s[0] == CRUX_EHIP) { err = s[0]; why = s[1]; }
     return CRUX_OK;
   };
   for (int ep = 0; ep < n_epochs && !stop && !err; ++ep) {
@@ -281,7 +276,7 @@ int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a, hipStream_t strm, int wh
   }
   // status row and epoch infos where the persistent kernels leave them (run_batch / collect read them back)
   if (err && epochs_run == 0) { ei[CRUX_INFO_LOSS] = hinfo[CRUX_INFO_LOSS]; ei[CRUX_INFO_GRAD_NORM] = NAN; }
-  int32_t hst[4] = {err, (int32_t)total_batches, epochs_run, 0};
+  int32_t hst[5] = {err, (int32_t)total_batches, epochs_run, 0, why ? why : 3};
   HIPCHK(c, hipMemcpyAsync(a.status, hst, sizeof hst, hipMemcpyHostToDevice, strm));
   if (a.epoch_infos) HIPCHK(c, hipMemcpyAsync(a.epoch_infos, ei.data(), sizeof(float) * ei.size(), hipMemcpyHostToDevice, strm));
   HIPCHK(c, hipStreamSynchronize(strm));            // hst / ei are stack / heap memory of this call

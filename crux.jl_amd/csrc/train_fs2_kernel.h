@@ -298,6 +298,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   // 0 = done, 1 = a replica did not answer or this learner had already failed (fERR is set), 2 = skipped: the step is suspect (a NaN total: the launch ends with CRUX_ENAN).
   float* const px_mine = PX ? a.px_tab[a.px_rank] : nullptr;
   const unsigned long long px0 = PX ? *(const unsigned long long*)(px_mine + CRUX_PX_COUNT) : 0ull;
+  if (PX && tid == 0) px_launch_begin(px_mine, p);      // the launch's wait budget starts from zero (peer_wait.h, bound 2)
   const float px_inv = PX ? 1.0f / (float)a.px_n : 1.0f;
   int pxc = 0;
   auto px_allreduce_mean = [&](auto nsec_c, f32x4* const (&Wp)[3], float* const (&Sp)[3], float& xT, const bool failed, const unsigned tag, const bool check_suspect) -> int {
@@ -320,7 +321,6 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      unsigned* abortw = (unsigned*)(px_mine + CRUX_PX_ABORT);
       const bool dead = fs2_flag_get(sm + Lt::fERR) != 0u, sus = check_suspect && fs2_flag_get(sm + Lt::fSUS) == tag;
       bool ok = !dead && !sus;
       if (ok) {
@@ -330,18 +330,15 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         for (int r = 0; r < a.px_n; ++r) { if (r == a.px_rank) continue;
           if ((pi_++ % NWG) != p) continue;
           __hip_atomic_store((unsigned long long*)(a.px_tab[r] + CRUX_PX_FLAGS) + 8 * a.px_rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-        const long long t0 = wall_clock64();                // 100 MHz: a missing peer becomes CRUX_EHIP after the timeout instead of a hung GPU
-        for (int r = 0; r < a.px_n && ok; ++r) { if (r == a.px_rank) continue;
-          const unsigned long long* fl = (const unsigned long long*)(px_mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
-          while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > a.px_timeout || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
-        if (!ok) fs2_flag_set(sm + Lt::fERR, 3u);            // 3: a replica of the group did not answer within the timeout, or raised the abort word
+        const long long t0 = wall_clock64();                // 100 MHz; the wait is bounded four ways (peer_wait.h): a peer that is absent, slow, gone, or a host that calls the launch off
+        const unsigned gave_up = px_wait_peers(px_mine, a.px_n, a.px_rank, xg + 1ull, t0, a.px_timeout, p, true);
+        if (gave_up) { ok = false; fs2_flag_set(sm + Lt::fERR, 16u + gave_up); }      // 16 + bound: the replica group ended this launch (train.hip names the bound)
         if (a.px_hist) {      // how long this workgroup waited for the slowest peer's flag (10 ns ticks, log2 bins; workgroups 0 and 1 report)
           const unsigned long long dtk = (unsigned long long)(wall_clock64() - t0) | 1ull;
           if (p < 2) { unsigned* hb = (unsigned*)(px_mine + CRUX_PX_HIST) + 32 * p + (63 - __builtin_clzll(dtk) > 31 ? 31 : 63 - __builtin_clzll(dtk)); *hb = *hb + 1u; } }
       }
       if (!ok) {      // this learner leaves the group (failure, or a NaN step): the peers must not wait for it
-        for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        { const unsigned e = fs2_flag_get(sm + Lt::fERR); px_raise_abort(a.px_tab, a.px_n, sus && !dead ? 5u : (e >= 16u ? e - 16u : 1u)); }      // the bound that fired (5: left on a NaN step)
         if (!sus || dead) __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                       // system scope, one lane: drops this compute unit's L1 (the slot loads below bypass it anyway: sc0 sc1)
     }
@@ -979,7 +976,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(NW * p + w) * 16 + k] = tacc[k]; }
   if (PX && tid == 0 && p == 0) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)pxc;
   if constexpr (PX && PXK) {      // periodic form: a replica that leaves on a NaN step between two exchanges will not show up at the next one -- its peers must not wait for the timeout
-    if (tid == 0 && p == 0 && err == CRUX_ENAN) { for (int r = 0; r < a.px_n; ++r) if (r != a.px_rank) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }
+    if (tid == 0 && p == 0 && err == CRUX_ENAN) { for (int r = 0; r < a.px_n; ++r) if (r != a.px_rank) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }
   if (tid == 0 && (p == 0 || err)) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 3 replica group timeout / abort, 4 a workgroup missed the abort-latch consensus

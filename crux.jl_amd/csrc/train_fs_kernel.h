@@ -20,6 +20,7 @@
 #include "train_args.h"
 
 #include "mfma_helpers.h"
+#include "peer_wait.h"
 
 #define FS_LD 72
 __device__ __forceinline__ int fs_tx(int q) { return (4 - q) & 3; }   // {0,3,2,1}
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   // replica group: exchanges done on this learner stream before this launch -- slot parity and flag values continue across launches
   float* const px_mine = PX ? a.px_tab[a.px_rank] : nullptr;
   const unsigned long long px0 = PX ? *(const unsigned long long*)(px_mine + CRUX_PX_COUNT) : 0ull;
+  if (PX && tid == 0) px_launch_begin(px_mine, p);      // the launch's wait budget starts from zero (peer_wait.h, bound 2)
   const float px_inv = PX ? 1.0f / (float)a.px_n : 1.0f;
   const int n_epochs = a.epochs;
   if (!a.ord_all) { for (int64_t j = tid; j < a.len; j += NT) order_cur[j] = (int32_t)j; }
@@ -642,18 +644,14 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
             for (int r = 0; r < a.px_n; ++r) { if (r == a.px_rank) continue;
               if ((pi_++ % NWG) != p) continue;
               __hip_atomic_store((unsigned long long*)(a.px_tab[r] + CRUX_PX_FLAGS) + 8 * a.px_rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-            bool ok = true; const long long t0 = wall_clock64();                // 100 MHz: a missing peer becomes CRUX_EHIP after ~30 s instead of a hung GPU
-            unsigned* abortw = (unsigned*)(px_mine + CRUX_PX_ABORT);
-            for (int r = 0; r < a.px_n && ok; ++r) { if (r == a.px_rank) continue;
-              const unsigned long long* fl = (const unsigned long long*)(px_mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
-              while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > a.px_timeout || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
-            if (!ok) { for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const long long t0 = wall_clock64();                // 100 MHz; the wait is bounded four ways (peer_wait.h)
+            const unsigned gave_up = px_wait_peers(px_mine, a.px_n, a.px_rank, xg + 1ull, t0, a.px_timeout, p, true); const bool ok = gave_up == 0u;
+            if (!ok) { px_raise_abort(a.px_tab, a.px_n, gave_up);
               __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             if (a.px_hist) {      // how long this workgroup waited for the slowest peer's flag (10 ns ticks, log2 bins; workgroups 0 and 1 report)
               const unsigned long long dtk = (unsigned long long)(wall_clock64() - t0) | 1ull;
               if (p < 2) { unsigned* hb = (unsigned*)(px_mine + CRUX_PX_HIST) + 32 * p + (63 - __builtin_clzll(dtk) > 31 ? 31 : 63 - __builtin_clzll(dtk)); *hb = *hb + 1u; } }
-            sm[Lt::oRED + 16] = ok ? 0.f : 3.f;                         // 3: a replica of the group did not answer within the timeout, or raised the abort word
+            sm[Lt::oRED + 16] = ok ? 0.f : (float)(16u + gave_up);      // 16 + bound (peer_wait.h): the replica group ended this launch
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                       // system scope, one lane: drops this compute unit's L1 (the slot loads below bypass it anyway: sc0 sc1)
           }
           __syncthreads();
@@ -921,7 +919,7 @@ __global__ __launch_bounds__(64 * (HELP ? 2 : 1) * (16 / NWG)) void k_train_fs(T
   if (TIMING && lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[(NW * p + w) * 16 + k] = tacc[k]; }
   if (PX && tid == 0 && p == 0) *(unsigned long long*)(px_mine + CRUX_PX_COUNT) = px0 + (unsigned long long)pxc;
   if constexpr (PX && PXK) {      // periodic form: a replica that leaves on a NaN step between two exchanges will not show up at the next one -- its peers must not wait for the timeout
-    if (tid == 0 && p == 0 && err == CRUX_ENAN) { for (int r = 0; r < a.px_n; ++r) if (r != a.px_rank) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }
+    if (tid == 0 && p == 0 && err == CRUX_ENAN) { for (int r = 0; r < a.px_n; ++r) if (r != a.px_rank) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }
   if (tid == 0 && (p == 0 || err)) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 3 replica group timeout / abort, 4 a workgroup missed the abort-latch consensus of a speculative run

@@ -21,6 +21,7 @@
 #include "train_args.h"
 
 #include "mfma_helpers.h"
+#include "peer_wait.h"
 
 // LDS layouts are chosen against the gfx950 banking rules (ds_read_b128: 64 banks, four non-contiguous 16-lane groups; b32 accesses:
 // 32 banks, two 32-lane halves): master rows are 72 floats, the per-wave exchange tiles are unpadded [64 features][16 samples]
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
   // replica group (comm.hip "peer"): exchanges done on this learner stream before this launch -- slot parity and flag values continue across launches
   float* const px_mine = PX ? a.px_tab[a.px_rank] : nullptr;
   const unsigned long long px0 = PX ? *(const unsigned long long*)(px_mine + CRUX_PX_COUNT) : 0ull;
+  if (PX && tid == 0) px_launch_begin(px_mine, p);      // the launch's wait budget starts from zero (peer_wait.h, bound 2)
   const float px_inv = PX ? 1.0f / (float)a.px_n : 1.0f;
   constexpr int XSLOT = 4096 + NSI * NT + 16;
   // the reported minibatch's info (training.jl:22-23) is kept by thread 0 -- its only reader (epoch_infos) -- in free words of the reduction area, not in registers of every
@@ -584,19 +586,15 @@ __global__ __launch_bounds__(64 * NW) void k_train_mfma(TrainArgs a_single, cons
               if ((pi_++ & 1) != p) continue;
               // relaxed: the release above covers the slot stores of every wave (all drained before the barrier)
               __hip_atomic_store((unsigned long long*)(a.px_tab[r] + CRUX_PX_FLAGS) + 8 * a.px_rank, xg + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-            bool ok = true; const long long t0 = wall_clock64();                // 100 MHz: a missing peer becomes CRUX_EHIP after ~30 s instead of a hung GPU
-            unsigned* abortw = (unsigned*)(px_mine + CRUX_PX_ABORT);
-            for (int r = 0; r < a.px_n && ok; ++r) { if (r == a.px_rank) continue;
-              const unsigned long long* fl = (const unsigned long long*)(px_mine + CRUX_PX_FLAGS) + 8 * r; unsigned spins = 0;
-              while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xg + 1ull) { __builtin_amdgcn_s_sleep(1);      // the acquire is the fence after the barrier below
-                if ((++spins & 1023u) == 0u && (wall_clock64() - t0 > a.px_timeout || __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) { ok = false; break; } } }
-            if (!ok) { for (int r = 0; r < a.px_n; ++r) __hip_atomic_store((unsigned*)(a.px_tab[r] + CRUX_PX_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const long long t0 = wall_clock64();                // 100 MHz; the wait is bounded four ways (peer_wait.h)
+            const unsigned gave_up = px_wait_peers(px_mine, a.px_n, a.px_rank, xg + 1ull, t0, a.px_timeout, p, true); const bool ok = gave_up == 0u;
+            if (!ok) { px_raise_abort(a.px_tab, a.px_n, gave_up);
               __hip_atomic_store(a.xctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             if (a.px_hist) {      // how long this workgroup waited for the slowest peer's flag (10 ns ticks, log2 bins): the selftest's view of the xGMI hand-off
               const unsigned long long dtk = (unsigned long long)(wall_clock64() - t0) | 1ull;
               unsigned* hb = (unsigned*)(px_mine + CRUX_PX_HIST) + 32 * p + (63 - __builtin_clzll(dtk) > 31 ? 31 : 63 - __builtin_clzll(dtk));
               *hb = *hb + 1u; }
-            sm[Lt::oRED + 16] = ok ? 0.f : 3.f;                         // 3: a replica of the group did not answer within the timeout, or raised the abort word
+            sm[Lt::oRED + 16] = ok ? 0.f : (float)(16u + gave_up);      // 16 + bound (peer_wait.h): the replica group ended this launch
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                       // system scope, one lane (the slot loads below are sc0 sc1 and pass the L1 anyway)
           }
           __syncthreads();

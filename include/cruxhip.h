@@ -422,6 +422,24 @@ int32_t crux_peer_sync_every(const crux_ctx* ctx);
 /* how long a learner workgroup waits for a peer's flag of ONE exchange before it gives up (default 30 000 ms; 1 .. 600 000): the training call then returns CRUX_EHIP and
  * the abort word of every peer is raised, so the surviving ranks of a group whose member died leave their kernels too instead of hanging the GPU.                      */
 int32_t crux_peer_set_timeout_ms(crux_ctx* ctx, int32_t ms);
+/* The waits of the in-kernel exchange are bounded four ways (csrc/peer_wait.h): the per-exchange timeout above (a peer that is ABSENT); a per-launch budget -- what the flag
+ * waits of ONE learner launch may add up to (default 60 000 ms; 0 = none): a peer that is SLOW, e.g. replicas sharing a device whose hardware queues the firmware time-slices
+ * answer every exchange after a scheduling quantum and never trip the timeout; a peer's abort word (it LEFT: failure, NaN step); and the host's abort word: crux_peer_abort
+ * raises a pinned word that every flag wait of this context polls -- no GPU work, callable from any thread or a signal handler while another thread sits in a training call,
+ * which then returns CRUX_EHIP within ~100 us (crux_abort_all: the same for every live context of the process -- a test watchdog, a launcher tearing a job down).
+ * An abort is TERMINAL for the group (a rank that left holds other parameters than its peers): detach and attach again. crux_peer_abort_reason reads this rank's abort words
+ * (one per learner stream): 0 none, 1 timeout, 2 budget, 3 passed on, 4 host, 5 a peer left on a NaN step -- crux_last_error of the failed call already names it.          */
+int32_t crux_peer_set_budget_ms(crux_ctx* ctx, int32_t ms);
+int32_t crux_peer_abort(crux_ctx* ctx);
+int32_t crux_peer_abort_clear(crux_ctx* ctx);
+int32_t crux_abort_all(void);                               /* returns the number of contexts told */
+int32_t crux_peer_abort_reason(crux_ctx* ctx, int32_t* out2);
+/* COLLECTIVE rendezvous probe: do the replicas answer each other at the speed the in-kernel exchange assumes? Every rank calls it at about the same time after the attach
+ * (the first round absorbs up to first_bound_ms of skew between the hosts); one wave per learner stream runs `rounds` (2 .. 100 000) rendezvous through the regions with the
+ * exchange's own primitives. out_us4 = {first-round wait, longest later wait} of learner stream 0, then 1, in microseconds: a few us on one device, ~10 us over xGMI;
+ * milliseconds mean time-sliced hardware queues (several processes on one GPU) -- a group there runs 100x below its speed (profiles/r06_same_device_oversubscription.txt).
+ * CRUX_EHIP when the replicas did not meet within the bounds. crux_peer_attach_local runs it itself and refuses such a group.                                             */
+int32_t crux_peer_probe(crux_ctx* ctx, int32_t rounds, int32_t first_bound_ms, int32_t round_bound_ms, float* out_us4);
 int32_t crux_peer_hist_enable(crux_ctx* ctx, int32_t on);
 int32_t crux_peer_wait_hist(crux_ctx* ctx, uint32_t* out128, int32_t reset);
 int32_t crux_peer_size(const crux_ctx* ctx);               /* 1 when no group is attached */

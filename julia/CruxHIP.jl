@@ -333,6 +333,15 @@ peer_detach!(c::Ctx) = check(c, ccall((:crux_peer_detach, LIB), Int32, (Ptr{Cvoi
 # periodic form (round 4): k = 1 exchanges the gradient every minibatch (exact); k > 1: local Adam steps, theta / m / v averaged in the kernel after every k-th
 peer_set_sync_every!(c::Ctx, k::Integer) = check(c, ccall((:crux_peer_set_sync_every, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, k))
 peer_set_timeout_ms!(c::Ctx, ms::Integer) = check(c, ccall((:crux_peer_set_timeout_ms, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, ms))   # a rank whose peer died gets CRUX_EHIP after this long instead of a hung GPU
+# the other bounds of the in-kernel waits (csrc/peer_wait.h): a per-launch wait budget (slow peers), the host's abort word (no GPU work: callable from another task while a
+# training call is in flight), the abort reason of a failed call, and the collective rendezvous probe every rank runs after the attach
+peer_set_budget_ms!(c::Ctx, ms::Integer) = check(c, ccall((:crux_peer_set_budget_ms, LIB), Int32, (Ptr{Cvoid}, Int32), c.h, ms))
+peer_abort!(c::Ctx) = ccall((:crux_peer_abort, LIB), Int32, (Ptr{Cvoid},), c.h)
+peer_abort_clear!(c::Ctx) = ccall((:crux_peer_abort_clear, LIB), Int32, (Ptr{Cvoid},), c.h)
+abort_all!() = ccall((:crux_abort_all, LIB), Int32, ())
+peer_abort_reason(c::Ctx) = (o = zeros(Int32, 2); check(c, ccall((:crux_peer_abort_reason, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}), c.h, o)); o)
+peer_probe(c::Ctx; rounds::Integer=64, first_bound_ms::Integer=2000, round_bound_ms::Integer=20) =
+    (o = zeros(Float32, 4); check(c, ccall((:crux_peer_probe, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Float32}), c.h, rounds, first_bound_ms, round_bound_ms, o)); o)
 # multi-seed / population training: n independent (actor, critic, buffer) triples in two batched launches (on_policy.jl:56-78 per triple)
 function policy_gradient_training_multi(𝒮::Crux.OnPolicySolver, actors::Vector{HipNetwork}, critics::Vector{HipNetwork}, bufs::Vector{HipBuffer})
     n = length(actors); ia, ic = zeros(Float32, INFO_N, n), zeros(Float32, INFO_N, n)
@@ -624,15 +633,17 @@ function POMDPs.solve(𝒮::Crux.OffPolicySolver, mdp::HipMDP)
         Crux.steps!(s, 𝒮.buffer, Nsteps=Nfill, explore=true, i=𝒮.i, cb=(D) -> 𝒮.post_sample_callback(D, 𝒮=𝒮, info=info))             # :126
     end
     evaluating && Crux.log(𝒮.log, 𝒮.i, info, 𝒮=𝒮)                                                              # :130
+    pending = PendingInfo[]          # asynchronous chains whose info rows nobody has fetched yet. Declared OUTSIDE the loop (a name first assigned in a `for` body is local to it: ADVICE r5) and bounded
     for 𝒮.i in range(𝒮.i, stop=istart + 𝒮.N - 𝒮.ΔN, step=𝒮.ΔN)                                                 # :133
         info = Dict()
         Crux.steps!(s, 𝒮.buffer, Nsteps=𝒮.ΔN, explore=true, i=𝒮.i, cb=(D) -> 𝒮.post_sample_callback(D, 𝒮=𝒮, info=info))            # :138
         𝒮.pre_train_callback(𝒮, info=info)                                                                      # :140
         training_info = Crux.value_training(𝒮, 𝒟, γ)                                                            # :143 -> value_training(::OffPolicySolver, ::HipBuffer, γ): the asynchronous chains when nobody logs
         evaluating && Crux.log(𝒮.log, 𝒮.i + 1:𝒮.i + 𝒮.ΔN, resolve(training_info), info, 𝒮=𝒮)                    # :146
-        last_info = training_info
+        training_info isa PendingInfo && isnothing(training_info.value) && push!(pending, training_info)
+        length(pending) >= 64 && (foreach(resolve, pending); empty!(pending))                                   # one synchronisation per 64 iterations: the device rows are freed and a NaN of an earlier iteration surfaces (training.jl:20)
     end
-    @isdefined(last_info) && resolve(last_info)                                                                 # one synchronisation per solve: also where "NaN detected!" surfaces for the asynchronous chains
+    foreach(resolve, pending)                                                                                   # every chain's rows fetched and freed, "NaN detected!" raised for any of them, before solve returns
     𝒮.i += 𝒮.ΔN                                                                                                 # :148
     𝒮.agent.π
 end

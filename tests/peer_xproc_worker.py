@@ -65,6 +65,10 @@ def main():
     barrier(d, "attached", rank, world)            # every rank has attached before any of them trains (cruxhip.h)
     if cfg.get("die_rank") == rank:               # this rank dies with the group attached and never trains: the survivors' kernels must time out, not hang
         os._exit(0)
+    ctx.peer_set_budget_ms(int(cfg.get("budget_ms", 20000)))      # all waits of one launch together (csrc/peer_wait.h): a group that answers, but slowly, ends inside the test's limits
+    probe_us = None
+    if cfg.get("die_rank") is None and cfg.get("probe", True):      # the collective rendezvous probe: both processes' kernels answer each other at exchange speed
+        probe_us = ctx.peer_probe(rounds=128, first_bound_ms=10000, round_bound_ms=50)
     if int(cfg.get("k", 1)) > 1:
         ctx.peer_set_sync_every(int(cfg["k"]))
     od, ad, disc, adims, cdims, acts, kind, head, okind = parity.FAMILIES[cfg["family"]]
@@ -110,6 +114,8 @@ def main():
         m, v, bp = net.adam_state()
         out[name + "_params"], out[name + "_m"], out[name + "_v"], out[name + "_bp"] = net.get_params(), m, v, bp
     out["seconds"] = np.array([time.time() - t0])
+    if probe_us is not None:
+        out["probe_us"] = np.array(probe_us, np.float64)
     np.savez(os.path.join(d, "out_%d.tmp.npz" % rank), **out)
     os.rename(os.path.join(d, "out_%d.tmp.npz" % rank), os.path.join(d, "out_%d.npz" % rank))
     barrier(d, "done", rank, world)                # nobody unmaps a region a peer's kernel may still write to

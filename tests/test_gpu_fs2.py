@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import parity
+import replica_group as RG
 from parity import L, O, crux
 
 pytestmark = pytest.mark.gpu
@@ -147,7 +148,7 @@ def test_fs2_replica_group_forms_against_those_of_fs(gpu_ctx, monkeypatch, famil
     c1 = crux.Context(0); ctxs = [gpu_ctx, c1]
     out = {}
     try:
-        crux.peer_attach_local(ctxs)
+        RG.attach_or_skip(ctxs)
         for c in ctxs:
             c.peer_set_sync_every(k)
         for form in ("fs2", "fs"):
@@ -172,8 +173,7 @@ def test_fs2_replica_group_forms_against_those_of_fs(gpu_ctx, monkeypatch, famil
                         infos[r] = crux.batch_train_(nets[r], opt, P, bufs[r], perms=perms[r] + 1)
                     except Exception as e:      # noqa: BLE001
                         errs[r] = e
-                ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]; [t.start() for t in ts]; [t.join(120) for t in ts]
-                assert not any(t.is_alive() for t in ts), "a replica did not return"
+                RG.run_threads([(lambda r=r: run(r)) for r in range(2)])
                 for e in errs:
                     if e is not None:
                         raise e
@@ -207,7 +207,7 @@ def test_fs2_group_of_two_on_identical_shards_equals_a_group_of_one(gpu_ctx, fam
     rng = np.random.default_rng(13); perms = np.stack([rng.permutation(N) for _ in range(epochs)])
     P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1 if disc else 0.0}
     def run_group(ctxs):
-        crux.peer_attach_local(ctxs)
+        RG.attach_or_skip(ctxs)
         try:
             for c in ctxs:
                 c.peer_set_sync_every(k)
@@ -230,8 +230,7 @@ def test_fs2_group_of_two_on_identical_shards_equals_a_group_of_one(gpu_ctx, fam
                         crux.batch_train_(nets[r], crux.TrainingParams(loss=crux.ppo_loss if which == 0 else crux.value_mse_loss, batch_size=128, epochs=epochs, name="n_"), P, bufs[r], perms=perms + 1)
                     except Exception as e:      # noqa: BLE001
                         errs[r] = e
-                ts = [threading.Thread(target=run, args=(r,)) for r in range(len(ctxs))]; [t.start() for t in ts]; [t.join(120) for t in ts]
-                assert not any(t.is_alive() for t in ts), "a replica did not return"
+                RG.run_threads([(lambda r=r: run(r)) for r in range(len(ctxs))])
                 for e in errs:
                     if e is not None:
                         raise e
@@ -268,7 +267,7 @@ def test_fs2_replica_group_nan_step(gpu_ctx, monkeypatch, form, k):
     P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1}
     c1 = crux.Context(0); ctxs = [gpu_ctx, c1]
     try:
-        crux.peer_attach_local(ctxs)
+        RG.attach_or_skip(ctxs)
         for c in ctxs:
             c.peer_set_sync_every(k)
         nets, bufs = [], []
@@ -282,8 +281,7 @@ def test_fs2_replica_group_nan_step(gpu_ctx, monkeypatch, form, k):
                 crux.batch_train_(nets[r], crux.TrainingParams(loss=crux.ppo_loss, batch_size=128, epochs=1, name="n_"), P, bufs[r], perms=perm[None, :] + 1)
             except crux.CruxError as e:
                 errs[r] = e
-        ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]; [t.start() for t in ts]; [t.join(120) for t in ts]
-        assert not any(t.is_alive() for t in ts), "a replica did not return"
+        RG.run_threads([(lambda r=r: run(r)) for r in range(2)])
         assert errs[1] is not None and errs[1].code == L.ENAN
         st = [_state(n) for n in nets]
         if k == 1:

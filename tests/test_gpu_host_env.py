@@ -134,3 +134,20 @@ def test_dqn_solve_on_a_host_mdp_trains_like_the_device_environment(gpu_ctx):
     for k in ("s", "a", "sp", "r", "done"):
         assert _bits_equal(sv_d.buffer[k], sv_h.buffer[k]), k
     assert np.array_equal(pd.get_params(), ph.get_params())
+
+
+def test_steps_push_checks_its_arguments_before_the_ring_moves(gpu_ctx):
+    """crux_steps_push on a buffer with an :advantage column and no critic: CRUX_EINVAL and the ring exactly as it was -- not pushed rows with stale advantages."""
+    N = 64; extras = ["return", "logprob", "advantage"]
+    b = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), 256, extras, ctx=gpu_ctx)
+    rng = np.random.default_rng(3)
+    cols = {"s": rng.standard_normal((4, N)).astype(np.float32), "sp": rng.standard_normal((4, N)).astype(np.float32), "a": np.eye(2, dtype=bool)[rng.integers(0, 2, N)].T.copy(),
+            "r": np.ones((1, N), np.float32), "done": np.zeros((1, N), bool), "episode_end": np.zeros((1, N), bool), "logprob": np.zeros((1, N), np.float32)}
+    cols["episode_end"][0, -1] = True
+    ptrs = (C.c_void_p * L.NCOLS)(); keep = []
+    for k, v in cols.items():
+        arr = np.asfortranarray(v); keep.append(arr); ptrs[L.COL[k]] = arr.ctypes.data
+    fr = C.c_int64(-1)
+    rc = gpu_ctx.lib.crux_steps_push(b.h, N, ptrs, N, 1, None, 0.95, 0.99, None, None, 0, C.byref(fr))
+    assert rc == L.EINVAL and "no critic" in (gpu_ctx.lib.crux_last_error(gpu_ctx.h) or b"").decode()
+    assert len(b) == 0 and b.next_ind == 1 and fr.value == -1          # nothing moved (next_ind is 1-based like the reference field)

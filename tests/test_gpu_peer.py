@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import parity
+import replica_group as RG
 from parity import L, O, crux
 
 pytestmark = pytest.mark.gpu
@@ -43,29 +44,13 @@ def _interleave(shards, bs):
 @pytest.fixture()
 def two_contexts(gpu_ctx):
     c1 = crux.Context(0)
-    crux.peer_attach_local([gpu_ctx, c1])
+    RG.attach_or_skip([gpu_ctx, c1], owned=[c1])
     yield gpu_ctx, c1
     gpu_ctx.peer_detach(); c1.peer_detach(); c1.close()
 
 
-def _run_threads(fns):
-    errs = [None] * len(fns)
-    def wrap(i):
-        try:
-            fns[i]()
-        except Exception as e:      # noqa: BLE001
-            errs[i] = e
-    ts = [threading.Thread(target=wrap, args=(i,)) for i in range(len(fns))]
-    import faulthandler, sys
-    faulthandler.dump_traceback_later(20, file=sys.stderr)          # a group that has not finished after 20 s is stuck: show where every thread is
-    [t.start() for t in ts]; [t.join(120) for t in ts]
-    faulthandler.cancel_dump_traceback_later()
-    if any(e is not None for e in errs):
-        print("replica errors:", [repr(e)[:160] if e is not None else None for e in errs], file=sys.stderr)
-    assert not any(t.is_alive() for t in ts), "a replica did not return"
-    for e in errs:
-        if e is not None:
-            raise e
+_bound = RG.bound
+_run_threads = RG.run_threads_raise
 
 
 @pytest.mark.parametrize("which", ["actor", "critic"])
@@ -151,6 +136,89 @@ def test_two_replicas_on_identical_shards_reproduce_the_ungrouped_learner(two_co
         c3.close()
 
 
+def _one_learner(ctx, seed=210, which="critic"):
+    shard = _shard(seed); N = shard["s"].shape[1]; extras = ["return", "logprob", "advantage"]
+    dims = parity.ACTOR_DIMS if which == "actor" else parity.CRITIC_DIMS; ch = parity.chain(dims, parity.ACTS)
+    g = crux.DiscreteNetwork(ch, [1, 2], ctx=ctx, seed=79, stream=3) if which == "actor" else crux.ContinuousNetwork(ch, ctx=ctx, seed=79, stream=3)
+    b = crux.ExperienceBuffer(crux.ContinuousSpace(4), crux.DiscreteSpace(2), N, extras, ctx=ctx); b.push_(shard)
+    opt = crux.TrainingParams(loss=crux.ppo_loss if which == "actor" else crux.value_mse_loss, batch_size=128, epochs=2, name="n_")
+    return g, b, opt
+
+
+def test_the_host_calls_a_waiting_launch_off(two_contexts):
+    """bound 4 of csrc/peer_wait.h (VERDICT r5 #1c): replica 0 trains, replica 1 never does -- the learner's workgroups wait for a flag that will not come (timeout 30 s, budget
+    off). crux_peer_abort from another host thread -- no GPU work, while the training call sits in its stream synchronisation -- ends the launch: CRUX_EHIP within moments, the
+    message names the host; the device is usable afterwards."""
+    import time
+    c0, c1 = two_contexts
+    c0.peer_set_timeout_ms(30000); c0.peer_set_budget_ms(0)
+    g, b, opt = _one_learner(c0)
+    box = {}
+    def train():
+        t0 = time.time()
+        try:
+            crux.batch_train_(g, opt, {}, b)
+        except crux.CruxError as e:
+            box["err"] = e
+        box["seconds"] = time.time() - t0
+    t = threading.Thread(target=train, daemon=True); t.start()
+    time.sleep(0.5); assert t.is_alive(), "the learner did not wait for its peer: %r" % box
+    c0.peer_abort(); t.join(10.0)
+    assert not t.is_alive(), "the launch did not end after crux_peer_abort"
+    print("host abort: the call returned after %.2f s: %s" % (box["seconds"], box.get("err")))
+    assert box.get("err") is not None and box["err"].code == L.EHIP and "host called the launch off" in str(box["err"]) and box["seconds"] < 5.0
+    assert c0.peer_abort_reason()[0] == 4
+    c0.peer_abort_clear()
+    p = g.get_params(); assert np.isfinite(p).all()          # nothing was applied, the context answers
+
+
+def test_the_launch_budget_ends_a_group_whose_peer_is_slow(two_contexts):
+    """bound 2: replica 1 starts a second late. The per-exchange timeout (30 s) would sit that out; the launch budget (300 ms for all waits of one launch together) does not:
+    replica 0 gives up with CRUX_EHIP naming the budget and tells its peer, which leaves as soon as it starts -- the regime of replicas whose queues are time-sliced, where
+    every exchange is answered a scheduling quantum late (profiles/r06_same_device_oversubscription.txt)."""
+    import time
+    ctxs = two_contexts
+    for c in ctxs:
+        c.peer_set_timeout_ms(30000); c.peer_set_budget_ms(300)
+    L0, L1 = _one_learner(ctxs[0]), _one_learner(ctxs[1])
+    secs = [None, None]
+    def make(r, delay):
+        def f():
+            time.sleep(delay); t0 = time.time()
+            try:
+                crux.batch_train_((L0, L1)[r][0], (L0, L1)[r][2], {}, (L0, L1)[r][1])
+            finally:
+                secs[r] = time.time() - t0
+        return f
+    errs = RG.run_threads([make(0, 0.0), make(1, 1.0)], seconds=30.0)
+    print("budget: replica 0 after %.2f s: %s | replica 1 after %.2f s: %s" % (secs[0], errs[0], secs[1], errs[1]))
+    assert errs[0] is not None and errs[0].code == L.EHIP and "budget" in str(errs[0]) and 0.25 < secs[0] < 0.9
+    assert errs[1] is not None and errs[1].code == L.EHIP and secs[1] < 5.0          # told by replica 0's abort word: it does not wait for its own timeout
+    assert ctxs[1].peer_abort_reason()[0] == 2
+
+
+def test_the_rendezvous_probe(two_contexts):
+    """crux_peer_probe (collective; crux_peer_attach_local already ran it once): both replicas' kernels meet in microseconds on every learner stream. A probe only ONE rank
+    calls cannot meet anybody: CRUX_EHIP within its bounds, and the group refuses further probes until it is attached again."""
+    import time
+    ctxs = two_contexts; res = [None, None]
+    def make(r):
+        def f():
+            res[r] = ctxs[r].peer_probe(rounds=256, first_bound_ms=2000, round_bound_ms=20)
+        return f
+    _run_threads([make(0), make(1)])
+    print("rendezvous probe, us [first round, slowest later round] x 2 streams:", res)
+    for r in range(2):
+        assert max(res[r][1], res[r][3]) < 250.0, res
+    t0 = time.time()
+    with pytest.raises(crux.CruxError) as e:
+        ctxs[0].peer_probe(rounds=16, first_bound_ms=100, round_bound_ms=20)
+    assert e.value.code == L.EHIP and "did not meet" in str(e.value) and time.time() - t0 < 3.0
+    with pytest.raises(crux.CruxError) as e2:
+        ctxs[0].peer_probe(rounds=16, first_bound_ms=100, round_bound_ms=20)
+    assert e2.value.code == L.EINVAL
+
+
 def _group(gpu_ctx, R, attempts=5):
     """R contexts on device 0 wired into a replica group. Four replicas need all eight hardware queues (a learner and an auxiliary stream each): crux_peer_attach_local sometimes
     cannot place them and says so -- fresh contexts get fresh streams, so the attach is retried; if the placement never works the test is skipped with the library's message."""
@@ -159,6 +227,7 @@ def _group(gpu_ctx, R, attempts=5):
         extra = [crux.Context(0) for _ in range(R - 1)]; ctxs = [gpu_ctx] + extra
         try:
             crux.peer_attach_local(ctxs)
+            _bound(ctxs)
             return ctxs, extra
         except crux.CruxError as e:
             last = e
@@ -413,9 +482,8 @@ def test_three_replicas_of_the_c5_actor(gpu_ctx):
         O.OEnv(okind, E, 60, 0.99, seed, so=od, sa=ad).rollout(oa, parity.rollout_cfg(head=head), ob, T)
         O.chk(O.lib().orc_fill_gae(ob.h, oc.h, 0.95, 0.99)); O.chk(O.lib().orc_fill_returns(ob.h, 0.99)); O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"]))
         return {k: ob[k] for k in ob.keys()}
-    extra = [crux.Context(0) for _ in range(R - 1)]; ctxs = [gpu_ctx] + extra
+    ctxs, extra = _group(gpu_ctx, R)
     try:
-        crux.peer_attach_local(ctxs)
         shards = [shard(600 + r) for r in range(R)]; N = E * T
         rng = np.random.default_rng(9); perms = [rng.permutation(N)[None, :] for _ in range(R)]
         nets, bufs = [], []

@@ -55,7 +55,7 @@ def _interleave(shards, bs):
     return out, pos
 
 
-def _run_group(d, world, cfg, shards, perms, seconds=180):
+def _run_group(d, world, cfg, shards, perms, seconds=75):
     """write the inputs, start one worker process per rank, wait (killing exactly the PIDs started here on a timeout), return the exit codes"""
     json.dump(cfg, open(os.path.join(d, "cfg.json"), "w"))
     for r in range(world):
@@ -262,7 +262,7 @@ def test_a_dead_peer_yields_EHIP_on_the_survivor_not_a_hang(gpu_ctx):
     perms = [np.stack([np.arange(N)[None, :]] * 2) for _ in range(world)]
     cfg = _family_cfg(family, ["actor"], bs, 1, timeout_ms=2000, die_rank=1)
     with tempfile.TemporaryDirectory(prefix="crux_xproc_") as d:
-        rcs, outs = _run_group(d, world, cfg, shards, perms, seconds=90)
+        rcs, outs = _run_group(d, world, cfg, shards, perms, seconds=60)
         assert rcs == [0, 0], "\n".join(outs)
         assert not os.path.exists(os.path.join(d, "out_0.npz")), "the survivor trained to the end without its peer"
         err = json.load(open(os.path.join(d, "err_0.json")))
@@ -274,7 +274,7 @@ def test_a_dead_peer_yields_EHIP_on_the_survivor_not_a_hang(gpu_ctx):
     assert np.isfinite(g.get_params()).all(); gpu_ctx.sync()
 
 
-def _bench(args, seconds=420):
+def _bench(args, seconds=270):
     env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(29600 + os.getpid() % 300))
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=seconds)
@@ -283,6 +283,7 @@ def _bench(args, seconds=420):
     return json.loads(lines[0]), p.stderr
 
 
+@pytest.mark.watchdog(300)
 def test_bench_launcher_two_ranks_same_device_selftest_c5():
     """the command the driver's SCALE run issues, shrunk to one GPU: relaunch under torch.distributed.run, gloo rendezvous, hipIpc handle exchange, probe iteration, selftest,
     one timed C5-shard iteration per rank through the in-kernel exchange"""
@@ -295,6 +296,7 @@ def test_bench_launcher_two_ranks_same_device_selftest_c5():
     assert out["value"] > 0 and out["exchange"]["flag_wait_per_rank"][0]["n"] > 0
 
 
+@pytest.mark.watchdog(300)
 def test_bench_fallback_ladder_when_peer_attach_fails():
     """crux_peer_attach made to fail on every rank (corrupted handles): all ranks agree to leave the in-kernel exchange and land on periodic parameter averaging -- the library's
     RCCL communicator when every rank has its own device, torch.distributed (gloo here: the ranks share the device, where RCCL cannot run) otherwise -- and still finish with
