@@ -5,6 +5,7 @@ baseline from the oracle timed on a bounded sample of the same workload, so that
   c3  configs[2]: DQN + prioritized replay, 8-256-256-4, buffer 1 M, B = 128
   c4  configs[3]: SAC, actor 3-256-256-1 + twin Q 4-256-256-1, B = 256
   c1  configs[0]: DQN on SimpleGridWorld, 2-8-4, N = 100 000, dN = 4 (the README example)
+  host_env  the caller-stepped environment seam at C2 / C3 / C5 shapes (bench_hostenv.py)
 
 Every entry is wrapped: a failure here never takes the headline measurement down."""
 import ctypes as C
@@ -74,6 +75,11 @@ def run(crux, ctx, cpu=True):
             t0 = time.perf_counter(); out[name] = fn(crux, ctx, cpu); out[name]["bench_seconds"] = time.perf_counter() - t0
         except Exception as e:      # noqa: BLE001
             out[name] = {"error": repr(e)}
+    try:      # the caller-stepped environment seam: us per crux_policy_explore call at E = 32 / 1 / 128, env-steps/s end to end, the device environment beside it
+        import bench_hostenv
+        t0 = time.perf_counter(); out["host_env"] = bench_hostenv.run(crux, ctx); out["host_env"]["bench_seconds"] = time.perf_counter() - t0
+    except Exception as e:          # noqa: BLE001
+        out["host_env"] = {"error": repr(e)}
     try:
         import bench_offpolicy
         out.update(bench_offpolicy.run(crux, ctx, cpu))

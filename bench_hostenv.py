@@ -76,7 +76,7 @@ def one(crux, ctx, name):
     t_explore, t_push, t_env = [], [], []
 
     def block(i0):
-        nonlocal svec
+        nonlocal svec, steps_taken
         for t in range(T):
             cfg.i0 = i0 + t * E
             t0 = time.perf_counter()
@@ -88,7 +88,7 @@ def one(crux, ctx, name):
             cols["s"][:, rows + t] = svec; cols["a"][:, rows + t] = a_out; cols["sp"][:, rows + t] = sp
             if on_policy:
                 cols["logprob"][0, rows + t] = lp
-            svec = np.asfortranarray(sp); steps_taken += 1
+            svec = np.asfortranarray(sp); steps_taken = steps_taken + 1
             t2 = time.perf_counter()
             t_explore.append(t1 - t0); t_env.append(t2 - t1)
         t0 = time.perf_counter()
@@ -112,11 +112,11 @@ def one(crux, ctx, name):
     # the device-environment rollout of the same policy shape, E and T (crux_rollout: environment, policy and buffer write in one launch)
     try:
         if kind == "cartpole":
-            mdp = crux.CartPoleMDP(n_envs=E, seed=3, ctx=ctx) if "ctx" in crux.CartPoleMDP.__init__.__code__.co_varnames else crux.CartPoleMDP(n_envs=E, seed=3)
+            mdp = crux.CartPoleMDP(n_envs=E, seed=3)
         else:
             mdp = crux.SynthMDP(od, ad, n_envs=E, seed=3, discrete=disc)
         agent = crux.PolicyParams(crux.ActorCritic(pi, critic)) if on_policy else crux.PolicyParams(pi, pi_explore=crux.EpsGreedyPolicy(crux.LinearDecaySchedule(1.0, 0.1, 50000), list(range(1, ad + 1))))
-        smp = crux.Sampler(mdp, agent, S=S, max_steps=1000, required_columns=extras, lam=0.95)
+        smp = crux.Sampler(mdp, agent, max_steps=1000, required_columns=extras, lam=0.95 if on_policy else float("nan"), ctx=ctx)
         dbuf = crux.ExperienceBuffer(S, A, max(N, 1 << 16), extras, ctx=ctx)
         for _ in range(2):
             crux.steps_(smp, dbuf, Nsteps=N, explore=True, i=0, reset=True, want_info=False)
@@ -131,11 +131,19 @@ def one(crux, ctx, name):
     return out
 
 
-def run(crux, ctx):
+def run(crux, ctx, ab=True):
+    """ab: also time the round-5 form of the two calls (CRUX_HOST_ZEROCOPY=0: staged uploads and read-backs instead of the pinned, device-mapped block) beside the default"""
     out = {"note": "the caller-stepped environment seam (crux_policy_explore + crux_steps_push) under a trivial vectorised numpy environment; reference seam: src/sampler.jl:71-137"}
     for name in CONFIGS:
         try:
             out[name] = one(crux, ctx, name)
+            if ab:
+                os.environ["CRUX_HOST_ZEROCOPY"] = "0"; crux.reload_switches()
+                try:
+                    old = one(crux, ctx, name)
+                    out[name]["round5_form_staged_copies"] = {k: old[k] for k in ("us_per_policy_explore_call", "us_per_steps_push", "env_steps_per_s_end_to_end")}
+                finally:
+                    os.environ.pop("CRUX_HOST_ZEROCOPY", None); crux.reload_switches()
         except Exception as e:      # noqa: BLE001
             out[name] = {"error": repr(e)[:400]}
     return out

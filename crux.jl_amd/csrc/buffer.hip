@@ -2,6 +2,7 @@
 // Reference: src/experience_buffer.jl (mdp_data :4-35, ExperienceBuffer :53-80, shuffle! :118-124,
 // minibatch :170-171, get_last_N_indices :223-229, push! :232-259, update_priorities! :290-301).
 #include "common.h"
+#include <algorithm>
 #include "exec.h"
 #include "ops_small.h"
 
@@ -216,12 +217,41 @@ int32_t crux_buffer_column_ptr(crux_buffer* b, int32_t key, void** d_ptr) {
   *d_ptr = b->col[key]; return CRUX_OK;
 }
 
+// push! of a SMALL host block in one launch (the caller-stepped environment seam pushes E x T rows of six to nine columns per call -- C3: four rows):
+// the columns are gathered into the context's pinned, device-mapped staging block with plain memcpy and ONE kernel writes every column's rows to their ring positions,
+// instead of one staged upload per column and ring segment (each a dependent stream operation of ~5-10 us from pageable memory).
+struct PushCols { int n; unsigned src_off[CRUX_NCOLS]; unsigned stride[CRUX_NCOLS]; char* dst[CRUX_NCOLS]; };
+__global__ __launch_bounds__(256) void k_push_cols(PushCols pc, const char* __restrict__ stage, int64_t N, int64_t first, int64_t C) {
+  const int k = blockIdx.y; if (k >= pc.n) return;
+  const unsigned st = pc.stride[k]; const char* src = stage + pc.src_off[k]; char* dst = pc.dst[k];
+  if ((st & 3u) == 0u) { const unsigned w = st >> 2; const int64_t tot = N * (int64_t)w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) { const int64_t j = i / w; const unsigned q = (unsigned)(i - j * w);
+      ((uint32_t*)(dst + (size_t)((first + j) % C) * st))[q] = ((const uint32_t*)(src + (size_t)j * st))[q]; } }
+  else { const int64_t tot = N * (int64_t)st;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) { const int64_t j = i / st; const unsigned q = (unsigned)(i - j * st);
+      dst[(size_t)((first + j) % C) * st + q] = src[(size_t)j * st + q]; } }
+}
 int32_t crux_buffer_push_host(crux_buffer* b, int64_t N, const void* const* cols, int64_t* I_out) {   // push! :232-259
   if (!b || N < 0) return CRUX_EINVAL;
   crux_ctx* c = b->ctx;
   if (N == 0) return CRUX_OK;
   std::vector<int64_t> I; crux_buffer_ring_indices(b, N, I);
   const int64_t C = b->capacity;
+  size_t total = 0; for (int k = 0; k < CRUX_NCOLS; ++k) if (has_col(b, k) && cols && cols[k]) total += (col_stride(b, k) * (size_t)N + 15) / 16 * 16;
+  if (N <= C && total > 0 && total <= (1u << 20) && !b->prioritized && crux_sw().host_zerocopy) {      // (a prioritized ring goes on below: its priority bookkeeping needs the device index array anyway)
+    char* hs = (char*)crux_pinned_mapped(c, total); if (!hs) return crux_fail(c, CRUX_ENOMEM, "push!: pinned staging");
+    PushCols pc{}; size_t off = 0;
+    for (int k = 0; k < CRUX_NCOLS; ++k) { if (!has_col(b, k) || !cols[k]) continue;
+      const size_t st = col_stride(b, k); memcpy(hs + off, cols[k], st * (size_t)N);
+      pc.src_off[pc.n] = (unsigned)off; pc.stride[pc.n] = (unsigned)st; pc.dst[pc.n] = (char*)b->col[k]; pc.n += 1; off += (st * (size_t)N + 15) / 16 * 16; }
+    const unsigned gx = (unsigned)std::min<int64_t>(64, (N * 8 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_push_cols, dim3(gx, (unsigned)pc.n), dim3(256), 0, c->stream, pc, (const char*)c->pinned_mapped_dev, N, b->next_ind, C);
+    int32_t rc = crux_launch_check(c, "k_push_cols"); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // the staging block is the context's: it must be free again when the call returns (and so must the caller's arrays, as before)
+    crux_buffer_ring_advance(b, N);
+    if (I_out) memcpy(I_out, I.data(), 8 * (size_t)N);
+    return CRUX_OK;
+  }
   for (int k = 0; k < CRUX_NCOLS; ++k) {
     if (!has_col(b, k) || !cols || !cols[k]) continue;                                   // :238-241
     const size_t st = col_stride(b, k);

@@ -26,6 +26,7 @@ struct crux_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   void* scratch = nullptr; size_t scratch_bytes = 0;   // reusable device scratch
   void* pinned = nullptr; size_t pinned_bytes = 0;     // reusable pinned host staging
+  void* pinned_mapped = nullptr; void* pinned_mapped_dev = nullptr; size_t pinned_mapped_bytes = 0;   // reusable pinned, DEVICE-MAPPED staging (kernels read / write it in place: crux_policy_explore, the small-block push!)
   hipStream_t aux_stream = nullptr; hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr;   // second learner stream (actor || critic)
   hipStream_t aux_rejected[8] = {}; int aux_n_rejected = 0; float aux_probe_ms = 0.f;   // candidates that shared the main stream's hardware queue (kept alive until destroy)
   void* comm = nullptr; int comm_rank = 0, comm_n = 0;   // RCCL communicator of the replica group (comm.hip)
@@ -90,6 +91,7 @@ static inline bool crux_grouped(const crux_ctx* c) { return c->peer_n > 1 || c->
 int32_t crux_fail(crux_ctx* ctx, int32_t code, const char* fmt, ...);
 void* crux_scratch(crux_ctx* ctx, size_t bytes);       // grows; contents undefined
 void* crux_pinned(crux_ctx* ctx, size_t bytes);
+void* crux_pinned_mapped(crux_ctx* ctx, size_t bytes);   // grows (synchronising the stream first); host address returned, ctx->pinned_mapped_dev is the device's view
 // hipFree waits for the whole device. While contexts of this process form a replica group on ONE device (crux_peer_attach_local: tests, single-GPU
 // development), a learner kernel of one replica spins until the others answer -- a device-wide wait issued by another host thread (a growing scratch block,
 // or a finalizer of the host language's garbage collector destroying an unrelated handle) would wait for that kernel and stop the thread the kernel is

@@ -62,6 +62,16 @@ void* crux_pinned(crux_ctx* ctx, size_t bytes) {
   return ctx->pinned;
 }
 
+void* crux_pinned_mapped(crux_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pinned_mapped_bytes) return ctx->pinned_mapped;
+  if (ctx->pinned_mapped) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->pinned_mapped); ctx->pinned_mapped = nullptr; ctx->pinned_mapped_dev = nullptr; ctx->pinned_mapped_bytes = 0; }
+  size_t want = bytes < (1u << 16) ? (1u << 16) : bytes + bytes / 4;
+  if (hipHostMalloc(&ctx->pinned_mapped, want, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); ctx->pinned_mapped = nullptr; return nullptr; }
+  if (hipHostGetDevicePointer(&ctx->pinned_mapped_dev, ctx->pinned_mapped, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(ctx->pinned_mapped); ctx->pinned_mapped = nullptr; return nullptr; }
+  ctx->pinned_mapped_bytes = want;
+  return ctx->pinned_mapped;
+}
+
 static std::pair<hipEvent_t, hipEvent_t> take_events(crux_ctx* ctx) {
   if (!ctx->ev_pool.empty()) { auto p = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return p; }
   hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); return {a, b};
@@ -145,6 +155,7 @@ int32_t crux_ctx_destroy(crux_ctx* c) {
   if (c->scratch) (void)hipFree(c->scratch);
   for (int k = 0; k < 2; ++k) { if (c->xbuf[k]) (void)hipFree(c->xbuf[k]); if (c->xmulti[k]) (void)hipFree(c->xmulti[k]); if (c->amulti[k]) (void)hipFree(c->amulti[k]); }
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->pinned_mapped) (void)hipHostFree(c->pinned_mapped);
   for (int r = 0; r < 8; ++r) if (c->peer_ipc[r]) (void)hipIpcCloseMemHandle(c->peer_ptr[r]);
   if (c->peer_local) (void)hipFree(c->peer_local);
   if (c->peer_tab) (void)hipFree(c->peer_tab);

@@ -1094,13 +1094,20 @@ int32_t crux_policy_explore(crux_mlp* policy, const crux_rollout_cfg* cfg, int32
   if (cfg->head == CRUX_HEAD_GAUSSIAN && pn.n_extra != nout) return crux_fail(c, CRUX_EINVAL, "policy_explore: GaussianPolicy needs %d logSigma extras", nout);
   const bool disc = cfg->head == CRUX_HEAD_CATEGORICAL || cfg->head == CRUX_HEAD_GREEDY_Q;
   const size_t E = (size_t)n_envs, b_obs = (4 * E * od + 255) / 256 * 256, b_st = (8 * E + 255) / 256 * 256, b_act = (E * nout * (disc ? 1 : 4) + 255) / 256 * 256, b_lp = (4 * E + 255) / 256 * 256;
-  char* sc = (char*)crux_scratch(c, b_obs + b_st + b_act + b_lp); if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_explore: scratch");
+  // ONE launch per call: observations, step counters, actions and log-probabilities live in a pinned, device-mapped block of the context -- the kernel
+  // reads the E observations straight from host memory and writes the E actions back into it (a few hundred bytes to a few KB over the link, inside the launch) instead of
+  // two staged uploads before and two read-backs after the kernel: five dependent stream operations (~60-80 us per call from pageable memory) become one.
+  const bool zc = crux_sw().host_zerocopy;      // "0": the round-5 form (device scratch, two staged uploads, two read-backs) -- kept for the A/B of bench_hostenv.py and a bit-identity test
+  char* hs = zc ? (char*)crux_pinned_mapped(c, b_obs + b_st + b_act + b_lp) : nullptr; if (zc && !hs) return crux_fail(c, CRUX_ENOMEM, "policy_explore: pinned staging");
+  char* sc = zc ? (char*)c->pinned_mapped_dev : (char*)crux_scratch(c, b_obs + b_st + b_act + b_lp); if (!sc) return crux_fail(c, CRUX_ENOMEM, "policy_explore: scratch");
   RolloutArgs a = RolloutArgs{};
   a.nd = pn; a.p = policy->p; a.E = n_envs; a.od = od; a.ad = nout; a.act_kind = disc ? CRUX_ACTION_DISCRETE : CRUX_ACTION_CONTINUOUS; a.seed = seed;
   a.svec = (float*)sc; a.steps_taken = (int64_t*)(sc + b_obs); a.A = sc + b_obs + b_st; a.LP = (float*)(sc + b_obs + b_st + b_act); a.cfg = *cfg; a.squash = policy->squash;
-  HIPCHK(c, hipMemcpyAsync(a.svec, obs, 4 * E * od, hipMemcpyHostToDevice, c->stream));
-  if (steps_taken) HIPCHK(c, hipMemcpyAsync(a.steps_taken, steps_taken, 8 * E, hipMemcpyHostToDevice, c->stream));
-  else HIPCHK(c, hipMemsetAsync(a.steps_taken, 0, 8 * E, c->stream));
+  if (zc) { memcpy(hs, obs, 4 * E * od);
+    if (steps_taken) memcpy(hs + b_obs, steps_taken, 8 * E); else memset(hs + b_obs, 0, 8 * E); }
+  else { HIPCHK(c, hipMemcpyAsync(a.svec, obs, 4 * E * od, hipMemcpyHostToDevice, c->stream));
+    if (steps_taken) HIPCHK(c, hipMemcpyAsync(a.steps_taken, steps_taken, 8 * E, hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(c, hipMemsetAsync(a.steps_taken, 0, 8 * E, c->stream)); }
   // the arithmetic of the rollout kernel that serves this policy shape (crux_rollout: the register-resident form for the instantiated IN-64-64-OUT shapes, else the generic one)
   const bool h64 = pn.L == 3 && pn.dims[1] == 64 && pn.dims[2] == 64 && pn.acts[0] == pn.acts[1] && pn.acts[2] == CRUX_ACT_IDENTITY && !crux_sw().force_generic;
 #define EX_CASE(I, O, A_) if (h64 && od == I && nout == O && pn.acts[0] == A_) hipLaunchKernelGGL((k_explore_h64<I, O, A_>), dim3(n_envs), dim3(64), 0, c->stream, a); else
@@ -1109,9 +1116,11 @@ int32_t crux_policy_explore(crux_mlp* policy, const crux_rollout_cfg* cfg, int32
   if (pn.maxdim >= 128) hipLaunchKernelGGL(k_explore_generic<256>, dim3(n_envs), dim3(256), 0, c->stream, a);
   else hipLaunchKernelGGL(k_explore_generic<64>, dim3(n_envs), dim3(64), 0, c->stream, a);
   int32_t rc = crux_launch_check(c, "k_explore"); if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(actions_out, a.A, E * nout * (disc ? 1 : 4), hipMemcpyDeviceToHost, c->stream));
-  if (logprob_out) HIPCHK(c, hipMemcpyAsync(logprob_out, a.LP, 4 * E, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!zc) { HIPCHK(c, hipMemcpyAsync(actions_out, a.A, E * nout * (disc ? 1 : 4), hipMemcpyDeviceToHost, c->stream));
+    if (logprob_out) HIPCHK(c, hipMemcpyAsync(logprob_out, a.LP, 4 * E, hipMemcpyDeviceToHost, c->stream)); }
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // the one synchronisation of the call: the actions are what the caller steps its environment with
+  if (zc) { memcpy(actions_out, hs + b_obs + b_st, E * nout * (disc ? 1 : 4));
+    if (logprob_out) memcpy(logprob_out, hs + b_obs + b_st + b_act, 4 * E); }
   return CRUX_OK;
 }
 

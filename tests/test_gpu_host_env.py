@@ -84,8 +84,12 @@ def _bits_equal(a, b):
     return np.array_equal(a.view(np.uint32), b.view(np.uint32)) if a.dtype == np.float32 else np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("zerocopy", ["1", "0"], ids=["zero_copy_staging", "staged_copies"])
 @pytest.mark.parametrize("dims,acts", [([4, 64, 64, 2], ["relu", "relu", "identity"]), ([4, 32, 32, 2], ["tanh", "tanh", "identity"])], ids=["h64_policy", "generic_policy"])
-def test_cartpole_stepped_from_the_host_reproduces_crux_rollout_bit_for_bit(gpu_ctx, dims, acts):
+def test_cartpole_stepped_from_the_host_reproduces_crux_rollout_bit_for_bit(gpu_ctx, monkeypatch, dims, acts, zerocopy):
+    """(round 6: crux_policy_explore reads the observations from and writes the actions into a pinned, device-mapped block in ONE launch, and a small host block is pushed by
+    ONE kernel -- CRUX_HOST_ZEROCOPY=0 is the round-5 form with staged uploads and read-backs: both must reproduce the device rollout bit for bit)"""
+    monkeypatch.setenv("CRUX_HOST_ZEROCOPY", zerocopy)
     E, T, max_steps, seed = 4, 48, 21, 777
     extras = ["return", "logprob", "advantage", "t", "i", "weight", "cost"]
     S, A = crux.ContinuousSpace(4, mu=np.float32(0.01), sigma=np.float32(1.5)), crux.DiscreteSpace(2)
