@@ -31,6 +31,13 @@
 // gradient between the totals and Adam; PXK: local steps, theta / m / v averaged every k-th -- the exchange of train_fs_kernel.h, same bits); lagrange_ppo_loss stays on k_train_fs.
 #pragma once
 #include "train_fs_kernel.h"
+// CRUX_FS2_EXP (development builds only; tools/fs4_bound.sh): a TIMING experiment with WRONG results -- what would a step cost if every compute wave ran the MFMA chain of a
+// four-waves-per-tile decomposition (half the second-layer, dH1 and dW1 MFMAs of the pair form)? 1: the chain is cut (no extra load anywhere: the upper bound of the gain);
+// 2: the helper wave that shares the SIMD additionally issues the MFMAs and VALU work the second pair of compute waves would (the contention a real quad form has);
+// 3: as 2 with the MFMAs only.
+#ifndef CRUX_FS2_EXP
+#define CRUX_FS2_EXP 0
+#endif
 
 template <int IN, int OUT, int H2>
 struct Fs2Layout : FsLayout<IN, OUT, 4, true, H2, false> {
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
 #pragma unroll
             for (int mm = 0; mm < MH; ++mm) acc[mm] = *(const f32x4*)&sm[Lt::oB2 + HH * h + 16 * mm + 4 * g];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) { f32x4 wv[MH];
+            for (int m = 0; m < (CRUX_FS2_EXP ? 2 : 4); ++m) { f32x4 wv[MH];
 #pragma unroll
               for (int mm = 0; mm < MH; ++mm) wv[mm] = *(const f32x4*)&sm[Lt::oW2R + (HH * h + 16 * mm + c) * FS_LD + 16 * m + 4 * g];
 #pragma unroll
@@ -760,7 +767,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
           for (int mm = 0; mm < MH; ++mm) { av[mm] = h2[mm]; av[MH + mm] = *(const f32x4*)&dq[256 * mm]; }
           f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int q = 0; q < 2 * MH; ++q) { const int fo = HH * ((q >= MH) ? 1 - h : h) + 16 * (q % MH);
+          for (int q = 0; q < (CRUX_FS2_EXP ? MH : 2 * MH); ++q) { const int fo = HH * ((q >= MH) ? 1 - h : h) + 16 * (q % MH);
             const f32x4 wv0 = *(const f32x4*)&sm[Lt::oW2C + (32 * h + c) * FS_LD + fo + 4 * g];
             const f32x4 wv1 = *(const f32x4*)&sm[Lt::oW2C + (32 * h + 16 + c) * FS_LD + fo + 4 * g];
 #pragma unroll
@@ -794,7 +801,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) xR[r] = (16 * jt + c < IP) ? xs_c[(4 * g + r) * XP + 16 * jt + c] : 0.f;
 #pragma unroll
-          for (int mm = 0; mm < 2; ++mm) { f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          for (int mm = 0; mm < (CRUX_FS2_EXP ? 1 : 2); ++mm) { f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz1r[mm][r], xR[r], acc, 0, 0, 0);
             if (16 * jt + c < Lt::W1ROWS) *(f32x4*)&part[Lt::pW1 + (16 * jt + c) * FS_LD + 32 * h + 16 * mm + 4 * g] = acc; }
@@ -923,12 +930,28 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         FS2_T(1);
         if (st + bs < total_rows) stage(xcur ^ 1);
         FS2_T(2);
+#if CRUX_FS2_EXP >= 2
+        { f32x4 dacc = {0.f, 0.f, 0.f, 0.f}; float da = (float)lane, db = (float)w;      // the forward of a second compute pair on this SIMD: L1 (4) + a quarter of L2 (16) MFMAs, logits + head VALU
+#pragma unroll
+          for (int q = 0; q < 20; ++q) { dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(da, db, dacc, 0, 0, 0); asm volatile("" : "+v"(dacc)); }
+#pragma unroll
+          for (int q = 0; q < (CRUX_FS2_EXP == 2 ? 120 : 0); ++q) { da = fmaf(da, 1.0001f, db); asm volatile("" : "+v"(da)); }
+          if (da == 123.456f) sm[Lt::oRED + 28] = dacc[0]; }
+#endif
         __syncthreads();   // ---- B_1: T1 / T2 tiles of the workgroup are visible
         FS2_T(3);
         // ======================= dW2 of this wave's tiles, then phase 1 of the exchange: the hand-shake for the W2 partials of ALL eight waves =======================
         const unsigned tag = xstep + 1u;
         f32x4 gW2[WT];
         dw2_send(gW2);
+#if CRUX_FS2_EXP >= 2
+        { f32x4 dacc = {0.f, 0.f, 0.f, 0.f}; float da = (float)lane, db = (float)w;      // dH1 (16) + dW1 (4) MFMAs and the dZ1 / bias VALU of the second compute pair
+#pragma unroll
+          for (int q = 0; q < 20; ++q) { dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(da, db, dacc, 0, 0, 0); asm volatile("" : "+v"(dacc)); }
+#pragma unroll
+          for (int q = 0; q < (CRUX_FS2_EXP == 2 ? 60 : 0); ++q) { da = fmaf(da, 1.0001f, db); asm volatile("" : "+v"(da)); }
+          if (da == 123.456f) sm[Lt::oRED + 28] = dacc[0]; }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this lane has reached the L2 (and the prefetched rows are in)
         if (lane == 0) (void)__hip_atomic_fetch_add((unsigned*)(sm + Lt::cACK), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         FS2_T(4);
