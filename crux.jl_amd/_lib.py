@@ -94,7 +94,7 @@ SIGNATURES = {
     "crux_dqn_small_solve": (i32, [vp, vp, vp, P(RolloutCfg), vp, vp, i32, i32, i32, f32, f32, i32, u64, vp, P(f64), P(i64)]),
     "crux_dqn_epoch": (i32, [vp, vp, vp, vp, f32, i32, f32, u64, vp]),
     "crux_dqn_epochs": (i32, [vp, vp, vp, vp, f32, i32, f32, u64, i32, vp]),
-    "crux_dqn_epochs_async": (i32, [vp, vp, vp, vp, f32, i32, f32, u64, i32, vp]),
+    "crux_dqn_epochs_async": (i32, [vp, vp, vp, vp, f32, i32, f32, u64, i32, vp]), "crux_dqn_value_training_async": (i32, [vp, vp, vp, vp, f32, f32, i32, f32, u64, i32, f32, vp]),
     "crux_softq_epochs": (i32, [vp, vp, vp, vp, f32, f32, i32, f32, u64, i32, vp]),
     "crux_softq_epochs_async": (i32, [vp, vp, vp, vp, f32, f32, i32, f32, u64, i32, vp]),
     "crux_sac_epochs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i32, i32, u64, u64, u64, vp, vp, vp]),

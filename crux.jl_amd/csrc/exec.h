@@ -64,6 +64,7 @@ struct ExecRec {
   // asynchronous runs (crux_dqn_epochs_async): no read-back, no host synchronisation -- the info rows are copied to a caller-owned device array by ops of the list itself.
   // The op list is uploaded from a ring of pinned staging buffers, so the host may record and enqueue up to three chains ahead of the one the device is running.
   bool async = false;
+  float* info_row_override = nullptr;      // asynchronous tile-plan epochs: the epoch's info op writes the caller's device row itself (no copy op, no extra phase behind the chain's last epoch)
   void* h_ring[4] = {nullptr, nullptr, nullptr, nullptr}; size_t h_ring_cap[4] = {0, 0, 0, 0}; void* h_ring_ev[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned h_ring_next = 0;
 };
 bool crux_exec_recording(const crux_ctx* c);

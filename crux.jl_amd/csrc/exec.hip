@@ -570,6 +570,8 @@ static int32_t dqn_epoch_tiles(crux_mlp* net, crux_mlp* tnet, crux_buffer* sourc
   Carve sv{(char*)crux_exec_small(c, 256 * 6), 0}; if (!sv.p) return bail(crux_fail(c, CRUX_ENOMEM, "dqn_epoch: executor region"));
   float* dinfo = sv.take<float>(CRUX_INFO_N); double* ssq = sv.take<double>(2 + SUMSQ_BLOCKS); int32_t* status = sv.take<int32_t>(1); int32_t* nanf = sv.take<int32_t>(2);
   rc = crux_exec_zero(c, dinfo, 256 * 6, c->stream); if (rc) return bail(rc);
+  float* const info_dst = r->info_row_override ? r->info_row_override : dinfo;      // asynchronous chains: the info op writes the caller's device row itself (round 6: one launch less behind the chain's last epoch)
+  if (r->info_row_override) { rc = crux_exec_zero(c, r->info_row_override, sizeof(float) * CRUX_INFO_N, c->stream); if (rc) return bail(rc); }
   only(1);
   const float* S = (const float*)batch->col[CRUX_COL_S]; const float* SP = (const float*)batch->col[CRUX_COL_SP];
   rc = crux_dense_forward12(net, S, B, c->stream); if (!rc) rc = crux_dense_forward12(tnet, SP, B, c->stream); if (rc) return bail(rc);
@@ -590,7 +592,7 @@ static int32_t dqn_epoch_tiles(crux_mlp* net, crux_mlp* tnet, crux_buffer* sourc
   CRUX_RUN(c, Sumsq2Op, OP_SUMSQ2, k_sumsq2, SUMSQ_BLOCKS, 256, c->stream, net->g, (int64_t)net->nd.n_params, (float*)nullptr, (int64_t)0, ssq, fx);
   rc = adam_self(net, nanf, status, fx, 0); if (rc) return bail(rc);
   sect([](int kid) { return kid == OP_ADAM_ADVANCE_SELF ? 6 : 5; });
-  crux_exec_push<TdInfo2Op, OP_TD_INFO2>(c, 1u, (const float*)term, (const float*)qsel, (const double*)ssq, B, dinfo);
+  crux_exec_push<TdInfo2Op, OP_TD_INFO2>(c, 1u, (const float*)term, (const float*)qsel, (const double*)ssq, B, info_dst);
   only(6);
   crux_exec_add_readback(c, info_out, dinfo, status, "td_loss");
   if (!(plan_ok && ph.size() == r->ops.size() - ops0)) r->chain_ok = false;
@@ -703,7 +705,7 @@ int32_t crux_dqn_epoch(crux_mlp* net, crux_mlp* target_net, crux_buffer* source,
 // the iteration's (rand!(…, i = S.i)). infos: host [n x CRUX_INFO_N]. Falls back to n single-epoch calls wherever an epoch cannot be chained (narrow networks, a
 // priority tree that needs a full rebuild between epochs).
 static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float softq_alpha, int32_t use_weight, float beta,
-                               uint64_t sample_counter0, int32_t n_epochs, float* infos, float* d_infos_async = nullptr) {
+                               uint64_t sample_counter0, int32_t n_epochs, float* infos, float* d_infos_async = nullptr, float polyak_tau = -1.f) {
   if (!net || !target_net || !source || !batch || n_epochs < 1) return CRUX_EINVAL;
   crux_ctx* c = net->ctx;
   const bool fuse = net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && target_net->nd.maxdim >= CRUX_DENSE_MIN_WIDTH && !crux_sw().no_fused_epoch &&
@@ -747,15 +749,25 @@ static int32_t dqn_epochs_impl(crux_mlp* net, crux_mlp* target_net, crux_buffer*
     if (!in_chain) { if (source->prioritized) { rc = crux_per_prepare(source); if (rc) return rc; }
       rc = crux_exec_begin(c); if (rc) return rc; }
     rec_of(c)->chain = true;
-    rc = dqn_epoch_impl(net, target_net, source, batch, gamma, softq_alpha, use_weight, beta, sample_counter0 + (uint64_t)e, info_e);
-    if (rc) { if (c->rec) rec_of(c)->chain = false; crux_exec_abort(c); return rc; }
     const bool tiles = dqn_tile_case(net, target_net, source, batch) && !crux_sw().no_fused_epoch;
-    if (d_infos_async) {      // the epoch's info row goes to the caller's device array, copied in the epoch's last phase (one phase after the info op wrote it)
+    rec_of(c)->info_row_override = (d_infos_async && tiles) ? d_infos_async + (size_t)e * CRUX_INFO_N : nullptr;      // tile plan: the info op writes the caller's row itself
+    rc = dqn_epoch_impl(net, target_net, source, batch, gamma, softq_alpha, use_weight, beta, sample_counter0 + (uint64_t)e, info_e);
+    if (c->rec) rec_of(c)->info_row_override = nullptr;
+    if (rc) { if (c->rec) rec_of(c)->chain = false; crux_exec_abort(c); return rc; }
+    if (d_infos_async && !tiles) {      // the epoch's info row goes to the caller's device array, copied in the epoch's last phase (one phase after the info op wrote it)
       ExecRec* r = rec_of(c);
       crux_exec_push<CopyF32Op, OP_COPY_F32>(c, 1u, d_infos_async + (size_t)e * CRUX_INFO_N, (const float*)r->readbacks.back().d_info, (int64_t)CRUX_INFO_N);
       int tmax = 0; for (size_t k = r->epoch_marks.empty() ? 0 : r->epoch_marks.back(); k < r->chain_tags.size(); ++k) tmax = std::max(tmax, r->chain_tags[k] & ~3);      // the epoch's last phase (the beta-power advance)
       r->chain_tags.push_back(tmax + (tiles ? 4 : 0)); }      // (tile plan: the info op sits IN the epoch's last phase -- the copy joins the launch after it)
     ++in_chain;
+  }
+  // polyak_average!(pi_minus, pi, tau) after the epoch loop (off_policy.jl:108: the DQN family updates its target once per value_training call) as an op of the chain: it needs
+  // the last epoch's Adam (phase 5) and shares the launch of that epoch's info / beta-power phase -- the stand-alone k_polyak launch (~5 us of a 230 us C3 iteration) is gone.
+  if (fuse && polyak_tau >= 0.f && in_chain > 0) {
+    ExecRec* r = rec_of(c); const size_t n0 = r->ops.size();
+    rc = crux_polyak(target_net, net, polyak_tau); if (rc) { r->chain = false; crux_exec_abort(c); return rc; }
+    int tmax = 0; for (size_t k = r->epoch_marks.empty() ? 0 : r->epoch_marks.back(); k < r->chain_tags.size(); ++k) tmax = std::max(tmax, r->chain_tags[k] & ~3);
+    for (size_t k = n0; k < r->ops.size(); ++k) r->chain_tags.push_back(tmax);
   }
   return fuse ? flush() : rc;
 }
@@ -773,6 +785,15 @@ int32_t crux_dqn_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* 
   if (!d_infos) return CRUX_EINVAL;
   if (!net || !target_net || net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || target_net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || crux_sw().no_fused_epoch || crux_sw().no_chained_epochs) return CRUX_EUNSUP;
   return dqn_epochs_impl(net, target_net, source, batch, gamma, 0.f, use_weight, beta, sample_counter0, n_epochs, nullptr, d_infos);
+}
+// value_training of the DQN family INCLUDING its target update (off_policy.jl:66-111 with :108), without the host: the chain of crux_dqn_epochs_async (softq_alpha > 0:
+// crux_softq_epochs_async) with polyak_average!(target_net, net, tau) riding in the last epoch's final phase. tau < 0: no target update (== the plain async entries).
+int32_t crux_dqn_value_training_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float softq_alpha, int32_t use_weight, float beta,
+                                      uint64_t sample_counter0, int32_t n_epochs, float tau, float* d_infos) {
+  if (!d_infos || softq_alpha < 0.f || tau > 1.f) return CRUX_EINVAL;
+  if (!net || !target_net || net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || target_net->nd.maxdim < CRUX_DENSE_MIN_WIDTH || crux_sw().no_fused_epoch || crux_sw().no_chained_epochs) return CRUX_EUNSUP;
+  if (tau >= 0.f && net->nd.n_params != target_net->nd.n_params) return crux_fail(net->ctx, CRUX_EINVAL, "value_training: polyak_average! needs equal parameter counts");
+  return dqn_epochs_impl(net, target_net, source, batch, gamma, softq_alpha, use_weight, beta, sample_counter0, n_epochs, nullptr, d_infos, tau);
 }
 int32_t crux_softq_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
                                 uint64_t sample_counter0, int32_t n_epochs, float* d_infos) {      // crux_softq_epochs without the host in the loop (see crux_dqn_epochs_async)

@@ -318,17 +318,16 @@ def value_training(solver, D, gamma):
         if getattr(solver, "_async_now", False):
             # no host in the loop: the chain is enqueued and the info rows stay on the device (OffPolicySolver.history fetches them)
             d_rows, _row0 = _info_ring(solver, ctx, p.epochs)
-            if solver.target_fn == "softq":
-                rc = ctx.lib.crux_softq_epochs_async(pi.h, pim.h, buf.h, D.h, float(gamma), float(solver.P["alpha"]), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, d_rows)
-            else:
-                rc = ctx.lib.crux_dqn_epochs_async(pi.h, pim.h, buf.h, D.h, float(gamma), 1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, d_rows)
+            # the epoch loop AND the target update of :108 (polyak_average!(pi_minus, pi, tau): the built-in target_update of this fused path) in ONE chain: the polyak
+            # update rides in the last epoch's final phase instead of a launch of its own (cruxhip.h: crux_dqn_value_training_async)
+            rc = ctx.lib.crux_dqn_value_training_async(pi.h, pim.h, buf.h, D.h, float(gamma), float(solver.P["alpha"]) if solver.target_fn == "softq" else 0.0,
+                                                       1 if solver.weighted_loss else 0, beta, solver.i * p.epochs, p.epochs, float(np.float32(solver.tau)), d_rows)
             if rc == L.OK:
                 name = p.name; row0 = _row0
                 def decode(raws):
                     return [{name + "loss": float(r[0]), name + "grad_norm": float(r[1]), "Qavg": float(r[2])} for r in raws], bool(np.isnan(raws[:, 1]).any())
                 pend = _PendingInfo(row0, p.epochs, decode); solver._dinfos_used += p.epochs
-                solver._update_target(final=True)                                                          # :108
-                return pend
+                return pend                                                                                # (:108 ran inside the chain)
             if rc != L.EUNSUP:
                 ctx.check(rc)
             solver._async_now = False; solver._async_fell_back = True      # narrow networks: the synchronous entry point from here on

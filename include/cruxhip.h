@@ -527,6 +527,11 @@ int32_t crux_dqn_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source
  * the recorded form (narrower than the dense engine's minimum width) -- use crux_dqn_epochs.                                                               */
 int32_t crux_dqn_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, int32_t use_weight, float beta,
                               uint64_t sample_counter0, int32_t n_epochs, float* d_infos);
+/* value_training of the DQN family INCLUDING its target update (off_policy.jl:66-111: the epoch loop, then `target_update(pi_minus, pi)` once, :108), without the host:
+ * the chain of crux_dqn_epochs_async (softq_alpha > 0: of crux_softq_epochs_async) with polyak_average!(target_net, net, tau) (src/utils.jl polyak_average!) as an op of the
+ * chain's last phase instead of a launch of its own. tau < 0: no target update. Same results, bit for bit, as the async entry followed by crux_polyak.                   */
+int32_t crux_dqn_value_training_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float softq_alpha, int32_t use_weight, float beta,
+                                      uint64_t sample_counter0, int32_t n_epochs, float tau, float* d_infos);
 int32_t crux_softq_epochs(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,
                           uint64_t sample_counter0, int32_t n_epochs, float* infos);
 int32_t crux_softq_epochs_async(crux_mlp* net, crux_mlp* target_net, crux_buffer* source, crux_buffer* batch, float gamma, float alpha, int32_t use_weight, float beta,

@@ -477,8 +477,9 @@ function Crux.value_training(𝒮::Crux.OffPolicySolver, 𝒟::HipBuffer, γ; as
     if softq
         α = Float32(𝒮.𝒫[:alpha])
         if async
-            rc = ccall((:crux_softq_epochs_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Int32, Float32, UInt64, Int32, Ptr{Cvoid}),
-                       π.h, π⁻.h, 𝒮.buffer.h, 𝒟.h, γ, α, per, β, ctr0, n, d_rows)
+            # the epoch loop and :108's polyak_average!(π⁻, π, 0.005f0) in ONE chain (round 6: the target update rides in the last epoch's final phase)
+            rc = ccall((:crux_dqn_value_training_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Int32, Float32, UInt64, Int32, Float32, Ptr{Cvoid}),
+                       π.h, π⁻.h, 𝒮.buffer.h, 𝒟.h, γ, α, per, β, ctr0, n, 0.005f0, d_rows)
             rc == EUNSUP || (check(ctx, rc); return PendingInfo(ctx, d_rows, n, 1, decode, nothing))
             device_free(ctx, d_rows)
         end
@@ -486,9 +487,9 @@ function Crux.value_training(𝒮::Crux.OffPolicySolver, 𝒟::HipBuffer, γ; as
                          π.h, π⁻.h, 𝒮.buffer.h, 𝒟.h, γ, α, per, β, ctr0, n, infos))
     else
         if async
-            rc = ccall((:crux_dqn_epochs_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Int32, Float32, UInt64, Int32, Ptr{Cvoid}),
-                       π.h, π⁻.h, 𝒮.buffer.h, 𝒟.h, γ, per, β, ctr0, n, d_rows)
-            rc == EUNSUP || (check(ctx, rc); Crux.polyak_average!(π⁻, π, 0.005f0); return PendingInfo(ctx, d_rows, n, 1, decode, nothing))
+            rc = ccall((:crux_dqn_value_training_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Int32, Float32, UInt64, Int32, Float32, Ptr{Cvoid}),
+                       π.h, π⁻.h, 𝒮.buffer.h, 𝒟.h, γ, 0f0, per, β, ctr0, n, 0.005f0, d_rows)                              # softq_alpha = 0: dqn_target; tau = 0.005: :108 inside the chain
+            rc == EUNSUP || (check(ctx, rc); return PendingInfo(ctx, d_rows, n, 1, decode, nothing))
             device_free(ctx, d_rows)
         end
         check(ctx, ccall((:crux_dqn_epochs, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float32, Int32, Float32, UInt64, Int32, Ptr{Float32}),

@@ -154,3 +154,60 @@ def test_c3_full_size_value_training_epochs_replay_oracle(gpu_ctx):
     dp = np.abs(g.get_params() - o.params)
     print("C3 full size: 5 epochs, max |dtheta| = %.3g, entries above 2e-5: %.4f %%" % (dp.max(), 100 * np.mean(dp > 2e-5)))
     assert dp.max() < 5e-6                                         # measured 4.8e-7 after the five weighted td_loss steps
+
+
+def test_c4_full_size_solve_iterations_replay_oracle(gpu_ctx):
+    """BASELINE configs[3] at its sizes (every BASELINE configuration has a full-size oracle replay among the first tests of the run): SAC through
+    solve(::OffPolicySolver) (off_policy.jl:113-150; sac.jl:4-52) on the Pendulum restatement, GaussianPolicy 3->256->256->1 + twin Q 4->256->256->1, 256-row minibatches,
+    Adam 3e-4, polyak 0.005. buffer_init = 256 steps, then four iterations of dN = 4 `steps!` + 4 value_training epochs {rand! -> sac_target -> temperature step ->
+    double_Q_loss step -> actor step -> polyak_average!} = 16 epochs through the product path (the chained executor epochs); the ORACLE runs the same loop call by call.
+    Ring, networks, target networks and log alpha must agree (free-running from zero Adam moments: the tolerances of tests/test_gpu_sac.py's 32-wide solve)."""
+    from parity import L, O, crux
+    ctx = gpu_ctx
+    E, dN, B, N, cap, seed, max_steps, nseed = 1, 4, 256, 256 + 16, 4096, 6, 200, 77      # N counts from 0 and includes the buffer_init fill (off_policy.jl:122-133): four iterations after it
+    adims, qdims = [3, 256, 256, 1], [4, 256, 256, 1]; aacts = ["relu", "relu", "identity"]; qacts = ["relu", "relu", "identity"]
+    ga, oa = parity.make_pair(adims, aacts, 13, 0, "gaussian", n_extra=1, extra_init=-0.3)
+    g1, o1 = parity.make_pair(qdims, qacts, 13, 1); g2, o2 = parity.make_pair(qdims, qacts, 13, 2)
+    S = crux.ContinuousSpace(3)
+    mdp = crux.PendulumMDP(n_envs=E, seed=seed)
+    pi = crux.ActorCritic(ga, crux.DoubleNetwork(g1, g2))
+    lr = np.float32(3e-4); opt = {"batch_size": B, "optimizer": crux.Adam(lr)}
+    solver = crux.SAC(pi, S, N=N, dN=dN, c_opt=dict(opt), a_opt=dict(opt), SAC_alpha_opt=dict(opt), buffer_size=cap, buffer_init=B, max_steps=max_steps, noise_seed=nseed,
+                      pi_explore=crux.GaussianNoiseExplorationPolicy(0.5, a_min=-2.0, a_max=2.0))
+    crux.solve(solver, mdp)
+    # ---- the same loop on the oracle (tests/test_gpu_sac.py::test_sac_solve_matches_oracle_loop at C4's sizes)
+    ota, ot1, ot2 = O.OMlp(adims, aacts, 1), O.OMlp(qdims, qacts), O.OMlp(qdims, qacts)
+    for t, src in ((ota, oa), (ot1, o1), (ot2, o2)):
+        O.chk(O.lib().orc_mlp_copy(t.h, src.h))
+    ola = O.OMlp([0], [], 1); ola.params[:] = np.log(np.float32(1.0))
+    for o in (oa, o1, o2, ola):
+        o.adam_init(float(lr))
+    ob = O.OBuffer(3, 1, L.ACTION_CONTINUOUS, cap); obt = O.OBuffer(3, 1, L.ACTION_CONTINUOUS, B)
+    oe = O.OEnv("pendulum", E, max_steps, 0.99, seed)
+    cfg = parity.rollout_cfg(True, False, "deterministic"); cfg.noise_sigma, cfg.a_min, cfg.a_max = 0.5, -2.0, 2.0
+    i = 0; istart = 0
+    i += B; cfg.i0 = i; oe.rollout(oa, cfg, ob, B // E)
+    y, info, ol = np.empty(B, np.float32), np.zeros(L.INFO_N, np.float32), O.lib()
+    gamma = float(np.float32(crux.discount(mdp))); epochs = 0
+    while i <= istart + N - dN:
+        cfg.i0 = i; oe.rollout(oa, cfg, ob, dN // E)
+        for ep in range(dN):
+            ctr = i * dN + ep
+            O.chk(ol.orc_uniform_sample(obt.h, ob.h, B, None, ctr, crux.api.SAMPLE_SEED))
+            O.chk(ol.orc_sac_target(oa.h, ot1.h, ot2.h, ola.h, obt.h, gamma, nseed, 3 * ctr, O.vpz(y)))
+            O.chk(ol.orc_sac_temp_step(oa.h, ola.h, obt.h, -1.0, nseed, 3 * ctr + 1, O.vpz(info)))
+            O.chk(ol.orc_double_q_step(o1.h, o2.h, obt.h, O.vpz(y), 0, O.vpz(info)))
+            O.chk(ol.orc_sac_actor_step(oa.h, o1.h, o2.h, ola.h, obt.h, nseed, 3 * ctr + 2, O.vpz(info)))
+            for t, src in ((ota, oa), (ot1, o1), (ot2, o2)):
+                O.chk(ol.orc_polyak(t.h, src.h, 0.005))
+            epochs += 1
+        i += dN
+    assert solver.i == i and len(solver.buffer) == len(ob) == N and epochs == 16
+    worst_col = {k: float(np.abs(solver.buffer[k] - ob[k]).max()) for k in ("s", "a", "sp", "r")}
+    assert np.array_equal(solver.buffer["done"], ob["done"])
+    worst = {n: float(np.abs(g.get_params() - o.params).max()) for n, g, o in (("actor", ga, oa), ("q1", g1, o1), ("q2", g2, o2), ("log_alpha", solver.P["SAC_log_alpha"], ola),
+                                                                               ("q1_target", solver.agent.pi_minus.C.N1, ot1), ("q2_target", solver.agent.pi_minus.C.N2, ot2))}
+    print("C4 full size: %d epochs at B = %d; ring max |d| %s; max |dtheta| %s" % (epochs, B, worst_col, worst))
+    assert max(worst_col.values()) < 1e-4
+    assert max(worst.values()) < 5e-5
+    assert abs(solver.history[-1]["actor_loss"]) < 1e3 and "SAC alpha" in solver.history[-1]

@@ -239,7 +239,7 @@ def test_constant_tables_carry_the_headers_values():
 
 def test_the_benchmarked_paths_and_the_seams_are_bound():
     bound = {c[0] for c in shim_ccalls()}
-    need = ["crux_dqn_epochs_async", "crux_sac_epochs_async", "crux_softq_epochs_async", "crux_dpg_epochs_async", "crux_dqn_epochs", "crux_sac_epochs", "crux_softq_epochs", "crux_dpg_epochs",
+    need = ["crux_dqn_value_training_async", "crux_sac_epochs_async", "crux_dpg_epochs_async", "crux_peer_probe", "crux_peer_abort", "crux_peer_set_budget_ms", "crux_dqn_epochs", "crux_sac_epochs", "crux_softq_epochs", "crux_dpg_epochs",
             "crux_fill_gae_rows_keys", "crux_fill_returns_rows_keys", "crux_first_episode_metrics", "crux_buffer_shuffle", "crux_policy_gradient_training_multi", "crux_per_get",
             "crux_policy_explore", "crux_steps_push", "crux_rollout", "crux_policy_gradient_training", "crux_batch_train", "crux_batch_train_lagrange", "crux_peer_export", "crux_peer_attach",
             "crux_peer_set_sync_every", "crux_peer_set_timeout_ms", "crux_per_sample", "crux_uniform_sample", "crux_per_update", "crux_whiten", "crux_fill_gae_rows", "crux_fill_returns_rows"]
@@ -248,7 +248,7 @@ def test_the_benchmarked_paths_and_the_seams_are_bound():
     src = open(SHIM).read()
     body = src[src.index("function Crux.value_training(𝒮::Crux.OffPolicySolver, 𝒟::HipBuffer, γ"):]
     body = body[:body.index("\nend\n")]
-    assert "crux_dqn_epochs_async" in body and "crux_sac_epochs_async" in body and "dqn_epoch!(" not in body and "sac_epoch!(" not in body
+    assert "crux_dqn_value_training_async" in body and "crux_sac_epochs_async" in body and "dqn_epoch!(" not in body and "sac_epoch!(" not in body
 
 
 def test_the_shim_parses_as_balanced_julia():
