@@ -70,8 +70,9 @@ struct JlFrame { int64_t a, b; float v1; int st; };
 __device__ __forceinline__ float jlw_term(float x, bool centred, float m) { if (!centred) return x; const float d = __fsub_rn(x, m); return __fmul_rn(d, d); }
 __device__ float jlw_reduce(const float* __restrict__ v, int64_t n, bool centred, float m, int32_t* leaf_lo, float* leaf_sum, int* n_leaf) {      // leaves are contiguous: leaf q = [leaf_lo[q], leaf_lo[q + 1])
   const int tid = threadIdx.x;
+  __shared__ JlFrame stk[48];      // the recursion stack of thread 0 (its only user): LDS, not 1 152 bytes of private memory per thread of the launch
   if (tid == 0) {      // the leaves of mapreduce_impl(f, +, A, 1, n, 1024) in the order the recursion visits them
-    JlFrame stk[48]; int sp = 0, nl = 0; stk[sp++] = JlFrame{0, n - 1, 0.f, 0};
+    int sp = 0, nl = 0; stk[sp++] = JlFrame{0, n - 1, 0.f, 0};
     while (sp) { JlFrame f = stk[sp - 1];
       if (f.b - f.a < 1024) { leaf_lo[nl] = (int32_t)f.a; ++nl; --sp; continue; }
       const int64_t mid = f.a + ((f.b - f.a) >> 1);
@@ -94,7 +95,7 @@ __device__ float jlw_reduce(const float* __restrict__ v, int64_t n, bool centred
   __syncthreads();
   __shared__ float result;
   if (tid == 0) {      // op(v1, v2) up the same tree
-    JlFrame stk[48]; int sp = 0, nx = 0; float ret = 0.f; stk[sp++] = JlFrame{0, n - 1, 0.f, 0};
+    int sp = 0, nx = 0; float ret = 0.f; stk[sp++] = JlFrame{0, n - 1, 0.f, 0};
     while (sp) { JlFrame f = stk[sp - 1];
       if (f.b - f.a < 1024) { ret = leaf_sum[nx++]; --sp; continue; }
       const int64_t mid = f.a + ((f.b - f.a) >> 1);

@@ -213,9 +213,12 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     }
     if (a.ord_all) order_cur = const_cast<int32_t*>(a.ord_all) + (size_t)ep * (size_t)a.len;   // shuffle orders composed ahead of time by k_compose_order
     else {   // shuffle!(D) as an index composition (experience_buffer.jl:118-124)
-      if (a.perms) { for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[a.perms[(int64_t)ep * a.len + j]]; }
+      // (the thread index is laundered: from the plain `tid` the compiler hoists the 64-bit element addresses of this once-per-epoch loop out of the epoch loop and keeps them
+      //  alive across the whole launch -- in scratch, in the forms that sit at the 256-register limit: the two spilled dwords of the C5 periodic form, round 6)
+      int tidl = tid; asm volatile("" : "+v"(tidl));
+      if (a.perms) { for (int64_t j = tidl; j < a.len; j += NT) order_nxt[j] = order_cur[a.perms[(int64_t)ep * a.len + j]]; }
       else { const crux_perm pp = crux_perm_make(a.shuffle_seed, a.shuffle_counter + (uint64_t)ep, 0, (uint32_t)a.len);
-        for (int64_t j = tid; j < a.len; j += NT) order_nxt[j] = order_cur[crux_perm_at(&pp, (uint32_t)j)]; }
+        for (int64_t j = tidl; j < a.len; j += NT) order_nxt[j] = order_cur[crux_perm_at(&pp, (uint32_t)j)]; }
       __syncthreads();
       int32_t* tq = order_cur; order_cur = order_nxt; order_nxt = tq;
     }
