@@ -290,6 +290,7 @@ def test_fs2_replica_group_nan_step(gpu_ctx, monkeypatch, form, k):
             assert not np.isnan(st[0][0]).any() and float(st[0][3][0]) == pytest.approx(0.9 ** 3)      # two clean steps taken: beta1^(t+1) with t = 2
         else:
             assert errs[0] is not None and errs[0].code == L.EHIP
+            assert "NaN step" in str(errs[0]) and ctxs[0].peer_abort_reason()[0] == 5      # the peer learns WHY the group ended (round 6: it used to read "did not answer")
             assert not np.isnan(st[1][0]).any() and float(st[1][3][0]) == pytest.approx(0.9 ** 3)
     finally:
         for c in ctxs:
