@@ -368,6 +368,28 @@ def test_asynchronous_solve_loop_equals_the_synchronous_one(gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_asynchronous_softq_solve_loop_equals_the_synchronous_one(gpu_ctx):
+    """the same for SoftQ (rl/softq.jl:31-58): the asynchronous loop goes through crux_dqn_value_training_async with softq_alpha > 0 -- softq_target in the chain and the target
+    update of off_policy.jl:108 riding in its last phase (round 6) -- the synchronous one through crux_softq_epochs followed by a stand-alone polyak_average!: same ring, same
+    networks, same target networks and infos, bit for bit."""
+    def run(asyn):
+        S = crux.ContinuousSpace(8)
+        q = crux.DiscreteNetwork(parity.chain([8, 128, 128, 4], ["relu", "relu", "identity"]), [1, 2, 3, 4], seed=4)
+        mdp = crux.SynthMDP(8, 4, discrete=True, n_envs=1, seed=6, discount=0.97)
+        sv = crux.SoftQ(q, S, N=700, dN=4, buffer_size=512, buffer_init=300, max_steps=40, alpha=0.5, c_opt={"batch_size": 128})
+        sv.async_training = asyn
+        crux.solve(sv, mdp)
+        assert (len(sv._pending) == 0) and all(h is not None for h in sv._history)
+        if asyn:
+            assert getattr(sv, "_async_unsupported", False) is False          # it really took the asynchronous chains
+        return q.get_params(), sv.agent.pi_minus.get_params(), sv.buffer["s"], np.array([[h["critic_loss"], h["critic_grad_norm"], h["Qavg"]] for h in sv.history])
+    a, b = run(True), run(False)
+    assert len(a[3]) == len(b[3]) >= 90
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["cartpole", "synth17"])
 def test_lagrange_loss_on_the_feature_split_kernel_at_rollout_size(gpu_ctx, kind):
     """lagrange_ppo_loss inside k_train_fs<..., LAG> on a 16 x 1024 rollout, minibatches of 128: 128 (relu CartPole actor, one epoch) / 256 (tanh 17-64-64-6 actor, two
