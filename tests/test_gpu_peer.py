@@ -192,7 +192,7 @@ def test_the_launch_budget_ends_a_group_whose_peer_is_slow(two_contexts):
         return f
     errs = RG.run_threads([make(0, 0.0), make(1, 1.0)], seconds=30.0)
     print("budget: replica 0 after %.2f s: %s | replica 1 after %.2f s: %s" % (secs[0], errs[0], secs[1], errs[1]))
-    assert errs[0] is not None and errs[0].code == L.EHIP and "budget" in str(errs[0]) and 0.25 < secs[0] < 0.9
+    assert errs[0] is not None and errs[0].code == L.EHIP and "budget" in str(errs[0]) and 0.25 < secs[0] < 2.0      # (300 ms of waiting + the call's own setup; measured 0.30 s)
     assert errs[1] is not None and errs[1].code == L.EHIP and secs[1] < 5.0          # told by replica 0's abort word: it does not wait for its own timeout
     assert ctxs[1].peer_abort_reason()[0] == 2
 
@@ -209,7 +209,7 @@ def test_the_rendezvous_probe(two_contexts):
     _run_threads([make(0), make(1)])
     print("rendezvous probe, us [first round, slowest later round] x 2 streams:", res)
     for r in range(2):
-        assert max(res[r][1], res[r][3]) < 250.0, res
+        assert max(res[r][1], res[r][3]) < 1000.0, res          # measured 0.8-1.0 us; time-sliced queues answer after 20 000-50 000 us
     t0 = time.time()
     with pytest.raises(crux.CruxError) as e:
         ctxs[0].peer_probe(rounds=16, first_bound_ms=100, round_bound_ms=20)
