@@ -27,8 +27,89 @@ __global__ __launch_bounds__(256) void k_mlp_forward_multi(NetDesc nd, const cru
   const crux_fwd_job j = jobs[blockIdx.y];
   mlp_forward_body(nd, j.p, j.x, B, j.y);
 }
+// ---- value(pi, x) for IN -> 64 -> 64 -> OUT chains at large batches on the matrix pipes (round 6) -------------------------------------------------------------------
+// fill_gae! evaluates the critic on every s and sp of the buffer (sampler.jl:264-266: 2 x 65 536 rows per PPO iteration; x 128 learners in a population run, where the scalar
+// kernel above took 16 of an iteration's 472 ms). One WAVE per 16-sample tile, the three layers as v_mfma_f32_16x16x4_f32 chains with the weights of all layers in registers
+// for the whole launch; instruction ks of a layer carries k = 4 ks + (lane group) -- ASCENDING k, the order of the scalar loop above, and the MFMA is a sequential fma chain
+// over its four k slices (tools/mfma_chain_test.hip) -- then `acc + b`, then the activation through the same crux_act: the results are the scalar kernel's BIT FOR BIT
+// (tests/test_gpu_components.py compares under CRUX_FORCE_GENERIC=1). Activations pass from one layer's D layout [feature 4g + r][sample c] to the next layer's B layout
+// [k = 4 ks + g][sample c] through a per-wave LDS tile.
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+#define FWH_LD 17
+__device__ __forceinline__ void mlp_forward_h64_run(const NetDesc& nd, const float* __restrict__ p, const float* __restrict__ x, int64_t B, float* __restrict__ y, float* tile,
+                                                    const int64_t wave0, const int64_t n_waves) {
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int in0 = nd.dims[0], out3 = nd.dims[3], ks0 = (in0 + 3) >> 2;
+  const float* W1 = p + nd.woff[0]; const float* W2 = p + nd.woff[1]; const float* W3 = p + nd.woff[2];
+  float w1f[4][8], w2f[4][16], w3f[16]; f32x4_ b1v[4], b2v[4], b3v;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { const int k = 4 * ks + g; w1f[m][ks] = (ks < ks0 && k < in0) ? W1[16 * m + c + 64 * k] : 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) w2f[m][ks] = W2[16 * m + c + 64 * (4 * ks + g)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { b1v[m][r] = p[nd.boff[0] + 16 * m + 4 * g + r]; b2v[m][r] = p[nd.boff[1] + 16 * m + 4 * g + r]; } }
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) w3f[ks] = c < out3 ? W3[c + out3 * (4 * ks + g)] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b3v[r] = 4 * g + r < out3 ? p[nd.boff[2] + 4 * g + r] : 0.f;
+  const int a1 = nd.acts[0], a2 = nd.acts[1], a3 = nd.acts[2];
+  const int64_t n_tiles = (B + 15) >> 4;
+  for (int64_t t = wave0; t < n_tiles; t += n_waves) {
+    const int64_t s = 16 * t + c; const bool vs = s < B; const int64_t sc = vs ? s : B - 1;
+    float xB[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { const int k = 4 * ks + g; xB[ks] = (ks < ks0 && k < in0) ? x[sc * in0 + k] : 0.f; }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { f32x4_ acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) if (ks < ks0) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[m][ks], xB[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(16 * m + 4 * g + r) * FWH_LD + c] = crux_act(a1, acc[r] + b1v[m][r]); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    float hB[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) hB[ks] = tile[(4 * ks + g) * FWH_LD + c];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { f32x4_ acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[m][ks], hB[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(16 * m + 4 * g + r) * FWH_LD + c] = crux_act(a2, acc[r] + b2v[m][r]); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) hB[ks] = tile[(4 * ks + g) * FWH_LD + c];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    f32x4_ acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w3f[ks], hB[ks], acc, 0, 0, 0);
+    if (vs) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int o = 4 * g + r; if (o < out3) y[s * out3 + o] = crux_act(a3, acc[r] + b3v[r]); } }
+  }
+}
+static inline bool fwd_h64_ok(const NetDesc& nd, int64_t B) {
+  return nd.L == 3 && nd.dims[1] == 64 && nd.dims[2] == 64 && nd.dims[0] >= 1 && nd.dims[0] <= 32 && nd.dims[3] >= 1 && nd.dims[3] <= 16 && B >= 1024 && !crux_sw().force_generic;
+}
+__global__ __launch_bounds__(256) void k_mlp_forward_h64(NetDesc nd, const float* __restrict__ p, const float* __restrict__ x, int64_t B, float* __restrict__ y) {
+  __shared__ float tiles[4][64 * FWH_LD];
+  mlp_forward_h64_run(nd, p, x, B, y, tiles[threadIdx.x >> 6], (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), (int64_t)gridDim.x * 4);
+}
+__global__ __launch_bounds__(256) void k_mlp_forward_h64_multi(NetDesc nd, const crux_fwd_job* __restrict__ jobs, int64_t B) {
+  __shared__ float tiles[4][64 * FWH_LD];
+  const crux_fwd_job j = jobs[blockIdx.y];
+  mlp_forward_h64_run(nd, j.p, j.x, B, j.y, tiles[threadIdx.x >> 6], (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), (int64_t)gridDim.x * 4);
+}
+static inline unsigned fwd_h64_blocks(int64_t B, int n_jobs) {      // 4 tiles (waves) per block; a few tiles per wave so that the register-resident weights are loaded once per ~8 tiles
+  const int64_t tiles = (B + 15) >> 4; int64_t nb = (tiles + 31) / 32; const int64_t cap = n_jobs > 1 ? 64 : 1024; if (nb > cap) nb = cap; if (nb < 1) nb = 1; return (unsigned)nb;
+}
 int32_t crux_mlp_forward_multi_impl(crux_ctx* c, const NetDesc& nd, const crux_fwd_job* d_jobs, int n_jobs, int64_t B) {
   if (n_jobs < 1 || B < 1) return CRUX_OK;
+  if (fwd_h64_ok(nd, B)) {
+    hipLaunchKernelGGL(k_mlp_forward_h64_multi, dim3(fwd_h64_blocks(B, n_jobs), (unsigned)n_jobs), dim3(256), 0, c->stream, nd, d_jobs, B);
+    return crux_launch_check(c, "k_mlp_forward_h64_multi"); }
   const size_t lds = sizeof(float) * 2 * (size_t)nd.maxdim * FWD_TS;
   if (lds > 65536) return crux_fail(c, CRUX_EUNSUP, "mlp_forward: layer width %d exceeds the generic kernel's LDS tile", nd.maxdim);
   int64_t nb = (B + FWD_TS - 1) / FWD_TS; if (nb > 4096) nb = 4096;
@@ -217,6 +298,9 @@ int32_t crux_mlp_forward_impl(crux_mlp* n, const float* d_x, int64_t B, float* d
   if (B == 0) return CRUX_OK;
   crux_ctx* c = n->ctx;
   if (n->nd.L < 1) return crux_fail(c, CRUX_EINVAL, "mlp_forward: the handle is a bare parameter vector (n_layers = 0)");
+  if (fwd_h64_ok(n->nd, B)) {      // the 64-wide family at large batches (fill_gae!'s critic evaluations): the matrix pipes, same bits (above)
+    hipLaunchKernelGGL(k_mlp_forward_h64, dim3(fwd_h64_blocks(B, 1)), dim3(256), 0, c->stream, n->nd, params_override ? params_override : n->p, d_x, B, d_y);
+    return crux_launch_check(c, "k_mlp_forward_h64"); }
   const size_t lds = sizeof(float) * 2 * (size_t)n->nd.maxdim * FWD_TS;
   if (lds > 65536) return crux_fail(c, CRUX_EUNSUP, "mlp_forward: layer width %d exceeds the generic kernel's LDS tile", n->nd.maxdim);
   int64_t nb = (B + FWD_TS - 1) / FWD_TS; if (nb > 4096) nb = 4096;

@@ -26,6 +26,28 @@ def test_mlp_init_and_forward_match_oracle(gpu_ctx, dims, acts):
     ps = g.params(); assert ps[0].shape == (dims[1], dims[0]) and ps[1].shape == (dims[1],)
 
 
+@pytest.mark.parametrize("dims,acts", [([4, 64, 64, 1], ["relu", "relu", "identity"]), ([17, 64, 64, 1], ["tanh", "tanh", "identity"]), ([3, 64, 64, 1], ["relu", "tanh", "identity"]),
+                                       ([8, 64, 64, 4], ["relu", "relu", "identity"]), ([27, 64, 64, 8], ["tanh", "tanh", "tanh"]), ([17, 64, 64, 6], ["tanh", "tanh", "identity"])])
+def test_matrix_pipe_forward_is_the_scalar_forward_bit_for_bit(gpu_ctx, monkeypatch, dims, acts):
+    """value(pi, x) of the IN-64-64-OUT family at large batches (fill_gae!'s critic evaluations, sampler.jl:264-266) runs on the matrix pipes (k_mlp_forward_h64, round 6): the MFMA
+    chains carry k in ascending order, the order of the scalar kernel's fma loop, so the two kernels must agree BIT FOR BIT -- ragged last tile, non-zero biases, every
+    activation pair -- and with the oracle to the forward tolerance."""
+    g, o = parity.make_pair(dims, acts, 19, 2)
+    rng = np.random.default_rng(7)
+    p = g.get_params(); p = (p + rng.normal(0, 0.05, p.size)).astype(np.float32); g.set_params(p); o.params[:] = p          # non-zero biases
+    B = 5003                                                                                                               # 312 full tiles + 11 samples
+    x = np.asfortranarray(rng.standard_normal((dims[0], B)).astype(np.float32))
+    y_mfma = g.forward(x)
+    monkeypatch.setenv("CRUX_FORCE_GENERIC", "1")
+    y_scalar = g.forward(x)
+    monkeypatch.delenv("CRUX_FORCE_GENERIC")
+    assert y_mfma.shape == (dims[-1], B) and np.array_equal(y_mfma.view(np.uint32), y_scalar.view(np.uint32))
+    yo = o.forward(x)
+    assert np.abs(y_mfma - yo).max() <= 1e-5 * max(1.0, np.abs(yo).max())
+    small = g.forward(x[:, :301])                                                                                          # below the batch threshold: the scalar kernel itself
+    assert np.array_equal(small.view(np.uint32), y_mfma[:, :301].view(np.uint32))
+
+
 def test_polyak_and_copy_are_bit_exact(gpu_ctx):
     g1, o1 = parity.make_pair([3, 16, 1], ["relu", "identity"], 1, 0); g2, o2 = parity.make_pair([3, 16, 1], ["relu", "identity"], 2, 0)
     crux.polyak_average_(g1, g2, 0.005); O.chk(O.lib().orc_polyak(o1.h, o2.h, 0.005))
