@@ -110,11 +110,11 @@ int32_t crux_buffer_apply_order(crux_buffer* b, const int32_t* d_order, int64_t 
 struct ApplyPtrs { void* col[CRUX_NCOLS]; void* tmp; const int32_t* order; };
 template <typename T>
 __global__ void k_apply_order_multi(const ApplyPtrs* __restrict__ P, int k, int64_t n, int32_t re, int back) {
-  const ApplyPtrs p = P[blockIdx.y]; if (!p.order) return;
+  const ApplyPtrs& p = P[blockIdx.y]; const int32_t* __restrict__ order = p.order; if (!order) return;      // (fields read in place: a private copy of the struct, indexed by k, lived in scratch)
   T* col = (T*)p.col[k]; T* tmp = (T*)p.tmp; const int64_t total = n * re;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     if (back) col[t] = tmp[t];
-    else { const int64_t j = t / re; const int32_t e = (int32_t)(t - j * re); tmp[t] = col[(int64_t)p.order[j] * re + e]; }
+    else { const int64_t j = t / re; const int32_t e = (int32_t)(t - j * re); tmp[t] = col[(int64_t)order[j] * re + e]; }
   }
 }
 int32_t crux_buffer_apply_order_multi(int32_t n, crux_buffer* const* bufs, const int32_t* const* d_orders) {

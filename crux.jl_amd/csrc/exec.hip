@@ -171,6 +171,11 @@ template <> __device__ __forceinline__ void exec_dispatch_k<GatherRingAllOp>(con
   using P = OpPack<GatherRingAllOp>; const P* pp = (const P*)op->args;
   GatherRingAllOp::run_ptr(bid, op->nblocks, &pp->head, pp->tail.head, pp->tail.tail.head, pp->tail.tail.tail.head, pp->tail.tail.tail.tail.head);
 }
+// the same for the fused prioritized search + gather (its arguments carry the same table: taking the address of a by-value copy put 176 bytes of every thread into scratch,
+// on the one phase of a C3 epoch that is a chain of dependent memory round trips; round 6)
+template <> __device__ __forceinline__ void exec_dispatch_k<PerSampleGatherOp>(const KOp* op, unsigned bid) {
+  PerSampleGatherOp::run_ptr(bid, op->nblocks, &((const OpPack<PerSampleGatherOp>*)op->args)->head);
+}
 template <int BYTES, int EXEC_HEAVY>
 __global__ __launch_bounds__(256) void k_phase_k(PhaseK<BYTES> by_value) {
   // read through the kernel-argument segment pointer, not through the by-value parameter: indexing the parameter at a run-time offset would make the compiler

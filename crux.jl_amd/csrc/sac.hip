@@ -140,18 +140,27 @@ __global__ void k_td_info(const double* __restrict__ st, const double* __restric
 // sums, combined in block order by the last block to arrive (deterministic: the combine order is fixed, only who performs it varies)
 // Layer-0 gradient entries a fused pullback left as quarter partials (Sumsq2Fix, common.h): element i of flat gradient `slot` is formed here -- the additions Gemm16's
 // split-K combine would have done, in its order -- and stored, by the one thread that sums its square.
-__device__ __forceinline__ float ssq_elem(float* g, int64_t i, const Sumsq2Fix& fx, int slot) {
-  const float* part = fx.part[slot];
+// one slot of a Sumsq2Fix as scalars, picked with selects: indexing the struct's two-element arrays with a run-time slot put the whole struct into private memory (64 B of scratch
+// per thread in every phase kernel, read back per gradient element by AdamSelfOp; round 6)
+struct Sumsq2Slot { const float* part; int32_t out1, in0, woff, boff; float scale; };
+__device__ __forceinline__ Sumsq2Slot ssq_slot(const Sumsq2Fix& fx, int slot) {      // (device side: compile-time slots only -- Sumsq2Op's 0 and 1)
+  Sumsq2Slot s; const bool z = slot == 0;
+  s.part = z ? fx.part[0] : fx.part[1]; s.out1 = z ? fx.out1[0] : fx.out1[1]; s.in0 = z ? fx.in0[0] : fx.in0[1]; s.woff = z ? fx.woff[0] : fx.woff[1]; s.boff = z ? fx.boff[0] : fx.boff[1];
+  s.scale = z ? fx.scale[0] : fx.scale[1]; return s;
+}
+__device__ __forceinline__ float ssq_elem(float* g, int64_t i, const Sumsq2Slot& fs) {
+  const float* part = fs.part;
   if (!part) return g[i];
-  const int out1 = fx.out1[slot], in0 = fx.in0[slot], ps = in0 + 4; const int64_t w0 = fx.woff[slot], b0 = fx.boff[slot], qs = (int64_t)out1 * ps;
+  const int out1 = fs.out1, in0 = fs.in0, ps = in0 + 4; const int64_t w0 = fs.woff, b0 = fs.boff, qs = (int64_t)out1 * ps;
   if (i >= w0 && i < w0 + (int64_t)out1 * in0) { const int64_t e = i - w0; const int f = (int)(e % out1), qc = (int)(e / out1); const float* p = part + (int64_t)f * ps + qc;
-    const float v = (((p[0] + p[qs]) + p[2 * qs]) + p[3 * qs]) * fx.scale[slot]; g[i] = v; return v; }
+    const float v = (((p[0] + p[qs]) + p[2 * qs]) + p[3 * qs]) * fs.scale; g[i] = v; return v; }
   if (i >= b0 && i < b0 + out1) { const int f = (int)(i - b0); const float* p = part + (int64_t)f * ps + in0; float R[4];
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) R[gg] = ((p[gg] + p[qs + gg]) + p[2 * qs + gg]) + p[3 * qs + gg];
-    const float v = fx.scale[slot] * ((R[0] + R[1]) + (R[2] + R[3])); g[i] = v; return v; }
+    const float v = fs.scale * ((R[0] + R[1]) + (R[2] + R[3])); g[i] = v; return v; }
   return g[i];
 }
+__device__ __forceinline__ float ssq_elem(float* g, int64_t i, const Sumsq2Fix& fx, int slot) { return ssq_elem(g, i, ssq_slot(fx, slot)); }
 struct Sumsq2Op { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, float* __restrict__ g1, int64_t n1, float* __restrict__ g2, int64_t n2, double* __restrict__ out /* [1..64] per-block partials; [0] is filled by ssq_finalize */, Sumsq2Fix fx) {
   __shared__ double red[4];
   double s = 0;
@@ -252,28 +261,30 @@ struct AdamAdvanceOp { static __device__ __forceinline__ void run(const unsigned
 // in the flags[1] case only, on the deferred sums themselves, which every block then forms and inspects; so the update needs no reduced norm and can run beside Sumsq2Op
 // (which still forms the norm for the info row) instead of one dependent launch after it. Deferred layer-0 entries are formed here as Sumsq2Op forms them (ssq_elem: the same
 // additions; both store the same value).
-__device__ __forceinline__ bool adam_self_bad(const int32_t* __restrict__ flags, const Sumsq2Fix& fx, int slot) {
+__device__ __forceinline__ bool adam_self_bad(const int32_t* __restrict__ flags, const Sumsq2Slot& fs) {
   bool bad = flags[0] != 0;
-  if (flags[1] != 0 && fx.part[slot]) {      // rare: look at the sums
-    const int out1 = fx.out1[slot], in0 = fx.in0[slot], ps = in0 + 4; const int64_t qs = (int64_t)out1 * ps; const float* part = fx.part[slot]; bool b_ = false;
+  if (flags[1] != 0 && fs.part) {      // rare: look at the sums
+    const int out1 = fs.out1, in0 = fs.in0, ps = in0 + 4; const int64_t qs = (int64_t)out1 * ps; const float* part = fs.part; bool b_ = false;
     for (int64_t e = threadIdx.x; e < (int64_t)out1 * in0; e += blockDim.x) { const int f = (int)(e % out1), qc = (int)(e / out1); const float* p = part + (int64_t)f * ps + qc;
-      const float v = (((p[0] + p[qs]) + p[2 * qs]) + p[3 * qs]) * fx.scale[slot]; b_ = b_ || v != v; }
+      const float v = (((p[0] + p[qs]) + p[2 * qs]) + p[3 * qs]) * fs.scale; b_ = b_ || v != v; }
     for (int f = threadIdx.x; f < out1; f += blockDim.x) { const float* p = part + (int64_t)f * ps + in0; float R[4];
 #pragma unroll
       for (int gg = 0; gg < 4; ++gg) R[gg] = ((p[gg] + p[qs + gg]) + p[2 * qs + gg]) + p[3 * qs + gg];
-      const float v = fx.scale[slot] * ((R[0] + R[1]) + (R[2] + R[3])); b_ = b_ || v != v; }
+      const float v = fs.scale * ((R[0] + R[1]) + (R[2] + R[3])); b_ = b_ || v != v; }
     bad = __syncthreads_or(b_ ? 1 : 0) != 0 || bad;
   }
   return bad;
 }
 struct AdamSelfOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, const double* __restrict__ bp,
-                                                   double eta, double b1, double b2, double eps, int64_t n, const int32_t* __restrict__ flags, int32_t* __restrict__ status, Sumsq2Fix fx, int slot) {
-  const bool bad = adam_self_bad(flags, fx, slot);
+                                                   double eta, double b1, double b2, double eps, int64_t n, const int32_t* __restrict__ flags, int32_t* __restrict__ status, Sumsq2Slot fs) {
+  // (the slot of the Sumsq2Fix is resolved by the HOST when the op is recorded: a run-time index into the struct's two-element arrays -- and even a select between their
+  //  elements, which the compiler turns back into an indexed load -- put the whole argument pack into private memory, 176 bytes per thread of every phase kernel; round 6)
+  const bool bad = adam_self_bad(flags, fs);
   if (status[0] == CRUX_ENAN) return;      // an earlier step of this launch sequence already stopped with "NaN detected!" (training.jl:20)
   if (bad) { if (bid_ == 0 && threadIdx.x == 0) status[0] = CRUX_ENAN; return; }
   const double c1 = 1.0 - bp[0], c2 = 1.0 - bp[1];
   for (int64_t i = (int64_t)bid_ * blockDim.x + threadIdx.x; i < n; i += (int64_t)nb_ * blockDim.x) {
-    const double gd = (double)ssq_elem(g, i, fx, slot);
+    const double gd = (double)ssq_elem(g, i, fs);
     const float mi = (float)(b1 * (double)m[i] + (1.0 - b1) * gd);
     const float vi = (float)(b2 * (double)v[i] + ((1.0 - b2) * gd) * gd);
     const float d = (float)((double)mi / c1 / (sqrt((double)vi / c2) + eps) * eta);
@@ -281,8 +292,8 @@ struct AdamSelfOp { static __device__ __forceinline__ void run(const unsigned bi
   }
 } };
 // the beta powers advance one phase later (every block of AdamSelfOp has used them), on the same evidence
-struct AdamAdvanceSelfOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, double* __restrict__ bp, double b1, double b2, const int32_t* __restrict__ flags, Sumsq2Fix fx, int slot) {
-  const bool bad = adam_self_bad(flags, fx, slot);
+struct AdamAdvanceSelfOp { static __device__ __forceinline__ void run(const unsigned bid_, const unsigned nb_, double* __restrict__ bp, double b1, double b2, const int32_t* __restrict__ flags, Sumsq2Slot fs) {
+  const bool bad = adam_self_bad(flags, fs);
   if (bid_ == 0 && threadIdx.x == 0 && !bad) { bp[0] *= b1; bp[1] *= b2; }
 } };
 static int32_t adam_self(crux_mlp* n, const int32_t* d_flags, int32_t* d_status, const Sumsq2Fix& fx, int slot) {      // recorded sequences only
@@ -290,8 +301,9 @@ static int32_t adam_self(crux_mlp* n, const int32_t* d_flags, int32_t* d_status,
   if (!n->has_adam) return crux_fail(c, CRUX_EINVAL, "train!: crux_adam_init was not called on this handle");
   if (!crux_exec_recording(c)) return crux_fail(c, CRUX_EHIP, "adam_self: outside a recording");
   const int64_t cnt = n->nd.n_params; const unsigned nbk = (unsigned)((cnt + 255) / 256);
-  crux_exec_push<AdamSelfOp, OP_ADAM_SELF>(c, nbk < 64u ? nbk : 64u, n->p, n->g, n->m, n->v, (const double*)n->bp, n->eta, n->b1, n->b2, n->eps, cnt, d_flags, d_status, fx, slot);
-  crux_exec_push<AdamAdvanceSelfOp, OP_ADAM_ADVANCE_SELF>(c, 1u, n->bp, n->b1, n->b2, d_flags, fx, slot);
+  const Sumsq2Slot fs{fx.part[slot], fx.out1[slot], fx.in0[slot], fx.woff[slot], fx.boff[slot], fx.scale[slot]};
+  crux_exec_push<AdamSelfOp, OP_ADAM_SELF>(c, nbk < 64u ? nbk : 64u, n->p, n->g, n->m, n->v, (const double*)n->bp, n->eta, n->b1, n->b2, n->eps, cnt, d_flags, d_status, fs);
+  crux_exec_push<AdamAdvanceSelfOp, OP_ADAM_ADVANCE_SELF>(c, 1u, n->bp, n->b1, n->b2, d_flags, fs);
   return CRUX_OK;
 }
 

@@ -10,6 +10,7 @@
 // Results are bit-identical to the call-by-call chain (tools/fused_check.py, tests/test_gpu_round4.py).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 struct TileSet { const float* A; const float* bias; const float* H; float* Z; };      // A: the layer's weights; H: its input [K x B]; Z: its output [M x B] or NULL
 #define TILE_PART_FLOATS(NS) (3 * (NS) * 64 * 4)
@@ -17,13 +18,15 @@ struct TileSet { const float* A; const float* bias; const float* H; float* Z; };
 // On return wave 0 holds z[n][r] = row 4 g + r, sample j0 + c (bias added when given); the other waves hold garbage. Contains one __syncthreads.
 struct TileNoHook { __device__ __forceinline__ void operator()() const {} };
 // `between`: work of the caller that does not depend on the tile (random draws), placed between the issue of the loads and their first use
+// (the loops over the NS tile sets are compile-time recursions: with `#pragma unroll` the epilogue loop of the NS = 4 instance stayed a loop over a switch, its `s[n]` a
+//  run-time index, and the caller's whole argument struct went to private memory -- 176 bytes of scratch per thread in every phase kernel; round 6)
+template <int I, int N, class Fn> __device__ __forceinline__ void tile_static_for(Fn&& fn) { if constexpr (I < N) { fn(std::integral_constant<int, I>{}); tile_static_for<I + 1, N>(fn); } }
 template <int NS, bool AK, class F = TileNoHook> __device__ __forceinline__ void tile_splitk(const TileSet (&s)[NS], int M, int K, int B, int j0, float* part, f32x4 (&z)[NS], F between = F()) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int kper = K >> 2, ng = kper >> 4;                    // K in {128, 192, 256}: Gemm16's quarter = K / 4, 2..4 sixteen-groups
   const int jc = (j0 + c < B) ? j0 + c : B - 1; const int ic = c < M ? c : 0; const float mrow = c < M ? 1.f : 0.f;
   float a[NS][4][4]; f32x4 b[NS][4];
-#pragma unroll
-  for (int n = 0; n < NS; ++n)
+  tile_static_for<0, NS>([&](auto nc) { constexpr int n = decltype(nc)::value;
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int k16 = wv * kper + 16 * (u < ng ? u : 0) + 4 * g;      // (groups past the quarter re-read group 0 and are never used)
       b[n][u] = *(const f32x4*)(s[n].H + k16 + (int64_t)K * jc);
@@ -32,22 +35,19 @@ template <int NS, bool AK, class F = TileNoHook> __device__ __forceinline__ void
         for (int r = 0; r < 4; ++r) a[n][u][r] = t[r] * mrow; }
       else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[n][u][r] = s[n].A[ic + (int64_t)M * (k16 + r)] * mrow; } }
+        for (int r = 0; r < 4; ++r) a[n][u][r] = s[n].A[ic + (int64_t)M * (k16 + r)] * mrow; } } });
   between();
-#pragma unroll
-  for (int n = 0; n < NS; ++n) { f32x4 pa = {0.f, 0.f, 0.f, 0.f};
+  tile_static_for<0, NS>([&](auto nc) { constexpr int n = decltype(nc)::value; f32x4 pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 4; ++u) { if (u < ng) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) pa = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n][u][r], b[n][u][r], pa, 0, 0, 0); } }
-    z[n] = pa; }
+    z[n] = pa; });
   if (wv > 0) {
-#pragma unroll
-    for (int n = 0; n < NS; ++n) *(f32x4*)(part + (((wv - 1) * NS + n) * 64 + lane) * 4) = z[n]; }
+    tile_static_for<0, NS>([&](auto nc) { constexpr int n = decltype(nc)::value; *(f32x4*)(part + (((wv - 1) * NS + n) * 64 + lane) * 4) = z[n]; }); }
   __syncthreads();
   if (wv > 0) return;
-#pragma unroll
-  for (int n = 0; n < NS; ++n) {
+  tile_static_for<0, NS>([&](auto nc) { constexpr int n = decltype(nc)::value;
 #pragma unroll
     for (int w = 0; w < 3; ++w) { const f32x4 p = *(const f32x4*)(part + ((w * NS + n) * 64 + lane) * 4); z[n][0] += p[0]; z[n][1] += p[1]; z[n][2] += p[2]; z[n][3] += p[3]; }
     if (s[n].bias) {
@@ -55,7 +55,7 @@ template <int NS, bool AK, class F = TileNoHook> __device__ __forceinline__ void
       for (int r = 0; r < 4; ++r) { const int i = 4 * g + r; z[n][r] = z[n][r] + s[n].bias[i < M ? i : 0]; } }
     if (s[n].Z && j0 + c < B) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int i = 4 * g + r; if (i < M) s[n].Z[i + (int64_t)M * (j0 + c)] = z[n][r]; } } }
+      for (int r = 0; r < 4; ++r) { const int i = 4 * g + r; if (i < M) s[n].Z[i + (int64_t)M * (j0 + c)] = z[n][r]; } } });
 }
 
 // ---- the actor's output layer + exploration(pi::GaussianPolicy, s) for up to two independent draws from the same means --------------------------------
@@ -67,19 +67,28 @@ struct ActorExploreTileOp { static __device__ __forceinline__ void run(const uns
   const int64_t j = j0 + c; const bool mine = wv == 0 && g == 0 && j < q.B;      // ad <= 4: lane c of group 0 holds mu[0..ad) of sample j0 + c
   float epsv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   // the draws (Philox + Box-Muller in Float64: ~1 us) do not depend on the means: they are taken while the tile's operands are on their way
-  tile_splitk<1, false>(sets, q.ad, q.K, q.B, j0, df_lds, z, [&]() { if (mine) { for (int e = 0; e < q.n_cfg; ++e) for (int d = 0; d < q.ad; ++d) epsv[e][d] = sac_randn(q.seed, q.cfg[e].counter, (uint32_t)(j * q.ad + d)); } });
+  // (compile-time trip counts with predicates: run-time indices into q.cfg[], epsv[][] and z[0][] put the argument struct and the draws into private memory -- the 192 bytes of
+  //  scratch every phase kernel carried; round 6. n_cfg <= 2, ad <= 4: sac_tile_case)
+  tile_splitk<1, false>(sets, q.ad, q.K, q.B, j0, df_lds, z, [&]() { if (mine) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { const uint64_t ctr = e == 0 ? q.cfg[0].counter : q.cfg[1].counter;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) if (e < q.n_cfg && d < q.ad) epsv[e][d] = sac_randn(q.seed, ctr, (uint32_t)(j * q.ad + d)); } } });
   if (!mine) return;
-  for (int e = 0; e < q.n_cfg; ++e) { const ExploreCfg& x = q.cfg[e];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) { if (e >= q.n_cfg) continue;
+    float* const x_sa = e == 0 ? q.cfg[0].sa : q.cfg[1].sa; float* const x_lp = e == 0 ? q.cfg[0].lp : q.cfg[1].lp; float* const x_eps = e == 0 ? q.cfg[0].eps : q.cfg[1].eps;
     float acc = 0.f;
-    for (int d = 0; d < q.ad; ++d) {             // GaussExploreOp (sac.hip), the same expressions
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { if (d >= q.ad) continue;             // GaussExploreOp (sac.hip), the same expressions
       const float sg = expf(q.ls[d]); const float ep = epsv[e][d];
       const float m = z[0][d]; const float a = __fadd_rn(__fmul_rn(ep, sg), m);
       const float s2 = __fmul_rn(sg, sg), df = __fsub_rn(a, m);
       acc = __fadd_rn(acc, __fsub_rn(__fsub_rn(-(__fmul_rn(df, df)) / __fmul_rn(2.f, s2), 0.9189385332046727f), q.ls[d]));
-      if (x.sa) x.sa[j * (q.od + q.ad) + q.od + d] = a;
-      if (x.eps) x.eps[j * q.ad + d] = ep; }
-    if (x.sa) for (int k = 0; k < q.od; ++k) x.sa[j * (q.od + q.ad) + k] = q.s[j * q.od + k];
-    x.lp[j] = acc; }
+      if (x_sa) x_sa[j * (q.od + q.ad) + q.od + d] = a;
+      if (x_eps) x_eps[j * q.ad + d] = ep; }
+    if (x_sa) for (int k = 0; k < q.od; ++k) x_sa[j * (q.od + q.ad) + k] = q.s[j * q.od + k];
+    x_lp[j] = acc; }
 } };
 
 // ---- sac_target + the two heads of double_Q_loss ---------------------------------------------------------------------------------------------------------------------
