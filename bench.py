@@ -397,7 +397,7 @@ def run_selftest(crux, cdist, ctx, dist, torch, rank, world, local, args, P):
             res["identical_shards_max_abs_diff_vs_single_learner"] = float(np.abs(refs["ungrouped"] - mine).max())
             res["identical_shards_max_abs_diff_vs_group_of_one"] = float(np.abs(refs["group_of_one"] - mine).max())
             # (N = 2: g + g and the division by two are exact, so the group of one -- same kernel instantiation -- must be reproduced bit for bit; the un-grouped learner is another
-            #  instantiation of k_train_fs whose FMA contraction may differ in the last place. A lost, torn or stale slot read is orders larger than either.)
+            #  instantiation of k_train_fs2 (compiled without FMA contraction, so it too matches to the bit in practice). A lost, torn or stale slot read is orders larger than either.)
             res["identical_shards_bit_identical_to_group_of_one"] = bool(np.array_equal(refs["group_of_one"], mine))
             res["identical_shards_bit_identical_to_single_learner"] = bool(np.array_equal(refs["ungrouped"], mine))
             res["identical_shards_ok"] = bool((res["identical_shards_bit_identical_to_group_of_one"] if world == 2 else res["identical_shards_max_abs_diff_vs_group_of_one"] < 1e-5)

@@ -214,7 +214,7 @@ int32_t crux_peer_detach(crux_ctx* c) {
 // flag-wait histogram of the in-kernel exchange (diagnostics of a multi-GPU run): while enabled, lane 0 of each learner workgroup bins the time it waited for the
 // slowest peer's flag of every exchange, log2 of 10 ns ticks (bin b: [2^b, 2^(b+1)) x 10 ns). out: uint32 [2 learner streams][2 workgroups][32].
 // The periodic form of the replica group (local SGD / "sync_every"): between exchanges every replica takes k - 1 LOCAL Adam steps; after every k-th step the group
-// averages theta, m and v inside the persistent learner kernel (train_fs_kernel.h). k = 1 (default) is the exact form: the gradient is exchanged every minibatch.
+// averages theta, m and v inside the persistent learner kernel (train_fs2_kernel.h). k = 1 (default) is the exact form: the gradient is exchanged every minibatch.
 int32_t crux_peer_set_sync_every(crux_ctx* c, int32_t k) { if (!c) return CRUX_EINVAL; if (k < 1 || k > 65536) return crux_fail(c, CRUX_EINVAL, "peer_set_sync_every: k = %d", k); c->peer_every = k; return CRUX_OK; }
 int32_t crux_peer_sync_every(const crux_ctx* c) { return c ? c->peer_every : 1; }
 // how long a learner workgroup waits for a peer's flag of ONE exchange before it gives up: the launch then ends with CRUX_EHIP ("a replica of the group did not answer") and

@@ -33,8 +33,7 @@ struct crux_ctx {
   void* amulti[2] = {nullptr, nullptr}; size_t amulti_bytes[2] = {0, 0};   // argument blocks of the one-CU batched learner launch
   int learner_cus = 0;                 // 0 = automatic, 1 = one CU per learner (k_train_mfma<...,8,1>), 2 = two CUs (k_train_mfma<...,4,2>)
   void* xmulti[2] = {nullptr, nullptr}; size_t xmulti_bytes[2] = {0, 0};   // exchange areas + argument blocks of the batched multi-learner launch
-#define CRUX_XBUF_FLOATS (8 * 10240)    // exchange area of one learner stream: [parity 2][workgroups <= 4][slot <= 10240 floats; k_train_fs / x2: <= 8192], followed by 256 bytes of counters
-#define CRUX_FS_DEFAULT_WG 8           // form of the feature-split kernel (train_fs.hip; CRUX_FS_WG overrides): 2 = two CUs x 8 waves, 4 = four CUs x 4 waves, 8 = four CUs x (4 compute + 4 helper waves)
+#define CRUX_XBUF_FLOATS (8 * 10240)    // exchange area of one learner stream: [parity 2][workgroups <= 4][slot <= 10240 floats; x2: <= 8192], followed by 256 bytes of counters
   void* xbuf[2] = {nullptr, nullptr};   // gradient exchange areas of the two-CU learner kernel, one per learner stream
   // replica group with direct peer slots (comm.hip "peer"): every rank owns one fine-grained region that its peers write their minibatch
   // gradients into over xGMI; peer_ptr[r] is rank r's region as mapped here (own region for r == peer_rank)

@@ -1,5 +1,5 @@
 // peer_wait.h -- the bounded flag wait of the replica-group exchange (comm.hip "peer"), shared by every kernel that takes part in a group
-// (train_fs2_kernel.h, train_fs_kernel.h, train_mfma_kernel.h, train_dense.hip). SURVEY 8(e): the reference is single-process (src/model_free/on_policy.jl:80-109);
+// (train_fs2_kernel.h, train_mfma_kernel.h, train_dense.hip). SURVEY 8(e): the reference is single-process (src/model_free/on_policy.jl:80-109);
 // the exchange is this build's addition, so its failure modes are this build's to bound. A wait ends, besides on the flag it waits for, when
 //   1  the ONE exchange has waited longer than crux_peer_set_timeout_ms (a peer that is ABSENT);
 //   2  the waits of this LAUNCH add up to more than crux_peer_set_budget_ms (a peer that is SLOW: replicas whose hardware queues are time-sliced answer every exchange

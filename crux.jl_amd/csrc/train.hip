@@ -168,7 +168,7 @@ static int32_t ensure_pack(crux_ctx* c, crux_buffer* buf, hipStream_t st, TrainA
   return crux_launch_check(c, "k_pack_rows");
 }
 int32_t crux_train_dense_run(crux_ctx* c, TrainArgs& a, hipStream_t strm = nullptr, int which = 0);
-int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream, bool probe);      // train_fs.hip
+int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream, bool probe);      // train_fs2.hip
 static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_t stream = nullptr) {
   bool handled = false;
   if (!stream) stream = c->stream;
@@ -179,7 +179,7 @@ static int32_t launch_train(crux_ctx* c, TrainArgs& a, int prof_slot, hipStream_
   a.need_px = (crux_grouped(c) && a.apply && !a.ids) ? 1 : 0;
   a.px_timeout = c->peer_timeout_ticks;
   a.px_every = 1;
-  if (a.need_px && c->peer_every > 1) {      // periodic form: k_train_fs<..., PX> only, and only where every replica provably takes the same number of steps
+  if (a.need_px && c->peer_every > 1) {      // periodic form: k_train_fs2<..., PX, PXK> only, and only where every replica provably takes the same number of steps
     bool fs = false; int32_t prc = crux_train_fs_launch(c, a, &fs, stream, /*probe=*/true); if (prc) return prc;
     if (!fs) return crux_fail(c, CRUX_EUNSUP, "peer sync_every = %d: the periodic exchange lives in the register-resident learner kernels (IN-64-{64,32}-OUT, 64 < batch <= 128); this learner has the per-step gradient exchange only", c->peer_every);
     if (a.target_kl >= 0.f || a.max_batches > 0) return crux_fail(c, CRUX_EINVAL, "peer sync_every = %d: no KL early stopping / max_batches (the replicas' statistics are local between exchanges)", c->peer_every);

@@ -1,21 +1,24 @@
-// train_fs2.hip -- dispatch of the role-specialised form of the register-resident learner kernel (train_fs2_kernel.h: k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2>): the plain
-// policy-gradient / critic losses of full batch_train! loops (src/training.jl:28-55) on every IN->64->{64,32}->OUT shape k_train_fs serves, on four compute units of one XCD
-// with four compute + four helper waves each. Called by crux_train_fs_launch (train_fs.hip) for the launches that are neither lagrange_ppo_loss nor one of the explicitly
-// requested older forms (CRUX_FS_WG), replica groups included (PX / PXK instantiations; the 24- / 27-input shapes of a group stay on k_train_fs); CRUX_FS2=0 keeps k_train_fs.
+// train_fs2.hip -- dispatch of the feature-split, role-specialised learner kernel (train_fs2_kernel.h: k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING, PX, PXK, LAG>): full
+// batch_train! loops (src/training.jl:28-55) of the IN->64->{64,32}->OUT family with minibatches of 65..128 rows, on four compute units of one XCD with four compute + four
+// helper waves each -- the plain policy-gradient / critic losses, lagrange_ppo_loss (LAG) and the replica-group forms (PX / PXK) of every shape in the list below.
+// CRUX_FS=0 switches the kernel off (the sample-split two-CU kernel, or the dense engine for the 32-wide second layer, then run).
 #include "train_fs2_kernel.h"
 
-template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, bool TIMING, bool PX = false, bool PXK = false>
+template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2, bool TIMING, bool PX = false, bool PXK = false, bool LAG = false>
 static int32_t launch_fs2_form(crux_ctx* c, TrainArgs& a, hipStream_t stream) {
-  using Lt = Fs2Layout<IN, OUT, H2>;
+  using Lt = Fs2Layout<IN, OUT, H2, LAG>;
   constexpr size_t lds = sizeof(float) * (size_t)(PX && Lt::BK_FITS ? Lt::TOTAL_BK : Lt::TOTAL);
   static bool attr_dev[16] = {}; bool& attr = attr_dev[c->device & 15];
-  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING, PX, PXK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-  hipLaunchKernelGGL((k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING, PX, PXK>), dim3(32), dim3(512), lds, stream, a);
-  return crux_launch_check(c, PXK ? "k_train_fs2 (replica group, periodic form)" : PX ? "k_train_fs2 (replica group)" : "k_train_fs2");
+  if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING, PX, PXK, LAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL((k_train_fs2<IN, OUT, KIND, ACT, H2, ACT2, TIMING, PX, PXK, LAG>), dim3(32), dim3(512), lds, stream, a);
+  return crux_launch_check(c, PXK ? "k_train_fs2 (replica group, periodic form)" : PX ? "k_train_fs2 (replica group)" : LAG ? "k_train_fs2 (lagrange_ppo_loss)" : "k_train_fs2");
 }
-// the shapes whose replica-group forms (PX / PXK) are instantiated in the role-specialised kernel: every shape whose W2 backups fit into LDS beside the kernel's own
-// 113..132 KB (all but the 24- and 27-input ones, which spill without them and stay on k_train_fs)
-template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2> constexpr bool FS2_HAS_PX = IN < 24 && Fs2Layout<IN, OUT, H2>::BK_FITS;
+// the policy shapes lagrange_ppo_loss (ppo.jl:70-131) is instantiated for: C2's actor, the LunarLander-shaped one, Pendulum's and C5's
+template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2> constexpr bool FS2_HAS_LAG = KIND != MFK_VALUE && H2 == 64 && ACT2 == ACT &&
+  ((IN == 4 && OUT == 2 && ACT == CRUX_ACT_RELU) || (IN == 8 && OUT == 4 && ACT == CRUX_ACT_RELU) || (IN == 3 && OUT == 1 && ACT == CRUX_ACT_RELU) || (IN == 17 && OUT == 6 && ACT == CRUX_ACT_TANH));
+// replica-group forms (PX / PXK): every shape. Where the W2 backups fit into LDS beside the kernel's own 113..132 KB they live there; the 24- and 27-input shapes keep them in
+// registers (their periodic forms spill 2..61 registers, the per-step forms 0..4)
+template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2> constexpr bool FS2_HAS_PX = true;
 template <int IN, int OUT, int KIND, int ACT, int H2, int ACT2>
 static int32_t launch_fs2(crux_ctx* c, TrainArgs a, bool timing, hipStream_t stream) {
   const int which = stream == c->stream ? 0 : 1;
@@ -24,6 +27,8 @@ static int32_t launch_fs2(crux_ctx* c, TrainArgs a, bool timing, hipStream_t str
   a.xbuf = (float*)c->xbuf[which]; a.xctr = (unsigned*)((char*)c->xbuf[which] + sizeof(float) * xfloats);
   HIPCHK(c, hipMemsetAsync(c->xbuf[which], 0, sizeof(float) * xfloats + 256, stream));      // counters AND slots: the granules' step tags start from zero (a stale tag must never look like this launch's)
   a.xcd = which;      // actor / critic (the context's two learner streams) behind different L2s
+  if constexpr (FS2_HAS_LAG<IN, OUT, KIND, ACT, H2, ACT2>) { if (a.lag) return launch_fs2_form<IN, OUT, KIND, ACT, H2, ACT2, false, false, false, true>(c, a, stream); }
+  if (a.lag) return crux_fail(c, CRUX_EINVAL, "k_train_fs2: no lagrange instantiation for this shape");
   if constexpr (FS2_HAS_PX<IN, OUT, KIND, ACT, H2, ACT2>) if (crux_grouped(c) && a.need_px) {      // replica group: the in-kernel all-reduce over the peer slots (comm.hip)
     a.px_hist = c->peer_hist ? 1 : 0; a.px_n = c->peer_n; a.px_rank = c->peer_rank; a.px_tab = c->peer_tab + which * CRUX_PX_MAXR;
     if (a.px_every > 1) return launch_fs2_form<IN, OUT, KIND, ACT, H2, ACT2, false, true, true>(c, a, stream);      // periodic form: local Adam steps, theta / m / v averaged every k-th
@@ -49,11 +54,35 @@ static int32_t launch_fs2(crux_ctx* c, TrainArgs a, bool timing, hipStream_t str
   return launch_fs2_form<IN, OUT, KIND, ACT, H2, ACT2, false>(c, a, stream);
 }
 
-// the shape list of crux_train_fs_launch (train_fs.hip), which has already tested the call (full minibatch loops with Adam, 64 < batch <= 128, plain PG / critic loss, no group)
-int32_t crux_train_fs2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream, bool probe) {
+extern "C" int crux_x2_placement_ok(crux_ctx* c);      // train_mfma_x2.hip: workgroups i and i + 8 of a grid share an XCD (probed once per process)
+
+// Called first by crux_train_mfma_launch (train_mfma.hip): IN -> 64 -> {64, 32} -> OUT, identity output layer, full minibatch loops with Adam, the plain policy-gradient / critic
+// losses or lagrange_ppo_loss; replica groups take the PX / PXK instantiations.
+// probe: only answer whether this call would be taken (policy_gradient_training asks before it commits a pair of learners to the two learner streams)
+int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream, bool probe) {
   *handled = false;
+  if (crux_sw().fs == 0) return CRUX_OK;            // read per call: tests switch the form inside one process
+  if (c->learner_cus != 0 && !a.need_px) return CRUX_OK;      // crux_ctx_set_learner_cus(1 | 2): the caller asked for the one- / two-CU kernels (population runs)
   const NetDesc& nd = a.nd;
+  if (nd.L != 3 || nd.dims[1] != MF_HID || (nd.dims[2] != 64 && nd.dims[2] != 32) || nd.acts[2] != CRUX_ACT_IDENTITY) return CRUX_OK;
+  if (a.ids || !a.apply || a.bs <= 64 || a.bs > 128 || a.len < a.bs) return CRUX_OK;
+  int kind;
+  if (a.loss == CRUX_LOSS_VALUE_MSE) kind = MFK_VALUE;
+  else if (!CRUX_IS_PG(a.loss)) return CRUX_OK;
+  else if (a.head == CRUX_HEAD_CATEGORICAL) kind = MFK_CATEGORICAL;
+  else if (a.head == CRUX_HEAD_GAUSSIAN) kind = MFK_GAUSSIAN;
+  else return CRUX_OK;
+  if (!crux_x2_placement_ok(c)) return CRUX_OK;
+  // 32-bit loop control inside the kernel: buffers below 2^30 rows, launches below 2^31 steps (anything larger stays with the two-CU kernel / the dense-engine learner)
+  if (a.len >= (1ll << 30) || (long long)a.epochs * ((a.len + a.bs - 1) / a.bs) >= 0x7fffffffll) return CRUX_OK;
   const int in = nd.dims[0], h2 = nd.dims[2], out = nd.dims[3], act = nd.acts[0], act2 = nd.acts[1];
+  if (a.lag) {     // lagrange_ppo_loss (crux_batch_train_lagrange passes the PPO head with the controller attached): one replica, the shapes of FS2_HAS_LAG;
+                   // everything else stays with the two-CU kernel / the dense-engine learner
+    if (kind == MFK_VALUE || a.loss != CRUX_LOSS_PPO || (crux_grouped(c) && a.need_px) || h2 != 64 || act2 != act) return CRUX_OK;
+    const bool shape = (in == 4 && out == 2 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) || (in == 8 && out == 4 && kind == MFK_CATEGORICAL && act == CRUX_ACT_RELU) ||
+                       (in == 3 && out == 1 && kind == MFK_GAUSSIAN && act == CRUX_ACT_RELU) || (in == 17 && out == 6 && kind == MFK_GAUSSIAN && act == CRUX_ACT_TANH);
+    if (!shape) return CRUX_OK;
+  }
   const bool timing = crux_sw().mfma_timing;
   const bool grouped = crux_grouped(c) && a.need_px;
 #define FS2_CASE2(I, O, K, A1, H, A2) if (in == I && out == O && kind == K && act == A1 && h2 == H && act2 == A2) { if (grouped && !FS2_HAS_PX<I, O, K, A1, H, A2>) return CRUX_OK; \

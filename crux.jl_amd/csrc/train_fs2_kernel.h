@@ -1,7 +1,19 @@
-// train_fs2_kernel.h -- the persistent batch_train! kernel of the register-resident IN->64->{64,32}->OUT family, ROLE-SPECIALISED form (round 5; src/training.jl:13-55,
-// ppo.jl:4-21,59-60, Flux Adam). Same decomposition of a minibatch step over four compute units of one XCD as train_fs_kernel.h (feature-split wave pairs per 16-sample
-// tile, four helper waves per workgroup, every wave owning two 16x16 tiles of W2) and the same arithmetic in the same order -- parameters, Adam moments and statistics come out
-// bit-identical to k_train_fs --, but with two changes to how a step ends (40 % of a k_train_fs step is its tail, a chain of L2 round trips):
+// train_fs2_kernel.h -- the persistent batch_train! kernel of the register-resident IN->64->{64,32}->OUT family (src/training.jl:13-55, ppo.jl:4-21,59-60,70-131, Flux Adam):
+// FEATURE-SPLIT decomposition of a minibatch step over four compute units of one XCD, ROLE-SPECIALISED waves.
+//
+// The decomposition (round 3):
+//   * a 16-sample tile of the minibatch belongs to a PAIR of waves (t, h), h in {0, 1}: wave h computes the hidden features [32h, 32h + 32) of the second layer, of its
+//     gradient and of the first layer's gradient -- half of the 64x64 MFMA work (forward 32, dH1 32 instead of 64 each) and half of the per-feature VALU / LDS work of the
+//     tile. The first layer (IN <= 27 inputs: 4..28 MFMAs) is evaluated by both waves, so the second layer needs no exchange; the pair meets twice per step through LDS:
+//     the partial logits z (OUT values per sample) before the loss head, and the other half of dZ2 (A operand of dH1 = W2' dZ2) after it;
+//   * four workgroups (compute units of ONE XCD) share the 128 samples: 32 samples = 2 tiles = 4 compute waves per workgroup, one per SIMD. Per wave and step: 4 (L1) + 32 (L2)
+//     + 32 (dW2) + 32 (dH1) + 8 (dW1) = 108 MFMAs against 212 in the sample-split form (train_mfma_kernel.h) -- the step loop is instruction-issue bound, and this
+//     halves the per-feature instruction stream of a wave;
+//   * the 64x64 weight gradient stays model-parallel over the waves of a workgroup (two 16x16 tiles of W2 with theta, m, v in the owning wave's registers); it is formed
+//     BEFORE dH1 and its partial sums leave for the other workgroups' L2 slots at once, so the store acknowledgement is covered by the rest of the backward pass;
+//   * the four partial gradients are exchanged once per step through the shared L2 (plain stores, sc1 loads) and added in a fixed order -- (own + partner) + (other pair) -- by
+//     everyone: bit-identical totals, Adam updates and early-stopping decisions in all workgroups.
+// The roles (round 5; until round 6 a second kernel, k_train_fs, ran the same arithmetic with every wave in every role -- 40 % of its step was the tail, a chain of L2 round trips):
 //
 //   COMPUTE waves (0..3)                                        HELPER waves (4..7)
 //   forward L1, L2, partial logits                              prefetch minibatch k+2's row indices, k+1's rows; stage minibatch k+1
@@ -22,15 +34,63 @@
 //       compute waves are in dH1 / dZ1 / dW1: when the small partials are ready, the peers' W2 partials are known to be in the L2 already;
 //   (2) the small partials, the last bytes of the step, travel as data-tagged granules -- store, then poll the peers' granules until the tag is the step's: one L2 round trip
 //       where the flag protocol needs three (drain, arrival + wait, load);
-//   (3) each role is its own code path: the register allocation is the maximum of the two roles, not their union -- no instantiation spills;
+//   (3) each role is its own code path: the register allocation is the maximum of the two roles, not their union -- no plain or lagrange instantiation spills;
 //   (4) two workgroup barriers per step instead of five; pairs and roles meet through LDS counters.
 // NaN semantics (training.jl:20: a NaN gradient norm is an error BEFORE the update): every thread forms the totals of its own elements in every workgroup; one that finds a
 // NaN total marks the step SUSPECT in LDS; after B_b the whole workgroup puts the pre-step state back (W2 from registers, the small parameters from the values read for Adam)
-// and leaves with CRUX_ENAN -- a NaN step leaves every parameter as it was, exactly as in k_train_fs. The same totals, hence the same decision, in all four workgroups.
+// and leaves with CRUX_ENAN -- a NaN step leaves every parameter as it was. The same totals, hence the same decision, in all four workgroups.
 // Covers the plain policy-gradient / critic losses of full minibatch loops (65..128 rows), alone or as a member of a replica group (PX: the group's all-reduce of the minibatch
-// gradient between the totals and Adam; PXK: local steps, theta / m / v averaged every k-th -- the exchange of train_fs_kernel.h, same bits); lagrange_ppo_loss stays on k_train_fs.
+// gradient between the totals and Adam; PXK: local steps, theta / m / v averaged every k-th), and lagrange_ppo_loss (LAG).
 #pragma once
-#include "train_fs_kernel.h"
+#include <type_traits>
+#include "train_args.h"
+
+#include "mfma_helpers.h"
+#include "peer_wait.h"
+
+#define FS_LD 72
+__device__ __forceinline__ int fs_tx(int q) { return (4 - q) & 3; }   // {0,3,2,1}
+
+// H2: width of the second hidden layer, 64 or 32 (the first is MF_HID = 64): the reference's HalfCheetah PPO networks are 17-64-32-6 / 17-64-32-1
+// (examples/rl/half_cheetah_mujoco.jl:33-38); a wave's half of the layer is then ONE 16-feature tile instead of two.
+template <int IN, int OUT, int NWG, bool HELP = false, int H2 = 64, bool LAG = false>
+struct FsLayout {
+  static_assert(H2 == 64 || H2 == 32, "second hidden layer: 64 or 32 units");
+  static constexpr int MH = H2 / 32, NT2 = H2 / 16, HH = H2 / 2, W2N = H2 * MF_HID;      // 16-feature tiles per half / per layer, features per half, elements of W2
+  static constexpr int NWC = 16 / NWG, TILES = NWC / 2;                    // compute waves (a pair per 16-sample tile)
+  static constexpr int NW = HELP ? 2 * NWC : NWC, NT = 64 * NW;            // + as many helper waves: owners of half the W2 tiles, and the minibatch staging
+  static constexpr int NXB = HELP ? 2 : 1;                                 // staging rows are double-buffered when the helpers stage the next minibatch during the step
+  static constexpr int KS0 = (IN + 3) / 4, IP = KS0 * 4, JT = (IN + 15) / 16, XP = IP + 2, W1LD = IP + 2;
+  static constexpr int SCW = ((4 + (OUT > 4 ? OUT : 4)) | 1) + (LAG ? 2 : 0);      // lagrange_ppo_loss: :cost_advantage of the sample rides in the last slot
+  static constexpr int ZW = OUT;                                                          // partial logits per (tile, half, g, sample)
+  // flat index spaces of the small parameters (everything but W2): s = thread-owned index, c = canonical (Flux.params) index, p = index inside a tile's partial block
+  static constexpr int sW1 = 0, sB1 = MF_HID * IN, sB2 = sB1 + MF_HID, sW3 = sB2 + H2, sB3 = sW3 + H2 * OUT, sEX = sB3 + OUT, NS = sEX + 16;
+  static constexpr int cW1 = 0, cB1 = MF_HID * IN, cW2 = cB1 + MF_HID, cB2 = cW2 + W2N, cW3 = cB2 + H2, cB3 = cW3 + H2 * OUT, cEX = cB3 + OUT;
+  static constexpr int W1ROWS = IP < 16 * JT ? IP : 16 * JT;
+  static constexpr int pW1 = 0, pB1 = pW1 + W1ROWS * FS_LD, pB2 = pB1 + MF_HID, pW3 = pB2 + H2, pMISC = pW3 + OUT * H2;
+  static constexpr int pST = pMISC, pB3 = pMISC + 7, pEX = pB3 + OUT;
+  static constexpr int PART = ((pMISC + 48 + 3) / 4) * 4;
+  static constexpr int NSP = ((NS + 3) / 4) * 4;
+  static constexpr int TILE = MF_HID * 16, TILE2 = H2 * 16;
+  static constexpr int oW2R = 0, oW2C = oW2R + H2 * FS_LD, oW1R = oW2C + MF_HID * FS_LD;      // W2R: [H2 rows o][i], W2C: [64 rows i][o]
+  static constexpr int oB1 = oW1R + MF_HID * W1LD, oB2 = oB1 + MF_HID, oW3R = oB2 + H2, oB3 = oW3R + OUT * H2, oEX = oB3 + 16;
+  static constexpr int oMS = ((oEX + 16 + 3) / 4) * 4, oVS = oMS + NSP;
+  static constexpr int oT1 = oVS + NSP, oT2 = oT1 + TILES * TILE;
+  static constexpr int oD2X = oT2 + TILES * TILE2;                        // [tile][half][MH][64 lanes] f32x4: the dZ2 half of a wave in A-operand layout, for its partner
+  static constexpr int oZP = oD2X + TILES * 2 * MH * 256;                 // [tile][half][g 4][sample 16][ZW]
+  static constexpr int oPART = ((oZP + TILES * 2 * 64 * ZW + 3) / 4) * 4; // [tile][PART]
+  static constexpr int oXS = oPART + TILES * PART;
+  static constexpr int oSC = oXS + NXB * TILES * 16 * XP;
+  static constexpr int oRED = oSC + NXB * TILES * 16 * SCW;                     // [0,8): per-wave sum of squares; [8,15): reduced stat sums; [16]: abort flag
+  static constexpr int oLAG = oRED + 32;                                        // lagrange_ppo_loss: [buffer][cost 128 | episode_end 128] of the WHOLE minibatch
+  static constexpr int oLGS = oLAG + (LAG ? 2 * 256 : 0);                       // [wave][8]: the controller's state, one copy per wave (every wave advances its own, identically)
+  static constexpr int TOTAL = oLGS + (LAG ? 8 * NW : 0);
+  static constexpr int NSI = (NS + NT - 1) / NT;
+  static constexpr int XSLOT = ((W2N + NSI * NT + 16 + 3) / 4) * 4;       // floats per exchange slot
+  static_assert(TOTAL <= 40960, "LDS budget (160 KB) exceeded");
+  static_assert(XSLOT <= 8192, "exchange slot");
+};
+
 // CRUX_FS2_EXP (development builds only; tools/fs4_bound.sh): a TIMING experiment with WRONG results -- what would a step cost if every compute wave ran the MFMA chain of a
 // four-waves-per-tile decomposition (half the second-layer, dH1 and dW1 MFMAs of the pair form)? 1: the chain is cut (no extra load anywhere: the upper bound of the gain);
 // 2: the helper wave that shares the SIMD additionally issues the MFMAs and VALU work the second pair of compute waves would (the contention a real quad form has);
@@ -39,11 +99,11 @@
 #define CRUX_FS2_EXP 0
 #endif
 
-template <int IN, int OUT, int H2>
-struct Fs2Layout : FsLayout<IN, OUT, 4, true, H2, false> {
-  using B = FsLayout<IN, OUT, 4, true, H2, false>;
+template <int IN, int OUT, int H2, bool LAG = false>
+struct Fs2Layout : FsLayout<IN, OUT, 4, true, H2, LAG> {
+  using B = FsLayout<IN, OUT, 4, true, H2, LAG>;
   static constexpr int NTC = 256;                                   // compute threads = helper threads
-  static constexpr int NSC = (B::NS + 511) / 512;                   // small parameters per thread (all 512 threads share them, as in k_train_fs)
+  static constexpr int NSC = (B::NS + 511) / 512;                   // small parameters per thread (all 512 threads share them)
   static constexpr int WT2 = (B::NT2 * 4) / 8;                      // W2 tiles per wave (all eight waves own tiles)
   static constexpr int NGR = NSC * 512 + 8;                         // granules of a slot: the small partials, then the 7 statistics sums
   static constexpr int xW2 = 0, xGR = B::W2N;                       // exchange slot: W2 partials [thread][WT2][4] | granules {value, step} of the small partials and statistics
@@ -60,6 +120,9 @@ struct Fs2Layout : FsLayout<IN, OUT, 4, true, H2, false> {
   // the reported minibatch's info (training.jl:22-23), kept by thread 0 -- its only reader (epoch_infos) -- in free words of the same area instead of six registers per thread
   // that would stay live across the whole launch: loss, grad norm, entropy, clip fraction, avg advantage, avg return (the KL stays in a register: every thread's loop exit reads it)
   static constexpr int iLOSS = B::oRED + 19, iGN = B::oRED + 20, iENT = B::oRED + 21, iCLIP = B::oRED + 22, iADV = B::oRED + 23, iRET = B::oRED + 27;
+  // lagrange_ppo_loss: the reported penalty and current cost are words 5 and 6 of wave 0's copy of the controller state (B::oLGS); cost_loss and p_loss take the spare eighth words
+  // of wave 0's and wave 1's copies
+  static constexpr int iPEN = B::oLGS + 5, iCUR = B::oLGS + 6, iCLOSS = B::oLGS + 7, iPLOSS = B::oLGS + 15;
 };
 
 // meeting point of a subset of the workgroup's waves: one LDS counter, monotonic over the launch (target = members x number of uses so far). A wave's LDS operations execute in
@@ -78,11 +141,14 @@ __device__ __forceinline__ void fs2_flag_wait(const float* word, unsigned target
   asm volatile("" ::: "memory");
 }
 
-template <int IN, int OUT, int KIND, int ACT, int H2 = 64, int ACT2 = ACT, bool TIMING = false, bool PX = false, bool PXK = false>
+// LAG: lagrange_ppo_loss (ppo.jl:70-131) -- the PID penalty controller advanced once per minibatch inside the kernel (every wave, from the :cost / :episode_end columns of the
+// WHOLE minibatch, which two helper waves stage beside the tiles) and the cost-advantage term of the loss head. A separate instantiation: the plain kernels carry none of it.
+template <int IN, int OUT, int KIND, int ACT, int H2 = 64, int ACT2 = ACT, bool TIMING = false, bool PX = false, bool PXK = false, bool LAG = false>
 __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   static_assert(!PXK || PX, "PXK: the periodic form of the replica group");
+  static_assert(!LAG || (!PX && KIND != MFK_VALUE), "lagrange_ppo_loss: policy heads, one replica");
   static_assert(!PX || FsLayout<IN, OUT, 4, true, H2, false>::W2N + Fs2Layout<IN, OUT, H2>::NSC * 512 + 8 <= CRUX_PX_SEC, "a payload section must fit CRUX_PX_SEC");
-  using Lt = Fs2Layout<IN, OUT, H2>;
+  using Lt = Fs2Layout<IN, OUT, H2, LAG>;
   constexpr int NWG = 4, NWC = 4, TILES = 2, NT = 512, NTC = 256, MH = Lt::MH, HH = Lt::HH, W2N = Lt::W2N, NW = 8;
   constexpr int WT = Lt::WT2;                       // 16x16 tiles of W2 owned by a wave (all eight waves own tiles)
   constexpr int KS0 = Lt::KS0, IP = Lt::IP, JT = Lt::JT, XP = Lt::XP, NS = Lt::NS, NSC = Lt::NSC, XSLOT = Lt::XSLOT2;
@@ -159,6 +225,27 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
   AdamK ak; ak.b1 = (float)a.b1; ak.b2 = (float)a.b2; ak.omb1 = (float)(1.0 - a.b1); ak.omb2 = (float)(1.0 - a.b2); ak.eps = (float)a.eps; ak.eta = (float)a.eta;
   const double db1 = a.b1, db2 = a.b2;
   const float lambda_p = a.lambda_p, lambda_e = a.lambda_e, target_kl = a.target_kl, squash = a.squash;
+  float pen = 0.f;                                     // lagrange_ppo_loss: the penalty of the current minibatch; the controller's state sits in LDS, one copy per wave
+  float* lgs = sm + Lt::oLGS + 8 * w;                  // [I, smooth_delta, smooth_Jc, Jc_prev, deriv_term, penalty, cur_cost, -]
+  if constexpr (LAG) { if (lane == 0) { lgs[0] = a.lag->I; lgs[1] = a.lag->smooth_delta; lgs[2] = a.lag->smooth_Jc; lgs[3] = a.lag->Jc_prev; lgs[4] = a.lag->deriv_term; lgs[5] = a.lag->penalty; lgs[6] = a.lag->cur_cost; lgs[7] = 0.f; } }
+  // the penalty update inside the loss (ppo.jl:80-116), once per evaluation, by every wave of both roles at the top of its step: sums of the staged minibatch's :cost and
+  // :episode_end (buffer `buf`, visible since the previous step's B_1 or the epoch's first barrier), then the controller -- the same bits in every wave of every workgroup
+  auto lag_advance = [&](int buf) {
+    const float* lc = sm + Lt::oLAG + 256 * buf;
+    double sc_ = (double)lc[lane] + (double)lc[lane + 64], ne_ = (double)lc[128 + lane] + (double)lc[128 + lane + 64];      // Float32 terms: any summation order gives the same Float64 sum
+#pragma unroll
+    for (int o_ = 32; o_ >= 1; o_ >>= 1) { sc_ += __shfl_xor(sc_, o_, 64); ne_ += __shfl_xor(ne_, o_, 64); }
+    const crux_lagrange* L = a.lag;              // the keywords: uniform (scalar) loads
+    const float Jc = (float)sc_ / (float)ne_;                                      // :84-88
+    const float dl = Jc - L->target_cost;                                         // :91
+    float I_ = lgs[0], sd_ = lgs[1], sj_ = lgs[2]; const float jp_ = lgs[3];
+    { const float x = I_ + L->Ki * dl; I_ = x > L->Ki_max ? L->Ki_max : (x < 0.f ? 0.f : x); }                   // :94 clamp(I + Ki*Delta, 0, Ki_max)
+    sd_ = (float)(L->ema_alpha * (double)sd_ + (1.0 - L->ema_alpha) * (double)dl);                             // :98 (Float64 arithmetic, Float32 store)
+    sj_ = (float)(L->ema_alpha * (double)sj_ + (1.0 - L->ema_alpha) * (double)Jc);                             // :99
+    float dt_; { const float x = sj_ - jp_; dt_ = (x != x) ? x : (x > 0.f ? x : 0.f); }                          // :102 max(0, .) keeps NaN
+    { const float x = (L->Kp * sd_ + I_) + L->Kd * dt_; pen = x > L->penalty_max ? L->penalty_max : (x < 0.f ? 0.f : x); }   // :108
+    if (lane == 0) { lgs[0] = I_; lgs[1] = sd_; lgs[2] = sj_; lgs[3] = sj_ /* Jc_prev = smooth_Jc, :105 */; lgs[4] = dt_; lgs[5] = pen; lgs[6] = Jc; }
+  };
   // 32-bit loop control (the dispatcher sends only buffers below 2^30 rows and launches below 2^31 steps here): 64-bit counters cost SGPR pairs the wide heads do not have
   const int max_batches = a.max_batches > 0 && a.max_batches < 0x7fffffffll ? (int)a.max_batches : 0;
   const int bs = a.bs;
@@ -195,7 +282,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     if (target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > target_kl) return false;    // :46
     return true;
   };
-  // both roles run the same epoch prologue (same barriers): the speculative-run consensus of k_train_fs and the epoch's shuffle order. false = leave the epoch loop.
+  // both roles run the same epoch prologue (same barriers): the speculative-run consensus and the epoch's shuffle order. false = leave the epoch loop.
   auto epoch_prologue = [&](int ep) -> bool {
     if (a.spec_abort) {
       if (tid == 0) {
@@ -228,7 +315,8 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     if (tid == 0 && p == 0 && a.epoch_infos) { float* e = a.epoch_infos + (size_t)ep * CRUX_INFO_N;   // aggregate_info(minibatch_infos) == last minibatch (Q3)
       for (int k = 0; k < CRUX_INFO_N; ++k) e[k] = 0.f;
       e[CRUX_INFO_LOSS] = sm[Lt::iLOSS]; e[CRUX_INFO_GRAD_NORM] = sm[Lt::iGN];
-      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = sm[Lt::iENT]; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = sm[Lt::iCLIP]; e[CRUX_INFO_AVG_ADVANTAGE] = sm[Lt::iADV]; e[CRUX_INFO_AVG_RETURN] = sm[Lt::iRET]; } }
+      if (KIND != MFK_VALUE) { e[CRUX_INFO_ENTROPY] = sm[Lt::iENT]; e[CRUX_INFO_KL] = inf_kl; e[CRUX_INFO_CLIP_FRACTION] = sm[Lt::iCLIP]; e[CRUX_INFO_AVG_ADVANTAGE] = sm[Lt::iADV]; e[CRUX_INFO_AVG_RETURN] = sm[Lt::iRET]; }
+      if constexpr (LAG) { e[CRUX_INFO_PENALTY] = sm[Lt::iPEN]; e[CRUX_INFO_CUR_COST] = sm[Lt::iCUR]; e[CRUX_INFO_COST_LOSS] = sm[Lt::iCLOSS]; e[CRUX_INFO_P_LOSS] = sm[Lt::iPLOSS]; } }
     epochs_run += 1;
     if (target_kl >= 0.f && KIND != MFK_VALUE && inf_kl > target_kl) stop = true;   // training.jl:49
     if (max_batches > 0 && total_batches >= max_batches) stop = true;               // :50
@@ -268,7 +356,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(pw[j][mm]) : "v"(peer + Lt::xW2 + tid * (4 * WT) + 4 * mm) : "memory"); }
   };
   // ... and, once they are in (the caller has waited), the total (s0 + s1) + (s2 + s3) -- own + partner, the other pair in index order, then the two pair sums: the same bits
-  // in all four workgroups (train_fs_kernel.h)
+  // in all four workgroups
   auto w2_total = [&](f32x4 (&gW2)[WT], f32x4 (&pw)[NWG - 1][WT]) {
 #pragma unroll
     for (int j = 0; j < NWG - 1; ++j)
@@ -299,8 +387,8 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
 #pragma unroll
   for (int k = 0; k < NSC; ++k) { const int s = tid + NT * k; so_ok[k] = s < ns_valid; so_ex[k] = s >= Lt::sEX;
     so_part[k] = so_ok[k] ? s_part(s) : 0; so_master[k] = so_ok[k] ? s_master(s) : 0; }
-  const bool stat_lane = tid >= NT - 8 && tid < NT - 1;      // stat sums, by 7 lanes of the last wave
-  // ---- replica group (comm.hip "peer"; the exchange of train_fs_kernel.h): mean over the group of NSEC payload sections (the W2-tile registers + the small parameters'
+  const bool stat_lane = tid >= NT - 8 && tid < (LAG ? NT : NT - 1);      // stat sums, by 7 lanes of the last wave (an eighth: the cost term of lagrange_ppo_loss)
+  // ---- replica group (comm.hip "peer"): mean over the group of NSEC payload sections (the W2-tile registers + the small parameters'
   // registers of every thread) and one statistics word, the same bits on every workgroup of every rank. Per-step form: ONE section, the minibatch gradient and its statistics;
   // periodic form (PXK): THREE sections -- theta, m, v after every k-th Adam step -- in one exchange. All four workgroups hold the same local values and share the writes (peer i
   // of the N-1 goes to workgroup i mod 4): the sections go into slot [parity][my rank] of the peer's region, one lane issues the system-scope release and raises flag[my rank]
@@ -430,7 +518,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         for (int q = 1; q < TILES; ++q) gsum += sm[po + q * Lt::PART]; }
       gs[k] = gsum; }
     float stat_loc = 0.f;
-    if (stat_lane) { const int ko = Lt::pST + (tid - (NT - 8)); stat_loc = sm[Lt::oPART + ko];
+    if (stat_lane) { const int k_ = tid - (NT - 8); const int ko = (LAG && k_ == 7) ? Lt::pMISC + 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0) : Lt::pST + k_; stat_loc = sm[Lt::oPART + ko];
 #pragma unroll
       for (int q = 1; q < TILES; ++q) stat_loc += sm[Lt::oPART + q * Lt::PART + ko]; }
     // the small partials travel as granules: {value, step} in ONE naturally aligned 8-byte store -- the tag is the flag
@@ -524,7 +612,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     if (stat_lane) sm[Lt::oRED + 8 + (tid - (NT - 8))] = stat_tot;
 #pragma unroll
     for (int k = 0; k < NSC; ++k) if (so_ok[k]) {
-      if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += -lambda_e;       // d(-lambda_e H)/dlogSigma, H = const + sum(logSigma)
+      if (KIND == MFK_GAUSSIAN && so_ex[k]) gs[k] += LAG ? -lambda_e / (1.f + pen) : -lambda_e;       // d(-lambda_e H)/dlogSigma, H = const + sum(logSigma); lagrange: the whole loss is divided by 1 + penalty
       if (want_ssq) ssq += gs[k] * gs[k]; }
     if (want_ssq) { ssq = wave_sum(ssq);
       if (lane == 0) sm[Lt::oRED + w] = ssq; }      // this wave's share of the gradient norm (the report is formed after B_b)
@@ -592,6 +680,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         FS2_T(0);
         if (!staged) __syncthreads();      // the first minibatch of an epoch is staged by the helpers before this barrier; every other one during the previous step
         staged = false;
+        if constexpr (LAG) lag_advance(xcur);
         const float* xs_c = xs + xcur * XSB; const float* sc_c = sc + xcur * SCB;
         FS2_T(1);
         // ======================= forward, C orientation: D[feature 16m+4g+r][sample c] =======================
@@ -650,7 +739,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         }
         fs2_group_barrier(sm + Lt::cPAIR + t, 2u * (xstep + 1u), lane);      // ---- B_z: the pair's partial logits are visible (the two waves of the tile only)
         float dz[OUT], dex[OUT];
-        float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f;
+        float s_lossp = 0.f, s_H = 0.f, s_kl = 0.f, s_adv = 0.f, s_ret = 0.f, s_clip = 0.f, s_sq = 0.f, s_cost = 0.f;
         float ent_pre = 1.4189385332046727f;
         {
           float z[OUT];
@@ -681,10 +770,12 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
               const float newlp = __logf(pa); const float r = __expf(newlp - oldlp);
               const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
               const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;
+              float gcr = 0.f;                                                          // lagrange: d/dr of max(r Ac, clamp(r) Ac) times r (ppo.jl:119)
+              if constexpr (LAG) { const float Ac = q[Lt::SCW - 1]; const float uc = r * Ac, clc = rc * Ac; s_cost = cnt * (uc >= clc ? uc : clc); gcr = (uc >= clc ? Ac : 0.f) * r; }
 #pragma unroll
               for (int k = 0; k < OUT; ++k) { const float dlogpi = ((k == ai) ? 1.f : 0.f) - pk[k];
                 const float base = -lambda_p * coef * dlogpi - lambda_e * (pk[k] * (hk[k] - hp));
-                dz[k] = !valid ? 0.f : invB * base; }
+                dz[k] = !valid ? 0.f : (LAG ? invB * ((base + pen * gcr * dlogpi) / (1.f + pen)) : invB * base); }
               s_lossp = cnt * lterm; s_H = cnt * H; s_kl = cnt * (oldlp - newlp); s_adv = cnt * A; s_ret = cnt * R;
               s_clip = cnt * clipv;
             } else {   // gaussian with constant log-std (policies.jl:333-348)
@@ -698,7 +789,9 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
               if (squash > 0.f) newlp -= q[4 + NACT];
               const float r = __expf(newlp - oldlp); const float u = r * A, rc = fminf(fmaxf(r, lo), hi), cl = rc * A; const float gsel = (u <= cl) ? A : 0.f;
               const float coef = a2c ? A : gsel * r, lterm = a2c ? newlp * A : fminf(u, cl), clipv = (!a2c && (r > hi || r < lo)) ? 1.f : 0.f;
-              const float cf = -lambda_p * coef;
+              float cf = -lambda_p * coef;
+              if constexpr (LAG) { const float Ac = q[Lt::SCW - 1]; const float uc = r * Ac, clc = rc * Ac; s_cost = cnt * (uc >= clc ? uc : clc);
+                cf = (cf + pen * ((uc >= clc ? Ac : 0.f) * r)) / (1.f + pen); }
 #pragma unroll
               for (int k = 0; k < OUT; ++k) { dz[k] = valid ? invB * (cf * (dd[k] * s2[k])) : 0.f;
                 dex[k] = valid ? invB * (cf * (((dd[k] * dd[k]) * s2[k]) * inr[k] - 1.f)) : 0.f; }
@@ -736,13 +829,14 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) h2[mm][r] = actg<ACT2>(h2[mm][r], d2[mm][r]); }       // h2 now holds dZ2 of this half
           if (h == 0) {
-            constexpr int NV = 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0);
+            constexpr int NVB = 7 + OUT + (KIND == MFK_GAUSSIAN ? OUT : 0), NV = NVB + (LAG ? 1 : 0);
             float mv[((NV + 15) / 16) * 16];
 #pragma unroll
             for (int k = 0; k < ((NV + 15) / 16) * 16; ++k) mv[k] = 0.f;
             mv[0] = s_lossp; mv[1] = s_H; mv[2] = s_kl; mv[3] = s_adv; mv[4] = s_ret; mv[5] = s_clip; mv[6] = s_sq;
 #pragma unroll
             for (int o = 0; o < OUT; ++o) { mv[7 + o] = dz[o]; if (KIND == MFK_GAUSSIAN) mv[7 + OUT + o] = dex[o]; }
+            if constexpr (LAG) mv[NVB] = s_cost;             // the cost term of the loss rides behind the head's gradient sums
 #pragma unroll
             for (int ch = 0; ch < (NV + 15) / 16; ++ch) { float cv[16];
 #pragma unroll
@@ -826,7 +920,10 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
             if (tid == 0) { sm[Lt::iGN] = sqrtf(ss);
               if (KIND == MFK_VALUE) { sm[Lt::iLOSS] = tq[6] * invB; sm[Lt::iRET] = tq[4] * invB; }
               else { const float p_loss = -(tq[0] * invB); const float entropy = KIND == MFK_CATEGORICAL ? tq[1] * invB : ent_pre;
-                sm[Lt::iENT] = entropy; sm[Lt::iLOSS] = fmaf(lambda_p, p_loss, lambda_e * (-entropy)); sm[Lt::iADV] = tq[3] * invB; sm[Lt::iRET] = tq[4] * invB; sm[Lt::iCLIP] = tq[5] * invB; } } } }
+                sm[Lt::iENT] = entropy; sm[Lt::iLOSS] = fmaf(lambda_p, p_loss, lambda_e * (-entropy)); sm[Lt::iADV] = tq[3] * invB; sm[Lt::iRET] = tq[4] * invB; sm[Lt::iCLIP] = tq[5] * invB;
+                if constexpr (LAG) { const float cost_loss = pen * (tq[7] * invB);                                        // ppo.jl:119
+                  sm[Lt::iLOSS] = ((lambda_p * p_loss + lambda_e * (-entropy)) + cost_loss) / (1.f + pen);                  // :131   (iPEN / iCUR are wave 0's controller words: current)
+                  sm[Lt::iCLOSS] = cost_loss; sm[Lt::iPLOSS] = lambda_p * p_loss; } } } } }
         const bool go = step_exit(invB, any_bad != 0);
         if (!any_bad) { bp1 *= db1; bp2 *= db2; }
         xcur ^= 1; xstep += 1u; staged = st + bs < total_rows;
@@ -841,7 +938,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     // HELPER WAVES: the whole W2 path of the step (dW2, its exchange, total, Adam) and the minibatch prefetch / staging
     // =====================================================================================================================================================
     // ---- minibatch prefetch (HBM/L2 -> registers) and staging (registers -> the tile's LDS rows): wave h = 0 of a tile role fetches and stages the observation rows (four
-    // lanes per sample), wave h = 1 the scalars (logprob, advantage, return, action) -- the helper part of k_train_fs, unchanged
+    // lanes per sample), wave h = 1 the scalars (logprob, advantage, return, action)
     constexpr int NXL = (IN + 3) / 4;
     float px[NXL]; float p_lp = 0.f, p_adv = 0.f, p_ret = 0.f; float p_act[NACT]; int p_valid = 0; uint8_t p_abyte[OUT];
 #pragma unroll
@@ -851,23 +948,26 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
 #pragma unroll
     for (int e = 0; e < NXL; ++e) px[e] = 0.f;
     int n_row = 0, n_valid = 0;
+    int n_row2 = -1; float p_cost2 = 0.f, p_ee2 = 0.f, p_cadv = 0.f;      // LAG: helper thread ct < 128 carries row ct of the WHOLE minibatch (its :cost and :episode_end); :cost_advantage of the own sample
     auto fetch_index = [&](const int32_t* ord, int st, int nb) {
       const int sidx = 8 * NWC * p + 16 * t + c;
       n_valid = sidx < nb ? 1 : 0;
       n_row = n_valid ? CRUX_GLOBAL_PTR(int32_t, ord)[st + sidx] : 0;
+      if constexpr (LAG) n_row2 = ct < nb ? CRUX_GLOBAL_PTR(int32_t, ord)[st + ct] : -1;
     };
     auto fetch_data = [&]() {
       const int rowlo = n_row; p_valid = n_valid; const int64_t row = rowlo;
+      if constexpr (LAG) { p_cost2 = n_row2 >= 0 ? CRUX_GLOBAL_PTR(float, a.COST)[n_row2] : 0.f; p_ee2 = (n_row2 >= 0 && CRUX_GLOBAL_PTR(uint8_t, a.EE)[n_row2]) ? 1.f : 0.f; }
       if (h == 0) {
         const int rs = __shfl(rowlo, lane >> 2, 64), vs = __shfl(p_valid, lane >> 2, 64);
         const float* xrow = a.PACK ? CRUX_GLOBAL_PTR(float, a.PACK) + (int64_t)rs * a.pack_stride + (lane & 3) * NXL : CRUX_GLOBAL_PTR(float, a.S) + (int64_t)rs * IN + (lane & 3) * NXL;
 #pragma unroll
         for (int e = 0; e < NXL; ++e) px[e] = ((lane & 3) * NXL + e < IN && vs) ? xrow[e] : 0.f;
       } else {
-        p_lp = 0.f; p_adv = 0.f; p_ret = 0.f;
+        p_lp = 0.f; p_adv = 0.f; p_ret = 0.f; p_cadv = 0.f;
 #pragma unroll
         for (int k = 0; k < NACT; ++k) p_act[k] = 0.f;
-        if (a.PACK) {
+        if (a.PACK && !LAG) {
           if (lane < 16 && p_valid) { const float* q = CRUX_GLOBAL_PTR(float, a.PACK) + row * a.pack_stride;
             if (KIND != MFK_VALUE) { p_lp = q[a.pack_lp]; p_adv = q[a.pack_lp + 1]; }
             p_ret = q[a.pack_lp + 2];
@@ -879,6 +979,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
               for (int k = 0; k < OUT; ++k) p_act[k] = q[a.pack_act + k]; } }
         } else
         if (lane < 16 && p_valid) {
+          if constexpr (LAG) p_cadv = CRUX_GLOBAL_PTR(float, a.CADV)[row];
           if (KIND != MFK_VALUE) { p_lp = CRUX_GLOBAL_PTR(float, a.LP)[row]; p_adv = CRUX_GLOBAL_PTR(float, a.ADV)[row]; }
           p_ret = a.RET ? CRUX_GLOBAL_PTR(float, a.RET)[row] : 0.f;
           if (KIND == MFK_CATEGORICAL) { const auto* av = CRUX_GLOBAL_PTR(uint8_t, a.A) + row * OUT;
@@ -892,6 +993,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     };
     auto stage = [&](int buf) {
       float* xs_ = xs + buf * XSB; float* sc_ = sc + buf * SCB;
+      if constexpr (LAG) { if (ct < 128) { sm[Lt::oLAG + 256 * buf + ct] = p_cost2; sm[Lt::oLAG + 256 * buf + 128 + ct] = p_ee2; } }
       if (h == 0) {
 #pragma unroll
         for (int e = 0; e < NXL; ++e) { const int f = (lane & 3) * NXL + e; if (f < IN) xs_[(lane >> 2) * XP + f] = px[e]; }
@@ -901,6 +1003,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
           for (int k = 0; k < OUT; ++k) ai = p_abyte[k] ? k : ai;
           p_act[0] = (float)ai; }
         if (lane < 16) { float* q = sc_ + lane * Lt::SCW; q[0] = (float)p_valid; q[1] = p_lp; q[2] = p_adv; q[3] = p_ret;
+          if constexpr (LAG) q[Lt::SCW - 1] = p_cadv;
           if (KIND == MFK_GAUSSIAN) {
             static_assert(KIND != MFK_GAUSSIAN || ((4 + NACT) % 2 == 0), "the staging row needs its spare slot");
             float corr = 0.f;
@@ -925,6 +1028,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
         FS2_T(0);
         if (!staged) { stage(xcur); __syncthreads(); }      // the first minibatch of an epoch
         staged = false;
+        if constexpr (LAG) lag_advance(xcur);              // (the helpers' small-parameter Adam divides the entropy term by 1 + penalty)
         // rows of the NEXT minibatch (their indices came a step ago) and the indices of the one after it; the next minibatch goes into the other staging buffer, which the
         // compute waves left at the end of the previous step
         if (st + bs < total_rows) fetch_data();
@@ -1007,6 +1111,7 @@ __global__ __launch_bounds__(512) void k_train_fs2(TrainArgs a) {
     a.status[0] = err; a.status[1] = (int32_t)total_batches; a.status[2] = epochs_run; a.status[3] = (order_cur == a.order_a) ? 0 : 1;
     if (err == CRUX_EHIP) a.status[4] = why_failed;      // 1 a workgroup of the learner is missing, 2 workgroups on different XCDs, 3 replica group timeout / abort, 4 a workgroup missed the abort-latch consensus
     a.bp[0] = bp1; a.bp[1] = bp2;
+    if constexpr (LAG) { if (p == 0) { a.lag->I = lgs[0]; a.lag->smooth_delta = lgs[1]; a.lag->smooth_Jc = lgs[2]; a.lag->Jc_prev = lgs[3]; a.lag->deriv_term = lgs[4]; a.lag->penalty = lgs[5]; a.lag->cur_cost = lgs[6]; } }
     if (err && a.epoch_infos && epochs_run == 0) { a.epoch_infos[CRUX_INFO_LOSS] = sm[Lt::iLOSS]; a.epoch_infos[CRUX_INFO_GRAD_NORM] = NAN; }
   }
 #undef FS2_T

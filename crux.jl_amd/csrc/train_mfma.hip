@@ -15,7 +15,7 @@
 int32_t crux_train_mfma8_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream);   // train_mfma8.hip
 int32_t crux_train_mfma_x2_launch(crux_ctx* c, const TrainArgs& a, int kind, bool* handled, hipStream_t stream, bool any_mode);   // train_mfma_x2.hip
 
-int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream, bool probe = false);      // train_fs.hip: the feature-split form (its own shape test: IN -> 64 -> {64, 32} -> OUT)
+int32_t crux_train_fs_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream, bool probe = false);      // train_fs2.hip: the feature-split form (its own shape test: IN -> 64 -> {64, 32} -> OUT)
 int32_t crux_train_mfma_launch(crux_ctx* c, const TrainArgs& a, bool* handled, hipStream_t stream) {
   *handled = false;
   const NetDesc& nd = a.nd;

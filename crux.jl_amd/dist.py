@@ -79,7 +79,7 @@ def sync_due(steps_taken, k):
 
 
 class StateAverager:
-    """Host-side twin of the in-kernel periodic exchange (train_fs_kernel.h): replaces every float32 array by its mean over the ranks, in place -- SUM all-reduce, then x float32(1 / N),
+    """Host-side twin of the in-kernel periodic exchange (train_fs2_kernel.h): replaces every float32 array by its mean over the ranks, in place -- SUM all-reduce, then x float32(1 / N),
     the kernel's arithmetic (at N = 2 the sum is order-free, so the result is bit-identical to the kernel's rank-ordered sum). `arrays` are numpy float32 arrays on the host."""
 
     def __init__(self, group=None):

@@ -84,6 +84,9 @@ FAMILIES = {
     "cheetah_ref": (17, 6, False, [17, 64, 32, 6], [17, 64, 32, 1], ["tanh", "tanh", "identity"], "gaussian", "gaussian", "synth"),
     # 64-wide but with no instantiation in the register-resident kernels (5 observations / 3 actions): the dense engine, also on the second learner stream of a pair
     "synth_5_3": (5, 3, True, [5, 64, 64, 3], [5, 64, 64, 1], ACTS, "discrete", "categorical", "synth_discrete"),
+    # the widest inputs of the register-resident family: BipedalWalker-shaped 24 / 4 and Ant-shaped 27 / 8 (replica-group forms keep their W2 backups in registers there)
+    "synth_24_4": (24, 4, False, [24, 64, 64, 4], [24, 64, 64, 1], ACTS, "gaussian", "gaussian", "synth"),
+    "synth_27_8": (27, 8, False, [27, 64, 64, 8], [27, 64, 64, 1], ["tanh", "tanh", "identity"], "gaussian", "gaussian", "synth"),
     # outside the MFMA family (32-wide hidden layers): the generic learner
     "synth_8_4_h32": (8, 4, True, [8, 32, 32, 4], [8, 32, 32, 1], ACTS, "discrete", "categorical", "synth_discrete"),
 }

@@ -271,14 +271,11 @@ def test_offpolicy_user_priority_fn_and_sample_callback_write_back(gpu_ctx):
     assert np.abs(g.get_params() - o.params).max() < 2e-6
 
 
-# ---------------------------------------------------------------------------------------------------- the feature-split learner kernel (train_fs_kernel.h)
-@pytest.mark.parametrize("form", ["2", "4", "8"])
+# ---------------------------------------------------------------------------------------------------- the feature-split learner kernel (train_fs2_kernel.h)
 @pytest.mark.parametrize("family", ["cartpole", "synth_c5"])
-def test_feature_split_learner_forms_match_the_oracle(gpu_ctx, monkeypatch, capfd, form, family):
-    """k_train_fs in its three forms (CRUX_FS_WG: 2 = two compute units x eight waves, 4 = four x four, 8 = four x (four compute + four helper waves), the default)
-    through a whole PPO iteration -- rollout, GAE, whiten, actor || critic batch_train! of 2 epochs x 8 minibatches of 128 -- against the oracle: the same bounds as
-    the sample-split kernel's (tests/parity.py), whatever the decomposition of a step."""
-    monkeypatch.setenv("CRUX_FS_WG", form)
+def test_feature_split_learner_matches_the_oracle(gpu_ctx, capfd, family):
+    """k_train_fs2 (four compute units x (four compute + four helper waves)) through a whole PPO iteration -- rollout, GAE, whiten, actor || critic batch_train! of 2 epochs x 8
+    minibatches of 128 -- against the oracle: the same bounds as the sample-split kernel's (tests/parity.py), whatever the decomposition of a step."""
     res = parity.ppo_iteration_parity(n_envs=8, T=128, batch_size=128, epochs=2, seed=21, family=family, pair=True)
     assert res["ok"], res
     assert "outside the MFMA learner family" not in capfd.readouterr().err
@@ -293,7 +290,7 @@ def test_two_input_pendulum_shape_runs_on_the_feature_split_learner(gpu_ctx, cap
 
 def test_reference_half_cheetah_ppo_networks_run_on_the_feature_split_learner(gpu_ctx, capfd):
     """The networks of the reference's own HalfCheetah PPO example (examples/rl/half_cheetah_mujoco.jl:33-38): mu = 17 -tanh-> 64 -tanh-> 32 -> 6 with a trainable logSigma,
-    V = 17 -tanh-> 64 -> 32 -> 1 (no activation on its second layer). A 32-wide second hidden layer and per-layer activations are instantiations of k_train_fs (a wave's half of
+    V = 17 -tanh-> 64 -> 32 -> 1 (no activation on its second layer). A 32-wide second hidden layer and per-layer activations are instantiations of k_train_fs2 (a wave's half of
     the layer is one 16-feature tile); a whole PPO iteration against the oracle."""
     res = parity.ppo_iteration_parity(n_envs=8, T=128, batch_size=128, epochs=2, seed=9, family="cheetah_ref", pair=True)
     assert res["ok"], res
@@ -392,7 +389,7 @@ def test_asynchronous_softq_solve_loop_equals_the_synchronous_one(gpu_ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["cartpole", "synth17"])
 def test_lagrange_loss_on_the_feature_split_kernel_at_rollout_size(gpu_ctx, kind):
-    """lagrange_ppo_loss inside k_train_fs<..., LAG> on a 16 x 1024 rollout, minibatches of 128: 128 (relu CartPole actor, one epoch) / 256 (tanh 17-64-64-6 actor, two
+    """lagrange_ppo_loss inside k_train_fs2<..., LAG> on a 16 x 1024 rollout, minibatches of 128: 128 (relu CartPole actor, one epoch) / 256 (tanh 17-64-64-6 actor, two
     epochs) consecutive minibatch steps, every one advancing the PID controller on its own cost statistics, free-running against the oracle (tests/test_gpu_lagrange.py
     checks 18 steps on a 384-row buffer). The relu actor stays at one epoch: measured 2.2e-6 after 128 steps and 2.5e-3 after 256 -- a free-running relu learner leaves the
     oracle's trajectory once a unit flips at its kink (the two-CU kernel shows the same 2.5e-3, the two kernels agree to 6e-8; DESIGN 6: why the long runs are pinned with
@@ -409,7 +406,7 @@ def test_lagrange_loss_on_the_feature_split_kernel_at_rollout_size(gpu_ctx, kind
     cfg = parity.train_cfg("lagrange_ppo", head, bs, epochs, -1.0, 0); oi = np.zeros(L.INFO_N, np.float32); oe_ = np.zeros((epochs, L.INFO_N), np.float32)
     O.chk(O.lib().orc_batch_train_lagrange(oa.h, ob.h, C.byref(cfg), C.byref(olag), O.vpz(np.ascontiguousarray(perms, np.int64)), O.vpz(oi), O.vpz(oe_)))
     steps = epochs * (N // bs); d = float(np.abs(ga.get_params() - oa.params).max())
-    print(kind, "lagrange on k_train_fs: max |dtheta| after %d free-running steps = %.3g; penalty %.6g / %.6g" % (steps, d, glag.penalty, olag.penalty))
+    print(kind, "lagrange on k_train_fs2: max |dtheta| after %d free-running steps = %.3g; penalty %.6g / %.6g" % (steps, d, glag.penalty, olag.penalty))
     assert info["actor_batches_trained"] == steps == 128 * epochs
     assert d < 2e-5
     for f in ("I", "smooth_delta", "smooth_Jc", "penalty", "cur_cost"):
@@ -504,7 +501,7 @@ def test_asynchronous_dpg_solve_loop_equals_the_synchronous_one(gpu_ctx, algo):
 @pytest.mark.parametrize("od,ad,kind,act", [(6, 3, "categorical", "relu"), (2, 3, "categorical", "relu"), (8, 2, "gaussian", "tanh"), (11, 3, "gaussian", "tanh"), (24, 4, "gaussian", "relu"),
                                             (27, 8, "gaussian", "tanh"), (27, 8, "value", "tanh"), (24, 4, "value", "relu"), (6, 3, "value", "relu")])
 def test_gym_shapes_on_the_feature_split_kernel(gpu_ctx, capfd, od, ad, kind, act):
-    """The standard Gym observation / action sizes added to k_train_fs's dispatch in round 3 (Acrobot 6 / 3, MountainCar 2 / 3, LunarLanderContinuous 8 / 2, Hopper 11 / 3,
+    """The standard Gym observation / action sizes added to the feature-split learner's dispatch in round 3 (Acrobot 6 / 3, MountainCar 2 / 3, LunarLanderContinuous 8 / 2, Hopper 11 / 3,
     BipedalWalker 24 / 4, Ant 27 / 8; 64-64 hidden): two teacher-forced windows of eight full-minibatch steps each against the oracle (B = 128: the feature-split kernel;
     CRUX_FS=0 would send these shapes to the dense engine)."""
     rng = np.random.default_rng(77 + od + ad); bs = 128; N = bs * 20; disc = kind == "categorical"

@@ -1,5 +1,5 @@
 """The CRUX_* switches that select between two forms of the same computation, each against the default form: whatever a run leaves behind must be the same bits.
-(The other switches have tests of their own: CRUX_FS / CRUX_FS_WG / CRUX_FS2 / CRUX_MFMA_X2 / CRUX_FORCE_GENERIC in test_gpu_fs2.py, test_gpu_ppo_parity.py, test_gpu_round3.py;
+(The other switches have tests of their own: CRUX_FS / CRUX_MFMA_X2 / CRUX_FORCE_GENERIC in test_gpu_fs2.py, test_gpu_ppo_parity.py, test_gpu_round3.py;
 CRUX_SPEC_PAIR, CRUX_DENSE_FUSED, CRUX_PER_FUSED_GATHER, CRUX_SAC_TILE_OPS in test_gpu_round4.py; CRUX_PUSH_FUSED in test_gpu_round5.py; CRUX_DQN_PERSIST, CRUX_EXEC_NO_KERNARG,
 CRUX_SMALL_SOLVE_GENERIC in test_gpu_round3.py / test_gpu_round2.py. DESIGN.md section 8.2 has the table.)"""
 import os

@@ -1,5 +1,5 @@
 """step time of the reference's HalfCheetah PPO networks (17 -tanh-> 64 -tanh-> 32 -> 6 Gaussian actor, examples/rl/half_cheetah_mujoco.jl:33-38) on the feature-split learner
-(k_train_fs with a 32-wide second layer) against the dense-engine learner they took before round 3 (CRUX_FS=0)"""
+(k_train_fs2 with a 32-wide second layer) against the dense-engine learner they took before round 3 (CRUX_FS=0)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import dense_learner_bench as d

@@ -10,4 +10,4 @@ if __name__ == "__main__":
         for fs in ("1", "0"):
             os.environ["CRUX_FS"] = fs; d.crux.reload_switches()
             r[fs] = d.run([od, 64, 64, ad], [act, act, "identity"], disc, od, ad, E=32, T=512, epochs=4)
-        print("%-28s %s: k_train_fs actor %.2f / critic %.2f us per step; dense engine %.1f / %.1f" % (label, act, r["1"]["actor"], r["1"]["critic"], r["0"]["actor"], r["0"]["critic"]), flush=True)
+        print("%-28s %s: k_train_fs2 actor %.2f / critic %.2f us per step; dense engine %.1f / %.1f" % (label, act, r["1"]["actor"], r["1"]["critic"], r["0"]["actor"], r["0"]["critic"]), flush=True)
