@@ -716,7 +716,7 @@ def main():
             "grad_steps_per_s": grad_steps / dt,
             "phase_ms_per_iter": {k: v[0] / args.steps for k, v in prof.items()},
             "rollout_env_steps_per_s": (E * T * args.steps) / (prof["rollout"][0] * 1e-3) if prof["rollout"][0] > 0 else None,
-            "roofline": {"kernel": "batch_train! actor (k_train_fs2, the role-specialised form of the feature-split learner: persistent fwd + ppo_loss + bwd + gradient exchange + Adam, 40 960 steps per launch; N > 1: its replica-group form with the gradient all-reduce over the peer slots inside the step; lagrange_ppo_loss runs k_train_fs)", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "batch_train! actor (k_train_fs2, the role-specialised form of the feature-split learner: persistent fwd + ppo_loss + bwd + gradient exchange + Adam, 40 960 steps per launch; N > 1: its replica-group form with the gradient all-reduce over the peer slots inside the step; lagrange_ppo_loss is an instantiation of the same kernel)", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "frac_of_occupied_cus": achieved / (PEAK_F32_MFMA_TFLOPS * 4.0 / 256.0), "occupied_cus": 4, "traffic": traffic,
                          "traffic_note": "HBM-side bytes per actor launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes; FETCH_SIZE tallies 128-byte requests at 64 B, calibrated in profiles/r02_fetch_calibration.txt). " + traffic_how + ". Algorithmic minibatch bytes per launch are %.0f MB (%d steps x %d B): the buffer is re-read from L2/MALL, and the per-step gradient exchange between the learner's workgroups (4 x 18 KB written, 3 x 18 KB read per workgroup and step) stays inside one XCD's L2" % (steps_per_launch * BATCH * (4 * wl["obs"] + (wl["act"] if wl["discrete"] else 4 * wl["act"]) + 8) / 1e6, int(steps_per_launch), BATCH * (4 * wl["obs"] + (wl["act"] if wl["discrete"] else 4 * wl["act"]) + 8)),
                          "avg_launch_ms": avg_launch_s * 1e3, "grad_steps_per_launch": steps_per_launch,
