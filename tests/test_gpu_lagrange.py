@@ -27,10 +27,14 @@ def _pair(kind, E=6, T=64, max_steps=12, seed=21):
         od, ad, disc, acts = 4, 2, True, parity.ACTS
         mdp = crux.CartPoleMDP(n_envs=E, seed=seed); oe = O.OEnv("cartpole", E, max_steps, 0.99, seed)
         ga, oa = parity.make_pair([4, 64, 64, 2], acts, 50, 0, "discrete")
-    else:       # "synth": 5-32-32-2 (dense-engine learner); "synth17": the C5 shape 17-64-64-6 (register-resident learner, lagrange instantiation)
-        od, ad, disc, acts = (17, 6, False, ["tanh", "tanh", "identity"]) if kind == "synth17" else (5, 2, False, ["tanh", "tanh", "identity"])
+    elif kind == "synth84":       # the LunarLander-shaped discrete actor 8-64-64-4 (relu): the third lagrange instantiation of the feature-split learner
+        od, ad, disc, acts = 8, 4, True, parity.ACTS
+        mdp = crux.SynthMDP(od, ad, n_envs=E, seed=seed, discrete=True); oe = O.OEnv("synth_discrete", E, max_steps, 0.99, seed, so=od, sa=ad)
+        ga, oa = parity.make_pair([8, 64, 64, 4], acts, 50, 0, "discrete")
+    else:       # "synth": 5-32-32-2 (dense-engine learner); "synth17": the C5 shape 17-64-64-6; "synth31": the Pendulum shape 3-64-64-1 (relu) -- lagrange instantiations
+        od, ad, disc, acts = (17, 6, False, ["tanh", "tanh", "identity"]) if kind == "synth17" else (3, 1, False, parity.ACTS) if kind == "synth31" else (5, 2, False, ["tanh", "tanh", "identity"])
         mdp = crux.SynthMDP(od, ad, n_envs=E, seed=seed); oe = O.OEnv("synth", E, max_steps, 0.99, seed, so=od, sa=ad)
-        ga, oa = parity.make_pair([od, 64, 64, ad] if kind == "synth17" else [od, 32, 32, ad], acts, 50, 0, "gaussian", n_extra=ad, extra_init=-0.5)
+        ga, oa = parity.make_pair([od, 32, 32, ad] if kind == "synth" else [od, 64, 64, ad], acts, 50, 0, "gaussian", n_extra=ad, extra_init=-0.5)
     hid = 32 if kind == "synth" else 64
     gc, oc = parity.make_pair([od, hid, hid, 1], acts, 50, 1)
     gv, ov = parity.make_pair([od, hid, hid, 1], acts, 50, 2)               # Vc
@@ -62,10 +66,10 @@ def test_sampler_writes_cost_and_fills_cost_advantage_and_cost_return(gpu_ctx, k
 
 
 @pytest.mark.parametrize("bs", [64, 128])
-@pytest.mark.parametrize("kind", ["cartpole", "synth", "synth17"])
+@pytest.mark.parametrize("kind", ["cartpole", "synth", "synth17", "synth84", "synth31"])
 def test_lagrange_batch_train_matches_oracle(gpu_ctx, kind, bs):
     """batch_train!(actor, a_opt, P, D) with lagrange_ppo_loss: parameters, the controller's state after every executed minibatch's update, and the infos.
-    The 64-wide actors run on the register-resident learner's lagrange instantiation (train_mfma_kernel.h, LAG): bs = 128 fills both workgroups, 64 one."""
+    The 64-wide actors run on the register-resident learners' lagrange instantiations: bs = 128 on the feature-split kernel (train_fs2_kernel.h, LAG: all four of its shapes), bs = 64 on the two-CU kernel (train_mfma_kernel.h, LAG)."""
     (gb, ob), (ga, oa), _, _, head = _pair(kind)
     O.chk(O.lib().orc_whiten(ob.h, L.COL["advantage"])); crux.whiten_(gb, "advantage")
     N, epochs = len(gb), 3
