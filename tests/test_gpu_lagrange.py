@@ -111,6 +111,33 @@ def test_minibatch_without_an_episode_end_ends_in_nan_like_the_reference(gpu_ctx
     assert not np.array_equal(before, ga.get_params())                                          # the first Inf minibatch still trained (penalty = penalty_max = 3)
 
 
+def test_nan_penalty_inside_the_feature_split_learner_keeps_the_step_before(gpu_ctx):
+    """The same Inf -> NaN chain inside k_train_fs2<..., LAG> (17-64-64-6 actor, full minibatches of 128): rows 1..128 hold no episode end (Jc = Inf, penalty = penalty_max,
+    the step trains), rows 129..256 end an episode (smooth_Jc stays Inf, the derivative term is Inf - Inf = NaN, so is the penalty and with it the gradient): the second step is
+    the error of training.jl:20 and must leave exactly the parameters and Adam moments of the first -- the state a run stopped after one minibatch (max_batches = 1) has. The
+    controller keeps what both evaluations did to it."""
+    def run(**kw):
+        (gb, ob), (ga, oa), _, _, head = _pair("synth17", E=2, T=256, max_steps=1000, seed=5)
+        crux.whiten_(gb, "advantage")
+        ee = gb["episode_end"][0]; assert not ee[:128].any() and ee[128:256].any()
+        glag = _lag(penalty_max=3.0)
+        P = {"eps": 0.2, "lambda_p": 1.0, "lambda_e": 0.1, "lagrange": glag}
+        err = None
+        try:
+            crux.batch_train_(ga, crux.TrainingParams(loss=crux.lagrange_ppo_loss, batch_size=128, epochs=1, name="actor_", **kw), P, gb, perms=np.arange(1, 513)[None, :])
+        except crux.CruxError as e:
+            err = e
+        m, v, bp = ga.adam_state()
+        return err, ga.get_params(), m, v, glag
+    e2, p2, m2, v2, g2 = run()
+    assert e2 is not None and e2.code == L.ENAN
+    e1, p1, m1, v1, g1 = run(max_batches=1)
+    assert e1 is None and g1.penalty == 3.0 and np.isinf(g1.smooth_Jc)
+    for x, y in ((p2, p1), (m2, m1), (v2, v1)):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert np.isfinite(p2).all() and np.isnan(g2.penalty) and np.isnan(g2.deriv_term) and np.isinf(g2.smooth_Jc)
+
+
 def test_lagrange_ppo_solve_two_iterations_match_the_oracle_loop(gpu_ctx):
     """solve(LagrangePPO(...), mdp) (on_policy.jl:80-109): steps! with cost columns, whiten, actor (lagrange loss, KL stop), critic, cost critic."""
     E, T, ms, seed, bs = 4, 64, 10, 9, 64
